@@ -1,0 +1,756 @@
+"""Model compiler: MJCF / URDF robot description -> flat ``ModelSpec``.
+
+This replaces what the closed ``gym.load_asset`` does for the reference tasks
+(call sites: reference ``isaacgymenvs/tasks/ant.py:135-157``, ``humanoid.py:138-157``,
+``cartpole.py:72-88``, ``anymal_terrain.py:214-231``).  The output is a flat,
+array-only description of one articulated robot that both the CPU oracle
+(``oracle/physics.c``, table driven) and the HIP code generator
+(``isaacgymenvs_amd/codegen.py``, compile-time specialised) consume.
+
+Conventions (documented design decisions):
+  * bodies in depth-first document order (= Isaac Gym rigid-body order),
+    DoFs in joint traversal order (= Isaac Gym DoF order);
+  * quaternions are xyzw everywhere (reference ``torch_jit_utils.py:48``);
+  * body frame pose = parent frame * T(pos, quat) * prod_j [rotate/translate
+    about joint j's axis through its anchor], joints given in the child frame
+    (MuJoCo semantics; URDF joints have anchor = child origin);
+  * link inertia from collision geoms x density when no explicit inertial;
+  * welded children (no joint) are merged into their parent for dynamics but
+    remain addressable as "api bodies" (rigid-body tensor rows).
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+import xml.etree.ElementTree as ET
+from dataclasses import dataclass, field
+
+import numpy as np
+
+GEOM_SPHERE, GEOM_CAPSULE, GEOM_BOX, GEOM_CYLINDER = 0, 1, 2, 3
+JOINT_HINGE, JOINT_SLIDE = 0, 1
+
+
+# ----------------------------------------------------------------------------
+# small rotation helpers (numpy, xyzw)
+# ----------------------------------------------------------------------------
+def quat_mul(a, b):
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return np.array([
+        aw * bx + ax * bw + ay * bz - az * by,
+        aw * by - ax * bz + ay * bw + az * bx,
+        aw * bz + ax * by - ay * bx + az * bw,
+        aw * bw - ax * bx - ay * by - az * bz,
+    ])
+
+
+def quat_to_mat(q):
+    x, y, z, w = q / np.linalg.norm(q)
+    return np.array([
+        [1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+        [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+        [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)],
+    ])
+
+
+def mat_to_quat(R):
+    t = np.trace(R)
+    if t > 0:
+        s = math.sqrt(t + 1.0) * 2
+        w = 0.25 * s
+        x = (R[2, 1] - R[1, 2]) / s
+        y = (R[0, 2] - R[2, 0]) / s
+        z = (R[1, 0] - R[0, 1]) / s
+    elif R[0, 0] > R[1, 1] and R[0, 0] > R[2, 2]:
+        s = math.sqrt(1.0 + R[0, 0] - R[1, 1] - R[2, 2]) * 2
+        w = (R[2, 1] - R[1, 2]) / s
+        x = 0.25 * s
+        y = (R[0, 1] + R[1, 0]) / s
+        z = (R[0, 2] + R[2, 0]) / s
+    elif R[1, 1] > R[2, 2]:
+        s = math.sqrt(1.0 + R[1, 1] - R[0, 0] - R[2, 2]) * 2
+        w = (R[0, 2] - R[2, 0]) / s
+        x = (R[0, 1] + R[1, 0]) / s
+        y = 0.25 * s
+        z = (R[1, 2] + R[2, 1]) / s
+    else:
+        s = math.sqrt(1.0 + R[2, 2] - R[0, 0] - R[1, 1]) * 2
+        w = (R[1, 0] - R[0, 1]) / s
+        x = (R[0, 2] + R[2, 0]) / s
+        y = (R[1, 2] + R[2, 1]) / s
+        z = 0.25 * s
+    q = np.array([x, y, z, w])
+    return q / np.linalg.norm(q)
+
+
+def quat_from_z_to(v):
+    """Quaternion rotating +z onto unit vector v."""
+    v = np.asarray(v, float)
+    v = v / np.linalg.norm(v)
+    z = np.array([0.0, 0.0, 1.0])
+    c = float(np.dot(z, v))
+    if c > 1 - 1e-12:
+        return np.array([0.0, 0.0, 0.0, 1.0])
+    if c < -1 + 1e-12:
+        return np.array([1.0, 0.0, 0.0, 0.0])
+    ax = np.cross(z, v)
+    ax /= np.linalg.norm(ax)
+    ang = math.acos(c)
+    return np.array([*(ax * math.sin(ang / 2)), math.cos(ang / 2)])
+
+
+def rpy_to_quat(r, p, y):
+    cr, sr, cp, sp, cy, sy = math.cos(r / 2), math.sin(r / 2), math.cos(p / 2), math.sin(p / 2), math.cos(y / 2), math.sin(y / 2)
+    return np.array([
+        sr * cp * cy - cr * sp * sy,
+        cr * sp * cy + sr * cp * sy,
+        cr * cp * sy - sr * sp * cy,
+        cr * cp * cy + sr * sp * sy,
+    ])
+
+
+# ----------------------------------------------------------------------------
+# geom mass properties (uniform density), returned about the geom's own frame
+# ----------------------------------------------------------------------------
+def geom_mass_inertia(gtype, size, density):
+    """-> (mass, diag inertia about geom COM in geom axes)."""
+    if gtype == GEOM_SPHERE:
+        r = size[0]
+        m = density * 4.0 / 3.0 * math.pi * r ** 3
+        i = 0.4 * m * r * r
+        return m, np.array([i, i, i])
+    if gtype == GEOM_CAPSULE:
+        r, l = size[0], size[1]  # l = half length of the cylinder part, axis z
+        mc = density * math.pi * r * r * 2 * l
+        mh = density * 2.0 / 3.0 * math.pi * r ** 3
+        m = mc + 2 * mh
+        izz = 0.5 * mc * r * r + 2 * mh * 0.4 * r * r
+        ixx = mc * (r * r / 4 + l * l / 3) + 2 * mh * (0.4 * r * r + l * l + 0.75 * r * l)
+        return m, np.array([ixx, ixx, izz])
+    if gtype == GEOM_CYLINDER:
+        r, l = size[0], size[1]
+        m = density * math.pi * r * r * 2 * l
+        return m, np.array([m * (r * r / 4 + l * l / 3), m * (r * r / 4 + l * l / 3), 0.5 * m * r * r])
+    if gtype == GEOM_BOX:
+        hx, hy, hz = size[:3]
+        m = density * 8 * hx * hy * hz
+        return m, np.array([m / 3 * (hy * hy + hz * hz), m / 3 * (hx * hx + hz * hz), m / 3 * (hx * hx + hy * hy)])
+    raise ValueError(gtype)
+
+
+# ----------------------------------------------------------------------------
+# intermediate tree
+# ----------------------------------------------------------------------------
+@dataclass
+class _Joint:
+    name: str
+    jtype: int
+    axis: np.ndarray
+    anchor: np.ndarray
+    lower: float = 0.0
+    upper: float = 0.0
+    limited: bool = False
+    armature: float = 0.0
+    damping: float = 0.0
+    stiffness: float = 0.0
+    springref: float = 0.0
+    frictionloss: float = 0.0
+    effort: float = 1e30
+    velocity: float = 1e30
+
+
+@dataclass
+class _Geom:
+    name: str
+    gtype: int
+    pos: np.ndarray
+    quat: np.ndarray
+    size: np.ndarray
+    friction: float = 1.0
+    density: float = 1000.0
+    mass: float | None = None
+
+
+@dataclass
+class _Body:
+    name: str
+    parent: int
+    pos: np.ndarray
+    quat: np.ndarray
+    joints: list = field(default_factory=list)
+    geoms: list = field(default_factory=list)
+    free: bool = False
+    inertial: tuple | None = None  # (mass, com, quat, diag) explicit
+    gravity: bool = True
+
+
+@dataclass
+class ModelSpec:
+    name: str
+    fixed_base: bool
+    # dynamic bodies (welds merged)
+    body_names: list
+    parent: np.ndarray      # [nb] int
+    bpos: np.ndarray        # [nb,3] in parent frame
+    bquat: np.ndarray       # [nb,4] xyzw
+    mass: np.ndarray        # [nb]
+    com: np.ndarray         # [nb,3] body frame
+    inertia: np.ndarray     # [nb,6] xx,yy,zz,xy,xz,yz about COM, body axes
+    # dofs
+    dof_names: list
+    dof_body: np.ndarray    # [nd]
+    dof_type: np.ndarray    # [nd]
+    dof_axis: np.ndarray    # [nd,3] body frame (unit)
+    dof_anchor: np.ndarray  # [nd,3] body frame
+    dof_lower: np.ndarray
+    dof_upper: np.ndarray
+    dof_limited: np.ndarray
+    dof_armature: np.ndarray
+    dof_damping: np.ndarray
+    dof_stiffness: np.ndarray
+    dof_springref: np.ndarray
+    dof_effort: np.ndarray
+    dof_velocity: np.ndarray
+    # collision geoms (attached to dynamic bodies)
+    geom_names: list
+    geom_body: np.ndarray
+    geom_type: np.ndarray
+    geom_pos: np.ndarray    # [ng,3]
+    geom_quat: np.ndarray   # [ng,4]
+    geom_size: np.ndarray   # [ng,3]
+    geom_friction: np.ndarray
+    # derived: contact spheres vs ground (sphere centres, capsule end caps, box corners)
+    sph_body: np.ndarray
+    sph_pos: np.ndarray
+    sph_rad: np.ndarray
+    sph_friction: np.ndarray
+    sph_geom: np.ndarray
+    # actuators (MJCF <motor>) in file order
+    act_names: list
+    act_dof: np.ndarray
+    act_gear: np.ndarray
+    # api bodies (before weld merge): name, dynamic body index, local offset pose
+    api_body_names: list
+    api_body_dyn: np.ndarray
+    api_body_pos: np.ndarray
+    api_body_quat: np.ndarray
+
+    @property
+    def nb(self):
+        return len(self.parent)
+
+    @property
+    def nd(self):
+        return len(self.dof_body)
+
+    @property
+    def nv(self):
+        return self.nd + (0 if self.fixed_base else 6)
+
+    def total_mass(self):
+        return float(self.mass.sum())
+
+    # ---- (de)serialisation: compiled models are committed under isaacgymenvs_amd/models
+    def to_json(self):
+        d = {}
+        for k, v in self.__dict__.items():
+            d[k] = v.tolist() if isinstance(v, np.ndarray) else v
+        return d
+
+    @staticmethod
+    def from_json(d):
+        ints = {"parent", "dof_body", "dof_type", "dof_limited", "geom_body", "geom_type", "sph_body", "sph_geom",
+                "act_dof", "api_body_dyn"}
+        kw = {}
+        for k, v in d.items():
+            if isinstance(v, list) and not (k.endswith("names")):
+                kw[k] = np.array(v, dtype=np.int32 if k in ints else np.float64)
+                if kw[k].size == 0:
+                    shape = {"geom_pos": (0, 3), "geom_quat": (0, 4), "geom_size": (0, 3), "sph_pos": (0, 3),
+                             "dof_axis": (0, 3), "dof_anchor": (0, 3)}.get(k)
+                    if shape:
+                        kw[k] = kw[k].reshape(shape)
+            else:
+                kw[k] = v
+        return ModelSpec(**kw)
+
+    def save(self, path):
+        with open(path, "w") as f:
+            json.dump(self.to_json(), f, indent=0)
+
+    @staticmethod
+    def load(path):
+        with open(path) as f:
+            return ModelSpec.from_json(json.load(f))
+
+
+# ----------------------------------------------------------------------------
+# MJCF
+# ----------------------------------------------------------------------------
+def _floats(s, n=None):
+    v = np.array([float(x) for x in s.split()], dtype=float)
+    if n is not None and len(v) != n:
+        raise ValueError(f"expected {n} floats in '{s}'")
+    return v
+
+
+class _MjcfDefaults:
+    """MJCF <default> class tree: attribute dict per (class, element tag)."""
+
+    def __init__(self):
+        self.classes = {"main": {}}
+        self.parent = {"main": None}
+
+    def load(self, node, cls="main"):
+        for ch in node:
+            if ch.tag == "default":
+                name = ch.get("class")
+                if name is None:  # top-level anonymous default = main
+                    self.load(ch, cls)
+                    continue
+                self.classes[name] = {}
+                self.parent[name] = cls
+                self.load(ch, name)
+            else:
+                self.classes[cls].setdefault(ch.tag, {}).update(ch.attrib)
+
+    def resolve(self, tag, cls, attrib):
+        chain = []
+        c = cls or "main"
+        while c is not None:
+            chain.append(c)
+            c = self.parent.get(c)
+        out = {}
+        for c in reversed(chain):
+            out.update(self.classes.get(c, {}).get(tag, {}))
+        out.update(attrib)
+        return out
+
+
+def _expand_includes(root, base_dir):
+    for parent in list(root.iter()):
+        for i, ch in enumerate(list(parent)):
+            if ch.tag == "include":
+                sub = ET.parse(os.path.join(base_dir, ch.get("file"))).getroot()
+                _expand_includes(sub, base_dir)
+                idx = list(parent).index(ch)
+                parent.remove(ch)
+                for k, el in enumerate(list(sub)):
+                    parent.insert(idx + k, el)
+
+
+def _mjcf_geom(attr, angle_scale):
+    tname = attr.get("type", "sphere")
+    gtype = {"sphere": GEOM_SPHERE, "capsule": GEOM_CAPSULE, "box": GEOM_BOX, "cylinder": GEOM_CYLINDER}.get(tname)
+    if gtype is None:
+        return None  # plane / mesh / etc: not a primitive we collide
+    size = _floats(attr.get("size", "0"))
+    pos = _floats(attr.get("pos", "0 0 0"), 3)
+    quat = np.array([0.0, 0.0, 0.0, 1.0])
+    if "quat" in attr:
+        w, x, y, z = _floats(attr["quat"], 4)
+        quat = np.array([x, y, z, w])
+    elif "euler" in attr:
+        e = _floats(attr["euler"], 3) * angle_scale
+        quat = rpy_to_quat(*e)  # MuJoCo default eulerseq xyz intrinsic == rpy fixed zyx... approx; assets here don't use it on geoms
+    elif "zaxis" in attr:
+        quat = quat_from_z_to(_floats(attr["zaxis"], 3))
+    s = np.zeros(3)
+    if "fromto" in attr:
+        ft = _floats(attr["fromto"], 6)
+        a, b = ft[:3], ft[3:]
+        pos = 0.5 * (a + b)
+        quat = quat_from_z_to(b - a)
+        s[0] = size[0]
+        s[1] = 0.5 * np.linalg.norm(b - a)
+    else:
+        s[:len(size)] = size[:3]
+    fr = _floats(attr.get("friction", "1 0.005 0.0001"))[0]
+    g = _Geom(attr.get("name", ""), gtype, pos, quat, s, friction=fr, density=float(attr.get("density", 1000.0)))
+    if "mass" in attr:
+        g.mass = float(attr["mass"])
+    return g
+
+
+def parse_mjcf(path):
+    """Parse an MJCF file into the intermediate body list + actuators."""
+    root = ET.parse(path).getroot()
+    _expand_includes(root, os.path.dirname(path))
+    comp = root.find("compiler")
+    angle = (comp.get("angle") if comp is not None and comp.get("angle") else "degree")
+    ascale = math.pi / 180.0 if angle == "degree" else 1.0
+    defaults = _MjcfDefaults()
+    for d in root.findall("default"):
+        defaults.load(d, "main")
+
+    bodies: list[_Body] = []
+
+    def visit(node, parent_idx, childclass):
+        cc = node.get("childclass", childclass)
+        pos = _floats(node.get("pos", "0 0 0"), 3)
+        quat = np.array([0.0, 0.0, 0.0, 1.0])
+        if node.get("quat"):
+            w, x, y, z = _floats(node.get("quat"), 4)
+            quat = np.array([x, y, z, w])
+            quat = quat / np.linalg.norm(quat)
+        elif node.get("euler"):
+            quat = rpy_to_quat(*(_floats(node.get("euler"), 3) * ascale))
+        b = _Body(node.get("name", f"body{len(bodies)}"), parent_idx, pos, quat)
+        idx = len(bodies)
+        bodies.append(b)
+        for ch in node:
+            if ch.tag == "freejoint":
+                b.free = True
+            elif ch.tag == "joint":
+                a = defaults.resolve("joint", ch.get("class", cc), ch.attrib)
+                jt = a.get("type", "hinge")
+                if jt == "free":
+                    b.free = True
+                    continue
+                jtype = JOINT_HINGE if jt == "hinge" else JOINT_SLIDE
+                axis = _floats(a.get("axis", "0 0 1"), 3)
+                axis = axis / np.linalg.norm(axis)
+                rng = _floats(a.get("range", "0 0"), 2)
+                sc = ascale if jtype == JOINT_HINGE else 1.0
+                limited = a.get("limited", "false") == "true"
+                j = _Joint(a.get("name", f"joint{idx}"), jtype, axis, _floats(a.get("pos", "0 0 0"), 3),
+                           lower=rng[0] * sc, upper=rng[1] * sc, limited=limited,
+                           armature=float(a.get("armature", 0)), damping=float(a.get("damping", 0)),
+                           stiffness=float(a.get("stiffness", 0)), springref=float(a.get("springref", 0)) * sc,
+                           frictionloss=float(a.get("frictionloss", 0)))
+                b.joints.append(j)
+            elif ch.tag == "geom":
+                a = defaults.resolve("geom", ch.get("class", cc), ch.attrib)
+                g = _mjcf_geom(a, ascale)
+                if g is not None:
+                    b.geoms.append(g)
+            elif ch.tag == "inertial":
+                ipos = _floats(ch.get("pos", "0 0 0"), 3)
+                iq = np.array([0.0, 0.0, 0.0, 1.0])
+                if ch.get("quat"):
+                    w, x, y, z = _floats(ch.get("quat"), 4)
+                    iq = np.array([x, y, z, w])
+                    iq /= np.linalg.norm(iq)
+                b.inertial = (float(ch.get("mass")), ipos, iq, _floats(ch.get("diaginertia", "0 0 0"), 3))
+            elif ch.tag == "body":
+                visit(ch, idx, cc)
+
+    wb = root.find("worldbody")
+    tops = [n for n in wb if n.tag == "body"]
+    if len(tops) != 1:
+        raise ValueError("expected exactly one top-level body")
+    visit(tops[0], -1, None)
+
+    acts = []
+    an = root.find("actuator")
+    if an is not None:
+        for m in an:
+            a = defaults.resolve(m.tag, m.get("class"), m.attrib)
+            acts.append(dict(name=a.get("name", a.get("joint", "")), joint=a.get("joint"), kind=m.tag,
+                             gear=_floats(a.get("gear", "1"))[0], kp=float(a.get("kp", 0)),
+                             ctrlrange=_floats(a.get("ctrlrange", "0 0"), 2).tolist(),
+                             forcerange=_floats(a.get("forcerange", "0 0"), 2).tolist()))
+    return bodies, acts
+
+
+# ----------------------------------------------------------------------------
+# URDF
+# ----------------------------------------------------------------------------
+def parse_urdf(path, default_density=1000.0, replace_cylinder_with_capsule=False):
+    root = ET.parse(path).getroot()
+    links = {}
+    for ln in root.findall("link"):
+        name = ln.get("name")
+        geoms = []
+        for col in ln.findall("collision"):
+            org = col.find("origin")
+            pos = _floats(org.get("xyz", "0 0 0"), 3) if org is not None else np.zeros(3)
+            quat = rpy_to_quat(*_floats(org.get("rpy", "0 0 0"), 3)) if org is not None else np.array([0, 0, 0, 1.0])
+            geo = col.find("geometry")
+            if geo is None or len(geo) == 0:
+                continue
+            g = geo[0]
+            if g.tag == "box":
+                geoms.append(_Geom(name, GEOM_BOX, pos, quat, 0.5 * _floats(g.get("size"), 3), density=default_density))
+            elif g.tag == "sphere":
+                geoms.append(_Geom(name, GEOM_SPHERE, pos, quat, np.array([float(g.get("radius")), 0, 0]), density=default_density))
+            elif g.tag == "cylinder":
+                r, L = float(g.get("radius")), float(g.get("length"))
+                if replace_cylinder_with_capsule:
+                    geoms.append(_Geom(name, GEOM_CAPSULE, pos, quat, np.array([r, max(0.5 * L - r, 0.0), 0]), density=default_density))
+                else:
+                    geoms.append(_Geom(name, GEOM_CYLINDER, pos, quat, np.array([r, 0.5 * L, 0]), density=default_density))
+        inertial = None
+        iner = ln.find("inertial")
+        if iner is not None and iner.find("mass") is not None:
+            m = float(iner.find("mass").get("value"))
+            org = iner.find("origin")
+            ipos = _floats(org.get("xyz", "0 0 0"), 3) if org is not None else np.zeros(3)
+            iq = rpy_to_quat(*_floats(org.get("rpy", "0 0 0"), 3)) if org is not None else np.array([0, 0, 0, 1.0])
+            it = iner.find("inertia")
+            full = None
+            if it is not None:
+                full = np.array([[float(it.get("ixx", 0)), float(it.get("ixy", 0)), float(it.get("ixz", 0))],
+                                 [float(it.get("ixy", 0)), float(it.get("iyy", 0)), float(it.get("iyz", 0))],
+                                 [float(it.get("ixz", 0)), float(it.get("iyz", 0)), float(it.get("izz", 0))]])
+            inertial = (m, ipos, iq, full)
+        links[name] = dict(geoms=geoms, inertial=inertial)
+    joints = []
+    for jn in root.findall("joint"):
+        org = jn.find("origin")
+        pos = _floats(org.get("xyz", "0 0 0"), 3) if org is not None else np.zeros(3)
+        quat = rpy_to_quat(*_floats(org.get("rpy", "0 0 0"), 3)) if org is not None else np.array([0, 0, 0, 1.0])
+        ax = jn.find("axis")
+        axis = _floats(ax.get("xyz"), 3) if ax is not None else np.array([1.0, 0, 0])
+        lim = jn.find("limit")
+        dyn = jn.find("dynamics")
+        joints.append(dict(name=jn.get("name"), type=jn.get("type"), parent=jn.find("parent").get("link"),
+                           child=jn.find("child").get("link"), pos=pos, quat=quat, axis=axis / max(np.linalg.norm(axis), 1e-12),
+                           lower=float(lim.get("lower", 0)) if lim is not None else 0.0,
+                           upper=float(lim.get("upper", 0)) if lim is not None else 0.0,
+                           has_limits=lim is not None and lim.get("lower") is not None,
+                           effort=float(lim.get("effort", 1e30)) if lim is not None else 1e30,
+                           velocity=float(lim.get("velocity", 1e30)) if lim is not None else 1e30,
+                           damping=float(dyn.get("damping", 0)) if dyn is not None else 0.0))
+    children = {j["child"] for j in joints}
+    roots = [n for n in links if n not in children]
+    if len(roots) != 1:
+        raise ValueError(f"URDF must have a single root link, got {roots}")
+    bodies: list[_Body] = []
+
+    def visit(link_name, parent_idx, joint):
+        L = links[link_name]
+        if joint is None:
+            b = _Body(link_name, -1, np.zeros(3), np.array([0, 0, 0, 1.0]))
+        else:
+            b = _Body(link_name, parent_idx, joint["pos"], joint["quat"])
+            t = joint["type"]
+            if t in ("revolute", "continuous", "prismatic"):
+                limited = (t != "continuous") and joint["has_limits"]
+                b.joints.append(_Joint(joint["name"], JOINT_SLIDE if t == "prismatic" else JOINT_HINGE, joint["axis"],
+                                       np.zeros(3), lower=joint["lower"], upper=joint["upper"], limited=limited,
+                                       damping=joint["damping"], effort=joint["effort"], velocity=joint["velocity"]))
+            elif t != "fixed":
+                raise ValueError(f"unsupported URDF joint type {t}")
+        b.geoms = L["geoms"]
+        if L["inertial"] is not None:
+            m, ipos, iq, full = L["inertial"]
+            b.inertial = (m, ipos, iq, full)
+        idx = len(bodies)
+        bodies.append(b)
+        for j in joints:
+            if j["parent"] == link_name:
+                visit(j["child"], idx, j)
+
+    visit(roots[0], -1, None)
+    return bodies, []
+
+
+# ----------------------------------------------------------------------------
+# intermediate tree -> ModelSpec
+# ----------------------------------------------------------------------------
+def _body_mass_props(b: _Body, density_override=None):
+    """-> mass, com (3), inertia about com 3x3, all in body frame."""
+    if b.inertial is not None and b.inertial[3] is not None and np.any(np.asarray(b.inertial[3]) != 0):
+        m, ipos, iq, I = b.inertial
+        R = quat_to_mat(iq)
+        I = np.asarray(I, float)
+        Ifull = R @ (np.diag(I) if I.ndim == 1 else I) @ R.T
+        return m, np.asarray(ipos, float), Ifull
+    if not b.geoms:
+        if b.inertial is not None:
+            return b.inertial[0], np.asarray(b.inertial[1], float), np.eye(3) * 1e-9
+        return 0.0, np.zeros(3), np.zeros((3, 3))
+    ms, cs, Is = [], [], []
+    for g in b.geoms:
+        dens = density_override if density_override is not None else g.density
+        m, d = geom_mass_inertia(g.gtype, g.size, dens)
+        if g.mass is not None:
+            d = d * (g.mass / m)
+            m = g.mass
+        R = quat_to_mat(g.quat)
+        ms.append(m)
+        cs.append(g.pos)
+        Is.append(R @ np.diag(d) @ R.T)
+    M = sum(ms)
+    com = sum(m * c for m, c in zip(ms, cs)) / M
+    I = np.zeros((3, 3))
+    for m, c, Ig in zip(ms, cs, Is):
+        r = c - com
+        I += Ig + m * (np.dot(r, r) * np.eye(3) - np.outer(r, r))
+    if b.inertial is not None:  # explicit mass, geometry-derived shape (URDF without <inertia>)
+        m_exp, ipos = b.inertial[0], np.asarray(b.inertial[1], float)
+        I = I * (m_exp / M)
+        M, com = m_exp, ipos
+    return M, com, I
+
+
+def _contact_spheres(geom_body, geom_type, geom_pos, geom_quat, geom_size, geom_friction):
+    sb, sp, sr, sf, sg = [], [], [], [], []
+    for gi in range(len(geom_body)):
+        t, p, q, s = geom_type[gi], geom_pos[gi], geom_quat[gi], geom_size[gi]
+        R = quat_to_mat(q)
+        pts = []
+        if t == GEOM_SPHERE:
+            pts = [(p, s[0])]
+        elif t == GEOM_CAPSULE:
+            pts = [(p + R @ np.array([0, 0, s[1]]), s[0]), (p - R @ np.array([0, 0, s[1]]), s[0])]
+        elif t == GEOM_BOX:
+            for sx in (-1, 1):
+                for sy in (-1, 1):
+                    for sz in (-1, 1):
+                        pts.append((p + R @ (np.array([sx, sy, sz]) * s), 0.0))
+        elif t == GEOM_CYLINDER:  # rim approximated by 4 points per cap
+            for sz in (-1, 1):
+                for a in range(4):
+                    pts.append((p + R @ np.array([s[0] * math.cos(a * math.pi / 2), s[0] * math.sin(a * math.pi / 2), sz * s[1]]), 0.0))
+        for c, r in pts:
+            sb.append(geom_body[gi]); sp.append(c); sr.append(r); sf.append(geom_friction[gi]); sg.append(gi)
+    return (np.array(sb, np.int32), np.array(sp, float).reshape(-1, 3), np.array(sr, float), np.array(sf, float),
+            np.array(sg, np.int32))
+
+
+def build_model(name, bodies, acts, fix_base_link=False, density=None, dedupe_spheres=True,
+                collide_body_filter=None):
+    """Flatten the intermediate tree.  Welded (jointless, non-root) bodies are merged into parents."""
+    n = len(bodies)
+    root = bodies[0]
+    fixed_base = bool(fix_base_link or not (root.free or True) )
+    # Isaac Gym: a root body without fix_base_link is a free-floating base regardless of <freejoint>
+    fixed_base = bool(fix_base_link)
+    props = [_body_mass_props(b, density) for b in bodies]
+    # dynamic body assignment
+    dyn_of = [-1] * n
+    off_R = [np.eye(3)] * n
+    off_p = [np.zeros(3)] * n
+    dyn_bodies = []
+    for i, b in enumerate(bodies):
+        if i == 0 or b.joints:
+            dyn_of[i] = len(dyn_bodies)
+            dyn_bodies.append(i)
+        else:  # weld into parent's dynamic body
+            p = b.parent
+            dyn_of[i] = dyn_of[p]
+            Rb = quat_to_mat(b.quat)
+            off_R[i] = off_R[p] @ Rb
+            off_p[i] = off_p[p] + off_R[p] @ b.pos
+    nb = len(dyn_bodies)
+    parent = np.full(nb, -1, np.int32)
+    bpos = np.zeros((nb, 3)); bquat = np.zeros((nb, 4)); bquat[:, 3] = 1
+    mass = np.zeros(nb); com = np.zeros((nb, 3)); inertia = np.zeros((nb, 6))
+    # accumulate mass props (weld-aware)
+    acc = [[] for _ in range(nb)]
+    for i, b in enumerate(bodies):
+        m, c, I = props[i]
+        if m > 0:
+            acc[dyn_of[i]].append((m, off_p[i] + off_R[i] @ c, off_R[i] @ I @ off_R[i].T))
+    for k, i in enumerate(dyn_bodies):
+        b = bodies[i]
+        if b.parent >= 0:
+            p = b.parent
+            parent[k] = dyn_of[p]
+            bpos[k] = off_p[p] + off_R[p] @ b.pos
+            bquat[k] = mat_to_quat(off_R[p] @ quat_to_mat(b.quat))
+        else:
+            bpos[k] = 0.0  # root pose comes from the actor start pose (reference ant.py:164), not the file
+        M = sum(a[0] for a in acc[k]) if acc[k] else 0.0
+        if M > 0:
+            cm = sum(a[0] * a[1] for a in acc[k]) / M
+            I = np.zeros((3, 3))
+            for m, c, Ig in acc[k]:
+                r = c - cm
+                I += Ig + m * (np.dot(r, r) * np.eye(3) - np.outer(r, r))
+            mass[k] = M; com[k] = cm
+            inertia[k] = [I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2]]
+    # dofs
+    dn, db, dt, dax, dan, dlo, dup, dlim, darm, ddamp, dst, dref, deff, dvel = ([] for _ in range(14))
+    for k, i in enumerate(dyn_bodies):
+        for j in bodies[i].joints:
+            lo, up = j.lower, j.upper
+            dn.append(j.name); db.append(k); dt.append(j.jtype); dax.append(j.axis); dan.append(j.anchor)
+            dlo.append(lo); dup.append(up); dlim.append(1 if j.limited else 0)
+            darm.append(j.armature); ddamp.append(j.damping); dst.append(j.stiffness); dref.append(j.springref)
+            deff.append(j.effort); dvel.append(j.velocity)
+    # geoms
+    gn, gb, gt, gp, gq, gs, gf = ([] for _ in range(7))
+    for i, b in enumerate(bodies):
+        if collide_body_filter is not None and not collide_body_filter(b.name):
+            continue
+        for g in b.geoms:
+            gn.append(g.name or b.name); gb.append(dyn_of[i]); gt.append(g.gtype)
+            gp.append(off_p[i] + off_R[i] @ g.pos)
+            gq.append(mat_to_quat(off_R[i] @ quat_to_mat(g.quat)))
+            gs.append(g.size); gf.append(g.friction)
+    geom_body = np.array(gb, np.int32); geom_type = np.array(gt, np.int32)
+    geom_pos = np.array(gp, float).reshape(-1, 3); geom_quat = np.array(gq, float).reshape(-1, 4)
+    geom_size = np.array(gs, float).reshape(-1, 3); geom_friction = np.array(gf, float)
+    sb, sp, sr, sf, sg = _contact_spheres(geom_body, geom_type, geom_pos, geom_quat, geom_size, geom_friction)
+    dof_body = np.array(db, np.int32)
+    dof_anchor = np.array(dan, float).reshape(-1, 3)
+    if dedupe_spheres and len(sb):
+        sb, sp, sr, sf, sg = _dedupe_spheres(sb, sp, sr, sf, sg, parent, bpos, bquat, dof_body, dof_anchor,
+                                             np.array(dt, np.int32))
+    dof_index = {nme: k for k, nme in enumerate(dn)}
+    an, ad, ag = [], [], []
+    for a in acts:
+        if a["joint"] in dof_index:
+            an.append(a["name"]); ad.append(dof_index[a["joint"]]); ag.append(a["gear"])
+    return ModelSpec(
+        name=name, fixed_base=fixed_base, body_names=[bodies[i].name for i in dyn_bodies], parent=parent, bpos=bpos,
+        bquat=bquat, mass=mass, com=com, inertia=inertia, dof_names=dn, dof_body=dof_body,
+        dof_type=np.array(dt, np.int32), dof_axis=np.array(dax, float).reshape(-1, 3), dof_anchor=dof_anchor,
+        dof_lower=np.array(dlo, float), dof_upper=np.array(dup, float), dof_limited=np.array(dlim, np.int32),
+        dof_armature=np.array(darm, float), dof_damping=np.array(ddamp, float), dof_stiffness=np.array(dst, float),
+        dof_springref=np.array(dref, float), dof_effort=np.array(deff, float), dof_velocity=np.array(dvel, float),
+        geom_names=gn, geom_body=geom_body, geom_type=geom_type, geom_pos=geom_pos, geom_quat=geom_quat,
+        geom_size=geom_size, geom_friction=geom_friction, sph_body=sb, sph_pos=sp, sph_rad=sr, sph_friction=sf,
+        sph_geom=sg, act_names=an, act_dof=np.array(ad, np.int32), act_gear=np.array(ag, float),
+        api_body_names=[b.name for b in bodies], api_body_dyn=np.array(dyn_of, np.int32),
+        api_body_pos=np.array(off_p, float).reshape(-1, 3),
+        api_body_quat=np.array([mat_to_quat(R) for R in off_R], float).reshape(-1, 4))
+
+
+def _dedupe_spheres(sb, sp, sr, sf, sg, parent, bpos, bquat, dof_body, dof_anchor, dof_type):
+    """Drop a contact sphere that coincides (same world point at every configuration, same radius) with one on
+    the parent body: that is the case when it sits exactly on the hinge anchor(s) connecting the two bodies, where
+    both bodies have identical point velocity, so the second contact row would be a duplicate constraint."""
+    keep = np.ones(len(sb), bool)
+    # a sphere wholly inside another sphere of the same body can never be the first to touch anything
+    for i in range(len(sb)):
+        for k in range(len(sb)):
+            if i != k and keep[k] and sb[i] == sb[k] and np.linalg.norm(sp[i] - sp[k]) + sr[i] <= sr[k] + 1e-12 \
+                    and (sr[i] < sr[k] or k < i):
+                keep[i] = False
+                break
+    for i in range(len(sb)):
+        if not keep[i]:
+            continue
+        b = sb[i]
+        p = parent[b]
+        if p < 0:
+            continue
+        jd = [d for d in range(len(dof_body)) if dof_body[d] == b]
+        if not jd or any(dof_type[d] != JOINT_HINGE for d in jd):
+            continue
+        if not all(np.linalg.norm(dof_anchor[d] - sp[i]) < 1e-9 for d in jd):
+            continue
+        # position of this point in the parent frame (independent of q because it lies on every hinge axis)
+        pp = bpos[b] + quat_to_mat(bquat[b]) @ sp[i]
+        for k in range(len(sb)):
+            if keep[k] and sb[k] == p and abs(sr[k] - sr[i]) < 1e-9 and np.linalg.norm(sp[k] - pp) < 1e-9:
+                keep[i] = False
+                break
+    return sb[keep], sp[keep], sr[keep], sf[keep], sg[keep]
+
+
+def load_asset(path, name=None, fix_base_link=False, density=None, replace_cylinder_with_capsule=False, **kw):
+    """Front door mirroring ``gym.load_asset(sim, root, file, AssetOptions)`` for the options the five tasks use."""
+    name = name or os.path.splitext(os.path.basename(path))[0]
+    if path.endswith(".urdf"):
+        bodies, acts = parse_urdf(path, default_density=density if density is not None else 1000.0,
+                                  replace_cylinder_with_capsule=replace_cylinder_with_capsule)
+        return build_model(name, bodies, acts, fix_base_link=fix_base_link, density=density, **kw)
+    bodies, acts = parse_mjcf(path)
+    return build_model(name, bodies, acts, fix_base_link=fix_base_link, density=density, **kw)

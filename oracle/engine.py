@@ -1,0 +1,141 @@
+"""ctypes front-end of oracle/physics.c (see that file's header for scope and pinning)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def build(force=False):
+    out = os.path.join(_HERE, "_build", "liboracle_f64.so")
+    src = os.path.join(_HERE, "physics.c")
+    if force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B"])
+    return out
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _struct(real):
+    class OrModel(C.Structure):
+        _fields_ = [(n, C.c_int32) for n in ("nb", "nd", "fixed_base", "nsph", "nsens", "pad0")] + \
+                   [(n, C.c_void_p) for n in (
+                       "parent", "bpos", "bquat", "mass", "com", "inertia", "dof_body", "dof_type", "dof_axis",
+                       "dof_anchor", "dof_lower", "dof_upper", "dof_limited", "dof_armature", "dof_damping",
+                       "dof_stiffness", "dof_springref", "sph_body", "sph_pos", "sph_rad", "sph_mu", "sens_body")]
+
+    class OrParams(C.Structure):
+        _fields_ = [("dt", real), ("substeps", C.c_int32), ("iters", C.c_int32), ("gravity", real * 3),
+                    ("contact_offset", real), ("rest_offset", real), ("max_depen_vel", real), ("erp", real),
+                    ("plane_mu", real), ("ground_z", real), ("cfm", real), ("warm", real)]
+    return OrModel, OrParams
+
+
+DEFAULT_PARAMS = dict(dt=1.0 / 60.0, substeps=2, iters=4, gravity=(0.0, 0.0, -9.81), contact_offset=0.02,
+                      rest_offset=0.0, max_depen_vel=10.0, erp=0.5, plane_mu=1.0, ground_z=0.0, cfm=1e-6, warm=1.0)
+
+
+class OracleEngine:
+    """Batched CPU physics for one ModelSpec.  State is AoS per env:
+    root[13] (pos3, quat xyzw4, linvel3, angvel3) | q[nd] | qd[nd] | lam_c[3*nsph] | lam_l[nd]."""
+
+    def __init__(self, spec, num_envs, params=None, sensor_bodies=(), precision="f64"):
+        build()
+        self.spec = spec
+        self.np_real = np.float64 if precision == "f64" else np.float32
+        creal = C.c_double if precision == "f64" else C.c_float
+        self.lib = C.CDLL(os.path.join(_HERE, "_build", f"liboracle_{precision}.so"))
+        assert self.lib.or_sizeof_real() == np.dtype(self.np_real).itemsize
+        OrModel, OrParams = _struct(creal)
+        r = self.np_real
+        self._keep = k = {}
+        k["parent"] = np.ascontiguousarray(spec.parent, np.int32)
+        for n in ("bpos", "bquat", "mass", "com", "inertia", "dof_axis", "dof_anchor", "dof_lower", "dof_upper",
+                  "dof_armature", "dof_damping", "dof_stiffness", "dof_springref", "sph_pos", "sph_rad"):
+            k[n] = np.ascontiguousarray(getattr(spec, n), r)
+        k["sph_mu"] = np.ascontiguousarray(spec.sph_friction, r)
+        for n in ("dof_body", "dof_type", "dof_limited", "sph_body"):
+            k[n] = np.ascontiguousarray(getattr(spec, n), np.int32)
+        k["sens_body"] = np.ascontiguousarray(np.array(sensor_bodies, np.int32))
+        m = OrModel(nb=spec.nb, nd=spec.nd, fixed_base=int(spec.fixed_base), nsph=len(spec.sph_body),
+                    nsens=len(sensor_bodies), pad0=0)
+        for n, _ in OrModel._fields_[6:]:
+            setattr(m, n, _ptr(k[n]))
+        self.model = m
+        self.set_params(**(params or {}))
+        self.N = num_envs
+        self.nd, self.nsph, self.nsens = spec.nd, len(spec.sph_body), len(sensor_bodies)
+        self.ss = self.lib.or_state_size(C.byref(m))
+        self.os = self.lib.or_out_size(C.byref(m))
+        self.state = np.zeros((num_envs, self.ss), r)
+        self.state[:, 6] = 1.0
+        self.out = np.zeros((num_envs, self.os), r)
+
+    def set_params(self, **kw):
+        _, OrParams = _struct(C.c_double if self.np_real == np.float64 else C.c_float)
+        d = dict(DEFAULT_PARAMS)
+        d.update(kw)
+        self.params_dict = d
+        p = OrParams()
+        for key, val in d.items():
+            if key == "gravity":
+                for i in range(3):
+                    p.gravity[i] = val[i]
+            else:
+                setattr(p, key, val)
+        self.params = p
+
+    # ---- views
+    @property
+    def root(self):
+        return self.state[:, :13]
+
+    @property
+    def q(self):
+        return self.state[:, 13:13 + self.nd]
+
+    @property
+    def qd(self):
+        return self.state[:, 13 + self.nd:13 + 2 * self.nd]
+
+    @property
+    def lam(self):
+        return self.state[:, 13 + 2 * self.nd:]
+
+    @property
+    def sensor(self):
+        return self.out[:, :6 * self.nsens]
+
+    @property
+    def dof_force(self):
+        return self.out[:, 6 * self.nsens:6 * self.nsens + self.nd]
+
+    @property
+    def sph_force(self):
+        return self.out[:, 6 * self.nsens + self.nd:].reshape(self.N, self.nsph, 3)
+
+    def step(self, tau):
+        tau = np.ascontiguousarray(tau, self.np_real).reshape(self.N, self.nd)
+        self.lib.or_step(C.byref(self.model), C.byref(self.params), self.N, _ptr(self.state), _ptr(tau), _ptr(self.out))
+
+    def dynamics(self, env=0):
+        nv = self.spec.nv
+        M = np.zeros((nv, nv), self.np_real)
+        b = np.zeros(nv, self.np_real)
+        s = np.ascontiguousarray(self.state[env])
+        self.lib.or_dynamics(C.byref(self.model), C.byref(self.params), _ptr(s), _ptr(M), _ptr(b))
+        return M, b
+
+    def energy(self, env=0, poses=False):
+        creal = C.c_double if self.np_real == np.float64 else C.c_float
+        ke, pe = creal(), creal()
+        s = np.ascontiguousarray(self.state[env])
+        bp = np.zeros((self.spec.nb, 12), self.np_real)
+        self.lib.or_energy(C.byref(self.model), C.byref(self.params), _ptr(s), C.byref(ke), C.byref(pe), _ptr(bp))
+        return (ke.value, pe.value, bp) if poses else (ke.value, pe.value)

@@ -1,0 +1,538 @@
+/*
+ * oracle/physics.c -- CPU restatement of the per-env physics step.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.  The product
+ * path (isaacgymenvs_amd/csrc) never links or calls it.
+ *
+ * What it replaces: the closed `gym.simulate(sim)` + `gym.refresh_*_tensor` calls of the reference
+ * (call sites /root/reference/isaacgymenvs/tasks/base/vec_task.py:382,386; tasks/ant.py:233-235;
+ * tasks/humanoid.py:240-245).  The arithmetic of that path lives in the third-party, closed-source
+ * `isaacgym` Preview-4 binary (PhysX 5), which is not in /root/reference => PARITY UNPINNED against
+ * PhysX.  This file instead pins *our* engine's stated algorithm; it is itself pinned by first-principles
+ * known-answer tests (tests/test_oracle_physics.py: free fall, pendulum period, cart-pole ODE, energy and
+ * momentum conservation, static equilibrium weight).
+ *
+ * Algorithm (same maths as the HIP kernels, deliberately different formulation: table driven runtime
+ * loops, dense mass matrix, dense Cholesky, PGS in generalised-velocity space):
+ *   per sub-step h = dt/substeps
+ *     FK -> world-frame spatial quantities about O = root origin
+ *     bias  = RNEA(q, qd, qdd=0) incl. gravity              (world-frame spatial algebra)
+ *     M     = CRBA composite inertias
+ *     Mh    = M + diag(armature + h*damping + h^2*stiffness)        (implicit joint spring/damper)
+ *     qd*   = qd + h Mh^-1 (tau - bias - K(q-ref) - (D+hK) qd)
+ *     rows  = joint limits (1 row / limited dof), ground contacts (3 rows / active sphere)
+ *     PGS   iters sweeps, warm started, cone friction
+ *     integrate q with the new qd (semi-implicit Euler, exponential map for the root quaternion)
+ *
+ * Build: oracle/Makefile -> oracle/_build/liboracle_f64.so (real=double), liboracle_f32.so (real=float)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#ifdef REAL_FLOAT
+typedef float real;
+#define RSQRT(x) sqrtf(x)
+#define RSIN(x) sinf(x)
+#define RCOS(x) cosf(x)
+#define RFABS(x) fabsf(x)
+#else
+typedef double real;
+#define RSQRT(x) sqrt(x)
+#define RSIN(x) sin(x)
+#define RCOS(x) cos(x)
+#define RFABS(x) fabs(x)
+#endif
+
+#define MAXB 40
+#define MAXD 40
+#define MAXV 46
+#define MAXS 96
+#define MAXROWS (MAXD + 3 * MAXS)
+
+typedef struct {
+    int32_t nb, nd, fixed_base, nsph, nsens, pad0;
+    const int32_t *parent;       /* [nb] */
+    const real *bpos, *bquat;    /* [nb*3], [nb*4] xyzw */
+    const real *mass, *com, *inertia; /* [nb], [nb*3], [nb*6] xx yy zz xy xz yz */
+    const int32_t *dof_body, *dof_type; /* [nd] ; type 0 hinge 1 slide */
+    const real *dof_axis, *dof_anchor;  /* [nd*3] */
+    const real *dof_lower, *dof_upper;
+    const int32_t *dof_limited;
+    const real *dof_armature, *dof_damping, *dof_stiffness, *dof_springref;
+    const int32_t *sph_body;     /* [nsph] */
+    const real *sph_pos, *sph_rad, *sph_mu;
+    const int32_t *sens_body;    /* [nsens] */
+} OrModel;
+
+typedef struct {
+    real dt;
+    int32_t substeps, iters;
+    real gravity[3];
+    real contact_offset, rest_offset, max_depen_vel, erp, plane_mu, ground_z, cfm, warm;
+} OrParams;
+
+/* ------------------------------------------------------------------ small vector helpers */
+static inline void v3cross(const real *a, const real *b, real *o) {
+    real x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+static inline real v3dot(const real *a, const real *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static inline void m3v(const real *R, const real *v, real *o) {
+    real x = R[0] * v[0] + R[1] * v[1] + R[2] * v[2], y = R[3] * v[0] + R[4] * v[1] + R[5] * v[2],
+         z = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+static inline void m3tv(const real *R, const real *v, real *o) {
+    real x = R[0] * v[0] + R[3] * v[1] + R[6] * v[2], y = R[1] * v[0] + R[4] * v[1] + R[7] * v[2],
+         z = R[2] * v[0] + R[5] * v[1] + R[8] * v[2];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+static inline void m3m(const real *A, const real *B, real *o) {
+    real t[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) t[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+    memcpy(o, t, sizeof(t));
+}
+static inline void quat2mat(const real *q, real *R) { /* xyzw */
+    real x = q[0], y = q[1], z = q[2], w = q[3];
+    R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w); R[2] = 2 * (x * z + y * w);
+    R[3] = 2 * (x * y + z * w); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+    R[6] = 2 * (x * z - y * w); R[7] = 2 * (y * z + x * w); R[8] = 1 - 2 * (x * x + y * y);
+}
+static inline void axisangle2mat(const real *a, real th, real *R) {
+    real c = RCOS(th), s = RSIN(th), t = 1 - c;
+    R[0] = c + a[0] * a[0] * t; R[1] = a[0] * a[1] * t - a[2] * s; R[2] = a[0] * a[2] * t + a[1] * s;
+    R[3] = a[1] * a[0] * t + a[2] * s; R[4] = c + a[1] * a[1] * t; R[5] = a[1] * a[2] * t - a[0] * s;
+    R[6] = a[2] * a[0] * t - a[1] * s; R[7] = a[2] * a[1] * t + a[0] * s; R[8] = c + a[2] * a[2] * t;
+}
+/* spatial: X = [ang(3); lin(3)] */
+static inline void crm(const real *V, const real *S, real *o) { /* V x S (motion) */
+    real a[3], b[3], c[3];
+    v3cross(V, S, a); v3cross(V, S + 3, b); v3cross(V + 3, S, c);
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = b[0] + c[0]; o[4] = b[1] + c[1]; o[5] = b[2] + c[2];
+}
+static inline void crf(const real *V, const real *F, real *o) { /* V x* F (force: [n; f]) */
+    real a[3], b[3], c[3];
+    v3cross(V, F, a); v3cross(V + 3, F + 3, b); v3cross(V, F + 3, c);
+    o[0] = a[0] + b[0]; o[1] = a[1] + b[1]; o[2] = a[2] + b[2]; o[3] = c[0]; o[4] = c[1]; o[5] = c[2];
+}
+typedef struct { real m, h[3], I[6]; } SpI; /* I: xx yy zz xy xz yz about O */
+static inline void spi_mul(const SpI *I, const real *X, real *F) { /* F=[n;f] = I*[alpha;a] */
+    const real *al = X, *a = X + 3;
+    real Ia[3] = {I->I[0] * al[0] + I->I[3] * al[1] + I->I[4] * al[2], I->I[3] * al[0] + I->I[1] * al[1] + I->I[5] * al[2],
+                  I->I[4] * al[0] + I->I[5] * al[1] + I->I[2] * al[2]};
+    real hxa[3], hxal[3];
+    v3cross(I->h, a, hxa); v3cross(I->h, al, hxal);
+    F[0] = Ia[0] + hxa[0]; F[1] = Ia[1] + hxa[1]; F[2] = Ia[2] + hxa[2];
+    F[3] = I->m * a[0] - hxal[0]; F[4] = I->m * a[1] - hxal[1]; F[5] = I->m * a[2] - hxal[2];
+}
+
+/* ------------------------------------------------------------------ per-env workspace */
+typedef struct {
+    real R[MAXB][9], r[MAXB][3];      /* body frames (r relative to O) */
+    real ax[MAXD][3], an[MAXD][3];    /* world joint axes / anchors */
+    real S[MAXD][6];
+    SpI I[MAXB], Ic[MAXB];
+    real V[MAXB][6], A[MAXB][6], F[MAXB][6];
+    real M[MAXV][MAXV], L[MAXV][MAXV];
+    real bias[MAXV];
+} Work;
+
+static void fk(const OrModel *m, const real *root, const real *q, Work *w) {
+    for (int b = 0; b < m->nb; b++) {
+        real R[9], r[3];
+        if (b == 0) {
+            quat2mat(root + 3, R);
+            r[0] = r[1] = r[2] = 0;
+        } else {
+            int p = m->parent[b];
+            real Rl[9], t[3];
+            quat2mat(m->bquat + 4 * b, Rl);
+            m3m(w->R[p], Rl, R);
+            m3v(w->R[p], m->bpos + 3 * b, t);
+            r[0] = w->r[p][0] + t[0]; r[1] = w->r[p][1] + t[1]; r[2] = w->r[p][2] + t[2];
+        }
+        for (int d = 0; d < m->nd; d++) {
+            if (m->dof_body[d] != b) continue;
+            real a[3], pt[3], t[3];
+            m3v(R, m->dof_axis + 3 * d, a);
+            m3v(R, m->dof_anchor + 3 * d, t);
+            pt[0] = r[0] + t[0]; pt[1] = r[1] + t[1]; pt[2] = r[2] + t[2];
+            memcpy(w->ax[d], a, sizeof(a)); memcpy(w->an[d], pt, sizeof(pt));
+            if (m->dof_type[d] == 0) {
+                real Q[9], d3[3] = {r[0] - pt[0], r[1] - pt[1], r[2] - pt[2]}, dd[3];
+                axisangle2mat(a, q[d], Q);
+                m3m(Q, R, R);
+                m3v(Q, d3, dd);
+                r[0] = pt[0] + dd[0]; r[1] = pt[1] + dd[1]; r[2] = pt[2] + dd[2];
+                w->S[d][0] = a[0]; w->S[d][1] = a[1]; w->S[d][2] = a[2];
+                v3cross(pt, a, w->S[d] + 3);
+            } else {
+                r[0] += a[0] * q[d]; r[1] += a[1] * q[d]; r[2] += a[2] * q[d];
+                w->S[d][0] = w->S[d][1] = w->S[d][2] = 0;
+                w->S[d][3] = a[0]; w->S[d][4] = a[1]; w->S[d][5] = a[2];
+            }
+        }
+        memcpy(w->R[b], R, sizeof(R)); memcpy(w->r[b], r, sizeof(r));
+    }
+    /* world spatial inertias about O */
+    for (int b = 0; b < m->nb; b++) {
+        real c[3], t[3];
+        m3v(w->R[b], m->com + 3 * b, t);
+        c[0] = w->r[b][0] + t[0]; c[1] = w->r[b][1] + t[1]; c[2] = w->r[b][2] + t[2];
+        const real *il = m->inertia + 6 * b;
+        real Il[9] = {il[0], il[3], il[4], il[3], il[1], il[5], il[4], il[5], il[2]}, T[9], Iw[9], Rt[9];
+        const real *R = w->R[b];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rt[i * 3 + j] = R[j * 3 + i];
+        m3m(R, Il, T); m3m(T, Rt, Iw);
+        real mm = m->mass[b], cc = v3dot(c, c);
+        SpI *I = &w->I[b];
+        I->m = mm; I->h[0] = mm * c[0]; I->h[1] = mm * c[1]; I->h[2] = mm * c[2];
+        I->I[0] = Iw[0] + mm * (cc - c[0] * c[0]); I->I[1] = Iw[4] + mm * (cc - c[1] * c[1]);
+        I->I[2] = Iw[8] + mm * (cc - c[2] * c[2]);
+        I->I[3] = Iw[1] - mm * c[0] * c[1]; I->I[4] = Iw[2] - mm * c[0] * c[2]; I->I[5] = Iw[5] - mm * c[1] * c[2];
+    }
+}
+
+static inline int nvof(const OrModel *m) { return m->nd + (m->fixed_base ? 0 : 6); }
+static inline int jo(const OrModel *m) { return m->fixed_base ? 0 : 6; }
+
+/* bias = RNEA(q, qd, 0) incl. gravity; also fills body velocities V */
+static void rnea_bias(const OrModel *m, const real *root, const real *qd, const real *g, Work *w) {
+    int off = jo(m);
+    for (int b = 0; b < m->nb; b++) {
+        real Vc[6], Ac[6];
+        if (b == 0) {
+            if (m->fixed_base) {
+                for (int k = 0; k < 6; k++) Vc[k] = 0, Ac[k] = 0;
+                Ac[3] = -g[0]; Ac[4] = -g[1]; Ac[5] = -g[2];
+            } else {
+                const real *v = root + 7, *om = root + 10;
+                real wxv[3];
+                v3cross(om, v, wxv);
+                Vc[0] = om[0]; Vc[1] = om[1]; Vc[2] = om[2]; Vc[3] = v[0]; Vc[4] = v[1]; Vc[5] = v[2];
+                Ac[0] = Ac[1] = Ac[2] = 0;
+                Ac[3] = -wxv[0] - g[0]; Ac[4] = -wxv[1] - g[1]; Ac[5] = -wxv[2] - g[2];
+            }
+        } else {
+            memcpy(Vc, w->V[m->parent[b]], sizeof(Vc)); memcpy(Ac, w->A[m->parent[b]], sizeof(Ac));
+        }
+        for (int d = 0; d < m->nd; d++) {
+            if (m->dof_body[d] != b) continue;
+            real Sd[6];
+            crm(Vc, w->S[d], Sd);
+            for (int k = 0; k < 6; k++) { Ac[k] += Sd[k] * qd[d]; Vc[k] += w->S[d][k] * qd[d]; }
+        }
+        memcpy(w->V[b], Vc, sizeof(Vc)); memcpy(w->A[b], Ac, sizeof(Ac));
+        real IA[6], IV[6], VxIV[6];
+        spi_mul(&w->I[b], Ac, IA); spi_mul(&w->I[b], Vc, IV); crf(Vc, IV, VxIV);
+        for (int k = 0; k < 6; k++) w->F[b][k] = IA[k] + VxIV[k];
+    }
+    for (int b = m->nb - 1; b > 0; b--)
+        for (int k = 0; k < 6; k++) w->F[m->parent[b]][k] += w->F[b][k];
+    for (int d = 0; d < m->nd; d++) {
+        const real *F = w->F[m->dof_body[d]], *S = w->S[d];
+        real s = 0;
+        for (int k = 0; k < 6; k++) s += S[k] * F[k];
+        w->bias[off + d] = s;
+    }
+    if (!m->fixed_base) {
+        w->bias[0] = w->F[0][3]; w->bias[1] = w->F[0][4]; w->bias[2] = w->F[0][5];
+        w->bias[3] = w->F[0][0]; w->bias[4] = w->F[0][1]; w->bias[5] = w->F[0][2];
+    }
+}
+
+static void crba(const OrModel *m, Work *w) {
+    int nv = nvof(m), off = jo(m);
+    for (int i = 0; i < nv; i++) for (int j = 0; j < nv; j++) w->M[i][j] = 0;
+    for (int b = 0; b < m->nb; b++) w->Ic[b] = w->I[b];
+    for (int b = m->nb - 1; b > 0; b--) {
+        SpI *P = &w->Ic[m->parent[b]], *C = &w->Ic[b];
+        P->m += C->m;
+        for (int k = 0; k < 3; k++) P->h[k] += C->h[k];
+        for (int k = 0; k < 6; k++) P->I[k] += C->I[k];
+    }
+    for (int i = 0; i < m->nd; i++) {
+        real F[6];
+        int bi = m->dof_body[i];
+        spi_mul(&w->Ic[bi], w->S[i], F);
+        /* ancestors: earlier dofs on the same body, then every dof of every ancestor body */
+        for (int j = 0; j <= i; j++) {
+            int bj = m->dof_body[j], anc = 0;
+            if (bj == bi) anc = 1;
+            else { int b = m->parent[bi]; while (b >= 0) { if (b == bj) { anc = 1; break; } b = m->parent[b]; } }
+            if (!anc) continue;
+            real s = 0;
+            for (int k = 0; k < 6; k++) s += w->S[j][k] * F[k];
+            w->M[off + i][off + j] = w->M[off + j][off + i] = s;
+        }
+        if (!m->fixed_base) {
+            for (int k = 0; k < 3; k++) {
+                w->M[k][off + i] = w->M[off + i][k] = F[3 + k];
+                w->M[3 + k][off + i] = w->M[off + i][3 + k] = F[k];
+            }
+        }
+    }
+    if (!m->fixed_base) {
+        const SpI *I = &w->Ic[0];
+        for (int k = 0; k < 3; k++) w->M[k][k] = I->m;
+        /* M_vw = -[h]x ; M_wv = [h]x */
+        real hx[9] = {0, -I->h[2], I->h[1], I->h[2], 0, -I->h[0], -I->h[1], I->h[0], 0};
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { w->M[i][3 + j] = -hx[i * 3 + j]; w->M[3 + i][j] = hx[i * 3 + j]; }
+        w->M[3][3] = I->I[0]; w->M[4][4] = I->I[1]; w->M[5][5] = I->I[2];
+        w->M[3][4] = w->M[4][3] = I->I[3]; w->M[3][5] = w->M[5][3] = I->I[4]; w->M[4][5] = w->M[5][4] = I->I[5];
+    }
+}
+
+static void chol(int n, real A[MAXV][MAXV], real L[MAXV][MAXV]) {
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j <= i; j++) {
+            real s = A[i][j];
+            for (int k = 0; k < j; k++) s -= L[i][k] * L[j][k];
+            if (i == j) L[i][i] = RSQRT(s > (real)1e-30 ? s : (real)1e-30);
+            else L[i][j] = s / L[j][j];
+        }
+}
+static void chol_solve(int n, real L[MAXV][MAXV], const real *b, real *x) {
+    real y[MAXV];
+    for (int i = 0; i < n; i++) { real s = b[i]; for (int k = 0; k < i; k++) s -= L[i][k] * y[k]; y[i] = s / L[i][i]; }
+    for (int i = n - 1; i >= 0; i--) { real s = y[i]; for (int k = i + 1; k < n; k++) s -= L[k][i] * x[k]; x[i] = s / L[i][i]; }
+}
+
+/* J row of a world direction u at point xc (rel O) on body b */
+static void point_jac(const OrModel *m, const Work *w, int b, const real *xc, const real *u, real *J) {
+    int nv = nvof(m), off = jo(m);
+    for (int i = 0; i < nv; i++) J[i] = 0;
+    if (!m->fixed_base) {
+        real t[3];
+        v3cross(xc, u, t);
+        J[0] = u[0]; J[1] = u[1]; J[2] = u[2]; J[3] = t[0]; J[4] = t[1]; J[5] = t[2];
+    }
+    for (int bb = b; bb >= 0; bb = m->parent[bb])
+        for (int d = 0; d < m->nd; d++) {
+            if (m->dof_body[d] != bb) continue;
+            if (m->dof_type[d] == 0) {
+                real rr[3] = {xc[0] - w->an[d][0], xc[1] - w->an[d][1], xc[2] - w->an[d][2]}, t[3];
+                v3cross(w->ax[d], rr, t);
+                J[off + d] = v3dot(u, t);
+            } else J[off + d] = v3dot(u, w->ax[d]);
+        }
+}
+
+/* ------------------------------------------------------------------ one env, one full step of dt
+ * state layout per env:  root[13] | q[nd] | qd[nd] | lam_c[3*nsph] | lam_l[nd]
+ * outputs per env:       sensor[6*nsens] | dof_force[nd] | sph_force[3*nsph] (world)
+ */
+static void step_env(const OrModel *m, const OrParams *p, real *root, real *q, real *qd, real *lam_c, real *lam_l,
+                     const real *tau, real *sensor, real *dof_force, real *sph_force) {
+    static _Thread_local Work w;
+    int nv = nvof(m), off = jo(m), nd = m->nd;
+    real h = p->dt / p->substeps;
+    for (int ss = 0; ss < p->substeps; ss++) {
+        fk(m, root, q, &w);
+        rnea_bias(m, root, qd, p->gravity, &w);
+        crba(m, &w);
+        real rhs[MAXV], v[MAXV], dv[MAXV];
+        for (int i = 0; i < off; i++) rhs[i] = -w.bias[i];
+        for (int d = 0; d < nd; d++) {
+            real K = m->dof_stiffness[d], D = m->dof_damping[d];
+            w.M[off + d][off + d] += m->dof_armature[d] + h * D + h * h * K;
+            rhs[off + d] = tau[d] - w.bias[off + d] - K * (q[d] - m->dof_springref[d]) - (D + h * K) * qd[d];
+        }
+        chol(nv, w.M, w.L);
+        chol_solve(nv, w.L, rhs, dv);
+        if (!m->fixed_base) { for (int k = 0; k < 3; k++) { v[k] = root[7 + k]; v[3 + k] = root[10 + k]; } }
+        for (int d = 0; d < nd; d++) v[off + d] = qd[d];
+        for (int i = 0; i < nv; i++) v[i] += h * dv[i];
+
+        /* ---------------- constraint rows */
+        static _Thread_local real J[MAXROWS][MAXV], B[MAXROWS][MAXV];
+        static _Thread_local real Ainv[MAXROWS], vt[MAXROWS], lam[MAXROWS];
+        int nrow = 0;
+        int lim_row[MAXD], sph_row[MAXS];
+        real lim_sign[MAXD];
+        for (int d = 0; d < nd; d++) {
+            lim_row[d] = -1;
+            if (!m->dof_limited[d]) { lam_l[d] = 0; continue; }
+            real lo = m->dof_lower[d], up = m->dof_upper[d];
+            real dl = q[d] - lo, du = up - q[d], C, s;
+            if (dl < du) { C = dl; s = 1; } else { C = du; s = -1; }
+            /* warm-start impulse only survives if the same side stays active */
+            if (lam_l[d] * s < 0) lam_l[d] = 0;
+            int r = nrow++;
+            lim_row[d] = r; lim_sign[d] = s;
+            for (int i = 0; i < nv; i++) J[r][i] = 0;
+            J[r][off + d] = s;
+            vt[r] = (C >= 0) ? -C / h : fmin(-C * p->erp / h, p->max_depen_vel);
+            lam[r] = RFABS(lam_l[d]) * p->warm;
+        }
+        for (int s = 0; s < m->nsph; s++) {
+            sph_row[s] = -1;
+            int b = m->sph_body[s];
+            real t[3], x[3];
+            m3v(w.R[b], m->sph_pos + 3 * s, t);
+            x[0] = w.r[b][0] + t[0]; x[1] = w.r[b][1] + t[1]; x[2] = w.r[b][2] + t[2];
+            real dist = (root[2] + x[2]) - m->sph_rad[s] - p->ground_z;
+            if (dist >= p->contact_offset) { lam_c[3 * s] = lam_c[3 * s + 1] = lam_c[3 * s + 2] = 0; continue; }
+            real xc[3] = {x[0], x[1], x[2] - m->sph_rad[s]};
+            real gap = dist - p->rest_offset;
+            static const real dirs[3][3] = {{0, 0, 1}, {1, 0, 0}, {0, 1, 0}};
+            sph_row[s] = nrow;
+            for (int k = 0; k < 3; k++) {
+                int r = nrow++;
+                point_jac(m, &w, b, xc, dirs[k], J[r]);
+                vt[r] = (k == 0) ? ((gap >= 0) ? -gap / h : fmin(-gap * p->erp / h, p->max_depen_vel)) : 0;
+                lam[r] = lam_c[3 * s + k] * p->warm;
+            }
+        }
+        for (int r = 0; r < nrow; r++) {
+            chol_solve(nv, w.L, J[r], B[r]);
+            real a = p->cfm;
+            for (int i = 0; i < nv; i++) a += J[r][i] * B[r][i];
+            Ainv[r] = 1 / a;
+            if (lam[r] != 0) for (int i = 0; i < nv; i++) v[i] += B[r][i] * lam[r];
+        }
+        for (int it = 0; it < p->iters; it++) {
+            for (int d = 0; d < nd; d++) {
+                int r = lim_row[d];
+                if (r < 0) continue;
+                real vn = 0;
+                for (int i = 0; i < nv; i++) vn += J[r][i] * v[i];
+                real nl = lam[r] - (vn - vt[r]) * Ainv[r];
+                if (nl < 0) nl = 0;
+                real dl = nl - lam[r];
+                lam[r] = nl;
+                for (int i = 0; i < nv; i++) v[i] += B[r][i] * dl;
+            }
+            for (int s = 0; s < m->nsph; s++) {
+                int r0 = sph_row[s];
+                if (r0 < 0) continue;
+                real mu = (real)0.5 * (m->sph_mu[s] + p->plane_mu);
+                { /* normal */
+                    int r = r0;
+                    real vn = 0;
+                    for (int i = 0; i < nv; i++) vn += J[r][i] * v[i];
+                    real nl = lam[r] - (vn - vt[r]) * Ainv[r];
+                    if (nl < 0) nl = 0;
+                    real dl = nl - lam[r];
+                    lam[r] = nl;
+                    for (int i = 0; i < nv; i++) v[i] += B[r][i] * dl;
+                }
+                real lt[2];
+                for (int k = 1; k <= 2; k++) { /* unclamped tangential updates */
+                    int r = r0 + k;
+                    real vn = 0;
+                    for (int i = 0; i < nv; i++) vn += J[r][i] * v[i];
+                    real dl = -(vn - vt[r]) * Ainv[r];
+                    lt[k - 1] = lam[r] + dl;
+                    for (int i = 0; i < nv; i++) v[i] += B[r][i] * dl;
+                }
+                /* project onto the friction disc |lt| <= mu * ln, apply the correction */
+                real lim = mu * lam[r0], nrm = RSQRT(lt[0] * lt[0] + lt[1] * lt[1]);
+                real sc = (nrm > lim) ? lim / (nrm > (real)1e-30 ? nrm : (real)1e-30) : 1;
+                for (int k = 1; k <= 2; k++) {
+                    int r = r0 + k;
+                    real nl = lt[k - 1] * sc, dl = nl - lt[k - 1];
+                    lam[r] = nl;
+                    if (dl != 0) for (int i = 0; i < nv; i++) v[i] += B[r][i] * dl;
+                }
+            }
+        }
+        /* ---------------- write back impulses, sensors */
+        for (int d = 0; d < nd; d++) {
+            real ll = 0;
+            if (lim_row[d] >= 0) { ll = lam[lim_row[d]] * lim_sign[d]; lam_l[d] = ll; }
+            dof_force[d] = tau[d] - m->dof_stiffness[d] * (q[d] - m->dof_springref[d]) - m->dof_damping[d] * v[off + d] + ll / h;
+        }
+        for (int k = 0; k < 6 * m->nsens; k++) sensor[k] = 0;
+        for (int s = 0; s < m->nsph; s++) {
+            real f[3] = {0, 0, 0};
+            if (sph_row[s] >= 0) {
+                int r0 = sph_row[s];
+                lam_c[3 * s] = lam[r0]; lam_c[3 * s + 1] = lam[r0 + 1]; lam_c[3 * s + 2] = lam[r0 + 2];
+                f[0] = lam[r0 + 1] / h; f[1] = lam[r0 + 2] / h; f[2] = lam[r0] / h;
+            }
+            sph_force[3 * s] = f[0]; sph_force[3 * s + 1] = f[1]; sph_force[3 * s + 2] = f[2];
+            if (sph_row[s] < 0) continue;
+            int b = m->sph_body[s];
+            for (int k = 0; k < m->nsens; k++) {
+                if (m->sens_body[k] != b) continue;
+                real t[3], x[3], arm[3], tq[3], fl[3], tl[3];
+                m3v(w.R[b], m->sph_pos + 3 * s, t);
+                x[0] = w.r[b][0] + t[0]; x[1] = w.r[b][1] + t[1]; x[2] = w.r[b][2] + t[2] - m->sph_rad[s];
+                arm[0] = x[0] - w.r[b][0]; arm[1] = x[1] - w.r[b][1]; arm[2] = x[2] - w.r[b][2];
+                v3cross(arm, f, tq);
+                m3tv(w.R[b], f, fl); m3tv(w.R[b], tq, tl);
+                for (int c = 0; c < 3; c++) { sensor[6 * k + c] += fl[c]; sensor[6 * k + 3 + c] += tl[c]; }
+            }
+        }
+        /* ---------------- integrate */
+        for (int d = 0; d < nd; d++) { qd[d] = v[off + d]; q[d] += h * qd[d]; }
+        if (!m->fixed_base) {
+            for (int k = 0; k < 3; k++) { root[7 + k] = v[k]; root[10 + k] = v[3 + k]; root[k] += h * v[k]; }
+            real om[3] = {v[3], v[4], v[5]};
+            real an = RSQRT(v3dot(om, om)), th = an * h;
+            real dq[4];
+            if (th > (real)1e-12) {
+                real s = RSIN(th / 2) / an;
+                dq[0] = om[0] * s; dq[1] = om[1] * s; dq[2] = om[2] * s; dq[3] = RCOS(th / 2);
+            } else { dq[0] = om[0] * h / 2; dq[1] = om[1] * h / 2; dq[2] = om[2] * h / 2; dq[3] = 1; }
+            real *Q = root + 3;
+            real x = dq[3] * Q[0] + dq[0] * Q[3] + dq[1] * Q[2] - dq[2] * Q[1];
+            real y = dq[3] * Q[1] - dq[0] * Q[2] + dq[1] * Q[3] + dq[2] * Q[0];
+            real z = dq[3] * Q[2] + dq[0] * Q[1] - dq[1] * Q[0] + dq[2] * Q[3];
+            real ww = dq[3] * Q[3] - dq[0] * Q[0] - dq[1] * Q[1] - dq[2] * Q[2];
+            real n = 1 / RSQRT(x * x + y * y + z * z + ww * ww);
+            Q[0] = x * n; Q[1] = y * n; Q[2] = z * n; Q[3] = ww * n;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ exported API (ctypes) */
+int or_state_size(const OrModel *m) { return 13 + 2 * m->nd + 3 * m->nsph + m->nd; }
+int or_out_size(const OrModel *m) { return 6 * m->nsens + m->nd + 3 * m->nsph; }
+
+void or_step(const OrModel *m, const OrParams *p, int nenv, real *state, const real *tau, real *out) {
+    int ss = or_state_size(m), os = or_out_size(m), nd = m->nd;
+#pragma omp parallel for schedule(static)
+    for (int e = 0; e < nenv; e++) {
+        real *s = state + (size_t)e * ss, *o = out + (size_t)e * os;
+        step_env(m, p, s, s + 13, s + 13 + nd, s + 13 + 2 * nd, s + 13 + 2 * nd + 3 * m->nsph, tau + (size_t)e * nd, o,
+                 o + 6 * m->nsens, o + 6 * m->nsens + nd);
+    }
+}
+
+/* dense M (nv*nv row-major) and bias (nv) for one env: used to cross-check the HIP host build */
+void or_dynamics(const OrModel *m, const OrParams *p, const real *state, real *Mout, real *bias_out) {
+    static _Thread_local Work w;
+    int nv = nvof(m);
+    fk(m, state, state + 13, &w);
+    rnea_bias(m, state, state + 13 + m->nd, p->gravity, &w);
+    crba(m, &w);
+    for (int i = 0; i < nv; i++) { bias_out[i] = w.bias[i]; for (int j = 0; j < nv; j++) Mout[i * nv + j] = w.M[i][j]; }
+}
+
+/* kinetic + potential energy and world-frame body poses (pos[3]+R[9] per body), for known-answer tests */
+void or_energy(const OrModel *m, const OrParams *p, const real *state, real *ke, real *pe, real *body_pose) {
+    static _Thread_local Work w;
+    const real zero[3] = {0, 0, 0};
+    fk(m, state, state + 13, &w);
+    rnea_bias(m, state, state + 13 + m->nd, zero, &w);
+    real K = 0, P = 0;
+    for (int b = 0; b < m->nb; b++) {
+        real IV[6];
+        spi_mul(&w.I[b], w.V[b], IV);
+        for (int k = 0; k < 6; k++) K += (real)0.5 * w.V[b][k] * IV[k];
+        real c[3] = {w.I[b].h[0], w.I[b].h[1], w.I[b].h[2]}; /* m*c rel O */
+        real O[3] = {state[0], state[1], state[2]};
+        for (int k = 0; k < 3; k++) P -= p->gravity[k] * (c[k] + m->mass[b] * O[k]);
+        if (body_pose) {
+            for (int k = 0; k < 3; k++) body_pose[12 * b + k] = O[k] + w.r[b][k];
+            for (int k = 0; k < 9; k++) body_pose[12 * b + 3 + k] = w.R[b][k];
+        }
+    }
+    *ke = K; *pe = P;
+}
+
+int or_sizeof_real(void) { return (int)sizeof(real); }
