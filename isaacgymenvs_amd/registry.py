@@ -1,0 +1,39 @@
+"""Which compiled robot models exist, their generated C++ struct names and per-task sensor placement."""
+from __future__ import annotations
+
+import os
+
+from .assets.model import ModelSpec
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+# name -> (struct name, sensor body names (reference file:line))
+MODELS = {
+    "cartpole": dict(struct="ModelCartpole", sensors=[]),
+    # reference ant.py:170-178: force sensors on every body whose name contains "foot"
+    "ant": dict(struct="ModelAnt", sensors=["front_left_foot", "front_right_foot", "left_back_foot", "right_back_foot"]),
+    # reference humanoid.py:162-168: right_foot, left_foot
+    "humanoid": dict(struct="ModelHumanoid", sensors=["right_foot", "left_foot"]),
+}
+
+
+def load_model(name) -> ModelSpec:
+    return ModelSpec.load(os.path.join(_HERE, "models", name + ".json"))
+
+
+def sensor_bodies(name, spec=None):
+    spec = spec or load_model(name)
+    return [spec.body_names.index(n) for n in MODELS[name]["sensors"]]
+
+
+def generate_headers(out_dir=None):
+    from .codegen import emit_model_header, write_if_changed
+    out_dir = out_dir or os.path.join(_HERE, "csrc", "gen")
+    paths = []
+    for name, e in MODELS.items():
+        spec = load_model(name)
+        txt = emit_model_header(spec, e["struct"], sensor_bodies(name, spec))
+        p = os.path.join(out_dir, f"model_{name}.h")
+        write_if_changed(p, txt)
+        paths.append(p)
+    return paths

@@ -1,0 +1,44 @@
+// Host (g++) build of the specialised engine core -- TEST-ONLY.  Lets the CPU test-suite compare the exact
+// code the HIP kernels run (csrc/core/engine.hpp + generated model tables) against the independent oracle
+// without a GPU.  Never loaded by the product path.
+#include <cstring>
+#include "../../isaacgymenvs_amd/csrc/core/engine.hpp"
+#include "../../isaacgymenvs_amd/csrc/gen/model_cartpole.h"
+#include "../../isaacgymenvs_amd/csrc/gen/model_ant.h"
+#ifndef HOSTSIM_NO_HUMANOID
+#include "../../isaacgymenvs_amd/csrc/gen/model_humanoid.h"
+#endif
+
+using namespace mi;
+
+// state/out layouts identical to oracle/physics.c (AoS per env)
+template <class M>
+static void run(const SimParams* P, int nenv, float* state, const float* tau, float* out) {
+    constexpr int ND = M::ND, NSPH = M::NSPH, NSENS = M::NSENS;
+    const int ss = 13 + 2 * ND + 3 * NSPH + ND, os = 6 * NSENS + ND + 3 * NSPH;
+#pragma omp parallel for schedule(static)
+    for (int e = 0; e < nenv; ++e) {
+        float* s = state + (size_t)e * ss;
+        float* o = out + (size_t)e * os;
+        Sim<M> sim;
+        for (int k = 0; k < 13; ++k) sim.root[k] = s[k];
+        for (int k = 0; k < ND; ++k) { sim.q[k] = s[13 + k]; sim.qd[k] = s[13 + ND + k]; sim.laml[k] = s[13 + 2 * ND + 3 * NSPH + k]; }
+        for (int k = 0; k < 3 * NSPH; ++k) sim.lamc[k] = s[13 + 2 * ND + k];
+        sim.step(*P, tau + (size_t)e * ND);
+        for (int k = 0; k < 13; ++k) s[k] = sim.root[k];
+        for (int k = 0; k < ND; ++k) { s[13 + k] = sim.q[k]; s[13 + ND + k] = sim.qd[k]; s[13 + 2 * ND + 3 * NSPH + k] = sim.laml[k]; }
+        for (int k = 0; k < 3 * NSPH; ++k) s[13 + 2 * ND + k] = sim.lamc[k];
+        for (int k = 0; k < 6 * NSENS; ++k) o[k] = sim.sensor[k];
+        for (int k = 0; k < ND; ++k) o[6 * NSENS + k] = sim.dof_force[k];
+    }
+}
+
+extern "C" int hs_step(const char* model, const SimParams* P, int nenv, float* state, const float* tau, float* out) {
+    if (!strcmp(model, "cartpole")) run<ModelCartpole>(P, nenv, state, tau, out);
+    else if (!strcmp(model, "ant")) run<ModelAnt>(P, nenv, state, tau, out);
+#ifndef HOSTSIM_NO_HUMANOID
+    else if (!strcmp(model, "humanoid")) run<ModelHumanoid>(P, nenv, state, tau, out);
+#endif
+    else return -1;
+    return 0;
+}
