@@ -1,0 +1,148 @@
+/*
+ * mi_engine.h -- C ABI of the MI355X-native vectorised RL-environment engine (libmi_engine.so).
+ *
+ * The reference (isaac-sim/IsaacGymEnvs) has no FFI of its own: its hot path crosses from Python into the
+ * closed `isaacgym` pybind module.  This header is the C boundary a replacement for that module binds to.
+ * Each entry point cites the reference interface it replaces (paths relative to /root/reference/).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless stated otherwise; no torch types cross this boundary;
+ *   - the caller owns all memory: the engine state lives in one caller-allocated "arena"
+ *     (mi_engine_arena_bytes), tensors are described as (byte offset, shape, element strides) views of it,
+ *     exactly like `gym.acquire_*_tensor` + `gymtorch.wrap_tensor` expose simulator memory
+ *     (isaacgymenvs/tasks/ant.py:77-95);
+ *   - every launch is enqueued on the caller's HIP stream (`stream` = hipStream_t, NULL = default stream), no
+ *     host synchronisation inside;
+ *   - return value 0 = ok, negative = error, message via mi_last_error() (thread local);
+ *   - quaternions xyzw; fp32 state; reset/progress buffers int64 (isaacgymenvs/tasks/base/vec_task.py:316-323).
+ */
+#ifndef MI_ENGINE_H
+#define MI_ENGINE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_MAX_DOF 32
+#define MI_ABI_VERSION 1
+
+typedef struct MiEngine MiEngine;
+
+/* gymapi.SimParams subset parsed by VecTask.__parse_sim_params (vec_task.py:514-562) plus solver constants */
+typedef struct {
+    float dt;
+    int32_t substeps;          /* sim.substeps */
+    int32_t iters;             /* sim.physx.num_position_iterations */
+    float gravity[3];
+    float contact_offset;      /* sim.physx.contact_offset */
+    float rest_offset;         /* sim.physx.rest_offset */
+    float max_depen_vel;       /* sim.physx.max_depenetration_velocity */
+    float erp;                 /* penetration/limit error reduction per sub-step (engine constant, default 0.5) */
+    float plane_mu;            /* env.plane.staticFriction (ant.py:128-133) */
+    float ground_z;
+    float cfm;                 /* constraint regularisation (default 1e-6) */
+    float warm;                /* warm-start factor (default 1) */
+} MiSimParams;
+
+/* task parameters of Ant / Humanoid: the scalars the reference passes into compute_*_observations/_reward
+ * (ant.py:214-242, humanoid.py:218-251) and uses in reset_idx / pre_physics_step (ant.py:252-285) */
+typedef struct {
+    float dt, dof_vel_scale, contact_force_scale, angular_velocity_scale, power_scale;
+    float heading_weight, up_weight, actions_cost, energy_cost, joints_at_limit_cost;
+    float death_cost, termination_height, max_episode_length, clip_actions, max_motor_effort, start_height;
+    float gear[MI_MAX_DOF];
+    float dof_lower[MI_MAX_DOF], dof_upper[MI_MAX_DOF], initial_dof_pos[MI_MAX_DOF];
+    float targets[3];
+    float inv_start_rot[4];
+    float basis_vec0[3], basis_vec1[3];
+    float reset_pos_noise, reset_vel_noise;
+} MiLocoParams;
+
+/* task parameters of Cartpole (cartpole.py:40-47) */
+typedef struct {
+    float reset_dist, max_push_effort, max_episode_length, clip_actions;
+} MiCartpoleParams;
+
+typedef struct {
+    int32_t num_obs, num_actions, num_dofs, num_bodies, num_sensors, num_contact_spheres, fixed_base, task_params_bytes;
+} MiTaskInfo;
+
+enum { MI_F32 = 0, MI_I64 = 1, MI_U8 = 2, MI_I32 = 3 };
+
+typedef struct {
+    char name[48];
+    int32_t dtype;       /* MI_F32 ... */
+    int32_t ndim;
+    int64_t shape[4];
+    int64_t stride[4];   /* in elements */
+    int64_t byte_offset; /* from the arena base */
+} MiTensorDesc;
+
+/* ---- discovery ------------------------------------------------------------------------------------------- */
+int mi_abi_version(void);
+/* task in {"Cartpole","Ant","Humanoid"}: replaces isaacgym_task_map lookup (isaacgymenvs/tasks/__init__.py:88-114)
+ * + gym.get_asset_{dof,rigid_body}_count (ant.py:155-156) */
+int mi_task_info(const char* task, MiTaskInfo* out);
+size_t mi_engine_arena_bytes(const char* task, int num_envs);
+
+/* ---- lifecycle: replaces gym.create_sim / load_asset / create_env / create_actor / prepare_sim
+ *      (vec_task.py:261-262, ant.py:116-212) and VecTask.allocate_buffers (vec_task.py:301-324) ------------- */
+int mi_engine_create(const char* task, const MiSimParams* sim, const void* task_params, size_t task_params_bytes,
+                     int num_envs, int env_id_offset /* global id of env 0: rank * num_envs */, uint64_t seed,
+                     void* arena, size_t arena_bytes, MiEngine** out);
+/* fills the arena: initial root/dof state, reset_buf = 1, progress = 0 ... (vec_task.py:310-323) */
+int mi_engine_init_state(MiEngine* e, void* stream);
+void mi_engine_destroy(MiEngine* e);
+
+/* ---- tensor views: replaces gym.acquire_{actor_root_state,dof_state,force_sensor,dof_force}_tensor +
+ *      gymtorch.wrap_tensor (ant.py:77-95, humanoid.py:78-98) and the VecTask buffers -------------------------- */
+int mi_engine_num_tensors(const MiEngine* e);
+int mi_engine_tensor_desc(const MiEngine* e, int index, MiTensorDesc* out);
+
+/* ---- the hot path ------------------------------------------------------------------------------------------
+ * One fused launch = VecTask.step (vec_task.py:360-408): clamp actions -> pre_physics_step ->
+ * control_freq_inv x gym.simulate -> post_physics_step (progress++, reset flagged envs, observations, reward)
+ * -> timeout mask.  `actions` is [num_envs, num_actions] row-major fp32. */
+int mi_engine_step(MiEngine* e, const float* actions, void* stream);
+/* reset_idx(env_ids) for explicit resets (ant.py:252-279, cartpole.py:144-157; used by VecTask.reset_done,
+ * vec_task.py:440-455).  env_ids: int64 device pointer. */
+int mi_engine_reset_idx(MiEngine* e, const int64_t* env_ids, int n, void* stream);
+/* physics only: gym.simulate(sim) + refresh_* (vec_task.py:382; ant.py:233-235) with the efforts currently in
+ * the "dof_actuation_force" tensor (gym.set_dof_actuation_force_tensor, ant.py:285) */
+int mi_engine_simulate(MiEngine* e, void* stream);
+/* optional knobs: "clip_obs" (env.clipObservations, vec_task.py:115), "control_freq_inv" (env.controlFrequencyInv, :111) */
+int mi_engine_set_option(MiEngine* e, const char* key, double value);
+/* which slot of the "obs_out" ring ([2, N, num_obs], clamped copy of obs_buf = what VecTask.step returns as
+ * obs_dict["obs"], vec_task.py:402) the most recent step wrote */
+int mi_engine_last_ring(const MiEngine* e);
+
+/* ---- stand-alone replacements of the reference's @torch.jit.script functions (row-major contiguous
+ *      [n, k] fp32 tensors, int64 reset/progress, same argument meaning and order as the reference) ---------- */
+/* compute_ant_observations (ant.py:374-408) / compute_humanoid_observations (humanoid.py:378-413);
+ * dof_force may be NULL for Ant.  potentials is in/out (the function returns the new potentials and the old
+ * one as prev_potentials, ant.py:390-391). */
+int mi_compute_locomotion_observations(const char* task, int n, const MiLocoParams* p, const float* root_states,
+                                       const float* targets, float* potentials, float* prev_potentials,
+                                       const float* inv_start_rot, const float* dof_pos, const float* dof_vel,
+                                       const float* dof_force, const float* dof_limits_lower,
+                                       const float* dof_limits_upper, const float* sensor_force_torques,
+                                       const float* actions, const float* basis_vec0, const float* basis_vec1,
+                                       float* obs_buf, float* up_vec, float* heading_vec, void* stream);
+/* compute_ant_reward (ant.py:325-371) / compute_humanoid_reward (humanoid.py:323-375) */
+int mi_compute_locomotion_reward(const char* task, int n, const MiLocoParams* p, const float* obs_buf,
+                                 const int64_t* reset_buf_in, const int64_t* progress_buf, const float* actions,
+                                 const float* potentials, const float* prev_potentials, float* rew_buf,
+                                 int64_t* reset_buf_out, void* stream);
+/* compute_cartpole_reward (cartpole.py:180-196) */
+int mi_compute_cartpole_reward(int n, const MiCartpoleParams* p, const float* pole_angle, const float* pole_vel,
+                               const float* cart_vel, const float* cart_pos, const int64_t* reset_buf_in,
+                               const int64_t* progress_buf, float* rew_buf, int64_t* reset_buf_out, void* stream);
+
+const char* mi_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_ENGINE_H */

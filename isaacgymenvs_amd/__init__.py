@@ -1,0 +1,36 @@
+"""isaacgymenvs_amd -- MI355X-native vectorised RL-environment engine with the IsaacGymEnvs public API.
+
+`make()` mirrors reference isaacgymenvs/__init__.py:14-55 (same signature and quirks: `seed` is not consumed by
+env creation on the reference path -- here it additionally seeds the in-kernel reset RNG; `num_envs` is applied
+only when no cfg is passed).
+"""
+from __future__ import annotations
+
+import os
+
+__version__ = "0.1.0"
+
+
+def make(seed: int, task: str, num_envs: int, sim_device: str, rl_device: str, graphics_device_id: int = -1,
+         headless: bool = False, multi_gpu: bool = False, virtual_screen_capture: bool = False,
+         force_render: bool = True, cfg=None):
+    from .tasks import isaacgym_task_map
+    from .utils.config import compose, omegaconf_to_dict
+    if cfg is None:
+        root = compose("config", overrides=[f"task={task}"])
+        cfg_dict = omegaconf_to_dict(root["task"])
+        cfg_dict["env"]["numEnvs"] = num_envs
+    else:
+        cfg_dict = omegaconf_to_dict(cfg["task"] if "task" in cfg and hasattr(cfg["task"], "items") and "env" in cfg["task"] else cfg)
+    if multi_gpu:  # reference utils/rlgames_utils.py:89-107: one process per GPU, device = cuda:LOCAL_RANK
+        local_rank = int(os.getenv("LOCAL_RANK", "0"))
+        sim_device = f"cuda:{local_rank}"
+        rl_device = f"cuda:{local_rank}"
+        cfg_dict["_multi_gpu"] = True
+    cfg_dict["_seed"] = int(seed) if seed is not None and seed >= 0 else 0
+    name = cfg_dict["name"]
+    if name not in isaacgym_task_map:
+        raise KeyError(name)
+    return isaacgym_task_map[name](cfg=cfg_dict, rl_device=rl_device, sim_device=sim_device,
+                                   graphics_device_id=graphics_device_id, headless=headless,
+                                   virtual_screen_capture=virtual_screen_capture, force_render=force_render)

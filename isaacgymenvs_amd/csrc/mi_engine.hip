@@ -1,0 +1,614 @@
+// mi_engine.hip -- HIP kernels (gfx950) + the C ABI of include/mi_engine.h.
+//
+// Execution model: one environment per SIMD lane, 64 envs per wavefront, one wavefront per workgroup so that at
+// the benchmark sizes (4096-8192 envs = 64-128 waves) every wave lands on its own CU and owns that CU's register
+// file and LDS.  All persistent state is SoA [field][env] in the caller's arena => every state load/store of a
+// wave is one fully coalesced 256-byte transaction.  A whole VecTask.step() (reference vec_task.py:360-408) is ONE
+// kernel: clamp actions -> efforts -> `substeps` physics sub-steps in registers -> progress/reset -> observations
+// -> reward -> timeout, so the only HBM traffic per step is the API-visible state itself.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/mi_engine.h"
+#include "core/engine.hpp"
+#include "gen/model_ant.h"
+#include "gen/model_cartpole.h"
+#include "gen/model_humanoid.h"
+#include "tasks/locomotion.hpp"
+
+using namespace mi;
+
+static_assert(sizeof(MiSimParams) == sizeof(SimParams), "MiSimParams layout");
+static_assert(sizeof(MiLocoParams) == sizeof(LocoParams), "MiLocoParams layout");
+static_assert(sizeof(MiCartpoleParams) == sizeof(CartpoleParams), "MiCartpoleParams layout");
+static_assert(MI_MAX_DOF == mi::kMaxDof, "MI_MAX_DOF");
+
+static thread_local std::string g_err;
+static int fail(const std::string& m) { g_err = m; return -1; }
+extern "C" const char* mi_last_error(void) { return g_err.c_str(); }
+extern "C" int mi_abi_version(void) { return MI_ABI_VERSION; }
+
+#define HIP_OK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(_e)); } while (0)
+
+// ------------------------------------------------------------------------------------------------ arena view
+struct View {
+    int N;
+    int env_offset;
+    uint32_t seed;
+    int ring;  // which obs_out slot this step writes
+    float clip_obs;
+    float* root;        // [13][N]
+    float* dof;         // [2][ND][N]  (pos block, vel block)
+    float* tau;         // [ND][N]  dof_actuation_force
+    float* lamc;        // [3*NSPH][N]
+    float* laml;        // [ND][N]
+    float* sensor;      // [6*NSENS][N]
+    float* dof_force;   // [ND][N]
+    float* potentials;  // [N]
+    float* prev_potentials;
+    float* up_vec;      // [3][N]
+    float* heading_vec; // [3][N]
+    float* actions;     // [NACT][N]
+    float* init_root;   // [13][N]
+    float* obs;         // [N][NOBS] row-major
+    float* obs_out;     // [2][N][NOBS]
+    float* rew;         // [N]
+    long long* reset;   // [N]
+    long long* progress;
+    long long* randomize;
+    unsigned char* timeout;
+    int* episode;
+    float* ep_ret;      // [N] running return of the current episode
+    float* stats;       // [8] job statistics: sum finished returns, sum finished lengths, #finished, sum rewards, #env-steps
+};
+
+template <class M>
+__device__ __forceinline__ void load_sim(Sim<M>& s, const View& v, int e) {
+    const int N = v.N;
+    sfor<13>([&](auto K) MI_LAMBDA { s.root[K] = v.root[K * N + e]; });
+    sfor<M::ND>([&](auto K) MI_LAMBDA {
+        s.q[K] = v.dof[K * N + e];
+        s.qd[K] = v.dof[(M::ND + K) * N + e];
+        s.laml[K] = v.laml[K * N + e];
+    });
+    sfor<3 * M::NSPH>([&](auto K) MI_LAMBDA { s.lamc[K] = v.lamc[K * N + e]; });
+}
+template <class M>
+__device__ __forceinline__ void store_sim(const Sim<M>& s, const View& v, int e) {
+    const int N = v.N;
+    sfor<13>([&](auto K) MI_LAMBDA { v.root[K * N + e] = s.root[K]; });
+    sfor<M::ND>([&](auto K) MI_LAMBDA {
+        v.dof[K * N + e] = s.q[K];
+        v.dof[(M::ND + K) * N + e] = s.qd[K];
+        v.laml[K * N + e] = s.laml[K];
+        v.dof_force[K * N + e] = s.dof_force[K];
+    });
+    sfor<3 * M::NSPH>([&](auto K) MI_LAMBDA { v.lamc[K * N + e] = s.lamc[K]; });
+    sfor<6 * M::NSENS>([&](auto K) MI_LAMBDA { v.sensor[K * N + e] = s.sensor[K]; });
+}
+
+
+// ------------------------------------------------------------------------------------------------ episode statistics
+// Per-step episode bookkeeping fused into the step kernel: finished-episode return/length sums are reduced across
+// the 64 lanes of the wave with DPP/ds_swizzle shuffles and land in HBM with one atomic per wave and statistic.
+// These five floats are the only thing ever all-reduced across GPUs (RCCL, parallel.py).
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ void episode_stats(const View& v, int e, bool valid, float rew, long long reset, long long progress) {
+    float ret = 0.f, fin_ret = 0.f, fin_len = 0.f, fin = 0.f, r = 0.f, cnt = 0.f;
+    if (valid) {
+        ret = v.ep_ret[e] + rew;
+        r = rew; cnt = 1.f;
+        if (reset != 0) { fin_ret = ret; fin_len = (float)(progress + 1); fin = 1.f; ret = 0.f; }
+        v.ep_ret[e] = ret;
+    }
+    fin_ret = wave_sum(fin_ret); fin_len = wave_sum(fin_len); fin = wave_sum(fin); r = wave_sum(r); cnt = wave_sum(cnt);
+    if ((threadIdx.x & 63) == 0) {
+        if (fin > 0.f) { atomicAdd(v.stats + 0, fin_ret); atomicAdd(v.stats + 1, fin_len); atomicAdd(v.stats + 2, fin); }
+        atomicAdd(v.stats + 3, r);
+        atomicAdd(v.stats + 4, cnt);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ fused step
+template <class M, bool HUM>
+__global__ __launch_bounds__(64) void loco_step_kernel(View v, SimParams P, LocoParams tp, const float* __restrict__ actions_in,
+                                                       int control_freq_inv) {
+    using T = Loco<M::ND, 6 * M::NSENS, HUM>;
+    constexpr int ND = M::ND, NOBS = T::NOBS;
+    const int e0 = blockIdx.x * 64 + threadIdx.x;
+    const int N = v.N;
+    const bool valid = e0 < N;           // tail lanes shadow the last env (no stores) so wave reductions stay full
+    const int e = valid ? e0 : N - 1;
+    Sim<M> sim;
+    load_sim(sim, v, e);
+    // vec_task.py:374 clamp ; ant.py:281-285 efforts
+    float act[ND], tau[ND];
+    sfor<ND>([&](auto K) MI_LAMBDA {
+        const float a = fminf(fmaxf(actions_in[(size_t)e * ND + K], -tp.clip_actions), tp.clip_actions);
+        act[K] = a;
+        tau[K] = a * tp.gear[K] * tp.power_scale;
+    });
+    for (int c = 0; c < control_freq_inv; ++c) sim.step(P, tau);  // vec_task.py:379-382
+    // post_physics_step (ant.py:287-297)
+    long long progress = v.progress[e] + 1;
+    float potentials = v.potentials[e], prev_potentials;
+    int ep = v.episode[e];
+    if (v.reset[e] != 0) {
+        float init_root[13];
+        sfor<13>([&](auto K) MI_LAMBDA { init_root[K] = v.init_root[K * N + e]; });
+        T::reset(tp, v.seed, (uint32_t)(v.env_offset + e), (uint32_t)ep, init_root, sim.root, sim.q, sim.qd, &potentials,
+                 &prev_potentials);
+        sfor<3 * M::NSPH>([&](auto K) MI_LAMBDA { sim.lamc[K] = 0.f; });
+        sfor<ND>([&](auto K) MI_LAMBDA { sim.laml[K] = 0.f; });
+        ep += 1;
+        progress = 0;
+    }
+    float obs[NOBS], up_vec[3], heading_vec[3];
+    T::observations(tp, sim.root, tp.targets, potentials, tp.inv_start_rot, sim.q, sim.qd, sim.dof_force, tp.dof_lower,
+                    tp.dof_upper, sim.sensor, act, tp.basis_vec0, tp.basis_vec1, obs, &potentials, &prev_potentials,
+                    up_vec, heading_vec);
+    float rew;
+    long long reset;
+    T::reward(tp, obs, 0LL, progress, act, potentials, prev_potentials, &rew, &reset);
+    episode_stats(v, e, valid, rew, reset, progress);
+    if (!valid) return;
+    sfor<ND>([&](auto K) MI_LAMBDA { v.actions[K * N + e] = act[K]; v.tau[K * N + e] = tau[K]; });
+    v.randomize[e] += 1;
+    v.episode[e] = ep;
+    store_sim(sim, v, e);
+    v.potentials[e] = potentials;
+    v.prev_potentials[e] = prev_potentials;
+    sfor<3>([&](auto K) MI_LAMBDA { v.up_vec[K * N + e] = up_vec[K]; v.heading_vec[K * N + e] = heading_vec[K]; });
+    float* ob = v.obs + (size_t)e * NOBS;
+    float* oc = v.obs_out + ((size_t)v.ring * N + e) * NOBS;
+    sfor<NOBS>([&](auto K) MI_LAMBDA {
+        ob[K] = obs[K];
+        oc[K] = fminf(fmaxf(obs[K], -v.clip_obs), v.clip_obs);
+    });
+    v.rew[e] = rew;
+    v.reset[e] = reset;
+    v.progress[e] = progress;
+    // vec_task.py:394
+    v.timeout[e] = (unsigned char)(((float)progress >= tp.max_episode_length - 1.f) && (reset != 0));
+}
+
+__global__ __launch_bounds__(64) void cartpole_step_kernel(View v, SimParams P, CartpoleParams tp,
+                                                           const float* __restrict__ actions_in, int control_freq_inv) {
+    using M = ModelCartpole;
+    const int e0 = blockIdx.x * 64 + threadIdx.x;
+    const int N = v.N;
+    const bool valid = e0 < N;
+    const int e = valid ? e0 : N - 1;
+    Sim<M> sim;
+    load_sim(sim, v, e);
+    const float a = fminf(fmaxf(actions_in[e], -tp.clip_actions), tp.clip_actions);
+    const float tau[2] = {a * tp.max_push_effort, 0.f};  // cartpole.py:159-163
+    for (int c = 0; c < control_freq_inv; ++c) sim.step(P, tau);
+    long long progress = v.progress[e] + 1;  // cartpole.py:165-174
+    int ep = v.episode[e];
+    if (v.reset[e] != 0) {
+        cartpole_reset(v.seed, (uint32_t)(v.env_offset + e), (uint32_t)ep, sim.q, sim.qd);
+        sim.laml[0] = sim.laml[1] = 0.f;
+        ep += 1;
+        progress = 0;
+    }
+    const float obs[4] = {sim.q[0], sim.qd[0], sim.q[1], sim.qd[1]};  // cartpole.py:131-142
+    float rew;
+    long long reset;
+    cartpole_reward(tp, obs[2], obs[3], obs[1], obs[0], 0LL, progress, &rew, &reset);
+    episode_stats(v, e, valid, rew, reset, progress);
+    if (!valid) return;
+    v.actions[e] = a;
+    v.tau[e] = tau[0];
+    v.tau[N + e] = 0.f;
+    v.randomize[e] += 1;
+    v.episode[e] = ep;
+    store_sim(sim, v, e);
+    float* ob = v.obs + (size_t)e * 4;
+    float* oc = v.obs_out + ((size_t)v.ring * N + e) * 4;
+    sfor<4>([&](auto K) MI_LAMBDA { ob[K] = obs[K]; oc[K] = fminf(fmaxf(obs[K], -v.clip_obs), v.clip_obs); });
+    v.rew[e] = rew;
+    v.reset[e] = reset;
+    v.progress[e] = progress;
+    v.timeout[e] = (unsigned char)(((float)progress >= tp.max_episode_length - 1.f) && (reset != 0));
+}
+
+// ------------------------------------------------------------------------------------------------ physics only
+template <class M>
+__global__ __launch_bounds__(64) void simulate_kernel(View v, SimParams P) {
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= v.N) return;
+    Sim<M> sim;
+    load_sim(sim, v, e);
+    float tau[M::NDA];
+    sfor<M::ND>([&](auto K) MI_LAMBDA { tau[K] = v.tau[K * v.N + e]; });
+    sim.step(P, tau);
+    store_sim(sim, v, e);
+}
+
+// ------------------------------------------------------------------------------------------------ indexed reset
+template <class M, bool HUM>
+__global__ void loco_reset_kernel(View v, LocoParams tp, const long long* __restrict__ ids, int n) {
+    using T = Loco<M::ND, 6 * M::NSENS, HUM>;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int e = (int)ids[i], N = v.N;
+    if (e < 0 || e >= N) return;
+    float init_root[13], root[13], q[M::ND], qd[M::ND], pot, prev;
+    for (int k = 0; k < 13; ++k) init_root[k] = v.init_root[k * N + e];
+    const int ep = v.episode[e];
+    T::reset(tp, v.seed, (uint32_t)(v.env_offset + e), (uint32_t)ep, init_root, root, q, qd, &pot, &prev);
+    v.episode[e] = ep + 1;
+    for (int k = 0; k < 13; ++k) v.root[k * N + e] = root[k];
+    for (int k = 0; k < M::ND; ++k) {
+        v.dof[k * N + e] = q[k];
+        v.dof[(M::ND + k) * N + e] = qd[k];
+        v.laml[k * N + e] = 0.f;
+    }
+    for (int k = 0; k < 3 * M::NSPH; ++k) v.lamc[k * N + e] = 0.f;
+    v.potentials[e] = pot;
+    v.prev_potentials[e] = prev;
+    v.progress[e] = 0;
+    v.reset[e] = 0;
+}
+__global__ void cartpole_reset_kernel(View v, const long long* __restrict__ ids, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int e = (int)ids[i], N = v.N;
+    if (e < 0 || e >= N) return;
+    float q[2], qd[2];
+    const int ep = v.episode[e];
+    cartpole_reset(v.seed, (uint32_t)(v.env_offset + e), (uint32_t)ep, q, qd);
+    v.episode[e] = ep + 1;
+    for (int k = 0; k < 2; ++k) { v.dof[k * N + e] = q[k]; v.dof[(2 + k) * N + e] = qd[k]; v.laml[k * N + e] = 0.f; }
+    v.progress[e] = 0;
+    v.reset[e] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------ init
+__global__ void init_state_kernel(View v, int nd, int nsph3, int nsens6, int nobs, int nact, float root_z,
+                                  const float* __restrict__ init_dof /* [nd] or null */, float pot0) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = v.N;
+    if (e >= N) return;
+    const float root[13] = {0, 0, root_z, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < 13; ++k) { v.root[k * N + e] = root[k]; v.init_root[k * N + e] = root[k]; }
+    for (int k = 0; k < nd; ++k) {
+        v.dof[k * N + e] = init_dof ? init_dof[k] : 0.f;
+        v.dof[(nd + k) * N + e] = 0.f;
+        v.tau[k * N + e] = 0.f; v.laml[k * N + e] = 0.f; v.dof_force[k * N + e] = 0.f;
+    }
+    for (int k = 0; k < nsph3; ++k) v.lamc[k * N + e] = 0.f;
+    for (int k = 0; k < nsens6; ++k) v.sensor[k * N + e] = 0.f;
+    for (int k = 0; k < nact; ++k) v.actions[k * N + e] = 0.f;
+    for (int k = 0; k < nobs; ++k) { v.obs[(size_t)e * nobs + k] = 0.f; v.obs_out[(size_t)e * nobs + k] = 0.f; v.obs_out[((size_t)N + e) * nobs + k] = 0.f; }
+    v.potentials[e] = pot0; v.prev_potentials[e] = pot0;
+    for (int k = 0; k < 3; ++k) { v.up_vec[k * N + e] = (k == 2) ? 1.f : 0.f; v.heading_vec[k * N + e] = (k == 0) ? 1.f : 0.f; }
+    v.rew[e] = 0.f;
+    v.reset[e] = 1;  // vec_task.py:316-317: every env is reset inside the first step()
+    v.progress[e] = 0; v.randomize[e] = 0; v.timeout[e] = 0; v.episode[e] = 0;
+    v.ep_ret[e] = 0.f;
+    if (e == 0) for (int k = 0; k < 8; ++k) v.stats[k] = 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------ stand-alone jit-fn replacements
+template <int ND, int NSV, bool HUM>
+__global__ void loco_obs_kernel(int n, LocoParams p, const float* root_states, const float* targets, float* potentials,
+                                float* prev_potentials, const float* inv_start_rot, const float* dof_pos,
+                                const float* dof_vel, const float* dof_force, const float* lower, const float* upper,
+                                const float* sensors, const float* actions, const float* basis0, const float* basis1,
+                                float* obs_buf, float* up_vec, float* heading_vec) {
+    using T = Loco<ND, NSV, HUM>;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float root[13], q[ND], qd[ND], df[ND], se[NSV > 0 ? NSV : 1], ac[ND], lo[ND], up[ND], obs[T::NOBS], uv[3], hv[3], pot, prev;
+    for (int k = 0; k < 13; ++k) root[k] = root_states[(size_t)e * 13 + k];
+    for (int k = 0; k < ND; ++k) {
+        q[k] = dof_pos[(size_t)e * ND + k]; qd[k] = dof_vel[(size_t)e * ND + k];
+        df[k] = (HUM && dof_force) ? dof_force[(size_t)e * ND + k] : 0.f;
+        ac[k] = actions[(size_t)e * ND + k]; lo[k] = lower[k]; up[k] = upper[k];
+    }
+    for (int k = 0; k < NSV; ++k) se[k] = sensors[(size_t)e * NSV + k];
+    T::observations(p, root, targets + (size_t)e * 3, potentials[e], inv_start_rot + (size_t)e * 4, q, qd, df, lo, up, se, ac,
+                    basis0 + (size_t)e * 3, basis1 + (size_t)e * 3, obs, &pot, &prev, uv, hv);
+    for (int k = 0; k < T::NOBS; ++k) obs_buf[(size_t)e * T::NOBS + k] = obs[k];
+    potentials[e] = pot; prev_potentials[e] = prev;
+    for (int k = 0; k < 3; ++k) { up_vec[(size_t)e * 3 + k] = uv[k]; heading_vec[(size_t)e * 3 + k] = hv[k]; }
+}
+template <int ND, int NSV, bool HUM>
+__global__ void loco_reward_kernel(int n, LocoParams p, const float* obs_buf, const long long* reset_in,
+                                   const long long* progress, const float* actions, const float* potentials,
+                                   const float* prev_potentials, float* rew, long long* reset_out) {
+    using T = Loco<ND, NSV, HUM>;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float obs[T::NOBS], ac[ND];
+    for (int k = 0; k < T::NOBS; ++k) obs[k] = obs_buf[(size_t)e * T::NOBS + k];
+    for (int k = 0; k < ND; ++k) ac[k] = actions[(size_t)e * ND + k];
+    float r; long long rs;
+    T::reward(p, obs, reset_in[e], progress[e], ac, potentials[e], prev_potentials[e], &r, &rs);
+    rew[e] = r; reset_out[e] = rs;
+}
+__global__ void cartpole_reward_kernel(int n, CartpoleParams p, const float* pole_angle, const float* pole_vel,
+                                       const float* cart_vel, const float* cart_pos, const long long* reset_in,
+                                       const long long* progress, float* rew, long long* reset_out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float r; long long rs;
+    cartpole_reward(p, pole_angle[e], pole_vel[e], cart_vel[e], cart_pos[e], reset_in[e], progress[e], &r, &rs);
+    rew[e] = r; reset_out[e] = rs;
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+enum TaskId { T_CARTPOLE = 0, T_ANT = 1, T_HUMANOID = 2 };
+struct TaskMeta { const char* name; int nobs, nact, nd, nb, nsens, nsph, fixed; size_t pbytes; };
+static const TaskMeta kTasks[] = {
+    {"Cartpole", 4, 1, ModelCartpole::ND, ModelCartpole::NB, 0, ModelCartpole::NSPH, 1, sizeof(MiCartpoleParams)},
+    {"Ant", Loco<ModelAnt::ND, 6 * ModelAnt::NSENS, false>::NOBS, ModelAnt::ND, ModelAnt::ND, ModelAnt::NB, ModelAnt::NSENS, ModelAnt::NSPH, 0, sizeof(MiLocoParams)},
+    {"Humanoid", Loco<ModelHumanoid::ND, 6 * ModelHumanoid::NSENS, true>::NOBS, ModelHumanoid::ND, ModelHumanoid::ND, ModelHumanoid::NB, ModelHumanoid::NSENS, ModelHumanoid::NSPH, 0, sizeof(MiLocoParams)},
+};
+static int find_task(const char* t) {
+    for (int i = 0; i < 3; ++i) if (!strcmp(t, kTasks[i].name)) return i;
+    return -1;
+}
+
+struct MiEngine {
+    int task, N;
+    SimParams P;
+    LocoParams loco;
+    CartpoleParams cart;
+    View v;
+    float clip_obs;
+    int control_freq_inv;
+    std::vector<MiTensorDesc> descs;
+    unsigned long long steps;
+};
+
+struct Layout {
+    std::vector<MiTensorDesc> d;
+    size_t off = 0;
+    size_t add(const char* name, int dtype, std::vector<int64_t> shape, std::vector<int64_t> stride, size_t count) {
+        static const size_t es[] = {4, 8, 1, 4};
+        off = (off + 255) & ~size_t(255);
+        MiTensorDesc t;
+        memset(&t, 0, sizeof(t));
+        snprintf(t.name, sizeof(t.name), "%s", name);
+        t.dtype = dtype; t.ndim = (int)shape.size();
+        for (size_t i = 0; i < shape.size(); ++i) { t.shape[i] = shape[i]; t.stride[i] = stride[i]; }
+        t.byte_offset = (int64_t)off;
+        d.push_back(t);
+        size_t o = off;
+        off += count * es[dtype];
+        return o;
+    }
+};
+
+static void build_layout(int task, int N, Layout& L, View* v, char* base) {
+    const TaskMeta& m = kTasks[task];
+    const int64_t n = N, nd = m.nd, ns = m.nsens, nsp = m.nsph, no = m.nobs, na = m.nact;
+    auto P = [&](size_t o) { return base ? base + o : (char*)nullptr; };
+    size_t o;
+    o = L.add("root_states", MI_F32, {n, 13}, {1, n}, 13 * n); if (v) v->root = (float*)P(o);
+    o = L.add("dof_state", MI_F32, {n, nd, 2}, {1, n, nd * n}, 2 * nd * n); if (v) v->dof = (float*)P(o);
+    o = L.add("dof_actuation_force", MI_F32, {n, nd}, {1, n}, nd * n); if (v) v->tau = (float*)P(o);
+    o = L.add("contact_impulse", MI_F32, {n, nsp > 0 ? nsp : 1, 3}, {1, 3 * n, n}, (nsp > 0 ? 3 * nsp : 3) * n); if (v) v->lamc = (float*)P(o);
+    o = L.add("limit_impulse", MI_F32, {n, nd}, {1, n}, nd * n); if (v) v->laml = (float*)P(o);
+    o = L.add("force_sensor", MI_F32, {n, ns > 0 ? ns : 1, 6}, {1, 6 * n, n}, (ns > 0 ? 6 * ns : 6) * n); if (v) v->sensor = (float*)P(o);
+    o = L.add("dof_force", MI_F32, {n, nd}, {1, n}, nd * n); if (v) v->dof_force = (float*)P(o);
+    o = L.add("potentials", MI_F32, {n}, {1}, n); if (v) v->potentials = (float*)P(o);
+    o = L.add("prev_potentials", MI_F32, {n}, {1}, n); if (v) v->prev_potentials = (float*)P(o);
+    o = L.add("up_vec", MI_F32, {n, 3}, {1, n}, 3 * n); if (v) v->up_vec = (float*)P(o);
+    o = L.add("heading_vec", MI_F32, {n, 3}, {1, n}, 3 * n); if (v) v->heading_vec = (float*)P(o);
+    o = L.add("actions", MI_F32, {n, na}, {1, n}, na * n); if (v) v->actions = (float*)P(o);
+    o = L.add("initial_root_states", MI_F32, {n, 13}, {1, n}, 13 * n); if (v) v->init_root = (float*)P(o);
+    o = L.add("obs_buf", MI_F32, {n, no}, {no, 1}, no * n); if (v) v->obs = (float*)P(o);
+    o = L.add("obs_out", MI_F32, {2, n, no}, {n * no, no, 1}, 2 * no * n); if (v) v->obs_out = (float*)P(o);
+    o = L.add("rew_buf", MI_F32, {n}, {1}, n); if (v) v->rew = (float*)P(o);
+    o = L.add("reset_buf", MI_I64, {n}, {1}, n); if (v) v->reset = (long long*)P(o);
+    o = L.add("progress_buf", MI_I64, {n}, {1}, n); if (v) v->progress = (long long*)P(o);
+    o = L.add("randomize_buf", MI_I64, {n}, {1}, n); if (v) v->randomize = (long long*)P(o);
+    o = L.add("timeout_buf", MI_U8, {n}, {1}, n); if (v) v->timeout = (unsigned char*)P(o);
+    o = L.add("episode_count", MI_I32, {n}, {1}, n); if (v) v->episode = (int*)P(o);
+    o = L.add("episode_return", MI_F32, {n}, {1}, n); if (v) v->ep_ret = (float*)P(o);
+    o = L.add("episode_stats", MI_F32, {8}, {1}, 8); if (v) v->stats = (float*)P(o);
+    L.off = (L.off + 255) & ~size_t(255);
+}
+
+extern "C" int mi_task_info(const char* task, MiTaskInfo* out) {
+    int t = find_task(task);
+    if (t < 0) return fail(std::string("unknown task: ") + task);
+    const TaskMeta& m = kTasks[t];
+    out->num_obs = m.nobs; out->num_actions = m.nact; out->num_dofs = m.nd; out->num_bodies = m.nb;
+    out->num_sensors = m.nsens; out->num_contact_spheres = m.nsph; out->fixed_base = m.fixed;
+    out->task_params_bytes = (int)m.pbytes;
+    return 0;
+}
+
+extern "C" size_t mi_engine_arena_bytes(const char* task, int num_envs) {
+    int t = find_task(task);
+    if (t < 0 || num_envs <= 0) { fail("mi_engine_arena_bytes: bad task or num_envs"); return 0; }
+    Layout L;
+    build_layout(t, num_envs, L, nullptr, nullptr);
+    return L.off;
+}
+
+extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const void* task_params, size_t task_params_bytes,
+                                int num_envs, int env_id_offset, uint64_t seed, void* arena, size_t arena_bytes,
+                                MiEngine** out) {
+    int t = find_task(task);
+    if (t < 0) return fail(std::string("unknown task: ") + task);
+    if (!sim || !task_params || !arena || !out) return fail("mi_engine_create: null argument");
+    if (num_envs <= 0) return fail("mi_engine_create: num_envs must be positive");
+    if (task_params_bytes != kTasks[t].pbytes) return fail("mi_engine_create: task_params size mismatch (ABI)");
+    if (sim->substeps < 1 || sim->dt <= 0.f) return fail("mi_engine_create: invalid sim params");
+    MiEngine* e = new (std::nothrow) MiEngine();
+    if (!e) return fail("out of host memory");
+    e->task = t; e->N = num_envs; e->steps = 0; e->control_freq_inv = 1; e->clip_obs = INFINITY;
+    memcpy(&e->P, sim, sizeof(SimParams));
+    if (t == T_CARTPOLE) memcpy(&e->cart, task_params, sizeof(CartpoleParams));
+    else memcpy(&e->loco, task_params, sizeof(LocoParams));
+    Layout L;
+    memset(&e->v, 0, sizeof(View));
+    build_layout(t, num_envs, L, &e->v, (char*)arena);
+    if (arena_bytes < L.off) { delete e; return fail("mi_engine_create: arena too small"); }
+    e->descs = L.d;
+    e->v.N = num_envs; e->v.env_offset = env_id_offset; e->v.seed = (uint32_t)(seed ^ (seed >> 32));
+    e->v.clip_obs = INFINITY;
+    *out = e;
+    return 0;
+}
+
+extern "C" void mi_engine_destroy(MiEngine* e) { delete e; }
+extern "C" int mi_engine_num_tensors(const MiEngine* e) { return e ? (int)e->descs.size() : fail("null engine"); }
+extern "C" int mi_engine_tensor_desc(const MiEngine* e, int i, MiTensorDesc* out) {
+    if (!e || !out || i < 0 || i >= (int)e->descs.size()) return fail("mi_engine_tensor_desc: bad index");
+    *out = e->descs[i];
+    return 0;
+}
+// optional knobs (env.clipObservations vec_task.py:115, env.controlFrequencyInv :111)
+extern "C" int mi_engine_set_option(MiEngine* e, const char* key, double value) {
+    if (!e) return fail("null engine");
+    if (!strcmp(key, "clip_obs")) { e->clip_obs = (float)value; e->v.clip_obs = (float)value; return 0; }
+    if (!strcmp(key, "control_freq_inv")) { if (value < 1) return fail("control_freq_inv < 1"); e->control_freq_inv = (int)value; return 0; }
+    return fail(std::string("unknown option: ") + key);
+}
+
+extern "C" int mi_engine_init_state(MiEngine* e, void* stream) {
+    if (!e) return fail("null engine");
+    hipStream_t s = (hipStream_t)stream;
+    const TaskMeta& m = kTasks[e->task];
+    float* d_init = nullptr;
+    float root_z = 0.f, pot0 = 0.f;
+    if (e->task != T_CARTPOLE) {
+        HIP_OK(hipMalloc(&d_init, sizeof(float) * m.nd));
+        HIP_OK(hipMemcpyAsync(d_init, e->loco.initial_dof_pos, sizeof(float) * m.nd, hipMemcpyHostToDevice, s));
+        root_z = e->loco.start_height;
+        pot0 = -1000.f / e->loco.dt;  // ant.py:113
+    } else {
+        root_z = 2.0f;  // cartpole.py:93
+    }
+    const int blocks = (e->N + 255) / 256;
+    hipLaunchKernelGGL(init_state_kernel, dim3(blocks), dim3(256), 0, s, e->v, m.nd, 3 * m.nsph, 6 * m.nsens, m.nobs, m.nact,
+                       root_z, d_init, pot0);
+    HIP_OK(hipGetLastError());
+    if (d_init) { HIP_OK(hipStreamSynchronize(s)); HIP_OK(hipFree(d_init)); }
+    e->steps = 0;
+    return 0;
+}
+
+extern "C" int mi_engine_step(MiEngine* e, const float* actions, void* stream) {
+    if (!e || !actions) return fail("mi_engine_step: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = (e->N + 63) / 64;
+    e->v.ring = (int)(e->steps & 1);
+    switch (e->task) {
+        case T_CARTPOLE:
+            hipLaunchKernelGGL(cartpole_step_kernel, dim3(blocks), dim3(64), 0, s, e->v, e->P, e->cart, actions, e->control_freq_inv);
+            break;
+        case T_ANT:
+            hipLaunchKernelGGL((loco_step_kernel<ModelAnt, false>), dim3(blocks), dim3(64), 0, s, e->v, e->P, e->loco, actions, e->control_freq_inv);
+            break;
+        case T_HUMANOID:
+            hipLaunchKernelGGL((loco_step_kernel<ModelHumanoid, true>), dim3(blocks), dim3(64), 0, s, e->v, e->P, e->loco, actions, e->control_freq_inv);
+            break;
+    }
+    HIP_OK(hipGetLastError());
+    e->steps++;
+    return 0;
+}
+extern "C" int mi_engine_last_ring(const MiEngine* e) { return e ? (int)((e->steps + 1) & 1) : -1; }
+
+extern "C" int mi_engine_simulate(MiEngine* e, void* stream) {
+    if (!e) return fail("null engine");
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = (e->N + 63) / 64;
+    switch (e->task) {
+        case T_CARTPOLE: hipLaunchKernelGGL(simulate_kernel<ModelCartpole>, dim3(blocks), dim3(64), 0, s, e->v, e->P); break;
+        case T_ANT: hipLaunchKernelGGL(simulate_kernel<ModelAnt>, dim3(blocks), dim3(64), 0, s, e->v, e->P); break;
+        case T_HUMANOID: hipLaunchKernelGGL(simulate_kernel<ModelHumanoid>, dim3(blocks), dim3(64), 0, s, e->v, e->P); break;
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mi_engine_reset_idx(MiEngine* e, const int64_t* env_ids, int n, void* stream) {
+    if (!e) return fail("null engine");
+    if (n <= 0) return 0;
+    if (!env_ids) return fail("mi_engine_reset_idx: null env_ids");
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = (n + 127) / 128;
+    switch (e->task) {
+        case T_CARTPOLE: hipLaunchKernelGGL(cartpole_reset_kernel, dim3(blocks), dim3(128), 0, s, e->v, (const long long*)env_ids, n); break;
+        case T_ANT: hipLaunchKernelGGL((loco_reset_kernel<ModelAnt, false>), dim3(blocks), dim3(128), 0, s, e->v, e->loco, (const long long*)env_ids, n); break;
+        case T_HUMANOID: hipLaunchKernelGGL((loco_reset_kernel<ModelHumanoid, true>), dim3(blocks), dim3(128), 0, s, e->v, e->loco, (const long long*)env_ids, n); break;
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mi_compute_locomotion_observations(const char* task, int n, const MiLocoParams* p, const float* root_states,
+                                                  const float* targets, float* potentials, float* prev_potentials,
+                                                  const float* inv_start_rot, const float* dof_pos, const float* dof_vel,
+                                                  const float* dof_force, const float* lower, const float* upper,
+                                                  const float* sensors, const float* actions, const float* basis0,
+                                                  const float* basis1, float* obs_buf, float* up_vec, float* heading_vec,
+                                                  void* stream) {
+    int t = find_task(task);
+    if (t != T_ANT && t != T_HUMANOID) return fail("mi_compute_locomotion_observations: task must be Ant or Humanoid");
+    if (n <= 0) return 0;
+    LocoParams lp;
+    memcpy(&lp, p, sizeof(lp));
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = (n + 63) / 64;
+    if (t == T_ANT)
+        hipLaunchKernelGGL((loco_obs_kernel<ModelAnt::ND, 6 * ModelAnt::NSENS, false>), dim3(blocks), dim3(64), 0, s, n, lp, root_states, targets,
+                           potentials, prev_potentials, inv_start_rot, dof_pos, dof_vel, dof_force, lower, upper, sensors,
+                           actions, basis0, basis1, obs_buf, up_vec, heading_vec);
+    else
+        hipLaunchKernelGGL((loco_obs_kernel<ModelHumanoid::ND, 6 * ModelHumanoid::NSENS, true>), dim3(blocks), dim3(64), 0, s, n, lp, root_states,
+                           targets, potentials, prev_potentials, inv_start_rot, dof_pos, dof_vel, dof_force, lower, upper,
+                           sensors, actions, basis0, basis1, obs_buf, up_vec, heading_vec);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mi_compute_locomotion_reward(const char* task, int n, const MiLocoParams* p, const float* obs_buf,
+                                            const int64_t* reset_in, const int64_t* progress, const float* actions,
+                                            const float* potentials, const float* prev_potentials, float* rew,
+                                            int64_t* reset_out, void* stream) {
+    int t = find_task(task);
+    if (t != T_ANT && t != T_HUMANOID) return fail("mi_compute_locomotion_reward: task must be Ant or Humanoid");
+    if (n <= 0) return 0;
+    LocoParams lp;
+    memcpy(&lp, p, sizeof(lp));
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = (n + 63) / 64;
+    if (t == T_ANT)
+        hipLaunchKernelGGL((loco_reward_kernel<ModelAnt::ND, 6 * ModelAnt::NSENS, false>), dim3(blocks), dim3(64), 0, s, n, lp, obs_buf,
+                           (const long long*)reset_in, (const long long*)progress, actions, potentials, prev_potentials, rew, (long long*)reset_out);
+    else
+        hipLaunchKernelGGL((loco_reward_kernel<ModelHumanoid::ND, 6 * ModelHumanoid::NSENS, true>), dim3(blocks), dim3(64), 0, s, n, lp, obs_buf,
+                           (const long long*)reset_in, (const long long*)progress, actions, potentials, prev_potentials, rew, (long long*)reset_out);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mi_compute_cartpole_reward(int n, const MiCartpoleParams* p, const float* pole_angle, const float* pole_vel,
+                                          const float* cart_vel, const float* cart_pos, const int64_t* reset_in,
+                                          const int64_t* progress, float* rew, int64_t* reset_out, void* stream) {
+    if (n <= 0) return 0;
+    CartpoleParams cp;
+    memcpy(&cp, p, sizeof(cp));
+    hipLaunchKernelGGL(cartpole_reward_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, n, cp, pole_angle, pole_vel,
+                       cart_vel, cart_pos, (const long long*)reset_in, (const long long*)progress, rew, (long long*)reset_out);
+    HIP_OK(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,215 @@
+"""ctypes binding of libmi_engine.so (C ABI: include/mi_engine.h) + its hipcc build recipe.
+
+PyTorch is only plumbing here: it owns the device arena and the stream; every compute entry point is a raw-pointer
+C call.  There is no CPU fallback: if the library is missing or no ROCm device is visible the constructors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi_engine.so")
+SRC = os.path.join(_HERE, "csrc", "mi_engine.hip")
+MI_MAX_DOF = 32
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-signed-zeros",
+               "-ffinite-math-only", "-fno-trapping-math"]
+
+
+class MiSimParams(C.Structure):
+    _fields_ = [("dt", C.c_float), ("substeps", C.c_int32), ("iters", C.c_int32), ("gravity", C.c_float * 3),
+                ("contact_offset", C.c_float), ("rest_offset", C.c_float), ("max_depen_vel", C.c_float),
+                ("erp", C.c_float), ("plane_mu", C.c_float), ("ground_z", C.c_float), ("cfm", C.c_float),
+                ("warm", C.c_float)]
+
+
+class MiLocoParams(C.Structure):
+    _fields_ = [(n, C.c_float) for n in (
+        "dt", "dof_vel_scale", "contact_force_scale", "angular_velocity_scale", "power_scale", "heading_weight",
+        "up_weight", "actions_cost", "energy_cost", "joints_at_limit_cost", "death_cost", "termination_height",
+        "max_episode_length", "clip_actions", "max_motor_effort", "start_height")] + [
+        ("gear", C.c_float * MI_MAX_DOF), ("dof_lower", C.c_float * MI_MAX_DOF), ("dof_upper", C.c_float * MI_MAX_DOF),
+        ("initial_dof_pos", C.c_float * MI_MAX_DOF), ("targets", C.c_float * 3), ("inv_start_rot", C.c_float * 4),
+        ("basis_vec0", C.c_float * 3), ("basis_vec1", C.c_float * 3), ("reset_pos_noise", C.c_float),
+        ("reset_vel_noise", C.c_float)]
+
+
+class MiCartpoleParams(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("reset_dist", "max_push_effort", "max_episode_length", "clip_actions")]
+
+
+class MiTaskInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("num_obs", "num_actions", "num_dofs", "num_bodies", "num_sensors",
+                                         "num_contact_spheres", "fixed_base", "task_params_bytes")]
+
+
+class MiTensorDesc(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("dtype", C.c_int32), ("ndim", C.c_int32), ("shape", C.c_int64 * 4),
+                ("stride", C.c_int64 * 4), ("byte_offset", C.c_int64)]
+
+
+# every symbol include/mi_engine.h declares (checked by tests/test_abi.py)
+EXPORTS = ["mi_abi_version", "mi_task_info", "mi_engine_arena_bytes", "mi_engine_create", "mi_engine_init_state",
+           "mi_engine_destroy", "mi_engine_num_tensors", "mi_engine_tensor_desc", "mi_engine_step",
+           "mi_engine_reset_idx", "mi_engine_simulate", "mi_engine_set_option", "mi_engine_last_ring",
+           "mi_compute_locomotion_observations", "mi_compute_locomotion_reward", "mi_compute_cartpole_reward",
+           "mi_last_error"]
+
+
+def hipcc_path():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    root = os.path.join(_HERE, "csrc")
+    for d, _, fs in os.walk(root):
+        for f in fs:
+            if os.path.getmtime(os.path.join(d, f)) > t:
+                return True
+    return os.path.getmtime(os.path.join(_HERE, "..", "include", "mi_engine.h")) > t
+
+
+def build(force=False, verbose=False):
+    """Generate the per-robot constexpr headers and compile the HIP library for gfx950 (cross-compiles w/o a GPU)."""
+    from .registry import generate_headers
+    generate_headers()
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = [hipcc_path()] + HIPCC_FLAGS + [SRC, "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=os.path.join(_HERE, "csrc"))
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library.  Fails loudly (no fallback) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           f"(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path.")
+    L = C.CDLL(LIB_PATH)
+    L.mi_last_error.restype = C.c_char_p
+    L.mi_engine_arena_bytes.restype = C.c_size_t
+    L.mi_engine_arena_bytes.argtypes = [C.c_char_p, C.c_int]
+    L.mi_task_info.argtypes = [C.c_char_p, C.POINTER(MiTaskInfo)]
+    L.mi_engine_create.argtypes = [C.c_char_p, C.POINTER(MiSimParams), C.c_void_p, C.c_size_t, C.c_int, C.c_int,
+                                   C.c_uint64, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+    L.mi_engine_init_state.argtypes = [C.c_void_p, C.c_void_p]
+    L.mi_engine_destroy.argtypes = [C.c_void_p]
+    L.mi_engine_destroy.restype = None
+    L.mi_engine_num_tensors.argtypes = [C.c_void_p]
+    L.mi_engine_tensor_desc.argtypes = [C.c_void_p, C.c_int, C.POINTER(MiTensorDesc)]
+    L.mi_engine_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mi_engine_reset_idx.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.mi_engine_simulate.argtypes = [C.c_void_p, C.c_void_p]
+    L.mi_engine_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+    L.mi_engine_last_ring.argtypes = [C.c_void_p]
+    L.mi_compute_locomotion_observations.argtypes = [C.c_char_p, C.c_int, C.POINTER(MiLocoParams)] + [C.c_void_p] * 18
+    L.mi_compute_locomotion_reward.argtypes = [C.c_char_p, C.c_int, C.POINTER(MiLocoParams)] + [C.c_void_p] * 9
+    L.mi_compute_cartpole_reward.argtypes = [C.c_int, C.POINTER(MiCartpoleParams)] + [C.c_void_p] * 9
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("mi_engine: " + (lib().mi_last_error() or b"?").decode())
+
+
+def task_info(task):
+    info = MiTaskInfo()
+    check(lib().mi_task_info(task.encode(), C.byref(info)))
+    return info
+
+
+_DT = None
+
+
+def _dtypes():
+    global _DT
+    if _DT is None:
+        import torch
+        _DT = {0: torch.float32, 1: torch.int64, 2: torch.uint8, 3: torch.int32}
+    return _DT
+
+
+class Engine:
+    """Owns a torch uint8 arena on `device` and the native engine handle bound to it."""
+
+    def __init__(self, task, sim_params: MiSimParams, task_params, num_envs, device, seed=0, env_id_offset=0):
+        import torch
+        L = lib()
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("the MI355X engine runs on ROCm devices only (sim_device='cuda:N'); "
+                               "there is no CPU product path -- the CPU oracle lives in oracle/ for tests only")
+        if not torch.cuda.is_available():
+            raise RuntimeError("no ROCm device visible to PyTorch")
+        self.task, self.N, self.device = task, num_envs, dev
+        nbytes = L.mi_engine_arena_bytes(task.encode(), num_envs)
+        if nbytes == 0:
+            check(-1)
+        self.arena = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        self._sim, self._tp = sim_params, task_params
+        h = C.c_void_p()
+        check(L.mi_engine_create(task.encode(), C.byref(sim_params), C.cast(C.byref(task_params), C.c_void_p),
+                                 C.sizeof(task_params), num_envs, env_id_offset, seed & 0xFFFFFFFFFFFFFFFF,
+                                 self.arena.data_ptr(), nbytes, C.byref(h)))
+        self.h = h
+        self.tensors = {}
+        dts = _dtypes()
+        for i in range(L.mi_engine_num_tensors(h)):
+            d = MiTensorDesc()
+            check(L.mi_engine_tensor_desc(h, i, C.byref(d)))
+            dt = dts[d.dtype]
+            esz = torch.empty(0, dtype=dt).element_size()
+            shape = [d.shape[k] for k in range(d.ndim)]
+            stride = [d.stride[k] for k in range(d.ndim)]
+            extent = 1 + sum((s - 1) * st for s, st in zip(shape, stride))
+            flat = self.arena[d.byte_offset:d.byte_offset + extent * esz].view(dt)
+            self.tensors[d.name.decode()] = torch.as_strided(flat, shape, stride)
+        with torch.cuda.device(dev):
+            check(L.mi_engine_init_state(h, self._stream()))
+
+    def _stream(self):
+        import torch
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def step(self, actions):
+        check(lib().mi_engine_step(self.h, actions.data_ptr(), self._stream()))
+
+    def simulate(self):
+        check(lib().mi_engine_simulate(self.h, self._stream()))
+
+    def reset_idx(self, env_ids):
+        if env_ids.numel():
+            check(lib().mi_engine_reset_idx(self.h, env_ids.data_ptr(), env_ids.numel(), self._stream()))
+
+    def set_option(self, key, value):
+        check(lib().mi_engine_set_option(self.h, key.encode(), float(value)))
+
+    def last_ring(self):
+        return lib().mi_engine_last_ring(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().mi_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

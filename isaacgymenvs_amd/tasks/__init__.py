@@ -1,0 +1,10 @@
+"""Task name -> class map (reference isaacgymenvs/tasks/__init__.py:88-114; the tasks built so far)."""
+from .ant import Ant
+from .cartpole import Cartpole
+from .humanoid import Humanoid
+
+isaacgym_task_map = {
+    "Ant": Ant,
+    "Cartpole": Cartpole,
+    "Humanoid": Humanoid,
+}

@@ -1,0 +1,240 @@
+"""VecTask: the public vectorised-env API of the reference, hosted on the native HIP engine.
+
+Mirrors reference isaacgymenvs/tasks/base/vec_task.py (Env :67-205, VecTask :207-455): same constructor
+signature, attributes, buffer dtypes and `step/reset/reset_done/reset_idx` contract.  What differs is *where the
+work runs*: the reference's step() is ~30 torch ops around the closed `gym.simulate`; here the whole step is one
+fused HIP kernel (csrc/mi_engine.hip) and this class only moves pointers.
+
+Buffers are strided torch views of the engine's SoA arena (the analogue of gymtorch.wrap_tensor): writing through
+`env.dof_pos[env_ids] = ...` edits simulator state in place, as with the reference's CPU pipeline.
+"""
+from __future__ import annotations
+
+import os
+from typing import Any, Dict, Tuple
+
+import numpy as np
+import torch
+
+from ... import native
+from ...utils import spaces
+
+
+class Env:
+    """reference vec_task.py:67-205 (device resolution, spaces, clip values)."""
+
+    def __init__(self, config: Dict[str, Any], rl_device: str, sim_device: str, graphics_device_id: int, headless: bool):
+        split_device = sim_device.split(":")
+        self.device_type = split_device[0]
+        self.device_id = int(split_device[1]) if len(split_device) > 1 else 0
+        self.device = "cpu"
+        if config["sim"]["use_gpu_pipeline"]:
+            if self.device_type.lower() in ("cuda", "gpu"):
+                self.device = "cuda:" + str(self.device_id)
+            else:
+                print("GPU Pipeline can only be used with GPU simulation. Forcing CPU Pipeline.")
+                config["sim"]["use_gpu_pipeline"] = False
+        if self.device == "cpu":
+            # the reference would now run PhysX-CPU; this engine has no CPU product path by design
+            raise RuntimeError(
+                "isaacgymenvs_amd: sim_device/pipeline 'cpu' is not available -- the engine is MI355X-native "
+                "(use sim_device='cuda:N', pipeline='gpu').  The CPU restatement lives in oracle/ for tests only.")
+        self.rl_device = rl_device
+        self.headless = headless
+        enable_camera_sensors = config["env"].get("enableCameraSensors", False)
+        self.graphics_device_id = graphics_device_id
+        if not enable_camera_sensors and self.headless:
+            self.graphics_device_id = -1
+        self.num_environments = config["env"]["numEnvs"]
+        self.num_agents = config["env"].get("numAgents", 1)
+        self.num_observations = config["env"].get("numObservations", 0)
+        self.num_states = config["env"].get("numStates", 0)
+        self.obs_space = spaces.Box(np.ones(self.num_obs) * -np.inf, np.ones(self.num_obs) * np.inf)
+        self.state_space = spaces.Box(np.ones(self.num_states) * -np.inf, np.ones(self.num_states) * np.inf)
+        self.num_actions = config["env"]["numActions"]
+        self.control_freq_inv = config["env"].get("controlFrequencyInv", 1)
+        self.act_space = spaces.Box(np.ones(self.num_actions) * -1., np.ones(self.num_actions) * 1.)
+        self.clip_obs = config["env"].get("clipObservations", np.inf)
+        self.clip_actions = config["env"].get("clipActions", np.inf)
+        self.total_train_env_frames: int = 0
+        self.control_steps: int = 0
+        self.render_fps: int = config["env"].get("renderFPS", -1)
+        self.last_frame_time: float = 0.0
+        self.record_frames: bool = False
+
+    # -- API properties (vec_task.py:162-185)
+    @property
+    def observation_space(self):
+        return self.obs_space
+
+    @property
+    def action_space(self):
+        return self.act_space
+
+    @property
+    def num_envs(self) -> int:
+        return self.num_environments
+
+    @property
+    def num_acts(self) -> int:
+        return self.num_actions
+
+    @property
+    def num_obs(self) -> int:
+        return self.num_observations
+
+    def set_train_info(self, env_frames, *args, **kwargs):  # vec_task.py:187-194
+        self.total_train_env_frames = env_frames
+
+    def get_env_state(self):  # vec_task.py:196-200 (default None); overridden below with real physics state
+        return None
+
+    def set_env_state(self, env_state):
+        pass
+
+
+class VecTask(Env):
+    metadata = {"render.modes": ["human", "rgb_array"], "video.frames_per_second": 24}
+
+    #: name of the native task this class drives (subclasses set it)
+    native_task: str = ""
+
+    def __init__(self, config, rl_device, sim_device, graphics_device_id, headless,
+                 virtual_screen_capture: bool = False, force_render: bool = False):
+        super().__init__(config, rl_device, sim_device, graphics_device_id, headless)
+        self.virtual_screen_capture = virtual_screen_capture
+        self.force_render = force_render
+        self.viewer = None
+        self.sim_params = self._parse_sim_params(self.cfg["physics_engine"], self.cfg["sim"])
+        self.dt: float = self.sim_params.dt
+        self.first_randomization = True
+        self.dr_randomizations = {}
+        # multi-GPU sharding: global env ids are rank*num_envs + i (seed offset: reference utils/utils.py:94)
+        self.rank = int(os.getenv("RANK", "0")) if config.get("_multi_gpu", False) else 0
+        self.engine_seed = int(config.get("_seed", 0))
+        self.sim_initialized = False
+        self.create_sim()
+        self.sim_initialized = True
+        self.allocate_buffers()
+        self.obs_dict = {}
+
+    # ------------------------------------------------------------------ sim params (vec_task.py:514-562)
+    def _parse_sim_params(self, physics_engine: str, config_sim: Dict[str, Any]) -> native.MiSimParams:
+        if physics_engine not in ("physx", "flex"):
+            raise ValueError(f"Invalid physics engine backend: {physics_engine}")
+        if config_sim["up_axis"] not in ("z", "y"):
+            raise ValueError(f"Invalid physics up-axis: {config_sim['up_axis']}")
+        if config_sim["up_axis"] != "z":
+            raise ValueError("only up_axis 'z' is implemented (all five target tasks use z)")
+        p = native.MiSimParams()
+        p.dt = float(config_sim["dt"])
+        p.substeps = int(config_sim.get("substeps", 2))
+        g = config_sim.get("gravity", [0.0, 0.0, -9.81])
+        for i in range(3):
+            p.gravity[i] = float(g[i])
+        px = config_sim.get("physx", {})
+        p.iters = int(px.get("num_position_iterations", 4)) + int(px.get("num_velocity_iterations", 0))
+        p.contact_offset = float(px.get("contact_offset", 0.02))
+        p.rest_offset = float(px.get("rest_offset", 0.0))
+        p.max_depen_vel = float(px.get("max_depenetration_velocity", 10.0))
+        p.erp = float(config_sim.get("erp", 0.5))
+        p.plane_mu = float(self.cfg["env"].get("plane", {}).get("staticFriction", 1.0))
+        p.ground_z = 0.0
+        p.cfm = float(config_sim.get("cfm", 1e-6))
+        p.warm = float(config_sim.get("warm_start", 1.0))
+        return p
+
+    # ------------------------------------------------------------------ engine creation = create_sim + prepare_sim
+    def create_sim(self):
+        tp = self._task_params()
+        self.engine = native.Engine(self.native_task, self.sim_params, tp, self.num_envs, self.device,
+                                    seed=self.engine_seed, env_id_offset=self.rank * self.num_envs)
+        self._task_params_struct = tp
+        if np.isfinite(self.clip_obs):
+            self.engine.set_option("clip_obs", self.clip_obs)
+        self.engine.set_option("control_freq_inv", self.control_freq_inv)
+        self.sim = self.engine  # what the reference calls self.sim
+
+    def _task_params(self):
+        raise NotImplementedError
+
+    def allocate_buffers(self):
+        """vec_task.py:301-324 -- same names/dtypes; storage is the engine arena."""
+        t = self.engine.tensors
+        self.obs_buf = t["obs_buf"]
+        self.states_buf = torch.zeros((self.num_envs, self.num_states), device=self.device, dtype=torch.float)
+        self.rew_buf = t["rew_buf"]
+        self.reset_buf = t["reset_buf"]
+        self.timeout_buf = t["timeout_buf"].view(torch.bool)
+        self.progress_buf = t["progress_buf"]
+        self.randomize_buf = t["randomize_buf"]
+        self._obs_out = t["obs_out"]
+        self.extras = {}
+
+    def get_state(self):
+        return torch.clamp(self.states_buf, -self.clip_obs, self.clip_obs).to(self.rl_device)
+
+    # ------------------------------------------------------------------ the hot path (vec_task.py:360-408)
+    def step(self, actions: torch.Tensor) -> Tuple[Dict[str, torch.Tensor], torch.Tensor, torch.Tensor, Dict[str, Any]]:
+        if self.dr_randomizations.get("actions", None):
+            actions = self.dr_randomizations["actions"]["noise_lambda"](actions)
+        if actions.device != self.obs_buf.device or actions.dtype != torch.float32 or not actions.is_contiguous():
+            actions = actions.to(device=self.obs_buf.device, dtype=torch.float32).contiguous()
+        # one fused launch: clamp -> pre_physics_step -> simulate x control_freq_inv -> post_physics_step -> timeouts
+        self.engine.step(actions)
+        self.control_steps += 1
+        obs = self._obs_out[self.engine.last_ring()]
+        if self.dr_randomizations.get("observations", None):
+            self.obs_buf[:] = self.dr_randomizations["observations"]["noise_lambda"](self.obs_buf)
+            obs = torch.clamp(self.obs_buf, -self.clip_obs, self.clip_obs)
+        self._post_step_extras()
+        self.extras["time_outs"] = self.timeout_buf.to(self.rl_device)
+        self.obs_dict["obs"] = obs.to(self.rl_device)
+        if self.num_states > 0:
+            self.obs_dict["states"] = self.get_state()
+        return self.obs_dict, self.rew_buf.to(self.rl_device), self.reset_buf.to(self.rl_device), self.extras
+
+    def _post_step_extras(self):
+        pass
+
+    def zero_actions(self) -> torch.Tensor:
+        return torch.zeros([self.num_envs, self.num_actions], dtype=torch.float32, device=self.rl_device)
+
+    def reset_idx(self, env_ids):
+        """reference ant.py:252-279 etc.: re-draw the start state of the given envs (int64 indices)."""
+        env_ids = torch.as_tensor(env_ids, device=self.device, dtype=torch.int64).contiguous()
+        self.engine.reset_idx(env_ids)
+
+    def reset(self):
+        """vec_task.py:426-438: returns the current (clamped) observations; resets happen inside step()."""
+        self.obs_dict["obs"] = torch.clamp(self.obs_buf, -self.clip_obs, self.clip_obs).to(self.rl_device)
+        if self.num_states > 0:
+            self.obs_dict["states"] = self.get_state()
+        return self.obs_dict
+
+    def reset_done(self):
+        """vec_task.py:440-455"""
+        done_env_ids = self.reset_buf.nonzero(as_tuple=False).flatten()
+        if len(done_env_ids) > 0:
+            self.reset_idx(done_env_ids)
+        self.obs_dict["obs"] = torch.clamp(self.obs_buf, -self.clip_obs, self.clip_obs).to(self.rl_device)
+        if self.num_states > 0:
+            self.obs_dict["states"] = self.get_state()
+        return self.obs_dict, done_env_ids
+
+    def render(self, mode="rgb_array"):
+        return None  # headless engine (viewer is out of scope)
+
+    # ------------------------------------------------------------------ physics-state checkpointing
+    def get_env_state(self):
+        """Full simulator + task state (the reference never checkpoints physics, vec_task.py:196-204)."""
+        return {"arena": self.engine.arena.clone(), "control_steps": self.control_steps}
+
+    def set_env_state(self, env_state):
+        if env_state is None:
+            return
+        self.engine.arena.copy_(env_state["arena"])
+        self.control_steps = env_state.get("control_steps", 0)
+
+    def get_number_of_agents(self):
+        return self.num_agents

@@ -1,0 +1,99 @@
+"""CPU-side checks of the C-ABI shared library: it loads, exports every symbol include/mi_engine.h declares, and the
+host-only entry points (no kernel launch) behave.  No compute calls here -- those are the `-m gpu` tests."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from isaacgymenvs_amd import native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(native.LIB_PATH):
+        native.build()
+    return native.lib()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "mi_engine.h")).read()
+    declared = set(re.findall(r"\b(mi_[a-z_]+)\s*\(", hdr))
+    assert declared == set(native.EXPORTS), declared ^ set(native.EXPORTS)
+    for s in declared:
+        assert hasattr(lib, s), s
+    assert lib.mi_abi_version() == 1
+
+
+def test_task_info_and_unknown_task(lib):
+    for task, nobs, nact in (("Cartpole", 4, 1), ("Ant", 60, 8), ("Humanoid", 108, 21)):
+        info = native.task_info(task)
+        assert (info.num_obs, info.num_actions) == (nobs, nact)
+    info = native.MiTaskInfo()
+    assert lib.mi_task_info(b"Nope", C.byref(info)) != 0
+    assert b"unknown task" in lib.mi_last_error()
+
+
+def test_arena_layout_host_only(lib):
+    """mi_engine_create only lays out the arena (no device access): check views with a host buffer."""
+    n = 100
+    nbytes = lib.mi_engine_arena_bytes(b"Ant", n)
+    assert nbytes > 0 and nbytes % 256 == 0
+    buf = np.zeros(nbytes, np.uint8)
+    sim = native.MiSimParams(dt=0.0166, substeps=2, iters=4)
+    tp = native.MiLocoParams()
+    h = C.c_void_p()
+    rc = lib.mi_engine_create(b"Ant", C.byref(sim), C.cast(C.byref(tp), C.c_void_p), C.sizeof(tp), n, 0, 1,
+                              buf.ctypes.data, nbytes, C.byref(h))
+    assert rc == 0, lib.mi_last_error()
+    descs = {}
+    for i in range(lib.mi_engine_num_tensors(h)):
+        d = native.MiTensorDesc()
+        assert lib.mi_engine_tensor_desc(h, i, C.byref(d)) == 0
+        descs[d.name.decode()] = d
+    esz = {0: 4, 1: 8, 2: 1, 3: 4}
+    spans = []
+    for name, d in descs.items():
+        ext = 1 + sum((d.shape[k] - 1) * d.stride[k] for k in range(d.ndim))
+        assert d.byte_offset % 256 == 0
+        assert d.byte_offset + ext * esz[d.dtype] <= nbytes, name
+        spans.append((d.byte_offset, d.byte_offset + ext * esz[d.dtype], name))
+    spans.sort()
+    for (a0, a1, an), (b0, b1, bn) in zip(spans, spans[1:]):
+        assert a1 <= b0, (an, bn)  # no overlap
+    # reference dtypes / shapes (vec_task.py:310-323, ant.py:77-95)
+    assert tuple(descs["obs_buf"].shape[:2]) == (n, 60) and tuple(descs["obs_buf"].stride[:2]) == (60, 1)
+    assert descs["reset_buf"].dtype == 1
+    assert descs["progress_buf"].dtype == 1 and descs["rew_buf"].dtype == 0
+    assert tuple(descs["root_states"].shape[:2]) == (n, 13) and tuple(descs["root_states"].stride[:2]) == (1, n)
+    assert tuple(descs["dof_state"].shape[:3]) == (n, 8, 2) and tuple(descs["dof_state"].stride[:3]) == (1, n, 8 * n)
+    # bad arguments are rejected with a message
+    assert lib.mi_engine_create(b"Ant", C.byref(sim), C.cast(C.byref(tp), C.c_void_p), 12, n, 0, 1, buf.ctypes.data,
+                                nbytes, C.byref(h)) != 0
+    assert b"size mismatch" in lib.mi_last_error()
+    assert lib.mi_engine_create(b"Ant", C.byref(sim), C.cast(C.byref(tp), C.c_void_p), C.sizeof(tp), n, 0, 1,
+                                buf.ctypes.data, 16, C.byref(h)) != 0
+    lib.mi_engine_destroy(h)
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import isaacgymenvs_amd
+    with pytest.raises(RuntimeError):
+        isaacgymenvs_amd.make(seed=0, task="Ant", num_envs=64, sim_device="cuda:0", rl_device="cuda:0", headless=True)
+    with pytest.raises(RuntimeError):  # the reference's cpu pipeline is deliberately not offered
+        isaacgymenvs_amd.make(seed=0, task="Cartpole", num_envs=64, sim_device="cpu", rl_device="cpu", headless=True)
+
+
+def test_product_package_never_imports_oracle():
+    pkg = os.path.join(ROOT, "isaacgymenvs_amd")
+    for d, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(d, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "oracle/" not in src.replace("oracle/ for tests", "").replace("oracle/physics.c", "").replace("oracle/tasks.py", ""), os.path.join(d, f)

@@ -1,0 +1,299 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X).  Everything goes through the C ABI (libmi_engine.so).
+
+ 1. stand-alone jit-fn replacements vs golden vectors from the REFERENCE's own functions (tests/golden);
+ 2. physics: HIP kernels vs the independent CPU oracle (oracle/physics.c, fp64) from identical random states;
+ 3. whole VecTask.step trajectories vs the CPU restatement (oracle/tasks.py) on identical seeds/actions;
+ 4. size-independent properties at the BASELINE sizes (Ant@4096, Humanoid@8192).
+
+Stated FP tolerance (the closed PhysX reference cannot be run: parity vs PhysX is UNPINNED):
+obs/reward fns <= 2e-5 abs vs the reference's outputs; one physics step <= 5e-4 abs on positions/velocities vs
+the fp64 oracle (the fp32 oracle itself differs from fp64 by ~1e-4); trajectories are chaotic under contact, so
+multi-step agreement is asserted for the first steps and statistically afterwards.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from isaacgymenvs_amd import native  # noqa: E402
+from isaacgymenvs_amd.registry import load_model, sensor_bodies  # noqa: E402
+from isaacgymenvs_amd.tasks.cartpole import cartpole_params_from_cfg  # noqa: E402
+from isaacgymenvs_amd.tasks.locomotion import loco_params_from_cfg  # noqa: E402
+from isaacgymenvs_amd.utils.config import compose  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _t(a, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype, device=DEV).contiguous()
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _loco_params(task):
+    cfg = compose(overrides=[f"task={task}"])["task"]
+    return cfg, loco_params_from_cfg(cfg, task.lower(), 0.44 if task == "Ant" else 1.34)
+
+
+# ------------------------------------------------------------------ 1. jit-fn replacements vs reference golden vectors
+@pytest.mark.parametrize("task,name", [("Ant", "ant_obs_reward.npz"), ("Humanoid", "humanoid_obs_reward.npz")])
+def test_locomotion_obs_and_reward_kernels_match_reference(golden_dir, task, name):
+    g = dict(np.load(os.path.join(golden_dir, name)))
+    L = native.lib()
+    _, p = _loco_params(task)
+    n = g["obs"].shape[0]
+    pot = _t(g["potentials_in"])
+    prev = torch.zeros(n, device=DEV)
+    obs = torch.zeros(g["obs"].shape, device=DEV)
+    upv = torch.zeros(n, 3, device=DEV)
+    hv = torch.zeros(n, 3, device=DEV)
+    ins = [_t(g[k]) for k in ("root_states", "targets")]
+    rest = [_t(g[k]) for k in ("inv_start_rot", "dof_pos", "dof_vel", "dof_force", "dof_limits_lower", "dof_limits_upper",
+                               "sensors", "actions", "basis_vec0", "basis_vec1")]
+    native.check(L.mi_compute_locomotion_observations(
+        task.encode(), n, C.byref(p), ins[0].data_ptr(), ins[1].data_ptr(), pot.data_ptr(), prev.data_ptr(),
+        *[x.data_ptr() for x in rest], obs.data_ptr(), upv.data_ptr(), hv.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+    o = obs.cpu().numpy()
+    d = np.abs(o - g["obs"])
+    d[:, [7, 8, 9]] = np.minimum(d[:, [7, 8, 9]], np.abs(d[:, [7, 8, 9]] - 2 * np.pi))
+    assert d.max() < 2e-5, (d.max(), np.unravel_index(d.argmax(), d.shape))
+    np.testing.assert_allclose(pot.cpu().numpy(), g["potentials"], rtol=2e-7)
+    np.testing.assert_array_equal(prev.cpu().numpy(), g["prev_potentials"])
+    np.testing.assert_allclose(upv.cpu().numpy(), g["up_vec"], atol=2e-6)
+    np.testing.assert_allclose(hv.cpu().numpy(), g["heading_vec"], atol=2e-6)
+    # reward on the reference's own obs
+    rew = torch.zeros(n, device=DEV)
+    rs = torch.zeros(n, dtype=torch.int64, device=DEV)
+    native.check(L.mi_compute_locomotion_reward(
+        task.encode(), n, C.byref(p), _t(g["obs"]).data_ptr(), _t(g["reset_in"], torch.int64).data_ptr(),
+        _t(g["progress"], torch.int64).data_ptr(), _t(g["actions"]).data_ptr(), _t(g["potentials"]).data_ptr(),
+        _t(g["prev_potentials"]).data_ptr(), rew.data_ptr(), rs.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(rs.cpu().numpy(), g["reset"])
+    np.testing.assert_allclose(rew.cpu().numpy(), g["rew"], rtol=1e-5, atol=2e-5)
+
+
+def test_cartpole_reward_kernel_matches_reference(golden_dir):
+    g = dict(np.load(os.path.join(golden_dir, "cartpole_reward.npz")))
+    L = native.lib()
+    p = native.MiCartpoleParams(reset_dist=3.0, max_push_effort=400.0, max_episode_length=500.0, clip_actions=1.0)
+    n = len(g["rew"])
+    rew = torch.zeros(n, device=DEV)
+    rs = torch.zeros(n, dtype=torch.int64, device=DEV)
+    native.check(L.mi_compute_cartpole_reward(
+        n, C.byref(p), _t(g["pole_angle"]).data_ptr(), _t(g["pole_vel"]).data_ptr(), _t(g["cart_vel"]).data_ptr(),
+        _t(g["cart_pos"]).data_ptr(), _t(g["reset_in"], torch.int64).data_ptr(), _t(g["progress"], torch.int64).data_ptr(),
+        rew.data_ptr(), rs.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(rs.cpu().numpy(), g["reset"])
+    np.testing.assert_allclose(rew.cpu().numpy(), g["rew"], rtol=1e-6, atol=1e-6)
+
+
+# ------------------------------------------------------------------ helpers for engine-level tests
+def _sim_dict(sp):
+    return dict(dt=sp.dt, substeps=sp.substeps, iters=sp.iters, gravity=tuple(sp.gravity), contact_offset=sp.contact_offset,
+                rest_offset=sp.rest_offset, max_depen_vel=sp.max_depen_vel, erp=sp.erp, plane_mu=sp.plane_mu,
+                ground_z=sp.ground_z, cfm=sp.cfm, warm=sp.warm)
+
+
+def _make_env(task, n, seed=5):
+    import isaacgymenvs_amd
+    return isaacgymenvs_amd.make(seed=seed, task=task, num_envs=n, sim_device=DEV, rl_device=DEV, headless=True)
+
+
+def _random_state(spec, n, rng, z_lo, z_hi):
+    nd = spec.nd
+    lo, up = np.minimum(spec.dof_lower, spec.dof_upper), np.maximum(spec.dof_lower, spec.dof_upper)
+    root = np.zeros((n, 13))
+    root[:, 0:2] = rng.normal(size=(n, 2))
+    root[:, 2] = rng.uniform(z_lo, z_hi, n)
+    q = rng.normal(size=(n, 4)); q[:, 3] += 3; q /= np.linalg.norm(q, axis=1, keepdims=True)
+    root[:, 3:7] = q
+    root[:, 7:13] = rng.normal(size=(n, 6))
+    return root, rng.uniform(lo, up, (n, nd)), rng.normal(size=(n, nd)) * 2
+
+
+# ------------------------------------------------------------------ 2. physics vs the fp64 CPU oracle
+@pytest.mark.parametrize("task,z_lo,z_hi,gear", [("Ant", 0.3, 0.6, 15.0), ("Humanoid", 0.9, 1.4, 60.0)])
+def test_simulate_matches_cpu_oracle(task, z_lo, z_hi, gear):
+    from oracle.engine import OracleEngine
+    n = 256
+    env = _make_env(task, n)
+    spec = load_model(task.lower())
+    sb = sensor_bodies(task.lower())
+    orc = OracleEngine(spec, n, params=_sim_dict(env.sim_params), sensor_bodies=sb, precision="f64")
+    rng = np.random.default_rng(0)
+    root, q, qd = _random_state(spec, n, rng, z_lo, z_hi)
+    tau = rng.uniform(-gear, gear, (n, spec.nd))
+    t = env.engine.tensors
+    t["root_states"][:] = _t(root); env.dof_pos[:] = _t(q); env.dof_vel[:] = _t(qd)
+    t["contact_impulse"].zero_(); t["limit_impulse"].zero_()
+    t["dof_actuation_force"][:] = _t(tau)
+    orc.root[:] = root; orc.q[:] = q; orc.qd[:] = qd
+    worst = 0.0
+    for it in range(3):
+        env.engine.simulate()
+        orc.step(tau)
+        torch.cuda.synchronize()
+        g_root = t["root_states"].cpu().numpy(); g_q = env.dof_pos.cpu().numpy(); g_qd = env.dof_vel.cpu().numpy()
+        assert np.isfinite(g_root).all() and np.isfinite(g_qd).all()
+        e = max(np.abs(g_root - orc.root).max(), np.abs(g_q - orc.q).max(), np.abs(g_qd - orc.qd).max())
+        worst = max(worst, e)
+        scale = max(1.0, np.abs(orc.qd).max())
+        assert e < 5e-4 * scale * (it + 1), (task, it, e)
+        sens = env.vec_sensor_tensor.cpu().numpy()
+        # force sensors: relative to the largest force present
+        assert np.abs(sens - orc.sensor).max() < 2e-3 * max(1.0, np.abs(orc.sensor).max())
+    print(f"{task}: worst |hip - oracle_f64| over 3 steps = {worst:.2e}")
+
+
+def test_cartpole_simulate_matches_cpu_oracle_and_ode():
+    from oracle.engine import OracleEngine
+    n = 64
+    env = _make_env("Cartpole", n)
+    spec = load_model("cartpole")
+    orc = OracleEngine(spec, n, params=_sim_dict(env.sim_params), precision="f64")
+    rng = np.random.default_rng(1)
+    q = rng.uniform(-0.5, 0.5, (n, 2)); qd = rng.uniform(-1, 1, (n, 2)); tau = np.zeros((n, 2)); tau[:, 0] = rng.uniform(-400, 400, n)
+    env.dof_pos[:] = _t(q); env.dof_vel[:] = _t(qd)
+    env.engine.tensors["dof_actuation_force"][:] = _t(tau)
+    orc.root[:, 2] = 2.0; orc.q[:] = q; orc.qd[:] = qd
+    for _ in range(10):
+        env.engine.simulate(); orc.step(tau)
+    torch.cuda.synchronize()
+    assert np.abs(env.dof_pos.cpu().numpy() - orc.q).max() < 2e-4
+    assert np.abs(env.dof_vel.cpu().numpy() - orc.qd).max() < 2e-3
+
+
+# ------------------------------------------------------------------ 3. whole-step trajectories vs the CPU restatement
+@pytest.mark.parametrize("task,hum", [("Ant", False), ("Humanoid", True)])
+def test_step_trajectory_matches_cpu_restatement(task, hum):
+    from oracle.tasks import OracleLocomotionEnv
+    n, seed = 128, 11
+    env = _make_env(task, n, seed=seed)
+    spec = load_model(task.lower())
+    cfg, p = _loco_params(task)
+    orc = OracleLocomotionEnv(hum, spec, sensor_bodies(task.lower()), _sim_dict(env.sim_params), p, n, seed=seed, precision="f64")
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for step in range(12):
+        a = torch.rand((n, env.num_actions), generator=g) * 2 - 1
+        obs_d, rew, reset, extras = env.step(a.to(DEV))
+        o_obs, o_rew, o_reset = orc.step(a.numpy())
+        torch.cuda.synchronize()
+        obs = obs_d["obs"].cpu().numpy()
+        assert obs.shape == o_obs.shape
+        np.testing.assert_array_equal(env.progress_buf.cpu().numpy(), orc.progress_buf)
+        if step == 0:
+            # every env is reset inside the first step (vec_task.py:316-317): identical RNG => identical start state
+            np.testing.assert_allclose(env.dof_pos.cpu().numpy(), orc.eng.q, atol=1e-6)
+            np.testing.assert_allclose(env.dof_vel.cpu().numpy(), orc.eng.qd, atol=1e-6)
+        d = np.abs(obs - o_obs)
+        d[:, [7, 8, 9]] = np.minimum(d[:, [7, 8, 9]], np.abs(d[:, [7, 8, 9]] - 2 * np.pi))
+        tol = 2e-3 * (1 + step) * (4 if hum else 1)
+        frac_ok = (d.max(axis=1) < tol).mean()
+        assert frac_ok > 0.97, (task, step, frac_ok, d.max())
+        same_reset = (reset.cpu().numpy() == o_reset).mean()
+        assert same_reset > 0.98, (task, step, same_reset)
+        if step < 3:
+            ok = d.max(axis=1) < tol
+            np.testing.assert_allclose(rew.cpu().numpy()[ok], o_rew[ok], atol=0.05 + 2e-2 * step, rtol=1e-3)
+    assert extras["time_outs"].dtype == torch.bool
+
+
+def test_cartpole_step_matches_cpu_restatement():
+    from oracle.tasks import OracleCartpoleEnv
+    n, seed = 64, 2  # BASELINE configs[0]: Cartpole num_envs=64
+    env = _make_env("Cartpole", n, seed=seed)
+    cfg = compose(overrides=["task=Cartpole"])["task"]
+    orc = OracleCartpoleEnv(load_model("cartpole"), _sim_dict(env.sim_params), cartpole_params_from_cfg(cfg), n, seed=seed, precision="f64")
+    g = torch.Generator(device="cpu").manual_seed(9)
+    for step in range(60):
+        a = torch.rand((n, 1), generator=g) * 2 - 1
+        obs_d, rew, reset, _ = env.step(a.to(DEV))
+        o_obs, o_rew, o_reset = orc.step(a.numpy())
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(env.obs_buf.cpu().numpy(), o_obs, atol=2e-3 * (1 + step / 10))
+        np.testing.assert_array_equal(reset.cpu().numpy(), o_reset)
+        assert obs_d["obs"].abs().max() <= 5.0 + 1e-6  # clipObservations (Cartpole.yaml)
+    np.testing.assert_allclose(rew.cpu().numpy(), o_rew, atol=2e-2)
+
+
+# ------------------------------------------------------------------ 4. properties at the BASELINE sizes
+@pytest.mark.parametrize("task,n,z_term", [("Ant", 4096, 0.31), ("Humanoid", 8192, 0.8)])
+def test_full_size_rollout_properties(task, n, z_term):
+    env = _make_env(task, n, seed=42)
+    spec = load_model(task.lower())
+    lo = torch.tensor(np.minimum(spec.dof_lower, spec.dof_upper), device=DEV, dtype=torch.float32)
+    up = torch.tensor(np.maximum(spec.dof_lower, spec.dof_upper), device=DEV, dtype=torch.float32)
+    g = torch.Generator(device=DEV).manual_seed(42)
+    total_resets = 0
+    ret = torch.zeros(n, device=DEV)
+    for step in range(300):
+        a = torch.rand((n, env.num_actions), device=DEV, generator=g) * 2 - 1
+        obs_d, rew, reset, extras = env.step(a)
+        total_resets += int(reset.sum())
+        ret += rew
+        if step % 50 == 49:
+            assert torch.isfinite(obs_d["obs"]).all() and torch.isfinite(rew).all()
+            z = env.root_states[:, 2]
+            assert z.min() > 0.0 and z.max() < 5.0, (z.min(), z.max())
+            qn = torch.linalg.norm(env.root_states[:, 3:7], dim=-1)
+            assert (qn - 1).abs().max() < 1e-4
+            viol = torch.maximum(lo - env.dof_pos, env.dof_pos - up).max()
+            assert viol < 0.1, viol  # joint limits hold up to solver slop under 15-135 N.m random torques
+            assert env.progress_buf.max() <= step + 1
+    assert total_resets > 0  # random policies fall (termination height) => resets happen
+    assert obs_d["obs"].shape == (n, env.num_obs) and rew.shape == (n,) and reset.dtype == torch.int64
+
+
+def test_ant_static_equilibrium_weight():
+    """An ant at rest: the ground reaction summed over the foot sensors + torso contacts equals m*g."""
+    n = 64
+    env = _make_env("Ant", n)
+    spec = load_model("ant")
+    zero = torch.zeros((n, 8), device=DEV)
+    env.step(zero)
+    for _ in range(150):
+        env.step(zero)
+        env.reset_buf.zero_()
+    imp = env.engine.tensors["contact_impulse"]  # [n, nsph, 3] = (normal, t1, t2) impulses of the last sub-step
+    h = env.sim_params.dt / env.sim_params.substeps
+    fz = imp[:, :, 0].sum(dim=1) / h
+    np.testing.assert_allclose(fz.cpu().numpy(), spec.total_mass() * 9.81, rtol=2e-2)
+    assert env.root_states[:, 2].min() > 0.31  # stands above the termination height
+
+
+# ------------------------------------------------------------------ API contract (vec_task.py)
+def test_api_contract_and_state_checkpoint():
+    n = 64
+    env = _make_env("Ant", n)
+    assert env.num_envs == n and env.num_obs == 60 and env.num_acts == 8 and env.num_states == 0
+    assert env.observation_space.shape == (60,) and env.action_space.shape == (8,)
+    assert env.reset_buf.dtype == torch.int64 and env.progress_buf.dtype == torch.int64 and env.rew_buf.dtype == torch.float32
+    assert bool((env.reset_buf == 1).all())  # vec_task.py:316-317
+    od = env.reset()
+    assert od["obs"].shape == (n, 60) and float(od["obs"].abs().max()) == 0.0  # reset() returns the zero obs buffer
+    a = env.zero_actions()
+    env.step(a)
+    assert bool((env.progress_buf == 0).all()) and bool((env.reset_buf == 0).all())
+    snap = env.get_env_state()
+    g = torch.Generator(device=DEV).manual_seed(0)
+    acts = [torch.rand((n, 8), device=DEV, generator=g) * 2 - 1 for _ in range(5)]
+    outs1 = [env.step(x)[0]["obs"].clone() for x in acts]
+    env.set_env_state(snap)
+    outs2 = [env.step(x)[0]["obs"].clone() for x in acts]
+    for x, y in zip(outs1, outs2):
+        assert torch.equal(x, y)  # bit-exact replay from a physics-state checkpoint
+    env.reset_buf[:8] = 1
+    od, ids = env.reset_done()
+    assert ids.tolist() == list(range(8)) and bool((env.reset_buf[:8] == 0).all()) and bool((env.progress_buf[:8] == 0).all())
+    # writes through the views reach the simulator (gymtorch.wrap_tensor semantics, ant.py:260-261)
+    env.dof_pos[3] = 0.0
+    assert float(env.dof_state[3, :, 0].abs().max()) == 0.0

@@ -1,0 +1,150 @@
+#!/usr/bin/env python
+"""Generate golden input/output vectors by running the REFERENCE's own @torch.jit.script functions.
+
+Runs only in the development container (needs /root/reference); the .npz files it writes under tests/golden/
+are committed so the GPU box (no /root/reference) can check the HIP kernels and the oracle against them.
+
+Recipe: stub `isaacgym` and `gym` (absent here), pre-register the reference packages as
+namespace modules so their __init__ files (which import hydra) are skipped, then import the task modules by name.
+Functions captured:
+  isaacgymenvs/tasks/ant.py:325        compute_ant_reward
+  isaacgymenvs/tasks/ant.py:374        compute_ant_observations
+  isaacgymenvs/tasks/humanoid.py:323   compute_humanoid_reward
+  isaacgymenvs/tasks/humanoid.py:378   compute_humanoid_observations
+  isaacgymenvs/tasks/cartpole.py:180   compute_cartpole_reward
+"""
+import importlib
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def import_reference():
+    tmp = tempfile.mkdtemp()
+    stub = ("class _Dummy:\n    def __init__(self, *a, **k):\n        pass\n    def __call__(self, *a, **k):\n        return _Dummy()\n"
+            "    def __getattr__(self, n):\n        return _Dummy()\n\ndef __getattr__(name):\n    return _Dummy()\n")
+    os.makedirs(os.path.join(tmp, "isaacgym"))
+    for m in ("gymapi", "gymutil", "terrain_utils"):
+        open(os.path.join(tmp, "isaacgym", m + ".py"), "w").write(stub)
+    open(os.path.join(tmp, "isaacgym", "__init__.py"), "w").write("from . import gymapi, gymutil, gymtorch, terrain_utils\n" + stub)
+    open(os.path.join(tmp, "isaacgym", "gymtorch.py"), "w").write(
+        "def wrap_tensor(x):\n    return x\n\ndef unwrap_tensor(x):\n    return x\n")
+    os.makedirs(os.path.join(tmp, "gym"))
+    open(os.path.join(tmp, "gym", "__init__.py"), "w").write("from . import spaces\n\nclass Space:\n    pass\n")
+    open(os.path.join(tmp, "gym", "spaces.py"), "w").write("class Box:\n    def __init__(self, *a, **k):\n        pass\n")
+    sys.path.insert(0, tmp)
+    if not hasattr(np, "Inf"):
+        np.Inf = np.inf  # vec_task.py:107 uses np.Inf (removed in NumPy 2)
+    for name, rel in (("isaacgymenvs", "isaacgymenvs"), ("isaacgymenvs.tasks", "isaacgymenvs/tasks"),
+                      ("isaacgymenvs.utils", "isaacgymenvs/utils"), ("isaacgymenvs.tasks.base", "isaacgymenvs/tasks/base")):
+        mod = types.ModuleType(name)
+        mod.__path__ = [os.path.join(REF, rel)]
+        sys.modules[name] = mod
+    return {n: importlib.import_module("isaacgymenvs.tasks." + n) for n in ("ant", "humanoid", "cartpole")}
+
+
+def rand_quat(g, n):
+    q = torch.randn(n, 4, generator=g)
+    return q / q.norm(dim=-1, keepdim=True)
+
+
+def locomotion_case(mod, name, nd, nsv, n, seed, hum, lo, up, gears, scal):
+    g = torch.Generator().manual_seed(seed)
+    root = torch.zeros(n, 13)
+    root[:, 0:3] = torch.randn(n, 3, generator=g) * torch.tensor([3.0, 3.0, 0.3]) + torch.tensor([0.0, 0.0, 0.6 if not hum else 1.2])
+    root[:, 3:7] = rand_quat(g, n)
+    # make half the batch near-upright so the thresholds (up_proj > 0.93, heading > 0.8) are exercised on both sides
+    root[: n // 2, 3:7] = torch.nn.functional.normalize(torch.tensor([0.0, 0.0, 0.0, 1.0]) + 0.15 * torch.randn(n // 2, 4, generator=g), dim=-1)
+    root[:, 7:13] = torch.randn(n, 6, generator=g) * 2.0
+    lo_t, up_t = torch.tensor(lo, dtype=torch.float32), torch.tensor(up, dtype=torch.float32)
+    u = torch.rand(n, nd, generator=g) * 1.1 - 0.05  # slightly beyond the limits too
+    dof_pos = lo_t + u * (up_t - lo_t)
+    dof_vel = torch.randn(n, nd, generator=g) * 5.0
+    dof_force = torch.randn(n, nd, generator=g) * 50.0
+    sensors = torch.randn(n, nsv, generator=g) * 30.0
+    actions = torch.rand(n, nd, generator=g) * 2 - 1
+    targets = torch.tensor([1000.0, 0.0, 0.0]).repeat(n, 1)
+    potentials = -(targets[:, :2] - root[:, :2]).norm(dim=-1) / scal["dt"] + torch.randn(n, generator=g)
+    inv_start_rot = torch.tensor([0.0, 0.0, 0.0, 1.0]).repeat(n, 1)
+    b0 = torch.tensor([1.0, 0.0, 0.0]).repeat(n, 1)
+    b1 = torch.tensor([0.0, 0.0, 1.0]).repeat(n, 1)
+    obs0 = torch.zeros(n, 12 + nd * (4 if hum else 3) + nsv)
+    if hum:
+        obs, pot, prev, upv, hv = mod.compute_humanoid_observations(
+            obs0, root, targets, potentials.clone(), inv_start_rot, dof_pos, dof_vel, dof_force, lo_t, up_t,
+            scal["dof_vel_scale"], sensors, actions, scal["dt"], scal["contact_force_scale"],
+            scal["angular_velocity_scale"], b0, b1)
+    else:
+        obs, pot, prev, upv, hv = mod.compute_ant_observations(
+            obs0, root, targets, potentials.clone(), inv_start_rot, dof_pos, dof_vel, lo_t, up_t,
+            scal["dof_vel_scale"], sensors, actions, scal["dt"], scal["contact_force_scale"], b0, b1, 2)
+    reset_in = (torch.rand(n, generator=g) < 0.1).long()
+    progress = torch.randint(0, int(scal["max_episode_length"]) + 2, (n,), generator=g)
+    progress[:8] = torch.tensor([997, 998, 999, 1000, 0, 1, 998, 999])
+    gears_t = torch.tensor(gears, dtype=torch.float32)
+    if hum:
+        rew, reset = mod.compute_humanoid_reward(
+            obs, reset_in, progress, actions, scal["up_weight"], scal["heading_weight"], pot, prev,
+            scal["actions_cost"], scal["energy_cost"], scal["joints_at_limit_cost"], float(max(gears)), gears_t,
+            scal["termination_height"], scal["death_cost"], scal["max_episode_length"])
+    else:
+        rew, reset = mod.compute_ant_reward(
+            obs, reset_in, progress, actions, scal["up_weight"], scal["heading_weight"], pot, prev,
+            scal["actions_cost"], scal["energy_cost"], scal["joints_at_limit_cost"], scal["termination_height"],
+            scal["death_cost"], scal["max_episode_length"])
+    d = dict(root_states=root, targets=targets, potentials_in=potentials, inv_start_rot=inv_start_rot, dof_pos=dof_pos,
+             dof_vel=dof_vel, dof_force=dof_force, dof_limits_lower=lo_t, dof_limits_upper=up_t, sensors=sensors,
+             actions=actions, basis_vec0=b0, basis_vec1=b1, obs=obs, potentials=pot, prev_potentials=prev, up_vec=upv,
+             heading_vec=hv, reset_in=reset_in, progress=progress, gears=gears_t, rew=rew, reset=reset)
+    out = {k: v.numpy() for k, v in d.items()}
+    out.update({"scalar_" + k: np.float64(v) for k, v in scal.items()})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "obs", tuple(obs.shape), "rew mean", float(rew.mean()), "resets", int(reset.sum()))
+
+
+def cartpole_case(mod, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    pole_angle = torch.randn(n, generator=g) * 1.0
+    pole_vel = torch.randn(n, generator=g) * 3
+    cart_vel = torch.randn(n, generator=g) * 2
+    cart_pos = torch.randn(n, generator=g) * 2
+    reset_in = (torch.rand(n, generator=g) < 0.1).long()
+    progress = torch.randint(0, 502, (n,), generator=g)
+    progress[:4] = torch.tensor([497, 498, 499, 500])
+    rew, reset = mod.compute_cartpole_reward(pole_angle, pole_vel, cart_vel, cart_pos, 3.0, reset_in, progress, 500.0)
+    np.savez_compressed(os.path.join(OUT, "cartpole_reward.npz"), pole_angle=pole_angle.numpy(), pole_vel=pole_vel.numpy(),
+                        cart_vel=cart_vel.numpy(), cart_pos=cart_pos.numpy(), reset_in=reset_in.numpy(),
+                        progress=progress.numpy(), rew=rew.numpy(), reset=reset.numpy(), scalar_reset_dist=3.0,
+                        scalar_max_episode_length=500.0)
+    print("cartpole_reward", n, "resets", int(reset.sum()))
+
+
+def main():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from isaacgymenvs_amd.registry import load_model
+    torch.set_num_threads(1)
+    mods = import_reference()
+    os.makedirs(OUT, exist_ok=True)
+    ant, hum = load_model("ant"), load_model("humanoid")
+    a_lo, a_up = np.minimum(ant.dof_lower, ant.dof_upper), np.maximum(ant.dof_lower, ant.dof_upper)
+    h_lo, h_up = np.minimum(hum.dof_lower, hum.dof_upper), np.maximum(hum.dof_lower, hum.dof_upper)
+    ant_s = dict(dt=0.0166, dof_vel_scale=0.2, contact_force_scale=0.1, angular_velocity_scale=1.0, up_weight=0.1,
+                 heading_weight=0.5, actions_cost=0.005, energy_cost=0.05, joints_at_limit_cost=0.1,
+                 termination_height=0.31, death_cost=-2.0, max_episode_length=1000.0)
+    hum_s = dict(dt=0.0166, dof_vel_scale=0.1, contact_force_scale=0.01, angular_velocity_scale=0.25, up_weight=0.1,
+                 heading_weight=0.5, actions_cost=0.01, energy_cost=0.05, joints_at_limit_cost=0.25,
+                 termination_height=0.8, death_cost=-1.0, max_episode_length=1000.0)
+    locomotion_case(mods["ant"], "ant_obs_reward", 8, 24, 512, 1, False, a_lo, a_up, list(ant.act_gear), ant_s)
+    locomotion_case(mods["humanoid"], "humanoid_obs_reward", 21, 12, 512, 2, True, h_lo, h_up, list(hum.act_gear), hum_s)
+    cartpole_case(mods["cartpole"], 512, 3)
+
+
+if __name__ == "__main__":
+    main()
