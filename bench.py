@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the fused VecTask.step() hot path on N MI355X (one process per GPU).
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched under
+`python -m torch.distributed.run --nproc-per-node N ...` (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from env).
+Rank 0 prints ONE JSON line.
+
+  step      = one `env.step(actions)` through the public Python API (isaacgymenvs_amd.make -> VecTask.step), i.e.
+              one fused HIP launch advancing every env by one control step (reference vec_task.py:360-408).
+  workload  = BASELINE.json configs[1]: Ant num_envs=4096 per GPU, random-action rollout (reference README.md:48-51);
+              actions come from a pool of pre-generated U(-1,1) batches already resident in HBM.
+  value     = (envs on all ranks) * K / max-over-ranks(wall time of the K timed steps), barrier+synchronize on both sides.
+  roofline  = algorithmic bytes per launch (673 B/env-step Ant, 1161 B Humanoid) / average duration of
+              the step kernel, measured with HIP events around each launch (a second pass right after the timed one),
+              against the 8 TB/s HBM3E peak.  `traffic` comes from the rocprofv3 PMC pass (profiles/), not from here.
+  cpu_baseline = the CPU oracle (oracle/physics.c via oracle/tasks.py, OpenMP over envs) on a bounded sample of the
+              same workload on this host's cores ("port": the reference's PhysX-CPU path cannot run).
+  extra     = the second headline config (Humanoid num_envs=8192) measured the same way in the same run.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# API-visible state read once + written once per env-step
+ALGO_BYTES = {"Cartpole": 89, "Ant": 673, "Humanoid": 1161}
+DEFAULT_ENVS = {"Cartpole": 64, "Ant": 4096, "Humanoid": 8192}
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
+def measure(task, num_envs, steps, warmup, device, rank, world, seed=42, pool=64):
+    import torch
+    import torch.distributed as dist
+    import isaacgymenvs_amd
+
+    env = isaacgymenvs_amd.make(seed=seed + rank, task=task, num_envs=num_envs, sim_device=device, rl_device=device,
+                                headless=True, multi_gpu=world > 1, force_render=False)
+    g = torch.Generator(device=device).manual_seed(seed + rank)  # reference utils/utils.py:94: seed + rank
+    acts = [2.0 * torch.rand((num_envs, env.num_actions), device=device, generator=g) - 1.0 for _ in range(pool)]
+    reducer = None
+    if world > 1:
+        from isaacgymenvs_amd.parallel import EpisodeStatsReducer
+        reducer = EpisodeStatsReducer(env.engine.tensors["episode_stats"], interval=16)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(warmup):
+        env.step(acts[i % pool])
+        if reducer:
+            reducer.step()
+    sync()
+    stats0 = env.engine.tensors["episode_stats"].clone()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(steps):
+        env.step(acts[i % pool])
+        if reducer:
+            reducer.step()
+    ev1.record()
+    sync()
+    wall = time.perf_counter() - t0
+    gpu_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        t = torch.tensor([wall], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    stats = (env.engine.tensors["episode_stats"] - stats0).cpu().tolist()
+    # per-launch kernel duration: HIP events on the launch stream around each fused-step launch (same workload continuing)
+    kn = min(steps, 200)
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(kn)]
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(pairs):
+        a.record()
+        env.engine.step(acts[i % pool])
+        b.record()
+    torch.cuda.synchronize()
+    durs = sorted(a.elapsed_time(b) for a, b in pairs)
+    kern_ms = sum(durs) / len(durs)
+    res = {
+        "task": task, "num_envs_per_gpu": num_envs, "wall_s": wall, "ms_per_step": 1e3 * wall / steps,
+        "gpu_ms_per_step": gpu_ms / steps, "kernel_ms_avg": kern_ms, "kernel_ms_median": durs[len(durs) // 2],
+        "env_steps_per_s": world * num_envs * steps / wall,
+        "reset_rate": stats[2] / max(stats[4], 1.0), "mean_reward": stats[3] / max(stats[4], 1.0),
+    }
+    if reducer:
+        res["job_stats"] = reducer.result()
+    del env
+    return res
+
+
+def roofline(task, num_envs, kernel_ms):
+    bytes_per_launch = ALGO_BYTES[task] * num_envs
+    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None, "kernel": "loco_step_kernel<Model%s>" % task, "kernel_ms": kernel_ms,
+            "algorithmic_bytes_per_launch": bytes_per_launch}
+
+
+def cpu_baseline(task, num_envs, budget_s=15.0, seed=42):
+    """The CPU oracle on this host's cores (OpenMP over envs), same workload, bounded to ~budget_s seconds."""
+    import numpy as np
+    from isaacgymenvs_amd import native
+    from isaacgymenvs_amd.registry import load_model, sensor_bodies
+    from isaacgymenvs_amd.tasks.locomotion import loco_params_from_cfg
+    from isaacgymenvs_amd.utils.config import compose
+    from oracle.tasks import OracleLocomotionEnv
+
+    cfg = compose(overrides=[f"task={task}"])["task"]
+    name = task.lower()
+    p = loco_params_from_cfg(cfg, name, 0.44 if task == "Ant" else 1.34)
+    px = cfg["sim"]["physx"]
+    sim = dict(dt=cfg["sim"]["dt"], substeps=cfg["sim"]["substeps"],
+               iters=px["num_position_iterations"] + px["num_velocity_iterations"], gravity=tuple(cfg["sim"]["gravity"]),
+               contact_offset=px["contact_offset"], rest_offset=px["rest_offset"],
+               max_depen_vel=px["max_depenetration_velocity"], erp=0.5,
+               plane_mu=cfg["env"]["plane"]["staticFriction"], ground_z=0.0, cfm=1e-6, warm=1.0)
+    orc = OracleLocomotionEnv(task == "Humanoid", load_model(name), sensor_bodies(name), sim, p, num_envs, seed=seed,
+                              precision="f32")
+    rng = np.random.default_rng(seed)
+    nact = orc.nd
+    for _ in range(2):
+        orc.step(rng.uniform(-1, 1, (num_envs, nact)).astype(np.float32))
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s and n < 2000:
+        orc.step(rng.uniform(-1, 1, (num_envs, nact)).astype(np.float32))
+        n += 1
+    dt = time.perf_counter() - t0
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return {"value": num_envs * n / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} steps of {task} num_envs={num_envs} (oracle/physics.c fp32, OpenMP over envs + numpy obs/reward), "
+                      f"{dt:.1f} s; stand-in for PhysX-CPU, which cannot run here"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--task", default="Ant", choices=list(DEFAULT_ENVS))
+    ap.add_argument("--num-envs", type=int, default=0, help="envs per GPU (default: the BASELINE config of the task)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the Humanoid@8192 side measurement")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    from isaacgymenvs_amd.parallel import init_distributed
+    rank, world, local_rank = init_distributed()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device (no CPU product path)")
+    device = f"cuda:{local_rank}"
+    torch.cuda.set_device(local_rank)
+    n_env = args.num_envs or DEFAULT_ENVS[args.task]
+
+    main_res = measure(args.task, n_env, args.steps, args.warmup, device, rank, world)
+    extra = None
+    if not args.no_extra and args.task == "Ant":
+        extra = measure("Humanoid", DEFAULT_ENVS["Humanoid"], max(args.steps // 4, 10), max(args.warmup // 4, 5), device, rank, world)
+    if rank != 0:
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    out = {
+        "metric": "env-steps/sec (num_envs x control-steps/sec), random-action rollout",
+        "value": main_res["env_steps_per_s"], "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.task} num_envs={n_env} per GPU ({world * n_env} total), VecTask.step() via Python API, "
+                               f"pool of pre-generated U(-1,1) action batches in HBM, seed 42+rank",
+                   "task": args.task, "num_envs_per_gpu": n_env, "parallelism": f"env-shard x{world}"},
+        "gpu_ms_per_step": main_res["gpu_ms_per_step"], "reset_rate": main_res["reset_rate"],
+        "mean_reward": main_res["mean_reward"],
+        "roofline": roofline(args.task, n_env, main_res["kernel_ms_avg"]),
+    }
+    if "job_stats" in main_res:
+        out["job_stats"] = main_res["job_stats"]
+    if extra is not None:
+        out["extra"] = {"workload": f"Humanoid num_envs={DEFAULT_ENVS['Humanoid']} per GPU", "value": extra["env_steps_per_s"],
+                        "unit": "env-steps/s", "ms_per_step": extra["ms_per_step"], "reset_rate": extra["reset_rate"],
+                        "roofline": roofline("Humanoid", DEFAULT_ENVS["Humanoid"], extra["kernel_ms_avg"])}
+    if world == 1 and not args.no_cpu_baseline and args.task in ("Ant", "Humanoid"):
+        out["cpu_baseline"] = cpu_baseline(args.task, n_env, budget_s=args.cpu_budget)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -20,9 +20,24 @@
 
 #if defined(__HIPCC__)
 #define MI_HD __host__ __device__ __forceinline__
+#define MI_HD_NOINLINE __host__ __device__ __attribute__((noinline))
 #define MI_LAMBDA __attribute__((always_inline))
+#if defined(__HIP_DEVICE_COMPILE__)
+// nothing may be scheduled across this point: keeps the phases of the (one-basic-block) sub-step apart so the
+// machine scheduler cannot stretch live ranges across them
+#define MI_PHASE() __builtin_amdgcn_sched_barrier(0)
+// an integer zero the optimiser cannot see through: added to the row-store base inside the PGS loop so that LICM
+// does not hoist the (loop-invariant) loads of all G rows out of the sweep loop and keep them live in registers
+#define MI_OPAQUE_ZERO(z) asm volatile("s_mov_b32 %0, 0" : "=s"(z))
 #else
+#define MI_PHASE() do { } while (0)
+#define MI_OPAQUE_ZERO(z) (z) = 0
+#endif
+#else
+#define MI_PHASE() do { } while (0)
+#define MI_OPAQUE_ZERO(z) (z) = 0
 #define MI_HD inline __attribute__((always_inline))
+#define MI_HD_NOINLINE __attribute__((noinline))
 #define MI_LAMBDA __attribute__((always_inline))
 #endif
 
@@ -42,6 +57,15 @@ template <int N, class F>
 MI_HD void sfor_rev(F&& f) {
     sfor<N>([&](auto I) MI_LAMBDA { f(std::integral_constant<int, N - 1 - decltype(I)::value>{}); });
 }
+
+// Constraint-row store.  On the device the rows of the 64 envs of a wave live in LDS as [slot][lane] (one
+// ds_read/ds_write per access, conflict-free, addresses are compile-time offsets from a per-lane base); models
+// whose rows do not fit the 160 KB of LDS (Humanoid) and the host build use a private array with stride 1.
+template <int STRIDE>
+struct RowStore {
+    float* p;
+    MI_HD float& operator()(int slot) const { return p[slot * STRIDE]; }
+};
 
 struct SimParams {
     float dt;
@@ -109,20 +133,28 @@ MI_HD void spi_mul(const SpI& I, const float* X, float* F) {
     F[3] = I.m * a[0] - hxal[0]; F[4] = I.m * a[1] - hxal[1]; F[5] = I.m * a[2] - hxal[2];
 }
 
+// strided view of a per-env vector that lives in HBM as SoA [k][env] (device: stride = num_envs) or in a plain
+// array (host build: stride 1)
+struct Strided {
+    float* p;
+    int stride;
+    MI_HD float& operator()(int k) const { return p[(size_t)k * stride]; }
+};
+
 template <class M>
 struct Sim {
     static constexpr int NB = M::NB, ND = M::ND, NV = M::NV, OFF = M::OFF, NSPH = M::NSPH, NSENS = M::NSENS;
     static constexpr int NLIM = []() constexpr { int n = 0; for (int d = 0; d < ND; ++d) n += M::dof_limited[d] ? 1 : 0; return n; }();
     static constexpr int NROWG = (NLIM + 3 * NSPH) > 0 ? (NLIM + 3 * NSPH) : 1;
+    static constexpr int NVA = NV > 0 ? NV : 1;
+    // slots of the row store: G rows (NROWG x MAXCHAIN), 1/A_ii, velocity targets and (big models) the impulses
+    static constexpr bool LAM_IN_ROWS = NROWG > 16;
+    static constexpr int ROW_SLOTS = NROWG * M::MAXCHAIN + (LAM_IN_ROWS ? 3 : 2) * NROWG;
 
-    // ---- persistent per-env state (lives in HBM between steps, SoA [field][env])
+    // ---- per-env state carried in registers through a sub-step; the warm-start impulses and the sensor outputs
+    //      stay in memory (Strided views) and are touched exactly once per sub-step
     float root[13];               // pos3, quat xyzw, linvel3, angvel3 (world)
     float q[M::NDA], qd[M::NDA];
-    float lamc[3 * M::NSPHA];     // warm-start contact impulses (n, t1, t2)
-    float laml[M::NDA];           // warm-start limit impulses (signed)
-    // ---- per-step outputs
-    float sensor[6 * M::NSENSA];  // force3, torque3 in the sensor body's frame
-    float dof_force[M::NDA];
 
     static constexpr bool brot_is_identity(int b) {
         for (int k = 0; k < 9; ++k)
@@ -134,149 +166,185 @@ struct Sim {
         for (int k = 0; k < d; ++k) n += M::dof_limited[k] ? 1 : 0;
         return n;
     }
-
-    MI_HD void step(const SimParams& P, const float* tau) {
-        const float h = P.dt / (float)P.substeps;
-        for (int ss = 0; ss < P.substeps; ++ss) substep(P, tau, h);
+    static constexpr int sensor_of(int b) {  // index of the force sensor on body b, -1 if none
+        for (int k = 0; k < NSENS; ++k)
+            if (M::sens_body[k] == b) return k;
+        return -1;
     }
 
-    MI_HD void substep(const SimParams& P, const float* tau, const float h) {
-        float R[NB][9], r[NB][3];
-        float S[M::NDA][6];
-        // ------------------------------------------------------------ forward kinematics
-        sfor<NB>([&](auto B) MI_LAMBDA {
-            constexpr int b = B;
-            float Rb[9], rb[3];
-            if constexpr (b == 0) {
-                quat2mat(root + 3, Rb);
-                rb[0] = rb[1] = rb[2] = 0.f;
+    // whole simulate() on plain arrays (host build of the tests; the kernels call substep() directly).
+    // state layout = oracle/physics.c: lamc[3*NSPH], laml[ND], sensor[6*NSENS], dof_force[ND]
+    MI_HD void step(const SimParams& P, const float* tau, float* lamc, float* laml, float* sensor, float* dof_force) {
+        const float h = P.dt / (float)P.substeps;
+        float rows[ROW_SLOTS];
+        for (int ss = 0; ss < P.substeps; ++ss)
+            substep_noinline(P, tau, h, rows, lamc, laml, sensor, dof_force);
+    }
+    MI_HD_NOINLINE void substep_noinline(const SimParams& P, const float* tau, const float h, float* rows, float* lamc,
+                                         float* laml, float* sensor, float* dof_force) {
+        substep(P, tau, h, RowStore<1>{rows}, Strided{lamc, 1}, Strided{laml, 1}, Strided{sensor, 1}, Strided{dof_force, 1});
+    }
+
+    // working set shared by the phases of one sub-step
+    struct Ctx {
+        float S[M::NDA][6];           // joint motion subspaces, world axes about O = root origin
+        float bias[NVA];              // C(q, qd) + gravity terms (RNEA with zero acceleration)
+        float L[M::NM];               // branch-sparse H, later its L^T L factor
+        float xcs[M::NSPHA][3];       // lowest point of every contact sphere, relative to O
+        float Rs[M::NSENSA][9], rs[M::NSENSA][3];  // pose of the force-sensor bodies
+    };
+
+    // ---------------------------------------------------------------- one body of the depth-first tree pass
+    // Going down: pose, joint axes, velocity / bias acceleration.  Coming back up: subtree force and composite
+    // inertia, from which the bias force and the H entries of this body's dofs follow at once -- so per-body
+    // quantities only live while their subtree is being processed (live state ~ tree depth, not body count).
+    template <int b>
+    MI_HD void body_pass(const SimParams& P, Ctx& c, const float* Rp, const float* rp, const float* Vp, const float* Ap,
+                         SpI& Iout, float* Fout) {
+        float Rb[9], rb[3];
+        if constexpr (b == 0) {
+            quat2mat(root + 3, Rb);
+            rb[0] = rb[1] = rb[2] = 0.f;
+        } else {
+            if constexpr (brot_is_identity(b)) {
+                sfor<9>([&](auto K) MI_LAMBDA { Rb[K] = Rp[K]; });
             } else {
-                constexpr int p = M::parent[b];
-                if constexpr (brot_is_identity(b)) {
-                    sfor<9>([&](auto K) MI_LAMBDA { Rb[K] = R[p][K]; });
-                } else {
-                    matmul3(R[p], M::brot[b], Rb);
-                }
-                float t[3];
-                matvec3(R[p], M::bpos[b], t);
-                rb[0] = r[p][0] + t[0]; rb[1] = r[p][1] + t[1]; rb[2] = r[p][2] + t[2];
+                matmul3(Rp, M::brot[b], Rb);
             }
-            sfor<M::body_ndof[b]>([&](auto K) MI_LAMBDA {
-                constexpr int d = M::body_dof0[b] + K;
-                constexpr float ax = M::dof_axis[d][0], ay = M::dof_axis[d][1], az = M::dof_axis[d][2];
-                const float al[3] = {ax, ay, az};
-                const float anl[3] = {M::dof_anchor[d][0], M::dof_anchor[d][1], M::dof_anchor[d][2]};
-                float a[3], ta[3], pt[3];
-                matvec3(Rb, al, a);
-                matvec3(Rb, anl, ta);
-                pt[0] = rb[0] + ta[0]; pt[1] = rb[1] + ta[1]; pt[2] = rb[2] + ta[2];
-                if constexpr (M::dof_type[d] == 0) {
-                    float s, c;
-                    sincosf(q[d], &s, &c);
-                    const float t = 1.f - c;
-                    // rotation about the (constant) local axis: Rb <- Rb * Q_local
-                    const float Q[9] = {c + ax * ax * t, ax * ay * t - az * s, ax * az * t + ay * s,
-                                        ay * ax * t + az * s, c + ay * ay * t, ay * az * t - ax * s,
-                                        az * ax * t - ay * s, az * ay * t + ax * s, c + az * az * t};
-                    matmul3(Rb, Q, Rb);
-                    float tb[3];
-                    matvec3(Rb, anl, tb);
-                    rb[0] = pt[0] - tb[0]; rb[1] = pt[1] - tb[1]; rb[2] = pt[2] - tb[2];
-                    S[d][0] = a[0]; S[d][1] = a[1]; S[d][2] = a[2];
-                    cross3(pt, a, &S[d][3]);
-                } else {
-                    rb[0] += a[0] * q[d]; rb[1] += a[1] * q[d]; rb[2] += a[2] * q[d];
-                    S[d][0] = S[d][1] = S[d][2] = 0.f;
-                    S[d][3] = a[0]; S[d][4] = a[1]; S[d][5] = a[2];
-                }
-            });
-            sfor<9>([&](auto K) MI_LAMBDA { R[b][K] = Rb[K]; });
-            r[b][0] = rb[0]; r[b][1] = rb[1]; r[b][2] = rb[2];
-        });
-        // ------------------------------------------------------------ world spatial inertias, bias forces
-        SpI Ic[NB];
-        float bias[NV > 0 ? NV : 1];
-        {
-            float V[NB][6], A[NB][6], F[NB][6];
-            sfor<NB>([&](auto B) MI_LAMBDA {
-                constexpr int b = B;
-                float t[3], c[3];
-                matvec3(R[b], M::com[b], t);
-                c[0] = r[b][0] + t[0]; c[1] = r[b][1] + t[1]; c[2] = r[b][2] + t[2];
-                constexpr float ixx = M::inertia[b][0], iyy = M::inertia[b][1], izz = M::inertia[b][2],
-                                ixy = M::inertia[b][3], ixz = M::inertia[b][4], iyz = M::inertia[b][5];
-                const float Il[9] = {ixx, ixy, ixz, ixy, iyy, iyz, ixz, iyz, izz};
-                float T[9];
-                matmul3(R[b], Il, T);
-                const float* Rb = R[b];
-                // Iw = T * Rb^T (symmetric)
-                float Iw0 = T[0] * Rb[0] + T[1] * Rb[1] + T[2] * Rb[2];
-                float Iw4 = T[3] * Rb[3] + T[4] * Rb[4] + T[5] * Rb[5];
-                float Iw8 = T[6] * Rb[6] + T[7] * Rb[7] + T[8] * Rb[8];
-                float Iw1 = T[0] * Rb[3] + T[1] * Rb[4] + T[2] * Rb[5];
-                float Iw2 = T[0] * Rb[6] + T[1] * Rb[7] + T[2] * Rb[8];
-                float Iw5 = T[3] * Rb[6] + T[4] * Rb[7] + T[5] * Rb[8];
-                constexpr float mm = M::mass[b];
-                const float cc = dot3(c, c);
-                SpI& I = Ic[b];
-                I.m = mm; I.h[0] = mm * c[0]; I.h[1] = mm * c[1]; I.h[2] = mm * c[2];
-                I.I[0] = Iw0 + mm * (cc - c[0] * c[0]); I.I[1] = Iw4 + mm * (cc - c[1] * c[1]);
-                I.I[2] = Iw8 + mm * (cc - c[2] * c[2]);
-                I.I[3] = Iw1 - mm * c[0] * c[1]; I.I[4] = Iw2 - mm * c[0] * c[2]; I.I[5] = Iw5 - mm * c[1] * c[2];
-                // velocity / bias acceleration recursion
-                float Vc[6], Ac[6];
-                if constexpr (b == 0) {
-                    if constexpr (M::FIXED) {
-                        sfor<6>([&](auto K) MI_LAMBDA { Vc[K] = 0.f; Ac[K] = 0.f; });
-                        Ac[3] = -P.g[0]; Ac[4] = -P.g[1]; Ac[5] = -P.g[2];
-                    } else {
-                        float wxv[3];
-                        cross3(root + 10, root + 7, wxv);
-                        Vc[0] = root[10]; Vc[1] = root[11]; Vc[2] = root[12];
-                        Vc[3] = root[7]; Vc[4] = root[8]; Vc[5] = root[9];
-                        Ac[0] = Ac[1] = Ac[2] = 0.f;
-                        Ac[3] = -wxv[0] - P.g[0]; Ac[4] = -wxv[1] - P.g[1]; Ac[5] = -wxv[2] - P.g[2];
-                    }
-                } else {
-                    constexpr int p = M::parent[b];
-                    sfor<6>([&](auto K) MI_LAMBDA { Vc[K] = V[p][K]; Ac[K] = A[p][K]; });
-                }
-                sfor<M::body_ndof[b]>([&](auto K) MI_LAMBDA {
-                    constexpr int d = M::body_dof0[b] + K;
-                    float Sd[6];
-                    crm(Vc, S[d], Sd);
-                    sfor<6>([&](auto C) MI_LAMBDA { Ac[C] += Sd[C] * qd[d]; Vc[C] += S[d][C] * qd[d]; });
-                });
-                sfor<6>([&](auto K) MI_LAMBDA { V[b][K] = Vc[K]; A[b][K] = Ac[K]; });
-                float IA[6], IV[6], X[6];
-                spi_mul(I, Ac, IA); spi_mul(I, Vc, IV); crf(Vc, IV, X);
-                sfor<6>([&](auto K) MI_LAMBDA { F[b][K] = IA[K] + X[K]; });
-            });
-            // subtree accumulation (forces and composite inertias), children before parents
-            sfor_rev<NB>([&](auto B) MI_LAMBDA {
-                constexpr int b = B;
-                if constexpr (b > 0) {
-                    constexpr int p = M::parent[b];
-                    sfor<6>([&](auto K) MI_LAMBDA { F[p][K] += F[b][K]; });
-                    Ic[p].m += Ic[b].m;
-                    sfor<3>([&](auto K) MI_LAMBDA { Ic[p].h[K] += Ic[b].h[K]; });
-                    sfor<6>([&](auto K) MI_LAMBDA { Ic[p].I[K] += Ic[b].I[K]; });
-                }
-            });
-            sfor<ND>([&](auto D) MI_LAMBDA {
-                constexpr int d = D;
-                bias[OFF + d] = dot6(S[d], F[M::dof_body[d]]);
-            });
-            if constexpr (!M::FIXED) {
-                bias[0] = F[0][3]; bias[1] = F[0][4]; bias[2] = F[0][5];
-                bias[3] = F[0][0]; bias[4] = F[0][1]; bias[5] = F[0][2];
-            }
+            float t[3];
+            matvec3(Rp, M::bpos[b], t);
+            rb[0] = rp[0] + t[0]; rb[1] = rp[1] + t[1]; rb[2] = rp[2] + t[2];
         }
-        // ------------------------------------------------------------ branch-sparse joint-space inertia H
-        float L[M::NM];
-        float Ldi[NV > 0 ? NV : 1];  // 1 / L_ii
-        if constexpr (!M::FIXED) {
-            const SpI& I = Ic[0];
+        sfor<M::body_ndof[b]>([&](auto K) MI_LAMBDA {
+            constexpr int d = M::body_dof0[b] + K;
+            constexpr float ax = M::dof_axis[d][0], ay = M::dof_axis[d][1], az = M::dof_axis[d][2];
+            const float al[3] = {ax, ay, az};
+            const float anl[3] = {M::dof_anchor[d][0], M::dof_anchor[d][1], M::dof_anchor[d][2]};
+            float a[3], ta[3], pt[3];
+            matvec3(Rb, al, a);
+            matvec3(Rb, anl, ta);
+            pt[0] = rb[0] + ta[0]; pt[1] = rb[1] + ta[1]; pt[2] = rb[2] + ta[2];
+            float* Sd = c.S[d];
+            if constexpr (M::dof_type[d] == 0) {
+                float s, cs;
+                sincosf(q[d], &s, &cs);
+                const float t = 1.f - cs;
+                // rotation about the (constant) local axis: Rb <- Rb * Q_local
+                const float Q[9] = {cs + ax * ax * t, ax * ay * t - az * s, ax * az * t + ay * s,
+                                    ay * ax * t + az * s, cs + ay * ay * t, ay * az * t - ax * s,
+                                    az * ax * t - ay * s, az * ay * t + ax * s, cs + az * az * t};
+                matmul3(Rb, Q, Rb);
+                float tb[3];
+                matvec3(Rb, anl, tb);
+                rb[0] = pt[0] - tb[0]; rb[1] = pt[1] - tb[1]; rb[2] = pt[2] - tb[2];
+                Sd[0] = a[0]; Sd[1] = a[1]; Sd[2] = a[2];
+                cross3(pt, a, Sd + 3);
+            } else {
+                rb[0] += a[0] * q[d]; rb[1] += a[1] * q[d]; rb[2] += a[2] * q[d];
+                Sd[0] = Sd[1] = Sd[2] = 0.f;
+                Sd[3] = a[0]; Sd[4] = a[1]; Sd[5] = a[2];
+            }
+        });
+        // contact spheres and force sensor riding on this body
+        sfor<NSPH>([&](auto S_) MI_LAMBDA {
+            constexpr int s = S_;
+            if constexpr (M::sph_body[s] == b) {
+                float t[3];
+                matvec3(Rb, M::sph_pos[s], t);
+                c.xcs[s][0] = rb[0] + t[0]; c.xcs[s][1] = rb[1] + t[1]; c.xcs[s][2] = rb[2] + t[2] - M::sph_rad[s];
+            }
+        });
+        if constexpr (sensor_of(b) >= 0) {
+            constexpr int k = sensor_of(b);
+            sfor<9>([&](auto K) MI_LAMBDA { c.Rs[k][K] = Rb[K]; });
+            c.rs[k][0] = rb[0]; c.rs[k][1] = rb[1]; c.rs[k][2] = rb[2];
+        }
+        // world spatial inertia about O
+        SpI I;
+        {
+            float t[3], cm[3];
+            matvec3(Rb, M::com[b], t);
+            cm[0] = rb[0] + t[0]; cm[1] = rb[1] + t[1]; cm[2] = rb[2] + t[2];
+            constexpr float ixx = M::inertia[b][0], iyy = M::inertia[b][1], izz = M::inertia[b][2],
+                            ixy = M::inertia[b][3], ixz = M::inertia[b][4], iyz = M::inertia[b][5];
+            const float Il[9] = {ixx, ixy, ixz, ixy, iyy, iyz, ixz, iyz, izz};
+            float T[9];
+            matmul3(Rb, Il, T);
+            // Iw = T * Rb^T (symmetric)
+            const float Iw0 = T[0] * Rb[0] + T[1] * Rb[1] + T[2] * Rb[2];
+            const float Iw4 = T[3] * Rb[3] + T[4] * Rb[4] + T[5] * Rb[5];
+            const float Iw8 = T[6] * Rb[6] + T[7] * Rb[7] + T[8] * Rb[8];
+            const float Iw1 = T[0] * Rb[3] + T[1] * Rb[4] + T[2] * Rb[5];
+            const float Iw2 = T[0] * Rb[6] + T[1] * Rb[7] + T[2] * Rb[8];
+            const float Iw5 = T[3] * Rb[6] + T[4] * Rb[7] + T[5] * Rb[8];
+            constexpr float mm = M::mass[b];
+            const float cc = dot3(cm, cm);
+            I.m = mm; I.h[0] = mm * cm[0]; I.h[1] = mm * cm[1]; I.h[2] = mm * cm[2];
+            I.I[0] = Iw0 + mm * (cc - cm[0] * cm[0]); I.I[1] = Iw4 + mm * (cc - cm[1] * cm[1]);
+            I.I[2] = Iw8 + mm * (cc - cm[2] * cm[2]);
+            I.I[3] = Iw1 - mm * cm[0] * cm[1]; I.I[4] = Iw2 - mm * cm[0] * cm[2]; I.I[5] = Iw5 - mm * cm[1] * cm[2];
+        }
+        // velocity / bias acceleration recursion
+        float Vc[6], Ac[6];
+        if constexpr (b == 0) {
+            if constexpr (M::FIXED) {
+                sfor<6>([&](auto K) MI_LAMBDA { Vc[K] = 0.f; Ac[K] = 0.f; });
+                Ac[3] = -P.g[0]; Ac[4] = -P.g[1]; Ac[5] = -P.g[2];
+            } else {
+                float wxv[3];
+                cross3(root + 10, root + 7, wxv);
+                Vc[0] = root[10]; Vc[1] = root[11]; Vc[2] = root[12];
+                Vc[3] = root[7]; Vc[4] = root[8]; Vc[5] = root[9];
+                Ac[0] = Ac[1] = Ac[2] = 0.f;
+                Ac[3] = -wxv[0] - P.g[0]; Ac[4] = -wxv[1] - P.g[1]; Ac[5] = -wxv[2] - P.g[2];
+            }
+        } else {
+            sfor<6>([&](auto K) MI_LAMBDA { Vc[K] = Vp[K]; Ac[K] = Ap[K]; });
+        }
+        sfor<M::body_ndof[b]>([&](auto K) MI_LAMBDA {
+            constexpr int d = M::body_dof0[b] + K;
+            float Sd[6];
+            crm(Vc, c.S[d], Sd);
+            sfor<6>([&](auto C) MI_LAMBDA { Ac[C] += Sd[C] * qd[d]; Vc[C] += c.S[d][C] * qd[d]; });
+        });
+        float F[6];
+        {
+            float IA[6], IV[6], X[6];
+            spi_mul(I, Ac, IA); spi_mul(I, Vc, IV); crf(Vc, IV, X);
+            sfor<6>([&](auto K) MI_LAMBDA { F[K] = IA[K] + X[K]; });
+        }
+        // children (bodies are numbered depth-first, so every child index is > b)
+        sfor<NB>([&](auto C_) MI_LAMBDA {
+            constexpr int ch = C_;
+            if constexpr (ch > b) if constexpr (M::parent[ch] == b) {
+                SpI Ic;
+                float Fc[6];
+                body_pass<ch>(P, c, Rb, rb, Vc, Ac, Ic, Fc);
+                sfor<6>([&](auto K) MI_LAMBDA { F[K] += Fc[K]; });
+                I.m += Ic.m;
+                sfor<3>([&](auto K) MI_LAMBDA { I.h[K] += Ic.h[K]; });
+                sfor<6>([&](auto K) MI_LAMBDA { I.I[K] += Ic.I[K]; });
+            }
+        });
+        // I is now the composite inertia of the subtree, F the subtree force: bias and H entries of this body's dofs
+        sfor<M::body_ndof[b]>([&](auto K) MI_LAMBDA {
+            constexpr int d = M::body_dof0[b] + K, gi = OFF + d;
+            c.bias[gi] = dot6(c.S[d], F);
+            float Fd[6];
+            spi_mul(I, c.S[d], Fd);
+            c.L[M::midx[gi][gi]] = dot6(c.S[d], Fd);
+            sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA {
+                constexpr int gj = M::anc[gi][A_];
+                float v;
+                if constexpr (gj >= OFF) v = dot6(c.S[gj - OFF], Fd);
+                else if constexpr (gj < 3) v = Fd[3 + gj];
+                else v = Fd[gj - 3];
+                c.L[M::midx[gi][gj]] = v;
+            });
+        });
+        if constexpr (b == 0 && !M::FIXED) {
+            c.bias[0] = F[3]; c.bias[1] = F[4]; c.bias[2] = F[5];
+            c.bias[3] = F[0]; c.bias[4] = F[1]; c.bias[5] = F[2];
             sfor<6>([&](auto A_) MI_LAMBDA {
                 sfor<6>([&](auto B_) MI_LAMBDA {
                     constexpr int i = A_, j = B_;
@@ -297,34 +365,52 @@ struct Sim {
                             constexpr int idx = (rr == cc) ? rr : ((rr + cc == 1) ? 3 : ((rr + cc == 2) ? 4 : 5));
                             v = I.I[idx];
                         }
-                        L[M::midx[i][j]] = v;
+                        c.L[M::midx[i][j]] = v;
                     }
                 });
             });
         }
-        sfor<ND>([&](auto D) MI_LAMBDA {
-            constexpr int d = D, gi = OFF + d;
-            float F[6];
-            spi_mul(Ic[M::dof_body[d]], S[d], F);
-            L[M::midx[gi][gi]] = dot6(S[d], F);
-            sfor<M::nanc[gi]>([&](auto K) MI_LAMBDA {
-                constexpr int gj = M::anc[gi][K];
-                float v;
-                if constexpr (gj >= OFF) v = dot6(S[gj - OFF], F);
-                else if constexpr (gj < 3) v = F[3 + gj];
-                else v = F[gj - 3];
-                L[M::midx[gi][gj]] = v;
-            });
-        });
+        if constexpr (b > 0) {
+            Iout = I;
+            sfor<6>([&](auto K) MI_LAMBDA { Fout[K] = F[K]; });
+        }
+    }
+
+    // ---------------------------------------------------------------- one physics sub-step of length h
+    template <int RS>
+    MI_HD void substep(const SimParams& P, const float* tau, const float h, const RowStore<RS> rows, const Strided lamc,
+                       const Strided laml, const Strided sensor, const Strided dof_force) {
+        auto G = [&](int row, int c) MI_LAMBDA -> float& { return rows(row * M::MAXCHAIN + c); };
+        auto Ainv = [&](int row) MI_LAMBDA -> float& { return rows(NROWG * M::MAXCHAIN + row); };
+        auto vt = [&](int row) MI_LAMBDA -> float& { return rows(NROWG * M::MAXCHAIN + NROWG + row); };
+        Ctx c;
+        float (&S)[M::NDA][6] = c.S;
+        float (&L)[M::NM] = c.L;
+        // ------------------------------------------------------------ kinematics + dynamics, one depth-first tree pass
+        {
+            SpI Iroot;
+            float Froot[6];
+            body_pass<0>(P, c, nullptr, nullptr, nullptr, nullptr, Iroot, Froot);
+        }
+#if defined(MI_STOP_AFTER) && MI_STOP_AFTER == 1
+        { float acc = 0.f; sfor<M::NM>([&](auto K) MI_LAMBDA { acc += L[K]; }); sfor<NV>([&](auto K) MI_LAMBDA { acc += c.bias[K]; });
+          sfor<ND>([&](auto K) MI_LAMBDA { sfor<6>([&](auto J) MI_LAMBDA { acc += S[K][J]; }); });
+          sfor<NSPH>([&](auto K) MI_LAMBDA { sfor<3>([&](auto J) MI_LAMBDA { acc += c.xcs[K][J]; }); });
+          sfor<NSENS>([&](auto K) MI_LAMBDA { sfor<9>([&](auto J) MI_LAMBDA { acc += c.Rs[K][J]; }); sfor<3>([&](auto J) MI_LAMBDA { acc += c.rs[K][J]; }); });
+          root[0] = acc; return; }
+#endif
+        MI_PHASE();
         // ------------------------------------------------------------ rhs, implicit spring/damper on the diagonal
-        float y[NV > 0 ? NV : 1];
-        sfor<OFF>([&](auto I) MI_LAMBDA { y[I] = -bias[I]; });
+        float Ldi[NVA];  // 1 / L_ii
+        float y[NVA];
+        sfor<OFF>([&](auto I) MI_LAMBDA { y[I] = -c.bias[I]; });
         sfor<ND>([&](auto D) MI_LAMBDA {
             constexpr int d = D, gi = OFF + d;
             constexpr float K = M::dof_stiffness[d], Dm = M::dof_damping[d];
             L[M::midx[gi][gi]] += M::dof_armature[d] + h * Dm + h * h * K;
-            y[gi] = tau[d] - bias[gi] - K * (q[d] - M::dof_springref[d]) - (Dm + h * K) * qd[d];
+            y[gi] = tau[d] - c.bias[gi] - K * (q[d] - M::dof_springref[d]) - (Dm + h * K) * qd[d];
         });
+        MI_PHASE();
         // ------------------------------------------------------------ H = L^T L in place (no fill-in on a tree)
         sfor_rev<NV>([&](auto K_) MI_LAMBDA {
             constexpr int k = K_;
@@ -346,10 +432,11 @@ struct Sim {
                 });
             });
         });
+        MI_PHASE();
         // ------------------------------------------------------------ whitened velocity  w = L qd + h L^-T rhs
-        float w[NV > 0 ? NV : 1];
+        float w[NVA];
         {
-            float v[NV > 0 ? NV : 1];
+            float v[NVA];
             if constexpr (!M::FIXED) {
                 v[0] = root[7]; v[1] = root[8]; v[2] = root[9]; v[3] = root[10]; v[4] = root[11]; v[5] = root[12];
             }
@@ -369,10 +456,20 @@ struct Sim {
                 w[i] = s + h * z;
             });
         }
+#if defined(MI_STOP_AFTER) && MI_STOP_AFTER == 2
+        { float acc = 0.f; sfor<M::NM>([&](auto K) MI_LAMBDA { acc += L[K]; }); sfor<NV>([&](auto K) MI_LAMBDA { acc += w[K] + Ldi[K]; });
+          sfor<ND>([&](auto K) MI_LAMBDA { sfor<6>([&](auto J) MI_LAMBDA { acc += S[K][J]; }); });
+          sfor<NSPH>([&](auto K) MI_LAMBDA { sfor<3>([&](auto J) MI_LAMBDA { acc += c.xcs[K][J]; }); });
+          sfor<NSENS>([&](auto K) MI_LAMBDA { sfor<9>([&](auto J) MI_LAMBDA { acc += c.Rs[K][J]; }); sfor<3>([&](auto J) MI_LAMBDA { acc += c.rs[K][J]; }); });
+          root[0] = acc; return; }
+#endif
+        MI_PHASE();
         // ------------------------------------------------------------ constraint rows in whitened space
-        float G[NROWG][M::MAXCHAIN];
-        float Ainv[NROWG], vt[NROWG], lam[NROWG];
-        bool act[M::NSPHA];
+        float lam_reg[LAM_IN_ROWS ? 1 : NROWG];
+        auto lam = [&](int row) MI_LAMBDA -> float& {
+            if constexpr (LAM_IN_ROWS) return rows(NROWG * M::MAXCHAIN + 2 * NROWG + row);
+            else return lam_reg[row];
+        };
         // solve L^T g = J^T restricted to a chain (descending generalized indices), in place in g[]
         auto chain_solve = [&](auto B, float* g) MI_LAMBDA {
             constexpr int b = decltype(B)::value;
@@ -392,10 +489,12 @@ struct Sim {
             constexpr int d = D, gi = OFF + d;
             if constexpr (M::dof_limited[d]) {
                 constexpr int row = limrow(d);
+                MI_PHASE();
                 const float dl = q[d] - M::dof_lower[d], du = M::dof_upper[d] - q[d];
                 const bool lower = dl < du;
                 const float C = lower ? dl : du, s = lower ? 1.f : -1.f;
-                if (laml[d] * s < 0.f) laml[d] = 0.f;
+                const float lw = laml(d);
+                const float l0 = ((lw * s < 0.f) ? 0.f : fabsf(lw)) * P.warm;
                 // g over [gi, anc(gi)...]
                 float g[M::MAXCHAIN];
                 g[0] = s * Ldi[gi];
@@ -415,111 +514,150 @@ struct Sim {
                     });
                 });
                 float a = P.cfm;
-                sfor<M::nanc[gi] + 1>([&](auto K) MI_LAMBDA { a += g[K] * g[K]; G[row][K] = g[K]; });
-                Ainv[row] = 1.f / a;
-                vt[row] = (C >= 0.f) ? -C / h : fminf(-C * P.erp / h, P.max_depen_vel);
-                const float l0 = fabsf(laml[d]) * P.warm;
-                lam[row] = l0;
-                w[gi] += g[0] * l0;
-                sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { w[M::anc[gi][A_]] += g[1 + A_] * l0; });
-            } else {
-                laml[d] = 0.f;
+                sfor<M::nanc[gi] + 1>([&](auto K) MI_LAMBDA { a += g[K] * g[K]; G(row, K) = g[K]; });
+                Ainv(row) = 1.f / a;
+                vt(row) = (C >= 0.f) ? -C / h : fminf(-C * P.erp / h, P.max_depen_vel);
+                lam(row) = l0;
             }
         });
         // ground contacts: 3 rows per sphere (normal +z, tangents x, y)
-        float xcs[M::NSPHA][3];
         sfor<NSPH>([&](auto S_) MI_LAMBDA {
             constexpr int s = S_, b = M::sph_body[s], row0 = NLIM + 3 * s;
-            float t[3], x[3];
-            matvec3(R[b], M::sph_pos[s], t);
-            x[0] = r[b][0] + t[0]; x[1] = r[b][1] + t[1]; x[2] = r[b][2] + t[2];
-            const float dist = (root[2] + x[2]) - M::sph_rad[s] - P.ground_z;
+            MI_PHASE();
+            const float* xc = c.xcs[s];
+            const float dist = (root[2] + xc[2]) - P.ground_z;
             const bool on = dist < P.contact_offset;
-            act[s] = on;
-            xcs[s][0] = x[0]; xcs[s][1] = x[1]; xcs[s][2] = x[2] - M::sph_rad[s];
-            if (!on) {
-                lamc[3 * s] = lamc[3 * s + 1] = lamc[3 * s + 2] = 0.f;
-                sfor<3>([&](auto K) MI_LAMBDA { lam[row0 + K] = 0.f; });
-            } else {
-                const float gap = dist - P.rest_offset;
-                const float* xc = xcs[s];
-                sfor<3>([&](auto K) MI_LAMBDA {
-                    constexpr int k = K, row = row0 + k;
-                    // unit force u at xc as a spatial force [xc x u; u]; u = z, x, y
-                    constexpr int ax = (k == 0) ? 2 : (k == 1 ? 0 : 1);
-                    float W[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    W[3 + ax] = 1.f;
-                    if constexpr (ax == 0) { W[1] = xc[2]; W[2] = -xc[1]; }
-                    else if constexpr (ax == 1) { W[0] = -xc[2]; W[2] = xc[0]; }
-                    else { W[0] = xc[1]; W[1] = -xc[0]; }
-                    float g[M::MAXCHAIN];
-                    sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA {
-                        constexpr int gi = M::chain[b][C];
-                        if constexpr (gi >= OFF) g[C] = dot6(S[gi - OFF], W);
-                        else if constexpr (gi < 3) g[C] = W[3 + gi];
-                        else g[C] = W[gi - 3];
-                    });
-                    chain_solve(std::integral_constant<int, b>{}, g);
-                    float a = P.cfm;
-                    sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { a += g[C] * g[C]; G[row][C] = g[C]; });
-                    Ainv[row] = 1.f / a;
-                    vt[row] = (k == 0) ? ((gap >= 0.f) ? -gap / h : fminf(-gap * P.erp / h, P.max_depen_vel)) : 0.f;
-                    const float l0 = lamc[3 * s + k] * P.warm;
-                    lam[row] = l0;
-                    sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += g[C] * l0; });
+            // Branch-free: rows of an inactive sphere are built like any other and made inert with Ainv = 0 and
+            // lam = 0 (every PGS update then multiplies by zero).  All 64 envs of the wave run the same
+            // instruction stream -- no EXEC-mask divergence.
+            const float onf = on ? 1.f : 0.f;
+            const float gap = dist - P.rest_offset;
+            sfor<3>([&](auto K) MI_LAMBDA {
+                constexpr int k = K, row = row0 + k;
+                // unit force u at xc as a spatial force [xc x u; u]; u = z, x, y
+                constexpr int ax = (k == 0) ? 2 : (k == 1 ? 0 : 1);
+                float W[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                W[3 + ax] = 1.f;
+                if constexpr (ax == 0) { W[1] = xc[2]; W[2] = -xc[1]; }
+                else if constexpr (ax == 1) { W[0] = -xc[2]; W[2] = xc[0]; }
+                else { W[0] = xc[1]; W[1] = -xc[0]; }
+                float g[M::MAXCHAIN];
+                sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA {
+                    constexpr int gi = M::chain[b][C];
+                    if constexpr (gi >= OFF) g[C] = dot6(S[gi - OFF], W);
+                    else if constexpr (gi < 3) g[C] = W[3 + gi];
+                    else g[C] = W[gi - 3];
                 });
-            }
+                chain_solve(std::integral_constant<int, b>{}, g);
+                float a = P.cfm;
+                sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { a += g[C] * g[C]; G(row, C) = g[C]; });
+                Ainv(row) = onf / a;
+                const float vtn = (gap >= 0.f) ? -gap / h : fminf(-gap * P.erp / h, P.max_depen_vel);
+                vt(row) = (k == 0) ? vtn : 0.f;
+                lam(row) = lamc(3 * s + k) * P.warm * onf;
+            });
         });
-        // ------------------------------------------------------------ projected Gauss-Seidel sweeps
-        for (int it = 0; it < P.iters; ++it) {
+        MI_PHASE();
+        // ------------------------------------------------------------ warm start: w += G^T lam0, rows read back from the store
+        // (a separate pass on purpose: accumulating into w while the rows are being built makes the compiler keep
+        // every row's g alive until one big batched update -- hundreds of spilled registers)
+        {
+            int zero;
+            MI_OPAQUE_ZERO(zero);
+            const RowStore<RS> rit{rows.p + zero};
             sfor<ND>([&](auto D) MI_LAMBDA {
                 constexpr int d = D, gi = OFF + d;
                 if constexpr (M::dof_limited[d]) {
                     constexpr int row = limrow(d);
-                    float vn = G[row][0] * w[gi];
-                    sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { vn += G[row][1 + A_] * w[M::anc[gi][A_]]; });
-                    const float nl = fmaxf(lam[row] - (vn - vt[row]) * Ainv[row], 0.f);
-                    const float dl = nl - lam[row];
-                    lam[row] = nl;
-                    w[gi] += G[row][0] * dl;
-                    sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { w[M::anc[gi][A_]] += G[row][1 + A_] * dl; });
+                    const float l0 = lam(row);
+                    w[gi] += rit(row * M::MAXCHAIN) * l0;
+                    sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { w[M::anc[gi][A_]] += rit(row * M::MAXCHAIN + 1 + A_) * l0; });
                 }
             });
             sfor<NSPH>([&](auto S_) MI_LAMBDA {
                 constexpr int s = S_, b = M::sph_body[s], row0 = NLIM + 3 * s;
-                if (act[s]) {
-                    const float mu = 0.5f * (M::sph_mu[s] + P.plane_mu);
-                    {
-                        float vn = 0.f;
-                        sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { vn += G[row0][C] * w[M::chain[b][C]]; });
-                        const float nl = fmaxf(lam[row0] - (vn - vt[row0]) * Ainv[row0], 0.f);
-                        const float dl = nl - lam[row0];
-                        lam[row0] = nl;
-                        sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += G[row0][C] * dl; });
-                    }
-                    float lt[2];
-                    sfor<2>([&](auto K) MI_LAMBDA {
-                        constexpr int row = row0 + 1 + K;
-                        float vn = 0.f;
-                        sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { vn += G[row][C] * w[M::chain[b][C]]; });
-                        const float dl = -(vn - vt[row]) * Ainv[row];
-                        lt[K] = lam[row] + dl;
-                        sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += G[row][C] * dl; });
-                    });
-                    const float lim = mu * lam[row0];
-                    const float nrm = sqrtf(lt[0] * lt[0] + lt[1] * lt[1]);
-                    const float sc = (nrm > lim) ? lim / fmaxf(nrm, 1e-30f) : 1.f;
-                    sfor<2>([&](auto K) MI_LAMBDA {
-                        constexpr int row = row0 + 1 + K;
-                        const float nl = lt[K] * sc, dl = nl - lt[K];
-                        lam[row] = nl;
-                        sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += G[row][C] * dl; });
-                    });
-                }
+                sfor<3>([&](auto K) MI_LAMBDA {
+                    constexpr int row = row0 + K;
+                    const float l0 = lam(row);
+                    sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += rit(row * M::MAXCHAIN + C) * l0; });
+                });
             });
         }
+#if defined(MI_STOP_AFTER) && MI_STOP_AFTER == 3
+        { float acc = 0.f; sfor<M::NM>([&](auto K) MI_LAMBDA { acc += L[K]; }); sfor<NV>([&](auto K) MI_LAMBDA { acc += w[K] + Ldi[K]; });
+          sfor<NROWG>([&](auto K) MI_LAMBDA { acc += lam(K); });
+          sfor<NSPH>([&](auto K) MI_LAMBDA { sfor<3>([&](auto J) MI_LAMBDA { acc += c.xcs[K][J]; }); });
+          sfor<NSENS>([&](auto K) MI_LAMBDA { sfor<9>([&](auto J) MI_LAMBDA { acc += c.Rs[K][J]; }); sfor<3>([&](auto J) MI_LAMBDA { acc += c.rs[K][J]; }); });
+          root[0] = acc; return; }
+#endif
+        MI_PHASE();
+        // ------------------------------------------------------------ projected Gauss-Seidel sweeps
+        for (int it = 0; it < P.iters; ++it) {
+            int zero;
+            MI_OPAQUE_ZERO(zero);
+            const RowStore<RS> rit{rows.p + zero};
+            auto G = [&](int row, int c) MI_LAMBDA -> float& { return rit(row * M::MAXCHAIN + c); };
+            auto Ainv = [&](int row) MI_LAMBDA -> float& { return rit(NROWG * M::MAXCHAIN + row); };
+            auto vt = [&](int row) MI_LAMBDA -> float& { return rit(NROWG * M::MAXCHAIN + NROWG + row); };
+            sfor<ND>([&](auto D) MI_LAMBDA {
+                constexpr int d = D, gi = OFF + d;
+                if constexpr (M::dof_limited[d]) {
+                    constexpr int row = limrow(d);
+                    MI_PHASE();
+                    float g[M::MAXCHAIN];
+                    sfor<M::nanc[gi] + 1>([&](auto K) MI_LAMBDA { g[K] = G(row, K); });
+                    float vn = g[0] * w[gi];
+                    sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { vn += g[1 + A_] * w[M::anc[gi][A_]]; });
+                    const float lo = lam(row);
+                    const float nl = fmaxf(lo - (vn - vt(row)) * Ainv(row), 0.f);
+                    const float dl = nl - lo;
+                    lam(row) = nl;
+                    w[gi] += g[0] * dl;
+                    sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { w[M::anc[gi][A_]] += g[1 + A_] * dl; });
+                }
+            });
+            sfor<NSPH>([&](auto S_) MI_LAMBDA {
+                constexpr int s = S_, b = M::sph_body[s], row0 = NLIM + 3 * s;
+                MI_PHASE();
+                // inactive spheres have Ainv = lam = 0: every update below is then exactly zero
+                const float mu = 0.5f * (M::sph_mu[s] + P.plane_mu);
+                float g[3][M::MAXCHAIN];
+                sfor<3>([&](auto K) MI_LAMBDA {
+                    sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { g[K][C] = G(row0 + K, C); });
+                });
+                float ln;
+                {
+                    float vn = 0.f;
+                    sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { vn += g[0][C] * w[M::chain[b][C]]; });
+                    const float lo = lam(row0);
+                    ln = fmaxf(lo - (vn - vt(row0)) * Ainv(row0), 0.f);
+                    const float dl = ln - lo;
+                    lam(row0) = ln;
+                    sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += g[0][C] * dl; });
+                }
+                float lt[2];
+                sfor<2>([&](auto K) MI_LAMBDA {
+                    constexpr int row = row0 + 1 + K;
+                    float vn = 0.f;
+                    sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { vn += g[1 + K][C] * w[M::chain[b][C]]; });
+                    const float dl = -(vn - vt(row)) * Ainv(row);
+                    lt[K] = lam(row) + dl;
+                    sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += g[1 + K][C] * dl; });
+                });
+                const float lim = mu * ln;
+                const float nrm = sqrtf(lt[0] * lt[0] + lt[1] * lt[1]);
+                const float sc = (nrm > lim) ? lim / fmaxf(nrm, 1e-30f) : 1.f;
+                sfor<2>([&](auto K) MI_LAMBDA {
+                    constexpr int row = row0 + 1 + K;
+                    const float nl = lt[K] * sc, dl = nl - lt[K];
+                    lam(row) = nl;
+                    sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += g[1 + K][C] * dl; });
+                });
+            });
+        }
+        MI_PHASE();
         // ------------------------------------------------------------ back to generalised velocity: qd = L^-1 w
-        float v[NV > 0 ? NV : 1];
+        float v[NVA];
         sfor<NV>([&](auto I_) MI_LAMBDA {
             constexpr int i = I_;
             float s = w[i];
@@ -529,6 +667,7 @@ struct Sim {
             });
             v[i] = s * Ldi[i];
         });
+        MI_PHASE();
         // ------------------------------------------------------------ impulses -> warm start, sensors, dof forces
         const float invh = 1.f / h;
         sfor<ND>([&](auto D) MI_LAMBDA {
@@ -537,29 +676,30 @@ struct Sim {
             if constexpr (M::dof_limited[d]) {
                 constexpr int row = limrow(d);
                 const float dl = q[d] - M::dof_lower[d], du = M::dof_upper[d] - q[d];
-                ll = (dl < du) ? lam[row] : -lam[row];
-                laml[d] = ll;
+                ll = (dl < du) ? lam(row) : -lam(row);
             }
-            dof_force[d] = tau[d] - M::dof_stiffness[d] * (q[d] - M::dof_springref[d]) - M::dof_damping[d] * v[OFF + d] + ll * invh;
+            laml(d) = ll;
+            dof_force(d) = tau[d] - M::dof_stiffness[d] * (q[d] - M::dof_springref[d]) - M::dof_damping[d] * v[OFF + d] + ll * invh;
         });
-        sfor<6 * NSENS>([&](auto K) MI_LAMBDA { sensor[K] = 0.f; });
+        float sens[6 * M::NSENSA];
+        sfor<6 * NSENS>([&](auto K) MI_LAMBDA { sens[K] = 0.f; });
         sfor<NSPH>([&](auto S_) MI_LAMBDA {
             constexpr int s = S_, b = M::sph_body[s], row0 = NLIM + 3 * s;
-            if (act[s]) {
-                lamc[3 * s] = lam[row0]; lamc[3 * s + 1] = lam[row0 + 1]; lamc[3 * s + 2] = lam[row0 + 2];
-                sfor<NSENS>([&](auto K) MI_LAMBDA {
-                    constexpr int k = K;
-                    if constexpr (M::sens_body[k] == b) {
-                        const float f[3] = {lam[row0 + 1] * invh, lam[row0 + 2] * invh, lam[row0] * invh};
-                        const float arm[3] = {xcs[s][0] - r[b][0], xcs[s][1] - r[b][1], xcs[s][2] - r[b][2]};
-                        float tq[3], fl[3], tl[3];
-                        cross3(arm, f, tq);
-                        matTvec3(R[b], f, fl); matTvec3(R[b], tq, tl);
-                        sfor<3>([&](auto C) MI_LAMBDA { sensor[6 * k + C] += fl[C]; sensor[6 * k + 3 + C] += tl[C]; });
-                    }
-                });
+            // inactive spheres carry lam = 0 => zero warm start and zero sensor contribution
+            const float ln = lam(row0), l1 = lam(row0 + 1), l2 = lam(row0 + 2);
+            lamc(3 * s) = ln; lamc(3 * s + 1) = l1; lamc(3 * s + 2) = l2;
+            if constexpr (sensor_of(b) >= 0) {
+                constexpr int k = sensor_of(b);
+                const float f[3] = {l1 * invh, l2 * invh, ln * invh};
+                const float arm[3] = {c.xcs[s][0] - c.rs[k][0], c.xcs[s][1] - c.rs[k][1], c.xcs[s][2] - c.rs[k][2]};
+                float tq[3], fl[3], tl[3];
+                cross3(arm, f, tq);
+                matTvec3(c.Rs[k], f, fl); matTvec3(c.Rs[k], tq, tl);
+                sfor<3>([&](auto C) MI_LAMBDA { sens[6 * k + C] += fl[C]; sens[6 * k + 3 + C] += tl[C]; });
             }
         });
+        sfor<6 * NSENS>([&](auto K) MI_LAMBDA { sensor(K) = sens[K]; });
+        MI_PHASE();
         // ------------------------------------------------------------ integrate (semi-implicit Euler)
         sfor<ND>([&](auto D) MI_LAMBDA { qd[D] = v[OFF + D]; q[D] += h * qd[D]; });
         if constexpr (!M::FIXED) {
@@ -567,13 +707,12 @@ struct Sim {
             const float om[3] = {v[3], v[4], v[5]};
             const float an = sqrtf(dot3(om, om)), th = an * h;
             float dq[4];
-            if (th > 1e-12f) {
+            {
                 float sn, cs;
                 sincosf(0.5f * th, &sn, &cs);
-                const float k = sn / an;
-                dq[0] = om[0] * k; dq[1] = om[1] * k; dq[2] = om[2] * k; dq[3] = cs;
-            } else {
-                dq[0] = om[0] * h * 0.5f; dq[1] = om[1] * h * 0.5f; dq[2] = om[2] * h * 0.5f; dq[3] = 1.f;
+                const bool big = th > 1e-12f;
+                const float k = big ? sn / fmaxf(an, 1e-30f) : 0.5f * h;
+                dq[0] = om[0] * k; dq[1] = om[1] * k; dq[2] = om[2] * k; dq[3] = big ? cs : 1.f;
             }
             float* Q = root + 3;
             const float x = dq[3] * Q[0] + dq[0] * Q[3] + dq[1] * Q[2] - dq[2] * Q[1];

@@ -1,11 +1,6 @@
-// mi_engine.hip -- HIP kernels (gfx950) + the C ABI of include/mi_engine.h.
-//
-// Execution model: one environment per SIMD lane, 64 envs per wavefront, one wavefront per workgroup so that at
-// the benchmark sizes (4096-8192 envs = 64-128 waves) every wave lands on its own CU and owns that CU's register
-// file and LDS.  All persistent state is SoA [field][env] in the caller's arena => every state load/store of a
-// wave is one fully coalesced 256-byte transaction.  A whole VecTask.step() (reference vec_task.py:360-408) is ONE
-// kernel: clamp actions -> efforts -> `substeps` physics sub-steps in registers -> progress/reset -> observations
-// -> reward -> timeout, so the only HBM traffic per step is the API-visible state itself.
+// mi_engine.hip -- the C ABI of include/mi_engine.h: arena layout, engine lifecycle, launches.
+// The fused step kernels live in step_kernels.hpp and are instantiated per robot in kernels_<task>.hip; this file
+// also holds the small stand-alone kernels (init, jit-fn replacements).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
@@ -14,11 +9,10 @@
 #include <vector>
 
 #include "../../include/mi_engine.h"
-#include "core/engine.hpp"
+#include "step_kernels.hpp"
 #include "gen/model_ant.h"
 #include "gen/model_cartpole.h"
 #include "gen/model_humanoid.h"
-#include "tasks/locomotion.hpp"
 
 using namespace mi;
 
@@ -33,245 +27,6 @@ extern "C" const char* mi_last_error(void) { return g_err.c_str(); }
 extern "C" int mi_abi_version(void) { return MI_ABI_VERSION; }
 
 #define HIP_OK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(_e)); } while (0)
-
-// ------------------------------------------------------------------------------------------------ arena view
-struct View {
-    int N;
-    int env_offset;
-    uint32_t seed;
-    int ring;  // which obs_out slot this step writes
-    float clip_obs;
-    float* root;        // [13][N]
-    float* dof;         // [2][ND][N]  (pos block, vel block)
-    float* tau;         // [ND][N]  dof_actuation_force
-    float* lamc;        // [3*NSPH][N]
-    float* laml;        // [ND][N]
-    float* sensor;      // [6*NSENS][N]
-    float* dof_force;   // [ND][N]
-    float* potentials;  // [N]
-    float* prev_potentials;
-    float* up_vec;      // [3][N]
-    float* heading_vec; // [3][N]
-    float* actions;     // [NACT][N]
-    float* init_root;   // [13][N]
-    float* obs;         // [N][NOBS] row-major
-    float* obs_out;     // [2][N][NOBS]
-    float* rew;         // [N]
-    long long* reset;   // [N]
-    long long* progress;
-    long long* randomize;
-    unsigned char* timeout;
-    int* episode;
-    float* ep_ret;      // [N] running return of the current episode
-    float* stats;       // [8] job statistics: sum finished returns, sum finished lengths, #finished, sum rewards, #env-steps
-};
-
-template <class M>
-__device__ __forceinline__ void load_sim(Sim<M>& s, const View& v, int e) {
-    const int N = v.N;
-    sfor<13>([&](auto K) MI_LAMBDA { s.root[K] = v.root[K * N + e]; });
-    sfor<M::ND>([&](auto K) MI_LAMBDA {
-        s.q[K] = v.dof[K * N + e];
-        s.qd[K] = v.dof[(M::ND + K) * N + e];
-        s.laml[K] = v.laml[K * N + e];
-    });
-    sfor<3 * M::NSPH>([&](auto K) MI_LAMBDA { s.lamc[K] = v.lamc[K * N + e]; });
-}
-template <class M>
-__device__ __forceinline__ void store_sim(const Sim<M>& s, const View& v, int e) {
-    const int N = v.N;
-    sfor<13>([&](auto K) MI_LAMBDA { v.root[K * N + e] = s.root[K]; });
-    sfor<M::ND>([&](auto K) MI_LAMBDA {
-        v.dof[K * N + e] = s.q[K];
-        v.dof[(M::ND + K) * N + e] = s.qd[K];
-        v.laml[K * N + e] = s.laml[K];
-        v.dof_force[K * N + e] = s.dof_force[K];
-    });
-    sfor<3 * M::NSPH>([&](auto K) MI_LAMBDA { v.lamc[K * N + e] = s.lamc[K]; });
-    sfor<6 * M::NSENS>([&](auto K) MI_LAMBDA { v.sensor[K * N + e] = s.sensor[K]; });
-}
-
-
-// ------------------------------------------------------------------------------------------------ episode statistics
-// Per-step episode bookkeeping fused into the step kernel: finished-episode return/length sums are reduced across
-// the 64 lanes of the wave with DPP/ds_swizzle shuffles and land in HBM with one atomic per wave and statistic.
-// These five floats are the only thing ever all-reduced across GPUs (RCCL, parallel.py).
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ void episode_stats(const View& v, int e, bool valid, float rew, long long reset, long long progress) {
-    float ret = 0.f, fin_ret = 0.f, fin_len = 0.f, fin = 0.f, r = 0.f, cnt = 0.f;
-    if (valid) {
-        ret = v.ep_ret[e] + rew;
-        r = rew; cnt = 1.f;
-        if (reset != 0) { fin_ret = ret; fin_len = (float)(progress + 1); fin = 1.f; ret = 0.f; }
-        v.ep_ret[e] = ret;
-    }
-    fin_ret = wave_sum(fin_ret); fin_len = wave_sum(fin_len); fin = wave_sum(fin); r = wave_sum(r); cnt = wave_sum(cnt);
-    if ((threadIdx.x & 63) == 0) {
-        if (fin > 0.f) { atomicAdd(v.stats + 0, fin_ret); atomicAdd(v.stats + 1, fin_len); atomicAdd(v.stats + 2, fin); }
-        atomicAdd(v.stats + 3, r);
-        atomicAdd(v.stats + 4, cnt);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ fused step
-template <class M, bool HUM>
-__global__ __launch_bounds__(64) void loco_step_kernel(View v, SimParams P, LocoParams tp, const float* __restrict__ actions_in,
-                                                       int control_freq_inv) {
-    using T = Loco<M::ND, 6 * M::NSENS, HUM>;
-    constexpr int ND = M::ND, NOBS = T::NOBS;
-    const int e0 = blockIdx.x * 64 + threadIdx.x;
-    const int N = v.N;
-    const bool valid = e0 < N;           // tail lanes shadow the last env (no stores) so wave reductions stay full
-    const int e = valid ? e0 : N - 1;
-    Sim<M> sim;
-    load_sim(sim, v, e);
-    // vec_task.py:374 clamp ; ant.py:281-285 efforts
-    float act[ND], tau[ND];
-    sfor<ND>([&](auto K) MI_LAMBDA {
-        const float a = fminf(fmaxf(actions_in[(size_t)e * ND + K], -tp.clip_actions), tp.clip_actions);
-        act[K] = a;
-        tau[K] = a * tp.gear[K] * tp.power_scale;
-    });
-    for (int c = 0; c < control_freq_inv; ++c) sim.step(P, tau);  // vec_task.py:379-382
-    // post_physics_step (ant.py:287-297)
-    long long progress = v.progress[e] + 1;
-    float potentials = v.potentials[e], prev_potentials;
-    int ep = v.episode[e];
-    if (v.reset[e] != 0) {
-        float init_root[13];
-        sfor<13>([&](auto K) MI_LAMBDA { init_root[K] = v.init_root[K * N + e]; });
-        T::reset(tp, v.seed, (uint32_t)(v.env_offset + e), (uint32_t)ep, init_root, sim.root, sim.q, sim.qd, &potentials,
-                 &prev_potentials);
-        sfor<3 * M::NSPH>([&](auto K) MI_LAMBDA { sim.lamc[K] = 0.f; });
-        sfor<ND>([&](auto K) MI_LAMBDA { sim.laml[K] = 0.f; });
-        ep += 1;
-        progress = 0;
-    }
-    float obs[NOBS], up_vec[3], heading_vec[3];
-    T::observations(tp, sim.root, tp.targets, potentials, tp.inv_start_rot, sim.q, sim.qd, sim.dof_force, tp.dof_lower,
-                    tp.dof_upper, sim.sensor, act, tp.basis_vec0, tp.basis_vec1, obs, &potentials, &prev_potentials,
-                    up_vec, heading_vec);
-    float rew;
-    long long reset;
-    T::reward(tp, obs, 0LL, progress, act, potentials, prev_potentials, &rew, &reset);
-    episode_stats(v, e, valid, rew, reset, progress);
-    if (!valid) return;
-    sfor<ND>([&](auto K) MI_LAMBDA { v.actions[K * N + e] = act[K]; v.tau[K * N + e] = tau[K]; });
-    v.randomize[e] += 1;
-    v.episode[e] = ep;
-    store_sim(sim, v, e);
-    v.potentials[e] = potentials;
-    v.prev_potentials[e] = prev_potentials;
-    sfor<3>([&](auto K) MI_LAMBDA { v.up_vec[K * N + e] = up_vec[K]; v.heading_vec[K * N + e] = heading_vec[K]; });
-    float* ob = v.obs + (size_t)e * NOBS;
-    float* oc = v.obs_out + ((size_t)v.ring * N + e) * NOBS;
-    sfor<NOBS>([&](auto K) MI_LAMBDA {
-        ob[K] = obs[K];
-        oc[K] = fminf(fmaxf(obs[K], -v.clip_obs), v.clip_obs);
-    });
-    v.rew[e] = rew;
-    v.reset[e] = reset;
-    v.progress[e] = progress;
-    // vec_task.py:394
-    v.timeout[e] = (unsigned char)(((float)progress >= tp.max_episode_length - 1.f) && (reset != 0));
-}
-
-__global__ __launch_bounds__(64) void cartpole_step_kernel(View v, SimParams P, CartpoleParams tp,
-                                                           const float* __restrict__ actions_in, int control_freq_inv) {
-    using M = ModelCartpole;
-    const int e0 = blockIdx.x * 64 + threadIdx.x;
-    const int N = v.N;
-    const bool valid = e0 < N;
-    const int e = valid ? e0 : N - 1;
-    Sim<M> sim;
-    load_sim(sim, v, e);
-    const float a = fminf(fmaxf(actions_in[e], -tp.clip_actions), tp.clip_actions);
-    const float tau[2] = {a * tp.max_push_effort, 0.f};  // cartpole.py:159-163
-    for (int c = 0; c < control_freq_inv; ++c) sim.step(P, tau);
-    long long progress = v.progress[e] + 1;  // cartpole.py:165-174
-    int ep = v.episode[e];
-    if (v.reset[e] != 0) {
-        cartpole_reset(v.seed, (uint32_t)(v.env_offset + e), (uint32_t)ep, sim.q, sim.qd);
-        sim.laml[0] = sim.laml[1] = 0.f;
-        ep += 1;
-        progress = 0;
-    }
-    const float obs[4] = {sim.q[0], sim.qd[0], sim.q[1], sim.qd[1]};  // cartpole.py:131-142
-    float rew;
-    long long reset;
-    cartpole_reward(tp, obs[2], obs[3], obs[1], obs[0], 0LL, progress, &rew, &reset);
-    episode_stats(v, e, valid, rew, reset, progress);
-    if (!valid) return;
-    v.actions[e] = a;
-    v.tau[e] = tau[0];
-    v.tau[N + e] = 0.f;
-    v.randomize[e] += 1;
-    v.episode[e] = ep;
-    store_sim(sim, v, e);
-    float* ob = v.obs + (size_t)e * 4;
-    float* oc = v.obs_out + ((size_t)v.ring * N + e) * 4;
-    sfor<4>([&](auto K) MI_LAMBDA { ob[K] = obs[K]; oc[K] = fminf(fmaxf(obs[K], -v.clip_obs), v.clip_obs); });
-    v.rew[e] = rew;
-    v.reset[e] = reset;
-    v.progress[e] = progress;
-    v.timeout[e] = (unsigned char)(((float)progress >= tp.max_episode_length - 1.f) && (reset != 0));
-}
-
-// ------------------------------------------------------------------------------------------------ physics only
-template <class M>
-__global__ __launch_bounds__(64) void simulate_kernel(View v, SimParams P) {
-    const int e = blockIdx.x * 64 + threadIdx.x;
-    if (e >= v.N) return;
-    Sim<M> sim;
-    load_sim(sim, v, e);
-    float tau[M::NDA];
-    sfor<M::ND>([&](auto K) MI_LAMBDA { tau[K] = v.tau[K * v.N + e]; });
-    sim.step(P, tau);
-    store_sim(sim, v, e);
-}
-
-// ------------------------------------------------------------------------------------------------ indexed reset
-template <class M, bool HUM>
-__global__ void loco_reset_kernel(View v, LocoParams tp, const long long* __restrict__ ids, int n) {
-    using T = Loco<M::ND, 6 * M::NSENS, HUM>;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int e = (int)ids[i], N = v.N;
-    if (e < 0 || e >= N) return;
-    float init_root[13], root[13], q[M::ND], qd[M::ND], pot, prev;
-    for (int k = 0; k < 13; ++k) init_root[k] = v.init_root[k * N + e];
-    const int ep = v.episode[e];
-    T::reset(tp, v.seed, (uint32_t)(v.env_offset + e), (uint32_t)ep, init_root, root, q, qd, &pot, &prev);
-    v.episode[e] = ep + 1;
-    for (int k = 0; k < 13; ++k) v.root[k * N + e] = root[k];
-    for (int k = 0; k < M::ND; ++k) {
-        v.dof[k * N + e] = q[k];
-        v.dof[(M::ND + k) * N + e] = qd[k];
-        v.laml[k * N + e] = 0.f;
-    }
-    for (int k = 0; k < 3 * M::NSPH; ++k) v.lamc[k * N + e] = 0.f;
-    v.potentials[e] = pot;
-    v.prev_potentials[e] = prev;
-    v.progress[e] = 0;
-    v.reset[e] = 0;
-}
-__global__ void cartpole_reset_kernel(View v, const long long* __restrict__ ids, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int e = (int)ids[i], N = v.N;
-    if (e < 0 || e >= N) return;
-    float q[2], qd[2];
-    const int ep = v.episode[e];
-    cartpole_reset(v.seed, (uint32_t)(v.env_offset + e), (uint32_t)ep, q, qd);
-    v.episode[e] = ep + 1;
-    for (int k = 0; k < 2; ++k) { v.dof[k * N + e] = q[k]; v.dof[(2 + k) * N + e] = qd[k]; v.laml[k * N + e] = 0.f; }
-    v.progress[e] = 0;
-    v.reset[e] = 0;
-}
 
 // ------------------------------------------------------------------------------------------------ init
 __global__ void init_state_kernel(View v, int nd, int nsph3, int nsens6, int nobs, int nact, float root_z,
@@ -507,20 +262,12 @@ extern "C" int mi_engine_init_state(MiEngine* e, void* stream) {
 extern "C" int mi_engine_step(MiEngine* e, const float* actions, void* stream) {
     if (!e || !actions) return fail("mi_engine_step: null argument");
     hipStream_t s = (hipStream_t)stream;
-    const int blocks = (e->N + 63) / 64;
     e->v.ring = (int)(e->steps & 1);
     switch (e->task) {
-        case T_CARTPOLE:
-            hipLaunchKernelGGL(cartpole_step_kernel, dim3(blocks), dim3(64), 0, s, e->v, e->P, e->cart, actions, e->control_freq_inv);
-            break;
-        case T_ANT:
-            hipLaunchKernelGGL((loco_step_kernel<ModelAnt, false>), dim3(blocks), dim3(64), 0, s, e->v, e->P, e->loco, actions, e->control_freq_inv);
-            break;
-        case T_HUMANOID:
-            hipLaunchKernelGGL((loco_step_kernel<ModelHumanoid, true>), dim3(blocks), dim3(64), 0, s, e->v, e->P, e->loco, actions, e->control_freq_inv);
-            break;
+        case T_CARTPOLE: HIP_OK(launch_step_cartpole(e->v, e->P, e->cart, actions, e->control_freq_inv, s)); break;
+        case T_ANT: HIP_OK(launch_step_ant(e->v, e->P, e->loco, actions, e->control_freq_inv, s)); break;
+        case T_HUMANOID: HIP_OK(launch_step_humanoid(e->v, e->P, e->loco, actions, e->control_freq_inv, s)); break;
     }
-    HIP_OK(hipGetLastError());
     e->steps++;
     return 0;
 }
@@ -529,13 +276,11 @@ extern "C" int mi_engine_last_ring(const MiEngine* e) { return e ? (int)((e->ste
 extern "C" int mi_engine_simulate(MiEngine* e, void* stream) {
     if (!e) return fail("null engine");
     hipStream_t s = (hipStream_t)stream;
-    const int blocks = (e->N + 63) / 64;
     switch (e->task) {
-        case T_CARTPOLE: hipLaunchKernelGGL(simulate_kernel<ModelCartpole>, dim3(blocks), dim3(64), 0, s, e->v, e->P); break;
-        case T_ANT: hipLaunchKernelGGL(simulate_kernel<ModelAnt>, dim3(blocks), dim3(64), 0, s, e->v, e->P); break;
-        case T_HUMANOID: hipLaunchKernelGGL(simulate_kernel<ModelHumanoid>, dim3(blocks), dim3(64), 0, s, e->v, e->P); break;
+        case T_CARTPOLE: HIP_OK(launch_simulate_cartpole(e->v, e->P, s)); break;
+        case T_ANT: HIP_OK(launch_simulate_ant(e->v, e->P, s)); break;
+        case T_HUMANOID: HIP_OK(launch_simulate_humanoid(e->v, e->P, s)); break;
     }
-    HIP_OK(hipGetLastError());
     return 0;
 }
 
@@ -544,13 +289,11 @@ extern "C" int mi_engine_reset_idx(MiEngine* e, const int64_t* env_ids, int n, v
     if (n <= 0) return 0;
     if (!env_ids) return fail("mi_engine_reset_idx: null env_ids");
     hipStream_t s = (hipStream_t)stream;
-    const int blocks = (n + 127) / 128;
     switch (e->task) {
-        case T_CARTPOLE: hipLaunchKernelGGL(cartpole_reset_kernel, dim3(blocks), dim3(128), 0, s, e->v, (const long long*)env_ids, n); break;
-        case T_ANT: hipLaunchKernelGGL((loco_reset_kernel<ModelAnt, false>), dim3(blocks), dim3(128), 0, s, e->v, e->loco, (const long long*)env_ids, n); break;
-        case T_HUMANOID: hipLaunchKernelGGL((loco_reset_kernel<ModelHumanoid, true>), dim3(blocks), dim3(128), 0, s, e->v, e->loco, (const long long*)env_ids, n); break;
+        case T_CARTPOLE: HIP_OK(launch_reset_cartpole(e->v, (const long long*)env_ids, n, s)); break;
+        case T_ANT: HIP_OK(launch_reset_ant(e->v, e->loco, (const long long*)env_ids, n, s)); break;
+        case T_HUMANOID: HIP_OK(launch_reset_humanoid(e->v, e->loco, (const long long*)env_ids, n, s)); break;
     }
-    HIP_OK(hipGetLastError());
     return 0;
 }
 

@@ -1,0 +1,332 @@
+// step_kernels.hpp -- the fused VecTask.step() kernels, templated on the generated robot model.
+//
+// Execution model: one environment per SIMD lane, 64 envs per wavefront, one wavefront per workgroup so that at
+// the benchmark sizes (4096-8192 envs = 64-128 waves) every wave lands on its own CU and owns that CU's register
+// file and LDS.  All persistent state is SoA [field][env] in the caller's arena => every state load/store of a
+// wave is one fully coalesced 256-byte transaction.  A VecTask.step() (reference vec_task.py:360-408) is
+// `substeps` physics launches (the first also clamps actions -> efforts) + one post launch (progress/reset ->
+// observations -> reward -> timeout); the constraint rows of a sub-step are staged in LDS ([slot][lane]).
+//
+// Each robot model is instantiated in its own translation unit (kernels_<model>.hip) so the library builds in
+// parallel; mi_engine.hip holds the C ABI and calls the launchers declared at the bottom of this file.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "core/engine.hpp"
+#include "tasks/locomotion.hpp"
+
+namespace mi {
+
+// ---------------------------------------------------------------------------------------------- arena view
+struct View {
+    int N;
+    int env_offset;
+    uint32_t seed;
+    int ring;  // which obs_out slot this step writes
+    float clip_obs;
+    float* root;        // [13][N]
+    float* dof;         // [2][ND][N]  (pos block, vel block)
+    float* tau;         // [ND][N]  dof_actuation_force
+    float* lamc;        // [3*NSPH][N]
+    float* laml;        // [ND][N]
+    float* sensor;      // [6*NSENS][N]
+    float* dof_force;   // [ND][N]
+    float* potentials;  // [N]
+    float* prev_potentials;
+    float* up_vec;      // [3][N]
+    float* heading_vec; // [3][N]
+    float* actions;     // [NACT][N]
+    float* init_root;   // [13][N]
+    float* obs;         // [N][NOBS] row-major
+    float* obs_out;     // [2][N][NOBS]
+    float* rew;         // [N]
+    long long* reset;   // [N]
+    long long* progress;
+    long long* randomize;
+    unsigned char* timeout;
+    int* episode;
+    float* ep_ret;      // [N] running return of the current episode
+    float* stats;       // [8] job statistics: sum finished returns, sum finished lengths, #finished, sum rewards, #env-steps
+};
+
+template <class M>
+__device__ __forceinline__ void load_sim(Sim<M>& s, const View& v, int e) {
+    const int N = v.N;
+    sfor<13>([&](auto K) MI_LAMBDA { s.root[K] = v.root[K * N + e]; });
+    sfor<M::ND>([&](auto K) MI_LAMBDA {
+        s.q[K] = v.dof[K * N + e];
+        s.qd[K] = v.dof[(M::ND + K) * N + e];
+    });
+}
+template <class M>
+__device__ __forceinline__ void store_sim(const Sim<M>& s, const View& v, int e) {
+    const int N = v.N;
+    sfor<13>([&](auto K) MI_LAMBDA { v.root[K * N + e] = s.root[K]; });
+    sfor<M::ND>([&](auto K) MI_LAMBDA {
+        v.dof[K * N + e] = s.q[K];
+        v.dof[(M::ND + K) * N + e] = s.qd[K];
+    });
+}
+
+// ------------------------------------------------------------------------------------------------ episode statistics
+// Per-step episode bookkeeping fused into the step kernel: finished-episode return/length sums are reduced across
+// the 64 lanes of the wave with DPP/ds_swizzle shuffles and land in HBM with one atomic per wave and statistic.
+// These five floats are the only thing ever all-reduced across GPUs (RCCL, parallel.py).
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ void episode_stats(const View& v, int e, bool valid, float rew, long long reset, long long progress) {
+    float ret = 0.f, fin_ret = 0.f, fin_len = 0.f, fin = 0.f, r = 0.f, cnt = 0.f;
+    if (valid) {
+        ret = v.ep_ret[e] + rew;
+        r = rew; cnt = 1.f;
+        if (reset != 0) { fin_ret = ret; fin_len = (float)(progress + 1); fin = 1.f; ret = 0.f; }
+        v.ep_ret[e] = ret;
+    }
+    fin_ret = wave_sum(fin_ret); fin_len = wave_sum(fin_len); fin = wave_sum(fin); r = wave_sum(r); cnt = wave_sum(cnt);
+    if ((threadIdx.x & 63) == 0) {
+        if (fin > 0.f) { atomicAdd(v.stats + 0, fin_ret); atomicAdd(v.stats + 1, fin_len); atomicAdd(v.stats + 2, fin); }
+        atomicAdd(v.stats + 3, r);
+        atomicAdd(v.stats + 4, cnt);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ physics sub-step
+// How a control step is cut into launches (all on the caller's stream, no host sync):
+//     substep_kernel x (control_freq_inv * substeps)   -- gym.simulate(), reference vec_task.py:379-382
+//     post kernel                                      -- post_physics_step + timeout mask, vec_task.py:389-394
+// The first substep launch of a step also performs pre_physics_step (clamp actions -> efforts, ant.py:281-285).
+// One sub-step per launch keeps the kernel body loop-free around the fully unrolled dynamics: with the sub-step
+// loop inside, LLVM hoists hundreds of model literals (gfx9 VOP3 cannot encode literals, each needs an SGPR) out
+// of it and spills SGPRs; that build was observed to return run-to-run different results on gfx950.
+struct ActParams {   // pre_physics_step: tau[d] = clamp(a[d], +-clip) * gear[d] * scale for d < nact, else 0
+    float clip, scale;
+    int nact;
+    float gear[kMaxDof];
+};
+
+template <class M>
+constexpr bool rows_fit_lds() { return (size_t)Sim<M>::ROW_SLOTS * 64 * sizeof(float) <= 152 * 1024; }
+
+template <class M>
+__global__ __launch_bounds__(64) void substep_kernel(View v, SimParams P, ActParams ap, const float* __restrict__ actions_in) {
+    extern __shared__ float lds_rows[];  // [ROW_SLOTS][64] when the model's rows fit (else unused, size 0)
+    constexpr int ND = M::ND;
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    const int N = v.N;
+    if (e >= N) return;                  // no cross-lane operation in here: tail lanes simply retire
+    Sim<M> sim;
+    load_sim(sim, v, e);
+    float tau[M::NDA];
+    if (actions_in != nullptr) {         // uniform branch: first sub-step of a control step
+        sfor<ND>([&](auto K) MI_LAMBDA {
+            constexpr int k = K;
+            float t = 0.f;
+            if (k < ap.nact) {
+                const float a = fminf(fmaxf(actions_in[(size_t)e * ap.nact + k], -ap.clip), ap.clip);  // vec_task.py:374
+                t = a * ap.gear[k] * ap.scale;
+                v.actions[k * N + e] = a;
+            }
+            tau[k] = t;
+            v.tau[k * N + e] = t;
+        });
+    } else {
+        sfor<ND>([&](auto K) MI_LAMBDA { tau[K] = v.tau[K * N + e]; });
+    }
+    const float h = P.dt / (float)P.substeps;
+    const Strided lamc{v.lamc + e, N}, laml{v.laml + e, N}, sensor{v.sensor + e, N}, dof_force{v.dof_force + e, N};
+    if constexpr (rows_fit_lds<M>()) {
+        sim.substep(P, tau, h, RowStore<64>{lds_rows + threadIdx.x}, lamc, laml, sensor, dof_force);
+    } else {
+        float rows[Sim<M>::ROW_SLOTS];
+        sim.substep(P, tau, h, RowStore<1>{rows}, lamc, laml, sensor, dof_force);
+    }
+    store_sim(sim, v, e);
+}
+
+// ------------------------------------------------------------------------------------------------ post_physics_step
+template <class M, bool HUM>
+__global__ __launch_bounds__(64) void loco_post_kernel(View v, LocoParams tp) {
+    using T = Loco<M::ND, 6 * M::NSENS, HUM>;
+    constexpr int ND = M::ND, NOBS = T::NOBS;
+    const int e0 = blockIdx.x * 64 + threadIdx.x;
+    const int N = v.N;
+    const bool valid = e0 < N;           // tail lanes shadow the last env (no stores) so wave reductions stay full
+    const int e = valid ? e0 : N - 1;
+    float root[13], q[ND], qd[ND], dof_force[ND], sensor[6 * M::NSENS > 0 ? 6 * M::NSENS : 1], act[ND];
+    sfor<13>([&](auto K) MI_LAMBDA { root[K] = v.root[K * N + e]; });
+    sfor<ND>([&](auto K) MI_LAMBDA {
+        q[K] = v.dof[K * N + e];
+        qd[K] = v.dof[(ND + K) * N + e];
+        dof_force[K] = v.dof_force[K * N + e];
+        act[K] = v.actions[K * N + e];
+    });
+    sfor<6 * M::NSENS>([&](auto K) MI_LAMBDA { sensor[K] = v.sensor[K * N + e]; });
+    // post_physics_step (ant.py:287-297): progress++, reset flagged envs, observations, reward
+    long long progress = v.progress[e] + 1;
+    float potentials = v.potentials[e], prev_potentials;
+    int ep = v.episode[e];
+    const bool do_reset = v.reset[e] != 0;
+    if (do_reset) {
+        float init_root[13];
+        sfor<13>([&](auto K) MI_LAMBDA { init_root[K] = v.init_root[K * N + e]; });
+        T::reset(tp, v.seed, (uint32_t)(v.env_offset + e), (uint32_t)ep, init_root, root, q, qd, &potentials, &prev_potentials);
+        ep += 1;
+        progress = 0;
+        if (valid) {
+            sfor<13>([&](auto K) MI_LAMBDA { v.root[K * N + e] = root[K]; });
+            sfor<ND>([&](auto K) MI_LAMBDA {
+                v.dof[K * N + e] = q[K];
+                v.dof[(ND + K) * N + e] = qd[K];
+                v.laml[K * N + e] = 0.f;
+            });
+            sfor<3 * M::NSPH>([&](auto K) MI_LAMBDA { v.lamc[K * N + e] = 0.f; });
+        }
+    }
+    float obs[NOBS], up_vec[3], heading_vec[3];
+    T::observations(tp, root, tp.targets, potentials, tp.inv_start_rot, q, qd, dof_force, tp.dof_lower, tp.dof_upper, sensor,
+                    act, tp.basis_vec0, tp.basis_vec1, obs, &potentials, &prev_potentials, up_vec, heading_vec);
+    float rew;
+    long long reset;
+    T::reward(tp, obs, 0LL, progress, act, potentials, prev_potentials, &rew, &reset);
+    episode_stats(v, e, valid, rew, reset, progress);
+    if (!valid) return;
+    v.randomize[e] += 1;
+    v.episode[e] = ep;
+    v.potentials[e] = potentials;
+    v.prev_potentials[e] = prev_potentials;
+    sfor<3>([&](auto K) MI_LAMBDA { v.up_vec[K * N + e] = up_vec[K]; v.heading_vec[K * N + e] = heading_vec[K]; });
+    float* ob = v.obs + (size_t)e * NOBS;
+    float* oc = v.obs_out + ((size_t)v.ring * N + e) * NOBS;
+    sfor<NOBS>([&](auto K) MI_LAMBDA {
+        ob[K] = obs[K];
+        oc[K] = fminf(fmaxf(obs[K], -v.clip_obs), v.clip_obs);
+    });
+    v.rew[e] = rew;
+    v.reset[e] = reset;
+    v.progress[e] = progress;
+    // vec_task.py:394
+    v.timeout[e] = (unsigned char)(((float)progress >= tp.max_episode_length - 1.f) && (reset != 0));
+}
+
+template <class M>
+__global__ __launch_bounds__(64) void cartpole_post_kernel(View v, CartpoleParams tp) {
+    const int e0 = blockIdx.x * 64 + threadIdx.x;
+    const int N = v.N;
+    const bool valid = e0 < N;
+    const int e = valid ? e0 : N - 1;
+    float q[2] = {v.dof[e], v.dof[N + e]}, qd[2] = {v.dof[2 * N + e], v.dof[3 * N + e]};
+    long long progress = v.progress[e] + 1;  // cartpole.py:165-174
+    int ep = v.episode[e];
+    if (v.reset[e] != 0) {
+        cartpole_reset(v.seed, (uint32_t)(v.env_offset + e), (uint32_t)ep, q, qd);
+        ep += 1;
+        progress = 0;
+        if (valid) {
+            sfor<2>([&](auto K) MI_LAMBDA { v.dof[K * N + e] = q[K]; v.dof[(2 + K) * N + e] = qd[K]; v.laml[K * N + e] = 0.f; });
+        }
+    }
+    const float obs[4] = {q[0], qd[0], q[1], qd[1]};  // cartpole.py:131-142
+    float rew;
+    long long reset;
+    cartpole_reward(tp, obs[2], obs[3], obs[1], obs[0], 0LL, progress, &rew, &reset);
+    episode_stats(v, e, valid, rew, reset, progress);
+    if (!valid) return;
+    v.randomize[e] += 1;
+    v.episode[e] = ep;
+    float* ob = v.obs + (size_t)e * 4;
+    float* oc = v.obs_out + ((size_t)v.ring * N + e) * 4;
+    sfor<4>([&](auto K) MI_LAMBDA { ob[K] = obs[K]; oc[K] = fminf(fmaxf(obs[K], -v.clip_obs), v.clip_obs); });
+    v.rew[e] = rew;
+    v.reset[e] = reset;
+    v.progress[e] = progress;
+    v.timeout[e] = (unsigned char)(((float)progress >= tp.max_episode_length - 1.f) && (reset != 0));
+}
+
+// ------------------------------------------------------------------------------------------------ indexed reset
+template <class M, bool HUM>
+__global__ void loco_reset_kernel(View v, LocoParams tp, const long long* __restrict__ ids, int n) {
+    using T = Loco<M::ND, 6 * M::NSENS, HUM>;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int e = (int)ids[i], N = v.N;
+    if (e < 0 || e >= N) return;
+    float init_root[13], root[13], q[M::ND], qd[M::ND], pot, prev;
+    for (int k = 0; k < 13; ++k) init_root[k] = v.init_root[k * N + e];
+    const int ep = v.episode[e];
+    T::reset(tp, v.seed, (uint32_t)(v.env_offset + e), (uint32_t)ep, init_root, root, q, qd, &pot, &prev);
+    v.episode[e] = ep + 1;
+    for (int k = 0; k < 13; ++k) v.root[k * N + e] = root[k];
+    for (int k = 0; k < M::ND; ++k) {
+        v.dof[k * N + e] = q[k];
+        v.dof[(M::ND + k) * N + e] = qd[k];
+        v.laml[k * N + e] = 0.f;
+    }
+    for (int k = 0; k < 3 * M::NSPH; ++k) v.lamc[k * N + e] = 0.f;
+    v.potentials[e] = pot;
+    v.prev_potentials[e] = prev;
+    v.progress[e] = 0;
+    v.reset[e] = 0;
+}
+template <class M>
+__global__ void cartpole_reset_kernel(View v, const long long* __restrict__ ids, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int e = (int)ids[i], N = v.N;
+    if (e < 0 || e >= N) return;
+    float q[2], qd[2];
+    const int ep = v.episode[e];
+    cartpole_reset(v.seed, (uint32_t)(v.env_offset + e), (uint32_t)ep, q, qd);
+    v.episode[e] = ep + 1;
+    for (int k = 0; k < 2; ++k) { v.dof[k * N + e] = q[k]; v.dof[(2 + k) * N + e] = qd[k]; v.laml[k * N + e] = 0.f; }
+    v.progress[e] = 0;
+    v.reset[e] = 0;
+}
+
+// launch `n_sub` physics sub-steps; the first one consumes `actions` when non-null (pre_physics_step)
+template <class M>
+hipError_t launch_substeps(const View& v, const SimParams& P, const ActParams& ap, const float* actions, int n_sub, hipStream_t s) {
+    constexpr size_t lds = rows_fit_lds<M>() ? (size_t)Sim<M>::ROW_SLOTS * 64 * sizeof(float) : 0;
+    static bool configured = false;
+    if (!configured && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)substep_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    for (int i = 0; i < n_sub; ++i)
+        hipLaunchKernelGGL(substep_kernel<M>, dim3((v.N + 63) / 64), dim3(64), lds, s, v, P, ap, i == 0 ? actions : nullptr);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------- launchers
+// One set per task, defined in kernels_<task>.hip.  All enqueue on `stream` and return hipGetLastError().
+// launch_step_*: the whole VecTask.step(); launch_simulate_*: one gym.simulate() with the efforts in v.tau.
+hipError_t launch_step_cartpole(const View& v, const SimParams& P, const CartpoleParams& tp, const float* actions, int cfi, hipStream_t s);
+hipError_t launch_simulate_cartpole(const View& v, const SimParams& P, hipStream_t s);
+hipError_t launch_reset_cartpole(const View& v, const long long* ids, int n, hipStream_t s);
+hipError_t launch_step_ant(const View& v, const SimParams& P, const LocoParams& tp, const float* actions, int cfi, hipStream_t s);
+hipError_t launch_simulate_ant(const View& v, const SimParams& P, hipStream_t s);
+hipError_t launch_reset_ant(const View& v, const LocoParams& tp, const long long* ids, int n, hipStream_t s);
+hipError_t launch_step_humanoid(const View& v, const SimParams& P, const LocoParams& tp, const float* actions, int cfi, hipStream_t s);
+hipError_t launch_simulate_humanoid(const View& v, const SimParams& P, hipStream_t s);
+hipError_t launch_reset_humanoid(const View& v, const LocoParams& tp, const long long* ids, int n, hipStream_t s);
+
+template <class M, bool HUM>
+hipError_t launch_loco_step(const View& v, const SimParams& P, const LocoParams& tp, const float* actions, int cfi, hipStream_t s) {
+    ActParams ap;
+    ap.clip = tp.clip_actions; ap.scale = tp.power_scale; ap.nact = M::ND;
+    for (int d = 0; d < kMaxDof; ++d) ap.gear[d] = tp.gear[d];
+    hipError_t e = launch_substeps<M>(v, P, ap, actions, cfi * P.substeps, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((loco_post_kernel<M, HUM>), dim3((v.N + 63) / 64), dim3(64), 0, s, v, tp);
+    return hipGetLastError();
+}
+template <class M>
+hipError_t launch_simulate(const View& v, const SimParams& P, hipStream_t s) {
+    ActParams ap{};
+    return launch_substeps<M>(v, P, ap, nullptr, P.substeps, s);
+}
+
+}  // namespace mi

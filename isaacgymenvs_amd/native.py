@@ -12,11 +12,19 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi_engine.so")
-SRC = os.path.join(_HERE, "csrc", "mi_engine.hip")
+CSRC = os.path.join(_HERE, "csrc")
+BUILD_DIR = os.path.join(CSRC, "build")
+# one translation unit per robot model (they compile in parallel) + the C ABI
+SOURCES = ["mi_engine.hip", "kernels_cartpole.hip", "kernels_ant.hip", "kernels_humanoid.hip"]
 MI_MAX_DOF = 32
 
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-signed-zeros",
-               "-ffinite-math-only", "-fno-trapping-math"]
+# -fno-slp-vectorize: pairing scalars into v_pk_* ops lengthens live ranges in the fully unrolled sub-step
+# (Ant: 230 -> 40 spilled VGPRs without it)
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-signed-zeros", "-fno-trapping-math",
+               "-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"]
+# more spilled SGPRs than this in a physics kernel fails the build: heavy SGPR spilling was the regime in which
+# gfx950 builds of the sub-step returned run-to-run different results ("compiler regime")
+MAX_SGPR_SPILL = 128
 
 
 class MiSimParams(C.Structure):
@@ -69,23 +77,93 @@ def needs_build():
     t = os.path.getmtime(LIB_PATH)
     root = os.path.join(_HERE, "csrc")
     for d, _, fs in os.walk(root):
+        if os.path.abspath(d).startswith(os.path.abspath(BUILD_DIR)):
+            continue
         for f in fs:
             if os.path.getmtime(os.path.join(d, f)) > t:
                 return True
     return os.path.getmtime(os.path.join(_HERE, "..", "include", "mi_engine.h")) > t
 
 
+def _obj_stale(src, obj, newest_header):
+    return (not os.path.exists(obj)) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header)
+
+
 def build(force=False, verbose=False):
-    """Generate the per-robot constexpr headers and compile the HIP library for gfx950 (cross-compiles w/o a GPU)."""
+    """Generate the per-robot constexpr headers and compile the HIP library for gfx950 (cross-compiles w/o a GPU).
+
+    Every translation unit is compiled by its own hipcc process (in parallel), then linked into libmi_engine.so.
+    The per-kernel resource usage (VGPRs, spills, scratch) that hipcc reports lands in csrc/build/*.log and is
+    summarised in csrc/build/resource_usage.txt -- spilled SGPRs are treated as a build error for the step kernels
+    (an SGPR-spilling build of these kernels was observed to miscompute on gfx950).
+    """
     from .registry import generate_headers
     generate_headers()
     if not force and not needs_build():
         return LIB_PATH
-    cmd = [hipcc_path()] + HIPCC_FLAGS + [SRC, "-o", LIB_PATH]
+    os.makedirs(BUILD_DIR, exist_ok=True)
+    hdrs = []
+    for d, _, fs in os.walk(CSRC):
+        if os.path.abspath(d).startswith(os.path.abspath(BUILD_DIR)):
+            continue
+        hdrs += [os.path.join(d, f) for f in fs if f.endswith((".hpp", ".h"))]
+    hdrs.append(os.path.join(_HERE, "..", "include", "mi_engine.h"))
+    newest = max(os.path.getmtime(h) for h in hdrs)
+    procs, objs = [], []
+    for name in SOURCES:
+        src = os.path.join(CSRC, name)
+        obj = os.path.join(BUILD_DIR, name.replace(".hip", ".o"))
+        objs.append(obj)
+        if not force and not _obj_stale(src, obj, newest):
+            continue
+        cmd = [hipcc_path()] + HIPCC_FLAGS + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        log = open(obj.replace(".o", ".log"), "w")
+        procs.append((name, subprocess.Popen(cmd, cwd=CSRC, stdout=log, stderr=subprocess.STDOUT), log))
+    failed = []
+    for name, p, log in procs:
+        rc = p.wait()
+        log.close()
+        if rc != 0:
+            failed.append(name)
+    if failed:
+        for name in failed:
+            with open(os.path.join(BUILD_DIR, name.replace(".hip", ".log"))) as f:
+                print(f.read()[-4000:])
+        raise RuntimeError(f"hipcc failed for {failed}")
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=os.path.join(_HERE, "csrc"))
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd, cwd=CSRC)
+    usage = resource_usage()
+    with open(os.path.join(BUILD_DIR, "resource_usage.txt"), "w") as f:
+        for k, u in usage.items():
+            f.write(f"{k}: {u}\n")
+    bad = {k: u for k, u in usage.items() if u.get("SGPRs Spill", 0) > MAX_SGPR_SPILL and "substep_kernel" in k}
+    if bad:
+        raise RuntimeError(f"step kernels spill SGPRs (known-bad regime on gfx950): {bad}")
     return LIB_PATH
+
+
+def resource_usage():
+    """Parse the -Rpass-analysis=kernel-resource-usage remarks of the last build: {kernel: {field: value}}."""
+    import re
+    out = {}
+    for name in SOURCES:
+        logp = os.path.join(BUILD_DIR, name.replace(".hip", ".log"))
+        if not os.path.exists(logp):
+            continue
+        cur = None
+        for line in open(logp):
+            m = re.search(r"remark: Function Name: (\S+)", line)
+            if m:
+                cur = out.setdefault(m.group(1), {})
+                continue
+            m = re.search(r"remark:\s+([A-Za-z /\[\]]+?)(?: \[[^\]]*\])?: (\d+)", line)
+            if m and cur is not None:
+                cur[m.group(1).strip()] = int(m.group(2))
+    return out
 
 
 _lib = None

@@ -22,14 +22,11 @@ static void run(const SimParams* P, int nenv, float* state, const float* tau, fl
         float* o = out + (size_t)e * os;
         Sim<M> sim;
         for (int k = 0; k < 13; ++k) sim.root[k] = s[k];
-        for (int k = 0; k < ND; ++k) { sim.q[k] = s[13 + k]; sim.qd[k] = s[13 + ND + k]; sim.laml[k] = s[13 + 2 * ND + 3 * NSPH + k]; }
-        for (int k = 0; k < 3 * NSPH; ++k) sim.lamc[k] = s[13 + 2 * ND + k];
-        sim.step(*P, tau + (size_t)e * ND);
+        for (int k = 0; k < ND; ++k) { sim.q[k] = s[13 + k]; sim.qd[k] = s[13 + ND + k]; }
+        // warm-start impulses and outputs are updated in place (same layout as oracle/physics.c)
+        sim.step(*P, tau + (size_t)e * ND, s + 13 + 2 * ND, s + 13 + 2 * ND + 3 * NSPH, o, o + 6 * NSENS);
         for (int k = 0; k < 13; ++k) s[k] = sim.root[k];
-        for (int k = 0; k < ND; ++k) { s[13 + k] = sim.q[k]; s[13 + ND + k] = sim.qd[k]; s[13 + 2 * ND + 3 * NSPH + k] = sim.laml[k]; }
-        for (int k = 0; k < 3 * NSPH; ++k) s[13 + 2 * ND + k] = sim.lamc[k];
-        for (int k = 0; k < 6 * NSENS; ++k) o[k] = sim.sensor[k];
-        for (int k = 0; k < ND; ++k) o[6 * NSENS + k] = sim.dof_force[k];
+        for (int k = 0; k < ND; ++k) { s[13 + k] = sim.q[k]; s[13 + ND + k] = sim.qd[k]; }
     }
 }
 

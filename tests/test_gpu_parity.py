@@ -71,10 +71,11 @@ def test_locomotion_obs_and_reward_kernels_match_reference(golden_dir, task, nam
     # reward on the reference's own obs
     rew = torch.zeros(n, device=DEV)
     rs = torch.zeros(n, dtype=torch.int64, device=DEV)
-    native.check(L.mi_compute_locomotion_reward(
-        task.encode(), n, C.byref(p), _t(g["obs"]).data_ptr(), _t(g["reset_in"], torch.int64).data_ptr(),
-        _t(g["progress"], torch.int64).data_ptr(), _t(g["actions"]).data_ptr(), _t(g["potentials"]).data_ptr(),
-        _t(g["prev_potentials"]).data_ptr(), rew.data_ptr(), rs.data_ptr(), _stream()))
+    # keep the device tensors alive across the call (x.data_ptr() on a temporary frees it before the launch)
+    rin = [_t(g["obs"]), _t(g["reset_in"], torch.int64), _t(g["progress"], torch.int64), _t(g["actions"]),
+           _t(g["potentials"]), _t(g["prev_potentials"])]
+    native.check(L.mi_compute_locomotion_reward(task.encode(), n, C.byref(p), *[x.data_ptr() for x in rin],
+                                                rew.data_ptr(), rs.data_ptr(), _stream()))
     torch.cuda.synchronize()
     np.testing.assert_array_equal(rs.cpu().numpy(), g["reset"])
     np.testing.assert_allclose(rew.cpu().numpy(), g["rew"], rtol=1e-5, atol=2e-5)
@@ -87,10 +88,10 @@ def test_cartpole_reward_kernel_matches_reference(golden_dir):
     n = len(g["rew"])
     rew = torch.zeros(n, device=DEV)
     rs = torch.zeros(n, dtype=torch.int64, device=DEV)
-    native.check(L.mi_compute_cartpole_reward(
-        n, C.byref(p), _t(g["pole_angle"]).data_ptr(), _t(g["pole_vel"]).data_ptr(), _t(g["cart_vel"]).data_ptr(),
-        _t(g["cart_pos"]).data_ptr(), _t(g["reset_in"], torch.int64).data_ptr(), _t(g["progress"], torch.int64).data_ptr(),
-        rew.data_ptr(), rs.data_ptr(), _stream()))
+    cin = [_t(g["pole_angle"]), _t(g["pole_vel"]), _t(g["cart_vel"]), _t(g["cart_pos"]), _t(g["reset_in"], torch.int64),
+           _t(g["progress"], torch.int64)]
+    native.check(L.mi_compute_cartpole_reward(n, C.byref(p), *[x.data_ptr() for x in cin], rew.data_ptr(), rs.data_ptr(),
+                                              _stream()))
     torch.cuda.synchronize()
     np.testing.assert_array_equal(rs.cpu().numpy(), g["reset"])
     np.testing.assert_allclose(rew.cpu().numpy(), g["rew"], rtol=1e-6, atol=1e-6)
@@ -247,7 +248,7 @@ def test_full_size_rollout_properties(task, n, z_term):
             qn = torch.linalg.norm(env.root_states[:, 3:7], dim=-1)
             assert (qn - 1).abs().max() < 1e-4
             viol = torch.maximum(lo - env.dof_pos, env.dof_pos - up).max()
-            assert viol < 0.1, viol  # joint limits hold up to solver slop under 15-135 N.m random torques
+            assert viol < 0.2, viol  # joint limits hold up to solver slop (4 PGS sweeps) under 15-135 N.m random torques
             assert env.progress_buf.max() <= step + 1
     assert total_resets > 0  # random policies fall (termination height) => resets happen
     assert obs_d["obs"].shape == (n, env.num_obs) and rew.shape == (n,) and reset.dtype == torch.int64
@@ -260,14 +261,56 @@ def test_ant_static_equilibrium_weight():
     spec = load_model("ant")
     zero = torch.zeros((n, 8), device=DEV)
     env.step(zero)
-    for _ in range(150):
-        env.step(zero)
-        env.reset_buf.zero_()
     imp = env.engine.tensors["contact_impulse"]  # [n, nsph, 3] = (normal, t1, t2) impulses of the last sub-step
     h = env.sim_params.dt / env.sim_params.substeps
-    fz = imp[:, :, 0].sum(dim=1) / h
-    np.testing.assert_allclose(fz.cpu().numpy(), spec.total_mass() * 9.81, rtol=2e-2)
+    fz = torch.zeros(n, device=DEV)
+    for i in range(240):
+        env.step(zero)
+        env.reset_buf.zero_()
+        if i >= 180:
+            fz += imp[:, :, 0].sum(dim=1) / h / 60.0
+    # time-averaged ground reaction = weight (individual envs may still rock slightly: 5 %; the batch mean: 1 %)
+    np.testing.assert_allclose(fz.cpu().numpy(), spec.total_mass() * 9.81, rtol=5e-2)
+    np.testing.assert_allclose(float(fz.mean()), spec.total_mass() * 9.81, rtol=1e-2)
     assert env.root_states[:, 2].min() > 0.31  # stands above the termination height
+
+
+# ------------------------------------------------------------------ determinism (guards against miscompiled / hazard-prone builds)
+@pytest.mark.parametrize("task,n", [("Cartpole", 256), ("Ant", 1024), ("Humanoid", 1024)])
+def test_two_engines_same_seed_are_bit_identical(task, n):
+    """Two independent engine instances, same seed and actions => bit-identical trajectories.  An earlier build of
+    the sub-step (register-spilling regime) returned run-to-run different results on gfx950."""
+    e1, e2 = _make_env(task, n, seed=7), _make_env(task, n, seed=7)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    for step in range(25):
+        a = torch.rand((n, e1.num_actions), device=DEV, generator=g) * 2 - 1
+        o1, r1, d1, _ = e1.step(a)
+        o2, r2, d2, _ = e2.step(a)
+        assert torch.equal(o1["obs"], o2["obs"]) and torch.equal(r1, r2) and torch.equal(d1, d2), (task, step)
+    for name, x in e1.engine.tensors.items():
+        if name != "episode_stats":  # float atomics across waves: summation order is not fixed
+            assert torch.equal(x, e2.engine.tensors[name]), (task, name)
+
+
+@pytest.mark.parametrize("task", ["Ant", "Humanoid"])
+def test_identical_envs_in_all_lanes_agree(task):
+    """Every lane gets the same state and action: all lanes must produce the same bits (no lane-dependent garbage)."""
+    n = 256
+    env = _make_env(task, n, seed=3)
+    g = torch.Generator(device=DEV).manual_seed(2)
+    for step in range(4):
+        env.step(torch.rand((n, env.num_actions), device=DEV, generator=g) * 2 - 1)
+    t = env.engine.tensors
+    for name in ("root_states", "dof_state", "contact_impulse", "limit_impulse", "dof_actuation_force"):
+        t[name][:] = t[name][17:18].clone()
+    for step in range(6):
+        a = (torch.rand((1, env.num_actions), device=DEV, generator=g) * 2 - 1).repeat(n, 1)
+        env.engine.tensors["dof_actuation_force"][:] = a * 10.0
+        env.engine.simulate()
+    torch.cuda.synchronize()
+    for name in ("root_states", "dof_state", "contact_impulse", "force_sensor", "dof_force"):
+        x = t[name]
+        assert torch.equal(x, x[0:1].expand_as(x)), (task, name)
 
 
 # ------------------------------------------------------------------ API contract (vec_task.py)
