@@ -18,6 +18,12 @@
 #include <cmath>
 #include <utility>
 
+#if defined(MI_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+// tools/debug only: s_memtime stamps at the phase boundaries of a sub-step (never defined in the product build)
+#define MI_STAMP(i) do { if (tstamp) tstamp[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MI_STAMP(i) do { } while (0)
+#endif
 #if defined(__HIPCC__)
 #define MI_HD __host__ __device__ __forceinline__
 #define MI_HD_NOINLINE __host__ __device__ __attribute__((noinline))
@@ -65,7 +71,31 @@ template <int STRIDE>
 struct RowStore {
     float* p;
     MI_HD float& operator()(int slot) const { return p[slot * STRIDE]; }
+    MI_HD RowStore shifted(int off) const { return RowStore{p + off}; }
 };
+// LDS flavour: slot k of this lane sits at byte k*256 + lane*4.  DS instructions only encode a 16-bit byte offset,
+// so one base register per 64 KB segment is kept (3 VGPRs for up to 192 KB); with the segment picked at compile
+// time every access is `ds_read/ds_write base_seg offset:imm`, and neighbouring slots pair into ds_read2st64_b32
+// (whose offset unit is exactly our 256-byte slot stride).
+template <>
+struct RowStore<64> {
+    float* seg[3];
+    MI_HD explicit RowStore(float* p) : seg{p, p + 256 * 64, p + 512 * 64} {}
+    MI_HD float& operator()(int slot) const { return seg[slot >> 8][(slot & 255) * 64]; }
+    MI_HD RowStore shifted(int off) const { return RowStore(seg[0] + off); }
+};
+
+// reciprocal / reciprocal square root / square root: the 1-ulp hardware ops on the device (v_rcp_f32, v_rsq_f32,
+// v_sqrt_f32) instead of the 10-15 instruction IEEE sequences -- these sit on the per-row critical path of the solver
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MI_RCP(x) __builtin_amdgcn_rcpf(x)
+#define MI_RSQ(x) __builtin_amdgcn_rsqf(x)
+#define MI_SQRT(x) __builtin_amdgcn_sqrtf(x)
+#else
+#define MI_RCP(x) (1.f / (x))
+#define MI_RSQ(x) (1.f / sqrtf(x))
+#define MI_SQRT(x) sqrtf(x)
+#endif
 
 struct SimParams {
     float dt;
@@ -155,6 +185,9 @@ struct Sim {
     //      stay in memory (Strided views) and are touched exactly once per sub-step
     float root[13];               // pos3, quat xyzw, linvel3, angvel3 (world)
     float q[M::NDA], qd[M::NDA];
+#if defined(MI_TIMING)
+    unsigned long long* tstamp = nullptr;
+#endif
 
     static constexpr bool brot_is_identity(int b) {
         for (int k = 0; k < 9; ++k)
@@ -165,6 +198,13 @@ struct Sim {
         int n = 0;
         for (int k = 0; k < d; ++k) n += M::dof_limited[k] ? 1 : 0;
         return n;
+    }
+    static constexpr int limdof(int r) {  // inverse of limrow: dof of the r-th limit row
+        int n = 0;
+        for (int d = 0; d < ND; ++d) {
+            if (M::dof_limited[d]) { if (n == r) return d; ++n; }
+        }
+        return 0;
     }
     static constexpr int sensor_of(int b) {  // index of the force sensor on body b, -1 if none
         for (int k = 0; k < NSENS; ++k)
@@ -383,9 +423,23 @@ struct Sim {
         auto G = [&](int row, int c) MI_LAMBDA -> float& { return rows(row * M::MAXCHAIN + c); };
         auto Ainv = [&](int row) MI_LAMBDA -> float& { return rows(NROWG * M::MAXCHAIN + row); };
         auto vt = [&](int row) MI_LAMBDA -> float& { return rows(NROWG * M::MAXCHAIN + NROWG + row); };
+        const float invh = MI_RCP(h);
         Ctx c;
         float (&S)[M::NDA][6] = c.S;
         float (&L)[M::NM] = c.L;
+        MI_STAMP(0);
+        // ------------------------------------------------------------ stage last sub-step's impulses (warm start) in the row store
+        // all loads are issued back to back here, far ahead of their use in the row build, instead of one exposed
+        // HBM round trip per row (a wave has nobody to switch to while it waits)
+        static_assert(LAM_IN_ROWS || NROWG <= 16, "small models keep lam in registers");
+        if constexpr (LAM_IN_ROWS) {
+            sfor<ND>([&](auto D) MI_LAMBDA {
+                constexpr int d = D;
+                if constexpr (M::dof_limited[d]) rows(NROWG * M::MAXCHAIN + 2 * NROWG + limrow(d)) = laml(d);
+            });
+            sfor<3 * NSPH>([&](auto K) MI_LAMBDA { rows(NROWG * M::MAXCHAIN + 2 * NROWG + NLIM + K) = lamc(K); });
+        }
+        MI_STAMP(1);
         // ------------------------------------------------------------ kinematics + dynamics, one depth-first tree pass
         {
             SpI Iroot;
@@ -400,6 +454,7 @@ struct Sim {
           root[0] = acc; return; }
 #endif
         MI_PHASE();
+        MI_STAMP(2);
         // ------------------------------------------------------------ rhs, implicit spring/damper on the diagonal
         float Ldi[NVA];  // 1 / L_ii
         float y[NVA];
@@ -414,8 +469,9 @@ struct Sim {
         // ------------------------------------------------------------ H = L^T L in place (no fill-in on a tree)
         sfor_rev<NV>([&](auto K_) MI_LAMBDA {
             constexpr int k = K_;
-            const float dkk = sqrtf(fmaxf(L[M::midx[k][k]], 1e-30f));
-            const float inv = 1.f / dkk;
+            const float dk2 = fmaxf(L[M::midx[k][k]], 1e-30f);
+            const float inv = MI_RSQ(dk2);
+            const float dkk = dk2 * inv;
             L[M::midx[k][k]] = dkk;
             Ldi[k] = inv;
             sfor<M::nanc[k]>([&](auto A_) MI_LAMBDA {
@@ -464,6 +520,7 @@ struct Sim {
           root[0] = acc; return; }
 #endif
         MI_PHASE();
+        MI_STAMP(3);
         // ------------------------------------------------------------ constraint rows in whitened space
         float lam_reg[LAM_IN_ROWS ? 1 : NROWG];
         auto lam = [&](int row) MI_LAMBDA -> float& {
@@ -493,7 +550,8 @@ struct Sim {
                 const float dl = q[d] - M::dof_lower[d], du = M::dof_upper[d] - q[d];
                 const bool lower = dl < du;
                 const float C = lower ? dl : du, s = lower ? 1.f : -1.f;
-                const float lw = laml(d);
+                float lw;
+                if constexpr (LAM_IN_ROWS) lw = lam(row); else lw = laml(d);
                 const float l0 = ((lw * s < 0.f) ? 0.f : fabsf(lw)) * P.warm;
                 // g over [gi, anc(gi)...]
                 float g[M::MAXCHAIN];
@@ -515,11 +573,13 @@ struct Sim {
                 });
                 float a = P.cfm;
                 sfor<M::nanc[gi] + 1>([&](auto K) MI_LAMBDA { a += g[K] * g[K]; G(row, K) = g[K]; });
-                Ainv(row) = 1.f / a;
-                vt(row) = (C >= 0.f) ? -C / h : fminf(-C * P.erp / h, P.max_depen_vel);
+                Ainv(row) = MI_RCP(a);
+                vt(row) = (C >= 0.f) ? -C * invh : fminf(-C * P.erp * invh, P.max_depen_vel);
                 lam(row) = l0;
             }
         });
+        MI_PHASE();
+        MI_STAMP(4);
         // ground contacts: 3 rows per sphere (normal +z, tangents x, y)
         sfor<NSPH>([&](auto S_) MI_LAMBDA {
             constexpr int s = S_, b = M::sph_body[s], row0 = NLIM + 3 * s;
@@ -551,20 +611,23 @@ struct Sim {
                 chain_solve(std::integral_constant<int, b>{}, g);
                 float a = P.cfm;
                 sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { a += g[C] * g[C]; G(row, C) = g[C]; });
-                Ainv(row) = onf / a;
-                const float vtn = (gap >= 0.f) ? -gap / h : fminf(-gap * P.erp / h, P.max_depen_vel);
+                Ainv(row) = onf * MI_RCP(a);
+                const float vtn = (gap >= 0.f) ? -gap * invh : fminf(-gap * P.erp * invh, P.max_depen_vel);
                 vt(row) = (k == 0) ? vtn : 0.f;
-                lam(row) = lamc(3 * s + k) * P.warm * onf;
+                float lprev;
+                if constexpr (LAM_IN_ROWS) lprev = lam(row); else lprev = lamc(3 * s + k);
+                lam(row) = lprev * P.warm * onf;
             });
         });
         MI_PHASE();
+        MI_STAMP(5);
         // ------------------------------------------------------------ warm start: w += G^T lam0, rows read back from the store
         // (a separate pass on purpose: accumulating into w while the rows are being built makes the compiler keep
         // every row's g alive until one big batched update -- hundreds of spilled registers)
         {
             int zero;
             MI_OPAQUE_ZERO(zero);
-            const RowStore<RS> rit{rows.p + zero};
+            const RowStore<RS> rit = rows.shifted(zero);
             sfor<ND>([&](auto D) MI_LAMBDA {
                 constexpr int d = D, gi = OFF + d;
                 if constexpr (M::dof_limited[d]) {
@@ -591,71 +654,90 @@ struct Sim {
           root[0] = acc; return; }
 #endif
         MI_PHASE();
+        MI_STAMP(6);
         // ------------------------------------------------------------ projected Gauss-Seidel sweeps
-        for (int it = 0; it < P.iters; ++it) {
-            int zero;
-            MI_OPAQUE_ZERO(zero);
-            const RowStore<RS> rit{rows.p + zero};
-            auto G = [&](int row, int c) MI_LAMBDA -> float& { return rit(row * M::MAXCHAIN + c); };
-            auto Ainv = [&](int row) MI_LAMBDA -> float& { return rit(NROWG * M::MAXCHAIN + row); };
-            auto vt = [&](int row) MI_LAMBDA -> float& { return rit(NROWG * M::MAXCHAIN + NROWG + row); };
-            sfor<ND>([&](auto D) MI_LAMBDA {
-                constexpr int d = D, gi = OFF + d;
-                if constexpr (M::dof_limited[d]) {
-                    constexpr int row = limrow(d);
+        // Software-pipelined over "units" (one limit row, or the 3 rows of one sphere): while unit u is being
+        // solved, the rows of unit u+1 are already being read from the store into the other register buffer.  A wave
+        // owns its SIMD alone (512 VGPRs), so nobody else hides the LDS round trip -- the prefetch has to.
+        {
+            constexpr int NUNIT = NLIM + NSPH;
+            struct UBuf { float g[3][M::MAXCHAIN]; float ainv[3], vt[3], lam[3]; };
+            UBuf ub[2];
+            for (int it = 0; it < P.iters; ++it) {
+                int zero;
+                MI_OPAQUE_ZERO(zero);
+                const RowStore<RS> rit = rows.shifted(zero);
+                auto load_unit = [&](auto U_, UBuf& B) MI_LAMBDA {
+                    constexpr int u = decltype(U_)::value;
+                    if constexpr (u < NLIM) {
+                        constexpr int d = limdof(u), gi = OFF + d, row = u;
+                        sfor<M::nanc[gi] + 1>([&](auto K) MI_LAMBDA { B.g[0][K] = rit(row * M::MAXCHAIN + K); });
+                        B.ainv[0] = rit(NROWG * M::MAXCHAIN + row);
+                        B.vt[0] = rit(NROWG * M::MAXCHAIN + NROWG + row);
+                        B.lam[0] = lam(row);
+                    } else if constexpr (u < NUNIT) {
+                        constexpr int s = u - NLIM, b = M::sph_body[s], row0 = NLIM + 3 * s;
+                        sfor<3>([&](auto K) MI_LAMBDA {
+                            sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { B.g[K][C] = rit((row0 + K) * M::MAXCHAIN + C); });
+                            B.ainv[K] = rit(NROWG * M::MAXCHAIN + row0 + K);
+                            B.lam[K] = lam(row0 + K);
+                        });
+                        B.vt[0] = rit(NROWG * M::MAXCHAIN + NROWG + row0);  // tangential targets are zero
+                    }
+                };
+                if constexpr (NUNIT > 0) load_unit(std::integral_constant<int, 0>{}, ub[0]);
+                sfor<NUNIT>([&](auto U_) MI_LAMBDA {
+                    constexpr int u = U_;
+                    UBuf& B = ub[u & 1];
+                    load_unit(std::integral_constant<int, u + 1>{}, ub[(u + 1) & 1]);  // prefetch (no-op past the end)
                     MI_PHASE();
-                    float g[M::MAXCHAIN];
-                    sfor<M::nanc[gi] + 1>([&](auto K) MI_LAMBDA { g[K] = G(row, K); });
-                    float vn = g[0] * w[gi];
-                    sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { vn += g[1 + A_] * w[M::anc[gi][A_]]; });
-                    const float lo = lam(row);
-                    const float nl = fmaxf(lo - (vn - vt(row)) * Ainv(row), 0.f);
-                    const float dl = nl - lo;
-                    lam(row) = nl;
-                    w[gi] += g[0] * dl;
-                    sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { w[M::anc[gi][A_]] += g[1 + A_] * dl; });
-                }
-            });
-            sfor<NSPH>([&](auto S_) MI_LAMBDA {
-                constexpr int s = S_, b = M::sph_body[s], row0 = NLIM + 3 * s;
-                MI_PHASE();
-                // inactive spheres have Ainv = lam = 0: every update below is then exactly zero
-                const float mu = 0.5f * (M::sph_mu[s] + P.plane_mu);
-                float g[3][M::MAXCHAIN];
-                sfor<3>([&](auto K) MI_LAMBDA {
-                    sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { g[K][C] = G(row0 + K, C); });
+                    if constexpr (u < NLIM) {
+                        constexpr int d = limdof(u), gi = OFF + d, row = u;
+                        float vn = B.g[0][0] * w[gi];
+                        sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { vn += B.g[0][1 + A_] * w[M::anc[gi][A_]]; });
+                        const float lo = B.lam[0];
+                        const float nl = fmaxf(lo - (vn - B.vt[0]) * B.ainv[0], 0.f);
+                        const float dl = nl - lo;
+                        lam(row) = nl;
+                        w[gi] += B.g[0][0] * dl;
+                        sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { w[M::anc[gi][A_]] += B.g[0][1 + A_] * dl; });
+                    } else {
+                        constexpr int s = u - NLIM, b = M::sph_body[s], row0 = NLIM + 3 * s;
+                        // inactive spheres have Ainv = lam = 0: every update below is then exactly zero
+                        const float mu = 0.5f * (M::sph_mu[s] + P.plane_mu);
+                        float ln;
+                        {
+                            float vn = 0.f;
+                            sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { vn += B.g[0][C] * w[M::chain[b][C]]; });
+                            const float lo = B.lam[0];
+                            ln = fmaxf(lo - (vn - B.vt[0]) * B.ainv[0], 0.f);
+                            const float dl = ln - lo;
+                            lam(row0) = ln;
+                            sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += B.g[0][C] * dl; });
+                        }
+                        float lt[2];
+                        sfor<2>([&](auto K) MI_LAMBDA {
+                            float vn = 0.f;
+                            sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { vn += B.g[1 + K][C] * w[M::chain[b][C]]; });
+                            const float dl = -vn * B.ainv[1 + K];
+                            lt[K] = B.lam[1 + K] + dl;
+                            sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += B.g[1 + K][C] * dl; });
+                        });
+                        const float lim = mu * ln;
+                        const float n2 = lt[0] * lt[0] + lt[1] * lt[1];
+                        const float sc = (n2 > lim * lim) ? lim * MI_RSQ(fmaxf(n2, 1e-30f)) : 1.f;  // select, no branch
+                        sfor<2>([&](auto K) MI_LAMBDA {
+                            constexpr int row = row0 + 1 + K;
+                            const float nl = lt[K] * sc, dl = nl - lt[K];
+                            lam(row) = nl;
+                            sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += B.g[1 + K][C] * dl; });
+                        });
+                    }
                 });
-                float ln;
-                {
-                    float vn = 0.f;
-                    sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { vn += g[0][C] * w[M::chain[b][C]]; });
-                    const float lo = lam(row0);
-                    ln = fmaxf(lo - (vn - vt(row0)) * Ainv(row0), 0.f);
-                    const float dl = ln - lo;
-                    lam(row0) = ln;
-                    sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += g[0][C] * dl; });
-                }
-                float lt[2];
-                sfor<2>([&](auto K) MI_LAMBDA {
-                    constexpr int row = row0 + 1 + K;
-                    float vn = 0.f;
-                    sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { vn += g[1 + K][C] * w[M::chain[b][C]]; });
-                    const float dl = -(vn - vt(row)) * Ainv(row);
-                    lt[K] = lam(row) + dl;
-                    sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += g[1 + K][C] * dl; });
-                });
-                const float lim = mu * ln;
-                const float nrm = sqrtf(lt[0] * lt[0] + lt[1] * lt[1]);
-                const float sc = (nrm > lim) ? lim / fmaxf(nrm, 1e-30f) : 1.f;
-                sfor<2>([&](auto K) MI_LAMBDA {
-                    constexpr int row = row0 + 1 + K;
-                    const float nl = lt[K] * sc, dl = nl - lt[K];
-                    lam(row) = nl;
-                    sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += g[1 + K][C] * dl; });
-                });
-            });
+            }
         }
         MI_PHASE();
+        MI_STAMP(7);
         // ------------------------------------------------------------ back to generalised velocity: qd = L^-1 w
         float v[NVA];
         sfor<NV>([&](auto I_) MI_LAMBDA {
@@ -669,7 +751,6 @@ struct Sim {
         });
         MI_PHASE();
         // ------------------------------------------------------------ impulses -> warm start, sensors, dof forces
-        const float invh = 1.f / h;
         sfor<ND>([&](auto D) MI_LAMBDA {
             constexpr int d = D;
             float ll = 0.f;
@@ -705,13 +786,13 @@ struct Sim {
         if constexpr (!M::FIXED) {
             sfor<3>([&](auto K) MI_LAMBDA { root[7 + K] = v[K]; root[10 + K] = v[3 + K]; root[K] += h * v[K]; });
             const float om[3] = {v[3], v[4], v[5]};
-            const float an = sqrtf(dot3(om, om)), th = an * h;
+            const float an = MI_SQRT(dot3(om, om)), th = an * h;
             float dq[4];
             {
                 float sn, cs;
                 sincosf(0.5f * th, &sn, &cs);
                 const bool big = th > 1e-12f;
-                const float k = big ? sn / fmaxf(an, 1e-30f) : 0.5f * h;
+                const float k = big ? sn * MI_RCP(fmaxf(an, 1e-30f)) : 0.5f * h;
                 dq[0] = om[0] * k; dq[1] = om[1] * k; dq[2] = om[2] * k; dq[3] = big ? cs : 1.f;
             }
             float* Q = root + 3;
@@ -719,9 +800,10 @@ struct Sim {
             const float yy = dq[3] * Q[1] - dq[0] * Q[2] + dq[1] * Q[3] + dq[2] * Q[0];
             const float z = dq[3] * Q[2] + dq[0] * Q[1] - dq[1] * Q[0] + dq[2] * Q[3];
             const float ww = dq[3] * Q[3] - dq[0] * Q[0] - dq[1] * Q[1] - dq[2] * Q[2];
-            const float n = 1.f / sqrtf(x * x + yy * yy + z * z + ww * ww);
+            const float n = MI_RSQ(x * x + yy * yy + z * z + ww * ww);
             Q[0] = x * n; Q[1] = yy * n; Q[2] = z * n; Q[3] = ww * n;
         }
+        MI_STAMP(8);
     }
 };
 

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64) void substep_kernel(View v, SimParams P, ActPar
     const float h = P.dt / (float)P.substeps;
     const Strided lamc{v.lamc + e, N}, laml{v.laml + e, N}, sensor{v.sensor + e, N}, dof_force{v.dof_force + e, N};
     if constexpr (rows_fit_lds<M>()) {
-        sim.substep(P, tau, h, RowStore<64>{lds_rows + threadIdx.x}, lamc, laml, sensor, dof_force);
+        sim.substep(P, tau, h, RowStore<64>(lds_rows + threadIdx.x), lamc, laml, sensor, dof_force);
     } else {
         float rows[Sim<M>::ROW_SLOTS];
         sim.substep(P, tau, h, RowStore<1>{rows}, lamc, laml, sensor, dof_force);

@@ -11,7 +11,8 @@ import shutil
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi_engine.so")
+# MI_ENGINE_LIB lets tools/ab_bench.sh time two builds of the library inside one GPU session (never set in tests)
+LIB_PATH = os.environ.get("MI_ENGINE_LIB") or os.path.join(_HERE, "libmi_engine.so")
 CSRC = os.path.join(_HERE, "csrc")
 BUILD_DIR = os.path.join(CSRC, "build")
 # one translation unit per robot model (they compile in parallel) + the C ABI
