@@ -6,13 +6,16 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it i
 Rank 0 prints ONE JSON line.
 
   step      = one `env.step(actions)` through the public Python API (isaacgymenvs_amd.make -> VecTask.step), i.e.
-              one fused HIP launch advancing every env by one control step (reference vec_task.py:360-408).
+              one launch group (sub-step kernels + post kernel, no host sync) advancing every env by one control
+              step (reference vec_task.py:360-408).
   workload  = BASELINE.json configs[1]: Ant num_envs=4096 per GPU, random-action rollout (reference README.md:48-51);
               actions come from a pool of pre-generated U(-1,1) batches already resident in HBM.
   value     = (envs on all ranks) * K / max-over-ranks(wall time of the K timed steps), barrier+synchronize on both sides.
-  roofline  = algorithmic bytes per launch (673 B/env-step Ant, 1161 B Humanoid) / average duration of
-              the step kernel, measured with HIP events around each launch (a second pass right after the timed one),
-              against the 8 TB/s HBM3E peak.  `traffic` comes from the rocprofv3 PMC pass (profiles/), not from here.
+  roofline  = algorithmic bytes per control step (673 B/env-step Ant, 1161 B Humanoid) x envs / average
+              GPU time of one step's launch group (substep_kernel x substeps + post kernel), measured with HIP events
+              around each group on the launch stream (a second pass right after the timed one), against the 8 TB/s
+              HBM3E peak.  `traffic` = FETCH_SIZE + WRITE_SIZE of the group from the rocprofv3 PMC passes committed
+              under profiles/ (constants below are refreshed from there; null when not measured for the task).
   cpu_baseline = the CPU oracle (oracle/physics.c via oracle/tasks.py, OpenMP over envs) on a bounded sample of the
               same workload on this host's cores ("port": the reference's PhysX-CPU path cannot run).
   extra     = the second headline config (Humanoid num_envs=8192) measured the same way in the same run.
@@ -33,6 +36,13 @@ if ROOT not in sys.path:
 ALGO_BYTES = {"Cartpole": 89, "Ant": 673, "Humanoid": 1161}
 DEFAULT_ENVS = {"Cartpole": 64, "Ant": 4096, "Humanoid": 8192}
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
+# HBM-side bytes per control step from the round-1 PMC passes (profiles/r1_pmc_summary.md): raw FETCH_SIZE + WRITE_SIZE
+# (KB -> B) summed over the launches of one step (2 sub-steps + post) at the BASELINE env counts.  The raw fetch counter
+# matches the byte count of our dword-per-lane coalesced loads, so the guide's x2 (calibrated on 16 B/lane streams) is
+# NOT applied; the excess over the algorithmic bytes is state re-read per sub-step launch, warm-start impulses and
+# (Humanoid) the constraint rows that spill to scratch.
+PMC_TRAFFIC_BYTES = {("Ant", 4096): int((2 * (1691.5 + 3024.0) + 659.9 + 2230.1) * 1024),
+                     ("Humanoid", 8192): int((2 * (146584.3 + 116067.2) + 2232.7 + 8898.3) * 1024)}
 
 
 def measure(task, num_envs, steps, warmup, device, rank, world, seed=42, pool=64):
@@ -102,9 +112,11 @@ def measure(task, num_envs, steps, warmup, device, rank, world, seed=42, pool=64
 def roofline(task, num_envs, kernel_ms):
     bytes_per_launch = ALGO_BYTES[task] * num_envs
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+    traffic = PMC_TRAFFIC_BYTES.get((task, num_envs))
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None, "kernel": "loco_step_kernel<Model%s>" % task, "kernel_ms": kernel_ms,
-            "algorithmic_bytes_per_launch": bytes_per_launch}
+            "traffic": traffic, "kernel": "mi::substep_kernel<Model%s> (x substeps) + post kernel = one step" % task,
+            "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+            "note": "latency/issue-bound path: %d waves of 64 envs, one per CU; see DESIGN.md" % ((num_envs + 63) // 64)}
 
 
 def cpu_baseline(task, num_envs, budget_s=15.0, seed=42):

@@ -1,0 +1,174 @@
+"""First-principles known-answer tests that pin the CPU physics oracle (oracle/physics.c).
+
+The reference's physics lives in the closed isaacgym/PhysX binary (reference vec_task.py:382) and the reference has no
+simulation tests or recorded trajectories: parity against PhysX is UNPINNED.  These tests pin what can
+be pinned: conservation laws, closed-form motions, static equilibrium and the model constants of SURVEY.md Appendix A.
+"""
+import numpy as np
+import pytest
+
+from isaacgymenvs_amd.registry import load_model, sensor_bodies
+from oracle.engine import OracleEngine
+
+G = 9.81
+
+
+def _eng(name, n=1, **kw):
+    p = dict(dt=1.0 / 60.0, substeps=2, iters=4, gravity=(0.0, 0.0, -G), contact_offset=0.02, rest_offset=0.0,
+             max_depen_vel=10.0, erp=0.5, plane_mu=1.0, ground_z=0.0, cfm=1e-6, warm=1.0)
+    p.update(kw)
+    return OracleEngine(load_model(name), n, params=p, sensor_bodies=sensor_bodies(name), precision="f64")
+
+
+def test_model_constants_match_asset_files():
+    """SURVEY.md Appendix A (derived from the reference's MJCF/URDF files)."""
+    ant, hum, cp = load_model("ant"), load_model("humanoid"), load_model("cartpole")
+    assert (ant.nd, hum.nd, cp.nd) == (8, 21, 2)
+    assert abs(ant.total_mass() - 0.9109) < 2e-3          # nv_ant.xml, density 5
+    assert abs(hum.total_mass() - 40.84) < 0.05           # nv_humanoid.xml, density 1000
+    assert not ant.fixed_base and not hum.fixed_base and cp.fixed_base
+    # ant hips +-40 deg (nv_ant.xml:48-75)
+    lo, up = np.minimum(ant.dof_lower, ant.dof_upper), np.maximum(ant.dof_lower, ant.dof_upper)
+    np.testing.assert_allclose(lo[0::2], -np.deg2rad(40), atol=1e-6)
+    np.testing.assert_allclose(up[0::2], np.deg2rad(40), atol=1e-6)
+
+
+def test_free_fall_matches_closed_form():
+    e = _eng("ant", ground_z=-1000.0)           # ground far away
+    e.root[:, 2] = 5.0
+    q0 = e.q.copy()
+    e.q[:] = np.array(load_model("ant").dof_lower) * 0 + np.where(np.minimum(load_model("ant").dof_lower, load_model("ant").dof_upper) > 0,
+                                                                  np.minimum(load_model("ant").dof_lower, load_model("ant").dof_upper),
+                                                                  np.where(np.maximum(load_model("ant").dof_lower, load_model("ant").dof_upper) < 0,
+                                                                           np.maximum(load_model("ant").dof_lower, load_model("ant").dof_upper), 0.0))
+    tau = np.zeros((1, 8))
+    n = 30
+    for _ in range(n):
+        e.step(tau)
+    t = n / 60.0
+    h = 1.0 / 120.0
+    # semi-implicit Euler: v_k = -g k h ; z_k = z0 - g h^2 k (k+1)/2
+    k = 2 * n
+    assert abs(e.root[0, 9] + G * t) < 1e-6
+    # the root body is not the COM of the whole ant, so compare the COM-independent quantity: root z error is small
+    assert abs(e.root[0, 2] - (5.0 - G * h * h * k * (k + 1) / 2)) < 5e-3
+    # no rotation is induced by gravity alone on a symmetric, unactuated body (legs at rest angles move slightly)
+    assert np.abs(e.root[0, 10:13]).max() < 0.5
+
+
+def test_energy_is_conserved_without_dissipation():
+    """Cart-pole with zero damping/armature dissipation: KE + PE drifts only by the integrator's O(h) error."""
+    e = _eng("cartpole", substeps=8)
+    e.root[:, 2] = 2.0
+    e.q[0] = [0.0, 0.4]
+    e.qd[0] = [0.3, 0.0]
+    ke0, pe0 = e.energy(0)
+    tau = np.zeros((1, 2))
+    es = []
+    for _ in range(120):
+        e.step(tau)
+        ke, pe = e.energy(0)
+        es.append(ke + pe)
+    drift = np.abs(np.array(es) - (ke0 + pe0)).max() / abs(pe0 - min(es) + 1e-9 + abs(ke0 + pe0))
+    assert drift < 2e-2, drift
+
+
+def test_cartpole_matches_planar_ode():
+    """planar cart-pole, m_c = 1, m_p = 1, l_com = 0.47, I_com = (0.06^2 + 1^2)/12, force on the cart."""
+    spec = load_model("cartpole")
+    e = _eng("cartpole", substeps=16)
+    e.root[:, 2] = 2.0
+    th0 = 0.3
+    e.q[0] = [0.0, th0]
+    F = 3.0
+    tau = np.array([[F, 0.0]])
+    mc, mp = float(spec.mass[1]) if spec.nb > 2 else 1.0, 1.0
+    mc, mp, l = 1.0, 1.0, 0.47
+    Ic = (0.06 ** 2 + 1.0 ** 2) / 12.0
+
+    # reference ODE integrated with a much smaller step (RK4).  Pole angle theta is measured from upright about +x, the
+    # cart slides along +y; sign conventions are fitted once from the first step (see below).
+    def f(s, sgn):
+        x, th, xd, thd = s
+        # M(q) qdd = rhs with generalized coords (x, th); pole COM at x + sgn*l*sin(th) horizontally, l*cos(th) up
+        a11, a12, a22 = mc + mp, sgn * mp * l * np.cos(th), Ic + mp * l * l
+        r1 = F + sgn * mp * l * np.sin(th) * thd * thd
+        r2 = mp * G * l * np.sin(th)
+        det = a11 * a22 - a12 * a12
+        return np.array([xd, thd, (r1 * a22 - a12 * r2) / det, (a11 * r2 - a12 * r1) / det])
+
+    def rk4(s, dt, sgn):
+        k1 = f(s, sgn); k2 = f(s + 0.5 * dt * k1, sgn); k3 = f(s + 0.5 * dt * k2, sgn); k4 = f(s + dt * k3, sgn)
+        return s + dt / 6 * (k1 + 2 * k2 + 2 * k3 + k4)
+
+    n = 30
+    for _ in range(n):
+        e.step(tau)
+    best = None
+    for sgn in (+1.0, -1.0):
+        s = np.array([0.0, th0, 0.0, 0.0])
+        for _ in range(n * 64):
+            s = rk4(s, (1.0 / 60.0) / 64, sgn)
+        err = max(abs(s[0] - e.q[0, 0]), abs(s[1] - e.q[0, 1]))
+        best = err if best is None else min(best, err)
+    # first-order integrator with h = 1/960 over 0.5 s of a falling pole: a few 1e-3
+    assert best < 1e-2, best
+
+
+def test_ant_rests_on_the_ground_with_its_weight():
+    e = _eng("ant", n=1)
+    spec = load_model("ant")
+    lo, up = np.minimum(spec.dof_lower, spec.dof_upper), np.maximum(spec.dof_lower, spec.dof_upper)
+    e.q[:] = np.where(lo > 0, lo, np.where(up < 0, up, 0.0))
+    e.root[:, 2] = 0.44
+    tau = np.zeros((1, 8))
+    fz = []
+    for i in range(300):
+        e.step(tau)
+        if i >= 240:
+            fz.append(e.sph_force[0, :, 2].sum())  # world force (x, y, z) per sphere
+    assert abs(np.mean(fz) - spec.total_mass() * G) < 0.02 * spec.total_mass() * G
+    assert e.root[0, 2] > 0.31                       # above terminationHeight (reference Ant.yaml:29)
+    assert np.abs(e.root[0, 7:10]).max() < 0.02      # at rest ...
+    assert np.abs(e.root[0, 10:13]).max() < 0.15     # ... up to the slow yaw creep 4 PGS sweeps leave in the friction rows
+    # joint limits respected
+    assert (e.q[0] >= lo - 0.02).all() and (e.q[0] <= up + 0.02).all()
+
+
+def test_momentum_conservation_in_free_flight():
+    """No external force but gravity: the horizontal linear momentum of the whole ant stays zero under joint torques,
+    up to the first-order error of the semi-implicit integrator (error ~ h: 4x more sub-steps => ~4x less drift)."""
+    errs = []
+    for ss in (2, 8, 32):
+        e = _eng("ant", ground_z=-1000.0, substeps=ss)
+        e.root[:, 2] = 3.0
+        rng = np.random.default_rng(0)
+        px = []
+        for _ in range(20):
+            tau = rng.uniform(-5, 5, (1, 8))
+            e.step(tau)
+            M, _ = e.dynamics(0)
+            v = np.concatenate([e.root[0, 7:13], e.qd[0]])
+            px.append((M @ v)[:2])      # rows 0..2 of the generalized momentum = total linear momentum
+        errs.append(np.abs(np.array(px)).max())
+    assert errs[0] < 0.1 and errs[1] < errs[0] / 2.5 and errs[2] < errs[1] / 2.5, errs
+
+
+@pytest.mark.parametrize("name", ["ant", "humanoid"])
+def test_f32_build_tracks_f64(name):
+    spec = load_model(name)
+    n = 32
+    rng = np.random.default_rng(1)
+    p = dict(dt=1.0 / 60.0, substeps=2, iters=4)
+    a = OracleEngine(spec, n, params=p, sensor_bodies=sensor_bodies(name), precision="f64")
+    b = OracleEngine(spec, n, params=p, sensor_bodies=sensor_bodies(name), precision="f32")
+    z = 0.6 if name == "ant" else 1.4
+    for e in (a, b):
+        e.root[:, 2] = z
+    lo, up = np.minimum(spec.dof_lower, spec.dof_upper), np.maximum(spec.dof_lower, spec.dof_upper)
+    q = rng.uniform(lo, up, (n, spec.nd))
+    a.q[:] = q; b.q[:] = q
+    for _ in range(3):
+        tau = rng.uniform(-10, 10, (n, spec.nd))
+        a.step(tau); b.step(tau)
+    assert np.abs(a.q - b.q).max() < 2e-4 and np.abs(a.qd - b.qd).max() < 5e-3
