@@ -65,6 +65,26 @@ typedef struct {
     float reset_dist, max_push_effort, max_episode_length, clip_actions;
 } MiCartpoleParams;
 
+/* task parameters of AnymalTerrain: what the reference's __init__ reads from cfg["env"] (anymal_terrain.py:47-105).
+ * Reward scales are already multiplied by the control dt (:104-105). */
+typedef struct {
+    float lin_vel_scale, ang_vel_scale, dof_pos_scale, dof_vel_scale, height_meas_scale, action_scale;
+    float rew_termination, rew_lin_vel_xy, rew_lin_vel_z, rew_ang_vel_z, rew_ang_vel_xy, rew_orient, rew_torque, rew_joint_acc,
+          rew_base_height, rew_air_time, rew_collision, rew_stumble, rew_action_rate, rew_hip;
+    float command_x[2], command_y[2], command_yaw[2];
+    float base_init_state[13];
+    float default_dof_pos[12];
+    float kp, kd, torque_limit;
+    float dt;                       /* control dt = decimation * sim.dt */
+    float max_episode_length_s;
+    int32_t max_episode_length, push_interval, allow_knee_contacts, decimation, add_noise;
+    float noise_lin_vel, noise_ang_vel, noise_gravity, noise_dof_pos, noise_dof_vel, noise_height;
+    int32_t curriculum;
+    float clip_actions;
+    float friction_range[2];
+    float terrain_mu;
+} MiAnymalParams;
+
 typedef struct {
     int32_t num_obs, num_actions, num_dofs, num_bodies, num_sensors, num_contact_spheres, fixed_base, task_params_bytes;
 } MiTaskInfo;
@@ -82,7 +102,7 @@ typedef struct {
 
 /* ---- discovery ------------------------------------------------------------------------------------------- */
 int mi_abi_version(void);
-/* task in {"Cartpole","Ant","Humanoid"}: replaces isaacgym_task_map lookup (isaacgymenvs/tasks/__init__.py:88-114)
+/* task in {"Cartpole","Ant","Humanoid","AnymalTerrain"}: replaces isaacgym_task_map lookup (isaacgymenvs/tasks/__init__.py:88-114)
  * + gym.get_asset_{dof,rigid_body}_count (ant.py:155-156) */
 int mi_task_info(const char* task, MiTaskInfo* out);
 size_t mi_engine_arena_bytes(const char* task, int num_envs);
@@ -112,6 +132,13 @@ int mi_engine_reset_idx(MiEngine* e, const int64_t* env_ids, int n, void* stream
 /* physics only: gym.simulate(sim) + refresh_* (vec_task.py:382; ant.py:233-235) with the efforts currently in
  * the "dof_actuation_force" tensor (gym.set_dof_actuation_force_tensor, ant.py:285) */
 int mi_engine_simulate(MiEngine* e, void* stream);
+/* AnymalTerrain only: the terrain the reference builds with `Terrain(cfg["env"]["terrain"], num_envs)` and hands to
+ * gym.add_triangle_mesh (anymal_terrain.py:203-215).  height_samples: DEVICE int16 [rows*cols] (Terrain.heightsamples,
+ * row-major), env_origins: DEVICE fp32 [num_levels*num_terrains*3] (Terrain.env_origins).  Both stay owned by the
+ * caller and must outlive the engine.  Must be called before mi_engine_init_state. */
+int mi_engine_set_terrain(MiEngine* e, const int16_t* height_samples, int rows, int cols, float horizontal_scale,
+                          float vertical_scale, float border_size, const float* env_origins, int num_levels,
+                          int num_terrains, float env_length, int max_init_level);
 /* optional knobs: "clip_obs" (env.clipObservations, vec_task.py:115), "control_freq_inv" (env.controlFrequencyInv, :111) */
 int mi_engine_set_option(MiEngine* e, const char* key, double value);
 /* which slot of the "obs_out" ring ([2, N, num_obs], clamped copy of obs_buf = what VecTask.step returns as

@@ -163,6 +163,44 @@ MI_HD void spi_mul(const SpI& I, const float* X, float* F) {
     F[3] = I.m * a[0] - hxal[0]; F[4] = I.m * a[1] - hxal[1]; F[5] = I.m * a[2] - hxal[2];
 }
 
+// ---- ground policies.  PlaneGround: the z = ground_z plane of the Ant / Humanoid / Cartpole tasks (reference
+// ant.py:128-133).  HeightfieldGround: the rough terrain of AnymalTerrain -- the reference turns an int16 height grid
+// into a triangle mesh (anymal_terrain.py:569-575, each cell split along the (i,j)-(i+1,j+1) diagonal; vertex (i,j) at
+// world (i*hscale - border, j*hscale - border, h*vscale), :208-210); the surface queried here is exactly that
+// piecewise-linear mesh (without the slope-threshold vertex correction), read straight from the int16 grid.
+struct PlaneGround {
+    static constexpr bool HEIGHTFIELD = false;
+};
+struct HeightfieldGround {
+    static constexpr bool HEIGHTFIELD = true;
+    const short* hs;  // [rows * cols], row-major
+    int rows, cols;
+    float hscale, vscale, border;
+    // height z and unit normal n of the surface under world (x, y); same arithmetic as oracle/physics.c ground_query
+    MI_HD void query(float x, float y, float* z, float* n) const {
+        const float gx = (x + border) / hscale, gy = (y + border) / hscale;
+        int i = (int)floorf(gx), j = (int)floorf(gy);
+        i = i < 0 ? 0 : (i > rows - 2 ? rows - 2 : i);
+        j = j < 0 ? 0 : (j > cols - 2 ? cols - 2 : j);
+        const float fx = fminf(fmaxf(gx - (float)i, 0.f), 1.f), fy = fminf(fmaxf(gy - (float)j, 0.f), 1.f);
+        const float h00 = (float)hs[i * cols + j], h10 = (float)hs[(i + 1) * cols + j], h01 = (float)hs[i * cols + j + 1],
+                    h11 = (float)hs[(i + 1) * cols + j + 1];
+        const bool lower = fx >= fy;
+        const float dzx = lower ? h10 - h00 : h11 - h01, dzy = lower ? h11 - h10 : h01 - h00;
+        *z = (h00 + dzx * fx + dzy * fy) * vscale;
+        const float sx = dzx * vscale / hscale, sy = dzy * vscale / hscale;
+        const float inv = 1.f / sqrtf(sx * sx + sy * sy + 1.f);
+        n[0] = -sx * inv; n[1] = -sy * inv; n[2] = inv;
+    }
+};
+// contact frame: n, t1 = normalize(x - n (n.x)), t2 = n x t1   (n = z gives t1 = x, t2 = y)
+MI_HD void contact_frame(const float* n, float* t1, float* t2) {
+    const float a[3] = {1.f - n[0] * n[0], -n[0] * n[1], -n[0] * n[2]};
+    const float inv = 1.f / sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+    t1[0] = a[0] * inv; t1[1] = a[1] * inv; t1[2] = a[2] * inv;
+    cross3(n, t1, t2);
+}
+
 // strided view of a per-env vector that lives in HBM as SoA [k][env] (device: stride = num_envs) or in a plain
 // array (host build: stride 1)
 struct Strided {
@@ -222,7 +260,17 @@ struct Sim {
     }
     MI_HD_NOINLINE void substep_noinline(const SimParams& P, const float* tau, const float h, float* rows, float* lamc,
                                          float* laml, float* sensor, float* dof_force) {
-        substep(P, tau, h, RowStore<1>{rows}, Strided{lamc, 1}, Strided{laml, 1}, Strided{sensor, 1}, Strided{dof_force, 1});
+        substep(P, tau, h, RowStore<1>{rows}, Strided{lamc, 1}, Strided{laml, 1}, Strided{sensor, 1}, Strided{dof_force, 1},
+                PlaneGround{}, -1.f, Strided{nullptr, 1});
+    }
+    // same on a height field with per-env friction and per-body net contact forces netf[3*NB]
+    MI_HD void step_terrain(const SimParams& P, const float* tau, float* lamc, float* laml, float* sensor, float* dof_force,
+                            const HeightfieldGround& gnd, float mu_env, float* netf) {
+        const float h = P.dt / (float)P.substeps;
+        float rows[ROW_SLOTS];
+        for (int ss = 0; ss < P.substeps; ++ss)
+            substep(P, tau, h, RowStore<1>{rows}, Strided{lamc, 1}, Strided{laml, 1}, Strided{sensor, 1}, Strided{dof_force, 1},
+                    gnd, mu_env, Strided{netf, 1});
     }
 
     // working set shared by the phases of one sub-step
@@ -230,7 +278,7 @@ struct Sim {
         float S[M::NDA][6];           // joint motion subspaces, world axes about O = root origin
         float bias[NVA];              // C(q, qd) + gravity terms (RNEA with zero acceleration)
         float L[M::NM];               // branch-sparse H, later its L^T L factor
-        float xcs[M::NSPHA][3];       // lowest point of every contact sphere, relative to O
+        float xcs[M::NSPHA][3];       // centre of every contact sphere, relative to O
         float Rs[M::NSENSA][9], rs[M::NSENSA][3];  // pose of the force-sensor bodies
     };
 
@@ -291,7 +339,7 @@ struct Sim {
             if constexpr (M::sph_body[s] == b) {
                 float t[3];
                 matvec3(Rb, M::sph_pos[s], t);
-                c.xcs[s][0] = rb[0] + t[0]; c.xcs[s][1] = rb[1] + t[1]; c.xcs[s][2] = rb[2] + t[2] - M::sph_rad[s];
+                c.xcs[s][0] = rb[0] + t[0]; c.xcs[s][1] = rb[1] + t[1]; c.xcs[s][2] = rb[2] + t[2];
             }
         });
         if constexpr (sensor_of(b) >= 0) {
@@ -417,9 +465,13 @@ struct Sim {
     }
 
     // ---------------------------------------------------------------- one physics sub-step of length h
-    template <int RS>
+    // gnd: ground policy; mu_env >= 0 replaces the per-sphere model friction (per-env friction buckets of
+    // anymal_terrain.py:236-239,279-281); netf: per-body net contact force [3*NB] (world, this sub-step), written only on
+    // height fields (gym.acquire_net_contact_force_tensor, anymal_terrain.py:119)
+    template <int RS, class GND>
     MI_HD void substep(const SimParams& P, const float* tau, const float h, const RowStore<RS> rows, const Strided lamc,
-                       const Strided laml, const Strided sensor, const Strided dof_force) {
+                       const Strided laml, const Strided sensor, const Strided dof_force, const GND& gnd, const float mu_env,
+                       const Strided netf) {
         auto G = [&](int row, int c) MI_LAMBDA -> float& { return rows(row * M::MAXCHAIN + c); };
         auto Ainv = [&](int row) MI_LAMBDA -> float& { return rows(NROWG * M::MAXCHAIN + row); };
         auto vt = [&](int row) MI_LAMBDA -> float& { return rows(NROWG * M::MAXCHAIN + NROWG + row); };
@@ -580,12 +632,23 @@ struct Sim {
         });
         MI_PHASE();
         MI_STAMP(4);
-        // ground contacts: 3 rows per sphere (normal +z, tangents x, y)
+        // ground contacts: 3 rows per sphere (normal, two tangents; +z, x, y on the plane)
         sfor<NSPH>([&](auto S_) MI_LAMBDA {
             constexpr int s = S_, b = M::sph_body[s], row0 = NLIM + 3 * s;
             MI_PHASE();
-            const float* xc = c.xcs[s];
-            const float dist = (root[2] + xc[2]) - P.ground_z;
+            const float* cs = c.xcs[s];
+            float xc[3], dist;
+            float fr[3][3];  // contact frame n, t1, t2 (height field only)
+            if constexpr (GND::HEIGHTFIELD) {
+                float zt;
+                gnd.query(root[0] + cs[0], root[1] + cs[1], &zt, fr[0]);
+                contact_frame(fr[0], fr[1], fr[2]);
+                dist = ((root[2] + cs[2]) - zt) * fr[0][2] - M::sph_rad[s];  // distance to the local tangent plane
+                sfor<3>([&](auto K) MI_LAMBDA { xc[K] = cs[K] - M::sph_rad[s] * fr[0][K]; });
+            } else {
+                xc[0] = cs[0]; xc[1] = cs[1]; xc[2] = cs[2] - M::sph_rad[s];
+                dist = (root[2] + xc[2]) - P.ground_z;
+            }
             const bool on = dist < P.contact_offset;
             // Branch-free: rows of an inactive sphere are built like any other and made inert with Ainv = 0 and
             // lam = 0 (every PGS update then multiplies by zero).  All 64 envs of the wave run the same
@@ -594,13 +657,19 @@ struct Sim {
             const float gap = dist - P.rest_offset;
             sfor<3>([&](auto K) MI_LAMBDA {
                 constexpr int k = K, row = row0 + k;
-                // unit force u at xc as a spatial force [xc x u; u]; u = z, x, y
-                constexpr int ax = (k == 0) ? 2 : (k == 1 ? 0 : 1);
-                float W[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                W[3 + ax] = 1.f;
-                if constexpr (ax == 0) { W[1] = xc[2]; W[2] = -xc[1]; }
-                else if constexpr (ax == 1) { W[0] = -xc[2]; W[2] = xc[0]; }
-                else { W[0] = xc[1]; W[1] = -xc[0]; }
+                // unit force u at xc as a spatial force [xc x u; u]
+                float W[6];
+                if constexpr (GND::HEIGHTFIELD) {
+                    cross3(xc, fr[k], W);
+                    W[3] = fr[k][0]; W[4] = fr[k][1]; W[5] = fr[k][2];
+                } else {  // u = z, x, y: exploit the zeros
+                    constexpr int ax = (k == 0) ? 2 : (k == 1 ? 0 : 1);
+                    sfor<6>([&](auto I_) MI_LAMBDA { W[I_] = 0.f; });
+                    W[3 + ax] = 1.f;
+                    if constexpr (ax == 0) { W[1] = xc[2]; W[2] = -xc[1]; }
+                    else if constexpr (ax == 1) { W[0] = -xc[2]; W[2] = xc[0]; }
+                    else { W[0] = xc[1]; W[1] = -xc[0]; }
+                }
                 float g[M::MAXCHAIN];
                 sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA {
                     constexpr int gi = M::chain[b][C];
@@ -704,7 +773,7 @@ struct Sim {
                     } else {
                         constexpr int s = u - NLIM, b = M::sph_body[s], row0 = NLIM + 3 * s;
                         // inactive spheres have Ainv = lam = 0: every update below is then exactly zero
-                        const float mu = 0.5f * (M::sph_mu[s] + P.plane_mu);
+                        const float mu = 0.5f * ((mu_env >= 0.f ? mu_env : M::sph_mu[s]) + P.plane_mu);
                         float ln;
                         {
                             float vn = 0.f;
@@ -764,21 +833,38 @@ struct Sim {
         });
         float sens[6 * M::NSENSA];
         sfor<6 * NSENS>([&](auto K) MI_LAMBDA { sens[K] = 0.f; });
+        float nf[GND::HEIGHTFIELD ? NB : 1][3];
+        if constexpr (GND::HEIGHTFIELD) sfor<NB>([&](auto B_) MI_LAMBDA { nf[B_][0] = nf[B_][1] = nf[B_][2] = 0.f; });
         sfor<NSPH>([&](auto S_) MI_LAMBDA {
             constexpr int s = S_, b = M::sph_body[s], row0 = NLIM + 3 * s;
-            // inactive spheres carry lam = 0 => zero warm start and zero sensor contribution
+            // inactive spheres carry lam = 0 => zero warm start and zero sensor / net-force contribution
             const float ln = lam(row0), l1 = lam(row0 + 1), l2 = lam(row0 + 2);
             lamc(3 * s) = ln; lamc(3 * s + 1) = l1; lamc(3 * s + 2) = l2;
+            float f[3], xc[3];
+            if constexpr (GND::HEIGHTFIELD) {
+                // the frame is re-derived here (root has not moved yet) instead of being kept live through the solve
+                float zt, n[3], t1[3], t2[3];
+                gnd.query(root[0] + c.xcs[s][0], root[1] + c.xcs[s][1], &zt, n);
+                contact_frame(n, t1, t2);
+                sfor<3>([&](auto K) MI_LAMBDA {
+                    f[K] = (n[K] * ln + t1[K] * l1 + t2[K] * l2) * invh;
+                    xc[K] = c.xcs[s][K] - M::sph_rad[s] * n[K];
+                    nf[b][K] += f[K];
+                });
+            } else {
+                f[0] = l1 * invh; f[1] = l2 * invh; f[2] = ln * invh;
+                xc[0] = c.xcs[s][0]; xc[1] = c.xcs[s][1]; xc[2] = c.xcs[s][2] - M::sph_rad[s];
+            }
             if constexpr (sensor_of(b) >= 0) {
                 constexpr int k = sensor_of(b);
-                const float f[3] = {l1 * invh, l2 * invh, ln * invh};
-                const float arm[3] = {c.xcs[s][0] - c.rs[k][0], c.xcs[s][1] - c.rs[k][1], c.xcs[s][2] - c.rs[k][2]};
+                const float arm[3] = {xc[0] - c.rs[k][0], xc[1] - c.rs[k][1], xc[2] - c.rs[k][2]};
                 float tq[3], fl[3], tl[3];
                 cross3(arm, f, tq);
                 matTvec3(c.Rs[k], f, fl); matTvec3(c.Rs[k], tq, tl);
                 sfor<3>([&](auto C) MI_LAMBDA { sens[6 * k + C] += fl[C]; sens[6 * k + 3 + C] += tl[C]; });
             }
         });
+        if constexpr (GND::HEIGHTFIELD) sfor<NB>([&](auto B_) MI_LAMBDA { sfor<3>([&](auto K) MI_LAMBDA { netf(3 * B_ + K) = nf[B_][K]; }); });
         sfor<6 * NSENS>([&](auto K) MI_LAMBDA { sensor(K) = sens[K]; });
         MI_PHASE();
         // ------------------------------------------------------------ integrate (semi-implicit Euler)

@@ -1,0 +1,391 @@
+// kernels_anymal.hip -- AnymalTerrain: ModelAnymal sub-step on the height field + the task's post_physics_step kernel.
+#include "step_kernels.hpp"
+#include "gen/model_anymal.h"
+#include "tasks/anymal.hpp"
+
+namespace mi {
+
+static_assert(ModelAnymal::ND == kAnymalDof, "anymal dof count");
+
+// ------------------------------------------------------------------------------------------------ curriculum pre-pass
+// update_terrain_level (:431) compares every resetting env's walked distance with
+//     torch.norm(self.commands[env_ids, :2]) * max_episode_length_s * 0.25
+// where the norm runs over the commands of ALL envs that reset in this step (a batch-coupled quantity in the
+// reference).  This pre-pass evaluates the termination condition (:294-300) and accumulates sum(cx^2 + cy^2) over the
+// resetting envs into ep_stats[15]; the post kernel takes its square root.
+__global__ __launch_bounds__(64) void anymal_cmdnorm_kernel(View v, AnymalParams p) {
+    const int e0 = blockIdx.x * 64 + threadIdx.x;
+    const int N = v.N;
+    float acc = 0.f;
+    if (e0 < N) {
+        const int e = e0;
+        auto fnorm = [&](int b) MI_LAMBDA {
+            MI_NO_CONTRACT
+            const float fx = v.netf[(3 * b) * N + e], fy = v.netf[(3 * b + 1) * N + e], fz = v.netf[(3 * b + 2) * N + e];
+            return sqrtf((fx * fx + fy * fy) + fz * fz);
+        };
+        bool rs = fnorm(0) > 1.f;
+        if (!p.allow_knee_contacts)
+            for (int k = 0; k < 4; ++k) rs = rs || (fnorm(anymal_knee_body(k)) > 1.f);
+        if (v.progress[e] + 1 >= (long long)p.max_episode_length - 1) rs = true;
+        if (rs) {
+            const float cx = v.commands[e], cy = v.commands[N + e];
+            acc = cx * cx + cy * cy;
+        }
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0 && acc > 0.f) atomicAdd(v.ep_stats + 15, acc);
+}
+
+// ------------------------------------------------------------------------------------------------ post_physics_step
+// One env per lane.  Order of operations = reference anymal_terrain.py:453-485 (including its quirks: the base-frame
+// velocities / projected gravity of an env that resets this step are the PRE-reset ones, the yaw-aligned height scan
+// uses the POST-reset pose, reset_buf stays 1 after reset_idx (:418), the termination reward looks at the previous
+// step's timeout_buf because the base class refreshes it after post_physics_step, vec_task.py:394).
+__global__ __launch_bounds__(64) void anymal_post_kernel(View v, AnymalParams p, AnymalTerrainDesc T, unsigned step_counter) {
+    using M = ModelAnymal;
+    constexpr int ND = kAnymalDof;
+    const int e0 = blockIdx.x * 64 + threadIdx.x;
+    const int N = v.N;
+    const bool valid = e0 < N;
+    const int e = valid ? e0 : N - 1;
+    const uint32_t genv = (uint32_t)(v.env_offset + e);
+    float root[13], q[ND], qd[ND], act[ND], tau[ND], last_act[ND], last_qd[ND];
+    sfor<13>([&](auto K) MI_LAMBDA { root[K] = v.root[K * N + e]; });
+    sfor<ND>([&](auto K) MI_LAMBDA {
+        q[K] = v.dof[K * N + e]; qd[K] = v.dof[(ND + K) * N + e];
+        act[K] = v.actions[K * N + e]; tau[K] = v.tau[K * N + e];
+        last_act[K] = v.last_actions[K * N + e]; last_qd[K] = v.last_dof_vel[K * N + e];
+    });
+    float cmd[4];
+    sfor<4>([&](auto K) MI_LAMBDA { cmd[K] = v.commands[K * N + e]; });
+    long long progress = v.progress[e] + 1;                                  // :458
+    // push_robots every push_interval control steps (:461-462, :437-439): new xy velocity for EVERY env
+    if (p.push_interval > 0 && (step_counter % (unsigned)p.push_interval) == 0u) {
+        root[7] = 2.f * anymal_rand_step(v.seed, genv, step_counter | 0x80000000u, 0) - 1.f;
+        root[8] = 2.f * anymal_rand_step(v.seed, genv, step_counter | 0x80000000u, 1) - 1.f;
+        if (valid) { v.root[7 * N + e] = root[7]; v.root[8 * N + e] = root[8]; }
+    }
+    // prepare quantities (:465-472)
+    float base_lin_vel[3], base_ang_vel[3], proj_g[3], fwd[3];
+    const float gvec[3] = {0.f, 0.f, -1.f}, fvec[3] = {1.f, 0.f, 0.f};
+    quat_rotate_s(root + 3, root + 7, -1.f, base_lin_vel);
+    quat_rotate_s(root + 3, root + 10, -1.f, base_ang_vel);
+    quat_rotate_s(root + 3, gvec, -1.f, proj_g);
+    quat_apply(root + 3, fvec, fwd);
+    float rew, heights_pre_clip_dummy = 0.f;
+    (void)heights_pre_clip_dummy;
+    long long reset;
+    float sums[kAnymalSums];
+    sfor<kAnymalSums>([&](auto K) MI_LAMBDA { sums[K] = v.episode_sums[K * N + e]; });
+    float air[4];
+    sfor<4>([&](auto K) MI_LAMBDA { air[K] = v.feet_air_time[K * N + e]; });
+    {
+        MI_NO_CONTRACT
+        const float heading = atan2f(fwd[1], fwd[0]);
+        cmd[2] = fminf(fmaxf(0.5f * wrap_to_pi(cmd[3] - heading), -1.f), 1.f);
+        // check_termination (:294-300)
+        auto fnorm = [&](int b) MI_LAMBDA {
+            const float fx = v.netf[(3 * b) * N + e], fy = v.netf[(3 * b + 1) * N + e], fz = v.netf[(3 * b + 2) * N + e];
+            return sqrtf((fx * fx + fy * fy) + fz * fz);
+        };
+        bool rs = fnorm(0) > 1.f;
+        int knee_contacts = 0;
+        sfor<4>([&](auto K) MI_LAMBDA { knee_contacts += (fnorm(anymal_knee_body(K)) > 1.f) ? 1 : 0; });
+        if (!p.allow_knee_contacts) rs = rs || (knee_contacts > 0);
+        if (progress >= (long long)p.max_episode_length - 1) rs = true;
+        // compute_reward (:315-382)
+        const float dvx = cmd[0] - base_lin_vel[0], dvy = cmd[1] - base_lin_vel[1];
+        const float lin_vel_error = dvx * dvx + dvy * dvy;
+        const float dwz = cmd[2] - base_ang_vel[2];
+        const float ang_vel_error = dwz * dwz;
+        float r[kAnymalSums];
+        r[0] = expf(-lin_vel_error / 0.25f) * p.rew_lin_vel_xy;
+        r[2] = expf(-ang_vel_error / 0.25f) * p.rew_ang_vel_z;
+        r[1] = (base_lin_vel[2] * base_lin_vel[2]) * p.rew_lin_vel_z;
+        r[3] = (base_ang_vel[0] * base_ang_vel[0] + base_ang_vel[1] * base_ang_vel[1]) * p.rew_ang_vel_xy;
+        r[4] = (proj_g[0] * proj_g[0] + proj_g[1] * proj_g[1]) * p.rew_orient;
+        const float bh = root[2] - 0.52f;
+        r[7] = (bh * bh) * p.rew_base_height;
+        float st = 0.f, sa = 0.f, sr = 0.f, sh = 0.f;
+        for (int d = 0; d < ND; ++d) {
+            st += tau[d] * tau[d];
+            const float da = last_qd[d] - qd[d];
+            sa += da * da;
+            const float dr = last_act[d] - act[d];
+            sr += dr * dr;
+        }
+        r[5] = st * p.rew_torque;
+        r[6] = sa * p.rew_joint_acc;
+        r[9] = (float)knee_contacts * p.rew_collision;
+        int stumbles = 0;
+        float air_rew = 0.f;
+        sfor<4>([&](auto K) MI_LAMBDA {
+            constexpr int b = anymal_foot_body(K);
+            const float fx = v.netf[(3 * b) * N + e], fy = v.netf[(3 * b + 1) * N + e], fz = v.netf[(3 * b + 2) * N + e];
+            stumbles += ((sqrtf(fx * fx + fy * fy) > 5.f) && (fabsf(fz) < 1.f)) ? 1 : 0;
+            const bool contact = fz > 1.f;
+            const bool first_contact = (air[K] > 0.f) && contact;
+            air[K] += p.dt;
+            air_rew += (air[K] - 0.5f) * (first_contact ? 1.f : 0.f);
+            air[K] = contact ? 0.f : air[K];
+        });
+        r[10] = (float)stumbles * p.rew_stumble;
+        r[11] = sr * p.rew_action_rate;
+        r[8] = air_rew * p.rew_air_time;
+        r[8] *= (sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]) > 0.1f) ? 1.f : 0.f;
+        sh = fabsf(q[0] - p.default_dof_pos[0]) + fabsf(q[3] - p.default_dof_pos[3]) + fabsf(q[6] - p.default_dof_pos[6]) +
+             fabsf(q[9] - p.default_dof_pos[9]);
+        r[12] = sh * p.rew_hip;
+        // total (:361-366): lin_vel_xy + ang_vel_z + lin_vel_z + ang_vel_xy + orient + base_height + torque + joint_acc +
+        //                   collision + action_rate + airTime + hip + stumble, clipped at 0, + termination term
+        float total = r[0] + r[2] + r[1] + r[3] + r[4] + r[7] + r[5] + r[6] + r[9] + r[11] + r[8] + r[12] + r[10];
+        total = fmaxf(total, 0.f);
+        const bool prev_timeout = v.timeout[e] != 0;
+        total += p.rew_termination * ((rs && !prev_timeout) ? 1.f : 0.f);
+        rew = total;
+        reset = rs ? 1 : 0;
+        sfor<kAnymalSums>([&](auto K) MI_LAMBDA { sums[K] += r[K]; });
+    }
+    // ------------------------------------------------------------------ reset_idx for flagged envs (:384-425)
+    int ep = v.episode[e];
+    int level = v.terrain_levels[e];
+    float origin[3] = {v.env_origins[e], v.env_origins[N + e], v.env_origins[2 * N + e]};
+    float st_sums[kAnymalSums];
+    float st_cnt = 0.f;
+    sfor<kAnymalSums>([&](auto K) MI_LAMBDA { st_sums[K] = 0.f; });
+    if (reset != 0) {
+        MI_NO_CONTRACT
+        const uint32_t uep = (uint32_t)ep;
+        // update_terrain_level (:427-435) -- skipped on the very first reset (init_done False) and without curriculum
+        if (p.curriculum && T.hs != nullptr && ep > 0) {
+            const float ddx = root[0] - origin[0], ddy = root[1] - origin[1];
+            const float distance = sqrtf(ddx * ddx + ddy * ddy);
+            // torch.norm(self.commands[env_ids, :2]): norm over ALL envs resetting this step (anymal_cmdnorm_kernel)
+            const float cn = sqrtf(v.ep_stats[15]);
+            level -= (distance < cn * p.max_episode_length_s * 0.25f) ? 1 : 0;
+            level += (distance > T.env_length / 2.f) ? 1 : 0;
+            level = (level < 0 ? 0 : level) % T.levels;
+            const int type = v.terrain_types[e];
+            sfor<3>([&](auto K) MI_LAMBDA { origin[K] = T.origins[(level * T.types + type) * 3 + K]; });
+        }
+        for (int d = 0; d < ND; ++d) {
+            const float off = (1.5f - 0.5f) * uniform01(v.seed, genv, uep, (uint32_t)d) + 0.5f;          // torch_rand_float(0.5, 1.5)
+            q[d] = p.default_dof_pos[d] * off;
+            qd[d] = (0.1f - (-0.1f)) * uniform01(v.seed, genv, uep, (uint32_t)(ND + d)) + (-0.1f);
+        }
+        sfor<13>([&](auto K) MI_LAMBDA { root[K] = p.base_init_state[K]; });
+        if (T.hs != nullptr) {   // custom_origins (:395-399)
+            sfor<3>([&](auto K) MI_LAMBDA { root[K] += origin[K]; });
+            root[0] += (0.5f - (-0.5f)) * uniform01(v.seed, genv, uep, 2 * ND + 0) + (-0.5f);
+            root[1] += (0.5f - (-0.5f)) * uniform01(v.seed, genv, uep, 2 * ND + 1) + (-0.5f);
+        }
+        cmd[0] = (p.command_x[1] - p.command_x[0]) * uniform01(v.seed, genv, uep, 2 * ND + 2) + p.command_x[0];
+        cmd[1] = (p.command_y[1] - p.command_y[0]) * uniform01(v.seed, genv, uep, 2 * ND + 3) + p.command_y[0];
+        cmd[3] = (p.command_yaw[1] - p.command_yaw[0]) * uniform01(v.seed, genv, uep, 2 * ND + 4) + p.command_yaw[0];
+        const float keep = (sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]) > 0.25f) ? 1.f : 0.f;   // set small commands to zero (:415)
+        sfor<4>([&](auto K) MI_LAMBDA { cmd[K] *= keep; });
+        sfor<ND>([&](auto K) MI_LAMBDA { last_act[K] = 0.f; last_qd[K] = 0.f; });
+        sfor<4>([&](auto K) MI_LAMBDA { air[K] = 0.f; });
+        progress = 0;
+        if (valid) {
+            st_cnt = 1.f;
+            sfor<kAnymalSums>([&](auto K) MI_LAMBDA { st_sums[K] = sums[K]; });
+        }
+        sfor<kAnymalSums>([&](auto K) MI_LAMBDA { sums[K] = 0.f; });
+        ep += 1;
+        if (valid) {
+            sfor<13>([&](auto K) MI_LAMBDA { v.root[K * N + e] = root[K]; });
+            sfor<ND>([&](auto K) MI_LAMBDA { v.dof[K * N + e] = q[K]; v.dof[(ND + K) * N + e] = qd[K]; });
+            sfor<3 * M::NSPH>([&](auto K) MI_LAMBDA { v.lamc[K * N + e] = 0.f; });
+            v.terrain_levels[e] = level;
+            sfor<3>([&](auto K) MI_LAMBDA { v.env_origins[K * N + e] = origin[K]; });
+        }
+    }
+    // extras["episode"] partial sums: wave reduction, one atomic per wave and statistic (:421-425)
+    {
+        float lv = valid ? (float)level : 0.f;
+        st_cnt = wave_sum(st_cnt);
+        lv = wave_sum(lv);
+        float red[kAnymalSums];
+        sfor<kAnymalSums>([&](auto K) MI_LAMBDA { red[K] = wave_sum(st_sums[K]); });
+        if ((threadIdx.x & 63) == 0) {
+            if (st_cnt > 0.f) {
+                sfor<kAnymalSums>([&](auto K) MI_LAMBDA { atomicAdd(v.ep_stats + K, red[K]); });
+                atomicAdd(v.ep_stats + 13, st_cnt);
+            }
+            atomicAdd(v.ep_stats + 14, lv);
+        }
+    }
+    episode_stats(v, e, valid, rew, reset, progress);
+    if (!valid) return;
+    // ------------------------------------------------------------------ compute_observations (:302-313) + noise (:481-482)
+    float* ob = v.obs + (size_t)e * kAnymalObs;
+    float* oc = v.obs_out + ((size_t)v.ring * N + e) * kAnymalObs;
+    const uint32_t sk = step_counter | 0x80000000u;
+    auto emit = [&](int k, float val, float noise_scale) MI_LAMBDA {
+        MI_NO_CONTRACT
+        if (p.add_noise) val += (2.f * anymal_rand_step(v.seed, genv, sk, (uint32_t)(16 + k)) - 1.f) * noise_scale;
+        ob[k] = val;
+        oc[k] = fminf(fmaxf(val, -v.clip_obs), v.clip_obs);
+    };
+    {
+        MI_NO_CONTRACT
+        sfor<3>([&](auto K) MI_LAMBDA { emit(K, base_lin_vel[K] * p.lin_vel_scale, p.noise_lin_vel); });
+        sfor<3>([&](auto K) MI_LAMBDA { emit(3 + K, base_ang_vel[K] * p.ang_vel_scale, p.noise_ang_vel); });
+        sfor<3>([&](auto K) MI_LAMBDA { emit(6 + K, proj_g[K], p.noise_gravity); });
+        emit(9, cmd[0] * p.lin_vel_scale, 0.f); emit(10, cmd[1] * p.lin_vel_scale, 0.f); emit(11, cmd[2] * p.ang_vel_scale, 0.f);
+        sfor<ND>([&](auto K) MI_LAMBDA { emit(12 + K, q[K] * p.dof_pos_scale, p.noise_dof_pos); });
+        sfor<ND>([&](auto K) MI_LAMBDA { emit(24 + K, qd[K] * p.dof_vel_scale, p.noise_dof_vel); });
+        // yaw-only quaternion of the (post-reset) base orientation (:676-681)
+        float yq[4] = {0.f, 0.f, root[5], root[6]};
+        const float yn = fmaxf(sqrtf(yq[2] * yq[2] + yq[3] * yq[3]), 1e-9f);
+        yq[2] /= yn; yq[3] /= yn;
+        for (int k = 0; k < kAnymalHeightPts; ++k) {
+            float hm = 0.f;
+            if (T.hs != nullptr) hm = anymal_height_at(T, yq, root, k);
+            const float hv = fminf(fmaxf(root[2] - 0.5f - hm, -1.f), 1.f) * p.height_meas_scale;
+            emit(36 + k, hv, p.noise_height);
+        }
+        sfor<ND>([&](auto K) MI_LAMBDA { emit(176 + K, act[K], 0.f); });
+    }
+    // bookkeeping (:484-485, vec_task.py:394)
+    sfor<ND>([&](auto K) MI_LAMBDA { v.last_actions[K * N + e] = act[K]; v.last_dof_vel[K * N + e] = qd[K]; });
+    sfor<4>([&](auto K) MI_LAMBDA { v.feet_air_time[K * N + e] = air[K]; v.commands[K * N + e] = cmd[K]; });
+    sfor<kAnymalSums>([&](auto K) MI_LAMBDA { v.episode_sums[K * N + e] = sums[K]; });
+    v.randomize[e] += 1;
+    v.episode[e] = ep;
+    v.rew[e] = rew;
+    v.reset[e] = reset;     // stays 1 for an env that was just reset (:418)
+    v.progress[e] = progress;
+    v.timeout[e] = (unsigned char)((progress >= (long long)p.max_episode_length - 1) && (reset != 0));
+}
+
+// extras["episode"] (:421-425): means over the envs reset this step, divided by max_episode_length_s; terrain level mean
+__global__ void anymal_extras_kernel(View v, AnymalParams p) {
+    const int k = threadIdx.x;
+    if (k < kAnymalSums) {
+        const float cnt = v.ep_stats[13];
+        if (cnt > 0.f) v.ep_means[k] = v.ep_stats[k] / cnt / p.max_episode_length_s;   // untouched when nobody reset (the
+    }                                                                                   // reference keeps the last dict)
+    if (k == 14) v.ep_means[14] = v.ep_stats[14] / (float)v.N;
+    if (k == 13) v.ep_means[13] = v.ep_stats[13];
+}
+
+// ------------------------------------------------------------------------------------------------ init / explicit reset
+// the constructor's reset_idx(arange(num_envs)) (:170) with init_done False: terrain level 0..maxInitMapLevel, random type
+__global__ void anymal_init_kernel(View v, AnymalParams p, AnymalTerrainDesc T, int max_init_level) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = v.N;
+    if (e >= N) return;
+    const uint32_t genv = (uint32_t)(v.env_offset + e);
+    // terrain_levels = randint(0, maxInitMapLevel+1), terrain_types = randint(0, numTerrains) (:260-261)
+    int level = 0, type = 0;
+    float origin[3] = {0.f, 0.f, 0.f};
+    if (T.hs != nullptr) {
+        level = (int)(uniform01(v.seed ^ 0x1234567u, genv, 0u, 0u) * (float)(max_init_level + 1));
+        level = level > max_init_level ? max_init_level : level;
+        type = (int)(uniform01(v.seed ^ 0x1234567u, genv, 0u, 1u) * (float)T.types);
+        type = type >= T.types ? T.types - 1 : type;
+        for (int k = 0; k < 3; ++k) origin[k] = T.origins[(level * T.types + type) * 3 + k];
+    }
+    v.terrain_levels[e] = level;
+    v.terrain_types[e] = type;
+    for (int k = 0; k < 3; ++k) v.env_origins[k * N + e] = origin[k];
+    // friction buckets (:236-239, 279-281): 100 buckets U(frictionRange), env i uses bucket i % 100
+    const float fb = (p.friction_range[1] - p.friction_range[0]) * uniform01(v.seed ^ 0x7654321u, (uint32_t)(genv % 100u), 0u, 0u) +
+                     p.friction_range[0];
+    v.friction[e] = fb;
+    for (int k = 0; k < 4; ++k) { v.commands[k * N + e] = 0.f; v.feet_air_time[k * N + e] = 0.f; }
+    for (int k = 0; k < kAnymalDof; ++k) { v.last_actions[k * N + e] = 0.f; v.last_dof_vel[k * N + e] = 0.f; }
+    for (int k = 0; k < kAnymalSums; ++k) v.episode_sums[k * N + e] = 0.f;
+    for (int k = 0; k < 3 * ModelAnymal::NB; ++k) v.netf[k * N + e] = 0.f;
+    if (e == 0) for (int k = 0; k < 16; ++k) { v.ep_stats[k] = 0.f; v.ep_means[k] = 0.f; }
+}
+
+// reset_idx(env_ids) (:384-425) outside step(): same draws as the in-step reset of the env's current episode number
+__global__ void anymal_reset_kernel(View v, AnymalParams p, AnymalTerrainDesc T, const long long* __restrict__ ids, int n) {
+    MI_NO_CONTRACT
+    constexpr int ND = kAnymalDof;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int e = (int)ids[i], N = v.N;
+    if (e < 0 || e >= N) return;
+    const uint32_t genv = (uint32_t)(v.env_offset + e), uep = (uint32_t)v.episode[e];
+    for (int d = 0; d < ND; ++d) {
+        v.dof[d * N + e] = p.default_dof_pos[d] * ((1.5f - 0.5f) * uniform01(v.seed, genv, uep, (uint32_t)d) + 0.5f);
+        v.dof[(ND + d) * N + e] = (0.1f - (-0.1f)) * uniform01(v.seed, genv, uep, (uint32_t)(ND + d)) + (-0.1f);
+        v.last_actions[d * N + e] = 0.f; v.last_dof_vel[d * N + e] = 0.f;
+    }
+    float root[13];
+    for (int k = 0; k < 13; ++k) root[k] = p.base_init_state[k];
+    if (T.hs != nullptr) {
+        for (int k = 0; k < 3; ++k) root[k] += v.env_origins[k * N + e];
+        root[0] += (0.5f - (-0.5f)) * uniform01(v.seed, genv, uep, 2 * ND + 0) + (-0.5f);
+        root[1] += (0.5f - (-0.5f)) * uniform01(v.seed, genv, uep, 2 * ND + 1) + (-0.5f);
+    }
+    for (int k = 0; k < 13; ++k) v.root[k * N + e] = root[k];
+    float cmd[4];
+    cmd[0] = (p.command_x[1] - p.command_x[0]) * uniform01(v.seed, genv, uep, 2 * ND + 2) + p.command_x[0];
+    cmd[1] = (p.command_y[1] - p.command_y[0]) * uniform01(v.seed, genv, uep, 2 * ND + 3) + p.command_y[0];
+    cmd[2] = v.commands[2 * N + e];
+    cmd[3] = (p.command_yaw[1] - p.command_yaw[0]) * uniform01(v.seed, genv, uep, 2 * ND + 4) + p.command_yaw[0];
+    const float keep = (sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]) > 0.25f) ? 1.f : 0.f;
+    for (int k = 0; k < 4; ++k) { v.commands[k * N + e] = cmd[k] * keep; v.feet_air_time[k * N + e] = 0.f; }
+    for (int k = 0; k < kAnymalSums; ++k) v.episode_sums[k * N + e] = 0.f;
+    for (int k = 0; k < 3 * ModelAnymal::NSPH; ++k) v.lamc[k * N + e] = 0.f;
+    v.episode[e] += 1;
+    v.progress[e] = 0;
+    v.reset[e] = 1;   // :418
+}
+
+static HeightfieldGround ground_of(const AnymalTerrainDesc& T) {
+    return HeightfieldGround{T.hs, T.rows, T.cols, T.hscale, T.vscale, T.border};
+}
+static ActParams act_of(const AnymalParams& tp) {
+    ActParams ap{};
+    ap.clip = tp.clip_actions; ap.scale = tp.action_scale; ap.nact = kAnymalDof; ap.mode = 1;
+    ap.kp = tp.kp; ap.kd = tp.kd; ap.torque_limit = tp.torque_limit;
+    for (int d = 0; d < kAnymalDof; ++d) ap.gear[d] = tp.default_dof_pos[d];
+    return ap;
+}
+
+// VecTask.step for AnymalTerrain: `decimation` sim steps with the PD torques recomputed before each (:443-451), then
+// control_freq_inv more sim steps with the last torques (the base class simulates again, vec_task.py:379-382; the task
+// YAML has no controlFrequencyInv => 1), then post_physics_step.
+hipError_t launch_step_anymal(const View& v, const SimParams& P, const AnymalParams& tp, const AnymalTerrainDesc& T,
+                              const float* actions, int cfi, unsigned step_counter, hipStream_t s) {
+    const ActParams ap = act_of(tp);
+    hipError_t e;
+    if (T.hs != nullptr) {
+        e = launch_substeps<ModelAnymal, HeightfieldGround>(v, P, ap, actions, tp.decimation * P.substeps, ACT_FROM_ACTIONS,
+                                                            ACT_FROM_STORED_ACTIONS, s, ground_of(T));
+        if (e != hipSuccess) return e;
+        e = launch_substeps<ModelAnymal, HeightfieldGround>(v, P, ap, nullptr, cfi * P.substeps, ACT_STORED_TAU, ACT_STORED_TAU, s,
+                                                            ground_of(T));
+    } else {
+        return hipErrorInvalidValue;  // mi_engine_step refuses to run AnymalTerrain before mi_engine_set_terrain
+    }
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(v.ep_stats, 0, 16 * sizeof(float), s);
+    if (e != hipSuccess) return e;
+    if (tp.curriculum) hipLaunchKernelGGL(anymal_cmdnorm_kernel, dim3((v.N + 63) / 64), dim3(64), 0, s, v, tp);
+    hipLaunchKernelGGL(anymal_post_kernel, dim3((v.N + 63) / 64), dim3(64), 0, s, v, tp, T, step_counter);
+    hipLaunchKernelGGL(anymal_extras_kernel, dim3(1), dim3(64), 0, s, v, tp);
+    return hipGetLastError();
+}
+hipError_t launch_simulate_anymal(const View& v, const SimParams& P, const AnymalTerrainDesc& T, hipStream_t s) {
+    ActParams ap{};
+    if (T.hs == nullptr) return hipErrorInvalidValue;
+    return launch_substeps<ModelAnymal, HeightfieldGround>(v, P, ap, nullptr, P.substeps, ACT_STORED_TAU, ACT_STORED_TAU, s, ground_of(T));
+}
+hipError_t launch_init_anymal(const View& v, const AnymalParams& tp, const AnymalTerrainDesc& T, int max_init_level, hipStream_t s) {
+    hipLaunchKernelGGL(anymal_init_kernel, dim3((v.N + 127) / 128), dim3(128), 0, s, v, tp, T, max_init_level);
+    return hipGetLastError();
+}
+hipError_t launch_reset_anymal(const View& v, const AnymalParams& tp, const AnymalTerrainDesc& T, const long long* ids, int n, hipStream_t s) {
+    hipLaunchKernelGGL(anymal_reset_kernel, dim3((n + 127) / 128), dim3(128), 0, s, v, tp, T, ids, n);
+    return hipGetLastError();
+}
+
+}  // namespace mi

@@ -8,7 +8,7 @@ hipError_t launch_step_cartpole(const View& v, const SimParams& P, const Cartpol
     ActParams ap{};
     ap.clip = tp.clip_actions; ap.scale = 1.f; ap.nact = 1;
     ap.gear[0] = tp.max_push_effort;  // cartpole.py:159-163: effort on DoF 0 only
-    hipError_t e = launch_substeps<ModelCartpole>(v, P, ap, actions, cfi * P.substeps, s);
+    hipError_t e = launch_substeps<ModelCartpole>(v, P, ap, actions, cfi * P.substeps, ACT_FROM_ACTIONS, ACT_STORED_TAU, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(cartpole_post_kernel<ModelCartpole>, dim3((v.N + 63) / 64), dim3(64), 0, s, v, tp);
     return hipGetLastError();

@@ -13,6 +13,8 @@
 #include "gen/model_ant.h"
 #include "gen/model_cartpole.h"
 #include "gen/model_humanoid.h"
+#include "gen/model_anymal.h"
+#include "tasks/anymal.hpp"
 
 using namespace mi;
 
@@ -20,6 +22,7 @@ static_assert(sizeof(MiSimParams) == sizeof(SimParams), "MiSimParams layout");
 static_assert(sizeof(MiLocoParams) == sizeof(LocoParams), "MiLocoParams layout");
 static_assert(sizeof(MiCartpoleParams) == sizeof(CartpoleParams), "MiCartpoleParams layout");
 static_assert(MI_MAX_DOF == mi::kMaxDof, "MI_MAX_DOF");
+static_assert(sizeof(MiAnymalParams) == sizeof(AnymalParams), "MiAnymalParams layout");
 
 static thread_local std::string g_err;
 static int fail(const std::string& m) { g_err = m; return -1; }
@@ -103,15 +106,24 @@ __global__ void cartpole_reward_kernel(int n, CartpoleParams p, const float* pol
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-enum TaskId { T_CARTPOLE = 0, T_ANT = 1, T_HUMANOID = 2 };
+namespace mi {  // defined in kernels_anymal.hip
+hipError_t launch_step_anymal(const View& v, const SimParams& P, const AnymalParams& tp, const AnymalTerrainDesc& T,
+                              const float* actions, int cfi, unsigned step_counter, hipStream_t s);
+hipError_t launch_simulate_anymal(const View& v, const SimParams& P, const AnymalTerrainDesc& T, hipStream_t s);
+hipError_t launch_init_anymal(const View& v, const AnymalParams& tp, const AnymalTerrainDesc& T, int max_init_level, hipStream_t s);
+hipError_t launch_reset_anymal(const View& v, const AnymalParams& tp, const AnymalTerrainDesc& T, const long long* ids, int n, hipStream_t s);
+}
+enum TaskId { T_CARTPOLE = 0, T_ANT = 1, T_HUMANOID = 2, T_ANYMAL = 3 };
+constexpr int kNumTasks = 4;
 struct TaskMeta { const char* name; int nobs, nact, nd, nb, nsens, nsph, fixed; size_t pbytes; };
 static const TaskMeta kTasks[] = {
     {"Cartpole", 4, 1, ModelCartpole::ND, ModelCartpole::NB, 0, ModelCartpole::NSPH, 1, sizeof(MiCartpoleParams)},
     {"Ant", Loco<ModelAnt::ND, 6 * ModelAnt::NSENS, false>::NOBS, ModelAnt::ND, ModelAnt::ND, ModelAnt::NB, ModelAnt::NSENS, ModelAnt::NSPH, 0, sizeof(MiLocoParams)},
     {"Humanoid", Loco<ModelHumanoid::ND, 6 * ModelHumanoid::NSENS, true>::NOBS, ModelHumanoid::ND, ModelHumanoid::ND, ModelHumanoid::NB, ModelHumanoid::NSENS, ModelHumanoid::NSPH, 0, sizeof(MiLocoParams)},
+    {"AnymalTerrain", kAnymalObs, kAnymalDof, ModelAnymal::ND, ModelAnymal::NB, 0, ModelAnymal::NSPH, 0, sizeof(MiAnymalParams)},
 };
 static int find_task(const char* t) {
-    for (int i = 0; i < 3; ++i) if (!strcmp(t, kTasks[i].name)) return i;
+    for (int i = 0; i < kNumTasks; ++i) if (!strcmp(t, kTasks[i].name)) return i;
     return -1;
 }
 
@@ -120,6 +132,9 @@ struct MiEngine {
     SimParams P;
     LocoParams loco;
     CartpoleParams cart;
+    AnymalParams anymal;
+    AnymalTerrainDesc terrain;
+    int max_init_level;
     View v;
     float clip_obs;
     int control_freq_inv;
@@ -174,6 +189,21 @@ static void build_layout(int task, int N, Layout& L, View* v, char* base) {
     o = L.add("episode_count", MI_I32, {n}, {1}, n); if (v) v->episode = (int*)P(o);
     o = L.add("episode_return", MI_F32, {n}, {1}, n); if (v) v->ep_ret = (float*)P(o);
     o = L.add("episode_stats", MI_F32, {8}, {1}, 8); if (v) v->stats = (float*)P(o);
+    if (task == T_ANYMAL) {   // anymal_terrain.py:117-168
+        const int64_t nb = m.nb;
+        o = L.add("net_contact_force", MI_F32, {n, nb, 3}, {1, 3 * n, n}, 3 * nb * n); if (v) v->netf = (float*)P(o);
+        o = L.add("commands", MI_F32, {n, 4}, {1, n}, 4 * n); if (v) v->commands = (float*)P(o);
+        o = L.add("last_actions", MI_F32, {n, nd}, {1, n}, nd * n); if (v) v->last_actions = (float*)P(o);
+        o = L.add("last_dof_vel", MI_F32, {n, nd}, {1, n}, nd * n); if (v) v->last_dof_vel = (float*)P(o);
+        o = L.add("feet_air_time", MI_F32, {n, 4}, {1, n}, 4 * n); if (v) v->feet_air_time = (float*)P(o);
+        o = L.add("episode_sums", MI_F32, {n, kAnymalSums}, {1, n}, kAnymalSums * n); if (v) v->episode_sums = (float*)P(o);
+        o = L.add("env_origins", MI_F32, {n, 3}, {1, n}, 3 * n); if (v) v->env_origins = (float*)P(o);
+        o = L.add("friction", MI_F32, {n}, {1}, n); if (v) v->friction = (float*)P(o);
+        o = L.add("terrain_levels", MI_I32, {n}, {1}, n); if (v) v->terrain_levels = (int*)P(o);
+        o = L.add("terrain_types", MI_I32, {n}, {1}, n); if (v) v->terrain_types = (int*)P(o);
+        o = L.add("episode_step_stats", MI_F32, {16}, {1}, 16); if (v) v->ep_stats = (float*)P(o);
+        o = L.add("episode_means", MI_F32, {16}, {1}, 16); if (v) v->ep_means = (float*)P(o);
+    }
     L.off = (L.off + 255) & ~size_t(255);
 }
 
@@ -208,7 +238,10 @@ extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const 
     if (!e) return fail("out of host memory");
     e->task = t; e->N = num_envs; e->steps = 0; e->control_freq_inv = 1; e->clip_obs = INFINITY;
     memcpy(&e->P, sim, sizeof(SimParams));
+    memset(&e->terrain, 0, sizeof(e->terrain));
+    e->max_init_level = 0;
     if (t == T_CARTPOLE) memcpy(&e->cart, task_params, sizeof(CartpoleParams));
+    else if (t == T_ANYMAL) memcpy(&e->anymal, task_params, sizeof(AnymalParams));
     else memcpy(&e->loco, task_params, sizeof(LocoParams));
     Layout L;
     memset(&e->v, 0, sizeof(View));
@@ -242,6 +275,25 @@ extern "C" int mi_engine_init_state(MiEngine* e, void* stream) {
     const TaskMeta& m = kTasks[e->task];
     float* d_init = nullptr;
     float root_z = 0.f, pot0 = 0.f;
+    if (e->task == T_ANYMAL) {
+        if (e->terrain.hs == nullptr) return fail("mi_engine_init_state: AnymalTerrain needs mi_engine_set_terrain first");
+        const int blocks = (e->N + 255) / 256;
+        hipLaunchKernelGGL(init_state_kernel, dim3(blocks), dim3(256), 0, s, e->v, m.nd, 3 * m.nsph, 0, m.nobs, m.nact,
+                           e->anymal.base_init_state[2], (const float*)nullptr, 0.f);
+        HIP_OK(hipGetLastError());
+        HIP_OK(launch_init_anymal(e->v, e->anymal, e->terrain, e->max_init_level, s));
+        // the constructor's reset_idx(arange(num_envs)) (anymal_terrain.py:170)
+        long long* ids = nullptr;
+        HIP_OK(hipMalloc(&ids, sizeof(long long) * e->N));
+        std::vector<long long> h(e->N);
+        for (int i = 0; i < e->N; ++i) h[i] = i;
+        HIP_OK(hipMemcpyAsync(ids, h.data(), sizeof(long long) * e->N, hipMemcpyHostToDevice, s));
+        HIP_OK(launch_reset_anymal(e->v, e->anymal, e->terrain, ids, e->N, s));
+        HIP_OK(hipStreamSynchronize(s));
+        HIP_OK(hipFree(ids));
+        e->steps = 0;
+        return 0;
+    }
     if (e->task != T_CARTPOLE) {
         HIP_OK(hipMalloc(&d_init, sizeof(float) * m.nd));
         HIP_OK(hipMemcpyAsync(d_init, e->loco.initial_dof_pos, sizeof(float) * m.nd, hipMemcpyHostToDevice, s));
@@ -267,6 +319,11 @@ extern "C" int mi_engine_step(MiEngine* e, const float* actions, void* stream) {
         case T_CARTPOLE: HIP_OK(launch_step_cartpole(e->v, e->P, e->cart, actions, e->control_freq_inv, s)); break;
         case T_ANT: HIP_OK(launch_step_ant(e->v, e->P, e->loco, actions, e->control_freq_inv, s)); break;
         case T_HUMANOID: HIP_OK(launch_step_humanoid(e->v, e->P, e->loco, actions, e->control_freq_inv, s)); break;
+        case T_ANYMAL:
+            if (e->terrain.hs == nullptr) return fail("mi_engine_step: AnymalTerrain needs mi_engine_set_terrain first");
+            // common_step_counter is incremented before the push test (anymal_terrain.py:460-462)
+            HIP_OK(launch_step_anymal(e->v, e->P, e->anymal, e->terrain, actions, e->control_freq_inv, (unsigned)(e->steps + 1), s));
+            break;
     }
     e->steps++;
     return 0;
@@ -280,6 +337,10 @@ extern "C" int mi_engine_simulate(MiEngine* e, void* stream) {
         case T_CARTPOLE: HIP_OK(launch_simulate_cartpole(e->v, e->P, s)); break;
         case T_ANT: HIP_OK(launch_simulate_ant(e->v, e->P, s)); break;
         case T_HUMANOID: HIP_OK(launch_simulate_humanoid(e->v, e->P, s)); break;
+        case T_ANYMAL:
+            if (e->terrain.hs == nullptr) return fail("mi_engine_simulate: AnymalTerrain needs mi_engine_set_terrain first");
+            HIP_OK(launch_simulate_anymal(e->v, e->P, e->terrain, s));
+            break;
     }
     return 0;
 }
@@ -293,7 +354,23 @@ extern "C" int mi_engine_reset_idx(MiEngine* e, const int64_t* env_ids, int n, v
         case T_CARTPOLE: HIP_OK(launch_reset_cartpole(e->v, (const long long*)env_ids, n, s)); break;
         case T_ANT: HIP_OK(launch_reset_ant(e->v, e->loco, (const long long*)env_ids, n, s)); break;
         case T_HUMANOID: HIP_OK(launch_reset_humanoid(e->v, e->loco, (const long long*)env_ids, n, s)); break;
+        case T_ANYMAL: HIP_OK(launch_reset_anymal(e->v, e->anymal, e->terrain, (const long long*)env_ids, n, s)); break;
     }
+    return 0;
+}
+
+extern "C" int mi_engine_set_terrain(MiEngine* e, const int16_t* height_samples, int rows, int cols, float horizontal_scale,
+                                     float vertical_scale, float border_size, const float* env_origins, int num_levels,
+                                     int num_terrains, float env_length, int max_init_level) {
+    if (!e) return fail("null engine");
+    if (e->task != T_ANYMAL) return fail("mi_engine_set_terrain: only AnymalTerrain uses a terrain");
+    if (!height_samples || !env_origins || rows < 2 || cols < 2 || num_levels < 1 || num_terrains < 1 || horizontal_scale <= 0.f)
+        return fail("mi_engine_set_terrain: bad argument");
+    e->terrain.hs = (const short*)height_samples; e->terrain.rows = rows; e->terrain.cols = cols;
+    e->terrain.hscale = horizontal_scale; e->terrain.vscale = vertical_scale; e->terrain.border = border_size;
+    e->terrain.origins = env_origins; e->terrain.levels = num_levels; e->terrain.types = num_terrains;
+    e->terrain.env_length = env_length;
+    e->max_init_level = max_init_level < 0 ? 0 : (max_init_level >= num_levels ? num_levels - 1 : max_init_level);
     return 0;
 }
 

@@ -47,6 +47,19 @@ struct View {
     int* episode;
     float* ep_ret;      // [N] running return of the current episode
     float* stats;       // [8] job statistics: sum finished returns, sum finished lengths, #finished, sum rewards, #env-steps
+    // ---- AnymalTerrain only (null otherwise)
+    float* netf;          // [3*NB][N] net contact force per body, world frame (gym net_contact_force tensor)
+    float* commands;      // [4][N] x vel, y vel, yaw vel, heading (anymal_terrain.py:140)
+    float* last_actions;  // [12][N]
+    float* last_dof_vel;  // [12][N]
+    float* feet_air_time; // [4][N]
+    float* episode_sums;  // [13][N]
+    float* env_origins;   // [3][N]
+    float* friction;      // [N] per-env shape friction (100 buckets, :236-239,279-281)
+    int* terrain_levels;  // [N]
+    int* terrain_types;   // [N]
+    float* ep_stats;      // [16] this step: sum of the 13 episode sums over resetting envs, #resets, sum terrain levels
+    float* ep_means;      // [16] extras["episode"]: rew_* means / max_episode_length_s, terrain_level mean (:421-425)
 };
 
 template <class M>
@@ -101,17 +114,27 @@ __device__ __forceinline__ void episode_stats(const View& v, int e, bool valid, 
 // One sub-step per launch keeps the kernel body loop-free around the fully unrolled dynamics: with the sub-step
 // loop inside, LLVM hoists hundreds of model literals (gfx9 VOP3 cannot encode literals, each needs an SGPR) out
 // of it and spills SGPRs; that build was observed to return run-to-run different results on gfx950.
-struct ActParams {   // pre_physics_step: tau[d] = clamp(a[d], +-clip) * gear[d] * scale for d < nact, else 0
+struct ActParams {   // pre_physics_step
+    // mode 0 (effort, ant.py:281-285): tau[d] = clamp(a[d], +-clip) * gear[d] * scale for d < nact, else 0
+    // mode 1 (PD position targets recomputed every sim step, anymal_terrain.py:443-446):
+    //         tau[d] = clip(kp * (scale * a[d] + default_pos[d] - q[d]) - kd * qd[d], +-torque_limit)
     float clip, scale;
     int nact;
-    float gear[kMaxDof];
+    int mode;
+    float kp, kd, torque_limit;
+    float gear[kMaxDof];         // mode 1: default_pos
 };
+// where a sub-step takes its efforts from
+enum ActSource { ACT_STORED_TAU = 0,      // v.tau as left by an earlier launch / gym.set_dof_actuation_force_tensor
+                 ACT_FROM_ACTIONS = 1,    // clamp the caller's row-major actions, store them in v.actions, derive tau
+                 ACT_FROM_STORED_ACTIONS = 2 };  // PD mode: re-derive tau from v.actions and the current joint state
 
 template <class M>
 constexpr bool rows_fit_lds() { return (size_t)Sim<M>::ROW_SLOTS * 64 * sizeof(float) <= 152 * 1024; }
 
-template <class M>
-__global__ __launch_bounds__(64) void substep_kernel(View v, SimParams P, ActParams ap, const float* __restrict__ actions_in) {
+template <class M, class GND>
+__global__ __launch_bounds__(64) void substep_kernel(View v, SimParams P, ActParams ap, const float* __restrict__ actions_in, int src,
+                                                     GND gnd) {
     extern __shared__ float lds_rows[];  // [ROW_SLOTS][64] when the model's rows fit (else unused, size 0)
     constexpr int ND = M::ND;
     const int e = blockIdx.x * 64 + threadIdx.x;
@@ -120,14 +143,24 @@ __global__ __launch_bounds__(64) void substep_kernel(View v, SimParams P, ActPar
     Sim<M> sim;
     load_sim(sim, v, e);
     float tau[M::NDA];
-    if (actions_in != nullptr) {         // uniform branch: first sub-step of a control step
+    if (src != ACT_STORED_TAU) {         // uniform branch
         sfor<ND>([&](auto K) MI_LAMBDA {
             constexpr int k = K;
             float t = 0.f;
             if (k < ap.nact) {
-                const float a = fminf(fmaxf(actions_in[(size_t)e * ap.nact + k], -ap.clip), ap.clip);  // vec_task.py:374
-                t = a * ap.gear[k] * ap.scale;
-                v.actions[k * N + e] = a;
+                float a;
+                if (src == ACT_FROM_ACTIONS) {
+                    a = fminf(fmaxf(actions_in[(size_t)e * ap.nact + k], -ap.clip), ap.clip);  // vec_task.py:374
+                    v.actions[k * N + e] = a;
+                } else {
+                    a = v.actions[k * N + e];
+                }
+                if (ap.mode == 0) {
+                    t = a * ap.gear[k] * ap.scale;
+                } else {
+                    const float u = ap.kp * (ap.scale * a + ap.gear[k] - sim.q[k]) - ap.kd * sim.qd[k];
+                    t = fminf(fmaxf(u, -ap.torque_limit), ap.torque_limit);
+                }
             }
             tau[k] = t;
             v.tau[k * N + e] = t;
@@ -137,11 +170,13 @@ __global__ __launch_bounds__(64) void substep_kernel(View v, SimParams P, ActPar
     }
     const float h = P.dt / (float)P.substeps;
     const Strided lamc{v.lamc + e, N}, laml{v.laml + e, N}, sensor{v.sensor + e, N}, dof_force{v.dof_force + e, N};
+    const Strided netf{GND::HEIGHTFIELD ? v.netf + e : nullptr, N};
+    const float mu_env = GND::HEIGHTFIELD ? v.friction[e] : -1.f;
     if constexpr (rows_fit_lds<M>()) {
-        sim.substep(P, tau, h, RowStore<64>(lds_rows + threadIdx.x), lamc, laml, sensor, dof_force);
+        sim.substep(P, tau, h, RowStore<64>(lds_rows + threadIdx.x), lamc, laml, sensor, dof_force, gnd, mu_env, netf);
     } else {
         float rows[Sim<M>::ROW_SLOTS];
-        sim.substep(P, tau, h, RowStore<1>{rows}, lamc, laml, sensor, dof_force);
+        sim.substep(P, tau, h, RowStore<1>{rows}, lamc, laml, sensor, dof_force, gnd, mu_env, netf);
     }
     store_sim(sim, v, e);
 }
@@ -285,18 +320,19 @@ __global__ void cartpole_reset_kernel(View v, const long long* __restrict__ ids,
     v.reset[e] = 0;
 }
 
-// launch `n_sub` physics sub-steps; the first one consumes `actions` when non-null (pre_physics_step)
-template <class M>
-hipError_t launch_substeps(const View& v, const SimParams& P, const ActParams& ap, const float* actions, int n_sub, hipStream_t s) {
+// launch `n_sub` physics sub-steps.  `first`: effort source of the first launch, `rest`: of the following ones.
+template <class M, class GND = PlaneGround>
+hipError_t launch_substeps(const View& v, const SimParams& P, const ActParams& ap, const float* actions, int n_sub, int first,
+                           int rest, hipStream_t s, const GND& gnd = GND{}) {
     constexpr size_t lds = rows_fit_lds<M>() ? (size_t)Sim<M>::ROW_SLOTS * 64 * sizeof(float) : 0;
     static bool configured = false;
     if (!configured && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)substep_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)substep_kernel<M, GND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured = true;
     }
     for (int i = 0; i < n_sub; ++i)
-        hipLaunchKernelGGL(substep_kernel<M>, dim3((v.N + 63) / 64), dim3(64), lds, s, v, P, ap, i == 0 ? actions : nullptr);
+        hipLaunchKernelGGL((substep_kernel<M, GND>), dim3((v.N + 63) / 64), dim3(64), lds, s, v, P, ap, actions, i == 0 ? first : rest, gnd);
     return hipGetLastError();
 }
 
@@ -318,7 +354,8 @@ hipError_t launch_loco_step(const View& v, const SimParams& P, const LocoParams&
     ActParams ap;
     ap.clip = tp.clip_actions; ap.scale = tp.power_scale; ap.nact = M::ND;
     for (int d = 0; d < kMaxDof; ++d) ap.gear[d] = tp.gear[d];
-    hipError_t e = launch_substeps<M>(v, P, ap, actions, cfi * P.substeps, s);
+    ap.mode = 0;
+    hipError_t e = launch_substeps<M>(v, P, ap, actions, cfi * P.substeps, ACT_FROM_ACTIONS, ACT_STORED_TAU, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((loco_post_kernel<M, HUM>), dim3((v.N + 63) / 64), dim3(64), 0, s, v, tp);
     return hipGetLastError();
@@ -326,7 +363,7 @@ hipError_t launch_loco_step(const View& v, const SimParams& P, const LocoParams&
 template <class M>
 hipError_t launch_simulate(const View& v, const SimParams& P, hipStream_t s) {
     ActParams ap{};
-    return launch_substeps<M>(v, P, ap, nullptr, P.substeps, s);
+    return launch_substeps<M>(v, P, ap, nullptr, P.substeps, ACT_STORED_TAU, ACT_STORED_TAU, s);
 }
 
 }  // namespace mi

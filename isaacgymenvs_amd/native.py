@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("MI_ENGINE_LIB") or os.path.join(_HERE, "libmi_engine.
 CSRC = os.path.join(_HERE, "csrc")
 BUILD_DIR = os.path.join(CSRC, "build")
 # one translation unit per robot model (they compile in parallel) + the C ABI
-SOURCES = ["mi_engine.hip", "kernels_cartpole.hip", "kernels_ant.hip", "kernels_humanoid.hip"]
+SOURCES = ["mi_engine.hip", "kernels_cartpole.hip", "kernels_ant.hip", "kernels_humanoid.hip", "kernels_anymal.hip"]
 MI_MAX_DOF = 32
 
 # -fno-slp-vectorize: pairing scalars into v_pk_* ops lengthens live ranges in the fully unrolled sub-step
@@ -25,7 +25,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-sign
                "-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"]
 # more spilled SGPRs than this in a physics kernel fails the build: heavy SGPR spilling was the regime in which
 # gfx950 builds of the sub-step returned run-to-run different results ("compiler regime")
-MAX_SGPR_SPILL = 128
+MAX_SGPR_SPILL = 160
 
 
 class MiSimParams(C.Structure):
@@ -50,6 +50,21 @@ class MiCartpoleParams(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("reset_dist", "max_push_effort", "max_episode_length", "clip_actions")]
 
 
+class MiAnymalParams(C.Structure):
+    _fields_ = [(n, C.c_float) for n in (
+        "lin_vel_scale", "ang_vel_scale", "dof_pos_scale", "dof_vel_scale", "height_meas_scale", "action_scale",
+        "rew_termination", "rew_lin_vel_xy", "rew_lin_vel_z", "rew_ang_vel_z", "rew_ang_vel_xy", "rew_orient", "rew_torque",
+        "rew_joint_acc", "rew_base_height", "rew_air_time", "rew_collision", "rew_stumble", "rew_action_rate", "rew_hip")] + [
+        ("command_x", C.c_float * 2), ("command_y", C.c_float * 2), ("command_yaw", C.c_float * 2),
+        ("base_init_state", C.c_float * 13), ("default_dof_pos", C.c_float * 12),
+        ("kp", C.c_float), ("kd", C.c_float), ("torque_limit", C.c_float), ("dt", C.c_float),
+        ("max_episode_length_s", C.c_float), ("max_episode_length", C.c_int32), ("push_interval", C.c_int32),
+        ("allow_knee_contacts", C.c_int32), ("decimation", C.c_int32), ("add_noise", C.c_int32)] + [
+        (n, C.c_float) for n in ("noise_lin_vel", "noise_ang_vel", "noise_gravity", "noise_dof_pos", "noise_dof_vel",
+                                 "noise_height")] + [
+        ("curriculum", C.c_int32), ("clip_actions", C.c_float), ("friction_range", C.c_float * 2), ("terrain_mu", C.c_float)]
+
+
 class MiTaskInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("num_obs", "num_actions", "num_dofs", "num_bodies", "num_sensors",
                                          "num_contact_spheres", "fixed_base", "task_params_bytes")]
@@ -63,7 +78,7 @@ class MiTensorDesc(C.Structure):
 # every symbol include/mi_engine.h declares (checked by tests/test_abi.py)
 EXPORTS = ["mi_abi_version", "mi_task_info", "mi_engine_arena_bytes", "mi_engine_create", "mi_engine_init_state",
            "mi_engine_destroy", "mi_engine_num_tensors", "mi_engine_tensor_desc", "mi_engine_step",
-           "mi_engine_reset_idx", "mi_engine_simulate", "mi_engine_set_option", "mi_engine_last_ring",
+           "mi_engine_reset_idx", "mi_engine_simulate", "mi_engine_set_option", "mi_engine_last_ring", "mi_engine_set_terrain",
            "mi_compute_locomotion_observations", "mi_compute_locomotion_reward", "mi_compute_cartpole_reward",
            "mi_last_error"]
 
@@ -195,6 +210,8 @@ def lib():
     L.mi_engine_simulate.argtypes = [C.c_void_p, C.c_void_p]
     L.mi_engine_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
     L.mi_engine_last_ring.argtypes = [C.c_void_p]
+    L.mi_engine_set_terrain.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p,
+                                        C.c_int, C.c_int, C.c_float, C.c_int]
     L.mi_compute_locomotion_observations.argtypes = [C.c_char_p, C.c_int, C.POINTER(MiLocoParams)] + [C.c_void_p] * 18
     L.mi_compute_locomotion_reward.argtypes = [C.c_char_p, C.c_int, C.POINTER(MiLocoParams)] + [C.c_void_p] * 9
     L.mi_compute_cartpole_reward.argtypes = [C.c_int, C.POINTER(MiCartpoleParams)] + [C.c_void_p] * 9
@@ -227,7 +244,7 @@ def _dtypes():
 class Engine:
     """Owns a torch uint8 arena on `device` and the native engine handle bound to it."""
 
-    def __init__(self, task, sim_params: MiSimParams, task_params, num_envs, device, seed=0, env_id_offset=0):
+    def __init__(self, task, sim_params: MiSimParams, task_params, num_envs, device, seed=0, env_id_offset=0, terrain=None):
         import torch
         L = lib()
         dev = torch.device(device)
@@ -259,6 +276,17 @@ class Engine:
             extent = 1 + sum((s - 1) * st for s, st in zip(shape, stride))
             flat = self.arena[d.byte_offset:d.byte_offset + extent * esz].view(dt)
             self.tensors[d.name.decode()] = torch.as_strided(flat, shape, stride)
+        if terrain is not None:
+            # terrain: object with heightsamples [rows, cols] int16, env_origins [levels, types, 3], horizontal_scale,
+            # vertical_scale, border_size, env_length (isaacgymenvs_amd/tasks/terrain.py) + max_init_level
+            self.height_samples = torch.as_tensor(terrain.heightsamples, dtype=torch.int16).contiguous().to(dev)
+            self.terrain_origins = torch.as_tensor(terrain.env_origins, dtype=torch.float32).contiguous().to(dev)
+            check(L.mi_engine_set_terrain(h, self.height_samples.data_ptr(), self.height_samples.shape[0],
+                                          self.height_samples.shape[1], float(terrain.horizontal_scale),
+                                          float(terrain.vertical_scale), float(terrain.border_size),
+                                          self.terrain_origins.data_ptr(), self.terrain_origins.shape[0],
+                                          self.terrain_origins.shape[1], float(terrain.env_length),
+                                          int(getattr(terrain, "max_init_level", 0))))
         with torch.cuda.device(dev):
             check(L.mi_engine_init_state(h, self._stream()))
 

@@ -14,6 +14,8 @@ MODELS = {
     "ant": dict(struct="ModelAnt", sensors=["front_left_foot", "front_right_foot", "left_back_foot", "right_back_foot"]),
     # reference humanoid.py:162-168: right_foot, left_foot
     "humanoid": dict(struct="ModelHumanoid", sensors=["right_foot", "left_foot"]),
+    # reference anymal_terrain.py: no force sensors (it reads net contact forces per body, :119)
+    "anymal": dict(struct="ModelAnymal", sensors=[]),
 }
 
 

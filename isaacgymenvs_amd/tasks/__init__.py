@@ -1,10 +1,12 @@
 """Task name -> class map (reference isaacgymenvs/tasks/__init__.py:88-114; the tasks built so far)."""
 from .ant import Ant
+from .anymal_terrain import AnymalTerrain
 from .cartpole import Cartpole
 from .humanoid import Humanoid
 
 isaacgym_task_map = {
     "Ant": Ant,
+    "AnymalTerrain": AnymalTerrain,
     "Cartpole": Cartpole,
     "Humanoid": Humanoid,
 }

@@ -120,9 +120,28 @@ class OracleEngine:
     def sph_force(self):
         return self.out[:, 6 * self.nsens + self.nd:].reshape(self.N, self.nsph, 3)
 
-    def step(self, tau):
+    def set_ground(self, height_samples, hscale, vscale, border):
+        """Height field (int16 [rows, cols], reference Terrain.height_field_raw) instead of the z = ground_z plane."""
+        creal = C.c_double if self.np_real == np.float64 else C.c_float
+
+        class OrGround(C.Structure):
+            _fields_ = [("hs", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32), ("hscale", creal), ("vscale", creal),
+                        ("border", creal)]
+        self._hs = np.ascontiguousarray(height_samples, np.int16)
+        self.ground = OrGround(_ptr(self._hs), self._hs.shape[0], self._hs.shape[1], hscale, vscale, border)
+
+    def step(self, tau, env_mu=None):
         tau = np.ascontiguousarray(tau, self.np_real).reshape(self.N, self.nd)
-        self.lib.or_step(C.byref(self.model), C.byref(self.params), self.N, _ptr(self.state), _ptr(tau), _ptr(self.out))
+        gnd = getattr(self, "ground", None)
+        if gnd is None and env_mu is None and not getattr(self, "want_netf", False):
+            self.lib.or_step(C.byref(self.model), C.byref(self.params), self.N, _ptr(self.state), _ptr(tau), _ptr(self.out))
+            return
+        if not hasattr(self, "netf"):
+            self.netf = np.zeros((self.N, self.spec.nb, 3), self.np_real)
+        mu = None if env_mu is None else np.ascontiguousarray(env_mu, self.np_real)
+        self.lib.or_step_ex(C.byref(self.model), C.byref(self.params), C.byref(gnd) if gnd is not None else None,
+                            _ptr(mu) if mu is not None else None, self.N, _ptr(self.state), _ptr(tau), _ptr(self.out),
+                            _ptr(self.netf))
 
     def dynamics(self, env=0):
         nv = self.spec.nv

@@ -300,6 +300,45 @@ static void chol_solve(int n, real L[MAXV][MAXV], const real *b, real *x) {
     for (int i = n - 1; i >= 0; i--) { real s = y[i]; for (int k = i + 1; k < n; k++) s -= L[k][i] * x[k]; x[i] = s / L[i][i]; }
 }
 
+/* Ground: the z = ground_z plane (hs == NULL) or a height field sampled on a regular grid, int16 heights, laid out
+ * like the reference's `Terrain.height_field_raw` (tasks/anymal_terrain.py:569, converted to a triangle mesh by
+ * `convert_heightfield_to_trimesh`, :575, each cell split along the (i,j)-(i+1,j+1) diagonal; vertex (i,j) sits at
+ * world (i*hscale - border, j*hscale - border, h*vscale), :208-210).  The surface used here is exactly that
+ * piecewise-linear mesh (without the slope-threshold vertex correction). */
+typedef struct {
+    const int16_t *hs; /* [rows*cols], row-major: hs[i*cols + j] */
+    int32_t rows, cols;
+    real hscale, vscale, border;
+} OrGround;
+
+/* height z and unit normal n of the surface under world (x, y) */
+static void ground_query(const OrGround *g, real ground_z, real x, real y, real *z, real *n) {
+    if (g == 0 || g->hs == 0) { *z = ground_z; n[0] = 0; n[1] = 0; n[2] = 1; return; }
+    real gx = (x + g->border) / g->hscale, gy = (y + g->border) / g->hscale;
+    int i = (int)floor(gx), j = (int)floor(gy);
+    if (i < 0) i = 0; if (i > g->rows - 2) i = g->rows - 2;
+    if (j < 0) j = 0; if (j > g->cols - 2) j = g->cols - 2;
+    real fx = gx - i, fy = gy - j;
+    if (fx < 0) fx = 0; if (fx > 1) fx = 1; if (fy < 0) fy = 0; if (fy > 1) fy = 1;
+    real h00 = g->hs[i * g->cols + j], h10 = g->hs[(i + 1) * g->cols + j], h01 = g->hs[i * g->cols + j + 1],
+         h11 = g->hs[(i + 1) * g->cols + j + 1];
+    real dzx, dzy, zz;
+    if (fx >= fy) { dzx = h10 - h00; dzy = h11 - h10; } else { dzx = h11 - h01; dzy = h01 - h00; }
+    zz = h00 + dzx * fx + dzy * fy;
+    *z = zz * g->vscale;
+    real sx = dzx * g->vscale / g->hscale, sy = dzy * g->vscale / g->hscale;
+    real inv = 1 / RSQRT(sx * sx + sy * sy + 1);
+    n[0] = -sx * inv; n[1] = -sy * inv; n[2] = inv;
+}
+
+/* contact frame: n, t1 = normalize(x - n (n.x)), t2 = n x t1   (n = z gives t1 = x, t2 = y) */
+static void contact_frame(const real *n, real *t1, real *t2) {
+    real a[3] = {1 - n[0] * n[0], -n[0] * n[1], -n[0] * n[2]};
+    real inv = 1 / RSQRT(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+    t1[0] = a[0] * inv; t1[1] = a[1] * inv; t1[2] = a[2] * inv;
+    v3cross(n, t1, t2);
+}
+
 /* J row of a world direction u at point xc (rel O) on body b */
 static void point_jac(const OrModel *m, const Work *w, int b, const real *xc, const real *u, real *J) {
     int nv = nvof(m), off = jo(m);
@@ -323,9 +362,11 @@ static void point_jac(const OrModel *m, const Work *w, int b, const real *xc, co
 /* ------------------------------------------------------------------ one env, one full step of dt
  * state layout per env:  root[13] | q[nd] | qd[nd] | lam_c[3*nsph] | lam_l[nd]
  * outputs per env:       sensor[6*nsens] | dof_force[nd] | sph_force[3*nsph] (world)
+ * optional: gnd (height field), mu_env >= 0 (per-env friction replacing the per-sphere model value), netf[3*nb]
+ * (net contact force per body, world frame, last sub-step = `contact_collection: 1`, reference AnymalTerrain.yaml:148)
  */
-static void step_env(const OrModel *m, const OrParams *p, real *root, real *q, real *qd, real *lam_c, real *lam_l,
-                     const real *tau, real *sensor, real *dof_force, real *sph_force) {
+static void step_env(const OrModel *m, const OrParams *p, const OrGround *gnd, real mu_env, real *root, real *q, real *qd,
+                     real *lam_c, real *lam_l, const real *tau, real *sensor, real *dof_force, real *sph_force, real *netf) {
     static _Thread_local Work w;
     int nv = nvof(m), off = jo(m), nd = m->nd;
     real h = p->dt / p->substeps;
@@ -373,11 +414,14 @@ static void step_env(const OrModel *m, const OrParams *p, real *root, real *q, r
             real t[3], x[3];
             m3v(w.R[b], m->sph_pos + 3 * s, t);
             x[0] = w.r[b][0] + t[0]; x[1] = w.r[b][1] + t[1]; x[2] = w.r[b][2] + t[2];
-            real dist = (root[2] + x[2]) - m->sph_rad[s] - p->ground_z;
+            real zt, dirs[3][3];
+            ground_query(gnd, p->ground_z, root[0] + x[0], root[1] + x[1], &zt, dirs[0]);
+            contact_frame(dirs[0], dirs[1], dirs[2]);
+            /* distance of the sphere to the local tangent plane of the surface */
+            real dist = ((root[2] + x[2]) - zt) * dirs[0][2] - m->sph_rad[s];
             if (dist >= p->contact_offset) { lam_c[3 * s] = lam_c[3 * s + 1] = lam_c[3 * s + 2] = 0; continue; }
-            real xc[3] = {x[0], x[1], x[2] - m->sph_rad[s]};
+            real xc[3] = {x[0] - m->sph_rad[s] * dirs[0][0], x[1] - m->sph_rad[s] * dirs[0][1], x[2] - m->sph_rad[s] * dirs[0][2]};
             real gap = dist - p->rest_offset;
-            static const real dirs[3][3] = {{0, 0, 1}, {1, 0, 0}, {0, 1, 0}};
             sph_row[s] = nrow;
             for (int k = 0; k < 3; k++) {
                 int r = nrow++;
@@ -408,7 +452,7 @@ static void step_env(const OrModel *m, const OrParams *p, real *root, real *q, r
             for (int s = 0; s < m->nsph; s++) {
                 int r0 = sph_row[s];
                 if (r0 < 0) continue;
-                real mu = (real)0.5 * (m->sph_mu[s] + p->plane_mu);
+                real mu = (real)0.5 * ((mu_env >= 0 ? mu_env : m->sph_mu[s]) + p->plane_mu);
                 { /* normal */
                     int r = r0;
                     real vn = 0;
@@ -446,21 +490,29 @@ static void step_env(const OrModel *m, const OrParams *p, real *root, real *q, r
             dof_force[d] = tau[d] - m->dof_stiffness[d] * (q[d] - m->dof_springref[d]) - m->dof_damping[d] * v[off + d] + ll / h;
         }
         for (int k = 0; k < 6 * m->nsens; k++) sensor[k] = 0;
+        if (netf) for (int k = 0; k < 3 * m->nb; k++) netf[k] = 0;
         for (int s = 0; s < m->nsph; s++) {
-            real f[3] = {0, 0, 0};
+            real f[3] = {0, 0, 0}, nrm[3] = {0, 0, 1};
+            int b = m->sph_body[s];
             if (sph_row[s] >= 0) {
                 int r0 = sph_row[s];
                 lam_c[3 * s] = lam[r0]; lam_c[3 * s + 1] = lam[r0 + 1]; lam_c[3 * s + 2] = lam[r0 + 2];
-                f[0] = lam[r0 + 1] / h; f[1] = lam[r0 + 2] / h; f[2] = lam[r0] / h;
+                real t[3], x[3], zt, t1[3], t2[3];
+                m3v(w.R[b], m->sph_pos + 3 * s, t);
+                x[0] = w.r[b][0] + t[0]; x[1] = w.r[b][1] + t[1];
+                ground_query(gnd, p->ground_z, root[0] + x[0], root[1] + x[1], &zt, nrm);
+                contact_frame(nrm, t1, t2);
+                for (int c = 0; c < 3; c++) f[c] = (nrm[c] * lam[r0] + t1[c] * lam[r0 + 1] + t2[c] * lam[r0 + 2]) / h;
+                if (netf) for (int c = 0; c < 3; c++) netf[3 * b + c] += f[c];
             }
             sph_force[3 * s] = f[0]; sph_force[3 * s + 1] = f[1]; sph_force[3 * s + 2] = f[2];
             if (sph_row[s] < 0) continue;
-            int b = m->sph_body[s];
             for (int k = 0; k < m->nsens; k++) {
                 if (m->sens_body[k] != b) continue;
                 real t[3], x[3], arm[3], tq[3], fl[3], tl[3];
                 m3v(w.R[b], m->sph_pos + 3 * s, t);
-                x[0] = w.r[b][0] + t[0]; x[1] = w.r[b][1] + t[1]; x[2] = w.r[b][2] + t[2] - m->sph_rad[s];
+                x[0] = w.r[b][0] + t[0] - m->sph_rad[s] * nrm[0]; x[1] = w.r[b][1] + t[1] - m->sph_rad[s] * nrm[1];
+                x[2] = w.r[b][2] + t[2] - m->sph_rad[s] * nrm[2];
                 arm[0] = x[0] - w.r[b][0]; arm[1] = x[1] - w.r[b][1]; arm[2] = x[2] - w.r[b][2];
                 v3cross(arm, f, tq);
                 m3tv(w.R[b], f, fl); m3tv(w.R[b], tq, tl);
@@ -498,8 +550,22 @@ void or_step(const OrModel *m, const OrParams *p, int nenv, real *state, const r
 #pragma omp parallel for schedule(static)
     for (int e = 0; e < nenv; e++) {
         real *s = state + (size_t)e * ss, *o = out + (size_t)e * os;
-        step_env(m, p, s, s + 13, s + 13 + nd, s + 13 + 2 * nd, s + 13 + 2 * nd + 3 * m->nsph, tau + (size_t)e * nd, o,
-                 o + 6 * m->nsens, o + 6 * m->nsens + nd);
+        step_env(m, p, 0, (real)-1, s, s + 13, s + 13 + nd, s + 13 + 2 * nd, s + 13 + 2 * nd + 3 * m->nsph, tau + (size_t)e * nd, o,
+                 o + 6 * m->nsens, o + 6 * m->nsens + nd, 0);
+    }
+}
+
+/* as or_step, on a height field (gnd may be NULL), with per-env friction env_mu[nenv] (NULL = model friction) and the
+ * per-body net contact forces netf[nenv][3*nb] (NULL = not wanted) */
+void or_step_ex(const OrModel *m, const OrParams *p, const OrGround *gnd, const real *env_mu, int nenv, real *state,
+                const real *tau, real *out, real *netf) {
+    int ss = or_state_size(m), os = or_out_size(m), nd = m->nd;
+#pragma omp parallel for schedule(static)
+    for (int e = 0; e < nenv; e++) {
+        real *s = state + (size_t)e * ss, *o = out + (size_t)e * os;
+        step_env(m, p, gnd, env_mu ? env_mu[e] : (real)-1, s, s + 13, s + 13 + nd, s + 13 + 2 * nd,
+                 s + 13 + 2 * nd + 3 * m->nsph, tau + (size_t)e * nd, o, o + 6 * m->nsens, o + 6 * m->nsens + nd,
+                 netf ? netf + (size_t)e * 3 * m->nb : 0);
     }
 }
 

@@ -308,3 +308,279 @@ class OracleCartpoleEnv:
                                                                self.progress_buf, p.max_episode_length)
         self.timeout_buf = (self.progress_buf.astype(f32) >= f32(p.max_episode_length) - f32(1)) & (self.reset_buf != 0)
         return self.obs_buf, self.rew_buf, self.reset_buf
+
+
+# ------------------------------------------------------------------ tasks/anymal_terrain.py
+def quat_apply(a, b):  # utils/torch_jit_utils.py:67-73
+    xyz = a[:, :3]
+    t = _cross(xyz, b) * f32(2)
+    return (b + a[:, 3:4] * t + _cross(xyz, t)).astype(f32)
+
+
+def quat_apply_yaw(quat, vec):  # anymal_terrain.py:676-681
+    qy = quat.astype(f32).copy()
+    qy[:, :2] = 0
+    n = np.maximum(np.sqrt((qy * qy).sum(-1, dtype=f32)).astype(f32), f32(1e-9))[:, None]   # normalize(), :66-67
+    return quat_apply((qy / n).astype(f32), vec.astype(f32))
+
+
+def wrap_to_pi(angles):  # anymal_terrain.py:683-687
+    # `angles %= 2*np.pi` inside @torch.jit.script is the in-place op aten::fmod_ (C semantics: sign of the dividend), NOT
+    # Python's modulo -- pinned by the golden vectors produced by the reference's own function: inputs in (-2pi, -pi) come
+    # back unwrapped.  Restated as executed, not as intended.
+    a = np.fmod(angles.astype(f32), f32(2 * np.pi)).astype(f32)
+    return (a - f32(2 * np.pi) * (a > f32(np.pi)).astype(f32)).astype(f32)
+
+
+def anymal_height_points():  # init_height_points, :487-498
+    y = f32(0.1) * np.array([-5, -4, -3, -2, -1, 1, 2, 3, 4, 5], f32)
+    x = f32(0.1) * np.array([-8, -7, -6, -5, -4, -3, -2, 2, 3, 4, 5, 6, 7, 8], f32)
+    gx, gy = np.meshgrid(x, y, indexing="ij")
+    pts = np.zeros((gx.size, 3), f32)
+    pts[:, 0], pts[:, 1] = gx.ravel(), gy.ravel()
+    return pts
+
+
+def anymal_get_heights(base_quat, root_pos, height_points, height_samples, border_size, horizontal_scale, vertical_scale):
+    """get_heights, :515-538 (trimesh branch)."""
+    n, npts = len(base_quat), len(height_points)
+    q = np.repeat(base_quat.astype(f32), npts, axis=0)
+    pts = quat_apply_yaw(q, np.tile(height_points, (n, 1))).reshape(n, npts, 3) + root_pos.astype(f32)[:, None, :]
+    pts = pts + f32(border_size)
+    pts = (pts / f32(horizontal_scale)).astype(np.int64)           # .long(): truncation toward zero
+    px = np.clip(pts[:, :, 0].reshape(-1), 0, height_samples.shape[0] - 2)
+    py = np.clip(pts[:, :, 1].reshape(-1), 0, height_samples.shape[1] - 2)
+    h = np.minimum(height_samples[px, py], height_samples[px + 1, py + 1])
+    return h.reshape(n, npts).astype(f32) * f32(vertical_scale)
+
+
+ANYMAL_SUM_KEYS = ("lin_vel_xy", "lin_vel_z", "ang_vel_z", "ang_vel_xy", "orient", "torques", "joint_acc", "base_height",
+                   "air_time", "collision", "stumble", "action_rate", "hip")
+
+
+def anymal_compute_reward(p, commands, base_lin_vel, base_ang_vel, projected_gravity, root_z, torques, last_dof_vel, dof_vel,
+                          contact_forces, knee_indices, feet_indices, last_actions, actions, feet_air_time, dof_pos,
+                          default_dof_pos, reset_buf, timeout_buf):
+    """compute_reward, :315-382.  Returns (rew_buf, terms dict in ANYMAL_SUM_KEYS order, new feet_air_time).
+    `p` carries the dt-scaled reward scales (MiAnymalParams)."""
+    def sq(x):
+        return (x * x).astype(f32)
+    lin_vel_error = (sq(commands[:, 0] - base_lin_vel[:, 0]) + sq(commands[:, 1] - base_lin_vel[:, 1])).astype(f32)
+    ang_vel_error = sq(commands[:, 2] - base_ang_vel[:, 2])
+    t = {}
+    t["lin_vel_xy"] = np.exp(-lin_vel_error / f32(0.25)).astype(f32) * f32(p.rew_lin_vel_xy)
+    t["ang_vel_z"] = np.exp(-ang_vel_error / f32(0.25)).astype(f32) * f32(p.rew_ang_vel_z)
+    t["lin_vel_z"] = sq(base_lin_vel[:, 2]) * f32(p.rew_lin_vel_z)
+    t["ang_vel_xy"] = (sq(base_ang_vel[:, 0]) + sq(base_ang_vel[:, 1])) * f32(p.rew_ang_vel_xy)
+    t["orient"] = (sq(projected_gravity[:, 0]) + sq(projected_gravity[:, 1])) * f32(p.rew_orient)
+    t["base_height"] = sq(root_z - f32(0.52)) * f32(p.rew_base_height)
+    st = np.zeros(len(root_z), f32); sa = st.copy(); sr = st.copy()
+    for d in range(torques.shape[1]):   # sequential fp32 sums, like the kernel
+        st = st + sq(torques[:, d]); sa = sa + sq(last_dof_vel[:, d] - dof_vel[:, d]); sr = sr + sq(last_actions[:, d] - actions[:, d])
+    t["torques"] = st * f32(p.rew_torque)
+    t["joint_acc"] = sa * f32(p.rew_joint_acc)
+    cf = contact_forces.astype(f32)
+    knee_norm = np.sqrt((sq(cf[:, knee_indices, 0]) + sq(cf[:, knee_indices, 1])) + sq(cf[:, knee_indices, 2])).astype(f32)
+    knee_contact = knee_norm > f32(1.)
+    t["collision"] = knee_contact.sum(1).astype(f32) * f32(p.rew_collision)
+    feet = cf[:, feet_indices, :]
+    stumble = (np.sqrt(sq(feet[:, :, 0]) + sq(feet[:, :, 1])).astype(f32) > f32(5.)) & (np.abs(feet[:, :, 2]) < f32(1.))
+    t["stumble"] = stumble.sum(1).astype(f32) * f32(p.rew_stumble)
+    t["action_rate"] = sr * f32(p.rew_action_rate)
+    contact = feet[:, :, 2] > f32(1.)
+    first_contact = (feet_air_time > 0.) & contact
+    air = (feet_air_time + f32(p.dt)).astype(f32)
+    ar = np.zeros(len(root_z), f32)
+    for k in range(4):
+        ar = ar + (air[:, k] - f32(0.5)) * first_contact[:, k].astype(f32)
+    ar = ar * f32(p.rew_air_time)
+    ar = ar * (np.sqrt(sq(commands[:, 0]) + sq(commands[:, 1])).astype(f32) > f32(0.1)).astype(f32)
+    t["air_time"] = ar.astype(f32)
+    air = (air * (~contact).astype(f32)).astype(f32)
+    hip = np.zeros(len(root_z), f32)
+    for j in (0, 3, 6, 9):
+        hip = hip + np.abs(dof_pos[:, j] - default_dof_pos[:, j])
+    t["hip"] = hip.astype(f32) * f32(p.rew_hip)
+    total = (t["lin_vel_xy"] + t["ang_vel_z"] + t["lin_vel_z"] + t["ang_vel_xy"] + t["orient"] + t["base_height"] +
+             t["torques"] + t["joint_acc"] + t["collision"] + t["action_rate"] + t["air_time"] + t["hip"] + t["stumble"]).astype(f32)
+    total = np.maximum(total, f32(0.))
+    total = total + f32(p.rew_termination) * (reset_buf & ~timeout_buf).astype(f32)
+    return total.astype(f32), t, air
+
+
+def _anymal_rand_step(seed, genv, step, k):
+    return mi_uniform(np.uint32(seed) ^ np.uint32(0x5bd1e995), genv, step, k)
+
+
+class OracleAnymalTerrainEnv:
+    """vec_task.py:360-408 + anymal_terrain.py pre/post_physics_step on oracle/physics.c with the height-field ground."""
+
+    def __init__(self, spec, sim_params: dict, params, terrain, num_envs, seed=0, env_id_offset=0, precision="f64",
+                 control_freq_inv=1):
+        from .engine import OracleEngine
+        self.N, self.p, self.nd, self.spec = num_envs, params, spec.nd, spec
+        self.eng = OracleEngine(spec, num_envs, params=sim_params, precision=precision)
+        self.eng.set_ground(terrain.heightsamples, terrain.horizontal_scale, terrain.vertical_scale, terrain.border_size)
+        self.eng.want_netf = True
+        self.terrain = terrain
+        self.seed, self.off, self.cfi = fold_seed(seed), env_id_offset, control_freq_inv
+        p, N = params, num_envs
+        self.hs = np.asarray(terrain.heightsamples)
+        self.origins_tab = np.asarray(terrain.env_origins, f32)
+        self.levels_n, self.types_n = self.origins_tab.shape[:2]
+        genv = (self.off + np.arange(N)).astype(np.uint32)
+        self.genv = genv
+        mil = int(getattr(terrain, "max_init_level", 0))
+        lv = (mi_uniform(np.uint32(self.seed) ^ np.uint32(0x1234567), genv, 0, 0) * f32(mil + 1)).astype(np.int32)
+        self.terrain_levels = np.minimum(lv, mil)
+        ty = (mi_uniform(np.uint32(self.seed) ^ np.uint32(0x1234567), genv, 0, 1) * f32(self.types_n)).astype(np.int32)
+        self.terrain_types = np.minimum(ty, self.types_n - 1)
+        self.env_origins = self.origins_tab[self.terrain_levels, self.terrain_types].copy()
+        fr = p.friction_range
+        self.friction = ((f32(fr[1]) - f32(fr[0])) * mi_uniform(np.uint32(self.seed) ^ np.uint32(0x7654321), genv % np.uint32(100), 0, 0)
+                         + f32(fr[0])).astype(f32)
+        self.default_dof_pos = np.tile(np.array(p.default_dof_pos[:], f32), (N, 1))
+        self.base_init_state = np.array(p.base_init_state[:], f32)
+        self.commands = np.zeros((N, 4), f32)
+        self.last_actions = np.zeros((N, self.nd), f32)
+        self.last_dof_vel = np.zeros((N, self.nd), f32)
+        self.feet_air_time = np.zeros((N, 4), f32)
+        self.episode_sums = {k: np.zeros(N, f32) for k in ANYMAL_SUM_KEYS}
+        self.torques = np.zeros((N, self.nd), f32)
+        self.actions = np.zeros((N, self.nd), f32)
+        self.progress_buf = np.zeros(N, np.int64)
+        self.reset_buf = np.ones(N, np.int64)
+        self.timeout_buf = np.zeros(N, bool)
+        self.episode = np.zeros(N, np.uint32)
+        self.common_step_counter = 0
+        self.height_points = anymal_height_points()
+        self.feet_indices = np.array([i for i, n in enumerate(spec.body_names) if "SHANK" in n])
+        self.knee_indices = np.array([i for i, n in enumerate(spec.body_names) if "THIGH" in n])
+        self.extras = {}
+        self.init_done = False
+        self.reset_idx(np.arange(N))   # :170
+        self.init_done = True
+
+    def reset_idx(self, ids):  # :384-425
+        if len(ids) == 0:
+            return
+        p, nd = self.p, self.nd
+        genv = self.genv[ids][:, None]
+        ep = self.episode[ids][:, None]
+        k = np.arange(nd, dtype=np.uint32)[None, :]
+        off = (f32(1.5) - f32(0.5)) * mi_uniform(self.seed, genv, ep, k) + f32(0.5)
+        vel = (f32(0.1) - f32(-0.1)) * mi_uniform(self.seed, genv, ep, k + np.uint32(nd)) + f32(-0.1)
+        self.eng.q[ids] = self.default_dof_pos[ids] * off
+        self.eng.qd[ids] = vel
+        self.update_terrain_level(ids)
+        root = np.tile(self.base_init_state, (len(ids), 1))
+        root[:, :3] += self.env_origins[ids]
+        g1, e1 = genv[:, 0], ep[:, 0]
+        root[:, 0] += (f32(0.5) - f32(-0.5)) * mi_uniform(self.seed, g1, e1, 2 * nd + 0) + f32(-0.5)
+        root[:, 1] += (f32(0.5) - f32(-0.5)) * mi_uniform(self.seed, g1, e1, 2 * nd + 1) + f32(-0.5)
+        self.eng.root[ids] = root
+        self.eng.lam[ids, :3 * len(self.spec.sph_body)] = 0
+        c = self.commands
+        c[ids, 0] = (f32(p.command_x[1]) - f32(p.command_x[0])) * mi_uniform(self.seed, g1, e1, 2 * nd + 2) + f32(p.command_x[0])
+        c[ids, 1] = (f32(p.command_y[1]) - f32(p.command_y[0])) * mi_uniform(self.seed, g1, e1, 2 * nd + 3) + f32(p.command_y[0])
+        c[ids, 3] = (f32(p.command_yaw[1]) - f32(p.command_yaw[0])) * mi_uniform(self.seed, g1, e1, 2 * nd + 4) + f32(p.command_yaw[0])
+        keep = (np.sqrt(c[ids, 0] * c[ids, 0] + c[ids, 1] * c[ids, 1]).astype(f32) > f32(0.25)).astype(f32)
+        c[ids] *= keep[:, None]
+        self.last_actions[ids] = 0
+        self.last_dof_vel[ids] = 0
+        self.feet_air_time[ids] = 0
+        self.progress_buf[ids] = 0
+        self.reset_buf[ids] = 1
+        self.extras["episode"] = {}
+        for key in ANYMAL_SUM_KEYS:
+            self.extras["episode"]["rew_" + key] = f32(np.mean(self.episode_sums[key][ids], dtype=f32)) / f32(p.max_episode_length_s)
+            self.episode_sums[key][ids] = 0
+        self.extras["episode"]["terrain_level"] = f32(np.mean(self.terrain_levels.astype(f32), dtype=f32))
+        self.episode[ids] += 1
+
+    def update_terrain_level(self, ids):  # :427-435
+        if not self.init_done or not self.p.curriculum:
+            return
+        root = self.eng.root.astype(f32)
+        d = root[ids, :2] - self.env_origins[ids, :2]
+        distance = np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(f32)
+        c = self.commands[ids, :2]
+        cn = f32(np.sqrt(np.sum((c * c).astype(f32), dtype=f32)))       # norm over ALL resetting envs (batch coupled)
+        lv = self.terrain_levels[ids].copy()
+        lv -= (distance < cn * f32(self.p.max_episode_length_s) * f32(0.25)).astype(np.int32)
+        lv += (distance > f32(self.terrain.env_length) / f32(2)).astype(np.int32)
+        lv = np.maximum(lv, 0) % self.levels_n
+        self.terrain_levels[ids] = lv
+        self.env_origins[ids] = self.origins_tab[lv, self.terrain_types[ids]]
+
+    def step(self, actions):
+        p = self.p
+        a = np.clip(actions.astype(f32), -f32(p.clip_actions), f32(p.clip_actions))     # vec_task.py:374
+        self.actions = a.copy()
+        for _ in range(p.decimation):                                                    # :441-451
+            q, qd = self.eng.q.astype(f32), self.eng.qd.astype(f32)
+            tq = np.clip(f32(p.kp) * (f32(p.action_scale) * a + self.default_dof_pos - q) - f32(p.kd) * qd, f32(-p.torque_limit), f32(p.torque_limit))
+            self.torques = tq.astype(f32)
+            self.eng.step(self.torques, env_mu=self.friction)
+        for _ in range(self.cfi):                                                        # vec_task.py:379-382
+            self.eng.step(self.torques, env_mu=self.friction)
+        return self.post_physics_step()
+
+    def post_physics_step(self):  # :453-485
+        p, N = self.p, self.N
+        self.progress_buf += 1
+        self.common_step_counter += 1
+        sc = np.uint32(self.common_step_counter)
+        if p.push_interval > 0 and self.common_step_counter % p.push_interval == 0:
+            sk = sc | np.uint32(0x80000000)
+            self.eng.root[:, 7] = f32(2) * _anymal_rand_step(self.seed, self.genv, sk, 0) - f32(1)
+            self.eng.root[:, 8] = f32(2) * _anymal_rand_step(self.seed, self.genv, sk, 1) - f32(1)
+        root = self.eng.root.astype(f32)
+        base_quat = root[:, 3:7]
+        base_lin_vel = quat_rotate(base_quat, root[:, 7:10], inverse=True)
+        base_ang_vel = quat_rotate(base_quat, root[:, 10:13], inverse=True)
+        gravity_vec = np.tile(np.array([0, 0, -1], f32), (N, 1))
+        projected_gravity = quat_rotate(base_quat, gravity_vec, inverse=True)
+        forward = quat_apply(base_quat, np.tile(np.array([1, 0, 0], f32), (N, 1)))
+        heading = np.arctan2(forward[:, 1], forward[:, 0]).astype(f32)
+        self.commands[:, 2] = np.clip(f32(0.5) * wrap_to_pi(self.commands[:, 3] - heading), f32(-1), f32(1))
+        cf = self.eng.netf.astype(f32)
+        # check_termination (:294-300)
+        rs = np.sqrt((cf[:, 0, 0] ** 2 + cf[:, 0, 1] ** 2) + cf[:, 0, 2] ** 2).astype(f32) > f32(1.)
+        if not p.allow_knee_contacts:
+            kn = np.sqrt((cf[:, self.knee_indices, 0] ** 2 + cf[:, self.knee_indices, 1] ** 2) + cf[:, self.knee_indices, 2] ** 2)
+            rs |= (kn.astype(f32) > f32(1.)).any(1)
+        rs = np.where(self.progress_buf >= p.max_episode_length - 1, True, rs)
+        self.reset_buf = rs
+        q, qd = self.eng.q.astype(f32), self.eng.qd.astype(f32)
+        self.rew_buf, terms, self.feet_air_time = anymal_compute_reward(
+            p, self.commands, base_lin_vel, base_ang_vel, projected_gravity, root[:, 2], self.torques, self.last_dof_vel, qd, cf,
+            self.knee_indices, self.feet_indices, self.last_actions, self.actions, self.feet_air_time, q, self.default_dof_pos,
+            self.reset_buf, self.timeout_buf)
+        for key in ANYMAL_SUM_KEYS:
+            self.episode_sums[key] = (self.episode_sums[key] + terms[key]).astype(f32)
+        ids = np.nonzero(self.reset_buf)[0]
+        self.reset_idx(ids)
+        # compute_observations (:302-313): base velocities / gravity are the pre-reset ones, pose and dofs post-reset
+        root = self.eng.root.astype(f32)
+        q, qd = self.eng.q.astype(f32), self.eng.qd.astype(f32)
+        mh = anymal_get_heights(root[:, 3:7], root[:, :3], self.height_points, self.hs, self.terrain.border_size,
+                                self.terrain.horizontal_scale, self.terrain.vertical_scale)
+        heights = np.clip(root[:, 2:3] - f32(0.5) - mh, f32(-1), f32(1.)) * f32(p.height_meas_scale)
+        cs = np.array([p.lin_vel_scale, p.lin_vel_scale, p.ang_vel_scale], f32)
+        obs = np.concatenate([base_lin_vel * f32(p.lin_vel_scale), base_ang_vel * f32(p.ang_vel_scale), projected_gravity,
+                              self.commands[:, :3] * cs, q * f32(p.dof_pos_scale), qd * f32(p.dof_vel_scale), heights, self.actions],
+                             axis=-1).astype(f32)
+        self.obs_clean = obs.copy()
+        if p.add_noise:
+            nv = np.zeros(188, f32)
+            nv[0:3] = p.noise_lin_vel; nv[3:6] = p.noise_ang_vel; nv[6:9] = p.noise_gravity
+            nv[12:24] = p.noise_dof_pos; nv[24:36] = p.noise_dof_vel; nv[36:176] = p.noise_height
+            k = (np.arange(188, dtype=np.uint32) + np.uint32(16))[None, :]
+            u = _anymal_rand_step(self.seed, self.genv[:, None], sc | np.uint32(0x80000000), k)
+            obs = (obs + (f32(2) * u - f32(1)) * nv[None, :]).astype(f32)
+        self.obs_buf = obs
+        self.last_actions = self.actions.copy()
+        self.last_dof_vel = qd.copy()
+        self.timeout_buf = (self.progress_buf >= p.max_episode_length - 1) & (self.reset_buf != 0)    # vec_task.py:394
+        return self.obs_buf, self.rew_buf, self.reset_buf.astype(np.int64)

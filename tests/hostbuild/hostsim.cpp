@@ -5,6 +5,7 @@
 #include "../../isaacgymenvs_amd/csrc/core/engine.hpp"
 #include "../../isaacgymenvs_amd/csrc/gen/model_cartpole.h"
 #include "../../isaacgymenvs_amd/csrc/gen/model_ant.h"
+#include "../../isaacgymenvs_amd/csrc/gen/model_anymal.h"
 #ifndef HOSTSIM_NO_HUMANOID
 #include "../../isaacgymenvs_amd/csrc/gen/model_humanoid.h"
 #endif
@@ -37,5 +38,29 @@ extern "C" int hs_step(const char* model, const SimParams* P, int nenv, float* s
     else if (!strcmp(model, "humanoid")) run<ModelHumanoid>(P, nenv, state, tau, out);
 #endif
     else return -1;
+    return 0;
+}
+
+// height-field variant (AnymalTerrain): per-env friction mu[nenv], net contact forces netf[nenv][3*NB]
+extern "C" int hs_step_terrain(const char* model, const SimParams* P, int nenv, float* state, const float* tau, float* out,
+                               const short* hs, int rows, int cols, float hscale, float vscale, float border, const float* mu,
+                               float* netf) {
+    if (strcmp(model, "anymal")) return -1;
+    using M = ModelAnymal;
+    constexpr int ND = M::ND, NSPH = M::NSPH, NSENS = M::NSENS;
+    const int ss = 13 + 2 * ND + 3 * NSPH + ND, os = 6 * NSENS + ND + 3 * NSPH;
+    const HeightfieldGround g{hs, rows, cols, hscale, vscale, border};
+#pragma omp parallel for schedule(static)
+    for (int e = 0; e < nenv; ++e) {
+        float* s = state + (size_t)e * ss;
+        float* o = out + (size_t)e * os;
+        Sim<M> sim;
+        for (int k = 0; k < 13; ++k) sim.root[k] = s[k];
+        for (int k = 0; k < ND; ++k) { sim.q[k] = s[13 + k]; sim.qd[k] = s[13 + ND + k]; }
+        sim.step_terrain(*P, tau + (size_t)e * ND, s + 13 + 2 * ND, s + 13 + 2 * ND + 3 * NSPH, o, o + 6 * NSENS, g, mu[e],
+                         netf + (size_t)e * 3 * M::NB);
+        for (int k = 0; k < 13; ++k) s[k] = sim.root[k];
+        for (int k = 0; k < ND; ++k) { s[13 + k] = sim.q[k]; s[13 + ND + k] = sim.qd[k]; }
+    }
     return 0;
 }

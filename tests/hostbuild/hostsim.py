@@ -46,3 +46,14 @@ def step(lib, model, params, state, tau, out):
     rc = lib.hs_step(model.encode(), C.byref(params), state.shape[0], state.ctypes.data_as(C.c_void_p),
                      tau.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
     assert rc == 0
+
+
+def step_terrain(lib, model, params, state, tau, out, hs, hscale, vscale, border, mu, netf):
+    hs = np.ascontiguousarray(hs, np.int16)
+    lib.hs_step_terrain.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                    C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    rc = lib.hs_step_terrain(model.encode(), C.cast(C.byref(params), C.c_void_p), state.shape[0], state.ctypes.data_as(C.c_void_p),
+                             tau.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), hs.ctypes.data_as(C.c_void_p),
+                             hs.shape[0], hs.shape[1], hscale, vscale, border, mu.ctypes.data_as(C.c_void_p),
+                             netf.ctypes.data_as(C.c_void_p))
+    assert rc == 0

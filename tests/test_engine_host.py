@@ -58,3 +58,41 @@ def test_host_build_of_engine_core_matches_oracle(task, z_lo, z_hi, gear, full):
         if len(sb):
             assert np.abs(out[:, :6 * len(sb)] - orc.sensor).max() < 2e-3 * max(1.0, np.abs(orc.sensor).max())
         assert np.abs(out[:, 6 * len(sb):6 * len(sb) + nd] - orc.dof_force).max() < 2e-3 * max(1.0, np.abs(orc.dof_force).max())
+
+
+def test_host_build_on_heightfield_matches_oracle():
+    """ANYmal on a random rough height field: general contact normals, per-env friction, per-body net contact forces."""
+    spec = load_model("anymal")
+    n = 128
+    lib = hostsim.build()
+    rng = np.random.default_rng(3)
+    rows, cols, hscale, vscale, border = 120, 140, 0.1, 0.005, 2.0
+    hs = (rng.integers(-30, 30, (rows // 4 + 1, cols // 4 + 1)).repeat(4, 0).repeat(4, 1)[:rows, :cols]
+          + rng.integers(-6, 6, (rows, cols))).astype(np.int16)
+    sim = dict(SIM, dt=0.005, substeps=1, iters=5, max_depen_vel=100.0)
+    root, q, qd = _random_state(spec, n, rng, 0.25, 0.7)
+    root[:, 0] = rng.uniform(1, 8, n); root[:, 1] = rng.uniform(1, 10, n)
+    q = rng.uniform(-1.0, 1.0, (n, spec.nd))
+    tau = rng.uniform(-80, 80, (n, spec.nd))
+    mu = rng.uniform(0.5, 1.25, n).astype(np.float32)
+    orc = OracleEngine(spec, n, params=sim, precision="f64")
+    orc.set_ground(hs, hscale, vscale, border)
+    orc.root[:] = root; orc.q[:] = q; orc.qd[:] = qd
+    nd, nsph = spec.nd, len(spec.sph_body)
+    st = np.zeros((n, 13 + 2 * nd + 3 * nsph + nd), np.float32)
+    st[:, :13] = root; st[:, 13:13 + nd] = q; st[:, 13 + nd:13 + 2 * nd] = qd
+    out = np.zeros((n, nd + 3 * nsph), np.float32)
+    netf = np.zeros((n, spec.nb, 3), np.float32)
+    p = hostsim.make_params(sim)
+    tau32 = np.ascontiguousarray(tau, np.float32)
+    contacts = 0
+    for it in range(4):
+        hostsim.step_terrain(lib, "anymal", p, st, tau32, out, hs, hscale, vscale, border, mu, netf)
+        orc.step(tau, env_mu=mu)
+        scale = max(1.0, np.abs(orc.qd).max())
+        e = max(np.abs(st[:, :13] - orc.root).max(), np.abs(st[:, 13:13 + nd] - orc.q).max(),
+                np.abs(st[:, 13 + nd:13 + 2 * nd] - orc.qd).max())
+        assert e < 5e-4 * scale * (it + 1), (it, e)
+        assert np.abs(netf - orc.netf).max() < 2e-3 * max(1.0, np.abs(orc.netf).max())
+        contacts += int((np.abs(orc.netf).sum(-1) > 0).sum())
+    assert contacts > 50   # the scenario does exercise contacts

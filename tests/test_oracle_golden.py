@@ -64,3 +64,72 @@ def test_reset_rng_is_uniform_and_deterministic():
     a = T.mi_uniform(7, np.uint32(64 + 36), np.uint32(0), np.arange(8, dtype=np.uint32))
     b = T.mi_uniform(7, np.uint32(100), np.uint32(0), np.arange(8, dtype=np.uint32))
     np.testing.assert_array_equal(a, b)
+
+
+# ------------------------------------------------------------------ AnymalTerrain (reference methods run on a mock self)
+def _anymal_golden(golden_dir):
+    return dict(np.load(os.path.join(golden_dir, "anymal_terrain.npz")))
+
+
+class _P:  # the dt-scaled reward scales the reference used for the golden run (tools/gen_golden.py)
+    pass
+
+
+def _anymal_params(g):
+    p = _P()
+    for k in ("termination", "lin_vel_xy", "lin_vel_z", "ang_vel_z", "ang_vel_xy", "orient", "torque", "joint_acc", "base_height",
+              "air_time", "collision", "stumble", "action_rate", "hip"):
+        setattr(p, "rew_" + k, float(g["scale_" + k]))
+    p.dt = 0.02
+    return p
+
+
+def test_anymal_helpers_match_reference(golden_dir):
+    from oracle import tasks as T
+    g = _anymal_golden(golden_dir)
+    np.testing.assert_allclose(T.wrap_to_pi(g["heading_in"]), g["wrapped"], atol=1e-6)
+    n = len(g["root_states"])
+    q = np.repeat(g["root_states"][:, 3:7], 140, axis=0)
+    pts = T.quat_apply_yaw(q, np.tile(g["height_points"], (n, 1)))
+    np.testing.assert_allclose(pts.reshape(n, 140, 3), g["yaw_points"], atol=2e-6)
+    np.testing.assert_array_equal(T.anymal_height_points(), g["height_points"])
+
+
+def test_anymal_heights_and_observations_match_reference(golden_dir):
+    from oracle import tasks as T
+    from isaacgymenvs_amd.tasks.terrain import Terrain
+    from isaacgymenvs_amd.utils.config import compose
+    g = _anymal_golden(golden_dir)
+    cfg = compose(overrides=["task=AnymalTerrain"])["task"]
+    ter = Terrain(cfg["env"]["terrain"], num_robots=len(g["root_states"]), seed=int(g["terrain_seed"]))
+    root = g["root_states"]
+    mh = T.anymal_get_heights(root[:, 3:7], root[:, :3], T.anymal_height_points(), ter.heightsamples, ter.border_size,
+                              ter.horizontal_scale, ter.vertical_scale)
+    # a height-scan point exactly on a grid line can fall into the neighbouring cell after fp32 rounding: allow a handful
+    bad = np.abs(mh - g["measured_heights"]) > 1e-6
+    assert bad.mean() < 2e-3, bad.mean()
+    learn = cfg["env"]["learn"]
+    heights = np.clip(root[:, 2:3] - np.float32(0.5) - g["measured_heights"], -1, 1) * np.float32(learn["heightMeasurementScale"])
+    obs = np.concatenate([g["base_lin_vel"] * np.float32(2.0), g["base_ang_vel"] * np.float32(0.25), g["projected_gravity"],
+                          g["commands"][:, :3] * np.array([2.0, 2.0, 0.25], np.float32), g["dof_pos"] * np.float32(1.0),
+                          g["dof_vel"] * np.float32(0.05), heights, g["actions"]], axis=-1)
+    np.testing.assert_allclose(obs, g["obs"], atol=1e-6)
+
+
+def test_anymal_reward_matches_reference(golden_dir):
+    from oracle import tasks as T
+    g = _anymal_golden(golden_dir)
+    p = _anymal_params(g)
+    # check_termination (anymal_terrain.py:294-300) with allowKneeContacts = True
+    cf = g["contact_forces"]
+    rs = np.linalg.norm(cf[:, 0, :], axis=1) > 1.0
+    rs = np.where(g["progress"] >= 1000 - 1, True, rs)
+    np.testing.assert_array_equal(rs, g["reset"])
+    rew, terms, air = T.anymal_compute_reward(
+        p, g["commands"], g["base_lin_vel"], g["base_ang_vel"], g["projected_gravity"], g["root_states"][:, 2], g["torques"],
+        g["last_dof_vel"], g["dof_vel"], cf, g["knee_indices"], g["feet_indices"], g["last_actions"], g["actions"],
+        g["feet_air_time_in"], g["dof_pos"], g["default_dof_pos"], g["reset"], g["timeout_in"])
+    np.testing.assert_allclose(rew, g["rew"], atol=2e-6)
+    np.testing.assert_allclose(air, g["feet_air_time_out"], atol=1e-7)
+    for k in T.ANYMAL_SUM_KEYS:
+        np.testing.assert_allclose(terms[k], g["sum_" + k], atol=2e-6, err_msg=k)

@@ -20,6 +20,9 @@ ENTRIES = {
     "ant": dict(file="mjcf/nv_ant.xml"),
     # reference humanoid.py:142-157
     "humanoid": dict(file="mjcf/nv_humanoid.xml"),
+    # reference anymal_terrain.py:214-231: collapse_fixed_joints, replace_cylinder_with_capsule, density 0.001 (only used
+    # for links without <inertial>), armature 0, fix_base_link False
+    "anymal": dict(file="urdf/anymal_c/urdf/anymal_minimal.urdf", density=0.001, replace_cylinder_with_capsule=True),
 }
 
 

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(64) void k(int n, SimParams P, float* state, const 
     const float h = P.dt / (float)P.substeps;
     for (int ss = 0; ss < P.substeps; ++ss)
         sim.substep(P, t, h, RowStore<64>(lds_rows + threadIdx.x), Strided{s + 13 + 2 * ND, 1}, Strided{s + 13 + 2 * ND + 3 * NSPH, 1},
-                    Strided{outb, 1}, Strided{outb + 6 * NSENS, 1});
+                    Strided{outb, 1}, Strided{outb + 6 * NSENS, 1}, PlaneGround{}, -1.f, Strided{nullptr, 1});
     for (int i = 0; i < 13; ++i) s[i] = sim.root[i];
     for (int i = 0; i < ND; ++i) { s[13 + i] = sim.q[i]; s[13 + ND + i] = sim.qd[i]; }
 }

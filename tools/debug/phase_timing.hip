@@ -26,8 +26,8 @@ __global__ __launch_bounds__(64) void k(int N, SimParams P, float* root, float* 
     sim.tstamp = (threadIdx.x == 0) ? stamps + blockIdx.x * 16 : nullptr;
     const float h = P.dt / (float)P.substeps;
     const Strided a{lamc + e, N}, b{laml + e, N}, c{sens + e, N}, d{dff + e, N};
-    if constexpr (LDS_ROWS) sim.substep(P, t, h, RowStore<64>(lds_rows + threadIdx.x), a, b, c, d);
-    else { float rows[Sim<M>::ROW_SLOTS]; sim.substep(P, t, h, RowStore<1>{rows}, a, b, c, d); }
+    if constexpr (LDS_ROWS) sim.substep(P, t, h, RowStore<64>(lds_rows + threadIdx.x), a, b, c, d, PlaneGround{}, -1.f, Strided{nullptr, 1});
+    else { float rows[Sim<M>::ROW_SLOTS]; sim.substep(P, t, h, RowStore<1>{rows}, a, b, c, d, PlaneGround{}, -1.f, Strided{nullptr, 1}); }
     for (int i = 0; i < 13; ++i) root[i * N + e] = sim.root[i];
     for (int i = 0; i < ND; ++i) { dof[i * N + e] = sim.q[i]; dof[(ND + i) * N + e] = sim.qd[i]; }
 }

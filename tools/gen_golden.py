@@ -12,6 +12,8 @@ Functions captured:
   isaacgymenvs/tasks/humanoid.py:323   compute_humanoid_reward
   isaacgymenvs/tasks/humanoid.py:378   compute_humanoid_observations
   isaacgymenvs/tasks/cartpole.py:180   compute_cartpole_reward
+  isaacgymenvs/tasks/anymal_terrain.py:294,302,315,515   AnymalTerrain.check_termination / compute_observations /
+                                       compute_reward / get_heights (bound to a mock `self`), :676 quat_apply_yaw, :683 wrap_to_pi
 """
 import importlib
 import os
@@ -31,8 +33,10 @@ def import_reference():
     stub = ("class _Dummy:\n    def __init__(self, *a, **k):\n        pass\n    def __call__(self, *a, **k):\n        return _Dummy()\n"
             "    def __getattr__(self, n):\n        return _Dummy()\n\ndef __getattr__(name):\n    return _Dummy()\n")
     os.makedirs(os.path.join(tmp, "isaacgym"))
-    for m in ("gymapi", "gymutil", "terrain_utils"):
+    for m in ("gymapi", "gymutil"):
         open(os.path.join(tmp, "isaacgym", m + ".py"), "w").write(stub)
+    # `from isaacgym.terrain_utils import *` (anymal_terrain.py:542): the module is absent from the reference tree
+    open(os.path.join(tmp, "isaacgym", "terrain_utils.py"), "w").write("__all__ = []\n")
     open(os.path.join(tmp, "isaacgym", "__init__.py"), "w").write("from . import gymapi, gymutil, gymtorch, terrain_utils\n" + stub)
     open(os.path.join(tmp, "isaacgym", "gymtorch.py"), "w").write(
         "def wrap_tensor(x):\n    return x\n\ndef unwrap_tensor(x):\n    return x\n")
@@ -47,7 +51,7 @@ def import_reference():
         mod = types.ModuleType(name)
         mod.__path__ = [os.path.join(REF, rel)]
         sys.modules[name] = mod
-    return {n: importlib.import_module("isaacgymenvs.tasks." + n) for n in ("ant", "humanoid", "cartpole")}
+    return {n: importlib.import_module("isaacgymenvs.tasks." + n) for n in ("ant", "humanoid", "cartpole", "anymal_terrain")}
 
 
 def rand_quat(g, n):
@@ -126,6 +130,100 @@ def cartpole_case(mod, n, seed):
     print("cartpole_reward", n, "resets", int(reset.sum()))
 
 
+def anymal_case(mod, n, seed):
+    """Run the reference's own AnymalTerrain methods on a mock `self` holding random-but-plausible tensors."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from isaacgymenvs_amd.tasks.terrain import Terrain
+    from isaacgymenvs_amd.utils.config import compose
+    from isaacgymenvs_amd.registry import load_model
+    cfg = compose(overrides=["task=AnymalTerrain"])["task"]
+    learn = cfg["env"]["learn"]
+    spec = load_model("anymal")
+    terrain = Terrain(cfg["env"]["terrain"], num_robots=n, seed=7)
+    g = torch.Generator().manual_seed(seed)
+    A = mod.AnymalTerrain
+    dt = 0.02
+    m = types.SimpleNamespace()
+    m.cfg = cfg
+    m.device = "cpu"
+    m.num_envs = n
+    m.dt = dt
+    m.terrain = terrain
+    m.height_samples = torch.tensor(terrain.heightsamples).view(terrain.tot_rows, terrain.tot_cols)
+    m.num_height_points = 140
+    m.height_points = A.init_height_points(m)
+    keys = {"termination": "terminalReward", "lin_vel_xy": "linearVelocityXYRewardScale", "lin_vel_z": "linearVelocityZRewardScale",
+            "ang_vel_z": "angularVelocityZRewardScale", "ang_vel_xy": "angularVelocityXYRewardScale", "orient": "orientationRewardScale",
+            "torque": "torqueRewardScale", "joint_acc": "jointAccRewardScale", "base_height": "baseHeightRewardScale",
+            "air_time": "feetAirTimeRewardScale", "collision": "kneeCollisionRewardScale", "stumble": "feetStumbleRewardScale",
+            "action_rate": "actionRateRewardScale", "hip": "hipRewardScale"}
+    # non-zero values for the scales the shipped YAML sets to 0, so every term is exercised
+    over = {"termination": -1.0, "orient": -1.0, "base_height": -5.0, "stumble": -2.0, "hip": -0.25}
+    m.rew_scales = {k: float(over.get(k, learn[v])) * dt for k, v in keys.items()}
+    m.lin_vel_scale, m.ang_vel_scale = learn["linearVelocityScale"], learn["angularVelocityScale"]
+    m.dof_pos_scale, m.dof_vel_scale = learn["dofPositionScale"], learn["dofVelocityScale"]
+    m.height_meas_scale = learn["heightMeasurementScale"]
+    m.commands_scale = torch.tensor([m.lin_vel_scale, m.lin_vel_scale, m.ang_vel_scale])
+    m.max_episode_length = 1000
+    m.allow_knee_contacts = True
+    m.base_index = 0
+    m.knee_indices = torch.tensor([i for i, nm in enumerate(spec.body_names) if "THIGH" in nm])
+    m.feet_indices = torch.tensor([i for i, nm in enumerate(spec.body_names) if "SHANK" in nm])
+    root = torch.zeros(n, 13)
+    root[:, 0] = torch.rand(n, generator=g) * 80.0
+    root[:, 1] = torch.rand(n, generator=g) * 160.0
+    root[:, 2] = 0.55 + 0.3 * torch.randn(n, generator=g)
+    root[:, 3:7] = torch.nn.functional.normalize(torch.tensor([0.0, 0.0, 0.0, 1.0]) + 0.4 * torch.randn(n, 4, generator=g), dim=-1)
+    root[:, 7:13] = torch.randn(n, 6, generator=g)
+    m.root_states = root
+    m.base_quat = root[:, 3:7]
+    tj = importlib.import_module("isaacgymenvs.utils.torch_jit_utils")
+    m.base_lin_vel = tj.quat_rotate_inverse(m.base_quat, root[:, 7:10])
+    m.base_ang_vel = tj.quat_rotate_inverse(m.base_quat, root[:, 10:13])
+    m.projected_gravity = tj.quat_rotate_inverse(m.base_quat, torch.tensor([0.0, 0.0, -1.0]).repeat(n, 1))
+    m.commands = torch.rand(n, 4, generator=g) * 2 - 1
+    m.commands[: n // 8] *= 0.05
+    heading = torch.rand(n, generator=g) * 20 - 10
+    wrapped = mod.wrap_to_pi(heading.clone())
+    m.dof_pos = torch.randn(n, 12, generator=g) * 0.5
+    m.dof_vel = torch.randn(n, 12, generator=g) * 3
+    m.last_dof_vel = m.dof_vel + torch.randn(n, 12, generator=g)
+    m.default_dof_pos = torch.tensor([cfg["env"]["defaultJointAngles"][nm] for nm in spec.dof_names], dtype=torch.float32).repeat(n, 1)
+    m.torques = torch.randn(n, 12, generator=g) * 30
+    m.actions = torch.rand(n, 12, generator=g) * 2 - 1
+    m.last_actions = torch.rand(n, 12, generator=g) * 2 - 1
+    cf = torch.randn(n, 13, 3, generator=g) * 3.0
+    cf[:, :, 2] = cf[:, :, 2].abs() * (torch.rand(n, 13, generator=g) < 0.5)
+    cf[:, 0] *= (torch.rand(n, 1, generator=g) < 0.15)
+    m.contact_forces = cf
+    m.feet_air_time = torch.rand(n, 4, generator=g) * (torch.rand(n, 4, generator=g) < 0.7)
+    m.progress_buf = torch.randint(0, 1002, (n,), generator=g)
+    m.progress_buf[:4] = torch.tensor([997, 998, 999, 1000])
+    m.timeout_buf = torch.rand(n, generator=g) < 0.05
+    m.episode_sums = {k: torch.zeros(n) for k in ("lin_vel_xy", "lin_vel_z", "ang_vel_z", "ang_vel_xy", "orient", "torques",
+                                                  "joint_acc", "base_height", "air_time", "collision", "stumble", "action_rate", "hip")}
+    m.get_heights = lambda env_ids=None: A.get_heights(m, env_ids)
+    inp = dict(root_states=root.clone(), commands=m.commands.clone(), dof_pos=m.dof_pos.clone(), dof_vel=m.dof_vel.clone(),
+               last_dof_vel=m.last_dof_vel.clone(), torques=m.torques.clone(), actions=m.actions.clone(),
+               last_actions=m.last_actions.clone(), contact_forces=cf.clone(), feet_air_time_in=m.feet_air_time.clone(),
+               progress=m.progress_buf.clone(), timeout_in=m.timeout_buf.clone(), base_lin_vel=m.base_lin_vel.clone(),
+               base_ang_vel=m.base_ang_vel.clone(), projected_gravity=m.projected_gravity.clone(), heading_in=heading, wrapped=wrapped,
+               default_dof_pos=m.default_dof_pos.clone())
+    A.check_termination(m)
+    reset = m.reset_buf.clone()
+    A.compute_reward(m)
+    A.compute_observations(m)
+    yaw_pts = mod.quat_apply_yaw(m.base_quat.repeat(1, 140), m.height_points)
+    out = dict(inp, reset=reset, rew=m.rew_buf, feet_air_time_out=m.feet_air_time, obs=m.obs_buf, measured_heights=m.measured_heights,
+               yaw_points=yaw_pts, height_points=m.height_points[0], knee_indices=m.knee_indices, feet_indices=m.feet_indices,
+               **{"sum_" + k: v for k, v in m.episode_sums.items()})
+    out = {k: (v.numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in out.items()}
+    out.update({"scale_" + k: np.float64(v) for k, v in m.rew_scales.items()})
+    out["terrain_seed"] = np.int64(7)
+    np.savez_compressed(os.path.join(OUT, "anymal_terrain.npz"), **out)
+    print("anymal_terrain", n, "resets", int(reset.sum()), "rew mean", float(m.rew_buf.mean()), "obs", tuple(m.obs_buf.shape))
+
+
 def main():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     from isaacgymenvs_amd.registry import load_model
@@ -144,6 +242,7 @@ def main():
     locomotion_case(mods["ant"], "ant_obs_reward", 8, 24, 512, 1, False, a_lo, a_up, list(ant.act_gear), ant_s)
     locomotion_case(mods["humanoid"], "humanoid_obs_reward", 21, 12, 512, 2, True, h_lo, h_up, list(hum.act_gear), hum_s)
     cartpole_case(mods["cartpole"], 512, 3)
+    anymal_case(mods["anymal_terrain"], 256, 4)
 
 
 if __name__ == "__main__":
