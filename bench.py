@@ -33,8 +33,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 # API-visible state read once + written once per env-step
-ALGO_BYTES = {"Cartpole": 89, "Ant": 673, "Humanoid": 1161}
-DEFAULT_ENVS = {"Cartpole": 64, "Ant": 4096, "Humanoid": 8192}
+ALGO_BYTES = {"Cartpole": 89, "Ant": 673, "Humanoid": 1161, "AnymalTerrain": 2240}
+DEFAULT_ENVS = {"Cartpole": 64, "Ant": 4096, "Humanoid": 8192, "AnymalTerrain": 4096}
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 # HBM-side bytes per control step from the round-1 PMC passes (profiles/r1_pmc_summary.md): raw FETCH_SIZE + WRITE_SIZE
 # (KB -> B) summed over the launches of one step (2 sub-steps + post) at the BASELINE env counts.  The raw fetch counter
@@ -114,7 +114,7 @@ def roofline(task, num_envs, kernel_ms):
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
     traffic = PMC_TRAFFIC_BYTES.get((task, num_envs))
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "kernel": "mi::substep_kernel<Model%s> (x substeps) + post kernel = one step" % task,
+            "traffic": traffic, "kernel": "mi::substep_kernel<%s> (x sim steps) + post kernel = one step" % task,
             "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
             "note": "latency/issue-bound path: %d waves of 64 envs, one per CU; see DESIGN.md" % ((num_envs + 63) // 64)}
 
@@ -178,9 +178,10 @@ def main():
     n_env = args.num_envs or DEFAULT_ENVS[args.task]
 
     main_res = measure(args.task, n_env, args.steps, args.warmup, device, rank, world)
-    extra = None
+    extra = extra2 = None
     if not args.no_extra and args.task == "Ant":
         extra = measure("Humanoid", DEFAULT_ENVS["Humanoid"], max(args.steps // 4, 10), max(args.warmup // 4, 5), device, rank, world)
+        extra2 = measure("AnymalTerrain", DEFAULT_ENVS["AnymalTerrain"], max(args.steps // 4, 10), max(args.warmup // 4, 5), device, rank, world)
     if rank != 0:
         if world > 1:
             import torch.distributed as dist
@@ -205,6 +206,11 @@ def main():
         out["extra"] = {"workload": f"Humanoid num_envs={DEFAULT_ENVS['Humanoid']} per GPU", "value": extra["env_steps_per_s"],
                         "unit": "env-steps/s", "ms_per_step": extra["ms_per_step"], "reset_rate": extra["reset_rate"],
                         "roofline": roofline("Humanoid", DEFAULT_ENVS["Humanoid"], extra["kernel_ms_avg"])}
+    if extra2 is not None:
+        out["extra2"] = {"workload": f"AnymalTerrain num_envs={DEFAULT_ENVS['AnymalTerrain']} per GPU (5 sim steps of 5 ms per control step)",
+                         "value": extra2["env_steps_per_s"], "unit": "env-steps/s", "ms_per_step": extra2["ms_per_step"],
+                         "reset_rate": extra2["reset_rate"],
+                         "roofline": roofline("AnymalTerrain", DEFAULT_ENVS["AnymalTerrain"], extra2["kernel_ms_avg"])}
     if world == 1 and not args.no_cpu_baseline and args.task in ("Ant", "Humanoid"):
         out["cpu_baseline"] = cpu_baseline(args.task, n_env, budget_s=args.cpu_budget)
     print(json.dumps(out), flush=True)

@@ -85,6 +85,16 @@ typedef struct {
     float terrain_mu;
 } MiAnymalParams;
 
+/* scalars of compute_hand_reward (shadow_hand.py:746-756) */
+typedef struct {
+    float max_episode_length;
+    float dist_reward_scale, rot_reward_scale, rot_eps, action_penalty_scale;
+    float success_tolerance, reach_goal_bonus, fall_dist, fall_penalty;
+    int32_t max_consecutive_successes;
+    float av_factor;
+    int32_t ignore_z_rot;
+} MiHandRewardParams;
+
 typedef struct {
     int32_t num_obs, num_actions, num_dofs, num_bodies, num_sensors, num_contact_spheres, fixed_base, task_params_bytes;
 } MiTaskInfo;
@@ -166,6 +176,26 @@ int mi_compute_locomotion_reward(const char* task, int n, const MiLocoParams* p,
 int mi_compute_cartpole_reward(int n, const MiCartpoleParams* p, const float* pole_angle, const float* pole_vel,
                                const float* cart_vel, const float* cart_pos, const int64_t* reset_buf_in,
                                const int64_t* progress_buf, float* rew_buf, int64_t* reset_buf_out, void* stream);
+
+/* ---- ShadowHand task functions (the hand/cube physics is not in the engine yet; these run on caller tensors) ------- */
+/* compute_hand_reward (shadow_hand.py:746-800).  rew_buf out; reset_buf, reset_goal_buf, progress_buf (int64), successes
+ * (fp32 [n]) and consecutive_successes (fp32 [1]) are updated IN PLACE = the tuple the jitted function returns.
+ * workspace2: 2 floats of device scratch for the cross-env sums (:792-793). */
+int mi_compute_hand_reward(int n, const MiHandRewardParams* p, float* rew_buf, int64_t* reset_buf, int64_t* reset_goal_buf,
+                           int64_t* progress_buf, float* successes, float* consecutive_successes, const float* object_pos,
+                           const float* object_rot, const float* target_pos, const float* target_rot, const float* actions,
+                           int num_actions, float* workspace2, void* stream);
+/* compute_full_state (shadow_hand.py:528-584): writes 3*num_dofs + 24 + 19*num_fingertips + num_actions floats per env
+ * (211 for the Shadow hand) into obs_buf rows of `obs_stride` floats.  object_state [n,13], goal_pose [n,7],
+ * fingertip_state [n,nf,13], fingertip_force_torque [n,6*nf]; all row-major contiguous. */
+int mi_compute_hand_full_state(int n, int num_dofs, int num_fingertips, int num_actions, float vel_obs_scale,
+                               float force_torque_obs_scale, const float* dof_pos, const float* dof_vel, const float* dof_force,
+                               const float* dof_lower, const float* dof_upper, const float* object_state, const float* goal_pose,
+                               const float* fingertip_state, const float* fingertip_force_torque, const float* actions,
+                               float* obs_buf, int obs_stride, void* stream);
+/* randomize_rotation (shadow_hand.py:803-806): out_quat [n,4] = q(rand0*pi, x_unit) * q(rand1*pi, y_unit) */
+int mi_randomize_rotation(int n, const float* rand0, const float* rand1, const float* x_unit, const float* y_unit, float* out_quat,
+                          void* stream);
 
 const char* mi_last_error(void);
 

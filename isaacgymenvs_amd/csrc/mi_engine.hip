@@ -15,6 +15,7 @@
 #include "gen/model_humanoid.h"
 #include "gen/model_anymal.h"
 #include "tasks/anymal.hpp"
+#include "tasks/shadow_hand.hpp"
 
 using namespace mi;
 
@@ -23,6 +24,7 @@ static_assert(sizeof(MiLocoParams) == sizeof(LocoParams), "MiLocoParams layout")
 static_assert(sizeof(MiCartpoleParams) == sizeof(CartpoleParams), "MiCartpoleParams layout");
 static_assert(MI_MAX_DOF == mi::kMaxDof, "MI_MAX_DOF");
 static_assert(sizeof(MiAnymalParams) == sizeof(AnymalParams), "MiAnymalParams layout");
+static_assert(sizeof(MiHandRewardParams) == sizeof(HandRewardParams), "MiHandRewardParams layout");
 
 static thread_local std::string g_err;
 static int fail(const std::string& m) { g_err = m; return -1; }
@@ -103,6 +105,71 @@ __global__ void cartpole_reward_kernel(int n, CartpoleParams p, const float* pol
     float r; long long rs;
     cartpole_reward(p, pole_angle[e], pole_vel[e], cart_vel[e], cart_pos[e], reset_in[e], progress[e], &r, &rs);
     rew[e] = r; reset_out[e] = rs;
+}
+
+// ------------------------------------------------------------------------------------------------ ShadowHand jit-fn replacements
+__global__ void hand_reward_kernel(int n, HandRewardParams p, const float* object_pos, const float* object_rot, const float* target_pos,
+                                   const float* target_rot, const float* actions, int nact, float* rew, long long* reset_buf,
+                                   long long* reset_goal_buf, long long* progress_buf, float* successes, float* ws /* [2] */) {
+    const int e0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = e0 < n;
+    const int e = valid ? e0 : n - 1;
+    float r, succ;
+    long long rs, gr, prog;
+    hand_reward(p, object_pos + (size_t)e * 3, object_rot + (size_t)e * 4, target_pos + (size_t)e * 3, target_rot + (size_t)e * 4,
+                actions + (size_t)e * nact, nact, reset_buf[e], reset_goal_buf[e], progress_buf[e], successes[e], &r, &rs, &gr, &prog, &succ);
+    float nres = valid ? (float)rs : 0.f, fin = valid ? succ * (float)rs : 0.f;
+    for (int o = 32; o > 0; o >>= 1) { nres += __shfl_xor(nres, o, 64); fin += __shfl_xor(fin, o, 64); }
+    if ((threadIdx.x & 63) == 0 && nres > 0.f) { atomicAdd(ws, nres); atomicAdd(ws + 1, fin); }
+    if (!valid) return;
+    rew[e] = r; reset_buf[e] = rs; reset_goal_buf[e] = gr; progress_buf[e] = prog; successes[e] = succ;
+}
+// consecutive_successes moving average over the whole batch (shadow_hand.py:792-797)
+__global__ void hand_reward_finalize_kernel(HandRewardParams p, const float* ws, float* consecutive_successes) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float num_resets = ws[0], finished = ws[1], cs = consecutive_successes[0];
+        consecutive_successes[0] = (num_resets > 0.f) ? p.av_factor * finished / num_resets + (1.0f - p.av_factor) * cs : cs;
+    }
+}
+// compute_full_state (shadow_hand.py:528-584): 3*nd | obj pose 7, linvel 3, angvel*s 3 | goal pose 7, quat diff 4 |
+// fingertip states 13*nf | fingertip force-torques*s 6*nf | actions
+__global__ void hand_full_state_kernel(int n, int nd, int nf, int nact, float vel_obs_scale, float ft_scale, const float* dof_pos,
+                                       const float* dof_vel, const float* dof_force, const float* lower, const float* upper,
+                                       const float* object_state /* [n,13] */, const float* goal_pose /* [n,7] */,
+                                       const float* fingertip_state /* [n,nf,13] */, const float* sensors /* [n,6nf] */,
+                                       const float* actions, float* obs, int obs_stride) {
+    MI_NO_CONTRACT
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float* o = obs + (size_t)e * obs_stride;
+    for (int d = 0; d < nd; ++d) {
+        o[d] = (2.0f * dof_pos[(size_t)e * nd + d] - upper[d] - lower[d]) / (upper[d] - lower[d]);   // unscale, torch_jit_utils.py:239
+        o[nd + d] = vel_obs_scale * dof_vel[(size_t)e * nd + d];
+        o[2 * nd + d] = ft_scale * dof_force[(size_t)e * nd + d];
+    }
+    const float* os = object_state + (size_t)e * 13;
+    int k = 3 * nd;
+    for (int i = 0; i < 7; ++i) o[k + i] = os[i];
+    for (int i = 0; i < 3; ++i) o[k + 7 + i] = os[7 + i];
+    for (int i = 0; i < 3; ++i) o[k + 10 + i] = vel_obs_scale * os[10 + i];
+    k += 13;
+    const float* gp = goal_pose + (size_t)e * 7;
+    for (int i = 0; i < 7; ++i) o[k + i] = gp[i];
+    float conj[4], qd[4];
+    quat_conjugate(gp + 3, conj);
+    quat_mul(os + 3, conj, qd);
+    for (int i = 0; i < 4; ++i) o[k + 7 + i] = qd[i];
+    k += 11;
+    for (int i = 0; i < 13 * nf; ++i) o[k + i] = fingertip_state[(size_t)e * 13 * nf + i];
+    k += 13 * nf;
+    for (int i = 0; i < 6 * nf; ++i) o[k + i] = ft_scale * sensors[(size_t)e * 6 * nf + i];
+    k += 6 * nf;
+    for (int i = 0; i < nact; ++i) o[k + i] = actions[(size_t)e * nact + i];
+}
+__global__ void randomize_rotation_kernel(int n, const float* rand0, const float* rand1, const float* x_unit, const float* y_unit, float* out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    randomize_rotation(rand0[e], rand1[e], x_unit + (size_t)e * 3, y_unit + (size_t)e * 3, out + (size_t)e * 4);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -429,6 +496,45 @@ extern "C" int mi_compute_cartpole_reward(int n, const MiCartpoleParams* p, cons
     memcpy(&cp, p, sizeof(cp));
     hipLaunchKernelGGL(cartpole_reward_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, n, cp, pole_angle, pole_vel,
                        cart_vel, cart_pos, (const long long*)reset_in, (const long long*)progress, rew, (long long*)reset_out);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mi_compute_hand_reward(int n, const MiHandRewardParams* p, float* rew_buf, int64_t* reset_buf, int64_t* reset_goal_buf,
+                                      int64_t* progress_buf, float* successes, float* consecutive_successes, const float* object_pos,
+                                      const float* object_rot, const float* target_pos, const float* target_rot, const float* actions,
+                                      int num_actions, float* workspace2, void* stream) {
+    if (n <= 0) return 0;
+    if (!p || !workspace2) return fail("mi_compute_hand_reward: null argument");
+    HandRewardParams hp;
+    memcpy(&hp, p, sizeof(hp));
+    hipStream_t s = (hipStream_t)stream;
+    HIP_OK(hipMemsetAsync(workspace2, 0, 2 * sizeof(float), s));
+    hipLaunchKernelGGL(hand_reward_kernel, dim3((n + 63) / 64), dim3(64), 0, s, n, hp, object_pos, object_rot, target_pos, target_rot, actions,
+                       num_actions, rew_buf, (long long*)reset_buf, (long long*)reset_goal_buf, (long long*)progress_buf, successes, workspace2);
+    hipLaunchKernelGGL(hand_reward_finalize_kernel, dim3(1), dim3(64), 0, s, hp, workspace2, consecutive_successes);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mi_compute_hand_full_state(int n, int num_dofs, int num_fingertips, int num_actions, float vel_obs_scale,
+                                          float force_torque_obs_scale, const float* dof_pos, const float* dof_vel, const float* dof_force,
+                                          const float* dof_lower, const float* dof_upper, const float* object_state, const float* goal_pose,
+                                          const float* fingertip_state, const float* fingertip_force_torque, const float* actions,
+                                          float* obs_buf, int obs_stride, void* stream) {
+    if (n <= 0) return 0;
+    if (obs_stride < 3 * num_dofs + 24 + 19 * num_fingertips + num_actions) return fail("mi_compute_hand_full_state: obs_stride too small");
+    hipLaunchKernelGGL(hand_full_state_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, n, num_dofs, num_fingertips, num_actions,
+                       vel_obs_scale, force_torque_obs_scale, dof_pos, dof_vel, dof_force, dof_lower, dof_upper, object_state, goal_pose,
+                       fingertip_state, fingertip_force_torque, actions, obs_buf, obs_stride);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mi_randomize_rotation(int n, const float* rand0, const float* rand1, const float* x_unit, const float* y_unit, float* out_quat,
+                                     void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(randomize_rotation_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, n, rand0, rand1, x_unit, y_unit, out_quat);
     HIP_OK(hipGetLastError());
     return 0;
 }

@@ -65,6 +65,13 @@ class MiAnymalParams(C.Structure):
         ("curriculum", C.c_int32), ("clip_actions", C.c_float), ("friction_range", C.c_float * 2), ("terrain_mu", C.c_float)]
 
 
+class MiHandRewardParams(C.Structure):
+    _fields_ = [("max_episode_length", C.c_float), ("dist_reward_scale", C.c_float), ("rot_reward_scale", C.c_float),
+                ("rot_eps", C.c_float), ("action_penalty_scale", C.c_float), ("success_tolerance", C.c_float),
+                ("reach_goal_bonus", C.c_float), ("fall_dist", C.c_float), ("fall_penalty", C.c_float),
+                ("max_consecutive_successes", C.c_int32), ("av_factor", C.c_float), ("ignore_z_rot", C.c_int32)]
+
+
 class MiTaskInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("num_obs", "num_actions", "num_dofs", "num_bodies", "num_sensors",
                                          "num_contact_spheres", "fixed_base", "task_params_bytes")]
@@ -80,6 +87,7 @@ EXPORTS = ["mi_abi_version", "mi_task_info", "mi_engine_arena_bytes", "mi_engine
            "mi_engine_destroy", "mi_engine_num_tensors", "mi_engine_tensor_desc", "mi_engine_step",
            "mi_engine_reset_idx", "mi_engine_simulate", "mi_engine_set_option", "mi_engine_last_ring", "mi_engine_set_terrain",
            "mi_compute_locomotion_observations", "mi_compute_locomotion_reward", "mi_compute_cartpole_reward",
+           "mi_compute_hand_reward", "mi_compute_hand_full_state", "mi_randomize_rotation",
            "mi_last_error"]
 
 
@@ -215,6 +223,9 @@ def lib():
     L.mi_compute_locomotion_observations.argtypes = [C.c_char_p, C.c_int, C.POINTER(MiLocoParams)] + [C.c_void_p] * 18
     L.mi_compute_locomotion_reward.argtypes = [C.c_char_p, C.c_int, C.POINTER(MiLocoParams)] + [C.c_void_p] * 9
     L.mi_compute_cartpole_reward.argtypes = [C.c_int, C.POINTER(MiCartpoleParams)] + [C.c_void_p] * 9
+    L.mi_compute_hand_reward.argtypes = [C.c_int, C.POINTER(MiHandRewardParams)] + [C.c_void_p] * 11 + [C.c_int, C.c_void_p, C.c_void_p]
+    L.mi_compute_hand_full_state.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float] + [C.c_void_p] * 11 + [C.c_int, C.c_void_p]
+    L.mi_randomize_rotation.argtypes = [C.c_int] + [C.c_void_p] * 6
     _lib = L
     return L
 

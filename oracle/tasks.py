@@ -584,3 +584,73 @@ class OracleAnymalTerrainEnv:
         self.last_dof_vel = qd.copy()
         self.timeout_buf = (self.progress_buf >= p.max_episode_length - 1) & (self.reset_buf != 0)    # vec_task.py:394
         return self.obs_buf, self.rew_buf, self.reset_buf.astype(np.int64)
+
+
+# ------------------------------------------------------------------ tasks/shadow_hand.py
+def quat_conjugate(a):  # torch_jit_utils.py:107-110
+    return np.concatenate([-a[:, :3], a[:, 3:4]], axis=-1).astype(f32)
+
+
+def compute_hand_reward(rew_buf, reset_buf, reset_goal_buf, progress_buf, successes, consecutive_successes, max_episode_length,
+                        object_pos, object_rot, target_pos, target_rot, dist_reward_scale, rot_reward_scale, rot_eps, actions,
+                        action_penalty_scale, success_tolerance, reach_goal_bonus, fall_dist, fall_penalty,
+                        max_consecutive_successes, av_factor, ignore_z_rot):
+    """shadow_hand.py:746-800, fp32."""
+    d = (object_pos - target_pos).astype(f32)
+    goal_dist = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]).astype(f32)
+    tol = f32(success_tolerance)
+    if ignore_z_rot:
+        tol = f32(2.0) * tol
+    qd = quat_mul(object_rot.astype(f32), quat_conjugate(target_rot.astype(f32)))
+    vn = np.sqrt((qd[:, 0] * qd[:, 0] + qd[:, 1] * qd[:, 1]) + qd[:, 2] * qd[:, 2]).astype(f32)
+    rot_dist = (f32(2.0) * np.arcsin(np.minimum(vn, f32(1.0)))).astype(f32)
+    dist_rew = goal_dist * f32(dist_reward_scale)
+    rot_rew = (f32(1.0) / (np.abs(rot_dist) + f32(rot_eps)) * f32(rot_reward_scale)).astype(f32)
+    ap = np.zeros(len(goal_dist), f32)
+    for i in range(actions.shape[1]):
+        ap = ap + actions[:, i].astype(f32) * actions[:, i].astype(f32)
+    reward = (dist_rew + rot_rew + ap * f32(action_penalty_scale)).astype(f32)
+    hit = np.abs(rot_dist) <= tol
+    goal_resets = np.where(hit, 1, reset_goal_buf).astype(np.int64)
+    successes = (successes.astype(f32) + goal_resets.astype(f32)).astype(f32)
+    reward = np.where(goal_resets == 1, reward + f32(reach_goal_bonus), reward).astype(f32)
+    fell = goal_dist >= f32(fall_dist)
+    reward = np.where(fell, reward + f32(fall_penalty), reward).astype(f32)
+    resets = np.where(fell, 1, reset_buf).astype(np.int64)
+    progress = progress_buf.copy()
+    if max_consecutive_successes > 0:
+        progress = np.where(hit, 0, progress)
+        resets = np.where(successes >= max_consecutive_successes, 1, resets)
+    timeout = progress.astype(f32) >= f32(max_episode_length) - f32(1)
+    resets = np.where(timeout, 1, resets).astype(np.int64)
+    if max_consecutive_successes > 0:
+        reward = np.where(timeout, reward + f32(0.5) * f32(fall_penalty), reward).astype(f32)
+    num_resets = f32(resets.sum())
+    fin = f32(np.sum(successes * resets.astype(f32), dtype=f32))
+    cs = f32(consecutive_successes)
+    cons = f32(av_factor) * fin / num_resets + (f32(1.0) - f32(av_factor)) * cs if num_resets > 0 else cs
+    return reward, resets, goal_resets, progress, successes, f32(cons)
+
+
+def quat_from_angle_axis(angle, axis):  # torch_jit_utils.py:119-123
+    theta = (angle.astype(f32) / f32(2))[:, None]
+    n = np.maximum(np.sqrt((axis * axis).sum(-1, dtype=f32)).astype(f32), f32(1e-9))[:, None]
+    xyz = (axis.astype(f32) / n) * np.sin(theta).astype(f32)
+    q = np.concatenate([xyz, np.cos(theta).astype(f32)], axis=-1).astype(f32)
+    m = np.maximum(np.sqrt((q * q).sum(-1, dtype=f32)).astype(f32), f32(1e-9))[:, None]
+    return (q / m).astype(f32)
+
+
+def randomize_rotation(rand0, rand1, x_unit, y_unit):  # shadow_hand.py:803-806
+    return quat_mul(quat_from_angle_axis(rand0.astype(f32) * f32(np.pi), x_unit), quat_from_angle_axis(rand1.astype(f32) * f32(np.pi), y_unit))
+
+
+def compute_hand_full_state(dof_pos, dof_vel, dof_force, lower, upper, object_state, goal_pose, fingertip_state, sensors, actions,
+                            vel_obs_scale, ft_scale):
+    """compute_full_state, shadow_hand.py:528-584 (asymm_obs False branch)."""
+    n = len(dof_pos)
+    cols = [unscale(dof_pos.astype(f32), lower.astype(f32), upper.astype(f32)), f32(vel_obs_scale) * dof_vel.astype(f32),
+            f32(ft_scale) * dof_force.astype(f32), object_state[:, 0:7], object_state[:, 7:10], f32(vel_obs_scale) * object_state[:, 10:13],
+            goal_pose, quat_mul(object_state[:, 3:7].astype(f32), quat_conjugate(goal_pose[:, 3:7].astype(f32))),
+            fingertip_state.reshape(n, -1), f32(ft_scale) * sensors.astype(f32), actions]
+    return np.concatenate([c.astype(f32) for c in cols], axis=-1)

@@ -97,6 +97,51 @@ def test_cartpole_reward_kernel_matches_reference(golden_dir):
     np.testing.assert_allclose(rew.cpu().numpy(), g["rew"], rtol=1e-6, atol=1e-6)
 
 
+# ------------------------------------------------------------------ ShadowHand task functions vs reference golden vectors
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_hand_reward_kernel_matches_reference(golden_dir, tag):
+    g = dict(np.load(os.path.join(golden_dir, "shadow_hand.npz")))
+    sc = {k[len(tag) + 8:]: float(v) for k, v in g.items() if k.startswith(tag + "_scalar_")}
+    p = native.MiHandRewardParams(max_episode_length=sc["max_episode_length"], dist_reward_scale=sc["dist_reward_scale"],
+                                  rot_reward_scale=sc["rot_reward_scale"], rot_eps=sc["rot_eps"],
+                                  action_penalty_scale=sc["action_penalty_scale"], success_tolerance=sc["success_tolerance"],
+                                  reach_goal_bonus=sc["reach_goal_bonus"], fall_dist=sc["fall_dist"], fall_penalty=sc["fall_penalty"],
+                                  max_consecutive_successes=int(sc["max_consecutive_successes"]), av_factor=sc["av_factor"],
+                                  ignore_z_rot=int(sc["ignore_z_rot"]))
+    n = len(g["object_pos"])
+    rew = torch.zeros(n, device=DEV)
+    rb, rg, pr = _t(g["reset_buf"], torch.int64), _t(g["reset_goal_buf"], torch.int64), _t(g["progress"], torch.int64)
+    su, cs = _t(g["successes"]), _t(g["cons"].reshape(1))
+    ws = torch.zeros(2, device=DEV)
+    ins = [_t(g[k]) for k in ("object_pos", "object_rot", "target_pos", "target_rot", "actions")]
+    native.check(native.lib().mi_compute_hand_reward(n, C.byref(p), rew.data_ptr(), rb.data_ptr(), rg.data_ptr(), pr.data_ptr(),
+                                                     su.data_ptr(), cs.data_ptr(), *[x.data_ptr() for x in ins], 20, ws.data_ptr(),
+                                                     _stream()))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(rb.cpu().numpy(), g[tag + "_resets"])
+    np.testing.assert_array_equal(rg.cpu().numpy(), g[tag + "_goal_resets"])
+    np.testing.assert_array_equal(pr.cpu().numpy(), g[tag + "_progress_out"])
+    np.testing.assert_array_equal(su.cpu().numpy(), g[tag + "_successes_out"])
+    np.testing.assert_allclose(rew.cpu().numpy(), g[tag + "_rew"], rtol=3e-6, atol=5e-5)
+    np.testing.assert_allclose(cs.cpu().numpy()[0], g[tag + "_cons_out"], rtol=1e-5)
+
+
+def test_hand_full_state_and_random_rotation_kernels_match_reference(golden_dir):
+    g = dict(np.load(os.path.join(golden_dir, "shadow_hand.npz")))
+    n = len(g["dof_pos"])
+    obs = torch.zeros(n, 211, device=DEV)
+    ins = [_t(g[k]) for k in ("dof_pos", "dof_vel", "dof_force", "dof_lower", "dof_upper", "object_state", "goal_pose",
+                              "fingertip_state", "sensors", "actions")]
+    native.check(native.lib().mi_compute_hand_full_state(n, 24, 5, 20, 0.2, 10.0, *[x.data_ptr() for x in ins], obs.data_ptr(), 211,
+                                                         _stream()))
+    q = torch.zeros(n, 4, device=DEV)
+    rin = [_t(g[k]) for k in ("rand0", "rand1", "x_unit", "y_unit")]
+    native.check(native.lib().mi_randomize_rotation(n, *[x.data_ptr() for x in rin], q.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(obs.cpu().numpy(), g["full_state"], atol=2e-6)
+    np.testing.assert_allclose(q.cpu().numpy(), g["rand_rot"], atol=5e-7)
+
+
 # ------------------------------------------------------------------ helpers for engine-level tests
 def _sim_dict(sp):
     return dict(dt=sp.dt, substeps=sp.substeps, iters=sp.iters, gravity=tuple(sp.gravity), contact_offset=sp.contact_offset,

@@ -3,6 +3,8 @@
 ~6e4 so one ulp is 4e-3, which also bounds the progress term of the reward."""
 import os
 
+import pytest
+
 import numpy as np
 import pytest
 
@@ -133,3 +135,38 @@ def test_anymal_reward_matches_reference(golden_dir):
     np.testing.assert_allclose(air, g["feet_air_time_out"], atol=1e-7)
     for k in T.ANYMAL_SUM_KEYS:
         np.testing.assert_allclose(terms[k], g["sum_" + k], atol=2e-6, err_msg=k)
+
+
+# ------------------------------------------------------------------ ShadowHand task functions
+def _hand_golden(golden_dir):
+    return dict(np.load(os.path.join(golden_dir, "shadow_hand.npz")))
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_hand_reward_matches_reference(golden_dir, tag):
+    from oracle import tasks as T
+    g = _hand_golden(golden_dir)
+    sc = {k[len(tag) + 8:]: float(v) for k, v in g.items() if k.startswith(tag + "_scalar_")}
+    r = T.compute_hand_reward(None, g["reset_buf"], g["reset_goal_buf"], g["progress"], g["successes"], g["cons"],
+                              sc["max_episode_length"], g["object_pos"], g["object_rot"], g["target_pos"], g["target_rot"],
+                              sc["dist_reward_scale"], sc["rot_reward_scale"], sc["rot_eps"], g["actions"], sc["action_penalty_scale"],
+                              sc["success_tolerance"], sc["reach_goal_bonus"], sc["fall_dist"], sc["fall_penalty"],
+                              int(sc["max_consecutive_successes"]), sc["av_factor"], bool(sc["ignore_z_rot"]))
+    rew, resets, goal_resets, progress, successes, cons = r
+    np.testing.assert_array_equal(resets, g[tag + "_resets"])
+    np.testing.assert_array_equal(goal_resets, g[tag + "_goal_resets"])
+    np.testing.assert_array_equal(progress, g[tag + "_progress_out"])
+    np.testing.assert_array_equal(successes, g[tag + "_successes_out"])
+    np.testing.assert_allclose(rew, g[tag + "_rew"], rtol=2e-6, atol=2e-5)
+    np.testing.assert_allclose(cons, g[tag + "_cons_out"], rtol=1e-6)
+
+
+def test_hand_full_state_and_random_rotation_match_reference(golden_dir):
+    from oracle import tasks as T
+    g = _hand_golden(golden_dir)
+    obs = T.compute_hand_full_state(g["dof_pos"], g["dof_vel"], g["dof_force"], g["dof_lower"], g["dof_upper"], g["object_state"],
+                                    g["goal_pose"], g["fingertip_state"], g["sensors"], g["actions"], 0.2, 10.0)
+    assert obs.shape == (len(g["dof_pos"]), 211)
+    np.testing.assert_allclose(obs, g["full_state"], atol=1e-6)
+    q = T.randomize_rotation(g["rand0"], g["rand1"], g["x_unit"], g["y_unit"])
+    np.testing.assert_allclose(q, g["rand_rot"], atol=2e-7)
