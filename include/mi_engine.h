@@ -149,7 +149,8 @@ int mi_engine_simulate(MiEngine* e, void* stream);
 int mi_engine_set_terrain(MiEngine* e, const int16_t* height_samples, int rows, int cols, float horizontal_scale,
                           float vertical_scale, float border_size, const float* env_origins, int num_levels,
                           int num_terrains, float env_length, int max_init_level);
-/* optional knobs: "clip_obs" (env.clipObservations, vec_task.py:115), "control_freq_inv" (env.controlFrequencyInv, :111) */
+/* optional knobs: "clip_obs" (env.clipObservations, vec_task.py:115), "control_freq_inv" (env.controlFrequencyInv, :111),
+ * "gravity_x|y|z" (gym.set_sim_params after sim_params.gravity randomisation, vec_task.py:720-732) */
 int mi_engine_set_option(MiEngine* e, const char* key, double value);
 /* which slot of the "obs_out" ring ([2, N, num_obs], clamped copy of obs_buf = what VecTask.step returns as
  * obs_dict["obs"], vec_task.py:402) the most recent step wrote */

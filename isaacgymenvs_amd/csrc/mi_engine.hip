@@ -332,6 +332,10 @@ extern "C" int mi_engine_tensor_desc(const MiEngine* e, int i, MiTensorDesc* out
 extern "C" int mi_engine_set_option(MiEngine* e, const char* key, double value) {
     if (!e) return fail("null engine");
     if (!strcmp(key, "clip_obs")) { e->clip_obs = (float)value; e->v.clip_obs = (float)value; return 0; }
+    // sim_params.gravity randomisation (reference vec_task.py:720-732 -> gym.set_sim_params)
+    if (!strcmp(key, "gravity_x")) { e->P.g[0] = (float)value; return 0; }
+    if (!strcmp(key, "gravity_y")) { e->P.g[1] = (float)value; return 0; }
+    if (!strcmp(key, "gravity_z")) { e->P.g[2] = (float)value; return 0; }
     if (!strcmp(key, "control_freq_inv")) { if (value < 1) return fail("control_freq_inv < 1"); e->control_freq_inv = (int)value; return 0; }
     return fail(std::string("unknown option: ") + key);
 }

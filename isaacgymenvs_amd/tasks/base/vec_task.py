@@ -108,6 +108,7 @@ class VecTask(Env):
         self.sim_params = self._parse_sim_params(self.cfg["physics_engine"], self.cfg["sim"])
         self.dt: float = self.sim_params.dt
         self.first_randomization = True
+        self.last_rand_step = 0
         self.dr_randomizations = {}
         # multi-GPU sharding: global env ids are rank*num_envs + i (seed offset: reference utils/utils.py:94)
         self.rank = int(os.getenv("RANK", "0")) if config.get("_multi_gpu", False) else 0
@@ -176,6 +177,10 @@ class VecTask(Env):
 
     # ------------------------------------------------------------------ the hot path (vec_task.py:360-408)
     def step(self, actions: torch.Tensor) -> Tuple[Dict[str, torch.Tensor], torch.Tensor, torch.Tensor, Dict[str, Any]]:
+        if getattr(self, "randomize", False):
+            # the reference calls this from reset_idx (ant.py:253-255), i.e. on steps where some env resets; resets are
+            # in-kernel here, so the (frequency-gated) refresh is evaluated every step
+            self.apply_randomizations(self.randomization_params)
         if self.dr_randomizations.get("actions", None):
             actions = self.dr_randomizations["actions"]["noise_lambda"](actions)
         if actions.device != self.obs_buf.device or actions.dtype != torch.float32 or not actions.is_contiguous():
@@ -221,6 +226,95 @@ class VecTask(Env):
         if self.num_states > 0:
             self.obs_dict["states"] = self.get_state()
         return self.obs_dict, done_env_ids
+
+    # ------------------------------------------------------------------ domain randomisation (vec_task.py:610-840)
+    def apply_randomizations(self, dr_params):
+        """Reference vec_task.py:610-840, for the parts that exist without PhysX property structs:
+        observation / action noise closures (white + per-env correlated, gaussian or uniform, additive or scaling, linear /
+        constant schedules, :650-718) and `sim_params.gravity` (:720-732).  `actor_params` (per-actor mass / friction /
+        dof property randomisation through gym.get/set_actor_*_properties, :752-828) has no counterpart yet and raises."""
+        import operator
+        from ...utils.dr_utils import apply_random_gravity
+        rand_freq = dr_params.get("frequency", 1)
+        self.last_step = int(self.control_steps * max(1, self.control_freq_inv))       # gym.get_frame_count
+        if self.first_randomization:
+            do_nonenv_randomize = True
+        else:
+            do_nonenv_randomize = (self.last_step - self.last_rand_step) >= rand_freq
+            rand_envs = torch.logical_and(self.randomize_buf >= rand_freq, self.reset_buf.bool())
+            self.randomize_buf[rand_envs] = 0
+        if do_nonenv_randomize:
+            self.last_rand_step = self.last_step
+        for name in ("observations", "actions"):
+            if name in dr_params and do_nonenv_randomize:
+                prm = dr_params[name]
+                dist, op_type = prm["distribution"], prm["operation"]
+                sched_type = prm["schedule"] if "schedule" in prm else None
+                sched_step = prm["schedule_steps"] if "schedule" in prm else None
+                op = operator.add if op_type == "additive" else operator.mul
+                if sched_type == "linear":
+                    s = 1.0 / sched_step * min(self.last_step, sched_step)
+                elif sched_type == "constant":
+                    s = 0 if self.last_step < sched_step else 1
+                else:
+                    s = 1
+                if dist == "gaussian":
+                    mu, var = prm["range"]
+                    mu_corr, var_corr = prm.get("range_correlated", [0., 0.])
+                    if op_type == "additive":
+                        mu *= s; var *= s; mu_corr *= s; var_corr *= s
+                    elif op_type == "scaling":
+                        var = var * s; mu = mu * s + 1.0 * (1.0 - s)
+                        var_corr = var_corr * s; mu_corr = mu_corr * s + 1.0 * (1.0 - s)
+
+                    def noise_lambda(tensor, param_name=name, op=op):
+                        params = self.dr_randomizations[param_name]
+                        corr = params.get("corr", None)
+                        if corr is None:
+                            corr = torch.randn_like(tensor)
+                            params["corr"] = corr
+                        corr = corr * params["var_corr"] + params["mu_corr"]
+                        return op(tensor, corr + torch.randn_like(tensor) * params["var"] + params["mu"])
+                    self.dr_randomizations[name] = {"mu": mu, "var": var, "mu_corr": mu_corr, "var_corr": var_corr,
+                                                    "noise_lambda": noise_lambda}
+                elif dist == "uniform":
+                    lo, hi = prm["range"]
+                    lo_corr, hi_corr = prm.get("range_correlated", [0., 0.])
+                    if op_type == "additive":
+                        lo *= s; hi *= s; lo_corr *= s; hi_corr *= s
+                    elif op_type == "scaling":
+                        lo = lo * s + 1.0 * (1.0 - s); hi = hi * s + 1.0 * (1.0 - s)
+                        lo_corr = lo_corr * s + 1.0 * (1.0 - s); hi_corr = hi_corr * s + 1.0 * (1.0 - s)
+
+                    def noise_lambda(tensor, param_name=name, op=op):
+                        params = self.dr_randomizations[param_name]
+                        corr = params.get("corr", None)
+                        if corr is None:
+                            corr = torch.randn_like(tensor)
+                            params["corr"] = corr
+                        corr = corr * (params["hi_corr"] - params["lo_corr"]) + params["lo_corr"]
+                        return op(tensor, corr + torch.rand_like(tensor) * (params["hi"] - params["lo"]) + params["lo"])
+                    self.dr_randomizations[name] = {"lo": lo, "hi": hi, "lo_corr": lo_corr, "hi_corr": hi_corr,
+                                                    "noise_lambda": noise_lambda}
+                else:
+                    raise ValueError(f"unsupported noise distribution {dist}")
+        if "sim_params" in dr_params and do_nonenv_randomize:
+            if self.first_randomization:
+                self.original_props = getattr(self, "original_props", {})
+                self.original_props["sim_params"] = {"gravity": [float(self.sim_params.gravity[i]) for i in range(3)]}
+            for attr, attr_prm in dr_params["sim_params"].items():
+                if attr != "gravity":
+                    raise NotImplementedError(f"sim_params.{attr} randomisation is not supported by the engine")
+                g = apply_random_gravity([float(self.sim_params.gravity[i]) for i in range(3)],
+                                         self.original_props["sim_params"]["gravity"], attr_prm, self.last_step)
+                for i in range(3):
+                    self.sim_params.gravity[i] = float(g[i])
+                    self.engine.set_option(("gravity_x", "gravity_y", "gravity_z")[i], float(g[i]))
+        if dr_params.get("actor_params") and self.first_randomization:
+            import warnings
+            warnings.warn("actor_params randomisation (per-actor PhysX property structs, reference vec_task.py:752-828) is "
+                          "not implemented by the engine and is skipped: " + ", ".join(dr_params["actor_params"].keys()))
+        self.first_randomization = False
 
     def render(self, mode="rgb_array"):
         return None  # headless engine (viewer is out of scope, SURVEY.md section 8f-4)

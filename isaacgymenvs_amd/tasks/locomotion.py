@@ -85,8 +85,6 @@ class LocomotionTask(VecTask):
         self.num_dof = info.num_dofs
         self.num_bodies = info.num_bodies
         self.up_axis_idx = 2
-        if self.randomize:
-            raise NotImplementedError("task.randomize=True (domain randomisation) is not implemented in this round")
         super().__init__(config=self.cfg, rl_device=rl_device, sim_device=sim_device,
                          graphics_device_id=graphics_device_id, headless=headless,
                          virtual_screen_capture=virtual_screen_capture, force_render=force_render)

