@@ -72,6 +72,8 @@ struct RowStore {
     float* p;
     MI_HD float& operator()(int slot) const { return p[slot * STRIDE]; }
     MI_HD RowStore shifted(int off) const { return RowStore{p + off}; }
+    MI_HD float* ptr(int slot) const { return p + slot * STRIDE; }   // data-dependent slot (compact contact store)
+    static constexpr int stride = STRIDE;
 };
 // LDS flavour: slot k of this lane sits at byte k*256 + lane*4.  DS instructions only encode a 16-bit byte offset,
 // so one base register per 64 KB segment is kept (3 VGPRs for up to 192 KB); with the segment picked at compile
@@ -83,6 +85,8 @@ struct RowStore<64> {
     MI_HD explicit RowStore(float* p) : seg{p, p + 256 * 64, p + 512 * 64} {}
     MI_HD float& operator()(int slot) const { return seg[slot >> 8][(slot & 255) * 64]; }
     MI_HD RowStore shifted(int off) const { return RowStore(seg[0] + off); }
+    MI_HD float* ptr(int slot) const { return seg[0] + slot * 64; }
+    static constexpr int stride = 64;
 };
 
 // reciprocal / reciprocal square root / square root: the 1-ulp hardware ops on the device (v_rcp_f32, v_rsq_f32,
@@ -217,7 +221,33 @@ struct Sim {
     static constexpr int NVA = NV > 0 ? NV : 1;
     // slots of the row store: G rows (NROWG x MAXCHAIN), 1/A_ii, velocity targets and (big models) the impulses
     static constexpr bool LAM_IN_ROWS = NROWG > 16;
-    static constexpr int ROW_SLOTS = NROWG * M::MAXCHAIN + (LAM_IN_ROWS ? 3 : 2) * NROWG;
+    static constexpr int ROW_SLOTS_STATIC = NROWG * M::MAXCHAIN + (LAM_IN_ROWS ? 3 : 2) * NROWG;
+    // ---- compact contact store.  When the static store (a row set for EVERY contact sphere) does not fit the LDS of a
+    // CU even at 64 envs per wave (Humanoid: 126 rows x 15 = 7.5 KB per env), only ACTIVE contacts get a slot: at most
+    // KMAX contacts per env, 32 envs per wave (half-filled waves cost nothing while there are more CUs than waves), the
+    // slot index of sphere s is data dependent.  Layout [slot][lane] makes any per-lane slot bank-conflict free.
+    static constexpr bool COMPACT = (size_t)ROW_SLOTS_STATIC * 64 * sizeof(float) > 152 * 1024;
+    static constexpr int LANES = COMPACT ? 32 : 64;       // envs per workgroup (= per wave)
+    static constexpr int KMAX = 16;                       // active ground contacts kept per env (compact store only)
+    static constexpr int limoff(int r) {                  // tight packing of the limit rows: offset of row r
+        int n = 0;
+        for (int k = 0; k < r; ++k) n += M::nanc[OFF + limdof_c(k)] + 1;
+        return n;
+    }
+    static constexpr int limdof_c(int r) {
+        int n = 0;
+        for (int d = 0; d < ND; ++d) {
+            if (M::dof_limited[d]) { if (n == r) return d; ++n; }
+        }
+        return 0;
+    }
+    static constexpr int C_LIMG = limoff(NLIM);           // floats of limit-row G
+    static constexpr int C_CB = C_LIMG + 3 * NLIM;        // first contact slot (after limit Ainv, vt, lam)
+    static constexpr int C_CSZ = 3 * M::MAXCHAIN + 7;     // 3 rows + Ainv x3, vt_n, lam x3
+    static constexpr int C_SLOTOF = C_CB + KMAX * C_CSZ;  // [NSPH] slot index of each sphere (-1: inactive), as int bits
+    static constexpr int ROW_SLOTS_COMPACT = C_SLOTOF + NSPH;
+    static constexpr int C_WARM_OK = (KMAX * C_CSZ - 3 * NSPH) / C_CSZ - 1;   // last slot whose write cannot reach the staged warm-start values
+    static constexpr int ROW_SLOTS = COMPACT ? ROW_SLOTS_COMPACT : ROW_SLOTS_STATIC;
 
     // ---- per-env state carried in registers through a sub-step; the warm-start impulses and the sensor outputs
     //      stay in memory (Strided views) and are touched exactly once per sub-step
@@ -472,9 +502,10 @@ struct Sim {
     MI_HD void substep(const SimParams& P, const float* tau, const float h, const RowStore<RS> rows, const Strided lamc,
                        const Strided laml, const Strided sensor, const Strided dof_force, const GND& gnd, const float mu_env,
                        const Strided netf) {
-        auto G = [&](int row, int c) MI_LAMBDA -> float& { return rows(row * M::MAXCHAIN + c); };
-        auto Ainv = [&](int row) MI_LAMBDA -> float& { return rows(NROWG * M::MAXCHAIN + row); };
-        auto vt = [&](int row) MI_LAMBDA -> float& { return rows(NROWG * M::MAXCHAIN + NROWG + row); };
+        // static store: row r at r*MAXCHAIN; compact store: only the limit rows (r < NLIM) live at fixed, tightly packed places
+        auto G = [&](int row, int c) MI_LAMBDA -> float& { return rows(COMPACT ? limoff(row) + c : row * M::MAXCHAIN + c); };
+        auto Ainv = [&](int row) MI_LAMBDA -> float& { return rows(COMPACT ? C_LIMG + row : NROWG * M::MAXCHAIN + row); };
+        auto vt = [&](int row) MI_LAMBDA -> float& { return rows(COMPACT ? C_LIMG + NLIM + row : NROWG * M::MAXCHAIN + NROWG + row); };
         const float invh = MI_RCP(h);
         Ctx c;
         float (&S)[M::NDA][6] = c.S;
@@ -484,7 +515,17 @@ struct Sim {
         // all loads are issued back to back here, far ahead of their use in the row build, instead of one exposed
         // HBM round trip per row (a wave has nobody to switch to while it waits)
         static_assert(LAM_IN_ROWS || NROWG <= 16, "small models keep lam in registers");
-        if constexpr (LAM_IN_ROWS) {
+        if constexpr (COMPACT) {
+            sfor<ND>([&](auto D) MI_LAMBDA {
+                constexpr int d = D;
+                if constexpr (M::dof_limited[d]) rows(C_LIMG + 2 * NLIM + limrow(d)) = laml(d);
+            });
+            // contact impulses are parked at the END of the (still empty) contact-slot region, sphere 0 last: slots fill
+            // from the front and sphere s is read before any slot > s can be written
+            sfor<NSPH>([&](auto S_) MI_LAMBDA {
+                sfor<3>([&](auto K) MI_LAMBDA { rows(C_SLOTOF - 3 * (S_ + 1) + K) = lamc(3 * S_ + K); });
+            });
+        } else if constexpr (LAM_IN_ROWS) {
             sfor<ND>([&](auto D) MI_LAMBDA {
                 constexpr int d = D;
                 if constexpr (M::dof_limited[d]) rows(NROWG * M::MAXCHAIN + 2 * NROWG + limrow(d)) = laml(d);
@@ -576,7 +617,8 @@ struct Sim {
         // ------------------------------------------------------------ constraint rows in whitened space
         float lam_reg[LAM_IN_ROWS ? 1 : NROWG];
         auto lam = [&](int row) MI_LAMBDA -> float& {
-            if constexpr (LAM_IN_ROWS) return rows(NROWG * M::MAXCHAIN + 2 * NROWG + row);
+            if constexpr (COMPACT) return rows(C_LIMG + 2 * NLIM + row);   // limit rows only
+            else if constexpr (LAM_IN_ROWS) return rows(NROWG * M::MAXCHAIN + 2 * NROWG + row);
             else return lam_reg[row];
         };
         // solve L^T g = J^T restricted to a chain (descending generalized indices), in place in g[]
@@ -632,6 +674,7 @@ struct Sim {
         });
         MI_PHASE();
         MI_STAMP(4);
+        if constexpr (!COMPACT) {
         // ground contacts: 3 rows per sphere (normal, two tangents; +z, x, y on the plane)
         sfor<NSPH>([&](auto S_) MI_LAMBDA {
             constexpr int s = S_, b = M::sph_body[s], row0 = NLIM + 3 * s;
@@ -688,6 +731,70 @@ struct Sim {
                 lam(row) = lprev * P.warm * onf;
             });
         });
+        } else {
+        // ground contacts, compact store: a sphere within contact_offset takes the next free slot of its env (at most
+        // KMAX); the three rows are only built -- by the lanes that need them -- when some env of the wave has the
+        // sphere active (EXEC-masked region, skipped by the whole wave otherwise)
+        int cnt = 0;
+        sfor<NSPH>([&](auto S_) MI_LAMBDA {
+            constexpr int s = S_, b = M::sph_body[s];
+            MI_PHASE();
+            const float* cs = c.xcs[s];
+            float xc[3], dist;
+            float fr[3][3];
+            if constexpr (GND::HEIGHTFIELD) {
+                float zt;
+                gnd.query(root[0] + cs[0], root[1] + cs[1], &zt, fr[0]);
+                contact_frame(fr[0], fr[1], fr[2]);
+                dist = ((root[2] + cs[2]) - zt) * fr[0][2] - M::sph_rad[s];
+                sfor<3>([&](auto K) MI_LAMBDA { xc[K] = cs[K] - M::sph_rad[s] * fr[0][K]; });
+            } else {
+                xc[0] = cs[0]; xc[1] = cs[1]; xc[2] = cs[2] - M::sph_rad[s];
+                dist = (root[2] + xc[2]) - P.ground_z;
+            }
+            const bool on = (dist < P.contact_offset) && (cnt < KMAX);
+            const int j = on ? cnt : -1;
+            // the parked warm-start impulses of this sphere must be read before its slot (possibly) overwrites them
+            float lprev[3];
+            sfor<3>([&](auto K) MI_LAMBDA { lprev[K] = rows(C_SLOTOF - 3 * (s + 1) + K); });
+            if (on) {
+                float* cb = rows.ptr(C_CB + j * C_CSZ);
+                constexpr int ST = RowStore<RS>::stride;
+                const float gap = dist - P.rest_offset;
+                sfor<3>([&](auto K) MI_LAMBDA {
+                    constexpr int k = K;
+                    float W[6];
+                    if constexpr (GND::HEIGHTFIELD) {
+                        cross3(xc, fr[k], W);
+                        W[3] = fr[k][0]; W[4] = fr[k][1]; W[5] = fr[k][2];
+                    } else {
+                        constexpr int ax = (k == 0) ? 2 : (k == 1 ? 0 : 1);
+                        sfor<6>([&](auto I_) MI_LAMBDA { W[I_] = 0.f; });
+                        W[3 + ax] = 1.f;
+                        if constexpr (ax == 0) { W[1] = xc[2]; W[2] = -xc[1]; }
+                        else if constexpr (ax == 1) { W[0] = -xc[2]; W[2] = xc[0]; }
+                        else { W[0] = xc[1]; W[1] = -xc[0]; }
+                    }
+                    float g[M::MAXCHAIN];
+                    sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA {
+                        constexpr int gi = M::chain[b][C];
+                        if constexpr (gi >= OFF) g[C] = dot6(S[gi - OFF], W);
+                        else if constexpr (gi < 3) g[C] = W[3 + gi];
+                        else g[C] = W[gi - 3];
+                    });
+                    chain_solve(std::integral_constant<int, b>{}, g);
+                    float a = P.cfm;
+                    sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { a += g[C] * g[C]; cb[(k * M::MAXCHAIN + C) * ST] = g[C]; });
+                    cb[(3 * M::MAXCHAIN + k) * ST] = MI_RCP(a);
+                    // slots past C_WARM_OK may already have overwritten parked values of later spheres: no warm start there
+                    cb[(3 * M::MAXCHAIN + 4 + k) * ST] = (j <= C_WARM_OK) ? lprev[k] * P.warm : 0.f;
+                });
+                cb[(3 * M::MAXCHAIN + 3) * ST] = (gap >= 0.f) ? -gap * invh : fminf(-gap * P.erp * invh, P.max_depen_vel);
+            }
+            cnt += on ? 1 : 0;
+            rows(C_SLOTOF + s) = __builtin_bit_cast(float, j);
+        });
+        }
         MI_PHASE();
         MI_STAMP(5);
         // ------------------------------------------------------------ warm start: w += G^T lam0, rows read back from the store
@@ -702,18 +809,34 @@ struct Sim {
                 if constexpr (M::dof_limited[d]) {
                     constexpr int row = limrow(d);
                     const float l0 = lam(row);
-                    w[gi] += rit(row * M::MAXCHAIN) * l0;
-                    sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { w[M::anc[gi][A_]] += rit(row * M::MAXCHAIN + 1 + A_) * l0; });
+                    constexpr int g0 = COMPACT ? limoff(row) : row * M::MAXCHAIN;
+                    w[gi] += rit(g0) * l0;
+                    sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { w[M::anc[gi][A_]] += rit(g0 + 1 + A_) * l0; });
                 }
             });
-            sfor<NSPH>([&](auto S_) MI_LAMBDA {
-                constexpr int s = S_, b = M::sph_body[s], row0 = NLIM + 3 * s;
-                sfor<3>([&](auto K) MI_LAMBDA {
-                    constexpr int row = row0 + K;
-                    const float l0 = lam(row);
-                    sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += rit(row * M::MAXCHAIN + C) * l0; });
+            if constexpr (!COMPACT) {
+                sfor<NSPH>([&](auto S_) MI_LAMBDA {
+                    constexpr int s = S_, b = M::sph_body[s], row0 = NLIM + 3 * s;
+                    sfor<3>([&](auto K) MI_LAMBDA {
+                        constexpr int row = row0 + K;
+                        const float l0 = lam(row);
+                        sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += rit(row * M::MAXCHAIN + C) * l0; });
+                    });
                 });
-            });
+            } else {
+                sfor<NSPH>([&](auto S_) MI_LAMBDA {
+                    constexpr int s = S_, b = M::sph_body[s];
+                    const int j = __builtin_bit_cast(int, rit(C_SLOTOF + s));
+                    if (j >= 0) {
+                        const float* cb = rit.ptr(C_CB + j * C_CSZ);
+                        constexpr int ST = RowStore<RS>::stride;
+                        sfor<3>([&](auto K) MI_LAMBDA {
+                            const float l0 = cb[(3 * M::MAXCHAIN + 4 + K) * ST];
+                            sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += cb[(K * M::MAXCHAIN + C) * ST] * l0; });
+                        });
+                    }
+                });
+            }
         }
 #if defined(MI_STOP_AFTER) && MI_STOP_AFTER == 3
         { float acc = 0.f; sfor<M::NM>([&](auto K) MI_LAMBDA { acc += L[K]; }); sfor<NV>([&](auto K) MI_LAMBDA { acc += w[K] + Ldi[K]; });
@@ -724,6 +847,7 @@ struct Sim {
 #endif
         MI_PHASE();
         MI_STAMP(6);
+        if constexpr (!COMPACT) {
         // ------------------------------------------------------------ projected Gauss-Seidel sweeps
         // Software-pipelined over "units" (one limit row, or the 3 rows of one sphere): while unit u is being
         // solved, the rows of unit u+1 are already being read from the store into the other register buffer.  A wave
@@ -805,6 +929,71 @@ struct Sim {
                 });
             }
         }
+        } else {
+        // projected Gauss-Seidel sweeps, compact store: limit rows at their fixed places, then every sphere that holds a slot
+        for (int it = 0; it < P.iters; ++it) {
+            int zero;
+            MI_OPAQUE_ZERO(zero);
+            const RowStore<RS> rit = rows.shifted(zero);
+            constexpr int ST = RowStore<RS>::stride;
+            sfor<ND>([&](auto D) MI_LAMBDA {
+                constexpr int d = D, gi = OFF + d;
+                if constexpr (M::dof_limited[d]) {
+                    constexpr int row = limrow(d), g0 = limoff(row);
+                    float g[M::MAXCHAIN];
+                    sfor<M::nanc[gi] + 1>([&](auto K) MI_LAMBDA { g[K] = rit(g0 + K); });
+                    float vn = g[0] * w[gi];
+                    sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { vn += g[1 + A_] * w[M::anc[gi][A_]]; });
+                    const float lo = rit(C_LIMG + 2 * NLIM + row);
+                    const float nl = fmaxf(lo - (vn - rit(C_LIMG + NLIM + row)) * rit(C_LIMG + row), 0.f);
+                    const float dl = nl - lo;
+                    rit(C_LIMG + 2 * NLIM + row) = nl;
+                    w[gi] += g[0] * dl;
+                    sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { w[M::anc[gi][A_]] += g[1 + A_] * dl; });
+                }
+            });
+            sfor<NSPH>([&](auto S_) MI_LAMBDA {
+                constexpr int s = S_, b = M::sph_body[s];
+                const int j = __builtin_bit_cast(int, rit(C_SLOTOF + s));
+                if (j >= 0) {
+                    float* cb = rit.ptr(C_CB + j * C_CSZ);
+                    const float mu = 0.5f * ((mu_env >= 0.f ? mu_env : M::sph_mu[s]) + P.plane_mu);
+                    float g[3][M::MAXCHAIN], ainv[3], lm[3];
+                    sfor<3>([&](auto K) MI_LAMBDA {
+                        sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { g[K][C] = cb[(K * M::MAXCHAIN + C) * ST]; });
+                        ainv[K] = cb[(3 * M::MAXCHAIN + K) * ST];
+                        lm[K] = cb[(3 * M::MAXCHAIN + 4 + K) * ST];
+                    });
+                    const float vtn = cb[(3 * M::MAXCHAIN + 3) * ST];
+                    float ln;
+                    {
+                        float vn = 0.f;
+                        sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { vn += g[0][C] * w[M::chain[b][C]]; });
+                        ln = fmaxf(lm[0] - (vn - vtn) * ainv[0], 0.f);
+                        const float dl = ln - lm[0];
+                        sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += g[0][C] * dl; });
+                    }
+                    float lt[2];
+                    sfor<2>([&](auto K) MI_LAMBDA {
+                        float vn = 0.f;
+                        sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { vn += g[1 + K][C] * w[M::chain[b][C]]; });
+                        const float dl = -vn * ainv[1 + K];
+                        lt[K] = lm[1 + K] + dl;
+                        sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += g[1 + K][C] * dl; });
+                    });
+                    const float lim = mu * ln;
+                    const float n2 = lt[0] * lt[0] + lt[1] * lt[1];
+                    const float sc = (n2 > lim * lim) ? lim * MI_RSQ(fmaxf(n2, 1e-30f)) : 1.f;
+                    cb[(3 * M::MAXCHAIN + 4) * ST] = ln;
+                    sfor<2>([&](auto K) MI_LAMBDA {
+                        const float nl = lt[K] * sc, dl = nl - lt[K];
+                        cb[(3 * M::MAXCHAIN + 5 + K) * ST] = nl;
+                        sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += g[1 + K][C] * dl; });
+                    });
+                }
+            });
+        }
+        }
         MI_PHASE();
         MI_STAMP(7);
         // ------------------------------------------------------------ back to generalised velocity: qd = L^-1 w
@@ -838,7 +1027,19 @@ struct Sim {
         sfor<NSPH>([&](auto S_) MI_LAMBDA {
             constexpr int s = S_, b = M::sph_body[s], row0 = NLIM + 3 * s;
             // inactive spheres carry lam = 0 => zero warm start and zero sensor / net-force contribution
-            const float ln = lam(row0), l1 = lam(row0 + 1), l2 = lam(row0 + 2);
+            float ln, l1, l2;
+            if constexpr (COMPACT) {
+                const int j = __builtin_bit_cast(int, rows(C_SLOTOF + s));
+                const float* cb = rows.ptr(C_CB + (j >= 0 ? j : 0) * C_CSZ);
+                constexpr int ST = RowStore<RS>::stride;
+                const bool onj = j >= 0;
+                ln = onj ? cb[(3 * M::MAXCHAIN + 4) * ST] : 0.f;
+                l1 = onj ? cb[(3 * M::MAXCHAIN + 5) * ST] : 0.f;
+                l2 = onj ? cb[(3 * M::MAXCHAIN + 6) * ST] : 0.f;
+                (void)row0;
+            } else {
+                ln = lam(row0); l1 = lam(row0 + 1); l2 = lam(row0 + 2);
+            }
             lamc(3 * s) = ln; lamc(3 * s + 1) = l1; lamc(3 * s + 2) = l2;
             float f[3], xc[3];
             if constexpr (GND::HEIGHTFIELD) {

@@ -129,15 +129,18 @@ enum ActSource { ACT_STORED_TAU = 0,      // v.tau as left by an earlier launch 
                  ACT_FROM_ACTIONS = 1,    // clamp the caller's row-major actions, store them in v.actions, derive tau
                  ACT_FROM_STORED_ACTIONS = 2 };  // PD mode: re-derive tau from v.actions and the current joint state
 
+// envs per workgroup (= per wave): 64, or 32 for models on the compact contact store (Sim<M>::COMPACT)
 template <class M>
-constexpr bool rows_fit_lds() { return (size_t)Sim<M>::ROW_SLOTS * 64 * sizeof(float) <= 152 * 1024; }
+constexpr size_t lds_bytes() { return (size_t)Sim<M>::ROW_SLOTS * Sim<M>::LANES * sizeof(float); }
+template <class M>
+constexpr bool rows_fit_lds() { return lds_bytes<M>() <= 160 * 1024; }
 
 template <class M, class GND>
 __global__ __launch_bounds__(64) void substep_kernel(View v, SimParams P, ActParams ap, const float* __restrict__ actions_in, int src,
                                                      GND gnd) {
-    extern __shared__ float lds_rows[];  // [ROW_SLOTS][64] when the model's rows fit (else unused, size 0)
-    constexpr int ND = M::ND;
-    const int e = blockIdx.x * 64 + threadIdx.x;
+    extern __shared__ float lds_rows[];  // [ROW_SLOTS][LANES] when the model's rows fit (else unused, size 0)
+    constexpr int ND = M::ND, LANES = Sim<M>::LANES;
+    const int e = blockIdx.x * LANES + threadIdx.x;
     const int N = v.N;
     if (e >= N) return;                  // no cross-lane operation in here: tail lanes simply retire
     Sim<M> sim;
@@ -173,7 +176,8 @@ __global__ __launch_bounds__(64) void substep_kernel(View v, SimParams P, ActPar
     const Strided netf{GND::HEIGHTFIELD ? v.netf + e : nullptr, N};
     const float mu_env = GND::HEIGHTFIELD ? v.friction[e] : -1.f;
     if constexpr (rows_fit_lds<M>()) {
-        sim.substep(P, tau, h, RowStore<64>(lds_rows + threadIdx.x), lamc, laml, sensor, dof_force, gnd, mu_env, netf);
+        if constexpr (LANES == 64) sim.substep(P, tau, h, RowStore<64>(lds_rows + threadIdx.x), lamc, laml, sensor, dof_force, gnd, mu_env, netf);
+        else sim.substep(P, tau, h, RowStore<LANES>{lds_rows + threadIdx.x}, lamc, laml, sensor, dof_force, gnd, mu_env, netf);
     } else {
         float rows[Sim<M>::ROW_SLOTS];
         sim.substep(P, tau, h, RowStore<1>{rows}, lamc, laml, sensor, dof_force, gnd, mu_env, netf);
@@ -324,7 +328,8 @@ __global__ void cartpole_reset_kernel(View v, const long long* __restrict__ ids,
 template <class M, class GND = PlaneGround>
 hipError_t launch_substeps(const View& v, const SimParams& P, const ActParams& ap, const float* actions, int n_sub, int first,
                            int rest, hipStream_t s, const GND& gnd = GND{}) {
-    constexpr size_t lds = rows_fit_lds<M>() ? (size_t)Sim<M>::ROW_SLOTS * 64 * sizeof(float) : 0;
+    constexpr size_t lds = rows_fit_lds<M>() ? lds_bytes<M>() : 0;
+    constexpr int LANES = Sim<M>::LANES;
     static bool configured = false;
     if (!configured && lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)substep_kernel<M, GND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -332,7 +337,7 @@ hipError_t launch_substeps(const View& v, const SimParams& P, const ActParams& a
         configured = true;
     }
     for (int i = 0; i < n_sub; ++i)
-        hipLaunchKernelGGL((substep_kernel<M, GND>), dim3((v.N + 63) / 64), dim3(64), lds, s, v, P, ap, actions, i == 0 ? first : rest, gnd);
+        hipLaunchKernelGGL((substep_kernel<M, GND>), dim3((v.N + LANES - 1) / LANES), dim3(LANES), lds, s, v, P, ap, actions, i == 0 ? first : rest, gnd);
     return hipGetLastError();
 }
 
