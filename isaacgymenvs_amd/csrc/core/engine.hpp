@@ -200,8 +200,10 @@ struct HeightfieldGround {
 // contact frame: n, t1 = normalize(x - n (n.x)), t2 = n x t1   (n = z gives t1 = x, t2 = y)
 MI_HD void contact_frame(const float* n, float* t1, float* t2) {
     const float a[3] = {1.f - n[0] * n[0], -n[0] * n[1], -n[0] * n[2]};
-    const float inv = 1.f / sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
-    t1[0] = a[0] * inv; t1[1] = a[1] * inv; t1[2] = a[2] * inv;
+    const float a2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
+    const bool ok = a2 > 1e-12f;                       // n = +-x (possible for object contacts): fall back to y
+    const float inv = 1.f / sqrtf(ok ? a2 : 1.f);
+    t1[0] = ok ? a[0] * inv : 0.f; t1[1] = ok ? a[1] * inv : 1.f; t1[2] = ok ? a[2] * inv : 0.f;
     cross3(n, t1, t2);
 }
 
@@ -310,6 +312,7 @@ struct Sim {
         float L[M::NM];               // branch-sparse H, later its L^T L factor
         float xcs[M::NSPHA][3];       // centre of every contact sphere, relative to O
         float Rs[M::NSENSA][9], rs[M::NSENSA][3];  // pose of the force-sensor bodies
+        float ocs[M::NOS > 0 ? M::NOS : 1][3];     // centres of the object-contact spheres (manipulation models), rel O
     };
 
     // ---------------------------------------------------------------- one body of the depth-first tree pass
@@ -370,6 +373,14 @@ struct Sim {
                 float t[3];
                 matvec3(Rb, M::sph_pos[s], t);
                 c.xcs[s][0] = rb[0] + t[0]; c.xcs[s][1] = rb[1] + t[1]; c.xcs[s][2] = rb[2] + t[2];
+            }
+        });
+        sfor<M::NOS>([&](auto S_) MI_LAMBDA {
+            constexpr int s = S_;
+            if constexpr (M::os_body[s] == b) {
+                float t[3];
+                matvec3(Rb, M::os_pos[s], t);
+                c.ocs[s][0] = rb[0] + t[0]; c.ocs[s][1] = rb[1] + t[1]; c.ocs[s][2] = rb[2] + t[2];
             }
         });
         if constexpr (sensor_of(b) >= 0) {

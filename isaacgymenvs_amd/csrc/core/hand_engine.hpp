@@ -1,0 +1,472 @@
+// hand_engine.hpp -- physics sub-step of a fixed-base manipulator + ONE free isotropic rigid object (ShadowHand task).
+//
+// Replaces gym.simulate() for reference isaacgymenvs/tasks/shadow_hand.py.  Built on the pieces of core/engine.hpp (tree
+// pass, branch-sparse L^T L factor, whitened PGS, compact LDS row store); what is specific here:
+//   * gravity is disabled on the hand (shadow_hand.py:239) and enabled on the object;
+//   * implicit PD position drives: tau = kp (target - q) - D qd with kp from the MJCF position actuators
+//     (shared.xml:250-269), targets = cur_targets of the task (shadow_hand.py:683-698);
+//   * the four fixed tendons coupling J0/J1 (shared.xml:53-69) as soft two-sided limits on c0 q0 + c1 q1
+//     (limit_stiffness / damping set by the task, shadow_hand.py:256-266), implicit like the drives;
+//   * the manipulated cube: a free body with isotropic inertia (cube_multicolor.urdf: 5 cm box, density 567), so its
+//     whitening is a constant diagonal; contact = hand collision geometry sampled by spheres (generated os_* tables)
+//     against the exact box; every active contact takes a data-dependent slot of the compact LDS store and contributes
+//     3 rows over [chain of the hand body | 6 object dofs].
+// Same maths as oracle/hand.py (dense, numpy, fp64).
+#pragma once
+#include "engine.hpp"
+
+namespace mi {
+
+struct FreeBody {           // world frame
+    float pos[3], quat[4], vel[3], angvel[3];
+};
+struct ObjectParams {       // mirrors the object part of MiHandParams
+    float half, mass, inertia, mu;   // cube half size, mass, isotropic inertia, combined friction
+};
+
+template <class M>
+struct HandSim : Sim<M> {
+    using B = Sim<M>;
+    static constexpr int NB = M::NB, ND = M::ND, NV = M::NV, OFF = M::OFF, NSENS = M::NSENS, NOS = M::NOS, NLIM = B::NLIM, NVA = B::NVA;
+    static_assert(M::FIXED == 1 && M::NSPH == 0, "HandSim: fixed-base model without ground spheres");
+    static constexpr int KMAX = 16;                          // active object contacts kept per env
+    static constexpr int UCH = M::MAXCHAIN + 6;              // row width: hand chain + object dofs
+    static constexpr int H_LIMG = B::limoff(NLIM);
+    static constexpr int H_CB = H_LIMG + 3 * NLIM;           // limit G | Ainv, vt, lam | contact slots
+    static constexpr int H_CSZ = 3 * UCH + 7;                // 3 rows + Ainv x3, vt_n, lam x3
+    static constexpr int H_SLOTOF = H_CB + KMAX * H_CSZ;     // [NOS] slot of each sphere (-1: none), int bits
+    static constexpr int ROW_SLOTS = H_SLOTOF + NOS;
+    static constexpr int LANES = 32;
+
+    FreeBody obj;
+
+    static constexpr int sensor_of(int b) { return B::sensor_of(b); }
+
+    // sphere (centre c in box frame, radius r) vs cube of half size a: signed distance, outward normal (box frame)
+    MI_HD static void sphere_box(const float* c, float r, float a, float* dist, float* n) {
+        const float qx = fminf(fmaxf(c[0], -a), a), qy = fminf(fmaxf(c[1], -a), a), qz = fminf(fmaxf(c[2], -a), a);
+        const float dx = c[0] - qx, dy = c[1] - qy, dz = c[2] - qz;
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        const float px = a - fabsf(c[0]), py = a - fabsf(c[1]), pz = a - fabsf(c[2]);
+        // inside: push out along the axis of least penetration
+        const bool ix = (px <= py) && (px <= pz), iy = !ix && (py <= pz);
+        const float pen = ix ? px : (iy ? py : pz);
+        const bool outside = d2 > 1e-24f;
+        const float inv = MI_RSQ(fmaxf(d2, 1e-30f));
+        const float nd = d2 * inv;
+        *dist = outside ? nd - r : -pen - r;
+        n[0] = outside ? dx * inv : (ix ? (c[0] >= 0.f ? 1.f : -1.f) : 0.f);
+        n[1] = outside ? dy * inv : (iy ? (c[1] >= 0.f ? 1.f : -1.f) : 0.f);
+        n[2] = outside ? dz * inv : ((!ix && !iy) ? (c[2] >= 0.f ? 1.f : -1.f) : 0.f);
+    }
+
+    // one sub-step of length h.  target[ND]: drive targets; laml: warm-start limit impulses; sensor: 6*NSENS fingertip
+    // force/torque (body frame); dof_force[ND]; ncontact: number of object contacts taken (diagnostic)
+    template <int RS>
+    MI_HD void substep_hand(const SimParams& P, const ObjectParams& OP, const float* target, const float h, const RowStore<RS> rows,
+                            const Strided laml, const Strided sensor, const Strided dof_force, int* ncontact) {
+        constexpr int ST = RowStore<RS>::stride;
+        float (&q)[M::NDA] = this->q;        // (dependent base: make the state names visible inside the generic lambdas)
+        float (&qd)[M::NDA] = this->qd;
+        float (&root)[13] = this->root;
+        auto G = [&](int row, int c) MI_LAMBDA -> float& { return rows(B::limoff(row) + c); };
+        auto Ainv = [&](int row) MI_LAMBDA -> float& { return rows(H_LIMG + row); };
+        auto vt = [&](int row) MI_LAMBDA -> float& { return rows(H_LIMG + NLIM + row); };
+        auto lam = [&](int row) MI_LAMBDA -> float& { return rows(H_LIMG + 2 * NLIM + row); };
+        const float invh = MI_RCP(h);
+        typename B::Ctx c;
+        float (&S)[M::NDA][6] = c.S;
+        float (&L)[M::NM] = c.L;
+        // ------------------------------------------------------------ stage the limit impulses of the last sub-step
+        sfor<ND>([&](auto D) MI_LAMBDA {
+            constexpr int d = D;
+            if constexpr (M::dof_limited[d]) lam(B::limrow(d)) = laml(d);
+        });
+        // ------------------------------------------------------------ tree pass with gravity off (disable_gravity on the hand)
+        {
+            SimParams P0 = P;
+            P0.g[0] = P0.g[1] = P0.g[2] = 0.f;
+            SpI Iroot;
+            float Froot[6];
+            this->template body_pass<0>(P0, c, nullptr, nullptr, nullptr, nullptr, Iroot, Froot);
+        }
+        MI_PHASE();
+        // ------------------------------------------------------------ rhs: implicit PD drives, passive damping, tendons
+        float Ldi[NVA], y[NVA];
+        sfor<ND>([&](auto D) MI_LAMBDA {
+            constexpr int d = D, gi = OFF + d;
+            constexpr float kp = M::dof_kp[d], Dm = M::dof_damping[d];
+            L[M::midx[gi][gi]] += M::dof_armature[d] + h * Dm + h * h * kp;
+            y[gi] = -c.bias[gi] - kp * (q[d] - target[d]) - (Dm + h * kp) * qd[d];
+        });
+        sfor<M::NTEND>([&](auto T_) MI_LAMBDA {
+            constexpr int t = T_, d0 = M::tend_d0[t], d1 = M::tend_d1[t], g0 = OFF + d0, g1 = OFF + d1;
+            constexpr float c0 = M::tend_c0[t], c1 = M::tend_c1[t];
+            static_assert(M::midx[g0][g1] >= 0 || M::midx[g1][g0] >= 0, "tendon joints must be on one kinematic chain");
+            const float Lt = c0 * q[d0] + c1 * q[d1], Ld = c0 * qd[d0] + c1 * qd[d1];
+            const float viol = Lt - fminf(fmaxf(Lt, M::tend_lo[t]), M::tend_hi[t]);
+            const float k = (viol != 0.f) ? M::tend_stiffness : 0.f;
+            const float a = h * M::tend_damping + h * h * k;
+            const float f = k * viol + (M::tend_damping + h * k) * Ld;
+            L[M::midx[g0][g0]] += a * c0 * c0;
+            L[M::midx[g1][g1]] += a * c1 * c1;
+            if constexpr (M::midx[g0][g1] >= 0) L[M::midx[g0][g1]] += a * c0 * c1; else L[M::midx[g1][g0]] += a * c0 * c1;
+            y[g0] -= c0 * f;
+            y[g1] -= c1 * f;
+        });
+        MI_PHASE();
+        // ------------------------------------------------------------ H = L^T L
+        sfor_rev<NV>([&](auto K_) MI_LAMBDA {
+            constexpr int k = K_;
+            const float dk2 = fmaxf(L[M::midx[k][k]], 1e-30f);
+            const float inv = MI_RSQ(dk2);
+            L[M::midx[k][k]] = dk2 * inv;
+            Ldi[k] = inv;
+            sfor<M::nanc[k]>([&](auto A_) MI_LAMBDA { L[M::midx[k][M::anc[k][A_]]] *= inv; });
+            sfor<M::nanc[k]>([&](auto A_) MI_LAMBDA {
+                constexpr int i = M::anc[k][A_];
+                const float lki = L[M::midx[k][i]];
+                L[M::midx[i][i]] -= lki * lki;
+                sfor<M::nanc[i]>([&](auto B_) MI_LAMBDA {
+                    constexpr int j = M::anc[i][B_];
+                    L[M::midx[i][j]] -= lki * L[M::midx[k][j]];
+                });
+            });
+        });
+        MI_PHASE();
+        // ------------------------------------------------------------ whitened velocities: hand w = L qd + h L^-T rhs, object wo
+        float w[NVA];
+        sfor_rev<NV>([&](auto I_) MI_LAMBDA {
+            constexpr int i = I_;
+            const float z = y[i] * Ldi[i];
+            sfor<M::nanc[i]>([&](auto A_) MI_LAMBDA { y[M::anc[i][A_]] -= L[M::midx[i][M::anc[i][A_]]] * z; });
+            float s = L[M::midx[i][i]] * qd[i];
+            sfor<M::nanc[i]>([&](auto A_) MI_LAMBDA { s += L[M::midx[i][M::anc[i][A_]]] * qd[M::anc[i][A_]]; });
+            w[i] = s + h * z;
+        });
+        const float sm = MI_SQRT(OP.mass), si = MI_SQRT(OP.inertia);
+        const float ism = MI_RCP(sm), isi = MI_RCP(si);
+        float wo[6];
+        sfor<3>([&](auto K) MI_LAMBDA { wo[K] = sm * (obj.vel[K] + h * P.g[K]); wo[3 + K] = si * obj.angvel[K]; });
+        float Ro[9];
+        quat2mat(obj.quat, Ro);
+        const float xo[3] = {obj.pos[0] - root[0], obj.pos[1] - root[1], obj.pos[2] - root[2]};   // object COM rel O
+        MI_PHASE();
+        // ------------------------------------------------------------ joint limit rows (as core/engine.hpp)
+        sfor<ND>([&](auto D) MI_LAMBDA {
+            constexpr int d = D, gi = OFF + d;
+            if constexpr (M::dof_limited[d]) {
+                constexpr int row = B::limrow(d);
+                MI_PHASE();
+                const float dl = q[d] - M::dof_lower[d], du = M::dof_upper[d] - q[d];
+                const bool lower = dl < du;
+                const float C = lower ? dl : du, s = lower ? 1.f : -1.f;
+                const float lw = lam(row);
+                const float l0 = ((lw * s < 0.f) ? 0.f : fabsf(lw)) * P.warm;
+                float g[M::MAXCHAIN];
+                g[0] = s * Ldi[gi];
+                sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { g[1 + A_] = 0.f; });
+                sfor<M::nanc[gi] + 1>([&](auto K) MI_LAMBDA {
+                    constexpr int k = K;
+                    constexpr int i = (k == 0) ? gi : M::anc[gi][k == 0 ? 0 : k - 1];
+                    if constexpr (k > 0) g[k] *= Ldi[i];
+                    const float z = g[k];
+                    sfor<M::nanc[gi] - k>([&](auto T) MI_LAMBDA {
+                        constexpr int kk = k + 1 + T, j = M::anc[gi][kk - 1];
+                        g[kk] -= L[M::midx[i][j]] * z;
+                    });
+                });
+                float a = P.cfm;
+                sfor<M::nanc[gi] + 1>([&](auto K) MI_LAMBDA { a += g[K] * g[K]; G(row, K) = g[K]; });
+                Ainv(row) = MI_RCP(a);
+                vt(row) = (C >= 0.f) ? -C * invh : fminf(-C * P.erp * invh, P.max_depen_vel);
+                lam(row) = l0;
+            }
+        });
+        MI_PHASE();
+        // ------------------------------------------------------------ object contacts -> compact slots
+        int cnt = 0;
+        sfor<NOS>([&](auto S_) MI_LAMBDA {
+            constexpr int s = S_, b = M::os_body[s];
+            const float* cs = c.ocs[s];
+            const float rel[3] = {cs[0] - xo[0], cs[1] - xo[1], cs[2] - xo[2]};
+            float cl[3], nl[3], dist;
+            matTvec3(Ro, rel, cl);
+            sphere_box(cl, M::os_rad[s], OP.half, &dist, nl);
+            const bool on = (dist < P.contact_offset) && (cnt < KMAX);
+            const int j = on ? cnt : -1;
+            if (on) {
+                float fr[3][3];
+                matvec3(Ro, nl, fr[0]);                 // from the object towards the sphere
+                contact_frame(fr[0], fr[1], fr[2]);
+                float pc[3], rc[3];
+                sfor<3>([&](auto K) MI_LAMBDA { pc[K] = cs[K] - M::os_rad[s] * fr[0][K]; rc[K] = pc[K] - xo[K]; });
+                float* cb = rows.ptr(H_CB + j * H_CSZ);
+                const float gap = dist - P.rest_offset;
+                sfor<3>([&](auto K) MI_LAMBDA {
+                    constexpr int k = K;
+                    float W[6];
+                    cross3(pc, fr[k], W);
+                    W[3] = fr[k][0]; W[4] = fr[k][1]; W[5] = fr[k][2];
+                    float g[UCH];
+                    sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { g[C] = dot6(S[M::chain[b][C] - OFF], W); });
+                    // chain solve (descending indices; the later entries of a chain are exactly the ancestors)
+                    sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA {
+                        constexpr int kk0 = C, i = M::chain[b][kk0];
+                        const float z = g[kk0] * Ldi[i];
+                        g[kk0] = z;
+                        sfor<M::chain_len[b] - 1 - kk0>([&](auto T) MI_LAMBDA {
+                            constexpr int kk = kk0 + 1 + T, jj = M::chain[b][kk];
+                            g[kk] -= L[M::midx[i][jj]] * z;
+                        });
+                    });
+                    // object part: J_o = -[u; rc x u], whitened by the constant diagonal
+                    float cx[3];
+                    cross3(rc, fr[k], cx);
+                    sfor<3>([&](auto I_) MI_LAMBDA { g[M::chain_len[b] + I_] = -fr[k][I_] * ism; g[M::chain_len[b] + 3 + I_] = -cx[I_] * isi; });
+                    float a = P.cfm;
+                    sfor<M::chain_len[b] + 6>([&](auto C) MI_LAMBDA { a += g[C] * g[C]; cb[(k * UCH + C) * ST] = g[C]; });
+                    cb[(3 * UCH + k) * ST] = MI_RCP(a);
+                    cb[(3 * UCH + 4 + k) * ST] = 0.f;    // no warm start for object contacts
+                });
+                cb[(3 * UCH + 3) * ST] = (gap >= 0.f) ? -gap * invh : fminf(-gap * P.erp * invh, P.max_depen_vel);
+            }
+            cnt += on ? 1 : 0;
+            rows(H_SLOTOF + s) = __builtin_bit_cast(float, j);
+        });
+        *ncontact = cnt;
+        MI_PHASE();
+        // ------------------------------------------------------------ warm start (limit rows only)
+        {
+            int zero;
+            MI_OPAQUE_ZERO(zero);
+            const RowStore<RS> rit = rows.shifted(zero);
+            sfor<ND>([&](auto D) MI_LAMBDA {
+                constexpr int d = D, gi = OFF + d;
+                if constexpr (M::dof_limited[d]) {
+                    constexpr int row = B::limrow(d), g0 = B::limoff(row);
+                    const float l0 = rit(H_LIMG + 2 * NLIM + row);
+                    w[gi] += rit(g0) * l0;
+                    sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { w[M::anc[gi][A_]] += rit(g0 + 1 + A_) * l0; });
+                }
+            });
+        }
+        MI_PHASE();
+        // ------------------------------------------------------------ projected Gauss-Seidel sweeps
+        for (int it = 0; it < P.iters; ++it) {
+            int zero;
+            MI_OPAQUE_ZERO(zero);
+            const RowStore<RS> rit = rows.shifted(zero);
+            sfor<ND>([&](auto D) MI_LAMBDA {
+                constexpr int d = D, gi = OFF + d;
+                if constexpr (M::dof_limited[d]) {
+                    constexpr int row = B::limrow(d), g0 = B::limoff(row);
+                    float g[M::MAXCHAIN];
+                    sfor<M::nanc[gi] + 1>([&](auto K) MI_LAMBDA { g[K] = rit(g0 + K); });
+                    float vn = g[0] * w[gi];
+                    sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { vn += g[1 + A_] * w[M::anc[gi][A_]]; });
+                    const float lo = rit(H_LIMG + 2 * NLIM + row);
+                    const float nl_ = fmaxf(lo - (vn - rit(H_LIMG + NLIM + row)) * rit(H_LIMG + row), 0.f);
+                    const float dl = nl_ - lo;
+                    rit(H_LIMG + 2 * NLIM + row) = nl_;
+                    w[gi] += g[0] * dl;
+                    sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { w[M::anc[gi][A_]] += g[1 + A_] * dl; });
+                }
+            });
+            sfor<NOS>([&](auto S_) MI_LAMBDA {
+                constexpr int s = S_, b = M::os_body[s], CL = M::chain_len[b];
+                const int j = __builtin_bit_cast(int, rit(H_SLOTOF + s));
+                if (j >= 0) {
+                    float* cb = rit.ptr(H_CB + j * H_CSZ);
+                    float g[3][UCH], ainv[3], lm[3];
+                    sfor<3>([&](auto K) MI_LAMBDA {
+                        sfor<CL + 6>([&](auto C) MI_LAMBDA { g[K][C] = cb[(K * UCH + C) * ST]; });
+                        ainv[K] = cb[(3 * UCH + K) * ST];
+                        lm[K] = cb[(3 * UCH + 4 + K) * ST];
+                    });
+                    const float vtn = cb[(3 * UCH + 3) * ST];
+                    auto rowvel = [&](int k) MI_LAMBDA {
+                        float vn = 0.f;
+                        sfor<CL>([&](auto C) MI_LAMBDA { vn += g[k][C] * w[M::chain[b][C]]; });
+                        sfor<6>([&](auto C) MI_LAMBDA { vn += g[k][CL + C] * wo[C]; });
+                        return vn;
+                    };
+                    auto apply = [&](int k, float dl) MI_LAMBDA {
+                        sfor<CL>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += g[k][C] * dl; });
+                        sfor<6>([&](auto C) MI_LAMBDA { wo[C] += g[k][CL + C] * dl; });
+                    };
+                    const float ln = fmaxf(lm[0] - (rowvel(0) - vtn) * ainv[0], 0.f);
+                    apply(0, ln - lm[0]);
+                    float lt[2];
+                    sfor<2>([&](auto K) MI_LAMBDA {
+                        const float dl = -rowvel(1 + K) * ainv[1 + K];
+                        lt[K] = lm[1 + K] + dl;
+                        apply(1 + K, dl);
+                    });
+                    const float lim = OP.mu * ln;
+                    const float n2 = lt[0] * lt[0] + lt[1] * lt[1];
+                    const float sc = (n2 > lim * lim) ? lim * MI_RSQ(fmaxf(n2, 1e-30f)) : 1.f;
+                    cb[(3 * UCH + 4) * ST] = ln;
+                    sfor<2>([&](auto K) MI_LAMBDA {
+                        const float nl_ = lt[K] * sc;
+                        cb[(3 * UCH + 5 + K) * ST] = nl_;
+                        apply(1 + K, nl_ - lt[K]);
+                    });
+                }
+            });
+        }
+        MI_PHASE();
+        // ------------------------------------------------------------ back to generalised velocity
+        float v[NVA];
+        sfor<NV>([&](auto I_) MI_LAMBDA {
+            constexpr int i = I_;
+            float s = w[i];
+            sfor<M::nanc[i]>([&](auto A_) MI_LAMBDA { s -= L[M::midx[i][M::anc[i][A_]]] * v[M::anc[i][A_]]; });
+            v[i] = s * Ldi[i];
+        });
+        // ------------------------------------------------------------ outputs: limit impulses, dof forces, fingertip sensors
+        sfor<ND>([&](auto D) MI_LAMBDA {
+            constexpr int d = D;
+            float ll = 0.f;
+            if constexpr (M::dof_limited[d]) {
+                constexpr int row = B::limrow(d);
+                const float dl = q[d] - M::dof_lower[d], du = M::dof_upper[d] - q[d];
+                ll = (dl < du) ? lam(row) : -lam(row);
+            }
+            laml(d) = ll;
+            dof_force(d) = -M::dof_kp[d] * (q[d] - target[d]) - M::dof_damping[d] * v[OFF + d] + ll * invh;
+        });
+        float sens[6 * M::NSENSA];
+        sfor<6 * NSENS>([&](auto K) MI_LAMBDA { sens[K] = 0.f; });
+        sfor<NOS>([&](auto S_) MI_LAMBDA {
+            constexpr int s = S_, b = M::os_body[s];
+            if constexpr (sensor_of(b) >= 0) {
+                constexpr int k = sensor_of(b);
+                const int j = __builtin_bit_cast(int, rows(H_SLOTOF + s));
+                if (j >= 0) {
+                    const float* cb = rows.ptr(H_CB + j * H_CSZ);
+                    const float ln = cb[(3 * UCH + 4) * ST], l1 = cb[(3 * UCH + 5) * ST], l2 = cb[(3 * UCH + 6) * ST];
+                    // the frame is re-derived (neither body has moved yet)
+                    const float* cs = c.ocs[s];
+                    const float rel[3] = {cs[0] - xo[0], cs[1] - xo[1], cs[2] - xo[2]};
+                    float cl[3], nl[3], dist, n[3], t1[3], t2[3];
+                    matTvec3(Ro, rel, cl);
+                    sphere_box(cl, M::os_rad[s], OP.half, &dist, nl);
+                    matvec3(Ro, nl, n);
+                    contact_frame(n, t1, t2);
+                    float f[3], arm[3], tq[3], fl[3], tl[3];
+                    sfor<3>([&](auto K) MI_LAMBDA {
+                        f[K] = (n[K] * ln + t1[K] * l1 + t2[K] * l2) * invh;
+                        arm[K] = cs[K] - M::os_rad[s] * n[K] - c.rs[k][K];
+                    });
+                    cross3(arm, f, tq);
+                    matTvec3(c.Rs[k], f, fl); matTvec3(c.Rs[k], tq, tl);
+                    sfor<3>([&](auto C) MI_LAMBDA { sens[6 * k + C] += fl[C]; sens[6 * k + 3 + C] += tl[C]; });
+                }
+            }
+        });
+        sfor<6 * NSENS>([&](auto K) MI_LAMBDA { sensor(K) = sens[K]; });
+        MI_PHASE();
+        // ------------------------------------------------------------ integrate hand and object (semi-implicit Euler)
+        sfor<ND>([&](auto D) MI_LAMBDA { qd[D] = v[OFF + D]; q[D] += h * qd[D]; });
+        sfor<3>([&](auto K) MI_LAMBDA {
+            obj.vel[K] = wo[K] * ism; obj.angvel[K] = wo[3 + K] * isi;
+            obj.pos[K] += h * obj.vel[K];
+        });
+        {
+            const float* om = obj.angvel;
+            const float an = MI_SQRT(dot3(om, om)), th = an * h;
+            float sn, cs;
+            sincosf(0.5f * th, &sn, &cs);
+            const bool big = th > 1e-12f;
+            const float k = big ? sn * MI_RCP(fmaxf(an, 1e-30f)) : 0.5f * h;
+            const float dq[4] = {om[0] * k, om[1] * k, om[2] * k, big ? cs : 1.f};
+            float* Q = obj.quat;
+            const float x = dq[3] * Q[0] + dq[0] * Q[3] + dq[1] * Q[2] - dq[2] * Q[1];
+            const float yy = dq[3] * Q[1] - dq[0] * Q[2] + dq[1] * Q[3] + dq[2] * Q[0];
+            const float z = dq[3] * Q[2] + dq[0] * Q[1] - dq[1] * Q[0] + dq[2] * Q[3];
+            const float ww = dq[3] * Q[3] - dq[0] * Q[0] - dq[1] * Q[1] - dq[2] * Q[2];
+            const float n = MI_RSQ(x * x + yy * yy + z * z + ww * ww);
+            Q[0] = x * n; Q[1] = yy * n; Q[2] = z * n; Q[3] = ww * n;
+        }
+    }
+
+    // world pose and velocity of the force-sensor (fingertip) bodies at the CURRENT state: [NSENS][13] = pos3, quat xyzw,
+    // linvel3, angvel3 -- what gym.refresh_rigid_body_state_tensor exposes (shadow_hand.py:440,456-457)
+    MI_HD void fingertip_states(float (*out)[13]) {
+        sfor<NSENS>([&](auto K_) MI_LAMBDA {
+            constexpr int k = K_, tip = M::sens_body[k];
+            // walk the chain root -> tip (static): bodies on the path, in order
+            float Rb[9], rb[3] = {0.f, 0.f, 0.f}, om[3] = {0.f, 0.f, 0.f}, vl[3] = {0.f, 0.f, 0.f};
+            quat2mat(this->root + 3, Rb);
+            sfor<NB>([&](auto B_) MI_LAMBDA {
+                constexpr int b = B_;
+                if constexpr (b > 0 && is_ancestor_or_self(b, tip)) {
+                    // parent frame -> body frame (same steps as body_pass)
+                    float t[3];
+                    matvec3(Rb, M::bpos[b], t);
+                    // velocity of the new origin: v += om x t
+                    float cx[3];
+                    cross3(om, t, cx);
+                    sfor<3>([&](auto I_) MI_LAMBDA { rb[I_] += t[I_]; vl[I_] += cx[I_]; });
+                    if constexpr (!B::brot_is_identity(b)) matmul3(Rb, M::brot[b], Rb);
+                    sfor<M::body_ndof[b]>([&](auto J_) MI_LAMBDA {
+                        constexpr int d = M::body_dof0[b] + J_;
+                        constexpr float ax = M::dof_axis[d][0], ay = M::dof_axis[d][1], az = M::dof_axis[d][2];
+                        const float al[3] = {ax, ay, az}, anl[3] = {M::dof_anchor[d][0], M::dof_anchor[d][1], M::dof_anchor[d][2]};
+                        float a[3], ta[3];
+                        matvec3(Rb, al, a);
+                        matvec3(Rb, anl, ta);
+                        static_assert(M::dof_type[d] == 0, "fingertip chains are hinge-only");
+                        float s_, c_;
+                        sincosf(this->q[d], &s_, &c_);
+                        const float tt = 1.f - c_;
+                        const float Q[9] = {c_ + ax * ax * tt, ax * ay * tt - az * s_, ax * az * tt + ay * s_,
+                                            ay * ax * tt + az * s_, c_ + ay * ay * tt, ay * az * tt - ax * s_,
+                                            az * ax * tt - ay * s_, az * ay * tt + ax * s_, c_ + az * az * tt};
+                        matmul3(Rb, Q, Rb);
+                        float tb[3];
+                        matvec3(Rb, anl, tb);
+                        // the body origin moves on a circle about the anchor: r = pt - tb ; its velocity picks up the joint
+                        // rate about the anchor
+                        const float dr[3] = {ta[0] - tb[0], ta[1] - tb[1], ta[2] - tb[2]};
+                        float c1[3], c2[3];
+                        cross3(om, dr, c1);
+                        const float wj[3] = {a[0] * this->qd[d], a[1] * this->qd[d], a[2] * this->qd[d]};
+                        const float mtb[3] = {-tb[0], -tb[1], -tb[2]};
+                        cross3(wj, mtb, c2);
+                        sfor<3>([&](auto I_) MI_LAMBDA { rb[I_] += dr[I_]; vl[I_] += c1[I_] + c2[I_]; om[I_] += wj[I_]; });
+                    });
+                }
+            });
+            float* o = out[k];
+            sfor<3>([&](auto I_) MI_LAMBDA { o[I_] = this->root[I_] + rb[I_]; o[7 + I_] = vl[I_]; o[10 + I_] = om[I_]; });
+            mat2quat(Rb, o + 3);
+        });
+    }
+    static constexpr bool is_ancestor_or_self(int a, int b) {
+        while (b >= 0) { if (b == a) return true; b = M::parent[b]; }
+        return false;
+    }
+    // rotation matrix -> quaternion xyzw (Shepperd), w >= 0 branch first
+    MI_HD static void mat2quat(const float* R, float* qo) {
+        const float tr = R[0] + R[4] + R[8];
+        float x, y, z, w;
+        if (tr > 0.f) {
+            const float s = sqrtf(tr + 1.f) * 2.f;
+            w = 0.25f * s; x = (R[7] - R[5]) / s; y = (R[2] - R[6]) / s; z = (R[3] - R[1]) / s;
+        } else if (R[0] > R[4] && R[0] > R[8]) {
+            const float s = sqrtf(1.f + R[0] - R[4] - R[8]) * 2.f;
+            w = (R[7] - R[5]) / s; x = 0.25f * s; y = (R[1] + R[3]) / s; z = (R[2] + R[6]) / s;
+        } else if (R[4] > R[8]) {
+            const float s = sqrtf(1.f + R[4] - R[0] - R[8]) * 2.f;
+            w = (R[2] - R[6]) / s; x = (R[1] + R[3]) / s; y = 0.25f * s; z = (R[5] + R[7]) / s;
+        } else {
+            const float s = sqrtf(1.f + R[8] - R[0] - R[4]) * 2.f;
+            w = (R[3] - R[1]) / s; x = (R[2] + R[6]) / s; y = (R[5] + R[7]) / s; z = 0.25f * s;
+        }
+        qo[0] = x; qo[1] = y; qo[2] = z; qo[3] = w;
+    }
+};
+
+}  // namespace mi

@@ -16,7 +16,16 @@ MODELS = {
     "humanoid": dict(struct="ModelHumanoid", sensors=["right_foot", "left_foot"]),
     # reference anymal_terrain.py: no force sensors (it reads net contact forces per body, :119)
     "anymal": dict(struct="ModelAnymal", sensors=[]),
+    # reference shadow_hand.py:291-297: force sensors on the five fingertips (distal links)
+    "shadow_hand": dict(struct="ModelShadowHand", sensors=["robot0:ffdistal", "robot0:mfdistal", "robot0:rfdistal", "robot0:lfdistal",
+                                                           "robot0:thdistal"], extras="shadow_hand_extras.json"),
 }
+
+
+def load_extras(name):
+    import json
+    with open(os.path.join(_HERE, "models", MODELS[name]["extras"])) as f:
+        return json.load(f)
 
 
 def load_model(name) -> ModelSpec:
@@ -34,7 +43,12 @@ def generate_headers(out_dir=None):
     paths = []
     for name, e in MODELS.items():
         spec = load_model(name)
-        txt = emit_model_header(spec, e["struct"], sensor_bodies(name, spec))
+        extras = None
+        if e.get("extras"):
+            import json
+            with open(os.path.join(_HERE, "models", e["extras"])) as f:
+                extras = json.load(f)
+        txt = emit_model_header(spec, e["struct"], sensor_bodies(name, spec), extras)
         p = os.path.join(out_dir, f"model_{name}.h")
         write_if_changed(p, txt)
         paths.append(p)

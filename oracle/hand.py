@@ -1,0 +1,242 @@
+"""CPU oracle of the Shadow-Hand physics step (fixed-base 24-DoF hand + one free cube).  TEST INFRASTRUCTURE ONLY.
+
+Same stated algorithm as csrc/core/hand_engine.hpp, deliberately written differently: dense generalized-coordinate
+matrices from oracle/physics.c (or_dynamics / or_point_jac / or_energy), numpy linear algebra in fp64, PGS in
+generalized-velocity space.  What it replaces in the reference: gym.simulate() for the ShadowHand task
+(reference isaacgymenvs/tasks/shadow_hand.py; closed PhysX => PARITY UNPINNED).
+
+  hand   : joint-space dynamics, gravity disabled (shadow_hand.py:239), implicit PD position drives
+           tau = kp (target - q) - D qd (kp from the MJCF position actuators, shared.xml:250-269), joint-limit rows,
+           4 fixed tendons as soft two-sided limits (limit_stiffness 30, damping 0.1, shadow_hand.py:256-266)
+  object : free rigid cube (5 cm, density 567 => isotropic inertia), gravity on
+  contact: hand collision geometry sampled by spheres (models/shadow_hand_extras.json) against the exact box; at most
+           KMAX active contacts per env (taken in sphere order), 3 rows each (normal + friction disc), no warm start
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .engine import OracleEngine, _ptr
+
+KMAX = 16
+CUBE_HALF = 0.025
+CUBE_MASS = 567.0 * 0.05 ** 3                      # cube_multicolor.urdf: box 0.05, density 567
+CUBE_INERTIA = CUBE_MASS * 0.05 ** 2 / 6.0         # isotropic
+
+
+def quat2mat(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def contact_frame(n):
+    a = np.array([1 - n[0] * n[0], -n[0] * n[1], -n[0] * n[2]])
+    na = np.linalg.norm(a)
+    t1 = a / na if na > 1e-6 else np.array([0.0, 1.0, 0.0])       # n = +-x: fall back to y
+    return t1, np.cross(n, t1)
+
+
+def sphere_box(c_local, r, half):
+    """signed distance of a sphere (centre in box frame) to a cube of half size `half`, outward normal (box frame)."""
+    qc = np.clip(c_local, -half, half)
+    d = c_local - qc
+    nd = np.linalg.norm(d)
+    if nd > 1e-12:
+        return nd - r, d / nd
+    pen = half - np.abs(c_local)
+    i = int(np.argmin(pen))
+    n = np.zeros(3)
+    n[i] = 1.0 if c_local[i] >= 0 else -1.0
+    return -pen[i] - r, n
+
+
+class OracleHandEngine:
+    def __init__(self, spec, extras, num_envs, sim: dict, sensor_bodies):
+        self.spec, self.ex, self.N = spec, extras, num_envs
+        self.eng = OracleEngine(spec, num_envs, params=dict(sim, gravity=(0.0, 0.0, 0.0)), sensor_bodies=sensor_bodies, precision="f64")
+        self.sim = sim
+        self.nd = spec.nd
+        self.kp = np.array(extras["dof_kp"], float)
+        self.os_body = np.array(extras["os_body"]); self.os_pos = np.array(extras["os_pos"], float); self.os_rad = np.array(extras["os_rad"], float)
+        self.sens = list(sensor_bodies)
+        N, nd = num_envs, self.nd
+        self.eng.root[:, :3] = [0.0, 0.0, 0.5]
+        self.eng.root[:, 3:7] = extras["mount_quat"]
+        self.targets = np.zeros((N, nd))
+        self.obj = np.zeros((N, 13)); self.obj[:, 6] = 1.0
+        self.sensor = np.zeros((N, 6 * len(self.sens)))
+        self.dof_force = np.zeros((N, nd))
+        self.ncontacts = np.zeros(N, int)
+        self.lo = np.minimum(spec.dof_lower, spec.dof_upper); self.up = np.maximum(spec.dof_lower, spec.dof_upper)
+
+    # views on the wrapped engine's state
+    @property
+    def q(self): return self.eng.q
+    @property
+    def qd(self): return self.eng.qd
+    @property
+    def laml(self): return self.eng.lam[:, :]     # nsph = 0 => lam is just the limit impulses
+
+    def _poses(self, e):
+        _, _, bp = self.eng.energy(e, poses=True)
+        return bp
+
+    def fingertip_states(self):
+        """[N, 5, 13] world pos, quat xyzw, linvel, angvel of the sensor (fingertip) bodies."""
+        from isaacgymenvs_amd.assets.model import mat_to_quat
+        out = np.zeros((self.N, len(self.sens), 13))
+        v6 = np.zeros(6)
+        for e in range(self.N):
+            bp = self._poses(e)
+            s = np.ascontiguousarray(self.eng.state[e])
+            for k, b in enumerate(self.sens):
+                self.eng.lib.or_body_vel(C.byref(self.eng.model), _ptr(s), b, _ptr(v6))
+                p = bp[b, 0:3]; R = bp[b, 3:12].reshape(3, 3)
+                r = p - self.eng.root[e, :3]
+                out[e, k, 0:3] = p; out[e, k, 3:7] = mat_to_quat(R)
+                out[e, k, 7:10] = v6[3:6] + np.cross(v6[0:3], r); out[e, k, 10:13] = v6[0:3]
+        return out
+
+    def step(self):
+        P = self.sim
+        h = P["dt"] / P["substeps"]
+        for _ in range(P["substeps"]):
+            for e in range(self.N):
+                self._substep_env(e, h)
+
+    def _substep_env(self, e, h):
+        P, nd, spec, ex = self.sim, self.nd, self.spec, self.ex
+        q, qd, tgt = self.q[e].copy(), self.qd[e].copy(), self.targets[e]
+        M, bias = self.eng.dynamics(e)
+        D = np.array(spec.dof_damping, float)
+        Mh = M + np.diag(np.array(spec.dof_armature, float) + h * D + h * h * self.kp)
+        rhs = -bias - self.kp * (q - tgt) - (D + h * self.kp) * qd
+        for t in ex["tendons"]:                                   # soft two-sided limit on the tendon length
+            d0, d1 = t["dof"]; c0, c1 = t["coef"]; lo, hi = t["range"]
+            Lt = c0 * q[d0] + c1 * q[d1]
+            Ld = c0 * qd[d0] + c1 * qd[d1]
+            viol = Lt - min(max(Lt, lo), hi)
+            k = ex["tendon_limit_stiffness"] if viol != 0.0 else 0.0
+            dmp = ex["tendon_damping"]
+            cvec = np.zeros(nd); cvec[d0] = c0; cvec[d1] = c1
+            Mh += (h * dmp + h * h * k) * np.outer(cvec, cvec)
+            rhs -= cvec * (k * viol + (dmp + h * k) * Ld)
+        Minv = np.linalg.inv(Mh)
+        v = qd + h * (Minv @ rhs)
+        g = np.array(P["gravity"], float)
+        xo, qo = self.obj[e, 0:3].copy(), self.obj[e, 3:7].copy()
+        vo = self.obj[e, 7:10] + h * g
+        wo = self.obj[e, 10:13].copy()
+        Ro = quat2mat(qo)
+        # ---- rows
+        rows = []   # (Jh[nd], Jo[6], vt, kind, idx)
+        lim_sign = {}
+        for d in range(nd):
+            if not spec.dof_limited[d]:
+                self.laml[e, d] = 0.0
+                continue
+            dl, du = q[d] - self.lo[d], self.up[d] - q[d]
+            Cc, s = (dl, 1.0) if dl < du else (du, -1.0)
+            lw = self.laml[e, d]
+            l0 = (0.0 if lw * s < 0 else abs(lw)) * P["warm"]
+            Jh = np.zeros(nd); Jh[d] = s
+            vt = -Cc / h if Cc >= 0 else min(-Cc * P["erp"] / h, P["max_depen_vel"])
+            rows.append(dict(Jh=Jh, Jo=np.zeros(6), vt=vt, lam=l0, kind="lim", d=d, s=s))
+        bp = self._poses(e)
+        O = self.eng.root[e, :3]
+        s_state = np.ascontiguousarray(self.eng.state[e])
+        J3 = np.zeros((3, nd))
+        ncon = 0
+        contacts = []
+        for si in range(len(self.os_body)):
+            b = int(self.os_body[si])
+            c = bp[b, 0:3] + bp[b, 3:12].reshape(3, 3) @ self.os_pos[si]      # world
+            dist, nl = sphere_box(Ro.T @ (c - xo), self.os_rad[si], CUBE_HALF)
+            if dist >= P["contact_offset"] or ncon >= KMAX:
+                continue
+            n = Ro @ nl                                                   # from the cube towards the sphere
+            t1, t2 = contact_frame(n)
+            pc = c - self.os_rad[si] * n                                  # contact point, world
+            self.eng.lib.or_point_jac(C.byref(self.eng.model), _ptr(s_state), b, _ptr(np.ascontiguousarray(pc - O)), _ptr(J3))
+            rc = pc - xo
+            gap = dist - P["rest_offset"]
+            vtn = -gap / h if gap >= 0 else min(-gap * P["erp"] / h, P["max_depen_vel"])
+            for k, u in enumerate((n, t1, t2)):
+                Jo = -np.concatenate([u, np.cross(rc, u)])
+                rows.append(dict(Jh=u @ J3, Jo=Jo, vt=vtn if k == 0 else 0.0, lam=0.0, kind="con", k=k, c=ncon))
+            contacts.append(dict(b=b, pc=pc, n=n, t1=t1, t2=t2, row0=len(rows) - 3))
+            ncon += 1
+        self.ncontacts[e] = ncon
+        Moinv = np.array([1 / CUBE_MASS] * 3 + [1 / CUBE_INERTIA] * 3)
+        for r in rows:
+            r["Bh"] = Minv @ r["Jh"]; r["Bo"] = Moinv * r["Jo"]
+            r["Ainv"] = 1.0 / (P["cfm"] + r["Jh"] @ r["Bh"] + r["Jo"] @ r["Bo"])
+            if r["lam"] != 0.0:
+                v += r["Bh"] * r["lam"]
+        vobj = np.concatenate([vo, wo])
+        mu = 0.5 * (1.0 + 1.0)                                            # hand geom friction 1 (shared.xml:12), cube default 1
+        for _ in range(P["iters"]):
+            i = 0
+            while i < len(rows):
+                r = rows[i]
+                if r["kind"] == "lim":
+                    vn = r["Jh"] @ v
+                    nl_ = max(r["lam"] - (vn - r["vt"]) * r["Ainv"], 0.0)
+                    dl = nl_ - r["lam"]; r["lam"] = nl_
+                    v += r["Bh"] * dl
+                    i += 1
+                else:
+                    rn, ra, rb = rows[i], rows[i + 1], rows[i + 2]
+                    vn = rn["Jh"] @ v + rn["Jo"] @ vobj
+                    ln = max(rn["lam"] - (vn - rn["vt"]) * rn["Ainv"], 0.0)
+                    dl = ln - rn["lam"]; rn["lam"] = ln
+                    v += rn["Bh"] * dl; vobj += rn["Bo"] * dl
+                    lt = []
+                    for rt in (ra, rb):
+                        vt_ = rt["Jh"] @ v + rt["Jo"] @ vobj
+                        dl = -vt_ * rt["Ainv"]
+                        lt.append(rt["lam"] + dl)
+                        v += rt["Bh"] * dl; vobj += rt["Bo"] * dl
+                    lim = mu * ln
+                    nrm = np.hypot(lt[0], lt[1])
+                    sc = lim / max(nrm, 1e-30) if nrm > lim else 1.0
+                    for rt, l in zip((ra, rb), lt):
+                        nl_ = l * sc; dl = nl_ - l; rt["lam"] = nl_
+                        v += rt["Bh"] * dl; vobj += rt["Bo"] * dl
+                    i += 3
+        # ---- outputs
+        ll = np.zeros(nd)
+        for r in rows:
+            if r["kind"] == "lim":
+                ll[r["d"]] = r["lam"] * r["s"]
+        self.laml[e] = ll
+        self.dof_force[e] = -self.kp * (q - tgt) - D * v + ll / h
+        sens = np.zeros(6 * len(self.sens))
+        for cdat in contacts:
+            if cdat["b"] in self.sens:
+                k = self.sens.index(cdat["b"])
+                r0 = cdat["row0"]
+                f = (cdat["n"] * rows[r0]["lam"] + cdat["t1"] * rows[r0 + 1]["lam"] + cdat["t2"] * rows[r0 + 2]["lam"]) / h
+                Rb = bp[cdat["b"], 3:12].reshape(3, 3); pb = bp[cdat["b"], 0:3]
+                sens[6 * k:6 * k + 3] += Rb.T @ f
+                sens[6 * k + 3:6 * k + 6] += Rb.T @ np.cross(cdat["pc"] - pb, f)
+        self.sensor[e] = sens
+        # ---- integrate
+        self.qd[e] = v; self.q[e] = q + h * v
+        self.obj[e, 7:10] = vobj[:3]; self.obj[e, 10:13] = vobj[3:]
+        self.obj[e, 0:3] = xo + h * vobj[:3]
+        om = vobj[3:]; an = np.linalg.norm(om); th = an * h
+        if th > 1e-12:
+            dq = np.concatenate([om * np.sin(th / 2) / an, [np.cos(th / 2)]])
+        else:
+            dq = np.concatenate([om * h / 2, [1.0]])
+        Q = qo
+        x = dq[3] * Q[0] + dq[0] * Q[3] + dq[1] * Q[2] - dq[2] * Q[1]
+        y = dq[3] * Q[1] - dq[0] * Q[2] + dq[1] * Q[3] + dq[2] * Q[0]
+        z = dq[3] * Q[2] + dq[0] * Q[1] - dq[1] * Q[0] + dq[2] * Q[3]
+        w = dq[3] * Q[3] - dq[0] * Q[0] - dq[1] * Q[1] - dq[2] * Q[2]
+        qn = np.array([x, y, z, w]); self.obj[e, 3:7] = qn / np.linalg.norm(qn)

@@ -334,8 +334,9 @@ static void ground_query(const OrGround *g, real ground_z, real x, real y, real 
 /* contact frame: n, t1 = normalize(x - n (n.x)), t2 = n x t1   (n = z gives t1 = x, t2 = y) */
 static void contact_frame(const real *n, real *t1, real *t2) {
     real a[3] = {1 - n[0] * n[0], -n[0] * n[1], -n[0] * n[2]};
-    real inv = 1 / RSQRT(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
-    t1[0] = a[0] * inv; t1[1] = a[1] * inv; t1[2] = a[2] * inv;
+    real a2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
+    if (a2 > (real)1e-12) { real inv = 1 / RSQRT(a2); t1[0] = a[0] * inv; t1[1] = a[1] * inv; t1[2] = a[2] * inv; }
+    else { t1[0] = 0; t1[1] = 1; t1[2] = 0; }
     v3cross(n, t1, t2);
 }
 
@@ -599,6 +600,24 @@ void or_energy(const OrModel *m, const OrParams *p, const real *state, real *ke,
         }
     }
     *ke = K; *pe = P;
+}
+
+/* linear Jacobian (3 x nv, rows = world x, y, z) of a point fixed on body b, given relative to O (oracle/hand.py) */
+void or_point_jac(const OrModel *m, const real *state, int b, const real *xc, real *J3) {
+    static _Thread_local Work w;
+    int nv = nvof(m);
+    fk(m, state, state + 13, &w);
+    const real dirs[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int k = 0; k < 3; k++) point_jac(m, &w, b, xc, dirs[k], J3 + k * nv);
+}
+
+/* spatial velocity [omega; v_O] of body b about O, world axes (oracle/hand.py: fingertip states) */
+void or_body_vel(const OrModel *m, const real *state, int b, real *out6) {
+    static _Thread_local Work w;
+    const real zero[3] = {0, 0, 0};
+    fk(m, state, state + 13, &w);
+    rnea_bias(m, state, state + 13 + m->nd, zero, &w);
+    for (int k = 0; k < 6; k++) out6[k] = w.V[b][k];
 }
 
 int or_sizeof_real(void) { return (int)sizeof(real); }

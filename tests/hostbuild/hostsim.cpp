@@ -6,6 +6,10 @@
 #include "../../isaacgymenvs_amd/csrc/gen/model_cartpole.h"
 #include "../../isaacgymenvs_amd/csrc/gen/model_ant.h"
 #include "../../isaacgymenvs_amd/csrc/gen/model_anymal.h"
+#ifdef HOSTSIM_HAND
+#include "../../isaacgymenvs_amd/csrc/core/hand_engine.hpp"
+#include "../../isaacgymenvs_amd/csrc/gen/model_shadow_hand.h"
+#endif
 #ifndef HOSTSIM_NO_HUMANOID
 #include "../../isaacgymenvs_amd/csrc/gen/model_humanoid.h"
 #endif
@@ -64,3 +68,46 @@ extern "C" int hs_step_terrain(const char* model, const SimParams* P, int nenv, 
     }
     return 0;
 }
+
+#ifdef HOSTSIM_HAND
+// Shadow hand + cube: per env  q[24] | qd[24] | laml[24] | target[24] | obj[13]  ->  updated in place; out: sensor[30] | dof_force[24] | ncontact
+extern "C" int hs_step_hand(const SimParams* P, int nenv, float* state, float* out, const float* root13, float half, float mass, float inertia,
+                            float mu) {
+    using M = ModelShadowHand;
+    constexpr int ND = M::ND, NS = M::NSENS;
+    const int ss = 4 * ND + 13, os = 6 * NS + ND + 1;
+    const ObjectParams OP{half, mass, inertia, mu};
+#pragma omp parallel for schedule(static)
+    for (int e = 0; e < nenv; ++e) {
+        float* s = state + (size_t)e * ss;
+        float* o = out + (size_t)e * os;
+        HandSim<M> sim;
+        for (int k = 0; k < 13; ++k) sim.root[k] = root13[k];
+        for (int k = 0; k < ND; ++k) { sim.q[k] = s[k]; sim.qd[k] = s[ND + k]; }
+        float* ob = s + 4 * ND;
+        for (int k = 0; k < 3; ++k) { sim.obj.pos[k] = ob[k]; sim.obj.vel[k] = ob[7 + k]; sim.obj.angvel[k] = ob[10 + k]; }
+        for (int k = 0; k < 4; ++k) sim.obj.quat[k] = ob[3 + k];
+        static thread_local float rows[HandSim<M>::ROW_SLOTS];
+        const float h = P->dt / (float)P->substeps;
+        int nc = 0;
+        for (int it = 0; it < P->substeps; ++it)
+            sim.substep_hand(*P, OP, s + 3 * ND, h, RowStore<1>{rows}, Strided{s + 2 * ND, 1}, Strided{o, 1}, Strided{o + 6 * NS, 1}, &nc);
+        o[6 * NS + ND] = (float)nc;
+        for (int k = 0; k < ND; ++k) { s[k] = sim.q[k]; s[ND + k] = sim.qd[k]; }
+        for (int k = 0; k < 3; ++k) { ob[k] = sim.obj.pos[k]; ob[7 + k] = sim.obj.vel[k]; ob[10 + k] = sim.obj.angvel[k]; }
+        for (int k = 0; k < 4; ++k) ob[3 + k] = sim.obj.quat[k];
+    }
+    return 0;
+}
+extern "C" int hs_hand_fingertips(int nenv, const float* state, const float* root13, float* out /* [nenv][5][13] */) {
+    using M = ModelShadowHand;
+    constexpr int ND = M::ND;
+    for (int e = 0; e < nenv; ++e) {
+        HandSim<M> sim;
+        for (int k = 0; k < 13; ++k) sim.root[k] = root13[k];
+        for (int k = 0; k < ND; ++k) { sim.q[k] = state[(size_t)e * (4 * ND + 13) + k]; sim.qd[k] = state[(size_t)e * (4 * ND + 13) + ND + k]; }
+        sim.fingertip_states((float (*)[13])(out + (size_t)e * M::NSENS * 13));
+    }
+    return 0;
+}
+#endif

@@ -27,6 +27,19 @@ def make_params(d):
     return p
 
 
+def build_hand():
+    from isaacgymenvs_amd.registry import generate_headers
+    hdrs = generate_headers()
+    os.makedirs(_OUT, exist_ok=True)
+    out = os.path.join(_OUT, "libhostsim_hand.so")
+    core = os.path.join(_HERE, "..", "..", "isaacgymenvs_amd", "csrc", "core")
+    deps = hdrs + [os.path.join(_HERE, "hostsim.cpp"), os.path.join(core, "engine.hpp"), os.path.join(core, "hand_engine.hpp")]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-DHOSTSIM_NO_HUMANOID",
+                               "-DHOSTSIM_HAND", os.path.join(_HERE, "hostsim.cpp"), "-o", out])
+    return C.CDLL(out)
+
+
 def build(humanoid=False):
     from isaacgymenvs_amd.registry import generate_headers
     hdrs = generate_headers()

@@ -23,7 +23,73 @@ ENTRIES = {
     # reference anymal_terrain.py:214-231: collapse_fixed_joints, replace_cylinder_with_capsule, density 0.001 (only used
     # for links without <inertial>), armature 0, fix_base_link False
     "anymal": dict(file="urdf/anymal_c/urdf/anymal_minimal.urdf", density=0.001, replace_cylinder_with_capsule=True),
+    # reference shadow_hand.py:234-245: fix_base_link, collapse_fixed_joints; the hand never touches the ground plane (it is
+    # mounted 0.5 m above it, shadow_hand.py:303-304): no ground-contact spheres; its collision geometry is used against
+    # the manipulated cube instead (extras below)
+    "shadow_hand": dict(file="mjcf/open_ai_assets/hand/shadow_hand.xml", fix_base_link=True, collide_body_filter=lambda n: False),
 }
+
+
+def hand_extras(asset_root, spec):
+    """What the generic ModelSpec does not carry for the Shadow Hand (written to models/shadow_hand_extras.json):
+      * object-contact spheres: the collision capsules / boxes of the hand sampled by spheres (capsules: along the axis,
+        boxes: a grid in the mid-plane of the thin dimension) -- the cube is an exact box, the hand side is spheres;
+      * the 4 fixed tendons the task uses (shared.xml:53-69; shadow_hand.py:256-266 sets limit_stiffness 30, damping 0.1);
+      * position-actuator gains kp and force ranges (shared.xml:250-269), the mount orientation (robot.xml:3)."""
+    import json
+    import xml.etree.ElementTree as ET
+    import numpy as np
+    from isaacgymenvs_amd.assets.model import quat_to_mat
+    hand_dir = os.path.join(asset_root, "mjcf/open_ai_assets/hand")
+    sph = []
+    for g in range(len(spec.geom_body)):
+        b, t = int(spec.geom_body[g]), int(spec.geom_type[g])
+        pos, R, size = np.asarray(spec.geom_pos[g], float), quat_to_mat(np.asarray(spec.geom_quat[g], float)), np.asarray(spec.geom_size[g], float)
+        if t == 1:  # capsule: radius, half length along local z
+            r, hl = size[0], size[1]
+            n = max(2, int(np.ceil(2 * hl / (1.6 * r))) + 1)
+            for k in range(n):
+                z = -hl + 2 * hl * k / (n - 1)
+                sph.append((b, pos + R @ np.array([0, 0, z]), r))
+        elif t == 2 and size.min() > 0.005:  # box (the 1 mm thumb helper boxes are skipped)
+            thin = int(np.argmin(size))
+            r = size[thin]
+            others = [a for a in range(3) if a != thin]
+            grids = []
+            for a in others:
+                ext = size[a] - r
+                n = max(1, int(np.ceil(2 * ext / (1.6 * r))) + 1) if ext > 0 else 1
+                grids.append(np.linspace(-ext, ext, n) if n > 1 else np.array([0.0]))
+            for u in grids[0]:
+                for v in grids[1]:
+                    p = np.zeros(3); p[others[0]] = u; p[others[1]] = v
+                    sph.append((b, pos + R @ p, r))
+    shared = ET.parse(os.path.join(hand_dir, "shared.xml")).getroot()
+    dofs = list(spec.dof_names)
+    tendons = []
+    for f in shared.find("tendon").findall("fixed"):
+        if f.get("name") in ("robot0:T_FFJ1c", "robot0:T_MFJ1c", "robot0:T_RFJ1c", "robot0:T_LFJ1c"):
+            js = f.findall("joint")
+            lo, hi = [float(x) for x in f.get("range").split()]
+            tendons.append(dict(name=f.get("name"), dof=[dofs.index(j.get("joint")) for j in js],
+                                coef=[float(j.get("coef")) for j in js], range=[lo, hi]))
+    kp = [0.0] * len(dofs)
+    frc = [0.0] * len(dofs)
+    act_dof = []
+    for a in shared.find("actuator").findall("position"):
+        d = dofs.index(a.get("joint"))
+        kp[d] = float(a.get("kp"))
+        frc[d] = float(a.get("forcerange").split()[1])
+        act_dof.append(d)
+    mount = ET.parse(os.path.join(hand_dir, "robot.xml")).getroot().find("body")
+    ex, ey, ez = [float(x) for x in mount.get("euler").split()]
+    from isaacgymenvs_amd.assets.model import quat_mul
+    qx = np.array([np.sin(ex / 2), 0, 0, np.cos(ex / 2)]); qy = np.array([0, np.sin(ey / 2), 0, np.cos(ey / 2)]); qz = np.array([0, 0, np.sin(ez / 2), np.cos(ez / 2)])
+    q = quat_mul(quat_mul(qx, qy), qz)  # MuJoCo default eulerseq "xyz" (intrinsic)
+    return dict(os_body=[int(s[0]) for s in sph], os_pos=[[float(x) for x in s[1]] for s in sph], os_rad=[float(s[2]) for s in sph],
+                tendons=tendons, tendon_limit_stiffness=30.0, tendon_damping=0.1, dof_kp=kp, dof_force_limit=frc, actuated_dofs=act_dof,
+                mount_quat=[float(x) for x in q],
+                fingertips=["robot0:ffdistal", "robot0:mfdistal", "robot0:rfdistal", "robot0:lfdistal", "robot0:thdistal"])
 
 
 def main():
@@ -36,6 +102,11 @@ def main():
         kw = {k: v for k, v in e.items() if k != "file"}
         spec = load_asset(os.path.join(a.asset_root, e["file"]), name=name, **kw)
         spec.save(os.path.join(a.out, name + ".json"))
+        if name == "shadow_hand":
+            import json
+            with open(os.path.join(a.out, "shadow_hand_extras.json"), "w") as f:
+                full = load_asset(os.path.join(a.asset_root, e["file"]), name=name, fix_base_link=True)   # with collision geoms
+                json.dump(hand_extras(a.asset_root, full), f, indent=1)
         print(f"{name}: nb={spec.nb} nd={spec.nd} nv={spec.nv} nsph={len(spec.sph_body)} mass={spec.total_mass():.4f}")
 
 

@@ -13,11 +13,12 @@ using M = ModelAnt;
 #endif
 using namespace mi;
 constexpr int ND = M::ND, NSPH = M::NSPH, NSENS = M::NSENS;
-constexpr bool LDS_ROWS = (size_t)Sim<M>::ROW_SLOTS * 64 * 4 <= 152 * 1024;
+constexpr int LANES = Sim<M>::LANES;
+constexpr bool LDS_ROWS = (size_t)Sim<M>::ROW_SLOTS * LANES * 4 <= 160 * 1024;
 __global__ __launch_bounds__(64) void k(int N, SimParams P, float* root, float* dof, float* lamc, float* laml, float* sens, float* dff,
                                         unsigned long long* stamps) {
     extern __shared__ float lds_rows[];
-    const int e = blockIdx.x * 64 + threadIdx.x;
+    const int e = blockIdx.x * LANES + threadIdx.x;
     Sim<M> sim;
     for (int i = 0; i < 13; ++i) sim.root[i] = root[i * N + e];
     for (int i = 0; i < ND; ++i) { sim.q[i] = dof[i * N + e]; sim.qd[i] = dof[(ND + i) * N + e]; }
@@ -26,13 +27,14 @@ __global__ __launch_bounds__(64) void k(int N, SimParams P, float* root, float* 
     sim.tstamp = (threadIdx.x == 0) ? stamps + blockIdx.x * 16 : nullptr;
     const float h = P.dt / (float)P.substeps;
     const Strided a{lamc + e, N}, b{laml + e, N}, c{sens + e, N}, d{dff + e, N};
-    if constexpr (LDS_ROWS) sim.substep(P, t, h, RowStore<64>(lds_rows + threadIdx.x), a, b, c, d, PlaneGround{}, -1.f, Strided{nullptr, 1});
+    if constexpr (LDS_ROWS && LANES == 64) sim.substep(P, t, h, RowStore<64>(lds_rows + threadIdx.x), a, b, c, d, PlaneGround{}, -1.f, Strided{nullptr, 1});
+    else if constexpr (LDS_ROWS) sim.substep(P, t, h, RowStore<LANES>{lds_rows + threadIdx.x}, a, b, c, d, PlaneGround{}, -1.f, Strided{nullptr, 1});
     else { float rows[Sim<M>::ROW_SLOTS]; sim.substep(P, t, h, RowStore<1>{rows}, a, b, c, d, PlaneGround{}, -1.f, Strided{nullptr, 1}); }
     for (int i = 0; i < 13; ++i) root[i * N + e] = sim.root[i];
     for (int i = 0; i < ND; ++i) { dof[i * N + e] = sim.q[i]; dof[(ND + i) * N + e] = sim.qd[i]; }
 }
 int main() {
-    const int N = 4096, W = N / 64;
+    const int N = 4096, W = N / LANES;
     SimParams P{0.0166f, 2, 4, {0, 0, -9.81f}, 0.02f, 0.f, 10.f, 0.5f, 1.f, 0.f, 1e-6f, 1.f};
     std::vector<float> root(13 * N, 0.f), dof(2 * ND * N, 0.f);
 #ifdef HUM
@@ -46,9 +48,9 @@ int main() {
     hipMalloc(&dsens, (6 * NSENS + 1) * N * 4); hipMalloc(&ddff, ND * N * 4); hipMalloc(&dst, W * 16 * 8);
     hipMemcpy(droot, root.data(), root.size() * 4, hipMemcpyHostToDevice); hipMemcpy(ddof, dof.data(), dof.size() * 4, hipMemcpyHostToDevice);
     hipMemset(dlamc, 0, 3 * NSPH * N * 4); hipMemset(dlaml, 0, ND * N * 4); hipMemset(dst, 0, W * 16 * 8);
-    const size_t lds = LDS_ROWS ? (size_t)Sim<M>::ROW_SLOTS * 64 * 4 : 0;
+    const size_t lds = LDS_ROWS ? (size_t)Sim<M>::ROW_SLOTS * LANES * 4 : 0;
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    for (int rep = 0; rep < 20; ++rep) hipLaunchKernelGGL(k, dim3(W), dim3(64), lds, 0, N, P, droot, ddof, dlamc, dlaml, dsens, ddff, dst);
+    for (int rep = 0; rep < 20; ++rep) hipLaunchKernelGGL(k, dim3(W), dim3(LANES), lds, 0, N, P, droot, ddof, dlamc, dlaml, dsens, ddff, dst);
     hipError_t err = hipDeviceSynchronize();
     if (err != hipSuccess) { printf("hip error %s\n", hipGetErrorString(err)); return 1; }
     std::vector<unsigned long long> st(W * 16);
