@@ -33,8 +33,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 # API-visible state read once + written once per env-step
-ALGO_BYTES = {"Cartpole": 89, "Ant": 673, "Humanoid": 1161, "AnymalTerrain": 2240}
-DEFAULT_ENVS = {"Cartpole": 64, "Ant": 4096, "Humanoid": 8192, "AnymalTerrain": 4096}
+ALGO_BYTES = {"Cartpole": 89, "Ant": 673, "Humanoid": 1161, "AnymalTerrain": 2240, "ShadowHand": 3600}
+DEFAULT_ENVS = {"Cartpole": 64, "Ant": 4096, "Humanoid": 8192, "AnymalTerrain": 4096, "ShadowHand": 16384}
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 # HBM-side bytes per control step from the round-1 PMC passes (profiles/r1_pmc_summary.md): raw FETCH_SIZE + WRITE_SIZE
 # (KB -> B) summed over the launches of one step (2 sub-steps + post) at the BASELINE env counts.  The raw fetch counter
@@ -111,12 +111,13 @@ def measure(task, num_envs, steps, warmup, device, rank, world, seed=42, pool=64
 
 def roofline(task, num_envs, kernel_ms):
     bytes_per_launch = ALGO_BYTES[task] * num_envs
+    lanes = 32 if task in ("Humanoid", "ShadowHand") else 64   # compact-store models run 32 envs per wave
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
     traffic = PMC_TRAFFIC_BYTES.get((task, num_envs))
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "kernel": "mi::substep_kernel<%s> (x sim steps) + post kernel = one step" % task,
             "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
-            "note": "latency/issue-bound path: %d waves of 64 envs, one per CU; see DESIGN.md" % ((num_envs + 63) // 64)}
+            "note": "latency/issue-bound path: %d waves of %d envs, one per SIMD; see DESIGN.md" % ((num_envs + lanes - 1) // lanes, lanes)}
 
 
 def cpu_baseline(task, num_envs, budget_s=15.0, seed=42):
@@ -178,10 +179,11 @@ def main():
     n_env = args.num_envs or DEFAULT_ENVS[args.task]
 
     main_res = measure(args.task, n_env, args.steps, args.warmup, device, rank, world)
-    extra = extra2 = None
+    extra = extra2 = extra3 = None
     if not args.no_extra and args.task == "Ant":
         extra = measure("Humanoid", DEFAULT_ENVS["Humanoid"], max(args.steps // 4, 10), max(args.warmup // 4, 5), device, rank, world)
         extra2 = measure("AnymalTerrain", DEFAULT_ENVS["AnymalTerrain"], max(args.steps // 4, 10), max(args.warmup // 4, 5), device, rank, world)
+        extra3 = measure("ShadowHand", DEFAULT_ENVS["ShadowHand"], max(args.steps // 8, 10), max(args.warmup // 8, 5), device, rank, world)
     if rank != 0:
         if world > 1:
             import torch.distributed as dist
@@ -211,6 +213,11 @@ def main():
                          "value": extra2["env_steps_per_s"], "unit": "env-steps/s", "ms_per_step": extra2["ms_per_step"],
                          "reset_rate": extra2["reset_rate"],
                          "roofline": roofline("AnymalTerrain", DEFAULT_ENVS["AnymalTerrain"], extra2["kernel_ms_avg"])}
+    if extra3 is not None:
+        out["extra3"] = {"workload": f"ShadowHand (block, full_state) num_envs={DEFAULT_ENVS['ShadowHand']} per GPU (2 sub-steps per control step)",
+                         "value": extra3["env_steps_per_s"], "unit": "env-steps/s", "ms_per_step": extra3["ms_per_step"],
+                         "reset_rate": extra3["reset_rate"],
+                         "roofline": roofline("ShadowHand", DEFAULT_ENVS["ShadowHand"], extra3["kernel_ms_avg"])}
     if world == 1 and not args.no_cpu_baseline and args.task in ("Ant", "Humanoid"):
         out["cpu_baseline"] = cpu_baseline(args.task, n_env, budget_s=args.cpu_budget)
     print(json.dumps(out), flush=True)

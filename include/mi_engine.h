@@ -95,6 +95,20 @@ typedef struct {
     int32_t ignore_z_rot;
 } MiHandRewardParams;
 
+/* task parameters of ShadowHand (shadow_hand.py:45-110, cfg/task/ShadowHand.yaml) */
+typedef struct {
+    MiHandRewardParams rew;
+    float vel_obs_scale, force_torque_obs_scale;
+    float reset_position_noise, reset_dof_pos_noise, reset_dof_vel_noise;
+    float act_moving_average, dof_speed_scale, dt;
+    int32_t use_relative_control;
+    float clip_actions;
+    float object_init_pos[3], goal_init_pos[3];
+    float hand_pos[3], hand_quat[4];
+    float cube_half, cube_mass, cube_inertia, mu;
+    int32_t actuated[20];
+} MiHandParams;
+
 typedef struct {
     int32_t num_obs, num_actions, num_dofs, num_bodies, num_sensors, num_contact_spheres, fixed_base, task_params_bytes;
 } MiTaskInfo;
@@ -112,7 +126,7 @@ typedef struct {
 
 /* ---- discovery ------------------------------------------------------------------------------------------- */
 int mi_abi_version(void);
-/* task in {"Cartpole","Ant","Humanoid","AnymalTerrain"}: replaces isaacgym_task_map lookup (isaacgymenvs/tasks/__init__.py:88-114)
+/* task in {"Cartpole","Ant","Humanoid","AnymalTerrain","ShadowHand"}: replaces isaacgym_task_map lookup (isaacgymenvs/tasks/__init__.py:88-114)
  * + gym.get_asset_{dof,rigid_body}_count (ant.py:155-156) */
 int mi_task_info(const char* task, MiTaskInfo* out);
 size_t mi_engine_arena_bytes(const char* task, int num_envs);

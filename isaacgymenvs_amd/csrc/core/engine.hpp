@@ -312,8 +312,21 @@ struct Sim {
         float L[M::NM];               // branch-sparse H, later its L^T L factor
         float xcs[M::NSPHA][3];       // centre of every contact sphere, relative to O
         float Rs[M::NSENSA][9], rs[M::NSENSA][3];  // pose of the force-sensor bodies
-        float ocs[M::NOS > 0 ? M::NOS : 1][3];     // centres of the object-contact spheres (manipulation models), rel O
+        // manipulation models: pose (R row-major 9, r 3) of every body that carries object-contact spheres is written to
+        // pose_out[(12 * os_slot(b) + i) * pose_stride] during the tree pass (the hand engine points this into LDS)
+        float* pose_out = nullptr;
+        int pose_stride = 1;
     };
+    // object-contact spheres are grouped by body (generated os_body is non-decreasing)
+    static constexpr int os_first(int b) { for (int s = 0; s < M::NOS; ++s) if (M::os_body[s] == b) return s; return 0; }
+    static constexpr int os_count(int b) { int n = 0; for (int s = 0; s < M::NOS; ++s) n += (M::os_body[s] == b) ? 1 : 0; return n; }
+    static constexpr int os_slot(int b) {  // index among the bodies that carry spheres, -1 if none
+        if (os_count(b) == 0) return -1;
+        int k = 0;
+        for (int bb = 0; bb < b; ++bb) k += os_count(bb) > 0 ? 1 : 0;
+        return k;
+    }
+    static constexpr int NOSB = []() constexpr { int k = 0; for (int b = 0; b < NB; ++b) k += os_count(b) > 0 ? 1 : 0; return k; }();
 
     // ---------------------------------------------------------------- one body of the depth-first tree pass
     // Going down: pose, joint axes, velocity / bias acceleration.  Coming back up: subtree force and composite
@@ -375,14 +388,11 @@ struct Sim {
                 c.xcs[s][0] = rb[0] + t[0]; c.xcs[s][1] = rb[1] + t[1]; c.xcs[s][2] = rb[2] + t[2];
             }
         });
-        sfor<M::NOS>([&](auto S_) MI_LAMBDA {
-            constexpr int s = S_;
-            if constexpr (M::os_body[s] == b) {
-                float t[3];
-                matvec3(Rb, M::os_pos[s], t);
-                c.ocs[s][0] = rb[0] + t[0]; c.ocs[s][1] = rb[1] + t[1]; c.ocs[s][2] = rb[2] + t[2];
-            }
-        });
+        if constexpr (os_slot(b) >= 0) {
+            constexpr int k = os_slot(b);
+            sfor<9>([&](auto I_) MI_LAMBDA { c.pose_out[(12 * k + I_) * c.pose_stride] = Rb[I_]; });
+            sfor<3>([&](auto I_) MI_LAMBDA { c.pose_out[(12 * k + 9 + I_) * c.pose_stride] = rb[I_]; });
+        }
         if constexpr (sensor_of(b) >= 0) {
             constexpr int k = sensor_of(b);
             sfor<9>([&](auto K) MI_LAMBDA { c.Rs[k][K] = Rb[K]; });

@@ -35,7 +35,8 @@ struct HandSim : Sim<M> {
     static constexpr int H_CB = H_LIMG + 3 * NLIM;           // limit G | Ainv, vt, lam | contact slots
     static constexpr int H_CSZ = 3 * UCH + 7;                // 3 rows + Ainv x3, vt_n, lam x3
     static constexpr int H_SLOTOF = H_CB + KMAX * H_CSZ;     // [NOS] slot of each sphere (-1: none), int bits
-    static constexpr int ROW_SLOTS = H_SLOTOF + NOS;
+    static constexpr int H_POSE = H_SLOTOF + NOS;            // [NOSB][12] pose of the sphere-carrying bodies (tree pass output)
+    static constexpr int ROW_SLOTS = H_POSE + 12 * B::NOSB;
     static constexpr int LANES = 32;
 
     FreeBody obj;
@@ -86,6 +87,8 @@ struct HandSim : Sim<M> {
         {
             SimParams P0 = P;
             P0.g[0] = P0.g[1] = P0.g[2] = 0.f;
+            c.pose_out = rows.ptr(H_POSE);
+            c.pose_stride = ST;
             SpI Iroot;
             float Froot[6];
             this->template body_pass<0>(P0, c, nullptr, nullptr, nullptr, nullptr, Iroot, Froot);
@@ -185,54 +188,72 @@ struct HandSim : Sim<M> {
         });
         MI_PHASE();
         // ------------------------------------------------------------ object contacts -> compact slots
+        // Static over the sphere-carrying bodies (the kinematic chain of a row is compile-time), a run-time loop over the
+        // spheres of one body with their positions / radii read from the constant tables (scalar loads): one copy of the
+        // narrow phase + row build per BODY, not per sphere -- the per-sphere unrolled version had ~1000 distinct literals
+        // in SGPRs, spilled 472 of them and miscomputed on gfx950 ("compiler regime").
         int cnt = 0;
-        sfor<NOS>([&](auto S_) MI_LAMBDA {
-            constexpr int s = S_, b = M::os_body[s];
-            const float* cs = c.ocs[s];
-            const float rel[3] = {cs[0] - xo[0], cs[1] - xo[1], cs[2] - xo[2]};
-            float cl[3], nl[3], dist;
-            matTvec3(Ro, rel, cl);
-            sphere_box(cl, M::os_rad[s], OP.half, &dist, nl);
-            const bool on = (dist < P.contact_offset) && (cnt < KMAX);
-            const int j = on ? cnt : -1;
-            if (on) {
-                float fr[3][3];
-                matvec3(Ro, nl, fr[0]);                 // from the object towards the sphere
-                contact_frame(fr[0], fr[1], fr[2]);
-                float pc[3], rc[3];
-                sfor<3>([&](auto K) MI_LAMBDA { pc[K] = cs[K] - M::os_rad[s] * fr[0][K]; rc[K] = pc[K] - xo[K]; });
-                float* cb = rows.ptr(H_CB + j * H_CSZ);
-                const float gap = dist - P.rest_offset;
-                sfor<3>([&](auto K) MI_LAMBDA {
-                    constexpr int k = K;
-                    float W[6];
-                    cross3(pc, fr[k], W);
-                    W[3] = fr[k][0]; W[4] = fr[k][1]; W[5] = fr[k][2];
-                    float g[UCH];
-                    sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { g[C] = dot6(S[M::chain[b][C] - OFF], W); });
-                    // chain solve (descending indices; the later entries of a chain are exactly the ancestors)
-                    sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA {
-                        constexpr int kk0 = C, i = M::chain[b][kk0];
-                        const float z = g[kk0] * Ldi[i];
-                        g[kk0] = z;
-                        sfor<M::chain_len[b] - 1 - kk0>([&](auto T) MI_LAMBDA {
-                            constexpr int kk = kk0 + 1 + T, jj = M::chain[b][kk];
-                            g[kk] -= L[M::midx[i][jj]] * z;
+        sfor<NB>([&](auto B_) MI_LAMBDA {
+            constexpr int b = B_;
+            if constexpr (B::os_count(b) > 0) {
+                constexpr int CL = M::chain_len[b];
+                MI_PHASE();
+                float Rb[9], rb[3];
+                sfor<9>([&](auto I_) MI_LAMBDA { Rb[I_] = rows(H_POSE + 12 * B::os_slot(b) + I_); });
+                sfor<3>([&](auto I_) MI_LAMBDA { rb[I_] = rows(H_POSE + 12 * B::os_slot(b) + 9 + I_); });
+                for (int i = 0; i < B::os_count(b); ++i) {
+                    const int s = B::os_first(b) + i;
+                    const float pl[3] = {M::os_pos[s][0], M::os_pos[s][1], M::os_pos[s][2]};
+                    const float rad = M::os_rad[s];
+                    float t[3], cs[3];
+                    matvec3(Rb, pl, t);
+                    sfor<3>([&](auto K) MI_LAMBDA { cs[K] = rb[K] + t[K]; });
+                    const float rel[3] = {cs[0] - xo[0], cs[1] - xo[1], cs[2] - xo[2]};
+                    float cl[3], nl[3], dist;
+                    matTvec3(Ro, rel, cl);
+                    sphere_box(cl, rad, OP.half, &dist, nl);
+                    const bool on = (dist < P.contact_offset) && (cnt < KMAX);
+                    const int j = on ? cnt : -1;
+                    if (on) {
+                        float fr[3][3];
+                        matvec3(Ro, nl, fr[0]);                 // from the object towards the sphere
+                        contact_frame(fr[0], fr[1], fr[2]);
+                        float pc[3], rc[3];
+                        sfor<3>([&](auto K) MI_LAMBDA { pc[K] = cs[K] - rad * fr[0][K]; rc[K] = pc[K] - xo[K]; });
+                        float* cb = rows.ptr(H_CB + j * H_CSZ);
+                        const float gap = dist - P.rest_offset;
+                        sfor<3>([&](auto K) MI_LAMBDA {
+                            constexpr int k = K;
+                            float W[6];
+                            cross3(pc, fr[k], W);
+                            W[3] = fr[k][0]; W[4] = fr[k][1]; W[5] = fr[k][2];
+                            float g[UCH];
+                            sfor<CL>([&](auto C) MI_LAMBDA { g[C] = dot6(S[M::chain[b][C] - OFF], W); });
+                            // chain solve (descending indices; the later entries of a chain are exactly the ancestors)
+                            sfor<CL>([&](auto C) MI_LAMBDA {
+                                constexpr int kk0 = C, ii = M::chain[b][kk0];
+                                const float z = g[kk0] * Ldi[ii];
+                                g[kk0] = z;
+                                sfor<CL - 1 - kk0>([&](auto T) MI_LAMBDA {
+                                    constexpr int kk = kk0 + 1 + T, jj = M::chain[b][kk];
+                                    g[kk] -= L[M::midx[ii][jj]] * z;
+                                });
+                            });
+                            // object part: J_o = -[u; rc x u], whitened by the constant diagonal
+                            float cx[3];
+                            cross3(rc, fr[k], cx);
+                            sfor<3>([&](auto I_) MI_LAMBDA { g[CL + I_] = -fr[k][I_] * ism; g[CL + 3 + I_] = -cx[I_] * isi; });
+                            float a = P.cfm;
+                            sfor<CL + 6>([&](auto C) MI_LAMBDA { a += g[C] * g[C]; cb[(k * UCH + C) * ST] = g[C]; });
+                            cb[(3 * UCH + k) * ST] = MI_RCP(a);
+                            cb[(3 * UCH + 4 + k) * ST] = 0.f;    // no warm start for object contacts
                         });
-                    });
-                    // object part: J_o = -[u; rc x u], whitened by the constant diagonal
-                    float cx[3];
-                    cross3(rc, fr[k], cx);
-                    sfor<3>([&](auto I_) MI_LAMBDA { g[M::chain_len[b] + I_] = -fr[k][I_] * ism; g[M::chain_len[b] + 3 + I_] = -cx[I_] * isi; });
-                    float a = P.cfm;
-                    sfor<M::chain_len[b] + 6>([&](auto C) MI_LAMBDA { a += g[C] * g[C]; cb[(k * UCH + C) * ST] = g[C]; });
-                    cb[(3 * UCH + k) * ST] = MI_RCP(a);
-                    cb[(3 * UCH + 4 + k) * ST] = 0.f;    // no warm start for object contacts
-                });
-                cb[(3 * UCH + 3) * ST] = (gap >= 0.f) ? -gap * invh : fminf(-gap * P.erp * invh, P.max_depen_vel);
+                        cb[(3 * UCH + 3) * ST] = (gap >= 0.f) ? -gap * invh : fminf(-gap * P.erp * invh, P.max_depen_vel);
+                    }
+                    cnt += on ? 1 : 0;
+                    rows(H_SLOTOF + s) = __builtin_bit_cast(float, j);
+                }
             }
-            cnt += on ? 1 : 0;
-            rows(H_SLOTOF + s) = __builtin_bit_cast(float, j);
         });
         *ncontact = cnt;
         MI_PHASE();
@@ -273,45 +294,51 @@ struct HandSim : Sim<M> {
                     sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { w[M::anc[gi][A_]] += g[1 + A_] * dl; });
                 }
             });
-            sfor<NOS>([&](auto S_) MI_LAMBDA {
-                constexpr int s = S_, b = M::os_body[s], CL = M::chain_len[b];
-                const int j = __builtin_bit_cast(int, rit(H_SLOTOF + s));
-                if (j >= 0) {
-                    float* cb = rit.ptr(H_CB + j * H_CSZ);
-                    float g[3][UCH], ainv[3], lm[3];
-                    sfor<3>([&](auto K) MI_LAMBDA {
-                        sfor<CL + 6>([&](auto C) MI_LAMBDA { g[K][C] = cb[(K * UCH + C) * ST]; });
-                        ainv[K] = cb[(3 * UCH + K) * ST];
-                        lm[K] = cb[(3 * UCH + 4 + K) * ST];
-                    });
-                    const float vtn = cb[(3 * UCH + 3) * ST];
-                    auto rowvel = [&](int k) MI_LAMBDA {
-                        float vn = 0.f;
-                        sfor<CL>([&](auto C) MI_LAMBDA { vn += g[k][C] * w[M::chain[b][C]]; });
-                        sfor<6>([&](auto C) MI_LAMBDA { vn += g[k][CL + C] * wo[C]; });
-                        return vn;
-                    };
-                    auto apply = [&](int k, float dl) MI_LAMBDA {
-                        sfor<CL>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += g[k][C] * dl; });
-                        sfor<6>([&](auto C) MI_LAMBDA { wo[C] += g[k][CL + C] * dl; });
-                    };
-                    const float ln = fmaxf(lm[0] - (rowvel(0) - vtn) * ainv[0], 0.f);
-                    apply(0, ln - lm[0]);
-                    float lt[2];
-                    sfor<2>([&](auto K) MI_LAMBDA {
-                        const float dl = -rowvel(1 + K) * ainv[1 + K];
-                        lt[K] = lm[1 + K] + dl;
-                        apply(1 + K, dl);
-                    });
-                    const float lim = OP.mu * ln;
-                    const float n2 = lt[0] * lt[0] + lt[1] * lt[1];
-                    const float sc = (n2 > lim * lim) ? lim * MI_RSQ(fmaxf(n2, 1e-30f)) : 1.f;
-                    cb[(3 * UCH + 4) * ST] = ln;
-                    sfor<2>([&](auto K) MI_LAMBDA {
-                        const float nl_ = lt[K] * sc;
-                        cb[(3 * UCH + 5 + K) * ST] = nl_;
-                        apply(1 + K, nl_ - lt[K]);
-                    });
+            sfor<NB>([&](auto B_) MI_LAMBDA {
+                constexpr int b = B_;
+                if constexpr (B::os_count(b) > 0) {
+                    constexpr int CL = M::chain_len[b];
+                    for (int i = 0; i < B::os_count(b); ++i) {
+                        const int s = B::os_first(b) + i;
+                        const int j = __builtin_bit_cast(int, rit(H_SLOTOF + s));
+                        if (j >= 0) {
+                            float* cb = rit.ptr(H_CB + j * H_CSZ);
+                            float g[3][UCH], ainv[3], lm[3];
+                            sfor<3>([&](auto K) MI_LAMBDA {
+                                sfor<CL + 6>([&](auto C) MI_LAMBDA { g[K][C] = cb[(K * UCH + C) * ST]; });
+                                ainv[K] = cb[(3 * UCH + K) * ST];
+                                lm[K] = cb[(3 * UCH + 4 + K) * ST];
+                            });
+                            const float vtn = cb[(3 * UCH + 3) * ST];
+                            auto rowvel = [&](int k) MI_LAMBDA {
+                                float vn = 0.f;
+                                sfor<CL>([&](auto C) MI_LAMBDA { vn += g[k][C] * w[M::chain[b][C]]; });
+                                sfor<6>([&](auto C) MI_LAMBDA { vn += g[k][CL + C] * wo[C]; });
+                                return vn;
+                            };
+                            auto apply = [&](int k, float dl) MI_LAMBDA {
+                                sfor<CL>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += g[k][C] * dl; });
+                                sfor<6>([&](auto C) MI_LAMBDA { wo[C] += g[k][CL + C] * dl; });
+                            };
+                            const float ln = fmaxf(lm[0] - (rowvel(0) - vtn) * ainv[0], 0.f);
+                            apply(0, ln - lm[0]);
+                            float lt[2];
+                            sfor<2>([&](auto K) MI_LAMBDA {
+                                const float dl = -rowvel(1 + K) * ainv[1 + K];
+                                lt[K] = lm[1 + K] + dl;
+                                apply(1 + K, dl);
+                            });
+                            const float lim = OP.mu * ln;
+                            const float n2 = lt[0] * lt[0] + lt[1] * lt[1];
+                            const float sc = (n2 > lim * lim) ? lim * MI_RSQ(fmaxf(n2, 1e-30f)) : 1.f;
+                            cb[(3 * UCH + 4) * ST] = ln;
+                            sfor<2>([&](auto K) MI_LAMBDA {
+                                const float nl_ = lt[K] * sc;
+                                cb[(3 * UCH + 5 + K) * ST] = nl_;
+                                apply(1 + K, nl_ - lt[K]);
+                            });
+                        }
+                    }
                 }
             });
         }
@@ -338,30 +365,40 @@ struct HandSim : Sim<M> {
         });
         float sens[6 * M::NSENSA];
         sfor<6 * NSENS>([&](auto K) MI_LAMBDA { sens[K] = 0.f; });
-        sfor<NOS>([&](auto S_) MI_LAMBDA {
-            constexpr int s = S_, b = M::os_body[s];
-            if constexpr (sensor_of(b) >= 0) {
+        sfor<NB>([&](auto B_) MI_LAMBDA {
+            constexpr int b = B_;
+            if constexpr (sensor_of(b) >= 0 && B::os_count(b) > 0) {
                 constexpr int k = sensor_of(b);
-                const int j = __builtin_bit_cast(int, rows(H_SLOTOF + s));
-                if (j >= 0) {
-                    const float* cb = rows.ptr(H_CB + j * H_CSZ);
-                    const float ln = cb[(3 * UCH + 4) * ST], l1 = cb[(3 * UCH + 5) * ST], l2 = cb[(3 * UCH + 6) * ST];
-                    // the frame is re-derived (neither body has moved yet)
-                    const float* cs = c.ocs[s];
-                    const float rel[3] = {cs[0] - xo[0], cs[1] - xo[1], cs[2] - xo[2]};
-                    float cl[3], nl[3], dist, n[3], t1[3], t2[3];
-                    matTvec3(Ro, rel, cl);
-                    sphere_box(cl, M::os_rad[s], OP.half, &dist, nl);
-                    matvec3(Ro, nl, n);
-                    contact_frame(n, t1, t2);
-                    float f[3], arm[3], tq[3], fl[3], tl[3];
-                    sfor<3>([&](auto K) MI_LAMBDA {
-                        f[K] = (n[K] * ln + t1[K] * l1 + t2[K] * l2) * invh;
-                        arm[K] = cs[K] - M::os_rad[s] * n[K] - c.rs[k][K];
-                    });
-                    cross3(arm, f, tq);
-                    matTvec3(c.Rs[k], f, fl); matTvec3(c.Rs[k], tq, tl);
-                    sfor<3>([&](auto C) MI_LAMBDA { sens[6 * k + C] += fl[C]; sens[6 * k + 3 + C] += tl[C]; });
+                float Rb[9], rb[3];
+                sfor<9>([&](auto I_) MI_LAMBDA { Rb[I_] = rows(H_POSE + 12 * B::os_slot(b) + I_); });
+                sfor<3>([&](auto I_) MI_LAMBDA { rb[I_] = rows(H_POSE + 12 * B::os_slot(b) + 9 + I_); });
+                for (int i = 0; i < B::os_count(b); ++i) {
+                    const int s = B::os_first(b) + i;
+                    const int j = __builtin_bit_cast(int, rows(H_SLOTOF + s));
+                    if (j >= 0) {
+                        const float* cb = rows.ptr(H_CB + j * H_CSZ);
+                        const float ln = cb[(3 * UCH + 4) * ST], l1 = cb[(3 * UCH + 5) * ST], l2 = cb[(3 * UCH + 6) * ST];
+                        // the contact frame is re-derived (neither body has moved yet)
+                        const float pl[3] = {M::os_pos[s][0], M::os_pos[s][1], M::os_pos[s][2]};
+                        const float rad = M::os_rad[s];
+                        float t[3], cs[3];
+                        matvec3(Rb, pl, t);
+                        sfor<3>([&](auto K) MI_LAMBDA { cs[K] = rb[K] + t[K]; });
+                        const float rel[3] = {cs[0] - xo[0], cs[1] - xo[1], cs[2] - xo[2]};
+                        float cl[3], nl[3], dist, n[3], t1[3], t2[3];
+                        matTvec3(Ro, rel, cl);
+                        sphere_box(cl, rad, OP.half, &dist, nl);
+                        matvec3(Ro, nl, n);
+                        contact_frame(n, t1, t2);
+                        float f[3], arm[3], tq[3], fl[3], tl[3];
+                        sfor<3>([&](auto K) MI_LAMBDA {
+                            f[K] = (n[K] * ln + t1[K] * l1 + t2[K] * l2) * invh;
+                            arm[K] = cs[K] - rad * n[K] - rb[K];
+                        });
+                        cross3(arm, f, tq);
+                        matTvec3(Rb, f, fl); matTvec3(Rb, tq, tl);
+                        sfor<3>([&](auto C) MI_LAMBDA { sens[6 * k + C] += fl[C]; sens[6 * k + 3 + C] += tl[C]; });
+                    }
                 }
             }
         });

@@ -1,0 +1,283 @@
+// kernels_shadow_hand.hip -- ShadowHand (reference isaacgymenvs/tasks/shadow_hand.py): pre_physics_step (deferred resets,
+// actions -> position targets), hand + cube physics sub-steps (core/hand_engine.hpp), post_physics_step (fingertip states,
+// full_state observation, compute_hand_reward).  One env per lane; 32 envs per wave in the physics kernel (the compact
+// contact store needs 4 KB of LDS per env).
+#include "step_kernels.hpp"
+#include "core/hand_engine.hpp"
+#include "gen/model_shadow_hand.h"
+#include "tasks/shadow_hand.hpp"
+
+namespace mi {
+
+using HM = ModelShadowHand;
+using HS = HandSim<HM>;
+constexpr int kHandDof = 24, kHandAct = 20, kHandTips = 5, kHandObs = 211;
+static_assert(HM::ND == kHandDof && HM::NSENS == kHandTips, "shadow hand model");
+
+// arena view of the task (device pointers, SoA [k][N] unless noted) -- same definition in mi_engine.hip
+struct HandView {
+    float* cur_targets;    // [24][N]
+    float* prev_targets;   // [24][N]
+    float* object_state;   // [13][N]  root state of the cube
+    float* goal_state;     // [7][N]   goal pose (pos, quat)
+    float* fingertip;      // [5*13][N] fingertip body states
+    float* successes;      // [N]
+    long long* reset_goal; // [N]
+    int* goal_count;       // [N] number of goal resets so far (RNG counter)
+    float* cons;           // [1] consecutive_successes (shadow_hand.py:795-798)
+    float* ws;             // [2] per-step scratch of the cross-env sums
+    int* ncontact;         // [N] object contacts of the last sub-step (diagnostic)
+};
+
+__device__ __forceinline__ float hand_u(uint32_t seed, uint32_t genv, uint32_t ep, uint32_t k) { return 2.f * uniform01(seed, genv, ep, k) - 1.f; }
+
+// reset_target_pose (shadow_hand.py:586-602): new random goal orientation
+__device__ __forceinline__ void hand_reset_goal(const View& v, const HandView& hv, const HandParams& p, int e, uint32_t genv) {
+    const int N = v.N;
+    const uint32_t gc = (uint32_t)hv.goal_count[e];
+    const float r0 = hand_u(v.seed ^ 0x2545F491u, genv, gc, 0), r1 = hand_u(v.seed ^ 0x2545F491u, genv, gc, 1);
+    const float xu[3] = {1.f, 0.f, 0.f}, yu[3] = {0.f, 1.f, 0.f};
+    float q[4];
+    randomize_rotation(r0, r1, xu, yu, q);
+    sfor<3>([&](auto K) MI_LAMBDA { hv.goal_state[K * N + e] = p.goal_init_pos[K]; });
+    sfor<4>([&](auto K) MI_LAMBDA { hv.goal_state[(3 + K) * N + e] = q[K]; });
+    hv.goal_count[e] = (int)gc + 1;
+    hv.reset_goal[e] = 0;
+}
+
+// reset_idx (shadow_hand.py:604-668) for one env
+__device__ __forceinline__ void hand_reset_env(const View& v, const HandView& hv, const HandParams& p, int e, uint32_t genv) {
+    MI_NO_CONTRACT
+    const int N = v.N, ND = kHandDof;
+    const uint32_t ep = (uint32_t)v.episode[e];
+    auto rf = [&](int k) MI_LAMBDA { return hand_u(v.seed, genv, ep, (uint32_t)k); };   // rand_floats[:, k], U(-1, 1)
+    hand_reset_goal(v, hv, p, e, genv);
+    // object: initial pose + position noise, random rotation, zero velocity
+    hv.object_state[0 * N + e] = p.object_init_pos[0] + p.reset_position_noise * rf(0);
+    hv.object_state[1 * N + e] = p.object_init_pos[1] + p.reset_position_noise * rf(1);
+    hv.object_state[2 * N + e] = p.object_init_pos[2] + p.reset_position_noise * rf(2);
+    const float xu[3] = {1.f, 0.f, 0.f}, yu[3] = {0.f, 1.f, 0.f};
+    float q[4];
+    randomize_rotation(rf(3), rf(4), xu, yu, q);
+    sfor<4>([&](auto K) MI_LAMBDA { hv.object_state[(3 + K) * N + e] = q[K]; });
+    sfor<6>([&](auto K) MI_LAMBDA { hv.object_state[(7 + K) * N + e] = 0.f; });
+    // hand: default pose (0) + noise * random point of the joint range (:642-651)
+    sfor<ND>([&](auto D) MI_LAMBDA {
+        constexpr int d = D;
+        const float delta_max = HM::dof_upper[d] - 0.f, delta_min = HM::dof_lower[d] - 0.f;
+        const float rand_delta = delta_min + (delta_max - delta_min) * 0.5f * (rf(5 + d) + 1.f);
+        const float pos = 0.f + p.reset_dof_pos_noise * rand_delta;
+        v.dof[d * N + e] = pos;
+        v.dof[(ND + d) * N + e] = 0.f + p.reset_dof_vel_noise * rf(5 + ND + d);
+        hv.prev_targets[d * N + e] = pos;
+        hv.cur_targets[d * N + e] = pos;
+        v.laml[d * N + e] = 0.f;
+    });
+    v.episode[e] = (int)ep + 1;
+    v.progress[e] = 0;
+    v.reset[e] = 0;
+    hv.successes[e] = 0.f;
+}
+
+// pre_physics_step (shadow_hand.py:670-698): deferred resets, then actions -> targets
+__global__ void hand_pre_kernel(View v, HandView hv, HandParams p, const float* __restrict__ actions_in) {
+    MI_NO_CONTRACT
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = v.N;
+    if (e >= N) return;
+    const uint32_t genv = (uint32_t)(v.env_offset + e);
+    if (v.reset[e] != 0) hand_reset_env(v, hv, p, e, genv);           // also resets the goal (:615)
+    else if (hv.reset_goal[e] != 0) hand_reset_goal(v, hv, p, e, genv);
+    sfor<kHandAct>([&](auto A_) MI_LAMBDA {
+        constexpr int a = A_;
+        const int d = p.actuated[a];
+        const float act = fminf(fmaxf(actions_in[(size_t)e * kHandAct + a], -p.clip_actions), p.clip_actions);   // vec_task.py:374
+        v.actions[a * N + e] = act;
+        // the actuated dof index is a runtime table: read the limits through a tiny switch-free lookup
+        float lo = 0.f, up = 0.f;
+        sfor<kHandDof>([&](auto D) MI_LAMBDA { if (d == D) { lo = HM::dof_lower[D]; up = HM::dof_upper[D]; } });
+        const float prev = hv.prev_targets[d * N + e];
+        float t;
+        if (p.use_relative_control) {
+            t = prev + p.dof_speed_scale * p.dt * act;                                     // :686
+        } else {
+            t = 0.5f * (act + 1.0f) * (up - lo) + lo;                                      // scale(), torch_jit_utils.py:234-235
+            t = p.act_moving_average * t + (1.0f - p.act_moving_average) * prev;            // :692-693
+        }
+        t = fmaxf(fminf(t, up), lo);                                                       // tensor_clamp
+        hv.cur_targets[d * N + e] = t;
+        hv.prev_targets[d * N + e] = t;                                                     // :697
+    });
+}
+
+// gym.simulate(): one physics sub-step of hand + cube
+__global__ __launch_bounds__(32) void hand_substep_kernel(View v, HandView hv, SimParams P, HandParams p) {
+    extern __shared__ float lds_rows[];
+    constexpr int ND = kHandDof, LANES = HS::LANES;
+    const int e = blockIdx.x * LANES + threadIdx.x;
+    const int N = v.N;
+    if (e >= N) return;
+    HS sim;
+    sfor<3>([&](auto K) MI_LAMBDA { sim.root[K] = p.hand_pos[K]; });
+    sfor<4>([&](auto K) MI_LAMBDA { sim.root[3 + K] = p.hand_quat[K]; });
+    sfor<6>([&](auto K) MI_LAMBDA { sim.root[7 + K] = 0.f; });
+    float target[ND];
+    sfor<ND>([&](auto K) MI_LAMBDA {
+        sim.q[K] = v.dof[K * N + e];
+        sim.qd[K] = v.dof[(ND + K) * N + e];
+        target[K] = hv.cur_targets[K * N + e];
+    });
+    sfor<3>([&](auto K) MI_LAMBDA { sim.obj.pos[K] = hv.object_state[K * N + e]; sim.obj.vel[K] = hv.object_state[(7 + K) * N + e];
+                                    sim.obj.angvel[K] = hv.object_state[(10 + K) * N + e]; });
+    sfor<4>([&](auto K) MI_LAMBDA { sim.obj.quat[K] = hv.object_state[(3 + K) * N + e]; });
+    const ObjectParams OP{p.cube_half, p.cube_mass, p.cube_inertia, p.mu};
+    const float h = P.dt / (float)P.substeps;
+    int nc = 0;
+    sim.substep_hand(P, OP, target, h, RowStore<LANES>{lds_rows + threadIdx.x}, Strided{v.laml + e, N}, Strided{v.sensor + e, N},
+                     Strided{v.dof_force + e, N}, &nc);
+    sfor<ND>([&](auto K) MI_LAMBDA { v.dof[K * N + e] = sim.q[K]; v.dof[(ND + K) * N + e] = sim.qd[K]; });
+    sfor<3>([&](auto K) MI_LAMBDA { hv.object_state[K * N + e] = sim.obj.pos[K]; hv.object_state[(7 + K) * N + e] = sim.obj.vel[K];
+                                    hv.object_state[(10 + K) * N + e] = sim.obj.angvel[K]; });
+    sfor<4>([&](auto K) MI_LAMBDA { hv.object_state[(3 + K) * N + e] = sim.obj.quat[K]; });
+    hv.ncontact[e] = nc;
+}
+
+// post_physics_step (shadow_hand.py:710-715): progress++, compute_observations (full_state), compute_reward
+__global__ __launch_bounds__(64) void hand_post_kernel(View v, HandView hv, HandParams p) {
+    MI_NO_CONTRACT
+    constexpr int ND = kHandDof;
+    const int e0 = blockIdx.x * 64 + threadIdx.x;
+    const int N = v.N;
+    const bool valid = e0 < N;
+    const int e = valid ? e0 : N - 1;
+    HS sim;
+    sfor<3>([&](auto K) MI_LAMBDA { sim.root[K] = p.hand_pos[K]; });
+    sfor<4>([&](auto K) MI_LAMBDA { sim.root[3 + K] = p.hand_quat[K]; });
+    sfor<ND>([&](auto K) MI_LAMBDA { sim.q[K] = v.dof[K * N + e]; sim.qd[K] = v.dof[(ND + K) * N + e]; });
+    float tips[kHandTips][13];
+    sim.fingertip_states(tips);                                    // gym.refresh_rigid_body_state_tensor (:440)
+    float os[13], gp[7], act[kHandAct];
+    sfor<13>([&](auto K) MI_LAMBDA { os[K] = hv.object_state[K * N + e]; });
+    sfor<7>([&](auto K) MI_LAMBDA { gp[K] = hv.goal_state[K * N + e]; });
+    sfor<kHandAct>([&](auto K) MI_LAMBDA { act[K] = v.actions[K * N + e]; });
+    const long long progress_in = v.progress[e] + 1;               // :711
+    // compute_full_state (:528-584)
+    float* ob = v.obs + (size_t)e * kHandObs;
+    float* oc = v.obs_out + ((size_t)v.ring * N + e) * kHandObs;
+    auto emit = [&](int k, float val) MI_LAMBDA {
+        if (valid) { ob[k] = val; oc[k] = fminf(fmaxf(val, -v.clip_obs), v.clip_obs); }
+    };
+    sfor<ND>([&](auto D) MI_LAMBDA {
+        constexpr int d = D;
+        emit(d, (2.0f * sim.q[d] - HM::dof_upper[d] - HM::dof_lower[d]) / (HM::dof_upper[d] - HM::dof_lower[d]));   // unscale
+        emit(ND + d, p.vel_obs_scale * sim.qd[d]);
+        emit(2 * ND + d, p.force_torque_obs_scale * v.dof_force[d * N + e]);
+    });
+    sfor<7>([&](auto K) MI_LAMBDA { emit(72 + K, os[K]); });
+    sfor<3>([&](auto K) MI_LAMBDA { emit(79 + K, os[7 + K]); emit(82 + K, p.vel_obs_scale * os[10 + K]); });
+    sfor<7>([&](auto K) MI_LAMBDA { emit(85 + K, gp[K]); });
+    {
+        float conj[4], qd4[4];
+        quat_conjugate(gp + 3, conj);
+        quat_mul(os + 3, conj, qd4);
+        sfor<4>([&](auto K) MI_LAMBDA { emit(92 + K, qd4[K]); });
+    }
+    sfor<kHandTips>([&](auto T_) MI_LAMBDA {
+        sfor<13>([&](auto K) MI_LAMBDA {
+            emit(96 + T_ * 13 + K, tips[T_][K]);
+            if (valid) hv.fingertip[(T_ * 13 + K) * N + e] = tips[T_][K];
+        });
+    });
+    sfor<6 * kHandTips>([&](auto K) MI_LAMBDA { emit(161 + K, p.force_torque_obs_scale * v.sensor[K * N + e]); });
+    sfor<kHandAct>([&](auto K) MI_LAMBDA { emit(191 + K, act[K]); });
+    // compute_hand_reward (:746-800)
+    float r, succ;
+    long long rs, gr, prog;
+    hand_reward(p.rew, os, os + 3, gp, gp + 3, act, kHandAct, v.reset[e], hv.reset_goal[e], progress_in, hv.successes[e], &r, &rs, &gr, &prog, &succ);
+    float nres = valid ? (float)rs : 0.f, fin = valid ? succ * (float)rs : 0.f;
+    nres = wave_sum(nres); fin = wave_sum(fin);
+    if ((threadIdx.x & 63) == 0 && nres > 0.f) { atomicAdd(hv.ws, nres); atomicAdd(hv.ws + 1, fin); }
+    episode_stats(v, e, valid, r, rs, prog);
+    if (!valid) return;
+    v.rew[e] = r;
+    v.reset[e] = rs;
+    hv.reset_goal[e] = gr;
+    v.progress[e] = prog;
+    hv.successes[e] = succ;
+    v.randomize[e] += 1;
+    v.timeout[e] = (unsigned char)(((float)prog >= p.rew.max_episode_length - 1.f) && (rs != 0));      // vec_task.py:394
+}
+__global__ void hand_finalize_kernel(HandView hv, HandParams p) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float num_resets = hv.ws[0], finished = hv.ws[1], cs = hv.cons[0];
+        hv.cons[0] = (num_resets > 0.f) ? p.rew.av_factor * finished / num_resets + (1.0f - p.rew.av_factor) * cs : cs;
+    }
+}
+
+// initial state: buffers as the reference's __init__ leaves them (reset_buf = 1 => everything is reset at the first
+// pre_physics_step), hand at its default pose, cube and goal at their initial poses
+__global__ void hand_init_kernel(View v, HandView hv, HandParams p) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = v.N;
+    if (e >= N) return;
+    for (int d = 0; d < kHandDof; ++d) {
+        v.dof[d * N + e] = 0.f; v.dof[(kHandDof + d) * N + e] = 0.f; v.laml[d * N + e] = 0.f; v.dof_force[d * N + e] = 0.f;
+        hv.cur_targets[d * N + e] = 0.f; hv.prev_targets[d * N + e] = 0.f;
+    }
+    for (int k = 0; k < 13; ++k) hv.object_state[k * N + e] = (k < 3) ? p.object_init_pos[k] : (k == 6 ? 1.f : 0.f);
+    for (int k = 0; k < 7; ++k) hv.goal_state[k * N + e] = (k < 3) ? p.goal_init_pos[k] : (k == 6 ? 1.f : 0.f);
+    for (int k = 0; k < 13; ++k) v.root[k * N + e] = (k < 3) ? p.hand_pos[k] : (k < 7 ? p.hand_quat[k - 3] : 0.f);
+    for (int k = 0; k < 6 * kHandTips; ++k) v.sensor[k * N + e] = 0.f;
+    for (int k = 0; k < 13 * kHandTips; ++k) hv.fingertip[k * N + e] = 0.f;
+    for (int k = 0; k < kHandAct; ++k) v.actions[k * N + e] = 0.f;
+    for (int k = 0; k < kHandObs; ++k) { v.obs[(size_t)e * kHandObs + k] = 0.f; v.obs_out[(size_t)e * kHandObs + k] = 0.f; v.obs_out[((size_t)N + e) * kHandObs + k] = 0.f; }
+    hv.successes[e] = 0.f; hv.reset_goal[e] = 1; hv.goal_count[e] = 0; hv.ncontact[e] = 0;
+    v.rew[e] = 0.f; v.reset[e] = 1; v.progress[e] = 0; v.randomize[e] = 0; v.timeout[e] = 0; v.episode[e] = 0; v.ep_ret[e] = 0.f;
+    if (e == 0) { hv.cons[0] = 0.f; hv.ws[0] = hv.ws[1] = 0.f; for (int k = 0; k < 8; ++k) v.stats[k] = 0.f; }
+}
+
+static hipError_t hand_substeps(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s) {
+    constexpr size_t lds = (size_t)HS::ROW_SLOTS * HS::LANES * sizeof(float);
+    static_assert(lds <= 160 * 1024, "hand row store must fit LDS");
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)hand_substep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    for (int i = 0; i < n; ++i)
+        hipLaunchKernelGGL(hand_substep_kernel, dim3((v.N + HS::LANES - 1) / HS::LANES), dim3(HS::LANES), lds, s, v, hv, P, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_step_shadow_hand(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, const float* actions, int cfi,
+                                   hipStream_t s) {
+    hipLaunchKernelGGL(hand_pre_kernel, dim3((v.N + 127) / 128), dim3(128), 0, s, v, hv, p, actions);
+    hipError_t e = hand_substeps(v, hv, P, p, cfi * P.substeps, s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(hv.ws, 0, 2 * sizeof(float), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(hand_post_kernel, dim3((v.N + 63) / 64), dim3(64), 0, s, v, hv, p);
+    hipLaunchKernelGGL(hand_finalize_kernel, dim3(1), dim3(64), 0, s, hv, p);
+    return hipGetLastError();
+}
+hipError_t launch_simulate_shadow_hand(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, hipStream_t s) {
+    return hand_substeps(v, hv, P, p, P.substeps, s);
+}
+hipError_t launch_init_shadow_hand(const View& v, const HandView& hv, const HandParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(hand_init_kernel, dim3((v.N + 127) / 128), dim3(128), 0, s, v, hv, p);
+    return hipGetLastError();
+}
+__global__ void hand_reset_ids_kernel(View v, HandView hv, HandParams p, const long long* __restrict__ ids, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int e = (int)ids[i];
+    if (e < 0 || e >= v.N) return;
+    hand_reset_env(v, hv, p, e, (uint32_t)(v.env_offset + e));
+}
+hipError_t launch_reset_shadow_hand(const View& v, const HandView& hv, const HandParams& p, const long long* ids, int n, hipStream_t s) {
+    hipLaunchKernelGGL(hand_reset_ids_kernel, dim3((n + 127) / 128), dim3(128), 0, s, v, hv, p, ids, n);
+    return hipGetLastError();
+}
+
+}  // namespace mi

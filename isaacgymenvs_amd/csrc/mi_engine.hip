@@ -14,6 +14,7 @@
 #include "gen/model_cartpole.h"
 #include "gen/model_humanoid.h"
 #include "gen/model_anymal.h"
+#include "gen/model_shadow_hand.h"
 #include "tasks/anymal.hpp"
 #include "tasks/shadow_hand.hpp"
 
@@ -25,6 +26,7 @@ static_assert(sizeof(MiCartpoleParams) == sizeof(CartpoleParams), "MiCartpolePar
 static_assert(MI_MAX_DOF == mi::kMaxDof, "MI_MAX_DOF");
 static_assert(sizeof(MiAnymalParams) == sizeof(AnymalParams), "MiAnymalParams layout");
 static_assert(sizeof(MiHandRewardParams) == sizeof(HandRewardParams), "MiHandRewardParams layout");
+static_assert(sizeof(MiHandParams) == sizeof(HandParams), "MiHandParams layout");
 
 static thread_local std::string g_err;
 static int fail(const std::string& m) { g_err = m; return -1; }
@@ -180,14 +182,25 @@ hipError_t launch_simulate_anymal(const View& v, const SimParams& P, const Anyma
 hipError_t launch_init_anymal(const View& v, const AnymalParams& tp, const AnymalTerrainDesc& T, int max_init_level, hipStream_t s);
 hipError_t launch_reset_anymal(const View& v, const AnymalParams& tp, const AnymalTerrainDesc& T, const long long* ids, int n, hipStream_t s);
 }
-enum TaskId { T_CARTPOLE = 0, T_ANT = 1, T_HUMANOID = 2, T_ANYMAL = 3 };
-constexpr int kNumTasks = 4;
+namespace mi {  // defined in kernels_shadow_hand.hip
+struct HandView {
+    float* cur_targets; float* prev_targets; float* object_state; float* goal_state; float* fingertip; float* successes;
+    long long* reset_goal; int* goal_count; float* cons; float* ws; int* ncontact;
+};
+hipError_t launch_step_shadow_hand(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, const float* actions, int cfi, hipStream_t s);
+hipError_t launch_simulate_shadow_hand(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, hipStream_t s);
+hipError_t launch_init_shadow_hand(const View& v, const HandView& hv, const HandParams& p, hipStream_t s);
+hipError_t launch_reset_shadow_hand(const View& v, const HandView& hv, const HandParams& p, const long long* ids, int n, hipStream_t s);
+}
+enum TaskId { T_CARTPOLE = 0, T_ANT = 1, T_HUMANOID = 2, T_ANYMAL = 3, T_SHADOWHAND = 4 };
+constexpr int kNumTasks = 5;
 struct TaskMeta { const char* name; int nobs, nact, nd, nb, nsens, nsph, fixed; size_t pbytes; };
 static const TaskMeta kTasks[] = {
     {"Cartpole", 4, 1, ModelCartpole::ND, ModelCartpole::NB, 0, ModelCartpole::NSPH, 1, sizeof(MiCartpoleParams)},
     {"Ant", Loco<ModelAnt::ND, 6 * ModelAnt::NSENS, false>::NOBS, ModelAnt::ND, ModelAnt::ND, ModelAnt::NB, ModelAnt::NSENS, ModelAnt::NSPH, 0, sizeof(MiLocoParams)},
     {"Humanoid", Loco<ModelHumanoid::ND, 6 * ModelHumanoid::NSENS, true>::NOBS, ModelHumanoid::ND, ModelHumanoid::ND, ModelHumanoid::NB, ModelHumanoid::NSENS, ModelHumanoid::NSPH, 0, sizeof(MiLocoParams)},
     {"AnymalTerrain", kAnymalObs, kAnymalDof, ModelAnymal::ND, ModelAnymal::NB, 0, ModelAnymal::NSPH, 0, sizeof(MiAnymalParams)},
+    {"ShadowHand", 211, 20, ModelShadowHand::ND, ModelShadowHand::NB, ModelShadowHand::NSENS, 0, 1, sizeof(MiHandParams)},
 };
 static int find_task(const char* t) {
     for (int i = 0; i < kNumTasks; ++i) if (!strcmp(t, kTasks[i].name)) return i;
@@ -201,6 +214,8 @@ struct MiEngine {
     CartpoleParams cart;
     AnymalParams anymal;
     AnymalTerrainDesc terrain;
+    HandParams hand;
+    HandView hv;
     int max_init_level;
     View v;
     float clip_obs;
@@ -273,6 +288,24 @@ static void build_layout(int task, int N, Layout& L, View* v, char* base) {
     }
     L.off = (L.off + 255) & ~size_t(255);
 }
+// ShadowHand extras (shadow_hand.py:150-222): object / goal root states, targets, fingertip body states, success counters
+static void build_hand_layout(int N, Layout& L, HandView* hv, char* base) {
+    const int64_t n = N;
+    auto P = [&](size_t o) { return base ? base + o : (char*)nullptr; };
+    size_t o;
+    o = L.add("cur_targets", MI_F32, {n, 24}, {1, n}, 24 * n); if (hv) hv->cur_targets = (float*)P(o);
+    o = L.add("prev_targets", MI_F32, {n, 24}, {1, n}, 24 * n); if (hv) hv->prev_targets = (float*)P(o);
+    o = L.add("object_state", MI_F32, {n, 13}, {1, n}, 13 * n); if (hv) hv->object_state = (float*)P(o);
+    o = L.add("goal_states", MI_F32, {n, 7}, {1, n}, 7 * n); if (hv) hv->goal_state = (float*)P(o);
+    o = L.add("fingertip_state", MI_F32, {n, 5, 13}, {1, 13 * n, n}, 65 * n); if (hv) hv->fingertip = (float*)P(o);
+    o = L.add("successes", MI_F32, {n}, {1}, n); if (hv) hv->successes = (float*)P(o);
+    o = L.add("reset_goal_buf", MI_I64, {n}, {1}, n); if (hv) hv->reset_goal = (long long*)P(o);
+    o = L.add("goal_reset_count", MI_I32, {n}, {1}, n); if (hv) hv->goal_count = (int*)P(o);
+    o = L.add("consecutive_successes", MI_F32, {1}, {1}, 1); if (hv) hv->cons = (float*)P(o);
+    o = L.add("reward_workspace", MI_F32, {2}, {1}, 2); if (hv) hv->ws = (float*)P(o);
+    o = L.add("object_contact_count", MI_I32, {n}, {1}, n); if (hv) hv->ncontact = (int*)P(o);
+    L.off = (L.off + 255) & ~size_t(255);
+}
 
 extern "C" int mi_task_info(const char* task, MiTaskInfo* out) {
     int t = find_task(task);
@@ -289,6 +322,7 @@ extern "C" size_t mi_engine_arena_bytes(const char* task, int num_envs) {
     if (t < 0 || num_envs <= 0) { fail("mi_engine_arena_bytes: bad task or num_envs"); return 0; }
     Layout L;
     build_layout(t, num_envs, L, nullptr, nullptr);
+    if (t == T_SHADOWHAND) build_hand_layout(num_envs, L, nullptr, nullptr);
     return L.off;
 }
 
@@ -309,10 +343,13 @@ extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const 
     e->max_init_level = 0;
     if (t == T_CARTPOLE) memcpy(&e->cart, task_params, sizeof(CartpoleParams));
     else if (t == T_ANYMAL) memcpy(&e->anymal, task_params, sizeof(AnymalParams));
+    else if (t == T_SHADOWHAND) memcpy(&e->hand, task_params, sizeof(HandParams));
     else memcpy(&e->loco, task_params, sizeof(LocoParams));
     Layout L;
     memset(&e->v, 0, sizeof(View));
     build_layout(t, num_envs, L, &e->v, (char*)arena);
+    memset(&e->hv, 0, sizeof(e->hv));
+    if (t == T_SHADOWHAND) build_hand_layout(num_envs, L, &e->hv, (char*)arena);
     if (arena_bytes < L.off) { delete e; return fail("mi_engine_create: arena too small"); }
     e->descs = L.d;
     e->v.N = num_envs; e->v.env_offset = env_id_offset; e->v.seed = (uint32_t)(seed ^ (seed >> 32));
@@ -346,6 +383,11 @@ extern "C" int mi_engine_init_state(MiEngine* e, void* stream) {
     const TaskMeta& m = kTasks[e->task];
     float* d_init = nullptr;
     float root_z = 0.f, pot0 = 0.f;
+    if (e->task == T_SHADOWHAND) {
+        HIP_OK(launch_init_shadow_hand(e->v, e->hv, e->hand, s));
+        e->steps = 0;
+        return 0;
+    }
     if (e->task == T_ANYMAL) {
         if (e->terrain.hs == nullptr) return fail("mi_engine_init_state: AnymalTerrain needs mi_engine_set_terrain first");
         const int blocks = (e->N + 255) / 256;
@@ -390,6 +432,7 @@ extern "C" int mi_engine_step(MiEngine* e, const float* actions, void* stream) {
         case T_CARTPOLE: HIP_OK(launch_step_cartpole(e->v, e->P, e->cart, actions, e->control_freq_inv, s)); break;
         case T_ANT: HIP_OK(launch_step_ant(e->v, e->P, e->loco, actions, e->control_freq_inv, s)); break;
         case T_HUMANOID: HIP_OK(launch_step_humanoid(e->v, e->P, e->loco, actions, e->control_freq_inv, s)); break;
+        case T_SHADOWHAND: HIP_OK(launch_step_shadow_hand(e->v, e->hv, e->P, e->hand, actions, e->control_freq_inv, s)); break;
         case T_ANYMAL:
             if (e->terrain.hs == nullptr) return fail("mi_engine_step: AnymalTerrain needs mi_engine_set_terrain first");
             // common_step_counter is incremented before the push test (anymal_terrain.py:460-462)
@@ -408,6 +451,7 @@ extern "C" int mi_engine_simulate(MiEngine* e, void* stream) {
         case T_CARTPOLE: HIP_OK(launch_simulate_cartpole(e->v, e->P, s)); break;
         case T_ANT: HIP_OK(launch_simulate_ant(e->v, e->P, s)); break;
         case T_HUMANOID: HIP_OK(launch_simulate_humanoid(e->v, e->P, s)); break;
+        case T_SHADOWHAND: HIP_OK(launch_simulate_shadow_hand(e->v, e->hv, e->P, e->hand, s)); break;
         case T_ANYMAL:
             if (e->terrain.hs == nullptr) return fail("mi_engine_simulate: AnymalTerrain needs mi_engine_set_terrain first");
             HIP_OK(launch_simulate_anymal(e->v, e->P, e->terrain, s));
@@ -426,6 +470,7 @@ extern "C" int mi_engine_reset_idx(MiEngine* e, const int64_t* env_ids, int n, v
         case T_ANT: HIP_OK(launch_reset_ant(e->v, e->loco, (const long long*)env_ids, n, s)); break;
         case T_HUMANOID: HIP_OK(launch_reset_humanoid(e->v, e->loco, (const long long*)env_ids, n, s)); break;
         case T_ANYMAL: HIP_OK(launch_reset_anymal(e->v, e->anymal, e->terrain, (const long long*)env_ids, n, s)); break;
+        case T_SHADOWHAND: HIP_OK(launch_reset_shadow_hand(e->v, e->hv, e->hand, (const long long*)env_ids, n, s)); break;
     }
     return 0;
 }

@@ -17,6 +17,20 @@ struct HandRewardParams {  // mirrors MiHandRewardParams (include/mi_engine.h)
     int ignore_z_rot;
 };
 
+struct HandParams {   // mirrors MiHandParams (include/mi_engine.h): what ShadowHand.__init__ reads (shadow_hand.py:45-110)
+    HandRewardParams rew;
+    float vel_obs_scale, force_torque_obs_scale;              // :61-62
+    float reset_position_noise, reset_dof_pos_noise, reset_dof_vel_noise;   // :69-72
+    float act_moving_average, dof_speed_scale, dt;            // :80-81, sim dt
+    int use_relative_control;                                 // :79
+    float clip_actions;
+    float object_init_pos[3];                                 // hand start + (0, -0.39, 0.10), :309-315
+    float goal_init_pos[3];                                   // object init - 0.04 z, :393-395
+    float hand_pos[3], hand_quat[4];                          // actor pose (:306-307) x mount orientation (robot.xml:3)
+    float cube_half, cube_mass, cube_inertia, mu;             // cube_multicolor.urdf
+    int actuated[20];                                         // dof index of each of the 20 actuators (:268-269)
+};
+
 MI_HD void quat_conjugate(const float* a, float* o) { o[0] = -a[0]; o[1] = -a[1]; o[2] = -a[2]; o[3] = a[3]; }
 
 // per-env part of compute_hand_reward (:757-790); the cross-env consecutive_successes average (:792-797) is reduced by

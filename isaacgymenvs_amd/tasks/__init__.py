@@ -3,10 +3,12 @@ from .ant import Ant
 from .anymal_terrain import AnymalTerrain
 from .cartpole import Cartpole
 from .humanoid import Humanoid
+from .shadow_hand import ShadowHand
 
 isaacgym_task_map = {
     "Ant": Ant,
     "AnymalTerrain": AnymalTerrain,
     "Cartpole": Cartpole,
     "Humanoid": Humanoid,
+    "ShadowHand": ShadowHand,
 }

@@ -1,0 +1,121 @@
+"""ShadowHand: 24-DoF Shadow hand (20 actuated, 4 tendon-coupled) re-orienting a cube in hand
+(reference isaacgymenvs/tasks/shadow_hand.py).
+
+Host side only: config -> MiHandParams and the reference's attribute names as views of the engine arena.  Supported
+subset: objectType "block" (the cube: an isotropic free body), observationType "full_state" (211), absolute or relative
+position control, in-kernel resets.  Not supported (raise): egg / pen objects, the "openai" / "full_no_vel" / "full"
+observation layouts, asymmetric observations, random object forces (forceScale > 0).  Physics simplifications are listed
+in DESIGN.md (hand geometry sampled by spheres against the exact box, no hand self-collision, soft tendons, drive force
+limits not clamped).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .. import native
+from ..registry import load_extras, load_model
+from .base.vec_task import VecTask
+
+CUBE_SIZE = 0.05          # assets/urdf/objects/cube_multicolor.urdf: box 0.05
+CUBE_DENSITY = 567.0
+
+
+def hand_params_from_cfg(cfg):
+    env = cfg["env"]
+    ex = load_extras("shadow_hand")
+    p = native.MiHandParams()
+    r = p.rew
+    r.max_episode_length = float(env["episodeLength"])
+    r.dist_reward_scale = float(env["distRewardScale"]); r.rot_reward_scale = float(env["rotRewardScale"])
+    r.rot_eps = float(env["rotEps"]); r.action_penalty_scale = float(env["actionPenaltyScale"])
+    r.success_tolerance = float(env["successTolerance"]); r.reach_goal_bonus = float(env["reachGoalBonus"])
+    r.fall_dist = float(env["fallDistance"]); r.fall_penalty = float(env["fallPenalty"])
+    r.max_consecutive_successes = int(env["maxConsecutiveSuccesses"])
+    r.av_factor = float(env.get("averFactor", 0.1))
+    r.ignore_z_rot = 0                                            # object_type == "pen" (shadow_hand.py:421)
+    p.vel_obs_scale, p.force_torque_obs_scale = 0.2, 10.0         # shadow_hand.py:61-62
+    p.reset_position_noise = float(env["resetPositionNoise"])
+    p.reset_dof_pos_noise = float(env["resetDofPosRandomInterval"])
+    p.reset_dof_vel_noise = float(env["resetDofVelRandomInterval"])
+    p.act_moving_average = float(env["actionsMovingAverage"])
+    p.dof_speed_scale = float(env["dofSpeedScale"])
+    p.dt = float(cfg["sim"]["dt"])
+    p.use_relative_control = int(bool(env["useRelativeControl"]))
+    ca = env.get("clipActions", np.inf)
+    p.clip_actions = float(ca) if np.isfinite(ca) else 3.0e38
+    hand_pos = (0.0, 0.0, 0.5)                                    # get_axis_params(0.5, up_axis_idx), :306-307
+    obj = (hand_pos[0], hand_pos[1] - 0.39, hand_pos[2] + 0.10)  # :309-315
+    for k in range(3):
+        p.hand_pos[k] = hand_pos[k]
+        p.object_init_pos[k] = obj[k]
+        p.goal_init_pos[k] = obj[k] - (0.04 if k == 2 else 0.0)   # goal_states = object_init_state, z -= 0.04 (:393-395)
+    for k in range(4):
+        p.hand_quat[k] = float(ex["mount_quat"][k])
+    p.cube_half = CUBE_SIZE / 2
+    p.cube_mass = CUBE_DENSITY * CUBE_SIZE ** 3
+    p.cube_inertia = p.cube_mass * CUBE_SIZE ** 2 / 6.0
+    p.mu = 1.0
+    for a, d in enumerate(ex["actuated_dofs"]):
+        p.actuated[a] = int(d)
+    return p
+
+
+class ShadowHand(VecTask):
+    native_task = "ShadowHand"
+
+    def __init__(self, cfg, rl_device, sim_device, graphics_device_id, headless, virtual_screen_capture=False,
+                 force_render=False):
+        self.cfg = cfg
+        env = cfg["env"]
+        if env["objectType"] != "block":
+            raise NotImplementedError("only objectType 'block' is implemented (the cube is an isotropic free body)")
+        if env["observationType"] != "full_state" or env.get("asymmetric_observations", False):
+            raise NotImplementedError("only observationType 'full_state' without asymmetric observations is implemented")
+        if float(env.get("forceScale", 0.0)) > 0.0:
+            raise NotImplementedError("random object forces (forceScale > 0) are not implemented")
+        self.randomize = cfg["task"]["randomize"]
+        self.randomization_params = cfg["task"].get("randomization_params", {})
+        self.max_episode_length = env["episodeLength"]
+        self.obs_type = env["observationType"]
+        self.object_type = env["objectType"]
+        self.num_obs_dict = {"openai": 42, "full_no_vel": 77, "full": 157, "full_state": 211}
+        self.fingertips = ["robot0:ffdistal", "robot0:mfdistal", "robot0:rfdistal", "robot0:lfdistal", "robot0:thdistal"]
+        self.num_fingertips = 5
+        cfg["env"]["numObservations"] = 211
+        cfg["env"]["numStates"] = 0
+        cfg["env"]["numActions"] = 20
+        cfg["env"].setdefault("plane", {"staticFriction": 1.0})
+        self.spec = load_model("shadow_hand")
+        self.num_shadow_hand_dofs = self.spec.nd
+        self.num_shadow_hand_bodies = self.spec.nb
+        super().__init__(config=self.cfg, rl_device=rl_device, sim_device=sim_device,
+                         graphics_device_id=graphics_device_id, headless=headless,
+                         virtual_screen_capture=virtual_screen_capture, force_render=force_render)
+        t = self.engine.tensors
+        dev = self.device
+        ex = load_extras("shadow_hand")
+        self.dof_state = t["dof_state"]
+        self.shadow_hand_dof_pos, self.shadow_hand_dof_vel = self.dof_state[..., 0], self.dof_state[..., 1]
+        self.dof_force_tensor = t["dof_force"]
+        self.vec_sensor_tensor = torch.as_strided(t["force_sensor"], (self.num_envs, 30), (1, self.num_envs))
+        self.object_state = t["object_state"]
+        self.object_pose, self.object_pos, self.object_rot = self.object_state[:, 0:7], self.object_state[:, 0:3], self.object_state[:, 3:7]
+        self.object_linvel, self.object_angvel = self.object_state[:, 7:10], self.object_state[:, 10:13]
+        self.goal_states = t["goal_states"]
+        self.goal_pose, self.goal_pos, self.goal_rot = self.goal_states, self.goal_states[:, 0:3], self.goal_states[:, 3:7]
+        self.fingertip_state = t["fingertip_state"]
+        self.fingertip_pos = self.fingertip_state[:, :, 0:3]
+        self.cur_targets, self.prev_targets = t["cur_targets"], t["prev_targets"]
+        self.actions = t["actions"]
+        self.successes, self.consecutive_successes = t["successes"], t["consecutive_successes"]
+        self.reset_goal_buf = t["reset_goal_buf"]
+        lo = np.minimum(self.spec.dof_lower, self.spec.dof_upper); up = np.maximum(self.spec.dof_lower, self.spec.dof_upper)
+        self.shadow_hand_dof_lower_limits = torch.tensor(lo, dtype=torch.float32, device=dev)
+        self.shadow_hand_dof_upper_limits = torch.tensor(up, dtype=torch.float32, device=dev)
+        self.actuated_dof_indices = torch.tensor(ex["actuated_dofs"], dtype=torch.long, device=dev)
+        self.fingertip_handles = torch.tensor([self.spec.body_names.index(n) for n in self.fingertips], dtype=torch.long, device=dev)
+        self.extras["consecutive_successes"] = self.consecutive_successes[0]       # shadow_hand.py:424 (.mean() of a 1-vector)
+
+    def _task_params(self):
+        return hand_params_from_cfg(self.cfg)

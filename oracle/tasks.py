@@ -654,3 +654,115 @@ def compute_hand_full_state(dof_pos, dof_vel, dof_force, lower, upper, object_st
             goal_pose, quat_mul(object_state[:, 3:7].astype(f32), quat_conjugate(goal_pose[:, 3:7].astype(f32))),
             fingertip_state.reshape(n, -1), f32(ft_scale) * sensors.astype(f32), actions]
     return np.concatenate([c.astype(f32) for c in cols], axis=-1)
+
+
+class OracleShadowHandEnv:
+    """vec_task.py:360-408 + shadow_hand.py pre/post_physics_step on oracle/hand.py (numpy, fp64 physics, fp32 task maths).
+    `params` is the MiHandParams struct the HIP engine receives."""
+
+    def __init__(self, spec, extras, sensor_bodies, sim_params: dict, params, num_envs, seed=0, env_id_offset=0):
+        from .hand import OracleHandEngine
+        self.N, self.p, self.nd = num_envs, params, spec.nd
+        self.eng = OracleHandEngine(spec, extras, num_envs, sim_params, sensor_bodies)
+        self.eng.eng.root[:, :3] = list(params.hand_pos)
+        self.eng.eng.root[:, 3:7] = list(params.hand_quat)
+        self.seed, self.off = fold_seed(seed), env_id_offset
+        self.genv = (self.off + np.arange(num_envs)).astype(np.uint32)
+        N, p = num_envs, params
+        self.lo = np.minimum(spec.dof_lower, spec.dof_upper).astype(f32)
+        self.up = np.maximum(spec.dof_lower, spec.dof_upper).astype(f32)
+        self.act = np.array(p.actuated[:], int)
+        self.cur_targets = np.zeros((N, self.nd), f32)
+        self.prev_targets = np.zeros((N, self.nd), f32)
+        self.eng.obj[:, 0:3] = list(p.object_init_pos)
+        self.goal_states = np.zeros((N, 7), f32); self.goal_states[:, 0:3] = list(p.goal_init_pos); self.goal_states[:, 6] = 1
+        self.successes = np.zeros(N, f32)
+        self.consecutive_successes = f32(0)
+        self.reset_buf = np.ones(N, np.int64)
+        self.reset_goal_buf = np.ones(N, np.int64)
+        self.progress_buf = np.zeros(N, np.int64)
+        self.episode = np.zeros(N, np.uint32)
+        self.goal_count = np.zeros(N, np.uint32)
+        self.actions = np.zeros((N, 20), f32)
+
+    def _u(self, seed, genv, ep, k):
+        return f32(2) * mi_uniform(seed, genv, ep, k) - f32(1)
+
+    def reset_target_pose(self, ids):  # shadow_hand.py:586-602
+        if len(ids) == 0:
+            return
+        s = np.uint32(self.seed) ^ np.uint32(0x2545F491)
+        r0 = self._u(s, self.genv[ids], self.goal_count[ids], 0); r1 = self._u(s, self.genv[ids], self.goal_count[ids], 1)
+        xu = np.tile(np.array([1, 0, 0], f32), (len(ids), 1)); yu = np.tile(np.array([0, 1, 0], f32), (len(ids), 1))
+        self.goal_states[ids, 0:3] = np.array(self.p.goal_init_pos[:], f32)
+        self.goal_states[ids, 3:7] = randomize_rotation(r0, r1, xu, yu)
+        self.goal_count[ids] += 1
+        self.reset_goal_buf[ids] = 0
+
+    def reset_idx(self, ids):  # shadow_hand.py:604-668
+        if len(ids) == 0:
+            return
+        p, nd = self.p, self.nd
+        self.reset_target_pose(ids)
+        g, ep = self.genv[ids], self.episode[ids]
+        rf = lambda k: self._u(self.seed, g, ep, k)
+        obj = self.eng.obj
+        for k in range(3):
+            obj[ids, k] = f32(p.object_init_pos[k]) + f32(p.reset_position_noise) * rf(k)
+        xu = np.tile(np.array([1, 0, 0], f32), (len(ids), 1)); yu = np.tile(np.array([0, 1, 0], f32), (len(ids), 1))
+        obj[ids, 3:7] = randomize_rotation(rf(3), rf(4), xu, yu)
+        obj[ids, 7:13] = 0
+        for d in range(nd):
+            delta_max, delta_min = self.up[d] - f32(0), self.lo[d] - f32(0)
+            rand_delta = delta_min + (delta_max - delta_min) * f32(0.5) * (rf(5 + d) + f32(1))
+            pos = (f32(0) + f32(p.reset_dof_pos_noise) * rand_delta).astype(f32)
+            self.eng.q[ids, d] = pos
+            self.eng.qd[ids, d] = f32(0) + f32(p.reset_dof_vel_noise) * rf(5 + nd + d)
+            self.prev_targets[ids, d] = pos
+            self.cur_targets[ids, d] = pos
+        self.eng.laml[ids] = 0
+        self.episode[ids] += 1
+        self.progress_buf[ids] = 0
+        self.reset_buf[ids] = 0
+        self.successes[ids] = 0
+
+    def step(self, actions):
+        p = self.p
+        # pre_physics_step (:670-698)
+        env_ids = np.nonzero(self.reset_buf)[0]
+        goal_only = np.nonzero((self.reset_goal_buf != 0) & (self.reset_buf == 0))[0]
+        self.reset_idx(env_ids)
+        self.reset_target_pose(goal_only)
+        a = np.clip(actions.astype(f32), -f32(p.clip_actions), f32(p.clip_actions))
+        self.actions = a
+        lo, up = self.lo[self.act], self.up[self.act]
+        prev = self.prev_targets[:, self.act]
+        if p.use_relative_control:
+            t = prev + f32(p.dof_speed_scale) * f32(p.dt) * a
+        else:
+            t = (f32(0.5) * (a + f32(1.0)) * (up - lo) + lo).astype(f32)
+            t = f32(p.act_moving_average) * t + (f32(1.0) - f32(p.act_moving_average)) * prev
+        t = np.maximum(np.minimum(t, up), lo).astype(f32)
+        self.cur_targets[:, self.act] = t
+        self.prev_targets[:, self.act] = t
+        self.eng.targets[:] = self.cur_targets
+        self.eng.step()
+        return self.post_physics_step()
+
+    def post_physics_step(self):  # :710-715
+        p = self.p
+        self.progress_buf += 1
+        e = self.eng
+        self.fingertip_state = e.fingertip_states().astype(f32)
+        obj = e.obj.astype(f32)
+        self.obs_buf = compute_hand_full_state(e.q.astype(f32), e.qd.astype(f32), e.dof_force.astype(f32), self.lo, self.up, obj,
+                                               self.goal_states, self.fingertip_state, e.sensor.astype(f32), self.actions,
+                                               p.vel_obs_scale, p.force_torque_obs_scale)
+        r = p.rew
+        out = compute_hand_reward(None, self.reset_buf, self.reset_goal_buf, self.progress_buf, self.successes, self.consecutive_successes,
+                                  r.max_episode_length, obj[:, 0:3], obj[:, 3:7], self.goal_states[:, 0:3], self.goal_states[:, 3:7],
+                                  r.dist_reward_scale, r.rot_reward_scale, r.rot_eps, self.actions, r.action_penalty_scale,
+                                  r.success_tolerance, r.reach_goal_bonus, r.fall_dist, r.fall_penalty, r.max_consecutive_successes,
+                                  r.av_factor, bool(r.ignore_z_rot))
+        self.rew_buf, self.reset_buf, self.reset_goal_buf, self.progress_buf, self.successes, self.consecutive_successes = out
+        return self.obs_buf, self.rew_buf, self.reset_buf

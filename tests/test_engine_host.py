@@ -96,3 +96,51 @@ def test_host_build_on_heightfield_matches_oracle():
         assert np.abs(netf - orc.netf).max() < 2e-3 * max(1.0, np.abs(orc.netf).max())
         contacts += int((np.abs(orc.netf).sum(-1) > 0).sum())
     assert contacts > 50   # the scenario does exercise contacts
+
+
+def test_host_build_of_hand_engine_matches_oracle():
+    """csrc/core/hand_engine.hpp compiled for the host (fp32) against oracle/hand.py (fp64 restatement): hand + cube sub-steps
+    with finger/cube contacts, tendon rows, implicit PD drives; contact counts identical, states agree to fp32 rounding."""
+    import ctypes as C
+    from oracle.hand import OracleHandEngine
+    from isaacgymenvs_amd.registry import load_model, load_extras, sensor_bodies
+    lib = hostsim.build_hand()
+    spec, ex = load_model("shadow_hand"), load_extras("shadow_hand")
+    sim = dict(dt=1.0 / 60.0, substeps=2, iters=8, gravity=(0.0, 0.0, -9.81), contact_offset=0.002, rest_offset=0.0,
+               max_depen_vel=1000.0, erp=0.2, plane_mu=1.0, ground_z=0.0, cfm=1e-4, warm=0.9)
+    N, nd = 6, spec.nd
+    rng = np.random.default_rng(5)
+    orc = OracleHandEngine(spec, ex, N, sim, sensor_bodies("shadow_hand"))
+    lo, up = orc.lo, orc.up
+    orc.q[:] = lo + (up - lo) * rng.uniform(0.2, 0.5, (N, nd))
+    orc.qd[:] = rng.normal(0, 0.5, (N, nd))
+    orc.targets[:] = lo + (up - lo) * rng.uniform(0.1, 0.9, (N, nd))
+    # cube a little above the palm, dropping onto the fingers
+    tips = orc.fingertip_states()
+    orc.obj[:, 0:3] = tips[:, :, 0:3].mean(1) + rng.normal(0, 0.01, (N, 3)) + np.array([0.0, 0.0, 0.02])
+    qn = rng.normal(size=(N, 4)); orc.obj[:, 3:7] = qn / np.linalg.norm(qn, axis=1, keepdims=True)
+    orc.obj[:, 7:10] = rng.normal(0, 0.1, (N, 3))
+    from oracle.hand import CUBE_HALF as half, CUBE_MASS as mass, CUBE_INERTIA as inertia
+    mu = 1.0
+    ss = 4 * nd + 13
+    state = np.zeros((N, ss), np.float32)
+    state[:, 0:nd] = orc.q; state[:, nd:2 * nd] = orc.qd; state[:, 3 * nd:4 * nd] = orc.targets; state[:, 4 * nd:] = orc.obj
+    root13 = np.zeros(13, np.float32); root13[:7] = orc.eng.root[0, :7]
+    ns = len(orc.sens)
+    out = np.zeros((N, 6 * ns + nd + 1), np.float32)
+    P = hostsim.make_params(sim)
+    tipsh = np.zeros((N, ns, 13), np.float32)
+    lib.hs_hand_fingertips(N, state.ctypes.data_as(C.c_void_p), root13.ctypes.data_as(C.c_void_p), tipsh.ctypes.data_as(C.c_void_p))
+    np.testing.assert_allclose(tipsh, tips, atol=2e-5)
+    total = 0
+    for it in range(12):
+        orc.step()
+        rc = lib.hs_step_hand(C.byref(P), N, state.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                              root13.ctypes.data_as(C.c_void_p), C.c_float(half), C.c_float(mass), C.c_float(inertia), C.c_float(mu))
+        assert rc == 0
+        np.testing.assert_array_equal(out[:, -1].astype(int), orc.ncontacts)
+        total += int(orc.ncontacts.sum())
+        np.testing.assert_allclose(state[:, 0:nd], orc.q, atol=2e-3)
+        np.testing.assert_allclose(state[:, 4 * nd:4 * nd + 7], orc.obj[:, 0:7], atol=5e-3)
+    assert total > 0, "scenario never produced finger/cube contacts"
+    assert np.isfinite(state).all()
