@@ -37,12 +37,14 @@ ALGO_BYTES = {"Cartpole": 89, "Ant": 673, "Humanoid": 1161, "AnymalTerrain": 224
 DEFAULT_ENVS = {"Cartpole": 64, "Ant": 4096, "Humanoid": 8192, "AnymalTerrain": 4096, "ShadowHand": 16384}
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 # HBM-side bytes per control step from the round-1 PMC passes (profiles/r1_pmc_summary.md): raw FETCH_SIZE + WRITE_SIZE
-# (KB -> B) summed over the launches of one step (2 sub-steps + post) at the BASELINE env counts.  The raw fetch counter
+# (KB -> B) summed over the launches of one step (sub-steps + pre/post kernels) at the BASELINE env counts.  The raw fetch counter
 # matches the byte count of our dword-per-lane coalesced loads, so the guide's x2 (calibrated on 16 B/lane streams) is
 # NOT applied; the excess over the algorithmic bytes is state re-read per sub-step launch, warm-start impulses and
 # (Humanoid) the constraint rows that spill to scratch.
-PMC_TRAFFIC_BYTES = {("Ant", 4096): int((2 * (1691.5 + 3024.0) + 659.9 + 2230.1) * 1024),
-                     ("Humanoid", 8192): int((2 * (146584.3 + 116067.2) + 2232.7 + 8898.3) * 1024)}
+PMC_TRAFFIC_BYTES = {("Ant", 4096): int((2 * (1278.9 + 2144.0) + 671.0 + 2230.1) * 1024),
+                     ("Humanoid", 8192): int((2 * (16098.3 + 31864.1) + 2265.6 + 8898.3) * 1024),
+                     ("AnymalTerrain", 4096): int((5 * (2836.2 + 4384.0) + 65.1 + 1715.7 + 6891.9 + 1.8) * 1024),
+                     ("ShadowHand", 16384): int((1674.1 + 4620.9 + 2 * (9353.3 + 31551.8) + 6369.4 + 44704.4 + 1.5) * 1024)}
 
 
 def measure(task, num_envs, steps, warmup, device, rank, world, seed=42, pool=64):

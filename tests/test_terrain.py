@@ -1,0 +1,131 @@
+"""Property tests of the host terrain generator (isaacgymenvs_amd/tasks/terrain.py), the restatement of the reference's
+`Terrain` (isaacgymenvs/tasks/anymal_terrain.py:543-673) and of the `isaacgym.terrain_utils` primitives it calls (that
+module is part of the closed Isaac Gym package and absent from the reference tree, so these are geometry known-answer
+checks, not golden comparisons)."""
+import numpy as np
+import pytest
+
+from isaacgymenvs_amd.tasks import terrain as T
+
+HS, VS = 0.1, 0.005
+
+
+def _sub(n=80):
+    return T.SubTerrain("terrain", width=n, length=n, vertical_scale=VS, horizontal_scale=HS)
+
+
+@pytest.mark.parametrize("slope", [0.2, -0.3, 0.0])
+def test_pyramid_slope_geometry(slope):
+    t = T.pyramid_sloped_terrain(_sub(), slope=slope, platform_size=3.0)
+    h = t.height_field_raw.astype(float) * VS
+    assert t.height_field_raw.dtype == np.int16
+    # borders are at height 0, the centre platform is flat at the clipped apex height, the sign follows the slope
+    assert h[0, :].max() == 0 and h[:, 0].max() == 0 and h[0, :].min() == 0
+    plat = h[40 - 14:40 + 14, 40 - 14:40 + 14]
+    assert np.ptp(plat) == 0.0
+    assert np.sign(plat[0, 0]) == np.sign(slope)
+    # along the mid line the height profile is piecewise linear with the requested slope (int16 truncation)
+    mid = h[:12, 40]
+    if slope != 0:
+        np.testing.assert_allclose(np.diff(mid), slope * HS, atol=VS + 1e-9)
+    # 4-fold symmetry of the pyramid
+    np.testing.assert_array_equal(t.height_field_raw[1:, 1:], t.height_field_raw[1:, 1:][::-1, ::-1])
+
+
+@pytest.mark.parametrize("step_height", [0.15, -0.1])
+def test_pyramid_stairs_geometry(step_height):
+    t = T.pyramid_stairs_terrain(_sub(), step_width=0.31, step_height=step_height, platform_size=3.0)
+    raw = t.height_field_raw
+    sw, sh = int(0.31 / HS), int(step_height / VS)
+    levels = np.unique(raw)
+    # heights are integer multiples of the step, rings are `step_width` pixels wide, the outermost ring is level 0
+    assert set(levels.tolist()) <= {k * sh for k in range(0, 40)}
+    assert (raw[:sw, :] == 0).all() and (raw[sw:2 * sw, sw:-sw] == sh).all()
+    # monotone towards the centre
+    line = raw[40, :41].astype(int)
+    assert (np.diff(line) * np.sign(sh) >= 0).all()
+    assert abs(raw[40, 40]) == abs(levels).max()
+
+
+def test_discrete_obstacles_properties():
+    rng = np.random.RandomState(3)
+    t = T.discrete_obstacles_terrain(_sub(), 0.15, 1.0, 2.0, 40, platform_size=3.0, rng=rng)
+    raw = t.height_field_raw
+    mh = int(0.15 / VS)
+    assert set(np.unique(raw).tolist()) <= {-mh, -mh // 2, 0, mh // 2, mh}
+    assert (raw[25:55, 25:55] == 0).all()          # 3 m platform
+    assert (raw != 0).sum() > 200                  # obstacles exist
+    # deterministic for a given stream
+    t2 = T.discrete_obstacles_terrain(_sub(), 0.15, 1.0, 2.0, 40, platform_size=3.0, rng=np.random.RandomState(3))
+    np.testing.assert_array_equal(raw, t2.height_field_raw)
+
+
+def test_stepping_stones_properties():
+    rng = np.random.RandomState(4)
+    t = T.stepping_stones_terrain(_sub(), stone_size=1.0, stone_distance=0.1, max_height=0.0, platform_size=3.0, rng=rng)
+    raw = t.height_field_raw
+    depth = int(-10 / VS)
+    vals = set(np.unique(raw).tolist())
+    assert depth in vals and vals <= {depth, -1, 0}     # pit, stones at height in [-1, 0) units, platform 0
+    assert (raw[25:55, 25:55] == 0).all()
+    # gaps are one pixel wide (0.1 m) columns/rows of pit between 10-pixel stones
+    col_is_gap = (raw[:, :20] == depth).all(axis=0)
+    assert col_is_gap.sum() >= 1
+
+
+def test_random_uniform_is_additive_bounded_and_quantised():
+    rng = np.random.RandomState(5)
+    t = _sub()
+    t.height_field_raw[:] = 7
+    T.random_uniform_terrain(t, min_height=-0.1, max_height=0.1, step=0.025, downsampled_scale=0.2, rng=rng)
+    d = t.height_field_raw.astype(int) - 7
+    assert d.min() >= int(-0.1 / VS) - 1 and d.max() <= int(0.1 / VS) + 1
+    assert d.std() > 2          # noise present
+    # the coarse and fine grids (both linspace over the tile) share only the corner nodes: those are exact multiples of the
+    # height step (0.025 m = 5 units); everything else is a linear blend of such values
+    assert all(int(v) % 5 == 0 for v in (d[0, 0], d[0, -1], d[-1, 0], d[-1, -1]))
+    assert np.abs(np.diff(d, axis=0)).max() <= 40 // 2 + 1     # no jump larger than one coarse cell allows
+
+
+def _cfg(curriculum):
+    return dict(terrainType="trimesh", mapLength=8.0, mapWidth=8.0, numLevels=4, numTerrains=5, curriculum=curriculum,
+                terrainProportions=[0.1, 0.1, 0.35, 0.25, 0.2])
+
+
+@pytest.mark.parametrize("curriculum", [True, False])
+def test_terrain_layout_and_origins(curriculum):
+    ter = T.Terrain(_cfg(curriculum), num_robots=64, seed=1)
+    assert ter.border == 200 and ter.tot_rows == 4 * 80 + 400 and ter.tot_cols == 5 * 80 + 400
+    assert ter.heightsamples.dtype == np.int16 and ter.heightsamples.shape == (ter.tot_rows, ter.tot_cols)
+    # the 20 m border stays flat
+    hs = ter.heightsamples
+    assert (hs[:200] == 0).all() and (hs[-200:] == 0).all() and (hs[:, :200] == 0).all() and (hs[:, -200:] == 0).all()
+    # env origins: tile centres, z = max height of the central 2 m x 2 m patch (anymal_terrain.py:664-672)
+    for i in range(4):
+        for j in range(5):
+            ox, oy, oz = ter.env_origins[i, j]
+            assert ox == (i + 0.5) * 8.0 and oy == (j + 0.5) * 8.0
+            tile = hs[200 + 80 * i:200 + 80 * (i + 1), 200 + 80 * j:200 + 80 * (j + 1)]
+            assert oz == pytest.approx(tile[30:50, 30:50].max() * VS)
+    # same seed -> same terrain on every rank; another seed differs (when random parts exist)
+    ter2 = T.Terrain(_cfg(curriculum), num_robots=64, seed=1)
+    np.testing.assert_array_equal(hs, ter2.heightsamples)
+
+
+def test_curriculum_difficulty_grows_with_level():
+    cfg = dict(_cfg(True), numLevels=10, numTerrains=20)
+    ter = T.Terrain(cfg, num_robots=200, seed=0)
+    hs = ter.heightsamples.astype(float) * VS
+    # cumulative proportions [.1,.2,.55,.8,1]: column 12 of 20 (choice 0.6) is stairs-up, column 8 (0.4) stairs-down
+    # (anymal_terrain.py:650-653): the apex height grows / falls monotonically with the level
+    apex = [hs[200 + 80 * i + 40, 200 + 80 * 12 + 40] for i in range(10)]
+    assert all(b >= a for a, b in zip(apex, apex[1:])) and apex[-1] > apex[0] > 0
+    pit = [hs[200 + 80 * i + 40, 200 + 80 * 8 + 40] for i in range(10)]
+    assert all(b <= a for a, b in zip(pit, pit[1:])) and pit[-1] < pit[0] < 0
+    # column 0 (choice 0 < 0.05) is a downward slope
+    assert hs[200 + 80 * 9 + 40, 200 + 40] < 0
+
+
+def test_plane_terrain_builds_nothing():
+    ter = T.Terrain(dict(terrainType="plane"), num_robots=4)
+    assert not hasattr(ter, "heightsamples")

@@ -18,8 +18,12 @@ rows = list(csv.reader(open(os.path.join(src, "trace", f"{tag}_kernel_stats.csv"
 with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
     w = csv.writer(f)
     w.writerow(rows[0])
-    for r in rows[1:12]:
+    for r in rows[1:26]:
         w.writerow([r[0][:160]] + r[1:])
+
+def ours(k):
+    return k.startswith("mi::") or ("_kernel" in k and "at::" not in k and "elementwise" not in k)
+
 
 def agg(path):
     d = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -31,7 +35,7 @@ def agg(path):
                        vgpr=int(r["VGPR_Count"]), agpr=int(r["Accum_VGPR_Count"]), sgpr=int(r["SGPR_Count"]))
     return d, meta
 
-out = [f"# rocprofv3 PMC summary `{tag}` (bench.py --steps 300 --warmup 50, Ant@4096 then Humanoid@8192, 1x MI355X)\n",
+out = [f"# rocprofv3 PMC summary `{tag}` (bench.py --steps 300 --warmup 50, Ant@4096, Humanoid@8192, AnymalTerrain@4096, ShadowHand@16384, 1x MI355X)\n",
        "Separate passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, SQ counters), as /opt/skills/guides/MI355X_MICROARCH.md prescribes.",
        "FETCH_SIZE / WRITE_SIZE are reported in KB per launch; `fetch_x2` applies the guide's gfx950 correction (the counter tallies",
        "128-B requests at 64 B).  SQ counters are summed over all waves of a launch; the per-wave column divides by SQ_WAVES;",
@@ -40,7 +44,7 @@ traffic = {}
 for name, label in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     d, meta = agg(os.path.join(src, name, f"{tag}_counter_collection.csv"))
     for k, v in d.items():
-        if k.startswith("mi::"):
+        if ours(k):
             traffic.setdefault(k, {})[label] = sum(v[label]) / len(v[label])
             traffic[k]["meta"] = meta[k]
 out.append("| kernel | grid | LDS B/WG | scratch B/lane | VGPR+AGPR | FETCH_SIZE KB | fetch_x2 KB | WRITE_SIZE KB |")
@@ -53,7 +57,7 @@ d, meta = agg(os.path.join(src, "pmc_sq", f"{tag}_counter_collection.csv"))
 out.append("\n| kernel | waves | per-wave: VALU insts | SALU | LDS insts | WAVE_CYCLES (quad) | ACTIVE_INST_ANY | WAIT_ANY | wait % |")
 out.append("|---|---|---|---|---|---|---|---|---|")
 for k, v in d.items():
-    if not k.startswith("mi::"):
+    if not ours(k):
         continue
     a = {c: sum(x) / len(x) for c, x in v.items()}
     wv = max(a.get("SQ_WAVES", 1.0), 1.0)
