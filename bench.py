@@ -57,12 +57,13 @@ def measure(task, num_envs, steps, warmup, device, rank, world, seed=42, pool=64
     g = torch.Generator(device=device).manual_seed(seed + rank)  # reference utils/utils.py:94: seed + rank
     acts = [2.0 * torch.rand((num_envs, env.num_actions), device=device, generator=g) - 1.0 for _ in range(pool)]
     reducer = None
-    if world > 1:
+    use_dist = dist.is_available() and dist.is_initialized()
+    if use_dist:
         from isaacgymenvs_amd.parallel import EpisodeStatsReducer
         reducer = EpisodeStatsReducer(env.engine.tensors["episode_stats"], interval=16)
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -83,7 +84,7 @@ def measure(task, num_envs, steps, warmup, device, rank, world, seed=42, pool=64
     sync()
     wall = time.perf_counter() - t0
     gpu_ms = ev0.elapsed_time(ev1)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([wall], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
@@ -182,13 +183,13 @@ def main():
 
     main_res = measure(args.task, n_env, args.steps, args.warmup, device, rank, world)
     extra = extra2 = extra3 = None
-    if not args.no_extra and args.task == "Ant":
+    if not args.no_extra and args.task == "Ant" and world == 1:   # side measurements only in the single-GPU run
         extra = measure("Humanoid", DEFAULT_ENVS["Humanoid"], max(args.steps // 4, 10), max(args.warmup // 4, 5), device, rank, world)
         extra2 = measure("AnymalTerrain", DEFAULT_ENVS["AnymalTerrain"], max(args.steps // 4, 10), max(args.warmup // 4, 5), device, rank, world)
         extra3 = measure("ShadowHand", DEFAULT_ENVS["ShadowHand"], max(args.steps // 8, 10), max(args.warmup // 8, 5), device, rank, world)
+    import torch.distributed as dist
     if rank != 0:
-        if world > 1:
-            import torch.distributed as dist
+        if dist.is_initialized():
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -223,8 +224,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline and args.task in ("Ant", "Humanoid"):
         out["cpu_baseline"] = cpu_baseline(args.task, n_env, budget_s=args.cpu_budget)
     print(json.dumps(out), flush=True)
-    if world > 1:
-        import torch.distributed as dist
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -19,7 +19,9 @@ def init_distributed(backend=None):
     world = int(os.getenv("WORLD_SIZE", "1"))
     rank = int(os.getenv("RANK", "0"))
     local_rank = int(os.getenv("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # MI_FORCE_DIST=1 joins the rendezvous even at world size 1 (exercises the RCCL path on a single-GPU box)
+    force = os.getenv("MI_FORCE_DIST") == "1" and "MASTER_PORT" in os.environ
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
@@ -68,11 +70,11 @@ class EpisodeStatsReducer:
             self.side.wait_stream(torch.cuda.current_stream(self.stats.device))
             with torch.cuda.stream(self.side):
                 self.global_stats.copy_(self.stats)
-                if self.world > 1:
+                if dist.is_initialized():
                     self._work = dist.all_reduce(self.global_stats, op=dist.ReduceOp.SUM, async_op=True)
         else:
             self.global_stats.copy_(self.stats)
-            if self.world > 1:
+            if dist.is_initialized():
                 self._work = dist.all_reduce(self.global_stats, op=dist.ReduceOp.SUM, async_op=True)
 
     def result(self):
