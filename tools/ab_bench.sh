@@ -6,6 +6,6 @@ for rep in 1 2; do
     MI_ENGINE_LIB=$PWD/$lib python bench.py --steps 1000 --warmup 100 --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.readline())
-print('$lib', 'rep$rep', 'Ant ms/step %.4f kernel %.4f | Humanoid ms/step %.4f kernel %.4f' % (d['ms_per_step'], d['roofline']['kernel_ms'], d['extra']['ms_per_step'], d['extra']['roofline']['kernel_ms']))"
+print('$lib', 'rep$rep', 'Ant %.4f | Humanoid %.4f | Anymal %.4f | Hand %.4f  (ms/step)' % (d['ms_per_step'], d['extra']['ms_per_step'], d['extra2']['ms_per_step'], d['extra3']['ms_per_step']))"
   done
 done
