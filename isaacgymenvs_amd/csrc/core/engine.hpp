@@ -20,7 +20,11 @@
 
 #if defined(MI_TIMING) && defined(__HIP_DEVICE_COMPILE__)
 // tools/debug only: s_memtime stamps at the phase boundaries of a sub-step (never defined in the product build)
-#define MI_STAMP(i) do { if (tstamp) tstamp[i] = __builtin_readcyclecounter(); } while (0)
+#define MI_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+                         if (tstamp) tstamp[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#elif defined(MI_MARKERS) && defined(__HIP_DEVICE_COMPILE__)
+// tools/debug only: assembler comments at the phase boundaries (tools/debug/phasecount.py counts spill traffic per phase)
+#define MI_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; MI_MARK %0" ::"n"(i)); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define MI_STAMP(i) do { } while (0)
 #endif
@@ -35,13 +39,17 @@
 // an integer zero the optimiser cannot see through: added to the row-store base inside the PGS loop so that LICM
 // does not hoist the (loop-invariant) loads of all G rows out of the sweep loop and keep them live in registers
 #define MI_OPAQUE_ZERO(z) asm volatile("s_mov_b32 %0, 0" : "=s"(z))
+// wave-uniform "does any env of this wavefront ...": lets the whole wave branch around work no lane needs
+#define MI_WAVE_ANY(x) (__builtin_amdgcn_ballot_w64(x) != 0ull)
 #else
 #define MI_PHASE() do { } while (0)
 #define MI_OPAQUE_ZERO(z) (z) = 0
+#define MI_WAVE_ANY(x) (x)
 #endif
 #else
 #define MI_PHASE() do { } while (0)
 #define MI_OPAQUE_ZERO(z) (z) = 0
+#define MI_WAVE_ANY(x) (x)
 #define MI_HD inline __attribute__((always_inline))
 #define MI_HD_NOINLINE __attribute__((noinline))
 #define MI_LAMBDA __attribute__((always_inline))
@@ -695,6 +703,10 @@ struct Sim {
         });
         MI_PHASE();
         MI_STAMP(4);
+        // bit s set <=> some env of this wave has sphere s within contact_offset (wave-uniform, lives in an SGPR): rows of
+        // a sphere no env touches are neither built nor swept -- their contribution would be exactly zero anyway
+        unsigned long long sph_active = 0ull;
+        static_assert(COMPACT || NSPH <= 64, "sph_active is a 64-bit mask");
         if constexpr (!COMPACT) {
         // ground contacts: 3 rows per sphere (normal, two tangents; +z, x, y on the plane)
         sfor<NSPH>([&](auto S_) MI_LAMBDA {
@@ -714,11 +726,16 @@ struct Sim {
                 dist = (root[2] + xc[2]) - P.ground_z;
             }
             const bool on = dist < P.contact_offset;
-            // Branch-free: rows of an inactive sphere are built like any other and made inert with Ainv = 0 and
-            // lam = 0 (every PGS update then multiplies by zero).  All 64 envs of the wave run the same
-            // instruction stream -- no EXEC-mask divergence.
+            // Within an active sphere the build is branch-free: rows of an env that does not touch are built like any
+            // other and made inert with Ainv = 0 and lam = 0 (every PGS update then multiplies by zero) -- no EXEC-mask
+            // divergence; the only branch is the wave-uniform one.
             const float onf = on ? 1.f : 0.f;
             const float gap = dist - P.rest_offset;
+            if (!MI_WAVE_ANY(on)) {
+                sfor<3>([&](auto K) MI_LAMBDA { lam(row0 + K) = 0.f; });
+                return;
+            }
+            sph_active |= 1ull << s;
             sfor<3>([&](auto K) MI_LAMBDA {
                 constexpr int k = K, row = row0 + k;
                 // unit force u at xc as a spatial force [xc x u; u]
@@ -838,11 +855,13 @@ struct Sim {
             if constexpr (!COMPACT) {
                 sfor<NSPH>([&](auto S_) MI_LAMBDA {
                     constexpr int s = S_, b = M::sph_body[s], row0 = NLIM + 3 * s;
-                    sfor<3>([&](auto K) MI_LAMBDA {
-                        constexpr int row = row0 + K;
-                        const float l0 = lam(row);
-                        sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += rit(row * M::MAXCHAIN + C) * l0; });
-                    });
+                    if (sph_active >> s & 1ull) {
+                        sfor<3>([&](auto K) MI_LAMBDA {
+                            constexpr int row = row0 + K;
+                            const float l0 = lam(row);
+                            sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += rit(row * M::MAXCHAIN + C) * l0; });
+                        });
+                    }
                 });
             } else {
                 sfor<NSPH>([&](auto S_) MI_LAMBDA {
@@ -899,12 +918,20 @@ struct Sim {
                         B.vt[0] = rit(NROWG * M::MAXCHAIN + NROWG + row0);  // tangential targets are zero
                     }
                 };
+                auto unit_on = [&](auto U_) MI_LAMBDA -> bool {    // wave-uniform
+                    constexpr int u = decltype(U_)::value;
+                    if constexpr (u < NLIM) return true;
+                    else if constexpr (u < NUNIT) return (sph_active >> (u - NLIM) & 1ull) != 0ull;
+                    else return false;
+                };
                 if constexpr (NUNIT > 0) load_unit(std::integral_constant<int, 0>{}, ub[0]);
                 sfor<NUNIT>([&](auto U_) MI_LAMBDA {
                     constexpr int u = U_;
                     UBuf& B = ub[u & 1];
-                    load_unit(std::integral_constant<int, u + 1>{}, ub[(u + 1) & 1]);  // prefetch (no-op past the end)
+                    if (unit_on(std::integral_constant<int, u + 1>{}))
+                        load_unit(std::integral_constant<int, u + 1>{}, ub[(u + 1) & 1]);  // prefetch (no-op past the end)
                     MI_PHASE();
+                    if (!unit_on(std::integral_constant<int, u>{})) return;
                     if constexpr (u < NLIM) {
                         constexpr int d = limdof(u), gi = OFF + d, row = u;
                         float vn = B.g[0][0] * w[gi];
@@ -1059,6 +1086,10 @@ struct Sim {
                 l2 = onj ? cb[(3 * M::MAXCHAIN + 6) * ST] : 0.f;
                 (void)row0;
             } else {
+                if (!(sph_active >> s & 1ull)) {   // wave-uniform: nobody touches with this sphere
+                    lamc(3 * s) = 0.f; lamc(3 * s + 1) = 0.f; lamc(3 * s + 2) = 0.f;
+                    return;
+                }
                 ln = lam(row0); l1 = lam(row0 + 1); l2 = lam(row0 + 2);
             }
             lamc(3 * s) = ln; lamc(3 * s + 1) = l1; lamc(3 * s + 2) = l2;
