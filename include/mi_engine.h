@@ -85,6 +85,19 @@ typedef struct {
     float terrain_mu;
 } MiAnymalParams;
 
+/* task parameters of Anymal (flat ground): what the reference's __init__ reads from cfg["env"] (anymal.py:42-97).
+ * Reward scales are the YAML values already multiplied by dt (anymal.py:96-97). */
+typedef struct {
+    float lin_vel_scale, ang_vel_scale, dof_pos_scale, dof_vel_scale, action_scale; /* learn.*Scale, control.actionScale */
+    float rew_lin_vel_xy, rew_ang_vel_z, rew_torque;
+    float command_x[2], command_y[2], command_yaw[2];   /* randomCommandVelocityRanges */
+    float base_init_state[13];                          /* baseInitState pos, rot, vLinear, vAngular */
+    float default_dof_pos[12];                          /* defaultJointAngles in dof order */
+    float kp, kd, torque_limit;                         /* control.stiffness / damping (DOF_MODE_POS drive); URDF effort */
+    int32_t max_episode_length;                         /* int(episodeLength_s / dt + 0.5) (anymal.py:92) */
+    float clip_actions;
+} MiAnymalFlatParams;
+
 /* scalars of compute_hand_reward (shadow_hand.py:746-756) */
 typedef struct {
     float max_episode_length;
@@ -126,7 +139,7 @@ typedef struct {
 
 /* ---- discovery ------------------------------------------------------------------------------------------- */
 int mi_abi_version(void);
-/* task in {"Cartpole","Ant","Humanoid","AnymalTerrain","ShadowHand"}: replaces isaacgym_task_map lookup (isaacgymenvs/tasks/__init__.py:88-114)
+/* task in {"Cartpole","Ant","Humanoid","AnymalTerrain","ShadowHand","Anymal"}: replaces isaacgym_task_map lookup (isaacgymenvs/tasks/__init__.py:88-114)
  * + gym.get_asset_{dof,rigid_body}_count (ant.py:155-156) */
 int mi_task_info(const char* task, MiTaskInfo* out);
 size_t mi_engine_arena_bytes(const char* task, int num_envs);
@@ -191,6 +204,18 @@ int mi_compute_locomotion_reward(const char* task, int n, const MiLocoParams* p,
 int mi_compute_cartpole_reward(int n, const MiCartpoleParams* p, const float* pole_angle, const float* pole_vel,
                                const float* cart_vel, const float* cart_pos, const int64_t* reset_buf_in,
                                const int64_t* progress_buf, float* rew_buf, int64_t* reset_buf_out, void* stream);
+
+/* compute_anymal_observations (anymal.py:354-386): root_states [n,13], commands [n,3], dof_pos / dof_vel / actions
+ * [n,12] -> obs [n,48].  gravity_vec is the constant (0,0,-1) of anymal.py:143; default_dof_pos and the scales come
+ * from p. */
+int mi_compute_anymal_observations(int n, const MiAnymalFlatParams* p, const float* root_states, const float* commands,
+                                   const float* dof_pos, const float* dof_vel, const float* actions, float* obs_buf,
+                                   void* stream);
+/* compute_anymal_reward (anymal.py:311-351): torques [n,12], contact_forces [n,num_bodies,3] (base = body 0, knees =
+ * the *_THIGH bodies), episode_lengths int64 [n] -> rew [n], reset int64 [n] */
+int mi_compute_anymal_reward(int n, const MiAnymalFlatParams* p, const float* root_states, const float* commands,
+                             const float* torques, const float* contact_forces, int num_bodies,
+                             const int64_t* episode_lengths, float* rew_buf, int64_t* reset_buf, void* stream);
 
 /* ---- ShadowHand task functions (the hand/cube physics is not in the engine yet; these run on caller tensors) ------- */
 /* compute_hand_reward (shadow_hand.py:746-800).  rew_buf out; reset_buf, reset_goal_buf, progress_buf (int64), successes

@@ -182,9 +182,15 @@ MI_HD void spi_mul(const SpI& I, const float* X, float* F) {
 // piecewise-linear mesh (without the slope-threshold vertex correction), read straight from the int16 grid.
 struct PlaneGround {
     static constexpr bool HEIGHTFIELD = false;
+    static constexpr bool NETF = false;   // per-body net contact forces (gym.acquire_net_contact_force_tensor) not wanted
+};
+struct PlaneGroundNF {                     // flat ground, net contact forces reported (Anymal: anymal.py:110)
+    static constexpr bool HEIGHTFIELD = false;
+    static constexpr bool NETF = true;
 };
 struct HeightfieldGround {
     static constexpr bool HEIGHTFIELD = true;
+    static constexpr bool NETF = true;
     const short* hs;  // [rows * cols], row-major
     int rows, cols;
     float hscale, vscale, border;
@@ -1070,8 +1076,8 @@ struct Sim {
         });
         float sens[6 * M::NSENSA];
         sfor<6 * NSENS>([&](auto K) MI_LAMBDA { sens[K] = 0.f; });
-        float nf[GND::HEIGHTFIELD ? NB : 1][3];
-        if constexpr (GND::HEIGHTFIELD) sfor<NB>([&](auto B_) MI_LAMBDA { nf[B_][0] = nf[B_][1] = nf[B_][2] = 0.f; });
+        float nf[GND::NETF ? NB : 1][3];
+        if constexpr (GND::NETF) sfor<NB>([&](auto B_) MI_LAMBDA { nf[B_][0] = nf[B_][1] = nf[B_][2] = 0.f; });
         sfor<NSPH>([&](auto S_) MI_LAMBDA {
             constexpr int s = S_, b = M::sph_body[s], row0 = NLIM + 3 * s;
             // inactive spheres carry lam = 0 => zero warm start and zero sensor / net-force contribution
@@ -1107,6 +1113,7 @@ struct Sim {
             } else {
                 f[0] = l1 * invh; f[1] = l2 * invh; f[2] = ln * invh;
                 xc[0] = c.xcs[s][0]; xc[1] = c.xcs[s][1]; xc[2] = c.xcs[s][2] - M::sph_rad[s];
+                if constexpr (GND::NETF) sfor<3>([&](auto K) MI_LAMBDA { nf[b][K] += f[K]; });
             }
             if constexpr (sensor_of(b) >= 0) {
                 constexpr int k = sensor_of(b);
@@ -1117,7 +1124,7 @@ struct Sim {
                 sfor<3>([&](auto C) MI_LAMBDA { sens[6 * k + C] += fl[C]; sens[6 * k + 3 + C] += tl[C]; });
             }
         });
-        if constexpr (GND::HEIGHTFIELD) sfor<NB>([&](auto B_) MI_LAMBDA { sfor<3>([&](auto K) MI_LAMBDA { netf(3 * B_ + K) = nf[B_][K]; }); });
+        if constexpr (GND::NETF) sfor<NB>([&](auto B_) MI_LAMBDA { sfor<3>([&](auto K) MI_LAMBDA { netf(3 * B_ + K) = nf[B_][K]; }); });
         sfor<6 * NSENS>([&](auto K) MI_LAMBDA { sensor(K) = sens[K]; });
         MI_PHASE();
         // ------------------------------------------------------------ integrate (semi-implicit Euler)

@@ -388,4 +388,149 @@ hipError_t launch_reset_anymal(const View& v, const AnymalParams& tp, const Anym
     return hipGetLastError();
 }
 
+
+// =================================================================================================== Anymal (flat ground)
+// post_physics_step of isaacgymenvs/tasks/anymal.py:231-241: progress++, reset_idx of flagged envs, observations, reward.
+// State tensors are written immediately (CPU-pipeline semantics), contact forces / dof forces are
+// those of the last sim step -- so an env that terminates on a base contact is flagged again right after its reset and
+// resets twice, exactly as the reference's stale `contact_forces` make it do.
+__global__ __launch_bounds__(64) void anymal_flat_post_kernel(View v, AnymalFlatParams p) {
+    constexpr int ND = kAnymalDof;
+    const int e0 = blockIdx.x * 64 + threadIdx.x;
+    const int N = v.N;
+    const bool valid = e0 < N;
+    const int e = valid ? e0 : N - 1;
+    float root[13], q[ND], qd[ND], act[ND], torques[ND], cmd[3];
+    sfor<13>([&](auto K) MI_LAMBDA { root[K] = v.root[K * N + e]; });
+    sfor<ND>([&](auto K) MI_LAMBDA {
+        q[K] = v.dof[K * N + e]; qd[K] = v.dof[(ND + K) * N + e];
+        act[K] = v.actions[K * N + e]; torques[K] = v.dof_force[K * N + e];
+    });
+    sfor<3>([&](auto K) MI_LAMBDA { cmd[K] = v.commands[K * N + e]; });
+    long long progress = v.progress[e] + 1;
+    int ep = v.episode[e];
+    if (v.reset[e] != 0) {
+        anymal_flat_reset(p, v.seed, (uint32_t)(v.env_offset + e), (uint32_t)ep, root, q, qd, cmd);
+        ep += 1;
+        progress = 0;
+        if (valid) {
+            sfor<13>([&](auto K) MI_LAMBDA { v.root[K * N + e] = root[K]; });
+            sfor<ND>([&](auto K) MI_LAMBDA { v.dof[K * N + e] = q[K]; v.dof[(ND + K) * N + e] = qd[K]; v.laml[K * N + e] = 0.f; });
+            sfor<3>([&](auto K) MI_LAMBDA { v.commands[K * N + e] = cmd[K]; });
+            sfor<3 * ModelAnymal::NSPH>([&](auto K) MI_LAMBDA { v.lamc[K * N + e] = 0.f; });
+        }
+    }
+    float obs[kAnymalFlatObs];
+    anymal_flat_observations(p, root, cmd, q, qd, act, obs);
+    float base_c[3], knee_c[4][3];
+    sfor<3>([&](auto K) MI_LAMBDA { base_c[K] = v.netf[K * N + e]; });
+    sfor<4>([&](auto J) MI_LAMBDA { sfor<3>([&](auto K) MI_LAMBDA { knee_c[J][K] = v.netf[(3 * anymal_knee_body(J) + K) * N + e]; }); });
+    float rew;
+    long long reset;
+    anymal_flat_reward(p, root, cmd, torques, base_c, knee_c, progress, &rew, &reset);
+    episode_stats(v, e, valid, rew, reset, progress);
+    if (!valid) return;
+    v.randomize[e] += 1;
+    v.episode[e] = ep;
+    float* ob = v.obs + (size_t)e * kAnymalFlatObs;
+    float* oc = v.obs_out + ((size_t)v.ring * N + e) * kAnymalFlatObs;
+    sfor<kAnymalFlatObs>([&](auto K) MI_LAMBDA { ob[K] = obs[K]; oc[K] = fminf(fmaxf(obs[K], -v.clip_obs), v.clip_obs); });
+    v.rew[e] = rew;
+    v.reset[e] = reset;
+    v.progress[e] = progress;
+    v.timeout[e] = (unsigned char)((progress >= (long long)p.max_episode_length - 1) && (reset != 0));   // vec_task.py:394
+}
+
+// constructor state (anymal.py:141-146): initial_root_states := base_init_state, then reset_idx(arange(num_envs))
+__global__ void anymal_flat_init_kernel(View v, AnymalFlatParams p) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = v.N;
+    if (e >= N) return;
+    for (int k = 0; k < 13; ++k) v.init_root[k * N + e] = p.base_init_state[k];
+    for (int k = 0; k < 3 * ModelAnymal::NB; ++k) v.netf[k * N + e] = 0.f;
+    for (int k = 0; k < 3; ++k) v.commands[k * N + e] = 0.f;
+}
+__global__ void anymal_flat_reset_kernel(View v, AnymalFlatParams p, const long long* __restrict__ ids, int n) {
+    constexpr int ND = kAnymalDof;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = v.N;
+    if (i >= (ids ? n : N)) return;
+    const int e = ids ? (int)ids[i] : i;
+    if (e < 0 || e >= N) return;
+    float root[13], q[ND], qd[ND], cmd[3];
+    anymal_flat_reset(p, v.seed, (uint32_t)(v.env_offset + e), (uint32_t)v.episode[e], root, q, qd, cmd);
+    for (int k = 0; k < 13; ++k) v.root[k * N + e] = root[k];
+    for (int d = 0; d < ND; ++d) { v.dof[d * N + e] = q[d]; v.dof[(ND + d) * N + e] = qd[d]; v.laml[d * N + e] = 0.f; }
+    for (int k = 0; k < 3; ++k) v.commands[k * N + e] = cmd[k];
+    for (int k = 0; k < 3 * ModelAnymal::NSPH; ++k) v.lamc[k * N + e] = 0.f;
+    v.episode[e] += 1;
+    v.progress[e] = 0;
+    v.reset[e] = 1;   // anymal.py:301
+}
+static ActParams act_of(const AnymalFlatParams& tp) {
+    ActParams ap{};
+    ap.clip = tp.clip_actions; ap.scale = tp.action_scale; ap.nact = kAnymalDof; ap.mode = 1;
+    ap.kp = tp.kp; ap.kd = tp.kd; ap.torque_limit = tp.torque_limit;
+    for (int d = 0; d < kAnymalDof; ++d) ap.gear[d] = tp.default_dof_pos[d];
+    return ap;
+}
+// VecTask.step for Anymal: position targets = action_scale * a + default (anymal.py:226-229) held for the control step; the
+// PD drive (stiffness / damping set on the dofs, :203-206) is evaluated at every physics sub-step like PhysX does.
+hipError_t launch_step_anymal_flat(const View& v, const SimParams& P, const AnymalFlatParams& tp, const float* actions, int cfi,
+                                   hipStream_t s) {
+    hipError_t e = launch_substeps<ModelAnymal, PlaneGroundNF>(v, P, act_of(tp), actions, cfi * P.substeps, ACT_FROM_ACTIONS,
+                                                               ACT_FROM_STORED_ACTIONS, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(anymal_flat_post_kernel, dim3((v.N + 63) / 64), dim3(64), 0, s, v, tp);
+    return hipGetLastError();
+}
+// gym.simulate() alone: the drive keeps tracking the targets of the last step (stored actions)
+hipError_t launch_simulate_anymal_flat(const View& v, const SimParams& P, const AnymalFlatParams& tp, hipStream_t s) {
+    return launch_substeps<ModelAnymal, PlaneGroundNF>(v, P, act_of(tp), nullptr, P.substeps, ACT_FROM_STORED_ACTIONS,
+                                                       ACT_FROM_STORED_ACTIONS, s);
+}
+hipError_t launch_init_anymal_flat(const View& v, const AnymalFlatParams& tp, hipStream_t s) {
+    hipLaunchKernelGGL(anymal_flat_init_kernel, dim3((v.N + 127) / 128), dim3(128), 0, s, v, tp);
+    hipLaunchKernelGGL(anymal_flat_reset_kernel, dim3((v.N + 127) / 128), dim3(128), 0, s, v, tp, (const long long*)nullptr, v.N);
+    return hipGetLastError();
+}
+hipError_t launch_reset_anymal_flat(const View& v, const AnymalFlatParams& tp, const long long* ids, int n, hipStream_t s) {
+    hipLaunchKernelGGL(anymal_flat_reset_kernel, dim3((n + 127) / 128), dim3(128), 0, s, v, tp, ids, n);
+    return hipGetLastError();
+}
+
+// stand-alone replacements of the jitted functions (row-major contiguous tensors, reference argument meaning)
+__global__ void anymal_obs_kernel(int n, AnymalFlatParams p, const float* root_states, const float* commands, const float* dof_pos,
+                                  const float* dof_vel, const float* actions, float* obs) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float o[kAnymalFlatObs];
+    anymal_flat_observations(p, root_states + 13 * (size_t)e, commands + 3 * (size_t)e, dof_pos + kAnymalDof * (size_t)e,
+                             dof_vel + kAnymalDof * (size_t)e, actions + kAnymalDof * (size_t)e, o);
+    for (int k = 0; k < kAnymalFlatObs; ++k) obs[(size_t)e * kAnymalFlatObs + k] = o[k];
+}
+__global__ void anymal_reward_kernel(int n, AnymalFlatParams p, const float* root_states, const float* commands, const float* torques,
+                                     const float* contact_forces, int num_bodies, const long long* episode_lengths, float* rew,
+                                     long long* reset) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const float* cf = contact_forces + (size_t)e * num_bodies * 3;
+    float knee[4][3];
+    for (int k = 0; k < 4; ++k) for (int j = 0; j < 3; ++j) knee[k][j] = cf[3 * anymal_knee_body(k) + j];
+    anymal_flat_reward(p, root_states + 13 * (size_t)e, commands + 3 * (size_t)e, torques + kAnymalDof * (size_t)e, cf, knee,
+                       episode_lengths[e], rew + e, reset + e);
+}
+hipError_t launch_anymal_obs(int n, const AnymalFlatParams& p, const float* root_states, const float* commands, const float* dof_pos,
+                             const float* dof_vel, const float* actions, float* obs, hipStream_t s) {
+    hipLaunchKernelGGL(anymal_obs_kernel, dim3((n + 127) / 128), dim3(128), 0, s, n, p, root_states, commands, dof_pos, dof_vel, actions, obs);
+    return hipGetLastError();
+}
+hipError_t launch_anymal_reward(int n, const AnymalFlatParams& p, const float* root_states, const float* commands, const float* torques,
+                                const float* contact_forces, int num_bodies, const long long* episode_lengths, float* rew,
+                                long long* reset, hipStream_t s) {
+    hipLaunchKernelGGL(anymal_reward_kernel, dim3((n + 127) / 128), dim3(128), 0, s, n, p, root_states, commands, torques, contact_forces,
+                       num_bodies, episode_lengths, rew, reset);
+    return hipGetLastError();
+}
+
 }  // namespace mi

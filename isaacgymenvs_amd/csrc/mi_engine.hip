@@ -25,6 +25,7 @@ static_assert(sizeof(MiLocoParams) == sizeof(LocoParams), "MiLocoParams layout")
 static_assert(sizeof(MiCartpoleParams) == sizeof(CartpoleParams), "MiCartpoleParams layout");
 static_assert(MI_MAX_DOF == mi::kMaxDof, "MI_MAX_DOF");
 static_assert(sizeof(MiAnymalParams) == sizeof(AnymalParams), "MiAnymalParams layout");
+static_assert(sizeof(MiAnymalFlatParams) == sizeof(AnymalFlatParams), "MiAnymalFlatParams layout");
 static_assert(sizeof(MiHandRewardParams) == sizeof(HandRewardParams), "MiHandRewardParams layout");
 static_assert(sizeof(MiHandParams) == sizeof(HandParams), "MiHandParams layout");
 
@@ -183,6 +184,15 @@ hipError_t launch_init_anymal(const View& v, const AnymalParams& tp, const Anyma
 hipError_t launch_reset_anymal(const View& v, const AnymalParams& tp, const AnymalTerrainDesc& T, const long long* ids, int n, hipStream_t s);
 }
 namespace mi {  // defined in kernels_shadow_hand.hip
+hipError_t launch_step_anymal_flat(const View& v, const SimParams& P, const AnymalFlatParams& tp, const float* actions, int cfi, hipStream_t s);
+hipError_t launch_simulate_anymal_flat(const View& v, const SimParams& P, const AnymalFlatParams& tp, hipStream_t s);
+hipError_t launch_init_anymal_flat(const View& v, const AnymalFlatParams& tp, hipStream_t s);
+hipError_t launch_reset_anymal_flat(const View& v, const AnymalFlatParams& tp, const long long* ids, int n, hipStream_t s);
+hipError_t launch_anymal_obs(int n, const AnymalFlatParams& p, const float* root_states, const float* commands, const float* dof_pos,
+                             const float* dof_vel, const float* actions, float* obs, hipStream_t s);
+hipError_t launch_anymal_reward(int n, const AnymalFlatParams& p, const float* root_states, const float* commands, const float* torques,
+                                const float* contact_forces, int num_bodies, const long long* episode_lengths, float* rew,
+                                long long* reset, hipStream_t s);
 struct HandView {
     float* cur_targets; float* prev_targets; float* object_state; float* goal_state; float* fingertip; float* successes;
     long long* reset_goal; int* goal_count; float* cons; float* ws; int* ncontact;
@@ -192,8 +202,8 @@ hipError_t launch_simulate_shadow_hand(const View& v, const HandView& hv, const 
 hipError_t launch_init_shadow_hand(const View& v, const HandView& hv, const HandParams& p, hipStream_t s);
 hipError_t launch_reset_shadow_hand(const View& v, const HandView& hv, const HandParams& p, const long long* ids, int n, hipStream_t s);
 }
-enum TaskId { T_CARTPOLE = 0, T_ANT = 1, T_HUMANOID = 2, T_ANYMAL = 3, T_SHADOWHAND = 4 };
-constexpr int kNumTasks = 5;
+enum TaskId { T_CARTPOLE = 0, T_ANT = 1, T_HUMANOID = 2, T_ANYMAL = 3, T_SHADOWHAND = 4, T_ANYMAL_FLAT = 5 };
+constexpr int kNumTasks = 6;
 struct TaskMeta { const char* name; int nobs, nact, nd, nb, nsens, nsph, fixed; size_t pbytes; };
 static const TaskMeta kTasks[] = {
     {"Cartpole", 4, 1, ModelCartpole::ND, ModelCartpole::NB, 0, ModelCartpole::NSPH, 1, sizeof(MiCartpoleParams)},
@@ -201,6 +211,7 @@ static const TaskMeta kTasks[] = {
     {"Humanoid", Loco<ModelHumanoid::ND, 6 * ModelHumanoid::NSENS, true>::NOBS, ModelHumanoid::ND, ModelHumanoid::ND, ModelHumanoid::NB, ModelHumanoid::NSENS, ModelHumanoid::NSPH, 0, sizeof(MiLocoParams)},
     {"AnymalTerrain", kAnymalObs, kAnymalDof, ModelAnymal::ND, ModelAnymal::NB, 0, ModelAnymal::NSPH, 0, sizeof(MiAnymalParams)},
     {"ShadowHand", 211, 20, ModelShadowHand::ND, ModelShadowHand::NB, ModelShadowHand::NSENS, 0, 1, sizeof(MiHandParams)},
+    {"Anymal", kAnymalFlatObs, kAnymalDof, ModelAnymal::ND, ModelAnymal::NB, 0, ModelAnymal::NSPH, 0, sizeof(MiAnymalFlatParams)},
 };
 static int find_task(const char* t) {
     for (int i = 0; i < kNumTasks; ++i) if (!strcmp(t, kTasks[i].name)) return i;
@@ -213,6 +224,7 @@ struct MiEngine {
     LocoParams loco;
     CartpoleParams cart;
     AnymalParams anymal;
+    AnymalFlatParams anymal_flat;
     AnymalTerrainDesc terrain;
     HandParams hand;
     HandView hv;
@@ -286,6 +298,11 @@ static void build_layout(int task, int N, Layout& L, View* v, char* base) {
         o = L.add("episode_step_stats", MI_F32, {16}, {1}, 16); if (v) v->ep_stats = (float*)P(o);
         o = L.add("episode_means", MI_F32, {16}, {1}, 16); if (v) v->ep_means = (float*)P(o);
     }
+    if (task == T_ANYMAL_FLAT) {   // anymal.py:100-125
+        const int64_t nb = m.nb;
+        o = L.add("net_contact_force", MI_F32, {n, nb, 3}, {1, 3 * n, n}, 3 * nb * n); if (v) v->netf = (float*)P(o);
+        o = L.add("commands", MI_F32, {n, 3}, {1, n}, 3 * n); if (v) v->commands = (float*)P(o);
+    }
     L.off = (L.off + 255) & ~size_t(255);
 }
 // ShadowHand extras (shadow_hand.py:150-222): object / goal root states, targets, fingertip body states, success counters
@@ -343,6 +360,7 @@ extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const 
     e->max_init_level = 0;
     if (t == T_CARTPOLE) memcpy(&e->cart, task_params, sizeof(CartpoleParams));
     else if (t == T_ANYMAL) memcpy(&e->anymal, task_params, sizeof(AnymalParams));
+    else if (t == T_ANYMAL_FLAT) memcpy(&e->anymal_flat, task_params, sizeof(AnymalFlatParams));
     else if (t == T_SHADOWHAND) memcpy(&e->hand, task_params, sizeof(HandParams));
     else memcpy(&e->loco, task_params, sizeof(LocoParams));
     Layout L;
@@ -385,6 +403,15 @@ extern "C" int mi_engine_init_state(MiEngine* e, void* stream) {
     float root_z = 0.f, pot0 = 0.f;
     if (e->task == T_SHADOWHAND) {
         HIP_OK(launch_init_shadow_hand(e->v, e->hv, e->hand, s));
+        e->steps = 0;
+        return 0;
+    }
+    if (e->task == T_ANYMAL_FLAT) {
+        const int blocks = (e->N + 255) / 256;
+        hipLaunchKernelGGL(init_state_kernel, dim3(blocks), dim3(256), 0, s, e->v, m.nd, 3 * m.nsph, 0, m.nobs, m.nact,
+                           e->anymal_flat.base_init_state[2], (const float*)nullptr, 0.f);
+        HIP_OK(hipGetLastError());
+        HIP_OK(launch_init_anymal_flat(e->v, e->anymal_flat, s));
         e->steps = 0;
         return 0;
     }
@@ -438,6 +465,7 @@ extern "C" int mi_engine_step(MiEngine* e, const float* actions, void* stream) {
             // common_step_counter is incremented before the push test (anymal_terrain.py:460-462)
             HIP_OK(launch_step_anymal(e->v, e->P, e->anymal, e->terrain, actions, e->control_freq_inv, (unsigned)(e->steps + 1), s));
             break;
+        case T_ANYMAL_FLAT: HIP_OK(launch_step_anymal_flat(e->v, e->P, e->anymal_flat, actions, e->control_freq_inv, s)); break;
     }
     e->steps++;
     return 0;
@@ -456,6 +484,7 @@ extern "C" int mi_engine_simulate(MiEngine* e, void* stream) {
             if (e->terrain.hs == nullptr) return fail("mi_engine_simulate: AnymalTerrain needs mi_engine_set_terrain first");
             HIP_OK(launch_simulate_anymal(e->v, e->P, e->terrain, s));
             break;
+        case T_ANYMAL_FLAT: HIP_OK(launch_simulate_anymal_flat(e->v, e->P, e->anymal_flat, s)); break;
     }
     return 0;
 }
@@ -471,6 +500,7 @@ extern "C" int mi_engine_reset_idx(MiEngine* e, const int64_t* env_ids, int n, v
         case T_HUMANOID: HIP_OK(launch_reset_humanoid(e->v, e->loco, (const long long*)env_ids, n, s)); break;
         case T_ANYMAL: HIP_OK(launch_reset_anymal(e->v, e->anymal, e->terrain, (const long long*)env_ids, n, s)); break;
         case T_SHADOWHAND: HIP_OK(launch_reset_shadow_hand(e->v, e->hv, e->hand, (const long long*)env_ids, n, s)); break;
+        case T_ANYMAL_FLAT: HIP_OK(launch_reset_anymal_flat(e->v, e->anymal_flat, (const long long*)env_ids, n, s)); break;
     }
     return 0;
 }
@@ -546,6 +576,30 @@ extern "C" int mi_compute_cartpole_reward(int n, const MiCartpoleParams* p, cons
     hipLaunchKernelGGL(cartpole_reward_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, n, cp, pole_angle, pole_vel,
                        cart_vel, cart_pos, (const long long*)reset_in, (const long long*)progress, rew, (long long*)reset_out);
     HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mi_compute_anymal_observations(int n, const MiAnymalFlatParams* p, const float* root_states, const float* commands,
+                                              const float* dof_pos, const float* dof_vel, const float* actions, float* obs_buf,
+                                              void* stream) {
+    if (n <= 0) return 0;
+    if (!p || !root_states || !commands || !dof_pos || !dof_vel || !actions || !obs_buf) return fail("mi_compute_anymal_observations: null argument");
+    AnymalFlatParams ap;
+    memcpy(&ap, p, sizeof(ap));
+    HIP_OK(launch_anymal_obs(n, ap, root_states, commands, dof_pos, dof_vel, actions, obs_buf, (hipStream_t)stream));
+    return 0;
+}
+extern "C" int mi_compute_anymal_reward(int n, const MiAnymalFlatParams* p, const float* root_states, const float* commands,
+                                        const float* torques, const float* contact_forces, int num_bodies,
+                                        const int64_t* episode_lengths, float* rew_buf, int64_t* reset_buf, void* stream) {
+    if (n <= 0) return 0;
+    if (!p || !root_states || !commands || !torques || !contact_forces || !episode_lengths || !rew_buf || !reset_buf)
+        return fail("mi_compute_anymal_reward: null argument");
+    if (num_bodies < ModelAnymal::NB) return fail("mi_compute_anymal_reward: contact_forces must cover the 13 ANYmal bodies");
+    AnymalFlatParams ap;
+    memcpy(&ap, p, sizeof(ap));
+    HIP_OK(launch_anymal_reward(n, ap, root_states, commands, torques, contact_forces, num_bodies, (const long long*)episode_lengths,
+                                rew_buf, (long long*)reset_buf, (hipStream_t)stream));
     return 0;
 }
 

@@ -107,4 +107,82 @@ MI_HD float anymal_height_at(const AnymalTerrainDesc& T, const float* yaw_quat, 
     return (float)(h1 < h2 ? h1 : h2) * T.vscale;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Anymal on flat ground (reference isaacgymenvs/tasks/anymal.py): PD position drives, 48 observations, 3 reward terms.
+//   pre_physics_step :226-229      compute_anymal_reward       :311-351 (@torch.jit.script)
+//   reset_idx        :274-301      compute_anymal_observations :354-386 (@torch.jit.script)
+constexpr int kAnymalFlatObs = 48;    // 3+3+3+3+12+12+12 (anymal.py:376-384)
+
+struct AnymalFlatParams {  // mirrors MiAnymalFlatParams in include/mi_engine.h (same layout)
+    float lin_vel_scale, ang_vel_scale, dof_pos_scale, dof_vel_scale, action_scale;   // :47-51
+    float rew_lin_vel_xy, rew_ang_vel_z, rew_torque;       // learn.*RewardScale, already multiplied by dt (:96-97)
+    float command_x[2], command_y[2], command_yaw[2];      // randomCommandVelocityRanges (:64-66)
+    float base_init_state[13];                              // :74-80
+    float default_dof_pos[kAnymalDof];                      // :133-136
+    float kp, kd, torque_limit;                             // control.stiffness / damping (:203-206); URDF effort limit
+    int max_episode_length;                                 // :92
+    float clip_actions;
+};
+
+// compute_anymal_observations (anymal.py:354-386); gravity_vec = (0, 0, -1) (:143).  Note the reference projects gravity
+// with quat_rotate, not quat_rotate_inverse (:372) -- kept.
+MI_HD void anymal_flat_observations(const AnymalFlatParams& p, const float* root, const float* cmd, const float* q, const float* qd,
+                                    const float* act, float* obs) {
+    MI_NO_CONTRACT
+    float blv[3], bav[3], pg[3];
+    const float gvec[3] = {0.f, 0.f, -1.f};
+    quat_rotate_s(root + 3, root + 7, -1.f, blv);
+    quat_rotate_s(root + 3, root + 10, -1.f, bav);
+    quat_rotate_s(root + 3, gvec, 1.f, pg);
+    for (int i = 0; i < 3; ++i) {
+        obs[i] = blv[i] * p.lin_vel_scale;
+        obs[3 + i] = bav[i] * p.ang_vel_scale;
+        obs[6 + i] = pg[i];
+    }
+    obs[9] = cmd[0] * p.lin_vel_scale; obs[10] = cmd[1] * p.lin_vel_scale; obs[11] = cmd[2] * p.ang_vel_scale;
+    for (int d = 0; d < kAnymalDof; ++d) {
+        obs[12 + d] = (q[d] - p.default_dof_pos[d]) * p.dof_pos_scale;
+        obs[24 + d] = qd[d] * p.dof_vel_scale;
+        obs[36 + d] = act[d];
+    }
+}
+
+// compute_anymal_reward (anymal.py:311-351).  contact = net contact force of base / knee bodies, [3] each.
+MI_HD void anymal_flat_reward(const AnymalFlatParams& p, const float* root, const float* cmd, const float* torques,
+                              const float* base_contact, const float (*knee_contact)[3], long long episode_length, float* rew,
+                              long long* reset) {
+    MI_NO_CONTRACT
+    float blv[3], bav[3];
+    quat_rotate_s(root + 3, root + 7, -1.f, blv);
+    quat_rotate_s(root + 3, root + 10, -1.f, bav);
+    const float ex = cmd[0] - blv[0], ey = cmd[1] - blv[1], ez = cmd[2] - bav[2];
+    const float lin_vel_error = ex * ex + ey * ey;
+    const float ang_vel_error = ez * ez;
+    const float rew_lin = expf(-lin_vel_error / 0.25f) * p.rew_lin_vel_xy;
+    const float rew_ang = expf(-ang_vel_error / 0.25f) * p.rew_ang_vel_z;
+    float tsq = 0.f;
+    for (int d = 0; d < kAnymalDof; ++d) tsq += torques[d] * torques[d];
+    const float total = (rew_lin + rew_ang) + tsq * p.rew_torque;
+    *rew = fmaxf(total, 0.f);
+    auto norm3 = [](const float* f) MI_LAMBDA { return sqrtf((f[0] * f[0] + f[1] * f[1]) + f[2] * f[2]); };
+    bool rs = norm3(base_contact) > 1.f;
+    for (int k = 0; k < 4; ++k) rs = rs || (norm3(knee_contact[k]) > 1.f);
+    rs = rs || (episode_length >= (long long)p.max_episode_length - 1);   // no terminal reward for time-outs
+    *reset = rs ? 1 : 0;
+}
+
+// reset_idx (anymal.py:274-301) with the engine's counter-based draws (one stream per (env, episode))
+MI_HD void anymal_flat_reset(const AnymalFlatParams& p, uint32_t seed, uint32_t genv, uint32_t ep, float* root, float* q, float* qd,
+                             float* cmd) {
+    MI_NO_CONTRACT
+    for (int d = 0; d < kAnymalDof; ++d) {
+        q[d] = p.default_dof_pos[d] * ((1.5f - 0.5f) * uniform01(seed, genv, ep, (uint32_t)d) + 0.5f);
+        qd[d] = (0.1f - (-0.1f)) * uniform01(seed, genv, ep, (uint32_t)(kAnymalDof + d)) + (-0.1f);
+    }
+    for (int k = 0; k < 13; ++k) root[k] = p.base_init_state[k];
+    cmd[0] = (p.command_x[1] - p.command_x[0]) * uniform01(seed, genv, ep, 2 * kAnymalDof + 0) + p.command_x[0];
+    cmd[1] = (p.command_y[1] - p.command_y[0]) * uniform01(seed, genv, ep, 2 * kAnymalDof + 1) + p.command_y[0];
+    cmd[2] = (p.command_yaw[1] - p.command_yaw[0]) * uniform01(seed, genv, ep, 2 * kAnymalDof + 2) + p.command_yaw[0];
+}
+
 }  // namespace mi

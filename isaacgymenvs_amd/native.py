@@ -68,6 +68,16 @@ class MiAnymalParams(C.Structure):
         ("curriculum", C.c_int32), ("clip_actions", C.c_float), ("friction_range", C.c_float * 2), ("terrain_mu", C.c_float)]
 
 
+class MiAnymalFlatParams(C.Structure):
+    _fields_ = [(n, C.c_float) for n in (
+        "lin_vel_scale", "ang_vel_scale", "dof_pos_scale", "dof_vel_scale", "action_scale",
+        "rew_lin_vel_xy", "rew_ang_vel_z", "rew_torque")] + [
+        ("command_x", C.c_float * 2), ("command_y", C.c_float * 2), ("command_yaw", C.c_float * 2),
+        ("base_init_state", C.c_float * 13), ("default_dof_pos", C.c_float * 12),
+        ("kp", C.c_float), ("kd", C.c_float), ("torque_limit", C.c_float), ("max_episode_length", C.c_int32),
+        ("clip_actions", C.c_float)]
+
+
 class MiHandRewardParams(C.Structure):
     _fields_ = [("max_episode_length", C.c_float), ("dist_reward_scale", C.c_float), ("rot_reward_scale", C.c_float),
                 ("rot_eps", C.c_float), ("action_penalty_scale", C.c_float), ("success_tolerance", C.c_float),
@@ -101,6 +111,7 @@ EXPORTS = ["mi_abi_version", "mi_task_info", "mi_engine_arena_bytes", "mi_engine
            "mi_engine_reset_idx", "mi_engine_simulate", "mi_engine_set_option", "mi_engine_last_ring", "mi_engine_set_terrain",
            "mi_compute_locomotion_observations", "mi_compute_locomotion_reward", "mi_compute_cartpole_reward",
            "mi_compute_hand_reward", "mi_compute_hand_full_state", "mi_randomize_rotation",
+           "mi_compute_anymal_observations", "mi_compute_anymal_reward",
            "mi_last_error"]
 
 
@@ -237,6 +248,8 @@ def lib():
     L.mi_compute_locomotion_observations.argtypes = [C.c_char_p, C.c_int, C.POINTER(MiLocoParams)] + [C.c_void_p] * 18
     L.mi_compute_locomotion_reward.argtypes = [C.c_char_p, C.c_int, C.POINTER(MiLocoParams)] + [C.c_void_p] * 9
     L.mi_compute_cartpole_reward.argtypes = [C.c_int, C.POINTER(MiCartpoleParams)] + [C.c_void_p] * 9
+    L.mi_compute_anymal_observations.argtypes = [C.c_int, C.POINTER(MiAnymalFlatParams)] + [C.c_void_p] * 7
+    L.mi_compute_anymal_reward.argtypes = [C.c_int, C.POINTER(MiAnymalFlatParams)] + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4
     L.mi_compute_hand_reward.argtypes = [C.c_int, C.POINTER(MiHandRewardParams)] + [C.c_void_p] * 11 + [C.c_int, C.c_void_p, C.c_void_p]
     L.mi_compute_hand_full_state.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float] + [C.c_void_p] * 11 + [C.c_int, C.c_void_p]
     L.mi_randomize_rotation.argtypes = [C.c_int] + [C.c_void_p] * 6

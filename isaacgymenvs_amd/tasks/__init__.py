@@ -1,5 +1,6 @@
 """Task name -> class map (reference isaacgymenvs/tasks/__init__.py:88-114; the tasks built so far)."""
 from .ant import Ant
+from .anymal import Anymal
 from .anymal_terrain import AnymalTerrain
 from .cartpole import Cartpole
 from .humanoid import Humanoid
@@ -7,6 +8,7 @@ from .shadow_hand import ShadowHand
 
 isaacgym_task_map = {
     "Ant": Ant,
+    "Anymal": Anymal,
     "AnymalTerrain": AnymalTerrain,
     "Cartpole": Cartpole,
     "Humanoid": Humanoid,

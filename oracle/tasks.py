@@ -587,6 +587,113 @@ class OracleAnymalTerrainEnv:
 
 
 # ------------------------------------------------------------------ tasks/shadow_hand.py
+# ===================================================================================================== Anymal (flat ground)
+def compute_anymal_observations(root_states, commands, dof_pos, default_dof_pos, dof_vel, gravity_vec, actions, lin_vel_scale,
+                                ang_vel_scale, dof_pos_scale, dof_vel_scale):  # anymal.py:354-386
+    root_states = root_states.astype(f32)
+    base_quat = root_states[:, 3:7]
+    base_lin_vel = quat_rotate(base_quat, root_states[:, 7:10], inverse=True) * f32(lin_vel_scale)
+    base_ang_vel = quat_rotate(base_quat, root_states[:, 10:13], inverse=True) * f32(ang_vel_scale)
+    projected_gravity = quat_rotate(base_quat, gravity_vec.astype(f32))          # quat_rotate, as in the reference (:372)
+    dof_pos_scaled = (dof_pos.astype(f32) - default_dof_pos.astype(f32)) * f32(dof_pos_scale)
+    commands_scaled = commands.astype(f32) * np.array([lin_vel_scale, lin_vel_scale, ang_vel_scale], f32)
+    return np.concatenate([base_lin_vel, base_ang_vel, projected_gravity, commands_scaled, dof_pos_scaled,
+                           dof_vel.astype(f32) * f32(dof_vel_scale), actions.astype(f32)], axis=-1).astype(f32)
+
+
+def compute_anymal_reward(root_states, commands, torques, contact_forces, knee_indices, episode_lengths, rew_scales, base_index,
+                          max_episode_length):  # anymal.py:311-351
+    root_states, commands, torques, cf = root_states.astype(f32), commands.astype(f32), torques.astype(f32), contact_forces.astype(f32)
+    base_quat = root_states[:, 3:7]
+    base_lin_vel = quat_rotate(base_quat, root_states[:, 7:10], inverse=True)
+    base_ang_vel = quat_rotate(base_quat, root_states[:, 10:13], inverse=True)
+    d = commands[:, :2] - base_lin_vel[:, :2]
+    lin_vel_error = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(f32)
+    ang_vel_error = np.square(commands[:, 2] - base_ang_vel[:, 2]).astype(f32)
+    rew_lin_vel_xy = np.exp(-lin_vel_error / f32(0.25)).astype(f32) * f32(rew_scales["lin_vel_xy"])
+    rew_ang_vel_z = np.exp(-ang_vel_error / f32(0.25)).astype(f32) * f32(rew_scales["ang_vel_z"])
+    rew_torque = np.sum(np.square(torques), axis=1, dtype=f32) * f32(rew_scales["torque"])
+    total_reward = np.clip(rew_lin_vel_xy + rew_ang_vel_z + rew_torque, f32(0.), None).astype(f32)
+
+    def norm(x):
+        return np.sqrt((x[..., 0] * x[..., 0] + x[..., 1] * x[..., 1]) + x[..., 2] * x[..., 2]).astype(f32)
+    reset = norm(cf[:, base_index, :]) > f32(1.)
+    reset = reset | np.any(norm(cf[:, knee_indices, :]) > f32(1.), axis=1)
+    time_out = episode_lengths >= max_episode_length - 1
+    reset = reset | time_out
+    return total_reward, reset.astype(np.int64)
+
+
+class OracleAnymalEnv:
+    """vec_task.py:360-408 + anymal.py pre/post_physics_step on oracle/physics.c (plane ground, net contact forces).  The
+    DOF_MODE_POS drive is evaluated explicitly at every physics sub-step (what the HIP engine does)."""
+
+    def __init__(self, spec, sim_params: dict, params, num_envs, seed=0, env_id_offset=0, precision="f64", control_freq_inv=1):
+        from .engine import OracleEngine
+        self.N, self.p, self.nd, self.spec = num_envs, params, spec.nd, spec
+        self.substeps = int(sim_params.get("substeps", 2))
+        sp = dict(sim_params, dt=sim_params["dt"] / self.substeps, substeps=1)
+        self.eng = OracleEngine(spec, num_envs, params=sp, precision=precision)
+        self.eng.want_netf = True
+        self.seed, self.off, self.cfi = fold_seed(seed), env_id_offset, control_freq_inv
+        p, N = params, num_envs
+        self.genv = (self.off + np.arange(N)).astype(np.uint32)
+        self.default_dof_pos = np.tile(np.array(p.default_dof_pos[:], f32), (N, 1))
+        self.base_init_state = np.array(p.base_init_state[:], f32)
+        self.commands = np.zeros((N, 3), f32)
+        self.actions = np.zeros((N, self.nd), f32)
+        self.torques = np.zeros((N, self.nd), f32)
+        self.contact_forces = np.zeros((N, spec.nb, 3), f32)
+        self.progress_buf = np.zeros(N, np.int64)
+        self.reset_buf = np.ones(N, np.int64)
+        self.episode = np.zeros(N, np.uint32)
+        self.knee_indices = np.array([i for i, n in enumerate(spec.body_names) if "THIGH" in n])
+        self.rew_scales = {"lin_vel_xy": p.rew_lin_vel_xy, "ang_vel_z": p.rew_ang_vel_z, "torque": p.rew_torque}
+        self.reset_idx(np.arange(N))   # anymal.py:146
+
+    def reset_idx(self, ids):  # anymal.py:274-301
+        if len(ids) == 0:
+            return
+        p, nd = self.p, self.nd
+        genv, ep = self.genv[ids][:, None], self.episode[ids][:, None]
+        k = np.arange(nd, dtype=np.uint32)[None, :]
+        off = (f32(1.5) - f32(0.5)) * mi_uniform(self.seed, genv, ep, k) + f32(0.5)
+        vel = (f32(0.1) - f32(-0.1)) * mi_uniform(self.seed, genv, ep, k + np.uint32(nd)) + f32(-0.1)
+        self.eng.q[ids] = self.default_dof_pos[ids] * off
+        self.eng.qd[ids] = vel
+        self.eng.root[ids] = self.base_init_state
+        self.eng.lam[ids] = 0
+        g1, e1 = genv[:, 0], ep[:, 0]
+        for j, rng in enumerate((p.command_x, p.command_y, p.command_yaw)):
+            self.commands[ids, j] = (f32(rng[1]) - f32(rng[0])) * mi_uniform(self.seed, g1, e1, 2 * nd + j) + f32(rng[0])
+        self.episode[ids] += 1
+        self.progress_buf[ids] = 0
+        self.reset_buf[ids] = 1
+
+    def step(self, actions):
+        p = self.p
+        a = np.clip(actions.astype(f32), -f32(p.clip_actions), f32(p.clip_actions))     # vec_task.py:374
+        self.actions = a.copy()
+        target = f32(p.action_scale) * a + self.default_dof_pos                           # anymal.py:226-229
+        for _ in range(self.cfi * self.substeps):
+            q, qd = self.eng.q.astype(f32), self.eng.qd.astype(f32)
+            tq = np.clip(f32(p.kp) * (target - q) - f32(p.kd) * qd, f32(-p.torque_limit), f32(p.torque_limit)).astype(f32)
+            self.eng.step(tq)
+        self.torques = self.eng.dof_force.astype(f32)
+        self.contact_forces = self.eng.netf.astype(f32)
+        # post_physics_step (anymal.py:231-241)
+        self.progress_buf += 1
+        self.reset_idx(np.nonzero(self.reset_buf)[0])
+        root, q, qd = self.eng.root.astype(f32), self.eng.q.astype(f32), self.eng.qd.astype(f32)
+        gv = np.tile(np.array([0, 0, -1], f32), (self.N, 1))
+        self.obs_buf = compute_anymal_observations(root, self.commands, q, self.default_dof_pos, qd, gv, self.actions, p.lin_vel_scale,
+                                                   p.ang_vel_scale, p.dof_pos_scale, p.dof_vel_scale)
+        self.rew_buf, self.reset_buf = compute_anymal_reward(root, self.commands, self.torques, self.contact_forces, self.knee_indices,
+                                                             self.progress_buf, self.rew_scales, 0, p.max_episode_length)
+        self.timeout_buf = (self.progress_buf >= p.max_episode_length - 1) & (self.reset_buf != 0)   # vec_task.py:394
+        return self.obs_buf, self.rew_buf, self.reset_buf
+
+
 def quat_conjugate(a):  # torch_jit_utils.py:107-110
     return np.concatenate([-a[:, :3], a[:, 3:4]], axis=-1).astype(f32)
 

@@ -388,6 +388,97 @@ def test_anymal_terrain_full_size_properties():
     assert float(extras["episode"]["terrain_level"]) >= 0.0
 
 
+# ------------------------------------------------------------------ Anymal (flat ground, PD position drives; reference tasks/anymal.py)
+def _anymal_flat_params():
+    from isaacgymenvs_amd.tasks.anymal import anymal_flat_params_from_cfg
+    cfg = compose(overrides=["task=Anymal"])["task"]
+    return anymal_flat_params_from_cfg(cfg, list(load_model("anymal").dof_names))
+
+
+def test_anymal_flat_obs_and_reward_kernels_match_reference(golden_dir):
+    g = dict(np.load(os.path.join(golden_dir, "anymal_flat.npz")))
+    p = _anymal_flat_params()
+    # the golden vectors were generated with the YAML's scales and dof order
+    assert abs(p.lin_vel_scale - float(g["scalar_lin_vel_scale"])) < 1e-7 and p.max_episode_length == int(g["scalar_max_episode_length"])
+    np.testing.assert_allclose(np.array(p.default_dof_pos[:]), g["default_dof_pos"][0], atol=1e-7)
+    assert abs(p.rew_torque - float(g["scalar_rew_torque"])) < 1e-12
+    n = g["obs"].shape[0]
+    keep = [_t(g[k]) for k in ("root_states", "commands", "dof_pos", "dof_vel", "actions", "torques", "contact_forces")]
+    el = _t(g["episode_lengths"], torch.int64)
+    obs = torch.empty((n, 48), device=DEV)
+    rew = torch.empty(n, device=DEV)
+    reset = torch.empty(n, device=DEV, dtype=torch.int64)
+    L = native.lib()
+    native.check(L.mi_compute_anymal_observations(n, C.byref(p), keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(),
+                                                  keep[3].data_ptr(), keep[4].data_ptr(), obs.data_ptr(), _stream()))
+    native.check(L.mi_compute_anymal_reward(n, C.byref(p), keep[0].data_ptr(), keep[1].data_ptr(), keep[5].data_ptr(), keep[6].data_ptr(),
+                                            13, el.data_ptr(), rew.data_ptr(), reset.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(obs.cpu().numpy(), g["obs"], rtol=1e-5, atol=2e-5)
+    np.testing.assert_array_equal(reset.cpu().numpy().astype(bool), g["reset"].astype(bool))
+    np.testing.assert_allclose(rew.cpu().numpy(), g["rew"], rtol=2e-5, atol=1e-7)
+
+
+def test_anymal_flat_step_matches_cpu_restatement():
+    from oracle.tasks import OracleAnymalEnv
+    n, seed = 128, 17
+    env = _make_env("Anymal", n, seed=seed)
+    orc = OracleAnymalEnv(load_model("anymal"), _sim_dict(env.sim_params), env._task_params_struct, n, seed=seed, precision="f64")
+    np.testing.assert_allclose(env.root_states.cpu().numpy(), orc.eng.root, atol=1e-6)
+    np.testing.assert_allclose(env.dof_pos.cpu().numpy(), orc.eng.q, atol=1e-6)
+    np.testing.assert_allclose(env.commands.cpu().numpy(), orc.commands, atol=1e-6)
+    g = torch.Generator(device="cpu").manual_seed(9)
+    for step in range(12):
+        a = torch.rand((n, 12), generator=g) * 2 - 1
+        obs_d, rew, reset, extras = env.step(a.to(DEV))
+        o_obs, o_rew, o_reset = orc.step(a.numpy())
+        torch.cuda.synchronize()
+        obs = env.obs_buf.cpu().numpy()
+        assert np.isfinite(obs).all()
+        d = np.abs(obs - o_obs).max(axis=1)
+        tol = 2e-3 * (1 + step)                       # fp32 engine vs fp64 oracle; contact makes the gap grow with time
+        ok = d < tol
+        assert ok.mean() > 0.95, (step, ok.mean(), d.max())
+        same = reset.cpu().numpy().astype(bool) == o_reset.astype(bool)
+        assert same.mean() > 0.97, (step, same.mean())
+        if step < 5:
+            np.testing.assert_allclose(rew.cpu().numpy()[ok & same], o_rew[ok & same], atol=2e-3)
+            tq, otq = env.torques.cpu().numpy()[ok], orc.torques[ok]
+            excess = np.abs(tq - otq) - (0.5 + 0.05 * np.abs(otq))
+            assert (excess < 0).mean() > 0.99, (step, excess.max(), tq[excess.argmax() // 12], otq[excess.argmax() // 12])
+        np.testing.assert_array_equal(env.progress_buf.cpu().numpy()[same], orc.progress_buf[same])
+    assert obs_d["obs"].shape == (n, 48) and extras["time_outs"].dtype == torch.bool
+    assert float(obs_d["obs"].abs().max()) <= 5.0 + 1e-6          # clipObservations 5.0 (Anymal.yaml)
+
+
+def test_anymal_flat_full_size_properties():
+    n = 4096
+    env = _make_env("Anymal", n, seed=42)
+    g = torch.Generator(device=DEV).manual_seed(42)
+    resets = 0
+    z0 = env.root_states[:, 2].clone()
+    assert float((z0 - 0.62).abs().max()) < 1e-6                    # baseInitState (Anymal.yaml)
+    for step in range(300):
+        a = torch.rand((n, 12), device=DEV, generator=g) * 2 - 1
+        # small actions for 200 steps (robots keep standing), then full-amplitude random targets (some fall => base/knee contact)
+        obs_d, rew, reset, extras = env.step(a * (0.2 if step < 200 else 1.0))
+        resets += int(reset.sum())
+        if step == 199:
+            assert resets == 0, resets
+        if step % 60 == 59 and step < 200:
+            assert torch.isfinite(obs_d["obs"]).all() and torch.isfinite(rew).all()
+            assert (rew >= 0).all()                                   # torch.clip(total_reward, 0., None) (anymal.py:342)
+            qn = torch.linalg.norm(env.root_states[:, 3:7], dim=-1)
+            assert (qn - 1).abs().max() < 1e-4
+            z = env.root_states[:, 2]
+            assert z.min() > 0.05 and z.max() < 1.0, (z.min(), z.max())  # robots stay on / above the ground plane
+            assert env.contact_forces.abs().max() < 2e4
+            # with small actions most robots stand: the feet carry the weight (ANYmal-C ~ 50 kg => ~ 490 N)
+            fz = env.contact_forces[:, :, 2].sum(1)
+            assert 200.0 < float(fz.median()) < 900.0, float(fz.median())
+    assert resets > 0
+
+
 # ------------------------------------------------------------------ ShadowHand (hand + cube physics, deferred resets, full_state obs)
 def test_shadow_hand_step_matches_cpu_restatement():
     from isaacgymenvs_amd.registry import load_extras
@@ -442,7 +533,7 @@ def test_shadow_hand_full_size_properties():
 
 
 # ------------------------------------------------------------------ determinism (guards against miscompiled / hazard-prone builds)
-@pytest.mark.parametrize("task,n", [("Cartpole", 256), ("Ant", 1024), ("Humanoid", 1024), ("AnymalTerrain", 1024), ("ShadowHand", 512)])
+@pytest.mark.parametrize("task,n", [("Cartpole", 256), ("Ant", 1024), ("Humanoid", 1024), ("AnymalTerrain", 1024), ("ShadowHand", 512), ("Anymal", 1024)])
 def test_two_engines_same_seed_are_bit_identical(task, n):
     """Two independent engine instances, same seed and actions => bit-identical trajectories.  An earlier build of
     the sub-step (register-spilling regime) returned run-to-run different results on gfx950."""

@@ -170,3 +170,22 @@ def test_hand_full_state_and_random_rotation_match_reference(golden_dir):
     np.testing.assert_allclose(obs, g["full_state"], atol=1e-6)
     q = T.randomize_rotation(g["rand0"], g["rand1"], g["x_unit"], g["y_unit"])
     np.testing.assert_allclose(q, g["rand_rot"], atol=2e-7)
+
+
+# ------------------------------------------------------------------ Anymal (flat): the reference's jitted functions (anymal.py:311-386)
+def test_anymal_flat_observations_and_reward_match_reference(golden_dir):
+    g = _load(golden_dir, "anymal_flat.npz")
+    obs = T.compute_anymal_observations(g["root_states"], g["commands"], g["dof_pos"], g["default_dof_pos"], g["dof_vel"], g["gravity_vec"],
+                                        g["actions"], float(g["scalar_lin_vel_scale"]), float(g["scalar_ang_vel_scale"]),
+                                        float(g["scalar_dof_pos_scale"]), float(g["scalar_dof_vel_scale"]))
+    assert obs.shape == (512, 48) and obs.dtype == np.float32
+    np.testing.assert_allclose(obs, g["obs"], rtol=1e-5, atol=2e-5)
+    scales = {k: float(g["scalar_rew_" + k]) for k in ("lin_vel_xy", "ang_vel_z", "torque")}
+    rew, reset = T.compute_anymal_reward(g["root_states"], g["commands"], g["torques"], g["contact_forces"], g["knee_indices"],
+                                         g["episode_lengths"], scales, int(g["scalar_base_index"]), int(g["scalar_max_episode_length"]))
+    np.testing.assert_array_equal(reset.astype(bool), g["reset"].astype(bool))
+    np.testing.assert_allclose(rew, g["rew"], rtol=1e-5, atol=1e-7)
+    assert (g["rew"] > 0).mean() > 0.3 and 0.2 < g["reset"].mean() < 0.8      # the vectors exercise both branches
+    # episode_lengths 2497..2500 with max_episode_length 2500: time-out from 2499 on (anymal.py:348)
+    quiet = (np.linalg.norm(g["contact_forces"][:4, [0, 2, 5, 8, 11]], axis=-1) <= 1).all(1)
+    np.testing.assert_array_equal(reset[:4][quiet], np.array([0, 0, 1, 1])[quiet])

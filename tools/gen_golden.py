@@ -12,6 +12,7 @@ Functions captured:
   isaacgymenvs/tasks/humanoid.py:323   compute_humanoid_reward
   isaacgymenvs/tasks/humanoid.py:378   compute_humanoid_observations
   isaacgymenvs/tasks/cartpole.py:180   compute_cartpole_reward
+  isaacgymenvs/tasks/anymal.py:311     compute_anymal_reward, :354 compute_anymal_observations
   isaacgymenvs/tasks/shadow_hand.py:746 compute_hand_reward, :803 randomize_rotation, :528 ShadowHand.compute_full_state (mock self)
   isaacgymenvs/tasks/anymal_terrain.py:294,302,315,515   AnymalTerrain.check_termination / compute_observations /
                                        compute_reward / get_heights (bound to a mock `self`), :676 quat_apply_yaw, :683 wrap_to_pi
@@ -52,7 +53,7 @@ def import_reference():
         mod = types.ModuleType(name)
         mod.__path__ = [os.path.join(REF, rel)]
         sys.modules[name] = mod
-    return {n: importlib.import_module("isaacgymenvs.tasks." + n) for n in ("ant", "humanoid", "cartpole", "anymal_terrain", "shadow_hand")}
+    return {n: importlib.import_module("isaacgymenvs.tasks." + n) for n in ("ant", "humanoid", "cartpole", "anymal_terrain", "shadow_hand", "anymal")}
 
 
 def rand_quat(g, n):
@@ -287,6 +288,50 @@ def shadow_hand_case(mod, n, seed):
     print("shadow_hand", n, "resets a/b", int(out["a_resets"].sum()), int(out["b_resets"].sum()), "goal resets", int(out["a_goal_resets"].sum()))
 
 
+def anymal_flat_case(mod, n, seed):
+    """compute_anymal_observations / compute_anymal_reward (anymal.py:311-386) on random states; scales = cfg/task/Anymal.yaml."""
+    g = torch.Generator().manual_seed(seed)
+    root = torch.zeros(n, 13)
+    root[:, :3] = torch.randn(n, 3, generator=g)
+    root[:, 3:7] = rand_quat(g, n)
+    root[:, 7:13] = torch.randn(n, 6, generator=g) * 1.5
+    commands = torch.rand(n, 3, generator=g) * 4 - 2
+    root[:192, 7:13] *= 0.15          # a share of envs tracks its command well enough for a non-zero (unclipped) reward
+    commands[:192] *= 0.1
+    dof_pos = torch.randn(n, 12, generator=g) * 0.5
+    # defaultJointAngles of the reference YAML in the asset's dof order (LF, RF, LH, RH x HAA, HFE, KFE after collapsing)
+    import yaml
+    from isaacgymenvs_amd.registry import load_model
+    angles = yaml.safe_load(open(os.path.join(REF, "isaacgymenvs/cfg/task/Anymal.yaml")))["env"]["defaultJointAngles"]
+    default_dof_pos = torch.tensor([float(angles[nm]) for nm in load_model("anymal").dof_names]).repeat(n, 1)
+    dof_vel = torch.randn(n, 12, generator=g) * 5
+    gravity_vec = torch.tensor([0.0, 0.0, -1.0]).repeat(n, 1)
+    actions = torch.rand(n, 12, generator=g) * 2 - 1
+    torques = torch.randn(n, 12, generator=g) * 30
+    torques[:96] *= 0.1
+    contact = torch.zeros(n, 13, 3)
+    contact[:, 0] = torch.randn(n, 3, generator=g) * (torch.rand(n, 1, generator=g) < 0.2) * 2
+    knee_indices = torch.tensor([2, 5, 8, 11])
+    contact[:, knee_indices] = torch.randn(n, 4, 3, generator=g) * (torch.rand(n, 4, 1, generator=g) < 0.1) * 2
+    contact[:, [3, 6, 9, 12]] = torch.randn(n, 4, 3, generator=g) * 50
+    episode_lengths = torch.randint(0, 2501, (n,), generator=g)
+    episode_lengths[:4] = torch.tensor([2497, 2498, 2499, 2500])
+    dt = 0.02
+    rew_scales = {"lin_vel_xy": 1.0 * dt, "ang_vel_z": 0.5 * dt, "torque": -0.000025 * dt}
+    sc = dict(lin_vel_scale=2.0, ang_vel_scale=0.25, dof_pos_scale=1.0, dof_vel_scale=0.05)
+    obs = mod.compute_anymal_observations(root, commands, dof_pos, default_dof_pos, dof_vel, gravity_vec, actions, sc["lin_vel_scale"],
+                                          sc["ang_vel_scale"], sc["dof_pos_scale"], sc["dof_vel_scale"])
+    rew, reset = mod.compute_anymal_reward(root, commands, torques, contact, knee_indices, episode_lengths, rew_scales, 0, 2500)
+    out = dict(root_states=root.numpy(), commands=commands.numpy(), dof_pos=dof_pos.numpy(), default_dof_pos=default_dof_pos.numpy(),
+               dof_vel=dof_vel.numpy(), gravity_vec=gravity_vec.numpy(), actions=actions.numpy(), torques=torques.numpy(),
+               contact_forces=contact.numpy(), knee_indices=knee_indices.numpy(), episode_lengths=episode_lengths.numpy(),
+               obs=obs.numpy(), rew=rew.numpy(), reset=reset.numpy(), scalar_max_episode_length=2500, scalar_base_index=0)
+    out.update({"scalar_" + k: v for k, v in sc.items()})
+    out.update({"scalar_rew_" + k: v for k, v in rew_scales.items()})
+    np.savez_compressed(os.path.join(OUT, "anymal_flat.npz"), **out)
+    print("anymal_flat", n, "resets", int(reset.sum()), "rew mean", float(rew.mean()), "obs", tuple(obs.shape))
+
+
 def main():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     from isaacgymenvs_amd.registry import load_model
@@ -307,6 +352,7 @@ def main():
     cartpole_case(mods["cartpole"], 512, 3)
     anymal_case(mods["anymal_terrain"], 256, 4)
     shadow_hand_case(mods["shadow_hand"], 512, 5)
+    anymal_flat_case(mods["anymal"], 512, 6)
 
 
 if __name__ == "__main__":
