@@ -120,6 +120,13 @@ typedef struct {
     float hand_pos[3], hand_quat[4];
     float cube_half, cube_mass, cube_inertia, mu;
     int32_t actuated[20];
+    /* observationType (shadow_hand.py:97-110): 0 full_state (211), 1 openai (42), 2 full_no_vel (77), 3 full (157).
+     * For types 1-3 obs_buf[:, k] = full_state[:, obs_map[k]] (the layouts of shadow_hand.py:472-526 are column subsets of
+     * compute_full_state's); asymmetric_obs != 0 additionally exposes the full state as "states_buf" (:584). */
+    int32_t obs_type, num_obs, asymmetric_obs;
+    int16_t obs_map[160];
+    /* random object forces (shadow_hand.py:69-72, 196-201, 700-708); force_scale <= 0 disables them */
+    float force_scale, force_prob_range[2], force_decay, force_decay_interval;
 } MiHandParams;
 
 typedef struct {

@@ -22,6 +22,7 @@ struct FreeBody {           // world frame
 };
 struct ObjectParams {       // mirrors the object part of MiHandParams
     float half, mass, inertia, mu;   // cube half size, mass, isotropic inertia, combined friction
+    float fw[3] = {0.f, 0.f, 0.f};   // external world-frame force on the object for this step (apply_rigid_body_force_tensors)
 };
 
 template <class M>
@@ -150,7 +151,7 @@ struct HandSim : Sim<M> {
         const float sm = MI_SQRT(OP.mass), si = MI_SQRT(OP.inertia);
         const float ism = MI_RCP(sm), isi = MI_RCP(si);
         float wo[6];
-        sfor<3>([&](auto K) MI_LAMBDA { wo[K] = sm * (obj.vel[K] + h * P.g[K]); wo[3 + K] = si * obj.angvel[K]; });
+        sfor<3>([&](auto K) MI_LAMBDA { wo[K] = sm * (obj.vel[K] + h * (P.g[K] + OP.fw[K] * (ism * ism))); wo[3 + K] = si * obj.angvel[K]; });
         float Ro[9];
         quat2mat(obj.quat, Ro);
         const float xo[3] = {obj.pos[0] - root[0], obj.pos[1] - root[1], obj.pos[2] - root[2]};   // object COM rel O

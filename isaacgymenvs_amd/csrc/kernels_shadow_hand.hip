@@ -27,9 +27,18 @@ struct HandView {
     float* cons;           // [1] consecutive_successes (shadow_hand.py:795-798)
     float* ws;             // [2] per-step scratch of the cross-env sums
     int* ncontact;         // [N] object contacts of the last sub-step (diagnostic)
+    float* full_state;     // [N][211] row-major: compute_full_state's vector when it is not obs_buf itself (states_buf, :584)
+    float* obj_force;      // [3][N] world-frame force on the cube during this control step (apply_rigid_body_force_tensors)
+    float* rb_force;       // [3][N] rb_forces[:, object] in the object's local frame (:201, 700-708)
+    float* force_prob;     // [N] random_force_prob (:198-199)
 };
 
 __device__ __forceinline__ float hand_u(uint32_t seed, uint32_t genv, uint32_t ep, uint32_t k) { return 2.f * uniform01(seed, genv, ep, k) - 1.f; }
+// random_force_prob (:198-199, 642-643): log-uniform in force_prob_range
+__device__ __forceinline__ float hand_force_prob(const HandParams& p, float u) {
+    MI_NO_CONTRACT
+    return expf((logf(p.force_prob_range[0]) - logf(p.force_prob_range[1])) * u + logf(p.force_prob_range[1]));
+}
 
 // reset_target_pose (shadow_hand.py:586-602): new random goal orientation
 __device__ __forceinline__ void hand_reset_goal(const View& v, const HandView& hv, const HandParams& p, int e, uint32_t genv) {
@@ -73,6 +82,8 @@ __device__ __forceinline__ void hand_reset_env(const View& v, const HandView& hv
         hv.cur_targets[d * N + e] = pos;
         v.laml[d * N + e] = 0.f;
     });
+    sfor<3>([&](auto K) MI_LAMBDA { hv.rb_force[K * N + e] = 0.f; hv.obj_force[K * N + e] = 0.f; });       // :616
+    hv.force_prob[e] = hand_force_prob(p, uniform01(v.seed, genv, ep, 5 + 2 * ND));                           // :642-643
     v.episode[e] = (int)ep + 1;
     v.progress[e] = 0;
     v.reset[e] = 0;
@@ -80,7 +91,7 @@ __device__ __forceinline__ void hand_reset_env(const View& v, const HandView& hv
 }
 
 // pre_physics_step (shadow_hand.py:670-698): deferred resets, then actions -> targets
-__global__ void hand_pre_kernel(View v, HandView hv, HandParams p, const float* __restrict__ actions_in) {
+__global__ void hand_pre_kernel(View v, HandView hv, HandParams p, const float* __restrict__ actions_in, unsigned step_counter) {
     MI_NO_CONTRACT
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const int N = v.N;
@@ -108,6 +119,26 @@ __global__ void hand_pre_kernel(View v, HandView hv, HandParams p, const float* 
         hv.cur_targets[d * N + e] = t;
         hv.prev_targets[d * N + e] = t;                                                     // :697
     });
+    if (p.force_scale > 0.f) {   // random forces on the object (:700-708)
+        const float decay = powf(p.force_decay, p.dt / p.force_decay_interval);
+        float f[3];
+        sfor<3>([&](auto K) MI_LAMBDA { f[K] = hv.rb_force[K * N + e] * decay; });
+        const uint32_t sk = step_counter | 0x80000000u, sd = v.seed ^ 0x9E3779B9u;
+        if (uniform01(sd, genv, sk, 0) < hv.force_prob[e]) {
+            // torch.randn(3) * object mass * force_scale; Box-Muller on the engine's counter-based uniforms
+            const float u1 = fmaxf(uniform01(sd, genv, sk, 1), 1e-7f), u2 = uniform01(sd, genv, sk, 2);
+            const float u3 = fmaxf(uniform01(sd, genv, sk, 3), 1e-7f), u4 = uniform01(sd, genv, sk, 4);
+            const float r1 = sqrtf(-2.f * logf(u1)), r2 = sqrtf(-2.f * logf(u3));
+            const float k = p.cube_mass * p.force_scale;
+            f[0] = r1 * cosf(6.283185307179586f * u2) * k;
+            f[1] = r1 * sinf(6.283185307179586f * u2) * k;
+            f[2] = r2 * cosf(6.283185307179586f * u4) * k;
+        }
+        float q[4], fw[3];
+        sfor<4>([&](auto K) MI_LAMBDA { q[K] = hv.object_state[(3 + K) * N + e]; });
+        quat_rotate_s(q, f, 1.f, fw);                                                      // LOCAL_SPACE -> world at application time
+        sfor<3>([&](auto K) MI_LAMBDA { hv.rb_force[K * N + e] = f[K]; hv.obj_force[K * N + e] = fw[K]; });
+    }
 }
 
 // gym.simulate(): one physics sub-step of hand + cube
@@ -130,7 +161,8 @@ __global__ __launch_bounds__(32) void hand_substep_kernel(View v, HandView hv, S
     sfor<3>([&](auto K) MI_LAMBDA { sim.obj.pos[K] = hv.object_state[K * N + e]; sim.obj.vel[K] = hv.object_state[(7 + K) * N + e];
                                     sim.obj.angvel[K] = hv.object_state[(10 + K) * N + e]; });
     sfor<4>([&](auto K) MI_LAMBDA { sim.obj.quat[K] = hv.object_state[(3 + K) * N + e]; });
-    const ObjectParams OP{p.cube_half, p.cube_mass, p.cube_inertia, p.mu};
+    const ObjectParams OP{p.cube_half, p.cube_mass, p.cube_inertia, p.mu,
+                          {hv.obj_force[e], hv.obj_force[N + e], hv.obj_force[2 * N + e]}};
     const float h = P.dt / (float)P.substeps;
     int nc = 0;
     sim.substep_hand(P, OP, target, h, RowStore<LANES>{lds_rows + threadIdx.x}, Strided{v.laml + e, N}, Strided{v.sensor + e, N},
@@ -162,10 +194,17 @@ __global__ __launch_bounds__(64) void hand_post_kernel(View v, HandView hv, Hand
     sfor<kHandAct>([&](auto K) MI_LAMBDA { act[K] = v.actions[K * N + e]; });
     const long long progress_in = v.progress[e] + 1;               // :711
     // compute_full_state (:528-584)
+    // obs_type 0: the vector IS obs_buf; otherwise it goes to full_state and hand_obs_select_kernel picks obs_buf's columns.
+    // With asymmetric observations full_state (= states_buf) is written in both cases.
+    const bool direct = p.obs_type == 0, to_full = !direct || p.asymmetric_obs != 0;
     float* ob = v.obs + (size_t)e * kHandObs;
     float* oc = v.obs_out + ((size_t)v.ring * N + e) * kHandObs;
+    float* fs = hv.full_state + (size_t)e * kHandObs;
     auto emit = [&](int k, float val) MI_LAMBDA {
-        if (valid) { ob[k] = val; oc[k] = fminf(fmaxf(val, -v.clip_obs), v.clip_obs); }
+        if (valid) {
+            if (direct) { ob[k] = val; oc[k] = fminf(fmaxf(val, -v.clip_obs), v.clip_obs); }
+            if (to_full) fs[k] = val;
+        }
     };
     sfor<ND>([&](auto D) MI_LAMBDA {
         constexpr int d = D;
@@ -207,6 +246,16 @@ __global__ __launch_bounds__(64) void hand_post_kernel(View v, HandView hv, Hand
     v.randomize[e] += 1;
     v.timeout[e] = (unsigned char)(((float)prog >= p.rew.max_episode_length - 1.f) && (rs != 0));      // vec_task.py:394
 }
+// observationType openai / full_no_vel / full (shadow_hand.py:472-526): column subsets of the full state
+__global__ void hand_obs_select_kernel(View v, HandView hv, HandParams p) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int no = p.num_obs;
+    if (i >= v.N * no) return;
+    const int e = i / no, k = i - e * no;
+    const float val = hv.full_state[(size_t)e * kHandObs + p.obs_map[k]];
+    v.obs[(size_t)e * no + k] = val;
+    v.obs_out[((size_t)v.ring * v.N + e) * no + k] = fminf(fmaxf(val, -v.clip_obs), v.clip_obs);
+}
 __global__ void hand_finalize_kernel(HandView hv, HandParams p) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         const float num_resets = hv.ws[0], finished = hv.ws[1], cs = hv.cons[0];
@@ -230,7 +279,11 @@ __global__ void hand_init_kernel(View v, HandView hv, HandParams p) {
     for (int k = 0; k < 6 * kHandTips; ++k) v.sensor[k * N + e] = 0.f;
     for (int k = 0; k < 13 * kHandTips; ++k) hv.fingertip[k * N + e] = 0.f;
     for (int k = 0; k < kHandAct; ++k) v.actions[k * N + e] = 0.f;
-    for (int k = 0; k < kHandObs; ++k) { v.obs[(size_t)e * kHandObs + k] = 0.f; v.obs_out[(size_t)e * kHandObs + k] = 0.f; v.obs_out[((size_t)N + e) * kHandObs + k] = 0.f; }
+    const int no = p.num_obs;
+    for (int k = 0; k < no; ++k) { v.obs[(size_t)e * no + k] = 0.f; v.obs_out[(size_t)e * no + k] = 0.f; v.obs_out[((size_t)N + e) * no + k] = 0.f; }
+    for (int k = 0; k < kHandObs; ++k) hv.full_state[(size_t)e * kHandObs + k] = 0.f;
+    for (int k = 0; k < 3; ++k) { hv.obj_force[k * N + e] = 0.f; hv.rb_force[k * N + e] = 0.f; }
+    hv.force_prob[e] = hand_force_prob(p, uniform01(v.seed ^ 0x51ED27u, (uint32_t)(v.env_offset + e), 0u, 0u));
     hv.successes[e] = 0.f; hv.reset_goal[e] = 1; hv.goal_count[e] = 0; hv.ncontact[e] = 0;
     v.rew[e] = 0.f; v.reset[e] = 1; v.progress[e] = 0; v.randomize[e] = 0; v.timeout[e] = 0; v.episode[e] = 0; v.ep_ret[e] = 0.f;
     if (e == 0) { hv.cons[0] = 0.f; hv.ws[0] = hv.ws[1] = 0.f; for (int k = 0; k < 8; ++k) v.stats[k] = 0.f; }
@@ -251,13 +304,14 @@ static hipError_t hand_substeps(const View& v, const HandView& hv, const SimPara
 }
 
 hipError_t launch_step_shadow_hand(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, const float* actions, int cfi,
-                                   hipStream_t s) {
-    hipLaunchKernelGGL(hand_pre_kernel, dim3((v.N + 127) / 128), dim3(128), 0, s, v, hv, p, actions);
+                                   unsigned step_counter, hipStream_t s) {
+    hipLaunchKernelGGL(hand_pre_kernel, dim3((v.N + 127) / 128), dim3(128), 0, s, v, hv, p, actions, step_counter);
     hipError_t e = hand_substeps(v, hv, P, p, cfi * P.substeps, s);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(hv.ws, 0, 2 * sizeof(float), s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(hand_post_kernel, dim3((v.N + 63) / 64), dim3(64), 0, s, v, hv, p);
+    if (p.obs_type != 0) hipLaunchKernelGGL(hand_obs_select_kernel, dim3((v.N * p.num_obs + 255) / 256), dim3(256), 0, s, v, hv, p);
     hipLaunchKernelGGL(hand_finalize_kernel, dim3(1), dim3(64), 0, s, hv, p);
     return hipGetLastError();
 }

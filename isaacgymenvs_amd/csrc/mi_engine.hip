@@ -196,8 +196,10 @@ hipError_t launch_anymal_reward(int n, const AnymalFlatParams& p, const float* r
 struct HandView {
     float* cur_targets; float* prev_targets; float* object_state; float* goal_state; float* fingertip; float* successes;
     long long* reset_goal; int* goal_count; float* cons; float* ws; int* ncontact;
+    float* full_state; float* obj_force; float* rb_force; float* force_prob;
 };
-hipError_t launch_step_shadow_hand(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, const float* actions, int cfi, hipStream_t s);
+hipError_t launch_step_shadow_hand(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, const float* actions, int cfi,
+                                   unsigned step_counter, hipStream_t s);
 hipError_t launch_simulate_shadow_hand(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, hipStream_t s);
 hipError_t launch_init_shadow_hand(const View& v, const HandView& hv, const HandParams& p, hipStream_t s);
 hipError_t launch_reset_shadow_hand(const View& v, const HandView& hv, const HandParams& p, const long long* ids, int n, hipStream_t s);
@@ -255,9 +257,10 @@ struct Layout {
     }
 };
 
-static void build_layout(int task, int N, Layout& L, View* v, char* base) {
+// nobs: observation width; 0 = the task's (maximum) width.  ShadowHand's observationType variants are narrower.
+static void build_layout(int task, int N, Layout& L, View* v, char* base, int nobs = 0) {
     const TaskMeta& m = kTasks[task];
-    const int64_t n = N, nd = m.nd, ns = m.nsens, nsp = m.nsph, no = m.nobs, na = m.nact;
+    const int64_t n = N, nd = m.nd, ns = m.nsens, nsp = m.nsph, no = nobs > 0 ? nobs : m.nobs, na = m.nact;
     auto P = [&](size_t o) { return base ? base + o : (char*)nullptr; };
     size_t o;
     o = L.add("root_states", MI_F32, {n, 13}, {1, n}, 13 * n); if (v) v->root = (float*)P(o);
@@ -321,6 +324,10 @@ static void build_hand_layout(int N, Layout& L, HandView* hv, char* base) {
     o = L.add("consecutive_successes", MI_F32, {1}, {1}, 1); if (hv) hv->cons = (float*)P(o);
     o = L.add("reward_workspace", MI_F32, {2}, {1}, 2); if (hv) hv->ws = (float*)P(o);
     o = L.add("object_contact_count", MI_I32, {n}, {1}, n); if (hv) hv->ncontact = (int*)P(o);
+    o = L.add("states_buf", MI_F32, {n, 211}, {211, 1}, 211 * n); if (hv) hv->full_state = (float*)P(o);
+    o = L.add("object_force", MI_F32, {n, 3}, {1, n}, 3 * n); if (hv) hv->obj_force = (float*)P(o);
+    o = L.add("rb_forces_object", MI_F32, {n, 3}, {1, n}, 3 * n); if (hv) hv->rb_force = (float*)P(o);
+    o = L.add("random_force_prob", MI_F32, {n}, {1}, n); if (hv) hv->force_prob = (float*)P(o);
     L.off = (L.off + 255) & ~size_t(255);
 }
 
@@ -365,7 +372,16 @@ extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const 
     else memcpy(&e->loco, task_params, sizeof(LocoParams));
     Layout L;
     memset(&e->v, 0, sizeof(View));
-    build_layout(t, num_envs, L, &e->v, (char*)arena);
+    int nobs = 0;
+    if (t == T_SHADOWHAND) {
+        const HandParams& hp = e->hand;
+        const bool ok = (hp.obs_type == 0 && hp.num_obs == 211) || (hp.obs_type >= 1 && hp.obs_type <= 3 && hp.num_obs >= 1 && hp.num_obs <= 160);
+        if (!ok) { delete e; return fail("mi_engine_create: ShadowHand obs_type / num_obs invalid"); }
+        for (int k = 0; hp.obs_type != 0 && k < hp.num_obs; ++k)
+            if (hp.obs_map[k] < 0 || hp.obs_map[k] >= 211) { delete e; return fail("mi_engine_create: ShadowHand obs_map entry out of range"); }
+        nobs = hp.num_obs;
+    }
+    build_layout(t, num_envs, L, &e->v, (char*)arena, nobs);
     memset(&e->hv, 0, sizeof(e->hv));
     if (t == T_SHADOWHAND) build_hand_layout(num_envs, L, &e->hv, (char*)arena);
     if (arena_bytes < L.off) { delete e; return fail("mi_engine_create: arena too small"); }
@@ -459,7 +475,9 @@ extern "C" int mi_engine_step(MiEngine* e, const float* actions, void* stream) {
         case T_CARTPOLE: HIP_OK(launch_step_cartpole(e->v, e->P, e->cart, actions, e->control_freq_inv, s)); break;
         case T_ANT: HIP_OK(launch_step_ant(e->v, e->P, e->loco, actions, e->control_freq_inv, s)); break;
         case T_HUMANOID: HIP_OK(launch_step_humanoid(e->v, e->P, e->loco, actions, e->control_freq_inv, s)); break;
-        case T_SHADOWHAND: HIP_OK(launch_step_shadow_hand(e->v, e->hv, e->P, e->hand, actions, e->control_freq_inv, s)); break;
+        case T_SHADOWHAND:
+            HIP_OK(launch_step_shadow_hand(e->v, e->hv, e->P, e->hand, actions, e->control_freq_inv, (unsigned)(e->steps + 1), s));
+            break;
         case T_ANYMAL:
             if (e->terrain.hs == nullptr) return fail("mi_engine_step: AnymalTerrain needs mi_engine_set_terrain first");
             // common_step_counter is incremented before the push test (anymal_terrain.py:460-462)

@@ -29,6 +29,9 @@ struct HandParams {   // mirrors MiHandParams (include/mi_engine.h): what Shadow
     float hand_pos[3], hand_quat[4];                          // actor pose (:306-307) x mount orientation (robot.xml:3)
     float cube_half, cube_mass, cube_inertia, mu;             // cube_multicolor.urdf
     int actuated[20];                                         // dof index of each of the 20 actuators (:268-269)
+    int obs_type, num_obs, asymmetric_obs;                    // observationType (:97-110), asymmetric_observations (:88)
+    short obs_map[160];                                       // obs_buf[:, k] = full_state[:, obs_map[k]] for obs_type != 0
+    float force_scale, force_prob_range[2], force_decay, force_decay_interval;   // :69-72
 };
 
 MI_HD void quat_conjugate(const float* a, float* o) { o[0] = -a[0]; o[1] = -a[1]; o[2] = -a[2]; o[3] = a[3]; }

@@ -92,7 +92,10 @@ class MiHandParams(C.Structure):
                 ("use_relative_control", C.c_int32), ("clip_actions", C.c_float), ("object_init_pos", C.c_float * 3),
                 ("goal_init_pos", C.c_float * 3), ("hand_pos", C.c_float * 3), ("hand_quat", C.c_float * 4),
                 ("cube_half", C.c_float), ("cube_mass", C.c_float), ("cube_inertia", C.c_float), ("mu", C.c_float),
-                ("actuated", C.c_int32 * 20)]
+                ("actuated", C.c_int32 * 20),
+                ("obs_type", C.c_int32), ("num_obs", C.c_int32), ("asymmetric_obs", C.c_int32), ("obs_map", C.c_int16 * 160),
+                ("force_scale", C.c_float), ("force_prob_range", C.c_float * 2), ("force_decay", C.c_float),
+                ("force_decay_interval", C.c_float)]
 
 
 class MiTaskInfo(C.Structure):

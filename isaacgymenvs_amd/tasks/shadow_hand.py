@@ -2,9 +2,9 @@
 (reference isaacgymenvs/tasks/shadow_hand.py).
 
 Host side only: config -> MiHandParams and the reference's attribute names as views of the engine arena.  Supported
-subset: objectType "block" (the cube: an isotropic free body), observationType "full_state" (211), absolute or relative
-position control, in-kernel resets.  Not supported (raise): egg / pen objects, the "openai" / "full_no_vel" / "full"
-observation layouts, asymmetric observations, random object forces (forceScale > 0).  Physics simplifications are listed
+subset: objectType "block" (the cube: an isotropic free body), all four observation layouts (full_state 211, full 157,
+full_no_vel 77, openai 42), asymmetric observations (states_buf = full state), absolute or relative position control,
+random object forces (forceScale > 0), in-kernel resets.  Not supported (raise): egg / pen objects.  Physics simplifications are listed
 in DESIGN.md (hand geometry sampled by spheres against the exact box, no hand self-collision, soft tendons, drive force
 limits not clamped).
 """
@@ -19,6 +19,28 @@ from .base.vec_task import VecTask
 
 CUBE_SIZE = 0.05          # assets/urdf/objects/cube_multicolor.urdf: box 0.05
 CUBE_DENSITY = 567.0
+
+
+NUM_OBS = {"openai": 42, "full_no_vel": 77, "full": 157, "full_state": 211}     # shadow_hand.py:101-106
+OBS_TYPE_ID = {"full_state": 0, "openai": 1, "full_no_vel": 2, "full": 3}
+
+
+def obs_columns(obs_type):
+    """Columns of compute_full_state's 211-vector (shadow_hand.py:528-584) that make up the other observation layouts
+    (compute_fingertip_observations(True) :472-485, compute_full_observations :498-526).  Full-state layout: dof pos 0:24,
+    dof vel 24:48, dof force 48:72, object pose 72:79, linvel 79:82, angvel 82:85, goal pose 85:92, rel. rotation 92:96,
+    fingertip states 96:161 (5 x 13), fingertip force-torques 161:191, actions 191:211."""
+    r = lambda a, b: list(range(a, b))
+    tip_pos = [96 + 13 * t + k for t in range(5) for k in range(3)]
+    if obs_type == "openai":
+        return tip_pos + r(72, 75) + r(92, 96) + r(191, 211)
+    if obs_type == "full_no_vel":
+        return r(0, 24) + r(72, 79) + r(85, 92) + r(92, 96) + tip_pos + r(191, 211)
+    if obs_type == "full":
+        return r(0, 24) + r(24, 48) + r(72, 79) + r(79, 82) + r(82, 85) + r(85, 92) + r(92, 96) + r(96, 161) + r(191, 211)
+    if obs_type == "full_state":
+        return r(0, 211)
+    raise ValueError("Unknown type of observations!\nobservationType should be one of: [openai, full_no_vel, full, full_state]")
 
 
 def hand_params_from_cfg(cfg):
@@ -58,6 +80,19 @@ def hand_params_from_cfg(cfg):
     p.mu = 1.0
     for a, d in enumerate(ex["actuated_dofs"]):
         p.actuated[a] = int(d)
+    ot = env["observationType"]
+    cols = obs_columns(ot)
+    assert len(cols) == NUM_OBS[ot]
+    p.obs_type, p.num_obs = OBS_TYPE_ID[ot], len(cols)
+    p.asymmetric_obs = int(bool(env.get("asymmetric_observations", False)))
+    if ot != "full_state":
+        for k, c in enumerate(cols):
+            p.obs_map[k] = c
+    p.force_scale = float(env.get("forceScale", 0.0))                          # :69-72
+    fr = env.get("forceProbRange", [0.001, 0.1])
+    p.force_prob_range[0], p.force_prob_range[1] = float(fr[0]), float(fr[1])
+    p.force_decay = float(env.get("forceDecay", 0.99))
+    p.force_decay_interval = float(env.get("forceDecayInterval", 0.08))
     return p
 
 
@@ -70,20 +105,20 @@ class ShadowHand(VecTask):
         env = cfg["env"]
         if env["objectType"] != "block":
             raise NotImplementedError("only objectType 'block' is implemented (the cube is an isotropic free body)")
-        if env["observationType"] != "full_state" or env.get("asymmetric_observations", False):
-            raise NotImplementedError("only observationType 'full_state' without asymmetric observations is implemented")
-        if float(env.get("forceScale", 0.0)) > 0.0:
-            raise NotImplementedError("random object forces (forceScale > 0) are not implemented")
+        if env["observationType"] not in NUM_OBS:                                   # shadow_hand.py:97-99
+            raise Exception("Unknown type of observations!\nobservationType should be one of: [openai, full_no_vel, full, full_state]")
         self.randomize = cfg["task"]["randomize"]
         self.randomization_params = cfg["task"].get("randomization_params", {})
         self.max_episode_length = env["episodeLength"]
         self.obs_type = env["observationType"]
         self.object_type = env["objectType"]
-        self.num_obs_dict = {"openai": 42, "full_no_vel": 77, "full": 157, "full_state": 211}
+        self.asymmetric_obs = bool(env.get("asymmetric_observations", False))
+        self.force_scale = env.get("forceScale", 0.0)
+        self.num_obs_dict = dict(NUM_OBS)
         self.fingertips = ["robot0:ffdistal", "robot0:mfdistal", "robot0:rfdistal", "robot0:lfdistal", "robot0:thdistal"]
         self.num_fingertips = 5
-        cfg["env"]["numObservations"] = 211
-        cfg["env"]["numStates"] = 0
+        cfg["env"]["numObservations"] = self.num_obs_dict[self.obs_type]           # :113-116
+        cfg["env"]["numStates"] = 211 if self.asymmetric_obs else 0
         cfg["env"]["numActions"] = 20
         cfg["env"].setdefault("plane", {"staticFriction": 1.0})
         self.spec = load_model("shadow_hand")
@@ -110,6 +145,9 @@ class ShadowHand(VecTask):
         self.actions = t["actions"]
         self.successes, self.consecutive_successes = t["successes"], t["consecutive_successes"]
         self.reset_goal_buf = t["reset_goal_buf"]
+        if self.asymmetric_obs:
+            self.states_buf = t["states_buf"]                                         # compute_full_state(True), :584
+        self.rb_forces_object, self.random_force_prob = t["rb_forces_object"], t["random_force_prob"]
         lo = np.minimum(self.spec.dof_lower, self.spec.dof_upper); up = np.maximum(self.spec.dof_lower, self.spec.dof_upper)
         self.shadow_hand_dof_lower_limits = torch.tensor(lo, dtype=torch.float32, device=dev)
         self.shadow_hand_dof_upper_limits = torch.tensor(up, dtype=torch.float32, device=dev)

@@ -71,6 +71,7 @@ class OracleHandEngine:
         self.sensor = np.zeros((N, 6 * len(self.sens)))
         self.dof_force = np.zeros((N, nd))
         self.ncontacts = np.zeros(N, int)
+        self.obj_force = np.zeros((N, 3))                 # world-frame external force on the cube for the current step
         self.lo = np.minimum(spec.dof_lower, spec.dof_upper); self.up = np.maximum(spec.dof_lower, spec.dof_upper)
 
     # views on the wrapped engine's state
@@ -129,7 +130,7 @@ class OracleHandEngine:
         v = qd + h * (Minv @ rhs)
         g = np.array(P["gravity"], float)
         xo, qo = self.obj[e, 0:3].copy(), self.obj[e, 3:7].copy()
-        vo = self.obj[e, 7:10] + h * g
+        vo = self.obj[e, 7:10] + h * (g + self.obj_force[e] / CUBE_MASS)   # + apply_rigid_body_force_tensors on the cube
         wo = self.obj[e, 10:13].copy()
         Ro = quat2mat(qo)
         # ---- rows

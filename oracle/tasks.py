@@ -763,6 +763,44 @@ def compute_hand_full_state(dof_pos, dof_vel, dof_force, lower, upper, object_st
     return np.concatenate([c.astype(f32) for c in cols], axis=-1)
 
 
+def compute_hand_observations(obs_type, dof_pos, dof_vel, lower, upper, object_state, goal_pose, fingertip_state, actions,
+                              vel_obs_scale):
+    """shadow_hand.py:472-526: compute_fingertip_observations(True) ("openai"), compute_full_observations(True)
+    ("full_no_vel"), compute_full_observations() ("full"); written out layout by layout like the reference."""
+    n = dof_pos.shape[0]
+    object_pose, object_linvel, object_angvel = object_state[:, 0:7], object_state[:, 7:10], object_state[:, 10:13]
+    rel = quat_mul(object_state[:, 3:7], quat_conjugate(goal_pose[:, 3:7]))
+    fingertip_pos = fingertip_state[:, :, 0:3].reshape(n, 15)
+    if obs_type == "openai":                                                  # :472-485
+        obs = np.zeros((n, 42), f32)
+        obs[:, 0:15] = fingertip_pos
+        obs[:, 15:18] = object_pose[:, 0:3]
+        obs[:, 18:22] = rel
+        obs[:, 22:42] = actions
+    elif obs_type == "full_no_vel":                                           # :498-509
+        obs = np.zeros((n, 77), f32)
+        obs[:, 0:24] = unscale(dof_pos, lower, upper)
+        obs[:, 24:31] = object_pose
+        obs[:, 31:38] = goal_pose
+        obs[:, 38:42] = rel
+        obs[:, 42:57] = fingertip_pos
+        obs[:, 57:77] = actions
+    elif obs_type == "full":                                                  # :510-526
+        obs = np.zeros((n, 157), f32)
+        obs[:, 0:24] = unscale(dof_pos, lower, upper)
+        obs[:, 24:48] = f32(vel_obs_scale) * dof_vel
+        obs[:, 48:55] = object_pose
+        obs[:, 55:58] = object_linvel
+        obs[:, 58:61] = f32(vel_obs_scale) * object_angvel
+        obs[:, 61:68] = goal_pose
+        obs[:, 68:72] = rel
+        obs[:, 72:137] = fingertip_state.reshape(n, 65)
+        obs[:, 137:157] = actions
+    else:
+        raise ValueError(obs_type)
+    return obs
+
+
 class OracleShadowHandEnv:
     """vec_task.py:360-408 + shadow_hand.py pre/post_physics_step on oracle/hand.py (numpy, fp64 physics, fp32 task maths).
     `params` is the MiHandParams struct the HIP engine receives."""
@@ -791,6 +829,14 @@ class OracleShadowHandEnv:
         self.episode = np.zeros(N, np.uint32)
         self.goal_count = np.zeros(N, np.uint32)
         self.actions = np.zeros((N, 20), f32)
+        self.obs_type = {0: "full_state", 1: "openai", 2: "full_no_vel", 3: "full"}[int(getattr(p, "obs_type", 0))]
+        self.rb_forces = np.zeros((N, 3), f32)                                    # rb_forces[:, object] (local frame)
+        self.random_force_prob = np.zeros(N, f32)
+        self.step_counter = 0
+
+    def _force_prob(self, u):  # shadow_hand.py:198-199
+        lo, hi = f32(self.p.force_prob_range[0]), f32(self.p.force_prob_range[1])
+        return np.exp((np.log(lo) - np.log(hi)) * u + np.log(hi)).astype(f32)
 
     def _u(self, seed, genv, ep, k):
         return f32(2) * mi_uniform(seed, genv, ep, k) - f32(1)
@@ -828,6 +874,9 @@ class OracleShadowHandEnv:
             self.prev_targets[ids, d] = pos
             self.cur_targets[ids, d] = pos
         self.eng.laml[ids] = 0
+        self.rb_forces[ids] = 0                                                                    # :616
+        self.eng.obj_force[ids] = 0
+        self.random_force_prob[ids] = self._force_prob(mi_uniform(self.seed, g, ep, 5 + 2 * nd))   # :642-643
         self.episode[ids] += 1
         self.progress_buf[ids] = 0
         self.reset_buf[ids] = 0
@@ -853,6 +902,20 @@ class OracleShadowHandEnv:
         self.cur_targets[:, self.act] = t
         self.prev_targets[:, self.act] = t
         self.eng.targets[:] = self.cur_targets
+        self.step_counter += 1
+        if p.force_scale > 0.0:                                                                    # :700-708
+            self.rb_forces *= np.power(f32(p.force_decay), f32(p.dt) / f32(p.force_decay_interval)).astype(f32)
+            sk = np.uint32(self.step_counter) | np.uint32(0x80000000)
+            sd = np.uint32(self.seed) ^ np.uint32(0x9E3779B9)
+            hit = mi_uniform(sd, self.genv, sk, 0) < self.random_force_prob
+            u1 = np.maximum(mi_uniform(sd, self.genv, sk, 1), f32(1e-7)); u2 = mi_uniform(sd, self.genv, sk, 2)
+            u3 = np.maximum(mi_uniform(sd, self.genv, sk, 3), f32(1e-7)); u4 = mi_uniform(sd, self.genv, sk, 4)
+            r1, r2 = np.sqrt(f32(-2) * np.log(u1)).astype(f32), np.sqrt(f32(-2) * np.log(u3)).astype(f32)
+            k = f32(p.cube_mass) * f32(p.force_scale)
+            tw = f32(6.283185307179586)
+            new = np.stack([r1 * np.cos(tw * u2) * k, r1 * np.sin(tw * u2) * k, r2 * np.cos(tw * u4) * k], axis=1).astype(f32)
+            self.rb_forces[hit] = new[hit]
+            self.eng.obj_force[:] = quat_rotate(self.eng.obj[:, 3:7].astype(f32), self.rb_forces)      # LOCAL_SPACE
         self.eng.step()
         return self.post_physics_step()
 
@@ -862,9 +925,14 @@ class OracleShadowHandEnv:
         e = self.eng
         self.fingertip_state = e.fingertip_states().astype(f32)
         obj = e.obj.astype(f32)
-        self.obs_buf = compute_hand_full_state(e.q.astype(f32), e.qd.astype(f32), e.dof_force.astype(f32), self.lo, self.up, obj,
-                                               self.goal_states, self.fingertip_state, e.sensor.astype(f32), self.actions,
-                                               p.vel_obs_scale, p.force_torque_obs_scale)
+        self.states_buf = compute_hand_full_state(e.q.astype(f32), e.qd.astype(f32), e.dof_force.astype(f32), self.lo, self.up, obj,
+                                                  self.goal_states, self.fingertip_state, e.sensor.astype(f32), self.actions,
+                                                  p.vel_obs_scale, p.force_torque_obs_scale)
+        if self.obs_type == "full_state":
+            self.obs_buf = self.states_buf
+        else:
+            self.obs_buf = compute_hand_observations(self.obs_type, e.q.astype(f32), e.qd.astype(f32), self.lo, self.up, obj,
+                                                     self.goal_states, self.fingertip_state, self.actions, p.vel_obs_scale)
         r = p.rew
         out = compute_hand_reward(None, self.reset_buf, self.reset_goal_buf, self.progress_buf, self.successes, self.consecutive_successes,
                                   r.max_episode_length, obj[:, 0:3], obj[:, 3:7], self.goal_states[:, 0:3], self.goal_states[:, 3:7],

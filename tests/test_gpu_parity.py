@@ -510,6 +510,51 @@ def test_shadow_hand_step_matches_cpu_restatement():
     assert "consecutive_successes" in extras
 
 
+@pytest.mark.parametrize("obs_type,nobs", [("openai", 42), ("full_no_vel", 77), ("full", 157)])
+def test_shadow_hand_observation_types_asymmetric_states_and_random_forces(obs_type, nobs):
+    """observationType variants (shadow_hand.py:472-526) + asymmetric_observations (states_buf, :584) + random object forces
+    (:700-708): the engine picks columns of its full-state vector through obs_map; the oracle builds every layout the way the
+    reference writes it, so a wrong column would show."""
+    import isaacgymenvs_amd
+    from isaacgymenvs_amd.registry import load_extras
+    from isaacgymenvs_amd.utils.config import compose as _compose
+    from oracle.tasks import OracleShadowHandEnv
+    n, seed = 48, 31
+    cfg = _compose(overrides=["task=ShadowHand"])
+    cfg["task"]["env"]["numEnvs"] = n
+    cfg["task"]["env"]["observationType"] = obs_type
+    cfg["task"]["env"]["asymmetric_observations"] = True
+    cfg["task"]["env"]["forceScale"] = 1.0
+    cfg["task"]["env"]["forceProbRange"] = [0.2, 0.6]
+    env = isaacgymenvs_amd.make(seed=seed, task="ShadowHand", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True, cfg=cfg)
+    assert env.num_obs == nobs and env.num_states == 211
+    orc = OracleShadowHandEnv(load_model("shadow_hand"), load_extras("shadow_hand"), sensor_bodies("shadow_hand"),
+                              _sim_dict(env.sim_params), env._task_params_struct, n, seed=seed)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    forced = 0
+    for step in range(6):
+        a = torch.rand((n, 20), generator=g) * 2 - 1
+        obs_d, rew, reset, extras = env.step(a.to(DEV))
+        o_obs, o_rew, o_reset = orc.step(a.numpy())
+        torch.cuda.synchronize()
+        assert obs_d["obs"].shape == (n, nobs) and obs_d["states"].shape == (n, 211)
+        obs, st = env.obs_buf.cpu().numpy(), env.states_buf.cpu().numpy()
+        # the random forces are the same draws on both sides
+        np.testing.assert_allclose(env.random_force_prob.cpu().numpy(), orc.random_force_prob, rtol=1e-5)
+        np.testing.assert_allclose(env.rb_forces_object.cpu().numpy(), orc.rb_forces, rtol=1e-4, atol=1e-6)
+        forced += int((np.abs(orc.rb_forces).sum(1) > 0).sum())
+        tol = 2e-3 * (1 + step)
+        ok = np.abs(st - orc.states_buf).max(axis=1) < 40 * tol       # contact-force columns (x10) dominate the full state
+        assert ok.mean() > 0.9, (step, ok.mean())
+        d = np.abs(obs - o_obs)
+        assert (d[ok].max(axis=1) < 40 * tol).all(), (step, d[ok].max())
+        # obs_buf is an exact column subset of states_buf (same kernel values)
+        from isaacgymenvs_amd.tasks.shadow_hand import obs_columns
+        np.testing.assert_array_equal(obs, st[:, obs_columns(obs_type)])
+    assert forced > 0
+    assert float(obs_d["states"].abs().max()) <= env.clip_obs + 1e-6
+
+
 def test_shadow_hand_full_size_properties():
     n = 2048   # BASELINE configs[4]: ShadowHand 16384 envs over 8 GPUs = 2048 per GPU
     env = _make_env("ShadowHand", n, seed=42)
