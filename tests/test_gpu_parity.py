@@ -673,3 +673,24 @@ def test_api_contract_and_state_checkpoint():
     # writes through the views reach the simulator (gymtorch.wrap_tensor semantics, ant.py:260-261)
     env.dof_pos[3] = 0.0
     assert float(env.dof_state[3, :, 0].abs().max()) == 0.0
+
+
+def test_rlgames_adapter_surface():
+    """RLGPUEnv pass-through (rlgames_utils.py:242-295): info dict, agents, state checkpoint hooks, step/reset types."""
+    from isaacgymenvs_amd.utils.config import compose as _compose, omegaconf_to_dict
+    from isaacgymenvs_amd.utils.rlgames_utils import RLGPUEnv, get_rlgames_env_creator
+    cfg = omegaconf_to_dict(_compose(overrides=["task=Cartpole"])["task"])
+    cfg["env"]["numEnvs"] = 64
+    creator = get_rlgames_env_creator(seed=3, task_config=cfg, task_name="Cartpole", sim_device=DEV, rl_device=DEV, headless=True)
+    venv = RLGPUEnv(env_creator=creator)
+    info = venv.get_env_info()
+    assert info["action_space"].shape == (1,) and info["observation_space"].shape == (4,) and "state_space" not in info
+    assert venv.get_number_of_agents() == 1
+    obs = venv.reset()
+    assert obs["obs"].shape == (64, 4)
+    o, r, d, ex = venv.step(torch.zeros((64, 1), device=DEV))
+    assert r.shape == (64,) and d.dtype == torch.int64 and "time_outs" in ex
+    venv.set_train_info(1000)
+    st = venv.get_env_state()
+    venv.set_env_state(st)
+    assert venv.reset_done()[0]["obs"].shape == (64, 4)
