@@ -98,6 +98,20 @@ typedef struct {
     float clip_actions;
 } MiAnymalFlatParams;
 
+/* task parameters of Quadcopter (quadcopter.py:45-101, 203-240): constants the reference hard-codes in the task file */
+typedef struct {
+    float max_episode_length;            /* env.maxEpisodeLength */
+    float dt;                            /* sim.dt */
+    float dof_lower[8], dof_upper[8];    /* rotor joint limits of the generated asset (+-30 degrees) */
+    float max_thrust;                    /* 2 (quadcopter.py:88) */
+    float dof_action_speed_scale;        /* 8 pi (:283) */
+    float thrust_action_speed_scale;     /* 200 (:287) */
+    float drive_stiffness, drive_damping; /* DOF_MODE_POS drive, 1000 / 0 (:236-238) */
+    float max_angular_velocity;          /* asset option, 4 pi (:208) */
+    float init_height;                   /* default_pose.p.z = 1 (:226) */
+    float clip_actions;
+} MiQuadcopterParams;
+
 /* scalars of compute_hand_reward (shadow_hand.py:746-756) */
 typedef struct {
     float max_episode_length;
@@ -146,7 +160,7 @@ typedef struct {
 
 /* ---- discovery ------------------------------------------------------------------------------------------- */
 int mi_abi_version(void);
-/* task in {"Cartpole","Ant","Humanoid","AnymalTerrain","ShadowHand","Anymal"}: replaces isaacgym_task_map lookup (isaacgymenvs/tasks/__init__.py:88-114)
+/* task in {"Cartpole","Ant","Humanoid","AnymalTerrain","ShadowHand","Anymal","Quadcopter"}: replaces isaacgym_task_map lookup (isaacgymenvs/tasks/__init__.py:88-114)
  * + gym.get_asset_{dof,rigid_body}_count (ant.py:155-156) */
 int mi_task_info(const char* task, MiTaskInfo* out);
 size_t mi_engine_arena_bytes(const char* task, int num_envs);
@@ -212,6 +226,11 @@ int mi_compute_cartpole_reward(int n, const MiCartpoleParams* p, const float* po
                                const float* cart_vel, const float* cart_pos, const int64_t* reset_buf_in,
                                const int64_t* progress_buf, float* rew_buf, int64_t* reset_buf_out, void* stream);
 
+/* compute_quadcopter_reward (quadcopter.py:348-386): root_positions / root_linvels / root_angvels [n,3], root_quats [n,4]
+ * (xyzw), reset_buf / progress_buf int64 [n] -> reward [n], reset int64 [n] */
+int mi_compute_quadcopter_reward(int n, const float* root_positions, const float* root_quats, const float* root_linvels,
+                                 const float* root_angvels, const int64_t* reset_buf_in, const int64_t* progress_buf,
+                                 float max_episode_length, float* rew_buf, int64_t* reset_buf_out, void* stream);
 /* compute_anymal_observations (anymal.py:354-386): root_states [n,13], commands [n,3], dof_pos / dof_vel / actions
  * [n,12] -> obs [n,48].  gravity_vec is the constant (0,0,-1) of anymal.py:143; default_dof_pos and the scales come
  * from p. */

@@ -1,0 +1,38 @@
+"""Robot descriptions the reference builds in code instead of loading from its asset tree.
+
+quadcopter_mjcf(): the MJCF document `Quadcopter._create_quadcopter_asset` writes to ./quadcopter.xml before loading it
+(reference isaacgymenvs/tasks/quadcopter.py:119-198): a cylindrical chassis with a free joint and four rotor arms at
+45/135/225/315 degrees, each arm a small sphere body with a pitch hinge (axis y) carrying a rotor cylinder with a roll
+hinge (axis x), both limited to +-30 degrees.  Same dimensions, densities, names and element order (=> same body / dof
+order: chassis, rotor_arm0, rotor0, rotor_arm1, ...; rotor_pitch0, rotor_roll0, rotor_pitch1, ...).
+"""
+from __future__ import annotations
+
+import math
+
+
+def quadcopter_mjcf() -> str:
+    chassis_radius, chassis_thickness = 0.1, 0.03                    # quadcopter.py:121-125
+    rotor_radius, rotor_thickness, rotor_arm_radius = 0.04, 0.01, 0.01
+    arm_offset = chassis_radius + 0.25 * rotor_arm_radius           # :146, along the arm's own x axis
+    rotor_offset = rotor_radius + 0.25 * rotor_arm_radius           # :149
+    out = ['<mujoco model="Quadcopter">',
+           '  <compiler angle="degree" coordinate="local" inertiafromgeom="true"/>',
+           '  <worldbody>',
+           '    <body name="chassis" pos="0 0 0">',
+           f'      <geom type="cylinder" size="{chassis_radius:g} {0.5 * chassis_thickness:g}" pos="0 0 0" density="50"/>',
+           '      <joint name="root_joint" type="free"/>']
+    for i, angle in enumerate((0.25 * math.pi, 0.75 * math.pi, 1.25 * math.pi, 1.75 * math.pi)):   # :151
+        # Quat.from_axis_angle(z, angle) and the arm offset rotated by it (:155-156)
+        qw, qz = math.cos(0.5 * angle), math.sin(0.5 * angle)
+        px, py = arm_offset * math.cos(angle), arm_offset * math.sin(angle)
+        out += [f'      <body name="rotor_arm{i}" pos="{px:g} {py:g} 0" quat="{qw:g} 0 0 {qz:g}">',
+                f'        <geom type="sphere" size="{rotor_arm_radius:g}" density="200"/>',
+                f'        <joint name="rotor_pitch{i}" type="hinge" pos="0 0 0" axis="0 1 0" limited="true" range="-30 30"/>',
+                f'        <body name="rotor{i}" pos="{rotor_offset:g} 0 0" quat="1 0 0 0">',
+                f'          <geom type="cylinder" size="{rotor_radius:g} {0.5 * rotor_thickness:g}" density="1000"/>',
+                f'          <joint name="rotor_roll{i}" type="hinge" pos="0 0 0" axis="1 0 0" limited="true" range="-30 30"/>',
+                '        </body>',
+                '      </body>']
+    out += ['    </body>', '  </worldbody>', '</mujoco>']
+    return "\n".join(out) + "\n"

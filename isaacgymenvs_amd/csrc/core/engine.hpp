@@ -180,6 +180,14 @@ MI_HD void spi_mul(const SpI& I, const float* X, float* F) {
 // into a triangle mesh (anymal_terrain.py:569-575, each cell split along the (i,j)-(i+1,j+1) diagonal; vertex (i,j) at
 // world (i*hscale - border, j*hscale - border, h*vscale), :208-210); the surface queried here is exactly that
 // piecewise-linear mesh (without the slope-threshold vertex correction), read straight from the int16 grid.
+// Optional extras of a sub-step (nullptr = none: every call site that passes nullptr compiles to exactly the code it had
+// before this existed, the branches below fold away after inlining).
+struct Drive {
+    float kp, kd;          // implicit PD position drive on every dof (gym DOF_MODE_POS: stiffness, damping)
+    const float* target;   // [ND] position targets (gym.set_dof_position_target_tensor)
+    const float* fsens;    // [NSENS][3] external force at the centre of mass of each force-sensor body, in that body's own
+                           // frame (gym.apply_rigid_body_force_tensors(..., LOCAL_SPACE)), or nullptr
+};
 struct PlaneGround {
     static constexpr bool HEIGHTFIELD = false;
     static constexpr bool NETF = false;   // per-body net contact forces (gym.acquire_net_contact_force_tensor) not wanted
@@ -536,7 +544,7 @@ struct Sim {
     template <int RS, class GND>
     MI_HD void substep(const SimParams& P, const float* tau, const float h, const RowStore<RS> rows, const Strided lamc,
                        const Strided laml, const Strided sensor, const Strided dof_force, const GND& gnd, const float mu_env,
-                       const Strided netf) {
+                       const Strided netf, const Drive* drv = nullptr) {
         // static store: row r at r*MAXCHAIN; compact store: only the limit rows (r < NLIM) live at fixed, tightly packed places
         auto G = [&](int row, int c) MI_LAMBDA -> float& { return rows(COMPACT ? limoff(row) + c : row * M::MAXCHAIN + c); };
         auto Ainv = [&](int row) MI_LAMBDA -> float& { return rows(COMPACT ? C_LIMG + row : NROWG * M::MAXCHAIN + row); };
@@ -592,7 +600,29 @@ struct Sim {
             constexpr float K = M::dof_stiffness[d], Dm = M::dof_damping[d];
             L[M::midx[gi][gi]] += M::dof_armature[d] + h * Dm + h * h * K;
             y[gi] = tau[d] - c.bias[gi] - K * (q[d] - M::dof_springref[d]) - (Dm + h * K) * qd[d];
+            if (drv) {   // position drive: the same implicit linearisation as the passive spring / damper
+                L[M::midx[gi][gi]] += h * drv->kd + h * h * drv->kp;
+                y[gi] += drv->kp * (drv->target[d] - q[d]) - (drv->kd + h * drv->kp) * qd[d];
+            }
         });
+        if (drv && drv->fsens) {   // generalised force J^T f of the externally forced bodies (chain-sparse, like a contact row)
+            sfor<NSENS>([&](auto K_) MI_LAMBDA {
+                constexpr int k = K_, b = M::sens_body[k];
+                const float fl[3] = {drv->fsens[3 * k], drv->fsens[3 * k + 1], drv->fsens[3 * k + 2]};
+                float fw[3], cm[3], W[6];
+                matvec3(c.Rs[k], fl, fw);
+                matvec3(c.Rs[k], M::com[b], cm);
+                sfor<3>([&](auto I_) MI_LAMBDA { cm[I_] += c.rs[k][I_]; });
+                cross3(cm, fw, W);
+                W[3] = fw[0]; W[4] = fw[1]; W[5] = fw[2];
+                sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA {
+                    constexpr int gi = M::chain[b][C];
+                    if constexpr (gi >= OFF) y[gi] += dot6(S[gi - OFF], W);
+                    else if constexpr (gi < 3) y[gi] += W[3 + gi];
+                    else y[gi] += W[gi - 3];
+                });
+            });
+        }
         MI_PHASE();
         // ------------------------------------------------------------ H = L^T L in place (no fill-in on a tree)
         sfor_rev<NV>([&](auto K_) MI_LAMBDA {
@@ -1072,7 +1102,9 @@ struct Sim {
                 ll = (dl < du) ? lam(row) : -lam(row);
             }
             laml(d) = ll;
-            dof_force(d) = tau[d] - M::dof_stiffness[d] * (q[d] - M::dof_springref[d]) - M::dof_damping[d] * v[OFF + d] + ll * invh;
+            float df = tau[d] - M::dof_stiffness[d] * (q[d] - M::dof_springref[d]) - M::dof_damping[d] * v[OFF + d] + ll * invh;
+            if (drv) df += drv->kp * (drv->target[d] - q[d]) - drv->kd * v[OFF + d];
+            dof_force(d) = df;
         });
         float sens[6 * M::NSENSA];
         sfor<6 * NSENS>([&](auto K) MI_LAMBDA { sens[K] = 0.f; });

@@ -16,6 +16,8 @@
 #include "gen/model_anymal.h"
 #include "gen/model_shadow_hand.h"
 #include "tasks/anymal.hpp"
+#include "gen/model_quadcopter.h"
+#include "tasks/quadcopter.hpp"
 #include "tasks/shadow_hand.hpp"
 
 using namespace mi;
@@ -26,6 +28,7 @@ static_assert(sizeof(MiCartpoleParams) == sizeof(CartpoleParams), "MiCartpolePar
 static_assert(MI_MAX_DOF == mi::kMaxDof, "MI_MAX_DOF");
 static_assert(sizeof(MiAnymalParams) == sizeof(AnymalParams), "MiAnymalParams layout");
 static_assert(sizeof(MiAnymalFlatParams) == sizeof(AnymalFlatParams), "MiAnymalFlatParams layout");
+static_assert(sizeof(MiQuadcopterParams) == sizeof(QuadcopterParams), "MiQuadcopterParams layout");
 static_assert(sizeof(MiHandRewardParams) == sizeof(HandRewardParams), "MiHandRewardParams layout");
 static_assert(sizeof(MiHandParams) == sizeof(HandParams), "MiHandParams layout");
 
@@ -193,6 +196,15 @@ hipError_t launch_anymal_obs(int n, const AnymalFlatParams& p, const float* root
 hipError_t launch_anymal_reward(int n, const AnymalFlatParams& p, const float* root_states, const float* commands, const float* torques,
                                 const float* contact_forces, int num_bodies, const long long* episode_lengths, float* rew,
                                 long long* reset, hipStream_t s);
+struct QuadView { float* targets; float* thrusts; float* forces; };
+hipError_t launch_step_quadcopter(const View& v, const QuadView& qv, const SimParams& P, const QuadcopterParams& p, const float* actions,
+                                  int cfi, hipStream_t s);
+hipError_t launch_simulate_quadcopter(const View& v, const QuadView& qv, const SimParams& P, const QuadcopterParams& p, hipStream_t s);
+hipError_t launch_init_quadcopter(const View& v, const QuadView& qv, const QuadcopterParams& p, hipStream_t s);
+hipError_t launch_reset_quadcopter(const View& v, const QuadView& qv, const QuadcopterParams& p, const long long* ids, int n, hipStream_t s);
+hipError_t launch_quadcopter_reward(int n, const float* root_positions, const float* root_quats, const float* root_linvels,
+                                    const float* root_angvels, const long long* progress_buf, float max_episode_length, float* rew,
+                                    long long* reset, hipStream_t s);
 struct HandView {
     float* cur_targets; float* prev_targets; float* object_state; float* goal_state; float* fingertip; float* successes;
     long long* reset_goal; int* goal_count; float* cons; float* ws; int* ncontact;
@@ -204,8 +216,8 @@ hipError_t launch_simulate_shadow_hand(const View& v, const HandView& hv, const 
 hipError_t launch_init_shadow_hand(const View& v, const HandView& hv, const HandParams& p, hipStream_t s);
 hipError_t launch_reset_shadow_hand(const View& v, const HandView& hv, const HandParams& p, const long long* ids, int n, hipStream_t s);
 }
-enum TaskId { T_CARTPOLE = 0, T_ANT = 1, T_HUMANOID = 2, T_ANYMAL = 3, T_SHADOWHAND = 4, T_ANYMAL_FLAT = 5 };
-constexpr int kNumTasks = 6;
+enum TaskId { T_CARTPOLE = 0, T_ANT = 1, T_HUMANOID = 2, T_ANYMAL = 3, T_SHADOWHAND = 4, T_ANYMAL_FLAT = 5, T_QUADCOPTER = 6 };
+constexpr int kNumTasks = 7;
 struct TaskMeta { const char* name; int nobs, nact, nd, nb, nsens, nsph, fixed; size_t pbytes; };
 static const TaskMeta kTasks[] = {
     {"Cartpole", 4, 1, ModelCartpole::ND, ModelCartpole::NB, 0, ModelCartpole::NSPH, 1, sizeof(MiCartpoleParams)},
@@ -214,6 +226,7 @@ static const TaskMeta kTasks[] = {
     {"AnymalTerrain", kAnymalObs, kAnymalDof, ModelAnymal::ND, ModelAnymal::NB, 0, ModelAnymal::NSPH, 0, sizeof(MiAnymalParams)},
     {"ShadowHand", 211, 20, ModelShadowHand::ND, ModelShadowHand::NB, ModelShadowHand::NSENS, 0, 1, sizeof(MiHandParams)},
     {"Anymal", kAnymalFlatObs, kAnymalDof, ModelAnymal::ND, ModelAnymal::NB, 0, ModelAnymal::NSPH, 0, sizeof(MiAnymalFlatParams)},
+    {"Quadcopter", kQuadObs, kQuadAct, ModelQuadcopter::ND, ModelQuadcopter::NB, ModelQuadcopter::NSENS, ModelQuadcopter::NSPH, 0, sizeof(MiQuadcopterParams)},
 };
 static int find_task(const char* t) {
     for (int i = 0; i < kNumTasks; ++i) if (!strcmp(t, kTasks[i].name)) return i;
@@ -227,6 +240,8 @@ struct MiEngine {
     CartpoleParams cart;
     AnymalParams anymal;
     AnymalFlatParams anymal_flat;
+    QuadcopterParams quad;
+    QuadView qv;
     AnymalTerrainDesc terrain;
     HandParams hand;
     HandView hv;
@@ -308,6 +323,16 @@ static void build_layout(int task, int N, Layout& L, View* v, char* base, int no
     }
     L.off = (L.off + 255) & ~size_t(255);
 }
+// Quadcopter extras (quadcopter.py:90-97)
+static void build_quad_layout(int N, Layout& L, QuadView* qv, char* base) {
+    const int64_t n = N;
+    auto P = [&](size_t o) { return base ? base + o : (char*)nullptr; };
+    size_t o;
+    o = L.add("dof_position_targets", MI_F32, {n, 8}, {1, n}, 8 * n); if (qv) qv->targets = (float*)P(o);
+    o = L.add("thrusts", MI_F32, {n, 4}, {1, n}, 4 * n); if (qv) qv->thrusts = (float*)P(o);
+    o = L.add("forces", MI_F32, {n, 9, 3}, {1, 3 * n, n}, 27 * n); if (qv) qv->forces = (float*)P(o);
+    L.off = (L.off + 255) & ~size_t(255);
+}
 // ShadowHand extras (shadow_hand.py:150-222): object / goal root states, targets, fingertip body states, success counters
 static void build_hand_layout(int N, Layout& L, HandView* hv, char* base) {
     const int64_t n = N;
@@ -347,6 +372,7 @@ extern "C" size_t mi_engine_arena_bytes(const char* task, int num_envs) {
     Layout L;
     build_layout(t, num_envs, L, nullptr, nullptr);
     if (t == T_SHADOWHAND) build_hand_layout(num_envs, L, nullptr, nullptr);
+    if (t == T_QUADCOPTER) build_quad_layout(num_envs, L, nullptr, nullptr);
     return L.off;
 }
 
@@ -368,6 +394,7 @@ extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const 
     if (t == T_CARTPOLE) memcpy(&e->cart, task_params, sizeof(CartpoleParams));
     else if (t == T_ANYMAL) memcpy(&e->anymal, task_params, sizeof(AnymalParams));
     else if (t == T_ANYMAL_FLAT) memcpy(&e->anymal_flat, task_params, sizeof(AnymalFlatParams));
+    else if (t == T_QUADCOPTER) memcpy(&e->quad, task_params, sizeof(QuadcopterParams));
     else if (t == T_SHADOWHAND) memcpy(&e->hand, task_params, sizeof(HandParams));
     else memcpy(&e->loco, task_params, sizeof(LocoParams));
     Layout L;
@@ -384,6 +411,8 @@ extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const 
     build_layout(t, num_envs, L, &e->v, (char*)arena, nobs);
     memset(&e->hv, 0, sizeof(e->hv));
     if (t == T_SHADOWHAND) build_hand_layout(num_envs, L, &e->hv, (char*)arena);
+    memset(&e->qv, 0, sizeof(e->qv));
+    if (t == T_QUADCOPTER) build_quad_layout(num_envs, L, &e->qv, (char*)arena);
     if (arena_bytes < L.off) { delete e; return fail("mi_engine_create: arena too small"); }
     e->descs = L.d;
     e->v.N = num_envs; e->v.env_offset = env_id_offset; e->v.seed = (uint32_t)(seed ^ (seed >> 32));
@@ -419,6 +448,15 @@ extern "C" int mi_engine_init_state(MiEngine* e, void* stream) {
     float root_z = 0.f, pot0 = 0.f;
     if (e->task == T_SHADOWHAND) {
         HIP_OK(launch_init_shadow_hand(e->v, e->hv, e->hand, s));
+        e->steps = 0;
+        return 0;
+    }
+    if (e->task == T_QUADCOPTER) {
+        const int blocks = (e->N + 255) / 256;
+        hipLaunchKernelGGL(init_state_kernel, dim3(blocks), dim3(256), 0, s, e->v, m.nd, 3 * m.nsph, 6 * m.nsens, m.nobs, m.nact,
+                           e->quad.init_height, (const float*)nullptr, 0.f);
+        HIP_OK(hipGetLastError());
+        HIP_OK(launch_init_quadcopter(e->v, e->qv, e->quad, s));
         e->steps = 0;
         return 0;
     }
@@ -484,6 +522,7 @@ extern "C" int mi_engine_step(MiEngine* e, const float* actions, void* stream) {
             HIP_OK(launch_step_anymal(e->v, e->P, e->anymal, e->terrain, actions, e->control_freq_inv, (unsigned)(e->steps + 1), s));
             break;
         case T_ANYMAL_FLAT: HIP_OK(launch_step_anymal_flat(e->v, e->P, e->anymal_flat, actions, e->control_freq_inv, s)); break;
+        case T_QUADCOPTER: HIP_OK(launch_step_quadcopter(e->v, e->qv, e->P, e->quad, actions, e->control_freq_inv, s)); break;
     }
     e->steps++;
     return 0;
@@ -503,6 +542,7 @@ extern "C" int mi_engine_simulate(MiEngine* e, void* stream) {
             HIP_OK(launch_simulate_anymal(e->v, e->P, e->terrain, s));
             break;
         case T_ANYMAL_FLAT: HIP_OK(launch_simulate_anymal_flat(e->v, e->P, e->anymal_flat, s)); break;
+        case T_QUADCOPTER: HIP_OK(launch_simulate_quadcopter(e->v, e->qv, e->P, e->quad, s)); break;
     }
     return 0;
 }
@@ -519,6 +559,7 @@ extern "C" int mi_engine_reset_idx(MiEngine* e, const int64_t* env_ids, int n, v
         case T_ANYMAL: HIP_OK(launch_reset_anymal(e->v, e->anymal, e->terrain, (const long long*)env_ids, n, s)); break;
         case T_SHADOWHAND: HIP_OK(launch_reset_shadow_hand(e->v, e->hv, e->hand, (const long long*)env_ids, n, s)); break;
         case T_ANYMAL_FLAT: HIP_OK(launch_reset_anymal_flat(e->v, e->anymal_flat, (const long long*)env_ids, n, s)); break;
+        case T_QUADCOPTER: HIP_OK(launch_reset_quadcopter(e->v, e->qv, e->quad, (const long long*)env_ids, n, s)); break;
     }
     return 0;
 }
@@ -597,6 +638,17 @@ extern "C" int mi_compute_cartpole_reward(int n, const MiCartpoleParams* p, cons
     return 0;
 }
 
+extern "C" int mi_compute_quadcopter_reward(int n, const float* root_positions, const float* root_quats, const float* root_linvels,
+                                            const float* root_angvels, const int64_t* reset_buf_in, const int64_t* progress_buf,
+                                            float max_episode_length, float* rew_buf, int64_t* reset_buf_out, void* stream) {
+    if (n <= 0) return 0;
+    (void)reset_buf_in;   // the reference only uses its shape (torch.ones_like / zeros_like, quadcopter.py:376-377)
+    if (!root_positions || !root_quats || !root_linvels || !root_angvels || !progress_buf || !rew_buf || !reset_buf_out)
+        return fail("mi_compute_quadcopter_reward: null argument");
+    HIP_OK(launch_quadcopter_reward(n, root_positions, root_quats, root_linvels, root_angvels, (const long long*)progress_buf,
+                                    max_episode_length, rew_buf, (long long*)reset_buf_out, (hipStream_t)stream));
+    return 0;
+}
 extern "C" int mi_compute_anymal_observations(int n, const MiAnymalFlatParams* p, const float* root_states, const float* commands,
                                               const float* dof_pos, const float* dof_vel, const float* actions, float* obs_buf,
                                               void* stream) {

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("MI_ENGINE_LIB") or os.path.join(_HERE, "libmi_engine.
 CSRC = os.path.join(_HERE, "csrc")
 BUILD_DIR = os.path.join(CSRC, "build")
 # one translation unit per robot model (they compile in parallel) + the C ABI
-SOURCES = ["mi_engine.hip", "kernels_cartpole.hip", "kernels_ant.hip", "kernels_humanoid.hip", "kernels_anymal.hip", "kernels_shadow_hand.hip"]
+SOURCES = ["mi_engine.hip", "kernels_cartpole.hip", "kernels_ant.hip", "kernels_humanoid.hip", "kernels_anymal.hip", "kernels_shadow_hand.hip", "kernels_quadcopter.hip"]
 MI_MAX_DOF = 32
 
 # -fno-slp-vectorize: pairing scalars into v_pk_* ops lengthens live ranges in the fully unrolled sub-step
@@ -78,6 +78,13 @@ class MiAnymalFlatParams(C.Structure):
         ("clip_actions", C.c_float)]
 
 
+class MiQuadcopterParams(C.Structure):
+    _fields_ = [("max_episode_length", C.c_float), ("dt", C.c_float), ("dof_lower", C.c_float * 8), ("dof_upper", C.c_float * 8),
+                ("max_thrust", C.c_float), ("dof_action_speed_scale", C.c_float), ("thrust_action_speed_scale", C.c_float),
+                ("drive_stiffness", C.c_float), ("drive_damping", C.c_float), ("max_angular_velocity", C.c_float),
+                ("init_height", C.c_float), ("clip_actions", C.c_float)]
+
+
 class MiHandRewardParams(C.Structure):
     _fields_ = [("max_episode_length", C.c_float), ("dist_reward_scale", C.c_float), ("rot_reward_scale", C.c_float),
                 ("rot_eps", C.c_float), ("action_penalty_scale", C.c_float), ("success_tolerance", C.c_float),
@@ -114,7 +121,7 @@ EXPORTS = ["mi_abi_version", "mi_task_info", "mi_engine_arena_bytes", "mi_engine
            "mi_engine_reset_idx", "mi_engine_simulate", "mi_engine_set_option", "mi_engine_last_ring", "mi_engine_set_terrain",
            "mi_compute_locomotion_observations", "mi_compute_locomotion_reward", "mi_compute_cartpole_reward",
            "mi_compute_hand_reward", "mi_compute_hand_full_state", "mi_randomize_rotation",
-           "mi_compute_anymal_observations", "mi_compute_anymal_reward",
+           "mi_compute_anymal_observations", "mi_compute_anymal_reward", "mi_compute_quadcopter_reward",
            "mi_last_error"]
 
 
@@ -251,6 +258,7 @@ def lib():
     L.mi_compute_locomotion_observations.argtypes = [C.c_char_p, C.c_int, C.POINTER(MiLocoParams)] + [C.c_void_p] * 18
     L.mi_compute_locomotion_reward.argtypes = [C.c_char_p, C.c_int, C.POINTER(MiLocoParams)] + [C.c_void_p] * 9
     L.mi_compute_cartpole_reward.argtypes = [C.c_int, C.POINTER(MiCartpoleParams)] + [C.c_void_p] * 9
+    L.mi_compute_quadcopter_reward.argtypes = [C.c_int] + [C.c_void_p] * 6 + [C.c_float] + [C.c_void_p] * 3
     L.mi_compute_anymal_observations.argtypes = [C.c_int, C.POINTER(MiAnymalFlatParams)] + [C.c_void_p] * 7
     L.mi_compute_anymal_reward.argtypes = [C.c_int, C.POINTER(MiAnymalFlatParams)] + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4
     L.mi_compute_hand_reward.argtypes = [C.c_int, C.POINTER(MiHandRewardParams)] + [C.c_void_p] * 11 + [C.c_int, C.c_void_p, C.c_void_p]

@@ -4,6 +4,7 @@ from .anymal import Anymal
 from .anymal_terrain import AnymalTerrain
 from .cartpole import Cartpole
 from .humanoid import Humanoid
+from .quadcopter import Quadcopter
 from .shadow_hand import ShadowHand
 
 isaacgym_task_map = {
@@ -12,5 +13,6 @@ isaacgym_task_map = {
     "AnymalTerrain": AnymalTerrain,
     "Cartpole": Cartpole,
     "Humanoid": Humanoid,
+    "Quadcopter": Quadcopter,
     "ShadowHand": ShadowHand,
 }

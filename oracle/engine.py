@@ -143,6 +143,17 @@ class OracleEngine:
                             _ptr(mu) if mu is not None else None, self.N, _ptr(self.state), _ptr(tau), _ptr(self.out),
                             _ptr(self.netf))
 
+    def step_drive(self, tau, kp, kd, target=None, fext_local=None):
+        """One step with implicit PD position drives (DOF_MODE_POS: stiffness kp, damping kd, targets [N, nd]) and external
+        forces at the bodies' centres of mass in their local frames ([N, nb, 3]); plane ground, model friction."""
+        r = self.np_real
+        creal = C.c_double if r == np.float64 else C.c_float
+        tau = np.ascontiguousarray(tau, r).reshape(self.N, self.nd)
+        tg = None if target is None else np.ascontiguousarray(target, r).reshape(self.N, self.nd)
+        fx = None if fext_local is None else np.ascontiguousarray(fext_local, r).reshape(self.N, self.spec.nb * 3)
+        self.lib.or_step_drive(C.byref(self.model), C.byref(self.params), self.N, _ptr(self.state), _ptr(tau), _ptr(self.out),
+                               creal(kp), creal(kd), _ptr(tg) if tg is not None else None, _ptr(fx) if fx is not None else None)
+
     def dynamics(self, env=0):
         nv = self.spec.nv
         M = np.zeros((nv, nv), self.np_real)

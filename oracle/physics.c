@@ -366,8 +366,18 @@ static void point_jac(const OrModel *m, const Work *w, int b, const real *xc, co
  * optional: gnd (height field), mu_env >= 0 (per-env friction replacing the per-sphere model value), netf[3*nb]
  * (net contact force per body, world frame, last sub-step = `contact_collection: 1`, reference AnymalTerrain.yaml:148)
  */
+/* optional per-env extras of a step: implicit PD position drives on every dof (gym DOF_MODE_POS: stiffness kp, damping kd,
+ * targets target[nd]) and external forces fext[3*nb] applied at the bodies' centres of mass, given in each body's LOCAL
+ * frame (gym.apply_rigid_body_force_tensors(..., LOCAL_SPACE), reference quadcopter.py:291-292) */
+typedef struct {
+    real kp, kd;
+    const real *target; /* [nd] or NULL */
+    const real *fext;   /* [3*nb] or NULL */
+} OrExtra;
+
 static void step_env(const OrModel *m, const OrParams *p, const OrGround *gnd, real mu_env, real *root, real *q, real *qd,
-                     real *lam_c, real *lam_l, const real *tau, real *sensor, real *dof_force, real *sph_force, real *netf) {
+                     real *lam_c, real *lam_l, const real *tau, real *sensor, real *dof_force, real *sph_force, real *netf,
+                     const OrExtra *ex) {
     static _Thread_local Work w;
     int nv = nvof(m), off = jo(m), nd = m->nd;
     real h = p->dt / p->substeps;
@@ -381,6 +391,25 @@ static void step_env(const OrModel *m, const OrParams *p, const OrGround *gnd, r
             real K = m->dof_stiffness[d], D = m->dof_damping[d];
             w.M[off + d][off + d] += m->dof_armature[d] + h * D + h * h * K;
             rhs[off + d] = tau[d] - w.bias[off + d] - K * (q[d] - m->dof_springref[d]) - (D + h * K) * qd[d];
+            if (ex && ex->target) {   /* implicit PD drive: same linearisation as the passive spring/damper */
+                w.M[off + d][off + d] += h * ex->kd + h * h * ex->kp;
+                rhs[off + d] += ex->kp * (ex->target[d] - q[d]) - (ex->kd + h * ex->kp) * qd[d];
+            }
+        }
+        if (ex && ex->fext) {         /* generalised force J^T f of every externally forced body */
+            for (int b = 0; b < m->nb; b++) {
+                const real *fl = ex->fext + 3 * b;
+                if (fl[0] == 0 && fl[1] == 0 && fl[2] == 0) continue;
+                real fw[3], cw[3], xc[3], Jr[MAXV];
+                m3v(w.R[b], fl, fw);
+                m3v(w.R[b], m->com + 3 * b, cw);
+                for (int k = 0; k < 3; k++) xc[k] = w.r[b][k] + cw[k];
+                const real dirs[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+                for (int k = 0; k < 3; k++) {
+                    point_jac(m, &w, b, xc, dirs[k], Jr);
+                    for (int i = 0; i < nv; i++) rhs[i] += Jr[i] * fw[k];
+                }
+            }
         }
         chol(nv, w.M, w.L);
         chol_solve(nv, w.L, rhs, dv);
@@ -489,6 +518,7 @@ static void step_env(const OrModel *m, const OrParams *p, const OrGround *gnd, r
             real ll = 0;
             if (lim_row[d] >= 0) { ll = lam[lim_row[d]] * lim_sign[d]; lam_l[d] = ll; }
             dof_force[d] = tau[d] - m->dof_stiffness[d] * (q[d] - m->dof_springref[d]) - m->dof_damping[d] * v[off + d] + ll / h;
+            if (ex && ex->target) dof_force[d] += ex->kp * (ex->target[d] - q[d]) - ex->kd * v[off + d];
         }
         for (int k = 0; k < 6 * m->nsens; k++) sensor[k] = 0;
         if (netf) for (int k = 0; k < 3 * m->nb; k++) netf[k] = 0;
@@ -552,7 +582,7 @@ void or_step(const OrModel *m, const OrParams *p, int nenv, real *state, const r
     for (int e = 0; e < nenv; e++) {
         real *s = state + (size_t)e * ss, *o = out + (size_t)e * os;
         step_env(m, p, 0, (real)-1, s, s + 13, s + 13 + nd, s + 13 + 2 * nd, s + 13 + 2 * nd + 3 * m->nsph, tau + (size_t)e * nd, o,
-                 o + 6 * m->nsens, o + 6 * m->nsens + nd, 0);
+                 o + 6 * m->nsens, o + 6 * m->nsens + nd, 0, 0);
     }
 }
 
@@ -566,7 +596,21 @@ void or_step_ex(const OrModel *m, const OrParams *p, const OrGround *gnd, const 
         real *s = state + (size_t)e * ss, *o = out + (size_t)e * os;
         step_env(m, p, gnd, env_mu ? env_mu[e] : (real)-1, s, s + 13, s + 13 + nd, s + 13 + 2 * nd,
                  s + 13 + 2 * nd + 3 * m->nsph, tau + (size_t)e * nd, o, o + 6 * m->nsens, o + 6 * m->nsens + nd,
-                 netf ? netf + (size_t)e * 3 * m->nb : 0);
+                 netf ? netf + (size_t)e * 3 * m->nb : 0, 0);
+    }
+}
+
+/* as or_step, with PD position drives (kp, kd, target[nenv][nd]; target may be NULL) and local-frame external body forces
+ * fext[nenv][3*nb] (may be NULL) */
+void or_step_drive(const OrModel *m, const OrParams *p, int nenv, real *state, const real *tau, real *out, real kp, real kd,
+                   const real *target, const real *fext) {
+    int ss = or_state_size(m), os = or_out_size(m), nd = m->nd;
+#pragma omp parallel for schedule(static)
+    for (int e = 0; e < nenv; e++) {
+        real *s = state + (size_t)e * ss, *o = out + (size_t)e * os;
+        OrExtra ex = {kp, kd, target ? target + (size_t)e * nd : 0, fext ? fext + (size_t)e * 3 * m->nb : 0};
+        step_env(m, p, 0, (real)-1, s, s + 13, s + 13 + nd, s + 13 + 2 * nd, s + 13 + 2 * nd + 3 * m->nsph, tau + (size_t)e * nd, o,
+                 o + 6 * m->nsens, o + 6 * m->nsens + nd, 0, &ex);
     }
 }
 

@@ -694,6 +694,106 @@ class OracleAnymalEnv:
         return self.obs_buf, self.rew_buf, self.reset_buf
 
 
+# ===================================================================================================== Quadcopter
+def quat_axis(q, axis):  # torch_jit_utils.py:113-116
+    basis = np.zeros((q.shape[0], 3), f32); basis[:, axis] = 1
+    return quat_rotate(q, basis)
+
+
+def compute_quadcopter_reward(root_positions, root_quats, root_linvels, root_angvels, reset_buf, progress_buf, max_episode_length):
+    """quadcopter.py:348-386"""
+    rp = root_positions.astype(f32)
+    target_dist = np.sqrt(rp[..., 0] * rp[..., 0] + rp[..., 1] * rp[..., 1] + (f32(1) - rp[..., 2]) * (f32(1) - rp[..., 2])).astype(f32)
+    pos_reward = f32(1.0) / (f32(1.0) + target_dist * target_dist)
+    ups = quat_axis(root_quats.astype(f32), 2)
+    tiltage = np.abs(f32(1) - ups[..., 2])
+    up_reward = f32(1.0) / (f32(1.0) + tiltage * tiltage)
+    spinnage = np.abs(root_angvels.astype(f32)[..., 2])
+    spinnage_reward = f32(1.0) / (f32(1.0) + spinnage * spinnage)
+    reward = (pos_reward + pos_reward * (up_reward + spinnage_reward)).astype(f32)
+    ones, die = np.ones_like(reset_buf), np.zeros_like(reset_buf)
+    die = np.where(target_dist > f32(3.0), ones, die)
+    die = np.where(rp[..., 2] < f32(0.3), ones, die)
+    reset = np.where(progress_buf >= max_episode_length - 1, ones, die)
+    return reward, reset
+
+
+class OracleQuadcopterEnv:
+    """vec_task.py:360-408 + quadcopter.py pre/post_physics_step on oracle/physics.c (or_step_drive: implicit PD position
+    drives on the rotor joints, thrust forces on the rotor bodies in their local frames, no contacts)."""
+
+    def __init__(self, spec, sensor_bodies, sim_params: dict, params, num_envs, seed=0, env_id_offset=0, precision="f64", control_freq_inv=1):
+        from .engine import OracleEngine
+        self.N, self.p, self.nd, self.spec = num_envs, params, spec.nd, spec
+        self.substeps = int(sim_params.get("substeps", 2))
+        sp = dict(sim_params, dt=sim_params["dt"] / self.substeps, substeps=1)   # one call per sub-step (angular-velocity clamp)
+        self.eng = OracleEngine(spec, num_envs, params=sp, sensor_bodies=sensor_bodies, precision=precision)
+        self.rotors = list(sensor_bodies)
+        self.seed, self.off, self.cfi = fold_seed(seed), env_id_offset, control_freq_inv
+        self.genv = (self.off + np.arange(num_envs)).astype(np.uint32)
+        N = num_envs
+        self.eng.root[:, 2] = params.init_height
+        self.targets = np.zeros((N, 8), f32)
+        self.thrusts = np.zeros((N, 4), f32)
+        self.forces = np.zeros((N, spec.nb, 3), f32)
+        self.progress_buf = np.zeros(N, np.int64)
+        self.reset_buf = np.ones(N, np.int64)
+        self.episode = np.zeros(N, np.uint32)
+        self.lo, self.up = np.array(params.dof_lower[:], f32), np.array(params.dof_upper[:], f32)
+
+    def reset_idx(self, ids):  # quadcopter.py:254-274
+        if len(ids) == 0:
+            return
+        g, ep = self.genv[ids], self.episode[ids]
+        root = np.zeros((len(ids), 13), f32); root[:, 2] = f32(self.p.init_height); root[:, 6] = 1
+        root[:, 0] += (f32(1.5) - f32(-1.5)) * mi_uniform(self.seed, g, ep, 0) + f32(-1.5)
+        root[:, 1] += (f32(1.5) - f32(-1.5)) * mi_uniform(self.seed, g, ep, 1) + f32(-1.5)
+        root[:, 2] += (f32(1.5) - f32(-0.2)) * mi_uniform(self.seed, g, ep, 2) + f32(-0.2)
+        self.eng.root[ids] = root
+        k = np.arange(8, dtype=np.uint32)[None, :] + np.uint32(3)
+        self.eng.q[ids] = (f32(0.2) - f32(-0.2)) * mi_uniform(self.seed, g[:, None], ep[:, None], k) + f32(-0.2)
+        self.eng.qd[ids] = 0
+        self.eng.lam[ids] = 0
+        self.episode[ids] += 1
+        self.reset_buf[ids] = 0
+        self.progress_buf[ids] = 0
+
+    def step(self, actions):
+        p = self.p
+        ids = np.nonzero(self.reset_buf)[0]                                        # :279-281
+        self.reset_idx(ids)
+        a = np.clip(actions.astype(f32), -f32(p.clip_actions), f32(p.clip_actions))
+        self.targets = self.targets + f32(p.dt) * f32(p.dof_action_speed_scale) * a[:, 0:8]
+        self.targets = np.maximum(np.minimum(self.targets, self.up), self.lo).astype(f32)
+        self.thrusts = self.thrusts + f32(p.dt) * f32(p.thrust_action_speed_scale) * a[:, 8:12]
+        self.thrusts = np.maximum(np.minimum(self.thrusts, f32(p.max_thrust)), f32(0)).astype(f32)
+        self.forces[:] = 0
+        self.forces[:, self.rotors, 2] = self.thrusts
+        self.thrusts[ids] = 0                                                       # :294-297
+        self.forces[ids] = 0
+        self.targets[ids] = self.eng.q[ids].astype(f32)
+        wmax = float(p.max_angular_velocity)
+        for _ in range(self.cfi * self.substeps):
+            self.eng.step_drive(np.zeros((self.N, self.nd)), p.drive_stiffness, p.drive_damping, self.targets, self.forces)
+            w = self.eng.root[:, 10:13]
+            n = np.linalg.norm(w, axis=1)
+            big = n > wmax
+            w[big] *= (wmax / n[big])[:, None]
+        # post_physics_step (:294-302)
+        self.progress_buf += 1
+        root, q = self.eng.root.astype(f32), self.eng.q.astype(f32)
+        obs = np.zeros((self.N, 21), f32)
+        obs[:, 0] = (f32(0.0) - root[:, 0]) / f32(3); obs[:, 1] = (f32(0.0) - root[:, 1]) / f32(3); obs[:, 2] = (f32(1.0) - root[:, 2]) / f32(3)
+        obs[:, 3:7] = root[:, 3:7]
+        obs[:, 7:10] = root[:, 7:10] / f32(2)
+        obs[:, 10:13] = root[:, 10:13] / f32(np.pi)
+        obs[:, 13:21] = q
+        self.obs_buf = obs
+        self.rew_buf, self.reset_buf = compute_quadcopter_reward(root[:, 0:3], root[:, 3:7], root[:, 7:10], root[:, 10:13], self.reset_buf,
+                                                                  self.progress_buf, f32(p.max_episode_length))
+        return self.obs_buf, self.rew_buf, self.reset_buf
+
+
 def quat_conjugate(a):  # torch_jit_utils.py:107-110
     return np.concatenate([-a[:, :3], a[:, 3:4]], axis=-1).astype(f32)
 

@@ -6,6 +6,7 @@
 #include "../../isaacgymenvs_amd/csrc/gen/model_cartpole.h"
 #include "../../isaacgymenvs_amd/csrc/gen/model_ant.h"
 #include "../../isaacgymenvs_amd/csrc/gen/model_anymal.h"
+#include "../../isaacgymenvs_amd/csrc/gen/model_quadcopter.h"
 #ifdef HOSTSIM_HAND
 #include "../../isaacgymenvs_amd/csrc/core/hand_engine.hpp"
 #include "../../isaacgymenvs_amd/csrc/gen/model_shadow_hand.h"
@@ -42,6 +43,32 @@ extern "C" int hs_step(const char* model, const SimParams* P, int nenv, float* s
     else if (!strcmp(model, "humanoid")) run<ModelHumanoid>(P, nenv, state, tau, out);
 #endif
     else return -1;
+    return 0;
+}
+
+// PD position drives + local-frame forces on the sensor bodies (Quadcopter): target[nenv][ND], fsens[nenv][NSENS][3]
+extern "C" int hs_step_drive(const char* model, const SimParams* P, int nenv, float* state, float* out, float kp, float kd,
+                             const float* target, const float* fsens) {
+    if (strcmp(model, "quadcopter")) return -1;
+    using M = ModelQuadcopter;
+    constexpr int ND = M::ND, NSPH = M::NSPH, NSENS = M::NSENS;
+    const int ss = 13 + 2 * ND + 3 * NSPH + ND, os = 6 * NSENS + ND + 3 * NSPH;
+#pragma omp parallel for schedule(static)
+    for (int e = 0; e < nenv; ++e) {
+        float* s = state + (size_t)e * ss;
+        float* o = out + (size_t)e * os;
+        Sim<M> sim;
+        for (int k = 0; k < 13; ++k) sim.root[k] = s[k];
+        for (int k = 0; k < ND; ++k) { sim.q[k] = s[13 + k]; sim.qd[k] = s[13 + ND + k]; }
+        const Drive drv{kp, kd, target + (size_t)e * ND, fsens ? fsens + (size_t)e * 3 * NSENS : nullptr};
+        float tau[ND] = {0}, rows[Sim<M>::ROW_SLOTS > 0 ? Sim<M>::ROW_SLOTS : 1];
+        const float h = P->dt / (float)P->substeps;
+        for (int it = 0; it < P->substeps; ++it)
+            sim.substep(*P, tau, h, RowStore<1>{rows}, Strided{s + 13 + 2 * ND, 1}, Strided{s + 13 + 2 * ND + 3 * NSPH, 1}, Strided{o, 1},
+                        Strided{o + 6 * NSENS, 1}, PlaneGround{}, -1.f, Strided{nullptr, 1}, &drv);
+        for (int k = 0; k < 13; ++k) s[k] = sim.root[k];
+        for (int k = 0; k < ND; ++k) { s[13 + k] = sim.q[k]; s[13 + ND + k] = sim.qd[k]; }
+    }
     return 0;
 }
 

@@ -144,3 +144,46 @@ def test_host_build_of_hand_engine_matches_oracle():
         np.testing.assert_allclose(state[:, 4 * nd:4 * nd + 7], orc.obj[:, 0:7], atol=5e-3)
     assert total > 0, "scenario never produced finger/cube contacts"
     assert np.isfinite(state).all()
+
+
+def test_host_build_with_position_drives_and_body_forces_matches_oracle():
+    """Quadcopter model: implicit PD position drives (kp 1000) on the rotor joints + thrust forces on the rotor bodies in
+    their local frames (engine.hpp Drive) against oracle/physics.c or_step_drive; free flight, no contacts."""
+    import ctypes as C
+    lib = hostsim.build()
+    spec = load_model("quadcopter")
+    sens = sensor_bodies("quadcopter")
+    sim = dict(dt=0.01, substeps=2, iters=4, gravity=(0.0, 0.0, -9.81), contact_offset=0.02, rest_offset=0.001,
+               max_depen_vel=1000.0, erp=0.2, plane_mu=1.0, ground_z=0.0, cfm=1e-6, warm=0.9)
+    N, nd = 16, spec.nd
+    rng = np.random.default_rng(11)
+    orc = OracleEngine(spec, N, params=sim, sensor_bodies=sens, precision="f64")
+    orc.root[:, 2] = 1.0 + rng.uniform(-0.2, 0.5, N)
+    qn = rng.normal(size=(N, 4)); qn[:, 3] += 4; orc.root[:, 3:7] = qn / np.linalg.norm(qn, axis=1, keepdims=True)
+    orc.root[:, 7:13] = rng.normal(0, 0.5, (N, 6))
+    orc.q[:] = rng.uniform(-0.2, 0.2, (N, nd))
+    state = np.ascontiguousarray(orc.state, np.float32)
+    out = np.zeros((N, orc.os), np.float32)
+    P = hostsim.make_params(sim)
+    lo, up = np.minimum(spec.dof_lower, spec.dof_upper), np.maximum(spec.dof_lower, spec.dof_upper)
+    assert np.allclose(up, np.deg2rad(30)) and np.allclose(lo, -np.deg2rad(30))
+    for it in range(40):
+        target = rng.uniform(lo, up, (N, nd))
+        thrust = rng.uniform(0.0, 2.0, (N, 4))
+        fext = np.zeros((N, spec.nb, 3)); fext[:, sens, 2] = thrust
+        fs = np.zeros((N, 4, 3), np.float32); fs[:, :, 2] = thrust
+        tg = np.ascontiguousarray(target, np.float32)
+        orc.step_drive(np.zeros((N, nd)), 1000.0, 0.0, target, fext)
+        rc = lib.hs_step_drive(b"quadcopter", C.byref(P), N, state.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                               C.c_float(1000.0), C.c_float(0.0), tg.ctypes.data_as(C.c_void_p), fs.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        tol = 2e-4 * (1 + it)
+        np.testing.assert_allclose(state[:, :13], orc.root, atol=tol)
+        np.testing.assert_allclose(state[:, 13:13 + nd], orc.q, atol=tol)
+    # hover check: total thrust = weight along a level craft => no vertical acceleration
+    orc.root[:] = 0; orc.root[:, 2] = 1; orc.root[:, 6] = 1; orc.q[:] = 0; orc.qd[:] = 0
+    w = spec.total_mass() * 9.81 / 4
+    fext = np.zeros((N, spec.nb, 3)); fext[:, sens, 2] = w
+    for _ in range(50):
+        orc.step_drive(np.zeros((N, nd)), 1000.0, 0.0, np.zeros((N, nd)), fext)
+    assert np.abs(orc.root[:, 2] - 1.0).max() < 1e-6 and np.abs(orc.root[:, 7:13]).max() < 1e-6

@@ -479,6 +479,76 @@ def test_anymal_flat_full_size_properties():
     assert resets > 0
 
 
+# ------------------------------------------------------------------ Quadcopter (position drives + thrust forces; reference tasks/quadcopter.py)
+def test_quadcopter_reward_kernel_matches_reference(golden_dir):
+    g = dict(np.load(os.path.join(golden_dir, "quadcopter_reward.npz")))
+    n = g["rew"].shape[0]
+    keep = [_t(g[k]) for k in ("root_positions", "root_quats", "root_linvels", "root_angvels")]
+    ri, pr = _t(g["reset_in"], torch.int64), _t(g["progress"], torch.int64)
+    rew = torch.empty(n, device=DEV)
+    reset = torch.empty(n, device=DEV, dtype=torch.int64)
+    native.check(native.lib().mi_compute_quadcopter_reward(n, keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), keep[3].data_ptr(),
+                                                           ri.data_ptr(), pr.data_ptr(), C.c_float(float(g["scalar_max_episode_length"])),
+                                                           rew.data_ptr(), reset.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(reset.cpu().numpy(), g["reset"])
+    np.testing.assert_allclose(rew.cpu().numpy(), g["rew"], rtol=5e-6, atol=1e-7)
+
+
+def test_quadcopter_step_matches_cpu_restatement():
+    from oracle.tasks import OracleQuadcopterEnv
+    n, seed = 128, 23
+    env = _make_env("Quadcopter", n, seed=seed)
+    orc = OracleQuadcopterEnv(load_model("quadcopter"), sensor_bodies("quadcopter"), _sim_dict(env.sim_params), env._task_params_struct, n,
+                              seed=seed, precision="f64")
+    g = torch.Generator(device="cpu").manual_seed(4)
+    for step in range(40):
+        a = torch.rand((n, 12), generator=g) * 2 - 1
+        a[:, 8:] = a[:, 8:] * 0.5 + 0.4                      # mostly positive thrust rates: the craft climbs, tilts and tumbles
+        obs_d, rew, reset, extras = env.step(a.to(DEV))
+        o_obs, o_rew, o_reset = orc.step(a.numpy())
+        torch.cuda.synchronize()
+        obs = env.obs_buf.cpu().numpy()
+        assert np.isfinite(obs).all()
+        np.testing.assert_allclose(env.dof_position_targets.cpu().numpy(), orc.targets, atol=1e-6)
+        np.testing.assert_allclose(env.thrusts.cpu().numpy(), orc.thrusts, atol=1e-6)
+        np.testing.assert_allclose(env.forces.cpu().numpy(), orc.forces, atol=1e-6)
+        tol = 1e-4 * (1 + step)                               # smooth free flight: fp32 vs fp64 drift only
+        np.testing.assert_allclose(obs, o_obs, atol=tol)
+        np.testing.assert_array_equal(reset.cpu().numpy(), o_reset)
+        np.testing.assert_allclose(rew.cpu().numpy(), o_rew, atol=5 * tol)
+        np.testing.assert_array_equal(env.progress_buf.cpu().numpy(), orc.progress_buf)
+    assert obs_d["obs"].shape == (n, 21)
+
+
+def test_quadcopter_full_size_properties():
+    n = 8192                                                  # cfg/task/Quadcopter.yaml numEnvs
+    env = _make_env("Quadcopter", n, seed=42)
+    g = torch.Generator(device=DEV).manual_seed(42)
+    resets = 0
+    hover = env.spec.total_mass() * 9.81 / 4
+    for step in range(300):
+        a = torch.zeros((n, 12), device=DEV)
+        a[:, :8] = torch.rand((n, 8), device=DEV, generator=g) * 0.4 - 0.2
+        # a crude altitude hold: thrust rate towards the hover thrust, damped by the vertical speed
+        a[:, 8:] = ((hover - env.thrusts) * 2.0 - env.root_linvels[:, 2:3] * 0.5 + (1.0 - env.root_positions[:, 2:3]) * 0.5).clamp(-1, 1)
+        obs_d, rew, reset, extras = env.step(a)
+        resets += int(reset.sum())
+        if step % 50 == 49:
+            assert torch.isfinite(obs_d["obs"]).all() and torch.isfinite(rew).all()
+            assert (rew > 0).all() and (rew <= 3.0 + 1e-5).all()          # pos + pos * (up + spin) <= 3 (quadcopter.py:368)
+            qn = torch.linalg.norm(env.root_quats, dim=-1)
+            assert (qn - 1).abs().max() < 1e-4
+            assert env.root_angvels.norm(dim=-1).max() <= 4 * np.pi + 1e-3  # max_angular_velocity
+            assert (env.thrusts >= 0).all() and (env.thrusts <= 2.0).all()
+            lim = np.deg2rad(30) + 0.02
+            assert env.dof_positions.abs().max() < lim + 0.05
+            # the position drives track their targets
+            assert (env.dof_positions - env.dof_position_targets).abs().median() < 0.02
+    # with the altitude hold most crafts stay inside the 3 m ball for the whole run
+    assert (env.root_positions[:, 2] > 0.3).float().mean() > 0.9
+
+
 # ------------------------------------------------------------------ ShadowHand (hand + cube physics, deferred resets, full_state obs)
 def test_shadow_hand_step_matches_cpu_restatement():
     from isaacgymenvs_amd.registry import load_extras
@@ -578,7 +648,7 @@ def test_shadow_hand_full_size_properties():
 
 
 # ------------------------------------------------------------------ determinism (guards against miscompiled / hazard-prone builds)
-@pytest.mark.parametrize("task,n", [("Cartpole", 256), ("Ant", 1024), ("Humanoid", 1024), ("AnymalTerrain", 1024), ("ShadowHand", 512), ("Anymal", 1024)])
+@pytest.mark.parametrize("task,n", [("Cartpole", 256), ("Ant", 1024), ("Humanoid", 1024), ("AnymalTerrain", 1024), ("ShadowHand", 512), ("Anymal", 1024), ("Quadcopter", 1024)])
 def test_two_engines_same_seed_are_bit_identical(task, n):
     """Two independent engine instances, same seed and actions => bit-identical trajectories.  An earlier build of
     the sub-step (register-spilling regime) returned run-to-run different results on gfx950."""

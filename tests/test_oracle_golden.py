@@ -189,3 +189,15 @@ def test_anymal_flat_observations_and_reward_match_reference(golden_dir):
     # episode_lengths 2497..2500 with max_episode_length 2500: time-out from 2499 on (anymal.py:348)
     quiet = (np.linalg.norm(g["contact_forces"][:4, [0, 2, 5, 8, 11]], axis=-1) <= 1).all(1)
     np.testing.assert_array_equal(reset[:4][quiet], np.array([0, 0, 1, 1])[quiet])
+
+
+# ------------------------------------------------------------------ Quadcopter: the reference's jitted reward (quadcopter.py:348-386)
+def test_quadcopter_reward_matches_reference(golden_dir):
+    g = _load(golden_dir, "quadcopter_reward.npz")
+    rew, reset = T.compute_quadcopter_reward(g["root_positions"], g["root_quats"], g["root_linvels"], g["root_angvels"], g["reset_in"],
+                                             g["progress"], float(g["scalar_max_episode_length"]))
+    np.testing.assert_array_equal(reset, g["reset"])
+    np.testing.assert_allclose(rew, g["rew"], rtol=2e-6, atol=1e-7)
+    # edge rows written by the generator: z = 0.29 dies, 0.3 / 0.31 do not; |x| just above / below 3 m; time-out from 499 on
+    assert g["reset"][0] == 1 and g["reset"][8] == 1 and g["reset"][11] == 1
+    assert list(g["reset"][2:4]) == [1, 1] or g["progress"][2] >= 499

@@ -92,6 +92,14 @@ def hand_extras(asset_root, spec):
                 fingertips=["robot0:ffdistal", "robot0:mfdistal", "robot0:rfdistal", "robot0:lfdistal", "robot0:thdistal"])
 
 
+# robots the reference generates in code (isaacgymenvs_amd/assets/procedural.py restates the generators)
+PROCEDURAL = {
+    # reference quadcopter.py:119-198; the craft is reset below z = 0.3 m (:411) before it can reach the ground plane, so no
+    # contact geometry is generated; thrust is applied at the four rotor bodies (:287-292)
+    "quadcopter": dict(gen="quadcopter_mjcf", collide_body_filter=lambda n: False),
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--asset-root", default="/root/reference/assets")
@@ -108,6 +116,16 @@ def main():
                 full = load_asset(os.path.join(a.asset_root, e["file"]), name=name, fix_base_link=True)   # with collision geoms
                 json.dump(hand_extras(a.asset_root, full), f, indent=1)
         print(f"{name}: nb={spec.nb} nd={spec.nd} nv={spec.nv} nsph={len(spec.sph_body)} mass={spec.total_mass():.4f}")
+    import tempfile
+    from isaacgymenvs_amd.assets import procedural
+    for name, e in PROCEDURAL.items():
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, name + ".xml")
+            with open(path, "w") as f:
+                f.write(getattr(procedural, e["gen"])())
+            spec = load_asset(path, name=name, **{k: v for k, v in e.items() if k != "gen"})
+        spec.save(os.path.join(a.out, name + ".json"))
+        print(f"{name}: nb={spec.nb} nd={spec.nd} nv={spec.nv} nsph={len(spec.sph_body)} mass={spec.total_mass():.4f} bodies={list(spec.body_names)} dofs={list(spec.dof_names)}")
 
 
 if __name__ == "__main__":
