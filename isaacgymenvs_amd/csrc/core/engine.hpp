@@ -269,7 +269,11 @@ struct Sim {
     static constexpr int C_CB = C_LIMG + 3 * NLIM;        // first contact slot (after limit Ainv, vt, lam)
     static constexpr int C_CSZ = 3 * M::MAXCHAIN + 7;     // 3 rows + Ainv x3, vt_n, lam x3
     static constexpr int C_SLOTOF = C_CB + KMAX * C_CSZ;  // [NSPH] slot index of each sphere (-1: inactive), as int bits
-    static constexpr int ROW_SLOTS_COMPACT = C_SLOTOF + NSPH;
+    // [ND][6] joint motion subspaces, parked here by the tree pass for the contact-row build: with S out of the register file
+    // after the tree pass the Humanoid sub-step keeps ~126 fewer values live (it overflows the 512 registers of its lane)
+    static constexpr int C_S = C_SLOTOF + NSPH;
+    static constexpr bool S_IN_ROWS = (size_t)(C_S + 6 * ND) * 32 * sizeof(float) <= 160 * 1024;
+    static constexpr int ROW_SLOTS_COMPACT = C_S + (S_IN_ROWS ? 6 * ND : 0);
     static constexpr int C_WARM_OK = (KMAX * C_CSZ - 3 * NSPH) / C_CSZ - 1;   // last slot whose write cannot reach the staged warm-start values
     static constexpr int ROW_SLOTS = COMPACT ? ROW_SLOTS_COMPACT : ROW_SLOTS_STATIC;
 
@@ -338,6 +342,9 @@ struct Sim {
         // pose_out[(12 * os_slot(b) + i) * pose_stride] during the tree pass (the hand engine points this into LDS)
         float* pose_out = nullptr;
         int pose_stride = 1;
+        // compact-store models: S[d][k] is also written to s_out[(6 * d + k) * s_stride] (row store, C_S) when non-null
+        float* s_out = nullptr;
+        int s_stride = 1;
     };
     // object-contact spheres are grouped by body (generated os_body is non-decreasing)
     static constexpr int os_first(int b) { for (int s = 0; s < M::NOS; ++s) if (M::os_body[s] == b) return s; return 0; }
@@ -399,6 +406,9 @@ struct Sim {
                 rb[0] += a[0] * q[d]; rb[1] += a[1] * q[d]; rb[2] += a[2] * q[d];
                 Sd[0] = Sd[1] = Sd[2] = 0.f;
                 Sd[3] = a[0]; Sd[4] = a[1]; Sd[5] = a[2];
+            }
+            if constexpr (COMPACT && S_IN_ROWS && M::NOS == 0) {
+                if (c.s_out) sfor<6>([&](auto I_) MI_LAMBDA { c.s_out[(6 * d + I_) * c.s_stride] = Sd[I_]; });
             }
         });
         // contact spheres and force sensor riding on this body
@@ -577,6 +587,10 @@ struct Sim {
         }
         MI_STAMP(1);
         // ------------------------------------------------------------ kinematics + dynamics, one depth-first tree pass
+        if constexpr (COMPACT && S_IN_ROWS && M::NOS == 0) {
+            c.s_out = rows.ptr(C_S);
+            c.s_stride = RowStore<RS>::stride;
+        }
         {
             SpI Iroot;
             float Froot[6];
@@ -685,6 +699,21 @@ struct Sim {
             if constexpr (COMPACT) return rows(C_LIMG + 2 * NLIM + row);   // limit rows only
             else if constexpr (LAM_IN_ROWS) return rows(NROWG * M::MAXCHAIN + 2 * NROWG + row);
             else return lam_reg[row];
+        };
+        // the same for the three rows of one contact at once: every L entry and 1/L_ii is fetched once for the three right-hand sides
+        auto chain_solve3 = [&](auto B, float (*g)[M::MAXCHAIN]) MI_LAMBDA {
+            constexpr int b = decltype(B)::value;
+            sfor<M::chain_len[b]>([&](auto K) MI_LAMBDA {
+                constexpr int k = K, i = M::chain[b][k];
+                const float di = Ldi[i];
+                const float z0 = g[0][k] * di, z1 = g[1][k] * di, z2 = g[2][k] * di;
+                g[0][k] = z0; g[1][k] = z1; g[2][k] = z2;
+                sfor<M::chain_len[b] - 1 - k>([&](auto T) MI_LAMBDA {
+                    constexpr int kk = k + 1 + T, j = M::chain[b][kk];
+                    const float l = L[M::midx[i][j]];
+                    g[0][kk] -= l * z0; g[1][kk] -= l * z1; g[2][kk] -= l * z2;
+                });
+            });
         };
         // solve L^T g = J^T restricted to a chain (descending generalized indices), in place in g[]
         auto chain_solve = [&](auto B, float* g) MI_LAMBDA {
@@ -835,30 +864,43 @@ struct Sim {
                 float* cb = rows.ptr(C_CB + j * C_CSZ);
                 constexpr int ST = RowStore<RS>::stride;
                 const float gap = dist - P.rest_offset;
+                // unit forces of the three rows (normal, two tangents) at xc as spatial forces [xc x u; u]
+                float W[3][6];
                 sfor<3>([&](auto K) MI_LAMBDA {
                     constexpr int k = K;
-                    float W[6];
                     if constexpr (GND::HEIGHTFIELD) {
-                        cross3(xc, fr[k], W);
-                        W[3] = fr[k][0]; W[4] = fr[k][1]; W[5] = fr[k][2];
+                        cross3(xc, fr[k], W[k]);
+                        W[k][3] = fr[k][0]; W[k][4] = fr[k][1]; W[k][5] = fr[k][2];
                     } else {
                         constexpr int ax = (k == 0) ? 2 : (k == 1 ? 0 : 1);
-                        sfor<6>([&](auto I_) MI_LAMBDA { W[I_] = 0.f; });
-                        W[3 + ax] = 1.f;
-                        if constexpr (ax == 0) { W[1] = xc[2]; W[2] = -xc[1]; }
-                        else if constexpr (ax == 1) { W[0] = -xc[2]; W[2] = xc[0]; }
-                        else { W[0] = xc[1]; W[1] = -xc[0]; }
+                        sfor<6>([&](auto I_) MI_LAMBDA { W[k][I_] = 0.f; });
+                        W[k][3 + ax] = 1.f;
+                        if constexpr (ax == 0) { W[k][1] = xc[2]; W[k][2] = -xc[1]; }
+                        else if constexpr (ax == 1) { W[k][0] = -xc[2]; W[k][2] = xc[0]; }
+                        else { W[k][0] = xc[1]; W[k][1] = -xc[0]; }
                     }
-                    float g[M::MAXCHAIN];
-                    sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA {
-                        constexpr int gi = M::chain[b][C];
-                        if constexpr (gi >= OFF) g[C] = dot6(S[gi - OFF], W);
-                        else if constexpr (gi < 3) g[C] = W[3 + gi];
-                        else g[C] = W[gi - 3];
-                    });
-                    chain_solve(std::integral_constant<int, b>{}, g);
+                });
+                // Jacobian entries of the three rows share the joint subspace S_i (read once from the row store where the tree
+                // pass parked it), the chain solve shares the L entries
+                float g[3][M::MAXCHAIN];
+                sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA {
+                    constexpr int gi = M::chain[b][C];
+                    if constexpr (gi >= OFF) {
+                        float Sd[6];
+                        if constexpr (S_IN_ROWS && M::NOS == 0) sfor<6>([&](auto I_) MI_LAMBDA { Sd[I_] = rows(C_S + 6 * (gi - OFF) + I_); });
+                        else sfor<6>([&](auto I_) MI_LAMBDA { Sd[I_] = S[gi - OFF][I_]; });
+                        sfor<3>([&](auto K) MI_LAMBDA { g[K][C] = dot6(Sd, W[K]); });
+                    } else if constexpr (gi < 3) {
+                        sfor<3>([&](auto K) MI_LAMBDA { g[K][C] = W[K][3 + gi]; });
+                    } else {
+                        sfor<3>([&](auto K) MI_LAMBDA { g[K][C] = W[K][gi - 3]; });
+                    }
+                });
+                chain_solve3(std::integral_constant<int, b>{}, g);
+                sfor<3>([&](auto K) MI_LAMBDA {
+                    constexpr int k = K;
                     float a = P.cfm;
-                    sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { a += g[C] * g[C]; cb[(k * M::MAXCHAIN + C) * ST] = g[C]; });
+                    sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { a += g[k][C] * g[k][C]; cb[(k * M::MAXCHAIN + C) * ST] = g[k][C]; });
                     cb[(3 * M::MAXCHAIN + k) * ST] = MI_RCP(a);
                     // slots past C_WARM_OK may already have overwritten parked values of later spheres: no warm start there
                     cb[(3 * M::MAXCHAIN + 4 + k) * ST] = (j <= C_WARM_OK) ? lprev[k] * P.warm : 0.f;
@@ -1078,6 +1120,12 @@ struct Sim {
             });
         }
         }
+#if defined(MI_STOP_AFTER) && MI_STOP_AFTER == 4
+        { float acc = 0.f; sfor<M::NM>([&](auto K) MI_LAMBDA { acc += L[K]; }); sfor<NV>([&](auto K) MI_LAMBDA { acc += w[K] + Ldi[K]; });
+          sfor<NSPH>([&](auto K) MI_LAMBDA { sfor<3>([&](auto J) MI_LAMBDA { acc += c.xcs[K][J]; }); });
+          sfor<NSENS>([&](auto K) MI_LAMBDA { sfor<9>([&](auto J) MI_LAMBDA { acc += c.Rs[K][J]; }); sfor<3>([&](auto J) MI_LAMBDA { acc += c.rs[K][J]; }); });
+          root[0] = acc; return; }
+#endif
         MI_PHASE();
         MI_STAMP(7);
         // ------------------------------------------------------------ back to generalised velocity: qd = L^-1 w

@@ -24,7 +24,9 @@ __global__ __launch_bounds__(64) void k(int N, SimParams P, float* root, float* 
     for (int i = 0; i < ND; ++i) { sim.q[i] = dof[i * N + e]; sim.qd[i] = dof[(ND + i) * N + e]; }
     float t[M::NDA];
     for (int i = 0; i < ND; ++i) t[i] = 0.3f * (float)((e + i) % 7 - 3);
+#if defined(MI_TIMING)
     sim.tstamp = (threadIdx.x == 0) ? stamps + blockIdx.x * 16 : nullptr;
+#endif
     const float h = P.dt / (float)P.substeps;
     const Strided a{lamc + e, N}, b{laml + e, N}, c{sens + e, N}, d{dff + e, N};
     if constexpr (LDS_ROWS && LANES == 64) sim.substep(P, t, h, RowStore<64>(lds_rows + threadIdx.x), a, b, c, d, PlaneGround{}, -1.f, Strided{nullptr, 1});
@@ -50,8 +52,35 @@ int main() {
     hipMemset(dlamc, 0, 3 * NSPH * N * 4); hipMemset(dlaml, 0, ND * N * 4); hipMemset(dst, 0, W * 16 * 8);
     const size_t lds = LDS_ROWS ? (size_t)Sim<M>::ROW_SLOTS * LANES * 4 : 0;
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    for (int rep = 0; rep < 20; ++rep) hipLaunchKernelGGL(k, dim3(W), dim3(LANES), lds, 0, N, P, droot, ddof, dlamc, dlaml, dsens, ddff, dst);
+    for (int rep = 0; rep < 5; ++rep) hipLaunchKernelGGL(k, dim3(W), dim3(LANES), lds, 0, N, P, droot, ddof, dlamc, dlaml, dsens, ddff, dst);
+    float *proot, *pdof;   // pristine device copies of the initial state
+    hipMalloc(&proot, root.size() * 4); hipMalloc(&pdof, dof.size() * 4);
+    hipMemcpy(proot, root.data(), root.size() * 4, hipMemcpyHostToDevice); hipMemcpy(pdof, dof.data(), dof.size() * 4, hipMemcpyHostToDevice);
+    hipEvent_t ev0, ev1;
+    hipEventCreate(&ev0); hipEventCreate(&ev1);
+    hipDeviceSynchronize();
+    hipEventRecord(ev0, 0);
+    for (int rep = 0; rep < 20; ++rep) {
+        hipMemcpyAsync(droot, proot, root.size() * 4, hipMemcpyDeviceToDevice, 0);
+        hipMemcpyAsync(ddof, pdof, dof.size() * 4, hipMemcpyDeviceToDevice, 0);
+    }
+    hipEventRecord(ev1, 0);
+    hipDeviceSynchronize();
+    float ms0 = 0.f;
+    hipEventElapsedTime(&ms0, ev0, ev1);
+    hipDeviceSynchronize();
+    hipEventRecord(ev0, 0);
+    for (int rep = 0; rep < 20; ++rep) {
+        // same initial state every launch: the timing must not depend on where the robots have fallen to
+        hipMemcpyAsync(droot, proot, root.size() * 4, hipMemcpyDeviceToDevice, 0);
+        hipMemcpyAsync(ddof, pdof, dof.size() * 4, hipMemcpyDeviceToDevice, 0);
+        hipLaunchKernelGGL(k, dim3(W), dim3(LANES), lds, 0, N, P, droot, ddof, dlamc, dlaml, dsens, ddff, dst);
+    }
+    hipEventRecord(ev1, 0);
     hipError_t err = hipDeviceSynchronize();
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, ev0, ev1);
+    printf("kernel: %.1f us per launch (copies alone %.1f us)\n", 1e3f * (ms - ms0) / 20, 1e3f * ms0 / 20);
     if (err != hipSuccess) { printf("hip error %s\n", hipGetErrorString(err)); return 1; }
     std::vector<unsigned long long> st(W * 16);
     hipMemcpy(st.data(), dst, st.size() * 8, hipMemcpyDeviceToHost);
