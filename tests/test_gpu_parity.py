@@ -764,3 +764,53 @@ def test_rlgames_adapter_surface():
     st = venv.get_env_state()
     venv.set_env_state(st)
     assert venv.reset_done()[0]["obs"].shape == (64, 4)
+
+
+@pytest.mark.parametrize("task,nact", [("Cartpole", 1), ("Ant", 8), ("Humanoid", 21), ("Anymal", 12), ("Quadcopter", 12)])
+def test_ragged_env_counts_and_shard_invariance(task, nact, monkeypatch):
+    """Env counts that do not fill a wave (1, 37, 100; 32- and 64-lane kernels) and sharding: an env's trajectory depends
+    only on (seed, global env id, actions) -- never on how many envs run beside it or on which rank it lives."""
+    import isaacgymenvs_amd
+    g = torch.Generator(device="cpu").manual_seed(12)
+    acts = [(torch.rand((100, nact), generator=g) * 2 - 1).to(DEV) for _ in range(6)]
+
+    def rollout(n, lo, rank=None):
+        if rank is not None:
+            monkeypatch.setenv("RANK", str(rank)); monkeypatch.setenv("LOCAL_RANK", "0")
+            env = isaacgymenvs_amd.make(seed=9, task=task, num_envs=n, sim_device=DEV, rl_device=DEV, headless=True, multi_gpu=True)
+            monkeypatch.delenv("RANK"); monkeypatch.delenv("LOCAL_RANK")
+        else:
+            env = isaacgymenvs_amd.make(seed=9, task=task, num_envs=n, sim_device=DEV, rl_device=DEV, headless=True)
+        outs = []
+        for a in acts:
+            od, rew, reset, _ = env.step(a[lo:lo + n].contiguous())
+            outs.append((od["obs"].clone(), rew.clone(), reset.clone()))
+        torch.cuda.synchronize()
+        return outs
+    full = rollout(100, 0)
+    for n in (1, 37):
+        part = rollout(n, 0)
+        for (o1, r1, d1), (o2, r2, d2) in zip(full, part):
+            assert torch.isfinite(o2).all()
+            assert torch.equal(o1[:n], o2) and torch.equal(r1[:n], r2) and torch.equal(d1[:n], d2)
+    # rank 1 of a 2 x 50 job owns global envs 50..99
+    shard = rollout(50, 50, rank=1)
+    for (o1, r1, d1), (o2, r2, d2) in zip(full, shard):
+        assert torch.equal(o1[50:], o2) and torch.equal(r1[50:], r2) and torch.equal(d1[50:], d2)
+
+
+def test_reset_idx_edge_cases():
+    """reset_idx with an empty id list, duplicated ids and the last env of a partially filled wave."""
+    env = _make_env("Ant", 70)
+    env.step(env.zero_actions())
+    before = env.root_states.clone()
+    env.reset_idx(torch.zeros(0, dtype=torch.int64, device=DEV))             # no-op
+    torch.cuda.synchronize()
+    assert torch.equal(before, env.root_states)
+    env.progress_buf[:] = 5
+    env.reset_idx(torch.tensor([69, 69, 0], dtype=torch.int64, device=DEV))
+    torch.cuda.synchronize()
+    assert env.progress_buf[69] == 0 and env.progress_buf[0] == 0 and bool((env.progress_buf[1:69] == 5).all())
+    assert abs(float(env.root_states[69, 2]) - 0.44) < 1e-6                   # Ant spawn height (ant.py:164)
+    with pytest.raises(Exception):
+        _make_env("Ant", 0)
