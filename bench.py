@@ -41,10 +41,10 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 # matches the byte count of our dword-per-lane coalesced loads, so the guide's x2 (calibrated on 16 B/lane streams) is
 # NOT applied; the excess over the algorithmic bytes is state re-read per sub-step launch, warm-start impulses and
 # (Humanoid) the constraint rows that spill to scratch.
-PMC_TRAFFIC_BYTES = {("Ant", 4096): int((2 * (1278.9 + 2144.0) + 671.0 + 2230.1) * 1024),
-                     ("Humanoid", 8192): int((2 * (16098.3 + 31864.1) + 2265.6 + 8898.3) * 1024),
-                     ("AnymalTerrain", 4096): int((5 * (2836.2 + 4384.0) + 65.1 + 1715.7 + 6891.9 + 1.8) * 1024),
-                     ("ShadowHand", 16384): int((1674.1 + 4620.9 + 2 * (9353.3 + 31551.8) + 6369.4 + 44704.4 + 1.5) * 1024)}
+PMC_TRAFFIC_BYTES = {("Ant", 4096): int((2 * (1288.4 + 2128.0) + 673.4 + 2230.1) * 1024),
+                     ("Humanoid", 8192): int((2 * (15910.8 + 29182.8) + 2263.1 + 8898.3) * 1024),
+                     ("AnymalTerrain", 4096): int((5 * (2802.6 + 4320.0) + 58.6 + 1708.8 + 6891.8 + 1.8) * 1024),
+                     ("ShadowHand", 16384): int((1699.6 + 4672.3 + 2 * (9546.6 + 31830.9) + 6946.5 + 45710.0 + 1.5) * 1024)}
 
 
 def measure(task, num_envs, steps, warmup, device, rank, world, seed=42, pool=64):
