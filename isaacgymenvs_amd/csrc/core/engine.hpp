@@ -252,6 +252,16 @@ struct Sim {
     // slot index of sphere s is data dependent.  Layout [slot][lane] makes any per-lane slot bank-conflict free.
     static constexpr bool COMPACT = (size_t)ROW_SLOTS_STATIC * 64 * sizeof(float) > 152 * 1024;
     static constexpr int LANES = COMPACT ? 32 : 64;       // envs per workgroup (= per wave)
+#ifndef MI_INLINE_WARM
+#define MI_INLINE_WARM 2
+#endif
+    // static store: the warm-start impulses of a sphere's rows are applied to w right where the rows are built (their g is in
+    // registers) instead of re-reading the rows from LDS in a separate pass; the MI_PHASE() fence per sphere keeps the
+    // scheduler from batching these updates (which once made it hold every row alive, see DESIGN.md "compiler regime").
+    // Measured (A/B in one session): spheres inline -3..-6 % Ant step, -9 % AnymalTerrain step; doing the same for the limit
+    // rows (MI_INLINE_WARM=1) costs more spills than it saves, limit rows only (=3) is slower than the separate pass (=0).
+    static constexpr bool INLINE_WARM = MI_INLINE_WARM && !COMPACT;
+    static constexpr bool INLINE_WARM_LIM = INLINE_WARM && (MI_INLINE_WARM != 2), INLINE_WARM_SPH = INLINE_WARM && (MI_INLINE_WARM != 3);
     static constexpr int KMAX = 16;                       // active ground contacts kept per env (compact store only)
     static constexpr int limoff(int r) {                  // tight packing of the limit rows: offset of row r
         int n = 0;
@@ -764,6 +774,11 @@ struct Sim {
                 Ainv(row) = MI_RCP(a);
                 vt(row) = (C >= 0.f) ? -C * invh : fminf(-C * P.erp * invh, P.max_depen_vel);
                 lam(row) = l0;
+                if constexpr (INLINE_WARM_LIM) {
+                    w[gi] += g[0] * l0;
+                    sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { w[M::anc[gi][A_]] += g[1 + A_] * l0; });
+                    MI_PHASE();
+                }
             }
         });
         MI_PHASE();
@@ -831,7 +846,9 @@ struct Sim {
                 vt(row) = (k == 0) ? vtn : 0.f;
                 float lprev;
                 if constexpr (LAM_IN_ROWS) lprev = lam(row); else lprev = lamc(3 * s + k);
-                lam(row) = lprev * P.warm * onf;
+                const float l0 = lprev * P.warm * onf;
+                lam(row) = l0;
+                if constexpr (INLINE_WARM_SPH) sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += g[C] * l0; });
             });
         });
         } else {
@@ -920,7 +937,7 @@ struct Sim {
             int zero;
             MI_OPAQUE_ZERO(zero);
             const RowStore<RS> rit = rows.shifted(zero);
-            sfor<ND>([&](auto D) MI_LAMBDA {
+            if constexpr (!INLINE_WARM_LIM) sfor<ND>([&](auto D) MI_LAMBDA {
                 constexpr int d = D, gi = OFF + d;
                 if constexpr (M::dof_limited[d]) {
                     constexpr int row = limrow(d);
@@ -930,7 +947,8 @@ struct Sim {
                     sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { w[M::anc[gi][A_]] += rit(g0 + 1 + A_) * l0; });
                 }
             });
-            if constexpr (!COMPACT) {
+            if constexpr (INLINE_WARM_SPH) {
+            } else if constexpr (!COMPACT) {
                 sfor<NSPH>([&](auto S_) MI_LAMBDA {
                     constexpr int s = S_, b = M::sph_body[s], row0 = NLIM + 3 * s;
                     if (sph_active >> s & 1ull) {
