@@ -341,6 +341,12 @@ struct Sim {
                     gnd, mu_env, Strided{netf, 1});
     }
 
+    // row-store slot in which the sub-step expects last sub-step's impulse of limit row `d` / of contact row k (= 3 * sphere +
+    // direction) when it starts -- staged there either by the sub-step itself or, on the GPU, by LDS-direct loads issued by the
+    // kernel before it calls the sub-step (`prestaged`)
+    static constexpr bool STAGES_LAM = COMPACT || LAM_IN_ROWS;
+    static constexpr int stage_slot_lim(int d) { return COMPACT ? C_LIMG + 2 * NLIM + limrow(d) : NROWG * M::MAXCHAIN + 2 * NROWG + limrow(d); }
+    static constexpr int stage_slot_con(int k) { return COMPACT ? C_SLOTOF - 3 * (k / 3 + 1) + (k % 3) : NROWG * M::MAXCHAIN + 2 * NROWG + NLIM + k; }
     // working set shared by the phases of one sub-step
     struct Ctx {
         float S[M::NDA][6];           // joint motion subspaces, world axes about O = root origin
@@ -564,7 +570,7 @@ struct Sim {
     template <int RS, class GND>
     MI_HD void substep(const SimParams& P, const float* tau, const float h, const RowStore<RS> rows, const Strided lamc,
                        const Strided laml, const Strided sensor, const Strided dof_force, const GND& gnd, const float mu_env,
-                       const Strided netf, const Drive* drv = nullptr) {
+                       const Strided netf, const Drive* drv = nullptr, const bool prestaged = false) {
         // static store: row r at r*MAXCHAIN; compact store: only the limit rows (r < NLIM) live at fixed, tightly packed places
         auto G = [&](int row, int c) MI_LAMBDA -> float& { return rows(COMPACT ? limoff(row) + c : row * M::MAXCHAIN + c); };
         auto Ainv = [&](int row) MI_LAMBDA -> float& { return rows(COMPACT ? C_LIMG + row : NROWG * M::MAXCHAIN + row); };
@@ -578,22 +584,16 @@ struct Sim {
         // all loads are issued back to back here, far ahead of their use in the row build, instead of one exposed
         // HBM round trip per row (a wave has nobody to switch to while it waits)
         static_assert(LAM_IN_ROWS || NROWG <= 16, "small models keep lam in registers");
-        if constexpr (COMPACT) {
-            sfor<ND>([&](auto D) MI_LAMBDA {
-                constexpr int d = D;
-                if constexpr (M::dof_limited[d]) rows(C_LIMG + 2 * NLIM + limrow(d)) = laml(d);
-            });
-            // contact impulses are parked at the END of the (still empty) contact-slot region, sphere 0 last: slots fill
-            // from the front and sphere s is read before any slot > s can be written
-            sfor<NSPH>([&](auto S_) MI_LAMBDA {
-                sfor<3>([&](auto K) MI_LAMBDA { rows(C_SLOTOF - 3 * (S_ + 1) + K) = lamc(3 * S_ + K); });
-            });
-        } else if constexpr (LAM_IN_ROWS) {
-            sfor<ND>([&](auto D) MI_LAMBDA {
-                constexpr int d = D;
-                if constexpr (M::dof_limited[d]) rows(NROWG * M::MAXCHAIN + 2 * NROWG + limrow(d)) = laml(d);
-            });
-            sfor<3 * NSPH>([&](auto K) MI_LAMBDA { rows(NROWG * M::MAXCHAIN + 2 * NROWG + NLIM + K) = lamc(K); });
+        // compact store: contact impulses are parked at the END of the (still empty) contact-slot region, sphere 0 last: slots
+        // fill from the front and sphere s is read before any slot > s can be written
+        if constexpr (STAGES_LAM) {
+            if (!prestaged) {
+                sfor<ND>([&](auto D) MI_LAMBDA {
+                    constexpr int d = D;
+                    if constexpr (M::dof_limited[d]) rows(stage_slot_lim(d)) = laml(d);
+                });
+                sfor<3 * NSPH>([&](auto K) MI_LAMBDA { rows(stage_slot_con(K)) = lamc(K); });
+            }
         }
         MI_STAMP(1);
         // ------------------------------------------------------------ kinematics + dynamics, one depth-first tree pass
@@ -704,6 +704,10 @@ struct Sim {
         MI_PHASE();
         MI_STAMP(3);
         // ------------------------------------------------------------ constraint rows in whitened space
+#if defined(__HIP_DEVICE_COMPILE__)
+        // LDS-direct staging loads were issued before the tree pass; they are long done, but the compiler cannot know
+        if constexpr (STAGES_LAM) { if (prestaged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
         float lam_reg[LAM_IN_ROWS ? 1 : NROWG];
         auto lam = [&](int row) MI_LAMBDA -> float& {
             if constexpr (COMPACT) return rows(C_LIMG + 2 * NLIM + row);   // limit rows only

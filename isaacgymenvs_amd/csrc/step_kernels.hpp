@@ -171,13 +171,30 @@ __global__ __launch_bounds__(64) void substep_kernel(View v, SimParams P, ActPar
     } else {
         sfor<ND>([&](auto K) MI_LAMBDA { tau[K] = v.tau[K * N + e]; });
     }
+    // Last sub-step's impulses go from HBM straight into their row-store slots with LDS-direct loads (global_load_lds_dword:
+    // lane l of the wave lands at slot base + 4 l, exactly the [slot][lane] layout): no VGPR holds them in flight, so the ~50
+    // (Ant) / ~130 (Humanoid) loads no longer push that many live values out of the register file at the top of the kernel.
+    constexpr bool PRESTAGE = rows_fit_lds<M>() && Sim<M>::STAGES_LAM;
+    if constexpr (PRESTAGE) {
+        using S = Sim<M>;
+        typedef const __attribute__((address_space(1))) void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        sfor<ND>([&](auto D) MI_LAMBDA {
+            constexpr int d = D;
+            if constexpr (M::dof_limited[d])
+                __builtin_amdgcn_global_load_lds((gptr_t)(v.laml + (size_t)d * N + e), (lptr_t)(lds_rows + S::stage_slot_lim(d) * LANES), 4, 0, 0);
+        });
+        sfor<3 * M::NSPH>([&](auto K) MI_LAMBDA {
+            __builtin_amdgcn_global_load_lds((gptr_t)(v.lamc + (size_t)K * N + e), (lptr_t)(lds_rows + S::stage_slot_con(K) * LANES), 4, 0, 0);
+        });
+    }
     const float h = P.dt / (float)P.substeps;
     const Strided lamc{v.lamc + e, N}, laml{v.laml + e, N}, sensor{v.sensor + e, N}, dof_force{v.dof_force + e, N};
     const Strided netf{GND::NETF ? v.netf + e : nullptr, N};
     const float mu_env = GND::HEIGHTFIELD ? v.friction[e] : -1.f;
     if constexpr (rows_fit_lds<M>()) {
-        if constexpr (LANES == 64) sim.substep(P, tau, h, RowStore<64>(lds_rows + threadIdx.x), lamc, laml, sensor, dof_force, gnd, mu_env, netf);
-        else sim.substep(P, tau, h, RowStore<LANES>{lds_rows + threadIdx.x}, lamc, laml, sensor, dof_force, gnd, mu_env, netf);
+        if constexpr (LANES == 64) sim.substep(P, tau, h, RowStore<64>(lds_rows + threadIdx.x), lamc, laml, sensor, dof_force, gnd, mu_env, netf, nullptr, PRESTAGE);
+        else sim.substep(P, tau, h, RowStore<LANES>{lds_rows + threadIdx.x}, lamc, laml, sensor, dof_force, gnd, mu_env, netf, nullptr, PRESTAGE);
     } else {
         float rows[Sim<M>::ROW_SLOTS];
         sim.substep(P, tau, h, RowStore<1>{rows}, lamc, laml, sensor, dof_force, gnd, mu_env, netf);
