@@ -29,8 +29,17 @@ __global__ __launch_bounds__(64) void k(int N, SimParams P, float* root, float* 
 #endif
     const float h = P.dt / (float)P.substeps;
     const Strided a{lamc + e, N}, b{laml + e, N}, c{sens + e, N}, d{dff + e, N};
-    if constexpr (LDS_ROWS && LANES == 64) sim.substep(P, t, h, RowStore<64>(lds_rows + threadIdx.x), a, b, c, d, PlaneGround{}, -1.f, Strided{nullptr, 1});
-    else if constexpr (LDS_ROWS) sim.substep(P, t, h, RowStore<LANES>{lds_rows + threadIdx.x}, a, b, c, d, PlaneGround{}, -1.f, Strided{nullptr, 1});
+    constexpr bool PRE = LDS_ROWS && Sim<M>::STAGES_LAM;   // LDS-direct staging exactly like step_kernels.hpp
+    if constexpr (PRE) {
+        typedef const __attribute__((address_space(1))) void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        sfor<ND>([&](auto D) { constexpr int dd = D; if constexpr (M::dof_limited[dd])
+            __builtin_amdgcn_global_load_lds((gptr_t)(laml + (size_t)dd * N + e), (lptr_t)(lds_rows + Sim<M>::stage_slot_lim(dd) * LANES), 4, 0, 0); });
+        sfor<3 * NSPH>([&](auto K) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(lamc + (size_t)K * N + e), (lptr_t)(lds_rows + Sim<M>::stage_slot_con(K) * LANES), 4, 0, 0); });
+    }
+    if constexpr (LDS_ROWS && LANES == 64) sim.substep(P, t, h, RowStore<64>(lds_rows + threadIdx.x), a, b, c, d, PlaneGround{}, -1.f, Strided{nullptr, 1}, nullptr, PRE);
+    else if constexpr (LDS_ROWS) sim.substep(P, t, h, RowStore<LANES>{lds_rows + threadIdx.x}, a, b, c, d, PlaneGround{}, -1.f, Strided{nullptr, 1}, nullptr, PRE);
     else { float rows[Sim<M>::ROW_SLOTS]; sim.substep(P, t, h, RowStore<1>{rows}, a, b, c, d, PlaneGround{}, -1.f, Strided{nullptr, 1}); }
     for (int i = 0; i < 13; ++i) root[i * N + e] = sim.root[i];
     for (int i = 0; i < ND; ++i) { dof[i * N + e] = sim.q[i]; dof[(ND + i) * N + e] = sim.qd[i]; }
