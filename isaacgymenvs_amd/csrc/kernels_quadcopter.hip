@@ -147,7 +147,8 @@ static hipError_t quad_substeps(const View& v, const QuadView& qv, const SimPara
 }
 hipError_t launch_step_quadcopter(const View& v, const QuadView& qv, const SimParams& P, const QuadcopterParams& p, const float* actions,
                                   int cfi, hipStream_t s) {
-    hipLaunchKernelGGL(quad_pre_kernel, dim3((v.N + 127) / 128), dim3(128), 0, s, v, qv, p, actions);
+    // 64-thread blocks like the sub-step kernel: block b of every kernel of the step lands on the same XCD (own L2)
+    hipLaunchKernelGGL(quad_pre_kernel, dim3((v.N + 63) / 64), dim3(64), 0, s, v, qv, p, actions);
     hipError_t e = quad_substeps(v, qv, P, p, cfi * P.substeps, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(quad_post_kernel, dim3((v.N + 63) / 64), dim3(64), 0, s, v, qv, p);

@@ -93,8 +93,8 @@ __device__ __forceinline__ void hand_reset_env(const View& v, const HandView& hv
 // pre_physics_step (shadow_hand.py:670-698): deferred resets, then actions -> targets
 __global__ void hand_pre_kernel(View v, HandView hv, HandParams p, const float* __restrict__ actions_in, unsigned step_counter) {
     MI_NO_CONTRACT
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const int N = v.N;
+    const int e = post_env_index<HS::LANES>(blockIdx.x, threadIdx.x, N);   // same env -> XCD mapping as the sub-step kernel
     if (e >= N) return;
     const uint32_t genv = (uint32_t)(v.env_offset + e);
     if (v.reset[e] != 0) hand_reset_env(v, hv, p, e, genv);           // also resets the goal (:615)
@@ -178,8 +178,8 @@ __global__ __launch_bounds__(32) void hand_substep_kernel(View v, HandView hv, S
 __global__ __launch_bounds__(64) void hand_post_kernel(View v, HandView hv, HandParams p) {
     MI_NO_CONTRACT
     constexpr int ND = kHandDof;
-    const int e0 = blockIdx.x * 64 + threadIdx.x;
     const int N = v.N;
+    const int e0 = post_env_index<HS::LANES>(blockIdx.x, threadIdx.x, N);
     const bool valid = e0 < N;
     const int e = valid ? e0 : N - 1;
     HS sim;
@@ -305,7 +305,7 @@ static hipError_t hand_substeps(const View& v, const HandView& hv, const SimPara
 
 hipError_t launch_step_shadow_hand(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, const float* actions, int cfi,
                                    unsigned step_counter, hipStream_t s) {
-    hipLaunchKernelGGL(hand_pre_kernel, dim3((v.N + 127) / 128), dim3(128), 0, s, v, hv, p, actions, step_counter);
+    hipLaunchKernelGGL(hand_pre_kernel, dim3((v.N + 63) / 64), dim3(64), 0, s, v, hv, p, actions, step_counter);
     hipError_t e = hand_substeps(v, hv, P, p, cfi * P.substeps, s);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(hv.ws, 0, 2 * sizeof(float), s);

@@ -202,13 +202,35 @@ __global__ __launch_bounds__(64) void substep_kernel(View v, SimParams P, ActPar
     store_sim(sim, v, e);
 }
 
+// XCD-aware env mapping of the 64-lane post kernels.  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).
+// A sub-step kernel with 32 envs per workgroup puts env e on XCD (e / 32) % 8; a post kernel that simply took envs
+// 64 b .. 64 b + 63 in block b would put half of them on another XCD, and the next sub-step launch would then pull its
+// whole state across L2s (measured: the first sub-step launch after the post kernel 256 us instead of 186 us, Humanoid@8192).
+// Block b = 8 j + x therefore takes the two 32-env groups 16 j + x and 16 j + 8 + x, both of which live on XCD x.
+template <int SUB_LANES>
+__device__ __forceinline__ int post_env_index(int block, int lane, int N) {
+    if constexpr (SUB_LANES == 64) {
+        return block * 64 + lane;
+    } else {
+        static_assert(SUB_LANES == 32, "sub-step workgroups hold 32 or 64 envs");
+        const int groups = (N + 31) / 32;                     // sub-step workgroups
+        const int full = (groups / 16) * 8;                   // post blocks covered by the regular 16-group pattern
+        if (block < full) {
+            const int j = block >> 3, x = block & 7;
+            const int g = 16 * j + x + ((lane >> 5) << 3);
+            return g * 32 + (lane & 31);
+        }
+        return full * 64 + (block - full) * 64 + lane;        // ragged tail: plain mapping
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ post_physics_step
 template <class M, bool HUM>
 __global__ __launch_bounds__(64) void loco_post_kernel(View v, LocoParams tp) {
     using T = Loco<M::ND, 6 * M::NSENS, HUM>;
     constexpr int ND = M::ND, NOBS = T::NOBS;
-    const int e0 = blockIdx.x * 64 + threadIdx.x;
     const int N = v.N;
+    const int e0 = post_env_index<Sim<M>::LANES>(blockIdx.x, threadIdx.x, N);
     const bool valid = e0 < N;           // tail lanes shadow the last env (no stores) so wave reductions stay full
     const int e = valid ? e0 : N - 1;
     float root[13], q[ND], qd[ND], dof_force[ND], sensor[6 * M::NSENS > 0 ? 6 * M::NSENS : 1], act[ND];
@@ -353,8 +375,18 @@ hipError_t launch_substeps(const View& v, const SimParams& P, const ActParams& a
         if (e != hipSuccess) return e;
         configured = true;
     }
+#ifdef MI_DEBUG_ACT_POS   // timing experiment only: which launch of a step takes the action path
+    for (int i = 0; i < n_sub; ++i)
+        hipLaunchKernelGGL((substep_kernel<M, GND>), dim3((v.N + LANES - 1) / LANES), dim3(LANES), lds, s, v, P, ap, actions, i == MI_DEBUG_ACT_POS ? first : rest, gnd);
+#elif defined(MI_DEBUG_INTERLEAVE)   // timing experiment only: a foreign (fill) kernel between the sub-step launches
+    for (int i = 0; i < n_sub; ++i) {
+        hipLaunchKernelGGL((substep_kernel<M, GND>), dim3((v.N + LANES - 1) / LANES), dim3(LANES), lds, s, v, P, ap, actions, i == 0 ? first : rest, gnd);
+        (void)hipMemsetAsync(v.stats + 7, 0, 4, s);
+    }
+#else
     for (int i = 0; i < n_sub; ++i)
         hipLaunchKernelGGL((substep_kernel<M, GND>), dim3((v.N + LANES - 1) / LANES), dim3(LANES), lds, s, v, P, ap, actions, i == 0 ? first : rest, gnd);
+#endif
     return hipGetLastError();
 }
 
