@@ -47,7 +47,7 @@ PMC_TRAFFIC_BYTES = {("Ant", 4096): int((2 * (1288.4 + 2128.0) + 673.4 + 2230.1)
                      ("ShadowHand", 16384): int((1699.6 + 4672.3 + 2 * (9546.6 + 31830.9) + 6946.5 + 45710.0 + 1.5) * 1024)}
 
 
-def measure(task, num_envs, steps, warmup, device, rank, world, seed=42, pool=64):
+def measure(task, num_envs, steps, warmup, device, rank, world, seed=42, pool=8):
     import torch
     import torch.distributed as dist
     import isaacgymenvs_amd
@@ -168,6 +168,10 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the Humanoid@8192 side measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--pool", type=int, default=8,
+                    help="number of pre-generated U(-1,1) action batches cycled through.  The reference protocol draws the actions with "
+                         "torch.rand right before every step (README.md:48-51), i.e. they are cache-hot when step() reads them; a small "
+                         "pool reproduces that without timing torch.rand (a pool of 64 distinct batches made every read a cold miss, +5 %)")
     args = ap.parse_args()
 
     import torch
@@ -181,7 +185,7 @@ def main():
     torch.cuda.set_device(local_rank)
     n_env = args.num_envs or DEFAULT_ENVS[args.task]
 
-    main_res = measure(args.task, n_env, args.steps, args.warmup, device, rank, world)
+    main_res = measure(args.task, n_env, args.steps, args.warmup, device, rank, world, pool=args.pool)
     extra = extra2 = extra3 = None
     if not args.no_extra and args.task == "Ant" and world == 1:   # side measurements only in the single-GPU run
         extra = measure("Humanoid", DEFAULT_ENVS["Humanoid"], max(args.steps // 4, 10), max(args.warmup // 4, 5), device, rank, world)
@@ -199,7 +203,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.task} num_envs={n_env} per GPU ({world * n_env} total), VecTask.step() via Python API, "
-                               f"pool of pre-generated U(-1,1) action batches in HBM, seed 42+rank",
+                               f"pool of {args.pool} pre-generated U(-1,1) action batches, seed 42+rank",
                    "task": args.task, "num_envs_per_gpu": n_env, "parallelism": f"env-shard x{world}"},
         "gpu_ms_per_step": main_res["gpu_ms_per_step"], "reset_rate": main_res["reset_rate"],
         "mean_reward": main_res["mean_reward"],
