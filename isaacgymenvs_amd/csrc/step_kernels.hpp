@@ -375,18 +375,8 @@ hipError_t launch_substeps(const View& v, const SimParams& P, const ActParams& a
         if (e != hipSuccess) return e;
         configured = true;
     }
-#ifdef MI_DEBUG_ACT_POS   // timing experiment only: which launch of a step takes the action path
-    for (int i = 0; i < n_sub; ++i)
-        hipLaunchKernelGGL((substep_kernel<M, GND>), dim3((v.N + LANES - 1) / LANES), dim3(LANES), lds, s, v, P, ap, actions, i == MI_DEBUG_ACT_POS ? first : rest, gnd);
-#elif defined(MI_DEBUG_INTERLEAVE)   // timing experiment only: a foreign (fill) kernel between the sub-step launches
-    for (int i = 0; i < n_sub; ++i) {
-        hipLaunchKernelGGL((substep_kernel<M, GND>), dim3((v.N + LANES - 1) / LANES), dim3(LANES), lds, s, v, P, ap, actions, i == 0 ? first : rest, gnd);
-        (void)hipMemsetAsync(v.stats + 7, 0, 4, s);
-    }
-#else
     for (int i = 0; i < n_sub; ++i)
         hipLaunchKernelGGL((substep_kernel<M, GND>), dim3((v.N + LANES - 1) / LANES), dim3(LANES), lds, s, v, P, ap, actions, i == 0 ? first : rest, gnd);
-#endif
     return hipGetLastError();
 }
 
