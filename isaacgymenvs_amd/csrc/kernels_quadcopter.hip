@@ -136,12 +136,8 @@ __global__ void quad_reset_ids_kernel(View v, QuadView qv, QuadcopterParams p, c
 
 static hipError_t quad_substeps(const View& v, const QuadView& qv, const SimParams& P, const QuadcopterParams& p, int n, hipStream_t s) {
     constexpr size_t lds = lds_bytes<QM>();
-    static bool configured = false;
-    if (!configured && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)quad_substep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
+    static unsigned long long configured = 0ull;
+    if (hipError_t e = ensure_dynamic_lds((const void*)quad_substep_kernel, lds, &configured); e != hipSuccess) return e;
     for (int i = 0; i < n; ++i) hipLaunchKernelGGL(quad_substep_kernel, dim3((v.N + 63) / 64), dim3(64), lds, s, v, qv, P, p);
     return hipGetLastError();
 }

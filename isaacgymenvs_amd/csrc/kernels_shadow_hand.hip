@@ -292,12 +292,8 @@ __global__ void hand_init_kernel(View v, HandView hv, HandParams p) {
 static hipError_t hand_substeps(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s) {
     constexpr size_t lds = (size_t)HS::ROW_SLOTS * HS::LANES * sizeof(float);
     static_assert(lds <= 160 * 1024, "hand row store must fit LDS");
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)hand_substep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
+    static unsigned long long configured = 0ull;
+    if (hipError_t e = ensure_dynamic_lds((const void*)hand_substep_kernel, lds, &configured); e != hipSuccess) return e;
     for (int i = 0; i < n; ++i)
         hipLaunchKernelGGL(hand_substep_kernel, dim3((v.N + HS::LANES - 1) / HS::LANES), dim3(HS::LANES), lds, s, v, hv, P, p);
     return hipGetLastError();

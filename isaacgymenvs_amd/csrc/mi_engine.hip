@@ -246,6 +246,7 @@ struct MiEngine {
     HandParams hand;
     HandView hv;
     int max_init_level;
+    int device;            // HIP device the caller's arena lives on: every entry point must be called with it current
     View v;
     float clip_obs;
     int control_freq_inv;
@@ -415,6 +416,12 @@ extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const 
     if (t == T_QUADCOPTER) build_quad_layout(num_envs, L, &e->qv, (char*)arena);
     if (arena_bytes < L.off) { delete e; return fail("mi_engine_create: arena too small"); }
     e->descs = L.d;
+    {
+        // a host arena is accepted for layout inspection (mi_engine_tensor_desc); every launching entry point refuses it
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, arena) == hipSuccess && attr.type == hipMemoryTypeDevice) e->device = attr.device;
+        else { (void)hipGetLastError(); e->device = -1; }
+    }
     e->v.N = num_envs; e->v.env_offset = env_id_offset; e->v.seed = (uint32_t)(seed ^ (seed >> 32));
     e->v.clip_obs = INFINITY;
     *out = e;
@@ -440,8 +447,20 @@ extern "C" int mi_engine_set_option(MiEngine* e, const char* key, double value) 
     return fail(std::string("unknown option: ") + key);
 }
 
+// kernels launch on the current device; the arena belongs to one device
+static int check_device(const MiEngine* e, const char* where) {
+    int dev = -1;
+    if (e->device < 0) return fail(std::string(where) + ": the engine's arena is not device memory");
+    if (hipGetDevice(&dev) != hipSuccess) return fail(std::string(where) + ": hipGetDevice failed");
+    if (dev != e->device)
+        return fail(std::string(where) + ": the engine's arena is on device " + std::to_string(e->device) + " but device " +
+                    std::to_string(dev) + " is current (hipSetDevice / torch.cuda.set_device first)");
+    return 0;
+}
+
 extern "C" int mi_engine_init_state(MiEngine* e, void* stream) {
     if (!e) return fail("null engine");
+    if (int rc = check_device(e, "mi_engine_init_state")) return rc;
     hipStream_t s = (hipStream_t)stream;
     const TaskMeta& m = kTasks[e->task];
     float* d_init = nullptr;
@@ -507,6 +526,7 @@ extern "C" int mi_engine_init_state(MiEngine* e, void* stream) {
 
 extern "C" int mi_engine_step(MiEngine* e, const float* actions, void* stream) {
     if (!e || !actions) return fail("mi_engine_step: null argument");
+    if (int rc = check_device(e, "mi_engine_step")) return rc;
     hipStream_t s = (hipStream_t)stream;
     e->v.ring = (int)(e->steps & 1);
     switch (e->task) {
@@ -531,6 +551,7 @@ extern "C" int mi_engine_last_ring(const MiEngine* e) { return e ? (int)((e->ste
 
 extern "C" int mi_engine_simulate(MiEngine* e, void* stream) {
     if (!e) return fail("null engine");
+    if (int rc = check_device(e, "mi_engine_simulate")) return rc;
     hipStream_t s = (hipStream_t)stream;
     switch (e->task) {
         case T_CARTPOLE: HIP_OK(launch_simulate_cartpole(e->v, e->P, s)); break;
@@ -551,6 +572,7 @@ extern "C" int mi_engine_reset_idx(MiEngine* e, const int64_t* env_ids, int n, v
     if (!e) return fail("null engine");
     if (n <= 0) return 0;
     if (!env_ids) return fail("mi_engine_reset_idx: null env_ids");
+    if (int rc = check_device(e, "mi_engine_reset_idx")) return rc;
     hipStream_t s = (hipStream_t)stream;
     switch (e->task) {
         case T_CARTPOLE: HIP_OK(launch_reset_cartpole(e->v, (const long long*)env_ids, n, s)); break;

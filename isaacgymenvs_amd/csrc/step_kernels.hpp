@@ -363,18 +363,28 @@ __global__ void cartpole_reset_kernel(View v, const long long* __restrict__ ids,
     v.reset[e] = 0;
 }
 
+// Kernels that need more than 48 KB of dynamic LDS must opt in once per device (hipFuncSetAttribute is a per-device setting; a
+// process normally drives one GPU, but nothing here should break if it drives several).
+inline hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes, unsigned long long* configured_mask) {
+    if (bytes <= 48 * 1024) return hipSuccess;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (*configured_mask & bit) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) *configured_mask |= bit;
+    return e;
+}
+
 // launch `n_sub` physics sub-steps.  `first`: effort source of the first launch, `rest`: of the following ones.
 template <class M, class GND = PlaneGround>
 hipError_t launch_substeps(const View& v, const SimParams& P, const ActParams& ap, const float* actions, int n_sub, int first,
                            int rest, hipStream_t s, const GND& gnd = GND{}) {
     constexpr size_t lds = rows_fit_lds<M>() ? lds_bytes<M>() : 0;
     constexpr int LANES = Sim<M>::LANES;
-    static bool configured = false;
-    if (!configured && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)substep_kernel<M, GND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
+    static unsigned long long configured = 0ull;
+    if (hipError_t e = ensure_dynamic_lds((const void*)substep_kernel<M, GND>, lds, &configured); e != hipSuccess) return e;
     for (int i = 0; i < n_sub; ++i)
         hipLaunchKernelGGL((substep_kernel<M, GND>), dim3((v.N + LANES - 1) / LANES), dim3(LANES), lds, s, v, P, ap, actions, i == 0 ? first : rest, gnd);
     return hipGetLastError();
