@@ -814,3 +814,28 @@ def test_reset_idx_edge_cases():
     assert abs(float(env.root_states[69, 2]) - 0.44) < 1e-6                   # Ant spawn height (ant.py:164)
     with pytest.raises(Exception):
         _make_env("Ant", 0)
+
+
+def test_xcd_aware_post_mapping_covers_every_env_once():
+    """Humanoid's post kernel takes its envs in the XCD-aware order (two 32-env groups per 64-lane block, csrc/step_kernels.hpp
+    post_env_index) with a plain-order tail: env counts that end inside / after the regular 16-group pattern must give every
+    env exactly the trajectory it has at any other env count."""
+    import isaacgymenvs_amd
+    g = torch.Generator(device="cpu").manual_seed(2)
+    acts = [(torch.rand((1120, 21), generator=g) * 2 - 1).to(DEV) for _ in range(4)]
+
+    def rollout(n):
+        env = isaacgymenvs_amd.make(seed=4, task="Humanoid", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True)
+        outs = []
+        for a in acts:
+            od, rew, reset, _ = env.step(a[:n].contiguous())
+            outs.append((od["obs"].clone(), rew.clone(), reset.clone(), env.progress_buf.clone()))
+        torch.cuda.synchronize()
+        return outs
+    big = rollout(1120)            # 35 groups: 16 regular blocks + a 96-env tail
+    for n in (1056, 1000, 520):    # 33 groups (32-env tail) / 32 groups with 24 invalid lanes / 17 groups (8 regular blocks + 8-env tail)
+        small = rollout(n)
+        for (o1, r1, d1, p1), (o2, r2, d2, p2) in zip(big, small):
+            assert torch.isfinite(o2).all()
+            assert torch.equal(o1[:n], o2) and torch.equal(r1[:n], r2) and torch.equal(d1[:n], d2) and torch.equal(p1[:n], p2)
+    assert bool((big[-1][3] >= 0).all())
