@@ -172,3 +172,101 @@ def test_f32_build_tracks_f64(name):
         tau = rng.uniform(-10, 10, (n, spec.nd))
         a.step(tau); b.step(tau)
     assert np.abs(a.q - b.q).max() < 2e-4 and np.abs(a.qd - b.qd).max() < 5e-3
+
+
+def test_friction_cone_on_a_tilted_plane():
+    """Coulomb cone: a robot resting on the plane with gravity tilted by theta starts to slide iff tan(theta) > mu (combined
+    coefficient = mean of the geom / per-env value and the plane's).  Gentle slopes (mu = 0.1) so that nothing topples or rolls."""
+    mu = 0.1
+    spec = load_model("ant")
+    lo, up = np.minimum(spec.dof_lower, spec.dof_upper), np.maximum(spec.dof_lower, spec.dof_upper)
+    out = {}
+    for name, factor in (("stick", 0.6), ("slide", 1.5)):
+        th = np.arctan(mu * factor)
+        e = _eng("ant", plane_mu=mu, erp=0.2)
+        e.q[:] = 0.5 * (lo + up)
+        e.root[:, 2] = 0.30
+        for _ in range(90):                                   # settle on level ground first
+            e.step(np.zeros((1, spec.nd)), env_mu=np.array([mu]))
+        e.set_params(**dict(e.params_dict, gravity=(G * np.sin(th), 0.0, -G * np.cos(th))))
+        x0 = e.root[0, 0]
+        for _ in range(120):                                  # 2 s on the slope
+            e.step(np.zeros((1, spec.nd)), env_mu=np.array([mu]))
+        out[name] = (e.root[0, 0] - x0, e.root[0, 7], th)
+    assert abs(out["stick"][1]) < 1e-2 and abs(out["stick"][0]) < 0.02, out           # static friction holds
+    th = out["slide"][2]
+    a = G * (np.sin(th) - mu * np.cos(th))                    # net acceleration along the plane of a rigidly translating body
+    # The passive legs shuffle and the body yaws a little while it slides, so the per-foot friction vectors are not all exactly
+    # uphill: the acceleration lies between the rigid-translation value and frictionless sliding
+    assert 0.95 * a * 2.0 < out["slide"][1] < G * np.sin(th) * 2.0, (out, a)
+    # what must hold exactly: every touching sphere sits ON the friction cone, and the normal forces carry the weight
+    f = e.sph_force[0]
+    touching = f[:, 2] > 1e-6
+    assert touching.sum() >= 3
+    np.testing.assert_allclose(np.hypot(f[touching, 0], f[touching, 1]), mu * f[touching, 2], rtol=1e-6)
+    np.testing.assert_allclose(f[:, 2].sum(), spec.total_mass() * G * np.cos(th), rtol=2e-3)
+
+
+def test_angular_momentum_of_a_tumbling_body_converges_first_order():
+    """Torque-free flight of the articulated Humanoid with all joints moving.  Joint springs / dampers are internal forces, so
+    the total angular momentum about the centre of mass (from the oracle's own body velocities) is conserved by the equations of
+    motion; the semi-implicit Euler integrator conserves it to first order: the drift over a fixed time halves with the step."""
+    import ctypes as C
+    from oracle.engine import _ptr
+    spec = load_model("humanoid")
+    lo, up = np.minimum(spec.dof_lower, spec.dof_upper), np.maximum(spec.dof_lower, spec.dof_upper)
+
+    def drift(dt, T=0.5):
+        e = _eng("humanoid", gravity=(0.0, 0.0, 0.0), ground_z=-1000.0, dt=dt, substeps=1)
+        rng = np.random.default_rng(2)
+        e.root[:, 2] = 2.0
+        e.root[:, 10:13] = rng.normal(0, 1.5, 3)
+        e.qd[:] = rng.normal(0, 1.0, spec.nd)
+        e.q[:] = 0.5 * (lo + up)
+
+        def momentum():
+            _, _, bp = e.energy(0, poses=True)
+            s = np.ascontiguousarray(e.state[0])
+            v6 = np.zeros(6)
+            items, M, com = [], 0.0, np.zeros(3)
+            for b in range(spec.nb):
+                e.lib.or_body_vel(C.byref(e.model), _ptr(s), b, _ptr(v6))       # [omega; v of the body point at O]
+                R = bp[b, 3:12].reshape(3, 3)
+                c = bp[b, 0:3] + R @ np.asarray(spec.com[b])
+                om = v6[0:3].copy()
+                vc = v6[3:6] + np.cross(om, c - e.root[0, :3])
+                I6 = np.asarray(spec.inertia[b])
+                Il = np.array([[I6[0], I6[3], I6[4]], [I6[3], I6[1], I6[5]], [I6[4], I6[5], I6[2]]])
+                items.append((spec.mass[b], c, vc, R @ Il @ R.T @ om))
+                M += spec.mass[b]; com += spec.mass[b] * c
+            com /= M
+            L, P = np.zeros(3), np.zeros(3)
+            for m, c, vc, Lb in items:
+                L += Lb + m * np.cross(c - com, vc); P += m * vc
+            return L, P
+        L0, P0 = momentum()
+        for _ in range(int(round(T / dt))):
+            e.step(np.zeros((1, spec.nd)))
+        L1, P1 = momentum()
+        assert np.linalg.norm(L0) > 1.0
+        return np.linalg.norm(L1 - L0) / np.linalg.norm(L0), np.linalg.norm(P1 - P0) / (np.linalg.norm(P0) + 1e-9)
+    d = [drift(dt) for dt in (1 / 240, 1 / 480, 1 / 960)]
+    assert d[2][0] < 0.012, d
+    assert 0.45 < d[1][0] / d[0][0] < 0.55 and 0.45 < d[2][0] / d[1][0] < 0.55, d      # first order
+    assert max(x[1] for x in d) < 0.05, d                                              # linear momentum too
+
+
+def test_joint_limits_hold_against_a_constant_torque():
+    """A hinge pushed into its limit by a constant effort stops there: the limit row's impulse balances the effort
+    (dof_force = applied + limit force ~ 0 at rest) and the overshoot stays within the ERP band."""
+    spec = load_model("ant")
+    e = _eng("ant", gravity=(0.0, 0.0, 0.0), ground_z=-1000.0)
+    lo, up = np.minimum(spec.dof_lower, spec.dof_upper), np.maximum(spec.dof_lower, spec.dof_upper)
+    e.root[:, 2] = 3.0
+    e.q[:] = 0.5 * (lo + up)
+    tau = np.zeros((1, spec.nd)); tau[0, 0] = 2.0; tau[0, 1] = -2.0
+    for _ in range(300):
+        e.step(tau)
+    assert e.q[0, 0] <= up[0] + 0.02 and e.q[0, 0] >= up[0] - 0.02, (e.q[0, 0], up[0])
+    assert e.q[0, 1] >= lo[1] - 0.02 and e.q[0, 1] <= lo[1] + 0.02, (e.q[0, 1], lo[1])
+    assert abs(e.qd[0, 0]) < 5e-2 and abs(e.qd[0, 1]) < 5e-2
