@@ -2,16 +2,26 @@
 // code the HIP kernels run (csrc/core/engine.hpp + generated model tables) against the independent oracle
 // without a GPU.  Never loaded by the product path.
 #include <cstring>
+// One library per robot model (-DHOSTSIM_<MODEL>): the unrolled cores take minutes to compile, so tests/hostbuild/hostsim.py
+// builds the models in parallel and routes each call to the library that holds its model.
 #include "../../isaacgymenvs_amd/csrc/core/engine.hpp"
+#ifdef HOSTSIM_CARTPOLE
 #include "../../isaacgymenvs_amd/csrc/gen/model_cartpole.h"
+#endif
+#ifdef HOSTSIM_ANT
 #include "../../isaacgymenvs_amd/csrc/gen/model_ant.h"
+#endif
+#ifdef HOSTSIM_ANYMAL
 #include "../../isaacgymenvs_amd/csrc/gen/model_anymal.h"
+#endif
+#ifdef HOSTSIM_QUADCOPTER
 #include "../../isaacgymenvs_amd/csrc/gen/model_quadcopter.h"
+#endif
 #ifdef HOSTSIM_HAND
 #include "../../isaacgymenvs_amd/csrc/core/hand_engine.hpp"
 #include "../../isaacgymenvs_amd/csrc/gen/model_shadow_hand.h"
 #endif
-#ifndef HOSTSIM_NO_HUMANOID
+#ifdef HOSTSIM_HUMANOID
 #include "../../isaacgymenvs_amd/csrc/gen/model_humanoid.h"
 #endif
 
@@ -37,15 +47,19 @@ static void run(const SimParams* P, int nenv, float* state, const float* tau, fl
 }
 
 extern "C" int hs_step(const char* model, const SimParams* P, int nenv, float* state, const float* tau, float* out) {
-    if (!strcmp(model, "cartpole")) run<ModelCartpole>(P, nenv, state, tau, out);
-    else if (!strcmp(model, "ant")) run<ModelAnt>(P, nenv, state, tau, out);
-#ifndef HOSTSIM_NO_HUMANOID
-    else if (!strcmp(model, "humanoid")) run<ModelHumanoid>(P, nenv, state, tau, out);
+#ifdef HOSTSIM_CARTPOLE
+    if (!strcmp(model, "cartpole")) { run<ModelCartpole>(P, nenv, state, tau, out); return 0; }
 #endif
-    else return -1;
-    return 0;
+#ifdef HOSTSIM_ANT
+    if (!strcmp(model, "ant")) { run<ModelAnt>(P, nenv, state, tau, out); return 0; }
+#endif
+#ifdef HOSTSIM_HUMANOID
+    if (!strcmp(model, "humanoid")) { run<ModelHumanoid>(P, nenv, state, tau, out); return 0; }
+#endif
+    return -1;
 }
 
+#ifdef HOSTSIM_QUADCOPTER
 // PD position drives + local-frame forces on the sensor bodies (Quadcopter): target[nenv][ND], fsens[nenv][NSENS][3]
 extern "C" int hs_step_drive(const char* model, const SimParams* P, int nenv, float* state, float* out, float kp, float kd,
                              const float* target, const float* fsens) {
@@ -72,6 +86,9 @@ extern "C" int hs_step_drive(const char* model, const SimParams* P, int nenv, fl
     return 0;
 }
 
+#endif
+
+#ifdef HOSTSIM_ANYMAL
 // height-field variant (AnymalTerrain): per-env friction mu[nenv], net contact forces netf[nenv][3*NB]
 extern "C" int hs_step_terrain(const char* model, const SimParams* P, int nenv, float* state, const float* tau, float* out,
                                const short* hs, int rows, int cols, float hscale, float vscale, float border, const float* mu,
@@ -95,6 +112,8 @@ extern "C" int hs_step_terrain(const char* model, const SimParams* P, int nenv, 
     }
     return 0;
 }
+
+#endif
 
 #ifdef HOSTSIM_HAND
 // Shadow hand + cube: per env  q[24] | qd[24] | laml[24] | target[24] | obj[13]  ->  updated in place; out: sensor[30] | dof_force[24] | ncontact

@@ -27,32 +27,61 @@ def make_params(d):
     return p
 
 
-def build_hand():
+# model -> (compile-time switch, optimisation level): one library per model, compiled in parallel
+_MODELS = {"cartpole": ("HOSTSIM_CARTPOLE", "-O2"), "ant": ("HOSTSIM_ANT", "-O2"), "anymal": ("HOSTSIM_ANYMAL", "-O2"),
+           "quadcopter": ("HOSTSIM_QUADCOPTER", "-O2"), "humanoid": ("HOSTSIM_HUMANOID", "-O2"), "hand": ("HOSTSIM_HAND", "-O1")}
+_ENTRY_MODEL = {"hs_step_terrain": "anymal", "hs_step_drive": "quadcopter", "hs_step_hand": "hand", "hs_hand_fingertips": "hand"}
+_libs = {}
+
+
+def _deps():
     from isaacgymenvs_amd.registry import generate_headers
-    hdrs = generate_headers()
-    os.makedirs(_OUT, exist_ok=True)
-    out = os.path.join(_OUT, "libhostsim_hand.so")
     core = os.path.join(_HERE, "..", "..", "isaacgymenvs_amd", "csrc", "core")
-    deps = hdrs + [os.path.join(_HERE, "hostsim.cpp"), os.path.join(core, "engine.hpp"), os.path.join(core, "hand_engine.hpp")]
-    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-DHOSTSIM_NO_HUMANOID",
-                               "-DHOSTSIM_HAND", os.path.join(_HERE, "hostsim.cpp"), "-o", out])
-    return C.CDLL(out)
+    return generate_headers() + [os.path.join(_HERE, "hostsim.cpp"), os.path.join(core, "engine.hpp"), os.path.join(core, "hand_engine.hpp")]
+
+
+def _build_models(names):
+    """Compile the stale per-model libraries concurrently (g++ releases the GIL: plain threads suffice)."""
+    from concurrent.futures import ThreadPoolExecutor
+    deps = _deps()
+    os.makedirs(_OUT, exist_ok=True)
+    newest = max(os.path.getmtime(d) for d in deps)
+    jobs = []
+    for n in names:
+        out = os.path.join(_OUT, f"libhostsim_{n}.so")
+        if not os.path.exists(out) or os.path.getmtime(out) < newest:
+            macro, opt = _MODELS[n]
+            jobs.append(["g++", opt, "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-D" + macro,
+                         os.path.join(_HERE, "hostsim.cpp"), "-o", out])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+            list(ex.map(subprocess.check_call, jobs))
+    for n in names:
+        if n not in _libs:
+            _libs[n] = C.CDLL(os.path.join(_OUT, f"libhostsim_{n}.so"))
+
+
+class _Router:
+    """Looks like one library: hs_step(model, ...) goes to the library of `model`, the model-specific entry points to theirs."""
+
+    def __getattr__(self, name):
+        if name in _ENTRY_MODEL:
+            return getattr(_libs[_ENTRY_MODEL[name]], name)
+        if name == "hs_step":
+            def call(model, *args):
+                return _libs[model.decode()].hs_step(model, *args)
+            return call
+        raise AttributeError(name)
 
 
 def build(humanoid=False):
-    from isaacgymenvs_amd.registry import generate_headers
-    hdrs = generate_headers()
-    os.makedirs(_OUT, exist_ok=True)
-    name = "libhostsim_full.so" if humanoid else "libhostsim_small.so"
-    out = os.path.join(_OUT, name)
-    deps = hdrs + [os.path.join(_HERE, "hostsim.cpp"), os.path.join(_HERE, "..", "..", "isaacgymenvs_amd", "csrc", "core", "engine.hpp")]
-    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off"]
-        if not humanoid:
-            cmd.append("-DHOSTSIM_NO_HUMANOID")
-        subprocess.check_call(cmd + [os.path.join(_HERE, "hostsim.cpp"), "-o", out])
-    return C.CDLL(out)
+    """All models a CPU test may ask for are (re)built in one parallel batch the first time any of them is needed."""
+    _build_models(list(_MODELS))
+    return _Router()
+
+
+def build_hand():
+    return build()
 
 
 def step(lib, model, params, state, tau, out):
