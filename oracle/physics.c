@@ -9,8 +9,9 @@
  * tasks/humanoid.py:240-245).  The arithmetic of that path lives in the third-party, closed-source
  * `isaacgym` Preview-4 binary (PhysX 5), which is not in /root/reference => PARITY UNPINNED against
  * PhysX.  This file instead pins *our* engine's stated algorithm; it is itself pinned by first-principles
- * known-answer tests (tests/test_oracle_physics.py: free fall, pendulum period, cart-pole ODE, energy and
- * momentum conservation, static equilibrium weight).
+ * known-answer tests (tests/test_oracle_physics.py: free fall, cart-pole ODE, energy, linear / angular momentum
+ * first-order convergence, static equilibrium weight, Coulomb cone on a tilted plane, joint limits under a constant
+ * effort, asset constants).
  *
  * Algorithm (same maths as the HIP kernels, deliberately different formulation: table driven runtime
  * loops, dense mass matrix, dense Cholesky, PGS in generalised-velocity space):
@@ -22,6 +23,7 @@
  *     qd*   = qd + h Mh^-1 (tau - bias - K(q-ref) - (D+hK) qd)
  *     rows  = joint limits (1 row / limited dof), ground contacts (3 rows / active sphere)
  *     PGS   iters sweeps, warm started, cone friction
+ *     optional (or_step_drive): implicit PD position drives on the dofs, external forces at body centres of mass
  *     integrate q with the new qd (semi-implicit Euler, exponential map for the root quaternion)
  *
  * Build: oracle/Makefile -> oracle/_build/liboracle_f64.so (real=double), liboracle_f32.so (real=float)
