@@ -95,8 +95,9 @@ class AnymalTerrain(VecTask):
         if env["terrain"]["terrainType"] not in ("plane", "trimesh"):
             raise ValueError("terrainType must be 'plane' or 'trimesh'")
         cfg["env"]["plane"] = {"staticFriction": env["terrain"]["staticFriction"]}   # terrain friction -> sim params
-        if cfg["task"].get("randomize", False):
-            raise NotImplementedError("task.randomize=True (domain randomisation) is not implemented in this round")
+        # the reference task never calls apply_randomizations (task.randomize is read by nobody in anymal_terrain.py; its own
+        # randomisation is the per-env friction buckets and the observation noise, both in-kernel here)
+        self.randomize = False
         if self.custom_origins:
             # same terrain on every rank of a multi-GPU job: the seed of the terrain stream is the job seed, not seed+rank
             self.terrain = Terrain(env["terrain"], num_robots=env["numEnvs"], seed=int(cfg.get("_terrain_seed", cfg.get("_seed", 0))))
