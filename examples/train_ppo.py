@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--reward-scale", type=float, default=0.01)
     ap.add_argument("--log", default="")
+    ap.add_argument("--units", default="256,128,64", help="hidden layer sizes of the MLP (HumanoidPPO.yaml: 400,200,100)")
+    ap.add_argument("--lr", type=float, default=3e-4)
     args = ap.parse_args()
 
     import isaacgymenvs_amd
@@ -84,9 +86,9 @@ def main():
     torch.manual_seed(args.seed)
     env = isaacgymenvs_amd.make(seed=args.seed, task=args.task, num_envs=args.num_envs, sim_device=dev, rl_device=dev, headless=True)
     N, T, A, O = args.num_envs, args.horizon, env.num_actions, env.num_obs
-    net = ActorCritic(O, A).to(dev)
-    opt = torch.optim.Adam(net.parameters(), lr=3e-4, eps=1e-8)
-    lr, gamma, lam, clip = 3e-4, 0.99, 0.95, 0.2
+    net = ActorCritic(O, A, tuple(int(u) for u in args.units.split(","))).to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=args.lr, eps=1e-8)
+    lr, gamma, lam, clip = args.lr, 0.99, 0.95, 0.2
     obs_rms, val_rms = RunningMeanStd((O,), dev), RunningMeanStd((), dev)
 
     obs = env.reset()["obs"].clone()
