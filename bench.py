@@ -41,10 +41,10 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 # matches the byte count of our dword-per-lane coalesced loads, so the guide's x2 (calibrated on 16 B/lane streams) is
 # NOT applied; the excess over the algorithmic bytes is state re-read per sub-step launch, warm-start impulses and
 # (Humanoid) the constraint rows that spill to scratch.
-PMC_TRAFFIC_BYTES = {("Ant", 4096): int((2 * (1288.4 + 2128.0) + 673.4 + 2230.1) * 1024),
-                     ("Humanoid", 8192): int((2 * (15910.8 + 29182.8) + 2263.1 + 8898.3) * 1024),
-                     ("AnymalTerrain", 4096): int((5 * (2802.6 + 4320.0) + 58.6 + 1708.8 + 6891.8 + 1.8) * 1024),
-                     ("ShadowHand", 16384): int((1699.6 + 4672.3 + 2 * (9546.6 + 31830.9) + 6946.5 + 45710.0 + 1.5) * 1024)}
+PMC_TRAFFIC_BYTES = {("Ant", 4096): int((2 * (1247.1 + 1856.0) + 661.2 + 2213.1) * 1024),
+                     ("Humanoid", 8192): int((2 * (11804.1 + 21219.3) + 2267.3 + 8931.9) * 1024),
+                     ("AnymalTerrain", 4096): int((5 * (1765.8 + 2272.0) + 59.0 + 1340.9 + 2549.0 + 734.6 + 4744.0 + 1.9) * 1024),
+                     ("ShadowHand", 16384): int((1681.6 + 4689.5 + 2 * (9523.0 + 31647.1) + 6682.4 + 45930.1 + 1.5) * 1024)}
 
 
 def measure(task, num_envs, steps, warmup, device, rank, world, seed=42, pool=8):
