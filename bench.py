@@ -112,15 +112,28 @@ def measure(task, num_envs, steps, warmup, device, rank, world, seed=42, pool=8)
     return res
 
 
+# Instructions one wave executes per control step (rocprofv3 SQ_INSTS_VALU + SALU + LDS per wave, profiles/r1_pmc_summary.md: sub-step
+# launches + post kernel) and what a wave that owns its SIMD can issue (tools/debug/ifetch_bench.hip: 4 cycles per 4-byte and ~5.3
+# per 8-byte instruction at ~1.8 GHz, ~45 % 8-byte => ~2.55 ns).  Every wave runs concurrently at the BASELINE sizes, so this
+# per-wave issue time is the floor of the step on the current one-env-per-lane design; reported next to the mandatory HBM roofline.
+WAVE_INSTRS_PER_STEP = {"Ant": 2 * 11180 + 1200, "Humanoid": 2 * 36280 + 3520}
+ISSUE_NS_PER_INSTR = 2.55
+
+
 def roofline(task, num_envs, kernel_ms):
     bytes_per_launch = ALGO_BYTES[task] * num_envs
     lanes = 32 if task in ("Humanoid", "ShadowHand") else 64   # compact-store models run 32 envs per wave
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
     traffic = PMC_TRAFFIC_BYTES.get((task, num_envs))
-    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "kernel": "mi::substep_kernel<%s> (x sim steps) + post kernel = one step" % task,
-            "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
-            "note": "latency/issue-bound path: %d waves of %d envs, one per SIMD; see DESIGN.md" % ((num_envs + lanes - 1) // lanes, lanes)}
+    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "traffic": traffic, "kernel": "mi::substep_kernel<%s> (x sim steps) + post kernel = one step" % task,
+           "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+           "note": "latency/issue-bound path: %d waves of %d envs, one per SIMD; see DESIGN.md" % ((num_envs + lanes - 1) // lanes, lanes)}
+    if task in WAVE_INSTRS_PER_STEP:
+        floor_ms = WAVE_INSTRS_PER_STEP[task] * ISSUE_NS_PER_INSTR * 1e-6
+        out["single_wave_issue_floor"] = {"instructions_per_wave_per_step": WAVE_INSTRS_PER_STEP[task], "ns_per_instruction": ISSUE_NS_PER_INSTR,
+                                          "floor_ms": floor_ms, "frac_of_floor": floor_ms / kernel_ms}
+    return out
 
 
 def cpu_baseline(task, num_envs, budget_s=15.0, seed=42):
