@@ -188,7 +188,13 @@ __global__ __launch_bounds__(64) void hand_post_kernel(View v, HandView hv, Hand
     sfor<ND>([&](auto K) MI_LAMBDA { sim.q[K] = v.dof[K * N + e]; sim.qd[K] = v.dof[(ND + K) * N + e]; });
     float tips[kHandTips][13];
     sim.fingertip_states(tips);                                    // gym.refresh_rigid_body_state_tensor (:440)
-    float os[13], gp[7], act[kHandAct];
+    float os[13], gp[7], act[kHandAct], dff[ND], sns[6 * kHandTips];
+    // every input is loaded before the first observation is stored: the stores below may alias these arrays as far as the
+    // compiler knows, and a load that has to wait for them is a fully exposed memory round trip for a lone wave
+    sfor<ND>([&](auto K) MI_LAMBDA { dff[K] = v.dof_force[K * N + e]; });
+    sfor<6 * kHandTips>([&](auto K) MI_LAMBDA { sns[K] = v.sensor[K * N + e]; });
+    const long long reset_in = v.reset[e], reset_goal_in = hv.reset_goal[e];
+    const float successes_in = hv.successes[e];
     sfor<13>([&](auto K) MI_LAMBDA { os[K] = hv.object_state[K * N + e]; });
     sfor<7>([&](auto K) MI_LAMBDA { gp[K] = hv.goal_state[K * N + e]; });
     sfor<kHandAct>([&](auto K) MI_LAMBDA { act[K] = v.actions[K * N + e]; });
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(64) void hand_post_kernel(View v, HandView hv, Hand
         constexpr int d = D;
         emit(d, (2.0f * sim.q[d] - HM::dof_upper[d] - HM::dof_lower[d]) / (HM::dof_upper[d] - HM::dof_lower[d]));   // unscale
         emit(ND + d, p.vel_obs_scale * sim.qd[d]);
-        emit(2 * ND + d, p.force_torque_obs_scale * v.dof_force[d * N + e]);
+        emit(2 * ND + d, p.force_torque_obs_scale * dff[d]);
     });
     sfor<7>([&](auto K) MI_LAMBDA { emit(72 + K, os[K]); });
     sfor<3>([&](auto K) MI_LAMBDA { emit(79 + K, os[7 + K]); emit(82 + K, p.vel_obs_scale * os[10 + K]); });
@@ -227,12 +233,12 @@ __global__ __launch_bounds__(64) void hand_post_kernel(View v, HandView hv, Hand
             if (valid) hv.fingertip[(T_ * 13 + K) * N + e] = tips[T_][K];
         });
     });
-    sfor<6 * kHandTips>([&](auto K) MI_LAMBDA { emit(161 + K, p.force_torque_obs_scale * v.sensor[K * N + e]); });
+    sfor<6 * kHandTips>([&](auto K) MI_LAMBDA { emit(161 + K, p.force_torque_obs_scale * sns[K]); });
     sfor<kHandAct>([&](auto K) MI_LAMBDA { emit(191 + K, act[K]); });
     // compute_hand_reward (:746-800)
     float r, succ;
     long long rs, gr, prog;
-    hand_reward(p.rew, os, os + 3, gp, gp + 3, act, kHandAct, v.reset[e], hv.reset_goal[e], progress_in, hv.successes[e], &r, &rs, &gr, &prog, &succ);
+    hand_reward(p.rew, os, os + 3, gp, gp + 3, act, kHandAct, reset_in, reset_goal_in, progress_in, successes_in, &r, &rs, &gr, &prog, &succ);
     float nres = valid ? (float)rs : 0.f, fin = valid ? succ * (float)rs : 0.f;
     nres = wave_sum(nres); fin = wave_sum(fin);
     if ((threadIdx.x & 63) == 0 && nres > 0.f) { atomicAdd(hv.ws, nres); atomicAdd(hv.ws + 1, fin); }
