@@ -35,6 +35,7 @@ struct HandSim : Sim<M> {
     static constexpr int H_LIMG = B::limoff(NLIM);
     static constexpr int H_CB = H_LIMG + 3 * NLIM;           // limit G | Ainv, vt, lam | contact slots
     static constexpr int H_CSZ = 3 * UCH + 7;                // 3 rows + Ainv x3, vt_n, lam x3
+    static constexpr int BODY_CAP = 4;                        // contacts admitted per hand body (manifold size)
     static constexpr int H_SLOTOF = H_CB + KMAX * H_CSZ;     // [NOS] slot of each sphere (-1: none), int bits
     static constexpr int H_POSE = H_SLOTOF + NOS;            // [NOSB][12] pose of the sphere-carrying bodies (tree pass output)
     static constexpr int ROW_SLOTS = H_POSE + 12 * B::NOSB;
@@ -202,6 +203,7 @@ struct HandSim : Sim<M> {
                 float Rb[9], rb[3];
                 sfor<9>([&](auto I_) MI_LAMBDA { Rb[I_] = rows(H_POSE + 12 * B::os_slot(b) + I_); });
                 sfor<3>([&](auto I_) MI_LAMBDA { rb[I_] = rows(H_POSE + 12 * B::os_slot(b) + 9 + I_); });
+                int nbody = 0;
                 for (int i = 0; i < B::os_count(b); ++i) {
                     const int s = B::os_first(b) + i;
                     const float pl[3] = {M::os_pos[s][0], M::os_pos[s][1], M::os_pos[s][2]};
@@ -213,7 +215,10 @@ struct HandSim : Sim<M> {
                     float cl[3], nl[3], dist;
                     matTvec3(Ro, rel, cl);
                     sphere_box(cl, rad, OP.half, &dist, nl);
-                    const bool on = (dist < P.contact_offset) && (cnt < KMAX);
+                    // contact manifold: at most BODY_CAP contacts per hand body, taken in the body's (spread-out, farthest-point) sphere
+                    // order, so that a cube lying on the 30-sphere palm cannot use up all KMAX slots before the fingers are looked at
+                    const bool on = (dist < P.contact_offset) && (cnt < KMAX) && (nbody < BODY_CAP);
+                    nbody += on ? 1 : 0;
                     const int j = on ? cnt : -1;
                     if (on) {
                         float fr[3][3];

@@ -21,6 +21,7 @@ import numpy as np
 from .engine import OracleEngine, _ptr
 
 KMAX = 16
+BODY_CAP = 4        # contacts admitted per hand body, in the body's (farthest-point ordered) sphere order -- csrc/core/hand_engine.hpp
 CUBE_HALF = 0.025
 CUBE_MASS = 567.0 * 0.05 ** 3                      # cube_multicolor.urdf: box 0.05, density 567
 CUBE_INERTIA = CUBE_MASS * 0.05 ** 2 / 6.0         # isotropic
@@ -153,12 +154,14 @@ class OracleHandEngine:
         J3 = np.zeros((3, nd))
         ncon = 0
         contacts = []
+        per_body = {}
         for si in range(len(self.os_body)):
             b = int(self.os_body[si])
             c = bp[b, 0:3] + bp[b, 3:12].reshape(3, 3) @ self.os_pos[si]      # world
             dist, nl = sphere_box(Ro.T @ (c - xo), self.os_rad[si], CUBE_HALF)
-            if dist >= P["contact_offset"] or ncon >= KMAX:
+            if dist >= P["contact_offset"] or ncon >= KMAX or per_body.get(b, 0) >= BODY_CAP:
                 continue
+            per_body[b] = per_body.get(b, 0) + 1
             n = Ro @ nl                                                   # from the cube towards the sphere
             t1, t2 = contact_frame(n)
             pc = c - self.os_rad[si] * n                                  # contact point, world

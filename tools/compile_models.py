@@ -64,6 +64,23 @@ def hand_extras(asset_root, spec):
                 for v in grids[1]:
                     p = np.zeros(3); p[others[0]] = u; p[others[1]] = v
                     sph.append((b, pos + R @ p, r))
+    # Per body, order the spheres by farthest-point sampling (first the one farthest from the body's sphere centroid, then always
+    # the one farthest from those already taken).  The engine admits at most BODY_CONTACT_CAP contacts per body in this order
+    # (a contact manifold, like PhysX's <= 4 points per pair): with a spread-out order the first few touching spheres span the
+    # contact patch instead of clustering in one corner of the palm's 30-sphere grid.
+    by_body = {}
+    for b, pos, r in sph:
+        by_body.setdefault(b, []).append((pos, r))
+    sph = []
+    for b in sorted(by_body):
+        items = by_body[b]
+        P = np.array([q for q, _ in items])
+        order = [int(np.argmax(np.linalg.norm(P - P.mean(0), axis=1)))]
+        while len(order) < len(items):
+            d = np.min(np.linalg.norm(P[:, None, :] - P[None, order, :], axis=2), axis=1)
+            d[order] = -1.0
+            order.append(int(np.argmax(d)))
+        sph += [(b, items[i][0], items[i][1]) for i in order]
     shared = ET.parse(os.path.join(hand_dir, "shared.xml")).getroot()
     dofs = list(spec.dof_names)
     tendons = []
