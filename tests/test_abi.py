@@ -97,3 +97,62 @@ def test_product_package_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 src = open(os.path.join(d, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "oracle/" not in src.replace("oracle/ for tests", "").replace("oracle/physics.c", "").replace("oracle/tasks.py", "").replace("oracle/hand.py", ""), os.path.join(d, f)
+
+
+def test_all_tasks_lay_out_and_reject_device_calls_on_a_host_arena(lib):
+    """Every task of the table lays out its arena on a host buffer (views inside the arena, non-overlapping, reference shapes of
+    the API tensors); the launching entry points refuse an arena that is not device memory instead of faulting."""
+    cases = {"Cartpole": (native.MiCartpoleParams, 4, 1, 2), "Ant": (native.MiLocoParams, 60, 8, 8), "Humanoid": (native.MiLocoParams, 108, 21, 21),
+             "AnymalTerrain": (native.MiAnymalParams, 188, 12, 12), "Anymal": (native.MiAnymalFlatParams, 48, 12, 12),
+             "Quadcopter": (native.MiQuadcopterParams, 21, 12, 8), "ShadowHand": (native.MiHandParams, 211, 20, 24)}
+    n = 70
+    for task, (ptype, nobs, nact, nd) in cases.items():
+        info = native.task_info(task)
+        assert (info.num_obs, info.num_actions, info.num_dofs) == (nobs, nact, nd), task
+        assert info.task_params_bytes == C.sizeof(ptype), task
+        nbytes = lib.mi_engine_arena_bytes(task.encode(), n)
+        buf = np.zeros(nbytes, np.uint8)
+        sim = native.MiSimParams(dt=0.0166, substeps=2, iters=4)
+        tp = ptype()
+        if task == "ShadowHand":
+            tp.obs_type, tp.num_obs = 0, 211
+        h = C.c_void_p()
+        rc = lib.mi_engine_create(task.encode(), C.byref(sim), C.cast(C.byref(tp), C.c_void_p), C.sizeof(tp), n, 0, 1,
+                                  buf.ctypes.data, nbytes, C.byref(h))
+        assert rc == 0, (task, lib.mi_last_error())
+        names = {}
+        for i in range(lib.mi_engine_num_tensors(h)):
+            d = native.MiTensorDesc()
+            assert lib.mi_engine_tensor_desc(h, i, C.byref(d)) == 0
+            names[d.name.decode()] = d
+            ext = 1 + sum((d.shape[k] - 1) * d.stride[k] for k in range(d.ndim))
+            assert d.byte_offset + ext * {0: 4, 1: 8, 2: 1, 3: 4}[d.dtype] <= nbytes, (task, d.name)
+        assert tuple(names["obs_buf"].shape[:2]) == (n, nobs) and tuple(names["actions"].shape[:2]) == (n, nact), task
+        assert tuple(names["dof_state"].shape[:3]) == (n, nd, 2), task
+        for must in ("root_states", "rew_buf", "reset_buf", "progress_buf", "timeout_buf", "randomize_buf"):
+            assert must in names, (task, must)
+        d = native.MiTensorDesc()
+        assert lib.mi_engine_tensor_desc(h, 10_000, C.byref(d)) != 0                     # bad index
+        acts = np.zeros((n, nact), np.float32)
+        assert lib.mi_engine_step(h, acts.ctypes.data, None) != 0 and b"not device memory" in lib.mi_last_error(), task
+        assert lib.mi_engine_simulate(h, None) != 0
+        ids = np.zeros(1, np.int64)
+        assert lib.mi_engine_reset_idx(h, ids.ctypes.data, 1, None) != 0
+        assert lib.mi_engine_reset_idx(h, ids.ctypes.data, 0, None) == 0                  # empty id list: no-op
+        assert lib.mi_engine_set_option(h, b"no_such_option", 1.0) != 0 and b"unknown option" in lib.mi_last_error()
+        assert lib.mi_engine_set_option(h, b"control_freq_inv", 0.0) != 0
+        lib.mi_engine_destroy(h)
+    # ShadowHand observation layouts are validated at creation
+    tp = native.MiHandParams()
+    tp.obs_type, tp.num_obs = 1, 500
+    nbytes = lib.mi_engine_arena_bytes(b"ShadowHand", n)
+    buf = np.zeros(nbytes, np.uint8)
+    h = C.c_void_p()
+    assert lib.mi_engine_create(b"ShadowHand", C.byref(native.MiSimParams(dt=0.01, substeps=2, iters=4)), C.cast(C.byref(tp), C.c_void_p),
+                                C.sizeof(tp), n, 0, 1, buf.ctypes.data, nbytes, C.byref(h)) != 0
+    assert b"obs_type" in lib.mi_last_error()
+    # invalid sim parameters / env counts
+    tp2 = native.MiLocoParams()
+    assert lib.mi_engine_create(b"Ant", C.byref(native.MiSimParams(dt=0.0, substeps=2, iters=4)), C.cast(C.byref(tp2), C.c_void_p), C.sizeof(tp2),
+                                n, 0, 1, buf.ctypes.data, nbytes, C.byref(h)) != 0
+    assert lib.mi_engine_arena_bytes(b"Ant", 0) == 0 and lib.mi_engine_arena_bytes(b"Nope", 8) == 0
