@@ -263,6 +263,112 @@ int mi_compute_hand_full_state(int n, int num_dofs, int num_fingertips, int num_
 int mi_randomize_rotation(int n, const float* rand0, const float* rand1, const float* x_unit, const float* y_unit, float* out_quat,
                           void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Stand-alone replacements of the reference's remaining @torch.jit.script task functions (kernels in
+ * csrc/kernels_jit_twins.hip).  Same argument order as the jitted signatures; every tensor is a contiguous row-major
+ * device buffer of the shape the reference passes ([n,3] positions, [n,4] xyzw quaternions, int64 reset/progress buffers).
+ * Buffers the reference only reads for their shape may be NULL where noted.  All return 0 or -1 (mi_last_error()).
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* compute_bbot_reward (ball_balance.py:459-476); tray_positions is unused there and may be NULL */
+int mi_compute_bbot_reward(int n, const float* tray_positions, const float* ball_positions, const float* ball_velocities, float ball_radius,
+                           const int64_t* reset_buf_in, const int64_t* progress_buf, float max_episode_length, float* rew_buf,
+                           int64_t* reset_buf_out, void* stream);
+/* compute_ingenuity_reward (ingenuity.py:410-442); root_linvels and reset_buf_in are not read there and may be NULL */
+int mi_compute_ingenuity_reward(int n, const float* root_positions, const float* target_root_positions, const float* root_quats,
+                                const float* root_linvels, const float* root_angvels, const int64_t* reset_buf_in, const int64_t* progress_buf,
+                                float max_episode_length, float* rew_buf, int64_t* reset_buf_out, void* stream);
+
+typedef struct MiFrankaCabinetRewardParams {   /* float arguments of compute_franka_reward, franka_cabinet.py:494-496 */
+    float dist_reward_scale, rot_reward_scale, around_handle_reward_scale, open_reward_scale;
+    float finger_dist_reward_scale, action_penalty_scale, distX_offset, max_episode_length;
+} MiFrankaCabinetRewardParams;
+/* compute_franka_reward (franka_cabinet.py:488-553): actions [n,num_actions<=16], cabinet_dof_pos [n,num_cabinet_dofs>=4]
+ * (column 3 = drawer_top_joint), the four *_axis tensors [n,3] */
+int mi_compute_franka_cabinet_reward(int n, const MiFrankaCabinetRewardParams* p, const int64_t* reset_buf_in, const int64_t* progress_buf,
+                                     const float* actions, int num_actions, const float* cabinet_dof_pos, int num_cabinet_dofs,
+                                     const float* franka_grasp_pos, const float* drawer_grasp_pos, const float* franka_grasp_rot,
+                                     const float* drawer_grasp_rot, const float* franka_lfinger_pos, const float* franka_rfinger_pos,
+                                     const float* gripper_forward_axis, const float* drawer_inward_axis, const float* gripper_up_axis,
+                                     const float* drawer_up_axis, float* rew_buf, int64_t* reset_buf_out, void* stream);
+/* compute_grasp_transforms (franka_cabinet.py:556-568): two tf_combine's (torch_jit_utils.py:148) */
+int mi_compute_grasp_transforms(int n, const float* hand_rot, const float* hand_pos, const float* franka_local_grasp_rot,
+                                const float* franka_local_grasp_pos, const float* drawer_rot, const float* drawer_pos,
+                                const float* drawer_local_grasp_rot, const float* drawer_local_grasp_pos, float* global_franka_rot,
+                                float* global_franka_pos, float* global_drawer_rot, float* global_drawer_pos, void* stream);
+
+/* axisangle2quat (franka_cube_stack.py:40-71): vec [n,3] -> quat [n,4] */
+int mi_axisangle2quat(int n, const float* vec, float eps, float* quat, void* stream);
+typedef struct MiFrankaCubeStackRewardParams {   /* reward_settings dict (franka_cube_stack.py:82-87, 461) + max_episode_length */
+    float r_dist_scale, r_lift_scale, r_align_scale, r_stack_scale, table_height, max_episode_length;
+} MiFrankaCubeStackRewardParams;
+/* compute_franka_reward (franka_cube_stack.py:697-752); the `states` dict entries are passed as separate tensors:
+ * cubeA_size / cubeB_size [n], the positions [n,3] */
+int mi_compute_franka_cube_stack_reward(int n, const MiFrankaCubeStackRewardParams* p, const int64_t* reset_buf_in, const int64_t* progress_buf,
+                                        const float* cubeA_size, const float* cubeB_size, const float* cubeA_pos, const float* cubeA_pos_relative,
+                                        const float* eef_lf_pos, const float* eef_rf_pos, const float* cubeA_to_cubeB_pos, float* rew_buf,
+                                        int64_t* reset_buf_out, void* stream);
+
+/* AllegroHand: compute_hand_reward (allegro_hand.py:663-718) is the same function as shadow_hand.py:746-800 -> mi_compute_hand_reward.
+ * randomize_rotation_pen (allegro_hand.py:728-732): rand1 and y_unit are unused by the reference but must be valid pointers */
+int mi_randomize_rotation_pen(int n, const float* rand0, const float* rand1, float max_angle, const float* x_unit, const float* y_unit,
+                              const float* z_unit, float* out_quat, void* stream);
+
+/* Trifinger: lgsk_kernel (trifinger.py:1260-1274) elementwise over n floats */
+int mi_lgsk_kernel(int n, const float* x, float scale, float eps, float* out, void* stream);
+/* gen_keypoints (trifinger.py:1277-1290): pose rows of pose_stride >= 7 floats (pos3, quat4), size3 = 3 HOST floats -> keypoints [n,8,3] */
+int mi_gen_keypoints(int n, const float* pose, int pose_stride, const float* size3, float* keypoints, void* stream);
+typedef struct MiTrifingerRewardParams {   /* scalar arguments of compute_trifinger_reward, trifinger.py:1296-1308 */
+    int episode_length;
+    float dt, finger_move_penalty_weight, finger_reach_object_weight, object_dist_weight, object_rot_weight;
+    int64_t env_steps_count;
+    int use_keypoints;
+    float keypoint_size[3];    /* gen_keypoints' default (0.065, 0.065, 0.065) */
+} MiTrifingerRewardParams;
+/* compute_trifinger_reward (trifinger.py:1292-1383): object_goal_poses [n,7], object states [n,13], fingertip states [n,3,13];
+ * obs_buf / reset_buf inputs of the reference are not read there and are not passed; the two info arrays [n] may be NULL */
+int mi_compute_trifinger_reward(int n, const MiTrifingerRewardParams* p, const int64_t* progress_buf, const float* object_goal_poses,
+                                const float* object_state, const float* last_object_state, const float* fingertip_state,
+                                const float* last_fingertip_state, float* rew_buf, int64_t* reset_buf_out, float* info_finger_movement_penalty,
+                                float* info_finger_reach_object_reward, void* stream);
+/* compute_trifinger_observations_states (trifinger.py:1386-1420): obs_buf [n, 2 num_dofs + 14 + num_actions]; states_buf (may be NULL)
+ * [n, obs + 6 + fingertip_state_cols + num_dofs + tip_wrench_cols] when asymmetric_obs, else a copy of obs_buf */
+int mi_compute_trifinger_observations_states(int n, int asymmetric_obs, int num_dofs, int num_actions, int fingertip_state_cols,
+                                             int tip_wrench_cols, const float* dof_position, const float* dof_velocity, const float* object_state,
+                                             const float* object_goal_poses, const float* actions, const float* fingertip_state,
+                                             const float* joint_torques, const float* tip_wrenches, float* obs_buf, float* states_buf,
+                                             void* stream);
+
+/* HumanoidAMP: dof_to_obs (amp/humanoid_amp_base.py:462-492): pose [n,28] -> dof_obs [n,52] */
+int mi_amp_dof_to_obs(int n, const float* pose, float* dof_obs, void* stream);
+/* compute_humanoid_observations (amp/humanoid_amp_base.py:494-528) == build_amp_observations (humanoid_amp.py:299-330):
+ * key_body_pos [n,num_key_bodies<=8,3] -> obs [n, 13 + 52 + 28 + 3 num_key_bodies] */
+int mi_compute_humanoid_amp_observations(int n, const float* root_states, const float* dof_pos, const float* dof_vel, const float* key_body_pos,
+                                         int num_key_bodies, int local_root_obs, float* obs, void* stream);
+/* compute_humanoid_reset (amp/humanoid_amp_base.py:536-564): contact_buf / rigid_body_pos [n,num_bodies<=64,3]; contact_body_ids is a
+ * HOST int64 list; reset_buf_in is read for its shape only and may be NULL */
+int mi_compute_humanoid_amp_reset(int n, const int64_t* reset_buf_in, const int64_t* progress_buf, const float* contact_buf,
+                                  const int64_t* contact_body_ids, int num_contact_body_ids, const float* rigid_body_pos, int num_bodies,
+                                  float max_episode_length, int enable_early_termination, float termination_height, int64_t* reset_buf_out,
+                                  int64_t* terminated_out, void* stream);
+
+typedef struct MiDextremeRewardParams {   /* scalar arguments of compute_hand_reward, dextreme/allegro_hand_dextreme.py:1598-1606 */
+    float max_episode_length, dist_reward_scale, rot_reward_scale, rot_eps, action_penalty_scale, action_delta_penalty_scale;
+    float success_tolerance, reach_goal_bonus, fall_dist, fall_penalty;
+    int max_consecutive_successes;
+    float av_factor;
+    int num_success_hold_steps;
+} MiDextremeRewardParams;
+/* compute_hand_reward (dextreme/allegro_hand_dextreme.py:1598-1663), in place on reset_buf / reset_goal_buf / progress_buf /
+ * hold_count_buf / successes / consecutive_successes[1] like the reference's return tuple; reward_terms8 (may be NULL) [8,n] =
+ * dist_rew, rot_rew, action_penalty, action_delta_penalty, velocity_penalty, reach_goal_rew, fall_rew, timeout_rew;
+ * workspace2 = 2 device floats of scratch */
+int mi_compute_hand_reward_dextreme(int n, const MiDextremeRewardParams* p, float* rew_buf, int64_t* reset_buf, int64_t* reset_goal_buf,
+                                    int64_t* progress_buf, int64_t* hold_count_buf, const float* cur_targets, const float* prev_targets,
+                                    const float* hand_dof_vel, int num_dofs, float* successes, float* consecutive_successes,
+                                    const float* object_pos, const float* object_rot, const float* target_pos, const float* target_rot,
+                                    const float* actions, int num_actions, float* reward_terms8, float* workspace2, void* stream);
+
 const char* mi_last_error(void);
 
 #ifdef __cplusplus

@@ -34,6 +34,7 @@ static_assert(sizeof(MiHandParams) == sizeof(HandParams), "MiHandParams layout")
 
 static thread_local std::string g_err;
 static int fail(const std::string& m) { g_err = m; return -1; }
+namespace mi { int abi_fail(const char* msg) { return fail(msg); } }   // for the entry points that live in other translation units
 extern "C" const char* mi_last_error(void) { return g_err.c_str(); }
 extern "C" int mi_abi_version(void) { return MI_ABI_VERSION; }
 

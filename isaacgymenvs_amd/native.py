@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("MI_ENGINE_LIB") or os.path.join(_HERE, "libmi_engine.
 CSRC = os.path.join(_HERE, "csrc")
 BUILD_DIR = os.path.join(CSRC, "build")
 # one translation unit per robot model (they compile in parallel) + the C ABI
-SOURCES = ["mi_engine.hip", "kernels_cartpole.hip", "kernels_ant.hip", "kernels_humanoid.hip", "kernels_anymal.hip", "kernels_shadow_hand.hip", "kernels_quadcopter.hip"]
+SOURCES = ["mi_engine.hip", "kernels_cartpole.hip", "kernels_ant.hip", "kernels_humanoid.hip", "kernels_anymal.hip", "kernels_shadow_hand.hip", "kernels_quadcopter.hip", "kernels_jit_twins.hip"]
 MI_MAX_DOF = 32
 
 # -fno-slp-vectorize: pairing scalars into v_pk_* ops lengthens live ranges in the fully unrolled sub-step
@@ -105,6 +105,28 @@ class MiHandParams(C.Structure):
                 ("force_decay_interval", C.c_float)]
 
 
+class MiFrankaCabinetRewardParams(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("dist_reward_scale", "rot_reward_scale", "around_handle_reward_scale", "open_reward_scale",
+                                         "finger_dist_reward_scale", "action_penalty_scale", "distX_offset", "max_episode_length")]
+
+
+class MiFrankaCubeStackRewardParams(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("r_dist_scale", "r_lift_scale", "r_align_scale", "r_stack_scale", "table_height",
+                                         "max_episode_length")]
+
+
+class MiTrifingerRewardParams(C.Structure):
+    _fields_ = [("episode_length", C.c_int32), ("dt", C.c_float), ("finger_move_penalty_weight", C.c_float),
+                ("finger_reach_object_weight", C.c_float), ("object_dist_weight", C.c_float), ("object_rot_weight", C.c_float),
+                ("env_steps_count", C.c_int64), ("use_keypoints", C.c_int32), ("keypoint_size", C.c_float * 3)]
+
+
+class MiDextremeRewardParams(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("max_episode_length", "dist_reward_scale", "rot_reward_scale", "rot_eps", "action_penalty_scale",
+                                         "action_delta_penalty_scale", "success_tolerance", "reach_goal_bonus", "fall_dist", "fall_penalty")] + \
+               [("max_consecutive_successes", C.c_int32), ("av_factor", C.c_float), ("num_success_hold_steps", C.c_int32)]
+
+
 class MiTaskInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("num_obs", "num_actions", "num_dofs", "num_bodies", "num_sensors",
                                          "num_contact_spheres", "fixed_base", "task_params_bytes")]
@@ -122,6 +144,10 @@ EXPORTS = ["mi_abi_version", "mi_task_info", "mi_engine_arena_bytes", "mi_engine
            "mi_compute_locomotion_observations", "mi_compute_locomotion_reward", "mi_compute_cartpole_reward",
            "mi_compute_hand_reward", "mi_compute_hand_full_state", "mi_randomize_rotation",
            "mi_compute_anymal_observations", "mi_compute_anymal_reward", "mi_compute_quadcopter_reward",
+           "mi_compute_bbot_reward", "mi_compute_ingenuity_reward", "mi_compute_franka_cabinet_reward", "mi_compute_grasp_transforms",
+           "mi_axisangle2quat", "mi_compute_franka_cube_stack_reward", "mi_randomize_rotation_pen", "mi_lgsk_kernel", "mi_gen_keypoints",
+           "mi_compute_trifinger_reward", "mi_compute_trifinger_observations_states", "mi_amp_dof_to_obs",
+           "mi_compute_humanoid_amp_observations", "mi_compute_humanoid_amp_reset", "mi_compute_hand_reward_dextreme",
            "mi_last_error"]
 
 
@@ -264,6 +290,22 @@ def lib():
     L.mi_compute_hand_reward.argtypes = [C.c_int, C.POINTER(MiHandRewardParams)] + [C.c_void_p] * 11 + [C.c_int, C.c_void_p, C.c_void_p]
     L.mi_compute_hand_full_state.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float] + [C.c_void_p] * 11 + [C.c_int, C.c_void_p]
     L.mi_randomize_rotation.argtypes = [C.c_int] + [C.c_void_p] * 6
+    V, F, I = C.c_void_p, C.c_float, C.c_int
+    L.mi_compute_bbot_reward.argtypes = [I, V, V, V, F, V, V, F, V, V, V]
+    L.mi_compute_ingenuity_reward.argtypes = [I] + [V] * 7 + [F, V, V, V]
+    L.mi_compute_franka_cabinet_reward.argtypes = [I, C.POINTER(MiFrankaCabinetRewardParams), V, V, V, I, V, I] + [V] * 13
+    L.mi_compute_grasp_transforms.argtypes = [I] + [V] * 13
+    L.mi_axisangle2quat.argtypes = [I, V, F, V, V]
+    L.mi_compute_franka_cube_stack_reward.argtypes = [I, C.POINTER(MiFrankaCubeStackRewardParams)] + [V] * 12
+    L.mi_randomize_rotation_pen.argtypes = [I, V, V, F, V, V, V, V, V]
+    L.mi_lgsk_kernel.argtypes = [I, V, F, F, V, V]
+    L.mi_gen_keypoints.argtypes = [I, V, I, C.POINTER(C.c_float), V, V]
+    L.mi_compute_trifinger_reward.argtypes = [I, C.POINTER(MiTrifingerRewardParams)] + [V] * 11
+    L.mi_compute_trifinger_observations_states.argtypes = [I, I, I, I, I, I] + [V] * 11
+    L.mi_amp_dof_to_obs.argtypes = [I, V, V, V]
+    L.mi_compute_humanoid_amp_observations.argtypes = [I, V, V, V, V, I, I, V, V]
+    L.mi_compute_humanoid_amp_reset.argtypes = [I, V, V, V, C.POINTER(C.c_int64), I, V, I, F, I, F, V, V, V]
+    L.mi_compute_hand_reward_dextreme.argtypes = [I, C.POINTER(MiDextremeRewardParams)] + [V] * 8 + [I] + [V] * 7 + [I, V, V, V]
     _lib = L
     return L
 

@@ -21,7 +21,7 @@ def lib():
 
 def test_every_declared_symbol_is_exported(lib):
     hdr = open(os.path.join(ROOT, "include", "mi_engine.h")).read()
-    declared = set(re.findall(r"\b(mi_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(native.EXPORTS), declared ^ set(native.EXPORTS)
     for s in declared:
         assert hasattr(lib, s), s
