@@ -310,7 +310,7 @@ int mi_compute_franka_cube_stack_reward(int n, const MiFrankaCubeStackRewardPara
                                         int64_t* reset_buf_out, void* stream);
 
 /* AllegroHand: compute_hand_reward (allegro_hand.py:663-718) is the same function as shadow_hand.py:746-800 -> mi_compute_hand_reward.
- * randomize_rotation_pen (allegro_hand.py:728-732): rand1 and y_unit are unused by the reference but must be valid pointers */
+ * randomize_rotation_pen (allegro_hand.py:728-732 == shadow_hand.py:809-813): rand1 and y_unit are unused by the reference but must be valid pointers */
 int mi_randomize_rotation_pen(int n, const float* rand0, const float* rand1, float max_angle, const float* x_unit, const float* y_unit,
                               const float* z_unit, float* out_quat, void* stream);
 
@@ -345,6 +345,8 @@ int mi_amp_dof_to_obs(int n, const float* pose, float* dof_obs, void* stream);
  * key_body_pos [n,num_key_bodies<=8,3] -> obs [n, 13 + 52 + 28 + 3 num_key_bodies] */
 int mi_compute_humanoid_amp_observations(int n, const float* root_states, const float* dof_pos, const float* dof_vel, const float* key_body_pos,
                                          int num_key_bodies, int local_root_obs, float* obs, void* stream);
+/* compute_humanoid_reward (amp/humanoid_amp_base.py:530-534): ones; obs_buf is read for its shape only and may be NULL */
+int mi_compute_humanoid_amp_reward(int n, const float* obs_buf, float* rew_buf, void* stream);
 /* compute_humanoid_reset (amp/humanoid_amp_base.py:536-564): contact_buf / rigid_body_pos [n,num_bodies<=64,3]; contact_body_ids is a
  * HOST int64 list; reset_buf_in is read for its shape only and may be NULL */
 int mi_compute_humanoid_amp_reset(int n, const int64_t* reset_buf_in, const int64_t* progress_buf, const float* contact_buf,

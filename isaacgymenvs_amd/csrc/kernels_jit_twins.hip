@@ -343,6 +343,18 @@ extern "C" int mi_compute_humanoid_amp_observations(int n, const float* root_sta
     TWIN_OK("mi_compute_humanoid_amp_observations");
     return 0;
 }
+__global__ void amp_reward_kernel(int n, float* rew) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) rew[e] = 1.f;
+}
+extern "C" int mi_compute_humanoid_amp_reward(int n, const float* obs_buf, float* rew_buf, void* stream) {
+    if (n <= 0) return 0;
+    (void)obs_buf;   // shape only (humanoid_amp_base.py:530-534: the task reward is constant, the style reward comes from the discriminator)
+    if (!rew_buf) return abi_fail("mi_compute_humanoid_amp_reward: null argument");
+    TWIN_LAUNCH(amp_reward_kernel, n, stream, rew_buf);
+    TWIN_OK("mi_compute_humanoid_amp_reward");
+    return 0;
+}
 __global__ void amp_reset_kernel(int n, const long long* progress, const float* contact, const float* body_pos, int nb, unsigned long long mask,
                                  float max_len, int early, float term_h, long long* reset, long long* terminated) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;

@@ -147,7 +147,7 @@ EXPORTS = ["mi_abi_version", "mi_task_info", "mi_engine_arena_bytes", "mi_engine
            "mi_compute_bbot_reward", "mi_compute_ingenuity_reward", "mi_compute_franka_cabinet_reward", "mi_compute_grasp_transforms",
            "mi_axisangle2quat", "mi_compute_franka_cube_stack_reward", "mi_randomize_rotation_pen", "mi_lgsk_kernel", "mi_gen_keypoints",
            "mi_compute_trifinger_reward", "mi_compute_trifinger_observations_states", "mi_amp_dof_to_obs",
-           "mi_compute_humanoid_amp_observations", "mi_compute_humanoid_amp_reset", "mi_compute_hand_reward_dextreme",
+           "mi_compute_humanoid_amp_observations", "mi_compute_humanoid_amp_reward", "mi_compute_humanoid_amp_reset", "mi_compute_hand_reward_dextreme",
            "mi_last_error"]
 
 
@@ -304,6 +304,7 @@ def lib():
     L.mi_compute_trifinger_observations_states.argtypes = [I, I, I, I, I, I] + [V] * 11
     L.mi_amp_dof_to_obs.argtypes = [I, V, V, V]
     L.mi_compute_humanoid_amp_observations.argtypes = [I, V, V, V, V, I, I, V, V]
+    L.mi_compute_humanoid_amp_reward.argtypes = [I, V, V, V]
     L.mi_compute_humanoid_amp_reset.argtypes = [I, V, V, V, C.POINTER(C.c_int64), I, V, I, F, I, F, V, V, V]
     L.mi_compute_hand_reward_dextreme.argtypes = [I, C.POINTER(MiDextremeRewardParams)] + [V] * 8 + [I] + [V] * 7 + [I, V, V, V]
     _lib = L

@@ -186,6 +186,9 @@ def test_humanoid_amp_kernels(golden_dir):
         native.check(L.mi_compute_humanoid_amp_observations(n, root.data_ptr(), q.data_ptr(), qd.data_ptr(), key.data_ptr(), nk, local,
                                                             obs.data_ptr(), _stream()))
         np.testing.assert_allclose(_np(obs), g[tag], atol=3e-6)
+    rew = torch.zeros(n, device=DEV)
+    native.check(L.mi_compute_humanoid_amp_reward(n, None, rew.data_ptr(), _stream()))      # humanoid_amp_base.py:530-534
+    assert bool((_np(rew) == 1.0).all())
     contact, pos, pr = _t(g["contact_buf"]), _t(g["rigid_body_pos"]), _i(g["progress"])
     ids = (C.c_int64 * len(g["contact_body_ids"]))(*[int(v) for v in g["contact_body_ids"]])
     for early, tag in ((1, "early"), (0, "noearly")):
