@@ -253,6 +253,19 @@ __global__ __launch_bounds__(64) void anymal_post_kernel(View v, AnymalParams p,
     v.timeout[e] = (unsigned char)((progress >= (long long)p.max_episode_length - 1) && (reset != 0));
 }
 
+// extras["episode"] (:421-425): means over the envs reset this step, divided by max_episode_length_s; terrain level mean.
+// Runs in block 0 of the height-scan kernel (the last kernel of the step: every post block has finished its atomics by then) and
+// leaves ep_stats zeroed for the next step, which saves a memset and a one-block launch per step.
+__device__ __forceinline__ void anymal_extras(const View& v, const AnymalParams& p, int k) {
+    float mine = 0.f, cnt = 0.f;
+    if (k < 16) { mine = v.ep_stats[k]; cnt = v.ep_stats[13]; }
+    __syncthreads();                                                                    // all reads before the zeroing below
+    if (k < kAnymalSums && cnt > 0.f) v.ep_means[k] = mine / cnt / p.max_episode_length_s;   // untouched when nobody reset (the
+    if (k == 14) v.ep_means[14] = mine / (float)v.N;                                         // reference keeps the last dict)
+    if (k == 13) v.ep_means[13] = mine;
+    if (k < 16) v.ep_stats[k] = 0.f;
+}
+
 // get_heights (:515-538) + the height columns of compute_observations (:311) + their noise (:481-482), one thread per
 // (env, scan point): 573 k threads at 4096 envs instead of a 140-iteration gather loop in each of 64 waves.  Runs after the post
 // kernel because the scan uses the POST-reset base pose; same functions, same draw indices => same values as a serial scan.
@@ -260,6 +273,7 @@ __global__ void anymal_heights_kernel(View v, AnymalParams p, AnymalTerrainDesc 
     MI_NO_CONTRACT
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int N = v.N;
+    if (blockIdx.x == 0) anymal_extras(v, p, threadIdx.x);
     if (t >= N * kAnymalHeightPts) return;
     const int e = t / kAnymalHeightPts, k = t - e * kAnymalHeightPts;
     const float root[7] = {v.root[e], v.root[N + e], v.root[2 * N + e], 0.f, 0.f, v.root[5 * N + e], v.root[6 * N + e]};
@@ -277,17 +291,6 @@ __global__ void anymal_heights_kernel(View v, AnymalParams p, AnymalTerrainDesc 
     const size_t o = (size_t)e * kAnymalObs + 36 + k;
     v.obs[o] = val;
     v.obs_out[(size_t)v.ring * N * kAnymalObs + o] = fminf(fmaxf(val, -v.clip_obs), v.clip_obs);
-}
-
-// extras["episode"] (:421-425): means over the envs reset this step, divided by max_episode_length_s; terrain level mean
-__global__ void anymal_extras_kernel(View v, AnymalParams p) {
-    const int k = threadIdx.x;
-    if (k < kAnymalSums) {
-        const float cnt = v.ep_stats[13];
-        if (cnt > 0.f) v.ep_means[k] = v.ep_stats[k] / cnt / p.max_episode_length_s;   // untouched when nobody reset (the
-    }                                                                                   // reference keeps the last dict)
-    if (k == 14) v.ep_means[14] = v.ep_stats[14] / (float)v.N;
-    if (k == 13) v.ep_means[13] = v.ep_stats[13];
 }
 
 // ------------------------------------------------------------------------------------------------ init / explicit reset
@@ -385,12 +388,9 @@ hipError_t launch_step_anymal(const View& v, const SimParams& P, const AnymalPar
         return hipErrorInvalidValue;  // mi_engine_step refuses to run AnymalTerrain before mi_engine_set_terrain
     }
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(v.ep_stats, 0, 16 * sizeof(float), s);
-    if (e != hipSuccess) return e;
     if (tp.curriculum) hipLaunchKernelGGL(anymal_cmdnorm_kernel, dim3((v.N + 63) / 64), dim3(64), 0, s, v, tp);
     hipLaunchKernelGGL(anymal_post_kernel, dim3((v.N + 63) / 64), dim3(64), 0, s, v, tp, T, step_counter);
     hipLaunchKernelGGL(anymal_heights_kernel, dim3((v.N * kAnymalHeightPts + 255) / 256), dim3(256), 0, s, v, tp, T, step_counter);
-    hipLaunchKernelGGL(anymal_extras_kernel, dim3(1), dim3(64), 0, s, v, tp);
     return hipGetLastError();
 }
 hipError_t launch_simulate_anymal(const View& v, const SimParams& P, const AnymalTerrainDesc& T, hipStream_t s) {
