@@ -118,6 +118,8 @@ def measure(task, num_envs, steps, warmup, device, rank, world, seed=42, pool=8)
 # per-wave issue time is the floor of the step on the current one-env-per-lane design; reported next to the mandatory HBM roofline.
 WAVE_INSTRS_PER_STEP = {"Ant": 2 * 10790 + 1200, "Humanoid": 2 * 36030 + 3570}   # SQ_INSTS_VALU + SALU + LDS per wave (profiles/r1_pmc_summary.md)
 ISSUE_NS_PER_INSTR = 2.55
+WAVE_VALU_PER_STEP = {"Ant": 2 * 9210 + 1104, "Humanoid": 2 * 30899 + 3385, "AnymalTerrain": 5 * 15148 + 2718, "ShadowHand": 2 * 62341 + 1313 + 7549}
+VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 
 
 def roofline(task, num_envs, kernel_ms):
@@ -129,6 +131,13 @@ def roofline(task, num_envs, kernel_ms):
            "traffic": traffic, "kernel": "mi::substep_kernel<%s> (x sim steps) + post kernel = one step" % task,
            "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
            "note": "latency/issue-bound path: %d waves of %d envs, one per SIMD; see DESIGN.md" % ((num_envs + lanes - 1) // lanes, lanes)}
+    if task in WAVE_VALU_PER_STEP:
+        # SURVEY 8(d) asks for the fp32 side next to the HBM fraction: executed VALU lane-operations (SQ_INSTS_VALU per wave x waves x
+        # lanes) against what the chip can issue, 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-ops/s (an FMA counts once)
+        waves = (num_envs + lanes - 1) // lanes
+        lane_ops = WAVE_VALU_PER_STEP[task] * waves * lanes / (kernel_ms * 1e-3)
+        out["valu"] = {"achieved": lane_ops / 1e12, "peak": VALU_PEAK_TLANEOPS, "unit": "T lane-ops/s", "frac": lane_ops / 1e12 / VALU_PEAK_TLANEOPS,
+                       "note": "%d of 1024 SIMDs hold a wave at this env count" % waves}
     if task in WAVE_INSTRS_PER_STEP:
         floor_ms = WAVE_INSTRS_PER_STEP[task] * ISSUE_NS_PER_INSTR * 1e-6
         out["single_wave_issue_floor"] = {"instructions_per_wave_per_step": WAVE_INSTRS_PER_STEP[task], "ns_per_instruction": ISSUE_NS_PER_INSTR,
@@ -166,9 +175,24 @@ def cpu_baseline(task, num_envs, budget_s=15.0, seed=42):
         n += 1
     dt = time.perf_counter() - t0
     cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-    return {"value": num_envs * n / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} steps of {task} num_envs={num_envs} (oracle/physics.c fp32, OpenMP over envs + numpy obs/reward), "
-                      f"{dt:.1f} s; stand-in for PhysX-CPU, which cannot run here"}
+    out = {"value": num_envs * n / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+           "sample": f"{n} steps of {task} num_envs={num_envs} (oracle/physics.c fp32, OpenMP over envs + numpy obs/reward), "
+                     f"{dt:.1f} s; stand-in for PhysX-CPU, which cannot run here"}
+    # the reference's CPU pipeline runs PhysX on `num_threads: 4` (cfg/config.yaml:30): the same port on 4 OpenMP threads, a short sample
+    try:
+        import ctypes
+        gomp = ctypes.CDLL("libgomp.so.1")
+        gomp.omp_set_num_threads(4)
+        n4, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s / 3 and n4 < 2000:
+            orc.step(rng.uniform(-1, 1, (num_envs, nact)).astype(np.float32))
+            n4 += 1
+        dt4 = time.perf_counter() - t0
+        gomp.omp_set_num_threads(cores)
+        out["threads4"] = {"value": num_envs * n4 / dt4, "unit": "env-steps/s", "cores": 4, "sample": f"{n4} steps, {dt4:.1f} s"}
+    except OSError:
+        pass
+    return out
 
 
 def main():
