@@ -169,29 +169,31 @@ def cpu_baseline(task, num_envs, budget_s=15.0, seed=42):
     nact = orc.nd
     for _ in range(2):
         orc.step(rng.uniform(-1, 1, (num_envs, nact)).astype(np.float32))
-    n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < budget_s and n < 2000:
-        orc.step(rng.uniform(-1, 1, (num_envs, nact)).astype(np.float32))
-        n += 1
-    dt = time.perf_counter() - t0
-    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-    out = {"value": num_envs * n / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-           "sample": f"{n} steps of {task} num_envs={num_envs} (oracle/physics.c fp32, OpenMP over envs + numpy obs/reward), "
-                     f"{dt:.1f} s; stand-in for PhysX-CPU, which cannot run here"}
-    # the reference's CPU pipeline runs PhysX on `num_threads: 4` (cfg/config.yaml:30): the same port on 4 OpenMP threads, a short sample
+    # OpenMP over envs: more threads is not monotonically faster (at 4096 envs a chunk is 16 envs on 256 threads and the numpy obs /
+    # reward share is serial), so the port is timed at several thread counts, ~budget_s in total, and the best one is the baseline;
+    # 4 threads is also what the reference's CPU pipeline gives PhysX (`num_threads: 4`, cfg/config.yaml:30).
+    import ctypes
+    all_cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
     try:
-        import ctypes
         gomp = ctypes.CDLL("libgomp.so.1")
-        gomp.omp_set_num_threads(4)
-        n4, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < budget_s / 3 and n4 < 2000:
-            orc.step(rng.uniform(-1, 1, (num_envs, nact)).astype(np.float32))
-            n4 += 1
-        dt4 = time.perf_counter() - t0
-        gomp.omp_set_num_threads(cores)
-        out["threads4"] = {"value": num_envs * n4 / dt4, "unit": "env-steps/s", "cores": 4, "sample": f"{n4} steps, {dt4:.1f} s"}
     except OSError:
-        pass
+        gomp = None
+    counts = sorted({c for c in (4, 16, 64, all_cores) if c <= all_cores}) if gomp is not None else [all_cores]
+    sweep = {}
+    for c in counts:
+        if gomp is not None:
+            gomp.omp_set_num_threads(c)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s / len(counts) and n < 2000:
+            orc.step(rng.uniform(-1, 1, (num_envs, nact)).astype(np.float32))
+            n += 1
+        dt = time.perf_counter() - t0
+        sweep[c] = (num_envs * n / dt, n, dt)
+    best = max(sweep, key=lambda c: sweep[c][0])
+    out = {"value": sweep[best][0], "unit": "env-steps/s", "cores": best, "kind": "port",
+           "sample": f"{sweep[best][1]} steps of {task} num_envs={num_envs} (oracle/physics.c fp32, OpenMP over envs + numpy obs/reward), "
+                     f"{sweep[best][2]:.1f} s on {best} threads (best of the sweep); stand-in for PhysX-CPU, which cannot run here",
+           "thread_sweep": {str(c): round(v[0]) for c, v in sweep.items()}, "host_threads": all_cores}
     return out
 
 
