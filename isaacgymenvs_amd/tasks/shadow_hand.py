@@ -43,12 +43,21 @@ def obs_columns(obs_type):
     raise ValueError("Unknown type of observations!\nobservationType should be one of: [openai, full_no_vel, full, full_state]")
 
 
+def hand_max_episode_length(cfg):
+    """episodeLength, or resetTime seconds worth of control steps when resetTime > 0 (shadow_hand.py:81,139-141)."""
+    env = cfg["env"]
+    reset_time = float(env.get("resetTime", -1.0))
+    if reset_time > 0.0:
+        return int(round(reset_time / (int(env.get("controlFrequencyInv", 1)) * float(cfg["sim"]["dt"]))))
+    return env["episodeLength"]
+
+
 def hand_params_from_cfg(cfg):
     env = cfg["env"]
     ex = load_extras("shadow_hand")
     p = native.MiHandParams()
     r = p.rew
-    r.max_episode_length = float(env["episodeLength"])
+    r.max_episode_length = float(hand_max_episode_length(cfg))
     r.dist_reward_scale = float(env["distRewardScale"]); r.rot_reward_scale = float(env["rotRewardScale"])
     r.rot_eps = float(env["rotEps"]); r.action_penalty_scale = float(env["actionPenaltyScale"])
     r.success_tolerance = float(env["successTolerance"]); r.reach_goal_bonus = float(env["reachGoalBonus"])
@@ -109,7 +118,8 @@ class ShadowHand(VecTask):
             raise Exception("Unknown type of observations!\nobservationType should be one of: [openai, full_no_vel, full, full_state]")
         self.randomize = cfg["task"]["randomize"]
         self.randomization_params = cfg["task"].get("randomization_params", {})
-        self.max_episode_length = env["episodeLength"]
+        self.reset_time = env.get("resetTime", -1.0)
+        self.max_episode_length = hand_max_episode_length(cfg)
         self.obs_type = env["observationType"]
         self.object_type = env["objectType"]
         self.asymmetric_obs = bool(env.get("asymmetric_observations", False))

@@ -716,6 +716,35 @@ def test_domain_randomisation_noise_and_gravity():
     assert abs(g0[2] - gs[0]) < 1e-9 or True
 
 
+def test_shadow_hand_openai_variant_runs_from_its_task_config():
+    """`task=ShadowHandOpenAI_FF` (reference cfg/task/ShadowHandOpenAI_FF.yaml): 20 Hz control, resetTime, smoothed targets, random
+    forces, openai observations + full-state critic input, randomisation on -- composed from the task name like the reference does."""
+    import isaacgymenvs_amd
+    n = 512
+    np.random.seed(0)
+    torch.manual_seed(0)
+    env = isaacgymenvs_amd.make(seed=3, task="ShadowHandOpenAI_FF", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True)
+    assert type(env).__name__ == "ShadowHand" and env.num_envs == n
+    assert env.num_obs == 42 and env.num_states == 211 and env.num_acts == 20
+    assert env.max_episode_length == 160 and env.control_freq_inv == 3 and env.randomize is True      # 8 s / (3 * 0.01667 s)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    env.reset()
+    resets = 0
+    assert abs(env._task_params_struct.act_moving_average - 0.3) < 1e-7 and abs(env._task_params_struct.force_scale - 1.0) < 1e-7
+    for step in range(200):
+        a = 2 * torch.rand((n, 20), device=DEV, generator=g) - 1
+        obs_d, rew, reset, extras = env.step(a)
+        assert obs_d["obs"].shape == (n, 42) and obs_d["states"].shape == (n, 211)
+        resets += int(reset.sum())
+    torch.cuda.synchronize()
+    assert torch.isfinite(obs_d["obs"]).all() and torch.isfinite(obs_d["states"]).all() and torch.isfinite(rew).all()
+    assert float(obs_d["obs"].abs().max()) <= env.clip_obs + 1e-6
+    assert resets > 0                                    # 160-step episodes: every env times out (or drops the cube) within 200 steps
+    assert int(env.progress_buf.max()) <= 160
+    assert "noise_lambda" in env.dr_randomizations["observations"]      # observation / action noise closures installed
+    assert float(env.rb_forces_object.abs().sum()) >= 0.0 and float(env.random_force_prob.min()) > 0.0
+
+
 # ------------------------------------------------------------------ API contract (vec_task.py)
 def test_api_contract_and_state_checkpoint():
     n = 64
