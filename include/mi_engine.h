@@ -339,6 +339,19 @@ int mi_compute_trifinger_observations_states(int n, int asymmetric_obs, int num_
                                              const float* joint_torques, const float* tip_wrenches, float* obs_buf, float* states_buf,
                                              void* stream);
 
+/* Trifinger cuboid-pose samplers (trifinger.py:1427-1512).  The reference draws from torch.rand / torch.randn inside the jitted function; these
+ * take the SAME draws as a tensor (columns in the order the reference calls the generator) and apply the same map:
+ * random_xy: rand2 [n,2] (radius draw, angle draw) -> xy [n,2];  random_z: rand1 [n] -> z [n];  default_orientation -> quat [n,4];
+ * random_orientation: randn4 [n,4] -> quat;  random_orientation_within_angle: rand3 [n,3], base [n,4] -> quat;
+ * random_angular_vel: randn4 [n,4] = axis draws 3 + magnitude draw 1 -> angvel [n,3];  random_yaw_orientation: rand1 [n] -> quat */
+int mi_trifinger_random_xy(int n, const float* rand2, float max_com_distance_to_center, float* xy, void* stream);
+int mi_trifinger_random_z(int n, const float* rand1, float min_height, float max_height, float* z, void* stream);
+int mi_trifinger_default_orientation(int n, float* quat, void* stream);
+int mi_trifinger_random_orientation(int n, const float* randn4, float* quat, void* stream);
+int mi_trifinger_random_orientation_within_angle(int n, const float* rand3, const float* base, float max_angle, float* quat, void* stream);
+int mi_trifinger_random_angular_vel(int n, const float* randn4, float magnitude_stdev, float* angvel, void* stream);
+int mi_trifinger_random_yaw_orientation(int n, const float* rand1, float* quat, void* stream);
+
 /* HumanoidAMP: dof_to_obs (amp/humanoid_amp_base.py:462-492): pose [n,28] -> dof_obs [n,52] */
 int mi_amp_dof_to_obs(int n, const float* pose, float* dof_obs, void* stream);
 /* compute_humanoid_observations (amp/humanoid_amp_base.py:494-528) == build_amp_observations (humanoid_amp.py:299-330):

@@ -305,6 +305,56 @@ extern "C" int mi_compute_trifinger_observations_states(int n, int asymmetric_ob
     return 0;
 }
 
+// cuboid-pose samplers (trifinger.py:1427-1512) on injected draws: kind 0 random_xy (rand [n,2] -> out [n,2]), 1 random_z (rand [n] -> [n]),
+// 2 default_orientation (-> [n,4]), 3 random_orientation (randn [n,4] -> [n,4]), 4 random_orientation_within_angle (rand [n,3], base [n,4]
+// -> [n,4]), 5 random_angular_vel (randn [n,4] = axis 3 + magnitude 1 -> [n,3]), 6 random_yaw_orientation (rand [n] -> [n,4])
+__global__ void trifinger_sample_kernel(int n, int kind, const float* draws, const float* base, float a0, float a1, float* out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float q[4];
+    switch (kind) {
+        case 0: { const float u[2] = {draws[2 * e], draws[2 * e + 1]}; tri_random_xy(u, a0, out + 2 * e, out + 2 * e + 1); return; }
+        case 1: out[e] = tri_random_z(draws[e], a0, a1); return;
+        case 2: q[0] = q[1] = q[2] = 0.f; q[3] = 1.f; break;
+        case 3: { const float g[4] = {draws[4 * e], draws[4 * e + 1], draws[4 * e + 2], draws[4 * e + 3]}; tri_random_orientation(g, q); break; }
+        case 4: { const float u[3] = {draws[3 * e], draws[3 * e + 1], draws[3 * e + 2]};
+                  const float b[4] = {base[4 * e], base[4 * e + 1], base[4 * e + 2], base[4 * e + 3]};
+                  tri_random_orientation_within_angle(u, b, a0, q); break; }
+        case 5: { const float g[4] = {draws[4 * e], draws[4 * e + 1], draws[4 * e + 2], draws[4 * e + 3]}; float w[3]; tri_random_angular_vel(g, a0, w);
+                  for (int k = 0; k < 3; ++k) out[3 * e + k] = w[k]; return; }
+        default: tri_random_yaw_orientation(draws[e], q); break;
+    }
+    for (int k = 0; k < 4; ++k) out[4 * e + k] = q[k];
+}
+static int trifinger_sample(const char* name, int n, int kind, const float* draws, const float* base, float a0, float a1, float* out, void* stream) {
+    if (n <= 0) return 0;
+    if (!out || (kind != 2 && !draws) || (kind == 4 && !base)) return abi_fail((std::string(name) + ": null argument").c_str());
+    TWIN_LAUNCH(trifinger_sample_kernel, n, stream, kind, draws, base, a0, a1, out);
+    TWIN_OK(name);
+    return 0;
+}
+extern "C" int mi_trifinger_random_xy(int n, const float* rand2, float max_com_distance_to_center, float* xy, void* stream) {
+    return trifinger_sample("mi_trifinger_random_xy", n, 0, rand2, nullptr, max_com_distance_to_center, 0.f, xy, stream);
+}
+extern "C" int mi_trifinger_random_z(int n, const float* rand1, float min_height, float max_height, float* z, void* stream) {
+    return trifinger_sample("mi_trifinger_random_z", n, 1, rand1, nullptr, min_height, max_height, z, stream);
+}
+extern "C" int mi_trifinger_default_orientation(int n, float* quat, void* stream) {
+    return trifinger_sample("mi_trifinger_default_orientation", n, 2, nullptr, nullptr, 0.f, 0.f, quat, stream);
+}
+extern "C" int mi_trifinger_random_orientation(int n, const float* randn4, float* quat, void* stream) {
+    return trifinger_sample("mi_trifinger_random_orientation", n, 3, randn4, nullptr, 0.f, 0.f, quat, stream);
+}
+extern "C" int mi_trifinger_random_orientation_within_angle(int n, const float* rand3, const float* base, float max_angle, float* quat, void* stream) {
+    return trifinger_sample("mi_trifinger_random_orientation_within_angle", n, 4, rand3, base, max_angle, 0.f, quat, stream);
+}
+extern "C" int mi_trifinger_random_angular_vel(int n, const float* randn4, float magnitude_stdev, float* angvel, void* stream) {
+    return trifinger_sample("mi_trifinger_random_angular_vel", n, 5, randn4, nullptr, magnitude_stdev, 0.f, angvel, stream);
+}
+extern "C" int mi_trifinger_random_yaw_orientation(int n, const float* rand1, float* quat, void* stream) {
+    return trifinger_sample("mi_trifinger_random_yaw_orientation", n, 6, rand1, nullptr, 0.f, 0.f, quat, stream);
+}
+
 // ------------------------------------------------------------------------------------------------ HumanoidAMP
 __global__ void amp_dof_to_obs_kernel(int n, const float* pose, float* out) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;

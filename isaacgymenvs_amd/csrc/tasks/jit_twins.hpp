@@ -263,6 +263,53 @@ MI_HD void trifinger_reward(const TrifingerRewardParams& p, long long progress, 
     *finger_reach_object_reward_out = finger_reach_object_reward;
 }
 
+// The cuboid-pose samplers (trifinger.py:1427-1505) draw from torch.rand / torch.randn INSIDE the jitted function; the twins take the
+// same draws as an input tensor (column order = the order the reference calls the generator in) and apply the same map.
+MI_HD void tri_random_xy(const float* u /*2*/, float max_com_distance_to_center, float* x, float* y) {   // :1427-1439
+    MI_NO_CONTRACT
+    float radius = sqrtf(u[0]);
+    radius = radius * max_com_distance_to_center;
+    const float theta = (2.f * 3.14159265358979323846f) * u[1];
+    *x = radius * cosf(theta);
+    *y = radius * sinf(theta);
+}
+MI_HD float tri_random_z(float u, float min_height, float max_height) { MI_NO_CONTRACT return (max_height - min_height) * u + min_height; }   // :1442-1448
+MI_HD void tri_random_orientation(const float* g /*4 normal draws*/, float* q) {   // :1460-1470 (F.normalize, eps 1e-12)
+    MI_NO_CONTRACT
+    const float n = fmaxf(sqrtf(((g[0] * g[0] + g[1] * g[1]) + g[2] * g[2]) + g[3] * g[3]), 1e-12f);
+    for (int k = 0; k < 4; ++k) q[k] = g[k] / n;
+}
+MI_HD void tri_random_orientation_within_angle(const float* u /*3*/, const float* base, float max_angle, float* out) {   // :1472-1493
+    MI_NO_CONTRACT
+    const float c = cosf(u[0] * max_angle);
+    const float n = sqrtf((1.f - c) / 2.f);
+    float q[4];
+    q[3] = sqrtf((1.f + c) / 2.f);
+    q[2] = (u[1] * 2.f - 1.f) * n;
+    const float s = sqrtf(1.f - q[2] * q[2]);
+    const float ang = (2.f * 3.14159265358979323846f) * u[2];
+    q[0] = (s * cosf(ang)) * n;
+    q[1] = (s * sinf(ang)) * n;
+    const float m = fmaxf(sqrtf(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]), 1e-12f);
+    for (int k = 0; k < 4; ++k) q[k] = q[k] / m;
+    quat_mul(q, base, out);
+}
+MI_HD void tri_random_angular_vel(const float* g /*4 normal draws: axis 3, magnitude 1*/, float magnitude_stdev, float* w) {   // :1495-1503
+    MI_NO_CONTRACT
+    const float n = norm3(g);
+    const float mag = g[3] * magnitude_stdev;
+    for (int k = 0; k < 3; ++k) w[k] = mag * (g[k] / n);
+}
+MI_HD void tri_random_yaw_orientation(float u, float* q) {   // :1505-1512 with quat_from_euler_xyz (torch_jit_utils.py:199-212), roll = pitch = 0
+    MI_NO_CONTRACT
+    const float yaw = (2.f * 3.14159265358979323846f) * u;
+    const float cy = cosf(yaw * 0.5f), sy = sinf(yaw * 0.5f), cr = 1.f, sr = 0.f, cp = 1.f, sp = 0.f;
+    q[3] = cy * cr * cp + sy * sr * sp;
+    q[0] = cy * sr * cp - sy * cr * sp;
+    q[1] = cy * cr * sp + sy * sr * cp;
+    q[2] = sy * cr * cp - cy * sr * sp;
+}
+
 // ------------------------------------------------------------------------------------------------ HumanoidAMP
 MI_HD void quat_to_tan_norm(const float* q, float* o /*6*/) {   // torch_jit_utils.py:548-560
     const float rt[3] = {1.f, 0.f, 0.f}, rn[3] = {0.f, 0.f, 1.f};

@@ -146,7 +146,9 @@ EXPORTS = ["mi_abi_version", "mi_task_info", "mi_engine_arena_bytes", "mi_engine
            "mi_compute_anymal_observations", "mi_compute_anymal_reward", "mi_compute_quadcopter_reward",
            "mi_compute_bbot_reward", "mi_compute_ingenuity_reward", "mi_compute_franka_cabinet_reward", "mi_compute_grasp_transforms",
            "mi_axisangle2quat", "mi_compute_franka_cube_stack_reward", "mi_randomize_rotation_pen", "mi_lgsk_kernel", "mi_gen_keypoints",
-           "mi_compute_trifinger_reward", "mi_compute_trifinger_observations_states", "mi_amp_dof_to_obs",
+           "mi_compute_trifinger_reward", "mi_compute_trifinger_observations_states", "mi_trifinger_random_xy", "mi_trifinger_random_z",
+           "mi_trifinger_default_orientation", "mi_trifinger_random_orientation", "mi_trifinger_random_orientation_within_angle",
+           "mi_trifinger_random_angular_vel", "mi_trifinger_random_yaw_orientation", "mi_amp_dof_to_obs",
            "mi_compute_humanoid_amp_observations", "mi_compute_humanoid_amp_reward", "mi_compute_humanoid_amp_reset", "mi_compute_hand_reward_dextreme",
            "mi_last_error"]
 
@@ -302,6 +304,13 @@ def lib():
     L.mi_gen_keypoints.argtypes = [I, V, I, C.POINTER(C.c_float), V, V]
     L.mi_compute_trifinger_reward.argtypes = [I, C.POINTER(MiTrifingerRewardParams)] + [V] * 11
     L.mi_compute_trifinger_observations_states.argtypes = [I, I, I, I, I, I] + [V] * 11
+    L.mi_trifinger_random_xy.argtypes = [I, V, F, V, V]
+    L.mi_trifinger_random_z.argtypes = [I, V, F, F, V, V]
+    L.mi_trifinger_default_orientation.argtypes = [I, V, V]
+    L.mi_trifinger_random_orientation.argtypes = [I, V, V, V]
+    L.mi_trifinger_random_orientation_within_angle.argtypes = [I, V, V, F, V, V]
+    L.mi_trifinger_random_angular_vel.argtypes = [I, V, F, V, V]
+    L.mi_trifinger_random_yaw_orientation.argtypes = [I, V, V, V]
     L.mi_amp_dof_to_obs.argtypes = [I, V, V, V]
     L.mi_compute_humanoid_amp_observations.argtypes = [I, V, V, V, V, I, I, V, V]
     L.mi_compute_humanoid_amp_reward.argtypes = [I, V, V, V]

@@ -339,3 +339,53 @@ def compute_hand_reward_dextreme(rew_buf, reset_buf, reset_goal_buf, progress_bu
     cons = f32(av_factor) * fin / num_resets + (f32(1.0) - f32(av_factor)) * cs if num_resets > 0 else cs
     return (reward, resets, goal_resets, progress, hold, successes, f32(cons), dist_rew, rot_rew, action_penalty, action_delta_penalty,
             velocity_penalty, reach_goal_rew, fall_rew, timeout_rew)
+
+
+# ------------------------------------------------------------------ tasks/trifinger.py cuboid-pose samplers on injected draws
+def tri_random_xy(u, max_com_distance_to_center):
+    """trifinger.py:1427-1439; u[:, 0] is the radius draw, u[:, 1] the angle draw."""
+    radius = np.sqrt(u[:, 0].astype(f32)) * f32(max_com_distance_to_center)
+    theta = f32(2 * np.pi) * u[:, 1].astype(f32)
+    return (radius * np.cos(theta).astype(f32)).astype(f32), (radius * np.sin(theta).astype(f32)).astype(f32)
+
+
+def tri_random_z(u, min_height, max_height):
+    """trifinger.py:1442-1448."""
+    return ((f32(max_height) - f32(min_height)) * u.astype(f32) + f32(min_height)).astype(f32)
+
+
+def tri_random_orientation(g):
+    """trifinger.py:1460-1470."""
+    g = g.astype(f32)
+    n = np.maximum(np.sqrt(((g[:, 0] * g[:, 0] + g[:, 1] * g[:, 1]) + g[:, 2] * g[:, 2]) + g[:, 3] * g[:, 3]).astype(f32), f32(1e-12))
+    return (g / n[:, None]).astype(f32)
+
+
+def tri_random_orientation_within_angle(u, base, max_angle):
+    """trifinger.py:1472-1493."""
+    u = u.astype(f32)
+    c = np.cos(u[:, 0] * f32(max_angle)).astype(f32)
+    n = np.sqrt((f32(1.) - c) / f32(2.)).astype(f32)
+    q = np.zeros((len(u), 4), f32)
+    q[:, 3] = np.sqrt((f32(1) + c) / f32(2.))
+    q[:, 2] = (u[:, 1] * f32(2.) - f32(1.)) * n
+    s = np.sqrt(f32(1) - q[:, 2] * q[:, 2]).astype(f32)
+    ang = f32(2 * np.pi) * u[:, 2]
+    q[:, 0] = (s * np.cos(ang).astype(f32)) * n
+    q[:, 1] = (s * np.sin(ang).astype(f32)) * n
+    return quat_mul(tri_random_orientation(q), base.astype(f32))
+
+
+def tri_random_angular_vel(g, magnitude_stdev):
+    """trifinger.py:1495-1503; g[:, 0:3] the axis draws, g[:, 3] the magnitude draw."""
+    g = g.astype(f32)
+    axis = g[:, 0:3] / _norm3(g[:, 0:3])[:, None]
+    return ((g[:, 3:4] * f32(magnitude_stdev)) * axis).astype(f32)
+
+
+def tri_random_yaw_orientation(u):
+    """trifinger.py:1505-1512 with quat_from_euler_xyz (utils/torch_jit_utils.py:199-212), roll = pitch = 0."""
+    yaw = f32(2 * np.pi) * u.astype(f32)
+    cy, sy = np.cos(yaw * f32(0.5)).astype(f32), np.sin(yaw * f32(0.5)).astype(f32)
+    z = np.zeros_like(cy)
+    return np.stack([z, z, sy, cy], axis=-1).astype(f32)

@@ -171,6 +171,34 @@ def test_trifinger_kernels(golden_dir):
         np.testing.assert_array_equal(_np(st), o["states_" + tag])
 
 
+def test_trifinger_sampler_kernels(golden_dir):
+    L = native.lib()
+    g = _load(golden_dir, "trifinger_samplers")
+    n = len(g["z"])
+    out2, out1, out4, out3 = torch.empty(n, 2, device=DEV), torch.empty(n, device=DEV), torch.empty(n, 4, device=DEV), torch.empty(n, 3, device=DEV)
+    u = _t(g["rand_xy"])
+    native.check(L.mi_trifinger_random_xy(n, u.data_ptr(), float(g["scalar_max_dist"]), out2.data_ptr(), _stream()))
+    np.testing.assert_allclose(_np(out2), g["xy"], atol=3e-8)
+    u = _t(g["rand_z"])
+    native.check(L.mi_trifinger_random_z(n, u.data_ptr(), float(g["scalar_min_height"]), float(g["scalar_max_height"]), out1.data_ptr(), _stream()))
+    np.testing.assert_allclose(_np(out1), g["z"], atol=1e-8)
+    native.check(L.mi_trifinger_default_orientation(n, out4.data_ptr(), _stream()))
+    np.testing.assert_array_equal(_np(out4), g["default"])
+    u = _t(g["randn_orientation"])
+    native.check(L.mi_trifinger_random_orientation(n, u.data_ptr(), out4.data_ptr(), _stream()))
+    np.testing.assert_allclose(_np(out4), g["orientation"], atol=2e-7)
+    u, b = _t(g["rand_within"]), _t(g["base"])
+    native.check(L.mi_trifinger_random_orientation_within_angle(n, u.data_ptr(), b.data_ptr(), float(g["scalar_max_angle"]), out4.data_ptr(), _stream()))
+    np.testing.assert_allclose(_np(out4), g["within"], atol=3e-6)     # sqrt((1 - cos)/2) amplifies the last bit of cos
+    u = _t(g["randn_angvel"])
+    native.check(L.mi_trifinger_random_angular_vel(n, u.data_ptr(), float(g["scalar_magnitude_stdev"]), out3.data_ptr(), _stream()))
+    np.testing.assert_allclose(_np(out3), g["angvel"], atol=4e-7)
+    u = _t(g["rand_yaw"])
+    native.check(L.mi_trifinger_random_yaw_orientation(n, u.data_ptr(), out4.data_ptr(), _stream()))
+    np.testing.assert_allclose(_np(out4), g["yaw"], atol=3e-7)
+    assert L.mi_trifinger_random_xy(n, None, 0.1, out2.data_ptr(), _stream()) == -1 and b"null argument" in L.mi_last_error()
+
+
 def test_humanoid_amp_kernels(golden_dir):
     L = native.lib()
     d = _load(golden_dir, "amp_dof_to_obs")

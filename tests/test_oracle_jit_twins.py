@@ -150,3 +150,21 @@ def test_dextreme_hand_reward(golden_dir):
         else:
             np.testing.assert_allclose(o, np.squeeze(g[k]), rtol=2e-5, atol=1e-5, err_msg=k)
     assert g["goal_resets"].sum() > 0 and g["resets"].sum() > 0 and (g["hold_count"] > 0).any()
+
+
+def test_trifinger_samplers_on_the_reference_draws(golden_dir):
+    """trifinger.py:1427-1512 draw inside the jitted function; the golden file holds the draws the global generator handed them
+    (replayed with the same seed) next to their outputs."""
+    g = _load(golden_dir, "trifinger_samplers")
+    x, y = J.tri_random_xy(g["rand_xy"], float(g["scalar_max_dist"]))
+    np.testing.assert_allclose(np.stack([x, y], -1), g["xy"], atol=2e-8)
+    np.testing.assert_allclose(J.tri_random_z(g["rand_z"], float(g["scalar_min_height"]), float(g["scalar_max_height"])), g["z"], atol=1e-8)
+    np.testing.assert_allclose(J.tri_random_orientation(g["randn_orientation"]), g["orientation"], atol=2e-7)
+    np.testing.assert_allclose(J.tri_random_orientation_within_angle(g["rand_within"], g["base"], float(g["scalar_max_angle"])), g["within"], atol=3e-6)   # sqrt((1 - cos)/2) amplifies the last bit of cos for small angles
+    np.testing.assert_allclose(J.tri_random_angular_vel(g["randn_angvel"], float(g["scalar_magnitude_stdev"])), g["angvel"], atol=3e-7)
+    np.testing.assert_allclose(J.tri_random_yaw_orientation(g["rand_yaw"]), g["yaw"], atol=2e-7)
+    assert np.array_equal(g["default"], np.tile(np.array([0, 0, 0, 1], np.float32), (len(g["default"]), 1)))
+    # reference quirk kept as is: the construction uses sqrt(1 - z^2) with the already n-scaled z (trifinger.py:1487-1488), so the vector
+    # part is longer than sin(theta / 2) before the re-normalisation and the result can exceed max_angle (0.78 rad here for 0.6)
+    d = J.quat_diff_rad(g["within"], g["base"])
+    assert float(g["scalar_max_angle"]) < float(d.max()) < 1.5 * float(g["scalar_max_angle"])

@@ -205,6 +205,28 @@ def main():
     save("trifinger_obs", dof_position=dof_pos, dof_velocity=dof_vel, object_state=obj, object_goal_poses=goal, actions=actions, fingertip_state=ft,
          joint_torques=tau, tip_wrenches=wrench, obs_sym=obs_s, states_sym=st_s, obs_asym=obs_a, states_asym=st_a)
 
+    # the cuboid-pose samplers draw inside the jitted function: replay the global generator to capture the draws they consume
+    def replay(seed, *shapes_kinds):
+        torch.manual_seed(seed)
+        return [torch.rand(s) if k == "u" else torch.randn(s) for s, k in shapes_kinds]
+    u0, u1 = replay(101, ((n,), "u"), ((n,), "u"))
+    torch.manual_seed(101); x, y = m.random_xy(n, 0.08, "cpu")
+    (uz,) = replay(102, ((n,), "u"))
+    torch.manual_seed(102); z = m.random_z(n, 0.0325, 0.1, "cpu")
+    (g4,) = replay(103, ((n, 4), "n"))
+    torch.manual_seed(103); qo = m.random_orientation(n, "cpu")
+    (u3,) = replay(104, ((n, 3), "u"))
+    base = unit(g, n)
+    torch.manual_seed(104); qw = m.random_orientation_within_angle(n, "cpu", base, 0.6)
+    ax, mg = replay(105, ((n, 3), "n"), ((n, 1), "n"))
+    torch.manual_seed(105); av = m.random_angular_vel(n, "cpu", 0.5)
+    (uy,) = replay(106, ((n,), "u"))
+    torch.manual_seed(106); qy = m.random_yaw_orientation(n, "cpu")
+    save("trifinger_samplers", rand_xy=torch.stack([u0, u1], -1), xy=torch.stack([x, y], -1), rand_z=uz, z=z, randn_orientation=g4, orientation=qo,
+         rand_within=u3, base=base, within=qw, randn_angvel=torch.cat([ax, mg], -1), angvel=av, rand_yaw=uy, yaw=qy,
+         default=m.default_orientation(n, "cpu"), scalar_max_dist=0.08, scalar_min_height=0.0325, scalar_max_height=0.1, scalar_max_angle=0.6,
+         scalar_magnitude_stdev=0.5)
+
     # ---- HumanoidAMP
     g = torch.Generator().manual_seed(17)
     m = imp("amp.humanoid_amp_base")
