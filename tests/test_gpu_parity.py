@@ -200,6 +200,59 @@ def test_simulate_matches_cpu_oracle(task, z_lo, z_hi, gear):
     print(f"{task}: worst |hip - oracle_f64| over 3 steps = {worst:.2e}")
 
 
+# ------------------------------------------------------------------ known answers on the HIP kernels themselves (not via the oracle)
+@pytest.mark.parametrize("task,z0", [("Ant", 5.0), ("Humanoid", 6.0)])
+def test_free_fall_closed_form_on_the_gpu(task, z0):
+    """No contact, no effort: every env falls with v_k = -g k h and z_k = z0 - g h^2 k (k + 1) / 2 (semi-implicit Euler, h = dt / substeps);
+    the root is not the centre of mass, so z is compared with a band that covers the small limb motion (as tests/test_oracle_physics.py)."""
+    n = 128
+    env = _make_env(task, n)
+    spec = load_model(task.lower())
+    lo, up = np.minimum(spec.dof_lower, spec.dof_upper), np.maximum(spec.dof_lower, spec.dof_upper)
+    q0 = np.where(lo > 0, lo, np.where(up < 0, up, 0.0))                       # inside the limits: no limit row fires
+    t = env.engine.tensors
+    root = np.zeros((n, 13), np.float32); root[:, 2] = z0; root[:, 6] = 1.0
+    t["root_states"][:] = _t(root); env.dof_pos[:] = _t(np.tile(q0, (n, 1))); env.dof_vel.zero_()
+    t["contact_impulse"].zero_(); t["limit_impulse"].zero_(); t["dof_actuation_force"].zero_()
+    steps = 30
+    for _ in range(steps):
+        env.engine.simulate()
+    torch.cuda.synchronize()
+    g = 9.81
+    h = float(env.sim_params.dt) / int(env.sim_params.substeps)
+    k = steps * int(env.sim_params.substeps)
+    r = t["root_states"].cpu().numpy()
+    # the root is not the centre of mass: passive joint springs / dampers settling let it move by millimetres relative to the COM
+    assert np.abs(r[:, 9] + g * k * h).max() < 0.05, np.abs(r[:, 9] + g * k * h).max()
+    assert np.abs(r[:, 2] - (z0 - g * h * h * k * (k + 1) / 2)).max() < 2e-2
+    assert np.abs(r[:, 0:2]).max() < 1e-2 and np.abs(r[:, 10:13]).max() < 0.5
+    assert float(env.vec_sensor_tensor.abs().max()) < 1e-3                       # nothing touches anything
+    assert np.ptp(r[:, 2]) < 1e-6                                                 # every lane computes the same fall
+
+
+def test_joint_limits_hold_against_a_constant_effort_on_the_gpu():
+    """A hinge pushed into its limit by a constant effort stops there (zero gravity, no ground): overshoot within the ERP band,
+    velocity ~ 0, and the reported dof_force (applied + limit reaction) ~ 0 at rest."""
+    n = 64
+    env = _make_env("Ant", n)
+    spec = load_model("ant")
+    lo, up = np.minimum(spec.dof_lower, spec.dof_upper), np.maximum(spec.dof_lower, spec.dof_upper)
+    for ax in "xyz":
+        env.engine.set_option("gravity_" + ax, 0.0)
+    t = env.engine.tensors
+    root = np.zeros((n, 13), np.float32); root[:, 2] = 3.0; root[:, 6] = 1.0
+    t["root_states"][:] = _t(root); env.dof_pos[:] = _t(np.tile(0.5 * (lo + up), (n, 1))); env.dof_vel.zero_()
+    t["contact_impulse"].zero_(); t["limit_impulse"].zero_()
+    tau = np.zeros((n, spec.nd), np.float32); tau[:, 0] = 2.0; tau[:, 1] = -2.0
+    t["dof_actuation_force"][:] = _t(tau)
+    for _ in range(300):
+        env.engine.simulate()
+    torch.cuda.synchronize()
+    q, qd = env.dof_pos.cpu().numpy(), env.dof_vel.cpu().numpy()
+    assert np.abs(q[:, 0] - up[0]).max() < 0.02 and np.abs(q[:, 1] - lo[1]).max() < 0.02, (q[0, :2], up[0], lo[1])
+    assert np.abs(qd[:, 0:2]).max() < 5e-2
+
+
 def test_cartpole_simulate_matches_cpu_oracle_and_ode():
     from oracle.engine import OracleEngine
     n = 64
