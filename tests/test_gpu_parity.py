@@ -253,6 +253,36 @@ def test_joint_limits_hold_against_a_constant_effort_on_the_gpu():
     assert np.abs(qd[:, 0:2]).max() < 5e-2
 
 
+def test_shadow_hand_cube_free_flight_on_the_gpu():
+    """The cube far above the hand, thrown with a spin: linear velocity follows gravity exactly, the angular velocity of an isotropic
+    body is constant, the orientation advances by |w| t about the spin axis and stays a unit quaternion."""
+    n = 64
+    env = _make_env("ShadowHand", n)
+    t = env.engine.tensors
+    st = np.zeros((n, 13), np.float32)
+    st[:, 0:3] = [0.3, -0.2, 2.0]; st[:, 6] = 1.0
+    st[:, 7:10] = [0.4, -0.3, 1.0]
+    w = np.array([1.5, -2.0, 0.7], np.float32)
+    st[:, 10:13] = w
+    env.object_state[:] = _t(st)
+    steps = 20
+    for _ in range(steps):
+        env.engine.simulate()
+    torch.cuda.synchronize()
+    o = env.object_state.cpu().numpy()
+    h = float(env.sim_params.dt) / int(env.sim_params.substeps)
+    k = steps * int(env.sim_params.substeps)
+    np.testing.assert_allclose(o[:, 7:9], st[:, 7:9], atol=1e-6)
+    np.testing.assert_allclose(o[:, 9], 1.0 - 9.81 * k * h, atol=2e-5)
+    np.testing.assert_allclose(o[:, 2], 2.0 + 1.0 * k * h - 9.81 * h * h * k * (k + 1) / 2, atol=1e-4)
+    np.testing.assert_allclose(o[:, 10:13], np.tile(w, (n, 1)), atol=1e-6)
+    np.testing.assert_allclose(np.linalg.norm(o[:, 3:7], axis=1), 1.0, atol=1e-6)
+    ang = 2 * np.arccos(np.clip(np.abs(o[:, 6]), 0, 1))
+    np.testing.assert_allclose(ang, np.linalg.norm(w) * k * h, atol=2e-4)
+    axis = o[:, 3:6] / np.linalg.norm(o[:, 3:6], axis=1, keepdims=True)
+    np.testing.assert_allclose(axis, np.tile(w / np.linalg.norm(w), (n, 1)), atol=2e-4)
+
+
 def test_cartpole_simulate_matches_cpu_oracle_and_ode():
     from oracle.engine import OracleEngine
     n = 64
