@@ -23,7 +23,11 @@ struct FreeBody {           // world frame
 struct ObjectParams {       // mirrors the object part of MiHandParams
     float half, mass, inertia, mu;   // cube half size, mass, isotropic inertia, combined friction
     float fw[3] = {0.f, 0.f, 0.f};   // external world-frame force on the object for this step (apply_rigid_body_force_tensors)
+    // objects other than the cube (SHAPE != 0): semi-axes of the ellipsoid and the principal inertias about the body axes
+    float dims[3] = {0.f, 0.f, 0.f};
+    float inertia3[3] = {0.f, 0.f, 0.f};
 };
+constexpr int OBJ_BOX = 0, OBJ_ELLIPSOID = 2;   // objectType "block" / "egg" (shadow_hand.py:86-96); 1 is reserved for the pen's capsule
 
 template <class M>
 struct HandSim : Sim<M> {
@@ -63,9 +67,37 @@ struct HandSim : Sim<M> {
         n[2] = outside ? dz * inv : ((!ix && !iy) ? (c[2] >= 0.f ? 1.f : -1.f) : 0.f);
     }
 
+    // sphere (centre c in the object frame, radius r) vs ellipsoid with semi-axes a: first-order signed distance f / |grad f| of
+    // f = |c / a| - 1 scaled back to length (exact on the surface and along the axes, a few % off one radius away -- contacts live within
+    // contact_offset = 2 mm of the surface), outward normal = normalised gradient (exact direction on the surface)
+    MI_HD static void sphere_ellipsoid(const float* c, float r, const float* a, float* dist, float* n) {
+        const float u[3] = {c[0] / a[0], c[1] / a[1], c[2] / a[2]};
+        const float g[3] = {u[0] / a[0], u[1] / a[1], u[2] / a[2]};
+        const float k0 = MI_SQRT(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+        const float k1sq = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
+        const bool ok = k1sq > 1e-20f;
+        const float ik1 = MI_RSQ(fmaxf(k1sq, 1e-30f));
+        *dist = (ok ? k0 * (k0 - 1.f) * ik1 : -fminf(a[0], fminf(a[1], a[2]))) - r;
+        n[0] = ok ? g[0] * ik1 : 0.f; n[1] = ok ? g[1] * ik1 : 0.f; n[2] = ok ? g[2] * ik1 : 1.f;
+    }
+    template <int SHAPE>
+    MI_HD static void sphere_object(const float* c, float r, const ObjectParams& OP, float* dist, float* n) {
+        if constexpr (SHAPE == OBJ_BOX) sphere_box(c, r, OP.half, dist, n);
+        else sphere_ellipsoid(c, r, OP.dims, dist, n);
+    }
+    // y = Ro diag(s) Ro^T x: a body-diagonal operator (inertia^{+-1/2}) applied to a world-frame vector
+    MI_HD static void body_diag(const float* Ro, const float* s, const float* x, float* y) {
+        float t[3];
+        matTvec3(Ro, x, t);
+        sfor<3>([&](auto K) MI_LAMBDA { t[K] *= s[K]; });
+        matvec3(Ro, t, y);
+    }
+
     // one sub-step of length h.  target[ND]: drive targets; laml: warm-start limit impulses; sensor: 6*NSENS fingertip
     // force/torque (body frame); dof_force[ND]; ncontact: number of object contacts taken (diagnostic)
-    template <int RS>
+    // SHAPE: OBJ_BOX (isotropic inertia OP.inertia, the benchmark configuration -- code unchanged) or OBJ_ELLIPSOID (OP.dims, OP.inertia3:
+    // the angular part of the object's whitened velocity / rows goes through Ro diag(I^{+-1/2}) Ro^T; no gyroscopic torque, as PhysX's default)
+    template <int RS, int SHAPE = OBJ_BOX>
     MI_HD void substep_hand(const SimParams& P, const ObjectParams& OP, const float* target, const float h, const RowStore<RS> rows,
                             const Strided laml, const Strided sensor, const Strided dof_force, int* ncontact) {
         constexpr int ST = RowStore<RS>::stride;
@@ -149,12 +181,18 @@ struct HandSim : Sim<M> {
             sfor<M::nanc[i]>([&](auto A_) MI_LAMBDA { s += L[M::midx[i][M::anc[i][A_]]] * qd[M::anc[i][A_]]; });
             w[i] = s + h * z;
         });
-        const float sm = MI_SQRT(OP.mass), si = MI_SQRT(OP.inertia);
+        const float sm = MI_SQRT(OP.mass), si = MI_SQRT(SHAPE == OBJ_BOX ? OP.inertia : 1.f);
         const float ism = MI_RCP(sm), isi = MI_RCP(si);
         float wo[6];
         sfor<3>([&](auto K) MI_LAMBDA { wo[K] = sm * (obj.vel[K] + h * (P.g[K] + OP.fw[K] * (ism * ism))); wo[3 + K] = si * obj.angvel[K]; });
         float Ro[9];
         quat2mat(obj.quat, Ro);
+        float isqI[3] = {1.f, 1.f, 1.f};     // SHAPE != OBJ_BOX: 1 / sqrt of the principal inertias
+        if constexpr (SHAPE != OBJ_BOX) {
+            float sqI[3];
+            sfor<3>([&](auto K) MI_LAMBDA { sqI[K] = MI_SQRT(OP.inertia3[K]); isqI[K] = MI_RCP(sqI[K]); });
+            body_diag(Ro, sqI, obj.angvel, wo + 3);
+        }
         const float xo[3] = {obj.pos[0] - root[0], obj.pos[1] - root[1], obj.pos[2] - root[2]};   // object COM rel O
         MI_PHASE();
         // ------------------------------------------------------------ joint limit rows (as core/engine.hpp)
@@ -214,7 +252,7 @@ struct HandSim : Sim<M> {
                     const float rel[3] = {cs[0] - xo[0], cs[1] - xo[1], cs[2] - xo[2]};
                     float cl[3], nl[3], dist;
                     matTvec3(Ro, rel, cl);
-                    sphere_box(cl, rad, OP.half, &dist, nl);
+                    sphere_object<SHAPE>(cl, rad, OP, &dist, nl);
                     // contact manifold: at most BODY_CAP contacts per hand body, taken in the body's (spread-out, farthest-point) sphere
                     // order, so that a cube lying on the 30-sphere palm cannot use up all KMAX slots before the fingers are looked at
                     const bool on = (dist < P.contact_offset) && (cnt < KMAX) && (nbody < BODY_CAP);
@@ -248,6 +286,7 @@ struct HandSim : Sim<M> {
                             // object part: J_o = -[u; rc x u], whitened by the constant diagonal
                             float cx[3];
                             cross3(rc, fr[k], cx);
+                            if constexpr (SHAPE != OBJ_BOX) { float cw[3]; body_diag(Ro, isqI, cx, cw); sfor<3>([&](auto I_) MI_LAMBDA { cx[I_] = cw[I_]; }); }
                             sfor<3>([&](auto I_) MI_LAMBDA { g[CL + I_] = -fr[k][I_] * ism; g[CL + 3 + I_] = -cx[I_] * isi; });
                             float a = P.cfm;
                             sfor<CL + 6>([&](auto C) MI_LAMBDA { a += g[C] * g[C]; cb[(k * UCH + C) * ST] = g[C]; });
@@ -393,7 +432,7 @@ struct HandSim : Sim<M> {
                         const float rel[3] = {cs[0] - xo[0], cs[1] - xo[1], cs[2] - xo[2]};
                         float cl[3], nl[3], dist, n[3], t1[3], t2[3];
                         matTvec3(Ro, rel, cl);
-                        sphere_box(cl, rad, OP.half, &dist, nl);
+                        sphere_object<SHAPE>(cl, rad, OP, &dist, nl);
                         matvec3(Ro, nl, n);
                         contact_frame(n, t1, t2);
                         float f[3], arm[3], tq[3], fl[3], tl[3];
@@ -416,6 +455,7 @@ struct HandSim : Sim<M> {
             obj.vel[K] = wo[K] * ism; obj.angvel[K] = wo[3 + K] * isi;
             obj.pos[K] += h * obj.vel[K];
         });
+        if constexpr (SHAPE != OBJ_BOX) { float om[3]; body_diag(Ro, isqI, wo + 3, om); sfor<3>([&](auto K) MI_LAMBDA { obj.angvel[K] = om[K]; }); }
         {
             const float* om = obj.angvel;
             const float an = MI_SQRT(dot3(om, om)), th = an * h;

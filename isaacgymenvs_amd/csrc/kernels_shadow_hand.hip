@@ -142,6 +142,7 @@ __global__ void hand_pre_kernel(View v, HandView hv, HandParams p, const float* 
 }
 
 // gym.simulate(): one physics sub-step of hand + cube
+template <int SHAPE>
 __global__ __launch_bounds__(32) void hand_substep_kernel(View v, HandView hv, SimParams P, HandParams p) {
     extern __shared__ float lds_rows[];
     constexpr int ND = kHandDof, LANES = HS::LANES;
@@ -161,12 +162,13 @@ __global__ __launch_bounds__(32) void hand_substep_kernel(View v, HandView hv, S
     sfor<3>([&](auto K) MI_LAMBDA { sim.obj.pos[K] = hv.object_state[K * N + e]; sim.obj.vel[K] = hv.object_state[(7 + K) * N + e];
                                     sim.obj.angvel[K] = hv.object_state[(10 + K) * N + e]; });
     sfor<4>([&](auto K) MI_LAMBDA { sim.obj.quat[K] = hv.object_state[(3 + K) * N + e]; });
-    const ObjectParams OP{p.cube_half, p.cube_mass, p.cube_inertia, p.mu,
-                          {hv.obj_force[e], hv.obj_force[N + e], hv.obj_force[2 * N + e]}};
+    ObjectParams OP{p.cube_half, p.cube_mass, p.cube_inertia, p.mu,
+                    {hv.obj_force[e], hv.obj_force[N + e], hv.obj_force[2 * N + e]}};
+    if constexpr (SHAPE != OBJ_BOX) sfor<3>([&](auto K) MI_LAMBDA { OP.dims[K] = p.object_dims[K]; OP.inertia3[K] = p.object_inertia[K]; });
     const float h = P.dt / (float)P.substeps;
     int nc = 0;
-    sim.substep_hand(P, OP, target, h, RowStore<LANES>{lds_rows + threadIdx.x}, Strided{v.laml + e, N}, Strided{v.sensor + e, N},
-                     Strided{v.dof_force + e, N}, &nc);
+    sim.template substep_hand<LANES, SHAPE>(P, OP, target, h, RowStore<LANES>{lds_rows + threadIdx.x}, Strided{v.laml + e, N}, Strided{v.sensor + e, N},
+                                            Strided{v.dof_force + e, N}, &nc);
     sfor<ND>([&](auto K) MI_LAMBDA { v.dof[K * N + e] = sim.q[K]; v.dof[(ND + K) * N + e] = sim.qd[K]; });
     sfor<3>([&](auto K) MI_LAMBDA { hv.object_state[K * N + e] = sim.obj.pos[K]; hv.object_state[(7 + K) * N + e] = sim.obj.vel[K];
                                     hv.object_state[(10 + K) * N + e] = sim.obj.angvel[K]; });
@@ -296,14 +298,19 @@ __global__ void hand_init_kernel(View v, HandView hv, HandParams p) {
     if (e == 0) { hv.cons[0] = 0.f; hv.ws[0] = hv.ws[1] = 0.f; for (int k = 0; k < 8; ++k) v.stats[k] = 0.f; }
 }
 
-static hipError_t hand_substeps(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s) {
+template <int SHAPE>
+static hipError_t hand_substeps_shape(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s) {
     constexpr size_t lds = (size_t)HS::ROW_SLOTS * HS::LANES * sizeof(float);
     static_assert(lds <= 160 * 1024, "hand row store must fit LDS");
     static unsigned long long configured = 0ull;
-    if (hipError_t e = ensure_dynamic_lds((const void*)hand_substep_kernel, lds, &configured); e != hipSuccess) return e;
+    if (hipError_t e = ensure_dynamic_lds((const void*)hand_substep_kernel<SHAPE>, lds, &configured); e != hipSuccess) return e;
     for (int i = 0; i < n; ++i)
-        hipLaunchKernelGGL(hand_substep_kernel, dim3((v.N + HS::LANES - 1) / HS::LANES), dim3(HS::LANES), lds, s, v, hv, P, p);
+        hipLaunchKernelGGL(hand_substep_kernel<SHAPE>, dim3((v.N + HS::LANES - 1) / HS::LANES), dim3(HS::LANES), lds, s, v, hv, P, p);
     return hipGetLastError();
+}
+static hipError_t hand_substeps(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s) {
+    if (p.object_shape == OBJ_ELLIPSOID) return hand_substeps_shape<OBJ_ELLIPSOID>(v, hv, P, p, n, s);
+    return hand_substeps_shape<OBJ_BOX>(v, hv, P, p, n, s);   // mi_engine_create admits no other shape
 }
 
 hipError_t launch_step_shadow_hand(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, const float* actions, int cfi,

@@ -32,6 +32,8 @@ struct HandParams {   // mirrors MiHandParams (include/mi_engine.h): what Shadow
     int obs_type, num_obs, asymmetric_obs;                    // observationType (:97-110), asymmetric_observations (:88)
     short obs_map[160];                                       // obs_buf[:, k] = full_state[:, obs_map[k]] for obs_type != 0
     float force_scale, force_prob_range[2], force_decay, force_decay_interval;   // :69-72
+    int object_shape;                                         // objectType (:86-96): 0 block (cube_* above), 2 egg (ellipsoid below)
+    float object_dims[3], object_inertia[3];                  // egg: semi-axes (egg.xml:10) and principal inertias of the solid ellipsoid
 };
 
 MI_HD void quat_conjugate(const float* a, float* o) { o[0] = -a[0]; o[1] = -a[1]; o[2] = -a[2]; o[3] = a[3]; }

@@ -102,7 +102,8 @@ class MiHandParams(C.Structure):
                 ("actuated", C.c_int32 * 20),
                 ("obs_type", C.c_int32), ("num_obs", C.c_int32), ("asymmetric_obs", C.c_int32), ("obs_map", C.c_int16 * 160),
                 ("force_scale", C.c_float), ("force_prob_range", C.c_float * 2), ("force_decay", C.c_float),
-                ("force_decay_interval", C.c_float)]
+                ("force_decay_interval", C.c_float),
+                ("object_shape", C.c_int32), ("object_dims", C.c_float * 3), ("object_inertia", C.c_float * 3)]
 
 
 class MiFrankaCabinetRewardParams(C.Structure):

@@ -2,9 +2,9 @@
 (reference isaacgymenvs/tasks/shadow_hand.py).
 
 Host side only: config -> MiHandParams and the reference's attribute names as views of the engine arena.  Supported
-subset: objectType "block" (the cube: an isotropic free body), all four observation layouts (full_state 211, full 157,
+subset: objectType "block" (the cube: an isotropic free body) and "egg" (ellipsoid, principal inertias), all four observation layouts (full_state 211, full 157,
 full_no_vel 77, openai 42), asymmetric observations (states_buf = full state), absolute or relative position control,
-random object forces (forceScale > 0), in-kernel resets.  Not supported (raise): egg / pen objects.  Physics simplifications are listed
+random object forces (forceScale > 0), in-kernel resets.  Not supported (raise): the pen object.  Physics simplifications are listed
 in DESIGN.md (hand geometry sampled by spheres against the exact box, no hand self-collision, soft tendons, drive force
 limits not clamped).
 """
@@ -19,6 +19,11 @@ from .base.vec_task import VecTask
 
 CUBE_SIZE = 0.05          # assets/urdf/objects/cube_multicolor.urdf: box 0.05
 CUBE_DENSITY = 567.0
+
+
+OBJECT_SHAPE_ID = {"block": 0, "pen": 1, "egg": 2}   # include/mi_engine.h MiHandParams.object_shape (1 is refused by the engine)
+EGG_SEMI_AXES = (0.03, 0.03, 0.04)
+EGG_DENSITY = 1000.0
 
 
 NUM_OBS = {"openai": 42, "full_no_vel": 77, "full": 157, "full_state": 211}     # shadow_hand.py:101-106
@@ -87,6 +92,18 @@ def hand_params_from_cfg(cfg):
     p.cube_mass = CUBE_DENSITY * CUBE_SIZE ** 3
     p.cube_inertia = p.cube_mass * CUBE_SIZE ** 2 / 6.0
     p.mu = 1.0
+    p.object_shape = OBJECT_SHAPE_ID[env.get("objectType", "block")]
+    if env.get("objectType", "block") == "egg":
+        # mjcf/open_ai_assets/hand/egg.xml:10: ellipsoid, semi-axes 0.03 0.03 0.04, no mass given -> AssetOptions.density default 1000 kg/m^3
+        a, b, c = EGG_SEMI_AXES
+        m = EGG_DENSITY * 4.0 / 3.0 * np.pi * a * b * c
+        p.cube_mass = m                                           # the object's mass, whatever its shape
+        p.cube_half = max(EGG_SEMI_AXES)
+        inertia = (m / 5.0 * (b * b + c * c), m / 5.0 * (a * a + c * c), m / 5.0 * (a * a + b * b))
+        p.cube_inertia = sum(inertia) / 3.0
+        for k in range(3):
+            p.object_dims[k] = EGG_SEMI_AXES[k]
+            p.object_inertia[k] = inertia[k]
     for a, d in enumerate(ex["actuated_dofs"]):
         p.actuated[a] = int(d)
     ot = env["observationType"]
@@ -112,8 +129,10 @@ class ShadowHand(VecTask):
                  force_render=False):
         self.cfg = cfg
         env = cfg["env"]
-        if env["objectType"] != "block":
-            raise NotImplementedError("only objectType 'block' is implemented (the cube is an isotropic free body)")
+        if env["objectType"] not in ("block", "egg", "pen"):                        # shadow_hand.py:86-87
+            raise AssertionError("objectType must be one of block, egg, pen")
+        if env["objectType"] == "pen":
+            raise NotImplementedError("objectType 'pen' is not implemented: an 8 mm capsule falls through the sphere-sampled hand geometry")
         if env["observationType"] not in NUM_OBS:                                   # shadow_hand.py:97-99
             raise Exception("Unknown type of observations!\nobservationType should be one of: [openai, full_no_vel, full, full_state]")
         self.randomize = cfg["task"]["randomize"]

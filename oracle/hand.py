@@ -55,8 +55,22 @@ def sphere_box(c_local, r, half):
     return -pen[i] - r, n
 
 
+def sphere_ellipsoid(c_local, r, axes):
+    """first-order signed distance of a sphere (centre in the object frame) to an ellipsoid with semi-axes `axes`:
+    f / |grad f| with f = |c / a| - 1, scaled to length; outward normal = normalised gradient (csrc/core/hand_engine.hpp)."""
+    a = np.asarray(axes, float)
+    u = c_local / a
+    g = u / a
+    k0 = np.linalg.norm(u); k1 = np.linalg.norm(g)
+    if k1 * k1 <= 1e-20:
+        return -a.min() - r, np.array([0.0, 0.0, 1.0])
+    return k0 * (k0 - 1.0) / k1 - r, g / k1
+
+
 class OracleHandEngine:
-    def __init__(self, spec, extras, num_envs, sim: dict, sensor_bodies):
+    def __init__(self, spec, extras, num_envs, sim: dict, sensor_bodies, obj=None):
+        # obj: None = the 5 cm cube; dict(shape="egg", dims=semi-axes, mass=, inertia=principal inertias) = an ellipsoid
+        self.objp = obj
         self.spec, self.ex, self.N = spec, extras, num_envs
         self.eng = OracleEngine(spec, num_envs, params=dict(sim, gravity=(0.0, 0.0, 0.0)), sensor_bodies=sensor_bodies, precision="f64")
         self.sim = sim
@@ -131,7 +145,9 @@ class OracleHandEngine:
         v = qd + h * (Minv @ rhs)
         g = np.array(P["gravity"], float)
         xo, qo = self.obj[e, 0:3].copy(), self.obj[e, 3:7].copy()
-        vo = self.obj[e, 7:10] + h * (g + self.obj_force[e] / CUBE_MASS)   # + apply_rigid_body_force_tensors on the cube
+        egg = self.objp is not None
+        omass = float(self.objp["mass"]) if egg else CUBE_MASS
+        vo = self.obj[e, 7:10] + h * (g + self.obj_force[e] / omass)   # + apply_rigid_body_force_tensors on the object
         wo = self.obj[e, 10:13].copy()
         Ro = quat2mat(qo)
         # ---- rows
@@ -158,7 +174,10 @@ class OracleHandEngine:
         for si in range(len(self.os_body)):
             b = int(self.os_body[si])
             c = bp[b, 0:3] + bp[b, 3:12].reshape(3, 3) @ self.os_pos[si]      # world
-            dist, nl = sphere_box(Ro.T @ (c - xo), self.os_rad[si], CUBE_HALF)
+            if egg:
+                dist, nl = sphere_ellipsoid(Ro.T @ (c - xo), self.os_rad[si], self.objp["dims"])
+            else:
+                dist, nl = sphere_box(Ro.T @ (c - xo), self.os_rad[si], CUBE_HALF)
             if dist >= P["contact_offset"] or ncon >= KMAX or per_body.get(b, 0) >= BODY_CAP:
                 continue
             per_body[b] = per_body.get(b, 0) + 1
@@ -175,9 +194,12 @@ class OracleHandEngine:
             contacts.append(dict(b=b, pc=pc, n=n, t1=t1, t2=t2, row0=len(rows) - 3))
             ncon += 1
         self.ncontacts[e] = ncon
-        Moinv = np.array([1 / CUBE_MASS] * 3 + [1 / CUBE_INERTIA] * 3)
+        Moinv = np.zeros((6, 6))
+        Moinv[:3, :3] = np.eye(3) / omass
+        # world-frame inverse inertia: Ro diag(1 / I) Ro^T for the ellipsoid's principal inertias, a multiple of identity for the cube
+        Moinv[3:, 3:] = Ro @ np.diag(1.0 / np.asarray(self.objp["inertia"], float)) @ Ro.T if egg else np.eye(3) / CUBE_INERTIA
         for r in rows:
-            r["Bh"] = Minv @ r["Jh"]; r["Bo"] = Moinv * r["Jo"]
+            r["Bh"] = Minv @ r["Jh"]; r["Bo"] = Moinv @ r["Jo"]
             r["Ainv"] = 1.0 / (P["cfm"] + r["Jh"] @ r["Bh"] + r["Jo"] @ r["Bo"])
             if r["lam"] != 0.0:
                 v += r["Bh"] * r["lam"]

@@ -908,7 +908,10 @@ class OracleShadowHandEnv:
     def __init__(self, spec, extras, sensor_bodies, sim_params: dict, params, num_envs, seed=0, env_id_offset=0):
         from .hand import OracleHandEngine
         self.N, self.p, self.nd = num_envs, params, spec.nd
-        self.eng = OracleHandEngine(spec, extras, num_envs, sim_params, sensor_bodies)
+        obj = None
+        if int(getattr(params, "object_shape", 0)) == 2:                          # objectType "egg"
+            obj = dict(shape="egg", dims=list(params.object_dims), mass=float(params.cube_mass), inertia=list(params.object_inertia))
+        self.eng = OracleHandEngine(spec, extras, num_envs, sim_params, sensor_bodies, obj=obj)
         self.eng.eng.root[:, :3] = list(params.hand_pos)
         self.eng.eng.root[:, 3:7] = list(params.hand_quat)
         self.seed, self.off = fold_seed(seed), env_id_offset

@@ -253,6 +253,38 @@ def test_joint_limits_hold_against_a_constant_effort_on_the_gpu():
     assert np.abs(qd[:, 0:2]).max() < 5e-2
 
 
+def test_shadow_hand_egg_free_flight_spins_about_its_symmetry_axis():
+    """Ellipsoid object (objectType egg), no contact: spinning about the symmetry axis (a principal axis) the angular velocity is constant;
+    the engine, like PhysX by default, applies no gyroscopic torque, so angular momentum I w is what the whitened state carries: a spin about
+    a non-principal axis keeps R diag(I) R^T w ... here only the principal-axis case, which any integrator must hold, is asserted."""
+    import isaacgymenvs_amd
+    n = 32
+    cfg = compose(overrides=["task=ShadowHand"])
+    cfg["task"]["env"]["numEnvs"] = n
+    cfg["task"]["env"]["objectType"] = "egg"
+    env = isaacgymenvs_amd.make(seed=1, task="ShadowHand", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True, cfg=cfg)
+    st = np.zeros((n, 13), np.float32)
+    st[:, 0:3] = [0.3, -0.2, 2.0]
+    q = np.array([0.3, -0.2, 0.1, 0.9], np.float32); q /= np.linalg.norm(q)
+    st[:, 3:7] = q
+    # world-frame direction of the body z axis (the egg's long, symmetry axis)
+    x, y, z, w = q
+    zaxis = np.array([2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y)], np.float32)
+    st[:, 10:13] = 3.0 * zaxis
+    env.object_state[:] = _t(st)
+    for _ in range(20):
+        env.engine.simulate()
+    torch.cuda.synchronize()
+    o = env.object_state.cpu().numpy()
+    np.testing.assert_allclose(o[:, 10:13], st[:, 10:13], atol=2e-5)
+    np.testing.assert_allclose(np.linalg.norm(o[:, 3:7], axis=1), 1.0, atol=1e-6)
+    k, h = 20 * int(env.sim_params.substeps), float(env.sim_params.dt) / int(env.sim_params.substeps)
+    np.testing.assert_allclose(o[:, 9], -9.81 * k * h, atol=2e-5)
+    # the symmetry axis itself does not move
+    x, y, z, w = o[0, 3:7]
+    np.testing.assert_allclose([2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y)], zaxis, atol=1e-4)
+
+
 def test_shadow_hand_cube_free_flight_on_the_gpu():
     """The cube far above the hand, thrown with a spin: linear velocity follows gravity exactly, the angular velocity of an isotropic
     body is constant, the orientation advances by |w| t about the spin axis and stays a unit quaternion."""
@@ -633,11 +665,17 @@ def test_quadcopter_full_size_properties():
 
 
 # ------------------------------------------------------------------ ShadowHand (hand + cube physics, deferred resets, full_state obs)
-def test_shadow_hand_step_matches_cpu_restatement():
+@pytest.mark.parametrize("object_type", ["block", "egg"])
+def test_shadow_hand_step_matches_cpu_restatement(object_type):
+    import isaacgymenvs_amd
     from isaacgymenvs_amd.registry import load_extras
     from oracle.tasks import OracleShadowHandEnv
     n, seed = 64, 13
-    env = _make_env("ShadowHand", n, seed=seed)
+    cfg = compose(overrides=["task=ShadowHand"])
+    cfg["task"]["env"]["numEnvs"] = n
+    cfg["task"]["env"]["objectType"] = object_type          # egg: ellipsoid 3 x 3 x 4 cm with principal inertias (egg.xml)
+    env = isaacgymenvs_amd.make(seed=seed, task="ShadowHand", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True, cfg=cfg)
+    assert env._task_params_struct.object_shape == {"block": 0, "egg": 2}[object_type]
     orc = OracleShadowHandEnv(load_model("shadow_hand"), load_extras("shadow_hand"), sensor_bodies("shadow_hand"),
                               _sim_dict(env.sim_params), env._task_params_struct, n, seed=seed)
     g = torch.Generator(device="cpu").manual_seed(7)
