@@ -142,8 +142,8 @@ typedef struct {
     /* random object forces (shadow_hand.py:69-72, 196-201, 700-708); force_scale <= 0 disables them */
     float force_scale, force_prob_range[2], force_decay, force_decay_interval;
     /* objectType (shadow_hand.py:86-96): 0 "block" (the cube_* fields), 2 "egg" = ellipsoid with semi-axes object_dims
-     * (mjcf/open_ai_assets/hand/egg.xml:10) and principal inertias object_inertia; cube_mass is the object's mass for every shape.
-     * 1 is reserved for "pen" (capsule), which mi_engine_create refuses. */
+     * (mjcf/open_ai_assets/hand/egg.xml:10), 1 "pen" = capsule along the object's z axis, object_dims = {radius, half length, -}
+     * (pen.xml:20); object_inertia = principal inertias about the object's axes; cube_mass is the object's mass for every shape. */
     int32_t object_shape;
     float object_dims[3], object_inertia[3];
 } MiHandParams;

@@ -27,7 +27,7 @@ struct ObjectParams {       // mirrors the object part of MiHandParams
     float dims[3] = {0.f, 0.f, 0.f};
     float inertia3[3] = {0.f, 0.f, 0.f};
 };
-constexpr int OBJ_BOX = 0, OBJ_ELLIPSOID = 2;   // objectType "block" / "egg" (shadow_hand.py:86-96); 1 is reserved for the pen's capsule
+constexpr int OBJ_BOX = 0, OBJ_CAPSULE = 1, OBJ_ELLIPSOID = 2;   // objectType "block" / "pen" / "egg" (shadow_hand.py:86-96)
 
 template <class M>
 struct HandSim : Sim<M> {
@@ -80,9 +80,20 @@ struct HandSim : Sim<M> {
         *dist = (ok ? k0 * (k0 - 1.f) * ik1 : -fminf(a[0], fminf(a[1], a[2]))) - r;
         n[0] = ok ? g[0] * ik1 : 0.f; n[1] = ok ? g[1] * ik1 : 0.f; n[2] = ok ? g[2] * ik1 : 1.f;
     }
+    // sphere vs capsule along the object's z axis (radius rc, half length hl of the cylindrical part): exact
+    MI_HD static void sphere_capsule(const float* c, float r, float rc, float hl, float* dist, float* n) {
+        const float pz = fminf(fmaxf(c[2], -hl), hl);
+        const float d[3] = {c[0], c[1], c[2] - pz};
+        const float d2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+        const bool ok = d2 > 1e-24f;
+        const float inv = MI_RSQ(fmaxf(d2, 1e-30f));
+        *dist = d2 * inv - rc - r;
+        n[0] = ok ? d[0] * inv : 1.f; n[1] = ok ? d[1] * inv : 0.f; n[2] = ok ? d[2] * inv : 0.f;
+    }
     template <int SHAPE>
     MI_HD static void sphere_object(const float* c, float r, const ObjectParams& OP, float* dist, float* n) {
         if constexpr (SHAPE == OBJ_BOX) sphere_box(c, r, OP.half, dist, n);
+        else if constexpr (SHAPE == OBJ_CAPSULE) sphere_capsule(c, r, OP.dims[0], OP.dims[1], dist, n);
         else sphere_ellipsoid(c, r, OP.dims, dist, n);
     }
     // y = Ro diag(s) Ro^T x: a body-diagonal operator (inertia^{+-1/2}) applied to a world-frame vector

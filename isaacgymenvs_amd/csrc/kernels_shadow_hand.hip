@@ -68,6 +68,10 @@ __device__ __forceinline__ void hand_reset_env(const View& v, const HandView& hv
     const float xu[3] = {1.f, 0.f, 0.f}, yu[3] = {0.f, 1.f, 0.f};
     float q[4];
     randomize_rotation(rf(3), rf(4), xu, yu, q);
+    if (p.object_shape == OBJ_CAPSULE) {                 // pen: randomize_rotation_pen with rand_angle_y = 0.3 (shadow_hand.py:626-629)
+        const float zu[3] = {0.f, 0.f, 1.f};
+        randomize_rotation_pen(rf(3), rf(4), 0.3f, xu, yu, zu, q);
+    }
     sfor<4>([&](auto K) MI_LAMBDA { hv.object_state[(3 + K) * N + e] = q[K]; });
     sfor<6>([&](auto K) MI_LAMBDA { hv.object_state[(7 + K) * N + e] = 0.f; });
     // hand: default pose (0) + noise * random point of the joint range (:642-651)
@@ -310,6 +314,7 @@ static hipError_t hand_substeps_shape(const View& v, const HandView& hv, const S
 }
 static hipError_t hand_substeps(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s) {
     if (p.object_shape == OBJ_ELLIPSOID) return hand_substeps_shape<OBJ_ELLIPSOID>(v, hv, P, p, n, s);
+    if (p.object_shape == OBJ_CAPSULE) return hand_substeps_shape<OBJ_CAPSULE>(v, hv, P, p, n, s);
     return hand_substeps_shape<OBJ_BOX>(v, hv, P, p, n, s);   // mi_engine_create admits no other shape
 }
 

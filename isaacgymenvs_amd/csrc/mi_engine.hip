@@ -406,10 +406,13 @@ extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const 
         const HandParams& hp = e->hand;
         const bool ok = (hp.obs_type == 0 && hp.num_obs == 211) || (hp.obs_type >= 1 && hp.obs_type <= 3 && hp.num_obs >= 1 && hp.num_obs <= 160);
         if (!ok) { delete e; return fail("mi_engine_create: ShadowHand obs_type / num_obs invalid"); }
-        if (hp.object_shape != 0 && hp.object_shape != 2) { delete e; return fail("mi_engine_create: ShadowHand object_shape must be 0 (block) or 2 (egg)"); }
-        if (hp.object_shape == 2)
+        if (hp.object_shape < 0 || hp.object_shape > 2) { delete e; return fail("mi_engine_create: ShadowHand object_shape must be 0 (block), 1 (pen) or 2 (egg)"); }
+        if (hp.object_shape != 0)
             for (int k = 0; k < 3; ++k)
-                if (!(hp.object_dims[k] > 0.f) || !(hp.object_inertia[k] > 0.f)) { delete e; return fail("mi_engine_create: ShadowHand egg needs positive object_dims / object_inertia"); }
+                if ((!(hp.object_dims[k] > 0.f) && !(hp.object_shape == 1 && k == 2)) || !(hp.object_inertia[k] > 0.f)) {
+                    delete e;
+                    return fail("mi_engine_create: ShadowHand egg / pen need positive object_dims / object_inertia");
+                }
         if (!(hp.cube_mass > 0.f)) { delete e; return fail("mi_engine_create: ShadowHand object mass must be positive"); }
         for (int k = 0; hp.obs_type != 0 && k < hp.num_obs; ++k)
             if (hp.obs_map[k] < 0 || hp.obs_map[k] >= 211) { delete e; return fail("mi_engine_create: ShadowHand obs_map entry out of range"); }

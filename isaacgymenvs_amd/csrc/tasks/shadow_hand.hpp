@@ -32,8 +32,8 @@ struct HandParams {   // mirrors MiHandParams (include/mi_engine.h): what Shadow
     int obs_type, num_obs, asymmetric_obs;                    // observationType (:97-110), asymmetric_observations (:88)
     short obs_map[160];                                       // obs_buf[:, k] = full_state[:, obs_map[k]] for obs_type != 0
     float force_scale, force_prob_range[2], force_decay, force_decay_interval;   // :69-72
-    int object_shape;                                         // objectType (:86-96): 0 block (cube_* above), 2 egg (ellipsoid below)
-    float object_dims[3], object_inertia[3];                  // egg: semi-axes (egg.xml:10) and principal inertias of the solid ellipsoid
+    int object_shape;                                         // objectType (:86-96): 0 block (cube_* above), 1 pen (capsule), 2 egg (ellipsoid)
+    float object_dims[3], object_inertia[3];                  // egg: semi-axes (egg.xml:10); pen: radius, half length (pen.xml:20); principal inertias
 };
 
 MI_HD void quat_conjugate(const float* a, float* o) { o[0] = -a[0]; o[1] = -a[1]; o[2] = -a[2]; o[3] = a[3]; }
@@ -94,6 +94,16 @@ MI_HD void randomize_rotation(float rand0, float rand1, const float* x_unit, con
     float a[4], b[4];
     quat_from_angle_axis(rand0 * PI_, x_unit, a);
     quat_from_angle_axis(rand1 * PI_, y_unit, b);
+    quat_mul(a, b, q);
+}
+// randomize_rotation_pen (:809-813): rand1 and y_unit are unused by the reference
+MI_HD void randomize_rotation_pen(float rand0, float /*rand1*/, float max_angle, const float* x_unit, const float* /*y_unit*/, const float* z_unit,
+                                  float* q) {
+    MI_NO_CONTRACT
+    const float PI_ = 3.141592653589793f;
+    float a[4], b[4];
+    quat_from_angle_axis(0.5f * PI_ + rand0 * max_angle, x_unit, a);
+    quat_from_angle_axis(rand0 * PI_, z_unit, b);
     quat_mul(a, b, q);
 }
 

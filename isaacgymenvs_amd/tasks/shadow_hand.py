@@ -2,9 +2,9 @@
 (reference isaacgymenvs/tasks/shadow_hand.py).
 
 Host side only: config -> MiHandParams and the reference's attribute names as views of the engine arena.  Supported
-subset: objectType "block" (the cube: an isotropic free body) and "egg" (ellipsoid, principal inertias), all four observation layouts (full_state 211, full 157,
+subset: objectType "block" (the cube: an isotropic free body), "egg" (ellipsoid) and "pen" (capsule) with principal inertias, all four observation layouts (full_state 211, full 157,
 full_no_vel 77, openai 42), asymmetric observations (states_buf = full state), absolute or relative position control,
-random object forces (forceScale > 0), in-kernel resets.  Not supported (raise): the pen object.  Physics simplifications are listed
+random object forces (forceScale > 0), in-kernel resets.  Physics simplifications are listed
 in DESIGN.md (hand geometry sampled by spheres against the exact box, no hand self-collision, soft tendons, drive force
 limits not clamped).
 """
@@ -24,6 +24,16 @@ CUBE_DENSITY = 567.0
 OBJECT_SHAPE_ID = {"block": 0, "pen": 1, "egg": 2}   # include/mi_engine.h MiHandParams.object_shape (1 is refused by the engine)
 EGG_SEMI_AXES = (0.03, 0.03, 0.04)
 EGG_DENSITY = 1000.0
+PEN_RADIUS, PEN_HALF_LENGTH, PEN_DENSITY = 0.008, 0.1, 1000.0     # mjcf/open_ai_assets/hand/pen.xml:20 (capsule "0.008 0.1"), default density
+
+
+def capsule_mass_inertia(r, hl, density):
+    """mass and principal inertias (x = y transverse, z along the axis) of a solid capsule: cylinder 2 hl long + two hemispheres."""
+    mc = density * np.pi * r * r * 2.0 * hl
+    ms = density * 4.0 / 3.0 * np.pi * r ** 3
+    izz = 0.5 * mc * r * r + 0.4 * ms * r * r
+    ixx = mc * (3.0 * r * r + (2.0 * hl) ** 2) / 12.0 + ms * (0.4 * r * r + hl * hl + 0.75 * hl * r)
+    return mc + ms, (ixx, ixx, izz)
 
 
 NUM_OBS = {"openai": 42, "full_no_vel": 77, "full": 157, "full_state": 211}     # shadow_hand.py:101-106
@@ -104,6 +114,19 @@ def hand_params_from_cfg(cfg):
         for k in range(3):
             p.object_dims[k] = EGG_SEMI_AXES[k]
             p.object_inertia[k] = inertia[k]
+    if env.get("objectType", "block") == "pen":
+        m, inertia = capsule_mass_inertia(PEN_RADIUS, PEN_HALF_LENGTH, PEN_DENSITY)
+        p.cube_mass = m
+        p.cube_half = PEN_HALF_LENGTH
+        p.cube_inertia = sum(inertia) / 3.0
+        p.object_dims[0], p.object_dims[1], p.object_dims[2] = PEN_RADIUS, PEN_HALF_LENGTH, 0.0
+        for k in range(3):
+            p.object_inertia[k] = inertia[k]
+        r.ignore_z_rot = 1                                        # shadow_hand.py:421
+        obj = (hand_pos[0], hand_pos[1] - 0.39, hand_pos[2] + 0.02)   # the pen starts lower (:316-317)
+        for k in range(3):
+            p.object_init_pos[k] = obj[k]
+            p.goal_init_pos[k] = obj[k] - (0.04 if k == 2 else 0.0)
     for a, d in enumerate(ex["actuated_dofs"]):
         p.actuated[a] = int(d)
     ot = env["observationType"]
@@ -131,8 +154,6 @@ class ShadowHand(VecTask):
         env = cfg["env"]
         if env["objectType"] not in ("block", "egg", "pen"):                        # shadow_hand.py:86-87
             raise AssertionError("objectType must be one of block, egg, pen")
-        if env["objectType"] == "pen":
-            raise NotImplementedError("objectType 'pen' is not implemented: an 8 mm capsule falls through the sphere-sampled hand geometry")
         if env["observationType"] not in NUM_OBS:                                   # shadow_hand.py:97-99
             raise Exception("Unknown type of observations!\nobservationType should be one of: [openai, full_no_vel, full, full_state]")
         self.randomize = cfg["task"]["randomize"]

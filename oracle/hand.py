@@ -67,9 +67,19 @@ def sphere_ellipsoid(c_local, r, axes):
     return k0 * (k0 - 1.0) / k1 - r, g / k1
 
 
+def sphere_capsule(c_local, r, rc, hl):
+    """exact signed distance of a sphere to a capsule along the object's z axis (radius rc, half length hl), outward normal."""
+    pz = min(max(c_local[2], -hl), hl)
+    d = np.array([c_local[0], c_local[1], c_local[2] - pz])
+    n = np.linalg.norm(d)
+    if n * n <= 1e-24:
+        return -rc - r, np.array([1.0, 0.0, 0.0])
+    return n - rc - r, d / n
+
+
 class OracleHandEngine:
     def __init__(self, spec, extras, num_envs, sim: dict, sensor_bodies, obj=None):
-        # obj: None = the 5 cm cube; dict(shape="egg", dims=semi-axes, mass=, inertia=principal inertias) = an ellipsoid
+        # obj: None = the 5 cm cube; dict(shape="egg" | "pen", dims=semi-axes | (radius, half length), mass=, inertia=principal inertias)
         self.objp = obj
         self.spec, self.ex, self.N = spec, extras, num_envs
         self.eng = OracleEngine(spec, num_envs, params=dict(sim, gravity=(0.0, 0.0, 0.0)), sensor_bodies=sensor_bodies, precision="f64")
@@ -174,7 +184,9 @@ class OracleHandEngine:
         for si in range(len(self.os_body)):
             b = int(self.os_body[si])
             c = bp[b, 0:3] + bp[b, 3:12].reshape(3, 3) @ self.os_pos[si]      # world
-            if egg:
+            if egg and self.objp["shape"] == "pen":
+                dist, nl = sphere_capsule(Ro.T @ (c - xo), self.os_rad[si], self.objp["dims"][0], self.objp["dims"][1])
+            elif egg:
                 dist, nl = sphere_ellipsoid(Ro.T @ (c - xo), self.os_rad[si], self.objp["dims"])
             else:
                 dist, nl = sphere_box(Ro.T @ (c - xo), self.os_rad[si], CUBE_HALF)

@@ -909,8 +909,9 @@ class OracleShadowHandEnv:
         from .hand import OracleHandEngine
         self.N, self.p, self.nd = num_envs, params, spec.nd
         obj = None
-        if int(getattr(params, "object_shape", 0)) == 2:                          # objectType "egg"
-            obj = dict(shape="egg", dims=list(params.object_dims), mass=float(params.cube_mass), inertia=list(params.object_inertia))
+        if int(getattr(params, "object_shape", 0)) != 0:                          # objectType "pen" (1) / "egg" (2)
+            obj = dict(shape={1: "pen", 2: "egg"}[int(params.object_shape)], dims=list(params.object_dims), mass=float(params.cube_mass),
+                       inertia=list(params.object_inertia))
         self.eng = OracleHandEngine(spec, extras, num_envs, sim_params, sensor_bodies, obj=obj)
         self.eng.eng.root[:, :3] = list(params.hand_pos)
         self.eng.eng.root[:, 3:7] = list(params.hand_quat)
@@ -967,6 +968,10 @@ class OracleShadowHandEnv:
             obj[ids, k] = f32(p.object_init_pos[k]) + f32(p.reset_position_noise) * rf(k)
         xu = np.tile(np.array([1, 0, 0], f32), (len(ids), 1)); yu = np.tile(np.array([0, 1, 0], f32), (len(ids), 1))
         obj[ids, 3:7] = randomize_rotation(rf(3), rf(4), xu, yu)
+        if int(getattr(p, "object_shape", 0)) == 1:                               # pen: randomize_rotation_pen, rand_angle_y = 0.3 (:626-629)
+            from .jit_twins import randomize_rotation_pen
+            zu = np.tile(np.array([0, 0, 1], f32), (len(ids), 1))
+            obj[ids, 3:7] = randomize_rotation_pen(rf(3), rf(4), 0.3, xu, yu, zu)
         obj[ids, 7:13] = 0
         for d in range(nd):
             delta_max, delta_min = self.up[d] - f32(0), self.lo[d] - f32(0)

@@ -151,7 +151,7 @@ def test_all_tasks_lay_out_and_reject_device_calls_on_a_host_arena(lib):
     assert lib.mi_engine_create(b"ShadowHand", C.byref(native.MiSimParams(dt=0.01, substeps=2, iters=4)), C.cast(C.byref(tp), C.c_void_p),
                                 C.sizeof(tp), n, 0, 1, buf.ctypes.data, nbytes, C.byref(h)) != 0
     assert b"obs_type" in lib.mi_last_error()
-    # ... and so is the object: shape 0 (block) or 2 (egg, with positive semi-axes and inertias); 1 (pen) is refused
+    # ... and so is the object: shape 0 (block), 1 (pen: radius, half length) or 2 (egg: semi-axes), the latter two with positive inertias
     def create_hand(**kw):
         t = native.MiHandParams()
         t.obs_type, t.num_obs, t.cube_mass = 0, 211, 0.07
@@ -167,8 +167,10 @@ def test_all_tasks_lay_out_and_reject_device_calls_on_a_host_arena(lib):
         if rc == 0:
             lib.mi_engine_destroy(hh)
         return rc
-    assert create_hand(object_shape=1) != 0 and b"object_shape" in lib.mi_last_error()
+    assert create_hand(object_shape=3) != 0 and b"object_shape" in lib.mi_last_error()
     assert create_hand(object_shape=2) != 0 and b"egg" in lib.mi_last_error()
+    assert create_hand(object_shape=1, object_dims=[0.008, 0.1, 0.0]) != 0 and b"object_inertia" in lib.mi_last_error()
+    assert create_hand(object_shape=1, object_dims=[0.008, 0.1, 0.0], object_inertia=[1.5e-4, 1.5e-4, 1.4e-6]) == 0
     assert create_hand(object_shape=2, object_dims=[0.03, 0.03, 0.04], object_inertia=[7.5e-5, 7.5e-5, 5.4e-5]) == 0
     assert create_hand(cube_mass=0.0) != 0 and b"mass" in lib.mi_last_error()
     # invalid sim parameters / env counts

@@ -665,7 +665,7 @@ def test_quadcopter_full_size_properties():
 
 
 # ------------------------------------------------------------------ ShadowHand (hand + cube physics, deferred resets, full_state obs)
-@pytest.mark.parametrize("object_type", ["block", "egg"])
+@pytest.mark.parametrize("object_type", ["block", "egg", "pen"])
 def test_shadow_hand_step_matches_cpu_restatement(object_type):
     import isaacgymenvs_amd
     from isaacgymenvs_amd.registry import load_extras
@@ -675,7 +675,7 @@ def test_shadow_hand_step_matches_cpu_restatement(object_type):
     cfg["task"]["env"]["numEnvs"] = n
     cfg["task"]["env"]["objectType"] = object_type          # egg: ellipsoid 3 x 3 x 4 cm with principal inertias (egg.xml)
     env = isaacgymenvs_amd.make(seed=seed, task="ShadowHand", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True, cfg=cfg)
-    assert env._task_params_struct.object_shape == {"block": 0, "egg": 2}[object_type]
+    assert env._task_params_struct.object_shape == {"block": 0, "pen": 1, "egg": 2}[object_type]
     orc = OracleShadowHandEnv(load_model("shadow_hand"), load_extras("shadow_hand"), sensor_bodies("shadow_hand"),
                               _sim_dict(env.sim_params), env._task_params_struct, n, seed=seed)
     g = torch.Generator(device="cpu").manual_seed(7)

@@ -2,7 +2,7 @@ import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np, torch, isaacgymenvs_amd
 from isaacgymenvs_amd.utils.config import compose
-for ot in ("block", "egg"):
+for ot in ("block", "egg", "pen"):
     n = 512
     cfg = compose(overrides=["task=ShadowHand"]); cfg["task"]["env"]["numEnvs"] = n; cfg["task"]["env"]["objectType"] = ot
     env = isaacgymenvs_amd.make(seed=3, task="ShadowHand", num_envs=n, sim_device="cuda:0", rl_device="cuda:0", headless=True, cfg=cfg)
