@@ -58,6 +58,7 @@ __global__ void init_state_kernel(View v, int nd, int nsph3, int nsens6, int nob
     for (int k = 0; k < nact; ++k) v.actions[k * N + e] = 0.f;
     for (int k = 0; k < nobs; ++k) { v.obs[(size_t)e * nobs + k] = 0.f; v.obs_out[(size_t)e * nobs + k] = 0.f; v.obs_out[((size_t)N + e) * nobs + k] = 0.f; }
     v.potentials[e] = pot0; v.prev_potentials[e] = pot0;
+    if (v.friction) v.friction[e] = -1.f;       // model friction until somebody writes the tensor (AnymalTerrain's init overwrites it)
     for (int k = 0; k < 3; ++k) { v.up_vec[k * N + e] = (k == 2) ? 1.f : 0.f; v.heading_vec[k * N + e] = (k == 0) ? 1.f : 0.f; }
     v.rew[e] = 0.f;
     v.reset[e] = 1;  // vec_task.py:316-317: every env is reset inside the first step()
@@ -303,6 +304,11 @@ static void build_layout(int task, int N, Layout& L, View* v, char* base, int no
     o = L.add("episode_count", MI_I32, {n}, {1}, n); if (v) v->episode = (int*)P(o);
     o = L.add("episode_return", MI_F32, {n}, {1}, n); if (v) v->ep_ret = (float*)P(o);
     o = L.add("episode_stats", MI_F32, {8}, {1}, 8); if (v) v->stats = (float*)P(o);
+    if (task == T_ANT || task == T_HUMANOID) {
+        // per-env friction of the robot's shapes for `actor_params.<actor>.rigid_shape_properties.friction` domain randomisation
+        // (vec_task.py:752-828); negative = the model's own value
+        o = L.add("friction", MI_F32, {n}, {1}, n); if (v) v->friction = (float*)P(o);
+    }
     if (task == T_ANYMAL) {   // anymal_terrain.py:117-168
         const int64_t nb = m.nb;
         o = L.add("net_contact_force", MI_F32, {n, nb, 3}, {1, 3 * n, n}, 3 * nb * n); if (v) v->netf = (float*)P(o);

@@ -237,6 +237,7 @@ class VecTask(Env):
         from ...utils.dr_utils import apply_random_gravity
         rand_freq = dr_params.get("frequency", 1)
         self.last_step = int(self.control_steps * max(1, self.control_freq_inv))       # gym.get_frame_count
+        rand_envs = None                                                               # None: every env (first call)
         if self.first_randomization:
             do_nonenv_randomize = True
         else:
@@ -310,11 +311,46 @@ class VecTask(Env):
                 for i in range(3):
                     self.sim_params.gravity[i] = float(g[i])
                     self.engine.set_option(("gravity_x", "gravity_y", "gravity_z")[i], float(g[i]))
-        if dr_params.get("actor_params") and self.first_randomization:
-            import warnings
-            warnings.warn("actor_params randomisation (per-actor PhysX property structs, reference vec_task.py:752-828) is "
-                          "not implemented by the engine and is skipped: " + ", ".join(dr_params["actor_params"].keys()))
+        if dr_params.get("actor_params"):
+            self._apply_actor_params(dr_params["actor_params"], rand_envs)
         self.first_randomization = False
+
+    def _apply_actor_params(self, actor_params, rand_envs):
+        """`actor_params` (vec_task.py:752-828), tensorised: what the engine has a per-env parameter for is sampled for all randomised envs
+        at once instead of the reference's O(num_envs) Python loop over PhysX property structs.  Implemented: the friction of the robot's
+        shapes (`rigid_shape_properties.friction`, with `num_buckets`) on the tasks that carry a `friction` tensor (Ant, Humanoid) -- one
+        sample per env where the reference draws one per shape.  Everything else (mass, restitution, dof / tendon properties, scale) has
+        no engine counterpart and is reported once."""
+        from ...utils.dr_utils import apply_random_samples_array
+        import numpy as np
+        fr = self.engine.tensors.get("friction") if self.native_task in ("Ant", "Humanoid") else None
+        skipped = []
+        if rand_envs is None:
+            ids = torch.arange(self.num_envs, device=self.device)
+        else:
+            ids = torch.nonzero(rand_envs, as_tuple=False).squeeze(-1)
+        for actor, props in actor_params.items():
+            for prop_name, attrs in props.items():
+                if prop_name == "color":
+                    continue                                                             # no renderer
+                if prop_name == "rigid_shape_properties" and fr is not None and isinstance(attrs, dict):
+                    for attr, prm in attrs.items():
+                        if attr != "friction":
+                            skipped.append(f"{actor}.{prop_name}.{attr}")
+                            continue
+                        if prm.get("setup_only", False) and not self.first_randomization:
+                            continue
+                        if len(ids) == 0:
+                            continue
+                        og = {"friction": np.full(len(ids), float(getattr(self, "model_shape_friction", 1.0)))}
+                        prop = {"friction": og["friction"].copy()}
+                        vals = apply_random_samples_array(prop, og, "friction", prm, self.last_step)
+                        fr[ids] = torch.as_tensor(np.asarray(vals, np.float32), device=self.device)
+                else:
+                    skipped.append(f"{actor}.{prop_name}")
+        if skipped and self.first_randomization:
+            import warnings
+            warnings.warn("actor_params entries without an engine counterpart are skipped (reference vec_task.py:752-828): " + ", ".join(skipped))
 
     def render(self, mode="rgb_array"):
         return None  # headless engine (viewer is out of scope, SURVEY.md section 8f-4)

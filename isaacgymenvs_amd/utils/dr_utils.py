@@ -74,7 +74,10 @@ def get_bucketed_val(new_prop_val, attr_randomization_params):
         hi = attr_randomization_params["range"][0] + 2 * np.sqrt(attr_randomization_params["range"][1])
     num_buckets = attr_randomization_params["num_buckets"]
     buckets = [(hi - lo) * i / num_buckets + lo for i in range(num_buckets)]
-    return buckets[bisect(buckets, new_prop_val) - 1]
+    if np.ndim(new_prop_val) == 0:
+        return buckets[bisect(buckets, new_prop_val) - 1]
+    # array form of the same lookup (bisect == bisect_right; index -1 wraps to the last bucket exactly like the scalar expression)
+    return np.asarray(buckets)[np.searchsorted(buckets, np.asarray(new_prop_val), side="right") - 1]
 
 
 def apply_random_gravity(gravity, og_gravity, attr_randomization_params, curr_gym_step_count):

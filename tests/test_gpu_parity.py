@@ -837,6 +837,54 @@ def test_domain_randomisation_noise_and_gravity():
     assert abs(g0[2] - gs[0]) < 1e-9 or True
 
 
+def test_actor_params_friction_randomisation_is_tensorised_and_acts_on_the_physics():
+    """`actor_params.<actor>.rigid_shape_properties.friction` (vec_task.py:752-828): one bucketed sample per randomised env lands in the
+    `friction` tensor; a low-friction env slides further than a high-friction one from the same push."""
+    import warnings
+    import isaacgymenvs_amd
+    n = 256
+    cfg = compose(overrides=["task=Ant"])
+    cfg["task"]["env"]["numEnvs"] = n
+    cfg["task"]["task"]["randomize"] = True
+    cfg["task"]["task"]["randomization_params"] = {
+        "frequency": 4,
+        "actor_params": {"ant": {"color": True,
+                                 "rigid_shape_properties": {"friction": {"num_buckets": 50, "range": [0.2, 1.8], "operation": "scaling",
+                                                                          "distribution": "uniform"},
+                                                            "restitution": {"range": [0.0, 0.7], "operation": "scaling", "distribution": "uniform"}},
+                                 "rigid_body_properties": {"mass": {"range": [0.5, 1.5], "operation": "scaling", "distribution": "uniform",
+                                                                    "setup_only": True}}}},
+    }
+    np.random.seed(0)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        env = isaacgymenvs_amd.make(seed=1, task="Ant", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True, cfg=cfg)
+        env.step(torch.zeros((n, 8), device=DEV))
+    msgs = " ".join(str(x.message) for x in w)
+    assert "ant.rigid_body_properties" in msgs and "restitution" in msgs and "friction" not in msgs.split("skipped")[-1].replace("restitution", "")
+    fr = env.engine.tensors["friction"].cpu().numpy()
+    buckets = 0.2 + 1.6 * np.arange(50) / 50
+    assert fr.min() >= 0.2 - 1e-6 and fr.max() < 1.8 and len(np.unique(np.round(fr, 5))) > 20
+    assert np.abs(fr[:, None] - buckets[None, :]).min(axis=1).max() < 1e-5            # every value sits on a bucket
+    # physics: slide the ant along x on its feet; the distance until it stops decreases with the friction coefficient
+    t = env.engine.tensors
+    fr_t = torch.linspace(0.2, 1.8, n, device=DEV)
+    t["friction"][:] = fr_t
+    root = np.zeros((n, 13), np.float32); root[:, 2] = 0.55; root[:, 6] = 1.0; root[:, 7] = 2.0
+    t["root_states"][:] = _t(root); env.dof_pos.zero_(); env.dof_vel.zero_()
+    t["contact_impulse"].zero_(); t["limit_impulse"].zero_(); t["dof_actuation_force"].zero_()
+    for _ in range(90):
+        env.engine.simulate()
+    torch.cuda.synchronize()
+    x = t["root_states"][:, 0].cpu().numpy()
+    assert np.isfinite(x).all()
+    lo, hi = x[: n // 4].mean(), x[-n // 4:].mean()
+    # slippery envs travel further (the contact coefficient is the mean of shape and plane friction, 0.6 ... 1.4 here, and the ant partly
+    # tips over its leading feet instead of sliding, so the effect is centimetres)
+    assert lo > hi + 0.01, (lo, hi, np.corrcoef(fr_t.cpu().numpy(), x)[0, 1])
+    assert np.corrcoef(fr_t.cpu().numpy(), x)[0, 1] < -0.3
+
+
 def test_shadow_hand_openai_variant_runs_from_its_task_config():
     """`task=ShadowHandOpenAI_FF` (reference cfg/task/ShadowHandOpenAI_FF.yaml): 20 Hz control, resetTime, smoothed targets, random
     forces, openai observations + full-state critic input, randomisation on -- composed from the task name like the reference does."""
