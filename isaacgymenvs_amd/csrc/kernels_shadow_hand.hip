@@ -31,6 +31,7 @@ struct HandView {
     float* obj_force;      // [3][N] world-frame force on the cube during this control step (apply_rigid_body_force_tensors)
     float* rb_force;       // [3][N] rb_forces[:, object] in the object's local frame (:201, 700-708)
     float* force_prob;     // [N] random_force_prob (:198-199)
+    float* mu_env;         // [N] per-env hand-object contact friction for actor_params friction randomisation; negative = HandParams.mu
 };
 
 __device__ __forceinline__ float hand_u(uint32_t seed, uint32_t genv, uint32_t ep, uint32_t k) { return 2.f * uniform01(seed, genv, ep, k) - 1.f; }
@@ -169,6 +170,8 @@ __global__ __launch_bounds__(32) void hand_substep_kernel(View v, HandView hv, S
     ObjectParams OP{p.cube_half, p.cube_mass, p.cube_inertia, p.mu,
                     {hv.obj_force[e], hv.obj_force[N + e], hv.obj_force[2 * N + e]}};
     if constexpr (SHAPE != OBJ_BOX) sfor<3>([&](auto K) MI_LAMBDA { OP.dims[K] = p.object_dims[K]; OP.inertia3[K] = p.object_inertia[K]; });
+    const float mu_e = hv.mu_env[e];
+    if (mu_e >= 0.f) OP.mu = mu_e;
     const float h = P.dt / (float)P.substeps;
     int nc = 0;
     sim.template substep_hand<LANES, SHAPE>(P, OP, target, h, RowStore<LANES>{lds_rows + threadIdx.x}, Strided{v.laml + e, N}, Strided{v.sensor + e, N},
@@ -297,6 +300,7 @@ __global__ void hand_init_kernel(View v, HandView hv, HandParams p) {
     for (int k = 0; k < kHandObs; ++k) hv.full_state[(size_t)e * kHandObs + k] = 0.f;
     for (int k = 0; k < 3; ++k) { hv.obj_force[k * N + e] = 0.f; hv.rb_force[k * N + e] = 0.f; }
     hv.force_prob[e] = hand_force_prob(p, uniform01(v.seed ^ 0x51ED27u, (uint32_t)(v.env_offset + e), 0u, 0u));
+    hv.mu_env[e] = -1.f;
     hv.successes[e] = 0.f; hv.reset_goal[e] = 1; hv.goal_count[e] = 0; hv.ncontact[e] = 0;
     v.rew[e] = 0.f; v.reset[e] = 1; v.progress[e] = 0; v.randomize[e] = 0; v.timeout[e] = 0; v.episode[e] = 0; v.ep_ret[e] = 0.f;
     if (e == 0) { hv.cons[0] = 0.f; hv.ws[0] = hv.ws[1] = 0.f; for (int k = 0; k < 8; ++k) v.stats[k] = 0.f; }

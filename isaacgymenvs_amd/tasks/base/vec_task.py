@@ -323,7 +323,12 @@ class VecTask(Env):
         no engine counterpart and is reported once."""
         from ...utils.dr_utils import apply_random_samples_array
         import numpy as np
-        fr = self.engine.tensors.get("friction") if self.native_task in ("Ant", "Humanoid") else None
+        fr = self.engine.tensors.get("friction") if self.native_task in ("Ant", "Humanoid", "ShadowHand") else None
+        # ShadowHand: one contact coefficient per env = the mean of the hand's and the object's shape friction (PhysX's default combine
+        # mode), each of which the reference randomises as its own actor
+        pair = self.native_task == "ShadowHand"
+        if pair and not hasattr(self, "_dr_actor_friction"):
+            self._dr_actor_friction = {}
         skipped = []
         if rand_envs is None:
             ids = torch.arange(self.num_envs, device=self.device)
@@ -345,7 +350,16 @@ class VecTask(Env):
                         og = {"friction": np.full(len(ids), float(getattr(self, "model_shape_friction", 1.0)))}
                         prop = {"friction": og["friction"].copy()}
                         vals = apply_random_samples_array(prop, og, "friction", prm, self.last_step)
-                        fr[ids] = torch.as_tensor(np.asarray(vals, np.float32), device=self.device)
+                        vals_t = torch.as_tensor(np.asarray(vals, np.float32), device=self.device)
+                        if pair:
+                            mine = self._dr_actor_friction.setdefault(actor, torch.full((self.num_envs,), float(getattr(self, "model_shape_friction", 1.0)),
+                                                                                        device=self.device))
+                            mine[ids] = vals_t
+                            others = [v for k, v in self._dr_actor_friction.items() if k != actor]
+                            other = others[0] if others else torch.full_like(mine, float(getattr(self, "model_shape_friction", 1.0)))
+                            fr[ids] = 0.5 * (mine[ids] + other[ids])
+                        else:
+                            fr[ids] = vals_t
                 else:
                     skipped.append(f"{actor}.{prop_name}")
         if skipped and self.first_randomization:

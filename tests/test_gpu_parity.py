@@ -911,6 +911,12 @@ def test_shadow_hand_openai_variant_runs_from_its_task_config():
     assert resets > 0                                    # 160-step episodes: every env times out (or drops the cube) within 200 steps
     assert int(env.progress_buf.max()) <= 160
     assert "noise_lambda" in env.dr_randomizations["observations"]      # observation / action noise closures installed
+    # hand and object shape friction are randomised per env (250 buckets in 0.7 .. 1.3 each); the contact coefficient is their mean
+    fr = env.engine.tensors["friction"].cpu().numpy()
+    assert fr.min() >= 0.7 - 1e-6 and fr.max() <= 1.3 and len(np.unique(np.round(fr, 5))) > 50
+    assert set(env._dr_actor_friction.keys()) == {"hand", "object"}
+    both = 0.5 * (env._dr_actor_friction["hand"] + env._dr_actor_friction["object"]).cpu().numpy()
+    np.testing.assert_allclose(fr, both, atol=1e-6)
     assert float(env.rb_forces_object.abs().sum()) >= 0.0 and float(env.random_force_prob.min()) > 0.0
 
 
