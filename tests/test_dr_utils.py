@@ -70,3 +70,28 @@ def test_bucketing_and_gravity():
     np.random.seed(3)
     g = D.apply_random_gravity([0, 0, -9.81], [0, 0, -9.81], dict(range=[0, 0.4], operation="additive", distribution="gaussian"), 10)
     assert abs(g[2] + 9.81) < 2.5 and abs(g[0]) < 2.5
+
+
+def test_array_bucketing_equals_the_scalar_lookup():
+    """The tensorised friction randomisation buckets a whole batch at once: same values as the reference's per-shape scalar lookup
+    (dr_utils.py:135-145), including its quirk below the range (index -1 wraps to the LAST bucket)."""
+    ref = _reference_dr_utils()
+    p = dict(range=[0.7, 1.3], distribution="uniform", operation="scaling", num_buckets=250)
+    rng = np.random.default_rng(0)
+    v = np.concatenate([rng.uniform(0.7, 1.3, 500), [0.7, 1.2999999, 0.69, 1.3]])
+    a = D.get_bucketed_val(v, p)
+    s = np.array([D.get_bucketed_val(float(x), p) for x in v])
+    np.testing.assert_array_equal(a, s)
+    if ref is not None:
+        np.testing.assert_array_equal(a, np.array([ref.get_bucketed_val(float(x), p) for x in v]))
+    assert a[-2] == a.max()                                   # 0.69 < lo: the reference's bisect - 1 = -1 picks the last bucket
+    g = dict(range=[1.0, 0.01], distribution="gaussian", operation="scaling", num_buckets=10)
+    vg = rng.normal(1.0, 0.1, 100)
+    np.testing.assert_array_equal(D.get_bucketed_val(vg, g), np.array([D.get_bucketed_val(float(x), g) for x in vg]))
+    # apply_random_samples_array: scaling of the original value, bucketed
+    np.random.seed(1)
+    prop, og = {"friction": np.ones(64)}, {"friction": np.ones(64)}
+    out = D.apply_random_samples_array(prop, og, "friction", p, 0)
+    assert out.shape == (64,) and out.min() >= 0.7 and out.max() < 1.3 and np.array_equal(prop["friction"], out)
+    buckets = 0.7 + 0.6 * np.arange(250) / 250
+    assert np.abs(out[:, None] - buckets[None, :]).min(axis=1).max() < 1e-12
