@@ -85,11 +85,13 @@ __device__ __forceinline__ void store_sim(const Sim<M>& s, const View& v, int e)
 // Per-step episode bookkeeping fused into the step kernel: finished-episode return/length sums are reduced across
 // the 64 lanes of the wave with DPP/ds_swizzle shuffles and land in HBM with one atomic per wave and statistic.
 // These five floats are the only thing ever all-reduced across GPUs (RCCL, parallel.py).
+template <int ACTIVE = 64>      // lanes 0 .. ACTIVE-1 of the wave hold data (a 32-thread workgroup is a half-filled wave64)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    for (int o = ACTIVE / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+template <int ACTIVE = 64>
 __device__ __forceinline__ void episode_stats(const View& v, int e, bool valid, float rew, long long reset, long long progress) {
     float ret = 0.f, fin_ret = 0.f, fin_len = 0.f, fin = 0.f, r = 0.f, cnt = 0.f;
     if (valid) {
@@ -98,7 +100,7 @@ __device__ __forceinline__ void episode_stats(const View& v, int e, bool valid, 
         if (reset != 0) { fin_ret = ret; fin_len = (float)(progress + 1); fin = 1.f; ret = 0.f; }
         v.ep_ret[e] = ret;
     }
-    fin_ret = wave_sum(fin_ret); fin_len = wave_sum(fin_len); fin = wave_sum(fin); r = wave_sum(r); cnt = wave_sum(cnt);
+    fin_ret = wave_sum<ACTIVE>(fin_ret); fin_len = wave_sum<ACTIVE>(fin_len); fin = wave_sum<ACTIVE>(fin); r = wave_sum<ACTIVE>(r); cnt = wave_sum<ACTIVE>(cnt);
     if ((threadIdx.x & 63) == 0) {
         if (fin > 0.f) { atomicAdd(v.stats + 0, fin_ret); atomicAdd(v.stats + 1, fin_len); atomicAdd(v.stats + 2, fin); }
         atomicAdd(v.stats + 3, r);
@@ -225,12 +227,17 @@ __device__ __forceinline__ int post_env_index(int block, int lane, int N) {
 }
 
 // ------------------------------------------------------------------------------------------------ post_physics_step
+// Envs per post workgroup.  The Humanoid's post step stores 2 x 108 observation columns row-major, i.e. every store instruction of a full
+// wave touches 64 cache lines; with 32-env workgroups (half-filled waves, one per sub-step workgroup, same XCD) each store touches 32 and
+// twice as many CUs share the work: Humanoid step -0.6 % (fast box) to -2 % (slow box).  Ant (60 columns) showed no robust gain and keeps 64.
+template <class M>
+constexpr int post_lanes() { return Sim<M>::LANES == 32 ? 32 : 64; }
 template <class M, bool HUM>
-__global__ __launch_bounds__(64) void loco_post_kernel(View v, LocoParams tp) {
+__global__ __launch_bounds__(post_lanes<M>()) void loco_post_kernel(View v, LocoParams tp) {
     using T = Loco<M::ND, 6 * M::NSENS, HUM>;
-    constexpr int ND = M::ND, NOBS = T::NOBS;
+    constexpr int ND = M::ND, NOBS = T::NOBS, PL = post_lanes<M>();
     const int N = v.N;
-    const int e0 = post_env_index<Sim<M>::LANES>(blockIdx.x, threadIdx.x, N);
+    const int e0 = PL == 64 ? post_env_index<Sim<M>::LANES>(blockIdx.x, threadIdx.x, N) : blockIdx.x * 32 + threadIdx.x;
     const bool valid = e0 < N;           // tail lanes shadow the last env (no stores) so wave reductions stay full
     const int e = valid ? e0 : N - 1;
     float root[13], q[ND], qd[ND], dof_force[ND], sensor[6 * M::NSENS > 0 ? 6 * M::NSENS : 1], act[ND];
@@ -269,7 +276,7 @@ __global__ __launch_bounds__(64) void loco_post_kernel(View v, LocoParams tp) {
     float rew;
     long long reset;
     T::reward(tp, obs, 0LL, progress, act, potentials, prev_potentials, &rew, &reset);
-    episode_stats(v, e, valid, rew, reset, progress);
+    episode_stats<PL>(v, e, valid, rew, reset, progress);
     if (!valid) return;
     v.randomize[e] += 1;
     v.episode[e] = ep;
@@ -411,7 +418,8 @@ hipError_t launch_loco_step(const View& v, const SimParams& P, const LocoParams&
     ap.mode = 0;
     hipError_t e = launch_substeps<M>(v, P, ap, actions, cfi * P.substeps, ACT_FROM_ACTIONS, ACT_STORED_TAU, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((loco_post_kernel<M, HUM>), dim3((v.N + 63) / 64), dim3(64), 0, s, v, tp);
+    constexpr int PL = post_lanes<M>();
+    hipLaunchKernelGGL((loco_post_kernel<M, HUM>), dim3((v.N + PL - 1) / PL), dim3(PL), 0, s, v, tp);
     return hipGetLastError();
 }
 template <class M>
