@@ -178,3 +178,20 @@ def test_all_tasks_lay_out_and_reject_device_calls_on_a_host_arena(lib):
     assert lib.mi_engine_create(b"Ant", C.byref(native.MiSimParams(dt=0.0, substeps=2, iters=4)), C.cast(C.byref(tp2), C.c_void_p), C.sizeof(tp2),
                                 n, 0, 1, buf.ctypes.data, nbytes, C.byref(h)) != 0
     assert lib.mi_engine_arena_bytes(b"Ant", 0) == 0 and lib.mi_engine_arena_bytes(b"Nope", 8) == 0
+
+
+def test_header_is_plain_c_and_a_c_client_can_drive_the_library(lib, tmp_path):
+    """include/mi_engine.h compiles as strict C99 and examples/c_abi_probe.c -- dlopen, task table, arena layout, error path -- runs
+    against the built library: the boundary is a C ABI with plain pointers and sizes, nothing torch- or C++-typed."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "c_abi_probe")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "c_abi_probe.c"), "-ldl", "-o", exe])
+    out = subprocess.run([exe, native.LIB_PATH], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Ant            obs  60  actions  8  dofs  8" in out.stdout and "ShadowHand     obs 211  actions 20  dofs 24" in out.stdout
+    assert "root_states  dtype 0  shape [64, 13]  stride [1, 64]" in out.stdout
+    assert "not device memory" in out.stdout
