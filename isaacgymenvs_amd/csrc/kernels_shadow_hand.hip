@@ -2,37 +2,9 @@
 // actions -> position targets), hand + cube physics sub-steps (core/hand_engine.hpp), post_physics_step (fingertip states,
 // full_state observation, compute_hand_reward).  One env per lane; 32 envs per wave in the physics kernel (the compact
 // contact store needs 4 KB of LDS per env).
-#include "step_kernels.hpp"
-#include "core/hand_engine.hpp"
-#include "gen/model_shadow_hand.h"
-#include "tasks/shadow_hand.hpp"
+#include "hand_kernels.hpp"
 
 namespace mi {
-
-using HM = ModelShadowHand;
-using HS = HandSim<HM>;
-constexpr int kHandDof = 24, kHandAct = 20, kHandTips = 5, kHandObs = 211;
-static_assert(HM::ND == kHandDof && HM::NSENS == kHandTips, "shadow hand model");
-
-// arena view of the task (device pointers, SoA [k][N] unless noted) -- same definition in mi_engine.hip
-struct HandView {
-    float* cur_targets;    // [24][N]
-    float* prev_targets;   // [24][N]
-    float* object_state;   // [13][N]  root state of the cube
-    float* goal_state;     // [7][N]   goal pose (pos, quat)
-    float* fingertip;      // [5*13][N] fingertip body states
-    float* successes;      // [N]
-    long long* reset_goal; // [N]
-    int* goal_count;       // [N] number of goal resets so far (RNG counter)
-    float* cons;           // [1] consecutive_successes (shadow_hand.py:795-798)
-    float* ws;             // [2] per-step scratch of the cross-env sums
-    int* ncontact;         // [N] object contacts of the last sub-step (diagnostic)
-    float* full_state;     // [N][211] row-major: compute_full_state's vector when it is not obs_buf itself (states_buf, :584)
-    float* obj_force;      // [3][N] world-frame force on the cube during this control step (apply_rigid_body_force_tensors)
-    float* rb_force;       // [3][N] rb_forces[:, object] in the object's local frame (:201, 700-708)
-    float* force_prob;     // [N] random_force_prob (:198-199)
-    float* mu_env;         // [N] per-env hand-object contact friction for actor_params friction randomisation; negative = HandParams.mu
-};
 
 __device__ __forceinline__ float hand_u(uint32_t seed, uint32_t genv, uint32_t ep, uint32_t k) { return 2.f * uniform01(seed, genv, ep, k) - 1.f; }
 // random_force_prob (:198-199, 642-643): log-uniform in force_prob_range
@@ -144,43 +116,6 @@ __global__ void hand_pre_kernel(View v, HandView hv, HandParams p, const float* 
         quat_rotate_s(q, f, 1.f, fw);                                                      // LOCAL_SPACE -> world at application time
         sfor<3>([&](auto K) MI_LAMBDA { hv.rb_force[K * N + e] = f[K]; hv.obj_force[K * N + e] = fw[K]; });
     }
-}
-
-// gym.simulate(): one physics sub-step of hand + cube
-template <int SHAPE>
-__global__ __launch_bounds__(32) void hand_substep_kernel(View v, HandView hv, SimParams P, HandParams p) {
-    extern __shared__ float lds_rows[];
-    constexpr int ND = kHandDof, LANES = HS::LANES;
-    const int e = blockIdx.x * LANES + threadIdx.x;
-    const int N = v.N;
-    if (e >= N) return;
-    HS sim;
-    sfor<3>([&](auto K) MI_LAMBDA { sim.root[K] = p.hand_pos[K]; });
-    sfor<4>([&](auto K) MI_LAMBDA { sim.root[3 + K] = p.hand_quat[K]; });
-    sfor<6>([&](auto K) MI_LAMBDA { sim.root[7 + K] = 0.f; });
-    float target[ND];
-    sfor<ND>([&](auto K) MI_LAMBDA {
-        sim.q[K] = v.dof[K * N + e];
-        sim.qd[K] = v.dof[(ND + K) * N + e];
-        target[K] = hv.cur_targets[K * N + e];
-    });
-    sfor<3>([&](auto K) MI_LAMBDA { sim.obj.pos[K] = hv.object_state[K * N + e]; sim.obj.vel[K] = hv.object_state[(7 + K) * N + e];
-                                    sim.obj.angvel[K] = hv.object_state[(10 + K) * N + e]; });
-    sfor<4>([&](auto K) MI_LAMBDA { sim.obj.quat[K] = hv.object_state[(3 + K) * N + e]; });
-    ObjectParams OP{p.cube_half, p.cube_mass, p.cube_inertia, p.mu,
-                    {hv.obj_force[e], hv.obj_force[N + e], hv.obj_force[2 * N + e]}};
-    if constexpr (SHAPE != OBJ_BOX) sfor<3>([&](auto K) MI_LAMBDA { OP.dims[K] = p.object_dims[K]; OP.inertia3[K] = p.object_inertia[K]; });
-    const float mu_e = hv.mu_env[e];
-    if (mu_e >= 0.f) OP.mu = mu_e;
-    const float h = P.dt / (float)P.substeps;
-    int nc = 0;
-    sim.template substep_hand<LANES, SHAPE>(P, OP, target, h, RowStore<LANES>{lds_rows + threadIdx.x}, Strided{v.laml + e, N}, Strided{v.sensor + e, N},
-                                            Strided{v.dof_force + e, N}, &nc);
-    sfor<ND>([&](auto K) MI_LAMBDA { v.dof[K * N + e] = sim.q[K]; v.dof[(ND + K) * N + e] = sim.qd[K]; });
-    sfor<3>([&](auto K) MI_LAMBDA { hv.object_state[K * N + e] = sim.obj.pos[K]; hv.object_state[(7 + K) * N + e] = sim.obj.vel[K];
-                                    hv.object_state[(10 + K) * N + e] = sim.obj.angvel[K]; });
-    sfor<4>([&](auto K) MI_LAMBDA { hv.object_state[(3 + K) * N + e] = sim.obj.quat[K]; });
-    hv.ncontact[e] = nc;
 }
 
 // post_physics_step (shadow_hand.py:710-715): progress++, compute_observations (full_state), compute_reward
@@ -306,19 +241,9 @@ __global__ void hand_init_kernel(View v, HandView hv, HandParams p) {
     if (e == 0) { hv.cons[0] = 0.f; hv.ws[0] = hv.ws[1] = 0.f; for (int k = 0; k < 8; ++k) v.stats[k] = 0.f; }
 }
 
-template <int SHAPE>
-static hipError_t hand_substeps_shape(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s) {
-    constexpr size_t lds = (size_t)HS::ROW_SLOTS * HS::LANES * sizeof(float);
-    static_assert(lds <= 160 * 1024, "hand row store must fit LDS");
-    static unsigned long long configured = 0ull;
-    if (hipError_t e = ensure_dynamic_lds((const void*)hand_substep_kernel<SHAPE>, lds, &configured); e != hipSuccess) return e;
-    for (int i = 0; i < n; ++i)
-        hipLaunchKernelGGL(hand_substep_kernel<SHAPE>, dim3((v.N + HS::LANES - 1) / HS::LANES), dim3(HS::LANES), lds, s, v, hv, P, p);
-    return hipGetLastError();
-}
 static hipError_t hand_substeps(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s) {
-    if (p.object_shape == OBJ_ELLIPSOID) return hand_substeps_shape<OBJ_ELLIPSOID>(v, hv, P, p, n, s);
-    if (p.object_shape == OBJ_CAPSULE) return hand_substeps_shape<OBJ_CAPSULE>(v, hv, P, p, n, s);
+    if (p.object_shape == OBJ_ELLIPSOID) return hand_substeps_egg(v, hv, P, p, n, s);
+    if (p.object_shape == OBJ_CAPSULE) return hand_substeps_pen(v, hv, P, p, n, s);
     return hand_substeps_shape<OBJ_BOX>(v, hv, P, p, n, s);   // mi_engine_create admits no other shape
 }
 

@@ -16,7 +16,8 @@ LIB_PATH = os.environ.get("MI_ENGINE_LIB") or os.path.join(_HERE, "libmi_engine.
 CSRC = os.path.join(_HERE, "csrc")
 BUILD_DIR = os.path.join(CSRC, "build")
 # one translation unit per robot model (they compile in parallel) + the C ABI
-SOURCES = ["mi_engine.hip", "kernels_cartpole.hip", "kernels_ant.hip", "kernels_humanoid.hip", "kernels_anymal.hip", "kernels_shadow_hand.hip", "kernels_quadcopter.hip", "kernels_jit_twins.hip"]
+SOURCES = ["mi_engine.hip", "kernels_cartpole.hip", "kernels_ant.hip", "kernels_humanoid.hip", "kernels_anymal.hip", "kernels_shadow_hand.hip",
+           "kernels_shadow_hand_pen.hip", "kernels_shadow_hand_egg.hip", "kernels_quadcopter.hip", "kernels_jit_twins.hip"]
 MI_MAX_DOF = 32
 
 # -fno-slp-vectorize: pairing scalars into v_pk_* ops lengthens live ranges in the fully unrolled sub-step
