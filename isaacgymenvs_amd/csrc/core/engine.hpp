@@ -857,7 +857,10 @@ struct Sim {
                 sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { a += g[C] * g[C]; G(row, C) = g[C]; });
                 Ainv(row) = onf * MI_RCP(a);
                 const float vtn = (gap >= 0.f) ? -gap * invh : fminf(-gap * P.erp * invh, P.max_depen_vel);
-                vt(row) = (k == 0) ? vtn : 0.f;
+                // the velocity target of a tangent row is zero and the sweeps never read its slot: on a height field the two slots keep the
+                // surface normal (x, y; z > 0 follows) for the net-contact-force pass after the solve, which would otherwise repeat the query
+                if constexpr (GND::HEIGHTFIELD) vt(row) = (k == 0) ? vtn : fr[0][k - 1];
+                else vt(row) = (k == 0) ? vtn : 0.f;
                 float lprev;
                 if constexpr (LAM_IN_ROWS) lprev = lam(row); else lprev = lamc(3 * s + k);
                 const float l0 = lprev * P.warm * onf;
@@ -1213,9 +1216,16 @@ struct Sim {
             lamc(3 * s) = ln; lamc(3 * s + 1) = l1; lamc(3 * s + 2) = l2;
             float f[3], xc[3];
             if constexpr (GND::HEIGHTFIELD) {
-                // the frame is re-derived here (root has not moved yet) instead of being kept live through the solve
-                float zt, n[3], t1[3], t2[3];
-                gnd.query(root[0] + c.xcs[s][0], root[1] + c.xcs[s][1], &zt, n);
+                // the frame is re-derived here instead of being kept live through the solve: static store -- from the normal parked in the
+                // tangent rows' unused target slots (row build above); compact store -- by repeating the query (root has not moved yet)
+                float n[3], t1[3], t2[3];
+                if constexpr (!COMPACT) {
+                    n[0] = vt(row0 + 1); n[1] = vt(row0 + 2);
+                    n[2] = MI_SQRT(fmaxf(1.f - n[0] * n[0] - n[1] * n[1], 0.f));
+                } else {
+                    float zt;
+                    gnd.query(root[0] + c.xcs[s][0], root[1] + c.xcs[s][1], &zt, n);
+                }
                 contact_frame(n, t1, t2);
                 sfor<3>([&](auto K) MI_LAMBDA {
                     f[K] = (n[K] * ln + t1[K] * l1 + t2[K] * l2) * invh;
