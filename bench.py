@@ -42,9 +42,9 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 # NOT applied; the excess over the algorithmic bytes is state re-read per sub-step launch, warm-start impulses and
 # (Humanoid) the constraint rows that spill to scratch.
 PMC_TRAFFIC_BYTES = {("Ant", 4096): int((2 * (1196.8 + 1856.0) + 661.1 + 2213.1) * 1024),
-                     ("Humanoid", 8192): int((2 * (12271.4 + 22452.3) + 2271.8 + 8931.7) * 1024),
-                     ("AnymalTerrain", 4096): int((5 * (1656.7 + 2272.0) + 65.0 + 0.1 + 1342.6 + 2549.4 + 740.7 + 4744.1) * 1024),
-                     ("ShadowHand", 16384): int((1694.9 + 4689.2 + 2 * (9240.4 + 27381.3) + 7969.7 + 48811.8 + 1.6) * 1024)}
+                     ("Humanoid", 8192): int((2 * (12271.3 + 22448.9) + 2265.5 + 8945.1) * 1024),
+                     ("AnymalTerrain", 4096): int((5 * (1623.6 + 2272.0) + 65.0 + 0.1 + 1342.6 + 2549.4 + 740.7 + 4744.1) * 1024),
+                     ("ShadowHand", 16384): int((1699.0 + 4689.0 + 2 * (9257.8 + 27090.6) + 7982.1 + 48825.9 + 1.3) * 1024)}
 
 
 def measure(task, num_envs, steps, warmup, device, rank, world, seed=42, pool=8):
@@ -116,9 +116,9 @@ def measure(task, num_envs, steps, warmup, device, rank, world, seed=42, pool=8)
 # launches + post kernel) and what a wave that owns its SIMD can issue (tools/debug/ifetch_bench.hip: 4 cycles per 4-byte and ~5.3
 # per 8-byte instruction at ~1.8 GHz, ~45 % 8-byte => ~2.55 ns).  Every wave runs concurrently at the BASELINE sizes, so this
 # per-wave issue time is the floor of the step on the current one-env-per-lane design; reported next to the mandatory HBM roofline.
-WAVE_INSTRS_PER_STEP = {"Ant": 2 * 10800 + 1200, "Humanoid": 2 * 35940 + 3570}   # SQ_INSTS_VALU + SALU + LDS per wave (profiles/r1_pmc_summary.md)
+WAVE_INSTRS_PER_STEP = {"Ant": 2 * 10800 + 1200, "Humanoid": 2 * 35940 + 2 * 3350}   # Humanoid post: 2 half-filled waves per 64 envs   # SQ_INSTS_VALU + SALU + LDS per wave (profiles/r1_pmc_summary.md)
 ISSUE_NS_PER_INSTR = 2.55
-WAVE_VALU_PER_STEP = {"Ant": 2 * 9213 + 1104, "Humanoid": 2 * 30808 + 3385, "AnymalTerrain": 5 * 15148 + 2718, "ShadowHand": 2 * 62341 + 1313 + 7549}
+WAVE_VALU_PER_STEP = {"Ant": 2 * 9213 + 1104, "Humanoid": 2 * 30808 + 3188, "AnymalTerrain": 5 * 14594 + 2718, "ShadowHand": 2 * 62333 + 1313 + 7549}
 VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 
 
