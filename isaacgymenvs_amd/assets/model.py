@@ -754,3 +754,169 @@ def load_asset(path, name=None, fix_base_link=False, density=None, replace_cylin
         return build_model(name, bodies, acts, fix_base_link=fix_base_link, density=density, **kw)
     bodies, acts = parse_mjcf(path)
     return build_model(name, bodies, acts, fix_base_link=fix_base_link, density=density, **kw)
+
+
+# ----------------------------------------------------------------------------
+# self-collision (actors created with collision filter 0: reference humanoid.py:194)
+# ----------------------------------------------------------------------------
+def collision_capsules(spec: ModelSpec):
+    """Sphere / capsule collision geoms as segments in their (dynamic) body frame:
+    -> (body [G], p0 [G,3], p1 [G,3], radius [G], friction [G], geom index [G]).  A sphere is a zero-length segment."""
+    gb, p0, p1, rad, mu, gi = [], [], [], [], [], []
+    for g in range(len(spec.geom_body)):
+        t = int(spec.geom_type[g])
+        if t not in (GEOM_SPHERE, GEOM_CAPSULE):
+            continue
+        c = np.asarray(spec.geom_pos[g], float)
+        half = np.zeros(3)
+        if t == GEOM_CAPSULE:
+            half = quat_to_mat(np.asarray(spec.geom_quat[g], float)) @ np.array([0.0, 0.0, float(spec.geom_size[g][1])])
+        gb.append(int(spec.geom_body[g])); p0.append(c + half); p1.append(c - half)
+        rad.append(float(spec.geom_size[g][0])); mu.append(float(spec.geom_friction[g])); gi.append(g)
+    return (np.array(gb, np.int32), np.array(p0, float).reshape(-1, 3), np.array(p1, float).reshape(-1, 3),
+            np.array(rad, float), np.array(mu, float), np.array(gi, np.int32))
+
+
+def _axis_angle_mats(a, th):
+    """Rodrigues, batched: a [N,3] unit axes, th [N] -> [N,3,3]."""
+    c, s = np.cos(th)[:, None, None], np.sin(th)[:, None, None]
+    K = np.zeros((len(th), 3, 3))
+    K[:, 0, 1], K[:, 0, 2], K[:, 1, 0], K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -a[:, 2], a[:, 1], a[:, 2], -a[:, 0], -a[:, 1], a[:, 0]
+    return c * np.eye(3)[None] + s * K + (1 - c) * a[:, :, None] * a[:, None, :]
+
+
+def body_frames(spec: ModelSpec, q):
+    """Batched forward kinematics with the root at the origin: q [N, nd] -> (R [N, nb, 3, 3], r [N, nb, 3]).
+    Same convention as the engine's tree pass (joints rotate / slide the child about anchors given in the child frame)."""
+    q = np.atleast_2d(np.asarray(q, float))
+    n = len(q)
+    R = np.zeros((n, spec.nb, 3, 3)); r = np.zeros((n, spec.nb, 3))
+    for b in range(spec.nb):
+        p = int(spec.parent[b])
+        if p < 0:
+            Rb = np.tile(np.eye(3), (n, 1, 1)); rb = np.zeros((n, 3))
+        else:
+            Rb = R[:, p] @ quat_to_mat(np.asarray(spec.bquat[b], float))
+            rb = r[:, p] + R[:, p] @ np.asarray(spec.bpos[b], float)
+        for d in range(spec.nd):
+            if int(spec.dof_body[d]) != b:
+                continue
+            a = Rb @ np.asarray(spec.dof_axis[d], float)
+            pt = rb + Rb @ np.asarray(spec.dof_anchor[d], float)
+            if int(spec.dof_type[d]) == JOINT_HINGE:
+                Q = _axis_angle_mats(a, q[:, d])
+                Rb = Q @ Rb
+                rb = pt + np.einsum("nij,nj->ni", Q, rb - pt)
+            else:
+                rb = rb + a * q[:, d:d + 1]
+        R[:, b], r[:, b] = Rb, rb
+    return R, r
+
+
+def segment_distance(a0, a1, b0, b1):
+    """Closest points of segments [a0,a1], [b0,b1], batched [N,3] -> (ca, cb).  Clamped closest-point construction; a zero-length
+    segment degenerates to a point.  The engine (csrc/core/engine.hpp `seg_seg_closest`) and the oracle use the same
+    sequence of operations."""
+    d1, d2, rr = a1 - a0, b1 - b0, a0 - b0
+    A = (d1 * d1).sum(-1); E = (d2 * d2).sum(-1); F = (d2 * rr).sum(-1); Cc = (d1 * rr).sum(-1); Bb = (d1 * d2).sum(-1)
+    eps = 1e-12
+    den = A * E - Bb * Bb
+    s = np.where(den > eps, np.clip((Bb * F - Cc * E) / np.where(den > eps, den, 1.0), 0.0, 1.0), 0.0)
+    s = np.where(A > eps, s, 0.0)
+    t = np.where(E > eps, (Bb * s + F) / np.where(E > eps, E, 1.0), 0.0)
+    t_c = np.clip(t, 0.0, 1.0)
+    s2 = np.where(A > eps, np.clip((Bb * t_c - Cc) / np.where(A > eps, A, 1.0), 0.0, 1.0), 0.0)
+    s = np.where((t != t_c) | ~(E > eps), s2, s)
+    return a0 + d1 * s[:, None], b0 + d2 * t_c[:, None]
+
+
+def self_collision_pairs(spec: ModelSpec, n_samples=40000, margin=0.03, limit_slack=0.15, seed=0):
+    """Static broad phase of an actor that collides with itself: the body pairs (a < b) that are not joined by a joint and whose
+    collision capsules come within `margin` of each other somewhere inside the joint limits (widened by `limit_slack` rad, since
+    limits are soft constraints), found by sampling configurations.  Pairs that can never touch -- most of them -- cost nothing
+    at run time.  -> list of (body_a, body_b, [(capsule_i, capsule_j), ...])."""
+    gb, p0, p1, rad, _, _ = collision_capsules(spec)
+    if len(gb) < 2:
+        return []
+    rng = np.random.default_rng(seed)
+    lo = np.minimum(spec.dof_lower, spec.dof_upper) - limit_slack
+    up = np.maximum(spec.dof_lower, spec.dof_upper) + limit_slack
+    lim = np.asarray(spec.dof_limited, bool)
+    lo = np.where(lim, lo, -np.pi); up = np.where(lim, up, np.pi)
+    q = rng.uniform(lo, up, (n_samples, spec.nd))
+    R, r = body_frames(spec, q)
+    w0 = r[:, gb] + np.einsum("ngij,gj->ngi", R[:, gb], p0)
+    w1 = r[:, gb] + np.einsum("ngij,gj->ngi", R[:, gb], p1)
+    out = {}
+    for i in range(len(gb)):
+        for j in range(i + 1, len(gb)):
+            a, b = int(gb[i]), int(gb[j])
+            if a == b or int(spec.parent[a]) == b or int(spec.parent[b]) == a:
+                continue
+            ca, cb = segment_distance(w0[:, i], w1[:, i], w0[:, j], w1[:, j])
+            dmin = (np.linalg.norm(ca - cb, axis=1) - rad[i] - rad[j]).min()
+            if dmin < margin:
+                key = (min(a, b), max(a, b))
+                out.setdefault(key, []).append((i, j) if a < b else (j, i))
+    return [(a, b, gp) for (a, b), gp in sorted(out.items())]
+
+
+def limb_paths(spec: ModelSpec):
+    """Partition of the bodies into ancestor->descendant paths ("limbs"): a body continues its parent's limb when it is the only child or
+    the child with the strictly largest subtree, and starts a new limb otherwise.  Humanoid: {torso, lower_waist, pelvis}, two legs,
+    two arms.  -> (limb id per body [nb], list of body lists)."""
+    nb = spec.nb
+    children = [[] for _ in range(nb)]
+    for b in range(1, nb):
+        children[int(spec.parent[b])].append(b)
+    size = [1] * nb
+    for b in range(nb - 1, 0, -1):
+        size[int(spec.parent[b])] += size[b]
+    limb = [-1] * nb
+    limbs = []
+    for b in range(nb):
+        p = int(spec.parent[b])
+        cont = False
+        if p >= 0:
+            sib = children[p]
+            cont = len(sib) == 1 or all(size[b] > size[c] for c in sib if c != b)
+        if cont:
+            limb[b] = limb[p]
+            limbs[limb[b]].append(b)
+        else:
+            limb[b] = len(limbs)
+            limbs.append([b])
+    return limb, limbs
+
+
+def self_collision_groups(spec: ModelSpec, pairs=None):
+    """Run-time organisation of the self-collision pairs: one *group* per pair of limbs (and per limb with non-adjacent bodies of
+    its own).  A group carries at most one contact per sub-step -- its deepest capsule pair -- and all its body pairs share one
+    constraint-row code path whose chain is the union of the two limb tips' kinematic chains.
+    -> list of dicts {tip_a, tip_b, pairs: [(capsule_a, capsule_b)]} with body(capsule_a) in limb A, body(capsule_b) in limb B."""
+    pairs = self_collision_pairs(spec) if pairs is None else pairs
+    gb = collision_capsules(spec)[0]
+    limb, limbs = limb_paths(spec)
+    groups = {}
+    for a, b, gps in pairs:
+        la, lb = limb[a], limb[b]
+        for (i, j) in gps:
+            # order the two sides by limb id so that a group has one orientation (intra-limb: ancestor first)
+            if (la, a) <= (lb, b):
+                groups.setdefault((la, lb), []).append((int(i), int(j)))
+            else:
+                groups.setdefault((lb, la), []).append((int(j), int(i)))
+    out = []
+    for (la, lb), gps in sorted(groups.items()):
+        out.append(dict(limb_a=la, limb_b=lb, tip_a=limbs[la][-1], tip_b=limbs[lb][-1], pairs=sorted(gps)))
+    return out
+
+
+def self_collision_tables(spec: ModelSpec, **kw):
+    """Everything the engine and the oracle need for self-collision, as plain lists (stored next to the model as <name>_selfcol.json
+    by tools/compile_models.py): the collision capsules and, grouped by limb pair, the capsule pairs that can touch."""
+    gb, p0, p1, rad, mu, gi = collision_capsules(spec)
+    groups = self_collision_groups(spec, self_collision_pairs(spec, **kw))
+    return dict(cap_body=[int(x) for x in gb], cap_p0=[[float(v) for v in p] for p in p0], cap_p1=[[float(v) for v in p] for p in p1],
+                cap_rad=[float(x) for x in rad], cap_mu=[float(x) for x in mu], cap_geom=[int(x) for x in gi],
+                groups=[dict(tip_a=int(g["tip_a"]), tip_b=int(g["tip_b"]), pairs=[[int(i), int(j)] for i, j in g["pairs"]]) for g in groups])

@@ -246,6 +246,41 @@ struct Strided {
     int stride;
     MI_HD float& operator()(int k) const { return p[(size_t)k * stride]; }
 };
+// self-collision state of an actor created with collision filter 0 (reference humanoid.py:194); nullptr = the actor ignores itself
+struct SelfCol {
+    Strided lamp;          // [3 * NPG] warm-start impulses of the limb-pair groups (normal, two tangents)
+    Strided pairf;         // [3 * NPG] world force on side a of each group's contact, this sub-step (p == nullptr: not wanted)
+};
+
+// closest points ca, cb of the segments [a0,a1], [b0,b1] (capsule axes; A_PT / B_PT: that side is a sphere, i.e. a point).  Clamped
+// closest-point construction, branch-free; the same operation sequence as oracle/physics.c::seg_seg_closest.
+template <bool A_PT, bool B_PT>
+MI_HD void seg_seg_closest(const float* a0, const float* a1, const float* b0, const float* b1, float* ca, float* cb) {
+    if constexpr (A_PT && B_PT) {
+        sfor<3>([&](auto K) MI_LAMBDA { ca[K] = a0[K]; cb[K] = b0[K]; });
+    } else if constexpr (A_PT) {        // point vs segment: t = clamp(d2.(a0 - b0) / |d2|^2)
+        float d2[3], rr[3];
+        sfor<3>([&](auto K) MI_LAMBDA { d2[K] = b1[K] - b0[K]; rr[K] = a0[K] - b0[K]; });
+        const float E = dot3(d2, d2), F = dot3(d2, rr);
+        const float t = (E > 1e-12f) ? fminf(fmaxf(F * MI_RCP(fmaxf(E, 1e-30f)), 0.f), 1.f) : 0.f;
+        sfor<3>([&](auto K) MI_LAMBDA { ca[K] = a0[K]; cb[K] = b0[K] + d2[K] * t; });
+    } else if constexpr (B_PT) {
+        seg_seg_closest<true, false>(b0, b1, a0, a1, cb, ca);
+    } else {
+        float d1[3], d2[3], rr[3];
+        sfor<3>([&](auto K) MI_LAMBDA { d1[K] = a1[K] - a0[K]; d2[K] = b1[K] - b0[K]; rr[K] = a0[K] - b0[K]; });
+        const float A = dot3(d1, d1), E = dot3(d2, d2), F = dot3(d2, rr), C = dot3(d1, rr), B = dot3(d1, d2);
+        const float den = A * E - B * B;
+        const bool okA = A > 1e-12f, okE = E > 1e-12f, okD = (den > 1e-12f) && okA;
+        const float rA = MI_RCP(fmaxf(A, 1e-30f)), rE = MI_RCP(fmaxf(E, 1e-30f));
+        float sp = okD ? fminf(fmaxf((B * F - C * E) * MI_RCP(fmaxf(den, 1e-30f)), 0.f), 1.f) : 0.f;
+        const float t = okE ? (B * sp + F) * rE : 0.f;
+        const float tc = fminf(fmaxf(t, 0.f), 1.f);
+        const float s2 = fminf(fmaxf((B * tc - C) * rA, 0.f), 1.f);
+        sp = ((t != tc || !okE) && okA) ? s2 : sp;      // clamped t (or a point-like b) moves the closest point on a
+        sfor<3>([&](auto K) MI_LAMBDA { ca[K] = a0[K] + d1[K] * sp; cb[K] = b0[K] + d2[K] * tc; });
+    }
+}
 
 template <class M>
 struct Sim {
@@ -272,7 +307,11 @@ struct Sim {
     // rows (MI_INLINE_WARM=1) costs more spills than it saves, limit rows only (=3) is slower than the separate pass (=0).
     static constexpr bool INLINE_WARM = MI_INLINE_WARM && !COMPACT;
     static constexpr bool INLINE_WARM_LIM = INLINE_WARM && (MI_INLINE_WARM != 2), INLINE_WARM_SPH = INLINE_WARM && (MI_INLINE_WARM != 3);
-    static constexpr int KMAX = 16;                       // active ground contacts kept per env (compact store only)
+    // ---- self-collision (compact store only): at most one contact per limb-pair group, KPAIR of them per env, each in a slot of
+    // 3 rows over the union of the two limb tips' chains (PCHAIN entries) behind the ground-contact slots
+    static constexpr int NPG = COMPACT ? M::NPG : 0, PCH = M::PCHAIN, KPAIR = 3;
+    static constexpr int P_CSZ = 3 * PCH + 7;
+    static constexpr int KMAX = NPG > 0 ? 12 : 16;        // active ground contacts kept per env (compact store only)
     static constexpr int limoff(int r) {                  // tight packing of the limit rows: offset of row r
         int n = 0;
         for (int k = 0; k < r; ++k) n += M::nanc[OFF + limdof_c(k)] + 1;
@@ -288,13 +327,14 @@ struct Sim {
     static constexpr int C_LIMG = limoff(NLIM);           // floats of limit-row G
     static constexpr int C_CB = C_LIMG + 3 * NLIM;        // first contact slot (after limit Ainv, vt, lam)
     static constexpr int C_CSZ = 3 * M::MAXCHAIN + 7;     // 3 rows + Ainv x3, vt_n, lam x3
-    static constexpr int C_SLOTOF = C_CB + KMAX * C_CSZ;  // [NSPH] slot index of each sphere (-1: inactive), as int bits
+    static constexpr int C_PB = C_CB + KMAX * C_CSZ;      // first self-contact slot
+    static constexpr int C_SLOTOF = C_PB + (NPG > 0 ? KPAIR * P_CSZ : 0);  // [NSPH] slot index of each sphere (-1: inactive), as int bits
     // [ND][6] joint motion subspaces, parked here by the tree pass for the contact-row build: with S out of the register file
     // after the tree pass the Humanoid sub-step keeps ~126 fewer values live (it overflows the 512 registers of its lane)
     static constexpr int C_S = C_SLOTOF + NSPH;
     static constexpr bool S_IN_ROWS = (size_t)(C_S + 6 * ND) * 32 * sizeof(float) <= 160 * 1024;
     static constexpr int ROW_SLOTS_COMPACT = C_S + (S_IN_ROWS ? 6 * ND : 0);
-    static constexpr int C_WARM_OK = (KMAX * C_CSZ - 3 * NSPH) / C_CSZ - 1;   // last slot whose write cannot reach the staged warm-start values
+    static constexpr int C_WARM_OK = (C_SLOTOF - C_CB - 3 * NSPH) / C_CSZ - 1;   // last slot whose write cannot reach the staged warm-start values
     static constexpr int ROW_SLOTS = COMPACT ? ROW_SLOTS_COMPACT : ROW_SLOTS_STATIC;
 
     // ---- per-env state carried in registers through a sub-step; the warm-start impulses and the sensor outputs
@@ -322,6 +362,12 @@ struct Sim {
         }
         return 0;
     }
+    static constexpr bool cap_is_point(int c) { return M::cap_s0[c] == M::cap_s1[c]; }
+    static constexpr bool group_has_body(int g, int b) {  // can body b take part in a contact of group g?
+        for (int k = M::pg_first[g]; k < M::pg_first[g] + M::pg_count[g]; ++k)
+            if (M::cap_body[M::gp_a[k]] == b || M::cap_body[M::gp_b[k]] == b) return true;
+        return false;
+    }
     static constexpr int sensor_of(int b) {  // index of the force sensor on body b, -1 if none
         for (int k = 0; k < NSENS; ++k)
             if (M::sens_body[k] == b) return k;
@@ -330,16 +376,19 @@ struct Sim {
 
     // whole simulate() on plain arrays (host build of the tests; the kernels call substep() directly).
     // state layout = oracle/physics.c: lamc[3*NSPH], laml[ND], sensor[6*NSENS], dof_force[ND]
-    MI_HD void step(const SimParams& P, const float* tau, float* lamc, float* laml, float* sensor, float* dof_force) {
+    // lamp [3 * NPG] (self-contact warm start; nullptr: the actor ignores itself), pairf [stride 6 per group]: world force per group
+    MI_HD void step(const SimParams& P, const float* tau, float* lamc, float* laml, float* sensor, float* dof_force,
+                    float* lamp = nullptr, float* pairf = nullptr) {
         const float h = P.dt / (float)P.substeps;
         float rows[ROW_SLOTS];
         for (int ss = 0; ss < P.substeps; ++ss)
-            substep_noinline(P, tau, h, rows, lamc, laml, sensor, dof_force);
+            substep_noinline(P, tau, h, rows, lamc, laml, sensor, dof_force, lamp, pairf);
     }
     MI_HD_NOINLINE void substep_noinline(const SimParams& P, const float* tau, const float h, float* rows, float* lamc,
-                                         float* laml, float* sensor, float* dof_force) {
+                                         float* laml, float* sensor, float* dof_force, float* lamp, float* pairf) {
+        const SelfCol sc{Strided{lamp, 1}, Strided{pairf, 1}};
         substep(P, tau, h, RowStore<1>{rows}, Strided{lamc, 1}, Strided{laml, 1}, Strided{sensor, 1}, Strided{dof_force, 1},
-                PlaneGround{}, -1.f, Strided{nullptr, 1});
+                PlaneGround{}, -1.f, Strided{nullptr, 1}, nullptr, false, lamp ? &sc : nullptr);
     }
     // same on a height field with per-env friction and per-body net contact forces netf[3*NB]
     MI_HD void step_terrain(const SimParams& P, const float* tau, float* lamc, float* laml, float* sensor, float* dof_force,
@@ -580,7 +629,7 @@ struct Sim {
     template <int RS, class GND>
     MI_HD void substep(const SimParams& P, const float* tau, const float h, const RowStore<RS> rows, const Strided lamc,
                        const Strided laml, const Strided sensor, const Strided dof_force, const GND& gnd, const float mu_env,
-                       const Strided netf, const Drive* drv = nullptr, const bool prestaged = false) {
+                       const Strided netf, const Drive* drv = nullptr, const bool prestaged = false, const SelfCol* scol = nullptr) {
         // static store: row r at r*MAXCHAIN; compact store: only the limit rows (r < NLIM) live at fixed, tightly packed places
         auto G = [&](int row, int c) MI_LAMBDA -> float& { return rows(COMPACT ? limoff(row) + c : row * M::MAXCHAIN + c); };
         auto Ainv = [&](int row) MI_LAMBDA -> float& { return rows(COMPACT ? C_LIMG + row : NROWG * M::MAXCHAIN + row); };
@@ -801,6 +850,13 @@ struct Sim {
         // a sphere no env touches are neither built nor swept -- their contribution would be exactly zero anyway
         unsigned long long sph_active = 0ull;
         static_assert(COMPACT || NSPH <= 64, "sph_active is a 64-bit mask");
+        // self-collision bookkeeping: 2 bits per group = the slot of its contact (3: none); per slot the contact point (rel. O), the
+        // normal (side b -> side a), the two bodies (a | b << 8, as int bits) and the friction coefficient
+        static_assert(NPG <= 16, "pmap holds 2 bits per group");
+        unsigned pmap = 0xFFFFFFFFu;
+        float pinf[NPG > 0 ? KPAIR : 1][8];
+        if constexpr (NPG > 0) sfor<KPAIR>([&](auto J_) MI_LAMBDA { sfor<8>([&](auto I_) MI_LAMBDA { pinf[J_][I_] = 0.f; }); });
+        const bool selfcol = (NPG > 0) && (scol != nullptr);
         if constexpr (!COMPACT) {
         // ground contacts: 3 rows per sphere (normal, two tangents; +z, x, y on the plane)
         sfor<NSPH>([&](auto S_) MI_LAMBDA {
@@ -944,6 +1000,120 @@ struct Sim {
             cnt += on ? 1 : 0;
             rows(C_SLOTOF + s) = __builtin_bit_cast(float, j);
         });
+        // ---- self-collision: per limb-pair group the deepest capsule pair becomes one contact between the two bodies.  The capsule
+        // axes end on contact spheres, whose centres the tree pass left in c.xcs.  The Jacobian of the row is J_a - J_b: dofs that
+        // carry both bodies drop out, the others enter with the sign of their side -- which side(s) a dof moves depends on the bodies
+        // the env's deepest pair happens to join, so it is read from the per-lane chain masks instead of being unrolled per body pair
+        // (13 row-build code paths for the Humanoid instead of 66).
+        if constexpr (NPG > 0) { if (selfcol) {
+        int cntp = 0;
+        sfor<NPG>([&](auto G_) MI_LAMBDA {
+            constexpr int g = G_, LEN = M::pg_chain_len[g];
+            MI_PHASE();
+            float best = 3.0e38f, bca[3] = {0.f, 0.f, 0.f}, bcb[3] = {0.f, 0.f, 0.f}, brb = 0.f, bmu = 0.f;
+            int bab = 0;
+            unsigned mA = 0u, mB = 0u;
+            sfor<M::pg_count[g]>([&](auto K_) MI_LAMBDA {
+                constexpr int k = M::pg_first[g] + K_, ia = M::gp_a[k], ib = M::gp_b[k];
+                float ca[3], cb[3];
+                seg_seg_closest<cap_is_point(ia), cap_is_point(ib)>(c.xcs[M::cap_s0[ia]], c.xcs[M::cap_s1[ia]], c.xcs[M::cap_s0[ib]],
+                                                                      c.xcs[M::cap_s1[ib]], ca, cb);
+                const float dv[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]};
+                const float dist = MI_SQRT(dot3(dv, dv)) - (M::cap_rad[ia] + M::cap_rad[ib]);
+#if defined(MI_DEBUG_PAIRS) && !defined(__HIP_DEVICE_COMPILE__)
+                if (g == 3) printf("  g3 k %d caps %d %d dist %g  a0 %g %g %g a1 %g %g %g b0 %g %g %g b1 %g %g %g\n", k, ia, ib, dist, c.xcs[M::cap_s0[ia]][0], c.xcs[M::cap_s0[ia]][1], c.xcs[M::cap_s0[ia]][2],
+                    c.xcs[M::cap_s1[ia]][0], c.xcs[M::cap_s1[ia]][1], c.xcs[M::cap_s1[ia]][2], c.xcs[M::cap_s0[ib]][0], c.xcs[M::cap_s0[ib]][1], c.xcs[M::cap_s0[ib]][2], c.xcs[M::cap_s1[ib]][0], c.xcs[M::cap_s1[ib]][1], c.xcs[M::cap_s1[ib]][2]);
+#endif
+                const bool better = dist < best;                 // the first pair of the list wins ties
+                best = better ? dist : best;
+                sfor<3>([&](auto I_) MI_LAMBDA { bca[I_] = better ? ca[I_] : bca[I_]; bcb[I_] = better ? cb[I_] : bcb[I_]; });
+                brb = better ? M::cap_rad[ib] : brb;
+                bmu = better ? 0.5f * (M::cap_mu[ia] + M::cap_mu[ib]) : bmu;
+                bab = better ? (M::cap_body[ia] | (M::cap_body[ib] << 8)) : bab;
+                mA = better ? M::chain_mask[M::cap_body[ia]] : mA;
+                mB = better ? M::chain_mask[M::cap_body[ib]] : mB;
+            });
+            const bool on = (best < P.contact_offset) && (cntp < KPAIR);
+            if (MI_WAVE_ANY(on)) {
+                if (on) {
+                    float* pb = rows.ptr(C_PB + cntp * P_CSZ);
+                    constexpr int ST = RowStore<RS>::stride;
+                    float fr[3][3], x[3];
+                    {
+                        const float dv[3] = {bca[0] - bcb[0], bca[1] - bcb[1], bca[2] - bcb[2]};
+                        const float d2 = dot3(dv, dv);
+                        const bool okd = d2 > 1e-18f;
+                        const float inv = MI_RSQ(fmaxf(d2, 1e-30f));
+                        fr[0][0] = okd ? dv[0] * inv : 0.f; fr[0][1] = okd ? dv[1] * inv : 0.f; fr[0][2] = okd ? dv[2] * inv : 1.f;
+                    }
+                    contact_frame(fr[0], fr[1], fr[2]);
+                    sfor<3>([&](auto I_) MI_LAMBDA { x[I_] = bcb[I_] + fr[0][I_] * (brb + 0.5f * best); });   // middle of the gap / overlap
+                    float W[3][6];
+                    sfor<3>([&](auto K) MI_LAMBDA {
+                        cross3(x, fr[K], W[K]);
+                        W[K][3] = fr[K][0]; W[K][4] = fr[K][1]; W[K][5] = fr[K][2];
+                    });
+                    float gg[3][PCH];
+                    sfor<LEN>([&](auto C) MI_LAMBDA {
+                        constexpr int gi = M::pg_chain[g][C];
+                        if constexpr ((M::pg_common[g] >> gi) & 1u) {          // moves both bodies alike
+                            sfor<3>([&](auto K) MI_LAMBDA { gg[K][C] = 0.f; });
+                        } else {
+                            const float cf = (float)((mA >> gi) & 1u) - (float)((mB >> gi) & 1u);
+                            if constexpr (gi >= OFF) {
+                                float Sd[6];
+                                if constexpr (S_IN_ROWS && M::NOS == 0) sfor<6>([&](auto I_) MI_LAMBDA { Sd[I_] = rows(C_S + 6 * (gi - OFF) + I_); });
+                                else sfor<6>([&](auto I_) MI_LAMBDA { Sd[I_] = S[gi - OFF][I_]; });
+                                sfor<3>([&](auto K) MI_LAMBDA { gg[K][C] = cf * dot6(Sd, W[K]); });
+                            } else if constexpr (gi < 3) {
+                                sfor<3>([&](auto K) MI_LAMBDA { gg[K][C] = cf * W[K][3 + gi]; });
+                            } else {
+                                sfor<3>([&](auto K) MI_LAMBDA { gg[K][C] = cf * W[K][gi - 3]; });
+                            }
+                        }
+                    });
+                    // L^T g = J^T over the union chain (descending indices): an entry feeds exactly its ancestors among the later ones
+                    sfor<LEN>([&](auto C) MI_LAMBDA {
+                        constexpr int k = C, i = M::pg_chain[g][k];
+                        const float di = Ldi[i];
+                        const float z0 = gg[0][k] * di, z1 = gg[1][k] * di, z2 = gg[2][k] * di;
+                        gg[0][k] = z0; gg[1][k] = z1; gg[2][k] = z2;
+                        sfor<LEN - 1 - k>([&](auto T) MI_LAMBDA {
+                            constexpr int kk = k + 1 + T, jj = M::pg_chain[g][kk];
+                            if constexpr (M::midx[i][jj] >= 0) {
+                                const float l = L[M::midx[i][jj]];
+                                gg[0][kk] -= l * z0; gg[1][kk] -= l * z1; gg[2][kk] -= l * z2;
+                            }
+                        });
+                    });
+                    const float gap = best - P.rest_offset;
+                    sfor<3>([&](auto K) MI_LAMBDA {
+                        constexpr int k = K;
+                        float a = P.cfm;
+                        sfor<LEN>([&](auto C) MI_LAMBDA { a += gg[k][C] * gg[k][C]; pb[(k * PCH + C) * ST] = gg[k][C]; });
+                        pb[(3 * PCH + k) * ST] = MI_RCP(a);
+                        pb[(3 * PCH + 4 + k) * ST] = scol->lamp(3 * g + k) * P.warm;
+                    });
+                    pb[(3 * PCH + 3) * ST] = (gap >= 0.f) ? -gap * invh : fminf(-gap * P.erp * invh, P.max_depen_vel);
+#if defined(MI_DEBUG_PAIRS) && !defined(__HIP_DEVICE_COMPILE__)
+                    printf("group %d slot %d best %g bab %x x %g %g %g n %g %g %g mA %x mB %x\n  g0:", g, cntp, best, bab, x[0], x[1], x[2], fr[0][0], fr[0][1], fr[0][2], mA, mB);
+                    for (int cc = 0; cc < LEN; ++cc) printf(" %g", gg[0][cc]);
+                    printf("\n  vt %g ainv %g w:", pb[(3 * PCH + 3) * ST], pb[(3 * PCH) * ST]);
+                    for (int cc = 0; cc < NV; ++cc) printf(" %g", w[cc]);
+                    printf("\n");
+#endif
+                    sfor<KPAIR>([&](auto J_) MI_LAMBDA {
+                        const bool me = cntp == J_;
+                        sfor<3>([&](auto I_) MI_LAMBDA { pinf[J_][I_] = me ? x[I_] : pinf[J_][I_]; pinf[J_][3 + I_] = me ? fr[0][I_] : pinf[J_][3 + I_]; });
+                        pinf[J_][6] = me ? __builtin_bit_cast(float, bab) : pinf[J_][6];
+                        pinf[J_][7] = me ? bmu : pinf[J_][7];
+                    });
+                }
+            }
+            pmap = (pmap & ~(3u << (2 * g))) | ((unsigned)(on ? cntp : 3) << (2 * g));
+            cntp += on ? 1 : 0;
+        });
+        } }
         }
         MI_PHASE();
         MI_STAMP(5);
@@ -989,6 +1159,20 @@ struct Sim {
                         });
                     }
                 });
+                if constexpr (NPG > 0) { if (selfcol) {
+                    sfor<NPG>([&](auto G_) MI_LAMBDA {
+                        constexpr int g = G_, LEN = M::pg_chain_len[g];
+                        const int j = (int)((pmap >> (2 * g)) & 3u);
+                        if (j != 3) {
+                            const float* pb = rit.ptr(C_PB + j * P_CSZ);
+                            constexpr int ST = RowStore<RS>::stride;
+                            sfor<3>([&](auto K) MI_LAMBDA {
+                                const float l0 = pb[(3 * PCH + 4 + K) * ST];
+                                sfor<LEN>([&](auto C) MI_LAMBDA { w[M::pg_chain[g][C]] += pb[(K * PCH + C) * ST] * l0; });
+                            });
+                        }
+                    });
+                } }
             }
         }
 #if defined(MI_STOP_AFTER) && MI_STOP_AFTER == 3
@@ -1153,6 +1337,49 @@ struct Sim {
                     });
                 }
             });
+            if constexpr (NPG > 0) { if (selfcol) {
+                sfor<NPG>([&](auto G_) MI_LAMBDA {
+                    constexpr int g = G_, LEN = M::pg_chain_len[g];
+                    const int j = (int)((pmap >> (2 * g)) & 3u);
+                    if (j != 3) {
+                        float* pb = rit.ptr(C_PB + j * P_CSZ);
+                        float mu = pinf[0][7];
+                        sfor<KPAIR - 1>([&](auto J_) MI_LAMBDA { mu = (j == J_ + 1) ? pinf[J_ + 1][7] : mu; });
+                        float gq[3][PCH], ainv[3], lm[3];
+                        sfor<3>([&](auto K) MI_LAMBDA {
+                            sfor<LEN>([&](auto C) MI_LAMBDA { gq[K][C] = pb[(K * PCH + C) * ST]; });
+                            ainv[K] = pb[(3 * PCH + K) * ST];
+                            lm[K] = pb[(3 * PCH + 4 + K) * ST];
+                        });
+                        const float vtn = pb[(3 * PCH + 3) * ST];
+                        float ln;
+                        {
+                            float vn = 0.f;
+                            sfor<LEN>([&](auto C) MI_LAMBDA { vn += gq[0][C] * w[M::pg_chain[g][C]]; });
+                            ln = fmaxf(lm[0] - (vn - vtn) * ainv[0], 0.f);
+                            const float dl = ln - lm[0];
+                            sfor<LEN>([&](auto C) MI_LAMBDA { w[M::pg_chain[g][C]] += gq[0][C] * dl; });
+                        }
+                        float lt[2];
+                        sfor<2>([&](auto K) MI_LAMBDA {
+                            float vn = 0.f;
+                            sfor<LEN>([&](auto C) MI_LAMBDA { vn += gq[1 + K][C] * w[M::pg_chain[g][C]]; });
+                            const float dl = -vn * ainv[1 + K];
+                            lt[K] = lm[1 + K] + dl;
+                            sfor<LEN>([&](auto C) MI_LAMBDA { w[M::pg_chain[g][C]] += gq[1 + K][C] * dl; });
+                        });
+                        const float lim = mu * ln;
+                        const float n2 = lt[0] * lt[0] + lt[1] * lt[1];
+                        const float scl = (n2 > lim * lim) ? lim * MI_RSQ(fmaxf(n2, 1e-30f)) : 1.f;
+                        pb[(3 * PCH + 4) * ST] = ln;
+                        sfor<2>([&](auto K) MI_LAMBDA {
+                            const float nl = lt[K] * scl, dl = nl - lt[K];
+                            pb[(3 * PCH + 5 + K) * ST] = nl;
+                            sfor<LEN>([&](auto C) MI_LAMBDA { w[M::pg_chain[g][C]] += gq[1 + K][C] * dl; });
+                        });
+                    }
+                });
+            } }
         }
         }
 #if defined(MI_STOP_AFTER) && MI_STOP_AFTER == 4
@@ -1246,6 +1473,39 @@ struct Sim {
                 sfor<3>([&](auto C) MI_LAMBDA { sens[6 * k + C] += fl[C]; sens[6 * k + 3 + C] += tl[C]; });
             }
         });
+        // self-contacts: impulses -> warm start, forces on the sensor bodies (+f on side a, -f on side b, at the contact point)
+        if constexpr (NPG > 0) { if (selfcol) {
+            sfor<NPG>([&](auto G_) MI_LAMBDA {
+                constexpr int g = G_;
+                const int j = (int)((pmap >> (2 * g)) & 3u);
+                const bool onj = j != 3;
+                const float* pb = rows.ptr(C_PB + (onj ? j : 0) * P_CSZ);
+                constexpr int ST = RowStore<RS>::stride;
+                const float ln = onj ? pb[(3 * PCH + 4) * ST] : 0.f, l1 = onj ? pb[(3 * PCH + 5) * ST] : 0.f, l2 = onj ? pb[(3 * PCH + 6) * ST] : 0.f;
+                scol->lamp(3 * g) = ln; scol->lamp(3 * g + 1) = l1; scol->lamp(3 * g + 2) = l2;
+                float pi[7];
+                sfor<7>([&](auto I_) MI_LAMBDA {
+                    pi[I_] = pinf[0][I_];
+                    sfor<KPAIR - 1>([&](auto J_) MI_LAMBDA { pi[I_] = (j == J_ + 1) ? pinf[J_ + 1][I_] : pi[I_]; });
+                });
+                float t1[3], t2[3], f[3];
+                contact_frame(pi + 3, t1, t2);
+                sfor<3>([&](auto K) MI_LAMBDA { f[K] = (pi[3 + K] * ln + t1[K] * l1 + t2[K] * l2) * invh; });
+                if (scol->pairf.p) sfor<3>([&](auto K) MI_LAMBDA { scol->pairf(3 * g + K) = f[K]; });
+                const int bab = __builtin_bit_cast(int, pi[6]);
+                sfor<NSENS>([&](auto K_) MI_LAMBDA {
+                    constexpr int k = K_, sb = M::sens_body[k];
+                    if constexpr (group_has_body(g, sb)) {
+                        const float cf = ((bab & 255) == sb ? 1.f : 0.f) - (((bab >> 8) & 255) == sb ? 1.f : 0.f);
+                        const float arm[3] = {pi[0] - c.rs[k][0], pi[1] - c.rs[k][1], pi[2] - c.rs[k][2]};
+                        float tq[3], fl[3], tl[3];
+                        cross3(arm, f, tq);
+                        matTvec3(c.Rs[k], f, fl); matTvec3(c.Rs[k], tq, tl);
+                        sfor<3>([&](auto C) MI_LAMBDA { sens[6 * k + C] += cf * fl[C]; sens[6 * k + 3 + C] += cf * tl[C]; });
+                    }
+                });
+            });
+        } }
         if constexpr (GND::NETF) sfor<NB>([&](auto B_) MI_LAMBDA { sfor<3>([&](auto K) MI_LAMBDA { netf(3 * B_ + K) = nf[B_][K]; }); });
         sfor<6 * NSENS>([&](auto K) MI_LAMBDA { sensor(K) = sens[K]; });
         MI_PHASE();

@@ -13,7 +13,8 @@ MODELS = {
     # reference ant.py:170-178: force sensors on every body whose name contains "foot"
     "ant": dict(struct="ModelAnt", sensors=["front_left_foot", "front_right_foot", "left_back_foot", "right_back_foot"]),
     # reference humanoid.py:162-168: right_foot, left_foot
-    "humanoid": dict(struct="ModelHumanoid", sensors=["right_foot", "left_foot"]),
+    # the actor collides with itself (collision filter 0, humanoid.py:194): capsule pairs in models/humanoid_selfcol.json
+    "humanoid": dict(struct="ModelHumanoid", sensors=["right_foot", "left_foot"], selfcol="humanoid_selfcol.json"),
     # reference anymal_terrain.py: no force sensors (it reads net contact forces per body, :119)
     "anymal": dict(struct="ModelAnymal", sensors=[]),
     # reference shadow_hand.py:291-297: force sensors on the five fingertips (distal links)
@@ -29,6 +30,16 @@ def load_extras(name):
     import json
     with open(os.path.join(_HERE, "models", MODELS[name]["extras"])) as f:
         return json.load(f)
+
+
+def load_selfcol(name):
+    """Self-collision tables of a model (assets/model.py::self_collision_tables), or None when the actor does not collide with itself."""
+    import json
+    f = MODELS.get(name, {}).get("selfcol")
+    if not f:
+        return None
+    with open(os.path.join(_HERE, "models", f)) as fh:
+        return json.load(fh)
 
 
 def load_model(name) -> ModelSpec:
@@ -51,7 +62,7 @@ def generate_headers(out_dir=None):
             import json
             with open(os.path.join(_HERE, "models", e["extras"])) as f:
                 extras = json.load(f)
-        txt = emit_model_header(spec, e["struct"], sensor_bodies(name, spec), extras)
+        txt = emit_model_header(spec, e["struct"], sensor_bodies(name, spec), extras, load_selfcol(name))
         p = os.path.join(out_dir, f"model_{name}.h")
         write_if_changed(p, txt)
         paths.append(p)

@@ -185,6 +185,9 @@ class VecTask(Env):
             actions = self.dr_randomizations["actions"]["noise_lambda"](actions)
         if actions.device != self.obs_buf.device or actions.dtype != torch.float32 or not actions.is_contiguous():
             actions = actions.to(device=self.obs_buf.device, dtype=torch.float32).contiguous()
+        if actions.shape != (self.num_envs, self.num_actions):
+            # the kernel reads num_envs * num_actions floats from a raw pointer: a short tensor would be read out of bounds
+            raise ValueError(f"actions must have shape ({self.num_envs}, {self.num_actions}), got {tuple(actions.shape)}")
         # one fused launch: clamp -> pre_physics_step -> simulate x control_freq_inv -> post_physics_step -> timeouts
         self.engine.step(actions)
         self.control_steps += 1

@@ -91,6 +91,9 @@ class LocomotionTask(VecTask):
         t = self.engine.tensors
         p = self._task_params_struct
         dev = self.device
+        # baseline of the `rigid_shape_properties.friction` randomisation: the compiled model's own shape friction (Ant 1.5)
+        fr = load_model(self.model_name).sph_friction
+        self.model_shape_friction = float(fr[0]) if len(fr) else 1.0
         # reference attribute names (ant.py:77-114)
         self.root_states = t["root_states"]
         self.initial_root_states = t["initial_root_states"]

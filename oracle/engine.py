@@ -28,7 +28,9 @@ def _struct(real):
                    [(n, C.c_void_p) for n in (
                        "parent", "bpos", "bquat", "mass", "com", "inertia", "dof_body", "dof_type", "dof_axis",
                        "dof_anchor", "dof_lower", "dof_upper", "dof_limited", "dof_armature", "dof_damping",
-                       "dof_stiffness", "dof_springref", "sph_body", "sph_pos", "sph_rad", "sph_mu", "sens_body")]
+                       "dof_stiffness", "dof_springref", "sph_body", "sph_pos", "sph_rad", "sph_mu", "sens_body")] + \
+                   [(n, C.c_int32) for n in ("ncap", "npg", "ngp", "kmax", "kpair", "pad1")] + \
+                   [(n, C.c_void_p) for n in ("cap_body", "cap_p0", "cap_p1", "cap_rad", "cap_mu", "gp_a", "gp_b", "pg_first", "pg_count")]
 
     class OrParams(C.Structure):
         _fields_ = [("dt", real), ("substeps", C.c_int32), ("iters", C.c_int32), ("gravity", real * 3),
@@ -45,7 +47,9 @@ class OracleEngine:
     """Batched CPU physics for one ModelSpec.  State is AoS per env:
     root[13] (pos3, quat xyzw4, linvel3, angvel3) | q[nd] | qd[nd] | lam_c[3*nsph] | lam_l[nd]."""
 
-    def __init__(self, spec, num_envs, params=None, sensor_bodies=(), precision="f64"):
+    def __init__(self, spec, num_envs, params=None, sensor_bodies=(), precision="f64", selfcol=None, kmax=0, kpair=0):
+        """selfcol: self-collision tables (isaacgymenvs_amd.assets.model.self_collision_tables) or None; kmax / kpair: caps of
+        the ground / self contacts per env (0 = unlimited; the engine's LDS contact store holds 12 + 3)."""
         build()
         self.spec = spec
         self.np_real = np.float64 if precision == "f64" else np.float32
@@ -65,8 +69,26 @@ class OracleEngine:
         k["sens_body"] = np.ascontiguousarray(np.array(sensor_bodies, np.int32))
         m = OrModel(nb=spec.nb, nd=spec.nd, fixed_base=int(spec.fixed_base), nsph=len(spec.sph_body),
                     nsens=len(sensor_bodies), pad0=0)
-        for n, _ in OrModel._fields_[6:]:
+        for n, _ in OrModel._fields_[6:28]:
             setattr(m, n, _ptr(k[n]))
+        self.npg = 0
+        if selfcol and selfcol.get("groups"):
+            first, count, ga, gb = [], [], [], []
+            for g in selfcol["groups"]:
+                first.append(len(ga)); count.append(len(g["pairs"]))
+                for i, j in g["pairs"]:
+                    ga.append(i); gb.append(j)
+            k["cap_body"] = np.ascontiguousarray(selfcol["cap_body"], np.int32)
+            for n in ("cap_p0", "cap_p1", "cap_rad", "cap_mu"):
+                k[n] = np.ascontiguousarray(selfcol[n], r)
+            k["gp_a"], k["gp_b"] = np.ascontiguousarray(ga, np.int32), np.ascontiguousarray(gb, np.int32)
+            k["pg_first"], k["pg_count"] = np.ascontiguousarray(first, np.int32), np.ascontiguousarray(count, np.int32)
+            m.ncap, m.npg, m.ngp = len(k["cap_body"]), len(first), len(ga)
+            for n in ("cap_body", "cap_p0", "cap_p1", "cap_rad", "cap_mu", "gp_a", "gp_b", "pg_first", "pg_count"):
+                setattr(m, n, _ptr(k[n]))
+            self.npg = len(first)
+            self.pair_list = list(zip(ga, gb))
+        m.kmax, m.kpair = int(kmax), int(kpair)
         self.model = m
         self.set_params(**(params or {}))
         self.N = num_envs
@@ -106,7 +128,19 @@ class OracleEngine:
 
     @property
     def lam(self):
-        return self.state[:, 13 + 2 * self.nd:]
+        """warm-start impulses of the ground contacts [3 nsph] and the joint limits [nd]"""
+        return self.state[:, 13 + 2 * self.nd:13 + 3 * self.nd + 3 * self.nsph]
+
+    @property
+    def lam_pair(self):
+        """warm-start impulses (normal, two tangents) of the self-collision groups [npg, 3]"""
+        return self.state[:, 13 + 3 * self.nd + 3 * self.nsph:].reshape(self.N, self.npg, 3)
+
+    @property
+    def pair_info(self):
+        """per self-collision group: world force on side a (3), selected capsule-pair index or -1, its signed distance,
+        number of contacts dropped by the kmax / kpair caps in this env"""
+        return self.out[:, 6 * self.nsens + self.nd + 3 * self.nsph:].reshape(self.N, self.npg, 6)
 
     @property
     def sensor(self):
@@ -118,7 +152,7 @@ class OracleEngine:
 
     @property
     def sph_force(self):
-        return self.out[:, 6 * self.nsens + self.nd:].reshape(self.N, self.nsph, 3)
+        return self.out[:, 6 * self.nsens + self.nd:6 * self.nsens + self.nd + 3 * self.nsph].reshape(self.N, self.nsph, 3)
 
     def set_ground(self, height_samples, hscale, vscale, border):
         """Height field (int16 [rows, cols], reference Terrain.height_field_raw) instead of the z = ground_z plane."""

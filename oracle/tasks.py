@@ -192,10 +192,11 @@ class OracleLocomotionEnv:
     """
 
     def __init__(self, hum, spec, sensor_bodies, sim_params: dict, params, num_envs, seed=0, env_id_offset=0,
-                 precision="f32", control_freq_inv=1):
+                 precision="f32", control_freq_inv=1, selfcol=None, kmax=0, kpair=0):
         from .engine import OracleEngine
         self.hum, self.N, self.p, self.nd = hum, num_envs, params, spec.nd
-        self.eng = OracleEngine(spec, num_envs, params=sim_params, sensor_bodies=sensor_bodies, precision=precision)
+        self.eng = OracleEngine(spec, num_envs, params=sim_params, sensor_bodies=sensor_bodies, precision=precision,
+                                selfcol=selfcol, kmax=kmax, kpair=kpair)
         self.seed, self.off, self.cfi = fold_seed(seed), env_id_offset, control_freq_inv
         nd = self.nd
         self.lower = np.array(params.dof_lower[:nd], f32)
@@ -235,6 +236,7 @@ class OracleLocomotionEnv:
         self.eng.qd[ids] = rv
         self.eng.root[ids] = self.initial_root[ids]
         self.eng.lam[ids] = 0
+        self.eng.lam_pair[ids] = 0
         tx = f32(p.targets[0]) - self.initial_root[ids, 0]
         ty = f32(p.targets[1]) - self.initial_root[ids, 1]
         pp = (-np.sqrt((tx * tx + ty * ty) + f32(0)) / f32(p.dt)).astype(f32)

@@ -28,10 +28,11 @@
 using namespace mi;
 
 // state/out layouts identical to oracle/physics.c (AoS per env)
+// selfcol != 0: per-env state additionally carries lamp[3*NPG] after laml, out carries 6 floats per group (first 3: world force on side a)
 template <class M>
-static void run(const SimParams* P, int nenv, float* state, const float* tau, float* out) {
-    constexpr int ND = M::ND, NSPH = M::NSPH, NSENS = M::NSENS;
-    const int ss = 13 + 2 * ND + 3 * NSPH + ND, os = 6 * NSENS + ND + 3 * NSPH;
+static void run(const SimParams* P, int nenv, float* state, const float* tau, float* out, int selfcol = 0) {
+    constexpr int ND = M::ND, NSPH = M::NSPH, NSENS = M::NSENS, NPG = Sim<M>::NPG;
+    const int ss = 13 + 2 * ND + 3 * NSPH + ND + (selfcol ? 3 * NPG : 0), os = 6 * NSENS + ND + 3 * NSPH + (selfcol ? 6 * NPG : 0);
 #pragma omp parallel for schedule(static)
     for (int e = 0; e < nenv; ++e) {
         float* s = state + (size_t)e * ss;
@@ -40,11 +41,24 @@ static void run(const SimParams* P, int nenv, float* state, const float* tau, fl
         for (int k = 0; k < 13; ++k) sim.root[k] = s[k];
         for (int k = 0; k < ND; ++k) { sim.q[k] = s[13 + k]; sim.qd[k] = s[13 + ND + k]; }
         // warm-start impulses and outputs are updated in place (same layout as oracle/physics.c)
-        sim.step(*P, tau + (size_t)e * ND, s + 13 + 2 * ND, s + 13 + 2 * ND + 3 * NSPH, o, o + 6 * NSENS);
+        if (selfcol && NPG > 0) {
+            float pf[3 * (NPG > 0 ? NPG : 1)];
+            sim.step(*P, tau + (size_t)e * ND, s + 13 + 2 * ND, s + 13 + 2 * ND + 3 * NSPH, o, o + 6 * NSENS, s + 13 + 3 * ND + 3 * NSPH, pf);
+            for (int g = 0; g < NPG; ++g) for (int k = 0; k < 3; ++k) o[6 * NSENS + ND + 3 * NSPH + 6 * g + k] = pf[3 * g + k];
+        } else {
+            sim.step(*P, tau + (size_t)e * ND, s + 13 + 2 * ND, s + 13 + 2 * ND + 3 * NSPH, o, o + 6 * NSENS);
+        }
         for (int k = 0; k < 13; ++k) s[k] = sim.root[k];
         for (int k = 0; k < ND; ++k) { s[13 + k] = sim.q[k]; s[13 + ND + k] = sim.qd[k]; }
     }
 }
+
+#ifdef HOSTSIM_HUMANOID
+extern "C" int hs_step_selfcol(const SimParams* P, int nenv, float* state, const float* tau, float* out) {
+    run<ModelHumanoid>(P, nenv, state, tau, out, 1);
+    return 0;
+}
+#endif
 
 extern "C" int hs_step(const char* model, const SimParams* P, int nenv, float* state, const float* tau, float* out) {
 #ifdef HOSTSIM_CARTPOLE

@@ -30,7 +30,7 @@ def make_params(d):
 # model -> (compile-time switch, optimisation level): one library per model, compiled in parallel
 _MODELS = {"cartpole": ("HOSTSIM_CARTPOLE", "-O2"), "ant": ("HOSTSIM_ANT", "-O2"), "anymal": ("HOSTSIM_ANYMAL", "-O2"),
            "quadcopter": ("HOSTSIM_QUADCOPTER", "-O2"), "humanoid": ("HOSTSIM_HUMANOID", "-O2"), "hand": ("HOSTSIM_HAND", "-O1")}
-_ENTRY_MODEL = {"hs_step_terrain": "anymal", "hs_step_drive": "quadcopter", "hs_step_hand": "hand", "hs_hand_fingertips": "hand"}
+_ENTRY_MODEL = {"hs_step_selfcol": "humanoid", "hs_step_terrain": "anymal", "hs_step_drive": "quadcopter", "hs_step_hand": "hand", "hs_hand_fingertips": "hand"}
 _libs = {}
 
 
@@ -87,6 +87,13 @@ def build_hand():
 def step(lib, model, params, state, tau, out):
     rc = lib.hs_step(model.encode(), C.byref(params), state.shape[0], state.ctypes.data_as(C.c_void_p),
                      tau.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+
+
+def step_selfcol(lib, params, state, tau, out):
+    """Humanoid with self-collision: state rows carry lamp[3 NPG] after laml, out rows 6 floats per group (world force first)."""
+    rc = lib.hs_step_selfcol(C.byref(params), state.shape[0], state.ctypes.data_as(C.c_void_p),
+                             tau.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
     assert rc == 0
 
 

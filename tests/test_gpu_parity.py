@@ -863,9 +863,14 @@ def test_actor_params_friction_randomisation_is_tensorised_and_acts_on_the_physi
     msgs = " ".join(str(x.message) for x in w)
     assert "ant.rigid_body_properties" in msgs and "restitution" in msgs and "friction" not in msgs.split("skipped")[-1].replace("restitution", "")
     fr = env.engine.tensors["friction"].cpu().numpy()
+    og = 1.5                                                                          # nv_ant.xml geom friction: the scaling baseline
+    assert abs(env.model_shape_friction - og) < 1e-6
+    # dr_utils.py:135-145 buckets the NEW value (og * sample in 0.3 .. 2.7) into the buckets of the configured range: values past the
+    # last bucket collapse onto it, so with og = 1.5 the mean sits well above the 1.0 an og = 1.0 baseline would give
     buckets = 0.2 + 1.6 * np.arange(50) / 50
     assert fr.min() >= 0.2 - 1e-6 and fr.max() < 1.8 and len(np.unique(np.round(fr, 5))) > 20
     assert np.abs(fr[:, None] - buckets[None, :]).min(axis=1).max() < 1e-5            # every value sits on a bucket
+    assert fr.mean() > 1.15 and (np.abs(fr - buckets[-1]) < 1e-5).mean() > 0.2
     # physics: slide the ant along x on its feet; the distance until it stops decreases with the friction coefficient
     t = env.engine.tensors
     fr_t = torch.linspace(0.2, 1.8, n, device=DEV)
