@@ -149,7 +149,7 @@ def cpu_baseline(task, num_envs, budget_s=15.0, seed=42):
     """The CPU oracle on this host's cores (OpenMP over envs), same workload, bounded to ~budget_s seconds."""
     import numpy as np
     from isaacgymenvs_amd import native
-    from isaacgymenvs_amd.registry import load_model, sensor_bodies
+    from isaacgymenvs_amd.registry import load_model, load_selfcol, sensor_bodies
     from isaacgymenvs_amd.tasks.locomotion import loco_params_from_cfg
     from isaacgymenvs_amd.utils.config import compose
     from oracle.tasks import OracleLocomotionEnv
@@ -163,8 +163,9 @@ def cpu_baseline(task, num_envs, budget_s=15.0, seed=42):
                contact_offset=px["contact_offset"], rest_offset=px["rest_offset"],
                max_depen_vel=px["max_depenetration_velocity"], erp=0.5,
                plane_mu=cfg["env"]["plane"]["staticFriction"], ground_z=0.0, cfm=1e-6, warm=1.0)
+    sc = load_selfcol(name)        # the Humanoid collides with itself, in the port as in the kernels
     orc = OracleLocomotionEnv(task == "Humanoid", load_model(name), sensor_bodies(name), sim, p, num_envs, seed=seed,
-                              precision="f32")
+                              precision="f32", **(dict(selfcol=sc, kmax=12, kpair=3) if sc else {}))
     rng = np.random.default_rng(seed)
     nact = orc.nd
     for _ in range(2):

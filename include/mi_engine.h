@@ -203,8 +203,13 @@ int mi_engine_set_terrain(MiEngine* e, const int16_t* height_samples, int rows, 
                           float vertical_scale, float border_size, const float* env_origins, int num_levels,
                           int num_terrains, float env_length, int max_init_level);
 /* optional knobs: "clip_obs" (env.clipObservations, vec_task.py:115), "control_freq_inv" (env.controlFrequencyInv, :111),
- * "gravity_x|y|z" (gym.set_sim_params after sim_params.gravity randomisation, vec_task.py:720-732) */
+ * "gravity_x|y|z" (gym.set_sim_params after sim_params.gravity randomisation, vec_task.py:720-732),
+ * "self_collision" 0 | 1 (the collision filter of gym.create_actor: humanoid.py:194 passes 0 = the actor collides with itself;
+ * default 1 for the tasks whose arena carries "self_contact_impulse", rejected with 1 elsewhere),
+ * "steps" (the control-step counter: observation-ring parity and per-step RNG counters; restore it together with the arena) */
 int mi_engine_set_option(MiEngine* e, const char* key, double value);
+/* reads back any of the keys of mi_engine_set_option (replaces gym.get_sim_params / gym.get_frame_count, vec_task.py:620,723) */
+int mi_engine_get_option(const MiEngine* e, const char* key, double* value);
 /* which slot of the "obs_out" ring ([2, N, num_obs], clamped copy of obs_buf = what VecTask.step returns as
  * obs_dict["obs"], vec_task.py:402) the most recent step wrote */
 int mi_engine_last_ring(const MiEngine* e);

@@ -54,6 +54,7 @@ __global__ void init_state_kernel(View v, int nd, int nsph3, int nsens6, int nob
         v.tau[k * N + e] = 0.f; v.laml[k * N + e] = 0.f; v.dof_force[k * N + e] = 0.f;
     }
     for (int k = 0; k < nsph3; ++k) v.lamc[k * N + e] = 0.f;
+    if (v.lamp) for (int k = 0; k < 3 * ModelHumanoid::NPG; ++k) { v.lamp[k * N + e] = 0.f; v.pairf[k * N + e] = 0.f; }
     for (int k = 0; k < nsens6; ++k) v.sensor[k * N + e] = 0.f;
     for (int k = 0; k < nact; ++k) v.actions[k * N + e] = 0.f;
     for (int k = 0; k < nobs; ++k) { v.obs[(size_t)e * nobs + k] = 0.f; v.obs_out[(size_t)e * nobs + k] = 0.f; v.obs_out[((size_t)N + e) * nobs + k] = 0.f; }
@@ -254,6 +255,7 @@ struct MiEngine {
     int control_freq_inv;
     std::vector<MiTensorDesc> descs;
     unsigned long long steps;
+    float* lamp_arena;     // the self-contact impulse tensor (Humanoid), kept while the option self_collision is 0
 };
 
 struct Layout {
@@ -308,6 +310,13 @@ static void build_layout(int task, int N, Layout& L, View* v, char* base, int no
         // per-env friction of the robot's shapes for `actor_params.<actor>.rigid_shape_properties.friction` domain randomisation
         // (vec_task.py:752-828); negative = the model's own value
         o = L.add("friction", MI_F32, {n}, {1}, n); if (v) v->friction = (float*)P(o);
+    }
+    if (task == T_HUMANOID) {
+        // the Humanoid actor collides with itself (collision filter 0, humanoid.py:194): warm-start impulses and contact forces of the
+        // limb-pair groups (normal + 2 tangents; force = world force on the first body of the group's contact, last sub-step)
+        const int64_t npg = ModelHumanoid::NPG;
+        o = L.add("self_contact_impulse", MI_F32, {n, npg, 3}, {1, 3 * n, n}, 3 * npg * n); if (v) v->lamp = (float*)P(o);
+        o = L.add("self_contact_force", MI_F32, {n, npg, 3}, {1, 3 * n, n}, 3 * npg * n); if (v) v->pairf = (float*)P(o);
     }
     if (task == T_ANYMAL) {   // anymal_terrain.py:117-168
         const int64_t nb = m.nb;
@@ -426,6 +435,7 @@ extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const 
         nobs = hp.num_obs;
     }
     build_layout(t, num_envs, L, &e->v, (char*)arena, nobs);
+    e->lamp_arena = e->v.lamp;       // self-collision is on by default where the reference's actor collides with itself
     memset(&e->hv, 0, sizeof(e->hv));
     if (t == T_SHADOWHAND) build_hand_layout(num_envs, L, &e->hv, (char*)arena);
     memset(&e->qv, 0, sizeof(e->qv));
@@ -460,6 +470,26 @@ extern "C" int mi_engine_set_option(MiEngine* e, const char* key, double value) 
     if (!strcmp(key, "gravity_y")) { e->P.g[1] = (float)value; return 0; }
     if (!strcmp(key, "gravity_z")) { e->P.g[2] = (float)value; return 0; }
     if (!strcmp(key, "control_freq_inv")) { if (value < 1) return fail("control_freq_inv < 1"); e->control_freq_inv = (int)value; return 0; }
+    // self-collision of the actor (reference: the collision filter passed to gym.create_actor, humanoid.py:194 uses 0 = collide);
+    // only tasks whose arena has the self_contact_impulse tensor accept 1
+    if (!strcmp(key, "self_collision")) {
+        if (value != 0 && !e->lamp_arena) return fail("self_collision: this task's actor has no self-collision tables");
+        e->v.lamp = value != 0 ? e->lamp_arena : nullptr;
+        return 0;
+    }
+    // control-step counter (observation ring parity, AnymalTerrain push schedule, noise counters): part of a state checkpoint
+    if (!strcmp(key, "steps")) { if (value < 0) return fail("steps < 0"); e->steps = (unsigned long long)value; return 0; }
+    return fail(std::string("unknown option: ") + key);
+}
+extern "C" int mi_engine_get_option(const MiEngine* e, const char* key, double* out) {
+    if (!e || !key || !out) return fail("mi_engine_get_option: null argument");
+    if (!strcmp(key, "clip_obs")) { *out = e->clip_obs; return 0; }
+    if (!strcmp(key, "gravity_x")) { *out = e->P.g[0]; return 0; }
+    if (!strcmp(key, "gravity_y")) { *out = e->P.g[1]; return 0; }
+    if (!strcmp(key, "gravity_z")) { *out = e->P.g[2]; return 0; }
+    if (!strcmp(key, "control_freq_inv")) { *out = e->control_freq_inv; return 0; }
+    if (!strcmp(key, "self_collision")) { *out = e->v.lamp != nullptr ? 1.0 : 0.0; return 0; }
+    if (!strcmp(key, "steps")) { *out = (double)e->steps; return 0; }
     return fail(std::string("unknown option: ") + key);
 }
 

@@ -45,6 +45,9 @@ struct View {
     long long* randomize;
     unsigned char* timeout;
     int* episode;
+    // ---- actors that collide with themselves (Humanoid, reference humanoid.py:194); null otherwise / when switched off
+    float* lamp;        // [3*NPG][N] warm-start impulses of the self-contact groups
+    float* pairf;       // [3*NPG][N] world force on side a of each group's contact, last sub-step
     float* ep_ret;      // [N] running return of the current episode
     float* stats;       // [8] job statistics: sum finished returns, sum finished lengths, #finished, sum rewards, #env-steps
     // ---- AnymalTerrain only (null otherwise)
@@ -194,9 +197,11 @@ __global__ __launch_bounds__(64) void substep_kernel(View v, SimParams P, ActPar
     const Strided lamc{v.lamc + e, N}, laml{v.laml + e, N}, sensor{v.sensor + e, N}, dof_force{v.dof_force + e, N};
     const Strided netf{GND::NETF ? v.netf + e : nullptr, N};
     const float mu_env = (GND::HEIGHTFIELD || v.friction != nullptr) ? v.friction[e] : -1.f;   // per-env shape friction where the task has the tensor
+    const SelfCol selfcol{Strided{v.lamp ? v.lamp + e : nullptr, N}, Strided{v.pairf ? v.pairf + e : nullptr, N}};
+    const SelfCol* scp = (Sim<M>::NPG > 0 && v.lamp != nullptr) ? &selfcol : nullptr;   // uniform
     if constexpr (rows_fit_lds<M>()) {
-        if constexpr (LANES == 64) sim.substep(P, tau, h, RowStore<64>(lds_rows + threadIdx.x), lamc, laml, sensor, dof_force, gnd, mu_env, netf, nullptr, PRESTAGE);
-        else sim.substep(P, tau, h, RowStore<LANES>{lds_rows + threadIdx.x}, lamc, laml, sensor, dof_force, gnd, mu_env, netf, nullptr, PRESTAGE);
+        if constexpr (LANES == 64) sim.substep(P, tau, h, RowStore<64>(lds_rows + threadIdx.x), lamc, laml, sensor, dof_force, gnd, mu_env, netf, nullptr, PRESTAGE, scp);
+        else sim.substep(P, tau, h, RowStore<LANES>{lds_rows + threadIdx.x}, lamc, laml, sensor, dof_force, gnd, mu_env, netf, nullptr, PRESTAGE, scp);
     } else {
         float rows[Sim<M>::ROW_SLOTS];
         sim.substep(P, tau, h, RowStore<1>{rows}, lamc, laml, sensor, dof_force, gnd, mu_env, netf);
@@ -268,6 +273,7 @@ __global__ __launch_bounds__(post_lanes<M>()) void loco_post_kernel(View v, Loco
                 v.laml[K * N + e] = 0.f;
             });
             sfor<3 * M::NSPH>([&](auto K) MI_LAMBDA { v.lamc[K * N + e] = 0.f; });
+            if constexpr (M::NPG > 0) { if (v.lamp) sfor<3 * M::NPG>([&](auto K) MI_LAMBDA { v.lamp[K * N + e] = 0.f; }); }
         }
     }
     float obs[NOBS], up_vec[3], heading_vec[3];
@@ -350,6 +356,7 @@ __global__ void loco_reset_kernel(View v, LocoParams tp, const long long* __rest
         v.laml[k * N + e] = 0.f;
     }
     for (int k = 0; k < 3 * M::NSPH; ++k) v.lamc[k * N + e] = 0.f;
+    if (M::NPG > 0 && v.lamp) for (int k = 0; k < 3 * M::NPG; ++k) v.lamp[k * N + e] = 0.f;
     v.potentials[e] = pot;
     v.prev_potentials[e] = prev;
     v.progress[e] = 0;

@@ -139,7 +139,7 @@ class MiTensorDesc(C.Structure):
 # every symbol include/mi_engine.h declares (checked by tests/test_abi.py)
 EXPORTS = ["mi_abi_version", "mi_task_info", "mi_engine_arena_bytes", "mi_engine_create", "mi_engine_init_state",
            "mi_engine_destroy", "mi_engine_num_tensors", "mi_engine_tensor_desc", "mi_engine_step",
-           "mi_engine_reset_idx", "mi_engine_simulate", "mi_engine_set_option", "mi_engine_last_ring", "mi_engine_set_terrain",
+           "mi_engine_reset_idx", "mi_engine_simulate", "mi_engine_set_option", "mi_engine_get_option", "mi_engine_last_ring", "mi_engine_set_terrain",
            "mi_compute_locomotion_observations", "mi_compute_locomotion_reward", "mi_compute_cartpole_reward",
            "mi_compute_hand_reward", "mi_compute_hand_full_state", "mi_randomize_rotation",
            "mi_compute_anymal_observations", "mi_compute_anymal_reward", "mi_compute_quadcopter_reward",
@@ -284,6 +284,7 @@ def lib():
     L.mi_engine_reset_idx.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.mi_engine_simulate.argtypes = [C.c_void_p, C.c_void_p]
     L.mi_engine_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+    L.mi_engine_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
     L.mi_engine_last_ring.argtypes = [C.c_void_p]
     L.mi_engine_set_terrain.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p,
                                         C.c_int, C.c_int, C.c_float, C.c_int]
@@ -411,6 +412,11 @@ class Engine:
 
     def set_option(self, key, value):
         check(lib().mi_engine_set_option(self.h, key.encode(), float(value)))
+
+    def get_option(self, key):
+        out = C.c_double()
+        check(lib().mi_engine_get_option(self.h, key.encode(), C.byref(out)))
+        return out.value
 
     def last_ring(self):
         return lib().mi_engine_last_ring(self.h)

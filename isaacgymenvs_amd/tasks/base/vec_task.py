@@ -375,13 +375,15 @@ class VecTask(Env):
     # ------------------------------------------------------------------ physics-state checkpointing
     def get_env_state(self):
         """Full simulator + task state (the reference never checkpoints physics, vec_task.py:196-204)."""
-        return {"arena": self.engine.arena.clone(), "control_steps": self.control_steps}
+        return {"arena": self.engine.arena.clone(), "control_steps": self.control_steps, "engine_steps": self.engine.get_option("steps")}
 
     def set_env_state(self, env_state):
         if env_state is None:
             return
         self.engine.arena.copy_(env_state["arena"])
         self.control_steps = env_state.get("control_steps", 0)
+        # the engine's own step counter drives the observation-ring parity, the AnymalTerrain push schedule and the noise counters
+        self.engine.set_option("steps", env_state.get("engine_steps", self.control_steps))
 
     def get_number_of_agents(self):
         return self.num_agents

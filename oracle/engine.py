@@ -139,8 +139,8 @@ class OracleEngine:
     @property
     def pair_info(self):
         """per self-collision group: world force on side a (3), selected capsule-pair index or -1, its signed distance,
-        number of contacts dropped by the kmax / kpair caps in this env"""
-        return self.out[:, 6 * self.nsens + self.nd + 3 * self.nsph:].reshape(self.N, self.npg, 6)
+        number of contacts dropped by the kmax / kpair caps in this env, contact point relative to the root origin (3)"""
+        return self.out[:, 6 * self.nsens + self.nd + 3 * self.nsph:].reshape(self.N, self.npg, 9)
 
     @property
     def sensor(self):

@@ -679,8 +679,9 @@ static void step_env(const OrModel *m, const OrParams *p, const OrGround *gnd, r
                 }
             }
             if (pair_out) {
-                real *po = pair_out + 6 * g;
+                real *po = pair_out + 9 * g;   /* world force on side a, selected capsule pair (-1: none), its distance, #dropped, contact point rel. O */
                 po[0] = f[0]; po[1] = f[1]; po[2] = f[2]; po[3] = (real)grp_sel[g]; po[4] = grp_dist[g]; po[5] = (real)dropped;
+                for (int c = 0; c < 3; c++) po[6 + c] = grp_row[g] >= 0 ? grp_x[g][c] : 0;
             }
         }
         /* ---------------- integrate */
@@ -707,7 +708,7 @@ static void step_env(const OrModel *m, const OrParams *p, const OrGround *gnd, r
 
 /* ------------------------------------------------------------------ exported API (ctypes) */
 int or_state_size(const OrModel *m) { return 13 + 2 * m->nd + 3 * m->nsph + m->nd + 3 * m->npg; }
-int or_out_size(const OrModel *m) { return 6 * m->nsens + m->nd + 3 * m->nsph + 6 * m->npg; }
+int or_out_size(const OrModel *m) { return 6 * m->nsens + m->nd + 3 * m->nsph + 9 * m->npg; }
 
 void or_step(const OrModel *m, const OrParams *p, int nenv, real *state, const real *tau, real *out) {
     int ss = or_state_size(m), os = or_out_size(m), nd = m->nd;
@@ -799,4 +800,7 @@ void or_body_vel(const OrModel *m, const real *state, int b, real *out6) {
     for (int k = 0; k < 6; k++) out6[k] = w.V[b][k];
 }
 
+void or_seg_seg_closest(const real *a0, const real *a1, const real *b0, const real *b1, real *ca, real *cb) {
+    seg_seg_closest(a0, a1, b0, b1, ca, cb);
+}
 int or_sizeof_real(void) { return (int)sizeof(real); }

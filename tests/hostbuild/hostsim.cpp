@@ -28,11 +28,11 @@
 using namespace mi;
 
 // state/out layouts identical to oracle/physics.c (AoS per env)
-// selfcol != 0: per-env state additionally carries lamp[3*NPG] after laml, out carries 6 floats per group (first 3: world force on side a)
+// selfcol != 0: per-env state additionally carries lamp[3*NPG] after laml, out carries 9 floats per group (first 3: world force on side a), the oracle's layout
 template <class M>
 static void run(const SimParams* P, int nenv, float* state, const float* tau, float* out, int selfcol = 0) {
     constexpr int ND = M::ND, NSPH = M::NSPH, NSENS = M::NSENS, NPG = Sim<M>::NPG;
-    const int ss = 13 + 2 * ND + 3 * NSPH + ND + (selfcol ? 3 * NPG : 0), os = 6 * NSENS + ND + 3 * NSPH + (selfcol ? 6 * NPG : 0);
+    const int ss = 13 + 2 * ND + 3 * NSPH + ND + (selfcol ? 3 * NPG : 0), os = 6 * NSENS + ND + 3 * NSPH + (selfcol ? 9 * NPG : 0);
 #pragma omp parallel for schedule(static)
     for (int e = 0; e < nenv; ++e) {
         float* s = state + (size_t)e * ss;
@@ -44,7 +44,7 @@ static void run(const SimParams* P, int nenv, float* state, const float* tau, fl
         if (selfcol && NPG > 0) {
             float pf[3 * (NPG > 0 ? NPG : 1)];
             sim.step(*P, tau + (size_t)e * ND, s + 13 + 2 * ND, s + 13 + 2 * ND + 3 * NSPH, o, o + 6 * NSENS, s + 13 + 3 * ND + 3 * NSPH, pf);
-            for (int g = 0; g < NPG; ++g) for (int k = 0; k < 3; ++k) o[6 * NSENS + ND + 3 * NSPH + 6 * g + k] = pf[3 * g + k];
+            for (int g = 0; g < NPG; ++g) for (int k = 0; k < 3; ++k) o[6 * NSENS + ND + 3 * NSPH + 9 * g + k] = pf[3 * g + k];
         } else {
             sim.step(*P, tau + (size_t)e * ND, s + 13 + 2 * ND, s + 13 + 2 * ND + 3 * NSPH, o, o + 6 * NSENS);
         }

@@ -91,7 +91,7 @@ def step(lib, model, params, state, tau, out):
 
 
 def step_selfcol(lib, params, state, tau, out):
-    """Humanoid with self-collision: state rows carry lamp[3 NPG] after laml, out rows 6 floats per group (world force first)."""
+    """Humanoid with self-collision: state rows carry lamp[3 NPG] after laml, out rows 9 floats per group (world force first)."""
     rc = lib.hs_step_selfcol(C.byref(params), state.shape[0], state.ctypes.data_as(C.c_void_p),
                              tau.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
     assert rc == 0

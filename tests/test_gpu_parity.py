@@ -154,6 +154,14 @@ def _make_env(task, n, seed=5):
     return isaacgymenvs_amd.make(seed=seed, task=task, num_envs=n, sim_device=DEV, rl_device=DEV, headless=True)
 
 
+def _selfcol_kw(task):
+    """Oracle options that mirror the engine: the Humanoid collides with itself (humanoid.py:194); its contact store holds 12 ground
+    and 3 self contacts per env."""
+    from isaacgymenvs_amd.registry import load_selfcol
+    sc = load_selfcol(task.lower())
+    return dict(selfcol=sc, kmax=12, kpair=3) if sc else {}
+
+
 def _random_state(spec, n, rng, z_lo, z_hi):
     nd = spec.nd
     lo, up = np.minimum(spec.dof_lower, spec.dof_upper), np.maximum(spec.dof_lower, spec.dof_upper)
@@ -174,16 +182,19 @@ def test_simulate_matches_cpu_oracle(task, z_lo, z_hi, gear):
     env = _make_env(task, n)
     spec = load_model(task.lower())
     sb = sensor_bodies(task.lower())
-    orc = OracleEngine(spec, n, params=_sim_dict(env.sim_params), sensor_bodies=sb, precision="f64")
+    orc = OracleEngine(spec, n, params=_sim_dict(env.sim_params), sensor_bodies=sb, precision="f64", **_selfcol_kw(task))
     rng = np.random.default_rng(0)
     root, q, qd = _random_state(spec, n, rng, z_lo, z_hi)
     tau = rng.uniform(-gear, gear, (n, spec.nd))
     t = env.engine.tensors
     t["root_states"][:] = _t(root); env.dof_pos[:] = _t(q); env.dof_vel[:] = _t(qd)
     t["contact_impulse"].zero_(); t["limit_impulse"].zero_()
+    if "self_contact_impulse" in t:
+        t["self_contact_impulse"].zero_()
     t["dof_actuation_force"][:] = _t(tau)
     orc.root[:] = root; orc.q[:] = q; orc.qd[:] = qd
     worst = 0.0
+    nsph = len(spec.sph_body)
     for it in range(3):
         env.engine.simulate()
         orc.step(tau)
@@ -195,8 +206,19 @@ def test_simulate_matches_cpu_oracle(task, z_lo, z_hi, gear):
         scale = max(1.0, np.abs(orc.qd).max())
         assert e < 5e-4 * scale * (it + 1), (task, it, e)
         sens = env.vec_sensor_tensor.cpu().numpy()
-        # force sensors: relative to the largest force present
+        # force sensors, joint forces, contact / limit / self-contact impulses: per element, relative to the largest one present
         assert np.abs(sens - orc.sensor).max() < 2e-3 * max(1.0, np.abs(orc.sensor).max())
+        assert np.abs(t["dof_force"].cpu().numpy() - orc.dof_force).max() < 2e-3 * max(1.0, np.abs(orc.dof_force).max())
+        lamc = t["contact_impulse"].cpu().numpy().reshape(n, 3 * nsph)
+        assert np.abs(lamc - orc.lam[:, :3 * nsph]).max() < 2e-3 * max(1.0, np.abs(orc.lam).max())
+        assert np.abs(t["limit_impulse"].cpu().numpy() - orc.lam[:, 3 * nsph:]).max() < 2e-3 * max(1.0, np.abs(orc.lam).max())
+        if orc.npg:
+            lamp = t["self_contact_impulse"].cpu().numpy()
+            assert np.abs(lamp - orc.lam_pair).max() < 2e-3 * max(1.0, np.abs(orc.lam_pair).max())
+            pf = t["self_contact_force"].cpu().numpy()
+            assert np.abs(pf - orc.pair_info[:, :, :3]).max() < 2e-3 * max(1.0, np.abs(orc.pair_info[:, :, :3]).max())
+            if it == 0:
+                assert (np.abs(orc.lam_pair).sum(2) > 0).any(1).mean() > 0.3          # the random poses do touch themselves
     print(f"{task}: worst |hip - oracle_f64| over 3 steps = {worst:.2e}")
 
 
@@ -341,7 +363,8 @@ def test_step_trajectory_matches_cpu_restatement(task, hum):
     env = _make_env(task, n, seed=seed)
     spec = load_model(task.lower())
     cfg, p = _loco_params(task)
-    orc = OracleLocomotionEnv(hum, spec, sensor_bodies(task.lower()), _sim_dict(env.sim_params), p, n, seed=seed, precision="f64")
+    orc = OracleLocomotionEnv(hum, spec, sensor_bodies(task.lower()), _sim_dict(env.sim_params), p, n, seed=seed, precision="f64",
+                              **_selfcol_kw(task))
     g = torch.Generator(device="cpu").manual_seed(3)
     for step in range(12):
         a = torch.rand((n, env.num_actions), generator=g) * 2 - 1
