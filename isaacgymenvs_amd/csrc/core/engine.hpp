@@ -363,6 +363,13 @@ struct Sim {
         return 0;
     }
     static constexpr bool cap_is_point(int c) { return M::cap_s0[c] == M::cap_s1[c]; }
+    static constexpr float cap_bound(int c) {   // radius of the capsule's bounding sphere about the middle of its axis
+        const float d[3] = {M::cap_p0[c][0] - M::cap_p1[c][0], M::cap_p0[c][1] - M::cap_p1[c][1], M::cap_p0[c][2] - M::cap_p1[c][2]};
+        const float l2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+        float r = l2 > 0.f ? 0.5f : 0.f;       // constexpr square root of l2 / 4 by Newton iteration
+        if (l2 > 0.f) { r = l2; for (int it = 0; it < 40; ++it) r = 0.5f * (r + l2 / r); r *= 0.5f; }
+        return r * 1.0001f + M::cap_rad[c];
+    }
     static constexpr bool group_has_body(int g, int b) {  // can body b take part in a contact of group g?
         for (int k = M::pg_first[g]; k < M::pg_first[g] + M::pg_count[g]; ++k)
             if (M::cap_body[M::gp_a[k]] == b || M::cap_body[M::gp_b[k]] == b) return true;
@@ -1007,35 +1014,50 @@ struct Sim {
         // (13 row-build code paths for the Humanoid instead of 66).
         if constexpr (NPG > 0) { if (selfcol) {
         int cntp = 0;
+        // broad phase: bounding sphere of every capsule (centre = middle of its axis, radius = half length + capsule radius); the
+        // narrow phase of a capsule pair is skipped by the whole wave when no env has the two spheres within reach
+        float capm[M::NCAP][3];
+        sfor<M::NCAP>([&](auto C_) MI_LAMBDA {
+            constexpr int cc = C_;
+            sfor<3>([&](auto I_) MI_LAMBDA { capm[cc][I_] = 0.5f * (c.xcs[M::cap_s0[cc]][I_] + c.xcs[M::cap_s1[cc]][I_]); });
+        });
         sfor<NPG>([&](auto G_) MI_LAMBDA {
             constexpr int g = G_, LEN = M::pg_chain_len[g];
             MI_PHASE();
-            float best = 3.0e38f, bca[3] = {0.f, 0.f, 0.f}, bcb[3] = {0.f, 0.f, 0.f}, brb = 0.f, bmu = 0.f;
-            int bab = 0;
-            unsigned mA = 0u, mB = 0u;
+            float best = 3.0e38f, bca[3] = {0.f, 0.f, 0.f}, bcb[3] = {0.f, 0.f, 0.f};
+            int bk = 0;
             sfor<M::pg_count[g]>([&](auto K_) MI_LAMBDA {
                 constexpr int k = M::pg_first[g] + K_, ia = M::gp_a[k], ib = M::gp_b[k];
+                constexpr float reach = cap_bound(ia) + cap_bound(ib);
+                const float dm[3] = {capm[ia][0] - capm[ib][0], capm[ia][1] - capm[ib][1], capm[ia][2] - capm[ib][2]};
+                const float rr = reach + P.contact_offset;
+                if (!MI_WAVE_ANY(dot3(dm, dm) < rr * rr)) return;
                 float ca[3], cb[3];
                 seg_seg_closest<cap_is_point(ia), cap_is_point(ib)>(c.xcs[M::cap_s0[ia]], c.xcs[M::cap_s1[ia]], c.xcs[M::cap_s0[ib]],
                                                                       c.xcs[M::cap_s1[ib]], ca, cb);
                 const float dv[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]};
                 const float dist = MI_SQRT(dot3(dv, dv)) - (M::cap_rad[ia] + M::cap_rad[ib]);
-#if defined(MI_DEBUG_PAIRS) && !defined(__HIP_DEVICE_COMPILE__)
-                if (g == 3) printf("  g3 k %d caps %d %d dist %g  a0 %g %g %g a1 %g %g %g b0 %g %g %g b1 %g %g %g\n", k, ia, ib, dist, c.xcs[M::cap_s0[ia]][0], c.xcs[M::cap_s0[ia]][1], c.xcs[M::cap_s0[ia]][2],
-                    c.xcs[M::cap_s1[ia]][0], c.xcs[M::cap_s1[ia]][1], c.xcs[M::cap_s1[ia]][2], c.xcs[M::cap_s0[ib]][0], c.xcs[M::cap_s0[ib]][1], c.xcs[M::cap_s0[ib]][2], c.xcs[M::cap_s1[ib]][0], c.xcs[M::cap_s1[ib]][1], c.xcs[M::cap_s1[ib]][2]);
-#endif
                 const bool better = dist < best;                 // the first pair of the list wins ties
                 best = better ? dist : best;
                 sfor<3>([&](auto I_) MI_LAMBDA { bca[I_] = better ? ca[I_] : bca[I_]; bcb[I_] = better ? cb[I_] : bcb[I_]; });
-                brb = better ? M::cap_rad[ib] : brb;
-                bmu = better ? 0.5f * (M::cap_mu[ia] + M::cap_mu[ib]) : bmu;
-                bab = better ? (M::cap_body[ia] | (M::cap_body[ib] << 8)) : bab;
-                mA = better ? M::chain_mask[M::cap_body[ia]] : mA;
-                mB = better ? M::chain_mask[M::cap_body[ib]] : mB;
+                bk = better ? K_ : bk;
             });
             const bool on = (best < P.contact_offset) && (cntp < KPAIR);
             if (MI_WAVE_ANY(on)) {
                 if (on) {
+                    // what the chosen pair implies (bodies, chain masks, radius of side b, friction): looked up by its index
+                    int bab = 0;
+                    unsigned mA = 0u, mB = 0u;
+                    float brb = 0.f, bmu = 0.f;
+                    sfor<M::pg_count[g]>([&](auto K_) MI_LAMBDA {
+                        constexpr int k = M::pg_first[g] + K_, ia = M::gp_a[k], ib = M::gp_b[k];
+                        const bool me = bk == K_;
+                        bab = me ? (M::cap_body[ia] | (M::cap_body[ib] << 8)) : bab;
+                        mA = me ? M::chain_mask[M::cap_body[ia]] : mA;
+                        mB = me ? M::chain_mask[M::cap_body[ib]] : mB;
+                        brb = me ? M::cap_rad[ib] : brb;
+                        bmu = me ? 0.5f * (M::cap_mu[ia] + M::cap_mu[ib]) : bmu;
+                    });
                     float* pb = rows.ptr(C_PB + cntp * P_CSZ);
                     constexpr int ST = RowStore<RS>::stride;
                     float fr[3][3], x[3];
@@ -1053,28 +1075,33 @@ struct Sim {
                         cross3(x, fr[K], W[K]);
                         W[K][3] = fr[K][0]; W[K][4] = fr[K][1]; W[K][5] = fr[K][2];
                     });
+                    // Jacobian entries J_a - J_b over the union chain.  A dof below the two contact bodies (a thigh contact does not
+                    // involve the knee) has no entry: such dofs are skipped by the whole wave when no env needs them.
                     float gg[3][PCH];
                     sfor<LEN>([&](auto C) MI_LAMBDA {
                         constexpr int gi = M::pg_chain[g][C];
-                        if constexpr ((M::pg_common[g] >> gi) & 1u) {          // moves both bodies alike
-                            sfor<3>([&](auto K) MI_LAMBDA { gg[K][C] = 0.f; });
-                        } else {
+                        sfor<3>([&](auto K) MI_LAMBDA { gg[K][C] = 0.f; });
+                        if constexpr (!((M::pg_common[g] >> gi) & 1u)) {       // (a dof that moves both bodies alike has none either)
                             const float cf = (float)((mA >> gi) & 1u) - (float)((mB >> gi) & 1u);
-                            if constexpr (gi >= OFF) {
-                                float Sd[6];
-                                if constexpr (S_IN_ROWS && M::NOS == 0) sfor<6>([&](auto I_) MI_LAMBDA { Sd[I_] = rows(C_S + 6 * (gi - OFF) + I_); });
-                                else sfor<6>([&](auto I_) MI_LAMBDA { Sd[I_] = S[gi - OFF][I_]; });
-                                sfor<3>([&](auto K) MI_LAMBDA { gg[K][C] = cf * dot6(Sd, W[K]); });
-                            } else if constexpr (gi < 3) {
-                                sfor<3>([&](auto K) MI_LAMBDA { gg[K][C] = cf * W[K][3 + gi]; });
-                            } else {
-                                sfor<3>([&](auto K) MI_LAMBDA { gg[K][C] = cf * W[K][gi - 3]; });
+                            if (MI_WAVE_ANY(cf != 0.f)) {
+                                if constexpr (gi >= OFF) {
+                                    float Sd[6];
+                                    if constexpr (S_IN_ROWS && M::NOS == 0) sfor<6>([&](auto I_) MI_LAMBDA { Sd[I_] = rows(C_S + 6 * (gi - OFF) + I_); });
+                                    else sfor<6>([&](auto I_) MI_LAMBDA { Sd[I_] = S[gi - OFF][I_]; });
+                                    sfor<3>([&](auto K) MI_LAMBDA { gg[K][C] = cf * dot6(Sd, W[K]); });
+                                } else if constexpr (gi < 3) {
+                                    sfor<3>([&](auto K) MI_LAMBDA { gg[K][C] = cf * W[K][3 + gi]; });
+                                } else {
+                                    sfor<3>([&](auto K) MI_LAMBDA { gg[K][C] = cf * W[K][gi - 3]; });
+                                }
                             }
                         }
                     });
-                    // L^T g = J^T over the union chain (descending indices): an entry feeds exactly its ancestors among the later ones
+                    // L^T g = J^T over the union chain (descending indices): an entry feeds exactly its ancestors among the later ones;
+                    // entries that are zero in every env of the wave feed nothing
                     sfor<LEN>([&](auto C) MI_LAMBDA {
                         constexpr int k = C, i = M::pg_chain[g][k];
+                        if (!MI_WAVE_ANY((gg[0][k] != 0.f) || (gg[1][k] != 0.f) || (gg[2][k] != 0.f))) return;
                         const float di = Ldi[i];
                         const float z0 = gg[0][k] * di, z1 = gg[1][k] * di, z2 = gg[2][k] * di;
                         gg[0][k] = z0; gg[1][k] = z1; gg[2][k] = z2;
@@ -1095,13 +1122,6 @@ struct Sim {
                         pb[(3 * PCH + 4 + k) * ST] = scol->lamp(3 * g + k) * P.warm;
                     });
                     pb[(3 * PCH + 3) * ST] = (gap >= 0.f) ? -gap * invh : fminf(-gap * P.erp * invh, P.max_depen_vel);
-#if defined(MI_DEBUG_PAIRS) && !defined(__HIP_DEVICE_COMPILE__)
-                    printf("group %d slot %d best %g bab %x x %g %g %g n %g %g %g mA %x mB %x\n  g0:", g, cntp, best, bab, x[0], x[1], x[2], fr[0][0], fr[0][1], fr[0][2], mA, mB);
-                    for (int cc = 0; cc < LEN; ++cc) printf(" %g", gg[0][cc]);
-                    printf("\n  vt %g ainv %g w:", pb[(3 * PCH + 3) * ST], pb[(3 * PCH) * ST]);
-                    for (int cc = 0; cc < NV; ++cc) printf(" %g", w[cc]);
-                    printf("\n");
-#endif
                     sfor<KPAIR>([&](auto J_) MI_LAMBDA {
                         const bool me = cntp == J_;
                         sfor<3>([&](auto I_) MI_LAMBDA { pinf[J_][I_] = me ? x[I_] : pinf[J_][I_]; pinf[J_][3 + I_] = me ? fr[0][I_] : pinf[J_][3 + I_]; });
