@@ -206,6 +206,8 @@ int mi_engine_set_terrain(MiEngine* e, const int16_t* height_samples, int rows, 
  * "gravity_x|y|z" (gym.set_sim_params after sim_params.gravity randomisation, vec_task.py:720-732),
  * "self_collision" 0 | 1 (the collision filter of gym.create_actor: humanoid.py:194 passes 0 = the actor collides with itself;
  * default 1 for the tasks whose arena carries "self_contact_impulse", rejected with 1 elsewhere),
+ * "multi_wave" 0 | 32 (physics sub-step of Ant / Anymal / AnymalTerrain spread over the four waves of a workgroup of that many
+ * envs -- same results up to summation order, see csrc/core/engine_mw.hpp; other tasks ignore it),
  * "steps" (the control-step counter: observation-ring parity and per-step RNG counters; restore it together with the arena) */
 int mi_engine_set_option(MiEngine* e, const char* key, double value);
 /* reads back any of the keys of mi_engine_set_option (replaces gym.get_sim_params / gym.get_frame_count, vec_task.py:620,723) */

@@ -443,10 +443,18 @@ struct Sim {
     // Going down: pose, joint axes, velocity / bias acceleration.  Coming back up: subtree force and composite
     // inertia, from which the bias force and the H entries of this body's dofs follow at once -- so per-body
     // quantities only live while their subtree is being processed (live state ~ tree depth, not body count).
+    // per-body quantities handed from the downward half of the tree pass to the upward half
+    struct BodyTmp {
+        float Rb[9], rb[3];     // pose (rb relative to O = root origin)
+        SpI I;                  // own spatial inertia about O; after the children have been added: composite inertia of the subtree
+        float Vc[6], Ac[6];     // spatial velocity / bias acceleration
+        float F[6];             // own force; after the children have been added: subtree force
+    };
+    // going down: pose, joint axes S, contact-sphere centres, sensor frame, own inertia, velocity / bias acceleration, own force
     template <int b>
-    MI_HD void body_pass(const SimParams& P, Ctx& c, const float* Rp, const float* rp, const float* Vp, const float* Ap,
-                         SpI& Iout, float* Fout) {
-        float Rb[9], rb[3];
+    MI_HD void body_down(const SimParams& P, Ctx& c, const float* Rp, const float* rp, const float* Vp, const float* Ap, BodyTmp& t) {
+        float (&Rb)[9] = t.Rb;
+        float (&rb)[3] = t.rb;
         if constexpr (b == 0) {
             quat2mat(root + 3, Rb);
             rb[0] = rb[1] = rb[2] = 0.f;
@@ -513,7 +521,7 @@ struct Sim {
             c.rs[k][0] = rb[0]; c.rs[k][1] = rb[1]; c.rs[k][2] = rb[2];
         }
         // world spatial inertia about O
-        SpI I;
+        SpI& I = t.I;
         {
             float t[3], cm[3];
             matvec3(Rb, M::com[b], t);
@@ -538,7 +546,8 @@ struct Sim {
             I.I[3] = Iw1 - mm * cm[0] * cm[1]; I.I[4] = Iw2 - mm * cm[0] * cm[2]; I.I[5] = Iw5 - mm * cm[1] * cm[2];
         }
         // velocity / bias acceleration recursion
-        float Vc[6], Ac[6];
+        float (&Vc)[6] = t.Vc;
+        float (&Ac)[6] = t.Ac;
         if constexpr (b == 0) {
             if constexpr (M::FIXED) {
                 sfor<6>([&](auto K) MI_LAMBDA { Vc[K] = 0.f; Ac[K] = 0.f; });
@@ -560,26 +569,18 @@ struct Sim {
             crm(Vc, c.S[d], Sd);
             sfor<6>([&](auto C) MI_LAMBDA { Ac[C] += Sd[C] * qd[d]; Vc[C] += c.S[d][C] * qd[d]; });
         });
-        float F[6];
+        float (&F)[6] = t.F;
         {
             float IA[6], IV[6], X[6];
             spi_mul(I, Ac, IA); spi_mul(I, Vc, IV); crf(Vc, IV, X);
             sfor<6>([&](auto K) MI_LAMBDA { F[K] = IA[K] + X[K]; });
         }
-        // children (bodies are numbered depth-first, so every child index is > b)
-        sfor<NB>([&](auto C_) MI_LAMBDA {
-            constexpr int ch = C_;
-            if constexpr (ch > b) if constexpr (M::parent[ch] == b) {
-                SpI Ic;
-                float Fc[6];
-                body_pass<ch>(P, c, Rb, rb, Vc, Ac, Ic, Fc);
-                sfor<6>([&](auto K) MI_LAMBDA { F[K] += Fc[K]; });
-                I.m += Ic.m;
-                sfor<3>([&](auto K) MI_LAMBDA { I.h[K] += Ic.h[K]; });
-                sfor<6>([&](auto K) MI_LAMBDA { I.I[K] += Ic.I[K]; });
-            }
-        });
-        // I is now the composite inertia of the subtree, F the subtree force: bias and H entries of this body's dofs
+    }
+    // coming back up (t.I / t.F hold the subtree's composite inertia / force): bias force and H entries of this body's dofs
+    template <int b>
+    MI_HD void body_up(Ctx& c, BodyTmp& t) {
+        SpI& I = t.I;
+        float (&F)[6] = t.F;
         sfor<M::body_ndof[b]>([&](auto K) MI_LAMBDA {
             constexpr int d = M::body_dof0[b] + K, gi = OFF + d;
             c.bias[gi] = dot6(c.S[d], F);
@@ -623,9 +624,29 @@ struct Sim {
                 });
             });
         }
+    }
+    template <int b>
+    MI_HD void body_pass(const SimParams& P, Ctx& c, const float* Rp, const float* rp, const float* Vp, const float* Ap,
+                         SpI& Iout, float* Fout) {
+        BodyTmp t;
+        body_down<b>(P, c, Rp, rp, Vp, Ap, t);
+        // children (bodies are numbered depth-first, so every child index is > b)
+        sfor<NB>([&](auto C_) MI_LAMBDA {
+            constexpr int ch = C_;
+            if constexpr (ch > b) if constexpr (M::parent[ch] == b) {
+                SpI Ic;
+                float Fc[6];
+                body_pass<ch>(P, c, t.Rb, t.rb, t.Vc, t.Ac, Ic, Fc);
+                sfor<6>([&](auto K) MI_LAMBDA { t.F[K] += Fc[K]; });
+                t.I.m += Ic.m;
+                sfor<3>([&](auto K) MI_LAMBDA { t.I.h[K] += Ic.h[K]; });
+                sfor<6>([&](auto K) MI_LAMBDA { t.I.I[K] += Ic.I[K]; });
+            }
+        });
+        body_up<b>(c, t);
         if constexpr (b > 0) {
-            Iout = I;
-            sfor<6>([&](auto K) MI_LAMBDA { Fout[K] = F[K]; });
+            Iout = t.I;
+            sfor<6>([&](auto K) MI_LAMBDA { Fout[K] = t.F[K]; });
         }
     }
 

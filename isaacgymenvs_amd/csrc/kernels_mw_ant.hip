@@ -1,0 +1,8 @@
+// kernels_mw_ant.hip -- multi-wave sub-step of the Ant (one leg per wave), gfx950.
+#include "mw_kernels.hpp"
+#include "gen/model_ant.h"
+
+namespace mi {
+template hipError_t launch_substeps_mw<ModelAnt, PlaneGround>(const View&, const SimParams&, const ActParams&, const float*, int, int, int, hipStream_t,
+                                                              const PlaneGround&);
+}  // namespace mi

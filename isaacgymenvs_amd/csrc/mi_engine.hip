@@ -477,6 +477,13 @@ extern "C" int mi_engine_set_option(MiEngine* e, const char* key, double value) 
         e->v.lamp = value != 0 ? e->lamp_arena : nullptr;
         return 0;
     }
+    // multi-wave sub-step (core/engine_mw.hpp): envs per workgroup, 0 = one wave per workgroup.  Ignored by tasks whose model has
+    // no multi-wave form (Cartpole, Humanoid, ShadowHand, Quadcopter).
+    if (!strcmp(key, "multi_wave")) {
+        if (value != 0 && value != 32 && !(MI_MW_HAS16 && value == 16)) return fail("multi_wave: 0 or 32 (envs per workgroup)");
+        e->v.mw = (int)value;
+        return 0;
+    }
     // control-step counter (observation ring parity, AnymalTerrain push schedule, noise counters): part of a state checkpoint
     if (!strcmp(key, "steps")) { if (value < 0) return fail("steps < 0"); e->steps = (unsigned long long)value; return 0; }
     return fail(std::string("unknown option: ") + key);
@@ -489,6 +496,7 @@ extern "C" int mi_engine_get_option(const MiEngine* e, const char* key, double* 
     if (!strcmp(key, "gravity_z")) { *out = e->P.g[2]; return 0; }
     if (!strcmp(key, "control_freq_inv")) { *out = e->control_freq_inv; return 0; }
     if (!strcmp(key, "self_collision")) { *out = e->v.lamp != nullptr ? 1.0 : 0.0; return 0; }
+    if (!strcmp(key, "multi_wave")) { *out = e->v.mw; return 0; }
     if (!strcmp(key, "steps")) { *out = (double)e->steps; return 0; }
     return fail(std::string("unknown option: ") + key);
 }

@@ -1,0 +1,135 @@
+// mw_kernels.hpp -- the multi-wave physics sub-step kernel (core/engine_mw.hpp) and its launcher.  Included only by the
+// kernels_mw_<model>.hip translation units, which instantiate launch_substeps_mw for one model / ground pair each.
+#pragma once
+#include "step_kernels.hpp"
+#include "core/engine_mw.hpp"
+
+namespace mi {
+
+// ------------------------------------------------------------------------------------------------ multi-wave sub-step
+// One env's sub-step spread over the 4 waves of a workgroup (core/engine_mw.hpp): blockDim = (64, NROLE), wave y = role y, lanes
+// 0 .. E-1 of every wave hold the same E envs (the other lanes retire at once).  Workgroups are dealt round-robin to the 8 XCDs, so
+// workgroup (x, j) = (id % 8, id / 8) takes the envs 64 * (8 * (j / SUBS) + x) + E * (j % SUBS) ...: the 64 / E workgroups that share a
+// 64-env group sit on the same XCD as the 64-lane post kernel block that reads their state next.
+struct DevBarrier {
+    __device__ __forceinline__ void operator()() const { __syncthreads(); }
+};
+template <class M, int E>
+constexpr size_t mw_lds_bytes() { return (size_t)SimMW<M>::MW_SLOTS * E * sizeof(float); }
+template <int E>
+__device__ __forceinline__ int mw_env_base(int wg) {
+    constexpr int SUBS = 64 / E;
+    const int x = wg & 7, j = wg >> 3;
+    return 64 * (8 * (j / SUBS) + x) + E * (j % SUBS);
+}
+template <int E>
+inline int mw_grid(int N) {            // workgroups, rounded up so that the (x, j) mapping covers every env
+    constexpr int SUBS = 64 / E;
+    const int groups64 = (N + 63) / 64;
+    return ((groups64 + 7) / 8) * 8 * SUBS;
+}
+template <class M, class GND, int E, int R>
+__device__ __forceinline__ void mw_role(const View& v, const SimParams& P, const ActParams& ap, const float* __restrict__ actions_in,
+                                        const int src, const GND& gnd, float* lds_rows, const int e, const int lane) {
+    using S = SimMW<M>;
+    constexpr int ND = M::ND;
+    const int N = v.N;
+    S sim;
+    load_sim(sim, v, e);
+    float tau[M::NDA];
+    if (src != ACT_STORED_TAU) {
+        sfor<ND>([&](auto K) MI_LAMBDA {
+            constexpr int k = K;
+            constexpr bool mine = S::template owns_gi<R>(M::OFF + k);
+            float t = 0.f;
+            if (k < ap.nact) {
+                float a;
+                if (src == ACT_FROM_ACTIONS) {
+                    a = fminf(fmaxf(actions_in[(size_t)e * ap.nact + k], -ap.clip), ap.clip);
+                    if constexpr (mine) v.actions[k * N + e] = a;
+                } else {
+                    a = v.actions[k * N + e];
+                }
+                if (ap.mode == 0) {
+                    t = a * ap.gear[k] * ap.scale;
+                } else {
+                    const float u = ap.kp * (ap.scale * a + ap.gear[k] - sim.q[k]) - ap.kd * sim.qd[k];
+                    t = fminf(fmaxf(u, -ap.torque_limit), ap.torque_limit);
+                }
+            }
+            tau[k] = t;
+            if constexpr (mine) v.tau[k * N + e] = t;
+        });
+    } else {
+        sfor<ND>([&](auto K) MI_LAMBDA { tau[K] = v.tau[K * N + e]; });
+    }
+    {   // last sub-step's impulses of the own rows: HBM -> row-store slots, LDS-direct
+        typedef const __attribute__((address_space(1))) void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        float* slot0 = lds_rows;     // lane l lands at slot base + 4 l
+        sfor<ND>([&](auto D) MI_LAMBDA {
+            constexpr int d = D;
+            if constexpr (M::dof_limited[d] && S::template owns_gi<R>(M::OFF + d)) {
+                constexpr int o = Sim<M>::stage_slot_lim(d) * E;
+                __builtin_amdgcn_global_load_lds((gptr_t)(v.laml + (size_t)d * N + e), (lptr_t)(slot0 + o), 4, 0, 0);
+            }
+        });
+        sfor<3 * M::NSPH>([&](auto K) MI_LAMBDA {
+            if constexpr (S::template owns_body<R>(M::sph_body[K / 3])) {
+                constexpr int o = Sim<M>::stage_slot_con(K) * E;
+                __builtin_amdgcn_global_load_lds((gptr_t)(v.lamc + (size_t)K * N + e), (lptr_t)(slot0 + o), 4, 0, 0);
+            }
+        });
+    }
+    const float h = P.dt / (float)P.substeps;
+    const Strided lamc{v.lamc + e, N}, laml{v.laml + e, N}, sensor{v.sensor + e, N}, dof_force{v.dof_force + e, N};
+    const Strided netf{GND::NETF ? v.netf + e : nullptr, N};
+    const float mu_env = (GND::HEIGHTFIELD || v.friction != nullptr) ? v.friction[e] : -1.f;
+    sim.template substep_role<R>(P, tau, h, RowStore<E>{lds_rows + lane}, lamc, laml, sensor, dof_force, gnd, mu_env, netf, true, DevBarrier{});
+    sfor<ND>([&](auto K) MI_LAMBDA {
+        if constexpr (S::template owns_gi<R>(M::OFF + K)) {
+            v.dof[K * N + e] = sim.q[K];
+            v.dof[(ND + K) * N + e] = sim.qd[K];
+        }
+    });
+    if constexpr (R == M::TRUNK_ROLE) sfor<13>([&](auto K) MI_LAMBDA { v.root[K * N + e] = sim.root[K]; });
+}
+template <class M, class GND, int E>
+__global__ __launch_bounds__(64 * M::NROLE) void substep_mw_kernel(View v, SimParams P, ActParams ap, const float* __restrict__ actions_in,
+                                                                   int src, GND gnd) {
+    extern __shared__ float lds_rows[];   // [MW_SLOTS][E]
+    static_assert(M::NROLE == 4, "four roles, one per SIMD of a CU");
+    const int lane = threadIdx.x;
+    if (lane >= E) return;               // barriers count waves, not lanes: the upper lanes of every wave simply retire
+    const int e = mw_env_base<E>(blockIdx.x) + lane;
+    if (e >= v.N) return;                // every wave of the workgroup holds the same envs, so all four agree on this
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    switch (role) {
+        case 0: mw_role<M, GND, E, 0>(v, P, ap, actions_in, src, gnd, lds_rows, e, lane); break;
+        case 1: mw_role<M, GND, E, 1>(v, P, ap, actions_in, src, gnd, lds_rows, e, lane); break;
+        case 2: mw_role<M, GND, E, 2>(v, P, ap, actions_in, src, gnd, lds_rows, e, lane); break;
+        default: mw_role<M, GND, E, 3>(v, P, ap, actions_in, src, gnd, lds_rows, e, lane); break;
+    }
+}
+
+template <class M, class GND>
+hipError_t launch_substeps_mw(const View& v, const SimParams& P, const ActParams& ap, const float* actions, int n_sub, int first, int rest,
+                              hipStream_t s, const GND& gnd) {
+    static unsigned long long conf16 = 0ull, conf32 = 0ull;
+    constexpr size_t lds16 = mw_lds_bytes<M, 16>(), lds32 = mw_lds_bytes<M, 32>();
+    const dim3 block(64, M::NROLE);
+    if (MI_MW_HAS16 && v.mw == 16) {
+        auto kern = substep_mw_kernel<M, GND, MI_MW_HAS16 ? 16 : 32>;
+        if (hipError_t e = ensure_dynamic_lds((const void*)kern, lds16, &conf16); e != hipSuccess) return e;
+        const dim3 grid(mw_grid<16>(v.N));
+        for (int i = 0; i < n_sub; ++i) hipLaunchKernelGGL(kern, grid, block, lds16, s, v, P, ap, actions, i == 0 ? first : rest, gnd);
+    } else {
+        auto kern = substep_mw_kernel<M, GND, 32>;
+        if (hipError_t e = ensure_dynamic_lds((const void*)kern, lds32, &conf32); e != hipSuccess) return e;
+        const dim3 grid(mw_grid<32>(v.N));
+        for (int i = 0; i < n_sub; ++i) hipLaunchKernelGGL(kern, grid, block, lds32, s, v, P, ap, actions, i == 0 ? first : rest, gnd);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace mi

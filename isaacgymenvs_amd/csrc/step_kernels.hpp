@@ -12,6 +12,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <type_traits>
 #include "core/engine.hpp"
 #include "tasks/locomotion.hpp"
 
@@ -23,6 +24,7 @@ struct View {
     int env_offset;
     uint32_t seed;
     int ring;  // which obs_out slot this step writes
+    int mw;    // multi-wave sub-step: envs per workgroup (16 or 32), 0 = one wave per workgroup (option "multi_wave")
     float clip_obs;
     float* root;        // [13][N]
     float* dof;         // [2][ND][N]  (pos block, vel block)
@@ -208,6 +210,18 @@ __global__ __launch_bounds__(64) void substep_kernel(View v, SimParams P, ActPar
     }
     store_sim(sim, v, e);
 }
+
+// ------------------------------------------------------------------------------------------------ multi-wave sub-step
+// (kernels in mw_kernels.hpp, instantiated in their own translation units kernels_mw_<model>.hip: they take minutes to compile)
+#ifndef MI_MW_HAS16
+#define MI_MW_HAS16 0          // also build the 16-envs-per-workgroup variant (A/B builds only: it doubles the compile time)
+#endif
+template <class M, class GND>
+constexpr bool mw_capable() { return !Sim<M>::COMPACT && Sim<M>::LAM_IN_ROWS && !M::FIXED && M::NLIMB >= 3 && !std::is_same<GND, PlaneGroundNF>::value; }
+// launches n_sub multi-wave sub-steps with v.mw envs per workgroup (defined for the model / ground pairs of kernels_mw_*.hip)
+template <class M, class GND>
+hipError_t launch_substeps_mw(const View& v, const SimParams& P, const ActParams& ap, const float* actions, int n_sub, int first, int rest,
+                              hipStream_t s, const GND& gnd);
 
 // XCD-aware env mapping of the 64-lane post kernels.  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).
 // A sub-step kernel with 32 envs per workgroup puts env e on XCD (e / 32) % 8; a post kernel that simply took envs
@@ -395,6 +409,9 @@ inline hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes, unsigned 
 template <class M, class GND = PlaneGround>
 hipError_t launch_substeps(const View& v, const SimParams& P, const ActParams& ap, const float* actions, int n_sub, int first,
                            int rest, hipStream_t s, const GND& gnd = GND{}) {
+    if constexpr (mw_capable<M, GND>()) {
+        if (v.mw != 0) return launch_substeps_mw<M, GND>(v, P, ap, actions, n_sub, first, rest, s, gnd);
+    }
     constexpr size_t lds = rows_fit_lds<M>() ? lds_bytes<M>() : 0;
     constexpr int LANES = Sim<M>::LANES;
     static unsigned long long configured = 0ull;

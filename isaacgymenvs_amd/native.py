@@ -17,13 +17,14 @@ CSRC = os.path.join(_HERE, "csrc")
 BUILD_DIR = os.path.join(CSRC, "build")
 # one translation unit per robot model (they compile in parallel) + the C ABI
 SOURCES = ["mi_engine.hip", "kernels_cartpole.hip", "kernels_ant.hip", "kernels_humanoid.hip", "kernels_anymal.hip", "kernels_shadow_hand.hip",
-           "kernels_shadow_hand_pen.hip", "kernels_shadow_hand_egg.hip", "kernels_quadcopter.hip", "kernels_jit_twins.hip"]
+           "kernels_shadow_hand_pen.hip", "kernels_shadow_hand_egg.hip", "kernels_quadcopter.hip", "kernels_jit_twins.hip",
+           "kernels_mw_ant.hip", "kernels_mw_anymal.hip"]
 MI_MAX_DOF = 32
 
 # -fno-slp-vectorize: pairing scalars into v_pk_* ops lengthens live ranges in the fully unrolled sub-step
 # (Ant: 230 -> 40 spilled VGPRs without it)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-signed-zeros", "-fno-trapping-math",
-               "-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"]
+               "-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"] + os.environ.get("MI_EXTRA_HIPCC_FLAGS", "").split()
 # more spilled SGPRs than this in a physics kernel fails the build: heavy SGPR spilling was the regime in which
 # gfx950 builds of the sub-step returned run-to-run different results ("compiler regime")
 MAX_SGPR_SPILL = 160

@@ -5,6 +5,9 @@
 // One library per robot model (-DHOSTSIM_<MODEL>): the unrolled cores take minutes to compile, so tests/hostbuild/hostsim.py
 // builds the models in parallel and routes each call to the library that holds its model.
 #include "../../isaacgymenvs_amd/csrc/core/engine.hpp"
+#include "../../isaacgymenvs_amd/csrc/core/engine_mw.hpp"
+#include <pthread.h>
+#include <thread>
 #ifdef HOSTSIM_CARTPOLE
 #include "../../isaacgymenvs_amd/csrc/gen/model_cartpole.h"
 #endif
@@ -52,6 +55,67 @@ static void run(const SimParams* P, int nenv, float* state, const float* tau, fl
         for (int k = 0; k < ND; ++k) { s[13 + k] = sim.q[k]; s[13 + ND + k] = sim.qd[k]; }
     }
 }
+
+// ---- multi-wave sub-step (core/engine_mw.hpp) on the host: the four roles of an env run as four threads that meet at a
+// pthread barrier where the GPU waves meet at s_barrier; the row store + exchange area is one plain array (stride 1).
+struct HostBarrier {
+    pthread_barrier_t* b;
+    void operator()() const { pthread_barrier_wait(b); }
+};
+template <class M, class GND, int R>
+static void mw_thread(const SimParams* P, float* s, const float* tau, float* o, float* rows, pthread_barrier_t* bar, const GND* gnd,
+                      float mu_env, float* netf) {
+    constexpr int ND = M::ND, NSPH = M::NSPH, NSENS = M::NSENS;
+    using S = SimMW<M>;
+    const float h = P->dt / (float)P->substeps;
+    for (int ss = 0; ss < P->substeps; ++ss) {
+        S sim;
+        for (int k = 0; k < 13; ++k) sim.root[k] = s[k];
+        for (int k = 0; k < ND; ++k) { sim.q[k] = s[13 + k]; sim.qd[k] = s[13 + ND + k]; }
+        pthread_barrier_wait(bar);     // everybody has read the state of the previous sub-step
+        sim.template substep_role<R>(*P, tau, h, RowStore<1>{rows}, Strided{s + 13 + 2 * ND, 1}, Strided{s + 13 + 2 * ND + 3 * NSPH, 1},
+                                     Strided{o, 1}, Strided{o + 6 * NSENS, 1}, *gnd, mu_env, Strided{netf, 1}, false, HostBarrier{bar});
+        for (int k = 0; k < ND; ++k)
+            if (S::role_of_gi(M::OFF + k) == R || (S::trunk_gi(M::OFF + k) && R == M::TRUNK_ROLE)) { s[13 + k] = sim.q[k]; s[13 + ND + k] = sim.qd[k]; }
+        if (R == M::TRUNK_ROLE) for (int k = 0; k < 13; ++k) s[k] = sim.root[k];
+        pthread_barrier_wait(bar);     // the new state is complete
+    }
+}
+template <class M, class GND>
+static void run_mw(const SimParams* P, int nenv, float* state, const float* tau, float* out, const GND* gnd, const float* mu, float* netf) {
+    constexpr int ND = M::ND, NSPH = M::NSPH, NSENS = M::NSENS;
+    const int ss = 13 + 2 * ND + 3 * NSPH + ND, os = 6 * NSENS + ND + 3 * NSPH;
+    for (int e = 0; e < nenv; ++e) {
+        float* s = state + (size_t)e * ss;
+        float* o = out + (size_t)e * os;
+        float rows[SimMW<M>::MW_SLOTS];
+        for (int k = 0; k < SimMW<M>::MW_SLOTS; ++k) rows[k] = 0.f;
+        pthread_barrier_t bar;
+        pthread_barrier_init(&bar, nullptr, 4);
+        const float* t = tau + (size_t)e * ND;
+        float* nf = netf ? netf + (size_t)e * 3 * M::NB : nullptr;
+        const float m = mu ? mu[e] : -1.f;
+        std::thread t0(mw_thread<M, GND, 0>, P, s, t, o, rows, &bar, gnd, m, nf), t1(mw_thread<M, GND, 1>, P, s, t, o, rows, &bar, gnd, m, nf),
+            t2(mw_thread<M, GND, 2>, P, s, t, o, rows, &bar, gnd, m, nf), t3(mw_thread<M, GND, 3>, P, s, t, o, rows, &bar, gnd, m, nf);
+        t0.join(); t1.join(); t2.join(); t3.join();
+        pthread_barrier_destroy(&bar);
+    }
+}
+#ifdef HOSTSIM_ANT
+extern "C" int hs_step_mw_ant(const SimParams* P, int nenv, float* state, const float* tau, float* out) {
+    const PlaneGround g{};
+    run_mw<ModelAnt, PlaneGround>(P, nenv, state, tau, out, &g, nullptr, nullptr);
+    return 0;
+}
+#endif
+#ifdef HOSTSIM_ANYMAL
+extern "C" int hs_step_mw_terrain(const SimParams* P, int nenv, float* state, const float* tau, float* out, const short* hs, int rows,
+                                  int cols, float hscale, float vscale, float border, const float* mu, float* netf) {
+    const HeightfieldGround g{hs, rows, cols, hscale, vscale, border};
+    run_mw<ModelAnymal, HeightfieldGround>(P, nenv, state, tau, out, &g, mu, netf);
+    return 0;
+}
+#endif
 
 #ifdef HOSTSIM_HUMANOID
 extern "C" int hs_step_selfcol(const SimParams* P, int nenv, float* state, const float* tau, float* out) {

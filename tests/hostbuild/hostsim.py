@@ -30,14 +30,15 @@ def make_params(d):
 # model -> (compile-time switch, optimisation level): one library per model, compiled in parallel
 _MODELS = {"cartpole": ("HOSTSIM_CARTPOLE", "-O2"), "ant": ("HOSTSIM_ANT", "-O2"), "anymal": ("HOSTSIM_ANYMAL", "-O2"),
            "quadcopter": ("HOSTSIM_QUADCOPTER", "-O2"), "humanoid": ("HOSTSIM_HUMANOID", "-O2"), "hand": ("HOSTSIM_HAND", "-O1")}
-_ENTRY_MODEL = {"hs_step_selfcol": "humanoid", "hs_step_terrain": "anymal", "hs_step_drive": "quadcopter", "hs_step_hand": "hand", "hs_hand_fingertips": "hand"}
+_ENTRY_MODEL = {"hs_step_mw_ant": "ant", "hs_step_mw_terrain": "anymal", "hs_step_selfcol": "humanoid", "hs_step_terrain": "anymal", "hs_step_drive": "quadcopter", "hs_step_hand": "hand", "hs_hand_fingertips": "hand"}
 _libs = {}
 
 
 def _deps():
     from isaacgymenvs_amd.registry import generate_headers
     core = os.path.join(_HERE, "..", "..", "isaacgymenvs_amd", "csrc", "core")
-    return generate_headers() + [os.path.join(_HERE, "hostsim.cpp"), os.path.join(core, "engine.hpp"), os.path.join(core, "hand_engine.hpp")]
+    return generate_headers() + [os.path.join(_HERE, "hostsim.cpp"), os.path.join(core, "engine.hpp"), os.path.join(core, "engine_mw.hpp"),
+                                 os.path.join(core, "hand_engine.hpp")]
 
 
 def _build_models(names):
@@ -51,7 +52,7 @@ def _build_models(names):
         out = os.path.join(_OUT, f"libhostsim_{n}.so")
         if not os.path.exists(out) or os.path.getmtime(out) < newest:
             macro, opt = _MODELS[n]
-            jobs.append(["g++", opt, "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-D" + macro,
+            jobs.append(["g++", opt, "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-pthread", "-ffp-contract=off", "-D" + macro,
                          os.path.join(_HERE, "hostsim.cpp"), "-o", out])
     if jobs:
         with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
@@ -87,6 +88,24 @@ def build_hand():
 def step(lib, model, params, state, tau, out):
     rc = lib.hs_step(model.encode(), C.byref(params), state.shape[0], state.ctypes.data_as(C.c_void_p),
                      tau.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+
+
+def step_mw_ant(lib, params, state, tau, out):
+    """Ant through the multi-wave sub-step (four role threads per env); same layouts as step()."""
+    rc = lib.hs_step_mw_ant(C.byref(params), state.shape[0], state.ctypes.data_as(C.c_void_p), tau.ctypes.data_as(C.c_void_p),
+                            out.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+
+
+def step_mw_terrain(lib, params, state, tau, out, hs, hscale, vscale, border, mu, netf):
+    hs = np.ascontiguousarray(hs, np.int16)
+    lib.hs_step_mw_terrain.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                       C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    rc = lib.hs_step_mw_terrain(C.cast(C.byref(params), C.c_void_p), state.shape[0], state.ctypes.data_as(C.c_void_p),
+                                tau.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), hs.ctypes.data_as(C.c_void_p),
+                                hs.shape[0], hs.shape[1], hscale, vscale, border, mu.ctypes.data_as(C.c_void_p),
+                                netf.ctypes.data_as(C.c_void_p))
     assert rc == 0
 
 

@@ -187,3 +187,75 @@ def test_host_build_with_position_drives_and_body_forces_matches_oracle():
     for _ in range(50):
         orc.step_drive(np.zeros((N, nd)), 1000.0, 0.0, np.zeros((N, nd)), fext)
     assert np.abs(orc.root[:, 2] - 1.0).max() < 1e-6 and np.abs(orc.root[:, 7:13]).max() < 1e-6
+
+
+def test_multi_wave_substep_matches_oracle_and_single_wave():
+    """core/engine_mw.hpp (one leg per wave, trunk recomputed by every wave, Schur complements / right-hand-side carries exchanged
+    through the row store) run as four host threads per env that meet at a barrier: same state, impulses, sensors and joint forces as
+    the fp64 oracle within the stated tolerance, and within fp32 round-off of the single-wave form (only summation order differs)."""
+    spec, sb = load_model("ant"), sensor_bodies("ant")
+    n = 96
+    lib = hostsim.build()
+    rng = np.random.default_rng(5)
+    root, q, qd = _random_state(spec, n, rng, 0.3, 0.6)
+    tau = rng.uniform(-15, 15, (n, spec.nd))
+    orc = OracleEngine(spec, n, params=SIM, sensor_bodies=sb, precision="f64")
+    orc.root[:] = root; orc.q[:] = q; orc.qd[:] = qd
+    nd, nsph = spec.nd, len(spec.sph_body)
+
+    def fresh():
+        st = np.zeros((n, 13 + 2 * nd + 3 * nsph + nd), np.float32)
+        st[:, :13] = root; st[:, 13:13 + nd] = q; st[:, 13 + nd:13 + 2 * nd] = qd
+        return st, np.zeros((n, 6 * len(sb) + nd + 3 * nsph), np.float32)
+    (st, out), (st1, out1) = fresh(), fresh()
+    p = hostsim.make_params(SIM)
+    tau32 = np.ascontiguousarray(tau, np.float32)
+    for it in range(3):
+        hostsim.step_mw_ant(lib, p, st, tau32, out)
+        hostsim.step(lib, "ant", p, st1, tau32, out1)
+        orc.step(tau)
+        scale = max(1.0, np.abs(orc.qd).max())
+        e = max(np.abs(st[:, :13] - orc.root).max(), np.abs(st[:, 13:13 + nd] - orc.q).max(), np.abs(st[:, 13 + nd:13 + 2 * nd] - orc.qd).max())
+        assert e < 5e-4 * scale * (it + 1), (it, e)
+        assert np.abs(st[:, 13 + 2 * nd:] - orc.lam).max() < 2e-3 * max(1.0, np.abs(orc.lam).max())
+        assert np.abs(out[:, :6 * len(sb)] - orc.sensor).max() < 2e-3 * max(1.0, np.abs(orc.sensor).max())
+        assert np.abs(out[:, 6 * len(sb):6 * len(sb) + nd] - orc.dof_force).max() < 2e-3 * max(1.0, np.abs(orc.dof_force).max())
+        assert np.abs(st - st1).max() < 1e-3 * (it + 1)                     # the two forms of the same arithmetic stay together
+    assert np.abs(orc.sensor).max() > 10.0                                  # the ants do stand on the ground
+
+
+def test_multi_wave_substep_on_heightfield_matches_oracle():
+    """ANYmal on a rough height field through the multi-wave sub-step: general contact normals, per-env friction, per-body net contact
+    forces written by the wave that owns the body."""
+    spec = load_model("anymal")
+    n = 64
+    lib = hostsim.build()
+    rng = np.random.default_rng(3)
+    rows, cols, hscale, vscale, border = 120, 140, 0.1, 0.005, 2.0
+    hs = (rng.integers(-30, 30, (rows // 4 + 1, cols // 4 + 1)).repeat(4, 0).repeat(4, 1)[:rows, :cols]
+          + rng.integers(-6, 6, (rows, cols))).astype(np.int16)
+    sim = dict(SIM, dt=0.005, substeps=1, iters=5, max_depen_vel=100.0)
+    root, q, qd = _random_state(spec, n, rng, 0.25, 0.7)
+    root[:, 0] = rng.uniform(1, 8, n); root[:, 1] = rng.uniform(1, 10, n)
+    q = rng.uniform(-1.0, 1.0, (n, spec.nd))
+    tau = rng.uniform(-80, 80, (n, spec.nd))
+    mu = rng.uniform(0.5, 1.25, n).astype(np.float32)
+    orc = OracleEngine(spec, n, params=sim, precision="f64")
+    orc.set_ground(hs, hscale, vscale, border)
+    orc.root[:] = root; orc.q[:] = q; orc.qd[:] = qd
+    nd, nsph = spec.nd, len(spec.sph_body)
+    st = np.zeros((n, 13 + 2 * nd + 3 * nsph + nd), np.float32)
+    st[:, :13] = root; st[:, 13:13 + nd] = q; st[:, 13 + nd:13 + 2 * nd] = qd
+    out = np.zeros((n, nd + 3 * nsph), np.float32)
+    netf = np.zeros((n, spec.nb, 3), np.float32)
+    p = hostsim.make_params(sim)
+    tau32 = np.ascontiguousarray(tau, np.float32)
+    for it in range(4):
+        hostsim.step_mw_terrain(lib, p, st, tau32, out, hs, hscale, vscale, border, mu, netf)
+        orc.step(tau, env_mu=mu)
+        scale = max(1.0, np.abs(orc.qd).max())
+        e = max(np.abs(st[:, :13] - orc.root).max(), np.abs(st[:, 13:13 + nd] - orc.q).max(), np.abs(st[:, 13 + nd:13 + 2 * nd] - orc.qd).max())
+        assert e < 5e-4 * scale * (it + 1), (it, e)
+        assert np.abs(netf - orc.netf).max() < 2e-3 * max(1.0, np.abs(orc.netf).max())
+        assert np.abs(st[:, 13 + 2 * nd:] - orc.lam).max() < 2e-3 * max(1.0, np.abs(orc.lam).max())
+    assert np.abs(orc.netf).max() > 50.0

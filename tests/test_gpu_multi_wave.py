@@ -1,0 +1,103 @@
+"""GPU tests of the multi-wave physics sub-step (csrc/core/engine_mw.hpp, option "multi_wave"): one env's sub-step spread over the four
+waves of a workgroup.  It must be the same engine: against the fp64 oracle within the stated tolerance, next to the single-wave kernel
+within fp32 round-off, bit-identical from run to run (the cross-wave sums have a fixed order)."""
+import numpy as np
+import pytest
+import torch
+
+from isaacgymenvs_amd.registry import load_model, sensor_bodies
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _t(a):
+    return torch.as_tensor(np.ascontiguousarray(a, np.float32), device=DEV)
+
+
+def _make(task, n, seed=5, mw=0):
+    import isaacgymenvs_amd
+    env = isaacgymenvs_amd.make(seed=seed, task=task, num_envs=n, sim_device=DEV, rl_device=DEV, headless=True)
+    env.engine.set_option("multi_wave", mw)
+    assert int(env.engine.get_option("multi_wave")) == mw
+    return env
+
+
+def _sim_dict(p):
+    return dict(dt=float(p.dt), substeps=int(p.substeps), iters=int(p.iters), gravity=tuple(float(p.gravity[i]) for i in range(3)),
+                contact_offset=float(p.contact_offset), rest_offset=float(p.rest_offset), max_depen_vel=float(p.max_depen_vel),
+                erp=float(p.erp), plane_mu=float(p.plane_mu), ground_z=float(p.ground_z), cfm=float(p.cfm), warm=float(p.warm))
+
+
+def _random_state(spec, n, rng, z_lo, z_hi):
+    lo, up = np.minimum(spec.dof_lower, spec.dof_upper), np.maximum(spec.dof_lower, spec.dof_upper)
+    root = np.zeros((n, 13))
+    root[:, 0:2] = rng.normal(size=(n, 2))
+    root[:, 2] = rng.uniform(z_lo, z_hi, n)
+    q = rng.normal(size=(n, 4)); q[:, 3] += 3; q /= np.linalg.norm(q, axis=1, keepdims=True)
+    root[:, 3:7] = q
+    root[:, 7:13] = rng.normal(size=(n, 6))
+    return root, rng.uniform(lo, up, (n, spec.nd)), rng.normal(size=(n, spec.nd)) * 2
+
+
+@pytest.mark.parametrize("n", [200, 4096])      # a ragged count (partly filled workgroups, the XCD-aware env mapping) and the BASELINE size
+def test_multi_wave_simulate_matches_cpu_oracle(n):
+    from oracle.engine import OracleEngine
+    env = _make("Ant", n, mw=32)
+    spec, sb = load_model("ant"), sensor_bodies("ant")
+    stride = max(1, n // 256)                   # the oracle follows a strided subset of the envs
+    ids = np.arange(0, n, stride)
+    orc = OracleEngine(spec, len(ids), params=_sim_dict(env.sim_params), sensor_bodies=sb, precision="f64")
+    rng = np.random.default_rng(0)
+    root, q, qd = _random_state(spec, n, rng, 0.3, 0.6)
+    tau = rng.uniform(-15, 15, (n, spec.nd))
+    t = env.engine.tensors
+    t["root_states"][:] = _t(root); env.dof_pos[:] = _t(q); env.dof_vel[:] = _t(qd)
+    t["contact_impulse"].zero_(); t["limit_impulse"].zero_()
+    t["dof_actuation_force"][:] = _t(tau)
+    orc.root[:] = root[ids]; orc.q[:] = q[ids]; orc.qd[:] = qd[ids]
+    nsph = len(spec.sph_body)
+    for it in range(3):
+        env.engine.simulate()
+        orc.step(tau[ids])
+        torch.cuda.synchronize()
+        g_root = t["root_states"].cpu().numpy(); g_q = env.dof_pos.cpu().numpy(); g_qd = env.dof_vel.cpu().numpy()
+        assert np.isfinite(g_root).all() and np.isfinite(g_qd).all()
+        e = max(np.abs(g_root[ids] - orc.root).max(), np.abs(g_q[ids] - orc.q).max(), np.abs(g_qd[ids] - orc.qd).max())
+        scale = max(1.0, np.abs(orc.qd).max())
+        assert e < 5e-4 * scale * (it + 1), (it, e)
+        assert np.abs(env.vec_sensor_tensor.cpu().numpy()[ids] - orc.sensor).max() < 2e-3 * max(1.0, np.abs(orc.sensor).max())
+        assert np.abs(t["dof_force"].cpu().numpy()[ids] - orc.dof_force).max() < 2e-3 * max(1.0, np.abs(orc.dof_force).max())
+        lamc = t["contact_impulse"].cpu().numpy().reshape(n, 3 * nsph)[ids]
+        assert np.abs(lamc - orc.lam[:, :3 * nsph]).max() < 2e-3 * max(1.0, np.abs(orc.lam).max())
+        assert np.abs(t["limit_impulse"].cpu().numpy()[ids] - orc.lam[:, 3 * nsph:]).max() < 2e-3 * max(1.0, np.abs(orc.lam).max())
+
+
+@pytest.mark.parametrize("task,nact", [("Ant", 8), ("AnymalTerrain", 12)])
+def test_multi_wave_rollout_tracks_single_wave_and_is_deterministic(task, nact):
+    n = 1024
+    envs = [_make(task, n, seed=9, mw=0), _make(task, n, seed=9, mw=32), _make(task, n, seed=9, mw=32)]
+    g = torch.Generator(device="cpu").manual_seed(2)
+    for step in range(8):
+        a = (torch.rand((n, nact), generator=g) * 2 - 1).to(DEV)
+        outs = [e.step(a.clone()) for e in envs]
+        torch.cuda.synchronize()
+        obs = [o[0]["obs"].cpu().numpy() for o in outs]
+        assert np.isfinite(obs[1]).all()
+        np.testing.assert_array_equal(obs[1], obs[2])                                            # run-to-run identical
+        np.testing.assert_array_equal(outs[1][2].cpu().numpy(), outs[2][2].cpu().numpy())
+        d = np.abs(obs[0] - obs[1])
+        if task == "Ant":
+            d[:, [7, 8, 9]] = np.minimum(d[:, [7, 8, 9]], np.abs(d[:, [7, 8, 9]] - 2 * np.pi))
+        # same arithmetic, different summation order of the limbs' trunk contributions: the envs stay together for the first steps
+        # (contact is chaotic, so a growing tolerance and a small allowance of envs that took another contact branch)
+        frac = (d.max(axis=1) < 2e-3 * (1 + step)).mean()
+        assert frac > 0.97, (task, step, frac, d.max())
+        assert (outs[0][2].cpu().numpy() == outs[1][2].cpu().numpy()).mean() > 0.99              # same resets
+
+
+def test_multi_wave_option_is_ignored_by_models_without_a_multi_wave_form():
+    env = _make("Humanoid", 64, mw=32)          # compact contact store: stays on the single-wave kernel
+    env.step(torch.zeros((64, 21), device=DEV))
+    torch.cuda.synchronize()
+    assert torch.isfinite(env.obs_buf).all()

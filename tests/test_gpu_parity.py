@@ -817,16 +817,18 @@ def test_identical_envs_in_all_lanes_agree(task):
     for step in range(4):
         env.step(torch.rand((n, env.num_actions), device=DEV, generator=g) * 2 - 1)
     t = env.engine.tensors
-    for name in ("root_states", "dof_state", "contact_impulse", "limit_impulse", "dof_actuation_force"):
-        t[name][:] = t[name][17:18].clone()
+    for name in ("root_states", "dof_state", "contact_impulse", "limit_impulse", "dof_actuation_force", "self_contact_impulse"):
+        if name in t:                                                  # (the Humanoid also warm-starts its self contacts)
+            t[name][:] = t[name][17:18].clone()
     for step in range(6):
         a = (torch.rand((1, env.num_actions), device=DEV, generator=g) * 2 - 1).repeat(n, 1)
         env.engine.tensors["dof_actuation_force"][:] = a * 10.0
         env.engine.simulate()
     torch.cuda.synchronize()
-    for name in ("root_states", "dof_state", "contact_impulse", "force_sensor", "dof_force"):
-        x = t[name]
-        assert torch.equal(x, x[0:1].expand_as(x)), (task, name)
+    for name in ("root_states", "dof_state", "contact_impulse", "force_sensor", "dof_force", "self_contact_impulse", "self_contact_force"):
+        if name in t:
+            x = t[name]
+            assert torch.equal(x, x[0:1].expand_as(x)), (task, name)
 
 
 # ------------------------------------------------------------------ domain randomisation (vec_task.py:610-840)
