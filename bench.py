@@ -8,17 +8,21 @@ Rank 0 prints ONE JSON line.
   step      = one `env.step(actions)` through the public Python API (isaacgymenvs_amd.make -> VecTask.step), i.e.
               one launch group (sub-step kernels + post kernel, no host sync) advancing every env by one control
               step (reference vec_task.py:360-408).
-  workload  = BASELINE.json configs[1]: Ant num_envs=4096 per GPU, random-action rollout (reference README.md:48-51);
-              actions come from a pool of pre-generated U(-1,1) batches already resident in HBM.
+  workload  = BASELINE.json configs[1]: Ant num_envs=4096 per GPU, random-action rollout exactly as reference README.md:48-51:
+              `actions = 2 * torch.rand((N, A), device) - 1` drawn inside the loop, right before every step (the three torch kernels of
+              that draw are inside the timed region).  `pooled` = the same loop fed from 8 pre-generated batches (engine only).
   value     = (envs on all ranks) * K / max-over-ranks(wall time of the K timed steps), barrier+synchronize on both sides.
   roofline  = algorithmic bytes per control step (673 B/env-step Ant, 1161 B Humanoid) x envs / average
               GPU time of one step's launch group (substep_kernel x substeps + post kernel), measured with HIP events
               around each group on the launch stream (a second pass right after the timed one), against the 8 TB/s
-              HBM3E peak.  `traffic` = FETCH_SIZE + WRITE_SIZE of the group from the rocprofv3 PMC passes committed
-              under profiles/ (constants below are refreshed from there; null when not measured for the task).
+              HBM3E peak.  `traffic` = calibrated FETCH_SIZE + WRITE_SIZE of the group from the rocprofv3 PMC passes of this
+              command, read from profiles/traffic.json (written by tools/summarize_profile.py; null when the file has no entry).
   cpu_baseline = the CPU oracle (oracle/physics.c via oracle/tasks.py, OpenMP over envs) on a bounded sample of the
               same workload on this host's cores ("port": the reference's PhysX-CPU path cannot run).
-  extra     = the second headline config (Humanoid num_envs=8192) measured the same way in the same run.
+              `cpu_baseline.reference_jit_fns` = the reference's own jitted obs / reward functions on torch-CPU where
+              /root/reference is reachable (development container), else marked absent.
+  extra     = the second headline config (Humanoid num_envs=8192, self-collision on) measured the same way in the same run;
+              extra2 / extra3 = AnymalTerrain@4096 and ShadowHand@16384 (N = 1), or their per-GPU shards 512 / 2048 (N > 1).
 """
 from __future__ import annotations
 
@@ -36,18 +40,24 @@ if ROOT not in sys.path:
 ALGO_BYTES = {"Cartpole": 89, "Ant": 673, "Humanoid": 1161, "AnymalTerrain": 2240, "ShadowHand": 3600}
 DEFAULT_ENVS = {"Cartpole": 64, "Ant": 4096, "Humanoid": 8192, "AnymalTerrain": 4096, "ShadowHand": 16384}
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
-# HBM-side bytes per control step from the round-1 PMC passes (profiles/r1_pmc_summary.md): raw FETCH_SIZE + WRITE_SIZE
-# (KB -> B) summed over the launches of one step (sub-steps + pre/post kernels) at the BASELINE env counts.  The raw fetch counter
-# matches the byte count of our dword-per-lane coalesced loads, so the guide's x2 (calibrated on 16 B/lane streams) is
-# NOT applied; the excess over the algorithmic bytes is state re-read per sub-step launch, warm-start impulses and
-# (Humanoid) the constraint rows that spill to scratch.
-PMC_TRAFFIC_BYTES = {("Ant", 4096): int((2 * (1196.8 + 1856.0) + 661.1 + 2213.1) * 1024),
-                     ("Humanoid", 8192): int((2 * (12271.3 + 22448.9) + 2265.5 + 8945.1) * 1024),
-                     ("AnymalTerrain", 4096): int((5 * (1623.6 + 2272.0) + 65.0 + 0.1 + 1342.6 + 2549.4 + 740.7 + 4744.1) * 1024),
-                     ("ShadowHand", 16384): int((1699.0 + 4689.0 + 2 * (9257.8 + 27090.6) + 7982.1 + 48825.9 + 1.3) * 1024)}
+# chip-wide VALU issue peak in wave-instructions: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
+VALU_PEAK_GINST = 256 * 4 * 2.4e9 / 4 / 1e9
+
+
+def load_traffic():
+    """HBM-side bytes and executed VALU instructions per control step, per task at its BASELINE size: written by
+    tools/summarize_profile.py from the rocprofv3 PMC passes of THIS command (tools/profile_r2.sh), with the FETCH_SIZE / WRITE_SIZE
+    calibration factors measured by tools/calib/calib_fetch on the same box.  Absent file or entry -> null in the JSON line."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
 
 
 def measure(task, num_envs, steps, warmup, device, rank, world, seed=42, pool=8):
+    """Times `steps` control steps twice: with the reference's protocol (actions drawn by torch.rand right before every step,
+    README.md:48-51 -- this is the reported value) and with a small pool of pre-generated action batches (engine only)."""
     import torch
     import torch.distributed as dist
     import isaacgymenvs_amd
@@ -55,7 +65,8 @@ def measure(task, num_envs, steps, warmup, device, rank, world, seed=42, pool=8)
     env = isaacgymenvs_amd.make(seed=seed + rank, task=task, num_envs=num_envs, sim_device=device, rl_device=device,
                                 headless=True, multi_gpu=world > 1, force_render=False)
     g = torch.Generator(device=device).manual_seed(seed + rank)  # reference utils/utils.py:94: seed + rank
-    acts = [2.0 * torch.rand((num_envs, env.num_actions), device=device, generator=g) - 1.0 for _ in range(pool)]
+    na = env.num_actions
+    acts = [2.0 * torch.rand((num_envs, na), device=device, generator=g) - 1.0 for _ in range(pool)]
     reducer = None
     use_dist = dist.is_available() and dist.is_initialized()
     if use_dist:
@@ -67,29 +78,35 @@ def measure(task, num_envs, steps, warmup, device, rank, world, seed=42, pool=8)
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(fresh):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for i in range(steps):
+            a = 2.0 * torch.rand((num_envs, na), device=device, generator=g) - 1.0 if fresh else acts[i % pool]
+            env.step(a)
+            if reducer:
+                reducer.step()
+        ev1.record()
+        sync()
+        wall = time.perf_counter() - t0
+        gpu_ms = ev0.elapsed_time(ev1)
+        if use_dist:
+            t = torch.tensor([wall], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall = float(t.item())
+        return wall, gpu_ms
+
     for i in range(warmup):
-        env.step(acts[i % pool])
+        env.step(2.0 * torch.rand((num_envs, na), device=device, generator=g) - 1.0)
         if reducer:
             reducer.step()
     sync()
     stats0 = env.engine.tensors["episode_stats"].clone()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for i in range(steps):
-        env.step(acts[i % pool])
-        if reducer:
-            reducer.step()
-    ev1.record()
-    sync()
-    wall = time.perf_counter() - t0
-    gpu_ms = ev0.elapsed_time(ev1)
-    if use_dist:
-        t = torch.tensor([wall], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
+    wall, gpu_ms = timed(True)
     stats = (env.engine.tensors["episode_stats"] - stats0).cpu().tolist()
-    # per-launch kernel duration: HIP events on the launch stream around each fused-step launch (same workload continuing)
+    wall_pool, _ = timed(False)
+    # per-launch duration of the fused step (sub-step kernels + post kernel): HIP events on the launch stream around each launch group
     kn = min(steps, 200)
     pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(kn)]
     torch.cuda.synchronize()
@@ -104,45 +121,77 @@ def measure(task, num_envs, steps, warmup, device, rank, world, seed=42, pool=8)
         "task": task, "num_envs_per_gpu": num_envs, "wall_s": wall, "ms_per_step": 1e3 * wall / steps,
         "gpu_ms_per_step": gpu_ms / steps, "kernel_ms_avg": kern_ms, "kernel_ms_median": durs[len(durs) // 2],
         "env_steps_per_s": world * num_envs * steps / wall,
+        "pooled": {"ms_per_step": 1e3 * wall_pool / steps, "env_steps_per_s": world * num_envs * steps / wall_pool,
+                   "note": f"same loop with a pool of {pool} pre-generated action batches instead of torch.rand per step"},
         "reset_rate": stats[2] / max(stats[4], 1.0), "mean_reward": stats[3] / max(stats[4], 1.0),
+        "multi_wave": int(env.engine.get_option("multi_wave")),
     }
+    if task == "Humanoid":
+        res["self_collision"] = int(env.engine.get_option("self_collision"))
     if reducer:
         res["job_stats"] = reducer.result()
     del env
     return res
 
 
-# Instructions one wave executes per control step (rocprofv3 SQ_INSTS_VALU + SALU + LDS per wave, profiles/r1_pmc_summary.md: sub-step
-# launches + post kernel) and what a wave that owns its SIMD can issue (tools/debug/ifetch_bench.hip: 4 cycles per 4-byte and ~5.3
-# per 8-byte instruction at ~1.8 GHz, ~45 % 8-byte => ~2.55 ns).  Every wave runs concurrently at the BASELINE sizes, so this
-# per-wave issue time is the floor of the step on the current one-env-per-lane design; reported next to the mandatory HBM roofline.
-WAVE_INSTRS_PER_STEP = {"Ant": 2 * 10800 + 1200, "Humanoid": 2 * 35940 + 2 * 3350}   # Humanoid post: 2 half-filled waves per 64 envs   # SQ_INSTS_VALU + SALU + LDS per wave (profiles/r1_pmc_summary.md)
-ISSUE_NS_PER_INSTR = 2.55
-WAVE_VALU_PER_STEP = {"Ant": 2 * 9213 + 1104, "Humanoid": 2 * 30808 + 3188, "AnymalTerrain": 5 * 14594 + 2718, "ShadowHand": 2 * 62333 + 1313 + 7549}
-VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
-
-
-def roofline(task, num_envs, kernel_ms):
+def roofline(task, num_envs, kernel_ms, mw=0):
     bytes_per_launch = ALGO_BYTES[task] * num_envs
-    lanes = 32 if task in ("Humanoid", "ShadowHand") else 64   # compact-store models run 32 envs per wave
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-    traffic = PMC_TRAFFIC_BYTES.get((task, num_envs))
+    tr = load_traffic().get(f"{task}@{num_envs}", {})
+    if mw:
+        shape = "%d workgroups of %d envs x 4 waves (one limb per wave)" % ((num_envs + mw - 1) // mw, mw)
+    else:
+        lanes = 32 if task in ("Humanoid", "ShadowHand") else 64   # compact-store models run 32 envs per wave
+        shape = "%d waves of %d envs, one per SIMD" % ((num_envs + lanes - 1) // lanes, lanes)
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-           "traffic": traffic, "kernel": "mi::substep_kernel<%s> (x sim steps) + post kernel = one step" % task,
+           "traffic": tr.get("traffic_bytes_per_step"), "traffic_source": tr.get("source"),
+           "kernel": "one control step = physics sub-step kernel x sim steps + post kernel(s) (%s)" % task,
            "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
-           "note": "latency/issue-bound path: %d waves of %d envs, one per SIMD; see DESIGN.md" % ((num_envs + lanes - 1) // lanes, lanes)}
-    if task in WAVE_VALU_PER_STEP:
-        # SURVEY 8(d) asks for the fp32 side next to the HBM fraction: executed VALU lane-operations (SQ_INSTS_VALU per wave x waves x
-        # lanes) against what the chip can issue, 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-ops/s (an FMA counts once)
-        waves = (num_envs + lanes - 1) // lanes
-        lane_ops = WAVE_VALU_PER_STEP[task] * waves * lanes / (kernel_ms * 1e-3)
-        out["valu"] = {"achieved": lane_ops / 1e12, "peak": VALU_PEAK_TLANEOPS, "unit": "T lane-ops/s", "frac": lane_ops / 1e12 / VALU_PEAK_TLANEOPS,
-                       "note": "%d of 1024 SIMDs hold a wave at this env count" % waves}
-    if task in WAVE_INSTRS_PER_STEP:
-        floor_ms = WAVE_INSTRS_PER_STEP[task] * ISSUE_NS_PER_INSTR * 1e-6
-        out["single_wave_issue_floor"] = {"instructions_per_wave_per_step": WAVE_INSTRS_PER_STEP[task], "ns_per_instruction": ISSUE_NS_PER_INSTR,
-                                          "floor_ms": floor_ms, "frac_of_floor": floor_ms / kernel_ms}
+           "note": "latency / issue-bound path, not HBM-bound: %s; see DESIGN.md 6" % shape}
+    if tr.get("valu_wave_insts_per_step"):
+        # SURVEY 8(d) asks for the compute side next to the HBM fraction: executed VALU wave-instructions per step against what the
+        # chip's 1024 SIMDs can issue (one per 4 cycles each)
+        rate = tr["valu_wave_insts_per_step"] / (kernel_ms * 1e-3) / 1e9
+        out["valu"] = {"achieved": rate, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s", "frac": rate / VALU_PEAK_GINST}
     return out
+
+
+def reference_jit_leg(task, num_envs, budget_s=4.0):
+    """the reference's OWN jitted compute_*_observations + compute_*_reward on torch-CPU, for the obs / reward share of
+    its CPU pipeline.  Only where /root/reference is reachable (the development container); absent on the GPU box."""
+    ref = "/root/reference"
+    if task != "Ant" or not os.path.isdir(os.path.join(ref, "isaacgymenvs")):
+        return None
+    try:
+        import torch
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import gen_golden
+        mod = gen_golden.import_reference()["ant"]
+        n = num_envs
+        g = torch.Generator().manual_seed(0)
+        root = torch.randn(n, 13, generator=g); root[:, 3:7] = torch.nn.functional.normalize(root[:, 3:7], dim=-1)
+        z = lambda *s: torch.zeros(*s)
+        args = dict(obs=z(n, 60), root=root, targets=torch.tensor([1000.0, 0.0, 0.0]).repeat(n, 1), pot=z(n), inv=torch.tensor([0.0, 0, 0, 1]).repeat(n, 1),
+                    dof_pos=torch.rand(n, 8, generator=g), dof_vel=torch.randn(n, 8, generator=g), lo=-torch.ones(8), up=torch.ones(8),
+                    sens=torch.randn(n, 24, generator=g), act=torch.rand(n, 8, generator=g), b0=torch.tensor([1.0, 0, 0]).repeat(n, 1),
+                    b1=torch.tensor([0.0, 0, 1]).repeat(n, 1))
+
+        def once():
+            o = mod.compute_ant_observations(args["obs"], args["root"], args["targets"], args["pot"], args["inv"], args["dof_pos"], args["dof_vel"],
+                                             args["lo"], args["up"], 0.2, args["sens"], args["act"], 0.0166, 0.1, args["b0"], args["b1"], 2)
+            mod.compute_ant_reward(o[0], torch.zeros(n, dtype=torch.long), torch.zeros(n, dtype=torch.long), args["act"], 0.1, 0.5, o[1], o[2],
+                                   0.005, 0.05, 0.1, 0.31, -2.0, 1000.0)
+        for _ in range(3):
+            once()
+        k, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s:
+            once(); k += 1
+        dt = time.perf_counter() - t0
+        return {"value": n * k / dt, "unit": "env-steps/s (obs + reward only)", "cores": torch.get_num_threads(), "kind": "reference",
+                "sample": f"{k} calls of the reference's jitted compute_ant_observations + compute_ant_reward (ant.py:325-408) on torch-CPU, "
+                          f"{n} envs, {dt:.1f} s -- the obs / reward share only; its physics (PhysX-CPU) cannot run here"}
+    except Exception as ex:  # noqa: BLE001 -- a missing / changed reference tree must not break the bench line
+        return {"absent": f"{type(ex).__name__}: {ex}"[:200]}
 
 
 def cpu_baseline(task, num_envs, budget_s=15.0, seed=42):
@@ -227,10 +276,15 @@ def main():
 
     main_res = measure(args.task, n_env, args.steps, args.warmup, device, rank, world, pool=args.pool)
     extra = extra2 = extra3 = None
-    if not args.no_extra and args.task == "Ant" and world == 1:   # side measurements only in the single-GPU run
-        extra = measure("Humanoid", DEFAULT_ENVS["Humanoid"], max(args.steps // 4, 10), max(args.warmup // 4, 5), device, rank, world)
-        extra2 = measure("AnymalTerrain", DEFAULT_ENVS["AnymalTerrain"], max(args.steps // 4, 10), max(args.warmup // 4, 5), device, rank, world)
-        extra3 = measure("ShadowHand", DEFAULT_ENVS["ShadowHand"], max(args.steps // 8, 10), max(args.warmup // 8, 5), device, rank, world)
+    side = {"Humanoid": DEFAULT_ENVS["Humanoid"], "AnymalTerrain": DEFAULT_ENVS["AnymalTerrain"], "ShadowHand": DEFAULT_ENVS["ShadowHand"]}
+    if world > 1:      # BASELINE configs 4 / 5 are quoted sharded over the GPUs of the node: 4096 / 8 and 16384 / 8 envs per GPU
+        side["AnymalTerrain"] = max(DEFAULT_ENVS["AnymalTerrain"] // world, 64)
+        side["ShadowHand"] = max(DEFAULT_ENVS["ShadowHand"] // world, 64)
+    if not args.no_extra and args.task == "Ant":
+        if world == 1:
+            extra = measure("Humanoid", side["Humanoid"], max(args.steps // 4, 10), max(args.warmup // 4, 5), device, rank, world)
+        extra2 = measure("AnymalTerrain", side["AnymalTerrain"], max(args.steps // 4, 10), max(args.warmup // 4, 5), device, rank, world)
+        extra3 = measure("ShadowHand", side["ShadowHand"], max(args.steps // 8, 10), max(args.warmup // 8, 5), device, rank, world)
     import torch.distributed as dist
     if rank != 0:
         if dist.is_initialized():
@@ -243,30 +297,38 @@ def main():
         "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.task} num_envs={n_env} per GPU ({world * n_env} total), VecTask.step() via Python API, "
-                               f"pool of {args.pool} pre-generated U(-1,1) action batches, seed 42+rank",
-                   "task": args.task, "num_envs_per_gpu": n_env, "parallelism": f"env-shard x{world}"},
+                               f"actions = 2*torch.rand-1 drawn before every step (README.md:48-51), seed 42+rank",
+                   "task": args.task, "num_envs_per_gpu": n_env, "parallelism": f"env-shard x{world}",
+                   "multi_wave": main_res["multi_wave"]},
         "gpu_ms_per_step": main_res["gpu_ms_per_step"], "reset_rate": main_res["reset_rate"],
-        "mean_reward": main_res["mean_reward"],
-        "roofline": roofline(args.task, n_env, main_res["kernel_ms_avg"]),
+        "mean_reward": main_res["mean_reward"], "pooled": main_res["pooled"],
+        "roofline": roofline(args.task, n_env, main_res["kernel_ms_avg"], main_res["multi_wave"]),
     }
     if "job_stats" in main_res:
         out["job_stats"] = main_res["job_stats"]
     if extra is not None:
-        out["extra"] = {"workload": f"Humanoid num_envs={DEFAULT_ENVS['Humanoid']} per GPU", "value": extra["env_steps_per_s"],
-                        "unit": "env-steps/s", "ms_per_step": extra["ms_per_step"], "reset_rate": extra["reset_rate"],
-                        "roofline": roofline("Humanoid", DEFAULT_ENVS["Humanoid"], extra["kernel_ms_avg"])}
+        out["extra"] = {"workload": f"Humanoid num_envs={side['Humanoid']} per GPU, self-collision {'on' if extra.get('self_collision') else 'off'} "
+                                    f"(humanoid.py:194)", "value": extra["env_steps_per_s"],
+                        "unit": "env-steps/s", "ms_per_step": extra["ms_per_step"], "reset_rate": extra["reset_rate"], "pooled": extra["pooled"],
+                        "roofline": roofline("Humanoid", side["Humanoid"], extra["kernel_ms_avg"])}
     if extra2 is not None:
-        out["extra2"] = {"workload": f"AnymalTerrain num_envs={DEFAULT_ENVS['AnymalTerrain']} per GPU (5 sim steps of 5 ms per control step)",
+        out["extra2"] = {"workload": f"AnymalTerrain num_envs={side['AnymalTerrain']} per GPU ({world * side['AnymalTerrain']} total; 5 sim steps of 5 ms per control step)",
                          "value": extra2["env_steps_per_s"], "unit": "env-steps/s", "ms_per_step": extra2["ms_per_step"],
-                         "reset_rate": extra2["reset_rate"],
-                         "roofline": roofline("AnymalTerrain", DEFAULT_ENVS["AnymalTerrain"], extra2["kernel_ms_avg"])}
+                         "reset_rate": extra2["reset_rate"], "pooled": extra2["pooled"], "multi_wave": extra2["multi_wave"],
+                         "roofline": roofline("AnymalTerrain", side["AnymalTerrain"], extra2["kernel_ms_avg"], extra2["multi_wave"])}
+        if "job_stats" in extra2:
+            out["extra2"]["job_stats"] = extra2["job_stats"]
     if extra3 is not None:
-        out["extra3"] = {"workload": f"ShadowHand (block, full_state) num_envs={DEFAULT_ENVS['ShadowHand']} per GPU (2 sub-steps per control step)",
+        out["extra3"] = {"workload": f"ShadowHand (block, full_state) num_envs={side['ShadowHand']} per GPU ({world * side['ShadowHand']} total; 2 sub-steps per control step)",
                          "value": extra3["env_steps_per_s"], "unit": "env-steps/s", "ms_per_step": extra3["ms_per_step"],
-                         "reset_rate": extra3["reset_rate"],
-                         "roofline": roofline("ShadowHand", DEFAULT_ENVS["ShadowHand"], extra3["kernel_ms_avg"])}
+                         "reset_rate": extra3["reset_rate"], "pooled": extra3["pooled"],
+                         "roofline": roofline("ShadowHand", side["ShadowHand"], extra3["kernel_ms_avg"])}
+        if "job_stats" in extra3:
+            out["extra3"]["job_stats"] = extra3["job_stats"]
     if world == 1 and not args.no_cpu_baseline and args.task in ("Ant", "Humanoid"):
         out["cpu_baseline"] = cpu_baseline(args.task, n_env, budget_s=args.cpu_budget)
+        leg = reference_jit_leg(args.task, n_env)
+        out["cpu_baseline"]["reference_jit_fns"] = leg if leg is not None else {"absent": "/root/reference is not reachable on this host"}
     print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()

@@ -1,0 +1,56 @@
+// arena.hpp -- the view of the caller-owned SoA arena that every kernel (and the CPU backend) receives.  No HIP dependency.
+#pragma once
+#include <cstdint>
+
+namespace mi {
+
+// ---------------------------------------------------------------------------------------------- arena view
+struct View {
+    int N;
+    int env_offset;
+    uint32_t seed;
+    int ring;  // which obs_out slot this step writes
+    int mw;    // multi-wave sub-step: envs per workgroup (16 or 32), 0 = one wave per workgroup (option "multi_wave")
+    float clip_obs;
+    float* root;        // [13][N]
+    float* dof;         // [2][ND][N]  (pos block, vel block)
+    float* tau;         // [ND][N]  dof_actuation_force
+    float* lamc;        // [3*NSPH][N]
+    float* laml;        // [ND][N]
+    float* sensor;      // [6*NSENS][N]
+    float* dof_force;   // [ND][N]
+    float* potentials;  // [N]
+    float* prev_potentials;
+    float* up_vec;      // [3][N]
+    float* heading_vec; // [3][N]
+    float* actions;     // [NACT][N]
+    float* init_root;   // [13][N]
+    float* obs;         // [N][NOBS] row-major
+    float* obs_out;     // [2][N][NOBS]
+    float* rew;         // [N]
+    long long* reset;   // [N]
+    long long* progress;
+    long long* randomize;
+    unsigned char* timeout;
+    int* episode;
+    // ---- actors that collide with themselves (Humanoid, reference humanoid.py:194); null otherwise / when switched off
+    float* lamp;        // [3*NPG][N] warm-start impulses of the self-contact groups
+    float* pairf;       // [3*NPG][N] world force on side a of each group's contact, last sub-step
+    float* ep_ret;      // [N] running return of the current episode
+    float* stats;       // [8] job statistics: sum finished returns, sum finished lengths, #finished, sum rewards, #env-steps
+    // ---- AnymalTerrain only (null otherwise)
+    float* netf;          // [3*NB][N] net contact force per body, world frame (gym net_contact_force tensor)
+    float* commands;      // [4][N] x vel, y vel, yaw vel, heading (anymal_terrain.py:140)
+    float* last_actions;  // [12][N]
+    float* last_dof_vel;  // [12][N]
+    float* feet_air_time; // [4][N]
+    float* episode_sums;  // [13][N]
+    float* env_origins;   // [3][N]
+    float* friction;      // [N] per-env shape friction (100 buckets, :236-239,279-281)
+    int* terrain_levels;  // [N]
+    int* terrain_types;   // [N]
+    float* ep_stats;      // [16] this step: sum of the 13 episode sums over resetting envs, #resets, sum terrain levels
+    float* ep_means;      // [16] extras["episode"]: rew_* means / max_episode_length_s, terrain_level mean (:421-425)
+};
+
+}  // namespace mi

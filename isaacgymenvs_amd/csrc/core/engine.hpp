@@ -296,7 +296,14 @@ struct Sim {
     // KMAX contacts per env, 32 envs per wave (half-filled waves cost nothing while there are more CUs than waves), the
     // slot index of sphere s is data dependent.  Layout [slot][lane] makes any per-lane slot bank-conflict free.
     static constexpr bool COMPACT = (size_t)ROW_SLOTS_STATIC * 64 * sizeof(float) > 152 * 1024;
-    static constexpr int LANES = COMPACT ? 32 : 64;       // envs per workgroup (= per wave)
+#ifndef MI_COMPACT_LANES
+#define MI_COMPACT_LANES 32
+#endif
+    // envs per workgroup (= per wave).  Compact store: 32.  Measured (profiles/r2d_lanes_ab.txt, Humanoid@8192): 16 envs per wave
+    // -- two 79 KB workgroups per CU, more wave-uniform skipping of inactive spheres / self-contact groups -- is 1.2-1.3x SLOWER
+    // (0.425 vs 0.326 ms per step without, 0.630 vs 0.526 ms with self-collision): twice the waves stream the same 250 KB of
+    // straight-line code through the instruction caches.
+    static constexpr int LANES = COMPACT ? MI_COMPACT_LANES : 64;
 #ifndef MI_INLINE_WARM
 #define MI_INLINE_WARM 2
 #endif
@@ -311,7 +318,10 @@ struct Sim {
     // 3 rows over the union of the two limb tips' chains (PCHAIN entries) behind the ground-contact slots
     static constexpr int NPG = COMPACT ? M::NPG : 0, PCH = M::PCHAIN, KPAIR = 3;
     static constexpr int P_CSZ = 3 * PCH + 7;
-    static constexpr int KMAX = NPG > 0 ? 12 : 16;        // active ground contacts kept per env (compact store only)
+#ifndef MI_KMAX_SELFCOL
+#define MI_KMAX_SELFCOL 12
+#endif
+    static constexpr int KMAX = NPG > 0 ? MI_KMAX_SELFCOL : 16;   // active ground contacts kept per env (compact store only)
     static constexpr int limoff(int r) {                  // tight packing of the limit rows: offset of row r
         int n = 0;
         for (int k = 0; k < r; ++k) n += M::nanc[OFF + limdof_c(k)] + 1;
@@ -1033,6 +1043,7 @@ struct Sim {
         // carry both bodies drop out, the others enter with the sign of their side -- which side(s) a dof moves depends on the bodies
         // the env's deepest pair happens to join, so it is read from the per-lane chain masks instead of being unrolled per body pair
         // (13 row-build code paths for the Humanoid instead of 66).
+        MI_STAMP(45);
         if constexpr (NPG > 0) { if (selfcol) {
         int cntp = 0;
         // broad phase: bounding sphere of every capsule (centre = middle of its axis, radius = half length + capsule radius); the

@@ -1,0 +1,394 @@
+// mi_engine_cpu.cpp -- CPU product backend: the engine lifecycle part of include/mi_engine.h on a HOST arena.
+//
+// What it is for: the reference's `sim_device=cpu pipeline=cpu` configuration (BASELINE.json config 1: Cartpole num_envs=64;
+// reference device resolution isaacgymenvs/tasks/base/vec_task.py:78-88, PhysX worker threads `num_threads`, cfg/config.yaml:30).
+// What it is built from: the SAME sources the HIP kernels compile -- csrc/core/engine.hpp (per-env physics sub-step, host build of
+// the specialised code), csrc/tasks/locomotion.hpp (observations / reward / reset), csrc/arena_layout.hpp (arena layout) -- with
+// OpenMP over envs where the kernels have one env per lane.  It does NOT use oracle/ (test infrastructure).  Same SoA arena layout,
+// same counter-based reset RNG: the Python side sees identical tensors and, up to fp32 summation order in the episode statistics,
+// identical numbers on both devices.
+//
+// Tasks: Cartpole, Ant, Humanoid (self-collision included).  The other tasks exist on the MI355X only: mi_engine_create says so.
+// Build: g++ -O2 -fopenmp -shared (isaacgymenvs_amd/native.py::build_cpu); libmi_engine_cpu.so exports the lifecycle subset.
+#include <omp.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../core/engine.hpp"
+#include "../arena_layout.hpp"
+
+using namespace mi;
+
+static_assert(sizeof(MiSimParams) == sizeof(SimParams), "MiSimParams layout");
+static_assert(sizeof(MiLocoParams) == sizeof(LocoParams), "MiLocoParams layout");
+static_assert(sizeof(MiCartpoleParams) == sizeof(CartpoleParams), "MiCartpoleParams layout");
+
+static thread_local std::string g_err;
+static int fail(const std::string& m) { g_err = m; return -1; }
+extern "C" const char* mi_last_error(void) { return g_err.c_str(); }
+extern "C" int mi_abi_version(void) { return MI_ABI_VERSION; }
+
+struct MiEngine {
+    int task, N;
+    SimParams P;
+    LocoParams loco;
+    CartpoleParams cart;
+    View v;
+    float clip_obs;
+    int control_freq_inv, num_threads;
+    std::vector<MiTensorDesc> descs;
+    unsigned long long steps;
+    float* lamp_arena;
+};
+
+static bool cpu_task(int t) { return t == T_CARTPOLE || t == T_ANT || t == T_HUMANOID; }
+
+extern "C" int mi_task_info(const char* task, MiTaskInfo* out) {
+    const int t = task ? find_task(task) : -1;
+    if (t < 0 || !out) return fail(std::string("unknown task: ") + (task ? task : "(null)"));
+    const TaskMeta& m = kTasks[t];
+    out->num_obs = m.nobs; out->num_actions = m.nact; out->num_dofs = m.nd; out->num_bodies = m.nb; out->num_sensors = m.nsens;
+    out->num_contact_spheres = m.nsph; out->fixed_base = m.fixed; out->task_params_bytes = (int)m.pbytes;
+    return 0;
+}
+extern "C" size_t mi_engine_arena_bytes(const char* task, int num_envs) {
+    const int t = task ? find_task(task) : -1;
+    if (t < 0 || num_envs <= 0 || !cpu_task(t)) { fail("mi_engine_arena_bytes: task not available on the CPU backend"); return 0; }
+    Layout L;
+    build_layout(t, num_envs, L, nullptr, nullptr);
+    return L.off;
+}
+extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const void* task_params, size_t task_params_bytes, int num_envs,
+                                int env_id_offset, uint64_t seed, void* arena, size_t arena_bytes, MiEngine** out) {
+    if (!task || !sim || !task_params || !arena || !out) return fail("mi_engine_create: null argument");
+    const int t = find_task(task);
+    if (t < 0) return fail(std::string("unknown task: ") + task);
+    if (!cpu_task(t)) return fail(std::string("task ") + task + " runs on the MI355X only (CPU backend: Cartpole, Ant, Humanoid)");
+    if (task_params_bytes != kTasks[t].pbytes) return fail("mi_engine_create: task_params size mismatch");
+    if (num_envs <= 0) return fail("mi_engine_create: num_envs <= 0");
+    if (sim->substeps < 1 || sim->dt <= 0.f) return fail("mi_engine_create: invalid sim params");
+    MiEngine* e = new (std::nothrow) MiEngine();
+    if (!e) return fail("out of host memory");
+    e->task = t; e->N = num_envs; e->steps = 0; e->control_freq_inv = 1; e->clip_obs = INFINITY; e->num_threads = 4;   // cfg/config.yaml:30
+    memcpy(&e->P, sim, sizeof(SimParams));
+    if (t == T_CARTPOLE) memcpy(&e->cart, task_params, sizeof(CartpoleParams));
+    else memcpy(&e->loco, task_params, sizeof(LocoParams));
+    memset(&e->v, 0, sizeof(View));
+    Layout L;
+    build_layout(t, num_envs, L, &e->v, (char*)arena);
+    if (arena_bytes < L.off) { delete e; return fail("mi_engine_create: arena too small"); }
+    e->descs = L.d;
+    e->lamp_arena = e->v.lamp;
+    e->v.N = num_envs; e->v.env_offset = env_id_offset; e->v.seed = (uint32_t)(seed ^ (seed >> 32));
+    e->v.clip_obs = INFINITY;
+    *out = e;
+    return 0;
+}
+extern "C" void mi_engine_destroy(MiEngine* e) { delete e; }
+extern "C" int mi_engine_num_tensors(const MiEngine* e) { return e ? (int)e->descs.size() : fail("null engine"); }
+extern "C" int mi_engine_tensor_desc(const MiEngine* e, int i, MiTensorDesc* out) {
+    if (!e || !out || i < 0 || i >= (int)e->descs.size()) return fail("mi_engine_tensor_desc: bad index");
+    *out = e->descs[i];
+    return 0;
+}
+extern "C" int mi_engine_set_option(MiEngine* e, const char* key, double value) {
+    if (!e) return fail("null engine");
+    if (!strcmp(key, "clip_obs")) { e->clip_obs = (float)value; e->v.clip_obs = (float)value; return 0; }
+    if (!strcmp(key, "gravity_x")) { e->P.g[0] = (float)value; return 0; }
+    if (!strcmp(key, "gravity_y")) { e->P.g[1] = (float)value; return 0; }
+    if (!strcmp(key, "gravity_z")) { e->P.g[2] = (float)value; return 0; }
+    if (!strcmp(key, "control_freq_inv")) { if (value < 1) return fail("control_freq_inv < 1"); e->control_freq_inv = (int)value; return 0; }
+    if (!strcmp(key, "self_collision")) {
+        if (value != 0 && !e->lamp_arena) return fail("self_collision: this task's actor has no self-collision tables");
+        e->v.lamp = value != 0 ? e->lamp_arena : nullptr;
+        return 0;
+    }
+    if (!strcmp(key, "multi_wave")) return 0;                                  // a GPU launch shape: nothing to do here
+    if (!strcmp(key, "steps")) { if (value < 0) return fail("steps < 0"); e->steps = (unsigned long long)value; return 0; }
+    // sim.physx.num_threads of the reference's CPU pipeline (vec_task.py:541, cfg/config.yaml:30): OpenMP threads over envs
+    if (!strcmp(key, "num_threads")) { if (value < 1) return fail("num_threads < 1"); e->num_threads = (int)value; return 0; }
+    return fail(std::string("unknown option: ") + key);
+}
+extern "C" int mi_engine_get_option(const MiEngine* e, const char* key, double* out) {
+    if (!e || !key || !out) return fail("mi_engine_get_option: null argument");
+    if (!strcmp(key, "clip_obs")) { *out = e->clip_obs; return 0; }
+    if (!strcmp(key, "gravity_x")) { *out = e->P.g[0]; return 0; }
+    if (!strcmp(key, "gravity_y")) { *out = e->P.g[1]; return 0; }
+    if (!strcmp(key, "gravity_z")) { *out = e->P.g[2]; return 0; }
+    if (!strcmp(key, "control_freq_inv")) { *out = e->control_freq_inv; return 0; }
+    if (!strcmp(key, "self_collision")) { *out = e->v.lamp != nullptr ? 1.0 : 0.0; return 0; }
+    if (!strcmp(key, "multi_wave")) { *out = 0; return 0; }
+    if (!strcmp(key, "steps")) { *out = (double)e->steps; return 0; }
+    if (!strcmp(key, "num_threads")) { *out = e->num_threads; return 0; }
+    return fail(std::string("unknown option: ") + key);
+}
+extern "C" int mi_engine_last_ring(const MiEngine* e) { return e ? (int)((e->steps + 1) & 1) : -1; }
+extern "C" int mi_engine_set_terrain(MiEngine*, const int16_t*, int, int, float, float, float, const float*, int, int, float, int) {
+    return fail("mi_engine_set_terrain: AnymalTerrain runs on the MI355X only");
+}
+
+// ------------------------------------------------------------------------------------------------ initial state (= init_state_kernel)
+extern "C" int mi_engine_init_state(MiEngine* e, void*) {
+    if (!e) return fail("null engine");
+    const TaskMeta& m = kTasks[e->task];
+    const View& v = e->v;
+    const int N = v.N, nd = m.nd;
+    const float root_z = e->task == T_CARTPOLE ? 2.0f : e->loco.start_height;               // cartpole.py:93 / ant.py:164
+    const float pot0 = e->task == T_CARTPOLE ? 0.f : -1000.f / e->loco.dt;                  // ant.py:113
+    const float root[13] = {0, 0, root_z, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0};
+    for (int en = 0; en < N; ++en) {
+        for (int k = 0; k < 13; ++k) { v.root[k * N + en] = root[k]; v.init_root[k * N + en] = root[k]; }
+        for (int k = 0; k < nd; ++k) {
+            v.dof[k * N + en] = e->task == T_CARTPOLE ? 0.f : e->loco.initial_dof_pos[k];
+            v.dof[(nd + k) * N + en] = 0.f;
+            v.tau[k * N + en] = 0.f; v.laml[k * N + en] = 0.f; v.dof_force[k * N + en] = 0.f;
+        }
+        for (int k = 0; k < 3 * m.nsph; ++k) v.lamc[k * N + en] = 0.f;
+        if (v.lamp) for (int k = 0; k < 3 * ModelHumanoid::NPG; ++k) { v.lamp[k * N + en] = 0.f; v.pairf[k * N + en] = 0.f; }
+        for (int k = 0; k < 6 * m.nsens; ++k) v.sensor[k * N + en] = 0.f;
+        for (int k = 0; k < m.nact; ++k) v.actions[k * N + en] = 0.f;
+        for (int k = 0; k < m.nobs; ++k) { v.obs[(size_t)en * m.nobs + k] = 0.f; v.obs_out[(size_t)en * m.nobs + k] = 0.f; v.obs_out[((size_t)N + en) * m.nobs + k] = 0.f; }
+        v.potentials[en] = pot0; v.prev_potentials[en] = pot0;
+        if (v.friction) v.friction[en] = -1.f;
+        for (int k = 0; k < 3; ++k) { v.up_vec[k * N + en] = (k == 2) ? 1.f : 0.f; v.heading_vec[k * N + en] = (k == 0) ? 1.f : 0.f; }
+        v.rew[en] = 0.f;
+        v.reset[en] = 1;      // vec_task.py:316-317: every env is reset inside the first step()
+        v.progress[en] = 0; v.randomize[en] = 0; v.timeout[en] = 0; v.episode[en] = 0;
+        v.ep_ret[en] = 0.f;
+    }
+    for (int k = 0; k < 8; ++k) v.stats[k] = 0.f;
+    e->steps = 0;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ one env on the host
+template <class M>
+static inline void load_env(Sim<M>& s, const View& v, int en) {
+    const int N = v.N;
+    for (int k = 0; k < 13; ++k) s.root[k] = v.root[k * N + en];
+    for (int k = 0; k < M::ND; ++k) { s.q[k] = v.dof[k * N + en]; s.qd[k] = v.dof[(M::ND + k) * N + en]; }
+}
+template <class M>
+static inline void store_env(const Sim<M>& s, const View& v, int en) {
+    const int N = v.N;
+    for (int k = 0; k < 13; ++k) v.root[k * N + en] = s.root[k];
+    for (int k = 0; k < M::ND; ++k) { v.dof[k * N + en] = s.q[k]; v.dof[(M::ND + k) * N + en] = s.qd[k]; }
+}
+// gym.simulate(): `substeps` sub-steps with the efforts in tau (what substep_kernel does per lane)
+template <class M>
+static void simulate_env(const View& v, const SimParams& P, int en, const float* tau) {
+    const int N = v.N;
+    Sim<M> sim;
+    load_env(sim, v, en);
+    const float h = P.dt / (float)P.substeps;
+    float rows[Sim<M>::ROW_SLOTS > 0 ? Sim<M>::ROW_SLOTS : 1];
+    const SelfCol sc{Strided{v.lamp ? v.lamp + en : nullptr, N}, Strided{v.pairf ? v.pairf + en : nullptr, N}};
+    const float mu_env = v.friction ? v.friction[en] : -1.f;
+    for (int ss = 0; ss < P.substeps; ++ss)
+        sim.substep(P, tau, h, RowStore<1>{rows}, Strided{v.lamc + en, N}, Strided{v.laml + en, N}, Strided{v.sensor + en, N},
+                    Strided{v.dof_force + en, N}, PlaneGround{}, mu_env, Strided{nullptr, N}, nullptr, false,
+                    (Sim<M>::NPG > 0 && v.lamp) ? &sc : nullptr);
+    store_env(sim, v, en);
+}
+struct StatAcc { double fin_ret = 0, fin_len = 0, fin = 0, r = 0, cnt = 0; };
+static inline void episode_stats_env(const View& v, int en, float rew, long long reset, long long progress, StatAcc& a) {
+    float ret = v.ep_ret[en] + rew;
+    a.r += rew; a.cnt += 1;
+    if (reset != 0) { a.fin_ret += ret; a.fin_len += (double)(progress + 1); a.fin += 1; ret = 0.f; }
+    v.ep_ret[en] = ret;
+}
+// post_physics_step of Ant / Humanoid for one env (what loco_post_kernel does per lane; reference ant.py:287-297)
+template <class M, bool HUM>
+static void loco_post_env(const View& v, const LocoParams& tp, int en, StatAcc& acc) {
+    using T = Loco<M::ND, 6 * M::NSENS, HUM>;
+    constexpr int ND = M::ND, NOBS = T::NOBS;
+    const int N = v.N;
+    float root[13], q[ND], qd[ND], dof_force[ND], sensor[6 * M::NSENS > 0 ? 6 * M::NSENS : 1], act[ND];
+    for (int k = 0; k < 13; ++k) root[k] = v.root[k * N + en];
+    for (int k = 0; k < ND; ++k) {
+        q[k] = v.dof[k * N + en]; qd[k] = v.dof[(ND + k) * N + en];
+        dof_force[k] = v.dof_force[k * N + en]; act[k] = v.actions[k * N + en];
+    }
+    for (int k = 0; k < 6 * M::NSENS; ++k) sensor[k] = v.sensor[k * N + en];
+    long long progress = v.progress[en] + 1;
+    float potentials = v.potentials[en], prev_potentials;
+    int ep = v.episode[en];
+    if (v.reset[en] != 0) {
+        float init_root[13];
+        for (int k = 0; k < 13; ++k) init_root[k] = v.init_root[k * N + en];
+        T::reset(tp, v.seed, (uint32_t)(v.env_offset + en), (uint32_t)ep, init_root, root, q, qd, &potentials, &prev_potentials);
+        ep += 1;
+        progress = 0;
+        for (int k = 0; k < 13; ++k) v.root[k * N + en] = root[k];
+        for (int k = 0; k < ND; ++k) { v.dof[k * N + en] = q[k]; v.dof[(ND + k) * N + en] = qd[k]; v.laml[k * N + en] = 0.f; }
+        for (int k = 0; k < 3 * M::NSPH; ++k) v.lamc[k * N + en] = 0.f;
+        if (M::NPG > 0 && v.lamp) for (int k = 0; k < 3 * M::NPG; ++k) v.lamp[k * N + en] = 0.f;
+    }
+    float obs[NOBS], up_vec[3], heading_vec[3];
+    T::observations(tp, root, tp.targets, potentials, tp.inv_start_rot, q, qd, dof_force, tp.dof_lower, tp.dof_upper, sensor, act,
+                    tp.basis_vec0, tp.basis_vec1, obs, &potentials, &prev_potentials, up_vec, heading_vec);
+    float rew;
+    long long reset;
+    T::reward(tp, obs, 0LL, progress, act, potentials, prev_potentials, &rew, &reset);
+    episode_stats_env(v, en, rew, reset, progress, acc);
+    v.randomize[en] += 1;
+    v.episode[en] = ep;
+    v.potentials[en] = potentials; v.prev_potentials[en] = prev_potentials;
+    for (int k = 0; k < 3; ++k) { v.up_vec[k * N + en] = up_vec[k]; v.heading_vec[k * N + en] = heading_vec[k]; }
+    float* ob = v.obs + (size_t)en * NOBS;
+    float* oc = v.obs_out + ((size_t)v.ring * N + en) * NOBS;
+    for (int k = 0; k < NOBS; ++k) { ob[k] = obs[k]; oc[k] = fminf(fmaxf(obs[k], -v.clip_obs), v.clip_obs); }
+    v.rew[en] = rew; v.reset[en] = reset; v.progress[en] = progress;
+    v.timeout[en] = (unsigned char)(((float)progress >= tp.max_episode_length - 1.f) && (reset != 0));   // vec_task.py:394
+}
+static void cartpole_post_env(const View& v, const CartpoleParams& tp, int en, StatAcc& acc) {
+    const int N = v.N;
+    float q[2] = {v.dof[en], v.dof[N + en]}, qd[2] = {v.dof[2 * N + en], v.dof[3 * N + en]};
+    long long progress = v.progress[en] + 1;                   // cartpole.py:165-174
+    int ep = v.episode[en];
+    if (v.reset[en] != 0) {
+        cartpole_reset(v.seed, (uint32_t)(v.env_offset + en), (uint32_t)ep, q, qd);
+        ep += 1;
+        progress = 0;
+        for (int k = 0; k < 2; ++k) { v.dof[k * N + en] = q[k]; v.dof[(2 + k) * N + en] = qd[k]; v.laml[k * N + en] = 0.f; }
+    }
+    const float obs[4] = {q[0], qd[0], q[1], qd[1]};           // cartpole.py:131-142
+    float rew;
+    long long reset;
+    cartpole_reward(tp, obs[2], obs[3], obs[1], obs[0], 0LL, progress, &rew, &reset);
+    episode_stats_env(v, en, rew, reset, progress, acc);
+    v.randomize[en] += 1;
+    v.episode[en] = ep;
+    float* ob = v.obs + (size_t)en * 4;
+    float* oc = v.obs_out + ((size_t)v.ring * N + en) * 4;
+    for (int k = 0; k < 4; ++k) { ob[k] = obs[k]; oc[k] = fminf(fmaxf(obs[k], -v.clip_obs), v.clip_obs); }
+    v.rew[en] = rew; v.reset[en] = reset; v.progress[en] = progress;
+    v.timeout[en] = (unsigned char)(((float)progress >= tp.max_episode_length - 1.f) && (reset != 0));
+}
+
+template <class M>
+static void load_tau(const View& v, int en, float* tau) { for (int k = 0; k < M::ND; ++k) tau[k] = v.tau[k * v.N + en]; }
+
+// VecTask.step for one env: clamp -> efforts (pre_physics_step) -> control_freq_inv x simulate -> post_physics_step
+template <class M, bool HUM>
+static void step_loco(MiEngine* e, const float* actions) {
+    const View& v = e->v;
+    const int N = v.N;
+    const LocoParams& tp = e->loco;
+    std::vector<StatAcc> accs(e->num_threads);
+#pragma omp parallel for schedule(static) num_threads(e->num_threads)
+    for (int en = 0; en < N; ++en) {
+        float tau[M::NDA];
+        for (int k = 0; k < M::ND; ++k) {
+            const float a = fminf(fmaxf(actions[(size_t)en * M::ND + k], -tp.clip_actions), tp.clip_actions);   // vec_task.py:374
+            v.actions[k * N + en] = a;
+            tau[k] = a * tp.gear[k] * tp.power_scale;                                                            // ant.py:281-285
+            v.tau[k * N + en] = tau[k];
+        }
+        for (int c = 0; c < e->control_freq_inv; ++c) simulate_env<M>(v, e->P, en, tau);
+        loco_post_env<M, HUM>(v, tp, en, accs[omp_get_thread_num()]);
+    }
+    for (const StatAcc& a : accs) { v.stats[0] += (float)a.fin_ret; v.stats[1] += (float)a.fin_len; v.stats[2] += (float)a.fin; v.stats[3] += (float)a.r; v.stats[4] += (float)a.cnt; }
+}
+static void step_cartpole(MiEngine* e, const float* actions) {
+    using M = ModelCartpole;
+    const View& v = e->v;
+    const int N = v.N;
+    const CartpoleParams& tp = e->cart;
+    std::vector<StatAcc> accs(e->num_threads);
+#pragma omp parallel for schedule(static) num_threads(e->num_threads)
+    for (int en = 0; en < N; ++en) {
+        float tau[M::NDA];
+        const float a = fminf(fmaxf(actions[en], -tp.clip_actions), tp.clip_actions);
+        v.actions[en] = a;
+        tau[0] = a * tp.max_push_effort; tau[1] = 0.f;            // cartpole.py:159-163: effort on DoF 0 only
+        v.tau[en] = tau[0]; v.tau[N + en] = 0.f;
+        for (int c = 0; c < e->control_freq_inv; ++c) simulate_env<M>(v, e->P, en, tau);
+        cartpole_post_env(v, tp, en, accs[omp_get_thread_num()]);
+    }
+    for (const StatAcc& a : accs) { v.stats[0] += (float)a.fin_ret; v.stats[1] += (float)a.fin_len; v.stats[2] += (float)a.fin; v.stats[3] += (float)a.r; v.stats[4] += (float)a.cnt; }
+}
+
+extern "C" int mi_engine_step(MiEngine* e, const float* actions, void*) {
+    if (!e || !actions) return fail("mi_engine_step: null argument");
+    e->v.ring = (int)(e->steps & 1);
+    switch (e->task) {
+        case T_CARTPOLE: step_cartpole(e, actions); break;
+        case T_ANT: step_loco<ModelAnt, false>(e, actions); break;
+        case T_HUMANOID: step_loco<ModelHumanoid, true>(e, actions); break;
+        default: return fail("mi_engine_step: task not on the CPU backend");
+    }
+    e->steps++;
+    return 0;
+}
+template <class M>
+static void simulate_all(MiEngine* e) {
+    const View& v = e->v;
+#pragma omp parallel for schedule(static) num_threads(e->num_threads)
+    for (int en = 0; en < v.N; ++en) {
+        float tau[M::NDA];
+        load_tau<M>(v, en, tau);
+        simulate_env<M>(v, e->P, en, tau);
+    }
+}
+extern "C" int mi_engine_simulate(MiEngine* e, void*) {
+    if (!e) return fail("null engine");
+    switch (e->task) {
+        case T_CARTPOLE: simulate_all<ModelCartpole>(e); break;
+        case T_ANT: simulate_all<ModelAnt>(e); break;
+        case T_HUMANOID: simulate_all<ModelHumanoid>(e); break;
+        default: return fail("mi_engine_simulate: task not on the CPU backend");
+    }
+    return 0;
+}
+template <class M, bool HUM>
+static void reset_loco(MiEngine* e, const int64_t* ids, int n) {
+    using T = Loco<M::ND, 6 * M::NSENS, HUM>;
+    const View& v = e->v;
+    const int N = v.N;
+    for (int i = 0; i < n; ++i) {
+        const int en = (int)ids[i];
+        if (en < 0 || en >= N) continue;
+        float init_root[13], root[13], q[M::ND], qd[M::ND], pot, prev;
+        for (int k = 0; k < 13; ++k) init_root[k] = v.init_root[k * N + en];
+        const int ep = v.episode[en];
+        T::reset(e->loco, v.seed, (uint32_t)(v.env_offset + en), (uint32_t)ep, init_root, root, q, qd, &pot, &prev);
+        v.episode[en] = ep + 1;
+        for (int k = 0; k < 13; ++k) v.root[k * N + en] = root[k];
+        for (int k = 0; k < M::ND; ++k) { v.dof[k * N + en] = q[k]; v.dof[(M::ND + k) * N + en] = qd[k]; v.laml[k * N + en] = 0.f; }
+        for (int k = 0; k < 3 * M::NSPH; ++k) v.lamc[k * N + en] = 0.f;
+        if (M::NPG > 0 && v.lamp) for (int k = 0; k < 3 * M::NPG; ++k) v.lamp[k * N + en] = 0.f;
+        v.potentials[en] = pot; v.prev_potentials[en] = prev;
+        v.progress[en] = 0; v.reset[en] = 0;
+    }
+}
+extern "C" int mi_engine_reset_idx(MiEngine* e, const int64_t* env_ids, int n, void*) {
+    if (!e) return fail("null engine");
+    if (n <= 0) return 0;
+    if (!env_ids) return fail("mi_engine_reset_idx: null env_ids");
+    const View& v = e->v;
+    const int N = v.N;
+    switch (e->task) {
+        case T_CARTPOLE:
+            for (int i = 0; i < n; ++i) {
+                const int en = (int)env_ids[i];
+                if (en < 0 || en >= N) continue;
+                float q[2], qd[2];
+                const int ep = v.episode[en];
+                cartpole_reset(v.seed, (uint32_t)(v.env_offset + en), (uint32_t)ep, q, qd);
+                v.episode[en] = ep + 1;
+                for (int k = 0; k < 2; ++k) { v.dof[k * N + en] = q[k]; v.dof[(2 + k) * N + en] = qd[k]; v.laml[k * N + en] = 0.f; }
+                v.progress[en] = 0; v.reset[en] = 0;
+            }
+            break;
+        case T_ANT: reset_loco<ModelAnt, false>(e, env_ids, n); break;
+        case T_HUMANOID: reset_loco<ModelHumanoid, true>(e, env_ids, n); break;
+        default: return fail("mi_engine_reset_idx: task not on the CPU backend");
+    }
+    return 0;
+}

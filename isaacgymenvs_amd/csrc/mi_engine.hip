@@ -10,6 +10,7 @@
 
 #include "../../include/mi_engine.h"
 #include "step_kernels.hpp"
+#include "arena_layout.hpp"
 #include "gen/model_ant.h"
 #include "gen/model_cartpole.h"
 #include "gen/model_humanoid.h"
@@ -219,23 +220,6 @@ hipError_t launch_simulate_shadow_hand(const View& v, const HandView& hv, const 
 hipError_t launch_init_shadow_hand(const View& v, const HandView& hv, const HandParams& p, hipStream_t s);
 hipError_t launch_reset_shadow_hand(const View& v, const HandView& hv, const HandParams& p, const long long* ids, int n, hipStream_t s);
 }
-enum TaskId { T_CARTPOLE = 0, T_ANT = 1, T_HUMANOID = 2, T_ANYMAL = 3, T_SHADOWHAND = 4, T_ANYMAL_FLAT = 5, T_QUADCOPTER = 6 };
-constexpr int kNumTasks = 7;
-struct TaskMeta { const char* name; int nobs, nact, nd, nb, nsens, nsph, fixed; size_t pbytes; };
-static const TaskMeta kTasks[] = {
-    {"Cartpole", 4, 1, ModelCartpole::ND, ModelCartpole::NB, 0, ModelCartpole::NSPH, 1, sizeof(MiCartpoleParams)},
-    {"Ant", Loco<ModelAnt::ND, 6 * ModelAnt::NSENS, false>::NOBS, ModelAnt::ND, ModelAnt::ND, ModelAnt::NB, ModelAnt::NSENS, ModelAnt::NSPH, 0, sizeof(MiLocoParams)},
-    {"Humanoid", Loco<ModelHumanoid::ND, 6 * ModelHumanoid::NSENS, true>::NOBS, ModelHumanoid::ND, ModelHumanoid::ND, ModelHumanoid::NB, ModelHumanoid::NSENS, ModelHumanoid::NSPH, 0, sizeof(MiLocoParams)},
-    {"AnymalTerrain", kAnymalObs, kAnymalDof, ModelAnymal::ND, ModelAnymal::NB, 0, ModelAnymal::NSPH, 0, sizeof(MiAnymalParams)},
-    {"ShadowHand", 211, 20, ModelShadowHand::ND, ModelShadowHand::NB, ModelShadowHand::NSENS, 0, 1, sizeof(MiHandParams)},
-    {"Anymal", kAnymalFlatObs, kAnymalDof, ModelAnymal::ND, ModelAnymal::NB, 0, ModelAnymal::NSPH, 0, sizeof(MiAnymalFlatParams)},
-    {"Quadcopter", kQuadObs, kQuadAct, ModelQuadcopter::ND, ModelQuadcopter::NB, ModelQuadcopter::NSENS, ModelQuadcopter::NSPH, 0, sizeof(MiQuadcopterParams)},
-};
-static int find_task(const char* t) {
-    for (int i = 0; i < kNumTasks; ++i) if (!strcmp(t, kTasks[i].name)) return i;
-    return -1;
-}
-
 struct MiEngine {
     int task, N;
     SimParams P;
@@ -258,88 +242,6 @@ struct MiEngine {
     float* lamp_arena;     // the self-contact impulse tensor (Humanoid), kept while the option self_collision is 0
 };
 
-struct Layout {
-    std::vector<MiTensorDesc> d;
-    size_t off = 0;
-    size_t add(const char* name, int dtype, std::vector<int64_t> shape, std::vector<int64_t> stride, size_t count) {
-        static const size_t es[] = {4, 8, 1, 4};
-        off = (off + 255) & ~size_t(255);
-        MiTensorDesc t;
-        memset(&t, 0, sizeof(t));
-        snprintf(t.name, sizeof(t.name), "%s", name);
-        t.dtype = dtype; t.ndim = (int)shape.size();
-        for (size_t i = 0; i < shape.size(); ++i) { t.shape[i] = shape[i]; t.stride[i] = stride[i]; }
-        t.byte_offset = (int64_t)off;
-        d.push_back(t);
-        size_t o = off;
-        off += count * es[dtype];
-        return o;
-    }
-};
-
-// nobs: observation width; 0 = the task's (maximum) width.  ShadowHand's observationType variants are narrower.
-static void build_layout(int task, int N, Layout& L, View* v, char* base, int nobs = 0) {
-    const TaskMeta& m = kTasks[task];
-    const int64_t n = N, nd = m.nd, ns = m.nsens, nsp = m.nsph, no = nobs > 0 ? nobs : m.nobs, na = m.nact;
-    auto P = [&](size_t o) { return base ? base + o : (char*)nullptr; };
-    size_t o;
-    o = L.add("root_states", MI_F32, {n, 13}, {1, n}, 13 * n); if (v) v->root = (float*)P(o);
-    o = L.add("dof_state", MI_F32, {n, nd, 2}, {1, n, nd * n}, 2 * nd * n); if (v) v->dof = (float*)P(o);
-    o = L.add("dof_actuation_force", MI_F32, {n, nd}, {1, n}, nd * n); if (v) v->tau = (float*)P(o);
-    o = L.add("contact_impulse", MI_F32, {n, nsp > 0 ? nsp : 1, 3}, {1, 3 * n, n}, (nsp > 0 ? 3 * nsp : 3) * n); if (v) v->lamc = (float*)P(o);
-    o = L.add("limit_impulse", MI_F32, {n, nd}, {1, n}, nd * n); if (v) v->laml = (float*)P(o);
-    o = L.add("force_sensor", MI_F32, {n, ns > 0 ? ns : 1, 6}, {1, 6 * n, n}, (ns > 0 ? 6 * ns : 6) * n); if (v) v->sensor = (float*)P(o);
-    o = L.add("dof_force", MI_F32, {n, nd}, {1, n}, nd * n); if (v) v->dof_force = (float*)P(o);
-    o = L.add("potentials", MI_F32, {n}, {1}, n); if (v) v->potentials = (float*)P(o);
-    o = L.add("prev_potentials", MI_F32, {n}, {1}, n); if (v) v->prev_potentials = (float*)P(o);
-    o = L.add("up_vec", MI_F32, {n, 3}, {1, n}, 3 * n); if (v) v->up_vec = (float*)P(o);
-    o = L.add("heading_vec", MI_F32, {n, 3}, {1, n}, 3 * n); if (v) v->heading_vec = (float*)P(o);
-    o = L.add("actions", MI_F32, {n, na}, {1, n}, na * n); if (v) v->actions = (float*)P(o);
-    o = L.add("initial_root_states", MI_F32, {n, 13}, {1, n}, 13 * n); if (v) v->init_root = (float*)P(o);
-    o = L.add("obs_buf", MI_F32, {n, no}, {no, 1}, no * n); if (v) v->obs = (float*)P(o);
-    o = L.add("obs_out", MI_F32, {2, n, no}, {n * no, no, 1}, 2 * no * n); if (v) v->obs_out = (float*)P(o);
-    o = L.add("rew_buf", MI_F32, {n}, {1}, n); if (v) v->rew = (float*)P(o);
-    o = L.add("reset_buf", MI_I64, {n}, {1}, n); if (v) v->reset = (long long*)P(o);
-    o = L.add("progress_buf", MI_I64, {n}, {1}, n); if (v) v->progress = (long long*)P(o);
-    o = L.add("randomize_buf", MI_I64, {n}, {1}, n); if (v) v->randomize = (long long*)P(o);
-    o = L.add("timeout_buf", MI_U8, {n}, {1}, n); if (v) v->timeout = (unsigned char*)P(o);
-    o = L.add("episode_count", MI_I32, {n}, {1}, n); if (v) v->episode = (int*)P(o);
-    o = L.add("episode_return", MI_F32, {n}, {1}, n); if (v) v->ep_ret = (float*)P(o);
-    o = L.add("episode_stats", MI_F32, {8}, {1}, 8); if (v) v->stats = (float*)P(o);
-    if (task == T_ANT || task == T_HUMANOID) {
-        // per-env friction of the robot's shapes for `actor_params.<actor>.rigid_shape_properties.friction` domain randomisation
-        // (vec_task.py:752-828); negative = the model's own value
-        o = L.add("friction", MI_F32, {n}, {1}, n); if (v) v->friction = (float*)P(o);
-    }
-    if (task == T_HUMANOID) {
-        // the Humanoid actor collides with itself (collision filter 0, humanoid.py:194): warm-start impulses and contact forces of the
-        // limb-pair groups (normal + 2 tangents; force = world force on the first body of the group's contact, last sub-step)
-        const int64_t npg = ModelHumanoid::NPG;
-        o = L.add("self_contact_impulse", MI_F32, {n, npg, 3}, {1, 3 * n, n}, 3 * npg * n); if (v) v->lamp = (float*)P(o);
-        o = L.add("self_contact_force", MI_F32, {n, npg, 3}, {1, 3 * n, n}, 3 * npg * n); if (v) v->pairf = (float*)P(o);
-    }
-    if (task == T_ANYMAL) {   // anymal_terrain.py:117-168
-        const int64_t nb = m.nb;
-        o = L.add("net_contact_force", MI_F32, {n, nb, 3}, {1, 3 * n, n}, 3 * nb * n); if (v) v->netf = (float*)P(o);
-        o = L.add("commands", MI_F32, {n, 4}, {1, n}, 4 * n); if (v) v->commands = (float*)P(o);
-        o = L.add("last_actions", MI_F32, {n, nd}, {1, n}, nd * n); if (v) v->last_actions = (float*)P(o);
-        o = L.add("last_dof_vel", MI_F32, {n, nd}, {1, n}, nd * n); if (v) v->last_dof_vel = (float*)P(o);
-        o = L.add("feet_air_time", MI_F32, {n, 4}, {1, n}, 4 * n); if (v) v->feet_air_time = (float*)P(o);
-        o = L.add("episode_sums", MI_F32, {n, kAnymalSums}, {1, n}, kAnymalSums * n); if (v) v->episode_sums = (float*)P(o);
-        o = L.add("env_origins", MI_F32, {n, 3}, {1, n}, 3 * n); if (v) v->env_origins = (float*)P(o);
-        o = L.add("friction", MI_F32, {n}, {1}, n); if (v) v->friction = (float*)P(o);
-        o = L.add("terrain_levels", MI_I32, {n}, {1}, n); if (v) v->terrain_levels = (int*)P(o);
-        o = L.add("terrain_types", MI_I32, {n}, {1}, n); if (v) v->terrain_types = (int*)P(o);
-        o = L.add("episode_step_stats", MI_F32, {16}, {1}, 16); if (v) v->ep_stats = (float*)P(o);
-        o = L.add("episode_means", MI_F32, {16}, {1}, 16); if (v) v->ep_means = (float*)P(o);
-    }
-    if (task == T_ANYMAL_FLAT) {   // anymal.py:100-125
-        const int64_t nb = m.nb;
-        o = L.add("net_contact_force", MI_F32, {n, nb, 3}, {1, 3 * n, n}, 3 * nb * n); if (v) v->netf = (float*)P(o);
-        o = L.add("commands", MI_F32, {n, 3}, {1, n}, 3 * n); if (v) v->commands = (float*)P(o);
-    }
-    L.off = (L.off + 255) & ~size_t(255);
-}
 // Quadcopter extras (quadcopter.py:90-97)
 static void build_quad_layout(int N, Layout& L, QuadView* qv, char* base) {
     const int64_t n = N;
@@ -480,7 +382,7 @@ extern "C" int mi_engine_set_option(MiEngine* e, const char* key, double value) 
     // multi-wave sub-step (core/engine_mw.hpp): envs per workgroup, 0 = one wave per workgroup.  Ignored by tasks whose model has
     // no multi-wave form (Cartpole, Humanoid, ShadowHand, Quadcopter).
     if (!strcmp(key, "multi_wave")) {
-        if (value != 0 && value != 32 && !(MI_MW_HAS16 && value == 16)) return fail("multi_wave: 0 or 32 (envs per workgroup)");
+        if (value != 0 && value != 32 && !(MI_MW_HAS16 && value == 16)) return fail("multi_wave: 0, 16 or 32 (envs per workgroup)");
         e->v.mw = (int)value;
         return 0;
     }

@@ -8,26 +8,12 @@ namespace mi {
 
 // ------------------------------------------------------------------------------------------------ multi-wave sub-step
 // One env's sub-step spread over the 4 waves of a workgroup (core/engine_mw.hpp): blockDim = (64, NROLE), wave y = role y, lanes
-// 0 .. E-1 of every wave hold the same E envs (the other lanes retire at once).  Workgroups are dealt round-robin to the 8 XCDs, so
-// workgroup (x, j) = (id % 8, id / 8) takes the envs 64 * (8 * (j / SUBS) + x) + E * (j % SUBS) ...: the 64 / E workgroups that share a
-// 64-env group sit on the same XCD as the 64-lane post kernel block that reads their state next.
+// 0 .. E-1 of every wave hold the same E envs (the other lanes retire at once); env -> workgroup through xcd_env_base (step_kernels.hpp).
 struct DevBarrier {
     __device__ __forceinline__ void operator()() const { __syncthreads(); }
 };
 template <class M, int E>
 constexpr size_t mw_lds_bytes() { return (size_t)SimMW<M>::MW_SLOTS * E * sizeof(float); }
-template <int E>
-__device__ __forceinline__ int mw_env_base(int wg) {
-    constexpr int SUBS = 64 / E;
-    const int x = wg & 7, j = wg >> 3;
-    return 64 * (8 * (j / SUBS) + x) + E * (j % SUBS);
-}
-template <int E>
-inline int mw_grid(int N) {            // workgroups, rounded up so that the (x, j) mapping covers every env
-    constexpr int SUBS = 64 / E;
-    const int groups64 = (N + 63) / 64;
-    return ((groups64 + 7) / 8) * 8 * SUBS;
-}
 template <class M, class GND, int E, int R>
 __device__ __forceinline__ void mw_role(const View& v, const SimParams& P, const ActParams& ap, const float* __restrict__ actions_in,
                                         const int src, const GND& gnd, float* lds_rows, const int e, const int lane) {
@@ -101,7 +87,7 @@ __global__ __launch_bounds__(64 * M::NROLE) void substep_mw_kernel(View v, SimPa
     static_assert(M::NROLE == 4, "four roles, one per SIMD of a CU");
     const int lane = threadIdx.x;
     if (lane >= E) return;               // barriers count waves, not lanes: the upper lanes of every wave simply retire
-    const int e = mw_env_base<E>(blockIdx.x) + lane;
+    const int e = xcd_env_base<E>(blockIdx.x) + lane;
     if (e >= v.N) return;                // every wave of the workgroup holds the same envs, so all four agree on this
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.y);
     switch (role) {
@@ -121,12 +107,12 @@ hipError_t launch_substeps_mw(const View& v, const SimParams& P, const ActParams
     if (MI_MW_HAS16 && v.mw == 16) {
         auto kern = substep_mw_kernel<M, GND, MI_MW_HAS16 ? 16 : 32>;
         if (hipError_t e = ensure_dynamic_lds((const void*)kern, lds16, &conf16); e != hipSuccess) return e;
-        const dim3 grid(mw_grid<16>(v.N));
+        const dim3 grid(xcd_grid<16>(v.N));
         for (int i = 0; i < n_sub; ++i) hipLaunchKernelGGL(kern, grid, block, lds16, s, v, P, ap, actions, i == 0 ? first : rest, gnd);
     } else {
         auto kern = substep_mw_kernel<M, GND, 32>;
         if (hipError_t e = ensure_dynamic_lds((const void*)kern, lds32, &conf32); e != hipSuccess) return e;
-        const dim3 grid(mw_grid<32>(v.N));
+        const dim3 grid(xcd_grid<32>(v.N));
         for (int i = 0; i < n_sub; ++i) hipLaunchKernelGGL(kern, grid, block, lds32, s, v, P, ap, actions, i == 0 ? first : rest, gnd);
     }
     return hipGetLastError();

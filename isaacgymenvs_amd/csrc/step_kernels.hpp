@@ -14,58 +14,10 @@
 #include <cstdint>
 #include <type_traits>
 #include "core/engine.hpp"
+#include "arena.hpp"
 #include "tasks/locomotion.hpp"
 
 namespace mi {
-
-// ---------------------------------------------------------------------------------------------- arena view
-struct View {
-    int N;
-    int env_offset;
-    uint32_t seed;
-    int ring;  // which obs_out slot this step writes
-    int mw;    // multi-wave sub-step: envs per workgroup (16 or 32), 0 = one wave per workgroup (option "multi_wave")
-    float clip_obs;
-    float* root;        // [13][N]
-    float* dof;         // [2][ND][N]  (pos block, vel block)
-    float* tau;         // [ND][N]  dof_actuation_force
-    float* lamc;        // [3*NSPH][N]
-    float* laml;        // [ND][N]
-    float* sensor;      // [6*NSENS][N]
-    float* dof_force;   // [ND][N]
-    float* potentials;  // [N]
-    float* prev_potentials;
-    float* up_vec;      // [3][N]
-    float* heading_vec; // [3][N]
-    float* actions;     // [NACT][N]
-    float* init_root;   // [13][N]
-    float* obs;         // [N][NOBS] row-major
-    float* obs_out;     // [2][N][NOBS]
-    float* rew;         // [N]
-    long long* reset;   // [N]
-    long long* progress;
-    long long* randomize;
-    unsigned char* timeout;
-    int* episode;
-    // ---- actors that collide with themselves (Humanoid, reference humanoid.py:194); null otherwise / when switched off
-    float* lamp;        // [3*NPG][N] warm-start impulses of the self-contact groups
-    float* pairf;       // [3*NPG][N] world force on side a of each group's contact, last sub-step
-    float* ep_ret;      // [N] running return of the current episode
-    float* stats;       // [8] job statistics: sum finished returns, sum finished lengths, #finished, sum rewards, #env-steps
-    // ---- AnymalTerrain only (null otherwise)
-    float* netf;          // [3*NB][N] net contact force per body, world frame (gym net_contact_force tensor)
-    float* commands;      // [4][N] x vel, y vel, yaw vel, heading (anymal_terrain.py:140)
-    float* last_actions;  // [12][N]
-    float* last_dof_vel;  // [12][N]
-    float* feet_air_time; // [4][N]
-    float* episode_sums;  // [13][N]
-    float* env_origins;   // [3][N]
-    float* friction;      // [N] per-env shape friction (100 buckets, :236-239,279-281)
-    int* terrain_levels;  // [N]
-    int* terrain_types;   // [N]
-    float* ep_stats;      // [16] this step: sum of the 13 episode sums over resetting envs, #resets, sum terrain levels
-    float* ep_means;      // [16] extras["episode"]: rew_* means / max_episode_length_s, terrain_level mean (:421-425)
-};
 
 template <class M>
 __device__ __forceinline__ void load_sim(Sim<M>& s, const View& v, int e) {
@@ -136,7 +88,31 @@ enum ActSource { ACT_STORED_TAU = 0,      // v.tau as left by an earlier launch 
                  ACT_FROM_ACTIONS = 1,    // clamp the caller's row-major actions, store them in v.actions, derive tau
                  ACT_FROM_STORED_ACTIONS = 2 };  // PD mode: re-derive tau from v.actions and the current joint state
 
-// envs per workgroup (= per wave): 64, or 32 for models on the compact contact store (Sim<M>::COMPACT)
+// XCD-aware env mapping of workgroups that hold E < 64 envs.  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so
+// workgroup (x, j) = (id % 8, id / 8) takes the envs 64 * (8 * (j / SUBS) + x) + E * (j % SUBS) ...: every aligned group of 64 envs lives on
+// one XCD, whichever kernel (sub-step with 16 / 32 envs per workgroup, multi-wave sub-step, 32- or 64-lane post kernel) touches it next.
+// (A post kernel on another XCD than the sub-step made the next sub-step launch pull its state across L2s: +25 %, round 1.)
+template <int E>
+__device__ __forceinline__ int xcd_env_base(int wg) {
+    if constexpr (E >= 64) {
+        return wg * E;
+    } else {
+        constexpr int SUBS = 64 / E;
+        const int x = wg & 7, j = wg >> 3;
+        return 64 * (8 * (j / SUBS) + x) + E * (j % SUBS);
+    }
+}
+template <int E>
+inline int xcd_grid(int N) {           // workgroups, rounded up so that the (x, j) mapping covers every env
+    if constexpr (E >= 64) {
+        return (N + E - 1) / E;
+    } else {
+        constexpr int SUBS = 64 / E;
+        return (((N + 63) / 64 + 7) / 8) * 8 * SUBS;
+    }
+}
+
+// envs per workgroup (= per wave): 64, or 16 for models on the compact contact store (Sim<M>::COMPACT)
 template <class M>
 constexpr size_t lds_bytes() { return (size_t)Sim<M>::ROW_SLOTS * Sim<M>::LANES * sizeof(float); }
 template <class M>
@@ -147,7 +123,7 @@ __global__ __launch_bounds__(64) void substep_kernel(View v, SimParams P, ActPar
                                                      GND gnd) {
     extern __shared__ float lds_rows[];  // [ROW_SLOTS][LANES] when the model's rows fit (else unused, size 0)
     constexpr int ND = M::ND, LANES = Sim<M>::LANES;
-    const int e = blockIdx.x * LANES + threadIdx.x;
+    const int e = xcd_env_base<LANES>(blockIdx.x) + threadIdx.x;
     const int N = v.N;
     if (e >= N) return;                  // no cross-lane operation in here: tail lanes simply retire
     Sim<M> sim;
@@ -214,7 +190,7 @@ __global__ __launch_bounds__(64) void substep_kernel(View v, SimParams P, ActPar
 // ------------------------------------------------------------------------------------------------ multi-wave sub-step
 // (kernels in mw_kernels.hpp, instantiated in their own translation units kernels_mw_<model>.hip: they take minutes to compile)
 #ifndef MI_MW_HAS16
-#define MI_MW_HAS16 0          // also build the 16-envs-per-workgroup variant (A/B builds only: it doubles the compile time)
+#define MI_MW_HAS16 1          // also build the 16-envs-per-workgroup variant (best at <= 4096 envs; 0 halves the compile time of kernels_mw_*.hip)
 #endif
 template <class M, class GND>
 constexpr bool mw_capable() { return !Sim<M>::COMPACT && Sim<M>::LAM_IN_ROWS && !M::FIXED && M::NLIMB >= 3 && !std::is_same<GND, PlaneGroundNF>::value; }
@@ -250,13 +226,13 @@ __device__ __forceinline__ int post_env_index(int block, int lane, int N) {
 // wave touches 64 cache lines; with 32-env workgroups (half-filled waves, one per sub-step workgroup, same XCD) each store touches 32 and
 // twice as many CUs share the work: Humanoid step -0.6 % (fast box) to -2 % (slow box).  Ant (60 columns) showed no robust gain and keeps 64.
 template <class M>
-constexpr int post_lanes() { return Sim<M>::LANES == 32 ? 32 : 64; }
+constexpr int post_lanes() { return Sim<M>::LANES < 64 ? 32 : 64; }
 template <class M, bool HUM>
 __global__ __launch_bounds__(post_lanes<M>()) void loco_post_kernel(View v, LocoParams tp) {
     using T = Loco<M::ND, 6 * M::NSENS, HUM>;
     constexpr int ND = M::ND, NOBS = T::NOBS, PL = post_lanes<M>();
     const int N = v.N;
-    const int e0 = PL == 64 ? post_env_index<Sim<M>::LANES>(blockIdx.x, threadIdx.x, N) : blockIdx.x * 32 + threadIdx.x;
+    const int e0 = xcd_env_base<PL>(blockIdx.x) + threadIdx.x;
     const bool valid = e0 < N;           // tail lanes shadow the last env (no stores) so wave reductions stay full
     const int e = valid ? e0 : N - 1;
     float root[13], q[ND], qd[ND], dof_force[ND], sensor[6 * M::NSENS > 0 ? 6 * M::NSENS : 1], act[ND];
@@ -417,7 +393,7 @@ hipError_t launch_substeps(const View& v, const SimParams& P, const ActParams& a
     static unsigned long long configured = 0ull;
     if (hipError_t e = ensure_dynamic_lds((const void*)substep_kernel<M, GND>, lds, &configured); e != hipSuccess) return e;
     for (int i = 0; i < n_sub; ++i)
-        hipLaunchKernelGGL((substep_kernel<M, GND>), dim3((v.N + LANES - 1) / LANES), dim3(LANES), lds, s, v, P, ap, actions, i == 0 ? first : rest, gnd);
+        hipLaunchKernelGGL((substep_kernel<M, GND>), dim3(xcd_grid<LANES>(v.N)), dim3(LANES), lds, s, v, P, ap, actions, i == 0 ? first : rest, gnd);
     return hipGetLastError();
 }
 
@@ -443,7 +419,7 @@ hipError_t launch_loco_step(const View& v, const SimParams& P, const LocoParams&
     hipError_t e = launch_substeps<M>(v, P, ap, actions, cfi * P.substeps, ACT_FROM_ACTIONS, ACT_STORED_TAU, s);
     if (e != hipSuccess) return e;
     constexpr int PL = post_lanes<M>();
-    hipLaunchKernelGGL((loco_post_kernel<M, HUM>), dim3((v.N + PL - 1) / PL), dim3(PL), 0, s, v, tp);
+    hipLaunchKernelGGL((loco_post_kernel<M, HUM>), dim3(xcd_grid<PL>(v.N)), dim3(PL), 0, s, v, tp);
     return hipGetLastError();
 }
 template <class M>

@@ -13,6 +13,9 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MI_ENGINE_LIB lets tools/ab_bench.sh time two builds of the library inside one GPU session (never set in tests)
 LIB_PATH = os.environ.get("MI_ENGINE_LIB") or os.path.join(_HERE, "libmi_engine.so")
+# CPU product backend (sim_device="cpu": the reference's CPU pipeline, BASELINE config 1), built with g++ from the same engine sources
+CPU_LIB_PATH = os.path.join(_HERE, "libmi_engine_cpu.so")
+CPU_TASKS = ("Cartpole", "Ant", "Humanoid")
 CSRC = os.path.join(_HERE, "csrc")
 BUILD_DIR = os.path.join(CSRC, "build")
 # one translation unit per robot model (they compile in parallel) + the C ABI
@@ -185,7 +188,9 @@ def build(force=False, verbose=False):
     """
     from .registry import generate_headers
     generate_headers()
+    cpu_job = build_cpu(force=force, wait=False)        # g++ job of the CPU backend runs beside the hipcc jobs
     if not force and not needs_build():
+        _finish_cpu(cpu_job)
         return LIB_PATH
     os.makedirs(BUILD_DIR, exist_ok=True)
     hdrs = []
@@ -235,6 +240,7 @@ def build(force=False, verbose=False):
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd, cwd=CSRC)
     os.replace(tmp, LIB_PATH)
+    _finish_cpu(cpu_job)
     return LIB_PATH
 
 
@@ -258,18 +264,8 @@ def resource_usage():
     return out
 
 
-_lib = None
-
-
-def lib():
-    """Load the HIP library.  Fails loudly (no fallback) when it has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                           f"(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path.")
-    L = C.CDLL(LIB_PATH)
+def _bind_lifecycle(L):
+    """ctypes signatures of the engine lifecycle entry points (the part of include/mi_engine.h both libraries export)."""
     L.mi_last_error.restype = C.c_char_p
     L.mi_engine_arena_bytes.restype = C.c_size_t
     L.mi_engine_arena_bytes.argtypes = [C.c_char_p, C.c_int]
@@ -289,6 +285,77 @@ def lib():
     L.mi_engine_last_ring.argtypes = [C.c_void_p]
     L.mi_engine_set_terrain.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p,
                                         C.c_int, C.c_int, C.c_float, C.c_int]
+    return L
+
+
+_lib_cpu = None
+
+
+def cpu_needs_build():
+    if not os.path.exists(CPU_LIB_PATH):
+        return True
+    t = os.path.getmtime(CPU_LIB_PATH)
+    deps = [os.path.join(CSRC, "cpu", "mi_engine_cpu.cpp"), os.path.join(CSRC, "arena.hpp"), os.path.join(CSRC, "arena_layout.hpp"),
+            os.path.join(CSRC, "core", "engine.hpp"), os.path.join(CSRC, "tasks", "locomotion.hpp"), os.path.join(_HERE, "..", "include", "mi_engine.h")]
+    deps += [os.path.join(CSRC, "gen", f) for f in os.listdir(os.path.join(CSRC, "gen"))]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_cpu(force=False, wait=True):
+    """g++ build of the CPU backend (csrc/cpu/mi_engine_cpu.cpp: engine.hpp + tasks/locomotion.hpp on the host, OpenMP over envs).
+    Returns the Popen when wait=False (build() overlaps it with the hipcc jobs)."""
+    from .registry import generate_headers
+    generate_headers()
+    if not force and not cpu_needs_build():
+        return None
+    tmp = CPU_LIB_PATH + ".tmp"
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", os.path.join(CSRC, "cpu", "mi_engine_cpu.cpp"),
+           "-o", tmp]
+    os.makedirs(BUILD_DIR, exist_ok=True)
+    log = open(os.path.join(BUILD_DIR, "mi_engine_cpu.log"), "w")
+    p = subprocess.Popen(cmd, cwd=CSRC, stdout=log, stderr=subprocess.STDOUT)
+    p._mi_finish = lambda: (log.close(), os.replace(tmp, CPU_LIB_PATH))
+    if not wait:
+        return p
+    _finish_cpu(p)
+    return None
+
+
+def _finish_cpu(p):
+    if p is None:
+        return
+    rc = p.wait()
+    if rc != 0:
+        with open(os.path.join(BUILD_DIR, "mi_engine_cpu.log")) as f:
+            print(f.read()[-4000:])
+        raise RuntimeError("g++ failed for the CPU backend (csrc/cpu/mi_engine_cpu.cpp)")
+    p._mi_finish()
+
+
+def lib_cpu():
+    """Load the CPU backend.  Fails loudly when it has not been built (there is no fallback onto anything else)."""
+    global _lib_cpu
+    if _lib_cpu is not None:
+        return _lib_cpu
+    if not os.path.exists(CPU_LIB_PATH):
+        raise RuntimeError(f"{CPU_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    _lib_cpu = _bind_lifecycle(C.CDLL(CPU_LIB_PATH))
+    return _lib_cpu
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library.  Fails loudly (no fallback) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           f"(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path.")
+    L = C.CDLL(LIB_PATH)
+    _bind_lifecycle(L)
     L.mi_compute_locomotion_observations.argtypes = [C.c_char_p, C.c_int, C.POINTER(MiLocoParams)] + [C.c_void_p] * 18
     L.mi_compute_locomotion_reward.argtypes = [C.c_char_p, C.c_int, C.POINTER(MiLocoParams)] + [C.c_void_p] * 9
     L.mi_compute_cartpole_reward.argtypes = [C.c_int, C.POINTER(MiCartpoleParams)] + [C.c_void_p] * 9
@@ -326,14 +393,17 @@ def lib():
     return L
 
 
-def check(rc):
+def check(rc, L=None):
     if rc != 0:
-        raise RuntimeError("mi_engine: " + (lib().mi_last_error() or b"?").decode())
+        raise RuntimeError("mi_engine: " + ((L or lib()).mi_last_error() or b"?").decode())
 
 
 def task_info(task):
+    """Static facts of a task (observation / action widths ...).  Answered by whichever library is present: the table is shared
+    (csrc/arena_layout.hpp), so a CPU-only install can still size its buffers."""
     info = MiTaskInfo()
-    check(lib().mi_task_info(task.encode(), C.byref(info)))
+    L = lib() if os.path.exists(LIB_PATH) else lib_cpu()
+    check(L.mi_task_info(task.encode(), C.byref(info)), L)
     return info
 
 
@@ -353,29 +423,35 @@ class Engine:
 
     def __init__(self, task, sim_params: MiSimParams, task_params, num_envs, device, seed=0, env_id_offset=0, terrain=None):
         import torch
-        L = lib()
         dev = torch.device(device)
-        if dev.type != "cuda":
-            raise RuntimeError("the MI355X engine runs on ROCm devices only (sim_device='cuda:N'); "
-                               "there is no CPU product path -- the CPU oracle lives in oracle/ for tests only")
-        if not torch.cuda.is_available():
-            raise RuntimeError("no ROCm device visible to PyTorch")
+        if dev.type == "cpu":
+            # the reference's CPU pipeline (sim_device=cpu): the engine's own host build, OpenMP over envs -- not the test oracle
+            if task not in CPU_TASKS:
+                raise RuntimeError(f"task {task} runs on the MI355X only (sim_device='cuda:N'); the CPU backend has {', '.join(CPU_TASKS)}")
+            L = lib_cpu()
+        elif dev.type == "cuda":
+            if not torch.cuda.is_available():
+                raise RuntimeError("no ROCm device visible to PyTorch")
+            L = lib()
+        else:
+            raise RuntimeError(f"unsupported sim device {device!r}")
+        self.L = L
         self.task, self.N, self.device = task, num_envs, dev
         nbytes = L.mi_engine_arena_bytes(task.encode(), num_envs)
         if nbytes == 0:
-            check(-1)
+            check(-1, L)
         self.arena = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
         self._sim, self._tp = sim_params, task_params
         h = C.c_void_p()
         check(L.mi_engine_create(task.encode(), C.byref(sim_params), C.cast(C.byref(task_params), C.c_void_p),
                                  C.sizeof(task_params), num_envs, env_id_offset, seed & 0xFFFFFFFFFFFFFFFF,
-                                 self.arena.data_ptr(), nbytes, C.byref(h)))
+                                 self.arena.data_ptr(), nbytes, C.byref(h)), L)
         self.h = h
         self.tensors = {}
         dts = _dtypes()
         for i in range(L.mi_engine_num_tensors(h)):
             d = MiTensorDesc()
-            check(L.mi_engine_tensor_desc(h, i, C.byref(d)))
+            check(L.mi_engine_tensor_desc(h, i, C.byref(d)), L)
             dt = dts[d.dtype]
             esz = torch.empty(0, dtype=dt).element_size()
             shape = [d.shape[k] for k in range(d.ndim)]
@@ -394,37 +470,42 @@ class Engine:
                                           self.terrain_origins.data_ptr(), self.terrain_origins.shape[0],
                                           self.terrain_origins.shape[1], float(terrain.env_length),
                                           int(getattr(terrain, "max_init_level", 0))))
-        with torch.cuda.device(dev):
-            check(L.mi_engine_init_state(h, self._stream()))
+        if dev.type == "cuda":
+            with torch.cuda.device(dev):
+                check(L.mi_engine_init_state(h, self._stream()), L)
+        else:
+            check(L.mi_engine_init_state(h, None), L)
 
     def _stream(self):
+        if self.device.type != "cuda":
+            return None
         import torch
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def step(self, actions):
-        check(lib().mi_engine_step(self.h, actions.data_ptr(), self._stream()))
+        check(self.L.mi_engine_step(self.h, actions.data_ptr(), self._stream()), self.L)
 
     def simulate(self):
-        check(lib().mi_engine_simulate(self.h, self._stream()))
+        check(self.L.mi_engine_simulate(self.h, self._stream()), self.L)
 
     def reset_idx(self, env_ids):
         if env_ids.numel():
-            check(lib().mi_engine_reset_idx(self.h, env_ids.data_ptr(), env_ids.numel(), self._stream()))
+            check(self.L.mi_engine_reset_idx(self.h, env_ids.data_ptr(), env_ids.numel(), self._stream()), self.L)
 
     def set_option(self, key, value):
-        check(lib().mi_engine_set_option(self.h, key.encode(), float(value)))
+        check(self.L.mi_engine_set_option(self.h, key.encode(), float(value)), self.L)
 
     def get_option(self, key):
         out = C.c_double()
-        check(lib().mi_engine_get_option(self.h, key.encode(), C.byref(out)))
+        check(self.L.mi_engine_get_option(self.h, key.encode(), C.byref(out)), self.L)
         return out.value
 
     def last_ring(self):
-        return lib().mi_engine_last_ring(self.h)
+        return self.L.mi_engine_last_ring(self.h)
 
     def close(self):
         if getattr(self, "h", None):
-            lib().mi_engine_destroy(self.h)
+            self.L.mi_engine_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -34,11 +34,8 @@ class Env:
             else:
                 print("GPU Pipeline can only be used with GPU simulation. Forcing CPU Pipeline.")
                 config["sim"]["use_gpu_pipeline"] = False
-        if self.device == "cpu":
-            # the reference would now run PhysX-CPU; this engine has no CPU product path by design
-            raise RuntimeError(
-                "isaacgymenvs_amd: sim_device/pipeline 'cpu' is not available -- the engine is MI355X-native "
-                "(use sim_device='cuda:N', pipeline='gpu').  The CPU restatement lives in oracle/ for tests only.")
+        # self.device == "cpu": the reference runs PhysX-CPU here (vec_task.py:78-88); this engine runs its own host build (OpenMP over
+        # envs, csrc/cpu/mi_engine_cpu.cpp) for the tasks that have one -- native.Engine raises for the others
         self.rl_device = rl_device
         self.headless = headless
         enable_camera_sensors = config["env"].get("enableCameraSensors", False)
@@ -154,7 +151,26 @@ class VecTask(Env):
         if np.isfinite(self.clip_obs):
             self.engine.set_option("clip_obs", self.clip_obs)
         self.engine.set_option("control_freq_inv", self.control_freq_inv)
+        if self.device == "cpu":
+            # sim.physx.num_threads (vec_task.py:541; cfg/config.yaml:30 default 4): worker threads of the CPU pipeline
+            self.engine.set_option("num_threads", max(1, int(self.cfg["sim"].get("physx", {}).get("num_threads", 4))))
+        else:
+            self._select_multi_wave()
         self.sim = self.engine  # what the reference calls self.sim
+
+    def _select_multi_wave(self):
+        """Launch shape of the physics sub-step (csrc/core/engine_mw.hpp).  `sim.multi_wave`: "auto" (default), 0, 16 or 32 envs per
+        workgroup.  auto: the multi-wave form while its 4 * N / E waves still find a SIMD each (1024 on an MI355X) -- measured
+        1.4x faster at 4096 envs, slower from 16384 envs on (profiles/r2b_mw_ab.txt); tasks without a multi-wave form ignore it."""
+        mw = self.cfg["sim"].get("multi_wave", "auto")
+        if mw == "auto":
+            mw = 16 if self.num_envs <= 4096 else (32 if self.num_envs <= 8192 else 0)
+        for cand in (int(mw), 32):
+            try:
+                self.engine.set_option("multi_wave", cand)
+                return
+            except RuntimeError:
+                continue
 
     def _task_params(self):
         raise NotImplementedError

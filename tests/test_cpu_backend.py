@@ -1,0 +1,107 @@
+"""CPU product backend (isaacgymenvs_amd/csrc/cpu/mi_engine_cpu.cpp): the reference's `sim_device=cpu pipeline=cpu` configuration --
+BASELINE.json config 1 is `Cartpole num_envs=64 sim_device=cpu pipeline=cpu` -- served by the engine's own host build (the sources
+of the HIP kernels compiled with g++, OpenMP over envs), never by oracle/.  Here: through the public make() / VecTask API against
+the independent CPU restatement, on identical seeds and actions."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import isaacgymenvs_amd
+from isaacgymenvs_amd import native
+from isaacgymenvs_amd.registry import load_model, load_selfcol, sensor_bodies
+from isaacgymenvs_amd.tasks.cartpole import cartpole_params_from_cfg
+from isaacgymenvs_amd.tasks.locomotion import loco_params_from_cfg
+from isaacgymenvs_amd.utils.config import compose
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    native.build_cpu()
+
+
+def _sim_dict(p):
+    return dict(dt=float(p.dt), substeps=int(p.substeps), iters=int(p.iters), gravity=tuple(float(p.gravity[i]) for i in range(3)),
+                contact_offset=float(p.contact_offset), rest_offset=float(p.rest_offset), max_depen_vel=float(p.max_depen_vel),
+                erp=float(p.erp), plane_mu=float(p.plane_mu), ground_z=float(p.ground_z), cfm=float(p.cfm), warm=float(p.warm))
+
+
+def test_cartpole_64_on_cpu_matches_the_cpu_restatement():
+    """BASELINE config 1 as specified: make(seed, "Cartpole", 64, "cpu", "cpu")."""
+    from oracle.tasks import OracleCartpoleEnv
+    n, seed = 64, 2
+    env = isaacgymenvs_amd.make(seed=seed, task="Cartpole", num_envs=n, sim_device="cpu", rl_device="cpu", headless=True)
+    assert env.device == "cpu" and env.obs_buf.device.type == "cpu" and env.reset_buf.dtype == torch.int64
+    assert env.cfg["sim"]["use_gpu_pipeline"] is False                        # forced like the reference does (vec_task.py:84-88)
+    assert int(env.engine.get_option("num_threads")) == 4                     # cfg/config.yaml:30
+    cfg = compose(overrides=["task=Cartpole"])["task"]
+    orc = OracleCartpoleEnv(load_model("cartpole"), _sim_dict(env.sim_params), cartpole_params_from_cfg(cfg), n, seed=seed, precision="f64")
+    g = torch.Generator(device="cpu").manual_seed(9)
+    for step in range(60):
+        a = torch.rand((n, 1), generator=g) * 2 - 1
+        obs_d, rew, reset, extras = env.step(a)
+        o_obs, o_rew, o_reset = orc.step(a.numpy())
+        np.testing.assert_allclose(env.obs_buf.numpy(), o_obs, atol=2e-3 * (1 + step / 10))
+        np.testing.assert_array_equal(reset.numpy(), o_reset)
+        assert obs_d["obs"].abs().max() <= 5.0 + 1e-6                          # clipObservations (Cartpole.yaml)
+    np.testing.assert_allclose(rew.numpy(), o_rew, atol=2e-2)
+    assert extras["time_outs"].dtype == torch.bool
+    # reset_done / reset_idx / zero_actions work on the host arena too
+    env.reset_buf[:] = 1
+    _, done = env.reset_done()
+    assert len(done) == n and int(env.progress_buf.abs().sum()) == 0
+    assert env.zero_actions().shape == (n, 1)
+
+
+@pytest.mark.parametrize("task,hum,z0", [("Ant", False, 0.44), ("Humanoid", True, 1.34)])
+def test_locomotion_on_cpu_matches_the_cpu_restatement(task, hum, z0):
+    from oracle.tasks import OracleLocomotionEnv
+    n, seed = 48, 11
+    env = isaacgymenvs_amd.make(seed=seed, task=task, num_envs=n, sim_device="cpu", rl_device="cpu", headless=True)
+    spec = load_model(task.lower())
+    cfg = compose(overrides=[f"task={task}"])["task"]
+    p = loco_params_from_cfg(cfg, task.lower(), z0)
+    sc = load_selfcol(task.lower())
+    orc = OracleLocomotionEnv(hum, spec, sensor_bodies(task.lower()), _sim_dict(env.sim_params), p, n, seed=seed, precision="f64",
+                              **(dict(selfcol=sc, kmax=12, kpair=3) if sc else {}))
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for step in range(6):
+        a = torch.rand((n, env.num_actions), generator=g) * 2 - 1
+        obs_d, rew, reset, _ = env.step(a)
+        o_obs, o_rew, o_reset = orc.step(a.numpy())
+        np.testing.assert_array_equal(env.progress_buf.numpy(), orc.progress_buf)
+        if step == 0:
+            np.testing.assert_allclose(env.dof_pos.numpy(), orc.eng.q, atol=1e-6)       # same counter-based reset draws
+        d = np.abs(obs_d["obs"].numpy() - o_obs)
+        d[:, [7, 8, 9]] = np.minimum(d[:, [7, 8, 9]], np.abs(d[:, [7, 8, 9]] - 2 * np.pi))
+        assert (d.max(axis=1) < 2e-3 * (1 + step) * (4 if hum else 1)).mean() > 0.95, (task, step, d.max())
+        assert (reset.numpy() == o_reset).mean() > 0.97
+    assert torch.isfinite(env.obs_buf).all()
+
+
+def test_cpu_backend_scope_and_threads():
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        isaacgymenvs_amd.make(seed=0, task="ShadowHand", num_envs=8, sim_device="cpu", rl_device="cpu", headless=True)
+    env = isaacgymenvs_amd.make(seed=0, task="Cartpole", num_envs=8, sim_device="cpu", rl_device="cpu", headless=True)
+    env.engine.set_option("num_threads", 2)
+    a = torch.zeros((8, 1))
+    r1 = env.step(a)[0]["obs"].clone()
+    env2 = isaacgymenvs_amd.make(seed=0, task="Cartpole", num_envs=8, sim_device="cpu", rl_device="cpu", headless=True)
+    env2.engine.set_option("num_threads", 1)
+    assert torch.equal(r1, env2.step(a)[0]["obs"])                            # the thread count does not change results
+    # the CPU library is built from the engine sources, not from the test oracle
+    src = open(os.path.join(os.path.dirname(native.__file__), "csrc", "cpu", "mi_engine_cpu.cpp")).read()
+    assert '#include "../core/engine.hpp"' in src and "physics.c" not in src.replace("oracle/", "")
+
+
+def test_reference_user_script_runs_unedited():
+    """reference README.md:33-51 `import isaacgymenvs; envs = isaacgymenvs.make(...)` with the alias package."""
+    import isaacgymenvs
+    envs = isaacgymenvs.make(seed=0, task="Cartpole", num_envs=16, sim_device="cpu", rl_device="cpu")
+    assert envs.observation_space.shape == (4,) and envs.action_space.shape == (1,)
+    obs = envs.reset()
+    for _ in range(5):
+        random_actions = 2.0 * torch.rand((16,) + envs.action_space.shape, device="cpu") - 1.0
+        envs.step(random_actions)
+    assert obs["obs"].shape == (16, 4)
