@@ -166,7 +166,13 @@ def reference_jit_leg(task, num_envs, budget_s=4.0):
         import torch
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import gen_golden
-        mod = gen_golden.import_reference()["ant"]
+        saved = {k: v for k, v in sys.modules.items() if k == "isaacgymenvs" or k.startswith("isaacgymenvs.")}
+        try:
+            mod = gen_golden.import_reference()["ant"]          # registers the REFERENCE tree under the name `isaacgymenvs` ...
+        finally:                                                 # ... which must not shadow this repo's alias package afterwards
+            for k in [k for k in sys.modules if k == "isaacgymenvs" or k.startswith("isaacgymenvs.")]:
+                del sys.modules[k]
+            sys.modules.update(saved)
         n = num_envs
         g = torch.Generator().manual_seed(0)
         root = torch.randn(n, 13, generator=g); root[:, 3:7] = torch.nn.functional.normalize(root[:, 3:7], dim=-1)
