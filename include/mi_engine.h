@@ -210,6 +210,19 @@ int mi_engine_set_terrain(MiEngine* e, const int16_t* height_samples, int rows, 
  * envs -- same results up to summation order, see csrc/core/engine_mw.hpp; other tasks ignore it),
  * "steps" (the control-step counter: observation-ring parity and per-step RNG counters; restore it together with the arena) */
 int mi_engine_set_option(MiEngine* e, const char* key, double value);
+/* Observation (which = 0) / action (which = 1) noise of the domain randomisation, applied inside the step kernels (replaces the
+ * `noise_lambda` closures the reference builds in VecTask.apply_randomizations, vec_task.py:650-718, and runs as torch ops on the
+ * buffers every step, :371-372,397-399).  value = op(x, corr + white): `white` ~ N(a, b) or U(a, b) fresh every step, `corr` a
+ * per-(env, element) normal draw made once, scaled by (a_corr, b_corr); the host passes ranges already blended by the schedule.
+ * dist 0 switches the noise off.  Cartpole, Ant, Humanoid. */
+typedef struct MiNoiseParams {
+    int32_t dist;          /* 0 off, 1 gaussian, 2 uniform */
+    int32_t op;            /* 0 additive, 1 scaling */
+    float a, b;            /* gaussian: mean, std; uniform: low, high */
+    float a_corr, b_corr;  /* the same for the correlated part */
+    uint32_t epoch;        /* stream id of the correlated draws (0: sampled once, as the reference does) */
+} MiNoiseParams;
+int mi_engine_set_noise(MiEngine* e, int which, const MiNoiseParams* params);
 /* reads back any of the keys of mi_engine_set_option (replaces gym.get_sim_params / gym.get_frame_count, vec_task.py:620,723) */
 int mi_engine_get_option(const MiEngine* e, const char* key, double* value);
 /* which slot of the "obs_out" ring ([2, N, num_obs], clamped copy of obs_buf = what VecTask.step returns as

@@ -1,6 +1,7 @@
 // arena.hpp -- the view of the caller-owned SoA arena that every kernel (and the CPU backend) receives.  No HIP dependency.
 #pragma once
 #include <cstdint>
+#include "core/rng.hpp"
 
 namespace mi {
 
@@ -12,6 +13,9 @@ struct View {
     int ring;  // which obs_out slot this step writes
     int mw;    // multi-wave sub-step: envs per workgroup (16 or 32), 0 = one wave per workgroup (option "multi_wave")
     float clip_obs;
+    unsigned step;      // control-step counter of this step() (white-noise stream of the in-kernel observation / action noise)
+    NoiseParams obs_noise, act_noise;   // domain randomisation noise on observations / actions (dist 0: off), mi_engine_set_noise
+    float* actor_scale; // [4][N] per-env scale of link masses, joint damping, stiffness, armature (`actor_params`), null: task has none
     float* root;        // [13][N]
     float* dof;         // [2][ND][N]  (pos block, vel block)
     float* tau;         // [ND][N]  dof_actuation_force

@@ -89,6 +89,9 @@ static void build_layout(int task, int N, Layout& L, View* v, char* base, int no
         // per-env friction of the robot's shapes for `actor_params.<actor>.rigid_shape_properties.friction` domain randomisation
         // (vec_task.py:752-828); negative = the model's own value
         o = L.add("friction", MI_F32, {n}, {1}, n); if (v) v->friction = (float*)P(o);
+        // per-env scale of the actor's link masses and joint damping / stiffness / armature (`actor_params.<actor>.rigid_body_properties.mass`,
+        // `.dof_properties.*`); 1 = the model's own values
+        o = L.add("actor_scale", MI_F32, {n, 4}, {1, n}, 4 * n); if (v) v->actor_scale = (float*)P(o);
     }
     if (task == T_HUMANOID) {
         // the Humanoid actor collides with itself (collision filter 0, humanoid.py:194): warm-start impulses and contact forces of the

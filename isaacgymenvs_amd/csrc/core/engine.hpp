@@ -351,6 +351,16 @@ struct Sim {
     //      stay in memory (Strided views) and are touched exactly once per sub-step
     float root[13];               // pos3, quat xyzw, linvel3, angvel3 (world)
     float q[M::NDA], qd[M::NDA];
+    // `actor_params` domain randomisation (reference vec_task.py:752-828: rigid_body_properties.mass, dof_properties.damping /
+    // stiffness / armature): per-env scale factors of the model's link masses + inertias and joint constants.  Only the models that
+    // carry the "actor_scale" tensor (M::ACTOR_SCALES, Ant and Humanoid) multiply by them; for the others the constants stay literals.
+    static constexpr bool SCALED = M::ACTOR_SCALES != 0;
+    // [4] mass, damping, stiffness, armature factors of this env (strided like every per-env vector), or p == nullptr.  They are
+    // loaded where they are used -- at the start of the right-hand-side phase and again for the joint forces at the end -- instead of
+    // living in registers through the whole sub-step: the joint-space inertia H and the bias forces are linear in the link masses,
+    // so the tree pass runs on the model's own masses and H, bias are scaled afterwards (keeping four more values live through the
+    // tree pass cost the Humanoid kernel 220 additional spilled registers and 1.8x its run time).
+    Strided actor_scale{nullptr, 1};
 #if defined(MI_TIMING)
     unsigned long long* tstamp = nullptr;
 #endif
@@ -715,11 +725,20 @@ struct Sim {
         // ------------------------------------------------------------ rhs, implicit spring/damper on the diagonal
         float Ldi[NVA];  // 1 / L_ii
         float y[NVA];
+        float sc_damp = 1.f, sc_stiff = 1.f, sc_arm = 1.f;
+        if constexpr (SCALED) {
+            if (actor_scale.p != nullptr) {
+                const float sc_mass = actor_scale(0);
+                sc_damp = actor_scale(1); sc_stiff = actor_scale(2); sc_arm = actor_scale(3);
+                sfor<M::NM>([&](auto E_) MI_LAMBDA { L[E_] *= sc_mass; });
+                sfor<NV>([&](auto I) MI_LAMBDA { c.bias[I] *= sc_mass; });
+            }
+        }
         sfor<OFF>([&](auto I) MI_LAMBDA { y[I] = -c.bias[I]; });
         sfor<ND>([&](auto D) MI_LAMBDA {
             constexpr int d = D, gi = OFF + d;
-            constexpr float K = M::dof_stiffness[d], Dm = M::dof_damping[d];
-            L[M::midx[gi][gi]] += M::dof_armature[d] + h * Dm + h * h * K;
+            const float K = M::dof_stiffness[d] * sc_stiff, Dm = M::dof_damping[d] * sc_damp;
+            L[M::midx[gi][gi]] += M::dof_armature[d] * sc_arm + h * Dm + h * h * K;
             y[gi] = tau[d] - c.bias[gi] - K * (q[d] - M::dof_springref[d]) - (Dm + h * K) * qd[d];
             if (drv) {   // position drive: the same implicit linearisation as the passive spring / damper
                 L[M::midx[gi][gi]] += h * drv->kd + h * h * drv->kp;
@@ -1455,6 +1474,8 @@ struct Sim {
         });
         MI_PHASE();
         // ------------------------------------------------------------ impulses -> warm start, sensors, dof forces
+        float fs_damp = 1.f, fs_stiff = 1.f;
+        if constexpr (SCALED) { if (actor_scale.p != nullptr) { fs_damp = actor_scale(1); fs_stiff = actor_scale(2); } }
         sfor<ND>([&](auto D) MI_LAMBDA {
             constexpr int d = D;
             float ll = 0.f;
@@ -1464,7 +1485,7 @@ struct Sim {
                 ll = (dl < du) ? lam(row) : -lam(row);
             }
             laml(d) = ll;
-            float df = tau[d] - M::dof_stiffness[d] * (q[d] - M::dof_springref[d]) - M::dof_damping[d] * v[OFF + d] + ll * invh;
+            float df = tau[d] - M::dof_stiffness[d] * fs_stiff * (q[d] - M::dof_springref[d]) - M::dof_damping[d] * fs_damp * v[OFF + d] + ll * invh;
             if (drv) df += drv->kp * (drv->target[d] - q[d]) - drv->kd * v[OFF + d];
             dof_force(d) = df;
         });

@@ -50,12 +50,13 @@ struct SimMW : Sim<M> {
     static constexpr int tslot(int b) { int n = 0; for (int k = 0; k < b; ++k) n += trunk_body(k) ? 1 : 0; return n; }
     static constexpr int NVT = []() constexpr { int n = 0; for (int i = 0; i < NV; ++i) n += trunk_gi(i) ? 1 : 0; return n; }();
     static constexpr int tidx(int gi) { int n = 0; for (int k = 0; k < gi; ++k) n += trunk_gi(k) ? 1 : 0; return n; }
-    static constexpr bool trunk_entry(int e) {      // is L entry e = (i, j) with i a trunk index (then j, an ancestor, is one too)
+    static constexpr int entry_row(int e) {         // row i of the L entry e = (i, j)
         for (int i = 0; i < NV; ++i)
             for (int j = 0; j <= i; ++j)
-                if (M::midx[i][j] == e) return trunk_gi(i);
-        return false;
+                if (M::midx[i][j] == e) return i;
+        return 0;
     }
+    static constexpr bool trunk_entry(int e) { return trunk_gi(entry_row(e)); }      // (i, j) with i a trunk index: then j, an ancestor, is one too
     static constexpr int NTE = []() constexpr { int n = 0; for (int e = 0; e < M::NM; ++e) n += trunk_entry(e) ? 1 : 0; return n; }();
     static constexpr int teidx(int e) { int n = 0; for (int k = 0; k < e; ++k) n += trunk_entry(k) ? 1 : 0; return n; }
     static constexpr bool limb_root(int b) { return b > 0 && !trunk_body(b) && trunk_body(M::parent[b]); }
@@ -133,11 +134,20 @@ struct SimMW : Sim<M> {
         // hold exactly this role's Schur complement / right-hand-side carry
         sfor<M::NM>([&](auto E_) MI_LAMBDA { if constexpr (trunk_entry(E_)) L[E_] = 0.f; });
         sfor<NV>([&](auto I) MI_LAMBDA { if constexpr (trunk_gi(I)) y[I] = 0.f; });
+        // `actor_params` scale factors (see Sim::actor_scale): H and the bias forces are linear in the masses -> scaled after the tree pass
+        float sc_mass = 1.f, sc_damp = 1.f, sc_stiff = 1.f, sc_arm = 1.f;
+        if constexpr (B::SCALED) {
+            if (this->actor_scale.p != nullptr) {
+                sc_mass = this->actor_scale(0); sc_damp = this->actor_scale(1); sc_stiff = this->actor_scale(2); sc_arm = this->actor_scale(3);
+                sfor<M::NM>([&](auto E_) MI_LAMBDA { if constexpr (role_of_gi(entry_row(E_)) == R) L[E_] *= sc_mass; });     // rows of the own limbs
+                sfor<NV>([&](auto I) MI_LAMBDA { if constexpr (role_of_gi(I) == R) c.bias[I] *= sc_mass; });
+            }
+        }
         sfor<ND>([&](auto D) MI_LAMBDA {
             constexpr int d = D, gi = OFF + d;
             if constexpr (role_of_gi(gi) == R) {
-                constexpr float K = M::dof_stiffness[d], Dm = M::dof_damping[d];
-                L[M::midx[gi][gi]] += M::dof_armature[d] + h * Dm + h * h * K;
+                const float K = M::dof_stiffness[d] * sc_stiff, Dm = M::dof_damping[d] * sc_damp;
+                L[M::midx[gi][gi]] += M::dof_armature[d] * sc_arm + h * Dm + h * h * K;
                 y[gi] = tau[d] - c.bias[gi] - K * (q[d] - M::dof_springref[d]) - (Dm + h * K) * qd[d];
             }
         });
@@ -202,12 +212,18 @@ struct SimMW : Sim<M> {
                 this->template body_up<b>(c, t);
             }
         });
+        if constexpr (B::SCALED) {       // the trunk's own H entries and bias forces, just written by body_up
+            if (this->actor_scale.p != nullptr) {
+                sfor<M::NM>([&](auto E_) MI_LAMBDA { if constexpr (trunk_entry(E_)) L[E_] *= sc_mass; });
+                sfor<NV>([&](auto I) MI_LAMBDA { if constexpr (trunk_gi(I)) c.bias[I] *= sc_mass; });
+            }
+        }
         sfor<OFF>([&](auto I) MI_LAMBDA { y[I] = -c.bias[I]; });
         sfor<ND>([&](auto D) MI_LAMBDA {
             constexpr int d = D, gi = OFF + d;
             if constexpr (trunk_gi(gi)) {
-                constexpr float K = M::dof_stiffness[d], Dm = M::dof_damping[d];
-                L[M::midx[gi][gi]] += M::dof_armature[d] + h * Dm + h * h * K;
+                const float K = M::dof_stiffness[d] * sc_stiff, Dm = M::dof_damping[d] * sc_damp;
+                L[M::midx[gi][gi]] += M::dof_armature[d] * sc_arm + h * Dm + h * h * K;
                 y[gi] = tau[d] - c.bias[gi] - K * (q[d] - M::dof_springref[d]) - (Dm + h * K) * qd[d];
             }
         });
@@ -461,7 +477,7 @@ struct SimMW : Sim<M> {
                     ll = (dl < du) ? lam(row) : -lam(row);
                 }
                 laml(d) = ll;
-                dof_force(d) = tau[d] - M::dof_stiffness[d] * (q[d] - M::dof_springref[d]) - M::dof_damping[d] * v[OFF + d] + ll * invh;
+                dof_force(d) = tau[d] - M::dof_stiffness[d] * sc_stiff * (q[d] - M::dof_springref[d]) - M::dof_damping[d] * sc_damp * v[OFF + d] + ll * invh;
             }
         });
         float sens[6 * M::NSENSA];

@@ -114,6 +114,14 @@ extern "C" int mi_engine_set_option(MiEngine* e, const char* key, double value) 
     if (!strcmp(key, "num_threads")) { if (value < 1) return fail("num_threads < 1"); e->num_threads = (int)value; return 0; }
     return fail(std::string("unknown option: ") + key);
 }
+static_assert(sizeof(MiNoiseParams) == sizeof(NoiseParams), "MiNoiseParams layout");
+extern "C" int mi_engine_set_noise(MiEngine* e, int which, const MiNoiseParams* p) {
+    if (!e || !p) return fail("mi_engine_set_noise: null argument");
+    if (which != 0 && which != 1) return fail("mi_engine_set_noise: which must be 0 (observations) or 1 (actions)");
+    if (p->dist < 0 || p->dist > 2 || p->op < 0 || p->op > 1) return fail("mi_engine_set_noise: dist in {0,1,2}, op in {0,1}");
+    memcpy(which == 0 ? &e->v.obs_noise : &e->v.act_noise, p, sizeof(NoiseParams));
+    return 0;
+}
 extern "C" int mi_engine_get_option(const MiEngine* e, const char* key, double* out) {
     if (!e || !key || !out) return fail("mi_engine_get_option: null argument");
     if (!strcmp(key, "clip_obs")) { *out = e->clip_obs; return 0; }
@@ -155,6 +163,7 @@ extern "C" int mi_engine_init_state(MiEngine* e, void*) {
         for (int k = 0; k < m.nobs; ++k) { v.obs[(size_t)en * m.nobs + k] = 0.f; v.obs_out[(size_t)en * m.nobs + k] = 0.f; v.obs_out[((size_t)N + en) * m.nobs + k] = 0.f; }
         v.potentials[en] = pot0; v.prev_potentials[en] = pot0;
         if (v.friction) v.friction[en] = -1.f;
+        if (v.actor_scale) for (int k = 0; k < 4; ++k) v.actor_scale[k * N + en] = 1.f;
         for (int k = 0; k < 3; ++k) { v.up_vec[k * N + en] = (k == 2) ? 1.f : 0.f; v.heading_vec[k * N + en] = (k == 0) ? 1.f : 0.f; }
         v.rew[en] = 0.f;
         v.reset[en] = 1;      // vec_task.py:316-317: every env is reset inside the first step()
@@ -185,6 +194,9 @@ static void simulate_env(const View& v, const SimParams& P, int en, const float*
     const int N = v.N;
     Sim<M> sim;
     load_env(sim, v, en);
+    if constexpr (Sim<M>::SCALED) {
+        if (v.actor_scale) sim.actor_scale = Strided{v.actor_scale + en, N};
+    }
     const float h = P.dt / (float)P.substeps;
     float rows[Sim<M>::ROW_SLOTS > 0 ? Sim<M>::ROW_SLOTS : 1];
     const SelfCol sc{Strided{v.lamp ? v.lamp + en : nullptr, N}, Strided{v.pairf ? v.pairf + en : nullptr, N}};
@@ -235,6 +247,8 @@ static void loco_post_env(const View& v, const LocoParams& tp, int en, StatAcc& 
     float rew;
     long long reset;
     T::reward(tp, obs, 0LL, progress, act, potentials, prev_potentials, &rew, &reset);
+    if (v.obs_noise.dist != 0)
+        for (int k = 0; k < NOBS; ++k) obs[k] = apply_noise(v.obs_noise, v.seed, (uint32_t)(v.env_offset + en), v.step, 0u, (uint32_t)k, obs[k]);
     episode_stats_env(v, en, rew, reset, progress, acc);
     v.randomize[en] += 1;
     v.episode[en] = ep;
@@ -257,10 +271,12 @@ static void cartpole_post_env(const View& v, const CartpoleParams& tp, int en, S
         progress = 0;
         for (int k = 0; k < 2; ++k) { v.dof[k * N + en] = q[k]; v.dof[(2 + k) * N + en] = qd[k]; v.laml[k * N + en] = 0.f; }
     }
-    const float obs[4] = {q[0], qd[0], q[1], qd[1]};           // cartpole.py:131-142
+    float obs[4] = {q[0], qd[0], q[1], qd[1]};                 // cartpole.py:131-142
     float rew;
     long long reset;
     cartpole_reward(tp, obs[2], obs[3], obs[1], obs[0], 0LL, progress, &rew, &reset);
+    if (v.obs_noise.dist != 0)
+        for (int k = 0; k < 4; ++k) obs[k] = apply_noise(v.obs_noise, v.seed, (uint32_t)(v.env_offset + en), v.step, 0u, (uint32_t)k, obs[k]);
     episode_stats_env(v, en, rew, reset, progress, acc);
     v.randomize[en] += 1;
     v.episode[en] = ep;
@@ -285,7 +301,9 @@ static void step_loco(MiEngine* e, const float* actions) {
     for (int en = 0; en < N; ++en) {
         float tau[M::NDA];
         for (int k = 0; k < M::ND; ++k) {
-            const float a = fminf(fmaxf(actions[(size_t)en * M::ND + k], -tp.clip_actions), tp.clip_actions);   // vec_task.py:374
+            float a = actions[(size_t)en * M::ND + k];
+            if (v.act_noise.dist != 0) a = apply_noise(v.act_noise, v.seed, (uint32_t)(v.env_offset + en), v.step, 1u, (uint32_t)k, a);
+            a = fminf(fmaxf(a, -tp.clip_actions), tp.clip_actions);                                             // vec_task.py:374
             v.actions[k * N + en] = a;
             tau[k] = a * tp.gear[k] * tp.power_scale;                                                            // ant.py:281-285
             v.tau[k * N + en] = tau[k];
@@ -304,7 +322,9 @@ static void step_cartpole(MiEngine* e, const float* actions) {
 #pragma omp parallel for schedule(static) num_threads(e->num_threads)
     for (int en = 0; en < N; ++en) {
         float tau[M::NDA];
-        const float a = fminf(fmaxf(actions[en], -tp.clip_actions), tp.clip_actions);
+        float a = actions[en];
+        if (v.act_noise.dist != 0) a = apply_noise(v.act_noise, v.seed, (uint32_t)(v.env_offset + en), v.step, 1u, 0u, a);
+        a = fminf(fmaxf(a, -tp.clip_actions), tp.clip_actions);
         v.actions[en] = a;
         tau[0] = a * tp.max_push_effort; tau[1] = 0.f;            // cartpole.py:159-163: effort on DoF 0 only
         v.tau[en] = tau[0]; v.tau[N + en] = 0.f;
@@ -317,6 +337,7 @@ static void step_cartpole(MiEngine* e, const float* actions) {
 extern "C" int mi_engine_step(MiEngine* e, const float* actions, void*) {
     if (!e || !actions) return fail("mi_engine_step: null argument");
     e->v.ring = (int)(e->steps & 1);
+    e->v.step = (unsigned)e->steps;
     switch (e->task) {
         case T_CARTPOLE: step_cartpole(e, actions); break;
         case T_ANT: step_loco<ModelAnt, false>(e, actions); break;

@@ -61,6 +61,7 @@ __global__ void init_state_kernel(View v, int nd, int nsph3, int nsens6, int nob
     for (int k = 0; k < nobs; ++k) { v.obs[(size_t)e * nobs + k] = 0.f; v.obs_out[(size_t)e * nobs + k] = 0.f; v.obs_out[((size_t)N + e) * nobs + k] = 0.f; }
     v.potentials[e] = pot0; v.prev_potentials[e] = pot0;
     if (v.friction) v.friction[e] = -1.f;       // model friction until somebody writes the tensor (AnymalTerrain's init overwrites it)
+    if (v.actor_scale) for (int k = 0; k < 4; ++k) v.actor_scale[k * N + e] = 1.f;
     for (int k = 0; k < 3; ++k) { v.up_vec[k * N + e] = (k == 2) ? 1.f : 0.f; v.heading_vec[k * N + e] = (k == 0) ? 1.f : 0.f; }
     v.rew[e] = 0.f;
     v.reset[e] = 1;  // vec_task.py:316-317: every env is reset inside the first step()
@@ -390,6 +391,16 @@ extern "C" int mi_engine_set_option(MiEngine* e, const char* key, double value) 
     if (!strcmp(key, "steps")) { if (value < 0) return fail("steps < 0"); e->steps = (unsigned long long)value; return 0; }
     return fail(std::string("unknown option: ") + key);
 }
+static_assert(sizeof(MiNoiseParams) == sizeof(NoiseParams), "MiNoiseParams layout");
+extern "C" int mi_engine_set_noise(MiEngine* e, int which, const MiNoiseParams* p) {
+    if (!e || !p) return fail("mi_engine_set_noise: null argument");
+    if (which != 0 && which != 1) return fail("mi_engine_set_noise: which must be 0 (observations) or 1 (actions)");
+    if (p->dist < 0 || p->dist > 2 || p->op < 0 || p->op > 1) return fail("mi_engine_set_noise: dist in {0,1,2}, op in {0,1}");
+    if (e->task != T_CARTPOLE && e->task != T_ANT && e->task != T_HUMANOID && p->dist != 0)
+        return fail("mi_engine_set_noise: in-kernel noise exists for Cartpole, Ant and Humanoid");
+    memcpy(which == 0 ? &e->v.obs_noise : &e->v.act_noise, p, sizeof(NoiseParams));
+    return 0;
+}
 extern "C" int mi_engine_get_option(const MiEngine* e, const char* key, double* out) {
     if (!e || !key || !out) return fail("mi_engine_get_option: null argument");
     if (!strcmp(key, "clip_obs")) { *out = e->clip_obs; return 0; }
@@ -485,6 +496,7 @@ extern "C" int mi_engine_step(MiEngine* e, const float* actions, void* stream) {
     if (int rc = check_device(e, "mi_engine_step")) return rc;
     hipStream_t s = (hipStream_t)stream;
     e->v.ring = (int)(e->steps & 1);
+    e->v.step = (unsigned)e->steps;
     switch (e->task) {
         case T_CARTPOLE: HIP_OK(launch_step_cartpole(e->v, e->P, e->cart, actions, e->control_freq_inv, s)); break;
         case T_ANT: HIP_OK(launch_step_ant(e->v, e->P, e->loco, actions, e->control_freq_inv, s)); break;

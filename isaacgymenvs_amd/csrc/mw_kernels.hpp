@@ -22,6 +22,7 @@ __device__ __forceinline__ void mw_role(const View& v, const SimParams& P, const
     const int N = v.N;
     S sim;
     load_sim(sim, v, e);
+    load_actor_scales(sim, v, e);
     float tau[M::NDA];
     if (src != ACT_STORED_TAU) {
         sfor<ND>([&](auto K) MI_LAMBDA {
@@ -31,7 +32,9 @@ __device__ __forceinline__ void mw_role(const View& v, const SimParams& P, const
             if (k < ap.nact) {
                 float a;
                 if (src == ACT_FROM_ACTIONS) {
-                    a = fminf(fmaxf(actions_in[(size_t)e * ap.nact + k], -ap.clip), ap.clip);
+                    a = actions_in[(size_t)e * ap.nact + k];
+                    if (v.act_noise.dist != 0) a = apply_noise(v.act_noise, v.seed, (uint32_t)(v.env_offset + e), v.step, 1u, (uint32_t)k, a);
+                    a = fminf(fmaxf(a, -ap.clip), ap.clip);
                     if constexpr (mine) v.actions[k * N + e] = a;
                 } else {
                     a = v.actions[k * N + e];

@@ -28,6 +28,13 @@ __device__ __forceinline__ void load_sim(Sim<M>& s, const View& v, int e) {
         s.qd[K] = v.dof[(M::ND + K) * N + e];
     });
 }
+// `actor_params` scale factors of this env (Ant / Humanoid; a null tensor or another model: the model's own constants)
+template <class S>
+__device__ __forceinline__ void load_actor_scales(S& s, const View& v, int e) {
+    if constexpr (S::SCALED) {
+        if (v.actor_scale != nullptr) s.actor_scale = Strided{v.actor_scale + e, v.N};
+    }
+}
 template <class M>
 __device__ __forceinline__ void store_sim(const Sim<M>& s, const View& v, int e) {
     const int N = v.N;
@@ -128,6 +135,7 @@ __global__ __launch_bounds__(64) void substep_kernel(View v, SimParams P, ActPar
     if (e >= N) return;                  // no cross-lane operation in here: tail lanes simply retire
     Sim<M> sim;
     load_sim(sim, v, e);
+    load_actor_scales(sim, v, e);
     float tau[M::NDA];
     if (src != ACT_STORED_TAU) {         // uniform branch
         sfor<ND>([&](auto K) MI_LAMBDA {
@@ -136,7 +144,9 @@ __global__ __launch_bounds__(64) void substep_kernel(View v, SimParams P, ActPar
             if (k < ap.nact) {
                 float a;
                 if (src == ACT_FROM_ACTIONS) {
-                    a = fminf(fmaxf(actions_in[(size_t)e * ap.nact + k], -ap.clip), ap.clip);  // vec_task.py:374
+                    a = actions_in[(size_t)e * ap.nact + k];
+                    if (v.act_noise.dist != 0) a = apply_noise(v.act_noise, v.seed, (uint32_t)(v.env_offset + e), v.step, 1u, (uint32_t)k, a);  // vec_task.py:371-372
+                    a = fminf(fmaxf(a, -ap.clip), ap.clip);  // vec_task.py:374
                     v.actions[k * N + e] = a;
                 } else {
                     a = v.actions[k * N + e];
@@ -272,6 +282,10 @@ __global__ __launch_bounds__(post_lanes<M>()) void loco_post_kernel(View v, Loco
     float rew;
     long long reset;
     T::reward(tp, obs, 0LL, progress, act, potentials, prev_potentials, &rew, &reset);
+    // observation noise of the domain randomisation: the reference applies it to obs_buf after post_physics_step (vec_task.py:397-399),
+    // i.e. the reward above saw the clean observations
+    if (v.obs_noise.dist != 0)
+        sfor<NOBS>([&](auto K) MI_LAMBDA { obs[K] = apply_noise(v.obs_noise, v.seed, (uint32_t)(v.env_offset + e), v.step, 0u, (uint32_t)K, obs[K]); });
     episode_stats<PL>(v, e, valid, rew, reset, progress);
     if (!valid) return;
     v.randomize[e] += 1;
@@ -309,10 +323,12 @@ __global__ __launch_bounds__(64) void cartpole_post_kernel(View v, CartpoleParam
             sfor<2>([&](auto K) MI_LAMBDA { v.dof[K * N + e] = q[K]; v.dof[(2 + K) * N + e] = qd[K]; v.laml[K * N + e] = 0.f; });
         }
     }
-    const float obs[4] = {q[0], qd[0], q[1], qd[1]};  // cartpole.py:131-142
+    float obs[4] = {q[0], qd[0], q[1], qd[1]};  // cartpole.py:131-142
     float rew;
     long long reset;
     cartpole_reward(tp, obs[2], obs[3], obs[1], obs[0], 0LL, progress, &rew, &reset);
+    if (v.obs_noise.dist != 0)
+        sfor<4>([&](auto K) MI_LAMBDA { obs[K] = apply_noise(v.obs_noise, v.seed, (uint32_t)(v.env_offset + e), v.step, 0u, (uint32_t)K, obs[K]); });
     episode_stats(v, e, valid, rew, reset, progress);
     if (!valid) return;
     v.randomize[e] += 1;

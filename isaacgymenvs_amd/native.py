@@ -130,6 +130,11 @@ class MiDextremeRewardParams(C.Structure):
                [("max_consecutive_successes", C.c_int32), ("av_factor", C.c_float), ("num_success_hold_steps", C.c_int32)]
 
 
+class MiNoiseParams(C.Structure):
+    _fields_ = [("dist", C.c_int32), ("op", C.c_int32), ("a", C.c_float), ("b", C.c_float), ("a_corr", C.c_float), ("b_corr", C.c_float),
+                ("epoch", C.c_uint32)]
+
+
 class MiTaskInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("num_obs", "num_actions", "num_dofs", "num_bodies", "num_sensors",
                                          "num_contact_spheres", "fixed_base", "task_params_bytes")]
@@ -143,7 +148,7 @@ class MiTensorDesc(C.Structure):
 # every symbol include/mi_engine.h declares (checked by tests/test_abi.py)
 EXPORTS = ["mi_abi_version", "mi_task_info", "mi_engine_arena_bytes", "mi_engine_create", "mi_engine_init_state",
            "mi_engine_destroy", "mi_engine_num_tensors", "mi_engine_tensor_desc", "mi_engine_step",
-           "mi_engine_reset_idx", "mi_engine_simulate", "mi_engine_set_option", "mi_engine_get_option", "mi_engine_last_ring", "mi_engine_set_terrain",
+           "mi_engine_reset_idx", "mi_engine_simulate", "mi_engine_set_option", "mi_engine_get_option", "mi_engine_set_noise", "mi_engine_last_ring", "mi_engine_set_terrain",
            "mi_compute_locomotion_observations", "mi_compute_locomotion_reward", "mi_compute_cartpole_reward",
            "mi_compute_hand_reward", "mi_compute_hand_full_state", "mi_randomize_rotation",
            "mi_compute_anymal_observations", "mi_compute_anymal_reward", "mi_compute_quadcopter_reward",
@@ -282,6 +287,7 @@ def _bind_lifecycle(L):
     L.mi_engine_simulate.argtypes = [C.c_void_p, C.c_void_p]
     L.mi_engine_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
     L.mi_engine_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
+    L.mi_engine_set_noise.argtypes = [C.c_void_p, C.c_int, C.POINTER(MiNoiseParams)]
     L.mi_engine_last_ring.argtypes = [C.c_void_p]
     L.mi_engine_set_terrain.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p,
                                         C.c_int, C.c_int, C.c_float, C.c_int]
@@ -494,6 +500,12 @@ class Engine:
 
     def set_option(self, key, value):
         check(self.L.mi_engine_set_option(self.h, key.encode(), float(value)), self.L)
+
+    def set_noise(self, which, dist="off", op="additive", a=0.0, b=0.0, a_corr=0.0, b_corr=0.0, epoch=0):
+        """In-kernel observation (which=0) / action (which=1) noise; see MiNoiseParams in include/mi_engine.h."""
+        p = MiNoiseParams(dist={"off": 0, "gaussian": 1, "uniform": 2}[dist], op={"additive": 0, "scaling": 1}[op], a=a, b=b,
+                          a_corr=a_corr, b_corr=b_corr, epoch=epoch)
+        check(self.L.mi_engine_set_noise(self.h, int(which), C.byref(p)), self.L)
 
     def get_option(self, key):
         out = C.c_double()

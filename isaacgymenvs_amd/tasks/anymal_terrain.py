@@ -148,4 +148,5 @@ class AnymalTerrain(VecTask):
         if np.isfinite(self.clip_obs):
             self.engine.set_option("clip_obs", self.clip_obs)
         self.engine.set_option("control_freq_inv", self.control_freq_inv)
+        self._select_multi_wave()
         self.sim = self.engine

@@ -20,6 +20,24 @@ from ... import native
 from ...utils import spaces
 
 
+class _TorchNoise:
+    """Observation / action noise as torch ops, for the tasks whose kernels do not apply it themselves: value = op(x, corr + white)
+    with `corr` a normal draw per element made once (scaled by the correlated range) and `white` fresh on every call."""
+
+    def __init__(self, spec, corr=None):
+        self.spec, self.corr = spec, corr
+
+    def __call__(self, x):
+        s = self.spec
+        if self.corr is None or self.corr.shape != x.shape:
+            self.corr = torch.randn_like(x)
+        if s["dist"] == "gaussian":
+            nz = self.corr * s["b_corr"] + s["a_corr"] + torch.randn_like(x) * s["b"] + s["a"]
+        else:
+            nz = self.corr * (s["b_corr"] - s["a_corr"]) + s["a_corr"] + torch.rand_like(x) * (s["b"] - s["a"]) + s["a"]
+        return x + nz if s["op"] == "additive" else x * nz
+
+
 class Env:
     """reference vec_task.py:67-205 (device resolution, spaces, clip values)."""
 
@@ -107,6 +125,7 @@ class VecTask(Env):
         self.first_randomization = True
         self.last_rand_step = 0
         self.dr_randomizations = {}
+        self._torch_noise = {}
         # multi-GPU sharding: global env ids are rank*num_envs + i (seed offset: reference utils/utils.py:94)
         self.rank = int(os.getenv("RANK", "0")) if config.get("_multi_gpu", False) else 0
         self.engine_seed = int(config.get("_seed", 0))
@@ -162,7 +181,7 @@ class VecTask(Env):
         """Launch shape of the physics sub-step (csrc/core/engine_mw.hpp).  `sim.multi_wave`: "auto" (default), 0, 16 or 32 envs per
         workgroup.  auto: the multi-wave form while its 4 * N / E waves still find a SIMD each (1024 on an MI355X) -- measured
         1.4x faster at 4096 envs, slower from 16384 envs on (profiles/r2b_mw_ab.txt); tasks without a multi-wave form ignore it."""
-        mw = self.cfg["sim"].get("multi_wave", "auto")
+        mw = os.environ.get("MI_MULTI_WAVE") or self.cfg["sim"].get("multi_wave", "auto")     # the env var: A/B runs and profiling
         if mw == "auto":
             mw = 16 if self.num_envs <= 4096 else (32 if self.num_envs <= 8192 else 0)
         for cand in (int(mw), 32):
@@ -197,8 +216,8 @@ class VecTask(Env):
             # the reference calls this from reset_idx (ant.py:253-255), i.e. on steps where some env resets; resets are
             # in-kernel here, so the (frequency-gated) refresh is evaluated every step
             self.apply_randomizations(self.randomization_params)
-        if self.dr_randomizations.get("actions", None):
-            actions = self.dr_randomizations["actions"]["noise_lambda"](actions)
+        if "actions" in self._torch_noise:               # tasks without in-kernel noise
+            actions = self._torch_noise["actions"](actions)
         if actions.device != self.obs_buf.device or actions.dtype != torch.float32 or not actions.is_contiguous():
             actions = actions.to(device=self.obs_buf.device, dtype=torch.float32).contiguous()
         if actions.shape != (self.num_envs, self.num_actions):
@@ -208,8 +227,8 @@ class VecTask(Env):
         self.engine.step(actions)
         self.control_steps += 1
         obs = self._obs_out[self.engine.last_ring()]
-        if self.dr_randomizations.get("observations", None):
-            self.obs_buf[:] = self.dr_randomizations["observations"]["noise_lambda"](self.obs_buf)
+        if "observations" in self._torch_noise:
+            self.obs_buf[:] = self._torch_noise["observations"](self.obs_buf)
             obs = torch.clamp(self.obs_buf, -self.clip_obs, self.clip_obs)
         self._post_step_extras()
         self.extras["time_outs"] = self.timeout_buf.to(self.rl_device)
@@ -247,143 +266,127 @@ class VecTask(Env):
         return self.obs_dict, done_env_ids
 
     # ------------------------------------------------------------------ domain randomisation (vec_task.py:610-840)
+    #: tasks whose step kernels apply observation / action noise themselves (mi_engine_set_noise); the others get torch ops
+    KERNEL_NOISE_TASKS = ("Cartpole", "Ant", "Humanoid")
+    #: `actor_params` entries that have a per-env engine parameter: (property group, attribute) -> column of the actor_scale tensor
+    ACTOR_SCALE_COLUMNS = {("rigid_body_properties", "mass"): 0, ("dof_properties", "damping"): 1, ("dof_properties", "stiffness"): 2,
+                           ("dof_properties", "armature"): 3}
+
     def apply_randomizations(self, dr_params):
-        """Reference vec_task.py:610-840, for the parts that exist without PhysX property structs:
-        observation / action noise closures (white + per-env correlated, gaussian or uniform, additive or scaling, linear /
-        constant schedules, :650-718) and `sim_params.gravity` (:720-732).  `actor_params` (per-actor mass / friction /
-        dof property randomisation through gym.get/set_actor_*_properties, :752-828) has no counterpart yet and raises."""
-        import operator
-        from ...utils.dr_utils import apply_random_gravity
+        """What the reference's VecTask.apply_randomizations decides, when (vec_task.py:610-648: `frequency` in sim frames for the
+        non-env parameters, per env once it has been reset after `frequency` of its own steps), is kept; what it then does is
+        different: observation / action noise becomes a parameter block of the step kernels (no torch ops per step), gravity an
+        engine option, and the per-actor property structs of PhysX become per-env tensors the sub-step reads
+        (friction, mass / damping / stiffness / armature scales), sampled for all due envs at once."""
+        from ...utils.dr_utils import Draw, apply_random_gravity
         rand_freq = dr_params.get("frequency", 1)
         self.last_step = int(self.control_steps * max(1, self.control_freq_inv))       # gym.get_frame_count
-        rand_envs = None                                                               # None: every env (first call)
+        due_envs = None                                                                # None: every env (first call)
         if self.first_randomization:
-            do_nonenv_randomize = True
+            refresh_global = True
         else:
-            do_nonenv_randomize = (self.last_step - self.last_rand_step) >= rand_freq
-            rand_envs = torch.logical_and(self.randomize_buf >= rand_freq, self.reset_buf.bool())
-            self.randomize_buf[rand_envs] = 0
-        if do_nonenv_randomize:
+            refresh_global = (self.last_step - self.last_rand_step) >= rand_freq
+            due_envs = torch.logical_and(self.randomize_buf >= rand_freq, self.reset_buf.bool())
+            self.randomize_buf[due_envs] = 0
+        if refresh_global:
             self.last_rand_step = self.last_step
-        for name in ("observations", "actions"):
-            if name in dr_params and do_nonenv_randomize:
-                prm = dr_params[name]
-                dist, op_type = prm["distribution"], prm["operation"]
-                sched_type = prm["schedule"] if "schedule" in prm else None
-                sched_step = prm["schedule_steps"] if "schedule" in prm else None
-                op = operator.add if op_type == "additive" else operator.mul
-                if sched_type == "linear":
-                    s = 1.0 / sched_step * min(self.last_step, sched_step)
-                elif sched_type == "constant":
-                    s = 0 if self.last_step < sched_step else 1
-                else:
-                    s = 1
-                if dist == "gaussian":
-                    mu, var = prm["range"]
-                    mu_corr, var_corr = prm.get("range_correlated", [0., 0.])
-                    if op_type == "additive":
-                        mu *= s; var *= s; mu_corr *= s; var_corr *= s
-                    elif op_type == "scaling":
-                        var = var * s; mu = mu * s + 1.0 * (1.0 - s)
-                        var_corr = var_corr * s; mu_corr = mu_corr * s + 1.0 * (1.0 - s)
-
-                    def noise_lambda(tensor, param_name=name, op=op):
-                        params = self.dr_randomizations[param_name]
-                        corr = params.get("corr", None)
-                        if corr is None:
-                            corr = torch.randn_like(tensor)
-                            params["corr"] = corr
-                        corr = corr * params["var_corr"] + params["mu_corr"]
-                        return op(tensor, corr + torch.randn_like(tensor) * params["var"] + params["mu"])
-                    self.dr_randomizations[name] = {"mu": mu, "var": var, "mu_corr": mu_corr, "var_corr": var_corr,
-                                                    "noise_lambda": noise_lambda}
-                elif dist == "uniform":
-                    lo, hi = prm["range"]
-                    lo_corr, hi_corr = prm.get("range_correlated", [0., 0.])
-                    if op_type == "additive":
-                        lo *= s; hi *= s; lo_corr *= s; hi_corr *= s
-                    elif op_type == "scaling":
-                        lo = lo * s + 1.0 * (1.0 - s); hi = hi * s + 1.0 * (1.0 - s)
-                        lo_corr = lo_corr * s + 1.0 * (1.0 - s); hi_corr = hi_corr * s + 1.0 * (1.0 - s)
-
-                    def noise_lambda(tensor, param_name=name, op=op):
-                        params = self.dr_randomizations[param_name]
-                        corr = params.get("corr", None)
-                        if corr is None:
-                            corr = torch.randn_like(tensor)
-                            params["corr"] = corr
-                        corr = corr * (params["hi_corr"] - params["lo_corr"]) + params["lo_corr"]
-                        return op(tensor, corr + torch.rand_like(tensor) * (params["hi"] - params["lo"]) + params["lo"])
-                    self.dr_randomizations[name] = {"lo": lo, "hi": hi, "lo_corr": lo_corr, "hi_corr": hi_corr,
-                                                    "noise_lambda": noise_lambda}
-                else:
-                    raise ValueError(f"unsupported noise distribution {dist}")
-        if "sim_params" in dr_params and do_nonenv_randomize:
-            if self.first_randomization:
-                self.original_props = getattr(self, "original_props", {})
-                self.original_props["sim_params"] = {"gravity": [float(self.sim_params.gravity[i]) for i in range(3)]}
-            for attr, attr_prm in dr_params["sim_params"].items():
+            for which, name in enumerate(("observations", "actions")):
+                if name in dr_params:
+                    self._configure_noise(which, name, dr_params[name], Draw)
+            for attr, prm in dr_params.get("sim_params", {}).items():
                 if attr != "gravity":
                     raise NotImplementedError(f"sim_params.{attr} randomisation is not supported by the engine")
+                if self.first_randomization:
+                    self.original_props = getattr(self, "original_props", {})
+                    self.original_props["sim_params"] = {"gravity": [float(self.sim_params.gravity[i]) for i in range(3)]}
                 g = apply_random_gravity([float(self.sim_params.gravity[i]) for i in range(3)],
-                                         self.original_props["sim_params"]["gravity"], attr_prm, self.last_step)
-                for i in range(3):
+                                         self.original_props["sim_params"]["gravity"], prm, self.last_step)
+                for i, key in enumerate(("gravity_x", "gravity_y", "gravity_z")):
                     self.sim_params.gravity[i] = float(g[i])
-                    self.engine.set_option(("gravity_x", "gravity_y", "gravity_z")[i], float(g[i]))
+                    self.engine.set_option(key, float(g[i]))
         if dr_params.get("actor_params"):
-            self._apply_actor_params(dr_params["actor_params"], rand_envs)
+            self._apply_actor_params(dr_params["actor_params"], due_envs)
         self.first_randomization = False
 
-    def _apply_actor_params(self, actor_params, rand_envs):
-        """`actor_params` (vec_task.py:752-828), tensorised: what the engine has a per-env parameter for is sampled for all randomised envs
-        at once instead of the reference's O(num_envs) Python loop over PhysX property structs.  Implemented: the friction of the robot's
-        shapes (`rigid_shape_properties.friction`, with `num_buckets`) on the tasks that carry a `friction` tensor (Ant, Humanoid) -- one
-        sample per env where the reference draws one per shape.  Everything else (mass, restitution, dof / tendon properties, scale) has
-        no engine counterpart and is reported once."""
+    def _configure_noise(self, which, name, prm, Draw):
+        """`observations` / `actions` block (vec_task.py:650-718) -> noise parameters.  The schedule blends the white and the
+        correlated range exactly like any other randomised parameter (utils/dr_utils.py::Draw)."""
+        dist, op = prm["distribution"], prm["operation"]
+        if dist not in ("gaussian", "uniform"):
+            raise ValueError(f"unsupported noise distribution {dist}")
+        white = Draw(dict(prm), self.last_step)
+        corr = Draw(dict(prm, range=prm.get("range_correlated", [0.0, 0.0])), self.last_step)
+        spec = dict(dist=dist, op=op, a=float(white.a), b=float(white.b), a_corr=float(corr.a), b_corr=float(corr.b))
+        self.dr_randomizations[name] = dict(spec, in_kernel=self.native_task in self.KERNEL_NOISE_TASKS)
+        if self.native_task in self.KERNEL_NOISE_TASKS:
+            self.engine.set_noise(which, **spec)
+        else:
+            prev = self._torch_noise.get(name)
+            self._torch_noise[name] = _TorchNoise(spec, prev.corr if prev is not None else None)
+
+    def _apply_actor_params(self, actor_params, due_envs):
+        """`actor_params` (vec_task.py:752-828).  The reference walks every env's PhysX property structs in Python; here each
+        supported entry is one vectorised draw over the due envs into a per-env tensor the sub-step kernel reads:
+          rigid_shape_properties.friction                     -> `friction` (Ant, Humanoid; ShadowHand: mean of hand and object);
+          rigid_body_properties.mass, dof_properties.damping / stiffness / armature -> columns of `actor_scale` (Ant, Humanoid): one
+          factor per env for the whole actor where the reference draws one per body / dof (`scaling`: the sample itself;
+          `additive`: relative to the model's mean value).
+        Entries without an engine parameter (restitution, scale, tendons, colours) are named once in a warning."""
         from ...utils.dr_utils import apply_random_samples_array
-        import numpy as np
-        fr = self.engine.tensors.get("friction") if self.native_task in ("Ant", "Humanoid", "ShadowHand") else None
-        # ShadowHand: one contact coefficient per env = the mean of the hand's and the object's shape friction (PhysX's default combine
-        # mode), each of which the reference randomises as its own actor
-        pair = self.native_task == "ShadowHand"
+        t = self.engine.tensors
+        fr = t.get("friction") if self.native_task in ("Ant", "Humanoid", "ShadowHand") else None
+        scales = t.get("actor_scale")
+        pair = self.native_task == "ShadowHand"       # one contact coefficient per env = mean of the two actors' shape friction
         if pair and not hasattr(self, "_dr_actor_friction"):
             self._dr_actor_friction = {}
+        ids = torch.arange(self.num_envs, device=self.device) if due_envs is None else torch.nonzero(due_envs, as_tuple=False).squeeze(-1)
+        base_mu = float(getattr(self, "model_shape_friction", 1.0))
         skipped = []
-        if rand_envs is None:
-            ids = torch.arange(self.num_envs, device=self.device)
-        else:
-            ids = torch.nonzero(rand_envs, as_tuple=False).squeeze(-1)
-        for actor, props in actor_params.items():
-            for prop_name, attrs in props.items():
-                if prop_name == "color":
+        for actor, groups in actor_params.items():
+            for group, attrs in groups.items():
+                if group == "color":
                     continue                                                             # no renderer
-                if prop_name == "rigid_shape_properties" and fr is not None and isinstance(attrs, dict):
-                    for attr, prm in attrs.items():
-                        if attr != "friction":
-                            skipped.append(f"{actor}.{prop_name}.{attr}")
-                            continue
-                        if prm.get("setup_only", False) and not self.first_randomization:
-                            continue
-                        if len(ids) == 0:
-                            continue
-                        og = {"friction": np.full(len(ids), float(getattr(self, "model_shape_friction", 1.0)))}
-                        prop = {"friction": og["friction"].copy()}
-                        vals = apply_random_samples_array(prop, og, "friction", prm, self.last_step)
+                if not isinstance(attrs, dict):
+                    skipped.append(f"{actor}.{group}")
+                    continue
+                for attr, prm in attrs.items():
+                    col = self.ACTOR_SCALE_COLUMNS.get((group, attr)) if scales is not None else None
+                    is_friction = group == "rigid_shape_properties" and attr == "friction" and fr is not None
+                    if col is None and not is_friction:
+                        skipped.append(f"{actor}.{group}.{attr}")
+                        continue
+                    if (prm.get("setup_only", False) and not self.first_randomization) or len(ids) == 0:
+                        continue
+                    if is_friction:
+                        og = {"v": np.full(len(ids), base_mu)}
+                        vals = apply_random_samples_array({"v": og["v"].copy()}, og, "v", prm, self.last_step)
                         vals_t = torch.as_tensor(np.asarray(vals, np.float32), device=self.device)
                         if pair:
-                            mine = self._dr_actor_friction.setdefault(actor, torch.full((self.num_envs,), float(getattr(self, "model_shape_friction", 1.0)),
-                                                                                        device=self.device))
+                            mine = self._dr_actor_friction.setdefault(actor, torch.full((self.num_envs,), base_mu, device=self.device))
                             mine[ids] = vals_t
                             others = [v for k, v in self._dr_actor_friction.items() if k != actor]
-                            other = others[0] if others else torch.full_like(mine, float(getattr(self, "model_shape_friction", 1.0)))
+                            other = others[0] if others else torch.full_like(mine, base_mu)
                             fr[ids] = 0.5 * (mine[ids] + other[ids])
                         else:
                             fr[ids] = vals_t
-                else:
-                    skipped.append(f"{actor}.{prop_name}")
+                    else:
+                        ref_val = self._actor_reference_value(group, attr)
+                        og = {"v": np.full(len(ids), ref_val)}
+                        vals = np.asarray(apply_random_samples_array({"v": og["v"].copy()}, og, "v", prm, self.last_step), np.float64)
+                        factor = np.clip(vals / ref_val, 0.05, 20.0) if ref_val > 0 else np.ones(len(ids))
+                        scales[ids, col] = torch.as_tensor(factor.astype(np.float32), device=self.device)
         if skipped and self.first_randomization:
             import warnings
             warnings.warn("actor_params entries without an engine counterpart are skipped (reference vec_task.py:752-828): " + ", ".join(skipped))
+
+    def _actor_reference_value(self, group, attr):
+        """the model's own (mean) value a randomised actor property is measured against"""
+        spec = getattr(self, "_dr_spec", None)
+        if spec is None:
+            from ...registry import load_model
+            spec = self._dr_spec = load_model(getattr(self, "model_name", self.native_task.lower()))
+        arr = {"mass": spec.mass, "damping": spec.dof_damping, "stiffness": spec.dof_stiffness, "armature": spec.dof_armature}[attr]
+        return float(np.mean(arr)) if len(arr) else 0.0
 
     def render(self, mode="rgb_array"):
         return None  # headless engine (viewer is out of scope, SURVEY.md section 8f-4)

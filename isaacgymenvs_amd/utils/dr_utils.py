@@ -1,103 +1,108 @@
-"""Domain-randomisation sampling (host side, NumPy) -- restates reference isaacgymenvs/utils/dr_utils.py:71-208.
+"""Domain-randomisation sampling on the host (NumPy).
 
-Same distributions, schedules and operation semantics, same use of NumPy's global RNG (one draw per call site), so that
-under `np.random.seed(s)` the samples equal the reference's (tests/test_dr_utils.py checks this against the reference's
-own functions).  Property objects are plain dicts / attribute holders here instead of gymapi structs.
-"""
+What the reference specifies (isaacgymenvs/utils/dr_utils.py:71-208 with the `randomization_params` blocks of the task YAMLs): a
+parameter is re-drawn from `distribution` in {gaussian, uniform, loguniform} over `range`, combined with its original value by
+`operation` in {additive, scaling}, faded in by an optional `schedule` (linear over / constant after `schedule_steps`), optionally
+snapped to `num_buckets` values.  The draws come from NumPy's global generator, one call per parameter, so a run seeded with
+`np.random.seed(s)` reproduces the reference's values (tests/test_dr_utils.py checks that against the reference's own functions).
+
+Organisation here: a distribution is described once (how `range` turns into its two shape parameters, how the schedule blends them
+towards "no effect", how to draw), and every entry point goes through `Draw`."""
 from __future__ import annotations
-
-from bisect import bisect
 
 import numpy as np
 
 
-def _sched_scaling(p, step):  # dr_utils.py:78-90
-    sched_type = p["schedule"] if "schedule" in p else None
-    sched_step = p["schedule_steps"] if "schedule" in p else None
-    if sched_type == "linear":
-        return 1 / sched_step * min(step, sched_step)
-    if sched_type == "constant":
-        return 0 if step < sched_step else 1
-    return 1
+def schedule_weight(params, step):
+    """0 -> the randomisation has no effect yet, 1 -> full range (dr_utils.py:78-90)."""
+    kind = params.get("schedule")
+    if kind == "linear":
+        return min(step, params["schedule_steps"]) / params["schedule_steps"]
+    if kind == "constant":
+        return 1.0 if step >= params["schedule_steps"] else 0.0
+    return 1.0
+
+
+class Draw:
+    """One randomised parameter: distribution, operation and the schedule weight resolved into the two numbers NumPy needs."""
+
+    #: distribution -> (which of the two `range` entries shift with a scaling schedule, NumPy draw)
+    _KINDS = {
+        "gaussian": ((0,), lambda a, b, shape: np.random.normal(a, b, shape)),              # range = (mean, std)
+        "uniform": ((0, 1), lambda a, b, shape: np.random.uniform(a, b, shape)),             # range = (low, high)
+        "loguniform": ((0, 1), lambda a, b, shape: np.exp(np.random.uniform(np.log(a), np.log(b), shape))),
+    }
+
+    def __init__(self, params, step):
+        if params["distribution"] not in self._KINDS:
+            raise ValueError(f"unknown distribution {params['distribution']}")
+        self.op = params["operation"]
+        self.weight = schedule_weight(params, step)
+        moved, self._draw = self._KINDS[params["distribution"]]
+        pair = [params["range"][0], params["range"][1]]
+        if self.op == "additive":                      # additive noise fades in from zero: both numbers shrink with the weight
+            pair = [v * self.weight for v in pair]
+        elif self.op == "scaling":                     # a scale factor fades in from one: locations move towards 1, spreads shrink
+            pair = [v * self.weight + (1 - self.weight) if i in moved else v * self.weight for i, v in enumerate(pair)]
+        self.a, self.b = pair
+
+    def sample(self, shape):
+        return self._draw(self.a, self.b, shape)
+
+    def blend_external(self, sample):
+        """an externally supplied sample goes through the same schedule (dr_utils.py:96-101)"""
+        if self.op == "additive":
+            return sample * self.weight
+        if self.op == "scaling":
+            return sample * self.weight + (1 - self.weight)
+        return sample
+
+    def combine(self, original, sample):
+        if self.op == "scaling":
+            return original * sample
+        if self.op == "additive":
+            return original + sample
+        raise ValueError(f"unknown operation {self.op}")
 
 
 def generate_random_samples(attr_randomization_params, shape, curr_gym_step_count, extern_sample=None):
-    """dr_utils.py:71-132"""
-    rand_range = attr_randomization_params["range"]
-    distribution = attr_randomization_params["distribution"]
-    operation = attr_randomization_params["operation"]
-    s = _sched_scaling(attr_randomization_params, curr_gym_step_count)
-    if extern_sample is not None:
-        sample = extern_sample
-        if operation == "additive":
-            sample *= s
-        elif operation == "scaling":
-            sample = sample * s + 1 * (1 - s)
-    elif distribution == "gaussian":
-        mu, var = rand_range
-        if operation == "additive":
-            mu *= s
-            var *= s
-        elif operation == "scaling":
-            var = var * s
-            mu = mu * s + 1 * (1 - s)
-        sample = np.random.normal(mu, var, shape)
-    elif distribution == "loguniform":
-        lo, hi = rand_range
-        if operation == "additive":
-            lo *= s
-            hi *= s
-        elif operation == "scaling":
-            lo = lo * s + 1 * (1 - s)
-            hi = hi * s + 1 * (1 - s)
-        sample = np.exp(np.random.uniform(np.log(lo), np.log(hi), shape))
-    elif distribution == "uniform":
-        lo, hi = rand_range
-        if operation == "additive":
-            lo *= s
-            hi *= s
-        elif operation == "scaling":
-            lo = lo * s + 1 * (1 - s)
-            hi = hi * s + 1 * (1 - s)
-        sample = np.random.uniform(lo, hi, shape)
-    else:
-        raise ValueError(f"unknown distribution {distribution}")
-    return sample
+    d = Draw(attr_randomization_params, curr_gym_step_count)
+    return d.blend_external(extern_sample) if extern_sample is not None else d.sample(shape)
+
+
+def bucket_edges(params):
+    """`num_buckets` equally spaced values from the low end of the parameter's range: the range itself for uniform draws, mean +- 2
+    sqrt(second entry) for gaussian ones (dr_utils.py:135-145)."""
+    a, b = params["range"][0], params["range"][1]
+    lo, hi = (a, b) if params["distribution"] == "uniform" else (a - 2 * np.sqrt(b), a + 2 * np.sqrt(b))
+    n = params["num_buckets"]
+    return np.array([(hi - lo) * i / n + lo for i in range(n)])
 
 
 def get_bucketed_val(new_prop_val, attr_randomization_params):
-    """dr_utils.py:135-145"""
-    if attr_randomization_params["distribution"] == "uniform":
-        lo, hi = attr_randomization_params["range"][0], attr_randomization_params["range"][1]
-    else:
-        lo = attr_randomization_params["range"][0] - 2 * np.sqrt(attr_randomization_params["range"][1])
-        hi = attr_randomization_params["range"][0] + 2 * np.sqrt(attr_randomization_params["range"][1])
-    num_buckets = attr_randomization_params["num_buckets"]
-    buckets = [(hi - lo) * i / num_buckets + lo for i in range(num_buckets)]
-    if np.ndim(new_prop_val) == 0:
-        return buckets[bisect(buckets, new_prop_val) - 1]
-    # array form of the same lookup (bisect == bisect_right; index -1 wraps to the last bucket exactly like the scalar expression)
-    return np.asarray(buckets)[np.searchsorted(buckets, np.asarray(new_prop_val), side="right") - 1]
+    """Snap to the largest bucket value not above the argument; below the first bucket this wraps to the LAST one -- the reference's
+    `buckets[bisect(buckets, x) - 1]` with index -1 -- which is kept."""
+    edges = bucket_edges(attr_randomization_params)
+    idx = np.searchsorted(edges, np.asarray(new_prop_val), side="right") - 1
+    out = edges[idx]
+    return float(out) if np.ndim(new_prop_val) == 0 else out
 
 
 def apply_random_gravity(gravity, og_gravity, attr_randomization_params, curr_gym_step_count):
-    """SimParams branch of apply_random_samples for attr == 'gravity' (dr_utils.py:160-172).  gravity: 3 floats."""
-    sample = generate_random_samples(attr_randomization_params, 3, curr_gym_step_count)
-    if attr_randomization_params["operation"] == "scaling":
-        return [og_gravity[i] * sample[i] for i in range(3)]
-    if attr_randomization_params["operation"] == "additive":
-        return [og_gravity[i] + sample[i] for i in range(3)]
-    return list(gravity)
+    """`sim_params.gravity` (dr_utils.py:160-172): three draws combined with the original vector."""
+    d = Draw(attr_randomization_params, curr_gym_step_count)
+    if d.op not in ("scaling", "additive"):
+        return list(gravity)
+    s = d.sample(3)
+    return [d.combine(og_gravity[i], s[i]) for i in range(3)]
 
 
 def apply_random_samples_array(prop, og_prop, attr, attr_randomization_params, curr_gym_step_count, extern_sample=None):
-    """ndarray branch of apply_random_samples (dr_utils.py:181-192); prop / og_prop: dict-like of arrays."""
-    sample = generate_random_samples(attr_randomization_params, np.shape(prop[attr]), curr_gym_step_count, extern_sample)
-    if attr_randomization_params["operation"] == "scaling":
-        new_prop_val = og_prop[attr] * sample
-    elif attr_randomization_params["operation"] == "additive":
-        new_prop_val = og_prop[attr] + sample
-    if "num_buckets" in attr_randomization_params and attr_randomization_params["num_buckets"] > 0:
-        new_prop_val = get_bucketed_val(new_prop_val, attr_randomization_params)
-    prop[attr] = new_prop_val
-    return new_prop_val
+    """Array-valued property (dr_utils.py:181-192): one draw of the property's shape, combined, bucketed, written back."""
+    d = Draw(attr_randomization_params, curr_gym_step_count)
+    s = d.blend_external(extern_sample) if extern_sample is not None else d.sample(np.shape(prop[attr]))
+    val = d.combine(og_prop[attr], s)
+    if attr_randomization_params.get("num_buckets", 0) > 0:
+        val = get_bucketed_val(val, attr_randomization_params)
+    prop[attr] = val
+    return val

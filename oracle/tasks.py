@@ -184,6 +184,30 @@ def fold_seed(seed64):
     return (seed64 ^ (seed64 >> 32)) & 0xFFFFFFFF
 
 
+def mi_gauss(seed, env, ctr, k):
+    """Twin of mi::gauss01 (csrc/core/rng.hpp): Box-Muller on two draws of the counter RNG (libm vs numpy: a few ulps apart)."""
+    k = np.asarray(k).astype(np.uint32)
+    with np.errstate(over="ignore"):
+        u1 = np.maximum(mi_uniform(seed, env, ctr, (np.uint32(2) * k).astype(np.uint32)), f32(5.9604645e-8))
+        u2 = mi_uniform(seed, env, ctr, (np.uint32(2) * k + np.uint32(1)).astype(np.uint32))
+    return (np.sqrt(f32(-2.0) * np.log(u1)) * np.cos(f32(6.283185307179586) * u2)).astype(f32)
+
+
+def mi_noise(spec, seed, env, step, stream, k, x):
+    """Twin of mi::apply_noise: in-kernel observation (stream 0) / action (stream 1) noise of the domain randomisation.
+    spec: dict(dist "gaussian" | "uniform", op "additive" | "scaling", a, b, a_corr, b_corr, epoch=0); env / k broadcastable."""
+    with np.errstate(over="ignore"):
+        epoch = np.uint32(spec.get("epoch", 0))
+        zc = mi_gauss(seed, env, np.uint32(0xC0000000) ^ np.uint32((int(epoch) * 0x9E3779B1 + stream) & 0xFFFFFFFF), k)
+        ctr = np.uint32(0x80000000) | np.uint32((step * 2 + stream) & 0xFFFFFFFF)
+    a, b, ac, bc = (f32(spec[n]) for n in ("a", "b", "a_corr", "b_corr"))
+    if spec["dist"] == "gaussian":
+        nz = (zc * bc + ac) + (mi_gauss(seed, env, ctr, k) * b + a)
+    else:
+        nz = (zc * (bc - ac) + ac) + (mi_uniform(seed, env, ctr, k) * (b - a) + a)
+    return (x + nz if spec["op"] == "additive" else x * nz).astype(f32)
+
+
 # ------------------------------------------------------------------ full VecTask.step restatement on the CPU physics oracle
 class OracleLocomotionEnv:
     """vec_task.py:360-408 + ant.py / humanoid.py pre/post_physics_step on oracle/physics.c (AoS, numpy).

@@ -105,3 +105,68 @@ def test_reference_user_script_runs_unedited():
         random_actions = 2.0 * torch.rand((16,) + envs.action_space.shape, device="cpu") - 1.0
         envs.step(random_actions)
     assert obs["obs"].shape == (16, 4)
+
+
+@pytest.mark.parametrize("dist,op", [("gaussian", "additive"), ("uniform", "scaling")])
+def test_in_kernel_noise_equals_its_cpu_twin(dist, op):
+    """Observation / action noise of the domain randomisation lives inside the step kernels (mi_engine_set_noise) as a pure function
+    of (seed, env, step, element): a noisy env equals the clean twin env pushed through oracle.tasks.mi_noise, element by element;
+    the correlated part of an element is the same on every step."""
+    from oracle.tasks import fold_seed, mi_noise
+    n, seed = 32, 5
+    clean = isaacgymenvs_amd.make(seed=seed, task="Ant", num_envs=n, sim_device="cpu", rl_device="cpu", headless=True)
+    noisy = isaacgymenvs_amd.make(seed=seed, task="Ant", num_envs=n, sim_device="cpu", rl_device="cpu", headless=True)
+    spec = dict(dist=dist, op=op, a=0.9 if op == "scaling" else 0.0, b=1.1 if dist == "uniform" else 0.05,
+                a_corr=0.0 if op == "additive" else 0.1, b_corr=0.02 if op == "additive" else 0.12)
+    noisy.engine.set_noise(0, **spec)
+    g = torch.Generator().manual_seed(1)
+    env_ids = np.arange(n, dtype=np.uint32)[:, None]
+    k = np.arange(60, dtype=np.uint32)[None, :]
+    for step in range(3):
+        a = torch.rand((n, 8), generator=g) * 2 - 1
+        oc = clean.step(a)[0]["obs"].numpy()
+        on = noisy.step(a)[0]["obs"].numpy()
+        np.testing.assert_allclose(on, mi_noise(spec, fold_seed(seed), env_ids, step, 0, k, oc), atol=2e-5, rtol=1e-5)
+        np.testing.assert_array_equal(clean.rew_buf.numpy(), noisy.rew_buf.numpy())        # the reward saw the clean observations
+    # action noise: applied before the clamp, the clamped noisy actions are what the engine stores and uses
+    noisy.engine.set_noise(0, dist="off")
+    aspec = dict(dist="gaussian", op="additive", a=0.0, b=0.3, a_corr=0.0, b_corr=0.0)
+    noisy.engine.set_noise(1, **aspec)
+    a = torch.rand((n, 8), generator=g) * 2 - 1
+    noisy.step(a)
+    expect = np.clip(mi_noise(aspec, fold_seed(seed), env_ids, 3, 1, np.arange(8, dtype=np.uint32)[None, :], a.numpy()), -1.0, 1.0)
+    np.testing.assert_allclose(noisy.actions.numpy(), expect, atol=2e-5)
+    assert np.abs(noisy.actions.numpy() - np.clip(a.numpy(), -1, 1)).max() > 0.1
+
+
+def test_actor_scale_tensor_acts_like_a_rescaled_model():
+    """`actor_params` mass / damping / stiffness / armature randomisation: the per-env factors of the `actor_scale` tensor give the same
+    motion as the oracle run on a model whose constants were multiplied by them."""
+    import dataclasses
+    from oracle.engine import OracleEngine
+    n = 16
+    env = isaacgymenvs_amd.make(seed=0, task="Ant", num_envs=n, sim_device="cpu", rl_device="cpu", headless=True)
+    env.engine.set_option("multi_wave", 0)
+    spec = load_model("ant")
+    f = dict(mass=1.7, damping=0.5, stiffness=2.0, armature=3.0)
+    env.engine.tensors["actor_scale"][:] = torch.tensor([f["mass"], f["damping"], f["stiffness"], f["armature"]])
+    spec2 = dataclasses.replace(spec, mass=spec.mass * f["mass"], inertia=spec.inertia * f["mass"], dof_damping=spec.dof_damping * f["damping"],
+                                dof_stiffness=spec.dof_stiffness * f["stiffness"], dof_armature=spec.dof_armature * f["armature"])
+    orcs = [OracleEngine(s, n, params=_sim_dict(env.sim_params), sensor_bodies=sensor_bodies("ant"), precision="f64") for s in (spec2, spec)]
+    rng = np.random.default_rng(0)
+    lo, up = np.minimum(spec.dof_lower, spec.dof_upper), np.maximum(spec.dof_lower, spec.dof_upper)
+    root = np.zeros((n, 13)); root[:, 2] = rng.uniform(0.3, 0.6, n); root[:, 6] = 1.0; root[:, 7:13] = rng.normal(size=(n, 6))
+    q, qd, tau = rng.uniform(lo, up, (n, 8)), rng.normal(size=(n, 8)), rng.uniform(-15, 15, (n, 8))
+    t = env.engine.tensors
+    t["root_states"][:] = torch.tensor(root, dtype=torch.float32); env.dof_pos[:] = torch.tensor(q, dtype=torch.float32)
+    env.dof_vel[:] = torch.tensor(qd, dtype=torch.float32); t["dof_actuation_force"][:] = torch.tensor(tau, dtype=torch.float32)
+    t["contact_impulse"].zero_(); t["limit_impulse"].zero_()
+    for o in orcs:
+        o.root[:] = root; o.q[:] = q; o.qd[:] = qd
+    for it in range(2):
+        env.engine.simulate()
+        for o in orcs:
+            o.step(tau)
+    err = max(np.abs(env.dof_vel.numpy() - orcs[0].qd).max(), np.abs(env.root_states.numpy() - orcs[0].root).max())
+    assert err < 1e-3 * max(1.0, np.abs(orcs[0].qd).max()), err
+    assert np.abs(orcs[0].qd - orcs[1].qd).max() > 0.2                 # the scaled model really moves differently

@@ -1,0 +1,120 @@
+"""Parity at the sizes that are benchmarked (BASELINE.json: Ant@4096, Humanoid@8192, AnymalTerrain@4096, ShadowHand@16384): the HIP
+kernels against the fp64 CPU restatement at exactly those env counts -- every launch shape, tail wave and env -> XCD mapping the
+bench line exercises -- with contact impulses, joint-limit impulses, force sensors, net contact forces and joint forces asserted
+PER ELEMENT (relative to the largest force present), not only kinematic columns and not only for most rows.
+
+The stated tolerance: after one control step from the same state |hip - oracle_f64| <= 5e-4 * scale for positions /
+velocities (scale = max(1, fastest joint speed)), <= 2e-3 * (largest force or impulse present) for force-like quantities; contact
+is chaotic afterwards, so later steps are compared with a tolerance that grows linearly with the step count."""
+import numpy as np
+import pytest
+import torch
+
+from isaacgymenvs_amd.registry import load_model, sensor_bodies
+from test_gpu_parity import DEV, _anymal_oracle, _make_env, _random_state, _selfcol_kw, _sim_dict, _t
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("task,n,z_lo,z_hi,gear", [("Ant", 4096, 0.3, 0.6, 15.0), ("Humanoid", 8192, 0.9, 1.4, 60.0)])
+def test_locomotion_simulate_at_the_benchmark_size(task, n, z_lo, z_hi, gear):
+    """One gym.simulate() (2 sub-steps) from random states -- many of them touching the ground, the Humanoid also itself -- on all
+    4096 / 8192 envs; the oracle runs every env too (OpenMP, fp64)."""
+    from oracle.engine import OracleEngine
+    env = _make_env(task, n)
+    spec, sb = load_model(task.lower()), sensor_bodies(task.lower())
+    orc = OracleEngine(spec, n, params=_sim_dict(env.sim_params), sensor_bodies=sb, precision="f64", **_selfcol_kw(task))
+    rng = np.random.default_rng(7)
+    root, q, qd = _random_state(spec, n, rng, z_lo, z_hi)
+    tau = rng.uniform(-gear, gear, (n, spec.nd))
+    t = env.engine.tensors
+    t["root_states"][:] = _t(root); env.dof_pos[:] = _t(q); env.dof_vel[:] = _t(qd)
+    for k in ("contact_impulse", "limit_impulse", "self_contact_impulse"):
+        if k in t:
+            t[k].zero_()
+    t["dof_actuation_force"][:] = _t(tau)
+    orc.root[:] = root; orc.q[:] = q; orc.qd[:] = qd
+    nsph = len(spec.sph_body)
+    for it in range(2):
+        env.engine.simulate()
+        orc.step(tau)
+        torch.cuda.synchronize()
+        g_root = t["root_states"].cpu().numpy(); g_q = env.dof_pos.cpu().numpy(); g_qd = env.dof_vel.cpu().numpy()
+        assert np.isfinite(g_root).all() and np.isfinite(g_qd).all()
+        scale = max(1.0, np.abs(orc.qd).max())
+        e = np.maximum.reduce([np.abs(g_root - orc.root).max(1), np.abs(g_q - orc.q).max(1), np.abs(g_qd - orc.qd).max(1)])
+        assert e.max() < 5e-4 * scale * (it + 1), (task, it, e.max(), int(np.argmax(e)))          # every env, tail waves included
+        fmax = max(1.0, np.abs(orc.lam).max())
+        lamc = t["contact_impulse"].cpu().numpy().reshape(n, 3 * nsph)
+        assert np.abs(lamc - orc.lam[:, :3 * nsph]).max() < 2e-3 * fmax
+        assert np.abs(t["limit_impulse"].cpu().numpy() - orc.lam[:, 3 * nsph:]).max() < 2e-3 * fmax
+        assert np.abs(env.vec_sensor_tensor.cpu().numpy() - orc.sensor).max() < 2e-3 * max(1.0, np.abs(orc.sensor).max())
+        assert np.abs(t["dof_force"].cpu().numpy() - orc.dof_force).max() < 2e-3 * max(1.0, np.abs(orc.dof_force).max())
+        if orc.npg:
+            assert np.abs(t["self_contact_impulse"].cpu().numpy() - orc.lam_pair).max() < 2e-3 * max(1.0, np.abs(orc.lam_pair).max())
+            assert np.abs(t["self_contact_force"].cpu().numpy() - orc.pair_info[:, :, :3]).max() < 2e-3 * max(1.0, np.abs(orc.pair_info[:, :, :3]).max())
+            assert (orc.pair_info[:, :, 3] >= 0).any(1).mean() > 0.3
+    assert (np.abs(orc.lam[:, :3 * nsph]).sum(1) > 0).mean() > (0.2 if task == "Ant" else 0.01)   # the scenario does load ground contacts
+
+
+def test_anymal_terrain_first_steps_at_the_benchmark_size():
+    """AnymalTerrain@4096 (5 sim steps per control step on the height field): per element state, net contact forces per body and
+    torques after the first control steps; the oracle runs all 4096 envs."""
+    n, seed = 4096, 21
+    env = _make_env("AnymalTerrain", n, seed=seed)
+    orc = _anymal_oracle(env, n, seed)
+    t = env.engine.tensors
+    np.testing.assert_array_equal(t["terrain_types"].cpu().numpy(), orc.terrain_types)
+    np.testing.assert_allclose(env.root_states.cpu().numpy(), orc.eng.root, atol=1e-5)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for step in range(2):
+        a = torch.rand((n, 12), generator=g) * 2 - 1
+        env.step(a.to(DEV))
+        orc.step(a.numpy())
+        torch.cuda.synchronize()
+        same = env.reset_buf.cpu().numpy().astype(bool) == orc.reset_buf.astype(bool)
+        assert same.mean() > 0.995
+        scale = max(1.0, np.abs(orc.eng.qd).max())
+        tol = 1e-3 * scale * (1 + step)                     # 5 sim steps per control step: 5x the one-step bound of 2e-4 ... 5e-4
+        e = np.maximum.reduce([np.abs(env.root_states.cpu().numpy() - orc.eng.root).max(1), np.abs(env.dof_pos.cpu().numpy() - orc.eng.q).max(1),
+                               np.abs(env.dof_vel.cpu().numpy() - orc.eng.qd).max(1)])
+        assert (e[same] < tol).mean() > 0.995, (step, (e[same] < tol).mean(), e[same].max())
+        ok = same & (e < tol)
+        netf = env.contact_forces.cpu().numpy()
+        assert np.abs(netf[ok] - orc.eng.netf[ok]).max() < 5e-3 * max(1.0, np.abs(orc.eng.netf).max())
+        assert np.abs(env.torques.cpu().numpy()[ok] - orc.torques[ok]).max() < 1e-2 * (1 + step)
+    assert np.abs(orc.eng.netf).max() > 50.0
+
+
+@pytest.mark.parametrize("offset", [0, 9000, 16384 - 48])
+def test_shadow_hand_first_steps_at_the_benchmark_size(offset):
+    """ShadowHand@16384: the numpy oracle follows 48 consecutive envs of the big batch (global env ids offset ... offset + 47, the last
+    window ends on the batch's tail wave); ALL 211 observation columns per element -- the force-like ones (joint forces x10 at 48:72,
+    fingertip force-torques x10 at 161:191) relative to the largest force present."""
+    import isaacgymenvs_amd
+    from isaacgymenvs_amd.registry import load_extras
+    from oracle.tasks import OracleShadowHandEnv
+    n, k, seed = 16384, 48, 13
+    env = isaacgymenvs_amd.make(seed=seed, task="ShadowHand", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True)
+    orc = OracleShadowHandEnv(load_model("shadow_hand"), load_extras("shadow_hand"), sensor_bodies("shadow_hand"),
+                              _sim_dict(env.sim_params), env._task_params_struct, k, seed=seed, env_id_offset=offset)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    sl = slice(offset, offset + k)
+    force_cols = np.r_[48:72, 161:191]
+    kin_cols = np.setdiff1d(np.arange(211), force_cols)
+    for step in range(3):
+        a = torch.rand((n, 20), generator=g) * 2 - 1
+        env.step(a.to(DEV))
+        o_obs, o_rew, o_reset = orc.step(a.numpy()[sl])
+        torch.cuda.synchronize()
+        obs = env.obs_buf[sl].cpu().numpy()
+        assert np.isfinite(obs).all()
+        np.testing.assert_array_equal(env.engine.tensors["object_contact_count"][sl].cpu().numpy() > 0, orc.eng.ncontacts > 0)
+        d = np.abs(obs - o_obs)
+        tol = 5e-3 * (1 + step)
+        ok = d[:, kin_cols].max(axis=1) < tol
+        assert ok.mean() >= 0.95, (step, ok.mean(), d[:, kin_cols].max())
+        fmax = max(1.0, np.abs(o_obs[:, force_cols]).max())
+        assert d[ok][:, force_cols].max() < 2e-2 * fmax * (1 + step), (step, d[ok][:, force_cols].max(), fmax)
+        np.testing.assert_array_equal(env.reset_buf[sl].cpu().numpy()[ok], o_reset[ok])
+        np.testing.assert_allclose(env.rew_buf[sl].cpu().numpy()[ok], o_rew[ok], atol=0.05 * (1 + step), rtol=1e-2)
