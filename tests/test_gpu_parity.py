@@ -886,7 +886,11 @@ def test_actor_params_friction_randomisation_is_tensorised_and_acts_on_the_physi
         env = isaacgymenvs_amd.make(seed=1, task="Ant", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True, cfg=cfg)
         env.step(torch.zeros((n, 8), device=DEV))
     msgs = " ".join(str(x.message) for x in w)
-    assert "ant.rigid_body_properties" in msgs and "restitution" in msgs and "friction" not in msgs.split("skipped")[-1].replace("restitution", "")
+    # restitution has no engine parameter (named once); friction and mass do
+    assert "restitution" in msgs and "rigid_body_properties" not in msgs and "friction" not in msgs.split("skipped")[-1].replace("restitution", "")
+    ms = env.engine.tensors["actor_scale"][:, 0].cpu().numpy()                     # rigid_body_properties.mass -> one factor per env
+    assert ms.min() >= 0.5 - 1e-6 and ms.max() <= 1.5 + 1e-6 and ms.std() > 0.2
+    assert float((env.engine.tensors["actor_scale"][:, 1:] - 1.0).abs().max()) == 0.0    # damping / stiffness / armature untouched
     fr = env.engine.tensors["friction"].cpu().numpy()
     og = 1.5                                                                          # nv_ant.xml geom friction: the scaling baseline
     assert abs(env.model_shape_friction - og) < 1e-6

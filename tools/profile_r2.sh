@@ -7,7 +7,7 @@ TAG=${1:-r2}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 300 --warmup 50 --no-cpu-baseline"
+BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 40 --no-cpu-baseline"
 CAL=$GRAFT_REPO_ROOT/tools/calib/calib_fetch
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o $TAG -- $BENCH > $OUT/trace.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o $TAG -- $BENCH > $OUT/pmc_fetch.log 2>&1

@@ -42,7 +42,7 @@ def agg(path):
     return d, meta
 
 
-out = [f"# rocprofv3 PMC summary `{tag}` (bench.py --steps 300 --warmup 50: Ant@4096, Humanoid@8192, AnymalTerrain@4096, ShadowHand@16384, 1x MI355X)\n",
+out = [f"# rocprofv3 PMC summary `{tag}` (bench.py --steps 200 --warmup 40: Ant@4096, Humanoid@8192, AnymalTerrain@4096, ShadowHand@16384, 1x MI355X)\n",
        "Separate passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, SQ counters), as /opt/skills/guides/MI355X_MICROARCH.md prescribes.",
        "FETCH_SIZE / WRITE_SIZE are in KB per launch as rocprofv3 reports them; the calibration section turns them into bytes.",
        "SQ counters are summed over all waves of a launch; the per-wave columns divide by SQ_WAVES; SQ_*CYCLES count quad-cycles.\n"]
