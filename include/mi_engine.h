@@ -112,6 +112,20 @@ typedef struct {
     float clip_actions;
 } MiQuadcopterParams;
 
+/* task parameters of Ingenuity (ingenuity.py:45-97, 233-282): constants the reference hard-codes in the task file */
+typedef struct {
+    float max_episode_length;            /* env.maxEpisodeLength */
+    float dt;                            /* sim.dt */
+    float thrust_upper_limit;            /* 2000 (ingenuity.py:91) */
+    float thrust_lateral_component;      /* 0.2 (:92) */
+    float thrust_action_speed_scale;     /* 2000 (:337) */
+    float max_angular_velocity;          /* asset option, 4 pi (:248) */
+    float init_height;                   /* default_pose.p.z = 1 (:254) */
+    float rotor_speed;                   /* 50: speed the two visual rotors are given at every reset (:298-299) */
+    int32_t target_period;               /* 500: a new target whenever progress_buf % 500 == 0 (:324) */
+    float clip_actions;
+} MiIngenuityParams;
+
 /* scalars of compute_hand_reward (shadow_hand.py:746-756) */
 typedef struct {
     float max_episode_length;
@@ -165,7 +179,7 @@ typedef struct {
 
 /* ---- discovery ------------------------------------------------------------------------------------------- */
 int mi_abi_version(void);
-/* task in {"Cartpole","Ant","Humanoid","AnymalTerrain","ShadowHand","Anymal","Quadcopter"}: replaces isaacgym_task_map lookup (isaacgymenvs/tasks/__init__.py:88-114)
+/* task in {"Cartpole","Ant","Humanoid","AnymalTerrain","ShadowHand","Anymal","Quadcopter","Ingenuity"}: replaces isaacgym_task_map lookup (isaacgymenvs/tasks/__init__.py:88-114)
  * + gym.get_asset_{dof,rigid_body}_count (ant.py:155-156) */
 int mi_task_info(const char* task, MiTaskInfo* out);
 size_t mi_engine_arena_bytes(const char* task, int num_envs);

@@ -5,6 +5,14 @@ quadcopter_mjcf(): the MJCF document `Quadcopter._create_quadcopter_asset` write
 45/135/225/315 degrees, each arm a small sphere body with a pitch hinge (axis y) carrying a rotor cylinder with a roll
 hinge (axis x), both limited to +-30 degrees.  Same dimensions, densities, names and element order (=> same body / dof
 order: chassis, rotor_arm0, rotor0, rotor_arm1, ...; rotor_pitch0, rotor_roll0, rotor_pitch1, ...).
+
+ingenuity_mjcf(): the document `Ingenuity._create_ingenuity_asset` writes to ./ingenuity.xml (reference
+isaacgymenvs/tasks/ingenuity.py:120-231), minus what cannot be restated: its three GLB meshes (../assets/glb/ingenuity/*.glb) are
+not part of the reference tree, so the mesh geoms -- non-colliding (contype = conaffinity = 0), they only add mass -- are left out of
+the chassis and each mesh-only "rotor_visual_i" body carries a stand-in blade (a thin box of the rotor's span) so that its free
+hinge has an inertia.  Body / dof order as in the reference (6 bodies per env with the marker actor, 4 dofs): chassis,
+rotor_physics_0, rotor_visual_0, rotor_physics_1, rotor_visual_1; rotor_roll0 (locked, range 0 0), rotor_roll0 (free, axis z),
+rotor_roll1 (locked), rotor_roll1 (free).
 """
 from __future__ import annotations
 
@@ -33,6 +41,32 @@ def quadcopter_mjcf() -> str:
                 f'          <geom type="cylinder" size="{rotor_radius:g} {0.5 * rotor_thickness:g}" density="1000"/>',
                 f'          <joint name="rotor_roll{i}" type="hinge" pos="0 0 0" axis="1 0 0" limited="true" range="-30 30"/>',
                 '        </body>',
+                '      </body>']
+    out += ['    </body>', '  </worldbody>', '</mujoco>']
+    return "\n".join(out) + "\n"
+
+
+def ingenuity_mjcf() -> str:
+    chassis_size = 0.06                                              # ingenuity.py:121-125
+    rotor_radius, rotor_thickness = 0.15, 0.01
+    blade = (rotor_radius, 0.01, 0.001)                              # stand-in for lower_prop.glb / upper_prop.glb (see the module docstring)
+    out = ['<mujoco model="Ingenuity">',
+           '  <compiler angle="degree" coordinate="local" inertiafromgeom="true"/>',
+           '  <worldbody>',
+           '    <body name="chassis" pos="0 0 0">',
+           f'      <geom type="box" size="{chassis_size:g} {chassis_size:g} {chassis_size:g}" pos="0 0 0" density="50"/>',
+           # the reference gives the chassis a hinge "root_joint" with range 0 0 (:176-180); the actor is created without
+           # fix_base_link, so the chassis floats and that joint is not one of the 4 dofs (:61, dofs_per_env)
+           '      <joint name="root_joint" type="free"/>']
+    for i in range(2):                                               # :187-229, rotor_separation = (0, 0, 0.025)
+        z = 0.025 * i
+        out += [f'      <body name="rotor_physics_{i}" pos="0 0 {z:g}" quat="1 0 0 0">',
+                f'        <geom type="cylinder" size="{rotor_radius:g} {0.5 * rotor_thickness:g}" density="1000"/>',
+                f'        <joint name="rotor_roll{i}" type="hinge" limited="true" range="0 0" pos="0 0 0"/>',
+                '      </body>',
+                f'      <body name="rotor_visual_{i}" pos="0 0 {z:g}" quat="1 0 0 0">',
+                f'        <geom type="box" size="{blade[0]:g} {blade[1]:g} {blade[2]:g}" density="1000"/>',
+                f'        <joint name="rotor_roll{i}" type="hinge" axis="0 0 1" pos="0 0 0"/>',
                 '      </body>']
     out += ['    </body>', '  </worldbody>', '</mujoco>']
     return "\n".join(out) + "\n"

@@ -1062,7 +1062,7 @@ struct Sim {
         // carry both bodies drop out, the others enter with the sign of their side -- which side(s) a dof moves depends on the bodies
         // the env's deepest pair happens to join, so it is read from the per-lane chain masks instead of being unrolled per body pair
         // (13 row-build code paths for the Humanoid instead of 66).
-        MI_STAMP(45);
+        MI_STAMP(9);      // (debug stamps: 4 .. 9 = ground contact rows, 9 .. 5 = self-collision phase)
         if constexpr (NPG > 0) { if (selfcol) {
         int cntp = 0;
         // broad phase: bounding sphere of every capsule (centre = middle of its axis, radius = half length + capsule radius); the

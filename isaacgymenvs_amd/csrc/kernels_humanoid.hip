@@ -14,3 +14,9 @@ hipError_t launch_reset_humanoid(const View& v, const LocoParams& tp, const long
 }
 
 }  // namespace mi
+
+#if defined(MI_TIMING)
+extern "C" int mi_debug_set_tstamp(void* device_buffer) {   // debug builds only (tools/debug/phase_timing_live.py)
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(mi::g_mi_tstamp), &device_buffer, sizeof(void*));
+}
+#endif

@@ -30,6 +30,7 @@ static_assert(MI_MAX_DOF == mi::kMaxDof, "MI_MAX_DOF");
 static_assert(sizeof(MiAnymalParams) == sizeof(AnymalParams), "MiAnymalParams layout");
 static_assert(sizeof(MiAnymalFlatParams) == sizeof(AnymalFlatParams), "MiAnymalFlatParams layout");
 static_assert(sizeof(MiQuadcopterParams) == sizeof(QuadcopterParams), "MiQuadcopterParams layout");
+static_assert(sizeof(MiIngenuityParams) == sizeof(IngenuityParams), "MiIngenuityParams layout");
 static_assert(sizeof(MiHandRewardParams) == sizeof(HandRewardParams), "MiHandRewardParams layout");
 static_assert(sizeof(MiHandParams) == sizeof(HandParams), "MiHandParams layout");
 
@@ -210,6 +211,12 @@ hipError_t launch_reset_quadcopter(const View& v, const QuadView& qv, const Quad
 hipError_t launch_quadcopter_reward(int n, const float* root_positions, const float* root_quats, const float* root_linvels,
                                     const float* root_angvels, const long long* progress_buf, float max_episode_length, float* rew,
                                     long long* reset, hipStream_t s);
+struct IngenuityView { float* thrusts; float* forces; float* target; float* marker; };
+hipError_t launch_step_ingenuity(const View& v, const IngenuityView& iv, const SimParams& P, const IngenuityParams& p, const float* actions,
+                                 int cfi, hipStream_t s);
+hipError_t launch_simulate_ingenuity(const View& v, const IngenuityView& iv, const SimParams& P, const IngenuityParams& p, hipStream_t s);
+hipError_t launch_init_ingenuity(const View& v, const IngenuityView& iv, const IngenuityParams& p, hipStream_t s);
+hipError_t launch_reset_ingenuity(const View& v, const IngenuityView& iv, const IngenuityParams& p, const long long* ids, int n, hipStream_t s);
 struct HandView {
     float* cur_targets; float* prev_targets; float* object_state; float* goal_state; float* fingertip; float* successes;
     long long* reset_goal; int* goal_count; float* cons; float* ws; int* ncontact;
@@ -230,6 +237,8 @@ struct MiEngine {
     AnymalFlatParams anymal_flat;
     QuadcopterParams quad;
     QuadView qv;
+    IngenuityParams ing;
+    IngenuityView iv;
     AnymalTerrainDesc terrain;
     HandParams hand;
     HandView hv;
@@ -251,6 +260,17 @@ static void build_quad_layout(int N, Layout& L, QuadView* qv, char* base) {
     o = L.add("dof_position_targets", MI_F32, {n, 8}, {1, n}, 8 * n); if (qv) qv->targets = (float*)P(o);
     o = L.add("thrusts", MI_F32, {n, 4}, {1, n}, 4 * n); if (qv) qv->thrusts = (float*)P(o);
     o = L.add("forces", MI_F32, {n, 9, 3}, {1, 3 * n, n}, 27 * n); if (qv) qv->forces = (float*)P(o);
+    L.off = (L.off + 255) & ~size_t(255);
+}
+// Ingenuity extras (ingenuity.py:63-97): the marker actor's root state is the second row of the reference's [N, 2, 13] root tensor
+static void build_ingenuity_layout(int N, Layout& L, IngenuityView* iv, char* base) {
+    const int64_t n = N;
+    auto P = [&](size_t o) { return base ? base + o : (char*)nullptr; };
+    size_t o;
+    o = L.add("thrusts", MI_F32, {n, 2, 3}, {1, 3 * n, n}, 6 * n); if (iv) iv->thrusts = (float*)P(o);
+    o = L.add("forces", MI_F32, {n, 6, 3}, {1, 3 * n, n}, 18 * n); if (iv) iv->forces = (float*)P(o);
+    o = L.add("target_root_positions", MI_F32, {n, 3}, {1, n}, 3 * n); if (iv) iv->target = (float*)P(o);
+    o = L.add("marker_states", MI_F32, {n, 13}, {1, n}, 13 * n); if (iv) iv->marker = (float*)P(o);
     L.off = (L.off + 255) & ~size_t(255);
 }
 // ShadowHand extras (shadow_hand.py:150-222): object / goal root states, targets, fingertip body states, success counters
@@ -294,6 +314,7 @@ extern "C" size_t mi_engine_arena_bytes(const char* task, int num_envs) {
     build_layout(t, num_envs, L, nullptr, nullptr);
     if (t == T_SHADOWHAND) build_hand_layout(num_envs, L, nullptr, nullptr);
     if (t == T_QUADCOPTER) build_quad_layout(num_envs, L, nullptr, nullptr);
+    if (t == T_INGENUITY) build_ingenuity_layout(num_envs, L, nullptr, nullptr);
     return L.off;
 }
 
@@ -316,6 +337,10 @@ extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const 
     else if (t == T_ANYMAL) memcpy(&e->anymal, task_params, sizeof(AnymalParams));
     else if (t == T_ANYMAL_FLAT) memcpy(&e->anymal_flat, task_params, sizeof(AnymalFlatParams));
     else if (t == T_QUADCOPTER) memcpy(&e->quad, task_params, sizeof(QuadcopterParams));
+    else if (t == T_INGENUITY) {
+        memcpy(&e->ing, task_params, sizeof(IngenuityParams));
+        if (e->ing.target_period < 1) { delete e; return fail("mi_engine_create: Ingenuity target_period must be positive"); }
+    }
     else if (t == T_SHADOWHAND) memcpy(&e->hand, task_params, sizeof(HandParams));
     else memcpy(&e->loco, task_params, sizeof(LocoParams));
     Layout L;
@@ -343,6 +368,8 @@ extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const 
     if (t == T_SHADOWHAND) build_hand_layout(num_envs, L, &e->hv, (char*)arena);
     memset(&e->qv, 0, sizeof(e->qv));
     if (t == T_QUADCOPTER) build_quad_layout(num_envs, L, &e->qv, (char*)arena);
+    memset(&e->iv, 0, sizeof(e->iv));
+    if (t == T_INGENUITY) build_ingenuity_layout(num_envs, L, &e->iv, (char*)arena);
     if (arena_bytes < L.off) { delete e; return fail("mi_engine_create: arena too small"); }
     e->descs = L.d;
     {
@@ -446,6 +473,15 @@ extern "C" int mi_engine_init_state(MiEngine* e, void* stream) {
         e->steps = 0;
         return 0;
     }
+    if (e->task == T_INGENUITY) {
+        const int blocks = (e->N + 255) / 256;
+        hipLaunchKernelGGL(init_state_kernel, dim3(blocks), dim3(256), 0, s, e->v, m.nd, 3 * m.nsph, 6 * m.nsens, m.nobs, m.nact,
+                           e->ing.init_height, (const float*)nullptr, 0.f);
+        HIP_OK(hipGetLastError());
+        HIP_OK(launch_init_ingenuity(e->v, e->iv, e->ing, s));
+        e->steps = 0;
+        return 0;
+    }
     if (e->task == T_ANYMAL_FLAT) {
         const int blocks = (e->N + 255) / 256;
         hipLaunchKernelGGL(init_state_kernel, dim3(blocks), dim3(256), 0, s, e->v, m.nd, 3 * m.nsph, 0, m.nobs, m.nact,
@@ -511,6 +547,7 @@ extern "C" int mi_engine_step(MiEngine* e, const float* actions, void* stream) {
             break;
         case T_ANYMAL_FLAT: HIP_OK(launch_step_anymal_flat(e->v, e->P, e->anymal_flat, actions, e->control_freq_inv, s)); break;
         case T_QUADCOPTER: HIP_OK(launch_step_quadcopter(e->v, e->qv, e->P, e->quad, actions, e->control_freq_inv, s)); break;
+        case T_INGENUITY: HIP_OK(launch_step_ingenuity(e->v, e->iv, e->P, e->ing, actions, e->control_freq_inv, s)); break;
     }
     e->steps++;
     return 0;
@@ -532,6 +569,7 @@ extern "C" int mi_engine_simulate(MiEngine* e, void* stream) {
             break;
         case T_ANYMAL_FLAT: HIP_OK(launch_simulate_anymal_flat(e->v, e->P, e->anymal_flat, s)); break;
         case T_QUADCOPTER: HIP_OK(launch_simulate_quadcopter(e->v, e->qv, e->P, e->quad, s)); break;
+        case T_INGENUITY: HIP_OK(launch_simulate_ingenuity(e->v, e->iv, e->P, e->ing, s)); break;
     }
     return 0;
 }
@@ -550,6 +588,7 @@ extern "C" int mi_engine_reset_idx(MiEngine* e, const int64_t* env_ids, int n, v
         case T_SHADOWHAND: HIP_OK(launch_reset_shadow_hand(e->v, e->hv, e->hand, (const long long*)env_ids, n, s)); break;
         case T_ANYMAL_FLAT: HIP_OK(launch_reset_anymal_flat(e->v, e->anymal_flat, (const long long*)env_ids, n, s)); break;
         case T_QUADCOPTER: HIP_OK(launch_reset_quadcopter(e->v, e->qv, e->quad, (const long long*)env_ids, n, s)); break;
+        case T_INGENUITY: HIP_OK(launch_reset_ingenuity(e->v, e->iv, e->ing, (const long long*)env_ids, n, s)); break;
     }
     return 0;
 }

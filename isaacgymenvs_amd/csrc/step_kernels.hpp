@@ -125,6 +125,10 @@ constexpr size_t lds_bytes() { return (size_t)Sim<M>::ROW_SLOTS * Sim<M>::LANES 
 template <class M>
 constexpr bool rows_fit_lds() { return lds_bytes<M>() <= 160 * 1024; }
 
+#if defined(MI_TIMING)
+// debug builds only (tools/debug/phase_timing_live.py): per-workgroup s_memtime stamps of the sub-step phases, 16 slots per workgroup
+__device__ unsigned long long* g_mi_tstamp = nullptr;
+#endif
 template <class M, class GND>
 __global__ __launch_bounds__(64) void substep_kernel(View v, SimParams P, ActParams ap, const float* __restrict__ actions_in, int src,
                                                      GND gnd) {
@@ -136,6 +140,9 @@ __global__ __launch_bounds__(64) void substep_kernel(View v, SimParams P, ActPar
     Sim<M> sim;
     load_sim(sim, v, e);
     load_actor_scales(sim, v, e);
+#if defined(MI_TIMING)
+    sim.tstamp = (threadIdx.x == 0 && g_mi_tstamp != nullptr) ? g_mi_tstamp + (size_t)blockIdx.x * 16 : nullptr;   // tools/debug/phase_timing_live.py
+#endif
     float tau[M::NDA];
     if (src != ACT_STORED_TAU) {         // uniform branch
         sfor<ND>([&](auto K) MI_LAMBDA {

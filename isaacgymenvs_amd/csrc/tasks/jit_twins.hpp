@@ -12,6 +12,7 @@
 // quat_diff_rad :354, local_to_world_space :376, exp_map_to_quat :599, quat_to_tan_norm :548, calc_heading_quat_inv :656).
 #pragma once
 #include "../core/quat.hpp"
+#include "ingenuity.hpp"   // ingenuity_reward
 
 namespace mi {
 
@@ -80,26 +81,7 @@ MI_HD void bbot_reward(const float* ball_pos, const float* ball_vel, float ball_
     *reset = r;
 }
 
-// ------------------------------------------------------------------------------------------------ Ingenuity
-MI_HD void ingenuity_reward(const float* pos, const float* target, const float* quat, const float* angvel, long long progress,
-                            float max_episode_length, float* reward, long long* reset) {
-    MI_NO_CONTRACT
-    const float d[3] = {target[0] - pos[0], target[1] - pos[1], target[2] - pos[2]};
-    const float target_dist = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
-    const float pos_reward = 1.0f / (1.0f + target_dist * target_dist);
-    const float zaxis[3] = {0.f, 0.f, 1.f};
-    float ups[3];
-    quat_rotate_s(quat, zaxis, 1.f, ups);
-    const float tiltage = fabsf(1.f - ups[2]);
-    const float up_reward = 5.0f / (1.0f + tiltage * tiltage);
-    const float spinnage = fabsf(angvel[2]);
-    const float spinnage_reward = 1.0f / (1.0f + spinnage * spinnage);
-    *reward = pos_reward + pos_reward * (up_reward + spinnage_reward);
-    long long die = 0;
-    if (target_dist > 8.0f) die = 1;
-    if (pos[2] < 0.5f) die = 1;
-    *reset = ((float)progress >= max_episode_length - 1.f) ? 1 : die;
-}
+// ------------------------------------------------------------------------------------------------ Ingenuity: tasks/ingenuity.hpp (shared with the task kernels)
 
 // ------------------------------------------------------------------------------------------------ FrankaCabinet
 struct FrankaCabinetRewardParams {  // mirrors MiFrankaCabinetRewardParams; the float arguments of franka_cabinet.py:488-497

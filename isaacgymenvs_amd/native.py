@@ -20,7 +20,7 @@ CSRC = os.path.join(_HERE, "csrc")
 BUILD_DIR = os.path.join(CSRC, "build")
 # one translation unit per robot model (they compile in parallel) + the C ABI
 SOURCES = ["mi_engine.hip", "kernels_cartpole.hip", "kernels_ant.hip", "kernels_humanoid.hip", "kernels_anymal.hip", "kernels_shadow_hand.hip",
-           "kernels_shadow_hand_pen.hip", "kernels_shadow_hand_egg.hip", "kernels_quadcopter.hip", "kernels_jit_twins.hip",
+           "kernels_shadow_hand_pen.hip", "kernels_shadow_hand_egg.hip", "kernels_quadcopter.hip", "kernels_ingenuity.hip", "kernels_jit_twins.hip",
            "kernels_mw_ant.hip", "kernels_mw_anymal.hip"]
 MI_MAX_DOF = 32
 
@@ -85,6 +85,12 @@ class MiQuadcopterParams(C.Structure):
                 ("max_thrust", C.c_float), ("dof_action_speed_scale", C.c_float), ("thrust_action_speed_scale", C.c_float),
                 ("drive_stiffness", C.c_float), ("drive_damping", C.c_float), ("max_angular_velocity", C.c_float),
                 ("init_height", C.c_float), ("clip_actions", C.c_float)]
+
+
+class MiIngenuityParams(C.Structure):
+    _fields_ = [("max_episode_length", C.c_float), ("dt", C.c_float), ("thrust_upper_limit", C.c_float),
+                ("thrust_lateral_component", C.c_float), ("thrust_action_speed_scale", C.c_float), ("max_angular_velocity", C.c_float),
+                ("init_height", C.c_float), ("rotor_speed", C.c_float), ("target_period", C.c_int32), ("clip_actions", C.c_float)]
 
 
 class MiHandRewardParams(C.Structure):

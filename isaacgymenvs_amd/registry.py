@@ -23,6 +23,8 @@ MODELS = {
     # reference quadcopter.py:287-292: thrust forces act on the four rotor bodies (bodies 2, 4, 6, 8); they are listed as
     # "sensor" bodies because the engine records the world pose of exactly those bodies during its tree pass
     "quadcopter": dict(struct="ModelQuadcopter", sensors=["rotor0", "rotor1", "rotor2", "rotor3"]),
+    # reference ingenuity.py:347-348: the thrust vectors act on bodies 1 and 3 (rotor_physics_0 / _1), in their local frames
+    "ingenuity": dict(struct="ModelIngenuity", sensors=["rotor_physics_0", "rotor_physics_1"]),
 }
 
 

@@ -4,6 +4,7 @@ from .anymal import Anymal
 from .anymal_terrain import AnymalTerrain
 from .cartpole import Cartpole
 from .humanoid import Humanoid
+from .ingenuity import Ingenuity
 from .quadcopter import Quadcopter
 from .shadow_hand import ShadowHand
 
@@ -13,6 +14,7 @@ isaacgym_task_map = {
     "AnymalTerrain": AnymalTerrain,
     "Cartpole": Cartpole,
     "Humanoid": Humanoid,
+    "Ingenuity": Ingenuity,
     "Quadcopter": Quadcopter,
     "ShadowHand": ShadowHand,
 }

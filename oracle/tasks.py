@@ -820,6 +820,98 @@ class OracleQuadcopterEnv:
         return self.obs_buf, self.rew_buf, self.reset_buf
 
 
+# ===================================================================================================== Ingenuity
+class OracleIngenuityEnv:
+    """vec_task.py:360-408 + ingenuity.py pre/post_physics_step on oracle/physics.c (or_step_drive with zero gains: passive
+    joints, the two thrust vectors on the rotor bodies in their local frames, no contacts, Mars gravity from sim_params)."""
+
+    def __init__(self, spec, sensor_bodies, sim_params: dict, params, num_envs, seed=0, env_id_offset=0, precision="f64", control_freq_inv=1):
+        from .engine import OracleEngine
+        self.N, self.p, self.nd, self.spec = num_envs, params, spec.nd, spec
+        self.substeps = int(sim_params.get("substeps", 2))
+        sp = dict(sim_params, dt=sim_params["dt"] / self.substeps, substeps=1)   # one call per sub-step (angular-velocity clamp)
+        self.eng = OracleEngine(spec, num_envs, params=sp, sensor_bodies=sensor_bodies, precision=precision)
+        self.rotors = list(sensor_bodies)
+        self.seed, self.off, self.cfi = fold_seed(seed), env_id_offset, control_freq_inv
+        self.genv = (self.off + np.arange(num_envs)).astype(np.uint32)
+        N = num_envs
+        self.eng.root[:, 2] = params.init_height
+        self.thrusts = np.zeros((N, 2, 3), f32)
+        self.forces = np.zeros((N, 6, 3), f32)                                   # bodies_per_env counts the marker (ingenuity.py:62)
+        self.target = np.zeros((N, 3), f32); self.target[:, 2] = 1               # :72-73
+        self.marker = np.zeros((N, 13), f32); self.marker[:, 2] = params.init_height; self.marker[:, 6] = 1
+        self.progress_buf = np.zeros(N, np.int64)
+        self.reset_buf = np.ones(N, np.int64)
+        self.episode = np.zeros(N, np.uint32)
+
+    def set_targets(self, ids, slot):  # ingenuity.py:284-293
+        if len(ids) == 0:
+            return
+        g, ep = self.genv[ids], self.episode[ids]
+        slot = np.asarray(slot, np.uint32)
+        t = np.stack([mi_uniform(self.seed, g, ep, slot) * f32(10) - f32(5), mi_uniform(self.seed, g, ep, slot + np.uint32(1)) * f32(10) - f32(5),
+                      mi_uniform(self.seed, g, ep, slot + np.uint32(2)) + f32(1)], axis=1).astype(f32)
+        self.target[ids] = t
+        self.marker[ids, 0:3] = t
+        self.marker[ids, 2] += f32(0.4)
+
+    def reset_idx(self, ids):  # :295-319
+        if len(ids) == 0:
+            return
+        self.set_targets(ids, np.full(len(ids), 3, np.uint32))
+        g, ep = self.genv[ids], self.episode[ids]
+        root = np.zeros((len(ids), 13), f32); root[:, 2] = f32(self.p.init_height); root[:, 6] = 1
+        root[:, 0] += (f32(1.5) - f32(-1.5)) * mi_uniform(self.seed, g, ep, 0) + f32(-1.5)
+        root[:, 1] += (f32(1.5) - f32(-1.5)) * mi_uniform(self.seed, g, ep, 1) + f32(-1.5)
+        root[:, 2] += (f32(1.5) - f32(-0.2)) * mi_uniform(self.seed, g, ep, 2) + f32(-0.2)
+        self.eng.root[ids] = root
+        self.eng.qd[ids, 1] = -float(self.p.rotor_speed)                         # positions and the other two speeds stay (:298-312)
+        self.eng.qd[ids, 3] = float(self.p.rotor_speed)
+        self.eng.lam[ids] = 0
+        self.episode[ids] += 1
+        self.reset_buf[ids] = 0
+        self.progress_buf[ids] = 0
+
+    def step(self, actions):
+        from .jit_twins import compute_ingenuity_reward
+        p = self.p
+        period = int(p.target_period)
+        tid = np.nonzero(self.progress_buf % period == 0)[0]                      # :324-327
+        self.set_targets(tid, (8 + 3 * (self.progress_buf[tid] // period)).astype(np.uint32))
+        ids = np.nonzero(self.reset_buf)[0]                                       # :329-332
+        self.reset_idx(ids)
+        a = np.clip(actions.astype(f32), -f32(p.clip_actions), f32(p.clip_actions))
+        up, lat, dt = f32(p.thrust_upper_limit), f32(p.thrust_lateral_component), f32(p.dt)
+        for r in range(2):                                                        # :337-345
+            vertical = np.clip(a[:, 3 * r + 2] * f32(p.thrust_action_speed_scale), -up, up).astype(f32)
+            self.thrusts[:, r, 2] = dt * vertical
+            self.thrusts[:, r, 0:2] = self.thrusts[:, r, 2, None] * np.clip(a[:, 3 * r:3 * r + 2], -lat, lat)
+        self.forces[:] = 0
+        self.forces[:, self.rotors[0]] = self.thrusts[:, 0]                       # :347-348 (bodies 1 and 3)
+        self.forces[:, self.rotors[1]] = self.thrusts[:, 1]
+        self.thrusts[ids] = 0                                                     # :350-352
+        self.forces[ids] = 0
+        wmax = float(p.max_angular_velocity)
+        for _ in range(self.cfi * self.substeps):
+            self.eng.step_drive(np.zeros((self.N, self.nd)), 0.0, 0.0, np.zeros((self.N, self.nd), f32), self.forces[:, :self.spec.nb])
+            w = self.eng.root[:, 10:13]
+            n = np.linalg.norm(w, axis=1)
+            big = n > wmax
+            w[big] *= (wmax / n[big])[:, None]
+        # post_physics_step (:356-365)
+        self.progress_buf += 1
+        root = self.eng.root.astype(f32)
+        obs = np.zeros((self.N, 13), f32)
+        obs[:, 0:3] = (self.target - root[:, 0:3]) / f32(3)
+        obs[:, 3:7] = root[:, 3:7]
+        obs[:, 7:10] = root[:, 7:10] / f32(2)
+        obs[:, 10:13] = root[:, 10:13] / f32(np.pi)
+        self.obs_buf = obs
+        self.rew_buf, self.reset_buf = compute_ingenuity_reward(root[:, 0:3], self.target, root[:, 3:7], root[:, 7:10], root[:, 10:13],
+                                                                self.reset_buf, self.progress_buf, f32(p.max_episode_length))
+        return self.obs_buf, self.rew_buf, self.reset_buf
+
+
 def quat_conjugate(a):  # torch_jit_utils.py:107-110
     return np.concatenate([-a[:, :3], a[:, 3:4]], axis=-1).astype(f32)
 

@@ -687,6 +687,70 @@ def test_quadcopter_full_size_properties():
     assert (env.root_positions[:, 2] > 0.3).float().mean() > 0.9
 
 
+# ------------------------------------------------------------------ Ingenuity (thrust vectors on two rotor bodies, Mars gravity, moving targets; reference tasks/ingenuity.py)
+def test_ingenuity_step_matches_cpu_restatement():
+    from oracle.tasks import OracleIngenuityEnv
+    n, seed = 128, 29
+    env = _make_env("Ingenuity", n, seed=seed)
+    assert tuple(env.sim_params.gravity) == pytest.approx((0.0, 0.0, -3.721))          # ingenuity.py:109-112
+    env._task_params_struct.target_period                                               # (the struct the engine was created with)
+    orc = OracleIngenuityEnv(load_model("ingenuity"), sensor_bodies("ingenuity"), _sim_dict(env.sim_params), env._task_params_struct, n,
+                             seed=seed, precision="f64")
+    hover = env.spec.total_mass() * 3.721 / (2 * 0.01 * 2000.0)                        # action that makes each rotor carry half the weight
+    g = torch.Generator(device="cpu").manual_seed(4)
+    for step in range(60):
+        a = torch.rand((n, 6), generator=g) * 2 - 1
+        a[:, [2, 5]] = hover + 0.15 * a[:, [2, 5]]                                      # around hover: the craft drifts, tilts and tumbles
+        obs_d, rew, reset, extras = env.step(a.to(DEV))
+        o_obs, o_rew, o_reset = orc.step(a.numpy())
+        torch.cuda.synchronize()
+        obs = env.obs_buf.cpu().numpy()
+        assert np.isfinite(obs).all()
+        np.testing.assert_allclose(env.thrusts.cpu().numpy(), orc.thrusts, atol=1e-6)
+        np.testing.assert_allclose(env.forces.cpu().numpy(), orc.forces, atol=1e-6)
+        np.testing.assert_allclose(env.target_root_positions.cpu().numpy(), orc.target, atol=1e-6)
+        np.testing.assert_allclose(env.marker_states.cpu().numpy(), orc.marker, atol=1e-6)
+        tol = 2e-4 * (1 + step)                               # smooth free flight: fp32 vs fp64 drift only
+        np.testing.assert_allclose(obs, o_obs, atol=tol)
+        np.testing.assert_array_equal(reset.cpu().numpy(), o_reset)
+        np.testing.assert_allclose(rew.cpu().numpy(), o_rew, atol=5 * tol)
+        np.testing.assert_array_equal(env.progress_buf.cpu().numpy(), orc.progress_buf)
+        np.testing.assert_allclose(env.dof_velocities.cpu().numpy(), orc.eng.qd, atol=50 * tol)
+    assert obs_d["obs"].shape == (n, 13)
+    assert abs(float(env.dof_velocities[:, 1].mean()) + 50.0) < 1.0 and abs(float(env.dof_velocities[:, 3].mean()) - 50.0) < 1.0
+    assert float(env.dof_positions[:, [0, 2]].abs().max()) < 0.02                       # the two locked rotor joints (range 0 0)
+
+
+def test_ingenuity_targets_move_every_500_steps_at_full_size():
+    n = 4096                                                  # cfg/task/Ingenuity.yaml numEnvs
+    env = _make_env("Ingenuity", n, seed=42)
+    hover = env.spec.total_mass() * 3.721 / (2 * 0.01 * 2000.0)
+    first = None
+    resets = 0
+    for step in range(520):
+        a = torch.zeros((n, 6), device=DEV)
+        # a crude position hold: thrust towards the target height, damped by the vertical speed; lateral fractions towards the target
+        dz = env.target_root_positions[:, 2] - env.root_positions[:, 2]
+        up = (hover * (1.0 + 0.4 * dz - 0.4 * env.root_linvels[:, 2])).clamp(0.0, 1.0)
+        a[:, 2] = up; a[:, 5] = up
+        obs_d, rew, reset, extras = env.step(a)
+        resets += int(reset.sum())
+        if step == 1:
+            first = env.target_root_positions.clone()
+        if step == 400:
+            alive = env.progress_buf > 400
+            assert alive.float().mean() > 0.5                               # the hold keeps most crafts inside the 8 m ball
+            assert torch.equal(env.target_root_positions[alive], first[alive])   # no new target before step 500
+    moved = (env.target_root_positions != first).any(dim=1)
+    old = env.progress_buf > 500
+    assert old.any() and moved[old].all()                                   # ingenuity.py:324: progress % 500 == 0 draws a new one
+    t = env.target_root_positions
+    assert (t[:, :2].abs() <= 5).all() and (t[:, 2] >= 1).all() and (t[:, 2] <= 2).all()          # :286-287
+    np.testing.assert_allclose((env.marker_positions - t).cpu().numpy(), np.tile([0, 0, 0.4], (n, 1)), atol=1e-6)
+    assert torch.isfinite(obs_d["obs"]).all() and (rew > 0).all() and (rew <= 7.0 + 1e-5).all()   # pos + pos * (5 + 1)
+    assert env.root_angvels.norm(dim=-1).max() <= 4 * np.pi + 1e-3
+
+
 # ------------------------------------------------------------------ ShadowHand (hand + cube physics, deferred resets, full_state obs)
 @pytest.mark.parametrize("object_type", ["block", "egg", "pen"])
 def test_shadow_hand_step_matches_cpu_restatement(object_type):
@@ -792,7 +856,7 @@ def test_shadow_hand_full_size_properties():
 
 
 # ------------------------------------------------------------------ determinism (guards against miscompiled / hazard-prone builds)
-@pytest.mark.parametrize("task,n", [("Cartpole", 256), ("Ant", 1024), ("Humanoid", 1024), ("AnymalTerrain", 1024), ("ShadowHand", 512), ("Anymal", 1024), ("Quadcopter", 1024)])
+@pytest.mark.parametrize("task,n", [("Cartpole", 256), ("Ant", 1024), ("Humanoid", 1024), ("AnymalTerrain", 1024), ("ShadowHand", 512), ("Anymal", 1024), ("Quadcopter", 1024), ("Ingenuity", 1024)])
 def test_two_engines_same_seed_are_bit_identical(task, n):
     """Two independent engine instances, same seed and actions => bit-identical trajectories.  An earlier build of
     the sub-step (register-spilling regime) returned run-to-run different results on gfx950."""
@@ -1004,7 +1068,7 @@ def test_rlgames_adapter_surface():
     assert venv.reset_done()[0]["obs"].shape == (64, 4)
 
 
-@pytest.mark.parametrize("task,nact", [("Cartpole", 1), ("Ant", 8), ("Humanoid", 21), ("Anymal", 12), ("Quadcopter", 12)])
+@pytest.mark.parametrize("task,nact", [("Cartpole", 1), ("Ant", 8), ("Humanoid", 21), ("Anymal", 12), ("Quadcopter", 12), ("Ingenuity", 6)])
 def test_ragged_env_counts_and_shard_invariance(task, nact, monkeypatch):
     """Env counts that do not fill a wave (1, 37, 100; 32- and 64-lane kernels) and sharding: an env's trajectory depends
     only on (seed, global env id, actions) -- never on how many envs run beside it or on which rank it lives."""

@@ -114,6 +114,9 @@ PROCEDURAL = {
     # reference quadcopter.py:119-198; the craft is reset below z = 0.3 m (:411) before it can reach the ground plane, so no
     # contact geometry is generated; thrust is applied at the four rotor bodies (:287-292)
     "quadcopter": dict(gen="quadcopter_mjcf", collide_body_filter=lambda n: False),
+    # reference ingenuity.py:120-231; reset below z = 0.5 m (:449) with a 6 cm chassis and 15 cm rotors: the ground is out of reach,
+    # the marker actor shares the craft's collision filter bit (:262, :268): no contact geometry
+    "ingenuity": dict(gen="ingenuity_mjcf", collide_body_filter=lambda n: False),
 }
 
 
