@@ -126,6 +126,27 @@ typedef struct {
     float clip_actions;
 } MiIngenuityParams;
 
+/* task parameters of BallBalance (ball_balance.py:56-62, 136-306): the lengths of the generated asset and the constants the
+ * reference hard-codes in the task file */
+typedef struct {
+    float max_episode_length;            /* env.maxEpisodeLength */
+    float dt;                            /* sim.dt */
+    float action_speed_scale;            /* env.actionSpeedScale */
+    float dof_lower[6], dof_upper[6];    /* joint limits of the generated asset: +-45 degrees upper, -70 .. 90 degrees lower leg joints */
+    float tray_height;                   /* bbot_pose.p.z (ball_balance.py:251-252) */
+    float ball_init_pos[3];              /* (0.2, 0, 2) (:303-306) */
+    float clip_actions;
+    /* physics of the sub-step (csrc/core/bbot_engine.hpp) */
+    float pin_stiffness, pin_damping;    /* attractors, 5e7 / 5e3 (:287-288) */
+    float drive_kp, drive_kd;            /* DOF_MODE_POS drive of the actuated dofs, 4000 / 100 (:276-277) */
+    int32_t actuated_mask;               /* bit d: dof d is position driven; dofs 1, 3, 5 (:271) */
+    float ball_radius, ball_mass, ball_inertia, mu;   /* sphere radius 0.1, density 200 (:263-266); combined friction */
+    float tray_radius, tray_half;        /* collision cylinder of the tray (:139-140) */
+    float pin_offset[3];                 /* attractor offset in the lower leg's frame (:299) */
+    float pin_target[3][3];              /* attractor targets, env frame (:293-297) */
+    float sensor_pos[3][3];              /* force-sensor origins in the tray frame (:256-259) */
+} MiBallBalanceParams;
+
 /* scalars of compute_hand_reward (shadow_hand.py:746-756) */
 typedef struct {
     float max_episode_length;
@@ -179,7 +200,7 @@ typedef struct {
 
 /* ---- discovery ------------------------------------------------------------------------------------------- */
 int mi_abi_version(void);
-/* task in {"Cartpole","Ant","Humanoid","AnymalTerrain","ShadowHand","Anymal","Quadcopter","Ingenuity"}: replaces isaacgym_task_map lookup (isaacgymenvs/tasks/__init__.py:88-114)
+/* task in {"Cartpole","Ant","Humanoid","AnymalTerrain","ShadowHand","Anymal","Quadcopter","Ingenuity","BallBalance"}: replaces isaacgym_task_map lookup (isaacgymenvs/tasks/__init__.py:88-114)
  * + gym.get_asset_{dof,rigid_body}_count (ant.py:155-156) */
 int mi_task_info(const char* task, MiTaskInfo* out);
 size_t mi_engine_arena_bytes(const char* task, int num_envs);

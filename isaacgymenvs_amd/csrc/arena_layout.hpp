@@ -12,6 +12,7 @@
 #include "tasks/anymal.hpp"
 #include "tasks/quadcopter.hpp"
 #include "tasks/ingenuity.hpp"
+#include "tasks/ball_balance.hpp"
 #include "gen/model_ant.h"
 #include "gen/model_cartpole.h"
 #include "gen/model_humanoid.h"
@@ -19,11 +20,12 @@
 #include "gen/model_shadow_hand.h"
 #include "gen/model_quadcopter.h"
 #include "gen/model_ingenuity.h"
+#include "gen/model_balance_bot.h"
 
 using namespace mi;
 
-enum TaskId { T_CARTPOLE = 0, T_ANT = 1, T_HUMANOID = 2, T_ANYMAL = 3, T_SHADOWHAND = 4, T_ANYMAL_FLAT = 5, T_QUADCOPTER = 6, T_INGENUITY = 7 };
-constexpr int kNumTasks = 8;
+enum TaskId { T_CARTPOLE = 0, T_ANT = 1, T_HUMANOID = 2, T_ANYMAL = 3, T_SHADOWHAND = 4, T_ANYMAL_FLAT = 5, T_QUADCOPTER = 6, T_INGENUITY = 7, T_BALLBALANCE = 8 };
+constexpr int kNumTasks = 9;
 struct TaskMeta { const char* name; int nobs, nact, nd, nb, nsens, nsph, fixed; size_t pbytes; };
 static const TaskMeta kTasks[] = {
     {"Cartpole", 4, 1, ModelCartpole::ND, ModelCartpole::NB, 0, ModelCartpole::NSPH, 1, sizeof(MiCartpoleParams)},
@@ -34,6 +36,7 @@ static const TaskMeta kTasks[] = {
     {"Anymal", kAnymalFlatObs, kAnymalDof, ModelAnymal::ND, ModelAnymal::NB, 0, ModelAnymal::NSPH, 0, sizeof(MiAnymalFlatParams)},
     {"Quadcopter", kQuadObs, kQuadAct, ModelQuadcopter::ND, ModelQuadcopter::NB, ModelQuadcopter::NSENS, ModelQuadcopter::NSPH, 0, sizeof(MiQuadcopterParams)},
     {"Ingenuity", kIngObs, kIngAct, ModelIngenuity::ND, ModelIngenuity::NB, ModelIngenuity::NSENS, ModelIngenuity::NSPH, 0, sizeof(MiIngenuityParams)},
+    {"BallBalance", kBbotObs, kBbotAct, ModelBalanceBot::ND, ModelBalanceBot::NB, ModelBalanceBot::NSENS, ModelBalanceBot::NSPH, 0, sizeof(MiBallBalanceParams)},
 };
 static int find_task(const char* t) {
     for (int i = 0; i < kNumTasks; ++i) if (!strcmp(t, kTasks[i].name)) return i;

@@ -31,6 +31,7 @@ static_assert(sizeof(MiAnymalParams) == sizeof(AnymalParams), "MiAnymalParams la
 static_assert(sizeof(MiAnymalFlatParams) == sizeof(AnymalFlatParams), "MiAnymalFlatParams layout");
 static_assert(sizeof(MiQuadcopterParams) == sizeof(QuadcopterParams), "MiQuadcopterParams layout");
 static_assert(sizeof(MiIngenuityParams) == sizeof(IngenuityParams), "MiIngenuityParams layout");
+static_assert(sizeof(MiBallBalanceParams) == sizeof(BallBalanceParams), "MiBallBalanceParams layout");
 static_assert(sizeof(MiHandRewardParams) == sizeof(HandRewardParams), "MiHandRewardParams layout");
 static_assert(sizeof(MiHandParams) == sizeof(HandParams), "MiHandParams layout");
 
@@ -217,6 +218,12 @@ hipError_t launch_step_ingenuity(const View& v, const IngenuityView& iv, const S
 hipError_t launch_simulate_ingenuity(const View& v, const IngenuityView& iv, const SimParams& P, const IngenuityParams& p, hipStream_t s);
 hipError_t launch_init_ingenuity(const View& v, const IngenuityView& iv, const IngenuityParams& p, hipStream_t s);
 hipError_t launch_reset_ingenuity(const View& v, const IngenuityView& iv, const IngenuityParams& p, const long long* ids, int n, hipStream_t s);
+struct BbotView { float* targets; float* ball; float* lamp; int* ncontact; };
+hipError_t launch_step_ball_balance(const View& v, const BbotView& bv, const SimParams& P, const BallBalanceParams& p, const float* actions,
+                                    int cfi, hipStream_t s);
+hipError_t launch_simulate_ball_balance(const View& v, const BbotView& bv, const SimParams& P, const BallBalanceParams& p, hipStream_t s);
+hipError_t launch_init_ball_balance(const View& v, const BbotView& bv, const BallBalanceParams& p, hipStream_t s);
+hipError_t launch_reset_ball_balance(const View& v, const BbotView& bv, const BallBalanceParams& p, const long long* ids, int n, hipStream_t s);
 struct HandView {
     float* cur_targets; float* prev_targets; float* object_state; float* goal_state; float* fingertip; float* successes;
     long long* reset_goal; int* goal_count; float* cons; float* ws; int* ncontact;
@@ -239,6 +246,8 @@ struct MiEngine {
     QuadView qv;
     IngenuityParams ing;
     IngenuityView iv;
+    BallBalanceParams bbot;
+    BbotView bv;
     AnymalTerrainDesc terrain;
     HandParams hand;
     HandView hv;
@@ -271,6 +280,17 @@ static void build_ingenuity_layout(int N, Layout& L, IngenuityView* iv, char* ba
     o = L.add("forces", MI_F32, {n, 6, 3}, {1, 3 * n, n}, 18 * n); if (iv) iv->forces = (float*)P(o);
     o = L.add("target_root_positions", MI_F32, {n, 3}, {1, n}, 3 * n); if (iv) iv->target = (float*)P(o);
     o = L.add("marker_states", MI_F32, {n, 13}, {1, n}, 13 * n); if (iv) iv->marker = (float*)P(o);
+    L.off = (L.off + 255) & ~size_t(255);
+}
+// BallBalance extras (ball_balance.py:88-112): the ball actor's root state is the second row of the reference's [N, 2, 13] root tensor
+static void build_bbot_layout(int N, Layout& L, BbotView* bv, char* base) {
+    const int64_t n = N;
+    auto P = [&](size_t o) { return base ? base + o : (char*)nullptr; };
+    size_t o;
+    o = L.add("dof_position_targets", MI_F32, {n, 6}, {1, n}, 6 * n); if (bv) bv->targets = (float*)P(o);
+    o = L.add("ball_states", MI_F32, {n, 13}, {1, n}, 13 * n); if (bv) bv->ball = (float*)P(o);
+    o = L.add("attractor_impulse", MI_F32, {n, 3, 3}, {1, 3 * n, n}, 9 * n); if (bv) bv->lamp = (float*)P(o);
+    o = L.add("ball_contact_count", MI_I32, {n}, {1}, n); if (bv) bv->ncontact = (int*)P(o);
     L.off = (L.off + 255) & ~size_t(255);
 }
 // ShadowHand extras (shadow_hand.py:150-222): object / goal root states, targets, fingertip body states, success counters
@@ -315,6 +335,7 @@ extern "C" size_t mi_engine_arena_bytes(const char* task, int num_envs) {
     if (t == T_SHADOWHAND) build_hand_layout(num_envs, L, nullptr, nullptr);
     if (t == T_QUADCOPTER) build_quad_layout(num_envs, L, nullptr, nullptr);
     if (t == T_INGENUITY) build_ingenuity_layout(num_envs, L, nullptr, nullptr);
+    if (t == T_BALLBALANCE) build_bbot_layout(num_envs, L, nullptr, nullptr);
     return L.off;
 }
 
@@ -340,6 +361,15 @@ extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const 
     else if (t == T_INGENUITY) {
         memcpy(&e->ing, task_params, sizeof(IngenuityParams));
         if (e->ing.target_period < 1) { delete e; return fail("mi_engine_create: Ingenuity target_period must be positive"); }
+    }
+    else if (t == T_BALLBALANCE) {
+        memcpy(&e->bbot, task_params, sizeof(BallBalanceParams));
+        const BallBalanceParams& b = e->bbot;
+        if (!(b.ball_mass > 0.f) || !(b.ball_inertia > 0.f) || !(b.ball_radius > 0.f) || !(b.pin_stiffness >= 0.f) || !(b.pin_damping >= 0.f) ||
+            !(b.pin_stiffness + b.pin_damping > 0.f)) {
+            delete e;
+            return fail("mi_engine_create: BallBalance needs positive ball mass / inertia / radius and a non-zero attractor");
+        }
     }
     else if (t == T_SHADOWHAND) memcpy(&e->hand, task_params, sizeof(HandParams));
     else memcpy(&e->loco, task_params, sizeof(LocoParams));
@@ -370,6 +400,8 @@ extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const 
     if (t == T_QUADCOPTER) build_quad_layout(num_envs, L, &e->qv, (char*)arena);
     memset(&e->iv, 0, sizeof(e->iv));
     if (t == T_INGENUITY) build_ingenuity_layout(num_envs, L, &e->iv, (char*)arena);
+    memset(&e->bv, 0, sizeof(e->bv));
+    if (t == T_BALLBALANCE) build_bbot_layout(num_envs, L, &e->bv, (char*)arena);
     if (arena_bytes < L.off) { delete e; return fail("mi_engine_create: arena too small"); }
     e->descs = L.d;
     {
@@ -482,6 +514,15 @@ extern "C" int mi_engine_init_state(MiEngine* e, void* stream) {
         e->steps = 0;
         return 0;
     }
+    if (e->task == T_BALLBALANCE) {
+        const int blocks = (e->N + 255) / 256;
+        hipLaunchKernelGGL(init_state_kernel, dim3(blocks), dim3(256), 0, s, e->v, m.nd, 3 * m.nsph, 6 * m.nsens, m.nobs, m.nact,
+                           e->bbot.tray_height, (const float*)nullptr, 0.f);
+        HIP_OK(hipGetLastError());
+        HIP_OK(launch_init_ball_balance(e->v, e->bv, e->bbot, s));
+        e->steps = 0;
+        return 0;
+    }
     if (e->task == T_ANYMAL_FLAT) {
         const int blocks = (e->N + 255) / 256;
         hipLaunchKernelGGL(init_state_kernel, dim3(blocks), dim3(256), 0, s, e->v, m.nd, 3 * m.nsph, 0, m.nobs, m.nact,
@@ -548,6 +589,7 @@ extern "C" int mi_engine_step(MiEngine* e, const float* actions, void* stream) {
         case T_ANYMAL_FLAT: HIP_OK(launch_step_anymal_flat(e->v, e->P, e->anymal_flat, actions, e->control_freq_inv, s)); break;
         case T_QUADCOPTER: HIP_OK(launch_step_quadcopter(e->v, e->qv, e->P, e->quad, actions, e->control_freq_inv, s)); break;
         case T_INGENUITY: HIP_OK(launch_step_ingenuity(e->v, e->iv, e->P, e->ing, actions, e->control_freq_inv, s)); break;
+        case T_BALLBALANCE: HIP_OK(launch_step_ball_balance(e->v, e->bv, e->P, e->bbot, actions, e->control_freq_inv, s)); break;
     }
     e->steps++;
     return 0;
@@ -570,6 +612,7 @@ extern "C" int mi_engine_simulate(MiEngine* e, void* stream) {
         case T_ANYMAL_FLAT: HIP_OK(launch_simulate_anymal_flat(e->v, e->P, e->anymal_flat, s)); break;
         case T_QUADCOPTER: HIP_OK(launch_simulate_quadcopter(e->v, e->qv, e->P, e->quad, s)); break;
         case T_INGENUITY: HIP_OK(launch_simulate_ingenuity(e->v, e->iv, e->P, e->ing, s)); break;
+        case T_BALLBALANCE: HIP_OK(launch_simulate_ball_balance(e->v, e->bv, e->P, e->bbot, s)); break;
     }
     return 0;
 }
@@ -589,6 +632,7 @@ extern "C" int mi_engine_reset_idx(MiEngine* e, const int64_t* env_ids, int n, v
         case T_ANYMAL_FLAT: HIP_OK(launch_reset_anymal_flat(e->v, e->anymal_flat, (const long long*)env_ids, n, s)); break;
         case T_QUADCOPTER: HIP_OK(launch_reset_quadcopter(e->v, e->qv, e->quad, (const long long*)env_ids, n, s)); break;
         case T_INGENUITY: HIP_OK(launch_reset_ingenuity(e->v, e->iv, e->ing, (const long long*)env_ids, n, s)); break;
+        case T_BALLBALANCE: HIP_OK(launch_reset_ball_balance(e->v, e->bv, e->bbot, (const long long*)env_ids, n, s)); break;
     }
     return 0;
 }

@@ -12,6 +12,7 @@
 // quat_diff_rad :354, local_to_world_space :376, exp_map_to_quat :599, quat_to_tan_norm :548, calc_heading_quat_inv :656).
 #pragma once
 #include "../core/quat.hpp"
+#include "ball_balance.hpp"   // bbot_reward
 #include "ingenuity.hpp"   // ingenuity_reward
 
 namespace mi {
@@ -67,19 +68,7 @@ MI_HD void local_to_world_space(const float* p_local, const float* pose, float* 
     for (int k = 0; k < 3; ++k) o[k] = r[k] + pose[k];
 }
 
-// ------------------------------------------------------------------------------------------------ BallBalance
-MI_HD void bbot_reward(const float* ball_pos, const float* ball_vel, float ball_radius, long long reset_in, long long progress,
-                       float max_episode_length, float* reward, long long* reset) {
-    MI_NO_CONTRACT
-    const float ball_dist = sqrtf((ball_pos[0] * ball_pos[0] + (ball_pos[2] - 0.7f) * (ball_pos[2] - 0.7f)) + ball_pos[1] * ball_pos[1]);
-    const float ball_speed = sqrtf((ball_vel[0] * ball_vel[0] + ball_vel[1] * ball_vel[1]) + ball_vel[2] * ball_vel[2]);
-    const float pos_reward = 1.0f / (1.0f + ball_dist);
-    const float speed_reward = 1.0f / (1.0f + ball_speed);
-    *reward = pos_reward * speed_reward;
-    long long r = ((float)progress >= max_episode_length - 1.f) ? 1 : reset_in;
-    if (ball_pos[2] < ball_radius * 1.5f) r = 1;
-    *reset = r;
-}
+// ------------------------------------------------------------------------------------------------ BallBalance: tasks/ball_balance.hpp (shared with the task kernels)
 
 // ------------------------------------------------------------------------------------------------ Ingenuity: tasks/ingenuity.hpp (shared with the task kernels)
 

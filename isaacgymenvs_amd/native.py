@@ -20,7 +20,7 @@ CSRC = os.path.join(_HERE, "csrc")
 BUILD_DIR = os.path.join(CSRC, "build")
 # one translation unit per robot model (they compile in parallel) + the C ABI
 SOURCES = ["mi_engine.hip", "kernels_cartpole.hip", "kernels_ant.hip", "kernels_humanoid.hip", "kernels_anymal.hip", "kernels_shadow_hand.hip",
-           "kernels_shadow_hand_pen.hip", "kernels_shadow_hand_egg.hip", "kernels_quadcopter.hip", "kernels_ingenuity.hip", "kernels_jit_twins.hip",
+           "kernels_shadow_hand_pen.hip", "kernels_shadow_hand_egg.hip", "kernels_quadcopter.hip", "kernels_ingenuity.hip", "kernels_ball_balance.hip", "kernels_jit_twins.hip",
            "kernels_mw_ant.hip", "kernels_mw_anymal.hip"]
 MI_MAX_DOF = 32
 
@@ -91,6 +91,15 @@ class MiIngenuityParams(C.Structure):
     _fields_ = [("max_episode_length", C.c_float), ("dt", C.c_float), ("thrust_upper_limit", C.c_float),
                 ("thrust_lateral_component", C.c_float), ("thrust_action_speed_scale", C.c_float), ("max_angular_velocity", C.c_float),
                 ("init_height", C.c_float), ("rotor_speed", C.c_float), ("target_period", C.c_int32), ("clip_actions", C.c_float)]
+
+
+class MiBallBalanceParams(C.Structure):
+    _fields_ = [("max_episode_length", C.c_float), ("dt", C.c_float), ("action_speed_scale", C.c_float), ("dof_lower", C.c_float * 6),
+                ("dof_upper", C.c_float * 6), ("tray_height", C.c_float), ("ball_init_pos", C.c_float * 3), ("clip_actions", C.c_float),
+                ("pin_stiffness", C.c_float), ("pin_damping", C.c_float), ("drive_kp", C.c_float), ("drive_kd", C.c_float),
+                ("actuated_mask", C.c_int32), ("ball_radius", C.c_float), ("ball_mass", C.c_float), ("ball_inertia", C.c_float),
+                ("mu", C.c_float), ("tray_radius", C.c_float), ("tray_half", C.c_float), ("pin_offset", C.c_float * 3),
+                ("pin_target", (C.c_float * 3) * 3), ("sensor_pos", (C.c_float * 3) * 3)]
 
 
 class MiHandRewardParams(C.Structure):

@@ -25,6 +25,9 @@ MODELS = {
     "quadcopter": dict(struct="ModelQuadcopter", sensors=["rotor0", "rotor1", "rotor2", "rotor3"]),
     # reference ingenuity.py:347-348: the thrust vectors act on bodies 1 and 3 (rotor_physics_0 / _1), in their local frames
     "ingenuity": dict(struct="ModelIngenuity", sensors=["rotor_physics_0", "rotor_physics_1"]),
+    # reference ball_balance.py:285-300: attractors hold a point of each lower leg (the "sensor" bodies: the tree pass records their
+    # poses); the reference's three force sensors sit on the tray itself (:254-260) and are computed from the tray's momentum balance
+    "balance_bot": dict(struct="ModelBalanceBot", sensors=["lower_leg0", "lower_leg1", "lower_leg2"]),
 }
 
 

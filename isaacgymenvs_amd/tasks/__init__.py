@@ -2,6 +2,7 @@
 from .ant import Ant
 from .anymal import Anymal
 from .anymal_terrain import AnymalTerrain
+from .ball_balance import BallBalance
 from .cartpole import Cartpole
 from .humanoid import Humanoid
 from .ingenuity import Ingenuity
@@ -12,6 +13,7 @@ isaacgym_task_map = {
     "Ant": Ant,
     "Anymal": Anymal,
     "AnymalTerrain": AnymalTerrain,
+    "BallBalance": BallBalance,
     "Cartpole": Cartpole,
     "Humanoid": Humanoid,
     "Ingenuity": Ingenuity,

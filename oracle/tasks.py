@@ -912,6 +912,77 @@ class OracleIngenuityEnv:
         return self.obs_buf, self.rew_buf, self.reset_buf
 
 
+# ===================================================================================================== BallBalance
+class OracleBallBalanceEnv:
+    """vec_task.py:360-408 + ball_balance.py pre/post_physics_step on oracle/bbot.py (attractor-pinned feet, position drives on the
+    lower-leg joints, ball <-> tray contact)."""
+
+    def __init__(self, spec, foot_bodies, sim_params: dict, params, dims, num_envs, seed=0, env_id_offset=0, control_freq_inv=1):
+        from .bbot import OracleBbotEngine
+        self.N, self.p, self.spec = num_envs, params, spec
+        self.eng = OracleBbotEngine(spec, dims, num_envs, sim_params, foot_bodies)
+        self.seed, self.off, self.cfi = fold_seed(seed), env_id_offset, control_freq_inv
+        self.genv = (self.off + np.arange(num_envs)).astype(np.uint32)
+        N = num_envs
+        self.eng.ball[:, 0:3] = list(params.ball_init_pos)
+        self.init_root = self.eng.root.copy()
+        self.progress_buf = np.zeros(N, np.int64)
+        self.reset_buf = np.ones(N, np.int64)
+        self.episode = np.zeros(N, np.uint32)
+        self.lo, self.up = np.array(params.dof_lower[:], f32), np.array(params.dof_upper[:], f32)
+        self.targets = np.zeros((N, 6), f32)
+
+    def reset_idx(self, ids):  # ball_balance.py:349-393
+        if len(ids) == 0:
+            return
+        g, ep = self.genv[ids], self.episode[ids]
+        min_d, max_d, min_h, max_h, min_s, max_s = f32(0.001), f32(0.5), f32(1.0), f32(2.0), f32(0.0), f32(5.0)
+        dist = (max_d - min_d) * mi_uniform(self.seed, g, ep, 0) + min_d
+        pi = f32(3.14159265358979323846)
+        angle = (pi - (-pi)) * mi_uniform(self.seed, g, ep, 1) + (-pi)
+        dirs = np.stack([np.cos(angle), np.sin(angle)], axis=1).astype(f32)
+        speedscale = (dist - min_d) / (max_d - min_d)
+        hspeed = (max_s - min_s) * mi_uniform(self.seed, g, ep, 2) + min_s
+        ball = np.zeros((len(ids), 13), f32)
+        ball[:, 0:2] = dist[:, None] * dirs
+        ball[:, 2] = (max_h - min_h) * mi_uniform(self.seed, g, ep, 3) + min_h
+        ball[:, 6] = 1
+        ball[:, 7:9] = -(speedscale * hspeed)[:, None] * dirs
+        ball[:, 9] = f32(-5.0)
+        self.eng.ball[ids] = ball
+        self.eng.root[ids] = self.init_root[ids]
+        self.eng.q[ids] = 0; self.eng.qd[ids] = 0
+        self.eng.laml[ids] = 0; self.eng.lam_pin[ids] = 0
+        self.episode[ids] += 1
+        self.reset_buf[ids] = 0
+        self.progress_buf[ids] = 0
+
+    def step(self, actions):
+        from .jit_twins import compute_bbot_reward
+        p = self.p
+        ids = np.nonzero(self.reset_buf)[0]                                        # :398-400
+        self.reset_idx(ids)
+        a = np.clip(actions.astype(f32), -f32(p.clip_actions), f32(p.clip_actions))
+        self.targets[:, [1, 3, 5]] += f32(p.dt) * f32(p.action_speed_scale) * a       # :405
+        self.targets = np.maximum(np.minimum(self.targets, self.up), self.lo).astype(f32)   # :406
+        self.targets[ids] = 0                                                      # :409
+        self.eng.targets[:] = self.targets
+        for _ in range(self.cfi):
+            self.eng.step()
+        # post_physics_step (:415-424)
+        self.progress_buf += 1
+        q, qd, ball, sens = self.eng.q.astype(f32), self.eng.qd.astype(f32), self.eng.ball.astype(f32), self.eng.sensor.astype(f32).reshape(self.N, 3, 6)
+        obs = np.zeros((self.N, 24), f32)
+        obs[:, 0:3] = q[:, [1, 3, 5]]; obs[:, 3:6] = qd[:, [1, 3, 5]]
+        obs[:, 6:9] = ball[:, 0:3]; obs[:, 9:12] = ball[:, 7:10]
+        obs[:, 12:15] = sens[:, :, 0] / f32(20); obs[:, 15:18] = sens[:, :, 3] / f32(20)
+        obs[:, 18:21] = sens[:, :, 4] / f32(20); obs[:, 21:24] = sens[:, :, 5] / f32(20)
+        self.obs_buf = obs
+        self.rew_buf, self.reset_buf = compute_bbot_reward(self.eng.root[:, 0:3].astype(f32), ball[:, 0:3], ball[:, 7:10], f32(p.ball_radius),
+                                                           self.reset_buf, self.progress_buf, f32(p.max_episode_length))
+        return self.obs_buf, self.rew_buf, self.reset_buf
+
+
 def quat_conjugate(a):  # torch_jit_utils.py:107-110
     return np.concatenate([-a[:, :3], a[:, 3:4]], axis=-1).astype(f32)
 

@@ -29,8 +29,9 @@ def make_params(d):
 
 # model -> (compile-time switch, optimisation level): one library per model, compiled in parallel
 _MODELS = {"cartpole": ("HOSTSIM_CARTPOLE", "-O2"), "ant": ("HOSTSIM_ANT", "-O2"), "anymal": ("HOSTSIM_ANYMAL", "-O2"),
-           "quadcopter": ("HOSTSIM_QUADCOPTER", "-O2"), "humanoid": ("HOSTSIM_HUMANOID", "-O2"), "hand": ("HOSTSIM_HAND", "-O1")}
-_ENTRY_MODEL = {"hs_step_mw_ant": "ant", "hs_step_mw_terrain": "anymal", "hs_step_selfcol": "humanoid", "hs_step_terrain": "anymal", "hs_step_drive": "quadcopter", "hs_step_hand": "hand", "hs_hand_fingertips": "hand"}
+           "quadcopter": ("HOSTSIM_QUADCOPTER", "-O2"), "humanoid": ("HOSTSIM_HUMANOID", "-O2"), "hand": ("HOSTSIM_HAND", "-O1"),
+           "bbot": ("HOSTSIM_BBOT", "-O2")}
+_ENTRY_MODEL = {"hs_step_mw_ant": "ant", "hs_step_mw_terrain": "anymal", "hs_step_selfcol": "humanoid", "hs_step_terrain": "anymal", "hs_step_drive": "quadcopter", "hs_step_hand": "hand", "hs_hand_fingertips": "hand", "hs_step_bbot": "bbot"}
 _libs = {}
 
 
@@ -47,10 +48,12 @@ def _build_models(names):
     deps = _deps()
     os.makedirs(_OUT, exist_ok=True)
     newest = max(os.path.getmtime(d) for d in deps)
+    core = os.path.join(_HERE, "..", "..", "isaacgymenvs_amd", "csrc", "core")
+    own = {"bbot": [os.path.join(core, "bbot_engine.hpp")]}      # headers only one model's library includes
     jobs = []
     for n in names:
         out = os.path.join(_OUT, f"libhostsim_{n}.so")
-        if not os.path.exists(out) or os.path.getmtime(out) < newest:
+        if not os.path.exists(out) or os.path.getmtime(out) < max([newest] + [os.path.getmtime(d) for d in own.get(n, [])]):
             macro, opt = _MODELS[n]
             jobs.append(["g++", opt, "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-pthread", "-ffp-contract=off", "-D" + macro,
                          os.path.join(_HERE, "hostsim.cpp"), "-o", out])

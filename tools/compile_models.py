@@ -117,6 +117,9 @@ PROCEDURAL = {
     # reference ingenuity.py:120-231; reset below z = 0.5 m (:449) with a 6 cm chassis and 15 cm rotors: the ground is out of reach,
     # the marker actor shares the craft's collision filter bit (:262, :268): no contact geometry
     "ingenuity": dict(gen="ingenuity_mjcf", collide_body_filter=lambda n: False),
+    # reference ball_balance.py:136-224; the feet are pinned by attractors (:285-300) and the episode ends before the ball can reach
+    # the legs or the ground (:473): the only contact is ball <-> tray, handled by the task's own engine (csrc/core/bbot_engine.hpp)
+    "balance_bot": dict(gen="balance_bot_mjcf", collide_body_filter=lambda n: False),
 }
 
 
