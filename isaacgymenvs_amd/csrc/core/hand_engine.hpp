@@ -34,15 +34,26 @@ struct HandSim : Sim<M> {
     using B = Sim<M>;
     static constexpr int NB = M::NB, ND = M::ND, NV = M::NV, OFF = M::OFF, NSENS = M::NSENS, NOS = M::NOS, NLIM = B::NLIM, NVA = B::NVA;
     static_assert(M::FIXED == 1 && M::NSPH == 0, "HandSim: fixed-base model without ground spheres");
-    static constexpr int KMAX = 16;                          // active object contacts kept per env
-    static constexpr int UCH = M::MAXCHAIN + 6;              // row width: hand chain + object dofs
+#ifndef MI_HAND_KMAX
+#define MI_HAND_KMAX 12
+#endif
+    static constexpr int KMAX = MI_HAND_KMAX;                // active object contacts kept per env
+    static constexpr int HCH = M::MAXCHAIN;                  // stored row width: the hand chain; the 6 object entries are re-derived
     static constexpr int H_LIMG = B::limoff(NLIM);
     static constexpr int H_CB = H_LIMG + 3 * NLIM;           // limit G | Ainv, vt, lam | contact slots
-    static constexpr int H_CSZ = 3 * UCH + 7;                // 3 rows + Ainv x3, vt_n, lam x3
+    // one contact slot: 3 rows over the hand chain | normal n (3), lever rc = contact point - object COM (3) | Ainv x3, vt_n, lam x3.
+    // The object part of row k, -[u_k; rc x u_k] whitened, follows from (n, rc): 6 floats stored instead of 18.
+    static constexpr int H_GEO = 3 * HCH, H_AUX = H_GEO + 6;
+    static constexpr int H_CSZ = H_AUX + 7;
     static constexpr int BODY_CAP = 4;                        // contacts admitted per hand body (manifold size)
-    static constexpr int H_SLOTOF = H_CB + KMAX * H_CSZ;     // [NOS] slot of each sphere (-1: none), int bits
-    static constexpr int H_POSE = H_SLOTOF + NOS;            // [NOSB][12] pose of the sphere-carrying bodies (tree pass output)
-    static constexpr int ROW_SLOTS = H_POSE + 12 * B::NOSB;
+    static constexpr int H_SLOTOF = H_CB + KMAX * H_CSZ;     // slot of each sphere (-1: none), one BYTE per sphere (ds_read_i8 / ds_write_b8)
+    static constexpr int ROW_SLOTS = H_SLOTOF + (NOS + 3) / 4;
+    // Round 2: the store is 611 floats per env (78 KB per 32-env workgroup) -- TWO workgroups fit a CU's 160 KB, so the 512
+    // workgroups of ShadowHand@16384 are resident at once instead of running in two rounds (it was 1224 floats: contact slots with
+    // the object part stored, KMAX 16, one dword per sphere for slot_of and a 216-float block of body poses handed from the tree
+    // pass to the narrow phase, which now lives in a per-lane local array).  Measured before the rewrite with a KMAX = 3 build and
+    // its padded twin (tools/hand_residency_ab.sh): two resident workgroups per CU run the same 16384 envs 1.64x faster.
+    static_assert((size_t)ROW_SLOTS * 32 * sizeof(float) <= 80 * 1024, "two hand workgroups per CU");
     static constexpr int LANES = 32;
 
     FreeBody obj;
@@ -123,6 +134,13 @@ struct HandSim : Sim<M> {
         typename B::Ctx c;
         float (&S)[M::NDA][6] = c.S;
         float (&L)[M::NM] = c.L;
+        // pose (R 9, r 3) of the sphere-carrying bodies, handed from the tree pass to the narrow phase in per-lane memory (scratch),
+        // not in LDS.  The opaque zero in every index keeps the array in memory: promoted to registers its 216 values would be
+        // spilled one by one around the tree pass (601 instead of 360 spilled registers, the sub-step 1.5x slower).
+        float pose[12 * (B::NOSB > 0 ? B::NOSB : 1)];
+        int pz;
+        MI_OPAQUE_ZERO(pz);
+        auto slot_of = [&](const RowStore<RS>& r, int s) MI_LAMBDA -> signed char& { return reinterpret_cast<signed char*>(r.ptr(H_SLOTOF + (s >> 2)))[s & 3]; };
         // ------------------------------------------------------------ stage the limit impulses of the last sub-step
         sfor<ND>([&](auto D) MI_LAMBDA {
             constexpr int d = D;
@@ -132,8 +150,8 @@ struct HandSim : Sim<M> {
         {
             SimParams P0 = P;
             P0.g[0] = P0.g[1] = P0.g[2] = 0.f;
-            c.pose_out = rows.ptr(H_POSE);
-            c.pose_stride = ST;
+            c.pose_out = pose + pz;
+            c.pose_stride = 1;
             SpI Iroot;
             float Froot[6];
             this->template body_pass<0>(P0, c, nullptr, nullptr, nullptr, nullptr, Iroot, Froot);
@@ -250,8 +268,8 @@ struct HandSim : Sim<M> {
                 constexpr int CL = M::chain_len[b];
                 MI_PHASE();
                 float Rb[9], rb[3];
-                sfor<9>([&](auto I_) MI_LAMBDA { Rb[I_] = rows(H_POSE + 12 * B::os_slot(b) + I_); });
-                sfor<3>([&](auto I_) MI_LAMBDA { rb[I_] = rows(H_POSE + 12 * B::os_slot(b) + 9 + I_); });
+                sfor<9>([&](auto I_) MI_LAMBDA { Rb[I_] = pose[pz + 12 * B::os_slot(b) + I_]; });
+                sfor<3>([&](auto I_) MI_LAMBDA { rb[I_] = pose[pz + 12 * B::os_slot(b) + 9 + I_]; });
                 int nbody = 0;
                 for (int i = 0; i < B::os_count(b); ++i) {
                     const int s = B::os_first(b) + i;
@@ -282,7 +300,7 @@ struct HandSim : Sim<M> {
                             float W[6];
                             cross3(pc, fr[k], W);
                             W[3] = fr[k][0]; W[4] = fr[k][1]; W[5] = fr[k][2];
-                            float g[UCH];
+                            float g[HCH + 6];
                             sfor<CL>([&](auto C) MI_LAMBDA { g[C] = dot6(S[M::chain[b][C] - OFF], W); });
                             // chain solve (descending indices; the later entries of a chain are exactly the ancestors)
                             sfor<CL>([&](auto C) MI_LAMBDA {
@@ -300,14 +318,16 @@ struct HandSim : Sim<M> {
                             if constexpr (SHAPE != OBJ_BOX) { float cw[3]; body_diag(Ro, isqI, cx, cw); sfor<3>([&](auto I_) MI_LAMBDA { cx[I_] = cw[I_]; }); }
                             sfor<3>([&](auto I_) MI_LAMBDA { g[CL + I_] = -fr[k][I_] * ism; g[CL + 3 + I_] = -cx[I_] * isi; });
                             float a = P.cfm;
-                            sfor<CL + 6>([&](auto C) MI_LAMBDA { a += g[C] * g[C]; cb[(k * UCH + C) * ST] = g[C]; });
-                            cb[(3 * UCH + k) * ST] = MI_RCP(a);
-                            cb[(3 * UCH + 4 + k) * ST] = 0.f;    // no warm start for object contacts
+                            sfor<CL + 6>([&](auto C) MI_LAMBDA { a += g[C] * g[C]; });
+                            sfor<CL>([&](auto C) MI_LAMBDA { cb[(k * HCH + C) * ST] = g[C]; });
+                            cb[(H_AUX + k) * ST] = MI_RCP(a);
+                            cb[(H_AUX + 4 + k) * ST] = 0.f;    // no warm start for object contacts
                         });
-                        cb[(3 * UCH + 3) * ST] = (gap >= 0.f) ? -gap * invh : fminf(-gap * P.erp * invh, P.max_depen_vel);
+                        sfor<3>([&](auto I_) MI_LAMBDA { cb[(H_GEO + I_) * ST] = fr[0][I_]; cb[(H_GEO + 3 + I_) * ST] = rc[I_]; });
+                        cb[(H_AUX + 3) * ST] = (gap >= 0.f) ? -gap * invh : fminf(-gap * P.erp * invh, P.max_depen_vel);
                     }
                     cnt += on ? 1 : 0;
-                    rows(H_SLOTOF + s) = __builtin_bit_cast(float, j);
+                    slot_of(rows, s) = (signed char)j;
                 }
             }
         });
@@ -356,25 +376,38 @@ struct HandSim : Sim<M> {
                     constexpr int CL = M::chain_len[b];
                     for (int i = 0; i < B::os_count(b); ++i) {
                         const int s = B::os_first(b) + i;
-                        const int j = __builtin_bit_cast(int, rit(H_SLOTOF + s));
+                        const int j = (int)slot_of(rit, s);
                         if (j >= 0) {
                             float* cb = rit.ptr(H_CB + j * H_CSZ);
-                            float g[3][UCH], ainv[3], lm[3];
+                            float g[3][HCH + 6], ainv[3], lm[3];
                             sfor<3>([&](auto K) MI_LAMBDA {
-                                sfor<CL + 6>([&](auto C) MI_LAMBDA { g[K][C] = cb[(K * UCH + C) * ST]; });
-                                ainv[K] = cb[(3 * UCH + K) * ST];
-                                lm[K] = cb[(3 * UCH + 4 + K) * ST];
+                                sfor<CL>([&](auto C) MI_LAMBDA { g[K][C] = cb[(K * HCH + C) * ST]; });
+                                ainv[K] = cb[(H_AUX + K) * ST];
+                                lm[K] = cb[(H_AUX + 4 + K) * ST];
                             });
-                            const float vtn = cb[(3 * UCH + 3) * ST];
+                            {   // object part of the three rows from the stored normal and lever (as in the row build)
+                                float fr[3][3], rc[3];
+                                sfor<3>([&](auto I_) MI_LAMBDA { fr[0][I_] = cb[(H_GEO + I_) * ST]; rc[I_] = cb[(H_GEO + 3 + I_) * ST]; });
+                                contact_frame(fr[0], fr[1], fr[2]);
+                                sfor<3>([&](auto K) MI_LAMBDA {
+                                    float cx[3];
+                                    cross3(rc, fr[K], cx);
+                                    if constexpr (SHAPE != OBJ_BOX) { float cw[3]; body_diag(Ro, isqI, cx, cw); sfor<3>([&](auto I_) MI_LAMBDA { cx[I_] = cw[I_]; }); }
+                                    sfor<3>([&](auto I_) MI_LAMBDA { g[K][CL + I_] = -fr[K][I_]; g[K][CL + 3 + I_] = -cx[I_]; });   // whitening scales: below
+                                });
+                            }
+                            const float vtn = cb[(H_AUX + 3) * ST];
                             auto rowvel = [&](int k) MI_LAMBDA {
                                 float vn = 0.f;
                                 sfor<CL>([&](auto C) MI_LAMBDA { vn += g[k][C] * w[M::chain[b][C]]; });
-                                sfor<6>([&](auto C) MI_LAMBDA { vn += g[k][CL + C] * wo[C]; });
-                                return vn;
+                                float vl = 0.f, va = 0.f;
+                                sfor<3>([&](auto C) MI_LAMBDA { vl += g[k][CL + C] * wo[C]; va += g[k][CL + 3 + C] * wo[3 + C]; });
+                                return vn + (ism * vl + isi * va);
                             };
                             auto apply = [&](int k, float dl) MI_LAMBDA {
                                 sfor<CL>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += g[k][C] * dl; });
-                                sfor<6>([&](auto C) MI_LAMBDA { wo[C] += g[k][CL + C] * dl; });
+                                const float dll = ism * dl, dla = isi * dl;
+                                sfor<3>([&](auto C) MI_LAMBDA { wo[C] += g[k][CL + C] * dll; wo[3 + C] += g[k][CL + 3 + C] * dla; });
                             };
                             const float ln = fmaxf(lm[0] - (rowvel(0) - vtn) * ainv[0], 0.f);
                             apply(0, ln - lm[0]);
@@ -387,10 +420,10 @@ struct HandSim : Sim<M> {
                             const float lim = OP.mu * ln;
                             const float n2 = lt[0] * lt[0] + lt[1] * lt[1];
                             const float sc = (n2 > lim * lim) ? lim * MI_RSQ(fmaxf(n2, 1e-30f)) : 1.f;
-                            cb[(3 * UCH + 4) * ST] = ln;
+                            cb[(H_AUX + 4) * ST] = ln;
                             sfor<2>([&](auto K) MI_LAMBDA {
                                 const float nl_ = lt[K] * sc;
-                                cb[(3 * UCH + 5 + K) * ST] = nl_;
+                                cb[(H_AUX + 5 + K) * ST] = nl_;
                                 apply(1 + K, nl_ - lt[K]);
                             });
                         }
@@ -425,31 +458,25 @@ struct HandSim : Sim<M> {
             constexpr int b = B_;
             if constexpr (sensor_of(b) >= 0 && B::os_count(b) > 0) {
                 constexpr int k = sensor_of(b);
+                // the fingertip's pose from the per-lane pose array (keeping the tree pass's own sensor frames c.Rs / c.rs alive
+                // until here costs 100 more spilled registers)
                 float Rb[9], rb[3];
-                sfor<9>([&](auto I_) MI_LAMBDA { Rb[I_] = rows(H_POSE + 12 * B::os_slot(b) + I_); });
-                sfor<3>([&](auto I_) MI_LAMBDA { rb[I_] = rows(H_POSE + 12 * B::os_slot(b) + 9 + I_); });
+                sfor<9>([&](auto I_) MI_LAMBDA { Rb[I_] = pose[pz + 12 * B::os_slot(b) + I_]; });
+                sfor<3>([&](auto I_) MI_LAMBDA { rb[I_] = pose[pz + 12 * B::os_slot(b) + 9 + I_]; });
                 for (int i = 0; i < B::os_count(b); ++i) {
                     const int s = B::os_first(b) + i;
-                    const int j = __builtin_bit_cast(int, rows(H_SLOTOF + s));
+                    const int j = (int)slot_of(rows, s);
                     if (j >= 0) {
                         const float* cb = rows.ptr(H_CB + j * H_CSZ);
-                        const float ln = cb[(3 * UCH + 4) * ST], l1 = cb[(3 * UCH + 5) * ST], l2 = cb[(3 * UCH + 6) * ST];
-                        // the contact frame is re-derived (neither body has moved yet)
-                        const float pl[3] = {M::os_pos[s][0], M::os_pos[s][1], M::os_pos[s][2]};
-                        const float rad = M::os_rad[s];
-                        float t[3], cs[3];
-                        matvec3(Rb, pl, t);
-                        sfor<3>([&](auto K) MI_LAMBDA { cs[K] = rb[K] + t[K]; });
-                        const float rel[3] = {cs[0] - xo[0], cs[1] - xo[1], cs[2] - xo[2]};
-                        float cl[3], nl[3], dist, n[3], t1[3], t2[3];
-                        matTvec3(Ro, rel, cl);
-                        sphere_object<SHAPE>(cl, rad, OP, &dist, nl);
-                        matvec3(Ro, nl, n);
+                        const float ln = cb[(H_AUX + 4) * ST], l1 = cb[(H_AUX + 5) * ST], l2 = cb[(H_AUX + 6) * ST];
+                        // contact frame and point from the slot (neither body has moved yet): n, lever rc = point - object COM
+                        float n[3], t1[3], t2[3], rc[3];
+                        sfor<3>([&](auto K) MI_LAMBDA { n[K] = cb[(H_GEO + K) * ST]; rc[K] = cb[(H_GEO + 3 + K) * ST]; });
                         contact_frame(n, t1, t2);
                         float f[3], arm[3], tq[3], fl[3], tl[3];
                         sfor<3>([&](auto K) MI_LAMBDA {
                             f[K] = (n[K] * ln + t1[K] * l1 + t2[K] * l2) * invh;
-                            arm[K] = cs[K] - rad * n[K] - rb[K];
+                            arm[K] = (rc[K] + xo[K]) - rb[K];
                         });
                         cross3(arm, f, tq);
                         matTvec3(Rb, f, fl); matTvec3(Rb, tq, tl);

@@ -20,7 +20,7 @@ import numpy as np
 
 from .engine import OracleEngine, _ptr
 
-KMAX = 16
+KMAX = 12            # csrc/core/hand_engine.hpp MI_HAND_KMAX (16 until round 2: the 611-float store holds 12 slots)
 BODY_CAP = 4        # contacts admitted per hand body, in the body's (farthest-point ordered) sphere order -- csrc/core/hand_engine.hpp
 CUBE_HALF = 0.025
 CUBE_MASS = 567.0 * 0.05 ** 3                      # cube_multicolor.urdf: box 0.05, density 567
