@@ -46,11 +46,13 @@ struct HandSim : Sim<M> {
     static constexpr int H_GEO = 3 * HCH, H_AUX = H_GEO + 6;
     static constexpr int H_CSZ = H_AUX + 7;
     static constexpr int BODY_CAP = 4;                        // contacts admitted per hand body (manifold size)
-    static constexpr int H_SLOTOF = H_CB + KMAX * H_CSZ;     // slot of each sphere (-1: none), one BYTE per sphere (ds_read_i8 / ds_write_b8)
-    static constexpr int ROW_SLOTS = H_SLOTOF + (NOS + 3) / 4;
-    // Round 2: the store is 611 floats per env (78 KB per 32-env workgroup) -- TWO workgroups fit a CU's 160 KB, so the 512
+    // The contacts of one hand body take consecutive slots (slots are handed out body by body): one dword per sphere-carrying body,
+    // first slot | count << 8.  The sweeps and the sensor pass walk a body's <= BODY_CAP contacts instead of its (up to 30) spheres.
+    static constexpr int H_BODYSLOT = H_CB + KMAX * H_CSZ;
+    static constexpr int ROW_SLOTS = H_BODYSLOT + B::NOSB;
+    // Round 2: the store is 605 floats per env (77 KB per 32-env workgroup) -- TWO workgroups fit a CU's 160 KB, so the 512
     // workgroups of ShadowHand@16384 are resident at once instead of running in two rounds (it was 1224 floats: contact slots with
-    // the object part stored, KMAX 16, one dword per sphere for slot_of and a 216-float block of body poses handed from the tree
+    // the object part stored, KMAX 16, a slot index per sphere and a 216-float block of body poses handed from the tree
     // pass to the narrow phase, which now lives in a per-lane local array).  Measured before the rewrite with a KMAX = 3 build and
     // its padded twin (tools/hand_residency_ab.sh): two resident workgroups per CU run the same 16384 envs 1.64x faster.
     static_assert((size_t)ROW_SLOTS * 32 * sizeof(float) <= 80 * 1024, "two hand workgroups per CU");
@@ -140,7 +142,6 @@ struct HandSim : Sim<M> {
         float pose[12 * (B::NOSB > 0 ? B::NOSB : 1)];
         int pz;
         MI_OPAQUE_ZERO(pz);
-        auto slot_of = [&](const RowStore<RS>& r, int s) MI_LAMBDA -> signed char& { return reinterpret_cast<signed char*>(r.ptr(H_SLOTOF + (s >> 2)))[s & 3]; };
         // ------------------------------------------------------------ stage the limit impulses of the last sub-step
         sfor<ND>([&](auto D) MI_LAMBDA {
             constexpr int d = D;
@@ -271,6 +272,7 @@ struct HandSim : Sim<M> {
                 sfor<9>([&](auto I_) MI_LAMBDA { Rb[I_] = pose[pz + 12 * B::os_slot(b) + I_]; });
                 sfor<3>([&](auto I_) MI_LAMBDA { rb[I_] = pose[pz + 12 * B::os_slot(b) + 9 + I_]; });
                 int nbody = 0;
+                const int first = cnt;
                 for (int i = 0; i < B::os_count(b); ++i) {
                     const int s = B::os_first(b) + i;
                     const float pl[3] = {M::os_pos[s][0], M::os_pos[s][1], M::os_pos[s][2]};
@@ -327,8 +329,8 @@ struct HandSim : Sim<M> {
                         cb[(H_AUX + 3) * ST] = (gap >= 0.f) ? -gap * invh : fminf(-gap * P.erp * invh, P.max_depen_vel);
                     }
                     cnt += on ? 1 : 0;
-                    slot_of(rows, s) = (signed char)j;
                 }
+                rows(H_BODYSLOT + B::os_slot(b)) = __builtin_bit_cast(float, first | (nbody << 8));
             }
         });
         *ncontact = cnt;
@@ -374,11 +376,12 @@ struct HandSim : Sim<M> {
                 constexpr int b = B_;
                 if constexpr (B::os_count(b) > 0) {
                     constexpr int CL = M::chain_len[b];
-                    for (int i = 0; i < B::os_count(b); ++i) {
-                        const int s = B::os_first(b) + i;
-                        const int j = (int)slot_of(rit, s);
-                        if (j >= 0) {
-                            float* cb = rit.ptr(H_CB + j * H_CSZ);
+                    const int fc = __builtin_bit_cast(int, rit(H_BODYSLOT + B::os_slot(b)));
+                    const int first = fc & 255, nb_ = fc >> 8;
+                    for (int i = 0; i < BODY_CAP; ++i) {
+                        if (!MI_WAVE_ANY(i < nb_)) break;           // no env of the wave has an (i+1)-th contact on this body
+                        if (i < nb_) {
+                            float* cb = rit.ptr(H_CB + (first + i) * H_CSZ);
                             float g[3][HCH + 6], ainv[3], lm[3];
                             sfor<3>([&](auto K) MI_LAMBDA {
                                 sfor<CL>([&](auto C) MI_LAMBDA { g[K][C] = cb[(K * HCH + C) * ST]; });
@@ -463,11 +466,12 @@ struct HandSim : Sim<M> {
                 float Rb[9], rb[3];
                 sfor<9>([&](auto I_) MI_LAMBDA { Rb[I_] = pose[pz + 12 * B::os_slot(b) + I_]; });
                 sfor<3>([&](auto I_) MI_LAMBDA { rb[I_] = pose[pz + 12 * B::os_slot(b) + 9 + I_]; });
-                for (int i = 0; i < B::os_count(b); ++i) {
-                    const int s = B::os_first(b) + i;
-                    const int j = (int)slot_of(rows, s);
-                    if (j >= 0) {
-                        const float* cb = rows.ptr(H_CB + j * H_CSZ);
+                const int fc = __builtin_bit_cast(int, rows(H_BODYSLOT + B::os_slot(b)));
+                const int first = fc & 255, nb_ = fc >> 8;
+                for (int i = 0; i < BODY_CAP; ++i) {
+                    if (!MI_WAVE_ANY(i < nb_)) break;
+                    if (i < nb_) {
+                        const float* cb = rows.ptr(H_CB + (first + i) * H_CSZ);
                         const float ln = cb[(H_AUX + 4) * ST], l1 = cb[(H_AUX + 5) * ST], l2 = cb[(H_AUX + 6) * ST];
                         // contact frame and point from the slot (neither body has moved yet): n, lever rc = point - object COM
                         float n[3], t1[3], t2[3], rc[3];
