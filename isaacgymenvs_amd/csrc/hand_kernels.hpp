@@ -76,24 +76,14 @@ inline hipError_t hand_substeps_shape(const View& v, const HandView& hv, const S
 #ifndef MI_HAND_LDS_PAD
 #define MI_HAND_LDS_PAD 0      // residency experiments only (tools/hand_residency_ab.sh): extra LDS bytes requested per workgroup
 #endif
-    constexpr size_t store = (size_t)HS::ROW_SLOTS * HS::LANES * sizeof(float) + MI_HAND_LDS_PAD;
-    // Two workgroups fit a CU (78 KB each) and the dispatcher pairs them up even when there are CUs to spare; a pair runs 1.25x slower
-    // per workgroup than two CUs would (measured: ShadowHand@8192 0.89 vs 0.71 ms per step).  So while every workgroup can have a CU
-    // of its own, ask for more than half the LDS; beyond that, residency wins (16384 envs: 0.88 vs 1.36 ms).
-    constexpr size_t alone = store > 81 * 1024 ? store : 81 * 1024;
-    static_assert(alone <= 160 * 1024, "hand row store must fit LDS");
+    constexpr size_t lds = (size_t)HS::ROW_SLOTS * HS::LANES * sizeof(float) + MI_HAND_LDS_PAD;
+    static_assert(lds <= 160 * 1024, "hand row store must fit LDS");
     static unsigned long long configured = 0ull;
-    static int num_cu = 0;
-    if (num_cu == 0) {
-        int dev = 0;
-        if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
-        if (hipError_t e = hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev); e != hipSuccess) return e;
-    }
-    if (hipError_t e = ensure_dynamic_lds((const void*)hand_substep_kernel<SHAPE>, alone, &configured); e != hipSuccess) return e;
-    const int grid = (v.N + HS::LANES - 1) / HS::LANES;
-    const size_t lds = grid <= num_cu ? alone : store;
+    if (hipError_t e = ensure_dynamic_lds((const void*)hand_substep_kernel<SHAPE>, lds, &configured); e != hipSuccess) return e;
+    // (Two workgroups fit a CU.  Asking for more than half the LDS while CUs are spare makes no difference -- the dispatcher spreads
+    // the workgroups over the CUs by itself: tools/lds_alone_ab.py, ShadowHand@8192 0.605 ms either way.)
     for (int i = 0; i < n; ++i)
-        hipLaunchKernelGGL(hand_substep_kernel<SHAPE>, dim3(grid), dim3(HS::LANES), lds, s, v, hv, P, p);
+        hipLaunchKernelGGL(hand_substep_kernel<SHAPE>, dim3((v.N + HS::LANES - 1) / HS::LANES), dim3(HS::LANES), lds, s, v, hv, P, p);
     return hipGetLastError();
 }
 
