@@ -118,7 +118,7 @@ struct HandSim : Sim<M> {
     }
 
     // one sub-step of length h.  target[ND]: drive targets; laml: warm-start limit impulses; sensor: 6*NSENS fingertip
-    // force/torque (body frame); dof_force[ND]; ncontact: number of object contacts taken (diagnostic)
+    // force/torque (body frame); dof_force[ND]; ncontact: number of object contacts taken | number refused for want of a slot << 16
     // SHAPE: OBJ_BOX (isotropic inertia OP.inertia, the benchmark configuration -- code unchanged) or OBJ_ELLIPSOID (OP.dims, OP.inertia3:
     // the angular part of the object's whitened velocity / rows goes through Ro diag(I^{+-1/2}) Ro^T; no gyroscopic torque, as PhysX's default)
     template <int RS, int SHAPE = OBJ_BOX>
@@ -262,7 +262,7 @@ struct HandSim : Sim<M> {
         // spheres of one body with their positions / radii read from the constant tables (scalar loads): one copy of the
         // narrow phase + row build per BODY, not per sphere -- the per-sphere unrolled version had ~1000 distinct literals
         // in SGPRs, spilled 472 of them and miscomputed on gfx950 ("compiler regime").
-        int cnt = 0;
+        int cnt = 0, refused = 0;
         sfor<NB>([&](auto B_) MI_LAMBDA {
             constexpr int b = B_;
             if constexpr (B::os_count(b) > 0) {
@@ -287,6 +287,7 @@ struct HandSim : Sim<M> {
                     // contact manifold: at most BODY_CAP contacts per hand body, taken in the body's (spread-out, farthest-point) sphere
                     // order, so that a cube lying on the 30-sphere palm cannot use up all KMAX slots before the fingers are looked at
                     const bool on = (dist < P.contact_offset) && (cnt < KMAX) && (nbody < BODY_CAP);
+                    refused += ((dist < P.contact_offset) && (nbody < BODY_CAP) && (cnt >= KMAX)) ? 1 : 0;   // all KMAX slots taken
                     nbody += on ? 1 : 0;
                     const int j = on ? cnt : -1;
                     if (on) {
@@ -333,7 +334,7 @@ struct HandSim : Sim<M> {
                 rows(H_BODYSLOT + B::os_slot(b)) = __builtin_bit_cast(float, first | (nbody << 8));
             }
         });
-        *ncontact = cnt;
+        *ncontact = cnt | (refused << 16);
         MI_PHASE();
         // ------------------------------------------------------------ warm start (limit rows only)
         {

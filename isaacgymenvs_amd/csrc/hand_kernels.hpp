@@ -32,6 +32,7 @@ struct HandView {
     float* rb_force;       // [3][N] rb_forces[:, object] in the object's local frame (:201, 700-708)
     float* force_prob;     // [N] random_force_prob (:198-199)
     float* mu_env;         // [N] per-env hand-object contact friction for actor_params friction randomisation; negative = HandParams.mu
+    int* ndropped;         // [N] contacts refused since init because all KMAX slots of the env were taken (diagnostic; a manifold's 5th+ contact does not count)
 };
 
 // gym.simulate(): one physics sub-step of hand + cube
@@ -68,7 +69,8 @@ __global__ __launch_bounds__(32) void hand_substep_kernel(View v, HandView hv, S
     sfor<3>([&](auto K) MI_LAMBDA { hv.object_state[K * N + e] = sim.obj.pos[K]; hv.object_state[(7 + K) * N + e] = sim.obj.vel[K];
                                     hv.object_state[(10 + K) * N + e] = sim.obj.angvel[K]; });
     sfor<4>([&](auto K) MI_LAMBDA { hv.object_state[(3 + K) * N + e] = sim.obj.quat[K]; });
-    hv.ncontact[e] = nc;
+    hv.ncontact[e] = nc & 0xFFFF;
+    if (nc >> 16) hv.ndropped[e] += nc >> 16;
 }
 
 template <int SHAPE>

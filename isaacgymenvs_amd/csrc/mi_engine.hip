@@ -228,6 +228,7 @@ struct HandView {
     float* cur_targets; float* prev_targets; float* object_state; float* goal_state; float* fingertip; float* successes;
     long long* reset_goal; int* goal_count; float* cons; float* ws; int* ncontact;
     float* full_state; float* obj_force; float* rb_force; float* force_prob; float* mu_env;
+    int* ndropped;
 };
 hipError_t launch_step_shadow_hand(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, const float* actions, int cfi,
                                    unsigned step_counter, hipStream_t s);
@@ -314,6 +315,7 @@ static void build_hand_layout(int N, Layout& L, HandView* hv, char* base) {
     o = L.add("rb_forces_object", MI_F32, {n, 3}, {1, n}, 3 * n); if (hv) hv->rb_force = (float*)P(o);
     o = L.add("random_force_prob", MI_F32, {n}, {1}, n); if (hv) hv->force_prob = (float*)P(o);
     o = L.add("friction", MI_F32, {n}, {1}, n); if (hv) hv->mu_env = (float*)P(o);   // hand-object contact friction per env (negative: HandParams.mu)
+    o = L.add("object_contact_dropped", MI_I32, {n}, {1}, n); if (hv) hv->ndropped = (int*)P(o);   // contacts refused since init: all KMAX slots taken
     L.off = (L.off + 255) & ~size_t(255);
 }
 

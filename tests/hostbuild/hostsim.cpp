@@ -220,7 +220,7 @@ extern "C" int hs_step_hand(const SimParams* P, int nenv, float* state, float* o
         int nc = 0;
         for (int it = 0; it < P->substeps; ++it)
             sim.substep_hand(*P, OP, s + 3 * ND, h, RowStore<1>{rows}, Strided{s + 2 * ND, 1}, Strided{o, 1}, Strided{o + 6 * NS, 1}, &nc);
-        o[6 * NS + ND] = (float)nc;
+        o[6 * NS + ND] = (float)(nc & 0xFFFF);
         for (int k = 0; k < ND; ++k) { s[k] = sim.q[k]; s[ND + k] = sim.qd[k]; }
         for (int k = 0; k < 3; ++k) { ob[k] = sim.obj.pos[k]; ob[7 + k] = sim.obj.vel[k]; ob[10 + k] = sim.obj.angvel[k]; }
         for (int k = 0; k < 4; ++k) ob[3 + k] = sim.obj.quat[k];

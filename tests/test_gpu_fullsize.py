@@ -86,6 +86,23 @@ def test_anymal_terrain_first_steps_at_the_benchmark_size():
     assert np.abs(orc.eng.netf).max() > 50.0
 
 
+def test_shadow_hand_contact_slots_suffice_at_the_benchmark_size():
+    """ShadowHand@16384 under the random policy of the benchmark: with the per-body manifold cap the 12 contact slots per env (KMAX,
+    csrc/core/hand_engine.hpp) are rarely all taken -- `object_contact_dropped` counts the contacts refused for want of a slot."""
+    import isaacgymenvs_amd
+    n = 16384
+    env = isaacgymenvs_amd.make(seed=42, task="ShadowHand", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    steps, taken = 150, 0
+    for _ in range(steps):
+        env.step(torch.rand((n, 20), device=DEV, generator=g) * 2 - 1)
+        taken += int(env.engine.tensors["object_contact_count"].sum())
+    dropped = int(env.engine.tensors["object_contact_dropped"].sum())
+    assert int(env.engine.tensors["object_contact_count"].max()) <= 12
+    assert taken > 2 * n * steps                    # the cube does lie in the hand: several contacts per env and sub-step
+    assert dropped < 2e-3 * 2 * taken, (dropped, taken)      # (two sub-steps per step are counted in `dropped`, the last one in `taken`)
+
+
 @pytest.mark.parametrize("offset", [0, 9000, 16384 - 48])
 def test_shadow_hand_first_steps_at_the_benchmark_size(offset):
     """ShadowHand@16384: the numpy oracle follows 48 consecutive envs of the big batch (global env ids offset ... offset + 47, the last
