@@ -220,7 +220,7 @@ def cpu_baseline(task, num_envs, budget_s=15.0, seed=42):
                plane_mu=cfg["env"]["plane"]["staticFriction"], ground_z=0.0, cfm=1e-6, warm=1.0)
     sc = load_selfcol(name)        # the Humanoid collides with itself, in the port as in the kernels
     orc = OracleLocomotionEnv(task == "Humanoid", load_model(name), sensor_bodies(name), sim, p, num_envs, seed=seed,
-                              precision="f32", **(dict(selfcol=sc, kmax=12, kpair=3) if sc else {}))
+                              precision="f32", **(dict(selfcol=sc, kmax=12, kpair=3, warm_slots=9) if sc else {}))
     rng = np.random.default_rng(seed)
     nact = orc.nd
     for _ in range(2):

@@ -338,13 +338,20 @@ struct Sim {
     static constexpr int C_CB = C_LIMG + 3 * NLIM;        // first contact slot (after limit Ainv, vt, lam)
     static constexpr int C_CSZ = 3 * M::MAXCHAIN + 7;     // 3 rows + Ainv x3, vt_n, lam x3
     static constexpr int C_PB = C_CB + KMAX * C_CSZ;      // first self-contact slot
-    static constexpr int C_SLOTOF = C_PB + (NPG > 0 ? KPAIR * P_CSZ : 0);  // [NSPH] slot index of each sphere (-1: inactive), as int bits
+    static constexpr int C_SLOTOF = C_PB + (NPG > 0 ? KPAIR * P_CSZ : 0);  // [NSPH] slot index of each sphere (-1: inactive), one BYTE per sphere
+    // [1 + 8 KPAIR] self-contact bookkeeping (group -> slot map, per slot contact point / normal / bodies / friction) handed from
+    // the helper wave to the main wave when the sub-step runs on two waves (role 1 -> role 0, below)
+    static constexpr int C_X = C_SLOTOF + (NSPH + 3) / 4;
     // [ND][6] joint motion subspaces, parked here by the tree pass for the contact-row build: with S out of the register file
     // after the tree pass the Humanoid sub-step keeps ~126 fewer values live (it overflows the 512 registers of its lane)
-    static constexpr int C_S = C_SLOTOF + NSPH;
+    static constexpr int C_S = C_X + (NPG > 0 ? 1 + 8 * KPAIR : 0);
     static constexpr bool S_IN_ROWS = (size_t)(C_S + 6 * ND) * 32 * sizeof(float) <= 160 * 1024;
     static constexpr int ROW_SLOTS_COMPACT = C_S + (S_IN_ROWS ? 6 * ND : 0);
-    static constexpr int C_WARM_OK = (C_SLOTOF - C_CB - 3 * NSPH) / C_CSZ - 1;   // last slot whose write cannot reach the staged warm-start values
+    // last sub-step's contact impulses are parked in the last 3 NSPH floats of the (still empty) GROUND-slot region -- not further
+    // up, over the self-contact slots: on two waves those are being filled while the ground spheres still read their parked values
+    static constexpr int C_PARK = C_PB;
+    static constexpr int C_WARM_OK = (C_PARK - C_CB - 3 * NSPH) / C_CSZ - 1;   // last slot whose write cannot reach the staged warm-start values
+    static_assert(!COMPACT || NPG == 0 || C_WARM_OK == 8, "the oracle is told warm_slots = C_WARM_OK + 1 = 9 (tests, bench.py)");
     static constexpr int ROW_SLOTS = COMPACT ? ROW_SLOTS_COMPACT : ROW_SLOTS_STATIC;
 
     // ---- per-env state carried in registers through a sub-step; the warm-start impulses and the sensor outputs
@@ -432,7 +439,7 @@ struct Sim {
     // kernel before it calls the sub-step (`prestaged`)
     static constexpr bool STAGES_LAM = COMPACT || LAM_IN_ROWS;
     static constexpr int stage_slot_lim(int d) { return COMPACT ? C_LIMG + 2 * NLIM + limrow(d) : NROWG * M::MAXCHAIN + 2 * NROWG + limrow(d); }
-    static constexpr int stage_slot_con(int k) { return COMPACT ? C_SLOTOF - 3 * (k / 3 + 1) + (k % 3) : NROWG * M::MAXCHAIN + 2 * NROWG + NLIM + k; }
+    static constexpr int stage_slot_con(int k) { return COMPACT ? C_PARK - 3 * (k / 3 + 1) + (k % 3) : NROWG * M::MAXCHAIN + 2 * NROWG + NLIM + k; }
     // working set shared by the phases of one sub-step
     struct Ctx {
         float S[M::NDA][6];           // joint motion subspaces, world axes about O = root origin
@@ -674,10 +681,19 @@ struct Sim {
     // gnd: ground policy; mu_env >= 0 replaces the per-sphere model friction (per-env friction buckets of
     // anymal_terrain.py:236-239,279-281); netf: per-body net contact force [3*NB] (world, this sub-step), written only on
     // height fields (gym.acquire_net_contact_force_tensor, anymal_terrain.py:119)
-    template <int RS, class GND>
+    // role / bar: the sub-step of a self-colliding robot on TWO waves of one workgroup that share the row store.  role -1: one wave
+    // does everything (bar unused).  role 1, the helper: tree pass and factorisation like the main wave, then ONLY the self-collision
+    // phase (broad + narrow phase, rows into the self-contact slots), publishes its bookkeeping at C_X, meets the main wave at
+    // bar() and is done.  role 0, the main wave: everything except that phase; it meets the helper at bar() after its own ground
+    // rows and picks the bookkeeping up.  Both waves compute bit-identical L, S, sphere centres (same code, same inputs).
+    struct NoBarrier { MI_HD void operator()() const {} };
+    template <int RS, class GND, class BAR = NoBarrier>
     MI_HD void substep(const SimParams& P, const float* tau, const float h, const RowStore<RS> rows, const Strided lamc,
                        const Strided laml, const Strided sensor, const Strided dof_force, const GND& gnd, const float mu_env,
-                       const Strided netf, const Drive* drv = nullptr, const bool prestaged = false, const SelfCol* scol = nullptr) {
+                       const Strided netf, const Drive* drv = nullptr, const bool prestaged = false, const SelfCol* scol = nullptr,
+                       const int role = -1, const BAR& bar = BAR{}) {
+        const bool helper = (role == 1), not_helper = (role != 1);
+        auto slot8 = [&](const RowStore<RS>& r, int s) MI_LAMBDA -> signed char& { return reinterpret_cast<signed char*>(r.ptr(C_SLOTOF + (s >> 2)))[s & 3]; };
         // static store: row r at r*MAXCHAIN; compact store: only the limit rows (r < NLIM) live at fixed, tightly packed places
         auto G = [&](int row, int c) MI_LAMBDA -> float& { return rows(COMPACT ? limoff(row) + c : row * M::MAXCHAIN + c); };
         auto Ainv = [&](int row) MI_LAMBDA -> float& { return rows(COMPACT ? C_LIMG + row : NROWG * M::MAXCHAIN + row); };
@@ -694,7 +710,7 @@ struct Sim {
         // compact store: contact impulses are parked at the END of the (still empty) contact-slot region, sphere 0 last: slots
         // fill from the front and sphere s is read before any slot > s can be written
         if constexpr (STAGES_LAM) {
-            if (!prestaged) {
+            if (!prestaged && not_helper) {
                 sfor<ND>([&](auto D) MI_LAMBDA {
                     constexpr int d = D;
                     if constexpr (M::dof_limited[d]) rows(stage_slot_lim(d)) = laml(d);
@@ -789,7 +805,7 @@ struct Sim {
         MI_PHASE();
         // ------------------------------------------------------------ whitened velocity  w = L qd + h L^-T rhs
         float w[NVA];
-        {
+        if (not_helper) {
             float v[NVA];
             if constexpr (!M::FIXED) {
                 v[0] = root[7]; v[1] = root[8]; v[2] = root[9]; v[3] = root[10]; v[4] = root[11]; v[5] = root[12];
@@ -860,7 +876,7 @@ struct Sim {
             });
         };
         // limits: one speculative row per limited dof (nearest bound), chain = dof + its ancestors
-        sfor<ND>([&](auto D) MI_LAMBDA {
+        if (not_helper) sfor<ND>([&](auto D) MI_LAMBDA {
             constexpr int d = D, gi = OFF + d;
             if constexpr (M::dof_limited[d]) {
                 constexpr int row = limrow(d);
@@ -986,7 +1002,7 @@ struct Sim {
         // KMAX); the three rows are only built -- by the lanes that need them -- when some env of the wave has the
         // sphere active (EXEC-masked region, skipped by the whole wave otherwise)
         int cnt = 0;
-        sfor<NSPH>([&](auto S_) MI_LAMBDA {
+        if (not_helper) sfor<NSPH>([&](auto S_) MI_LAMBDA {
             constexpr int s = S_, b = M::sph_body[s];
             MI_PHASE();
             const float* cs = c.xcs[s];
@@ -1006,7 +1022,7 @@ struct Sim {
             const int j = on ? cnt : -1;
             // the parked warm-start impulses of this sphere must be read before its slot (possibly) overwrites them
             float lprev[3];
-            sfor<3>([&](auto K) MI_LAMBDA { lprev[K] = rows(C_SLOTOF - 3 * (s + 1) + K); });
+            sfor<3>([&](auto K) MI_LAMBDA { lprev[K] = rows(C_PARK - 3 * (s + 1) + K); });
             if (on) {
                 float* cb = rows.ptr(C_CB + j * C_CSZ);
                 constexpr int ST = RowStore<RS>::stride;
@@ -1055,7 +1071,7 @@ struct Sim {
                 cb[(3 * M::MAXCHAIN + 3) * ST] = (gap >= 0.f) ? -gap * invh : fminf(-gap * P.erp * invh, P.max_depen_vel);
             }
             cnt += on ? 1 : 0;
-            rows(C_SLOTOF + s) = __builtin_bit_cast(float, j);
+            slot8(rows, s) = (signed char)j;
         });
         // ---- self-collision: per limb-pair group the deepest capsule pair becomes one contact between the two bodies.  The capsule
         // axes end on contact spheres, whose centres the tree pass left in c.xcs.  The Jacobian of the row is J_a - J_b: dofs that
@@ -1063,7 +1079,7 @@ struct Sim {
         // the env's deepest pair happens to join, so it is read from the per-lane chain masks instead of being unrolled per body pair
         // (13 row-build code paths for the Humanoid instead of 66).
         MI_STAMP(9);      // (debug stamps: 4 .. 9 = ground contact rows, 9 .. 5 = self-collision phase)
-        if constexpr (NPG > 0) { if (selfcol) {
+        if constexpr (NPG > 0) { if (selfcol && role != 0) {
         int cntp = 0;
         // broad phase: bounding sphere of every capsule (centre = middle of its axis, radius = half length + capsule radius); the
         // narrow phase of a capsule pair is skipped by the whole wave when no env has the two spheres within reach
@@ -1185,6 +1201,25 @@ struct Sim {
             cntp += on ? 1 : 0;
         });
         } }
+        if constexpr (NPG > 0) {
+            // two waves: the helper hands its bookkeeping over through the row store and is done; the main wave waits for it here,
+            // with its own limit and ground rows already built
+            if (helper) {
+                if (selfcol) {
+                    rows(C_X) = __builtin_bit_cast(float, pmap);
+                    sfor<KPAIR>([&](auto J_) MI_LAMBDA { sfor<8>([&](auto I_) MI_LAMBDA { rows(C_X + 1 + 8 * J_ + I_) = pinf[J_][I_]; }); });
+                }
+                bar();
+                return;
+            }
+            if (role == 0) {
+                bar();
+                if (selfcol) {
+                    pmap = __builtin_bit_cast(unsigned, rows(C_X));
+                    sfor<KPAIR>([&](auto J_) MI_LAMBDA { sfor<8>([&](auto I_) MI_LAMBDA { pinf[J_][I_] = rows(C_X + 1 + 8 * J_ + I_); }); });
+                }
+            }
+        }
         }
         MI_PHASE();
         MI_STAMP(5);
@@ -1220,7 +1255,7 @@ struct Sim {
             } else {
                 sfor<NSPH>([&](auto S_) MI_LAMBDA {
                     constexpr int s = S_, b = M::sph_body[s];
-                    const int j = __builtin_bit_cast(int, rit(C_SLOTOF + s));
+                    const int j = (int)slot8(rit, s);
                     if (j >= 0) {
                         const float* cb = rit.ptr(C_CB + j * C_CSZ);
                         constexpr int ST = RowStore<RS>::stride;
@@ -1370,7 +1405,7 @@ struct Sim {
             });
             sfor<NSPH>([&](auto S_) MI_LAMBDA {
                 constexpr int s = S_, b = M::sph_body[s];
-                const int j = __builtin_bit_cast(int, rit(C_SLOTOF + s));
+                const int j = (int)slot8(rit, s);
                 if (j >= 0) {
                     float* cb = rit.ptr(C_CB + j * C_CSZ);
                     const float mu = 0.5f * ((mu_env >= 0.f ? mu_env : M::sph_mu[s]) + P.plane_mu);
@@ -1498,7 +1533,7 @@ struct Sim {
             // inactive spheres carry lam = 0 => zero warm start and zero sensor / net-force contribution
             float ln, l1, l2;
             if constexpr (COMPACT) {
-                const int j = __builtin_bit_cast(int, rows(C_SLOTOF + s));
+                const int j = (int)slot8(rows, s);
                 const float* cb = rows.ptr(C_CB + (j >= 0 ? j : 0) * C_CSZ);
                 constexpr int ST = RowStore<RS>::stride;
                 const bool onj = j >= 0;

@@ -125,25 +125,13 @@ constexpr size_t lds_bytes() { return (size_t)Sim<M>::ROW_SLOTS * Sim<M>::LANES 
 template <class M>
 constexpr bool rows_fit_lds() { return lds_bytes<M>() <= 160 * 1024; }
 
-#if defined(MI_TIMING)
-// debug builds only (tools/debug/phase_timing_live.py): per-workgroup s_memtime stamps of the sub-step phases, 16 slots per workgroup
-__device__ unsigned long long* g_mi_tstamp = nullptr;
-#endif
-template <class M, class GND>
-__global__ __launch_bounds__(64) void substep_kernel(View v, SimParams P, ActParams ap, const float* __restrict__ actions_in, int src,
-                                                     GND gnd) {
-    extern __shared__ float lds_rows[];  // [ROW_SLOTS][LANES] when the model's rows fit (else unused, size 0)
-    constexpr int ND = M::ND, LANES = Sim<M>::LANES;
-    const int e = xcd_env_base<LANES>(blockIdx.x) + threadIdx.x;
+// efforts of one env for this sub-step: from the policy's actions (first launch of a step: clamp, noise, gear / PD), from the stored
+// clamped actions (PD re-evaluated every decimation sub-step) or the stored efforts
+template <class M>
+__device__ __forceinline__ void efforts_for_substep(const View& v, const ActParams& ap, const float* __restrict__ actions_in, const int src,
+                                                    const int e, const Sim<M>& sim, float* tau) {
+    constexpr int ND = M::ND;
     const int N = v.N;
-    if (e >= N) return;                  // no cross-lane operation in here: tail lanes simply retire
-    Sim<M> sim;
-    load_sim(sim, v, e);
-    load_actor_scales(sim, v, e);
-#if defined(MI_TIMING)
-    sim.tstamp = (threadIdx.x == 0 && g_mi_tstamp != nullptr) ? g_mi_tstamp + (size_t)blockIdx.x * 16 : nullptr;   // tools/debug/phase_timing_live.py
-#endif
-    float tau[M::NDA];
     if (src != ACT_STORED_TAU) {         // uniform branch
         sfor<ND>([&](auto K) MI_LAMBDA {
             constexpr int k = K;
@@ -171,23 +159,49 @@ __global__ __launch_bounds__(64) void substep_kernel(View v, SimParams P, ActPar
     } else {
         sfor<ND>([&](auto K) MI_LAMBDA { tau[K] = v.tau[K * N + e]; });
     }
-    // Last sub-step's impulses go from HBM straight into their row-store slots with LDS-direct loads (global_load_lds_dword:
-    // lane l of the wave lands at slot base + 4 l, exactly the [slot][lane] layout): no VGPR holds them in flight, so the ~50
-    // (Ant) / ~130 (Humanoid) loads no longer push that many live values out of the register file at the top of the kernel.
+}
+// Last sub-step's impulses go from HBM straight into their row-store slots with LDS-direct loads (global_load_lds_dword:
+// lane l of the wave lands at slot base + 4 l, exactly the [slot][lane] layout): no VGPR holds them in flight, so the ~50
+// (Ant) / ~130 (Humanoid) loads no longer push that many live values out of the register file at the top of the kernel.
+template <class M>
+__device__ __forceinline__ void prestage_warm_start(const View& v, const int e, float* lds_rows) {
+    using S = Sim<M>;
+    constexpr int LANES = S::LANES;
+    const int N = v.N;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    sfor<M::ND>([&](auto D) MI_LAMBDA {
+        constexpr int d = D;
+        if constexpr (M::dof_limited[d])
+            __builtin_amdgcn_global_load_lds((gptr_t)(v.laml + (size_t)d * N + e), (lptr_t)(lds_rows + S::stage_slot_lim(d) * LANES), 4, 0, 0);
+    });
+    sfor<3 * M::NSPH>([&](auto K) MI_LAMBDA {
+        __builtin_amdgcn_global_load_lds((gptr_t)(v.lamc + (size_t)K * N + e), (lptr_t)(lds_rows + S::stage_slot_con(K) * LANES), 4, 0, 0);
+    });
+}
+
+#if defined(MI_TIMING)
+// debug builds only (tools/debug/phase_timing_live.py): per-workgroup s_memtime stamps of the sub-step phases, 16 slots per workgroup
+__device__ unsigned long long* g_mi_tstamp = nullptr;
+#endif
+template <class M, class GND>
+__global__ __launch_bounds__(64) void substep_kernel(View v, SimParams P, ActParams ap, const float* __restrict__ actions_in, int src,
+                                                     GND gnd) {
+    extern __shared__ float lds_rows[];  // [ROW_SLOTS][LANES] when the model's rows fit (else unused, size 0)
+    constexpr int ND = M::ND, LANES = Sim<M>::LANES;
+    const int e = xcd_env_base<LANES>(blockIdx.x) + threadIdx.x;
+    const int N = v.N;
+    if (e >= N) return;                  // no cross-lane operation in here: tail lanes simply retire
+    Sim<M> sim;
+    load_sim(sim, v, e);
+    load_actor_scales(sim, v, e);
+#if defined(MI_TIMING)
+    sim.tstamp = (threadIdx.x == 0 && g_mi_tstamp != nullptr) ? g_mi_tstamp + (size_t)blockIdx.x * 16 : nullptr;   // tools/debug/phase_timing_live.py
+#endif
+    float tau[M::NDA];
+    efforts_for_substep<M>(v, ap, actions_in, src, e, sim, tau);
     constexpr bool PRESTAGE = rows_fit_lds<M>() && Sim<M>::STAGES_LAM;
-    if constexpr (PRESTAGE) {
-        using S = Sim<M>;
-        typedef const __attribute__((address_space(1))) void* gptr_t;
-        typedef __attribute__((address_space(3))) void* lptr_t;
-        sfor<ND>([&](auto D) MI_LAMBDA {
-            constexpr int d = D;
-            if constexpr (M::dof_limited[d])
-                __builtin_amdgcn_global_load_lds((gptr_t)(v.laml + (size_t)d * N + e), (lptr_t)(lds_rows + S::stage_slot_lim(d) * LANES), 4, 0, 0);
-        });
-        sfor<3 * M::NSPH>([&](auto K) MI_LAMBDA {
-            __builtin_amdgcn_global_load_lds((gptr_t)(v.lamc + (size_t)K * N + e), (lptr_t)(lds_rows + S::stage_slot_con(K) * LANES), 4, 0, 0);
-        });
-    }
+    if constexpr (PRESTAGE) prestage_warm_start<M>(v, e, lds_rows);
     const float h = P.dt / (float)P.substeps;
     const Strided lamc{v.lamc + e, N}, laml{v.laml + e, N}, sensor{v.sensor + e, N}, dof_force{v.dof_force + e, N};
     const Strided netf{GND::NETF ? v.netf + e : nullptr, N};
@@ -211,6 +225,10 @@ __global__ __launch_bounds__(64) void substep_kernel(View v, SimParams P, ActPar
 #endif
 template <class M, class GND>
 constexpr bool mw_capable() { return !Sim<M>::COMPACT && Sim<M>::LAM_IN_ROWS && !M::FIXED && M::NLIMB >= 3 && !std::is_same<GND, PlaneGroundNF>::value; }
+// launches n_sub sub-steps of a self-colliding robot on two waves per workgroup (sc2_kernels.hpp, instantiated in kernels_humanoid_sc2.hip)
+template <class M>
+hipError_t launch_substeps_sc2(const View& v, const SimParams& P, const ActParams& ap, const float* actions, int n_sub, int first, int rest,
+                               hipStream_t s);
 // launches n_sub multi-wave sub-steps with v.mw envs per workgroup (defined for the model / ground pairs of kernels_mw_*.hip)
 template <class M, class GND>
 hipError_t launch_substeps_mw(const View& v, const SimParams& P, const ActParams& ap, const float* actions, int n_sub, int first, int rest,
@@ -408,6 +426,10 @@ inline hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes, unsigned 
 template <class M, class GND = PlaneGround>
 hipError_t launch_substeps(const View& v, const SimParams& P, const ActParams& ap, const float* actions, int n_sub, int first,
                            int rest, hipStream_t s, const GND& gnd = GND{}) {
+    if constexpr (Sim<M>::NPG > 0 && std::is_same<GND, PlaneGround>::value) {
+        // self-colliding robot: the self-collision phase on a second wave of the workgroup (kernels_<model>_sc2.hip)
+        if (v.mw != 0 && v.lamp != nullptr) return launch_substeps_sc2<M>(v, P, ap, actions, n_sub, first, rest, s);
+    }
     if constexpr (mw_capable<M, GND>()) {
         if (v.mw != 0) return launch_substeps_mw<M, GND>(v, P, ap, actions, n_sub, first, rest, s, gnd);
     }

@@ -29,7 +29,7 @@ def _struct(real):
                        "parent", "bpos", "bquat", "mass", "com", "inertia", "dof_body", "dof_type", "dof_axis",
                        "dof_anchor", "dof_lower", "dof_upper", "dof_limited", "dof_armature", "dof_damping",
                        "dof_stiffness", "dof_springref", "sph_body", "sph_pos", "sph_rad", "sph_mu", "sens_body")] + \
-                   [(n, C.c_int32) for n in ("ncap", "npg", "ngp", "kmax", "kpair", "pad1")] + \
+                   [(n, C.c_int32) for n in ("ncap", "npg", "ngp", "kmax", "kpair", "warm_slots")] + \
                    [(n, C.c_void_p) for n in ("cap_body", "cap_p0", "cap_p1", "cap_rad", "cap_mu", "gp_a", "gp_b", "pg_first", "pg_count")]
 
     class OrParams(C.Structure):
@@ -47,7 +47,7 @@ class OracleEngine:
     """Batched CPU physics for one ModelSpec.  State is AoS per env:
     root[13] (pos3, quat xyzw4, linvel3, angvel3) | q[nd] | qd[nd] | lam_c[3*nsph] | lam_l[nd]."""
 
-    def __init__(self, spec, num_envs, params=None, sensor_bodies=(), precision="f64", selfcol=None, kmax=0, kpair=0):
+    def __init__(self, spec, num_envs, params=None, sensor_bodies=(), precision="f64", selfcol=None, kmax=0, kpair=0, warm_slots=0):
         """selfcol: self-collision tables (isaacgymenvs_amd.assets.model.self_collision_tables) or None; kmax / kpair: caps of
         the ground / self contacts per env (0 = unlimited; the engine's LDS contact store holds 12 + 3)."""
         build()
@@ -88,7 +88,7 @@ class OracleEngine:
                 setattr(m, n, _ptr(k[n]))
             self.npg = len(first)
             self.pair_list = list(zip(ga, gb))
-        m.kmax, m.kpair = int(kmax), int(kpair)
+        m.kmax, m.kpair, m.warm_slots = int(kmax), int(kpair), int(warm_slots)
         self.model = m
         self.set_params(**(params or {}))
         self.N = num_envs

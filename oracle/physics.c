@@ -71,7 +71,7 @@ typedef struct {
      * pair list).  A group carries at most ONE contact per sub-step, its deepest capsule pair.  kmax / kpair > 0 cap the
      * number of ground contacts / group contacts per env (first come first served in sphere / group order), as the engine's
      * LDS-resident contact store does. */
-    int32_t ncap, npg, ngp, kmax, kpair, pad1;
+    int32_t ncap, npg, ngp, kmax, kpair, warm_slots;   /* warm_slots > 0: only the first warm_slots ground-contact slots of an env are warm started (the engine's compact store parks last step's impulses in the tail of its slot region, csrc/core/engine.hpp C_WARM_OK) */
     const int32_t *cap_body;     /* [ncap] */
     const real *cap_p0, *cap_p1, *cap_rad, *cap_mu; /* [ncap*3] x2, [ncap] x2 */
     const int32_t *gp_a, *gp_b;  /* [ngp] capsule indices; side a receives +lambda n, side b -lambda n */
@@ -489,7 +489,7 @@ static void step_env(const OrModel *m, const OrParams *p, const OrGround *gnd, r
                 int r = nrow++;
                 point_jac(m, &w, b, xc, dirs[k], J[r]);
                 vt[r] = (k == 0) ? ((gap >= 0) ? -gap / h : fmin(-gap * p->erp / h, p->max_depen_vel)) : 0;
-                lam[r] = lam_c[3 * s + k] * p->warm;
+                lam[r] = (m->warm_slots > 0 && nground > m->warm_slots) ? 0 : lam_c[3 * s + k] * p->warm;
             }
         }
         /* self-collision: per group the deepest capsule pair; one contact (normal + 2 tangents) between the two bodies */

@@ -216,11 +216,11 @@ class OracleLocomotionEnv:
     """
 
     def __init__(self, hum, spec, sensor_bodies, sim_params: dict, params, num_envs, seed=0, env_id_offset=0,
-                 precision="f32", control_freq_inv=1, selfcol=None, kmax=0, kpair=0):
+                 precision="f32", control_freq_inv=1, selfcol=None, kmax=0, kpair=0, warm_slots=0):
         from .engine import OracleEngine
         self.hum, self.N, self.p, self.nd = hum, num_envs, params, spec.nd
         self.eng = OracleEngine(spec, num_envs, params=sim_params, sensor_bodies=sensor_bodies, precision=precision,
-                                selfcol=selfcol, kmax=kmax, kpair=kpair)
+                                selfcol=selfcol, kmax=kmax, kpair=kpair, warm_slots=warm_slots)
         self.seed, self.off, self.cfi = fold_seed(seed), env_id_offset, control_freq_inv
         nd = self.nd
         self.lower = np.array(params.dof_lower[:nd], f32)

@@ -126,6 +126,47 @@ extern "C" int hs_step_selfcol(const SimParams* P, int nenv, float* state, const
     run<ModelHumanoid>(P, nenv, state, tau, out, 1);
     return 0;
 }
+// the self-colliding sub-step on TWO waves (Sim::substep role 0 / 1): two threads per env share the row store and meet at a pthread
+// barrier where the GPU waves meet at s_barrier.  Same state / out layout as hs_step_selfcol.
+template <int ROLE>
+static void sc2_thread(const SimParams* P, float* s, const float* tau, float* o, float* rows, float* pf, pthread_barrier_t* bar) {
+    using M = ModelHumanoid;
+    constexpr int ND = M::ND, NSPH = M::NSPH, NSENS = M::NSENS;
+    const float h = P->dt / (float)P->substeps;
+    for (int ss = 0; ss < P->substeps; ++ss) {
+        Sim<M> sim;
+        for (int k = 0; k < 13; ++k) sim.root[k] = s[k];
+        for (int k = 0; k < ND; ++k) { sim.q[k] = s[13 + k]; sim.qd[k] = s[13 + ND + k]; }
+        pthread_barrier_wait(bar);     // both have read the state of the previous sub-step
+        const SelfCol sc{Strided{s + 13 + 3 * ND + 3 * NSPH, 1}, Strided{pf, 1}};
+        sim.substep(*P, tau, h, RowStore<1>{rows}, Strided{s + 13 + 2 * ND, 1}, Strided{s + 13 + 2 * ND + 3 * NSPH, 1}, Strided{o, 1},
+                    Strided{o + 6 * NSENS, 1}, PlaneGround{}, -1.f, Strided{nullptr, 1}, nullptr, false, &sc, ROLE, HostBarrier{bar});
+        if (ROLE == 0) {
+            for (int k = 0; k < 13; ++k) s[k] = sim.root[k];
+            for (int k = 0; k < ND; ++k) { s[13 + k] = sim.q[k]; s[13 + ND + k] = sim.qd[k]; }
+        }
+        pthread_barrier_wait(bar);     // the new state is complete
+    }
+}
+extern "C" int hs_step_selfcol2(const SimParams* P, int nenv, float* state, const float* tau, float* out) {
+    using M = ModelHumanoid;
+    constexpr int ND = M::ND, NSPH = M::NSPH, NSENS = M::NSENS, NPG = Sim<M>::NPG;
+    const int ss = 13 + 2 * ND + 3 * NSPH + ND + 3 * NPG, os = 6 * NSENS + ND + 3 * NSPH + 9 * NPG;
+    for (int e = 0; e < nenv; ++e) {
+        float* s = state + (size_t)e * ss;
+        float* o = out + (size_t)e * os;
+        static float rows[Sim<M>::ROW_SLOTS];
+        float pf[3 * NPG];
+        for (int k = 0; k < Sim<M>::ROW_SLOTS; ++k) rows[k] = 0.f;
+        pthread_barrier_t bar;
+        pthread_barrier_init(&bar, nullptr, 2);
+        std::thread t0(sc2_thread<0>, P, s, tau + (size_t)e * ND, o, rows, pf, &bar), t1(sc2_thread<1>, P, s, tau + (size_t)e * ND, o, rows, pf, &bar);
+        t0.join(); t1.join();
+        pthread_barrier_destroy(&bar);
+        for (int g = 0; g < NPG; ++g) for (int k = 0; k < 3; ++k) o[6 * NSENS + ND + 3 * NSPH + 9 * g + k] = pf[3 * g + k];
+    }
+    return 0;
+}
 #endif
 
 extern "C" int hs_step(const char* model, const SimParams* P, int nenv, float* state, const float* tau, float* out) {

@@ -64,7 +64,7 @@ def test_locomotion_on_cpu_matches_the_cpu_restatement(task, hum, z0):
     p = loco_params_from_cfg(cfg, task.lower(), z0)
     sc = load_selfcol(task.lower())
     orc = OracleLocomotionEnv(hum, spec, sensor_bodies(task.lower()), _sim_dict(env.sim_params), p, n, seed=seed, precision="f64",
-                              **(dict(selfcol=sc, kmax=12, kpair=3) if sc else {}))
+                              **(dict(selfcol=sc, kmax=12, kpair=3, warm_slots=9) if sc else {}))
     g = torch.Generator(device="cpu").manual_seed(3)
     for step in range(6):
         a = torch.rand((n, env.num_actions), generator=g) * 2 - 1

@@ -159,7 +159,7 @@ def _selfcol_kw(task):
     and 3 self contacts per env."""
     from isaacgymenvs_amd.registry import load_selfcol
     sc = load_selfcol(task.lower())
-    return dict(selfcol=sc, kmax=12, kpair=3) if sc else {}
+    return dict(selfcol=sc, kmax=12, kpair=3, warm_slots=9) if sc else {}
 
 
 def _random_state(spec, n, rng, z_lo, z_hi):

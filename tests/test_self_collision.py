@@ -199,7 +199,7 @@ def test_host_build_of_engine_core_matches_oracle_with_self_collision():
     rng = np.random.default_rng(0)
     root, q, qd = _random_state(spec, n, rng, 0.9, 1.6)
     tau = rng.uniform(-60, 60, (n, nd))
-    orc = OracleEngine(spec, n, params=SIM, sensor_bodies=sb, precision="f64", selfcol=sc, kmax=12, kpair=3)
+    orc = OracleEngine(spec, n, params=SIM, sensor_bodies=sb, precision="f64", selfcol=sc, kmax=12, kpair=3, warm_slots=9)
     orc.root[:] = root; orc.q[:] = q; orc.qd[:] = qd
     st = np.zeros((n, 13 + 2 * nd + 3 * nsph + nd + 3 * npg), np.float32)
     st[:, :13] = root; st[:, 13:13 + nd] = q; st[:, 13 + nd:13 + 2 * nd] = qd
@@ -224,3 +224,30 @@ def test_host_build_of_engine_core_matches_oracle_with_self_collision():
         assert np.abs(st[:, 13 + 2 * nd:13 + 3 * nd + 3 * nsph] - orc.lam).max() < 2e-3 * max(1.0, np.abs(orc.lam).max())
         assert np.abs(out[:, :12] - orc.sensor).max() < 2e-3 * max(1.0, np.abs(orc.sensor).max())
     assert touched > 0.3 * 3 * n
+
+
+def test_two_wave_split_of_the_sub_step_is_bit_identical_on_the_host():
+    """Sim::substep with role 0 (everything but the self-collision phase) and role 1 (tree pass, factor, self-collision phase) on two
+    threads that share the row store and meet at one barrier -- what the GPU runs as two waves of a workgroup -- against the same
+    sub-step on one thread: the same arithmetic on the same values, so every output bit is the same."""
+    import hostsim
+    spec, sb, sc = load_model("humanoid"), sensor_bodies("humanoid"), load_selfcol("humanoid")
+    lib = hostsim.build(humanoid=True)
+    n, nd, nsph, npg = 96, spec.nd, len(spec.sph_body), len(sc["groups"])
+    rng = np.random.default_rng(5)
+    root, q, qd = _random_state(spec, n, rng, 0.9, 1.6)
+    tau32 = np.ascontiguousarray(rng.uniform(-60, 60, (n, nd)), np.float32)
+    st1 = np.zeros((n, 13 + 2 * nd + 3 * nsph + nd + 3 * npg), np.float32)
+    st1[:, :13] = root; st1[:, 13:13 + nd] = q; st1[:, 13 + nd:13 + 2 * nd] = qd
+    st2 = st1.copy()
+    out1 = np.zeros((n, 6 * len(sb) + nd + 3 * nsph + 9 * npg), np.float32)
+    out2 = out1.copy()
+    p = hostsim.make_params(SIM)
+    touched = 0
+    for it in range(3):
+        hostsim.step_selfcol(lib, p, st1, tau32, out1)
+        hostsim.step_selfcol2(lib, p, st2, tau32, out2)
+        np.testing.assert_array_equal(st1, st2)
+        np.testing.assert_array_equal(out1, out2)
+        touched += int((np.abs(st1[:, 13 + 3 * nd + 3 * nsph:]).sum(1) > 0).sum())
+    assert touched > 0.1 * 3 * n                      # envs whose self contacts carry load

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Humanoid@8192 step time with and without self-collision, same process / same box (GPU)."""
+"""Humanoid@8192 step time with and without self-collision, one wave per workgroup and with the self-collision phase on a helper wave
+(csrc/sc2_kernels.hpp), same process / same box (GPU)."""
 import os
 import sys
 import time
@@ -13,7 +14,11 @@ n = 8192
 env = isaacgymenvs_amd.make(seed=42, task="Humanoid", num_envs=n, sim_device="cuda:0", rl_device="cuda:0", headless=True)
 acts = [torch.rand((n, 21), device="cuda:0") * 2 - 1 for _ in range(8)]
 for rep in range(2):
+  for mw in (32, 0):
+    env.engine.set_option("multi_wave", mw)
     for on in (1, 0):
+        if not on and mw:
+            continue
         env.engine.set_option("self_collision", on)
         for i in range(100):
             env.step(acts[i % 8])
@@ -25,4 +30,4 @@ for rep in range(2):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / k
         act = (env.self_contact_impulse[:, :, 0] > 0).sum(1).float().mean().item() if on else 0.0
-        print(f"rep{rep} self_collision={on}: {dt * 1e3:.4f} ms/step, {n / dt / 1e6:.2f} M env-steps/s, loaded self contacts per env {act:.3f}", flush=True)
+        print(f"rep{rep} self_collision={on} waves={2 if (mw and on) else 1}: {dt * 1e3:.4f} ms/step, {n / dt / 1e6:.2f} M env-steps/s, loaded self contacts per env {act:.3f}", flush=True)
