@@ -138,11 +138,13 @@ def roofline(task, num_envs, kernel_ms, mw=0):
     bytes_per_launch = ALGO_BYTES[task] * num_envs
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
     tr = load_traffic().get(f"{task}@{num_envs}", {})
-    if mw:
+    if mw and task == "Humanoid":
+        shape = "%d workgroups of 32 envs x 2 waves (main wave + self-collision helper wave)" % ((num_envs + 31) // 32)
+    elif mw:
         shape = "%d workgroups of %d envs x 4 waves (one limb per wave)" % ((num_envs + mw - 1) // mw, mw)
     else:
         lanes = 32 if task in ("Humanoid", "ShadowHand") else 64   # compact-store models run 32 envs per wave
-        shape = "%d waves of %d envs, one per SIMD" % ((num_envs + lanes - 1) // lanes, lanes)
+        shape = "%d waves of %d envs, one per SIMD%s" % ((num_envs + lanes - 1) // lanes, lanes, " (two resident per CU)" if task == "ShadowHand" else "")
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
            "traffic": tr.get("traffic_bytes_per_step"), "traffic_source": tr.get("source"),
            "kernel": "one control step = physics sub-step kernel x sim steps + post kernel(s) (%s)" % task,
@@ -316,7 +318,8 @@ def main():
         out["extra"] = {"workload": f"Humanoid num_envs={side['Humanoid']} per GPU, self-collision {'on' if extra.get('self_collision') else 'off'} "
                                     f"(humanoid.py:194)", "value": extra["env_steps_per_s"],
                         "unit": "env-steps/s", "ms_per_step": extra["ms_per_step"], "reset_rate": extra["reset_rate"], "pooled": extra["pooled"],
-                        "roofline": roofline("Humanoid", side["Humanoid"], extra["kernel_ms_avg"])}
+                        "multi_wave": extra["multi_wave"],
+                        "roofline": roofline("Humanoid", side["Humanoid"], extra["kernel_ms_avg"], extra["multi_wave"])}
     if extra2 is not None:
         out["extra2"] = {"workload": f"AnymalTerrain num_envs={side['AnymalTerrain']} per GPU ({world * side['AnymalTerrain']} total; 5 sim steps of 5 ms per control step)",
                          "value": extra2["env_steps_per_s"], "unit": "env-steps/s", "ms_per_step": extra2["ms_per_step"],

@@ -119,7 +119,7 @@ for k, v in d.items():
 # ---- one control step per task = these launches (pattern, launches per step)
 RECIPE = {
     "Ant@4096": [(r"substep(_mw)?_kernel<ModelAnt", 2), (r"loco_post_kernel<ModelAnt", 1)],
-    "Humanoid@8192": [(r"substep_kernel<ModelHumanoid", 2), (r"loco_post_kernel<ModelHumanoid", 1)],
+    "Humanoid@8192": [(r"substep_(sc2_)?kernel<ModelHumanoid", 2), (r"loco_post_kernel<ModelHumanoid", 1)],
     "AnymalTerrain@4096": [(r"substep(_mw)?_kernel<ModelAnymal, mi::HeightfieldGround", 5), (r"anymal_post_kernel", 1), (r"anymal_heights_kernel", 1),
                            (r"anymal_cmdnorm_kernel", 1)],
     "ShadowHand@16384": [(r"hand_pre_kernel", 1), (r"hand_substep_kernel<0>", 2), (r"hand_post_kernel", 1), (r"hand_finalize_kernel", 1)],
