@@ -290,14 +290,27 @@ struct HandSim : Sim<M> {
                     refused += ((dist < P.contact_offset) && (nbody < BODY_CAP) && (cnt >= KMAX)) ? 1 : 0;   // all KMAX slots taken
                     nbody += on ? 1 : 0;
                     const int j = on ? cnt : -1;
-                    if (on) {
-                        float fr[3][3];
-                        matvec3(Ro, nl, fr[0]);                 // from the object towards the sphere
-                        contact_frame(fr[0], fr[1], fr[2]);
-                        float pc[3], rc[3];
-                        sfor<3>([&](auto K) MI_LAMBDA { pc[K] = cs[K] - rad * fr[0][K]; rc[K] = pc[K] - xo[K]; });
+                    if (on) {      // narrow phase only: the contact's geometry goes into its slot, the rows are built below
+                        float n[3], rc[3];
+                        matvec3(Ro, nl, n);                     // from the object towards the sphere
+                        sfor<3>([&](auto K) MI_LAMBDA { rc[K] = (cs[K] - rad * n[K]) - xo[K]; });
                         float* cb = rows.ptr(H_CB + j * H_CSZ);
                         const float gap = dist - P.rest_offset;
+                        sfor<3>([&](auto I_) MI_LAMBDA { cb[(H_GEO + I_) * ST] = n[I_]; cb[(H_GEO + 3 + I_) * ST] = rc[I_]; });
+                        cb[(H_AUX + 3) * ST] = (gap >= 0.f) ? -gap * invh : fminf(-gap * P.erp * invh, P.max_depen_vel);
+                    }
+                    cnt += on ? 1 : 0;
+                }
+                // rows of this body's contacts, walked by contact (at most BODY_CAP, left by the whole wave as soon as no env has an
+                // (i+1)-th one) instead of being built inside the sphere loop: one wave executes the UNION of its envs' work, and the
+                // union of touched spheres of a body is several times larger than the largest per-env contact count on it
+                for (int i = 0; i < BODY_CAP; ++i) {
+                    if (!MI_WAVE_ANY(i < nbody)) break;
+                    if (i < nbody) {
+                        float* cb = rows.ptr(H_CB + (first + i) * H_CSZ);
+                        float fr[3][3], rc[3], pc[3];
+                        sfor<3>([&](auto I_) MI_LAMBDA { fr[0][I_] = cb[(H_GEO + I_) * ST]; rc[I_] = cb[(H_GEO + 3 + I_) * ST]; pc[I_] = rc[I_] + xo[I_]; });
+                        contact_frame(fr[0], fr[1], fr[2]);
                         sfor<3>([&](auto K) MI_LAMBDA {
                             constexpr int k = K;
                             float W[6];
@@ -326,10 +339,7 @@ struct HandSim : Sim<M> {
                             cb[(H_AUX + k) * ST] = MI_RCP(a);
                             cb[(H_AUX + 4 + k) * ST] = 0.f;    // no warm start for object contacts
                         });
-                        sfor<3>([&](auto I_) MI_LAMBDA { cb[(H_GEO + I_) * ST] = fr[0][I_]; cb[(H_GEO + 3 + I_) * ST] = rc[I_]; });
-                        cb[(H_AUX + 3) * ST] = (gap >= 0.f) ? -gap * invh : fminf(-gap * P.erp * invh, P.max_depen_vel);
                     }
-                    cnt += on ? 1 : 0;
                 }
                 rows(H_BODYSLOT + B::os_slot(b)) = __builtin_bit_cast(float, first | (nbody << 8));
             }
