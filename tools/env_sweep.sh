@@ -1,7 +1,7 @@
 #!/bin/bash
 # Throughput against the env count on one GPU (run on the GPU box): the BASELINE sizes occupy 64-256 of the chip's 1024 SIMDs,
 # this shows where the one-env-per-lane design saturates.  Usage: tools/env_sweep.sh > gpurun_out/env_sweep.txt
-for spec in "Ant 4096 16384 65536 262144 1048576" "Humanoid 8192 32768 131072 524288" "AnymalTerrain 4096 16384 65536" "ShadowHand 16384 65536 131072"; do
+for spec in "Ant 1024 4096 16384 65536 262144" "Humanoid 2048 8192 32768 131072" "AnymalTerrain 4096 16384 65536" "ShadowHand 4096 16384 65536 131072"; do
   set -- $spec; task=$1; shift
   for n in "$@"; do
     steps=$(( 400000000 / n / 50 )); [ $steps -gt 1000 ] && steps=1000; [ $steps -lt 30 ] && steps=30
