@@ -612,6 +612,10 @@ def _contact_spheres(geom_body, geom_type, geom_pos, geom_quat, geom_size, geom_
             np.array(sg, np.int32))
 
 
+# weld of a locked joint (bounds coincide) in the mass matrix, see build_model
+LOCKED_ARMATURE, LOCKED_STIFFNESS, LOCKED_DAMPING = 100.0, 1000.0, 600.0
+
+
 def build_model(name, bodies, acts, fix_base_link=False, density=None, dedupe_spheres=True,
                 collide_body_filter=None):
     """Flatten the intermediate tree.  Welded (jointless, non-root) bodies are merged into parents."""
@@ -670,6 +674,20 @@ def build_model(name, bodies, acts, fix_base_link=False, density=None, dedupe_sp
         for j in bodies[i].joints:
             lo, up = j.lower, j.upper
             dn.append(j.name); db.append(k); dt.append(j.jtype); dax.append(j.axis); dan.append(j.anchor)
+            locked = bool(j.limited) and lo == up
+            if locked:
+                # A limited joint whose bounds coincide (MJCF range="0 0": the physics rotors of Ingenuity) is a weld that keeps its dof
+                # slot.  As a limit row it is the worst case for the Gauss-Seidel sweeps -- two such joints on one light parent give a
+                # constraint matrix with 0.975 off-diagonal correlation (6 sweeps remove a quarter of the error) and, on the GPU, a
+                # growing oscillation.  It is welded in the mass matrix instead: a large armature on the joint coordinate (the child
+                # cannot move relative to its parent, its inertia still loads the parent) plus a stiff, overdamped centering spring;
+                # no limit row.  H stays well conditioned for the sparse factorisation (diagonal 1e2 against inertias of 1e-2).
+                dlim.append(0)
+                darm.append(j.armature + LOCKED_ARMATURE); ddamp.append(j.damping + LOCKED_DAMPING); dst.append(j.stiffness + LOCKED_STIFFNESS)
+                dref.append(lo)
+                dlo.append(lo); dup.append(up)
+                deff.append(j.effort); dvel.append(j.velocity)
+                continue
             dlo.append(lo); dup.append(up); dlim.append(1 if j.limited else 0)
             darm.append(j.armature); ddamp.append(j.damping); dst.append(j.stiffness); dref.append(j.springref)
             deff.append(j.effort); dvel.append(j.velocity)

@@ -721,6 +721,33 @@ def test_ingenuity_step_matches_cpu_restatement():
     assert float(env.dof_positions[:, [0, 2]].abs().max()) < 0.02                       # the two locked rotor joints (range 0 0)
 
 
+def test_ingenuity_locked_rotor_joints_hold_under_full_range_thrusts():
+    """The two rotor joints with range 0 0 are welded in the mass matrix (assets/model.py LOCKED_ARMATURE).  As limit rows they were the
+    worst case for the sweeps -- two constraints on one light chassis, 0.975 correlated: 6 sweeps remove a quarter of the error -- and,
+    seeded by fp32 round-off, pumped a yaw oscillation between the chassis and the heavy rotors that reached the angular-velocity
+    clamp after ~230 steps of full-range random thrusts (the near-hover thrusts of the parity test above never showed it)."""
+    from oracle.tasks import OracleIngenuityEnv
+    n, seed = 128, 29
+    env = _make_env("Ingenuity", n, seed=seed)
+    orc = OracleIngenuityEnv(load_model("ingenuity"), sensor_bodies("ingenuity"), _sim_dict(env.sim_params), env._task_params_struct, n,
+                             seed=seed, precision="f64")
+    g = torch.Generator(device="cpu").manual_seed(4)
+    for step in range(600):
+        a = torch.rand((n, 6), generator=g) * 2 - 1
+        env.step(a.to(DEV))
+        if step < 300:
+            orc.step(a.numpy())
+            if step % 50 == 49:
+                torch.cuda.synchronize()
+                same = env.progress_buf.cpu().numpy() == orc.progress_buf         # a reset one step apart ends the comparison for that env
+                assert same.mean() > 0.9
+                np.testing.assert_allclose(env.dof_velocities.cpu().numpy()[same], orc.eng.qd[same], atol=0.05)
+                np.testing.assert_allclose(env.root_angvels.cpu().numpy()[same], orc.eng.root[same, 10:13], atol=0.02 * (1 + step / 50))
+    assert float(env.dof_positions[:, [0, 2]].abs().max()) < 1e-3
+    assert float((env.dof_velocities[:, 1] + 50).abs().max()) < 0.5 and float((env.dof_velocities[:, 3] - 50).abs().max()) < 0.5
+    assert float(env.root_angvels.abs().max()) < 6.0                               # nowhere near the 4 pi clamp
+
+
 def test_ingenuity_targets_move_every_500_steps_at_full_size():
     n = 4096                                                  # cfg/task/Ingenuity.yaml numEnvs
     env = _make_env("Ingenuity", n, seed=42)

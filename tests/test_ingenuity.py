@@ -27,7 +27,10 @@ def test_procedural_asset_matches_the_generator_in_the_reference():
     spec = load_model("ingenuity")
     assert list(spec.body_names) == ["chassis", "rotor_physics_0", "rotor_visual_0", "rotor_physics_1", "rotor_visual_1"]   # ingenuity.py:156-229
     assert list(spec.dof_names) == ["rotor_roll0", "rotor_roll0", "rotor_roll1", "rotor_roll1"]                             # 4 dofs (:61)
-    assert list(spec.dof_limited) == [1, 0, 1, 0] and not np.any(spec.dof_lower) and not np.any(spec.dof_upper)             # range 0 0 (:200-201)
+    # range 0 0 (:200-201): the two locked rotor joints keep their dof slots and are welded in the mass matrix (assets/model.py
+    # LOCKED_ARMATURE: armature 100 kg m^2 against a rotor inertia of 8e-3, overdamped centering spring), not held by limit rows
+    assert list(spec.dof_limited) == [0, 0, 0, 0] and not np.any(spec.dof_lower) and not np.any(spec.dof_upper)
+    assert list(spec.dof_armature) == [100.0, 0.0, 100.0, 0.0] and list(spec.dof_stiffness) == [1000.0, 0.0, 1000.0, 0.0]
     assert sensor_bodies("ingenuity") == [1, 3]                                                                              # forces[:, 1], forces[:, 3] (:347-348)
     box = 0.12 ** 3 * 50.0                                        # chassis box, half extent 0.06, density 50 (:161-166)
     rotor = math.pi * 0.15 ** 2 * 0.01 * 1000.0                   # rotor cylinder radius 0.15, thickness 0.01, density 1000 (:196-199)
