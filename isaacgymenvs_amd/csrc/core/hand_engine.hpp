@@ -125,6 +125,9 @@ struct HandSim : Sim<M> {
     MI_HD void substep_hand(const SimParams& P, const ObjectParams& OP, const float* target, const float h, const RowStore<RS> rows,
                             const Strided laml, const Strided sensor, const Strided dof_force, int* ncontact) {
         constexpr int ST = RowStore<RS>::stride;
+#if defined(MI_TIMING)
+        unsigned long long* tstamp = this->tstamp;   // MI_STAMP (debug builds: tools/debug/phase_timing_live.py)
+#endif
         float (&q)[M::NDA] = this->q;        // (dependent base: make the state names visible inside the generic lambdas)
         float (&qd)[M::NDA] = this->qd;
         float (&root)[13] = this->root;
@@ -147,6 +150,7 @@ struct HandSim : Sim<M> {
             constexpr int d = D;
             if constexpr (M::dof_limited[d]) lam(B::limrow(d)) = laml(d);
         });
+        MI_STAMP(0);
         // ------------------------------------------------------------ tree pass with gravity off (disable_gravity on the hand)
         {
             SimParams P0 = P;
@@ -158,6 +162,7 @@ struct HandSim : Sim<M> {
             this->template body_pass<0>(P0, c, nullptr, nullptr, nullptr, nullptr, Iroot, Froot);
         }
         MI_PHASE();
+        MI_STAMP(1);
         // ------------------------------------------------------------ rhs: implicit PD drives, passive damping, tendons
         float Ldi[NVA], y[NVA];
         sfor<ND>([&](auto D) MI_LAMBDA {
@@ -225,6 +230,7 @@ struct HandSim : Sim<M> {
         }
         const float xo[3] = {obj.pos[0] - root[0], obj.pos[1] - root[1], obj.pos[2] - root[2]};   // object COM rel O
         MI_PHASE();
+        MI_STAMP(2);
         // ------------------------------------------------------------ joint limit rows (as core/engine.hpp)
         sfor<ND>([&](auto D) MI_LAMBDA {
             constexpr int d = D, gi = OFF + d;
@@ -257,6 +263,7 @@ struct HandSim : Sim<M> {
             }
         });
         MI_PHASE();
+        MI_STAMP(3);
         // ------------------------------------------------------------ object contacts -> compact slots
         // Static over the sphere-carrying bodies (the kinematic chain of a row is compile-time), a run-time loop over the
         // spheres of one body with their positions / radii read from the constant tables (scalar loads): one copy of the
@@ -346,6 +353,7 @@ struct HandSim : Sim<M> {
         });
         *ncontact = cnt | (refused << 16);
         MI_PHASE();
+        MI_STAMP(4);
         // ------------------------------------------------------------ warm start (limit rows only)
         {
             int zero;
@@ -362,6 +370,7 @@ struct HandSim : Sim<M> {
             });
         }
         MI_PHASE();
+        MI_STAMP(5);
         // ------------------------------------------------------------ projected Gauss-Seidel sweeps
         for (int it = 0; it < P.iters; ++it) {
             int zero;
@@ -446,6 +455,7 @@ struct HandSim : Sim<M> {
             });
         }
         MI_PHASE();
+        MI_STAMP(6);
         // ------------------------------------------------------------ back to generalised velocity
         float v[NVA];
         sfor<NV>([&](auto I_) MI_LAMBDA {
@@ -502,6 +512,7 @@ struct HandSim : Sim<M> {
         });
         sfor<6 * NSENS>([&](auto K) MI_LAMBDA { sensor(K) = sens[K]; });
         MI_PHASE();
+        MI_STAMP(7);
         // ------------------------------------------------------------ integrate hand and object (semi-implicit Euler)
         sfor<ND>([&](auto D) MI_LAMBDA { qd[D] = v[OFF + D]; q[D] += h * qd[D]; });
         sfor<3>([&](auto K) MI_LAMBDA {
@@ -525,6 +536,7 @@ struct HandSim : Sim<M> {
             const float n = MI_RSQ(x * x + yy * yy + z * z + ww * ww);
             Q[0] = x * n; Q[1] = yy * n; Q[2] = z * n; Q[3] = ww * n;
         }
+        MI_STAMP(8);
     }
 
     // world pose and velocity of the force-sensor (fingertip) bodies at the CURRENT state: [NSENS][13] = pos3, quat xyzw,

@@ -61,6 +61,9 @@ __global__ __launch_bounds__(32) void hand_substep_kernel(View v, HandView hv, S
     if constexpr (SHAPE != OBJ_BOX) sfor<3>([&](auto K) MI_LAMBDA { OP.dims[K] = p.object_dims[K]; OP.inertia3[K] = p.object_inertia[K]; });
     const float mu_e = hv.mu_env[e];
     if (mu_e >= 0.f) OP.mu = mu_e;
+#if defined(MI_TIMING)
+    sim.tstamp = (threadIdx.x == 0 && g_mi_tstamp != nullptr) ? g_mi_tstamp + (size_t)blockIdx.x * 16 : nullptr;   // tools/debug/phase_timing_live.py
+#endif
     const float h = P.dt / (float)P.substeps;
     int nc = 0;
     sim.template substep_hand<LANES, SHAPE>(P, OP, target, h, RowStore<LANES>{lds_rows + threadIdx.x}, Strided{v.laml + e, N}, Strided{v.sensor + e, N},

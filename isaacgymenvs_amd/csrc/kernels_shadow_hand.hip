@@ -277,3 +277,9 @@ hipError_t launch_reset_shadow_hand(const View& v, const HandView& hv, const Han
 }
 
 }  // namespace mi
+
+#if defined(MI_TIMING)
+extern "C" int mi_debug_set_tstamp_hand(void* device_buffer) {   // debug builds only (tools/debug/phase_timing_live.py)
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(mi::g_mi_tstamp), &device_buffer, sizeof(void*));
+}
+#endif
