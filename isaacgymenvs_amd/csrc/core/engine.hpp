@@ -681,18 +681,22 @@ struct Sim {
     // gnd: ground policy; mu_env >= 0 replaces the per-sphere model friction (per-env friction buckets of
     // anymal_terrain.py:236-239,279-281); netf: per-body net contact force [3*NB] (world, this sub-step), written only on
     // height fields (gym.acquire_net_contact_force_tensor, anymal_terrain.py:119)
-    // role / bar: the sub-step of a self-colliding robot on TWO waves of one workgroup that share the row store.  role -1: one wave
-    // does everything (bar unused).  role 1, the helper: tree pass and factorisation like the main wave, then ONLY the self-collision
-    // phase (broad + narrow phase, rows into the self-contact slots), publishes its bookkeeping at C_X, meets the main wave at
-    // bar() and is done.  role 0, the main wave: everything except that phase; it meets the helper at bar() after its own ground
-    // rows and picks the bookkeeping up.  Both waves compute bit-identical L, S, sphere centres (same code, same inputs).
+    // role / nroles / bar: the sub-step of a self-colliding robot on TWO or THREE waves of one workgroup that share the row store.
+    // role -1: one wave does everything (bar unused).  role 1, the self-collision helper: tree pass and factorisation like the main
+    // wave, then ONLY the self-collision phase (broad + narrow phase, rows into the self-contact slots), publishes its bookkeeping
+    // at C_X, meets the others at bar() and is done.  role 2 (nroles == 3), the limit-row helper: tree pass, factorisation, the
+    // joint-limit rows (it stages their warm-start impulses itself), bar(), done.  role 0, the main wave: everything the helpers do
+    // not do; it meets them at bar() after its ground rows and picks the bookkeeping up.  All waves compute bit-identical L, S,
+    // sphere centres (same code, same inputs), and write disjoint parts of the store.
     struct NoBarrier { MI_HD void operator()() const {} };
     template <int RS, class GND, class BAR = NoBarrier>
     MI_HD void substep(const SimParams& P, const float* tau, const float h, const RowStore<RS> rows, const Strided lamc,
                        const Strided laml, const Strided sensor, const Strided dof_force, const GND& gnd, const float mu_env,
                        const Strided netf, const Drive* drv = nullptr, const bool prestaged = false, const SelfCol* scol = nullptr,
-                       const int role = -1, const BAR& bar = BAR{}) {
-        const bool helper = (role == 1), not_helper = (role != 1);
+                       const int role = -1, const BAR& bar = BAR{}, const int nroles = 2) {
+        const bool main_wave = role <= 0;                                   // right-hand side, w, ground rows, everything after the barrier
+        const bool do_limits = role < 0 || role == (nroles == 3 ? 2 : 0);   // who builds the joint-limit rows
+        const bool do_pairs = role < 0 || role == 1;
         auto slot8 = [&](const RowStore<RS>& r, int s) MI_LAMBDA -> signed char& { return reinterpret_cast<signed char*>(r.ptr(C_SLOTOF + (s >> 2)))[s & 3]; };
         // static store: row r at r*MAXCHAIN; compact store: only the limit rows (r < NLIM) live at fixed, tightly packed places
         auto G = [&](int row, int c) MI_LAMBDA -> float& { return rows(COMPACT ? limoff(row) + c : row * M::MAXCHAIN + c); };
@@ -710,12 +714,12 @@ struct Sim {
         // compact store: contact impulses are parked at the END of the (still empty) contact-slot region, sphere 0 last: slots
         // fill from the front and sphere s is read before any slot > s can be written
         if constexpr (STAGES_LAM) {
-            if (!prestaged && not_helper) {
-                sfor<ND>([&](auto D) MI_LAMBDA {
+            if (!prestaged) {     // (a kernel that prestages does it for exactly the rows this wave owns)
+                if (do_limits) sfor<ND>([&](auto D) MI_LAMBDA {
                     constexpr int d = D;
                     if constexpr (M::dof_limited[d]) rows(stage_slot_lim(d)) = laml(d);
                 });
-                sfor<3 * NSPH>([&](auto K) MI_LAMBDA { rows(stage_slot_con(K)) = lamc(K); });
+                if (main_wave) sfor<3 * NSPH>([&](auto K) MI_LAMBDA { rows(stage_slot_con(K)) = lamc(K); });
             }
         }
         MI_STAMP(1);
@@ -805,7 +809,7 @@ struct Sim {
         MI_PHASE();
         // ------------------------------------------------------------ whitened velocity  w = L qd + h L^-T rhs
         float w[NVA];
-        if (not_helper) {
+        if (main_wave) {
             float v[NVA];
             if constexpr (!M::FIXED) {
                 v[0] = root[7]; v[1] = root[8]; v[2] = root[9]; v[3] = root[10]; v[4] = root[11]; v[5] = root[12];
@@ -876,7 +880,7 @@ struct Sim {
             });
         };
         // limits: one speculative row per limited dof (nearest bound), chain = dof + its ancestors
-        if (not_helper) sfor<ND>([&](auto D) MI_LAMBDA {
+        if (do_limits) sfor<ND>([&](auto D) MI_LAMBDA {
             constexpr int d = D, gi = OFF + d;
             if constexpr (M::dof_limited[d]) {
                 constexpr int row = limrow(d);
@@ -1002,7 +1006,7 @@ struct Sim {
         // KMAX); the three rows are only built -- by the lanes that need them -- when some env of the wave has the
         // sphere active (EXEC-masked region, skipped by the whole wave otherwise)
         int cnt = 0;
-        if (not_helper) sfor<NSPH>([&](auto S_) MI_LAMBDA {
+        if (main_wave) sfor<NSPH>([&](auto S_) MI_LAMBDA {
             constexpr int s = S_, b = M::sph_body[s];
             MI_PHASE();
             const float* cs = c.xcs[s];
@@ -1079,7 +1083,7 @@ struct Sim {
         // the env's deepest pair happens to join, so it is read from the per-lane chain masks instead of being unrolled per body pair
         // (13 row-build code paths for the Humanoid instead of 66).
         MI_STAMP(9);      // (debug stamps: 4 .. 9 = ground contact rows, 9 .. 5 = self-collision phase)
-        if constexpr (NPG > 0) { if (selfcol && role != 0) {
+        if constexpr (NPG > 0) { if (selfcol && do_pairs) {
         int cntp = 0;
         // broad phase: bounding sphere of every capsule (centre = middle of its axis, radius = half length + capsule radius); the
         // narrow phase of a capsule pair is skipped by the whole wave when no env has the two spheres within reach
@@ -1204,8 +1208,8 @@ struct Sim {
         if constexpr (NPG > 0) {
             // two waves: the helper hands its bookkeeping over through the row store and is done; the main wave waits for it here,
             // with its own limit and ground rows already built
-            if (helper) {
-                if (selfcol) {
+            if (role >= 1) {
+                if (selfcol && role == 1) {
                     rows(C_X) = __builtin_bit_cast(float, pmap);
                     sfor<KPAIR>([&](auto J_) MI_LAMBDA { sfor<8>([&](auto I_) MI_LAMBDA { rows(C_X + 1 + 8 * J_ + I_) = pinf[J_][I_]; }); });
                 }

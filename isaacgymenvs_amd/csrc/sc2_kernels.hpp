@@ -14,8 +14,9 @@
 
 namespace mi {
 
-template <class M>
-__global__ __launch_bounds__(128) void substep_sc2_kernel(View v, SimParams P, ActParams ap, const float* __restrict__ actions_in, int src) {
+// NR = 2: main + self-collision helper; NR = 3: + a third wave that builds the joint-limit rows
+template <class M, int NR>
+__global__ __launch_bounds__(64 * NR) void substep_sc2_kernel(View v, SimParams P, ActParams ap, const float* __restrict__ actions_in, int src) {
     extern __shared__ float lds_rows[];  // [ROW_SLOTS][LANES], shared by the two waves
     using S = Sim<M>;
     constexpr int LANES = S::LANES;
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(128) void substep_sc2_kernel(View v, SimParams P, A
     float tau[M::NDA];
     if (role == 0) {
         efforts_for_substep<M>(v, ap, actions_in, src, e, sim, tau);
-        prestage_warm_start<M>(v, e, lds_rows);
+        prestage_warm_start<M, NR == 2>(v, e, lds_rows);       // with three waves the limit-row helper stages its own impulses
     } else {
         sfor<M::ND>([&](auto K) MI_LAMBDA { tau[K] = 0.f; });   // the helper never looks at the right-hand side
     }
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(128) void substep_sc2_kernel(View v, SimParams P, A
     const float mu_env = (v.friction != nullptr) ? v.friction[e] : -1.f;
     const SelfCol selfcol{Strided{v.lamp + e, N}, Strided{v.pairf ? v.pairf + e : nullptr, N}};
     sim.substep(P, tau, h, RowStore<LANES>{lds_rows + lane}, lamc, laml, sensor, dof_force, PlaneGround{}, mu_env, Strided{nullptr, N}, nullptr,
-                true, &selfcol, role, DevBarrier{});
+                role != 2, &selfcol, role, DevBarrier{}, NR);
     if (role == 0) store_sim(sim, v, e);
 }
 
@@ -48,10 +49,13 @@ hipError_t launch_substeps_sc2(const View& v, const SimParams& P, const ActParam
                                hipStream_t s) {
     constexpr size_t lds = lds_bytes<M>();
     constexpr int LANES = Sim<M>::LANES;
+    // NR = 3 (a third wave for the joint-limit rows, Sim::substep role 2) was measured and is not instantiated: Humanoid@8192 0.444 ms
+    // per step against 0.412 ms with two waves (one wave: 0.521 ms) -- three waves of this kernel on one CU cost each other more than the
+    // 16 us of limit rows they take off the main wave.  The role logic stays (host-tested for 2 and 3 threads, tests/test_self_collision.py).
     static unsigned long long configured = 0ull;
-    if (hipError_t e = ensure_dynamic_lds((const void*)substep_sc2_kernel<M>, lds, &configured); e != hipSuccess) return e;
+    if (hipError_t e = ensure_dynamic_lds((const void*)substep_sc2_kernel<M, 2>, lds, &configured); e != hipSuccess) return e;
     for (int i = 0; i < n_sub; ++i)
-        hipLaunchKernelGGL((substep_sc2_kernel<M>), dim3(xcd_grid<LANES>(v.N)), dim3(64, 2), lds, s, v, P, ap, actions, i == 0 ? first : rest);
+        hipLaunchKernelGGL((substep_sc2_kernel<M, 2>), dim3(xcd_grid<LANES>(v.N)), dim3(64, 2), lds, s, v, P, ap, actions, i == 0 ? first : rest);
     return hipGetLastError();
 }
 

@@ -163,14 +163,14 @@ __device__ __forceinline__ void efforts_for_substep(const View& v, const ActPara
 // Last sub-step's impulses go from HBM straight into their row-store slots with LDS-direct loads (global_load_lds_dword:
 // lane l of the wave lands at slot base + 4 l, exactly the [slot][lane] layout): no VGPR holds them in flight, so the ~50
 // (Ant) / ~130 (Humanoid) loads no longer push that many live values out of the register file at the top of the kernel.
-template <class M>
+template <class M, bool LIMITS = true>
 __device__ __forceinline__ void prestage_warm_start(const View& v, const int e, float* lds_rows) {
     using S = Sim<M>;
     constexpr int LANES = S::LANES;
     const int N = v.N;
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
-    sfor<M::ND>([&](auto D) MI_LAMBDA {
+    if constexpr (LIMITS) sfor<M::ND>([&](auto D) MI_LAMBDA {
         constexpr int d = D;
         if constexpr (M::dof_limited[d])
             __builtin_amdgcn_global_load_lds((gptr_t)(v.laml + (size_t)d * N + e), (lptr_t)(lds_rows + S::stage_slot_lim(d) * LANES), 4, 0, 0);

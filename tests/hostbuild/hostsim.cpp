@@ -129,7 +129,7 @@ extern "C" int hs_step_selfcol(const SimParams* P, int nenv, float* state, const
 // the self-colliding sub-step on TWO waves (Sim::substep role 0 / 1): two threads per env share the row store and meet at a pthread
 // barrier where the GPU waves meet at s_barrier.  Same state / out layout as hs_step_selfcol.
 template <int ROLE>
-static void sc2_thread(const SimParams* P, float* s, const float* tau, float* o, float* rows, float* pf, pthread_barrier_t* bar) {
+static void sc2_thread(const SimParams* P, float* s, const float* tau, float* o, float* rows, float* pf, pthread_barrier_t* bar, int nroles) {
     using M = ModelHumanoid;
     constexpr int ND = M::ND, NSPH = M::NSPH, NSENS = M::NSENS;
     const float h = P->dt / (float)P->substeps;
@@ -140,7 +140,7 @@ static void sc2_thread(const SimParams* P, float* s, const float* tau, float* o,
         pthread_barrier_wait(bar);     // both have read the state of the previous sub-step
         const SelfCol sc{Strided{s + 13 + 3 * ND + 3 * NSPH, 1}, Strided{pf, 1}};
         sim.substep(*P, tau, h, RowStore<1>{rows}, Strided{s + 13 + 2 * ND, 1}, Strided{s + 13 + 2 * ND + 3 * NSPH, 1}, Strided{o, 1},
-                    Strided{o + 6 * NSENS, 1}, PlaneGround{}, -1.f, Strided{nullptr, 1}, nullptr, false, &sc, ROLE, HostBarrier{bar});
+                    Strided{o + 6 * NSENS, 1}, PlaneGround{}, -1.f, Strided{nullptr, 1}, nullptr, false, &sc, ROLE, HostBarrier{bar}, nroles);
         if (ROLE == 0) {
             for (int k = 0; k < 13; ++k) s[k] = sim.root[k];
             for (int k = 0; k < ND; ++k) { s[13 + k] = sim.q[k]; s[13 + ND + k] = sim.qd[k]; }
@@ -148,7 +148,10 @@ static void sc2_thread(const SimParams* P, float* s, const float* tau, float* o,
         pthread_barrier_wait(bar);     // the new state is complete
     }
 }
-extern "C" int hs_step_selfcol2(const SimParams* P, int nenv, float* state, const float* tau, float* out) {
+static int step_selfcol_waves(const SimParams* P, int nenv, float* state, const float* tau, float* out, int nroles);
+extern "C" int hs_step_selfcol2(const SimParams* P, int nenv, float* state, const float* tau, float* out) { return step_selfcol_waves(P, nenv, state, tau, out, 2); }
+extern "C" int hs_step_selfcol3(const SimParams* P, int nenv, float* state, const float* tau, float* out) { return step_selfcol_waves(P, nenv, state, tau, out, 3); }
+static int step_selfcol_waves(const SimParams* P, int nenv, float* state, const float* tau, float* out, int nroles) {
     using M = ModelHumanoid;
     constexpr int ND = M::ND, NSPH = M::NSPH, NSENS = M::NSENS, NPG = Sim<M>::NPG;
     const int ss = 13 + 2 * ND + 3 * NSPH + ND + 3 * NPG, os = 6 * NSENS + ND + 3 * NSPH + 9 * NPG;
@@ -159,8 +162,9 @@ extern "C" int hs_step_selfcol2(const SimParams* P, int nenv, float* state, cons
         float pf[3 * NPG];
         for (int k = 0; k < Sim<M>::ROW_SLOTS; ++k) rows[k] = 0.f;
         pthread_barrier_t bar;
-        pthread_barrier_init(&bar, nullptr, 2);
-        std::thread t0(sc2_thread<0>, P, s, tau + (size_t)e * ND, o, rows, pf, &bar), t1(sc2_thread<1>, P, s, tau + (size_t)e * ND, o, rows, pf, &bar);
+        pthread_barrier_init(&bar, nullptr, nroles);
+        std::thread t0(sc2_thread<0>, P, s, tau + (size_t)e * ND, o, rows, pf, &bar, nroles), t1(sc2_thread<1>, P, s, tau + (size_t)e * ND, o, rows, pf, &bar, nroles);
+        if (nroles == 3) { std::thread t2(sc2_thread<2>, P, s, tau + (size_t)e * ND, o, rows, pf, &bar, nroles); t2.join(); }
         t0.join(); t1.join();
         pthread_barrier_destroy(&bar);
         for (int g = 0; g < NPG; ++g) for (int k = 0; k < 3; ++k) o[6 * NSENS + ND + 3 * NSPH + 9 * g + k] = pf[3 * g + k];

@@ -31,7 +31,7 @@ def make_params(d):
 _MODELS = {"cartpole": ("HOSTSIM_CARTPOLE", "-O2"), "ant": ("HOSTSIM_ANT", "-O2"), "anymal": ("HOSTSIM_ANYMAL", "-O2"),
            "quadcopter": ("HOSTSIM_QUADCOPTER", "-O2"), "humanoid": ("HOSTSIM_HUMANOID", "-O2"), "hand": ("HOSTSIM_HAND", "-O1"),
            "bbot": ("HOSTSIM_BBOT", "-O2")}
-_ENTRY_MODEL = {"hs_step_mw_ant": "ant", "hs_step_mw_terrain": "anymal", "hs_step_selfcol": "humanoid", "hs_step_selfcol2": "humanoid", "hs_step_terrain": "anymal", "hs_step_drive": "quadcopter", "hs_step_hand": "hand", "hs_hand_fingertips": "hand", "hs_step_bbot": "bbot"}
+_ENTRY_MODEL = {"hs_step_mw_ant": "ant", "hs_step_mw_terrain": "anymal", "hs_step_selfcol": "humanoid", "hs_step_selfcol2": "humanoid", "hs_step_selfcol3": "humanoid", "hs_step_terrain": "anymal", "hs_step_drive": "quadcopter", "hs_step_hand": "hand", "hs_hand_fingertips": "hand", "hs_step_bbot": "bbot"}
 _libs = {}
 
 
@@ -119,10 +119,11 @@ def step_selfcol(lib, params, state, tau, out):
     assert rc == 0
 
 
-def step_selfcol2(lib, params, state, tau, out):
-    """The same sub-step on two threads per env (main wave + self-collision helper wave, Sim::substep role 0 / 1)."""
-    rc = lib.hs_step_selfcol2(C.byref(params), state.shape[0], state.ctypes.data_as(C.c_void_p),
-                              tau.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+def step_selfcol2(lib, params, state, tau, out, waves=2):
+    """The same sub-step on two / three threads per env (main wave + self-collision helper [+ limit-row helper], Sim::substep roles)."""
+    fn = lib.hs_step_selfcol2 if waves == 2 else lib.hs_step_selfcol3
+    rc = fn(C.byref(params), state.shape[0], state.ctypes.data_as(C.c_void_p),
+            tau.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
     assert rc == 0
 
 

@@ -226,7 +226,8 @@ def test_host_build_of_engine_core_matches_oracle_with_self_collision():
     assert touched > 0.3 * 3 * n
 
 
-def test_two_wave_split_of_the_sub_step_is_bit_identical_on_the_host():
+@pytest.mark.parametrize("waves", [2, 3])
+def test_two_wave_split_of_the_sub_step_is_bit_identical_on_the_host(waves):
     """Sim::substep with role 0 (everything but the self-collision phase) and role 1 (tree pass, factor, self-collision phase) on two
     threads that share the row store and meet at one barrier -- what the GPU runs as two waves of a workgroup -- against the same
     sub-step on one thread: the same arithmetic on the same values, so every output bit is the same."""
@@ -246,7 +247,7 @@ def test_two_wave_split_of_the_sub_step_is_bit_identical_on_the_host():
     touched = 0
     for it in range(3):
         hostsim.step_selfcol(lib, p, st1, tau32, out1)
-        hostsim.step_selfcol2(lib, p, st2, tau32, out2)
+        hostsim.step_selfcol2(lib, p, st2, tau32, out2, waves=waves)
         np.testing.assert_array_equal(st1, st2)
         np.testing.assert_array_equal(out1, out2)
         touched += int((np.abs(st1[:, 13 + 3 * nd + 3 * nsph:]).sum(1) > 0).sum())
