@@ -16,10 +16,20 @@ from oracle.tasks import OracleAnymalTerrainEnv, OracleShadowHandEnv  # noqa: E4
 from test_gpu_parity import _sim_dict  # noqa: E402
 
 DEV = "cuda:0"
-for task, n, steps in (("AnymalTerrain", 128, 400), ("ShadowHand", 32, 250)):
-    seed = 13
+from isaacgymenvs_amd.utils.config import compose  # noqa: E402
+CASES = (("AnymalTerrain", 128, 400, 13), ("ShadowHand", 32, 250, 13), ("ShadowHand:egg", 32, 200, 13), ("ShadowHand:pen", 32, 200, 13))
+if len(sys.argv) > 1 and sys.argv[1] == "pen":      # is a gpu / oracle difference of the pen noise or bias?  other seeds, more envs
+    CASES = (("ShadowHand:pen", 48, 200, 29), ("ShadowHand:pen", 48, 200, 71), ("ShadowHand:egg", 48, 200, 29))
+for task, n, steps, seed in CASES:
+    obj = task.split(":")[1] if ":" in task else None
+    task = task.split(":")[0]
     t0 = time.time()
-    env = isaacgymenvs_amd.make(seed=seed, task=task, num_envs=n, sim_device=DEV, rl_device=DEV, headless=True)
+    cfg = None
+    if obj:
+        cfg = compose(overrides=["task=ShadowHand"])
+        cfg["task"]["env"]["numEnvs"] = n
+        cfg["task"]["env"]["objectType"] = obj
+    env = isaacgymenvs_amd.make(seed=seed, task=task, num_envs=n, sim_device=DEV, rl_device=DEV, headless=True, **({"cfg": cfg} if cfg else {}))
     if task == "AnymalTerrain":
         orc = OracleAnymalTerrainEnv(load_model("anymal"), _sim_dict(env.sim_params), env._task_params_struct, env.terrain, n, seed=seed, precision="f64")
     else:
@@ -35,6 +45,6 @@ for task, n, steps in (("AnymalTerrain", 128, 400), ("ShadowHand", 32, 250)):
         O["rew"] += float(np.mean(out[1])); O["resets"] += int(np.sum(out[2]))
         if task == "ShadowHand":
             G["nc"] += int(env.engine.tensors["object_contact_count"].sum()); O["nc"] += int(orc.eng.ncontacts.sum())
-    print(f"{task}@{n} x {steps}: mean step reward gpu {G['rew'] / steps:.4f} / oracle {O['rew'] / steps:.4f}; resets gpu {G['resets']} / oracle {O['resets']}; "
+    print(f"{task}{':' + obj if obj else ''}@{n} x {steps}: mean step reward gpu {G['rew'] / steps:.4f} / oracle {O['rew'] / steps:.4f}; resets gpu {G['resets']} / oracle {O['resets']}; "
           f"contacts gpu {G['nc']} / oracle {O['nc']}  ({time.time() - t0:.0f} s)", flush=True)
     del env
