@@ -40,6 +40,7 @@ struct View {
     // ---- actors that collide with themselves (Humanoid, reference humanoid.py:194); null otherwise / when switched off
     float* lamp;        // [3*NPG][N] warm-start impulses of the self-contact groups
     float* pairf;       // [3*NPG][N] world force on side a of each group's contact, last sub-step
+    int* dropped;       // [2][N] contacts refused since init because the env's slots were taken: ground (KMAX), self contacts (KPAIR); models with the compact store
     float* ep_ret;      // [N] running return of the current episode
     float* stats;       // [8] job statistics: sum finished returns, sum finished lengths, #finished, sum rewards, #env-steps
     // ---- AnymalTerrain only (null otherwise)

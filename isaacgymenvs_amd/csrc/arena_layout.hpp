@@ -105,6 +105,7 @@ static void build_layout(int task, int N, Layout& L, View* v, char* base, int no
         const int64_t npg = ModelHumanoid::NPG;
         o = L.add("self_contact_impulse", MI_F32, {n, npg, 3}, {1, 3 * n, n}, 3 * npg * n); if (v) v->lamp = (float*)P(o);
         o = L.add("self_contact_force", MI_F32, {n, npg, 3}, {1, 3 * n, n}, 3 * npg * n); if (v) v->pairf = (float*)P(o);
+        o = L.add("contact_dropped", MI_I32, {n, 2}, {1, n}, 2 * n); if (v) v->dropped = (int*)P(o);   // refused for want of a slot: ground, self
     }
     if (task == T_ANYMAL) {   // anymal_terrain.py:117-168
         const int64_t nb = m.nb;

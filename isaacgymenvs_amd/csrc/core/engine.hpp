@@ -250,6 +250,8 @@ struct Strided {
 struct SelfCol {
     Strided lamp;          // [3 * NPG] warm-start impulses of the limb-pair groups (normal, two tangents)
     Strided pairf;         // [3 * NPG] world force on side a of each group's contact, this sub-step (p == nullptr: not wanted)
+    int* dropped = nullptr;      // [2] running counts of contacts refused because the env's slots were taken: ground (KMAX), self (KPAIR); or null
+    int dstride = 1;
 };
 
 // closest points ca, cb of the segments [a0,a1], [b0,b1] (capsule axes; A_PT / B_PT: that side is a sphere, i.e. a point).  Clamped
@@ -1005,7 +1007,7 @@ struct Sim {
         // ground contacts, compact store: a sphere within contact_offset takes the next free slot of its env (at most
         // KMAX); the three rows are only built -- by the lanes that need them -- when some env of the wave has the
         // sphere active (EXEC-masked region, skipped by the whole wave otherwise)
-        int cnt = 0;
+        int cnt = 0, ndrop = 0;
         if (main_wave) sfor<NSPH>([&](auto S_) MI_LAMBDA {
             constexpr int s = S_, b = M::sph_body[s];
             MI_PHASE();
@@ -1023,6 +1025,7 @@ struct Sim {
                 dist = (root[2] + xc[2]) - P.ground_z;
             }
             const bool on = (dist < P.contact_offset) && (cnt < KMAX);
+            ndrop += ((dist < P.contact_offset) && (cnt >= KMAX)) ? 1 : 0;
             const int j = on ? cnt : -1;
             // the parked warm-start impulses of this sphere must be read before its slot (possibly) overwrites them
             float lprev[3];
@@ -1083,8 +1086,9 @@ struct Sim {
         // the env's deepest pair happens to join, so it is read from the per-lane chain masks instead of being unrolled per body pair
         // (13 row-build code paths for the Humanoid instead of 66).
         MI_STAMP(9);      // (debug stamps: 4 .. 9 = ground contact rows, 9 .. 5 = self-collision phase)
+        if (scol != nullptr && scol->dropped != nullptr && main_wave && ndrop > 0) scol->dropped[0] += ndrop;
         if constexpr (NPG > 0) { if (selfcol && do_pairs) {
-        int cntp = 0;
+        int cntp = 0, pdrop = 0;
         // broad phase: bounding sphere of every capsule (centre = middle of its axis, radius = half length + capsule radius); the
         // narrow phase of a capsule pair is skipped by the whole wave when no env has the two spheres within reach
         float capm[M::NCAP][3];
@@ -1114,6 +1118,7 @@ struct Sim {
                 bk = better ? K_ : bk;
             });
             const bool on = (best < P.contact_offset) && (cntp < KPAIR);
+            pdrop += ((best < P.contact_offset) && (cntp >= KPAIR)) ? 1 : 0;
             if (MI_WAVE_ANY(on)) {
                 if (on) {
                     // what the chosen pair implies (bodies, chain masks, radius of side b, friction): looked up by its index
@@ -1204,6 +1209,7 @@ struct Sim {
             pmap = (pmap & ~(3u << (2 * g))) | ((unsigned)(on ? cntp : 3) << (2 * g));
             cntp += on ? 1 : 0;
         });
+        if (scol->dropped != nullptr && pdrop > 0) scol->dropped[scol->dstride] += pdrop;
         } }
         if constexpr (NPG > 0) {
             // two waves: the helper hands its bookkeeping over through the row store and is done; the main wave waits for it here,

@@ -158,6 +158,7 @@ extern "C" int mi_engine_init_state(MiEngine* e, void*) {
         }
         for (int k = 0; k < 3 * m.nsph; ++k) v.lamc[k * N + en] = 0.f;
         if (v.lamp) for (int k = 0; k < 3 * ModelHumanoid::NPG; ++k) { v.lamp[k * N + en] = 0.f; v.pairf[k * N + en] = 0.f; }
+        if (v.dropped) { v.dropped[en] = 0; v.dropped[N + en] = 0; }
         for (int k = 0; k < 6 * m.nsens; ++k) v.sensor[k * N + en] = 0.f;
         for (int k = 0; k < m.nact; ++k) v.actions[k * N + en] = 0.f;
         for (int k = 0; k < m.nobs; ++k) { v.obs[(size_t)en * m.nobs + k] = 0.f; v.obs_out[(size_t)en * m.nobs + k] = 0.f; v.obs_out[((size_t)N + en) * m.nobs + k] = 0.f; }
@@ -199,7 +200,7 @@ static void simulate_env(const View& v, const SimParams& P, int en, const float*
     }
     const float h = P.dt / (float)P.substeps;
     float rows[Sim<M>::ROW_SLOTS > 0 ? Sim<M>::ROW_SLOTS : 1];
-    const SelfCol sc{Strided{v.lamp ? v.lamp + en : nullptr, N}, Strided{v.pairf ? v.pairf + en : nullptr, N}};
+    const SelfCol sc{Strided{v.lamp ? v.lamp + en : nullptr, N}, Strided{v.pairf ? v.pairf + en : nullptr, N}, v.dropped ? v.dropped + en : nullptr, N};
     const float mu_env = v.friction ? v.friction[en] : -1.f;
     for (int ss = 0; ss < P.substeps; ++ss)
         sim.substep(P, tau, h, RowStore<1>{rows}, Strided{v.lamc + en, N}, Strided{v.laml + en, N}, Strided{v.sensor + en, N},

@@ -58,6 +58,7 @@ __global__ void init_state_kernel(View v, int nd, int nsph3, int nsens6, int nob
     }
     for (int k = 0; k < nsph3; ++k) v.lamc[k * N + e] = 0.f;
     if (v.lamp) for (int k = 0; k < 3 * ModelHumanoid::NPG; ++k) { v.lamp[k * N + e] = 0.f; v.pairf[k * N + e] = 0.f; }
+    if (v.dropped) { v.dropped[e] = 0; v.dropped[N + e] = 0; }
     for (int k = 0; k < nsens6; ++k) v.sensor[k * N + e] = 0.f;
     for (int k = 0; k < nact; ++k) v.actions[k * N + e] = 0.f;
     for (int k = 0; k < nobs; ++k) { v.obs[(size_t)e * nobs + k] = 0.f; v.obs_out[(size_t)e * nobs + k] = 0.f; v.obs_out[((size_t)N + e) * nobs + k] = 0.f; }

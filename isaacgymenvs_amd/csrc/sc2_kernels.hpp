@@ -38,7 +38,7 @@ __global__ __launch_bounds__(64 * NR) void substep_sc2_kernel(View v, SimParams 
     const float h = P.dt / (float)P.substeps;
     const Strided lamc{v.lamc + e, N}, laml{v.laml + e, N}, sensor{v.sensor + e, N}, dof_force{v.dof_force + e, N};
     const float mu_env = (v.friction != nullptr) ? v.friction[e] : -1.f;
-    const SelfCol selfcol{Strided{v.lamp + e, N}, Strided{v.pairf ? v.pairf + e : nullptr, N}};
+    const SelfCol selfcol{Strided{v.lamp + e, N}, Strided{v.pairf ? v.pairf + e : nullptr, N}, v.dropped ? v.dropped + e : nullptr, N};
     sim.substep(P, tau, h, RowStore<LANES>{lds_rows + lane}, lamc, laml, sensor, dof_force, PlaneGround{}, mu_env, Strided{nullptr, N}, nullptr,
                 role != 2, &selfcol, role, DevBarrier{}, NR);
     if (role == 0) store_sim(sim, v, e);

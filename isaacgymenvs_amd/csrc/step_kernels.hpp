@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64) void substep_kernel(View v, SimParams P, ActPar
     const Strided lamc{v.lamc + e, N}, laml{v.laml + e, N}, sensor{v.sensor + e, N}, dof_force{v.dof_force + e, N};
     const Strided netf{GND::NETF ? v.netf + e : nullptr, N};
     const float mu_env = (GND::HEIGHTFIELD || v.friction != nullptr) ? v.friction[e] : -1.f;   // per-env shape friction where the task has the tensor
-    const SelfCol selfcol{Strided{v.lamp ? v.lamp + e : nullptr, N}, Strided{v.pairf ? v.pairf + e : nullptr, N}};
+    const SelfCol selfcol{Strided{v.lamp ? v.lamp + e : nullptr, N}, Strided{v.pairf ? v.pairf + e : nullptr, N}, v.dropped ? v.dropped + e : nullptr, N};
     const SelfCol* scp = (Sim<M>::NPG > 0 && v.lamp != nullptr) ? &selfcol : nullptr;   // uniform
     if constexpr (rows_fit_lds<M>()) {
         if constexpr (LANES == 64) sim.substep(P, tau, h, RowStore<64>(lds_rows + threadIdx.x), lamc, laml, sensor, dof_force, gnd, mu_env, netf, nullptr, PRESTAGE, scp);

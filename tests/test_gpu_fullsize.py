@@ -86,6 +86,21 @@ def test_anymal_terrain_first_steps_at_the_benchmark_size():
     assert np.abs(orc.eng.netf).max() > 50.0
 
 
+def test_humanoid_contact_slots_suffice_at_the_benchmark_size():
+    """Humanoid@8192 under the random policy of the benchmark: 12 ground + 3 self-contact slots per env (csrc/core/engine.hpp KMAX / KPAIR);
+    `contact_dropped` counts what was refused for want of a slot -- ground contacts never, self contacts in about one env-step per thousand
+    (profiles/r2_contact_counts.txt measured the same in the oracle)."""
+    env = _make_env("Humanoid", 8192, seed=42)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    steps = 200
+    for _ in range(steps):
+        env.step(torch.rand((8192, 21), device=DEV, generator=g) * 2 - 1)
+    d = env.engine.tensors["contact_dropped"]
+    assert int(d[:, 0].sum()) == 0
+    assert int(d[:, 1].sum()) < 0.005 * 8192 * steps * 2, int(d[:, 1].sum())
+    assert int((env.engine.tensors["self_contact_impulse"].abs().sum(2) > 0).sum()) > 0      # self contacts do occur
+
+
 def test_shadow_hand_contact_slots_suffice_at_the_benchmark_size():
     """ShadowHand@16384 under the random policy of the benchmark: with the per-body manifold cap the 12 contact slots per env (KMAX,
     csrc/core/hand_engine.hpp) are rarely all taken -- `object_contact_dropped` counts the contacts refused for want of a slot."""
