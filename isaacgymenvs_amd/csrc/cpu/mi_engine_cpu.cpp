@@ -8,7 +8,8 @@
 // same counter-based reset RNG: the Python side sees identical tensors and, up to fp32 summation order in the episode statistics,
 // identical numbers on both devices.
 //
-// Tasks: Cartpole, Ant, Humanoid (self-collision included).  The other tasks exist on the MI355X only: mi_engine_create says so.
+// Tasks: Cartpole, Ant, Humanoid (self-collision included), Quadcopter, Ingenuity, BallBalance.  AnymalTerrain / Anymal / ShadowHand exist
+// on the MI355X only: mi_engine_create says so.
 // Build: g++ -O2 -fopenmp -shared (isaacgymenvs_amd/native.py::build_cpu); libmi_engine_cpu.so exports the lifecycle subset.
 #include <omp.h>
 
@@ -20,13 +21,18 @@
 #include <vector>
 
 #include "../core/engine.hpp"
+#include "../core/bbot_engine.hpp"
 #include "../arena_layout.hpp"
+#include "../task_views.hpp"
 
 using namespace mi;
 
 static_assert(sizeof(MiSimParams) == sizeof(SimParams), "MiSimParams layout");
 static_assert(sizeof(MiLocoParams) == sizeof(LocoParams), "MiLocoParams layout");
 static_assert(sizeof(MiCartpoleParams) == sizeof(CartpoleParams), "MiCartpoleParams layout");
+static_assert(sizeof(MiQuadcopterParams) == sizeof(QuadcopterParams), "MiQuadcopterParams layout");
+static_assert(sizeof(MiIngenuityParams) == sizeof(IngenuityParams), "MiIngenuityParams layout");
+static_assert(sizeof(MiBallBalanceParams) == sizeof(BallBalanceParams), "MiBallBalanceParams layout");
 
 static thread_local std::string g_err;
 static int fail(const std::string& m) { g_err = m; return -1; }
@@ -38,6 +44,12 @@ struct MiEngine {
     SimParams P;
     LocoParams loco;
     CartpoleParams cart;
+    QuadcopterParams quad;
+    IngenuityParams ing;
+    BallBalanceParams bbot;
+    QuadView qv;
+    IngenuityView iv;
+    BbotView bv;
     View v;
     float clip_obs;
     int control_freq_inv, num_threads;
@@ -46,7 +58,12 @@ struct MiEngine {
     float* lamp_arena;
 };
 
-static bool cpu_task(int t) { return t == T_CARTPOLE || t == T_ANT || t == T_HUMANOID; }
+static bool cpu_task(int t) { return t == T_CARTPOLE || t == T_ANT || t == T_HUMANOID || t == T_QUADCOPTER || t == T_INGENUITY || t == T_BALLBALANCE; }
+static void build_task_extras(int t, int n, Layout& L, MiEngine* e, char* base) {
+    if (t == T_QUADCOPTER) build_quad_layout(n, L, e ? &e->qv : nullptr, base);
+    if (t == T_INGENUITY) build_ingenuity_layout(n, L, e ? &e->iv : nullptr, base);
+    if (t == T_BALLBALANCE) build_bbot_layout(n, L, e ? &e->bv : nullptr, base);
+}
 
 extern "C" int mi_task_info(const char* task, MiTaskInfo* out) {
     const int t = task ? find_task(task) : -1;
@@ -61,6 +78,7 @@ extern "C" size_t mi_engine_arena_bytes(const char* task, int num_envs) {
     if (t < 0 || num_envs <= 0 || !cpu_task(t)) { fail("mi_engine_arena_bytes: task not available on the CPU backend"); return 0; }
     Layout L;
     build_layout(t, num_envs, L, nullptr, nullptr);
+    build_task_extras(t, num_envs, L, nullptr, nullptr);
     return L.off;
 }
 extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const void* task_params, size_t task_params_bytes, int num_envs,
@@ -68,7 +86,7 @@ extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const 
     if (!task || !sim || !task_params || !arena || !out) return fail("mi_engine_create: null argument");
     const int t = find_task(task);
     if (t < 0) return fail(std::string("unknown task: ") + task);
-    if (!cpu_task(t)) return fail(std::string("task ") + task + " runs on the MI355X only (CPU backend: Cartpole, Ant, Humanoid)");
+    if (!cpu_task(t)) return fail(std::string("task ") + task + " runs on the MI355X only (CPU backend: Cartpole, Ant, Humanoid, Quadcopter, Ingenuity, BallBalance)");
     if (task_params_bytes != kTasks[t].pbytes) return fail("mi_engine_create: task_params size mismatch");
     if (num_envs <= 0) return fail("mi_engine_create: num_envs <= 0");
     if (sim->substeps < 1 || sim->dt <= 0.f) return fail("mi_engine_create: invalid sim params");
@@ -77,10 +95,20 @@ extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const 
     e->task = t; e->N = num_envs; e->steps = 0; e->control_freq_inv = 1; e->clip_obs = INFINITY; e->num_threads = 4;   // cfg/config.yaml:30
     memcpy(&e->P, sim, sizeof(SimParams));
     if (t == T_CARTPOLE) memcpy(&e->cart, task_params, sizeof(CartpoleParams));
+    else if (t == T_QUADCOPTER) memcpy(&e->quad, task_params, sizeof(QuadcopterParams));
+    else if (t == T_INGENUITY) memcpy(&e->ing, task_params, sizeof(IngenuityParams));
+    else if (t == T_BALLBALANCE) memcpy(&e->bbot, task_params, sizeof(BallBalanceParams));
     else memcpy(&e->loco, task_params, sizeof(LocoParams));
+    if (t == T_INGENUITY && e->ing.target_period < 1) { delete e; return fail("mi_engine_create: Ingenuity target_period must be positive"); }
+    if (t == T_BALLBALANCE && !(e->bbot.ball_mass > 0.f && e->bbot.ball_inertia > 0.f && e->bbot.ball_radius > 0.f && e->bbot.pin_stiffness + e->bbot.pin_damping > 0.f)) {
+        delete e;
+        return fail("mi_engine_create: BallBalance needs positive ball mass / inertia / radius and a non-zero attractor");
+    }
     memset(&e->v, 0, sizeof(View));
+    memset(&e->qv, 0, sizeof(e->qv)); memset(&e->iv, 0, sizeof(e->iv)); memset(&e->bv, 0, sizeof(e->bv));
     Layout L;
     build_layout(t, num_envs, L, &e->v, (char*)arena);
+    build_task_extras(t, num_envs, L, e, (char*)arena);
     if (arena_bytes < L.off) { delete e; return fail("mi_engine_create: arena too small"); }
     e->descs = L.d;
     e->lamp_arena = e->v.lamp;
@@ -146,13 +174,15 @@ extern "C" int mi_engine_init_state(MiEngine* e, void*) {
     const TaskMeta& m = kTasks[e->task];
     const View& v = e->v;
     const int N = v.N, nd = m.nd;
-    const float root_z = e->task == T_CARTPOLE ? 2.0f : e->loco.start_height;               // cartpole.py:93 / ant.py:164
-    const float pot0 = e->task == T_CARTPOLE ? 0.f : -1000.f / e->loco.dt;                  // ant.py:113
+    const bool loco = e->task == T_ANT || e->task == T_HUMANOID;
+    const float root_z = e->task == T_CARTPOLE ? 2.0f : e->task == T_QUADCOPTER ? e->quad.init_height : e->task == T_INGENUITY ? e->ing.init_height
+                       : e->task == T_BALLBALANCE ? e->bbot.tray_height : e->loco.start_height;      // cartpole.py:93 / ant.py:164 / the tasks' default poses
+    const float pot0 = loco ? -1000.f / e->loco.dt : 0.f;                                   // ant.py:113
     const float root[13] = {0, 0, root_z, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0};
     for (int en = 0; en < N; ++en) {
         for (int k = 0; k < 13; ++k) { v.root[k * N + en] = root[k]; v.init_root[k * N + en] = root[k]; }
         for (int k = 0; k < nd; ++k) {
-            v.dof[k * N + en] = e->task == T_CARTPOLE ? 0.f : e->loco.initial_dof_pos[k];
+            v.dof[k * N + en] = loco ? e->loco.initial_dof_pos[k] : 0.f;
             v.dof[(nd + k) * N + en] = 0.f;
             v.tau[k * N + en] = 0.f; v.laml[k * N + en] = 0.f; v.dof_force[k * N + en] = 0.f;
         }
@@ -172,6 +202,23 @@ extern "C" int mi_engine_init_state(MiEngine* e, void*) {
         v.ep_ret[en] = 0.f;
     }
     for (int k = 0; k < 8; ++k) v.stats[k] = 0.f;
+    for (int en = 0; en < N; ++en) {      // the tasks' own tensors (quad_init_kernel / ing_init_kernel / bbot_init_kernel)
+        if (e->task == T_QUADCOPTER) {
+            for (int d = 0; d < kQuadDof; ++d) e->qv.targets[d * N + en] = 0.f;
+            for (int k = 0; k < kQuadRotors; ++k) e->qv.thrusts[k * N + en] = 0.f;
+            for (int k = 0; k < 3 * ModelQuadcopter::NB; ++k) e->qv.forces[k * N + en] = 0.f;
+        } else if (e->task == T_INGENUITY) {
+            for (int k = 0; k < 13; ++k) e->iv.marker[k * N + en] = root[k];
+            for (int k = 0; k < 3; ++k) e->iv.target[k * N + en] = (k == 2) ? 1.f : 0.f;
+            for (int k = 0; k < 3 * kIngRotors; ++k) e->iv.thrusts[k * N + en] = 0.f;
+            for (int k = 0; k < 3 * kIngBodies; ++k) e->iv.forces[k * N + en] = 0.f;
+        } else if (e->task == T_BALLBALANCE) {
+            for (int k = 0; k < 13; ++k) e->bv.ball[k * N + en] = (k < 3) ? e->bbot.ball_init_pos[k] : (k == 6 ? 1.f : 0.f);
+            for (int d = 0; d < kBbotDof; ++d) e->bv.targets[d * N + en] = 0.f;
+            for (int k = 0; k < 9; ++k) e->bv.lamp[k * N + en] = 0.f;
+            e->bv.ncontact[en] = 0;
+        }
+    }
     e->steps = 0;
     return 0;
 }
@@ -335,6 +382,227 @@ static void step_cartpole(MiEngine* e, const float* actions) {
     for (const StatAcc& a : accs) { v.stats[0] += (float)a.fin_ret; v.stats[1] += (float)a.fin_len; v.stats[2] += (float)a.fin; v.stats[3] += (float)a.r; v.stats[4] += (float)a.cnt; }
 }
 
+// ---- the small tasks: the per-env bodies of kernels_quadcopter.hip / kernels_ingenuity.hip / kernels_ball_balance.hip, one env at a time
+static inline void write_obs(const View& v, int en, const float* obs, int nobs) {
+    float* ob = v.obs + (size_t)en * nobs;
+    float* oc = v.obs_out + ((size_t)v.ring * v.N + en) * nobs;
+    for (int k = 0; k < nobs; ++k) { ob[k] = obs[k]; oc[k] = fminf(fmaxf(obs[k], -v.clip_obs), v.clip_obs); }
+}
+static inline void clamp_angular_speed(float* root, float lim) {      // asset_options.max_angular_velocity
+    const float w2 = root[10] * root[10] + root[11] * root[11] + root[12] * root[12];
+    if (w2 > lim * lim) { const float sc = lim / sqrtf(w2); root[10] *= sc; root[11] *= sc; root[12] *= sc; }
+}
+template <class M, int NR>
+static void drive_substeps(const View& v, const SimParams& P, int en, int n_sub, float kp, float kd, const float* target, const float* fs, float wmax) {
+    const int N = v.N;
+    Sim<M> sim;
+    load_env(sim, v, en);
+    float tau[M::NDA] = {0}, rows[Sim<M>::ROW_SLOTS > 0 ? Sim<M>::ROW_SLOTS : 1];
+    const Drive drv{kp, kd, target, fs};
+    const float h = P.dt / (float)P.substeps;
+    for (int ss = 0; ss < n_sub; ++ss) {
+        sim.substep(P, tau, h, RowStore<1>{rows}, Strided{v.lamc + en, N}, Strided{v.laml + en, N}, Strided{v.sensor + en, N},
+                    Strided{v.dof_force + en, N}, PlaneGround{}, -1.f, Strided{nullptr, N}, &drv);
+        clamp_angular_speed(sim.root, wmax);
+    }
+    store_env(sim, v, en);
+}
+static void quad_reset_env(MiEngine* e, int en) {
+    const View& v = e->v;
+    const int N = v.N;
+    float root[13], q[kQuadDof], qd[kQuadDof];
+    const int ep = v.episode[en];
+    quadcopter_reset(e->quad, v.seed, (uint32_t)(v.env_offset + en), (uint32_t)ep, root, q, qd);
+    for (int k = 0; k < 13; ++k) v.root[k * N + en] = root[k];
+    for (int d = 0; d < kQuadDof; ++d) { v.dof[d * N + en] = q[d]; v.dof[(kQuadDof + d) * N + en] = 0.f; v.laml[d * N + en] = 0.f; }
+    v.episode[en] = ep + 1; v.reset[en] = 0; v.progress[en] = 0;
+}
+static void step_quadcopter(MiEngine* e, const float* actions, bool simulate_only) {
+    using QM = ModelQuadcopter;
+    const View& v = e->v;
+    const QuadView& qv = e->qv;
+    const QuadcopterParams& p = e->quad;
+    const int N = v.N;
+    std::vector<StatAcc> accs(e->num_threads);
+#pragma omp parallel for schedule(static) num_threads(e->num_threads)
+    for (int en = 0; en < N; ++en) {
+        if (!simulate_only) {          // pre_physics_step (quadcopter.py:276-292)
+            const bool rs = v.reset[en] != 0;
+            if (rs) quad_reset_env(e, en);
+            for (int d = 0; d < kQuadDof; ++d) {
+                const float a = fminf(fmaxf(actions[(size_t)en * kQuadAct + d], -p.clip_actions), p.clip_actions);
+                v.actions[d * N + en] = a;
+                float t = qv.targets[d * N + en] + p.dt * p.dof_action_speed_scale * a;
+                t = fmaxf(fminf(t, p.dof_upper[d]), p.dof_lower[d]);
+                if (rs) t = v.dof[d * N + en];
+                qv.targets[d * N + en] = t;
+            }
+            for (int k = 0; k < kQuadRotors; ++k) {
+                const float a = fminf(fmaxf(actions[(size_t)en * kQuadAct + kQuadDof + k], -p.clip_actions), p.clip_actions);
+                v.actions[(kQuadDof + k) * N + en] = a;
+                float th = qv.thrusts[k * N + en] + p.dt * p.thrust_action_speed_scale * a;
+                th = fmaxf(fminf(th, p.max_thrust), 0.f);
+                qv.thrusts[k * N + en] = rs ? 0.f : th;
+                qv.forces[(3 * QM::sens_body[k] + 2) * N + en] = rs ? 0.f : th;
+            }
+        }
+        float target[kQuadDof], fs[kQuadRotors][3];
+        for (int d = 0; d < kQuadDof; ++d) target[d] = qv.targets[d * N + en];
+        for (int k = 0; k < kQuadRotors; ++k) { fs[k][0] = fs[k][1] = 0.f; fs[k][2] = qv.forces[(3 * QM::sens_body[k] + 2) * N + en]; }
+        drive_substeps<QM, kQuadRotors>(v, e->P, en, (simulate_only ? 1 : e->control_freq_inv) * e->P.substeps, p.drive_stiffness, p.drive_damping, target, &fs[0][0], p.max_angular_velocity);
+        if (simulate_only) continue;
+        float root[13], q[kQuadDof], obs[kQuadObs], rew;     // post_physics_step (:294-302)
+        for (int k = 0; k < 13; ++k) root[k] = v.root[k * N + en];
+        for (int d = 0; d < kQuadDof; ++d) q[d] = v.dof[d * N + en];
+        const long long progress = v.progress[en] + 1;
+        long long reset;
+        quadcopter_observations(root, q, obs);
+        quadcopter_reward(root, progress, p.max_episode_length, &rew, &reset);
+        episode_stats_env(v, en, rew, reset, progress, accs[omp_get_thread_num()]);
+        v.randomize[en] += 1;
+        write_obs(v, en, obs, kQuadObs);
+        v.rew[en] = rew; v.reset[en] = reset; v.progress[en] = progress;
+        v.timeout[en] = (unsigned char)(((float)progress >= p.max_episode_length - 1.f) && (reset != 0));
+    }
+    for (const StatAcc& a : accs) { v.stats[0] += (float)a.fin_ret; v.stats[1] += (float)a.fin_len; v.stats[2] += (float)a.fin; v.stats[3] += (float)a.r; v.stats[4] += (float)a.cnt; }
+}
+static void ing_set_target(MiEngine* e, int en, const float* t) {
+    const int N = e->v.N;
+    for (int k = 0; k < 3; ++k) { e->iv.target[k * N + en] = t[k]; e->iv.marker[k * N + en] = t[k] + (k == 2 ? 0.4f : 0.f); }
+}
+static void ing_reset_env(MiEngine* e, int en) {
+    const View& v = e->v;
+    const int N = v.N;
+    const uint32_t genv = (uint32_t)(v.env_offset + en);
+    const int ep = v.episode[en];
+    float root[13], target[3];
+    ingenuity_target(v.seed, genv, (uint32_t)ep, 3u, target);
+    ing_set_target(e, en, target);
+    ingenuity_reset_root(e->ing, v.seed, genv, (uint32_t)ep, root);
+    for (int k = 0; k < 13; ++k) v.root[k * N + en] = root[k];
+    v.dof[(kIngDof + 1) * N + en] = -e->ing.rotor_speed;
+    v.dof[(kIngDof + 3) * N + en] = e->ing.rotor_speed;
+    for (int d = 0; d < kIngDof; ++d) v.laml[d * N + en] = 0.f;
+    v.episode[en] = ep + 1; v.reset[en] = 0; v.progress[en] = 0;
+}
+static void step_ingenuity(MiEngine* e, const float* actions, bool simulate_only) {
+    using IM = ModelIngenuity;
+    const View& v = e->v;
+    const IngenuityView& iv = e->iv;
+    const IngenuityParams& p = e->ing;
+    const int N = v.N;
+    std::vector<StatAcc> accs(e->num_threads);
+#pragma omp parallel for schedule(static) num_threads(e->num_threads)
+    for (int en = 0; en < N; ++en) {
+        if (!simulate_only) {          // pre_physics_step (ingenuity.py:321-354)
+            const uint32_t genv = (uint32_t)(v.env_offset + en);
+            const long long progress = v.progress[en];
+            float target[3];
+            if (progress % p.target_period == 0) {
+                ingenuity_target(v.seed, genv, (uint32_t)v.episode[en], 8u + 3u * (uint32_t)(progress / p.target_period), target);
+                ing_set_target(e, en, target);
+            }
+            const bool rs = v.reset[en] != 0;
+            if (rs) ing_reset_env(e, en);
+            float a[kIngAct];
+            for (int k = 0; k < kIngAct; ++k) { a[k] = fminf(fmaxf(actions[(size_t)en * kIngAct + k], -p.clip_actions), p.clip_actions); v.actions[k * N + en] = a[k]; }
+            for (int r = 0; r < kIngRotors; ++r) {
+                const float vertical = fminf(fmaxf(a[3 * r + 2] * p.thrust_action_speed_scale, -p.thrust_upper_limit), p.thrust_upper_limit);
+                float th[3];
+                th[2] = p.dt * vertical;
+                for (int k = 0; k < 2; ++k) th[k] = th[2] * fminf(fmaxf(a[3 * r + k], -p.thrust_lateral_component), p.thrust_lateral_component);
+                for (int k = 0; k < 3; ++k) {
+                    const float x = rs ? 0.f : th[k];
+                    iv.thrusts[(3 * r + k) * N + en] = x;
+                    iv.forces[(3 * IM::sens_body[r] + k) * N + en] = x;
+                }
+            }
+        }
+        float target[kIngDof] = {0}, fs[kIngRotors][3];
+        for (int r = 0; r < kIngRotors; ++r) for (int k = 0; k < 3; ++k) fs[r][k] = iv.forces[(3 * IM::sens_body[r] + k) * N + en];
+        drive_substeps<IM, kIngRotors>(v, e->P, en, (simulate_only ? 1 : e->control_freq_inv) * e->P.substeps, 0.f, 0.f, target, &fs[0][0], p.max_angular_velocity);
+        if (simulate_only) continue;
+        float root[13], tg[3], obs[kIngObs], rew;          // post_physics_step (:356-365)
+        for (int k = 0; k < 13; ++k) root[k] = v.root[k * N + en];
+        for (int k = 0; k < 3; ++k) tg[k] = iv.target[k * N + en];
+        const long long progress = v.progress[en] + 1;
+        long long reset;
+        ingenuity_observations(root, tg, obs);
+        ingenuity_reward(root, tg, root + 3, root + 10, progress, p.max_episode_length, &rew, &reset);
+        episode_stats_env(v, en, rew, reset, progress, accs[omp_get_thread_num()]);
+        v.randomize[en] += 1;
+        write_obs(v, en, obs, kIngObs);
+        v.rew[en] = rew; v.reset[en] = reset; v.progress[en] = progress;
+        v.timeout[en] = (unsigned char)(((float)progress >= p.max_episode_length - 1.f) && (reset != 0));
+    }
+    for (const StatAcc& a : accs) { v.stats[0] += (float)a.fin_ret; v.stats[1] += (float)a.fin_len; v.stats[2] += (float)a.fin; v.stats[3] += (float)a.r; v.stats[4] += (float)a.cnt; }
+}
+static void bbot_reset_env(MiEngine* e, int en) {
+    const View& v = e->v;
+    const int N = v.N;
+    const int ep = v.episode[en];
+    float ball[13];
+    bbot_reset_ball(e->bbot, v.seed, (uint32_t)(v.env_offset + en), (uint32_t)ep, ball);
+    for (int k = 0; k < 13; ++k) { v.root[k * N + en] = v.init_root[k * N + en]; e->bv.ball[k * N + en] = ball[k]; }
+    for (int d = 0; d < kBbotDof; ++d) { v.dof[d * N + en] = 0.f; v.dof[(kBbotDof + d) * N + en] = 0.f; v.laml[d * N + en] = 0.f; }
+    for (int k = 0; k < 9; ++k) e->bv.lamp[k * N + en] = 0.f;
+    v.episode[en] = ep + 1; v.reset[en] = 0; v.progress[en] = 0;
+}
+static void step_ball_balance(MiEngine* e, const float* actions, bool simulate_only) {
+    using BM = ModelBalanceBot;
+    const View& v = e->v;
+    const BbotView& bv = e->bv;
+    const BallBalanceParams& p = e->bbot;
+    const BbotPhys& ph = *reinterpret_cast<const BbotPhys*>(&p.pin_stiffness);
+    static_assert(sizeof(BbotPhys) == sizeof(BallBalanceParams) - offsetof(BallBalanceParams, pin_stiffness), "BbotPhys is the tail of BallBalanceParams");
+    const int N = v.N;
+    std::vector<StatAcc> accs(e->num_threads);
+#pragma omp parallel for schedule(static) num_threads(e->num_threads)
+    for (int en = 0; en < N; ++en) {
+        if (!simulate_only) {          // pre_physics_step (ball_balance.py:395-413)
+            const bool rs = v.reset[en] != 0;
+            if (rs) bbot_reset_env(e, en);
+            float a[kBbotAct];
+            for (int k = 0; k < kBbotAct; ++k) { a[k] = fminf(fmaxf(actions[(size_t)en * kBbotAct + k], -p.clip_actions), p.clip_actions); v.actions[k * N + en] = a[k]; }
+            for (int d = 0; d < kBbotDof; ++d) {
+                float t = bv.targets[d * N + en];
+                if (d & 1) t += p.dt * p.action_speed_scale * a[d >> 1];
+                t = fmaxf(fminf(t, p.dof_upper[d]), p.dof_lower[d]);
+                bv.targets[d * N + en] = rs ? 0.f : t;
+            }
+        }
+        BbotSim<BM> sim;
+        load_env(sim, v, en);
+        float target[kBbotDof];
+        for (int d = 0; d < kBbotDof; ++d) target[d] = bv.targets[d * N + en];
+        for (int k = 0; k < 3; ++k) { sim.ball.pos[k] = bv.ball[k * N + en]; sim.ball.vel[k] = bv.ball[(7 + k) * N + en]; sim.ball.angvel[k] = bv.ball[(10 + k) * N + en]; }
+        for (int k = 0; k < 4; ++k) sim.ball.quat[k] = bv.ball[(3 + k) * N + en];
+        int nc = 0;
+        const int n_sub = (simulate_only ? 1 : e->control_freq_inv) * e->P.substeps;
+        for (int ss = 0; ss < n_sub; ++ss)
+            sim.substep(e->P, ph, e->P.dt / (float)e->P.substeps, target, Strided{v.laml + en, N}, Strided{bv.lamp + en, N}, Strided{v.sensor + en, N}, &nc);
+        bv.ncontact[en] = nc;
+        store_env(sim, v, en);
+        for (int k = 0; k < 3; ++k) { bv.ball[k * N + en] = sim.ball.pos[k]; bv.ball[(7 + k) * N + en] = sim.ball.vel[k]; bv.ball[(10 + k) * N + en] = sim.ball.angvel[k]; }
+        for (int k = 0; k < 4; ++k) bv.ball[(3 + k) * N + en] = sim.ball.quat[k];
+        if (simulate_only) continue;
+        float q[kBbotDof], qd[kBbotDof], ball[13], sens[18], obs[kBbotObs], rew;     // post_physics_step (:415-424)
+        for (int d = 0; d < kBbotDof; ++d) { q[d] = v.dof[d * N + en]; qd[d] = v.dof[(kBbotDof + d) * N + en]; }
+        for (int k = 0; k < 13; ++k) ball[k] = bv.ball[k * N + en];
+        for (int k = 0; k < 18; ++k) sens[k] = v.sensor[k * N + en];
+        const long long progress = v.progress[en] + 1;
+        long long reset;
+        bbot_observations(q, qd, ball, sens, obs);
+        bbot_reward(ball, ball + 7, p.ball_radius, v.reset[en], progress, p.max_episode_length, &rew, &reset);
+        episode_stats_env(v, en, rew, reset, progress, accs[omp_get_thread_num()]);
+        v.randomize[en] += 1;
+        write_obs(v, en, obs, kBbotObs);
+        v.rew[en] = rew; v.reset[en] = reset; v.progress[en] = progress;
+        v.timeout[en] = (unsigned char)(((float)progress >= p.max_episode_length - 1.f) && (reset != 0));
+    }
+    for (const StatAcc& a : accs) { v.stats[0] += (float)a.fin_ret; v.stats[1] += (float)a.fin_len; v.stats[2] += (float)a.fin; v.stats[3] += (float)a.r; v.stats[4] += (float)a.cnt; }
+}
+
 extern "C" int mi_engine_step(MiEngine* e, const float* actions, void*) {
     if (!e || !actions) return fail("mi_engine_step: null argument");
     e->v.ring = (int)(e->steps & 1);
@@ -343,6 +611,9 @@ extern "C" int mi_engine_step(MiEngine* e, const float* actions, void*) {
         case T_CARTPOLE: step_cartpole(e, actions); break;
         case T_ANT: step_loco<ModelAnt, false>(e, actions); break;
         case T_HUMANOID: step_loco<ModelHumanoid, true>(e, actions); break;
+        case T_QUADCOPTER: step_quadcopter(e, actions, false); break;
+        case T_INGENUITY: step_ingenuity(e, actions, false); break;
+        case T_BALLBALANCE: step_ball_balance(e, actions, false); break;
         default: return fail("mi_engine_step: task not on the CPU backend");
     }
     e->steps++;
@@ -364,6 +635,9 @@ extern "C" int mi_engine_simulate(MiEngine* e, void*) {
         case T_CARTPOLE: simulate_all<ModelCartpole>(e); break;
         case T_ANT: simulate_all<ModelAnt>(e); break;
         case T_HUMANOID: simulate_all<ModelHumanoid>(e); break;
+        case T_QUADCOPTER: step_quadcopter(e, nullptr, true); break;
+        case T_INGENUITY: step_ingenuity(e, nullptr, true); break;
+        case T_BALLBALANCE: step_ball_balance(e, nullptr, true); break;
         default: return fail("mi_engine_simulate: task not on the CPU backend");
     }
     return 0;
@@ -410,6 +684,14 @@ extern "C" int mi_engine_reset_idx(MiEngine* e, const int64_t* env_ids, int n, v
             break;
         case T_ANT: reset_loco<ModelAnt, false>(e, env_ids, n); break;
         case T_HUMANOID: reset_loco<ModelHumanoid, true>(e, env_ids, n); break;
+        case T_QUADCOPTER: for (int i = 0; i < n; ++i) if (env_ids[i] >= 0 && env_ids[i] < N) quad_reset_env(e, (int)env_ids[i]); break;
+        case T_INGENUITY: for (int i = 0; i < n; ++i) if (env_ids[i] >= 0 && env_ids[i] < N) ing_reset_env(e, (int)env_ids[i]); break;
+        case T_BALLBALANCE:
+            for (int i = 0; i < n; ++i) if (env_ids[i] >= 0 && env_ids[i] < N) {
+                bbot_reset_env(e, (int)env_ids[i]);
+                for (int d = 0; d < kBbotDof; ++d) e->bv.targets[d * N + (int)env_ids[i]] = 0.f;
+            }
+            break;
         default: return fail("mi_engine_reset_idx: task not on the CPU backend");
     }
     return 0;

@@ -3,6 +3,7 @@
 // gym.simulate on core/bbot_engine.hpp (attractor-pinned feet, ball <-> tray contact), post kernel = post_physics_step.
 // One env per lane, 64 envs per wave; the sub-step keeps its 18 constraint rows in registers (no LDS).
 #include "step_kernels.hpp"
+#include "task_views.hpp"
 #include "core/bbot_engine.hpp"
 #include "gen/model_balance_bot.h"
 #include "tasks/ball_balance.hpp"
@@ -13,12 +14,6 @@ using BM = ModelBalanceBot;
 static_assert(BM::ND == kBbotDof && BM::NSENS == kBbotSensors && BM::NB == 7, "balance bot model");
 static_assert(sizeof(BbotPhys) == sizeof(BallBalanceParams) - offsetof(BallBalanceParams, pin_stiffness), "BbotPhys is the tail of BallBalanceParams");
 
-struct BbotView {          // same definition in mi_engine.hip
-    float* targets;        // [6][N]  dof_position_targets
-    float* ball;           // [13][N] root state of the ball actor (vec_root_tensor[:, 1, :])
-    float* lamp;           // [9][N]  attractor impulses (warm start)
-    int* ncontact;         // [N]     1 while the ball touches the tray
-};
 
 static __device__ __forceinline__ const BbotPhys& phys_of(const BallBalanceParams& p) { return *reinterpret_cast<const BbotPhys*>(&p.pin_stiffness); }
 

@@ -4,6 +4,7 @@
 // sub-step kernel = gym.simulate with the engine's Drive extras (zero gains: the joints are passive), post kernel =
 // post_physics_step.  One env per lane, 64 envs per wave.
 #include "step_kernels.hpp"
+#include "task_views.hpp"
 #include "gen/model_ingenuity.h"
 #include "tasks/ingenuity.hpp"
 
@@ -12,12 +13,6 @@ namespace mi {
 using IM = ModelIngenuity;
 static_assert(IM::ND == kIngDof && IM::NSENS == kIngRotors && IM::NB + 1 == kIngBodies, "ingenuity model");
 
-struct IngenuityView {     // same definition in mi_engine.hip
-    float* thrusts;        // [2][3][N]
-    float* forces;         // [6][3][N]  forces[:, body, xyz] as the reference keeps them (bodies 1 and 3 carry the thrusts)
-    float* target;         // [3][N]     target_root_positions
-    float* marker;         // [13][N]    root state of the marker actor (vec_root_tensor[:, 1, :])
-};
 
 static __device__ __forceinline__ void ing_set_target(const View& v, const IngenuityView& iv, int e, const float* target) {
     const int N = v.N;

@@ -3,6 +3,7 @@
 // LOCAL_SPACE).  pre kernel = pre_physics_step (deferred resets, action integration), sub-step kernel = gym.simulate with the
 // engine's Drive extras, post kernel = post_physics_step.  One env per lane, 64 envs per wave.
 #include "step_kernels.hpp"
+#include "task_views.hpp"
 #include "gen/model_quadcopter.h"
 #include "tasks/quadcopter.hpp"
 
@@ -11,11 +12,6 @@ namespace mi {
 using QM = ModelQuadcopter;
 static_assert(QM::ND == kQuadDof && QM::NSENS == kQuadRotors && QM::NB == 9, "quadcopter model");
 
-struct QuadView {          // same definition in mi_engine.hip
-    float* targets;        // [8][N] dof_position_targets
-    float* thrusts;        // [4][N]
-    float* forces;         // [27][N] forces[:, body, xyz] as the reference keeps them (rotor bodies' z = thrust)
-};
 
 // pre_physics_step (quadcopter.py:276-292)
 __global__ void quad_pre_kernel(View v, QuadView qv, QuadcopterParams p, const float* __restrict__ actions_in) {

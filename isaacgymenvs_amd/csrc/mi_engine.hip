@@ -11,6 +11,7 @@
 #include "../../include/mi_engine.h"
 #include "step_kernels.hpp"
 #include "arena_layout.hpp"
+#include "task_views.hpp"
 #include "gen/model_ant.h"
 #include "gen/model_cartpole.h"
 #include "gen/model_humanoid.h"
@@ -204,7 +205,6 @@ hipError_t launch_anymal_obs(int n, const AnymalFlatParams& p, const float* root
 hipError_t launch_anymal_reward(int n, const AnymalFlatParams& p, const float* root_states, const float* commands, const float* torques,
                                 const float* contact_forces, int num_bodies, const long long* episode_lengths, float* rew,
                                 long long* reset, hipStream_t s);
-struct QuadView { float* targets; float* thrusts; float* forces; };
 hipError_t launch_step_quadcopter(const View& v, const QuadView& qv, const SimParams& P, const QuadcopterParams& p, const float* actions,
                                   int cfi, hipStream_t s);
 hipError_t launch_simulate_quadcopter(const View& v, const QuadView& qv, const SimParams& P, const QuadcopterParams& p, hipStream_t s);
@@ -213,13 +213,11 @@ hipError_t launch_reset_quadcopter(const View& v, const QuadView& qv, const Quad
 hipError_t launch_quadcopter_reward(int n, const float* root_positions, const float* root_quats, const float* root_linvels,
                                     const float* root_angvels, const long long* progress_buf, float max_episode_length, float* rew,
                                     long long* reset, hipStream_t s);
-struct IngenuityView { float* thrusts; float* forces; float* target; float* marker; };
 hipError_t launch_step_ingenuity(const View& v, const IngenuityView& iv, const SimParams& P, const IngenuityParams& p, const float* actions,
                                  int cfi, hipStream_t s);
 hipError_t launch_simulate_ingenuity(const View& v, const IngenuityView& iv, const SimParams& P, const IngenuityParams& p, hipStream_t s);
 hipError_t launch_init_ingenuity(const View& v, const IngenuityView& iv, const IngenuityParams& p, hipStream_t s);
 hipError_t launch_reset_ingenuity(const View& v, const IngenuityView& iv, const IngenuityParams& p, const long long* ids, int n, hipStream_t s);
-struct BbotView { float* targets; float* ball; float* lamp; int* ncontact; };
 hipError_t launch_step_ball_balance(const View& v, const BbotView& bv, const SimParams& P, const BallBalanceParams& p, const float* actions,
                                     int cfi, hipStream_t s);
 hipError_t launch_simulate_ball_balance(const View& v, const BbotView& bv, const SimParams& P, const BallBalanceParams& p, hipStream_t s);
@@ -263,38 +261,6 @@ struct MiEngine {
     float* lamp_arena;     // the self-contact impulse tensor (Humanoid), kept while the option self_collision is 0
 };
 
-// Quadcopter extras (quadcopter.py:90-97)
-static void build_quad_layout(int N, Layout& L, QuadView* qv, char* base) {
-    const int64_t n = N;
-    auto P = [&](size_t o) { return base ? base + o : (char*)nullptr; };
-    size_t o;
-    o = L.add("dof_position_targets", MI_F32, {n, 8}, {1, n}, 8 * n); if (qv) qv->targets = (float*)P(o);
-    o = L.add("thrusts", MI_F32, {n, 4}, {1, n}, 4 * n); if (qv) qv->thrusts = (float*)P(o);
-    o = L.add("forces", MI_F32, {n, 9, 3}, {1, 3 * n, n}, 27 * n); if (qv) qv->forces = (float*)P(o);
-    L.off = (L.off + 255) & ~size_t(255);
-}
-// Ingenuity extras (ingenuity.py:63-97): the marker actor's root state is the second row of the reference's [N, 2, 13] root tensor
-static void build_ingenuity_layout(int N, Layout& L, IngenuityView* iv, char* base) {
-    const int64_t n = N;
-    auto P = [&](size_t o) { return base ? base + o : (char*)nullptr; };
-    size_t o;
-    o = L.add("thrusts", MI_F32, {n, 2, 3}, {1, 3 * n, n}, 6 * n); if (iv) iv->thrusts = (float*)P(o);
-    o = L.add("forces", MI_F32, {n, 6, 3}, {1, 3 * n, n}, 18 * n); if (iv) iv->forces = (float*)P(o);
-    o = L.add("target_root_positions", MI_F32, {n, 3}, {1, n}, 3 * n); if (iv) iv->target = (float*)P(o);
-    o = L.add("marker_states", MI_F32, {n, 13}, {1, n}, 13 * n); if (iv) iv->marker = (float*)P(o);
-    L.off = (L.off + 255) & ~size_t(255);
-}
-// BallBalance extras (ball_balance.py:88-112): the ball actor's root state is the second row of the reference's [N, 2, 13] root tensor
-static void build_bbot_layout(int N, Layout& L, BbotView* bv, char* base) {
-    const int64_t n = N;
-    auto P = [&](size_t o) { return base ? base + o : (char*)nullptr; };
-    size_t o;
-    o = L.add("dof_position_targets", MI_F32, {n, 6}, {1, n}, 6 * n); if (bv) bv->targets = (float*)P(o);
-    o = L.add("ball_states", MI_F32, {n, 13}, {1, n}, 13 * n); if (bv) bv->ball = (float*)P(o);
-    o = L.add("attractor_impulse", MI_F32, {n, 3, 3}, {1, 3 * n, n}, 9 * n); if (bv) bv->lamp = (float*)P(o);
-    o = L.add("ball_contact_count", MI_I32, {n}, {1}, n); if (bv) bv->ncontact = (int*)P(o);
-    L.off = (L.off + 255) & ~size_t(255);
-}
 // ShadowHand extras (shadow_hand.py:150-222): object / goal root states, targets, fingertip body states, success counters
 static void build_hand_layout(int N, Layout& L, HandView* hv, char* base) {
     const int64_t n = N;

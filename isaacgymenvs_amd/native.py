@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI_ENGINE_LIB") or os.path.join(_HERE, "libmi_engine.so")
 # CPU product backend (sim_device="cpu": the reference's CPU pipeline, BASELINE config 1), built with g++ from the same engine sources
 CPU_LIB_PATH = os.path.join(_HERE, "libmi_engine_cpu.so")
-CPU_TASKS = ("Cartpole", "Ant", "Humanoid")
+CPU_TASKS = ("Cartpole", "Ant", "Humanoid", "Quadcopter", "Ingenuity", "BallBalance")
 CSRC = os.path.join(_HERE, "csrc")
 BUILD_DIR = os.path.join(CSRC, "build")
 # one translation unit per robot model (they compile in parallel) + the C ABI

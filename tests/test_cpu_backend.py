@@ -170,3 +170,55 @@ def test_actor_scale_tensor_acts_like_a_rescaled_model():
     err = max(np.abs(env.dof_vel.numpy() - orcs[0].qd).max(), np.abs(env.root_states.numpy() - orcs[0].root).max())
     assert err < 1e-3 * max(1.0, np.abs(orcs[0].qd).max()), err
     assert np.abs(orcs[0].qd - orcs[1].qd).max() > 0.2                 # the scaled model really moves differently
+
+
+def _small_task_oracle(task, env, n, seed):
+    from isaacgymenvs_amd.assets.procedural import balance_bot_dims
+    from oracle.tasks import OracleBallBalanceEnv, OracleIngenuityEnv, OracleQuadcopterEnv
+    sim = _sim_dict(env.sim_params)
+    if task == "Quadcopter":
+        return OracleQuadcopterEnv(load_model("quadcopter"), sensor_bodies("quadcopter"), sim, env._task_params_struct, n, seed=seed, precision="f64")
+    if task == "Ingenuity":
+        return OracleIngenuityEnv(load_model("ingenuity"), sensor_bodies("ingenuity"), sim, env._task_params_struct, n, seed=seed, precision="f64")
+    return OracleBallBalanceEnv(load_model("balance_bot"), sensor_bodies("balance_bot"), sim, env._task_params_struct, balance_bot_dims(), n, seed=seed)
+
+
+@pytest.mark.parametrize("task,nact,steps", [("Quadcopter", 12, 25), ("Ingenuity", 6, 25), ("BallBalance", 3, 45)])
+def test_small_tasks_on_cpu_match_the_cpu_restatement(task, nact, steps):
+    """The tasks whose robots the reference generates in code run on the host build too (the per-env functions of
+    csrc/tasks/{quadcopter,ingenuity,ball_balance}.hpp and core/bbot_engine.hpp, looped over envs with OpenMP)."""
+    n, seed = 40, 17
+    env = isaacgymenvs_amd.make(seed=seed, task=task, num_envs=n, sim_device="cpu", rl_device="cpu", headless=True)
+    assert env.device == "cpu" and env.obs_buf.device.type == "cpu"
+    orc = _small_task_oracle(task, env, n, seed)
+    g = torch.Generator(device="cpu").manual_seed(4)
+    for step in range(steps):
+        a = torch.rand((n, nact), generator=g) * 2 - 1
+        if task == "Quadcopter":
+            a[:, 8:] = a[:, 8:] * 0.5 + 0.4
+        obs_d, rew, reset, extras = env.step(a)
+        o_obs, o_rew, o_reset = orc.step(a.numpy())
+        obs = env.obs_buf.numpy()
+        assert np.isfinite(obs).all()
+        np.testing.assert_array_equal(env.progress_buf.numpy(), orc.progress_buf)
+        tol = 3e-4 * (1 + step)
+        if task == "BallBalance":
+            same = env.engine.tensors["ball_contact_count"].numpy() == orc.eng.ncontacts
+            ok = same & (np.abs(obs[:, :12] - o_obs[:, :12]).max(axis=1) < tol)
+            assert ok.mean() > 0.95, (step, ok.mean())
+            np.testing.assert_allclose(env.dof_position_targets.numpy(), orc.targets, atol=1e-6)
+            np.testing.assert_allclose(env.ball_states.numpy()[ok][:, 0:3], orc.eng.ball[ok][:, 0:3], atol=tol)
+        else:
+            np.testing.assert_allclose(env.thrusts.numpy(), orc.thrusts, atol=1e-6)
+            np.testing.assert_allclose(env.forces.numpy(), orc.forces, atol=1e-6)
+            np.testing.assert_allclose(obs, o_obs, atol=tol)
+            np.testing.assert_array_equal(reset.numpy(), o_reset)
+            np.testing.assert_allclose(rew.numpy(), o_rew, atol=5 * tol)
+    if task == "Ingenuity":
+        np.testing.assert_allclose(env.target_root_positions.numpy(), orc.target, atol=1e-6)
+        np.testing.assert_allclose(env.marker_states.numpy(), orc.marker, atol=1e-6)
+    # the explicit reset path and simulate() run on the host arena too
+    env.reset_idx(torch.arange(0, n, 2))
+    assert int(env.progress_buf[::2].abs().sum()) == 0 and int(env.progress_buf[1::2].min()) == steps
+    env.engine.simulate()
+    assert torch.isfinite(env.root_states).all()
