@@ -171,6 +171,8 @@ class _Geom:
     friction: float = 1.0
     density: float = 1000.0
     mass: float | None = None
+    contype: int = 1
+    conaffinity: int = 1
 
 
 @dataclass
@@ -371,7 +373,28 @@ def _mjcf_geom(attr, angle_scale):
     g = _Geom(attr.get("name", ""), gtype, pos, quat, s, friction=fr, density=float(attr.get("density", 1000.0)))
     if "mass" in attr:
         g.mass = float(attr["mass"])
+    g.contype = int(attr.get("contype", 1))
+    g.conaffinity = int(attr.get("conaffinity", 1))
     return g
+
+
+def mjcf_self_collision_filter(path):
+    """The collision filters an MJCF asset itself carries, the ones `create_actor(..., collision_filter=-1, ...)` asks for ("use asset
+    collision filters set in mjcf loader", reference shadow_hand.py:357-358): two geoms may touch when
+    `contype_a & conaffinity_b or contype_b & conaffinity_a`.  -> dict(collision_geoms = number of primitive geoms that collide with
+    anything, accepting = the geoms with a non-zero conaffinity [(body, geom, largest half extent)], pairs = the (geom_a, geom_b)
+    names on different bodies that may touch).  For the Shadow Hand every collision geom is contype 1 / conaffinity 0 (shared.xml:21,
+    class robot0:DC_Hand): no hand shape accepts another hand shape.  What is left are two 1 mm placeholder boxes at the thumb's joint
+    origins (robot.xml:129,138, default class) -- the manipulated objects (contype = conaffinity = 1) accept all hand shapes."""
+    bodies, _ = parse_mjcf(path)
+    geoms = [(b.name, g) for b in bodies for g in b.geoms if (g.contype | g.conaffinity)]
+    pairs = []
+    for i, (ba, ga) in enumerate(geoms):
+        for bb, gb in geoms[i + 1:]:
+            if ba != bb and ((ga.contype & gb.conaffinity) or (gb.contype & ga.conaffinity)):
+                pairs.append((ga.name or ba, gb.name or bb))
+    accepting = [(b, g.name or b, float(np.max(g.size))) for b, g in geoms if g.conaffinity]
+    return dict(collision_geoms=len(geoms), accepting=accepting, pairs=pairs)
 
 
 def parse_mjcf(path):

@@ -252,3 +252,27 @@ def test_two_wave_split_of_the_sub_step_is_bit_identical_on_the_host(waves):
         np.testing.assert_array_equal(out1, out2)
         touched += int((np.abs(st1[:, 13 + 3 * nd + 3 * nsph:]).sum(1) > 0).sum())
     assert touched > 0.1 * 3 * n                      # envs whose self contacts carry load
+
+
+def test_shadow_hand_asset_filters_leave_no_hand_to_hand_contact():
+    """shadow_hand.py:357-358 creates the hand with collision filter -1 = "use asset collision filters set in mjcf loader".  The asset's
+    filters (shared.xml:21: every collision geom of the hand is contype 1 / conaffinity 0) let no hand shape accept another one; only
+    two 1 mm placeholder boxes at the thumb's joint origins (default class) would.  The engine therefore builds no hand self-collision
+    rows, while the Humanoid (filter 0, humanoid.py:194) gets its pair list from geometry."""
+    import os
+    from isaacgymenvs_amd.assets.model import mjcf_self_collision_filter
+    from isaacgymenvs_amd.registry import load_extras
+    rec = load_extras("shadow_hand")["self_collision_filter"]
+    assert rec["collision_geoms"] == 21
+    assert sorted(g for _, g, _ in rec["accepting"]) == ["robot0:V_thbase", "robot0:V_thhub"]
+    assert all(ext <= 0.001 for _, _, ext in rec["accepting"])
+    assert rec["n_pairs"] == 2 * (21 - 2) + 1                                # each placeholder against the other shapes, and each other
+    assert load_selfcol("shadow_hand") is None
+    ref = "/root/reference/assets/mjcf"
+    if not os.path.isdir(ref):
+        return
+    flt = mjcf_self_collision_filter(os.path.join(ref, "open_ai_assets/hand/shadow_hand.xml"))
+    assert flt["collision_geoms"] == rec["collision_geoms"] and len(flt["pairs"]) == rec["n_pairs"]
+    assert all(("V_thbase" in a or "V_thhub" in a or "V_thbase" in b or "V_thhub" in b) for a, b in flt["pairs"])
+    hum = mjcf_self_collision_filter(os.path.join(ref, "nv_humanoid.xml"))
+    assert len(hum["accepting"]) == hum["collision_geoms"] and len(hum["pairs"]) > 100   # default contype = conaffinity = 1 everywhere

@@ -142,7 +142,12 @@ def main():
             import json
             with open(os.path.join(a.out, "shadow_hand_extras.json"), "w") as f:
                 full = load_asset(os.path.join(a.asset_root, e["file"]), name=name, fix_base_link=True)   # with collision geoms
-                json.dump(hand_extras(a.asset_root, full), f, indent=1)
+                extras = hand_extras(a.asset_root, full)
+                from isaacgymenvs_amd.assets.model import mjcf_self_collision_filter
+                flt = mjcf_self_collision_filter(os.path.join(a.asset_root, e["file"]))
+                # collision filter -1 (shadow_hand.py:357-358): which hand shapes the asset lets touch each other
+                extras["self_collision_filter"] = dict(collision_geoms=flt["collision_geoms"], accepting=flt["accepting"], n_pairs=len(flt["pairs"]))
+                json.dump(extras, f, indent=1)
         print(f"{name}: nb={spec.nb} nd={spec.nd} nv={spec.nv} nsph={len(spec.sph_body)} mass={spec.total_mass():.4f}")
     import tempfile
     from isaacgymenvs_amd.assets import procedural
