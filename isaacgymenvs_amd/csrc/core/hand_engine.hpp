@@ -26,8 +26,17 @@ struct ObjectParams {       // mirrors the object part of MiHandParams
     // objects other than the cube (SHAPE != 0): semi-axes of the ellipsoid and the principal inertias about the body axes
     float dims[3] = {0.f, 0.f, 0.f};
     float inertia3[3] = {0.f, 0.f, 0.f};
+    // `actor_params.object` factors (ShadowHand.yaml:132-159): mass -- with it the inertia -- and size (gym.set_actor_scale leaves the
+    // mass alone)
+    MI_HD void randomise(float mass_factor, float size_factor) {
+        mass *= mass_factor; inertia *= mass_factor; half *= size_factor;
+        for (int k = 0; k < 3; ++k) { inertia3[k] *= mass_factor; dims[k] *= size_factor; }
+    }
 };
 constexpr int OBJ_BOX = 0, OBJ_CAPSULE = 1, OBJ_ELLIPSOID = 2;   // objectType "block" / "pen" / "egg" (shadow_hand.py:86-96)
+// columns of the ShadowHand's per-env `actor_scale` tensor (`actor_params` domain randomisation, ShadowHand.yaml:104-159)
+constexpr int HS_MASS = 0, HS_DAMPING = 1, HS_STIFFNESS = 2, HS_TENDON_STIFFNESS = 3, HS_TENDON_DAMPING = 4, HS_OBJECT_MASS = 5,
+              HS_OBJECT_SCALE = 6, HS_COLUMNS = 8;
 
 template <class M>
 struct HandSim : Sim<M> {
@@ -38,6 +47,7 @@ struct HandSim : Sim<M> {
 #define MI_HAND_KMAX 12
 #endif
     static constexpr int KMAX = MI_HAND_KMAX;                // active object contacts kept per env
+    Strided limit_shift{nullptr, 1};                         // [2 * ND] per-env shifts of the lower / upper joint limits (required)
     static constexpr int HCH = M::MAXCHAIN;                  // stored row width: the hand chain; the 6 object entries are re-derived
     static constexpr int H_LIMG = B::limoff(NLIM);
     static constexpr int H_CB = H_LIMG + 3 * NLIM;           // limit G | Ainv, vt, lam | contact slots
@@ -136,6 +146,9 @@ struct HandSim : Sim<M> {
         auto vt = [&](int row) MI_LAMBDA -> float& { return rows(H_LIMG + NLIM + row); };
         auto lam = [&](int row) MI_LAMBDA -> float& { return rows(H_LIMG + 2 * NLIM + row); };
         const float invh = MI_RCP(h);
+        // `actor_params.hand.dof_properties.lower / upper` (ShadowHand.yaml:118-129): per-env shifts of the joint limits, [ND] lower then
+        // [ND] upper, read once where the limit rows are built (the caller always provides them: zeros = the model's limits)
+        const Strided limit_shift = this->limit_shift;
         typename B::Ctx c;
         float (&S)[M::NDA][6] = c.S;
         float (&L)[M::NM] = c.L;
@@ -165,9 +178,20 @@ struct HandSim : Sim<M> {
         MI_STAMP(1);
         // ------------------------------------------------------------ rhs: implicit PD drives, passive damping, tendons
         float Ldi[NVA], y[NVA];
+        // `actor_params.hand` domain randomisation (ShadowHand.yaml:104-131): per-env factors of the link masses, the joints' damping and
+        // drive stiffness and the tendons' limit stiffness / damping, loaded here where they are used (H and the bias forces are linear
+        // in the link masses: the tree pass ran on the model's own).  this->actor_scale.p == nullptr: the model's constants.
+        float sc_damp = 1.f, sc_kp = 1.f, sc_tk = 1.f, sc_td = 1.f;
+        if (this->actor_scale.p != nullptr) {
+            const float sc_mass = this->actor_scale(HS_MASS);
+            sc_damp = this->actor_scale(HS_DAMPING); sc_kp = this->actor_scale(HS_STIFFNESS);
+            sc_tk = this->actor_scale(HS_TENDON_STIFFNESS); sc_td = this->actor_scale(HS_TENDON_DAMPING);
+            sfor<M::NM>([&](auto E_) MI_LAMBDA { L[E_] *= sc_mass; });
+            sfor<NV>([&](auto I) MI_LAMBDA { c.bias[I] *= sc_mass; });
+        }
         sfor<ND>([&](auto D) MI_LAMBDA {
             constexpr int d = D, gi = OFF + d;
-            constexpr float kp = M::dof_kp[d], Dm = M::dof_damping[d];
+            const float kp = M::dof_kp[d] * sc_kp, Dm = M::dof_damping[d] * sc_damp;
             L[M::midx[gi][gi]] += M::dof_armature[d] + h * Dm + h * h * kp;
             y[gi] = -c.bias[gi] - kp * (q[d] - target[d]) - (Dm + h * kp) * qd[d];
         });
@@ -177,9 +201,10 @@ struct HandSim : Sim<M> {
             static_assert(M::midx[g0][g1] >= 0 || M::midx[g1][g0] >= 0, "tendon joints must be on one kinematic chain");
             const float Lt = c0 * q[d0] + c1 * q[d1], Ld = c0 * qd[d0] + c1 * qd[d1];
             const float viol = Lt - fminf(fmaxf(Lt, M::tend_lo[t]), M::tend_hi[t]);
-            const float k = (viol != 0.f) ? M::tend_stiffness : 0.f;
-            const float a = h * M::tend_damping + h * h * k;
-            const float f = k * viol + (M::tend_damping + h * k) * Ld;
+            const float k = (viol != 0.f) ? M::tend_stiffness * sc_tk : 0.f;
+            const float td = M::tend_damping * sc_td;
+            const float a = h * td + h * h * k;
+            const float f = k * viol + (td + h * k) * Ld;
             L[M::midx[g0][g0]] += a * c0 * c0;
             L[M::midx[g1][g1]] += a * c1 * c1;
             if constexpr (M::midx[g0][g1] >= 0) L[M::midx[g0][g1]] += a * c0 * c1; else L[M::midx[g1][g0]] += a * c0 * c1;
@@ -237,7 +262,7 @@ struct HandSim : Sim<M> {
             if constexpr (M::dof_limited[d]) {
                 constexpr int row = B::limrow(d);
                 MI_PHASE();
-                const float dl = q[d] - M::dof_lower[d], du = M::dof_upper[d] - q[d];
+                const float dl = q[d] - (M::dof_lower[d] + limit_shift(d)), du = (M::dof_upper[d] + limit_shift(ND + d)) - q[d];
                 const bool lower = dl < du;
                 const float C = lower ? dl : du, s = lower ? 1.f : -1.f;
                 const float lw = lam(row);
@@ -465,16 +490,18 @@ struct HandSim : Sim<M> {
             v[i] = s * Ldi[i];
         });
         // ------------------------------------------------------------ outputs: limit impulses, dof forces, fingertip sensors
+        float fs_kp = 1.f, fs_damp = 1.f;     // (re-loaded: not kept live through the contact phases)
+        if (this->actor_scale.p != nullptr) { fs_damp = this->actor_scale(HS_DAMPING); fs_kp = this->actor_scale(HS_STIFFNESS); }
         sfor<ND>([&](auto D) MI_LAMBDA {
             constexpr int d = D;
             float ll = 0.f;
             if constexpr (M::dof_limited[d]) {
                 constexpr int row = B::limrow(d);
-                const float dl = q[d] - M::dof_lower[d], du = M::dof_upper[d] - q[d];
-                ll = (dl < du) ? lam(row) : -lam(row);
+                // which limit the row was built for: G(row, 0) = s / L_dd, s = +1 lower, -1 upper
+                ll = (G(row, 0) > 0.f) ? lam(row) : -lam(row);
             }
             laml(d) = ll;
-            dof_force(d) = -M::dof_kp[d] * (q[d] - target[d]) - M::dof_damping[d] * v[OFF + d] + ll * invh;
+            dof_force(d) = -M::dof_kp[d] * fs_kp * (q[d] - target[d]) - M::dof_damping[d] * fs_damp * v[OFF + d] + ll * invh;
         });
         float sens[6 * M::NSENSA];
         sfor<6 * NSENS>([&](auto K) MI_LAMBDA { sens[K] = 0.f; });

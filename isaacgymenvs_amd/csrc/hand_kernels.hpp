@@ -32,6 +32,9 @@ struct HandView {
     float* rb_force;       // [3][N] rb_forces[:, object] in the object's local frame (:201, 700-708)
     float* force_prob;     // [N] random_force_prob (:198-199)
     float* mu_env;         // [N] per-env hand-object contact friction for actor_params friction randomisation; negative = HandParams.mu
+    float* scale;          // [8][N] per-env `actor_params` factors (core/hand_engine.hpp HS_*): hand link masses, joint damping, drive stiffness,
+                           //        tendon limit stiffness / damping, object mass, object size; 1 = the model's own values
+    float* limit_shift;    // [48][N] per-env shifts of the lower / upper joint limits (`actor_params.hand.dof_properties.lower / upper`)
     int* ndropped;         // [N] contacts refused since init because all KMAX slots of the env were taken (diagnostic; a manifold's 5th+ contact does not count)
 };
 
@@ -61,6 +64,9 @@ __global__ __launch_bounds__(32) void hand_substep_kernel(View v, HandView hv, S
     if constexpr (SHAPE != OBJ_BOX) sfor<3>([&](auto K) MI_LAMBDA { OP.dims[K] = p.object_dims[K]; OP.inertia3[K] = p.object_inertia[K]; });
     const float mu_e = hv.mu_env[e];
     if (mu_e >= 0.f) OP.mu = mu_e;
+    OP.randomise(hv.scale[HS_OBJECT_MASS * N + e], hv.scale[HS_OBJECT_SCALE * N + e]);
+    sim.actor_scale = Strided{hv.scale + e, N};
+    sim.limit_shift = Strided{hv.limit_shift + e, N};
 #if defined(MI_TIMING)
     sim.tstamp = (threadIdx.x == 0 && g_mi_tstamp != nullptr) ? g_mi_tstamp + (size_t)blockIdx.x * 16 : nullptr;   // tools/debug/phase_timing_live.py
 #endif

@@ -236,6 +236,8 @@ __global__ void hand_init_kernel(View v, HandView hv, HandParams p) {
     for (int k = 0; k < 3; ++k) { hv.obj_force[k * N + e] = 0.f; hv.rb_force[k * N + e] = 0.f; }
     hv.force_prob[e] = hand_force_prob(p, uniform01(v.seed ^ 0x51ED27u, (uint32_t)(v.env_offset + e), 0u, 0u));
     hv.mu_env[e] = -1.f;
+    for (int k = 0; k < HS_COLUMNS; ++k) hv.scale[k * N + e] = 1.f;
+    for (int k = 0; k < 2 * kHandDof; ++k) hv.limit_shift[k * N + e] = 0.f;
     hv.successes[e] = 0.f; hv.reset_goal[e] = 1; hv.goal_count[e] = 0; hv.ncontact[e] = 0; hv.ndropped[e] = 0;
     v.rew[e] = 0.f; v.reset[e] = 1; v.progress[e] = 0; v.randomize[e] = 0; v.timeout[e] = 0; v.episode[e] = 0; v.ep_ret[e] = 0.f;
     if (e == 0) { hv.cons[0] = 0.f; hv.ws[0] = hv.ws[1] = 0.f; for (int k = 0; k < 8; ++k) v.stats[k] = 0.f; }

@@ -227,6 +227,8 @@ struct HandView {
     float* cur_targets; float* prev_targets; float* object_state; float* goal_state; float* fingertip; float* successes;
     long long* reset_goal; int* goal_count; float* cons; float* ws; int* ncontact;
     float* full_state; float* obj_force; float* rb_force; float* force_prob; float* mu_env;
+    float* scale;
+    float* limit_shift;
     int* ndropped;
 };
 hipError_t launch_step_shadow_hand(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, const float* actions, int cfi,
@@ -282,6 +284,10 @@ static void build_hand_layout(int N, Layout& L, HandView* hv, char* base) {
     o = L.add("rb_forces_object", MI_F32, {n, 3}, {1, n}, 3 * n); if (hv) hv->rb_force = (float*)P(o);
     o = L.add("random_force_prob", MI_F32, {n}, {1}, n); if (hv) hv->force_prob = (float*)P(o);
     o = L.add("friction", MI_F32, {n}, {1}, n); if (hv) hv->mu_env = (float*)P(o);   // hand-object contact friction per env (negative: HandParams.mu)
+    // `actor_params` factors of the hand and the object (core/hand_engine.hpp HS_*), 1 = the model's own values
+    o = L.add("actor_scale", MI_F32, {n, 8}, {1, n}, 8 * n); if (hv) hv->scale = (float*)P(o);
+    // `actor_params.hand.dof_properties.lower / upper`: shifts of the 24 lower, then the 24 upper joint limits of each env's hand
+    o = L.add("dof_limit_shift", MI_F32, {n, 48}, {1, n}, 48 * n); if (hv) hv->limit_shift = (float*)P(o);
     o = L.add("object_contact_dropped", MI_I32, {n}, {1}, n); if (hv) hv->ndropped = (int*)P(o);   // contacts refused since init: all KMAX slots taken
     L.off = (L.off + 255) & ~size_t(255);
 }

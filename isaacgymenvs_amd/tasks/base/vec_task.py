@@ -274,6 +274,10 @@ class VecTask(Env):
     ACTOR_SCALE_COLUMNS = {("rigid_body_properties", "mass"): 0, ("dof_properties", "damping"): 1, ("dof_properties", "stiffness"): 2,
                            ("dof_properties", "armature"): 3}
 
+    def _actor_scale_column(self, actor, group, attr):
+        """column of the engine's `actor_scale` tensor an `actor_params.<actor>.<group>.<attr>` entry drives, or None"""
+        return self.ACTOR_SCALE_COLUMNS.get((group, attr))
+
     def apply_randomizations(self, dr_params):
         """What the reference's VecTask.apply_randomizations decides, when (vec_task.py:610-648: `frequency` in sim frames for the
         non-env parameters, per env once it has been reset after `frequency` of its own steps), is kept; what it then does is
@@ -332,8 +336,11 @@ class VecTask(Env):
           rigid_shape_properties.friction                     -> `friction` (Ant, Humanoid; ShadowHand: mean of hand and object);
           rigid_body_properties.mass, dof_properties.damping / stiffness / armature -> columns of `actor_scale` (Ant, Humanoid): one
           factor per env for the whole actor where the reference draws one per body / dof (`scaling`: the sample itself;
-          `additive`: relative to the model's mean value).
-        Entries without an engine parameter (restitution, scale, tendons, colours) are named once in a warning."""
+          `additive`: relative to the model's mean value);
+          ShadowHand (`_actor_scale_column` of the task): hand mass / dof damping / dof stiffness (the drives' kp) / tendon stiffness /
+          tendon damping, object mass and `scale` (vec_task.py:760-775) -> columns of its `actor_scale`; dof_properties.lower / upper ->
+          one shift per joint and env in `dof_limit_shift`.
+        Entries without an engine parameter (restitution, colours, ...) are named once in a warning."""
         from ...utils.dr_utils import apply_random_samples_array
         t = self.engine.tensors
         fr = t.get("friction") if self.native_task in ("Ant", "Humanoid", "ShadowHand") else None
@@ -351,15 +358,27 @@ class VecTask(Env):
                 if not isinstance(attrs, dict):
                     skipped.append(f"{actor}.{group}")
                     continue
+                if group == "scale":                                                     # the entry is the parameter block itself (:760-775)
+                    attrs = {"scale": attrs}
                 for attr, prm in attrs.items():
-                    col = self.ACTOR_SCALE_COLUMNS.get((group, attr)) if scales is not None else None
+                    col = self._actor_scale_column(actor, group, attr) if scales is not None else None
                     is_friction = group == "rigid_shape_properties" and attr == "friction" and fr is not None
-                    if col is None and not is_friction:
-                        skipped.append(f"{actor}.{group}.{attr}")
+                    shift = t.get("dof_limit_shift") if (group == "dof_properties" and attr in ("lower", "upper")) else None
+                    if col is None and not is_friction and shift is None:
+                        skipped.append(f"{actor}.{group}" if group == "scale" else f"{actor}.{group}.{attr}")
                         continue
                     if (prm.get("setup_only", False) and not self.first_randomization) or len(ids) == 0:
                         continue
-                    if is_friction:
+                    if shift is not None:
+                        # one draw per joint and env, like the reference's per-element sampling of the dof property array; the engine
+                        # keeps the model's limits and adds the shift (`additive`) or the scaled-minus-original value (`scaling`)
+                        nd = shift.shape[1] // 2
+                        base = np.asarray(self._dr_model().dof_lower if attr == "lower" else self._dr_model().dof_upper, np.float64)
+                        og = {"v": np.tile(base, (len(ids), 1))}
+                        vals = np.asarray(apply_random_samples_array({"v": og["v"].copy()}, og, "v", prm, self.last_step), np.float64)
+                        c0 = 0 if attr == "lower" else nd
+                        shift[ids, c0:c0 + nd] = torch.as_tensor((vals - og["v"]).astype(np.float32), device=self.device)
+                    elif is_friction:
                         og = {"v": np.full(len(ids), base_mu)}
                         vals = apply_random_samples_array({"v": og["v"].copy()}, og, "v", prm, self.last_step)
                         vals_t = torch.as_tensor(np.asarray(vals, np.float32), device=self.device)
@@ -372,7 +391,7 @@ class VecTask(Env):
                         else:
                             fr[ids] = vals_t
                     else:
-                        ref_val = self._actor_reference_value(group, attr)
+                        ref_val = self._actor_reference_value(group, attr, actor)
                         og = {"v": np.full(len(ids), ref_val)}
                         vals = np.asarray(apply_random_samples_array({"v": og["v"].copy()}, og, "v", prm, self.last_step), np.float64)
                         factor = np.clip(vals / ref_val, 0.05, 20.0) if ref_val > 0 else np.ones(len(ids))
@@ -381,12 +400,16 @@ class VecTask(Env):
             import warnings
             warnings.warn("actor_params entries without an engine counterpart are skipped (reference vec_task.py:752-828): " + ", ".join(skipped))
 
-    def _actor_reference_value(self, group, attr):
-        """the model's own (mean) value a randomised actor property is measured against"""
+    def _dr_model(self):
         spec = getattr(self, "_dr_spec", None)
         if spec is None:
             from ...registry import load_model
             spec = self._dr_spec = load_model(getattr(self, "model_name", self.native_task.lower()))
+        return spec
+
+    def _actor_reference_value(self, group, attr, actor=None):
+        """the model's own (mean) value a randomised actor property is measured against"""
+        spec = self._dr_model()
         arr = {"mass": spec.mass, "damping": spec.dof_damping, "stiffness": spec.dof_stiffness, "armature": spec.dof_armature}[attr]
         return float(np.mean(arr)) if len(arr) else 0.0
 

@@ -147,6 +147,7 @@ def hand_params_from_cfg(cfg):
 
 class ShadowHand(VecTask):
     native_task = "ShadowHand"
+    model_name = "shadow_hand"
 
     def __init__(self, cfg, rl_device, sim_device, graphics_device_id, headless, virtual_screen_capture=False,
                  force_render=False):
@@ -207,3 +208,26 @@ class ShadowHand(VecTask):
 
     def _task_params(self):
         return hand_params_from_cfg(self.cfg)
+
+    #: `actor_params` entries of the two actors -> columns of the `actor_scale` tensor (csrc/core/hand_engine.hpp HS_*; reference
+    #: cfg/task/ShadowHand.yaml:89-161).  dof_properties.stiffness is the position drives' kp (DOF_MODE_POS).
+    HAND_SCALE_COLUMNS = {("hand", "rigid_body_properties", "mass"): 0, ("hand", "dof_properties", "damping"): 1,
+                          ("hand", "dof_properties", "stiffness"): 2, ("hand", "tendon_properties", "stiffness"): 3,
+                          ("hand", "tendon_properties", "damping"): 4, ("object", "rigid_body_properties", "mass"): 5,
+                          ("object", "scale", "scale"): 6}
+
+    def _actor_scale_column(self, actor, group, attr):
+        return self.HAND_SCALE_COLUMNS.get((actor, group, attr))
+
+    def _actor_reference_value(self, group, attr, actor=None):
+        """what an `additive` draw is relative to (a `scaling` draw is the factor itself)"""
+        ex = load_extras("shadow_hand")
+        if group == "scale":
+            return 1.0
+        if group == "tendon_properties":
+            return float(ex["tendon_limit_stiffness"] if attr == "stiffness" else ex["tendon_damping"])
+        if actor == "object":
+            return float(self._task_params_struct.cube_mass)
+        if (group, attr) == ("dof_properties", "stiffness"):
+            return float(np.mean(ex["dof_kp"]))
+        return super()._actor_reference_value(group, attr, actor)

@@ -98,6 +98,10 @@ class OracleHandEngine:
         self.ncontacts = np.zeros(N, int)
         self.obj_force = np.zeros((N, 3))                 # world-frame external force on the cube for the current step
         self.lo = np.minimum(spec.dof_lower, spec.dof_upper); self.up = np.maximum(spec.dof_lower, spec.dof_upper)
+        # per-env `actor_params` factors (reference ShadowHand.yaml:104-159; columns as csrc/core/hand_engine.hpp HS_*): hand link masses,
+        # joint damping, drive stiffness, tendon limit stiffness, tendon damping, object mass (+ inertia), object size
+        self.scale = np.ones((num_envs, 8))
+        self.limit_shift = np.zeros((num_envs, 2 * spec.nd))       # dof_properties.lower / upper: shifts of the lower, then the upper limits
 
     # views on the wrapped engine's state
     @property
@@ -138,16 +142,19 @@ class OracleHandEngine:
         P, nd, spec, ex = self.sim, self.nd, self.spec, self.ex
         q, qd, tgt = self.q[e].copy(), self.qd[e].copy(), self.targets[e]
         M, bias = self.eng.dynamics(e)
-        D = np.array(spec.dof_damping, float)
-        Mh = M + np.diag(np.array(spec.dof_armature, float) + h * D + h * h * self.kp)
-        rhs = -bias - self.kp * (q - tgt) - (D + h * self.kp) * qd
+        s_mass, s_damp, s_kp, s_tk, s_td, s_om, s_os = self.scale[e, :7]
+        M, bias = M * s_mass, bias * s_mass
+        D = np.array(spec.dof_damping, float) * s_damp
+        kp = self.kp * s_kp
+        Mh = M + np.diag(np.array(spec.dof_armature, float) + h * D + h * h * kp)
+        rhs = -bias - kp * (q - tgt) - (D + h * kp) * qd
         for t in ex["tendons"]:                                   # soft two-sided limit on the tendon length
             d0, d1 = t["dof"]; c0, c1 = t["coef"]; lo, hi = t["range"]
             Lt = c0 * q[d0] + c1 * q[d1]
             Ld = c0 * qd[d0] + c1 * qd[d1]
             viol = Lt - min(max(Lt, lo), hi)
-            k = ex["tendon_limit_stiffness"] if viol != 0.0 else 0.0
-            dmp = ex["tendon_damping"]
+            k = ex["tendon_limit_stiffness"] * s_tk if viol != 0.0 else 0.0
+            dmp = ex["tendon_damping"] * s_td
             cvec = np.zeros(nd); cvec[d0] = c0; cvec[d1] = c1
             Mh += (h * dmp + h * h * k) * np.outer(cvec, cvec)
             rhs -= cvec * (k * viol + (dmp + h * k) * Ld)
@@ -156,7 +163,7 @@ class OracleHandEngine:
         g = np.array(P["gravity"], float)
         xo, qo = self.obj[e, 0:3].copy(), self.obj[e, 3:7].copy()
         egg = self.objp is not None
-        omass = float(self.objp["mass"]) if egg else CUBE_MASS
+        omass = (float(self.objp["mass"]) if egg else CUBE_MASS) * s_om
         vo = self.obj[e, 7:10] + h * (g + self.obj_force[e] / omass)   # + apply_rigid_body_force_tensors on the object
         wo = self.obj[e, 10:13].copy()
         Ro = quat2mat(qo)
@@ -167,7 +174,7 @@ class OracleHandEngine:
             if not spec.dof_limited[d]:
                 self.laml[e, d] = 0.0
                 continue
-            dl, du = q[d] - self.lo[d], self.up[d] - q[d]
+            dl, du = q[d] - (self.lo[d] + self.limit_shift[e, d]), (self.up[d] + self.limit_shift[e, nd + d]) - q[d]
             Cc, s = (dl, 1.0) if dl < du else (du, -1.0)
             lw = self.laml[e, d]
             l0 = (0.0 if lw * s < 0 else abs(lw)) * P["warm"]
@@ -185,11 +192,11 @@ class OracleHandEngine:
             b = int(self.os_body[si])
             c = bp[b, 0:3] + bp[b, 3:12].reshape(3, 3) @ self.os_pos[si]      # world
             if egg and self.objp["shape"] == "pen":
-                dist, nl = sphere_capsule(Ro.T @ (c - xo), self.os_rad[si], self.objp["dims"][0], self.objp["dims"][1])
+                dist, nl = sphere_capsule(Ro.T @ (c - xo), self.os_rad[si], self.objp["dims"][0] * s_os, self.objp["dims"][1] * s_os)
             elif egg:
-                dist, nl = sphere_ellipsoid(Ro.T @ (c - xo), self.os_rad[si], self.objp["dims"])
+                dist, nl = sphere_ellipsoid(Ro.T @ (c - xo), self.os_rad[si], np.asarray(self.objp["dims"], float) * s_os)
             else:
-                dist, nl = sphere_box(Ro.T @ (c - xo), self.os_rad[si], CUBE_HALF)
+                dist, nl = sphere_box(Ro.T @ (c - xo), self.os_rad[si], CUBE_HALF * s_os)
             if dist >= P["contact_offset"] or ncon >= KMAX or per_body.get(b, 0) >= BODY_CAP:
                 continue
             per_body[b] = per_body.get(b, 0) + 1
@@ -209,7 +216,7 @@ class OracleHandEngine:
         Moinv = np.zeros((6, 6))
         Moinv[:3, :3] = np.eye(3) / omass
         # world-frame inverse inertia: Ro diag(1 / I) Ro^T for the ellipsoid's principal inertias, a multiple of identity for the cube
-        Moinv[3:, 3:] = Ro @ np.diag(1.0 / np.asarray(self.objp["inertia"], float)) @ Ro.T if egg else np.eye(3) / CUBE_INERTIA
+        Moinv[3:, 3:] = (Ro @ np.diag(1.0 / np.asarray(self.objp["inertia"], float)) @ Ro.T if egg else np.eye(3) / CUBE_INERTIA) / s_om
         for r in rows:
             r["Bh"] = Minv @ r["Jh"]; r["Bo"] = Moinv @ r["Jo"]
             r["Ainv"] = 1.0 / (P["cfm"] + r["Jh"] @ r["Bh"] + r["Jo"] @ r["Bo"])
@@ -252,7 +259,7 @@ class OracleHandEngine:
             if r["kind"] == "lim":
                 ll[r["d"]] = r["lam"] * r["s"]
         self.laml[e] = ll
-        self.dof_force[e] = -self.kp * (q - tgt) - D * v + ll / h
+        self.dof_force[e] = -kp * (q - tgt) - D * v + ll / h
         sens = np.zeros(6 * len(self.sens))
         for cdat in contacts:
             if cdat["b"] in self.sens:

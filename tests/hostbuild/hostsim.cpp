@@ -244,17 +244,24 @@ extern "C" int hs_step_terrain(const char* model, const SimParams* P, int nenv, 
 
 #ifdef HOSTSIM_HAND
 // Shadow hand + cube: per env  q[24] | qd[24] | laml[24] | target[24] | obj[13]  ->  updated in place; out: sensor[30] | dof_force[24] | ncontact
+// scale: null or [nenv][8] per-env `actor_params` factors (core/hand_engine.hpp HS_*); limit_shift: null or [nenv][48]
 extern "C" int hs_step_hand(const SimParams* P, int nenv, float* state, float* out, const float* root13, float half, float mass, float inertia,
-                            float mu) {
+                            float mu, const float* scale, const float* limit_shift) {
     using M = ModelShadowHand;
     constexpr int ND = M::ND, NS = M::NSENS;
     const int ss = 4 * ND + 13, os = 6 * NS + ND + 1;
-    const ObjectParams OP{half, mass, inertia, mu};
 #pragma omp parallel for schedule(static)
     for (int e = 0; e < nenv; ++e) {
         float* s = state + (size_t)e * ss;
         float* o = out + (size_t)e * os;
         HandSim<M> sim;
+        ObjectParams OP{half, mass, inertia, mu};
+        if (scale) {
+            OP.randomise(scale[e * HS_COLUMNS + HS_OBJECT_MASS], scale[e * HS_COLUMNS + HS_OBJECT_SCALE]);
+            sim.actor_scale = Strided{const_cast<float*>(scale) + e * HS_COLUMNS, 1};
+        }
+        static const float no_shift[2 * ND] = {0};
+        sim.limit_shift = Strided{const_cast<float*>(limit_shift ? limit_shift + e * 2 * ND : no_shift), 1};
         for (int k = 0; k < 13; ++k) sim.root[k] = root13[k];
         for (int k = 0; k < ND; ++k) { sim.q[k] = s[k]; sim.qd[k] = s[ND + k]; }
         float* ob = s + 4 * ND;

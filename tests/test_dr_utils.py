@@ -95,3 +95,42 @@ def test_array_bucketing_equals_the_scalar_lookup():
     assert out.shape == (64,) and out.min() >= 0.7 and out.max() < 1.3 and np.array_equal(prop["friction"], out)
     buckets = 0.7 + 0.6 * np.arange(250) / 250
     assert np.abs(out[:, None] - buckets[None, :]).min(axis=1).max() < 1e-12
+
+
+def test_shadow_hand_actor_params_map_onto_the_engine_tensors():
+    """VecTask._apply_actor_params with the `actor_params` block of cfg/task/ShadowHand.yaml, on stand-in engine tensors (no GPU): every
+    entry except the colours lands in `actor_scale` / `dof_limit_shift` / `friction`; `setup_only` entries are drawn once."""
+    import types
+    import warnings
+    import torch
+    from isaacgymenvs_amd.tasks.shadow_hand import ShadowHand, hand_params_from_cfg
+    from isaacgymenvs_amd.utils.config import compose
+    cfg = compose(overrides=["task=ShadowHand"])["task"]
+    n = 400
+    env = ShadowHand.__new__(ShadowHand)
+    env.num_environments, env.device, env.native_task, env.last_step, env.first_randomization = n, "cpu", "ShadowHand", 0, True
+    env._task_params_struct = hand_params_from_cfg(cfg)
+    tensors = {"actor_scale": torch.ones(n, 8), "dof_limit_shift": torch.zeros(n, 48), "friction": -torch.ones(n)}
+    env.engine = types.SimpleNamespace(tensors=tensors)
+    ap = cfg["task"]["randomization_params"]["actor_params"]
+    np.random.seed(0)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        env._apply_actor_params(ap, None)
+    assert not w, [str(x.message) for x in w]
+    sc = tensors["actor_scale"].numpy().copy()
+    for col, (a, b) in {0: (0.5, 1.5), 1: (0.3, 3.0), 2: (0.75, 1.5), 3: (0.75, 1.5), 4: (0.3, 3.0), 5: (0.5, 1.5), 6: (0.95, 1.05)}.items():
+        assert sc[:, col].min() >= a - 1e-5 and sc[:, col].max() <= b + 1e-5 and sc[:, col].std() > 0.1 * (b - a), col
+    assert np.all(sc[:, 7] == 1.0)
+    sh = tensors["dof_limit_shift"].numpy()
+    assert abs(sh.std() - 0.01) < 0.001 and abs(sh.mean()) < 0.001 and np.abs(np.corrcoef(sh[:, 0], sh[:, 1])[0, 1]) < 0.2
+    fr = tensors["friction"].numpy()
+    assert fr.min() >= 0.7 - 1e-5 and fr.max() <= 1.3 + 1e-5
+    # a later randomisation of half the envs: setup_only columns stay, the others are re-drawn for exactly those envs
+    env.first_randomization = False
+    due = torch.zeros(n, dtype=torch.bool); due[::2] = True
+    env._apply_actor_params(ap, due)
+    sc2 = tensors["actor_scale"].numpy()
+    np.testing.assert_array_equal(sc2[:, [0, 5, 6]], sc[:, [0, 5, 6]])
+    np.testing.assert_array_equal(sc2[1::2], sc[1::2])
+    assert (sc2[::2, 1] != sc[::2, 1]).mean() > 0.95

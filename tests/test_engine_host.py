@@ -98,9 +98,12 @@ def test_host_build_on_heightfield_matches_oracle():
     assert contacts > 50   # the scenario does exercise contacts
 
 
-def test_host_build_of_hand_engine_matches_oracle():
+@pytest.mark.parametrize("scaled", [False, True])
+def test_host_build_of_hand_engine_matches_oracle(scaled):
     """csrc/core/hand_engine.hpp compiled for the host (fp32) against oracle/hand.py (fp64 restatement): hand + cube sub-steps
-    with finger/cube contacts, tendon rows, implicit PD drives; contact counts identical, states agree to fp32 rounding."""
+    with finger/cube contacts, tendon rows, implicit PD drives; contact counts identical, states agree to fp32 rounding.
+    scaled: with per-env `actor_params` factors (hand link masses, joint damping, drive stiffness, tendon stiffness / damping, object
+    mass and size; reference ShadowHand.yaml:104-159) -- and those factors do change the motion."""
     import ctypes as C
     from oracle.hand import OracleHandEngine
     from isaacgymenvs_amd.registry import load_model, load_extras, sensor_bodies
@@ -133,11 +136,28 @@ def test_host_build_of_hand_engine_matches_oracle():
     lib.hs_hand_fingertips(N, state.ctypes.data_as(C.c_void_p), root13.ctypes.data_as(C.c_void_p), tipsh.ctypes.data_as(C.c_void_p))
     np.testing.assert_allclose(tipsh, tips, atol=2e-5)
     total = 0
+    scale = None
+    if scaled:
+        scale = np.ones((N, 8), np.float32)
+        scale[:, 0] = rng.uniform(0.5, 1.5, N); scale[:, 1] = rng.uniform(0.3, 3.0, N); scale[:, 2] = rng.uniform(0.75, 1.5, N)
+        scale[:, 3] = rng.uniform(0.75, 1.5, N); scale[:, 4] = rng.uniform(0.3, 3.0, N); scale[:, 5] = rng.uniform(0.5, 1.5, N)
+        scale[:, 6] = rng.uniform(0.95, 1.05, N)
+        orc.scale[:] = scale
+        lsh = rng.normal(0, 0.03, (N, 2 * nd)).astype(np.float32)
+        orc.limit_shift[:] = lsh
+        plain = OracleHandEngine(spec, ex, N, sim, sensor_bodies("shadow_hand"))
+        plain.q[:] = orc.q; plain.qd[:] = orc.qd; plain.targets[:] = orc.targets; plain.obj[:] = orc.obj
     for it in range(12):
         orc.step()
         rc = lib.hs_step_hand(C.byref(P), N, state.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
-                              root13.ctypes.data_as(C.c_void_p), C.c_float(half), C.c_float(mass), C.c_float(inertia), C.c_float(mu))
+                              root13.ctypes.data_as(C.c_void_p), C.c_float(half), C.c_float(mass), C.c_float(inertia), C.c_float(mu),
+                              scale.ctypes.data_as(C.c_void_p) if scaled else None, lsh.ctypes.data_as(C.c_void_p) if scaled else None)
         assert rc == 0
+        np.testing.assert_allclose(out[:, 6 * ns:6 * ns + nd], orc.dof_force, atol=2e-2 * max(1.0, np.abs(orc.dof_force).max()))
+        if scaled and it < 3:
+            plain.step()
+            if it == 2:
+                assert np.abs(plain.q - orc.q).max() > 5e-3          # the factors matter
         np.testing.assert_array_equal(out[:, -1].astype(int), orc.ncontacts)
         total += int(orc.ncontacts.sum())
         np.testing.assert_allclose(state[:, 0:nd], orc.q, atol=2e-3)

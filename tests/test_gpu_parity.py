@@ -891,6 +891,89 @@ def test_shadow_hand_step_matches_cpu_restatement(object_type):
     assert "consecutive_successes" in extras
 
 
+@pytest.mark.parametrize("object_type", ["block", "egg"])
+def test_shadow_hand_actor_scales_and_limit_shifts_match_cpu_restatement(object_type):
+    """`actor_params` domain randomisation of the hand and the object (reference cfg/task/ShadowHand.yaml:89-161) as per-env tensors the
+    sub-step reads: link masses, joint damping, drive stiffness, tendon stiffness / damping, object mass and size (`actor_scale`),
+    joint-limit shifts (`dof_limit_shift`) -- against the CPU restatement run with the same factors."""
+    import isaacgymenvs_amd
+    from isaacgymenvs_amd.registry import load_extras
+    from oracle.tasks import OracleShadowHandEnv
+    n, seed = 48, 5
+    cfg = compose(overrides=["task=ShadowHand"])
+    cfg["task"]["env"]["numEnvs"] = n
+    cfg["task"]["env"]["objectType"] = object_type
+    env = isaacgymenvs_amd.make(seed=seed, task="ShadowHand", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True, cfg=cfg)
+    orc = OracleShadowHandEnv(load_model("shadow_hand"), load_extras("shadow_hand"), sensor_bodies("shadow_hand"),
+                              _sim_dict(env.sim_params), env._task_params_struct, n, seed=seed)
+    plain = OracleShadowHandEnv(load_model("shadow_hand"), load_extras("shadow_hand"), sensor_bodies("shadow_hand"),
+                                _sim_dict(env.sim_params), env._task_params_struct, n, seed=seed)
+    rng = np.random.default_rng(3)
+    sc = np.ones((n, 8), np.float32)
+    for col, (a, b) in enumerate([(0.5, 1.5), (0.3, 3.0), (0.75, 1.5), (0.75, 1.5), (0.3, 3.0), (0.5, 1.5), (0.95, 1.05)]):
+        sc[:, col] = rng.uniform(a, b, n)
+    lsh = rng.normal(0.0, 0.02, (n, 48)).astype(np.float32)
+    t = env.engine.tensors
+    assert tuple(t["actor_scale"].shape) == (n, 8) and float((t["actor_scale"] - 1).abs().max()) == 0.0
+    assert tuple(t["dof_limit_shift"].shape) == (n, 48) and float(t["dof_limit_shift"].abs().max()) == 0.0
+    t["actor_scale"][:] = _t(sc); t["dof_limit_shift"][:] = _t(lsh)
+    orc.eng.scale[:] = sc; orc.eng.limit_shift[:] = lsh
+    g = torch.Generator(device="cpu").manual_seed(7)
+    for step in range(6):
+        a = torch.rand((n, 20), generator=g) * 2 - 1
+        obs_d, rew, reset, extras = env.step(a.to(DEV))
+        o_obs, o_rew, o_reset = orc.step(a.numpy())
+        p_obs, _, _ = plain.step(a.numpy())
+        torch.cuda.synchronize()
+        obs = env.obs_buf.cpu().numpy()
+        assert np.isfinite(obs).all()
+        np.testing.assert_array_equal(env.engine.tensors["object_contact_count"].cpu().numpy() > 0, orc.eng.ncontacts > 0)
+        d = np.abs(obs - o_obs)
+        tol = 5e-3 * (1 + step)
+        kin = np.concatenate([d[:, :48], d[:, 72:161], d[:, 191:]], axis=1)
+        ok = kin.max(axis=1) < tol
+        assert ok.mean() > 0.9, (step, ok.mean(), kin.max())
+    # the factors matter: the unrandomised restatement has moved elsewhere (joint positions, unscaled to [-1, 1], are columns 0:24)
+    assert np.abs(p_obs[:, :24] - o_obs[:, :24]).max() > 0.05
+    assert float((t["actor_scale"].cpu() - torch.from_numpy(sc)).abs().max()) == 0.0       # the step does not touch them
+
+
+def test_shadow_hand_actor_params_block_of_the_task_config_reaches_the_engine():
+    """`task.randomize=True` with the randomization_params of cfg/task/ShadowHand.yaml as they are: every `actor_params` entry of the
+    hand and the object except the colours has an engine tensor behind it; `setup_only` entries are drawn once."""
+    import warnings
+    import isaacgymenvs_amd
+    n = 512
+    cfg = compose(overrides=["task=ShadowHand"])
+    cfg["task"]["env"]["numEnvs"] = n
+    cfg["task"]["task"]["randomize"] = True
+    cfg["task"]["task"]["randomization_params"]["frequency"] = 2
+    np.random.seed(0)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        env = isaacgymenvs_amd.make(seed=1, task="ShadowHand", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True, cfg=cfg)
+        env.step(torch.zeros((n, 20), device=DEV))
+    assert not [x for x in w if "actor_params" in str(x.message)], [str(x.message) for x in w]
+    t = env.engine.tensors
+    sc = t["actor_scale"].cpu().numpy()
+    for col, (a, b) in {0: (0.5, 1.5), 1: (0.3, 3.0), 2: (0.75, 1.5), 3: (0.75, 1.5), 4: (0.3, 3.0), 5: (0.5, 1.5), 6: (0.95, 1.05)}.items():
+        assert sc[:, col].min() >= a - 1e-5 and sc[:, col].max() <= b + 1e-5 and sc[:, col].std() > 0.1 * (b - a), col
+    assert float(np.abs(sc[:, 7] - 1).max()) == 0.0
+    sh = t["dof_limit_shift"].cpu().numpy()
+    assert abs(sh.std() - 0.01) < 0.002 and abs(sh.mean()) < 0.002                       # additive gaussian (0, 0.01), one per joint and env
+    fr = t["friction"].cpu().numpy()
+    assert fr.min() >= 0.7 - 1e-5 and fr.max() <= 1.3 + 1e-5 and fr.std() > 0.05
+    # setup_only (masses, object size): not re-drawn when envs are re-randomised after a reset; the others are
+    before = sc.copy()
+    for _ in range(3):
+        env.reset_buf[:] = 1
+        env.step(torch.zeros((n, 20), device=DEV))
+    sc2 = t["actor_scale"].cpu().numpy()
+    np.testing.assert_array_equal(sc2[:, [0, 5, 6]], before[:, [0, 5, 6]])
+    assert (sc2[:, 1] != before[:, 1]).mean() > 0.9
+    assert torch.isfinite(env.obs_buf).all()
+
+
 @pytest.mark.parametrize("obs_type,nobs", [("openai", 42), ("full_no_vel", 77), ("full", 157)])
 def test_shadow_hand_observation_types_asymmetric_states_and_random_forces(obs_type, nobs):
     """observationType variants (shadow_hand.py:472-526) + asymmetric_observations (states_buf, :584) + random object forces
