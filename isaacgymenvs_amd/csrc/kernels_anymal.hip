@@ -324,6 +324,25 @@ __global__ void anymal_init_kernel(View v, AnymalParams p, AnymalTerrainDesc T, 
     if (e == 0) for (int k = 0; k < 16; ++k) { v.ep_stats[k] = 0.f; v.ep_means[k] = 0.f; }
 }
 
+// reset_idx(env_ids) outside step(), curriculum part: torch.norm(self.commands[env_ids, :2]) over the envs of THIS call (:431), left in
+// ep_stats[15] for the reset kernel below (one block; mode 1 clears the slot again for the next step's own accumulation)
+__global__ __launch_bounds__(256) void anymal_reset_cmdnorm_kernel(View v, const long long* __restrict__ ids, int n, int mode) {
+    if (mode == 1) { if (threadIdx.x == 0) v.ep_stats[15] = 0.f; return; }
+    __shared__ float part[4];
+    const int N = v.N;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int e = (int)ids[i];
+        if (e < 0 || e >= N) continue;
+        const float cx = v.commands[e], cy = v.commands[N + e];
+        acc += cx * cx + cy * cy;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) v.ep_stats[15] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
 // reset_idx(env_ids) (:384-425) outside step(): same draws as the in-step reset of the env's current episode number
 __global__ void anymal_reset_kernel(View v, AnymalParams p, AnymalTerrainDesc T, const long long* __restrict__ ids, int n) {
     MI_NO_CONTRACT
@@ -333,6 +352,18 @@ __global__ void anymal_reset_kernel(View v, AnymalParams p, AnymalTerrainDesc T,
     const int e = (int)ids[i], N = v.N;
     if (e < 0 || e >= N) return;
     const uint32_t genv = (uint32_t)(v.env_offset + e), uep = (uint32_t)v.episode[e];
+    // update_terrain_level (:427-435), as in the step's own reset: not before the first episode, not without curriculum
+    if (p.curriculum && T.hs != nullptr && uep > 0) {
+        const float ddx = v.root[e] - v.env_origins[e], ddy = v.root[N + e] - v.env_origins[N + e];
+        const float distance = sqrtf(ddx * ddx + ddy * ddy);
+        const float cn = sqrtf(v.ep_stats[15]);
+        int level = v.terrain_levels[e];
+        level -= (distance < cn * p.max_episode_length_s * 0.25f) ? 1 : 0;
+        level += (distance > T.env_length / 2.f) ? 1 : 0;
+        level = (level < 0 ? 0 : level) % T.levels;
+        v.terrain_levels[e] = level;
+        for (int k = 0; k < 3; ++k) v.env_origins[k * N + e] = T.origins[(level * T.types + v.terrain_types[e]) * 3 + k];
+    }
     for (int d = 0; d < ND; ++d) {
         v.dof[d * N + e] = p.default_dof_pos[d] * ((1.5f - 0.5f) * uniform01(v.seed, genv, uep, (uint32_t)d) + 0.5f);
         v.dof[(ND + d) * N + e] = (0.1f - (-0.1f)) * uniform01(v.seed, genv, uep, (uint32_t)(ND + d)) + (-0.1f);
@@ -403,7 +434,10 @@ hipError_t launch_init_anymal(const View& v, const AnymalParams& tp, const Anyma
     return hipGetLastError();
 }
 hipError_t launch_reset_anymal(const View& v, const AnymalParams& tp, const AnymalTerrainDesc& T, const long long* ids, int n, hipStream_t s) {
+    const bool levels = tp.curriculum && T.hs != nullptr;
+    if (levels) hipLaunchKernelGGL(anymal_reset_cmdnorm_kernel, dim3(1), dim3(256), 0, s, v, ids, n, 0);
     hipLaunchKernelGGL(anymal_reset_kernel, dim3((n + 127) / 128), dim3(128), 0, s, v, tp, T, ids, n);
+    if (levels) hipLaunchKernelGGL(anymal_reset_cmdnorm_kernel, dim3(1), dim3(256), 0, s, v, ids, n, 1);
     return hipGetLastError();
 }
 

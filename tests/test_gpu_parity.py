@@ -501,6 +501,46 @@ def test_anymal_terrain_step_matches_cpu_restatement():
     assert set(extras["episode"].keys()) >= {"rew_lin_vel_xy", "rew_air_time", "terrain_level"}
 
 
+def test_anymal_terrain_explicit_reset_idx_moves_the_envs_through_the_curriculum():
+    """reset_idx(env_ids) called from outside step() runs update_terrain_level too (anymal_terrain.py:384-435): the walked distance of
+    each env against `torch.norm(commands[env_ids, :2])` of the envs of THIS call, new level -> new origin -> new spawn position."""
+    n, seed = 256, 4
+    env = _make_env("AnymalTerrain", n, seed=seed)
+    orc = _anymal_oracle(env, n, seed)
+    t = env.engine.tensors
+    a = torch.zeros((n, 12))
+    for _ in range(2):
+        env.step(a.to(DEV)); orc.step(a.numpy())
+    # put the robots at chosen distances from their origins: a third stays (level down), a third walks past half a tile (level up)
+    rng = np.random.default_rng(0)
+    shift = np.zeros((n, 2), np.float32)
+    far = rng.random(n) < 0.35
+    shift[far, 0] = 5.0
+    mid = (~far) & (rng.random(n) < 0.5)
+    shift[mid, 1] = 2.5
+    root = env.root_states.clone(); root[:, 0:2] += _t(shift); t["root_states"][:] = root
+    orc.eng.root[:, 0:2] += shift
+    env.commands[:, 0:2] = 0.02; orc.commands[:, 0:2] = 0.02     # norm over the 150 envs of the call ~ 0.35 -> "too slow" below 1.7 m
+    lv0 = t["terrain_levels"].cpu().numpy().copy()
+    np.testing.assert_array_equal(lv0, orc.terrain_levels)
+    ids = np.sort(rng.choice(n, 150, replace=False))
+    env.reset_idx(torch.as_tensor(ids, device=DEV))
+    orc.reset_idx(ids)
+    torch.cuda.synchronize()
+    lv1 = t["terrain_levels"].cpu().numpy()
+    np.testing.assert_array_equal(lv1, orc.terrain_levels)
+    assert (lv1[ids] != lv0[ids]).mean() > 0.3 and (lv1[ids] > lv0[ids]).any() and (lv1[ids] < lv0[ids]).any()
+    rest = np.setdiff1d(np.arange(n), ids)
+    np.testing.assert_array_equal(lv1[rest], lv0[rest])
+    np.testing.assert_allclose(t["env_origins"].cpu().numpy(), orc.env_origins, atol=1e-6)
+    np.testing.assert_allclose(env.root_states.cpu().numpy()[ids], orc.eng.root[ids], atol=1e-5)
+    assert float(t["episode_step_stats"].abs().max()) == 0.0       # the norm's scratch slot is clear again for the next step
+    # and the next step still agrees (the step's own curriculum accumulation starts from zero)
+    obs_d, rew, reset, _ = env.step(a.to(DEV)); o_obs, _, o_reset = orc.step(a.numpy())
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(t["terrain_levels"].cpu().numpy(), orc.terrain_levels)
+
+
 def test_anymal_terrain_full_size_properties():
     n = 4096   # BASELINE configs[3]: AnymalTerrain num_envs=4096
     env = _make_env("AnymalTerrain", n, seed=42)
