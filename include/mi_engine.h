@@ -243,7 +243,9 @@ int mi_engine_set_terrain(MiEngine* e, const int16_t* height_samples, int rows, 
  * default 1 for the tasks whose arena carries "self_contact_impulse", rejected with 1 elsewhere),
  * "multi_wave" 0 | 32 (physics sub-step of Ant / Anymal / AnymalTerrain spread over the four waves of a workgroup of that many
  * envs -- same results up to summation order, see csrc/core/engine_mw.hpp; other tasks ignore it),
- * "steps" (the control-step counter: observation-ring parity and per-step RNG counters; restore it together with the arena) */
+ * "steps" (the control-step counter: observation-ring parity and per-step RNG counters; restore it together with the arena),
+ * "terrain_slope_threshold" (AnymalTerrain: terrain.slopeTreshold of the reference's height-field -> triangle-mesh conversion,
+ * anymal_terrain.py:576; steeper cell edges are levelled to their lower end in the ground query; 0 = off) */
 int mi_engine_set_option(MiEngine* e, const char* key, double value);
 /* Observation (which = 0) / action (which = 1) noise of the domain randomisation, applied inside the step kernels (replaces the
  * `noise_lambda` closures the reference builds in VecTask.apply_randomizations, vec_task.py:650-718, and runs as torch ops on the

@@ -392,7 +392,8 @@ __global__ void anymal_reset_kernel(View v, AnymalParams p, AnymalTerrainDesc T,
 }
 
 static HeightfieldGround ground_of(const AnymalTerrainDesc& T) {
-    return HeightfieldGround{T.hs, T.rows, T.cols, T.hscale, T.vscale, T.border};
+    return HeightfieldGround{T.hs, T.rows, T.cols, T.hscale, T.vscale, T.border,
+                             T.slope_threshold > 0.f ? T.slope_threshold * T.hscale / T.vscale : 3.0e38f};
 }
 static ActParams act_of(const AnymalParams& tp) {
     ActParams ap{};

@@ -423,6 +423,11 @@ extern "C" int mi_engine_set_option(MiEngine* e, const char* key, double value) 
     }
     // control-step counter (observation ring parity, AnymalTerrain push schedule, noise counters): part of a state checkpoint
     if (!strcmp(key, "steps")) { if (value < 0) return fail("steps < 0"); e->steps = (unsigned long long)value; return 0; }
+    if (!strcmp(key, "terrain_slope_threshold")) {   // terrain.slopeTreshold of the mesh generator (anymal_terrain.py:576); 0 = off
+        if (e->task != T_ANYMAL) return fail("terrain_slope_threshold: only AnymalTerrain has a terrain");
+        e->terrain.slope_threshold = (float)value;
+        return 0;
+    }
     return fail(std::string("unknown option: ") + key);
 }
 static_assert(sizeof(MiNoiseParams) == sizeof(NoiseParams), "MiNoiseParams layout");
@@ -445,6 +450,7 @@ extern "C" int mi_engine_get_option(const MiEngine* e, const char* key, double* 
     if (!strcmp(key, "self_collision")) { *out = e->v.lamp != nullptr ? 1.0 : 0.0; return 0; }
     if (!strcmp(key, "multi_wave")) { *out = e->v.mw; return 0; }
     if (!strcmp(key, "steps")) { *out = (double)e->steps; return 0; }
+    if (!strcmp(key, "terrain_slope_threshold")) { *out = e->terrain.slope_threshold; return 0; }
     return fail(std::string("unknown option: ") + key);
 }
 

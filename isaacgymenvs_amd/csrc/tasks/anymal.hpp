@@ -52,6 +52,7 @@ struct AnymalTerrainDesc {   // device-side view of the terrain (set once throug
     const float* origins;    // [levels][types][3] terrain.env_origins
     int levels, types;
     float env_length;
+    float slope_threshold;   // terrain.slopeTreshold (anymal_terrain.py:576), <= 0: the uncorrected mesh (option "terrain_slope_threshold")
 };
 
 // body indices in the compiled model (base, then LF, RF, LH, RH x {HIP, THIGH, SHANK}); `footName: SHANK`, `kneeName: THIGH`

@@ -491,6 +491,8 @@ class Engine:
                                           self.terrain_origins.data_ptr(), self.terrain_origins.shape[0],
                                           self.terrain_origins.shape[1], float(terrain.env_length),
                                           int(getattr(terrain, "max_init_level", 0))))
+            if float(getattr(terrain, "slope_threshold", 0.0) or 0.0) > 0.0:
+                check(L.mi_engine_set_option(h, b"terrain_slope_threshold", float(terrain.slope_threshold)), L)
         if dev.type == "cuda":
             with torch.cuda.device(dev):
                 check(L.mi_engine_init_state(h, self._stream()), L)

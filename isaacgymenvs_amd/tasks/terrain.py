@@ -183,6 +183,8 @@ class Terrain:
         else:
             self.randomized_terrain()
         self.heightsamples = self.height_field_raw
+        # anymal_terrain.py:576 hands this to the height-field -> triangle-mesh conversion; the engine's ground query applies it
+        self.slope_threshold = float(cfg.get("slopeTreshold", 0.0) or 0.0)
 
     def _new_sub(self):
         return SubTerrain("terrain", width=self.width_per_env_pixels, length=self.width_per_env_pixels,

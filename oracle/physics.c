@@ -316,12 +316,15 @@ static void chol_solve(int n, real L[MAXV][MAXV], const real *b, real *x) {
 /* Ground: the z = ground_z plane (hs == NULL) or a height field sampled on a regular grid, int16 heights, laid out
  * like the reference's `Terrain.height_field_raw` (tasks/anymal_terrain.py:569, converted to a triangle mesh by
  * `convert_heightfield_to_trimesh`, :575, each cell split along the (i,j)-(i+1,j+1) diagonal; vertex (i,j) sits at
- * world (i*hscale - border, j*hscale - border, h*vscale), :208-210).  The surface used here is exactly that
- * piecewise-linear mesh (without the slope-threshold vertex correction). */
+ * world (i*hscale - border, j*hscale - border, h*vscale), :208-210).  The surface used here is that piecewise-linear
+ * mesh; the generator's slope correction (slopeTreshold: the lower vertex of a steep edge slides under the upper one) is
+ * applied per query by levelling every cell edge that rises by more than thr raw units to its lower end -- see
+ * oracle/terrain_mesh.py for the corrected mesh itself and how close this comes to it. */
 typedef struct {
     const int16_t *hs; /* [rows*cols], row-major: hs[i*cols + j] */
     int32_t rows, cols;
     real hscale, vscale, border;
+    real thr;          /* slope_threshold * hscale / vscale; <= 0: no correction */
 } OrGround;
 
 /* height z and unit normal n of the surface under world (x, y) */
@@ -336,6 +339,13 @@ static void ground_query(const OrGround *g, real ground_z, real x, real y, real 
     real h00 = g->hs[i * g->cols + j], h10 = g->hs[(i + 1) * g->cols + j], h01 = g->hs[i * g->cols + j + 1],
          h11 = g->hs[(i + 1) * g->cols + j + 1];
     real dzx, dzy, zz;
+    if (g->thr > 0) {
+        real m;
+        if (RFABS(h10 - h00) > g->thr) { m = h00 < h10 ? h00 : h10; h00 = m; h10 = m; }
+        if (RFABS(h11 - h01) > g->thr) { m = h01 < h11 ? h01 : h11; h01 = m; h11 = m; }
+        if (RFABS(h01 - h00) > g->thr) { m = h00 < h01 ? h00 : h01; h00 = m; h01 = m; }
+        if (RFABS(h11 - h10) > g->thr) { m = h10 < h11 ? h10 : h11; h10 = m; h11 = m; }
+    }
     if (fx >= fy) { dzx = h10 - h00; dzy = h11 - h10; } else { dzx = h11 - h01; dzy = h01 - h00; }
     zz = h00 + dzx * fx + dzy * fy;
     *z = zz * g->vscale;
@@ -343,6 +353,8 @@ static void ground_query(const OrGround *g, real ground_z, real x, real y, real 
     real inv = 1 / RSQRT(sx * sx + sy * sy + 1);
     n[0] = -sx * inv; n[1] = -sy * inv; n[2] = inv;
 }
+/* the query by itself (tests/test_terrain.py compares it with oracle/terrain_mesh.py) */
+void or_ground_query(const OrGround *g, real ground_z, real x, real y, real *z, real *n) { ground_query(g, ground_z, x, y, z, n); }
 
 /* contact frame: n, t1 = normalize(x - n (n.x)), t2 = n x t1   (n = z gives t1 = x, t2 = y) */
 static void contact_frame(const real *n, real *t1, real *t2) {

@@ -446,7 +446,8 @@ class OracleAnymalTerrainEnv:
         from .engine import OracleEngine
         self.N, self.p, self.nd, self.spec = num_envs, params, spec.nd, spec
         self.eng = OracleEngine(spec, num_envs, params=sim_params, precision=precision)
-        self.eng.set_ground(terrain.heightsamples, terrain.horizontal_scale, terrain.vertical_scale, terrain.border_size)
+        self.eng.set_ground(terrain.heightsamples, terrain.horizontal_scale, terrain.vertical_scale, terrain.border_size,
+                            slope_threshold=float(getattr(terrain, "slope_threshold", 0.0) or 0.0))
         self.eng.want_netf = True
         self.terrain = terrain
         self.seed, self.off, self.cfi = fold_seed(seed), env_id_offset, control_freq_inv

@@ -60,11 +60,17 @@ def test_host_build_of_engine_core_matches_oracle(task, z_lo, z_hi, gear, full):
         assert np.abs(out[:, 6 * len(sb):6 * len(sb) + nd] - orc.dof_force).max() < 2e-3 * max(1.0, np.abs(orc.dof_force).max())
 
 
-def test_host_build_on_heightfield_matches_oracle():
-    """ANYmal on a random rough height field: general contact normals, per-env friction, per-body net contact forces."""
+@pytest.mark.parametrize("slope_threshold", [0.0, 0.5])
+def test_host_build_on_heightfield_matches_oracle(slope_threshold):
+    """ANYmal on a random rough height field: general contact normals, per-env friction, per-body net contact forces.
+    slope_threshold 0.5 (terrain.slopeTreshold of AnymalTerrain.yaml): edges steeper than that are levelled to their lower end, as the
+    reference's mesh generator turns them into vertical walls -- most block edges of this field (up to 60 raw units, threshold 10)."""
+    import ctypes as C
     spec = load_model("anymal")
     n = 128
     lib = hostsim.build()
+    lib.hs_set_slope_threshold.argtypes = [C.c_float]
+    lib.hs_set_slope_threshold.restype = None
     rng = np.random.default_rng(3)
     rows, cols, hscale, vscale, border = 120, 140, 0.1, 0.005, 2.0
     hs = (rng.integers(-30, 30, (rows // 4 + 1, cols // 4 + 1)).repeat(4, 0).repeat(4, 1)[:rows, :cols]
@@ -76,7 +82,8 @@ def test_host_build_on_heightfield_matches_oracle():
     tau = rng.uniform(-80, 80, (n, spec.nd))
     mu = rng.uniform(0.5, 1.25, n).astype(np.float32)
     orc = OracleEngine(spec, n, params=sim, precision="f64")
-    orc.set_ground(hs, hscale, vscale, border)
+    orc.set_ground(hs, hscale, vscale, border, slope_threshold=slope_threshold)
+    lib.hs_set_slope_threshold(slope_threshold * hscale / vscale)
     orc.root[:] = root; orc.q[:] = q; orc.qd[:] = qd
     nd, nsph = spec.nd, len(spec.sph_body)
     st = np.zeros((n, 13 + 2 * nd + 3 * nsph + nd), np.float32)
@@ -95,6 +102,7 @@ def test_host_build_on_heightfield_matches_oracle():
         assert e < 5e-4 * scale * (it + 1), (it, e)
         assert np.abs(netf - orc.netf).max() < 2e-3 * max(1.0, np.abs(orc.netf).max())
         contacts += int((np.abs(orc.netf).sum(-1) > 0).sum())
+    lib.hs_set_slope_threshold(0.0)
     assert contacts > 50   # the scenario does exercise contacts
 
 

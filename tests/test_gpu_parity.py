@@ -541,6 +541,26 @@ def test_anymal_terrain_explicit_reset_idx_moves_the_envs_through_the_curriculum
     np.testing.assert_array_equal(t["terrain_levels"].cpu().numpy(), orc.terrain_levels)
 
 
+def test_anymal_terrain_slope_threshold_reaches_the_ground_query():
+    """terrain.slopeTreshold (AnymalTerrain.yaml, anymal_terrain.py:576) -> engine option `terrain_slope_threshold`: on by default, and
+    the stairs / obstacle tiles carry the robots differently once it is switched off (risers become 0.1 m ramps again)."""
+    n = 512
+    env = _make_env("AnymalTerrain", n, seed=8)
+    assert env.engine.get_option("terrain_slope_threshold") == pytest.approx(0.5)
+    other = _make_env("AnymalTerrain", n, seed=8)
+    other.engine.set_option("terrain_slope_threshold", 0.0)
+    a = torch.zeros((n, 12), device=DEV)
+    for _ in range(40):
+        env.step(a); other.step(a)
+    torch.cuda.synchronize()
+    za, zb = env.root_states[:, 2].cpu().numpy(), other.root_states[:, 2].cpu().numpy()
+    assert np.isfinite(za).all() and np.isfinite(zb).all()
+    types = env.engine.tensors["terrain_types"].cpu().numpy()
+    d = np.abs(za - zb)
+    assert (d > 1e-3).mean() > 0.1                                    # a good part of the robots stand on steps or obstacles
+    assert d.max() < 0.5
+
+
 def test_anymal_terrain_full_size_properties():
     n = 4096   # BASELINE configs[3]: AnymalTerrain num_envs=4096
     env = _make_env("AnymalTerrain", n, seed=42)

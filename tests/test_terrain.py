@@ -129,3 +129,55 @@ def test_curriculum_difficulty_grows_with_level():
 def test_plane_terrain_builds_nothing():
     ter = T.Terrain(dict(terrainType="plane"), num_robots=4)
     assert not hasattr(ter, "heightsamples")
+
+
+def test_ground_query_slope_correction_tracks_the_corrected_trimesh():
+    """terrain.slopeTreshold (anymal_terrain.py:576): the reference's mesh generator slides the lower vertex of a steep edge under the
+    upper one.  The engine's ground query levels steep cell edges to their lower end instead (csrc/core/engine.hpp, oracle/physics.c);
+    oracle/terrain_mesh.py holds the corrected mesh itself (restated from the Isaac Gym package's terrain_utils, not in /root/reference)
+    and this test measures how close the two surfaces are on the task's own terrain."""
+    from isaacgymenvs_amd.tasks.terrain import Terrain
+    from isaacgymenvs_amd.utils.config import compose
+    from oracle.terrain_mesh import snapped_height, trimesh_height, trimesh_vertices
+    cfg = compose(overrides=["task=AnymalTerrain"])["task"]["env"]["terrain"]
+    t = Terrain(cfg, num_robots=512, seed=3)
+    assert t.slope_threshold == 0.5
+    hf, hs, vs = t.height_field_raw, t.horizontal_scale, t.vertical_scale
+    rng = np.random.default_rng(0)
+    n = 60000
+    px = rng.uniform(2 * hs, (hf.shape[0] - 3) * hs, n); py = rng.uniform(2 * hs, (hf.shape[1] - 3) * hs, n)
+    exact = trimesh_height(hf, hs, vs, t.slope_threshold, px, py)
+    snapped = np.abs(snapped_height(hf, hs, vs, t.slope_threshold, px, py) - exact)
+    plain = np.abs(snapped_height(hf, hs, vs, None, px, py) - exact)
+    assert (snapped < 1e-3).mean() > 0.96 and snapped.mean() < 1e-3           # measured 97.0 %, mean 0.6 mm
+    assert (plain < 1e-3).mean() < 0.90 and plain.mean() > 5 * snapped.mean()  # the uncorrected grid: 88 %, mean 6.9 mm
+    # without a threshold the two restatements are the same surface
+    exact0 = trimesh_height(hf, hs, vs, None, px[:5000], py[:5000], reach=0)
+    np.testing.assert_allclose(snapped_height(hf, hs, vs, None, px[:5000], py[:5000]), exact0, atol=1e-9)
+    # the corrected mesh really has vertical risers: a stair tile has vertices that share their xy position with a neighbour
+    xx, yy, _ = trimesh_vertices(hf, hs, vs, t.slope_threshold)
+    moved = (np.abs(xx - np.arange(hf.shape[0])[:, None] * hs) > 1e-9) | (np.abs(yy - np.arange(hf.shape[1])[None, :] * hs) > 1e-9)
+    assert 0.02 < moved.mean() < 0.5
+
+
+def test_oracle_ground_query_applies_the_slope_threshold():
+    """oracle/physics.c ground_query against its numpy twin (oracle/terrain_mesh.py::snapped_height):
+    a noisy stair field queried point by point through the C library's or_ground_query."""
+    import ctypes as C
+    from oracle.engine import OracleEngine, _ptr
+    from isaacgymenvs_amd.registry import load_model
+    from oracle.terrain_mesh import snapped_height
+    rng = np.random.default_rng(1)
+    rows, cols, hs, vs, border = 60, 50, 0.1, 0.005, 1.0
+    hf = (np.arange(rows)[:, None] // 3 * 26 + rng.integers(-2, 3, (rows, cols))).astype(np.int16)     # stairs of 13 cm, noisy treads
+    eng = OracleEngine(load_model("anymal"), 1, precision="f64")
+    eng.set_ground(hf, hs, vs, border, slope_threshold=0.5)
+    px = rng.uniform(0.3, (rows - 3) * hs, 400); py = rng.uniform(0.3, (cols - 3) * hs, 400)
+    z = np.zeros(1); nrm = np.zeros(3)
+    got = []
+    for x, y in zip(px, py):
+        eng.lib.or_ground_query(C.byref(eng.ground), C.c_double(0.0), C.c_double(x - border), C.c_double(y - border), _ptr(z), _ptr(nrm))
+        got.append(z[0])
+        assert abs(np.linalg.norm(nrm) - 1) < 1e-12 and nrm[2] > 0
+    np.testing.assert_allclose(got, snapped_height(hf, hs, vs, 0.5, px, py), atol=1e-12)
+    assert np.abs(np.array(got) - snapped_height(hf, hs, vs, None, px, py)).max() > 0.05
