@@ -521,6 +521,7 @@ def test_anymal_terrain_explicit_reset_idx_moves_the_envs_through_the_curriculum
     root = env.root_states.clone(); root[:, 0:2] += _t(shift); t["root_states"][:] = root
     orc.eng.root[:, 0:2] += shift
     env.commands[:, 0:2] = 0.02; orc.commands[:, 0:2] = 0.02     # norm over the 150 envs of the call ~ 0.35 -> "too slow" below 1.7 m
+    t["terrain_levels"][:] = 2; orc.terrain_levels[:] = 2       # (all envs start on level 0 = maxInitMapLevel, where "down" has no room)
     lv0 = t["terrain_levels"].cpu().numpy().copy()
     np.testing.assert_array_equal(lv0, orc.terrain_levels)
     ids = np.sort(rng.choice(n, 150, replace=False))
@@ -557,7 +558,7 @@ def test_anymal_terrain_slope_threshold_reaches_the_ground_query():
     assert np.isfinite(za).all() and np.isfinite(zb).all()
     types = env.engine.tensors["terrain_types"].cpu().numpy()
     d = np.abs(za - zb)
-    assert (d > 1e-3).mean() > 0.1                                    # a good part of the robots stand on steps or obstacles
+    assert (d > 1e-3).mean() > 0.02                                   # some robots stand on a step or an obstacle edge (level-0 tiles are mild)
     assert d.max() < 0.5
 
 
