@@ -147,15 +147,12 @@ __global__ __launch_bounds__(64) void hand_post_kernel(View v, HandView hv, Hand
     // obs_type 0: the vector IS obs_buf; otherwise it goes to full_state and hand_obs_select_kernel picks obs_buf's columns.
     // With asymmetric observations full_state (= states_buf) is written in both cases.
     const bool direct = p.obs_type == 0, to_full = !direct || p.asymmetric_obs != 0;
-    float* ob = v.obs + (size_t)e * kHandObs;
-    float* oc = v.obs_out + ((size_t)v.ring * N + e) * kHandObs;
-    float* fs = hv.full_state + (size_t)e * kHandObs;
-    auto emit = [&](int k, float val) MI_LAMBDA {
-        if (valid) {
-            if (direct) { ob[k] = val; oc[k] = fminf(fmaxf(val, -v.clip_obs), v.clip_obs); }
-            if (to_full) fs[k] = val;
-        }
-    };
+    // The 211 columns of an env are a row of the row-major obs tensors: written lane by lane, every store instruction of the wave
+    // touches 64 rows (64 cache lines for 4 bytes each).  They are staged in LDS instead, column-major with a pad ([k][65]: the
+    // lanes of a column and the columns of a lane both fall on distinct banks), and the wave writes the rows out together below,
+    // 64 consecutive floats per store instruction.
+    __shared__ float stage[kHandObs * 65];
+    auto emit = [&](int k, float val) MI_LAMBDA { stage[k * 65 + (int)threadIdx.x] = val; };
     sfor<ND>([&](auto D) MI_LAMBDA {
         constexpr int d = D;
         emit(d, (2.0f * sim.q[d] - HM::dof_upper[d] - HM::dof_lower[d]) / (HM::dof_upper[d] - HM::dof_lower[d]));   // unscale
@@ -187,6 +184,19 @@ __global__ __launch_bounds__(64) void hand_post_kernel(View v, HandView hv, Hand
     nres = wave_sum(nres); fin = wave_sum(fin);
     if ((threadIdx.x & 63) == 0 && nres > 0.f) { atomicAdd(hv.ws, nres); atomicAdd(hv.ws + 1, fin); }
     episode_stats(v, e, valid, r, rs, prog);
+    __syncthreads();
+    for (int row = 0; row < 64; ++row) {                      // wave-uniform: env of lane `row`
+        const int er = __shfl(e0, row);
+        if (er >= N) continue;
+        float* ob = v.obs + (size_t)er * kHandObs;
+        float* oc = v.obs_out + ((size_t)v.ring * N + er) * kHandObs;
+        float* fs = hv.full_state + (size_t)er * kHandObs;
+        for (int k = (int)threadIdx.x; k < kHandObs; k += 64) {
+            const float val = stage[k * 65 + row];
+            if (direct) { ob[k] = val; oc[k] = fminf(fmaxf(val, -v.clip_obs), v.clip_obs); }
+            if (to_full) fs[k] = val;
+        }
+    }
     if (!valid) return;
     v.rew[e] = r;
     v.reset[e] = rs;
