@@ -251,7 +251,7 @@ int mi_engine_set_option(MiEngine* e, const char* key, double value);
  * `noise_lambda` closures the reference builds in VecTask.apply_randomizations, vec_task.py:650-718, and runs as torch ops on the
  * buffers every step, :371-372,397-399).  value = op(x, corr + white): `white` ~ N(a, b) or U(a, b) fresh every step, `corr` a
  * per-(env, element) normal draw made once, scaled by (a_corr, b_corr); the host passes ranges already blended by the schedule.
- * dist 0 switches the noise off.  Cartpole, Ant, Humanoid. */
+ * dist 0 switches the noise off.  Cartpole, Ant, Humanoid, ShadowHand (obs_buf only: states_buf stays clean). */
 typedef struct MiNoiseParams {
     int32_t dist;          /* 0 off, 1 gaussian, 2 uniform */
     int32_t op;            /* 0 additive, 1 scaling */

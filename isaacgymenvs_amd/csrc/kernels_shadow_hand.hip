@@ -79,7 +79,9 @@ __global__ void hand_pre_kernel(View v, HandView hv, HandParams p, const float* 
     sfor<kHandAct>([&](auto A_) MI_LAMBDA {
         constexpr int a = A_;
         const int d = p.actuated[a];
-        const float act = fminf(fmaxf(actions_in[(size_t)e * kHandAct + a], -p.clip_actions), p.clip_actions);   // vec_task.py:374
+        float raw = actions_in[(size_t)e * kHandAct + a];
+        if (v.act_noise.dist != 0) raw = apply_noise(v.act_noise, v.seed, genv, v.step, 1u, (uint32_t)a, raw);   // vec_task.py:371-372
+        const float act = fminf(fmaxf(raw, -p.clip_actions), p.clip_actions);                                      // vec_task.py:374
         v.actions[a * N + e] = act;
         // the actuated dof index is a runtime table: read the limits through a tiny switch-free lookup
         float lo = 0.f, up = 0.f;
@@ -193,7 +195,13 @@ __global__ __launch_bounds__(64) void hand_post_kernel(View v, HandView hv, Hand
         float* fs = hv.full_state + (size_t)er * kHandObs;
         for (int k = (int)threadIdx.x; k < kHandObs; k += 64) {
             const float val = stage[k * 65 + row];
-            if (direct) { ob[k] = val; oc[k] = fminf(fmaxf(val, -v.clip_obs), v.clip_obs); }
+            if (direct) {
+                // observation noise of the domain randomisation: on obs_buf only, after the reward was computed from the clean state
+                // (vec_task.py:397-399); states_buf stays clean
+                const float nv = v.obs_noise.dist != 0 ? apply_noise(v.obs_noise, v.seed, (uint32_t)(v.env_offset + er), v.step, 0u, (uint32_t)k, val) : val;
+                ob[k] = nv;
+                oc[k] = fminf(fmaxf(nv, -v.clip_obs), v.clip_obs);
+            }
             if (to_full) fs[k] = val;
         }
     }
@@ -212,7 +220,8 @@ __global__ void hand_obs_select_kernel(View v, HandView hv, HandParams p) {
     const int no = p.num_obs;
     if (i >= v.N * no) return;
     const int e = i / no, k = i - e * no;
-    const float val = hv.full_state[(size_t)e * kHandObs + p.obs_map[k]];
+    float val = hv.full_state[(size_t)e * kHandObs + p.obs_map[k]];
+    if (v.obs_noise.dist != 0) val = apply_noise(v.obs_noise, v.seed, (uint32_t)(v.env_offset + e), v.step, 0u, (uint32_t)k, val);
     v.obs[(size_t)e * no + k] = val;
     v.obs_out[((size_t)v.ring * v.N + e) * no + k] = fminf(fmaxf(val, -v.clip_obs), v.clip_obs);
 }

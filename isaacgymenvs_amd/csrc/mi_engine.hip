@@ -435,8 +435,8 @@ extern "C" int mi_engine_set_noise(MiEngine* e, int which, const MiNoiseParams* 
     if (!e || !p) return fail("mi_engine_set_noise: null argument");
     if (which != 0 && which != 1) return fail("mi_engine_set_noise: which must be 0 (observations) or 1 (actions)");
     if (p->dist < 0 || p->dist > 2 || p->op < 0 || p->op > 1) return fail("mi_engine_set_noise: dist in {0,1,2}, op in {0,1}");
-    if (e->task != T_CARTPOLE && e->task != T_ANT && e->task != T_HUMANOID && p->dist != 0)
-        return fail("mi_engine_set_noise: in-kernel noise exists for Cartpole, Ant and Humanoid");
+    if (e->task != T_CARTPOLE && e->task != T_ANT && e->task != T_HUMANOID && e->task != T_SHADOWHAND && p->dist != 0)
+        return fail("mi_engine_set_noise: in-kernel noise exists for Cartpole, Ant, Humanoid and ShadowHand");
     memcpy(which == 0 ? &e->v.obs_noise : &e->v.act_noise, p, sizeof(NoiseParams));
     return 0;
 }

@@ -269,7 +269,7 @@ class VecTask(Env):
 
     # ------------------------------------------------------------------ domain randomisation (vec_task.py:610-840)
     #: tasks whose step kernels apply observation / action noise themselves (mi_engine_set_noise); the others get torch ops
-    KERNEL_NOISE_TASKS = ("Cartpole", "Ant", "Humanoid")
+    KERNEL_NOISE_TASKS = ("Cartpole", "Ant", "Humanoid", "ShadowHand")
     #: `actor_params` entries that have a per-env engine parameter: (property group, attribute) -> column of the actor_scale tensor
     ACTOR_SCALE_COLUMNS = {("rigid_body_properties", "mass"): 0, ("dof_properties", "damping"): 1, ("dof_properties", "stiffness"): 2,
                            ("dof_properties", "armature"): 3}

@@ -1035,6 +1035,47 @@ def test_shadow_hand_actor_params_block_of_the_task_config_reaches_the_engine():
     assert torch.isfinite(env.obs_buf).all()
 
 
+@pytest.mark.parametrize("obs_type,nobs", [("full_state", 211), ("openai", 42)])
+def test_shadow_hand_in_kernel_noise_equals_its_cpu_twin(obs_type, nobs):
+    """Observation / action noise of the domain randomisation inside the ShadowHand kernels (mi_engine_set_noise; the write-out of
+    hand_post_kernel / hand_obs_select_kernel, the action read of hand_pre_kernel): a noisy env equals its clean twin pushed through
+    oracle.tasks.mi_noise element by element, the reward and the asymmetric states see the clean values."""
+    import isaacgymenvs_amd
+    from oracle.tasks import fold_seed, mi_noise
+    n, seed = 96, 5
+    def mk():
+        cfg = compose(overrides=["task=ShadowHand"])
+        cfg["task"]["env"]["numEnvs"] = n
+        cfg["task"]["env"]["observationType"] = obs_type
+        cfg["task"]["env"]["asymmetric_observations"] = True
+        return isaacgymenvs_amd.make(seed=seed, task="ShadowHand", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True, cfg=cfg)
+    clean, noisy = mk(), mk()
+    spec = dict(dist="gaussian", op="additive", a=0.0, b=0.05, a_corr=0.0, b_corr=0.02)
+    noisy.engine.set_noise(0, **spec)
+    g = torch.Generator().manual_seed(1)
+    env_ids = np.arange(n, dtype=np.uint32)[:, None]
+    k = np.arange(nobs, dtype=np.uint32)[None, :]
+    for step in range(3):
+        a = (torch.rand((n, 20), generator=g) * 2 - 1).to(DEV)
+        oc = clean.step(a)[0]
+        on = noisy.step(a)[0]
+        torch.cuda.synchronize()
+        want = np.clip(mi_noise(spec, fold_seed(seed), env_ids, step, 0, k, clean.obs_buf.cpu().numpy()), -5.0, 5.0)
+        np.testing.assert_allclose(on["obs"].cpu().numpy(), want, atol=2e-5, rtol=1e-5)
+        assert torch.equal(on["states"], oc["states"])                                   # states_buf: no noise
+        assert torch.equal(clean.rew_buf, noisy.rew_buf)                                 # the reward saw the clean state
+    assert float((on["obs"] - oc["obs"]).abs().max()) > 0.05
+    noisy.engine.set_noise(0, dist="off")
+    aspec = dict(dist="gaussian", op="additive", a=0.0, b=0.3, a_corr=0.0, b_corr=0.0)
+    noisy.engine.set_noise(1, **aspec)
+    a = torch.rand((n, 20), generator=g) * 2 - 1
+    noisy.step(a.to(DEV))
+    torch.cuda.synchronize()
+    expect = np.clip(mi_noise(aspec, fold_seed(seed), env_ids, 3, 1, np.arange(20, dtype=np.uint32)[None, :], a.numpy()), -1.0, 1.0)
+    np.testing.assert_allclose(noisy.actions.cpu().numpy(), expect, atol=2e-5)
+    assert np.abs(noisy.actions.cpu().numpy() - np.clip(a.numpy(), -1, 1)).max() > 0.1
+
+
 @pytest.mark.parametrize("obs_type,nobs", [("openai", 42), ("full_no_vel", 77), ("full", 157)])
 def test_shadow_hand_observation_types_asymmetric_states_and_random_forces(obs_type, nobs):
     """observationType variants (shadow_hand.py:472-526) + asymmetric_observations (states_buf, :584) + random object forces
@@ -1255,7 +1296,7 @@ def test_shadow_hand_openai_variant_runs_from_its_task_config():
     assert float(obs_d["obs"].abs().max()) <= env.clip_obs + 1e-6
     assert resets > 0                                    # 160-step episodes: every env times out (or drops the cube) within 200 steps
     assert int(env.progress_buf.max()) <= 160
-    assert env.dr_randomizations["observations"]["in_kernel"] is False and "observations" in env._torch_noise   # the hand keeps torch-op noise
+    assert env.dr_randomizations["observations"]["in_kernel"] is True and not env._torch_noise       # the noise runs inside the hand kernels
     # hand and object shape friction are randomised per env (250 buckets in 0.7 .. 1.3 each); the contact coefficient is their mean
     fr = env.engine.tensors["friction"].cpu().numpy()
     assert fr.min() >= 0.7 - 1e-6 and fr.max() <= 1.3 and len(np.unique(np.round(fr, 5))) > 50
