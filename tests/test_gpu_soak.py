@@ -27,3 +27,30 @@ def test_random_policy_soak(task, n, steps, vmax):
             assert torch.isfinite(t["root_states"]).all() and torch.isfinite(t["dof_state"]).all(), (task, i)
             worst = max(worst, float(t["root_states"][:, 7:13].abs().max()), float(t["dof_state"][..., 1].abs().max()))
             assert worst < vmax, (task, i, worst)
+
+
+def test_shadow_hand_soak_at_the_corners_of_its_actor_params_ranges():
+    """ShadowHand with every env at a corner of the `actor_params` ranges of cfg/task/ShadowHand.yaml (light hand + stiff drives + weak
+    damping, heavy object on a light hand, ...) and joint limits shifted by three standard deviations, under full-range random actions:
+    the implicit drives and the tendon rows stay stable, nothing blows up."""
+    import isaacgymenvs_amd
+    n, steps = 2048, 500
+    env = isaacgymenvs_amd.make(seed=321, task="ShadowHand", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True)
+    t = env.engine.tensors
+    g = torch.Generator(device=DEV).manual_seed(11)
+    ranges = torch.tensor([[0.5, 1.5], [0.3, 3.0], [0.75, 1.5], [0.75, 1.5], [0.3, 3.0], [0.5, 1.5], [0.95, 1.05]], device=DEV)
+    pick = torch.randint(0, 2, (n, 7), device=DEV, generator=g)
+    t["actor_scale"][:, :7] = torch.where(pick == 0, ranges[:, 0], ranges[:, 1])
+    t["dof_limit_shift"][:] = 0.03 * (torch.randint(0, 2, (n, 48), device=DEV, generator=g) * 2 - 1).float()
+    worst = 0.0
+    for i in range(steps):
+        obs, rew, reset, _ = env.step(torch.rand((n, 20), device=DEV, generator=g) * 2 - 1)
+        if i % 50 == 49:
+            assert torch.isfinite(obs["obs"]).all() and torch.isfinite(rew).all(), i
+            assert torch.isfinite(t["dof_state"]).all() and torch.isfinite(t["object_state"]).all(), i
+            worst = max(worst, float(t["dof_state"][..., 1].abs().max()))
+            assert worst < 80.0, (i, worst)
+            lo = env.shadow_hand_dof_lower_limits - 0.03; up = env.shadow_hand_dof_upper_limits + 0.03
+            viol = torch.maximum(lo - env.shadow_hand_dof_pos, env.shadow_hand_dof_pos - up).max()
+            assert float(viol) < 0.35, (i, float(viol))
+    assert int(t["object_contact_count"].sum()) > 0
