@@ -15,6 +15,7 @@ struct View {
     float clip_obs;
     unsigned step;      // control-step counter of this step() (white-noise stream of the in-kernel observation / action noise)
     NoiseParams obs_noise, act_noise;   // domain randomisation noise on observations / actions (dist 0: off), mi_engine_set_noise
+    float* limit_shift; // [2*ND][N] per-env shifts of the lower, then the upper joint limits (`actor_params` dof_properties.lower / upper), null: task has none
     float* actor_scale; // [4][N] per-env scale of link masses, joint damping, stiffness, armature (`actor_params`), null: task has none
     float* root;        // [13][N]
     float* dof;         // [2][ND][N]  (pos block, vel block)

@@ -98,6 +98,8 @@ static void build_layout(int task, int N, Layout& L, View* v, char* base, int no
         // per-env scale of the actor's link masses and joint damping / stiffness / armature (`actor_params.<actor>.rigid_body_properties.mass`,
         // `.dof_properties.*`); 1 = the model's own values
         o = L.add("actor_scale", MI_F32, {n, 4}, {1, n}, 4 * n); if (v) v->actor_scale = (float*)P(o);
+        // `.dof_properties.lower / upper`: one shift per joint limit and env (0 = the model's limits)
+        o = L.add("dof_limit_shift", MI_F32, {n, 2 * nd}, {1, n}, 2 * nd * n); if (v) v->limit_shift = (float*)P(o);
     }
     if (task == T_HUMANOID) {
         // the Humanoid actor collides with itself (collision filter 0, humanoid.py:194): warm-start impulses and contact forces of the

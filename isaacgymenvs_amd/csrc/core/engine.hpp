@@ -383,6 +383,19 @@ struct Sim {
     // so the tree pass runs on the model's own masses and H, bias are scaled afterwards (keeping four more values live through the
     // tree pass cost the Humanoid kernel 220 additional spilled registers and 1.8x its run time).
     Strided actor_scale{nullptr, 1};
+    // `actor_params.<actor>.dof_properties.lower / upper` (Ant.yaml:94-101): per-env shifts of the joint limits, [ND] lower then [ND] upper,
+    // or p == nullptr; same models as actor_scale
+    Strided limit_shift{nullptr, 1};
+    template <int D> MI_HD float limit_lower() const {
+        float x = M::dof_lower[D];
+        if constexpr (SCALED) { if (limit_shift.p != nullptr) x += limit_shift(D); }
+        return x;
+    }
+    template <int D> MI_HD float limit_upper() const {
+        float x = M::dof_upper[D];
+        if constexpr (SCALED) { if (limit_shift.p != nullptr) x += limit_shift(ND + D); }
+        return x;
+    }
 #if defined(MI_TIMING)
     unsigned long long* tstamp = nullptr;
 #endif
@@ -900,7 +913,7 @@ struct Sim {
             if constexpr (M::dof_limited[d]) {
                 constexpr int row = limrow(d);
                 MI_PHASE();
-                const float dl = q[d] - M::dof_lower[d], du = M::dof_upper[d] - q[d];
+                const float dl = q[d] - this->template limit_lower<d>(), du = this->template limit_upper<d>() - q[d];
                 const bool lower = dl < du;
                 const float C = lower ? dl : du, s = lower ? 1.f : -1.f;
                 float lw;
@@ -1539,7 +1552,7 @@ struct Sim {
             float ll = 0.f;
             if constexpr (M::dof_limited[d]) {
                 constexpr int row = limrow(d);
-                const float dl = q[d] - M::dof_lower[d], du = M::dof_upper[d] - q[d];
+                const float dl = q[d] - this->template limit_lower<d>(), du = this->template limit_upper<d>() - q[d];
                 ll = (dl < du) ? lam(row) : -lam(row);
             }
             laml(d) = ll;

@@ -261,7 +261,7 @@ struct SimMW : Sim<M> {
             if constexpr (M::dof_limited[d] && owns_gi<R>(gi)) {
                 constexpr int row = B::limrow(d);
                 MI_PHASE();
-                const float dl = q[d] - M::dof_lower[d], du = M::dof_upper[d] - q[d];
+                const float dl = q[d] - this->template limit_lower<d>(), du = this->template limit_upper<d>() - q[d];
                 const bool lower = dl < du;
                 const float C = lower ? dl : du, s = lower ? 1.f : -1.f;
                 const float lw = lam(row);
@@ -473,7 +473,7 @@ struct SimMW : Sim<M> {
                 float ll = 0.f;
                 if constexpr (M::dof_limited[d]) {
                     constexpr int row = B::limrow(d);
-                    const float dl = q[d] - M::dof_lower[d], du = M::dof_upper[d] - q[d];
+                    const float dl = q[d] - this->template limit_lower<d>(), du = this->template limit_upper<d>() - q[d];
                     ll = (dl < du) ? lam(row) : -lam(row);
                 }
                 laml(d) = ll;

@@ -195,6 +195,7 @@ extern "C" int mi_engine_init_state(MiEngine* e, void*) {
         v.potentials[en] = pot0; v.prev_potentials[en] = pot0;
         if (v.friction) v.friction[en] = -1.f;
         if (v.actor_scale) for (int k = 0; k < 4; ++k) v.actor_scale[k * N + en] = 1.f;
+        if (v.limit_shift) for (int k = 0; k < 2 * nd; ++k) v.limit_shift[k * N + en] = 0.f;
         for (int k = 0; k < 3; ++k) { v.up_vec[k * N + en] = (k == 2) ? 1.f : 0.f; v.heading_vec[k * N + en] = (k == 0) ? 1.f : 0.f; }
         v.rew[en] = 0.f;
         v.reset[en] = 1;      // vec_task.py:316-317: every env is reset inside the first step()
@@ -244,6 +245,7 @@ static void simulate_env(const View& v, const SimParams& P, int en, const float*
     load_env(sim, v, en);
     if constexpr (Sim<M>::SCALED) {
         if (v.actor_scale) sim.actor_scale = Strided{v.actor_scale + en, N};
+        if (v.limit_shift) sim.limit_shift = Strided{v.limit_shift + en, N};
     }
     const float h = P.dt / (float)P.substeps;
     float rows[Sim<M>::ROW_SLOTS > 0 ? Sim<M>::ROW_SLOTS : 1];

@@ -66,6 +66,7 @@ __global__ void init_state_kernel(View v, int nd, int nsph3, int nsens6, int nob
     v.potentials[e] = pot0; v.prev_potentials[e] = pot0;
     if (v.friction) v.friction[e] = -1.f;       // model friction until somebody writes the tensor (AnymalTerrain's init overwrites it)
     if (v.actor_scale) for (int k = 0; k < 4; ++k) v.actor_scale[k * N + e] = 1.f;
+    if (v.limit_shift) for (int k = 0; k < 2 * nd; ++k) v.limit_shift[k * N + e] = 0.f;
     for (int k = 0; k < 3; ++k) { v.up_vec[k * N + e] = (k == 2) ? 1.f : 0.f; v.heading_vec[k * N + e] = (k == 0) ? 1.f : 0.f; }
     v.rew[e] = 0.f;
     v.reset[e] = 1;  // vec_task.py:316-317: every env is reset inside the first step()

@@ -33,6 +33,7 @@ template <class S>
 __device__ __forceinline__ void load_actor_scales(S& s, const View& v, int e) {
     if constexpr (S::SCALED) {
         if (v.actor_scale != nullptr) s.actor_scale = Strided{v.actor_scale + e, v.N};
+        if (v.limit_shift != nullptr) s.limit_shift = Strided{v.limit_shift + e, v.N};
     }
 }
 template <class M>

@@ -134,3 +134,31 @@ def test_shadow_hand_actor_params_map_onto_the_engine_tensors():
     np.testing.assert_array_equal(sc2[:, [0, 5, 6]], sc[:, [0, 5, 6]])
     np.testing.assert_array_equal(sc2[1::2], sc[1::2])
     assert (sc2[::2, 1] != sc[::2, 1]).mean() > 0.95
+
+
+def test_ant_actor_params_block_is_fully_mapped():
+    """cfg/task/Ant.yaml `actor_params.ant`: mass / damping / stiffness -> actor_scale columns, lower / upper -> dof_limit_shift; no entry
+    is skipped (Ant's passive joint stiffness is 0, so its `scaling` leaves the factor at 1 like the reference leaves 0 at 0)."""
+    import types
+    import warnings
+    import torch
+    from isaacgymenvs_amd.tasks.ant import Ant
+    from isaacgymenvs_amd.utils.config import compose
+    cfg = compose(overrides=["task=Ant"])["task"]
+    n = 300
+    env = Ant.__new__(Ant)
+    env.num_environments, env.device, env.native_task, env.last_step, env.first_randomization = n, "cpu", "Ant", 0, True
+    env.model_name = "ant"
+    tensors = {"actor_scale": torch.ones(n, 4), "dof_limit_shift": torch.zeros(n, 16), "friction": -torch.ones(n)}
+    env.engine = types.SimpleNamespace(tensors=tensors)
+    np.random.seed(1)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        env._apply_actor_params(cfg["task"]["randomization_params"]["actor_params"], None)
+    assert not w, [str(x.message) for x in w]
+    sc = tensors["actor_scale"].numpy()
+    assert sc[:, 0].std() > 0.2 and sc[:, 1].std() > 0.2 and np.all(sc[:, 2:] == 1.0)
+    assert 0.5 - 1e-6 <= sc[:, :2].min() and sc[:, :2].max() <= 1.5 + 1e-6
+    sh = tensors["dof_limit_shift"].numpy()
+    assert abs(sh.std() - 0.01) < 0.001 and abs(sh.mean()) < 0.001
+    assert float(tensors["friction"].max()) == -1.0                   # Ant.yaml randomises no friction

@@ -40,16 +40,31 @@ def _random_state(spec, n, rng, z_lo, z_hi):
     return root, rng.uniform(lo, up, (n, spec.nd)), rng.normal(size=(n, spec.nd)) * 2
 
 
-@pytest.mark.parametrize("n", [200, 4096])      # a ragged count (partly filled workgroups, the XCD-aware env mapping) and the BASELINE size
-def test_multi_wave_simulate_matches_cpu_oracle(n):
+@pytest.mark.parametrize("n,randomised", [(200, False), (4096, False), (1000, True)])   # a ragged count (partly filled workgroups, the XCD-aware env mapping), the BASELINE size
+def test_multi_wave_simulate_matches_cpu_oracle(n, randomised):
+    """randomised: with `actor_params` tensors set (actor_scale factors, dof_limit_shift) against the oracle on a model whose constants and
+    joint limits were changed accordingly."""
+    import dataclasses
     from oracle.engine import OracleEngine
     env = _make("Ant", n, mw=32)
     spec, sb = load_model("ant"), sensor_bodies("ant")
+    if randomised:
+        f = dict(mass=0.6, damping=1.4, stiffness=0.5, armature=2.0)
+        lo0, up0 = np.minimum(spec.dof_lower, spec.dof_upper), np.maximum(spec.dof_lower, spec.dof_upper)
+        shift = np.concatenate([0.12 * np.cos(np.arange(8)), -0.12 * np.abs(np.sin(1 + np.arange(8)))])
+        env.engine.tensors["actor_scale"][:] = torch.tensor([f["mass"], f["damping"], f["stiffness"], f["armature"]], device=DEV)
+        env.engine.tensors["dof_limit_shift"][:] = _t(shift)
+        state_spec = spec                                           # random joint angles inside the ORIGINAL limits: some violate the shifted ones
+        spec = dataclasses.replace(spec, mass=spec.mass * f["mass"], inertia=spec.inertia * f["mass"], dof_damping=spec.dof_damping * f["damping"],
+                                   dof_stiffness=spec.dof_stiffness * f["stiffness"], dof_armature=spec.dof_armature * f["armature"],
+                                   dof_lower=lo0 + shift[:8], dof_upper=up0 + shift[8:])
+    else:
+        state_spec = spec
     stride = max(1, n // 256)                   # the oracle follows a strided subset of the envs
     ids = np.arange(0, n, stride)
     orc = OracleEngine(spec, len(ids), params=_sim_dict(env.sim_params), sensor_bodies=sb, precision="f64")
     rng = np.random.default_rng(0)
-    root, q, qd = _random_state(spec, n, rng, 0.3, 0.6)
+    root, q, qd = _random_state(state_spec, n, rng, 0.3, 0.6)
     tau = rng.uniform(-15, 15, (n, spec.nd))
     t = env.engine.tensors
     t["root_states"][:] = _t(root); env.dof_pos[:] = _t(q); env.dof_vel[:] = _t(qd)
@@ -103,8 +118,8 @@ def test_multi_wave_option_is_ignored_by_models_without_a_multi_wave_form():
     assert torch.isfinite(env.obs_buf).all()
 
 
-@pytest.mark.parametrize("n", [8192, 300])     # the BASELINE size and a ragged count (partly filled workgroups)
-def test_humanoid_self_collision_on_a_helper_wave_is_the_same_sub_step(n):
+@pytest.mark.parametrize("n,randomised", [(8192, False), (300, False), (500, True)])     # the BASELINE size, a ragged count (partly filled workgroups),
+def test_humanoid_self_collision_on_a_helper_wave_is_the_same_sub_step(n, randomised):    # and per-env `actor_params` tensors in both kernels
     """Humanoid with the self-collision phase on a second wave of the workgroup (csrc/sc2_kernels.hpp, option multi_wave != 0) against
     the one-wave kernel: the same arithmetic on the same values (bit-identical on the host build, tests/test_self_collision.py); the
     two GPU kernels are separate compilations, so the comparison is within fp32 round-off growing with the contact-rich steps."""
@@ -119,6 +134,10 @@ def test_humanoid_self_collision_on_a_helper_wave_is_the_same_sub_step(n):
         for k in ("contact_impulse", "limit_impulse", "self_contact_impulse"):
             t[k].zero_()
         t["dof_actuation_force"][:] = _t(tau)
+        if randomised:
+            r2 = np.random.default_rng(8)
+            t["actor_scale"][:] = _t(r2.uniform(0.5, 1.5, (n, 4)))
+            t["dof_limit_shift"][:] = _t(r2.normal(0.0, 0.05, (n, 2 * spec.nd)))
     touched = 0
     for it in range(3):
         e1.engine.simulate(); e2.engine.simulate()
