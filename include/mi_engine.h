@@ -244,6 +244,8 @@ int mi_engine_set_terrain(MiEngine* e, const int16_t* height_samples, int rows, 
  * "multi_wave" 0 | 32 (physics sub-step of Ant / Anymal / AnymalTerrain spread over the four waves of a workgroup of that many
  * envs -- same results up to summation order, see csrc/core/engine_mw.hpp; other tasks ignore it),
  * "steps" (the control-step counter: observation-ring parity and per-step RNG counters; restore it together with the arena),
+ * "actor_tensors" 0 | 1 (Ant, Humanoid: whether the sub-step reads the per-env `actor_scale` / `dof_limit_shift` tensors of the
+ * `actor_params` domain randomisation, vec_task.py:752-828; default 0 = the model's constants, no loads; ShadowHand always reads its own),
  * "terrain_slope_threshold" (AnymalTerrain: terrain.slopeTreshold of the reference's height-field -> triangle-mesh conversion,
  * anymal_terrain.py:576; steeper cell edges are levelled to their lower end in the ground query; 0 = off) */
 int mi_engine_set_option(MiEngine* e, const char* key, double value);

@@ -56,6 +56,8 @@ struct MiEngine {
     std::vector<MiTensorDesc> descs;
     unsigned long long steps;
     float* lamp_arena;
+    float* actor_scale_arena;   // the `actor_params` tensors: read by the sub-step once option "actor_tensors" is on (as in mi_engine.hip)
+    float* limit_shift_arena;
 };
 
 static bool cpu_task(int t) { return t == T_CARTPOLE || t == T_ANT || t == T_HUMANOID || t == T_QUADCOPTER || t == T_INGENUITY || t == T_BALLBALANCE; }
@@ -112,6 +114,8 @@ extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const 
     if (arena_bytes < L.off) { delete e; return fail("mi_engine_create: arena too small"); }
     e->descs = L.d;
     e->lamp_arena = e->v.lamp;
+    e->actor_scale_arena = e->v.actor_scale; e->limit_shift_arena = e->v.limit_shift;
+    e->v.actor_scale = nullptr; e->v.limit_shift = nullptr;
     e->v.N = num_envs; e->v.env_offset = env_id_offset; e->v.seed = (uint32_t)(seed ^ (seed >> 32));
     e->v.clip_obs = INFINITY;
     *out = e;
@@ -137,6 +141,12 @@ extern "C" int mi_engine_set_option(MiEngine* e, const char* key, double value) 
         return 0;
     }
     if (!strcmp(key, "multi_wave")) return 0;                                  // a GPU launch shape: nothing to do here
+    if (!strcmp(key, "actor_tensors")) {
+        if (value != 0 && e->actor_scale_arena == nullptr) return fail("actor_tensors: this task carries no actor_scale / dof_limit_shift tensors");
+        e->v.actor_scale = value != 0 ? e->actor_scale_arena : nullptr;
+        e->v.limit_shift = value != 0 ? e->limit_shift_arena : nullptr;
+        return 0;
+    }
     if (!strcmp(key, "steps")) { if (value < 0) return fail("steps < 0"); e->steps = (unsigned long long)value; return 0; }
     // sim.physx.num_threads of the reference's CPU pipeline (vec_task.py:541, cfg/config.yaml:30): OpenMP threads over envs
     if (!strcmp(key, "num_threads")) { if (value < 1) return fail("num_threads < 1"); e->num_threads = (int)value; return 0; }
@@ -159,6 +169,7 @@ extern "C" int mi_engine_get_option(const MiEngine* e, const char* key, double* 
     if (!strcmp(key, "control_freq_inv")) { *out = e->control_freq_inv; return 0; }
     if (!strcmp(key, "self_collision")) { *out = e->v.lamp != nullptr ? 1.0 : 0.0; return 0; }
     if (!strcmp(key, "multi_wave")) { *out = 0; return 0; }
+    if (!strcmp(key, "actor_tensors")) { *out = e->v.actor_scale != nullptr ? 1.0 : 0.0; return 0; }
     if (!strcmp(key, "steps")) { *out = (double)e->steps; return 0; }
     if (!strcmp(key, "num_threads")) { *out = e->num_threads; return 0; }
     return fail(std::string("unknown option: ") + key);
@@ -194,8 +205,8 @@ extern "C" int mi_engine_init_state(MiEngine* e, void*) {
         for (int k = 0; k < m.nobs; ++k) { v.obs[(size_t)en * m.nobs + k] = 0.f; v.obs_out[(size_t)en * m.nobs + k] = 0.f; v.obs_out[((size_t)N + en) * m.nobs + k] = 0.f; }
         v.potentials[en] = pot0; v.prev_potentials[en] = pot0;
         if (v.friction) v.friction[en] = -1.f;
-        if (v.actor_scale) for (int k = 0; k < 4; ++k) v.actor_scale[k * N + en] = 1.f;
-        if (v.limit_shift) for (int k = 0; k < 2 * nd; ++k) v.limit_shift[k * N + en] = 0.f;
+        if (e->actor_scale_arena) for (int k = 0; k < 4; ++k) e->actor_scale_arena[k * N + en] = 1.f;
+        if (e->limit_shift_arena) for (int k = 0; k < 2 * nd; ++k) e->limit_shift_arena[k * N + en] = 0.f;
         for (int k = 0; k < 3; ++k) { v.up_vec[k * N + en] = (k == 2) ? 1.f : 0.f; v.heading_vec[k * N + en] = (k == 0) ? 1.f : 0.f; }
         v.rew[en] = 0.f;
         v.reset[en] = 1;      // vec_task.py:316-317: every env is reset inside the first step()

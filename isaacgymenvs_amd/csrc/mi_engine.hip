@@ -261,6 +261,10 @@ struct MiEngine {
     int control_freq_inv;
     std::vector<MiTensorDesc> descs;
     unsigned long long steps;
+    // the `actor_params` tensors (actor_scale, dof_limit_shift) of Ant / Humanoid: the kernels only read them once the option
+    // "actor_tensors" is on -- with the option off (default) the sub-step runs on the model's constants and skips the loads
+    float* actor_scale_arena;
+    float* limit_shift_arena;
     float* lamp_arena;     // the self-contact impulse tensor (Humanoid), kept while the option self_collision is 0
 };
 
@@ -370,6 +374,8 @@ extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const 
     }
     build_layout(t, num_envs, L, &e->v, (char*)arena, nobs);
     e->lamp_arena = e->v.lamp;       // self-collision is on by default where the reference's actor collides with itself
+    e->actor_scale_arena = e->v.actor_scale; e->limit_shift_arena = e->v.limit_shift;
+    e->v.actor_scale = nullptr; e->v.limit_shift = nullptr;
     memset(&e->hv, 0, sizeof(e->hv));
     if (t == T_SHADOWHAND) build_hand_layout(num_envs, L, &e->hv, (char*)arena);
     memset(&e->qv, 0, sizeof(e->qv));
@@ -424,6 +430,13 @@ extern "C" int mi_engine_set_option(MiEngine* e, const char* key, double value) 
     }
     // control-step counter (observation ring parity, AnymalTerrain push schedule, noise counters): part of a state checkpoint
     if (!strcmp(key, "steps")) { if (value < 0) return fail("steps < 0"); e->steps = (unsigned long long)value; return 0; }
+    if (!strcmp(key, "actor_tensors")) {   // 1: the sub-step reads actor_scale / dof_limit_shift (Ant, Humanoid); ShadowHand always reads its own
+        if (e->task == T_SHADOWHAND) return 0;
+        if (value != 0 && e->actor_scale_arena == nullptr) return fail("actor_tensors: this task carries no actor_scale / dof_limit_shift tensors");
+        e->v.actor_scale = value != 0 ? e->actor_scale_arena : nullptr;
+        e->v.limit_shift = value != 0 ? e->limit_shift_arena : nullptr;
+        return 0;
+    }
     if (!strcmp(key, "terrain_slope_threshold")) {   // terrain.slopeTreshold of the mesh generator (anymal_terrain.py:576); 0 = off
         if (e->task != T_ANYMAL) return fail("terrain_slope_threshold: only AnymalTerrain has a terrain");
         e->terrain.slope_threshold = (float)value;
@@ -452,6 +465,7 @@ extern "C" int mi_engine_get_option(const MiEngine* e, const char* key, double* 
     if (!strcmp(key, "multi_wave")) { *out = e->v.mw; return 0; }
     if (!strcmp(key, "steps")) { *out = (double)e->steps; return 0; }
     if (!strcmp(key, "terrain_slope_threshold")) { *out = e->terrain.slope_threshold; return 0; }
+    if (!strcmp(key, "actor_tensors")) { *out = (e->task == T_SHADOWHAND || e->v.actor_scale != nullptr) ? 1.0 : 0.0; return 0; }
     return fail(std::string("unknown option: ") + key);
 }
 
@@ -466,6 +480,12 @@ static int check_device(const MiEngine* e, const char* where) {
     return 0;
 }
 
+// the view the initial-state kernel writes through: the `actor_params` tensors are initialised whether the kernels read them or not
+static View init_view(const MiEngine* e) {
+    View v = e->v;
+    v.actor_scale = e->actor_scale_arena; v.limit_shift = e->limit_shift_arena;
+    return v;
+}
 extern "C" int mi_engine_init_state(MiEngine* e, void* stream) {
     if (!e) return fail("null engine");
     if (int rc = check_device(e, "mi_engine_init_state")) return rc;
@@ -480,7 +500,7 @@ extern "C" int mi_engine_init_state(MiEngine* e, void* stream) {
     }
     if (e->task == T_QUADCOPTER) {
         const int blocks = (e->N + 255) / 256;
-        hipLaunchKernelGGL(init_state_kernel, dim3(blocks), dim3(256), 0, s, e->v, m.nd, 3 * m.nsph, 6 * m.nsens, m.nobs, m.nact,
+        hipLaunchKernelGGL(init_state_kernel, dim3(blocks), dim3(256), 0, s, init_view(e), m.nd, 3 * m.nsph, 6 * m.nsens, m.nobs, m.nact,
                            e->quad.init_height, (const float*)nullptr, 0.f);
         HIP_OK(hipGetLastError());
         HIP_OK(launch_init_quadcopter(e->v, e->qv, e->quad, s));
@@ -489,7 +509,7 @@ extern "C" int mi_engine_init_state(MiEngine* e, void* stream) {
     }
     if (e->task == T_INGENUITY) {
         const int blocks = (e->N + 255) / 256;
-        hipLaunchKernelGGL(init_state_kernel, dim3(blocks), dim3(256), 0, s, e->v, m.nd, 3 * m.nsph, 6 * m.nsens, m.nobs, m.nact,
+        hipLaunchKernelGGL(init_state_kernel, dim3(blocks), dim3(256), 0, s, init_view(e), m.nd, 3 * m.nsph, 6 * m.nsens, m.nobs, m.nact,
                            e->ing.init_height, (const float*)nullptr, 0.f);
         HIP_OK(hipGetLastError());
         HIP_OK(launch_init_ingenuity(e->v, e->iv, e->ing, s));
@@ -498,7 +518,7 @@ extern "C" int mi_engine_init_state(MiEngine* e, void* stream) {
     }
     if (e->task == T_BALLBALANCE) {
         const int blocks = (e->N + 255) / 256;
-        hipLaunchKernelGGL(init_state_kernel, dim3(blocks), dim3(256), 0, s, e->v, m.nd, 3 * m.nsph, 6 * m.nsens, m.nobs, m.nact,
+        hipLaunchKernelGGL(init_state_kernel, dim3(blocks), dim3(256), 0, s, init_view(e), m.nd, 3 * m.nsph, 6 * m.nsens, m.nobs, m.nact,
                            e->bbot.tray_height, (const float*)nullptr, 0.f);
         HIP_OK(hipGetLastError());
         HIP_OK(launch_init_ball_balance(e->v, e->bv, e->bbot, s));
@@ -507,7 +527,7 @@ extern "C" int mi_engine_init_state(MiEngine* e, void* stream) {
     }
     if (e->task == T_ANYMAL_FLAT) {
         const int blocks = (e->N + 255) / 256;
-        hipLaunchKernelGGL(init_state_kernel, dim3(blocks), dim3(256), 0, s, e->v, m.nd, 3 * m.nsph, 0, m.nobs, m.nact,
+        hipLaunchKernelGGL(init_state_kernel, dim3(blocks), dim3(256), 0, s, init_view(e), m.nd, 3 * m.nsph, 0, m.nobs, m.nact,
                            e->anymal_flat.base_init_state[2], (const float*)nullptr, 0.f);
         HIP_OK(hipGetLastError());
         HIP_OK(launch_init_anymal_flat(e->v, e->anymal_flat, s));
@@ -517,7 +537,7 @@ extern "C" int mi_engine_init_state(MiEngine* e, void* stream) {
     if (e->task == T_ANYMAL) {
         if (e->terrain.hs == nullptr) return fail("mi_engine_init_state: AnymalTerrain needs mi_engine_set_terrain first");
         const int blocks = (e->N + 255) / 256;
-        hipLaunchKernelGGL(init_state_kernel, dim3(blocks), dim3(256), 0, s, e->v, m.nd, 3 * m.nsph, 0, m.nobs, m.nact,
+        hipLaunchKernelGGL(init_state_kernel, dim3(blocks), dim3(256), 0, s, init_view(e), m.nd, 3 * m.nsph, 0, m.nobs, m.nact,
                            e->anymal.base_init_state[2], (const float*)nullptr, 0.f);
         HIP_OK(hipGetLastError());
         HIP_OK(launch_init_anymal(e->v, e->anymal, e->terrain, e->max_init_level, s));
@@ -542,7 +562,7 @@ extern "C" int mi_engine_init_state(MiEngine* e, void* stream) {
         root_z = 2.0f;  // cartpole.py:93
     }
     const int blocks = (e->N + 255) / 256;
-    hipLaunchKernelGGL(init_state_kernel, dim3(blocks), dim3(256), 0, s, e->v, m.nd, 3 * m.nsph, 6 * m.nsens, m.nobs, m.nact,
+    hipLaunchKernelGGL(init_state_kernel, dim3(blocks), dim3(256), 0, s, init_view(e), m.nd, 3 * m.nsph, 6 * m.nsens, m.nobs, m.nact,
                        root_z, d_init, pot0);
     HIP_OK(hipGetLastError());
     if (d_init) { HIP_OK(hipStreamSynchronize(s)); HIP_OK(hipFree(d_init)); }

@@ -349,6 +349,8 @@ class VecTask(Env):
         if pair and not hasattr(self, "_dr_actor_friction"):
             self._dr_actor_friction = {}
         ids = torch.arange(self.num_envs, device=self.device) if due_envs is None else torch.nonzero(due_envs, as_tuple=False).squeeze(-1)
+        if scales is not None and not getattr(self, "_actor_tensors_on", False):
+            self._enable_actor_tensors()
         base_mu = float(getattr(self, "model_shape_friction", 1.0))
         skipped = []
         for actor, groups in actor_params.items():
@@ -399,6 +401,13 @@ class VecTask(Env):
         if skipped and self.first_randomization:
             import warnings
             warnings.warn("actor_params entries without an engine counterpart are skipped (reference vec_task.py:752-828): " + ", ".join(skipped))
+
+    def _enable_actor_tensors(self):
+        """the sub-step kernels of Ant / Humanoid read `actor_scale` / `dof_limit_shift` only when told to (option "actor_tensors")"""
+        set_option = getattr(self.engine, "set_option", None)
+        if set_option is not None:
+            set_option("actor_tensors", 1)
+        self._actor_tensors_on = True
 
     def _dr_model(self):
         spec = getattr(self, "_dr_spec", None)

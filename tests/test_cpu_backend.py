@@ -150,6 +150,8 @@ def test_actor_scale_tensor_acts_like_a_rescaled_model():
     env.engine.set_option("multi_wave", 0)
     spec = load_model("ant")
     f = dict(mass=1.7, damping=0.5, stiffness=2.0, armature=3.0)
+    assert env.engine.get_option("actor_tensors") == 0                       # off until somebody randomises: the sub-step skips the loads
+    env.engine.set_option("actor_tensors", 1)
     env.engine.tensors["actor_scale"][:] = torch.tensor([f["mass"], f["damping"], f["stiffness"], f["armature"]])
     lo0, up0 = np.minimum(spec.dof_lower, spec.dof_upper), np.maximum(spec.dof_lower, spec.dof_upper)
     shift = np.concatenate([0.15 * np.cos(np.arange(8)), -0.15 * np.abs(np.sin(1 + np.arange(8)))])    # lower limits moved both ways, upper ones inwards

@@ -52,6 +52,7 @@ def test_multi_wave_simulate_matches_cpu_oracle(n, randomised):
         f = dict(mass=0.6, damping=1.4, stiffness=0.5, armature=2.0)
         lo0, up0 = np.minimum(spec.dof_lower, spec.dof_upper), np.maximum(spec.dof_lower, spec.dof_upper)
         shift = np.concatenate([0.12 * np.cos(np.arange(8)), -0.12 * np.abs(np.sin(1 + np.arange(8)))])
+        env.engine.set_option("actor_tensors", 1)
         env.engine.tensors["actor_scale"][:] = torch.tensor([f["mass"], f["damping"], f["stiffness"], f["armature"]], device=DEV)
         env.engine.tensors["dof_limit_shift"][:] = _t(shift)
         state_spec = spec                                           # random joint angles inside the ORIGINAL limits: some violate the shifted ones
@@ -136,6 +137,7 @@ def test_humanoid_self_collision_on_a_helper_wave_is_the_same_sub_step(n, random
         t["dof_actuation_force"][:] = _t(tau)
         if randomised:
             r2 = np.random.default_rng(8)
+            env.engine.set_option("actor_tensors", 1)
             t["actor_scale"][:] = _t(r2.uniform(0.5, 1.5, (n, 4)))
             t["dof_limit_shift"][:] = _t(r2.normal(0.0, 0.05, (n, 2 * spec.nd)))
     touched = 0

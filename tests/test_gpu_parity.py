@@ -1240,6 +1240,7 @@ def test_actor_params_friction_randomisation_is_tensorised_and_acts_on_the_physi
     msgs = " ".join(str(x.message) for x in w)
     # restitution has no engine parameter (named once); friction and mass do
     assert "restitution" in msgs and "rigid_body_properties" not in msgs and "friction" not in msgs.split("skipped")[-1].replace("restitution", "")
+    assert env.engine.get_option("actor_tensors") == 1                             # switched on by the first randomisation
     ms = env.engine.tensors["actor_scale"][:, 0].cpu().numpy()                     # rigid_body_properties.mass -> one factor per env
     assert ms.min() >= 0.5 - 1e-6 and ms.max() <= 1.5 + 1e-6 and ms.std() > 0.2
     assert float((env.engine.tensors["actor_scale"][:, 1:] - 1.0).abs().max()) == 0.0    # damping / stiffness / armature untouched
