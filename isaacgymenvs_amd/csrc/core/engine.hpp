@@ -376,7 +376,11 @@ struct Sim {
     // `actor_params` domain randomisation (reference vec_task.py:752-828: rigid_body_properties.mass, dof_properties.damping /
     // stiffness / armature): per-env scale factors of the model's link masses + inertias and joint constants.  Only the models that
     // carry the "actor_scale" tensor (M::ACTOR_SCALES, Ant and Humanoid) multiply by them; for the others the constants stay literals.
+#if defined(MI_NO_ACTOR_SCALES)   // measurement builds only: what the `actor_params` code costs when it is compiled in but switched off
+    static constexpr bool SCALED = false;
+#else
     static constexpr bool SCALED = M::ACTOR_SCALES != 0;
+#endif
     // [4] mass, damping, stiffness, armature factors of this env (strided like every per-env vector), or p == nullptr.  They are
     // loaded where they are used -- at the start of the right-hand-side phase and again for the joint forces at the end -- instead of
     // living in registers through the whole sub-step: the joint-space inertia H and the bias forces are linear in the link masses,
