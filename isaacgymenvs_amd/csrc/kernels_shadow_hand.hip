@@ -68,7 +68,7 @@ __device__ __forceinline__ void hand_reset_env(const View& v, const HandView& hv
 }
 
 // pre_physics_step (shadow_hand.py:670-698): deferred resets, then actions -> targets
-__global__ void hand_pre_kernel(View v, HandView hv, HandParams p, const float* __restrict__ actions_in, unsigned step_counter) {
+__global__ __launch_bounds__(64) void hand_pre_kernel(View v, HandView hv, HandParams p, const float* __restrict__ actions_in, unsigned step_counter) {
     MI_NO_CONTRACT
     const int N = v.N;
     const int e = post_env_index<HS::LANES>(blockIdx.x, threadIdx.x, N);   // same env -> XCD mapping as the sub-step kernel
@@ -76,12 +76,14 @@ __global__ void hand_pre_kernel(View v, HandView hv, HandParams p, const float* 
     const uint32_t genv = (uint32_t)(v.env_offset + e);
     if (v.reset[e] != 0) hand_reset_env(v, hv, p, e, genv);           // also resets the goal (:615)
     else if (hv.reset_goal[e] != 0) hand_reset_goal(v, hv, p, e, genv);
+    float raw_act[kHandAct];
+    sfor<kHandAct>([&](auto A_) MI_LAMBDA { raw_act[A_] = actions_in[(size_t)e * kHandAct + A_]; });
+    if (v.act_noise.dist != 0)                                                                                     // vec_task.py:371-372 (one block: a real branch)
+        sfor<kHandAct>([&](auto A_) MI_LAMBDA { raw_act[A_] = apply_noise(v.act_noise, v.seed, genv, v.step, 1u, (uint32_t)A_, raw_act[A_]); });
     sfor<kHandAct>([&](auto A_) MI_LAMBDA {
         constexpr int a = A_;
         const int d = p.actuated[a];
-        float raw = actions_in[(size_t)e * kHandAct + a];
-        if (v.act_noise.dist != 0) raw = apply_noise(v.act_noise, v.seed, genv, v.step, 1u, (uint32_t)a, raw);   // vec_task.py:371-372
-        const float act = fminf(fmaxf(raw, -p.clip_actions), p.clip_actions);                                      // vec_task.py:374
+        const float act = fminf(fmaxf(raw_act[a], -p.clip_actions), p.clip_actions);                               // vec_task.py:374
         v.actions[a * N + e] = act;
         // the actuated dof index is a runtime table: read the limits through a tiny switch-free lookup
         float lo = 0.f, up = 0.f;
@@ -193,15 +195,22 @@ __global__ __launch_bounds__(64) void hand_post_kernel(View v, HandView hv, Hand
         float* ob = v.obs + (size_t)er * kHandObs;
         float* oc = v.obs_out + ((size_t)v.ring * N + er) * kHandObs;
         float* fs = hv.full_state + (size_t)er * kHandObs;
-        for (int k = (int)threadIdx.x; k < kHandObs; k += 64) {
-            const float val = stage[k * 65 + row];
-            if (direct) {
-                // observation noise of the domain randomisation: on obs_buf only, after the reward was computed from the clean state
-                // (vec_task.py:397-399); states_buf stays clean
-                const float nv = v.obs_noise.dist != 0 ? apply_noise(v.obs_noise, v.seed, (uint32_t)(v.env_offset + er), v.step, 0u, (uint32_t)k, val) : val;
+        if (direct && v.obs_noise.dist != 0) {
+            // observation noise of the domain randomisation: on obs_buf only, after the reward was computed from the clean state
+            // (vec_task.py:397-399); states_buf stays clean.  (Its own loop: as a select inside the common loop the compiler evaluated
+            // the noise hash for every element whether it was wanted or not, +7 us on the kernel.)
+            for (int k = (int)threadIdx.x; k < kHandObs; k += 64) {
+                const float val = stage[k * 65 + row];
+                const float nv = apply_noise(v.obs_noise, v.seed, (uint32_t)(v.env_offset + er), v.step, 0u, (uint32_t)k, val);
                 ob[k] = nv;
                 oc[k] = fminf(fmaxf(nv, -v.clip_obs), v.clip_obs);
+                if (to_full) fs[k] = val;
             }
+            continue;
+        }
+        for (int k = (int)threadIdx.x; k < kHandObs; k += 64) {
+            const float val = stage[k * 65 + row];
+            if (direct) { ob[k] = val; oc[k] = fminf(fmaxf(val, -v.clip_obs), v.clip_obs); }
             if (to_full) fs[k] = val;
         }
     }
@@ -221,7 +230,12 @@ __global__ void hand_obs_select_kernel(View v, HandView hv, HandParams p) {
     if (i >= v.N * no) return;
     const int e = i / no, k = i - e * no;
     float val = hv.full_state[(size_t)e * kHandObs + p.obs_map[k]];
-    if (v.obs_noise.dist != 0) val = apply_noise(v.obs_noise, v.seed, (uint32_t)(v.env_offset + e), v.step, 0u, (uint32_t)k, val);
+    if (v.obs_noise.dist != 0) {   // (a block of its own so that the hash is not evaluated speculatively)
+        const float nv = apply_noise(v.obs_noise, v.seed, (uint32_t)(v.env_offset + e), v.step, 0u, (uint32_t)k, val);
+        v.obs[(size_t)e * no + k] = nv;
+        v.obs_out[((size_t)v.ring * v.N + e) * no + k] = fminf(fmaxf(nv, -v.clip_obs), v.clip_obs);
+        return;
+    }
     v.obs[(size_t)e * no + k] = val;
     v.obs_out[((size_t)v.ring * v.N + e) * no + k] = fminf(fmaxf(val, -v.clip_obs), v.clip_obs);
 }
