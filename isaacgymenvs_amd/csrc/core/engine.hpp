@@ -202,6 +202,9 @@ struct Drive {
     const float* fsens;    // [NSENS][3] external force at the centre of mass of each force-sensor body, in that body's own
                            // frame (gym.apply_rigid_body_force_tensors(..., LOCAL_SPACE)), or nullptr
 };
+// gymapi.AssetOptions defaults the reference's tasks leave alone (ant.py / humanoid.py / anymal*.py set neither): the simulator clamps
+// every actor's linear / angular velocity to these
+constexpr float kMaxAngularVelocity = 64.f, kMaxLinearVelocity = 1000.f;
 struct PlaneGround {
     static constexpr bool HEIGHTFIELD = false;
     static constexpr bool NETF = false;   // per-body net contact forces (gym.acquire_net_contact_force_tensor) not wanted
@@ -1660,6 +1663,13 @@ struct Sim {
         // ------------------------------------------------------------ integrate (semi-implicit Euler)
         sfor<ND>([&](auto D) MI_LAMBDA { qd[D] = v[OFF + D]; q[D] += h * qd[D]; });
         if constexpr (!M::FIXED) {
+            {   // AssetOptions.max_angular_velocity / max_linear_velocity, Isaac Gym's defaults (64 rad/s, 1000 m/s): PhysX clamps the body
+                // velocities; without it a robot flung into a fast spin (100 rad/s = 0.8 rad per sub-step) gains energy until it is NaN
+                const float w2 = v[3] * v[3] + v[4] * v[4] + v[5] * v[5], l2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+                const float sw = (w2 > kMaxAngularVelocity * kMaxAngularVelocity) ? kMaxAngularVelocity * MI_RSQ(w2) : 1.f;
+                const float sl = (l2 > kMaxLinearVelocity * kMaxLinearVelocity) ? kMaxLinearVelocity * MI_RSQ(l2) : 1.f;
+                v[0] *= sl; v[1] *= sl; v[2] *= sl; v[3] *= sw; v[4] *= sw; v[5] *= sw;
+            }
             sfor<3>([&](auto K) MI_LAMBDA { root[7 + K] = v[K]; root[10 + K] = v[3 + K]; root[K] += h * v[K]; });
             const float om[3] = {v[3], v[4], v[5]};
             const float an = MI_SQRT(dot3(om, om)), th = an * h;

@@ -699,6 +699,12 @@ static void step_env(const OrModel *m, const OrParams *p, const OrGround *gnd, r
         /* ---------------- integrate */
         for (int d = 0; d < nd; d++) { qd[d] = v[off + d]; q[d] += h * qd[d]; }
         if (!m->fixed_base) {
+            {   /* gymapi.AssetOptions defaults max_angular_velocity = 64 rad/s, max_linear_velocity = 1000 m/s (the tasks restated here
+                 * set neither): the simulator clamps the actor's velocities */
+                real w2 = v[3] * v[3] + v[4] * v[4] + v[5] * v[5], l2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+                real sw = w2 > (real)(64.0 * 64.0) ? (real)64.0 / RSQRT(w2) : 1, sl = l2 > (real)(1000.0 * 1000.0) ? (real)1000.0 / RSQRT(l2) : 1;
+                v[0] *= sl; v[1] *= sl; v[2] *= sl; v[3] *= sw; v[4] *= sw; v[5] *= sw;
+            }
             for (int k = 0; k < 3; k++) { root[7 + k] = v[k]; root[10 + k] = v[3 + k]; root[k] += h * v[k]; }
             real om[3] = {v[3], v[4], v[5]};
             real an = RSQRT(v3dot(om, om)), th = an * h;

@@ -230,3 +230,27 @@ def test_small_tasks_on_cpu_match_the_cpu_restatement(task, nact, steps):
     assert int(env.progress_buf[::2].abs().sum()) == 0 and int(env.progress_buf[1::2].min()) == steps
     env.engine.simulate()
     assert torch.isfinite(env.root_states).all()
+
+
+def test_actor_velocities_are_clamped_like_the_simulator_does():
+    """gymapi.AssetOptions defaults max_angular_velocity = 64 rad/s and max_linear_velocity = 1000 m/s, and ant.py leaves them alone: the
+    simulator clamps the actor's velocities.  Without the clamp an Ant flung into a 100 rad/s spin (0.8 rad per sub-step) by a periodic
+    full-amplitude policy gained energy until its state was NaN (one env in 4096 after 665 steps, tools/debug/mw_policy_check.py)."""
+    n = 64
+    env = isaacgymenvs_amd.make(seed=0, task="Ant", num_envs=n, sim_device="cpu", rl_device="cpu", headless=True)
+    env.step(torch.zeros((n, 8)))
+    t = env.engine.tensors
+    root = t["root_states"].clone()
+    root[:, 2] = 3.0                                                   # in the air
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn((n, 3), generator=g); w = w / w.norm(dim=1, keepdim=True) * torch.linspace(40.0, 400.0, n)[:, None]
+    root[:, 10:13] = w
+    t["root_states"][:] = root
+    env.dof_vel[:] = 30.0 * torch.randn((n, 8), generator=g)
+    phase = torch.rand((n, 8), generator=g) * 6.283
+    for k in range(60):
+        env.step(torch.sin(0.25 * k + phase))
+        wn = t["root_states"][:, 10:13].norm(dim=1)
+        assert torch.isfinite(t["root_states"]).all() and torch.isfinite(env.dof_vel).all(), k
+        assert float(wn.max()) <= 64.0 * (1 + 1e-4), (k, float(wn.max()))
+    assert float(env.dof_vel.abs().max()) < 400.0

@@ -54,3 +54,23 @@ def test_shadow_hand_soak_at_the_corners_of_its_actor_params_ranges():
             viol = torch.maximum(lo - env.shadow_hand_dof_pos, env.shadow_hand_dof_pos - up).max()
             assert float(viol) < 0.35, (i, float(viol))
     assert int(t["object_contact_count"].sum()) > 0
+
+
+@pytest.mark.parametrize("mw", [0, 16])
+def test_periodic_full_amplitude_policy_soak(mw):
+    """A crude periodic gait at full amplitude flings some Ants into the air spinning at > 100 rad/s; before the simulator's velocity
+    clamp (AssetOptions.max_angular_velocity = 64 rad/s by default) was in the engine, the single-wave kernel ended with a NaN state
+    for one env in 4096 after ~660 steps of this (tools/debug/mw_policy_check.py)."""
+    import isaacgymenvs_amd
+    n, steps = 4096, 800
+    env = isaacgymenvs_amd.make(seed=3, task="Ant", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True)
+    env.engine.set_option("multi_wave", mw)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    phase = torch.rand((n, 8), device=DEV, generator=g) * 6.283
+    freq = 0.15 + 0.1 * torch.rand((n, 1), device=DEV, generator=g)
+    t = env.engine.tensors
+    for k in range(steps):
+        obs, rew, reset, _ = env.step(torch.sin(freq * k + phase))
+        if k % 40 == 39:
+            assert torch.isfinite(rew).all() and torch.isfinite(t["root_states"]).all() and torch.isfinite(t["dof_state"]).all(), (mw, k)
+            assert float(t["root_states"][:, 10:13].norm(dim=1).max()) <= 64.0 * (1 + 1e-3), (mw, k)
