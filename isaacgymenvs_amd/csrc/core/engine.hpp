@@ -1663,6 +1663,7 @@ struct Sim {
         // ------------------------------------------------------------ integrate (semi-implicit Euler)
         sfor<ND>([&](auto D) MI_LAMBDA { qd[D] = v[OFF + D]; q[D] += h * qd[D]; });
         if constexpr (!M::FIXED) {
+#if !defined(MI_NO_VEL_CLAMP)   // (measurement builds only)
             {   // AssetOptions.max_angular_velocity / max_linear_velocity, Isaac Gym's defaults (64 rad/s, 1000 m/s): PhysX clamps the body
                 // velocities; without it a robot flung into a fast spin (100 rad/s = 0.8 rad per sub-step) gains energy until it is NaN
                 const float w2 = v[3] * v[3] + v[4] * v[4] + v[5] * v[5], l2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
@@ -1670,6 +1671,7 @@ struct Sim {
                 const float sl = (l2 > kMaxLinearVelocity * kMaxLinearVelocity) ? kMaxLinearVelocity * MI_RSQ(l2) : 1.f;
                 v[0] *= sl; v[1] *= sl; v[2] *= sl; v[3] *= sw; v[4] *= sw; v[5] *= sw;
             }
+#endif
             sfor<3>([&](auto K) MI_LAMBDA { root[7 + K] = v[K]; root[10 + K] = v[3 + K]; root[K] += h * v[K]; });
             const float om[3] = {v[3], v[4], v[5]};
             const float an = MI_SQRT(dot3(om, om)), th = an * h;

@@ -530,12 +530,14 @@ struct SimMW : Sim<M> {
             if constexpr (owns_gi<R>(OFF + D)) { qd[D] = v[OFF + D]; q[D] += h * qd[D]; }
         });
         if constexpr (R == M::TRUNK_ROLE) {
+#if !defined(MI_NO_VEL_CLAMP)   // (measurement builds only)
             {   // AssetOptions.max_angular_velocity / max_linear_velocity (core/engine.hpp kMax*Velocity)
                 const float w2 = v[3] * v[3] + v[4] * v[4] + v[5] * v[5], l2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
                 const float sw = (w2 > kMaxAngularVelocity * kMaxAngularVelocity) ? kMaxAngularVelocity * MI_RSQ(w2) : 1.f;
                 const float sl = (l2 > kMaxLinearVelocity * kMaxLinearVelocity) ? kMaxLinearVelocity * MI_RSQ(l2) : 1.f;
                 v[0] *= sl; v[1] *= sl; v[2] *= sl; v[3] *= sw; v[4] *= sw; v[5] *= sw;
             }
+#endif
             sfor<3>([&](auto K) MI_LAMBDA { root[7 + K] = v[K]; root[10 + K] = v[3 + K]; root[K] += h * v[K]; });
             const float om[3] = {v[3], v[4], v[5]};
             const float an = MI_SQRT(dot3(om, om)), th = an * h;
