@@ -74,3 +74,26 @@ def test_periodic_full_amplitude_policy_soak(mw):
         if k % 40 == 39:
             assert torch.isfinite(rew).all() and torch.isfinite(t["root_states"]).all() and torch.isfinite(t["dof_state"]).all(), (mw, k)
             assert float(t["root_states"][:, 10:13].norm(dim=1).max()) <= 64.0 * (1 + 1e-3), (mw, k)
+
+
+PERIODIC = [("Cartpole", 1024, 600), ("Humanoid", 4096, 600), ("Anymal", 2048, 600), ("AnymalTerrain", 2048, 600), ("ShadowHand", 4096, 500),
+            ("Quadcopter", 2048, 600), ("Ingenuity", 2048, 800), ("BallBalance", 2048, 600)]
+
+
+@pytest.mark.parametrize("task,n,steps", PERIODIC)
+def test_periodic_policy_soak_of_the_other_tasks(task, n, steps):
+    """The periodic full-amplitude policy (per-env random phases and frequencies) that found the missing velocity clamp on the Ant, on
+    every other task: everything stays finite, the root's angular speed stays inside the simulator's clamp (tools/debug/periodic_policy_soak.py)."""
+    import isaacgymenvs_amd
+    env = isaacgymenvs_amd.make(seed=3, task=task, num_envs=n, sim_device=DEV, rl_device=DEV, headless=True)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    phase = torch.rand((n, env.num_actions), device=DEV, generator=g) * 6.283
+    freq = 0.1 + 0.3 * torch.rand((n, 1), device=DEV, generator=g)
+    t = env.engine.tensors
+    for k in range(steps):
+        obs, rew, reset, _ = env.step(torch.sin(freq * k + phase))
+        if k % 40 == 39:
+            assert torch.isfinite(rew).all() and torch.isfinite(obs["obs"]).all(), (task, k)
+            assert torch.isfinite(t["root_states"]).all() and torch.isfinite(t["dof_state"]).all(), (task, k)
+            assert float(t["root_states"][:, 10:13].norm(dim=1).max()) <= 64.0 * (1 + 1e-3), (task, k)
+            assert float(t["dof_state"][..., 1].abs().max()) < 400.0, (task, k)
