@@ -930,6 +930,39 @@ def limb_paths(spec: ModelSpec):
     return limb, limbs
 
 
+def wave_roles(spec: ModelSpec, nrole: int = 4):
+    """Limbs dealt to the `nrole` wavefronts of the multi-wave sub-step (csrc/core/engine_mw.hpp): the limb of the root body is the
+    shared trunk (role -1, every wave recomputes it), the others go heaviest (most dofs) first to the least loaded wave; the trunk's
+    own constraint rows go to the wave with the lightest limbs.  -> (limb per body, body lists, role per limb, trunk role, nrole)."""
+    limb, limbs = limb_paths(spec)
+    cnt = [0] * spec.nb
+    for d in range(spec.nd):
+        cnt[int(spec.dof_body[d])] += 1
+    load = [0] * nrole
+    role_of_limb = [-1] * len(limbs)
+    order = sorted(range(1, len(limbs)), key=lambda l: -sum(cnt[b] for b in limbs[l]))
+    for l in order:
+        r = min(range(nrole), key=lambda k: (load[k], k))
+        role_of_limb[l] = r
+        load[r] += sum(cnt[b] for b in limbs[l]) + 0.01 * len(limbs[l])
+    trunk_role = min(range(nrole), key=lambda k: (load[k], k))
+    return limb, limbs, role_of_limb, trunk_role, nrole
+
+
+def solver_blocks(spec: ModelSpec, self_collision: bool = False):
+    """What the block solver order needs to know about a model (oracle/physics.c OrModel.solver = 1, the engine's multi-wave kernels):
+    gi_group [nv] -- coordinate group of every generalised velocity index (0 = trunk incl. the floating base, l = limb l),
+    body_block [nb] -- the block (wavefront) that sweeps the limit rows / ground contacts of each body, nblk (the self contacts are
+    block nblk - 1 when self_collision)."""
+    limb, limbs, role_of_limb, trunk_role, nrole = wave_roles(spec)
+    off = 0 if spec.fixed_base else 6
+    gi_group = [0] * (off + spec.nd)
+    for d in range(spec.nd):
+        gi_group[off + d] = limb[int(spec.dof_body[d])]
+    body_block = [trunk_role if role_of_limb[limb[b]] < 0 else role_of_limb[limb[b]] for b in range(spec.nb)]
+    return dict(gi_group=gi_group, body_block=body_block, nblk=nrole + (1 if self_collision else 0))
+
+
 def self_collision_groups(spec: ModelSpec, pairs=None):
     """Run-time organisation of the self-collision pairs: one *group* per pair of limbs (and per limb with non-adjacent bodies of
     its own).  A group carries at most one contact per sub-step -- its deepest capsule pair -- and all its body pairs share one

@@ -30,7 +30,9 @@ def _struct(real):
                        "dof_anchor", "dof_lower", "dof_upper", "dof_limited", "dof_armature", "dof_damping",
                        "dof_stiffness", "dof_springref", "sph_body", "sph_pos", "sph_rad", "sph_mu", "sens_body")] + \
                    [(n, C.c_int32) for n in ("ncap", "npg", "ngp", "kmax", "kpair", "warm_slots")] + \
-                   [(n, C.c_void_p) for n in ("cap_body", "cap_p0", "cap_p1", "cap_rad", "cap_mu", "gp_a", "gp_b", "pg_first", "pg_count")]
+                   [(n, C.c_void_p) for n in ("cap_body", "cap_p0", "cap_p1", "cap_rad", "cap_mu", "gp_a", "gp_b", "pg_first", "pg_count")] + \
+                   [(n, C.c_int32) for n in ("solver", "nblk", "pad1", "pad2")] + \
+                   [("gi_group", C.c_void_p), ("body_block", C.c_void_p)]
 
     class OrParams(C.Structure):
         _fields_ = [("dt", real), ("substeps", C.c_int32), ("iters", C.c_int32), ("gravity", real * 3),
@@ -47,9 +49,12 @@ class OracleEngine:
     """Batched CPU physics for one ModelSpec.  State is AoS per env:
     root[13] (pos3, quat xyzw4, linvel3, angvel3) | q[nd] | qd[nd] | lam_c[3*nsph] | lam_l[nd]."""
 
-    def __init__(self, spec, num_envs, params=None, sensor_bodies=(), precision="f64", selfcol=None, kmax=0, kpair=0, warm_slots=0):
+    def __init__(self, spec, num_envs, params=None, sensor_bodies=(), precision="f64", selfcol=None, kmax=0, kpair=0, warm_slots=0,
+                 solver="gs", blocks=None):
         """selfcol: self-collision tables (isaacgymenvs_amd.assets.model.self_collision_tables) or None; kmax / kpair: caps of
-        the ground / self contacts per env (0 = unlimited; the engine's LDS contact store holds 12 + 3)."""
+        the ground / self contacts per env (0 = unlimited; the engine's LDS contact store holds 12 + 3).
+        solver: "gs" -- one Gauss-Seidel sequence over all rows (the single-wave kernels' order); "blocks" -- the limb-per-wave
+        kernels' order (physics.c OrModel.solver = 1), with `blocks` = isaacgymenvs_amd.assets.model.solver_blocks(spec, ...)."""
         build()
         self.spec = spec
         self.np_real = np.float64 if precision == "f64" else np.float32
@@ -89,6 +94,15 @@ class OracleEngine:
             self.npg = len(first)
             self.pair_list = list(zip(ga, gb))
         m.kmax, m.kpair, m.warm_slots = int(kmax), int(kpair), int(warm_slots)
+        self.solver = solver
+        if solver == "blocks":
+            assert blocks is not None, "solver='blocks' needs the model's block tables"
+            k["gi_group"] = np.ascontiguousarray(blocks["gi_group"], np.int32)
+            k["body_block"] = np.ascontiguousarray(blocks["body_block"], np.int32)
+            m.solver, m.nblk = 1, int(blocks["nblk"])
+            m.gi_group, m.body_block = _ptr(k["gi_group"]), _ptr(k["body_block"])
+        else:
+            assert solver == "gs"
         self.model = m
         self.set_params(**(params or {}))
         self.N = num_envs

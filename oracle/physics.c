@@ -76,6 +76,18 @@ typedef struct {
     const real *cap_p0, *cap_p1, *cap_rad, *cap_mu; /* [ncap*3] x2, [ncap] x2 */
     const int32_t *gp_a, *gp_b;  /* [ngp] capsule indices; side a receives +lambda n, side b -lambda n */
     const int32_t *pg_first, *pg_count; /* [npg] */
+    /* ---- solver order.  solver 0: one Gauss-Seidel sequence over all rows (limits, ground contacts, self contacts), the order of the
+     * single-wave kernels.  solver 1: BLOCK sweeps, the order of the limb-per-wave kernels (csrc/core/engine_mw.hpp, engine_mwc.hpp): the
+     * rows are dealt to nblk blocks (a block = what one wavefront sweeps: the limit rows of the dofs and the ground contacts of the
+     * bodies with body_block[b] == k; all self contacts form block nblk - 1 when npg > 0); inside a block Gauss-Seidel in the usual row
+     * order, across blocks Jacobi with mass splitting (Tonge et al. 2012, the scheme of PhysX's GPU solver): the whitened velocity
+     * coordinates come in groups (gi_group: 0 = the trunk incl. the floating base, 1.. = one per limb); a group shared by n armed blocks
+     * coordinates come in groups (gi_group: 0 = the trunk incl. the floating base, 1.. = one per limb); a group shared by n active blocks
+     * answers each of them with the weight (n + 1) / 2, and after every sweep the blocks' true contributions are summed in block
+     * order -- solve_blocks() below. */
+    int32_t solver, nblk, pad1, pad2;
+    const int32_t *gi_group;     /* [nv] coordinate group of every generalised velocity index */
+    const int32_t *body_block;   /* [nb] */
 } OrModel;
 
 typedef struct {
@@ -401,6 +413,112 @@ static void seg_seg_closest(const real *a0, const real *a1, const real *b0, cons
     for (int k = 0; k < 3; k++) { ca[k] = a0[k] + d1[k] * s; cb[k] = b0[k] + d2[k] * tc; }
 }
 
+
+/* ------------------------------------------------------------------ solver 1: block sweeps with mass splitting (OrModel.solver)
+ * Whitened coordinates w = L^T P v with P H P^T = L L^T, P ordering every limb's coordinates before the trunk's (group 0): then the
+ * trunk part of w is the trunk's own velocity under the inertia the trunk shows with its limbs free, a limb's part is the limb's
+ * velocity relative to what the trunk imposes on it -- the same split of the kinetic energy into groups as the engine's branch-sparse
+ * L^T L factor produces (inside a group the two bases differ by a rotation, which none of the quantities below notices).
+ *
+ * One sweep: every block starts from the same w and runs Gauss-Seidel over its own rows in the usual order; a coordinate group that
+ * n >= 2 ACTIVE blocks touch answers each of them with the weight om = (n + 1) / 2 (the row's diagonal is cfm + sum_G om_G |g_G|^2,
+ * its local velocity update om_G g_G dlam); afterwards the blocks' true contributions g_G dlam are added up in block order.  With
+ * D = the block diagonal of these weighted rows, A <= D_n (Cauchy-Schwarz over the n blocks sharing a coordinate) gives A < 2 D_om:
+ * the scaled projected-Jacobi condition.  A block is active in a sweep when one of its rows carries an impulse, and before the first
+ * sweep also when it holds a contact or a violated joint limit.  tools/solver_convergence.py compares the order with plain
+ * Gauss-Seidel. */
+#define MAXGRP 16
+#define MAXBLK 16
+static void solve_blocks(const OrModel *m, const OrParams *p, Work *wk, int nv, int nrow, real (*J)[MAXV], const real *vt, real *lam,
+                         real *v, int nunit, const int *u_row, const int *u_kind, const int *u_blk, const real *u_mu,
+                         const int *u_ga, const int *u_gb) {
+    static _Thread_local real Hp[MAXV][MAXV], Lp[MAXV][MAXV], G[MAXROWS][MAXV];
+    int perm[MAXV], grp[MAXV], np_ = 0, ngrp = 0;
+    for (int i = 0; i < nv; i++) if (m->gi_group[i] + 1 > ngrp) ngrp = m->gi_group[i] + 1;
+    for (int g = ngrp - 1; g >= 0; g--)       /* limbs first (any order: they do not couple), the trunk (group 0) last */
+        for (int i = 0; i < nv; i++) if (m->gi_group[i] == g) { perm[np_] = i; grp[np_] = g; np_++; }
+    for (int i = 0; i < nv; i++) for (int j = 0; j < nv; j++) Hp[i][j] = wk->M[perm[i]][perm[j]];
+    chol(nv, Hp, Lp);
+    real wv[MAXV], wloc[MAXV], dsum[MAXV];
+    for (int i = 0; i < nv; i++) { real s = 0; for (int j = i; j < nv; j++) s += Lp[j][i] * v[perm[j]]; wv[i] = s; }
+    for (int r = 0; r < nrow; r++)            /* g = L^-1 P J^T */
+        for (int i = 0; i < nv; i++) { real s = J[r][perm[i]]; for (int k = 0; k < i; k++) s -= Lp[i][k] * G[r][k]; G[r][i] = s / Lp[i][i]; }
+    /* which coordinate groups a block's rows touch: a limb block the trunk and the groups of its own bodies, the self contacts the
+     * trunk and the groups of the two bodies of every contact */
+    int touch[MAXBLK][MAXGRP];
+    for (int b = 0; b < m->nblk; b++) for (int g = 0; g < ngrp; g++) touch[b][g] = 0;
+    for (int b = 0; b < m->nb; b++) {
+        int g = 0;
+        for (int bb = b; bb >= 0 && g == 0; bb = m->parent[bb])
+            for (int d = 0; d < m->nd; d++) if (m->dof_body[d] == bb) g = m->gi_group[jo(m) + d];
+        touch[m->body_block[b]][g] = 1; touch[m->body_block[b]][0] = 1;
+    }
+    for (int u = 0; u < nunit; u++)
+        if (u_ga[u] >= 0) { touch[u_blk[u]][0] = 1; touch[u_blk[u]][u_ga[u]] = 1; touch[u_blk[u]][u_gb[u]] = 1; }
+    for (int r = 0; r < nrow; r++) if (lam[r] != 0) for (int i = 0; i < nv; i++) wv[i] += G[r][i] * lam[r];   /* warm start */
+    for (int it = 0; it < p->iters; it++) {
+        int active[MAXBLK];
+        real om[MAXGRP];
+        for (int b = 0; b < m->nblk; b++) active[b] = 0;
+        for (int u = 0; u < nunit; u++) {
+            int r0 = u_row[u];
+            if (lam[r0] > 0 || (it == 0 && (u_kind[u] == 1 || vt[r0] > 0))) active[u_blk[u]] = 1;
+        }
+        for (int g = 0; g < ngrp; g++) {
+            int n = 0;
+            for (int b = 0; b < m->nblk; b++) n += (active[b] && touch[b][g]) ? 1 : 0;
+            om[g] = n > 1 ? (real)0.5 * (real)(n + 1) : 1;
+        }
+        for (int i = 0; i < nv; i++) dsum[i] = 0;
+        for (int b = 0; b < m->nblk; b++) {
+            for (int i = 0; i < nv; i++) wloc[i] = wv[i];
+            for (int u = 0; u < nunit; u++) {
+                if (u_blk[u] != b) continue;
+                int r0 = u_row[u];
+                real Ain[3];
+                for (int k = 0; k < (u_kind[u] ? 3 : 1); k++) {
+                    real a = p->cfm;
+                    for (int i = 0; i < nv; i++) a += om[grp[i]] * G[r0 + k][i] * G[r0 + k][i];
+                    Ain[k] = 1 / a;
+                }
+                {   /* limit row / contact normal */
+                    real vn = 0;
+                    for (int i = 0; i < nv; i++) vn += G[r0][i] * wloc[i];
+                    real nl = lam[r0] - (vn - vt[r0]) * Ain[0];
+                    if (nl < 0) nl = 0;
+                    real dl = nl - lam[r0];
+                    lam[r0] = nl;
+                    for (int i = 0; i < nv; i++) wloc[i] += om[grp[i]] * G[r0][i] * dl;
+                }
+                if (u_kind[u] == 0) continue;
+                real lt[2];
+                for (int k = 1; k <= 2; k++) {
+                    int r = r0 + k;
+                    real vn = 0;
+                    for (int i = 0; i < nv; i++) vn += G[r][i] * wloc[i];
+                    real dl = -(vn - vt[r]) * Ain[k];
+                    lt[k - 1] = lam[r] + dl;
+                    for (int i = 0; i < nv; i++) wloc[i] += om[grp[i]] * G[r][i] * dl;
+                }
+                real lim = u_mu[u] * lam[r0], nrm = RSQRT(lt[0] * lt[0] + lt[1] * lt[1]);
+                real sc = (nrm > lim) ? lim / (nrm > (real)1e-30 ? nrm : (real)1e-30) : 1;
+                for (int k = 1; k <= 2; k++) {
+                    int r = r0 + k;
+                    real nl = lt[k - 1] * sc, dl = nl - lt[k - 1];
+                    lam[r] = nl;
+                    if (dl != 0) for (int i = 0; i < nv; i++) wloc[i] += om[grp[i]] * G[r][i] * dl;
+                }
+            }
+            for (int i = 0; i < nv; i++) dsum[i] += (wloc[i] - wv[i]) / om[grp[i]];     /* the block's true contribution, in block order */
+        }
+        for (int i = 0; i < nv; i++) wv[i] += dsum[i];
+    }
+    /* back to generalised velocities: P v = L^-T w */
+    real x[MAXV];
+    for (int i = nv - 1; i >= 0; i--) { real s = wv[i]; for (int k = i + 1; k < nv; k++) s -= Lp[k][i] * x[k]; x[i] = s / Lp[i][i]; }
+    for (int i = 0; i < nv; i++) v[perm[i]] = x[i];
+}
+
 /* ------------------------------------------------------------------ one env, one full step of dt
  * state layout per env:  root[13] | q[nd] | qd[nd] | lam_c[3*nsph] | lam_l[nd]
  * outputs per env:       sensor[6*nsens] | dof_force[nd] | sph_force[3*nsph] (world)
@@ -546,6 +664,38 @@ static void step_env(const OrModel *m, const OrParams *p, const OrGround *gnd, r
                 lam[r] = lam_p[3 * g + k] * p->warm;
             }
         }
+        if (m->solver == 1) {
+            /* units in the canonical order: limit rows by dof, ground contacts by sphere, self contacts by group */
+            int nunit = 0;
+            static _Thread_local int u_row[MAXROWS], u_kind[MAXROWS], u_blk[MAXROWS], u_ga[MAXROWS], u_gb[MAXROWS];
+            static _Thread_local real u_mu[MAXROWS];
+            int bgrp[MAXB];
+            for (int b = 0; b < m->nb; b++) {
+                bgrp[b] = b == 0 ? 0 : bgrp[m->parent[b]];
+                for (int d = 0; d < nd; d++) if (m->dof_body[d] == b) bgrp[b] = m->gi_group[off + d];
+            }
+            for (int d = 0; d < nd; d++) {
+                int r = lim_row[d];
+                if (r < 0) continue;
+                u_row[nunit] = r; u_kind[nunit] = 0; u_blk[nunit] = m->body_block[m->dof_body[d]];
+                u_mu[nunit] = 0; u_ga[nunit] = u_gb[nunit] = -1;
+                nunit++;
+            }
+            for (int s = 0; s < m->nsph; s++) {
+                if (sph_row[s] < 0) continue;
+                u_row[nunit] = sph_row[s]; u_kind[nunit] = 1; u_blk[nunit] = m->body_block[m->sph_body[s]];
+                u_mu[nunit] = (real)0.5 * ((mu_env >= 0 ? mu_env : m->sph_mu[s]) + p->plane_mu); u_ga[nunit] = u_gb[nunit] = -1;
+                nunit++;
+            }
+            for (int g = 0; g < m->npg; g++) {
+                if (grp_row[g] < 0) continue;
+                u_row[nunit] = grp_row[g]; u_kind[nunit] = 1; u_blk[nunit] = m->nblk - 1;
+                u_mu[nunit] = (real)0.5 * (m->cap_mu[m->gp_a[grp_sel[g]]] + m->cap_mu[m->gp_b[grp_sel[g]]]);
+                u_ga[nunit] = bgrp[m->cap_body[m->gp_a[grp_sel[g]]]]; u_gb[nunit] = bgrp[m->cap_body[m->gp_b[grp_sel[g]]]];
+                nunit++;
+            }
+            solve_blocks(m, p, &w, nv, nrow, J, vt, lam, v, nunit, u_row, u_kind, u_blk, u_mu, u_ga, u_gb);
+        } else {
         for (int r = 0; r < nrow; r++) {
             chol_solve(nv, w.L, J[r], B[r]);
             real a = p->cfm;
@@ -630,6 +780,7 @@ static void step_env(const OrModel *m, const OrParams *p, const OrGround *gnd, r
                     if (dl != 0) for (int i = 0; i < nv; i++) v[i] += B[r][i] * dl;
                 }
             }
+        }
         }
         /* ---------------- write back impulses, sensors */
         for (int d = 0; d < nd; d++) {

@@ -295,3 +295,69 @@ def test_ellipsoid_distance_approximation_used_for_the_egg():
     assert worst_ang < 3.0, worst_ang
     d, n = sphere_ellipsoid(np.zeros(3), 0.001, a)              # centre: deepest, some unit normal
     assert d < -0.03 and abs(np.linalg.norm(n) - 1) < 1e-12
+
+
+# ------------------------------------------------------------------ solver orders (physics.c OrModel.solver)
+SIM = dict(dt=1.0 / 60.0, substeps=2, iters=4, gravity=(0.0, 0.0, -G), contact_offset=0.02, rest_offset=0.0, max_depen_vel=10.0,
+           erp=0.5, plane_mu=1.0, ground_z=0.0, cfm=1e-6, warm=1.0)
+
+
+def _rollout_states(name, n, steps, seed=0):
+    """states of a random-torque rollout (resets when the robot falls): contacts, joint limits, self contacts all occur"""
+    from isaacgymenvs_amd.registry import load_selfcol
+    spec, sc = load_model(name), load_selfcol(name)
+    kw = dict(selfcol=sc, kmax=12, kpair=3, warm_slots=9) if sc else {}
+    rng = np.random.default_rng(seed)
+    z0, term, gear = dict(ant=(0.44, 0.31, 15.0), humanoid=(1.34, 0.8, 60.0))[name]
+    e = OracleEngine(spec, n, params=dict(SIM), sensor_bodies=sensor_bodies(name), precision="f64", **kw)
+    e.root[:, 2] = z0
+    e.q[:] = np.clip(rng.uniform(-0.2, 0.2, (n, spec.nd)), spec.dof_lower, spec.dof_upper)
+    for _ in range(steps):
+        e.step(rng.uniform(-1, 1, (n, spec.nd)) * gear)
+        bad = np.nonzero(e.root[:, 2] < term)[0]
+        e.state[bad] = 0
+        e.state[bad, 6] = 1
+        e.state[bad, 2] = z0
+    return spec, sc, kw, e.state.copy(), rng.uniform(-1, 1, (n, spec.nd)) * gear
+
+
+@pytest.mark.parametrize("name", ["ant", "humanoid"])
+def test_block_solver_order_converges_to_the_gauss_seidel_solution(name):
+    """The limb-per-wave kernels sweep their rows block by block (Gauss-Seidel inside a block, weighted Jacobi across blocks, physics.c
+    solve_blocks).  Both orders solve the same complementarity problem: with many sweeps they must agree, and after the task's 4
+    sweeps the block order must be within a small factor of plain Gauss-Seidel's distance to that solution."""
+    from isaacgymenvs_amd.assets.model import solver_blocks
+    n = 64
+    spec, sc, kw, state, tau = _rollout_states(name, n, 60)
+    blocks = solver_blocks(spec, self_collision=bool(sc))
+
+    def solve(solver, iters):
+        e = OracleEngine(spec, n, params=dict(SIM, iters=iters, substeps=1, dt=SIM["dt"] / 2), sensor_bodies=sensor_bodies(name),
+                         precision="f64", solver=solver, blocks=blocks if solver == "blocks" else None, **kw)
+        e.state[:] = state
+        e.step(tau)
+        return np.concatenate([e.root[:, 7:], e.qd], 1)
+    ref = solve("gs", 3000)
+    far = solve("blocks", 3000)
+    # frictional contact has no unique solution in general (the cone depends on the normal impulse): most envs agree exactly
+    d = np.abs(far - ref).max(1)
+    assert np.median(d) < 1e-9 and (d < 1e-3).mean() > 0.75, (np.median(d), (d < 1e-3).mean())
+    e_gs = np.abs(solve("gs", 4) - ref).max(1).mean()
+    e_bl = np.abs(solve("blocks", 4) - ref).max(1).mean()
+    e_bl8 = np.abs(solve("blocks", 8) - ref).max(1).mean()
+    assert e_bl < 4.0 * e_gs + 1e-3 and e_bl8 < e_bl, (e_gs, e_bl, e_bl8)
+
+
+def test_block_solver_keeps_the_known_answers():
+    """static weight and free fall do not depend on the order the rows are swept in"""
+    from isaacgymenvs_amd.assets.model import solver_blocks
+    spec = load_model("ant")
+    e = OracleEngine(spec, 1, params=dict(SIM), sensor_bodies=sensor_bodies("ant"), precision="f64", solver="blocks",
+                     blocks=solver_blocks(spec))
+    e.root[:, 2] = 0.3
+    e.q[:] = [0, 0.9, 0, -0.9, 0, -0.9, 0, 0.9]
+    for _ in range(400):
+        e.step(np.zeros((1, spec.nd)))
+    fz = e.sph_force[0, :, 2].sum()
+    assert abs(fz - float(np.sum(spec.mass)) * 9.81) < 2e-3 * float(np.sum(spec.mass)) * 9.81, fz
+    assert np.abs(e.qd).max() < 1e-3 and np.abs(e.root[0, 7:]).max() < 1e-3
