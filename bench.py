@@ -19,10 +19,19 @@ Rank 0 prints ONE JSON line.
               command, read from profiles/traffic.json (written by tools/summarize_profile.py; null when the file has no entry).
   cpu_baseline = the CPU oracle (oracle/physics.c via oracle/tasks.py, OpenMP over envs) on a bounded sample of the
               same workload on this host's cores ("port": the reference's PhysX-CPU path cannot run).
+              `cpu_baseline.product_backend` = the engine's own g++ host build through make(seed, task, N, "cpu", "cpu") at 4 and all threads.
               `cpu_baseline.reference_jit_fns` = the reference's own jitted obs / reward functions on torch-CPU where
               /root/reference is reachable (development container), else marked absent.
-  extra     = the second headline config (Humanoid num_envs=8192, self-collision on) measured the same way in the same run;
+  extra     = the second headline config (Humanoid num_envs=8192, self-collision on) measured the same way in the same run, at every N;
               extra2 / extra3 = AnymalTerrain@4096 and ShadowHand@16384 (N = 1), or their per-GPU shards 512 / 2048 (N > 1).
+              The side legs time max(K / 4, 200) steps after max(W / 4, 50) warm-ups whatever the driver's K / W are, so that a short
+              driver run does not quote them on the first steps of the first episode.
+  --scaling strong : BASELINE's "per-GPU shard = N/G" reading -- Ant 4096 / N and Humanoid 8192 / N envs per GPU ("scaling": "strong");
+              the default is weak scaling (4096 / 8192 per GPU).
+  settle    = untimed steps run before the W warm-ups of the headline leg so that at least 100 steps ("warm-up 100 steps")
+              precede the timed region even with the driver's W = 5: the first step resets every env (reset_buf starts at 1,
+              vec_task.py:316) and a fresh episode has no falls / resets yet, i.e. less work than the steady state.
+  legs carry `consistent` = the HIP-event time of a step's launch group fits inside the wall-clock step (kernel_ms * 0.9 <= pooled ms).
 """
 from __future__ import annotations
 
@@ -55,7 +64,14 @@ def load_traffic():
         return {}
 
 
-def measure(task, num_envs, steps, warmup, device, rank, world, seed=42, pool=8):
+def leg_consistent(res):
+    """A leg's numbers hang together when the GPU time of one step's launch group (HIP events) is not longer than the wall-clock
+    step it is quoted against (10 % slack for event granularity) -- VERDICT r2: a 10-step Humanoid leg quoted 0.345 ms per step
+    beside 0.395 ms of kernels."""
+    return res["kernel_ms_avg"] * 0.9 <= res["ms_per_step"]
+
+
+def measure(task, num_envs, steps, warmup, device, rank, world, seed=42, pool=8, settle=0):
     """Times `steps` control steps twice: with the reference's protocol (actions drawn by torch.rand right before every step,
     README.md:48-51 -- this is the reported value) and with a small pool of pre-generated action batches (engine only)."""
     import torch
@@ -97,7 +113,7 @@ def measure(task, num_envs, steps, warmup, device, rank, world, seed=42, pool=8)
             wall = float(t.item())
         return wall, gpu_ms
 
-    for i in range(warmup):
+    for i in range(settle + warmup):
         env.step(2.0 * torch.rand((num_envs, na), device=device, generator=g) - 1.0)
         if reducer:
             reducer.step()
@@ -107,7 +123,7 @@ def measure(task, num_envs, steps, warmup, device, rank, world, seed=42, pool=8)
     stats = (env.engine.tensors["episode_stats"] - stats0).cpu().tolist()
     wall_pool, _ = timed(False)
     # per-launch duration of the fused step (sub-step kernels + post kernel): HIP events on the launch stream around each launch group
-    kn = min(steps, 200)
+    kn = 200
     pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(kn)]
     torch.cuda.synchronize()
     for i, (a, b) in enumerate(pairs):
@@ -124,8 +140,9 @@ def measure(task, num_envs, steps, warmup, device, rank, world, seed=42, pool=8)
         "pooled": {"ms_per_step": 1e3 * wall_pool / steps, "env_steps_per_s": world * num_envs * steps / wall_pool,
                    "note": f"same loop with a pool of {pool} pre-generated action batches instead of torch.rand per step"},
         "reset_rate": stats[2] / max(stats[4], 1.0), "mean_reward": stats[3] / max(stats[4], 1.0),
-        "multi_wave": int(env.engine.get_option("multi_wave")),
+        "multi_wave": int(env.engine.get_option("multi_wave")), "steps": steps, "warmup": warmup, "settle": settle,
     }
+    res["consistent"] = bool(leg_consistent(res))
     if task == "Humanoid":
         res["self_collision"] = int(env.engine.get_option("self_collision"))
     if reducer:
@@ -221,8 +238,12 @@ def cpu_baseline(task, num_envs, budget_s=15.0, seed=42):
                max_depen_vel=px["max_depenetration_velocity"], erp=0.5,
                plane_mu=cfg["env"]["plane"]["staticFriction"], ground_z=0.0, cfm=1e-6, warm=1.0)
     sc = load_selfcol(name)        # the Humanoid collides with itself, in the port as in the kernels
-    orc = OracleLocomotionEnv(task == "Humanoid", load_model(name), sensor_bodies(name), sim, p, num_envs, seed=seed,
-                              precision="f32", **(dict(selfcol=sc, kmax=12, kpair=3, warm_slots=9) if sc else {}))
+    from isaacgymenvs_amd.assets.model import solver_blocks
+    spec = load_model(name)
+    # same solver order as the kernels that run this size on the GPU: the limb-per-wave kernels sweep block by block
+    orc = OracleLocomotionEnv(task == "Humanoid", spec, sensor_bodies(name), sim, p, num_envs, seed=seed,
+                              precision="f32", solver="blocks", blocks=solver_blocks(spec, self_collision=bool(sc)),
+                              **(dict(selfcol=sc, kmax=12, kpair=3, warm_slots=9) if sc else {}))
     rng = np.random.default_rng(seed)
     nact = orc.nd
     for _ in range(2):
@@ -255,6 +276,34 @@ def cpu_baseline(task, num_envs, budget_s=15.0, seed=42):
     return out
 
 
+def cpu_product_backend(task, num_envs, budget_s=8.0, seed=42):
+    """The engine's OWN host build (libmi_engine_cpu.so: csrc/core/engine.hpp + the task headers compiled by g++, OpenMP over envs)
+    through the public API -- `make(seed, task, num_envs, "cpu", "cpu")`, i.e. the reference's `sim_device=cpu pipeline=cpu` call -- at
+    the reference's `num_threads: 4` (cfg/config.yaml:30) and at all host threads.  The closest stand-in for the reference's CPU
+    pipeline that can run here; it is the product's CPU path, not the oracle."""
+    import torch
+    import isaacgymenvs_amd
+    out = {"kind": "product_cpu_backend", "unit": "env-steps/s", "task": task, "num_envs": num_envs}
+    try:
+        env = isaacgymenvs_amd.make(seed=seed, task=task, num_envs=num_envs, sim_device="cpu", rl_device="cpu", headless=True, force_render=False)
+        g = torch.Generator().manual_seed(seed)
+        all_cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+        for c in sorted({4, all_cores}):
+            env.engine.set_option("num_threads", c)
+            for _ in range(3):
+                env.step(2.0 * torch.rand((num_envs, env.num_actions), generator=g) - 1.0)
+            n, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < budget_s / 2 and n < 2000:
+                env.step(2.0 * torch.rand((num_envs, env.num_actions), generator=g) - 1.0)
+                n += 1
+            dt = time.perf_counter() - t0
+            out[f"threads_{c}"] = {"value": num_envs * n / dt, "steps": n, "seconds": round(dt, 2)}
+        out["host_threads"] = all_cores
+    except Exception as ex:  # noqa: BLE001 -- a missing CPU library must not break the bench line; it is reported
+        out["absent"] = f"{type(ex).__name__}: {ex}"[:200]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -264,6 +313,8 @@ def main():
     ap.add_argument("--num-envs", type=int, default=0, help="envs per GPU (default: the BASELINE config of the task)")
     ap.add_argument("--no-extra", action="store_true", help="skip the Humanoid@8192 side measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: the BASELINE env count PER GPU (default); strong: the BASELINE env count split over the GPUs (N/G per GPU)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--pool", type=int, default=8,
                     help="number of pre-generated U(-1,1) action batches cycled through.  The reference protocol draws the actions with "
@@ -282,19 +333,27 @@ def main():
     torch.cuda.set_device(local_rank)
     n_env = args.num_envs or DEFAULT_ENVS[args.task]
 
+    strong = args.scaling == "strong"
+    if strong and not args.num_envs:
+        n_env = max(DEFAULT_ENVS[args.task] // world, 64)       # BASELINE "per-GPU shard = N/G"
     extra = extra2 = extra3 = None
     side = {"Humanoid": DEFAULT_ENVS["Humanoid"], "AnymalTerrain": DEFAULT_ENVS["AnymalTerrain"], "ShadowHand": DEFAULT_ENVS["ShadowHand"]}
     if world > 1:      # BASELINE configs 4 / 5 are quoted sharded over the GPUs of the node: 4096 / 8 and 16384 / 8 envs per GPU
         side["AnymalTerrain"] = max(DEFAULT_ENVS["AnymalTerrain"] // world, 64)
         side["ShadowHand"] = max(DEFAULT_ENVS["ShadowHand"] // world, 64)
+        if strong:
+            side["Humanoid"] = max(DEFAULT_ENVS["Humanoid"] // world, 64)
+    # side legs: long enough to be steady-state numbers whatever K / W the driver passes for the headline
+    sk, sw = max(args.steps // 4, 200), max(args.warmup // 4, 50)
     if not args.no_extra and args.task == "Ant":
-        if world == 1:
-            extra = measure("Humanoid", side["Humanoid"], max(args.steps // 4, 10), max(args.warmup // 4, 5), device, rank, world)
-        extra2 = measure("AnymalTerrain", side["AnymalTerrain"], max(args.steps // 4, 10), max(args.warmup // 4, 5), device, rank, world)
-        extra3 = measure("ShadowHand", side["ShadowHand"], max(args.steps // 8, 10), max(args.warmup // 8, 5), device, rank, world)
-    # The headline configuration is measured last (still W untimed + exactly K timed steps): with the driver's short runs (K = 20, W = 5,
-    # i.e. 1.5 ms of GPU work) it would otherwise be timed on a device that is still ramping its clocks up from idle.
-    main_res = measure(args.task, n_env, args.steps, args.warmup, device, rank, world, pool=args.pool)
+        extra = measure("Humanoid", side["Humanoid"], sk, sw, device, rank, world)
+        extra2 = measure("AnymalTerrain", side["AnymalTerrain"], sk, sw, device, rank, world)
+        extra3 = measure("ShadowHand", side["ShadowHand"], sk, sw, device, rank, world)
+    # The headline configuration is measured last (W untimed warm-ups + exactly K timed steps, after `settle` more untimed steps that
+    # bring the episodes to their steady-state reset rate): with the driver's short runs (K = 20, W = 5, i.e. 1.5 ms of GPU work) it
+    # would otherwise be timed on a device that is still ramping its clocks up from idle, on envs that were all reset one step ago.
+    settle = max(100 - args.warmup, 0)
+    main_res = measure(args.task, n_env, args.steps, args.warmup, device, rank, world, pool=args.pool, settle=settle)
     import torch.distributed as dist
     if rank != 0:
         if dist.is_initialized():
@@ -304,12 +363,13 @@ def main():
     out = {
         "metric": "env-steps/sec (num_envs x control-steps/sec), random-action rollout",
         "value": main_res["env_steps_per_s"], "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+        "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.task} num_envs={n_env} per GPU ({world * n_env} total), VecTask.step() via Python API, "
                                f"actions = 2*torch.rand-1 drawn before every step (README.md:48-51), seed 42+rank",
                    "task": args.task, "num_envs_per_gpu": n_env, "parallelism": f"env-shard x{world}",
                    "multi_wave": main_res["multi_wave"]},
+        "settle": settle, "consistent": main_res["consistent"],
         "gpu_ms_per_step": main_res["gpu_ms_per_step"], "reset_rate": main_res["reset_rate"],
         "mean_reward": main_res["mean_reward"], "pooled": main_res["pooled"],
         "roofline": roofline(args.task, n_env, main_res["kernel_ms_avg"], main_res["multi_wave"]),
@@ -317,22 +377,26 @@ def main():
     if "job_stats" in main_res:
         out["job_stats"] = main_res["job_stats"]
     if extra is not None:
-        out["extra"] = {"workload": f"Humanoid num_envs={side['Humanoid']} per GPU, self-collision {'on' if extra.get('self_collision') else 'off'} "
-                                    f"(humanoid.py:194)", "value": extra["env_steps_per_s"],
+        out["extra"] = {"workload": f"Humanoid num_envs={side['Humanoid']} per GPU ({world * side['Humanoid']} total), self-collision "
+                                    f"{'on' if extra.get('self_collision') else 'off'} (humanoid.py:194)", "value": extra["env_steps_per_s"],
                         "unit": "env-steps/s", "ms_per_step": extra["ms_per_step"], "reset_rate": extra["reset_rate"], "pooled": extra["pooled"],
-                        "multi_wave": extra["multi_wave"],
+                        "multi_wave": extra["multi_wave"], "steps": extra["steps"], "warmup": extra["warmup"], "consistent": extra["consistent"],
                         "roofline": roofline("Humanoid", side["Humanoid"], extra["kernel_ms_avg"], extra["multi_wave"])}
     if extra2 is not None:
         out["extra2"] = {"workload": f"AnymalTerrain num_envs={side['AnymalTerrain']} per GPU ({world * side['AnymalTerrain']} total; 5 sim steps of 5 ms per control step)",
                          "value": extra2["env_steps_per_s"], "unit": "env-steps/s", "ms_per_step": extra2["ms_per_step"],
                          "reset_rate": extra2["reset_rate"], "pooled": extra2["pooled"], "multi_wave": extra2["multi_wave"],
+                         "steps": extra2["steps"], "warmup": extra2["warmup"], "consistent": extra2["consistent"],
                          "roofline": roofline("AnymalTerrain", side["AnymalTerrain"], extra2["kernel_ms_avg"], extra2["multi_wave"])}
         if "job_stats" in extra2:
             out["extra2"]["job_stats"] = extra2["job_stats"]
+    if extra is not None and "job_stats" in extra:
+        out["extra"]["job_stats"] = extra["job_stats"]
     if extra3 is not None:
         out["extra3"] = {"workload": f"ShadowHand (block, full_state) num_envs={side['ShadowHand']} per GPU ({world * side['ShadowHand']} total; 2 sub-steps per control step)",
                          "value": extra3["env_steps_per_s"], "unit": "env-steps/s", "ms_per_step": extra3["ms_per_step"],
                          "reset_rate": extra3["reset_rate"], "pooled": extra3["pooled"],
+                         "steps": extra3["steps"], "warmup": extra3["warmup"], "consistent": extra3["consistent"],
                          "roofline": roofline("ShadowHand", side["ShadowHand"], extra3["kernel_ms_avg"])}
         if "job_stats" in extra3:
             out["extra3"]["job_stats"] = extra3["job_stats"]
@@ -340,6 +404,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args.task, n_env, budget_s=args.cpu_budget)
         leg = reference_jit_leg(args.task, n_env)
         out["cpu_baseline"]["reference_jit_fns"] = leg if leg is not None else {"absent": "/root/reference is not reachable on this host"}
+        out["cpu_baseline"]["product_backend"] = cpu_product_backend(args.task, n_env, budget_s=min(args.cpu_budget, 8.0))
     print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()

@@ -28,9 +28,15 @@ def make(seed: int, task: str, num_envs: int, sim_device: str, rl_device: str, g
         rl_device = f"cuda:{local_rank}"
         cfg_dict["_multi_gpu"] = True
     cfg_dict["_seed"] = int(seed) if seed is not None and seed >= 0 else 0
-    # callers pass seed + rank under multi_gpu (reference rlgames_utils.py:89-107, utils/utils.py:94); whatever must be IDENTICAL on
-    # every rank -- the AnymalTerrain height field -- is seeded with the job's base seed
-    cfg_dict["_terrain_seed"] = cfg_dict["_seed"] - (int(os.getenv("RANK", "0")) if multi_gpu else 0)
+    # Contract under multi_gpu: the caller passes seed + RANK, as the reference's launcher does (rlgames_utils.py:89-107,
+    # utils/utils.py:94 `seed += rank`); whatever must be IDENTICAL on every rank -- the AnymalTerrain height field -- is seeded with
+    # the job's base seed = seed - RANK.  A caller that passes the same seed on every rank (README-style make() per rank) says so with
+    # cfg["_base_seed"]; without it the subtraction is clamped at 0 (np.random.RandomState rejects negative seeds) and the ranks of
+    # such a job would build different terrains.
+    if "_base_seed" in cfg_dict:
+        cfg_dict["_terrain_seed"] = max(0, int(cfg_dict["_base_seed"]))
+    else:
+        cfg_dict["_terrain_seed"] = max(0, cfg_dict["_seed"] - (int(os.getenv("RANK", "0")) if multi_gpu else 0))
     name = cfg_dict["name"]
     if name not in isaacgym_task_map:
         raise KeyError(name)

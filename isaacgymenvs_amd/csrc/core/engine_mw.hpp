@@ -16,12 +16,16 @@
 //   P2  all roles   (redundantly) trunk coming up with every limb's contribution, trunk factor, trunk part of the whitened velocity
 //   P3  all roles   constraint rows of the own limbs (joint limits, ground contacts) into the LDS row store, warm start
 //   --- barrier ---
-//   P4  one role    projected Gauss-Seidel sweeps over all rows (inherently sequential), whitened velocity back to LDS
-//   --- barrier ---
+//   P4  all roles   the constraint sweeps, BLOCK by block: every wave runs Gauss-Seidel over its OWN rows (their limb part of the
+//                   whitened velocity never leaves its registers); the waves couple only through the trunk part of w, which is
+//                   treated Jacobi-fashion with mass splitting -- a trunk shared by n >= 2 active waves answers each of them with the
+//                   weight (n + 1) / 2, and after every sweep the waves' true trunk contributions are summed in role order
+//                   (one barrier per sweep, exchange area double buffered).  oracle/physics.c solve_blocks() states the order.
 //   P5  all roles   generalised velocity of trunk + own limbs, impulses / sensors / joint forces of the own rows, integration
 //
-// Same arithmetic per row as Sim<M>::substep (the oracle does not distinguish the two); the summation order of the limbs' trunk
-// contributions is fixed (role 0, 1, 2, 3), so results do not depend on wave timing.  Static row store only.
+// Same arithmetic per row as Sim<M>::substep; the sums over roles have a fixed order (role 0, 1, 2, 3), so results do not depend on
+// wave timing.  Static row store only.  (Until round 3 P4 was ONE role sweeping all rows in the single-wave kernel's Gauss-Seidel
+// order -- 37 % of the sub-step with three waves idle; tools/solver_convergence.py compares the two orders.)
 #pragma once
 #include "engine.hpp"
 
@@ -44,7 +48,6 @@ struct SimMW : Sim<M> {
     template <int R> static constexpr bool owns_body(int b) { return role_of_body(b) == R || (trunk_body(b) && R == M::TRUNK_ROLE); }
     template <int R> static constexpr bool owns_gi(int gi) { return role_of_gi(gi) == R || (trunk_gi(gi) && R == M::TRUNK_ROLE); }
     template <int R> static constexpr bool sees_gi(int gi) { return role_of_gi(gi) == R || trunk_gi(gi); }   // holds valid L / w entries
-    static constexpr int PGS_ROLE = M::TRUNK_ROLE;
     // trunk bookkeeping: bodies, generalised indices, trunk x trunk entries of L, limb roots
     static constexpr int NTB = []() constexpr { int n = 0; for (int b = 0; b < NB; ++b) n += trunk_body(b) ? 1 : 0; return n; }();
     static constexpr int tslot(int b) { int n = 0; for (int k = 0; k < b; ++k) n += trunk_body(k) ? 1 : 0; return n; }
@@ -67,10 +70,22 @@ struct SimMW : Sim<M> {
     static constexpr int X_LR = B::ROW_SLOTS_STATIC;             // [NLR][16]  composite inertia (10) + force (6) of every limb root
     static constexpr int X_DT = X_LR + 16 * NLR;                 // [NR][NTE]  Schur complement of the role's limbs on the trunk block
     static constexpr int X_DY = X_DT + NR * NTE;                 // [NR][NVT]  right-hand-side carry of the role's limbs
-    static constexpr int X_DW = X_DY + NR * NVT;                 // [NR][NVT]  warm-start contribution of the role's rows to the trunk w
-    static constexpr int X_W = X_DW + NR * NVT;                  // [NV]       whitened velocity (limb parts before the sweeps, all after)
-    static constexpr int X_ACT = X_W + NV;                       // [NR][2]    wave-uniform "sphere touched by some env" bits
-    static constexpr int MW_SLOTS = X_ACT + 2 * NR;
+    static constexpr int X_DW = X_DY + NR * NVT;                 // [2][NR][NVT] the role's contribution to the trunk part of w: warm start, then one per sweep (double buffered)
+    static constexpr int X_FLG = X_DW + 2 * NR * NVT;            // [2][NR]    "this role's block is active" (1.f / 0.f), double buffered like X_DW
+    static constexpr int X_AT = X_FLG + 2 * NR;                  // [NROWG]    trunk part |g_T|^2 of every row's diagonal (Ainv slot: cfm + limb part, +inf = inert row)
+    static constexpr int MW_SLOTS = X_AT + NROWG;
+
+    // units of the constraint sweeps (one limit row, or the 3 rows of a sphere) in row order, and which role sweeps them
+    static constexpr int NUNIT = NLIM + NSPH;
+    template <int R> static constexpr bool own_unit(int u) {
+        if (u < 0 || u >= NUNIT) return false;
+        return u < NLIM ? owns_gi<R>(OFF + B::limdof(u)) : owns_body<R>(M::sph_body[u - NLIM]);
+    }
+    template <int R> static constexpr int next_own(int u) {       // first unit of role R after u (NUNIT: none)
+        for (int k = u + 1; k < NUNIT; ++k) if (own_unit<R>(k)) return k;
+        return NUNIT;
+    }
+    template <int R> static constexpr int own_pos(int u) { int n = 0; for (int k = 0; k < u; ++k) n += own_unit<R>(k) ? 1 : 0; return n; }
 
     // ------------------------------------------------------------------------------------------------ trunk, going down
     template <int R, int b, int RS>
@@ -237,6 +252,8 @@ struct SimMW : Sim<M> {
         // ============================================================ P3: constraint rows of the own limbs (static store)
         float dw[NVT];                      // this role's warm-start contribution to the trunk part of w
         sfor<NVT>([&](auto I) MI_LAMBDA { dw[I] = 0.f; });
+        // is this role's block active in the first sweep: a row with a warm-start impulse, a violated joint limit, a contact
+        float act = 0.f;
         auto wadd = [&](auto GI, const float val) MI_LAMBDA {
             constexpr int gi = decltype(GI)::value;
             if constexpr (trunk_gi(gi)) { constexpr int ti = tidx(gi); dw[ti] += val; } else w[gi] += val;
@@ -279,11 +296,18 @@ struct SimMW : Sim<M> {
                         g[kk] -= L[M::midx[i][j]] * z;
                     });
                 });
-                float a = P.cfm;
-                sfor<M::nanc[gi] + 1>([&](auto K) MI_LAMBDA { a += g[K] * g[K]; G(row, K) = g[K]; });
-                Ainv(row) = MI_RCP(a);
-                vt(row) = (C >= 0.f) ? -C * invh : fminf(-C * P.erp * invh, P.max_depen_vel);
+                float al = P.cfm, at = 0.f;      // diagonal of the row, limb and trunk part apart (the sweeps weight the trunk part)
+                sfor<M::nanc[gi] + 1>([&](auto K) MI_LAMBDA {
+                    constexpr int k = K, i = (k == 0) ? gi : M::anc[gi][k == 0 ? 0 : k - 1];
+                    if constexpr (trunk_gi(i)) at += g[k] * g[k]; else al += g[k] * g[k];
+                    G(row, k) = g[k];
+                });
+                Ainv(row) = al;
+                rows(X_AT + row) = at;
+                const float vtl = (C >= 0.f) ? -C * invh : fminf(-C * P.erp * invh, P.max_depen_vel);
+                vt(row) = vtl;
                 lam(row) = l0;
+                act = ((l0 > 0.f) || (vtl > 0.f)) ? 1.f : act;
                 wadd(std::integral_constant<int, gi>{}, g[0] * l0);
                 sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { wadd(std::integral_constant<int, M::anc[gi][A_]>{}, g[1 + A_] * l0); });
             }
@@ -315,6 +339,7 @@ struct SimMW : Sim<M> {
                     return;
                 }
                 sph_active |= 1ull << s;
+                act = on ? 1.f : act;
                 sfor<3>([&](auto K) MI_LAMBDA {
                     constexpr int k = K, row = row0 + k;
                     float W[6];
@@ -337,9 +362,13 @@ struct SimMW : Sim<M> {
                         else g[C] = W[gi - 3];
                     });
                     chain_solve(std::integral_constant<int, b>{}, g);
-                    float a = P.cfm;
-                    sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { a += g[C] * g[C]; G(row, C) = g[C]; });
-                    Ainv(row) = onf * MI_RCP(a);
+                    float al = P.cfm, at = 0.f;
+                    sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA {
+                        if constexpr (trunk_gi(M::chain[b][C])) at += g[C] * g[C]; else al += g[C] * g[C];
+                        G(row, C) = g[C];
+                    });
+                    Ainv(row) = on ? al : __builtin_inff();          // inert row: 1 / inf = 0 in every sweep
+                    rows(X_AT + row) = at;
                     const float vtn = (gap >= 0.f) ? -gap * invh : fminf(-gap * P.erp * invh, P.max_depen_vel);
                     if constexpr (GND::HEIGHTFIELD) vt(row) = (k == 0) ? vtn : fr[0][k - 1];
                     else vt(row) = (k == 0) ? vtn : 0.f;
@@ -349,51 +378,58 @@ struct SimMW : Sim<M> {
                 });
             }
         });
-        sfor<NV>([&](auto I) MI_LAMBDA { if constexpr (role_of_gi(I) == R) rows(X_W + I) = w[I]; });
         sfor<NVT>([&](auto I) MI_LAMBDA { rows(X_DW + R * NVT + I) = dw[I]; });
-        rows(X_ACT + 2 * R) = __builtin_bit_cast(float, (unsigned)(sph_active & 0xffffffffull));
-        rows(X_ACT + 2 * R + 1) = __builtin_bit_cast(float, (unsigned)(sph_active >> 32));
+        rows(X_FLG + R) = act;
         bar();
-        // ============================================================ P4 (one role): projected Gauss-Seidel sweeps over all rows
-        if constexpr (R == PGS_ROLE) {
-            sfor<NV>([&](auto I) MI_LAMBDA {
-                constexpr int i = I;
-                if constexpr (trunk_gi(i)) { sfor<NR>([&](auto R_) MI_LAMBDA { constexpr int o = X_DW + R_ * NVT + tidx(i); w[i] += rows(o); }); }
-                else if constexpr (role_of_gi(i) != R) w[i] = rows(X_W + i);
-            });
-            sfor<NR>([&](auto R_) MI_LAMBDA {
-                if constexpr (R_ != R) {
-                    const unsigned lo = __builtin_bit_cast(unsigned, (float)rows(X_ACT + 2 * R_)), hi = __builtin_bit_cast(unsigned, (float)rows(X_ACT + 2 * R_ + 1));
-                    unsigned long long m = ((unsigned long long)hi << 32) | lo;
-#if defined(__HIP_DEVICE_COMPILE__)
-                    m = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)hi) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)lo);   // wave-uniform: keep it scalar
-#endif
-                    sph_active |= m;
-                }
-            });
-            constexpr int NUNIT = NLIM + NSPH;
-            struct UBuf { float g[3][M::MAXCHAIN]; float ainv[3], vt[3], lam[3]; };
+        // ============================================================ P4 (every role): block sweeps
+        // trunk part of w: every role adds all roles' warm-start contributions, in role order
+        sfor<NV>([&](auto I) MI_LAMBDA {
+            constexpr int i = I;
+            if constexpr (trunk_gi(i)) { sfor<NR>([&](auto R_) MI_LAMBDA { constexpr int o = X_DW + R_ * NVT + tidx(i); w[i] += rows(o); }); }
+        });
+        {
+            struct UBuf { float g[3][M::MAXCHAIN]; float al[3], at[3], vt, lam[3]; };
             UBuf ub[2];
+            float wtl[NVT];                  // trunk part of w as this block sees it during a sweep
             for (int it = 0; it < P.iters; ++it) {
                 int zero;
                 MI_OPAQUE_ZERO(zero);
                 const RowStore<RS> rit = rows.shifted(zero);
+                const int par = it & 1;
+                const RowStore<RS> xout = rows.shifted((X_DW + (par ^ 1) * NR * NVT) * RowStore<RS>::stride);
+                const RowStore<RS> fin = rows.shifted((X_FLG + par * NR) * RowStore<RS>::stride), fout = rows.shifted((X_FLG + (par ^ 1) * NR) * RowStore<RS>::stride);
+                float nact = 0.f;
+                sfor<NR>([&](auto R_) MI_LAMBDA { nact += fin(R_); });
+                const float om = (nact > 1.5f) ? 0.5f * (nact + 1.f) : 1.f;      // weight of the shared trunk coordinates in this sweep
+                const float iom = 1.f / om;
+                sfor<NV>([&](auto I) MI_LAMBDA { if constexpr (trunk_gi(I)) { constexpr int ti = tidx(I); wtl[ti] = w[I]; } });
+                auto wget = [&](auto GI) MI_LAMBDA -> float {
+                    constexpr int gi = decltype(GI)::value;
+                    if constexpr (trunk_gi(gi)) { constexpr int ti = tidx(gi); return wtl[ti]; } else return w[gi];
+                };
+                auto wupd = [&](auto GI, const float val) MI_LAMBDA {
+                    constexpr int gi = decltype(GI)::value;
+                    if constexpr (trunk_gi(gi)) { constexpr int ti = tidx(gi); wtl[ti] += om * val; } else w[gi] += val;
+                };
+                float actn = 0.f;
                 auto load_unit = [&](auto U_, UBuf& Bf) MI_LAMBDA {
                     constexpr int u = decltype(U_)::value;
                     if constexpr (u < NLIM) {
                         constexpr int d = B::limdof(u), gi = OFF + d, row = u;
                         sfor<M::nanc[gi] + 1>([&](auto K) MI_LAMBDA { Bf.g[0][K] = rit(row * M::MAXCHAIN + K); });
-                        Bf.ainv[0] = rit(NROWG * M::MAXCHAIN + row);
-                        Bf.vt[0] = rit(NROWG * M::MAXCHAIN + NROWG + row);
+                        Bf.al[0] = rit(NROWG * M::MAXCHAIN + row);
+                        Bf.at[0] = rit(X_AT + row);
+                        Bf.vt = rit(NROWG * M::MAXCHAIN + NROWG + row);
                         Bf.lam[0] = rit(NROWG * M::MAXCHAIN + 2 * NROWG + row);
                     } else if constexpr (u < NUNIT) {
                         constexpr int s = u - NLIM, b = M::sph_body[s], row0 = NLIM + 3 * s;
                         sfor<3>([&](auto K) MI_LAMBDA {
                             sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { Bf.g[K][C] = rit((row0 + K) * M::MAXCHAIN + C); });
-                            Bf.ainv[K] = rit(NROWG * M::MAXCHAIN + row0 + K);
+                            Bf.al[K] = rit(NROWG * M::MAXCHAIN + row0 + K);
+                            Bf.at[K] = rit(X_AT + row0 + K);
                             Bf.lam[K] = rit(NROWG * M::MAXCHAIN + 2 * NROWG + row0 + K);
                         });
-                        Bf.vt[0] = rit(NROWG * M::MAXCHAIN + NROWG + row0);
+                        Bf.vt = rit(NROWG * M::MAXCHAIN + NROWG + row0);
                     }
                 };
                 auto unit_on = [&](auto U_) MI_LAMBDA -> bool {
@@ -402,62 +438,76 @@ struct SimMW : Sim<M> {
                     else if constexpr (u < NUNIT) return (sph_active >> (u - NLIM) & 1ull) != 0ull;
                     else return false;
                 };
-                if constexpr (NUNIT > 0) load_unit(std::integral_constant<int, 0>{}, ub[0]);
+                constexpr int U0 = next_own<R>(-1);
+                if constexpr (U0 < NUNIT) load_unit(std::integral_constant<int, U0>{}, ub[0]);
                 sfor<NUNIT>([&](auto U_) MI_LAMBDA {
                     constexpr int u = U_;
-                    UBuf& Bf = ub[u & 1];
-                    if (unit_on(std::integral_constant<int, u + 1>{}))
-                        load_unit(std::integral_constant<int, u + 1>{}, ub[(u + 1) & 1]);
-                    MI_PHASE();
-                    if (!unit_on(std::integral_constant<int, u>{})) return;
-                    if constexpr (u < NLIM) {
-                        constexpr int d = B::limdof(u), gi = OFF + d, row = u;
-                        float vn = Bf.g[0][0] * w[gi];
-                        sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { vn += Bf.g[0][1 + A_] * w[M::anc[gi][A_]]; });
-                        const float lo = Bf.lam[0];
-                        const float nl = fmaxf(lo - (vn - Bf.vt[0]) * Bf.ainv[0], 0.f);
-                        const float dl = nl - lo;
-                        lam(row) = nl;
-                        w[gi] += Bf.g[0][0] * dl;
-                        sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { w[M::anc[gi][A_]] += Bf.g[0][1 + A_] * dl; });
-                    } else {
-                        constexpr int s = u - NLIM, b = M::sph_body[s], row0 = NLIM + 3 * s;
-                        const float mu = 0.5f * ((mu_env >= 0.f ? mu_env : M::sph_mu[s]) + P.plane_mu);
-                        float ln;
-                        {
-                            float vn = 0.f;
-                            sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { vn += Bf.g[0][C] * w[M::chain[b][C]]; });
+                    if constexpr (own_unit<R>(u)) {
+                        // position of u among the own units picks the register buffer
+                        constexpr int pos = own_pos<R>(u), un = next_own<R>(u);
+                        UBuf& Bf = ub[pos & 1];
+                        if (unit_on(std::integral_constant<int, un>{}))
+                            load_unit(std::integral_constant<int, un>{}, ub[(pos + 1) & 1]);  // prefetch (no-op past the end)
+                        MI_PHASE();
+                        if (!unit_on(std::integral_constant<int, u>{})) return;
+                        if constexpr (u < NLIM) {
+                            constexpr int d = B::limdof(u), gi = OFF + d, row = u;
+                            float vn = Bf.g[0][0] * wget(std::integral_constant<int, gi>{});
+                            sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { vn += Bf.g[0][1 + A_] * wget(std::integral_constant<int, M::anc[gi][A_]>{}); });
                             const float lo = Bf.lam[0];
-                            ln = fmaxf(lo - (vn - Bf.vt[0]) * Bf.ainv[0], 0.f);
-                            const float dl = ln - lo;
-                            lam(row0) = ln;
-                            sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += Bf.g[0][C] * dl; });
-                        }
-                        float lt[2];
-                        sfor<2>([&](auto K) MI_LAMBDA {
-                            float vn = 0.f;
-                            sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { vn += Bf.g[1 + K][C] * w[M::chain[b][C]]; });
-                            const float dl = -vn * Bf.ainv[1 + K];
-                            lt[K] = Bf.lam[1 + K] + dl;
-                            sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += Bf.g[1 + K][C] * dl; });
-                        });
-                        const float lim = mu * ln;
-                        const float n2 = lt[0] * lt[0] + lt[1] * lt[1];
-                        const float scl = (n2 > lim * lim) ? lim * MI_RSQ(fmaxf(n2, 1e-30f)) : 1.f;
-                        sfor<2>([&](auto K) MI_LAMBDA {
-                            constexpr int row = row0 + 1 + K;
-                            const float nl = lt[K] * scl, dl = nl - lt[K];
+                            const float nl = fmaxf(lo - (vn - Bf.vt) * MI_RCP(Bf.al[0] + om * Bf.at[0]), 0.f);
+                            const float dl = nl - lo;
                             lam(row) = nl;
-                            sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += Bf.g[1 + K][C] * dl; });
-                        });
+                            actn = (nl > 0.f) ? 1.f : actn;
+                            wupd(std::integral_constant<int, gi>{}, Bf.g[0][0] * dl);
+                            sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { wupd(std::integral_constant<int, M::anc[gi][A_]>{}, Bf.g[0][1 + A_] * dl); });
+                        } else {
+                            constexpr int s = u - NLIM, b = M::sph_body[s], row0 = NLIM + 3 * s;
+                            const float mu = 0.5f * ((mu_env >= 0.f ? mu_env : M::sph_mu[s]) + P.plane_mu);
+                            float ainv[3];
+                            sfor<3>([&](auto K) MI_LAMBDA { ainv[K] = MI_RCP(Bf.al[K] + om * Bf.at[K]); });
+                            float ln;
+                            {
+                                float vn = 0.f;
+                                sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { vn += Bf.g[0][C] * wget(std::integral_constant<int, M::chain[b][C]>{}); });
+                                const float lo = Bf.lam[0];
+                                ln = fmaxf(lo - (vn - Bf.vt) * ainv[0], 0.f);
+                                const float dl = ln - lo;
+                                lam(row0) = ln;
+                                actn = (ln > 0.f) ? 1.f : actn;
+                                sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { wupd(std::integral_constant<int, M::chain[b][C]>{}, Bf.g[0][C] * dl); });
+                            }
+                            float lt[2];
+                            sfor<2>([&](auto K) MI_LAMBDA {
+                                float vn = 0.f;
+                                sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { vn += Bf.g[1 + K][C] * wget(std::integral_constant<int, M::chain[b][C]>{}); });
+                                const float dl = -vn * ainv[1 + K];
+                                lt[K] = Bf.lam[1 + K] + dl;
+                                sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { wupd(std::integral_constant<int, M::chain[b][C]>{}, Bf.g[1 + K][C] * dl); });
+                            });
+                            const float lim = mu * ln;
+                            const float n2 = lt[0] * lt[0] + lt[1] * lt[1];
+                            const float scl = (n2 > lim * lim) ? lim * MI_RSQ(fmaxf(n2, 1e-30f)) : 1.f;
+                            sfor<2>([&](auto K) MI_LAMBDA {
+                                constexpr int row = row0 + 1 + K;
+                                const float nl = lt[K] * scl, dl = nl - lt[K];
+                                lam(row) = nl;
+                                sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { wupd(std::integral_constant<int, M::chain[b][C]>{}, Bf.g[1 + K][C] * dl); });
+                            });
+                        }
                     }
                 });
+                // this block's true contribution to the trunk part, its activity in the next sweep; then everybody's, in role order
+                sfor<NV>([&](auto I) MI_LAMBDA { if constexpr (trunk_gi(I)) { constexpr int ti = tidx(I); xout(R * NVT + ti) = (wtl[ti] - w[I]) * iom; } });
+                fout(R) = actn;
+                bar();
+                sfor<NV>([&](auto I) MI_LAMBDA {
+                    constexpr int i = I;
+                    if constexpr (trunk_gi(i)) { sfor<NR>([&](auto R_) MI_LAMBDA { constexpr int o = R_ * NVT + tidx(i); w[i] += xout(o); }); }
+                });
             }
-            sfor<NV>([&](auto I) MI_LAMBDA { rows(X_W + I) = w[I]; });
         }
-        bar();
         // ============================================================ P5: back to generalised velocity, outputs, integration
-        if constexpr (R != PGS_ROLE) sfor<NV>([&](auto I) MI_LAMBDA { if constexpr (sees_gi<R>(I)) w[I] = rows(X_W + I); });
         sfor<NV>([&](auto I_) MI_LAMBDA {       // ascending: ancestors (trunk or own limb) first
             constexpr int i = I_;
             if constexpr (sees_gi<R>(i)) {

@@ -212,54 +212,62 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         _finish_cpu(cpu_job)
         return LIB_PATH
-    os.makedirs(BUILD_DIR, exist_ok=True)
-    hdrs = []
-    for d, _, fs in os.walk(CSRC):
-        if os.path.abspath(d).startswith(os.path.abspath(BUILD_DIR)):
-            continue
-        hdrs += [os.path.join(d, f) for f in fs if f.endswith((".hpp", ".h"))]
-    hdrs.append(os.path.join(_HERE, "..", "include", "mi_engine.h"))
-    newest = max(os.path.getmtime(h) for h in hdrs)
-    procs, objs = [], []
-    for name in SOURCES:
-        src = os.path.join(CSRC, name)
-        obj = os.path.join(BUILD_DIR, name.replace(".hip", ".o"))
-        objs.append(obj)
-        if not force and not _obj_stale(src, obj, newest):
-            continue
-        cmd = [hipcc_path()] + HIPCC_FLAGS + ["-c", src, "-o", obj]
+    try:
+        os.makedirs(BUILD_DIR, exist_ok=True)
+        hdrs = []
+        for d, _, fs in os.walk(CSRC):
+            if os.path.abspath(d).startswith(os.path.abspath(BUILD_DIR)):
+                continue
+            hdrs += [os.path.join(d, f) for f in fs if f.endswith((".hpp", ".h"))]
+        hdrs.append(os.path.join(_HERE, "..", "include", "mi_engine.h"))
+        newest = max(os.path.getmtime(h) for h in hdrs)
+        procs, objs = [], []
+        for name in SOURCES:
+            src = os.path.join(CSRC, name)
+            obj = os.path.join(BUILD_DIR, name.replace(".hip", ".o"))
+            objs.append(obj)
+            if not force and not _obj_stale(src, obj, newest):
+                continue
+            cmd = [hipcc_path()] + HIPCC_FLAGS + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            log = open(obj.replace(".o", ".log"), "w")
+            procs.append((name, subprocess.Popen(cmd, cwd=CSRC, stdout=log, stderr=subprocess.STDOUT), log))
+        failed = []
+        for name, p, log in procs:
+            rc = p.wait()
+            log.close()
+            if rc != 0:
+                failed.append(name)
+        if failed:
+            for name in failed:
+                with open(os.path.join(BUILD_DIR, name.replace(".hip", ".log"))) as f:
+                    print(f.read()[-4000:])
+            raise RuntimeError(f"hipcc failed for {failed}")
+        # the resource check runs on the object logs BEFORE anything is linked: a library that fails it never exists on disk,
+        # so a later needs_build() / lib() cannot silently pick it up
+        usage = resource_usage()
+        with open(os.path.join(BUILD_DIR, "resource_usage.txt"), "w") as f:
+            for k, u in usage.items():
+                f.write(f"{k}: {u}\n")
+        bad = {k: u for k, u in usage.items() if u.get("SGPRs Spill", 0) > MAX_SGPR_SPILL and "substep" in k}
+        if bad:
+            if os.path.exists(LIB_PATH):
+                os.remove(LIB_PATH)
+            raise RuntimeError(f"step kernels spill SGPRs (known-bad regime on gfx950): {bad}")
+        tmp = LIB_PATH + ".tmp"
+        cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp]
         if verbose:
             print(" ".join(cmd), flush=True)
-        log = open(obj.replace(".o", ".log"), "w")
-        procs.append((name, subprocess.Popen(cmd, cwd=CSRC, stdout=log, stderr=subprocess.STDOUT), log))
-    failed = []
-    for name, p, log in procs:
-        rc = p.wait()
-        log.close()
-        if rc != 0:
-            failed.append(name)
-    if failed:
-        for name in failed:
-            with open(os.path.join(BUILD_DIR, name.replace(".hip", ".log"))) as f:
-                print(f.read()[-4000:])
-        raise RuntimeError(f"hipcc failed for {failed}")
-    # the resource check runs on the object logs BEFORE anything is linked: a library that fails it never exists on disk,
-    # so a later needs_build() / lib() cannot silently pick it up
-    usage = resource_usage()
-    with open(os.path.join(BUILD_DIR, "resource_usage.txt"), "w") as f:
-        for k, u in usage.items():
-            f.write(f"{k}: {u}\n")
-    bad = {k: u for k, u in usage.items() if u.get("SGPRs Spill", 0) > MAX_SGPR_SPILL and "substep" in k}
-    if bad:
-        if os.path.exists(LIB_PATH):
-            os.remove(LIB_PATH)
-        raise RuntimeError(f"step kernels spill SGPRs (known-bad regime on gfx950): {bad}")
-    tmp = LIB_PATH + ".tmp"
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd, cwd=CSRC)
-    os.replace(tmp, LIB_PATH)
+        subprocess.check_call(cmd, cwd=CSRC)
+        os.replace(tmp, LIB_PATH)
+    except BaseException:
+        # the g++ job of the CPU backend must not be left running / half written, and its own failure must not be hidden
+        try:
+            _finish_cpu(cpu_job)
+        except Exception as e:      # noqa: BLE001 -- report it beside the hipcc error
+            print(f"(CPU backend build also failed: {e})")
+        raise
     _finish_cpu(cpu_job)
     return LIB_PATH
 
@@ -313,13 +321,18 @@ _lib_cpu = None
 
 
 def cpu_needs_build():
+    """Same staleness rule as the HIP library: any source or header under csrc/ (the CPU backend includes the engine core, the task
+    headers and the arena layout the kernels use) or the public header newer than the library."""
     if not os.path.exists(CPU_LIB_PATH):
         return True
     t = os.path.getmtime(CPU_LIB_PATH)
-    deps = [os.path.join(CSRC, "cpu", "mi_engine_cpu.cpp"), os.path.join(CSRC, "arena.hpp"), os.path.join(CSRC, "arena_layout.hpp"),
-            os.path.join(CSRC, "core", "engine.hpp"), os.path.join(CSRC, "tasks", "locomotion.hpp"), os.path.join(_HERE, "..", "include", "mi_engine.h")]
-    deps += [os.path.join(CSRC, "gen", f) for f in os.listdir(os.path.join(CSRC, "gen"))]
-    return any(os.path.getmtime(d) > t for d in deps)
+    for d, _, fs in os.walk(CSRC):
+        if os.path.abspath(d).startswith(os.path.abspath(BUILD_DIR)):
+            continue
+        for f in fs:
+            if f.endswith((".hpp", ".h", ".cpp")) and os.path.getmtime(os.path.join(d, f)) > t:
+                return True
+    return os.path.getmtime(os.path.join(_HERE, "..", "include", "mi_engine.h")) > t
 
 
 def build_cpu(force=False, wait=True):

@@ -216,11 +216,11 @@ class OracleLocomotionEnv:
     """
 
     def __init__(self, hum, spec, sensor_bodies, sim_params: dict, params, num_envs, seed=0, env_id_offset=0,
-                 precision="f32", control_freq_inv=1, selfcol=None, kmax=0, kpair=0, warm_slots=0):
+                 precision="f32", control_freq_inv=1, selfcol=None, kmax=0, kpair=0, warm_slots=0, solver="gs", blocks=None):
         from .engine import OracleEngine
         self.hum, self.N, self.p, self.nd = hum, num_envs, params, spec.nd
         self.eng = OracleEngine(spec, num_envs, params=sim_params, sensor_bodies=sensor_bodies, precision=precision,
-                                selfcol=selfcol, kmax=kmax, kpair=kpair, warm_slots=warm_slots)
+                                selfcol=selfcol, kmax=kmax, kpair=kpair, warm_slots=warm_slots, solver=solver, blocks=blocks)
         self.seed, self.off, self.cfi = fold_seed(seed), env_id_offset, control_freq_inv
         nd = self.nd
         self.lower = np.array(params.dof_lower[:nd], f32)
@@ -442,10 +442,10 @@ class OracleAnymalTerrainEnv:
     """vec_task.py:360-408 + anymal_terrain.py pre/post_physics_step on oracle/physics.c with the height-field ground."""
 
     def __init__(self, spec, sim_params: dict, params, terrain, num_envs, seed=0, env_id_offset=0, precision="f64",
-                 control_freq_inv=1):
+                 control_freq_inv=1, solver="gs", blocks=None):
         from .engine import OracleEngine
         self.N, self.p, self.nd, self.spec = num_envs, params, spec.nd, spec
-        self.eng = OracleEngine(spec, num_envs, params=sim_params, precision=precision)
+        self.eng = OracleEngine(spec, num_envs, params=sim_params, precision=precision, solver=solver, blocks=blocks)
         self.eng.set_ground(terrain.heightsamples, terrain.horizontal_scale, terrain.vertical_scale, terrain.border_size,
                             slope_threshold=float(getattr(terrain, "slope_threshold", 0.0) or 0.0))
         self.eng.want_netf = True

@@ -39,3 +39,31 @@ def test_reference_jit_leg_runs_where_the_reference_is_reachable():
         assert leg["kind"] == "reference" and leg["value"] > 0 and "compute_ant_observations" in leg["sample"]
     else:
         assert leg is None or "absent" in leg
+
+
+def test_every_leg_is_checked_for_kernel_time_inside_step_time():
+    """a leg whose HIP-event kernel time exceeds the wall-clock step it is quoted against is an early-episode artefact of a
+    too-short run; measure() flags it (`consistent`) and the side legs run at least 200 steps after 50 warm-ups."""
+    ok = dict(kernel_ms_avg=0.384, ms_per_step=0.393, pooled=dict(ms_per_step=0.397))
+    bad = dict(kernel_ms_avg=0.395, ms_per_step=0.345, pooled=dict(ms_per_step=0.34))
+    assert bench.leg_consistent(ok) and not bench.leg_consistent(bad)
+    import inspect
+    src = inspect.getsource(bench.main)
+    assert "max(args.steps // 4, 200)" in src and "max(args.warmup // 4, 50)" in src
+    assert 'res["consistent"]' in inspect.getsource(bench.measure)
+    # committed bench lines of this round carry the flag on every leg, and it holds
+    import glob
+    import json
+    for f in glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r3*_bench.json")):
+        with open(f) as fh:
+            line = json.loads(fh.read().strip().splitlines()[-1])
+        legs = [line] + [line[k] for k in ("extra", "extra2", "extra3") if k in line]
+        for leg in legs:
+            assert leg.get("consistent") is True, (f, leg.get("workload", "headline"))
+            assert leg["roofline"]["kernel_ms"] * 0.9 <= leg["ms_per_step"]
+
+
+def test_cpu_product_backend_leg_runs_through_the_public_api():
+    r = bench.cpu_product_backend("Ant", 64, budget_s=0.6)
+    assert "absent" not in r, r
+    assert r["threads_4"]["value"] > 0 and r["kind"] == "product_cpu_backend"

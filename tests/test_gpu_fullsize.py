@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from isaacgymenvs_amd.registry import load_model, sensor_bodies
-from test_gpu_parity import DEV, _anymal_oracle, _make_env, _random_state, _selfcol_kw, _sim_dict, _t
+from test_gpu_parity import DEV, _anymal_oracle, _make_env, _oracle_kw, _random_state, _selfcol_kw, _sim_dict, _t
 
 pytestmark = pytest.mark.gpu
 
@@ -23,7 +23,7 @@ def test_locomotion_simulate_at_the_benchmark_size(task, n, z_lo, z_hi, gear):
     from oracle.engine import OracleEngine
     env = _make_env(task, n)
     spec, sb = load_model(task.lower()), sensor_bodies(task.lower())
-    orc = OracleEngine(spec, n, params=_sim_dict(env.sim_params), sensor_bodies=sb, precision="f64", **_selfcol_kw(task))
+    orc = OracleEngine(spec, n, params=_sim_dict(env.sim_params), sensor_bodies=sb, precision="f64", **_oracle_kw(task, env))
     rng = np.random.default_rng(7)
     root, q, qd = _random_state(spec, n, rng, z_lo, z_hi)
     tau = rng.uniform(-gear, gear, (n, spec.nd))

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from isaacgymenvs_amd.registry import load_model, sensor_bodies
-from test_gpu_parity import DEV, _make_env, _selfcol_kw, _sim_dict
+from test_gpu_parity import DEV, _make_env, _oracle_kw, _sim_dict
 
 pytestmark = pytest.mark.gpu
 
@@ -18,7 +18,7 @@ def _oracle(task, env, n, seed):
     sd, p = _sim_dict(env.sim_params), env._task_params_struct
     if task in ("Ant", "Humanoid"):
         return OT.OracleLocomotionEnv(task == "Humanoid", load_model(task.lower()), sensor_bodies(task.lower()), sd, p, n, seed=seed,
-                                      precision="f64", **_selfcol_kw(task))
+                                      precision="f64", **_oracle_kw(task, env))
     if task == "Quadcopter":
         return OT.OracleQuadcopterEnv(load_model("quadcopter"), sensor_bodies("quadcopter"), sd, p, n, seed=seed, precision="f64")
     if task == "Ingenuity":

@@ -63,7 +63,9 @@ def test_multi_wave_simulate_matches_cpu_oracle(n, randomised):
         state_spec = spec
     stride = max(1, n // 256)                   # the oracle follows a strided subset of the envs
     ids = np.arange(0, n, stride)
-    orc = OracleEngine(spec, len(ids), params=_sim_dict(env.sim_params), sensor_bodies=sb, precision="f64")
+    from isaacgymenvs_amd.assets.model import solver_blocks
+    orc = OracleEngine(spec, len(ids), params=_sim_dict(env.sim_params), sensor_bodies=sb, precision="f64", solver="blocks",
+                       blocks=solver_blocks(spec))                  # the limb waves sweep block by block (engine_mw.hpp P4)
     rng = np.random.default_rng(0)
     root, q, qd = _random_state(state_spec, n, rng, 0.3, 0.6)
     tau = rng.uniform(-15, 15, (n, spec.nd))
@@ -105,11 +107,11 @@ def test_multi_wave_rollout_tracks_single_wave_and_is_deterministic(task, nact):
         d = np.abs(obs[0] - obs[1])
         if task == "Ant":
             d[:, [7, 8, 9]] = np.minimum(d[:, [7, 8, 9]], np.abs(d[:, [7, 8, 9]] - 2 * np.pi))
-        # same arithmetic, different summation order of the limbs' trunk contributions: the envs stay together for the first steps
-        # (contact is chaotic, so a growing tolerance and a small allowance of envs that took another contact branch)
-        frac = (d.max(axis=1) < 2e-3 * (1 + step)).mean()
-        assert frac > 0.97, (task, step, frac, d.max())
-        assert (outs[0][2].cpu().numpy() == outs[1][2].cpu().numpy()).mean() > 0.99              # same resets
+        # the single-wave kernel sweeps the same rows in one Gauss-Seidel sequence, the limb waves block by block: two orders of one
+        # solver that agree where 4 sweeps converge (most envs of a rollout) and differ at first order where they do not
+        frac = (d.max(axis=1) < 2e-2 * (1 + step)).mean()
+        assert frac > 0.7, (task, step, frac, d.max())
+        assert (outs[0][2].cpu().numpy() == outs[1][2].cpu().numpy()).mean() > 0.97              # (almost) the same resets
 
 
 def test_multi_wave_option_is_ignored_by_models_without_a_multi_wave_form():

@@ -162,6 +162,20 @@ def _selfcol_kw(task):
     return dict(selfcol=sc, kmax=12, kpair=3, warm_slots=9) if sc else {}
 
 
+# tasks whose multi-wave sub-step sweeps its rows block by block (csrc/core/engine_mw.hpp P4); the oracle must be told the same order
+BLOCK_ORDER_TASKS = {"Ant": "ant", "AnymalTerrain": "anymal"}
+
+
+def _oracle_kw(task, env=None):
+    """Oracle options that mirror the engine as `env` runs it: self-collision tables and contact caps (_selfcol_kw) and the solver order
+    -- "blocks" when the env's sub-step runs on limb waves (option multi_wave != 0), one Gauss-Seidel sequence otherwise."""
+    from isaacgymenvs_amd.assets.model import solver_blocks
+    kw = dict(_selfcol_kw(task))
+    if env is not None and task in BLOCK_ORDER_TASKS and int(env.engine.get_option("multi_wave")) != 0:
+        kw.update(solver="blocks", blocks=solver_blocks(load_model(BLOCK_ORDER_TASKS[task]), self_collision=bool(kw.get("selfcol"))))
+    return kw
+
+
 def _random_state(spec, n, rng, z_lo, z_hi):
     nd = spec.nd
     lo, up = np.minimum(spec.dof_lower, spec.dof_upper), np.maximum(spec.dof_lower, spec.dof_upper)
@@ -182,7 +196,7 @@ def test_simulate_matches_cpu_oracle(task, z_lo, z_hi, gear):
     env = _make_env(task, n)
     spec = load_model(task.lower())
     sb = sensor_bodies(task.lower())
-    orc = OracleEngine(spec, n, params=_sim_dict(env.sim_params), sensor_bodies=sb, precision="f64", **_selfcol_kw(task))
+    orc = OracleEngine(spec, n, params=_sim_dict(env.sim_params), sensor_bodies=sb, precision="f64", **_oracle_kw(task, env))
     rng = np.random.default_rng(0)
     root, q, qd = _random_state(spec, n, rng, z_lo, z_hi)
     tau = rng.uniform(-gear, gear, (n, spec.nd))
@@ -364,7 +378,7 @@ def test_step_trajectory_matches_cpu_restatement(task, hum):
     spec = load_model(task.lower())
     cfg, p = _loco_params(task)
     orc = OracleLocomotionEnv(hum, spec, sensor_bodies(task.lower()), _sim_dict(env.sim_params), p, n, seed=seed, precision="f64",
-                              **_selfcol_kw(task))
+                              **_oracle_kw(task, env))
     g = torch.Generator(device="cpu").manual_seed(3)
     for step in range(12):
         a = torch.rand((n, env.num_actions), generator=g) * 2 - 1
@@ -461,8 +475,9 @@ def test_ant_static_equilibrium_weight():
 # ------------------------------------------------------------------ AnymalTerrain (height field, PD decimation, curriculum)
 def _anymal_oracle(env, n, seed):
     from oracle.tasks import OracleAnymalTerrainEnv
+    kw = _oracle_kw("AnymalTerrain", env)
     return OracleAnymalTerrainEnv(load_model("anymal"), _sim_dict(env.sim_params), env._task_params_struct, env.terrain, n,
-                                  seed=seed, precision="f64")
+                                  seed=seed, precision="f64", solver=kw.get("solver", "gs"), blocks=kw.get("blocks"))
 
 
 def test_anymal_terrain_step_matches_cpu_restatement():
