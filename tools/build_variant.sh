@@ -5,7 +5,7 @@ set -e
 SRC=$1; OUT=$2; shift 2
 B=$(mktemp -d)
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-signed-zeros -fno-trapping-math -fno-slp-vectorize $@"
-for f in mi_engine kernels_cartpole kernels_ant kernels_humanoid kernels_anymal kernels_shadow_hand kernels_shadow_hand_pen kernels_shadow_hand_egg kernels_quadcopter kernels_jit_twins kernels_mw_ant kernels_mw_anymal; do
+for f in $(cd $SRC/isaacgymenvs_amd/csrc && ls *.hip | sed 's/\.hip$//'); do
   ( cd $SRC/isaacgymenvs_amd/csrc && hipcc $FLAGS -c $f.hip -o $B/$f.o 2>/dev/null ) &
 done
 wait
