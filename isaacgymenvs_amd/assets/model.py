@@ -949,18 +949,34 @@ def wave_roles(spec: ModelSpec, nrole: int = 4):
     return limb, limbs, role_of_limb, trunk_role, nrole
 
 
-def solver_blocks(spec: ModelSpec, self_collision: bool = False):
+def wave_contact_caps(spec: ModelSpec):
+    """Ground contacts each wave of the compact-store limb-per-wave sub-step keeps per env (csrc/core/engine_mwc.hpp gives every role its
+    own contact slots in LDS): 4 for a role whose limb has at least 4 dofs (a leg: one flat foot is 4 spheres), 2 for the role that also
+    sweeps the trunk's rows, 1 otherwise.  -> [nrole]"""
+    limb, limbs, role_of_limb, trunk_role, nrole = wave_roles(spec)
+    ndof = [0] * nrole
+    for d in range(spec.nd):
+        r = role_of_limb[limb[int(spec.dof_body[d])]]
+        if r >= 0:
+            ndof[r] += 1
+    return [4 if ndof[r] >= 4 else (2 if r == trunk_role else 1) for r in range(nrole)]
+
+
+def solver_blocks(spec: ModelSpec, self_collision: bool = False, wave_caps: bool = False):
     """What the block solver order needs to know about a model (oracle/physics.c OrModel.solver = 1, the engine's multi-wave kernels):
     gi_group [nv] -- coordinate group of every generalised velocity index (0 = trunk incl. the floating base, l = limb l),
     body_block [nb] -- the block (wavefront) that sweeps the limit rows / ground contacts of each body, nblk (the self contacts are
-    block nblk - 1 when self_collision)."""
+    block nblk - 1 when self_collision); wave_caps: also kmax_blk, the per-block caps of the ground contacts."""
     limb, limbs, role_of_limb, trunk_role, nrole = wave_roles(spec)
     off = 0 if spec.fixed_base else 6
     gi_group = [0] * (off + spec.nd)
     for d in range(spec.nd):
         gi_group[off + d] = limb[int(spec.dof_body[d])]
     body_block = [trunk_role if role_of_limb[limb[b]] < 0 else role_of_limb[limb[b]] for b in range(spec.nb)]
-    return dict(gi_group=gi_group, body_block=body_block, nblk=nrole + (1 if self_collision else 0))
+    out = dict(gi_group=gi_group, body_block=body_block, nblk=nrole + (1 if self_collision else 0))
+    if wave_caps:       # the compact-store form keeps its ground contacts per wave
+        out["kmax_blk"] = wave_contact_caps(spec)
+    return out
 
 
 def self_collision_groups(spec: ModelSpec, pairs=None):

@@ -38,7 +38,8 @@ struct SimMW : Sim<M> {
     using typename B::BodyTmp;
     static constexpr int NB = B::NB, ND = B::ND, NV = B::NV, OFF = B::OFF, NSPH = B::NSPH, NSENS = B::NSENS, NLIM = B::NLIM,
                          NROWG = B::NROWG, NVA = B::NVA, NR = M::NROLE;
-    static_assert(!B::COMPACT && B::LAM_IN_ROWS && !M::FIXED, "multi-wave sub-step: free-base models on the static row store");
+    static_assert(!M::FIXED, "multi-wave sub-step: free-base models");
+    // (substep_role below is the static-row-store form; core/engine_mwc.hpp derives the compact-store form from this struct)
 
     // ---- who owns what
     static constexpr int role_of_body(int b) { return M::role_of_limb[M::limb_of_body[b]]; }       // -1: trunk
@@ -88,7 +89,7 @@ struct SimMW : Sim<M> {
     template <int R> static constexpr int own_pos(int u) { int n = 0; for (int k = 0; k < u; ++k) n += own_unit<R>(k) ? 1 : 0; return n; }
 
     // ------------------------------------------------------------------------------------------------ trunk, going down
-    template <int R, int b, int RS>
+    template <int R, int b, int XLR, int RS>
     MI_HD void trunk_down(const SimParams& P, Ctx& c, BodyTmp (&tb)[NTB], const float* Rp, const float* rp, const float* Vp,
                           const float* Ap, const RowStore<RS> rows) {
         constexpr int ts = tslot(b);
@@ -98,12 +99,12 @@ struct SimMW : Sim<M> {
             constexpr int ch = C_;
             if constexpr (ch > b) if constexpr (M::parent[ch] == b) {
                 if constexpr (trunk_body(ch)) {
-                    trunk_down<R, ch>(P, c, tb, t.Rb, t.rb, t.Vc, t.Ac, rows);
+                    trunk_down<R, ch, XLR>(P, c, tb, t.Rb, t.rb, t.Vc, t.Ac, rows);
                 } else if constexpr (role_of_body(ch) == R) {     // root of one of my limbs: the whole subtree, down and up
                     SpI Ic;
                     float Fc[6];
                     this->template body_pass<ch>(P, c, t.Rb, t.rb, t.Vc, t.Ac, Ic, Fc);
-                    constexpr int o = X_LR + 16 * lridx(ch);
+                    constexpr int o = XLR + 16 * lridx(ch);
                     rows(o) = Ic.m;
                     sfor<3>([&](auto K) MI_LAMBDA { rows(o + 1 + K) = Ic.h[K]; });
                     sfor<6>([&](auto K) MI_LAMBDA { rows(o + 4 + K) = Ic.I[K]; rows(o + 10 + K) = Fc[K]; });
@@ -140,7 +141,8 @@ struct SimMW : Sim<M> {
             });
         }
         BodyTmp tb[NTB];
-        trunk_down<R, 0>(P, c, tb, nullptr, nullptr, nullptr, nullptr, rows);
+        static_assert(!B::COMPACT && B::LAM_IN_ROWS, "substep_role: models on the static row store");
+        trunk_down<R, 0, X_LR>(P, c, tb, nullptr, nullptr, nullptr, nullptr, rows);
         MI_PHASE();
         float Ldi[NVA], y[NVA], w[NVA], v[NVA];
         v[0] = root[7]; v[1] = root[8]; v[2] = root[9]; v[3] = root[10]; v[4] = root[11]; v[5] = root[12];

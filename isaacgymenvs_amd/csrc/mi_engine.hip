@@ -421,10 +421,10 @@ extern "C" int mi_engine_set_option(MiEngine* e, const char* key, double value) 
         e->v.lamp = value != 0 ? e->lamp_arena : nullptr;
         return 0;
     }
-    // multi-wave sub-step (core/engine_mw.hpp): envs per workgroup, 0 = one wave per workgroup.  Ignored by tasks whose model has
-    // no multi-wave form (Cartpole, Humanoid, ShadowHand, Quadcopter).
+    // multi-wave sub-step (core/engine_mw.hpp, core/engine_mwc.hpp): envs per workgroup, 0 = one wave per workgroup.  Ignored by tasks
+    // whose model has no multi-wave form (Cartpole, ShadowHand, Quadcopter).  2: the Humanoid's round-2 form (main wave + self-collision helper).
     if (!strcmp(key, "multi_wave")) {
-        if (value != 0 && value != 32 && !(MI_MW_HAS16 && value == 16)) return fail("multi_wave: 0, 16 or 32 (envs per workgroup)");
+        if (value != 0 && value != 32 && value != 2 && !(MI_MW_HAS16 && value == 16)) return fail("multi_wave: 0, 16 or 32 (envs per workgroup); 2: main + helper wave");
         e->v.mw = (int)value;
         return 0;
     }

@@ -1,0 +1,98 @@
+// mwc_kernels.hpp -- the limb-per-wave sub-step of a compact-store robot (core/engine_mwc.hpp: Humanoid) and its launcher.  Included only
+// by kernels_<model>_mwc.hip.  blockDim = (64, NROLE): wave y = role y, lanes 0 .. 31 of every wave hold the same 32 envs (the upper lanes
+// retire at once: barriers count waves), one workgroup per CU (the row store + exchange areas take 159 KB of its LDS).
+#pragma once
+#include "step_kernels.hpp"
+#include "mw_kernels.hpp"          // DevBarrier
+#include "core/engine_mwc.hpp"
+
+namespace mi {
+
+template <class M>
+constexpr size_t mwc_lds_bytes() { return (size_t)SimMWC<M>::MWC_SLOTS * SimMWC<M>::LANES * sizeof(float); }
+
+template <class M, int R>
+__device__ __forceinline__ void mwc_role(const View& v, const SimParams& P, const ActParams& ap, const float* __restrict__ actions_in,
+                                         const int src, float* lds_rows, const int e, const int lane) {
+    using S = SimMWC<M>;
+    using MW = SimMW<M>;
+    constexpr int ND = M::ND, E = S::LANES;
+    const int N = v.N;
+    S sim;
+    load_sim(sim, v, e);
+    load_actor_scales(sim, v, e);
+    float tau[M::NDA];
+    if (src != ACT_STORED_TAU) {
+        sfor<ND>([&](auto K) MI_LAMBDA {
+            constexpr int k = K;
+            constexpr bool mine = MW::template owns_gi<R>(M::OFF + k);
+            float t = 0.f;
+            if (k < ap.nact) {
+                float a;
+                if (src == ACT_FROM_ACTIONS) {
+                    a = actions_in[(size_t)e * ap.nact + k];
+                    if (v.act_noise.dist != 0) a = apply_noise(v.act_noise, v.seed, (uint32_t)(v.env_offset + e), v.step, 1u, (uint32_t)k, a);
+                    a = fminf(fmaxf(a, -ap.clip), ap.clip);
+                    if constexpr (mine) v.actions[k * N + e] = a;
+                } else {
+                    a = v.actions[k * N + e];
+                }
+                t = a * ap.gear[k] * ap.scale;          // effort mode (humanoid.py:281-285)
+            }
+            tau[k] = t;
+            if constexpr (mine) v.tau[k * N + e] = t;
+        });
+    } else {
+        sfor<ND>([&](auto K) MI_LAMBDA { tau[K] = v.tau[K * N + e]; });
+    }
+    const float h = P.dt / (float)P.substeps;
+    const Strided lamc{v.lamc + e, N}, laml{v.laml + e, N}, sensor{v.sensor + e, N}, dof_force{v.dof_force + e, N};
+    const float mu_env = (v.friction != nullptr) ? v.friction[e] : -1.f;
+    const SelfCol selfcol{Strided{v.lamp ? v.lamp + e : nullptr, N}, Strided{v.pairf ? v.pairf + e : nullptr, N}, v.dropped ? v.dropped + e : nullptr, N};
+    const SelfCol* scp = (M::NPG > 0 && v.lamp != nullptr) ? &selfcol : nullptr;    // uniform
+    sim.template substep_role_c<R>(P, tau, h, RowStore<E>{lds_rows + lane}, lamc, laml, sensor, dof_force, mu_env, scp, DevBarrier{});
+    sfor<ND>([&](auto K) MI_LAMBDA {
+        if constexpr (MW::template owns_gi<R>(M::OFF + K)) {
+            v.dof[K * N + e] = sim.q[K];
+            v.dof[(ND + K) * N + e] = sim.qd[K];
+        }
+    });
+    if constexpr (R == M::TRUNK_ROLE) sfor<13>([&](auto K) MI_LAMBDA { v.root[K * N + e] = sim.root[K]; });
+}
+
+template <class M>
+__global__ __launch_bounds__(64 * M::NROLE) void substep_mwc_kernel(View v, SimParams P, ActParams ap, const float* __restrict__ actions_in, int src) {
+    extern __shared__ float lds_rows[];   // [MWC_SLOTS][32]
+    static_assert(M::NROLE == 4, "four roles, one per SIMD of a CU");
+    constexpr int E = SimMWC<M>::LANES;
+    const int lane = threadIdx.x;
+    if (lane >= E) return;
+    const int e = xcd_env_base<E>(blockIdx.x) + lane;
+    if (e >= v.N) return;                 // all four waves hold the same envs and agree on this
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.y);
+#if defined(MI_MWC_ONLY_ROLE)     // tools/debug only: resource usage of one role's instruction stream
+    if (role == MI_MWC_ONLY_ROLE) mwc_role<M, MI_MWC_ONLY_ROLE>(v, P, ap, actions_in, src, lds_rows, e, lane);
+#else
+    switch (role) {
+        case 0: mwc_role<M, 0>(v, P, ap, actions_in, src, lds_rows, e, lane); break;
+        case 1: mwc_role<M, 1>(v, P, ap, actions_in, src, lds_rows, e, lane); break;
+        case 2: mwc_role<M, 2>(v, P, ap, actions_in, src, lds_rows, e, lane); break;
+        default: mwc_role<M, 3>(v, P, ap, actions_in, src, lds_rows, e, lane); break;
+    }
+#endif
+}
+
+template <class M>
+hipError_t launch_substeps_mwc(const View& v, const SimParams& P, const ActParams& ap, const float* actions, int n_sub, int first, int rest,
+                               hipStream_t s) {
+    static unsigned long long configured = 0ull;
+    constexpr size_t lds = mwc_lds_bytes<M>();
+    constexpr int E = SimMWC<M>::LANES;
+    auto kern = substep_mwc_kernel<M>;
+    if (hipError_t e = ensure_dynamic_lds((const void*)kern, lds, &configured); e != hipSuccess) return e;
+    const dim3 grid(xcd_grid<E>(v.N)), block(64, M::NROLE);
+    for (int i = 0; i < n_sub; ++i) hipLaunchKernelGGL(kern, grid, block, lds, s, v, P, ap, actions, i == 0 ? first : rest);
+    return hipGetLastError();
+}
+
+}  // namespace mi

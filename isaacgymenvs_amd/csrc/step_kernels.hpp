@@ -230,6 +230,10 @@ constexpr bool mw_capable() { return !Sim<M>::COMPACT && Sim<M>::LAM_IN_ROWS && 
 template <class M>
 hipError_t launch_substeps_sc2(const View& v, const SimParams& P, const ActParams& ap, const float* actions, int n_sub, int first, int rest,
                                hipStream_t s);
+// launches n_sub limb-per-wave sub-steps of a compact-store robot (mwc_kernels.hpp, instantiated in kernels_humanoid_mwc.hip)
+template <class M>
+hipError_t launch_substeps_mwc(const View& v, const SimParams& P, const ActParams& ap, const float* actions, int n_sub, int first, int rest,
+                               hipStream_t s);
 // launches n_sub multi-wave sub-steps with v.mw envs per workgroup (defined for the model / ground pairs of kernels_mw_*.hip)
 template <class M, class GND>
 hipError_t launch_substeps_mw(const View& v, const SimParams& P, const ActParams& ap, const float* actions, int n_sub, int first, int rest,
@@ -428,8 +432,11 @@ template <class M, class GND = PlaneGround>
 hipError_t launch_substeps(const View& v, const SimParams& P, const ActParams& ap, const float* actions, int n_sub, int first,
                            int rest, hipStream_t s, const GND& gnd = GND{}) {
     if constexpr (Sim<M>::NPG > 0 && std::is_same<GND, PlaneGround>::value) {
-        // self-colliding robot: the self-collision phase on a second wave of the workgroup (kernels_<model>_sc2.hip)
-        if (v.mw != 0 && v.lamp != nullptr) return launch_substeps_sc2<M>(v, P, ap, actions, n_sub, first, rest, s);
+        // self-colliding robot on the compact store.  multi_wave 32 (default): one limb per wave, every wave sweeping its own rows
+        // (kernels_<model>_mwc.hip, round 3); 2: round 2's form, the self-collision phase on a helper wave beside one main wave
+        // (kernels_<model>_sc2.hip; kept for A/B runs and as the Gauss-Seidel-order reference on the GPU)
+        if (v.mw == 2 && v.lamp != nullptr) return launch_substeps_sc2<M>(v, P, ap, actions, n_sub, first, rest, s);
+        if (v.mw != 0 && v.mw != 2 && ap.mode == 0) return launch_substeps_mwc<M>(v, P, ap, actions, n_sub, first, rest, s);
     }
     if constexpr (mw_capable<M, GND>()) {
         if (v.mw != 0) return launch_substeps_mw<M, GND>(v, P, ap, actions, n_sub, first, rest, s, gnd);

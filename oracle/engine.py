@@ -32,7 +32,7 @@ def _struct(real):
                    [(n, C.c_int32) for n in ("ncap", "npg", "ngp", "kmax", "kpair", "warm_slots")] + \
                    [(n, C.c_void_p) for n in ("cap_body", "cap_p0", "cap_p1", "cap_rad", "cap_mu", "gp_a", "gp_b", "pg_first", "pg_count")] + \
                    [(n, C.c_int32) for n in ("solver", "nblk", "pad1", "pad2")] + \
-                   [("gi_group", C.c_void_p), ("body_block", C.c_void_p)]
+                   [("gi_group", C.c_void_p), ("body_block", C.c_void_p), ("kmax_blk", C.c_void_p)]
 
     class OrParams(C.Structure):
         _fields_ = [("dt", real), ("substeps", C.c_int32), ("iters", C.c_int32), ("gravity", real * 3),
@@ -100,6 +100,9 @@ class OracleEngine:
             k["gi_group"] = np.ascontiguousarray(blocks["gi_group"], np.int32)
             k["body_block"] = np.ascontiguousarray(blocks["body_block"], np.int32)
             m.solver, m.nblk = 1, int(blocks["nblk"])
+            if blocks.get("kmax_blk") is not None:        # per-block caps of the ground contacts (compact-store limb waves)
+                k["kmax_blk"] = np.ascontiguousarray(list(blocks["kmax_blk"]) + [0] * (m.nblk - len(blocks["kmax_blk"])), np.int32)
+                m.kmax_blk = _ptr(k["kmax_blk"])
             m.gi_group, m.body_block = _ptr(k["gi_group"]), _ptr(k["body_block"])
         else:
             assert solver == "gs"

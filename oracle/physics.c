@@ -88,6 +88,8 @@ typedef struct {
     int32_t solver, nblk, pad1, pad2;
     const int32_t *gi_group;     /* [nv] coordinate group of every generalised velocity index */
     const int32_t *body_block;   /* [nb] */
+    const int32_t *kmax_blk;     /* [nblk] or NULL: ground contacts kept per BLOCK (the limb-per-wave kernels of the compact store give every
+                                  * wave its own contact slots, csrc/core/engine_mwc.hpp), first come first served in sphere order */
 } OrModel;
 
 typedef struct {
@@ -582,7 +584,7 @@ static void step_env(const OrModel *m, const OrParams *p, const OrGround *gnd, r
         int nrow = 0;
         int lim_row[MAXD], sph_row[MAXS], grp_row[MAXG], grp_sel[MAXG];
         real lim_sign[MAXD], grp_x[MAXG][3], grp_fr[MAXG][3][3], grp_dist[MAXG];
-        int nground = 0, ngrp = 0, dropped = 0;
+        int nground = 0, ngrp = 0, dropped = 0, nblkc[16] = {0};
         for (int d = 0; d < nd; d++) {
             lim_row[d] = -1;
             if (!m->dof_limited[d]) { lam_l[d] = 0; continue; }
@@ -611,6 +613,11 @@ static void step_env(const OrModel *m, const OrParams *p, const OrGround *gnd, r
             real dist = ((root[2] + x[2]) - zt) * dirs[0][2] - m->sph_rad[s];
             if (dist >= p->contact_offset) { lam_c[3 * s] = lam_c[3 * s + 1] = lam_c[3 * s + 2] = 0; continue; }
             if (m->kmax > 0 && nground >= m->kmax) { lam_c[3 * s] = lam_c[3 * s + 1] = lam_c[3 * s + 2] = 0; dropped++; continue; }
+            if (m->solver == 1 && m->kmax_blk) {
+                int blk = m->body_block[b];
+                if (nblkc[blk] >= m->kmax_blk[blk]) { lam_c[3 * s] = lam_c[3 * s + 1] = lam_c[3 * s + 2] = 0; dropped++; continue; }
+                nblkc[blk]++;
+            }
             nground++;
             real xc[3] = {x[0] - m->sph_rad[s] * dirs[0][0], x[1] - m->sph_rad[s] * dirs[0][1], x[2] - m->sph_rad[s] * dirs[0][2]};
             real gap = dist - p->rest_offset;

@@ -31,14 +31,14 @@ def make_params(d):
 _MODELS = {"cartpole": ("HOSTSIM_CARTPOLE", "-O2"), "ant": ("HOSTSIM_ANT", "-O2"), "anymal": ("HOSTSIM_ANYMAL", "-O2"),
            "quadcopter": ("HOSTSIM_QUADCOPTER", "-O2"), "humanoid": ("HOSTSIM_HUMANOID", "-O2"), "hand": ("HOSTSIM_HAND", "-O1"),
            "bbot": ("HOSTSIM_BBOT", "-O2")}
-_ENTRY_MODEL = {"hs_step_mw_ant": "ant", "hs_step_mw_terrain": "anymal", "hs_step_selfcol": "humanoid", "hs_step_selfcol2": "humanoid", "hs_step_selfcol3": "humanoid", "hs_step_terrain": "anymal", "hs_set_slope_threshold": "anymal", "hs_step_drive": "quadcopter", "hs_step_hand": "hand", "hs_hand_fingertips": "hand", "hs_step_bbot": "bbot"}
+_ENTRY_MODEL = {"hs_step_mw_ant": "ant", "hs_step_mw_terrain": "anymal", "hs_step_selfcol": "humanoid", "hs_step_selfcol2": "humanoid", "hs_step_selfcol3": "humanoid", "hs_step_mwc": "humanoid", "hs_step_terrain": "anymal", "hs_set_slope_threshold": "anymal", "hs_step_drive": "quadcopter", "hs_step_hand": "hand", "hs_hand_fingertips": "hand", "hs_step_bbot": "bbot"}
 _libs = {}
 
 
 def _deps():
     from isaacgymenvs_amd.registry import generate_headers
     core = os.path.join(_HERE, "..", "..", "isaacgymenvs_amd", "csrc", "core")
-    return generate_headers() + [os.path.join(_HERE, "hostsim.cpp"), os.path.join(core, "engine.hpp"), os.path.join(core, "engine_mw.hpp"),
+    return generate_headers() + [os.path.join(_HERE, "hostsim.cpp"), os.path.join(core, "engine.hpp"), os.path.join(core, "engine_mw.hpp"), os.path.join(core, "engine_mwc.hpp"),
                                  os.path.join(core, "hand_engine.hpp")]
 
 
@@ -116,6 +116,14 @@ def step_selfcol(lib, params, state, tau, out):
     """Humanoid with self-collision: state rows carry lamp[3 NPG] after laml, out rows 9 floats per group (world force first)."""
     rc = lib.hs_step_selfcol(C.byref(params), state.shape[0], state.ctypes.data_as(C.c_void_p),
                              tau.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+
+
+def step_mwc(lib, params, state, tau, out, selfcol=True, dropped=None):
+    """Humanoid through the limb-per-wave sub-step of the compact store (core/engine_mwc.hpp, four role threads per env); layouts of
+    step_selfcol.  dropped: optional int32 [n, 2] -- ground / self contacts refused because the slots were taken."""
+    rc = lib.hs_step_mwc(C.byref(params), state.shape[0], state.ctypes.data_as(C.c_void_p), tau.ctypes.data_as(C.c_void_p),
+                         out.ctypes.data_as(C.c_void_p), int(selfcol), dropped.ctypes.data_as(C.c_void_p) if dropped is not None else None)
     assert rc == 0
 
 

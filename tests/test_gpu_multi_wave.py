@@ -118,18 +118,18 @@ def test_multi_wave_rollout_tracks_single_wave_and_is_deterministic(task, nact):
 
 
 def test_multi_wave_option_is_ignored_by_models_without_a_multi_wave_form():
-    env = _make("Humanoid", 64, mw=32)          # compact contact store: stays on the single-wave kernel
-    env.step(torch.zeros((64, 21), device=DEV))
+    env = _make("Cartpole", 64, mw=32)          # no limbs: stays on the single-wave kernel
+    env.step(torch.zeros((64, 1), device=DEV))
     torch.cuda.synchronize()
     assert torch.isfinite(env.obs_buf).all()
 
 
 @pytest.mark.parametrize("n,randomised", [(8192, False), (300, False), (500, True)])     # the BASELINE size, a ragged count (partly filled workgroups),
 def test_humanoid_self_collision_on_a_helper_wave_is_the_same_sub_step(n, randomised):    # and per-env `actor_params` tensors in both kernels
-    """Humanoid with the self-collision phase on a second wave of the workgroup (csrc/sc2_kernels.hpp, option multi_wave != 0) against
+    """Humanoid with the self-collision phase on a second wave of the workgroup (csrc/sc2_kernels.hpp, option multi_wave = 2) against
     the one-wave kernel: the same arithmetic on the same values (bit-identical on the host build, tests/test_self_collision.py); the
     two GPU kernels are separate compilations, so the comparison is within fp32 round-off growing with the contact-rich steps."""
-    e1, e2 = _make("Humanoid", n, seed=9, mw=0), _make("Humanoid", n, seed=9, mw=32)
+    e1, e2 = _make("Humanoid", n, seed=9, mw=0), _make("Humanoid", n, seed=9, mw=2)
     spec = load_model("humanoid")
     rng = np.random.default_rng(3)
     root, q, qd = _random_state(spec, n, rng, 0.9, 1.5)           # many envs touch themselves, some the ground
@@ -164,6 +164,66 @@ def test_humanoid_self_collision_on_a_helper_wave_is_the_same_sub_step(n, random
             assert torch.equal(t1["self_contact_impulse"].abs().sum(2) > 0, t2["self_contact_impulse"].abs().sum(2) > 0)    # the same groups carry load
         touched += int((t1["self_contact_impulse"].abs().sum(2) > 0).any(1).sum())
     assert touched > 0.2 * n
+
+
+@pytest.mark.parametrize("n,selfcol,randomised", [(8192, True, False), (300, True, False), (300, False, False), (500, True, True)])
+def test_humanoid_limb_waves_match_cpu_oracle(n, selfcol, randomised):
+    """Humanoid on four limb waves (csrc/core/engine_mwc.hpp, option multi_wave = 32, the default): per-wave contact slots, self-contact
+    rows built by the two bodies' waves, every wave sweeping its own block -- against the fp64 oracle in the block order with the same
+    per-wave caps, per element on every env; randomised: with `actor_params` tensors against the oracle on a model changed accordingly."""
+    import dataclasses
+    from isaacgymenvs_amd.assets.model import solver_blocks
+    from isaacgymenvs_amd.registry import load_selfcol
+    from oracle.engine import OracleEngine
+    env = _make("Humanoid", n, seed=4, mw=32)
+    env.engine.set_option("self_collision", int(selfcol))
+    spec, sb, sc = load_model("humanoid"), sensor_bodies("humanoid"), load_selfcol("humanoid")
+    state_spec = spec
+    if randomised:
+        f = dict(mass=0.7, damping=1.3, stiffness=0.6, armature=1.8)
+        lo0, up0 = np.minimum(spec.dof_lower, spec.dof_upper), np.maximum(spec.dof_lower, spec.dof_upper)
+        shift = np.concatenate([0.1 * np.cos(np.arange(21)), -0.1 * np.abs(np.sin(1 + np.arange(21)))])
+        env.engine.set_option("actor_tensors", 1)
+        env.engine.tensors["actor_scale"][:] = torch.tensor([f["mass"], f["damping"], f["stiffness"], f["armature"]], device=DEV)
+        env.engine.tensors["dof_limit_shift"][:] = _t(shift)
+        spec = dataclasses.replace(spec, mass=spec.mass * f["mass"], inertia=spec.inertia * f["mass"], dof_damping=spec.dof_damping * f["damping"],
+                                   dof_stiffness=spec.dof_stiffness * f["stiffness"], dof_armature=spec.dof_armature * f["armature"],
+                                   dof_lower=lo0 + shift[:21], dof_upper=up0 + shift[21:])
+    kw = dict(solver="blocks", blocks=solver_blocks(spec, self_collision=selfcol, wave_caps=True))
+    if selfcol:
+        kw.update(selfcol=sc, kpair=3)
+    orc = OracleEngine(spec, n, params=_sim_dict(env.sim_params), sensor_bodies=sb, precision="f64", **kw)
+    rng = np.random.default_rng(11)
+    root, q, qd = _random_state(state_spec, n, rng, 0.9, 1.5)
+    tau = rng.uniform(-60, 60, (n, spec.nd))
+    t = env.engine.tensors
+    t["root_states"][:] = _t(root); env.dof_pos[:] = _t(q); env.dof_vel[:] = _t(qd)
+    for k in ("contact_impulse", "limit_impulse", "self_contact_impulse"):
+        t[k].zero_()
+    t["dof_actuation_force"][:] = _t(tau)
+    orc.root[:] = root; orc.q[:] = q; orc.qd[:] = qd
+    nsph = len(spec.sph_body)
+    touched = 0
+    for it in range(3):
+        env.engine.simulate()
+        orc.step(tau)
+        torch.cuda.synchronize()
+        g_root = t["root_states"].cpu().numpy(); g_q = env.dof_pos.cpu().numpy(); g_qd = env.dof_vel.cpu().numpy()
+        assert np.isfinite(g_root).all() and np.isfinite(g_qd).all()
+        e = max(np.abs(g_root - orc.root).max(), np.abs(g_q - orc.q).max(), np.abs(g_qd - orc.qd).max())
+        scale = max(1.0, np.abs(orc.qd).max())
+        assert e < 5e-4 * scale * (it + 1), (it, e)
+        assert np.abs(env.vec_sensor_tensor.cpu().numpy() - orc.sensor).max() < 2e-3 * max(1.0, np.abs(orc.sensor).max())
+        assert np.abs(t["dof_force"].cpu().numpy() - orc.dof_force).max() < 2e-3 * max(1.0, np.abs(orc.dof_force).max())
+        lamc = t["contact_impulse"].cpu().numpy().reshape(n, 3 * nsph)
+        assert np.abs(lamc - orc.lam[:, :3 * nsph]).max() < 2e-3 * max(1.0, np.abs(orc.lam).max())
+        assert np.abs(t["limit_impulse"].cpu().numpy() - orc.lam[:, 3 * nsph:]).max() < 2e-3 * max(1.0, np.abs(orc.lam).max())
+        if selfcol:
+            lamp = t["self_contact_impulse"].cpu().numpy()
+            assert np.abs(lamp - orc.lam_pair).max() < 2e-3 * max(1.0, np.abs(orc.lam_pair).max())
+            np.testing.assert_array_equal(np.abs(lamp).sum(2) > 0, np.abs(orc.lam_pair).sum(2) > 0)
+            touched += int((np.abs(lamp).sum(2) > 0).any(1).sum())
+    assert (not selfcol) or touched > 0.2 * n
 
 
 def test_humanoid_helper_wave_rollout_is_bit_identical_from_run_to_run():

@@ -162,17 +162,25 @@ def _selfcol_kw(task):
     return dict(selfcol=sc, kmax=12, kpair=3, warm_slots=9) if sc else {}
 
 
-# tasks whose multi-wave sub-step sweeps its rows block by block (csrc/core/engine_mw.hpp P4); the oracle must be told the same order
-BLOCK_ORDER_TASKS = {"Ant": "ant", "AnymalTerrain": "anymal"}
+# tasks whose multi-wave sub-step sweeps its rows block by block (csrc/core/engine_mw.hpp / engine_mwc.hpp P4); the oracle must be told the same order
+BLOCK_ORDER_TASKS = {"Ant": "ant", "AnymalTerrain": "anymal", "Humanoid": "humanoid"}
 
 
 def _oracle_kw(task, env=None):
-    """Oracle options that mirror the engine as `env` runs it: self-collision tables and contact caps (_selfcol_kw) and the solver order
-    -- "blocks" when the env's sub-step runs on limb waves (option multi_wave != 0), one Gauss-Seidel sequence otherwise."""
+    """Oracle options that mirror the engine as `env` runs it: self-collision tables and contact caps and the solver order -- "blocks"
+    when the env's sub-step runs on limb waves (option multi_wave 16 / 32), one Gauss-Seidel sequence otherwise (0; Humanoid: 2 = main
+    wave + helper).  The Humanoid's limb waves keep their ground contacts per wave (wave_kcap) instead of 12 per env."""
     from isaacgymenvs_amd.assets.model import solver_blocks
+    from isaacgymenvs_amd.registry import load_selfcol
     kw = dict(_selfcol_kw(task))
-    if env is not None and task in BLOCK_ORDER_TASKS and int(env.engine.get_option("multi_wave")) != 0:
-        kw.update(solver="blocks", blocks=solver_blocks(load_model(BLOCK_ORDER_TASKS[task]), self_collision=bool(kw.get("selfcol"))))
+    mw = int(env.engine.get_option("multi_wave")) if env is not None else 0
+    if task in BLOCK_ORDER_TASKS and mw not in (0, 2):
+        spec = load_model(BLOCK_ORDER_TASKS[task])
+        sc = load_selfcol(BLOCK_ORDER_TASKS[task])
+        on = bool(sc) and (task != "Humanoid" or int(env.engine.get_option("self_collision")) != 0)
+        kw = dict(solver="blocks", blocks=solver_blocks(spec, self_collision=on, wave_caps=bool(sc)))
+        if on:
+            kw.update(selfcol=sc, kpair=3)
     return kw
 
 
