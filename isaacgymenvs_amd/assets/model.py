@@ -930,22 +930,41 @@ def limb_paths(spec: ModelSpec):
     return limb, limbs
 
 
-def wave_roles(spec: ModelSpec, nrole: int = 4):
-    """Limbs dealt to the `nrole` wavefronts of the multi-wave sub-step (csrc/core/engine_mw.hpp): the limb of the root body is the
-    shared trunk (role -1, every wave recomputes it), the others go heaviest (most dofs) first to the least loaded wave; the trunk's
-    own constraint rows go to the wave with the lightest limbs.  -> (limb per body, body lists, role per limb, trunk role, nrole)."""
+def _has_selfcol(spec: ModelSpec) -> bool:
+    try:
+        from ..registry import load_selfcol
+        return bool(load_selfcol(spec.name))
+    except Exception:      # noqa: BLE001 -- models outside the registry (tests build specs by hand)
+        return False
+
+
+def wave_roles(spec: ModelSpec, nrole: int = 4, pair_role=None):
+    """Limbs dealt to the `nrole` wavefronts of the multi-wave sub-step (csrc/core/engine_mw.hpp, engine_mwc.hpp): the limb of the root
+    body is the shared trunk (role -1, every wave recomputes it), the others go heaviest first to the least loaded wave, where a limb
+    weighs the summed chain lengths of its dofs (what its rows cost); the trunk's own constraint rows go to the wave with the lightest
+    limbs.  pair_role (default: the model has self-collision tables): the LAST wave owns no limb -- it runs the self-collision narrow
+    phase and sweeps the self-contact rows (engine_mwc.hpp).  -> (limb per body, body lists, role per limb, trunk role, nrole)."""
     limb, limbs = limb_paths(spec)
+    if pair_role is None:
+        pair_role = _has_selfcol(spec)
+    off = 0 if spec.fixed_base else 6
+    depth = [0] * spec.nb                     # dofs on the path root .. body (incl. the floating base)
     cnt = [0] * spec.nb
     for d in range(spec.nd):
         cnt[int(spec.dof_body[d])] += 1
-    load = [0] * nrole
+    for b in range(spec.nb):
+        p = int(spec.parent[b])
+        depth[b] = (depth[p] if p >= 0 else off) + cnt[b]
+    weight = [sum(sum(depth[b] - cnt[b] + k + 1 for k in range(cnt[b])) for b in limbs[l]) for l in range(len(limbs))]
+    nlr = nrole - 1 if pair_role else nrole
+    load = [0.0] * nlr
     role_of_limb = [-1] * len(limbs)
-    order = sorted(range(1, len(limbs)), key=lambda l: -sum(cnt[b] for b in limbs[l]))
+    order = sorted(range(1, len(limbs)), key=lambda l: (-weight[l], l))
     for l in order:
-        r = min(range(nrole), key=lambda k: (load[k], k))
+        r = min(range(nlr), key=lambda k: (load[k], k))
         role_of_limb[l] = r
-        load[r] += sum(cnt[b] for b in limbs[l]) + 0.01 * len(limbs[l])
-    trunk_role = min(range(nrole), key=lambda k: (load[k], k))
+        load[r] += weight[l] + 0.01 * len(limbs[l])
+    trunk_role = min(range(nlr), key=lambda k: (load[k], k))
     return limb, limbs, role_of_limb, trunk_role, nrole
 
 
@@ -954,12 +973,13 @@ def wave_contact_caps(spec: ModelSpec):
     own contact slots in LDS): 4 for a role whose limb has at least 4 dofs (a leg: one flat foot is 4 spheres), 2 for the role that also
     sweeps the trunk's rows, 1 otherwise.  -> [nrole]"""
     limb, limbs, role_of_limb, trunk_role, nrole = wave_roles(spec)
-    ndof = [0] * nrole
-    for d in range(spec.nd):
-        r = role_of_limb[limb[int(spec.dof_body[d])]]
+    maxd = [0] * nrole                        # dofs of the role's longest limb
+    for l, bodies in enumerate(limbs):
+        r = role_of_limb[l]
         if r >= 0:
-            ndof[r] += 1
-    return [4 if ndof[r] >= 4 else (2 if r == trunk_role else 1) for r in range(nrole)]
+            maxd[r] = max(maxd[r], sum(1 for d in range(spec.nd) if int(spec.dof_body[d]) in bodies))
+    owns = [any(role_of_limb[l] == r for l in range(len(limbs))) or r == trunk_role for r in range(nrole)]
+    return [0 if not owns[r] else (4 if maxd[r] >= 4 else (2 if r == trunk_role else 1)) for r in range(nrole)]
 
 
 def solver_blocks(spec: ModelSpec, self_collision: bool = False, wave_caps: bool = False):
@@ -973,7 +993,8 @@ def solver_blocks(spec: ModelSpec, self_collision: bool = False, wave_caps: bool
     for d in range(spec.nd):
         gi_group[off + d] = limb[int(spec.dof_body[d])]
     body_block = [trunk_role if role_of_limb[limb[b]] < 0 else role_of_limb[limb[b]] for b in range(spec.nb)]
-    out = dict(gi_group=gi_group, body_block=body_block, nblk=nrole + (1 if self_collision else 0))
+    # a model with self-collision tables reserves its last wave for the self contacts (block nrole - 1, whether or not they are switched on)
+    out = dict(gi_group=gi_group, body_block=body_block, nblk=nrole if _has_selfcol(spec) else nrole + (1 if self_collision else 0))
     if wave_caps:       # the compact-store form keeps its ground contacts per wave
         out["kmax_blk"] = wave_contact_caps(spec)
     return out

@@ -2,23 +2,26 @@
 //
 // Round 2 ran this robot on one main wave (plus a helper for the self-collision phase): 49 % of the sub-step was a serial tail on that
 // wave (warm start, Gauss-Seidel sweeps, write-back), it executed the UNION of its 32 envs' active contact sets, and its live state (the
-// whole factor L, all joint axes, 105 sphere coordinates) overflowed the register file into 1 KB of scratch per lane.  Here the four
-// waves of the workgroup each own ONE limb (engine_mw.hpp roles; the trunk is recomputed by all) -- tree pass, factor, constraint
-// rows, SWEEPS and outputs of that limb -- so a wave's live state is one limb's L / S / rows and nothing spills by construction:
+// whole factor L, all joint axes, 105 sphere coordinates) overflowed the register file into 1 KB of scratch per lane.  Here the limb
+// roles of the workgroup (engine_mw.hpp; Humanoid: right leg | left leg | trunk rows + both arms) each own their limbs' tree pass,
+// factor, constraint rows, SWEEPS and outputs, and the LAST wave owns no limb: it is the pair role -- positions-only forward kinematics
+// and the self-collision narrow phase while the others work through P1 .. P3, then the sweeps of the self-contact rows:
 //
-//   P1  all     trunk down, own limb down + up, limb factor + whitened velocity; Schur complement / carries -> LDS          | B1
-//   P2  all     trunk up with every limb's contribution, trunk factor (redundantly)
-//   P3  all     own joint-limit rows; own ground contacts into the role's OWN contact slots (per-role caps M::wave_kcap, rows in a
-//               FIXED shape [limb dofs | trunk dofs]: every body of a limb shares it, so the sweeps walk a lane's actual contacts in
-//               a run-time loop instead of the union of the wave's spheres).  The pair role (the lightest one) also runs a
-//               positions-only forward kinematics of the whole body + the self-collision narrow phase and publishes <= KPAIR contacts | B2
-//   S1  all     self-contact half rows, side a: the wave that owns body a builds g_a = L^-T J_a^T (limb part, trunk part)            | B3
-//   S2  all     side b: -g_b into the other limb part (or folded into side a's when both bodies sit on one limb), trunk part -=     | B4
-//   W   pair    warm start of the self-contact rows                                                                                 | B5
-//   P4  all     block sweeps (oracle/physics.c solve_blocks): own rows Gauss-Seidel; the self contacts are a fifth block swept by the
-//               pair role after its own; coordinates shared by n >= 2 active blocks (the trunk: all; a limb: its owner + the pair
-//               block) answer with weight (n + 1) / 2; true contributions exchanged through LDS after every sweep                  | 1 per sweep
-//   P5  all     velocities, impulses / sensors / joint forces of the own rows, integration of the own dofs
+//   P1  limb roles  trunk down, own limbs down + up, limb factor + whitened velocity; Schur complement / carries -> LDS     | B1
+//       pair role   forward kinematics (positions), first groups of the narrow phase
+//   P2  limb roles  trunk up with every limb's contribution, trunk factor (redundantly)
+//   P3  limb roles  own joint-limit rows; own ground contacts into the role's OWN contact slots (caps M::wave_kcap, rows in a FIXED
+//                   shape [limb dofs | trunk dofs] shared by every body of the role, so the sweeps walk a lane's actual contacts in a
+//                   run-time loop instead of the union of the wave's spheres)
+//       pair role   the other groups, <= KPAIR self contacts (point, normal, bodies) -> C_X                                  | B2
+//   Z   pair role   zeroes the dense rows [3][NV] of the contacts, stores their velocity targets and warm-start impulses      | B3
+//   S   limb roles  for every self contact with a body of mine: g = +-L^-T J^T over that body's chain, ADDED to the dense rows
+//                   (ds_add_f32: at most two waves add to an entry of a zeroed row -- commutative, so bit-reproducible)      | B4
+//   W   limb roles  warm start of the self-contact rows on the own limb coordinates (and, redundantly, the trunk's)            | B5
+//   P4  all         block sweeps (oracle/physics.c solve_blocks): every limb role Gauss-Seidel over its own rows, the pair role over the
+//                   self contacts; coordinates shared by n >= 2 active blocks (the trunk: all; a limb: its owner + the pair block)
+//                   answer with weight (n + 1) / 2; true contributions exchanged through LDS (double buffered)                | 1 per sweep
+//   P5  limb roles  velocities, impulses / sensors / joint forces of the own rows, integration; pair role: impulses of the groups
 //
 // LDS per env: <= 1280 floats (32 envs per workgroup, one workgroup per CU).  The exchange areas of P1 / P2 and everything that is only
 // needed after B2 (self-contact rows, sweep exchange) share one region.
@@ -33,6 +36,17 @@
 
 namespace mi {
 
+// float add into the shared row store: ds_add_f32 on the device (no return value); a CAS loop in the host build of the tests
+MI_HD void lds_add(float* p, const float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+    unsigned* u = reinterpret_cast<unsigned*>(p);
+    unsigned old = __atomic_load_n(u, __ATOMIC_RELAXED), nw;
+    do { nw = __builtin_bit_cast(unsigned, __builtin_bit_cast(float, old) + v); } while (!__atomic_compare_exchange_n(u, &old, nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+#endif
+}
+
 template <class M>
 struct SimMWC : SimMW<M> {
     using MW = SimMW<M>;
@@ -40,64 +54,74 @@ struct SimMWC : SimMW<M> {
     using typename B::Ctx;
     using typename B::BodyTmp;
     static constexpr int NB = M::NB, ND = M::ND, NV = M::NV, OFF = M::OFF, NSPH = M::NSPH, NSENS = M::NSENS, NLIM = B::NLIM, NVA = B::NVA,
-                         NR = M::NROLE, NVT = MW::NVT, NTE = MW::NTE, NLR = MW::NLR, NTB = MW::NTB, NPG = M::NPG, KPAIR = 3, NBLK = NR + 1;
-    static_assert(M::NLIMB == NR + 1 && !M::FIXED && B::COMPACT, "one limb per role, free base, compact-store model");
-    // ---- the limb of a role: generalised indices lfirst(r) .. lfirst(r) + nl(r) - 1
+                         NR = M::NROLE, NVT = MW::NVT, NTE = MW::NTE, NLR = MW::NLR, NTB = MW::NTB, NPG = M::NPG, KPAIR = 3, NLIMB = M::NLIMB;
+    static_assert(!M::FIXED && B::COMPACT, "free base, compact-store model");
+    // ---- roles.  A limb role owns the limbs dealt to it (consecutive generalised indices lfirst(r) .. lfirst(r) + nl(r) - 1); a model
+    //      with self-collision tables keeps its last role free of limbs: the pair role.
     static constexpr int lfirst(int r) { for (int i = OFF; i < NV; ++i) if (MW::role_of_gi(i) == r) return i; return NV; }
     static constexpr int nl(int r) { int n = 0; for (int i = 0; i < NV; ++i) n += (MW::role_of_gi(i) == r) ? 1 : 0; return n; }
+    static constexpr bool owns_any(int r) { for (int b = 0; b < NB; ++b) if (MW::role_of_body(b) == r || (MW::trunk_body(b) && r == M::TRUNK_ROLE)) return true; return false; }
+    static constexpr bool HAS_PAIR_ROLE = NPG > 0;
+    static constexpr int PAIR_ROLE = NR - 1;
+    static_assert(!HAS_PAIR_ROLE || !owns_any(PAIR_ROLE), "self-colliding model: the last role owns no body (assets/model.py wave_roles)");
+    static constexpr int NRL = HAS_PAIR_ROLE ? NR - 1 : NR;                               // limb roles
     static constexpr bool limbs_contiguous() {
         for (int r = 0; r < NR; ++r) for (int i = lfirst(r); i < lfirst(r) + nl(r); ++i) if (MW::role_of_gi(i) != r) return false;
         return true;
     }
-    static_assert(limbs_contiguous(), "a limb's dofs are numbered consecutively (depth-first numbering)");
-    static constexpr int NLMAX = []() constexpr { int m = 0; for (int r = 0; r < NR; ++r) m = nl(r) > m ? nl(r) : m; return m; }();
+    static_assert(limbs_contiguous(), "a role's limb dofs are numbered consecutively (depth-first numbering)");
     static constexpr int NVL = NV - NVT;                                                   // limb coordinates of all roles
-    static constexpr int loff(int r) { int o = 0; for (int k = 0; k < r; ++k) o += nl(k); return o; }   // role r's place in an [NVL] vector
+    static constexpr int lidx(int gi) { int n = 0; for (int k = 0; k < gi; ++k) n += MW::trunk_gi(k) ? 0 : 1; return n; }   // place in an [NVL] vector
+    static constexpr int limb_of_gi(int gi) { return gi < OFF ? 0 : M::limb_of_body[M::dof_body[gi - OFF]]; }               // coordinate group (0: trunk)
     static constexpr int rlen(int r) { return nl(r) + NVT; }                               // fixed row shape of role r: [limb | trunk]
-    static constexpr int gcsz(int r) { return 3 * rlen(r) + 7; }                           // ground slot: 3 rows, |g_limb|^2 x3, vt, lam x3
+    static constexpr int gcsz(int r) { return 3 * rlen(r) + 4; }                           // ground slot: 3 rows, vt, lam x3
     static constexpr int kcap(int r) { return M::wave_kcap[r]; }
-    static constexpr int PAIR_ROLE = []() constexpr {                                      // the lightest role hosts the self-contact block
-        int best = 0, bl = 1 << 30;
-        for (int r = 0; r < NR; ++r) { const int l = nl(r) + (r == M::TRUNK_ROLE ? NVT : 0); if (l <= bl) { bl = l; best = r; } }
-        return best;
-    }();
+    static constexpr bool uniform_mu() { for (int s = 1; s < NSPH; ++s) if (M::sph_mu[s] != M::sph_mu[0]) return false; return true; }
+    static_assert(uniform_mu(), "the ground slots do not carry their sphere's friction: one value per model");
     // ---- LDS layout (floats per env)
     static constexpr int C_LIMG = B::C_LIMG;                                               // limit rows' G, packed by B::limoff
-    static constexpr int L_SL = C_LIMG, L_VT = C_LIMG + NLIM, L_LAM = C_LIMG + 2 * NLIM;   // |g_limb|^2, velocity target, impulse
-    static constexpr int gcb(int r) { int o = C_LIMG + 3 * NLIM; for (int k = 0; k < r; ++k) o += kcap(k) * gcsz(k); return o; }
+    static constexpr int L_VT = C_LIMG, L_LAM = C_LIMG + NLIM;                             // velocity target, impulse
+    static constexpr int gcb(int r) { int o = C_LIMG + 2 * NLIM; for (int k = 0; k < r; ++k) o += kcap(k) * gcsz(k); return o; }
     static constexpr int C_SLOTOF = gcb(NR);                                               // one byte per sphere: its slot in the owner's range, -1
-    static constexpr int C_X = C_SLOTOF + (NSPH + 3) / 4;                                  // group -> slot map, then per self contact 12 floats:
-    static constexpr int XI = 12;                                                          //   point (3), normal (3), bodies / sides word, mu, vt, lam0 (3)
+    static constexpr int C_X = C_SLOTOF + (NSPH + 3) / 4;                                  // group -> slot map, then per self contact 8 floats:
+    static constexpr int XI = 8;                                                           //   point (3), normal (3), bodies word, mu
     static constexpr int A0 = C_X + 1 + XI * KPAIR;                                        // shared region: before B2 ...
     static constexpr int X_LR = A0, X_DT = X_LR + 16 * NLR, X_DY = X_DT + NR * NTE, X_END = X_DY + NR * NVT;
-    static constexpr int P_CSZ = 3 * (2 * NLMAX + NVT) + 4;                                // ... after B2: self-contact rows LA, LB, T; vt, lam x3
-    static constexpr int P_B = A0, PW = P_B + KPAIR * P_CSZ;                               // [NVL]        limb part of w as the pair block starts a sweep
-    static constexpr int DOWN = PW + NVL;                                                  // [2][NVL]     true contribution of every owner's block to its limb part
+    static constexpr int P_CSZ = 3 * NV + 4;                                               // ... after B2: self-contact rows, dense [3][NV]; vt, lam x3
+    static constexpr int P_B = A0, XW0 = P_B + KPAIR * P_CSZ;                              // [NVT]        trunk part of w before any warm start (for the pair role)
+    static constexpr int DOWN = XW0 + NVT;                                                 // [2][NVL]     true contribution of the owners' blocks to their limb coordinates
     static constexpr int DPAIR = DOWN + 2 * NVL;                                           // [2][NVL]     ... of the pair block
-    static constexpr int X_DW = DPAIR + 2 * NVL;                                           // [2][NBLK][NVT] ... of every block to the trunk part
-    static constexpr int X_FLG = X_DW + 2 * NBLK * NVT;                                    // [2][NBLK]    block active
-    static constexpr int X_TOUCH = X_FLG + 2 * NBLK;                                       // [1]          roles whose limbs the self contacts touch (bit mask)
+    static constexpr int X_DW = DPAIR + 2 * NVL;                                           // [2][NR][NVT] ... of every block to the trunk part
+    static constexpr int X_FLG = X_DW + 2 * NR * NVT;                                      // [2][NR]      block active
+    static constexpr int X_TOUCH = X_FLG + 2 * NR;                                         // [1]          limbs the self contacts touch (bit l - 1 for limb l)
     static constexpr int S_END = X_TOUCH + 1;
     static constexpr int MWC_SLOTS = X_END > S_END ? X_END : S_END;
     static constexpr int LANES = 32;
     static_assert((size_t)MWC_SLOTS * LANES * sizeof(float) <= 160 * 1024, "row store + exchange areas fit the LDS of a CU at 32 envs per workgroup");
-    static constexpr int PLA = 0, PLB = 3 * NLMAX, PT = 6 * NLMAX, PVT = 6 * NLMAX + 3 * NVT, PLAM = PVT + 1;   // inside a self-contact slot
+    static constexpr int PVT = 3 * NV, PLAM = PVT + 1;                                     // inside a self-contact slot
 
-    // position of generalised index gi in role R's fixed row shape
     template <int R> static constexpr int shape_idx(int gi) { return MW::trunk_gi(gi) ? nl(R) + MW::tidx(gi) : gi - lfirst(R); }
     template <int R> static constexpr bool in_chain(int b, int idx) {
         for (int c = 0; c < M::chain_len[b]; ++c) if (shape_idx<R>(M::chain[b][c]) == idx) return true;
         return false;
     }
-    static constexpr bool chain_has_t(int b, int t) {
-        for (int c = 0; c < M::chain_len[b]; ++c) if (MW::trunk_gi(M::chain[b][c]) && MW::tidx(M::chain[b][c]) == t) return true;
-        return false;
+    // weight of a coordinate in a sweep: trunk omT, limb l oml[l - 1]
+    template <int GI> static MI_HD float om_of(const float omT, const float (&oml)[NLIMB > 1 ? NLIMB - 1 : 1]) {
+        if constexpr (MW::trunk_gi(GI)) return omT; else { constexpr int l = limb_of_gi(GI); return oml[l - 1]; }
     }
-    static constexpr bool chain_has_l(int b, int k) {      // limb-local index k of the body's own limb
-        const int r = MW::role_of_body(b);
-        if (r < 0) return false;
-        for (int c = 0; c < M::chain_len[b]; ++c) if (!MW::trunk_gi(M::chain[b][c]) && M::chain[b][c] - lfirst(r) == k) return true;
-        return false;
+    // per-sweep weights from the blocks' activity flags and the limbs the self contacts touch
+    template <int RS>
+    MI_HD void sweep_weights(const RowStore<RS>& fin, const unsigned touch, float& omT, float (&oml)[NLIMB > 1 ? NLIMB - 1 : 1]) const {
+        float fl[NR];
+        sfor<NR>([&](auto B_) MI_LAMBDA { fl[B_] = fin(B_); });
+        float nact = 0.f;
+        sfor<NR>([&](auto B_) MI_LAMBDA { nact += fl[B_]; });
+        omT = (nact > 1.5f) ? 0.5f * (nact + 1.f) : 1.f;
+        sfor<NLIMB - 1>([&](auto L_) MI_LAMBDA {
+            constexpr int l = L_ + 1, r = M::role_of_limb[l];
+            const float fp = HAS_PAIR_ROLE ? (((touch >> L_) & 1u) ? fl[PAIR_ROLE] : 0.f) : 0.f;
+            oml[L_] = (fl[r] + fp > 1.5f) ? 1.5f : 1.f;
+        });
     }
 
     // ---------------------------------------------------------------- positions-only forward kinematics (pair role: all sphere centres)
@@ -152,6 +176,285 @@ struct SimMWC : SimMW<M> {
         });
     }
 
+    // ================================================================ the pair role: narrow phase, sweeps of the self contacts
+    // groups 0 .. G_SPLIT - 1 are examined before B1 (while the limb roles run their tree pass), the others before B2
+    static constexpr int G_SPLIT = []() constexpr {
+        int tot = 0, acc = 0;
+        for (int g = 0; g < (NPG > 0 ? NPG : 0); ++g) tot += M::pg_count[g];
+        for (int g = 0; g < (NPG > 0 ? NPG : 0); ++g) { if (5 * (acc + M::pg_count[g]) > tot) return g; acc += M::pg_count[g]; }
+        return NPG > 0 ? NPG : 0;
+    }();
+    template <int RS, class BAR>
+    MI_HD void substep_pair(const SimParams& P, const float h, const RowStore<RS> rows, const SelfCol* scol, const BAR& bar) {
+        constexpr int ST = RowStore<RS>::stride;
+        const float invh = MI_RCP(h);
+        const bool selfcol = (NPG > 0) && (scol != nullptr);
+        unsigned pmap = 0xFFFFFFFFu;
+        float pvt[KPAIR], pl0[KPAIR][3];       // velocity targets / warm-start impulses of the contacts, kept until the shared region is free
+        sfor<KPAIR>([&](auto J_) MI_LAMBDA { pvt[J_] = 0.f; sfor<3>([&](auto K) MI_LAMBDA { pl0[J_][K] = 0.f; }); });
+#if defined(MI_TIMING)
+        unsigned long long* const tstamp = this->tstamp;
+#endif
+        MI_STAMP(0);
+        if constexpr (NPG > 0) {
+            float xa[NSPH][3], capm[M::NCAP][3];
+            int cntp = 0, pdrop = 0;
+            auto group = [&](auto G_) MI_LAMBDA {
+                constexpr int g = decltype(G_)::value;
+                MI_PHASE();
+                float best = 3.0e38f, bca[3] = {0.f, 0.f, 0.f}, bcb[3] = {0.f, 0.f, 0.f};
+                int bk = 0;
+                sfor<M::pg_count[g]>([&](auto K_) MI_LAMBDA {
+                    constexpr int k = M::pg_first[g] + K_, ia = M::gp_a[k], ib = M::gp_b[k];
+                    constexpr float reach = B::cap_bound(ia) + B::cap_bound(ib);
+                    const float dm[3] = {capm[ia][0] - capm[ib][0], capm[ia][1] - capm[ib][1], capm[ia][2] - capm[ib][2]};
+                    const float rr = reach + P.contact_offset;
+                    if (!MI_WAVE_ANY(dot3(dm, dm) < rr * rr)) return;
+                    float ca[3], cb[3];
+                    seg_seg_closest<B::cap_is_point(ia), B::cap_is_point(ib)>(xa[M::cap_s0[ia]], xa[M::cap_s1[ia]], xa[M::cap_s0[ib]], xa[M::cap_s1[ib]], ca, cb);
+                    const float dv[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]};
+                    const float dist = MI_SQRT(dot3(dv, dv)) - (M::cap_rad[ia] + M::cap_rad[ib]);
+                    const bool better = dist < best;
+                    best = better ? dist : best;
+                    sfor<3>([&](auto I_) MI_LAMBDA { bca[I_] = better ? ca[I_] : bca[I_]; bcb[I_] = better ? cb[I_] : bcb[I_]; });
+                    bk = better ? K_ : bk;
+                });
+                const bool near = best < P.contact_offset;
+                const bool on = near && (cntp < KPAIR);
+                pdrop += (near && !on) ? 1 : 0;
+                if (MI_WAVE_ANY(on)) {
+                    if (on) {
+                        int bab = 0;
+                        float brb = 0.f, bmu = 0.f;
+                        sfor<M::pg_count[g]>([&](auto K_) MI_LAMBDA {
+                            constexpr int k = M::pg_first[g] + K_, ia = M::gp_a[k], ib = M::gp_b[k], ba = M::cap_body[ia], bb = M::cap_body[ib];
+                            constexpr int la = M::limb_of_body[ba], lb = M::limb_of_body[bb];     // 0: trunk
+                            constexpr int word = ba | (bb << 8) | (la << 16) | (lb << 20) | (g << 24);
+                            const bool me = bk == K_;
+                            bab = me ? word : bab;
+                            brb = me ? M::cap_rad[ib] : brb;
+                            bmu = me ? 0.5f * (M::cap_mu[ia] + M::cap_mu[ib]) : bmu;
+                        });
+                        float n[3];
+                        {
+                            const float dv[3] = {bca[0] - bcb[0], bca[1] - bcb[1], bca[2] - bcb[2]};
+                            const float d2 = dot3(dv, dv);
+                            const bool okd = d2 > 1e-18f;
+                            const float inv = MI_RSQ(fmaxf(d2, 1e-30f));
+                            n[0] = okd ? dv[0] * inv : 0.f; n[1] = okd ? dv[1] * inv : 0.f; n[2] = okd ? dv[2] * inv : 1.f;
+                        }
+                        float* xi = rows.ptr(C_X + 1 + XI * cntp);
+                        sfor<3>([&](auto I_) MI_LAMBDA { xi[I_ * ST] = bcb[I_] + n[I_] * (brb + 0.5f * best); xi[(3 + I_) * ST] = n[I_]; });
+                        xi[6 * ST] = __builtin_bit_cast(float, bab);
+                        xi[7 * ST] = bmu;
+                        // (velocity target and warm-start impulses go straight into the slot once the shared region is free: kept per slot)
+                        const float gap = best - P.rest_offset;
+                        sfor<KPAIR>([&](auto J_) MI_LAMBDA {
+                            const bool mej = cntp == J_;
+                            pvt[J_] = mej ? ((gap >= 0.f) ? -gap * invh : fminf(-gap * P.erp * invh, P.max_depen_vel)) : pvt[J_];
+                            sfor<3>([&](auto K) MI_LAMBDA { pl0[J_][K] = mej ? scol->lamp(3 * g + K) * P.warm : pl0[J_][K]; });
+                        });
+                    }
+                }
+                pmap = (pmap & ~(3u << (2 * g))) | ((unsigned)(on ? cntp : 3) << (2 * g));
+                cntp += on ? 1 : 0;
+            };
+            if (selfcol) {
+                fk_pos<0>(nullptr, nullptr, xa);
+                sfor<M::NCAP>([&](auto C_) MI_LAMBDA {
+                    sfor<3>([&](auto I_) MI_LAMBDA { capm[C_][I_] = 0.5f * (xa[M::cap_s0[C_]][I_] + xa[M::cap_s1[C_]][I_]); });
+                });
+                sfor<KPAIR>([&](auto J_) MI_LAMBDA { rows(C_X + 1 + XI * J_ + 6) = __builtin_bit_cast(float, 0xFFFFFFFFu); });
+                sfor<G_SPLIT>([&](auto G_) MI_LAMBDA { group(G_); });
+            }
+            MI_STAMP(1);
+            bar();                                                                                   // ---- B1
+            MI_STAMP(2);
+            if (selfcol) {
+                sfor<NPG - G_SPLIT>([&](auto G_) MI_LAMBDA { group(std::integral_constant<int, G_SPLIT + decltype(G_)::value>{}); });
+                rows(C_X) = __builtin_bit_cast(float, pmap);
+                if (scol->dropped != nullptr && pdrop > 0) MI_ATOMIC_ADD_INT(scol->dropped + scol->dstride, pdrop);
+            }
+            MI_STAMP(4);
+        } else {
+            bar();
+        }
+        bar();                                                                                       // ---- B2
+        MI_STAMP(5);
+        if constexpr (NPG > 0) { if (selfcol) {
+            // Z: zero the dense rows of the contacts; their velocity targets and warm-start impulses
+            sfor<KPAIR>([&](auto J_) MI_LAMBDA {
+                constexpr int j = J_;
+                const unsigned bab = __builtin_bit_cast(unsigned, (float)rows(C_X + 1 + XI * j + 6));
+                const bool onj = bab != 0xFFFFFFFFu;
+                if (MI_WAVE_ANY(onj)) {
+                    if (onj) {
+                        sfor<3 * NV>([&](auto I) MI_LAMBDA { rows(P_B + j * P_CSZ + I) = 0.f; });
+                        rows(P_B + j * P_CSZ + PVT) = pvt[j];
+                        sfor<3>([&](auto K) MI_LAMBDA { rows(P_B + j * P_CSZ + PLAM + K) = pl0[j][K]; });
+                    }
+                }
+            });
+            MI_STAMP(6);
+            bar();                                                                                   // ---- B3
+            MI_STAMP(7);
+            MI_STAMP(8);
+            bar();                                                                                   // ---- B4: rows complete
+            MI_STAMP(9);
+        } }
+        // ---- round 0 of the exchange: this block contributes nothing to it (the warm start of its rows is added by the limb roles)
+        unsigned touch = 0u;
+        float actp = 0.f;
+        if constexpr (NPG > 0) { if (selfcol) {
+            sfor<KPAIR>([&](auto J_) MI_LAMBDA {
+                const unsigned bab = __builtin_bit_cast(unsigned, (float)rows(C_X + 1 + XI * J_ + 6));
+                const bool onj = bab != 0xFFFFFFFFu;
+                const unsigned la = (bab >> 16) & 15u, lb = (bab >> 20) & 15u;
+                touch |= onj ? ((la ? 1u << (la - 1) : 0u) | (lb ? 1u << (lb - 1) : 0u)) : 0u;
+                actp = onj ? 1.f : actp;
+            });
+        } }
+        // warm start of the self-contact rows on the trunk part: every role computes it (same order, same rounding) BEFORE B5 -- afterwards
+        // the sweeps overwrite the impulses in the slots -- and adds it after the blocks' round-0 contributions
+        float dwp[NVT];
+        sfor<NVT>([&](auto T_) MI_LAMBDA { dwp[T_] = 0.f; });
+        if constexpr (NPG > 0) { if (selfcol) {
+            sfor<KPAIR>([&](auto J_) MI_LAMBDA {
+                constexpr int j = J_;
+                const unsigned bab = __builtin_bit_cast(unsigned, (float)rows(C_X + 1 + XI * j + 6));
+                if (bab != 0xFFFFFFFFu) {
+                    sfor<3>([&](auto K) MI_LAMBDA {
+                        const float l0 = rows(P_B + j * P_CSZ + PLAM + K);
+                        sfor<NV>([&](auto I) MI_LAMBDA { if constexpr (MW::trunk_gi(I)) { constexpr int ti = MW::tidx(I); dwp[ti] += rows(P_B + j * P_CSZ + K * NV + I) * l0; } });
+                    });
+                }
+            });
+        } }
+        sfor<NVT>([&](auto I) MI_LAMBDA { rows(X_DW + PAIR_ROLE * NVT + I) = 0.f; });
+        rows(X_FLG + PAIR_ROLE) = actp;
+        rows(X_TOUCH) = __builtin_bit_cast(float, touch);
+        MI_STAMP(10);
+        bar();                                                                                       // ---- B5
+        MI_STAMP(11);
+        // ============================================================ P4: the self contacts' block
+        float wt[NVT], pw[NVL > 0 ? NVL : 1];
+        sfor<NVT>([&](auto T_) MI_LAMBDA {
+            wt[T_] = rows(XW0 + T_);
+            sfor<NR>([&](auto B_) MI_LAMBDA { constexpr int o = X_DW + B_ * NVT + T_; wt[T_] += rows(o); });
+        });
+        sfor<NVL>([&](auto I) MI_LAMBDA { pw[I] = rows(DOWN + I); });
+        sfor<NVT>([&](auto T_) MI_LAMBDA { wt[T_] += dwp[T_]; });
+        for (int it = 0; it < P.iters; ++it) {
+            MI_STAMP(15);
+            int zero;
+            MI_OPAQUE_ZERO(zero);
+            const RowStore<RS> rit = rows.shifted(zero);
+            const int par = it & 1;
+            const RowStore<RS> xdw = rows.shifted((X_DW + (par ^ 1) * NR * NVT) * ST), fin = rows.shifted((X_FLG + par * NR) * ST),
+                               fout = rows.shifted((X_FLG + (par ^ 1) * NR) * ST), down = rows.shifted((DOWN + (par ^ 1) * NVL) * ST),
+                               dpair = rows.shifted((DPAIR + (par ^ 1) * NVL) * ST);
+            float omT, oml[NLIMB > 1 ? NLIMB - 1 : 1];
+            sweep_weights(fin, touch, omT, oml);
+            float wtl[NVT], pwl[NVL > 0 ? NVL : 1];
+            sfor<NVT>([&](auto T_) MI_LAMBDA { wtl[T_] = wt[T_]; });
+            sfor<NVL>([&](auto I) MI_LAMBDA { pwl[I] = pw[I]; });
+            float actn = 0.f;
+            MI_STAMP(16);
+            MI_STAMP(17);
+            if constexpr (NPG > 0) { if (selfcol) {
+                for (int j = 0; j < KPAIR; ++j) {
+                    const float* xi = rit.ptr(C_X + 1 + XI * j);
+                    const unsigned bab = __builtin_bit_cast(unsigned, xi[6 * ST]);
+                    const bool onj = bab != 0xFFFFFFFFu;
+                    if (!MI_WAVE_ANY(onj)) break;                // slots fill from the front
+                    if (onj) {
+                        float* pb = rit.ptr(P_B + j * P_CSZ);
+                        const float mu = xi[7 * ST];
+                        float g[3][NV], ainv[3], lm[3];
+                        sfor<3>([&](auto K) MI_LAMBDA {
+                            float a = P.cfm;
+                            sfor<NV>([&](auto I) MI_LAMBDA {
+                                g[K][I] = pb[(K * NV + I) * ST];
+                                a += om_of<decltype(I)::value>(omT, oml) * g[K][I] * g[K][I];
+                            });
+                            ainv[K] = MI_RCP(a);
+                            lm[K] = pb[(PLAM + K) * ST];
+                        });
+                        const float vtn = pb[PVT * ST];
+                        auto wref = [&](auto I) MI_LAMBDA -> float& {
+                            constexpr int i = decltype(I)::value;
+                            if constexpr (MW::trunk_gi(i)) { constexpr int ti = MW::tidx(i); return wtl[ti]; } else { constexpr int li = lidx(i); return pwl[li]; }
+                        };
+                        auto dotw = [&](const float (&gr)[NV]) MI_LAMBDA -> float {
+                            float s = 0.f;
+                            sfor<NV>([&](auto I) MI_LAMBDA { s += gr[I] * wref(I); });
+                            return s;
+                        };
+                        auto addw = [&](const float (&gr)[NV], const float dl) MI_LAMBDA {
+                            sfor<NV>([&](auto I) MI_LAMBDA { wref(I) += om_of<decltype(I)::value>(omT, oml) * gr[I] * dl; });
+                        };
+                        const float ln = fmaxf(lm[0] - (dotw(g[0]) - vtn) * ainv[0], 0.f);
+                        addw(g[0], ln - lm[0]);
+                        float lt[2];
+                        sfor<2>([&](auto K) MI_LAMBDA {
+                            const float dl = -dotw(g[1 + K]) * ainv[1 + K];
+                            lt[K] = lm[1 + K] + dl;
+                            addw(g[1 + K], dl);
+                        });
+                        const float lim = mu * ln;
+                        const float n2 = lt[0] * lt[0] + lt[1] * lt[1];
+                        const float sc = (n2 > lim * lim) ? lim * MI_RSQ(fmaxf(n2, 1e-30f)) : 1.f;
+                        pb[PLAM * ST] = ln;
+                        actn = (ln > 0.f) ? 1.f : actn;
+                        sfor<2>([&](auto K) MI_LAMBDA {
+                            const float nl_ = lt[K] * sc;
+                            pb[(PLAM + 1 + K) * ST] = nl_;
+                            addw(g[1 + K], nl_ - lt[K]);
+                        });
+                    }
+                }
+            } }
+            MI_STAMP(18);
+            const float iomT = 1.f / omT;
+            sfor<NVT>([&](auto T_) MI_LAMBDA { xdw(PAIR_ROLE * NVT + T_) = (wtl[T_] - wt[T_]) * iomT; });
+            float dp[NVL > 0 ? NVL : 1];
+            sfor<NV>([&](auto I) MI_LAMBDA {
+                if constexpr (!MW::trunk_gi(I)) {
+                    constexpr int li = lidx(I);
+                    dp[li] = (pwl[li] - pw[li]) / om_of<decltype(I)::value>(omT, oml);
+                    dpair(li) = dp[li];
+                }
+            });
+            fout(PAIR_ROLE) = actn;
+            MI_STAMP(19);
+            bar();                                                                                   // ---- one barrier per sweep
+            MI_STAMP(20);
+            sfor<NVT>([&](auto T_) MI_LAMBDA { sfor<NR>([&](auto B_) MI_LAMBDA { constexpr int o = B_ * NVT + T_; wt[T_] += xdw(o); }); });
+            sfor<NVL>([&](auto I) MI_LAMBDA { pw[I] += down(I) + dp[I]; });
+            MI_STAMP(21);
+        }
+        MI_STAMP(12);
+        // ============================================================ P5: impulses of the groups -> warm start of the next sub-step, world force on side a
+        if constexpr (NPG > 0) { if (selfcol) {
+            sfor<NPG>([&](auto G_) MI_LAMBDA {
+                constexpr int g = G_;
+                const int j = (int)((pmap >> (2 * g)) & 3u);
+                const bool onj = j != 3;
+                const float* pb = rows.ptr(P_B + (onj ? j : 0) * P_CSZ);
+                const float* xi = rows.ptr(C_X + 1 + XI * (onj ? j : 0));
+                const float ln = onj ? pb[PLAM * ST] : 0.f, l1 = onj ? pb[(PLAM + 1) * ST] : 0.f, l2 = onj ? pb[(PLAM + 2) * ST] : 0.f;
+                scol->lamp(3 * g) = ln; scol->lamp(3 * g + 1) = l1; scol->lamp(3 * g + 2) = l2;
+                if (scol->pairf.p) {
+                    float n[3], t1[3], t2[3];
+                    sfor<3>([&](auto I_) MI_LAMBDA { n[I_] = onj ? xi[(3 + I_) * ST] : (I_ == 2 ? 1.f : 0.f); });
+                    contact_frame(n, t1, t2);
+                    sfor<3>([&](auto K) MI_LAMBDA { scol->pairf(3 * g + K) = (n[K] * ln + t1[K] * l1 + t2[K] * l2) * invh; });
+                }
+            });
+        } }
+        MI_STAMP(13);
+    }
+
     // ---------------------------------------------------------------- one role of a sub-step
     template <int R, int RS, class BAR>
     MI_HD void substep_role_c(const SimParams& P, const float* tau, const float h, const RowStore<RS> rows, const Strided lamc,
@@ -159,7 +462,7 @@ struct SimMWC : SimMW<M> {
                               const BAR& bar) {
         constexpr int ST = RowStore<RS>::stride;
         constexpr int NLR_ = nl(R), RLEN = rlen(R), GCB = gcb(R), GCSZ = gcsz(R), KCAP = kcap(R), LF = lfirst(R);
-        constexpr bool PAIRW = (R == PAIR_ROLE) && (NPG > 0);
+        static_assert(R < NRL, "limb role");
         auto slot8 = [&](int s) MI_LAMBDA -> signed char& { return reinterpret_cast<signed char*>(rows.ptr(C_SLOTOF + (s >> 2)))[s & 3]; };
         const float invh = MI_RCP(h);
         float (&root)[13] = this->root;
@@ -170,6 +473,10 @@ struct SimMWC : SimMW<M> {
         float (&S)[M::NDA][6] = c.S;
         float (&L)[M::NM] = c.L;
         // ============================================================ P1 (as engine_mw.hpp)
+#if defined(MI_TIMING)
+        unsigned long long* const tstamp = this->tstamp;
+#endif
+        MI_STAMP(0);
         BodyTmp tb[NTB];
         this->template trunk_down<R, 0, X_LR>(P, c, tb, nullptr, nullptr, nullptr, nullptr, rows);
         MI_PHASE();
@@ -224,7 +531,9 @@ struct SimMWC : SimMW<M> {
         sfor_rev<NV>([&](auto I_) MI_LAMBDA { if constexpr (MW::role_of_gi(I_) == R) whiten(I_); });
         sfor<M::NM>([&](auto E_) MI_LAMBDA { if constexpr (MW::trunk_entry(E_)) { constexpr int o = X_DT + R * NTE + MW::teidx(E_); rows(o) = L[E_]; } });
         sfor<NV>([&](auto I) MI_LAMBDA { if constexpr (MW::trunk_gi(I)) { constexpr int o = X_DY + R * NVT + MW::tidx(I); rows(o) = y[I]; } });
+        MI_STAMP(1);
         bar();                                                                                       // ---- B1
+        MI_STAMP(2);
         // ============================================================ P2 (every role, redundantly): trunk coming up, trunk factor
         sfor_rev<NB>([&](auto B_) MI_LAMBDA {
             constexpr int b = B_;
@@ -266,7 +575,7 @@ struct SimMWC : SimMW<M> {
                 y[gi] = tau[d] - c.bias[gi] - K * (q[d] - M::dof_springref[d]) - (Dm + h * K) * qd[d];
             }
         });
-        sfor<NR>([&](auto R_) MI_LAMBDA {
+        sfor<NRL>([&](auto R_) MI_LAMBDA {      // (the limb roles: the pair role has no limb to eliminate)
             sfor<M::NM>([&](auto E_) MI_LAMBDA { if constexpr (MW::trunk_entry(E_)) { constexpr int o = X_DT + R_ * NTE + MW::teidx(E_); L[E_] += rows(o); } });
             sfor<NV>([&](auto I) MI_LAMBDA { if constexpr (MW::trunk_gi(I)) { constexpr int o = X_DY + R_ * NVT + MW::tidx(I); y[I] += rows(o); } });
         });
@@ -302,9 +611,11 @@ struct SimMWC : SimMW<M> {
                 });
             });
         };
-        // last sub-step's impulses of the own ground spheres: issued together, consumed sphere by sphere below
-        float lprev[NSPH > 0 ? NSPH : 1][3];
-        sfor<NSPH>([&](auto S_) MI_LAMBDA {
+        // last sub-step's impulses of the own ground spheres: a role whose spheres usually touch (a leg) issues the loads together up
+        // front; a role that rarely touches the ground (trunk, arms: 19 spheres) loads them where a contact is built -- 57 registers less
+        constexpr bool PREFETCH_LAMC = KCAP >= 4;
+        float lprev[PREFETCH_LAMC ? (NSPH > 0 ? NSPH : 1) : 1][3];
+        if constexpr (PREFETCH_LAMC) sfor<NSPH>([&](auto S_) MI_LAMBDA {
             if constexpr (MW::template owns_body<R>(M::sph_body[S_])) sfor<3>([&](auto K) MI_LAMBDA { lprev[S_][K] = lamc(3 * S_ + K); });
         });
         sfor<ND>([&](auto D) MI_LAMBDA {
@@ -330,13 +641,7 @@ struct SimMWC : SimMW<M> {
                         g[kk] -= L[M::midx[i][j]] * z;
                     });
                 });
-                float sl = 0.f;
-                sfor<M::nanc[gi] + 1>([&](auto K) MI_LAMBDA {
-                    constexpr int k = K, i = (k == 0) ? gi : M::anc[gi][k == 0 ? 0 : k - 1];
-                    if constexpr (!MW::trunk_gi(i)) sl += g[k] * g[k];
-                    rows(g0 + k) = g[k];
-                });
-                rows(L_SL + row) = sl;
+                sfor<M::nanc[gi] + 1>([&](auto K) MI_LAMBDA { rows(g0 + K) = g[K]; });
                 const float vtl = (C >= 0.f) ? -C * invh : fminf(-C * P.erp * invh, P.max_depen_vel);
                 rows(L_VT + row) = vtl;
                 rows(L_LAM + row) = l0;
@@ -375,19 +680,17 @@ struct SimMWC : SimMW<M> {
                         const float gap = dist - P.rest_offset;
                         sfor<3>([&](auto K) MI_LAMBDA {
                             constexpr int k = K;
-                            float sl = 0.f;
                             sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA {
                                 constexpr int gi = M::chain[b][C], idx = shape_idx<R>(gi);
-                                if constexpr (!MW::trunk_gi(gi)) sl += g[k][C] * g[k][C];
                                 cb[(k * RLEN + idx) * ST] = g[k][C];
                             });
                             sfor<RLEN>([&](auto I_) MI_LAMBDA { if constexpr (!in_chain<R>(b, I_)) cb[(k * RLEN + I_) * ST] = 0.f; });   // the rest of the fixed shape
-                            cb[(3 * RLEN + k) * ST] = sl;
-                            const float l0 = lprev[s][k] * P.warm;
-                            cb[(3 * RLEN + 4 + k) * ST] = l0;
+                            float l0;
+                            if constexpr (PREFETCH_LAMC) l0 = lprev[s][k] * P.warm; else l0 = lamc(3 * s + k) * P.warm;
+                            cb[(3 * RLEN + 1 + k) * ST] = l0;
                             sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { wadd(std::integral_constant<int, M::chain[b][C]>{}, g[k][C] * l0); });
                         });
-                        cb[(3 * RLEN + 3) * ST] = (gap >= 0.f) ? -gap * invh : fminf(-gap * P.erp * invh, P.max_depen_vel);
+                        cb[(3 * RLEN) * ST] = (gap >= 0.f) ? -gap * invh : fminf(-gap * P.erp * invh, P.max_depen_vel);
                         act = 1.f;
                     }
                 }
@@ -396,221 +699,95 @@ struct SimMWC : SimMW<M> {
             }
         });
         if (scol != nullptr && scol->dropped != nullptr && ndrop > 0) MI_ATOMIC_ADD_INT(scol->dropped, ndrop);
-        // ---- pair role: positions of all spheres, narrow phase of the self-collision groups, <= KPAIR contacts -> C_X
-        unsigned pmap = 0xFFFFFFFFu;
-        if constexpr (PAIRW) { if (selfcol) {
-            MI_PHASE();
-            float xa[NSPH][3];
-            fk_pos<0>(nullptr, nullptr, xa);
-            int cntp = 0, pdrop = 0;
-            sfor<KPAIR>([&](auto J_) MI_LAMBDA { rows(C_X + 1 + XI * J_ + 6) = __builtin_bit_cast(float, 0xFFFFFFFFu); });
-            sfor<NPG>([&](auto G_) MI_LAMBDA {
-                constexpr int g = G_;
-                MI_PHASE();
-                float best = 3.0e38f, bca[3] = {0.f, 0.f, 0.f}, bcb[3] = {0.f, 0.f, 0.f};
-                int bk = 0;
-                sfor<M::pg_count[g]>([&](auto K_) MI_LAMBDA {
-                    constexpr int k = M::pg_first[g] + K_, ia = M::gp_a[k], ib = M::gp_b[k];
-                    constexpr float reach = B::cap_bound(ia) + B::cap_bound(ib);
-                    float dm[3];
-                    sfor<3>([&](auto I_) MI_LAMBDA {
-                        dm[I_] = 0.5f * (xa[M::cap_s0[ia]][I_] + xa[M::cap_s1[ia]][I_]) - 0.5f * (xa[M::cap_s0[ib]][I_] + xa[M::cap_s1[ib]][I_]);
-                    });
-                    const float rr = reach + P.contact_offset;
-                    if (!MI_WAVE_ANY(dot3(dm, dm) < rr * rr)) return;
-                    float ca[3], cb[3];
-                    seg_seg_closest<B::cap_is_point(ia), B::cap_is_point(ib)>(xa[M::cap_s0[ia]], xa[M::cap_s1[ia]], xa[M::cap_s0[ib]], xa[M::cap_s1[ib]], ca, cb);
-                    const float dv[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]};
-                    const float dist = MI_SQRT(dot3(dv, dv)) - (M::cap_rad[ia] + M::cap_rad[ib]);
-                    const bool better = dist < best;
-                    best = better ? dist : best;
-                    sfor<3>([&](auto I_) MI_LAMBDA { bca[I_] = better ? ca[I_] : bca[I_]; bcb[I_] = better ? cb[I_] : bcb[I_]; });
-                    bk = better ? K_ : bk;
-                });
-                const bool near = best < P.contact_offset;
-                const bool on = near && (cntp < KPAIR);
-                pdrop += (near && !on) ? 1 : 0;
-                if (MI_WAVE_ANY(on)) {
-                    if (on) {
-                        int bab = 0;
-                        float brb = 0.f, bmu = 0.f;
-                        sfor<M::pg_count[g]>([&](auto K_) MI_LAMBDA {
-                            constexpr int k = M::pg_first[g] + K_, ia = M::gp_a[k], ib = M::gp_b[k], ba = M::cap_body[ia], bb = M::cap_body[ib];
-                            constexpr int ra = MW::role_of_body(ba), rb = MW::role_of_body(bb);
-                            constexpr bool fold = (ra >= 0) && (ra == rb);                    // both bodies on one limb: side b folds into side a's limb part
-                            constexpr int word = ba | (bb << 8) | ((ra + 1) << 16) | ((fold ? 0 : rb + 1) << 20) | ((fold ? 1 : 0) << 24);
-                            const bool me = bk == K_;
-                            bab = me ? word : bab;
-                            brb = me ? M::cap_rad[ib] : brb;
-                            bmu = me ? 0.5f * (M::cap_mu[ia] + M::cap_mu[ib]) : bmu;
-                        });
-                        float n[3];
-                        {
-                            const float dv[3] = {bca[0] - bcb[0], bca[1] - bcb[1], bca[2] - bcb[2]};
-                            const float d2 = dot3(dv, dv);
-                            const bool okd = d2 > 1e-18f;
-                            const float inv = MI_RSQ(fmaxf(d2, 1e-30f));
-                            n[0] = okd ? dv[0] * inv : 0.f; n[1] = okd ? dv[1] * inv : 0.f; n[2] = okd ? dv[2] * inv : 1.f;
-                        }
-                        float* xi = rows.ptr(C_X + 1 + XI * cntp);
-                        sfor<3>([&](auto I_) MI_LAMBDA { xi[I_ * ST] = bcb[I_] + n[I_] * (brb + 0.5f * best); xi[(3 + I_) * ST] = n[I_]; });
-                        xi[6 * ST] = __builtin_bit_cast(float, bab);
-                        xi[7 * ST] = bmu;
-                        const float gap = best - P.rest_offset;
-                        xi[8 * ST] = (gap >= 0.f) ? -gap * invh : fminf(-gap * P.erp * invh, P.max_depen_vel);
-                        sfor<3>([&](auto K) MI_LAMBDA { xi[(9 + K) * ST] = scol->lamp(3 * g + K) * P.warm; });
-                    }
-                }
-                pmap = (pmap & ~(3u << (2 * g))) | ((unsigned)(on ? cntp : 3) << (2 * g));
-                cntp += on ? 1 : 0;
-            });
-            rows(C_X) = __builtin_bit_cast(float, pmap);
-            if (scol->dropped != nullptr && pdrop > 0) MI_ATOMIC_ADD_INT(scol->dropped + scol->dstride, pdrop);
-        } }
+        MI_STAMP(3);
+        MI_STAMP(4);
         bar();                                                                                       // ---- B2: tree-pass exchange is dead, C_X is published
-        // ============================================================ exchange for the sweeps; self-contact half rows
-        sfor<NVT>([&](auto I) MI_LAMBDA { rows(X_DW + R * NVT + I) = dw[I]; });
-        sfor<NLR_>([&](auto K) MI_LAMBDA { rows(DOWN + loff(R) + K) = w[LF + K]; });          // (round 0 carries the values themselves)
-        rows(X_FLG + R) = act;
+        MI_STAMP(5);
+        // ============================================================ self-contact rows: every body of mine adds its half
+        if constexpr (R == M::TRUNK_ROLE) sfor<NV>([&](auto I) MI_LAMBDA { if constexpr (MW::trunk_gi(I)) { constexpr int o = XW0 + MW::tidx(I); rows(o) = w[I]; } });
+        float dwp[NVT];
+        sfor<NVT>([&](auto T_) MI_LAMBDA { dwp[T_] = 0.f; });
         if (selfcol) {
-            // side a (SIDE 0, stage S1) / side b (SIDE 1, stage S2) of every self contact whose body on that side is one of mine
-            auto pair_side = [&](auto SIDE_) MI_LAMBDA {
-                constexpr int SIDE = decltype(SIDE_)::value;
-                for (int j = 0; j < KPAIR; ++j) {
-                    const float* xi = rows.ptr(C_X + 1 + XI * j);
-                    const unsigned bab = __builtin_bit_cast(unsigned, xi[6 * ST]);
-                    const bool onj = bab != 0xFFFFFFFFu;
-                    if (!MI_WAVE_ANY(onj)) break;                    // slots fill from the front
-                    const int bs = (SIDE == 0) ? (int)(bab & 255u) : (int)((bab >> 8) & 255u);
-                    const bool fold = ((bab >> 24) & 1u) != 0u;
-                    float* pb = rows.ptr(P_B + j * P_CSZ);
-                    sfor<NB>([&](auto B_) MI_LAMBDA {
-                        constexpr int b = B_;
-                        if constexpr (MW::template owns_body<R>(b)) {
-                            const bool me = onj && (bs == b);
-                            if (MI_WAVE_ANY(me)) {
-                                if (me) {
-                                    float x[3], fr[3][3], W[3][6];
-                                    sfor<3>([&](auto I_) MI_LAMBDA { x[I_] = xi[I_ * ST]; fr[0][I_] = xi[(3 + I_) * ST]; });
-                                    contact_frame(fr[0], fr[1], fr[2]);
-                                    sfor<3>([&](auto K) MI_LAMBDA {
-                                        cross3(x, fr[K], W[K]);
-                                        W[K][3] = fr[K][0]; W[K][4] = fr[K][1]; W[K][5] = fr[K][2];
-                                    });
-                                    float g[3][M::MAXCHAIN];
-                                    rows3(std::integral_constant<int, b>{}, W, g);
-                                    constexpr int rb_ = MW::role_of_body(b);
-                                    sfor<3>([&](auto K) MI_LAMBDA {
-                                        constexpr int k = K;
-                                        sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA {
-                                            constexpr int gi = M::chain[b][C];
-                                            if constexpr (MW::trunk_gi(gi)) {
-                                                constexpr int t = MW::tidx(gi);
-                                                if constexpr (SIDE == 0) pb[(PT + k * NVT + t) * ST] = g[k][C];
-                                                else pb[(PT + k * NVT + t) * ST] -= g[k][C];
-                                            } else {
-                                                constexpr int kk = gi - lfirst(rb_ < 0 ? 0 : rb_);
-                                                if constexpr (SIDE == 0) pb[(PLA + k * NLMAX + kk) * ST] = g[k][C];
-                                                else { if (fold) pb[(PLA + k * NLMAX + kk) * ST] -= g[k][C]; else pb[(PLB + k * NLMAX + kk) * ST] = -g[k][C]; }
-                                            }
-                                        });
-                                        // the rest of the fixed shape: zeros (side a owns the trunk part and its limb part, side b its limb part)
-                                        if constexpr (SIDE == 0) sfor<NVT>([&](auto T_) MI_LAMBDA { if constexpr (!chain_has_t(b, T_)) pb[(PT + k * NVT + T_) * ST] = 0.f; });
-                                        if constexpr (rb_ >= 0) sfor<NLMAX>([&](auto K2) MI_LAMBDA {
-                                            if constexpr (!chain_has_l(b, K2)) {
-                                                if constexpr (SIDE == 0) pb[(PLA + k * NLMAX + K2) * ST] = 0.f;
-                                                else { if (!fold) pb[(PLB + k * NLMAX + K2) * ST] = 0.f; }
-                                            }
-                                        });
-                                    });
-                                }
-                            }
-                        }
-                    });
-                }
-            };
-            pair_side(std::integral_constant<int, 0>{});
-            bar();                                                                                   // ---- B3
-            pair_side(std::integral_constant<int, 1>{});
-            bar();                                                                                   // ---- B4: rows complete
-        }
-        // limb part of a self-contact row / of w for the limb role word `r1` (1 + role, 0: none): run-time offsets into [NVL] vectors
-        auto lofs = [&](const unsigned r1) MI_LAMBDA -> int {
-            int o = 0;
-            sfor<NR>([&](auto R_) MI_LAMBDA { o = (r1 == (unsigned)(R_ + 1)) ? loff(R_) : o; });
-            return o;
-        };
-        auto lnum = [&](const unsigned r1) MI_LAMBDA -> int {
-            int n = 0;
-            sfor<NR>([&](auto R_) MI_LAMBDA { n = (r1 == (unsigned)(R_ + 1)) ? nl(R_) : n; });
-            return n;
-        };
-        if constexpr (PAIRW) { if (selfcol) {
-            // warm start of the self-contact rows: their contribution to the trunk part (block NR of X_DW) and to the limbs (DPAIR)
-            float dtp[NVT];
-            sfor<NVT>([&](auto I) MI_LAMBDA { dtp[I] = 0.f; });
-            sfor<NVL>([&](auto I) MI_LAMBDA { rows(DPAIR + I) = 0.f; });
-            float actp = 0.f;
-            unsigned touch = 0u;
+            MI_STAMP(6);
+            bar();                                                                                   // ---- B3: the pair role has zeroed the dense rows
+            MI_STAMP(7);
             for (int j = 0; j < KPAIR; ++j) {
                 const float* xi = rows.ptr(C_X + 1 + XI * j);
                 const unsigned bab = __builtin_bit_cast(unsigned, xi[6 * ST]);
                 const bool onj = bab != 0xFFFFFFFFu;
-                if (!MI_WAVE_ANY(onj)) break;
-                if (onj) {
-                    float* pb = rows.ptr(P_B + j * P_CSZ);
-                    const unsigned ra1 = (bab >> 16) & 15u, rb1 = (bab >> 20) & 15u;
-                    const int oa = lofs(ra1), ob = lofs(rb1), na = lnum(ra1), nb_ = lnum(rb1);
-                    touch |= (ra1 ? 1u << (ra1 - 1) : 0u) | (rb1 ? 1u << (rb1 - 1) : 0u);
-                    actp = 1.f;
-                    pb[PVT * ST] = xi[8 * ST];
+                if (!MI_WAVE_ANY(onj)) break;                    // slots fill from the front
+                const int ba = (int)(bab & 255u), bb = (int)((bab >> 8) & 255u);
+                float* pb = rows.ptr(P_B + j * P_CSZ);
+                sfor<NB>([&](auto B_) MI_LAMBDA {
+                    constexpr int b = B_;
+                    if constexpr (MW::template owns_body<R>(b)) {
+                        const bool me = onj && ((ba == b) || (bb == b));
+                        if (MI_WAVE_ANY(me)) {
+                            if (me) {
+                                const float sgn = (ba == b) ? 1.f : -1.f;       // +lambda on side a, -lambda on side b
+                                float x[3], fr[3][3], W[3][6];
+                                sfor<3>([&](auto I_) MI_LAMBDA { x[I_] = xi[I_ * ST]; fr[0][I_] = xi[(3 + I_) * ST]; });
+                                contact_frame(fr[0], fr[1], fr[2]);
+                                sfor<3>([&](auto K) MI_LAMBDA {
+                                    cross3(x, fr[K], W[K]);
+                                    W[K][3] = fr[K][0]; W[K][4] = fr[K][1]; W[K][5] = fr[K][2];
+                                });
+                                float g[3][M::MAXCHAIN];
+                                rows3(std::integral_constant<int, b>{}, W, g);
+                                sfor<3>([&](auto K) MI_LAMBDA {
+                                    sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { constexpr int gi = M::chain[b][C]; lds_add(&pb[(K * NV + gi) * ST], sgn * g[K][C]); });
+                                });
+                            }
+                        }
+                    }
+                });
+            }
+            MI_STAMP(8);
+            bar();                                                                                   // ---- B4: rows complete
+            MI_STAMP(9);
+            // W: warm start of the self-contact rows on the own limb coordinates; their trunk part (every role alike, see substep_pair)
+            sfor<KPAIR>([&](auto J_) MI_LAMBDA {
+                constexpr int j = J_;
+                const unsigned bab = __builtin_bit_cast(unsigned, (float)rows(C_X + 1 + XI * j + 6));
+                if (bab != 0xFFFFFFFFu) {
                     sfor<3>([&](auto K) MI_LAMBDA {
-                        constexpr int k = K;
-                        const float l0 = xi[(9 + k) * ST];
-                        pb[(PLAM + k) * ST] = l0;
-                        sfor<NVT>([&](auto T_) MI_LAMBDA { dtp[T_] += pb[(PT + k * NVT + T_) * ST] * l0; });
-                        sfor<NLMAX>([&](auto K2) MI_LAMBDA {
-                            if (K2 < na) rows.ptr(DPAIR + oa + K2)[0] += pb[(PLA + k * NLMAX + K2) * ST] * l0;
-                            if (K2 < nb_) rows.ptr(DPAIR + ob + K2)[0] += pb[(PLB + k * NLMAX + K2) * ST] * l0;
-                        });
+                        const float l0 = rows(P_B + j * P_CSZ + PLAM + K);
+                        sfor<NLR_>([&](auto K2) MI_LAMBDA { w[LF + K2] += rows(P_B + j * P_CSZ + K * NV + LF + K2) * l0; });
+                        sfor<NV>([&](auto I) MI_LAMBDA { if constexpr (MW::trunk_gi(I)) { constexpr int ti = MW::tidx(I); dwp[ti] += rows(P_B + j * P_CSZ + K * NV + I) * l0; } });
                     });
                 }
-            }
-            sfor<NVT>([&](auto I) MI_LAMBDA { rows(X_DW + NR * NVT + I) = dtp[I]; });
-            rows(X_FLG + NR) = actp;
-            rows(X_TOUCH) = __builtin_bit_cast(float, touch);
-        } }
-        if constexpr (PAIRW) { if (!selfcol) { rows(X_FLG + NR) = 0.f; rows(X_TOUCH) = 0.f; sfor<NVT>([&](auto I) MI_LAMBDA { rows(X_DW + NR * NVT + I) = 0.f; }); sfor<NVL>([&](auto I) MI_LAMBDA { rows(DPAIR + I) = 0.f; }); } }
-        if constexpr (NPG == 0 && R == PAIR_ROLE) { rows(X_FLG + NR) = 0.f; rows(X_TOUCH) = 0.f; sfor<NVT>([&](auto I) MI_LAMBDA { rows(X_DW + NR * NVT + I) = 0.f; }); sfor<NVL>([&](auto I) MI_LAMBDA { rows(DPAIR + I) = 0.f; }); }
+            });
+        }
+        sfor<NVT>([&](auto I) MI_LAMBDA { rows(X_DW + R * NVT + I) = dw[I]; });
+        sfor<NLR_>([&](auto K) MI_LAMBDA { constexpr int o = DOWN + lidx(LF + K); rows(o) = w[LF + K]; });     // (round 0 carries the values themselves)
+        rows(X_FLG + R) = act;
+        if constexpr (!HAS_PAIR_ROLE && R == NR - 1) { rows(X_TOUCH) = 0.f; }
+        MI_STAMP(10);
         bar();                                                                                       // ---- B5: round 0 of the exchange is complete
+        MI_STAMP(11);
         // ============================================================ P4: block sweeps
-        // round 0: every block's warm-start contribution (trunk part in block order; own limb part: the pair block's)
+        // round 0: every block's warm-start contribution to the trunk part, in block order; then the self-contact rows' (every role alike)
         sfor<NV>([&](auto I) MI_LAMBDA {
             constexpr int i = I;
-            if constexpr (MW::trunk_gi(i)) { sfor<NBLK>([&](auto B_) MI_LAMBDA { constexpr int o = X_DW + B_ * NVT + MW::tidx(i); w[i] += rows(o); }); }
-            else if constexpr (MW::role_of_gi(i) == R) { constexpr int o = DPAIR + loff(R) + (i - LF); w[i] += rows(o); }
+            if constexpr (MW::trunk_gi(i)) { sfor<NR>([&](auto B_) MI_LAMBDA { constexpr int o = X_DW + B_ * NVT + MW::tidx(i); w[i] += rows(o); }); }
         });
-        if constexpr (PAIRW) sfor<NVL>([&](auto I) MI_LAMBDA { rows(PW + I) = rows(DOWN + I) + rows(DPAIR + I); });
+        sfor<NV>([&](auto I) MI_LAMBDA { if constexpr (MW::trunk_gi(I)) { constexpr int ti = MW::tidx(I); w[I] += dwp[ti]; } });
         const unsigned touch = __builtin_bit_cast(unsigned, (float)rows(X_TOUCH));
         {
             float wtl[NVT], wll[NLR_ > 0 ? NLR_ : 1];
             for (int it = 0; it < P.iters; ++it) {
+                MI_STAMP(15);
                 int zero;
                 MI_OPAQUE_ZERO(zero);
                 const RowStore<RS> rit = rows.shifted(zero);
                 const int par = it & 1;
-                const RowStore<RS> xdw = rows.shifted((X_DW + (par ^ 1) * NBLK * NVT) * ST), fin = rows.shifted((X_FLG + par * NBLK) * ST),
-                                   fout = rows.shifted((X_FLG + (par ^ 1) * NBLK) * ST), down = rows.shifted((DOWN + (par ^ 1) * NVL) * ST),
+                const RowStore<RS> xdw = rows.shifted((X_DW + (par ^ 1) * NR * NVT) * ST), fin = rows.shifted((X_FLG + par * NR) * ST),
+                                   fout = rows.shifted((X_FLG + (par ^ 1) * NR) * ST), down = rows.shifted((DOWN + (par ^ 1) * NVL) * ST),
                                    dpair = rows.shifted((DPAIR + (par ^ 1) * NVL) * ST);
                 // weights of this sweep: the trunk is shared by all active blocks, a limb by its owner's block and the pair block
-                float fl[NBLK];
-                sfor<NBLK>([&](auto B_) MI_LAMBDA { fl[B_] = fin(B_); });
-                float nact = 0.f;
-                sfor<NBLK>([&](auto B_) MI_LAMBDA { nact += fl[B_]; });
-                const float omT = (nact > 1.5f) ? 0.5f * (nact + 1.f) : 1.f, iomT = 1.f / omT;
-                float oml[NR];      // weight of every role's limb coordinates
-                sfor<NR>([&](auto R_) MI_LAMBDA { oml[R_] = (fl[R_] + (((touch >> R_) & 1u) ? fl[NR] : 0.f) > 1.5f) ? 1.5f : 1.f; });
-                const float omL = oml[R], iomL = 1.f / omL;
+                float omT, oml[NLIMB > 1 ? NLIMB - 1 : 1];
+                this->sweep_weights(fin, touch, omT, oml);
+                const float iomT = 1.f / omT;
                 sfor<NV>([&](auto I) MI_LAMBDA { if constexpr (MW::trunk_gi(I)) { constexpr int ti = MW::tidx(I); wtl[ti] = w[I]; } });
                 sfor<NLR_>([&](auto K) MI_LAMBDA { wll[K] = w[LF + K]; });
                 auto wget = [&](auto GI) MI_LAMBDA -> float {
@@ -619,9 +796,10 @@ struct SimMWC : SimMW<M> {
                 };
                 auto wupd = [&](auto GI, const float val) MI_LAMBDA {
                     constexpr int gi = decltype(GI)::value;
-                    if constexpr (MW::trunk_gi(gi)) { constexpr int ti = MW::tidx(gi); wtl[ti] += omT * val; } else { constexpr int k = gi - LF; wll[k] += omL * val; }
+                    if constexpr (MW::trunk_gi(gi)) { constexpr int ti = MW::tidx(gi); wtl[ti] += omT * val; } else { constexpr int k = gi - LF; wll[k] += om_of<gi>(omT, oml) * val; }
                 };
                 float actn = 0.f;
+                MI_STAMP(16);
                 // ---- own limit rows
                 sfor<ND>([&](auto D) MI_LAMBDA {
                     constexpr int d = D, gi = OFF + d;
@@ -629,15 +807,15 @@ struct SimMWC : SimMW<M> {
                         constexpr int row = B::limrow(d), g0 = B::limoff(row);
                         float g[M::MAXCHAIN];
                         sfor<M::nanc[gi] + 1>([&](auto K) MI_LAMBDA { g[K] = rit(g0 + K); });
-                        float at = 0.f;
+                        float a = P.cfm;
                         sfor<M::nanc[gi] + 1>([&](auto K) MI_LAMBDA {
                             constexpr int k = K, i = (k == 0) ? gi : M::anc[gi][k == 0 ? 0 : k - 1];
-                            if constexpr (MW::trunk_gi(i)) at += g[k] * g[k];
+                            a += om_of<i>(omT, oml) * g[k] * g[k];
                         });
                         float vn = g[0] * wget(std::integral_constant<int, gi>{});
                         sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { vn += g[1 + A_] * wget(std::integral_constant<int, M::anc[gi][A_]>{}); });
                         const float lo = rit(L_LAM + row);
-                        const float nl_ = fmaxf(lo - (vn - rit(L_VT + row)) * MI_RCP(P.cfm + omL * rit(L_SL + row) + omT * at), 0.f);
+                        const float nl_ = fmaxf(lo - (vn - rit(L_VT + row)) * MI_RCP(a), 0.f);
                         const float dl = nl_ - lo;
                         rit(L_LAM + row) = nl_;
                         actn = (nl_ > 0.f) ? 1.f : actn;
@@ -645,6 +823,7 @@ struct SimMWC : SimMW<M> {
                         sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { wupd(std::integral_constant<int, M::anc[gi][A_]>{}, g[1 + A_] * dl); });
                     }
                 });
+                MI_STAMP(17);
                 // ---- own ground contacts: a lane's j-th contact, whichever sphere it is (fixed row shape [limb | trunk])
                 for (int j = 0; j < KCAP; ++j) {
                     const bool onj = j < cnt;
@@ -655,12 +834,14 @@ struct SimMWC : SimMW<M> {
                         float g[3][RLEN], ainv[3], lm[3];
                         sfor<3>([&](auto K) MI_LAMBDA {
                             sfor<RLEN>([&](auto C) MI_LAMBDA { g[K][C] = cb[(K * RLEN + C) * ST]; });
+                            float a = P.cfm;
+                            sfor<NLR_>([&](auto K2) MI_LAMBDA { a += om_of<LF + decltype(K2)::value>(omT, oml) * g[K][K2] * g[K][K2]; });
                             float at = 0.f;
                             sfor<NVT>([&](auto T_) MI_LAMBDA { at += g[K][NLR_ + T_] * g[K][NLR_ + T_]; });
-                            ainv[K] = MI_RCP(P.cfm + omL * cb[(3 * RLEN + K) * ST] + omT * at);
-                            lm[K] = cb[(3 * RLEN + 4 + K) * ST];
+                            ainv[K] = MI_RCP(a + omT * at);
+                            lm[K] = cb[(3 * RLEN + 1 + K) * ST];
                         });
-                        const float vtn = cb[(3 * RLEN + 3) * ST];
+                        const float vtn = cb[(3 * RLEN) * ST];
                         auto dotw = [&](const float (&gr)[RLEN]) MI_LAMBDA -> float {
                             float s = 0.f;
                             sfor<NLR_>([&](auto K) MI_LAMBDA { s += gr[K] * wll[K]; });
@@ -668,7 +849,7 @@ struct SimMWC : SimMW<M> {
                             return s;
                         };
                         auto addw = [&](const float (&gr)[RLEN], const float dl) MI_LAMBDA {
-                            sfor<NLR_>([&](auto K) MI_LAMBDA { wll[K] += omL * gr[K] * dl; });
+                            sfor<NLR_>([&](auto K) MI_LAMBDA { wll[K] += om_of<LF + decltype(K)::value>(omT, oml) * gr[K] * dl; });
                             sfor<NVT>([&](auto T_) MI_LAMBDA { wtl[T_] += omT * gr[NLR_ + T_] * dl; });
                         };
                         const float ln = fmaxf(lm[0] - (dotw(g[0]) - vtn) * ainv[0], 0.f);
@@ -682,112 +863,38 @@ struct SimMWC : SimMW<M> {
                         const float lim = mu * ln;
                         const float n2 = lt[0] * lt[0] + lt[1] * lt[1];
                         const float sc = (n2 > lim * lim) ? lim * MI_RSQ(fmaxf(n2, 1e-30f)) : 1.f;
-                        cb[(3 * RLEN + 4) * ST] = ln;
+                        cb[(3 * RLEN + 1) * ST] = ln;
                         actn = (ln > 0.f) ? 1.f : actn;
                         sfor<2>([&](auto K) MI_LAMBDA {
                             const float nl_ = lt[K] * sc;
-                            cb[(3 * RLEN + 5 + K) * ST] = nl_;
+                            cb[(3 * RLEN + 2 + K) * ST] = nl_;
                             addw(g[1 + K], nl_ - lt[K]);
                         });
                     }
                 }
+                MI_STAMP(18);
                 // this block's true contributions
                 sfor<NV>([&](auto I) MI_LAMBDA { if constexpr (MW::trunk_gi(I)) { constexpr int ti = MW::tidx(I); xdw(R * NVT + ti) = (wtl[ti] - w[I]) * iomT; } });
                 float dlo[NLR_ > 0 ? NLR_ : 1];
-                sfor<NLR_>([&](auto K) MI_LAMBDA { dlo[K] = (wll[K] - w[LF + K]) * iomL; down(loff(R) + K) = dlo[K]; });
+                sfor<NLR_>([&](auto K) MI_LAMBDA {
+                    constexpr int gi = LF + K, li = lidx(gi);
+                    dlo[K] = (wll[K] - w[gi]) / om_of<gi>(omT, oml);
+                    down(li) = dlo[K];
+                });
                 fout(R) = actn;
-                // ---- the self contacts: a block of their own, swept by this role from the same sweep-start velocity
-                if constexpr (PAIRW) { if (selfcol) {
-                    float wtp[NVT];
-                    sfor<NV>([&](auto I) MI_LAMBDA { if constexpr (MW::trunk_gi(I)) { constexpr int ti = MW::tidx(I); wtp[ti] = w[I]; } });
-                    sfor<NVL>([&](auto I) MI_LAMBDA { dpair(I) = 0.f; });
-                    float actp = 0.f;
-                    for (int j = 0; j < KPAIR; ++j) {
-                        const float* xi = rit.ptr(C_X + 1 + XI * j);
-                        const unsigned bab = __builtin_bit_cast(unsigned, xi[6 * ST]);
-                        const bool onj = bab != 0xFFFFFFFFu;
-                        if (!MI_WAVE_ANY(onj)) break;
-                        if (onj) {
-                            float* pb = rit.ptr(P_B + j * P_CSZ);
-                            const unsigned ra1 = (bab >> 16) & 15u, rb1 = (bab >> 20) & 15u;
-                            const int oa = lofs(ra1), ob = lofs(rb1), na = lnum(ra1), nb_ = lnum(rb1);
-                            float omA = 1.f, omB = 1.f;
-                            sfor<NR>([&](auto R_) MI_LAMBDA { omA = (ra1 == (unsigned)(R_ + 1)) ? oml[R_] : omA; omB = (rb1 == (unsigned)(R_ + 1)) ? oml[R_] : omB; });
-                            const float mu = xi[7 * ST];
-                            // the two limbs' part of w as this block sees it: sweep-start value + weight x what the block has contributed so far
-                            float wa[NLMAX], wb[NLMAX], da[NLMAX], db[NLMAX];
-                            sfor<NLMAX>([&](auto K2) MI_LAMBDA {
-                                wa[K2] = (K2 < na) ? rit.ptr(PW + oa + K2)[0] + omA * dpair.ptr(oa + K2)[0] : 0.f;
-                                wb[K2] = (K2 < nb_) ? rit.ptr(PW + ob + K2)[0] + omB * dpair.ptr(ob + K2)[0] : 0.f;
-                                da[K2] = 0.f; db[K2] = 0.f;
-                            });
-                            float ga[3][NLMAX], gb[3][NLMAX], gt[3][NVT], ainv[3], lm[3];
-                            sfor<3>([&](auto K) MI_LAMBDA {
-                                float sa = 0.f, sb = 0.f, st = 0.f;
-                                sfor<NLMAX>([&](auto K2) MI_LAMBDA {
-                                    ga[K][K2] = (K2 < na) ? pb[(PLA + K * NLMAX + K2) * ST] : 0.f;
-                                    gb[K][K2] = (K2 < nb_) ? pb[(PLB + K * NLMAX + K2) * ST] : 0.f;
-                                    sa += ga[K][K2] * ga[K][K2]; sb += gb[K][K2] * gb[K][K2];
-                                });
-                                sfor<NVT>([&](auto T_) MI_LAMBDA { gt[K][T_] = pb[(PT + K * NVT + T_) * ST]; st += gt[K][T_] * gt[K][T_]; });
-                                ainv[K] = MI_RCP(P.cfm + omA * sa + omB * sb + omT * st);
-                                lm[K] = pb[(PLAM + K) * ST];
-                            });
-                            const float vtn = pb[PVT * ST];
-                            auto dotw = [&](const int r) MI_LAMBDA -> float {
-                                float s = 0.f;
-                                sfor<3>([&](auto K) MI_LAMBDA { if (r == K) {
-                                    sfor<NLMAX>([&](auto K2) MI_LAMBDA { s += ga[K][K2] * wa[K2] + gb[K][K2] * wb[K2]; });
-                                    sfor<NVT>([&](auto T_) MI_LAMBDA { s += gt[K][T_] * wtp[T_]; });
-                                } });
-                                return s;
-                            };
-                            auto addw = [&](const int r, const float dl) MI_LAMBDA {
-                                sfor<3>([&](auto K) MI_LAMBDA { if (r == K) {
-                                    sfor<NLMAX>([&](auto K2) MI_LAMBDA {
-                                        wa[K2] += omA * ga[K][K2] * dl; da[K2] += ga[K][K2] * dl;
-                                        wb[K2] += omB * gb[K][K2] * dl; db[K2] += gb[K][K2] * dl;
-                                    });
-                                    sfor<NVT>([&](auto T_) MI_LAMBDA { wtp[T_] += omT * gt[K][T_] * dl; });
-                                } });
-                            };
-                            const float ln = fmaxf(lm[0] - (dotw(0) - vtn) * ainv[0], 0.f);
-                            addw(0, ln - lm[0]);
-                            float lt[2];
-                            sfor<2>([&](auto K) MI_LAMBDA {
-                                const float dl = -dotw(1 + K) * ainv[1 + K];
-                                lt[K] = lm[1 + K] + dl;
-                                addw(1 + K, dl);
-                            });
-                            const float lim = mu * ln;
-                            const float n2 = lt[0] * lt[0] + lt[1] * lt[1];
-                            const float sc = (n2 > lim * lim) ? lim * MI_RSQ(fmaxf(n2, 1e-30f)) : 1.f;
-                            pb[PLAM * ST] = ln;
-                            actp = (ln > 0.f) ? 1.f : actp;
-                            sfor<2>([&](auto K) MI_LAMBDA {
-                                const float nl_ = lt[K] * sc;
-                                pb[(PLAM + 1 + K) * ST] = nl_;
-                                addw(1 + K, nl_ - lt[K]);
-                            });
-                            sfor<NLMAX>([&](auto K2) MI_LAMBDA {
-                                if (K2 < na) dpair.ptr(oa + K2)[0] += da[K2];
-                                if (K2 < nb_) dpair.ptr(ob + K2)[0] += db[K2];
-                            });
-                        }
-                    }
-                    sfor<NV>([&](auto I) MI_LAMBDA { if constexpr (MW::trunk_gi(I)) { constexpr int ti = MW::tidx(I); xdw(NR * NVT + ti) = (wtp[ti] - w[I]) * iomT; } });
-                    fout(NR) = actp;
-                } else { sfor<NVT>([&](auto I) MI_LAMBDA { xdw(NR * NVT + I) = 0.f; }); sfor<NVL>([&](auto I) MI_LAMBDA { dpair(I) = 0.f; }); fout(NR) = 0.f; } }
-                if constexpr (NPG == 0 && R == PAIR_ROLE) { sfor<NVT>([&](auto I) MI_LAMBDA { xdw(NR * NVT + I) = 0.f; }); sfor<NVL>([&](auto I) MI_LAMBDA { dpair(I) = 0.f; }); fout(NR) = 0.f; }
+                if constexpr (!HAS_PAIR_ROLE) { /* no pair block: nobody writes dpair; keep it zero */ if constexpr (R == 0) sfor<NVL>([&](auto I) MI_LAMBDA { dpair(I) = 0.f; }); }
+                MI_STAMP(19);
                 bar();                                                                               // ---- one barrier per sweep
+                MI_STAMP(20);
                 sfor<NV>([&](auto I) MI_LAMBDA {
                     constexpr int i = I;
-                    if constexpr (MW::trunk_gi(i)) { sfor<NBLK>([&](auto B_) MI_LAMBDA { constexpr int o = B_ * NVT + MW::tidx(i); w[i] += xdw(o); }); }
-                    else if constexpr (MW::role_of_gi(i) == R) { constexpr int k = i - LF; w[i] += dlo[k] + dpair(loff(R) + k); }
+                    if constexpr (MW::trunk_gi(i)) { sfor<NR>([&](auto B_) MI_LAMBDA { constexpr int o = B_ * NVT + MW::tidx(i); w[i] += xdw(o); }); }
+                    else if constexpr (MW::role_of_gi(i) == R) { constexpr int k = i - LF, li = lidx(i); w[i] += dlo[k] + dpair(li); }
                 });
-                if constexpr (PAIRW) sfor<NVL>([&](auto I) MI_LAMBDA { rit(PW + I) += down(I) + dpair(I); });
+                MI_STAMP(21);
             }
         }
+        MI_STAMP(12);
         // ============================================================ P5: back to generalised velocity, outputs, integration
         sfor<NV>([&](auto I_) MI_LAMBDA {
             constexpr int i = I_;
@@ -820,7 +927,7 @@ struct SimMWC : SimMW<M> {
                 const int j = (int)slot8(s);
                 const bool onj = j >= 0;
                 const float* cb = rows.ptr(GCB + (onj ? j : 0) * GCSZ);
-                const float ln = onj ? cb[(3 * RLEN + 4) * ST] : 0.f, l1 = onj ? cb[(3 * RLEN + 5) * ST] : 0.f, l2 = onj ? cb[(3 * RLEN + 6) * ST] : 0.f;
+                const float ln = onj ? cb[(3 * RLEN + 1) * ST] : 0.f, l1 = onj ? cb[(3 * RLEN + 2) * ST] : 0.f, l2 = onj ? cb[(3 * RLEN + 3) * ST] : 0.f;
                 lamc(3 * s) = ln; lamc(3 * s + 1) = l1; lamc(3 * s + 2) = l2;
                 if constexpr (B::sensor_of(b) >= 0) {
                     constexpr int k = B::sensor_of(b);
@@ -857,24 +964,6 @@ struct SimMWC : SimMW<M> {
                     }
                 });
             });
-            if constexpr (PAIRW) {
-                // impulses of the groups -> warm start of the next sub-step, world force on side a
-                sfor<NPG>([&](auto G_) MI_LAMBDA {
-                    constexpr int g = G_;
-                    const int j = (int)((pmap >> (2 * g)) & 3u);
-                    const bool onj = j != 3;
-                    const float* pb = rows.ptr(P_B + (onj ? j : 0) * P_CSZ);
-                    const float* xi = rows.ptr(C_X + 1 + XI * (onj ? j : 0));
-                    const float ln = onj ? pb[PLAM * ST] : 0.f, l1 = onj ? pb[(PLAM + 1) * ST] : 0.f, l2 = onj ? pb[(PLAM + 2) * ST] : 0.f;
-                    scol->lamp(3 * g) = ln; scol->lamp(3 * g + 1) = l1; scol->lamp(3 * g + 2) = l2;
-                    if (scol->pairf.p) {
-                        float n[3], t1[3], t2[3];
-                        sfor<3>([&](auto I_) MI_LAMBDA { n[I_] = onj ? xi[(3 + I_) * ST] : (I_ == 2 ? 1.f : 0.f); });
-                        contact_frame(n, t1, t2);
-                        sfor<3>([&](auto K) MI_LAMBDA { scol->pairf(3 * g + K) = (n[K] * ln + t1[K] * l1 + t2[K] * l2) * invh; });
-                    }
-                });
-            }
         } }
         sfor<NSENS>([&](auto K_) MI_LAMBDA {
             if constexpr (MW::template owns_body<R>(M::sens_body[K_])) sfor<6>([&](auto C) MI_LAMBDA { sensor(6 * K_ + C) = sens[6 * K_ + C]; });
@@ -911,6 +1000,7 @@ struct SimMWC : SimMW<M> {
             const float n = MI_RSQ(x * x + yy * yy + z * z + ww * ww);
             Q[0] = x * n; Q[1] = yy * n; Q[2] = z * n; Q[3] = ww * n;
         }
+        MI_STAMP(13);
     }
 };
 

@@ -8,6 +8,10 @@
 
 namespace mi {
 
+#if defined(MI_TIMING)
+// debug builds only (tools/debug/mwc_phases.py): per workgroup and role 16 s_memtime stamps of the sub-step's phases
+__device__ unsigned long long* g_mi_tstamp_mwc = nullptr;
+#endif
 template <class M>
 constexpr size_t mwc_lds_bytes() { return (size_t)SimMWC<M>::MWC_SLOTS * SimMWC<M>::LANES * sizeof(float); }
 
@@ -21,6 +25,9 @@ __device__ __forceinline__ void mwc_role(const View& v, const SimParams& P, cons
     S sim;
     load_sim(sim, v, e);
     load_actor_scales(sim, v, e);
+#if defined(MI_TIMING)
+    sim.tstamp = (lane == 0 && g_mi_tstamp_mwc != nullptr) ? g_mi_tstamp_mwc + ((size_t)blockIdx.x * 4 + R) * 32 : nullptr;   // tools/debug/mwc_phases.py
+#endif
     float tau[M::NDA];
     if (src != ACT_STORED_TAU) {
         sfor<ND>([&](auto K) MI_LAMBDA {
@@ -50,7 +57,11 @@ __device__ __forceinline__ void mwc_role(const View& v, const SimParams& P, cons
     const float mu_env = (v.friction != nullptr) ? v.friction[e] : -1.f;
     const SelfCol selfcol{Strided{v.lamp ? v.lamp + e : nullptr, N}, Strided{v.pairf ? v.pairf + e : nullptr, N}, v.dropped ? v.dropped + e : nullptr, N};
     const SelfCol* scp = (M::NPG > 0 && v.lamp != nullptr) ? &selfcol : nullptr;    // uniform
-    sim.template substep_role_c<R>(P, tau, h, RowStore<E>{lds_rows + lane}, lamc, laml, sensor, dof_force, mu_env, scp, DevBarrier{});
+    if constexpr (S::HAS_PAIR_ROLE && R == S::PAIR_ROLE) {
+        sim.substep_pair(P, h, RowStore<E>{lds_rows + lane}, scp, DevBarrier{});       // owns no dof: nothing to write back
+    } else {
+        sim.template substep_role_c<R>(P, tau, h, RowStore<E>{lds_rows + lane}, lamc, laml, sensor, dof_force, mu_env, scp, DevBarrier{});
+    }
     sfor<ND>([&](auto K) MI_LAMBDA {
         if constexpr (MW::template owns_gi<R>(M::OFF + K)) {
             v.dof[K * N + e] = sim.q[K];
@@ -60,24 +71,41 @@ __device__ __forceinline__ void mwc_role(const View& v, const SimParams& P, cons
     if constexpr (R == M::TRUNK_ROLE) sfor<13>([&](auto K) MI_LAMBDA { v.root[K * N + e] = sim.root[K]; });
 }
 
+// The kernel's arguments as ONE struct, read through the kernarg segment pointer where they are used instead of being taken as by-value
+// parameters: ~40 pointers of the View + the action / sim parameters would otherwise be preloaded into SGPRs and stay live through the
+// whole role body (the four role bodies together spilled 188 SGPRs to VGPR lanes); loads from the kernarg segment are invariant, so the
+// compiler re-issues them (scalar cache hits) instead of keeping the values.
+struct MwcArgs {
+    View v;
+    SimParams P;
+    ActParams ap;
+    const float* actions_in;
+    int src;
+};
 template <class M>
-__global__ __launch_bounds__(64 * M::NROLE) void substep_mwc_kernel(View v, SimParams P, ActParams ap, const float* __restrict__ actions_in, int src) {
+__global__ __launch_bounds__(64 * M::NROLE) void substep_mwc_kernel(MwcArgs args_by_value) {
     extern __shared__ float lds_rows[];   // [MWC_SLOTS][32]
     static_assert(M::NROLE == 4, "four roles, one per SIMD of a CU");
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)args_by_value;
+    const MwcArgs& a = *reinterpret_cast<const MwcArgs*>(__builtin_amdgcn_kernarg_segment_ptr());
+#else
+    const MwcArgs& a = args_by_value;       // (host pass of the compiler: never executed)
+#endif
     constexpr int E = SimMWC<M>::LANES;
     const int lane = threadIdx.x;
     if (lane >= E) return;
     const int e = xcd_env_base<E>(blockIdx.x) + lane;
-    if (e >= v.N) return;                 // all four waves hold the same envs and agree on this
+    if (e >= a.v.N) return;                 // all four waves hold the same envs and agree on this
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.y);
 #if defined(MI_MWC_ONLY_ROLE)     // tools/debug only: resource usage of one role's instruction stream
-    if (role == MI_MWC_ONLY_ROLE) mwc_role<M, MI_MWC_ONLY_ROLE>(v, P, ap, actions_in, src, lds_rows, e, lane);
+    if (role == MI_MWC_ONLY_ROLE) mwc_role<M, MI_MWC_ONLY_ROLE>(a.v, a.P, a.ap, a.actions_in, a.src, lds_rows, e, lane);
 #else
     switch (role) {
-        case 0: mwc_role<M, 0>(v, P, ap, actions_in, src, lds_rows, e, lane); break;
-        case 1: mwc_role<M, 1>(v, P, ap, actions_in, src, lds_rows, e, lane); break;
-        case 2: mwc_role<M, 2>(v, P, ap, actions_in, src, lds_rows, e, lane); break;
-        default: mwc_role<M, 3>(v, P, ap, actions_in, src, lds_rows, e, lane); break;
+        case 0: mwc_role<M, 0>(a.v, a.P, a.ap, a.actions_in, a.src, lds_rows, e, lane); break;
+        case 1: mwc_role<M, 1>(a.v, a.P, a.ap, a.actions_in, a.src, lds_rows, e, lane); break;
+        case 2: mwc_role<M, 2>(a.v, a.P, a.ap, a.actions_in, a.src, lds_rows, e, lane); break;
+        default: mwc_role<M, 3>(a.v, a.P, a.ap, a.actions_in, a.src, lds_rows, e, lane); break;
     }
 #endif
 }
@@ -91,7 +119,7 @@ hipError_t launch_substeps_mwc(const View& v, const SimParams& P, const ActParam
     auto kern = substep_mwc_kernel<M>;
     if (hipError_t e = ensure_dynamic_lds((const void*)kern, lds, &configured); e != hipSuccess) return e;
     const dim3 grid(xcd_grid<E>(v.N)), block(64, M::NROLE);
-    for (int i = 0; i < n_sub; ++i) hipLaunchKernelGGL(kern, grid, block, lds, s, v, P, ap, actions, i == 0 ? first : rest);
+    for (int i = 0; i < n_sub; ++i) hipLaunchKernelGGL(kern, grid, block, lds, s, MwcArgs{v, P, ap, actions, i == 0 ? first : rest});
     return hipGetLastError();
 }
 

@@ -193,8 +193,12 @@ static void mwc_thread(const SimParams* P, float* s, const float* tau, float* o,
         for (int k = 0; k < ND; ++k) { sim.q[k] = s[13 + k]; sim.qd[k] = s[13 + ND + k]; }
         pthread_barrier_wait(bar);
         const SelfCol sc{Strided{s + 13 + 3 * ND + 3 * NSPH, 1}, Strided{pf, 1}, dropped, 1};
-        sim.template substep_role_c<R>(*P, tau, h, RowStore<1>{rows}, Strided{s + 13 + 2 * ND, 1}, Strided{s + 13 + 2 * ND + 3 * NSPH, 1}, Strided{o, 1},
-                                       Strided{o + 6 * NSENS, 1}, -1.f, selfcol ? &sc : nullptr, HostBarrier{bar});
+        if constexpr (S::HAS_PAIR_ROLE && R == S::PAIR_ROLE) {
+            sim.substep_pair(*P, h, RowStore<1>{rows}, selfcol ? &sc : nullptr, HostBarrier{bar});
+        } else {
+            sim.template substep_role_c<R>(*P, tau, h, RowStore<1>{rows}, Strided{s + 13 + 2 * ND, 1}, Strided{s + 13 + 2 * ND + 3 * NSPH, 1}, Strided{o, 1},
+                                           Strided{o + 6 * NSENS, 1}, -1.f, selfcol ? &sc : nullptr, HostBarrier{bar});
+        }
         for (int k = 0; k < ND; ++k)
             if (S::MW::role_of_gi(M::OFF + k) == R || (S::MW::trunk_gi(M::OFF + k) && R == M::TRUNK_ROLE)) { s[13 + k] = sim.q[k]; s[13 + ND + k] = sim.qd[k]; }
         if (R == M::TRUNK_ROLE) for (int k = 0; k < 13; ++k) s[k] = sim.root[k];

@@ -226,6 +226,60 @@ def test_host_build_of_engine_core_matches_oracle_with_self_collision():
     assert touched > 0.3 * 3 * n
 
 
+@pytest.mark.parametrize("selfcol", [True, False])
+def test_limb_wave_sub_step_matches_oracle_in_the_block_order(selfcol):
+    """core/engine_mwc.hpp -- the Humanoid on three limb waves + the pair wave: per-wave contact slots, dense self-contact rows that the
+    two bodies' waves add their halves to, every wave sweeping its own block, the self contacts a block of their own -- as four host
+    threads per env that share one row store and meet at a barrier where the GPU waves meet at s_barrier.  Against the fp64 oracle in
+    the block solver order with the same per-wave caps: state within the stated 5e-4 * scale per step, impulses, sensors, self-contact
+    impulses per element, the same groups carrying load.  Run twice: the threads' timing must not matter (no race in the exchange)."""
+    import hostsim
+    from isaacgymenvs_amd.assets.model import solver_blocks
+    spec, sb, sc = load_model("humanoid"), sensor_bodies("humanoid"), load_selfcol("humanoid")
+    lib = hostsim.build(humanoid=True)
+    n, nd, nsph, npg = 192, spec.nd, len(spec.sph_body), len(sc["groups"])
+    rng = np.random.default_rng(0)
+    root, q, qd = _random_state(spec, n, rng, 0.9, 1.6)
+    tau = rng.uniform(-60, 60, (n, nd))
+    blocks = solver_blocks(spec, self_collision=selfcol, wave_caps=True)
+    assert blocks["nblk"] == 4 and blocks["kmax_blk"] == [4, 4, 2, 0] and sorted(set(blocks["body_block"])) == [0, 1, 2]
+    kw = dict(selfcol=sc, kpair=3) if selfcol else {}
+    orc = OracleEngine(spec, n, params=SIM, sensor_bodies=sb, precision="f64", solver="blocks", blocks=blocks, **kw)
+    orc.root[:] = root; orc.q[:] = q; orc.qd[:] = qd
+    p = hostsim.make_params(SIM)
+    tau32 = np.ascontiguousarray(tau, np.float32)
+    runs = []
+    for rep in range(2):
+        st = np.zeros((n, 13 + 2 * nd + 3 * nsph + nd + 3 * npg), np.float32)
+        st[:, :13] = root; st[:, 13:13 + nd] = q; st[:, 13 + nd:13 + 2 * nd] = qd
+        out = np.zeros((n, 6 * len(sb) + nd + 3 * nsph + 9 * npg), np.float32)
+        hist = []
+        for it in range(3):
+            hostsim.step_mwc(lib, p, st, tau32, out, selfcol=selfcol)
+            hist.append((st.copy(), out.copy()))
+        runs.append(hist)
+    touched = 0
+    for it in range(3):
+        orc.step(tau)
+        st, out = runs[0][it]
+        np.testing.assert_array_equal(st, runs[1][it][0])
+        np.testing.assert_array_equal(out, runs[1][it][1])
+        scale = max(1.0, np.abs(orc.qd).max())
+        e = max(np.abs(st[:, :13] - orc.root).max(), np.abs(st[:, 13:13 + nd] - orc.q).max(), np.abs(st[:, 13 + nd:13 + 2 * nd] - orc.qd).max())
+        assert e < 5e-4 * scale * (it + 1), (it, e)
+        assert np.abs(st[:, 13 + 2 * nd:13 + 3 * nd + 3 * nsph] - orc.lam).max() < 2e-3 * max(1.0, np.abs(orc.lam).max())
+        assert np.abs(out[:, :12] - orc.sensor).max() < 2e-3 * max(1.0, np.abs(orc.sensor).max())
+        assert np.abs(out[:, 12:12 + nd] - orc.dof_force).max() < 2e-3 * max(1.0, np.abs(orc.dof_force).max())
+        if selfcol:
+            lamp = st[:, 13 + 3 * nd + 3 * nsph:].reshape(n, npg, 3)
+            assert np.abs(lamp - orc.lam_pair).max() < 2e-3 * max(1.0, np.abs(orc.lam_pair).max())
+            np.testing.assert_array_equal(np.abs(lamp).sum(2) > 0, np.abs(orc.lam_pair).sum(2) > 0)
+            pf = out[:, 6 * len(sb) + nd + 3 * nsph:].reshape(n, npg, 9)[:, :, :3]
+            assert np.abs(pf - orc.pair_info[:, :, :3]).max() < 2e-3 * max(1.0, np.abs(orc.pair_info[:, :, :3]).max())
+            touched += int((orc.pair_info[:, :, 3] >= 0).any(1).sum())
+    assert (not selfcol) or touched > 0.3 * 3 * n
+
+
 @pytest.mark.parametrize("waves", [2, 3])
 def test_two_wave_split_of_the_sub_step_is_bit_identical_on_the_host(waves):
     """Sim::substep with role 0 (everything but the self-collision phase) and role 1 (tree pass, factor, self-collision phase) on two
