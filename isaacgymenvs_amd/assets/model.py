@@ -970,8 +970,8 @@ def wave_roles(spec: ModelSpec, nrole: int = 4, pair_role=None):
 
 def wave_contact_caps(spec: ModelSpec):
     """Ground contacts each wave of the compact-store limb-per-wave sub-step keeps per env (csrc/core/engine_mwc.hpp gives every role its
-    own contact slots in LDS): 4 for a role whose limb has at least 4 dofs (a leg: one flat foot is 4 spheres), 2 for the role that also
-    sweeps the trunk's rows, 1 otherwise.  -> [nrole]"""
+    own contact slots in LDS): 4 for a role whose limb has at least 4 dofs (a leg: one flat foot is 4 spheres), 3 for the role that also
+    sweeps the trunk's rows (what the LDS of a CU still has room for at 32 envs), 1 otherwise, 0 for a role without bodies.  -> [nrole]"""
     limb, limbs, role_of_limb, trunk_role, nrole = wave_roles(spec)
     maxd = [0] * nrole                        # dofs of the role's longest limb
     for l, bodies in enumerate(limbs):
@@ -979,7 +979,7 @@ def wave_contact_caps(spec: ModelSpec):
         if r >= 0:
             maxd[r] = max(maxd[r], sum(1 for d in range(spec.nd) if int(spec.dof_body[d]) in bodies))
     owns = [any(role_of_limb[l] == r for l in range(len(limbs))) or r == trunk_role for r in range(nrole)]
-    return [0 if not owns[r] else (4 if maxd[r] >= 4 else (2 if r == trunk_role else 1)) for r in range(nrole)]
+    return [0 if not owns[r] else (4 if maxd[r] >= 4 else (3 if r == trunk_role else 1)) for r in range(nrole)]
 
 
 def solver_blocks(spec: ModelSpec, self_collision: bool = False, wave_caps: bool = False):

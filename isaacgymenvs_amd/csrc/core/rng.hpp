@@ -30,7 +30,7 @@ struct NoiseParams {      // mirrors MiNoiseParams (include/mi_engine.h)
     int op;               // 0 additive, 1 scaling
     float a, b;           // gaussian: mean, std; uniform: low, high -- already blended by the schedule on the host
     float a_corr, b_corr; // the same for the per-env correlated part
-    unsigned epoch;       // stream of the correlated draws (the reference samples them once and keeps them: 0)
+    unsigned epoch;       // stream of the correlated draws: bumped on every global refresh of the randomisation (the reference re-draws `corr` then, vec_task.py:690,716)
 };
 MI_HD float gauss01(uint32_t seed, uint32_t env, uint32_t ctr, uint32_t k) {
     const float u1 = fmaxf(uniform01(seed, env, ctr, 2u * k), 5.9604645e-8f), u2 = uniform01(seed, env, ctr, 2u * k + 1u);

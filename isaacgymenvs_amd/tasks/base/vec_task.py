@@ -296,6 +296,9 @@ class VecTask(Env):
             self.randomize_buf[due_envs] = 0
         if refresh_global:
             self.last_rand_step = self.last_step
+            # every refresh replaces the noise closures (reference vec_task.py:690, :716: the new dict has no 'corr'), i.e. the correlated
+            # offset is re-drawn at the next call: the in-kernel generator gets a new epoch, the torch-op noise forgets its tensor
+            self._noise_epoch = getattr(self, "_noise_epoch", -1) + 1
             for which, name in enumerate(("observations", "actions")):
                 if name in dr_params:
                     self._configure_noise(which, name, dr_params[name], Draw)
@@ -323,12 +326,12 @@ class VecTask(Env):
         white = Draw(dict(prm), self.last_step)
         corr = Draw(dict(prm, range=prm.get("range_correlated", [0.0, 0.0])), self.last_step)
         spec = dict(dist=dist, op=op, a=float(white.a), b=float(white.b), a_corr=float(corr.a), b_corr=float(corr.b))
-        self.dr_randomizations[name] = dict(spec, in_kernel=self.native_task in self.KERNEL_NOISE_TASKS)
+        epoch = int(getattr(self, "_noise_epoch", 0))
+        self.dr_randomizations[name] = dict(spec, in_kernel=self.native_task in self.KERNEL_NOISE_TASKS, epoch=epoch)
         if self.native_task in self.KERNEL_NOISE_TASKS:
-            self.engine.set_noise(which, **spec)
+            self.engine.set_noise(which, epoch=epoch, **spec)
         else:
-            prev = self._torch_noise.get(name)
-            self._torch_noise[name] = _TorchNoise(spec, prev.corr if prev is not None else None)
+            self._torch_noise[name] = _TorchNoise(spec, None)
 
     def _apply_actor_params(self, actor_params, due_envs):
         """`actor_params` (vec_task.py:752-828).  The reference walks every env's PhysX property structs in Python; here each
@@ -427,8 +430,16 @@ class VecTask(Env):
 
     # ------------------------------------------------------------------ physics-state checkpointing
     def get_env_state(self):
-        """Full simulator + task state (the reference never checkpoints physics, vec_task.py:196-204)."""
-        return {"arena": self.engine.arena.clone(), "control_steps": self.control_steps, "engine_steps": self.engine.get_option("steps")}
+        """Full simulator + task state (the reference never checkpoints physics, vec_task.py:196-204): the arena, the step counters and
+        the domain-randomisation state that lives outside the arena (gravity, noise parameters and epoch, whether the sub-step reads the
+        actor tensors, the torch-op noise's correlated tensors, the randomisation schedule)."""
+        g = [float(self.sim_params.gravity[i]) for i in range(3)]
+        return {"arena": self.engine.arena.clone(), "control_steps": self.control_steps, "engine_steps": self.engine.get_option("steps"),
+                "gravity": g, "noise": {k: dict(v) for k, v in self.dr_randomizations.items() if isinstance(v, dict) and "dist" in v},
+                "noise_epoch": int(getattr(self, "_noise_epoch", -1)), "actor_tensors": bool(getattr(self, "_actor_tensors_on", False)),
+                "torch_noise_corr": {k: (None if n.corr is None else n.corr.clone()) for k, n in self._torch_noise.items()},
+                "last_rand_step": int(getattr(self, "last_rand_step", -1)), "first_randomization": bool(getattr(self, "first_randomization", True)),
+                "last_step": int(getattr(self, "last_step", -1))}
 
     def set_env_state(self, env_state):
         if env_state is None:
@@ -437,6 +448,27 @@ class VecTask(Env):
         self.control_steps = env_state.get("control_steps", 0)
         # the engine's own step counter drives the observation-ring parity, the AnymalTerrain push schedule and the noise counters
         self.engine.set_option("steps", env_state.get("engine_steps", self.control_steps))
+        if "gravity" in env_state:
+            for i, key in enumerate(("gravity_x", "gravity_y", "gravity_z")):
+                self.sim_params.gravity[i] = float(env_state["gravity"][i])
+                self.engine.set_option(key, float(env_state["gravity"][i]))
+        self._noise_epoch = int(env_state.get("noise_epoch", getattr(self, "_noise_epoch", -1)))
+        for which, name in enumerate(("observations", "actions")):
+            spec = env_state.get("noise", {}).get(name)
+            if spec is None:
+                continue
+            self.dr_randomizations[name] = dict(spec)
+            keys = {k: spec[k] for k in ("dist", "op", "a", "b", "a_corr", "b_corr")}
+            if spec.get("in_kernel"):
+                self.engine.set_noise(which, epoch=int(spec.get("epoch", 0)), **keys)
+            else:
+                corr = env_state.get("torch_noise_corr", {}).get(name)
+                self._torch_noise[name] = _TorchNoise(keys, None if corr is None else corr.clone())
+        if env_state.get("actor_tensors") and not getattr(self, "_actor_tensors_on", False):
+            self._enable_actor_tensors()
+        for k in ("last_rand_step", "first_randomization", "last_step"):
+            if k in env_state:
+                setattr(self, k, env_state[k])
 
     def get_number_of_agents(self):
         return self.num_agents

@@ -453,7 +453,9 @@ def test_full_size_rollout_properties(task, n, z_term):
             qn = torch.linalg.norm(env.root_states[:, 3:7], dim=-1)
             assert (qn - 1).abs().max() < 1e-4
             viol = torch.maximum(lo - env.dof_pos, env.dof_pos - up).max()
-            assert viol < 0.2, viol  # joint limits hold up to solver slop (4 PGS sweeps) under 15-135 N.m random torques
+            # joint limits hold up to solver slop under 15-135 N.m random torques: 4 sweeps, of the block order on the limb-wave kernels
+            # (tools/solver_convergence.py: about 1.3x the distance of one Gauss-Seidel sequence to the converged solution)
+            assert viol < 0.25, viol
             assert env.progress_buf.max() <= step + 1
     assert total_resets > 0  # random policies fall (termination height) => resets happen
     assert obs_d["obs"].shape == (n, env.num_obs) and rew.shape == (n,) and reset.dtype == torch.int64

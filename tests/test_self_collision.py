@@ -242,7 +242,7 @@ def test_limb_wave_sub_step_matches_oracle_in_the_block_order(selfcol):
     root, q, qd = _random_state(spec, n, rng, 0.9, 1.6)
     tau = rng.uniform(-60, 60, (n, nd))
     blocks = solver_blocks(spec, self_collision=selfcol, wave_caps=True)
-    assert blocks["nblk"] == 4 and blocks["kmax_blk"] == [4, 4, 2, 0] and sorted(set(blocks["body_block"])) == [0, 1, 2]
+    assert blocks["nblk"] == 4 and blocks["kmax_blk"] == [4, 4, 3, 0] and sorted(set(blocks["body_block"])) == [0, 1, 2]
     kw = dict(selfcol=sc, kpair=3) if selfcol else {}
     orc = OracleEngine(spec, n, params=SIM, sensor_bodies=sb, precision="f64", solver="blocks", blocks=blocks, **kw)
     orc.root[:] = root; orc.q[:] = q; orc.qd[:] = qd
