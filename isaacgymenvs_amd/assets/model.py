@@ -938,13 +938,19 @@ def _has_selfcol(spec: ModelSpec) -> bool:
         return False
 
 
-def wave_roles(spec: ModelSpec, nrole: int = 4, pair_role=None):
+# wavefronts per env of the multi-wave sub-step (default 4: one per SIMD of a CU)
+WAVE_ROLES = {"shadow_hand": 4}
+
+
+def wave_roles(spec: ModelSpec, nrole=None, pair_role=None):
     """Limbs dealt to the `nrole` wavefronts of the multi-wave sub-step (csrc/core/engine_mw.hpp, engine_mwc.hpp): the limb of the root
     body is the shared trunk (role -1, every wave recomputes it), the others go heaviest first to the least loaded wave, where a limb
     weighs the summed chain lengths of its dofs (what its rows cost); the trunk's own constraint rows go to the wave with the lightest
     limbs.  pair_role (default: the model has self-collision tables): the LAST wave owns no limb -- it runs the self-collision narrow
     phase and sweeps the self-contact rows (engine_mwc.hpp).  -> (limb per body, body lists, role per limb, trunk role, nrole)."""
     limb, limbs = limb_paths(spec)
+    if nrole is None:
+        nrole = WAVE_ROLES.get(getattr(spec, "name", ""), 4)
     if pair_role is None:
         pair_role = _has_selfcol(spec)
     off = 0 if spec.fixed_base else 6
@@ -997,6 +1003,31 @@ def solver_blocks(spec: ModelSpec, self_collision: bool = False, wave_caps: bool
     out = dict(gi_group=gi_group, body_block=body_block, nblk=nrole if _has_selfcol(spec) else nrole + (1 if self_collision else 0))
     if wave_caps:       # the compact-store form keeps its ground contacts per wave
         out["kmax_blk"] = wave_contact_caps(spec)
+    return out
+
+
+def hand_limb_caps(spec: ModelSpec):
+    """Object contacts each LIMB of a manipulator keeps per env in the finger-per-wave sub-step (csrc/core/hand_engine_mw.hpp gives every
+    limb its own contact slots in LDS, rows in the fixed shape [limb dofs | wrist dofs]): 5 for the limb of the root body (forearm, wrist,
+    palm: the palm alone may hold a manifold of 4), 3 for a finger (one per phalanx) -- what 80 KB of LDS per 32 envs hold.  -> [nlimb]"""
+    _, limbs = limb_paths(spec)
+    nd = [sum(1 for d in range(spec.nd) if int(spec.dof_body[d]) in bodies) for bodies in limbs]
+    # a five-joint finger (little finger with its metacarpal, thumb) lies against the object more often than a four-joint one; the
+    # LAST of them (the thumb) gets what is left of the LDS budget.  Measured on random-policy states (tools/hand_solver_study.py):
+    # palm limb <= 5 always, little finger > 3 in 10 % and > 4 in 2 % of the sub-steps, thumb > 3 in 1.6 %.
+    caps = [5] + [3] * (len(limbs) - 1)
+    five = [l for l in range(1, len(limbs)) if nd[l] >= 5]
+    if five:
+        caps[five[0]] = 4
+    return caps
+
+
+def hand_solver_blocks(spec: ModelSpec):
+    """solver_blocks() for a fixed-base manipulator + free object (oracle/hand.c solver 1): additionally limb_of_body [nb] and
+    limb_cap [nlimb] (hand_limb_caps)."""
+    limb, _ = limb_paths(spec)
+    out = solver_blocks(spec)
+    out.update(limb_of_body=[int(x) for x in limb], limb_cap=hand_limb_caps(spec))
     return out
 
 

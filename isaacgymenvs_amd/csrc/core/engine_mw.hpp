@@ -38,7 +38,7 @@ struct SimMW : Sim<M> {
     using typename B::BodyTmp;
     static constexpr int NB = B::NB, ND = B::ND, NV = B::NV, OFF = B::OFF, NSPH = B::NSPH, NSENS = B::NSENS, NLIM = B::NLIM,
                          NROWG = B::NROWG, NVA = B::NVA, NR = M::NROLE;
-    static_assert(!M::FIXED, "multi-wave sub-step: free-base models");
+    // (the ownership tables below also serve fixed-base manipulators -- core/hand_engine_mw.hpp; substep_role itself is for free bases)
     // (substep_role below is the static-row-store form; core/engine_mwc.hpp derives the compact-store form from this struct)
 
     // ---- who owns what
@@ -119,6 +119,7 @@ struct SimMW : Sim<M> {
     MI_HD void substep_role(const SimParams& P, const float* tau, const float h, const RowStore<RS> rows, const Strided lamc,
                             const Strided laml, const Strided sensor, const Strided dof_force, const GND& gnd, const float mu_env,
                             const Strided netf, const bool prestaged, const BAR& bar) {
+        static_assert(!M::FIXED, "multi-wave sub-step: free-base models");
         auto G = [&](int row, int cc) MI_LAMBDA -> float& { return rows(row * M::MAXCHAIN + cc); };
         auto Ainv = [&](int row) MI_LAMBDA -> float& { return rows(NROWG * M::MAXCHAIN + row); };
         auto vt = [&](int row) MI_LAMBDA -> float& { return rows(NROWG * M::MAXCHAIN + NROWG + row); };

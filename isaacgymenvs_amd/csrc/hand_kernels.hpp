@@ -98,6 +98,10 @@ inline hipError_t hand_substeps_shape(const View& v, const HandView& hv, const S
     return hipGetLastError();
 }
 
+// the finger-per-wave form (hand_mw_kernels.hpp), one translation unit per shape: kernels_shadow_hand_mw.hip, _mw_pen.hip, _mw_egg.hip
+hipError_t hand_substeps_mw_box(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s);
+hipError_t hand_substeps_mw_pen(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s);
+hipError_t hand_substeps_mw_egg(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s);
 // defined in kernels_shadow_hand_pen.hip / kernels_shadow_hand_egg.hip
 hipError_t hand_substeps_pen(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s);
 hipError_t hand_substeps_egg(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s);

@@ -1,0 +1,117 @@
+// hand_mw_kernels.hpp -- the finger-per-wave Shadow-Hand sub-step (core/hand_engine_mw.hpp) and its launcher, a template over the object's
+// shape.  Included by kernels_shadow_hand_mw*.hip (one shape per translation unit: they compile in parallel).  blockDim = (64, NROLE):
+// wave y = role y, lanes 0 .. 31 of every wave hold the same 32 envs (the upper lanes retire at once: barriers count waves); two
+// workgroups per CU (<= 80 KB of LDS each), i.e. 16384 envs = 512 workgroups are resident at once with two waves on every SIMD.
+#pragma once
+#include "hand_kernels.hpp"
+#include "mw_kernels.hpp"          // DevBarrier
+#include "core/hand_engine_mw.hpp"
+
+namespace mi {
+
+using HSW = HandSimMW<HM>;
+constexpr size_t hand_mw_lds_bytes() { return (size_t)HSW::MW_SLOTS * HSW::LANES * sizeof(float); }
+
+#if defined(MI_TIMING)
+__device__ unsigned long long* g_mi_tstamp_hmw = nullptr;     // debug builds: per workgroup and role 16 s_memtime stamps
+#endif
+
+template <int SHAPE, int R>
+__device__ __forceinline__ void hand_mw_role(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, float* lds_rows,
+                                             const int e, const int lane) {
+    using MW = SimMW<HM>;
+    constexpr int ND = kHandDof;
+    const int N = v.N;
+    HSW sim;
+    sfor<3>([&](auto K) MI_LAMBDA { sim.root[K] = p.hand_pos[K]; });
+    sfor<4>([&](auto K) MI_LAMBDA { sim.root[3 + K] = p.hand_quat[K]; });
+    sfor<6>([&](auto K) MI_LAMBDA { sim.root[7 + K] = 0.f; });
+    float target[ND];
+    sfor<ND>([&](auto K) MI_LAMBDA {            // the wrist and the own fingers
+        if constexpr (MW::template sees_gi<R>(K)) {
+            sim.q[K] = v.dof[K * N + e];
+            sim.qd[K] = v.dof[(ND + K) * N + e];
+            target[K] = hv.cur_targets[K * N + e];
+        } else {
+            sim.q[K] = 0.f; sim.qd[K] = 0.f; target[K] = 0.f;
+        }
+    });
+    sfor<3>([&](auto K) MI_LAMBDA { sim.obj.pos[K] = hv.object_state[K * N + e]; sim.obj.vel[K] = hv.object_state[(7 + K) * N + e];
+                                    sim.obj.angvel[K] = hv.object_state[(10 + K) * N + e]; });
+    sfor<4>([&](auto K) MI_LAMBDA { sim.obj.quat[K] = hv.object_state[(3 + K) * N + e]; });
+    ObjectParams OP{p.cube_half, p.cube_mass, p.cube_inertia, p.mu,
+                    {hv.obj_force[e], hv.obj_force[N + e], hv.obj_force[2 * N + e]}};
+    if constexpr (SHAPE != OBJ_BOX) sfor<3>([&](auto K) MI_LAMBDA { OP.dims[K] = p.object_dims[K]; OP.inertia3[K] = p.object_inertia[K]; });
+    const float mu_e = hv.mu_env[e];
+    if (mu_e >= 0.f) OP.mu = mu_e;
+    OP.randomise(hv.scale[HS_OBJECT_MASS * N + e], hv.scale[HS_OBJECT_SCALE * N + e]);
+    sim.actor_scale = Strided{hv.scale + e, N};
+    sim.limit_shift = Strided{hv.limit_shift + e, N};
+#if defined(MI_TIMING)
+    sim.tstamp = (lane == 0 && g_mi_tstamp_hmw != nullptr) ? g_mi_tstamp_hmw + ((size_t)blockIdx.x * 4 + R) * 16 : nullptr;
+#endif
+    const float h = P.dt / (float)P.substeps;
+    int nc = 0;
+    sim.template substep_hand_role<R, HSW::LANES, SHAPE>(P, OP, target, h, RowStore<HSW::LANES>{lds_rows + lane}, Strided{v.laml + e, N},
+                                                         Strided{v.sensor + e, N}, Strided{v.dof_force + e, N}, &nc, DevBarrier{});
+    sfor<ND>([&](auto K) MI_LAMBDA {
+        if constexpr (MW::template owns_gi<R>(K)) { v.dof[K * N + e] = sim.q[K]; v.dof[(ND + K) * N + e] = sim.qd[K]; }
+    });
+    if constexpr (R == HM::TRUNK_ROLE) {
+        sfor<3>([&](auto K) MI_LAMBDA { hv.object_state[K * N + e] = sim.obj.pos[K]; hv.object_state[(7 + K) * N + e] = sim.obj.vel[K];
+                                        hv.object_state[(10 + K) * N + e] = sim.obj.angvel[K]; });
+        sfor<4>([&](auto K) MI_LAMBDA { hv.object_state[(3 + K) * N + e] = sim.obj.quat[K]; });
+        hv.ncontact[e] = nc & 0xFFFF;
+        if (nc >> 16) hv.ndropped[e] += nc >> 16;
+    }
+}
+
+// the kernel's arguments as ONE struct read through the kernarg segment pointer (see mwc_kernels.hpp MwcArgs: by-value parameters would
+// be preloaded into SGPRs and stay live through the role bodies)
+struct HandMwArgs {
+    View v;
+    HandView hv;
+    SimParams P;
+    HandParams p;
+};
+template <int SHAPE>
+__global__ __launch_bounds__(64 * HM::NROLE) __attribute__((amdgpu_waves_per_eu(2, 2))) void hand_substep_mw_kernel(HandMwArgs args_by_value) {
+    extern __shared__ float lds_rows[];   // [MW_SLOTS][32]
+    static_assert(HM::NROLE == 4, "four roles, one per SIMD of a CU");
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)args_by_value;
+    const HandMwArgs& a = *reinterpret_cast<const HandMwArgs*>(__builtin_amdgcn_kernarg_segment_ptr());
+#else
+    const HandMwArgs& a = args_by_value;       // (host pass of the compiler: never executed)
+#endif
+    constexpr int E = HSW::LANES;
+    const int lane = threadIdx.x;
+    if (lane >= E) return;
+    const int e = xcd_env_base<E>(blockIdx.x) + lane;
+    if (e >= a.v.N) return;                 // all four waves hold the same envs and agree on this
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.y);
+#if defined(MI_HMW_ONLY_ROLE)     // tools/debug only: resource usage of one role's instruction stream
+    if (role == MI_HMW_ONLY_ROLE) hand_mw_role<SHAPE, MI_HMW_ONLY_ROLE>(a.v, a.hv, a.P, a.p, lds_rows, e, lane);
+#else
+    switch (role) {
+        case 0: hand_mw_role<SHAPE, 0>(a.v, a.hv, a.P, a.p, lds_rows, e, lane); break;
+        case 1: hand_mw_role<SHAPE, 1>(a.v, a.hv, a.P, a.p, lds_rows, e, lane); break;
+        case 2: hand_mw_role<SHAPE, 2>(a.v, a.hv, a.P, a.p, lds_rows, e, lane); break;
+        default: hand_mw_role<SHAPE, 3>(a.v, a.hv, a.P, a.p, lds_rows, e, lane); break;
+    }
+#endif
+}
+
+template <int SHAPE>
+inline hipError_t hand_substeps_mw_shape(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s) {
+    constexpr size_t lds = hand_mw_lds_bytes();
+    constexpr int E = HSW::LANES;
+    static unsigned long long configured = 0ull;
+    auto kern = hand_substep_mw_kernel<SHAPE>;
+    if (hipError_t e = ensure_dynamic_lds((const void*)kern, lds, &configured); e != hipSuccess) return e;
+    const dim3 grid(xcd_grid<E>(v.N)), block(64, HM::NROLE);
+    for (int i = 0; i < n; ++i) hipLaunchKernelGGL(kern, grid, block, lds, s, HandMwArgs{v, hv, P, p});
+    return hipGetLastError();
+}
+
+}  // namespace mi

@@ -281,6 +281,11 @@ __global__ void hand_init_kernel(View v, HandView hv, HandParams p) {
 }
 
 static hipError_t hand_substeps(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s) {
+    if (v.mw != 0) {     // option multi_wave: the finger-per-wave form (core/hand_engine_mw.hpp), block solver order
+        if (p.object_shape == OBJ_ELLIPSOID) return hand_substeps_mw_egg(v, hv, P, p, n, s);
+        if (p.object_shape == OBJ_CAPSULE) return hand_substeps_mw_pen(v, hv, P, p, n, s);
+        return hand_substeps_mw_box(v, hv, P, p, n, s);
+    }
     if (p.object_shape == OBJ_ELLIPSOID) return hand_substeps_egg(v, hv, P, p, n, s);
     if (p.object_shape == OBJ_CAPSULE) return hand_substeps_pen(v, hv, P, p, n, s);
     return hand_substeps_shape<OBJ_BOX>(v, hv, P, p, n, s);   // mi_engine_create admits no other shape

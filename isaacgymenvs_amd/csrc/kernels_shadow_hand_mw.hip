@@ -1,0 +1,8 @@
+// kernels_shadow_hand_mw.hip -- the finger-per-wave ShadowHand sub-step (hand_mw_kernels.hpp) instantiated for objectType "block".
+#include "hand_mw_kernels.hpp"
+
+namespace mi {
+hipError_t hand_substeps_mw_box(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s) {
+    return hand_substeps_mw_shape<OBJ_BOX>(v, hv, P, p, n, s);
+}
+}  // namespace mi

@@ -422,7 +422,8 @@ extern "C" int mi_engine_set_option(MiEngine* e, const char* key, double value) 
         return 0;
     }
     // multi-wave sub-step (core/engine_mw.hpp, core/engine_mwc.hpp): envs per workgroup, 0 = one wave per workgroup.  Ignored by tasks
-    // whose model has no multi-wave form (Cartpole, ShadowHand, Quadcopter).  2: the Humanoid's round-2 form (main wave + self-collision helper).
+    // whose model has no multi-wave form (Cartpole, Quadcopter).  ShadowHand: any non-zero value selects the finger-per-wave form (32 envs per
+    // workgroup, core/hand_engine_mw.hpp).  2: the Humanoid's round-2 form (main wave + self-collision helper).
     if (!strcmp(key, "multi_wave")) {
         if (value != 0 && value != 32 && value != 2 && !(MI_MW_HAS16 && value == 16)) return fail("multi_wave: 0, 16 or 32 (envs per workgroup); 2: main + helper wave");
         e->v.mw = (int)value;

@@ -21,7 +21,8 @@ BUILD_DIR = os.path.join(CSRC, "build")
 # one translation unit per robot model (they compile in parallel) + the C ABI
 SOURCES = ["mi_engine.hip", "kernels_cartpole.hip", "kernels_ant.hip", "kernels_humanoid.hip", "kernels_anymal.hip", "kernels_shadow_hand.hip",
            "kernels_shadow_hand_pen.hip", "kernels_shadow_hand_egg.hip", "kernels_quadcopter.hip", "kernels_ingenuity.hip", "kernels_ball_balance.hip", "kernels_jit_twins.hip",
-           "kernels_mw_ant.hip", "kernels_mw_anymal.hip", "kernels_humanoid_sc2.hip", "kernels_humanoid_mwc.hip"]
+           "kernels_mw_ant.hip", "kernels_mw_anymal.hip", "kernels_humanoid_sc2.hip", "kernels_humanoid_mwc.hip",
+           "kernels_shadow_hand_mw.hip", "kernels_shadow_hand_mw_pen.hip", "kernels_shadow_hand_mw_egg.hip"]
 MI_MAX_DOF = 32
 
 # -fno-slp-vectorize: pairing scalars into v_pk_* ops lengthens live ranges in the fully unrolled sub-step

@@ -184,8 +184,8 @@ class VecTask(Env):
         mw = os.environ.get("MI_MULTI_WAVE") or self.cfg["sim"].get("multi_wave", "auto")     # the env var: A/B runs and profiling
         if mw == "auto":
             mw = 16 if self.num_envs <= 4096 else (32 if self.num_envs <= 8192 else 0)
-            if self.native_task == "Humanoid":
-                mw = 32          # self-collision phase on a helper wave (csrc/sc2_kernels.hpp): a second SIMD of the CU, at any env count
+            if self.native_task in ("Humanoid", "ShadowHand"):
+                mw = 32          # Humanoid: limb waves + pair wave (csrc/mwc_kernels.hpp); ShadowHand: finger per wave (csrc/hand_mw_kernels.hpp) -- at any env count
         for cand in (int(mw), 32):
             try:
                 self.engine.set_option("multi_wave", cand)

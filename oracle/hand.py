@@ -77,12 +77,32 @@ def sphere_capsule(c_local, r, rc, hl):
     return n - rc - r, d / n
 
 
+def _hand_struct():
+    r = C.c_double
+
+    class OrHand(C.Structure):
+        _fields_ = [(n, C.c_int32) for n in ("nos", "ntend", "kmax", "body_cap", "shape", "solver", "nlimb", "pad")] + \
+                   [(n, C.c_void_p) for n in ("os_body", "os_pos", "os_rad", "tend_d0", "tend_d1", "tend_c0", "tend_c1", "tend_lo", "tend_hi")] + \
+                   [("tend_stiffness", r), ("tend_damping", r), ("kp", C.c_void_p), ("obj_mass", r), ("obj_inertia", r * 3),
+                    ("obj_dims", r * 3), ("mu", r), ("limb_of_body", C.c_void_p), ("limb_cap", C.c_void_p)]
+    return OrHand
+
+
 class OracleHandEngine:
-    def __init__(self, spec, extras, num_envs, sim: dict, sensor_bodies, obj=None):
-        # obj: None = the 5 cm cube; dict(shape="egg" | "pen", dims=semi-axes | (radius, half length), mass=, inertia=principal inertias)
+    def __init__(self, spec, extras, num_envs, sim: dict, sensor_bodies, obj=None, backend="c", solver="gs", blocks=None):
+        """obj: None = the 5 cm cube; dict(shape="egg" | "pen", dims=semi-axes | (radius, half length), mass=, inertia=principal inertias).
+        backend: "c" -- oracle/hand.c (OpenMP over the envs); "numpy" -- the restatement below (solver "gs" only; the cross-check of
+        hand.c).  solver: "gs" -- one Gauss-Seidel sequence, KMAX contacts per env (the single-wave kernel's order); "blocks" -- the
+        finger-per-wave kernel's order with `blocks` = isaacgymenvs_amd.assets.model.hand_solver_blocks(spec) (hand.c header)."""
         self.objp = obj
         self.spec, self.ex, self.N = spec, extras, num_envs
-        self.eng = OracleEngine(spec, num_envs, params=dict(sim, gravity=(0.0, 0.0, 0.0)), sensor_bodies=sensor_bodies, precision="f64")
+        assert backend in ("c", "numpy") and solver in ("gs", "blocks") and (solver == "gs" or backend == "c")
+        self.backend, self.solver = backend, solver
+        self.eng = OracleEngine(spec, num_envs, params=dict(sim, gravity=(0.0, 0.0, 0.0)), sensor_bodies=sensor_bodies, precision="f64",
+                                solver=solver, blocks=blocks)
+        self.blocks = blocks
+        self.env_mu = None                                # [N] per-env hand-object friction (negative: the default 1.0)
+        self.kmax = KMAX                                  # contacts per env of solver "gs" (set before the first step; backend "c")
         self.sim = sim
         self.nd = spec.nd
         self.kp = np.array(extras["dof_kp"], float)
@@ -131,8 +151,63 @@ class OracleHandEngine:
                 out[e, k, 7:10] = v6[3:6] + np.cross(v6[0:3], r); out[e, k, 10:13] = v6[0:3]
         return out
 
+    def _c_setup(self):
+        import os
+        import subprocess
+        here = os.path.dirname(os.path.abspath(__file__))
+        out = os.path.join(here, "_build", "liboracle_hand_f64.so")
+        srcs = [os.path.join(here, "hand.c"), os.path.join(here, "physics.c")]
+        if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(f) for f in srcs):
+            subprocess.check_call(["make", "-s", "-C", here, "_build/liboracle_hand_f64.so"])
+        self._hlib = C.CDLL(out)
+        OrHand = _hand_struct()
+        ex, spec = self.ex, self.spec
+        k = self._hkeep = {}
+        k["os_body"] = np.ascontiguousarray(self.os_body, np.int32)
+        k["os_pos"] = np.ascontiguousarray(self.os_pos, np.float64); k["os_rad"] = np.ascontiguousarray(self.os_rad, np.float64)
+        tends = ex["tendons"]
+        k["tend_d0"] = np.ascontiguousarray([t["dof"][0] for t in tends], np.int32); k["tend_d1"] = np.ascontiguousarray([t["dof"][1] for t in tends], np.int32)
+        k["tend_c0"] = np.ascontiguousarray([t["coef"][0] for t in tends], np.float64); k["tend_c1"] = np.ascontiguousarray([t["coef"][1] for t in tends], np.float64)
+        k["tend_lo"] = np.ascontiguousarray([t["range"][0] for t in tends], np.float64); k["tend_hi"] = np.ascontiguousarray([t["range"][1] for t in tends], np.float64)
+        k["kp"] = np.ascontiguousarray(self.kp, np.float64)
+        hd = OrHand(nos=len(self.os_body), ntend=len(tends), kmax=int(self.kmax), body_cap=BODY_CAP, solver=1 if self.solver == "blocks" else 0)
+        for n in ("os_body", "os_pos", "os_rad", "tend_d0", "tend_d1", "tend_c0", "tend_c1", "tend_lo", "tend_hi", "kp"):
+            setattr(hd, n, _ptr(k[n]))
+        hd.tend_stiffness, hd.tend_damping, hd.mu = float(ex["tendon_limit_stiffness"]), float(ex["tendon_damping"]), 1.0
+        if self.objp is None:
+            hd.shape, hd.obj_mass = 0, CUBE_MASS
+            hd.obj_inertia[:] = [CUBE_INERTIA] * 3; hd.obj_dims[:] = [CUBE_HALF, 0.0, 0.0]
+        else:
+            hd.shape, hd.obj_mass = {"pen": 1, "egg": 2}[self.objp["shape"]], float(self.objp["mass"])
+            hd.obj_inertia[:] = [float(x) for x in self.objp["inertia"]]
+            dims = [float(x) for x in self.objp["dims"]]
+            hd.obj_dims[:] = (dims + [0.0, 0.0, 0.0])[:3]
+        if self.solver == "blocks":
+            k["limb_of_body"] = np.ascontiguousarray(self.blocks["limb_of_body"], np.int32)
+            k["limb_cap"] = np.ascontiguousarray(self.blocks["limb_cap"], np.int32)
+            hd.nlimb = len(k["limb_cap"])
+            hd.limb_of_body, hd.limb_cap = _ptr(k["limb_of_body"]), _ptr(k["limb_cap"])
+        self._hd = hd
+        self._nc32 = np.zeros(self.N, np.int32)
+        self.limb_counts = np.zeros((self.N, max(int(hd.nlimb), 1)), np.int32)     # solver "blocks": contacts kept per limb, last sub-step
+
     def step(self):
         P = self.sim
+        if self.backend == "c":
+            if not hasattr(self, "_hlib"):
+                self._c_setup()
+            e = self.eng
+            e.set_params(**dict(P, gravity=tuple(P["gravity"])))     # (the object's gravity; the hand's is switched off inside hand.c)
+            st = e.state
+            assert st.shape[1] == 13 + 3 * self.nd and st.flags.c_contiguous
+            mu = None if self.env_mu is None else np.ascontiguousarray(self.env_mu, np.float64)
+            tg = np.ascontiguousarray(self.targets, np.float64); fo = np.ascontiguousarray(self.obj_force, np.float64)
+            sc = np.ascontiguousarray(self.scale, np.float64); ls = np.ascontiguousarray(self.limit_shift, np.float64)
+            self._hlib.or_hand_step(C.byref(e.model), C.byref(e.params), C.byref(self._hd), self.N, _ptr(st), _ptr(self.obj), _ptr(tg), _ptr(fo),
+                                    _ptr(sc), _ptr(ls), _ptr(mu) if mu is not None else None, _ptr(self.sensor), _ptr(self.dof_force),
+                                    _ptr(self._nc32), _ptr(self.limb_counts) if self.solver == "blocks" else None)
+            self.ncontacts[:] = self._nc32
+            return
         h = P["dt"] / P["substeps"]
         for _ in range(P["substeps"]):
             for e in range(self.N):

@@ -1095,14 +1095,16 @@ class OracleShadowHandEnv:
     """vec_task.py:360-408 + shadow_hand.py pre/post_physics_step on oracle/hand.py (numpy, fp64 physics, fp32 task maths).
     `params` is the MiHandParams struct the HIP engine receives."""
 
-    def __init__(self, spec, extras, sensor_bodies, sim_params: dict, params, num_envs, seed=0, env_id_offset=0):
+    def __init__(self, spec, extras, sensor_bodies, sim_params: dict, params, num_envs, seed=0, env_id_offset=0, solver="gs", blocks=None):
+        """solver / blocks: the physics' solver order (oracle/hand.py): "gs" = the one-wave kernel's, "blocks" = the finger-per-wave kernel's
+        with blocks = isaacgymenvs_amd.assets.model.hand_solver_blocks(spec)."""
         from .hand import OracleHandEngine
         self.N, self.p, self.nd = num_envs, params, spec.nd
         obj = None
         if int(getattr(params, "object_shape", 0)) != 0:                          # objectType "pen" (1) / "egg" (2)
             obj = dict(shape={1: "pen", 2: "egg"}[int(params.object_shape)], dims=list(params.object_dims), mass=float(params.cube_mass),
                        inertia=list(params.object_inertia))
-        self.eng = OracleHandEngine(spec, extras, num_envs, sim_params, sensor_bodies, obj=obj)
+        self.eng = OracleHandEngine(spec, extras, num_envs, sim_params, sensor_bodies, obj=obj, solver=solver, blocks=blocks)
         self.eng.eng.root[:, :3] = list(params.hand_pos)
         self.eng.eng.root[:, 3:7] = list(params.hand_quat)
         self.seed, self.off = fold_seed(seed), env_id_offset

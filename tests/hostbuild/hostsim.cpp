@@ -9,6 +9,7 @@
 #include "../../isaacgymenvs_amd/csrc/core/engine_mwc.hpp"
 #include <pthread.h>
 #include <thread>
+#include <vector>
 #ifdef HOSTSIM_CARTPOLE
 #include "../../isaacgymenvs_amd/csrc/gen/model_cartpole.h"
 #endif
@@ -23,6 +24,7 @@
 #endif
 #ifdef HOSTSIM_HAND
 #include "../../isaacgymenvs_amd/csrc/core/hand_engine.hpp"
+#include "../../isaacgymenvs_amd/csrc/core/hand_engine_mw.hpp"
 #include "../../isaacgymenvs_amd/csrc/gen/model_shadow_hand.h"
 #endif
 #ifdef HOSTSIM_HUMANOID
@@ -334,6 +336,70 @@ extern "C" int hs_step_hand(const SimParams* P, int nenv, float* state, float* o
         for (int k = 0; k < ND; ++k) { s[k] = sim.q[k]; s[ND + k] = sim.qd[k]; }
         for (int k = 0; k < 3; ++k) { ob[k] = sim.obj.pos[k]; ob[7 + k] = sim.obj.vel[k]; ob[10 + k] = sim.obj.angvel[k]; }
         for (int k = 0; k < 4; ++k) ob[3 + k] = sim.obj.quat[k];
+    }
+    return 0;
+}
+// the finger-per-wave form (core/hand_engine_mw.hpp): the NROLE role waves of an env run as threads that meet at a pthread barrier where
+// the GPU waves meet at s_barrier; one shared row store (stride 1).  State / out layout of hs_step_hand; shape 0 box, 1 capsule, 2 ellipsoid
+// (dims / inertia3: the object's dimensions and principal inertias for shapes 1, 2)
+struct HandMwJob {
+    const SimParams* P; float* s; float* o; const float* root13; ObjectParams OP; const float* scale; const float* lshift; float* rows;
+    pthread_barrier_t* bar; int* nc;
+};
+template <int R, int SHAPE>
+static void hand_mw_thread(HandMwJob j) {
+    using M = ModelShadowHand;
+    using MW = SimMW<M>;
+    constexpr int ND = M::ND, NS = M::NSENS;
+    HandSimMW<M> sim;
+    if (j.scale) sim.actor_scale = Strided{const_cast<float*>(j.scale), 1};
+    sim.limit_shift = Strided{const_cast<float*>(j.lshift), 1};
+    for (int k = 0; k < 13; ++k) sim.root[k] = j.root13[k];
+    float* ob = j.s + 4 * ND;
+    const float h = j.P->dt / (float)j.P->substeps;
+    for (int it = 0; it < j.P->substeps; ++it) {
+        for (int k = 0; k < ND; ++k) { sim.q[k] = j.s[k]; sim.qd[k] = j.s[ND + k]; }
+        for (int k = 0; k < 3; ++k) { sim.obj.pos[k] = ob[k]; sim.obj.vel[k] = ob[7 + k]; sim.obj.angvel[k] = ob[10 + k]; }
+        for (int k = 0; k < 4; ++k) sim.obj.quat[k] = ob[3 + k];
+        pthread_barrier_wait(j.bar);     // everybody has read the state of the previous sub-step
+        int nc = 0;
+        sim.template substep_hand_role<R, 1, SHAPE>(*j.P, j.OP, j.s + 3 * ND, h, RowStore<1>{j.rows}, Strided{j.s + 2 * ND, 1}, Strided{j.o, 1},
+                                                    Strided{j.o + 6 * NS, 1}, &nc, HostBarrier{j.bar});
+        sfor<ND>([&](auto K) { if constexpr (MW::template owns_gi<R>(K)) { j.s[K] = sim.q[K]; j.s[ND + K] = sim.qd[K]; } });
+        if constexpr (R == M::TRUNK_ROLE) {
+            for (int k = 0; k < 3; ++k) { ob[k] = sim.obj.pos[k]; ob[7 + k] = sim.obj.vel[k]; ob[10 + k] = sim.obj.angvel[k]; }
+            for (int k = 0; k < 4; ++k) ob[3 + k] = sim.obj.quat[k];
+            *j.nc = nc;
+        }
+        pthread_barrier_wait(j.bar);     // the new state is complete
+    }
+}
+template <int SHAPE>
+static void hand_mw_env(const HandMwJob& j) {
+    static_assert(ModelShadowHand::NROLE == 4, "four roles");
+    std::thread t0(hand_mw_thread<0, SHAPE>, j), t1(hand_mw_thread<1, SHAPE>, j), t2(hand_mw_thread<2, SHAPE>, j), t3(hand_mw_thread<3, SHAPE>, j);
+    t0.join(); t1.join(); t2.join(); t3.join();
+}
+extern "C" int hs_step_hand_mw(const SimParams* P, int nenv, float* state, float* out, const float* root13, float half, float mass, float inertia,
+                               float mu, const float* scale, const float* limit_shift, int shape, const float* dims, const float* inertia3) {
+    using M = ModelShadowHand;
+    constexpr int ND = M::ND, NS = M::NSENS;
+    const int ss = 4 * ND + 13, os = 6 * NS + ND + 1;
+    static const float no_shift[2 * ND] = {0};
+    for (int e = 0; e < nenv; ++e) {
+        float* s = state + (size_t)e * ss;
+        float* o = out + (size_t)e * os;
+        ObjectParams OP{half, mass, inertia, mu};
+        if (shape != 0) for (int k = 0; k < 3; ++k) { OP.dims[k] = dims[k]; OP.inertia3[k] = inertia3[k]; }
+        if (scale) OP.randomise(scale[e * HS_COLUMNS + HS_OBJECT_MASS], scale[e * HS_COLUMNS + HS_OBJECT_SCALE]);
+        std::vector<float> rows(HandSimMW<M>::MW_SLOTS, 0.f);
+        pthread_barrier_t bar;
+        pthread_barrier_init(&bar, nullptr, 4);
+        int nc = 0;
+        HandMwJob j{P, s, o, root13, OP, scale ? scale + e * HS_COLUMNS : nullptr, limit_shift ? limit_shift + e * 2 * ND : no_shift, rows.data(), &bar, &nc};
+        if (shape == 0) hand_mw_env<OBJ_BOX>(j); else if (shape == 1) hand_mw_env<OBJ_CAPSULE>(j); else hand_mw_env<OBJ_ELLIPSOID>(j);
+        pthread_barrier_destroy(&bar);
+        o[6 * NS + ND] = (float)(nc & 0xFFFF);
     }
     return 0;
 }

@@ -175,6 +175,70 @@ def test_host_build_of_hand_engine_matches_oracle(scaled):
     assert np.isfinite(state).all()
 
 
+@pytest.mark.parametrize("shape", ["block", "egg", "pen"])
+def test_host_build_of_finger_per_wave_hand_engine_matches_block_order_oracle(shape):
+    """csrc/core/hand_engine_mw.hpp compiled for the host (fp32; the four role waves of an env run as four threads that meet at a pthread
+    barrier) against oracle/hand.c with the block solver order (fp64): wrist Schur complement / carries exchanged between the roles,
+    joint-limit rows in registers, contacts kept per limb in the fixed row shape [limb | wrist], block sweeps with mass splitting on the
+    wrist and the object coordinates.  Contact counts identical, states agree to fp32 rounding -- with `actor_params` factors and
+    joint-limit shifts in place, for the cube, the egg and the pen."""
+    import ctypes as C
+    from oracle.hand import OracleHandEngine, CUBE_HALF as half, CUBE_MASS as mass, CUBE_INERTIA as inertia
+    from isaacgymenvs_amd.assets.model import hand_solver_blocks
+    from isaacgymenvs_amd.registry import load_model, load_extras, sensor_bodies
+    lib = hostsim.build_hand()
+    spec, ex = load_model("shadow_hand"), load_extras("shadow_hand")
+    sim = dict(dt=1.0 / 60.0, substeps=2, iters=8, gravity=(0.0, 0.0, -9.81), contact_offset=0.002, rest_offset=0.0,
+               max_depen_vel=1000.0, erp=0.2, plane_mu=1.0, ground_z=0.0, cfm=1e-4, warm=0.9)
+    N, nd = 8, spec.nd
+    rng = np.random.default_rng(11)
+    objp = {"block": None, "egg": dict(shape="egg", dims=[0.03, 0.03, 0.04], mass=0.151, inertia=[7.5e-5, 7.5e-5, 5.4e-5]),
+            "pen": dict(shape="pen", dims=[0.008, 0.1], mass=0.042, inertia=[1.5e-4, 1.5e-4, 1.5e-6])}[shape]
+    orc = OracleHandEngine(spec, ex, N, sim, sensor_bodies("shadow_hand"), obj=objp, solver="blocks", blocks=hand_solver_blocks(spec))
+    lo, up = orc.lo, orc.up
+    orc.q[:] = lo + (up - lo) * rng.uniform(0.2, 0.5, (N, nd))
+    orc.qd[:] = rng.normal(0, 0.5, (N, nd))
+    orc.targets[:] = lo + (up - lo) * rng.uniform(0.1, 0.9, (N, nd))
+    tips = orc.fingertip_states()
+    orc.obj[:, 0:3] = tips[:, :, 0:3].mean(1) + rng.normal(0, 0.01, (N, 3)) + np.array([0.0, 0.0, 0.02])
+    qn = rng.normal(size=(N, 4)); orc.obj[:, 3:7] = qn / np.linalg.norm(qn, axis=1, keepdims=True)
+    orc.obj[:, 7:10] = rng.normal(0, 0.1, (N, 3))
+    scale = np.ones((N, 8), np.float32)
+    scale[:, 0] = rng.uniform(0.5, 1.5, N); scale[:, 1] = rng.uniform(0.3, 3.0, N); scale[:, 2] = rng.uniform(0.75, 1.5, N)
+    scale[:, 3] = rng.uniform(0.75, 1.5, N); scale[:, 4] = rng.uniform(0.3, 3.0, N); scale[:, 5] = rng.uniform(0.5, 1.5, N)
+    scale[:, 6] = rng.uniform(0.95, 1.05, N)
+    lsh = rng.normal(0, 0.03, (N, 2 * nd)).astype(np.float32)
+    orc.scale[:] = scale; orc.limit_shift[:] = lsh
+    ss = 4 * nd + 13
+    state = np.zeros((N, ss), np.float32)
+    state[:, 0:nd] = orc.q; state[:, nd:2 * nd] = orc.qd; state[:, 3 * nd:4 * nd] = orc.targets; state[:, 4 * nd:] = orc.obj
+    root13 = np.zeros(13, np.float32); root13[:7] = orc.eng.root[0, :7]
+    ns = len(orc.sens)
+    out = np.zeros((N, 6 * ns + nd + 1), np.float32)
+    P = hostsim.make_params(sim)
+    shp = {"block": 0, "pen": 1, "egg": 2}[shape]
+    dims = np.zeros(3, np.float32); in3 = np.zeros(3, np.float32)
+    om, oi = mass, inertia
+    if objp is not None:
+        dims[:len(objp["dims"])] = objp["dims"]; in3[:] = objp["inertia"]; om, oi = objp["mass"], 1.0
+    total, fingers = 0, 0
+    for it in range(10):
+        orc.step()
+        rc = lib.hs_step_hand_mw(C.byref(P), N, state.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), root13.ctypes.data_as(C.c_void_p),
+                                 C.c_float(half), C.c_float(om), C.c_float(oi), C.c_float(1.0), scale.ctypes.data_as(C.c_void_p),
+                                 lsh.ctypes.data_as(C.c_void_p), shp, dims.ctypes.data_as(C.c_void_p), in3.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        np.testing.assert_array_equal(out[:, -1].astype(int), orc.ncontacts)
+        total += int(orc.ncontacts.sum()); fingers += int(orc.limb_counts[:, 1:].sum())
+        np.testing.assert_allclose(state[:, 0:nd], orc.q, atol=2e-4)
+        np.testing.assert_allclose(state[:, nd:2 * nd], orc.qd, atol=2e-2)
+        np.testing.assert_allclose(state[:, 4 * nd:4 * nd + 7], orc.obj[:, 0:7], atol=5e-4)
+        np.testing.assert_allclose(out[:, 6 * ns:6 * ns + nd], orc.dof_force, atol=2e-3 * max(1.0, np.abs(orc.dof_force).max()))
+        np.testing.assert_allclose(out[:, :6 * ns], orc.sensor, atol=2e-3 * max(1.0, np.abs(orc.sensor).max()))
+    assert total > 100 and fingers > 30, "scenario must exercise palm and finger contacts"
+    assert np.isfinite(state).all()
+
+
 def test_host_build_with_position_drives_and_body_forces_matches_oracle():
     """Quadcopter model: implicit PD position drives (kp 1000) on the rotor joints + thrust forces on the rotor bodies in
     their local frames (engine.hpp Drive) against oracle/physics.c or_step_drive; free flight, no contacts."""

@@ -149,6 +149,15 @@ def _sim_dict(sp):
                 ground_z=sp.ground_z, cfm=sp.cfm, warm=sp.warm)
 
 
+def _hand_order(env):
+    """Oracle options that mirror the ShadowHand engine's solver order: option multi_wave != 0 is the finger-per-wave kernel
+    (csrc/core/hand_engine_mw.hpp: block sweeps, contacts kept per limb), 0 the one-wave kernel (one Gauss-Seidel sequence)."""
+    from isaacgymenvs_amd.assets.model import hand_solver_blocks
+    if int(env.engine.get_option("multi_wave")) != 0:
+        return dict(solver="blocks", blocks=hand_solver_blocks(load_model("shadow_hand")))
+    return dict(solver="gs")
+
+
 def _make_env(task, n, seed=5):
     import isaacgymenvs_amd
     return isaacgymenvs_amd.make(seed=seed, task=task, num_envs=n, sim_device=DEV, rl_device=DEV, headless=True)
@@ -941,8 +950,11 @@ def test_ball_balance_full_size_properties():
 
 
 # ------------------------------------------------------------------ ShadowHand (hand + cube physics, deferred resets, full_state obs)
+@pytest.mark.parametrize("multi_wave", [32, 0])
 @pytest.mark.parametrize("object_type", ["block", "egg", "pen"])
-def test_shadow_hand_step_matches_cpu_restatement(object_type):
+def test_shadow_hand_step_matches_cpu_restatement(object_type, multi_wave):
+    """multi_wave 32: the finger-per-wave kernel against the block solver order of the restatement; 0: the one-wave kernel against the
+    Gauss-Seidel order."""
     import isaacgymenvs_amd
     from isaacgymenvs_amd.registry import load_extras
     from oracle.tasks import OracleShadowHandEnv
@@ -952,8 +964,10 @@ def test_shadow_hand_step_matches_cpu_restatement(object_type):
     cfg["task"]["env"]["objectType"] = object_type          # egg: ellipsoid 3 x 3 x 4 cm with principal inertias (egg.xml)
     env = isaacgymenvs_amd.make(seed=seed, task="ShadowHand", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True, cfg=cfg)
     assert env._task_params_struct.object_shape == {"block": 0, "pen": 1, "egg": 2}[object_type]
+    assert int(env.engine.get_option("multi_wave")) == 32      # the default form
+    env.engine.set_option("multi_wave", multi_wave)
     orc = OracleShadowHandEnv(load_model("shadow_hand"), load_extras("shadow_hand"), sensor_bodies("shadow_hand"),
-                              _sim_dict(env.sim_params), env._task_params_struct, n, seed=seed)
+                              _sim_dict(env.sim_params), env._task_params_struct, n, seed=seed, **_hand_order(env))
     g = torch.Generator(device="cpu").manual_seed(7)
     for step in range(8):
         a = torch.rand((n, 20), generator=g) * 2 - 1
@@ -991,9 +1005,9 @@ def test_shadow_hand_actor_scales_and_limit_shifts_match_cpu_restatement(object_
     cfg["task"]["env"]["objectType"] = object_type
     env = isaacgymenvs_amd.make(seed=seed, task="ShadowHand", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True, cfg=cfg)
     orc = OracleShadowHandEnv(load_model("shadow_hand"), load_extras("shadow_hand"), sensor_bodies("shadow_hand"),
-                              _sim_dict(env.sim_params), env._task_params_struct, n, seed=seed)
+                              _sim_dict(env.sim_params), env._task_params_struct, n, seed=seed, **_hand_order(env))
     plain = OracleShadowHandEnv(load_model("shadow_hand"), load_extras("shadow_hand"), sensor_bodies("shadow_hand"),
-                                _sim_dict(env.sim_params), env._task_params_struct, n, seed=seed)
+                                _sim_dict(env.sim_params), env._task_params_struct, n, seed=seed, **_hand_order(env))
     rng = np.random.default_rng(3)
     sc = np.ones((n, 8), np.float32)
     for col, (a, b) in enumerate([(0.5, 1.5), (0.3, 3.0), (0.75, 1.5), (0.75, 1.5), (0.3, 3.0), (0.5, 1.5), (0.95, 1.05)]):
@@ -1120,7 +1134,7 @@ def test_shadow_hand_observation_types_asymmetric_states_and_random_forces(obs_t
     env = isaacgymenvs_amd.make(seed=seed, task="ShadowHand", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True, cfg=cfg)
     assert env.num_obs == nobs and env.num_states == 211
     orc = OracleShadowHandEnv(load_model("shadow_hand"), load_extras("shadow_hand"), sensor_bodies("shadow_hand"),
-                              _sim_dict(env.sim_params), env._task_params_struct, n, seed=seed)
+                              _sim_dict(env.sim_params), env._task_params_struct, n, seed=seed, **_hand_order(env))
     g = torch.Generator(device="cpu").manual_seed(3)
     forced = 0
     for step in range(6):

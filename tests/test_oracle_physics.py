@@ -361,3 +361,86 @@ def test_block_solver_keeps_the_known_answers():
     fz = e.sph_force[0, :, 2].sum()
     assert abs(fz - float(np.sum(spec.mass)) * 9.81) < 2e-3 * float(np.sum(spec.mass)) * 9.81, fz
     assert np.abs(e.qd).max() < 1e-3 and np.abs(e.root[0, 7:]).max() < 1e-3
+
+
+@pytest.mark.parametrize("shape", ["block", "egg", "pen"])
+def test_hand_oracle_in_c_equals_its_numpy_twin(shape):
+    """oracle/hand.c (OpenMP, every env of ShadowHand@16384 in seconds) restates oracle/hand.py (numpy): same contacts, states equal to
+    1e-9 over 12 steps with contacts, tendon rows, `actor_params` factors, joint-limit shifts and an external force on the object."""
+    from oracle.hand import OracleHandEngine
+    from isaacgymenvs_amd.registry import load_model, load_extras, sensor_bodies
+    spec, ex = load_model("shadow_hand"), load_extras("shadow_hand")
+    sim = dict(dt=1.0 / 60.0, substeps=2, iters=8, gravity=(0.0, 0.0, -9.81), contact_offset=0.002, rest_offset=0.0,
+               max_depen_vel=1000.0, erp=0.2, plane_mu=1.0, ground_z=0.0, cfm=1e-4, warm=0.9)
+    N, nd = 6, spec.nd
+    objp = {"block": None, "egg": dict(shape="egg", dims=[0.03, 0.03, 0.04], mass=0.151, inertia=[7.5e-5, 7.5e-5, 5.4e-5]),
+            "pen": dict(shape="pen", dims=[0.008, 0.1], mass=0.042, inertia=[1.5e-4, 1.5e-4, 1.5e-6])}[shape]
+    rng = np.random.default_rng(5)
+    a = OracleHandEngine(spec, ex, N, sim, sensor_bodies("shadow_hand"), obj=objp, backend="numpy")
+    b = OracleHandEngine(spec, ex, N, sim, sensor_bodies("shadow_hand"), obj=objp, backend="c")
+    lo, up = a.lo, a.up
+    a.q[:] = lo + (up - lo) * rng.uniform(0.2, 0.5, (N, nd)); a.qd[:] = rng.normal(0, 0.5, (N, nd))
+    a.targets[:] = lo + (up - lo) * rng.uniform(0.1, 0.9, (N, nd))
+    tips = a.fingertip_states()
+    a.obj[:, 0:3] = tips[:, :, 0:3].mean(1) + rng.normal(0, 0.01, (N, 3)) + np.array([0.0, 0.0, 0.02])
+    qn = rng.normal(size=(N, 4)); a.obj[:, 3:7] = qn / np.linalg.norm(qn, axis=1, keepdims=True)
+    a.obj[:, 7:10] = rng.normal(0, 0.1, (N, 3))
+    for col, (x0, x1) in enumerate([(0.5, 1.5), (0.3, 3.0), (0.75, 1.5), (0.75, 1.5), (0.3, 3.0), (0.5, 1.5), (0.95, 1.05)]):
+        a.scale[:, col] = rng.uniform(x0, x1, N)
+    a.limit_shift[:] = rng.normal(0, 0.03, (N, 2 * nd)); a.obj_force[:] = rng.normal(0, 0.2, (N, 3))
+    for k in ("targets", "obj", "scale", "limit_shift", "obj_force"):
+        getattr(b, k)[:] = getattr(a, k)
+    b.q[:] = a.q; b.qd[:] = a.qd
+    tot = 0
+    for it in range(12):
+        a.step(); b.step()
+        tot += int(a.ncontacts.sum())
+        np.testing.assert_array_equal(a.ncontacts, b.ncontacts)
+        np.testing.assert_allclose(b.q, a.q, atol=1e-9); np.testing.assert_allclose(b.obj, a.obj, atol=1e-9)
+        np.testing.assert_allclose(b.laml, a.laml, atol=1e-9)
+        np.testing.assert_allclose(b.sensor, a.sensor, atol=1e-7 * max(1.0, np.abs(a.sensor).max()))
+        np.testing.assert_allclose(b.dof_force, a.dof_force, atol=1e-7 * max(1.0, np.abs(a.dof_force).max()))
+    assert tot > 100
+
+
+def test_hand_block_order_and_gauss_seidel_order_solve_the_same_problem():
+    """The block order of the finger-per-wave kernel (oracle/hand.c solver 1: Gauss-Seidel inside a block, Jacobi with mass splitting on the
+    wrist and object coordinates across blocks) and the one Gauss-Seidel sequence solve the same complementarity problem: on states of a
+    random-policy rollout of the task both end, with many sweeps, at the same velocities; after the task's 8 sweeps the block order is
+    within a small factor of the sequence's distance from that solution (tools/hand_solver_study.py reports the statistics)."""
+    from oracle.hand import OracleHandEngine
+    from oracle.tasks import OracleShadowHandEnv
+    from isaacgymenvs_amd.assets.model import hand_solver_blocks
+    from isaacgymenvs_amd.registry import load_model, load_extras, sensor_bodies
+    from isaacgymenvs_amd.tasks.shadow_hand import hand_params_from_cfg
+    from isaacgymenvs_amd.utils.config import compose
+    spec, ex, sens = load_model("shadow_hand"), load_extras("shadow_hand"), sensor_bodies("shadow_hand")
+    cfg = compose(overrides=["task=ShadowHand"])["task"]
+    ph = cfg["sim"]["physx"]
+    sim = dict(dt=cfg["sim"]["dt"], substeps=2, iters=8, gravity=tuple(cfg["sim"]["gravity"]), contact_offset=ph["contact_offset"],
+               rest_offset=ph["rest_offset"], max_depen_vel=ph["max_depenetration_velocity"], plane_mu=1.0, ground_z=0.0, erp=0.5, cfm=1e-6, warm=1.0)
+    n = 96
+    blocks = hand_solver_blocks(spec)
+    free = dict(blocks, limb_cap=[40] * len(blocks["limb_cap"]))       # caps out of the way: both orders keep every contact
+    env = OracleShadowHandEnv(spec, ex, sens, sim, hand_params_from_cfg(cfg), n, seed=3)
+
+    def make(solver, iters):
+        x = OracleHandEngine(spec, ex, n, dict(sim, iters=iters, substeps=1, dt=sim["dt"] / 2), sens, solver=solver, blocks=free if solver == "blocks" else None)
+        x.kmax = 40
+        return x
+    e = {k: make(*k) for k in [("gs", 8), ("blocks", 8), ("gs", 3000), ("blocks", 3000)]}
+    rng = np.random.default_rng(0)
+    for s in range(20):
+        env.step(rng.uniform(-1, 1, (n, 20)).astype(np.float32))
+    for x in e.values():
+        x.eng.state[:] = env.eng.eng.state; x.obj[:] = env.eng.obj; x.targets[:] = env.eng.targets; x.obj_force[:] = env.eng.obj_force
+        x.step()
+    ref, refb = e[("gs", 3000)], e[("blocks", 3000)]
+    assert int(ref.ncontacts.sum()) > n
+    np.testing.assert_array_equal(ref.ncontacts, refb.ncontacts)
+    vel = lambda x: np.concatenate([x.qd, x.obj[:, 7:13]], 1)         # noqa: E731
+    dconv = np.abs(vel(ref) - vel(refb)).max(1)
+    # (a friction LCP has more than one solution in rare configurations, and a few envs have not converged after 3000 sweeps)
+    assert np.median(dconv) < 1e-9 and np.percentile(dconv, 80) < 1e-3, (np.median(dconv), np.percentile(dconv, 80))
+    d_gs = np.abs(vel(e[("gs", 8)]) - vel(ref)).max(1); d_bl = np.abs(vel(e[("blocks", 8)]) - vel(ref)).max(1)
+    assert d_bl.mean() < 3.0 * d_gs.mean() + 1e-3, (d_bl.mean(), d_gs.mean())

@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import isaacgymenvs_amd  # noqa: E402
 from isaacgymenvs_amd.registry import load_extras, load_model, sensor_bodies  # noqa: E402
 from oracle.tasks import OracleAnymalTerrainEnv, OracleShadowHandEnv  # noqa: E402
-from test_gpu_parity import _sim_dict  # noqa: E402
+from test_gpu_parity import _hand_order, _sim_dict  # noqa: E402
 
 DEV = "cuda:0"
 from isaacgymenvs_amd.utils.config import compose  # noqa: E402
@@ -34,7 +34,7 @@ for task, n, steps, seed in CASES:
         orc = OracleAnymalTerrainEnv(load_model("anymal"), _sim_dict(env.sim_params), env._task_params_struct, env.terrain, n, seed=seed, precision="f64")
     else:
         orc = OracleShadowHandEnv(load_model("shadow_hand"), load_extras("shadow_hand"), sensor_bodies("shadow_hand"), _sim_dict(env.sim_params),
-                                  env._task_params_struct, n, seed=seed)
+                                  env._task_params_struct, n, seed=seed, **_hand_order(env))
     g = torch.Generator(device="cpu").manual_seed(3)
     G, O = dict(rew=0.0, resets=0, nc=0), dict(rew=0.0, resets=0, nc=0)
     for i in range(steps):
