@@ -156,7 +156,9 @@ def roofline(task, num_envs, kernel_ms, mw=0):
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
     tr = load_traffic().get(f"{task}@{num_envs}", {})
     if mw and task == "Humanoid":
-        shape = "%d workgroups of 32 envs x 2 waves (main wave + self-collision helper wave)" % ((num_envs + 31) // 32)
+        shape = "%d workgroups of 32 envs x 4 waves (three limb waves + the self-collision pair wave)" % ((num_envs + 31) // 32)
+    elif mw and task == "ShadowHand":
+        shape = "%d workgroups of %d envs x 4 waves (one finger per wave; %s)" % ((num_envs + mw - 1) // mw, mw, "full waves, one workgroup per CU" if mw == 64 else "half-filled waves, two workgroups per CU")
     elif mw:
         shape = "%d workgroups of %d envs x 4 waves (one limb per wave)" % ((num_envs + mw - 1) // mw, mw)
     else:
@@ -395,9 +397,9 @@ def main():
     if extra3 is not None:
         out["extra3"] = {"workload": f"ShadowHand (block, full_state) num_envs={side['ShadowHand']} per GPU ({world * side['ShadowHand']} total; 2 sub-steps per control step)",
                          "value": extra3["env_steps_per_s"], "unit": "env-steps/s", "ms_per_step": extra3["ms_per_step"],
-                         "reset_rate": extra3["reset_rate"], "pooled": extra3["pooled"],
+                         "reset_rate": extra3["reset_rate"], "pooled": extra3["pooled"], "multi_wave": extra3["multi_wave"],
                          "steps": extra3["steps"], "warmup": extra3["warmup"], "consistent": extra3["consistent"],
-                         "roofline": roofline("ShadowHand", side["ShadowHand"], extra3["kernel_ms_avg"])}
+                         "roofline": roofline("ShadowHand", side["ShadowHand"], extra3["kernel_ms_avg"], extra3["multi_wave"])}
         if "job_stats" in extra3:
             out["extra3"]["job_stats"] = extra3["job_stats"]
     if world == 1 and not args.no_cpu_baseline and args.task in ("Ant", "Humanoid"):

@@ -940,6 +940,8 @@ def _has_selfcol(spec: ModelSpec) -> bool:
 
 # wavefronts per env of the multi-wave sub-step (default 4: one per SIMD of a CU)
 WAVE_ROLES = {"shadow_hand": 4}
+# role of every limb where the greedy deal below is not the measured optimum: (role per limb, trunk role)
+WAVE_ROLE_OVERRIDE = {}     # (shadow_hand ([-1, 2, 1, 2, 0, 1], 3) -- thumb + middle finger on one wave, the trunk rows alone -- measured: slower, profiles/r3k_*)
 
 
 def wave_roles(spec: ModelSpec, nrole=None, pair_role=None):
@@ -971,6 +973,10 @@ def wave_roles(spec: ModelSpec, nrole=None, pair_role=None):
         role_of_limb[l] = r
         load[r] += weight[l] + 0.01 * len(limbs[l])
     trunk_role = min(range(nlr), key=lambda k: (load[k], k))
+    if getattr(spec, "name", "") in WAVE_ROLE_OVERRIDE:
+        role_of_limb, trunk_role = WAVE_ROLE_OVERRIDE[spec.name]
+        assert len(role_of_limb) == len(limbs) and role_of_limb[0] == -1
+        role_of_limb = list(role_of_limb)
     return limb, limbs, role_of_limb, trunk_role, nrole
 
 
@@ -1008,17 +1014,23 @@ def solver_blocks(spec: ModelSpec, self_collision: bool = False, wave_caps: bool
 
 def hand_limb_caps(spec: ModelSpec):
     """Object contacts each LIMB of a manipulator keeps per env in the finger-per-wave sub-step (csrc/core/hand_engine_mw.hpp gives every
-    limb its own contact slots in LDS, rows in the fixed shape [limb dofs | wrist dofs]): 5 for the limb of the root body (forearm, wrist,
-    palm: the palm alone may hold a manifold of 4), 3 for a finger (one per phalanx) -- what 80 KB of LDS per 32 envs hold.  -> [nlimb]"""
+    limb its own contact slots in LDS, rows in the fixed shape [limb dofs | wrist dofs]).  What 80 KB of LDS per 32 envs hold (a slot
+    is 3 (n_limb + 2) + 10 floats), dealt by where contacts were measured on random-policy states (tools/hand_solver_study.py: the palm
+    limb never holds more than 5, the little finger -- with its metacarpal it lies under the cube -- more than 3 in 10 % and more than 5
+    in 0.7 % of the sub-steps, the thumb more than 3 in 1.6 %, the other fingers more than 2 in 0.1 %): 5 for the limb of the root
+    body (forearm, wrist, palm: the palm alone may hold a manifold of 4); five-joint fingers 5, then 4; four-joint fingers 3, then 2.
+    -> [nlimb]"""
     _, limbs = limb_paths(spec)
     nd = [sum(1 for d in range(spec.nd) if int(spec.dof_body[d]) in bodies) for bodies in limbs]
-    # a five-joint finger (little finger with its metacarpal, thumb) lies against the object more often than a four-joint one; the
-    # LAST of them (the thumb) gets what is left of the LDS budget.  Measured on random-policy states (tools/hand_solver_study.py):
-    # palm limb <= 5 always, little finger > 3 in 10 % and > 4 in 2 % of the sub-steps, thumb > 3 in 1.6 %.
-    caps = [5] + [3] * (len(limbs) - 1)
-    five = [l for l in range(1, len(limbs)) if nd[l] >= 5]
-    if five:
-        caps[five[0]] = 4
+    caps = [5] + [0] * (len(limbs) - 1)
+    n5 = n4 = 0
+    for l in range(1, len(limbs)):
+        if nd[l] >= 5:
+            caps[l] = 5 if n5 == 0 else 4
+            n5 += 1
+        else:
+            caps[l] = 3 if n4 == 0 else 2
+            n4 += 1
     return caps
 
 

@@ -569,8 +569,13 @@ struct HandSim : Sim<M> {
     // world pose and velocity of the force-sensor (fingertip) bodies at the CURRENT state: [NSENS][13] = pos3, quat xyzw,
     // linvel3, angvel3 -- what gym.refresh_rigid_body_state_tensor exposes (shadow_hand.py:440,456-457)
     MI_HD void fingertip_states(float (*out)[13]) {
-        sfor<NSENS>([&](auto K_) MI_LAMBDA {
-            constexpr int k = K_, tip = M::sens_body[k];
+        sfor<NSENS>([&](auto K_) MI_LAMBDA { this->template fingertip_state<decltype(K_)::value>(out[K_]); });
+    }
+    // one fingertip: reads q / qd of the dofs on its chain only
+    template <int k>
+    MI_HD void fingertip_state(float* o) {
+        {
+            constexpr int tip = M::sens_body[k];
             // walk the chain root -> tip (static): bodies on the path, in order
             float Rb[9], rb[3] = {0.f, 0.f, 0.f}, om[3] = {0.f, 0.f, 0.f}, vl[3] = {0.f, 0.f, 0.f};
             quat2mat(this->root + 3, Rb);
@@ -614,10 +619,9 @@ struct HandSim : Sim<M> {
                     });
                 }
             });
-            float* o = out[k];
             sfor<3>([&](auto I_) MI_LAMBDA { o[I_] = this->root[I_] + rb[I_]; o[7 + I_] = vl[I_]; o[10 + I_] = om[I_]; });
             mat2quat(Rb, o + 3);
-        });
+        }
     }
     static constexpr bool is_ancestor_or_self(int a, int b) {
         while (b >= 0) { if (b == a) return true; b = M::parent[b]; }

@@ -11,13 +11,16 @@
 //     the trunk (forearm, wrist, palm: limb 0, two dofs) is recomputed by every wave; its rows (wrist limits, palm contacts) belong to
 //     role TRUNK_ROLE, which also integrates the object.
 //
-//   P1  all roles   trunk going down, own limbs down + up (gravity off on the hand), drives / tendons, limb factor + whitened velocity;
-//                   Schur complement of the limbs on the wrist block, limb-root composite inertias, right-hand-side carry -> LDS      | B1
+//   P1  all roles   trunk going down, own limbs down + up (gravity off on the hand); the NARROW PHASE of a body's spheres runs right
+//                   where the tree pass has its pose (conservative bounding tests skip far bodies / spheres for the whole wave; no
+//                   pose is handed on): the geometry of the kept contacts (normal, lever, velocity target) goes into the limb's OWN
+//                   slots (caps M::limb_kcap, <= BODY_CAP per body); drives / tendons, limb factor + whitened velocity; Schur
+//                   complement of the limbs on the wrist block, limb-root composite inertias, right-hand-side carry -> LDS          | B1
 //   P2  all roles   (redundantly) trunk coming up, wrist factor and whitened velocity; the object's whitened velocity                 | B1b
-//                   (B1b frees the exchange area of P1 / P2: the contact slots and the sweep exchange live in the same LDS)
-//   P3  all roles   joint-limit rows of the own dofs -- kept in REGISTERS (<= 9 rows per role); own object contacts, limb by limb, into
-//                   the limb's OWN slots (caps M::limb_kcap, <= BODY_CAP per body), rows in the fixed shape [limb dofs | wrist dofs]
-//                   shared by every body of the limb (the object part of a row follows from the stored normal and lever)             | B2
+//                   (B1b frees the exchange area of P1 / P2: the contacts' rows live in the same LDS)
+//   P3  all roles   joint-limit rows of the own dofs -- kept in REGISTERS (<= 9 rows per role); the rows of the own contacts, in the
+//                   fixed shape [limb dofs | wrist dofs] shared by every body of the limb (the object part of a row follows from the
+//                   stored normal and lever)                                                                                        | B2
 //   P4  all roles   block sweeps (oracle/physics.c solve_blocks, oracle/hand.c solver 1): every wave Gauss-Seidel over its own rows --
 //                   limb by limb the limit rows, then the limb's contacts in a run-time loop over the lane's ACTUAL contacts; the
 //                   coordinates the blocks share are treated Jacobi-fashion with mass splitting: the wrist pair answers the n_W active
@@ -45,7 +48,7 @@ struct HandSimMW : HandSim<M> {
                          NLIMB = M::NLIMB, NVT = MW::NVT, NTE = MW::NTE, NLR = MW::NLR, NTB = MW::NTB, BODY_CAP = HB::BODY_CAP;
     static_assert(M::FIXED == 1 && OFF == 0 && M::NSPH == 0 && M::limb_of_body[0] == 0, "fixed-base manipulator, limb 0 = the trunk");
     static constexpr int NSH = NVT + 6;                                   // coordinates the blocks share: wrist dofs | object
-    static constexpr int LANES = 32;
+    static constexpr int LANES = 32;                                      // envs per workgroup of the default launch shape (64: one workgroup per CU)
     // ---- limbs
     static constexpr int limb_of_gi(int gi) { return M::limb_of_body[M::dof_body[gi]]; }
     static constexpr int ldof0(int l) { for (int d = 0; d < ND; ++d) if (limb_of_gi(d) == l) return d; return ND; }
@@ -65,38 +68,153 @@ struct HandSimMW : HandSim<M> {
         for (int c = 0; c < M::chain_len[b]; ++c) if (shape_idx(l, M::chain[b][c]) == idx) return true;
         return false;
     }
-    // ---- LDS layout (floats per env).  Region A (P1 / P2 exchange) and region B (contact slots, sweep exchange) share the space.
-    static constexpr int X_LR = 0, X_DT = X_LR + 16 * NLR, X_DY = X_DT + NR * NTE, A_END = X_DY + NR * NVT;
-    static constexpr int cb(int l) { int o = 0; for (int k = 0; k < l; ++k) o += kcap(k) * csz(k); return o; }
-    static constexpr int X_DW = cb(NLIMB);                                // [2][NR][NSH] the block's true contribution to the shared coordinates
+    // ---- LDS layout (floats per env): per contact slot 10 floats of geometry / state (n 3, rc 3, vt_n, lam x3) in one array over all
+    //      limbs, the 3 rows [limb | wrist] in per-limb arrays behind it.  The exchange area of P1 / P2 (region A) aliases the ROWS arrays
+    //      only: geometry is written during P1, rows after B1b.
+    static constexpr int GSZ = 10, G_VT = 6, G_LAM = 7;
+    static constexpr int gslot(int l) { int n = 0; for (int k = 0; k < l; ++k) n += kcap(k); return n; }
+    static constexpr int KTOTAL = gslot(NLIMB);
+    static constexpr int G0 = 0, R0 = G0 + GSZ * KTOTAL;
+    static constexpr int rbase(int l) { int o = R0; for (int k = 0; k < l; ++k) o += kcap(k) * 3 * rl(k); return o; }
+    static constexpr int R_END = rbase(NLIMB);
+    static constexpr int X_LR = R0, X_DT = X_LR + 16 * NLR, X_DY = X_DT + NR * NTE, A_END = X_DY + NR * NVT;
+    static_assert(A_END <= R_END, "the P1 / P2 exchange fits behind the geometry array");
+    static constexpr int X_DW = R_END;                                    // [2][NR][NSH] the block's true contribution to the shared coordinates
     static constexpr int X_FLG = X_DW + 2 * NR * NSH;                     // [2][NR]      block active in this sweep
     static constexpr int X_HASC = X_FLG + 2 * NR;                         // [NR]         block holds a contact (touches the object's coordinates)
     static constexpr int X_CNT = X_HASC + NR;                             // [NLIMB]      contacts kept | refused << 16 (int bits)
-    static constexpr int B_END = X_CNT + NLIMB;
-    static constexpr int MW_SLOTS = A_END > B_END ? A_END : B_END;
-    static_assert((size_t)MW_SLOTS * LANES * sizeof(float) <= 80 * 1024, "two hand workgroups per CU");
-    static constexpr int KTOTAL = []() constexpr { int n = 0; for (int l = 0; l < NLIMB; ++l) n += kcap(l); return n; }();
+    static constexpr int MW_SLOTS = X_CNT + NLIMB;
+    static_assert((size_t)MW_SLOTS * LANES * sizeof(float) <= 80 * 1024, "two 32-env hand workgroups per CU, or one of 64 envs");
+    // ---- conservative bounds for the narrow phase: bounding sphere (centre in the body frame, radius) of the spheres of body b
+    static constexpr float csqrt(float x) { float r = x > 1.f ? x : 1.f; for (int i = 0; i < 40; ++i) r = 0.5f * (r + x / r); return r; }
+    static constexpr float bs_centre(int b, int k) {
+        float s = 0.f; int n = 0;
+        for (int i = 0; i < M::NOS; ++i) if (M::os_body[i] == b) { s += M::os_pos[i][k]; ++n; }
+        return n ? s / (float)n : 0.f;
+    }
+    static constexpr float bs_radius(int b) {
+        float r = 0.f;
+        for (int i = 0; i < M::NOS; ++i) if (M::os_body[i] == b) {
+            const float dx = M::os_pos[i][0] - bs_centre(b, 0), dy = M::os_pos[i][1] - bs_centre(b, 1), dz = M::os_pos[i][2] - bs_centre(b, 2);
+            const float d = csqrt(dx * dx + dy * dy + dz * dz) + M::os_rad[i];
+            r = d > r ? d : r;
+        }
+        return r * 1.001f + 1e-5f;
+    }
+    // what the narrow phase carries through the tree pass
+    struct Narrow {
+        float Ro[9], xo[3];                 // object frame, COM relative to O
+        float reach;                        // bounding radius of the object + contact offset, with a safety margin
+        int cnt[NLIMB], refused[NLIMB];     // contacts kept / refused for want of a slot, per own limb
+        unsigned bfc[B::NOSB > 0 ? B::NOSB : 1];   // per sphere-carrying body: first slot (inside its limb's range) | count << 8
+    };
     // ---- own joint-limit rows (registers)
     template <int R> static constexpr int nownl() { int n = 0; for (int d = 0; d < ND; ++d) n += (M::dof_limited[d] && MW::template owns_gi<R>(d)) ? 1 : 0; return n; }
     template <int R> static constexpr int own_lim_idx(int d) { int n = 0; for (int k = 0; k < d; ++k) n += (M::dof_limited[k] && MW::template owns_gi<R>(k)) ? 1 : 0; return n; }
     struct LimReg { float g[M::MAXCHAIN]; float al, at, vt, lam; };
 
+    // ------------------------------------------------------------------------------------------------ narrow phase of one body's spheres
+    // Spheres in the body's (farthest-point) order; kept: distance below the contact offset, < BODY_CAP on this body, a free slot in the
+    // limb's range.  The two bounding tests only skip work no lane of the wave needs: every evaluated sphere goes through the same
+    // arithmetic as in the one-wave form.
+    template <int SHAPE, int b, int RS>
+    MI_HD void narrow_body(const SimParams& P, const ObjectParams& OP, const float invh, Narrow& nw, const float* Rb, const float* rb, const RowStore<RS> rows) {
+        constexpr int ST = RowStore<RS>::stride;
+        constexpr int l = M::limb_of_body[b], KCAP = kcap(l), GS0 = gslot(l), bs = B::os_slot(b);
+        int& cnt = nw.cnt[l];
+        const int first = cnt;
+        int nbody = 0;
+        nw.bfc[bs] = (unsigned)first;
+        // object COM in the body frame
+        float xb[3];
+        {
+            const float d[3] = {nw.xo[0] - rb[0], nw.xo[1] - rb[1], nw.xo[2] - rb[2]};
+            matTvec3(Rb, d, xb);
+        }
+        {
+            constexpr float bc[3] = {bs_centre(b, 0), bs_centre(b, 1), bs_centre(b, 2)};
+            constexpr float br = bs_radius(b);
+            const float d[3] = {xb[0] - bc[0], xb[1] - bc[1], xb[2] - bc[2]};
+            const float lim = br + nw.reach;
+            if (!MI_WAVE_ANY(dot3(d, d) < lim * lim)) return;
+        }
+        for (int i = 0; i < B::os_count(b); ++i) {
+            const int s = B::os_first(b) + i;
+            const float pl[3] = {M::os_pos[s][0], M::os_pos[s][1], M::os_pos[s][2]};
+            const float rad = M::os_rad[s];
+            {
+                const float d[3] = {xb[0] - pl[0], xb[1] - pl[1], xb[2] - pl[2]};
+                const float lim = rad * 1.001f + nw.reach;
+                if (!MI_WAVE_ANY(dot3(d, d) < lim * lim)) continue;
+            }
+            float t[3], cs[3];
+            matvec3(Rb, pl, t);
+            sfor<3>([&](auto K) MI_LAMBDA { cs[K] = rb[K] + t[K]; });
+            const float rel[3] = {cs[0] - nw.xo[0], cs[1] - nw.xo[1], cs[2] - nw.xo[2]};
+            float cl[3], nloc[3], dist;
+            matTvec3(nw.Ro, rel, cl);
+            HB::template sphere_object<SHAPE>(cl, rad, OP, &dist, nloc);
+            const bool nearc = (dist < P.contact_offset) && (nbody < BODY_CAP);
+            const bool on = nearc && (cnt < KCAP);
+            nw.refused[l] += (nearc && !on) ? 1 : 0;                      // all slots of the limb taken
+            if (on) {
+                float n[3], rc[3];
+                matvec3(nw.Ro, nloc, n);                                 // from the object towards the sphere
+                sfor<3>([&](auto K) MI_LAMBDA { rc[K] = (cs[K] - rad * n[K]) - nw.xo[K]; });
+                float* gp = rows.ptr(G0 + (GS0 + cnt) * GSZ);
+                const float gap = dist - P.rest_offset;
+                sfor<3>([&](auto I_) MI_LAMBDA { gp[I_ * ST] = n[I_]; gp[(3 + I_) * ST] = rc[I_]; });
+                gp[G_VT * ST] = (gap >= 0.f) ? -gap * invh : fminf(-gap * P.erp * invh, P.max_depen_vel);
+                sfor<3>([&](auto K) MI_LAMBDA { gp[(G_LAM + K) * ST] = 0.f; });     // no warm start for object contacts
+            }
+            nbody += on ? 1 : 0;
+            cnt += on ? 1 : 0;
+        }
+        nw.bfc[bs] = (unsigned)first | ((unsigned)nbody << 8);
+    }
+
+    // ------------------------------------------------------------------------------------------------ a body of an own limb: down, narrow phase, children, up
+    template <int SHAPE, int b, int RS>
+    MI_HD void limb_pass(const SimParams& P, const ObjectParams& OP, const float invh, Ctx& c, Narrow& nw, const float* Rp, const float* rp,
+                         const float* Vp, const float* Ap, SpI& Iout, float* Fout, const RowStore<RS> rows) {
+        BodyTmp t;
+        this->template body_down<b>(P, c, Rp, rp, Vp, Ap, t);
+        if constexpr (B::os_count(b) > 0) narrow_body<SHAPE, b>(P, OP, invh, nw, t.Rb, t.rb, rows);
+        sfor<NB>([&](auto C_) MI_LAMBDA {
+            constexpr int ch = C_;
+            if constexpr (ch > b) if constexpr (M::parent[ch] == b) {
+                SpI Ic;
+                float Fc[6];
+                limb_pass<SHAPE, ch>(P, OP, invh, c, nw, t.Rb, t.rb, t.Vc, t.Ac, Ic, Fc, rows);
+                sfor<6>([&](auto K) MI_LAMBDA { t.F[K] += Fc[K]; });
+                t.I.m += Ic.m;
+                sfor<3>([&](auto K) MI_LAMBDA { t.I.h[K] += Ic.h[K]; });
+                sfor<6>([&](auto K) MI_LAMBDA { t.I.I[K] += Ic.I[K]; });
+            }
+        });
+        this->template body_up<b>(c, t);
+        Iout = t.I;
+        sfor<6>([&](auto K) MI_LAMBDA { Fout[K] = t.F[K]; });
+    }
+
     // ------------------------------------------------------------------------------------------------ trunk, going down (as SimMW::trunk_down)
-    template <int R, int b, int RS>
-    MI_HD void trunk_down_h(const SimParams& P, Ctx& c, BodyTmp (&tb)[NTB], const float* Rp, const float* rp, const float* Vp,
-                            const float* Ap, const RowStore<RS> rows) {
+    // P: the hand's parameters (gravity off).  The trunk's own spheres (wrist, palm) are looked at by TRUNK_ROLE.
+    template <int R, int SHAPE, int b, int RS>
+    MI_HD void trunk_down_h(const SimParams& P, const ObjectParams& OP, const float invh, Ctx& c, Narrow& nw, BodyTmp (&tb)[NTB], const float* Rp,
+                            const float* rp, const float* Vp, const float* Ap, const RowStore<RS> rows) {
         constexpr int ts = MW::tslot(b);
         BodyTmp& t = tb[ts];
         this->template body_down<b>(P, c, Rp, rp, Vp, Ap, t);
+        if constexpr (R == M::TRUNK_ROLE && B::os_count(b) > 0) narrow_body<SHAPE, b>(P, OP, invh, nw, t.Rb, t.rb, rows);
         sfor<NB>([&](auto C_) MI_LAMBDA {
             constexpr int ch = C_;
             if constexpr (ch > b) if constexpr (M::parent[ch] == b) {
                 if constexpr (MW::trunk_body(ch)) {
-                    trunk_down_h<R, ch>(P, c, tb, t.Rb, t.rb, t.Vc, t.Ac, rows);
+                    trunk_down_h<R, SHAPE, ch>(P, OP, invh, c, nw, tb, t.Rb, t.rb, t.Vc, t.Ac, rows);
                 } else if constexpr (MW::role_of_body(ch) == R) {     // root of one of my limbs: the whole subtree, down and up
                     SpI Ic;
                     float Fc[6];
-                    this->template body_pass<ch>(P, c, t.Rb, t.rb, t.Vc, t.Ac, Ic, Fc);
+                    limb_pass<SHAPE, ch>(P, OP, invh, c, nw, t.Rb, t.rb, t.Vc, t.Ac, Ic, Fc, rows);
                     constexpr int o = X_LR + 16 * MW::lridx(ch);
                     rows(o) = Ic.m;
                     sfor<3>([&](auto K) MI_LAMBDA { rows(o + 1 + K) = Ic.h[K]; });
@@ -122,19 +240,44 @@ struct HandSimMW : HandSim<M> {
         Ctx c;
         float (&S)[M::NDA][6] = c.S;
         float (&L)[M::NM] = c.L;
-        float pose[12 * (B::NOSB > 0 ? B::NOSB : 1)];       // poses of the sphere-carrying bodies this role passes (static indices: registers)
 #if defined(MI_TIMING)
         unsigned long long* const tstamp = this->tstamp;
 #endif
         MI_STAMP(0);
-        // ============================================================ P1: tree pass with gravity off (disable_gravity on the hand)
+        // the object's frame and whitened velocity (every role alike)
+        const float sm = MI_SQRT(OP.mass), si = MI_SQRT(SHAPE == OBJ_BOX ? OP.inertia : 1.f);
+        const float ism = MI_RCP(sm), isi = MI_RCP(si);
+        float wo[6];
+        sfor<3>([&](auto K) MI_LAMBDA { wo[K] = sm * (obj.vel[K] + h * (P.g[K] + OP.fw[K] * (ism * ism))); wo[3 + K] = si * obj.angvel[K]; });
+        Narrow nw;
+        float (&Ro)[9] = nw.Ro;
+        float (&xo)[3] = nw.xo;
+        quat2mat(obj.quat, Ro);
+        float isqI[3] = {1.f, 1.f, 1.f};
+        if constexpr (SHAPE != OBJ_BOX) {
+            float sqI[3];
+            sfor<3>([&](auto K) MI_LAMBDA { sqI[K] = MI_SQRT(OP.inertia3[K]); isqI[K] = MI_RCP(sqI[K]); });
+            HB::body_diag(Ro, sqI, obj.angvel, wo + 3);
+        }
+        sfor<3>([&](auto K) MI_LAMBDA { xo[K] = obj.pos[K] - root[K]; });                         // object COM rel O
+        {   // bounding radius of the object (box: half diagonal; capsule: radius + half length; ellipsoid: largest semi-axis)
+            float ro;
+            if constexpr (SHAPE == OBJ_BOX) ro = 1.7320508f * OP.half;
+            else if constexpr (SHAPE == OBJ_CAPSULE) ro = OP.dims[0] + OP.dims[1];
+            else ro = fmaxf(OP.dims[0], fmaxf(OP.dims[1], OP.dims[2]));
+            nw.reach = ro * 1.001f + P.contact_offset + 1e-5f;
+        }
+        sfor<NLIMB>([&](auto L_) MI_LAMBDA { nw.cnt[L_] = 0; nw.refused[L_] = 0; });
+        sfor<B::NOSB>([&](auto K) MI_LAMBDA { nw.bfc[K] = 0u; });
+        // ============================================================ P1: tree pass with gravity off (disable_gravity on the hand) + narrow phase
         BodyTmp tb[NTB];
         {
             SimParams P0 = P;
             P0.g[0] = P0.g[1] = P0.g[2] = 0.f;
-            c.pose_out = pose;
-            c.pose_stride = 1;
-            trunk_down_h<R, 0>(P0, c, tb, nullptr, nullptr, nullptr, nullptr, rows);
+            float pose_sink;                      // (the one-wave form's pose hand-off: nobody reads it here)
+            c.pose_out = &pose_sink;
+            c.pose_stride = 0;
+            trunk_down_h<R, SHAPE, 0>(P0, OP, invh, c, nw, tb, nullptr, nullptr, nullptr, nullptr, rows);
         }
         MI_PHASE();
         float Ldi[NVA], y[NVA], w[NVA], v[NVA];
@@ -244,20 +387,6 @@ struct HandSimMW : HandSim<M> {
         });
         sfor_rev<NV>([&](auto K_) MI_LAMBDA { if constexpr (MW::trunk_gi(K_)) factor(K_); });
         sfor_rev<NV>([&](auto I_) MI_LAMBDA { if constexpr (MW::trunk_gi(I_)) whiten(I_); });
-        // the object's whitened velocity (every role alike)
-        const float sm = MI_SQRT(OP.mass), si = MI_SQRT(SHAPE == OBJ_BOX ? OP.inertia : 1.f);
-        const float ism = MI_RCP(sm), isi = MI_RCP(si);
-        float wo[6];
-        sfor<3>([&](auto K) MI_LAMBDA { wo[K] = sm * (obj.vel[K] + h * (P.g[K] + OP.fw[K] * (ism * ism))); wo[3 + K] = si * obj.angvel[K]; });
-        float Ro[9];
-        quat2mat(obj.quat, Ro);
-        float isqI[3] = {1.f, 1.f, 1.f};
-        if constexpr (SHAPE != OBJ_BOX) {
-            float sqI[3];
-            sfor<3>([&](auto K) MI_LAMBDA { sqI[K] = MI_SQRT(OP.inertia3[K]); isqI[K] = MI_RCP(sqI[K]); });
-            HB::body_diag(Ro, sqI, obj.angvel, wo + 3);
-        }
-        const float xo[3] = {obj.pos[0] - root[0], obj.pos[1] - root[1], obj.pos[2] - root[2]};   // object COM rel O
         MI_STAMP(3);
         bar();                                                                                       // ---- B1b: region A is dead
         MI_STAMP(4);
@@ -310,62 +439,26 @@ struct HandSimMW : HandSim<M> {
         });
         MI_PHASE();
         MI_STAMP(5);
-        // ============================================================ P3: own object contacts -> the limbs' slots
-        int cntl[NLIMB];                    // contacts of every own limb
-        sfor<NLIMB>([&](auto L_) MI_LAMBDA { cntl[L_] = 0; });
-        unsigned sensfc[M::NSENSA];         // fingertip (sensor) bodies: first slot | count << 8 inside their limb's slots
-        sfor<NSENS>([&](auto K) MI_LAMBDA { sensfc[K] = 0u; });
+        // ============================================================ P3: rows of the own contacts (geometry in the slots since P1)
         float hasc = 0.f;
         sfor<NLIMB>([&](auto L_) MI_LAMBDA {
             constexpr int l = L_;
             if constexpr (limb_role(l) == R) {
-                constexpr int NL = nl(l), RL = rl(l), CSZ = csz(l), CB0 = cb(l), KCAP = kcap(l), D0 = ldof0(l);
-                constexpr int GEO = 3 * RL, AUX = GEO + 6;
-                int cnt = 0, refused = 0;
+                constexpr int RL = rl(l), GS0 = gslot(l), RB0 = rbase(l);
                 sfor<NB>([&](auto B_) MI_LAMBDA {
                     constexpr int b = B_;
                     if constexpr (M::limb_of_body[b] == l && B::os_count(b) > 0) {
                         constexpr int CL = M::chain_len[b];
                         MI_PHASE();
-                        float Rb[9], rb[3];
-                        sfor<9>([&](auto I_) MI_LAMBDA { Rb[I_] = pose[12 * B::os_slot(b) + I_]; });
-                        sfor<3>([&](auto I_) MI_LAMBDA { rb[I_] = pose[12 * B::os_slot(b) + 9 + I_]; });
-                        int nbody = 0;
-                        const int first = cnt;
-                        for (int i = 0; i < B::os_count(b); ++i) {
-                            const int s = B::os_first(b) + i;
-                            const float pl[3] = {M::os_pos[s][0], M::os_pos[s][1], M::os_pos[s][2]};
-                            const float rad = M::os_rad[s];
-                            float t[3], cs[3];
-                            matvec3(Rb, pl, t);
-                            sfor<3>([&](auto K) MI_LAMBDA { cs[K] = rb[K] + t[K]; });
-                            const float rel[3] = {cs[0] - xo[0], cs[1] - xo[1], cs[2] - xo[2]};
-                            float cl[3], nloc[3], dist;
-                            matTvec3(Ro, rel, cl);
-                            HB::template sphere_object<SHAPE>(cl, rad, OP, &dist, nloc);
-                            const bool nearc = (dist < P.contact_offset) && (nbody < BODY_CAP);
-                            const bool on = nearc && (cnt < KCAP);
-                            refused += (nearc && !on) ? 1 : 0;                  // all slots of the limb taken
-                            if (on) {      // narrow phase only: the contact's geometry goes into its slot, the rows are built below
-                                float n[3], rc[3];
-                                matvec3(Ro, nloc, n);                   // from the object towards the sphere
-                                sfor<3>([&](auto K) MI_LAMBDA { rc[K] = (cs[K] - rad * n[K]) - xo[K]; });
-                                float* cbp = rows.ptr(CB0 + cnt * CSZ);
-                                const float gap = dist - P.rest_offset;
-                                sfor<3>([&](auto I_) MI_LAMBDA { cbp[(GEO + I_) * ST] = n[I_]; cbp[(GEO + 3 + I_) * ST] = rc[I_]; });
-                                cbp[AUX * ST] = (gap >= 0.f) ? -gap * invh : fminf(-gap * P.erp * invh, P.max_depen_vel);
-                            }
-                            nbody += on ? 1 : 0;
-                            cnt += on ? 1 : 0;
-                        }
-                        // rows of this body's contacts, walked by contact (at most BODY_CAP, left by the whole wave as soon as no env has an
-                        // (i+1)-th one): the union of touched spheres of a body is several times larger than the largest per-env count on it
+                        const int first = (int)(nw.bfc[B::os_slot(b)] & 255u), nbody = (int)(nw.bfc[B::os_slot(b)] >> 8);
+                        // walked by contact (at most BODY_CAP, left by the whole wave as soon as no env has an (i+1)-th one on this body)
                         for (int i = 0; i < BODY_CAP; ++i) {
                             if (!MI_WAVE_ANY(i < nbody)) break;
                             if (i < nbody) {
-                                float* cbp = rows.ptr(CB0 + (first + i) * CSZ);
+                                const float* gp = rows.ptr(G0 + (GS0 + first + i) * GSZ);
+                                float* rp_ = rows.ptr(RB0 + (first + i) * 3 * RL);
                                 float fr[3][3], pc[3];
-                                sfor<3>([&](auto I_) MI_LAMBDA { fr[0][I_] = cbp[(GEO + I_) * ST]; pc[I_] = cbp[(GEO + 3 + I_) * ST] + xo[I_]; });
+                                sfor<3>([&](auto I_) MI_LAMBDA { fr[0][I_] = gp[I_ * ST]; pc[I_] = gp[(3 + I_) * ST] + xo[I_]; });
                                 contact_frame(fr[0], fr[1], fr[2]);
                                 sfor<3>([&](auto K) MI_LAMBDA {
                                     constexpr int k = K;
@@ -384,19 +477,15 @@ struct HandSimMW : HandSim<M> {
                                             g[kk] -= L[M::midx[ii][jj]] * z;
                                         });
                                     });
-                                    sfor<CL>([&](auto C) MI_LAMBDA { constexpr int idx = shape_idx(l, M::chain[b][C]); cbp[(k * RL + idx) * ST] = g[C]; });
-                                    sfor<RL>([&](auto I_) MI_LAMBDA { if constexpr (!in_chain(b, l, I_)) cbp[(k * RL + I_) * ST] = 0.f; });   // the rest of the fixed shape
-                                    cbp[(AUX + 1 + k) * ST] = 0.f;      // no warm start for object contacts
+                                    sfor<CL>([&](auto C) MI_LAMBDA { constexpr int idx = shape_idx(l, M::chain[b][C]); rp_[(k * RL + idx) * ST] = g[C]; });
+                                    sfor<RL>([&](auto I_) MI_LAMBDA { if constexpr (!in_chain(b, l, I_)) rp_[(k * RL + I_) * ST] = 0.f; });   // the rest of the fixed shape
                                 });
                             }
                         }
-                        if constexpr (B::sensor_of(b) >= 0) { constexpr int k = B::sensor_of(b); sensfc[k] = (unsigned)first | ((unsigned)nbody << 8); }
                     }
                 });
-                cntl[l] = cnt;
-                hasc = (cnt > 0) ? 1.f : hasc;
-                rows(X_CNT + l) = __builtin_bit_cast(float, cnt | (refused << 16));
-                (void)NL; (void)D0;
+                hasc = (nw.cnt[l] > 0) ? 1.f : hasc;
+                rows(X_CNT + l) = __builtin_bit_cast(float, nw.cnt[l] | (nw.refused[l] << 16));
             }
         });
         act = (hasc > 0.f) ? 1.f : act;
@@ -458,22 +547,22 @@ struct HandSimMW : HandSim<M> {
                             }
                         });
                         // ---- the limb's contacts: a lane's j-th contact, whichever body it is on (fixed row shape [limb | wrist])
-                        constexpr int NL = nl(l), RL = rl(l), CSZ = csz(l), CB0 = cb(l), KCAP = kcap(l), D0 = ldof0(l);
-                        constexpr int GEO = 3 * RL, AUX = GEO + 6;
-                        const int cnt = cntl[l];
+                        constexpr int NL = nl(l), RL = rl(l), GS0 = gslot(l), RB0 = rbase(l), KCAP = kcap(l), D0 = ldof0(l);
+                        const int cnt = nw.cnt[l];
                         for (int j = 0; j < KCAP; ++j) {
                             const bool onj = j < cnt;
                             if (!MI_WAVE_ANY(onj)) break;
                             if (onj) {
-                                float* cbp = rit.ptr(CB0 + j * CSZ);
+                                float* gp = rit.ptr(G0 + (GS0 + j) * GSZ);
+                                const float* rp_ = rit.ptr(RB0 + j * 3 * RL);
                                 float g[3][RL], go[3][6], lm[3];
                                 sfor<3>([&](auto K) MI_LAMBDA {
-                                    sfor<RL>([&](auto C) MI_LAMBDA { g[K][C] = cbp[(K * RL + C) * ST]; });
-                                    lm[K] = cbp[(AUX + 1 + K) * ST];
+                                    sfor<RL>([&](auto C) MI_LAMBDA { g[K][C] = rp_[(K * RL + C) * ST]; });
+                                    lm[K] = gp[(G_LAM + K) * ST];
                                 });
                                 {   // object part of the three rows from the stored normal and lever (unscaled: the whitening scales go in below)
                                     float fr[3][3], rc[3];
-                                    sfor<3>([&](auto I_) MI_LAMBDA { fr[0][I_] = cbp[(GEO + I_) * ST]; rc[I_] = cbp[(GEO + 3 + I_) * ST]; });
+                                    sfor<3>([&](auto I_) MI_LAMBDA { fr[0][I_] = gp[I_ * ST]; rc[I_] = gp[(3 + I_) * ST]; });
                                     contact_frame(fr[0], fr[1], fr[2]);
                                     sfor<3>([&](auto K) MI_LAMBDA {
                                         float cx[3];
@@ -482,7 +571,7 @@ struct HandSimMW : HandSim<M> {
                                         sfor<3>([&](auto I_) MI_LAMBDA { go[K][I_] = -fr[K][I_]; go[K][3 + I_] = -cx[I_]; });
                                     });
                                 }
-                                const float vtn = cbp[AUX * ST];
+                                const float vtn = gp[G_VT * ST];
                                 float ainv[3];
                                 sfor<3>([&](auto K) MI_LAMBDA {
                                     float a = P.cfm, at = 0.f;
@@ -518,13 +607,13 @@ struct HandSimMW : HandSim<M> {
                                 const float lim = OP.mu * ln;
                                 const float n2 = lt[0] * lt[0] + lt[1] * lt[1];
                                 const float sc = (n2 > lim * lim) ? lim * MI_RSQ(fmaxf(n2, 1e-30f)) : 1.f;
-                                cbp[(AUX + 1) * ST] = ln;
+                                gp[G_LAM * ST] = ln;
                                 actn = (ln > 0.f) ? 1.f : actn;
-                                sfor<2>([&](auto K) MI_LAMBDA {
-                                    const float nl_ = lt[K] * sc;
-                                    cbp[(AUX + 2 + K) * ST] = nl_;
-                                    apply(1 + K, nl_ - lt[K]);
-                                });
+                                const bool slide = sc != 1.f;
+                                sfor<2>([&](auto K) MI_LAMBDA { gp[(G_LAM + 1 + K) * ST] = lt[K] * sc; });
+                                if (MI_WAVE_ANY(slide)) {       // (sticking contacts: the correction is zero -- skipped when no lane of the wave slides)
+                                    sfor<2>([&](auto K) MI_LAMBDA { apply(1 + K, lt[K] * sc - lt[K]); });
+                                }
                             }
                         }
                     }
@@ -571,20 +660,19 @@ struct HandSimMW : HandSim<M> {
         sfor<NSENS>([&](auto K_) MI_LAMBDA {
             constexpr int k = K_, b = M::sens_body[k], l = M::limb_of_body[b];
             if constexpr (limb_role(l) == R) {
-                constexpr int RL = rl(l), CSZ = csz(l), CB0 = cb(l), GEO = 3 * RL, AUX = GEO + 6;
+                constexpr int GS0 = gslot(l);
                 float sens[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 if constexpr (B::os_count(b) > 0) {
-                    float Rb[9], rb[3];
-                    sfor<9>([&](auto I_) MI_LAMBDA { Rb[I_] = pose[12 * B::os_slot(b) + I_]; });
-                    sfor<3>([&](auto I_) MI_LAMBDA { rb[I_] = pose[12 * B::os_slot(b) + 9 + I_]; });
-                    const int first = (int)(sensfc[k] & 255u), nb_ = (int)(sensfc[k] >> 8);
+                    const float (&Rb)[9] = c.Rs[k];          // the fingertip's frame, kept by the tree pass (force-sensor body)
+                    const float (&rb)[3] = c.rs[k];
+                    const int first = (int)(nw.bfc[B::os_slot(b)] & 255u), nb_ = (int)(nw.bfc[B::os_slot(b)] >> 8);
                     for (int i = 0; i < BODY_CAP; ++i) {
                         if (!MI_WAVE_ANY(i < nb_)) break;
                         if (i < nb_) {
-                            const float* cbp = rows.ptr(CB0 + (first + i) * CSZ);
-                            const float ln = cbp[(AUX + 1) * ST], l1 = cbp[(AUX + 2) * ST], l2 = cbp[(AUX + 3) * ST];
+                            const float* gp = rows.ptr(G0 + (GS0 + first + i) * GSZ);
+                            const float ln = gp[G_LAM * ST], l1 = gp[(G_LAM + 1) * ST], l2 = gp[(G_LAM + 2) * ST];
                             float n[3], t1[3], t2[3], rc[3];
-                            sfor<3>([&](auto K) MI_LAMBDA { n[K] = cbp[(GEO + K) * ST]; rc[K] = cbp[(GEO + 3 + K) * ST]; });
+                            sfor<3>([&](auto K) MI_LAMBDA { n[K] = gp[K * ST]; rc[K] = gp[(3 + K) * ST]; });
                             contact_frame(n, t1, t2);
                             float f[3], arm[3], tq[3], fl[3], tl[3];
                             sfor<3>([&](auto K) MI_LAMBDA {

@@ -1,7 +1,10 @@
 // hand_mw_kernels.hpp -- the finger-per-wave Shadow-Hand sub-step (core/hand_engine_mw.hpp) and its launcher, a template over the object's
 // shape.  Included by kernels_shadow_hand_mw*.hip (one shape per translation unit: they compile in parallel).  blockDim = (64, NROLE):
-// wave y = role y, lanes 0 .. 31 of every wave hold the same 32 envs (the upper lanes retire at once: barriers count waves); two
-// workgroups per CU (<= 80 KB of LDS each), i.e. 16384 envs = 512 workgroups are resident at once with two waves on every SIMD.
+// wave y = role y, lanes 0 .. E-1 of every wave hold the same E envs.  E = 32 (option multi_wave 32): the upper lanes retire at once
+// (barriers count waves), two workgroups per CU (<= 80 KB of LDS each), two half-filled waves on every SIMD once 8192 envs are
+// exceeded.  E = 64 (multi_wave 64): full waves, one workgroup per CU (160 KB of LDS), one wave per SIMD with 512 registers -- the
+// sub-step is bound by the SIMDs' VALU issue (4 cycles per wave instruction whether 32 or 64 lanes are live), so at 16384 envs this
+// form executes half the wave instructions per env.
 #pragma once
 #include "hand_kernels.hpp"
 #include "mw_kernels.hpp"          // DevBarrier
@@ -10,13 +13,14 @@
 namespace mi {
 
 using HSW = HandSimMW<HM>;
-constexpr size_t hand_mw_lds_bytes() { return (size_t)HSW::MW_SLOTS * HSW::LANES * sizeof(float); }
+template <int E>
+constexpr size_t hand_mw_lds_bytes() { return (size_t)HSW::MW_SLOTS * E * sizeof(float); }
 
 #if defined(MI_TIMING)
 __device__ unsigned long long* g_mi_tstamp_hmw = nullptr;     // debug builds: per workgroup and role 16 s_memtime stamps
 #endif
 
-template <int SHAPE, int R>
+template <int SHAPE, int E, int R>
 __device__ __forceinline__ void hand_mw_role(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, float* lds_rows,
                                              const int e, const int lane) {
     using MW = SimMW<HM>;
@@ -52,7 +56,7 @@ __device__ __forceinline__ void hand_mw_role(const View& v, const HandView& hv, 
 #endif
     const float h = P.dt / (float)P.substeps;
     int nc = 0;
-    sim.template substep_hand_role<R, HSW::LANES, SHAPE>(P, OP, target, h, RowStore<HSW::LANES>{lds_rows + lane}, Strided{v.laml + e, N},
+    sim.template substep_hand_role<R, E, SHAPE>(P, OP, target, h, RowStore<E>{lds_rows + lane}, Strided{v.laml + e, N},
                                                          Strided{v.sensor + e, N}, Strided{v.dof_force + e, N}, &nc, DevBarrier{});
     sfor<ND>([&](auto K) MI_LAMBDA {
         if constexpr (MW::template owns_gi<R>(K)) { v.dof[K * N + e] = sim.q[K]; v.dof[(ND + K) * N + e] = sim.qd[K]; }
@@ -74,43 +78,66 @@ struct HandMwArgs {
     SimParams P;
     HandParams p;
 };
-template <int SHAPE>
-__global__ __launch_bounds__(64 * HM::NROLE) __attribute__((amdgpu_waves_per_eu(2, 2))) void hand_substep_mw_kernel(HandMwArgs args_by_value) {
-    extern __shared__ float lds_rows[];   // [MW_SLOTS][32]
+template <int SHAPE, int E>
+__device__ __forceinline__ void hand_mw_body(float* lds_rows) {
     static_assert(HM::NROLE == 4, "four roles, one per SIMD of a CU");
 #if defined(__HIP_DEVICE_COMPILE__)
-    (void)args_by_value;
     const HandMwArgs& a = *reinterpret_cast<const HandMwArgs*>(__builtin_amdgcn_kernarg_segment_ptr());
-#else
-    const HandMwArgs& a = args_by_value;       // (host pass of the compiler: never executed)
-#endif
-    constexpr int E = HSW::LANES;
     const int lane = threadIdx.x;
     if (lane >= E) return;
     const int e = xcd_env_base<E>(blockIdx.x) + lane;
     if (e >= a.v.N) return;                 // all four waves hold the same envs and agree on this
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.y);
 #if defined(MI_HMW_ONLY_ROLE)     // tools/debug only: resource usage of one role's instruction stream
-    if (role == MI_HMW_ONLY_ROLE) hand_mw_role<SHAPE, MI_HMW_ONLY_ROLE>(a.v, a.hv, a.P, a.p, lds_rows, e, lane);
+    if (role == MI_HMW_ONLY_ROLE) hand_mw_role<SHAPE, E, MI_HMW_ONLY_ROLE>(a.v, a.hv, a.P, a.p, lds_rows, e, lane);
 #else
     switch (role) {
-        case 0: hand_mw_role<SHAPE, 0>(a.v, a.hv, a.P, a.p, lds_rows, e, lane); break;
-        case 1: hand_mw_role<SHAPE, 1>(a.v, a.hv, a.P, a.p, lds_rows, e, lane); break;
-        case 2: hand_mw_role<SHAPE, 2>(a.v, a.hv, a.P, a.p, lds_rows, e, lane); break;
-        default: hand_mw_role<SHAPE, 3>(a.v, a.hv, a.P, a.p, lds_rows, e, lane); break;
+        case 0: hand_mw_role<SHAPE, E, 0>(a.v, a.hv, a.P, a.p, lds_rows, e, lane); break;
+        case 1: hand_mw_role<SHAPE, E, 1>(a.v, a.hv, a.P, a.p, lds_rows, e, lane); break;
+        case 2: hand_mw_role<SHAPE, E, 2>(a.v, a.hv, a.P, a.p, lds_rows, e, lane); break;
+        default: hand_mw_role<SHAPE, E, 3>(a.v, a.hv, a.P, a.p, lds_rows, e, lane); break;
     }
+#endif
+#else
+    (void)lds_rows;
+#endif
+}
+// (the kernel arguments are read through the kernarg segment pointer inside hand_mw_body; the host pass of the compiler never executes it)
+template <int SHAPE>
+__global__ __launch_bounds__(64 * HM::NROLE) __attribute__((amdgpu_waves_per_eu(2, 2))) void hand_substep_mw_kernel(HandMwArgs args_by_value) {
+    extern __shared__ float lds_rows[];   // [MW_SLOTS][32]
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)args_by_value;
+    hand_mw_body<SHAPE, 32>(lds_rows);
+#endif
+}
+template <int SHAPE>
+__global__ __launch_bounds__(64 * HM::NROLE) __attribute__((amdgpu_waves_per_eu(1, 1))) void hand_substep_mw64_kernel(HandMwArgs args_by_value) {
+    extern __shared__ float lds_rows[];   // [MW_SLOTS][64]
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)args_by_value;
+    hand_mw_body<SHAPE, 64>(lds_rows);
 #endif
 }
 
 template <int SHAPE>
 inline hipError_t hand_substeps_mw_shape(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s) {
-    constexpr size_t lds = hand_mw_lds_bytes();
-    constexpr int E = HSW::LANES;
-    static unsigned long long configured = 0ull;
-    auto kern = hand_substep_mw_kernel<SHAPE>;
-    if (hipError_t e = ensure_dynamic_lds((const void*)kern, lds, &configured); e != hipSuccess) return e;
-    const dim3 grid(xcd_grid<E>(v.N)), block(64, HM::NROLE);
-    for (int i = 0; i < n; ++i) hipLaunchKernelGGL(kern, grid, block, lds, s, HandMwArgs{v, hv, P, p});
+    static unsigned long long conf32 = 0ull, conf64 = 0ull;
+    const dim3 block(64, HM::NROLE);
+    if (v.mw == 64) {
+        constexpr size_t lds = hand_mw_lds_bytes<64>();
+        static_assert(lds <= 160 * 1024, "one 64-env hand workgroup per CU");
+        auto kern = hand_substep_mw64_kernel<SHAPE>;
+        if (hipError_t e = ensure_dynamic_lds((const void*)kern, lds, &conf64); e != hipSuccess) return e;
+        const dim3 grid(xcd_grid<64>(v.N));
+        for (int i = 0; i < n; ++i) hipLaunchKernelGGL(kern, grid, block, lds, s, HandMwArgs{v, hv, P, p});
+    } else {
+        constexpr size_t lds = hand_mw_lds_bytes<32>();
+        auto kern = hand_substep_mw_kernel<SHAPE>;
+        if (hipError_t e = ensure_dynamic_lds((const void*)kern, lds, &conf32); e != hipSuccess) return e;
+        const dim3 grid(xcd_grid<32>(v.N));
+        for (int i = 0; i < n; ++i) hipLaunchKernelGGL(kern, grid, block, lds, s, HandMwArgs{v, hv, P, p});
+    }
     return hipGetLastError();
 }
 

@@ -122,7 +122,39 @@ __global__ __launch_bounds__(64) void hand_pre_kernel(View v, HandView hv, HandP
     }
 }
 
-// post_physics_step (shadow_hand.py:710-715): progress++, compute_observations (full_state), compute_reward
+// gym.refresh_rigid_body_state_tensor (shadow_hand.py:440,456-457) for the five fingertip bodies: ONE THREAD PER (env, fingertip) -- blockIdx.y is
+// the fingertip, so a wave walks one chain (wrist + one finger, 6 or 7 hinges) and 5 N / 64 waves fill the chip, where the post kernel's
+// one lane per env walked all five chains in turn on 256 waves (latency-bound: 40 of its 61 us at 16384 envs).
+template <int K>
+__device__ __forceinline__ void hand_tip(const View& v, const HandView& hv, const HandParams& p, const int e) {
+    constexpr int ND = kHandDof, tip = HM::sens_body[K];
+    const int N = v.N;
+    HS sim;
+    sfor<3>([&](auto I_) MI_LAMBDA { sim.root[I_] = p.hand_pos[I_]; });
+    sfor<4>([&](auto I_) MI_LAMBDA { sim.root[3 + I_] = p.hand_quat[I_]; });
+    sfor<ND>([&](auto D) MI_LAMBDA {
+        if constexpr (HS::is_ancestor_or_self(HM::dof_body[D], tip)) { sim.q[D] = v.dof[D * N + e]; sim.qd[D] = v.dof[(ND + D) * N + e]; }
+    });
+    float o[13];
+    sim.template fingertip_state<K>(o);
+    sfor<13>([&](auto I_) MI_LAMBDA { hv.fingertip[(K * 13 + I_) * N + e] = o[I_]; });
+}
+__global__ __launch_bounds__(64) void hand_tips_kernel(View v, HandView hv, HandParams p) {
+    MI_NO_CONTRACT
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= v.N) return;
+    static_assert(kHandTips == 5, "five fingertips");
+    switch (blockIdx.y) {
+        case 0: hand_tip<0>(v, hv, p, e); break;
+        case 1: hand_tip<1>(v, hv, p, e); break;
+        case 2: hand_tip<2>(v, hv, p, e); break;
+        case 3: hand_tip<3>(v, hv, p, e); break;
+        default: hand_tip<4>(v, hv, p, e); break;
+    }
+}
+
+// post_physics_step (shadow_hand.py:710-715): progress++, compute_observations (full_state), compute_reward; the fingertip states come
+// from hand_tips_kernel
 __global__ __launch_bounds__(64) void hand_post_kernel(View v, HandView hv, HandParams p) {
     MI_NO_CONTRACT
     constexpr int ND = kHandDof;
@@ -130,16 +162,10 @@ __global__ __launch_bounds__(64) void hand_post_kernel(View v, HandView hv, Hand
     const int e0 = post_env_index<HS::LANES>(blockIdx.x, threadIdx.x, N);
     const bool valid = e0 < N;
     const int e = valid ? e0 : N - 1;
-    HS sim;
-    sfor<3>([&](auto K) MI_LAMBDA { sim.root[K] = p.hand_pos[K]; });
-    sfor<4>([&](auto K) MI_LAMBDA { sim.root[3 + K] = p.hand_quat[K]; });
-    sfor<ND>([&](auto K) MI_LAMBDA { sim.q[K] = v.dof[K * N + e]; sim.qd[K] = v.dof[(ND + K) * N + e]; });
+    float q[ND], qd[ND];
+    sfor<ND>([&](auto K) MI_LAMBDA { q[K] = v.dof[K * N + e]; qd[K] = v.dof[(ND + K) * N + e]; });
     float tips[kHandTips][13];
-    sim.fingertip_states(tips);                                    // gym.refresh_rigid_body_state_tensor (:440)
-    // A never-taken block that "modifies" the 65 fingertip values: they pass through phi nodes here, which splits the kernel into the
-    // kinematics pass and the observation / reward part for the register allocator -- 139 spilled VGPRs and 468 B of scratch per lane
-    // without it, none with it (-6 us on the kernel).
-    { int pz; MI_OPAQUE_ZERO(pz); if (pz != 0) { _Pragma("unroll") for (int t = 0; t < kHandTips; ++t) { _Pragma("unroll") for (int k = 0; k < 13; ++k) asm volatile("" : "+v"(tips[t][k])); } } }
+    sfor<kHandTips>([&](auto T_) MI_LAMBDA { sfor<13>([&](auto K) MI_LAMBDA { tips[T_][K] = hv.fingertip[(T_ * 13 + K) * N + e]; }); });
     float os[13], gp[7], act[kHandAct], dff[ND], sns[6 * kHandTips];
     // every input is loaded before the first observation is stored: the stores below may alias these arrays as far as the
     // compiler knows, and a load that has to wait for them is a fully exposed memory round trip for a lone wave
@@ -163,8 +189,8 @@ __global__ __launch_bounds__(64) void hand_post_kernel(View v, HandView hv, Hand
     auto emit = [&](int k, float val) MI_LAMBDA { stage[k * 65 + (int)threadIdx.x] = val; };
     sfor<ND>([&](auto D) MI_LAMBDA {
         constexpr int d = D;
-        emit(d, (2.0f * sim.q[d] - HM::dof_upper[d] - HM::dof_lower[d]) / (HM::dof_upper[d] - HM::dof_lower[d]));   // unscale
-        emit(ND + d, p.vel_obs_scale * sim.qd[d]);
+        emit(d, (2.0f * q[d] - HM::dof_upper[d] - HM::dof_lower[d]) / (HM::dof_upper[d] - HM::dof_lower[d]));   // unscale
+        emit(ND + d, p.vel_obs_scale * qd[d]);
         emit(2 * ND + d, p.force_torque_obs_scale * dff[d]);
     });
     sfor<7>([&](auto K) MI_LAMBDA { emit(72 + K, os[K]); });
@@ -179,7 +205,6 @@ __global__ __launch_bounds__(64) void hand_post_kernel(View v, HandView hv, Hand
     sfor<kHandTips>([&](auto T_) MI_LAMBDA {
         sfor<13>([&](auto K) MI_LAMBDA {
             emit(96 + T_ * 13 + K, tips[T_][K]);
-            if (valid) hv.fingertip[(T_ * 13 + K) * N + e] = tips[T_][K];
         });
     });
     sfor<6 * kHandTips>([&](auto K) MI_LAMBDA { emit(161 + K, p.force_torque_obs_scale * sns[K]); });
@@ -296,13 +321,16 @@ hipError_t launch_step_shadow_hand(const View& v, const HandView& hv, const SimP
     hipLaunchKernelGGL(hand_pre_kernel, dim3((v.N + 63) / 64), dim3(64), 0, s, v, hv, p, actions, step_counter);
     hipError_t e = hand_substeps(v, hv, P, p, cfi * P.substeps, s);
     if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(hand_tips_kernel, dim3((v.N + 63) / 64, kHandTips), dim3(64), 0, s, v, hv, p);
     hipLaunchKernelGGL(hand_post_kernel, dim3((v.N + 63) / 64), dim3(64), 0, s, v, hv, p);
     if (p.obs_type != 0) hipLaunchKernelGGL(hand_obs_select_kernel, dim3((v.N * p.num_obs + 255) / 256), dim3(256), 0, s, v, hv, p);
     hipLaunchKernelGGL(hand_finalize_kernel, dim3(1), dim3(64), 0, s, hv, p);
     return hipGetLastError();
 }
 hipError_t launch_simulate_shadow_hand(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, hipStream_t s) {
-    return hand_substeps(v, hv, P, p, P.substeps, s);
+    if (hipError_t e = hand_substeps(v, hv, P, p, P.substeps, s); e != hipSuccess) return e;
+    hipLaunchKernelGGL(hand_tips_kernel, dim3((v.N + 63) / 64, kHandTips), dim3(64), 0, s, v, hv, p);      // refresh_rigid_body_state_tensor
+    return hipGetLastError();
 }
 hipError_t launch_init_shadow_hand(const View& v, const HandView& hv, const HandParams& p, hipStream_t s) {
     hipLaunchKernelGGL(hand_init_kernel, dim3((v.N + 127) / 128), dim3(128), 0, s, v, hv, p);

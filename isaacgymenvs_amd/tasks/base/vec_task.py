@@ -184,9 +184,13 @@ class VecTask(Env):
         mw = os.environ.get("MI_MULTI_WAVE") or self.cfg["sim"].get("multi_wave", "auto")     # the env var: A/B runs and profiling
         if mw == "auto":
             mw = 16 if self.num_envs <= 4096 else (32 if self.num_envs <= 8192 else 0)
-            if self.native_task in ("Humanoid", "ShadowHand"):
-                mw = 32          # Humanoid: limb waves + pair wave (csrc/mwc_kernels.hpp); ShadowHand: finger per wave (csrc/hand_mw_kernels.hpp) -- at any env count
-        for cand in (int(mw), 32):
+            if self.native_task == "Humanoid":
+                mw = 32          # limb waves + pair wave (csrc/mwc_kernels.hpp), at any env count
+            if self.native_task == "ShadowHand":
+                # finger per wave (csrc/hand_mw_kernels.hpp): 32 envs per workgroup (two half-filled waves per SIMD) while that fills the
+                # chip (one workgroup per CU up to 8192 envs), full 64-env waves (half the wave instructions per env) from there on -- profiles/r3l_hand_mw_ab_0_32_64.txt
+                mw = 64 if self.num_envs >= 8192 else 32
+        for cand in (int(mw), 32):     # (a value the task's kernels do not take falls back to 32)
             try:
                 self.engine.set_option("multi_wave", cand)
                 return

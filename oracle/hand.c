@@ -325,3 +325,33 @@ void or_hand_step(const OrModel *m, const OrParams *p, const OrHand *hd, int nen
                          dof_force + (size_t)e * nd, ncontacts + e, limb_counts ? limb_counts + (size_t)e * hd->nlimb : NULL);
     }
 }
+
+/* world pos, quat xyzw, linear and angular velocity of the sensor (fingertip) bodies of every env: out [nenv][nsens][13]
+ * (gym.refresh_rigid_body_state_tensor, shadow_hand.py:440,456-457; the batch form of oracle/hand.py fingertip_states) */
+static void h_mat2quat(const real *R, real *q) {       /* isaacgymenvs_amd/assets/model.py mat_to_quat: Shepperd, w >= 0 branch first */
+    real tr = R[0] + R[4] + R[8], x, y, z, w;
+    if (tr > 0) { real s = RSQRT(tr + 1) * 2; w = s / 4; x = (R[7] - R[5]) / s; y = (R[2] - R[6]) / s; z = (R[3] - R[1]) / s; }
+    else if (R[0] > R[4] && R[0] > R[8]) { real s = RSQRT(1 + R[0] - R[4] - R[8]) * 2; w = (R[7] - R[5]) / s; x = s / 4; y = (R[1] + R[3]) / s; z = (R[2] + R[6]) / s; }
+    else if (R[4] > R[8]) { real s = RSQRT(1 + R[4] - R[0] - R[8]) * 2; w = (R[2] - R[6]) / s; x = (R[1] + R[3]) / s; y = s / 4; z = (R[5] + R[7]) / s; }
+    else { real s = RSQRT(1 + R[8] - R[0] - R[4]) * 2; w = (R[3] - R[1]) / s; x = (R[2] + R[6]) / s; y = (R[5] + R[7]) / s; z = s / 4; }
+    q[0] = x; q[1] = y; q[2] = z; q[3] = w;
+}
+void or_hand_fingertips(const OrModel *m, int nenv, const real *state, real *out) {
+    const int nd = m->nd, ss = 13 + 3 * nd;
+    const real zero3[3] = {0, 0, 0};
+#pragma omp parallel for schedule(static)
+    for (int e = 0; e < nenv; e++) {
+        static _Thread_local Work w;
+        const real *st = state + (size_t)e * ss;
+        fk(m, st, st + 13, &w);
+        rnea_bias(m, st, st + 13 + nd, zero3, &w);          /* fills the body velocities V = [omega; v_O] about O */
+        for (int k = 0; k < m->nsens; k++) {
+            int b = m->sens_body[k];
+            real *o = out + ((size_t)e * m->nsens + k) * 13, c[3];
+            for (int i = 0; i < 3; i++) o[i] = st[i] + w.r[b][i];
+            h_mat2quat(w.R[b], o + 3);
+            v3cross(w.V[b], w.r[b], c);
+            for (int i = 0; i < 3; i++) { o[7 + i] = w.V[b][3 + i] + c[i]; o[10 + i] = w.V[b][i]; }
+        }
+    }
+}

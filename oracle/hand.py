@@ -139,6 +139,13 @@ class OracleHandEngine:
         """[N, 5, 13] world pos, quat xyzw, linvel, angvel of the sensor (fingertip) bodies."""
         from isaacgymenvs_amd.assets.model import mat_to_quat
         out = np.zeros((self.N, len(self.sens), 13))
+        if self.backend == "c":                      # one OpenMP pass over the envs (oracle/hand.c or_hand_fingertips)
+            if not hasattr(self, "_hlib"):
+                self._c_setup()
+            st = self.eng.state
+            assert st.flags.c_contiguous
+            self._hlib.or_hand_fingertips(C.byref(self.eng.model), self.N, _ptr(st), _ptr(out))
+            return out
         v6 = np.zeros(6)
         for e in range(self.N):
             bp = self._poses(e)

@@ -104,7 +104,7 @@ def test_humanoid_contact_slots_suffice_at_the_benchmark_size():
 
 def test_shadow_hand_contact_slots_suffice_at_the_benchmark_size():
     """ShadowHand@16384 under the random policy of the benchmark: with the per-body manifold cap the contact slots of an env -- 5 for the
-    palm limb, 3 or 4 per finger in the finger-per-wave form (csrc/core/hand_engine_mw.hpp, model table limb_kcap; 21 in all), 12 in one pool
+    palm limb, 2 .. 5 per finger in the finger-per-wave form (csrc/core/hand_engine_mw.hpp, model table limb_kcap; 21 in all), 12 in one pool
     in the one-wave form (KMAX, csrc/core/hand_engine.hpp) -- are rarely all taken: `object_contact_dropped` counts the contacts refused for
     want of a slot."""
     import isaacgymenvs_amd
@@ -122,15 +122,16 @@ def test_shadow_hand_contact_slots_suffice_at_the_benchmark_size():
     assert dropped < 4e-2 * 2 * taken, (dropped, taken)
 
 
-@pytest.mark.parametrize("offset", [0, 9000, 16384 - 48])
-def test_shadow_hand_first_steps_at_the_benchmark_size(offset):
-    """ShadowHand@16384: the numpy oracle follows 48 consecutive envs of the big batch (global env ids offset ... offset + 47, the last
-    window ends on the batch's tail wave); ALL 211 observation columns per element -- the force-like ones (joint forces x10 at 48:72,
-    fingertip force-torques x10 at 161:191) relative to the largest force present."""
+@pytest.mark.parametrize("offset,k", [(0, 16384), (9000, 48), (16384 - 48, 48)])
+def test_shadow_hand_first_steps_at_the_benchmark_size(offset, k):
+    """ShadowHand@16384 against the CPU restatement (oracle/hand.c, fp64, the engine's solver order) on EVERY env of the batch, and on two
+    48-env windows addressed by their global env ids (offset ... offset + 47; the last one ends on the batch's tail wave): ALL 211
+    observation columns per element -- the force-like ones (joint forces x10 at 48:72, fingertip force-torques x10 at 161:191) relative to
+    the largest force present."""
     import isaacgymenvs_amd
     from isaacgymenvs_amd.registry import load_extras
     from oracle.tasks import OracleShadowHandEnv
-    n, k, seed = 16384, 48, 13
+    n, seed = 16384, 13
     env = isaacgymenvs_amd.make(seed=seed, task="ShadowHand", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True)
     orc = OracleShadowHandEnv(load_model("shadow_hand"), load_extras("shadow_hand"), sensor_bodies("shadow_hand"),
                               _sim_dict(env.sim_params), env._task_params_struct, k, seed=seed, env_id_offset=offset, **_hand_order(env))

@@ -950,11 +950,11 @@ def test_ball_balance_full_size_properties():
 
 
 # ------------------------------------------------------------------ ShadowHand (hand + cube physics, deferred resets, full_state obs)
-@pytest.mark.parametrize("multi_wave", [32, 0])
+@pytest.mark.parametrize("multi_wave", [32, 64, 0])
 @pytest.mark.parametrize("object_type", ["block", "egg", "pen"])
 def test_shadow_hand_step_matches_cpu_restatement(object_type, multi_wave):
-    """multi_wave 32: the finger-per-wave kernel against the block solver order of the restatement; 0: the one-wave kernel against the
-    Gauss-Seidel order."""
+    """multi_wave 32 / 64: the finger-per-wave kernel (32 / 64 envs per workgroup) against the block solver order of the restatement;
+    0: the one-wave kernel against the Gauss-Seidel order."""
     import isaacgymenvs_amd
     from isaacgymenvs_amd.registry import load_extras
     from oracle.tasks import OracleShadowHandEnv

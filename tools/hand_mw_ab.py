@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""ShadowHand step time: option multi_wave = 0 (one wave per 32 envs, core/hand_engine.hpp) against 32 (one finger per wave,
-core/hand_engine_mw.hpp) in one process on one box, alternating.  Also the episode statistics of each form (mean reward, reset rate,
+"""ShadowHand step time: option multi_wave = 0 (one wave per 32 envs, core/hand_engine.hpp) against 32 and 64 (one finger per wave,
+core/hand_engine_mw.hpp, 32 / 64 envs per workgroup) in one process on one box, alternating.  Also the episode statistics of each form (mean reward, reset rate,
 consecutive successes, contact counts): the solver order differs, the task-level behaviour must not.
 Usage: tools/hand_mw_ab.py [num_envs ...]"""
 import os
@@ -14,7 +14,7 @@ import isaacgymenvs_amd  # noqa: E402
 
 for n in [int(a) for a in sys.argv[1:]] or [16384]:
     envs = {}
-    for mw in (0, 32):
+    for mw in (0, 32, 64):
         envs[mw] = isaacgymenvs_amd.make(seed=42, task="ShadowHand", num_envs=n, sim_device="cuda:0", rl_device="cuda:0", headless=True)
         envs[mw].engine.set_option("multi_wave", mw)
     g = torch.Generator(device="cuda:0").manual_seed(1)
