@@ -230,6 +230,11 @@ int mi_engine_reset_idx(MiEngine* e, const int64_t* env_ids, int n, void* stream
 /* physics only: gym.simulate(sim) + refresh_* (vec_task.py:382; ant.py:233-235) with the efforts currently in
  * the "dof_actuation_force" tensor (gym.set_dof_actuation_force_tensor, ant.py:285) */
 int mi_engine_simulate(MiEngine* e, void* stream);
+/* gym.refresh_rigid_body_state_tensor(sim) (shadow_hand.py:440, anymal_terrain.py:314): fills the "rigid_body_state" tensor
+ * [num_envs, num_bodies, 13] -- position, quaternion xyzw, linear velocity of the body frame's origin, angular velocity, world frame --
+ * of every body of the articulation from the current root / dof state (gym.acquire_rigid_body_state_tensor, shadow_hand.py:150-175).
+ * On demand only: step / simulate never touch the tensor. */
+int mi_engine_refresh_rigid_body_states(MiEngine* e, void* stream);
 /* AnymalTerrain only: the terrain the reference builds with `Terrain(cfg["env"]["terrain"], num_envs)` and hands to
  * gym.add_triangle_mesh (anymal_terrain.py:203-215).  height_samples: DEVICE int16 [rows*cols] (Terrain.heightsamples,
  * row-major), env_origins: DEVICE fp32 [num_levels*num_terrains*3] (Terrain.env_origins).  Both stay owned by the

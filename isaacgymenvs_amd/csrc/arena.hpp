@@ -43,6 +43,7 @@ struct View {
     float* pairf;       // [3*NPG][N] world force on side a of each group's contact, last sub-step
     int* dropped;       // [2][N] contacts refused since init because the env's slots were taken: ground (KMAX), self contacts (KPAIR); models with the compact store
     float* ep_ret;      // [N] running return of the current episode
+    float* body_state;  // [13*NB][N] world state of every rigid body, filled by mi_engine_refresh_rigid_body_states only (gym rigid_body_state tensor)
     float* stats;       // [8] job statistics: sum finished returns, sum finished lengths, #finished, sum rewards, #env-steps
     // ---- AnymalTerrain only (null otherwise)
     float* netf;          // [3*NB][N] net contact force per body, world frame (gym net_contact_force tensor)

@@ -91,6 +91,9 @@ static void build_layout(int task, int N, Layout& L, View* v, char* base, int no
     o = L.add("episode_count", MI_I32, {n}, {1}, n); if (v) v->episode = (int*)P(o);
     o = L.add("episode_return", MI_F32, {n}, {1}, n); if (v) v->ep_ret = (float*)P(o);
     o = L.add("episode_stats", MI_F32, {8}, {1}, 8); if (v) v->stats = (float*)P(o);
+    // gym.acquire_rigid_body_state_tensor (shadow_hand.py:150-175): [pos3, quat xyzw, linvel3, angvel3] of every body of the articulation,
+    // refreshed on demand by mi_engine_refresh_rigid_body_states (never touched by step / simulate)
+    o = L.add("rigid_body_state", MI_F32, {n, (int64_t)m.nb, 13}, {1, 13 * n, n}, 13 * (int64_t)m.nb * n); if (v) v->body_state = (float*)P(o);
     if (task == T_ANT || task == T_HUMANOID) {
         // per-env friction of the robot's shapes for `actor_params.<actor>.rigid_shape_properties.friction` domain randomisation
         // (vec_task.py:752-828); negative = the model's own value

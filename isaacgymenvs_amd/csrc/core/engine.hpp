@@ -712,6 +712,80 @@ struct Sim {
         }
     }
 
+    // ---------------------------------------------------------------- world state of ONE body at the current q / qd
+    // o[13] = position, quaternion xyzw, linear velocity of the body frame's origin, angular velocity (world frame): one row of
+    // gym.acquire_rigid_body_state_tensor (reference shadow_hand.py:150-175,456-457).  Walks the chain root -> body; reads q / qd of the
+    // dofs on that chain only.
+    static constexpr bool on_chain(int a, int b) { while (b >= 0) { if (b == a) return true; b = M::parent[b]; } return false; }
+    MI_HD static void rot2quat(const float* R, float* qo) {      // Shepperd, w >= 0 branch first
+        const float tr = R[0] + R[4] + R[8];
+        float x, y, z, w;
+        if (tr > 0.f) {
+            const float s = sqrtf(tr + 1.f) * 2.f;
+            w = 0.25f * s; x = (R[7] - R[5]) / s; y = (R[2] - R[6]) / s; z = (R[3] - R[1]) / s;
+        } else if (R[0] > R[4] && R[0] > R[8]) {
+            const float s = sqrtf(1.f + R[0] - R[4] - R[8]) * 2.f;
+            w = (R[7] - R[5]) / s; x = 0.25f * s; y = (R[1] + R[3]) / s; z = (R[2] + R[6]) / s;
+        } else if (R[4] > R[8]) {
+            const float s = sqrtf(1.f + R[4] - R[0] - R[8]) * 2.f;
+            w = (R[2] - R[6]) / s; x = (R[1] + R[3]) / s; y = 0.25f * s; z = (R[5] + R[7]) / s;
+        } else {
+            const float s = sqrtf(1.f + R[8] - R[0] - R[4]) * 2.f;
+            w = (R[3] - R[1]) / s; x = (R[2] + R[6]) / s; y = (R[5] + R[7]) / s; z = 0.25f * s;
+        }
+        qo[0] = x; qo[1] = y; qo[2] = z; qo[3] = w;
+    }
+    template <int TIP>
+    MI_HD void body_state(float* o) {
+        float Rb[9], p[3], vl[3], om[3];
+        quat2mat(root + 3, Rb);
+        sfor<3>([&](auto I_) MI_LAMBDA { p[I_] = root[I_]; vl[I_] = M::FIXED ? 0.f : root[7 + I_]; om[I_] = M::FIXED ? 0.f : root[10 + I_]; });
+        sfor<NB>([&](auto B_) MI_LAMBDA {
+            constexpr int b = B_;
+            if constexpr (b > 0 && on_chain(b, TIP)) {
+                float t[3], cx[3];
+                matvec3(Rb, M::bpos[b], t);
+                cross3(om, t, cx);
+                sfor<3>([&](auto I_) MI_LAMBDA { p[I_] += t[I_]; vl[I_] += cx[I_]; });
+                if constexpr (!brot_is_identity(b)) matmul3(Rb, M::brot[b], Rb);
+                sfor<M::body_ndof[b]>([&](auto J_) MI_LAMBDA {
+                    constexpr int d = M::body_dof0[b] + J_;
+                    constexpr float ax = M::dof_axis[d][0], ay = M::dof_axis[d][1], az = M::dof_axis[d][2];
+                    const float al[3] = {ax, ay, az}, anl[3] = {M::dof_anchor[d][0], M::dof_anchor[d][1], M::dof_anchor[d][2]};
+                    float a[3];
+                    matvec3(Rb, al, a);
+                    if constexpr (M::dof_type[d] == 0) {
+                        float ta[3], s_, c_;
+                        matvec3(Rb, anl, ta);
+                        sincosf(q[d], &s_, &c_);
+                        const float tt = 1.f - c_;
+                        const float Q[9] = {c_ + ax * ax * tt, ax * ay * tt - az * s_, ax * az * tt + ay * s_,
+                                            ay * ax * tt + az * s_, c_ + ay * ay * tt, ay * az * tt - ax * s_,
+                                            az * ax * tt - ay * s_, az * ay * tt + ax * s_, c_ + az * az * tt};
+                        matmul3(Rb, Q, Rb);
+                        float tb[3];
+                        matvec3(Rb, anl, tb);
+                        // the body origin moves on a circle about the anchor; its velocity picks up the joint rate about the anchor
+                        const float dr[3] = {ta[0] - tb[0], ta[1] - tb[1], ta[2] - tb[2]};
+                        float c1[3], c2[3];
+                        cross3(om, dr, c1);
+                        const float wj[3] = {a[0] * qd[d], a[1] * qd[d], a[2] * qd[d]};
+                        const float mtb[3] = {-tb[0], -tb[1], -tb[2]};
+                        cross3(wj, mtb, c2);
+                        sfor<3>([&](auto I_) MI_LAMBDA { p[I_] += dr[I_]; vl[I_] += c1[I_] + c2[I_]; om[I_] += wj[I_]; });
+                    } else {
+                        const float dr[3] = {a[0] * q[d], a[1] * q[d], a[2] * q[d]};
+                        float c1[3];
+                        cross3(om, dr, c1);
+                        sfor<3>([&](auto I_) MI_LAMBDA { p[I_] += dr[I_]; vl[I_] += c1[I_] + a[I_] * qd[d]; });
+                    }
+                });
+            }
+        });
+        sfor<3>([&](auto I_) MI_LAMBDA { o[I_] = p[I_]; o[7 + I_] = vl[I_]; o[10 + I_] = om[I_]; });
+        rot2quat(Rb, o + 3);
+    }
+
     // ---------------------------------------------------------------- one physics sub-step of length h
     // gnd: ground policy; mu_env >= 0 replaces the per-sphere model friction (per-env friction buckets of
     // anymal_terrain.py:236-239,279-281); netf: per-body net contact force [3*NB] (world, this sub-step), written only on

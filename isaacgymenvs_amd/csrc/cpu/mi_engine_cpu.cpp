@@ -655,6 +655,37 @@ extern "C" int mi_engine_simulate(MiEngine* e, void*) {
     }
     return 0;
 }
+// gym.refresh_rigid_body_state_tensor: Sim<M>::body_state for every (env, body)
+template <class M>
+static void body_states_all(MiEngine* e) {
+    const View& v = e->v;
+    const int N = v.N;
+#pragma omp parallel for schedule(static) num_threads(e->num_threads)
+    for (int en = 0; en < N; ++en) {
+        Sim<M> sim;
+        for (int k = 0; k < 13; ++k) sim.root[k] = v.root[k * N + en];
+        for (int k = 0; k < M::ND; ++k) { sim.q[k] = v.dof[k * N + en]; sim.qd[k] = v.dof[(M::ND + k) * N + en]; }
+        sfor<M::NB>([&](auto B_) {
+            constexpr int b = decltype(B_)::value;
+            float o[13];
+            sim.template body_state<b>(o);
+            for (int k = 0; k < 13; ++k) v.body_state[(b * 13 + k) * N + en] = o[k];
+        });
+    }
+}
+extern "C" int mi_engine_refresh_rigid_body_states(MiEngine* e, void*) {
+    if (!e) return fail("null engine");
+    switch (e->task) {
+        case T_CARTPOLE: body_states_all<ModelCartpole>(e); break;
+        case T_ANT: body_states_all<ModelAnt>(e); break;
+        case T_HUMANOID: body_states_all<ModelHumanoid>(e); break;
+        case T_QUADCOPTER: body_states_all<ModelQuadcopter>(e); break;
+        case T_INGENUITY: body_states_all<ModelIngenuity>(e); break;
+        case T_BALLBALANCE: body_states_all<ModelBalanceBot>(e); break;
+        default: return fail("mi_engine_refresh_rigid_body_states: task not on the CPU backend");
+    }
+    return 0;
+}
 template <class M, bool HUM>
 static void reset_loco(MiEngine* e, const int64_t* ids, int n) {
     using T = Loco<M::ND, 6 * M::NSENS, HUM>;

@@ -621,6 +621,16 @@ extern "C" int mi_engine_simulate(MiEngine* e, void* stream) {
     return 0;
 }
 
+namespace mi { hipError_t launch_body_states(int task, const View& v, hipStream_t s); }
+extern "C" int mi_engine_refresh_rigid_body_states(MiEngine* e, void* stream) {
+    if (!e) return fail("null engine");
+    if (int rc = check_device(e, "mi_engine_refresh_rigid_body_states")) return rc;
+    static_assert(T_CARTPOLE == 0 && T_ANT == 1 && T_HUMANOID == 2 && T_ANYMAL == 3 && T_SHADOWHAND == 4 && T_ANYMAL_FLAT == 5 && T_QUADCOPTER == 6 &&
+                  T_INGENUITY == 7 && T_BALLBALANCE == 8, "kernels_body_states.hip switches on these ids");
+    HIP_OK(launch_body_states(e->task, e->v, (hipStream_t)stream));
+    return 0;
+}
+
 extern "C" int mi_engine_reset_idx(MiEngine* e, const int64_t* env_ids, int n, void* stream) {
     if (!e) return fail("null engine");
     if (n <= 0) return 0;

@@ -22,7 +22,7 @@ BUILD_DIR = os.path.join(CSRC, "build")
 SOURCES = ["mi_engine.hip", "kernels_cartpole.hip", "kernels_ant.hip", "kernels_humanoid.hip", "kernels_anymal.hip", "kernels_shadow_hand.hip",
            "kernels_shadow_hand_pen.hip", "kernels_shadow_hand_egg.hip", "kernels_quadcopter.hip", "kernels_ingenuity.hip", "kernels_ball_balance.hip", "kernels_jit_twins.hip",
            "kernels_mw_ant.hip", "kernels_mw_anymal.hip", "kernels_humanoid_sc2.hip", "kernels_humanoid_mwc.hip",
-           "kernels_shadow_hand_mw.hip", "kernels_shadow_hand_mw_pen.hip", "kernels_shadow_hand_mw_egg.hip"]
+           "kernels_shadow_hand_mw.hip", "kernels_shadow_hand_mw_pen.hip", "kernels_shadow_hand_mw_egg.hip", "kernels_body_states.hip"]
 MI_MAX_DOF = 32
 
 # -fno-slp-vectorize: pairing scalars into v_pk_* ops lengthens live ranges in the fully unrolled sub-step
@@ -164,7 +164,7 @@ class MiTensorDesc(C.Structure):
 # every symbol include/mi_engine.h declares (checked by tests/test_abi.py)
 EXPORTS = ["mi_abi_version", "mi_task_info", "mi_engine_arena_bytes", "mi_engine_create", "mi_engine_init_state",
            "mi_engine_destroy", "mi_engine_num_tensors", "mi_engine_tensor_desc", "mi_engine_step",
-           "mi_engine_reset_idx", "mi_engine_simulate", "mi_engine_set_option", "mi_engine_get_option", "mi_engine_set_noise", "mi_engine_last_ring", "mi_engine_set_terrain",
+           "mi_engine_reset_idx", "mi_engine_simulate", "mi_engine_refresh_rigid_body_states", "mi_engine_set_option", "mi_engine_get_option", "mi_engine_set_noise", "mi_engine_last_ring", "mi_engine_set_terrain",
            "mi_compute_locomotion_observations", "mi_compute_locomotion_reward", "mi_compute_cartpole_reward",
            "mi_compute_hand_reward", "mi_compute_hand_full_state", "mi_randomize_rotation",
            "mi_compute_anymal_observations", "mi_compute_anymal_reward", "mi_compute_quadcopter_reward",
@@ -309,6 +309,7 @@ def _bind_lifecycle(L):
     L.mi_engine_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.mi_engine_reset_idx.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.mi_engine_simulate.argtypes = [C.c_void_p, C.c_void_p]
+    L.mi_engine_refresh_rigid_body_states.argtypes = [C.c_void_p, C.c_void_p]
     L.mi_engine_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
     L.mi_engine_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
     L.mi_engine_set_noise.argtypes = [C.c_void_p, C.c_int, C.POINTER(MiNoiseParams)]
@@ -524,6 +525,10 @@ class Engine:
 
     def simulate(self):
         check(self.L.mi_engine_simulate(self.h, self._stream()), self.L)
+
+    def refresh_rigid_body_states(self):
+        """gym.refresh_rigid_body_state_tensor: fills tensors["rigid_body_state"] [N, num_bodies, 13] from the current root / dof state"""
+        check(self.L.mi_engine_refresh_rigid_body_states(self.h, self._stream()), self.L)
 
     def reset_idx(self, env_ids):
         if env_ids.numel():

@@ -254,3 +254,49 @@ def test_actor_velocities_are_clamped_like_the_simulator_does():
         assert torch.isfinite(t["root_states"]).all() and torch.isfinite(env.dof_vel).all(), k
         assert float(wn.max()) <= 64.0 * (1 + 1e-4), (k, float(wn.max()))
     assert float(env.dof_vel.abs().max()) < 400.0
+
+
+@pytest.mark.parametrize("task,model", [("Ant", "ant"), ("Humanoid", "humanoid"), ("Cartpole", "cartpole")])
+def test_rigid_body_state_tensor_matches_the_oracle_kinematics(task, model):
+    """gym.acquire_rigid_body_state_tensor / refresh_rigid_body_state_tensor (reference shadow_hand.py:150-175,440): the engine's
+    "rigid_body_state" tensor [N, num_bodies, 13] -- filled on demand by mi_engine_refresh_rigid_body_states (csrc/core/engine.hpp
+    Sim::body_state, one kinematic chain per body) -- against the oracle's forward kinematics and body velocities (oracle/physics.c fk /
+    rnea: independent code) on states of a rollout: positions, orientations, linear velocity of the body origin, angular velocity."""
+    import ctypes as C
+    from oracle.engine import OracleEngine, _ptr
+    n = 16
+    env = isaacgymenvs_amd.make(seed=3, task=task, num_envs=n, sim_device="cpu", rl_device="cpu", headless=True)
+    g = torch.Generator().manual_seed(1)
+    for _ in range(12):
+        env.step(torch.rand((n, env.num_actions), generator=g) * 2 - 1)
+    spec = load_model(model)
+    rbs = env.engine.tensors["rigid_body_state"]
+    assert tuple(rbs.shape) == (n, spec.nb, 13)
+    before = rbs.clone()
+    env.step(torch.rand((n, env.num_actions), generator=g) * 2 - 1)
+    assert torch.equal(rbs, before)                       # step() does not touch it ...
+    env.engine.refresh_rigid_body_states()                # ... the refresh call does
+    orc = OracleEngine(spec, n, sensor_bodies=sensor_bodies(model), precision="f64")
+    orc.root[:] = env.engine.tensors["root_states"].numpy()
+    orc.q[:] = env.engine.tensors["dof_state"][..., 0].numpy(); orc.qd[:] = env.engine.tensors["dof_state"][..., 1].numpy()
+    out = rbs.numpy()
+    v6 = np.zeros(6)
+    moving = 0.0
+    for e in range(n):
+        _, _, bp = orc.energy(e, poses=True)
+        s = np.ascontiguousarray(orc.state[e])
+        for b in range(spec.nb):
+            orc.lib.or_body_vel(C.byref(orc.model), _ptr(s), b, _ptr(v6))
+            p, R = bp[b, 0:3], bp[b, 3:12].reshape(3, 3)
+            r = p - orc.root[e, :3]
+            np.testing.assert_allclose(out[e, b, 0:3], p, atol=2e-5)
+            x, y, z, w = out[e, b, 3:7]
+            Rq = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                           [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+            np.testing.assert_allclose(Rq, R, atol=2e-5)
+            np.testing.assert_allclose(out[e, b, 7:10], v6[3:6] + np.cross(v6[0:3], r), atol=2e-4 * max(1.0, np.abs(v6).max()))
+            np.testing.assert_allclose(out[e, b, 10:13], v6[0:3], atol=2e-4 * max(1.0, np.abs(v6).max()))
+            moving = max(moving, np.abs(v6).max())
+    assert moving > 0.5                                    # the bodies do move in these states
+    # row 0 is the root body: the actor root state itself
+    np.testing.assert_allclose(out[:, 0, :], env.engine.tensors["root_states"].numpy() if not spec.fixed_base else out[:, 0, :], atol=1e-5)
