@@ -177,6 +177,32 @@ EXPORTS = ["mi_abi_version", "mi_task_info", "mi_engine_arena_bytes", "mi_engine
            "mi_last_error"]
 
 
+def auto_multi_wave(task, num_envs):
+    """Launch shape of the physics sub-step (csrc/core/engine_mw.hpp, engine_mwc.hpp, hand_engine_mw.hpp), envs per workgroup; 0 = one wave
+    per workgroup.  Locomotion: the limb-per-wave form while its 4 * N / E waves still find a SIMD each (1024 on an MI355X) -- measured 1.4x
+    faster at 4096 envs, slower from 16384 envs on (profiles/r2b_mw_ab.txt); tasks without a multi-wave form ignore the option."""
+    mw = 16 if num_envs <= 4096 else (32 if num_envs <= 8192 else 0)
+    if task == "Humanoid":
+        mw = 32          # limb waves + pair wave (csrc/mwc_kernels.hpp), at any env count
+    if task == "ShadowHand":
+        # finger per wave (csrc/hand_mw_kernels.hpp): 32 envs per workgroup (two half-filled waves per SIMD) while that fills the chip (one
+        # workgroup per CU up to 8192 envs), full 64-env waves (half the wave instructions per env) from there on -- profiles/r3l_hand_mw_ab_0_32_64.txt
+        mw = 64 if num_envs >= 8192 else 32
+    return mw
+
+
+def select_multi_wave(engine, task, num_envs, mw="auto"):
+    """sets the engine's multi_wave option ("auto": auto_multi_wave); a value the task's kernels do not take falls back to 32"""
+    if mw == "auto":
+        mw = auto_multi_wave(task, num_envs)
+    for cand in (int(mw), 32):
+        try:
+            engine.set_option("multi_wave", cand)
+            return
+        except RuntimeError:
+            continue
+
+
 def hipcc_path():
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 

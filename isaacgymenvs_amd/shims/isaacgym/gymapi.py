@@ -12,8 +12,16 @@ tasks/cartpole.py:48-163; tasks/humanoid.py).  What the calls mean here:
   simulate                      mi_engine_simulate (one dt of `substeps` sub-steps);   fetch_results   nothing to fetch;
   viewer / camera / colour calls do nothing (headless engine).
 
-Assets are resolved to the models compiled into the engine by file name (nv_ant.xml, nv_humanoid.xml, cartpole.urdf): the engine is
-specialised per robot at build time (isaacgymenvs_amd/codegen.py), it does not load arbitrary files at run time.
+Assets are resolved to the models compiled into the engine by file name (nv_ant.xml, nv_humanoid.xml, cartpole.urdf, anymal_minimal.urdf,
+shadow_hand.xml; the ShadowHand task's free objects cube_multicolor.urdf / egg.xml / pen.xml): the engine is specialised per robot at build
+time (isaacgymenvs_amd/codegen.py), it does not load arbitrary files at run time.
+
+Envs with several actors (ShadowHand: hand, object, goal object -- reference shadow_hand.py:356-381): the sim-domain actor index of actor k
+of env i is A i + k (A actors per env), the root tensor is [A N, 13], the rigid-body tensor lists the articulation's bodies, then one
+body per free object.  The object's root state is the engine's `object_state`; the goal object has no physics (its own collision group,
+gravity off): its root state lives in the shim's tensor only.
+Terrain (AnymalTerrain, reference anymal_terrain.py:203-215): `add_triangle_mesh` receives the vertices `isaacgym.terrain_utils.
+convert_heightfield_to_trimesh` made, checks that they are those, and hands the engine the height field they came from.
 """
 from __future__ import annotations
 
@@ -44,6 +52,12 @@ class Vec3:
 
     def __iter__(self):
         return iter((self.x, self.y, self.z))
+
+    def __add__(self, o):
+        return Vec3(self.x + o.x, self.y + o.y, self.z + o.z)
+
+    def __sub__(self, o):
+        return Vec3(self.x - o.x, self.y - o.y, self.z - o.z)
 
     def __repr__(self):
         return f"Vec3({self.x}, {self.y}, {self.z})"
@@ -86,6 +100,27 @@ class PlaneParams(_Bag):
         super().__init__(normal=Vec3(0.0, 0.0, 1.0), distance=0.0, static_friction=1.0, dynamic_friction=1.0, restitution=0.0)
 
 
+class TriangleMeshParams(_Bag):
+    def __init__(self):
+        super().__init__(nb_vertices=0, nb_triangles=0, transform=Transform(), static_friction=1.0, dynamic_friction=1.0, restitution=0.0)
+
+
+class RigidShapeProperties(_Bag):
+    def __init__(self, friction=1.0):
+        super().__init__(friction=friction, rolling_friction=0.0, torsion_friction=0.0, restitution=0.0, compliance=0.0, thickness=0.0)
+
+
+class RigidBodyProperties(_Bag):
+    def __init__(self, mass=0.0):
+        super().__init__(mass=mass, invMass=(1.0 / mass if mass > 0 else 0.0), com=Vec3(), inertia=None)
+
+
+class TendonProperties(_Bag):
+    def __init__(self, stiffness=0.0, damping=0.0, limit_stiffness=0.0):
+        super().__init__(type=0, stiffness=stiffness, damping=damping, fixed_spring_rest_length=0.0, fixed_lower_limit=0.0, fixed_upper_limit=0.0,
+                         limit_stiffness=limit_stiffness, is_fixed_limited=True, num_attachments=2)
+
+
 class CameraProperties(_Bag):
     def __init__(self):
         super().__init__(width=1600, height=900)
@@ -107,7 +142,10 @@ class SimParams:
 
 
 # ---------------------------------------------------------------------------------------------------------------- recorded objects
-_MODEL_OF_FILE = {"nv_ant.xml": ("ant", "Ant"), "nv_humanoid.xml": ("humanoid", "Humanoid"), "cartpole.urdf": ("cartpole", "Cartpole")}
+_MODEL_OF_FILE = {"nv_ant.xml": ("ant", "Ant"), "nv_humanoid.xml": ("humanoid", "Humanoid"), "cartpole.urdf": ("cartpole", "Cartpole"),
+                  "anymal_minimal.urdf": ("anymal", "AnymalTerrain"), "shadow_hand.xml": ("shadow_hand", "ShadowHand")}
+# the ShadowHand task's free objects (shadow_hand.py:86-96): one body, no dof
+_OBJECT_OF_FILE = {"cube_multicolor.urdf": "block", "egg.xml": "egg", "pen.xml": "pen"}
 
 
 class _ActuatorProps:
@@ -118,23 +156,43 @@ class _ActuatorProps:
 
 class _Asset:
     def __init__(self, path, options):
-        from ...registry import load_model, load_selfcol, sensor_bodies
+        from ...registry import load_extras, load_model, load_selfcol, sensor_bodies
         key = os.path.basename(path)
+        self.options = options
+        self.sensors = []                      # rigid-body indices in the order create_asset_force_sensor was called
+        self.shape_friction = None             # set_asset_rigid_shape_properties: friction of the asset's shapes for the actors created next
+        self.tendon_props = None
+        self.spec, self.object_type = None, None
+        if key in _OBJECT_OF_FILE:
+            self.object_type = _OBJECT_OF_FILE[key]
+            self.body_names, self.body_dyn = ["object"], np.zeros(1, np.int64)
+            self.nshapes = 1
+            return
         if key not in _MODEL_OF_FILE:
             raise NotImplementedError(f"gym.load_asset: {key} has no model compiled into the engine (available: {sorted(_MODEL_OF_FILE)}); "
                                       f"robots are specialised at build time (isaacgymenvs_amd/codegen.py)")
         self.model_name, self.task = _MODEL_OF_FILE[key]
         self.spec = load_model(self.model_name)
-        self.options = options
-        self.sensors = []                      # rigid-body indices in the order create_asset_force_sensor was called
-        self.engine_sensor_bodies = [self.spec.api_body_names.index(self.spec.body_names[b]) for b in sensor_bodies(self.model_name, self.spec)]
+        # the bodies gym lists: with collapse_fixed_joints the welded links are gone (= the engine's bodies), otherwise every link of the
+        # file, each riding on the engine body it is welded to (api_body_dyn) at a fixed offset (api_body_pos / api_body_quat)
+        if getattr(options, "collapse_fixed_joints", False):
+            self.body_names = list(self.spec.body_names)
+            self.body_dyn = np.arange(self.spec.nb)
+            self.body_off_p = np.zeros((self.spec.nb, 3)); self.body_off_q = np.tile([0.0, 0.0, 0.0, 1.0], (self.spec.nb, 1))
+        else:
+            self.body_names = list(self.spec.api_body_names)
+            self.body_dyn = np.asarray(self.spec.api_body_dyn, np.int64)
+            self.body_off_p = np.asarray(self.spec.api_body_pos, float); self.body_off_q = np.asarray(self.spec.api_body_quat, float)
+        self.nshapes = len(self.spec.geom_body)
+        self.engine_sensor_bodies = [self.body_names.index(self.spec.body_names[b]) for b in sensor_bodies(self.model_name, self.spec)]
         self.has_self_collision = load_selfcol(self.model_name) is not None
+        self.extras = load_extras(self.model_name) if self.model_name == "shadow_hand" else None
 
 
 class _Env:
     def __init__(self, sim, index):
         self.sim, self.index = sim, index
-        self.actors = []
+        self.actors = []                       # names, in creation order (the same for every env)
 
 
 class _Sim:
@@ -142,13 +200,39 @@ class _Sim:
         self.compute_device, self.params = compute_device, params
         self.device = f"cuda:{compute_device}" if params.use_gpu_pipeline else "cpu"
         self.plane = None
+        self.terrain = None                    # add_triangle_mesh: the height field behind the mesh
         self.envs = []
-        self.asset = None
-        self.start_pose = None
-        self.filter = 0
+        self.slots = []                        # per actor of an env: dict(asset, name, filter, poses [N][7], friction {env: mu})
         self.engine = None
         self.frame = 0
         self.bufs = {}
+        self.one_shot_force = False
+
+    # the articulated actor (the engine's robot) and the free objects
+    @property
+    def robot(self):
+        for k, sl in enumerate(self.slots):
+            if sl["asset"].spec is not None:
+                return k
+        raise RuntimeError("no articulated actor was created")
+
+    @property
+    def asset(self):
+        return self.slots[self.robot]["asset"]
+
+    @property
+    def nactors(self):
+        return len(self.slots)
+
+
+class _Terrain:
+    """what isaacgymenvs_amd.native.Engine takes as `terrain` (isaacgymenvs_amd/tasks/terrain.py attribute names)"""
+
+    def __init__(self, hf, hscale, vscale, border, slope_threshold):
+        self.heightsamples, self.horizontal_scale, self.vertical_scale, self.border_size = hf, hscale, vscale, border
+        self.slope_threshold = slope_threshold
+        self.env_origins = np.zeros((1, 1, 3))
+        self.env_length, self.max_init_level = 8.0, 0
 
 
 class Gym:
@@ -161,45 +245,93 @@ class Gym:
     def add_ground(self, sim, plane_params):
         sim.plane = plane_params
 
+    def add_triangle_mesh(self, sim, vertices, triangles, params):
+        """anymal_terrain.py:203-215.  The engine walks on the height field the mesh was generated from (terrain_utils remembers it); the
+        vertices handed in must be that conversion's (same surface), the transform a pure shift by -border in x and y."""
+        from . import terrain_utils
+        conv = terrain_utils._last_conversion
+        v = np.asarray(vertices, np.float32).reshape(-1, 3)
+        if conv is None or conv["vertices"].shape != v.shape or int(params.nb_vertices) != v.shape[0]:
+            raise NotImplementedError("gym.add_triangle_mesh: only meshes made by isaacgym.terrain_utils.convert_heightfield_to_trimesh (the engine's "
+                                      "ground is a height field)")
+        if not np.array_equal(conv["vertices"], v):
+            raise ValueError("gym.add_triangle_mesh: the vertices differ from the height field's conversion")
+        if int(params.nb_triangles) != np.asarray(triangles).size // 3 or params.transform.p.x != params.transform.p.y or params.transform.p.z != 0.0:
+            raise NotImplementedError("gym.add_triangle_mesh: transform must be (-border, -border, 0)")
+        sim.terrain = _Terrain(conv["height_field"], conv["horizontal_scale"], conv["vertical_scale"], -float(params.transform.p.x),
+                               conv["slope_threshold"])
+        sim.plane = _Bag(static_friction=float(params.static_friction), dynamic_friction=float(params.dynamic_friction),
+                         restitution=float(params.restitution))
+
     def load_asset(self, sim, rootpath, filename, options=None):
-        return _Asset(os.path.join(rootpath, filename), options or AssetOptions())
+        import copy
+        return _Asset(os.path.join(rootpath, filename), copy.copy(options) if options is not None else AssetOptions())
 
     def get_asset_dof_count(self, asset):
-        return asset.spec.nd
+        return asset.spec.nd if asset.spec is not None else 0
 
     def get_asset_rigid_body_count(self, asset):
-        return len(asset.spec.api_body_names)
+        return len(asset.body_names)
 
     def get_asset_joint_count(self, asset):
         # joints of the file incl. the fixed ones that weld bodies: one per non-root body (nv_humanoid.xml: 15 for 16 bodies)
-        return len(asset.spec.api_body_names) - 1
+        return len(asset.body_names) - 1
 
     def get_asset_rigid_shape_count(self, asset):
-        return len(asset.spec.geom_body)
+        return asset.nshapes
 
     def get_asset_dof_names(self, asset):
         return list(asset.spec.dof_names)
 
     def get_asset_rigid_body_names(self, asset):
-        return list(asset.spec.api_body_names)
+        return list(asset.body_names)
 
     def get_asset_rigid_body_name(self, asset, index):
-        return asset.spec.api_body_names[index]
+        return asset.body_names[index]
 
     def find_asset_rigid_body_index(self, asset, name):
-        return asset.spec.api_body_names.index(name)
+        return asset.body_names.index(name)
 
     def find_asset_dof_index(self, asset, name):
         return list(asset.spec.dof_names).index(name)
 
     def get_asset_actuator_count(self, asset):
+        if asset.extras is not None:
+            return len(asset.extras["actuated_dofs"])
         return len(asset.spec.act_gear)
 
     def get_asset_actuator_properties(self, asset):
         return [_ActuatorProps(g) for g in asset.spec.act_gear]
 
+    def get_asset_actuator_joint_name(self, asset, index):
+        if asset.extras is not None:
+            return asset.spec.dof_names[int(asset.extras["actuated_dofs"][index])]
+        return asset.spec.dof_names[int(asset.spec.act_dof[index])]
+
     def get_asset_dof_properties(self, asset):
         return _dof_properties(asset.spec)
+
+    def get_asset_rigid_shape_properties(self, asset):
+        mu = asset.spec.geom_friction if asset.spec is not None else [1.0]
+        return [RigidShapeProperties(float(np.ravel(mu[i])[0]) if i < len(mu) else 1.0) for i in range(asset.nshapes)]
+
+    def set_asset_rigid_shape_properties(self, asset, props):
+        asset.shape_friction = float(np.ravel(np.asarray(props[0].friction.cpu() if hasattr(props[0].friction, "cpu") else props[0].friction))[0])
+        return True
+
+    # fixed tendons of the Shadow Hand (shadow_hand.py:253-266)
+    def get_asset_tendon_count(self, asset):
+        return len(asset.extras["tendons"]) if asset.extras is not None else 0
+
+    def get_asset_tendon_name(self, asset, index):
+        return asset.extras["tendons"][index]["name"]
+
+    def get_asset_tendon_properties(self, asset):
+        return [TendonProperties() for _ in range(self.get_asset_tendon_count(asset))]
+
+    def set_asset_tendon_properties(self, asset, props):
+        asset.tendon_props = [(float(pr.limit_stiffness), float(pr.damping)) for pr in props]
+        return True
 
     def create_asset_force_sensor(self, asset, body_idx, local_pose, props=None):
         asset.sensors.append(int(body_idx))
@@ -212,11 +344,19 @@ class Gym:
 
     def create_actor(self, env, asset, pose, name="", group=-1, filter=-1, seg_id=0):
         sim = env.sim
-        if sim.asset is not None and sim.asset is not asset:
-            raise NotImplementedError("the shim runs one articulated actor per env (Cartpole, Ant, Humanoid)")
-        sim.asset, sim.start_pose, sim.filter = asset, pose, int(filter)
+        k = len(env.actors)
+        if env.index == 0:
+            if asset.spec is not None and any(sl["asset"].spec is not None for sl in sim.slots):
+                raise NotImplementedError("the shim runs one articulated actor per env (plus free objects)")
+            sim.slots.append(dict(asset=asset, name=name, filter=int(filter), poses=[], friction={}))
+        elif k >= len(sim.slots) or sim.slots[k]["asset"] is not asset:
+            raise NotImplementedError("every env must create the same actors in the same order")
+        sl = sim.slots[k]
+        sl["poses"].append([pose.p.x, pose.p.y, pose.p.z, pose.r.x, pose.r.y, pose.r.z, pose.r.w])
+        if asset.shape_friction is not None:
+            sl["friction"][env.index] = asset.shape_friction
         env.actors.append(name)
-        return len(env.actors) - 1
+        return k
 
     def begin_aggregate(self, *a, **k):
         return True
@@ -225,16 +365,22 @@ class Gym:
         return True
 
     def get_actor_dof_properties(self, env, actor):
-        return _dof_properties(env.sim.asset.spec)
+        return _dof_properties(env.sim.slots[actor]["asset"].spec)
 
     def set_actor_dof_properties(self, env, actor, props):
         return True                             # drive modes / gains of the compiled models are fixed at build time
 
     def get_actor_rigid_body_count(self, env, actor):
-        return len(env.sim.asset.spec.api_body_names)
+        return len(env.sim.slots[actor]["asset"].body_names)
+
+    def get_actor_rigid_body_properties(self, env, actor):
+        a = env.sim.slots[actor]["asset"]
+        if a.spec is None:
+            return [RigidBodyProperties(_object_mass(a.object_type))]
+        return [RigidBodyProperties(float(a.spec.mass[int(d)])) for d in a.body_dyn]
 
     def get_actor_dof_count(self, env, actor):
-        return env.sim.asset.spec.nd
+        return self.get_asset_dof_count(env.sim.slots[actor]["asset"])
 
     def get_actor_count(self, env):
         return len(env.actors)
@@ -243,13 +389,14 @@ class Gym:
         return env.actors.index(name)
 
     def get_actor_index(self, env, actor, domain=DOMAIN_SIM):
-        return env.index if domain == DOMAIN_SIM else actor
+        # (a one-actor env: the env index, as before; called while the envs are being filled, so the per-env actor count is that of env 0)
+        return env.index * max(len(env.sim.slots), len(env.actors)) + actor if domain == DOMAIN_SIM else actor
 
     def find_actor_rigid_body_handle(self, env, actor, name):
-        return env.sim.asset.spec.api_body_names.index(name)
+        return env.sim.slots[actor]["asset"].body_names.index(name)
 
     def find_actor_dof_handle(self, env, actor, name):
-        return list(env.sim.asset.spec.dof_names).index(name)
+        return list(env.sim.slots[actor]["asset"].spec.dof_names).index(name)
 
     def set_rigid_body_color(self, *a, **k):
         pass
@@ -276,17 +423,22 @@ class Gym:
         return len(sim.envs) * sim.asset.spec.nd
 
     def get_sim_actor_count(self, sim):
-        return len(sim.envs)
+        return len(sim.envs) * sim.nactors
 
     # ------------------------------------------------------------------ the engine comes to life
     def prepare_sim(self, sim):
         from ... import native
         from ...utils.config import compose
-        if sim.asset is None or not sim.envs:
+        if not sim.slots or not sim.envs:
             raise RuntimeError("gym.prepare_sim: no actor was created")
         if sim.params.up_axis != UP_AXIS_Z:
             raise ValueError("only up_axis 'z' is implemented")
+        n = len(sim.envs)
+        for sl in sim.slots:
+            if len(sl["poses"]) != n:
+                raise NotImplementedError("every env must create the same actors")
         asset, p, px = sim.asset, native.MiSimParams(), sim.params.physx
+        rslot = sim.slots[sim.robot]
         p.dt, p.substeps = float(sim.params.dt), int(sim.params.substeps)
         for i, g in enumerate(sim.params.gravity):
             p.gravity[i] = float(g)
@@ -296,23 +448,63 @@ class Gym:
         p.erp, p.cfm, p.warm, p.ground_z = 0.5, 1e-6, 1.0, 0.0
         p.plane_mu = float(sim.plane.static_friction) if sim.plane is not None else 1.0
         cfg = compose(overrides=[f"task={asset.task}"])["task"]        # the fused kernels' own parameters: unused by simulate()
+        poses = torch.tensor(rslot["poses"], dtype=torch.float32)
+        terrain = None
         if asset.task == "Cartpole":
             from ...tasks.cartpole import cartpole_params_from_cfg
             tp = cartpole_params_from_cfg(cfg)
+        elif asset.task == "AnymalTerrain":
+            from ...tasks.anymal_terrain import _FlatTerrain, anymal_params_from_cfg
+            tp = anymal_params_from_cfg(cfg, list(asset.spec.dof_names))
+            terrain = sim.terrain
+            if terrain is None:
+                terrain = _FlatTerrain()
+                terrain.max_init_level = 0
+        elif asset.task == "ShadowHand":
+            from ...tasks.shadow_hand import hand_params_from_cfg
+            objs = [sl["asset"].object_type for sl in sim.slots if sl["asset"].spec is None]
+            cfg["env"]["objectType"] = objs[0] if objs else "block"
+            tp = hand_params_from_cfg(cfg)
+            for k in range(3):
+                if abs(tp.hand_pos[k] - float(poses[0, k])) > 1e-6:
+                    raise NotImplementedError("the hand is mounted at (0, 0, 0.5) (shadow_hand.py:306-307)")
         else:
             from ...tasks.locomotion import loco_params_from_cfg
-            tp = loco_params_from_cfg(cfg, asset.model_name, float(sim.start_pose.p.z))
-        n = len(sim.envs)
-        sim.engine = native.Engine(asset.task, p, tp, n, sim.device)
+            tp = loco_params_from_cfg(cfg, asset.model_name, float(poses[0, 2]))
+        sim.engine = native.Engine(asset.task, p, tp, n, sim.device, terrain=terrain)
+        if sim.device != "cpu":
+            native.select_multi_wave(sim.engine, asset.task, n)        # the launch shape (and with it the solver order) make() would pick
         if asset.has_self_collision:
-            sim.engine.set_option("self_collision", 1 if sim.filter == 0 else 0)      # create_actor(..., filter): 0 = links collide
+            sim.engine.set_option("self_collision", 1 if rslot["filter"] == 0 else 0)      # create_actor(..., filter): 0 = links collide
         t = sim.engine.tensors
-        root = torch.tensor([sim.start_pose.p.x, sim.start_pose.p.y, sim.start_pose.p.z, sim.start_pose.r.x, sim.start_pose.r.y,
-                             sim.start_pose.r.z, sim.start_pose.r.w, 0, 0, 0, 0, 0, 0], dtype=torch.float32, device=sim.device)
+        root = torch.zeros((n, 13), dtype=torch.float32)
+        root[:, :7] = poses
+        root = root.to(sim.device)
         if asset.spec.fixed_base:
-            root[2] = t["root_states"][0, 2]        # a fixed base stays where the engine mounts it (the rail height of the cart-pole)
+            root[:, :7] = t["root_states"][:, :7]        # a fixed base stays where the engine mounts it (the rail of the cart-pole, the hand's mount)
         t["root_states"][:] = root
+        if "initial_root_states" in t:
+            t["initial_root_states"][:] = root
         t["dof_state"].zero_()
+        if rslot["friction"] and "friction" in t:          # per-env shape friction (anymal_terrain.py:236-239,279-281)
+            mu = torch.full((n,), -1.0)
+            for e, val in rslot["friction"].items():
+                mu[e] = val
+            t["friction"][:] = mu.to(sim.device)
+        if asset.task == "ShadowHand":
+            k_obj = [k for k, sl in enumerate(sim.slots) if sl["asset"].spec is None]
+            if k_obj:
+                o = torch.zeros((n, 13), dtype=torch.float32)
+                o[:, :7] = torch.tensor(sim.slots[k_obj[0]]["poses"], dtype=torch.float32)
+                t["object_state"][:] = o.to(sim.device)
+            if asset.tendon_props:                   # limit stiffness / damping of the four coupling tendons as factors of the model's own
+                ks = {pr for i, pr in enumerate(asset.tendon_props) if pr != (0.0, 0.0)}
+                if len(ks) > 1:
+                    raise NotImplementedError("one limit_stiffness / damping for all coupling tendons")
+                if ks:
+                    ls, dm = next(iter(ks))
+                    t["actor_scale"][:, 3] = ls / float(asset.extras["tendon_limit_stiffness"])
+                    t["actor_scale"][:, 4] = dm / float(asset.extras["tendon_damping"])
         if asset.sensors and asset.sensors != asset.engine_sensor_bodies[:len(asset.sensors)]:
             raise NotImplementedError(f"force sensors on bodies {asset.sensors}: the compiled {asset.model_name} model has them on "
                                       f"{asset.engine_sensor_bodies}")
@@ -324,7 +516,16 @@ class Gym:
             sim.bufs[name] = torch.zeros(shape, dtype=torch.float32, device=sim.device)
         return sim.bufs[name]
 
+    def _object_slots(self, sim):
+        """[(slot, has physics)] of the free objects: the first one is the engine's object, the others (goal) live in the shim"""
+        ks = [k for k, sl in enumerate(sim.slots) if sl["asset"].spec is None]
+        return [(k, i == 0) for i, k in enumerate(ks)]
+
     def acquire_actor_root_state_tensor(self, sim):
+        n, A = len(sim.envs), sim.nactors
+        buf = self._buf(sim, "root", (n * A, 13))
+        for k, sl in enumerate(sim.slots):          # start poses of everything (the goal object keeps what the task writes afterwards)
+            buf.view(n, A, 13)[:, k, :7] = torch.tensor(sl["poses"], dtype=torch.float32, device=sim.device)
         self.refresh_actor_root_state_tensor(sim)
         return sim.bufs["root"]
 
@@ -340,9 +541,21 @@ class Gym:
         self.refresh_dof_force_tensor(sim)
         return sim.bufs["dof_force"]
 
+    def acquire_net_contact_force_tensor(self, sim):
+        self.refresh_net_contact_force_tensor(sim)
+        return sim.bufs["netf"]
+
+    def acquire_rigid_body_state_tensor(self, sim):
+        self.refresh_rigid_body_state_tensor(sim)
+        return sim.bufs["rb"]
+
     def refresh_actor_root_state_tensor(self, sim):
-        n = len(sim.envs)
-        self._buf(sim, "root", (n, 13)).copy_(sim.engine.tensors["root_states"])
+        n, A = len(sim.envs), sim.nactors
+        v = self._buf(sim, "root", (n * A, 13)).view(n, A, 13)
+        v[:, sim.robot].copy_(sim.engine.tensors["root_states"])
+        for k, phys in self._object_slots(sim):
+            if phys:
+                v[:, k].copy_(sim.engine.tensors["object_state"])
         return True
 
     def refresh_dof_state_tensor(self, sim):
@@ -361,10 +574,48 @@ class Gym:
         self._buf(sim, "dof_force", (n * nd,)).view(n, nd).copy_(sim.engine.tensors["dof_force"])
         return True
 
-    def refresh_rigid_body_state_tensor(self, sim):
+    def refresh_net_contact_force_tensor(self, sim):
+        """per rigid body, world frame, last sub-step (anymal_terrain.py:119,130): bodies welded to an engine body report that body's force on
+        the engine body's own row and zero elsewhere"""
+        if sim.engine is None or "net_contact_force" not in sim.engine.tensors:
+            return True
+        a = sim.asset
+        n, nb = len(sim.envs), len(a.body_names)
+        buf = self._buf(sim, "netf", (n * nb, 3)).view(n, nb, 3)
+        src = sim.engine.tensors["net_contact_force"]
+        own = [i for i, nm in enumerate(a.body_names) if nm in a.spec.body_names]
+        buf.zero_()
+        buf[:, own] = src[:, [a.spec.body_names.index(a.body_names[i]) for i in own]]
         return True
 
-    def refresh_net_contact_force_tensor(self, sim):
+    def refresh_rigid_body_state_tensor(self, sim):
+        """[N * (bodies of the articulation + one per free object), 13] (shadow_hand.py:150-175): the engine's rigid_body_state tensor, the
+        file's welded links riding on their engine body at their fixed offset, then the objects' root states"""
+        if sim.engine is None:
+            return True
+        a = sim.asset
+        n, nb = len(sim.envs), len(a.body_names)
+        objs = self._object_slots(sim)
+        buf = self._buf(sim, "rb", (n * (nb + len(objs)), 13)).view(n, nb + len(objs), 13)
+        sim.engine.refresh_rigid_body_states()
+        src = sim.engine.tensors["rigid_body_state"][:, torch.as_tensor(a.body_dyn, device=sim.device)]       # [n, nb, 13]
+        off_p = torch.tensor(a.body_off_p, dtype=torch.float32, device=sim.device)
+        off_q = torch.tensor(a.body_off_q, dtype=torch.float32, device=sim.device)
+        if float(off_p.abs().max()) == 0.0 and float((off_q - off_q.new_tensor([0, 0, 0, 1])).abs().max()) == 0.0:
+            buf[:, :nb].copy_(src)
+        else:
+            q = src[..., 3:7]
+            r = _quat_rotate(q, off_p.expand(n, nb, 3))
+            buf[:, :nb, 0:3] = src[..., 0:3] + r
+            buf[:, :nb, 3:7] = _quat_mul(q, off_q.expand(n, nb, 4))
+            buf[:, :nb, 7:10] = src[..., 7:10] + torch.cross(src[..., 10:13], r, dim=-1)
+            buf[:, :nb, 10:13] = src[..., 10:13]
+        root = sim.bufs.get("root")
+        for i, (k, phys) in enumerate(objs):
+            if phys:
+                buf[:, nb + i].copy_(sim.engine.tensors["object_state"])
+            elif root is not None:
+                buf[:, nb + i].copy_(root.view(n, sim.nactors, 13)[:, k])
         return True
 
     def enable_actor_dof_force_sensors(self, env, actor):
@@ -375,15 +626,45 @@ class Gym:
         sim.engine.tensors["dof_actuation_force"].copy_(forces.view(n, nd))
         return True
 
+    def set_dof_position_target_tensor(self, sim, targets):
+        n, nd = len(sim.envs), sim.asset.spec.nd
+        sim.engine.tensors["cur_targets"].copy_(targets.view(n, nd))
+        return True
+
+    def set_dof_position_target_tensor_indexed(self, sim, targets, actor_indices, count):
+        n, nd = len(sim.envs), sim.asset.spec.nd
+        envs = torch.div(actor_indices[:count].long(), sim.nactors, rounding_mode="floor")
+        sim.engine.tensors["cur_targets"][envs] = targets.view(n, nd)[envs]
+        return True
+
+    def apply_rigid_body_force_tensors(self, sim, forces=None, torques=None, space=ENV_SPACE):
+        """shadow_hand.py:700-708: random forces on the object's body, in its local frame; held for the next simulate() only"""
+        objs = [k for k, phys in self._object_slots(sim) if phys]
+        if forces is None or not objs or "object_force" not in sim.engine.tensors:
+            raise NotImplementedError("apply_rigid_body_force_tensors: forces on the free object of the ShadowHand task")
+        n, nb = len(sim.envs), len(sim.asset.body_names)
+        f = forces.view(n, -1, 3)[:, nb]
+        if space == LOCAL_SPACE:
+            f = _quat_rotate(sim.engine.tensors["object_state"][:, 3:7], f)
+        sim.engine.tensors["object_force"].copy_(f)
+        sim.one_shot_force = True
+        return True
+
     def _clear_warm_start(self, sim, ids):
         t = sim.engine.tensors
         for k in ("contact_impulse", "limit_impulse", "self_contact_impulse"):
             if k in t:
                 t[k][ids] = 0.0
 
+    def _envs_of(self, sim, actor_indices, count, slot):
+        """env ids of the sim-domain actor indices that address actor `slot`"""
+        ids = actor_indices[:count].long()
+        A = sim.nactors
+        return torch.div(ids[ids % A == slot], A, rounding_mode="floor")
+
     def set_dof_state_tensor_indexed(self, sim, dof_state, actor_indices, count):
         n, nd = len(sim.envs), sim.asset.spec.nd
-        ids = actor_indices[:count].long()
+        ids = self._envs_of(sim, actor_indices, count, sim.robot)
         sim.engine.tensors["dof_state"][ids] = dof_state.view(n, nd, 2)[ids]
         self._clear_warm_start(sim, ids)
         return True
@@ -394,19 +675,38 @@ class Gym:
         return True
 
     def set_actor_root_state_tensor_indexed(self, sim, root_states, actor_indices, count):
-        ids = actor_indices[:count].long()
-        sim.engine.tensors["root_states"][ids] = root_states.view(len(sim.envs), 13)[ids]
-        self._clear_warm_start(sim, ids)
+        n, A = len(sim.envs), sim.nactors
+        src = root_states.view(n, A, 13)
+        ids = self._envs_of(sim, actor_indices, count, sim.robot)
+        if len(ids) and not sim.asset.spec.fixed_base:
+            sim.engine.tensors["root_states"][ids] = src[ids, sim.robot]
+            self._clear_warm_start(sim, ids)
+        for k, phys in self._object_slots(sim):
+            ids = self._envs_of(sim, actor_indices, count, k)
+            if phys and len(ids):
+                sim.engine.tensors["object_state"][ids] = src[ids, k]
+            # (the goal object: the task's own tensor IS the state)
+        if root_states.data_ptr() != self._buf(sim, "root", (n * A, 13)).data_ptr():
+            self._buf(sim, "root", (n * A, 13)).view(n, A, 13)[:] = src
         return True
 
     def set_actor_root_state_tensor(self, sim, root_states):
-        sim.engine.tensors["root_states"].copy_(root_states.view(len(sim.envs), 13))
+        n, A = len(sim.envs), sim.nactors
+        src = root_states.view(n, A, 13)
+        if not sim.asset.spec.fixed_base:
+            sim.engine.tensors["root_states"].copy_(src[:, sim.robot])
+        for k, phys in self._object_slots(sim):
+            if phys:
+                sim.engine.tensors["object_state"].copy_(src[:, k])
         return True
 
     # ------------------------------------------------------------------ stepping
     def simulate(self, sim):
         sim.engine.simulate()
         sim.frame += 1
+        if sim.one_shot_force:                      # gym applies body forces for one simulate() only
+            sim.engine.tensors["object_force"].zero_()
+            sim.one_shot_force = False
 
     def fetch_results(self, sim, wait=True):
         pass
@@ -455,6 +755,27 @@ class Gym:
         if sim.engine is not None:
             sim.engine.close()
             sim.engine = None
+
+
+def _object_mass(object_type):
+    from ...tasks import shadow_hand as sh
+    from ...utils.config import compose
+    cfgd = compose(overrides=["task=ShadowHand"])["task"]
+    cfgd["env"]["objectType"] = object_type
+    return float(sh.hand_params_from_cfg(cfgd).cube_mass)
+
+
+def _quat_mul(a, b):
+    x1, y1, z1, w1 = a.unbind(-1)
+    x2, y2, z2, w2 = b.unbind(-1)
+    return torch.stack([w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
+                        w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2, w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2], -1)
+
+
+def _quat_rotate(q, v):
+    qv, w = q[..., :3], q[..., 3:4]
+    t = 2.0 * torch.cross(qv, v, dim=-1)
+    return v + w * t + torch.cross(qv, t, dim=-1)
 
 
 def _dof_properties(spec):

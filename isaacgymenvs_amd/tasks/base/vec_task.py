@@ -178,24 +178,10 @@ class VecTask(Env):
         self.sim = self.engine  # what the reference calls self.sim
 
     def _select_multi_wave(self):
-        """Launch shape of the physics sub-step (csrc/core/engine_mw.hpp).  `sim.multi_wave`: "auto" (default), 0, 16 or 32 envs per
-        workgroup.  auto: the multi-wave form while its 4 * N / E waves still find a SIMD each (1024 on an MI355X) -- measured
-        1.4x faster at 4096 envs, slower from 16384 envs on (profiles/r2b_mw_ab.txt); tasks without a multi-wave form ignore it."""
-        mw = os.environ.get("MI_MULTI_WAVE") or self.cfg["sim"].get("multi_wave", "auto")     # the env var: A/B runs and profiling
-        if mw == "auto":
-            mw = 16 if self.num_envs <= 4096 else (32 if self.num_envs <= 8192 else 0)
-            if self.native_task == "Humanoid":
-                mw = 32          # limb waves + pair wave (csrc/mwc_kernels.hpp), at any env count
-            if self.native_task == "ShadowHand":
-                # finger per wave (csrc/hand_mw_kernels.hpp): 32 envs per workgroup (two half-filled waves per SIMD) while that fills the
-                # chip (one workgroup per CU up to 8192 envs), full 64-env waves (half the wave instructions per env) from there on -- profiles/r3l_hand_mw_ab_0_32_64.txt
-                mw = 64 if self.num_envs >= 8192 else 32
-        for cand in (int(mw), 32):     # (a value the task's kernels do not take falls back to 32)
-            try:
-                self.engine.set_option("multi_wave", cand)
-                return
-            except RuntimeError:
-                continue
+        """Launch shape of the physics sub-step: `sim.multi_wave` "auto" (default, native.auto_multi_wave), 0, 16, 32 or 64 envs per workgroup;
+        the env var MI_MULTI_WAVE overrides it for A/B runs and profiling."""
+        mw = os.environ.get("MI_MULTI_WAVE") or self.cfg["sim"].get("multi_wave", "auto")
+        native.select_multi_wave(self.engine, self.native_task, self.num_envs, mw)
 
     def _task_params(self):
         raise NotImplementedError

@@ -13,7 +13,11 @@ import numpy as np
 import pytest
 import torch
 
-REF = "/root/reference"
+# the reference tree: the development container has it at /root/reference; a GPU session stages the few files these tests import under
+# ab/ref_stage (git-ignored, never committed: tools/debug/stage_reference.sh) -- MI_REFERENCE_ROOT overrides both
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("MI_REFERENCE_ROOT") or next((p for p in ("/root/reference", os.path.join(_HERE, "..", "ab", "ref_stage"))
+                                                    if os.path.isdir(os.path.join(p, "isaacgymenvs", "tasks"))), "/root/reference")
 pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "isaacgymenvs", "tasks")), reason="reference tree not reachable")
 
 DEV = "cuda:0" if torch.cuda.is_available() else "cpu"
@@ -36,7 +40,7 @@ def reference_tasks():
         mod = types.ModuleType(name)
         mod.__path__ = [os.path.join(REF, rel)]
         sys.modules[name] = mod
-    mods = {n: importlib.import_module("isaacgymenvs.tasks." + n) for n in ("cartpole", "ant", "humanoid")}
+    mods = {n: importlib.import_module("isaacgymenvs.tasks." + n) for n in ("cartpole", "ant", "humanoid", "anymal_terrain", "shadow_hand")}
     vt = importlib.import_module("isaacgymenvs.tasks.base.vec_task")
     yield mods, vt
     for k in [k for k in sys.modules if k.split(".")[0] in ("isaacgymenvs", "isaacgym", "gym")]:
@@ -55,8 +59,8 @@ def _ref_cfg(task, n):
 
 def test_the_file_really_is_the_reference_one(reference_tasks):
     mods, vt = reference_tasks
-    assert mods["ant"].__file__ == os.path.join(REF, "isaacgymenvs", "tasks", "ant.py")
-    assert vt.__file__ == os.path.join(REF, "isaacgymenvs", "tasks", "base", "vec_task.py")
+    assert os.path.samefile(mods["ant"].__file__, os.path.join(REF, "isaacgymenvs", "tasks", "ant.py"))
+    assert os.path.samefile(vt.__file__, os.path.join(REF, "isaacgymenvs", "tasks", "base", "vec_task.py"))
     import isaacgym
     assert isaacgym._mi_shim and "shims" in isaacgym.gymapi.__file__
 
@@ -116,5 +120,141 @@ def test_reference_locomotion_task_matches_the_fused_kernels_on_the_same_state(r
     d = (r_obs["obs"] - n_obs["obs"]).abs()[keep]
     d[:, [7, 8, 9]] = torch.minimum(d[:, [7, 8, 9]], (d[:, [7, 8, 9]] - 2 * np.pi).abs())
     assert float(d.max()) < 2e-4, float(d.max())              # same engine state -> jitted observations == fused kernel's
+    assert float((r_rew - n_rew).abs()[keep].max()) < 2e-3 * max(1.0, float(r_rew.abs().max()))
+    assert torch.equal(r_reset[keep], n_reset[keep])
+
+
+gpu_only = pytest.mark.skipif(DEV == "cpu", reason="AnymalTerrain / ShadowHand run on the MI355X only")
+
+
+@pytest.mark.gpu
+@gpu_only
+def test_reference_anymal_terrain_runs_on_the_engine_and_matches_the_fused_kernels(reference_tasks):
+    """The reference's own anymal_terrain.py (BASELINE config 4), unmodified: its Terrain class builds the height field with the stand-in
+    `isaacgym.terrain_utils`, `add_triangle_mesh` hands the engine that field, its torch PD loop drives `set_dof_actuation_force_tensor` +
+    `simulate` four times per step, its observations read the root / dof / net-contact-force tensors and the height samples.  Then, on the
+    same state and action, one more step of the native task class (fused kernels): observations (188 columns incl. the 140-point height
+    scan) and rewards agree."""
+    import isaacgymenvs_amd
+    mods, vt = reference_tasks
+    vt.EXISTING_SIM = None
+    n, seed = 128, 7
+    cfg = _ref_cfg("AnymalTerrain", n)
+    cfg["env"]["terrain"].update(numLevels=3, numTerrains=4, curriculum=True)
+    cfg["env"]["learn"]["addNoise"] = False
+    cfg["env"]["learn"]["pushRobots"] = False
+    np.random.seed(seed)                                      # the reference's Terrain draws from the global NumPy stream
+    torch.manual_seed(seed)
+    ref = mods["anymal_terrain"].AnymalTerrain(cfg, rl_device=DEV, sim_device=DEV, graphics_device_id=-1, headless=True,
+                                               virtual_screen_capture=False, force_render=False)
+    assert ref.num_dof == 12 and ref.num_bodies == 13 and ref.obs_buf.shape[1] == 188
+    assert ref.contact_forces.shape == (n, 13, 3) and len(ref.feet_indices) == 4 and len(ref.knee_indices) == 4
+    eng = ref.sim.engine
+    assert torch.equal(eng.height_samples.cpu(), torch.as_tensor(ref.terrain.heightsamples))          # the engine walks on the task's terrain
+    fr = eng.tensors["friction"]
+    assert float(fr.min()) >= 0.5 and float(fr.max()) <= 1.25 and len(torch.unique(fr)) > 10           # the 100 friction buckets (:236-239)
+    g = torch.Generator().manual_seed(1)
+    resets = 0
+    for step in range(40):
+        obs, rew, reset, _ = ref.step((torch.rand((n, 12), generator=g) * 2 - 1).to(DEV))
+        resets += int(reset.sum())
+        assert torch.isfinite(obs["obs"]).all() and torch.isfinite(rew).all()
+    # the robots stand / stumble on the terrain under random actions: base above the local ground, feet do touch it
+    hz = ref.root_states[:, 2] - ref.env_origins[:, 2]
+    assert float(hz.median()) > 0.2 and float(hz.max()) < 1.5
+    assert float((ref.contact_forces[:, ref.feet_indices, 2] > 1.0).float().mean()) > 0.2
+    # ---- same state, same action, one more step: the native task class (fused kernels)
+    from isaacgymenvs_amd.utils.config import compose as _compose
+    ncfg = _compose(overrides=["task=AnymalTerrain"])
+    ncfg["task"]["env"]["numEnvs"] = n
+    ncfg["task"]["env"]["terrain"].update(numLevels=3, numTerrains=4, curriculum=True)
+    ncfg["task"]["env"]["learn"]["addNoise"] = False
+    ncfg["task"]["env"]["learn"]["pushRobots"] = False
+    nat = isaacgymenvs_amd.make(seed=seed, task="AnymalTerrain", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True, cfg=ncfg)
+    assert torch.equal(nat.engine.height_samples.cpu(), eng.height_samples.cpu())                     # same seed, same terrain
+    nat.step(torch.zeros((n, 12), device=DEV))
+    et, nt = eng.tensors, nat.engine.tensors
+    for k in ("root_states", "dof_state", "contact_impulse", "limit_impulse", "friction", "net_contact_force"):
+        nt[k].copy_(et[k])
+    nt["commands"].copy_(ref.commands); nt["last_actions"].copy_(ref.last_actions); nt["last_dof_vel"].copy_(ref.last_dof_vel)
+    nt["feet_air_time"].copy_(ref.feet_air_time); nt["env_origins"].copy_(ref.env_origins)
+    nat.progress_buf.copy_(ref.progress_buf); nat.reset_buf.copy_(ref.reset_buf.long())
+    a = (torch.rand((n, 12), generator=g) * 2 - 1).to(DEV)
+    keep = (ref.reset_buf == 0) & (ref.progress_buf < ref.max_episode_length - 3)
+    # The reference refreshes its dof tensor inside the decimation loop only (anymal_terrain.py:443-452; the refresh in post_physics_step is
+    # commented out, :455), not after the base class's own simulate() (vec_task.py:382): its joint observations -- and the first PD torque of
+    # the next step -- lag the physics by one sim step.  The fused kernels read the current state.  Compared here on a common footing: the
+    # tensor is refreshed before the step (first torque from the current state) and before the reference's compute_observations is re-run.
+    ref.gym.refresh_dof_state_tensor(ref.sim)
+    r_obs, r_rew, r_reset, _ = ref.step(a.clone())
+    n_obs, n_rew, n_reset, _ = nat.step(a.clone())
+    keep &= ~r_reset.bool() & ~n_reset.bool()                 # envs that end here resample commands from different generators
+    assert int(keep.sum()) > n // 2
+    assert float((et["root_states"] - nt["root_states"]).abs()[keep].max()) < 1e-3       # same physics through both boundaries
+    assert float((et["dof_state"] - nt["dof_state"]).abs()[keep].max()) < 5e-3
+    stale = (r_obs["obs"] - n_obs["obs"]).abs()[keep][:, 12:36]
+    ref.gym.refresh_dof_state_tensor(ref.sim)
+    ref.compute_observations()
+    d = (ref.obs_buf - n_obs["obs"]).abs()[keep]
+    assert float(d[:, :36].max()) < 2e-3, float(d[:, :36].max())          # base velocities, gravity, commands, joints
+    assert float(d[:, 36:176].max()) < 2e-3, float(d[:, 36:176].max())    # the 140-point height scan
+    assert float(d[:, 176:].max()) < 1e-5                                  # actions
+    assert float(stale.max()) > 10 * float(d[:, 12:36].max())             # (the lag is real: the un-refreshed joint columns are far off)
+    # the reward's joint terms (joint acceleration, hip, torques) see the lagging tensor in the reference: compared loosely
+    assert float((r_rew - n_rew).abs()[keep].max()) < 5e-2 * max(1.0, float(r_rew.abs().max()))
+
+
+@pytest.mark.gpu
+@gpu_only
+def test_reference_shadow_hand_runs_on_the_engine_and_matches_the_fused_kernels(reference_tasks):
+    """The reference's own shadow_hand.py (BASELINE config 5), unmodified: three actors per env (hand, object, goal object), tendon
+    properties, fingertip force sensors, aggregates, the [3 N, 13] root tensor, the rigid-body state tensor of hand + object + goal,
+    position targets, deferred resets through the indexed setters.  Then, on the same state and action, one more step of the native task
+    class: all 211 observation columns and the rewards agree."""
+    import isaacgymenvs_amd
+    mods, vt = reference_tasks
+    vt.EXISTING_SIM = None
+    n, seed = 96, 5
+    cfg = _ref_cfg("ShadowHand", n)
+    cfg["task"]["randomize"] = False
+    torch.manual_seed(seed)
+    ref = mods["shadow_hand"].ShadowHand(cfg, rl_device=DEV, sim_device=DEV, graphics_device_id=-1, headless=True,
+                                         virtual_screen_capture=False, force_render=False)
+    assert ref.num_shadow_hand_dofs == 24 and ref.num_shadow_hand_actuators == 20 and ref.num_shadow_hand_tendons == 4
+    assert ref.root_state_tensor.shape == (3 * n, 13) and ref.rigid_body_states.shape == (n, ref.num_shadow_hand_bodies + 2, 13)
+    assert ref.obs_buf.shape[1] == 211 and ref.vec_sensor_tensor.shape == (n, 30)
+    eng = ref.sim.engine
+    g = torch.Generator().manual_seed(1)
+    for step in range(25):
+        obs, rew, reset, _ = ref.step((torch.rand((n, 20), generator=g) * 2 - 1).to(DEV))
+        assert torch.isfinite(obs["obs"]).all() and torch.isfinite(rew).all()
+    # the cube lies in the hand (contacts) in most envs, fingertips are where the engine's own fingertip tensor puts them
+    assert float((eng.tensors["object_contact_count"] > 0).float().mean()) > 0.5
+    ref.gym.refresh_rigid_body_state_tensor(ref.sim)
+    tips = ref.rigid_body_states[:, ref.fingertip_handles][:, :, 0:13]
+    assert float((tips - eng.tensors["fingertip_state"]).abs().max()) < 1e-4
+    assert float((ref.object_pos - eng.tensors["object_state"][:, :3]).abs().max()) < 1e-6
+    # ---- same state, same action, one more step: the native task class (fused kernels)
+    nat = isaacgymenvs_amd.make(seed=seed, task="ShadowHand", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True)
+    nat.step(torch.zeros((n, 20), device=DEV))
+    et, nt = eng.tensors, nat.engine.tensors
+    for k in ("dof_state", "limit_impulse", "object_state", "force_sensor", "dof_force", "actor_scale"):
+        nt[k].copy_(et[k])
+    nt["cur_targets"].copy_(ref.cur_targets); nt["prev_targets"].copy_(ref.prev_targets)
+    nt["goal_states"].copy_(ref.goal_states[:, :7]); nt["successes"].copy_(ref.successes)
+    nat.progress_buf.copy_(ref.progress_buf); nat.reset_buf.copy_(ref.reset_buf); nt["reset_goal_buf"].copy_(ref.reset_goal_buf)
+    nt["consecutive_successes"].copy_(ref.consecutive_successes)
+    nt["random_force_prob"].zero_(); ref.random_force_prob.zero_()        # random object forces draw from different generators: off
+    nt["rb_forces_object"].zero_(); ref.rb_forces.zero_()
+    a = (torch.rand((n, 20), generator=g) * 2 - 1).to(DEV)
+    keep = (ref.reset_buf == 0) & (ref.reset_goal_buf == 0)
+    r_obs, r_rew, r_reset, _ = ref.step(a.clone())
+    n_obs, n_rew, n_reset, _ = nat.step(a.clone())
+    assert int(keep.sum()) > n // 2
+    d = (r_obs["obs"] - n_obs["obs"]).abs()[keep]
+    force_cols = np.r_[48:72, 161:191]
+    kin_cols = np.setdiff1d(np.arange(211), force_cols)
+    assert float(d[:, kin_cols].max()) < 2e-4, float(d[:, kin_cols].max())
+    assert float(d[:, force_cols].max()) < 2e-3 * max(1.0, float(r_obs["obs"][:, force_cols].abs().max()))
     assert float((r_rew - n_rew).abs()[keep].max()) < 2e-3 * max(1.0, float(r_rew.abs().max()))
     assert torch.equal(r_reset[keep], n_reset[keep])

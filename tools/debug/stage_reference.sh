@@ -1,0 +1,14 @@
+#!/bin/bash
+# Stages the FEW reference files tests/test_gymapi_shim.py imports under ab/ref_stage (git-ignored: they travel to the GPU box with a
+# gpurun snapshot and are never committed) so that the shim tests can run the reference's unmodified task files on the HIP backend.
+set -e
+ROOT=$(cd $(dirname $0)/../.. && pwd)
+REF=${1:-/root/reference}
+D=$ROOT/ab/ref_stage/isaacgymenvs
+rm -rf $ROOT/ab/ref_stage
+mkdir -p $D/tasks/base $D/utils $D/cfg
+for f in cartpole ant humanoid anymal_terrain shadow_hand; do cp $REF/isaacgymenvs/tasks/$f.py $D/tasks/; done
+cp $REF/isaacgymenvs/tasks/base/vec_task.py $D/tasks/base/
+cp $REF/isaacgymenvs/utils/*.py $D/utils/
+cp -r $REF/isaacgymenvs/cfg/. $D/cfg/
+echo staged $(find $ROOT/ab/ref_stage -type f | wc -l) files under ab/ref_stage
