@@ -1,0 +1,164 @@
+"""Run-time assets: `gym.load_asset(path)` for a robot description file the engine was NOT built with (reference ant.py:149-190 loads
+whatever file the task config names).
+
+The engine is specialised per robot at build time (codegen.py: one constexpr header per model, the kernels are templates over it).  A
+file whose parsed model differs from the compiled one is therefore COMPILED, once, into a library of its own and cached by the hash of
+its generated header:
+
+    parse (assets/model.py, the asset options of the compiled model it stands in for)  ->  ModelSpec
+    same topology as a compiled model (bodies, joints, sensors)?  that model's task kernels apply -- otherwise NotImplementedError
+    emit the header (codegen.py); equal to the compiled model's header -> the stock library
+    otherwise: copy of csrc/ with that one header replaced -> hipcc (gfx950) of the translation units that include it, linked with
+    the stock objects of the others; g++ of the CPU backend for sim_device="cpu"  ->  isaacgymenvs_amd/_variants/<hash>/
+    native.Engine(task, ..., lib_path=that library)
+
+What a variant may change: every number of the model (link lengths, masses, inertias, joint axes / limits / gains, contact spheres and
+their count up to the compiled kernels' row-store limits).  What it may not: the kinematic tree's shape and the dof order, which the task
+kernels' observation layout depends on.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+
+from ..registry import MODELS, load_extras, load_model, load_selfcol, sensor_bodies
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG = os.path.dirname(_HERE)
+VARIANT_DIR = os.path.join(_PKG, "_variants")
+
+# the asset options each compiled model was loaded with (tools/compile_models.py ENTRIES cites the reference lines) and the native task
+ASSET_OPTIONS = {
+    "cartpole": dict(fix_base_link=True, collide_body_filter=lambda n: False),
+    "ant": dict(),
+    "humanoid": dict(),
+    "anymal": dict(density=0.001, replace_cylinder_with_capsule=True),
+}
+TASK_OF_MODEL = {"cartpole": "Cartpole", "ant": "Ant", "humanoid": "Humanoid", "anymal": "AnymalTerrain"}
+
+
+def parse(path, model_name):
+    from .model import load_asset
+    return load_asset(path, name=model_name, **ASSET_OPTIONS[model_name])
+
+
+def same_topology(a, b):
+    import numpy as np
+    return (a.nb == b.nb and a.nd == b.nd and bool(a.fixed_base) == bool(b.fixed_base) and np.array_equal(a.parent, b.parent)
+            and np.array_equal(a.dof_body, b.dof_body) and np.array_equal(a.dof_type, b.dof_type) and list(a.body_names) == list(b.body_names)
+            and list(a.dof_names) == list(b.dof_names) and len(a.sph_body) == len(b.sph_body))
+
+
+def match_model(path):
+    """-> (model name, parsed spec) of the compiled model whose topology the file has, trying the options of every candidate"""
+    errs = []
+    for name in ASSET_OPTIONS:
+        try:
+            spec = parse(path, name)
+        except Exception as e:  # noqa: BLE001 -- a URDF is no MJCF and vice versa
+            errs.append(f"{name}: {e}")
+            continue
+        if same_topology(spec, load_model(name)):
+            return name, spec
+    raise NotImplementedError(f"{path}: no compiled model has this kinematic tree (tried {list(ASSET_OPTIONS)}); the task kernels are "
+                              f"specialised per robot (isaacgymenvs_amd/codegen.py)")
+
+
+def header_text(model_name, spec):
+    from ..codegen import emit_model_header
+    e = MODELS[model_name]
+    extras = load_extras(model_name) if e.get("extras") else None
+    if load_selfcol(model_name) is not None:
+        raise NotImplementedError("run-time variants of self-colliding models need their capsule-pair tables rebuilt (assets/model.py self_collision_tables)")
+    sens = [list(spec.body_names).index(n) for n in e["sensors"]]
+    return emit_model_header(spec, e["struct"], sens, extras, None)
+
+
+def _includes(path, seen):
+    """files reachable through #include "..." from `path` (relative to the including file's directory or csrc/)"""
+    import re
+    if path in seen or not os.path.exists(path):
+        return
+    seen.add(path)
+    csrc = os.path.join(_PKG, "csrc")
+    for m in re.finditer(r'#include\s+"([^"]+)"', open(path).read()):
+        for base in (os.path.dirname(path), csrc):
+            q = os.path.normpath(os.path.join(base, m.group(1)))
+            if os.path.exists(q):
+                _includes(q, seen)
+                break
+
+
+def dependent_sources(model_name):
+    from .. import native
+    csrc = os.path.join(_PKG, "csrc")
+    hdr = os.path.join(csrc, "gen", f"model_{model_name}.h")
+    out = []
+    for s in native.SOURCES:
+        seen = set()
+        _includes(os.path.join(csrc, s), seen)
+        if hdr in seen:
+            out.append(s)
+    return out
+
+
+def variant_library(model_name, spec, device="cuda", verbose=False):
+    """-> path of the library to create the engine from (the stock library when the header is the compiled model's own)"""
+    from .. import native
+    txt = header_text(model_name, spec)
+    csrc = os.path.join(_PKG, "csrc")
+    stock = open(os.path.join(csrc, "gen", f"model_{model_name}.h")).read()
+    cpu = str(device).startswith("cpu")
+    if txt == stock:
+        return None
+    h = hashlib.sha1((txt + model_name).encode()).hexdigest()[:16]
+    vdir = os.path.join(VARIANT_DIR, h)
+    out = os.path.join(vdir, "libmi_engine_cpu.so" if cpu else "libmi_engine.so")
+    stock_lib = native.CPU_LIB_PATH if cpu else native.LIB_PATH
+    if os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(stock_lib):
+        return out
+    src = os.path.join(vdir, "csrc")
+    if os.path.isdir(src):
+        shutil.rmtree(src)
+    shutil.copytree(csrc, src, ignore=shutil.ignore_patterns("build", "*.o", "*.log"))
+    shutil.copytree(os.path.join(_PKG, "..", "include"), os.path.join(vdir, "include"), dirs_exist_ok=True)      # csrc includes ../../include/mi_engine.h
+    # (csrc/ sits two levels below the repo root: keep that shape so that "../../include" resolves)
+    deep = os.path.join(vdir, "pkg", "csrc")
+    if os.path.isdir(os.path.join(vdir, "pkg")):
+        shutil.rmtree(os.path.join(vdir, "pkg"))
+    os.makedirs(os.path.join(vdir, "pkg"))
+    os.replace(src, deep)
+    with open(os.path.join(deep, "gen", f"model_{model_name}.h"), "w") as f:
+        f.write(txt)
+    tmp = out + ".tmp"
+    if cpu:
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", os.path.join(deep, "cpu", "mi_engine_cpu.cpp"), "-o", tmp]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd, cwd=deep)
+    else:
+        deps = dependent_sources(model_name)
+        objs, procs = [], []
+        os.makedirs(os.path.join(deep, "build"), exist_ok=True)
+        for s in native.SOURCES:
+            if s in deps:
+                o = os.path.join(deep, "build", s.replace(".hip", ".o"))
+                cmd = [native.hipcc_path()] + [f for f in native.HIPCC_FLAGS if not f.startswith("-Rpass")] + ["-c", os.path.join(deep, s), "-o", o]
+                if verbose:
+                    print(" ".join(cmd), flush=True)
+                procs.append((s, subprocess.Popen(cmd, cwd=deep, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+            else:
+                o = os.path.join(native.BUILD_DIR, s.replace(".hip", ".o"))
+                if not os.path.exists(o):
+                    raise RuntimeError(f"{o} is missing: build the stock library first (native.build())")
+            objs.append(o)
+        for s, p in procs:
+            log = p.communicate()[0]
+            if p.returncode != 0:
+                raise RuntimeError(f"hipcc failed for the variant of {s}:\n{log.decode()[-3000:]}")
+        subprocess.check_call([native.hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp], cwd=deep)
+    os.replace(tmp, out)
+    spec.save(os.path.join(vdir, "model.json"))
+    return out

@@ -406,6 +406,16 @@ def lib_cpu():
 
 
 _lib = None
+_variant_libs = {}
+
+
+def variant_lib(path):
+    """a library built for a run-time asset (assets/runtime.py): same ABI, another robot model compiled in"""
+    if path not in _variant_libs:
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing")
+        _variant_libs[path] = _bind_lifecycle(C.CDLL(path))
+    return _variant_libs[path]
 
 
 def lib():
@@ -483,18 +493,18 @@ def _dtypes():
 class Engine:
     """Owns a torch uint8 arena on `device` and the native engine handle bound to it."""
 
-    def __init__(self, task, sim_params: MiSimParams, task_params, num_envs, device, seed=0, env_id_offset=0, terrain=None):
+    def __init__(self, task, sim_params: MiSimParams, task_params, num_envs, device, seed=0, env_id_offset=0, terrain=None, lib_path=None):
         import torch
         dev = torch.device(device)
         if dev.type == "cpu":
             # the reference's CPU pipeline (sim_device=cpu): the engine's own host build, OpenMP over envs -- not the test oracle
             if task not in CPU_TASKS:
                 raise RuntimeError(f"task {task} runs on the MI355X only (sim_device='cuda:N'); the CPU backend has {', '.join(CPU_TASKS)}")
-            L = lib_cpu()
+            L = lib_cpu() if lib_path is None else variant_lib(lib_path)
         elif dev.type == "cuda":
             if not torch.cuda.is_available():
                 raise RuntimeError("no ROCm device visible to PyTorch")
-            L = lib()
+            L = lib() if lib_path is None else variant_lib(lib_path)
         else:
             raise RuntimeError(f"unsupported sim device {device!r}")
         self.L = L

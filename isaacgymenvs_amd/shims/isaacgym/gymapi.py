@@ -168,11 +168,24 @@ class _Asset:
             self.body_names, self.body_dyn = ["object"], np.zeros(1, np.int64)
             self.nshapes = 1
             return
-        if key not in _MODEL_OF_FILE:
-            raise NotImplementedError(f"gym.load_asset: {key} has no model compiled into the engine (available: {sorted(_MODEL_OF_FILE)}); "
-                                      f"robots are specialised at build time (isaacgymenvs_amd/codegen.py)")
-        self.model_name, self.task = _MODEL_OF_FILE[key]
-        self.spec = load_model(self.model_name)
+        from ...assets import runtime
+        self.variant = False                   # a file that differs from the compiled model: its own library (assets/runtime.py)
+        if key in _MODEL_OF_FILE:
+            self.model_name, self.task = _MODEL_OF_FILE[key]
+            self.spec = load_model(self.model_name)
+            if os.path.isfile(path) and self.model_name in runtime.ASSET_OPTIONS and runtime.load_selfcol(self.model_name) is None:
+                spec = runtime.parse(path, self.model_name)          # the file itself, not the copy compiled at build time
+                if runtime.header_text(self.model_name, spec) != runtime.header_text(self.model_name, self.spec):
+                    if not runtime.same_topology(spec, self.spec):
+                        raise NotImplementedError(f"gym.load_asset: {path} does not have the kinematic tree of the compiled {self.model_name} model")
+                    self.spec, self.variant = spec, True
+        elif os.path.isfile(path):
+            self.model_name, self.spec = runtime.match_model(path)   # a file of another name with the tree of a compiled model
+            self.task = runtime.TASK_OF_MODEL[self.model_name]
+            self.variant = runtime.header_text(self.model_name, self.spec) != runtime.header_text(self.model_name, load_model(self.model_name))
+        else:
+            raise NotImplementedError(f"gym.load_asset: {key} has no model compiled into the engine (available: {sorted(_MODEL_OF_FILE)}) and "
+                                      f"is not a readable file; robots are specialised per model (isaacgymenvs_amd/codegen.py, assets/runtime.py)")
         # the bodies gym lists: with collapse_fixed_joints the welded links are gone (= the engine's bodies), otherwise every link of the
         # file, each riding on the engine body it is welded to (api_body_dyn) at a fixed offset (api_body_pos / api_body_quat)
         if getattr(options, "collapse_fixed_joints", False):
@@ -471,7 +484,11 @@ class Gym:
         else:
             from ...tasks.locomotion import loco_params_from_cfg
             tp = loco_params_from_cfg(cfg, asset.model_name, float(poses[0, 2]))
-        sim.engine = native.Engine(asset.task, p, tp, n, sim.device, terrain=terrain)
+        lib_path = None
+        if asset.variant:                      # compiled once per distinct model, cached (isaacgymenvs_amd/_variants/<hash>/)
+            from ...assets import runtime
+            lib_path = runtime.variant_library(asset.model_name, asset.spec, sim.device)
+        sim.engine = native.Engine(asset.task, p, tp, n, sim.device, terrain=terrain, lib_path=lib_path)
         if sim.device != "cpu":
             native.select_multi_wave(sim.engine, asset.task, n)        # the launch shape (and with it the solver order) make() would pick
         if asset.has_self_collision:

@@ -11,4 +11,5 @@ for f in cartpole ant humanoid anymal_terrain shadow_hand; do cp $REF/isaacgymen
 cp $REF/isaacgymenvs/tasks/base/vec_task.py $D/tasks/base/
 cp $REF/isaacgymenvs/utils/*.py $D/utils/
 cp -r $REF/isaacgymenvs/cfg/. $D/cfg/
+mkdir -p $ROOT/ab/ref_stage/assets/mjcf && cp $REF/assets/mjcf/nv_ant.xml $ROOT/ab/ref_stage/assets/mjcf/     # tests/test_runtime_assets.py perturbs a copy
 echo staged $(find $ROOT/ab/ref_stage -type f | wc -l) files under ab/ref_stage
