@@ -1,0 +1,17 @@
+#!/bin/bash
+# round 3, session p: full GPU suite (reference tree staged for the shim tests), bench line, smoke, PMC profile -- with the ShadowHand finger waves in
+set -u
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r3p
+mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log; tail -4 $OUT/pytest_gpu.log
+timeout 600 python bench.py --steps 1000 --warmup 100 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; python -c "
+import json
+d=json.loads(open('$OUT/bench.json').read().strip().splitlines()[-1])
+print('Ant', d['value']/1e6, d['ms_per_step'], 'pooled', d['pooled']['ms_per_step'], 'kern', d['roofline']['kernel_ms'], 'frac', d['roofline']['frac'], d['consistent'])
+for k in ('extra','extra2','extra3'):
+    print(d[k]['workload'][:40], d[k]['value']/1e6, d[k]['ms_per_step'], d[k]['roofline']['kernel_ms'], d[k]['consistent'])
+print('cpu', d['cpu_baseline']['value'], d['cpu_baseline']['cores'], d['cpu_baseline'].get('product_backend'))
+"
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+bash tools/profile_r3.sh r3p > $OUT/profile.log 2>&1; tail -3 $OUT/profile.log

@@ -42,7 +42,7 @@ def agg(path):
     return d, meta
 
 
-out = [f"# rocprofv3 PMC summary `{tag}` (bench.py --steps 200 --warmup 40: Ant@4096, Humanoid@8192, AnymalTerrain@4096, ShadowHand@16384, 1x MI355X)\n",
+out = [f"# rocprofv3 PMC summary `{tag}` (bench.py --steps 400 --warmup 40: Ant@4096, Humanoid@8192, AnymalTerrain@4096, ShadowHand@16384, 1x MI355X)\n",
        "Separate passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, SQ counters), as /opt/skills/guides/MI355X_MICROARCH.md prescribes.",
        "FETCH_SIZE / WRITE_SIZE are in KB per launch as rocprofv3 reports them; the calibration section turns them into bytes.",
        "SQ counters are summed over all waves of a launch; the per-wave columns divide by SQ_WAVES; SQ_*CYCLES count quad-cycles.\n"]
@@ -119,10 +119,11 @@ for k, v in d.items():
 # ---- one control step per task = these launches (pattern, launches per step)
 RECIPE = {
     "Ant@4096": [(r"substep(_mw)?_kernel<ModelAnt", 2), (r"loco_post_kernel<ModelAnt", 1)],
-    "Humanoid@8192": [(r"substep_(sc2_)?kernel<ModelHumanoid", 2), (r"loco_post_kernel<ModelHumanoid", 1)],
+    "Humanoid@8192": [(r"substep_(sc2_|mwc_)?kernel<ModelHumanoid", 2), (r"loco_post_kernel<ModelHumanoid", 1)],
     "AnymalTerrain@4096": [(r"substep(_mw)?_kernel<ModelAnymal, mi::HeightfieldGround", 5), (r"anymal_post_kernel", 1), (r"anymal_heights_kernel", 1),
                            (r"anymal_cmdnorm_kernel", 1)],
-    "ShadowHand@16384": [(r"hand_pre_kernel", 1), (r"hand_substep_kernel<0>", 2), (r"hand_post_kernel", 1), (r"hand_finalize_kernel", 1)],
+    "ShadowHand@16384": [(r"hand_pre_kernel", 1), (r"hand_substep(_mw64|_mw)?_kernel<0>", 2), (r"hand_tips_kernel", 1), (r"hand_post_kernel", 1),
+                         (r"hand_finalize_kernel", 1)],
 }
 tj = {}
 out.append("\n## One control step (what bench.py reports as roofline.traffic / roofline.valu)\n")
