@@ -12,11 +12,14 @@ struct View {
     uint32_t seed;
     int ring;  // which obs_out slot this step writes
     int mw;    // multi-wave sub-step: envs per workgroup (16 or 32), 0 = one wave per workgroup (option "multi_wave")
+    int nas;   // columns of actor_scale (NB + 3 ND), 0: the task has none
+    int fused_post;   // limb-per-wave locomotion (Ant): post_physics_step inside the last sub-step launch instead of a kernel of its own (option "fused_post", default 0; the Python layer switches it on for small batches)
     float clip_obs;
     unsigned step;      // control-step counter of this step() (white-noise stream of the in-kernel observation / action noise)
     NoiseParams obs_noise, act_noise;   // domain randomisation noise on observations / actions (dist 0: off), mi_engine_set_noise
+    const float* alloc_fence;   // ALWAYS null: the pointer the never-taken register-allocation fence of the sub-step kernels tests (core/engine.hpp Sim::alloc_fence)
     float* limit_shift; // [2*ND][N] per-env shifts of the lower, then the upper joint limits (`actor_params` dof_properties.lower / upper), null: task has none
-    float* actor_scale; // [4][N] per-env scale of link masses, joint damping, stiffness, armature (`actor_params`), null: task has none
+    float* actor_scale; // [NB + 3 ND][N] per-env scales: link masses per body, then joint damping, stiffness, armature per dof (`actor_params`), null: task has none
     float* root;        // [13][N]
     float* dof;         // [2][ND][N]  (pos block, vel block)
     float* tau;         // [ND][N]  dof_actuation_force

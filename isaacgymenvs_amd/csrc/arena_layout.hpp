@@ -98,9 +98,11 @@ static void build_layout(int task, int N, Layout& L, View* v, char* base, int no
         // per-env friction of the robot's shapes for `actor_params.<actor>.rigid_shape_properties.friction` domain randomisation
         // (vec_task.py:752-828); negative = the model's own value
         o = L.add("friction", MI_F32, {n}, {1}, n); if (v) v->friction = (float*)P(o);
-        // per-env scale of the actor's link masses and joint damping / stiffness / armature (`actor_params.<actor>.rigid_body_properties.mass`,
-        // `.dof_properties.*`); 1 = the model's own values
-        o = L.add("actor_scale", MI_F32, {n, 4}, {1, n}, 4 * n); if (v) v->actor_scale = (float*)P(o);
+        // per-env scales of the actor's link masses (`actor_params.<actor>.rigid_body_properties.mass`: [0, nb)) and joint damping / stiffness /
+        // armature (`.dof_properties.*`: [nb, nb + nd), [nb + nd, nb + 2 nd), [nb + 2 nd, nb + 3 nd)); 1 = the model's own values
+        // (round 3: one factor per BODY for mass + inertia, then per DOF for damping, stiffness, armature -- the reference's granularity)
+        const int64_t nas = (int64_t)m.nb + 3 * nd;
+        o = L.add("actor_scale", MI_F32, {n, nas}, {1, n}, nas * n); if (v) { v->actor_scale = (float*)P(o); v->nas = (int)nas; }
         // `.dof_properties.lower / upper`: one shift per joint limit and env (0 = the model's limits)
         o = L.add("dof_limit_shift", MI_F32, {n, 2 * nd}, {1, n}, 2 * nd * n); if (v) v->limit_shift = (float*)P(o);
     }

@@ -17,6 +17,7 @@
 #pragma once
 #include <cmath>
 #include <utility>
+#include <type_traits>
 
 #if defined(MI_TIMING) && defined(__HIP_DEVICE_COMPILE__)
 // tools/debug only: s_memtime stamps at the phase boundaries of a sub-step (never defined in the product build)
@@ -300,6 +301,12 @@ MI_HD void seg_seg_closest(const float* a0, const float* a1, const float* b0, co
     }
 }
 
+// `actor_params` domain randomisation of a model's masses and joint constants: Scaled<M> is M with the per-env factor tensors switched on
+// (see Sim::SCALED); only models with M::ACTOR_SCALES != 0 (Ant, Humanoid) are ever wrapped.
+template <class M> struct Scaled : M { static constexpr bool MI_SCALED = true; };
+template <class M, class = void> struct is_scaled : std::false_type {};
+template <class M> struct is_scaled<M, std::void_t<decltype(M::MI_SCALED)>> : std::true_type {};
+
 template <class M>
 struct Sim {
     static constexpr int NB = M::NB, ND = M::ND, NV = M::NV, OFF = M::OFF, NSPH = M::NSPH, NSENS = M::NSENS;
@@ -379,17 +386,35 @@ struct Sim {
     // `actor_params` domain randomisation (reference vec_task.py:752-828: rigid_body_properties.mass, dof_properties.damping /
     // stiffness / armature): per-env scale factors of the model's link masses + inertias and joint constants.  Only the models that
     // carry the "actor_scale" tensor (M::ACTOR_SCALES, Ant and Humanoid) multiply by them; for the others the constants stay literals.
-#if defined(MI_NO_ACTOR_SCALES)   // measurement builds only: what the `actor_params` code costs when it is compiled in but switched off
-    static constexpr bool SCALED = false;
-#else
-    static constexpr bool SCALED = M::ACTOR_SCALES != 0;
-#endif
-    // [4] mass, damping, stiffness, armature factors of this env (strided like every per-env vector), or p == nullptr.  They are
-    // loaded where they are used -- at the start of the right-hand-side phase and again for the joint forces at the end -- instead of
-    // living in registers through the whole sub-step: the joint-space inertia H and the bias forces are linear in the link masses,
-    // so the tree pass runs on the model's own masses and H, bias are scaled afterwards (keeping four more values live through the
-    // tree pass cost the Humanoid kernel 220 additional spilled registers and 1.8x its run time).
+    // The factors are compiled into a SEPARATE instantiation, Sim<Scaled<M>>: the launchers pick it when the arena holds the tensors
+    // (option actor_tensors) and the plain Sim<M> otherwise, so the benchmark kernels carry none of this code.  (Rounds 1-2 compiled
+    // it into the one kernel behind a null-pointer test; the tree pass of the Humanoid then kept the factors live and its register
+    // allocation swung by hundreds of spilled registers with every change to this block.)
+    static constexpr bool SCALED = is_scaled<M>::value;
+    // [NB + 3 ND] factors of this env (strided like every per-env vector), or p == nullptr: one per BODY for its mass and inertia, then
+    // one per DOF for the joint's damping, its stiffness and its armature -- the granularity the reference draws them with (it walks
+    // every body / dof property struct of the actor, vec_task.py:783-828).  Each factor is loaded where it is used (a body's in the
+    // downward half of the tree pass, where its spatial inertia is formed; the joints' at the start of the right-hand-side phase and
+    // again for the joint forces at the end) instead of living in registers through the sub-step.  (Until round 3: one factor per
+    // actor for each of the four, applied to H and the bias forces after the tree pass.)
     Strided actor_scale{nullptr, 1};
+    // Register-allocation fence of the plain kernels of those models.  The sub-step is one huge basic block; LLVM's allocator does far
+    // better on the Humanoid when a conditional block that rewrites H and the bias forces splits it between the tree pass and the
+    // right-hand side (limb-wave kernel: 60 spilled registers with it, 220 without; DESIGN.md "compiler regime").  Up to round 3 the
+    // null-tested application of the mass factor happened to be that block; now that the factors live in Sim<Scaled<M>> the kernels
+    // keep a block of the same shape on purpose.  `fence` is View::alloc_fence, a pointer no arena ever sets, so the block is never
+    // executed; the compiler cannot know that.
+    static constexpr bool FENCED = M::ACTOR_SCALES != 0;
+    Strided fence{nullptr, 1};
+    template <class F> MI_HD void alloc_fence(F&& rewrite) const {
+        if constexpr (FENCED) { if (fence.p != nullptr) rewrite(fence(0)); }
+    }
+    static constexpr int AS_BODY = 0, AS_DAMP = M::NB, AS_STIFF = M::NB + M::ND, AS_ARM = M::NB + 2 * M::ND, AS_COLS = M::NB + 3 * M::ND;
+    template <int b> MI_HD float body_scale() const {
+        float x = 1.f;
+        if constexpr (SCALED) { if (actor_scale.p != nullptr) x = actor_scale(AS_BODY + b); }
+        return x;
+    }
     // `actor_params.<actor>.dof_properties.lower / upper` (Ant.yaml:94-101): per-env shifts of the joint limits, [ND] lower then [ND] upper,
     // or p == nullptr; same models as actor_scale
     Strided limit_shift{nullptr, 1};
@@ -600,12 +625,24 @@ struct Sim {
             const float Iw1 = T[0] * Rb[3] + T[1] * Rb[4] + T[2] * Rb[5];
             const float Iw2 = T[0] * Rb[6] + T[1] * Rb[7] + T[2] * Rb[8];
             const float Iw5 = T[3] * Rb[6] + T[4] * Rb[7] + T[5] * Rb[8];
-            constexpr float mm = M::mass[b];
             const float cc = dot3(cm, cm);
-            I.m = mm; I.h[0] = mm * cm[0]; I.h[1] = mm * cm[1]; I.h[2] = mm * cm[2];
-            I.I[0] = Iw0 + mm * (cc - cm[0] * cm[0]); I.I[1] = Iw4 + mm * (cc - cm[1] * cm[1]);
-            I.I[2] = Iw8 + mm * (cc - cm[2] * cm[2]);
-            I.I[3] = Iw1 - mm * cm[0] * cm[1]; I.I[4] = Iw2 - mm * cm[0] * cm[2]; I.I[5] = Iw5 - mm * cm[1] * cm[2];
+            if constexpr (SCALED) {
+                // `actor_params` rigid_body_properties.mass: this body's mass (and with it its inertia) times its factor.  Only in the
+                // Sim<Scaled<M>> instantiation: in the Humanoid's kernels this multiply costs ~300 more spilled registers (limb waves
+                // 154 -> 467, one wave 327 -> 727), which the runs without randomised masses must not pay.
+                const float sb = this->template body_scale<b>();
+                const float mm = M::mass[b] * sb;
+                I.m = mm; I.h[0] = mm * cm[0]; I.h[1] = mm * cm[1]; I.h[2] = mm * cm[2];
+                I.I[0] = sb * Iw0 + mm * (cc - cm[0] * cm[0]); I.I[1] = sb * Iw4 + mm * (cc - cm[1] * cm[1]);
+                I.I[2] = sb * Iw8 + mm * (cc - cm[2] * cm[2]);
+                I.I[3] = sb * Iw1 - mm * cm[0] * cm[1]; I.I[4] = sb * Iw2 - mm * cm[0] * cm[2]; I.I[5] = sb * Iw5 - mm * cm[1] * cm[2];
+            } else {
+                constexpr float mm = M::mass[b];
+                I.m = mm; I.h[0] = mm * cm[0]; I.h[1] = mm * cm[1]; I.h[2] = mm * cm[2];
+                I.I[0] = Iw0 + mm * (cc - cm[0] * cm[0]); I.I[1] = Iw4 + mm * (cc - cm[1] * cm[1]);
+                I.I[2] = Iw8 + mm * (cc - cm[2] * cm[2]);
+                I.I[3] = Iw1 - mm * cm[0] * cm[1]; I.I[4] = Iw2 - mm * cm[0] * cm[2]; I.I[5] = Iw5 - mm * cm[1] * cm[2];
+            }
         }
         // velocity / bias acceleration recursion
         float (&Vc)[6] = t.Vc;
@@ -854,20 +891,22 @@ struct Sim {
         // ------------------------------------------------------------ rhs, implicit spring/damper on the diagonal
         float Ldi[NVA];  // 1 / L_ii
         float y[NVA];
-        float sc_damp = 1.f, sc_stiff = 1.f, sc_arm = 1.f;
+        float sc_damp[M::NDA], sc_stiff[M::NDA], sc_arm[M::NDA];      // per-dof `actor_params` factors (folded away for unscaled models)
+        sfor<ND>([&](auto D) MI_LAMBDA { sc_damp[D] = 1.f; sc_stiff[D] = 1.f; sc_arm[D] = 1.f; });
         if constexpr (SCALED) {
             if (actor_scale.p != nullptr) {
-                const float sc_mass = actor_scale(0);
-                sc_damp = actor_scale(1); sc_stiff = actor_scale(2); sc_arm = actor_scale(3);
-                sfor<M::NM>([&](auto E_) MI_LAMBDA { L[E_] *= sc_mass; });
-                sfor<NV>([&](auto I) MI_LAMBDA { c.bias[I] *= sc_mass; });
+                sfor<ND>([&](auto D) MI_LAMBDA { sc_damp[D] = actor_scale(AS_DAMP + D); sc_stiff[D] = actor_scale(AS_STIFF + D); sc_arm[D] = actor_scale(AS_ARM + D); });
             }
         }
+        alloc_fence([&](float f) MI_LAMBDA {      // never taken (see alloc_fence)
+            sfor<M::NM>([&](auto E_) MI_LAMBDA { L[E_] *= f; });
+            sfor<NV>([&](auto I) MI_LAMBDA { c.bias[I] *= f; });
+        });
         sfor<OFF>([&](auto I) MI_LAMBDA { y[I] = -c.bias[I]; });
         sfor<ND>([&](auto D) MI_LAMBDA {
             constexpr int d = D, gi = OFF + d;
-            const float K = M::dof_stiffness[d] * sc_stiff, Dm = M::dof_damping[d] * sc_damp;
-            L[M::midx[gi][gi]] += M::dof_armature[d] * sc_arm + h * Dm + h * h * K;
+            const float K = M::dof_stiffness[d] * sc_stiff[d], Dm = M::dof_damping[d] * sc_damp[d];
+            L[M::midx[gi][gi]] += M::dof_armature[d] * sc_arm[d] + h * Dm + h * h * K;
             y[gi] = tau[d] - c.bias[gi] - K * (q[d] - M::dof_springref[d]) - (Dm + h * K) * qd[d];
             if (drv) {   // position drive: the same implicit linearisation as the passive spring / damper
                 L[M::midx[gi][gi]] += h * drv->kd + h * h * drv->kp;
@@ -1626,8 +1665,9 @@ struct Sim {
         });
         MI_PHASE();
         // ------------------------------------------------------------ impulses -> warm start, sensors, dof forces
-        float fs_damp = 1.f, fs_stiff = 1.f;
-        if constexpr (SCALED) { if (actor_scale.p != nullptr) { fs_damp = actor_scale(1); fs_stiff = actor_scale(2); } }
+        float fs_damp[M::NDA], fs_stiff[M::NDA];
+        sfor<ND>([&](auto D) MI_LAMBDA { fs_damp[D] = 1.f; fs_stiff[D] = 1.f; });
+        if constexpr (SCALED) { if (actor_scale.p != nullptr) { sfor<ND>([&](auto D) MI_LAMBDA { fs_damp[D] = actor_scale(AS_DAMP + D); fs_stiff[D] = actor_scale(AS_STIFF + D); }); } }
         sfor<ND>([&](auto D) MI_LAMBDA {
             constexpr int d = D;
             float ll = 0.f;
@@ -1637,7 +1677,7 @@ struct Sim {
                 ll = (dl < du) ? lam(row) : -lam(row);
             }
             laml(d) = ll;
-            float df = tau[d] - M::dof_stiffness[d] * fs_stiff * (q[d] - M::dof_springref[d]) - M::dof_damping[d] * fs_damp * v[OFF + d] + ll * invh;
+            float df = tau[d] - M::dof_stiffness[d] * fs_stiff[d] * (q[d] - M::dof_springref[d]) - M::dof_damping[d] * fs_damp[d] * v[OFF + d] + ll * invh;
             if (drv) df += drv->kp * (drv->target[d] - q[d]) - drv->kd * v[OFF + d];
             dof_force(d) = df;
         });

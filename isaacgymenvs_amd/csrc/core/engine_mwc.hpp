@@ -485,19 +485,23 @@ struct SimMWC : SimMW<M> {
         sfor<ND>([&](auto D) MI_LAMBDA { v[OFF + D] = qd[D]; });
         sfor<M::NM>([&](auto E_) MI_LAMBDA { if constexpr (MW::trunk_entry(E_)) L[E_] = 0.f; });
         sfor<NV>([&](auto I) MI_LAMBDA { if constexpr (MW::trunk_gi(I)) y[I] = 0.f; });
-        float sc_mass = 1.f, sc_damp = 1.f, sc_stiff = 1.f, sc_arm = 1.f;
+        // per-dof `actor_params` factors of the dofs this role sees (the bodies' mass factors are applied where the tree pass forms their inertias)
+        float sc_damp[M::NDA], sc_stiff[M::NDA], sc_arm[M::NDA];
+        sfor<ND>([&](auto D) MI_LAMBDA { sc_damp[D] = 1.f; sc_stiff[D] = 1.f; sc_arm[D] = 1.f; });
         if constexpr (B::SCALED) {
             if (this->actor_scale.p != nullptr) {
-                sc_mass = this->actor_scale(0); sc_damp = this->actor_scale(1); sc_stiff = this->actor_scale(2); sc_arm = this->actor_scale(3);
-                sfor<M::NM>([&](auto E_) MI_LAMBDA { if constexpr (MW::role_of_gi(MW::entry_row(E_)) == R) L[E_] *= sc_mass; });
-                sfor<NV>([&](auto I) MI_LAMBDA { if constexpr (MW::role_of_gi(I) == R) c.bias[I] *= sc_mass; });
+                sfor<ND>([&](auto D) MI_LAMBDA {
+                    if constexpr (MW::template sees_gi<R>(OFF + D)) {
+                        sc_damp[D] = this->actor_scale(B::AS_DAMP + D); sc_stiff[D] = this->actor_scale(B::AS_STIFF + D); sc_arm[D] = this->actor_scale(B::AS_ARM + D);
+                    }
+                });
             }
         }
         sfor<ND>([&](auto D) MI_LAMBDA {
             constexpr int d = D, gi = OFF + d;
             if constexpr (MW::role_of_gi(gi) == R) {
-                const float K = M::dof_stiffness[d] * sc_stiff, Dm = M::dof_damping[d] * sc_damp;
-                L[M::midx[gi][gi]] += M::dof_armature[d] * sc_arm + h * Dm + h * h * K;
+                const float K = M::dof_stiffness[d] * sc_stiff[d], Dm = M::dof_damping[d] * sc_damp[d];
+                L[M::midx[gi][gi]] += M::dof_armature[d] * sc_arm[d] + h * Dm + h * h * K;
                 y[gi] = tau[d] - c.bias[gi] - K * (q[d] - M::dof_springref[d]) - (Dm + h * K) * qd[d];
             }
         });
@@ -560,18 +564,17 @@ struct SimMWC : SimMW<M> {
                 this->template body_up<b>(c, t);
             }
         });
-        if constexpr (B::SCALED) {
-            if (this->actor_scale.p != nullptr) {
-                sfor<M::NM>([&](auto E_) MI_LAMBDA { if constexpr (MW::trunk_entry(E_)) L[E_] *= sc_mass; });
-                sfor<NV>([&](auto I) MI_LAMBDA { if constexpr (MW::trunk_gi(I)) c.bias[I] *= sc_mass; });
-            }
-        }
+        // register-allocation fence (Sim::alloc_fence): without this never-taken block the kernel spills 220 registers instead of 60
+        this->alloc_fence([&](float f) MI_LAMBDA {
+            sfor<M::NM>([&](auto E_) MI_LAMBDA { if constexpr (MW::trunk_entry(E_)) L[E_] *= f; });
+            sfor<NV>([&](auto I) MI_LAMBDA { if constexpr (MW::trunk_gi(I)) c.bias[I] *= f; });
+        });
         sfor<OFF>([&](auto I) MI_LAMBDA { y[I] = -c.bias[I]; });
         sfor<ND>([&](auto D) MI_LAMBDA {
             constexpr int d = D, gi = OFF + d;
             if constexpr (MW::trunk_gi(gi)) {
-                const float K = M::dof_stiffness[d] * sc_stiff, Dm = M::dof_damping[d] * sc_damp;
-                L[M::midx[gi][gi]] += M::dof_armature[d] * sc_arm + h * Dm + h * h * K;
+                const float K = M::dof_stiffness[d] * sc_stiff[d], Dm = M::dof_damping[d] * sc_damp[d];
+                L[M::midx[gi][gi]] += M::dof_armature[d] * sc_arm[d] + h * Dm + h * h * K;
                 y[gi] = tau[d] - c.bias[gi] - K * (q[d] - M::dof_springref[d]) - (Dm + h * K) * qd[d];
             }
         });
@@ -916,7 +919,7 @@ struct SimMWC : SimMW<M> {
                     ll = (dl < du) ? lr : -lr;
                 }
                 laml(d) = ll;
-                dof_force(d) = tau[d] - M::dof_stiffness[d] * sc_stiff * (q[d] - M::dof_springref[d]) - M::dof_damping[d] * sc_damp * v[OFF + d] + ll * invh;
+                dof_force(d) = tau[d] - M::dof_stiffness[d] * sc_stiff[d] * (q[d] - M::dof_springref[d]) - M::dof_damping[d] * sc_damp[d] * v[OFF + d] + ll * invh;
             }
         });
         float sens[6 * M::NSENSA];

@@ -205,7 +205,7 @@ extern "C" int mi_engine_init_state(MiEngine* e, void*) {
         for (int k = 0; k < m.nobs; ++k) { v.obs[(size_t)en * m.nobs + k] = 0.f; v.obs_out[(size_t)en * m.nobs + k] = 0.f; v.obs_out[((size_t)N + en) * m.nobs + k] = 0.f; }
         v.potentials[en] = pot0; v.prev_potentials[en] = pot0;
         if (v.friction) v.friction[en] = -1.f;
-        if (e->actor_scale_arena) for (int k = 0; k < 4; ++k) e->actor_scale_arena[k * N + en] = 1.f;
+        if (e->actor_scale_arena) for (int k = 0; k < v.nas; ++k) e->actor_scale_arena[k * N + en] = 1.f;
         if (e->limit_shift_arena) for (int k = 0; k < 2 * nd; ++k) e->limit_shift_arena[k * N + en] = 0.f;
         for (int k = 0; k < 3; ++k) { v.up_vec[k * N + en] = (k == 2) ? 1.f : 0.f; v.heading_vec[k * N + en] = (k == 0) ? 1.f : 0.f; }
         v.rew[en] = 0.f;
@@ -251,6 +251,10 @@ static inline void store_env(const Sim<M>& s, const View& v, int en) {
 // gym.simulate(): `substeps` sub-steps with the efforts in tau (what substep_kernel does per lane)
 template <class M>
 static void simulate_env(const View& v, const SimParams& P, int en, const float* tau) {
+    if constexpr (M::ACTOR_SCALES != 0 && !is_scaled<M>::value) {
+        // option actor_tensors: the instantiation that reads the `actor_params` factors, as on the device (step_kernels.hpp launch_substeps)
+        if (v.actor_scale != nullptr || v.limit_shift != nullptr) return simulate_env<Scaled<M>>(v, P, en, tau);
+    }
     const int N = v.N;
     Sim<M> sim;
     load_env(sim, v, en);

@@ -65,7 +65,7 @@ __global__ void init_state_kernel(View v, int nd, int nsph3, int nsens6, int nob
     for (int k = 0; k < nobs; ++k) { v.obs[(size_t)e * nobs + k] = 0.f; v.obs_out[(size_t)e * nobs + k] = 0.f; v.obs_out[((size_t)N + e) * nobs + k] = 0.f; }
     v.potentials[e] = pot0; v.prev_potentials[e] = pot0;
     if (v.friction) v.friction[e] = -1.f;       // model friction until somebody writes the tensor (AnymalTerrain's init overwrites it)
-    if (v.actor_scale) for (int k = 0; k < 4; ++k) v.actor_scale[k * N + e] = 1.f;
+    if (v.actor_scale) for (int k = 0; k < v.nas; ++k) v.actor_scale[k * N + e] = 1.f;
     if (v.limit_shift) for (int k = 0; k < 2 * nd; ++k) v.limit_shift[k * N + e] = 0.f;
     for (int k = 0; k < 3; ++k) { v.up_vec[k * N + e] = (k == 2) ? 1.f : 0.f; v.heading_vec[k * N + e] = (k == 0) ? 1.f : 0.f; }
     v.rew[e] = 0.f;
@@ -355,6 +355,7 @@ extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const 
     else memcpy(&e->loco, task_params, sizeof(LocoParams));
     Layout L;
     memset(&e->v, 0, sizeof(View));
+    e->v.fused_post = 0;
     int nobs = 0;
     if (t == T_SHADOWHAND) {
         const HandParams& hp = e->hand;
@@ -430,6 +431,9 @@ extern "C" int mi_engine_set_option(MiEngine* e, const char* key, double value) 
         e->v.mw = (int)value;
         return 0;
     }
+    // limb-per-wave locomotion (Ant): 1 = post_physics_step runs on one wave of every sub-step workgroup at the end of the step's last
+    // sub-step launch (mw_kernels.hpp), 0 (default) = in loco_post_kernel as for the one-wave form
+    if (!strcmp(key, "fused_post")) { e->v.fused_post = value != 0 ? 1 : 0; return 0; }
     // control-step counter (observation ring parity, AnymalTerrain push schedule, noise counters): part of a state checkpoint
     if (!strcmp(key, "steps")) { if (value < 0) return fail("steps < 0"); e->steps = (unsigned long long)value; return 0; }
     if (!strcmp(key, "actor_tensors")) {   // 1: the sub-step reads actor_scale / dof_limit_shift (Ant, Humanoid); ShadowHand always reads its own
@@ -465,6 +469,7 @@ extern "C" int mi_engine_get_option(const MiEngine* e, const char* key, double* 
     if (!strcmp(key, "control_freq_inv")) { *out = e->control_freq_inv; return 0; }
     if (!strcmp(key, "self_collision")) { *out = e->v.lamp != nullptr ? 1.0 : 0.0; return 0; }
     if (!strcmp(key, "multi_wave")) { *out = e->v.mw; return 0; }
+    if (!strcmp(key, "fused_post")) { *out = e->v.fused_post; return 0; }
     if (!strcmp(key, "steps")) { *out = (double)e->steps; return 0; }
     if (!strcmp(key, "terrain_slope_threshold")) { *out = e->terrain.slope_threshold; return 0; }
     if (!strcmp(key, "actor_tensors")) { *out = (e->task == T_SHADOWHAND || e->v.actor_scale != nullptr) ? 1.0 : 0.0; return 0; }

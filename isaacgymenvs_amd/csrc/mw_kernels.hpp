@@ -14,9 +14,11 @@ struct DevBarrier {
 };
 template <class M, int E>
 constexpr size_t mw_lds_bytes() { return (size_t)SimMW<M>::MW_SLOTS * E * sizeof(float); }
+// post_x: non-null = the step's last sub-step with post_physics_step fused in: the role also leaves its part of the new state (own q / qd; the
+// trunk role: the root state) in the LDS exchange area for the wave that runs loco_post_env
 template <class M, class GND, int E, int R>
 __device__ __forceinline__ void mw_role(const View& v, const SimParams& P, const ActParams& ap, const float* __restrict__ actions_in,
-                                        const int src, const GND& gnd, float* lds_rows, const int e, const int lane) {
+                                        const int src, const GND& gnd, float* lds_rows, const int e, const int lane, float* post_x = nullptr) {
     using S = SimMW<M>;
     constexpr int ND = M::ND;
     const int N = v.N;
@@ -82,6 +84,12 @@ __device__ __forceinline__ void mw_role(const View& v, const SimParams& P, const
         }
     });
     if constexpr (R == M::TRUNK_ROLE) sfor<13>([&](auto K) MI_LAMBDA { v.root[K * N + e] = sim.root[K]; });
+    if (post_x != nullptr) {     // [13 + 2 ND][E]
+        sfor<ND>([&](auto K) MI_LAMBDA {
+            if constexpr (S::template owns_gi<R>(M::OFF + K)) { post_x[(13 + K) * E] = sim.q[K]; post_x[(13 + ND + K) * E] = sim.qd[K]; }
+        });
+        if constexpr (R == M::TRUNK_ROLE) sfor<13>([&](auto K) MI_LAMBDA { post_x[K * E] = sim.root[K]; });
+    }
 }
 template <class M, class GND, int E>
 __global__ __launch_bounds__(64 * M::NROLE) void substep_mw_kernel(View v, SimParams P, ActParams ap, const float* __restrict__ actions_in,
@@ -117,6 +125,74 @@ hipError_t launch_substeps_mw(const View& v, const SimParams& P, const ActParams
         if (hipError_t e = ensure_dynamic_lds((const void*)kern, lds32, &conf32); e != hipSuccess) return e;
         const dim3 grid(xcd_grid<32>(v.N));
         for (int i = 0; i < n_sub; ++i) hipLaunchKernelGGL(kern, grid, block, lds32, s, v, P, ap, actions, i == 0 ? first : rest, gnd);
+    }
+    return hipGetLastError();
+}
+
+// The step's LAST sub-step with post_physics_step fused in (locomotion tasks on the limb-per-wave form): the four role waves finish the
+// sub-step as above, leave the new root / dof state in the (by then dead) tree-pass exchange area, meet at one more barrier, and ONE wave
+// runs loco_post_env for the workgroup's envs -- progress, in-kernel reset, observations, reward, write-out -- instead of a kernel of its
+// own on 64 waves (Ant@4096: 10.3 us of a 42 us step).  Force sensors, joint forces and actions come from global memory (written by this
+// or an earlier launch, never read before in this one: no stale L1 lines; __syncthreads orders the stores).
+// (arguments as ONE struct read through the kernarg segment pointer: as by-value parameters the ~190 dwords of LocoParams + View would be
+// preloaded into SGPRs and spill, see mwc_kernels.hpp MwcArgs)
+template <class GND>
+struct MwPostArgs {
+    View v;
+    SimParams P;
+    ActParams ap;
+    const float* actions_in;
+    int src;
+    GND gnd;
+    LocoParams tp;
+};
+template <class M, class GND, int E, bool HUM>
+__global__ __launch_bounds__(64 * M::NROLE) void substep_mw_post_kernel(MwPostArgs<GND> args_by_value) {
+    extern __shared__ float lds_rows[];   // [MW_SLOTS][E]
+    static_assert(M::NROLE == 4, "four roles, one per SIMD of a CU");
+    static_assert(13 + 2 * M::ND <= 16 * SimMW<M>::NLR, "the new state fits the tree-pass exchange area");
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)args_by_value;
+    const MwPostArgs<GND>& a = *reinterpret_cast<const MwPostArgs<GND>*>(__builtin_amdgcn_kernarg_segment_ptr());
+    const int lane = threadIdx.x;
+    if (lane >= E) return;
+    const int e = xcd_env_base<E>(blockIdx.x) + lane;
+    if (e >= a.v.N) return;
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    float* post_x = lds_rows + (size_t)SimMW<M>::X_LR * E + lane;
+    switch (role) {
+        case 0: mw_role<M, GND, E, 0>(a.v, a.P, a.ap, a.actions_in, a.src, a.gnd, lds_rows, e, lane, post_x); break;
+        case 1: mw_role<M, GND, E, 1>(a.v, a.P, a.ap, a.actions_in, a.src, a.gnd, lds_rows, e, lane, post_x); break;
+        case 2: mw_role<M, GND, E, 2>(a.v, a.P, a.ap, a.actions_in, a.src, a.gnd, lds_rows, e, lane, post_x); break;
+        default: mw_role<M, GND, E, 3>(a.v, a.P, a.ap, a.actions_in, a.src, a.gnd, lds_rows, e, lane, post_x); break;
+    }
+    __syncthreads();
+    if (role != M::TRUNK_ROLE) return;
+    float root[13], q[M::NDA], qd[M::NDA];
+    sfor<13>([&](auto K) MI_LAMBDA { root[K] = post_x[K * E]; });
+    sfor<M::ND>([&](auto K) MI_LAMBDA { q[K] = post_x[(13 + K) * E]; qd[K] = post_x[(13 + M::ND + K) * E]; });
+    loco_post_env<M, HUM, E, true>(a.v, a.tp, e, true, root, q, qd);
+#endif
+}
+
+template <class M, bool HUM>
+hipError_t launch_substeps_mw_post(const View& v, const SimParams& P, const ActParams& ap, const float* actions, int n_sub, int first, int rest,
+                                   hipStream_t s, const LocoParams& tp) {
+    if (n_sub > 1) {
+        if (hipError_t e = launch_substeps_mw<M, PlaneGround>(v, P, ap, actions, n_sub - 1, first, rest, s, PlaneGround{}); e != hipSuccess) return e;
+    }
+    const int src = n_sub > 1 ? rest : first;
+    static unsigned long long conf16 = 0ull, conf32 = 0ull;
+    constexpr size_t lds16 = mw_lds_bytes<M, 16>(), lds32 = mw_lds_bytes<M, 32>();
+    const dim3 block(64, M::NROLE);
+    if (MI_MW_HAS16 && v.mw == 16) {
+        auto kern = substep_mw_post_kernel<M, PlaneGround, MI_MW_HAS16 ? 16 : 32, HUM>;
+        if (hipError_t e = ensure_dynamic_lds((const void*)kern, lds16, &conf16); e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(xcd_grid<16>(v.N)), block, lds16, s, MwPostArgs<PlaneGround>{v, P, ap, actions, src, PlaneGround{}, tp});
+    } else {
+        auto kern = substep_mw_post_kernel<M, PlaneGround, 32, HUM>;
+        if (hipError_t e = ensure_dynamic_lds((const void*)kern, lds32, &conf32); e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(xcd_grid<32>(v.N)), block, lds32, s, MwPostArgs<PlaneGround>{v, P, ap, actions, src, PlaneGround{}, tp});
     }
     return hipGetLastError();
 }

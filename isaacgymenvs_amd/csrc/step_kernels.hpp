@@ -35,6 +35,7 @@ __device__ __forceinline__ void load_actor_scales(S& s, const View& v, int e) {
         if (v.actor_scale != nullptr) s.actor_scale = Strided{v.actor_scale + e, v.N};
         if (v.limit_shift != nullptr) s.limit_shift = Strided{v.limit_shift + e, v.N};
     }
+    if constexpr (S::FENCED) { if (v.alloc_fence != nullptr) s.fence = Strided{const_cast<float*>(v.alloc_fence) + e, v.N}; }   // never (Sim::alloc_fence)
 }
 template <class M>
 __device__ __forceinline__ void store_sim(const Sim<M>& s, const View& v, int e) {
@@ -56,7 +57,20 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = ACTIVE / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// the same where lanes of the wave have already retired (the fused post step of the limb-per-wave kernels: the lanes of a partly filled last
+// workgroup return at the top of the kernel): a retired lane's value is not defined, so it is masked by the wave's exec mask
 template <int ACTIVE = 64>
+__device__ __forceinline__ float wave_sum_live(float v) {
+    const unsigned long long live = __builtin_amdgcn_ballot_w64(true);
+    const int lane = (int)(threadIdx.x & 63);
+#pragma unroll
+    for (int o = ACTIVE / 2; o > 0; o >>= 1) {
+        const float other = __shfl_xor(v, o, 64);
+        v += ((live >> (lane ^ o)) & 1ull) ? other : 0.f;
+    }
+    return v;
+}
+template <int ACTIVE = 64, bool LIVE_MASK = false>
 __device__ __forceinline__ void episode_stats(const View& v, int e, bool valid, float rew, long long reset, long long progress) {
     float ret = 0.f, fin_ret = 0.f, fin_len = 0.f, fin = 0.f, r = 0.f, cnt = 0.f;
     if (valid) {
@@ -65,7 +79,12 @@ __device__ __forceinline__ void episode_stats(const View& v, int e, bool valid, 
         if (reset != 0) { fin_ret = ret; fin_len = (float)(progress + 1); fin = 1.f; ret = 0.f; }
         v.ep_ret[e] = ret;
     }
-    fin_ret = wave_sum<ACTIVE>(fin_ret); fin_len = wave_sum<ACTIVE>(fin_len); fin = wave_sum<ACTIVE>(fin); r = wave_sum<ACTIVE>(r); cnt = wave_sum<ACTIVE>(cnt);
+    if constexpr (LIVE_MASK) {
+        fin_ret = wave_sum_live<ACTIVE>(fin_ret); fin_len = wave_sum_live<ACTIVE>(fin_len); fin = wave_sum_live<ACTIVE>(fin); r = wave_sum_live<ACTIVE>(r);
+        cnt = wave_sum_live<ACTIVE>(cnt);
+    } else {
+        fin_ret = wave_sum<ACTIVE>(fin_ret); fin_len = wave_sum<ACTIVE>(fin_len); fin = wave_sum<ACTIVE>(fin); r = wave_sum<ACTIVE>(r); cnt = wave_sum<ACTIVE>(cnt);
+    }
     if ((threadIdx.x & 63) == 0) {
         if (fin > 0.f) { atomicAdd(v.stats + 0, fin_ret); atomicAdd(v.stats + 1, fin_len); atomicAdd(v.stats + 2, fin); }
         atomicAdd(v.stats + 3, r);
@@ -267,19 +286,17 @@ __device__ __forceinline__ int post_env_index(int block, int lane, int N) {
 // twice as many CUs share the work: Humanoid step -0.6 % (fast box) to -2 % (slow box).  Ant (60 columns) showed no robust gain and keeps 64.
 template <class M>
 constexpr int post_lanes() { return Sim<M>::LANES < 64 ? 32 : 64; }
-template <class M, bool HUM>
-__global__ __launch_bounds__(post_lanes<M>()) void loco_post_kernel(View v, LocoParams tp) {
+// post_physics_step of one env (ant.py:287-297): progress++, reset if flagged, observations, reward, write-out.  root / q / qd: the env's state
+// after the last sub-step (the post kernel loads them; the fused form of the limb-per-wave sub-step hands them over through LDS).
+// ACTIVE: lanes of the wave that hold envs (episode statistics reduction).
+template <class M, bool HUM, int ACTIVE, bool LIVE_MASK = false>
+__device__ __forceinline__ void loco_post_env(const View& v, const LocoParams& tp, const int e, const bool valid, float (&root)[13], float (&q)[M::NDA],
+                                              float (&qd)[M::NDA]) {
     using T = Loco<M::ND, 6 * M::NSENS, HUM>;
-    constexpr int ND = M::ND, NOBS = T::NOBS, PL = post_lanes<M>();
+    constexpr int ND = M::ND, NOBS = T::NOBS;
     const int N = v.N;
-    const int e0 = xcd_env_base<PL>(blockIdx.x) + threadIdx.x;
-    const bool valid = e0 < N;           // tail lanes shadow the last env (no stores) so wave reductions stay full
-    const int e = valid ? e0 : N - 1;
-    float root[13], q[ND], qd[ND], dof_force[ND], sensor[6 * M::NSENS > 0 ? 6 * M::NSENS : 1], act[ND];
-    sfor<13>([&](auto K) MI_LAMBDA { root[K] = v.root[K * N + e]; });
+    float dof_force[ND], sensor[6 * M::NSENS > 0 ? 6 * M::NSENS : 1], act[ND];
     sfor<ND>([&](auto K) MI_LAMBDA {
-        q[K] = v.dof[K * N + e];
-        qd[K] = v.dof[(ND + K) * N + e];
         dof_force[K] = v.dof_force[K * N + e];
         act[K] = v.actions[K * N + e];
     });
@@ -316,7 +333,7 @@ __global__ __launch_bounds__(post_lanes<M>()) void loco_post_kernel(View v, Loco
     // i.e. the reward above saw the clean observations
     if (v.obs_noise.dist != 0)
         sfor<NOBS>([&](auto K) MI_LAMBDA { obs[K] = apply_noise(v.obs_noise, v.seed, (uint32_t)(v.env_offset + e), v.step, 0u, (uint32_t)K, obs[K]); });
-    episode_stats<PL>(v, e, valid, rew, reset, progress);
+    episode_stats<ACTIVE, LIVE_MASK>(v, e, valid, rew, reset, progress);
     if (!valid) return;
     v.randomize[e] += 1;
     v.episode[e] = ep;
@@ -334,6 +351,21 @@ __global__ __launch_bounds__(post_lanes<M>()) void loco_post_kernel(View v, Loco
     v.progress[e] = progress;
     // vec_task.py:394
     v.timeout[e] = (unsigned char)(((float)progress >= tp.max_episode_length - 1.f) && (reset != 0));
+}
+template <class M, bool HUM>
+__global__ __launch_bounds__(post_lanes<M>()) void loco_post_kernel(View v, LocoParams tp) {
+    constexpr int ND = M::ND, PL = post_lanes<M>();
+    const int N = v.N;
+    const int e0 = xcd_env_base<PL>(blockIdx.x) + threadIdx.x;
+    const bool valid = e0 < N;           // tail lanes shadow the last env (no stores) so wave reductions stay full
+    const int e = valid ? e0 : N - 1;
+    float root[13], q[M::NDA], qd[M::NDA];
+    sfor<13>([&](auto K) MI_LAMBDA { root[K] = v.root[K * N + e]; });
+    sfor<ND>([&](auto K) MI_LAMBDA {
+        q[K] = v.dof[K * N + e];
+        qd[K] = v.dof[(ND + K) * N + e];
+    });
+    loco_post_env<M, HUM, PL>(v, tp, e, valid, root, q, qd);
 }
 
 template <class M>
@@ -428,9 +460,18 @@ inline hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes, unsigned 
 }
 
 // launch `n_sub` physics sub-steps.  `first`: effort source of the first launch, `rest`: of the following ones.
+// the same on Sim<Scaled<M>>, the instantiation that reads the `actor_params` factor tensors (scaled_kernels.hpp; instantiated in
+// kernels_scaled_<model>.hip for the models with M::ACTOR_SCALES)
+template <class M, class GND>
+hipError_t launch_substeps_scaled(const View& v, const SimParams& P, const ActParams& ap, const float* actions, int n_sub, int first,
+                                  int rest, hipStream_t s, const GND& gnd);
 template <class M, class GND = PlaneGround>
 hipError_t launch_substeps(const View& v, const SimParams& P, const ActParams& ap, const float* actions, int n_sub, int first,
                            int rest, hipStream_t s, const GND& gnd = GND{}) {
+    if constexpr (M::ACTOR_SCALES != 0 && !is_scaled<M>::value) {
+        // option actor_tensors: the arena holds per-env mass / joint-constant factors and limit shifts -> the kernels that read them
+        if (v.actor_scale != nullptr || v.limit_shift != nullptr) return launch_substeps_scaled<M, GND>(v, P, ap, actions, n_sub, first, rest, s, gnd);
+    }
     if constexpr (Sim<M>::NPG > 0 && std::is_same<GND, PlaneGround>::value) {
         // self-colliding robot on the compact store.  multi_wave 32 (default): one limb per wave, every wave sweeping its own rows
         // (kernels_<model>_mwc.hip, round 3); 2: round 2's form, the self-collision phase on a helper wave beside one main wave
@@ -463,12 +504,24 @@ hipError_t launch_step_humanoid(const View& v, const SimParams& P, const LocoPar
 hipError_t launch_simulate_humanoid(const View& v, const SimParams& P, hipStream_t s);
 hipError_t launch_reset_humanoid(const View& v, const LocoParams& tp, const long long* ids, int n, hipStream_t s);
 
+// the limb-per-wave sub-steps of a control step with post_physics_step FUSED into the last launch (mw_kernels.hpp; defined for the models of
+// kernels_mw_*.hip that run a locomotion task): one wave of every workgroup runs loco_post_env once the sub-step's state is complete
+template <class M, bool HUM>
+hipError_t launch_substeps_mw_post(const View& v, const SimParams& P, const ActParams& ap, const float* actions, int n_sub, int first, int rest,
+                                   hipStream_t s, const LocoParams& tp);
+template <class M>
+constexpr bool mw_post_capable() { return mw_capable<M, PlaneGround>() && Sim<M>::NPG == 0 && !Sim<M>::COMPACT; }
+
 template <class M, bool HUM>
 hipError_t launch_loco_step(const View& v, const SimParams& P, const LocoParams& tp, const float* actions, int cfi, hipStream_t s) {
     ActParams ap;
     ap.clip = tp.clip_actions; ap.scale = tp.power_scale; ap.nact = M::ND;
     for (int d = 0; d < kMaxDof; ++d) ap.gear[d] = tp.gear[d];
     ap.mode = 0;
+    if constexpr (mw_post_capable<M>()) {
+        // (the fused form exists for the plain kernels only: with randomised actor parameters the two-launch form below runs)
+        if (v.mw != 0 && v.fused_post != 0 && v.actor_scale == nullptr && v.limit_shift == nullptr) return launch_substeps_mw_post<M, HUM>(v, P, ap, actions, cfi * P.substeps, ACT_FROM_ACTIONS, ACT_STORED_TAU, s, tp);
+    }
     hipError_t e = launch_substeps<M>(v, P, ap, actions, cfi * P.substeps, ACT_FROM_ACTIONS, ACT_STORED_TAU, s);
     if (e != hipSuccess) return e;
     constexpr int PL = post_lanes<M>();

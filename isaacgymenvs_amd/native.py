@@ -22,7 +22,9 @@ BUILD_DIR = os.path.join(CSRC, "build")
 SOURCES = ["mi_engine.hip", "kernels_cartpole.hip", "kernels_ant.hip", "kernels_humanoid.hip", "kernels_anymal.hip", "kernels_shadow_hand.hip",
            "kernels_shadow_hand_pen.hip", "kernels_shadow_hand_egg.hip", "kernels_quadcopter.hip", "kernels_ingenuity.hip", "kernels_ball_balance.hip", "kernels_jit_twins.hip",
            "kernels_mw_ant.hip", "kernels_mw_anymal.hip", "kernels_humanoid_sc2.hip", "kernels_humanoid_mwc.hip",
-           "kernels_shadow_hand_mw.hip", "kernels_shadow_hand_mw_pen.hip", "kernels_shadow_hand_mw_egg.hip", "kernels_body_states.hip"]
+           "kernels_shadow_hand_mw.hip", "kernels_shadow_hand_mw_pen.hip", "kernels_shadow_hand_mw_egg.hip", "kernels_body_states.hip",
+           # the sub-step kernels that read the `actor_params` factor tensors (Sim<Scaled<M>>): their own objects, beside the plain ones
+           "kernels_scaled_ant.hip", "kernels_scaled_humanoid.hip", "kernels_scaled_humanoid_mwc.hip", "kernels_scaled_humanoid_sc2.hip"]
 MI_MAX_DOF = 32
 
 # -fno-slp-vectorize: pairing scalars into v_pk_* ops lengthens live ranges in the fully unrolled sub-step
@@ -198,9 +200,16 @@ def select_multi_wave(engine, task, num_envs, mw="auto"):
     for cand in (int(mw), 32):
         try:
             engine.set_option("multi_wave", cand)
-            return
+            break
         except RuntimeError:
             continue
+    if task == "Ant":
+        # post_physics_step on one wave of the last limb-per-wave sub-step launch instead of a kernel of its own: +9 % at 1024 envs, a wash at
+        # 4096 (+1 % on a fast box, -5 % on a slow one), +2 % at 8192 (tools/ant_fused_post_ab.py, profiles/r3r_*, r3s_*): on for small batches
+        try:
+            engine.set_option("fused_post", 1 if num_envs <= 2048 else 0)
+        except RuntimeError:
+            pass
 
 
 def hipcc_path():

@@ -260,13 +260,24 @@ class VecTask(Env):
     # ------------------------------------------------------------------ domain randomisation (vec_task.py:610-840)
     #: tasks whose step kernels apply observation / action noise themselves (mi_engine_set_noise); the others get torch ops
     KERNEL_NOISE_TASKS = ("Cartpole", "Ant", "Humanoid", "ShadowHand")
-    #: `actor_params` entries that have a per-env engine parameter: (property group, attribute) -> column of the actor_scale tensor
-    ACTOR_SCALE_COLUMNS = {("rigid_body_properties", "mass"): 0, ("dof_properties", "damping"): 1, ("dof_properties", "stiffness"): 2,
-                           ("dof_properties", "armature"): 3}
+    #: `actor_params` entries that have a per-env engine parameter (Ant, Humanoid): the `actor_scale` tensor carries one factor per BODY for
+    #: rigid_body_properties.mass and one per DOF for each of dof_properties.damping / stiffness / armature (csrc/core/engine.hpp AS_*)
+    ACTOR_SCALE_GROUPS = {("rigid_body_properties", "mass"): ("body", 0), ("dof_properties", "damping"): ("dof", 0), ("dof_properties", "stiffness"): ("dof", 1),
+                          ("dof_properties", "armature"): ("dof", 2)}
 
     def _actor_scale_column(self, actor, group, attr):
-        """column of the engine's `actor_scale` tensor an `actor_params.<actor>.<group>.<attr>` entry drives, or None"""
-        return self.ACTOR_SCALE_COLUMNS.get((group, attr))
+        """What an `actor_params.<actor>.<group>.<attr>` entry drives in the engine's `actor_scale` tensor, or None:
+        an int -- ONE column, one draw per env (the ShadowHand task's override);
+        (first column, model values [width]) -- one column per body / dof, one draw per env and element, as the reference samples its
+        property arrays (vec_task.py:783-828)."""
+        hit = self.ACTOR_SCALE_GROUPS.get((group, attr))
+        if hit is None:
+            return None
+        spec = self._dr_model()
+        if hit[0] == "body":
+            return 0, np.asarray(spec.mass, np.float64)
+        og = np.asarray({0: spec.dof_damping, 1: spec.dof_stiffness, 2: spec.dof_armature}[hit[1]], np.float64)
+        return spec.nb + hit[1] * spec.nd, og
 
     def apply_randomizations(self, dr_params):
         """What the reference's VecTask.apply_randomizations decides, when (vec_task.py:610-648: `frequency` in sim frames for the
@@ -327,9 +338,9 @@ class VecTask(Env):
         """`actor_params` (vec_task.py:752-828).  The reference walks every env's PhysX property structs in Python; here each
         supported entry is one vectorised draw over the due envs into a per-env tensor the sub-step kernel reads:
           rigid_shape_properties.friction                     -> `friction` (Ant, Humanoid; ShadowHand: mean of hand and object);
-          rigid_body_properties.mass, dof_properties.damping / stiffness / armature -> columns of `actor_scale` (Ant, Humanoid): one
-          factor per env for the whole actor where the reference draws one per body / dof (`scaling`: the sample itself;
-          `additive`: relative to the model's mean value);
+          rigid_body_properties.mass, dof_properties.damping / stiffness / armature -> `actor_scale` (Ant, Humanoid): one factor per env
+          and BODY resp. DOF, drawn per element like the reference draws its property arrays (`scaling`: the sample itself; `additive`:
+          relative to the element's model value);
           ShadowHand (`_actor_scale_column` of the task): hand mass / dof damping / dof stiffness (the drives' kp) / tendon stiffness /
           tendon damping, object mass and `scale` (vec_task.py:760-775) -> columns of its `actor_scale`; dof_properties.lower / upper ->
           one shift per joint and env in `dof_limit_shift`.
@@ -385,6 +396,16 @@ class VecTask(Env):
                             fr[ids] = 0.5 * (mine[ids] + other[ids])
                         else:
                             fr[ids] = vals_t
+                    elif isinstance(col, tuple):
+                        # one draw per env and body / dof; the engine multiplies the model's own value, so an element whose model value is
+                        # zero (an Ant joint has no stiffness) keeps factor 1: `scaling` leaves it zero anyway, `additive` cannot be expressed
+                        c0, base = col
+                        og = {"v": np.tile(base, (len(ids), 1))}
+                        vals = np.asarray(apply_random_samples_array({"v": og["v"].copy()}, og, "v", prm, self.last_step), np.float64)
+                        factor = np.where(base > 0, np.clip(vals / np.where(base > 0, base, 1.0), 0.05, 20.0), 1.0)
+                        if prm.get("operation") == "additive" and (base <= 0).any() and self.first_randomization:
+                            skipped.append(f"{actor}.{group}.{attr} (additive on model values of zero)")
+                        scales[ids, c0:c0 + len(base)] = torch.as_tensor(factor.astype(np.float32), device=self.device)
                     else:
                         ref_val = self._actor_reference_value(group, attr, actor)
                         og = {"v": np.full(len(ids), ref_val)}

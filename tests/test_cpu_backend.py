@@ -140,26 +140,26 @@ def test_in_kernel_noise_equals_its_cpu_twin(dist, op):
 
 
 def test_actor_scale_tensor_acts_like_a_rescaled_model():
-    """`actor_params` mass / damping / stiffness / armature randomisation: the per-env factors of the `actor_scale` tensor give the same
-    motion as the oracle run on a model whose constants were multiplied by them; likewise the joint-limit shifts of `dof_limit_shift`
-    (dof_properties.lower / upper) against a model with shifted limits."""
-    import dataclasses
+    """`actor_params` mass / damping / stiffness / armature randomisation: the factors of the `actor_scale` tensor -- a different one for every
+    BODY (mass, inertia) and every DOF (damping, stiffness, armature), the granularity the reference draws them with (vec_task.py:783-828)
+    -- give the same motion as the oracle run on a model whose constants were multiplied by them; likewise the joint-limit shifts of
+    `dof_limit_shift` (dof_properties.lower / upper) against a model with shifted limits."""
+    import actor_scale_util as asu
     from oracle.engine import OracleEngine
     n = 16
     env = isaacgymenvs_amd.make(seed=0, task="Ant", num_envs=n, sim_device="cpu", rl_device="cpu", headless=True)
     env.engine.set_option("multi_wave", 0)
     spec = load_model("ant")
-    f = dict(mass=1.7, damping=0.5, stiffness=2.0, armature=3.0)
+    f = asu.factors(spec, np.random.default_rng(3))
     assert env.engine.get_option("actor_tensors") == 0                       # off until somebody randomises: the sub-step skips the loads
     env.engine.set_option("actor_tensors", 1)
-    env.engine.tensors["actor_scale"][:] = torch.tensor([f["mass"], f["damping"], f["stiffness"], f["armature"]])
+    assert tuple(env.engine.tensors["actor_scale"].shape) == (n, spec.nb + 3 * spec.nd)
+    env.engine.tensors["actor_scale"][:] = torch.tensor(asu.row(spec, f))
     lo0, up0 = np.minimum(spec.dof_lower, spec.dof_upper), np.maximum(spec.dof_lower, spec.dof_upper)
     shift = np.concatenate([0.15 * np.cos(np.arange(8)), -0.15 * np.abs(np.sin(1 + np.arange(8)))])    # lower limits moved both ways, upper ones inwards
     assert tuple(env.engine.tensors["dof_limit_shift"].shape) == (n, 16)
     env.engine.tensors["dof_limit_shift"][:] = torch.tensor(shift, dtype=torch.float32)
-    spec2 = dataclasses.replace(spec, mass=spec.mass * f["mass"], inertia=spec.inertia * f["mass"], dof_damping=spec.dof_damping * f["damping"],
-                                dof_stiffness=spec.dof_stiffness * f["stiffness"], dof_armature=spec.dof_armature * f["armature"],
-                                dof_lower=lo0 + shift[:8], dof_upper=up0 + shift[8:])
+    spec2 = asu.rescaled(spec, f, dof_lower=lo0 + shift[:8], dof_upper=up0 + shift[8:])
     orcs = [OracleEngine(s, n, params=_sim_dict(env.sim_params), sensor_bodies=sensor_bodies("ant"), precision="f64") for s in (spec2, spec)]
     rng = np.random.default_rng(0)
     lo, up = np.minimum(spec.dof_lower, spec.dof_upper), np.maximum(spec.dof_lower, spec.dof_upper)

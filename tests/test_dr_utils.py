@@ -149,7 +149,8 @@ def test_ant_actor_params_block_is_fully_mapped():
     env = Ant.__new__(Ant)
     env.num_environments, env.device, env.native_task, env.last_step, env.first_randomization = n, "cpu", "Ant", 0, True
     env.model_name = "ant"
-    tensors = {"actor_scale": torch.ones(n, 4), "dof_limit_shift": torch.zeros(n, 16), "friction": -torch.ones(n)}
+    nb, nd = 9, 8                                                      # one column per body (mass), then per dof: damping, stiffness, armature
+    tensors = {"actor_scale": torch.ones(n, nb + 3 * nd), "dof_limit_shift": torch.zeros(n, 16), "friction": -torch.ones(n)}
     env.engine = types.SimpleNamespace(tensors=tensors)
     np.random.seed(1)
     with warnings.catch_warnings(record=True) as w:
@@ -157,8 +158,10 @@ def test_ant_actor_params_block_is_fully_mapped():
         env._apply_actor_params(cfg["task"]["randomization_params"]["actor_params"], None)
     assert not w, [str(x.message) for x in w]
     sc = tensors["actor_scale"].numpy()
-    assert sc[:, 0].std() > 0.2 and sc[:, 1].std() > 0.2 and np.all(sc[:, 2:] == 1.0)
-    assert 0.5 - 1e-6 <= sc[:, :2].min() and sc[:, :2].max() <= 1.5 + 1e-6
+    assert sc[:, :nb].std(0).min() > 0.2 and sc[:, nb:nb + nd].std(0).min() > 0.2 and np.all(sc[:, nb + nd:] == 1.0)    # mass, damping drawn; stiffness is 0 in the model
+    assert 0.5 - 1e-6 <= sc[:, :nb + nd].min() and sc[:, :nb + nd].max() <= 1.5 + 1e-6
+    # one draw per env AND element (the reference samples every body / dof property struct, vec_task.py:783-828): the bodies of an env differ
+    assert np.abs(np.corrcoef(sc[:, 0], sc[:, 1])[0, 1]) < 0.2 and (sc[:, :nb].std(1) > 0.05).mean() > 0.95
     sh = tensors["dof_limit_shift"].numpy()
     assert abs(sh.std() - 0.01) < 0.001 and abs(sh.mean()) < 0.001
     assert float(tensors["friction"].max()) == -1.0                   # Ant.yaml randomises no friction

@@ -49,16 +49,15 @@ def test_multi_wave_simulate_matches_cpu_oracle(n, randomised):
     env = _make("Ant", n, mw=32)
     spec, sb = load_model("ant"), sensor_bodies("ant")
     if randomised:
-        f = dict(mass=0.6, damping=1.4, stiffness=0.5, armature=2.0)
+        import actor_scale_util as asu
+        f = asu.factors(spec, np.random.default_rng(12))            # a different factor for every body and every dof
         lo0, up0 = np.minimum(spec.dof_lower, spec.dof_upper), np.maximum(spec.dof_lower, spec.dof_upper)
         shift = np.concatenate([0.12 * np.cos(np.arange(8)), -0.12 * np.abs(np.sin(1 + np.arange(8)))])
         env.engine.set_option("actor_tensors", 1)
-        env.engine.tensors["actor_scale"][:] = torch.tensor([f["mass"], f["damping"], f["stiffness"], f["armature"]], device=DEV)
+        env.engine.tensors["actor_scale"][:] = _t(asu.row(spec, f))
         env.engine.tensors["dof_limit_shift"][:] = _t(shift)
         state_spec = spec                                           # random joint angles inside the ORIGINAL limits: some violate the shifted ones
-        spec = dataclasses.replace(spec, mass=spec.mass * f["mass"], inertia=spec.inertia * f["mass"], dof_damping=spec.dof_damping * f["damping"],
-                                   dof_stiffness=spec.dof_stiffness * f["stiffness"], dof_armature=spec.dof_armature * f["armature"],
-                                   dof_lower=lo0 + shift[:8], dof_upper=up0 + shift[8:])
+        spec = asu.rescaled(spec, f, dof_lower=lo0 + shift[:8], dof_upper=up0 + shift[8:])
     else:
         state_spec = spec
     stride = max(1, n // 256)                   # the oracle follows a strided subset of the envs
@@ -143,7 +142,7 @@ def test_humanoid_self_collision_on_a_helper_wave_is_the_same_sub_step(n, random
         if randomised:
             r2 = np.random.default_rng(8)
             env.engine.set_option("actor_tensors", 1)
-            t["actor_scale"][:] = _t(r2.uniform(0.5, 1.5, (n, 4)))
+            t["actor_scale"][:] = _t(r2.uniform(0.5, 1.5, tuple(t["actor_scale"].shape)))
             t["dof_limit_shift"][:] = _t(r2.normal(0.0, 0.05, (n, 2 * spec.nd)))
     touched = 0
     for it in range(3):
@@ -180,15 +179,14 @@ def test_humanoid_limb_waves_match_cpu_oracle(n, selfcol, randomised):
     spec, sb, sc = load_model("humanoid"), sensor_bodies("humanoid"), load_selfcol("humanoid")
     state_spec = spec
     if randomised:
-        f = dict(mass=0.7, damping=1.3, stiffness=0.6, armature=1.8)
+        import actor_scale_util as asu
+        f = asu.factors(spec, np.random.default_rng(13), mass=(0.7, 1.4), damping=(0.7, 1.3), stiffness=(0.6, 1.5), armature=(0.6, 1.8))
         lo0, up0 = np.minimum(spec.dof_lower, spec.dof_upper), np.maximum(spec.dof_lower, spec.dof_upper)
         shift = np.concatenate([0.1 * np.cos(np.arange(21)), -0.1 * np.abs(np.sin(1 + np.arange(21)))])
         env.engine.set_option("actor_tensors", 1)
-        env.engine.tensors["actor_scale"][:] = torch.tensor([f["mass"], f["damping"], f["stiffness"], f["armature"]], device=DEV)
+        env.engine.tensors["actor_scale"][:] = _t(asu.row(spec, f))
         env.engine.tensors["dof_limit_shift"][:] = _t(shift)
-        spec = dataclasses.replace(spec, mass=spec.mass * f["mass"], inertia=spec.inertia * f["mass"], dof_damping=spec.dof_damping * f["damping"],
-                                   dof_stiffness=spec.dof_stiffness * f["stiffness"], dof_armature=spec.dof_armature * f["armature"],
-                                   dof_lower=lo0 + shift[:21], dof_upper=up0 + shift[21:])
+        spec = asu.rescaled(spec, f, dof_lower=lo0 + shift[:21], dof_upper=up0 + shift[21:])
     kw = dict(solver="blocks", blocks=solver_blocks(spec, self_collision=selfcol, wave_caps=True))
     if selfcol:
         kw.update(selfcol=sc, kpair=3)
@@ -235,3 +233,30 @@ def test_humanoid_helper_wave_rollout_is_bit_identical_from_run_to_run():
         o1, r1, d1, _ = e1.step(a)
         o2, r2, d2, _ = e2.step(a)
         assert torch.equal(o1["obs"], o2["obs"]) and torch.equal(r1, r2) and torch.equal(d1, d2), step
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [4096, 200])
+def test_ant_post_physics_step_fused_into_the_last_sub_step_is_bit_identical(n):
+    """Ant on the limb-per-wave form: with option fused_post = 1 (what make() picks up to 2048 envs) `post_physics_step` (progress, in-kernel
+    reset, observations, reward) runs on one wave of every sub-step workgroup at the end of the step's last sub-step launch
+    (csrc/mw_kernels.hpp substep_mw_post_kernel) instead of in loco_post_kernel.  Same state in, same arithmetic: observations, rewards, resets
+    and the physics state are bit-identical over a rollout with resets (n = 200: a batch whose last workgroup is partly empty)."""
+    import isaacgymenvs_amd
+    a = isaacgymenvs_amd.make(seed=4, task="Ant", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True)
+    b = isaacgymenvs_amd.make(seed=4, task="Ant", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True)
+    assert int(a.engine.get_option("multi_wave")) == 16 and int(a.engine.get_option("fused_post")) == (1 if n <= 2048 else 0)
+    a.engine.set_option("fused_post", 1); b.engine.set_option("fused_post", 0)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    resets = 0
+    for step in range(120):
+        act = torch.rand((n, 8), device=DEV, generator=g) * 2 - 1
+        oa, ra, da, _ = a.step(act)
+        ob, rb, db, _ = b.step(act)
+        assert torch.equal(oa["obs"], ob["obs"]) and torch.equal(ra, rb) and torch.equal(da, db), step
+        resets += int(da.sum())
+    for k in ("root_states", "dof_state", "contact_impulse", "limit_impulse", "potentials", "prev_potentials", "progress_buf", "episode_count"):
+        assert torch.equal(a.engine.tensors[k], b.engine.tensors[k]), k
+    assert resets > 0
+    sa, sb = a.engine.tensors["episode_stats"], b.engine.tensors["episode_stats"]
+    assert torch.allclose(sa, sb, rtol=1e-4)            # (sums of atomics: the order differs)

@@ -1280,9 +1280,9 @@ def test_actor_params_friction_randomisation_is_tensorised_and_acts_on_the_physi
     # restitution has no engine parameter (named once); friction and mass do
     assert "restitution" in msgs and "rigid_body_properties" not in msgs and "friction" not in msgs.split("skipped")[-1].replace("restitution", "")
     assert env.engine.get_option("actor_tensors") == 1                             # switched on by the first randomisation
-    ms = env.engine.tensors["actor_scale"][:, 0].cpu().numpy()                     # rigid_body_properties.mass -> one factor per env
-    assert ms.min() >= 0.5 - 1e-6 and ms.max() <= 1.5 + 1e-6 and ms.std() > 0.2
-    assert float((env.engine.tensors["actor_scale"][:, 1:] - 1.0).abs().max()) == 0.0    # damping / stiffness / armature untouched
+    ms = env.engine.tensors["actor_scale"][:, :9].cpu().numpy()                    # rigid_body_properties.mass -> one factor per env and body
+    assert ms.min() >= 0.5 - 1e-6 and ms.max() <= 1.5 + 1e-6 and ms.std(0).min() > 0.2 and (ms.std(1) > 0.05).mean() > 0.95
+    assert float((env.engine.tensors["actor_scale"][:, 9:] - 1.0).abs().max()) == 0.0    # damping / stiffness / armature untouched
     fr = env.engine.tensors["friction"].cpu().numpy()
     og = 1.5                                                                          # nv_ant.xml geom friction: the scaling baseline
     assert abs(env.model_shape_friction - og) < 1e-6
