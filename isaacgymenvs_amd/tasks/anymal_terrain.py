@@ -95,6 +95,8 @@ class AnymalTerrain(VecTask):
         if env["terrain"]["terrainType"] not in ("plane", "trimesh"):
             raise ValueError("terrainType must be 'plane' or 'trimesh'")
         cfg["env"]["plane"] = {"staticFriction": env["terrain"]["staticFriction"]}   # terrain friction -> sim params
+        if float(env["terrain"].get("restitution", 0.0)) != 0.0:    # AnymalTerrain.yaml:17 ships 0; the contact model has no restitution term
+            raise NotImplementedError(f"terrain restitution {env['terrain']['restitution']}: not modelled by the MI355X engine (the reference config uses 0)")
         # the reference task never calls apply_randomizations (task.randomize is read by nobody in anymal_terrain.py; its own
         # randomisation is the per-env friction buckets and the observation noise, both in-kernel here)
         self.randomize = False

@@ -79,6 +79,10 @@ class LocomotionTask(VecTask):
         self.plane_static_friction = env["plane"]["staticFriction"]
         self.plane_dynamic_friction = env["plane"]["dynamicFriction"]
         self.plane_restitution = env["plane"]["restitution"]
+        if float(self.plane_restitution) != 0.0:
+            # every shipped config has restitution 0 (Ant.yaml:34, Humanoid.yaml:37; the `actor_params` restitution entries of Humanoid.yaml:102
+            # SCALE that zero, i.e. change nothing): the contact model has no restitution term, so anything else is refused, not ignored
+            raise NotImplementedError(f"plane restitution {self.plane_restitution}: the MI355X engine's contact model has no restitution (the reference configs use 0)")
         info = native.task_info(self.native_task)
         self.cfg["env"]["numObservations"] = info.num_obs
         self.cfg["env"]["numActions"] = info.num_actions

@@ -97,3 +97,19 @@ def test_env_section_equals_the_reference_yaml(name):
     check(ref["env"], ours["env"], "env.")
     check(ref["task"], ours["task"], "task.")
     check(ref["sim"], ours["sim"], "sim.")
+
+
+def test_non_zero_restitution_is_refused_not_ignored():
+    """Every shipped config has restitution 0 and the engine's contact model has no restitution term: a config that asks for one must fail
+    loudly instead of running without it (reference plane params: ant.py:137-143, anymal_terrain.py:198-206)."""
+    import isaacgymenvs_amd
+    from isaacgymenvs_amd.utils.config import omegaconf_to_dict
+    for task, path in (("Ant", ("env", "plane", "restitution")), ("AnymalTerrain", ("env", "terrain", "restitution"))):
+        cfg = omegaconf_to_dict(compose("config", overrides=[f"task={task}"])["task"])
+        node = cfg
+        for k in path[:-1]:
+            node = node[k]
+        node[path[-1]] = 0.3
+        cfg["env"]["numEnvs"] = 4
+        with pytest.raises(NotImplementedError, match="restitution"):
+            isaacgymenvs_amd.make(seed=0, task=task, num_envs=4, sim_device="cpu", rl_device="cpu", headless=True, cfg=cfg)
