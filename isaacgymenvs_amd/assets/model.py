@@ -481,7 +481,23 @@ def parse_mjcf(path):
 # ----------------------------------------------------------------------------
 # URDF
 # ----------------------------------------------------------------------------
-def parse_urdf(path, default_density=1000.0, replace_cylinder_with_capsule=False):
+def _resolve_mesh(filename, urdf_path, mesh_root=None):
+    """A URDF mesh file name (relative to the asset root the task passes to gym.load_asset, or to the URDF's own directory; package://
+    URIs lose their prefix) -> an existing path, or None."""
+    name = filename.split("package://")[-1]
+    here = os.path.dirname(os.path.abspath(urdf_path))
+    roots = ([mesh_root] if mesh_root else []) + [here, os.path.dirname(here), os.path.dirname(os.path.dirname(here))]
+    for r in roots:
+        cand = os.path.join(r, name)
+        if os.path.exists(cand):
+            return cand
+    return None
+
+
+def parse_urdf(path, default_density=1000.0, replace_cylinder_with_capsule=False, mesh_spheres=False, mesh_root=None, mesh_options=None,
+               mesh_link_filter=None):
+    """mesh_spheres: collision <mesh> shapes become sphere geoms inscribed in the mesh's convex hull (assets/mesh.py hull_spheres; PhysX
+    collides a mesh shape as its hull); without it they are skipped -- fine for robots that never touch anything with those links."""
     root = ET.parse(path).getroot()
     links = {}
     for ln in root.findall("link"):
@@ -505,6 +521,17 @@ def parse_urdf(path, default_density=1000.0, replace_cylinder_with_capsule=False
                     geoms.append(_Geom(name, GEOM_CAPSULE, pos, quat, np.array([r, max(0.5 * L - r, 0.0), 0]), density=default_density))
                 else:
                     geoms.append(_Geom(name, GEOM_CYLINDER, pos, quat, np.array([r, 0.5 * L, 0]), density=default_density))
+            elif g.tag == "mesh" and mesh_spheres and (mesh_link_filter is None or mesh_link_filter(name)):
+                from .mesh import hull_spheres, load_mesh
+                mpath = _resolve_mesh(g.get("filename"), path, mesh_root)
+                if mpath is None:
+                    raise FileNotFoundError(f"{path}: collision mesh {g.get('filename')} of link {name} not found")
+                V, _ = load_mesh(mpath)
+                V = V * (_floats(g.get("scale"), 3) if g.get("scale") else 1.0)
+                C, rad = hull_spheres(V, **(mesh_options or {}))
+                R = quat_to_mat(quat)
+                for c in C:      # sphere geoms in the link frame; mass properties never come from them (density 0)
+                    geoms.append(_Geom(name, GEOM_SPHERE, pos + R @ c, np.array([0, 0, 0, 1.0]), np.array([rad, 0, 0]), density=0.0))
         inertial = None
         iner = ln.find("inertial")
         if iner is not None and iner.find("mass") is not None:
@@ -791,7 +818,9 @@ def load_asset(path, name=None, fix_base_link=False, density=None, replace_cylin
     name = name or os.path.splitext(os.path.basename(path))[0]
     if path.endswith(".urdf"):
         bodies, acts = parse_urdf(path, default_density=density if density is not None else 1000.0,
-                                  replace_cylinder_with_capsule=replace_cylinder_with_capsule)
+                                  replace_cylinder_with_capsule=replace_cylinder_with_capsule, mesh_spheres=kw.pop("mesh_spheres", False),
+                                  mesh_root=kw.pop("mesh_root", None), mesh_options=kw.pop("mesh_options", None),
+                                  mesh_link_filter=kw.pop("mesh_link_filter", None))
         return build_model(name, bodies, acts, fix_base_link=fix_base_link, density=density, **kw)
     bodies, acts = parse_mjcf(path)
     return build_model(name, bodies, acts, fix_base_link=fix_base_link, density=density, **kw)

@@ -20,6 +20,8 @@ MODELS = {
     # reference shadow_hand.py:291-297: force sensors on the five fingertips (distal links)
     "shadow_hand": dict(struct="ModelShadowHand", sensors=["robot0:ffdistal", "robot0:mfdistal", "robot0:rfdistal", "robot0:lfdistal",
                                                            "robot0:thdistal"], extras="shadow_hand_extras.json"),
+    # reference allegro_hand.py: no force sensors (the acquire call is commented out, :148-150), no fingertip states in the observations
+    "allegro_hand": dict(struct="ModelAllegroHand", sensors=[], extras="allegro_hand_extras.json"),
     # reference quadcopter.py:287-292: thrust forces act on the four rotor bodies (bodies 2, 4, 6, 8); they are listed as
     # "sensor" bodies because the engine records the world pose of exactly those bodies during its tree pass
     "quadcopter": dict(struct="ModelQuadcopter", sensors=["rotor0", "rotor1", "rotor2", "rotor3"]),

@@ -27,7 +27,41 @@ ENTRIES = {
     # mounted 0.5 m above it, shadow_hand.py:303-304): no ground-contact spheres; its collision geometry is used against
     # the manipulated cube instead (extras below)
     "shadow_hand": dict(file="mjcf/open_ai_assets/hand/shadow_hand.xml", fix_base_link=True, collide_body_filter=lambda n: False),
+    # reference allegro_hand.py:216-233: fix_base_link, collapse_fixed_joints, no gravity on the hand.  The task names
+    # urdf/kuka_allegro_description/allegro.urdf, which the reference tree does not ship; the hand it does ship is
+    # allegro_touch_sensor.urdf (the same 16-dof Allegro hand with the touch-sensor fingertips of the AllegroKuka tasks), all mesh collision
+    # shapes -> spheres inscribed in the meshes' convex hulls (isaacgymenvs_amd/assets/mesh.py).  The mounting flange `allegro_mount`
+    # (a 23 mm plate behind the wrist, 10 cm from the palm's inner face) is left without contact geometry: the cube is reset (fall_dist)
+    # long before it could reach it.
+    "allegro_hand": dict(file="urdf/kuka_allegro_description/allegro_touch_sensor.urdf", fix_base_link=True, collide_body_filter=lambda n: False),
 }
+
+
+def allegro_extras(asset_root, spec_with_geoms):
+    """The manipulation extras of the Allegro hand (models/allegro_hand_extras.json): object-contact spheres = the sphere geoms the mesh
+    sampler produced, per body in farthest-point order (the engine admits a body's first few touching spheres as its manifold); no tendons;
+    position drives with the gains the task sets (allegro_hand.py:256-264: stiffness 3, effort 0.5)."""
+    import numpy as np
+    spec = spec_with_geoms
+    by_body = {}
+    for g in range(len(spec.geom_body)):
+        if int(spec.geom_type[g]) != 0:
+            continue
+        by_body.setdefault(int(spec.geom_body[g]), []).append((np.asarray(spec.geom_pos[g], float), float(spec.geom_size[g][0])))
+    sph = []
+    for b in sorted(by_body):
+        items = by_body[b]
+        P = np.array([q for q, _ in items])
+        order = [int(np.argmax(np.linalg.norm(P - P.mean(0), axis=1)))]
+        while len(order) < len(items):
+            d = np.min(np.linalg.norm(P[:, None, :] - P[None, order, :], axis=2), axis=1)
+            d[order] = -1.0
+            order.append(int(np.argmax(d)))
+        sph += [(b, items[i][0], items[i][1]) for i in order]
+    nd = spec.nd
+    return dict(os_body=[int(s[0]) for s in sph], os_pos=[[float(x) for x in s[1]] for s in sph], os_rad=[float(s[2]) for s in sph],
+                tendons=[], tendon_limit_stiffness=0.0, tendon_damping=0.0, dof_kp=[3.0] * nd, dof_force_limit=[0.5] * nd,
+                actuated_dofs=list(range(nd)), mount_quat=[0.0, 0.0, 0.0, 1.0], fingertips=[])
 
 
 def hand_extras(asset_root, spec):
@@ -148,6 +182,17 @@ def main():
                 # collision filter -1 (shadow_hand.py:357-358): which hand shapes the asset lets touch each other
                 extras["self_collision_filter"] = dict(collision_geoms=flt["collision_geoms"], accepting=flt["accepting"], n_pairs=len(flt["pairs"]))
                 json.dump(extras, f, indent=1)
+        if name == "allegro_hand":
+            import json
+            import numpy as np
+            # the joint constants the task writes into the dof properties of every actor (allegro_hand.py:256-264) replace the URDF's
+            spec.dof_damping = np.full(spec.nd, 0.1)
+            spec.dof_armature = np.full(spec.nd, 0.001)
+            spec.save(os.path.join(a.out, name + ".json"))
+            full = load_asset(os.path.join(a.asset_root, e["file"]), name=name, fix_base_link=True, mesh_spheres=True,
+                              mesh_root=os.path.join(a.asset_root, "urdf"), mesh_link_filter=lambda link: link != "allegro_mount")
+            with open(os.path.join(a.out, "allegro_hand_extras.json"), "w") as f:
+                json.dump(allegro_extras(a.asset_root, full), f, indent=1)
         print(f"{name}: nb={spec.nb} nd={spec.nd} nv={spec.nv} nsph={len(spec.sph_body)} mass={spec.total_mass():.4f}")
     import tempfile
     from isaacgymenvs_amd.assets import procedural
