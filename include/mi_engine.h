@@ -157,7 +157,8 @@ typedef struct {
     int32_t ignore_z_rot;
 } MiHandRewardParams;
 
-/* task parameters of ShadowHand (shadow_hand.py:45-110, cfg/task/ShadowHand.yaml) */
+/* task parameters of ShadowHand (shadow_hand.py:45-110, cfg/task/ShadowHand.yaml) and of AllegroHand (allegro_hand.py:42-128,
+ * cfg/task/AllegroHand.yaml: the same fields; 16 driven dofs -> actuated[0..15], full state 88 wide, obs_type 0 / 2 / 3) */
 typedef struct {
     MiHandRewardParams rew;
     float vel_obs_scale, force_torque_obs_scale;
@@ -200,7 +201,7 @@ typedef struct {
 
 /* ---- discovery ------------------------------------------------------------------------------------------- */
 int mi_abi_version(void);
-/* task in {"Cartpole","Ant","Humanoid","AnymalTerrain","ShadowHand","Anymal","Quadcopter","Ingenuity","BallBalance"}: replaces isaacgym_task_map lookup (isaacgymenvs/tasks/__init__.py:88-114)
+/* task in {"Cartpole","Ant","Humanoid","AnymalTerrain","ShadowHand","Anymal","Quadcopter","Ingenuity","BallBalance","AllegroHand"}: replaces isaacgym_task_map lookup (isaacgymenvs/tasks/__init__.py:88-114)
  * + gym.get_asset_{dof,rigid_body}_count (ant.py:155-156) */
 int mi_task_info(const char* task, MiTaskInfo* out);
 size_t mi_engine_arena_bytes(const char* task, int num_envs);
@@ -258,7 +259,7 @@ int mi_engine_set_option(MiEngine* e, const char* key, double value);
  * `noise_lambda` closures the reference builds in VecTask.apply_randomizations, vec_task.py:650-718, and runs as torch ops on the
  * buffers every step, :371-372,397-399).  value = op(x, corr + white): `white` ~ N(a, b) or U(a, b) fresh every step, `corr` a
  * per-(env, element) normal draw made once, scaled by (a_corr, b_corr); the host passes ranges already blended by the schedule.
- * dist 0 switches the noise off.  Cartpole, Ant, Humanoid, ShadowHand (obs_buf only: states_buf stays clean). */
+ * dist 0 switches the noise off.  Cartpole, Ant, Humanoid, ShadowHand / AllegroHand (obs_buf only: states_buf stays clean). */
 typedef struct MiNoiseParams {
     int32_t dist;          /* 0 off, 1 gaussian, 2 uniform */
     int32_t op;            /* 0 additive, 1 scaling */

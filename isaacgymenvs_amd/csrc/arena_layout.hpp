@@ -18,14 +18,16 @@
 #include "gen/model_humanoid.h"
 #include "gen/model_anymal.h"
 #include "gen/model_shadow_hand.h"
+#include "gen/model_allegro_hand.h"
 #include "gen/model_quadcopter.h"
 #include "gen/model_ingenuity.h"
 #include "gen/model_balance_bot.h"
 
 using namespace mi;
 
-enum TaskId { T_CARTPOLE = 0, T_ANT = 1, T_HUMANOID = 2, T_ANYMAL = 3, T_SHADOWHAND = 4, T_ANYMAL_FLAT = 5, T_QUADCOPTER = 6, T_INGENUITY = 7, T_BALLBALANCE = 8 };
-constexpr int kNumTasks = 9;
+enum TaskId { T_CARTPOLE = 0, T_ANT = 1, T_HUMANOID = 2, T_ANYMAL = 3, T_SHADOWHAND = 4, T_ANYMAL_FLAT = 5, T_QUADCOPTER = 6, T_INGENUITY = 7, T_BALLBALANCE = 8, T_ALLEGROHAND = 9 };
+constexpr int kNumTasks = 10;
+static inline bool is_hand_task(int t) { return t == T_SHADOWHAND || t == T_ALLEGROHAND; }
 struct TaskMeta { const char* name; int nobs, nact, nd, nb, nsens, nsph, fixed; size_t pbytes; };
 static const TaskMeta kTasks[] = {
     {"Cartpole", 4, 1, ModelCartpole::ND, ModelCartpole::NB, 0, ModelCartpole::NSPH, 1, sizeof(MiCartpoleParams)},
@@ -37,6 +39,8 @@ static const TaskMeta kTasks[] = {
     {"Quadcopter", kQuadObs, kQuadAct, ModelQuadcopter::ND, ModelQuadcopter::NB, ModelQuadcopter::NSENS, ModelQuadcopter::NSPH, 0, sizeof(MiQuadcopterParams)},
     {"Ingenuity", kIngObs, kIngAct, ModelIngenuity::ND, ModelIngenuity::NB, ModelIngenuity::NSENS, ModelIngenuity::NSPH, 0, sizeof(MiIngenuityParams)},
     {"BallBalance", kBbotObs, kBbotAct, ModelBalanceBot::ND, ModelBalanceBot::NB, ModelBalanceBot::NSENS, ModelBalanceBot::NSPH, 0, sizeof(MiBallBalanceParams)},
+    // reference allegro_hand.py: 88-wide full_state (:485-507), 16 driven dofs, the task parameters of the ShadowHand
+    {"AllegroHand", 88, 16, ModelAllegroHand::ND, ModelAllegroHand::NB, ModelAllegroHand::NSENS, 0, 1, sizeof(MiHandParams)},
 };
 static int find_task(const char* t) {
     for (int i = 0; i < kNumTasks; ++i) if (!strcmp(t, kTasks[i].name)) return i;

@@ -5,14 +5,28 @@
 #include "step_kernels.hpp"
 #include "core/hand_engine.hpp"
 #include "gen/model_shadow_hand.h"
+#include "gen/model_allegro_hand.h"
 #include "tasks/shadow_hand.hpp"
 
 namespace mi {
 
+// the in-hand manipulation tasks built on HandSim (hand_task_kernels.hpp): model, driven dofs, fingertips with a state / force-torque block in
+// the observations, width of compute_full_state's vector
+struct ShadowHandTask {    // reference shadow_hand.py (24 dofs, 20 of them driven, 4 fixed tendons; :528-584: 211 columns)
+    using M = ModelShadowHand;
+    static constexpr int ND = 24, NACT = 20, NTIPS = 5, NFULL = 211;
+};
+struct AllegroHandTask {   // reference allegro_hand.py (16 dofs, all driven, :233-235; no fingertip / force-sensor columns, :485-507: 88 columns)
+    using M = ModelAllegroHand;
+    static constexpr int ND = 16, NACT = 16, NTIPS = 0, NFULL = 88;
+};
+static_assert(ShadowHandTask::M::ND == ShadowHandTask::ND && ShadowHandTask::M::NSENS == ShadowHandTask::NTIPS, "shadow hand model");
+static_assert(AllegroHandTask::M::ND == AllegroHandTask::ND && AllegroHandTask::M::NSENS == AllegroHandTask::NTIPS, "allegro hand model");
+
+// the ShadowHand's names, as the finger-per-wave form (hand_mw_kernels.hpp, ShadowHand only) uses them
 using HM = ModelShadowHand;
 using HS = HandSim<HM>;
 constexpr int kHandDof = 24, kHandAct = 20, kHandTips = 5, kHandObs = 211;
-static_assert(HM::ND == kHandDof && HM::NSENS == kHandTips, "shadow hand model");
 
 // arena view of the task (device pointers, SoA [k][N] unless noted) -- same definition in mi_engine.hip
 struct HandView {
@@ -39,10 +53,11 @@ struct HandView {
 };
 
 // gym.simulate(): one physics sub-step of hand + cube
-template <int SHAPE>
+template <class HT, int SHAPE>
 __global__ __launch_bounds__(32) void hand_substep_kernel(View v, HandView hv, SimParams P, HandParams p) {
     extern __shared__ float lds_rows[];
-    constexpr int ND = kHandDof, LANES = HS::LANES;
+    using HS = HandSim<typename HT::M>;
+    constexpr int ND = HT::ND, LANES = HS::LANES;
     const int e = blockIdx.x * LANES + threadIdx.x;
     const int N = v.N;
     if (e >= N) return;
@@ -82,19 +97,20 @@ __global__ __launch_bounds__(32) void hand_substep_kernel(View v, HandView hv, S
     if (nc >> 16) hv.ndropped[e] += nc >> 16;
 }
 
-template <int SHAPE>
+template <class HT, int SHAPE>
 inline hipError_t hand_substeps_shape(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s) {
 #ifndef MI_HAND_LDS_PAD
 #define MI_HAND_LDS_PAD 0      // residency experiments only (tools/hand_residency_ab.sh): extra LDS bytes requested per workgroup
 #endif
+    using HS = HandSim<typename HT::M>;
     constexpr size_t lds = (size_t)HS::ROW_SLOTS * HS::LANES * sizeof(float) + MI_HAND_LDS_PAD;
     static_assert(lds <= 160 * 1024, "hand row store must fit LDS");
     static unsigned long long configured = 0ull;
-    if (hipError_t e = ensure_dynamic_lds((const void*)hand_substep_kernel<SHAPE>, lds, &configured); e != hipSuccess) return e;
+    if (hipError_t e = ensure_dynamic_lds((const void*)hand_substep_kernel<HT, SHAPE>, lds, &configured); e != hipSuccess) return e;
     // (Two workgroups fit a CU.  Asking for more than half the LDS while CUs are spare makes no difference -- the dispatcher spreads
     // the workgroups over the CUs by itself: ShadowHand@8192 0.605 ms either way)
     for (int i = 0; i < n; ++i)
-        hipLaunchKernelGGL(hand_substep_kernel<SHAPE>, dim3((v.N + HS::LANES - 1) / HS::LANES), dim3(HS::LANES), lds, s, v, hv, P, p);
+        hipLaunchKernelGGL((hand_substep_kernel<HT, SHAPE>), dim3((v.N + HS::LANES - 1) / HS::LANES), dim3(HS::LANES), lds, s, v, hv, P, p);
     return hipGetLastError();
 }
 
@@ -105,5 +121,8 @@ hipError_t hand_substeps_mw_egg(const View& v, const HandView& hv, const SimPara
 // defined in kernels_shadow_hand_pen.hip / kernels_shadow_hand_egg.hip
 hipError_t hand_substeps_pen(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s);
 hipError_t hand_substeps_egg(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s);
+// the AllegroHand's: kernels_allegro_hand_pen.hip / kernels_allegro_hand_egg.hip
+hipError_t allegro_substeps_pen(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s);
+hipError_t allegro_substeps_egg(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s);
 
 }  // namespace mi

@@ -1,0 +1,9 @@
+// kernels_allegro_hand_pen.hip -- the AllegroHand physics sub-step instantiated for objectType "pen" (hand_kernels.hpp); its own translation
+// unit only so that it compiles in parallel with the block instantiation.
+#include "hand_kernels.hpp"
+
+namespace mi {
+hipError_t allegro_substeps_pen(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s) {
+    return hand_substeps_shape<AllegroHandTask, OBJ_CAPSULE>(v, hv, P, p, n, s);
+}
+}  // namespace mi

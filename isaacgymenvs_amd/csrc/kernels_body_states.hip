@@ -7,6 +7,7 @@
 #include "gen/model_humanoid.h"
 #include "gen/model_anymal.h"
 #include "gen/model_shadow_hand.h"
+#include "gen/model_allegro_hand.h"
 #include "gen/model_quadcopter.h"
 #include "gen/model_ingenuity.h"
 #include "gen/model_balance_bot.h"
@@ -48,6 +49,7 @@ hipError_t launch_body_states(int task, const View& v, hipStream_t s) {
         case 4: return launch_bs<ModelShadowHand>(v, s);
         case 6: return launch_bs<ModelQuadcopter>(v, s);
         case 7: return launch_bs<ModelIngenuity>(v, s);
+        case 9: return launch_bs<ModelAllegroHand>(v, s);
         default: return launch_bs<ModelBalanceBot>(v, s);
     }
 }

@@ -4,6 +4,6 @@
 
 namespace mi {
 hipError_t hand_substeps_egg(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s) {
-    return hand_substeps_shape<OBJ_ELLIPSOID>(v, hv, P, p, n, s);
+    return hand_substeps_shape<ShadowHandTask, OBJ_ELLIPSOID>(v, hv, P, p, n, s);
 }
 }  // namespace mi

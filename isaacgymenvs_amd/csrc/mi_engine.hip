@@ -17,6 +17,7 @@
 #include "gen/model_humanoid.h"
 #include "gen/model_anymal.h"
 #include "gen/model_shadow_hand.h"
+#include "gen/model_allegro_hand.h"
 #include "tasks/anymal.hpp"
 #include "gen/model_quadcopter.h"
 #include "tasks/quadcopter.hpp"
@@ -237,6 +238,12 @@ hipError_t launch_step_shadow_hand(const View& v, const HandView& hv, const SimP
 hipError_t launch_simulate_shadow_hand(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, hipStream_t s);
 hipError_t launch_init_shadow_hand(const View& v, const HandView& hv, const HandParams& p, hipStream_t s);
 hipError_t launch_reset_shadow_hand(const View& v, const HandView& hv, const HandParams& p, const long long* ids, int n, hipStream_t s);
+// kernels_allegro_hand.hip
+hipError_t launch_step_allegro_hand(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, const float* actions, int cfi,
+                                    unsigned step_counter, hipStream_t s);
+hipError_t launch_simulate_allegro_hand(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, hipStream_t s);
+hipError_t launch_init_allegro_hand(const View& v, const HandView& hv, const HandParams& p, hipStream_t s);
+hipError_t launch_reset_allegro_hand(const View& v, const HandView& hv, const HandParams& p, const long long* ids, int n, hipStream_t s);
 }
 struct MiEngine {
     int task, N;
@@ -269,22 +276,23 @@ struct MiEngine {
 };
 
 // ShadowHand extras (shadow_hand.py:150-222): object / goal root states, targets, fingertip body states, success counters
-static void build_hand_layout(int N, Layout& L, HandView* hv, char* base) {
-    const int64_t n = N;
+// (AllegroHand, allegro_hand.py:142-203: the same tensors for 16 dofs, no fingertips, an 88-wide full state)
+static void build_hand_layout(int task, int N, Layout& L, HandView* hv, char* base) {
+    const int64_t n = N, nd = kTasks[task].nd, nt = kTasks[task].nsens, nfull = kTasks[task].nobs;
     auto P = [&](size_t o) { return base ? base + o : (char*)nullptr; };
     size_t o;
-    o = L.add("cur_targets", MI_F32, {n, 24}, {1, n}, 24 * n); if (hv) hv->cur_targets = (float*)P(o);
-    o = L.add("prev_targets", MI_F32, {n, 24}, {1, n}, 24 * n); if (hv) hv->prev_targets = (float*)P(o);
+    o = L.add("cur_targets", MI_F32, {n, nd}, {1, n}, nd * n); if (hv) hv->cur_targets = (float*)P(o);
+    o = L.add("prev_targets", MI_F32, {n, nd}, {1, n}, nd * n); if (hv) hv->prev_targets = (float*)P(o);
     o = L.add("object_state", MI_F32, {n, 13}, {1, n}, 13 * n); if (hv) hv->object_state = (float*)P(o);
     o = L.add("goal_states", MI_F32, {n, 7}, {1, n}, 7 * n); if (hv) hv->goal_state = (float*)P(o);
-    o = L.add("fingertip_state", MI_F32, {n, 5, 13}, {1, 13 * n, n}, 65 * n); if (hv) hv->fingertip = (float*)P(o);
+    o = L.add("fingertip_state", MI_F32, {n, nt > 0 ? nt : 1, 13}, {1, 13 * n, n}, 13 * (nt > 0 ? nt : 1) * n); if (hv) hv->fingertip = (float*)P(o);
     o = L.add("successes", MI_F32, {n}, {1}, n); if (hv) hv->successes = (float*)P(o);
     o = L.add("reset_goal_buf", MI_I64, {n}, {1}, n); if (hv) hv->reset_goal = (long long*)P(o);
     o = L.add("goal_reset_count", MI_I32, {n}, {1}, n); if (hv) hv->goal_count = (int*)P(o);
     o = L.add("consecutive_successes", MI_F32, {1}, {1}, 1); if (hv) hv->cons = (float*)P(o);
     o = L.add("reward_workspace", MI_F32, {2}, {1}, 2); if (hv) hv->ws = (float*)P(o);
     o = L.add("object_contact_count", MI_I32, {n}, {1}, n); if (hv) hv->ncontact = (int*)P(o);
-    o = L.add("states_buf", MI_F32, {n, 211}, {211, 1}, 211 * n); if (hv) hv->full_state = (float*)P(o);
+    o = L.add("states_buf", MI_F32, {n, nfull}, {nfull, 1}, nfull * n); if (hv) hv->full_state = (float*)P(o);
     o = L.add("object_force", MI_F32, {n, 3}, {1, n}, 3 * n); if (hv) hv->obj_force = (float*)P(o);
     o = L.add("rb_forces_object", MI_F32, {n, 3}, {1, n}, 3 * n); if (hv) hv->rb_force = (float*)P(o);
     o = L.add("random_force_prob", MI_F32, {n}, {1}, n); if (hv) hv->force_prob = (float*)P(o);
@@ -292,7 +300,7 @@ static void build_hand_layout(int N, Layout& L, HandView* hv, char* base) {
     // `actor_params` factors of the hand and the object (core/hand_engine.hpp HS_*), 1 = the model's own values
     o = L.add("actor_scale", MI_F32, {n, 8}, {1, n}, 8 * n); if (hv) hv->scale = (float*)P(o);
     // `actor_params.hand.dof_properties.lower / upper`: shifts of the 24 lower, then the 24 upper joint limits of each env's hand
-    o = L.add("dof_limit_shift", MI_F32, {n, 48}, {1, n}, 48 * n); if (hv) hv->limit_shift = (float*)P(o);
+    o = L.add("dof_limit_shift", MI_F32, {n, 2 * nd}, {1, n}, 2 * nd * n); if (hv) hv->limit_shift = (float*)P(o);
     o = L.add("object_contact_dropped", MI_I32, {n}, {1}, n); if (hv) hv->ndropped = (int*)P(o);   // contacts refused since init: all KMAX slots taken
     L.off = (L.off + 255) & ~size_t(255);
 }
@@ -312,7 +320,7 @@ extern "C" size_t mi_engine_arena_bytes(const char* task, int num_envs) {
     if (t < 0 || num_envs <= 0) { fail("mi_engine_arena_bytes: bad task or num_envs"); return 0; }
     Layout L;
     build_layout(t, num_envs, L, nullptr, nullptr);
-    if (t == T_SHADOWHAND) build_hand_layout(num_envs, L, nullptr, nullptr);
+    if (is_hand_task(t)) build_hand_layout(t, num_envs, L, nullptr, nullptr);
     if (t == T_QUADCOPTER) build_quad_layout(num_envs, L, nullptr, nullptr);
     if (t == T_INGENUITY) build_ingenuity_layout(num_envs, L, nullptr, nullptr);
     if (t == T_BALLBALANCE) build_bbot_layout(num_envs, L, nullptr, nullptr);
@@ -351,26 +359,27 @@ extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const 
             return fail("mi_engine_create: BallBalance needs positive ball mass / inertia / radius and a non-zero attractor");
         }
     }
-    else if (t == T_SHADOWHAND) memcpy(&e->hand, task_params, sizeof(HandParams));
+    else if (is_hand_task(t)) memcpy(&e->hand, task_params, sizeof(HandParams));
     else memcpy(&e->loco, task_params, sizeof(LocoParams));
     Layout L;
     memset(&e->v, 0, sizeof(View));
     e->v.fused_post = 0;
     int nobs = 0;
-    if (t == T_SHADOWHAND) {
+    if (is_hand_task(t)) {
         const HandParams& hp = e->hand;
-        const bool ok = (hp.obs_type == 0 && hp.num_obs == 211) || (hp.obs_type >= 1 && hp.obs_type <= 3 && hp.num_obs >= 1 && hp.num_obs <= 160);
-        if (!ok) { delete e; return fail("mi_engine_create: ShadowHand obs_type / num_obs invalid"); }
-        if (hp.object_shape < 0 || hp.object_shape > 2) { delete e; return fail("mi_engine_create: ShadowHand object_shape must be 0 (block), 1 (pen) or 2 (egg)"); }
+        const int nfull = kTasks[t].nobs;     // ShadowHand 211, AllegroHand 88
+        const bool ok = (hp.obs_type == 0 && hp.num_obs == nfull) || (hp.obs_type >= 1 && hp.obs_type <= 3 && hp.num_obs >= 1 && hp.num_obs <= 160);
+        if (!ok) { delete e; return fail("mi_engine_create: hand task obs_type / num_obs invalid"); }
+        if (hp.object_shape < 0 || hp.object_shape > 2) { delete e; return fail("mi_engine_create: hand task object_shape must be 0 (block), 1 (pen) or 2 (egg)"); }
         if (hp.object_shape != 0)
             for (int k = 0; k < 3; ++k)
                 if ((!(hp.object_dims[k] > 0.f) && !(hp.object_shape == 1 && k == 2)) || !(hp.object_inertia[k] > 0.f)) {
                     delete e;
-                    return fail("mi_engine_create: ShadowHand egg / pen need positive object_dims / object_inertia");
+                    return fail("mi_engine_create: hand task egg / pen need positive object_dims / object_inertia");
                 }
-        if (!(hp.cube_mass > 0.f)) { delete e; return fail("mi_engine_create: ShadowHand object mass must be positive"); }
+        if (!(hp.cube_mass > 0.f)) { delete e; return fail("mi_engine_create: hand task object mass must be positive"); }
         for (int k = 0; hp.obs_type != 0 && k < hp.num_obs; ++k)
-            if (hp.obs_map[k] < 0 || hp.obs_map[k] >= 211) { delete e; return fail("mi_engine_create: ShadowHand obs_map entry out of range"); }
+            if (hp.obs_map[k] < 0 || hp.obs_map[k] >= nfull) { delete e; return fail("mi_engine_create: hand task obs_map entry out of range"); }
         nobs = hp.num_obs;
     }
     build_layout(t, num_envs, L, &e->v, (char*)arena, nobs);
@@ -378,7 +387,7 @@ extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const 
     e->actor_scale_arena = e->v.actor_scale; e->limit_shift_arena = e->v.limit_shift;
     e->v.actor_scale = nullptr; e->v.limit_shift = nullptr;
     memset(&e->hv, 0, sizeof(e->hv));
-    if (t == T_SHADOWHAND) build_hand_layout(num_envs, L, &e->hv, (char*)arena);
+    if (is_hand_task(t)) build_hand_layout(t, num_envs, L, &e->hv, (char*)arena);
     memset(&e->qv, 0, sizeof(e->qv));
     if (t == T_QUADCOPTER) build_quad_layout(num_envs, L, &e->qv, (char*)arena);
     memset(&e->iv, 0, sizeof(e->iv));
@@ -426,6 +435,7 @@ extern "C" int mi_engine_set_option(MiEngine* e, const char* key, double value) 
     // whose model has no multi-wave form (Cartpole, Quadcopter).  ShadowHand: any non-zero value selects the finger-per-wave form (32 envs per
     // workgroup, core/hand_engine_mw.hpp).  2: the Humanoid's round-2 form (main wave + self-collision helper).
     if (!strcmp(key, "multi_wave")) {
+        if (e->task == T_ALLEGROHAND) { e->v.mw = 0; return 0; }   // one-wave sub-step only
         const bool hand64 = value == 64 && e->task == T_SHADOWHAND;      // full 64-env waves, one workgroup per CU (hand_mw_kernels.hpp)
         if (value != 0 && value != 32 && value != 2 && !(MI_MW_HAS16 && value == 16) && !hand64) return fail("multi_wave: 0, 16 or 32 (envs per workgroup); 2: main + helper wave; 64: ShadowHand only");
         e->v.mw = (int)value;
@@ -437,7 +447,7 @@ extern "C" int mi_engine_set_option(MiEngine* e, const char* key, double value) 
     // control-step counter (observation ring parity, AnymalTerrain push schedule, noise counters): part of a state checkpoint
     if (!strcmp(key, "steps")) { if (value < 0) return fail("steps < 0"); e->steps = (unsigned long long)value; return 0; }
     if (!strcmp(key, "actor_tensors")) {   // 1: the sub-step reads actor_scale / dof_limit_shift (Ant, Humanoid); ShadowHand always reads its own
-        if (e->task == T_SHADOWHAND) return 0;
+        if (is_hand_task(e->task)) return 0;
         if (value != 0 && e->actor_scale_arena == nullptr) return fail("actor_tensors: this task carries no actor_scale / dof_limit_shift tensors");
         e->v.actor_scale = value != 0 ? e->actor_scale_arena : nullptr;
         e->v.limit_shift = value != 0 ? e->limit_shift_arena : nullptr;
@@ -455,7 +465,7 @@ extern "C" int mi_engine_set_noise(MiEngine* e, int which, const MiNoiseParams* 
     if (!e || !p) return fail("mi_engine_set_noise: null argument");
     if (which != 0 && which != 1) return fail("mi_engine_set_noise: which must be 0 (observations) or 1 (actions)");
     if (p->dist < 0 || p->dist > 2 || p->op < 0 || p->op > 1) return fail("mi_engine_set_noise: dist in {0,1,2}, op in {0,1}");
-    if (e->task != T_CARTPOLE && e->task != T_ANT && e->task != T_HUMANOID && e->task != T_SHADOWHAND && p->dist != 0)
+    if (e->task != T_CARTPOLE && e->task != T_ANT && e->task != T_HUMANOID && !is_hand_task(e->task) && p->dist != 0)
         return fail("mi_engine_set_noise: in-kernel noise exists for Cartpole, Ant, Humanoid and ShadowHand");
     memcpy(which == 0 ? &e->v.obs_noise : &e->v.act_noise, p, sizeof(NoiseParams));
     return 0;
@@ -472,7 +482,7 @@ extern "C" int mi_engine_get_option(const MiEngine* e, const char* key, double* 
     if (!strcmp(key, "fused_post")) { *out = e->v.fused_post; return 0; }
     if (!strcmp(key, "steps")) { *out = (double)e->steps; return 0; }
     if (!strcmp(key, "terrain_slope_threshold")) { *out = e->terrain.slope_threshold; return 0; }
-    if (!strcmp(key, "actor_tensors")) { *out = (e->task == T_SHADOWHAND || e->v.actor_scale != nullptr) ? 1.0 : 0.0; return 0; }
+    if (!strcmp(key, "actor_tensors")) { *out = (is_hand_task(e->task) || e->v.actor_scale != nullptr) ? 1.0 : 0.0; return 0; }
     return fail(std::string("unknown option: ") + key);
 }
 
@@ -500,8 +510,9 @@ extern "C" int mi_engine_init_state(MiEngine* e, void* stream) {
     const TaskMeta& m = kTasks[e->task];
     float* d_init = nullptr;
     float root_z = 0.f, pot0 = 0.f;
-    if (e->task == T_SHADOWHAND) {
-        HIP_OK(launch_init_shadow_hand(e->v, e->hv, e->hand, s));
+    if (is_hand_task(e->task)) {
+        if (e->task == T_SHADOWHAND) HIP_OK(launch_init_shadow_hand(e->v, e->hv, e->hand, s));
+        else HIP_OK(launch_init_allegro_hand(e->v, e->hv, e->hand, s));
         e->steps = 0;
         return 0;
     }
@@ -590,6 +601,9 @@ extern "C" int mi_engine_step(MiEngine* e, const float* actions, void* stream) {
         case T_SHADOWHAND:
             HIP_OK(launch_step_shadow_hand(e->v, e->hv, e->P, e->hand, actions, e->control_freq_inv, (unsigned)(e->steps + 1), s));
             break;
+        case T_ALLEGROHAND:
+            HIP_OK(launch_step_allegro_hand(e->v, e->hv, e->P, e->hand, actions, e->control_freq_inv, (unsigned)(e->steps + 1), s));
+            break;
         case T_ANYMAL:
             if (e->terrain.hs == nullptr) return fail("mi_engine_step: AnymalTerrain needs mi_engine_set_terrain first");
             // common_step_counter is incremented before the push test (anymal_terrain.py:460-462)
@@ -614,6 +628,7 @@ extern "C" int mi_engine_simulate(MiEngine* e, void* stream) {
         case T_ANT: HIP_OK(launch_simulate_ant(e->v, e->P, s)); break;
         case T_HUMANOID: HIP_OK(launch_simulate_humanoid(e->v, e->P, s)); break;
         case T_SHADOWHAND: HIP_OK(launch_simulate_shadow_hand(e->v, e->hv, e->P, e->hand, s)); break;
+        case T_ALLEGROHAND: HIP_OK(launch_simulate_allegro_hand(e->v, e->hv, e->P, e->hand, s)); break;
         case T_ANYMAL:
             if (e->terrain.hs == nullptr) return fail("mi_engine_simulate: AnymalTerrain needs mi_engine_set_terrain first");
             HIP_OK(launch_simulate_anymal(e->v, e->P, e->terrain, s));
@@ -631,7 +646,7 @@ extern "C" int mi_engine_refresh_rigid_body_states(MiEngine* e, void* stream) {
     if (!e) return fail("null engine");
     if (int rc = check_device(e, "mi_engine_refresh_rigid_body_states")) return rc;
     static_assert(T_CARTPOLE == 0 && T_ANT == 1 && T_HUMANOID == 2 && T_ANYMAL == 3 && T_SHADOWHAND == 4 && T_ANYMAL_FLAT == 5 && T_QUADCOPTER == 6 &&
-                  T_INGENUITY == 7 && T_BALLBALANCE == 8, "kernels_body_states.hip switches on these ids");
+                  T_INGENUITY == 7 && T_BALLBALANCE == 8 && T_ALLEGROHAND == 9, "kernels_body_states.hip switches on these ids");
     HIP_OK(launch_body_states(e->task, e->v, (hipStream_t)stream));
     return 0;
 }
@@ -648,6 +663,7 @@ extern "C" int mi_engine_reset_idx(MiEngine* e, const int64_t* env_ids, int n, v
         case T_HUMANOID: HIP_OK(launch_reset_humanoid(e->v, e->loco, (const long long*)env_ids, n, s)); break;
         case T_ANYMAL: HIP_OK(launch_reset_anymal(e->v, e->anymal, e->terrain, (const long long*)env_ids, n, s)); break;
         case T_SHADOWHAND: HIP_OK(launch_reset_shadow_hand(e->v, e->hv, e->hand, (const long long*)env_ids, n, s)); break;
+        case T_ALLEGROHAND: HIP_OK(launch_reset_allegro_hand(e->v, e->hv, e->hand, (const long long*)env_ids, n, s)); break;
         case T_ANYMAL_FLAT: HIP_OK(launch_reset_anymal_flat(e->v, e->anymal_flat, (const long long*)env_ids, n, s)); break;
         case T_QUADCOPTER: HIP_OK(launch_reset_quadcopter(e->v, e->qv, e->quad, (const long long*)env_ids, n, s)); break;
         case T_INGENUITY: HIP_OK(launch_reset_ingenuity(e->v, e->iv, e->ing, (const long long*)env_ids, n, s)); break;

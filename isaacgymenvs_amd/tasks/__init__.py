@@ -1,4 +1,5 @@
 """Task name -> class map (reference isaacgymenvs/tasks/__init__.py:88-114; the tasks built so far)."""
+from .allegro_hand import AllegroHand
 from .ant import Ant
 from .anymal import Anymal
 from .anymal_terrain import AnymalTerrain
@@ -10,6 +11,7 @@ from .quadcopter import Quadcopter
 from .shadow_hand import ShadowHand
 
 isaacgym_task_map = {
+    "AllegroHand": AllegroHand,
     "Ant": Ant,
     "Anymal": Anymal,
     "AnymalTerrain": AnymalTerrain,

@@ -259,7 +259,7 @@ class VecTask(Env):
 
     # ------------------------------------------------------------------ domain randomisation (vec_task.py:610-840)
     #: tasks whose step kernels apply observation / action noise themselves (mi_engine_set_noise); the others get torch ops
-    KERNEL_NOISE_TASKS = ("Cartpole", "Ant", "Humanoid", "ShadowHand")
+    KERNEL_NOISE_TASKS = ("Cartpole", "Ant", "Humanoid", "ShadowHand", "AllegroHand")
     #: `actor_params` entries that have a per-env engine parameter (Ant, Humanoid): the `actor_scale` tensor carries one factor per BODY for
     #: rigid_body_properties.mass and one per DOF for each of dof_properties.damping / stiffness / armature (csrc/core/engine.hpp AS_*)
     ACTOR_SCALE_GROUPS = {("rigid_body_properties", "mass"): ("body", 0), ("dof_properties", "damping"): ("dof", 0), ("dof_properties", "stiffness"): ("dof", 1),
@@ -347,9 +347,9 @@ class VecTask(Env):
         Entries without an engine parameter (restitution, colours, ...) are named once in a warning."""
         from ...utils.dr_utils import apply_random_samples_array
         t = self.engine.tensors
-        fr = t.get("friction") if self.native_task in ("Ant", "Humanoid", "ShadowHand") else None
+        fr = t.get("friction") if self.native_task in ("Ant", "Humanoid", "ShadowHand", "AllegroHand") else None
         scales = t.get("actor_scale")
-        pair = self.native_task == "ShadowHand"       # one contact coefficient per env = mean of the two actors' shape friction
+        pair = self.native_task in ("ShadowHand", "AllegroHand")       # one contact coefficient per env = mean of the two actors' shape friction
         if pair and not hasattr(self, "_dr_actor_friction"):
             self._dr_actor_friction = {}
         ids = torch.arange(self.num_envs, device=self.device) if due_envs is None else torch.nonzero(due_envs, as_tuple=False).squeeze(-1)

@@ -67,9 +67,14 @@ def hand_max_episode_length(cfg):
     return env["episodeLength"]
 
 
-def hand_params_from_cfg(cfg):
+def hand_params_from_cfg(cfg, model="shadow_hand", hand_quat=None, object_offset=(0.0, -0.39, 0.10), pen_offset_z=0.02,
+                         cube=(CUBE_SIZE, CUBE_DENSITY), obs_layout=None):
+    """cfg -> MiHandParams.  The keyword arguments are what differs for the AllegroHand task (tasks/allegro_hand.py): the model with its
+    extras, the actor's orientation, where the object starts relative to the hand, the cube asset, the observation layouts."""
     env = cfg["env"]
-    ex = load_extras("shadow_hand")
+    ex = load_extras(model)
+    cube_size, cube_density = cube
+    num_obs, obs_type_id, columns = obs_layout or (NUM_OBS, OBS_TYPE_ID, obs_columns)
     p = native.MiHandParams()
     r = p.rew
     r.max_episode_length = float(hand_max_episode_length(cfg))
@@ -91,16 +96,16 @@ def hand_params_from_cfg(cfg):
     ca = env.get("clipActions", np.inf)
     p.clip_actions = float(ca) if np.isfinite(ca) else 3.0e38
     hand_pos = (0.0, 0.0, 0.5)                                    # get_axis_params(0.5, up_axis_idx), :306-307
-    obj = (hand_pos[0], hand_pos[1] - 0.39, hand_pos[2] + 0.10)  # :309-315
+    obj = tuple(hand_pos[k] + object_offset[k] for k in range(3))   # shadow_hand.py:309-315 (0, -0.39, 0.10); allegro_hand.py:287-294
     for k in range(3):
         p.hand_pos[k] = hand_pos[k]
         p.object_init_pos[k] = obj[k]
         p.goal_init_pos[k] = obj[k] - (0.04 if k == 2 else 0.0)   # goal_states = object_init_state, z -= 0.04 (:393-395)
     for k in range(4):
-        p.hand_quat[k] = float(ex["mount_quat"][k])
-    p.cube_half = CUBE_SIZE / 2
-    p.cube_mass = CUBE_DENSITY * CUBE_SIZE ** 3
-    p.cube_inertia = p.cube_mass * CUBE_SIZE ** 2 / 6.0
+        p.hand_quat[k] = float((hand_quat if hand_quat is not None else ex["mount_quat"])[k])
+    p.cube_half = cube_size / 2
+    p.cube_mass = cube_density * cube_size ** 3
+    p.cube_inertia = p.cube_mass * cube_size ** 2 / 6.0
     p.mu = 1.0
     p.object_shape = OBJECT_SHAPE_ID[env.get("objectType", "block")]
     if env.get("objectType", "block") == "egg":
@@ -123,16 +128,16 @@ def hand_params_from_cfg(cfg):
         for k in range(3):
             p.object_inertia[k] = inertia[k]
         r.ignore_z_rot = 1                                        # shadow_hand.py:421
-        obj = (hand_pos[0], hand_pos[1] - 0.39, hand_pos[2] + 0.02)   # the pen starts lower (:316-317)
+        obj = (hand_pos[0] + object_offset[0], hand_pos[1] + object_offset[1], hand_pos[2] + pen_offset_z)   # the pen starts lower (:316-317)
         for k in range(3):
             p.object_init_pos[k] = obj[k]
             p.goal_init_pos[k] = obj[k] - (0.04 if k == 2 else 0.0)
     for a, d in enumerate(ex["actuated_dofs"]):
         p.actuated[a] = int(d)
     ot = env["observationType"]
-    cols = obs_columns(ot)
-    assert len(cols) == NUM_OBS[ot]
-    p.obs_type, p.num_obs = OBS_TYPE_ID[ot], len(cols)
+    cols = columns(ot)
+    assert len(cols) == num_obs[ot]
+    p.obs_type, p.num_obs = obs_type_id[ot], len(cols)
     p.asymmetric_obs = int(bool(env.get("asymmetric_observations", False)))
     if ot != "full_state":
         for k, c in enumerate(cols):

@@ -94,6 +94,12 @@ class OracleHandEngine:
         backend: "c" -- oracle/hand.c (OpenMP over the envs); "numpy" -- the restatement below (solver "gs" only; the cross-check of
         hand.c).  solver: "gs" -- one Gauss-Seidel sequence, KMAX contacts per env (the single-wave kernel's order); "blocks" -- the
         finger-per-wave kernel's order with `blocks` = isaacgymenvs_amd.assets.model.hand_solver_blocks(spec) (hand.c header)."""
+        # a block of another size / mass than the ShadowHand's 5 cm cube (AllegroHand: 6.5 cm, density 400): dict(shape="block", half=, mass=)
+        self.cube_half, self.cube_mass = CUBE_HALF, CUBE_MASS
+        if obj is not None and obj.get("shape") == "block":
+            self.cube_half, self.cube_mass = float(obj["half"]), float(obj["mass"])
+            obj = None
+        self.cube_inertia = self.cube_mass * (2.0 * self.cube_half) ** 2 / 6.0          # isotropic
         self.objp = obj
         self.spec, self.ex, self.N = spec, extras, num_envs
         assert backend in ("c", "numpy") and solver in ("gs", "blocks") and (solver == "gs" or backend == "c")
@@ -182,8 +188,8 @@ class OracleHandEngine:
             setattr(hd, n, _ptr(k[n]))
         hd.tend_stiffness, hd.tend_damping, hd.mu = float(ex["tendon_limit_stiffness"]), float(ex["tendon_damping"]), 1.0
         if self.objp is None:
-            hd.shape, hd.obj_mass = 0, CUBE_MASS
-            hd.obj_inertia[:] = [CUBE_INERTIA] * 3; hd.obj_dims[:] = [CUBE_HALF, 0.0, 0.0]
+            hd.shape, hd.obj_mass = 0, self.cube_mass
+            hd.obj_inertia[:] = [self.cube_inertia] * 3; hd.obj_dims[:] = [self.cube_half, 0.0, 0.0]
         else:
             hd.shape, hd.obj_mass = {"pen": 1, "egg": 2}[self.objp["shape"]], float(self.objp["mass"])
             hd.obj_inertia[:] = [float(x) for x in self.objp["inertia"]]
@@ -245,7 +251,7 @@ class OracleHandEngine:
         g = np.array(P["gravity"], float)
         xo, qo = self.obj[e, 0:3].copy(), self.obj[e, 3:7].copy()
         egg = self.objp is not None
-        omass = (float(self.objp["mass"]) if egg else CUBE_MASS) * s_om
+        omass = (float(self.objp["mass"]) if egg else self.cube_mass) * s_om
         vo = self.obj[e, 7:10] + h * (g + self.obj_force[e] / omass)   # + apply_rigid_body_force_tensors on the object
         wo = self.obj[e, 10:13].copy()
         Ro = quat2mat(qo)
@@ -278,7 +284,7 @@ class OracleHandEngine:
             elif egg:
                 dist, nl = sphere_ellipsoid(Ro.T @ (c - xo), self.os_rad[si], np.asarray(self.objp["dims"], float) * s_os)
             else:
-                dist, nl = sphere_box(Ro.T @ (c - xo), self.os_rad[si], CUBE_HALF * s_os)
+                dist, nl = sphere_box(Ro.T @ (c - xo), self.os_rad[si], self.cube_half * s_os)
             if dist >= P["contact_offset"] or ncon >= KMAX or per_body.get(b, 0) >= BODY_CAP:
                 continue
             per_body[b] = per_body.get(b, 0) + 1
@@ -298,7 +304,7 @@ class OracleHandEngine:
         Moinv = np.zeros((6, 6))
         Moinv[:3, :3] = np.eye(3) / omass
         # world-frame inverse inertia: Ro diag(1 / I) Ro^T for the ellipsoid's principal inertias, a multiple of identity for the cube
-        Moinv[3:, 3:] = (Ro @ np.diag(1.0 / np.asarray(self.objp["inertia"], float)) @ Ro.T if egg else np.eye(3) / CUBE_INERTIA) / s_om
+        Moinv[3:, 3:] = (Ro @ np.diag(1.0 / np.asarray(self.objp["inertia"], float)) @ Ro.T if egg else np.eye(3) / self.cube_inertia) / s_om
         for r in rows:
             r["Bh"] = Minv @ r["Jh"]; r["Bo"] = Moinv @ r["Jo"]
             r["Ainv"] = 1.0 / (P["cfm"] + r["Jh"] @ r["Bh"] + r["Jo"] @ r["Bo"])

@@ -1094,13 +1094,17 @@ def compute_hand_observations(obs_type, dof_pos, dof_vel, lower, upper, object_s
 class OracleShadowHandEnv:
     """vec_task.py:360-408 + shadow_hand.py pre/post_physics_step on oracle/hand.py (numpy, fp64 physics, fp32 task maths).
     `params` is the MiHandParams struct the HIP engine receives."""
+    NACT = 20          # driven dofs (shadow_hand.py:268-269)
 
-    def __init__(self, spec, extras, sensor_bodies, sim_params: dict, params, num_envs, seed=0, env_id_offset=0, solver="gs", blocks=None):
+    def __init__(self, spec, extras, sensor_bodies, sim_params: dict, params, num_envs, seed=0, env_id_offset=0, solver="gs", blocks=None,
+                 control_freq_inv=1):
         """solver / blocks: the physics' solver order (oracle/hand.py): "gs" = the one-wave kernel's, "blocks" = the finger-per-wave kernel's
-        with blocks = isaacgymenvs_amd.assets.model.hand_solver_blocks(spec)."""
+        with blocks = isaacgymenvs_amd.assets.model.hand_solver_blocks(spec).  control_freq_inv: gym.simulate() calls per control step
+        (vec_task.py:379-382; ShadowHand.yaml 1, AllegroHand.yaml 2)."""
         from .hand import OracleHandEngine
         self.N, self.p, self.nd = num_envs, params, spec.nd
-        obj = None
+        self.control_freq_inv = int(control_freq_inv)
+        obj = dict(shape="block", half=float(params.cube_half), mass=float(params.cube_mass))     # the task's cube (ShadowHand 5 cm, AllegroHand 6.5 cm)
         if int(getattr(params, "object_shape", 0)) != 0:                          # objectType "pen" (1) / "egg" (2)
             obj = dict(shape={1: "pen", 2: "egg"}[int(params.object_shape)], dims=list(params.object_dims), mass=float(params.cube_mass),
                        inertia=list(params.object_inertia))
@@ -1112,7 +1116,7 @@ class OracleShadowHandEnv:
         N, p = num_envs, params
         self.lo = np.minimum(spec.dof_lower, spec.dof_upper).astype(f32)
         self.up = np.maximum(spec.dof_lower, spec.dof_upper).astype(f32)
-        self.act = np.array(p.actuated[:], int)
+        self.act = np.array(p.actuated[:self.NACT], int)
         self.cur_targets = np.zeros((N, self.nd), f32)
         self.prev_targets = np.zeros((N, self.nd), f32)
         self.eng.obj[:, 0:3] = list(p.object_init_pos)
@@ -1124,7 +1128,7 @@ class OracleShadowHandEnv:
         self.progress_buf = np.zeros(N, np.int64)
         self.episode = np.zeros(N, np.uint32)
         self.goal_count = np.zeros(N, np.uint32)
-        self.actions = np.zeros((N, 20), f32)
+        self.actions = np.zeros((N, self.NACT), f32)
         self.obs_type = {0: "full_state", 1: "openai", 2: "full_no_vel", 3: "full"}[int(getattr(p, "obs_type", 0))]
         self.rb_forces = np.zeros((N, 3), f32)                                    # rb_forces[:, object] (local frame)
         self.random_force_prob = np.zeros(N, f32)
@@ -1216,15 +1220,13 @@ class OracleShadowHandEnv:
             new = np.stack([r1 * np.cos(tw * u2) * k, r1 * np.sin(tw * u2) * k, r2 * np.cos(tw * u4) * k], axis=1).astype(f32)
             self.rb_forces[hit] = new[hit]
             self.eng.obj_force[:] = quat_rotate(self.eng.obj[:, 3:7].astype(f32), self.rb_forces)      # LOCAL_SPACE
-        self.eng.step()
+        for _ in range(self.control_freq_inv):                                                         # vec_task.py:379-382
+            self.eng.step()
         return self.post_physics_step()
 
-    def post_physics_step(self):  # :710-715
-        p = self.p
-        self.progress_buf += 1
-        e = self.eng
+    def compute_observations(self, obj):  # shadow_hand.py:437-471
+        p, e = self.p, self.eng
         self.fingertip_state = e.fingertip_states().astype(f32)
-        obj = e.obj.astype(f32)
         self.states_buf = compute_hand_full_state(e.q.astype(f32), e.qd.astype(f32), e.dof_force.astype(f32), self.lo, self.up, obj,
                                                   self.goal_states, self.fingertip_state, e.sensor.astype(f32), self.actions,
                                                   p.vel_obs_scale, p.force_torque_obs_scale)
@@ -1233,6 +1235,13 @@ class OracleShadowHandEnv:
         else:
             self.obs_buf = compute_hand_observations(self.obs_type, e.q.astype(f32), e.qd.astype(f32), self.lo, self.up, obj,
                                                      self.goal_states, self.fingertip_state, self.actions, p.vel_obs_scale)
+
+    def post_physics_step(self):  # :710-715
+        p = self.p
+        self.progress_buf += 1
+        e = self.eng
+        obj = e.obj.astype(f32)
+        self.compute_observations(obj)
         r = p.rew
         out = compute_hand_reward(None, self.reset_buf, self.reset_goal_buf, self.progress_buf, self.successes, self.consecutive_successes,
                                   r.max_episode_length, obj[:, 0:3], obj[:, 3:7], self.goal_states[:, 0:3], self.goal_states[:, 3:7],
@@ -1241,3 +1250,55 @@ class OracleShadowHandEnv:
                                   r.av_factor, bool(r.ignore_z_rot))
         self.rew_buf, self.reset_buf, self.reset_goal_buf, self.progress_buf, self.successes, self.consecutive_successes = out
         return self.obs_buf, self.rew_buf, self.reset_buf
+
+
+def compute_allegro_observations(obs_type, dof_pos, dof_vel, dof_force, lower, upper, object_state, goal_pose, actions, vel_obs_scale, ft_scale):
+    """allegro_hand.py:441-507: compute_full_observations(True) ("full_no_vel", 50 columns), compute_full_observations() ("full", 72),
+    compute_full_state() ("full_state", 88); written out layout by layout like the reference."""
+    n = dof_pos.shape[0]
+    object_pose, object_linvel, object_angvel = object_state[:, 0:7], object_state[:, 7:10], object_state[:, 10:13]
+    rel = quat_mul(object_state[:, 3:7].astype(f32), quat_conjugate(goal_pose[:, 3:7].astype(f32)))
+    if obs_type == "full_no_vel":                                             # :442-449
+        obs = np.zeros((n, 50), f32)
+        obs[:, 0:16] = unscale(dof_pos, lower, upper)
+        obs[:, 16:23] = object_pose
+        obs[:, 23:30] = goal_pose
+        obs[:, 30:34] = rel
+        obs[:, 34:50] = actions
+    elif obs_type == "full":                                                  # :450-460
+        obs = np.zeros((n, 72), f32)
+        obs[:, 0:16] = unscale(dof_pos, lower, upper)
+        obs[:, 16:32] = f32(vel_obs_scale) * dof_vel
+        obs[:, 32:39] = object_pose
+        obs[:, 39:42] = object_linvel
+        obs[:, 42:45] = f32(vel_obs_scale) * object_angvel
+        obs[:, 45:52] = goal_pose
+        obs[:, 52:56] = rel
+        obs[:, 56:72] = actions
+    else:                                                                     # compute_full_state, :485-507
+        obs = np.zeros((n, 88), f32)
+        obs[:, 0:16] = unscale(dof_pos, lower, upper)
+        obs[:, 16:32] = f32(vel_obs_scale) * dof_vel
+        obs[:, 32:48] = f32(ft_scale) * dof_force
+        obs[:, 48:55] = object_pose
+        obs[:, 55:58] = object_linvel
+        obs[:, 58:61] = f32(vel_obs_scale) * object_angvel
+        obs[:, 61:68] = goal_pose
+        obs[:, 68:72] = rel
+        obs[:, 72:88] = actions
+    return obs
+
+
+class OracleAllegroHandEnv(OracleShadowHandEnv):
+    """allegro_hand.py on oracle/hand.py: the ShadowHand task's control flow (reset_idx :526-590, reset_target_pose :509-524, pre_physics_step
+    :592-625 are the same statements) with 16 driven dofs and the Allegro task's observation layouts."""
+    NACT = 16          # allegro_hand.py:233-235: every dof is driven
+
+    def compute_observations(self, obj):  # allegro_hand.py:409-439
+        p, e = self.p, self.eng
+        lo, up = self.lo.astype(f32), self.up.astype(f32)
+        args = (e.q.astype(f32), e.qd.astype(f32), e.dof_force.astype(f32), lo, up, obj, self.goal_states, self.actions,
+                p.vel_obs_scale, p.force_torque_obs_scale)
+        self.states_buf = compute_allegro_observations("full_state", *args)
+        self.obs_buf = self.states_buf if self.obs_type == "full_state" else compute_allegro_observations(self.obs_type, *args)
+

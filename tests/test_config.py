@@ -74,7 +74,7 @@ def test_variant_configs_compose_to_the_reference_values():
     assert hand_max_episode_length(compose(overrides=["task=ShadowHand"])["task"]) == 600
 
 
-@pytest.mark.parametrize("name", ["Ant", "AntSAC", "Humanoid", "HumanoidSAC", "Cartpole", "Anymal", "AnymalTerrain", "Quadcopter", "Ingenuity", "BallBalance", "ShadowHand",
+@pytest.mark.parametrize("name", ["Ant", "AntSAC", "Humanoid", "HumanoidSAC", "Cartpole", "Anymal", "AnymalTerrain", "Quadcopter", "Ingenuity", "BallBalance", "ShadowHand", "AllegroHand",
                                   "ShadowHandOpenAI_FF", "ShadowHandOpenAI_LSTM", "ShadowHandTest"])
 def test_env_section_equals_the_reference_yaml(name):
     """Every scalar the reference's task YAML sets in `env:` and in the noise part of `task:` has the same value here (the unresolved
