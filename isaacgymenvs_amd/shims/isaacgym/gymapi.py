@@ -73,6 +73,10 @@ class Quat:
         n = np.sqrt(axis.x ** 2 + axis.y ** 2 + axis.z ** 2) or 1.0
         return Quat(axis.x / n * s, axis.y / n * s, axis.z / n * s, np.cos(0.5 * angle))
 
+    def __mul__(self, o):          # Hamilton product (allegro_hand.py:283 composes the hand's start rotation from three axis-angle quats)
+        return Quat(self.w * o.x + self.x * o.w + self.y * o.z - self.z * o.y, self.w * o.y - self.x * o.z + self.y * o.w + self.z * o.x,
+                    self.w * o.z + self.x * o.y - self.y * o.x + self.z * o.w, self.w * o.w - self.x * o.x - self.y * o.y - self.z * o.z)
+
 
 class Transform:
     def __init__(self, p=None, r=None):
@@ -143,9 +147,12 @@ class SimParams:
 
 # ---------------------------------------------------------------------------------------------------------------- recorded objects
 _MODEL_OF_FILE = {"nv_ant.xml": ("ant", "Ant"), "nv_humanoid.xml": ("humanoid", "Humanoid"), "cartpole.urdf": ("cartpole", "Cartpole"),
-                  "anymal_minimal.urdf": ("anymal", "AnymalTerrain"), "shadow_hand.xml": ("shadow_hand", "ShadowHand")}
-# the ShadowHand task's free objects (shadow_hand.py:86-96): one body, no dof
-_OBJECT_OF_FILE = {"cube_multicolor.urdf": "block", "egg.xml": "egg", "pen.xml": "pen"}
+                  "anymal_minimal.urdf": ("anymal", "AnymalTerrain"), "shadow_hand.xml": ("shadow_hand", "ShadowHand"),
+                  # cfg/task/AllegroHand.yaml asset.assetFileName (allegro_hand.py:212-214)
+                  "allegro_touch_sensor.urdf": ("allegro_hand", "AllegroHand")}
+# the hand tasks' free objects (shadow_hand.py:86-96, allegro_hand.py:88-92 + AllegroHand.yaml assetFileNameBlock): one body, no dof
+_OBJECT_OF_FILE = {"cube_multicolor.urdf": "block", "cube_multicolor_allegro.urdf": "block", "egg.xml": "egg", "pen.xml": "pen"}
+_HAND_TASKS = ("ShadowHand", "AllegroHand")
 
 
 class _ActuatorProps:
@@ -199,7 +206,7 @@ class _Asset:
         self.nshapes = len(self.spec.geom_body)
         self.engine_sensor_bodies = [self.body_names.index(self.spec.body_names[b]) for b in sensor_bodies(self.model_name, self.spec)]
         self.has_self_collision = load_selfcol(self.model_name) is not None
-        self.extras = load_extras(self.model_name) if self.model_name == "shadow_hand" else None
+        self.extras = load_extras(self.model_name) if self.model_name in ("shadow_hand", "allegro_hand") else None
 
 
 class _Env:
@@ -389,7 +396,7 @@ class Gym:
     def get_actor_rigid_body_properties(self, env, actor):
         a = env.sim.slots[actor]["asset"]
         if a.spec is None:
-            return [RigidBodyProperties(_object_mass(a.object_type))]
+            return [RigidBodyProperties(_object_mass(a.object_type, env.sim.asset.task if env.sim.asset is not None else "ShadowHand"))]
         return [RigidBodyProperties(float(a.spec.mass[int(d)])) for d in a.body_dyn]
 
     def get_actor_dof_count(self, env, actor):
@@ -473,14 +480,21 @@ class Gym:
             if terrain is None:
                 terrain = _FlatTerrain()
                 terrain.max_init_level = 0
-        elif asset.task == "ShadowHand":
-            from ...tasks.shadow_hand import hand_params_from_cfg
+        elif asset.task in _HAND_TASKS:
             objs = [sl["asset"].object_type for sl in sim.slots if sl["asset"].spec is None]
             cfg["env"]["objectType"] = objs[0] if objs else "block"
-            tp = hand_params_from_cfg(cfg)
+            if asset.task == "ShadowHand":
+                from ...tasks.shadow_hand import hand_params_from_cfg
+                tp = hand_params_from_cfg(cfg)
+            else:
+                from ...tasks.allegro_hand import allegro_params_from_cfg
+                tp = allegro_params_from_cfg(cfg)
+                for k in range(4):       # the actor's orientation is a task parameter of the engine (allegro_hand.py:283)
+                    if abs(abs(tp.hand_quat[k]) - abs(float(poses[0, 3 + k]))) > 1e-5:
+                        raise NotImplementedError("the Allegro hand is created with the start rotation of allegro_hand.py:283")
             for k in range(3):
                 if abs(tp.hand_pos[k] - float(poses[0, k])) > 1e-6:
-                    raise NotImplementedError("the hand is mounted at (0, 0, 0.5) (shadow_hand.py:306-307)")
+                    raise NotImplementedError("the hand is mounted at (0, 0, 0.5) (shadow_hand.py:306-307, allegro_hand.py:282)")
         else:
             from ...tasks.locomotion import loco_params_from_cfg
             tp = loco_params_from_cfg(cfg, asset.model_name, float(poses[0, 2]))
@@ -508,7 +522,7 @@ class Gym:
             for e, val in rslot["friction"].items():
                 mu[e] = val
             t["friction"][:] = mu.to(sim.device)
-        if asset.task == "ShadowHand":
+        if asset.task in _HAND_TASKS:
             k_obj = [k for k, sl in enumerate(sim.slots) if sl["asset"].spec is None]
             if k_obj:
                 o = torch.zeros((n, 13), dtype=torch.float32)
@@ -774,11 +788,14 @@ class Gym:
             sim.engine = None
 
 
-def _object_mass(object_type):
-    from ...tasks import shadow_hand as sh
+def _object_mass(object_type, task="ShadowHand"):
     from ...utils.config import compose
-    cfgd = compose(overrides=["task=ShadowHand"])["task"]
+    cfgd = compose(overrides=[f"task={task}"])["task"]
     cfgd["env"]["objectType"] = object_type
+    if task == "AllegroHand":
+        from ...tasks.allegro_hand import allegro_params_from_cfg
+        return float(allegro_params_from_cfg(cfgd).cube_mass)
+    from ...tasks import shadow_hand as sh
     return float(sh.hand_params_from_cfg(cfgd).cube_mass)
 
 

@@ -40,7 +40,7 @@ def reference_tasks():
         mod = types.ModuleType(name)
         mod.__path__ = [os.path.join(REF, rel)]
         sys.modules[name] = mod
-    mods = {n: importlib.import_module("isaacgymenvs.tasks." + n) for n in ("cartpole", "ant", "humanoid", "anymal_terrain", "shadow_hand")}
+    mods = {n: importlib.import_module("isaacgymenvs.tasks." + n) for n in ("cartpole", "ant", "humanoid", "anymal_terrain", "shadow_hand", "allegro_hand")}
     vt = importlib.import_module("isaacgymenvs.tasks.base.vec_task")
     yield mods, vt
     for k in [k for k in sys.modules if k.split(".")[0] in ("isaacgymenvs", "isaacgym", "gym")]:
@@ -258,3 +258,57 @@ def test_reference_shadow_hand_runs_on_the_engine_and_matches_the_fused_kernels(
     assert float(d[:, force_cols].max()) < 2e-3 * max(1.0, float(r_obs["obs"][:, force_cols].abs().max()))
     assert float((r_rew - n_rew).abs()[keep].max()) < 2e-3 * max(1.0, float(r_rew.abs().max()))
     assert torch.equal(r_reset[keep], n_reset[keep])
+
+
+@pytest.mark.gpu
+@gpu_only
+def test_reference_allegro_hand_runs_on_the_engine_and_matches_the_fused_kernels(reference_tasks):
+    """The reference's own allegro_hand.py, unmodified (the last task of SURVEY 8f-1): the mesh-shaped hand of allegro_touch_sensor.urdf,
+    the dof properties the task writes (stiffness 3, damping 0.1, armature 0.001 -- the values compiled into the model), the start rotation
+    composed with Quat.__mul__, three actors per env, the [N, 19, 13] rigid-body tensor.  Then, on the same state and action, one more step
+    of the native task class: all 88 observation columns and the rewards agree."""
+    import isaacgymenvs_amd
+    mods, vt = reference_tasks
+    vt.EXISTING_SIM = None
+    n, seed = 96, 5
+    cfg = _ref_cfg("AllegroHand", n)
+    cfg["task"]["randomize"] = False
+    torch.manual_seed(seed)
+    ref = mods["allegro_hand"].AllegroHand(cfg, rl_device=DEV, sim_device=DEV, graphics_device_id=-1, headless=True,
+                                           virtual_screen_capture=False, force_render=False)
+    assert ref.num_shadow_hand_dofs == 16 and ref.num_shadow_hand_actuators == 16 and ref.num_shadow_hand_bodies == 17
+    assert ref.root_state_tensor.shape == (3 * n, 13) and ref.rigid_body_states.shape == (n, 19, 13)
+    assert ref.obs_buf.shape[1] == 88 and ref.control_freq_inv == 2
+    eng = ref.sim.engine
+    g = torch.Generator().manual_seed(1)
+    for step in range(15):
+        obs, rew, reset, _ = ref.step((torch.rand((n, 16), generator=g) * 2 - 1).to(DEV))
+        assert torch.isfinite(obs["obs"]).all() and torch.isfinite(rew).all()
+    # under full-range random actions the open Allegro hand drops the cube often (resets): contacts in a good part of the envs, not in most
+    assert float((eng.tensors["object_contact_count"] > 0).float().mean()) > 0.25
+    assert float((ref.object_pos - eng.tensors["object_state"][:, :3]).abs().max()) < 1e-6
+    # ---- same state, same action, one more step: the native task class (fused kernels)
+    nat = isaacgymenvs_amd.make(seed=seed, task="AllegroHand", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True)
+    nat.step(torch.zeros((n, 16), device=DEV))
+    et, nt = eng.tensors, nat.engine.tensors
+    for k in ("dof_state", "limit_impulse", "object_state", "dof_force", "actor_scale"):
+        nt[k].copy_(et[k])
+    nt["cur_targets"].copy_(ref.cur_targets); nt["prev_targets"].copy_(ref.prev_targets)
+    nt["goal_states"].copy_(ref.goal_states[:, :7]); nt["successes"].copy_(ref.successes)
+    nat.progress_buf.copy_(ref.progress_buf); nat.reset_buf.copy_(ref.reset_buf); nt["reset_goal_buf"].copy_(ref.reset_goal_buf)
+    nt["consecutive_successes"].copy_(ref.consecutive_successes)
+    nt["random_force_prob"].zero_(); ref.random_force_prob.zero_()
+    nt["rb_forces_object"].zero_(); ref.rb_forces.zero_()
+    a = (torch.rand((n, 16), generator=g) * 2 - 1).to(DEV)
+    keep = (ref.reset_buf == 0) & (ref.reset_goal_buf == 0)
+    r_obs, r_rew, r_reset, _ = ref.step(a.clone())
+    n_obs, n_rew, n_reset, _ = nat.step(a.clone())
+    assert int(keep.sum()) > n // 2
+    d = (r_obs["obs"] - n_obs["obs"]).abs()[keep]
+    force_cols = np.r_[32:48]
+    kin_cols = np.setdiff1d(np.arange(88), force_cols)
+    assert float(d[:, kin_cols].max()) < 2e-4, float(d[:, kin_cols].max())
+    assert float(d[:, force_cols].max()) < 2e-3 * max(1.0, float(r_obs["obs"][:, force_cols].abs().max()))
+    assert float((r_rew - n_rew).abs()[keep].max()) < 2e-3 * max(1.0, float(r_rew.abs().max()))
+    assert torch.equal(r_reset[keep], n_reset[keep])
+
