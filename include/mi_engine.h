@@ -236,6 +236,17 @@ int mi_engine_simulate(MiEngine* e, void* stream);
  * of every body of the articulation from the current root / dof state (gym.acquire_rigid_body_state_tensor, shadow_hand.py:150-175).
  * On demand only: step / simulate never touch the tensor. */
 int mi_engine_refresh_rigid_body_states(MiEngine* e, void* stream);
+/* gym.refresh_jacobian_tensors / gym.refresh_mass_matrix_tensors (franka_cube_stack.py:388-392,551-552; read by the operational-space
+ * controller of :595-612) into CALLER tensors on the engine's device, row-major like the simulator's.  nv = num_dofs for a fixed base,
+ * 6 + num_dofs otherwise; generalised velocity = [root linear velocity of the root frame's origin, root angular velocity (world frame;
+ * floating bases only)] ++ dof velocities.
+ *   jacobians     out [num_envs][num_bodies][6][nv]: rows 0-2 linear velocity of the body frame's origin, 3-5 angular velocity (world) per
+ *                 unit generalised velocity -- J qd equals the velocity block of mi_engine_refresh_rigid_body_states.  (The simulator drops
+ *                 the base link of a fixed-base actor: its tensor is out[:, 1:].)
+ *   mass matrices out [num_envs][nv][nv]: the joint-space inertia the sub-step factors, joint armatures on the diagonal.
+ * On demand only, from the current root / dof state. */
+int mi_engine_compute_jacobians(MiEngine* e, float* out, void* stream);
+int mi_engine_compute_mass_matrices(MiEngine* e, float* out, void* stream);
 /* AnymalTerrain only: the terrain the reference builds with `Terrain(cfg["env"]["terrain"], num_envs)` and hands to
  * gym.add_triangle_mesh (anymal_terrain.py:203-215).  height_samples: DEVICE int16 [rows*cols] (Terrain.heightsamples,
  * row-major), env_origins: DEVICE fp32 [num_levels*num_terrains*3] (Terrain.env_origins).  Both stay owned by the

@@ -823,6 +823,54 @@ struct Sim {
         rot2quat(Rb, o + 3);
     }
 
+    // ---------------------------------------------------------------- Jacobian of ONE body, joint-space inertia matrix
+    // gym.acquire_jacobian_tensor / acquire_mass_matrix_tensor (reference franka_cube_stack.py:388-392, the operational-space controller
+    // of :595-612 reads them every step).  Generalised velocity: [root linear velocity (of the root frame's origin), root angular velocity,
+    // both world frame -- floating bases only] ++ qd, NV entries.
+    // J[6][NV], row-major: rows 0-2 the linear velocity of body b's frame origin, rows 3-5 its angular velocity (world frame) per unit of
+    // each generalised velocity: column c is body_state's velocity block at the c-th unit velocity, so J qd == the velocities
+    // gym.refresh_rigid_body_state_tensor reports, by construction.
+    template <int b>
+    MI_HD void body_jacobian(float* J) const {
+        Sim s = *this;
+        sfor<6>([&](auto K) MI_LAMBDA { s.root[7 + K] = 0.f; });
+        sfor<ND>([&](auto D) MI_LAMBDA { s.qd[D] = 0.f; });
+        sfor<NV>([&](auto C_) MI_LAMBDA {
+            constexpr int c = C_;
+            constexpr bool moves = (c < OFF) || on_chain(M::dof_body[c < OFF ? 0 : c - OFF], b);
+            if constexpr (!moves) {
+                sfor<6>([&](auto K) MI_LAMBDA { J[K * NV + c] = 0.f; });
+            } else {
+                if constexpr (c < OFF) s.root[7 + c] = 1.f; else s.qd[c - OFF] = 1.f;
+                float o[13];
+                s.template body_state<b>(o);
+                sfor<3>([&](auto K) MI_LAMBDA { J[K * NV + c] = o[7 + K]; J[(3 + K) * NV + c] = o[10 + K]; });
+                if constexpr (c < OFF) s.root[7 + c] = 0.f; else s.qd[c - OFF] = 0.f;
+            }
+        });
+    }
+    // H[NV][NV], row-major, symmetric: the composite-rigid-body inertia the sub-step factors (tree pass), joint armatures on the diagonal
+    // (asset_options.use_physx_armature / dof_props['armature'], shadow_hand.py:243, allegro_hand.py:263)
+    MI_HD void mass_matrix(const SimParams& P, float* H) {
+        Ctx c;
+        SpI Iroot;
+        float Froot[6];
+        float pose[12 * (NOSB > 0 ? NOSB : 1)];      // manipulators: the tree pass hands the poses of the sphere-carrying bodies on (unused here)
+        c.pose_out = pose;
+        c.pose_stride = 1;
+        this->template body_pass<0>(P, c, nullptr, nullptr, nullptr, nullptr, Iroot, Froot);
+        sfor<NV * NV>([&](auto K) MI_LAMBDA { H[K] = 0.f; });
+        sfor<NV>([&](auto I_) MI_LAMBDA {
+            constexpr int i = I_;
+            H[i * NV + i] = c.L[M::midx[i][i]] + (i >= OFF ? M::dof_armature[i >= OFF ? i - OFF : 0] : 0.f);
+            sfor<M::nanc[i]>([&](auto A_) MI_LAMBDA {
+                constexpr int j = M::anc[i][A_];
+                H[i * NV + j] = c.L[M::midx[i][j]];
+                H[j * NV + i] = c.L[M::midx[i][j]];
+            });
+        });
+    }
+
     // ---------------------------------------------------------------- one physics sub-step of length h
     // gnd: ground policy; mu_env >= 0 replaces the per-sphere model friction (per-env friction buckets of
     // anymal_terrain.py:236-239,279-281); netf: per-body net contact force [3*NB] (world, this sub-step), written only on

@@ -690,6 +690,41 @@ extern "C" int mi_engine_refresh_rigid_body_states(MiEngine* e, void*) {
     }
     return 0;
 }
+// gym.refresh_jacobian_tensors / refresh_mass_matrix_tensors into caller tensors (csrc/kernels_body_states.hip on the device)
+template <class M>
+static void kinematics_views_all(MiEngine* e, float* out_j, float* out_h) {
+    const View& v = e->v;
+    const int N = v.N;
+    constexpr int NV = M::NV;
+#pragma omp parallel for schedule(static)
+    for (int en = 0; en < N; ++en) {
+        Sim<M> sim;
+        load_env(sim, v, en);
+        if (out_j) {
+            sfor<M::NB>([&](auto B_) {
+                constexpr int b = decltype(B_)::value;
+                sim.template body_jacobian<b>(out_j + ((size_t)en * M::NB + b) * 6 * NV);
+            });
+        }
+        if (out_h) sim.mass_matrix(e->P, out_h + (size_t)en * NV * NV);
+    }
+}
+static int kinematics_views(MiEngine* e, float* out_j, float* out_h, const char* who) {
+    if (!e || (!out_j && !out_h)) return fail(std::string(who) + ": null argument");
+    switch (e->task) {
+        case T_CARTPOLE: kinematics_views_all<ModelCartpole>(e, out_j, out_h); break;
+        case T_ANT: kinematics_views_all<ModelAnt>(e, out_j, out_h); break;
+        case T_HUMANOID: kinematics_views_all<ModelHumanoid>(e, out_j, out_h); break;
+        case T_QUADCOPTER: kinematics_views_all<ModelQuadcopter>(e, out_j, out_h); break;
+        case T_INGENUITY: kinematics_views_all<ModelIngenuity>(e, out_j, out_h); break;
+        case T_BALLBALANCE: kinematics_views_all<ModelBalanceBot>(e, out_j, out_h); break;
+        default: return fail(std::string(who) + ": task not on the CPU backend");
+    }
+    return 0;
+}
+extern "C" int mi_engine_compute_jacobians(MiEngine* e, float* out, void*) { return kinematics_views(e, out, nullptr, "mi_engine_compute_jacobians"); }
+extern "C" int mi_engine_compute_mass_matrices(MiEngine* e, float* out, void*) { return kinematics_views(e, nullptr, out, "mi_engine_compute_mass_matrices"); }
+
 template <class M, bool HUM>
 static void reset_loco(MiEngine* e, const int64_t* ids, int n) {
     using T = Loco<M::ND, 6 * M::NSENS, HUM>;

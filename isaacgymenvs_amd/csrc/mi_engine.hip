@@ -651,6 +651,20 @@ extern "C" int mi_engine_refresh_rigid_body_states(MiEngine* e, void* stream) {
     return 0;
 }
 
+namespace mi { hipError_t launch_kinematics_views(int task, const View& v, const SimParams& P, float* out_j, float* out_h, hipStream_t s); }
+extern "C" int mi_engine_compute_jacobians(MiEngine* e, float* out, void* stream) {
+    if (!e || !out) return fail("mi_engine_compute_jacobians: null argument");
+    if (int rc = check_device(e, "mi_engine_compute_jacobians")) return rc;
+    HIP_OK(launch_kinematics_views(e->task, e->v, e->P, out, nullptr, (hipStream_t)stream));
+    return 0;
+}
+extern "C" int mi_engine_compute_mass_matrices(MiEngine* e, float* out, void* stream) {
+    if (!e || !out) return fail("mi_engine_compute_mass_matrices: null argument");
+    if (int rc = check_device(e, "mi_engine_compute_mass_matrices")) return rc;
+    HIP_OK(launch_kinematics_views(e->task, e->v, e->P, nullptr, out, (hipStream_t)stream));
+    return 0;
+}
+
 extern "C" int mi_engine_reset_idx(MiEngine* e, const int64_t* env_ids, int n, void* stream) {
     if (!e) return fail("null engine");
     if (n <= 0) return 0;

@@ -168,7 +168,7 @@ class MiTensorDesc(C.Structure):
 # every symbol include/mi_engine.h declares (checked by tests/test_abi.py)
 EXPORTS = ["mi_abi_version", "mi_task_info", "mi_engine_arena_bytes", "mi_engine_create", "mi_engine_init_state",
            "mi_engine_destroy", "mi_engine_num_tensors", "mi_engine_tensor_desc", "mi_engine_step",
-           "mi_engine_reset_idx", "mi_engine_simulate", "mi_engine_refresh_rigid_body_states", "mi_engine_set_option", "mi_engine_get_option", "mi_engine_set_noise", "mi_engine_last_ring", "mi_engine_set_terrain",
+           "mi_engine_reset_idx", "mi_engine_simulate", "mi_engine_refresh_rigid_body_states", "mi_engine_compute_jacobians", "mi_engine_compute_mass_matrices", "mi_engine_set_option", "mi_engine_get_option", "mi_engine_set_noise", "mi_engine_last_ring", "mi_engine_set_terrain",
            "mi_compute_locomotion_observations", "mi_compute_locomotion_reward", "mi_compute_cartpole_reward",
            "mi_compute_hand_reward", "mi_compute_hand_full_state", "mi_randomize_rotation",
            "mi_compute_anymal_observations", "mi_compute_anymal_reward", "mi_compute_quadcopter_reward",
@@ -349,6 +349,8 @@ def _bind_lifecycle(L):
     L.mi_engine_reset_idx.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.mi_engine_simulate.argtypes = [C.c_void_p, C.c_void_p]
     L.mi_engine_refresh_rigid_body_states.argtypes = [C.c_void_p, C.c_void_p]
+    L.mi_engine_compute_jacobians.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mi_engine_compute_mass_matrices.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.mi_engine_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
     L.mi_engine_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
     L.mi_engine_set_noise.argtypes = [C.c_void_p, C.c_int, C.POINTER(MiNoiseParams)]
@@ -578,6 +580,31 @@ class Engine:
     def refresh_rigid_body_states(self):
         """gym.refresh_rigid_body_state_tensor: fills tensors["rigid_body_state"] [N, num_bodies, 13] from the current root / dof state"""
         check(self.L.mi_engine_refresh_rigid_body_states(self.h, self._stream()), self.L)
+
+    def _nv(self):
+        info = task_info(self.task)
+        return info.num_bodies, info.num_dofs + (0 if info.fixed_base else 6)
+
+    def compute_jacobians(self, out=None):
+        """gym.refresh_jacobian_tensors: [N, num_bodies, 6, nv] (rows: linear, angular velocity of the body origin, world frame; nv = 6 base +
+        dofs for a floating base) -- include/mi_engine.h mi_engine_compute_jacobians.  `out`: a contiguous fp32 tensor to fill."""
+        import torch
+        nb, nv = self._nv()
+        if out is None:
+            out = torch.empty((self.N, nb, 6, nv), dtype=torch.float32, device=self.device)
+        assert out.is_contiguous() and out.dtype == torch.float32 and out.numel() == self.N * nb * 6 * nv
+        check(self.L.mi_engine_compute_jacobians(self.h, out.data_ptr(), self._stream()), self.L)
+        return out
+
+    def compute_mass_matrices(self, out=None):
+        """gym.refresh_mass_matrix_tensors: [N, nv, nv] joint-space inertia (armatures on the diagonal)"""
+        import torch
+        _, nv = self._nv()
+        if out is None:
+            out = torch.empty((self.N, nv, nv), dtype=torch.float32, device=self.device)
+        assert out.is_contiguous() and out.dtype == torch.float32 and out.numel() == self.N * nv * nv
+        check(self.L.mi_engine_compute_mass_matrices(self.h, out.data_ptr(), self._stream()), self.L)
+        return out
 
     def reset_idx(self, env_ids):
         if env_ids.numel():

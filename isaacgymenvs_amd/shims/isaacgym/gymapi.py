@@ -580,6 +580,39 @@ class Gym:
         self.refresh_rigid_body_state_tensor(sim)
         return sim.bufs["rb"]
 
+    # Jacobians / mass matrices of the articulated actor (franka_cube_stack.py:388-392: acquire once, refresh every step, :551-552).  The
+    # simulator's layout: [num_envs, links, 6, dofs] with the base link left out and no base columns for a fixed-base actor, all links and
+    # 6 leading base columns for a floating one; mass matrix [num_envs, dofs (+ 6), dofs (+ 6)].
+    def acquire_jacobian_tensor(self, sim, actor_name=None):
+        self.refresh_jacobian_tensors(sim)
+        return sim.bufs["jacobian"]
+
+    def refresh_jacobian_tensors(self, sim):
+        if sim.engine is None:
+            raise RuntimeError("gym.acquire_jacobian_tensor: call gym.prepare_sim first")
+        full = sim.engine.compute_jacobians()
+        view = full[:, 1:] if sim.asset.spec.fixed_base else full
+        buf = sim.bufs.get("jacobian")
+        if buf is None:
+            sim.bufs["jacobian"] = view.contiguous()
+        else:
+            buf.copy_(view)
+        return True
+
+    def acquire_mass_matrix_tensor(self, sim, actor_name=None):
+        self.refresh_mass_matrix_tensors(sim)
+        return sim.bufs["mass_matrix"]
+
+    def refresh_mass_matrix_tensors(self, sim):
+        if sim.engine is None:
+            raise RuntimeError("gym.acquire_mass_matrix_tensor: call gym.prepare_sim first")
+        buf = sim.bufs.get("mass_matrix")
+        if buf is None:
+            sim.bufs["mass_matrix"] = sim.engine.compute_mass_matrices()
+        else:
+            sim.engine.compute_mass_matrices(buf)
+        return True
+
     def refresh_actor_root_state_tensor(self, sim):
         n, A = len(sim.envs), sim.nactors
         v = self._buf(sim, "root", (n * A, 13)).view(n, A, 13)

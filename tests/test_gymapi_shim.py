@@ -312,3 +312,31 @@ def test_reference_allegro_hand_runs_on_the_engine_and_matches_the_fused_kernels
     assert float((r_rew - n_rew).abs()[keep].max()) < 2e-3 * max(1.0, float(r_rew.abs().max()))
     assert torch.equal(r_reset[keep], n_reset[keep])
 
+
+def test_jacobian_and_mass_matrix_tensors_have_the_simulator_layouts(reference_tasks):
+    """gym.acquire_jacobian_tensor / acquire_mass_matrix_tensor + refresh_jacobian_tensors / refresh_mass_matrix_tensors
+    (franka_cube_stack.py:388-392,551-552) on the unmodified reference cart-pole and Ant: a fixed-base actor loses its base link's row and has
+    no base columns ([N, 2, 6, 2]), a floating one keeps all links and gets six leading base columns ([N, 9, 6, 14])."""
+    mods, vt = reference_tasks
+    vt.EXISTING_SIM = None
+    env = mods["cartpole"].Cartpole(_ref_cfg("Cartpole", 5), rl_device=DEV, sim_device=DEV, graphics_device_id=-1, headless=True,
+                                    virtual_screen_capture=False, force_render=False)
+    J = env.gym.acquire_jacobian_tensor(env.sim, "cartpole")
+    H = env.gym.acquire_mass_matrix_tensor(env.sim, "cartpole")
+    assert tuple(J.shape) == (5, 2, 6, 2) and tuple(H.shape) == (5, 2, 2)
+    env.step(torch.ones((5, 1), device=DEV))
+    J0, H0 = J.clone(), H.clone()
+    J.zero_(); H.zero_()
+    env.gym.refresh_jacobian_tensors(env.sim); env.gym.refresh_mass_matrix_tensors(env.sim)
+    assert torch.equal(J0, J) and float(J.abs().max()) == 1.0     # the acquired tensors are the ones the refresh calls fill (the cart-pole's
+    assert float((H - H0).abs().max()) > 0                       # Jacobian does not depend on its state, its mass matrix does)
+    Jc = J.cpu()
+    np.testing.assert_allclose(Jc[:, 0, 0:3, 0].abs().sum(dim=1).numpy(), 1.0, atol=1e-6)   # the cart slides along the rail's axis
+    np.testing.assert_allclose(Jc[:, 0, :, 1].numpy(), 0.0, atol=1e-7)                       # and does not move with the pole's hinge
+    assert float(H.cpu()[:, 0, 0].min()) > 0
+    vt.EXISTING_SIM = None
+    ant = mods["ant"].Ant(_ref_cfg("Ant", 4), rl_device=DEV, sim_device=DEV, graphics_device_id=-1, headless=True,
+                          virtual_screen_capture=False, force_render=False)
+    assert tuple(ant.gym.acquire_jacobian_tensor(ant.sim, "ant").shape) == (4, 9, 6, 14)
+    assert tuple(ant.gym.acquire_mass_matrix_tensor(ant.sim, "ant").shape) == (4, 14, 14)
+
