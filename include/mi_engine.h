@@ -260,11 +260,16 @@ int mi_engine_set_terrain(MiEngine* e, const int16_t* height_samples, int rows, 
  * default 1 for the tasks whose arena carries "self_contact_impulse", rejected with 1 elsewhere),
  * "multi_wave" 0 | 32 (physics sub-step of Ant / Anymal / AnymalTerrain spread over the four waves of a workgroup of that many
  * envs -- same results up to summation order, see csrc/core/engine_mw.hpp; other tasks ignore it),
+ * "fused_post" 0 | 1 (Ant on the limb-per-wave form: post_physics_step inside the step's last sub-step launch; same buffers),
+ * "fused_sub" 0 | 1 (Ant / AnymalTerrain on the limb-per-wave form: all physics sub-steps of a control step -- vec_task.py:379-382,
+ * anymal_terrain.py:443-451 -- in one launch, the state staying on chip between them; same buffers; HIP backend only),
  * "steps" (the control-step counter: observation-ring parity and per-step RNG counters; restore it together with the arena),
  * "actor_tensors" 0 | 1 (Ant, Humanoid: whether the sub-step reads the per-env `actor_scale` / `dof_limit_shift` tensors of the
  * `actor_params` domain randomisation, vec_task.py:752-828; default 0 = the model's constants, no loads; ShadowHand always reads its own),
  * "terrain_slope_threshold" (AnymalTerrain: terrain.slopeTreshold of the reference's height-field -> triangle-mesh conversion,
- * anymal_terrain.py:576; steeper cell edges are levelled to their lower end in the ground query; 0 = off) */
+ * anymal_terrain.py:576; steeper cell edges are levelled to their lower end in the ground query; 0 = off),
+ * "terrain_walls" 0 | 1 (AnymalTerrain, default 1: the vertical faces that the slope correction gives the triangle mesh of
+ * gym.add_triangle_mesh, anymal_terrain.py:198-211, collide from the side -- csrc/core/engine.hpp HeightfieldGround::contact) */
 int mi_engine_set_option(MiEngine* e, const char* key, double value);
 /* Observation (which = 0) / action (which = 1) noise of the domain randomisation, applied inside the step kernels (replaces the
  * `noise_lambda` closures the reference builds in VecTask.apply_randomizations, vec_task.py:650-718, and runs as torch ops on the

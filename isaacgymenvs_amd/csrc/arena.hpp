@@ -14,6 +14,7 @@ struct View {
     int mw;    // multi-wave sub-step: envs per workgroup (16 or 32), 0 = one wave per workgroup (option "multi_wave")
     int nas;   // columns of actor_scale (NB + 3 ND), 0: the task has none
     int fused_post;   // limb-per-wave locomotion (Ant): post_physics_step inside the last sub-step launch instead of a kernel of its own (option "fused_post", default 0; the Python layer switches it on for small batches)
+    int fused_sub;    // limb-per-wave sub-steps (Ant, ANYmal on the terrain): all sub-steps of a control step in ONE launch, the state staying in registers / LDS between them (option "fused_sub", default 0; mw_kernels.hpp)
     float clip_obs;
     unsigned step;      // control-step counter of this step() (white-noise stream of the in-kernel observation / action noise)
     NoiseParams obs_noise, act_noise;   // domain randomisation noise on observations / actions (dist 0: off), mi_engine_set_noise

@@ -194,7 +194,8 @@ MI_HD void spi_mul(const SpI& I, const float* X, float* F) {
 // edge steeper than the threshold slides under the upper one, so a stair riser becomes a vertical wall at the upper vertex and
 // the lower tread reaches up to it) is applied per query: every edge of the cell that rises by more than `thr` raw height units
 // is levelled to its lower end before the cell's two triangles are evaluated -- within 1 mm of the corrected mesh on 97 % of
-// the AnymalTerrain map (88 % without; oracle/terrain_mesh.py, tests/test_terrain.py), no wall contact from the side.
+// the AnymalTerrain map (88 % without; oracle/terrain_mesh.py, tests/test_terrain.py).  The walls themselves collide through
+// contact(): a sphere inside a steep cell, below the wall's top, takes the wall as its contact when that is the nearer surface.
 // Optional extras of a sub-step (nullptr = none: every call site that passes nullptr compiles to exactly the code it had
 // before this existed, the branches below fold away after inlining).
 struct Drive {
@@ -221,19 +222,24 @@ struct HeightfieldGround {
     int rows, cols;
     float hscale, vscale, border;
     float thr = 3.0e38f;   // slope_threshold * hscale / vscale (raw height units per cell), huge = no correction
-    // height z and unit normal n of the surface under world (x, y); same arithmetic as oracle/physics.c ground_query
-    MI_HD void query(float x, float y, float* z, float* n) const {
+    int walls = 1;         // with the correction on: the risers it creates collide from the side (contact()); 0: the surface below only
+    // the cell under world (x, y): position inside it and its four raw corner heights h00, h10, h01, h11
+    MI_HD void locate(float x, float y, float* fx, float* fy, float* h) const {
         const float gx = (x + border) / hscale, gy = (y + border) / hscale;
         int i = (int)floorf(gx), j = (int)floorf(gy);
         i = i < 0 ? 0 : (i > rows - 2 ? rows - 2 : i);
         j = j < 0 ? 0 : (j > cols - 2 ? cols - 2 : j);
-        const float fx = fminf(fmaxf(gx - (float)i, 0.f), 1.f), fy = fminf(fmaxf(gy - (float)j, 0.f), 1.f);
-        float h00 = (float)hs[i * cols + j], h10 = (float)hs[(i + 1) * cols + j], h01 = (float)hs[i * cols + j + 1],
-              h11 = (float)hs[(i + 1) * cols + j + 1];
+        *fx = fminf(fmaxf(gx - (float)i, 0.f), 1.f); *fy = fminf(fmaxf(gy - (float)j, 0.f), 1.f);
+        h[0] = (float)hs[i * cols + j]; h[1] = (float)hs[(i + 1) * cols + j]; h[2] = (float)hs[i * cols + j + 1]; h[3] = (float)hs[(i + 1) * cols + j + 1];
+    }
+    // surface of the cell: height and unit normal at (fx, fy); hx: the corner heights after the x edges have been levelled
+    MI_HD void surface(const float* h, float fx, float fy, float* z, float* n, float* hx) const {
+        float h00 = h[0], h10 = h[1], h01 = h[2], h11 = h[3];
         {   // risers: x edges first, then y edges (on the levelled values)
             const float m0 = fminf(h00, h10), m1 = fminf(h01, h11);
             const bool s0 = fabsf(h10 - h00) > thr, s1 = fabsf(h11 - h01) > thr;
             h00 = s0 ? m0 : h00; h10 = s0 ? m0 : h10; h01 = s1 ? m1 : h01; h11 = s1 ? m1 : h11;
+            hx[0] = h00; hx[1] = h10; hx[2] = h01; hx[3] = h11;
             const float m2 = fminf(h00, h01), m3 = fminf(h10, h11);
             const bool s2 = fabsf(h01 - h00) > thr, s3 = fabsf(h11 - h10) > thr;
             h00 = s2 ? m2 : h00; h01 = s2 ? m2 : h01; h10 = s3 ? m3 : h10; h11 = s3 ? m3 : h11;
@@ -244,6 +250,55 @@ struct HeightfieldGround {
         const float sx = dzx * vscale / hscale, sy = dzy * vscale / hscale;
         const float inv = 1.f / sqrtf(sx * sx + sy * sy + 1.f);
         n[0] = -sx * inv; n[1] = -sy * inv; n[2] = inv;
+    }
+    // height z and unit normal n of the surface under world (x, y); same arithmetic as oracle/physics.c ground_query
+    MI_HD void query(float x, float y, float* z, float* n) const {
+        float fx, fy, h[4], hx[4];
+        locate(x, y, &fx, &fy, h);
+        surface(h, fx, fy, z, n, hx);
+    }
+    // Contact of a sphere (centre (x, y, z), radius r <= hscale) with the terrain: distance and unit normal of the NEARER of the tangent
+    // plane of the surface below the centre and the wall of a riser in the centre's cell (both x edges, or both y edges, of the cell rise
+    // by more than thr in the same direction: floor at the lower level, a vertical wall on the boundary of the higher vertices; a candidate
+    // -- its face below the wall's top, the top's edge above it); inside both, one contact along the summed penetration vectors.  Statement and reasoning:
+    // oracle/physics.c ground_contact (same arithmetic, branch-free here).
+    MI_HD void contact(float x, float y, float z, float r, float* dist, float* n) const {
+        float fx, fy, h[4], hx[4], zt;
+        locate(x, y, &fx, &fy, h);
+        surface(h, fx, fy, &zt, n, hx);
+        float d = (z - zt) * n[2] - r;
+        const bool won = walls != 0;
+        float dw = 1e30f, nwx = 0.f, nwy = 0.f, nwz = 0.f;     // the nearer wall candidate: the wall's face, above its top the top's edge
+        {   // x walls, raw heights
+            const bool s0 = fabsf(h[1] - h[0]) > thr, s1 = fabsf(h[3] - h[2]) > thr, up0 = h[1] > h[0], up1 = h[3] > h[2];
+            const float t0 = up0 ? h[1] : h[0], t1 = up1 ? h[3] : h[2];
+            const float top = (t0 + (t1 - t0) * fy) * vscale;
+            const float dx = (up0 ? 1.f - fx : fx) * hscale, dz = fmaxf(z - top, 0.f);
+            const float len = sqrtf(dx * dx + dz * dz), il = 1.f / fmaxf(len, 1e-12f);
+            const bool use = won && s0 && s1 && (up0 == up1) && (len - r < dw);
+            dw = use ? len - r : dw;
+            nwx = use ? (up0 ? -dx : dx) * il : nwx; nwz = use ? dz * il : nwz;
+        }
+        {   // y walls, x-levelled heights
+            const bool s2 = fabsf(hx[2] - hx[0]) > thr, s3 = fabsf(hx[3] - hx[1]) > thr, up0 = hx[2] > hx[0], up1 = hx[3] > hx[1];
+            const float t0 = up0 ? hx[2] : hx[0], t1 = up1 ? hx[3] : hx[1];
+            const float top = (t0 + (t1 - t0) * fx) * vscale;
+            const float dy = (up0 ? 1.f - fy : fy) * hscale, dz = fmaxf(z - top, 0.f);
+            const float len = sqrtf(dy * dy + dz * dz), il = 1.f / fmaxf(len, 1e-12f);
+            const bool use = won && s2 && s3 && (up0 == up1) && (len - r < dw);
+            dw = use ? len - r : dw;
+            nwx = use ? 0.f : nwx; nwy = use ? (up0 ? -dy : dy) * il : nwy; nwz = use ? dz * il : nwz;
+        }
+        // inside both the surface below and a wall: one contact along the summed penetrations; else the nearer of the two
+        const bool both = (d < 0.f) && (dw < 0.f), wall = !both && (dw < d);
+        const float vx = -d * n[0] - dw * nwx, vy = -d * n[1] - dw * nwy, vz = -d * n[2] - dw * nwz;
+        const float L = sqrtf(vx * vx + vy * vy + vz * vz);
+        const float iL = 1.f / (both ? L : 1.f);
+        n[0] = both ? vx * iL : (wall ? nwx : n[0]);
+        n[1] = both ? vy * iL : (wall ? nwy : n[1]);
+        n[2] = both ? vz * iL : (wall ? nwz : n[2]);
+        d = both ? -L : (wall ? dw : d);
+        *dist = d;
     }
 };
 // contact frame: n, t1 = normalize(x - n (n.x)), t2 = n x t1   (n = z gives t1 = x, t2 = y)
@@ -1139,10 +1194,8 @@ struct Sim {
             float xc[3], dist;
             float fr[3][3];  // contact frame n, t1, t2 (height field only)
             if constexpr (GND::HEIGHTFIELD) {
-                float zt;
-                gnd.query(root[0] + cs[0], root[1] + cs[1], &zt, fr[0]);
+                gnd.contact(root[0] + cs[0], root[1] + cs[1], root[2] + cs[2], M::sph_rad[s], &dist, fr[0]);  // distance to the local tangent plane (or a riser's wall)
                 contact_frame(fr[0], fr[1], fr[2]);
-                dist = ((root[2] + cs[2]) - zt) * fr[0][2] - M::sph_rad[s];  // distance to the local tangent plane
                 sfor<3>([&](auto K) MI_LAMBDA { xc[K] = cs[K] - M::sph_rad[s] * fr[0][K]; });
             } else {
                 xc[0] = cs[0]; xc[1] = cs[1]; xc[2] = cs[2] - M::sph_rad[s];
@@ -1209,10 +1262,8 @@ struct Sim {
             float xc[3], dist;
             float fr[3][3];
             if constexpr (GND::HEIGHTFIELD) {
-                float zt;
-                gnd.query(root[0] + cs[0], root[1] + cs[1], &zt, fr[0]);
+                gnd.contact(root[0] + cs[0], root[1] + cs[1], root[2] + cs[2], M::sph_rad[s], &dist, fr[0]);
                 contact_frame(fr[0], fr[1], fr[2]);
-                dist = ((root[2] + cs[2]) - zt) * fr[0][2] - M::sph_rad[s];
                 sfor<3>([&](auto K) MI_LAMBDA { xc[K] = cs[K] - M::sph_rad[s] * fr[0][K]; });
             } else {
                 xc[0] = cs[0]; xc[1] = cs[1]; xc[2] = cs[2] - M::sph_rad[s];
@@ -1763,8 +1814,8 @@ struct Sim {
                     n[0] = vt(row0 + 1); n[1] = vt(row0 + 2);
                     n[2] = MI_SQRT(fmaxf(1.f - n[0] * n[0] - n[1] * n[1], 0.f));
                 } else {
-                    float zt;
-                    gnd.query(root[0] + c.xcs[s][0], root[1] + c.xcs[s][1], &zt, n);
+                    float dd;
+                    gnd.contact(root[0] + c.xcs[s][0], root[1] + c.xcs[s][1], root[2] + c.xcs[s][2], M::sph_rad[s], &dd, n);
                 }
                 contact_frame(n, t1, t2);
                 sfor<3>([&](auto K) MI_LAMBDA {

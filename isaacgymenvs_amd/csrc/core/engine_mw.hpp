@@ -115,10 +115,14 @@ struct SimMW : Sim<M> {
 
     // ------------------------------------------------------------------------------------------------ one role of a sub-step
     // tau: efforts of all dofs.  BAR: callable workgroup barrier (device: __syncthreads; host tests: a thread barrier).
-    template <int R, int RS, class GND, class BAR>
+    // stage: where last sub-step's impulses of the own rows are -- 0: in lamc / laml (read here), 1: on their way into the row store (LDS-direct
+    // loads issued by the caller), 2: already IN the row store, left there by the previous sub-step of the same launch (KEEP).
+    // KEEP: leave the signed limit impulses in the row store for a following sub-step of the same launch (mw_kernels.hpp, fused sub-steps);
+    // the contact impulses are there anyway.
+    template <int R, bool KEEP = false, int RS, class GND, class BAR>
     MI_HD void substep_role(const SimParams& P, const float* tau, const float h, const RowStore<RS> rows, const Strided lamc,
                             const Strided laml, const Strided sensor, const Strided dof_force, const GND& gnd, const float mu_env,
-                            const Strided netf, const bool prestaged, const BAR& bar) {
+                            const Strided netf, const int stage, const BAR& bar) {
         static_assert(!M::FIXED, "multi-wave sub-step: free-base models");
         auto G = [&](int row, int cc) MI_LAMBDA -> float& { return rows(row * M::MAXCHAIN + cc); };
         auto Ainv = [&](int row) MI_LAMBDA -> float& { return rows(NROWG * M::MAXCHAIN + row); };
@@ -132,7 +136,7 @@ struct SimMW : Sim<M> {
         float (&S)[M::NDA][6] = c.S;
         float (&L)[M::NM] = c.L;
         // ============================================================ P1
-        if (!prestaged) {
+        if (stage == 0) {
             sfor<ND>([&](auto D) MI_LAMBDA {
                 constexpr int d = D;
                 if constexpr (M::dof_limited[d] && owns_gi<R>(OFF + d)) { constexpr int o = B::stage_slot_lim(d); rows(o) = laml(d); }
@@ -260,7 +264,7 @@ struct SimMW : Sim<M> {
             if constexpr (trunk_gi(gi)) { constexpr int ti = tidx(gi); dw[ti] += val; } else w[gi] += val;
         };
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (prestaged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (stage == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         auto chain_solve = [&](auto Bd, float* g) MI_LAMBDA {
             constexpr int b = decltype(Bd)::value;
@@ -323,10 +327,8 @@ struct SimMW : Sim<M> {
                 float xc[3], dist;
                 float fr[3][3];
                 if constexpr (GND::HEIGHTFIELD) {
-                    float zt;
-                    gnd.query(root[0] + cs[0], root[1] + cs[1], &zt, fr[0]);
+                    gnd.contact(root[0] + cs[0], root[1] + cs[1], root[2] + cs[2], M::sph_rad[s], &dist, fr[0]);
                     contact_frame(fr[0], fr[1], fr[2]);
-                    dist = ((root[2] + cs[2]) - zt) * fr[0][2] - M::sph_rad[s];
                     sfor<3>([&](auto K) MI_LAMBDA { xc[K] = cs[K] - M::sph_rad[s] * fr[0][K]; });
                 } else {
                     xc[0] = cs[0]; xc[1] = cs[1]; xc[2] = cs[2] - M::sph_rad[s];
@@ -526,6 +528,7 @@ struct SimMW : Sim<M> {
                     constexpr int row = B::limrow(d);
                     const float dl = q[d] - this->template limit_lower<d>(), du = this->template limit_upper<d>() - q[d];
                     ll = (dl < du) ? lam(row) : -lam(row);
+                    if constexpr (KEEP) lam(row) = ll;
                 }
                 laml(d) = ll;
                 dof_force(d) = tau[d] - M::dof_stiffness[d] * sc_stiff[d] * (q[d] - M::dof_springref[d]) - M::dof_damping[d] * sc_damp[d] * v[OFF + d] + ll * invh;

@@ -393,7 +393,7 @@ __global__ void anymal_reset_kernel(View v, AnymalParams p, AnymalTerrainDesc T,
 
 static HeightfieldGround ground_of(const AnymalTerrainDesc& T) {
     return HeightfieldGround{T.hs, T.rows, T.cols, T.hscale, T.vscale, T.border,
-                             T.slope_threshold > 0.f ? T.slope_threshold * T.hscale / T.vscale : 3.0e38f};
+                             T.slope_threshold > 0.f ? T.slope_threshold * T.hscale / T.vscale : 3.0e38f, T.walls};
 }
 static ActParams act_of(const AnymalParams& tp) {
     ActParams ap{};
@@ -411,11 +411,17 @@ hipError_t launch_step_anymal(const View& v, const SimParams& P, const AnymalPar
     const ActParams ap = act_of(tp);
     hipError_t e;
     if (T.hs != nullptr) {
-        e = launch_substeps<ModelAnymal, HeightfieldGround>(v, P, ap, actions, tp.decimation * P.substeps, ACT_FROM_ACTIONS,
-                                                            ACT_FROM_STORED_ACTIONS, s, ground_of(T));
-        if (e != hipSuccess) return e;
-        e = launch_substeps<ModelAnymal, HeightfieldGround>(v, P, ap, nullptr, cfi * P.substeps, ACT_STORED_TAU, ACT_STORED_TAU, s,
-                                                            ground_of(T));
+        if (v.mw != 0) {    // limb-per-wave form: one call (with option fused_sub: one LAUNCH) for the decimation steps + the base class's simulate()
+            e = launch_substeps_mw<ModelAnymal, HeightfieldGround>(v, P, ap, actions, (tp.decimation + cfi) * P.substeps,
+                                                                   prepare_actions(v, ap, actions, ACT_FROM_ACTIONS, s), ACT_FROM_STORED_ACTIONS, s,
+                                                                   ground_of(T), cfi * P.substeps);
+        } else {
+            e = launch_substeps<ModelAnymal, HeightfieldGround>(v, P, ap, actions, tp.decimation * P.substeps, ACT_FROM_ACTIONS,
+                                                                ACT_FROM_STORED_ACTIONS, s, ground_of(T));
+            if (e != hipSuccess) return e;
+            e = launch_substeps<ModelAnymal, HeightfieldGround>(v, P, ap, nullptr, cfi * P.substeps, ACT_STORED_TAU, ACT_STORED_TAU, s,
+                                                                ground_of(T));
+        }
     } else {
         return hipErrorInvalidValue;  // mi_engine_step refuses to run AnymalTerrain before mi_engine_set_terrain
     }

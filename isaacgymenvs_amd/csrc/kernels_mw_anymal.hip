@@ -4,5 +4,5 @@
 
 namespace mi {
 template hipError_t launch_substeps_mw<ModelAnymal, HeightfieldGround>(const View&, const SimParams&, const ActParams&, const float*, int, int, int,
-                                                                       hipStream_t, const HeightfieldGround&);
+                                                                       hipStream_t, const HeightfieldGround&, int);
 }  // namespace mi

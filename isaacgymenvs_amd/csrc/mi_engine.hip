@@ -341,6 +341,7 @@ extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const 
     e->task = t; e->N = num_envs; e->steps = 0; e->control_freq_inv = 1; e->clip_obs = INFINITY;
     memcpy(&e->P, sim, sizeof(SimParams));
     memset(&e->terrain, 0, sizeof(e->terrain));
+    e->terrain.walls = 1;
     e->max_init_level = 0;
     if (t == T_CARTPOLE) memcpy(&e->cart, task_params, sizeof(CartpoleParams));
     else if (t == T_ANYMAL) memcpy(&e->anymal, task_params, sizeof(AnymalParams));
@@ -364,6 +365,7 @@ extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const 
     Layout L;
     memset(&e->v, 0, sizeof(View));
     e->v.fused_post = 0;
+    e->v.fused_sub = 0;
     int nobs = 0;
     if (is_hand_task(t)) {
         const HandParams& hp = e->hand;
@@ -444,6 +446,7 @@ extern "C" int mi_engine_set_option(MiEngine* e, const char* key, double value) 
     // limb-per-wave locomotion (Ant): 1 = post_physics_step runs on one wave of every sub-step workgroup at the end of the step's last
     // sub-step launch (mw_kernels.hpp), 0 (default) = in loco_post_kernel as for the one-wave form
     if (!strcmp(key, "fused_post")) { e->v.fused_post = value != 0 ? 1 : 0; return 0; }
+    if (!strcmp(key, "fused_sub")) { e->v.fused_sub = value != 0 ? 1 : 0; return 0; }
     // control-step counter (observation ring parity, AnymalTerrain push schedule, noise counters): part of a state checkpoint
     if (!strcmp(key, "steps")) { if (value < 0) return fail("steps < 0"); e->steps = (unsigned long long)value; return 0; }
     if (!strcmp(key, "actor_tensors")) {   // 1: the sub-step reads actor_scale / dof_limit_shift (Ant, Humanoid); ShadowHand always reads its own
@@ -456,6 +459,11 @@ extern "C" int mi_engine_set_option(MiEngine* e, const char* key, double value) 
     if (!strcmp(key, "terrain_slope_threshold")) {   // terrain.slopeTreshold of the mesh generator (anymal_terrain.py:576); 0 = off
         if (e->task != T_ANYMAL) return fail("terrain_slope_threshold: only AnymalTerrain has a terrain");
         e->terrain.slope_threshold = (float)value;
+        return 0;
+    }
+    if (!strcmp(key, "terrain_walls")) {   // the vertical faces of the slope-corrected triangle mesh (anymal_terrain.py:198-211, :576) collide from the side
+        if (e->task != T_ANYMAL) return fail("terrain_walls: only AnymalTerrain has a terrain");
+        e->terrain.walls = value != 0 ? 1 : 0;
         return 0;
     }
     return fail(std::string("unknown option: ") + key);
@@ -480,8 +488,10 @@ extern "C" int mi_engine_get_option(const MiEngine* e, const char* key, double* 
     if (!strcmp(key, "self_collision")) { *out = e->v.lamp != nullptr ? 1.0 : 0.0; return 0; }
     if (!strcmp(key, "multi_wave")) { *out = e->v.mw; return 0; }
     if (!strcmp(key, "fused_post")) { *out = e->v.fused_post; return 0; }
+    if (!strcmp(key, "fused_sub")) { *out = e->v.fused_sub; return 0; }
     if (!strcmp(key, "steps")) { *out = (double)e->steps; return 0; }
     if (!strcmp(key, "terrain_slope_threshold")) { *out = e->terrain.slope_threshold; return 0; }
+    if (!strcmp(key, "terrain_walls")) { *out = e->terrain.walls; return 0; }
     if (!strcmp(key, "actor_tensors")) { *out = (is_hand_task(e->task) || e->v.actor_scale != nullptr) ? 1.0 : 0.0; return 0; }
     return fail(std::string("unknown option: ") + key);
 }

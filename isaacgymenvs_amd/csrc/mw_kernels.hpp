@@ -35,7 +35,6 @@ __device__ __forceinline__ void mw_role(const View& v, const SimParams& P, const
                 float a;
                 if (src == ACT_FROM_ACTIONS) {
                     a = actions_in[(size_t)e * ap.nact + k];
-                    if (v.act_noise.dist != 0) a = apply_noise(v.act_noise, v.seed, (uint32_t)(v.env_offset + e), v.step, 1u, (uint32_t)k, a);
                     a = fminf(fmaxf(a, -ap.clip), ap.clip);
                     if constexpr (mine) v.actions[k * N + e] = a;
                 } else {
@@ -109,22 +108,168 @@ __global__ __launch_bounds__(64 * M::NROLE) void substep_mw_kernel(View v, SimPa
     }
 }
 
+// ------------------------------------------------------------------------------------------------ all sub-steps of a step in ONE launch
+// Option "fused_sub": the n sub-steps of a control step run inside one launch of the limb-per-wave kernel.  Between two sub-steps nothing
+// goes through HBM: every role keeps its own q / qd (and the efforts, the clamped actions) in registers, last sub-step's impulses of its
+// own rows stay where the sweeps left them in the LDS row store (substep_role<R, KEEP>, stage 2), and the one thing the other roles need
+// -- the new root state, integrated by the trunk role -- crosses through 13 LDS slots behind the exchange area, with one barrier.  Same
+// arithmetic per sub-step as the one-launch-per-sub-step form (bit-identical state: tests/test_gpu_multi_wave.py); the per-launch costs
+// (dispatch, kernarg + state loads at HBM latency, the LDS-direct warm-start loads, the drain of the stores) are paid once per control step.
+// Efforts: sub-step 0 from `first`, the following ones from `rest`, the last `tail` from the efforts of the sub-step before them
+// (AnymalTerrain: `decimation` sim steps with the PD torques re-evaluated on the current joint state, then the base class's simulate()
+// with the last torques, anymal_terrain.py:443-451 + vec_task.py:379-382).
+// The loop around the unrolled dynamics is what round 1 had to give up on the one-wave kernel (LLVM hoisted hundreds of model literals
+// into SGPRs and spilled them, step_kernels.hpp); a role's body is a quarter of that, and native.build() still refuses SGPR spills.
+template <class GND>
+struct MwFusedArgs {
+    View v;
+    SimParams P;
+    ActParams ap;
+    const float* actions_in;
+    int first, rest, n_sub, tail;
+    GND gnd;
+};
+template <class M, int E>
+constexpr size_t mw_fused_lds_bytes() { return (size_t)(SimMW<M>::MW_SLOTS + 13) * E * sizeof(float); }
+template <class M, class GND, int E, int R>
+__device__ __forceinline__ void mw_role_fused(const MwFusedArgs<GND>& a, float* lds_rows, const int e, const int lane) {
+    using S = SimMW<M>;
+    constexpr int ND = M::ND;
+    const View& v = a.v;
+    const ActParams& ap = a.ap;
+    const int N = v.N;
+    S sim;
+    load_sim(sim, v, e);
+    load_actor_scales(sim, v, e);
+    {   // last step's impulses of the own rows: HBM -> row-store slots, LDS-direct (as in mw_role)
+        typedef const __attribute__((address_space(1))) void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        float* slot0 = lds_rows;
+        sfor<ND>([&](auto D) MI_LAMBDA {
+            constexpr int d = D;
+            if constexpr (M::dof_limited[d] && S::template owns_gi<R>(M::OFF + d)) {
+                constexpr int o = Sim<M>::stage_slot_lim(d) * E;
+                __builtin_amdgcn_global_load_lds((gptr_t)(v.laml + (size_t)d * N + e), (lptr_t)(slot0 + o), 4, 0, 0);
+            }
+        });
+        sfor<3 * M::NSPH>([&](auto K) MI_LAMBDA {
+            if constexpr (S::template owns_body<R>(M::sph_body[K / 3])) {
+                constexpr int o = Sim<M>::stage_slot_con(K) * E;
+                __builtin_amdgcn_global_load_lds((gptr_t)(v.lamc + (size_t)K * N + e), (lptr_t)(slot0 + o), 4, 0, 0);
+            }
+        });
+    }
+    const float h = a.P.dt / (float)a.P.substeps;
+    const Strided lamc{v.lamc + e, N}, laml{v.laml + e, N}, sensor{v.sensor + e, N}, dof_force{v.dof_force + e, N};
+    const Strided netf{GND::NETF ? v.netf + e : nullptr, N};
+    const float mu_env = (GND::HEIGHTFIELD || v.friction != nullptr) ? v.friction[e] : -1.f;
+    float* xroot = lds_rows + (size_t)S::MW_SLOTS * E + lane;     // [13][E] the new root state, trunk role -> the others
+    float tau[M::NDA], act[M::NDA];
+    sfor<ND>([&](auto K) MI_LAMBDA { tau[K] = 0.f; act[K] = 0.f; });
+    for (int i = 0; i < a.n_sub; ++i) {
+        const int src = (i >= a.n_sub - a.tail) ? (i == 0 ? (int)ACT_STORED_TAU : -1) : (i == 0 ? a.first : a.rest);   // -1: keep the efforts
+        if (src == ACT_STORED_TAU) {
+            if (i == 0) sfor<ND>([&](auto K) MI_LAMBDA { tau[K] = v.tau[K * N + e]; });
+        } else if (src > 0) {
+            // (only the efforts of the dofs this role sees matter to it; it stores the ones it owns)
+            sfor<ND>([&](auto K) MI_LAMBDA {
+                constexpr int k = K;
+                constexpr bool mine = S::template owns_gi<R>(M::OFF + k);
+                float t = 0.f;
+                if (k < ap.nact) {
+                    float x;
+                    if (src == ACT_FROM_ACTIONS) {
+                        x = a.actions_in[(size_t)e * ap.nact + k];
+                        x = fminf(fmaxf(x, -ap.clip), ap.clip);
+                        if constexpr (mine) v.actions[k * N + e] = x;
+                        act[k] = x;
+                    } else if (i == 0) {
+                        x = v.actions[k * N + e];
+                        act[k] = x;
+                    } else {
+                        x = act[k];
+                    }
+                    if (ap.mode == 0) {
+                        t = x * ap.gear[k] * ap.scale;
+                    } else {
+                        const float u = ap.kp * (ap.scale * x + ap.gear[k] - sim.q[k]) - ap.kd * sim.qd[k];
+                        t = fminf(fmaxf(u, -ap.torque_limit), ap.torque_limit);
+                    }
+                }
+                tau[k] = t;
+                if constexpr (mine) v.tau[k * N + e] = t;
+            });
+        }
+        sim.template substep_role<R, true>(a.P, tau, h, RowStore<E>{lds_rows + lane}, lamc, laml, sensor, dof_force, a.gnd, mu_env, netf,
+                                           i == 0 ? 1 : 2, DevBarrier{});
+        if (i + 1 < a.n_sub) {
+            if constexpr (R == M::TRUNK_ROLE) sfor<13>([&](auto K) MI_LAMBDA { xroot[K * E] = sim.root[K]; });
+            __syncthreads();
+            if constexpr (R != M::TRUNK_ROLE) sfor<13>([&](auto K) MI_LAMBDA { sim.root[K] = xroot[K * E]; });
+        }
+    }
+    sfor<ND>([&](auto K) MI_LAMBDA {
+        if constexpr (S::template owns_gi<R>(M::OFF + K)) {
+            v.dof[K * N + e] = sim.q[K];
+            v.dof[(ND + K) * N + e] = sim.qd[K];
+        }
+    });
+    if constexpr (R == M::TRUNK_ROLE) sfor<13>([&](auto K) MI_LAMBDA { v.root[K * N + e] = sim.root[K]; });
+}
+template <class M, class GND, int E>
+__global__ __launch_bounds__(64 * M::NROLE) void substep_mw_fused_kernel(MwFusedArgs<GND> args_by_value) {
+    extern __shared__ float lds_rows[];   // [MW_SLOTS + 13][E]
+    static_assert(M::NROLE == 4, "four roles, one per SIMD of a CU");
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)args_by_value;
+    const MwFusedArgs<GND>& a = *reinterpret_cast<const MwFusedArgs<GND>*>(__builtin_amdgcn_kernarg_segment_ptr());
+    const int lane = threadIdx.x;
+    if (lane >= E) return;
+    const int e = xcd_env_base<E>(blockIdx.x) + lane;
+    if (e >= a.v.N) return;
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    switch (role) {
+        case 0: mw_role_fused<M, GND, E, 0>(a, lds_rows, e, lane); break;
+        case 1: mw_role_fused<M, GND, E, 1>(a, lds_rows, e, lane); break;
+        case 2: mw_role_fused<M, GND, E, 2>(a, lds_rows, e, lane); break;
+        default: mw_role_fused<M, GND, E, 3>(a, lds_rows, e, lane); break;
+    }
+#endif
+}
+
 template <class M, class GND>
 hipError_t launch_substeps_mw(const View& v, const SimParams& P, const ActParams& ap, const float* actions, int n_sub, int first, int rest,
-                              hipStream_t s, const GND& gnd) {
+                              hipStream_t s, const GND& gnd, int tail) {
+    const dim3 block(64, M::NROLE);
+    if (v.fused_sub != 0 && n_sub > 1) {
+        static unsigned long long fconf16 = 0ull, fconf32 = 0ull;
+        constexpr size_t flds16 = mw_fused_lds_bytes<M, 16>(), flds32 = mw_fused_lds_bytes<M, 32>();
+        const MwFusedArgs<GND> fa{v, P, ap, actions, first, rest, n_sub, tail, gnd};
+        if (MI_MW_HAS16 && v.mw == 16) {
+            auto kern = substep_mw_fused_kernel<M, GND, MI_MW_HAS16 ? 16 : 32>;
+            if (hipError_t e = ensure_dynamic_lds((const void*)kern, flds16, &fconf16); e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3(xcd_grid<16>(v.N)), block, flds16, s, fa);
+        } else {
+            auto kern = substep_mw_fused_kernel<M, GND, 32>;
+            if (hipError_t e = ensure_dynamic_lds((const void*)kern, flds32, &fconf32); e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3(xcd_grid<32>(v.N)), block, flds32, s, fa);
+        }
+        return hipGetLastError();
+    }
     static unsigned long long conf16 = 0ull, conf32 = 0ull;
     constexpr size_t lds16 = mw_lds_bytes<M, 16>(), lds32 = mw_lds_bytes<M, 32>();
-    const dim3 block(64, M::NROLE);
+    // (one launch per sub-step; the last `tail` ones run on the stored efforts)
+    auto src_of = [&](int i) { return i >= n_sub - tail ? (int)ACT_STORED_TAU : (i == 0 ? first : rest); };
     if (MI_MW_HAS16 && v.mw == 16) {
         auto kern = substep_mw_kernel<M, GND, MI_MW_HAS16 ? 16 : 32>;
         if (hipError_t e = ensure_dynamic_lds((const void*)kern, lds16, &conf16); e != hipSuccess) return e;
         const dim3 grid(xcd_grid<16>(v.N));
-        for (int i = 0; i < n_sub; ++i) hipLaunchKernelGGL(kern, grid, block, lds16, s, v, P, ap, actions, i == 0 ? first : rest, gnd);
+        for (int i = 0; i < n_sub; ++i) hipLaunchKernelGGL(kern, grid, block, lds16, s, v, P, ap, actions, src_of(i), gnd);
     } else {
         auto kern = substep_mw_kernel<M, GND, 32>;
         if (hipError_t e = ensure_dynamic_lds((const void*)kern, lds32, &conf32); e != hipSuccess) return e;
         const dim3 grid(xcd_grid<32>(v.N));
-        for (int i = 0; i < n_sub; ++i) hipLaunchKernelGGL(kern, grid, block, lds32, s, v, P, ap, actions, i == 0 ? first : rest, gnd);
+        for (int i = 0; i < n_sub; ++i) hipLaunchKernelGGL(kern, grid, block, lds32, s, v, P, ap, actions, src_of(i), gnd);
     }
     return hipGetLastError();
 }
@@ -171,7 +316,7 @@ __global__ __launch_bounds__(64 * M::NROLE) void substep_mw_post_kernel(MwPostAr
     float root[13], q[M::NDA], qd[M::NDA];
     sfor<13>([&](auto K) MI_LAMBDA { root[K] = post_x[K * E]; });
     sfor<M::ND>([&](auto K) MI_LAMBDA { q[K] = post_x[(13 + K) * E]; qd[K] = post_x[(13 + M::ND + K) * E]; });
-    loco_post_env<M, HUM, E, true>(a.v, a.tp, e, true, root, q, qd);
+    loco_post_env<M, HUM, E, true, false>(a.v, a.tp, e, true, root, q, qd);     // (launch_loco_step takes this form only with the observation noise off)
 #endif
 }
 
@@ -179,7 +324,7 @@ template <class M, bool HUM>
 hipError_t launch_substeps_mw_post(const View& v, const SimParams& P, const ActParams& ap, const float* actions, int n_sub, int first, int rest,
                                    hipStream_t s, const LocoParams& tp) {
     if (n_sub > 1) {
-        if (hipError_t e = launch_substeps_mw<M, PlaneGround>(v, P, ap, actions, n_sub - 1, first, rest, s, PlaneGround{}); e != hipSuccess) return e;
+        if (hipError_t e = launch_substeps_mw<M, PlaneGround>(v, P, ap, actions, n_sub - 1, first, rest, s, PlaneGround{}, 0); e != hipSuccess) return e;
     }
     const int src = n_sub > 1 ? rest : first;
     static unsigned long long conf16 = 0ull, conf32 = 0ull;

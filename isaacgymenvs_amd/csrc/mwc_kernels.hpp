@@ -38,7 +38,6 @@ __device__ __forceinline__ void mwc_role(const View& v, const SimParams& P, cons
                 float a;
                 if (src == ACT_FROM_ACTIONS) {
                     a = actions_in[(size_t)e * ap.nact + k];
-                    if (v.act_noise.dist != 0) a = apply_noise(v.act_noise, v.seed, (uint32_t)(v.env_offset + e), v.step, 1u, (uint32_t)k, a);
                     a = fminf(fmaxf(a, -ap.clip), ap.clip);
                     if constexpr (mine) v.actions[k * N + e] = a;
                 } else {

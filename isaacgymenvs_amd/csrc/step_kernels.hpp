@@ -70,6 +70,9 @@ __device__ __forceinline__ float wave_sum_live(float v) {
     }
     return v;
 }
+// job statistics: fire-and-forget hardware float atomics (global_atomic_add_f32).  Plain atomicAdd(float*) compiles to a compare-and-swap loop
+// here; every wave of a post kernel adds to the same five words, so the loops of 64-256 waves collided and retried.
+__device__ __forceinline__ void stat_add(float* p, float x) { unsafeAtomicAdd(p, x); }
 template <int ACTIVE = 64, bool LIVE_MASK = false>
 __device__ __forceinline__ void episode_stats(const View& v, int e, bool valid, float rew, long long reset, long long progress) {
     float ret = 0.f, fin_ret = 0.f, fin_len = 0.f, fin = 0.f, r = 0.f, cnt = 0.f;
@@ -86,9 +89,9 @@ __device__ __forceinline__ void episode_stats(const View& v, int e, bool valid, 
         fin_ret = wave_sum<ACTIVE>(fin_ret); fin_len = wave_sum<ACTIVE>(fin_len); fin = wave_sum<ACTIVE>(fin); r = wave_sum<ACTIVE>(r); cnt = wave_sum<ACTIVE>(cnt);
     }
     if ((threadIdx.x & 63) == 0) {
-        if (fin > 0.f) { atomicAdd(v.stats + 0, fin_ret); atomicAdd(v.stats + 1, fin_len); atomicAdd(v.stats + 2, fin); }
-        atomicAdd(v.stats + 3, r);
-        atomicAdd(v.stats + 4, cnt);
+        if (fin > 0.f) { stat_add(v.stats + 0, fin_ret); stat_add(v.stats + 1, fin_len); stat_add(v.stats + 2, fin); }
+        stat_add(v.stats + 3, r);
+        stat_add(v.stats + 4, cnt);
     }
 }
 
@@ -160,7 +163,6 @@ __device__ __forceinline__ void efforts_for_substep(const View& v, const ActPara
                 float a;
                 if (src == ACT_FROM_ACTIONS) {
                     a = actions_in[(size_t)e * ap.nact + k];
-                    if (v.act_noise.dist != 0) a = apply_noise(v.act_noise, v.seed, (uint32_t)(v.env_offset + e), v.step, 1u, (uint32_t)k, a);  // vec_task.py:371-372
                     a = fminf(fmaxf(a, -ap.clip), ap.clip);  // vec_task.py:374
                     v.actions[k * N + e] = a;
                 } else {
@@ -179,6 +181,24 @@ __device__ __forceinline__ void efforts_for_substep(const View& v, const ActPara
     } else {
         sfor<ND>([&](auto K) MI_LAMBDA { tau[K] = v.tau[K * N + e]; });
     }
+}
+// Action noise of the domain randomisation (vec_task.py:371-372, then the clamp of :374): a kernel of its own, launched only when the noise is
+// on, that leaves the noisy clamped actions in v.actions; the step's first sub-step launch then takes ACT_FROM_STORED_ACTIONS.  Inlined into
+// the sub-step kernels the never-taken noise block was two Box-Muller draws (logf / cosf with their argument reduction) per dof and role:
+// 3 k (Ant) to 8 k (Humanoid) dead instructions at the top of every role's stream.
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void act_noise_kernel(View v, const float* __restrict__ actions_in, float clip, int nact) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= v.N * nact) return;
+    const int e = i / nact, k = i - e * nact;
+    float a = apply_noise(v.act_noise, v.seed, (uint32_t)(v.env_offset + e), v.step, 1u, (uint32_t)k, actions_in[i]);
+    v.actions[(size_t)k * v.N + e] = fminf(fmaxf(a, -clip), clip);
+}
+// to be called before the sub-step launches of a step: returns the effort source of the first launch
+inline int prepare_actions(const View& v, const ActParams& ap, const float* actions, int first, hipStream_t s) {
+    if (first != ACT_FROM_ACTIONS || v.act_noise.dist == 0) return first;
+    hipLaunchKernelGGL(act_noise_kernel<0>, dim3((v.N * ap.nact + 255) / 256), dim3(256), 0, s, v, actions, ap.clip, ap.nact);
+    return ACT_FROM_STORED_ACTIONS;
 }
 // Last sub-step's impulses go from HBM straight into their row-store slots with LDS-direct loads (global_load_lds_dword:
 // lane l of the wave lands at slot base + 4 l, exactly the [slot][lane] layout): no VGPR holds them in flight, so the ~50
@@ -253,10 +273,11 @@ hipError_t launch_substeps_sc2(const View& v, const SimParams& P, const ActParam
 template <class M>
 hipError_t launch_substeps_mwc(const View& v, const SimParams& P, const ActParams& ap, const float* actions, int n_sub, int first, int rest,
                                hipStream_t s);
-// launches n_sub multi-wave sub-steps with v.mw envs per workgroup (defined for the model / ground pairs of kernels_mw_*.hip)
+// launches n_sub multi-wave sub-steps with v.mw envs per workgroup (defined for the model / ground pairs of kernels_mw_*.hip); the last
+// `tail` of them run on the efforts of the sub-step before them; option "fused_sub": all of them in ONE launch (mw_kernels.hpp)
 template <class M, class GND>
 hipError_t launch_substeps_mw(const View& v, const SimParams& P, const ActParams& ap, const float* actions, int n_sub, int first, int rest,
-                              hipStream_t s, const GND& gnd);
+                              hipStream_t s, const GND& gnd, int tail = 0);
 
 // XCD-aware env mapping of the 64-lane post kernels.  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).
 // A sub-step kernel with 32 envs per workgroup puts env e on XCD (e / 32) % 8; a post kernel that simply took envs
@@ -289,7 +310,16 @@ constexpr int post_lanes() { return Sim<M>::LANES < 64 ? 32 : 64; }
 // post_physics_step of one env (ant.py:287-297): progress++, reset if flagged, observations, reward, write-out.  root / q / qd: the env's state
 // after the last sub-step (the post kernel loads them; the fused form of the limb-per-wave sub-step hands them over through LDS).
 // ACTIVE: lanes of the wave that hold envs (episode statistics reduction).
-template <class M, bool HUM, int ACTIVE, bool LIVE_MASK = false>
+// What bounds this kernel (round 3, profiles/r3x_post_kernel_study.txt): not its instruction stream -- a form with FOUR lanes per env (a
+// quarter of the instructions per lane, 4 x the waves, observation rows leaving through an LDS tile as whole cache lines, bit-identical
+// buffers) ran 10.2 -> 11.8 us (Ant@4096) and 27.6 -> 29.6 us (Humanoid@8192); without the observation stores it takes 6.2 / 21.6 us,
+// with non-temporal stores 13.0 / 32.7 us; hardware float atomics instead of the compare-and-swap loops of atomicAdd(float*) changed
+// nothing measurable.  The one-lane form stays.
+// NOISE: the kernel carries the observation noise of the domain randomisation.  It is a kernel of its own because the noise code is most
+// of the kernel when it is there: two Box-Muller draws per observation column (logf / cosf with their full argument reduction, inlined per
+// column) are 24 k of the Ant post kernel's 26 k vector instructions and 256 + 153 of its registers (Humanoid: 363 spilled registers) --
+// never executed on a run without `task.randomize`, but fetched around and allocated for.
+template <class M, bool HUM, int ACTIVE, bool LIVE_MASK = false, bool NOISE = true>
 __device__ __forceinline__ void loco_post_env(const View& v, const LocoParams& tp, const int e, const bool valid, float (&root)[13], float (&q)[M::NDA],
                                               float (&qd)[M::NDA]) {
     using T = Loco<M::ND, 6 * M::NSENS, HUM>;
@@ -331,8 +361,10 @@ __device__ __forceinline__ void loco_post_env(const View& v, const LocoParams& t
     T::reward(tp, obs, 0LL, progress, act, potentials, prev_potentials, &rew, &reset);
     // observation noise of the domain randomisation: the reference applies it to obs_buf after post_physics_step (vec_task.py:397-399),
     // i.e. the reward above saw the clean observations
-    if (v.obs_noise.dist != 0)
-        sfor<NOBS>([&](auto K) MI_LAMBDA { obs[K] = apply_noise(v.obs_noise, v.seed, (uint32_t)(v.env_offset + e), v.step, 0u, (uint32_t)K, obs[K]); });
+    if constexpr (NOISE) {
+        if (v.obs_noise.dist != 0)
+            sfor<NOBS>([&](auto K) MI_LAMBDA { obs[K] = apply_noise(v.obs_noise, v.seed, (uint32_t)(v.env_offset + e), v.step, 0u, (uint32_t)K, obs[K]); });
+    }
     episode_stats<ACTIVE, LIVE_MASK>(v, e, valid, rew, reset, progress);
     if (!valid) return;
     v.randomize[e] += 1;
@@ -352,7 +384,7 @@ __device__ __forceinline__ void loco_post_env(const View& v, const LocoParams& t
     // vec_task.py:394
     v.timeout[e] = (unsigned char)(((float)progress >= tp.max_episode_length - 1.f) && (reset != 0));
 }
-template <class M, bool HUM>
+template <class M, bool HUM, bool NOISE>
 __global__ __launch_bounds__(post_lanes<M>()) void loco_post_kernel(View v, LocoParams tp) {
     constexpr int ND = M::ND, PL = post_lanes<M>();
     const int N = v.N;
@@ -365,8 +397,9 @@ __global__ __launch_bounds__(post_lanes<M>()) void loco_post_kernel(View v, Loco
         q[K] = v.dof[K * N + e];
         qd[K] = v.dof[(ND + K) * N + e];
     });
-    loco_post_env<M, HUM, PL>(v, tp, e, valid, root, q, qd);
+    loco_post_env<M, HUM, PL, false, NOISE>(v, tp, e, valid, root, q, qd);
 }
+
 
 template <class M>
 __global__ __launch_bounds__(64) void cartpole_post_kernel(View v, CartpoleParams tp) {
@@ -466,8 +499,9 @@ template <class M, class GND>
 hipError_t launch_substeps_scaled(const View& v, const SimParams& P, const ActParams& ap, const float* actions, int n_sub, int first,
                                   int rest, hipStream_t s, const GND& gnd);
 template <class M, class GND = PlaneGround>
-hipError_t launch_substeps(const View& v, const SimParams& P, const ActParams& ap, const float* actions, int n_sub, int first,
+hipError_t launch_substeps(const View& v, const SimParams& P, const ActParams& ap, const float* actions, int n_sub, int first_in,
                            int rest, hipStream_t s, const GND& gnd = GND{}) {
+    const int first = prepare_actions(v, ap, actions, first_in, s);
     if constexpr (M::ACTOR_SCALES != 0 && !is_scaled<M>::value) {
         // option actor_tensors: the arena holds per-env mass / joint-constant factors and limit shifts -> the kernels that read them
         if (v.actor_scale != nullptr || v.limit_shift != nullptr) return launch_substeps_scaled<M, GND>(v, P, ap, actions, n_sub, first, rest, s, gnd);
@@ -520,12 +554,13 @@ hipError_t launch_loco_step(const View& v, const SimParams& P, const LocoParams&
     ap.mode = 0;
     if constexpr (mw_post_capable<M>()) {
         // (the fused form exists for the plain kernels only: with randomised actor parameters the two-launch form below runs)
-        if (v.mw != 0 && v.fused_post != 0 && v.actor_scale == nullptr && v.limit_shift == nullptr) return launch_substeps_mw_post<M, HUM>(v, P, ap, actions, cfi * P.substeps, ACT_FROM_ACTIONS, ACT_STORED_TAU, s, tp);
+        if (v.mw != 0 && v.fused_post != 0 && v.actor_scale == nullptr && v.limit_shift == nullptr && v.obs_noise.dist == 0 && v.act_noise.dist == 0) return launch_substeps_mw_post<M, HUM>(v, P, ap, actions, cfi * P.substeps, ACT_FROM_ACTIONS, ACT_STORED_TAU, s, tp);
     }
     hipError_t e = launch_substeps<M>(v, P, ap, actions, cfi * P.substeps, ACT_FROM_ACTIONS, ACT_STORED_TAU, s);
     if (e != hipSuccess) return e;
     constexpr int PL = post_lanes<M>();
-    hipLaunchKernelGGL((loco_post_kernel<M, HUM>), dim3(xcd_grid<PL>(v.N)), dim3(PL), 0, s, v, tp);
+    if (v.obs_noise.dist != 0) hipLaunchKernelGGL((loco_post_kernel<M, HUM, true>), dim3(xcd_grid<PL>(v.N)), dim3(PL), 0, s, v, tp);
+    else hipLaunchKernelGGL((loco_post_kernel<M, HUM, false>), dim3(xcd_grid<PL>(v.N)), dim3(PL), 0, s, v, tp);
     return hipGetLastError();
 }
 template <class M>

@@ -53,6 +53,7 @@ struct AnymalTerrainDesc {   // device-side view of the terrain (set once throug
     int levels, types;
     float env_length;
     float slope_threshold;   // terrain.slopeTreshold (anymal_terrain.py:576), <= 0: the uncorrected mesh (option "terrain_slope_threshold")
+    int walls;               // the risers of the corrected mesh collide from the side (option "terrain_walls", default 1)
 };
 
 // body indices in the compiled model (base, then LF, RF, LH, RH x {HIP, THIGH, SHANK}); `footName: SHANK`, `kneeName: THIGH`

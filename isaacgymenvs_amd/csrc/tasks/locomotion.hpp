@@ -45,12 +45,12 @@ template <int ND, int NSV, bool HUM>
 struct Loco {
     static constexpr int NOBS = 12 + ND * (HUM ? 4 : 3) + NSV;
 
-    MI_HD static void observations(const LocoParams& p, const float* root, const float* targets, float potentials_in,
-                                   const float* inv_start_rot, const float* dof_pos, const float* dof_vel,
-                                   const float* dof_force, const float* lower, const float* upper,
-                                   const float* sensors, const float* actions, const float* basis0,
-                                   const float* basis1, float* obs, float* potentials_out,
-                                   float* prev_potentials_out, float* up_vec, float* heading_vec) {
+    // ---- the parts of the observation row (also what a kernel that deals an env's columns out to several lanes calls: the four-lane post
+    // kernel measured in round 3, step_kernels.hpp)
+    // the 12 root-derived columns; also potentials (ant.py:390-393) and the up / heading vectors
+    MI_HD static void obs_root(const LocoParams& p, const float* root, const float* targets, float potentials_in, const float* inv_start_rot,
+                               const float* basis0, const float* basis1, float* obs12, float* potentials_out, float* prev_potentials_out,
+                               float* up_vec, float* heading_vec) {
         MI_NO_CONTRACT
         const float* pos = root;
         const float* rot = root + 3;
@@ -84,19 +84,39 @@ struct Loco {
             angle_to_target = normalize_angle(angle_to_target);
             ang_scale = p.angular_velocity_scale;
         }
-        obs[0] = pos[2];
-        obs[1] = vel_loc[0]; obs[2] = vel_loc[1]; obs[3] = vel_loc[2];
-        obs[4] = angvel_loc[0] * ang_scale; obs[5] = angvel_loc[1] * ang_scale; obs[6] = angvel_loc[2] * ang_scale;
-        obs[7] = yaw; obs[8] = roll; obs[9] = angle_to_target; obs[10] = up_proj; obs[11] = heading_proj;
+        obs12[0] = pos[2];
+        obs12[1] = vel_loc[0]; obs12[2] = vel_loc[1]; obs12[3] = vel_loc[2];
+        obs12[4] = angvel_loc[0] * ang_scale; obs12[5] = angvel_loc[1] * ang_scale; obs12[6] = angvel_loc[2] * ang_scale;
+        obs12[7] = yaw; obs12[8] = roll; obs12[9] = angle_to_target; obs12[10] = up_proj; obs12[11] = heading_proj;
+    }
+    // columns of one dof: scaled position, scaled velocity, (Humanoid) scaled joint force
+    MI_HD static void obs_dof(const LocoParams& p, float dof_pos, float dof_vel, float dof_force, float lower, float upper, float* pos_scaled,
+                              float* vel_scaled, float* force_scaled) {
+        MI_NO_CONTRACT
+        *pos_scaled = unscale(dof_pos, lower, upper);
+        *vel_scaled = dof_vel * p.dof_vel_scale;
+        *force_scaled = dof_force * p.contact_force_scale;
+    }
+    static constexpr int COL_POS = 12, COL_VEL = 12 + ND, COL_FORCE = 12 + 2 * ND, COL_SENS = 12 + ND * (HUM ? 3 : 2), COL_ACT = COL_SENS + NSV;
+
+    MI_HD static void observations(const LocoParams& p, const float* root, const float* targets, float potentials_in,
+                                   const float* inv_start_rot, const float* dof_pos, const float* dof_vel,
+                                   const float* dof_force, const float* lower, const float* upper,
+                                   const float* sensors, const float* actions, const float* basis0,
+                                   const float* basis1, float* obs, float* potentials_out,
+                                   float* prev_potentials_out, float* up_vec, float* heading_vec) {
+        MI_NO_CONTRACT
+        obs_root(p, root, targets, potentials_in, inv_start_rot, basis0, basis1, obs, potentials_out, prev_potentials_out, up_vec, heading_vec);
         sfor<ND>([&](auto D) MI_LAMBDA {
             constexpr int d = D;
-            obs[12 + d] = unscale(dof_pos[d], lower[d], upper[d]);
-            obs[12 + ND + d] = dof_vel[d] * p.dof_vel_scale;
-            if constexpr (HUM) obs[12 + 2 * ND + d] = dof_force[d] * p.contact_force_scale;
+            float ps, vs, fs;
+            obs_dof(p, dof_pos[d], dof_vel[d], HUM ? dof_force[d] : 0.f, lower[d], upper[d], &ps, &vs, &fs);
+            obs[COL_POS + d] = ps;
+            obs[COL_VEL + d] = vs;
+            if constexpr (HUM) obs[COL_FORCE + d] = fs;
         });
-        constexpr int so = 12 + ND * (HUM ? 3 : 2);
-        sfor<NSV>([&](auto K) MI_LAMBDA { obs[so + K] = sensors[K] * p.contact_force_scale; });
-        sfor<ND>([&](auto D) MI_LAMBDA { obs[so + NSV + D] = actions[D]; });
+        sfor<NSV>([&](auto K) MI_LAMBDA { obs[COL_SENS + K] = sensors[K] * p.contact_force_scale; });
+        sfor<ND>([&](auto D) MI_LAMBDA { obs[COL_ACT + D] = actions[D]; });
     }
 
     MI_HD static float unscale(float x, float lo, float up) {  // torch_jit_utils.py:238-240
@@ -104,58 +124,81 @@ struct Loco {
         return (2.0f * x - up - lo) / (up - lo);
     }
 
-    MI_HD static void reward(const LocoParams& p, const float* obs, long long reset_in, long long progress,
-                             const float* actions, float potentials, float prev_potentials, float* reward_out,
-                             long long* reset_out) {
+    // ---- reward.  The three sums over the dofs (torch.sum(..., dim=-1) in the reference, whose order is torch's business) are DEFINED here
+    // as four strided partial sums, dof d into partial d % 4 in increasing d, combined as (p0 + p1) + (p2 + p3): an order that four lanes
+    // per env reproduce with an xor-1, then an xor-2 shuffle, so every form -- kernels, CPU backend, stand-alone twins -- agrees bit for bit.
+    struct DofSums { float actions = 0.f, electricity = 0.f, at_limit = 0.f; };
+    MI_HD static void reward_dof(const LocoParams& p, float action, float pos_scaled, float vel_scaled, float gear, DofSums& s) {
         MI_NO_CONTRACT
-        const float heading_reward = (obs[11] > 0.8f) ? p.heading_weight : p.heading_weight * obs[11] / 0.8f;
-        const float up_reward = (obs[10] > 0.93f) ? (0.f + p.up_weight) : 0.f;
-        float actions_cost = 0.f, electricity_cost = 0.f, dof_at_limit_cost = 0.f;
-        for (int d = 0; d < ND; ++d) {
-            actions_cost += actions[d] * actions[d];
-            if constexpr (HUM) {
-                const float ratio = p.gear[d] / p.max_motor_effort;
-                const float ap = fabsf(obs[12 + d]);
-                const float scaled = p.joints_at_limit_cost * (ap - 0.98f) / 0.02f;
-                dof_at_limit_cost += ((ap > 0.98f) ? 1.f : 0.f) * scaled * ratio;
-                electricity_cost += fabsf(actions[d] * obs[12 + ND + d]) * ratio;
-            } else {
-                electricity_cost += fabsf(actions[d] * obs[12 + ND + d]);
-                dof_at_limit_cost += (obs[12 + d] > 0.99f) ? 1.f : 0.f;
-            }
+        s.actions += action * action;
+        if constexpr (HUM) {
+            const float ratio = gear / p.max_motor_effort;
+            const float ap = fabsf(pos_scaled);
+            const float scaled = p.joints_at_limit_cost * (ap - 0.98f) / 0.02f;
+            s.at_limit += ((ap > 0.98f) ? 1.f : 0.f) * scaled * ratio;
+            s.electricity += fabsf(action * vel_scaled) * ratio;
+        } else {
+            s.electricity += fabsf(action * vel_scaled);
+            s.at_limit += (pos_scaled > 0.99f) ? 1.f : 0.f;
         }
+    }
+    MI_HD static void reward_total(const LocoParams& p, float height, float up_proj, float heading_proj, const DofSums& s, long long reset_in,
+                                   long long progress, float potentials, float prev_potentials, float* reward_out, long long* reset_out) {
+        MI_NO_CONTRACT
+        const float heading_reward = (heading_proj > 0.8f) ? p.heading_weight : p.heading_weight * heading_proj / 0.8f;
+        const float up_reward = (up_proj > 0.93f) ? (0.f + p.up_weight) : 0.f;
         const float alive_reward = HUM ? 2.0f : 0.5f;
         const float progress_reward = potentials - prev_potentials;
         float total;
         if constexpr (HUM)
-            total = progress_reward + alive_reward + up_reward + heading_reward - p.actions_cost * actions_cost -
-                    p.energy_cost * electricity_cost - dof_at_limit_cost;
+            total = progress_reward + alive_reward + up_reward + heading_reward - p.actions_cost * s.actions -
+                    p.energy_cost * s.electricity - s.at_limit;
         else
-            total = progress_reward + alive_reward + up_reward + heading_reward - p.actions_cost * actions_cost -
-                    p.energy_cost * electricity_cost - dof_at_limit_cost * p.joints_at_limit_cost;
-        const bool fallen = obs[0] < p.termination_height;
+            total = progress_reward + alive_reward + up_reward + heading_reward - p.actions_cost * s.actions -
+                    p.energy_cost * s.electricity - s.at_limit * p.joints_at_limit_cost;
+        const bool fallen = height < p.termination_height;
         if (fallen) total = p.death_cost;
         long long reset = fallen ? 1 : reset_in;
         if ((float)progress >= p.max_episode_length - 1.f) reset = 1;
         *reward_out = total;
         *reset_out = reset;
     }
+    MI_HD static void reward(const LocoParams& p, const float* obs, long long reset_in, long long progress,
+                             const float* actions, float potentials, float prev_potentials, float* reward_out,
+                             long long* reset_out) {
+        MI_NO_CONTRACT
+        DofSums part[4];
+        for (int d = 0; d < ND; ++d) reward_dof(p, actions[d], obs[COL_POS + d], obs[COL_VEL + d], p.gear[d], part[d & 3]);
+        DofSums s;
+        s.actions = (part[0].actions + part[1].actions) + (part[2].actions + part[3].actions);
+        s.electricity = (part[0].electricity + part[1].electricity) + (part[2].electricity + part[3].electricity);
+        s.at_limit = (part[0].at_limit + part[1].at_limit) + (part[2].at_limit + part[3].at_limit);
+        reward_total(p, obs[0], obs[10], obs[11], s, reset_in, progress, potentials, prev_potentials, reward_out, reset_out);
+    }
 
+    // reset_idx, the draws of one dof (torch_rand_float + tensor_clamp, ant.py:257-263)
+    MI_HD static void reset_dof(const LocoParams& p, uint32_t seed, uint32_t genv, uint32_t episode, int d, float initial, float lower, float upper,
+                                float* dof_pos, float* dof_vel) {
+        MI_NO_CONTRACT
+        const float up = p.reset_pos_noise, lo = -p.reset_pos_noise;
+        const float rp = (up - lo) * uniform01(seed, genv, episode, (uint32_t)d) + lo;        // torch_rand_float
+        const float vu = p.reset_vel_noise, vl = -p.reset_vel_noise;
+        const float rv = (vu - vl) * uniform01(seed, genv, episode, (uint32_t)(ND + d)) + vl;
+        *dof_pos = fmaxf(fminf(initial + rp, upper), lower);  // tensor_clamp
+        *dof_vel = rv;
+    }
+    MI_HD static float reset_potential(const LocoParams& p, const float* initial_root) {
+        MI_NO_CONTRACT
+        const float tx = p.targets[0] - initial_root[0], ty = p.targets[1] - initial_root[1];
+        return -sqrtf((tx * tx + ty * ty) + 0.f) / p.dt;
+    }
     // reset_idx for one env: returns the new dof state and potentials; root := initial root state
     MI_HD static void reset(const LocoParams& p, uint32_t seed, uint32_t genv, uint32_t episode, const float* initial_root,
                             float* root, float* dof_pos, float* dof_vel, float* potentials, float* prev_potentials) {
         MI_NO_CONTRACT
-        for (int d = 0; d < ND; ++d) {
-            const float up = p.reset_pos_noise, lo = -p.reset_pos_noise;
-            const float rp = (up - lo) * uniform01(seed, genv, episode, (uint32_t)d) + lo;        // torch_rand_float
-            const float vu = p.reset_vel_noise, vl = -p.reset_vel_noise;
-            const float rv = (vu - vl) * uniform01(seed, genv, episode, (uint32_t)(ND + d)) + vl;
-            dof_pos[d] = fmaxf(fminf(p.initial_dof_pos[d] + rp, p.dof_upper[d]), p.dof_lower[d]);  // tensor_clamp
-            dof_vel[d] = rv;
-        }
+        for (int d = 0; d < ND; ++d) reset_dof(p, seed, genv, episode, d, p.initial_dof_pos[d], p.dof_lower[d], p.dof_upper[d], &dof_pos[d], &dof_vel[d]);
         for (int k = 0; k < 13; ++k) root[k] = initial_root[k];
-        const float tx = p.targets[0] - initial_root[0], ty = p.targets[1] - initial_root[1];
-        const float pp = -sqrtf((tx * tx + ty * ty) + 0.f) / p.dt;
+        const float pp = reset_potential(p, initial_root);
         *prev_potentials = pp;
         *potentials = pp;
     }

@@ -207,6 +207,13 @@ def select_multi_wave(engine, task, num_envs, mw="auto"):
             break
         except RuntimeError:
             continue
+    if task in ("Ant", "AnymalTerrain"):
+        # all physics sub-steps of a control step in one launch (csrc/mw_kernels.hpp substep_mw_fused_kernel; bit-identical buffers):
+        # Ant@4096 0.0424 -> 0.0408 ms, AnymalTerrain@4096 0.1273 -> 0.1187 ms per step (tools/fused_sub_ab.py, profiles/r3x_fused_sub_ab.txt)
+        try:
+            engine.set_option("fused_sub", 1)
+        except RuntimeError:
+            pass
     if task == "Ant":
         # post_physics_step on one wave of the last limb-per-wave sub-step launch instead of a kernel of its own: +9 % at 1024 envs, a wash at
         # 4096 (+1 % on a fast box, -5 % on a slow one), +2 % at 8192 (tools/ant_fused_post_ab.py, profiles/r3r_*, r3s_*): on for small batches

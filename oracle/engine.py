@@ -171,17 +171,18 @@ class OracleEngine:
     def sph_force(self):
         return self.out[:, 6 * self.nsens + self.nd:6 * self.nsens + self.nd + 3 * self.nsph].reshape(self.N, self.nsph, 3)
 
-    def set_ground(self, height_samples, hscale, vscale, border, slope_threshold=0.0):
-        """Height field (int16 [rows, cols], reference Terrain.height_field_raw) instead of the z = ground_z plane."""
+    def set_ground(self, height_samples, hscale, vscale, border, slope_threshold=0.0, walls=True):
+        """Height field (int16 [rows, cols], reference Terrain.height_field_raw) instead of the z = ground_z plane.
+        walls: with the slope correction on, the risers it creates collide from the side (physics.c ground_contact)."""
         creal = C.c_double if self.np_real == np.float64 else C.c_float
 
         class OrGround(C.Structure):
             _fields_ = [("hs", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32), ("hscale", creal), ("vscale", creal),
-                        ("border", creal), ("thr", creal)]
+                        ("border", creal), ("thr", creal), ("walls", C.c_int32)]
         self._hs = np.ascontiguousarray(height_samples, np.int16)
         # slope_threshold: terrain.slopeTreshold of the mesh generator (anymal_terrain.py:576); 0 = the uncorrected mesh
         thr = slope_threshold * hscale / vscale if slope_threshold and slope_threshold > 0 else 0.0
-        self.ground = OrGround(_ptr(self._hs), self._hs.shape[0], self._hs.shape[1], hscale, vscale, border, thr)
+        self.ground = OrGround(_ptr(self._hs), self._hs.shape[0], self._hs.shape[1], hscale, vscale, border, thr, 1 if walls else 0)
 
     def step(self, tau, env_mu=None):
         tau = np.ascontiguousarray(tau, self.np_real).reshape(self.N, self.nd)

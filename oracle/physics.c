@@ -339,6 +339,7 @@ typedef struct {
     int32_t rows, cols;
     real hscale, vscale, border;
     real thr;          /* slope_threshold * hscale / vscale; <= 0: no correction */
+    int32_t walls;     /* with the correction on: the risers it creates collide from the side (ground_contact) */
 } OrGround;
 
 /* height z and unit normal n of the surface under world (x, y) */
@@ -366,6 +367,72 @@ static void ground_query(const OrGround *g, real ground_z, real x, real y, real 
     real sx = dzx * g->vscale / g->hscale, sy = dzy * g->vscale / g->hscale;
     real inv = 1 / RSQRT(sx * sx + sy * sy + 1);
     n[0] = -sx * inv; n[1] = -sy * inv; n[2] = inv;
+}
+/* Contact of a sphere (centre (x, y, z), radius r <= hscale) with the terrain: distance dist and unit normal n of the NEARER of
+ *  (a) the tangent plane of the surface below the centre (ground_query), and
+ *  (b) the wall of a riser.  The mesh generator's slope correction slides the lower vertex of a steep edge under the upper one
+ *      (oracle/terrain_mesh.py), so a cell whose two x edges (y edges) both rise by more than thr in the same direction is floor at
+ *      the lower level with a vertical wall on the cell boundary of the higher vertices, as tall as they are.  From inside that cell
+ *      the wall is a contact candidate: below its top with a horizontal normal and distance (distance to the cell boundary) - r, above
+ *      its top against the top EDGE (distance to the edge line - r, normal from the edge to the centre), which continues into the
+ *      surface candidate of the cell behind the wall.  x walls on the raw heights, y walls on the x-levelled ones, like the levelling.
+ * A sphere of radius <= hscale cannot reach a wall from another cell than the steep one, so only the centre's cell is looked at.  One
+ * contact per sphere: the nearer candidate; a sphere inside BOTH (a foot pressed into the corner of tread and riser) gets one contact along
+ * the sum of the two penetration vectors, as deep as that sum is long -- the direction adjusts itself to the ratio of the forces it has to
+ * carry and the position correction drives both penetrations to zero ("the deeper one wins" let a foot that carries weight creep through
+ * the wall on every other sub-step).
+ * The reference collides against the triangle mesh itself (anymal_terrain.py:198-211); tests/test_terrain.py compares this with the
+ * restated corrected mesh of oracle/terrain_mesh.py. */
+static void ground_contact(const OrGround *g, real ground_z, real x, real y, real z, real r, real *dist, real *n) {
+    real zt;
+    ground_query(g, ground_z, x, y, &zt, n);
+    real d = (z - zt) * n[2] - r;
+    *dist = d;
+    if (g == 0 || g->hs == 0 || !(g->thr > 0) || !g->walls) return;
+    real gx = (x + g->border) / g->hscale, gy = (y + g->border) / g->hscale;
+    int i = (int)floor(gx), j = (int)floor(gy);
+    if (i < 0) i = 0; if (i > g->rows - 2) i = g->rows - 2;
+    if (j < 0) j = 0; if (j > g->cols - 2) j = g->cols - 2;
+    real fx = gx - i, fy = gy - j;
+    if (fx < 0) fx = 0; if (fx > 1) fx = 1; if (fy < 0) fy = 0; if (fy > 1) fy = 1;
+    real h00 = g->hs[i * g->cols + j], h10 = g->hs[(i + 1) * g->cols + j], h01 = g->hs[i * g->cols + j + 1],
+         h11 = g->hs[(i + 1) * g->cols + j + 1];
+    real dw = 1e30, nw[3] = {0, 0, 0};      /* the nearer wall candidate */
+    {   /* x walls */
+        int s0 = RFABS(h10 - h00) > g->thr, s1 = RFABS(h11 - h01) > g->thr, up0 = h10 > h00, up1 = h11 > h01;
+        if (s0 && s1 && up0 == up1) {
+            real t0 = up0 ? h10 : h00, t1 = up1 ? h11 : h01;
+            real top = (t0 + (t1 - t0) * fy) * g->vscale;
+            real dx = (up0 ? 1 - fx : fx) * g->hscale, dz = z > top ? z - top : 0;     /* above the top: its edge */
+            real len = RSQRT(dx * dx + dz * dz), il = 1 / (len > 1e-12 ? len : 1e-12);
+            if (len - r < dw) { dw = len - r; nw[0] = (up0 ? -dx : dx) * il; nw[1] = 0; nw[2] = dz * il; }
+        }
+        real m;
+        if (s0) { m = h00 < h10 ? h00 : h10; h00 = m; h10 = m; }
+        if (s1) { m = h01 < h11 ? h01 : h11; h01 = m; h11 = m; }
+    }
+    {   /* y walls, on the x-levelled heights */
+        int s2 = RFABS(h01 - h00) > g->thr, s3 = RFABS(h11 - h10) > g->thr, up0 = h01 > h00, up1 = h11 > h10;
+        if (s2 && s3 && up0 == up1) {
+            real t0 = up0 ? h01 : h00, t1 = up1 ? h11 : h10;
+            real top = (t0 + (t1 - t0) * fx) * g->vscale;
+            real dy = (up0 ? 1 - fy : fy) * g->hscale, dz = z > top ? z - top : 0;
+            real len = RSQRT(dy * dy + dz * dz), il = 1 / (len > 1e-12 ? len : 1e-12);
+            if (len - r < dw) { dw = len - r; nw[0] = 0; nw[1] = (up0 ? -dy : dy) * il; nw[2] = dz * il; }
+        }
+    }
+    if (d < 0 && dw < 0) {          /* in the corner of tread and riser, inside both: one contact along the summed penetrations */
+        real v[3] = {-d * n[0] - dw * nw[0], -d * n[1] - dw * nw[1], -d * n[2] - dw * nw[2]};
+        real L = RSQRT(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        n[0] = v[0] / L; n[1] = v[1] / L; n[2] = v[2] / L;
+        d = -L;
+    } else if (dw < d) {
+        d = dw; n[0] = nw[0]; n[1] = nw[1]; n[2] = nw[2];
+    }
+    *dist = d;
+}
+void or_ground_contact(const OrGround *g, real ground_z, real x, real y, real z, real r, real *dist, real *n) {
+    ground_contact(g, ground_z, x, y, z, r, dist, n);
 }
 /* the query by itself (tests/test_terrain.py compares it with oracle/terrain_mesh.py) */
 void or_ground_query(const OrGround *g, real ground_z, real x, real y, real *z, real *n) { ground_query(g, ground_z, x, y, z, n); }
@@ -606,11 +673,10 @@ static void step_env(const OrModel *m, const OrParams *p, const OrGround *gnd, r
             real t[3], x[3];
             m3v(w.R[b], m->sph_pos + 3 * s, t);
             x[0] = w.r[b][0] + t[0]; x[1] = w.r[b][1] + t[1]; x[2] = w.r[b][2] + t[2];
-            real zt, dirs[3][3];
-            ground_query(gnd, p->ground_z, root[0] + x[0], root[1] + x[1], &zt, dirs[0]);
+            real dirs[3][3], dist;
+            /* distance of the sphere to the local tangent plane of the surface, or to the wall of a riser beside it */
+            ground_contact(gnd, p->ground_z, root[0] + x[0], root[1] + x[1], root[2] + x[2], m->sph_rad[s], &dist, dirs[0]);
             contact_frame(dirs[0], dirs[1], dirs[2]);
-            /* distance of the sphere to the local tangent plane of the surface */
-            real dist = ((root[2] + x[2]) - zt) * dirs[0][2] - m->sph_rad[s];
             if (dist >= p->contact_offset) { lam_c[3 * s] = lam_c[3 * s + 1] = lam_c[3 * s + 2] = 0; continue; }
             if (m->kmax > 0 && nground >= m->kmax) { lam_c[3 * s] = lam_c[3 * s + 1] = lam_c[3 * s + 2] = 0; dropped++; continue; }
             if (m->solver == 1 && m->kmax_blk) {
@@ -804,10 +870,10 @@ static void step_env(const OrModel *m, const OrParams *p, const OrGround *gnd, r
             if (sph_row[s] >= 0) {
                 int r0 = sph_row[s];
                 lam_c[3 * s] = lam[r0]; lam_c[3 * s + 1] = lam[r0 + 1]; lam_c[3 * s + 2] = lam[r0 + 2];
-                real t[3], x[3], zt, t1[3], t2[3];
+                real t[3], x[3], dd, t1[3], t2[3];
                 m3v(w.R[b], m->sph_pos + 3 * s, t);
-                x[0] = w.r[b][0] + t[0]; x[1] = w.r[b][1] + t[1];
-                ground_query(gnd, p->ground_z, root[0] + x[0], root[1] + x[1], &zt, nrm);
+                x[0] = w.r[b][0] + t[0]; x[1] = w.r[b][1] + t[1]; x[2] = w.r[b][2] + t[2];
+                ground_contact(gnd, p->ground_z, root[0] + x[0], root[1] + x[1], root[2] + x[2], m->sph_rad[s], &dd, nrm);
                 contact_frame(nrm, t1, t2);
                 for (int c = 0; c < 3; c++) f[c] = (nrm[c] * lam[r0] + t1[c] * lam[r0 + 1] + t2[c] * lam[r0 + 2]) / h;
                 if (netf) for (int c = 0; c < 3; c++) netf[3 * b + c] += f[c];

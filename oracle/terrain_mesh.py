@@ -80,3 +80,55 @@ def snapped_height(hf, hscale, vscale, slope_threshold, px, py):
     lower = fx >= fy
     dzx = np.where(lower, h10 - h00, h11 - h01); dzy = np.where(lower, h11 - h10, h01 - h00)
     return (h00 + dzx * fx + dzy * fy) * vscale
+
+
+def _closest_on_triangle(p, a, b, c):
+    """closest point of the triangles (a, b, c) [n, 3] to the points p [n, 3] (Ericson, Real-Time Collision Detection 5.1.5), vectorised"""
+    ab, ac, ap = b - a, c - a, p - a
+    d1, d2 = np.einsum("ij,ij->i", ab, ap), np.einsum("ij,ij->i", ac, ap)
+    bp = p - b
+    d3, d4 = np.einsum("ij,ij->i", ab, bp), np.einsum("ij,ij->i", ac, bp)
+    cp = p - c
+    d5, d6 = np.einsum("ij,ij->i", ab, cp), np.einsum("ij,ij->i", ac, cp)
+    vc, vb, va = d1 * d4 - d3 * d2, d5 * d2 - d1 * d6, d3 * d6 - d5 * d4
+    out = np.empty_like(p)
+    done = np.zeros(len(p), bool)
+
+    def put(mask, val):
+        m = mask & ~done
+        out[m] = val[m]
+        done[m] = True
+    with np.errstate(divide="ignore", invalid="ignore"):
+        put((d1 <= 0) & (d2 <= 0), a)
+        put((d3 >= 0) & (d4 <= d3), b)
+        put((vc <= 0) & (d1 >= 0) & (d3 <= 0), a + (d1 / (d1 - d3))[:, None] * ab)
+        put((d6 >= 0) & (d5 <= d6), c)
+        put((vb <= 0) & (d2 >= 0) & (d6 <= 0), a + (d2 / (d2 - d6))[:, None] * ac)
+        put((va <= 0) & ((d4 - d3) >= 0) & ((d5 - d6) >= 0), b + ((d4 - d3) / ((d4 - d3) + (d5 - d6)))[:, None] * (c - b))
+        den = va + vb + vc
+        v, w = vb / den, vc / den
+        put(np.ones(len(p), bool), a + v[:, None] * ab + w[:, None] * ac)
+    return out
+
+
+def trimesh_closest(hf, hscale, vscale, slope_threshold, pts, reach=2):
+    """Closest point of the (corrected) triangle mesh to every point of pts [n, 3] (grid frame), searched over the cells within `reach` of
+    the point's own cell -> (distance [n], closest point [n, 3]).  The yardstick for HeightfieldGround::contact's riser walls."""
+    xx, yy, zz = trimesh_vertices(hf, hscale, vscale, slope_threshold)
+    rows, cols = zz.shape
+    pts = np.asarray(pts, np.float64)
+    ci = np.clip(np.floor(pts[:, 0] / hscale).astype(int), 0, rows - 2)
+    cj = np.clip(np.floor(pts[:, 1] / hscale).astype(int), 0, cols - 2)
+    best = np.full(len(pts), np.inf)
+    bestp = np.zeros_like(pts)
+    for di in range(-reach, reach + 1):
+        for dj in range(-reach, reach + 1):
+            i = np.clip(ci + di, 0, rows - 2); j = np.clip(cj + dj, 0, cols - 2)
+            for tri in (((0, 0), (1, 1), (1, 0)), ((0, 0), (0, 1), (1, 1))):
+                v = [np.stack([xx[i + a, j + b], yy[i + a, j + b], zz[i + a, j + b]], axis=1) for a, b in tri]
+                q = _closest_on_triangle(pts, v[0], v[1], v[2])
+                d = np.linalg.norm(pts - q, axis=1)
+                better = d < best
+                best = np.where(better, d, best)
+                bestp[better] = q[better]
+    return best, bestp

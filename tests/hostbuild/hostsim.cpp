@@ -111,6 +111,14 @@ static void run_mw(const SimParams* P, int nenv, float* state, const float* tau,
 // slope correction of the height-field ground for the terrain entries below: slope_threshold * hscale / vscale (raw units), <= 0 = off
 static float g_slope_thr = 3.0e38f;
 extern "C" void hs_set_slope_threshold(float thr_raw) { g_slope_thr = thr_raw > 0.f ? thr_raw : 3.0e38f; }
+static int g_walls = 1;     // risers collide from the side (HeightfieldGround::contact)
+extern "C" void hs_set_walls(int on) { g_walls = on; }
+// the contact query by itself (tests/test_terrain.py)
+extern "C" void hs_ground_contact(const short* hs, int rows, int cols, float hscale, float vscale, float border, float x, float y, float z, float r,
+                                  float* dist, float* n) {
+    const HeightfieldGround g{hs, rows, cols, hscale, vscale, border, g_slope_thr, g_walls};
+    g.contact(x, y, z, r, dist, n);
+}
 #ifdef HOSTSIM_ANT
 extern "C" int hs_step_mw_ant(const SimParams* P, int nenv, float* state, const float* tau, float* out) {
     const PlaneGround g{};
@@ -121,7 +129,7 @@ extern "C" int hs_step_mw_ant(const SimParams* P, int nenv, float* state, const 
 #ifdef HOSTSIM_ANYMAL
 extern "C" int hs_step_mw_terrain(const SimParams* P, int nenv, float* state, const float* tau, float* out, const short* hs, int rows,
                                   int cols, float hscale, float vscale, float border, const float* mu, float* netf) {
-    const HeightfieldGround g{hs, rows, cols, hscale, vscale, border, g_slope_thr};
+    const HeightfieldGround g{hs, rows, cols, hscale, vscale, border, g_slope_thr, g_walls};
     run_mw<ModelAnymal, HeightfieldGround>(P, nenv, state, tau, out, &g, mu, netf);
     return 0;
 }
@@ -284,7 +292,7 @@ extern "C" int hs_step_terrain(const char* model, const SimParams* P, int nenv, 
     using M = ModelAnymal;
     constexpr int ND = M::ND, NSPH = M::NSPH, NSENS = M::NSENS;
     const int ss = 13 + 2 * ND + 3 * NSPH + ND, os = 6 * NSENS + ND + 3 * NSPH;
-    const HeightfieldGround g{hs, rows, cols, hscale, vscale, border, g_slope_thr};
+    const HeightfieldGround g{hs, rows, cols, hscale, vscale, border, g_slope_thr, g_walls};
 #pragma omp parallel for schedule(static)
     for (int e = 0; e < nenv; ++e) {
         float* s = state + (size_t)e * ss;

@@ -260,3 +260,35 @@ def test_ant_post_physics_step_fused_into_the_last_sub_step_is_bit_identical(n):
     assert resets > 0
     sa, sb = a.engine.tensors["episode_stats"], b.engine.tensors["episode_stats"]
     assert torch.allclose(sa, sb, rtol=1e-4)            # (sums of atomics: the order differs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("task,n,na", [("Ant", 4096, 8), ("Ant", 200, 8), ("AnymalTerrain", 1024, 12), ("AnymalTerrain", 200, 12)])
+def test_all_sub_steps_of_a_control_step_in_one_launch_are_bit_identical(task, n, na):
+    """Option fused_sub = 1 (csrc/mw_kernels.hpp substep_mw_fused_kernel): the sub-steps of a control step (Ant: 2 sub-steps of
+    gym.simulate, vec_task.py:379-382; AnymalTerrain: 4 decimation steps with the PD torques re-evaluated + the base class's simulate,
+    anymal_terrain.py:443-451) run inside ONE launch, the joint state / efforts staying in registers, the warm-start impulses in the LDS
+    row store and the root state crossing LDS between them.  Same arithmetic as one launch per sub-step: observations, rewards, resets
+    and every state / output tensor are bit-identical over a rollout with resets."""
+    import isaacgymenvs_amd
+    a = isaacgymenvs_amd.make(seed=5, task=task, num_envs=n, sim_device=DEV, rl_device=DEV, headless=True)
+    b = isaacgymenvs_amd.make(seed=5, task=task, num_envs=n, sim_device=DEV, rl_device=DEV, headless=True)
+    assert int(a.engine.get_option("multi_wave")) in (16, 32)
+    a.engine.set_option("fused_sub", 1); b.engine.set_option("fused_sub", 0)
+    if task == "Ant":
+        a.engine.set_option("fused_post", 0); b.engine.set_option("fused_post", 0)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    resets = 0
+    for step in range(150):
+        act = torch.rand((n, na), device=DEV, generator=g) * 2 - 1
+        oa, ra, da, _ = a.step(act)
+        ob, rb, db, _ = b.step(act)
+        assert torch.equal(oa["obs"], ob["obs"]) and torch.equal(ra, rb) and torch.equal(da, db), step
+        resets += int(da.sum())
+    names = ["root_states", "dof_state", "contact_impulse", "limit_impulse", "dof_actuation_force", "dof_force", "progress_buf"]
+    names += ["force_sensor"] if task == "Ant" else ["net_contact_force"]
+    for k in names:
+        if k in a.engine.tensors:
+            assert torch.equal(a.engine.tensors[k], b.engine.tensors[k]), k
+    assert resets > 0 or task != "Ant"
+

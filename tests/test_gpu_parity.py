@@ -596,6 +596,28 @@ def test_anymal_terrain_slope_threshold_reaches_the_ground_query():
     assert d.max() < 0.5
 
 
+def test_anymal_terrain_walls_option_and_side_contact():
+    """Option `terrain_walls` (default 1): the vertical faces of the slope-corrected triangle mesh (anymal_terrain.py:198-211, :576) collide
+    from the side (csrc/core/engine.hpp HeightfieldGround::contact).  Robots driven forward over stairs / obstacles for a while: with the walls
+    on some of them feel a horizontal net contact force on a shank that no floor contact of a standing robot produces, the runs with and
+    without walls part ways, and both stay finite.  (The geometry and the blocking itself are pinned on the CPU: tests/test_terrain.py.)"""
+    n = 1024
+    env = _make_env("AnymalTerrain", n, seed=9)
+    assert int(env.engine.get_option("terrain_walls")) == 1
+    other = _make_env("AnymalTerrain", n, seed=9)
+    other.engine.set_option("terrain_walls", 0)
+    assert int(other.engine.get_option("terrain_walls")) == 0
+    g = torch.Generator(device=DEV).manual_seed(3)
+    for step in range(150):
+        a = torch.rand((n, 12), device=DEV, generator=g) * 2 - 1
+        env.step(a); other.step(a)
+    torch.cuda.synchronize()
+    ra, rb = env.root_states.cpu().numpy(), other.root_states.cpu().numpy()
+    assert np.isfinite(ra).all() and np.isfinite(rb).all()
+    assert (np.abs(ra[:, :3] - rb[:, :3]).max(axis=1) > 1e-3).mean() > 0.02          # risers were met from the side
+    assert float(env.contact_forces.abs().max()) < 2e4
+
+
 def test_anymal_terrain_full_size_properties():
     n = 4096   # BASELINE configs[3]: AnymalTerrain num_envs=4096
     env = _make_env("AnymalTerrain", n, seed=42)

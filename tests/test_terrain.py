@@ -181,3 +181,121 @@ def test_oracle_ground_query_applies_the_slope_threshold():
         assert abs(np.linalg.norm(nrm) - 1) < 1e-12 and nrm[2] > 0
     np.testing.assert_allclose(got, snapped_height(hf, hs, vs, 0.5, px, py), atol=1e-12)
     assert np.abs(np.array(got) - snapped_height(hf, hs, vs, None, px, py)).max() > 0.05
+
+
+def _contact(eng_ground, lib, creal, x, y, z, r):
+    import ctypes as C
+    d = creal(0.0); n = (creal * 3)()
+    lib.or_ground_contact(C.byref(eng_ground), creal(0.0), creal(x), creal(y), creal(z), creal(r), C.byref(d), n)
+    return d.value, np.array(list(n))
+
+
+def test_riser_walls_of_the_corrected_mesh_collide_from_the_side():
+    """The slope-corrected triangle mesh the reference hands to PhysX (anymal_terrain.py:198-211, :576) has vertical faces where a stair rises;
+    feet meet them from the side.  The engine's ground is the height field itself: HeightfieldGround::contact / oracle ground_contact add the
+    wall of a riser in the sphere's own cell as a contact candidate.  Checked here against the restated mesh (oracle/terrain_mesh.py
+    trimesh_closest, exact point-to-triangle distances): beside a riser, clear of tread and top edge, distance and normal are the mesh's;
+    above the top, far from the wall, or with the walls switched off the contact is the surface below; host build == oracle."""
+    import ctypes as C
+    from oracle.engine import OracleEngine
+    from isaacgymenvs_amd.registry import load_model
+    from oracle.terrain_mesh import trimesh_closest
+    from tests.hostbuild import hostsim
+    rows, cols, hs, vs, border, r = 40, 36, 0.1, 0.005, 0.0, 0.03
+    ii, jj = np.meshgrid(np.arange(rows), np.arange(cols), indexing="ij")
+    hf = (np.maximum(np.abs(ii - 20) // 4, np.abs(jj - 18) // 4) * 30).astype(np.int16)      # a pit of square 15 cm stairs: walls in +-x and +-y
+    eng = OracleEngine(load_model("anymal"), 1, precision="f64")
+    eng.set_ground(hf, hs, vs, border, slope_threshold=0.5)
+    lib = eng.lib
+    lib.or_ground_contact.restype = None
+    rng = np.random.default_rng(5)
+    n = 4000
+    px = rng.uniform(3 * hs, (rows - 4) * hs, n); py = rng.uniform(3 * hs, (cols - 4) * hs, n)
+    # heights between the tread below (+ r + 1 cm: the tread is not the nearer surface) and the riser's top (- 1 cm)
+    ci, cj = np.floor(px / hs).astype(int), np.floor(py / hs).astype(int)
+    low = np.minimum(np.minimum(hf[ci, cj], hf[ci + 1, cj]), np.minimum(hf[ci, cj + 1], hf[ci + 1, cj + 1])) * vs
+    pz = low + r + 0.01 + rng.uniform(0, 0.15 - r - 0.02, n)
+    dist, closest = trimesh_closest(hf, hs, vs, 0.5, np.stack([px, py, pz], 1))
+    side = 0
+    for k in range(n):
+        d, nrm = _contact(eng.ground, lib, C.c_double, px[k], py[k], pz[k], r)
+        to_mesh = np.array([px[k], py[k], pz[k]]) - closest[k]
+        horizontal = abs(to_mesh[2]) < 1e-9 and dist[k] > 1e-6
+        c = hf[ci[k]:ci[k] + 2, cj[k]:cj[k] + 2].astype(int)
+        clean = (c[0, 0] == c[0, 1] and c[1, 0] == c[1, 1]) or (c[0, 0] == c[1, 0] and c[0, 1] == c[1, 1])   # a straight riser crosses the cell
+        if horizontal and dist[k] - r < 0.02 and clean:      # the mesh's nearest feature is a wall face within the contact range
+            # (corner cells, where the corrected mesh folds two walls into one cell, are modelled as one full wall: not compared)
+            side += 1
+            assert abs(d - (dist[k] - r)) < 1e-9, (k, d, dist[k] - r)
+            np.testing.assert_allclose(nrm, to_mesh / dist[k], atol=1e-9)
+        elif abs(nrm[2]) < 0.5 and clean and d < 0.02:                    # a wall contact of ours in a straight-riser cell: the mesh has that wall, at that distance
+            assert abs(d - (dist[k] - r)) < 1e-9
+    assert side > 150
+    # above the risers' tops, or with the walls off, the contact is the surface below (normal z > 0)
+    for k in range(200):
+        d, nrm = _contact(eng.ground, lib, C.c_double, px[k], py[k], 0.15 * 6 + 0.2, r)
+        assert nrm[2] > 0.5
+    eng.set_ground(hf, hs, vs, border, slope_threshold=0.5, walls=False)
+    for k in range(400):
+        d, nrm = _contact(eng.ground, lib, C.c_double, px[k], py[k], pz[k], r)
+        assert nrm[2] > 0.5
+    eng.set_ground(hf, hs, vs, border, slope_threshold=0.5)
+    # the fp32 host build of the engine's header agrees with the oracle
+    hl = hostsim.build()
+    hl.hs_set_slope_threshold.argtypes = [C.c_float]; hl.hs_set_slope_threshold.restype = None
+    hl.hs_set_slope_threshold(0.5 * hs / vs)
+    hl.hs_ground_contact.restype = None
+    hfc = np.ascontiguousarray(hf)
+    for k in range(600):
+        d, nrm = _contact(eng.ground, lib, C.c_double, px[k], py[k], pz[k], r)
+        df = C.c_float(0); nf = (C.c_float * 3)()
+        hl.hs_ground_contact(hfc.ctypes.data_as(C.c_void_p), rows, cols, C.c_float(hs), C.c_float(vs), C.c_float(border), C.c_float(px[k]),
+                             C.c_float(py[k]), C.c_float(pz[k]), C.c_float(r), C.byref(df), nf)
+        if abs(d - df.value) > 1e-4:      # (a point within fp32 rounding of a cell boundary may sit in the other cell)
+            gx, gy = px[k] / hs, py[k] / hs
+            assert min(abs(gx - round(gx)), abs(gy - round(gy))) < 1e-4
+            continue
+        np.testing.assert_allclose(np.array(list(nf)), nrm, atol=1e-5)
+    hl.hs_set_slope_threshold(0.0)
+
+
+def test_a_riser_stops_a_walking_foot_from_the_side():
+    """Dynamics of the wall contact in the oracle's physics (the GPU kernels follow it, tests/test_gpu_*): an ANYmal holding its default pose
+    runs at 1 m/s into a 25 cm riser.  With the walls (default) its front feet stop at the riser's face -- never deeper than a few
+    millimetres --, the net contact force on the front shanks points back and the robot stays on its feet; with `terrain_walls` off the feet
+    pass through the face and are thrown out from below."""
+    from oracle.engine import OracleEngine
+    from isaacgymenvs_amd.registry import load_model
+    spec = load_model("anymal")
+    rows, cols, hs, vs, border = 80, 40, 0.1, 0.005, 0.0
+    hf = np.zeros((rows, cols), np.int16)
+    hf[40:, :] = 50                                         # tread at 0.25 m from x = 4.0 on: the riser's wall stands at x = 4.0
+    q0 = np.array([0.03, 0.4, -0.8, -0.03, 0.4, -0.8, 0.03, -0.4, 0.8, -0.03, -0.4, 0.8])      # AnymalTerrain.yaml defaultJointAngles, dof order
+    sim = dict(dt=0.005, substeps=1, iters=5, gravity=(0.0, 0.0, -9.81), contact_offset=0.02, rest_offset=0.0, max_depen_vel=100.0, erp=0.5,
+               plane_mu=1.0, ground_z=0.0, cfm=1e-6, warm=1.0)
+    feet = [k for k in range(len(spec.sph_body)) if spec.body_names[spec.sph_body[k]].endswith("SHANK")]
+    sph_pos = np.array(spec.sph_pos).reshape(-1, 3)
+    deepest, back_force, lowest = {}, {}, {}
+    for walls in (True, False):
+        eng = OracleEngine(spec, 1, params=sim, precision="f64")
+        eng.set_ground(hf, hs, vs, border, slope_threshold=0.5, walls=walls)
+        eng.root[:] = 0; eng.root[0, :3] = (3.5, 2.05, 0.57); eng.root[0, 6] = 1.0; eng.root[0, 7] = 1.0
+        eng.q[:] = q0; eng.qd[:] = 0
+        deep, fx, zmin = -1.0, 0.0, 1.0
+        for it in range(240):
+            tau = np.clip(80.0 * (q0 - eng.q) - 2.0 * eng.qd, -80, 80)
+            eng.step(tau, env_mu=np.ones(1))
+            bp = eng.energy(0, poses=True)[2]
+            for k in feet:
+                b = spec.sph_body[k]
+                c = bp[b, :3] + bp[b, 3:12].reshape(3, 3) @ sph_pos[k]
+                if c[2] < 0.25 - 0.01:                       # below the top of the riser
+                    deep = max(deep, c[0] + spec.sph_rad[k] - 4.0)
+            fx = min(fx, min(eng.netf[0, spec.body_names.index(n), 0] for n in ("LF_SHANK", "RF_SHANK")))
+            zmin = min(zmin, eng.root[0, 2])
+        deepest[walls], back_force[walls], lowest[walls] = deep, fx, zmin
+        assert np.isfinite(eng.root).all()
+    assert -0.02 < deepest[True] < 0.006, deepest            # the feet reach the face and stay out of it (measured 1.3 mm)
+    assert deepest[False] > 0.03, deepest                    # no walls: through the face (7.7 cm)
+    assert back_force[True] < -50.0, back_force              # (-231 N)
+    assert lowest[True] > 0.4 and lowest[False] < 0.35, lowest   # stays on its feet / is thrown over
