@@ -267,37 +267,44 @@ struct HeightfieldGround {
         locate(x, y, &fx, &fy, h);
         surface(h, fx, fy, &zt, n, hx);
         float d = (z - zt) * n[2] - r;
-        const bool won = walls != 0;
-        float dw = 1e30f, nwx = 0.f, nwy = 0.f, nwz = 0.f;     // the nearer wall candidate: the wall's face, above its top the top's edge
-        {   // x walls, raw heights
-            const bool s0 = fabsf(h[1] - h[0]) > thr, s1 = fabsf(h[3] - h[2]) > thr, up0 = h[1] > h[0], up1 = h[3] > h[2];
-            const float t0 = up0 ? h[1] : h[0], t1 = up1 ? h[3] : h[2];
-            const float top = (t0 + (t1 - t0) * fy) * vscale;
-            const float dx = (up0 ? 1.f - fx : fx) * hscale, dz = fmaxf(z - top, 0.f);
-            const float len = sqrtf(dx * dx + dz * dz), il = 1.f / fmaxf(len, 1e-12f);
-            const bool use = won && s0 && s1 && (up0 == up1) && (len - r < dw);
-            dw = use ? len - r : dw;
-            nwx = use ? (up0 ? -dx : dx) * il : nwx; nwz = use ? dz * il : nwz;
+#if !defined(MI_NO_TERRAIN_WALLS)   // (measurement builds only)
+        // (branch-free on purpose: a wave-uniform skip of the wall block when no env is inside a steep cell made the fused AnymalTerrain
+        //  sub-step kernel 101 -> 139 us: the block is short, the branch breaks the schedule around every sphere)
+        const bool s0 = fabsf(h[1] - h[0]) > thr, s1 = fabsf(h[3] - h[2]) > thr, ux0 = h[1] > h[0], ux1 = h[3] > h[2];
+        const bool s2 = fabsf(hx[2] - hx[0]) > thr, s3 = fabsf(hx[3] - hx[1]) > thr, uy0 = hx[2] > hx[0], uy1 = hx[3] > hx[1];
+        const bool wx = (walls != 0) && s0 && s1 && (ux0 == ux1), wy = (walls != 0) && s2 && s3 && (uy0 == uy1);
+        {
+            float dw = 1e30f, nwx = 0.f, nwy = 0.f, nwz = 0.f;     // the nearer wall candidate: the wall's face, above its top the top's edge
+            {   // x walls, raw heights
+                const float t0 = ux0 ? h[1] : h[0], t1 = ux1 ? h[3] : h[2];
+                const float top = (t0 + (t1 - t0) * fy) * vscale;
+                // (below the top -- and up to 0.1 mm above it -- the normal is EXACTLY +-x: the output stage re-derives the contact frame from the
+                //  normal's x, y parked in the row store, and a normal that is x only to rounding would pick the other tangent pair there)
+                const float dx = (ux0 ? 1.f - fx : fx) * hscale, dzr = z - top, dz = dzr > 1e-4f ? dzr : 0.f;
+                const float l2 = dx * dx + dz * dz, il = MI_RSQ(fmaxf(l2, 1e-24f)), len = dz > 0.f ? l2 * il : dx;
+                const bool use = wx && (len - r < dw);
+                dw = use ? len - r : dw;
+                nwx = use ? (dz > 0.f ? (ux0 ? -dx : dx) * il : (ux0 ? -1.f : 1.f)) : nwx; nwz = use ? dz * il : nwz;
+            }
+            {   // y walls, x-levelled heights
+                const float t0 = uy0 ? hx[2] : hx[0], t1 = uy1 ? hx[3] : hx[1];
+                const float top = (t0 + (t1 - t0) * fx) * vscale;
+                const float dy = (uy0 ? 1.f - fy : fy) * hscale, dzr = z - top, dz = dzr > 1e-4f ? dzr : 0.f;
+                const float l2 = dy * dy + dz * dz, il = MI_RSQ(fmaxf(l2, 1e-24f)), len = dz > 0.f ? l2 * il : dy;
+                const bool use = wy && (len - r < dw);
+                dw = use ? len - r : dw;
+                nwx = use ? 0.f : nwx; nwy = use ? (dz > 0.f ? (uy0 ? -dy : dy) * il : (uy0 ? -1.f : 1.f)) : nwy; nwz = use ? dz * il : nwz;
+            }
+            // inside both the surface below and a wall: one contact along the summed penetrations; else the nearer of the two
+            const bool both = (d < 0.f) && (dw < 0.f), wall = !both && (dw < d);
+            const float vx = -d * n[0] - dw * nwx, vy = -d * n[1] - dw * nwy, vz = -d * n[2] - dw * nwz;
+            const float L2 = vx * vx + vy * vy + vz * vz, iL = MI_RSQ(fmaxf(L2, 1e-30f));
+            n[0] = both ? vx * iL : (wall ? nwx : n[0]);
+            n[1] = both ? vy * iL : (wall ? nwy : n[1]);
+            n[2] = both ? vz * iL : (wall ? nwz : n[2]);
+            d = both ? -L2 * iL : (wall ? dw : d);
         }
-        {   // y walls, x-levelled heights
-            const bool s2 = fabsf(hx[2] - hx[0]) > thr, s3 = fabsf(hx[3] - hx[1]) > thr, up0 = hx[2] > hx[0], up1 = hx[3] > hx[1];
-            const float t0 = up0 ? hx[2] : hx[0], t1 = up1 ? hx[3] : hx[1];
-            const float top = (t0 + (t1 - t0) * fx) * vscale;
-            const float dy = (up0 ? 1.f - fy : fy) * hscale, dz = fmaxf(z - top, 0.f);
-            const float len = sqrtf(dy * dy + dz * dz), il = 1.f / fmaxf(len, 1e-12f);
-            const bool use = won && s2 && s3 && (up0 == up1) && (len - r < dw);
-            dw = use ? len - r : dw;
-            nwx = use ? 0.f : nwx; nwy = use ? (up0 ? -dy : dy) * il : nwy; nwz = use ? dz * il : nwz;
-        }
-        // inside both the surface below and a wall: one contact along the summed penetrations; else the nearer of the two
-        const bool both = (d < 0.f) && (dw < 0.f), wall = !both && (dw < d);
-        const float vx = -d * n[0] - dw * nwx, vy = -d * n[1] - dw * nwy, vz = -d * n[2] - dw * nwz;
-        const float L = sqrtf(vx * vx + vy * vy + vz * vz);
-        const float iL = 1.f / (both ? L : 1.f);
-        n[0] = both ? vx * iL : (wall ? nwx : n[0]);
-        n[1] = both ? vy * iL : (wall ? nwy : n[1]);
-        n[2] = both ? vz * iL : (wall ? nwz : n[2]);
-        d = both ? -L : (wall ? dw : d);
+#endif
         *dist = d;
     }
 };

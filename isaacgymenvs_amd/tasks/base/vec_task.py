@@ -437,7 +437,32 @@ class VecTask(Env):
         return float(np.mean(arr)) if len(arr) else 0.0
 
     def render(self, mode="rgb_array"):
-        return None  # headless engine (viewer is out of scope)
+        """Reference vec_task.py:457-512 draws Isaac Gym's OpenGL viewer and, for `rgb_array`, grabs the virtual display.  Here the frame is
+        rasterised on the host from the rigid-body state tensor of ONE env (`env.viewerEnv`, default 0) by utils/viewer.py: returned as a
+        uint8 [H, W, 3] array for mode "rgb_array" (whenever `virtual_screen_capture` or `force_render` asked for frames, or the call is
+        made explicitly with that mode), written to `record_frames_dir/frame_<control step>.png` while `record_frames` is set (the viewer's
+        `record_frames` key event, :471-472,503-507).  Headless runs that never call it pay nothing: the body states are refreshed here."""
+        if mode not in ("rgb_array", "human"):
+            raise ValueError(f"render mode {mode!r}: 'human' or 'rgb_array'")
+        if mode == "human" and not self.record_frames:
+            return None                                   # no window to draw into
+        from ...utils.viewer import SoftwareViewer, write_png
+        if getattr(self, "_soft_viewer", None) is None:
+            vc = self.cfg["env"].get("viewer", {}) or {}
+            self._soft_viewer = SoftwareViewer(width=vc.get("width", 640), height=vc.get("height", 480))
+            self._viewer_env = int(self.cfg["env"].get("viewerEnv", 0))
+        spec = self._dr_model()
+        self.engine.refresh_rigid_body_states()
+        bs = self.engine.tensors["rigid_body_state"][self._viewer_env].detach().cpu().numpy().astype(np.float64)
+        centres, radii, colours = self._soft_viewer.spheres_of(spec, bs)
+        if hasattr(self, "env_origins") and "Terrain" in type(self).__name__:
+            self._soft_viewer.ground_z = float(self.env_origins[self._viewer_env, 2])
+        img = self._soft_viewer.draw(centres, radii, colours, focus=bs[0, :3])
+        if self.record_frames:
+            d = getattr(self, "record_frames_dir", os.path.join("recorded_frames", type(self).__name__))
+            os.makedirs(d, exist_ok=True)
+            write_png(os.path.join(d, f"frame_{self.control_steps}.png"), img)
+        return img if mode == "rgb_array" else None
 
     # ------------------------------------------------------------------ physics-state checkpointing
     def get_env_state(self):

@@ -403,7 +403,7 @@ static void ground_contact(const OrGround *g, real ground_z, real x, real y, rea
         if (s0 && s1 && up0 == up1) {
             real t0 = up0 ? h10 : h00, t1 = up1 ? h11 : h01;
             real top = (t0 + (t1 - t0) * fy) * g->vscale;
-            real dx = (up0 ? 1 - fx : fx) * g->hscale, dz = z > top ? z - top : 0;     /* above the top: its edge */
+            real dx = (up0 ? 1 - fx : fx) * g->hscale, dz = z - top > 1e-4 ? z - top : 0;     /* above the top (by more than 0.1 mm): its edge */
             real len = RSQRT(dx * dx + dz * dz), il = 1 / (len > 1e-12 ? len : 1e-12);
             if (len - r < dw) { dw = len - r; nw[0] = (up0 ? -dx : dx) * il; nw[1] = 0; nw[2] = dz * il; }
         }
@@ -416,7 +416,7 @@ static void ground_contact(const OrGround *g, real ground_z, real x, real y, rea
         if (s2 && s3 && up0 == up1) {
             real t0 = up0 ? h01 : h00, t1 = up1 ? h11 : h10;
             real top = (t0 + (t1 - t0) * fx) * g->vscale;
-            real dy = (up0 ? 1 - fy : fy) * g->hscale, dz = z > top ? z - top : 0;
+            real dy = (up0 ? 1 - fy : fy) * g->hscale, dz = z - top > 1e-4 ? z - top : 0;
             real len = RSQRT(dy * dy + dz * dz), il = 1 / (len > 1e-12 ? len : 1e-12);
             if (len - r < dw) { dw = len - r; nw[0] = 0; nw[1] = (up0 ? -dy : dy) * il; nw[2] = dz * il; }
         }

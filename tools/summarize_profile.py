@@ -118,9 +118,11 @@ for k, v in d.items():
 
 # ---- one control step per task = these launches (pattern, launches per step)
 RECIPE = {
-    "Ant@4096": [(r"substep(_mw)?_kernel<ModelAnt", 2), (r"loco_post_kernel<ModelAnt", 1)],
+    # (a fused-sub-step kernel, when the trace has one, is the step's ONE physics launch: option fused_sub, csrc/mw_kernels.hpp)
+    "Ant@4096": [(r"substep_mw_fused_kernel<ModelAnt|substep(_mw)?_kernel<ModelAnt", {"fused": 1, "plain": 2}), (r"loco_post_kernel<ModelAnt", 1)],
     "Humanoid@8192": [(r"substep_(sc2_|mwc_)?kernel<ModelHumanoid", 2), (r"loco_post_kernel<ModelHumanoid", 1)],
-    "AnymalTerrain@4096": [(r"substep(_mw)?_kernel<ModelAnymal, mi::HeightfieldGround", 5), (r"anymal_post_kernel", 1), (r"anymal_heights_kernel", 1),
+    "AnymalTerrain@4096": [(r"substep_mw_fused_kernel<ModelAnymal, mi::HeightfieldGround|substep(_mw)?_kernel<ModelAnymal, mi::HeightfieldGround", {"fused": 1, "plain": 5}),
+                           (r"anymal_post_kernel", 1), (r"anymal_heights_kernel", 1),
                            (r"anymal_cmdnorm_kernel", 1)],
     "ShadowHand@16384": [(r"hand_pre_kernel", 1), (r"hand_substep(_mw64|_mw)?_kernel<0>", 2), (r"hand_tips_kernel", 1), (r"hand_post_kernel", 1),
                          (r"hand_finalize_kernel", 1)],
@@ -132,8 +134,11 @@ out.append("|---|---|---|---|---|")
 for task, recipe in RECIPE.items():
     tot_b, tot_v, tot_t, names = 0.0, 0.0, 0.0, []
     for pat, cnt in recipe:
-        for k in traffic:
+        keys = sorted(traffic, key=lambda k: "fused" not in k)       # a fused kernel first
+        for k in keys:
             if re.search(pat, k):
+                if isinstance(cnt, dict):
+                    cnt = cnt["fused" if "fused" in k else "plain"]
                 tot_b += cnt * traffic[k]["bytes"]; tot_v += cnt * valu.get(k, 0.0); tot_t += cnt * dur_ns.get(k, 0.0) / 1e3
                 names.append(f"{cnt} x {k.split('<')[0].replace('mi::', '')}")
                 break
