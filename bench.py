@@ -142,6 +142,10 @@ def measure(task, num_envs, steps, warmup, device, rank, world, seed=42, pool=8,
         "reset_rate": stats[2] / max(stats[4], 1.0), "mean_reward": stats[3] / max(stats[4], 1.0),
         "multi_wave": int(env.engine.get_option("multi_wave")), "steps": steps, "warmup": warmup, "settle": settle,
     }
+    try:
+        res["fused_sub"] = int(env.engine.get_option("fused_sub"))     # all sub-steps of a control step in one launch (Ant, AnymalTerrain)
+    except RuntimeError:
+        res["fused_sub"] = 0
     res["consistent"] = bool(leg_consistent(res))
     if task == "Humanoid":
         res["self_collision"] = int(env.engine.get_option("self_collision"))
@@ -166,7 +170,8 @@ def roofline(task, num_envs, kernel_ms, mw=0):
         shape = "%d waves of %d envs, one per SIMD%s" % ((num_envs + lanes - 1) // lanes, lanes, " (two resident per CU)" if task == "ShadowHand" else "")
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
            "traffic": tr.get("traffic_bytes_per_step"), "traffic_source": tr.get("source"),
-           "kernel": "one control step = physics sub-step kernel x sim steps + post kernel(s) (%s)" % task,
+           "kernel": "one control step = physics sub-step kernel x sim steps (Ant / AnymalTerrain: ONE launch that loops over them, option "
+                     "fused_sub) + post kernel(s) (%s)" % task,
            "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
            "note": "latency / issue-bound path, not HBM-bound: %s; see DESIGN.md 6" % shape}
     if tr.get("valu_wave_insts_per_step"):
@@ -370,7 +375,7 @@ def main():
         "config": {"workload": f"{args.task} num_envs={n_env} per GPU ({world * n_env} total), VecTask.step() via Python API, "
                                f"actions = 2*torch.rand-1 drawn before every step (README.md:48-51), seed 42+rank",
                    "task": args.task, "num_envs_per_gpu": n_env, "parallelism": f"env-shard x{world}",
-                   "multi_wave": main_res["multi_wave"]},
+                   "multi_wave": main_res["multi_wave"], "fused_sub": main_res["fused_sub"]},
         "settle": settle, "consistent": main_res["consistent"],
         "gpu_ms_per_step": main_res["gpu_ms_per_step"], "reset_rate": main_res["reset_rate"],
         "mean_reward": main_res["mean_reward"], "pooled": main_res["pooled"],
