@@ -182,6 +182,31 @@ def roofline(task, num_envs, kernel_ms, mw=0):
     return out
 
 
+def box_probe(device):
+    """Which kind of box this line comes from (the boxes of one pool differ by up to 1.5x on the engine's kernels, profiles/r3z_box_probe.txt):
+    the two things the step kernels are bound by, measured by mi_device_probe (csrc/mi_engine.hip) outside the timed region -- the time of
+    1000 dependent FMAs on one wave (issue rate of a lone wave; the same with a wave on every SIMD: the clocks under load) and the latency of dependent loads through a 256 MB buffer."""
+    import ctypes as C
+    import torch
+    from isaacgymenvs_amd import native
+    try:
+        L = native.lib()
+        nbytes = 256 << 20
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        out2 = (C.c_float * 6)()
+        L.mi_device_probe.argtypes = [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p]
+        rc = L.mi_device_probe(C.c_void_p(scratch.data_ptr()), nbytes, 2_000_000, 20_000, out2, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        if rc != 0:
+            return {"error": L.mi_last_error().decode()}
+        return {"us_per_1000_dependent_fma": round(float(out2[0]), 4), "us_per_1000_dependent_fma_all_simds_busy": round(float(out2[2]), 4),
+                "ns_per_dependent_load_256MB": round(float(out2[1]), 1), "ns_per_workgroup_barrier_4_waves": round(float(out2[3]), 1),
+                "ns_per_dependent_lds_read": round(float(out2[4]), 2), "ns_per_dependent_rcp_sin_pair": round(float(out2[5]), 2),
+                "note": "one wave / one lane probes, outside the timed region; compare lines only between boxes with like values"}
+    except Exception as e:      # noqa: BLE001 -- a measurement aid must not take the benchmark line down
+        return {"error": repr(e)}
+
+
 def reference_jit_leg(task, num_envs, budget_s=4.0):
     """the reference's OWN jitted compute_*_observations + compute_*_reward on torch-CPU, for the obs / reward share of
     its CPU pipeline.  Only where /root/reference is reachable (the development container); absent on the GPU box."""
@@ -407,6 +432,7 @@ def main():
                          "roofline": roofline("ShadowHand", side["ShadowHand"], extra3["kernel_ms_avg"], extra3["multi_wave"])}
         if "job_stats" in extra3:
             out["extra3"]["job_stats"] = extra3["job_stats"]
+    out["box"] = box_probe(device)
     if world == 1 and not args.no_cpu_baseline and args.task in ("Ant", "Humanoid"):
         out["cpu_baseline"] = cpu_baseline(args.task, n_env, budget_s=args.cpu_budget)
         leg = reference_jit_leg(args.task, n_env)

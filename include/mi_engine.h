@@ -470,6 +470,16 @@ int mi_compute_hand_reward_dextreme(int n, const MiDextremeRewardParams* p, floa
                                     const float* object_pos, const float* object_rot, const float* target_pos, const float* target_rot,
                                     const float* actions, int num_actions, float* reward_terms8, float* workspace2, void* stream);
 
+/* Measurement aid (bench.py "box"; no reference counterpart): how fast THIS device runs the two things the step kernels are bound by -- the
+ * issue rate of a lone wave (a chain of `fma_iters` dependent v_fma_f32 on one wave) and the latency of dependent loads (`hops` pointer-chase
+ * steps through a `chase_bytes` buffer, a device scratch buffer of at least that size whose contents are overwritten).  out6[0] = us per
+ * 1000 dependent FMAs on a lone wave, out6[1] = ns per dependent load, out6[2] = us per 1000 dependent FMAs with one such wave on every
+ * SIMD of the chip (the clocks under load), out6[3] = ns per workgroup barrier of a four-wave workgroup with an LDS word exchanged (one
+ * workgroup per CU), out6[4] = ns per dependent LDS read, out6[5] = ns per dependent
+ * v_rcp_f32 + v_sin_f32 pair (a wave on every SIMD); host floats, the call synchronises the stream.  The boxes of one pool differ by up to
+ * 1.5x on the engine's kernels; these two numbers say which kind of box a benchmark line came from. */
+int mi_device_probe(void* scratch, long long chase_bytes, int fma_iters, int hops, float* out6, void* stream);
+
 const char* mi_last_error(void);
 
 #ifdef __cplusplus

@@ -843,3 +843,131 @@ extern "C" int mi_randomize_rotation(int n, const float* rand0, const float* ran
     HIP_OK(hipGetLastError());
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ device probe (bench.py "box")
+namespace {
+__global__ __launch_bounds__(256) void probe_fma_kernel(float* out, int iters, float a, float b) {
+    float x = (float)threadIdx.x * 1e-3f;
+#pragma unroll 16
+    for (int i = 0; i < iters; ++i) x = __builtin_fmaf(x, a, b);       // one dependent v_fma_f32 per iteration
+    out[threadIdx.x] = x;
+}
+__global__ void probe_chase_init_kernel(unsigned* buf, unsigned n, unsigned stride) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) buf[(size_t)i * 16] = (unsigned)(((unsigned long long)i * stride + 1u) % n);   // one hop per 64-byte line, a fixed odd stride: a full cycle
+}
+__global__ __launch_bounds__(64) void probe_chase_kernel(const unsigned* buf, unsigned* out, int hops, unsigned start) {
+    if (threadIdx.x != 0) return;
+    unsigned k = start;
+    for (int i = 0; i < hops; ++i) k = __builtin_nontemporal_load(buf + (size_t)k * 16);
+    out[0] = k;
+}
+// a chain of dependent quarter-rate operations (v_rcp_f32, v_sin_f32: what the tree pass and the fingertip chains are made of)
+__global__ __launch_bounds__(256) void probe_trans_kernel(float* out, int iters) {
+    float x = 0.3f + (float)threadIdx.x * 1e-3f;
+#pragma unroll 8
+    for (int i = 0; i < iters; ++i) x = __builtin_amdgcn_sinf(__builtin_amdgcn_rcpf(x + 1.5f)) + 0.25f;
+    out[blockIdx.x * 256 + threadIdx.x] = x;
+}
+// four waves of a workgroup meeting at `iters` barriers, each exchanging one LDS word per barrier (the limb-per-wave kernels' pattern)
+__global__ __launch_bounds__(256) void probe_barrier_kernel(float* out, int iters) {
+    __shared__ float x[4][64];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    float acc = (float)l;
+    for (int i = 0; i < iters; ++i) {
+        x[w][l] = acc;
+        __syncthreads();
+        acc += x[(w + 1) & 3][l] * 1e-6f;
+        __syncthreads();
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+// a chain of dependent LDS reads on one lane
+__global__ __launch_bounds__(64) void probe_lds_kernel(unsigned* out, int hops) {
+    __shared__ unsigned idx[1024];
+    for (int i = threadIdx.x; i < 1024; i += 64) idx[i] = (unsigned)((i * 389 + 1) & 1023);
+    __syncthreads();
+    unsigned k = threadIdx.x;
+    for (int i = 0; i < hops; ++i) k = idx[k];
+    out[threadIdx.x] = k;
+}
+}  // namespace
+extern "C" int mi_device_probe(void* scratch, long long chase_bytes, int fma_iters, int hops, float* out2 /* [6] */, void* stream) {
+    if (!scratch || !out2 || chase_bytes < 4096 || fma_iters < 1 || hops < 1) return fail("mi_device_probe: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    float* fout = (float*)scratch;
+    float ms = 0.f, best = 1e30f;
+    for (int rep = 0; rep < 4; ++rep) {       // (first launch: code upload, clocks ramping up)
+        HIP_OK(hipEventRecord(e0, s));
+        hipLaunchKernelGGL(probe_fma_kernel, dim3(1), dim3(64), 0, s, fout, fma_iters, 0.999f, 1e-3f);
+        HIP_OK(hipEventRecord(e1, s));
+        HIP_OK(hipEventSynchronize(e1));
+        HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep > 0 && ms < best) best = ms;
+    }
+    out2[0] = best * 1e3f / ((float)fma_iters / 1000.f);
+    // the same chain on one wave per SIMD of the whole chip (256 workgroups x 4 waves): what the clocks do under load
+    best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        HIP_OK(hipEventRecord(e0, s));
+        hipLaunchKernelGGL(probe_fma_kernel, dim3(256), dim3(256), 0, s, fout, fma_iters, 0.999f, 1e-3f);
+        HIP_OK(hipEventRecord(e1, s));
+        HIP_OK(hipEventSynchronize(e1));
+        HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    out2[2] = best * 1e3f / ((float)fma_iters / 1000.f);
+    {   // barrier + LDS exchange round trips of a four-wave workgroup, one workgroup per CU; dependent LDS reads
+        const int bi = 20000;
+        best = 1e30f;
+        for (int rep = 0; rep < 3; ++rep) {
+            HIP_OK(hipEventRecord(e0, s));
+            hipLaunchKernelGGL(probe_barrier_kernel, dim3(256), dim3(256), 0, s, fout, bi);
+            HIP_OK(hipEventRecord(e1, s));
+            HIP_OK(hipEventSynchronize(e1));
+            HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best) best = ms;
+        }
+        out2[3] = best * 1e6f / (2.f * bi);       // ns per barrier
+        best = 1e30f;
+        for (int rep = 0; rep < 3; ++rep) {
+            HIP_OK(hipEventRecord(e0, s));
+            hipLaunchKernelGGL(probe_lds_kernel, dim3(1), dim3(64), 0, s, (unsigned*)scratch, 200000);
+            HIP_OK(hipEventRecord(e1, s));
+            HIP_OK(hipEventSynchronize(e1));
+            HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best) best = ms;
+        }
+        out2[4] = best * 1e6f / 200000.f;         // ns per dependent LDS read
+        best = 1e30f;
+        for (int rep = 0; rep < 3; ++rep) {
+            HIP_OK(hipEventRecord(e0, s));
+            hipLaunchKernelGGL(probe_trans_kernel, dim3(256), dim3(256), 0, s, fout, 200000);
+            HIP_OK(hipEventRecord(e1, s));
+            HIP_OK(hipEventSynchronize(e1));
+            HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best) best = ms;
+        }
+        out2[5] = best * 1e6f / 200000.f;         // ns per dependent (v_add, v_rcp, v_sin, v_add) group, a wave on every SIMD
+    }
+    const unsigned n = (unsigned)(chase_bytes / 64);
+    unsigned stride = (unsigned)(n * 0.6180339887) | 1u;                 // odd: coprime with a power-of-two line count
+    while (n % 2 != 0 && stride > 1 && (n % stride) == 0) stride += 2;
+    hipLaunchKernelGGL(probe_chase_init_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (unsigned*)scratch, n, stride);
+    best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        HIP_OK(hipEventRecord(e0, s));
+        // (every repetition walks another stretch of the cycle: lines no earlier repetition left in a cache)
+        hipLaunchKernelGGL(probe_chase_kernel, dim3(1), dim3(64), 0, s, (const unsigned*)scratch, (unsigned*)scratch + 1, hops,
+                           (unsigned)(((unsigned long long)(rep + 1) * 1000003ull) % n));
+        HIP_OK(hipEventRecord(e1, s));
+        HIP_OK(hipEventSynchronize(e1));
+        HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep > 0 && ms < best) best = ms;
+    }
+    out2[1] = best * 1e6f / (float)hops;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return 0;
+}
