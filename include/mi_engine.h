@@ -264,7 +264,7 @@ int mi_engine_set_terrain(MiEngine* e, const int16_t* height_samples, int rows, 
  * "fused_sub" 0 | 1 (Ant / AnymalTerrain on the limb-per-wave form: all physics sub-steps of a control step -- vec_task.py:379-382,
  * anymal_terrain.py:443-451 -- in one launch, the state staying on chip between them; same buffers; HIP backend only),
  * "steps" (the control-step counter: observation-ring parity and per-step RNG counters; restore it together with the arena),
- * "actor_tensors" 0 | 1 (Ant, Humanoid: whether the sub-step reads the per-env `actor_scale` / `dof_limit_shift` tensors of the
+ * "actor_tensors" 0 | 1 (Ant, Humanoid, Anymal: whether the sub-step reads the per-env `actor_scale` / `dof_limit_shift` tensors of the
  * `actor_params` domain randomisation, vec_task.py:752-828; default 0 = the model's constants, no loads; ShadowHand always reads its own),
  * "terrain_slope_threshold" (AnymalTerrain: terrain.slopeTreshold of the reference's height-field -> triangle-mesh conversion,
  * anymal_terrain.py:576; steeper cell edges are levelled to their lower end in the ground query; 0 = off),

@@ -137,6 +137,12 @@ static void build_layout(int task, int N, Layout& L, View* v, char* base, int no
         const int64_t nb = m.nb;
         o = L.add("net_contact_force", MI_F32, {n, nb, 3}, {1, 3 * n, n}, 3 * nb * n); if (v) v->netf = (float*)P(o);
         o = L.add("commands", MI_F32, {n, 3}, {1, n}, 3 * n); if (v) v->commands = (float*)P(o);
+        // `actor_params` of Anymal.yaml (:121-165): per-env shape friction (negative = the model's own), link mass factors per body, and
+        // the factors of the dof properties `stiffness` / `damping`, which for this task ARE the position drives' gains (anymal.py:203-206);
+        // columns as for Ant / Humanoid: [nb] mass, [nd] damping, [nd] stiffness, [nd] armature.  The URDF has no joint limits: no limit shifts.
+        o = L.add("friction", MI_F32, {n}, {1}, n); if (v) v->friction = (float*)P(o);
+        const int64_t nas = nb + 3 * nd;
+        o = L.add("actor_scale", MI_F32, {n, nas}, {1, n}, nas * n); if (v) { v->actor_scale = (float*)P(o); v->nas = (int)nas; }
     }
     L.off = (L.off + 255) & ~size_t(255);
 }

@@ -538,14 +538,20 @@ static ActParams act_of(const AnymalFlatParams& tp) {
 // PD drive (stiffness / damping set on the dofs, :203-206) is evaluated at every physics sub-step like PhysX does.
 hipError_t launch_step_anymal_flat(const View& v, const SimParams& P, const AnymalFlatParams& tp, const float* actions, int cfi,
                                    hipStream_t s) {
-    hipError_t e = launch_substeps<ModelAnymal, PlaneGroundNF>(v, P, act_of(tp), actions, cfi * P.substeps, ACT_FROM_ACTIONS,
-                                                               ACT_FROM_STORED_ACTIONS, s);
+    // option actor_tensors: the kernel instantiation that reads the `actor_params` factors (kernels_scaled_anymal.hip)
+    hipError_t e = v.actor_scale != nullptr
+                       ? launch_substeps_scaled<ModelAnymal, PlaneGroundNF>(v, P, act_of(tp), actions, cfi * P.substeps,
+                                                                            prepare_actions(v, act_of(tp), actions, ACT_FROM_ACTIONS, s), ACT_FROM_STORED_ACTIONS, s, PlaneGroundNF{})
+                       : launch_substeps<ModelAnymal, PlaneGroundNF>(v, P, act_of(tp), actions, cfi * P.substeps, ACT_FROM_ACTIONS, ACT_FROM_STORED_ACTIONS, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(anymal_flat_post_kernel, dim3((v.N + 63) / 64), dim3(64), 0, s, v, tp);
     return hipGetLastError();
 }
 // gym.simulate() alone: the drive keeps tracking the targets of the last step (stored actions)
 hipError_t launch_simulate_anymal_flat(const View& v, const SimParams& P, const AnymalFlatParams& tp, hipStream_t s) {
+    if (v.actor_scale != nullptr)
+        return launch_substeps_scaled<ModelAnymal, PlaneGroundNF>(v, P, act_of(tp), nullptr, P.substeps, ACT_FROM_STORED_ACTIONS, ACT_FROM_STORED_ACTIONS, s,
+                                                                  PlaneGroundNF{});
     return launch_substeps<ModelAnymal, PlaneGroundNF>(v, P, act_of(tp), nullptr, P.substeps, ACT_FROM_STORED_ACTIONS,
                                                        ACT_FROM_STORED_ACTIONS, s);
 }

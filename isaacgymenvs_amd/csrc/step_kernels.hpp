@@ -171,7 +171,12 @@ __device__ __forceinline__ void efforts_for_substep(const View& v, const ActPara
                 if (ap.mode == 0) {
                     t = a * ap.gear[k] * ap.scale;
                 } else {
-                    const float u = ap.kp * (ap.scale * a + ap.gear[k] - sim.q[k]) - ap.kd * sim.qd[k];
+                    // (the drive's gains are the dofs' `stiffness` / `damping` properties: their `actor_params` factors scale kp / kd, Anymal.yaml:146-158)
+                    float kp = ap.kp, kd = ap.kd;
+                    if constexpr (Sim<M>::SCALED) {
+                        if (sim.actor_scale.p != nullptr) { kp *= sim.actor_scale(Sim<M>::AS_STIFF + k); kd *= sim.actor_scale(Sim<M>::AS_DAMP + k); }
+                    }
+                    const float u = kp * (ap.scale * a + ap.gear[k] - sim.q[k]) - kd * sim.qd[k];
                     t = fminf(fmaxf(u, -ap.torque_limit), ap.torque_limit);
                 }
             }

@@ -26,7 +26,8 @@ SOURCES = ["mi_engine.hip", "kernels_cartpole.hip", "kernels_ant.hip", "kernels_
            # the sub-step kernels that read the `actor_params` factor tensors (Sim<Scaled<M>>): their own objects, beside the plain ones
            # AllegroHand: the hand task kernels instantiated for the Allegro model, one object shape per translation unit
            "kernels_allegro_hand.hip", "kernels_allegro_hand_pen.hip", "kernels_allegro_hand_egg.hip",
-           "kernels_scaled_ant.hip", "kernels_scaled_humanoid.hip", "kernels_scaled_humanoid_mwc.hip", "kernels_scaled_humanoid_sc2.hip"]
+           "kernels_scaled_ant.hip", "kernels_scaled_humanoid.hip", "kernels_scaled_humanoid_mwc.hip", "kernels_scaled_humanoid_sc2.hip",
+           "kernels_scaled_anymal.hip"]
 MI_MAX_DOF = 32
 
 # -fno-slp-vectorize: pairing scalars into v_pk_* ops lengthens live ranges in the fully unrolled sub-step

@@ -96,3 +96,13 @@ class Anymal(VecTask):
 
     def _task_params(self):
         return anymal_flat_params_from_cfg(self.cfg, self.dof_names)
+
+    def _actor_scale_column(self, actor, group, attr):
+        """`actor_params.anymal` (Anymal.yaml:121-165): the dofs' `stiffness` / `damping` properties are the position drives' gains
+        (anymal.py:203-206 writes env.control.stiffness / damping into every dof), so their factors scale kp / kd per dof in the sub-step
+        (csrc/step_kernels.hpp efforts_for_substep); link masses per body as for Ant / Humanoid."""
+        if (group, attr) == ("dof_properties", "stiffness"):
+            return self.spec.nb + self.spec.nd, np.full(self.spec.nd, float(self.Kp))
+        if (group, attr) == ("dof_properties", "damping"):
+            return self.spec.nb, np.full(self.spec.nd, float(self.Kd))
+        return super()._actor_scale_column(actor, group, attr)

@@ -337,8 +337,9 @@ class VecTask(Env):
     def _apply_actor_params(self, actor_params, due_envs):
         """`actor_params` (vec_task.py:752-828).  The reference walks every env's PhysX property structs in Python; here each
         supported entry is one vectorised draw over the due envs into a per-env tensor the sub-step kernel reads:
-          rigid_shape_properties.friction                     -> `friction` (Ant, Humanoid; ShadowHand: mean of hand and object);
-          rigid_body_properties.mass, dof_properties.damping / stiffness / armature -> `actor_scale` (Ant, Humanoid): one factor per env
+          rigid_shape_properties.friction                     -> `friction` (Ant, Humanoid, Anymal; ShadowHand: mean of hand and object);
+          rigid_body_properties.mass, dof_properties.damping / stiffness / armature -> `actor_scale` (Ant, Humanoid; Anymal: masses and the
+          position drives' gains, which are its dofs' stiffness / damping, tasks/anymal.py): one factor per env
           and BODY resp. DOF, drawn per element like the reference draws its property arrays (`scaling`: the sample itself; `additive`:
           relative to the element's model value);
           ShadowHand (`_actor_scale_column` of the task): hand mass / dof damping / dof stiffness (the drives' kp) / tendon stiffness /
@@ -347,7 +348,7 @@ class VecTask(Env):
         Entries without an engine parameter (restitution, colours, ...) are named once in a warning."""
         from ...utils.dr_utils import apply_random_samples_array
         t = self.engine.tensors
-        fr = t.get("friction") if self.native_task in ("Ant", "Humanoid", "ShadowHand", "AllegroHand") else None
+        fr = t.get("friction") if self.native_task in ("Ant", "Humanoid", "ShadowHand", "AllegroHand", "Anymal") else None
         scales = t.get("actor_scale")
         pair = self.native_task in ("ShadowHand", "AllegroHand")       # one contact coefficient per env = mean of the two actors' shape friction
         if pair and not hasattr(self, "_dr_actor_friction"):

@@ -655,9 +655,15 @@ class OracleAnymalEnv:
     """vec_task.py:360-408 + anymal.py pre/post_physics_step on oracle/physics.c (plane ground, net contact forces).  The
     DOF_MODE_POS drive is evaluated explicitly at every physics sub-step (what the HIP engine does)."""
 
-    def __init__(self, spec, sim_params: dict, params, num_envs, seed=0, env_id_offset=0, precision="f64", control_freq_inv=1):
+    def __init__(self, spec, sim_params: dict, params, num_envs, seed=0, env_id_offset=0, precision="f64", control_freq_inv=1, kp_scale=None,
+                 kd_scale=None, env_mu=None):
+        """kp_scale / kd_scale [nd]: `actor_params` factors of the dofs' stiffness / damping properties = the drives' gains (Anymal.yaml:146-158);
+        env_mu [N]: per-env shape friction; link-mass factors come in through a rescaled `spec` (tests/actor_scale_util.py)."""
         from .engine import OracleEngine
         self.N, self.p, self.nd, self.spec = num_envs, params, spec.nd, spec
+        self.kp_scale = np.ones(spec.nd, f32) if kp_scale is None else np.asarray(kp_scale, f32)
+        self.kd_scale = np.ones(spec.nd, f32) if kd_scale is None else np.asarray(kd_scale, f32)
+        self.env_mu = env_mu
         self.substeps = int(sim_params.get("substeps", 2))
         sp = dict(sim_params, dt=sim_params["dt"] / self.substeps, substeps=1)
         self.eng = OracleEngine(spec, num_envs, params=sp, precision=precision)
@@ -704,8 +710,8 @@ class OracleAnymalEnv:
         target = f32(p.action_scale) * a + self.default_dof_pos                           # anymal.py:226-229
         for _ in range(self.cfi * self.substeps):
             q, qd = self.eng.q.astype(f32), self.eng.qd.astype(f32)
-            tq = np.clip(f32(p.kp) * (target - q) - f32(p.kd) * qd, f32(-p.torque_limit), f32(p.torque_limit)).astype(f32)
-            self.eng.step(tq)
+            tq = np.clip((f32(p.kp) * self.kp_scale) * (target - q) - (f32(p.kd) * self.kd_scale) * qd, f32(-p.torque_limit), f32(p.torque_limit)).astype(f32)
+            self.eng.step(tq, env_mu=self.env_mu)
         self.torques = self.eng.dof_force.astype(f32)
         self.contact_forces = self.eng.netf.astype(f32)
         # post_physics_step (anymal.py:231-241)

@@ -263,8 +263,9 @@ def test_ant_post_physics_step_fused_into_the_last_sub_step_is_bit_identical(n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("task,n,na", [("Ant", 4096, 8), ("Ant", 200, 8), ("AnymalTerrain", 1024, 12), ("AnymalTerrain", 200, 12)])
-def test_all_sub_steps_of_a_control_step_in_one_launch_are_bit_identical(task, n, na):
+@pytest.mark.parametrize("task,n,na,cfi", [("Ant", 4096, 8, 1), ("Ant", 200, 8, 1), ("AnymalTerrain", 1024, 12, 1), ("AnymalTerrain", 200, 12, 1),
+                                           ("Ant", 328, 8, 3), ("AnymalTerrain", 328, 12, 2)])
+def test_all_sub_steps_of_a_control_step_in_one_launch_are_bit_identical(task, n, na, cfi):
     """Option fused_sub = 1 (csrc/mw_kernels.hpp substep_mw_fused_kernel): the sub-steps of a control step (Ant: 2 sub-steps of
     gym.simulate, vec_task.py:379-382; AnymalTerrain: 4 decimation steps with the PD torques re-evaluated + the base class's simulate,
     anymal_terrain.py:443-451) run inside ONE launch, the joint state / efforts staying in registers, the warm-start impulses in the LDS
@@ -277,9 +278,11 @@ def test_all_sub_steps_of_a_control_step_in_one_launch_are_bit_identical(task, n
     a.engine.set_option("fused_sub", 1); b.engine.set_option("fused_sub", 0)
     if task == "Ant":
         a.engine.set_option("fused_post", 0); b.engine.set_option("fused_post", 0)
+    if cfi != 1:        # env.controlFrequencyInv > 1: more sub-steps per launch (Ant: 2 cfi; AnymalTerrain: decimation + cfi, the last cfi on the held torques)
+        a.engine.set_option("control_freq_inv", cfi); b.engine.set_option("control_freq_inv", cfi)
     g = torch.Generator(device=DEV).manual_seed(0)
     resets = 0
-    for step in range(150):
+    for step in range(150 if cfi == 1 else 80):
         act = torch.rand((n, na), device=DEV, generator=g) * 2 - 1
         oa, ra, da, _ = a.step(act)
         ob, rb, db, _ = b.step(act)
@@ -290,5 +293,5 @@ def test_all_sub_steps_of_a_control_step_in_one_launch_are_bit_identical(task, n
     for k in names:
         if k in a.engine.tensors:
             assert torch.equal(a.engine.tensors[k], b.engine.tensors[k]), k
-    assert resets > 0 or task != "Ant"
+    assert resets > 0 or task != "Ant" or cfi != 1
 

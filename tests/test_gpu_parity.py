@@ -706,6 +706,91 @@ def test_anymal_flat_step_matches_cpu_restatement():
     assert float(obs_d["obs"].abs().max()) <= 5.0 + 1e-6          # clipObservations 5.0 (Anymal.yaml)
 
 
+def test_anymal_flat_actor_params_tensors_match_the_rescaled_oracle():
+    """`actor_params.anymal` of Anymal.yaml (:121-165; vec_task.py:752-828) as per-env tensors the sub-step reads (option actor_tensors,
+    kernels_scaled_anymal.hip): link-mass factors per body, the position drives' gains per dof (the dofs' stiffness / damping properties,
+    anymal.py:203-206), shape friction per env.  Same factor set in every env against the oracle on the rescaled model with the scaled
+    gains; and the factors do change the motion."""
+    from oracle.tasks import OracleAnymalEnv
+    import actor_scale_util as asu
+    n, seed = 128, 19
+    spec = load_model("anymal")
+    rng = np.random.default_rng(4)
+    f = asu.factors(spec, rng, mass=(0.6, 1.5), damping=(0.5, 1.5), stiffness=(0.5, 1.5), armature=(1.0, 1.0))
+    mu = rng.uniform(0.7, 1.3, n).astype(np.float32)
+    env = _make_env("Anymal", n, seed=seed)
+    plain = _make_env("Anymal", n, seed=seed)
+    t = env.engine.tensors
+    assert t["actor_scale"].shape == (n, spec.nb + 3 * spec.nd) and float(t["actor_scale"].min()) == 1.0 and float(t["friction"].max()) == -1.0
+    env.engine.set_option("actor_tensors", 1)
+    t["actor_scale"][:] = torch.as_tensor(asu.row(spec, f), device=DEV)[None, :]
+    t["friction"][:] = torch.as_tensor(mu, device=DEV)
+    orc = OracleAnymalEnv(asu.rescaled(spec, f), _sim_dict(env.sim_params), env._task_params_struct, n, seed=seed, precision="f64",
+                          kp_scale=f["stiffness"], kd_scale=f["damping"], env_mu=mu)
+    g = torch.Generator(device="cpu").manual_seed(9)
+    moved = 0.0
+    for step in range(10):
+        a = torch.rand((n, 12), generator=g) * 2 - 1
+        obs_d, rew, reset, _ = env.step(a.to(DEV))
+        plain.step(a.to(DEV))
+        o_obs, o_rew, o_reset = orc.step(a.numpy())
+        torch.cuda.synchronize()
+        d = np.abs(env.obs_buf.cpu().numpy() - o_obs).max(axis=1)
+        ok = d < 2e-3 * (1 + step)
+        assert ok.mean() > (0.95 if step < 7 else 0.9), (step, ok.mean(), d.max())      # (contacts with per-env friction part ways sooner)
+        same = reset.cpu().numpy().astype(bool) == o_reset.astype(bool)
+        assert same.mean() > 0.97, (step, same.mean())
+        moved = max(moved, float((env.dof_pos - plain.dof_pos).abs().max()))
+    assert moved > 0.02                                             # another robot: lighter / heavier links, softer / stiffer drives
+    with pytest.raises(RuntimeError):
+        _make_env("AnymalTerrain", 64, seed=1).engine.set_option("actor_tensors", 1)      # that task carries no such tensors
+
+
+def test_anymal_flat_randomize_fills_the_actor_tensors_from_its_own_task_config():
+    """`task.randomize=True` with the `randomization_params` of cfg/task/Anymal.yaml as they are (the reference's, Anymal.yaml:85-165): masses
+    (setup_only, per body), friction (500 buckets), the drives' gains per dof land in the engine's tensors, the entries without an engine
+    parameter (restitution; limits of a robot whose URDF has none) are named in one warning, and the robots keep walking."""
+    import warnings
+    import isaacgymenvs_amd
+    n = 512
+    cfg = compose(overrides=["task=Anymal"])
+    cfg["task"]["env"]["numEnvs"] = n
+    cfg["task"]["task"]["randomize"] = True
+    np.random.seed(1)
+    torch.manual_seed(1)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        env = isaacgymenvs_amd.make(seed=2, task="Anymal", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True, cfg=cfg)
+        g = torch.Generator(device=DEV).manual_seed(0)
+        for step in range(30):
+            obs = env.step(torch.rand((n, 12), device=DEV, generator=g) * 2 - 1)[0]["obs"]
+    msgs = " ".join(str(x.message) for x in w)
+    assert "restitution" in msgs and "anymal.rigid_body_properties.mass" not in msgs and "stiffness" not in msgs.replace("restitution", "")
+    t = env.engine.tensors
+    spec = load_model("anymal")
+    sc = t["actor_scale"].cpu().numpy()
+    assert int(env.engine.get_option("actor_tensors")) == 1
+    mass, damp, stiff = sc[:, :spec.nb], sc[:, spec.nb:spec.nb + spec.nd], sc[:, spec.nb + spec.nd:spec.nb + 2 * spec.nd]
+    # schedule "linear" over 3000 steps: at step 0 the samples are still at the model's values, a little later they have begun to spread;
+    # masses are setup_only (drawn once, at the first randomisation = no spread yet)
+    assert np.isfinite(sc).all() and np.abs(mass - 1.0).max() < 1e-6
+    fr = t["friction"].cpu().numpy()
+    assert (fr > 0).all() and fr.min() > 0.6 and fr.max() < 1.4
+    assert torch.isfinite(obs).all()
+    # with the schedule out of the way the factors spread over their ranges, one draw per env and dof
+    for k in ("damping", "stiffness"):
+        cfg["task"]["task"]["randomization_params"]["actor_params"]["anymal"]["dof_properties"][k].pop("schedule", None)
+    cfg["task"]["task"]["randomization_params"]["actor_params"]["anymal"]["rigid_body_properties"]["mass"].pop("schedule", None)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        env2 = isaacgymenvs_amd.make(seed=2, task="Anymal", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True, cfg=cfg)
+        env2.step(torch.zeros((n, 12), device=DEV))
+    sc2 = env2.engine.tensors["actor_scale"].cpu().numpy()
+    for blk in (sc2[:, :spec.nb], sc2[:, spec.nb:spec.nb + spec.nd], sc2[:, spec.nb + spec.nd:spec.nb + 2 * spec.nd]):
+        assert 0.5 - 1e-6 <= blk.min() < 0.6 and 1.4 < blk.max() <= 1.5 + 1e-6 and blk.std() > 0.2
+        assert np.abs(blk[:, 0] - blk[:, 1]).max() > 0.1                 # per element, not one factor per env
+
+
 def test_anymal_flat_full_size_properties():
     n = 4096
     env = _make_env("Anymal", n, seed=42)
