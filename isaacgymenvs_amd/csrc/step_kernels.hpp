@@ -358,11 +358,56 @@ __device__ __forceinline__ void loco_post_env(const View& v, const LocoParams& t
             if constexpr (M::NPG > 0) { if (v.lamp) sfor<3 * M::NPG>([&](auto K) MI_LAMBDA { v.lamp[K * N + e] = 0.f; }); }
         }
     }
-    float obs[NOBS], up_vec[3], heading_vec[3];
-    T::observations(tp, root, tp.targets, potentials, tp.inv_start_rot, q, qd, dof_force, tp.dof_lower, tp.dof_upper, sensor,
-                    act, tp.basis_vec0, tp.basis_vec1, obs, &potentials, &prev_potentials, up_vec, heading_vec);
+    float up_vec[3], heading_vec[3];
     float rew;
     long long reset;
+    if constexpr (!NOISE) {
+        // Streaming form: every observation column is stored (raw into obs_buf, clamped into the ring slot) as soon as it exists, the
+        // pass-through columns -- sensors, actions, then the dof columns -- first, so that the 2 x NOBS row-major stores (each instruction
+        // touches one cache line per env) drain while the root part (quaternion products, atan2) is computed, instead of queueing up
+        // behind it at the end of the kernel; nothing but the reward's partial sums stays live.  Same helpers, same sums as
+        // Loco::observations / Loco::reward: bit-identical buffers.  (Lanes past the batch shadow the last env: their stores repeat its.)
+        float* ob = v.obs + (size_t)e * NOBS;
+        float* oc = v.obs_out + ((size_t)v.ring * N + e) * NOBS;
+        const float c = v.clip_obs;
+        auto put = [&](const int k, const float x) MI_LAMBDA { ob[k] = x; oc[k] = fminf(fmaxf(x, -c), c); };
+        sfor<6 * M::NSENS>([&](auto K) MI_LAMBDA { put(T::COL_SENS + K, sensor[K] * tp.contact_force_scale); });
+        sfor<ND>([&](auto D) MI_LAMBDA { put(T::COL_ACT + D, act[D]); });
+        typename T::DofSums part[4];
+        sfor<ND>([&](auto D) MI_LAMBDA {
+            constexpr int d = D;
+            float ps, vs, fs;
+            T::obs_dof(tp, q[d], qd[d], HUM ? dof_force[d] : 0.f, tp.dof_lower[d], tp.dof_upper[d], &ps, &vs, &fs);
+            put(T::COL_POS + d, ps);
+            put(T::COL_VEL + d, vs);
+            if constexpr (HUM) put(T::COL_FORCE + d, fs);
+            T::reward_dof(tp, act[d], ps, vs, tp.gear[d], part[d & 3]);
+        });
+        float o12[12];
+        T::obs_root(tp, root, tp.targets, potentials, tp.inv_start_rot, tp.basis_vec0, tp.basis_vec1, o12, &potentials, &prev_potentials, up_vec,
+                    heading_vec);
+        sfor<12>([&](auto K) MI_LAMBDA { put(K, o12[K]); });
+        typename T::DofSums sm;
+        sm.actions = (part[0].actions + part[1].actions) + (part[2].actions + part[3].actions);
+        sm.electricity = (part[0].electricity + part[1].electricity) + (part[2].electricity + part[3].electricity);
+        sm.at_limit = (part[0].at_limit + part[1].at_limit) + (part[2].at_limit + part[3].at_limit);
+        T::reward_total(tp, o12[0], o12[10], o12[11], sm, 0LL, progress, potentials, prev_potentials, &rew, &reset);
+        episode_stats<ACTIVE, LIVE_MASK>(v, e, valid, rew, reset, progress);
+        if (!valid) return;
+        v.randomize[e] += 1;
+        v.episode[e] = ep;
+        v.potentials[e] = potentials;
+        v.prev_potentials[e] = prev_potentials;
+        sfor<3>([&](auto K) MI_LAMBDA { v.up_vec[K * N + e] = up_vec[K]; v.heading_vec[K * N + e] = heading_vec[K]; });
+        v.rew[e] = rew;
+        v.reset[e] = reset;
+        v.progress[e] = progress;
+        v.timeout[e] = (unsigned char)(((float)progress >= tp.max_episode_length - 1.f) && (reset != 0));   // vec_task.py:394
+        return;
+    }
+    float obs[NOBS];
+    T::observations(tp, root, tp.targets, potentials, tp.inv_start_rot, q, qd, dof_force, tp.dof_lower, tp.dof_upper, sensor,
+                    act, tp.basis_vec0, tp.basis_vec1, obs, &potentials, &prev_potentials, up_vec, heading_vec);
     T::reward(tp, obs, 0LL, progress, act, potentials, prev_potentials, &rew, &reset);
     // observation noise of the domain randomisation: the reference applies it to obs_buf after post_physics_step (vec_task.py:397-399),
     // i.e. the reward above saw the clean observations
