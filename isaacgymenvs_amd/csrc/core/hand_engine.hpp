@@ -299,14 +299,17 @@ struct HandSim : Sim<M> {
             constexpr int b = B_;
             if constexpr (B::os_count(b) > 0) {
                 constexpr int CL = M::chain_len[b];
+                // (the table look-ups as constant expressions: left to the optimiser the helpers' loops over the model's sphere table ran at
+                //  RUN time for the Allegro hand's 119 spheres -- in the loop condition, in every pose index -- and its sub-step took 5.3 ms)
+                constexpr int OS_N = B::os_count(b), OS_0 = B::os_first(b), OS_SLOT = B::os_slot(b);
                 MI_PHASE();
                 float Rb[9], rb[3];
-                sfor<9>([&](auto I_) MI_LAMBDA { Rb[I_] = pose[pz + 12 * B::os_slot(b) + I_]; });
-                sfor<3>([&](auto I_) MI_LAMBDA { rb[I_] = pose[pz + 12 * B::os_slot(b) + 9 + I_]; });
+                sfor<9>([&](auto I_) MI_LAMBDA { Rb[I_] = pose[pz + 12 * OS_SLOT + I_]; });
+                sfor<3>([&](auto I_) MI_LAMBDA { rb[I_] = pose[pz + 12 * OS_SLOT + 9 + I_]; });
                 int nbody = 0;
                 const int first = cnt;
-                for (int i = 0; i < B::os_count(b); ++i) {
-                    const int s = B::os_first(b) + i;
+                for (int i = 0; i < OS_N; ++i) {
+                    const int s = OS_0 + i;
                     const float pl[3] = {M::os_pos[s][0], M::os_pos[s][1], M::os_pos[s][2]};
                     const float rad = M::os_rad[s];
                     float t[3], cs[3];
@@ -373,7 +376,7 @@ struct HandSim : Sim<M> {
                         });
                     }
                 }
-                rows(H_BODYSLOT + B::os_slot(b)) = __builtin_bit_cast(float, first | (nbody << 8));
+                rows(H_BODYSLOT + OS_SLOT) = __builtin_bit_cast(float, first | (nbody << 8));
             }
         });
         *ncontact = cnt | (refused << 16);
@@ -421,7 +424,8 @@ struct HandSim : Sim<M> {
                 constexpr int b = B_;
                 if constexpr (B::os_count(b) > 0) {
                     constexpr int CL = M::chain_len[b];
-                    const int fc = __builtin_bit_cast(int, rit(H_BODYSLOT + B::os_slot(b)));
+                    constexpr int OS_SLOT = B::os_slot(b);
+                    const int fc = __builtin_bit_cast(int, rit(H_BODYSLOT + OS_SLOT));
                     const int first = fc & 255, nb_ = fc >> 8;
                     for (int i = 0; i < BODY_CAP; ++i) {
                         if (!MI_WAVE_ANY(i < nb_)) break;           // no env of the wave has an (i+1)-th contact on this body
@@ -512,9 +516,10 @@ struct HandSim : Sim<M> {
                 // the fingertip's pose from the per-lane pose array (keeping the tree pass's own sensor frames c.Rs / c.rs alive
                 // until here costs 100 more spilled registers)
                 float Rb[9], rb[3];
-                sfor<9>([&](auto I_) MI_LAMBDA { Rb[I_] = pose[pz + 12 * B::os_slot(b) + I_]; });
-                sfor<3>([&](auto I_) MI_LAMBDA { rb[I_] = pose[pz + 12 * B::os_slot(b) + 9 + I_]; });
-                const int fc = __builtin_bit_cast(int, rows(H_BODYSLOT + B::os_slot(b)));
+                constexpr int OS_SLOT = B::os_slot(b);
+                sfor<9>([&](auto I_) MI_LAMBDA { Rb[I_] = pose[pz + 12 * OS_SLOT + I_]; });
+                sfor<3>([&](auto I_) MI_LAMBDA { rb[I_] = pose[pz + 12 * OS_SLOT + 9 + I_]; });
+                const int fc = __builtin_bit_cast(int, rows(H_BODYSLOT + OS_SLOT));
                 const int first = fc & 255, nb_ = fc >> 8;
                 for (int i = 0; i < BODY_CAP; ++i) {
                     if (!MI_WAVE_ANY(i < nb_)) break;

@@ -138,8 +138,9 @@ struct HandSimMW : HandSim<M> {
             const float lim = br + nw.reach;
             if (!MI_WAVE_ANY(dot3(d, d) < lim * lim)) return;
         }
-        for (int i = 0; i < B::os_count(b); ++i) {
-            const int s = B::os_first(b) + i;
+        constexpr int OS_N = B::os_count(b), OS_0 = B::os_first(b);     // (constant expressions on purpose: see hand_engine.hpp)
+        for (int i = 0; i < OS_N; ++i) {
+            const int s = OS_0 + i;
             const float pl[3] = {M::os_pos[s][0], M::os_pos[s][1], M::os_pos[s][2]};
             const float rad = M::os_rad[s];
             {
@@ -450,7 +451,8 @@ struct HandSimMW : HandSim<M> {
                     if constexpr (M::limb_of_body[b] == l && B::os_count(b) > 0) {
                         constexpr int CL = M::chain_len[b];
                         MI_PHASE();
-                        const int first = (int)(nw.bfc[B::os_slot(b)] & 255u), nbody = (int)(nw.bfc[B::os_slot(b)] >> 8);
+                        constexpr int OS_SLOT = B::os_slot(b);
+                        const int first = (int)(nw.bfc[OS_SLOT] & 255u), nbody = (int)(nw.bfc[OS_SLOT] >> 8);
                         // walked by contact (at most BODY_CAP, left by the whole wave as soon as no env has an (i+1)-th one on this body)
                         for (int i = 0; i < BODY_CAP; ++i) {
                             if (!MI_WAVE_ANY(i < nbody)) break;
@@ -665,7 +667,8 @@ struct HandSimMW : HandSim<M> {
                 if constexpr (B::os_count(b) > 0) {
                     const float (&Rb)[9] = c.Rs[k];          // the fingertip's frame, kept by the tree pass (force-sensor body)
                     const float (&rb)[3] = c.rs[k];
-                    const int first = (int)(nw.bfc[B::os_slot(b)] & 255u), nb_ = (int)(nw.bfc[B::os_slot(b)] >> 8);
+                    constexpr int OS_SLOT = B::os_slot(b);
+                    const int first = (int)(nw.bfc[OS_SLOT] & 255u), nb_ = (int)(nw.bfc[OS_SLOT] >> 8);
                     for (int i = 0; i < BODY_CAP; ++i) {
                         if (!MI_WAVE_ANY(i < nb_)) break;
                         if (i < nb_) {
