@@ -392,7 +392,7 @@ struct HandSimMW : HandSim<M> {
         bar();                                                                                       // ---- B1b: region A is dead
         MI_STAMP(4);
         // ============================================================ P3: own joint-limit rows (registers)
-        float dw[NVT];                      // this role's warm-start contribution to the wrist part of w
+        float dw[NVT > 0 ? NVT : 1];                      // this role's warm-start contribution to the wrist part of w
         sfor<NVT>([&](auto I) MI_LAMBDA { dw[I] = 0.f; });
         float act = 0.f;
         auto wadd = [&](auto GI, const float val) MI_LAMBDA {
@@ -506,7 +506,7 @@ struct HandSimMW : HandSim<M> {
         float hc[NR];
         sfor<NR>([&](auto R_) MI_LAMBDA { hc[R_] = rows(X_HASC + R_); });
         {
-            float wtl[NVT], wol[6];           // the shared coordinates as this block sees them during a sweep
+            float wtl[NVT > 0 ? NVT : 1], wol[6];           // the shared coordinates as this block sees them during a sweep
             for (int it = 0; it < P.iters; ++it) {
                 int zero;
                 MI_OPAQUE_ZERO(zero);

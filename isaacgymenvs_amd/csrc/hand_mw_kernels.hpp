@@ -12,19 +12,22 @@
 
 namespace mi {
 
-using HSW = HandSimMW<HM>;
-template <int E>
-constexpr size_t hand_mw_lds_bytes() { return (size_t)HSW::MW_SLOTS * E * sizeof(float); }
+// (a template over the hand task since the end of round 3: ShadowHandTask and AllegroHandTask -- the Allegro hand has no wrist dofs and no
+//  tendons: its fingers couple through the object alone)
+template <class HT, int E>
+constexpr size_t hand_mw_lds_bytes() { return (size_t)HandSimMW<typename HT::M>::MW_SLOTS * E * sizeof(float); }
 
 #if defined(MI_TIMING)
 __device__ unsigned long long* g_mi_tstamp_hmw = nullptr;     // debug builds: per workgroup and role 16 s_memtime stamps
 #endif
 
-template <int SHAPE, int E, int R>
+template <class HT, int SHAPE, int E, int R>
 __device__ __forceinline__ void hand_mw_role(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, float* lds_rows,
                                              const int e, const int lane) {
+    using HM = typename HT::M;
+    using HSW = HandSimMW<HM>;
     using MW = SimMW<HM>;
-    constexpr int ND = kHandDof;
+    constexpr int ND = HT::ND;
     const int N = v.N;
     HSW sim;
     sfor<3>([&](auto K) MI_LAMBDA { sim.root[K] = p.hand_pos[K]; });
@@ -78,9 +81,9 @@ struct HandMwArgs {
     SimParams P;
     HandParams p;
 };
-template <int SHAPE, int E>
+template <class HT, int SHAPE, int E>
 __device__ __forceinline__ void hand_mw_body(float* lds_rows) {
-    static_assert(HM::NROLE == 4, "four roles, one per SIMD of a CU");
+    static_assert(HT::M::NROLE == 4, "four roles, one per SIMD of a CU");
 #if defined(__HIP_DEVICE_COMPILE__)
     const HandMwArgs& a = *reinterpret_cast<const HandMwArgs*>(__builtin_amdgcn_kernarg_segment_ptr());
     const int lane = threadIdx.x;
@@ -89,13 +92,13 @@ __device__ __forceinline__ void hand_mw_body(float* lds_rows) {
     if (e >= a.v.N) return;                 // all four waves hold the same envs and agree on this
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.y);
 #if defined(MI_HMW_ONLY_ROLE)     // tools/debug only: resource usage of one role's instruction stream
-    if (role == MI_HMW_ONLY_ROLE) hand_mw_role<SHAPE, E, MI_HMW_ONLY_ROLE>(a.v, a.hv, a.P, a.p, lds_rows, e, lane);
+    if (role == MI_HMW_ONLY_ROLE) hand_mw_role<HT, SHAPE, E, MI_HMW_ONLY_ROLE>(a.v, a.hv, a.P, a.p, lds_rows, e, lane);
 #else
     switch (role) {
-        case 0: hand_mw_role<SHAPE, E, 0>(a.v, a.hv, a.P, a.p, lds_rows, e, lane); break;
-        case 1: hand_mw_role<SHAPE, E, 1>(a.v, a.hv, a.P, a.p, lds_rows, e, lane); break;
-        case 2: hand_mw_role<SHAPE, E, 2>(a.v, a.hv, a.P, a.p, lds_rows, e, lane); break;
-        default: hand_mw_role<SHAPE, E, 3>(a.v, a.hv, a.P, a.p, lds_rows, e, lane); break;
+        case 0: hand_mw_role<HT, SHAPE, E, 0>(a.v, a.hv, a.P, a.p, lds_rows, e, lane); break;
+        case 1: hand_mw_role<HT, SHAPE, E, 1>(a.v, a.hv, a.P, a.p, lds_rows, e, lane); break;
+        case 2: hand_mw_role<HT, SHAPE, E, 2>(a.v, a.hv, a.P, a.p, lds_rows, e, lane); break;
+        default: hand_mw_role<HT, SHAPE, E, 3>(a.v, a.hv, a.P, a.p, lds_rows, e, lane); break;
     }
 #endif
 #else
@@ -103,37 +106,37 @@ __device__ __forceinline__ void hand_mw_body(float* lds_rows) {
 #endif
 }
 // (the kernel arguments are read through the kernarg segment pointer inside hand_mw_body; the host pass of the compiler never executes it)
-template <int SHAPE>
-__global__ __launch_bounds__(64 * HM::NROLE) __attribute__((amdgpu_waves_per_eu(2, 2))) void hand_substep_mw_kernel(HandMwArgs args_by_value) {
+template <class HT, int SHAPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void hand_substep_mw_kernel(HandMwArgs args_by_value) {
     extern __shared__ float lds_rows[];   // [MW_SLOTS][32]
 #if defined(__HIP_DEVICE_COMPILE__)
     (void)args_by_value;
-    hand_mw_body<SHAPE, 32>(lds_rows);
+    hand_mw_body<HT, SHAPE, 32>(lds_rows);
 #endif
 }
-template <int SHAPE>
-__global__ __launch_bounds__(64 * HM::NROLE) __attribute__((amdgpu_waves_per_eu(1, 1))) void hand_substep_mw64_kernel(HandMwArgs args_by_value) {
+template <class HT, int SHAPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void hand_substep_mw64_kernel(HandMwArgs args_by_value) {
     extern __shared__ float lds_rows[];   // [MW_SLOTS][64]
 #if defined(__HIP_DEVICE_COMPILE__)
     (void)args_by_value;
-    hand_mw_body<SHAPE, 64>(lds_rows);
+    hand_mw_body<HT, SHAPE, 64>(lds_rows);
 #endif
 }
 
-template <int SHAPE>
+template <class HT, int SHAPE>
 inline hipError_t hand_substeps_mw_shape(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s) {
     static unsigned long long conf32 = 0ull, conf64 = 0ull;
-    const dim3 block(64, HM::NROLE);
+    const dim3 block(64, HT::M::NROLE);
     if (v.mw == 64) {
-        constexpr size_t lds = hand_mw_lds_bytes<64>();
+        constexpr size_t lds = hand_mw_lds_bytes<HT, 64>();
         static_assert(lds <= 160 * 1024, "one 64-env hand workgroup per CU");
-        auto kern = hand_substep_mw64_kernel<SHAPE>;
+        auto kern = hand_substep_mw64_kernel<HT, SHAPE>;
         if (hipError_t e = ensure_dynamic_lds((const void*)kern, lds, &conf64); e != hipSuccess) return e;
         const dim3 grid(xcd_grid<64>(v.N));
         for (int i = 0; i < n; ++i) hipLaunchKernelGGL(kern, grid, block, lds, s, HandMwArgs{v, hv, P, p});
     } else {
-        constexpr size_t lds = hand_mw_lds_bytes<32>();
-        auto kern = hand_substep_mw_kernel<SHAPE>;
+        constexpr size_t lds = hand_mw_lds_bytes<HT, 32>();
+        auto kern = hand_substep_mw_kernel<HT, SHAPE>;
         if (hipError_t e = ensure_dynamic_lds((const void*)kern, lds, &conf32); e != hipSuccess) return e;
         const dim3 grid(xcd_grid<32>(v.N));
         for (int i = 0; i < n; ++i) hipLaunchKernelGGL(kern, grid, block, lds, s, HandMwArgs{v, hv, P, p});

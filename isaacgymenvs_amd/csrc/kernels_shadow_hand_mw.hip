@@ -3,7 +3,7 @@
 
 namespace mi {
 hipError_t hand_substeps_mw_box(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s) {
-    return hand_substeps_mw_shape<OBJ_BOX>(v, hv, P, p, n, s);
+    return hand_substeps_mw_shape<ShadowHandTask, OBJ_BOX>(v, hv, P, p, n, s);
 }
 }  // namespace mi
 

@@ -3,6 +3,6 @@
 
 namespace mi {
 hipError_t hand_substeps_mw_egg(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s) {
-    return hand_substeps_mw_shape<OBJ_ELLIPSOID>(v, hv, P, p, n, s);
+    return hand_substeps_mw_shape<ShadowHandTask, OBJ_ELLIPSOID>(v, hv, P, p, n, s);
 }
 }  // namespace mi

@@ -438,9 +438,8 @@ extern "C" int mi_engine_set_option(MiEngine* e, const char* key, double value) 
     // whose model has no multi-wave form (Cartpole, Quadcopter).  ShadowHand: any non-zero value selects the finger-per-wave form (32 envs per
     // workgroup, core/hand_engine_mw.hpp).  2: the Humanoid's round-2 form (main wave + self-collision helper).
     if (!strcmp(key, "multi_wave")) {
-        if (e->task == T_ALLEGROHAND) { e->v.mw = 0; return 0; }   // one-wave sub-step only
-        const bool hand64 = value == 64 && e->task == T_SHADOWHAND;      // full 64-env waves, one workgroup per CU (hand_mw_kernels.hpp)
-        if (value != 0 && value != 32 && value != 2 && !(MI_MW_HAS16 && value == 16) && !hand64) return fail("multi_wave: 0, 16 or 32 (envs per workgroup); 2: main + helper wave; 64: ShadowHand only");
+        const bool hand64 = value == 64 && is_hand_task(e->task);        // full 64-env waves, one workgroup per CU (hand_mw_kernels.hpp)
+        if (value != 0 && value != 32 && value != 2 && !(MI_MW_HAS16 && value == 16) && !hand64) return fail("multi_wave: 0, 16 or 32 (envs per workgroup); 2: main + helper wave; 64: ShadowHand / AllegroHand only");
         e->v.mw = (int)value;
         return 0;
     }

@@ -26,6 +26,7 @@ SOURCES = ["mi_engine.hip", "kernels_cartpole.hip", "kernels_ant.hip", "kernels_
            # the sub-step kernels that read the `actor_params` factor tensors (Sim<Scaled<M>>): their own objects, beside the plain ones
            # AllegroHand: the hand task kernels instantiated for the Allegro model, one object shape per translation unit
            "kernels_allegro_hand.hip", "kernels_allegro_hand_pen.hip", "kernels_allegro_hand_egg.hip",
+           "kernels_allegro_hand_mw.hip", "kernels_allegro_hand_mw_pen.hip", "kernels_allegro_hand_mw_egg.hip",
            "kernels_scaled_ant.hip", "kernels_scaled_humanoid.hip", "kernels_scaled_humanoid_mwc.hip", "kernels_scaled_humanoid_sc2.hip",
            "kernels_scaled_anymal.hip"]
 MI_MAX_DOF = 32
@@ -189,9 +190,7 @@ def auto_multi_wave(task, num_envs):
     mw = 16 if num_envs <= 4096 else (32 if num_envs <= 8192 else 0)
     if task == "Humanoid":
         mw = 32          # limb waves + pair wave (csrc/mwc_kernels.hpp), at any env count
-    if task == "AllegroHand":
-        mw = 0           # one-wave sub-step only (csrc/kernels_allegro_hand.hip)
-    if task == "ShadowHand":
+    if task in ("ShadowHand", "AllegroHand"):
         # finger per wave (csrc/hand_mw_kernels.hpp): 32 envs per workgroup (two half-filled waves per SIMD) while that fills the chip (one
         # workgroup per CU up to 8192 envs), full 64-env waves (half the wave instructions per env) from there on -- profiles/r3l_hand_mw_ab_0_32_64.txt
         mw = 64 if num_envs >= 8192 else 32

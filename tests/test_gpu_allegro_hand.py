@@ -27,18 +27,28 @@ def _make(n, seed, **env_over):
 
 
 def _oracle(env, n, seed):
+    """the restatement in the solver order the engine runs: option multi_wave != 0 is the finger-per-wave kernel (block sweeps, contacts kept per
+    limb: csrc/core/hand_engine_mw.hpp), 0 the one-wave kernel (one Gauss-Seidel sequence)"""
     from oracle.tasks import OracleAllegroHandEnv
+    from isaacgymenvs_amd.assets.model import hand_solver_blocks
+    order = dict(solver="gs")
+    if int(env.engine.get_option("multi_wave")) != 0:
+        order = dict(solver="blocks", blocks=hand_solver_blocks(load_model("allegro_hand")))
     return OracleAllegroHandEnv(load_model("allegro_hand"), load_extras("allegro_hand"), [], _sim_dict(env.sim_params), env._task_params_struct, n, seed=seed,
-                                control_freq_inv=env.control_freq_inv)
+                                control_freq_inv=env.control_freq_inv, **order)
 
 
+@pytest.mark.parametrize("multi_wave", [0, 32, 64])
 @pytest.mark.parametrize("object_type", ["block", "egg", "pen"])
-def test_allegro_hand_trajectory_matches_cpu_restatement(object_type):
+def test_allegro_hand_trajectory_matches_cpu_restatement(object_type, multi_wave):
+    """multi_wave 32 / 64: the finger-per-wave kernel (four fingers = four waves, 32 / 64 envs per workgroup; make() picks it) against the
+    block solver order of the restatement; 0: the one-wave kernel against one Gauss-Seidel sequence."""
     n, seed = 64, 13
     env = _make(n, seed, objectType=object_type)
     assert env._task_params_struct.object_shape == {"block": 0, "pen": 1, "egg": 2}[object_type]
     assert (env.num_obs, env.num_actions, env.num_states) == (88, 16, 0)
-    assert int(env.engine.get_option("multi_wave")) == 0           # one-wave sub-step only
+    assert int(env.engine.get_option("multi_wave")) == 32          # what make() selects below 8192 envs
+    env.engine.set_option("multi_wave", multi_wave)
     orc = _oracle(env, n, seed)
     g = torch.Generator(device="cpu").manual_seed(7)
     touched = np.zeros(n, bool)

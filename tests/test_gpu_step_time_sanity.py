@@ -19,7 +19,7 @@ CASES = [("Cartpole", 4096, 0.15),        # 0.016
          ("Quadcopter", 8192, 0.35),      # 0.042
          ("Ingenuity", 4096, 0.25),       # 0.021
          ("BallBalance", 4096, 0.3),      # 0.031
-         ("AllegroHand", 4096, 6.0)]      # 1.03 (four one-wave sub-step launches per control step)
+         ("AllegroHand", 4096, 2.0)]      # 0.26 (four finger-per-wave sub-step launches per control step)
 
 
 @pytest.mark.gpu

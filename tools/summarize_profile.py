@@ -124,7 +124,7 @@ RECIPE = {
     "AnymalTerrain@4096": [(r"substep_mw_fused_kernel<ModelAnymal, mi::HeightfieldGround|substep(_mw)?_kernel<ModelAnymal, mi::HeightfieldGround", {"fused": 1, "plain": 5}),
                            (r"anymal_post_kernel", 1), (r"anymal_heights_kernel", 1),
                            (r"anymal_cmdnorm_kernel", 1)],
-    "ShadowHand@16384": [(r"hand_pre_kernel", 1), (r"hand_substep(_mw64|_mw)?_kernel<0>", 2), (r"hand_tips_kernel", 1), (r"hand_post_kernel", 1),
+    "ShadowHand@16384": [(r"hand_pre_kernel", 1), (r"hand_substep(_mw64|_mw)?_kernel<(mi::ShadowHandTask, )?0>", 2), (r"hand_tips_kernel", 1), (r"hand_post_kernel", 1),
                          (r"hand_finalize_kernel", 1)],     # (gone since the end of round 3: the post kernel's last block does it)
 }
 tj = {}
