@@ -257,20 +257,6 @@ __global__ __launch_bounds__(64) void hand_post_kernel(View v, HandView hv, Hand
             if (to_full) fs[k] = val;
         }
     }
-    // The LAST block of the grid to get here closes the step's bookkeeping: consecutive_successes' running average (shadow_hand.py:795-798)
-    // from the sums every block has added to, and the sums re-zeroed for the next step -- until round 3 a one-thread kernel of its own
-    // (4.5 us of launch latency per step).
-    if (threadIdx.x == 0) {
-        __threadfence();
-        unsigned* done = reinterpret_cast<unsigned*>(hv.ws + 2);
-        if (atomicAdd(done, 1u) == gridDim.x - 1) {
-            __threadfence();
-            const float num_resets = __hip_atomic_load(hv.ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float finished = __hip_atomic_load(hv.ws + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), cs = hv.cons[0];
-            hv.cons[0] = (num_resets > 0.f) ? p.rew.av_factor * finished / num_resets + (1.0f - p.rew.av_factor) * cs : cs;
-            hv.ws[0] = 0.f; hv.ws[1] = 0.f; *done = 0u;
-        }
-    }
     if (!valid) return;
     v.rew[e] = r;
     v.reset[e] = rs;
@@ -297,6 +283,17 @@ __global__ void hand_obs_select_kernel(View v, HandView hv, HandParams p) {
     v.obs[(size_t)e * no + k] = val;
     v.obs_out[((size_t)v.ring * v.N + e) * no + k] = fminf(fmaxf(val, -v.clip_obs), v.clip_obs);
 }
+template <class HT>
+__global__ void hand_finalize_kernel(HandView hv, HandParams p) {
+    // (folding this into the post kernel's last block -- a fence and a counter at the end of every block -- was measured at the end of round 3:
+    //  the post kernel grew by what this launch costs, 41.3 -> 45.0 us; a one-thread kernel hides in its neighbours' launch shadow)
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float num_resets = hv.ws[0], finished = hv.ws[1], cs = hv.cons[0];
+        hv.cons[0] = (num_resets > 0.f) ? p.rew.av_factor * finished / num_resets + (1.0f - p.rew.av_factor) * cs : cs;
+        hv.ws[0] = 0.f; hv.ws[1] = 0.f;   // last reader of the step's sums: re-zero them here instead of a memset before every post kernel
+    }
+}
+
 // initial state: buffers as the reference's __init__ leaves them (reset_buf = 1 => everything is reset at the first
 // pre_physics_step), hand at its default pose, cube and goal at their initial poses
 template <class HT>
@@ -340,6 +337,7 @@ hipError_t launch_step_hand(const View& v, const HandView& hv, const SimParams& 
     if constexpr (HT::NTIPS > 0) hipLaunchKernelGGL(hand_tips_kernel<HT>, dim3((v.N + 63) / 64, HT::NTIPS), dim3(64), 0, s, v, hv, p);
     hipLaunchKernelGGL(hand_post_kernel<HT>, dim3((v.N + 63) / 64), dim3(64), 0, s, v, hv, p);
     if (p.obs_type != 0) hipLaunchKernelGGL(hand_obs_select_kernel<HT>, dim3((v.N * p.num_obs + 255) / 256), dim3(256), 0, s, v, hv, p);
+    hipLaunchKernelGGL(hand_finalize_kernel<HT>, dim3(1), dim3(64), 0, s, hv, p);
     return hipGetLastError();
 }
 template <class HT>

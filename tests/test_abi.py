@@ -231,8 +231,11 @@ def test_hot_kernels_stay_inside_their_register_budgets():
         "substep_mw_post_kernelI8ModelAnt": 0,           # 0   (round 3: post_physics_step on one wave of the last sub-step launch)
         # round 3, structural rather than a compiler accident: a role wave of the finger-per-wave hand sub-step holds one finger's state; with
         # 64-env workgroups (one wave per SIMD, 512 registers) nothing is spilled and no scratch is used
-        "hand_substep_mw64_kernelILi0E": 0, "hand_substep_mw64_kernelILi1E": 0, "hand_substep_mw64_kernelILi2E": 0,
-        "hand_substep_mw_kernelILi0E": 300,              # 248 (32-env workgroups: two waves per SIMD, 256 registers each)
+        "hand_substep_mw64_kernelINS_14ShadowHandTaskELi0E": 0, "hand_substep_mw64_kernelINS_14ShadowHandTaskELi1E": 0,
+        "hand_substep_mw64_kernelINS_14ShadowHandTaskELi2E": 0,
+        "hand_substep_mw_kernelINS_14ShadowHandTaskELi0E": 300,              # 248 (32-env workgroups: two waves per SIMD, 256 registers each)
+        # the Allegro hand's finger waves (four-joint fingers, no wrist, no tendons): nothing spilled in either workgroup shape
+        "hand_substep_mw64_kernelINS_15AllegroHandTaskELi0E": 0, "hand_substep_mw_kernelINS_15AllegroHandTaskELi0E": 0,
     }
     seen = set()
     for name, use in ru.items():

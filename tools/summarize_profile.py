@@ -125,7 +125,7 @@ RECIPE = {
                            (r"anymal_post_kernel", 1), (r"anymal_heights_kernel", 1),
                            (r"anymal_cmdnorm_kernel", 1)],
     "ShadowHand@16384": [(r"hand_pre_kernel", 1), (r"hand_substep(_mw64|_mw)?_kernel<(mi::ShadowHandTask, )?0>", 2), (r"hand_tips_kernel", 1), (r"hand_post_kernel", 1),
-                         (r"hand_finalize_kernel", 1)],     # (gone since the end of round 3: the post kernel's last block does it)
+                         (r"hand_finalize_kernel", 1)],
 }
 tj = {}
 out.append("\n## One control step (what bench.py reports as roofline.traffic / roofline.valu)\n")
