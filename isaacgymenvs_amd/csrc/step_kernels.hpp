@@ -269,7 +269,11 @@ __global__ __launch_bounds__(64) void substep_kernel(View v, SimParams P, ActPar
 #define MI_MW_HAS16 1          // also build the 16-envs-per-workgroup variant (best at <= 4096 envs; 0 halves the compile time of kernels_mw_*.hip)
 #endif
 template <class M, class GND>
-constexpr bool mw_capable() { return !Sim<M>::COMPACT && Sim<M>::LAM_IN_ROWS && !M::FIXED && M::NLIMB >= 3 && !std::is_same<GND, PlaneGroundNF>::value; }
+constexpr bool mw_capable() {
+    // (flat ground with net contact forces = the flat Anymal task: the plain model has the limb-per-wave form, kernels_mw_anymal.hip; its
+    //  `actor_params` instantiation, Sim<Scaled<M>>, runs on one wave)
+    return !Sim<M>::COMPACT && Sim<M>::LAM_IN_ROWS && !M::FIXED && M::NLIMB >= 3 && !(std::is_same<GND, PlaneGroundNF>::value && is_scaled<M>::value);
+}
 // launches n_sub sub-steps of a self-colliding robot on two waves per workgroup (sc2_kernels.hpp, instantiated in kernels_humanoid_sc2.hip)
 template <class M>
 hipError_t launch_substeps_sc2(const View& v, const SimParams& P, const ActParams& ap, const float* actions, int n_sub, int first, int rest,

@@ -207,7 +207,7 @@ def select_multi_wave(engine, task, num_envs, mw="auto"):
             break
         except RuntimeError:
             continue
-    if task in ("Ant", "AnymalTerrain"):
+    if task in ("Ant", "AnymalTerrain", "Anymal"):
         # all physics sub-steps of a control step in one launch (csrc/mw_kernels.hpp substep_mw_fused_kernel; bit-identical buffers):
         # Ant@4096 0.0424 -> 0.0408 ms, AnymalTerrain@4096 0.1273 -> 0.1187 ms per step (tools/fused_sub_ab.py, profiles/r3x_fused_sub_ab.txt)
         try:

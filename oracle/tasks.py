@@ -656,7 +656,7 @@ class OracleAnymalEnv:
     DOF_MODE_POS drive is evaluated explicitly at every physics sub-step (what the HIP engine does)."""
 
     def __init__(self, spec, sim_params: dict, params, num_envs, seed=0, env_id_offset=0, precision="f64", control_freq_inv=1, kp_scale=None,
-                 kd_scale=None, env_mu=None):
+                 kd_scale=None, env_mu=None, solver="gs", blocks=None):
         """kp_scale / kd_scale [nd]: `actor_params` factors of the dofs' stiffness / damping properties = the drives' gains (Anymal.yaml:146-158);
         env_mu [N]: per-env shape friction; link-mass factors come in through a rescaled `spec` (tests/actor_scale_util.py)."""
         from .engine import OracleEngine
@@ -666,7 +666,7 @@ class OracleAnymalEnv:
         self.env_mu = env_mu
         self.substeps = int(sim_params.get("substeps", 2))
         sp = dict(sim_params, dt=sim_params["dt"] / self.substeps, substeps=1)
-        self.eng = OracleEngine(spec, num_envs, params=sp, precision=precision)
+        self.eng = OracleEngine(spec, num_envs, params=sp, precision=precision, solver=solver, blocks=blocks)     # solver order: as the engine runs it
         self.eng.want_netf = True
         self.seed, self.off, self.cfi = fold_seed(seed), env_id_offset, control_freq_inv
         p, N = params, num_envs

@@ -172,7 +172,7 @@ def _selfcol_kw(task):
 
 
 # tasks whose multi-wave sub-step sweeps its rows block by block (csrc/core/engine_mw.hpp / engine_mwc.hpp P4); the oracle must be told the same order
-BLOCK_ORDER_TASKS = {"Ant": "ant", "AnymalTerrain": "anymal", "Humanoid": "humanoid"}
+BLOCK_ORDER_TASKS = {"Ant": "ant", "AnymalTerrain": "anymal", "Humanoid": "humanoid", "Anymal": "anymal"}
 
 
 def _oracle_kw(task, env=None):
@@ -678,7 +678,9 @@ def test_anymal_flat_step_matches_cpu_restatement():
     from oracle.tasks import OracleAnymalEnv
     n, seed = 128, 17
     env = _make_env("Anymal", n, seed=seed)
-    orc = OracleAnymalEnv(load_model("anymal"), _sim_dict(env.sim_params), env._task_params_struct, n, seed=seed, precision="f64")
+    assert int(env.engine.get_option("multi_wave")) == 16 and int(env.engine.get_option("fused_sub")) == 1      # leg waves, both sub-steps in one launch
+    orc = OracleAnymalEnv(load_model("anymal"), _sim_dict(env.sim_params), env._task_params_struct, n, seed=seed, precision="f64",
+                          **_oracle_kw("Anymal", env))
     np.testing.assert_allclose(env.root_states.cpu().numpy(), orc.eng.root, atol=1e-6)
     np.testing.assert_allclose(env.dof_pos.cpu().numpy(), orc.eng.q, atol=1e-6)
     np.testing.assert_allclose(env.commands.cpu().numpy(), orc.commands, atol=1e-6)

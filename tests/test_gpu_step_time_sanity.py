@@ -15,7 +15,7 @@ CASES = [("Cartpole", 4096, 0.15),        # 0.016
          ("Humanoid", 8192, 1.2),         # 0.180
          ("AnymalTerrain", 4096, 0.9),    # 0.123
          ("ShadowHand", 16384, 1.6),      # 0.207
-         ("Anymal", 4096, 0.6),           # 0.082
+         ("Anymal", 4096, 0.4),           # 0.044 (leg waves, both sub-steps in one launch; one wave: 0.082)
          ("Quadcopter", 8192, 0.35),      # 0.042
          ("Ingenuity", 4096, 0.25),       # 0.021
          ("BallBalance", 4096, 0.3),      # 0.031
