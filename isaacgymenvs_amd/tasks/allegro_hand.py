@@ -110,6 +110,13 @@ class AllegroHand(VecTask):
         self.actuated_dof_indices = torch.tensor(ex["actuated_dofs"], dtype=torch.long, device=dev)
         self.extras["consecutive_successes"] = self.consecutive_successes[0]       # allegro_hand.py:406
 
+    def _viewer_extras(self, env):
+        """the manipulated object (drawn by its bounding ball) and the goal pose beside it (as tasks/shadow_hand.py)"""
+        obj = self.object_pos[env].detach().cpu().numpy().astype(np.float64)
+        goal = self.goal_pos[env].detach().cpu().numpy().astype(np.float64)
+        r = 0.045
+        return np.stack([obj, goal]), np.array([r, r]), np.array([[0.9, 0.75, 0.2], [0.55, 0.9, 0.55]])
+
     def _task_params(self):
         return allegro_params_from_cfg(self.cfg)
 

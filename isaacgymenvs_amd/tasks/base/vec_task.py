@@ -437,6 +437,10 @@ class VecTask(Env):
         arr = {"mass": spec.mass, "damping": spec.dof_damping, "stiffness": spec.dof_stiffness, "armature": spec.dof_armature}[attr]
         return float(np.mean(arr)) if len(arr) else 0.0
 
+    def _viewer_extras(self, env):
+        """(centres [k, 3], radii [k], colours [k, 3]) of what render() draws besides the articulation's bodies, or None"""
+        return None
+
     def render(self, mode="rgb_array"):
         """Reference vec_task.py:457-512 draws Isaac Gym's OpenGL viewer and, for `rgb_array`, grabs the virtual display.  Here the frame is
         rasterised on the host from the rigid-body state tensor of ONE env (`env.viewerEnv`, default 0) by utils/viewer.py: returned as a
@@ -456,6 +460,18 @@ class VecTask(Env):
         self.engine.refresh_rigid_body_states()
         bs = self.engine.tensors["rigid_body_state"][self._viewer_env].detach().cpu().numpy().astype(np.float64)
         centres, radii, colours = self._soft_viewer.spheres_of(spec, bs)
+        if spec.sph_body is None or len(spec.sph_body) == 0:
+            # manipulators carry their collision samples against the OBJECT (models/*_extras.json), not against the ground: draw those
+            from ...registry import load_extras
+            try:
+                ex = load_extras(getattr(self, "model_name", self.native_task.lower()))
+                shown = type("S", (), dict(sph_body=ex["os_body"], sph_pos=ex["os_pos"], sph_rad=ex["os_rad"], parent=spec.parent))
+                centres, radii, colours = self._soft_viewer.spheres_of(shown, bs)
+            except (KeyError, FileNotFoundError, TypeError):
+                pass
+        extra = self._viewer_extras(self._viewer_env)         # free bodies that are not part of the articulation (a hand's object and goal)
+        if extra is not None:
+            centres, radii, colours = np.concatenate([centres, extra[0]]), np.concatenate([radii, extra[1]]), np.concatenate([colours, extra[2]])
         if hasattr(self, "env_origins") and "Terrain" in type(self).__name__:
             self._soft_viewer.ground_z = float(self.env_origins[self._viewer_env, 2])
         img = self._soft_viewer.draw(centres, radii, colours, focus=bs[0, :3])

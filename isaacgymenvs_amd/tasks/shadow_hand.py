@@ -211,6 +211,13 @@ class ShadowHand(VecTask):
         self.fingertip_handles = torch.tensor([self.spec.body_names.index(n) for n in self.fingertips], dtype=torch.long, device=dev)
         self.extras["consecutive_successes"] = self.consecutive_successes[0]       # shadow_hand.py:424 (.mean() of a 1-vector)
 
+    def _viewer_extras(self, env):
+        """the manipulated object (drawn by its bounding ball) and, translucent in spirit, the goal pose beside it"""
+        obj = self.object_pos[env].detach().cpu().numpy().astype(np.float64)
+        goal = self.goal_pos[env].detach().cpu().numpy().astype(np.float64)
+        r = 0.035
+        return np.stack([obj, goal]), np.array([r, r]), np.array([[0.9, 0.75, 0.2], [0.55, 0.9, 0.55]])
+
     def _task_params(self):
         return hand_params_from_cfg(self.cfg)
 

@@ -141,3 +141,20 @@ def test_allegro_hand_rigid_body_states_match_the_oracle_kinematics():
     for e in (0, 7, 31):
         bp = orc.eng._poses(e)
         np.testing.assert_allclose(bs[e, :, 0:3], bp[:, 0:3], atol=2e-5)
+
+
+@pytest.mark.parametrize("task", ["AllegroHand", "ShadowHand"])
+def test_render_draws_the_hand_by_its_object_contact_spheres_and_the_object(task):
+    """VecTask.render (vec_task.py:457-512) on the software viewer for a manipulator: the hand's bodies carry no ground-contact samples, so they are
+    drawn by the spheres they collide the OBJECT with (models/*_extras.json), plus the object and the goal (`_viewer_extras`)."""
+    import isaacgymenvs_amd
+    env = isaacgymenvs_amd.make(seed=3, task=task, num_envs=16, sim_device=DEV, rl_device=DEV, headless=True)
+    for _ in range(3):
+        env.step(torch.zeros((16, env.num_actions), device=DEV))
+    img = env.render(mode="rgb_array")
+    assert img.shape == (480, 640, 3) and img.dtype == np.uint8
+    c = img.reshape(-1, 3).astype(int)
+    coloured = (c.max(axis=1) - c.min(axis=1)) > 60
+    assert coloured.mean() > 0.004                                       # the camera frames the hand (utils/viewer.py backs off by the bodies' extent)
+    yellow = (c[:, 0] - c[:, 2] > 70) & (c[:, 1] - c[:, 2] > 45) & (c[:, 0] >= c[:, 1])      # the object's colour, lit or shaded
+    assert yellow.sum() > 15
