@@ -480,6 +480,10 @@ int mi_compute_hand_reward_dextreme(int n, const MiDextremeRewardParams* p, floa
  * 1.5x on the engine's kernels; these two numbers say which kind of box a benchmark line came from. */
 int mi_device_probe(void* scratch, long long chase_bytes, int fma_iters, int hops, float* out6, void* stream);
 
+/* Test aid: fills the LDS of every CU with `pattern` (e.g. a NaN's bits).  LDS keeps what the last kernel on a CU left there; a step kernel that
+ * read a slot before writing it would depend on what ran before it -- the benchmark-size parity tests poison the LDS first. */
+int mi_debug_poison_lds(unsigned pattern, void* stream);
+
 const char* mi_last_error(void);
 
 #ifdef __cplusplus

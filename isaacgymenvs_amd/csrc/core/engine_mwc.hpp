@@ -952,7 +952,9 @@ struct SimMWC : SimMW<M> {
                 const float* pb = rows.ptr(P_B + J_ * P_CSZ);
                 const float ln = onj ? pb[PLAM * ST] : 0.f, l1 = onj ? pb[(PLAM + 1) * ST] : 0.f, l2 = onj ? pb[(PLAM + 2) * ST] : 0.f;
                 float x[3], n[3], t1[3], t2[3], f[3];
-                sfor<3>([&](auto I_) MI_LAMBDA { x[I_] = xi[I_ * ST]; n[I_] = onj ? xi[(3 + I_) * ST] : (I_ == 2 ? 1.f : 0.f); });
+                // (an unused pair slot holds whatever the LDS held before this launch: its contact point must not reach the lever arm below --
+                //  garbage x 0 is 0 for a finite pattern and NaN for an Inf / NaN one; found by poisoning the LDS, tests/test_gpu_fullsize.py)
+                sfor<3>([&](auto I_) MI_LAMBDA { x[I_] = onj ? xi[I_ * ST] : 0.f; n[I_] = onj ? xi[(3 + I_) * ST] : (I_ == 2 ? 1.f : 0.f); });
                 contact_frame(n, t1, t2);
                 sfor<3>([&](auto K) MI_LAMBDA { f[K] = (n[K] * ln + t1[K] * l1 + t2[K] * l2) * invh; });
                 sfor<NSENS>([&](auto K_) MI_LAMBDA {

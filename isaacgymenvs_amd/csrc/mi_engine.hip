@@ -971,3 +971,23 @@ extern "C" int mi_device_probe(void* scratch, long long chase_bytes, int fma_ite
     hipEventDestroy(e0); hipEventDestroy(e1);
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ LDS poison (tests)
+// Fills the LDS of every CU with a bit pattern (one 160 KB workgroup per CU, a few rounds).  LDS keeps what the last kernel on the CU left
+// in it; a kernel that reads a slot before writing it therefore depends on what ran before -- tests/test_gpu_fullsize.py poisons the LDS
+// with NaNs before the benchmark-size comparisons so that such a read shows up as a NaN instead of as a rare mismatch.
+namespace {
+__global__ __launch_bounds__(256) void poison_lds_kernel(unsigned pattern, unsigned* sink) {
+    extern __shared__ unsigned lds_words[];
+    for (int i = threadIdx.x; i < 160 * 1024 / 4; i += 256) lds_words[i] = pattern;
+    __syncthreads();
+    if (threadIdx.x == 0 && sink != nullptr && lds_words[17] != pattern) sink[0] = 1u;      // (keeps the stores alive)
+}
+}  // namespace
+extern "C" int mi_debug_poison_lds(unsigned pattern, void* stream) {
+    static unsigned long long conf = 0ull;
+    if (hipError_t e = ensure_dynamic_lds((const void*)poison_lds_kernel, 160 * 1024, &conf); e != hipSuccess) return fail(hipGetErrorString(e));
+    hipLaunchKernelGGL(poison_lds_kernel, dim3(1024), dim3(256), 160 * 1024, (hipStream_t)stream, pattern, (unsigned*)nullptr);
+    HIP_OK(hipGetLastError());
+    return 0;
+}

@@ -180,7 +180,7 @@ EXPORTS = ["mi_abi_version", "mi_task_info", "mi_engine_arena_bytes", "mi_engine
            "mi_trifinger_default_orientation", "mi_trifinger_random_orientation", "mi_trifinger_random_orientation_within_angle",
            "mi_trifinger_random_angular_vel", "mi_trifinger_random_yaw_orientation", "mi_amp_dof_to_obs",
            "mi_compute_humanoid_amp_observations", "mi_compute_humanoid_amp_reward", "mi_compute_humanoid_amp_reset", "mi_compute_hand_reward_dextreme",
-           "mi_device_probe", "mi_last_error"]
+           "mi_device_probe", "mi_debug_poison_lds", "mi_last_error"]
 
 
 def auto_multi_wave(task, num_envs):

@@ -21,7 +21,14 @@ def test_locomotion_simulate_at_the_benchmark_size(task, n, z_lo, z_hi, gear):
     """One gym.simulate() (2 sub-steps) from random states -- many of them touching the ground, the Humanoid also itself -- on all
     4096 / 8192 envs; the oracle runs every env too (OpenMP, fp64)."""
     from oracle.engine import OracleEngine
+    import ctypes as C
+    from isaacgymenvs_amd import native
     env = _make_env(task, n)
+    # LDS keeps what the last kernel on a CU left in it: poison it with NaNs so that a slot read before it is written shows up here, every
+    # time, instead of as a mismatch that depends on which test ran before this one
+    L = native.lib()
+    L.mi_debug_poison_lds.argtypes = [C.c_uint, C.c_void_p]
+    assert L.mi_debug_poison_lds(0x7FC00000, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
     spec, sb = load_model(task.lower()), sensor_bodies(task.lower())
     orc = OracleEngine(spec, n, params=_sim_dict(env.sim_params), sensor_bodies=sb, precision="f64", **_oracle_kw(task, env))
     rng = np.random.default_rng(7)
