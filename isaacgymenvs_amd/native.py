@@ -535,6 +535,10 @@ class Engine:
         if nbytes == 0:
             check(-1, L)
         self.arena = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        if os.environ.get("MI_ARENA_POISON"):
+            # tests only: an arena full of NaN bit patterns instead of zeros -- whatever mi_engine_init_state does not write shows
+            # (tests/test_gpu_step_time_sanity.py::test_init_state_writes_everything_the_step_reads)
+            self.arena.view(torch.int32)[:] = 0x7FC00000
         self._sim, self._tp = sim_params, task_params
         h = C.c_void_p()
         check(L.mi_engine_create(task.encode(), C.byref(sim_params), C.cast(C.byref(task_params), C.c_void_p),

@@ -39,3 +39,26 @@ def test_step_time_is_in_the_expected_order_of_magnitude(task, n, ceiling_ms):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / k * 1e3
     assert ms < ceiling_ms, f"{task}@{n}: {ms:.3f} ms per step (ceiling {ceiling_ms})"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("task", ["Cartpole", "Ant", "Humanoid", "AnymalTerrain", "ShadowHand", "Anymal", "AllegroHand", "Quadcopter", "Ingenuity", "BallBalance"])
+def test_init_state_writes_everything_the_step_reads(task, monkeypatch):
+    """The arena is caller-owned memory (include/mi_engine.h); the Python layer hands it over zeroed, a C client need not.  With the arena full
+    of NaN bit patterns before mi_engine_create / mi_engine_init_state (MI_ARENA_POISON) a rollout must give the same observations, rewards and
+    resets, bit for bit, as from a zeroed arena: nothing the step reads may be left to what the memory held before."""
+    import isaacgymenvs_amd
+    n = 256
+    ref = isaacgymenvs_amd.make(seed=7, task=task, num_envs=n, sim_device=DEV, rl_device=DEV, headless=True)
+    monkeypatch.setenv("MI_ARENA_POISON", "1")
+    env = isaacgymenvs_amd.make(seed=7, task=task, num_envs=n, sim_device=DEV, rl_device=DEV, headless=True)
+    monkeypatch.delenv("MI_ARENA_POISON")
+    # (the poison was there: the rigid-body state tensor is only ever written on demand)
+    assert torch.isnan(env.engine.tensors["rigid_body_state"]).all() and not torch.isnan(ref.engine.tensors["rigid_body_state"]).any()
+    g = torch.Generator(device=DEV).manual_seed(2)
+    for step in range(12):
+        a = torch.rand((n, env.num_actions), device=DEV, generator=g) * 2 - 1
+        o1, r1, d1, _ = env.step(a)
+        o2, r2, d2, _ = ref.step(a)
+        assert torch.isfinite(o1["obs"]).all() and torch.isfinite(r1).all(), (task, step)
+        assert torch.equal(o1["obs"], o2["obs"]) and torch.equal(r1, r2) and torch.equal(d1, d2), (task, step)
