@@ -1,5 +1,5 @@
-import sys, time, torch
-sys.path.insert(0, "/root/repo")
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import isaacgymenvs_amd
 from isaacgymenvs_amd.utils.config import compose
 for task, n, na in (("ShadowHand", 16384, 20), ("AllegroHand", 16384, 16)):

@@ -1,5 +1,5 @@
 """Which outputs of a Humanoid simulate() depend on what the LDS held before (tests/test_gpu_fullsize.py poisons it with NaNs)."""
-import sys; sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import sys; import os; _R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, _R); sys.path.insert(0, os.path.join(_R, "tests"))
 import ctypes as C, numpy as np, torch
 from isaacgymenvs_amd import native
 from isaacgymenvs_amd.registry import load_model
