@@ -188,6 +188,8 @@ def auto_multi_wave(task, num_envs):
     per workgroup.  Locomotion: the limb-per-wave form while its 4 * N / E waves still find a SIMD each (1024 on an MI355X) -- measured 1.4x
     faster at 4096 envs, slower from 16384 envs on (profiles/r2b_mw_ab.txt); tasks without a multi-wave form ignore the option."""
     mw = 16 if num_envs <= 4096 else (32 if num_envs <= 8192 else 0)
+    if task == "AnymalTerrain" and 8192 < num_envs <= 16384:
+        mw = 32          # with its five sim steps in one launch the leg waves still win at 16384 envs: 0.260 against 0.294 ms per step (profiles/r3zz_env_sweep.txt)
     if task == "Humanoid":
         mw = 32          # limb waves + pair wave (csrc/mwc_kernels.hpp), at any env count
     if task in ("ShadowHand", "AllegroHand"):
