@@ -264,7 +264,7 @@ def test_ant_post_physics_step_fused_into_the_last_sub_step_is_bit_identical(n):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("task,n,na,cfi", [("Ant", 4096, 8, 1), ("Ant", 200, 8, 1), ("AnymalTerrain", 1024, 12, 1), ("AnymalTerrain", 200, 12, 1),
-                                           ("Ant", 328, 8, 3), ("AnymalTerrain", 328, 12, 2)])
+                                           ("Ant", 328, 8, 3), ("AnymalTerrain", 328, 12, 2), ("AnymalTerrain", 9000, 12, 1)])
 def test_all_sub_steps_of_a_control_step_in_one_launch_are_bit_identical(task, n, na, cfi):
     """Option fused_sub = 1 (csrc/mw_kernels.hpp substep_mw_fused_kernel): the sub-steps of a control step (Ant: 2 sub-steps of
     gym.simulate, vec_task.py:379-382; AnymalTerrain: 4 decimation steps with the PD torques re-evaluated + the base class's simulate,
