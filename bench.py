@@ -28,11 +28,12 @@ Rank 0 prints ONE JSON line.
               driver run does not quote them on the first steps of the first episode.
   --scaling strong : BASELINE's "per-GPU shard = N/G" reading -- Ant 4096 / N and Humanoid 8192 / N envs per GPU ("scaling": "strong");
               the default is weak scaling (4096 / 8192 per GPU).
-  settle    = untimed steps run before the W warm-ups of the headline leg so that at least 100 steps ("warm-up 100 steps")
-              precede the timed region even with the driver's W = 5: the first step resets every env (reset_buf starts at 1,
-              vec_task.py:316) and a fresh episode has no falls / resets yet, i.e. less work than the steady state.
-  timed_regions / regions_ms_per_step = with K < 500 the K-step region (barrier + synchronize on both sides) is timed repeatedly until ~1000 steps
-              are in, `ms_per_step` / `value` are the MEDIAN region's; one region (the contract's literal reading) is the first list entry.
+  settle    = untimed steps run before the W warm-ups of the headline leg: at least 100 - W ("warm-up 100 steps") and at least 0.5 s
+              of back-to-back stepping: the first step resets every env (reset_buf starts at 1, vec_task.py:316) and a fresh episode has no
+              falls / resets yet, i.e. less work than the steady state; and a leg starts on a GPU that idled through the host-side set-up.
+  value / ms_per_step = the contract's literal region: W warm-ups, then exactly K steps between two barrier + synchronize pairs.
+  timed_regions / regions_ms_per_step / median_region = with K < 500 the same K-step region is timed again until ~1000 steps are in (diagnostic:
+              how noisy a 1 ms region is); the first list entry is the region `value` is computed from.
   legs carry `consistent` = the HIP-event time of a step's launch group fits inside the wall-clock step (kernel_ms * 0.9 <= pooled ms).
 """
 from __future__ import annotations
@@ -51,8 +52,12 @@ if ROOT not in sys.path:
 ALGO_BYTES = {"Cartpole": 89, "Ant": 673, "Humanoid": 1161, "AnymalTerrain": 2240, "ShadowHand": 3600}
 DEFAULT_ENVS = {"Cartpole": 64, "Ant": 4096, "Humanoid": 8192, "AnymalTerrain": 4096, "ShadowHand": 16384}
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
-# chip-wide VALU issue peak in wave-instructions: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
-VALU_PEAK_GINST = 256 * 4 * 2.4e9 / 4 / 1e9
+# chip-wide VALU issue peak in wave-instructions (/opt/skills/guides/MI355X_MICROARCH.md, "Wave scheduling" + the cycle-constants table): 256 CUs x
+# 4 SIMD-32 units, a wave64 VALU instruction issues over 2 cycles (32 lanes per cycle) at 2.4 GHz -> 1228.8 G wave-instructions/s; x 64 lanes x 2
+# FLOP (fma) = the 157.3 TFLOP/s fp32 vector spec.  ONE wave on a SIMD issues at most every ~4 cycles (in-order, dependent-issue latency), so
+# kernels that keep one wave per SIMD top out near 50 % of this by construction -- that is a finding about them, not a reason to halve the peak.
+VALU_PEAK_GINST = 256 * 4 * 2.4e9 / 2 / 1e9
+FP32_PEAK_TFLOPS = 157.3     # same guide, "Peak FP32 (vector)"
 
 
 def load_traffic():
@@ -73,7 +78,7 @@ def leg_consistent(res):
     return res["kernel_ms_avg"] * 0.9 <= res["ms_per_step"]
 
 
-def measure(task, num_envs, steps, warmup, device, rank, world, seed=42, pool=8, settle=0):
+def measure(task, num_envs, steps, warmup, device, rank, world, seed=42, pool=8, settle=0, settle_s=0.0):
     """Times `steps` control steps twice: with the reference's protocol (actions drawn by torch.rand right before every step,
     README.md:48-51 -- this is the reported value) and with a small pool of pre-generated action batches (engine only)."""
     import torch
@@ -115,7 +120,26 @@ def measure(task, num_envs, steps, warmup, device, rank, world, seed=42, pool=8,
             wall = float(t.item())
         return wall, gpu_ms
 
-    for i in range(settle + warmup):
+    # settle: untimed steps BEFORE the contract's W warm-ups -- at least `settle` of them and at least `settle_s` seconds of back-to-back stepping, so
+    # that the timed region starts on a device at its steady clocks (a leg starts after ~100 ms of host-side set-up with the GPU idle) and on
+    # episodes at their steady-state reset rate.  Every rank runs the same count (rank 0's) so the reducer's collectives stay matched.
+    t_settle, settled = time.perf_counter(), 0
+    while True:
+        more = settled < settle or time.perf_counter() - t_settle < settle_s
+        if use_dist:
+            flag = torch.tensor([1 if more else 0], device=device)
+            dist.broadcast(flag, 0)
+            more = bool(flag.item())
+        if not more:
+            break
+        for _ in range(50 if settled >= settle else max(settle - settled, 1)):
+            env.step(2.0 * torch.rand((num_envs, na), device=device, generator=g) - 1.0)
+            if reducer:
+                reducer.step()
+            settled += 1
+        torch.cuda.synchronize()
+    settle = settled
+    for i in range(warmup):
         env.step(2.0 * torch.rand((num_envs, na), device=device, generator=g) - 1.0)
         if reducer:
             reducer.step()
@@ -123,14 +147,15 @@ def measure(task, num_envs, steps, warmup, device, rank, world, seed=42, pool=8,
     stats0 = env.engine.tensors["episode_stats"].clone()
     wall, gpu_ms = timed(True)
     stats = (env.engine.tensors["episode_stats"] - stats0).cpu().tolist()
-    # A short timed region (the driver's --steps 20 is 1 ms of GPU time) is dominated by how the region starts -- an idle queue, the first
-    # launches' latency: the same K-step region (barrier + synchronize on both sides, exactly K steps) is therefore timed again until about
-    # 1000 steps have been timed in all, and the MEDIAN region is reported; every region's time is kept in `regions_ms_per_step`.
+    # `value` / `ms_per_step` are THIS region: W warm-ups, then exactly K steps between two barrier + synchronize pairs (the driver's contract,
+    # read literally).  A short region (the driver's --steps 20 is 1 ms of GPU time) is noisy, so the same K-step region is timed again until
+    # about 1000 steps are in; every region's time is kept in `regions_ms_per_step` and their median in `median_region` -- a diagnostic beside
+    # the value, not the value.
     regions = [(wall, gpu_ms)]
     for _ in range(min(24, max(0, -(-1000 // max(steps, 1)) - 1)) if steps < 500 else 0):
         regions.append(timed(True))
     regions_ms = [1e3 * w / steps for w, _ in regions]
-    wall, gpu_ms = sorted(regions)[len(regions) // 2]
+    med_wall = sorted(w for w, _ in regions)[len(regions) // 2]
     wall_pool, _ = timed(False)
     # per-launch duration of the fused step (sub-step kernels + post kernel): HIP events on the launch stream around each launch group
     kn = 200
@@ -152,6 +177,7 @@ def measure(task, num_envs, steps, warmup, device, rank, world, seed=42, pool=8,
         "reset_rate": stats[2] / max(stats[4], 1.0), "mean_reward": stats[3] / max(stats[4], 1.0),
         "multi_wave": int(env.engine.get_option("multi_wave")), "steps": steps, "warmup": warmup, "settle": settle,
         "timed_regions": len(regions), "regions_ms_per_step": [round(x, 5) for x in regions_ms],
+        "median_region": {"ms_per_step": 1e3 * med_wall / steps, "env_steps_per_s": world * num_envs * steps / med_wall},
     }
     try:
         res["fused_sub"] = int(env.engine.get_option("fused_sub"))     # all sub-steps of a control step in one launch (Ant, AnymalTerrain)
@@ -190,6 +216,15 @@ def roofline(task, num_envs, kernel_ms, mw=0):
         # chip's 1024 SIMDs can issue (one per 4 cycles each)
         rate = tr["valu_wave_insts_per_step"] / (kernel_ms * 1e-3) / 1e9
         out["valu"] = {"achieved": rate, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s", "frac": rate / VALU_PEAK_GINST}
+    if tr.get("fp32_flops_per_step"):
+        # SURVEY 8(d) `achieved_fp32_fraction`: COUNTED floating-point operations of one step (SQ_INSTS_VALU_{ADD,MUL,TRANS}_F32 + 2 x
+        # SQ_INSTS_VALU_FMA_F32 wave-instructions x the average live lanes per VALU instruction, SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU / 4;
+        # tools/summarize_profile.py) over the step's kernel time, against the fp32 vector peak
+        tf = tr["fp32_flops_per_step"] / (kernel_ms * 1e-3) / 1e12
+        out["fp32"] = {"achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS,
+                       "flops_per_env_step": tr["fp32_flops_per_step"] / num_envs}
+    if tr.get("live_lanes") is not None:
+        out["live_lanes"] = tr["live_lanes"]          # average live lanes per VALU wave-instruction of the step's dominant kernel (of 64)
     return out
 
 
@@ -396,7 +431,8 @@ def main():
     # bring the episodes to their steady-state reset rate): with the driver's short runs (K = 20, W = 5, i.e. 1.5 ms of GPU work) it
     # would otherwise be timed on a device that is still ramping its clocks up from idle, on envs that were all reset one step ago.
     settle = max(100 - args.warmup, 0)
-    main_res = measure(args.task, n_env, args.steps, args.warmup, device, rank, world, pool=args.pool, settle=settle)
+    main_res = measure(args.task, n_env, args.steps, args.warmup, device, rank, world, pool=args.pool, settle=settle, settle_s=0.5)
+    settle = main_res["settle"]
     import torch.distributed as dist
     if rank != 0:
         if dist.is_initialized():
@@ -414,6 +450,7 @@ def main():
                    "multi_wave": main_res["multi_wave"], "fused_sub": main_res["fused_sub"]},
         "settle": settle, "consistent": main_res["consistent"],
         "timed_regions": main_res["timed_regions"], "regions_ms_per_step": main_res["regions_ms_per_step"],
+        "median_region": main_res["median_region"],
         "gpu_ms_per_step": main_res["gpu_ms_per_step"], "reset_rate": main_res["reset_rate"],
         "mean_reward": main_res["mean_reward"], "pooled": main_res["pooled"],
         "roofline": roofline(args.task, n_env, main_res["kernel_ms_avg"], main_res["multi_wave"]),

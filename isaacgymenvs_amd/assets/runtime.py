@@ -35,8 +35,12 @@ ASSET_OPTIONS = {
     "ant": dict(),
     "humanoid": dict(),
     "anymal": dict(density=0.001, replace_cylinder_with_capsule=True),
+    # the files Quadcopter / BallBalance write before loading them (quadcopter.py:119-198, ball_balance.py:136-218; restated in procedural.py)
+    "quadcopter": dict(collide_body_filter=lambda n: False),
+    "balance_bot": dict(collide_body_filter=lambda n: False),
 }
-TASK_OF_MODEL = {"cartpole": "Cartpole", "ant": "Ant", "humanoid": "Humanoid", "anymal": "AnymalTerrain"}
+TASK_OF_MODEL = {"cartpole": "Cartpole", "ant": "Ant", "humanoid": "Humanoid", "anymal": "AnymalTerrain", "quadcopter": "Quadcopter",
+                 "balance_bot": "BallBalance"}
 
 
 def parse(path, model_name):
@@ -44,11 +48,17 @@ def parse(path, model_name):
     return load_asset(path, name=model_name, **ASSET_OPTIONS[model_name])
 
 
-def same_topology(a, b):
+def same_tree(a, b):
+    """the same kinematic tree: bodies, joints, their names and order (what the task kernels' observation layout depends on)"""
     import numpy as np
     return (a.nb == b.nb and a.nd == b.nd and bool(a.fixed_base) == bool(b.fixed_base) and np.array_equal(a.parent, b.parent)
             and np.array_equal(a.dof_body, b.dof_body) and np.array_equal(a.dof_type, b.dof_type) and list(a.body_names) == list(b.body_names)
-            and list(a.dof_names) == list(b.dof_names) and len(a.sph_body) == len(b.sph_body))
+            and list(a.dof_names) == list(b.dof_names))
+
+
+def same_topology(a, b):
+    """same_tree + the same number of contact spheres (the row store of the compiled kernels is laid out per sphere)"""
+    return same_tree(a, b) and len(a.sph_body) == len(b.sph_body)
 
 
 def match_model(path):
@@ -119,6 +129,24 @@ def variant_library(model_name, spec, device="cuda", verbose=False):
     stock_lib = native.CPU_LIB_PATH if cpu else native.LIB_PATH
     if os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(stock_lib):
         return out
+    os.makedirs(vdir, exist_ok=True)
+    # the ranks of a multi-GPU job ask for the same variant at the same time: one of them builds, the others wait for it and find the library
+    import fcntl
+    with open(os.path.join(vdir, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(stock_lib):
+                return out
+            _build_variant(model_name, txt, vdir, out, cpu, verbose)
+            spec.save(os.path.join(vdir, "model.json"))
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return out
+
+
+def _build_variant(model_name, txt, vdir, out, cpu, verbose):
+    from .. import native
+    csrc = os.path.join(_PKG, "csrc")
     src = os.path.join(vdir, "csrc")
     if os.path.isdir(src):
         shutil.rmtree(src)
@@ -133,19 +161,34 @@ def variant_library(model_name, spec, device="cuda", verbose=False):
     with open(os.path.join(deep, "gen", f"model_{model_name}.h"), "w") as f:
         f.write(txt)
     tmp = out + ".tmp"
+    os.makedirs(os.path.join(deep, "build"), exist_ok=True)
+    objs, procs = [], []
     if cpu:
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", os.path.join(deep, "cpu", "mi_engine_cpu.cpp"), "-o", tmp]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd, cwd=deep)
+        # the translation units of the CPU backend that instantiate this model (native.CPU_UNITS), linked with the stock objects of the others
+        for s, suffix, opt, defs, models in native.CPU_UNITS:
+            if models is None or model_name in models:
+                o = os.path.join(deep, "build", os.path.basename(native.cpu_object(s, suffix)))
+                cmd = ["g++", opt] + native.CPU_FLAGS + defs + ["-c", os.path.join(deep, "cpu", s), "-o", o]
+                if verbose:
+                    print(" ".join(cmd), flush=True)
+                procs.append((s, subprocess.Popen(cmd, cwd=deep, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+            else:
+                o = native.cpu_object(s, suffix)
+                if not os.path.exists(o):
+                    raise RuntimeError(f"{o} is missing: build the stock CPU library first (native.build_cpu())")
+            objs.append(o)
+        for s, p in procs:
+            log = p.communicate()[0]
+            if p.returncode != 0:
+                raise RuntimeError(f"g++ failed for the variant of {s}:\n{log.decode()[-3000:]}")
+        subprocess.check_call(["g++", "-shared", "-fPIC", "-fopenmp"] + objs + ["-o", tmp], cwd=deep)
     else:
         deps = dependent_sources(model_name)
-        objs, procs = [], []
-        os.makedirs(os.path.join(deep, "build"), exist_ok=True)
+        logs = {}
         for s in native.SOURCES:
             if s in deps:
                 o = os.path.join(deep, "build", s.replace(".hip", ".o"))
-                cmd = [native.hipcc_path()] + [f for f in native.HIPCC_FLAGS if not f.startswith("-Rpass")] + ["-c", os.path.join(deep, s), "-o", o]
+                cmd = [native.hipcc_path()] + native.HIPCC_FLAGS + ["-c", os.path.join(deep, s), "-o", o]
                 if verbose:
                     print(" ".join(cmd), flush=True)
                 procs.append((s, subprocess.Popen(cmd, cwd=deep, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -155,10 +198,17 @@ def variant_library(model_name, spec, device="cuda", verbose=False):
                     raise RuntimeError(f"{o} is missing: build the stock library first (native.build())")
             objs.append(o)
         for s, p in procs:
-            log = p.communicate()[0]
+            logs[s] = p.communicate()[0].decode()
             if p.returncode != 0:
-                raise RuntimeError(f"hipcc failed for the variant of {s}:\n{log.decode()[-3000:]}")
+                raise RuntimeError(f"hipcc failed for the variant of {s}:\n{logs[s][-3000:]}")
+        # the same gate as native.build(): a variant whose constants push a physics kernel into heavy SGPR spilling is refused, not linked
+        # (that regime returned run-to-run different results on gfx950)
+        for s, text in logs.items():
+            with open(os.path.join(deep, "build", s.replace(".hip", ".log")), "w") as f:
+                f.write(text)
+        usage = native.resource_usage(os.path.join(deep, "build"), deps)
+        bad = {k: u for k, u in usage.items() if u.get("SGPRs Spill", 0) > native.MAX_SGPR_SPILL and "substep" in k}
+        if bad:
+            raise RuntimeError(f"variant of {model_name}: step kernels spill SGPRs (known-bad regime on gfx950): {bad}")
         subprocess.check_call([native.hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp], cwd=deep)
     os.replace(tmp, out)
-    spec.save(os.path.join(vdir, "model.json"))
-    return out

@@ -8,24 +8,14 @@
 // same counter-based reset RNG: the Python side sees identical tensors and, up to fp32 summation order in the episode statistics,
 // identical numbers on both devices.
 //
-// Tasks: Cartpole, Ant, Humanoid (self-collision included), Quadcopter, Ingenuity, BallBalance.  AnymalTerrain / Anymal / ShadowHand exist
-// on the MI355X only: mi_engine_create says so.
-// Build: g++ -O2 -fopenmp -shared (isaacgymenvs_amd/native.py::build_cpu); libmi_engine_cpu.so exports the lifecycle subset.
-#include <omp.h>
-
-#include <cmath>
-#include <cstdio>
-#include <cstring>
-#include <new>
-#include <string>
-#include <vector>
-
-#include "../core/engine.hpp"
+// Tasks: every task of the table (csrc/arena_layout.hpp).  This file: the C ABI + Cartpole, Ant, Humanoid (self-collision included), Quadcopter,
+// Ingenuity, BallBalance; cpu_anymal.cpp: AnymalTerrain (BASELINE config 4), Anymal; cpu_hand.cpp + cpu_hand_physics.cpp: ShadowHand (config 5),
+// AllegroHand.
+// Build: g++ -fopenmp, one object per translation unit in parallel, linked into libmi_engine_cpu.so (isaacgymenvs_amd/native.py::build_cpu);
+// the library exports the lifecycle subset of include/mi_engine.h.
+#include "cpu_engine.hpp"
+#include "cpu_hand.hpp"
 #include "../core/bbot_engine.hpp"
-#include "../arena_layout.hpp"
-#include "../task_views.hpp"
-
-using namespace mi;
 
 static_assert(sizeof(MiSimParams) == sizeof(SimParams), "MiSimParams layout");
 static_assert(sizeof(MiLocoParams) == sizeof(LocoParams), "MiLocoParams layout");
@@ -33,35 +23,19 @@ static_assert(sizeof(MiCartpoleParams) == sizeof(CartpoleParams), "MiCartpolePar
 static_assert(sizeof(MiQuadcopterParams) == sizeof(QuadcopterParams), "MiQuadcopterParams layout");
 static_assert(sizeof(MiIngenuityParams) == sizeof(IngenuityParams), "MiIngenuityParams layout");
 static_assert(sizeof(MiBallBalanceParams) == sizeof(BallBalanceParams), "MiBallBalanceParams layout");
+static_assert(sizeof(MiAnymalParams) == sizeof(AnymalParams), "MiAnymalParams layout");
+static_assert(sizeof(MiAnymalFlatParams) == sizeof(AnymalFlatParams), "MiAnymalFlatParams layout");
+static_assert(sizeof(MiHandRewardParams) == sizeof(HandRewardParams), "MiHandRewardParams layout");
+static_assert(sizeof(MiHandParams) == sizeof(HandParams), "MiHandParams layout");
 
 static thread_local std::string g_err;
 static int fail(const std::string& m) { g_err = m; return -1; }
 extern "C" const char* mi_last_error(void) { return g_err.c_str(); }
 extern "C" int mi_abi_version(void) { return MI_ABI_VERSION; }
 
-struct MiEngine {
-    int task, N;
-    SimParams P;
-    LocoParams loco;
-    CartpoleParams cart;
-    QuadcopterParams quad;
-    IngenuityParams ing;
-    BallBalanceParams bbot;
-    QuadView qv;
-    IngenuityView iv;
-    BbotView bv;
-    View v;
-    float clip_obs;
-    int control_freq_inv, num_threads;
-    std::vector<MiTensorDesc> descs;
-    unsigned long long steps;
-    float* lamp_arena;
-    float* actor_scale_arena;   // the `actor_params` tensors: read by the sub-step once option "actor_tensors" is on (as in mi_engine.hip)
-    float* limit_shift_arena;
-};
-
-static bool cpu_task(int t) { return t == T_CARTPOLE || t == T_ANT || t == T_HUMANOID || t == T_QUADCOPTER || t == T_INGENUITY || t == T_BALLBALANCE; }
+static bool cpu_task(int t) { return t >= 0 && t < kNumTasks; }      // every task of the table has a host build
 static void build_task_extras(int t, int n, Layout& L, MiEngine* e, char* base) {
+    if (is_hand_task(t)) build_hand_layout(t, n, L, e ? &e->hv : nullptr, base);
     if (t == T_QUADCOPTER) build_quad_layout(n, L, e ? &e->qv : nullptr, base);
     if (t == T_INGENUITY) build_ingenuity_layout(n, L, e ? &e->iv : nullptr, base);
     if (t == T_BALLBALANCE) build_bbot_layout(n, L, e ? &e->bv : nullptr, base);
@@ -79,7 +53,7 @@ extern "C" size_t mi_engine_arena_bytes(const char* task, int num_envs) {
     const int t = task ? find_task(task) : -1;
     if (t < 0 || num_envs <= 0 || !cpu_task(t)) { fail("mi_engine_arena_bytes: task not available on the CPU backend"); return 0; }
     Layout L;
-    build_layout(t, num_envs, L, nullptr, nullptr);
+    build_layout(t, num_envs, L, nullptr, nullptr);      // (a narrower ShadowHand observationType only uses a prefix of obs_buf / obs_out)
     build_task_extras(t, num_envs, L, nullptr, nullptr);
     return L.off;
 }
@@ -88,7 +62,6 @@ extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const 
     if (!task || !sim || !task_params || !arena || !out) return fail("mi_engine_create: null argument");
     const int t = find_task(task);
     if (t < 0) return fail(std::string("unknown task: ") + task);
-    if (!cpu_task(t)) return fail(std::string("task ") + task + " runs on the MI355X only (CPU backend: Cartpole, Ant, Humanoid, Quadcopter, Ingenuity, BallBalance)");
     if (task_params_bytes != kTasks[t].pbytes) return fail("mi_engine_create: task_params size mismatch");
     if (num_envs <= 0) return fail("mi_engine_create: num_envs <= 0");
     if (sim->substeps < 1 || sim->dt <= 0.f) return fail("mi_engine_create: invalid sim params");
@@ -100,16 +73,40 @@ extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const 
     else if (t == T_QUADCOPTER) memcpy(&e->quad, task_params, sizeof(QuadcopterParams));
     else if (t == T_INGENUITY) memcpy(&e->ing, task_params, sizeof(IngenuityParams));
     else if (t == T_BALLBALANCE) memcpy(&e->bbot, task_params, sizeof(BallBalanceParams));
+    else if (t == T_ANYMAL) memcpy(&e->anymal, task_params, sizeof(AnymalParams));
+    else if (t == T_ANYMAL_FLAT) memcpy(&e->anymal_flat, task_params, sizeof(AnymalFlatParams));
+    else if (is_hand_task(t)) memcpy(&e->hand, task_params, sizeof(HandParams));
     else memcpy(&e->loco, task_params, sizeof(LocoParams));
+    memset(&e->terrain, 0, sizeof(e->terrain));
+    e->terrain.walls = 1;
+    e->max_init_level = 0;
+    int nobs = 0;
+    if (is_hand_task(t)) {          // the checks of mi_engine.hip
+        const HandParams& hp = e->hand;
+        const int nfull = kTasks[t].nobs;     // ShadowHand 211, AllegroHand 88
+        const bool ok = (hp.obs_type == 0 && hp.num_obs == nfull) || (hp.obs_type >= 1 && hp.obs_type <= 3 && hp.num_obs >= 1 && hp.num_obs <= 160);
+        if (!ok) { delete e; return fail("mi_engine_create: hand task obs_type / num_obs invalid"); }
+        if (hp.object_shape < 0 || hp.object_shape > 2) { delete e; return fail("mi_engine_create: hand task object_shape must be 0 (block), 1 (pen) or 2 (egg)"); }
+        if (hp.object_shape != 0)
+            for (int k = 0; k < 3; ++k)
+                if ((!(hp.object_dims[k] > 0.f) && !(hp.object_shape == 1 && k == 2)) || !(hp.object_inertia[k] > 0.f)) {
+                    delete e;
+                    return fail("mi_engine_create: hand task egg / pen need positive object_dims / object_inertia");
+                }
+        if (!(hp.cube_mass > 0.f)) { delete e; return fail("mi_engine_create: hand task object mass must be positive"); }
+        for (int k = 0; hp.obs_type != 0 && k < hp.num_obs; ++k)
+            if (hp.obs_map[k] < 0 || hp.obs_map[k] >= nfull) { delete e; return fail("mi_engine_create: hand task obs_map entry out of range"); }
+        nobs = hp.num_obs;
+    }
     if (t == T_INGENUITY && e->ing.target_period < 1) { delete e; return fail("mi_engine_create: Ingenuity target_period must be positive"); }
     if (t == T_BALLBALANCE && !(e->bbot.ball_mass > 0.f && e->bbot.ball_inertia > 0.f && e->bbot.ball_radius > 0.f && e->bbot.pin_stiffness + e->bbot.pin_damping > 0.f)) {
         delete e;
         return fail("mi_engine_create: BallBalance needs positive ball mass / inertia / radius and a non-zero attractor");
     }
     memset(&e->v, 0, sizeof(View));
-    memset(&e->qv, 0, sizeof(e->qv)); memset(&e->iv, 0, sizeof(e->iv)); memset(&e->bv, 0, sizeof(e->bv));
+    memset(&e->qv, 0, sizeof(e->qv)); memset(&e->iv, 0, sizeof(e->iv)); memset(&e->bv, 0, sizeof(e->bv)); memset(&e->hv, 0, sizeof(e->hv));
     Layout L;
-    build_layout(t, num_envs, L, &e->v, (char*)arena);
+    build_layout(t, num_envs, L, &e->v, (char*)arena, nobs);
     build_task_extras(t, num_envs, L, e, (char*)arena);
     if (arena_bytes < L.off) { delete e; return fail("mi_engine_create: arena too small"); }
     e->descs = L.d;
@@ -140,8 +137,19 @@ extern "C" int mi_engine_set_option(MiEngine* e, const char* key, double value) 
         e->v.lamp = value != 0 ? e->lamp_arena : nullptr;
         return 0;
     }
-    if (!strcmp(key, "multi_wave")) return 0;                                  // a GPU launch shape: nothing to do here
+    if (!strcmp(key, "multi_wave") || !strcmp(key, "fused_sub") || !strcmp(key, "fused_post")) return 0;     // GPU launch shapes: nothing to do here
+    if (!strcmp(key, "terrain_slope_threshold")) {   // terrain.slopeTreshold of the mesh generator (anymal_terrain.py:576); 0 = off
+        if (e->task != T_ANYMAL) return fail("terrain_slope_threshold: only AnymalTerrain has a terrain");
+        e->terrain.slope_threshold = (float)value;
+        return 0;
+    }
+    if (!strcmp(key, "terrain_walls")) {
+        if (e->task != T_ANYMAL) return fail("terrain_walls: only AnymalTerrain has a terrain");
+        e->terrain.walls = value != 0 ? 1 : 0;
+        return 0;
+    }
     if (!strcmp(key, "actor_tensors")) {
+        if (is_hand_task(e->task)) return 0;         // the hands always read their own factor tensors
         if (value != 0 && e->actor_scale_arena == nullptr) return fail("actor_tensors: this task carries no actor_scale / dof_limit_shift tensors");
         e->v.actor_scale = value != 0 ? e->actor_scale_arena : nullptr;
         e->v.limit_shift = value != 0 ? e->limit_shift_arena : nullptr;
@@ -157,6 +165,8 @@ extern "C" int mi_engine_set_noise(MiEngine* e, int which, const MiNoiseParams* 
     if (!e || !p) return fail("mi_engine_set_noise: null argument");
     if (which != 0 && which != 1) return fail("mi_engine_set_noise: which must be 0 (observations) or 1 (actions)");
     if (p->dist < 0 || p->dist > 2 || p->op < 0 || p->op > 1) return fail("mi_engine_set_noise: dist in {0,1,2}, op in {0,1}");
+    if (e->task != T_CARTPOLE && e->task != T_ANT && e->task != T_HUMANOID && !is_hand_task(e->task) && p->dist != 0)
+        return fail("mi_engine_set_noise: in-kernel noise exists for Cartpole, Ant, Humanoid and ShadowHand");
     memcpy(which == 0 ? &e->v.obs_noise : &e->v.act_noise, p, sizeof(NoiseParams));
     return 0;
 }
@@ -168,15 +178,40 @@ extern "C" int mi_engine_get_option(const MiEngine* e, const char* key, double* 
     if (!strcmp(key, "gravity_z")) { *out = e->P.g[2]; return 0; }
     if (!strcmp(key, "control_freq_inv")) { *out = e->control_freq_inv; return 0; }
     if (!strcmp(key, "self_collision")) { *out = e->v.lamp != nullptr ? 1.0 : 0.0; return 0; }
-    if (!strcmp(key, "multi_wave")) { *out = 0; return 0; }
-    if (!strcmp(key, "actor_tensors")) { *out = e->v.actor_scale != nullptr ? 1.0 : 0.0; return 0; }
+    if (!strcmp(key, "multi_wave") || !strcmp(key, "fused_sub") || !strcmp(key, "fused_post")) { *out = 0; return 0; }
+    if (!strcmp(key, "terrain_slope_threshold")) { *out = e->terrain.slope_threshold; return 0; }
+    if (!strcmp(key, "terrain_walls")) { *out = e->terrain.walls; return 0; }
+    if (!strcmp(key, "actor_tensors")) { *out = (is_hand_task(e->task) || e->v.actor_scale != nullptr) ? 1.0 : 0.0; return 0; }
     if (!strcmp(key, "steps")) { *out = (double)e->steps; return 0; }
     if (!strcmp(key, "num_threads")) { *out = e->num_threads; return 0; }
     return fail(std::string("unknown option: ") + key);
 }
 extern "C" int mi_engine_last_ring(const MiEngine* e) { return e ? (int)((e->steps + 1) & 1) : -1; }
-extern "C" int mi_engine_set_terrain(MiEngine*, const int16_t*, int, int, float, float, float, const float*, int, int, float, int) {
-    return fail("mi_engine_set_terrain: AnymalTerrain runs on the MI355X only");
+// the terrain arrays are copied: the engine does not depend on the caller keeping its buffers alive
+extern "C" int mi_engine_set_terrain(MiEngine* e, const int16_t* height_samples, int rows, int cols, float horizontal_scale, float vertical_scale,
+                                     float border_size, const float* env_origins, int num_levels, int num_terrains, float env_length, int max_init_level) {
+    if (!e) return fail("null engine");
+    if (e->task != T_ANYMAL) return fail("mi_engine_set_terrain: only AnymalTerrain uses a terrain");
+    if (!height_samples || !env_origins || rows < 2 || cols < 2 || num_levels < 1 || num_terrains < 1 || horizontal_scale <= 0.f)
+        return fail("mi_engine_set_terrain: bad argument");
+    e->terrain_hs.assign(height_samples, height_samples + (size_t)rows * cols);
+    e->terrain_origins.assign(env_origins, env_origins + (size_t)num_levels * num_terrains * 3);
+    e->terrain.hs = e->terrain_hs.data(); e->terrain.rows = rows; e->terrain.cols = cols;
+    e->terrain.hscale = horizontal_scale; e->terrain.vscale = vertical_scale; e->terrain.border = border_size;
+    e->terrain.origins = e->terrain_origins.data(); e->terrain.levels = num_levels; e->terrain.types = num_terrains;
+    e->terrain.env_length = env_length;
+    e->max_init_level = max_init_level < 0 ? 0 : (max_init_level >= num_levels ? num_levels - 1 : max_init_level);
+    return 0;
+}
+static int hand_call(MiEngine* e, int what, const float* actions, bool simulate_only, const int64_t* ids, int n, float* out_j, float* out_h) {
+    const bool sh = e->task == T_SHADOWHAND;
+    switch (what) {
+        case 0: return sh ? cpu_hand0_init(e) : cpu_hand1_init(e);
+        case 1: return sh ? cpu_hand0_step(e, actions, simulate_only) : cpu_hand1_step(e, actions, simulate_only);
+        case 2: return sh ? cpu_hand0_reset(e, ids, n) : cpu_hand1_reset(e, ids, n);
+        case 3: return sh ? cpu_hand0_body_states(e) : cpu_hand1_body_states(e);
+        default: return sh ? cpu_hand0_kinematics(e, out_j, out_h) : cpu_hand1_kinematics(e, out_j, out_h);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ initial state (= init_state_kernel)
@@ -185,9 +220,12 @@ extern "C" int mi_engine_init_state(MiEngine* e, void*) {
     const TaskMeta& m = kTasks[e->task];
     const View& v = e->v;
     const int N = v.N, nd = m.nd;
+    if (is_hand_task(e->task)) { e->steps = 0; return hand_call(e, 0, nullptr, false, nullptr, 0, nullptr, nullptr); }
+    if (e->task == T_ANYMAL && e->terrain.hs == nullptr) return fail("mi_engine_init_state: AnymalTerrain needs mi_engine_set_terrain first");
     const bool loco = e->task == T_ANT || e->task == T_HUMANOID;
     const float root_z = e->task == T_CARTPOLE ? 2.0f : e->task == T_QUADCOPTER ? e->quad.init_height : e->task == T_INGENUITY ? e->ing.init_height
-                       : e->task == T_BALLBALANCE ? e->bbot.tray_height : e->loco.start_height;      // cartpole.py:93 / ant.py:164 / the tasks' default poses
+                       : e->task == T_BALLBALANCE ? e->bbot.tray_height : e->task == T_ANYMAL ? e->anymal.base_init_state[2]
+                       : e->task == T_ANYMAL_FLAT ? e->anymal_flat.base_init_state[2] : e->loco.start_height;      // cartpole.py:93 / ant.py:164 / the tasks' default poses
     const float pot0 = loco ? -1000.f / e->loco.dt : 0.f;                                   // ant.py:113
     const float root[13] = {0, 0, root_z, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0};
     for (int en = 0; en < N; ++en) {
@@ -232,6 +270,10 @@ extern "C" int mi_engine_init_state(MiEngine* e, void*) {
         }
     }
     e->steps = 0;
+    if (e->task == T_ANYMAL || e->task == T_ANYMAL_FLAT) {
+        std::string err;
+        if (cpu_anymal_init(e, &err) != 0) return fail(err);
+    }
     return 0;
 }
 
@@ -271,13 +313,6 @@ static void simulate_env(const View& v, const SimParams& P, int en, const float*
                     Strided{v.dof_force + en, N}, PlaneGround{}, mu_env, Strided{nullptr, N}, nullptr, false,
                     (Sim<M>::NPG > 0 && v.lamp) ? &sc : nullptr);
     store_env(sim, v, en);
-}
-struct StatAcc { double fin_ret = 0, fin_len = 0, fin = 0, r = 0, cnt = 0; };
-static inline void episode_stats_env(const View& v, int en, float rew, long long reset, long long progress, StatAcc& a) {
-    float ret = v.ep_ret[en] + rew;
-    a.r += rew; a.cnt += 1;
-    if (reset != 0) { a.fin_ret += ret; a.fin_len += (double)(progress + 1); a.fin += 1; ret = 0.f; }
-    v.ep_ret[en] = ret;
 }
 // post_physics_step of Ant / Humanoid for one env (what loco_post_kernel does per lane; reference ant.py:287-297)
 template <class M, bool HUM>
@@ -631,6 +666,12 @@ extern "C" int mi_engine_step(MiEngine* e, const float* actions, void*) {
         case T_QUADCOPTER: step_quadcopter(e, actions, false); break;
         case T_INGENUITY: step_ingenuity(e, actions, false); break;
         case T_BALLBALANCE: step_ball_balance(e, actions, false); break;
+        case T_ANYMAL:
+            if (e->terrain.hs == nullptr) return fail("mi_engine_step: AnymalTerrain needs mi_engine_set_terrain first");
+            cpu_anymal_step(e, actions, false);
+            break;
+        case T_ANYMAL_FLAT: cpu_anymal_step(e, actions, false); break;
+        case T_SHADOWHAND: case T_ALLEGROHAND: hand_call(e, 1, actions, false, nullptr, 0, nullptr, nullptr); break;
         default: return fail("mi_engine_step: task not on the CPU backend");
     }
     e->steps++;
@@ -655,6 +696,12 @@ extern "C" int mi_engine_simulate(MiEngine* e, void*) {
         case T_QUADCOPTER: step_quadcopter(e, nullptr, true); break;
         case T_INGENUITY: step_ingenuity(e, nullptr, true); break;
         case T_BALLBALANCE: step_ball_balance(e, nullptr, true); break;
+        case T_ANYMAL:
+            if (e->terrain.hs == nullptr) return fail("mi_engine_simulate: AnymalTerrain needs mi_engine_set_terrain first");
+            cpu_anymal_step(e, nullptr, true);
+            break;
+        case T_ANYMAL_FLAT: cpu_anymal_step(e, nullptr, true); break;
+        case T_SHADOWHAND: case T_ALLEGROHAND: hand_call(e, 1, nullptr, true, nullptr, 0, nullptr, nullptr); break;
         default: return fail("mi_engine_simulate: task not on the CPU backend");
     }
     return 0;
@@ -686,6 +733,8 @@ extern "C" int mi_engine_refresh_rigid_body_states(MiEngine* e, void*) {
         case T_QUADCOPTER: body_states_all<ModelQuadcopter>(e); break;
         case T_INGENUITY: body_states_all<ModelIngenuity>(e); break;
         case T_BALLBALANCE: body_states_all<ModelBalanceBot>(e); break;
+        case T_ANYMAL: case T_ANYMAL_FLAT: cpu_anymal_body_states(e); break;
+        case T_SHADOWHAND: case T_ALLEGROHAND: hand_call(e, 3, nullptr, false, nullptr, 0, nullptr, nullptr); break;
         default: return fail("mi_engine_refresh_rigid_body_states: task not on the CPU backend");
     }
     return 0;
@@ -718,6 +767,8 @@ static int kinematics_views(MiEngine* e, float* out_j, float* out_h, const char*
         case T_QUADCOPTER: kinematics_views_all<ModelQuadcopter>(e, out_j, out_h); break;
         case T_INGENUITY: kinematics_views_all<ModelIngenuity>(e, out_j, out_h); break;
         case T_BALLBALANCE: kinematics_views_all<ModelBalanceBot>(e, out_j, out_h); break;
+        case T_ANYMAL: case T_ANYMAL_FLAT: cpu_anymal_kinematics(e, out_j, out_h); break;
+        case T_SHADOWHAND: case T_ALLEGROHAND: hand_call(e, 4, nullptr, false, nullptr, 0, out_j, out_h); break;
         default: return fail(std::string(who) + ": task not on the CPU backend");
     }
     return 0;
@@ -775,6 +826,8 @@ extern "C" int mi_engine_reset_idx(MiEngine* e, const int64_t* env_ids, int n, v
                 for (int d = 0; d < kBbotDof; ++d) e->bv.targets[d * N + (int)env_ids[i]] = 0.f;
             }
             break;
+        case T_ANYMAL: case T_ANYMAL_FLAT: cpu_anymal_reset(e, env_ids, n); break;
+        case T_SHADOWHAND: case T_ALLEGROHAND: hand_call(e, 2, nullptr, false, env_ids, n, nullptr, nullptr); break;
         default: return fail("mi_engine_reset_idx: task not on the CPU backend");
     }
     return 0;

@@ -442,8 +442,13 @@ template <class M, bool HUM, bool NOISE>
 __global__ __launch_bounds__(post_lanes<M>()) void loco_post_kernel(View v, LocoParams tp) {
     constexpr int ND = M::ND, PL = post_lanes<M>();
     const int N = v.N;
+    // xcd_grid rounds the grid up to whole XCD rounds: a workgroup entirely past the batch leaves here.  (It must not shadow env N - 1: its
+    // loads of that env's reset / progress flags are not ordered against the real wave's end-of-kernel stores, and the streaming form below
+    // stores as it goes -- a late shadow wave could overwrite the terminal observation with a post-reset one.)  Shadow lanes remain only
+    // inside the partly filled wave, in lockstep with the real lane whose values they repeat.
+    if (xcd_env_base<PL>(blockIdx.x) >= N) return;
     const int e0 = xcd_env_base<PL>(blockIdx.x) + threadIdx.x;
-    const bool valid = e0 < N;           // tail lanes shadow the last env (no stores) so wave reductions stay full
+    const bool valid = e0 < N;           // tail lanes shadow the last env so wave reductions stay full
     const int e = valid ? e0 : N - 1;
     float root[13], q[M::NDA], qd[M::NDA];
     sfor<13>([&](auto K) MI_LAMBDA { root[K] = v.root[K * N + e]; });

@@ -2,6 +2,7 @@
 // Shared by the HIP library (mi_engine.hip, kernels_<task>.hip) and the CPU backend (cpu/mi_engine_cpu.cpp): one definition each.
 #pragma once
 #include "arena_layout.hpp"
+#include "hand_view.hpp"
 
 namespace mi {
 
@@ -57,3 +58,34 @@ static inline void build_bbot_layout(int N, Layout& L, BbotView* bv, char* base)
     o = L.add("ball_contact_count", MI_I32, {n}, {1}, n); if (bv) bv->ncontact = (int*)P(o);
     L.off = (L.off + 255) & ~size_t(255);
 }
+// ShadowHand extras (shadow_hand.py:150-222): object / goal root states, targets, fingertip body states, success counters
+// (AllegroHand, allegro_hand.py:142-203: the same tensors for 16 dofs, no fingertips, an 88-wide full state)
+static inline void build_hand_layout(int task, int N, Layout& L, HandView* hv, char* base) {
+    const int64_t n = N, nd = kTasks[task].nd, nt = kTasks[task].nsens, nfull = kTasks[task].nobs;
+    auto P = [&](size_t o) { return base ? base + o : (char*)nullptr; };
+    size_t o;
+    o = L.add("cur_targets", MI_F32, {n, nd}, {1, n}, nd * n); if (hv) hv->cur_targets = (float*)P(o);
+    o = L.add("prev_targets", MI_F32, {n, nd}, {1, n}, nd * n); if (hv) hv->prev_targets = (float*)P(o);
+    o = L.add("object_state", MI_F32, {n, 13}, {1, n}, 13 * n); if (hv) hv->object_state = (float*)P(o);
+    o = L.add("goal_states", MI_F32, {n, 7}, {1, n}, 7 * n); if (hv) hv->goal_state = (float*)P(o);
+    o = L.add("fingertip_state", MI_F32, {n, nt > 0 ? nt : 1, 13}, {1, 13 * n, n}, 13 * (nt > 0 ? nt : 1) * n); if (hv) hv->fingertip = (float*)P(o);
+    o = L.add("successes", MI_F32, {n}, {1}, n); if (hv) hv->successes = (float*)P(o);
+    o = L.add("reset_goal_buf", MI_I64, {n}, {1}, n); if (hv) hv->reset_goal = (long long*)P(o);
+    o = L.add("goal_reset_count", MI_I32, {n}, {1}, n); if (hv) hv->goal_count = (int*)P(o);
+    o = L.add("consecutive_successes", MI_F32, {1}, {1}, 1); if (hv) hv->cons = (float*)P(o);
+    // [0], [1]: the step's sums for the consecutive-successes average; [2], [3]: spare
+    o = L.add("reward_workspace", MI_F32, {4}, {1}, 4); if (hv) hv->ws = (float*)P(o);
+    o = L.add("object_contact_count", MI_I32, {n}, {1}, n); if (hv) hv->ncontact = (int*)P(o);
+    o = L.add("states_buf", MI_F32, {n, nfull}, {nfull, 1}, nfull * n); if (hv) hv->full_state = (float*)P(o);
+    o = L.add("object_force", MI_F32, {n, 3}, {1, n}, 3 * n); if (hv) hv->obj_force = (float*)P(o);
+    o = L.add("rb_forces_object", MI_F32, {n, 3}, {1, n}, 3 * n); if (hv) hv->rb_force = (float*)P(o);
+    o = L.add("random_force_prob", MI_F32, {n}, {1}, n); if (hv) hv->force_prob = (float*)P(o);
+    o = L.add("friction", MI_F32, {n}, {1}, n); if (hv) hv->mu_env = (float*)P(o);   // hand-object contact friction per env (negative: HandParams.mu)
+    // `actor_params` factors of the hand and the object (core/hand_engine.hpp HS_*), 1 = the model's own values
+    o = L.add("actor_scale", MI_F32, {n, 8}, {1, n}, 8 * n); if (hv) hv->scale = (float*)P(o);
+    // `actor_params.hand.dof_properties.lower / upper`: shifts of the 24 lower, then the 24 upper joint limits of each env's hand
+    o = L.add("dof_limit_shift", MI_F32, {n, 2 * nd}, {1, n}, 2 * nd * n); if (hv) hv->limit_shift = (float*)P(o);
+    o = L.add("object_contact_dropped", MI_I32, {n}, {1}, n); if (hv) hv->ndropped = (int*)P(o);   // contacts refused since init: all KMAX slots taken
+    L.off = (L.off + 255) & ~size_t(255);
+}
+

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI_ENGINE_LIB") or os.path.join(_HERE, "libmi_engine.so")
 # CPU product backend (sim_device="cpu": the reference's CPU pipeline, BASELINE config 1), built with g++ from the same engine sources
 CPU_LIB_PATH = os.path.join(_HERE, "libmi_engine_cpu.so")
-CPU_TASKS = ("Cartpole", "Ant", "Humanoid", "Quadcopter", "Ingenuity", "BallBalance")
+CPU_TASKS = ("Cartpole", "Ant", "Humanoid", "AnymalTerrain", "ShadowHand", "Anymal", "Quadcopter", "Ingenuity", "BallBalance", "AllegroHand")
 CSRC = os.path.join(_HERE, "csrc")
 BUILD_DIR = os.path.join(CSRC, "build")
 # one translation unit per robot model (they compile in parallel) + the C ABI
@@ -321,12 +321,12 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
-def resource_usage():
+def resource_usage(build_dir=None, sources=None):
     """Parse the -Rpass-analysis=kernel-resource-usage remarks of the last build: {kernel: {field: value}}."""
     import re
     out = {}
-    for name in SOURCES:
-        logp = os.path.join(BUILD_DIR, name.replace(".hip", ".log"))
+    for name in (sources if sources is not None else SOURCES):
+        logp = os.path.join(build_dir or BUILD_DIR, name.replace(".hip", ".log"))
         if not os.path.exists(logp):
             continue
         cur = None
@@ -387,35 +387,80 @@ def cpu_needs_build():
     return os.path.getmtime(os.path.join(_HERE, "..", "include", "mi_engine.h")) > t
 
 
+# translation units of the CPU backend: (source, object suffix, optimisation level, defines).  The hand + object sub-step is compiled once per
+# hand and object shape (about a minute each at -O1; they run side by side and beside the hipcc jobs)
+# last column: the robot models whose constants the unit instantiates (None: all -- it holds the arena layout); a run-time variant of a model
+# (assets/runtime.py) recompiles only those
+_HAND_MODEL = {0: "shadow_hand", 1: "allegro_hand"}
+CPU_UNITS = [("mi_engine_cpu.cpp", "", "-O2", [], None), ("cpu_anymal.cpp", "", "-O2", [], ("anymal",))] + \
+            [("cpu_hand.cpp", f"_{h}", "-O2", [f"-DMI_CPU_HAND={h}"], (_HAND_MODEL[h],)) for h in (0, 1)] + \
+            [("cpu_hand_physics.cpp", f"_{h}_{sh}", "-O1", [f"-DMI_CPU_HAND={h}", f"-DMI_CPU_SHAPE={sh}"], (_HAND_MODEL[h],)) for h in (0, 1) for sh in (0, 1, 2)]
+CPU_FLAGS = ["-std=c++17", "-fPIC", "-fopenmp", "-ffp-contract=off"]
+
+
+def cpu_object(src, suffix):
+    return os.path.join(BUILD_DIR, "cpu_" + src.replace(".cpp", "") + suffix + ".o")
+
+
+class _CpuJob:
+    """the g++ processes of one CPU-backend build; finish() waits for them and links"""
+
+    def __init__(self, procs, objs):
+        self.procs, self.objs = procs, objs
+
+    def finish(self):
+        failed = []
+        for name, p, log in self.procs:
+            rc = p.wait()
+            log.close()
+            if rc != 0:
+                failed.append((name, log.name))
+        if failed:
+            for name, logp in failed:
+                with open(logp) as f:
+                    print(f.read()[-4000:])
+            raise RuntimeError(f"g++ failed for the CPU backend: {[n for n, _ in failed]}")
+        tmp = CPU_LIB_PATH + ".tmp"
+        subprocess.check_call(["g++", "-shared", "-fPIC", "-fopenmp"] + self.objs + ["-o", tmp])
+        os.replace(tmp, CPU_LIB_PATH)
+
+
 def build_cpu(force=False, wait=True):
-    """g++ build of the CPU backend (csrc/cpu/mi_engine_cpu.cpp: engine.hpp + tasks/locomotion.hpp on the host, OpenMP over envs).
-    Returns the Popen when wait=False (build() overlaps it with the hipcc jobs)."""
+    """g++ build of the CPU backend (csrc/cpu/: the engine core, the task headers and the arena layout the kernels use, on the host, OpenMP
+    over envs): one object per translation unit, compiled in parallel, linked into libmi_engine_cpu.so.
+    Returns the job when wait=False (build() overlaps it with the hipcc jobs)."""
     from .registry import generate_headers
     generate_headers()
     if not force and not cpu_needs_build():
         return None
-    tmp = CPU_LIB_PATH + ".tmp"
-    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", os.path.join(CSRC, "cpu", "mi_engine_cpu.cpp"),
-           "-o", tmp]
     os.makedirs(BUILD_DIR, exist_ok=True)
-    log = open(os.path.join(BUILD_DIR, "mi_engine_cpu.log"), "w")
-    p = subprocess.Popen(cmd, cwd=CSRC, stdout=log, stderr=subprocess.STDOUT)
-    p._mi_finish = lambda: (log.close(), os.replace(tmp, CPU_LIB_PATH))
+    hdrs = []
+    for d, _, fs in os.walk(CSRC):
+        if os.path.abspath(d).startswith(os.path.abspath(BUILD_DIR)):
+            continue
+        hdrs += [os.path.join(d, f) for f in fs if f.endswith((".hpp", ".h"))]
+    hdrs.append(os.path.join(_HERE, "..", "include", "mi_engine.h"))
+    newest = max(os.path.getmtime(h) for h in hdrs)
+    procs, objs = [], []
+    for src, suffix, opt, defs, _models in CPU_UNITS:
+        srcp = os.path.join(CSRC, "cpu", src)
+        obj = cpu_object(src, suffix)
+        objs.append(obj)
+        if not force and not _obj_stale(srcp, obj, newest):
+            continue
+        cmd = ["g++", opt] + CPU_FLAGS + defs + ["-c", srcp, "-o", obj]
+        log = open(obj.replace(".o", ".log"), "w")
+        procs.append((os.path.basename(obj), subprocess.Popen(cmd, cwd=CSRC, stdout=log, stderr=subprocess.STDOUT), log))
+    job = _CpuJob(procs, objs)
     if not wait:
-        return p
-    _finish_cpu(p)
+        return job
+    job.finish()
     return None
 
 
-def _finish_cpu(p):
-    if p is None:
-        return
-    rc = p.wait()
-    if rc != 0:
-        with open(os.path.join(BUILD_DIR, "mi_engine_cpu.log")) as f:
-            print(f.read()[-4000:])
-        raise RuntimeError("g++ failed for the CPU backend (csrc/cpu/mi_engine_cpu.cpp)")
-    p._mi_finish()
+def _finish_cpu(job):
+    if job is not None:
+        job.finish()
 
 
 def lib_cpu():
@@ -523,7 +568,7 @@ class Engine:
         if dev.type == "cpu":
             # the reference's CPU pipeline (sim_device=cpu): the engine's own host build, OpenMP over envs -- not the test oracle
             if task not in CPU_TASKS:
-                raise RuntimeError(f"task {task} runs on the MI355X only (sim_device='cuda:N'); the CPU backend has {', '.join(CPU_TASKS)}")
+                raise RuntimeError(f"unknown task {task} for the CPU backend ({', '.join(CPU_TASKS)})")
             L = lib_cpu() if lib_path is None else variant_lib(lib_path)
         elif dev.type == "cuda":
             if not torch.cuda.is_available():

@@ -59,6 +59,33 @@ class Vec3:
     def __sub__(self, o):
         return Vec3(self.x - o.x, self.y - o.y, self.z - o.z)
 
+    def __neg__(self):
+        return Vec3(-self.x, -self.y, -self.z)
+
+    def __mul__(self, k):            # scalar (ball_balance.py:180 `(upper_leg_from + upper_leg_to) * 0.5`, ingenuity.py:191 `rotor_separation * i`)
+        return Vec3(self.x * float(k), self.y * float(k), self.z * float(k))
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, k):
+        return Vec3(self.x / float(k), self.y / float(k), self.z / float(k))
+
+    def dot(self, o):
+        return self.x * o.x + self.y * o.y + self.z * o.z
+
+    def cross(self, o):
+        return Vec3(self.y * o.z - self.z * o.y, self.z * o.x - self.x * o.z, self.x * o.y - self.y * o.x)
+
+    def length(self):
+        return float(np.sqrt(self.dot(self)))
+
+    def length_sq(self):
+        return float(self.dot(self))
+
+    def normalize(self):
+        n = self.length() or 1.0
+        return Vec3(self.x / n, self.y / n, self.z / n)
+
     def __repr__(self):
         return f"Vec3({self.x}, {self.y}, {self.z})"
 
@@ -73,15 +100,73 @@ class Quat:
         n = np.sqrt(axis.x ** 2 + axis.y ** 2 + axis.z ** 2) or 1.0
         return Quat(axis.x / n * s, axis.y / n * s, axis.z / n * s, np.cos(0.5 * angle))
 
+    @staticmethod
+    def from_euler_zyx(x, y, z):
+        """the rotation Rz(z) Ry(y) Rx(x): the arguments are the angles about x, y and z in that order (only this reading puts the feet of the
+        BallBalance legs on their attractor targets, ball_balance.py:181,293-297; assets/procedural.py restates the same)"""
+        cz, sz, cy, sy, cx, sx = np.cos(z / 2), np.sin(z / 2), np.cos(y / 2), np.sin(y / 2), np.cos(x / 2), np.sin(x / 2)
+        return Quat(sx * cy * cz - cx * sy * sz, cx * sy * cz + sx * cy * sz, cx * cy * sz - sx * sy * cz, cx * cy * cz + sx * sy * sz)
+
+    def to_euler_zyx(self):
+        """(x, y, z) such that from_euler_zyx(x, y, z) is this rotation"""
+        x, y, z, w = self.x, self.y, self.z, self.w
+        return (float(np.arctan2(2 * (w * x + y * z), 1 - 2 * (x * x + y * y))), float(np.arcsin(np.clip(2 * (w * y - z * x), -1.0, 1.0))),
+                float(np.arctan2(2 * (w * z + x * y), 1 - 2 * (y * y + z * z))))
+
     def __mul__(self, o):          # Hamilton product (allegro_hand.py:283 composes the hand's start rotation from three axis-angle quats)
         return Quat(self.w * o.x + self.x * o.w + self.y * o.z - self.z * o.y, self.w * o.y - self.x * o.z + self.y * o.w + self.z * o.x,
                     self.w * o.z + self.x * o.y - self.y * o.x + self.z * o.w, self.w * o.w - self.x * o.x - self.y * o.y - self.z * o.z)
+
+    def rotate(self, v):           # quadcopter.py:160 `rotor_arm_quat.rotate(rotor_arm_offset)`: v + 2 w (q x v) + 2 q x (q x v)
+        q = Vec3(self.x, self.y, self.z)
+        t = q.cross(v) * 2.0
+        return v + t * self.w + q.cross(t)
+
+    def inverse(self):
+        n = self.x ** 2 + self.y ** 2 + self.z ** 2 + self.w ** 2 or 1.0
+        return Quat(-self.x / n, -self.y / n, -self.z / n, self.w / n)
+
+    def normalize(self):
+        n = np.sqrt(self.x ** 2 + self.y ** 2 + self.z ** 2 + self.w ** 2) or 1.0
+        return Quat(self.x / n, self.y / n, self.z / n, self.w / n)
+
+    def __repr__(self):
+        return f"Quat({self.x}, {self.y}, {self.z}, {self.w})"
 
 
 class Transform:
     def __init__(self, p=None, r=None):
         self.p = p if p is not None else Vec3()
         self.r = r if r is not None else Quat()
+
+    def transform_point(self, v):
+        return self.r.rotate(v) + self.p
+
+    def transform_vector(self, v):
+        return self.r.rotate(v)
+
+    def inverse(self):
+        ri = self.r.inverse()
+        return Transform(-ri.rotate(self.p), ri)
+
+    def __mul__(self, o):
+        return Transform(self.transform_point(o.p), self.r * o.r)
+
+
+# rigid-body attractors (ball_balance.py:285-300): a spring-damper that pulls a point of a body to a world target
+AXIS_NONE, AXIS_X, AXIS_Y, AXIS_Z, AXIS_TWIST, AXIS_SWING_1, AXIS_SWING_2 = 0, 1, 2, 4, 8, 16, 32
+AXIS_TRANSLATION, AXIS_ROTATION, AXIS_ALL = 7, 56, 63
+
+
+class AttractorProperties:
+    def __init__(self):
+        self.stiffness, self.damping, self.axes, self.rigid_handle = 0.0, 0.0, AXIS_NONE, -1
+        self.target, self.offset = Transform(), Transform()
+
+
+class VhacdParams:        # convex decomposition settings of mesh assets (trifinger.py:1120): recorded, the engine samples meshes by spheres
+    def __init__(self):
+        self.resolution, self.max_convex_hulls, self.max_num_vertices_per_ch = 100000, 64, 64
 
 
 class _Bag:
@@ -96,7 +181,8 @@ class AssetOptions(_Bag):
         super().__init__(default_dof_drive_mode=DOF_MODE_NONE, angular_damping=0.5, linear_damping=0.0, fix_base_link=False,
                          collapse_fixed_joints=False, density=1000.0, armature=0.0, thickness=0.02, disable_gravity=False,
                          replace_cylinder_with_capsule=False, flip_visual_attachments=False, max_angular_velocity=64.0,
-                         max_linear_velocity=1000.0, use_mesh_materials=False)
+                         max_linear_velocity=1000.0, use_mesh_materials=False, slices_per_cylinder=20, vhacd_enabled=False,
+                         vhacd_params=VhacdParams())
 
 
 class PlaneParams(_Bag):
@@ -148,11 +234,21 @@ class SimParams:
 # ---------------------------------------------------------------------------------------------------------------- recorded objects
 _MODEL_OF_FILE = {"nv_ant.xml": ("ant", "Ant"), "nv_humanoid.xml": ("humanoid", "Humanoid"), "cartpole.urdf": ("cartpole", "Cartpole"),
                   "anymal_minimal.urdf": ("anymal", "AnymalTerrain"), "shadow_hand.xml": ("shadow_hand", "ShadowHand"),
+                  # anymal.py:168 loads anymal.urdf: the same robot (13 bodies, 12 dofs, same names and order) with more collision shapes
+                  # (boxes / cylinders on base, hips, thighs, shanks) -- the engine's flat Anymal runs the compiled model's contact set (feet,
+                  # knees, base capsule); _Asset checks the kinematic tree of the file against it (tests/test_gymapi_shim.py)
+                  "anymal.urdf": ("anymal", "Anymal"),
+                  # the files the tasks write themselves before loading them (quadcopter.py:198, ingenuity.py:231, ball_balance.py:218);
+                  # assets/procedural.py restates the generators, the compiled models come from those restatements
+                  "quadcopter.xml": ("quadcopter", "Quadcopter"), "ingenuity.xml": ("ingenuity", "Ingenuity"),
+                  "balance_bot.xml": ("balance_bot", "BallBalance"),
                   # cfg/task/AllegroHand.yaml asset.assetFileName (allegro_hand.py:212-214)
                   "allegro_touch_sensor.urdf": ("allegro_hand", "AllegroHand")}
 # the hand tasks' free objects (shadow_hand.py:86-96, allegro_hand.py:88-92 + AllegroHand.yaml assetFileNameBlock): one body, no dof
 _OBJECT_OF_FILE = {"cube_multicolor.urdf": "block", "cube_multicolor_allegro.urdf": "block", "egg.xml": "egg", "pen.xml": "pen"}
 _HAND_TASKS = ("ShadowHand", "AllegroHand")
+# files that describe a compiled robot with a richer collision set: accepted when the kinematic tree is the compiled model's (anymal.py:168)
+_SAME_ROBOT_MORE_SHAPES = ("anymal.urdf",)
 
 
 class _ActuatorProps:
@@ -162,10 +258,21 @@ class _ActuatorProps:
 
 
 class _Asset:
+    @classmethod
+    def primitive(cls, shape, dims, options):
+        """gym.create_sphere / create_box / create_capsule: a one-body asset without dofs (ball_balance.py:277 the ball, ingenuity.py:254 the
+        target marker).  Which of the engine's free objects it is follows from the task of the articulated actor it shares its envs with."""
+        a = cls.__new__(cls)
+        a.options, a.sensors, a.shape_friction, a.tendon_props = options, [], None, None
+        a.spec, a.object_type, a.dims = None, shape, tuple(float(d) for d in dims)
+        a.body_names, a.body_dyn, a.nshapes = [shape], np.zeros(1, np.int64), 1
+        return a
+
     def __init__(self, path, options):
         from ...registry import load_extras, load_model, load_selfcol, sensor_bodies
         key = os.path.basename(path)
         self.options = options
+        self.file_spec = None
         self.sensors = []                      # rigid-body indices in the order create_asset_force_sensor was called
         self.shape_friction = None             # set_asset_rigid_shape_properties: friction of the asset's shapes for the actors created next
         self.tendon_props = None
@@ -183,9 +290,12 @@ class _Asset:
             if os.path.isfile(path) and self.model_name in runtime.ASSET_OPTIONS and runtime.load_selfcol(self.model_name) is None:
                 spec = runtime.parse(path, self.model_name)          # the file itself, not the copy compiled at build time
                 if runtime.header_text(self.model_name, spec) != runtime.header_text(self.model_name, self.spec):
-                    if not runtime.same_topology(spec, self.spec):
+                    if key in _SAME_ROBOT_MORE_SHAPES and runtime.same_tree(spec, self.spec):
+                        self.file_spec = spec        # the file as parsed; the engine runs the compiled model's contact set and constants
+                    elif not runtime.same_topology(spec, self.spec):
                         raise NotImplementedError(f"gym.load_asset: {path} does not have the kinematic tree of the compiled {self.model_name} model")
-                    self.spec, self.variant = spec, True
+                    else:
+                        self.spec, self.variant = spec, True
         elif os.path.isfile(path):
             self.model_name, self.spec = runtime.match_model(path)   # a file of another name with the tree of a compiled model
             self.task = runtime.TASK_OF_MODEL[self.model_name]
@@ -227,6 +337,7 @@ class _Sim:
         self.frame = 0
         self.bufs = {}
         self.one_shot_force = False
+        self.attractors = []                   # create_rigid_body_attractor, env 0
 
     # the articulated actor (the engine's robot) and the free objects
     @property
@@ -355,7 +466,34 @@ class Gym:
 
     def create_asset_force_sensor(self, asset, body_idx, local_pose, props=None):
         asset.sensors.append(int(body_idx))
+        if not hasattr(asset, "sensor_poses"):
+            asset.sensor_poses = []
+        asset.sensor_poses.append(local_pose)
         return len(asset.sensors) - 1
+
+    # primitive one-body assets (ball_balance.py:274-277, ingenuity.py:253-254)
+    def create_sphere(self, sim, radius, options=None):
+        return _Asset.primitive("sphere", (radius,), options if options is not None else AssetOptions())
+
+    def create_box(self, sim, width, height, depth, options=None):
+        return _Asset.primitive("box", (width, height, depth), options if options is not None else AssetOptions())
+
+    def create_capsule(self, sim, radius, length, options=None):
+        return _Asset.primitive("capsule", (radius, length), options if options is not None else AssetOptions())
+
+    def create_rigid_body_attractor(self, env, props):
+        """ball_balance.py:285-300: recorded (for env 0; every env must ask for the same); prepare_sim turns them into the engine's pins"""
+        if env.index == 0:
+            env.sim.attractors.append(dict(body=int(props.rigid_handle), stiffness=float(props.stiffness), damping=float(props.damping), axes=int(props.axes),
+                                           target=(props.target.p.x, props.target.p.y, props.target.p.z),
+                                           offset=(props.offset.p.x, props.offset.p.y, props.offset.p.z)))
+        return len(env.sim.attractors) - 1
+
+    def get_rigid_transform(self, env, handle):
+        return Transform()
+
+    def debug_print_asset(self, asset):
+        print(f"asset: bodies {asset.body_names}")
 
     def create_env(self, sim, lower, upper, num_per_row):
         env = _Env(sim, len(sim.envs))
@@ -388,7 +526,12 @@ class Gym:
         return _dof_properties(env.sim.slots[actor]["asset"].spec)
 
     def set_actor_dof_properties(self, env, actor, props):
-        return True                             # drive modes / gains of the compiled models are fixed at build time
+        """Drive modes and gains are task parameters of the engine: kept (env 0's; every env sets the same) and read by prepare_sim for the
+        tasks whose drives the engine implements (Anymal, Quadcopter, Ingenuity, BallBalance); the passive stiffness / damping of the other
+        compiled models are fixed at build time."""
+        if env.index == 0:
+            env.sim.slots[actor]["dof_props"] = np.array(props, copy=True)
+        return True
 
     def get_actor_rigid_body_count(self, env, actor):
         return len(env.sim.slots[actor]["asset"].body_names)
@@ -495,6 +638,72 @@ class Gym:
             for k in range(3):
                 if abs(tp.hand_pos[k] - float(poses[0, k])) > 1e-6:
                     raise NotImplementedError("the hand is mounted at (0, 0, 0.5) (shadow_hand.py:306-307, allegro_hand.py:282)")
+        elif asset.task == "Anymal":
+            # anymal.py:186-206: DOF_MODE_POS drives with env.control.stiffness / damping on every dof
+            from ...tasks.anymal import anymal_flat_params_from_cfg
+            tp = anymal_flat_params_from_cfg(cfg, list(asset.spec.dof_names))
+            dp = rslot.get("dof_props")
+            if dp is not None:
+                if not (np.all(dp["driveMode"] == DOF_MODE_POS) and np.ptp(dp["stiffness"]) == 0 and np.ptp(dp["damping"]) == 0):
+                    raise NotImplementedError("Anymal: one position drive gain pair for all dofs (anymal.py:203-206)")
+                tp.kp, tp.kd = float(dp["stiffness"][0]), float(dp["damping"][0])
+            for k in range(7):
+                tp.base_init_state[k] = float(poses[0, k])
+        elif asset.task == "Quadcopter":
+            from ...tasks.quadcopter import quadcopter_params_from_cfg
+            tp = quadcopter_params_from_cfg(cfg, asset.spec)
+            dp = rslot.get("dof_props")
+            if dp is not None:             # quadcopter.py:236-239: position drives, stiffness 1000, damping 0
+                if np.ptp(dp["stiffness"]) != 0 or np.ptp(dp["damping"]) != 0:
+                    raise NotImplementedError("Quadcopter: one drive gain pair for all dofs")
+                tp.drive_stiffness, tp.drive_damping = float(dp["stiffness"][0]), float(dp["damping"][0])
+            tp.max_angular_velocity = float(getattr(asset.options, "max_angular_velocity", tp.max_angular_velocity))
+            tp.init_height = float(poses[0, 2])
+        elif asset.task == "Ingenuity":
+            from ...tasks.ingenuity import ingenuity_params_from_cfg
+            tp = ingenuity_params_from_cfg(cfg)
+            dp = rslot.get("dof_props")
+            if dp is not None and (np.any(dp["stiffness"] != 0) or np.any(dp["damping"] != 0)):
+                raise NotImplementedError("Ingenuity: the rotor joints are undriven (ingenuity.py:265-268)")
+            tp.max_angular_velocity = float(getattr(asset.options, "max_angular_velocity", tp.max_angular_velocity))
+            tp.init_height = float(poses[0, 2])
+        elif asset.task == "BallBalance":
+            from ...tasks.ball_balance import ball_balance_params_from_cfg
+            tp = ball_balance_params_from_cfg(cfg, asset.spec)
+            dp = rslot.get("dof_props")
+            if dp is not None:             # ball_balance.py:271-281: the lower-leg joints are position drives, the upper ones free
+                act = [d for d in range(asset.spec.nd) if int(dp["driveMode"][d]) == DOF_MODE_POS]
+                if not act or np.ptp(dp["stiffness"][act]) != 0 or np.ptp(dp["damping"][act]) != 0:
+                    raise NotImplementedError("BallBalance: position drives with one gain pair")
+                tp.drive_kp, tp.drive_kd = float(dp["stiffness"][act[0]]), float(dp["damping"][act[0]])
+                tp.actuated_mask = sum(1 << d for d in act)
+            if sim.attractors:             # :285-300: three translation attractors on the lower legs = the engine's pins
+                legs = [asset.body_names.index(f"lower_leg{j}") for j in range(3)]
+                if [a["body"] for a in sim.attractors] != legs or any(a["axes"] != AXIS_TRANSLATION for a in sim.attractors):
+                    raise NotImplementedError("BallBalance: one translation attractor per lower leg (ball_balance.py:285-300)")
+                a0 = sim.attractors[0]
+                if any(a["stiffness"] != a0["stiffness"] or a["damping"] != a0["damping"] or a["offset"] != a0["offset"] for a in sim.attractors):
+                    raise NotImplementedError("BallBalance: the three attractors share stiffness, damping and body offset")
+                tp.pin_stiffness, tp.pin_damping = a0["stiffness"], a0["damping"]
+                for k in range(3):
+                    tp.pin_offset[k] = a0["offset"][k]
+                    for j in range(3):
+                        tp.pin_target[j][k] = sim.attractors[j]["target"][k]
+            else:
+                raise NotImplementedError("BallBalance without attractors: the engine's tray stands on pinned feet")
+            balls = [sl for sl in sim.slots if sl["asset"].spec is None]
+            if balls:                      # :274-277, 303-306: the ball's radius / density and start pose
+                ba = balls[0]["asset"]
+                if ba.object_type != "sphere":
+                    raise NotImplementedError("BallBalance: the free object is a sphere")
+                r, dens = ba.dims[0], float(getattr(ba.options, "density", 1000.0))
+                tp.ball_radius, tp.ball_mass = r, dens * 4.0 / 3.0 * np.pi * r ** 3
+                tp.ball_inertia = 0.4 * tp.ball_mass * r * r
+                for k in range(3):
+                    tp.ball_init_pos[k] = float(balls[0]["poses"][0][k])
+            tp.tray_height = float(poses[0, 2])
+            for j, sp_ in enumerate(getattr(asset, "sensor_poses", [])[:3]):
+                tp.sensor_pos[j][0], tp.sensor_pos[j][1], tp.sensor_pos[j][2] = sp_.p.x, sp_.p.y, sp_.p.z
         else:
             from ...tasks.locomotion import loco_params_from_cfg
             tp = loco_params_from_cfg(cfg, asset.model_name, float(poses[0, 2]))
@@ -522,12 +731,13 @@ class Gym:
             for e, val in rslot["friction"].items():
                 mu[e] = val
             t["friction"][:] = mu.to(sim.device)
-        if asset.task in _HAND_TASKS:
+        if self._object_tensor(sim) is not None:
             k_obj = [k for k, sl in enumerate(sim.slots) if sl["asset"].spec is None]
             if k_obj:
                 o = torch.zeros((n, 13), dtype=torch.float32)
                 o[:, :7] = torch.tensor(sim.slots[k_obj[0]]["poses"], dtype=torch.float32)
-                t["object_state"][:] = o.to(sim.device)
+                t[self._object_tensor(sim)][:] = o.to(sim.device)
+        if asset.task in _HAND_TASKS:
             if asset.tendon_props:                   # limit stiffness / damping of the four coupling tendons as factors of the model's own
                 ks = {pr for i, pr in enumerate(asset.tendon_props) if pr != (0.0, 0.0)}
                 if len(ks) > 1:
@@ -536,7 +746,9 @@ class Gym:
                     ls, dm = next(iter(ks))
                     t["actor_scale"][:, 3] = ls / float(asset.extras["tendon_limit_stiffness"])
                     t["actor_scale"][:, 4] = dm / float(asset.extras["tendon_damping"])
-        if asset.sensors and asset.sensors != asset.engine_sensor_bodies[:len(asset.sensors)]:
+        # (BallBalance: the task's three sensors sit on the tray, :254-260 -- the engine computes exactly those from the tray's momentum balance;
+        #  its `sensor` bodies are the lower legs the attractors hold)
+        if asset.task != "BallBalance" and asset.sensors and asset.sensors != asset.engine_sensor_bodies[:len(asset.sensors)]:
             raise NotImplementedError(f"force sensors on bodies {asset.sensors}: the compiled {asset.model_name} model has them on "
                                       f"{asset.engine_sensor_bodies}")
         return True
@@ -548,9 +760,16 @@ class Gym:
         return sim.bufs[name]
 
     def _object_slots(self, sim):
-        """[(slot, has physics)] of the free objects: the first one is the engine's object, the others (goal) live in the shim"""
+        """[(slot, lives in the engine)] of the free objects: the first one is the engine's object, the others (goal) live in the shim"""
         ks = [k for k, sl in enumerate(sim.slots) if sl["asset"].spec is None]
-        return [(k, i == 0) for i, k in enumerate(ks)]
+        return [(k, i == 0 and self._object_tensor(sim) is not None) for i, k in enumerate(ks)]
+
+    _OBJECT_TENSOR = {"ShadowHand": "object_state", "AllegroHand": "object_state", "BallBalance": "ball_states", "Ingenuity": "marker_states"}
+
+    def _object_tensor(self, sim):
+        """the engine tensor that holds the root state of the task's free object: the manipulated object of the hand tasks, BallBalance's ball
+        (ball_balance.py:303-306), Ingenuity's target marker (ingenuity.py:270; no physics, the engine only keeps its state)"""
+        return self._OBJECT_TENSOR.get(sim.asset.task)
 
     def acquire_actor_root_state_tensor(self, sim):
         n, A = len(sim.envs), sim.nactors
@@ -619,7 +838,7 @@ class Gym:
         v[:, sim.robot].copy_(sim.engine.tensors["root_states"])
         for k, phys in self._object_slots(sim):
             if phys:
-                v[:, k].copy_(sim.engine.tensors["object_state"])
+                v[:, k].copy_(sim.engine.tensors[self._object_tensor(sim)])
         return True
 
     def refresh_dof_state_tensor(self, sim):
@@ -677,7 +896,7 @@ class Gym:
         root = sim.bufs.get("root")
         for i, (k, phys) in enumerate(objs):
             if phys:
-                buf[:, nb + i].copy_(sim.engine.tensors["object_state"])
+                buf[:, nb + i].copy_(sim.engine.tensors[self._object_tensor(sim)])
             elif root is not None:
                 buf[:, nb + i].copy_(root.view(n, sim.nactors, 13)[:, k])
         return True
@@ -690,22 +909,54 @@ class Gym:
         sim.engine.tensors["dof_actuation_force"].copy_(forces.view(n, nd))
         return True
 
-    def set_dof_position_target_tensor(self, sim, targets):
+    def _write_targets(self, sim, targets, envs=None):
+        """position targets of the drives -> the engine tensor the task's simulate() reads: `cur_targets` (hands), `dof_position_targets`
+        (Quadcopter, BallBalance); the flat Anymal's engine keeps the policy's actions and derives target = action_scale * a + default
+        (anymal.py:226-229), so the targets are turned back into those"""
+        t = sim.engine.tensors
         n, nd = len(sim.envs), sim.asset.spec.nd
-        sim.engine.tensors["cur_targets"].copy_(targets.view(n, nd))
+        x = targets.view(n, nd)
+        if sim.asset.task == "Anymal":
+            tp = sim.engine._tp
+            dflt = torch.tensor([tp.default_dof_pos[d] for d in range(nd)], dtype=torch.float32, device=sim.device)
+            name, x = "actions", (x - dflt) / float(tp.action_scale)
+        else:
+            name = "cur_targets" if "cur_targets" in t else "dof_position_targets"
+        if envs is None:
+            t[name].copy_(x)
+        else:
+            t[name][envs] = x[envs]
         return True
 
+    def set_dof_position_target_tensor(self, sim, targets):
+        return self._write_targets(sim, targets)
+
     def set_dof_position_target_tensor_indexed(self, sim, targets, actor_indices, count):
+        return self._write_targets(sim, targets, torch.div(actor_indices[:count].long(), sim.nactors, rounding_mode="floor"))
+
+    def set_dof_actuation_force_tensor_indexed(self, sim, forces, actor_indices, count):
         n, nd = len(sim.envs), sim.asset.spec.nd
-        envs = torch.div(actor_indices[:count].long(), sim.nactors, rounding_mode="floor")
-        sim.engine.tensors["cur_targets"][envs] = targets.view(n, nd)[envs]
+        envs = self._envs_of(sim, actor_indices, count, sim.robot)
+        sim.engine.tensors["dof_actuation_force"][envs] = forces.view(n, nd)[envs]
         return True
 
     def apply_rigid_body_force_tensors(self, sim, forces=None, torques=None, space=ENV_SPACE):
         """shadow_hand.py:700-708: random forces on the object's body, in its local frame; held for the next simulate() only"""
+        t = sim.engine.tensors
+        if forces is not None and "forces" in t and "object_force" not in t:
+            # quadcopter.py:290-292 / ingenuity.py:350-352: thrust forces on the rotor bodies, in the bodies' own frames -- the engine's `forces`
+            # tensor [N, bodies, 3] (it applies the rows of its rotor bodies; the tasks leave the others zero); held for the next simulate()
+            if space != LOCAL_SPACE or torques is not None:
+                raise NotImplementedError("apply_rigid_body_force_tensors: forces in LOCAL_SPACE, no torques (quadcopter.py:292, ingenuity.py:352)")
+            n = len(sim.envs)
+            f = forces.view(n, -1, 3)
+            nbe = min(f.shape[1], t["forces"].shape[1])
+            t["forces"][:, :nbe].copy_(f[:, :nbe])
+            sim.one_shot_force = True
+            return True
         objs = [k for k, phys in self._object_slots(sim) if phys]
         if forces is None or not objs or "object_force" not in sim.engine.tensors:
-            raise NotImplementedError("apply_rigid_body_force_tensors: forces on the free object of the ShadowHand task")
+            raise NotImplementedError("apply_rigid_body_force_tensors: forces on the free object of the hand tasks or on the rotor bodies of Quadcopter / Ingenuity")
         n, nb = len(sim.envs), len(sim.asset.body_names)
         f = forces.view(n, -1, 3)[:, nb]
         if space == LOCAL_SPACE:
@@ -716,7 +967,7 @@ class Gym:
 
     def _clear_warm_start(self, sim, ids):
         t = sim.engine.tensors
-        for k in ("contact_impulse", "limit_impulse", "self_contact_impulse"):
+        for k in ("contact_impulse", "limit_impulse", "self_contact_impulse", "attractor_impulse"):
             if k in t:
                 t[k][ids] = 0.0
 
@@ -748,7 +999,7 @@ class Gym:
         for k, phys in self._object_slots(sim):
             ids = self._envs_of(sim, actor_indices, count, k)
             if phys and len(ids):
-                sim.engine.tensors["object_state"][ids] = src[ids, k]
+                sim.engine.tensors[self._object_tensor(sim)][ids] = src[ids, k]
             # (the goal object: the task's own tensor IS the state)
         if root_states.data_ptr() != self._buf(sim, "root", (n * A, 13)).data_ptr():
             self._buf(sim, "root", (n * A, 13)).view(n, A, 13)[:] = src
@@ -761,7 +1012,7 @@ class Gym:
             sim.engine.tensors["root_states"].copy_(src[:, sim.robot])
         for k, phys in self._object_slots(sim):
             if phys:
-                sim.engine.tensors["object_state"].copy_(src[:, k])
+                sim.engine.tensors[self._object_tensor(sim)].copy_(src[:, k])
         return True
 
     # ------------------------------------------------------------------ stepping
@@ -769,7 +1020,7 @@ class Gym:
         sim.engine.simulate()
         sim.frame += 1
         if sim.one_shot_force:                      # gym applies body forces for one simulate() only
-            sim.engine.tensors["object_force"].zero_()
+            sim.engine.tensors["object_force" if "object_force" in sim.engine.tensors else "forces"].zero_()
             sim.one_shot_force = False
 
     def fetch_results(self, sim, wait=True):

@@ -20,6 +20,13 @@ def test_roofline_object_fields_and_arithmetic():
         assert r["traffic_source"]
     if "valu" in r:
         assert 0 < r["valu"]["frac"] < 1
+    # the compute-side peaks are the guide's: SIMD-32, a wave64 VALU instruction per 2 cycles -> 256 x 4 x 2.4 GHz / 2 wave-instructions/s,
+    # which x 64 lanes x 2 FLOP is the 157.3 TFLOP/s fp32 vector spec (the line used half of it)
+    assert abs(bench.VALU_PEAK_GINST - 1228.8) < 1e-9
+    assert abs(bench.VALU_PEAK_GINST * 1e9 * 64 * 2 / 1e12 - bench.FP32_PEAK_TFLOPS) < 0.1
+    if "fp32" in r:
+        assert r["fp32"]["peak"] == 157.3 and 0 < r["fp32"]["frac"] < 1
+        assert abs(r["fp32"]["achieved"] - r["fp32"]["flops_per_env_step"] * 4096 / 0.075e-3 / 1e12) < 1e-9
     assert "multi-wave" not in r["note"] and "4 waves" in bench.roofline("Ant", 4096, 0.05, mw=16)["note"]
     for task, n in bench.DEFAULT_ENVS.items():
         assert bench.roofline(task, n, 1.0)["algorithmic_bytes_per_launch"] == bench.ALGO_BYTES[task] * n

@@ -81,8 +81,8 @@ def test_locomotion_on_cpu_matches_the_cpu_restatement(task, hum, z0):
 
 
 def test_cpu_backend_scope_and_threads():
-    with pytest.raises(RuntimeError, match="MI355X only"):
-        isaacgymenvs_amd.make(seed=0, task="ShadowHand", num_envs=8, sim_device="cpu", rl_device="cpu", headless=True)
+    assert set(native.CPU_TASKS) == {"Cartpole", "Ant", "Humanoid", "AnymalTerrain", "ShadowHand", "Anymal", "Quadcopter", "Ingenuity",
+                                     "BallBalance", "AllegroHand"}             # every task of the table (csrc/arena_layout.hpp)
     env = isaacgymenvs_amd.make(seed=0, task="Cartpole", num_envs=8, sim_device="cpu", rl_device="cpu", headless=True)
     env.engine.set_option("num_threads", 2)
     a = torch.zeros((8, 1))
@@ -92,7 +92,12 @@ def test_cpu_backend_scope_and_threads():
     assert torch.equal(r1, env2.step(a)[0]["obs"])                            # the thread count does not change results
     # the CPU library is built from the engine sources, not from the test oracle
     src = open(os.path.join(os.path.dirname(native.__file__), "csrc", "cpu", "mi_engine_cpu.cpp")).read()
-    assert '#include "../core/engine.hpp"' in src and "physics.c" not in src.replace("oracle/", "")
+    assert "physics.c\"" not in src and "oracle/physics" not in src
+    cdir = os.path.join(os.path.dirname(native.__file__), "csrc", "cpu")
+    for f in os.listdir(cdir):
+        body = open(os.path.join(cdir, f)).read()
+        assert not [ln for ln in body.splitlines() if ln.lstrip().startswith("#include") and "oracle" in ln] and "dlopen" not in body, f
+    assert '#include "../core/engine.hpp"' in open(os.path.join(cdir, "cpu_engine.hpp")).read()
 
 
 def test_reference_user_script_runs_unedited():
@@ -300,3 +305,140 @@ def test_rigid_body_state_tensor_matches_the_oracle_kinematics(task, model):
     assert moving > 0.5                                    # the bodies do move in these states
     # row 0 is the root body: the actor root state itself
     np.testing.assert_allclose(out[:, 0, :], env.engine.tensors["root_states"].numpy() if not spec.fixed_base else out[:, 0, :], atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configs 4 / 5 on the CPU pipeline
+# (round 4) AnymalTerrain, Anymal, ShadowHand, AllegroHand through make(..., "cpu", "cpu"): the per-env bodies of the HIP kernels
+# (csrc/tasks/anymal_step.hpp, csrc/tasks/hand_task.hpp) + the engine's one-wave sub-steps, against the independent restatement in its
+# Gauss-Seidel order -- the tests of tests/test_gpu_parity.py for these tasks, runnable without a GPU.
+def test_anymal_terrain_on_cpu_matches_the_cpu_restatement():
+    from oracle.tasks import OracleAnymalTerrainEnv
+    n, seed = 96, 21
+    env = isaacgymenvs_amd.make(seed=seed, task="AnymalTerrain", num_envs=n, sim_device="cpu", rl_device="cpu", headless=True)
+    orc = OracleAnymalTerrainEnv(load_model("anymal"), _sim_dict(env.sim_params), env._task_params_struct, env.terrain, n, seed=seed, precision="f64",
+                                 solver="gs", blocks=None)
+    t = env.engine.tensors
+    np.testing.assert_array_equal(t["terrain_types"].numpy(), orc.terrain_types)
+    np.testing.assert_allclose(t["friction"].numpy(), orc.friction, rtol=1e-6)
+    np.testing.assert_allclose(env.root_states.numpy(), orc.eng.root, atol=1e-5)
+    np.testing.assert_allclose(env.dof_pos.numpy(), orc.eng.q, atol=1e-6)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for step in range(8):
+        a = torch.rand((n, 12), generator=g) * 2 - 1
+        obs_d, rew, reset, extras = env.step(a)
+        o_obs, o_rew, o_reset = orc.step(a.numpy())
+        obs = env.obs_buf.numpy()
+        assert np.isfinite(obs).all()
+        d = np.abs(obs - o_obs)
+        other = np.concatenate([d[:, :36], d[:, 176:]], axis=1)     # (the height-scan columns jump by a grid cell at cell borders: statistically)
+        ok = other.max(axis=1) < 3e-3 * (1 + step)
+        assert ok.mean() > 0.95, (step, ok.mean(), other.max())
+        assert (d[:, 36:176] < 0.05).mean() > 0.97, step
+        same = reset.numpy().astype(bool) == o_reset.astype(bool)
+        assert same.mean() > 0.97, (step, same.mean())
+        if step < 4:
+            np.testing.assert_allclose(rew.numpy()[ok & same], o_rew[ok & same], atol=5e-3)
+        np.testing.assert_array_equal(env.progress_buf.numpy()[same], orc.progress_buf[same])
+    assert obs_d["obs"].shape == (n, 188) and set(extras["episode"].keys()) >= {"rew_lin_vel_xy", "rew_air_time", "terrain_level"}
+    assert np.abs(env.contact_forces.numpy()).max() > 20.0        # the feet do carry the robot (net contact forces, :119-130)
+
+
+def test_anymal_flat_on_cpu_matches_the_cpu_restatement():
+    from oracle.tasks import OracleAnymalEnv
+    n, seed = 96, 17
+    env = isaacgymenvs_amd.make(seed=seed, task="Anymal", num_envs=n, sim_device="cpu", rl_device="cpu", headless=True)
+    orc = OracleAnymalEnv(load_model("anymal"), _sim_dict(env.sim_params), env._task_params_struct, n, seed=seed, precision="f64")
+    np.testing.assert_allclose(env.root_states.numpy(), orc.eng.root, atol=1e-6)
+    np.testing.assert_allclose(env.commands.numpy(), orc.commands, atol=1e-6)
+    g = torch.Generator(device="cpu").manual_seed(9)
+    for step in range(10):
+        a = torch.rand((n, 12), generator=g) * 2 - 1
+        obs_d, rew, reset, extras = env.step(a)
+        o_obs, o_rew, o_reset = orc.step(a.numpy())
+        d = np.abs(env.obs_buf.numpy() - o_obs).max(axis=1)
+        ok = d < 2e-3 * (1 + step)
+        assert ok.mean() > 0.95, (step, ok.mean(), d.max())
+        same = reset.numpy().astype(bool) == o_reset.astype(bool)
+        assert same.mean() > 0.97, (step, same.mean())
+        if step < 5:
+            np.testing.assert_allclose(rew.numpy()[ok & same], o_rew[ok & same], atol=2e-3)
+        np.testing.assert_array_equal(env.progress_buf.numpy()[same], orc.progress_buf[same])
+    assert obs_d["obs"].shape == (n, 48) and float(obs_d["obs"].abs().max()) <= 5.0 + 1e-6
+
+
+@pytest.mark.parametrize("object_type", ["block", "egg", "pen"])
+def test_shadow_hand_on_cpu_matches_the_cpu_restatement(object_type):
+    """BASELINE config 5's task on the reference's CPU pipeline: hand + object physics, deferred resets, the 211-column full state."""
+    from isaacgymenvs_amd.registry import load_extras
+    from oracle.tasks import OracleShadowHandEnv
+    n, seed = 48, 13
+    cfg = compose(overrides=["task=ShadowHand"])
+    cfg["task"]["env"]["numEnvs"] = n
+    cfg["task"]["env"]["objectType"] = object_type
+    env = isaacgymenvs_amd.make(seed=seed, task="ShadowHand", num_envs=n, sim_device="cpu", rl_device="cpu", headless=True, cfg=cfg)
+    assert env._task_params_struct.object_shape == {"block": 0, "pen": 1, "egg": 2}[object_type]
+    orc = OracleShadowHandEnv(load_model("shadow_hand"), load_extras("shadow_hand"), sensor_bodies("shadow_hand"), _sim_dict(env.sim_params),
+                              env._task_params_struct, n, seed=seed, solver="gs")
+    g = torch.Generator(device="cpu").manual_seed(7)
+    for step in range(8):
+        a = torch.rand((n, 20), generator=g) * 2 - 1
+        obs_d, rew, reset, extras = env.step(a)
+        o_obs, o_rew, o_reset = orc.step(a.numpy())
+        obs = env.obs_buf.numpy()
+        assert np.isfinite(obs).all()
+        if step == 0:
+            np.testing.assert_allclose(env.goal_states.numpy(), orc.goal_states, atol=1e-6)
+        np.testing.assert_array_equal(env.engine.tensors["object_contact_count"].numpy() > 0, orc.eng.ncontacts > 0)
+        d = np.abs(obs - o_obs)
+        kin = np.concatenate([d[:, :48], d[:, 72:161], d[:, 191:]], axis=1)      # force-like columns scale with the contact impulses
+        ok = kin.max(axis=1) < 5e-3 * (1 + step)
+        assert ok.mean() > 0.9, (step, ok.mean(), kin.max())
+        np.testing.assert_array_equal(reset.numpy()[ok], o_reset[ok])
+        np.testing.assert_allclose(rew.numpy()[ok], o_rew[ok], atol=0.05 * (1 + step), rtol=1e-2)
+    assert obs_d["obs"].shape == (n, 211) and float(obs_d["obs"].abs().max()) <= 5.0 + 1e-6 and "consecutive_successes" in extras
+
+
+def test_allegro_hand_on_cpu_matches_the_cpu_restatement():
+    from isaacgymenvs_amd.registry import load_extras
+    from oracle.tasks import OracleAllegroHandEnv
+    n, seed = 48, 13
+    env = isaacgymenvs_amd.make(seed=seed, task="AllegroHand", num_envs=n, sim_device="cpu", rl_device="cpu", headless=True)
+    orc = OracleAllegroHandEnv(load_model("allegro_hand"), load_extras("allegro_hand"), [], _sim_dict(env.sim_params), env._task_params_struct, n, seed=seed,
+                               control_freq_inv=env.control_freq_inv, solver="gs")
+    g = torch.Generator(device="cpu").manual_seed(7)
+    touched = np.zeros(n, bool)
+    for step in range(5):
+        a = torch.rand((n, 16), generator=g) * 2 - 1
+        obs_d, rew, reset, extras = env.step(a)
+        o_obs, o_rew, o_reset = orc.step(a.numpy())
+        nc = env.engine.tensors["object_contact_count"].numpy()
+        np.testing.assert_array_equal(nc > 0, orc.eng.ncontacts > 0)
+        touched |= nc > 0
+        d = np.abs(env.obs_buf.numpy() - o_obs)
+        kin = np.concatenate([d[:, :32], d[:, 48:]], axis=1)
+        ok = kin.max(axis=1) < 5e-3 * (1 + step)
+        assert ok.mean() > 0.9, (step, ok.mean(), kin.max())
+        np.testing.assert_array_equal(reset.numpy()[ok], o_reset[ok])
+        np.testing.assert_allclose(rew.numpy()[ok], o_rew[ok], atol=0.05 * (1 + step), rtol=1e-2)
+    assert touched.mean() > 0.5 and obs_d["obs"].shape == (n, 88)
+
+
+def test_cpu_backend_explicit_reset_and_body_states_of_the_new_tasks():
+    """reset_idx / reset_done, gym.refresh_rigid_body_state_tensor and the Jacobian / mass-matrix tensors exist for the new CPU tasks too."""
+    for task, nb in (("AnymalTerrain", 13), ("ShadowHand", None), ("AllegroHand", None), ("Anymal", 13)):
+        env = isaacgymenvs_amd.make(seed=3, task=task, num_envs=16, sim_device="cpu", rl_device="cpu", headless=True)
+        a = torch.zeros((16, env.num_actions))
+        for _ in range(3):
+            env.step(a)
+        env.engine.refresh_rigid_body_states()
+        rb = env.engine.tensors["rigid_body_state"]
+        assert torch.isfinite(rb).all() and (rb[:, :, 3:7].norm(dim=-1) - 1).abs().max() < 1e-4
+        if nb:
+            assert rb.shape[1] == nb
+            assert torch.allclose(rb[:, 0, :7], env.root_states[:, :7], atol=1e-6)        # body 0 is the base
+        J = env.engine.compute_jacobians()
+        H = env.engine.compute_mass_matrices()
+        assert torch.isfinite(J).all() and torch.isfinite(H).all() and (torch.linalg.eigvalsh(H) > 0).all()
+        env.reset_buf[:] = 1
+        _, done = env.reset_done()
+        assert len(done) == 16 and int(env.progress_buf.abs().sum()) == 0

@@ -116,6 +116,24 @@ for k, v in d.items():
                f"{a.get('SQ_WAVE_CYCLES', 0) / wv:.0f} | {a.get('SQ_ACTIVE_INST_ANY', 0) / wv:.0f} | {a.get('SQ_WAIT_ANY', 0) / wv:.0f} | "
                f"{100 * a.get('SQ_WAIT_ANY', 0) / max(a.get('SQ_WAVE_CYCLES', 1), 1):.0f} |")
 
+# ---- counted fp32 operations and live lanes (round 4; its own pass: tools/profile_r4.sh pmc_flops)
+flops, live = {}, {}
+pf = os.path.join(src, "pmc_flops", f"{tag}_counter_collection.csv")
+if os.path.exists(pf):
+    d2, _ = agg(pf)
+    out.append("\n| kernel | VALU wave-insts | ADD_F32 | MUL_F32 | FMA_F32 | TRANS_F32 | fp32 share of VALU | live lanes per VALU inst (THREAD_CYCLES / ACTIVE_INST) | FLOP per launch |")
+    out.append("|---|---|---|---|---|---|---|---|---|")
+    for k, v in d2.items():
+        if not ours(k):
+            continue
+        a = {c: sum(x) / len(x) for c, x in v.items()}
+        ll = min(a.get("SQ_THREAD_CYCLES_VALU", 0.0) / max(a.get("SQ_ACTIVE_INST_VALU", 1.0), 1.0), 64.0)
+        fins = a.get("SQ_INSTS_VALU_ADD_F32", 0) + a.get("SQ_INSTS_VALU_MUL_F32", 0) + a.get("SQ_INSTS_VALU_TRANS_F32", 0) + a.get("SQ_INSTS_VALU_FMA_F32", 0)
+        fl = (a.get("SQ_INSTS_VALU_ADD_F32", 0) + a.get("SQ_INSTS_VALU_MUL_F32", 0) + a.get("SQ_INSTS_VALU_TRANS_F32", 0) + 2 * a.get("SQ_INSTS_VALU_FMA_F32", 0)) * ll
+        flops[k], live[k] = fl, ll
+        out.append(f"| `{k}` | {a.get('SQ_INSTS_VALU', 0):.0f} | {a.get('SQ_INSTS_VALU_ADD_F32', 0):.0f} | {a.get('SQ_INSTS_VALU_MUL_F32', 0):.0f} | {a.get('SQ_INSTS_VALU_FMA_F32', 0):.0f} | "
+                   f"{a.get('SQ_INSTS_VALU_TRANS_F32', 0):.0f} | {100 * fins / max(a.get('SQ_INSTS_VALU', 1), 1):.0f} % | {ll:.1f} | {fl / 1e6:.1f} M |")
+
 # ---- one control step per task = these launches (pattern, launches per step)
 RECIPE = {
     # (a fused-sub-step kernel, when the trace has one, is the step's ONE physics launch: option fused_sub, csrc/mw_kernels.hpp)
@@ -132,7 +150,7 @@ out.append("\n## One control step (what bench.py reports as roofline.traffic / r
 out.append("| task | launches | calibrated HBM-side bytes / step | VALU wave-instructions / step | kernel time / step (us) |")
 out.append("|---|---|---|---|---|")
 for task, recipe in RECIPE.items():
-    tot_b, tot_v, tot_t, names = 0.0, 0.0, 0.0, []
+    tot_b, tot_v, tot_t, tot_f, names, dom = 0.0, 0.0, 0.0, 0.0, [], (0.0, None)
     for pat, cnt in recipe:
         keys = sorted(traffic, key=lambda k: "fused" not in k)       # a fused kernel first
         for k in keys:
@@ -140,10 +158,14 @@ for task, recipe in RECIPE.items():
                 if isinstance(cnt, dict):
                     cnt = cnt["fused" if "fused" in k else "plain"]
                 tot_b += cnt * traffic[k]["bytes"]; tot_v += cnt * valu.get(k, 0.0); tot_t += cnt * dur_ns.get(k, 0.0) / 1e3
+                tot_f += cnt * flops.get(k, 0.0)
+                if cnt * dur_ns.get(k, 0.0) > dom[0]:
+                    dom = (cnt * dur_ns.get(k, 0.0), k)
                 names.append(f"{cnt} x {k.split('<')[0].replace('mi::', '')}")
                 break
     if tot_b > 0:
         tj[task] = {"traffic_bytes_per_step": int(tot_b), "valu_wave_insts_per_step": int(tot_v), "kernel_us_per_step": round(tot_t, 1),
+                    "fp32_flops_per_step": int(tot_f) if tot_f > 0 else None, "live_lanes": round(live[dom[1]], 1) if dom[1] in live else None,
                     "source": f"profiles/{tag}_pmc_summary.md (FETCH_SIZE x {f_fetch:.2f} + WRITE_SIZE x {f_write:.2f}, calibrated on tools/calib/calib_fetch.hip)"}
         out.append(f"| {task} | {', '.join(names)} | {tot_b / 1e6:.2f} MB | {tot_v / 1e6:.2f} M | {tot_t:.1f} |")
 json.dump(tj, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
