@@ -24,8 +24,9 @@ def make(seed: int, task: str, num_envs: int, sim_device: str, rl_device: str, g
         cfg_dict = omegaconf_to_dict(cfg["task"] if "task" in cfg and hasattr(cfg["task"], "items") and "env" in cfg["task"] else cfg)
     if multi_gpu:  # reference utils/rlgames_utils.py:89-107: one process per GPU, device = cuda:LOCAL_RANK
         local_rank = int(os.getenv("LOCAL_RANK", "0"))
-        sim_device = f"cuda:{local_rank}"
-        rl_device = f"cuda:{local_rank}"
+        if not str(sim_device).startswith("cpu"):      # (a sharded job on the CPU backend keeps its device: one process per shard, gloo)
+            sim_device = f"cuda:{local_rank}"
+            rl_device = f"cuda:{local_rank}"
         cfg_dict["_multi_gpu"] = True
     cfg_dict["_seed"] = int(seed) if seed is not None and seed >= 0 else 0
     # Contract under multi_gpu: the caller passes seed + RANK, as the reference's launcher does (rlgames_utils.py:89-107,

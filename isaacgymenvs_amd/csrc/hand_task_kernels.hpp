@@ -49,36 +49,47 @@ struct HandDevRed {
         episode_stats(v, e, valid, rew, reset, progress);
     }
 };
-// post_physics_step (shadow_hand.py:710-715): hand_post_env (tasks/hand_task.hpp) per lane; the fingertip states come from hand_tips_kernel
-template <class HT>
-__global__ __launch_bounds__(64) void hand_post_kernel(View v, HandView hv, HandParams p) {
+// post_physics_step (shadow_hand.py:710-715): hand_post_env (tasks/hand_task.hpp), ONE WAVE PER (64 envs, column group) -- blockIdx.y is the
+// group (HandCols: dof columns | object / goal + the reward | fingertip states | force-torques + actions).  Round 3 ran one lane per env over
+// all 211 columns: 256 waves at 16384 envs, each with ~150 loads, 4.5 k vector instructions and a 55 KB staging tile (45 us, 61 % of it
+// waiting); four times the waves with a quarter of the chain each fill the chip's 1024 SIMDs.  The fingertip states come from hand_tips_kernel.
+template <class HT, int G>
+__device__ __forceinline__ void hand_post_group(const View& v, const HandView& hv, const HandParams& p, float* stage) {
+    using C = HandCols<HT>;
+    constexpr int C0 = C::first(G), NC = C::count(G), LANES = HandSim<typename HT::M>::LANES;
+    if constexpr (NC == 0) return;          // (the Allegro hand has no fingertip columns)
     const int N = v.N;
-    const int e0 = post_env_index<HandSim<typename HT::M>::LANES>(blockIdx.x, threadIdx.x, N);
+    const int e0 = post_env_index<LANES>(blockIdx.x, threadIdx.x, N);
     const bool valid = e0 < N;
     const int e = valid ? e0 : N - 1;
     // obs_type 0: the vector IS obs_buf; otherwise it goes to full_state and hand_obs_select_kernel picks obs_buf's columns.
     // With asymmetric observations full_state (= states_buf) is written in both cases.
     const bool direct = p.obs_type == 0, to_full = !direct || p.asymmetric_obs != 0;
-    // The 211 columns of an env are a row of the row-major obs tensors: written lane by lane, every store instruction of the wave
-    // touches 64 rows (64 cache lines for 4 bytes each).  They are staged in LDS instead, column-major with a pad ([k][65]: the
-    // lanes of a column and the columns of a lane both fall on distinct banks), and the wave writes the rows out together below,
-    // 64 consecutive floats per store instruction.
-    __shared__ float stage[HT::NFULL * 65];
-    const HandPostOut o = hand_post_env<HT>(v, hv, p, e, valid, [&](int k, float val) MI_LAMBDA { stage[k * 65 + (int)threadIdx.x] = val; }, HandDevRed{});
+    // The columns of an env are a row of the row-major obs tensors: written lane by lane, every store instruction of the wave would touch
+    // 64 rows (64 cache lines for 4 bytes each).  They are staged in LDS instead, column-major with a pad ([k][65]: the lanes of a column and
+    // the columns of a lane both fall on distinct banks), and written out below with consecutive lanes on consecutive columns of a row.
+    const HandPostOut o = hand_post_env<HT, G>(v, hv, p, e, valid, [&](int k, float val) MI_LAMBDA { stage[(k - C0) * 65 + (int)threadIdx.x] = val; }, HandDevRed{});
     __syncthreads();
-    for (int row = 0; row < 64; ++row) {                      // wave-uniform: env of lane `row`
-        const int er = __shfl(e0, row);
+    const bool noisy = direct && v.obs_noise.dist != 0;         // (its own loop: as a select the noise hash was evaluated for every element, +7 us)
+    for (int idx = (int)threadIdx.x; idx < 64 * NC; idx += 64) {
+        const int row = idx / NC, k = idx - row * NC;
+        const int er = post_env_index<LANES>(blockIdx.x, row, N);
         if (er >= N) continue;
-        if (direct && v.obs_noise.dist != 0) {
-            // observation noise of the domain randomisation: its own loop -- as a select inside the common loop the compiler evaluated
-            // the noise hash for every element whether it was wanted or not, +7 us on the kernel
-            for (int k = (int)threadIdx.x; k < HT::NFULL; k += 64) hand_store_full_state_elem<HT::NFULL, true>(v, hv, er, k, stage[k * 65 + row], direct, to_full);
-            continue;
-        }
-        for (int k = (int)threadIdx.x; k < HT::NFULL; k += 64) hand_store_full_state_elem<HT::NFULL, false>(v, hv, er, k, stage[k * 65 + row], direct, to_full);
+        const float val = stage[k * 65 + row];
+        if (noisy) hand_store_full_state_elem<HT::NFULL, true>(v, hv, er, C0 + k, val, direct, to_full);
+        else hand_store_full_state_elem<HT::NFULL, false>(v, hv, er, C0 + k, val, direct, to_full);
     }
-    if (!valid) return;
-    hand_post_store(v, hv, p, e, o);
+    if constexpr (G == 1) { if (valid) hand_post_store(v, hv, p, e, o); }
+}
+template <class HT>
+__global__ __launch_bounds__(64) void hand_post_kernel(View v, HandView hv, HandParams p) {
+    __shared__ float stage[HandCols<HT>::max_count() * 65];
+    switch (blockIdx.y) {           // wave-uniform
+        case 0: hand_post_group<HT, 0>(v, hv, p, stage); break;
+        case 1: hand_post_group<HT, 1>(v, hv, p, stage); break;
+        case 2: hand_post_group<HT, 2>(v, hv, p, stage); break;
+        default: hand_post_group<HT, 3>(v, hv, p, stage); break;
+    }
 }
 // observationType openai / full_no_vel / full (shadow_hand.py:472-526): column subsets of the full state
 template <class HT>
@@ -115,7 +126,7 @@ hipError_t launch_step_hand(const View& v, const HandView& hv, const SimParams& 
     hipError_t e = hand_substeps<HT>(v, hv, P, p, cfi * P.substeps, s);
     if (e != hipSuccess) return e;
     if constexpr (HT::NTIPS > 0) hipLaunchKernelGGL(hand_tips_kernel<HT>, dim3((v.N + 63) / 64, HT::NTIPS), dim3(64), 0, s, v, hv, p);
-    hipLaunchKernelGGL(hand_post_kernel<HT>, dim3((v.N + 63) / 64), dim3(64), 0, s, v, hv, p);
+    hipLaunchKernelGGL(hand_post_kernel<HT>, dim3((v.N + 63) / 64, 4), dim3(64), 0, s, v, hv, p);
     if (p.obs_type != 0) hipLaunchKernelGGL(hand_obs_select_kernel<HT>, dim3((v.N * p.num_obs + 255) / 256), dim3(256), 0, s, v, hv, p);
     hipLaunchKernelGGL(hand_finalize_kernel<HT>, dim3(1), dim3(64), 0, s, hv, p);
     return hipGetLastError();

@@ -73,7 +73,7 @@ static inline void build_hand_layout(int task, int N, Layout& L, HandView* hv, c
     o = L.add("reset_goal_buf", MI_I64, {n}, {1}, n); if (hv) hv->reset_goal = (long long*)P(o);
     o = L.add("goal_reset_count", MI_I32, {n}, {1}, n); if (hv) hv->goal_count = (int*)P(o);
     o = L.add("consecutive_successes", MI_F32, {1}, {1}, 1); if (hv) hv->cons = (float*)P(o);
-    // [0], [1]: the step's sums for the consecutive-successes average; [2], [3]: spare
+    // [0], [1]: the step's sums for the consecutive-successes average (resets, successes of the envs that reset); [2], [3]: the same, cumulative
     o = L.add("reward_workspace", MI_F32, {4}, {1}, 4); if (hv) hv->ws = (float*)P(o);
     o = L.add("object_contact_count", MI_I32, {n}, {1}, n); if (hv) hv->ncontact = (int*)P(o);
     o = L.add("states_buf", MI_F32, {n, nfull}, {nfull, 1}, nfull * n); if (hv) hv->full_state = (float*)P(o);

@@ -163,58 +163,76 @@ MI_HD void hand_tip(const View& v, const HandView& hv, const HandParams& p, cons
 // from hand_tip.  `emit(k, val)` receives column k of compute_full_state's vector (:528-584); what is returned goes to hand_post_store
 // once the caller has written the observation rows out.
 struct HandPostOut { float r, succ; long long rs, gr, prog; };
-template <class HT, class EMIT, class RED>
+// column groups of the full-state vector: the device post kernel runs one wave per (64 envs, group) -- 4 x the waves, each with a quarter of the
+// loads and of the dependency chain (hand_task_kernels.hpp); the host runs all of them at once (GROUP = -1).  Group 1 also computes the reward.
+//   0: the 3 ND dof columns | 1: object pose / velocities, goal pose, quaternion difference + compute_hand_reward | 2: fingertip states |
+//   3: fingertip force-torques and the actions
+template <class HT> struct HandCols {
+    static constexpr int ND = HT::ND, O_OBJ = 3 * ND, O_GOAL = O_OBJ + 13, O_TIPS = O_GOAL + 11, O_FT = O_TIPS + 13 * HT::NTIPS, O_ACT = O_FT + 6 * HT::NTIPS;
+    static_assert(O_ACT + HT::NACT == HT::NFULL, "full_state width");
+    static constexpr int first(int g) { return g == 0 ? 0 : g == 1 ? O_OBJ : g == 2 ? O_TIPS : O_FT; }
+    static constexpr int count(int g) { return g == 0 ? O_OBJ : g == 1 ? O_TIPS - O_OBJ : g == 2 ? O_FT - O_TIPS : HT::NFULL - O_FT; }
+    static constexpr int max_count() { int m = 0; for (int g = 0; g < 4; ++g) m = count(g) > m ? count(g) : m; return m; }
+};
+template <class HT, int GROUP = -1, class EMIT, class RED>
 MI_HD HandPostOut hand_post_env(const View& v, const HandView& hv, const HandParams& p, const int e, const bool valid, const EMIT& emit, const RED& red) {
     MI_NO_CONTRACT
     constexpr int ND = HT::ND;
+    using C = HandCols<HT>;
+    constexpr bool G0 = GROUP < 0 || GROUP == 0, G1 = GROUP < 0 || GROUP == 1, G2 = GROUP < 0 || GROUP == 2, G3 = GROUP < 0 || GROUP == 3;
     const int N = v.N;
-    float q[ND], qd[ND];
-    sfor<ND>([&](auto K) MI_LAMBDA { q[K] = v.dof[K * N + e]; qd[K] = v.dof[(ND + K) * N + e]; });
-    float tips[HT::NTIPS > 0 ? HT::NTIPS : 1][13];
-    sfor<HT::NTIPS>([&](auto T_) MI_LAMBDA { sfor<13>([&](auto K) MI_LAMBDA { tips[T_][K] = hv.fingertip[(T_ * 13 + K) * N + e]; }); });
-    float os[13], gp[7], act[HT::NACT], dff[ND], sns[HT::NTIPS > 0 ? 6 * HT::NTIPS : 1];
     // every input is loaded before the first observation is stored: the stores below may alias these arrays as far as the
     // compiler knows, and a load that has to wait for them is a fully exposed memory round trip for a lone wave
-    sfor<ND>([&](auto K) MI_LAMBDA { dff[K] = v.dof_force[K * N + e]; });
-    sfor<6 * HT::NTIPS>([&](auto K) MI_LAMBDA { sns[K] = v.sensor[K * N + e]; });
-    const long long reset_in = v.reset[e], reset_goal_in = hv.reset_goal[e];
-    const float successes_in = hv.successes[e];
-    sfor<13>([&](auto K) MI_LAMBDA { os[K] = hv.object_state[K * N + e]; });
-    sfor<7>([&](auto K) MI_LAMBDA { gp[K] = hv.goal_state[K * N + e]; });
-    sfor<HT::NACT>([&](auto K) MI_LAMBDA { act[K] = v.actions[K * N + e]; });
-    const long long progress_in = v.progress[e] + 1;               // :711
+    float q[ND], qd[ND], dff[ND];
+    if constexpr (G0) sfor<ND>([&](auto K) MI_LAMBDA { q[K] = v.dof[K * N + e]; qd[K] = v.dof[(ND + K) * N + e]; dff[K] = v.dof_force[K * N + e]; });
+    float tips[HT::NTIPS > 0 ? HT::NTIPS : 1][13];
+    if constexpr (G2) sfor<HT::NTIPS>([&](auto T_) MI_LAMBDA { sfor<13>([&](auto K) MI_LAMBDA { tips[T_][K] = hv.fingertip[(T_ * 13 + K) * N + e]; }); });
+    float os[13], gp[7], act[HT::NACT], sns[HT::NTIPS > 0 ? 6 * HT::NTIPS : 1];
+    if constexpr (G3) sfor<6 * HT::NTIPS>([&](auto K) MI_LAMBDA { sns[K] = v.sensor[K * N + e]; });
+    long long reset_in = 0, reset_goal_in = 0, progress_in = 0;
+    float successes_in = 0.f;
+    if constexpr (G1) {
+        reset_in = v.reset[e]; reset_goal_in = hv.reset_goal[e];
+        successes_in = hv.successes[e];
+        sfor<13>([&](auto K) MI_LAMBDA { os[K] = hv.object_state[K * N + e]; });
+        sfor<7>([&](auto K) MI_LAMBDA { gp[K] = hv.goal_state[K * N + e]; });
+        progress_in = v.progress[e] + 1;               // :711
+    }
+    if constexpr (G1 || G3) sfor<HT::NACT>([&](auto K) MI_LAMBDA { act[K] = v.actions[K * N + e]; });
     // compute_full_state (:528-584)
-    sfor<ND>([&](auto D) MI_LAMBDA {
+    // layout (shadow_hand.py:528-584 with 24 dofs and 5 fingertips: 211 columns; allegro_hand.py:485-507 with 16 dofs and none: 88):
+    // 3 ND | object pose 7, linvel 3, angvel 3 | goal pose 7, quat diff 4 | 13 NTIPS fingertip states | 6 NTIPS force-torques | actions
+    if constexpr (G0) sfor<ND>([&](auto D) MI_LAMBDA {
         constexpr int d = D;
         emit(d, (2.0f * q[d] - HT::M::dof_upper[d] - HT::M::dof_lower[d]) / (HT::M::dof_upper[d] - HT::M::dof_lower[d]));   // unscale
         emit(ND + d, p.vel_obs_scale * qd[d]);
         emit(2 * ND + d, p.force_torque_obs_scale * dff[d]);
     });
-    // layout (shadow_hand.py:528-584 with 24 dofs and 5 fingertips: 211 columns; allegro_hand.py:485-507 with 16 dofs and none: 88):
-    // 3 ND | object pose 7, linvel 3, angvel 3 | goal pose 7, quat diff 4 | 13 NTIPS fingertip states | 6 NTIPS force-torques | actions
-    constexpr int O_OBJ = 3 * ND, O_GOAL = O_OBJ + 13, O_TIPS = O_GOAL + 11, O_FT = O_TIPS + 13 * HT::NTIPS, O_ACT = O_FT + 6 * HT::NTIPS;
-    static_assert(O_ACT + HT::NACT == HT::NFULL, "full_state width");
-    sfor<7>([&](auto K) MI_LAMBDA { emit(O_OBJ + K, os[K]); });
-    sfor<3>([&](auto K) MI_LAMBDA { emit(O_OBJ + 7 + K, os[7 + K]); emit(O_OBJ + 10 + K, p.vel_obs_scale * os[10 + K]); });
-    sfor<7>([&](auto K) MI_LAMBDA { emit(O_GOAL + K, gp[K]); });
-    {
+    if constexpr (G1) {
+        sfor<7>([&](auto K) MI_LAMBDA { emit(C::O_OBJ + K, os[K]); });
+        sfor<3>([&](auto K) MI_LAMBDA { emit(C::O_OBJ + 7 + K, os[7 + K]); emit(C::O_OBJ + 10 + K, p.vel_obs_scale * os[10 + K]); });
+        sfor<7>([&](auto K) MI_LAMBDA { emit(C::O_GOAL + K, gp[K]); });
         float conj[4], qd4[4];
         quat_conjugate(gp + 3, conj);
         quat_mul(os + 3, conj, qd4);
-        sfor<4>([&](auto K) MI_LAMBDA { emit(O_GOAL + 7 + K, qd4[K]); });
+        sfor<4>([&](auto K) MI_LAMBDA { emit(C::O_GOAL + 7 + K, qd4[K]); });
     }
-    sfor<HT::NTIPS>([&](auto T_) MI_LAMBDA {
+    if constexpr (G2) sfor<HT::NTIPS>([&](auto T_) MI_LAMBDA {
         sfor<13>([&](auto K) MI_LAMBDA {
-            emit(O_TIPS + T_ * 13 + K, tips[T_][K]);
+            emit(C::O_TIPS + T_ * 13 + K, tips[T_][K]);
         });
     });
-    sfor<6 * HT::NTIPS>([&](auto K) MI_LAMBDA { emit(O_FT + K, p.force_torque_obs_scale * sns[K]); });
-    sfor<HT::NACT>([&](auto K) MI_LAMBDA { emit(O_ACT + K, act[K]); });
+    if constexpr (G3) {
+        sfor<6 * HT::NTIPS>([&](auto K) MI_LAMBDA { emit(C::O_FT + K, p.force_torque_obs_scale * sns[K]); });
+        sfor<HT::NACT>([&](auto K) MI_LAMBDA { emit(C::O_ACT + K, act[K]); });
+    }
     // compute_hand_reward (:746-800)
-    HandPostOut o;
-    hand_reward(p.rew, os, os + 3, gp, gp + 3, act, HT::NACT, reset_in, reset_goal_in, progress_in, successes_in, &o.r, &o.rs, &o.gr, &o.prog, &o.succ);
-    red.successes(hv, valid, o.rs, o.succ);
-    red.episode(v, e, valid, o.r, o.rs, o.prog);
+    HandPostOut o{0.f, 0.f, 0, 0, 0};
+    if constexpr (G1) {
+        hand_reward(p.rew, os, os + 3, gp, gp + 3, act, HT::NACT, reset_in, reset_goal_in, progress_in, successes_in, &o.r, &o.rs, &o.gr, &o.prog, &o.succ);
+        red.successes(hv, valid, o.rs, o.succ);
+        red.episode(v, e, valid, o.r, o.rs, o.prog);
+    }
     return o;
 }
 // where column k (value `val`) of env er's full-state vector goes: obs_buf + the clamped ring slot when the vector IS the observation
@@ -263,6 +281,7 @@ MI_HD void hand_obs_select_elem(const View& v, const HandView& hv, const HandPar
 MI_HD void hand_finalize(const HandView& hv, const HandParams& p) {
     const float num_resets = hv.ws[0], finished = hv.ws[1], cs = hv.cons[0];
     hv.cons[0] = (num_resets > 0.f) ? p.rew.av_factor * finished / num_resets + (1.0f - p.rew.av_factor) * cs : cs;
+    hv.ws[2] += num_resets; hv.ws[3] += finished;     // cumulative since init: what a multi-GPU job all-reduces (parallel.py TaskExtrasReducer)
     hv.ws[0] = 0.f; hv.ws[1] = 0.f;   // last reader of the step's sums: re-zero them here instead of a memset before every post pass
 }
 

@@ -30,6 +30,10 @@ SOURCES = ["mi_engine.hip", "kernels_cartpole.hip", "kernels_ant.hip", "kernels_
            "kernels_scaled_ant.hip", "kernels_scaled_humanoid.hip", "kernels_scaled_humanoid_mwc.hip", "kernels_scaled_humanoid_sc2.hip",
            "kernels_scaled_anymal.hip"]
 MI_MAX_DOF = 32
+# include/mi_engine.h MI_ABI_VERSION: bumped whenever the arena layout, a parameter struct or an export changes (2: round 4 -- cumulative
+# episode statistics tensors, per-body actor scales, rigid_body_state).  A library of another version is refused when it is loaded, and a state
+# checkpoint (VecTask.get_env_state) carries the version + arena size it was taken with.
+MI_ABI_VERSION = 2
 
 # -fno-slp-vectorize: pairing scalars into v_pk_* ops lengthens live ranges in the fully unrolled sub-step
 # (Ant: 230 -> 40 spilled VGPRs without it)
@@ -343,6 +347,10 @@ def resource_usage(build_dir=None, sources=None):
 
 def _bind_lifecycle(L):
     """ctypes signatures of the engine lifecycle entry points (the part of include/mi_engine.h both libraries export)."""
+    L.mi_abi_version.restype = C.c_int
+    if L.mi_abi_version() != MI_ABI_VERSION:
+        raise RuntimeError(f"{getattr(L, '_name', 'library')}: ABI version {L.mi_abi_version()}, this package speaks {MI_ABI_VERSION} -- rebuild "
+                           f"(python -c 'import __graft_entry__ as g; g.build()'; a cached isaacgymenvs_amd/_variants/ library is rebuilt on demand)")
     L.mi_last_error.restype = C.c_char_p
     L.mi_engine_arena_bytes.restype = C.c_size_t
     L.mi_engine_arena_bytes.argtypes = [C.c_char_p, C.c_int]

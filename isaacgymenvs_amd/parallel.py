@@ -5,6 +5,10 @@ shard on cuda:LOCAL_RANK (utils/rlgames_utils.py:89-107) and rl_games all-reduce
 the only cross-rank quantity is the episode-statistics vector the fused step kernel accumulates
 ("episode_stats": sum finished returns, sum finished lengths, #finished, sum rewards, #env-steps), summed with one
 tiny all-reduce (<= 32 B payload, latency bound) on a side stream every `interval` steps -- never on the step stream.
+The tasks' own `extras` travel the same way: AnymalTerrain's `extras["episode"]` (13 episode sums + terrain level + count,
+anymal_terrain.py:421-425) and the hand tasks' consecutive-successes numerator / denominator (shadow_hand.py:795-798) are kept by the kernels
+as CUMULATIVE sums (`episode_cum_stats`, `reward_workspace[2:4]`), so a window's job-wide means are differences of two all-reduced snapshots
+-- no per-step torch op on the step stream (TaskExtrasReducer).
 """
 from __future__ import annotations
 
@@ -45,11 +49,12 @@ class EpisodeStatsReducer:
 
     FIELDS = ("sum_episode_return", "sum_episode_length", "num_episodes", "sum_reward", "num_env_steps")
 
-    def __init__(self, stats_tensor: torch.Tensor, interval: int = 16):
+    def __init__(self, stats_tensor: torch.Tensor, interval: int = 16, distributed: bool = True):
         self.stats = stats_tensor
         self.interval = max(1, int(interval))
         self.n = 0
-        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.dist = bool(distributed) and dist.is_initialized()        # False: this process's statistics only (a reference run inside a job)
+        self.world = dist.get_world_size() if self.dist else 1
         self.on_gpu = stats_tensor.is_cuda
         self.side = torch.cuda.Stream(device=stats_tensor.device) if self.on_gpu else None
         self.global_stats = torch.zeros_like(stats_tensor)
@@ -70,11 +75,11 @@ class EpisodeStatsReducer:
             self.side.wait_stream(torch.cuda.current_stream(self.stats.device))
             with torch.cuda.stream(self.side):
                 self.global_stats.copy_(self.stats)
-                if dist.is_initialized():
+                if self.dist:
                     self._work = dist.all_reduce(self.global_stats, op=dist.ReduceOp.SUM, async_op=True)
         else:
             self.global_stats.copy_(self.stats)
-            if dist.is_initialized():
+            if self.dist:
                 self._work = dist.all_reduce(self.global_stats, op=dist.ReduceOp.SUM, async_op=True)
 
     def result(self):
@@ -91,3 +96,62 @@ class EpisodeStatsReducer:
         d["mean_episode_length"] = d["sum_episode_length"] / ne
         d["mean_reward"] = d["sum_reward"] / max(d["num_env_steps"], 1.0)
         return d
+
+
+class TaskExtrasReducer(EpisodeStatsReducer):
+    """Job-wide task `extras` of a sharded run: SUM all-reduce of the task's cumulative statistics every `interval` steps (side stream), the
+    window's means from the difference to the previous reduced snapshot.
+
+      AnymalTerrain  extras["episode"] as the reference forms it per step (anymal_terrain.py:421-425), over the window and over all ranks:
+                     rew_<term> = sum of the episode sums of the envs that reset / their number / max_episode_length_s,
+                     terrain_level = mean level over envs and steps.  Tensor `episode_cum_stats` [16].
+      ShadowHand / AllegroHand   the consecutive-successes average's numerator and denominator (shadow_hand.py:795-798):
+                     mean successes of the episodes that ended in the window, and the job-wide moving average
+                     cs <- av_factor * that + (1 - av_factor) * cs, updated once per window (per step on a single rank).  `reward_workspace[2:4]`.
+    """
+
+    ANYMAL_KEYS = ("rew_lin_vel_xy", "rew_lin_vel_z", "rew_ang_vel_z", "rew_ang_vel_xy", "rew_orient", "rew_torques", "rew_joint_acc", "rew_base_height",
+                   "rew_air_time", "rew_collision", "rew_stumble", "rew_action_rate", "rew_hip")
+
+    def __init__(self, env, interval: int = 16, distributed: bool = True):
+        t = env.engine.tensors
+        self.task = env.native_task
+        if self.task == "AnymalTerrain":
+            src = t["episode_cum_stats"]
+        elif self.task in ("ShadowHand", "AllegroHand"):
+            src = t["reward_workspace"]
+        else:
+            raise ValueError(f"{self.task}: no task extras to reduce (its episode statistics go through EpisodeStatsReducer)")
+        super().__init__(src, interval, distributed)
+        self.env = env
+        self.prev = torch.zeros_like(src, device="cpu")
+        self.window = None
+        self.consecutive_successes = 0.0
+
+    def result(self):
+        """job-wide extras of the last reduced window (blocking)"""
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        if self.on_gpu:
+            self.side.synchronize()
+        cur = self.global_stats.detach().cpu()
+        d = cur - self.prev
+        self.prev = cur.clone()
+        if self.task == "AnymalTerrain":
+            cnt, steps = float(d[13]), max(float(d[15]), 1.0)          # [15] counts every rank's steps: steps of the window x ranks
+            out = {}
+            if cnt > 0:
+                for k, name in enumerate(self.ANYMAL_KEYS):
+                    out[name] = float(d[k]) / cnt / float(self.env.max_episode_length_s)
+            out["terrain_level"] = float(d[14]) / (self.env.num_envs * steps)        # mean over the envs of every rank and the window's steps
+            out["num_resets"] = cnt
+            self.window = out
+            return out
+        resets, fin = float(d[2]), float(d[3])
+        if resets > 0:
+            av = float(self.env._task_params_struct.rew.av_factor)
+            self.consecutive_successes = av * fin / resets + (1.0 - av) * self.consecutive_successes
+        self.window = {"num_resets": resets, "successes_per_reset": (fin / resets) if resets > 0 else 0.0,
+                       "consecutive_successes": self.consecutive_successes}
+        return self.window

@@ -487,7 +487,9 @@ class VecTask(Env):
         the domain-randomisation state that lives outside the arena (gravity, noise parameters and epoch, whether the sub-step reads the
         actor tensors, the torch-op noise's correlated tensors, the randomisation schedule)."""
         g = [float(self.sim_params.gravity[i]) for i in range(3)]
-        return {"arena": self.engine.arena.clone(), "control_steps": self.control_steps, "engine_steps": self.engine.get_option("steps"),
+        return {"arena": self.engine.arena.clone(), "abi_version": native.MI_ABI_VERSION, "arena_bytes": int(self.engine.arena.numel()),
+                "task": self.native_task, "num_envs": int(self.num_envs),
+                "control_steps": self.control_steps, "engine_steps": self.engine.get_option("steps"),
                 "gravity": g, "noise": {k: dict(v) for k, v in self.dr_randomizations.items() if isinstance(v, dict) and "dist" in v},
                 "noise_epoch": int(getattr(self, "_noise_epoch", -1)), "actor_tensors": bool(getattr(self, "_actor_tensors_on", False)),
                 "torch_noise_corr": {k: (None if n.corr is None else n.corr.clone()) for k, n in self._torch_noise.items()},
@@ -497,6 +499,13 @@ class VecTask(Env):
     def set_env_state(self, env_state):
         if env_state is None:
             return
+        # the arena is raw engine memory: a checkpoint of another layout (ABI version), task or env count must not be copied over it
+        abi = env_state.get("abi_version")
+        if abi is not None and abi != native.MI_ABI_VERSION:
+            raise RuntimeError(f"set_env_state: checkpoint of ABI version {abi}, this engine has {native.MI_ABI_VERSION} (the arena layout differs)")
+        if tuple(env_state["arena"].shape) != tuple(self.engine.arena.shape) or env_state.get("task", self.native_task) != self.native_task:
+            raise RuntimeError(f"set_env_state: checkpoint of {env_state.get('task', '?')} with {env_state['arena'].numel()} arena bytes does not fit "
+                               f"{self.native_task} with {self.engine.arena.numel()}")
         self.engine.arena.copy_(env_state["arena"])
         self.control_steps = env_state.get("control_steps", 0)
         # the engine's own step counter drives the observation-ring parity, the AnymalTerrain push schedule and the noise counters

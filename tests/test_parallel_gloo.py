@@ -1,4 +1,12 @@
-"""N>1 path on CPU: world_size-2 gloo run of the sharding helpers and the episode-statistics all-reduce."""
+"""N>1 path on CPU: world_size-2 gloo runs.
+
+1. Two ranks of the CPU product backend -- make(..., "cpu", "cpu", multi_gpu=True), Ant 2 x 128 envs -- are checked env for env against ONE
+   process of 256 envs: global env ids rank * N + i, so a shard's trajectories are the rows of the unsharded run, bit for bit; the RCCL-path
+   statistics (EpisodeStatsReducer: the 5-float vector, SUM all-reduce every K steps) equal the single process's.
+2. The tasks' own extras: AnymalTerrain's extras["episode"] (13 episode sums + terrain level + count) and the ShadowHand's
+   consecutive-successes numerator / denominator, all-reduced as cumulative sums (TaskExtrasReducer) -- two ranks of 48 envs against one
+   process of 96, same terrain on every rank (_terrain_seed).
+3. the sharding helpers."""
 import os
 import socket
 import subprocess
@@ -10,7 +18,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = textwrap.dedent("""
     import os, sys, torch
     sys.path.insert(0, %r)
-    from isaacgymenvs_amd.parallel import init_distributed, shard_range, EpisodeStatsReducer
+    import numpy as np
+    import isaacgymenvs_amd
+    from isaacgymenvs_amd.parallel import init_distributed, shard_range, EpisodeStatsReducer, TaskExtrasReducer
     import torch.distributed as dist
     rank, world, _ = init_distributed(backend="gloo")
     assert world == 2 and dist.get_backend() == "gloo"
@@ -18,14 +28,67 @@ WORKER = textwrap.dedent("""
     sizes = [None, None]
     dist.all_gather_object(sizes, (lo, hi))
     assert sizes[0][0] == 0 and sizes[0][1] == sizes[1][0] and sizes[1][1] == 4097
-    stats = torch.zeros(8)
-    red = EpisodeStatsReducer(stats, interval=4)
-    for step in range(8):
-        stats[0] += 10.0 * (rank + 1); stats[1] += 100.0; stats[2] += 1.0; stats[3] += 0.5; stats[4] += 64
-        red.step()
-    r = red.result()
-    assert r["num_episodes"] == 16 and r["sum_episode_return"] == 8 * 10 + 8 * 20 and r["num_env_steps"] == 2 * 8 * 64, r
-    assert abs(r["mean_episode_return"] - 15.0) < 1e-6 and r["mean_episode_length"] == 100.0
+
+    def rollout(task, n, steps, sharded, seed=7):
+        # every rank passes the job's seed (README-style make() per rank): the reset RNG is keyed by (seed, GLOBAL env id, episode, draw)
+        # every rank passes the job's seed, and says so (cfg["_base_seed"]: what must be identical on every rank -- the terrain -- is seeded with it)
+        from isaacgymenvs_amd.utils.config import compose
+        cfg = compose(overrides=["task=" + task])
+        cfg["task"]["env"]["numEnvs"] = n
+        cfg["task"]["_base_seed"] = seed
+        env = isaacgymenvs_amd.make(seed=seed, task=task, num_envs=n, sim_device="cpu", rl_device="cpu", headless=True, multi_gpu=sharded, cfg=cfg)
+        total = n * world if sharded else n
+        g = torch.Generator().manual_seed(3)
+        red = EpisodeStatsReducer(env.engine.tensors["episode_stats"], interval=4) if sharded else None
+        ext = TaskExtrasReducer(env, interval=4, distributed=sharded) if task != "Ant" else None
+        outs = []
+        for s in range(steps):
+            a = torch.rand((total, env.num_actions), generator=g) * 2 - 1          # the same global action batch on every rank
+            mine = a[rank * n:(rank + 1) * n] if sharded else a
+            od, rew, reset, extras = env.step(mine.contiguous())
+            outs.append((od["obs"].clone(), rew.clone(), reset.clone()))
+            if red is not None:
+                red.step()
+            if ext is not None:
+                ext.step()
+        return env, outs, red, ext
+
+    # ---- 1. Ant: 2 x 128 sharded == rows of 256 unsharded
+    env_s, outs_s, red, _ = rollout("Ant", 128, 24, True)
+    assert env_s.rank == rank and env_s.device == "cpu"
+    env_f, outs_f, _, _ = rollout("Ant", 256, 24, False)
+    sl = slice(rank * 128, (rank + 1) * 128)
+    for (o1, r1, d1), (o2, r2, d2) in zip(outs_f, outs_s):
+        assert torch.equal(o1[sl], o2) and torch.equal(r1[sl], r2) and torch.equal(d1[sl], d2)
+    job = red.result()
+    full = env_f.engine.tensors["episode_stats"]
+    assert job["num_env_steps"] == 24 * 256 == float(full[4]) and job["num_episodes"] == float(full[2])
+    assert abs(job["sum_reward"] - float(full[3])) < 1e-3 * max(1.0, abs(float(full[3])))
+
+    # ---- 2. AnymalTerrain extras: two shards of 48 == one process of 96, the same terrain on both ranks
+    env_s, outs_s, _, ext_s = rollout("AnymalTerrain", 48, 160, True)
+    env_f, outs_f, _, ext_f = rollout("AnymalTerrain", 96, 160, False)
+    hs = torch.as_tensor(env_s.terrain.heightsamples)
+    both = [None, None]
+    dist.all_gather_object(both, int(hs.long().abs().sum()))
+    assert both[0] == both[1] == int(torch.as_tensor(env_f.terrain.heightsamples).long().abs().sum())
+    sl = slice(rank * 48, (rank + 1) * 48)
+    for (o1, r1, d1), (o2, r2, d2) in zip(outs_f, outs_s):
+        assert torch.equal(o1[sl], o2) and torch.equal(d1[sl], d2)
+    w_s, w_f = ext_s.result(), ext_f.result()
+    assert w_s["num_resets"] == w_f["num_resets"] and w_f["num_resets"] > 0, (w_s, w_f)
+    for k in w_f:
+        assert abs(w_s[k] - w_f[k]) < 1e-4 * max(1.0, abs(w_f[k])), (k, w_s[k], w_f[k])
+    assert set(TaskExtrasReducer.ANYMAL_KEYS) <= set(w_s) and "terrain_level" in w_s
+
+    # ---- 3. ShadowHand: successes numerator / denominator
+    env_s, outs_s, _, ext_s = rollout("ShadowHand", 32, 12, True)
+    env_f, outs_f, _, ext_f = rollout("ShadowHand", 64, 12, False)
+    sl = slice(rank * 32, (rank + 1) * 32)
+    for (o1, r1, d1), (o2, r2, d2) in zip(outs_f, outs_s):
+        assert torch.equal(o1[sl], o2) and torch.equal(d1[sl], d2)
+    w_s, w_f = ext_s.result(), ext_f.result()
+    assert w_s["num_resets"] == w_f["num_resets"] and abs(w_s["successes_per_reset"] - w_f["successes_per_reset"]) < 1e-6, (w_s, w_f)
     dist.barrier()
     if rank == 0:
         print("GLOO_OK")
@@ -41,14 +104,16 @@ def _free_port():
 
 
 def test_world_size_2_gloo(tmp_path):
+    from isaacgymenvs_amd import native
+    native.build_cpu()
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     port = _free_port()
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port))
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="2")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "GLOO_OK" in outs[0]

@@ -7,9 +7,10 @@ REF=${1:-/root/reference}
 D=$ROOT/ab/ref_stage/isaacgymenvs
 rm -rf $ROOT/ab/ref_stage
 mkdir -p $D/tasks/base $D/utils $D/cfg
-for f in cartpole ant humanoid anymal_terrain shadow_hand allegro_hand; do cp $REF/isaacgymenvs/tasks/$f.py $D/tasks/; done
+for f in cartpole ant humanoid anymal_terrain shadow_hand allegro_hand anymal ball_balance quadcopter ingenuity; do cp $REF/isaacgymenvs/tasks/$f.py $D/tasks/; done
 cp $REF/isaacgymenvs/tasks/base/vec_task.py $D/tasks/base/
 cp $REF/isaacgymenvs/utils/*.py $D/utils/
 cp -r $REF/isaacgymenvs/cfg/. $D/cfg/
 mkdir -p $ROOT/ab/ref_stage/assets/mjcf && cp $REF/assets/mjcf/nv_ant.xml $ROOT/ab/ref_stage/assets/mjcf/     # tests/test_runtime_assets.py perturbs a copy
+mkdir -p $ROOT/ab/ref_stage/assets/urdf/anymal_c/urdf && cp $REF/assets/urdf/anymal_c/urdf/anymal.urdf $ROOT/ab/ref_stage/assets/urdf/anymal_c/urdf/   # anymal.py:168: parsed, its tree checked
 echo staged $(find $ROOT/ab/ref_stage -type f | wc -l) files under ab/ref_stage
