@@ -42,6 +42,11 @@
 #define MI_OPAQUE_ZERO(z) asm volatile("s_mov_b32 %0, 0" : "=s"(z))
 // wave-uniform "does any env of this wavefront ...": lets the whole wave branch around work no lane needs
 #define MI_WAVE_ANY(x) (__builtin_amdgcn_ballot_w64(x) != 0ull)
+// a value the optimiser cannot see through (uniform pointer / per-lane float): re-defined inside a loop body, nothing computed from it can be
+// hoisted out of the loop (the fused sub-steps: hundreds of loop-invariant expressions of the step size and the sim parameters)
+#define MI_OPAQUE_SPTR(p) asm volatile("" : "+s"(p))
+#define MI_OPAQUE_SINT(x) asm volatile("" : "+s"(x))
+#define MI_OPAQUE_VF(x) asm volatile("" : "+v"(x))
 #ifndef MI_EXACT_SINCOS
 // joint rotations in the tree pass: hardware v_sin_f32 / v_cos_f32 (input in revolutions; ~1e-6 absolute error for |q| <= pi, the
 // same order as the 1-ulp v_rcp / v_rsq the solver already uses) instead of libm's range-reducing sincosf (~40 instructions per
@@ -52,11 +57,17 @@
 #define MI_PHASE() do { } while (0)
 #define MI_OPAQUE_ZERO(z) (z) = 0
 #define MI_WAVE_ANY(x) (x)
+#define MI_OPAQUE_SPTR(p) do { } while (0)
+#define MI_OPAQUE_SINT(x) do { } while (0)
+#define MI_OPAQUE_VF(x) do { } while (0)
 #endif
 #else
 #define MI_PHASE() do { } while (0)
 #define MI_OPAQUE_ZERO(z) (z) = 0
 #define MI_WAVE_ANY(x) (x)
+#define MI_OPAQUE_SPTR(p) do { } while (0)
+#define MI_OPAQUE_SINT(x) do { } while (0)
+#define MI_OPAQUE_VF(x) do { } while (0)
 #define MI_HD inline __attribute__((always_inline))
 #define MI_HD_NOINLINE __attribute__((noinline))
 #define MI_LAMBDA __attribute__((always_inline))

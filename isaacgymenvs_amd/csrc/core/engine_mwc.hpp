@@ -456,7 +456,10 @@ struct SimMWC : SimMW<M> {
     }
 
     // ---------------------------------------------------------------- one role of a sub-step
-    template <int R, int RS, class BAR>
+    // FUSED: the sub-step is one of several inside one launch (substeps_fused below): the role also integrates the trunk's dofs and the root
+    // state -- every limb role holds the trunk part of the whitened velocity, identical bit for bit (the sweeps sum the blocks' contributions
+    // in role order), so each of them arrives at the same new root / trunk state by itself and nothing of it has to be handed over.
+    template <int R, bool FUSED = false, int RS, class BAR>
     MI_HD void substep_role_c(const SimParams& P, const float* tau, const float h, const RowStore<RS> rows, const Strided lamc,
                               const Strided laml, const Strided sensor, const Strided dof_force, const float mu_env, const SelfCol* scol,
                               const BAR& bar) {
@@ -616,7 +619,10 @@ struct SimMWC : SimMW<M> {
         };
         // last sub-step's impulses of the own ground spheres: a role whose spheres usually touch (a leg) issues the loads together up
         // front; a role that rarely touches the ground (trunk, arms: 19 spheres) loads them where a contact is built -- 57 registers less
-        constexpr bool PREFETCH_LAMC = KCAP >= 4;
+#ifndef MI_MWC_PREFETCH_KCAP
+#define MI_MWC_PREFETCH_KCAP 4
+#endif
+        constexpr bool PREFETCH_LAMC = KCAP >= MI_MWC_PREFETCH_KCAP;
         float lprev[PREFETCH_LAMC ? (NSPH > 0 ? NSPH : 1) : 1][3];
         if constexpr (PREFETCH_LAMC) sfor<NSPH>([&](auto S_) MI_LAMBDA {
             if constexpr (MW::template owns_body<R>(M::sph_body[S_])) sfor<3>([&](auto K) MI_LAMBDA { lprev[S_][K] = lamc(3 * S_ + K); });
@@ -975,9 +981,9 @@ struct SimMWC : SimMW<M> {
         });
         MI_PHASE();
         sfor<ND>([&](auto D) MI_LAMBDA {
-            if constexpr (MW::template owns_gi<R>(OFF + D)) { qd[D] = v[OFF + D]; q[D] += h * qd[D]; }
+            if constexpr (FUSED ? MW::template sees_gi<R>(OFF + D) : MW::template owns_gi<R>(OFF + D)) { qd[D] = v[OFF + D]; q[D] += h * qd[D]; }
         });
-        if constexpr (R == M::TRUNK_ROLE) {
+        if constexpr (FUSED || R == M::TRUNK_ROLE) {
 #if !defined(MI_NO_VEL_CLAMP)
             {
                 const float w2 = v[3] * v[3] + v[4] * v[4] + v[5] * v[5], l2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
@@ -1006,6 +1012,84 @@ struct SimMWC : SimMW<M> {
             Q[0] = x * n; Q[1] = yy * n; Q[2] = z * n; Q[3] = ww * n;
         }
         MI_STAMP(13);
+    }
+
+    // ================================================================ all sub-steps of a control step inside one launch
+    // Between two sub-steps nothing goes through HBM but the warm-start impulses, which each wave reads back from where it wrote them itself
+    // (joint limits and ground spheres: the owner role; the limb-pair groups: the pair role).  Every limb role keeps its own q / qd in registers
+    // and integrates the trunk's dofs and the root redundantly (FUSED above).  The one wave that has no dynamics of its own, the pair role, gets
+    // the new pose -- root position + orientation and the 21 joint angles, for its positions-only forward kinematics -- through H: the half of
+    // the trunk exchange area X_DW that the LAST sweep did not use (parity (iters - 1) & 1: written and read for the last time one barrier
+    // earlier; next written before B5 of the following sub-step, long after the pair role has read it).  One barrier per sub-step boundary.
+    static constexpr int H_Q = 7, H_SIZE = 7 + ND;
+    static_assert(H_SIZE <= NR * NVT, "the pose hand-over fits one half of the trunk exchange area");
+    // NSUB > 0: the sub-steps as straight-line code, one copy per sub-step (no loop for the optimiser to hoist out of); 0: a run-time loop
+    template <int R, int NSUB = 0, int RS, class BAR>
+    MI_HD void substeps_fused(const SimParams& P, const float* tau, const float h, const RowStore<RS> rows, const Strided lamc, const Strided laml,
+                              const Strided sensor, const Strided dof_force, const float mu_env, const SelfCol* scol, const BAR& bar, const int n_sub) {
+        constexpr int ST = RowStore<RS>::stride;
+        const RowStore<RS> H = rows.shifted((X_DW + ((P.iters - 1) & 1) * NR * NVT) * ST);
+        if constexpr (NSUB > 0) {
+            sfor<NSUB>([&](auto I_) MI_LAMBDA {
+                constexpr int i = decltype(I_)::value;
+                if constexpr (HAS_PAIR_ROLE && R == PAIR_ROLE) {
+                    if constexpr (i > 0) {
+                        sfor<7>([&](auto K) MI_LAMBDA { this->root[K] = H(K); });
+                        sfor<ND>([&](auto D) MI_LAMBDA { this->q[D] = H(H_Q + D); });
+                    }
+                    substep_pair(P, h, rows, scol, bar);
+                } else {
+                    this->template substep_role_c<R, true>(P, tau, h, rows, lamc, laml, sensor, dof_force, mu_env, scol, bar);
+                }
+                if constexpr (i + 1 < NSUB) {
+                    if constexpr (!(HAS_PAIR_ROLE && R == PAIR_ROLE)) {
+                        sfor<ND>([&](auto D) MI_LAMBDA { if constexpr (MW::template owns_gi<R>(OFF + D)) H(H_Q + D) = this->q[D]; });
+                        if constexpr (R == M::TRUNK_ROLE) sfor<7>([&](auto K) MI_LAMBDA { H(K) = this->root[K]; });
+                    }
+                    bar();
+                }
+            });
+            return;
+        }
+        for (int i = 0; i < n_sub; ++i) {
+            // An integer zero the optimiser cannot see through, added to every global pointer of the sub-step: the ~200 per-lane addresses
+            // of the impulse / sensor / joint-force tensors are loop invariant, and hoisted out of this loop they would stay live in VGPR
+            // pairs through the whole body (the first build of this loop spilled 306 VGPRs where the one-sub-step kernel spills 50).
+            int zero;
+            MI_OPAQUE_ZERO(zero);
+            // (and the step size, the friction and the parameter block: whatever is computed from them stays inside the iteration)
+            const SimParams* Pp = &P;
+            MI_OPAQUE_SPTR(Pp);
+            float h_i = h, mu_i = mu_env;
+            MI_OPAQUE_VF(h_i);
+            MI_OPAQUE_VF(mu_i);
+            // (the stride too: k * stride, the offset of row k of a [k][N] tensor, is a uniform 64-bit value per k -- ~170 of them)
+            int stride_i = lamc.stride;
+            MI_OPAQUE_SINT(stride_i);
+            const Strided lamc_i{lamc.p + zero, stride_i}, laml_i{laml.p + zero, stride_i}, sensor_i{sensor.p + zero, stride_i},
+                          dof_force_i{dof_force.p + zero, stride_i};
+            SelfCol sc_i{Strided{nullptr, 1}, Strided{nullptr, 1}, nullptr, 0};
+            if (scol != nullptr)
+                sc_i = SelfCol{Strided{scol->lamp.p + zero, stride_i}, Strided{scol->pairf.p ? scol->pairf.p + zero : nullptr, stride_i},
+                               scol->dropped ? scol->dropped + zero : nullptr, scol->dstride};
+            const SelfCol* scp = scol != nullptr ? &sc_i : nullptr;
+            if constexpr (HAS_PAIR_ROLE && R == PAIR_ROLE) {
+                if (i > 0) {
+                    sfor<7>([&](auto K) MI_LAMBDA { this->root[K] = H(K); });
+                    sfor<ND>([&](auto D) MI_LAMBDA { this->q[D] = H(H_Q + D); });
+                }
+                substep_pair(*Pp, h_i, rows, scp, bar);
+            } else {
+                this->template substep_role_c<R, true>(*Pp, tau, h_i, rows, lamc_i, laml_i, sensor_i, dof_force_i, mu_i, scp, bar);
+            }
+            if (i + 1 < n_sub) {
+                if constexpr (!(HAS_PAIR_ROLE && R == PAIR_ROLE)) {
+                    sfor<ND>([&](auto D) MI_LAMBDA { if constexpr (MW::template owns_gi<R>(OFF + D)) H(H_Q + D) = this->q[D]; });
+                    if constexpr (R == M::TRUNK_ROLE) sfor<7>([&](auto K) MI_LAMBDA { H(K) = this->root[K]; });
+                }
+                bar();
+            }
+        }
     }
 };
 

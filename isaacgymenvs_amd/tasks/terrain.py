@@ -205,52 +205,49 @@ class Terrain:
         env_origin_z = np.max(terrain.height_field_raw[x1:x2, y1:y2]) * self.vertical_scale
         self.env_origins[i, j] = [env_origin_x, env_origin_y, env_origin_z]
 
-    def randomized_terrain(self):  # :577-619
+    # ---- which sub-terrain goes on tile (i, j).  Both generators walk the tiles in the reference's order and draw from the NumPy stream in the
+    # reference's order (anymal_terrain.py:577-673): the terrain of a seed is the same on every rank and the same as the reference's mesh.
+    # A generator is a table of (upper edge of the selector, recipe); the first row whose edge exceeds the selector builds the tile.
+    def _build(self, table, selector, terrain, *args):
+        for edge, recipe in table:
+            if selector < edge:
+                recipe(terrain, *args)
+                return
+
+    def randomized_terrain(self):  # :577-619: one uniform draw per tile picks the kind, further draws its parameters
         rng = self.rng
+        slopes, noise = [-0.3, -0.2, 0, 0.2, 0.3], dict(min_height=-0.1, max_height=0.1, step=0.05, downsampled_scale=0.2)
+
+        def slope_tile(t):
+            rough = rng.choice([0, 1])                                     # (drawn before the slope, as the reference does)
+            pyramid_sloped_terrain(t, rng.choice(slopes))
+            if rough:
+                random_uniform_terrain(t, rng=rng, **noise)
+        table = ((0.1, slope_tile),
+                 (0.6, lambda t: pyramid_stairs_terrain(t, step_width=0.31, step_height=rng.choice([-0.15, 0.15]), platform_size=3.)),
+                 (1.0, lambda t: discrete_obstacles_terrain(t, 0.15, 1., 2., 40, platform_size=3., rng=rng)))
         for k in range(self.num_maps):
             (i, j) = np.unravel_index(k, (self.env_rows, self.env_cols))
             terrain = self._new_sub()
-            choice = rng.uniform(0, 1)
-            if choice < 0.1:
-                if rng.choice([0, 1]):
-                    pyramid_sloped_terrain(terrain, rng.choice([-0.3, -0.2, 0, 0.2, 0.3]))
-                    random_uniform_terrain(terrain, min_height=-0.1, max_height=0.1, step=0.05, downsampled_scale=0.2, rng=rng)
-                else:
-                    pyramid_sloped_terrain(terrain, rng.choice([-0.3, -0.2, 0, 0.2, 0.3]))
-            elif choice < 0.6:
-                step_height = rng.choice([-0.15, 0.15])
-                pyramid_stairs_terrain(terrain, step_width=0.31, step_height=step_height, platform_size=3.)
-            elif choice < 1.:
-                discrete_obstacles_terrain(terrain, 0.15, 1., 2., 40, platform_size=3., rng=rng)
+            self._build(table, rng.uniform(0, 1), terrain)
             self._place(terrain, i, j)
 
-    def curiculum(self, num_robots, num_terrains, num_levels):  # :621-673 (spelling as in the reference)
-        rng = self.rng
+    def curiculum(self, num_robots, num_terrains, num_levels):  # :621-673 (the method name is spelled as the reference spells it)
+        """column j -> kind through the cumulative `terrainProportions` (selector c = j / num_terrains), row i -> difficulty d = i / num_levels:
+        smooth slope up to 0.4 d (sunk for c < 0.05) | rough slope (sunk for c < 0.15) | stairs of 0.05 + 0.175 d (down below proportions[2]) |
+        40 discrete obstacles up to 0.025 + 0.15 d | stepping stones of 2 - 1.8 d m"""
+        rng, prop = self.rng, self.proportions
+        sign = lambda below: -1 if below else 1
+        table = (
+            (prop[0], lambda t, d, c: pyramid_sloped_terrain(t, slope=d * 0.4 * sign(c < 0.05), platform_size=3.)),
+            (prop[1], lambda t, d, c: (pyramid_sloped_terrain(t, slope=d * 0.4 * sign(c < 0.15), platform_size=3.),
+                                       random_uniform_terrain(t, min_height=-0.1, max_height=0.1, step=0.025, downsampled_scale=0.2, rng=rng))),
+            (prop[3], lambda t, d, c: pyramid_stairs_terrain(t, step_width=0.31, step_height=(0.05 + 0.175 * d) * sign(c < prop[2]), platform_size=3.)),
+            (prop[4], lambda t, d, c: discrete_obstacles_terrain(t, 0.025 + d * 0.15, 1., 2., 40, platform_size=3., rng=rng)),
+            (np.inf, lambda t, d, c: stepping_stones_terrain(t, stone_size=2 - 1.8 * d, stone_distance=0.1, max_height=0., platform_size=3., rng=rng)),
+        )
         for j in range(num_terrains):
             for i in range(num_levels):
                 terrain = self._new_sub()
-                difficulty = i / num_levels
-                choice = j / num_terrains
-                slope = difficulty * 0.4
-                step_height = 0.05 + 0.175 * difficulty
-                discrete_obstacles_height = 0.025 + difficulty * 0.15
-                stepping_stones_size = 2 - 1.8 * difficulty
-                if choice < self.proportions[0]:
-                    if choice < 0.05:
-                        slope *= -1
-                    pyramid_sloped_terrain(terrain, slope=slope, platform_size=3.)
-                elif choice < self.proportions[1]:
-                    if choice < 0.15:
-                        slope *= -1
-                    pyramid_sloped_terrain(terrain, slope=slope, platform_size=3.)
-                    random_uniform_terrain(terrain, min_height=-0.1, max_height=0.1, step=0.025, downsampled_scale=0.2, rng=rng)
-                elif choice < self.proportions[3]:
-                    if choice < self.proportions[2]:
-                        step_height *= -1
-                    pyramid_stairs_terrain(terrain, step_width=0.31, step_height=step_height, platform_size=3.)
-                elif choice < self.proportions[4]:
-                    discrete_obstacles_terrain(terrain, discrete_obstacles_height, 1., 2., 40, platform_size=3., rng=rng)
-                else:
-                    stepping_stones_terrain(terrain, stone_size=stepping_stones_size, stone_distance=0.1, max_height=0.,
-                                            platform_size=3., rng=rng)
+                self._build(table, j / num_terrains, terrain, i / num_levels, j / num_terrains)
                 self._place(terrain, i, j)

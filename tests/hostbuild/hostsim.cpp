@@ -215,6 +215,50 @@ static void mwc_thread(const SimParams* P, float* s, const float* tau, float* o,
         pthread_barrier_wait(bar);
     }
 }
+// the same with all sub-steps of the step inside ONE call per role (SimMWC::substeps_fused: what substep_mwc_fused_kernel runs per wave): the
+// roles keep their state between sub-steps, integrate the trunk redundantly and hand the pair role the new pose through the row store
+template <int R>
+static void mwc_fused_thread(const SimParams* P, float* s, const float* tau, float* o, float* rows, float* pf, int* dropped, pthread_barrier_t* bar, int selfcol) {
+    using M = ModelHumanoid;
+    using S = SimMWC<M>;
+    constexpr int ND = M::ND, NSPH = M::NSPH, NSENS = M::NSENS;
+    const float h = P->dt / (float)P->substeps;
+    S sim;
+    for (int k = 0; k < 13; ++k) sim.root[k] = s[k];
+    for (int k = 0; k < ND; ++k) { sim.q[k] = s[13 + k]; sim.qd[k] = s[13 + ND + k]; }
+    pthread_barrier_wait(bar);
+    const SelfCol sc{Strided{s + 13 + 3 * ND + 3 * NSPH, 1}, Strided{pf, 1}, dropped, 1};
+    sim.template substeps_fused<R>(*P, tau, h, RowStore<1>{rows}, Strided{s + 13 + 2 * ND, 1}, Strided{s + 13 + 2 * ND + 3 * NSPH, 1}, Strided{o, 1},
+                                   Strided{o + 6 * NSENS, 1}, -1.f, selfcol ? &sc : nullptr, HostBarrier{bar}, P->substeps);
+    pthread_barrier_wait(bar);
+    for (int k = 0; k < ND; ++k)
+        if (S::MW::role_of_gi(M::OFF + k) == R || (S::MW::trunk_gi(M::OFF + k) && R == M::TRUNK_ROLE)) { s[13 + k] = sim.q[k]; s[13 + ND + k] = sim.qd[k]; }
+    if (R == M::TRUNK_ROLE) for (int k = 0; k < 13; ++k) s[k] = sim.root[k];
+}
+extern "C" int hs_step_mwc_fused(const SimParams* P, int nenv, float* state, const float* tau, float* out, int selfcol, int* dropped_out) {
+    using M = ModelHumanoid;
+    constexpr int ND = M::ND, NSPH = M::NSPH, NSENS = M::NSENS, NPG = Sim<M>::NPG;
+    const int ss = 13 + 2 * ND + 3 * NSPH + ND + 3 * NPG, os = 6 * NSENS + ND + 3 * NSPH + 9 * NPG;
+    for (int e = 0; e < nenv; ++e) {
+        float* s = state + (size_t)e * ss;
+        float* o = out + (size_t)e * os;
+        static float rows[SimMWC<M>::MWC_SLOTS];
+        float pf[3 * NPG];
+        int dropped[2] = {0, 0};
+        for (int k = 0; k < SimMWC<M>::MWC_SLOTS; ++k) rows[k] = 0.f;
+        for (int k = 0; k < 3 * NPG; ++k) pf[k] = 0.f;
+        pthread_barrier_t bar;
+        pthread_barrier_init(&bar, nullptr, 4);
+        const float* t = tau + (size_t)e * ND;
+        std::thread t0(mwc_fused_thread<0>, P, s, t, o, rows, pf, dropped, &bar, selfcol), t1(mwc_fused_thread<1>, P, s, t, o, rows, pf, dropped, &bar, selfcol),
+            t2(mwc_fused_thread<2>, P, s, t, o, rows, pf, dropped, &bar, selfcol), t3(mwc_fused_thread<3>, P, s, t, o, rows, pf, dropped, &bar, selfcol);
+        t0.join(); t1.join(); t2.join(); t3.join();
+        pthread_barrier_destroy(&bar);
+        for (int g = 0; g < NPG; ++g) for (int k = 0; k < 3; ++k) o[6 * NSENS + ND + 3 * NSPH + 9 * g + k] = pf[3 * g + k];
+        if (dropped_out) { dropped_out[2 * e] = dropped[0]; dropped_out[2 * e + 1] = dropped[1]; }
+    }
+    return 0;
+}
 extern "C" int hs_step_mwc(const SimParams* P, int nenv, float* state, const float* tau, float* out, int selfcol, int* dropped_out) {
     using M = ModelHumanoid;
     constexpr int ND = M::ND, NSPH = M::NSPH, NSENS = M::NSENS, NPG = Sim<M>::NPG;

@@ -31,7 +31,7 @@ def make_params(d):
 _MODELS = {"cartpole": ("HOSTSIM_CARTPOLE", "-O2"), "ant": ("HOSTSIM_ANT", "-O2"), "anymal": ("HOSTSIM_ANYMAL", "-O2"),
            "quadcopter": ("HOSTSIM_QUADCOPTER", "-O2"), "humanoid": ("HOSTSIM_HUMANOID", "-O2"), "hand": ("HOSTSIM_HAND", "-O1"),
            "bbot": ("HOSTSIM_BBOT", "-O2")}
-_ENTRY_MODEL = {"hs_step_mw_ant": "ant", "hs_step_mw_terrain": "anymal", "hs_step_selfcol": "humanoid", "hs_step_selfcol2": "humanoid", "hs_step_selfcol3": "humanoid", "hs_step_mwc": "humanoid", "hs_step_terrain": "anymal", "hs_set_slope_threshold": "anymal", "hs_set_walls": "anymal", "hs_ground_contact": "anymal", "hs_step_drive": "quadcopter", "hs_step_hand": "hand", "hs_step_hand_mw": "hand", "hs_hand_fingertips": "hand", "hs_step_bbot": "bbot"}
+_ENTRY_MODEL = {"hs_step_mw_ant": "ant", "hs_step_mw_terrain": "anymal", "hs_step_selfcol": "humanoid", "hs_step_selfcol2": "humanoid", "hs_step_selfcol3": "humanoid", "hs_step_mwc": "humanoid", "hs_step_mwc_fused": "humanoid", "hs_step_terrain": "anymal", "hs_set_slope_threshold": "anymal", "hs_set_walls": "anymal", "hs_ground_contact": "anymal", "hs_step_drive": "quadcopter", "hs_step_hand": "hand", "hs_step_hand_mw": "hand", "hs_hand_fingertips": "hand", "hs_step_bbot": "bbot"}
 _libs = {}
 
 
@@ -124,6 +124,13 @@ def step_mwc(lib, params, state, tau, out, selfcol=True, dropped=None):
     step_selfcol.  dropped: optional int32 [n, 2] -- ground / self contacts refused because the slots were taken."""
     rc = lib.hs_step_mwc(C.byref(params), state.shape[0], state.ctypes.data_as(C.c_void_p), tau.ctypes.data_as(C.c_void_p),
                          out.ctypes.data_as(C.c_void_p), int(selfcol), dropped.ctypes.data_as(C.c_void_p) if dropped is not None else None)
+    assert rc == 0
+
+
+def step_mwc_fused(lib, params, state, tau, out, selfcol=True, dropped=None):
+    """the same with all sub-steps of the step inside one call per role thread (SimMWC::substeps_fused, what substep_mwc_fused_kernel runs)"""
+    rc = lib.hs_step_mwc_fused(C.byref(params), state.shape[0], state.ctypes.data_as(C.c_void_p), tau.ctypes.data_as(C.c_void_p),
+                               out.ctypes.data_as(C.c_void_p), int(selfcol), dropped.ctypes.data_as(C.c_void_p) if dropped is not None else None)
     assert rc == 0
 
 

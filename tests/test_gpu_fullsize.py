@@ -104,7 +104,7 @@ def test_humanoid_contact_slots_suffice_at_the_benchmark_size():
     for _ in range(steps):
         env.step(torch.rand((8192, 21), device=DEV, generator=g) * 2 - 1)
     d = env.engine.tensors["contact_dropped"]
-    # measured (tools/contact_drop_rates.py, profiles/r4b_contact_drop_rates.txt): ground 6.1e-5, self 1.46e-3 per env-sub-step
+    # measured (tools/contact_drop_rates.py, profiles/r4a_contact_drop_rates.txt): ground 6.1e-5, self 1.46e-3 per env-sub-step
     assert int(d[:, 0].sum()) < 1e-4 * 8192 * steps * 2, int(d[:, 0].sum())
     assert int(d[:, 1].sum()) < 0.003 * 8192 * steps * 2, int(d[:, 1].sum())
     assert int((env.engine.tensors["self_contact_impulse"].abs().sum(2) > 0).sum()) > 0      # self contacts do occur
@@ -127,7 +127,7 @@ def test_shadow_hand_contact_slots_suffice_at_the_benchmark_size():
     assert int(env.engine.tensors["object_contact_count"].max()) <= (21 if int(env.engine.get_option("multi_wave")) != 0 else 12)
     assert taken > 2 * n * steps                    # the cube does lie in the hand: several contacts per env and sub-step
     # (two sub-steps per step are counted in `dropped`, the last one in `taken`); the little finger's slots are the ones that run out.
-    # Measured (tools/contact_drop_rates.py, profiles/r4b_contact_drop_rates.txt): 0.62 % of the taken contacts in the finger-per-wave form
+    # Measured (tools/contact_drop_rates.py, profiles/r4a_contact_drop_rates.txt): 0.62 % of the taken contacts in the finger-per-wave form
     # (21 slots dealt per limb), 0.02 % in the one-wave form (one pool of 12); the bound sits at 2.4 x the measured rate
     assert dropped < (1.5e-2 if int(env.engine.get_option("multi_wave")) != 0 else 1e-3) * 2 * taken, (dropped, taken)
 

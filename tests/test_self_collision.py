@@ -280,6 +280,38 @@ def test_limb_wave_sub_step_matches_oracle_in_the_block_order(selfcol):
     assert (not selfcol) or touched > 0.3 * 3 * n
 
 
+@pytest.mark.parametrize("selfcol,iters", [(True, 4), (True, 3), (False, 4)])
+def test_fused_sub_steps_of_the_limb_waves_are_bit_identical_on_the_host(selfcol, iters):
+    """SimMWC::substeps_fused (round 4: both sub-steps of a Humanoid control step inside ONE launch) against one call per sub-step: every role
+    keeps its state between the sub-steps, the limb roles integrate the trunk and the root redundantly, the pair role gets the new pose through
+    the half of the trunk exchange area the last sweep left dead (its parity depends on the sweep count: 3 and 4 sweeps here).  Same arithmetic
+    on the same values: every bit of state, impulses, sensors, joint forces and pair forces is the same over several control steps."""
+    import hostsim
+    spec, sb, sc = load_model("humanoid"), sensor_bodies("humanoid"), load_selfcol("humanoid")
+    lib = hostsim.build(humanoid=True)
+    n, nd, nsph, npg = 128, spec.nd, len(spec.sph_body), len(sc["groups"])
+    rng = np.random.default_rng(11)
+    root, q, qd = _random_state(spec, n, rng, 0.9, 1.6)
+    tau32 = np.ascontiguousarray(rng.uniform(-60, 60, (n, nd)), np.float32)
+    p = hostsim.make_params(dict(SIM, iters=iters))
+    st1 = np.zeros((n, 13 + 2 * nd + 3 * nsph + nd + 3 * npg), np.float32)
+    st1[:, :13] = root; st1[:, 13:13 + nd] = q; st1[:, 13 + nd:13 + 2 * nd] = qd
+    st2 = st1.copy()
+    out1 = np.zeros((n, 6 * len(sb) + nd + 3 * nsph + 9 * npg), np.float32)
+    out2 = out1.copy()
+    d1, d2 = np.zeros((n, 2), np.int32), np.zeros((n, 2), np.int32)
+    touched = 0
+    for it in range(4):
+        hostsim.step_mwc(lib, p, st1, tau32, out1, selfcol=selfcol, dropped=d1)
+        hostsim.step_mwc_fused(lib, p, st2, tau32, out2, selfcol=selfcol, dropped=d2)
+        assert np.isfinite(st1).all()
+        np.testing.assert_array_equal(st1, st2)
+        np.testing.assert_array_equal(out1, out2)
+        np.testing.assert_array_equal(d1, d2)
+        touched += int((np.abs(st1[:, 13 + 3 * nd + 3 * nsph:]).reshape(n, npg, 3).sum(2) > 0).any(1).sum())
+    assert (not selfcol) or touched > 0.2 * 4 * n           # the pair role did work with the handed-over poses
+
+
 @pytest.mark.parametrize("waves", [2, 3])
 def test_two_wave_split_of_the_sub_step_is_bit_identical_on_the_host(waves):
     """Sim::substep with role 0 (everything but the self-collision phase) and role 1 (tree pass, factor, self-collision phase) on two
