@@ -112,6 +112,18 @@ typedef struct {
     float clip_actions;
 } MiQuadcopterParams;
 
+/* "Articulation": ANY articulated robot the asset parser accepts, on the ground plane, with no task logic of its own -- what gym.load_asset of a
+ * file with a new kinematic tree becomes (reference call sites: amp/humanoid_amp_base.py:177-200 mjcf/amp_humanoid.xml, franka_cube_stack.py:189-193
+ * franka_panda_gripper.urdf, ...).  The robot is compiled at run time from its parsed description (isaacgymenvs_amd/assets/runtime.py); the stock
+ * library carries the AMP humanoid.  Driven through mi_engine_simulate (gym.simulate) only: efforts in dof_actuation_force, position targets in
+ * dof_position_targets for the dofs whose drive gains are non-zero (gym DOF_MODE_POS: dof stiffness / damping are the drive's gains).
+ * mi_engine_step is refused -- the observation / reward functions of such a task stay the caller's (the reference's own torch code). */
+typedef struct {
+    float kp[MI_MAX_DOF], kd[MI_MAX_DOF];  /* per-dof position-drive gains; kp = kd = 0: no drive on that dof */
+    float max_angular_velocity;            /* asset option: clamp of the base's angular speed (rad/s); <= 0: none */
+    float init_root[13];                   /* actor start pose (create_actor) + zero velocities */
+} MiArticulationParams;
+
 /* task parameters of Ingenuity (ingenuity.py:45-97, 233-282): constants the reference hard-codes in the task file */
 typedef struct {
     float max_episode_length;            /* env.maxEpisodeLength */

@@ -76,14 +76,52 @@ def match_model(path):
                               f"specialised per robot (isaacgymenvs_amd/codegen.py)")
 
 
-def header_text(model_name, spec):
+def header_text(model_name, spec, sensors=None):
+    """`sensors`: engine body indices of the force sensors (the Articulation task: wherever the caller put them); None = the model's own"""
     from ..codegen import emit_model_header
     e = MODELS[model_name]
     extras = load_extras(model_name) if e.get("extras") else None
     if load_selfcol(model_name) is not None:
         raise NotImplementedError("run-time variants of self-colliding models need their capsule-pair tables rebuilt (assets/model.py self_collision_tables)")
-    sens = [list(spec.body_names).index(n) for n in e["sensors"]]
+    sens = [list(spec.body_names).index(n) for n in e["sensors"]] if sensors is None else [int(b) for b in sensors]
     return emit_model_header(spec, e["struct"], sens, extras, None)
+
+
+# ------------------------------------------------------------------------------------------------ a NEW kinematic tree: the Articulation task
+GENERIC_MODEL = "articulation"
+MAX_DOF = 32          # include/mi_engine.h MI_MAX_DOF
+
+
+def parse_generic(path, options=None):
+    """gym.load_asset of a file whose tree no compiled model has: parsed with the caller's AssetOptions into a ModelSpec of its own."""
+    from .model import load_asset
+    o = options
+    kw = dict(fix_base_link=bool(getattr(o, "fix_base_link", False)), replace_cylinder_with_capsule=bool(getattr(o, "replace_cylinder_with_capsule", False)))
+    dens = getattr(o, "density", None)
+    if dens is not None and float(dens) != 1000.0:
+        kw["density"] = float(dens)
+    if path.endswith(".urdf"):           # mesh collision shapes -> spheres inscribed in the meshes' hulls (assets/mesh.py), relative to the URDF's package root
+        kw.update(mesh_spheres=True, mesh_root=os.path.dirname(os.path.dirname(os.path.abspath(path))))
+    spec = load_asset(path, name=GENERIC_MODEL, **kw)
+    if spec.nd > MAX_DOF:
+        raise NotImplementedError(f"{path}: {spec.nd} dofs, the engine's parameter blocks hold {MAX_DOF} (MI_MAX_DOF)")
+    return spec
+
+
+def drive_split(spec, pos_dofs):
+    """gym semantics of DOF_MODE_POS: the dof's `stiffness` / `damping` properties ARE the position drive's gains (amp/humanoid_amp_base.py:219-222
+    switches every dof of the AMP humanoid to it, keeping the MJCF's joint stiffness / damping as gains); in DOF_MODE_NONE / EFFORT they are a passive
+    spring / damper about the joint's reference.  -> (copy of the spec with the driven dofs' passive terms removed, kp [nd], kd [nd])"""
+    import copy
+    import numpy as np
+    sp = copy.deepcopy(spec)
+    kp, kd = np.zeros(spec.nd), np.zeros(spec.nd)
+    k, dmp = np.array(sp.dof_stiffness, float), np.array(sp.dof_damping, float)
+    for d in pos_dofs:
+        kp[d], kd[d] = k[d], dmp[d]
+        k[d], dmp[d] = 0.0, 0.0
+    sp.dof_stiffness, sp.dof_damping = k, dmp
+    return sp, kp, kd
 
 
 def _includes(path, seen):
@@ -114,10 +152,10 @@ def dependent_sources(model_name):
     return out
 
 
-def variant_library(model_name, spec, device="cuda", verbose=False):
+def variant_library(model_name, spec, device="cuda", verbose=False, sensors=None):
     """-> path of the library to create the engine from (the stock library when the header is the compiled model's own)"""
     from .. import native
-    txt = header_text(model_name, spec)
+    txt = header_text(model_name, spec, sensors)
     csrc = os.path.join(_PKG, "csrc")
     stock = open(os.path.join(csrc, "gen", f"model_{model_name}.h")).read()
     cpu = str(device).startswith("cpu")

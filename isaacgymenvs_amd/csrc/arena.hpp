@@ -62,6 +62,7 @@ struct View {
     int* terrain_types;   // [N]
     float* ep_stats;      // [16] this step: sum of the 13 episode sums over resetting envs, #resets, sum terrain levels
     float* ep_means;      // [16] extras["episode"]: rew_* means / max_episode_length_s, terrain_level mean (:421-425)
+    float* targets;       // [ND][N] position targets of the Articulation task's drives (gym.set_dof_position_target_tensor); null otherwise
     float* ep_cum;        // [16] the same sums accumulated since init, never re-zeroed: 13 episode sums of the envs that reset, [13] their count,
                           //      [14] sum of the terrain levels of all envs over the steps, [15] the steps -- what a multi-GPU job all-reduces every K
                           //      steps to form job-wide extras["episode"] (parallel.py TaskExtrasReducer)

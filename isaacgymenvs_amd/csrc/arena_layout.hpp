@@ -25,8 +25,14 @@
 
 using namespace mi;
 
-enum TaskId { T_CARTPOLE = 0, T_ANT = 1, T_HUMANOID = 2, T_ANYMAL = 3, T_SHADOWHAND = 4, T_ANYMAL_FLAT = 5, T_QUADCOPTER = 6, T_INGENUITY = 7, T_BALLBALANCE = 8, T_ALLEGROHAND = 9 };
-constexpr int kNumTasks = 10;
+enum TaskId { T_CARTPOLE = 0, T_ANT = 1, T_HUMANOID = 2, T_ANYMAL = 3, T_SHADOWHAND = 4, T_ANYMAL_FLAT = 5, T_QUADCOPTER = 6, T_INGENUITY = 7, T_BALLBALANCE = 8, T_ALLEGROHAND = 9,
+              T_ARTICULATION = 10 };
+constexpr int kNumTasks = 11;
+// The Articulation task's robot is compiled at run time (assets/runtime.py): its constants live in ONE translation unit of each library
+// (kernels_articulation.hip / cpu/cpu_articulation.cpp), which is all a run-time variant has to recompile; everybody else learns the robot's sizes
+// from this function instead of including gen/model_articulation.h.
+struct ArticulationMeta { int nd, nb, nsens, nsph, fixed; };
+ArticulationMeta mi_articulation_meta();
 static inline bool is_hand_task(int t) { return t == T_SHADOWHAND || t == T_ALLEGROHAND; }
 struct TaskMeta { const char* name; int nobs, nact, nd, nb, nsens, nsph, fixed; size_t pbytes; };
 static const TaskMeta kTasks[] = {
@@ -41,6 +47,9 @@ static const TaskMeta kTasks[] = {
     {"BallBalance", kBbotObs, kBbotAct, ModelBalanceBot::ND, ModelBalanceBot::NB, ModelBalanceBot::NSENS, ModelBalanceBot::NSPH, 0, sizeof(MiBallBalanceParams)},
     // reference allegro_hand.py: 88-wide full_state (:485-507), 16 driven dofs, the task parameters of the ShadowHand
     {"AllegroHand", 88, 16, ModelAllegroHand::ND, ModelAllegroHand::NB, ModelAllegroHand::NSENS, 0, 1, sizeof(MiHandParams)},
+    // no observations / actions of its own (one placeholder column each); sizes from the articulation's translation unit, at load time
+    {"Articulation", 1, 1, mi_articulation_meta().nd, mi_articulation_meta().nb, mi_articulation_meta().nsens, mi_articulation_meta().nsph,
+     mi_articulation_meta().fixed, sizeof(MiArticulationParams)},
 };
 static int find_task(const char* t) {
     for (int i = 0; i < kNumTasks; ++i) if (!strcmp(t, kTasks[i].name)) return i;
@@ -133,6 +142,11 @@ static void build_layout(int task, int N, Layout& L, View* v, char* base, int no
         o = L.add("episode_step_stats", MI_F32, {16}, {1}, 16); if (v) v->ep_stats = (float*)P(o);
         o = L.add("episode_means", MI_F32, {16}, {1}, 16); if (v) v->ep_means = (float*)P(o);
         o = L.add("episode_cum_stats", MI_F32, {16}, {1}, 16); if (v) v->ep_cum = (float*)P(o);
+    }
+    if (task == T_ARTICULATION) {
+        const int64_t nb = m.nb;
+        o = L.add("net_contact_force", MI_F32, {n, nb, 3}, {1, 3 * n, n}, 3 * nb * n); if (v) v->netf = (float*)P(o);
+        o = L.add("dof_position_targets", MI_F32, {n, nd}, {1, n}, nd * n); if (v) v->targets = (float*)P(o);
     }
     if (task == T_ANYMAL_FLAT) {   // anymal.py:100-125
         const int64_t nb = m.nb;

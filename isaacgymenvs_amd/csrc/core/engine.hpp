@@ -214,6 +214,10 @@ struct Drive {
     const float* target;   // [ND] position targets (gym.set_dof_position_target_tensor)
     const float* fsens;    // [NSENS][3] external force at the centre of mass of each force-sensor body, in that body's own
                            // frame (gym.apply_rigid_body_force_tensors(..., LOCAL_SPACE)), or nullptr
+    const float* kpv = nullptr;   // [ND] per-dof gains instead of the one pair above (the Articulation task: every dof its own drive), or nullptr
+    const float* kdv = nullptr;
+    MI_HD float gain_p(int d) const { return kpv ? kpv[d] : kp; }
+    MI_HD float gain_d(int d) const { return kdv ? kdv[d] : kd; }
 };
 // gymapi.AssetOptions defaults the reference's tasks leave alone (ant.py / humanoid.py / anymal*.py set neither): the simulator clamps
 // every actor's linear / angular velocity to these
@@ -1030,8 +1034,9 @@ struct Sim {
             L[M::midx[gi][gi]] += M::dof_armature[d] * sc_arm[d] + h * Dm + h * h * K;
             y[gi] = tau[d] - c.bias[gi] - K * (q[d] - M::dof_springref[d]) - (Dm + h * K) * qd[d];
             if (drv) {   // position drive: the same implicit linearisation as the passive spring / damper
-                L[M::midx[gi][gi]] += h * drv->kd + h * h * drv->kp;
-                y[gi] += drv->kp * (drv->target[d] - q[d]) - (drv->kd + h * drv->kp) * qd[d];
+                const float kpd = drv->gain_p(d), kdd = drv->gain_d(d);
+                L[M::midx[gi][gi]] += h * kdd + h * h * kpd;
+                y[gi] += kpd * (drv->target[d] - q[d]) - (kdd + h * kpd) * qd[d];
             }
         });
         if (drv && drv->fsens) {   // generalised force J^T f of the externally forced bodies (chain-sparse, like a contact row)
@@ -1795,7 +1800,7 @@ struct Sim {
             }
             laml(d) = ll;
             float df = tau[d] - M::dof_stiffness[d] * fs_stiff[d] * (q[d] - M::dof_springref[d]) - M::dof_damping[d] * fs_damp[d] * v[OFF + d] + ll * invh;
-            if (drv) df += drv->kp * (drv->target[d] - q[d]) - drv->kd * v[OFF + d];
+            if (drv) df += drv->gain_p(d) * (drv->target[d] - q[d]) - drv->gain_d(d) * v[OFF + d];
             dof_force(d) = df;
         });
         float sens[6 * M::NSENSA];

@@ -617,10 +617,11 @@ struct SimMWC : SimMW<M> {
                 });
             });
         };
-        // last sub-step's impulses of the own ground spheres: a role whose spheres usually touch (a leg) issues the loads together up
-        // front; a role that rarely touches the ground (trunk, arms: 19 spheres) loads them where a contact is built -- 57 registers less
+        // last sub-step's impulses of the own ground spheres are loaded where a contact is built.  (Round 3 let the leg roles issue all their
+        // loads together up front -- 24 registers that pushed those roles into 24 spilled VGPRs / 100 B of scratch; without it they compile with
+        // no spill at all and the step takes the same time, profiles/r4b_humanoid_prefetch_and_hand_slp_ab.txt.  -DMI_MWC_PREFETCH_KCAP=4 restores it.)
 #ifndef MI_MWC_PREFETCH_KCAP
-#define MI_MWC_PREFETCH_KCAP 4
+#define MI_MWC_PREFETCH_KCAP 99
 #endif
         constexpr bool PREFETCH_LAMC = KCAP >= MI_MWC_PREFETCH_KCAP;
         float lprev[PREFETCH_LAMC ? (NSPH > 0 ? NSPH : 1) : 1][3];

@@ -29,6 +29,7 @@ struct MiEngine {
     AnymalParams anymal;
     AnymalFlatParams anymal_flat;
     HandParams hand;
+    float artic[(sizeof(MiArticulationParams) + 3) / 4];    // ArticulationParams (csrc/tasks/articulation.hpp), opaque outside cpu_articulation.cpp
     QuadView qv;
     IngenuityView iv;
     BbotView bv;
@@ -65,6 +66,10 @@ int cpu_anymal_step(MiEngine* e, const float* actions, bool simulate_only);
 int cpu_anymal_reset(MiEngine* e, const int64_t* ids, int n);
 int cpu_anymal_body_states(MiEngine* e);
 int cpu_anymal_kinematics(MiEngine* e, float* out_j, float* out_h);
+int cpu_articulation_reset(MiEngine* e, const int64_t* ids, int n);      // ids == nullptr: every env
+int cpu_articulation_simulate(MiEngine* e);
+int cpu_articulation_body_states(MiEngine* e);
+int cpu_articulation_kinematics(MiEngine* e, float* out_j, float* out_h);
 int cpu_hand_init(MiEngine* e);
 int cpu_hand_step(MiEngine* e, const float* actions, bool simulate_only);
 int cpu_hand_reset(MiEngine* e, const int64_t* ids, int n);

@@ -76,6 +76,7 @@ extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const 
     else if (t == T_ANYMAL) memcpy(&e->anymal, task_params, sizeof(AnymalParams));
     else if (t == T_ANYMAL_FLAT) memcpy(&e->anymal_flat, task_params, sizeof(AnymalFlatParams));
     else if (is_hand_task(t)) memcpy(&e->hand, task_params, sizeof(HandParams));
+    else if (t == T_ARTICULATION) memcpy(e->artic, task_params, sizeof(MiArticulationParams));
     else memcpy(&e->loco, task_params, sizeof(LocoParams));
     memset(&e->terrain, 0, sizeof(e->terrain));
     e->terrain.walls = 1;
@@ -225,7 +226,8 @@ extern "C" int mi_engine_init_state(MiEngine* e, void*) {
     const bool loco = e->task == T_ANT || e->task == T_HUMANOID;
     const float root_z = e->task == T_CARTPOLE ? 2.0f : e->task == T_QUADCOPTER ? e->quad.init_height : e->task == T_INGENUITY ? e->ing.init_height
                        : e->task == T_BALLBALANCE ? e->bbot.tray_height : e->task == T_ANYMAL ? e->anymal.base_init_state[2]
-                       : e->task == T_ANYMAL_FLAT ? e->anymal_flat.base_init_state[2] : e->loco.start_height;      // cartpole.py:93 / ant.py:164 / the tasks' default poses
+                       : e->task == T_ANYMAL_FLAT ? e->anymal_flat.base_init_state[2]
+                       : e->task == T_ARTICULATION ? reinterpret_cast<const MiArticulationParams*>(e->artic)->init_root[2] : e->loco.start_height;      // cartpole.py:93 / ant.py:164 / the tasks' default poses
     const float pot0 = loco ? -1000.f / e->loco.dt : 0.f;                                   // ant.py:113
     const float root[13] = {0, 0, root_z, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0};
     for (int en = 0; en < N; ++en) {
@@ -274,6 +276,7 @@ extern "C" int mi_engine_init_state(MiEngine* e, void*) {
         std::string err;
         if (cpu_anymal_init(e, &err) != 0) return fail(err);
     }
+    if (e->task == T_ARTICULATION) cpu_articulation_reset(e, nullptr, 0);
     return 0;
 }
 
@@ -672,6 +675,8 @@ extern "C" int mi_engine_step(MiEngine* e, const float* actions, void*) {
             break;
         case T_ANYMAL_FLAT: cpu_anymal_step(e, actions, false); break;
         case T_SHADOWHAND: case T_ALLEGROHAND: hand_call(e, 1, actions, false, nullptr, 0, nullptr, nullptr); break;
+        case T_ARTICULATION: return fail("mi_engine_step: the Articulation task has no task kernels -- drive it with mi_engine_simulate (gym.simulate) and keep "
+                                         "the observation / reward code on the caller's side");
         default: return fail("mi_engine_step: task not on the CPU backend");
     }
     e->steps++;
@@ -702,6 +707,7 @@ extern "C" int mi_engine_simulate(MiEngine* e, void*) {
             break;
         case T_ANYMAL_FLAT: cpu_anymal_step(e, nullptr, true); break;
         case T_SHADOWHAND: case T_ALLEGROHAND: hand_call(e, 1, nullptr, true, nullptr, 0, nullptr, nullptr); break;
+        case T_ARTICULATION: cpu_articulation_simulate(e); break;
         default: return fail("mi_engine_simulate: task not on the CPU backend");
     }
     return 0;
@@ -735,6 +741,7 @@ extern "C" int mi_engine_refresh_rigid_body_states(MiEngine* e, void*) {
         case T_BALLBALANCE: body_states_all<ModelBalanceBot>(e); break;
         case T_ANYMAL: case T_ANYMAL_FLAT: cpu_anymal_body_states(e); break;
         case T_SHADOWHAND: case T_ALLEGROHAND: hand_call(e, 3, nullptr, false, nullptr, 0, nullptr, nullptr); break;
+        case T_ARTICULATION: cpu_articulation_body_states(e); break;
         default: return fail("mi_engine_refresh_rigid_body_states: task not on the CPU backend");
     }
     return 0;
@@ -769,6 +776,7 @@ static int kinematics_views(MiEngine* e, float* out_j, float* out_h, const char*
         case T_BALLBALANCE: kinematics_views_all<ModelBalanceBot>(e, out_j, out_h); break;
         case T_ANYMAL: case T_ANYMAL_FLAT: cpu_anymal_kinematics(e, out_j, out_h); break;
         case T_SHADOWHAND: case T_ALLEGROHAND: hand_call(e, 4, nullptr, false, nullptr, 0, out_j, out_h); break;
+        case T_ARTICULATION: cpu_articulation_kinematics(e, out_j, out_h); break;
         default: return fail(std::string(who) + ": task not on the CPU backend");
     }
     return 0;
@@ -828,6 +836,7 @@ extern "C" int mi_engine_reset_idx(MiEngine* e, const int64_t* env_ids, int n, v
             break;
         case T_ANYMAL: case T_ANYMAL_FLAT: cpu_anymal_reset(e, env_ids, n); break;
         case T_SHADOWHAND: case T_ALLEGROHAND: hand_call(e, 2, nullptr, false, env_ids, n, nullptr, nullptr); break;
+        case T_ARTICULATION: cpu_articulation_reset(e, env_ids, n); break;
         default: return fail("mi_engine_reset_idx: task not on the CPU backend");
     }
     return 0;

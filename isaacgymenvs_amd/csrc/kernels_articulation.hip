@@ -1,0 +1,114 @@
+// kernels_articulation.hip -- the Articulation task: a robot compiled at RUN TIME from whatever file gym.load_asset names (assets/runtime.py emits
+// gen/model_articulation.h from the parsed description and rebuilds this one translation unit; the stock library carries the AMP humanoid,
+// reference amp/humanoid_amp_base.py:177).  gym.simulate with efforts and per-dof position drives, the rigid-body / Jacobian / mass-matrix tensors.
+// The one-wave sub-step in whichever row-store form the robot's size selects (core/engine.hpp: static rows in LDS, the compact store, or rows in
+// scratch) -- the limb-per-wave forms need role tables that are dealt per robot at build time.
+#include "step_kernels.hpp"
+#include "arena_layout.hpp"
+#include "gen/model_articulation.h"
+#include "tasks/articulation.hpp"
+
+ArticulationMeta mi_articulation_meta() { return ArticulationMeta{ModelArticulation::ND, ModelArticulation::NB, ModelArticulation::NSENS, ModelArticulation::NSPH, ModelArticulation::FIXED}; }
+
+namespace mi {
+
+using AM = ModelArticulation;
+static_assert(sizeof(MiArticulationParams) == sizeof(ArticulationParams), "MiArticulationParams layout");
+static_assert(AM::ND <= kMaxDof, "MI_MAX_DOF dofs");
+
+__global__ __launch_bounds__(64) void articulation_substep_kernel(View v, SimParams P, ArticulationParams p) {
+    extern __shared__ float lds_rows[];
+    constexpr int LANES = Sim<AM>::LANES;
+    const int e = xcd_env_base<LANES>(blockIdx.x) + threadIdx.x;
+    if (e >= v.N) return;
+    constexpr bool PRESTAGE = rows_fit_lds<AM>() && Sim<AM>::STAGES_LAM;
+    if constexpr (PRESTAGE) prestage_warm_start<AM>(v, e, lds_rows);
+    if constexpr (rows_fit_lds<AM>()) {
+        if constexpr (LANES == 64) articulation_substep_env<AM>(v, P, p, e, RowStore<64>(lds_rows + threadIdx.x), PRESTAGE);
+        else articulation_substep_env<AM>(v, P, p, e, RowStore<LANES>{lds_rows + threadIdx.x}, PRESTAGE);
+    } else {
+        float rows[Sim<AM>::ROW_SLOTS];
+        articulation_substep_env<AM>(v, P, p, e, RowStore<1>{rows}, false);
+    }
+}
+__global__ void articulation_reset_kernel(View v, ArticulationParams p, const long long* __restrict__ ids, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (ids ? n : v.N)) return;
+    const int e = ids ? (int)ids[i] : i;
+    if (e < 0 || e >= v.N) return;
+    articulation_reset_env<AM>(v, p, e);
+}
+__global__ __launch_bounds__(64) void articulation_body_states_kernel(View v) {
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    const int N = v.N;
+    if (e >= N) return;
+    const int body = blockIdx.y;
+    sfor<AM::NB>([&](auto B_) MI_LAMBDA {
+        constexpr int b = B_;
+        if (body == b) {         // wave-uniform
+            Sim<AM> sim;
+            sfor<13>([&](auto K) MI_LAMBDA { sim.root[K] = v.root[K * N + e]; });
+            sfor<AM::ND>([&](auto D) MI_LAMBDA {
+                if constexpr (Sim<AM>::on_chain(AM::dof_body[D], b)) { sim.q[D] = v.dof[D * N + e]; sim.qd[D] = v.dof[(AM::ND + D) * N + e]; }
+            });
+            float o[13];
+            sim.template body_state<b>(o);
+            sfor<13>([&](auto K) MI_LAMBDA { v.body_state[(b * 13 + K) * N + e] = o[K]; });
+        }
+    });
+}
+template <int b>
+__global__ __launch_bounds__(64) void articulation_jacobian_kernel(View v, float* __restrict__ out) {
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    const int N = v.N;
+    if (e >= N) return;
+    constexpr int NV = AM::NV;
+    Sim<AM> sim;
+    sfor<13>([&](auto K) MI_LAMBDA { sim.root[K] = v.root[K * N + e]; });
+    sfor<AM::ND>([&](auto D) MI_LAMBDA {
+        sim.qd[D] = 0.f;
+        if constexpr (Sim<AM>::on_chain(AM::dof_body[D], b)) sim.q[D] = v.dof[D * N + e]; else sim.q[D] = 0.f;
+    });
+    float J[6 * NV];
+    sim.template body_jacobian<b>(J);
+    float* o = out + ((size_t)e * AM::NB + b) * 6 * NV;
+    sfor<6 * NV>([&](auto K) MI_LAMBDA { o[K] = J[K]; });
+}
+__global__ __launch_bounds__(64) void articulation_mass_matrix_kernel(View v, SimParams P, float* __restrict__ out) {
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    const int N = v.N;
+    if (e >= N) return;
+    constexpr int NV = AM::NV;
+    Sim<AM> sim;
+    sfor<13>([&](auto K) MI_LAMBDA { sim.root[K] = v.root[K * N + e]; });
+    sfor<AM::ND>([&](auto D) MI_LAMBDA { sim.q[D] = v.dof[D * N + e]; sim.qd[D] = 0.f; });
+    float H[NV * NV];
+    sim.mass_matrix(P, H);
+    float* o = out + (size_t)e * NV * NV;
+    for (int k = 0; k < NV * NV; ++k) o[k] = H[k];
+}
+
+hipError_t launch_simulate_articulation(const View& v, const SimParams& P, const ArticulationParams& p, hipStream_t s) {
+    constexpr size_t lds = rows_fit_lds<AM>() ? lds_bytes<AM>() : 0;
+    constexpr int LANES = Sim<AM>::LANES;
+    static unsigned long long configured = 0ull;
+    if (hipError_t e = ensure_dynamic_lds((const void*)articulation_substep_kernel, lds, &configured); e != hipSuccess) return e;
+    for (int i = 0; i < P.substeps; ++i) hipLaunchKernelGGL(articulation_substep_kernel, dim3(xcd_grid<LANES>(v.N)), dim3(LANES), lds, s, v, P, p);
+    return hipGetLastError();
+}
+hipError_t launch_reset_articulation(const View& v, const ArticulationParams& p, const long long* ids, int n, hipStream_t s) {
+    const int cnt = ids ? n : v.N;
+    hipLaunchKernelGGL(articulation_reset_kernel, dim3((cnt + 127) / 128), dim3(128), 0, s, v, p, ids, n);
+    return hipGetLastError();
+}
+hipError_t launch_body_states_articulation(const View& v, hipStream_t s) {
+    hipLaunchKernelGGL(articulation_body_states_kernel, dim3((v.N + 63) / 64, AM::NB), dim3(64), 0, s, v);
+    return hipGetLastError();
+}
+hipError_t launch_kinematics_articulation(const View& v, const SimParams& P, float* out_j, float* out_h, hipStream_t s) {
+    if (out_j) sfor<AM::NB>([&](auto B_) { hipLaunchKernelGGL((articulation_jacobian_kernel<decltype(B_)::value>), dim3((v.N + 63) / 64), dim3(64), 0, s, v, out_j); });
+    if (out_h) hipLaunchKernelGGL(articulation_mass_matrix_kernel, dim3((v.N + 63) / 64), dim3(64), 0, s, v, P, out_h);
+    return hipGetLastError();
+}
+
+}  // namespace mi

@@ -22,6 +22,7 @@
 #include "gen/model_quadcopter.h"
 #include "tasks/quadcopter.hpp"
 #include "tasks/shadow_hand.hpp"
+#include "tasks/articulation.hpp"
 
 using namespace mi;
 
@@ -36,6 +37,7 @@ static_assert(sizeof(MiIngenuityParams) == sizeof(IngenuityParams), "MiIngenuity
 static_assert(sizeof(MiBallBalanceParams) == sizeof(BallBalanceParams), "MiBallBalanceParams layout");
 static_assert(sizeof(MiHandRewardParams) == sizeof(HandRewardParams), "MiHandRewardParams layout");
 static_assert(sizeof(MiHandParams) == sizeof(HandParams), "MiHandParams layout");
+static_assert(sizeof(MiArticulationParams) == sizeof(ArticulationParams), "MiArticulationParams layout");
 
 static thread_local std::string g_err;
 static int fail(const std::string& m) { g_err = m; return -1; }
@@ -225,6 +227,11 @@ hipError_t launch_step_ball_balance(const View& v, const BbotView& bv, const Sim
 hipError_t launch_simulate_ball_balance(const View& v, const BbotView& bv, const SimParams& P, const BallBalanceParams& p, hipStream_t s);
 hipError_t launch_init_ball_balance(const View& v, const BbotView& bv, const BallBalanceParams& p, hipStream_t s);
 hipError_t launch_reset_ball_balance(const View& v, const BbotView& bv, const BallBalanceParams& p, const long long* ids, int n, hipStream_t s);
+// kernels_articulation.hip (the one translation unit that holds the run-time-compiled robot)
+hipError_t launch_simulate_articulation(const View& v, const SimParams& P, const ArticulationParams& p, hipStream_t s);
+hipError_t launch_reset_articulation(const View& v, const ArticulationParams& p, const long long* ids, int n, hipStream_t s);
+hipError_t launch_body_states_articulation(const View& v, hipStream_t s);
+hipError_t launch_kinematics_articulation(const View& v, const SimParams& P, float* out_j, float* out_h, hipStream_t s);
 hipError_t launch_step_shadow_hand(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, const float* actions, int cfi,
                                    unsigned step_counter, hipStream_t s);
 hipError_t launch_simulate_shadow_hand(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, hipStream_t s);
@@ -253,6 +260,7 @@ struct MiEngine {
     AnymalTerrainDesc terrain;
     HandParams hand;
     HandView hv;
+    ArticulationParams artic;
     int max_init_level;
     int device;            // HIP device the caller's arena lives on: every entry point must be called with it current
     View v;
@@ -323,6 +331,7 @@ extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const 
         }
     }
     else if (is_hand_task(t)) memcpy(&e->hand, task_params, sizeof(HandParams));
+    else if (t == T_ARTICULATION) memcpy(&e->artic, task_params, sizeof(ArticulationParams));
     else memcpy(&e->loco, task_params, sizeof(LocoParams));
     Layout L;
     memset(&e->v, 0, sizeof(View));
@@ -514,6 +523,15 @@ extern "C" int mi_engine_init_state(MiEngine* e, void* stream) {
         e->steps = 0;
         return 0;
     }
+    if (e->task == T_ARTICULATION) {
+        const int blocks = (e->N + 255) / 256;
+        hipLaunchKernelGGL(init_state_kernel, dim3(blocks), dim3(256), 0, s, init_view(e), m.nd, 3 * m.nsph, 6 * m.nsens, m.nobs, m.nact,
+                           e->artic.init_root[2], (const float*)nullptr, 0.f);
+        HIP_OK(hipGetLastError());
+        HIP_OK(launch_reset_articulation(e->v, e->artic, nullptr, e->N, s));
+        e->steps = 0;
+        return 0;
+    }
     if (e->task == T_ANYMAL_FLAT) {
         const int blocks = (e->N + 255) / 256;
         hipLaunchKernelGGL(init_state_kernel, dim3(blocks), dim3(256), 0, s, init_view(e), m.nd, 3 * m.nsph, 0, m.nobs, m.nact,
@@ -584,6 +602,8 @@ extern "C" int mi_engine_step(MiEngine* e, const float* actions, void* stream) {
         case T_QUADCOPTER: HIP_OK(launch_step_quadcopter(e->v, e->qv, e->P, e->quad, actions, e->control_freq_inv, s)); break;
         case T_INGENUITY: HIP_OK(launch_step_ingenuity(e->v, e->iv, e->P, e->ing, actions, e->control_freq_inv, s)); break;
         case T_BALLBALANCE: HIP_OK(launch_step_ball_balance(e->v, e->bv, e->P, e->bbot, actions, e->control_freq_inv, s)); break;
+        case T_ARTICULATION: return fail("mi_engine_step: the Articulation task has no task kernels -- drive it with mi_engine_simulate (gym.simulate) and keep "
+                                         "the observation / reward code on the caller's side");
     }
     e->steps++;
     return 0;
@@ -608,6 +628,7 @@ extern "C" int mi_engine_simulate(MiEngine* e, void* stream) {
         case T_QUADCOPTER: HIP_OK(launch_simulate_quadcopter(e->v, e->qv, e->P, e->quad, s)); break;
         case T_INGENUITY: HIP_OK(launch_simulate_ingenuity(e->v, e->iv, e->P, e->ing, s)); break;
         case T_BALLBALANCE: HIP_OK(launch_simulate_ball_balance(e->v, e->bv, e->P, e->bbot, s)); break;
+        case T_ARTICULATION: HIP_OK(launch_simulate_articulation(e->v, e->P, e->artic, s)); break;
     }
     return 0;
 }
@@ -618,6 +639,7 @@ extern "C" int mi_engine_refresh_rigid_body_states(MiEngine* e, void* stream) {
     if (int rc = check_device(e, "mi_engine_refresh_rigid_body_states")) return rc;
     static_assert(T_CARTPOLE == 0 && T_ANT == 1 && T_HUMANOID == 2 && T_ANYMAL == 3 && T_SHADOWHAND == 4 && T_ANYMAL_FLAT == 5 && T_QUADCOPTER == 6 &&
                   T_INGENUITY == 7 && T_BALLBALANCE == 8 && T_ALLEGROHAND == 9, "kernels_body_states.hip switches on these ids");
+    if (e->task == T_ARTICULATION) { HIP_OK(launch_body_states_articulation(e->v, (hipStream_t)stream)); return 0; }
     HIP_OK(launch_body_states(e->task, e->v, (hipStream_t)stream));
     return 0;
 }
@@ -626,12 +648,14 @@ namespace mi { hipError_t launch_kinematics_views(int task, const View& v, const
 extern "C" int mi_engine_compute_jacobians(MiEngine* e, float* out, void* stream) {
     if (!e || !out) return fail("mi_engine_compute_jacobians: null argument");
     if (int rc = check_device(e, "mi_engine_compute_jacobians")) return rc;
+    if (e->task == T_ARTICULATION) { HIP_OK(launch_kinematics_articulation(e->v, e->P, out, nullptr, (hipStream_t)stream)); return 0; }
     HIP_OK(launch_kinematics_views(e->task, e->v, e->P, out, nullptr, (hipStream_t)stream));
     return 0;
 }
 extern "C" int mi_engine_compute_mass_matrices(MiEngine* e, float* out, void* stream) {
     if (!e || !out) return fail("mi_engine_compute_mass_matrices: null argument");
     if (int rc = check_device(e, "mi_engine_compute_mass_matrices")) return rc;
+    if (e->task == T_ARTICULATION) { HIP_OK(launch_kinematics_articulation(e->v, e->P, nullptr, out, (hipStream_t)stream)); return 0; }
     HIP_OK(launch_kinematics_views(e->task, e->v, e->P, nullptr, out, (hipStream_t)stream));
     return 0;
 }
@@ -653,6 +677,7 @@ extern "C" int mi_engine_reset_idx(MiEngine* e, const int64_t* env_ids, int n, v
         case T_QUADCOPTER: HIP_OK(launch_reset_quadcopter(e->v, e->qv, e->quad, (const long long*)env_ids, n, s)); break;
         case T_INGENUITY: HIP_OK(launch_reset_ingenuity(e->v, e->iv, e->ing, (const long long*)env_ids, n, s)); break;
         case T_BALLBALANCE: HIP_OK(launch_reset_ball_balance(e->v, e->bv, e->bbot, (const long long*)env_ids, n, s)); break;
+        case T_ARTICULATION: HIP_OK(launch_reset_articulation(e->v, e->artic, (const long long*)env_ids, n, s)); break;
     }
     return 0;
 }

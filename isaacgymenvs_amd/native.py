@@ -15,7 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI_ENGINE_LIB") or os.path.join(_HERE, "libmi_engine.so")
 # CPU product backend (sim_device="cpu": the reference's CPU pipeline, BASELINE config 1), built with g++ from the same engine sources
 CPU_LIB_PATH = os.path.join(_HERE, "libmi_engine_cpu.so")
-CPU_TASKS = ("Cartpole", "Ant", "Humanoid", "AnymalTerrain", "ShadowHand", "Anymal", "Quadcopter", "Ingenuity", "BallBalance", "AllegroHand")
+CPU_TASKS = ("Cartpole", "Ant", "Humanoid", "AnymalTerrain", "ShadowHand", "Anymal", "Quadcopter", "Ingenuity", "BallBalance", "AllegroHand",
+             "Articulation")
 CSRC = os.path.join(_HERE, "csrc")
 BUILD_DIR = os.path.join(CSRC, "build")
 # one translation unit per robot model (they compile in parallel) + the C ABI
@@ -28,7 +29,9 @@ SOURCES = ["mi_engine.hip", "kernels_cartpole.hip", "kernels_ant.hip", "kernels_
            "kernels_allegro_hand.hip", "kernels_allegro_hand_pen.hip", "kernels_allegro_hand_egg.hip",
            "kernels_allegro_hand_mw.hip", "kernels_allegro_hand_mw_pen.hip", "kernels_allegro_hand_mw_egg.hip",
            "kernels_scaled_ant.hip", "kernels_scaled_humanoid.hip", "kernels_scaled_humanoid_mwc.hip", "kernels_scaled_humanoid_sc2.hip",
-           "kernels_scaled_anymal.hip"]
+           "kernels_scaled_anymal.hip",
+           # the Articulation task: the ONE translation unit that holds the run-time-compiled robot (assets/runtime.py rebuilds only this)
+           "kernels_articulation.hip"]
 MI_MAX_DOF = 32
 # include/mi_engine.h MI_ABI_VERSION: bumped whenever the arena layout, a parameter struct or an export changes (2: round 4 -- cumulative
 # episode statistics tensors, per-body actor scales, rigid_body_state).  A library of another version is refused when it is loaded, and a state
@@ -111,6 +114,10 @@ class MiBallBalanceParams(C.Structure):
                 ("actuated_mask", C.c_int32), ("ball_radius", C.c_float), ("ball_mass", C.c_float), ("ball_inertia", C.c_float),
                 ("mu", C.c_float), ("tray_radius", C.c_float), ("tray_half", C.c_float), ("pin_offset", C.c_float * 3),
                 ("pin_target", (C.c_float * 3) * 3), ("sensor_pos", (C.c_float * 3) * 3)]
+
+
+class MiArticulationParams(C.Structure):
+    _fields_ = [("kp", C.c_float * MI_MAX_DOF), ("kd", C.c_float * MI_MAX_DOF), ("max_angular_velocity", C.c_float), ("init_root", C.c_float * 13)]
 
 
 class MiHandRewardParams(C.Structure):
@@ -400,7 +407,8 @@ def cpu_needs_build():
 # last column: the robot models whose constants the unit instantiates (None: all -- it holds the arena layout); a run-time variant of a model
 # (assets/runtime.py) recompiles only those
 _HAND_MODEL = {0: "shadow_hand", 1: "allegro_hand"}
-CPU_UNITS = [("mi_engine_cpu.cpp", "", "-O2", [], None), ("cpu_anymal.cpp", "", "-O2", [], ("anymal",))] + \
+CPU_UNITS = [("mi_engine_cpu.cpp", "", "-O2", [], ("cartpole", "ant", "humanoid", "quadcopter", "ingenuity", "balance_bot")),
+             ("cpu_anymal.cpp", "", "-O2", [], ("anymal",)), ("cpu_articulation.cpp", "", "-O2", [], ("articulation",))] + \
             [("cpu_hand.cpp", f"_{h}", "-O2", [f"-DMI_CPU_HAND={h}"], (_HAND_MODEL[h],)) for h in (0, 1)] + \
             [("cpu_hand_physics.cpp", f"_{h}_{sh}", "-O1", [f"-DMI_CPU_HAND={h}", f"-DMI_CPU_SHAPE={sh}"], (_HAND_MODEL[h],)) for h in (0, 1) for sh in (0, 1, 2)]
 CPU_FLAGS = ["-std=c++17", "-fPIC", "-fopenmp", "-ffp-contract=off"]

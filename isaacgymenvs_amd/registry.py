@@ -30,6 +30,9 @@ MODELS = {
     # reference ball_balance.py:285-300: attractors hold a point of each lower leg (the "sensor" bodies: the tree pass records their
     # poses); the reference's three force sensors sit on the tray itself (:254-260) and are computed from the tray's momentum balance
     "balance_bot": dict(struct="ModelBalanceBot", sensors=["lower_leg0", "lower_leg1", "lower_leg2"]),
+    # the Articulation task's robot: compiled at run time from whatever file gym.load_asset names (assets/runtime.py); the stock build carries the
+    # AMP humanoid (reference amp/humanoid_amp_base.py:177 mjcf/amp_humanoid.xml, force sensors on the feet :191-197)
+    "articulation": dict(struct="ModelArticulation", sensors=["right_foot", "left_foot"]),
 }
 
 

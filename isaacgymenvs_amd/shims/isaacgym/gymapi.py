@@ -264,7 +264,7 @@ class _Asset:
         target marker).  Which of the engine's free objects it is follows from the task of the articulated actor it shares its envs with."""
         a = cls.__new__(cls)
         a.options, a.sensors, a.shape_friction, a.tendon_props = options, [], None, None
-        a.spec, a.object_type, a.dims = None, shape, tuple(float(d) for d in dims)
+        a.spec, a.object_type, a.dims, a.generic = None, shape, tuple(float(d) for d in dims), False
         a.body_names, a.body_dyn, a.nshapes = [shape], np.zeros(1, np.int64), 1
         return a
 
@@ -277,6 +277,7 @@ class _Asset:
         self.shape_friction = None             # set_asset_rigid_shape_properties: friction of the asset's shapes for the actors created next
         self.tendon_props = None
         self.spec, self.object_type = None, None
+        self.generic = False                   # a robot no task of the engine was written for (the Articulation task)
         if key in _OBJECT_OF_FILE:
             self.object_type = _OBJECT_OF_FILE[key]
             self.body_names, self.body_dyn = ["object"], np.zeros(1, np.int64)
@@ -297,9 +298,16 @@ class _Asset:
                     else:
                         self.spec, self.variant = spec, True
         elif os.path.isfile(path):
-            self.model_name, self.spec = runtime.match_model(path)   # a file of another name with the tree of a compiled model
-            self.task = runtime.TASK_OF_MODEL[self.model_name]
-            self.variant = runtime.header_text(self.model_name, self.spec) != runtime.header_text(self.model_name, load_model(self.model_name))
+            try:
+                self.model_name, self.spec = runtime.match_model(path)   # a file of another name with the tree of a compiled model
+                self.task = runtime.TASK_OF_MODEL[self.model_name]
+                self.variant = runtime.header_text(self.model_name, self.spec) != runtime.header_text(self.model_name, load_model(self.model_name))
+            except NotImplementedError:
+                # a kinematic tree of its own: the engine's Articulation task (gym.simulate and the state tensors, no fused task kernels), compiled
+                # for this robot when prepare_sim knows its drives and sensors (assets/runtime.py variant_library; the stock library carries
+                # mjcf/amp_humanoid.xml as HumanoidAMP configures it)
+                self.model_name, self.task, self.generic = runtime.GENERIC_MODEL, "Articulation", True
+                self.spec = runtime.parse_generic(path, options)
         else:
             raise NotImplementedError(f"gym.load_asset: {key} has no model compiled into the engine (available: {sorted(_MODEL_OF_FILE)}) and "
                                       f"is not a readable file; robots are specialised per model (isaacgymenvs_amd/codegen.py, assets/runtime.py)")
@@ -314,7 +322,7 @@ class _Asset:
             self.body_dyn = np.asarray(self.spec.api_body_dyn, np.int64)
             self.body_off_p = np.asarray(self.spec.api_body_pos, float); self.body_off_q = np.asarray(self.spec.api_body_quat, float)
         self.nshapes = len(self.spec.geom_body)
-        self.engine_sensor_bodies = [self.body_names.index(self.spec.body_names[b]) for b in sensor_bodies(self.model_name, self.spec)]
+        self.engine_sensor_bodies = [] if self.generic else [self.body_names.index(self.spec.body_names[b]) for b in sensor_bodies(self.model_name, self.spec)]
         self.has_self_collision = load_selfcol(self.model_name) is not None
         self.extras = load_extras(self.model_name) if self.model_name in ("shadow_hand", "allegro_hand") else None
 
@@ -440,7 +448,7 @@ class Gym:
         return asset.spec.dof_names[int(asset.spec.act_dof[index])]
 
     def get_asset_dof_properties(self, asset):
-        return _dof_properties(asset.spec)
+        return _dof_properties(asset.spec, _drive_mode(asset))
 
     def get_asset_rigid_shape_properties(self, asset):
         mu = asset.spec.geom_friction if asset.spec is not None else [1.0]
@@ -523,7 +531,10 @@ class Gym:
         return True
 
     def get_actor_dof_properties(self, env, actor):
-        return _dof_properties(env.sim.slots[actor]["asset"].spec)
+        sl = env.sim.slots[actor]
+        if sl["asset"].generic and sl.get("dof_props") is not None:
+            return np.array(sl["dof_props"], copy=True)
+        return _dof_properties(sl["asset"].spec, _drive_mode(sl["asset"]))
 
     def set_actor_dof_properties(self, env, actor, props):
         """Drive modes and gains are task parameters of the engine: kept (env 0's; every env sets the same) and read by prepare_sim for the
@@ -610,10 +621,35 @@ class Gym:
         p.max_depen_vel = float(px.max_depenetration_velocity)
         p.erp, p.cfm, p.warm, p.ground_z = 0.5, 1e-6, 1.0, 0.0
         p.plane_mu = float(sim.plane.static_friction) if sim.plane is not None else 1.0
-        cfg = compose(overrides=[f"task={asset.task}"])["task"]        # the fused kernels' own parameters: unused by simulate()
+        cfg = None if asset.generic else compose(overrides=[f"task={asset.task}"])["task"]        # the fused kernels' own parameters: unused by simulate()
         poses = torch.tensor(rslot["poses"], dtype=torch.float32)
         terrain = None
-        if asset.task == "Cartpole":
+        lib_path = None
+        if asset.generic:
+            from ...assets import runtime
+            spec, nd = asset.spec, asset.spec.nd
+            dp = rslot.get("dof_props")
+            if dp is None:
+                dp = _dof_properties(spec, _drive_mode(asset))
+            modes = [int(m) for m in dp["driveMode"]]
+            if any(m not in (DOF_MODE_NONE, DOF_MODE_EFFORT, DOF_MODE_POS) for m in modes):
+                raise NotImplementedError("Articulation: dofs are position drives (DOF_MODE_POS) or effort / undriven; no velocity drives")
+            import copy
+            sp = copy.deepcopy(spec)            # the actor as its dof properties now describe it
+            sp.dof_stiffness, sp.dof_damping = np.array(dp["stiffness"], float), np.array(dp["damping"], float)
+            sp.dof_armature = np.array(dp["armature"], float)
+            sp.dof_lower, sp.dof_upper = np.array(dp["lower"], float), np.array(dp["upper"], float)
+            sp, kp, kd = runtime.drive_split(sp, [d for d in range(nd) if modes[d] == DOF_MODE_POS])
+            sens = [int(asset.body_dyn[b]) for b in asset.sensors] or [0]
+            tp = native.MiArticulationParams()
+            for d in range(nd):
+                tp.kp[d], tp.kd[d] = float(kp[d]), float(kd[d])
+            tp.max_angular_velocity = float(getattr(asset.options, "max_angular_velocity", 0.0) or 0.0)
+            for k in range(7):
+                tp.init_root[k] = float(poses[0, k])
+            lib_path = runtime.variant_library(asset.model_name, sp, sim.device, sensors=sens)
+            asset.engine_spec = sp
+        elif asset.task == "Cartpole":
             from ...tasks.cartpole import cartpole_params_from_cfg
             tp = cartpole_params_from_cfg(cfg)
         elif asset.task == "AnymalTerrain":
@@ -707,7 +743,6 @@ class Gym:
         else:
             from ...tasks.locomotion import loco_params_from_cfg
             tp = loco_params_from_cfg(cfg, asset.model_name, float(poses[0, 2]))
-        lib_path = None
         if asset.variant:                      # compiled once per distinct model, cached (isaacgymenvs_amd/_variants/<hash>/)
             from ...assets import runtime
             lib_path = runtime.variant_library(asset.model_name, asset.spec, sim.device)
@@ -748,7 +783,7 @@ class Gym:
                     t["actor_scale"][:, 4] = dm / float(asset.extras["tendon_damping"])
         # (BallBalance: the task's three sensors sit on the tray, :254-260 -- the engine computes exactly those from the tray's momentum balance;
         #  its `sensor` bodies are the lower legs the attractors hold)
-        if asset.task != "BallBalance" and asset.sensors and asset.sensors != asset.engine_sensor_bodies[:len(asset.sensors)]:
+        if asset.task not in ("BallBalance", "Articulation") and asset.sensors and asset.sensors != asset.engine_sensor_bodies[:len(asset.sensors)]:
             raise NotImplementedError(f"force sensors on bodies {asset.sensors}: the compiled {asset.model_name} model has them on "
                                       f"{asset.engine_sensor_bodies}")
         return True
@@ -1096,13 +1131,18 @@ def _quat_rotate(q, v):
     return v + w * t + torch.cross(qv, t, dim=-1)
 
 
-def _dof_properties(spec):
+def _drive_mode(asset):
+    return int(asset.options.default_dof_drive_mode) if asset.generic else DOF_MODE_EFFORT
+
+
+def _dof_properties(spec, mode=DOF_MODE_EFFORT):
     dt = np.dtype([("hasLimits", "?"), ("lower", "f4"), ("upper", "f4"), ("driveMode", "i4"), ("velocity", "f4"), ("effort", "f4"),
                    ("stiffness", "f4"), ("damping", "f4"), ("friction", "f4"), ("armature", "f4")])
     out = np.zeros(spec.nd, dt)
     out["hasLimits"] = np.asarray(spec.dof_limited, bool)
     out["lower"], out["upper"] = spec.dof_lower, spec.dof_upper
-    out["driveMode"] = DOF_MODE_EFFORT
+    # a robot of its own reports the drive mode it was loaded with (AssetOptions.default_dof_drive_mode, amp/humanoid_amp_base.py:187)
+    out["driveMode"] = mode
     out["velocity"], out["effort"] = spec.dof_velocity, spec.dof_effort
     out["stiffness"], out["damping"], out["armature"] = spec.dof_stiffness, spec.dof_damping, spec.dof_armature
     return out

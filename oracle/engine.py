@@ -208,6 +208,17 @@ class OracleEngine:
         self.lib.or_step_drive(C.byref(self.model), C.byref(self.params), self.N, _ptr(self.state), _ptr(tau), _ptr(self.out),
                                creal(kp), creal(kd), _ptr(tg) if tg is not None else None, _ptr(fx) if fx is not None else None)
 
+    def step_drive_v(self, tau, kp, kd, target):
+        """as step_drive with per-dof gains kp[nd], kd[nd] (gym dof properties stiffness / damping of DOF_MODE_POS dofs); fills self.netf"""
+        r = self.np_real
+        tau = np.ascontiguousarray(tau, r).reshape(self.N, self.nd)
+        tg = np.ascontiguousarray(target, r).reshape(self.N, self.nd)
+        kp, kd = np.ascontiguousarray(kp, r).reshape(self.nd), np.ascontiguousarray(kd, r).reshape(self.nd)
+        if not hasattr(self, "netf"):
+            self.netf = np.zeros((self.N, self.spec.nb, 3), self.np_real)
+        self.lib.or_step_drive_v(C.byref(self.model), C.byref(self.params), self.N, _ptr(self.state), _ptr(tau), _ptr(self.out),
+                                 _ptr(kp), _ptr(kd), _ptr(tg), _ptr(self.netf))
+
     def dynamics(self, env=0):
         nv = self.spec.nv
         M = np.zeros((nv, nv), self.np_real)

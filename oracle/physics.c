@@ -601,7 +601,11 @@ typedef struct {
     real kp, kd;
     const real *target; /* [nd] or NULL */
     const real *fext;   /* [3*nb] or NULL */
+    const real *kpv, *kdv; /* [nd] per-dof gains instead of kp / kd (gym dof properties stiffness / damping differ per dof:
+                            * amp/humanoid_amp_base.py:219-222 keeps the MJCF's), or NULL */
 } OrExtra;
+#define EX_KP(ex, d) ((ex)->kpv ? (ex)->kpv[d] : (ex)->kp)
+#define EX_KD(ex, d) ((ex)->kdv ? (ex)->kdv[d] : (ex)->kd)
 
 static void step_env(const OrModel *m, const OrParams *p, const OrGround *gnd, real mu_env, real *root, real *q, real *qd,
                      real *lam_c, real *lam_l, real *lam_p, const real *tau, real *sensor, real *dof_force, real *sph_force,
@@ -620,8 +624,9 @@ static void step_env(const OrModel *m, const OrParams *p, const OrGround *gnd, r
             w.M[off + d][off + d] += m->dof_armature[d] + h * D + h * h * K;
             rhs[off + d] = tau[d] - w.bias[off + d] - K * (q[d] - m->dof_springref[d]) - (D + h * K) * qd[d];
             if (ex && ex->target) {   /* implicit PD drive: same linearisation as the passive spring/damper */
-                w.M[off + d][off + d] += h * ex->kd + h * h * ex->kp;
-                rhs[off + d] += ex->kp * (ex->target[d] - q[d]) - (ex->kd + h * ex->kp) * qd[d];
+                real kp = EX_KP(ex, d), kd = EX_KD(ex, d);
+                w.M[off + d][off + d] += h * kd + h * h * kp;
+                rhs[off + d] += kp * (ex->target[d] - q[d]) - (kd + h * kp) * qd[d];
             }
         }
         if (ex && ex->fext) {         /* generalised force J^T f of every externally forced body */
@@ -860,7 +865,7 @@ static void step_env(const OrModel *m, const OrParams *p, const OrGround *gnd, r
             real ll = 0;
             if (lim_row[d] >= 0) { ll = lam[lim_row[d]] * lim_sign[d]; lam_l[d] = ll; }
             dof_force[d] = tau[d] - m->dof_stiffness[d] * (q[d] - m->dof_springref[d]) - m->dof_damping[d] * v[off + d] + ll / h;
-            if (ex && ex->target) dof_force[d] += ex->kp * (ex->target[d] - q[d]) - ex->kd * v[off + d];
+            if (ex && ex->target) dof_force[d] += EX_KP(ex, d) * (ex->target[d] - q[d]) - EX_KD(ex, d) * v[off + d];
         }
         for (int k = 0; k < 6 * m->nsens; k++) sensor[k] = 0;
         if (netf) for (int k = 0; k < 3 * m->nb; k++) netf[k] = 0;
@@ -985,10 +990,24 @@ void or_step_drive(const OrModel *m, const OrParams *p, int nenv, real *state, c
 #pragma omp parallel for schedule(static)
     for (int e = 0; e < nenv; e++) {
         real *s = state + (size_t)e * ss, *o = out + (size_t)e * os;
-        OrExtra ex = {kp, kd, target ? target + (size_t)e * nd : 0, fext ? fext + (size_t)e * 3 * m->nb : 0};
+        OrExtra ex = {kp, kd, target ? target + (size_t)e * nd : 0, fext ? fext + (size_t)e * 3 * m->nb : 0, 0, 0};
         step_env(m, p, 0, (real)-1, s, s + 13, s + 13 + nd, s + 13 + 2 * nd, s + 13 + 2 * nd + 3 * m->nsph,
                  s + 13 + 3 * nd + 3 * m->nsph, tau + (size_t)e * nd, o, o + 6 * m->nsens, o + 6 * m->nsens + nd,
                  o + 6 * m->nsens + nd + 3 * m->nsph, 0, &ex);
+    }
+}
+
+/* as or_step_drive with one gain pair per dof (kpv[nd], kdv[nd], the same for every env) and the net contact force per body */
+void or_step_drive_v(const OrModel *m, const OrParams *p, int nenv, real *state, const real *tau, real *out, const real *kpv,
+                     const real *kdv, const real *target, real *netf) {
+    int ss = or_state_size(m), os = or_out_size(m), nd = m->nd;
+#pragma omp parallel for schedule(static)
+    for (int e = 0; e < nenv; e++) {
+        real *s = state + (size_t)e * ss, *o = out + (size_t)e * os;
+        OrExtra ex = {0, 0, target + (size_t)e * nd, 0, kpv, kdv};
+        step_env(m, p, 0, (real)-1, s, s + 13, s + 13 + nd, s + 13 + 2 * nd, s + 13 + 2 * nd + 3 * m->nsph,
+                 s + 13 + 3 * nd + 3 * m->nsph, tau + (size_t)e * nd, o, o + 6 * m->nsens, o + 6 * m->nsens + nd,
+                 o + 6 * m->nsens + nd + 3 * m->nsph, netf ? netf + (size_t)e * 3 * m->nb : 0, &ex);
     }
 }
 

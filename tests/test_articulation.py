@@ -1,0 +1,292 @@
+"""The Articulation task: `gym.load_asset` of a robot whose kinematic tree no task of the engine was written for.
+The engine steps it through gym.simulate -- efforts, per-dof position drives, ground contacts, force sensors, net contact forces, rigid-body
+states, Jacobians / mass matrices -- and the task file keeps its own observation / reward code.
+
+  * the stock library carries mjcf/amp_humanoid.xml as HumanoidAMP configures it (every dof DOF_MODE_POS, amp/humanoid_amp_base.py:219-222):
+    engine vs oracle/physics.c (or_step_drive_v: per-dof gains) on the CPU backend here, on the HIP backend with -m gpu;
+  * a three-link hopper written by the test: parsed, compiled at run time into a library of its own, stepped, compared with the oracle
+    given the same parsed spec;
+  * the reference's unmodified tasks/humanoid_amp.py through the `isaacgym` stand-in (where the reference tree is reachable).
+"""
+import ctypes as C
+import importlib
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import pytest
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("MI_REFERENCE_ROOT") or next((p for p in ("/root/reference", os.path.join(_HERE, "..", "ab", "ref_stage"))
+                                                    if os.path.isdir(os.path.join(p, "isaacgymenvs", "tasks", "amp"))), "/root/reference")
+HAVE_REF = os.path.isfile(os.path.join(REF, "isaacgymenvs", "tasks", "humanoid_amp.py"))
+
+SIM = dict(dt=1 / 60.0, substeps=2, iters=4, gravity=(0.0, 0.0, -9.81), contact_offset=0.02, rest_offset=0.0, max_depen_vel=10.0, erp=0.2, plane_mu=1.0,
+           ground_z=0.0, cfm=1e-6, warm=0.9)
+
+
+def _sim_params():
+    from isaacgymenvs_amd import native
+    p = native.MiSimParams(dt=SIM["dt"], substeps=SIM["substeps"], iters=SIM["iters"], contact_offset=SIM["contact_offset"], rest_offset=SIM["rest_offset"],
+                           max_depen_vel=SIM["max_depen_vel"], erp=SIM["erp"], plane_mu=SIM["plane_mu"], ground_z=SIM["ground_z"], cfm=SIM["cfm"], warm=SIM["warm"])
+    for i, g in enumerate(SIM["gravity"]):
+        p.gravity[i] = g
+    return p
+
+
+def _engine_vs_oracle(device, steps=40):
+    from isaacgymenvs_amd import native
+    from isaacgymenvs_amd.registry import load_model, sensor_bodies
+    from oracle.engine import OracleEngine
+    if device == "cpu":
+        native.build_cpu()
+    spec, sens = load_model("articulation"), sensor_bodies("articulation")
+    N, nd = 64, spec.nd
+    rng = np.random.default_rng(3)
+    kp = rng.uniform(50, 600, nd)
+    kd = kp / 10
+    tp = native.MiArticulationParams()
+    for d in range(nd):
+        tp.kp[d], tp.kd[d] = kp[d], kd[d]
+    root0 = [0, 0, 0.89, 0, 0, 0, 1] + [0] * 6
+    for k in range(13):
+        tp.init_root[k] = root0[k]
+    eng = native.Engine("Articulation", _sim_params(), tp, N, device, seed=1)
+    T = eng.tensors
+    # the state mi_engine_init_state leaves: the actor at its start pose, joints at zero, targets = joint positions
+    assert torch.allclose(T["root_states"].cpu(), torch.tensor(root0).expand(N, 13))
+    assert float(T["dof_state"].abs().max()) == 0.0 and float(T["dof_position_targets"].abs().max()) == 0.0
+    orc = OracleEngine(spec, N, params=SIM, sensor_bodies=sens, precision="f32")
+    orc.root[:] = np.array(root0)
+    orc.root[:, 2] += rng.uniform(0, 0.3, N)
+    lo, up = np.minimum(spec.dof_lower, spec.dof_upper), np.maximum(spec.dof_lower, spec.dof_upper)
+    orc.q[:] = np.clip(rng.uniform(-0.2, 0.2, (N, nd)), lo, up)
+    T["root_states"].copy_(torch.tensor(orc.root, dtype=torch.float32))
+    T["dof_state"][..., 0].copy_(torch.tensor(orc.q, dtype=torch.float32))
+    touched = 0
+    for it in range(steps):
+        target = np.clip(rng.uniform(-0.5, 0.5, (N, nd)), lo, up)
+        tau = rng.uniform(-5, 5, (N, nd))
+        T["dof_position_targets"].copy_(torch.tensor(target, dtype=torch.float32))
+        T["dof_actuation_force"].copy_(torch.tensor(tau, dtype=torch.float32))
+        eng.simulate()
+        orc.step_drive_v(tau, kp, kd, target)
+        tol = 2e-4 * (1 + it) if it < 25 else 5e-2        # contacts from ~step 25 on: trajectories of a falling humanoid part ways slowly
+        np.testing.assert_allclose(T["root_states"].cpu().numpy(), orc.root, atol=tol * 5)
+        np.testing.assert_allclose(T["dof_state"][..., 0].cpu().numpy(), orc.q, atol=tol * 5)
+        nf = T["net_contact_force"].cpu().numpy()
+        touched += int((np.abs(orc.netf).sum(axis=(1, 2)) > 0).sum())
+        if it < 25:
+            np.testing.assert_allclose(nf, orc.netf, atol=0.5 + 0.02 * np.abs(orc.netf).max())
+            np.testing.assert_allclose(T["force_sensor"].cpu().numpy().reshape(N, -1), orc.sensor, atol=0.5 + 0.02 * np.abs(orc.sensor).max())
+            np.testing.assert_allclose(T["dof_force"].cpu().numpy(), orc.dof_force, atol=0.5 + 0.02 * np.abs(orc.dof_force).max())
+    assert touched > 0                      # the comparison covered contacts
+    # rigid-body states against the oracle's forward kinematics; reset_idx back to the start pose
+    eng.refresh_rigid_body_states()
+    rb = T["rigid_body_state"].cpu().numpy()
+    np.testing.assert_allclose(rb[:, 0, :7], T["root_states"].cpu().numpy()[:, :7], atol=1e-5)
+    ids = torch.tensor([1, 5], dtype=torch.int64, device=device)
+    eng.reset_idx(ids)
+    assert torch.allclose(T["root_states"][ids].cpu(), torch.tensor(root0).expand(2, 13))
+    assert float(T["dof_state"][ids].abs().max()) == 0.0
+    # Jacobian / mass matrix shapes of a floating base (gym: all links, 6 base columns)
+    J, H = eng.compute_jacobians(), eng.compute_mass_matrices()
+    assert tuple(J.shape) == (N, spec.nb, 6, spec.nv) and tuple(H.shape) == (N, spec.nv, spec.nv)
+    Hn = H.cpu().numpy()
+    np.testing.assert_allclose(Hn, Hn.transpose(0, 2, 1), atol=1e-4)
+    assert np.all(np.linalg.eigvalsh(Hn.astype(np.float64)) > 0)
+    assert abs(float(Hn[0, 0, 0]) - spec.total_mass()) < 1e-3
+    # step() is not this task's entry point
+    with pytest.raises(RuntimeError, match="simulate"):
+        eng.step(torch.zeros((N, nd), device=device))
+
+
+def test_articulation_amp_humanoid_matches_oracle_cpu():
+    _engine_vs_oracle("cpu")
+
+
+@pytest.mark.gpu
+def test_articulation_amp_humanoid_matches_oracle_hip():
+    _engine_vs_oracle("cuda:0")
+
+
+HOPPER = """<mujoco model="hopper3">
+  <compiler angle="degree" inertiafromgeom="true"/>
+  <default><joint armature="0.02" damping="0.5" limited="true"/><geom density="900" friction="1.0 0.5 0.5"/></default>
+  <worldbody>
+    <body name="trunk" pos="0 0 1.0">
+      <freejoint name="root"/>
+      <geom name="trunk_geom" type="capsule" fromto="0 0 -0.15 0 0 0.2" size="0.06"/>
+      <body name="thigh" pos="0 0 -0.15">
+        <joint name="hip" type="hinge" axis="0 1 0" range="-60 60" stiffness="4"/>
+        <geom name="thigh_geom" type="capsule" fromto="0 0 0 0 0 -0.35" size="0.045"/>
+        <body name="shin" pos="0 0 -0.35">
+          <joint name="knee" type="hinge" axis="0 1 0" range="-120 0"/>
+          <geom name="shin_geom" type="capsule" fromto="0 0 0 0 0 -0.35" size="0.035"/>
+          <body name="foot" pos="0 0 -0.35">
+            <joint name="ankle_y" type="hinge" axis="0 1 0" range="-40 40"/>
+            <joint name="ankle_x" type="hinge" axis="1 0 0" range="-20 20"/>
+            <geom name="foot_geom" type="capsule" fromto="-0.08 0 -0.03 0.14 0 -0.03" size="0.03"/>
+          </body>
+        </body>
+      </body>
+    </body>
+  </worldbody>
+  <actuator>
+    <motor joint="hip" gear="80"/><motor joint="knee" gear="80"/><motor joint="ankle_y" gear="30"/><motor joint="ankle_x" gear="30"/>
+  </actuator>
+</mujoco>
+"""
+
+
+def _hopper(device):
+    import isaacgymenvs_amd.shims as shims
+    from isaacgymenvs_amd import native
+    from isaacgymenvs_amd.assets import runtime
+    from oracle.engine import OracleEngine
+    if device == "cpu":
+        native.build_cpu()
+    shims.install(force=True)
+    from isaacgym import gymapi
+    tmp = tempfile.mkdtemp()
+    with open(os.path.join(tmp, "hopper3.xml"), "w") as f:
+        f.write(HOPPER)
+    gym = gymapi.acquire_gym()
+    sp = gymapi.SimParams()
+    sp.up_axis, sp.gravity, sp.dt, sp.substeps, sp.use_gpu_pipeline = gymapi.UP_AXIS_Z, gymapi.Vec3(0, 0, -9.81), 1 / 60.0, 2, device != "cpu"
+    sp.physx.max_depenetration_velocity = 10.0
+    sim = gym.create_sim(0, -1, gymapi.SIM_PHYSX, sp)
+    gym.add_ground(sim, gymapi.PlaneParams())
+    opts = gymapi.AssetOptions()
+    opts.default_dof_drive_mode = gymapi.DOF_MODE_NONE
+    opts.max_angular_velocity = 0.0
+    asset = gym.load_asset(sim, tmp, "hopper3.xml", opts)
+    assert asset.generic and asset.task == "Articulation"
+    assert gym.get_asset_dof_count(asset) == 4 and gym.get_asset_rigid_body_count(asset) == 4
+    assert gym.get_asset_dof_names(asset) == ["hip", "knee", "ankle_y", "ankle_x"]
+    assert [p.motor_effort for p in gym.get_asset_actuator_properties(asset)] == [80.0, 80.0, 30.0, 30.0]
+    gym.create_asset_force_sensor(asset, gym.find_asset_rigid_body_index(asset, "foot"), gymapi.Transform())
+    n = 16
+    for i in range(n):
+        env = gym.create_env(sim, gymapi.Vec3(), gymapi.Vec3(), 4)
+        h = gym.create_actor(env, asset, gymapi.Transform(gymapi.Vec3(0, 0, 1.05)), "hopper", i, 1, 0)
+        dp = gym.get_asset_dof_properties(asset)
+        assert np.all(dp["driveMode"] == gymapi.DOF_MODE_NONE) and dp["stiffness"][0] == 4.0
+        # hip stays effort-controlled with its passive spring; knee and ankles become position drives with gains of the task's choosing
+        dp["driveMode"][1:] = gymapi.DOF_MODE_POS
+        dp["stiffness"][1:] = [120.0, 40.0, 40.0]
+        dp["damping"][1:] = [6.0, 2.0, 2.0]
+        gym.set_actor_dof_properties(env, h, dp)
+    gym.prepare_sim(sim)                     # compiles the hopper's library (cached under isaacgymenvs_amd/_variants/<hash>/)
+    assert sim.engine.L is not (native.lib_cpu() if device == "cpu" else native.lib())
+    es = asset.engine_spec
+    assert list(es.dof_stiffness) == [4.0, 0.0, 0.0, 0.0] and list(es.dof_damping) == [0.5, 0.0, 0.0, 0.0]
+    lib_path = runtime.variant_library("articulation", es, sim.device, sensors=[3])
+    assert "_variants" in lib_path and sim.engine.L is native.variant_lib(lib_path)
+    root = gym.acquire_actor_root_state_tensor(sim)
+    dof = gym.acquire_dof_state_tensor(sim)
+    sensor = gym.acquire_force_sensor_tensor(sim)
+    netf = gym.acquire_net_contact_force_tensor(sim)
+    rb = gym.acquire_rigid_body_state_tensor(sim)
+    assert tuple(root.shape) == (n, 13) and tuple(dof.shape) == (n * 4, 2) and tuple(sensor.shape) == (n, 6) and tuple(netf.shape) == (n * 4, 3)
+    assert tuple(rb.shape) == (n * 4, 13)
+    prm = dict(dt=1 / 60.0, substeps=2, iters=4, gravity=(0, 0, -9.81), contact_offset=0.02, rest_offset=0.0, max_depen_vel=10.0, erp=0.5, plane_mu=1.0,
+               ground_z=0.0, cfm=1e-6, warm=1.0)
+    orc = OracleEngine(es, n, params=prm, sensor_bodies=[3], precision="f32")
+    orc.root[:] = sim.engine.tensors["root_states"].cpu().numpy()
+    orc.q[:] = sim.engine.tensors["dof_state"][..., 0].cpu().numpy()
+    kp, kd = np.array([0.0, 120.0, 40.0, 40.0]), np.array([0.0, 6.0, 2.0, 2.0])
+    rng = np.random.default_rng(5)
+    lo, up = np.minimum(es.dof_lower, es.dof_upper), np.maximum(es.dof_lower, es.dof_upper)
+    contact = 0
+    for it in range(60):
+        target = np.clip(rng.uniform(-0.6, 0.3, (n, 4)), lo, up)
+        tau = np.zeros((n, 4))
+        tau[:, 0] = rng.uniform(-20, 20, n)
+        gym.set_dof_position_target_tensor(sim, torch.tensor(target, dtype=torch.float32, device=sim.device).view(-1))
+        gym.set_dof_actuation_force_tensor(sim, torch.tensor(tau, dtype=torch.float32, device=sim.device).view(-1))
+        gym.simulate(sim)
+        gym.fetch_results(sim, True)
+        orc.step_drive_v(tau, kp, kd, target)
+        gym.refresh_actor_root_state_tensor(sim)
+        gym.refresh_dof_state_tensor(sim)
+        gym.refresh_net_contact_force_tensor(sim)
+        gym.refresh_force_sensor_tensor(sim)
+        tol = 1e-3 * (1 + it)
+        np.testing.assert_allclose(root.cpu().numpy(), orc.root, atol=tol)
+        np.testing.assert_allclose(dof.view(n, 4, 2)[..., 0].cpu().numpy(), orc.q, atol=tol)
+        f = netf.view(n, 4, 3).cpu().numpy()
+        contact += int((np.abs(orc.netf[:, 3]).sum(axis=1) > 0).sum())
+        np.testing.assert_allclose(f, orc.netf, atol=1.0 + 0.05 * np.abs(orc.netf).max())
+        np.testing.assert_allclose(sensor.cpu().numpy(), orc.sensor.reshape(n, 6), atol=1.0 + 0.05 * np.abs(orc.sensor).max())
+    assert contact > n                      # the hopper landed on its foot and the comparison covered it
+    assert float(root[:, 2].min()) > 0.3    # and did not fall through the ground
+
+
+def test_new_kinematic_tree_compiles_and_steps_cpu():
+    _hopper("cpu")
+
+
+@pytest.mark.gpu
+def test_new_kinematic_tree_compiles_and_steps_hip():
+    _hopper("cuda:0")
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="reference tree not reachable")
+def test_unmodified_humanoid_amp_task_file_steps():
+    """/root/reference/isaacgymenvs/tasks/humanoid_amp.py (with amp/humanoid_amp_base.py, its motion library and poselib) as it is: loads
+    mjcf/amp_humanoid.xml -- the Articulation task's stock robot --, switches every dof to DOF_MODE_POS, resets from the run motion clip,
+    steps; observations and the AMP observation buffer come from its own jitted functions on the engine's state."""
+    import isaacgymenvs_amd.shims as shims
+    from isaacgymenvs_amd import native
+    from isaacgymenvs_amd.utils.config import compose, omegaconf_to_dict
+    dev = "cuda:0" if torch.cuda.is_available() else "cpu"
+    if dev == "cpu":
+        native.build_cpu()
+    saved = {k: v for k, v in sys.modules.items() if k.split(".")[0] in ("isaacgymenvs", "isaacgym", "gym")}
+    for k in saved:
+        del sys.modules[k]
+    try:
+        shims.install(force=True)
+        for name, rel in (("isaacgymenvs", "isaacgymenvs"), ("isaacgymenvs.tasks", "isaacgymenvs/tasks"), ("isaacgymenvs.utils", "isaacgymenvs/utils"),
+                          ("isaacgymenvs.tasks.base", "isaacgymenvs/tasks/base")):
+            mod = types.ModuleType(name)
+            mod.__path__ = [os.path.join(REF, rel)]
+            sys.modules[name] = mod
+        m = importlib.import_module("isaacgymenvs.tasks.humanoid_amp")
+        assert os.path.samefile(m.__file__, os.path.join(REF, "isaacgymenvs", "tasks", "humanoid_amp.py"))
+        cfg = omegaconf_to_dict(compose("config", overrides=["task=HumanoidAMP"], cfg_dir=os.path.join(REF, "isaacgymenvs", "cfg"))["task"])
+        n = 32
+        cfg["env"]["numEnvs"] = n
+        cfg["sim"]["use_gpu_pipeline"] = dev != "cpu"
+        env = m.HumanoidAMP(cfg=cfg, rl_device=dev, sim_device=dev, graphics_device_id=-1, headless=True, virtual_screen_capture=False, force_render=False)
+        sim = env.sim
+        assert sim.asset.generic and sim.asset.task == "Articulation"
+        assert sim.engine.L is (native.lib_cpu() if dev == "cpu" else native.lib())          # the stock library: no run-time compile for the default config
+        assert env.num_dof == 28 and env.num_bodies == 15 and env.num_actions == 28 and env.num_obs == 105
+        kp = np.array([sim.engine._tp.kp[d] for d in range(28)])
+        assert kp.min() > 0 and kp.max() == 600.0                                              # the MJCF's joint stiffness became drive gains
+        torch.manual_seed(0)
+        z0 = env._root_states[:, 2].clone()
+        saw_reset = False
+        for i in range(60):
+            a = torch.rand((n, env.num_actions), device=dev) * 2 - 1
+            obs, rew, done, info = env.step(a)
+            assert torch.isfinite(obs["obs"]).all() and torch.isfinite(info["amp_obs"]).all()
+            assert tuple(info["amp_obs"].shape) == (n, 210)
+            saw_reset |= bool(done.any())
+        assert saw_reset                                                                       # random actions: the humanoids fall, early termination fires
+        assert float((env._root_states[:, 2] - z0).abs().max()) > 0.05
+        # the state the task reads is the engine's: rigid-body rows of the welded links ride on their engine bodies
+        env.gym.refresh_rigid_body_state_tensor(env.sim)
+        assert torch.allclose(env._rigid_body_pos[:, 0], env._root_states[:, :3], atol=1e-5)
+        # its position targets reach the engine
+        tg = sim.engine.tensors["dof_position_targets"]
+        assert float(tg.abs().max()) > 0.1
+    finally:
+        for k in [k for k in sys.modules if k.split(".")[0] in ("isaacgymenvs", "isaacgym", "gym")]:
+            del sys.modules[k]
+        sys.modules.update(saved)

@@ -34,6 +34,8 @@ ENTRIES = {
     # (a 23 mm plate behind the wrist, 10 cm from the palm's inner face) is left without contact geometry: the cube is reset (fall_dist)
     # long before it could reach it.
     "allegro_hand": dict(file="urdf/kuka_allegro_description/allegro_touch_sensor.urdf", fix_base_link=True, collide_body_filter=lambda n: False),
+    # the stock robot of the Articulation task (any other file is compiled at run time, assets/runtime.py): reference amp/humanoid_amp_base.py:177-186
+    "articulation": dict(file="mjcf/amp_humanoid.xml"),
 }
 
 
@@ -193,6 +195,13 @@ def main():
                               mesh_root=os.path.join(a.asset_root, "urdf"), mesh_link_filter=lambda link: link != "allegro_mount")
             with open(os.path.join(a.out, "allegro_hand_extras.json"), "w") as f:
                 json.dump(allegro_extras(a.asset_root, full), f, indent=1)
+        if name == "articulation":
+            # as its task drives it (HumanoidAMP.yaml pdControl: True -> every dof DOF_MODE_POS, amp/humanoid_amp_base.py:219-222): the joints'
+            # stiffness / damping are drive gains (engine parameters), not passive springs of the model -- so that the reference's default
+            # configuration runs on the stock library without a run-time compile
+            from isaacgymenvs_amd.assets.runtime import drive_split
+            spec, _, _ = drive_split(spec, range(spec.nd))
+            spec.save(os.path.join(a.out, name + ".json"))
         print(f"{name}: nb={spec.nb} nd={spec.nd} nv={spec.nv} nsph={len(spec.sph_body)} mass={spec.total_mass():.4f}")
     import tempfile
     from isaacgymenvs_amd.assets import procedural

@@ -13,4 +13,11 @@ cp $REF/isaacgymenvs/utils/*.py $D/utils/
 cp -r $REF/isaacgymenvs/cfg/. $D/cfg/
 mkdir -p $ROOT/ab/ref_stage/assets/mjcf && cp $REF/assets/mjcf/nv_ant.xml $ROOT/ab/ref_stage/assets/mjcf/     # tests/test_runtime_assets.py perturbs a copy
 mkdir -p $ROOT/ab/ref_stage/assets/urdf/anymal_c/urdf && cp $REF/assets/urdf/anymal_c/urdf/anymal.urdf $ROOT/ab/ref_stage/assets/urdf/anymal_c/urdf/   # anymal.py:168: parsed, its tree checked
+# tests/test_articulation.py: humanoid_amp.py with its base class, motion library and poselib (code only), the robot and one motion clip
+cp $REF/isaacgymenvs/tasks/humanoid_amp.py $D/tasks/
+mkdir -p $D/tasks/amp/poselib && cp $REF/isaacgymenvs/tasks/amp/*.py $D/tasks/amp/ && cp -r $REF/isaacgymenvs/tasks/amp/utils_amp $D/tasks/amp/
+cp -r $REF/isaacgymenvs/tasks/amp/poselib/poselib $D/tasks/amp/poselib/ && cp $REF/isaacgymenvs/tasks/amp/poselib/*.py $D/tasks/amp/poselib/ 2>/dev/null || true
+cp $REF/assets/mjcf/amp_humanoid.xml $ROOT/ab/ref_stage/assets/mjcf/
+mkdir -p $ROOT/ab/ref_stage/assets/amp/motions && cp $REF/assets/amp/motions/amp_humanoid_run.npy $ROOT/ab/ref_stage/assets/amp/motions/
+find $ROOT/ab/ref_stage -name __pycache__ -type d -prune -exec rm -rf {} +
 echo staged $(find $ROOT/ab/ref_stage -type f | wc -l) files under ab/ref_stage
