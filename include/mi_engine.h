@@ -484,7 +484,7 @@ int mi_compute_hand_reward_dextreme(int n, const MiDextremeRewardParams* p, floa
 
 /* Measurement aid (bench.py "box"; no reference counterpart): how fast THIS device runs the two things the step kernels are bound by -- the
  * issue rate of a lone wave (a chain of `fma_iters` dependent v_fma_f32 on one wave) and the latency of dependent loads (`hops` pointer-chase
- * steps through a `chase_bytes` buffer, a device scratch buffer of at least that size whose contents are overwritten).  out6[0] = us per
+ * steps through a `chase_bytes` buffer, a device scratch buffer of at least that size, >= 256 KB, whose contents are overwritten).  out6[0] = us per
  * 1000 dependent FMAs on a lone wave, out6[1] = ns per dependent load, out6[2] = us per 1000 dependent FMAs with one such wave on every
  * SIMD of the chip (the clocks under load), out6[3] = ns per workgroup barrier of a four-wave workgroup with an LDS word exchanged (one
  * workgroup per CU), out6[4] = ns per dependent LDS read, out6[5] = ns per dependent

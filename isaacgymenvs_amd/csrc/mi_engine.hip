@@ -879,10 +879,15 @@ __global__ __launch_bounds__(64) void probe_lds_kernel(unsigned* out, int hops) 
 }
 }  // namespace
 extern "C" int mi_device_probe(void* scratch, long long chase_bytes, int fma_iters, int hops, float* out2 /* [6] */, void* stream) {
-    if (!scratch || !out2 || chase_bytes < 4096 || fma_iters < 1 || hops < 1) return fail("mi_device_probe: bad argument");
+    // scratch: the barrier / transcendental probes write 65536 floats into it, the pointer chase walks all of it
+    if (!scratch || !out2 || chase_bytes < 65536 * (long long)sizeof(float) || fma_iters < 1 || hops < 1) return fail("mi_device_probe: bad argument (scratch of at least 256 KB)");
     hipStream_t s = (hipStream_t)stream;
-    hipEvent_t e0, e1;
-    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    struct Events {       // destroyed on every return path (HIP_OK leaves early)
+        hipEvent_t a = nullptr, b = nullptr;
+        ~Events() { if (a) hipEventDestroy(a); if (b) hipEventDestroy(b); }
+    } ev;
+    HIP_OK(hipEventCreate(&ev.a)); HIP_OK(hipEventCreate(&ev.b));
+    const hipEvent_t e0 = ev.a, e1 = ev.b;
     float* fout = (float*)scratch;
     float ms = 0.f, best = 1e30f;
     for (int rep = 0; rep < 4; ++rep) {       // (first launch: code upload, clocks ramping up)
@@ -954,7 +959,6 @@ extern "C" int mi_device_probe(void* scratch, long long chase_bytes, int fma_ite
         if (rep > 0 && ms < best) best = ms;
     }
     out2[1] = best * 1e6f / (float)hops;
-    hipEventDestroy(e0); hipEventDestroy(e1);
     return 0;
 }
 

@@ -64,17 +64,23 @@ __device__ __forceinline__ float quad_sum(float x) {
 }
 __global__ __launch_bounds__(256) void pgs_four_lanes(const float* __restrict__ rows_in, const float* __restrict__ w_in, float* __restrict__ w_out,
                                                       float* __restrict__ lam_out, int N, int nsweeps) {
-    // per role wave: entries [r][half][lane64] (lane = env * 4 + j holds entries 2 j + half), scalars [r][3][env]
+    // per role wave: entries [r][half][lane64] (lane = env * 4 + j holds entries 2 j + half), 1 / a and v* [r][2][env].  The impulses live in
+    // registers, replicated in the quad: every lane of a quad computes the same update from the same reduced v (the two DPP adds commute, so the
+    // four results are bit-identical) -- keeping them in LDS with one writer per quad would be an unsynchronised exchange between lanes, which
+    // the compiler may (and did) resolve by keeping a stale copy in the reading lanes.
     __shared__ float ent[ROLES][R * 2][64];
-    __shared__ float sca[ROLES][R * 3][E];
+    __shared__ float sca[ROLES][R * 2][E];
     const int lane = threadIdx.x, role = threadIdx.y, j = lane & 3, el = lane >> 2;
     const int e = blockIdx.x * E + el;
     if (e >= N) return;
     const float* src = rows_in + ((size_t)e * ROLES + role) * R * ROWF;
+    float lam[R];
+#pragma unroll
     for (int r = 0; r < R; ++r) {
         ent[role][2 * r][lane] = src[r * ROWF + 2 * j];
         ent[role][2 * r + 1][lane] = src[r * ROWF + 2 * j + 1];
-        if (j < 3) sca[role][3 * r + j][el] = src[r * ROWF + C + j];
+        if (j < 2) sca[role][2 * r + j][el] = src[r * ROWF + C + j];
+        lam[r] = src[r * ROWF + C + 2];
     }
     __syncthreads();
     float w0 = w_in[((size_t)e * ROLES + role) * C + 2 * j], w1 = w_in[((size_t)e * ROLES + role) * C + 2 * j + 1];
@@ -82,18 +88,32 @@ __global__ __launch_bounds__(256) void pgs_four_lanes(const float* __restrict__ 
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const float g0 = ent[role][2 * r][lane], g1 = ent[role][2 * r + 1][lane];
-            const float ainv = sca[role][3 * r][el], vt = sca[role][3 * r + 1][el], lam = sca[role][3 * r + 2][el];
+            const float ainv = sca[role][2 * r][el], vt = sca[role][2 * r + 1][el];
             const float v = quad_sum(fmaf(g1, w1, g0 * w0));
-            const float nl = fmaxf(lam - (v - vt) * ainv, 0.f), dl = nl - lam;
-            if (j == 0) sca[role][3 * r + 2][el] = nl;
+            const float nl = fmaxf(lam[r] - (v - vt) * ainv, 0.f), dl = nl - lam[r];
+            lam[r] = nl;
             w0 = fmaf(g0, dl, w0);
             w1 = fmaf(g1, dl, w1);
         }
     }
     w_out[((size_t)e * ROLES + role) * C + 2 * j] = w0;
     w_out[((size_t)e * ROLES + role) * C + 2 * j + 1] = w1;
-    __syncthreads();
-    for (int r = j; r < R; r += 4) lam_out[((size_t)e * ROLES + role) * R + r] = sca[role][3 * r + 2][el];
+#pragma unroll
+    for (int r = 0; r < R; ++r) if ((r & 3) == j) lam_out[((size_t)e * ROLES + role) * R + r] = lam[r];
+}
+
+// the same sweeps on the host, in double: what both kernels are checked against
+static void pgs_host(const float* rows, const float* w_in, double* w, double* lam, int nsweeps) {
+    for (int c = 0; c < C; ++c) w[c] = w_in[c];
+    for (int r = 0; r < R; ++r) lam[r] = rows[r * ROWF + C + 2];
+    for (int it = 0; it < nsweeps; ++it)
+        for (int r = 0; r < R; ++r) {
+            double v = 0;
+            for (int c = 0; c < C; ++c) v += (double)rows[r * ROWF + c] * w[c];
+            const double nl = fmax(lam[r] - (v - rows[r * ROWF + C + 1]) * rows[r * ROWF + C], 0.0), dl = nl - lam[r];
+            lam[r] = nl;
+            for (int c = 0; c < C; ++c) w[c] += (double)rows[r * ROWF + c] * dl;
+        }
 }
 
 int main() {
@@ -137,7 +157,13 @@ int main() {
     std::vector<float> a(w.size()), b(w.size()), la((size_t)N * ROLES * R), lb((size_t)N * ROLES * R);
     CHECK(hipMemcpy(a.data(), d_wo[0], a.size() * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(b.data(), d_wo[1], b.size() * 4, hipMemcpyDeviceToHost));
     CHECK(hipMemcpy(la.data(), d_lo[0], la.size() * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(lb.data(), d_lo[1], lb.size() * 4, hipMemcpyDeviceToHost));
-    double dw = 0, dl = 0, act = 0;
+    double dw = 0, dl = 0, act = 0, dha = 0, dhb = 0;
+    for (int i = 0; i < N * ROLES; ++i) {            // both against the host's double-precision sweeps (the last launches ran SWEEPS sweeps)
+        double hw[C], hl[R];
+        pgs_host(&rows[(size_t)i * R * ROWF], &w[(size_t)i * C], hw, hl, SWEEPS);
+        for (int c = 0; c < C; ++c) { dha = fmax(dha, fabs(hw[c] - a[(size_t)i * C + c])); dhb = fmax(dhb, fabs(hw[c] - b[(size_t)i * C + c])); }
+        for (int r = 0; r < R; ++r) { dha = fmax(dha, fabs(hl[r] - la[(size_t)i * R + r])); dhb = fmax(dhb, fabs(hl[r] - lb[(size_t)i * R + r])); }
+    }
     for (size_t i = 0; i < a.size(); ++i) dw = fmax(dw, fabs((double)a[i] - b[i]));
     for (size_t i = 0; i < la.size(); ++i) { dl = fmax(dl, fabs((double)la[i] - lb[i])); act += la[i] > 0.f; }
     printf("PGS sweeps of an Ant leg block (%d rows x %d entries, %d sweeps), %d envs, 256 workgroups x 4 waves, incl. the load of the rows into LDS:\n", R, C, SWEEPS, N);
@@ -145,5 +171,6 @@ int main() {
     printf("  (B) four lanes per env, DPP quad reduction  : %.2f us per launch (4 sweeps), %.2f us (36 sweeps) -> %.3f us per sweep\n", us[0][1], us[1][1], (us[1][1] - us[0][1]) / 32.f);
     printf("  A / B: %.2fx per launch at 4 sweeps, %.2fx per sweep\n", us[0][0] / us[0][1], (us[1][0] - us[0][0]) / (us[1][1] - us[0][1]));
     printf("  max |w_A - w_B| = %.2e, max |lambda_A - lambda_B| = %.2e, active rows %.0f %%\n", dw, dl, 100.0 * act / la.size());
-    return (dw < 1e-3 && dl < 1e-3) ? 0 : 1;
+    printf("  against the host's sweeps in double: (A) %.2e, (B) %.2e\n", dha, dhb);
+    return (dw < 1e-4 && dl < 1e-4 && dha < 1e-4 && dhb < 1e-4) ? 0 : 1;
 }
