@@ -281,7 +281,10 @@ int mi_engine_set_terrain(MiEngine* e, const int16_t* height_samples, int rows, 
  * "terrain_slope_threshold" (AnymalTerrain: terrain.slopeTreshold of the reference's height-field -> triangle-mesh conversion,
  * anymal_terrain.py:576; steeper cell edges are levelled to their lower end in the ground query; 0 = off),
  * "terrain_walls" 0 | 1 (AnymalTerrain, default 1: the vertical faces that the slope correction gives the triangle mesh of
- * gym.add_triangle_mesh, anymal_terrain.py:198-211, collide from the side -- csrc/core/engine.hpp HeightfieldGround::contact) */
+ * gym.add_triangle_mesh, anymal_terrain.py:198-211, collide from the side -- csrc/core/engine.hpp HeightfieldGround::contact),
+ * "drive_force_limit" 0 | 1 (ShadowHand / AllegroHand, default 1: the position drives deliver at most the force range of their
+ * actuators -- MJCF forcerange, shared.xml:250-269; the `effort` dof property, allegro_hand.py:264 -- the clamp being solved with the
+ * joint-limit and contact rows, csrc/core/hand_engine.hpp drive_clamp_update; 0 = unlimited drives) */
 int mi_engine_set_option(MiEngine* e, const char* key, double value);
 /* Observation (which = 0) / action (which = 1) noise of the domain randomisation, applied inside the step kernels (replaces the
  * `noise_lambda` closures the reference builds in VecTask.apply_randomizations, vec_task.py:650-718, and runs as torch ops on the

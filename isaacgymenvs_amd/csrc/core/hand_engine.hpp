@@ -38,6 +38,20 @@ constexpr int OBJ_BOX = 0, OBJ_CAPSULE = 1, OBJ_ELLIPSOID = 2;   // objectType "
 constexpr int HS_MASS = 0, HS_DAMPING = 1, HS_STIFFNESS = 2, HS_TENDON_STIFFNESS = 3, HS_TENDON_DAMPING = 4, HS_OBJECT_MASS = 5,
               HS_OBJECT_SCALE = 6, HS_COLUMNS = 8;
 
+// Effort-limited position drive of one dof, one Gauss-Seidel visit (oracle/physics.c drive_clamp_update).  The drive's implicit force at the end
+// of the sub-step is F = fa - c v_d (fa = kp (target - q), c = D + h kp: both already in the factor and the right-hand side); the actuator delivers
+// clamp(F, +-fmax).  What the clamp removes is an impulse rho on the dof with fa - c v_d + rho / h in [-fmax, fmax], rho = 0 inside; for the row's
+// own response a (v_d changes by a per unit impulse) the update is closed-form; while the dof's joint limit holds it (limit impulse > 0) the caller
+// passes a = 0: the limit row absorbs rho, rho = h (clamp(F) - F).  Returns the change of rho.
+MI_HD float drive_clamp_update(const float fa, const float c, const float fmax, const float invh, const float v_d, const float a, float& rho) {
+    const float k = fmaxf(invh - c * a, 0.1f * invh);
+    const float Ff = fa - c * v_d + rho * c * a;
+    const float rn = (Ff > fmax) ? (fmax - Ff) * MI_RCP(k) : ((Ff < -fmax) ? (-fmax - Ff) * MI_RCP(k) : 0.f);
+    const float dr = rn - rho;
+    rho = rn;
+    return dr;
+}
+
 template <class M>
 struct HandSim : Sim<M> {
     using B = Sim<M>;
@@ -48,9 +62,14 @@ struct HandSim : Sim<M> {
 #endif
     static constexpr int KMAX = MI_HAND_KMAX;                // active object contacts kept per env
     Strided limit_shift{nullptr, 1};                         // [2 * ND] per-env shifts of the lower / upper joint limits (required)
+    int drive_clamp = 1;                                     // effort-limited drives on (HandView::drive_clamp)
+    // a dof whose position drive has a force range (MJCF forcerange, shared.xml:250-269; allegro_hand.py:264 effort).  Its clamp rides on
+    // the dof's joint-limit row -- the same whitened vector g = s L^-1 e_d -- so every such dof has one
+    static constexpr bool clamped(int d) { return M::dof_force_limit[d] > 0.f && M::dof_kp[d] > 0.f && M::dof_limited[d]; }
+    static constexpr bool any_clamped() { for (int d = 0; d < ND; ++d) if (clamped(d)) return true; return false; }
     static constexpr int HCH = M::MAXCHAIN;                  // stored row width: the hand chain; the 6 object entries are re-derived
     static constexpr int H_LIMG = B::limoff(NLIM);
-    static constexpr int H_CB = H_LIMG + 3 * NLIM;           // limit G | Ainv, vt, lam | contact slots
+    static constexpr int H_CB = H_LIMG + 4 * NLIM;           // limit G | Ainv, vt, lam, rho (drive clamp impulse) | contact slots
     // one contact slot: 3 rows over the hand chain | normal n (3), lever rc = contact point - object COM (3) | Ainv x3, vt_n, lam x3.
     // The object part of row k, -[u_k; rc x u_k] whitened, follows from (n, rc): 6 floats stored instead of 18.
     static constexpr int H_GEO = 3 * HCH, H_AUX = H_GEO + 6;
@@ -145,6 +164,8 @@ struct HandSim : Sim<M> {
         auto Ainv = [&](int row) MI_LAMBDA -> float& { return rows(H_LIMG + row); };
         auto vt = [&](int row) MI_LAMBDA -> float& { return rows(H_LIMG + NLIM + row); };
         auto lam = [&](int row) MI_LAMBDA -> float& { return rows(H_LIMG + 2 * NLIM + row); };
+        auto rho = [&](int row) MI_LAMBDA -> float& { return rows(H_LIMG + 3 * NLIM + row); };
+        const bool clamp_on = any_clamped() && this->drive_clamp != 0;
         const float invh = MI_RCP(h);
         // `actor_params.hand.dof_properties.lower / upper` (ShadowHand.yaml:118-129): per-env shifts of the joint limits, [ND] lower then
         // [ND] upper, read once where the limit rows are built (the caller always provides them: zeros = the model's limits)
@@ -285,6 +306,7 @@ struct HandSim : Sim<M> {
                 Ainv(row) = MI_RCP(a);
                 vt(row) = (C >= 0.f) ? -C * invh : fminf(-C * P.erp * invh, P.max_depen_vel);
                 lam(row) = l0;
+                if constexpr (clamped(d)) rho(row) = 0.f;
             }
         });
         MI_PHASE();
@@ -400,6 +422,8 @@ struct HandSim : Sim<M> {
         MI_PHASE();
         MI_STAMP(5);
         // ------------------------------------------------------------ projected Gauss-Seidel sweeps
+        float cl_kp = 1.f, cl_damp = 1.f;     // `actor_params` factors of the drive gains, for the drive clamps (re-loaded here)
+        if (clamp_on && this->actor_scale.p != nullptr) { cl_damp = this->actor_scale(HS_DAMPING); cl_kp = this->actor_scale(HS_STIFFNESS); }
         for (int it = 0; it < P.iters; ++it) {
             int zero;
             MI_OPAQUE_ZERO(zero);
@@ -412,6 +436,19 @@ struct HandSim : Sim<M> {
                     sfor<M::nanc[gi] + 1>([&](auto K) MI_LAMBDA { g[K] = rit(g0 + K); });
                     float vn = g[0] * w[gi];
                     sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { vn += g[1 + A_] * w[M::anc[gi][A_]]; });
+                    if constexpr (clamped(d)) {
+                        if (clamp_on) {      // the dof's drive clamp, ahead of its limit row: g = s L^-1 e_d, v_d = s vn
+                            const float kp_ = M::dof_kp[d] * cl_kp, c_ = M::dof_damping[d] * cl_damp + h * kp_;
+                            const float sg = (g[0] > 0.f) ? 1.f : -1.f, a_ = MI_RCP(rit(H_LIMG + row)) - P.cfm;
+                            float r_ = rit(H_LIMG + 3 * NLIM + row);
+                            const float dr = sg * drive_clamp_update(-kp_ * (q[d] - target[d]), c_, M::dof_force_limit[d], invh, sg * vn,
+                                                                     (rit(H_LIMG + 2 * NLIM + row) > 0.f) ? 0.f : a_, r_);
+                            rit(H_LIMG + 3 * NLIM + row) = r_;
+                            w[gi] += g[0] * dr;
+                            sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { w[M::anc[gi][A_]] += g[1 + A_] * dr; });
+                            vn += a_ * dr;           // g . g = a
+                        }
+                    }
                     const float lo = rit(H_LIMG + 2 * NLIM + row);
                     const float nl_ = fmaxf(lo - (vn - rit(H_LIMG + NLIM + row)) * rit(H_LIMG + row), 0.f);
                     const float dl = nl_ - lo;
@@ -505,7 +542,11 @@ struct HandSim : Sim<M> {
                 ll = (G(row, 0) > 0.f) ? lam(row) : -lam(row);
             }
             laml(d) = ll;
-            dof_force(d) = -M::dof_kp[d] * fs_kp * (q[d] - target[d]) - M::dof_damping[d] * fs_damp * v[OFF + d] + ll * invh;
+            float df = -M::dof_kp[d] * fs_kp * (q[d] - target[d]) - M::dof_damping[d] * fs_damp * v[OFF + d] + ll * invh;
+            if constexpr (clamped(d)) {      // a force-limited drive reports the end-of-step force the clamp acts on: fa - c v + rho / h (+- fmax when saturated)
+                if (clamp_on) df += rho(B::limrow(d)) * invh - h * M::dof_kp[d] * fs_kp * v[OFF + d];
+            }
+            dof_force(d) = df;
         });
         float sens[6 * M::NSENSA];
         sfor<6 * NSENS>([&](auto K) MI_LAMBDA { sens[K] = 0.f; });

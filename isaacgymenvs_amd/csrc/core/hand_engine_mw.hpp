@@ -111,7 +111,7 @@ struct HandSimMW : HandSim<M> {
     // ---- own joint-limit rows (registers)
     template <int R> static constexpr int nownl() { int n = 0; for (int d = 0; d < ND; ++d) n += (M::dof_limited[d] && MW::template owns_gi<R>(d)) ? 1 : 0; return n; }
     template <int R> static constexpr int own_lim_idx(int d) { int n = 0; for (int k = 0; k < d; ++k) n += (M::dof_limited[k] && MW::template owns_gi<R>(k)) ? 1 : 0; return n; }
-    struct LimReg { float g[M::MAXCHAIN]; float al, at, vt, lam; };
+    struct LimReg { float g[M::MAXCHAIN]; float al, at, vt, lam, rho; };      // rho: the drive clamp's impulse on the dof (core/hand_engine.hpp drive_clamp_update)
 
     // ------------------------------------------------------------------------------------------------ narrow phase of one body's spheres
     // Spheres in the body's (farthest-point) order; kept: distance below the contact offset, < BODY_CAP on this body, a free slot in the
@@ -391,6 +391,7 @@ struct HandSimMW : HandSim<M> {
         MI_STAMP(3);
         bar();                                                                                       // ---- B1b: region A is dead
         MI_STAMP(4);
+        const bool clamp_on = HB::any_clamped() && this->drive_clamp != 0;
         // ============================================================ P3: own joint-limit rows (registers)
         float dw[NVT > 0 ? NVT : 1];                      // this role's warm-start contribution to the wrist part of w
         sfor<NVT>([&](auto I) MI_LAMBDA { dw[I] = 0.f; });
@@ -433,7 +434,12 @@ struct HandSimMW : HandSim<M> {
                 Rw.al = al; Rw.at = at;
                 Rw.vt = (C >= 0.f) ? -C * invh : fminf(-C * P.erp * invh, P.max_depen_vel);
                 Rw.lam = l0;
+                Rw.rho = 0.f;
                 act = ((l0 > 0.f) || (Rw.vt > 0.f)) ? 1.f : act;
+                if constexpr (HB::clamped(d)) {      // a drive that starts the sub-step beyond its force range makes the block active in the first sweep
+                    const float kp_ = M::dof_kp[d] * sc_kp, c_ = M::dof_damping[d] * sc_damp + h * kp_;
+                    act = (clamp_on && fabsf(-kp_ * (q[d] - target[d]) - c_ * qd[d]) > M::dof_force_limit[d]) ? 1.f : act;
+                }
                 wadd(std::integral_constant<int, gi>{}, g[0] * l0);
                 sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { wadd(std::integral_constant<int, M::anc[gi][A_]>{}, g[1 + A_] * l0); });
             }
@@ -539,6 +545,21 @@ struct HandSimMW : HandSim<M> {
                                 LimReg& Rw = lr[li];
                                 float vn = Rw.g[0] * wget(std::integral_constant<int, gi>{});
                                 sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { vn += Rw.g[1 + A_] * wget(std::integral_constant<int, M::anc[gi][A_]>{}); });
+                                if constexpr (HB::clamped(d)) {
+                                    if (clamp_on) {      // the dof's drive clamp, ahead of its limit row: g = s L^-1 e_d, v_d = s vn
+                                        const float kp_ = M::dof_kp[d] * sc_kp, c_ = M::dof_damping[d] * sc_damp + h * kp_;
+                                        // the closed form takes the dof's TRUE response g . g, not the block's wrist-weighted one: the weighted one
+                                        // (larger) would over-relax this row -- its slope 1 / h - c a shrinks with a, unlike a limit row's -- and the
+                                        // block order then oscillates on the wrist's clamps (oracle/physics.c solve_blocks)
+                                        const float sg = (Rw.g[0] > 0.f) ? 1.f : -1.f, a_true = (Rw.al - P.cfm) + Rw.at, a_loc = (Rw.al - P.cfm) + omW * Rw.at;
+                                        const float dr = sg * drive_clamp_update(-kp_ * (q[d] - target[d]), c_, M::dof_force_limit[d], invh, sg * vn,
+                                                                                 (Rw.lam > 0.f) ? 0.f : a_true, Rw.rho);
+                                        wupd(std::integral_constant<int, gi>{}, Rw.g[0] * dr);
+                                        sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { wupd(std::integral_constant<int, M::anc[gi][A_]>{}, Rw.g[1 + A_] * dr); });
+                                        vn += a_loc * dr;
+                                        actn = (Rw.rho != 0.f) ? 1.f : actn;
+                                    }
+                                }
                                 const float lo = Rw.lam;
                                 const float nl_ = fmaxf(lo - (vn - Rw.vt) * MI_RCP(Rw.al + omW * Rw.at), 0.f);
                                 const float dl = nl_ - lo;
@@ -656,7 +677,11 @@ struct HandSimMW : HandSim<M> {
                     ll = (lr[li].g[0] > 0.f) ? lr[li].lam : -lr[li].lam;
                 }
                 laml(d) = ll;
-                dof_force(d) = -M::dof_kp[d] * sc_kp * (q[d] - target[d]) - M::dof_damping[d] * sc_damp * v[d] + ll * invh;
+                float df = -M::dof_kp[d] * sc_kp * (q[d] - target[d]) - M::dof_damping[d] * sc_damp * v[d] + ll * invh;
+                if constexpr (HB::clamped(d)) {      // a force-limited drive reports the end-of-step force the clamp acts on: fa - c v + rho / h
+                    if (clamp_on) df += lr[own_lim_idx<R>(d)].rho * invh - h * M::dof_kp[d] * sc_kp * v[d];
+                }
+                dof_force(d) = df;
             }
         });
         sfor<NSENS>([&](auto K_) MI_LAMBDA {

@@ -106,6 +106,7 @@ extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const 
     }
     memset(&e->v, 0, sizeof(View));
     memset(&e->qv, 0, sizeof(e->qv)); memset(&e->iv, 0, sizeof(e->iv)); memset(&e->bv, 0, sizeof(e->bv)); memset(&e->hv, 0, sizeof(e->hv));
+    e->hv.drive_clamp = 1;
     Layout L;
     build_layout(t, num_envs, L, &e->v, (char*)arena, nobs);
     build_task_extras(t, num_envs, L, e, (char*)arena);
@@ -139,6 +140,10 @@ extern "C" int mi_engine_set_option(MiEngine* e, const char* key, double value) 
         return 0;
     }
     if (!strcmp(key, "multi_wave") || !strcmp(key, "fused_sub") || !strcmp(key, "fused_post")) return 0;     // GPU launch shapes: nothing to do here
+    if (!strcmp(key, "drive_force_limit")) {
+        if (!is_hand_task(e->task)) return fail("drive_force_limit: a hand-task option");
+        e->hv.drive_clamp = value != 0 ? 1 : 0; return 0;
+    }
     if (!strcmp(key, "terrain_slope_threshold")) {   // terrain.slopeTreshold of the mesh generator (anymal_terrain.py:576); 0 = off
         if (e->task != T_ANYMAL) return fail("terrain_slope_threshold: only AnymalTerrain has a terrain");
         e->terrain.slope_threshold = (float)value;
@@ -180,6 +185,7 @@ extern "C" int mi_engine_get_option(const MiEngine* e, const char* key, double* 
     if (!strcmp(key, "control_freq_inv")) { *out = e->control_freq_inv; return 0; }
     if (!strcmp(key, "self_collision")) { *out = e->v.lamp != nullptr ? 1.0 : 0.0; return 0; }
     if (!strcmp(key, "multi_wave") || !strcmp(key, "fused_sub") || !strcmp(key, "fused_post")) { *out = 0; return 0; }
+    if (!strcmp(key, "drive_force_limit")) { *out = is_hand_task(e->task) ? e->hv.drive_clamp : 0; return 0; }
     if (!strcmp(key, "terrain_slope_threshold")) { *out = e->terrain.slope_threshold; return 0; }
     if (!strcmp(key, "terrain_walls")) { *out = e->terrain.walls; return 0; }
     if (!strcmp(key, "actor_tensors")) { *out = (is_hand_task(e->task) || e->v.actor_scale != nullptr) ? 1.0 : 0.0; return 0; }

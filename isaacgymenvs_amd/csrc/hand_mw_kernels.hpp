@@ -54,6 +54,7 @@ __device__ __forceinline__ void hand_mw_role(const View& v, const HandView& hv, 
     OP.randomise(hv.scale[HS_OBJECT_MASS * N + e], hv.scale[HS_OBJECT_SCALE * N + e]);
     sim.actor_scale = Strided{hv.scale + e, N};
     sim.limit_shift = Strided{hv.limit_shift + e, N};
+    sim.drive_clamp = hv.drive_clamp;
 #if defined(MI_TIMING)
     sim.tstamp = (lane == 0 && g_mi_tstamp_hmw != nullptr) ? g_mi_tstamp_hmw + ((size_t)blockIdx.x * 4 + R) * 16 : nullptr;
 #endif

@@ -342,6 +342,7 @@ MI_HD void hand_substep_env(const View& v, const HandView& hv, const SimParams& 
     OP.randomise(hv.scale[HS_OBJECT_MASS * N + e], hv.scale[HS_OBJECT_SCALE * N + e]);
     sim.actor_scale = Strided{hv.scale + e, N};
     sim.limit_shift = Strided{hv.limit_shift + e, N};
+    sim.drive_clamp = hv.drive_clamp;
 #if defined(MI_TIMING)
     sim.tstamp = tstamp;
 #else

@@ -36,6 +36,7 @@ typedef struct {
     real obj_mass, obj_inertia[3], obj_dims[3], mu;   /* box: dims[0] = half size; capsule: radius, half length; ellipsoid: semi-axes */
     const int32_t *limb_of_body;             /* [nb] (solver 1) */
     const int32_t *limb_cap;                 /* [nlimb] (solver 1) */
+    const real *fmax;                        /* [nd] drive force limits (0: none), or NULL -- physics.c OrDriveClamp */
 } OrHand;
 
 static void h_contact_frame(const real *n, real *t1, real *t2) {       /* oracle/hand.py contact_frame */
@@ -139,9 +140,17 @@ static void hand_substep(const OrModel *m, const OrParams *p, const OrHand *hd, 
     /* ---- rows */
     int nrow = 0, lim_row[MAXD], lim_sign[MAXD];
     real vt[MAXROWS], lam[MAXROWS];
+    /* drive clamps ride on the limit row of their dof (every driven dof of the hands is limited) */
+    static _Thread_local real cl_fmax[MAXROWS], cl_fa[MAXROWS], cl_c[MAXROWS], cl_sgn[MAXROWS], cl_rho[MAXROWS];
+    static _Thread_local int cl_pred[MAXROWS];
     for (int d = 0; d < nd; d++) {
         lim_row[d] = -1;
         if (!m->dof_limited[d]) { laml[d] = 0; continue; }
+        {
+            real fm = (hd->fmax && kp[d] > 0) ? hd->fmax[d] : 0;
+            cl_fmax[nrow] = fm; cl_fa[nrow] = -kp[d] * (q[d] - tgt[d]); cl_c[nrow] = D[d] + h * kp[d]; cl_rho[nrow] = 0;
+            cl_pred[nrow] = fm > 0 && RFABS(cl_fa[nrow] - cl_c[nrow] * qd[d]) > fm;
+        }
         real lo = m->dof_lower[d] < m->dof_upper[d] ? m->dof_lower[d] : m->dof_upper[d], up = m->dof_lower[d] < m->dof_upper[d] ? m->dof_upper[d] : m->dof_lower[d];
         real dl = q[d] - (lo + lshift[d]), du = (up + lshift[nd + d]) - q[d];
         real Cc = dl < du ? dl : du, s = dl < du ? 1 : -1;
@@ -151,9 +160,10 @@ static void hand_substep(const OrModel *m, const OrParams *p, const OrHand *hd, 
         J[nrow][d] = s;
         vt[nrow] = Cc >= 0 ? -Cc / h : (-Cc * p->erp / h < p->max_depen_vel ? -Cc * p->erp / h : p->max_depen_vel);
         lam[nrow] = l0;
-        lim_row[d] = nrow; lim_sign[d] = (int)s;
+        lim_row[d] = nrow; lim_sign[d] = (int)s; cl_sgn[nrow] = s;
         nrow++;
     }
+    const OrDriveClamp clamp = {cl_fmax, cl_fa, cl_c, cl_sgn, cl_pred, cl_rho, h};
     HContact con[HMAXC];
     int ncon = 0, per_body[MAXB], per_limb[16];
     for (int b = 0; b < m->nb; b++) per_body[b] = 0;
@@ -216,7 +226,9 @@ static void hand_substep(const OrModel *m, const OrParams *p, const OrHand *hd, 
         }
         OrModel mm = *m;
         mm.gi_group = grp;
+        g_drive_clamp = hd->fmax ? &clamp : 0;
         solve_blocks(&mm, p, &w, nv, nrow, J, vt, lam, v, nunit, u_row, u_kind, u_blk, u_mu, u_ga, u_gb);
+        g_drive_clamp = 0;
     } else {
         real Ainv[MAXROWS];
         for (int r = 0; r < nrow; r++) {
@@ -230,6 +242,10 @@ static void hand_substep(const OrModel *m, const OrParams *p, const OrHand *hd, 
             for (int d = 0; d < nd; d++) {
                 int r = lim_row[d];
                 if (r < 0) continue;
+                if (hd->fmax && cl_fmax[r] > 0) {          /* the drive clamp of the dof, ahead of its limit row (physics.c OrDriveClamp) */
+                    real dr = drive_clamp_update(&clamp, r, v[d], lam[r] > 0 ? 0 : 1 / Ainv[r] - p->cfm, 0);
+                    if (dr != 0) for (int i = 0; i < nv; i++) v[i] += Bm[r][i] * (cl_sgn[r] * dr);
+                }
                 real vn = 0;
                 for (int i = 0; i < nv; i++) vn += J[r][i] * v[i];
                 real nl = lam[r] - (vn - vt[r]) * Ainv[r];
@@ -272,7 +288,10 @@ static void hand_substep(const OrModel *m, const OrParams *p, const OrHand *hd, 
     for (int d = 0; d < nd; d++) {
         real ll = lim_row[d] >= 0 ? lam[lim_row[d]] * lim_sign[d] : 0;
         laml[d] = ll;
+        /* (with a clamped drive: what the actuator delivers, clamp(F) = F + rho / h, plus the limit force) */
         dof_force[d] = -kp[d] * (q[d] - tgt[d]) - D[d] * v[d] + ll / h;
+        /* a force-limited drive reports what the actuator delivers: the end-of-step force the clamp acts on, fa - c v + rho / h (+- fmax when saturated) */
+        if (hd->fmax && lim_row[d] >= 0 && cl_fmax[lim_row[d]] > 0) dof_force[d] += cl_rho[lim_row[d]] / h - h * kp[d] * v[d];
     }
     for (int k = 0; k < 6 * m->nsens; k++) sensor[k] = 0;
     for (int c = 0; c < ncon; c++) {

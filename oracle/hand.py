@@ -84,7 +84,7 @@ def _hand_struct():
         _fields_ = [(n, C.c_int32) for n in ("nos", "ntend", "kmax", "body_cap", "shape", "solver", "nlimb", "pad")] + \
                    [(n, C.c_void_p) for n in ("os_body", "os_pos", "os_rad", "tend_d0", "tend_d1", "tend_c0", "tend_c1", "tend_lo", "tend_hi")] + \
                    [("tend_stiffness", r), ("tend_damping", r), ("kp", C.c_void_p), ("obj_mass", r), ("obj_inertia", r * 3),
-                    ("obj_dims", r * 3), ("mu", r), ("limb_of_body", C.c_void_p), ("limb_cap", C.c_void_p)]
+                    ("obj_dims", r * 3), ("mu", r), ("limb_of_body", C.c_void_p), ("limb_cap", C.c_void_p), ("fmax", C.c_void_p)]
     return OrHand
 
 
@@ -112,6 +112,9 @@ class OracleHandEngine:
         self.sim = sim
         self.nd = spec.nd
         self.kp = np.array(extras["dof_kp"], float)
+        # drive force limits (MJCF forcerange, shared.xml:250-269; allegro_hand.py:264 effort 0.5): clamp of the implicit PD force, solved with
+        # the rows (physics.c OrDriveClamp).  None: unclamped drives.  Set before the first step.
+        self.force_limit = np.array(extras["dof_force_limit"], float) if "dof_force_limit" in extras else None
         self.os_body = np.array(extras["os_body"]); self.os_pos = np.array(extras["os_pos"], float); self.os_rad = np.array(extras["os_rad"], float)
         self.sens = list(sensor_bodies)
         N, nd = num_envs, self.nd
@@ -183,10 +186,12 @@ class OracleHandEngine:
         k["tend_c0"] = np.ascontiguousarray([t["coef"][0] for t in tends], np.float64); k["tend_c1"] = np.ascontiguousarray([t["coef"][1] for t in tends], np.float64)
         k["tend_lo"] = np.ascontiguousarray([t["range"][0] for t in tends], np.float64); k["tend_hi"] = np.ascontiguousarray([t["range"][1] for t in tends], np.float64)
         k["kp"] = np.ascontiguousarray(self.kp, np.float64)
+        k["fmax"] = None if self.force_limit is None else np.ascontiguousarray(self.force_limit, np.float64)
         hd = OrHand(nos=len(self.os_body), ntend=len(tends), kmax=int(self.kmax), body_cap=BODY_CAP, solver=1 if self.solver == "blocks" else 0)
         for n in ("os_body", "os_pos", "os_rad", "tend_d0", "tend_d1", "tend_c0", "tend_c1", "tend_lo", "tend_hi", "kp"):
             setattr(hd, n, _ptr(k[n]))
         hd.tend_stiffness, hd.tend_damping, hd.mu = float(ex["tendon_limit_stiffness"]), float(ex["tendon_damping"]), 1.0
+        hd.fmax = _ptr(k["fmax"]) if k["fmax"] is not None else None
         if self.objp is None:
             hd.shape, hd.obj_mass = 0, self.cube_mass
             hd.obj_inertia[:] = [self.cube_inertia] * 3; hd.obj_dims[:] = [self.cube_half, 0.0, 0.0]
@@ -268,7 +273,8 @@ class OracleHandEngine:
             l0 = (0.0 if lw * s < 0 else abs(lw)) * P["warm"]
             Jh = np.zeros(nd); Jh[d] = s
             vt = -Cc / h if Cc >= 0 else min(-Cc * P["erp"] / h, P["max_depen_vel"])
-            rows.append(dict(Jh=Jh, Jo=np.zeros(6), vt=vt, lam=l0, kind="lim", d=d, s=s))
+            fm = float(self.force_limit[d]) if (self.force_limit is not None and kp[d] > 0) else 0.0
+            rows.append(dict(Jh=Jh, Jo=np.zeros(6), vt=vt, lam=l0, kind="lim", d=d, s=s, fmax=fm, fa=-kp[d] * (q[d] - tgt[d]), c=D[d] + h * kp[d], rho=0.0))
         bp = self._poses(e)
         O = self.eng.root[e, :3]
         s_state = np.ascontiguousarray(self.eng.state[e])
@@ -317,6 +323,13 @@ class OracleHandEngine:
             while i < len(rows):
                 r = rows[i]
                 if r["kind"] == "lim":
+                    if r["fmax"] > 0:          # the dof's drive clamp, ahead of its limit row (physics.c OrDriveClamp / drive_clamp_update)
+                        a = 0.0 if r["lam"] > 0 else 1.0 / r["Ainv"] - P["cfm"]      # held by its limit: the velocity does not answer to rho
+                        kk = max(1.0 / h - r["c"] * a, 0.1 / h)
+                        Ff = r["fa"] - r["c"] * v[r["d"]] + r["rho"] * r["c"] * a
+                        rn_ = (r["fmax"] - Ff) / kk if Ff > r["fmax"] else ((-r["fmax"] - Ff) / kk if Ff < -r["fmax"] else 0.0)
+                        dr = rn_ - r["rho"]; r["rho"] = rn_
+                        v += r["Bh"] * (r["s"] * dr)
                     vn = r["Jh"] @ v
                     nl_ = max(r["lam"] - (vn - r["vt"]) * r["Ainv"], 0.0)
                     dl = nl_ - r["lam"]; r["lam"] = nl_
@@ -342,12 +355,14 @@ class OracleHandEngine:
                         v += rt["Bh"] * dl; vobj += rt["Bo"] * dl
                     i += 3
         # ---- outputs
-        ll = np.zeros(nd)
+        ll, rho, lim = np.zeros(nd), np.zeros(nd), np.zeros(nd, bool)
         for r in rows:
             if r["kind"] == "lim":
                 ll[r["d"]] = r["lam"] * r["s"]
+                rho[r["d"]] = r["rho"]; lim[r["d"]] = r["fmax"] > 0
         self.laml[e] = ll
-        self.dof_force[e] = -kp * (q - tgt) - D * v + ll / h
+        # (a force-limited drive reports the end-of-step force the clamp acts on, fa - c v + rho / h)
+        self.dof_force[e] = -kp * (q - tgt) - D * v + ll / h + np.where(lim, rho / h - h * kp * v, 0.0)
         sens = np.zeros(6 * len(self.sens))
         for cdat in contacts:
             if cdat["b"] in self.sens:

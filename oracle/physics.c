@@ -498,6 +498,36 @@ static void seg_seg_closest(const real *a0, const real *a1, const real *b0, cons
  * Gauss-Seidel. */
 #define MAXGRP 16
 #define MAXBLK 16
+/* Effort-limited position drives (gym dof property `effort`; MJCF `forcerange`, shared.xml:250-269; allegro_hand.py:264).  The drive's
+ * implicit force on dof d at the end of the sub-step is F = fa - c v_d (fa = kp (target - q), c = D + h kp, both already in M' and the
+ * right-hand side); the actuator delivers clamp(F, +-fmax).  The part the clamp removes is an impulse rho on the dof with
+ *      fa - c v_d + rho / h  in [-fmax, fmax],   rho = 0 inside   (rho <= 0 at the upper bound, >= 0 at the lower),
+ * solved with the other rows: the unit of a dof's joint-limit row first updates rho in closed form for the row's own response a
+ * (g = L^-1 e_d is the limit row's, up to its sign s), then the limit impulse.  While the limit holds the dof (its impulse > 0) the
+ * dof's velocity does not answer to rho -- the limit row absorbs it -- so the update then takes a = 0: rho = h (clamp(F) - F).
+ * (Taken with the free response there, the pair (rho, limit impulse) on one and the same g oscillates with factor x / (1 - x),
+ * x = h c a, and diverges for light joints with stiff drives, x > 1/2.)  In the block order the closed form takes the dof's true
+ * response g . g, not the block's weighted one: the row's slope 1 / h - c a shrinks as a grows, so the larger weighted response
+ * would over-relax it (the wrist's clamps then oscillate between the blocks).  Arrays are indexed by the limit row. */
+typedef struct {
+    const real *fmax, *fa, *c, *sgn;   /* [nrow]: fmax 0 = no clamp on this row; sgn = the limit row's s */
+    const int *pred;                   /* [nrow]: |fa - c qd| > fmax at the start of the sub-step (block activity in the first sweep) */
+    real *rho;                         /* [nrow] in: 0, out: the impulses */
+    real h;
+} OrDriveClamp;
+static _Thread_local const OrDriveClamp *g_drive_clamp = 0;     /* set by the caller around solve_blocks (oracle/hand.c) */
+
+static real drive_clamp_update(const OrDriveClamp *cl, int r, real v_d, real a, real cfm_unused) {
+    (void)cfm_unused;
+    real c = cl->c[r], fm = cl->fmax[r], k = 1 / cl->h - c * a;
+    if (k < (real)0.1 / cl->h) k = (real)0.1 / cl->h;
+    real Ff = cl->fa[r] - c * v_d + cl->rho[r] * c * a;
+    real rn = Ff > fm ? (fm - Ff) / k : (Ff < -fm ? (-fm - Ff) / k : 0);
+    real dr = rn - cl->rho[r];
+    cl->rho[r] = rn;
+    return dr;
+}
+
 static void solve_blocks(const OrModel *m, const OrParams *p, Work *wk, int nv, int nrow, real (*J)[MAXV], const real *vt, real *lam,
                          real *v, int nunit, const int *u_row, const int *u_kind, const int *u_blk, const real *u_mu,
                          const int *u_ga, const int *u_gb) {
@@ -532,6 +562,8 @@ static void solve_blocks(const OrModel *m, const OrParams *p, Work *wk, int nv, 
         for (int u = 0; u < nunit; u++) {
             int r0 = u_row[u];
             if (lam[r0] > 0 || (it == 0 && (u_kind[u] == 1 || vt[r0] > 0))) active[u_blk[u]] = 1;
+            if (g_drive_clamp && u_kind[u] == 0 && g_drive_clamp->fmax[r0] > 0 && (g_drive_clamp->rho[r0] != 0 || (it == 0 && g_drive_clamp->pred[r0])))
+                active[u_blk[u]] = 1;
         }
         for (int g = 0; g < ngrp; g++) {
             int n = 0;
@@ -549,6 +581,14 @@ static void solve_blocks(const OrModel *m, const OrParams *p, Work *wk, int nv, 
                     real a = p->cfm;
                     for (int i = 0; i < nv; i++) a += om[grp[i]] * G[r0 + k][i] * G[r0 + k][i];
                     Ain[k] = 1 / a;
+                }
+                if (g_drive_clamp && u_kind[u] == 0 && g_drive_clamp->fmax[r0] > 0) {   /* the dof's drive clamp, ahead of its limit row */
+                    real vn = 0, sg = g_drive_clamp->sgn[r0];
+                    for (int i = 0; i < nv; i++) vn += G[r0][i] * wloc[i];
+                    real a_true = 0;            /* the dof's true response g . g: NOT the block's weighted one (which over-relaxes this row, see below) */
+                    for (int i = 0; i < nv; i++) a_true += G[r0][i] * G[r0][i];
+                    real dr = drive_clamp_update(g_drive_clamp, r0, sg * vn, lam[r0] > 0 ? 0 : a_true, 0);
+                    if (dr != 0) for (int i = 0; i < nv; i++) wloc[i] += om[grp[i]] * G[r0][i] * (sg * dr);
                 }
                 {   /* limit row / contact normal */
                     real vn = 0;

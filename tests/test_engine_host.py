@@ -233,10 +233,72 @@ def test_host_build_of_finger_per_wave_hand_engine_matches_block_order_oracle(sh
         np.testing.assert_allclose(state[:, 0:nd], orc.q, atol=2e-4)
         np.testing.assert_allclose(state[:, nd:2 * nd], orc.qd, atol=2e-2)
         np.testing.assert_allclose(state[:, 4 * nd:4 * nd + 7], orc.obj[:, 0:7], atol=5e-4)
-        np.testing.assert_allclose(out[:, 6 * ns:6 * ns + nd], orc.dof_force, atol=2e-3 * max(1.0, np.abs(orc.dof_force).max()))
+        # (force-limited drives: the largest joint force is now the wrist's limit force, not an unclamped drive's -- hence the relative part)
+        np.testing.assert_allclose(out[:, 6 * ns:6 * ns + nd], orc.dof_force, atol=2e-3 * max(1.0, np.abs(orc.dof_force).max()), rtol=5e-3)
         np.testing.assert_allclose(out[:, :6 * ns], orc.sensor, atol=2e-3 * max(1.0, np.abs(orc.sensor).max()))
     assert total > 100 and fingers > 30, "scenario must exercise palm and finger contacts"
     assert np.isfinite(state).all()
+
+
+@pytest.mark.parametrize("form", ["one_wave", "finger_per_wave"])
+def test_host_build_of_hand_engine_limits_the_drive_forces(form):
+    """Effort-limited position drives (shared.xml:250-269 forcerange; core/hand_engine.hpp drive_clamp_update) in both forms of the hand
+    engine: every driven dof's target far beyond its force range (kp dq = 2..4 x fmax, both directions), the hand at rest, the cube away.
+    The joint forces the engine reports are +- fmax while a joint moves freely, the motion is the oracle's (oracle/physics.c OrDriveClamp;
+    its closed form is pinned by tests/test_oracle_physics.py::test_hand_drive_force_limit_known_answer), and joints that reach a limit
+    stop there."""
+    import ctypes as C
+    from oracle.hand import OracleHandEngine, CUBE_HALF as half, CUBE_MASS as mass, CUBE_INERTIA as inertia
+    from isaacgymenvs_amd.assets.model import hand_solver_blocks
+    from isaacgymenvs_amd.registry import load_model, load_extras, sensor_bodies
+    lib = hostsim.build_hand()
+    spec, ex = load_model("shadow_hand"), load_extras("shadow_hand")
+    sim = dict(dt=1.0 / 60.0, substeps=2, iters=8, gravity=(0.0, 0.0, -9.81), contact_offset=0.002, rest_offset=0.0,
+               max_depen_vel=1000.0, erp=0.2, plane_mu=1.0, ground_z=0.0, cfm=1e-4, warm=0.9)
+    N, nd = 8, spec.nd
+    rng = np.random.default_rng(2)
+    kw = dict(solver="blocks", blocks=hand_solver_blocks(spec)) if form == "finger_per_wave" else {}
+    orc = OracleHandEngine(spec, ex, N, sim, sensor_bodies("shadow_hand"), **kw)
+    kp, fmax = np.array(ex["dof_kp"], float), np.array(ex["dof_force_limit"], float)
+    driven = kp > 0
+    orc.q[:] = 0.5 * (orc.lo + orc.up); orc.qd[:] = 0.0
+    orc.targets[:] = orc.q
+    orc.targets[:, driven] += rng.choice([-1.0, 1.0], (N, int(driven.sum()))) * rng.uniform(2.0, 4.0, (N, int(driven.sum()))) * (fmax / np.where(driven, kp, 1.0))[driven]
+    orc.obj[:, 0:3] = [0.0, 0.0, 5.0]
+    ss = 4 * nd + 13
+    state = np.zeros((N, ss), np.float32)
+    state[:, 0:nd] = orc.q; state[:, 3 * nd:4 * nd] = orc.targets; state[:, 4 * nd:] = orc.obj
+    root13 = np.zeros(13, np.float32); root13[:7] = orc.eng.root[0, :7]
+    ns = len(orc.sens)
+    out = np.zeros((N, 6 * ns + nd + 1), np.float32)
+    P = hostsim.make_params(sim)
+    dims = np.zeros(3, np.float32)
+    saturated = 0
+    for it in range(6):
+        orc.step()
+        if form == "one_wave":
+            rc = lib.hs_step_hand(C.byref(P), N, state.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), root13.ctypes.data_as(C.c_void_p),
+                                  C.c_float(half), C.c_float(mass), C.c_float(inertia), C.c_float(1.0), None, None)
+        else:
+            rc = lib.hs_step_hand_mw(C.byref(P), N, state.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), root13.ctypes.data_as(C.c_void_p),
+                                     C.c_float(half), C.c_float(mass), C.c_float(inertia), C.c_float(1.0), None, None, 0,
+                                     dims.ctypes.data_as(C.c_void_p), dims.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        np.testing.assert_allclose(state[:, 0:nd], orc.q, atol=5e-4)
+        np.testing.assert_allclose(state[:, nd:2 * nd], orc.qd, atol=5e-2)
+        f = out[:, 6 * ns:6 * ns + nd]
+        np.testing.assert_allclose(f, orc.dof_force, atol=5e-3, rtol=5e-3)
+        # away from the joint limits (no limit force in the sum) the delivered force never exceeds the force range -- it is the range itself until
+        # the joint moves fast enough for the drive's damping to take the force below it -- and points towards the target
+        free = driven[None, :] & (orc.laml == 0.0)
+        fm = np.broadcast_to(fmax, f.shape)
+        assert np.all(np.abs(f[free]) <= fm[free] * (1 + 2e-3))
+        at_range = free & (np.abs(f) >= fm * (1 - 2e-3))
+        saturated += int(at_range.sum())
+        assert np.all(np.sign(f[at_range]) == np.sign((orc.targets - orc.q)[at_range]))
+        assert np.abs(kp * (orc.targets - orc.q))[free].max() > 1.5 * fmax.max() or it > 0       # the unclamped drive would push harder
+    assert saturated > 40
+    assert np.all(state[:, 0:nd] < orc.up + 0.02) and np.all(state[:, 0:nd] > orc.lo - 0.02)
 
 
 def test_host_build_with_position_drives_and_body_forces_matches_oracle():

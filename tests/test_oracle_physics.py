@@ -403,6 +403,65 @@ def test_hand_oracle_in_c_equals_its_numpy_twin(shape):
     assert tot > 100
 
 
+@pytest.mark.parametrize("solver", ["gs", "blocks"])
+def test_hand_drive_force_limit_known_answer(solver):
+    """Effort-limited position drives (shared.xml:250-269 forcerange; allegro_hand.py:264): a finger joint whose target is far away
+    (kp dq = 3x its force range), everything else at its target, hand at rest, nothing in contact.  The actuator then delivers exactly
+    fmax, so the sub-step's velocities solve (M + armature + h (D + h kp) on the OTHER dofs) v = h fmax e_d -- the saturated drive's own
+    implicit terms are cancelled by the clamp impulse.  Inside the force range, and with a limit nobody reaches, nothing changes."""
+    from oracle.hand import OracleHandEngine
+    from isaacgymenvs_amd.assets.model import hand_solver_blocks
+    from isaacgymenvs_amd.registry import load_model, load_extras, sensor_bodies
+    spec, ex = load_model("shadow_hand"), load_extras("shadow_hand")
+    sim = dict(dt=1.0 / 60.0, substeps=1, iters=8, gravity=(0.0, 0.0, -9.81), contact_offset=0.002, rest_offset=0.0,
+               max_depen_vel=1000.0, erp=0.2, plane_mu=1.0, ground_z=0.0, cfm=1e-6, warm=0.9)
+    h, nd = sim["dt"], spec.nd
+    kw = dict(solver="blocks", blocks=hand_solver_blocks(spec)) if solver == "blocks" else {}
+    names = list(spec.dof_names)
+    for jn in ("robot0:FFJ2", "robot0:THJ3", "robot0:WRJ0"):
+        d = names.index(jn)
+        fmax, kp = ex["dof_force_limit"][d], ex["dof_kp"][d]
+        for sign in (1.0, -1.0):
+            o = OracleHandEngine(spec, ex, 1, sim, sensor_bodies("shadow_hand"), backend="c", **kw)
+            o.q[:] = 0.5 * (o.lo + o.up); o.qd[:] = 0.0
+            o.targets[:] = o.q
+            o.targets[0, d] = o.q[0, d] + sign * 3.0 * fmax / kp           # (targets are not clamped to the joint range here)
+            o.obj[:, 0:3] = [0.0, 0.0, 5.0]                                  # the cube far away: no contact
+            M, bias = o.eng.dynamics(0)
+            assert np.abs(bias).max() < 1e-12
+            c = np.array(spec.dof_damping, float) + h * np.array(ex["dof_kp"], float)
+            A = M + np.diag(np.array(spec.dof_armature, float) + h * c)
+            A[d, d] -= h * c[d]
+            for t in ex["tendons"]:                                          # the coupling tendons' damping (inside their range: no stiffness)
+                (d0, d1), (c0, c1) = t["dof"], t["coef"]
+                cv = np.zeros(nd); cv[d0], cv[d1] = c0, c1
+                A += h * float(ex["tendon_damping"]) * np.outer(cv, cv)
+            rhs = np.zeros(nd); rhs[d] = h * sign * fmax
+            v_expect = np.linalg.solve(A, rhs)
+            o.step()
+            np.testing.assert_allclose(o.qd[0], v_expect, atol=1e-9 * max(1.0, np.abs(v_expect).max()), rtol=1e-7)
+            assert abs(o.dof_force[0, d] - sign * fmax) < 1e-9                # what the actuator delivered
+            # unclamped, the same drive pushes harder (not three times: the light finger is already limited by the implicit damping h kp)
+            u = OracleHandEngine(spec, ex, 1, sim, sensor_bodies("shadow_hand"), backend="c", **kw)
+            u.force_limit = None
+            u.q[:] = 0.5 * (u.lo + u.up); u.qd[:] = 0.0; u.targets[:] = o.targets; u.obj[:] = 0.0; u.obj[:, 2] = 5.0; u.obj[:, 6] = 1.0
+            u.step()
+            assert abs(u.qd[0, d]) > 1.05 * abs(o.qd[0, d])
+    # inside the force range the clamp is inert: bit-equal to the unclamped drive
+    rng = np.random.default_rng(0)
+    a = OracleHandEngine(spec, ex, 4, sim, sensor_bodies("shadow_hand"), backend="c", **kw)
+    b = OracleHandEngine(spec, ex, 4, sim, sensor_bodies("shadow_hand"), backend="c", **kw)
+    b.force_limit = None
+    a.q[:] = a.lo + (a.up - a.lo) * rng.uniform(0.3, 0.7, (4, nd))
+    a.targets[:] = a.q + rng.uniform(-0.05, 0.05, (4, nd))
+    b.q[:] = a.q; b.targets[:] = a.targets
+    for x in (a, b):
+        x.obj[:, 0:3] = [0.0, 0.0, 5.0]
+    for _ in range(5):
+        a.step(); b.step()
+    np.testing.assert_array_equal(a.q, b.q)
+
+
 def test_hand_block_order_and_gauss_seidel_order_solve_the_same_problem():
     """The block order of the finger-per-wave kernel (oracle/hand.c solver 1: Gauss-Seidel inside a block, Jacobi with mass splitting on the
     wrist and object coordinates across blocks) and the one Gauss-Seidel sequence solve the same complementarity problem: on states of a
