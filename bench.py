@@ -210,7 +210,7 @@ def roofline(task, num_envs, kernel_ms, mw=0):
            "kernel": "one control step = physics sub-step kernel x sim steps (Ant / AnymalTerrain: ONE launch that loops over them, option "
                      "fused_sub) + post kernel(s) (%s)" % task,
            "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
-           "note": "latency / issue-bound path, not HBM-bound: %s; see DESIGN.md 6" % shape}
+           "note": "latency / issue-bound path, not HBM-bound: %s; see DESIGN.md 5 / 7" % shape}
     if tr.get("valu_wave_insts_per_step"):
         # SURVEY 8(d) asks for the compute side next to the HBM fraction: executed VALU wave-instructions per step against what the
         # chip's 1024 SIMDs can issue (one per 4 cycles each)

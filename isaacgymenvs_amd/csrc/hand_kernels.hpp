@@ -37,7 +37,7 @@ inline hipError_t hand_substeps_shape(const View& v, const HandView& hv, const S
     static unsigned long long configured = 0ull;
     if (hipError_t e = ensure_dynamic_lds((const void*)hand_substep_kernel<HT, SHAPE>, lds, &configured); e != hipSuccess) return e;
     // (Two workgroups fit a CU.  Asking for more than half the LDS while CUs are spare makes no difference -- the dispatcher spreads
-    // the workgroups over the CUs by itself: ShadowHand@8192 0.605 ms either way)
+    // the workgroups over the CUs by itself: ShadowHand@8192 0.605 ms either way, round 2 A/B.)
     for (int i = 0; i < n; ++i)
         hipLaunchKernelGGL((hand_substep_kernel<HT, SHAPE>), dim3((v.N + HS::LANES - 1) / HS::LANES), dim3(HS::LANES), lds, s, v, hv, P, p);
     return hipGetLastError();

@@ -1,8 +1,8 @@
 // shadow_hand.hpp -- ShadowHand task maths for one env (reference isaacgymenvs/tasks/shadow_hand.py).
 //   compute_hand_reward   :746-800 (@torch.jit.script)       randomize_rotation :803-806 (@torch.jit.script)
 //   compute_full_state    :528-584 (the 211-wide "full_state" observation)
-// Only the task functions: the hand + cube physics (fixed tendons, box/capsule contact) is not part of the engine yet
-// (DESIGN.md 8).  Expression order follows the reference (fp32, contraction off).
+// Only the task functions (the hand + object physics is core/hand_engine.hpp / hand_engine_mw.hpp).  Expression order follows the
+// reference (fp32, contraction off).
 #pragma once
 #include "../core/quat.hpp"
 

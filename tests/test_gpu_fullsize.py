@@ -3,7 +3,7 @@ kernels against the fp64 CPU restatement at exactly those env counts -- every la
 bench line exercises -- with contact impulses, joint-limit impulses, force sensors, net contact forces and joint forces asserted
 PER ELEMENT (relative to the largest force present), not only kinematic columns and not only for most rows.
 
-The stated tolerance (DESIGN.md 2): after one control step from the same state |hip - oracle_f64| <= 5e-4 * scale for positions /
+The stated tolerance (DESIGN.md 3): after one control step from the same state |hip - oracle_f64| <= 5e-4 * scale for positions /
 velocities (scale = max(1, fastest joint speed)), <= 2e-3 * (largest force or impulse present) for force-like quantities; contact
 is chaotic afterwards, so later steps are compared with a tolerance that grows linearly with the step count."""
 import numpy as np

@@ -1,6 +1,6 @@
 // GPU microbenchmark (tools/debug): issue rate of ONE wavefront per SIMD running straight-line VALU code once (our sub-step kernels) vs a
 // small loop body that stays in the instruction cache, VOP2 (4-byte) vs VOP3 (8-byte) encodings, and several waves per SIMD.
-// build: hipcc --offload-arch=gfx950 -O3 ifetch_bench.hip -o ifetch_bench     (results: DESIGN.md section 6)
+// build: hipcc --offload-arch=gfx950 -O3 ifetch_bench.hip -o ifetch_bench     (results: DESIGN.md 5, first paragraph; the table is in git history, round 1)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 // straight-line VALU stream executed once: is a lone wave limited by instruction fetch?

@@ -1,5 +1,5 @@
 // GPU microbenchmark (tools/debug): does a lone wave slow down when its straight-line code outgrows the 64 KB instruction cache?
-// (8 KB ... 192 KB of v_fma, executed once per launch, 4 launches each).  Answer on MI355X: no -- see DESIGN.md section 6.
+// (8 KB ... 192 KB of v_fma, executed once per launch, 4 launches each).  Answer on MI355X: no -- see DESIGN.md 5 (round-1 measurement, table in git history).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #define R4(x) x x x x
