@@ -124,3 +124,28 @@ def hull_spheres(V, r_cap=0.015, spacing=1.6, max_count=48, r_min=0.003, fit=0.9
         order.append(k)
         d = np.minimum(d, np.linalg.norm(C - C[k], axis=1))
     return C[order], float(r)
+
+
+def hull_mass_properties(V, density):
+    """Mass, centre of mass and inertia tensor about it of the convex hull of the points V at uniform density (what the simulator derives
+    for a link that has a collision mesh and no <inertial>): signed tetrahedra from the hull's centroid to its faces."""
+    V = np.asarray(V, float)
+    hull = _hull(V)
+    c0 = V[hull.vertices].mean(axis=0)
+    vol, first = 0.0, np.zeros(3)
+    second = np.zeros((3, 3))                 # integral of x x^T over the body, about c0
+    canon = (np.ones((3, 3)) + np.eye(3)) / 120.0
+    for tri in hull.simplices:
+        a, b, c = V[tri] - c0
+        A = np.stack([a, b, c], axis=1)       # columns: the tetrahedron's edge vectors from c0
+        d = abs(float(np.linalg.det(A)))      # 6 x volume; the hull is convex and c0 inside, so every tetrahedron counts positively
+        vol += d / 6.0
+        first += d / 24.0 * (a + b + c)
+        second += d * (A @ canon @ A.T)
+    if vol <= 0.0:
+        return 0.0, c0, np.zeros((3, 3))
+    com_rel = first / vol
+    second_c = second - vol * np.outer(com_rel, com_rel)
+    I = density * (np.trace(second_c) * np.eye(3) - second_c)
+    return density * vol, c0 + com_rel, I
+

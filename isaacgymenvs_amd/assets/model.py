@@ -503,6 +503,7 @@ def parse_urdf(path, default_density=1000.0, replace_cylinder_with_capsule=False
     for ln in root.findall("link"):
         name = ln.get("name")
         geoms = []
+        mesh_hulls = []                  # (vertices in the link frame, density) of the link's collision meshes
         for col in ln.findall("collision"):
             org = col.find("origin")
             pos = _floats(org.get("xyz", "0 0 0"), 3) if org is not None else np.zeros(3)
@@ -530,9 +531,20 @@ def parse_urdf(path, default_density=1000.0, replace_cylinder_with_capsule=False
                 V = V * (_floats(g.get("scale"), 3) if g.get("scale") else 1.0)
                 C, rad = hull_spheres(V, **(mesh_options or {}))
                 R = quat_to_mat(quat)
+                mesh_hulls.append((V @ R.T + pos, default_density))
                 for c in C:      # sphere geoms in the link frame; mass properties never come from them (density 0)
                     geoms.append(_Geom(name, GEOM_SPHERE, pos + R @ c, np.array([0, 0, 0, 1.0]), np.array([rad, 0, 0]), density=0.0))
         inertial = None
+        if mesh_hulls and ln.find("inertial") is None and not any(gm.density > 0 for gm in geoms):
+            # a link described by collision meshes alone (franka_panda_gripper.urdf): mass properties of the meshes' convex hulls at the
+            # asset's density, as the simulator derives them
+            from .mesh import hull_mass_properties
+            parts = [hull_mass_properties(Vh, dens) for Vh, dens in mesh_hulls]
+            mt = sum(pm for pm, _, _ in parts)
+            if mt > 0:
+                ct = sum(pm * pc for pm, pc, _ in parts) / mt
+                It = sum(pI + pm * (np.dot(pc - ct, pc - ct) * np.eye(3) - np.outer(pc - ct, pc - ct)) for pm, pc, pI in parts)
+                inertial = (mt, ct, np.array([0, 0, 0, 1.0]), It)
         iner = ln.find("inertial")
         if iner is not None and iner.find("mass") is not None:
             m = float(iner.find("mass").get("value"))
@@ -625,6 +637,14 @@ def _body_mass_props(b: _Body, density_override=None):
         cs.append(g.pos)
         Is.append(R @ np.diag(d) @ R.T)
     M = sum(ms)
+    if M <= 0.0:
+        # only mass-less geometry (the spheres a collision MESH was sampled by) and an explicit mass without an inertia tensor: a solid
+        # ball of that mass reaching the farthest sphere (franka_panda_gripper.urdf's finger links)
+        if b.inertial is None:
+            return 0.0, np.zeros(3), np.zeros((3, 3))
+        m_exp, ipos = b.inertial[0], np.asarray(b.inertial[1], float)
+        r = max([float(np.linalg.norm(np.asarray(c, float) - ipos)) + float(g.size[0]) for g, c in zip(b.geoms, cs)] + [0.01])
+        return m_exp, ipos, 0.4 * m_exp * r * r * np.eye(3)
     com = sum(m * c for m, c in zip(ms, cs)) / M
     I = np.zeros((3, 3))
     for m, c, Ig in zip(ms, cs, Is):

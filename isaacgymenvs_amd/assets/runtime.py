@@ -101,7 +101,10 @@ def parse_generic(path, options=None):
     if dens is not None and float(dens) != 1000.0:
         kw["density"] = float(dens)
     if path.endswith(".urdf"):           # mesh collision shapes -> spheres inscribed in the meshes' hulls (assets/mesh.py), relative to the URDF's package root
-        kw.update(mesh_spheres=True, mesh_root=os.path.dirname(os.path.dirname(os.path.abspath(path))))
+        # (coarse: at most 4 spheres of up to 5 cm per mesh -- the contact set of a whole robot, not of a manipulated object; the Articulation
+        #  kernels unroll one contact block per sphere)
+        kw.update(mesh_spheres=True, mesh_root=os.path.dirname(os.path.dirname(os.path.abspath(path))),
+                  mesh_options=dict(r_cap=0.05, max_count=4))
     spec = load_asset(path, name=GENERIC_MODEL, **kw)
     if spec.nd > MAX_DOF:
         raise NotImplementedError(f"{path}: {spec.nd} dofs, the engine's parameter blocks hold {MAX_DOF} (MI_MAX_DOF)")

@@ -656,7 +656,8 @@ class Engine:
         check(self.L.mi_engine_refresh_rigid_body_states(self.h, self._stream()), self.L)
 
     def _nv(self):
-        info = task_info(self.task)
+        info = MiTaskInfo()          # from the library the engine lives in: a run-time variant carries its own robot's table
+        check(self.L.mi_task_info(self.task.encode(), C.byref(info)), self.L)
         return info.num_bodies, info.num_dofs + (0 if info.fixed_base else 6)
 
     def compute_jacobians(self, out=None):

@@ -647,6 +647,9 @@ class Gym:
             tp.max_angular_velocity = float(getattr(asset.options, "max_angular_velocity", 0.0) or 0.0)
             for k in range(7):
                 tp.init_root[k] = float(poses[0, k])
+            if getattr(asset.options, "disable_gravity", False):      # franka_cube_stack.py:186: the only articulated actor of the env does not feel gravity
+                for i in range(3):
+                    p.gravity[i] = 0.0
             lib_path = runtime.variant_library(asset.model_name, sp, sim.device, sensors=sens)
             asset.engine_spec = sp
         elif asset.task == "Cartpole":

@@ -235,6 +235,134 @@ def test_new_kinematic_tree_compiles_and_steps_hip():
     _hopper("cuda:0")
 
 
+FRANKA = os.path.join(REF, "assets", "urdf", "franka_description", "robots", "franka_panda_gripper.urdf")
+
+
+def _franka(device):
+    """franka_cube_stack.py's robot (`:189` franka_panda_gripper.urdf: fixed base, 7 arm + 2 finger dofs, collision MESHES and no
+    <inertial> anywhere -- masses from the meshes' convex hulls, contact spheres inscribed in them) loaded as the task loads it (`:180-190`,
+    `:255-275`: gravity off, arm in effort mode, fingers position drives 5000 / 100) and driven by operational-space control computed from
+    gym.acquire_jacobian_tensor / acquire_mass_matrix_tensor (the task's control law, `:601-627`, restated): the end effector converges on
+    its target, the fingers open; one simulate() from the same state follows the oracle."""
+    import isaacgymenvs_amd.shims as shims
+    from isaacgymenvs_amd import native
+    from oracle.engine import OracleEngine
+    if device == "cpu":
+        native.build_cpu()
+    shims.install(force=True)
+    from isaacgym import gymapi
+    gym = gymapi.acquire_gym()
+    sp = gymapi.SimParams()
+    sp.up_axis, sp.gravity, sp.dt, sp.substeps, sp.use_gpu_pipeline = gymapi.UP_AXIS_Z, gymapi.Vec3(0, 0, -9.81), 1 / 60.0, 2, device != "cpu"
+    sp.physx.num_position_iterations, sp.physx.num_velocity_iterations = 8, 1
+    sim = gym.create_sim(0, -1, gymapi.SIM_PHYSX, sp)
+    gym.add_ground(sim, gymapi.PlaneParams())
+    opts = gymapi.AssetOptions()
+    opts.flip_visual_attachments, opts.fix_base_link, opts.collapse_fixed_joints, opts.disable_gravity = True, True, False, True
+    opts.thickness, opts.default_dof_drive_mode, opts.use_mesh_materials = 0.001, gymapi.DOF_MODE_EFFORT, True
+    asset = gym.load_asset(sim, os.path.join(REF, "assets"), "urdf/franka_description/robots/franka_panda_gripper.urdf", opts)
+    assert asset.generic and gym.get_asset_dof_count(asset) == 9
+    names = gym.get_asset_rigid_body_names(asset)
+    assert "panda_hand" in names and "panda_link7" in names and len(names) == gym.get_asset_rigid_body_count(asset)
+    spec = asset.spec
+    assert spec.fixed_base and 15.0 < spec.total_mass() < 25.0           # hull volumes at 1000 kg / m^3 (the real arm: 18 kg)
+    dp = gym.get_asset_dof_properties(asset)
+    assert list(dp["effort"][:7]) == [87.0, 87.0, 87.0, 87.0, 12.0, 12.0, 12.0]
+    dp["driveMode"][:7], dp["stiffness"][:7], dp["damping"][:7] = gymapi.DOF_MODE_EFFORT, 0.0, 0.0
+    dp["driveMode"][7:], dp["stiffness"][7:], dp["damping"][7:] = gymapi.DOF_MODE_POS, 5000.0, 100.0
+    n = 8
+    for i in range(n):
+        env = gym.create_env(sim, gymapi.Vec3(), gymapi.Vec3(), 4)
+        h = gym.create_actor(env, asset, gymapi.Transform(gymapi.Vec3(-0.45, 0.0, 1.0)), "franka", i, 0, 0)
+        gym.set_actor_dof_properties(env, h, dp)
+    gym.prepare_sim(sim)                    # compiles the arm's library once (cached)
+    assert [sim.engine.get_option(k) for k in ("gravity_x", "gravity_y", "gravity_z")] == [0.0, 0.0, 0.0]
+    es = asset.engine_spec
+    dof = gym.acquire_dof_state_tensor(sim).view(n, 9, 2)
+    rb = gym.acquire_rigid_body_state_tensor(sim).view(n, len(names), 13)
+    jac = gym.acquire_jacobian_tensor(sim, "franka")
+    mm = gym.acquire_mass_matrix_tensor(sim, "franka")
+    assert tuple(jac.shape) == (n, spec.nb - 1, 6, 9) and tuple(mm.shape) == (n, 9, 9)
+    q0 = torch.tensor([0.0, 0.1963, 0.0, -2.618, 0.0, 2.9416, 0.7854, 0.035, 0.035], device=sim.device)      # the task's default pose (:75-77)
+    ds = torch.zeros((n, 9, 2), device=sim.device)
+    ds[..., 0] = q0
+    gym.set_dof_state_tensor(sim, ds.view(-1, 2))
+    gym.set_dof_position_target_tensor(sim, q0.repeat(n, 1).view(-1))
+    l7 = names.index("panda_link7")
+    e7 = list(spec.body_names).index("panda_link7")
+    gym.refresh_rigid_body_state_tensor(sim)
+    x0 = rb[:, l7, 0:3].clone()
+    goal = x0 + torch.tensor([0.10, 0.10, -0.10], device=sim.device)
+    kp, kp_null = 150.0, 10.0
+    kd, kd_null = 2.0 * kp ** 0.5, 2.0 * kp_null ** 0.5
+    effort = torch.tensor(np.array(dp["effort"][:7], dtype=np.float32), device=sim.device)
+    lo, up = np.minimum(es.dof_lower, es.dof_upper), np.maximum(es.dof_lower, es.dof_upper)
+    err0 = float((goal - x0).norm(dim=1).max())
+    # ---- one simulate() against the oracle from this state: efforts on the arm, position drives on the fingers, no gravity, no contact
+    prm = dict(dt=1 / 60.0, substeps=2, iters=9, gravity=(0, 0, 0), contact_offset=0.02, rest_offset=0.0, max_depen_vel=100.0, erp=0.5, plane_mu=1.0,
+               ground_z=0.0, cfm=1e-6, warm=1.0)
+    orc = OracleEngine(es, n, params=prm, sensor_bodies=[0], precision="f64")
+    orc.root[:] = sim.engine.tensors["root_states"].cpu().numpy()
+    orc.q[:] = q0.cpu().numpy()
+    tau0 = np.zeros((n, 9)); tau0[:, :7] = np.random.default_rng(1).uniform(-5, 5, (n, 7))
+    tg0 = np.tile(q0.cpu().numpy(), (n, 1)); tg0[:, 7:] = up[7:]
+    kpv, kdv = np.array([0.0] * 7 + [5000.0] * 2), np.array([0.0] * 7 + [100.0] * 2)
+    gym.set_dof_actuation_force_tensor(sim, torch.tensor(tau0, dtype=torch.float32, device=sim.device).view(-1))
+    gym.set_dof_position_target_tensor(sim, torch.tensor(tg0, dtype=torch.float32, device=sim.device).view(-1))
+    gym.simulate(sim)
+    orc.step_drive_v(tau0, kpv, kdv, tg0)
+    gym.refresh_dof_state_tensor(sim)
+    np.testing.assert_allclose(dof[..., 0].cpu().numpy(), orc.q, atol=5e-4)
+    np.testing.assert_allclose(dof[..., 1].cpu().numpy(), orc.qd, atol=5e-2)
+    assert np.abs(orc.netf).max() == 0.0
+    # ---- operational-space control on the engine's Jacobian and mass matrix
+    gym.set_dof_state_tensor(sim, ds.view(-1, 2))
+    errs = []
+    for it in range(150):
+        gym.refresh_dof_state_tensor(sim); gym.refresh_rigid_body_state_tensor(sim)
+        gym.refresh_jacobian_tensors(sim); gym.refresh_mass_matrix_tensors(sim)
+        q, qd = dof[:, :7, 0], dof[:, :7, 1]
+        J = jac[:, e7 - 1, :, :7]                                   # [n, 6, 7]: the fixed base link has no row
+        Mq = mm[:, :7, :7]
+        x, xd = rb[:, l7, 0:3], rb[:, l7, 7:13]
+        np.testing.assert_allclose((J @ qd.unsqueeze(-1)).squeeze(-1).cpu().numpy(), xd.cpu().numpy(), atol=2e-3)     # J qd IS the link's twist
+        dpose = torch.cat([goal - x, torch.zeros((n, 3), device=sim.device)], dim=1)
+        Minv = torch.inverse(Mq)
+        Lam = torch.inverse(J @ Minv @ J.transpose(1, 2))          # task-space inertia
+        u = J.transpose(1, 2) @ Lam @ (kp * dpose - kd * xd).unsqueeze(-1)
+        Jbar = Lam @ J @ Minv
+        u_null = Mq @ (kd_null * -qd + kp_null * (q0[:7] - q)).unsqueeze(-1)
+        u = u + (torch.eye(7, device=sim.device) - J.transpose(1, 2) @ Jbar) @ u_null
+        u = torch.max(torch.min(u.squeeze(-1), effort), -effort)
+        tau = torch.zeros((n, 9), device=sim.device); tau[:, :7] = u
+        tg = q0.repeat(n, 1).clone(); tg[:, 7:] = torch.tensor(up[7:], dtype=torch.float32, device=sim.device)
+        gym.set_dof_actuation_force_tensor(sim, tau.view(-1))
+        gym.set_dof_position_target_tensor(sim, tg.view(-1))
+        gym.simulate(sim)
+        errs.append(float((goal - x).norm(dim=1).max()))
+    gym.refresh_dof_state_tensor(sim); gym.refresh_rigid_body_state_tensor(sim)
+    assert torch.isfinite(dof).all()
+    assert abs(errs[0] - err0) < 1e-3 and errs[-1] < 0.01 and errs[60] < 0.5 * err0, (errs[0], errs[60], errs[-1])
+    assert float((dof[:, 7:, 0] - torch.tensor(up[7:], dtype=torch.float32, device=sim.device)).abs().max()) < 2e-3      # fingers open to their stops
+    Mn = mm.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(Mn, Mn.transpose(0, 2, 1), atol=1e-4)
+    assert np.all(np.linalg.eigvalsh(Mn) > 0)
+    # the welded hand rides on link 7 (collapse_fixed_joints False: gym lists it as a body of its own)
+    hand = names.index("panda_hand")
+    assert float((rb[:, hand, 0:3] - rb[:, l7, 0:3]).norm(dim=1).max()) < 0.2 and float((rb[:, hand, 0:3] - rb[:, l7, 0:3]).norm(dim=1).min()) > 0.05
+
+
+@pytest.mark.skipif(not os.path.isfile(FRANKA), reason="the reference's franka_description is not reachable")
+def test_franka_arm_from_urdf_meshes_runs_osc_cpu():
+    _franka("cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.isfile(FRANKA), reason="the reference's franka_description is not reachable")
+def test_franka_arm_from_urdf_meshes_runs_osc_hip():
+    _franka("cuda:0")
+
+
 @pytest.mark.skipif(not HAVE_REF, reason="reference tree not reachable")
 def test_unmodified_humanoid_amp_task_file_steps():
     """/root/reference/isaacgymenvs/tasks/humanoid_amp.py (with amp/humanoid_amp_base.py, its motion library and poselib) as it is: loads

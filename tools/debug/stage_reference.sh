@@ -19,5 +19,9 @@ mkdir -p $D/tasks/amp/poselib && cp $REF/isaacgymenvs/tasks/amp/*.py $D/tasks/am
 cp -r $REF/isaacgymenvs/tasks/amp/poselib/poselib $D/tasks/amp/poselib/ && cp $REF/isaacgymenvs/tasks/amp/poselib/*.py $D/tasks/amp/poselib/ 2>/dev/null || true
 cp $REF/assets/mjcf/amp_humanoid.xml $ROOT/ab/ref_stage/assets/mjcf/
 mkdir -p $ROOT/ab/ref_stage/assets/amp/motions && cp $REF/assets/amp/motions/amp_humanoid_run.npy $ROOT/ab/ref_stage/assets/amp/motions/
+# tests/test_articulation.py: the Franka arm of franka_cube_stack.py:189 (URDF + its collision meshes)
+mkdir -p $ROOT/ab/ref_stage/assets/urdf/franka_description/robots $ROOT/ab/ref_stage/assets/urdf/franka_description/meshes/collision
+cp $REF/assets/urdf/franka_description/robots/franka_panda_gripper.urdf $ROOT/ab/ref_stage/assets/urdf/franka_description/robots/
+cp $REF/assets/urdf/franka_description/meshes/collision/*.obj $ROOT/ab/ref_stage/assets/urdf/franka_description/meshes/collision/
 find $ROOT/ab/ref_stage -name __pycache__ -type d -prune -exec rm -rf {} +
 echo staged $(find $ROOT/ab/ref_stage -type f | wc -l) files under ab/ref_stage
