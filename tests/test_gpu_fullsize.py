@@ -160,7 +160,12 @@ def test_shadow_hand_first_steps_at_the_benchmark_size(offset, k):
         d = np.abs(obs - o_obs)
         tol = 5e-3 * (1 + step)
         ok = d[:, kin_cols].max(axis=1) < tol
-        assert ok.mean() >= 0.95, (step, ok.mean(), d[:, kin_cols].max())
+        # Why an env ever leaves this band is known (tools/hand_band_leavers.py, profiles/r4e_hand_band_leavers_hip.txt: the same comparison over 24
+        # steps on all 16384 envs): none does in the first six steps (largest difference 8e-5 after three); after 24 steps 0.58 % are outside, and for
+        # 77 % of those the first differing discrete choice is the CONTACT SET (a sphere inside the contact offset in fp32 and outside in fp64, or
+        # the other way round), the rest differ inside a step's first sub-step.  So the first steps are held to (all but a rounding-flip's worth
+        # of) every env, not to a fitted fraction.
+        assert ok.mean() >= 0.999, (step, ok.mean(), d[:, kin_cols].max())
         fmax = max(1.0, np.abs(o_obs[:, force_cols]).max())
         assert d[ok][:, force_cols].max() < 2e-2 * fmax * (1 + step), (step, d[ok][:, force_cols].max(), fmax)
         np.testing.assert_array_equal(env.reset_buf[sl].cpu().numpy()[ok], o_reset[ok])
