@@ -413,7 +413,10 @@ def test_step_trajectory_matches_cpu_restatement(task, hum):
         d[:, [7, 8, 9]] = np.minimum(d[:, [7, 8, 9]], np.abs(d[:, [7, 8, 9]] - 2 * np.pi))
         tol = 2e-3 * (1 + step) * (4 if hum else 1)
         frac_ok = (d.max(axis=1) < tol).mean()
-        assert frac_ok > 0.97, (task, step, frac_ok, d.max())
+        # who leaves this band, and why: tools/loco_band_leavers.py (profiles/r4f_loco_band_leavers_hip.txt: Ant@4096 at most 2 envs = 0.05 %,
+        # Humanoid@8192 at most 6 = 0.07 % over these 12 steps on the HIP kernels; an env leaves when a contact sphere or a joint limit
+        # carries an impulse in fp32 and not in fp64 or the other way round; none on the CPU backend, profiles/r4_loco_band_leavers.txt)
+        assert frac_ok >= 0.99, (task, step, frac_ok, d.max())
         same_reset = (reset.cpu().numpy() == o_reset).mean()
         assert same_reset > 0.98, (task, step, same_reset)
         if step < 3:
