@@ -183,6 +183,10 @@ def measure(task, num_envs, steps, warmup, device, rank, world, seed=42, pool=8,
         res["fused_sub"] = int(env.engine.get_option("fused_sub"))     # all sub-steps of a control step in one launch (Ant, AnymalTerrain)
     except RuntimeError:
         res["fused_sub"] = 0
+    try:
+        res["fused_post"] = int(env.engine.get_option("fused_post"))   # Ant: post_physics_step inside that launch too, spread over the four role waves
+    except RuntimeError:
+        res["fused_post"] = 0
     res["consistent"] = bool(leg_consistent(res))
     if task == "Humanoid":
         res["self_collision"] = int(env.engine.get_option("self_collision"))
@@ -208,7 +212,7 @@ def roofline(task, num_envs, kernel_ms, mw=0):
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
            "traffic": tr.get("traffic_bytes_per_step"), "traffic_source": tr.get("source"),
            "kernel": "one control step = physics sub-step kernel x sim steps (Ant / AnymalTerrain: ONE launch that loops over them, option "
-                     "fused_sub) + post kernel(s) (%s)" % task,
+                     "fused_sub; Ant: post_physics_step on the role waves of the same launch, option fused_post) + post kernel(s) (%s)" % task,
            "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
            "note": "latency / issue-bound path, not HBM-bound: %s; see DESIGN.md 5 / 7" % shape}
     if tr.get("valu_wave_insts_per_step"):
@@ -447,7 +451,7 @@ def main():
         "config": {"workload": f"{args.task} num_envs={n_env} per GPU ({world * n_env} total), VecTask.step() via Python API, "
                                f"actions = 2*torch.rand-1 drawn before every step (README.md:48-51), seed 42+rank",
                    "task": args.task, "num_envs_per_gpu": n_env, "parallelism": f"env-shard x{world}",
-                   "multi_wave": main_res["multi_wave"], "fused_sub": main_res["fused_sub"]},
+                   "multi_wave": main_res["multi_wave"], "fused_sub": main_res["fused_sub"], "fused_post": main_res.get("fused_post", 0)},
         "settle": settle, "consistent": main_res["consistent"],
         "timed_regions": main_res["timed_regions"], "regions_ms_per_step": main_res["regions_ms_per_step"],
         "median_region": main_res["median_region"],

@@ -131,8 +131,103 @@ struct MwFusedArgs {
 };
 template <class M, int E>
 constexpr size_t mw_fused_lds_bytes() { return (size_t)(SimMW<M>::MW_SLOTS + 13) * E * sizeof(float); }
-template <class M, class GND, int E, int R>
-__device__ __forceinline__ void mw_role_fused(const MwFusedArgs<GND>& a, float* lds_rows, const int e, const int lane) {
+// ------------------------------------------------------------------------------------------------ ... and post_physics_step with them, on ALL FOUR waves
+// Options "fused_sub" + "fused_post" (locomotion tasks on the plane): after the last sub-step every role wave does ITS share of post_physics_step
+// on the state it holds in registers -- the in-kernel reset of its own dofs (the draws are a hash of (seed, env, episode, dof): separable), the
+// observation columns of its own dofs / actions / foot sensor, the three reward terms of its own dofs (published through the dead tree-pass
+// exchange area) -- and the trunk role the root part (heading / up projections, atan2), the reward and the flags.  The single-wave form below
+// (substep_mw_post_kernel) put the whole post step behind the one wave every workgroup waits for and only paid where launches dominate; here
+// the dof part runs on the three leg waves while the trunk wave does the quaternion part.  Same helpers and the same partial sums as
+// loco_post_env (part[d & 3], two terms each, whichever role they come from): bit-identical buffers (tests/test_gpu_multi_wave.py).
+template <class GND>
+struct MwFusedPostArgs {
+    MwFusedArgs<GND> f;
+    LocoParams tp;
+};
+template <class M, bool HUM, int E, int R>
+__device__ __forceinline__ void loco_post_role(const View& v, const LocoParams& tp, SimMW<M>& sim, const float (&act)[M::NDA], const int e, float* xpost) {
+    using S = SimMW<M>;
+    using T = Loco<M::ND, 6 * M::NSENS, HUM>;
+    static_assert(!HUM, "the joint-force columns of the Humanoid's observation are not handed over");
+    constexpr int ND = M::ND, NOBS = T::NOBS;
+    const int N = v.N;
+    const uint32_t genv = (uint32_t)(v.env_offset + e);
+    const bool do_reset = v.reset[e] != 0;
+    int ep = v.episode[e];
+    float* ob = v.obs + (size_t)e * NOBS;
+    float* oc = v.obs_out + ((size_t)v.ring * N + e) * NOBS;
+    const float c = v.clip_obs;
+    auto put = [&](const int k, const float x) MI_LAMBDA { ob[k] = x; oc[k] = fminf(fmaxf(x, -c), c); };
+    // ---- own dofs: reset, state write-out, observation columns, reward terms
+    sfor<ND>([&](auto D) MI_LAMBDA {
+        constexpr int d = D;
+        if constexpr (S::template owns_gi<R>(M::OFF + d)) {
+            if (do_reset) {
+                T::reset_dof(tp, v.seed, genv, (uint32_t)ep, d, tp.initial_dof_pos[d], tp.dof_lower[d], tp.dof_upper[d], &sim.q[d], &sim.qd[d]);
+                v.laml[d * N + e] = 0.f;
+            }
+            v.dof[d * N + e] = sim.q[d];
+            v.dof[(ND + d) * N + e] = sim.qd[d];
+            float ps, vs, fs;
+            T::obs_dof(tp, sim.q[d], sim.qd[d], 0.f, tp.dof_lower[d], tp.dof_upper[d], &ps, &vs, &fs);
+            put(T::COL_POS + d, ps);
+            put(T::COL_VEL + d, vs);
+            put(T::COL_ACT + d, act[d]);
+            typename T::DofSums one;
+            T::reward_dof(tp, act[d], ps, vs, tp.gear[d], one);
+            xpost[(3 * d + 0) * E] = one.actions; xpost[(3 * d + 1) * E] = one.electricity; xpost[(3 * d + 2) * E] = one.at_limit;
+        }
+    });
+    // ---- own force sensors (stored by this wave's P5; a load after the own store of the same address sees it)
+    sfor<M::NSENS>([&](auto K_) MI_LAMBDA {
+        constexpr int k = K_;
+        if constexpr (S::template owns_body<R>(M::sens_body[k]))
+            sfor<6>([&](auto J) MI_LAMBDA { put(T::COL_SENS + 6 * k + J, v.sensor[(6 * k + J) * N + e] * tp.contact_force_scale); });
+    });
+    if (do_reset) sfor<3 * M::NSPH>([&](auto K) MI_LAMBDA { if constexpr (S::template owns_body<R>(M::sph_body[K / 3])) v.lamc[K * N + e] = 0.f; });
+    if constexpr (R != M::TRUNK_ROLE) { __syncthreads(); return; }
+    // ---- trunk role: root part, reward, flags
+    long long progress = v.progress[e] + 1;
+    float potentials = v.potentials[e], prev_potentials;
+    if (do_reset) {
+        float init_root[13];
+        sfor<13>([&](auto K) MI_LAMBDA { init_root[K] = v.init_root[K * N + e]; sim.root[K] = init_root[K]; });
+        const float pp = T::reset_potential(tp, init_root);
+        potentials = pp;
+        ep += 1;
+        progress = 0;
+    }
+    sfor<13>([&](auto K) MI_LAMBDA { v.root[K * N + e] = sim.root[K]; });
+    float up_vec[3], heading_vec[3], o12[12];
+    T::obs_root(tp, sim.root, tp.targets, potentials, tp.inv_start_rot, tp.basis_vec0, tp.basis_vec1, o12, &potentials, &prev_potentials, up_vec, heading_vec);
+    sfor<12>([&](auto K) MI_LAMBDA { put(K, o12[K]); });
+    __syncthreads();
+    typename T::DofSums part[4];
+    sfor<ND>([&](auto D) MI_LAMBDA {
+        constexpr int d = D;
+        part[d & 3].actions += xpost[(3 * d + 0) * E]; part[d & 3].electricity += xpost[(3 * d + 1) * E]; part[d & 3].at_limit += xpost[(3 * d + 2) * E];
+    });
+    typename T::DofSums sm;
+    sm.actions = (part[0].actions + part[1].actions) + (part[2].actions + part[3].actions);
+    sm.electricity = (part[0].electricity + part[1].electricity) + (part[2].electricity + part[3].electricity);
+    sm.at_limit = (part[0].at_limit + part[1].at_limit) + (part[2].at_limit + part[3].at_limit);
+    float rew;
+    long long reset;
+    T::reward_total(tp, o12[0], o12[10], o12[11], sm, 0LL, progress, potentials, prev_potentials, &rew, &reset);
+    episode_stats<E, true>(v, e, true, rew, reset, progress);
+    v.randomize[e] += 1;
+    v.episode[e] = ep;
+    v.potentials[e] = potentials;
+    v.prev_potentials[e] = prev_potentials;
+    sfor<3>([&](auto K) MI_LAMBDA { v.up_vec[K * N + e] = up_vec[K]; v.heading_vec[K * N + e] = heading_vec[K]; });
+    v.rew[e] = rew;
+    v.reset[e] = reset;
+    v.progress[e] = progress;
+    v.timeout[e] = (unsigned char)(((float)progress >= tp.max_episode_length - 1.f) && (reset != 0));   // vec_task.py:394
+}
+
+template <class M, class GND, int E, int R, bool POST = false, bool HUM = false>
+__device__ __forceinline__ void mw_role_fused(const MwFusedArgs<GND>& a, float* lds_rows, const int e, const int lane, const LocoParams* tp = nullptr) {
     using S = SimMW<M>;
     constexpr int ND = M::ND;
     const View& v = a.v;
@@ -208,6 +303,11 @@ __device__ __forceinline__ void mw_role_fused(const MwFusedArgs<GND>& a, float* 
             if constexpr (R != M::TRUNK_ROLE) sfor<13>([&](auto K) MI_LAMBDA { sim.root[K] = xroot[K * E]; });
         }
     }
+    if constexpr (POST) {
+        static_assert(3 * M::ND <= 16 * S::NLR, "the reward terms fit the (by now dead) tree-pass exchange area");
+        loco_post_role<M, HUM, E, R>(v, *tp, sim, act, e, lds_rows + (size_t)S::X_LR * E + lane);
+        return;
+    }
     sfor<ND>([&](auto K) MI_LAMBDA {
         if constexpr (S::template owns_gi<R>(M::OFF + K)) {
             v.dof[K * N + e] = sim.q[K];
@@ -215,6 +315,26 @@ __device__ __forceinline__ void mw_role_fused(const MwFusedArgs<GND>& a, float* 
         }
     });
     if constexpr (R == M::TRUNK_ROLE) sfor<13>([&](auto K) MI_LAMBDA { v.root[K * N + e] = sim.root[K]; });
+}
+template <class M, class GND, int E, bool HUM>
+__global__ __launch_bounds__(64 * M::NROLE) void substep_mw_fused_post_kernel(MwFusedPostArgs<GND> args_by_value) {
+    extern __shared__ float lds_rows[];   // [MW_SLOTS + 13][E]
+    static_assert(M::NROLE == 4, "four roles, one per SIMD of a CU");
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)args_by_value;
+    const MwFusedPostArgs<GND>& a = *reinterpret_cast<const MwFusedPostArgs<GND>*>(__builtin_amdgcn_kernarg_segment_ptr());
+    const int lane = threadIdx.x;
+    if (lane >= E) return;
+    const int e = xcd_env_base<E>(blockIdx.x) + lane;
+    if (e >= a.f.v.N) return;
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    switch (role) {
+        case 0: mw_role_fused<M, GND, E, 0, true, HUM>(a.f, lds_rows, e, lane, &a.tp); break;
+        case 1: mw_role_fused<M, GND, E, 1, true, HUM>(a.f, lds_rows, e, lane, &a.tp); break;
+        case 2: mw_role_fused<M, GND, E, 2, true, HUM>(a.f, lds_rows, e, lane, &a.tp); break;
+        default: mw_role_fused<M, GND, E, 3, true, HUM>(a.f, lds_rows, e, lane, &a.tp); break;
+    }
+#endif
 }
 template <class M, class GND, int E>
 __global__ __launch_bounds__(64 * M::NROLE) void substep_mw_fused_kernel(MwFusedArgs<GND> args_by_value) {
@@ -323,6 +443,24 @@ __global__ __launch_bounds__(64 * M::NROLE) void substep_mw_post_kernel(MwPostAr
 template <class M, bool HUM>
 hipError_t launch_substeps_mw_post(const View& v, const SimParams& P, const ActParams& ap, const float* actions, int n_sub, int first, int rest,
                                    hipStream_t s, const LocoParams& tp) {
+    if constexpr (!HUM) {
+        if (v.fused_sub != 0 && n_sub > 1) {        // every sub-step AND the post step in one launch, the post step spread over the four role waves
+            static unsigned long long pconf16 = 0ull, pconf32 = 0ull;
+            constexpr size_t plds16 = mw_fused_lds_bytes<M, 16>(), plds32 = mw_fused_lds_bytes<M, 32>();
+            const MwFusedPostArgs<PlaneGround> pa{MwFusedArgs<PlaneGround>{v, P, ap, actions, first, rest, n_sub, 0, PlaneGround{}}, tp};
+            const dim3 block(64, M::NROLE);
+            if (MI_MW_HAS16 && v.mw == 16) {
+                auto kern = substep_mw_fused_post_kernel<M, PlaneGround, MI_MW_HAS16 ? 16 : 32, HUM>;
+                if (hipError_t e = ensure_dynamic_lds((const void*)kern, plds16, &pconf16); e != hipSuccess) return e;
+                hipLaunchKernelGGL(kern, dim3(xcd_grid<16>(v.N)), block, plds16, s, pa);
+            } else {
+                auto kern = substep_mw_fused_post_kernel<M, PlaneGround, 32, HUM>;
+                if (hipError_t e = ensure_dynamic_lds((const void*)kern, plds32, &pconf32); e != hipSuccess) return e;
+                hipLaunchKernelGGL(kern, dim3(xcd_grid<32>(v.N)), block, plds32, s, pa);
+            }
+            return hipGetLastError();
+        }
+    }
     if (n_sub > 1) {
         if (hipError_t e = launch_substeps_mw<M, PlaneGround>(v, P, ap, actions, n_sub - 1, first, rest, s, PlaneGround{}, 0); e != hipSuccess) return e;
     }

@@ -228,10 +228,11 @@ def select_multi_wave(engine, task, num_envs, mw="auto"):
         except RuntimeError:
             pass
     if task == "Ant":
-        # post_physics_step on one wave of the last limb-per-wave sub-step launch instead of a kernel of its own: +9 % at 1024 envs, a wash at
-        # 4096 (+1 % on a fast box, -5 % on a slow one), +2 % at 8192 (tools/ant_fused_post_ab.py, profiles/r3r_*, r3s_*): on for small batches
+        # post_physics_step inside the step's ONE launch, spread over the four role waves (csrc/mw_kernels.hpp loco_post_role; bit-identical
+        # buffers): Ant@1024 0.0394 -> 0.0351, @4096 0.0394 -> 0.0365, @8192 0.0478 -> 0.0431 ms per step (profiles/r4i_ant_fused_post_ab.txt).
+        # (Round 3's form -- the whole post step on ONE wave of the last sub-step launch -- only paid below 2048 envs, profiles/r3r_*, r3s_*.)
         try:
-            engine.set_option("fused_post", 1 if num_envs <= 2048 else 0)
+            engine.set_option("fused_post", 1)
         except RuntimeError:
             pass
 

@@ -236,16 +236,19 @@ def test_humanoid_helper_wave_rollout_is_bit_identical_from_run_to_run():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [4096, 200])
-def test_ant_post_physics_step_fused_into_the_last_sub_step_is_bit_identical(n):
-    """Ant on the limb-per-wave form: with option fused_post = 1 (what make() picks up to 2048 envs) `post_physics_step` (progress, in-kernel
-    reset, observations, reward) runs on one wave of every sub-step workgroup at the end of the step's last sub-step launch
-    (csrc/mw_kernels.hpp substep_mw_post_kernel) instead of in loco_post_kernel.  Same state in, same arithmetic: observations, rewards, resets
-    and the physics state are bit-identical over a rollout with resets (n = 200: a batch whose last workgroup is partly empty)."""
+@pytest.mark.parametrize("n,fused_sub", [(4096, 1), (200, 1), (8192, 1), (4096, 0), (200, 0)])
+def test_ant_post_physics_step_fused_into_the_last_sub_step_is_bit_identical(n, fused_sub):
+    """Ant on the limb-per-wave form with option fused_post = 1: `post_physics_step` (progress, in-kernel reset, observations, reward) runs inside
+    the step's sub-step launch instead of in loco_post_kernel.  With fused_sub = 1 (make()'s default) the whole control step is ONE launch and
+    the post step is spread over the four role waves -- every leg wave resets / observes / scores its own dofs, the trunk wave does the root part
+    and the reward (csrc/mw_kernels.hpp loco_post_role); with fused_sub = 0 one wave of the last sub-step launch runs all of it
+    (substep_mw_post_kernel).  Same state in, same arithmetic, the same partial sums: observations, rewards, resets and the physics state are
+    bit-identical over a rollout with resets (n = 200: a batch whose last workgroup is partly empty; 8192: 32-env workgroups)."""
     import isaacgymenvs_amd
     a = isaacgymenvs_amd.make(seed=4, task="Ant", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True)
     b = isaacgymenvs_amd.make(seed=4, task="Ant", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True)
-    assert int(a.engine.get_option("multi_wave")) == 16 and int(a.engine.get_option("fused_post")) == (1 if n <= 2048 else 0)
+    assert int(a.engine.get_option("multi_wave")) == (16 if n <= 4096 else 32) and int(a.engine.get_option("fused_sub")) == 1
+    a.engine.set_option("fused_sub", fused_sub); b.engine.set_option("fused_sub", fused_sub)
     a.engine.set_option("fused_post", 1); b.engine.set_option("fused_post", 0)
     g = torch.Generator(device=DEV).manual_seed(0)
     resets = 0
@@ -255,7 +258,8 @@ def test_ant_post_physics_step_fused_into_the_last_sub_step_is_bit_identical(n):
         ob, rb, db, _ = b.step(act)
         assert torch.equal(oa["obs"], ob["obs"]) and torch.equal(ra, rb) and torch.equal(da, db), step
         resets += int(da.sum())
-    for k in ("root_states", "dof_state", "contact_impulse", "limit_impulse", "potentials", "prev_potentials", "progress_buf", "episode_count"):
+    for k in ("root_states", "dof_state", "contact_impulse", "limit_impulse", "potentials", "prev_potentials", "progress_buf", "episode_count", "obs_buf",
+              "rew_buf", "reset_buf", "up_vec", "heading_vec", "randomize_buf", "timeout_buf", "force_sensor", "dof_force", "episode_return"):
         assert torch.equal(a.engine.tensors[k], b.engine.tensors[k]), k
     assert resets > 0
     sa, sb = a.engine.tensors["episode_stats"], b.engine.tensors["episode_stats"]

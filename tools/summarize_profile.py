@@ -137,7 +137,8 @@ if os.path.exists(pf):
 # ---- one control step per task = these launches (pattern, launches per step)
 RECIPE = {
     # (a fused-sub-step kernel, when the trace has one, is the step's ONE physics launch: option fused_sub, csrc/mw_kernels.hpp)
-    "Ant@4096": [(r"substep_mw_fused_kernel<ModelAnt|substep(_mw)?_kernel<ModelAnt", {"fused": 1, "plain": 2}), (r"loco_post_kernel<ModelAnt", 1)],
+    # (round 4: with option fused_post the Ant's launch is substep_mw_fused_post_kernel and there is no post kernel in the trace)
+    "Ant@4096": [(r"substep_mw_fused_post_kernel<ModelAnt|substep_mw_fused_kernel<ModelAnt|substep(_mw)?_kernel<ModelAnt", {"fused": 1, "plain": 2}), (r"loco_post_kernel<ModelAnt", 1)],
     "Humanoid@8192": [(r"substep_(sc2_|mwc_)?kernel<ModelHumanoid", 2), (r"loco_post_kernel<ModelHumanoid", 1)],
     "AnymalTerrain@4096": [(r"substep_mw_fused_kernel<ModelAnymal, mi::HeightfieldGround|substep(_mw)?_kernel<ModelAnymal, mi::HeightfieldGround", {"fused": 1, "plain": 5}),
                            (r"anymal_post_kernel", 1), (r"anymal_heights_kernel", 1),
