@@ -273,7 +273,8 @@ int mi_engine_set_terrain(MiEngine* e, const int16_t* height_samples, int rows, 
  * "multi_wave" 0 | 32 (physics sub-step of Ant / Anymal / AnymalTerrain spread over the four waves of a workgroup of that many
  * envs -- same results up to summation order, see csrc/core/engine_mw.hpp; other tasks ignore it),
  * "fused_post" 0 | 1 (Ant on the limb-per-wave form: post_physics_step inside the step's sub-step launch -- with "fused_sub" the whole
- * control step is then ONE launch, the post step spread over the four role waves, csrc/mw_kernels.hpp loco_post_role; same buffers),
+ * control step is then ONE launch, the post step spread over the four role waves, csrc/mw_kernels.hpp loco_post_role; Humanoid on limb
+ * waves: the step's last sub-step launch carries it on its role waves, csrc/mwc_kernels.hpp; same buffers),
  * "fused_sub" 0 | 1 (Ant / AnymalTerrain on the limb-per-wave form: all physics sub-steps of a control step -- vec_task.py:379-382,
  * anymal_terrain.py:443-451 -- in one launch, the state staying on chip between them; same buffers; HIP backend only),
  * "steps" (the control-step counter: observation-ring parity and per-step RNG counters; restore it together with the arena),

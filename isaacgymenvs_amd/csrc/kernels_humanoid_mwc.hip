@@ -4,6 +4,8 @@
 
 namespace mi {
 template hipError_t launch_substeps_mwc<ModelHumanoid>(const View&, const SimParams&, const ActParams&, const float*, int, int, int, hipStream_t);
+template hipError_t launch_substeps_mwc_post<ModelHumanoid, true>(const View&, const SimParams&, const ActParams&, const float*, int, int, int, hipStream_t,
+                                                                  const LocoParams&);
 }  // namespace mi
 
 #if defined(MI_TIMING)

@@ -144,13 +144,15 @@ struct MwFusedPostArgs {
     MwFusedArgs<GND> f;
     LocoParams tp;
 };
-template <class M, bool HUM, int E, int R>
-__device__ __forceinline__ void loco_post_role(const View& v, const LocoParams& tp, SimMW<M>& sim, const float (&act)[M::NDA], const int e, float* xpost) {
-    using S = SimMW<M>;
+// S: the role's simulator (SimMW<M>; SimMWC<M> for the Humanoid, whose launch is its LAST sub-step's: mwc_kernels.hpp).  act: the clamped actions in
+// the role's registers, or nullptr -- then they are read back from v.actions (stored by the step's first launch).  BAR_FIRST: a barrier before
+// anything is written to xpost (an area some role may still be reading in its output phase).
+template <class S, class M, bool HUM, int E, int R, bool BAR_FIRST = false>
+__device__ __forceinline__ void loco_post_role(const View& v, const LocoParams& tp, S& sim, const float* act, const int e, float* xpost) {
     using T = Loco<M::ND, 6 * M::NSENS, HUM>;
-    static_assert(!HUM, "the joint-force columns of the Humanoid's observation are not handed over");
     constexpr int ND = M::ND, NOBS = T::NOBS;
     const int N = v.N;
+    if constexpr (BAR_FIRST) __syncthreads();
     const uint32_t genv = (uint32_t)(v.env_offset + e);
     const bool do_reset = v.reset[e] != 0;
     int ep = v.episode[e];
@@ -169,12 +171,15 @@ __device__ __forceinline__ void loco_post_role(const View& v, const LocoParams& 
             v.dof[d * N + e] = sim.q[d];
             v.dof[(ND + d) * N + e] = sim.qd[d];
             float ps, vs, fs;
-            T::obs_dof(tp, sim.q[d], sim.qd[d], 0.f, tp.dof_lower[d], tp.dof_upper[d], &ps, &vs, &fs);
+            // (joint forces, like the sensors below: stored by this wave's output phase, read back by the same lane)
+            T::obs_dof(tp, sim.q[d], sim.qd[d], HUM ? v.dof_force[d * N + e] : 0.f, tp.dof_lower[d], tp.dof_upper[d], &ps, &vs, &fs);
+            const float a_d = (act != nullptr) ? act[d] : v.actions[d * N + e];
             put(T::COL_POS + d, ps);
             put(T::COL_VEL + d, vs);
-            put(T::COL_ACT + d, act[d]);
+            if constexpr (HUM) put(T::COL_FORCE + d, fs);
+            put(T::COL_ACT + d, a_d);
             typename T::DofSums one;
-            T::reward_dof(tp, act[d], ps, vs, tp.gear[d], one);
+            T::reward_dof(tp, a_d, ps, vs, tp.gear[d], one);
             xpost[(3 * d + 0) * E] = one.actions; xpost[(3 * d + 1) * E] = one.electricity; xpost[(3 * d + 2) * E] = one.at_limit;
         }
     });
@@ -196,6 +201,7 @@ __device__ __forceinline__ void loco_post_role(const View& v, const LocoParams& 
         potentials = pp;
         ep += 1;
         progress = 0;
+        if constexpr (M::NPG > 0) { if (v.lamp) sfor<3 * M::NPG>([&](auto K) MI_LAMBDA { v.lamp[K * N + e] = 0.f; }); }
     }
     sfor<13>([&](auto K) MI_LAMBDA { v.root[K * N + e] = sim.root[K]; });
     float up_vec[3], heading_vec[3], o12[12];
@@ -305,7 +311,7 @@ __device__ __forceinline__ void mw_role_fused(const MwFusedArgs<GND>& a, float* 
     }
     if constexpr (POST) {
         static_assert(3 * M::ND <= 16 * S::NLR, "the reward terms fit the (by now dead) tree-pass exchange area");
-        loco_post_role<M, HUM, E, R>(v, *tp, sim, act, e, lds_rows + (size_t)S::X_LR * E + lane);
+        loco_post_role<S, M, HUM, E, R>(v, *tp, sim, act, e, lds_rows + (size_t)S::X_LR * E + lane);
         return;
     }
     sfor<ND>([&](auto K) MI_LAMBDA {

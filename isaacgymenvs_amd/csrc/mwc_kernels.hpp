@@ -15,9 +15,9 @@ __device__ unsigned long long* g_mi_tstamp_mwc = nullptr;
 template <class M>
 constexpr size_t mwc_lds_bytes() { return (size_t)SimMWC<M>::MWC_SLOTS * SimMWC<M>::LANES * sizeof(float); }
 
-template <class M, int R>
+template <class M, int R, bool POST = false, bool HUM = true>
 __device__ __forceinline__ void mwc_role(const View& v, const SimParams& P, const ActParams& ap, const float* __restrict__ actions_in,
-                                         const int src, float* lds_rows, const int e, const int lane) {
+                                         const int src, float* lds_rows, const int e, const int lane, const LocoParams* tp = nullptr) {
     using S = SimMWC<M>;
     using MW = SimMW<M>;
     constexpr int ND = M::ND, E = S::LANES;
@@ -60,6 +60,15 @@ __device__ __forceinline__ void mwc_role(const View& v, const SimParams& P, cons
         sim.substep_pair(P, h, RowStore<E>{lds_rows + lane}, scp, DevBarrier{});       // owns no dof: nothing to write back
     } else {
         sim.template substep_role_c<R>(P, tau, h, RowStore<E>{lds_rows + lane}, lamc, laml, sensor, dof_force, mu_env, scp, DevBarrier{});
+    }
+    if constexpr (POST) {
+        // post_physics_step on the role waves of the step's last sub-step launch (mw_kernels.hpp loco_post_role): the f-terms cross through the
+        // self-contact rows' region, dead once every role has left its output phase (hence the barrier first)
+        static_assert(3 * M::ND <= S::KPAIR * S::P_CSZ, "the reward terms fit the self-contact rows' region");
+        // (this launch spills 72 registers where the plain sub-step spills 8 -- a never-taken block between the two parts, Sim::alloc_fence, does not
+        //  change that -- and still wins: the post kernel it replaces cost more)
+        loco_post_role<S, M, HUM, E, R, true>(v, *tp, sim, nullptr, e, lds_rows + (size_t)S::P_B * E + lane);
+        return;
     }
     sfor<ND>([&](auto K) MI_LAMBDA {
         if constexpr (MW::template owns_gi<R>(M::OFF + K)) {
@@ -107,6 +116,50 @@ __global__ __launch_bounds__(64 * M::NROLE) void substep_mwc_kernel(MwcArgs args
         default: mwc_role<M, 3>(a.v, a.P, a.ap, a.actions_in, a.src, lds_rows, e, lane); break;
     }
 #endif
+}
+
+// The step's LAST sub-step with post_physics_step on its role waves (option "fused_post"; mw_kernels.hpp loco_post_role): the leg roles and the
+// trunk + arms role reset / observe / score their own dofs, the trunk role -- the one with slack in this kernel -- does the root part and the reward.
+struct MwcPostArgs {
+    MwcArgs a;
+    LocoParams tp;
+};
+template <class M, bool HUM>
+__global__ __launch_bounds__(64 * M::NROLE) void substep_mwc_post_kernel(MwcPostArgs args_by_value) {
+    extern __shared__ float lds_rows[];   // [MWC_SLOTS][32]
+    static_assert(M::NROLE == 4, "four roles, one per SIMD of a CU");
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)args_by_value;
+    const MwcPostArgs& pa = *reinterpret_cast<const MwcPostArgs*>(__builtin_amdgcn_kernarg_segment_ptr());
+    const MwcArgs& a = pa.a;
+    constexpr int E = SimMWC<M>::LANES;
+    const int lane = threadIdx.x;
+    if (lane >= E) return;
+    const int e = xcd_env_base<E>(blockIdx.x) + lane;
+    if (e >= a.v.N) return;
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    switch (role) {
+        case 0: mwc_role<M, 0, true, HUM>(a.v, a.P, a.ap, a.actions_in, a.src, lds_rows, e, lane, &pa.tp); break;
+        case 1: mwc_role<M, 1, true, HUM>(a.v, a.P, a.ap, a.actions_in, a.src, lds_rows, e, lane, &pa.tp); break;
+        case 2: mwc_role<M, 2, true, HUM>(a.v, a.P, a.ap, a.actions_in, a.src, lds_rows, e, lane, &pa.tp); break;
+        default: mwc_role<M, 3, true, HUM>(a.v, a.P, a.ap, a.actions_in, a.src, lds_rows, e, lane, &pa.tp); break;
+    }
+#endif
+}
+template <class M, bool HUM>
+hipError_t launch_substeps_mwc_post(const View& v, const SimParams& P, const ActParams& ap, const float* actions, int n_sub, int first, int rest,
+                                    hipStream_t s, const LocoParams& tp) {
+    static unsigned long long configured = 0ull, pconfigured = 0ull;
+    constexpr size_t lds = mwc_lds_bytes<M>();
+    constexpr int E = SimMWC<M>::LANES;
+    const dim3 grid(xcd_grid<E>(v.N)), block(64, M::NROLE);
+    auto kern = substep_mwc_kernel<M>;
+    auto pkern = substep_mwc_post_kernel<M, HUM>;
+    if (hipError_t e = ensure_dynamic_lds((const void*)kern, lds, &configured); e != hipSuccess) return e;
+    if (hipError_t e = ensure_dynamic_lds((const void*)pkern, lds, &pconfigured); e != hipSuccess) return e;
+    for (int i = 0; i + 1 < n_sub; ++i) hipLaunchKernelGGL(kern, grid, block, lds, s, MwcArgs{v, P, ap, actions, i == 0 ? first : rest});
+    hipLaunchKernelGGL(pkern, grid, block, lds, s, MwcPostArgs{MwcArgs{v, P, ap, actions, n_sub == 1 ? first : rest}, tp});
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------ all sub-steps of a step in ONE launch

@@ -604,6 +604,13 @@ hipError_t launch_substeps_mw_post(const View& v, const SimParams& P, const ActP
                                    hipStream_t s, const LocoParams& tp);
 template <class M>
 constexpr bool mw_post_capable() { return mw_capable<M, PlaneGround>() && Sim<M>::NPG == 0 && !Sim<M>::COMPACT; }
+// the same for a compact-store robot on limb waves (mwc_kernels.hpp; instantiated in kernels_humanoid_mwc.hip): the LAST sub-step launch of the
+// step carries post_physics_step on its role waves
+template <class M, bool HUM>
+hipError_t launch_substeps_mwc_post(const View& v, const SimParams& P, const ActParams& ap, const float* actions, int n_sub, int first, int rest,
+                                    hipStream_t s, const LocoParams& tp);
+template <class M>
+constexpr bool mwc_post_capable() { return Sim<M>::COMPACT && M::NPG > 0 && !is_scaled<M>::value; }
 
 template <class M, bool HUM>
 hipError_t launch_loco_step(const View& v, const SimParams& P, const LocoParams& tp, const float* actions, int cfi, hipStream_t s) {
@@ -614,6 +621,9 @@ hipError_t launch_loco_step(const View& v, const SimParams& P, const LocoParams&
     if constexpr (mw_post_capable<M>()) {
         // (the fused form exists for the plain kernels only: with randomised actor parameters the two-launch form below runs)
         if (v.mw != 0 && v.fused_post != 0 && v.actor_scale == nullptr && v.limit_shift == nullptr && v.obs_noise.dist == 0 && v.act_noise.dist == 0) return launch_substeps_mw_post<M, HUM>(v, P, ap, actions, cfi * P.substeps, ACT_FROM_ACTIONS, ACT_STORED_TAU, s, tp);
+    }
+    if constexpr (mwc_post_capable<M>()) {
+        if (v.mw != 0 && v.mw != 2 && v.fused_post != 0 && v.actor_scale == nullptr && v.limit_shift == nullptr && v.obs_noise.dist == 0 && v.act_noise.dist == 0) return launch_substeps_mwc_post<M, HUM>(v, P, ap, actions, cfi * P.substeps, ACT_FROM_ACTIONS, ACT_STORED_TAU, s, tp);
     }
     hipError_t e = launch_substeps<M>(v, P, ap, actions, cfi * P.substeps, ACT_FROM_ACTIONS, ACT_STORED_TAU, s);
     if (e != hipSuccess) return e;

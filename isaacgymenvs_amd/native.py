@@ -227,6 +227,13 @@ def select_multi_wave(engine, task, num_envs, mw="auto"):
             engine.set_option("fused_sub", 1)
         except RuntimeError:
             pass
+    if task == "Humanoid":
+        # post_physics_step on the role waves of the step's last sub-step launch (csrc/mwc_kernels.hpp substep_mwc_post_kernel; bit-identical
+        # buffers): Humanoid@8192 0.1805 -> 0.1695, @4096 0.1758 -> 0.1704, @16384 0.3488 -> 0.3405 ms per step (profiles/r4j_humanoid_fused_post_ab.txt)
+        try:
+            engine.set_option("fused_post", 1)
+        except RuntimeError:
+            pass
     if task == "Ant":
         # post_physics_step inside the step's ONE launch, spread over the four role waves (csrc/mw_kernels.hpp loco_post_role; bit-identical
         # buffers): Ant@1024 0.0394 -> 0.0351, @4096 0.0394 -> 0.0365, @8192 0.0478 -> 0.0431 ms per step (profiles/r4i_ant_fused_post_ab.txt).

@@ -267,6 +267,32 @@ def test_ant_post_physics_step_fused_into_the_last_sub_step_is_bit_identical(n, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [8192, 200])
+def test_humanoid_post_physics_step_on_the_role_waves_of_the_last_sub_step_is_bit_identical(n):
+    """Humanoid on limb waves with option fused_post = 1: the step's LAST sub-step launch (csrc/mwc_kernels.hpp substep_mwc_post_kernel) carries
+    post_physics_step on its role waves -- legs and trunk + arms reset / observe / score their own dofs (joint-force and sensor columns read back
+    from what the same lane just stored), the trunk role does the root part, the reward and the flags -- instead of loco_post_kernel.  Observations
+    (all 108 columns), rewards, resets and the physics state incl. the self-contact impulses are bit-identical over a rollout with resets."""
+    import isaacgymenvs_amd
+    a = isaacgymenvs_amd.make(seed=4, task="Humanoid", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True)
+    b = isaacgymenvs_amd.make(seed=4, task="Humanoid", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True)
+    assert int(a.engine.get_option("multi_wave")) == 32 and int(a.engine.get_option("self_collision")) == 1
+    a.engine.set_option("fused_post", 1); b.engine.set_option("fused_post", 0)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    resets = 0
+    for step in range(100):
+        act = torch.rand((n, 21), device=DEV, generator=g) * 2 - 1
+        oa, ra, da, _ = a.step(act)
+        ob, rb, db, _ = b.step(act)
+        assert torch.equal(oa["obs"], ob["obs"]) and torch.equal(ra, rb) and torch.equal(da, db), step
+        resets += int(da.sum())
+    for k in ("root_states", "dof_state", "contact_impulse", "limit_impulse", "self_contact_impulse", "potentials", "prev_potentials", "progress_buf",
+              "episode_count", "obs_buf", "rew_buf", "reset_buf", "up_vec", "heading_vec", "randomize_buf", "timeout_buf", "force_sensor", "dof_force", "episode_return"):
+        assert torch.equal(a.engine.tensors[k], b.engine.tensors[k]), k
+    assert resets > 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("task,n,na,cfi", [("Ant", 4096, 8, 1), ("Ant", 200, 8, 1), ("AnymalTerrain", 1024, 12, 1), ("AnymalTerrain", 200, 12, 1),
                                            ("Ant", 328, 8, 3), ("AnymalTerrain", 328, 12, 2), ("AnymalTerrain", 9000, 12, 1)])
 def test_all_sub_steps_of_a_control_step_in_one_launch_are_bit_identical(task, n, na, cfi):

@@ -139,7 +139,8 @@ RECIPE = {
     # (a fused-sub-step kernel, when the trace has one, is the step's ONE physics launch: option fused_sub, csrc/mw_kernels.hpp)
     # (round 4: with option fused_post the Ant's launch is substep_mw_fused_post_kernel and there is no post kernel in the trace)
     "Ant@4096": [(r"substep_mw_fused_post_kernel<ModelAnt|substep_mw_fused_kernel<ModelAnt|substep(_mw)?_kernel<ModelAnt", {"fused": 1, "plain": 2}), (r"loco_post_kernel<ModelAnt", 1)],
-    "Humanoid@8192": [(r"substep_(sc2_|mwc_)?kernel<ModelHumanoid", 2), (r"loco_post_kernel<ModelHumanoid", 1)],
+    # (round 4, Humanoid with fused_post: one plain limb-wave launch + one that carries the post step; no post kernel in the trace)
+    "Humanoid@8192": [(r"substep_mwc_post_kernel<ModelHumanoid", 1), (r"substep_(sc2_|mwc_)?kernel<ModelHumanoid", {"plain": 2, "with_post": 1}), (r"loco_post_kernel<ModelHumanoid", 1)],
     "AnymalTerrain@4096": [(r"substep_mw_fused_kernel<ModelAnymal, mi::HeightfieldGround|substep(_mw)?_kernel<ModelAnymal, mi::HeightfieldGround", {"fused": 1, "plain": 5}),
                            (r"anymal_post_kernel", 1), (r"anymal_heights_kernel", 1),
                            (r"anymal_cmdnorm_kernel", 1)],
@@ -157,7 +158,10 @@ for task, recipe in RECIPE.items():
         for k in keys:
             if re.search(pat, k):
                 if isinstance(cnt, dict):
-                    cnt = cnt["fused" if "fused" in k else "plain"]
+                    if "with_post" in cnt:
+                        cnt = cnt["with_post" if any("substep_mwc_post_kernel" in x for x in traffic) else "plain"]
+                    else:
+                        cnt = cnt["fused" if "fused" in k else "plain"]
                 tot_b += cnt * traffic[k]["bytes"]; tot_v += cnt * valu.get(k, 0.0); tot_t += cnt * dur_ns.get(k, 0.0) / 1e3
                 tot_f += cnt * flops.get(k, 0.0)
                 if cnt * dur_ns.get(k, 0.0) > dom[0]:
