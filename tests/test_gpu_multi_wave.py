@@ -236,8 +236,8 @@ def test_humanoid_helper_wave_rollout_is_bit_identical_from_run_to_run():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,fused_sub", [(4096, 1), (200, 1), (8192, 1), (4096, 0), (200, 0)])
-def test_ant_post_physics_step_fused_into_the_last_sub_step_is_bit_identical(n, fused_sub):
+@pytest.mark.parametrize("n,fused_sub,cfi", [(4096, 1, 1), (200, 1, 1), (8192, 1, 1), (4096, 0, 1), (200, 0, 1), (328, 1, 3), (328, 0, 2)])
+def test_ant_post_physics_step_fused_into_the_last_sub_step_is_bit_identical(n, fused_sub, cfi):
     """Ant on the limb-per-wave form with option fused_post = 1: `post_physics_step` (progress, in-kernel reset, observations, reward) runs inside
     the step's sub-step launch instead of in loco_post_kernel.  With fused_sub = 1 (make()'s default) the whole control step is ONE launch and
     the post step is spread over the four role waves -- every leg wave resets / observes / scores its own dofs, the trunk wave does the root part
@@ -250,9 +250,11 @@ def test_ant_post_physics_step_fused_into_the_last_sub_step_is_bit_identical(n, 
     assert int(a.engine.get_option("multi_wave")) == (16 if n <= 4096 else 32) and int(a.engine.get_option("fused_sub")) == 1
     a.engine.set_option("fused_sub", fused_sub); b.engine.set_option("fused_sub", fused_sub)
     a.engine.set_option("fused_post", 1); b.engine.set_option("fused_post", 0)
+    if cfi != 1:        # env.controlFrequencyInv > 1: 2 cfi sub-steps per control step, the later ones on the held efforts
+        a.engine.set_option("control_freq_inv", cfi); b.engine.set_option("control_freq_inv", cfi)
     g = torch.Generator(device=DEV).manual_seed(0)
     resets = 0
-    for step in range(120):
+    for step in range(120 if cfi == 1 else 70):
         act = torch.rand((n, 8), device=DEV, generator=g) * 2 - 1
         oa, ra, da, _ = a.step(act)
         ob, rb, db, _ = b.step(act)
@@ -267,8 +269,8 @@ def test_ant_post_physics_step_fused_into_the_last_sub_step_is_bit_identical(n, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [8192, 200])
-def test_humanoid_post_physics_step_on_the_role_waves_of_the_last_sub_step_is_bit_identical(n):
+@pytest.mark.parametrize("n,cfi", [(8192, 1), (200, 1), (328, 2)])
+def test_humanoid_post_physics_step_on_the_role_waves_of_the_last_sub_step_is_bit_identical(n, cfi):
     """Humanoid on limb waves with option fused_post = 1: the step's LAST sub-step launch (csrc/mwc_kernels.hpp substep_mwc_post_kernel) carries
     post_physics_step on its role waves -- legs and trunk + arms reset / observe / score their own dofs (joint-force and sensor columns read back
     from what the same lane just stored), the trunk role does the root part, the reward and the flags -- instead of loco_post_kernel.  Observations
@@ -278,9 +280,11 @@ def test_humanoid_post_physics_step_on_the_role_waves_of_the_last_sub_step_is_bi
     b = isaacgymenvs_amd.make(seed=4, task="Humanoid", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True)
     assert int(a.engine.get_option("multi_wave")) == 32 and int(a.engine.get_option("self_collision")) == 1
     a.engine.set_option("fused_post", 1); b.engine.set_option("fused_post", 0)
+    if cfi != 1:
+        a.engine.set_option("control_freq_inv", cfi); b.engine.set_option("control_freq_inv", cfi)
     g = torch.Generator(device=DEV).manual_seed(0)
     resets = 0
-    for step in range(100):
+    for step in range(100 if cfi == 1 else 60):
         act = torch.rand((n, 21), device=DEV, generator=g) * 2 - 1
         oa, ra, da, _ = a.step(act)
         ob, rb, db, _ = b.step(act)
