@@ -228,6 +228,8 @@ def test_hot_kernels_stay_inside_their_register_budgets():
         "hand_substep_kernelINS_15AllegroHandTaskELi0E": 0,   # 0 (16 dofs, chains of 4: the one-wave form fits its registers; 832 B scratch = the body poses handed to the narrow phase)
         "substep_sc2_kernelI13ModelHumanoid": 280,       # 235
         "substep_mwc_kernelI13ModelHumanoid": 90,        # 60, scratch 152 B / lane (round 3: one limb per wave; 154 / 312 B while the `actor_params` code was still in this kernel, 220 / 488 B without the allocation fence)
+        "substep_mwc_post_kernelI13ModelHumanoid": 100,  # 72, scratch 288 B / lane (round 4: the step's last sub-step launch with post_physics_step on its role waves)
+        "substep_mw_fused_post_kernelI8ModelAnt": 0,     # 0   (round 4: the Ant's whole control step in one launch)
         "substep_kernelI13ModelHumanoid": 370,           # 312
         "substep_mw_kernelI8ModelAnt": 0,                # 0
         "substep_mw_kernelI11ModelAnymal": 0,            # 0
