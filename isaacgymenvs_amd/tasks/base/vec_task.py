@@ -197,6 +197,8 @@ class VecTask(Env):
         self.progress_buf = t["progress_buf"]
         self.randomize_buf = t["randomize_buf"]
         self._obs_out = t["obs_out"]
+        self._obs_ring = (self._obs_out[0], self._obs_out[1])       # the two slots of the clamped-observation ring, as views made once
+        self._rl_is_sim = torch.device(self.rl_device) == self.obs_buf.device      # then the `.to(rl_device)` of every output is the tensor itself
         self.extras = {}
 
     def get_state(self):
@@ -218,11 +220,17 @@ class VecTask(Env):
         # one fused launch: clamp -> pre_physics_step -> simulate x control_freq_inv -> post_physics_step -> timeouts
         self.engine.step(actions)
         self.control_steps += 1
-        obs = self._obs_out[self.engine.last_ring()]
+        obs = self._obs_ring[self.engine.last_ring()]
         if "observations" in self._torch_noise:
             self.obs_buf[:] = self._torch_noise["observations"](self.obs_buf)
             obs = torch.clamp(self.obs_buf, -self.clip_obs, self.clip_obs)
         self._post_step_extras()
+        if self._rl_is_sim:          # (vec_task.py:402-408 moves every output to rl_device: the same device here, so the tensors themselves)
+            self.extras["time_outs"] = self.timeout_buf
+            self.obs_dict["obs"] = obs
+            if self.num_states > 0:
+                self.obs_dict["states"] = self.get_state()
+            return self.obs_dict, self.rew_buf, self.reset_buf, self.extras
         self.extras["time_outs"] = self.timeout_buf.to(self.rl_device)
         self.obs_dict["obs"] = obs.to(self.rl_device)
         if self.num_states > 0:
