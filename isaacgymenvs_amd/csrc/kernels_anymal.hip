@@ -116,11 +116,15 @@ hipError_t launch_step_anymal(const View& v, const SimParams& P, const AnymalPar
                               const float* actions, int cfi, unsigned step_counter, hipStream_t s) {
     const ActParams ap = act_of(tp);
     hipError_t e;
+    bool cmdnorm_in_launch = false;
     if (T.hs != nullptr) {
         if (v.mw != 0) {    // limb-per-wave form: one call (with option fused_sub: one LAUNCH) for the decimation steps + the base class's simulate()
+            // (with the fused launch the curriculum pre-pass -- anymal_cmdnorm_env -- runs on the trunk wave at its end: one kernel less)
+            cmdnorm_in_launch = tp.curriculum && v.fused_sub != 0 && (tp.decimation + cfi) * P.substeps > 1;
+            const MwCmdNormTail cn{tp.allow_knee_contacts ? 1 : 0, (float)tp.max_episode_length};
             e = launch_substeps_mw<ModelAnymal, HeightfieldGround>(v, P, ap, actions, (tp.decimation + cfi) * P.substeps,
                                                                    prepare_actions(v, ap, actions, ACT_FROM_ACTIONS, s), ACT_FROM_STORED_ACTIONS, s,
-                                                                   ground_of(T), cfi * P.substeps);
+                                                                   ground_of(T), cfi * P.substeps, cmdnorm_in_launch ? &cn : nullptr);
         } else {
             e = launch_substeps<ModelAnymal, HeightfieldGround>(v, P, ap, actions, tp.decimation * P.substeps, ACT_FROM_ACTIONS,
                                                                 ACT_FROM_STORED_ACTIONS, s, ground_of(T));
@@ -132,7 +136,7 @@ hipError_t launch_step_anymal(const View& v, const SimParams& P, const AnymalPar
         return hipErrorInvalidValue;  // mi_engine_step refuses to run AnymalTerrain before mi_engine_set_terrain
     }
     if (e != hipSuccess) return e;
-    if (tp.curriculum) hipLaunchKernelGGL(anymal_cmdnorm_kernel, dim3((v.N + 63) / 64), dim3(64), 0, s, v, tp);
+    if (tp.curriculum && !cmdnorm_in_launch) hipLaunchKernelGGL(anymal_cmdnorm_kernel, dim3((v.N + 63) / 64), dim3(64), 0, s, v, tp);
     hipLaunchKernelGGL(anymal_post_kernel, dim3((v.N + 63) / 64), dim3(64), 0, s, v, tp, T, step_counter);
     hipLaunchKernelGGL(anymal_heights_kernel, dim3((v.N * kAnymalHeightPts + 255) / 256), dim3(256), 0, s, v, tp, T, step_counter);
     return hipGetLastError();

@@ -4,7 +4,7 @@
 
 namespace mi {
 template hipError_t launch_substeps_mw<ModelAnt, PlaneGround>(const View&, const SimParams&, const ActParams&, const float*, int, int, int, hipStream_t,
-                                                              const PlaneGround&, int);
+                                                              const PlaneGround&, int, const MwCmdNormTail*);
 template hipError_t launch_substeps_mw_post<ModelAnt, false>(const View&, const SimParams&, const ActParams&, const float*, int, int, int, hipStream_t,
                                                             const LocoParams&);
 }  // namespace mi

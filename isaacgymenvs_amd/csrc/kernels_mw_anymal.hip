@@ -4,8 +4,8 @@
 
 namespace mi {
 template hipError_t launch_substeps_mw<ModelAnymal, HeightfieldGround>(const View&, const SimParams&, const ActParams&, const float*, int, int, int,
-                                                                       hipStream_t, const HeightfieldGround&, int);
+                                                                       hipStream_t, const HeightfieldGround&, int, const MwCmdNormTail*);
 // flat ground, net contact forces reported: the Anymal task (anymal.py)
 template hipError_t launch_substeps_mw<ModelAnymal, PlaneGroundNF>(const View&, const SimParams&, const ActParams&, const float*, int, int, int,
-                                                                   hipStream_t, const PlaneGroundNF&, int);
+                                                                   hipStream_t, const PlaneGroundNF&, int, const MwCmdNormTail*);
 }  // namespace mi

@@ -7,5 +7,5 @@ namespace mi {
 template hipError_t launch_substeps_scaled<ModelAnt, PlaneGround>(const View&, const SimParams&, const ActParams&, const float*, int, int, int, hipStream_t,
                                                                   const PlaneGround&);
 template hipError_t launch_substeps_mw<Scaled<ModelAnt>, PlaneGround>(const View&, const SimParams&, const ActParams&, const float*, int, int, int,
-                                                                      hipStream_t, const PlaneGround&, int);
+                                                                      hipStream_t, const PlaneGround&, int, const MwCmdNormTail*);
 }  // namespace mi

@@ -3,6 +3,7 @@
 #pragma once
 #include "step_kernels.hpp"
 #include "core/engine_mw.hpp"
+#include "tasks/anymal_step.hpp"      // anymal_netf_norm, anymal_knee_body: the AnymalTerrain launch's curriculum tail (mw_role_fused)
 
 namespace mi {
 
@@ -128,6 +129,10 @@ struct MwFusedArgs {
     const float* actions_in;
     int first, rest, n_sub, tail;
     GND gnd;
+    // AnymalTerrain (height-field ground) only: the curriculum pre-pass of its post step -- sum of cx^2 + cy^2 over the envs that will reset this
+    // step (tasks/anymal_step.hpp anymal_cmdnorm_env) -- evaluated by the trunk wave at the end of this launch instead of by a kernel of its own
+    int cmdnorm = 0, cmdnorm_allow_knee = 0;
+    float cmdnorm_max_len = 0.f;
 };
 template <class M, int E>
 constexpr size_t mw_fused_lds_bytes() { return (size_t)(SimMW<M>::MW_SLOTS + 13) * E * sizeof(float); }
@@ -309,6 +314,21 @@ __device__ __forceinline__ void mw_role_fused(const MwFusedArgs<GND>& a, float* 
             if constexpr (R != M::TRUNK_ROLE) sfor<13>([&](auto K) MI_LAMBDA { sim.root[K] = xroot[K * E]; });
         }
     }
+    if constexpr (GND::HEIGHTFIELD && !POST) {
+        if (a.cmdnorm != 0) {                  // (uniform) every role's net contact forces of the last sub-step are in memory behind this barrier
+            __syncthreads();
+            if constexpr (R == M::TRUNK_ROLE) {
+                bool rs = anymal_netf_norm(v, e, 0) > 1.f;
+                if (a.cmdnorm_allow_knee == 0)
+                    for (int k = 0; k < 4; ++k) rs = rs || (anymal_netf_norm(v, e, anymal_knee_body(k)) > 1.f);
+                if (v.progress[e] + 1 >= (long long)a.cmdnorm_max_len - 1) rs = true;
+                float acc = 0.f;
+                if (rs) { const float cx = v.commands[e], cy = v.commands[N + e]; acc = cx * cx + cy * cy; }
+                acc = wave_sum_live<E>(acc);
+                if ((threadIdx.x & 63) == 0 && acc > 0.f) atomicAdd(v.ep_stats + 15, acc);
+            }
+        }
+    }
     if constexpr (POST) {
         static_assert(3 * M::ND <= 16 * S::NLR, "the reward terms fit the (by now dead) tree-pass exchange area");
         loco_post_role<S, M, HUM, E, R>(v, *tp, sim, act, e, lds_rows + (size_t)S::X_LR * E + lane);
@@ -365,12 +385,13 @@ __global__ __launch_bounds__(64 * M::NROLE) void substep_mw_fused_kernel(MwFused
 
 template <class M, class GND>
 hipError_t launch_substeps_mw(const View& v, const SimParams& P, const ActParams& ap, const float* actions, int n_sub, int first, int rest,
-                              hipStream_t s, const GND& gnd, int tail) {
+                              hipStream_t s, const GND& gnd, int tail, const MwCmdNormTail* cn) {
     const dim3 block(64, M::NROLE);
     if (v.fused_sub != 0 && n_sub > 1) {
         static unsigned long long fconf16 = 0ull, fconf32 = 0ull;
         constexpr size_t flds16 = mw_fused_lds_bytes<M, 16>(), flds32 = mw_fused_lds_bytes<M, 32>();
-        const MwFusedArgs<GND> fa{v, P, ap, actions, first, rest, n_sub, tail, gnd};
+        MwFusedArgs<GND> fa{v, P, ap, actions, first, rest, n_sub, tail, gnd};
+        if (cn != nullptr) { fa.cmdnorm = 1; fa.cmdnorm_allow_knee = cn->allow_knee_contacts; fa.cmdnorm_max_len = cn->max_episode_length; }
         if (MI_MW_HAS16 && v.mw == 16) {
             auto kern = substep_mw_fused_kernel<M, GND, MI_MW_HAS16 ? 16 : 32>;
             if (hipError_t e = ensure_dynamic_lds((const void*)kern, flds16, &fconf16); e != hipSuccess) return e;

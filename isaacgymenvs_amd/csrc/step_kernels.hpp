@@ -284,9 +284,11 @@ hipError_t launch_substeps_mwc(const View& v, const SimParams& P, const ActParam
                                hipStream_t s);
 // launches n_sub multi-wave sub-steps with v.mw envs per workgroup (defined for the model / ground pairs of kernels_mw_*.hip); the last
 // `tail` of them run on the efforts of the sub-step before them; option "fused_sub": all of them in ONE launch (mw_kernels.hpp)
+// `cn` (AnymalTerrain with the fused launch): the curriculum pre-pass of its post step runs on the trunk wave at the end of the launch
+struct MwCmdNormTail { int allow_knee_contacts; float max_episode_length; };
 template <class M, class GND>
 hipError_t launch_substeps_mw(const View& v, const SimParams& P, const ActParams& ap, const float* actions, int n_sub, int first, int rest,
-                              hipStream_t s, const GND& gnd, int tail = 0);
+                              hipStream_t s, const GND& gnd, int tail = 0, const MwCmdNormTail* cn = nullptr);
 
 // XCD-aware env mapping of the 64-lane post kernels.  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).
 // A sub-step kernel with 32 envs per workgroup puts env e on XCD (e / 32) % 8; a post kernel that simply took envs
