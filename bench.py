@@ -413,6 +413,14 @@ def main():
         raise SystemExit("bench.py needs a ROCm device (no CPU product path)")
     device = f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
+    import torch.distributed as _dist
+    if _dist.is_initialized():
+        # RCCL writes its version banner to the C-level stdout when the first communicator comes up; a pipe buffers it until the process
+        # exits, i.e. AFTER the JSON line.  Bring the communicator up now and flush the C streams, so that the JSON line is the last one.
+        _dist.barrier()
+        torch.cuda.synchronize()
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
     n_env = args.num_envs or DEFAULT_ENVS[args.task]
 
     strong = args.scaling == "strong"
@@ -491,6 +499,7 @@ def main():
         leg = reference_jit_leg(args.task, n_env)
         out["cpu_baseline"]["reference_jit_fns"] = leg if leg is not None else {"absent": "/root/reference is not reachable on this host"}
         out["cpu_baseline"]["product_backend"] = cpu_product_backend(args.task, n_env, budget_s=min(args.cpu_budget, 8.0))
+    sys.stdout.flush()
     print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()

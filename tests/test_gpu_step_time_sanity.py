@@ -2,6 +2,7 @@
 twenty times too slowly passes them all -- which is how the AllegroHand sub-step ran at 5.3 ms per launch for a while (constexpr table
 look-ups left as run-time loops, profiles/r3z_allegro_hand_fix.txt).  Ceilings are 5-10 x the measured step time on a fast box (the pool's
 slow boxes are 1.2-1.5 x slower): they catch pathologies, not regressions of a few per cent -- those are the A/B files' business."""
+import os
 import time
 
 import pytest
@@ -62,3 +63,23 @@ def test_init_state_writes_everything_the_step_reads(task, monkeypatch):
         o2, r2, d2, _ = ref.step(a)
         assert torch.isfinite(o1["obs"]).all() and torch.isfinite(r1).all(), (task, step)
         assert torch.equal(o1["obs"], o2["obs"]) and torch.equal(r1, r2) and torch.equal(d1, d2), (task, step)
+
+
+@pytest.mark.gpu
+def test_bench_line_is_the_last_stdout_line_when_a_process_group_is_up():
+    """`bench.py --gpus N` under torchrun prints ONE JSON line on rank 0 (the driver parses it).  RCCL prints a version banner to the C-level
+    stdout when its first communicator comes up; through a pipe that banner used to land AFTER the JSON line.  Exercised here with a one-rank
+    process group over RCCL (MI_FORCE_DIST=1: the same code path as N > 1 -- barriers, MAX all-reduce of the region time, the settle loop's
+    broadcast, the statistics reducers)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    env = dict(os.environ, MI_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--no-extra", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    d = json.loads(lines[-1])                       # the LAST line is the JSON line
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["value"] > 0
+    assert sum(1 for ln in lines if ln.lstrip().startswith("{")) == 1
