@@ -404,6 +404,10 @@ def main():
                          "pool reproduces that without timing torch.rand (a pool of 64 distinct batches made every read a cold miss, +5 %)")
     args = ap.parse_args()
 
+    # stdout carries ONE line, the JSON record of rank 0: whatever the legs print on the way (the reference's "Forcing CPU Pipeline" notice of the
+    # CPU-backend leg, ...) goes to stderr
+    json_out, sys.stdout = sys.stdout, sys.stderr
+
     import torch
     from isaacgymenvs_amd.parallel import init_distributed
     rank, world, local_rank = init_distributed()
@@ -500,7 +504,7 @@ def main():
         out["cpu_baseline"]["reference_jit_fns"] = leg if leg is not None else {"absent": "/root/reference is not reachable on this host"}
         out["cpu_baseline"]["product_backend"] = cpu_product_backend(args.task, n_env, budget_s=min(args.cpu_budget, 8.0))
     sys.stdout.flush()
-    print(json.dumps(out), flush=True)
+    print(json.dumps(out), file=json_out, flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
