@@ -50,7 +50,8 @@ struct HandDevRed {
     }
 };
 // post_physics_step (shadow_hand.py:710-715): hand_post_env (tasks/hand_task.hpp), ONE WAVE PER (64 envs, column group) -- blockIdx.y is the
-// group (HandCols: dof columns | object / goal + the reward | fingertip states | force-torques + actions).  Round 3 ran one lane per env over
+// group (HandCols: eight of them since round 4 -- dof positions | velocities | joint forces | object / goal + the reward | fingertip states in two | force-torques |
+// actions).  Round 3 ran one lane per env over
 // all 211 columns: 256 waves at 16384 envs, each with ~150 loads, 4.5 k vector instructions and a 55 KB staging tile (45 us, 61 % of it
 // waiting); four times the waves with a quarter of the chain each fill the chip's 1024 SIMDs.  The fingertip states come from hand_tips_kernel.
 template <class HT, int G>
@@ -88,7 +89,11 @@ __global__ __launch_bounds__(64) void hand_post_kernel(View v, HandView hv, Hand
         case 0: hand_post_group<HT, 0>(v, hv, p, stage); break;
         case 1: hand_post_group<HT, 1>(v, hv, p, stage); break;
         case 2: hand_post_group<HT, 2>(v, hv, p, stage); break;
-        default: hand_post_group<HT, 3>(v, hv, p, stage); break;
+        case 3: hand_post_group<HT, 3>(v, hv, p, stage); break;
+        case 4: hand_post_group<HT, 4>(v, hv, p, stage); break;
+        case 5: hand_post_group<HT, 5>(v, hv, p, stage); break;
+        case 6: hand_post_group<HT, 6>(v, hv, p, stage); break;
+        default: hand_post_group<HT, 7>(v, hv, p, stage); break;
     }
 }
 // observationType openai / full_no_vel / full (shadow_hand.py:472-526): column subsets of the full state
@@ -126,7 +131,7 @@ hipError_t launch_step_hand(const View& v, const HandView& hv, const SimParams& 
     hipError_t e = hand_substeps<HT>(v, hv, P, p, cfi * P.substeps, s);
     if (e != hipSuccess) return e;
     if constexpr (HT::NTIPS > 0) hipLaunchKernelGGL(hand_tips_kernel<HT>, dim3((v.N + 63) / 64, HT::NTIPS), dim3(64), 0, s, v, hv, p);
-    hipLaunchKernelGGL(hand_post_kernel<HT>, dim3((v.N + 63) / 64, 4), dim3(64), 0, s, v, hv, p);
+    hipLaunchKernelGGL(hand_post_kernel<HT>, dim3((v.N + 63) / 64, HandCols<HT>::NGROUPS), dim3(64), 0, s, v, hv, p);
     if (p.obs_type != 0) hipLaunchKernelGGL(hand_obs_select_kernel<HT>, dim3((v.N * p.num_obs + 255) / 256), dim3(256), 0, s, v, hv, p);
     hipLaunchKernelGGL(hand_finalize_kernel<HT>, dim3(1), dim3(64), 0, s, hv, p);
     return hipGetLastError();

@@ -163,32 +163,46 @@ MI_HD void hand_tip(const View& v, const HandView& hv, const HandParams& p, cons
 // from hand_tip.  `emit(k, val)` receives column k of compute_full_state's vector (:528-584); what is returned goes to hand_post_store
 // once the caller has written the observation rows out.
 struct HandPostOut { float r, succ; long long rs, gr, prog; };
-// column groups of the full-state vector: the device post kernel runs one wave per (64 envs, group) -- 4 x the waves, each with a quarter of the
-// loads and of the dependency chain (hand_task_kernels.hpp); the host runs all of them at once (GROUP = -1).  Group 1 also computes the reward.
-//   0: the 3 ND dof columns | 1: object pose / velocities, goal pose, quaternion difference + compute_hand_reward | 2: fingertip states |
-//   3: fingertip force-torques and the actions
+// column groups of the full-state vector: the device post kernel runs one wave per (64 envs, group) -- 8 x the waves of a one-lane-per-env kernel,
+// each with an eighth of the loads, of the dependency chain and of the row write-out (hand_task_kernels.hpp); the host runs all of them at once
+// (GROUP = -1).  Group 1 also computes the reward.
+//   0: dof positions | 4: dof velocities | 5: joint forces | 1: object pose / velocities, goal pose, quaternion difference + compute_hand_reward |
+//   2: the first three fingertip states | 6: the other two | 3: fingertip force-torques | 7: the actions
 template <class HT> struct HandCols {
     static constexpr int ND = HT::ND, O_OBJ = 3 * ND, O_GOAL = O_OBJ + 13, O_TIPS = O_GOAL + 11, O_FT = O_TIPS + 13 * HT::NTIPS, O_ACT = O_FT + 6 * HT::NTIPS;
     static_assert(O_ACT + HT::NACT == HT::NFULL, "full_state width");
-    static constexpr int first(int g) { return g == 0 ? 0 : g == 1 ? O_OBJ : g == 2 ? O_TIPS : O_FT; }
-    static constexpr int count(int g) { return g == 0 ? O_OBJ : g == 1 ? O_TIPS - O_OBJ : g == 2 ? O_FT - O_TIPS : HT::NFULL - O_FT; }
-    static constexpr int max_count() { int m = 0; for (int g = 0; g < 4; ++g) m = count(g) > m ? count(g) : m; return m; }
+    static constexpr int NGROUPS = 8, TIPS_A = (HT::NTIPS + 1) / 2;      // fingertips of group 2; the rest in group 6
+    static constexpr int first(int g) {
+        return g == 0 ? 0 : g == 4 ? ND : g == 5 ? 2 * ND : g == 1 ? O_OBJ : g == 2 ? O_TIPS : g == 6 ? O_TIPS + 13 * TIPS_A : g == 3 ? O_FT : O_ACT;
+    }
+    static constexpr int count(int g) {
+        return (g == 0 || g == 4 || g == 5) ? ND : g == 1 ? O_TIPS - O_OBJ : g == 2 ? 13 * TIPS_A : g == 6 ? 13 * (HT::NTIPS - TIPS_A) : g == 3 ? 6 * HT::NTIPS : HT::NACT;
+    }
+    static constexpr int max_count() { int m = 0; for (int g = 0; g < NGROUPS; ++g) m = count(g) > m ? count(g) : m; return m; }
+    static constexpr bool covers() { int n = 0; for (int g = 0; g < NGROUPS; ++g) n += count(g); return n == HT::NFULL; }
+    static_assert(covers(), "the groups partition the full-state vector");
 };
 template <class HT, int GROUP = -1, class EMIT, class RED>
 MI_HD HandPostOut hand_post_env(const View& v, const HandView& hv, const HandParams& p, const int e, const bool valid, const EMIT& emit, const RED& red) {
     MI_NO_CONTRACT
     constexpr int ND = HT::ND;
     using C = HandCols<HT>;
-    constexpr bool G0 = GROUP < 0 || GROUP == 0, G1 = GROUP < 0 || GROUP == 1, G2 = GROUP < 0 || GROUP == 2, G3 = GROUP < 0 || GROUP == 3;
+    constexpr bool ALL = GROUP < 0;
+    constexpr bool GP = ALL || GROUP == 0, GV = ALL || GROUP == 4, GF = ALL || GROUP == 5, G1 = ALL || GROUP == 1, GTA = ALL || GROUP == 2, GTB = ALL || GROUP == 6,
+                   GS = ALL || GROUP == 3, GA = ALL || GROUP == 7;
     const int N = v.N;
     // every input is loaded before the first observation is stored: the stores below may alias these arrays as far as the
     // compiler knows, and a load that has to wait for them is a fully exposed memory round trip for a lone wave
     float q[ND], qd[ND], dff[ND];
-    if constexpr (G0) sfor<ND>([&](auto K) MI_LAMBDA { q[K] = v.dof[K * N + e]; qd[K] = v.dof[(ND + K) * N + e]; dff[K] = v.dof_force[K * N + e]; });
+    if constexpr (GP) sfor<ND>([&](auto K) MI_LAMBDA { q[K] = v.dof[K * N + e]; });
+    if constexpr (GV) sfor<ND>([&](auto K) MI_LAMBDA { qd[K] = v.dof[(ND + K) * N + e]; });
+    if constexpr (GF) sfor<ND>([&](auto K) MI_LAMBDA { dff[K] = v.dof_force[K * N + e]; });
     float tips[HT::NTIPS > 0 ? HT::NTIPS : 1][13];
-    if constexpr (G2) sfor<HT::NTIPS>([&](auto T_) MI_LAMBDA { sfor<13>([&](auto K) MI_LAMBDA { tips[T_][K] = hv.fingertip[(T_ * 13 + K) * N + e]; }); });
+    sfor<HT::NTIPS>([&](auto T_) MI_LAMBDA {
+        if constexpr ((T_ < C::TIPS_A) ? GTA : GTB) sfor<13>([&](auto K) MI_LAMBDA { tips[T_][K] = hv.fingertip[(T_ * 13 + K) * N + e]; });
+    });
     float os[13], gp[7], act[HT::NACT], sns[HT::NTIPS > 0 ? 6 * HT::NTIPS : 1];
-    if constexpr (G3) sfor<6 * HT::NTIPS>([&](auto K) MI_LAMBDA { sns[K] = v.sensor[K * N + e]; });
+    if constexpr (GS) sfor<6 * HT::NTIPS>([&](auto K) MI_LAMBDA { sns[K] = v.sensor[K * N + e]; });
     long long reset_in = 0, reset_goal_in = 0, progress_in = 0;
     float successes_in = 0.f;
     if constexpr (G1) {
@@ -198,15 +212,15 @@ MI_HD HandPostOut hand_post_env(const View& v, const HandView& hv, const HandPar
         sfor<7>([&](auto K) MI_LAMBDA { gp[K] = hv.goal_state[K * N + e]; });
         progress_in = v.progress[e] + 1;               // :711
     }
-    if constexpr (G1 || G3) sfor<HT::NACT>([&](auto K) MI_LAMBDA { act[K] = v.actions[K * N + e]; });
+    if constexpr (G1 || GA) sfor<HT::NACT>([&](auto K) MI_LAMBDA { act[K] = v.actions[K * N + e]; });
     // compute_full_state (:528-584)
     // layout (shadow_hand.py:528-584 with 24 dofs and 5 fingertips: 211 columns; allegro_hand.py:485-507 with 16 dofs and none: 88):
     // 3 ND | object pose 7, linvel 3, angvel 3 | goal pose 7, quat diff 4 | 13 NTIPS fingertip states | 6 NTIPS force-torques | actions
-    if constexpr (G0) sfor<ND>([&](auto D) MI_LAMBDA {
+    sfor<ND>([&](auto D) MI_LAMBDA {
         constexpr int d = D;
-        emit(d, (2.0f * q[d] - HT::M::dof_upper[d] - HT::M::dof_lower[d]) / (HT::M::dof_upper[d] - HT::M::dof_lower[d]));   // unscale
-        emit(ND + d, p.vel_obs_scale * qd[d]);
-        emit(2 * ND + d, p.force_torque_obs_scale * dff[d]);
+        if constexpr (GP) emit(d, (2.0f * q[d] - HT::M::dof_upper[d] - HT::M::dof_lower[d]) / (HT::M::dof_upper[d] - HT::M::dof_lower[d]));   // unscale
+        if constexpr (GV) emit(ND + d, p.vel_obs_scale * qd[d]);
+        if constexpr (GF) emit(2 * ND + d, p.force_torque_obs_scale * dff[d]);
     });
     if constexpr (G1) {
         sfor<7>([&](auto K) MI_LAMBDA { emit(C::O_OBJ + K, os[K]); });
@@ -217,15 +231,11 @@ MI_HD HandPostOut hand_post_env(const View& v, const HandView& hv, const HandPar
         quat_mul(os + 3, conj, qd4);
         sfor<4>([&](auto K) MI_LAMBDA { emit(C::O_GOAL + 7 + K, qd4[K]); });
     }
-    if constexpr (G2) sfor<HT::NTIPS>([&](auto T_) MI_LAMBDA {
-        sfor<13>([&](auto K) MI_LAMBDA {
-            emit(C::O_TIPS + T_ * 13 + K, tips[T_][K]);
-        });
+    sfor<HT::NTIPS>([&](auto T_) MI_LAMBDA {
+        if constexpr ((T_ < C::TIPS_A) ? GTA : GTB) sfor<13>([&](auto K) MI_LAMBDA { emit(C::O_TIPS + T_ * 13 + K, tips[T_][K]); });
     });
-    if constexpr (G3) {
-        sfor<6 * HT::NTIPS>([&](auto K) MI_LAMBDA { emit(C::O_FT + K, p.force_torque_obs_scale * sns[K]); });
-        sfor<HT::NACT>([&](auto K) MI_LAMBDA { emit(C::O_ACT + K, act[K]); });
-    }
+    if constexpr (GS) sfor<6 * HT::NTIPS>([&](auto K) MI_LAMBDA { emit(C::O_FT + K, p.force_torque_obs_scale * sns[K]); });
+    if constexpr (GA) sfor<HT::NACT>([&](auto K) MI_LAMBDA { emit(C::O_ACT + K, act[K]); });
     // compute_hand_reward (:746-800)
     HandPostOut o{0.f, 0.f, 0, 0, 0};
     if constexpr (G1) {
