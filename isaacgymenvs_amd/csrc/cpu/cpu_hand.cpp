@@ -49,8 +49,9 @@ int HFN(_step)(MiEngine* e, const float* actions, bool simulate_only) {
     const int N = v.N;
     if (!simulate_only) {
         const unsigned step_counter = (unsigned)(e->steps + 1);
+        const HandActLimits<HT> al = HandActLimits<HT>::of(p);
 #pragma omp parallel for schedule(static) num_threads(e->num_threads)
-        for (int en = 0; en < N; ++en) hand_pre_env<HT>(v, hv, p, actions, step_counter, en);
+        for (int en = 0; en < N; ++en) hand_pre_env<HT>(v, hv, p, al, actions, step_counter, en);
     }
     substeps(e, (simulate_only ? 1 : e->control_freq_inv) * e->P.substeps);
     tips_all<0>(e);                                              // refresh_rigid_body_state_tensor for the fingertips

@@ -12,10 +12,11 @@ namespace mi {
 
 // pre_physics_step (shadow_hand.py:670-698): hand_pre_env (tasks/hand_task.hpp) for the env of this lane
 template <class HT>
-__global__ __launch_bounds__(64) void hand_pre_kernel(View v, HandView hv, HandParams p, const float* __restrict__ actions_in, unsigned step_counter) {
+__global__ __launch_bounds__(64) void hand_pre_kernel(View v, HandView hv, HandParams p, HandActLimits<HT> al, const float* __restrict__ actions_in,
+                                                      unsigned step_counter) {
     const int e = post_env_index<HandSim<typename HT::M>::LANES>(blockIdx.x, threadIdx.x, v.N);   // same env -> XCD mapping as the sub-step kernel
     if (e >= v.N) return;
-    hand_pre_env<HT>(v, hv, p, actions_in, step_counter, e);
+    hand_pre_env<HT>(v, hv, p, al, actions_in, step_counter, e);
 }
 
 // gym.refresh_rigid_body_state_tensor (shadow_hand.py:440,456-457) for the five fingertip bodies: ONE THREAD PER (env, fingertip) -- blockIdx.y is
@@ -127,7 +128,7 @@ hipError_t hand_substeps(const View& v, const HandView& hv, const SimParams& P, 
 template <class HT>
 hipError_t launch_step_hand(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, const float* actions, int cfi,
                             unsigned step_counter, hipStream_t s) {
-    hipLaunchKernelGGL(hand_pre_kernel<HT>, dim3((v.N + 63) / 64), dim3(64), 0, s, v, hv, p, actions, step_counter);
+    hipLaunchKernelGGL(hand_pre_kernel<HT>, dim3((v.N + 63) / 64), dim3(64), 0, s, v, hv, p, HandActLimits<HT>::of(p), actions, step_counter);
     hipError_t e = hand_substeps<HT>(v, hv, P, p, cfi * P.substeps, s);
     if (e != hipSuccess) return e;
     if constexpr (HT::NTIPS > 0) hipLaunchKernelGGL(hand_tips_kernel<HT>, dim3((v.N + 63) / 64, HT::NTIPS), dim3(64), 0, s, v, hv, p);

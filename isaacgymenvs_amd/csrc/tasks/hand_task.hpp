@@ -88,9 +88,25 @@ MI_HD void hand_reset_env(const View& v, const HandView& hv, const HandParams& p
     hv.successes[e] = 0.f;
 }
 
+// joint limits of the ACTUATED dofs, in actuator order: looked up on the host (HandParams::actuated is a run-time table; indexing the model's
+// constant tables with it on the device would either copy them to scratch or walk a 24-way select per action -- ~900 of this step's ~1000 vector /
+// scalar instructions per wave were that walk)
+template <class HT> struct HandActLimits {
+    float lo[HT::NACT], up[HT::NACT];
+    static HandActLimits of(const HandParams& p) {
+        HandActLimits a{};
+        for (int k = 0; k < HT::NACT; ++k) {
+            const int d = p.actuated[k];
+            a.lo[k] = (d >= 0 && d < HT::ND) ? HT::M::dof_lower[d] : 0.f;
+            a.up[k] = (d >= 0 && d < HT::ND) ? HT::M::dof_upper[d] : 0.f;
+        }
+        return a;
+    }
+};
 // pre_physics_step (shadow_hand.py:670-698): deferred resets, then actions -> targets
 template <class HT>
-MI_HD void hand_pre_env(const View& v, const HandView& hv, const HandParams& p, const float* __restrict__ actions_in, const unsigned step_counter, const int e) {
+MI_HD void hand_pre_env(const View& v, const HandView& hv, const HandParams& p, const HandActLimits<HT>& al, const float* __restrict__ actions_in,
+                        const unsigned step_counter, const int e) {
     MI_NO_CONTRACT
     const int N = v.N;
     const uint32_t genv = (uint32_t)(v.env_offset + e);
@@ -105,9 +121,7 @@ MI_HD void hand_pre_env(const View& v, const HandView& hv, const HandParams& p, 
         const int d = p.actuated[a];
         const float act = fminf(fmaxf(raw_act[a], -p.clip_actions), p.clip_actions);                               // vec_task.py:374
         v.actions[a * N + e] = act;
-        // the actuated dof index is a runtime table: read the limits through a tiny switch-free lookup
-        float lo = 0.f, up = 0.f;
-        sfor<HT::ND>([&](auto D) MI_LAMBDA { if (d == D) { lo = HT::M::dof_lower[D]; up = HT::M::dof_upper[D]; } });
+        const float lo = al.lo[a], up = al.up[a];
         const float prev = hv.prev_targets[d * N + e];
         float t;
         if (p.use_relative_control) {
