@@ -1,1 +1,1 @@
-from ...utils.spaces import Box  # noqa: F401
+from ...utils.spaces import Box, Dict  # noqa: F401

@@ -195,17 +195,29 @@ class TriangleMeshParams(_Bag):
         super().__init__(nb_vertices=0, nb_triangles=0, transform=Transform(), static_friction=1.0, dynamic_friction=1.0, restitution=0.0)
 
 
-class RigidShapeProperties(_Bag):
+class _Scalars(_Bag):
+    """a property struct whose numeric fields are C floats in the simulator's bindings: a one-element array assigned to one (what
+    utils/dr_utils.py:195-208 apply_random_samples does: `setattr(prop, attr, og * sample)` with a sample of shape (1,)) reads back as a float"""
+
+    def __setattr__(self, k, val):
+        if isinstance(val, np.ndarray) and val.size == 1:
+            val = float(val.reshape(-1)[0])
+        elif torch.is_tensor(val) and val.numel() == 1:
+            val = float(val)
+        object.__setattr__(self, k, val)
+
+
+class RigidShapeProperties(_Scalars):
     def __init__(self, friction=1.0):
         super().__init__(friction=friction, rolling_friction=0.0, torsion_friction=0.0, restitution=0.0, compliance=0.0, thickness=0.0)
 
 
-class RigidBodyProperties(_Bag):
+class RigidBodyProperties(_Scalars):
     def __init__(self, mass=0.0):
         super().__init__(mass=mass, invMass=(1.0 / mass if mass > 0 else 0.0), com=Vec3(), inertia=None)
 
 
-class TendonProperties(_Bag):
+class TendonProperties(_Scalars):
     def __init__(self, stiffness=0.0, damping=0.0, limit_stiffness=0.0):
         super().__init__(type=0, stiffness=stiffness, damping=damping, fixed_spring_rest_length=0.0, fixed_lower_limit=0.0, fixed_upper_limit=0.0,
                          limit_stiffness=limit_stiffness, is_fixed_limited=True, num_attachments=2)
@@ -327,6 +339,53 @@ class _Asset:
         self.extras = load_extras(self.model_name) if self.model_name in ("shadow_hand", "allegro_hand") else None
 
 
+class _ActorProps:
+    """Per-env actor properties as the reference's domain randomisation writes them: VecTask.apply_randomizations (vec_task.py:752-828) walks
+    every env and calls gym.get_actor_*_properties / set_actor_*_properties / set_actor_scale on it.  PhysX keeps one property struct per actor; the
+    engine keeps per-env FACTORS of the compiled model's constants in tensors the sub-step reads (`actor_scale`, `dof_limit_shift`, `friction`:
+    csrc/core/engine.hpp AS_*, csrc/core/hand_engine.hpp HS_*).  The setters turn what they are given into factors relative to the actor's own
+    values, staged here on the host (one row per env: the reference calls them env by env); Gym._flush_props writes the rows that changed to the
+    engine before the next simulate()."""
+
+    def __init__(self, sim):
+        robot = sim.slots[sim.robot]["asset"]
+        self.n, self.nb, self.nd = 0, robot.spec.nb, robot.spec.nd
+        self.body = np.ones((0, self.nb))                          # mass (and with it inertia) factor per engine body
+        self.damp, self.stiff, self.arm = (np.ones((0, self.nd)) for _ in range(3))
+        self.lower, self.upper = np.zeros((0, self.nd)), np.zeros((0, self.nd))       # shifts of the joint limits
+        self.tendon_k, self.tendon_d, self.obj_mass, self.obj_scale = (np.ones(0) for _ in range(4))
+        self.mu = {}                                               # actor slot -> [n] shape friction (nan: the asset's own)
+        self.dirty = False
+        self.grow(len(sim.envs))
+
+    def grow(self, n):
+        if n <= self.n:
+            return
+        pad = n - self.n
+        for k in ("body", "damp", "stiff", "arm"):
+            a = getattr(self, k)
+            setattr(self, k, np.concatenate([a, np.ones((pad, a.shape[1]))]))
+        for k in ("lower", "upper"):
+            a = getattr(self, k)
+            setattr(self, k, np.concatenate([a, np.zeros((pad, a.shape[1]))]))
+        for k in ("tendon_k", "tendon_d", "obj_mass", "obj_scale"):
+            setattr(self, k, np.concatenate([getattr(self, k), np.ones(pad)]))
+        for k in self.mu:
+            self.mu[k] = np.concatenate([self.mu[k], np.full(pad, np.nan)])
+        self.n = n
+
+    def friction(self, slot):
+        if slot not in self.mu:
+            self.mu[slot] = np.full(self.n, np.nan)
+        return self.mu[slot]
+
+
+def _ratio(new, base):
+    """element-wise new / base where the base value is positive, 1 elsewhere (a factor cannot express a change of a zero)"""
+    new, base = np.asarray(new, np.float64), np.asarray(base, np.float64)
+    return np.where(base > 0, new / np.where(base > 0, base, 1.0), 1.0)
+
+
 class _Env:
     def __init__(self, sim, index):
         self.sim, self.index = sim, index
@@ -346,6 +405,7 @@ class _Sim:
         self.bufs = {}
         self.one_shot_force = False
         self.attractors = []                   # create_rigid_body_attractor, env 0
+        self.props = None                      # _ActorProps: what the per-env property setters wrote (domain randomisation), staged on the host
 
     # the articulated actor (the engine's robot) and the free objects
     @property
@@ -448,7 +508,10 @@ class Gym:
         return asset.spec.dof_names[int(asset.spec.act_dof[index])]
 
     def get_asset_dof_properties(self, asset):
-        return _dof_properties(asset.spec, _drive_mode(asset))
+        out = _dof_properties(asset.spec, _drive_mode(asset))
+        if asset.extras is not None and "dof_kp" in asset.extras:       # the hands' position actuators: the dof's stiffness is the drive's kp
+            out["stiffness"] = np.asarray(asset.extras["dof_kp"], np.float32)
+        return out
 
     def get_asset_rigid_shape_properties(self, asset):
         mu = asset.spec.geom_friction if asset.spec is not None else [1.0]
@@ -530,28 +593,211 @@ class Gym:
     def end_aggregate(self, *a, **k):
         return True
 
+    # ---- per-env actor properties (the reference's domain randomisation: vec_task.py:752-828 through utils/dr_utils.py:34-56)
+    def _props(self, sim):
+        if sim.props is None:
+            sim.props = _ActorProps(sim)
+        sim.props.grow(len(sim.envs))
+        return sim.props
+
+    def _base_dof_props(self, sim, actor):
+        """the actor's dof properties before any per-env change: what the task wrote while it created the actor, else the asset's"""
+        sl = sim.slots[actor]
+        if sl.get("dof_props") is not None:
+            return sl["dof_props"]
+        return self.get_asset_dof_properties(sl["asset"])
+
     def get_actor_dof_properties(self, env, actor):
-        sl = env.sim.slots[actor]
-        if sl["asset"].generic and sl.get("dof_props") is not None:
-            return np.array(sl["dof_props"], copy=True)
-        return _dof_properties(sl["asset"].spec, _drive_mode(sl["asset"]))
+        sim = env.sim
+        sl = sim.slots[actor]
+        out = np.array(self._base_dof_props(sim, actor), copy=True)
+        if sim.props is not None and actor == sim.robot and env.index < sim.props.n:
+            pr, e = sim.props, env.index
+            out["stiffness"] *= pr.stiff[e]; out["damping"] *= pr.damp[e]; out["armature"] *= pr.arm[e]
+            out["lower"] += pr.lower[e]; out["upper"] += pr.upper[e]
+        return out
 
     def set_actor_dof_properties(self, env, actor, props):
-        """Drive modes and gains are task parameters of the engine: kept (env 0's; every env sets the same) and read by prepare_sim for the
-        tasks whose drives the engine implements (Anymal, Quadcopter, Ingenuity, BallBalance); the passive stiffness / damping of the other
-        compiled models are fixed at build time."""
-        if env.index == 0:
-            env.sim.slots[actor]["dof_props"] = np.array(props, copy=True)
+        """While the actor is being created (the env is the newest one, no engine yet): drive modes and gains are task parameters of the
+        engine -- kept (env 0's; every env sets the same) and read by prepare_sim for the tasks whose drives the engine implements (Anymal,
+        Quadcopter, Ingenuity, BallBalance, Articulation); the passive stiffness / damping of the other compiled models are fixed at build
+        time.  Afterwards (domain randomisation, vec_task.py:783-828): stiffness / damping / armature become this env's factors of those
+        values, lower / upper its shifts of the joint limits."""
+        sim = env.sim
+        sl = sim.slots[actor]
+        made = sl.setdefault("dof_props_made", set())
+        if sim.engine is None and sim.props is None and env.index == len(sim.envs) - 1 and env.index not in made:
+            made.add(env.index)
+            if env.index == 0:
+                sl["dof_props"] = np.array(props, copy=True)
+            return True
+        if actor != sim.robot:
+            return True
+        base, pr, e = self._base_dof_props(sim, actor), self._props(sim), env.index
+        pr.stiff[e], pr.damp[e], pr.arm[e] = _ratio(props["stiffness"], base["stiffness"]), _ratio(props["damping"], base["damping"]), \
+            _ratio(props["armature"], base["armature"])
+        pr.lower[e] = np.asarray(props["lower"], np.float64) - base["lower"]
+        pr.upper[e] = np.asarray(props["upper"], np.float64) - base["upper"]
+        pr.dirty = True
         return True
+
+    def _base_masses(self, sim, actor):
+        a = sim.slots[actor]["asset"]
+        if a.spec is None:
+            return np.array([_object_mass(a.object_type, sim.asset.task if sim.slots and any(sl["asset"].spec is not None for sl in sim.slots) else "ShadowHand")])
+        return np.asarray([float(a.spec.mass[int(d)]) for d in a.body_dyn])
+
+    def get_actor_rigid_body_properties(self, env, actor):
+        sim = env.sim
+        a = sim.slots[actor]["asset"]
+        m = self._base_masses(sim, actor)
+        if sim.props is not None and env.index < sim.props.n:
+            if a.spec is not None:
+                m = m * sim.props.body[env.index][np.asarray(a.body_dyn, int)]
+            elif actor == [k for k, sl in enumerate(sim.slots) if sl["asset"].spec is None][0]:
+                m = m * sim.props.obj_mass[env.index]
+        return [RigidBodyProperties(float(x)) for x in m]
+
+    def set_actor_rigid_body_properties(self, env, actor, props, recompute_inertia=False):
+        """rigid_body_properties.mass (vec_task.py:783-828 with dr_utils.py:63 recomputeInertia = True): the body's mass -- and with it its
+        inertia -- times new / own.  Links welded to one engine body share its factor (the mean of theirs)."""
+        sim = env.sim
+        a = sim.slots[actor]["asset"]
+        pr, e = self._props(sim), env.index
+        f = _ratio([float(p_.mass) for p_ in props], self._base_masses(sim, actor))
+        if a.spec is None:
+            ks = [k for k, sl in enumerate(sim.slots) if sl["asset"].spec is None]
+            if actor == ks[0]:                 # the engine's object; the goal copy has no dynamics
+                pr.obj_mass[e] = float(f[0])
+        elif actor == sim.robot:
+            dyn = np.asarray(a.body_dyn, int)
+            pr.body[e] = [float(np.mean(f[dyn == b])) if np.any(dyn == b) else 1.0 for b in range(pr.nb)]
+        pr.dirty = True
+        return True
+
+    def get_actor_rigid_shape_properties(self, env, actor):
+        sim = env.sim
+        sl = sim.slots[actor]
+        out = self.get_asset_rigid_shape_properties(sl["asset"]) or [RigidShapeProperties(1.0)]     # (a mesh-only asset lists no primitive shapes)
+        mu = sl["friction"].get(env.index)
+        if sim.props is not None and actor in sim.props.mu and env.index < sim.props.n and not np.isnan(sim.props.mu[actor][env.index]):
+            mu = float(sim.props.mu[actor][env.index])
+        if mu is not None:
+            for p_ in out:
+                p_.friction = mu
+        return out
+
+    def set_actor_rigid_shape_properties(self, env, actor, props):
+        """rigid_shape_properties.friction: the engine has one coefficient per env and contact pair type, the first shape's (the reference
+        draws one bucketed value for all shapes of an actor, vec_task.py:800-808); restitution has no counterpart (no bounce in the solver)"""
+        if not props:
+            return True
+        pr = self._props(env.sim)
+        f = props[0].friction
+        pr.friction(actor)[env.index] = float(np.ravel(np.asarray(f.cpu() if hasattr(f, "cpu") else f))[0])
+        pr.dirty = True
+        return True
+
+    def get_actor_tendon_properties(self, env, actor):
+        sim = env.sim
+        a = sim.slots[actor]["asset"]
+        n = self.get_asset_tendon_count(a)
+        tp = a.tendon_props or [(float(a.extras["tendon_limit_stiffness"]), float(a.extras["tendon_damping"]))] * n
+        fk, fd = (sim.props.tendon_k[env.index], sim.props.tendon_d[env.index]) if sim.props is not None and env.index < sim.props.n else (1.0, 1.0)
+        return [TendonProperties(stiffness=0.0, damping=tp[i][1] * fd, limit_stiffness=tp[i][0] * fk) for i in range(n)]
+
+    def set_actor_tendon_properties(self, env, actor, props):
+        """tendon_properties (ShadowHand.yaml:118-131): the coupling tendons' limit stiffness and damping as this env's factors of the asset's
+        (a fixed tendon of the MJCF has no spring of its own: `stiffness` is 0 and scaling it changes nothing, in PhysX as here)"""
+        sim = env.sim
+        a = sim.slots[actor]["asset"]
+        n = self.get_asset_tendon_count(a)
+        if n == 0:
+            return True
+        tp = a.tendon_props or [(float(a.extras["tendon_limit_stiffness"]), float(a.extras["tendon_damping"]))] * n
+        live = [i for i in range(n) if tp[i] != (0.0, 0.0)]
+        pr, e = self._props(sim), env.index
+        if live:
+            pr.tendon_k[e] = float(np.mean(_ratio([props[i].limit_stiffness for i in live], [tp[i][0] for i in live])))
+            pr.tendon_d[e] = float(np.mean(_ratio([props[i].damping for i in live], [tp[i][1] for i in live])))
+            pr.dirty = True
+        return True
+
+    def set_actor_scale(self, env, actor, scale):
+        """vec_task.py:760-775: the free object of a hand task changes size (its mass stays); the articulated actor cannot"""
+        sim = env.sim
+        if sim.slots[actor]["asset"].spec is not None:
+            return False
+        if actor != [k for k, sl in enumerate(sim.slots) if sl["asset"].spec is None][0]:
+            return True                        # the goal copy is only drawn
+        pr = self._props(sim)
+        pr.obj_scale[env.index] = float(np.ravel(np.asarray(scale))[0])
+        pr.dirty = True
+        return True
+
+    def _engine_object_slot(self, sim):
+        live = [k for k, lives in self._object_slots(sim) if lives]
+        return live[0] if live else -1
+
+    def _flush_props(self, sim):
+        """staged per-env properties -> the engine's tensors (csrc/core/engine.hpp AS_*: [nb] body factors, then [nd] damping, stiffness,
+        armature; csrc/core/hand_engine.hpp HS_*: one factor per env for each of hand mass, dof damping, drive stiffness, tendon stiffness,
+        tendon damping, object mass, object scale)"""
+        pr = sim.props
+        if pr is None or not pr.dirty or sim.engine is None:
+            return
+        pr.dirty = False
+        t, n, dev = sim.engine.tensors, len(sim.envs), sim.device
+        a = sim.asset
+        put = lambda x: torch.as_tensor(np.asarray(x, np.float32), device=dev)
+        sc = t.get("actor_scale")
+        unsupported = []
+        if sc is not None and sc.shape[1] == pr.nb + 3 * pr.nd and a.task not in _HAND_TASKS:
+            sc[:] = put(np.concatenate([pr.body[:n], pr.damp[:n], pr.stiff[:n], pr.arm[:n]], axis=1))
+            sim.engine.set_option("actor_tensors", 1)
+        elif sc is not None and a.task in _HAND_TASKS:
+            m = np.asarray(a.spec.mass, np.float64)
+            driven = np.asarray(self._base_dof_props(sim, sim.robot)["stiffness"]) > 0
+            damped = np.asarray(self._base_dof_props(sim, sim.robot)["damping"]) > 0
+            sc[:, 0] = put(pr.body[:n] @ m / m.sum())
+            sc[:, 1] = put(pr.damp[:n][:, damped].mean(1) if damped.any() else np.ones(n))
+            sc[:, 2] = put(pr.stiff[:n][:, driven].mean(1) if driven.any() else np.ones(n))
+            if a.tendon_props is None or any(tp_ != (0.0, 0.0) for tp_ in a.tendon_props):
+                k0 = [tp_ for tp_ in (a.tendon_props or []) if tp_ != (0.0, 0.0)]
+                ls, dm = k0[0] if k0 else (float(a.extras["tendon_limit_stiffness"]), float(a.extras["tendon_damping"]))
+                sc[:, 3] = put(pr.tendon_k[:n] * ls / float(a.extras["tendon_limit_stiffness"]))
+                sc[:, 4] = put(pr.tendon_d[:n] * dm / float(a.extras["tendon_damping"]))
+            sc[:, 5] = put(pr.obj_mass[:n]); sc[:, 6] = put(pr.obj_scale[:n])
+        elif any(np.any(x[:n] != 1.0) for x in (pr.body, pr.damp, pr.stiff, pr.arm)):
+            unsupported.append("mass / dof stiffness / damping / armature")
+        sh = t.get("dof_limit_shift")
+        if sh is not None and sh.shape[1] == 2 * pr.nd:
+            sh[:] = put(np.concatenate([pr.lower[:n], pr.upper[:n]], axis=1))
+            if a.task not in _HAND_TASKS:
+                sim.engine.set_option("actor_tensors", 1)
+        elif np.any(pr.lower[:n] != 0.0) or np.any(pr.upper[:n] != 0.0):
+            unsupported.append("joint limits")
+        if pr.mu and "friction" in t:
+            # one contact coefficient per env: the articulated actor's shape friction against the ground, or -- a hand task -- the mean of the
+            # hand's and the object's (the value the engine's own task classes use, tasks/base/vec_task.py); nan / -1: the model's own
+            cols = []
+            for k, sl in enumerate(sim.slots):
+                if k == sim.robot or (a.task in _HAND_TASKS and k == self._engine_object_slot(sim)):
+                    base = np.array([sl["friction"].get(e, np.nan) for e in range(n)])
+                    cols.append(np.where(np.isnan(pr.mu[k][:n]), base, pr.mu[k][:n]) if k in pr.mu else base)
+            mu = np.stack(cols, 1)
+            some = ~np.isnan(mu).all(1)
+            mu = np.where(np.isnan(mu), 1.0, mu).mean(1)
+            t["friction"][:] = put(np.where(some, mu, -1.0))
+        elif pr.mu:
+            unsupported.append("shape friction")
+        if unsupported and not getattr(sim, "_props_warned", False):
+            import warnings
+            sim._props_warned = True
+            warnings.warn(f"per-env actor properties without a counterpart in the {a.task} kernels are ignored: " + ", ".join(unsupported))
 
     def get_actor_rigid_body_count(self, env, actor):
         return len(env.sim.slots[actor]["asset"].body_names)
-
-    def get_actor_rigid_body_properties(self, env, actor):
-        a = env.sim.slots[actor]["asset"]
-        if a.spec is None:
-            return [RigidBodyProperties(_object_mass(a.object_type, env.sim.asset.task if env.sim.asset is not None else "ShadowHand"))]
-        return [RigidBodyProperties(float(a.spec.mass[int(d)])) for d in a.body_dyn]
 
     def get_actor_dof_count(self, env, actor):
         return self.get_asset_dof_count(env.sim.slots[actor]["asset"])
@@ -561,6 +807,15 @@ class Gym:
 
     def find_actor_handle(self, env, name):
         return env.actors.index(name)
+
+    def get_actor_handle(self, env, index):      # dr_utils.py:233-236 (check_buckets) walks an env's actors by index
+        return index
+
+    def get_actor_name(self, env, actor):
+        return env.actors[actor]
+
+    def get_actor_rigid_shape_count(self, env, actor):
+        return env.sim.slots[actor]["asset"].nshapes
 
     def get_actor_index(self, env, actor, domain=DOMAIN_SIM):
         # (a one-actor env: the env index, as before; called while the envs are being filled, so the per-env actor count is that of env 0)
@@ -574,9 +829,6 @@ class Gym:
 
     def set_rigid_body_color(self, *a, **k):
         pass
-
-    def set_actor_scale(self, *a, **k):
-        return False
 
     def get_env_origin(self, env):
         return Vec3(0.0, 0.0, 0.0)
@@ -789,6 +1041,7 @@ class Gym:
         if asset.task not in ("BallBalance", "Articulation") and asset.sensors and asset.sensors != asset.engine_sensor_bodies[:len(asset.sensors)]:
             raise NotImplementedError(f"force sensors on bodies {asset.sensors}: the compiled {asset.model_name} model has them on "
                                       f"{asset.engine_sensor_bodies}")
+        self._flush_props(sim)                   # what a setup-time randomisation wrote before the engine existed (shadow_hand.py:224-226)
         return True
 
     # ------------------------------------------------------------------ tensor API
@@ -1055,6 +1308,7 @@ class Gym:
 
     # ------------------------------------------------------------------ stepping
     def simulate(self, sim):
+        self._flush_props(sim)
         sim.engine.simulate()
         sim.frame += 1
         if sim.one_shot_force:                      # gym applies body forces for one simulate() only

@@ -29,3 +29,43 @@ except Exception:  # noqa: BLE001
 
             def __repr__(self):
                 return f"Box({self.low.min()}, {self.high.max()}, {self.shape}, {self.dtype})"
+
+try:  # pragma: no cover - depends on the environment
+    from gym.spaces import Dict  # type: ignore
+except Exception:  # noqa: BLE001
+    try:
+        from gymnasium.spaces import Dict  # type: ignore
+    except Exception:  # noqa: BLE001
+        class Dict:  # the dictionary observation space of the reference's dextreme tasks (tasks/dextreme/adr_vec_task.py:76-84): name -> Box
+            def __init__(self, spaces=None, **kw):
+                self.spaces = dict(spaces or {}, **kw)
+
+            def __getitem__(self, k):
+                return self.spaces[k]
+
+            def __setitem__(self, k, space):
+                self.spaces[k] = space
+
+            def __iter__(self):
+                return iter(self.spaces)
+
+            def __len__(self):
+                return len(self.spaces)
+
+            def keys(self):
+                return self.spaces.keys()
+
+            def items(self):
+                return self.spaces.items()
+
+            def values(self):
+                return self.spaces.values()
+
+            def sample(self):
+                return {k: s.sample() for k, s in self.spaces.items()}
+
+            def contains(self, x):
+                return isinstance(x, dict) and x.keys() == self.spaces.keys() and all(s.contains(x[k]) for k, s in self.spaces.items())
+
+            def __repr__(self):
+                return "Dict(" + ", ".join(f"{k}: {s!r}" for k, s in self.spaces.items()) + ")"

@@ -500,3 +500,103 @@ def test_reference_ball_balance_matches_the_fused_kernels_on_the_same_state(refe
     d = (r_obs["obs"] - n_obs["obs"]).abs()[keep]
     assert float(d.max()) < 2e-4, float(d.max())
     assert float((r_rew - n_rew).abs()[keep].max()) < 1e-4 and torch.equal(r_reset[keep].bool(), n_reset[keep].bool())
+
+
+def _with_fast_schedules(prm, steps):
+    """the task YAML's randomization_params with every `schedule_steps` cut to `steps` sim frames (Humanoid.yaml ramps its ranges in over 3000)"""
+    if isinstance(prm, dict):
+        return {k: (steps if k == "schedule_steps" else _with_fast_schedules(v, steps)) for k, v in prm.items()}
+    return prm
+
+
+@pytest.mark.parametrize("task,mod,cls", [("ShadowHand", "shadow_hand", "ShadowHand"), ("Ant", "ant", "Ant"), ("Humanoid", "humanoid", "Humanoid")])
+def test_reference_domain_randomisation_reaches_the_engine(reference_tasks, task, mod, cls):
+    """`task.randomize: True` with the reference's own randomization_params, through the reference's own VecTask.apply_randomizations
+    (vec_task.py:610-850: it walks the envs and calls gym.get_actor_*_properties / set_actor_*_properties / set_actor_scale on each, maps from
+    utils/dr_utils.py:34-56): the stand-in turns what the setters are given into the per-env factors the sub-step kernels read (`actor_scale`,
+    `dof_limit_shift`, `friction`), the getters give the values back.  Setup-time draws (before prepare_sim) and the ones at resets."""
+    mods, vt = reference_tasks
+    vt.EXISTING_SIM = None
+    n = 64
+    cfg = _ref_cfg(task, n)
+    cfg["task"]["randomize"] = True
+    prm = cfg["task"]["randomization_params"] = _with_fast_schedules(cfg["task"]["randomization_params"], 4)
+    prm["frequency"] = 8                     # sim frames between two draws for an env that has been reset (YAML: 600 / 720)
+    cfg["env"]["episodeLength"] = 12
+    torch.manual_seed(7); np.random.seed(7)
+    ref = getattr(mods[mod], cls)(cfg, rl_device=DEV, sim_device=DEV, graphics_device_id=-1, headless=True, virtual_screen_capture=False, force_render=False)
+    gym, eng = ref.gym, ref.sim.engine
+    t = eng.tensors
+    actor = next(iter(prm["actor_params"]))
+    ap = prm["actor_params"][actor]
+    robot = ref.sim.robot
+    spec = ref.sim.asset.spec
+    nb, nd = spec.nb, spec.nd
+    g = torch.Generator().manual_seed(1)
+
+    def step(k):
+        for _ in range(k):
+            obs, rew, _, _ = ref.step((torch.rand((n, ref.num_actions), generator=g) * 2 - 1).to(DEV))
+            assert torch.isfinite(obs["obs"]).all() and torch.isfinite(rew).all()
+
+    sc0 = t["actor_scale"].detach().cpu().numpy().copy()
+    if task == "ShadowHand":
+        # setup-time draws, staged before the engine existed: total hand mass (per-body factors in [0.5, 1.5], mass-weighted), object mass
+        assert sc0.shape == (n, 8)
+        assert (sc0[:, 0] > 0.5).all() and (sc0[:, 0] < 1.5).all() and sc0[:, 0].std() > 0.02
+        assert (sc0[:, 5] >= 0.5).all() and (sc0[:, 5] <= 1.5).all() and sc0[:, 5].std() > 0.1
+        assert (sc0[:, 1] > 0.3).all() and (sc0[:, 1] < 3.0).all() and sc0[:, 1].std() > 0.02          # dof damping: loguniform [0.3, 3], mean over dofs
+        assert (sc0[:, 2] > 0.75).all() and (sc0[:, 2] < 1.5).all() and sc0[:, 2].std() > 0.005        # drive stiffness
+        assert (sc0[:, 6] >= 0.95).all() and (sc0[:, 6] <= 1.05).all() and sc0[:, 6].std() > 0.005     # object scale (vec_task.py:760-775)
+        assert np.allclose(sc0[:, 3], 1.0)            # the MJCF's fixed tendons have no spring: scaling its stiffness of 0 changes nothing
+        assert sc0[:, 4].std() > 0.05                 # tendon damping
+        mu = t["friction"].detach().cpu().numpy()
+        assert (mu > 0.7 - 1e-6).all() and (mu < 1.3 + 1e-6).all() and mu.std() > 0.02                  # mean of the hand's and the object's
+    else:
+        assert sc0.shape == (n, nb + 3 * nd) and int(eng.get_option("actor_tensors")) == 1
+    step(3)
+    if task == "Humanoid":        # Humanoid.yaml ramps every range in from zero (`schedule: linear`): nothing is randomised at frame 0, so wait for
+        assert np.allclose(sc0, 1.0)          # the first resets past `frequency`
+        step(30)
+    e = 5
+    # ---- what the getters report is what the engine runs
+    sc = t["actor_scale"].detach().cpu().numpy().copy()
+    masses = np.array([p.mass for p in gym.get_actor_rigid_body_properties(ref.envs[e], robot)])
+    base_m = np.asarray(spec.mass)[np.asarray(ref.sim.asset.body_dyn, int)]
+    dp = gym.get_actor_dof_properties(ref.envs[e], robot)
+    base_dp = gym.get_asset_dof_properties(ref.sim.asset)
+    sh = t["dof_limit_shift"].detach().cpu().numpy()
+    assert np.allclose(dp["lower"] - base_dp["lower"], sh[e, :nd], atol=1e-6) and np.allclose(dp["upper"] - base_dp["upper"], sh[e, nd:], atol=1e-6)
+    assert np.abs(sh).max() > 1e-4 and np.abs(sh).max() < 0.1
+    if task == "ShadowHand":
+        dyn_m = np.asarray(spec.mass)
+        per_body = np.array([np.mean((masses / base_m)[np.asarray(ref.sim.asset.body_dyn, int) == b]) for b in range(nb)])
+        assert abs(float(per_body @ dyn_m / dyn_m.sum()) - sc[e, 0]) < 1e-4                    # the hand's kernels take ONE mass factor per env
+        obj = gym.find_actor_handle(ref.envs[e], "object")
+        m_obj = [gym.get_actor_rigid_body_properties(ref.envs[k], obj)[0].mass for k in (e, e + 1)]
+        assert abs(m_obj[0] / m_obj[1] - sc[e, 5] / sc[e + 1, 5]) < 1e-5
+    else:
+        assert np.allclose(masses / base_m, sc[e, :nb][np.asarray(ref.sim.asset.body_dyn, int)], rtol=1e-5)
+        mass_prm = ap["rigid_body_properties"]["mass"]
+        if mass_prm.get("setup_only", False) and "schedule" in mass_prm:
+            # Humanoid.yaml:86-93: drawn once, at frame 0, where the linear schedule still scales the range to nothing -- the reference
+            # never randomises these masses, and neither does the stand-in
+            assert np.allclose(sc[:, :nb], 1.0)
+        else:
+            assert sc[:, :nb].std() > 0.05 and (sc[:, :nb] >= 0.5 - 1e-6).all() and (sc[:, :nb] <= 1.5 + 1e-6).all()       # one draw per body and env
+        if "friction" in ap.get("rigid_shape_properties", {}):                        # Humanoid.yaml:94-101, in 500 buckets
+            mu = t["friction"].detach().cpu().numpy()
+            assert (mu > 0.7 - 1e-6).all() and (mu < 1.3 + 1e-6).all() and mu.std() > 0.02
+            assert abs(gym.get_actor_rigid_shape_properties(ref.envs[e], robot)[0].friction - mu[e]) < 1e-6
+        damp = sc[:, nb:nb + nd]
+        assert np.allclose(dp["damping"], base_dp["damping"] * damp[e], rtol=1e-5) and damp.std() > 0.05
+    # ---- resets after `frequency` frames draw again: everything that is not `setup_only`
+    step(30)
+    sc1 = t["actor_scale"].detach().cpu().numpy()
+    if task == "ShadowHand":
+        assert np.array_equal(sc1[:, 0], sc0[:, 0]) and np.array_equal(sc1[:, 5], sc0[:, 5])           # masses: setup_only
+        assert (sc1[:, 1] != sc0[:, 1]).mean() > 0.5
+    else:
+        assert (sc1[:, nb:nb + nd] != sc[:, nb:nb + nd]).any(1).mean() > 0.5
+        if ap.get("rigid_body_properties", {}).get("mass", {}).get("setup_only", False):
+            assert np.array_equal(sc1[:, :nb], sc[:, :nb])
