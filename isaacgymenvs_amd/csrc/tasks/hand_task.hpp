@@ -24,7 +24,9 @@ struct AllegroHandTask {   // reference allegro_hand.py (16 dofs, all driven, :2
     static constexpr int ND = 16, NACT = 16, NTIPS = 0, NFULL = 88;
 };
 static_assert(ShadowHandTask::M::ND == ShadowHandTask::ND && ShadowHandTask::M::NSENS == ShadowHandTask::NTIPS, "shadow hand model");
-static_assert(AllegroHandTask::M::ND == AllegroHandTask::ND && AllegroHandTask::M::NSENS == AllegroHandTask::NTIPS, "allegro hand model");
+// (the Allegro task observes no fingertip force; a run-time variant of the model may still carry force sensors for gym.acquire_force_sensor_tensor --
+//  the reference's dextreme task puts them on the four fingertips, tasks/dextreme/allegro_hand_dextreme.py:264-269)
+static_assert(AllegroHandTask::M::ND == AllegroHandTask::ND && AllegroHandTask::NTIPS == 0, "allegro hand model");
 
 MI_HD float hand_u(uint32_t seed, uint32_t genv, uint32_t ep, uint32_t k) { return 2.f * uniform01(seed, genv, ep, k) - 1.f; }
 // random_force_prob (:198-199, 642-643): log-uniform in force_prob_range

@@ -998,9 +998,14 @@ class Gym:
         else:
             from ...tasks.locomotion import loco_params_from_cfg
             tp = loco_params_from_cfg(cfg, asset.model_name, float(poses[0, 2]))
-        if asset.variant:                      # compiled once per distinct model, cached (isaacgymenvs_amd/_variants/<hash>/)
+        own_sensors = None
+        if asset.task in _HAND_TASKS and asset.sensors and not asset.engine_sensor_bodies:
+            # force sensors on a hand whose compiled model has none (the Allegro hand of allegro_hand.py observes no fingertip forces; the
+            # dextreme task creates one per fingertip, tasks/dextreme/allegro_hand_dextreme.py:264-269): a variant of the model that carries them
+            own_sensors = [int(asset.body_dyn[b]) for b in asset.sensors]
+        if asset.variant or own_sensors is not None:      # compiled once per distinct model, cached (isaacgymenvs_amd/_variants/<hash>/)
             from ...assets import runtime
-            lib_path = runtime.variant_library(asset.model_name, asset.spec, sim.device)
+            lib_path = runtime.variant_library(asset.model_name, asset.spec, sim.device, sensors=own_sensors)
         sim.engine = native.Engine(asset.task, p, tp, n, sim.device, terrain=terrain, lib_path=lib_path)
         if sim.device != "cpu":
             native.select_multi_wave(sim.engine, asset.task, n)        # the launch shape (and with it the solver order) make() would pick
@@ -1038,7 +1043,8 @@ class Gym:
                     t["actor_scale"][:, 4] = dm / float(asset.extras["tendon_damping"])
         # (BallBalance: the task's three sensors sit on the tray, :254-260 -- the engine computes exactly those from the tray's momentum balance;
         #  its `sensor` bodies are the lower legs the attractors hold)
-        if asset.task not in ("BallBalance", "Articulation") and asset.sensors and asset.sensors != asset.engine_sensor_bodies[:len(asset.sensors)]:
+        if asset.task not in ("BallBalance", "Articulation") and own_sensors is None and asset.sensors and \
+                asset.sensors != asset.engine_sensor_bodies[:len(asset.sensors)]:
             raise NotImplementedError(f"force sensors on bodies {asset.sensors}: the compiled {asset.model_name} model has them on "
                                       f"{asset.engine_sensor_bodies}")
         self._flush_props(sim)                   # what a setup-time randomisation wrote before the engine existed (shadow_hand.py:224-226)
