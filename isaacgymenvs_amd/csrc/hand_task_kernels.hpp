@@ -51,10 +51,10 @@ struct HandDevRed {
     }
 };
 // post_physics_step (shadow_hand.py:710-715): hand_post_env (tasks/hand_task.hpp), ONE WAVE PER (64 envs, column group) -- blockIdx.y is the
-// group (HandCols: eight of them since round 4 -- dof positions | velocities | joint forces | object / goal + the reward | fingertip states in two | force-torques |
-// actions).  Round 3 ran one lane per env over
+// group (HandCols: dof positions | velocities | joint forces | object / goal + the reward | force-torques | actions | one per fingertip: its wave
+// walks the fingertip's chain itself).  Round 3 ran one lane per env over
 // all 211 columns: 256 waves at 16384 envs, each with ~150 loads, 4.5 k vector instructions and a 55 KB staging tile (45 us, 61 % of it
-// waiting); four times the waves with a quarter of the chain each fill the chip's 1024 SIMDs.  The fingertip states come from hand_tips_kernel.
+// waiting); many more waves with a fraction of the chain each fill the chip's 1024 SIMDs.
 template <class HT, int G>
 __device__ __forceinline__ void hand_post_group(const View& v, const HandView& hv, const HandParams& p, float* stage) {
     using C = HandCols<HT>;
@@ -83,19 +83,17 @@ __device__ __forceinline__ void hand_post_group(const View& v, const HandView& h
     }
     if constexpr (G == 1) { if (valid) hand_post_store(v, hv, p, e, o); }
 }
+template <class HT, int G0 = 0>
+__device__ __forceinline__ void hand_post_dispatch(const int g, const View& v, const HandView& hv, const HandParams& p, float* stage) {
+    if constexpr (G0 < HandCols<HT>::NGROUPS) {
+        if (g == G0) hand_post_group<HT, G0>(v, hv, p, stage);          // wave-uniform
+        else hand_post_dispatch<HT, G0 + 1>(g, v, hv, p, stage);
+    }
+}
 template <class HT>
 __global__ __launch_bounds__(64) void hand_post_kernel(View v, HandView hv, HandParams p) {
     __shared__ float stage[HandCols<HT>::max_count() * 65];
-    switch (blockIdx.y) {           // wave-uniform
-        case 0: hand_post_group<HT, 0>(v, hv, p, stage); break;
-        case 1: hand_post_group<HT, 1>(v, hv, p, stage); break;
-        case 2: hand_post_group<HT, 2>(v, hv, p, stage); break;
-        case 3: hand_post_group<HT, 3>(v, hv, p, stage); break;
-        case 4: hand_post_group<HT, 4>(v, hv, p, stage); break;
-        case 5: hand_post_group<HT, 5>(v, hv, p, stage); break;
-        case 6: hand_post_group<HT, 6>(v, hv, p, stage); break;
-        default: hand_post_group<HT, 7>(v, hv, p, stage); break;
-    }
+    hand_post_dispatch<HT>((int)blockIdx.y, v, hv, p, stage);
 }
 // observationType openai / full_no_vel / full (shadow_hand.py:472-526): column subsets of the full state
 template <class HT>
@@ -131,7 +129,8 @@ hipError_t launch_step_hand(const View& v, const HandView& hv, const SimParams& 
     hipLaunchKernelGGL(hand_pre_kernel<HT>, dim3((v.N + 63) / 64), dim3(64), 0, s, v, hv, p, HandActLimits<HT>::of(p), actions, step_counter);
     hipError_t e = hand_substeps<HT>(v, hv, P, p, cfi * P.substeps, s);
     if (e != hipSuccess) return e;
-    if constexpr (HT::NTIPS > 0) hipLaunchKernelGGL(hand_tips_kernel<HT>, dim3((v.N + 63) / 64, HT::NTIPS), dim3(64), 0, s, v, hv, p);
+    // (the fingertip states: by the post kernel's fingertip groups since round 4 -- hand_tips_kernel stays for gym.simulate below and for the A/B)
+    if constexpr (HT::NTIPS > 0) { if (hv.tips_in_post == 0) hipLaunchKernelGGL(hand_tips_kernel<HT>, dim3((v.N + 63) / 64, HT::NTIPS), dim3(64), 0, s, v, hv, p); }
     hipLaunchKernelGGL(hand_post_kernel<HT>, dim3((v.N + 63) / 64, HandCols<HT>::NGROUPS), dim3(64), 0, s, v, hv, p);
     if (p.obs_type != 0) hipLaunchKernelGGL(hand_obs_select_kernel<HT>, dim3((v.N * p.num_obs + 255) / 256), dim3(256), 0, s, v, hv, p);
     hipLaunchKernelGGL(hand_finalize_kernel<HT>, dim3(1), dim3(64), 0, s, hv, p);

@@ -162,7 +162,7 @@ MI_HD void hand_pre_env(const View& v, const HandView& hv, const HandParams& p, 
 // the fingertip, so a wave walks one chain (wrist + one finger, 6 or 7 hinges) and 5 N / 64 waves fill the chip, where the post kernel's
 // one lane per env walked all five chains in turn on 256 waves (latency-bound: 40 of its 61 us at 16384 envs).
 template <class HT, int K>
-MI_HD void hand_tip(const View& v, const HandView& hv, const HandParams& p, const int e) {
+MI_HD void hand_tip_state(const View& v, const HandParams& p, const int e, float (&o)[13]) {
     constexpr int ND = HT::ND, tip = HT::M::sens_body[K];
     const int N = v.N;
     HandSim<typename HT::M> sim;
@@ -171,8 +171,13 @@ MI_HD void hand_tip(const View& v, const HandView& hv, const HandParams& p, cons
     sfor<ND>([&](auto D) MI_LAMBDA {
         if constexpr (HandSim<typename HT::M>::is_ancestor_or_self(HT::M::dof_body[D], tip)) { sim.q[D] = v.dof[D * N + e]; sim.qd[D] = v.dof[(ND + D) * N + e]; }
     });
-    float o[13];
     sim.template fingertip_state<K>(o);
+}
+template <class HT, int K>
+MI_HD void hand_tip(const View& v, const HandView& hv, const HandParams& p, const int e) {
+    const int N = v.N;
+    float o[13];
+    hand_tip_state<HT, K>(v, p, e, o);
     sfor<13>([&](auto I_) MI_LAMBDA { hv.fingertip[(K * 13 + I_) * N + e] = o[I_]; });
 }
 // post_physics_step (shadow_hand.py:710-715): progress++, compute_observations (full_state), compute_reward; the fingertip states come
@@ -183,16 +188,17 @@ struct HandPostOut { float r, succ; long long rs, gr, prog; };
 // each with an eighth of the loads, of the dependency chain and of the row write-out (hand_task_kernels.hpp); the host runs all of them at once
 // (GROUP = -1).  Group 1 also computes the reward.
 //   0: dof positions | 4: dof velocities | 5: joint forces | 1: object pose / velocities, goal pose, quaternion difference + compute_hand_reward |
-//   2: the first three fingertip states | 6: the other two | 3: fingertip force-torques | 7: the actions
+//   3: fingertip force-torques | 2: the actions | 6 + t: the state of fingertip t -- on the device the wave of that group walks the fingertip's chain
+//   itself (hand_tip_state: what hand_tips_kernel did in a launch of its own until round 4) and also writes the `fingertip` tensor
 template <class HT> struct HandCols {
     static constexpr int ND = HT::ND, O_OBJ = 3 * ND, O_GOAL = O_OBJ + 13, O_TIPS = O_GOAL + 11, O_FT = O_TIPS + 13 * HT::NTIPS, O_ACT = O_FT + 6 * HT::NTIPS;
     static_assert(O_ACT + HT::NACT == HT::NFULL, "full_state width");
-    static constexpr int NGROUPS = 8, TIPS_A = (HT::NTIPS + 1) / 2;      // fingertips of group 2; the rest in group 6
+    static constexpr int G_TIP0 = 6, NGROUPS = G_TIP0 + HT::NTIPS;
     static constexpr int first(int g) {
-        return g == 0 ? 0 : g == 4 ? ND : g == 5 ? 2 * ND : g == 1 ? O_OBJ : g == 2 ? O_TIPS : g == 6 ? O_TIPS + 13 * TIPS_A : g == 3 ? O_FT : O_ACT;
+        return g == 0 ? 0 : g == 4 ? ND : g == 5 ? 2 * ND : g == 1 ? O_OBJ : g == 3 ? O_FT : g == 2 ? O_ACT : O_TIPS + 13 * (g - G_TIP0);
     }
     static constexpr int count(int g) {
-        return (g == 0 || g == 4 || g == 5) ? ND : g == 1 ? O_TIPS - O_OBJ : g == 2 ? 13 * TIPS_A : g == 6 ? 13 * (HT::NTIPS - TIPS_A) : g == 3 ? 6 * HT::NTIPS : HT::NACT;
+        return (g == 0 || g == 4 || g == 5) ? ND : g == 1 ? O_TIPS - O_OBJ : g == 3 ? 6 * HT::NTIPS : g == 2 ? HT::NACT : 13;
     }
     static constexpr int max_count() { int m = 0; for (int g = 0; g < NGROUPS; ++g) m = count(g) > m ? count(g) : m; return m; }
     static constexpr bool covers() { int n = 0; for (int g = 0; g < NGROUPS; ++g) n += count(g); return n == HT::NFULL; }
@@ -204,8 +210,7 @@ MI_HD HandPostOut hand_post_env(const View& v, const HandView& hv, const HandPar
     constexpr int ND = HT::ND;
     using C = HandCols<HT>;
     constexpr bool ALL = GROUP < 0;
-    constexpr bool GP = ALL || GROUP == 0, GV = ALL || GROUP == 4, GF = ALL || GROUP == 5, G1 = ALL || GROUP == 1, GTA = ALL || GROUP == 2, GTB = ALL || GROUP == 6,
-                   GS = ALL || GROUP == 3, GA = ALL || GROUP == 7;
+    constexpr bool GP = ALL || GROUP == 0, GV = ALL || GROUP == 4, GF = ALL || GROUP == 5, G1 = ALL || GROUP == 1, GS = ALL || GROUP == 3, GA = ALL || GROUP == 2;
     const int N = v.N;
     // every input is loaded before the first observation is stored: the stores below may alias these arrays as far as the
     // compiler knows, and a load that has to wait for them is a fully exposed memory round trip for a lone wave
@@ -215,7 +220,16 @@ MI_HD HandPostOut hand_post_env(const View& v, const HandView& hv, const HandPar
     if constexpr (GF) sfor<ND>([&](auto K) MI_LAMBDA { dff[K] = v.dof_force[K * N + e]; });
     float tips[HT::NTIPS > 0 ? HT::NTIPS : 1][13];
     sfor<HT::NTIPS>([&](auto T_) MI_LAMBDA {
-        if constexpr ((T_ < C::TIPS_A) ? GTA : GTB) sfor<13>([&](auto K) MI_LAMBDA { tips[T_][K] = hv.fingertip[(T_ * 13 + K) * N + e]; });
+        constexpr int t = T_;
+        if constexpr (ALL) sfor<13>([&](auto K) MI_LAMBDA { tips[t][K] = hv.fingertip[(t * 13 + K) * N + e]; });     // (the host ran hand_tip first)
+        else if constexpr (GROUP == C::G_TIP0 + t) {
+            if (hv.tips_in_post != 0) {
+                hand_tip_state<HT, t>(v, p, e, tips[t]);
+                if (valid) sfor<13>([&](auto K) MI_LAMBDA { hv.fingertip[(t * 13 + K) * N + e] = tips[t][K]; });
+            } else {
+                sfor<13>([&](auto K) MI_LAMBDA { tips[t][K] = hv.fingertip[(t * 13 + K) * N + e]; });
+            }
+        }
     });
     float os[13], gp[7], act[HT::NACT], sns[HT::NTIPS > 0 ? 6 * HT::NTIPS : 1];
     if constexpr (GS) sfor<6 * HT::NTIPS>([&](auto K) MI_LAMBDA { sns[K] = v.sensor[K * N + e]; });
@@ -248,7 +262,7 @@ MI_HD HandPostOut hand_post_env(const View& v, const HandView& hv, const HandPar
         sfor<4>([&](auto K) MI_LAMBDA { emit(C::O_GOAL + 7 + K, qd4[K]); });
     }
     sfor<HT::NTIPS>([&](auto T_) MI_LAMBDA {
-        if constexpr ((T_ < C::TIPS_A) ? GTA : GTB) sfor<13>([&](auto K) MI_LAMBDA { emit(C::O_TIPS + T_ * 13 + K, tips[T_][K]); });
+        if constexpr (ALL || GROUP == C::G_TIP0 + T_) sfor<13>([&](auto K) MI_LAMBDA { emit(C::O_TIPS + T_ * 13 + K, tips[T_][K]); });
     });
     if constexpr (GS) sfor<6 * HT::NTIPS>([&](auto K) MI_LAMBDA { emit(C::O_FT + K, p.force_torque_obs_scale * sns[K]); });
     if constexpr (GA) sfor<HT::NACT>([&](auto K) MI_LAMBDA { emit(C::O_ACT + K, act[K]); });

@@ -170,3 +170,34 @@ def test_shadow_hand_first_steps_at_the_benchmark_size(offset, k):
         assert d[ok][:, force_cols].max() < 2e-2 * fmax * (1 + step), (step, d[ok][:, force_cols].max(), fmax)
         np.testing.assert_array_equal(env.reset_buf[sl].cpu().numpy()[ok], o_reset[ok])
         np.testing.assert_allclose(env.rew_buf[sl].cpu().numpy()[ok], o_rew[ok], atol=0.05 * (1 + step), rtol=1e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,obs_type", [(16384, "full_state"), (200, "full_state"), (328, "openai")])
+def test_shadow_hand_fingertip_states_from_the_post_kernels_own_groups_are_bit_identical(n, obs_type):
+    """Since round 4 the post kernel has one column group per fingertip whose wave walks the fingertip's chain itself (csrc/tasks/hand_task.hpp
+    hand_tip_state) instead of reading what hand_tips_kernel wrote in a launch of its own (option tips_in_post = 0): the same function on the
+    same state -- observations, rewards, resets and the `fingertip` tensor are bit-identical over a rollout with resets."""
+    import isaacgymenvs_amd
+    from isaacgymenvs_amd.utils.config import compose
+    envs = []
+    for tip in (1, 0):
+        cfg = compose(overrides=["task=ShadowHand"])
+        cfg["task"]["env"]["numEnvs"] = n
+        cfg["task"]["env"]["observationType"] = obs_type
+        env = isaacgymenvs_amd.make(seed=11, task="ShadowHand", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True, cfg=cfg)
+        assert int(env.engine.get_option("tips_in_post")) == 1
+        env.engine.set_option("tips_in_post", tip)
+        envs.append(env)
+    a, b = envs
+    g = torch.Generator(device=DEV).manual_seed(0)
+    resets = 0
+    for step in range(60):
+        act = torch.rand((n, 20), device=DEV, generator=g) * 2 - 1
+        oa, ra, da, _ = a.step(act)
+        ob, rb, db, _ = b.step(act)
+        assert torch.equal(oa["obs"], ob["obs"]) and torch.equal(ra, rb) and torch.equal(da, db), step
+        resets += int(da.sum())
+    for k in ("fingertip_state", "dof_state", "object_state", "obs_buf", "successes", "progress_buf"):
+        assert torch.equal(a.engine.tensors[k], b.engine.tensors[k]), k
+    assert float(a.engine.tensors["fingertip_state"].abs().max()) > 0.1 and resets > 0
