@@ -108,6 +108,7 @@ extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const 
     memset(&e->qv, 0, sizeof(e->qv)); memset(&e->iv, 0, sizeof(e->iv)); memset(&e->bv, 0, sizeof(e->bv)); memset(&e->hv, 0, sizeof(e->hv));
     e->hv.drive_clamp = 1;
     e->hv.tips_in_post = 1;
+    e->hv.pre_parts = 4;
     Layout L;
     build_layout(t, num_envs, L, &e->v, (char*)arena, nobs);
     build_task_extras(t, num_envs, L, e, (char*)arena);

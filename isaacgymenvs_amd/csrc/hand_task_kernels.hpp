@@ -19,6 +19,19 @@ __global__ __launch_bounds__(64) void hand_pre_kernel(View v, HandView hv, HandP
     hand_pre_env<HT>(v, hv, p, al, actions_in, step_counter, e);
 }
 
+// the same on four lanes per env (hand_pre_env_part): 4 N / 64 waves with a quarter of the loads and of the dependency chain each (round 3 / 4: 256
+// waves at 16384 envs, 75 % of their cycles waiting).  Real block rb = 8 m + x takes quarter m % 4 of the 64-env block 8 (m / 4) + x, which keeps
+// every env on the XCD (x) its sub-step workgroup runs on.
+template <class HT>
+__global__ __launch_bounds__(64) void hand_pre4_kernel(View v, HandView hv, HandParams p, HandActLimits<HT> al, const float* __restrict__ actions_in,
+                                                       unsigned step_counter) {
+    const int x = blockIdx.x & 7, m = blockIdx.x >> 3;
+    const int vb = 8 * (m >> 2) + x, t = (m & 3) * 16 + ((int)threadIdx.x >> 2);
+    const int e = post_env_index<HandSim<typename HT::M>::LANES>(vb, t, v.N);
+    if (e >= v.N) return;
+    hand_pre_env_part<HT>(v, hv, p, al, actions_in, step_counter, e, (int)threadIdx.x & 3);
+}
+
 // gym.refresh_rigid_body_state_tensor (shadow_hand.py:440,456-457) for the five fingertip bodies: ONE THREAD PER (env, fingertip) -- blockIdx.y is
 // the fingertip, so a wave walks one chain (wrist + one finger, 6 or 7 hinges) and 5 N / 64 waves fill the chip, where the post kernel's
 // one lane per env walked all five chains in turn on 256 waves (latency-bound: 40 of its 61 us at 16384 envs).
@@ -126,7 +139,12 @@ hipError_t hand_substeps(const View& v, const HandView& hv, const SimParams& P, 
 template <class HT>
 hipError_t launch_step_hand(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, const float* actions, int cfi,
                             unsigned step_counter, hipStream_t s) {
-    hipLaunchKernelGGL(hand_pre_kernel<HT>, dim3((v.N + 63) / 64), dim3(64), 0, s, v, hv, p, HandActLimits<HT>::of(p), actions, step_counter);
+    if (hv.pre_parts == 4) {
+        const int nvb = (v.N + 63) / 64;
+        hipLaunchKernelGGL(hand_pre4_kernel<HT>, dim3(((nvb + 7) / 8) * 32), dim3(64), 0, s, v, hv, p, HandActLimits<HT>::of(p), actions, step_counter);
+    } else {
+        hipLaunchKernelGGL(hand_pre_kernel<HT>, dim3((v.N + 63) / 64), dim3(64), 0, s, v, hv, p, HandActLimits<HT>::of(p), actions, step_counter);
+    }
     hipError_t e = hand_substeps<HT>(v, hv, P, p, cfi * P.substeps, s);
     if (e != hipSuccess) return e;
     // (the fingertip states: by the post kernel's fingertip groups since round 4 -- hand_tips_kernel stays for gym.simulate below and for the A/B)

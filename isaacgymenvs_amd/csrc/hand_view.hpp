@@ -25,6 +25,7 @@ struct HandView {
                            //        tendon limit stiffness / damping, object mass, object size; 1 = the model's own values
     float* limit_shift;    // [2*ND][N] per-env shifts of the lower / upper joint limits (`actor_params.hand.dof_properties.lower / upper`)
     int* ndropped;         // [N] contacts refused since init because all slots were taken (diagnostic; a manifold's 5th+ contact does not count)
+    int pre_parts = 4;     // lanes per env of the pre kernel (option "pre_parts": 4 = hand_pre4_kernel, 1 = one lane per env, the A/B of round 4)
     int tips_in_post = 1;  // the post kernel's fingertip groups walk the fingertip chains themselves (option "tips_in_post"; 0: hand_tips_kernel in a launch of its own, the A/B of round 4)
     int drive_clamp = 1;   // the position drives deliver at most M::dof_force_limit (option "drive_force_limit"; core/hand_engine.hpp drive_clamp_update)
 };

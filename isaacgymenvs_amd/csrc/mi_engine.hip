@@ -362,6 +362,7 @@ extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const 
     memset(&e->hv, 0, sizeof(e->hv));
     e->hv.drive_clamp = 1;
     e->hv.tips_in_post = 1;
+    e->hv.pre_parts = 4;
     if (is_hand_task(t)) build_hand_layout(t, num_envs, L, &e->hv, (char*)arena);
     memset(&e->qv, 0, sizeof(e->qv));
     if (t == T_QUADCOPTER) build_quad_layout(num_envs, L, &e->qv, (char*)arena);
@@ -417,6 +418,11 @@ extern "C" int mi_engine_set_option(MiEngine* e, const char* key, double value) 
     }
     // limb-per-wave locomotion (Ant): 1 = post_physics_step runs on one wave of every sub-step workgroup at the end of the step's last
     // sub-step launch (mw_kernels.hpp), 0 (default) = in loco_post_kernel as for the one-wave form
+    if (!strcmp(key, "pre_parts")) {           // hands: lanes per env of the pre kernel, 4 (default) or 1
+        if (!is_hand_task(e->task)) return fail("pre_parts: a hand-task option");
+        if (value != 1 && value != 4) return fail("pre_parts: 1 or 4");
+        e->hv.pre_parts = (int)value; return 0;
+    }
     if (!strcmp(key, "tips_in_post")) {        // hands: fingertip states by the post kernel's fingertip groups (1, default) or by hand_tips_kernel (0)
         if (!is_hand_task(e->task)) return fail("tips_in_post: a hand-task option");
         e->hv.tips_in_post = value != 0 ? 1 : 0; return 0;
@@ -469,6 +475,7 @@ extern "C" int mi_engine_get_option(const MiEngine* e, const char* key, double* 
     if (!strcmp(key, "multi_wave")) { *out = e->v.mw; return 0; }
     if (!strcmp(key, "drive_force_limit")) { *out = is_hand_task(e->task) ? e->hv.drive_clamp : 0; return 0; }
     if (!strcmp(key, "tips_in_post")) { *out = is_hand_task(e->task) ? e->hv.tips_in_post : 0; return 0; }
+    if (!strcmp(key, "pre_parts")) { *out = is_hand_task(e->task) ? e->hv.pre_parts : 0; return 0; }
     if (!strcmp(key, "fused_post")) { *out = e->v.fused_post; return 0; }
     if (!strcmp(key, "fused_sub")) { *out = e->v.fused_sub; return 0; }
     if (!strcmp(key, "steps")) { *out = (double)e->steps; return 0; }

@@ -49,12 +49,11 @@ MI_HD void hand_reset_goal(const View& v, const HandView& hv, const HandParams& 
     hv.reset_goal[e] = 0;
 }
 
-// reset_idx (shadow_hand.py:604-668, allegro_hand.py:526-590) for one env
+// reset_idx (shadow_hand.py:604-668, allegro_hand.py:526-590) for one env, in two parts: everything but the hand's dofs ...
 template <class HT>
-MI_HD void hand_reset_env(const View& v, const HandView& hv, const HandParams& p, int e, uint32_t genv) {
+MI_HD void hand_reset_env_object(const View& v, const HandView& hv, const HandParams& p, int e, uint32_t genv, const uint32_t ep) {
     MI_NO_CONTRACT
     const int N = v.N, ND = HT::ND;
-    const uint32_t ep = (uint32_t)v.episode[e];
     auto rf = [&](int k) MI_LAMBDA { return hand_u(v.seed, genv, ep, (uint32_t)k); };   // rand_floats[:, k], U(-1, 1)
     hand_reset_goal(v, hv, p, e, genv);
     // object: initial pose + position noise, random rotation, zero velocity
@@ -70,18 +69,6 @@ MI_HD void hand_reset_env(const View& v, const HandView& hv, const HandParams& p
     }
     sfor<4>([&](auto K) MI_LAMBDA { hv.object_state[(3 + K) * N + e] = q[K]; });
     sfor<6>([&](auto K) MI_LAMBDA { hv.object_state[(7 + K) * N + e] = 0.f; });
-    // hand: default pose (0) + noise * random point of the joint range (:642-651)
-    sfor<ND>([&](auto D) MI_LAMBDA {
-        constexpr int d = D;
-        const float delta_max = HT::M::dof_upper[d] - 0.f, delta_min = HT::M::dof_lower[d] - 0.f;
-        const float rand_delta = delta_min + (delta_max - delta_min) * 0.5f * (rf(5 + d) + 1.f);
-        const float pos = 0.f + p.reset_dof_pos_noise * rand_delta;
-        v.dof[d * N + e] = pos;
-        v.dof[(ND + d) * N + e] = 0.f + p.reset_dof_vel_noise * rf(5 + ND + d);
-        hv.prev_targets[d * N + e] = pos;
-        hv.cur_targets[d * N + e] = pos;
-        v.laml[d * N + e] = 0.f;
-    });
     sfor<3>([&](auto K) MI_LAMBDA { hv.rb_force[K * N + e] = 0.f; hv.obj_force[K * N + e] = 0.f; });       // :616
     hv.force_prob[e] = hand_force_prob(p, uniform01(v.seed, genv, ep, 5 + 2 * ND));                           // :642-643
     v.episode[e] = (int)ep + 1;
@@ -89,22 +76,78 @@ MI_HD void hand_reset_env(const View& v, const HandView& hv, const HandParams& p
     v.reset[e] = 0;
     hv.successes[e] = 0.f;
 }
+// ... and one dof: default pose (0) + noise * random point of the joint range (:642-651); returns the position (the new drive target)
+template <class HT>
+MI_HD float hand_reset_dof(const View& v, const HandView& hv, const HandParams& p, int e, uint32_t genv, const uint32_t ep, const int d, const float lower,
+                           const float upper) {
+    MI_NO_CONTRACT
+    const int N = v.N, ND = HT::ND;
+    auto rf = [&](int k) MI_LAMBDA { return hand_u(v.seed, genv, ep, (uint32_t)k); };
+    const float delta_max = upper - 0.f, delta_min = lower - 0.f;
+    const float rand_delta = delta_min + (delta_max - delta_min) * 0.5f * (rf(5 + d) + 1.f);
+    const float pos = 0.f + p.reset_dof_pos_noise * rand_delta;
+    v.dof[d * N + e] = pos;
+    v.dof[(ND + d) * N + e] = 0.f + p.reset_dof_vel_noise * rf(5 + ND + d);
+    hv.prev_targets[d * N + e] = pos;
+    hv.cur_targets[d * N + e] = pos;
+    v.laml[d * N + e] = 0.f;
+    return pos;
+}
+template <class HT>
+MI_HD void hand_reset_env(const View& v, const HandView& hv, const HandParams& p, int e, uint32_t genv) {
+    const uint32_t ep = (uint32_t)v.episode[e];
+    sfor<HT::ND>([&](auto D) MI_LAMBDA { hand_reset_dof<HT>(v, hv, p, e, genv, ep, (int)D, HT::M::dof_lower[D], HT::M::dof_upper[D]); });
+    hand_reset_env_object<HT>(v, hv, p, e, genv, ep);
+}
 
 // joint limits of the ACTUATED dofs, in actuator order: looked up on the host (HandParams::actuated is a run-time table; indexing the model's
 // constant tables with it on the device would either copy them to scratch or walk a 24-way select per action -- ~900 of this step's ~1000 vector /
 // scalar instructions per wave were that walk)
 template <class HT> struct HandActLimits {
+    static constexpr int NX = HT::ND - HT::NACT, NXA = NX > 0 ? NX : 1;       // dofs without an actuator (the Shadow Hand's four coupled distal joints)
     float lo[HT::NACT], up[HT::NACT];
+    int xdof[NXA];
+    float xlo[NXA], xup[NXA];
     static HandActLimits of(const HandParams& p) {
         HandActLimits a{};
+        bool driven[HT::ND] = {};
         for (int k = 0; k < HT::NACT; ++k) {
             const int d = p.actuated[k];
             a.lo[k] = (d >= 0 && d < HT::ND) ? HT::M::dof_lower[d] : 0.f;
             a.up[k] = (d >= 0 && d < HT::ND) ? HT::M::dof_upper[d] : 0.f;
+            if (d >= 0 && d < HT::ND) driven[d] = true;
         }
+        for (int d = 0, j = 0; d < HT::ND && j < NX; ++d)
+            if (!driven[d]) { a.xdof[j] = d; a.xlo[j] = HT::M::dof_lower[d]; a.xup[j] = HT::M::dof_upper[d]; ++j; }
         return a;
     }
 };
+// random forces on the object (shadow_hand.py:700-708)
+MI_HD void hand_random_force(const View& v, const HandView& hv, const HandParams& p, const unsigned step_counter, const int e, const uint32_t genv) {
+    MI_NO_CONTRACT
+    const int N = v.N;
+    if (p.force_scale > 0.f) {   // random forces on the object (:700-708)
+        const float decay = powf(p.force_decay, p.dt / p.force_decay_interval);
+        float f[3];
+        sfor<3>([&](auto K) MI_LAMBDA { f[K] = hv.rb_force[K * N + e] * decay; });
+        const uint32_t sk = step_counter | 0x80000000u, sd = v.seed ^ 0x9E3779B9u;
+        if (uniform01(sd, genv, sk, 0) < hv.force_prob[e]) {
+            // torch.randn(3) * object mass * force_scale; Box-Muller on the engine's counter-based uniforms
+            const float u1 = fmaxf(uniform01(sd, genv, sk, 1), 1e-7f), u2 = uniform01(sd, genv, sk, 2);
+            const float u3 = fmaxf(uniform01(sd, genv, sk, 3), 1e-7f), u4 = uniform01(sd, genv, sk, 4);
+            const float r1 = sqrtf(-2.f * logf(u1)), r2 = sqrtf(-2.f * logf(u3));
+            const float k = p.cube_mass * p.force_scale;
+            f[0] = r1 * cosf(6.283185307179586f * u2) * k;
+            f[1] = r1 * sinf(6.283185307179586f * u2) * k;
+            f[2] = r2 * cosf(6.283185307179586f * u4) * k;
+        }
+        float q[4], fw[3];
+        sfor<4>([&](auto K) MI_LAMBDA { q[K] = hv.object_state[(3 + K) * N + e]; });
+        quat_rotate_s(q, f, 1.f, fw);                                                      // LOCAL_SPACE -> world at application time
+        sfor<3>([&](auto K) MI_LAMBDA { hv.rb_force[K * N + e] = f[K]; hv.obj_force[K * N + e] = fw[K]; });
+    }
+}
+
 // pre_physics_step (shadow_hand.py:670-698): deferred resets, then actions -> targets
 template <class HT>
 MI_HD void hand_pre_env(const View& v, const HandView& hv, const HandParams& p, const HandActLimits<HT>& al, const float* __restrict__ actions_in,
@@ -136,26 +179,66 @@ MI_HD void hand_pre_env(const View& v, const HandView& hv, const HandParams& p, 
         hv.cur_targets[d * N + e] = t;
         hv.prev_targets[d * N + e] = t;                                                     // :697
     });
-    if (p.force_scale > 0.f) {   // random forces on the object (:700-708)
-        const float decay = powf(p.force_decay, p.dt / p.force_decay_interval);
-        float f[3];
-        sfor<3>([&](auto K) MI_LAMBDA { f[K] = hv.rb_force[K * N + e] * decay; });
-        const uint32_t sk = step_counter | 0x80000000u, sd = v.seed ^ 0x9E3779B9u;
-        if (uniform01(sd, genv, sk, 0) < hv.force_prob[e]) {
-            // torch.randn(3) * object mass * force_scale; Box-Muller on the engine's counter-based uniforms
-            const float u1 = fmaxf(uniform01(sd, genv, sk, 1), 1e-7f), u2 = uniform01(sd, genv, sk, 2);
-            const float u3 = fmaxf(uniform01(sd, genv, sk, 3), 1e-7f), u4 = uniform01(sd, genv, sk, 4);
-            const float r1 = sqrtf(-2.f * logf(u1)), r2 = sqrtf(-2.f * logf(u3));
-            const float k = p.cube_mass * p.force_scale;
-            f[0] = r1 * cosf(6.283185307179586f * u2) * k;
-            f[1] = r1 * sinf(6.283185307179586f * u2) * k;
-            f[2] = r2 * cosf(6.283185307179586f * u4) * k;
+    hand_random_force(v, hv, p, step_counter, e, genv);
+}
+
+// pre_physics_step on FOUR LANES PER ENV (the device kernel since round 4): lane `part` of an env takes a quarter of the actuators -- their actions
+// (consecutive floats of the env's row: the four lanes of an env and the envs of a wave read one contiguous stretch), their dofs' part of a
+// deferred reset -- and, lane 0, everything that is not per dof (object, goal, flags, the random force).  Every flag is loaded before any lane
+// stores one (one wave, program order).  Which actuators / limits a lane has is a select over the four parts of the host's tables (compile-time
+// indices: the tables stay in scalar registers).  Same arithmetic per element as hand_pre_env: bit-identical buffers.
+template <class T> MI_HD T hand_sel4(const int part, const T x0, const T x1, const T x2, const T x3) {
+    return part == 0 ? x0 : part == 1 ? x1 : part == 2 ? x2 : x3;
+}
+template <class HT>
+MI_HD void hand_pre_env_part(const View& v, const HandView& hv, const HandParams& p, const HandActLimits<HT>& al, const float* __restrict__ actions_in,
+                             const unsigned step_counter, const int e, const int part) {
+    MI_NO_CONTRACT
+    constexpr int NACT = HT::NACT, APP = NACT / 4, NX = HandActLimits<HT>::NX;
+    static_assert(NACT % 4 == 0 && NX <= 4, "a quarter of the actuators and at most one undriven dof per lane");
+    const int N = v.N;
+    const uint32_t genv = (uint32_t)(v.env_offset + e);
+    const bool rst = v.reset[e] != 0;
+    const bool rgoal = !rst && hv.reset_goal[e] != 0;
+    const uint32_t ep = (uint32_t)v.episode[e];
+    float raw_act[APP];
+    sfor<APP>([&](auto K) MI_LAMBDA { raw_act[K] = actions_in[(size_t)e * NACT + part * APP + K]; });
+    if (v.act_noise.dist != 0)
+        sfor<APP>([&](auto K) MI_LAMBDA { raw_act[K] = apply_noise(v.act_noise, v.seed, genv, v.step, 1u, (uint32_t)(part * APP + K), raw_act[K]); });
+    if constexpr (NX > 0) {
+        if (rst && part < NX) {
+            const int d = hand_sel4(part, al.xdof[0], al.xdof[NX > 1 ? 1 : 0], al.xdof[NX > 2 ? 2 : 0], al.xdof[NX > 3 ? 3 : 0]);
+            const float lo = hand_sel4(part, al.xlo[0], al.xlo[NX > 1 ? 1 : 0], al.xlo[NX > 2 ? 2 : 0], al.xlo[NX > 3 ? 3 : 0]);
+            const float up = hand_sel4(part, al.xup[0], al.xup[NX > 1 ? 1 : 0], al.xup[NX > 2 ? 2 : 0], al.xup[NX > 3 ? 3 : 0]);
+            hand_reset_dof<HT>(v, hv, p, e, genv, ep, d, lo, up);
         }
-        float q[4], fw[3];
-        sfor<4>([&](auto K) MI_LAMBDA { q[K] = hv.object_state[(3 + K) * N + e]; });
-        quat_rotate_s(q, f, 1.f, fw);                                                      // LOCAL_SPACE -> world at application time
-        sfor<3>([&](auto K) MI_LAMBDA { hv.rb_force[K * N + e] = f[K]; hv.obj_force[K * N + e] = fw[K]; });
     }
+    sfor<APP>([&](auto K) MI_LAMBDA {
+        constexpr int k = K;
+        const int a = part * APP + k;
+        const int d = hand_sel4(part, p.actuated[k], p.actuated[APP + k], p.actuated[2 * APP + k], p.actuated[3 * APP + k]);
+        const float lo = hand_sel4(part, al.lo[k], al.lo[APP + k], al.lo[2 * APP + k], al.lo[3 * APP + k]);
+        const float up = hand_sel4(part, al.up[k], al.up[APP + k], al.up[2 * APP + k], al.up[3 * APP + k]);
+        float prev;
+        if (rst) prev = hand_reset_dof<HT>(v, hv, p, e, genv, ep, d, lo, up);
+        else prev = hv.prev_targets[d * N + e];
+        const float act = fminf(fmaxf(raw_act[k], -p.clip_actions), p.clip_actions);                               // vec_task.py:374
+        v.actions[a * N + e] = act;
+        float t;
+        if (p.use_relative_control) {
+            t = prev + p.dof_speed_scale * p.dt * act;                                     // :686
+        } else {
+            t = 0.5f * (act + 1.0f) * (up - lo) + lo;                                      // scale(), torch_jit_utils.py:234-235
+            t = p.act_moving_average * t + (1.0f - p.act_moving_average) * prev;            // :692-693
+        }
+        t = fmaxf(fminf(t, up), lo);                                                       // tensor_clamp
+        hv.cur_targets[d * N + e] = t;
+        hv.prev_targets[d * N + e] = t;                                                     // :697
+    });
+    if (part != 0) return;
+    if (rst) hand_reset_env_object<HT>(v, hv, p, e, genv, ep);
+    else if (rgoal) hand_reset_goal(v, hv, p, e, genv);
+    hand_random_force(v, hv, p, step_counter, e, genv);
 }
 
 // gym.refresh_rigid_body_state_tensor (shadow_hand.py:440,456-457) for the five fingertip bodies: ONE THREAD PER (env, fingertip) -- blockIdx.y is

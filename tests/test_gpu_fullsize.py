@@ -201,3 +201,40 @@ def test_shadow_hand_fingertip_states_from_the_post_kernels_own_groups_are_bit_i
     for k in ("fingertip_state", "dof_state", "object_state", "obs_buf", "successes", "progress_buf"):
         assert torch.equal(a.engine.tensors[k], b.engine.tensors[k]), k
     assert float(a.engine.tensors["fingertip_state"].abs().max()) > 0.1 and resets > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("task,n,nact,relative", [("ShadowHand", 16384, 20, False), ("ShadowHand", 200, 20, True), ("ShadowHand", 1000, 20, False),
+                                                  ("AllegroHand", 328, 16, False)])
+def test_hand_pre_physics_step_on_four_lanes_per_env_is_bit_identical(task, n, nact, relative):
+    """hand_pre4_kernel (csrc/hand_task_kernels.hpp; option pre_parts = 4, the default) spreads an env's pre_physics_step -- deferred reset, actions ->
+    drive targets, the random force -- over four lanes: a quarter of the actuators each, the object / goal / flags on lane 0.  Against the
+    one-lane-per-env kernel (pre_parts = 1) over a rollout with resets, goal resets, action noise and random forces: every buffer bit-identical."""
+    import isaacgymenvs_amd
+    from isaacgymenvs_amd.utils.config import compose
+    envs = []
+    for parts in (4, 1):
+        cfg = compose(overrides=[f"task={task}"])
+        cfg["task"]["env"]["numEnvs"] = n
+        cfg["task"]["env"]["useRelativeControl"] = relative
+        cfg["task"]["env"]["forceScale"] = 1.0
+        cfg["task"]["env"]["episodeLength"] = 40
+        env = isaacgymenvs_amd.make(seed=13, task=task, num_envs=n, sim_device=DEV, rl_device=DEV, headless=True, cfg=cfg)
+        assert int(env.engine.get_option("pre_parts")) == 4
+        env.engine.set_option("pre_parts", parts)
+        env.engine.set_noise(1, dist="gaussian", op="additive", a=0.0, b=0.02, a_corr=0.0, b_corr=0.01, epoch=0)
+        envs.append(env)
+    a, b = envs
+    g = torch.Generator(device=DEV).manual_seed(0)
+    resets = 0
+    for step in range(90):
+        act = torch.rand((n, nact), device=DEV, generator=g) * 2 - 1
+        oa, ra, da, _ = a.step(act)
+        ob, rb, db, _ = b.step(act)
+        assert torch.equal(oa["obs"], ob["obs"]) and torch.equal(ra, rb) and torch.equal(da, db), step
+        resets += int(da.sum())
+    for k in ("dof_state", "object_state", "goal_states", "cur_targets", "prev_targets", "actions", "rb_forces_object", "limit_impulse", "successes",
+              "progress_buf", "episode_count", "random_force_prob", "goal_reset_count", "object_force", "reset_buf", "reset_goal_buf"):
+        if k in a.engine.tensors:
+            assert torch.equal(a.engine.tensors[k], b.engine.tensors[k]), k
+    assert resets > n // 4 and float(a.engine.tensors["rb_forces_object"].abs().max()) > 0
