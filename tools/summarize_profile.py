@@ -144,7 +144,8 @@ RECIPE = {
     "AnymalTerrain@4096": [(r"substep_mw_fused_kernel<ModelAnymal, mi::HeightfieldGround|substep(_mw)?_kernel<ModelAnymal, mi::HeightfieldGround", {"fused": 1, "plain": 5}),
                            (r"anymal_post_kernel", 1), (r"anymal_heights_kernel", 1),
                            (r"anymal_cmdnorm_kernel", 1)],
-    "ShadowHand@16384": [(r"hand_pre_kernel", 1), (r"hand_substep(_mw64|_mw)?_kernel<(mi::ShadowHandTask, )?0>", 2), (r"hand_tips_kernel", 1), (r"hand_post_kernel", 1),
+    # (round 4: hand_pre4_kernel -- four lanes per env -- replaces hand_pre_kernel, the post kernel's fingertip groups replace hand_tips_kernel)
+    "ShadowHand@16384": [(r"hand_pre4?_kernel", 1), (r"hand_substep(_mw64|_mw)?_kernel<(mi::ShadowHandTask, )?0>", 2), (r"hand_tips_kernel", 1), (r"hand_post_kernel", 1),
                          (r"hand_finalize_kernel", 1)],
 }
 tj = {}
