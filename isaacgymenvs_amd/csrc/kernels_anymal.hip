@@ -39,8 +39,9 @@ __global__ __launch_bounds__(64) void anymal_cmdnorm_kernel(View v, AnymalParams
 }
 
 // ------------------------------------------------------------------------------------------------ post_physics_step: one env per lane
+template <bool OBS_ALL>
 __global__ __launch_bounds__(64) void anymal_post_kernel(View v, AnymalParams p, AnymalTerrainDesc T, unsigned step_counter) {
-    anymal_post_env<3 * ModelAnymal::NSPH>(v, p, T, step_counter, (int)(blockIdx.x * 64 + threadIdx.x), DevRed{});
+    anymal_post_env<3 * ModelAnymal::NSPH, DevRed, OBS_ALL>(v, p, T, step_counter, (int)(blockIdx.x * 64 + threadIdx.x), DevRed{});
 }
 
 // extras["episode"] (:421-425): runs in block 0 of the height-scan kernel (the last kernel of the step: every post block has finished its
@@ -54,12 +55,24 @@ __device__ __forceinline__ void anymal_extras(const View& v, const AnymalParams&
 
 // get_heights (:515-538) + the height columns of compute_observations (:311) + their noise (:481-482), one thread per
 // (env, scan point): 573 k threads at 4096 envs instead of a 140-iteration gather loop in each of 64 waves.
+// PLAIN (option fused_post): the threads also write the 39 observation columns whose inputs are in memory after the post pass (anymal_obs_column) --
+// one thread per (env, column) with consecutive threads on consecutive columns of a row, where the post kernel's one lane per env wrote 78 more
+// row-strided stores and drew 39 more noise values in its dependency chain (64 waves at 4096 envs).
+template <bool PLAIN>
 __global__ void anymal_heights_kernel(View v, AnymalParams p, AnymalTerrainDesc T, unsigned step_counter) {
+    constexpr int PER_ENV = kAnymalHeightPts + (PLAIN ? kAnymalPlainCols : 0);
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.x == 0) anymal_extras(v, p, threadIdx.x);
-    if (t >= v.N * kAnymalHeightPts) return;
-    const int e = t / kAnymalHeightPts;
-    anymal_height_point(v, p, T, step_counter, e, t - e * kAnymalHeightPts);
+    if (t >= v.N * PER_ENV) return;
+    const int e = t / PER_ENV, k = t - e * PER_ENV;
+    if constexpr (PLAIN) {
+        // (row order: 9 .. 35 come before the scan's 36 .. 175, the actions after it)
+        if (k < 3 + 2 * kAnymalDof) { anymal_obs_column(v, p, step_counter, e, k); return; }
+        if (k >= 3 + 2 * kAnymalDof + kAnymalHeightPts) { anymal_obs_column(v, p, step_counter, e, k - kAnymalHeightPts); return; }
+        anymal_height_point(v, p, T, step_counter, e, k - (3 + 2 * kAnymalDof));
+    } else {
+        anymal_height_point(v, p, T, step_counter, e, k);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ init / explicit reset
@@ -137,8 +150,13 @@ hipError_t launch_step_anymal(const View& v, const SimParams& P, const AnymalPar
     }
     if (e != hipSuccess) return e;
     if (tp.curriculum && !cmdnorm_in_launch) hipLaunchKernelGGL(anymal_cmdnorm_kernel, dim3((v.N + 63) / 64), dim3(64), 0, s, v, tp);
-    hipLaunchKernelGGL(anymal_post_kernel, dim3((v.N + 63) / 64), dim3(64), 0, s, v, tp, T, step_counter);
-    hipLaunchKernelGGL(anymal_heights_kernel, dim3((v.N * kAnymalHeightPts + 255) / 256), dim3(256), 0, s, v, tp, T, step_counter);
+    if (v.fused_post != 0) {    // the observation columns that do not need pre-reset quantities: by the scan kernel's threads
+        hipLaunchKernelGGL(anymal_post_kernel<false>, dim3((v.N + 63) / 64), dim3(64), 0, s, v, tp, T, step_counter);
+        hipLaunchKernelGGL(anymal_heights_kernel<true>, dim3((v.N * (kAnymalHeightPts + kAnymalPlainCols) + 255) / 256), dim3(256), 0, s, v, tp, T, step_counter);
+    } else {
+        hipLaunchKernelGGL(anymal_post_kernel<true>, dim3((v.N + 63) / 64), dim3(64), 0, s, v, tp, T, step_counter);
+        hipLaunchKernelGGL(anymal_heights_kernel<false>, dim3((v.N * kAnymalHeightPts + 255) / 256), dim3(256), 0, s, v, tp, T, step_counter);
+    }
     return hipGetLastError();
 }
 hipError_t launch_simulate_anymal(const View& v, const SimParams& P, const AnymalTerrainDesc& T, hipStream_t s) {

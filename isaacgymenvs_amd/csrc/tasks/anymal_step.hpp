@@ -51,7 +51,10 @@ MI_HD void anymal_cmdnorm_env(const View& v, const AnymalParams& p, const int e0
 // step's timeout_buf because the base class refreshes it after post_physics_step, vec_task.py:394).
 // NSPH3 = 3 * contact spheres of the compiled model (warm-start impulses cleared by a reset).  e0 >= N: a lane past the batch, which
 // shadows the last env without storing (the device reductions want full waves).
-template <int NSPH3, class RED>
+// OBS_ALL = false (the device kernels with option fused_post): only the observation columns that use PRE-reset quantities (0 .. 8: base velocities and
+// projected gravity, which reset_idx does not recompute, :465-472) are written here; commands, dof positions / velocities and actions -- all of them
+// in memory in their post-reset form when this pass ends -- are written by anymal_obs_column from the scan kernel's threads, one per (env, column).
+template <int NSPH3, class RED, bool OBS_ALL = true>
 MI_HD void anymal_post_env(const View& v, const AnymalParams& p, const AnymalTerrainDesc& T, const unsigned step_counter, const int e0, const RED& red) {
     constexpr int ND = kAnymalDof;
     const int N = v.N;
@@ -224,12 +227,14 @@ MI_HD void anymal_post_env(const View& v, const AnymalParams& p, const AnymalTer
         sfor<3>([&](auto K) MI_LAMBDA { emit(K, base_lin_vel[K] * p.lin_vel_scale, p.noise_lin_vel); });
         sfor<3>([&](auto K) MI_LAMBDA { emit(3 + K, base_ang_vel[K] * p.ang_vel_scale, p.noise_ang_vel); });
         sfor<3>([&](auto K) MI_LAMBDA { emit(6 + K, proj_g[K], p.noise_gravity); });
-        emit(9, cmd[0] * p.lin_vel_scale, 0.f); emit(10, cmd[1] * p.lin_vel_scale, 0.f); emit(11, cmd[2] * p.ang_vel_scale, 0.f);
-        sfor<ND>([&](auto K) MI_LAMBDA { emit(12 + K, q[K] * p.dof_pos_scale, p.noise_dof_pos); });
-        sfor<ND>([&](auto K) MI_LAMBDA { emit(24 + K, qd[K] * p.dof_vel_scale, p.noise_dof_vel); });
-        // columns 36..175 (the 140-point height scan, :515-538) are written by anymal_height_point right after this pass:
-        // on the device one thread per (env, point) instead of 140 serial gathers per lane
-        sfor<ND>([&](auto K) MI_LAMBDA { emit(176 + K, act[K], 0.f); });
+        if constexpr (OBS_ALL) {
+            emit(9, cmd[0] * p.lin_vel_scale, 0.f); emit(10, cmd[1] * p.lin_vel_scale, 0.f); emit(11, cmd[2] * p.ang_vel_scale, 0.f);
+            sfor<ND>([&](auto K) MI_LAMBDA { emit(12 + K, q[K] * p.dof_pos_scale, p.noise_dof_pos); });
+            sfor<ND>([&](auto K) MI_LAMBDA { emit(24 + K, qd[K] * p.dof_vel_scale, p.noise_dof_vel); });
+            // columns 36..175 (the 140-point height scan, :515-538) are written by anymal_height_point right after this pass:
+            // on the device one thread per (env, point) instead of 140 serial gathers per lane
+            sfor<ND>([&](auto K) MI_LAMBDA { emit(176 + K, act[K], 0.f); });
+        }
     }
     // bookkeeping (:484-485, vec_task.py:394)
     sfor<ND>([&](auto K) MI_LAMBDA { v.last_actions[K * N + e] = act[K]; v.last_dof_vel[K * N + e] = qd[K]; });
@@ -273,6 +278,26 @@ MI_HD void anymal_height_point(const View& v, const AnymalParams& p, const Anyma
         val += (2.f * anymal_rand_step(v.seed, genv, sk, (uint32_t)(16 + 36 + k)) - 1.f) * p.noise_height;
     }
     const size_t o = (size_t)e * kAnymalObs + 36 + k;
+    v.obs[o] = val;
+    v.obs_out[(size_t)v.ring * N * kAnymalObs + o] = fminf(fmaxf(val, -v.clip_obs), v.clip_obs);
+}
+
+// The observation columns whose inputs sit in memory in their final form once anymal_post_env is through (commands 9 .. 11, dof positions 12 .. 23,
+// dof velocities 24 .. 35, actions 176 .. 187: 39 columns, c = 0 .. 38), for one env: same expressions, same noise draws (index 16 + column) as the
+// emit() calls of anymal_post_env<OBS_ALL = true>.
+constexpr int kAnymalPlainCols = 3 + 3 * kAnymalDof;
+MI_HD void anymal_obs_column(const View& v, const AnymalParams& p, const unsigned step_counter, const int e, const int c) {
+    MI_NO_CONTRACT
+    constexpr int ND = kAnymalDof;
+    const int N = v.N;
+    int k;
+    float val, noise_scale;
+    if (c < 3) { k = 9 + c; val = v.commands[c * N + e] * (c < 2 ? p.lin_vel_scale : p.ang_vel_scale); noise_scale = 0.f; }
+    else if (c < 3 + ND) { k = 12 + (c - 3); val = v.dof[(c - 3) * N + e] * p.dof_pos_scale; noise_scale = p.noise_dof_pos; }
+    else if (c < 3 + 2 * ND) { k = 24 + (c - 3 - ND); val = v.dof[(ND + c - 3 - ND) * N + e] * p.dof_vel_scale; noise_scale = p.noise_dof_vel; }
+    else { k = 176 + (c - 3 - 2 * ND); val = v.actions[(c - 3 - 2 * ND) * N + e]; noise_scale = 0.f; }
+    if (p.add_noise) val += (2.f * anymal_rand_step(v.seed, (uint32_t)(v.env_offset + e), step_counter | 0x80000000u, (uint32_t)(16 + k)) - 1.f) * noise_scale;
+    const size_t o = (size_t)e * kAnymalObs + k;
     v.obs[o] = val;
     v.obs_out[(size_t)v.ring * N * kAnymalObs + o] = fminf(fmaxf(val, -v.clip_obs), v.clip_obs);
 }

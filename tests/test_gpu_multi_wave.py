@@ -329,3 +329,39 @@ def test_all_sub_steps_of_a_control_step_in_one_launch_are_bit_identical(task, n
             assert torch.equal(a.engine.tensors[k], b.engine.tensors[k]), k
     assert resets > 0 or task != "Ant" or cfi != 1
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,episode", [(4096, 40), (200, 25), (1000, 1000)])
+def test_anymal_terrain_observation_columns_from_the_scan_kernel_are_bit_identical(n, episode):
+    """AnymalTerrain with option fused_post = 1 (the default on the GPU): the post kernel writes only the observation columns that use pre-reset
+    quantities (0 .. 8); commands, dof positions / velocities and actions (39 columns) are written by the height-scan kernel's threads, one per
+    (env, column), from the post-reset state in memory (csrc/tasks/anymal_step.hpp anymal_obs_column).  Same expressions and noise draws: observations,
+    rewards, resets and the state are bit-identical over a rollout with resets, curriculum moves, pushes and observation noise."""
+    import isaacgymenvs_amd
+    from isaacgymenvs_amd.utils.config import compose
+    envs = []
+    for on in (1, 0):
+        cfg = compose(overrides=["task=AnymalTerrain"])
+        cfg["task"]["env"]["numEnvs"] = n
+        cfg["task"]["env"]["learn"]["episodeLength_s"] = episode * 0.02
+        cfg["task"]["env"]["learn"]["pushInterval_s"] = 0.3
+        env = isaacgymenvs_amd.make(seed=9, task="AnymalTerrain", num_envs=n, sim_device=DEV, rl_device=DEV, headless=True, cfg=cfg)
+        assert int(env.engine.get_option("fused_post")) == 1          # (make() switches it on up to 8192 envs)
+        env.engine.set_option("fused_post", on)
+        envs.append(env)
+    a, b = envs
+    g = torch.Generator(device=DEV).manual_seed(0)
+    resets = 0
+    for step in range(70):
+        act = torch.rand((n, 12), device=DEV, generator=g) * 2 - 1
+        oa, ra, da, _ = a.step(act)
+        ob, rb, db, _ = b.step(act)
+        assert torch.equal(oa["obs"], ob["obs"]) and torch.equal(ra, rb) and torch.equal(da, db), step
+        resets += int(da.sum())
+    for k in ("root_states", "dof_state", "obs_buf", "commands", "last_actions", "last_dof_vel", "feet_air_time", "episode_sums", "terrain_levels",
+              "progress_buf", "reset_buf"):
+        if k in a.engine.tensors:
+            assert torch.equal(a.engine.tensors[k], b.engine.tensors[k]), k
+    assert resets > 0 or episode > 100
+    assert float(oa["obs"][:, 12:36].abs().max()) > 0 and float(oa["obs"][:, 176:].abs().max()) > 0
