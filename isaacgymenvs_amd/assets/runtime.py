@@ -142,6 +142,12 @@ def _includes(path, seen):
                 break
 
 
+def _model_sizes(header):
+    """(NB, ND, NSENS, NSPH) of a generated model header"""
+    import re
+    return tuple(int(re.search(r"\b%s = (\d+)" % k, header).group(1)) for k in ("NB", "ND", "NSENS", "NSPH"))
+
+
 def dependent_sources(model_name):
     from .. import native
     csrc = os.path.join(_PKG, "csrc")
@@ -205,9 +211,12 @@ def _build_variant(model_name, txt, vdir, out, cpu, verbose):
     os.makedirs(os.path.join(deep, "build"), exist_ok=True)
     objs, procs = [], []
     if cpu:
-        # the translation units of the CPU backend that instantiate this model (native.CPU_UNITS), linked with the stock objects of the others
+        # the translation units of the CPU backend that instantiate this model (native.CPU_UNITS), linked with the stock objects of the others;
+        # a variant that changes one of the model's SIZES (force sensors on a hand whose compiled model has none) also needs the unit that lays
+        # out the arena from the task table
+        resized = _model_sizes(txt) != _model_sizes(open(os.path.join(csrc, "gen", f"model_{model_name}.h")).read())
         for s, suffix, opt, defs, models in native.CPU_UNITS:
-            if models is None or model_name in models:
+            if models is None or model_name in models or (resized and s == "mi_engine_cpu.cpp"):
                 o = os.path.join(deep, "build", os.path.basename(native.cpu_object(s, suffix)))
                 cmd = ["g++", opt] + native.CPU_FLAGS + defs + ["-c", os.path.join(deep, "cpu", s), "-o", o]
                 if verbose:

@@ -11,6 +11,7 @@ using HT = AllegroHandTask;
 #endif
 #define MI_CAT2(a, b, c) a##b##c
 #define MI_FN2(h, name) MI_CAT2(cpu_hand, h, name)
+#include <cstring>
 #define HFN(name) MI_FN2(MI_CPU_HAND, name)
 
 namespace {
@@ -39,6 +40,12 @@ void tips_all(MiEngine* e) {
 }  // namespace
 
 int HFN(_init)(MiEngine* e) {
+    // the arena was laid out by mi_engine_cpu.cpp's task table: a run-time variant of the model that changes a SIZE (force sensors on a hand that has
+    // none, assets/runtime.py) must have recompiled that unit too -- refuse to run against a layout of other sizes instead of writing past a tensor
+    for (const MiTensorDesc& d : e->descs) {
+        if (!strcmp(d.name, "force_sensor") && d.shape[1] != (HT::M::NSENS > 0 ? HT::M::NSENS : 1)) return -2;
+        if (!strcmp(d.name, "dof_state") && d.shape[1] != HT::M::ND) return -2;
+    }
     for (int en = 0; en < e->v.N; ++en) hand_init_env<HT>(e->v, e->hv, e->hand, en);
     return 0;
 }

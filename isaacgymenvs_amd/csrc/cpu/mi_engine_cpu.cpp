@@ -229,7 +229,11 @@ extern "C" int mi_engine_init_state(MiEngine* e, void*) {
     const TaskMeta& m = kTasks[e->task];
     const View& v = e->v;
     const int N = v.N, nd = m.nd;
-    if (is_hand_task(e->task)) { e->steps = 0; return hand_call(e, 0, nullptr, false, nullptr, 0, nullptr, nullptr); }
+    if (is_hand_task(e->task)) {
+        e->steps = 0;
+        const int rc = hand_call(e, 0, nullptr, false, nullptr, 0, nullptr, nullptr);
+        return rc == -2 ? fail("mi_engine_init_state: the hand model of this library and its task table have different sizes (a variant built without its engine unit)") : rc;
+    }
     if (e->task == T_ANYMAL && e->terrain.hs == nullptr) return fail("mi_engine_init_state: AnymalTerrain needs mi_engine_set_terrain first");
     const bool loco = e->task == T_ANT || e->task == T_HUMANOID;
     const float root_z = e->task == T_CARTPOLE ? 2.0f : e->task == T_QUADCOPTER ? e->quad.init_height : e->task == T_INGENUITY ? e->ing.init_height

@@ -762,7 +762,7 @@ class Gym:
             sc[:, 0] = put(pr.body[:n] @ m / m.sum())
             sc[:, 1] = put(pr.damp[:n][:, damped].mean(1) if damped.any() else np.ones(n))
             sc[:, 2] = put(pr.stiff[:n][:, driven].mean(1) if driven.any() else np.ones(n))
-            if a.tendon_props is None or any(tp_ != (0.0, 0.0) for tp_ in a.tendon_props):
+            if self.get_asset_tendon_count(a) > 0 and (a.tendon_props is None or any(tp_ != (0.0, 0.0) for tp_ in a.tendon_props)):
                 k0 = [tp_ for tp_ in (a.tendon_props or []) if tp_ != (0.0, 0.0)]
                 ls, dm = k0[0] if k0 else (float(a.extras["tendon_limit_stiffness"]), float(a.extras["tendon_damping"]))
                 sc[:, 3] = put(pr.tendon_k[:n] * ls / float(a.extras["tendon_limit_stiffness"]))

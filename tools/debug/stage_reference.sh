@@ -19,6 +19,8 @@ mkdir -p $D/tasks/amp/poselib && cp $REF/isaacgymenvs/tasks/amp/*.py $D/tasks/am
 cp -r $REF/isaacgymenvs/tasks/amp/poselib/poselib $D/tasks/amp/poselib/ && cp $REF/isaacgymenvs/tasks/amp/poselib/*.py $D/tasks/amp/poselib/ 2>/dev/null || true
 cp $REF/assets/mjcf/amp_humanoid.xml $ROOT/ab/ref_stage/assets/mjcf/
 mkdir -p $ROOT/ab/ref_stage/assets/amp/motions && cp $REF/assets/amp/motions/amp_humanoid_run.npy $ROOT/ab/ref_stage/assets/amp/motions/
+# tests/test_gymapi_shim.py: the dextreme task (allegro_hand_dextreme.py + adr_vec_task.py)
+mkdir -p $D/tasks/dextreme && cp $REF/isaacgymenvs/tasks/dextreme/*.py $D/tasks/dextreme/
 # tests/test_articulation.py: the Franka arm of franka_cube_stack.py:189 (URDF + its collision meshes)
 mkdir -p $ROOT/ab/ref_stage/assets/urdf/franka_description/robots $ROOT/ab/ref_stage/assets/urdf/franka_description/meshes/collision
 cp $REF/assets/urdf/franka_description/robots/franka_panda_gripper.urdf $ROOT/ab/ref_stage/assets/urdf/franka_description/robots/
