@@ -644,8 +644,10 @@ def test_force_sensors_on_a_hand_whose_model_has_none_ask_for_a_variant_with_the
     assert asked["model"] == "allegro_hand" and [hand.spec.body_names[b] for b in asked["sensors"]] == names
 
 
-def test_reference_dextreme_manual_dr_task_steps_on_the_engine(reference_tasks):
-    """The reference's tasks/dextreme/allegro_hand_dextreme.py (AllegroHandDextremeManualDR, with its base classes in adr_vec_task.py), unmodified:
+@pytest.mark.parametrize("cls,steps", [("AllegroHandDextremeManualDR", 120), ("AllegroHandDextremeADR", 60)])
+def test_reference_dextreme_tasks_step_on_the_engine(reference_tasks, cls, steps):
+    """The reference's tasks/dextreme/allegro_hand_dextreme.py (AllegroHandDextremeManualDR and the automatic-domain-randomisation variant
+    AllegroHandDextremeADR, with their base classes in adr_vec_task.py), unmodified:
     the Allegro hand of allegro_touch_sensor.urdf with a force sensor on each fingertip -- which the compiled model does not carry: prepare_sim
     compiles a variant that does (cached under isaacgymenvs_amd/_variants/) --, dictionary observations (gym.spaces.Dict), the task's own
     apply_randomizations at setup and at resets (hand / object masses, friction, dof properties, gravity, object scale), random forces on the cube.
@@ -661,23 +663,26 @@ def test_reference_dextreme_manual_dr_task_steps_on_the_engine(reference_tasks):
         sys.modules["isaacgymenvs.tasks.dextreme"] = pkg
         mod = importlib.import_module("isaacgymenvs.tasks.dextreme.allegro_hand_dextreme")
         n = 48
-        cfg = _ref_cfg("AllegroHandDextremeManualDR", n)
+        cfg = _ref_cfg(cls, n)
         cfg["rl_device"] = DEV                                   # (the task reads it from its cfg, allegro_hand_dextreme.py:106)
         torch.manual_seed(3); np.random.seed(3)
-        env = mod.AllegroHandDextremeManualDR(cfg, rl_device=DEV, sim_device=DEV, graphics_device_id=-1, headless=True,
+        env = getattr(mod, cls)(cfg, rl_device=DEV, sim_device=DEV, graphics_device_id=-1, headless=True,
                                               virtual_screen_capture=False, force_render=False)
         eng = env.sim.engine
         assert env.num_actions == 16 and env.obs_dict["ft_force_torques"].shape == (n, 24) and env.obs_dict["ft_states"].shape == (n, 52)
         assert eng.tensors["force_sensor"].shape[1:] == (4, 6) or eng.tensors["force_sensor"].shape[1] == 24
         sc = eng.tensors["actor_scale"].detach().cpu().numpy().copy()
-        assert sc[:, 0].std() > 0.01 and sc[:, 5].std() > 0.01                      # hand and object masses drawn at setup (ManualDR.yaml actor_params)
+        if cls.endswith("ManualDR"):
+            assert sc[:, 0].std() > 0.01 and sc[:, 5].std() > 0.01                  # hand and object masses drawn at setup (ManualDR.yaml actor_params)
         g = torch.Generator().manual_seed(1)
         ft_max, resets = 0.0, 0
-        for step in range(120):
+        for step in range(steps):
             obs, rew, done, info = env.step((torch.rand((n, 16), generator=g) * 2 - 1).to(DEV))
             assert all(torch.isfinite(v).all() for v in obs.values()) and torch.isfinite(rew).all(), step
             ft_max = max(ft_max, float(obs["ft_force_torques"].abs().max()))
             resets += int(done.sum())
         assert ft_max > 0.1                                   # the fingertips do touch the cube: the variant's sensors report
         assert float((eng.tensors["object_contact_count"] > 0).float().mean()) > 0.1
+        if cls.endswith("ADR"):
+            assert "adr/npd" in info and "adr/params/hand_mass/upper" in info             # the ADR bookkeeping of adr_vec_task.py runs
         assert "consecutive_successes" in info and set(obs) >= {"dof_pos", "object_pose", "goal_pose", "ft_states", "ft_force_torques", "last_actions"}
