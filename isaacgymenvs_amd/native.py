@@ -244,15 +244,9 @@ def select_multi_wave(engine, task, num_envs, mw="auto"):
             pass
 
 
-    if task == "AnymalTerrain" and num_envs <= 8192:
-        # the observation columns that need no pre-reset quantity (commands, dof positions / velocities, actions: 39 of the post pass's 48) written by
-        # the height-scan kernel's threads, one per (env, column), instead of the post kernel's one lane per env (csrc/kernels_anymal.hip,
-        # csrc/tasks/anymal_step.hpp anymal_obs_column; bit-identical buffers): +2 % at 1024 envs, +1.5 % at 4096, -4 % at 16384 where the post
-        # kernel's waves fill the chip anyway (profiles/r4t_anymal_obs_columns_ab.txt)
-        try:
-            engine.set_option("fused_post", 1)
-        except RuntimeError:
-            pass
+    # (AnymalTerrain has a "fused_post" form too -- 39 of the post pass's 48 observation columns written by the height-scan kernel's threads, one per
+    #  (env, column): csrc/kernels_anymal.hip, bit-identical -- measured at +1.5 % on a slow box, +0.5 % on a fast one at 4096 envs, -4.5 % at 16384, with
+    #  27 % more HBM-side traffic (every column thread re-reads its inputs): left off, profiles/r4t_anymal_obs_columns_ab.txt)
 
 
 def hipcc_path():
