@@ -405,6 +405,7 @@ class _Sim:
         self.bufs = {}
         self.one_shot_force = False
         self.attractors = []                   # create_rigid_body_attractor, env 0
+        self.walked = False                    # a per-env property call has reached an env other than the newest: creation is over
         self.props = None                      # _ActorProps: what the per-env property setters wrote (domain randomisation), staged on the host
 
     # the articulated actor (the engine's robot) and the free objects
@@ -600,6 +601,12 @@ class Gym:
         sim.props.grow(len(sim.envs))
         return sim.props
 
+    @staticmethod
+    def _touch(env):
+        """a per-env property call on an env that is not the newest one: the envs are all there and somebody is walking them"""
+        if env.index < len(env.sim.envs) - 1:
+            env.sim.walked = True
+
     def _base_dof_props(self, sim, actor):
         """the actor's dof properties before any per-env change: what the task wrote while it created the actor, else the asset's"""
         sl = sim.slots[actor]
@@ -608,6 +615,7 @@ class Gym:
         return self.get_asset_dof_properties(sl["asset"])
 
     def get_actor_dof_properties(self, env, actor):
+        self._touch(env)
         sim = env.sim
         sl = sim.slots[actor]
         out = np.array(self._base_dof_props(sim, actor), copy=True)
@@ -623,10 +631,12 @@ class Gym:
         Quadcopter, Ingenuity, BallBalance, Articulation); the passive stiffness / damping of the other compiled models are fixed at build
         time.  Afterwards (domain randomisation, vec_task.py:783-828): stiffness / damping / armature become this env's factors of those
         values, lower / upper its shifts of the joint limits."""
+        self._touch(env)
         sim = env.sim
         sl = sim.slots[actor]
         made = sl.setdefault("dof_props_made", set())
-        if sim.engine is None and sim.props is None and env.index == len(sim.envs) - 1 and env.index not in made:
+        # (a randomisation pass walks the envs from the first: by the time it reaches the newest env it has touched an older one)
+        if sim.engine is None and not sim.walked and env.index == len(sim.envs) - 1 and env.index not in made:
             made.add(env.index)
             if env.index == 0:
                 sl["dof_props"] = np.array(props, copy=True)
@@ -648,6 +658,7 @@ class Gym:
         return np.asarray([float(a.spec.mass[int(d)]) for d in a.body_dyn])
 
     def get_actor_rigid_body_properties(self, env, actor):
+        self._touch(env)
         sim = env.sim
         a = sim.slots[actor]["asset"]
         m = self._base_masses(sim, actor)
@@ -661,6 +672,7 @@ class Gym:
     def set_actor_rigid_body_properties(self, env, actor, props, recompute_inertia=False):
         """rigid_body_properties.mass (vec_task.py:783-828 with dr_utils.py:63 recomputeInertia = True): the body's mass -- and with it its
         inertia -- times new / own.  Links welded to one engine body share its factor (the mean of theirs)."""
+        self._touch(env)
         sim = env.sim
         a = sim.slots[actor]["asset"]
         pr, e = self._props(sim), env.index
@@ -676,6 +688,7 @@ class Gym:
         return True
 
     def get_actor_rigid_shape_properties(self, env, actor):
+        self._touch(env)
         sim = env.sim
         sl = sim.slots[actor]
         out = self.get_asset_rigid_shape_properties(sl["asset"]) or [RigidShapeProperties(1.0)]     # (a mesh-only asset lists no primitive shapes)
@@ -690,6 +703,7 @@ class Gym:
     def set_actor_rigid_shape_properties(self, env, actor, props):
         """rigid_shape_properties.friction: the engine has one coefficient per env and contact pair type, the first shape's (the reference
         draws one bucketed value for all shapes of an actor, vec_task.py:800-808); restitution has no counterpart (no bounce in the solver)"""
+        self._touch(env)
         if not props:
             return True
         pr = self._props(env.sim)
@@ -699,6 +713,7 @@ class Gym:
         return True
 
     def get_actor_tendon_properties(self, env, actor):
+        self._touch(env)
         sim = env.sim
         a = sim.slots[actor]["asset"]
         n = self.get_asset_tendon_count(a)
@@ -709,6 +724,7 @@ class Gym:
     def set_actor_tendon_properties(self, env, actor, props):
         """tendon_properties (ShadowHand.yaml:118-131): the coupling tendons' limit stiffness and damping as this env's factors of the asset's
         (a fixed tendon of the MJCF has no spring of its own: `stiffness` is 0 and scaling it changes nothing, in PhysX as here)"""
+        self._touch(env)
         sim = env.sim
         a = sim.slots[actor]["asset"]
         n = self.get_asset_tendon_count(a)
@@ -725,6 +741,7 @@ class Gym:
 
     def set_actor_scale(self, env, actor, scale):
         """vec_task.py:760-775: the free object of a hand task changes size (its mass stays); the articulated actor cannot"""
+        self._touch(env)
         sim = env.sim
         if sim.slots[actor]["asset"].spec is not None:
             return False
