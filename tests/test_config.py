@@ -113,3 +113,29 @@ def test_non_zero_restitution_is_refused_not_ignored():
         cfg["env"]["numEnvs"] = 4
         with pytest.raises(NotImplementedError, match="restitution"):
             isaacgymenvs_amd.make(seed=0, task=task, num_envs=4, sim_device="cpu", rl_device="cpu", headless=True, cfg=cfg)
+
+
+def test_legacy_environment_restores_what_it_changes():
+    """shims/legacy.py: inside environment() torch.where takes integer masks (torch 1.x behaviour the reference's dextreme reward relies on),
+    torch.jit.script is the identity and the tkinter / omegaconf names resolve; afterwards everything is as before."""
+    import sys
+    import torch
+    from isaacgymenvs_amd.shims import legacy
+    where, script = torch.where, torch.jit.script
+    had = {m: m in sys.modules for m in ("tkinter", "omegaconf")}
+    mask = torch.tensor([1, 0, 2])
+    with legacy.environment():
+        assert torch.where(mask, torch.ones(3), torch.zeros(3)).tolist() == [1.0, 0.0, 1.0]
+        assert torch.where(mask > 0, torch.ones(3), torch.zeros(3)).tolist() == [1.0, 0.0, 1.0]
+
+        @torch.jit.script
+        def f(x):
+            return torch.where(x, x, x)                      # (would not even compile for a Long x under TorchScript)
+        assert f(mask).tolist() == [1, 0, 2]
+        from tkinter import W  # noqa: F401
+        from omegaconf import ListConfig
+        assert isinstance(ListConfig([1, 2]), list) or hasattr(ListConfig, "__mro__")
+    assert torch.where is where and torch.jit.script is script
+    assert {m: m in sys.modules for m in had} == had
+    with pytest.raises(RuntimeError):
+        torch.where(mask, torch.ones(3), torch.zeros(3))
