@@ -132,6 +132,10 @@ struct SimMW : Sim<M> {
         float (&root)[13] = this->root;
         float (&q)[M::NDA] = this->q;
         float (&qd)[M::NDA] = this->qd;
+#if defined(MI_TIMING)
+        unsigned long long* const tstamp = this->tstamp;     // tools/debug/mw_phases.py: [8] per sub-step
+#endif
+        MI_STAMP(0);
         Ctx c;
         float (&S)[M::NDA][6] = c.S;
         float (&L)[M::NM] = c.L;
@@ -211,7 +215,9 @@ struct SimMW : Sim<M> {
         //  run-time loops over the model tables -- 580 KB of scalar code per kernel instead of 60)
         sfor<M::NM>([&](auto E_) MI_LAMBDA { if constexpr (trunk_entry(E_)) { constexpr int o = X_DT + R * NTE + teidx(E_); rows(o) = L[E_]; } });
         sfor<NV>([&](auto I) MI_LAMBDA { if constexpr (trunk_gi(I)) { constexpr int o = X_DY + R * NVT + tidx(I); rows(o) = y[I]; } });
+        MI_STAMP(1);
         bar();
+        MI_STAMP(2);
         // ============================================================ P2 (every role, redundantly): trunk coming up, trunk factor
         sfor_rev<NB>([&](auto B_) MI_LAMBDA {
             constexpr int b = B_;
@@ -383,7 +389,9 @@ struct SimMW : Sim<M> {
         });
         sfor<NVT>([&](auto I) MI_LAMBDA { rows(X_DW + R * NVT + I) = dw[I]; });
         rows(X_FLG + R) = act;
+        MI_STAMP(3);
         bar();
+        MI_STAMP(4);
         // ============================================================ P4 (every role): block sweeps
         // trunk part of w: every role adds all roles' warm-start contributions, in role order
         sfor<NV>([&](auto I) MI_LAMBDA {
@@ -510,6 +518,7 @@ struct SimMW : Sim<M> {
                 });
             }
         }
+        MI_STAMP(5);
         // ============================================================ P5: back to generalised velocity, outputs, integration
         sfor<NV>([&](auto I_) MI_LAMBDA {       // ascending: ancestors (trunk or own limb) first
             constexpr int i = I_;
@@ -611,6 +620,7 @@ struct SimMW : Sim<M> {
             const float n = MI_RSQ(x * x + yy * yy + z * z + ww * ww);
             Q[0] = x * n; Q[1] = yy * n; Q[2] = z * n; Q[3] = ww * n;
         }
+        MI_STAMP(6);
     }
 };
 

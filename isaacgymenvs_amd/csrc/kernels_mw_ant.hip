@@ -8,3 +8,9 @@ template hipError_t launch_substeps_mw<ModelAnt, PlaneGround>(const View&, const
 template hipError_t launch_substeps_mw_post<ModelAnt, false>(const View&, const SimParams&, const ActParams&, const float*, int, int, int, hipStream_t,
                                                             const LocoParams&);
 }  // namespace mi
+
+#if defined(MI_TIMING)
+extern "C" int mi_debug_set_tstamp_mw(void* device_buffer) {   // debug builds only (tools/debug/mw_phases.py)
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(mi::g_mi_tstamp_mw), &device_buffer, sizeof(void*));
+}
+#endif

@@ -8,6 +8,9 @@
 namespace mi {
 
 // ------------------------------------------------------------------------------------------------ multi-wave sub-step
+#if defined(MI_TIMING)
+__device__ unsigned long long* g_mi_tstamp_mw = nullptr;      // tools/debug/mw_phases.py (debug builds only)
+#endif
 // One env's sub-step spread over the 4 waves of a workgroup (core/engine_mw.hpp): blockDim = (64, NROLE), wave y = role y, lanes
 // 0 .. E-1 of every wave hold the same E envs (the other lanes retire at once); env -> workgroup through xcd_env_base (step_kernels.hpp).
 struct DevBarrier {
@@ -245,6 +248,11 @@ __device__ __forceinline__ void mw_role_fused(const MwFusedArgs<GND>& a, float* 
     const ActParams& ap = a.ap;
     const int N = v.N;
     S sim;
+#if defined(MI_TIMING)
+    // tools/debug/mw_phases.py: [32] stamps per (workgroup, role) from lane 0 -- 30: role entered, 8 s + 0 .. 6: sub-step s, 31: post step done
+    unsigned long long* const tstamp = (lane == 0 && g_mi_tstamp_mw != nullptr) ? g_mi_tstamp_mw + ((size_t)blockIdx.x * 4 + R) * 32 : nullptr;
+    MI_STAMP(30);
+#endif
     load_sim(sim, v, e);
     load_actor_scales(sim, v, e);
     {   // last step's impulses of the own rows: HBM -> row-store slots, LDS-direct (as in mw_role)
@@ -306,6 +314,9 @@ __device__ __forceinline__ void mw_role_fused(const MwFusedArgs<GND>& a, float* 
                 if constexpr (mine) v.tau[k * N + e] = t;
             });
         }
+#if defined(MI_TIMING)
+        sim.tstamp = (tstamp != nullptr && i < 3) ? tstamp + 8 * i : nullptr;
+#endif
         sim.template substep_role<R, true>(a.P, tau, h, RowStore<E>{lds_rows + lane}, lamc, laml, sensor, dof_force, a.gnd, mu_env, netf,
                                            i == 0 ? 1 : 2, DevBarrier{});
         if (i + 1 < a.n_sub) {
@@ -332,6 +343,7 @@ __device__ __forceinline__ void mw_role_fused(const MwFusedArgs<GND>& a, float* 
     if constexpr (POST) {
         static_assert(3 * M::ND <= 16 * S::NLR, "the reward terms fit the (by now dead) tree-pass exchange area");
         loco_post_role<S, M, HUM, E, R>(v, *tp, sim, act, e, lds_rows + (size_t)S::X_LR * E + lane);
+        MI_STAMP(31);
         return;
     }
     sfor<ND>([&](auto K) MI_LAMBDA {

@@ -1,0 +1,11 @@
+#!/bin/bash
+# ab/lib_timing_mw.so = the current objects with kernels_mw_ant.hip rebuilt with -DMI_TIMING (s_memtime stamps per role and phase, tools/debug/mw_phases.py)
+set -e
+ROOT=$(cd $(dirname $0)/../.. && pwd)
+B=$ROOT/isaacgymenvs_amd/csrc/build
+cd $ROOT/isaacgymenvs_amd/csrc
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-signed-zeros -fno-trapping-math -fno-slp-vectorize"
+hipcc $FLAGS -DMI_TIMING -c kernels_mw_ant.hip -o /tmp/mw_ant_timing.o 2>/dev/null
+mkdir -p $ROOT/ab
+hipcc --offload-arch=gfx950 -shared -fPIC $(ls $B/*.o | grep -v "kernels_mw_ant.o" | grep -v "/cpu_") /tmp/mw_ant_timing.o -o $ROOT/ab/lib_timing_mw.so
+echo built $ROOT/ab/lib_timing_mw.so
