@@ -19,7 +19,7 @@ for _name in ("tasks", "utils", "registry", "native", "parallel"):
     _mod = importlib.import_module(f"isaacgymenvs_amd.{_name}")
     sys.modules[f"{__name__}.{_name}"] = _mod
     globals()[_name] = _mod
-for _name in ("tasks.base", "tasks.base.vec_task", "utils.utils", "utils.dr_utils", "utils.rlgames_utils", "utils.config"):
+for _name in ("tasks.base", "tasks.base.vec_task", "utils.utils", "utils.dr_utils", "utils.rlgames_utils", "utils.config", "utils.torch_jit_utils"):
     sys.modules[f"{__name__}.{_name}"] = importlib.import_module(f"isaacgymenvs_amd.{_name}")
 
 #: where the Hydra-style task configs live (the reference's `isaacgymenvs/cfg`)

@@ -364,7 +364,9 @@ def test_franka_arm_from_urdf_meshes_runs_osc_hip():
 
 
 @pytest.mark.skipif(not HAVE_REF, reason="reference tree not reachable")
-def test_unmodified_humanoid_amp_task_file_steps():
+@pytest.mark.parametrize("backend", [pytest.param("cpu", marks=pytest.mark.skipif(torch.cuda.is_available(), reason="the HIP variant runs here")),
+                                     pytest.param("hip", marks=[pytest.mark.gpu, pytest.mark.skipif(not torch.cuda.is_available(), reason="needs the MI355X")])])
+def test_unmodified_humanoid_amp_task_file_steps(backend):
     """/root/reference/isaacgymenvs/tasks/humanoid_amp.py (with amp/humanoid_amp_base.py, its motion library and poselib) as it is: loads
     mjcf/amp_humanoid.xml -- the Articulation task's stock robot --, switches every dof to DOF_MODE_POS, resets from the run motion clip,
     steps; observations and the AMP observation buffer come from its own jitted functions on the engine's state."""

@@ -18,9 +18,12 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REF = os.environ.get("MI_REFERENCE_ROOT") or next((p for p in ("/root/reference", os.path.join(_HERE, "..", "ab", "ref_stage"))
                                                     if os.path.isdir(os.path.join(p, "isaacgymenvs", "tasks"))), "/root/reference")
-pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "isaacgymenvs", "tasks")), reason="reference tree not reachable")
-
 DEV = "cuda:0" if torch.cuda.is_available() else "cpu"
+# Where a ROCm device is visible these tests run the stand-in on the HIP backend and carry the `gpu` mark, so that the driver's
+# `pytest -m gpu` on the MI355X box selects them (without the mark the B-inner boundary on HIP was evidenced only by builder-kept
+# logs); in the development container (no GPU) they are unmarked and run on the CPU backend under `-m "not gpu"`.
+pytestmark = [pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "isaacgymenvs", "tasks")), reason="reference tree not reachable")] + (
+    [pytest.mark.gpu] if DEV != "cpu" else [])
 
 
 @pytest.fixture()
