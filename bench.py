@@ -20,8 +20,8 @@ Rank 0 prints ONE JSON line.
   cpu_baseline = the CPU oracle (oracle/physics.c via oracle/tasks.py, OpenMP over envs) on a bounded sample of the
               same workload on this host's cores ("port": the reference's PhysX-CPU path cannot run).
               `cpu_baseline.product_backend` = the engine's own g++ host build through make(seed, task, N, "cpu", "cpu") at 4 and all threads.
-              `cpu_baseline.reference_jit_fns` = the reference's own jitted obs / reward functions on torch-CPU where
-              /root/reference is reachable (development container), else marked absent.
+              `cpu_baseline.reference_jit_fns` = the reference's own jitted obs / reward functions on torch-CPU, from MI_REFERENCE_ROOT, /root/reference
+              (development container) or the task files staged for the stand-in tests under ab/ref_stage (GPU box); else marked absent.
   extra     = the second headline config (Humanoid num_envs=8192, self-collision on) measured the same way in the same run, at every N;
               extra2 / extra3 = AnymalTerrain@4096 and ShadowHand@16384 (N = 1), or their per-GPU shards 512 / 2048 (N > 1).
               The side legs time max(K / 4, 200) steps after max(W / 4, 50) warm-ups whatever the driver's K / W are, so that a short
@@ -60,15 +60,43 @@ VALU_PEAK_GINST = 256 * 4 * 2.4e9 / 2 / 1e9
 FP32_PEAK_TFLOPS = 157.3     # same guide, "Peak FP32 (vector)"
 
 
+_LIB_SHA = None
+
+
+def lib_sha256():
+    """content hash of the engine library this process loads (isaacgymenvs_amd/libmi_engine.so, or MI_ENGINE_LIB)"""
+    global _LIB_SHA
+    if _LIB_SHA is None:
+        import hashlib
+        from isaacgymenvs_amd import native
+        h = hashlib.sha256()
+        try:
+            with open(native.LIB_PATH, "rb") as f:
+                for blk in iter(lambda: f.read(1 << 20), b""):
+                    h.update(blk)
+            _LIB_SHA = h.hexdigest()
+        except OSError:
+            _LIB_SHA = "unreadable"
+    return _LIB_SHA
+
+
 def load_traffic():
     """HBM-side bytes and executed VALU instructions per control step, per task at its BASELINE size: written by
-    tools/summarize_profile.py from the rocprofv3 PMC passes of THIS command (tools/profile_r2.sh), with the FETCH_SIZE / WRITE_SIZE
-    calibration factors measured by tools/calib/calib_fetch on the same box.  Absent file or entry -> null in the JSON line."""
+    tools/summarize_profile.py from the rocprofv3 PMC passes of THIS command (tools/profile_r5.sh), with the FETCH_SIZE / WRITE_SIZE
+    calibration factors measured by tools/calib/calib_fetch on the same box.  The file carries the content hash of the library the counters
+    were collected on (`_lib_sha256`); counters of ANOTHER build are not this build's: they are reported as null, with the reason in
+    `traffic_source` (nothing tied the constants to the library that ran).  Absent file or entry -> null as well."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            return json.load(f)
+            tj = json.load(f)
     except (OSError, ValueError):
         return {}
+    stamp = tj.pop("_lib_sha256", None)
+    if stamp != lib_sha256():
+        why = (f"stale: profiles/traffic.json was collected on library sha256 {str(stamp)[:12]}, this run loaded {lib_sha256()[:12]} -- "
+               "counter-derived fields withheld")
+        return {k: {"source": why} for k in tj}
+    return tj
 
 
 def leg_consistent(res):
@@ -101,7 +129,7 @@ def measure(task, num_envs, steps, warmup, device, rank, world, seed=42, pool=8,
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(fresh):
+    def timed(fresh, steps=steps):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record()
@@ -139,12 +167,16 @@ def measure(task, num_envs, steps, warmup, device, rank, world, seed=42, pool=8,
             settled += 1
         torch.cuda.synchronize()
     settle = settled
-    for i in range(warmup):
-        env.step(2.0 * torch.rand((num_envs, na), device=device, generator=g) - 1.0)
-        if reducer:
-            reducer.step()
-    sync()
+    # the W warm-ups go through the SAME code path as the timed steps (the loop, the events, the closing barrier + synchronize of timed()):
+    # what a first pass through that path costs once -- event pools, lazily initialised timing state, the first all-reduce of the wall time --
+    # is warm-up cost, not part of the K timed steps (round 5: the first 20-step region read 0.052 ms per step, every later one 0.045-0.047)
     stats0 = env.engine.tensors["episode_stats"].clone()
+    if warmup > 0:
+        timed(True, warmup)
+    else:
+        sync()
+    stats0.copy_(env.engine.tensors["episode_stats"])
+    torch.cuda.synchronize()
     wall, gpu_ms = timed(True)
     stats = (env.engine.tensors["episode_stats"] - stats0).cpu().tolist()
     # `value` / `ms_per_step` are THIS region: W warm-ups, then exactly K steps between two barrier + synchronize pairs (the driver's contract,
@@ -259,14 +291,16 @@ def box_probe(device):
 
 def reference_jit_leg(task, num_envs, budget_s=4.0):
     """the reference's OWN jitted compute_*_observations + compute_*_reward on torch-CPU, for the obs / reward share of
-    its CPU pipeline.  Only where /root/reference is reachable (the development container); absent on the GPU box."""
-    ref = "/root/reference"
-    if task != "Ant" or not os.path.isdir(os.path.join(ref, "isaacgymenvs")):
+    its CPU pipeline.  Wherever the reference's ant.py is reachable: MI_REFERENCE_ROOT, /root/reference, or ab/ref_stage (staged, git-ignored)."""
+    ref = os.environ.get("MI_REFERENCE_ROOT") or next((p for p in ("/root/reference", os.path.join(ROOT, "ab", "ref_stage"))
+                                                          if os.path.isfile(os.path.join(p, "isaacgymenvs", "tasks", "ant.py"))), None)
+    if task != "Ant" or ref is None:
         return None
     try:
         import torch
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import gen_golden
+        gen_golden.REF = ref          # (the GPU box has no /root/reference: the few task files the stand-in tests import are staged under ab/ref_stage)
         saved = {k: v for k, v in sys.modules.items() if k == "isaacgymenvs" or k.startswith("isaacgymenvs.")}
         try:
             mod = gen_golden.import_reference()["ant"]          # registers the REFERENCE tree under the name `isaacgymenvs` ...
@@ -296,7 +330,7 @@ def reference_jit_leg(task, num_envs, budget_s=4.0):
         dt = time.perf_counter() - t0
         return {"value": n * k / dt, "unit": "env-steps/s (obs + reward only)", "cores": torch.get_num_threads(), "kind": "reference",
                 "sample": f"{k} calls of the reference's jitted compute_ant_observations + compute_ant_reward (ant.py:325-408) on torch-CPU, "
-                          f"{n} envs, {dt:.1f} s -- the obs / reward share only; its physics (PhysX-CPU) cannot run here"}
+                          f"{n} envs, {dt:.1f} s -- the obs / reward share only; its physics (PhysX-CPU) cannot run here", "reference_root": ref}
     except Exception as ex:  # noqa: BLE001 -- a missing / changed reference tree must not break the bench line
         return {"absent": f"{type(ex).__name__}: {ex}"[:200]}
 
@@ -355,6 +389,10 @@ def cpu_baseline(task, num_envs, budget_s=15.0, seed=42):
            "sample": f"{sweep[best][1]} steps of {task} num_envs={num_envs} (oracle/physics.c fp32, OpenMP over envs + numpy obs/reward), "
                      f"{sweep[best][2]:.1f} s on {best} threads (best of the sweep); stand-in for PhysX-CPU, which cannot run here",
            "thread_sweep": {str(c): round(v[0]) for c, v in sweep.items()}, "host_threads": all_cores}
+    if 4 in sweep:
+        # the reference's CPU pipeline gives PhysX `num_threads: 4` (cfg/config.yaml:30): the like-for-like thread count, first class
+        out["threads_4"] = {"value": sweep[4][0], "unit": "env-steps/s", "cores": 4, "steps": sweep[4][1], "seconds": round(sweep[4][2], 2),
+                            "note": "the reference's default sim.physx.num_threads (cfg/config.yaml:30)"}
     return out
 
 
@@ -395,6 +433,8 @@ def main():
     ap.add_argument("--num-envs", type=int, default=0, help="envs per GPU (default: the BASELINE config of the task)")
     ap.add_argument("--no-extra", action="store_true", help="skip the Humanoid@8192 side measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-shard-legs", action="store_true", help="skip the 1/8-shard legs (AnymalTerrain@512, ShadowHand@2048); the profiling recipe "
+                    "sets it so that a kernel's counters are not averaged over two launch sizes")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: the BASELINE env count PER GPU (default); strong: the BASELINE env count split over the GPUs (N/G per GPU)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
@@ -443,6 +483,23 @@ def main():
         extra = measure("Humanoid", side["Humanoid"], sk, sw, device, rank, world)
         extra2 = measure("AnymalTerrain", side["AnymalTerrain"], sk, sw, device, rank, world)
         extra3 = measure("ShadowHand", side["ShadowHand"], sk, sw, device, rank, world)
+    shard_legs = None
+    if world == 1 and not args.no_extra and not args.no_shard_legs and args.task == "Ant":
+        # BASELINE configs 4 / 5 are quoted "sharded across 8 GPUs": what ONE GPU then runs is 4096 / 8 and 16384 / 8 envs.  Their step times at
+        # N = 1 put the strong-scaling expectation on record: these sizes sit on the launch-latency floor (a step of 512 AnymalTerrain envs costs
+        # about what 4096 cost), so 8 GPUs x 1/8 of the envs deliver roughly what one GPU delivers -- per-GPU efficiency ~ 1/8 by construction.
+        # Weak scaling (the default mode: the BASELINE size PER GPU) is the mode that can meet 0.9.
+        shard_legs = {}
+        for t, full in (("AnymalTerrain", DEFAULT_ENVS["AnymalTerrain"]), ("ShadowHand", DEFAULT_ENVS["ShadowHand"])):
+            r = measure(t, full // 8, sk, sw, device, rank, world)
+            ref = extra2 if t == "AnymalTerrain" else extra3
+            shard_legs[f"{t}@{full // 8}"] = {
+                "ms_per_step": r["ms_per_step"], "env_steps_per_s_per_gpu": r["env_steps_per_s"], "kernel_ms_avg": r["kernel_ms_avg"],
+                "multi_wave": r["multi_wave"], "steps": r["steps"],
+                "full_size_ms_per_step": ref["ms_per_step"],
+                "expected_8gpu_strong_scaling_efficiency": (8 * r["env_steps_per_s"] / ref["env_steps_per_s"]) / 8.0,
+                "note": f"1/8 shard of BASELINE's {t}@{full} on ONE GPU; 8 such shards = the strong-scaling job. "
+                        "expected efficiency = (8 x this rate / the full-size single-GPU rate) / 8: latency-floor-bound, see DESIGN.md 6"}
     # The headline configuration is measured last (W untimed warm-ups + exactly K timed steps, after `settle` more untimed steps that
     # bring the episodes to their steady-state reset rate): with the driver's short runs (K = 20, W = 5, i.e. 1.5 ms of GPU work) it
     # would otherwise be timed on a device that is still ramping its clocks up from idle, on envs that were all reset one step ago.
@@ -471,6 +528,13 @@ def main():
         "mean_reward": main_res["mean_reward"], "pooled": main_res["pooled"],
         "roofline": roofline(args.task, n_env, main_res["kernel_ms_avg"], main_res["multi_wave"]),
     }
+    if dist.is_initialized():
+        # what the collective layer actually spans (the driver's N>1 launches): torch.distributed world size, backend ("nccl" IS RCCL on ROCm)
+        out["dist_world_size"] = dist.get_world_size()
+        out["dist_backend"] = dist.get_backend()
+        out["rccl_ranks"] = dist.get_world_size() if dist.get_backend() == "nccl" else 0
+    if shard_legs is not None:
+        out["shard_legs"] = shard_legs
     if "job_stats" in main_res:
         out["job_stats"] = main_res["job_stats"]
     if extra is not None:

@@ -343,6 +343,38 @@ def _expand_includes(root, base_dir):
                     parent.insert(idx + k, el)
 
 
+def _mjcf_orientation(attr, angle_scale):
+    """Orientation of an MJCF frame (body, geom, site) as a quaternion xyzw.  MuJoCo accepts exactly one of `quat` (wxyz), `axisangle`
+    ("x y z a", the angle in the compiler's unit), `euler` (compiler eulerseq, default "xyz": INTRINSIC rotations about x, then the new y, then
+    the new z -- R = Rx Ry Rz, not URDF's fixed-axis rpy), `xyaxes` (the frame's x axis and a vector in its xy plane), `zaxis` (minimal rotation
+    taking z there).  Round 5: `axisangle` was silently dropped until then -- the Shadow Hand's thumb base (robot.xml:126, 0.785 rad about y) sat
+    unrotated -- and `euler` went through rpy_to_quat, which agrees with MuJoCo only while at most one angle is non-zero."""
+    get = attr.get
+    if get("quat"):
+        w, x, y, z = _floats(get("quat"), 4)
+        q = np.array([x, y, z, w])
+        return q / np.linalg.norm(q)
+    if get("axisangle"):
+        x, y, z, a = _floats(get("axisangle"), 4)
+        ax = np.array([x, y, z]) / np.linalg.norm([x, y, z])
+        a *= angle_scale
+        return np.concatenate([ax * math.sin(0.5 * a), [math.cos(0.5 * a)]])
+    if get("euler"):
+        e = _floats(get("euler"), 3) * angle_scale
+        qs = [np.array([math.sin(0.5 * e[0]), 0.0, 0.0, math.cos(0.5 * e[0])]), np.array([0.0, math.sin(0.5 * e[1]), 0.0, math.cos(0.5 * e[1])]),
+              np.array([0.0, 0.0, math.sin(0.5 * e[2]), math.cos(0.5 * e[2])])]
+        return quat_mul(quat_mul(qs[0], qs[1]), qs[2])
+    if get("xyaxes"):
+        v = _floats(get("xyaxes"), 6)
+        x = v[:3] / np.linalg.norm(v[:3])
+        y = v[3:] - x * (x @ v[3:])
+        y /= np.linalg.norm(y)
+        return mat_to_quat(np.stack([x, y, np.cross(x, y)], axis=1))
+    if get("zaxis"):
+        return quat_from_z_to(_floats(get("zaxis"), 3))
+    return np.array([0.0, 0.0, 0.0, 1.0])
+
+
 def _mjcf_geom(attr, angle_scale):
     tname = attr.get("type", "sphere")
     gtype = {"sphere": GEOM_SPHERE, "capsule": GEOM_CAPSULE, "box": GEOM_BOX, "cylinder": GEOM_CYLINDER}.get(tname)
@@ -350,15 +382,7 @@ def _mjcf_geom(attr, angle_scale):
         return None  # plane / mesh / etc: not a primitive we collide
     size = _floats(attr.get("size", "0"))
     pos = _floats(attr.get("pos", "0 0 0"), 3)
-    quat = np.array([0.0, 0.0, 0.0, 1.0])
-    if "quat" in attr:
-        w, x, y, z = _floats(attr["quat"], 4)
-        quat = np.array([x, y, z, w])
-    elif "euler" in attr:
-        e = _floats(attr["euler"], 3) * angle_scale
-        quat = rpy_to_quat(*e)  # MuJoCo default eulerseq xyz intrinsic == rpy fixed zyx... approx; assets here don't use it on geoms
-    elif "zaxis" in attr:
-        quat = quat_from_z_to(_floats(attr["zaxis"], 3))
+    quat = _mjcf_orientation(attr, angle_scale)
     s = np.zeros(3)
     if "fromto" in attr:
         ft = _floats(attr["fromto"], 6)
@@ -413,13 +437,7 @@ def parse_mjcf(path):
     def visit(node, parent_idx, childclass):
         cc = node.get("childclass", childclass)
         pos = _floats(node.get("pos", "0 0 0"), 3)
-        quat = np.array([0.0, 0.0, 0.0, 1.0])
-        if node.get("quat"):
-            w, x, y, z = _floats(node.get("quat"), 4)
-            quat = np.array([x, y, z, w])
-            quat = quat / np.linalg.norm(quat)
-        elif node.get("euler"):
-            quat = rpy_to_quat(*(_floats(node.get("euler"), 3) * ascale))
+        quat = _mjcf_orientation(node.attrib, ascale)
         b = _Body(node.get("name", f"body{len(bodies)}"), parent_idx, pos, quat)
         idx = len(bodies)
         bodies.append(b)

@@ -257,7 +257,7 @@ def _build_variant(model_name, txt, vdir, out, cpu, verbose):
             with open(os.path.join(deep, "build", s.replace(".hip", ".log")), "w") as f:
                 f.write(text)
         usage = native.resource_usage(os.path.join(deep, "build"), deps)
-        bad = {k: u for k, u in usage.items() if u.get("SGPRs Spill", 0) > native.MAX_SGPR_SPILL and "substep" in k}
+        bad = native.over_sgpr_budget(usage)
         if bad:
             raise RuntimeError(f"variant of {model_name}: step kernels spill SGPRs (known-bad regime on gfx950): {bad}")
         subprocess.check_call([native.hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp], cwd=deep)

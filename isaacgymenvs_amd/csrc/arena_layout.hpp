@@ -141,7 +141,7 @@ static void build_layout(int task, int N, Layout& L, View* v, char* base, int no
         o = L.add("terrain_types", MI_I32, {n}, {1}, n); if (v) v->terrain_types = (int*)P(o);
         o = L.add("episode_step_stats", MI_F32, {16}, {1}, 16); if (v) v->ep_stats = (float*)P(o);
         o = L.add("episode_means", MI_F32, {16}, {1}, 16); if (v) v->ep_means = (float*)P(o);
-        o = L.add("episode_cum_stats", MI_F32, {16}, {1}, 16); if (v) v->ep_cum = (float*)P(o);
+        o = L.add("episode_cum_stats", MI_F32, {32}, {1}, 32); if (v) v->ep_cum = (float*)P(o);
     }
     if (task == T_ARTICULATION) {
         const int64_t nb = m.nb;

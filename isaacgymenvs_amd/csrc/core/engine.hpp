@@ -487,9 +487,15 @@ struct Sim {
         if constexpr (FENCED) { if (fence.p != nullptr) rewrite(fence(0)); }
     }
     static constexpr int AS_BODY = 0, AS_DAMP = M::NB, AS_STIFF = M::NB + M::ND, AS_ARM = M::NB + 2 * M::ND, AS_COLS = M::NB + 3 * M::ND;
+    // manipulators (M::NOS > 0: the hands, whose `actor_scale` holds the hand_engine.hpp HS_* columns instead): one mass factor per body in a tensor
+    // of its own, `hand_body_mass_scale` [NB] (round 5: the reference draws rigid_body_properties.mass per BODY, vec_task.py:783-828)
+    Strided body_mass{nullptr, 1};
     template <int b> MI_HD float body_scale() const {
         float x = 1.f;
-        if constexpr (SCALED) { if (actor_scale.p != nullptr) x = actor_scale(AS_BODY + b); }
+        if constexpr (SCALED) {
+            if constexpr (M::NOS > 0) { if (body_mass.p != nullptr) x = body_mass(b); }
+            else { if (actor_scale.p != nullptr) x = actor_scale(AS_BODY + b); }
+        }
         return x;
     }
     // `actor_params.<actor>.dof_properties.lower / upper` (Ant.yaml:94-101): per-env shifts of the joint limits, [ND] lower then [ND] upper,

@@ -67,6 +67,12 @@ struct HandSim : Sim<M> {
     // the dof's joint-limit row -- the same whitened vector g = s L^-1 e_d -- so every such dof has one
     static constexpr bool clamped(int d) { return M::dof_force_limit[d] > 0.f && M::dof_kp[d] > 0.f && M::dof_limited[d]; }
     static constexpr bool any_clamped() { for (int d = 0; d < ND; ++d) if (clamped(d)) return true; return false; }
+    // (a driven dof with a force range but NO joint limit would silently get an unlimited drive -- refuse such a model at compile time)
+    static constexpr bool clamps_have_rows() {
+        for (int d = 0; d < ND; ++d) if (M::dof_force_limit[d] > 0.f && M::dof_kp[d] > 0.f && !M::dof_limited[d]) return false;
+        return true;
+    }
+    static_assert(clamps_have_rows(), "a force-limited position drive rides on its dof's joint-limit row: every such dof must be limited");
     static constexpr int HCH = M::MAXCHAIN;                  // stored row width: the hand chain; the 6 object entries are re-derived
     static constexpr int H_LIMG = B::limoff(NLIM);
     static constexpr int H_CB = H_LIMG + 4 * NLIM;           // limit G | Ainv, vt, lam, rho (drive clamp impulse) | contact slots
@@ -138,6 +144,114 @@ struct HandSim : Sim<M> {
         else if constexpr (SHAPE == OBJ_CAPSULE) sphere_capsule(c, r, OP.dims[0], OP.dims[1], dist, n);
         else sphere_ellipsoid(c, r, OP.dims, dist, n);
     }
+    // ------------------------------------------------------------------------------------------------ hand-to-hand contact pairs
+    // The asset lists its hand-to-hand contacts explicitly (MJCF <contact><pair>, shared.xml:31-51: 18 distinct geom pairs -- every finger's
+    // distal link, and the first finger's other two and the middle finger's proximal one, against the thumb's distal link; the palm against it;
+    // neighbouring distal / proximal links; four more around the little finger), all condim 1: frictionless.  The hand's shapes are contype 1 /
+    // conaffinity 0, so these are its ONLY self contacts.  They are COMPLIANT contacts here (a soft row each, like the fixed tendons), not rows
+    // of the Gauss-Seidel solve: for a pair whose shapes overlap by pen > 0 at the start of the sub-step (capsule axes: exact closest points;
+    // the palm box against the thumb tip's capsule sampled by three spheres), EACH side s is pushed along its outward direction u_s
+    // (u_a = n: from b towards a, u_b = -n) at the contact point by the implicit spring force
+    //         F_s = k (pen - h J_s qd+),    J_s = u_s^T (velocity Jacobian of the side's body at the contact point),
+    // i.e. H += h^2 k J_s^T J_s and the right-hand side gets J_s^T k (pen - h J_s qd): the side's own motion is implicit (unconditionally
+    // stable), the other side is taken where the sub-step found it.  Why not rows: a pair couples the private coordinates of two fingers, which
+    // in the finger-per-wave form live on different wavefronts whose LDS is full (637 of 640 floats per env) -- a compliant pair needs only the
+    // two capsule axes exchanged once per sub-step and no solver state; the same model in every form (one wave, finger waves, CPU backend,
+    // oracle/hand.c, oracle/hand.py), independent of the solver order.  k = pair_k (option "hand_pair_stiffness", N/m; 0 switches the pairs
+    // off): 2e4 holds a finger at its drive's force limit (~10 N at the tip) 0.5 mm inside the other shape.
+    float pair_k = 0.f;                                      // stiffness of the compliant pairs (HandView::pair_k); 0 = pairs off
+    int pair_active = 0;                                     // out: pair sides this instance pushed in the last sub-step
+    static constexpr int NHP = M::NHP;
+    // sphere (centre c in the box frame, radius r) vs box of half sizes a[3]: signed distance, outward normal (box frame)
+    MI_HD static void sphere_box3(const float* c, float r, const float* a, float* dist, float* n) {
+        float qd_[3], d[3], pn[3];
+        sfor<3>([&](auto K) MI_LAMBDA { qd_[K] = fminf(fmaxf(c[K], -a[K]), a[K]); d[K] = c[K] - qd_[K]; pn[K] = a[K] - fabsf(c[K]); });
+        const float d2 = dot3(d, d);
+        const bool ix = (pn[0] <= pn[1]) && (pn[0] <= pn[2]), iy = !ix && (pn[1] <= pn[2]);
+        const float pen = ix ? pn[0] : (iy ? pn[1] : pn[2]);
+        const bool outside = d2 > 1e-24f;
+        const float inv = MI_RSQ(fmaxf(d2, 1e-30f));
+        *dist = outside ? d2 * inv - r : -pen - r;
+        n[0] = outside ? d[0] * inv : (ix ? (c[0] >= 0.f ? 1.f : -1.f) : 0.f);
+        n[1] = outside ? d[1] * inv : (iy ? (c[1] >= 0.f ? 1.f : -1.f) : 0.f);
+        n[2] = outside ? d[2] * inv : ((!ix && !iy) ? (c[2] >= 0.f ? 1.f : -1.f) : 0.f);
+    }
+    // capsule pair P: world axis end points of both sides -> overlap pen (> 0: touching), n (from b towards a), contact point pc (middle of the overlap)
+    template <int P>
+    MI_HD static float pair_capsules(const float* a0, const float* a1, const float* b0, const float* b1, float* n, float* pc) {
+        float ca[3], cb[3], dv[3];
+        seg_seg_closest<false, false>(a0, a1, b0, b1, ca, cb);
+        sfor<3>([&](auto K) MI_LAMBDA { dv[K] = ca[K] - cb[K]; });
+        const float d2 = dot3(dv, dv);
+        const bool ok = d2 > 1e-18f;
+        const float inv = MI_RSQ(fmaxf(d2, 1e-30f));
+        const float dist = d2 * inv - M::hp_ra[P] - M::hp_rb[P];
+        n[0] = ok ? dv[0] * inv : 0.f; n[1] = ok ? dv[1] * inv : 0.f; n[2] = ok ? dv[2] * inv : 1.f;
+        sfor<3>([&](auto K) MI_LAMBDA { pc[K] = cb[K] + n[K] * (M::hp_rb[P] + 0.5f * dist); });
+        return -dist;
+    }
+    // box pair P (side a: the box of hp_a0 = centre, hp_a1 = half sizes in the frame Ra, ra of its body; side b: capsule with world end points):
+    // the capsule sampled by the spheres at its two ends and its middle, the deepest one counts
+    template <int P>
+    MI_HD static float pair_box(const float* Ra, const float* ra, const float* b0, const float* b1, float* n, float* pc) {
+        constexpr float ctr[3] = {M::hp_a0[P][0], M::hp_a0[P][1], M::hp_a0[P][2]}, half[3] = {M::hp_a1[P][0], M::hp_a1[P][1], M::hp_a1[P][2]};
+        float best = 1e30f;
+        sfor<3>([&](auto T) MI_LAMBDA {
+            constexpr float t = 0.5f * (float)decltype(T)::value;
+            float cw[3], rel[3], cl[3], nl[3], dist;
+            sfor<3>([&](auto K) MI_LAMBDA { cw[K] = b0[K] + t * (b1[K] - b0[K]); rel[K] = cw[K] - ra[K]; });
+            matTvec3(Ra, rel, cl);
+            sfor<3>([&](auto K) MI_LAMBDA { cl[K] -= ctr[K]; });
+            sphere_box3(cl, M::hp_rb[P], half, &dist, nl);
+            if (dist < best) {
+                float nw[3];
+                matvec3(Ra, nl, nw);                        // from the box towards the sphere: side b's push direction, n = -nw
+                best = dist;
+                sfor<3>([&](auto K) MI_LAMBDA { n[K] = -nw[K]; pc[K] = cw[K] - nw[K] * (M::hp_rb[P] + 0.5f * dist); });
+            }
+        });
+        return -best;
+    }
+    // one side of an active pair: body b pushed along u at pc (relative to O) -- the implicit spring's terms in H (before its factor) and in
+    // the right-hand side.  S: the joints' motion subspaces about O, qd: joint velocities; H entries as L[midx[descendant][ancestor]].
+    template <int b>
+    MI_HD void pair_side(const float* pc, const float* u, const float pen, const float h, const float (&S)[M::NDA][6], float* L, float* y) const {
+        constexpr int CL = M::chain_len[b];
+        float W[6];
+        cross3(pc, u, W);
+        W[3] = u[0]; W[4] = u[1]; W[5] = u[2];
+        float g[M::MAXCHAIN], vs = 0.f;
+        sfor<CL>([&](auto C) MI_LAMBDA { g[C] = dot6(S[M::chain[b][C] - OFF], W); vs += g[C] * this->qd[M::chain[b][C] - OFF]; });
+        const float kk = (pen > 0.f) ? pair_k : 0.f;
+        const float a = h * h * kk, f = kk * (pen - h * vs);
+        sfor<CL>([&](auto C1) MI_LAMBDA {
+            constexpr int i = M::chain[b][C1];
+            y[i] += g[C1] * f;
+            const float ag = a * g[C1];
+            sfor<CL - C1>([&](auto T) MI_LAMBDA { constexpr int c2 = C1 + T, j = M::chain[b][c2]; L[M::midx[i][j]] += ag * g[c2]; });
+        });
+    }
+    // the segment of body b's pair capsule in its own frame (every pair a body takes part in uses the same shape of it)
+    static constexpr bool hp_capsule_body(int b) {
+        for (int p = 0; p < NHP; ++p) if ((M::hp_ba[p] == b && !M::hp_box[p]) || M::hp_bb[p] == b) return true;
+        return false;
+    }
+    static constexpr float hp_seg(int b, int end, int k) {
+        for (int p = 0; p < NHP; ++p) {
+            if (M::hp_ba[p] == b && !M::hp_box[p]) return end ? M::hp_a1[p][k] : M::hp_a0[p][k];
+            if (M::hp_bb[p] == b) return end ? M::hp_b1[p][k] : M::hp_b0[p][k];
+        }
+        return 0.f;
+    }
+    // world end points (relative to O) of body b's pair capsule from its pose
+    template <int b>
+    MI_HD static void hp_endpoints(const float* Rb, const float* rb, float* e0, float* e1) {
+        constexpr float l0[3] = {hp_seg(b, 0, 0), hp_seg(b, 0, 1), hp_seg(b, 0, 2)}, l1[3] = {hp_seg(b, 1, 0), hp_seg(b, 1, 1), hp_seg(b, 1, 2)};
+        float t0[3], t1[3];
+        matvec3(Rb, l0, t0); matvec3(Rb, l1, t1);
+        sfor<3>([&](auto K) MI_LAMBDA { e0[K] = rb[K] + t0[K]; e1[K] = rb[K] + t1[K]; });
+    }
+
     // y = Ro diag(s) Ro^T x: a body-diagonal operator (inertia^{+-1/2}) applied to a world-frame vector
     MI_HD static void body_diag(const float* Ro, const float* s, const float* x, float* y) {
         float t[3];
@@ -232,6 +346,34 @@ struct HandSim : Sim<M> {
             y[g0] -= c0 * f;
             y[g1] -= c1 * f;
         });
+        // ------------------------------------------------------------ the asset's hand-to-hand pairs: compliant contacts (pair_side)
+        this->pair_active = 0;
+        if constexpr (NHP > 0) {
+            if (MI_WAVE_ANY(this->pair_k > 0.f)) {
+                int npa = 0;
+                sfor<NHP>([&](auto P_) MI_LAMBDA {
+                    constexpr int pp = P_, ba = M::hp_ba[pp], bb = M::hp_bb[pp];
+                    static_assert(B::os_count(ba) > 0 && B::os_count(bb) > 0, "pair bodies carry object spheres: their poses are in the pose array");
+                    MI_PHASE();
+                    float Ra[9], ra[3], Rb2[9], rb2[3];
+                    sfor<9>([&](auto I_) MI_LAMBDA { Ra[I_] = pose[pz + 12 * B::os_slot(ba) + I_]; Rb2[I_] = pose[pz + 12 * B::os_slot(bb) + I_]; });
+                    sfor<3>([&](auto I_) MI_LAMBDA { ra[I_] = pose[pz + 12 * B::os_slot(ba) + 9 + I_]; rb2[I_] = pose[pz + 12 * B::os_slot(bb) + 9 + I_]; });
+                    float b0[3], b1[3], n[3], pc[3], pen;
+                    hp_endpoints<bb>(Rb2, rb2, b0, b1);
+                    if constexpr (M::hp_box[pp]) pen = pair_box<pp>(Ra, ra, b0, b1, n, pc);
+                    else { float a0[3], a1[3]; hp_endpoints<ba>(Ra, ra, a0, a1); pen = pair_capsules<pp>(a0, a1, b0, b1, n, pc); }
+                    const bool on = (pen > 0.f) && (this->pair_k > 0.f);
+                    if (MI_WAVE_ANY(on)) {
+                        const float pe = on ? pen : 0.f;
+                        const float nm[3] = {-n[0], -n[1], -n[2]};
+                        this->template pair_side<ba>(pc, n, pe, h, S, L, y);
+                        this->template pair_side<bb>(pc, nm, pe, h, S, L, y);
+                        npa += on ? 2 : 0;
+                    }
+                });
+                this->pair_active = npa;
+            }
+        }
         MI_PHASE();
         // ------------------------------------------------------------ H = L^T L
         sfor_rev<NV>([&](auto K_) MI_LAMBDA {

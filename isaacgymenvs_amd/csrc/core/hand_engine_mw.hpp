@@ -84,6 +84,29 @@ struct HandSimMW : HandSim<M> {
     static constexpr int X_HASC = X_FLG + 2 * NR;                         // [NR]         block holds a contact (touches the object's coordinates)
     static constexpr int X_CNT = X_HASC + NR;                             // [NLIMB]      contacts kept | refused << 16 (int bits)
     static constexpr int MW_SLOTS = X_CNT + NLIMB;
+    // ---- the asset's hand-to-hand pairs (core/hand_engine.hpp pair_side): the axis end points of the pair capsules that sit on LIMB bodies go
+    //      through LDS once per sub-step (6 floats each; the palm is trunk: every wave has its pose).  They alias the sweeps' exchange area,
+    //      which is dead from the start of the sub-step until the end of P3.
+    static constexpr int NHP = M::NHP;
+    static constexpr int hp_slot(int b) {            // slot of limb body b among the pair capsules' bodies, or -1
+        if (!HB::hp_capsule_body(b) || MW::trunk_body(b)) return -1;
+        int n = 0;
+        for (int k = 0; k < b; ++k) n += (HB::hp_capsule_body(k) && !MW::trunk_body(k)) ? 1 : 0;
+        return n;
+    }
+    static constexpr int hp_nslots() { int n = 0; for (int b = 0; b < NB; ++b) n += (hp_slot(b) >= 0) ? 1 : 0; return n; }
+    static constexpr int X_PE = X_DW;
+    static_assert(X_PE + 6 * hp_nslots() <= MW_SLOTS, "the pair capsules' end points fit in the sweeps' exchange area");
+    static constexpr bool hp_pairs_ok() {
+        for (int p = 0; p < NHP; ++p) {
+            if (M::hp_box[p] && !MW::trunk_body(M::hp_ba[p])) return false;          // a box side's pose must be known to every wave
+            if (!M::hp_box[p] && MW::trunk_body(M::hp_ba[p])) return false;          // (capsules on trunk bodies: not needed by the Shadow Hand)
+            if (MW::trunk_body(M::hp_bb[p])) return false;
+        }
+        return true;
+    }
+    static_assert(hp_pairs_ok(), "pair shapes: boxes on trunk bodies, capsules on limb bodies");
+    static constexpr int role_of_body_h(int b) { return limb_role(M::limb_of_body[b]); }
     static_assert((size_t)MW_SLOTS * LANES * sizeof(float) <= 80 * 1024, "two 32-env hand workgroups per CU, or one of 64 envs");
     // ---- conservative bounds for the narrow phase: bounding sphere (centre in the body frame, radius) of the spheres of body b
     static constexpr float csqrt(float x) { float r = x > 1.f ? x : 1.f; for (int i = 0; i < 40; ++i) r = 0.5f * (r + x / r); return r; }
@@ -180,6 +203,13 @@ struct HandSimMW : HandSim<M> {
                          const float* Vp, const float* Ap, SpI& Iout, float* Fout, const RowStore<RS> rows) {
         BodyTmp t;
         this->template body_down<b>(P, c, Rp, rp, Vp, Ap, t);
+        if constexpr (hp_slot(b) >= 0) {       // this body's pair capsule, for the roles that own the other sides (read after barrier B0)
+            if (this->pair_k > 0.f) {
+                float e0[3], e1[3];
+                HB::template hp_endpoints<b>(t.Rb, t.rb, e0, e1);
+                sfor<3>([&](auto K) MI_LAMBDA { rows(X_PE + 6 * hp_slot(b) + K) = e0[K]; rows(X_PE + 6 * hp_slot(b) + 3 + K) = e1[K]; });
+            }
+        }
         if constexpr (B::os_count(b) > 0) narrow_body<SHAPE, b>(P, OP, invh, nw, t.Rb, t.rb, rows);
         sfor<NB>([&](auto C_) MI_LAMBDA {
             constexpr int ch = C_;
@@ -343,6 +373,40 @@ struct HandSimMW : HandSim<M> {
             sfor<M::nanc[i]>([&](auto A_) MI_LAMBDA { s += L[M::midx[i][M::anc[i][A_]]] * v[M::anc[i][A_]]; });
             w[i] = s + h * z;
         };
+        // ------------------------------------------------------------ the asset's hand-to-hand pairs: every role evaluates the pairs with a side on
+        // one of its bodies (both owners compute the same geometry from the same end points) and adds ITS side's implicit spring to its own H
+        // entries / right-hand side; the wrist part rides on the Schur-complement / carry exchange below (X_DT / X_DY, summed in role order)
+        this->pair_active = 0;
+        if constexpr (NHP > 0) {
+            if (this->pair_k > 0.f) {                                                                 // (uniform over the workgroup: a kernel argument)
+                bar();                                                                               // ---- B0: everybody's pair capsules are in LDS
+                int npa = 0;
+                sfor<NHP>([&](auto P_) MI_LAMBDA {
+                    constexpr int pp = P_, ba = M::hp_ba[pp], bb = M::hp_bb[pp];
+                    constexpr bool mine_a = role_of_body_h(ba) == R, mine_b = role_of_body_h(bb) == R;
+                    if constexpr (mine_a || mine_b) {
+                        MI_PHASE();
+                        float b0[3], b1[3], n[3], pc[3], pen;
+                        sfor<3>([&](auto K) MI_LAMBDA { b0[K] = rows(X_PE + 6 * hp_slot(bb) + K); b1[K] = rows(X_PE + 6 * hp_slot(bb) + 3 + K); });
+                        if constexpr (M::hp_box[pp]) {
+                            const BodyTmp& ta = tb[MW::tslot(ba)];
+                            pen = HB::template pair_box<pp>(ta.Rb, ta.rb, b0, b1, n, pc);
+                        } else {
+                            float a0[3], a1[3];
+                            sfor<3>([&](auto K) MI_LAMBDA { a0[K] = rows(X_PE + 6 * hp_slot(ba) + K); a1[K] = rows(X_PE + 6 * hp_slot(ba) + 3 + K); });
+                            pen = HB::template pair_capsules<pp>(a0, a1, b0, b1, n, pc);
+                        }
+                        const bool on = pen > 0.f;
+                        if (MI_WAVE_ANY(on)) {
+                            const float pe = on ? pen : 0.f;
+                            if constexpr (mine_a) { this->template pair_side<ba>(pc, n, pe, h, S, L, y); npa += on ? 1 : 0; }
+                            if constexpr (mine_b) { const float nm[3] = {-n[0], -n[1], -n[2]}; this->template pair_side<bb>(pc, nm, pe, h, S, L, y); npa += on ? 1 : 0; }
+                        }
+                    }
+                });
+                this->pair_active = npa;
+            }
+        }
         sfor_rev<NV>([&](auto K_) MI_LAMBDA { if constexpr (MW::role_of_gi(K_) == R) factor(K_); });
         MI_PHASE();
         sfor_rev<NV>([&](auto I_) MI_LAMBDA { if constexpr (MW::role_of_gi(I_) == R) whiten(I_); });

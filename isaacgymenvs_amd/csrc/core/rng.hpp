@@ -19,6 +19,14 @@ MI_HD float uniform01(uint32_t seed, uint32_t env, uint32_t episode, uint32_t k)
     return (float)(h >> 8) * (1.0f / 16777216.0f);
 }
 
+// Compensated accumulation (Knuth two-sum) for the cumulative job statistics: `hi + lo` carries ~48 bits, so that a sum that has grown past 2^24
+// keeps taking small increments (a float count stops at 16,777,216; window means are differences of two snapshots -- parallel.py).
+MI_HD void two_sum_acc(float& hi, float& lo, const float x) {   // (no products: FP contraction cannot touch it; the builds do not reassociate)
+    const float t = hi + x, bp = t - hi;
+    lo += (hi - (t - bp)) + (x - bp);
+    hi = t;
+}
+
 // ---- in-kernel observation / action noise of the domain randomisation (reference vec_task.py:650-718: `noise_lambda` closures of
 // torch.randn_like / rand_like ops run on the returned buffers).  Here the noise of element k of env e is a pure function of
 // (seed, e, step, k): nothing to store, identical on every launch shape, reproducible by the CPU twin (oracle/tasks.py: mi_noise).

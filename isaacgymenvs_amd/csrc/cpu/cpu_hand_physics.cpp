@@ -5,7 +5,9 @@
 #include "../tasks/hand_task.hpp"
 
 #if MI_CPU_HAND == 0
-using HT = ShadowHandTask;
+// the host build always runs the Sim<Scaled<M>> instantiation: with option "hand_body_mass" off (HandView::body_mass == nullptr) every factor is
+// the constant 1.0f, and x * 1.0f is x -- the results are the plain instantiation's, bit for bit (no second set of six translation units)
+using HT = ScaledShadowHandTask;
 #else
 using HT = AllegroHandTask;
 #endif

@@ -107,6 +107,8 @@ extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const 
     memset(&e->v, 0, sizeof(View));
     memset(&e->qv, 0, sizeof(e->qv)); memset(&e->iv, 0, sizeof(e->iv)); memset(&e->bv, 0, sizeof(e->bv)); memset(&e->hv, 0, sizeof(e->hv));
     e->hv.drive_clamp = 1;
+    // the asset's hand-to-hand contact pairs (Shadow Hand, shared.xml:31-51) are on by default; the Allegro hand's URDF lists none
+    e->hv.pair_k = (t == T_SHADOWHAND) ? 2.0e4f : 0.f;
     e->hv.tips_in_post = 1;
     e->hv.pre_parts = 4;
     Layout L;
@@ -142,6 +144,15 @@ extern "C" int mi_engine_set_option(MiEngine* e, const char* key, double value) 
         return 0;
     }
     if (!strcmp(key, "multi_wave") || !strcmp(key, "fused_sub") || !strcmp(key, "fused_post")) return 0;     // GPU launch shapes: nothing to do here
+    if (!strcmp(key, "hand_body_mass")) {       // ShadowHand: the sub-step reads the per-body link-mass factors of `hand_body_mass_scale` (0, default: it does not)
+        if (e->task != T_SHADOWHAND) return fail("hand_body_mass: a ShadowHand option (the Allegro hand's kernels take one mass factor per env)");
+        e->hv.body_mass = value != 0 ? e->hv.body_mass_arena : nullptr; return 0;
+    }
+    if (!strcmp(key, "hand_pair_stiffness")) {  // hands: N/m of the compliant hand-to-hand contact pairs; 0 = the pairs off
+        if (!is_hand_task(e->task)) return fail("hand_pair_stiffness: a hand-task option");
+        if (!(value >= 0)) return fail("hand_pair_stiffness: >= 0");
+        e->hv.pair_k = (float)value; return 0;
+    }
     if (!strcmp(key, "drive_force_limit")) {
         if (!is_hand_task(e->task)) return fail("drive_force_limit: a hand-task option");
         e->hv.drive_clamp = value != 0 ? 1 : 0; return 0;
@@ -188,6 +199,8 @@ extern "C" int mi_engine_get_option(const MiEngine* e, const char* key, double* 
     if (!strcmp(key, "self_collision")) { *out = e->v.lamp != nullptr ? 1.0 : 0.0; return 0; }
     if (!strcmp(key, "multi_wave") || !strcmp(key, "fused_sub") || !strcmp(key, "fused_post")) { *out = 0; return 0; }
     if (!strcmp(key, "drive_force_limit")) { *out = is_hand_task(e->task) ? e->hv.drive_clamp : 0; return 0; }
+    if (!strcmp(key, "hand_body_mass")) { *out = (is_hand_task(e->task) && e->hv.body_mass != nullptr) ? 1 : 0; return 0; }
+    if (!strcmp(key, "hand_pair_stiffness")) { *out = is_hand_task(e->task) ? e->hv.pair_k : 0; return 0; }
     if (!strcmp(key, "terrain_slope_threshold")) { *out = e->terrain.slope_threshold; return 0; }
     if (!strcmp(key, "terrain_walls")) { *out = e->terrain.walls; return 0; }
     if (!strcmp(key, "actor_tensors")) { *out = (is_hand_task(e->task) || e->v.actor_scale != nullptr) ? 1.0 : 0.0; return 0; }

@@ -47,6 +47,13 @@ inline hipError_t hand_substeps_shape(const View& v, const HandView& hv, const S
 hipError_t hand_substeps_mw_box(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s);
 hipError_t hand_substeps_mw_pen(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s);
 hipError_t hand_substeps_mw_egg(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s);
+// the ShadowHand's kernels on Sim<Scaled<M>> (per-body link-mass factors; kernels_scaled_shadow_hand_*.hip): one-wave and finger-per-wave form
+hipError_t hand_substeps_box_scaled(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s);
+hipError_t hand_substeps_pen_scaled(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s);
+hipError_t hand_substeps_egg_scaled(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s);
+hipError_t hand_substeps_mw_box_scaled(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s);
+hipError_t hand_substeps_mw_pen_scaled(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s);
+hipError_t hand_substeps_mw_egg_scaled(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s);
 // the same for the Allegro hand (kernels_allegro_hand_mw*.hip)
 hipError_t allegro_substeps_mw_box(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s);
 hipError_t allegro_substeps_mw_pen(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s);

@@ -55,6 +55,8 @@ __device__ __forceinline__ void hand_mw_role(const View& v, const HandView& hv, 
     sim.actor_scale = Strided{hv.scale + e, N};
     sim.limit_shift = Strided{hv.limit_shift + e, N};
     sim.drive_clamp = hv.drive_clamp;
+    sim.pair_k = hv.pair_k;
+    if constexpr (is_scaled<typename HT::M>::value) { if (hv.body_mass != nullptr) sim.body_mass = Strided{hv.body_mass + e, N}; }
 #if defined(MI_TIMING)
     sim.tstamp = (lane == 0 && g_mi_tstamp_hmw != nullptr) ? g_mi_tstamp_hmw + ((size_t)blockIdx.x * 4 + R) * 16 : nullptr;
 #endif
@@ -65,6 +67,7 @@ __device__ __forceinline__ void hand_mw_role(const View& v, const HandView& hv, 
     sfor<ND>([&](auto K) MI_LAMBDA {
         if constexpr (MW::template owns_gi<R>(K)) { v.dof[K * N + e] = sim.q[K]; v.dof[(ND + K) * N + e] = sim.qd[K]; }
     });
+    hv.npair[R * N + e] = sim.pair_active;
     if constexpr (R == HM::TRUNK_ROLE) {
         sfor<3>([&](auto K) MI_LAMBDA { hv.object_state[K * N + e] = sim.obj.pos[K]; hv.object_state[(7 + K) * N + e] = sim.obj.vel[K];
                                         hv.object_state[(10 + K) * N + e] = sim.obj.angvel[K]; });

@@ -27,6 +27,11 @@ struct HandView {
     int* ndropped;         // [N] contacts refused since init because all slots were taken (diagnostic; a manifold's 5th+ contact does not count)
     int pre_parts = 4;     // lanes per env of the pre kernel (option "pre_parts": 4 = hand_pre4_kernel, 1 = one lane per env, the A/B of round 4)
     int tips_in_post = 1;  // the post kernel's fingertip groups walk the fingertip chains themselves (option "tips_in_post"; 0: hand_tips_kernel in a launch of its own, the A/B of round 4)
+    float* body_mass;      // [NB][N] per-env, per-BODY factors of the hand's link masses (`actor_params.hand.rigid_body_properties.mass`), or nullptr: the plain
+                           //         kernels run (option "hand_body_mass": the Sim<Scaled<M>> instantiations read them in the tree pass)
+    float* body_mass_arena;// where that tensor sits (always; `body_mass` is this pointer or null)
+    int* npair;            // [NROLE][N] sides of the asset's hand-to-hand contact pairs that were pushed in the last sub-step, per role wave (one-wave form / CPU: column 0)
+    float pair_k = 0.f;    // stiffness (N/m) of the compliant hand-to-hand pairs (option "hand_pair_stiffness"; 0 = off; core/hand_engine.hpp pair_side)
     int drive_clamp = 1;   // the position drives deliver at most M::dof_force_limit (option "drive_force_limit"; core/hand_engine.hpp drive_clamp_update)
 };
 

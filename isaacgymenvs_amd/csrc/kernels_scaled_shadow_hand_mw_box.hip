@@ -1,0 +1,9 @@
+// kernels_scaled_shadow_hand_mw_box.hip -- the finger-per-wave ShadowHand sub-step on Sim<Scaled<M>> (per-env, per-BODY link-mass factors), objectType
+// shape OBJ_BOX; see kernels_scaled_shadow_hand_box.hip.
+#include "hand_mw_kernels.hpp"
+
+namespace mi {
+hipError_t hand_substeps_mw_box_scaled(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s) {
+    return hand_substeps_mw_shape<ScaledShadowHandTask, OBJ_BOX>(v, hv, P, p, n, s);
+}
+}  // namespace mi

@@ -6,6 +6,16 @@ namespace mi {
 
 template <>
 hipError_t hand_substeps<ShadowHandTask>(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s) {
+    if (hv.body_mass != nullptr) {     // option hand_body_mass: per-body link-mass factors -> the Sim<Scaled<M>> instantiations
+        if (v.mw != 0) {
+            if (p.object_shape == OBJ_ELLIPSOID) return hand_substeps_mw_egg_scaled(v, hv, P, p, n, s);
+            if (p.object_shape == OBJ_CAPSULE) return hand_substeps_mw_pen_scaled(v, hv, P, p, n, s);
+            return hand_substeps_mw_box_scaled(v, hv, P, p, n, s);
+        }
+        if (p.object_shape == OBJ_ELLIPSOID) return hand_substeps_egg_scaled(v, hv, P, p, n, s);
+        if (p.object_shape == OBJ_CAPSULE) return hand_substeps_pen_scaled(v, hv, P, p, n, s);
+        return hand_substeps_box_scaled(v, hv, P, p, n, s);
+    }
     if (v.mw != 0) {     // option multi_wave: the finger-per-wave form (core/hand_engine_mw.hpp), block solver order
         if (p.object_shape == OBJ_ELLIPSOID) return hand_substeps_mw_egg(v, hv, P, p, n, s);
         if (p.object_shape == OBJ_CAPSULE) return hand_substeps_mw_pen(v, hv, P, p, n, s);

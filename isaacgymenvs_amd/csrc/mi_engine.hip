@@ -361,6 +361,8 @@ extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const 
     e->v.actor_scale = nullptr; e->v.limit_shift = nullptr;
     memset(&e->hv, 0, sizeof(e->hv));
     e->hv.drive_clamp = 1;
+    // the asset's hand-to-hand contact pairs (Shadow Hand, shared.xml:31-51) are on by default; the Allegro hand's URDF lists none
+    e->hv.pair_k = (t == T_SHADOWHAND) ? 2.0e4f : 0.f;
     e->hv.tips_in_post = 1;
     e->hv.pre_parts = 4;
     if (is_hand_task(t)) build_hand_layout(t, num_envs, L, &e->hv, (char*)arena);
@@ -427,6 +429,15 @@ extern "C" int mi_engine_set_option(MiEngine* e, const char* key, double value) 
         if (!is_hand_task(e->task)) return fail("tips_in_post: a hand-task option");
         e->hv.tips_in_post = value != 0 ? 1 : 0; return 0;
     }
+    if (!strcmp(key, "hand_body_mass")) {       // ShadowHand: the sub-step reads the per-body link-mass factors of `hand_body_mass_scale` (0, default: it does not)
+        if (e->task != T_SHADOWHAND) return fail("hand_body_mass: a ShadowHand option (the Allegro hand's kernels take one mass factor per env)");
+        e->hv.body_mass = value != 0 ? e->hv.body_mass_arena : nullptr; return 0;
+    }
+    if (!strcmp(key, "hand_pair_stiffness")) {  // hands: N/m of the compliant hand-to-hand contact pairs; 0 = the pairs off
+        if (!is_hand_task(e->task)) return fail("hand_pair_stiffness: a hand-task option");
+        if (!(value >= 0)) return fail("hand_pair_stiffness: >= 0");
+        e->hv.pair_k = (float)value; return 0;
+    }
     if (!strcmp(key, "drive_force_limit")) {   // hands: the position drives deliver at most their force range (shared.xml:250-269, allegro_hand.py:264); default 1
         if (!is_hand_task(e->task)) return fail("drive_force_limit: a hand-task option");
         e->hv.drive_clamp = value != 0 ? 1 : 0; return 0;
@@ -474,6 +485,8 @@ extern "C" int mi_engine_get_option(const MiEngine* e, const char* key, double* 
     if (!strcmp(key, "self_collision")) { *out = e->v.lamp != nullptr ? 1.0 : 0.0; return 0; }
     if (!strcmp(key, "multi_wave")) { *out = e->v.mw; return 0; }
     if (!strcmp(key, "drive_force_limit")) { *out = is_hand_task(e->task) ? e->hv.drive_clamp : 0; return 0; }
+    if (!strcmp(key, "hand_body_mass")) { *out = (is_hand_task(e->task) && e->hv.body_mass != nullptr) ? 1 : 0; return 0; }
+    if (!strcmp(key, "hand_pair_stiffness")) { *out = is_hand_task(e->task) ? e->hv.pair_k : 0; return 0; }
     if (!strcmp(key, "tips_in_post")) { *out = is_hand_task(e->task) ? e->hv.tips_in_post : 0; return 0; }
     if (!strcmp(key, "pre_parts")) { *out = is_hand_task(e->task) ? e->hv.pre_parts : 0; return 0; }
     if (!strcmp(key, "fused_post")) { *out = e->v.fused_post; return 0; }

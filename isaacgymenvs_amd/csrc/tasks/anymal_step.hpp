@@ -252,8 +252,9 @@ MI_HD void anymal_post_env(const View& v, const AnymalParams& p, const AnymalTer
 // mean.  `mine` = ep_stats[k], `cnt` = ep_stats[13], both read BEFORE any slot is re-zeroed (the caller orders that).
 MI_HD void anymal_extras_slot(const View& v, const AnymalParams& p, const int k, const float mine, const float cnt) {
     // job-wide extras of a multi-GPU run: the same sums, cumulative ([15] counts the steps; [14] the per-step level sums)
-    if (k < 15) v.ep_cum[k] += mine;
-    if (k == 15) v.ep_cum[15] += 1.f;
+    // ([16 + k]: the low part of slot k's compensated sum)
+    if (k < 15) two_sum_acc(v.ep_cum[k], v.ep_cum[16 + k], mine);
+    if (k == 15) two_sum_acc(v.ep_cum[15], v.ep_cum[31], 1.f);
     if (k < kAnymalSums && cnt > 0.f) v.ep_means[k] = mine / cnt / p.max_episode_length_s;   // untouched when nobody reset (the
     if (k == 14) v.ep_means[14] = mine / (float)v.N;                                         // reference keeps the last dict)
     if (k == 13) v.ep_means[13] = mine;
@@ -329,7 +330,7 @@ MI_HD void anymal_init_env(const View& v, const AnymalParams& p, const AnymalTer
     for (int k = 0; k < kAnymalDof; ++k) { v.last_actions[k * N + e] = 0.f; v.last_dof_vel[k * N + e] = 0.f; }
     for (int k = 0; k < kAnymalSums; ++k) v.episode_sums[k * N + e] = 0.f;
     for (int k = 0; k < NB3; ++k) v.netf[k * N + e] = 0.f;
-    if (e == 0) for (int k = 0; k < 16; ++k) { v.ep_stats[k] = 0.f; v.ep_means[k] = 0.f; v.ep_cum[k] = 0.f; }
+    if (e == 0) for (int k = 0; k < 16; ++k) { v.ep_stats[k] = 0.f; v.ep_means[k] = 0.f; v.ep_cum[k] = 0.f; v.ep_cum[16 + k] = 0.f; }
 }
 
 // reset_idx(env_ids) (:384-425) outside step(): same draws as the in-step reset of the env's current episode number.  ep_stats[15] holds

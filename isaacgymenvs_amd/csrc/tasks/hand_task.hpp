@@ -23,6 +23,10 @@ struct AllegroHandTask {   // reference allegro_hand.py (16 dofs, all driven, :2
     using M = ModelAllegroHand;
     static constexpr int ND = 16, NACT = 16, NTIPS = 0, NFULL = 88;
 };
+// the same task on Sim<Scaled<M>>: the instantiation whose tree pass multiplies every link's mass and inertia by its per-env factor
+// (HandView::body_mass; core/engine.hpp body_scale).  Separate translation units (kernels_scaled_shadow_hand*.hip), picked by the launchers while
+// option "hand_body_mass" is on, so that the plain kernels' register allocation never sees the factor code.
+struct ScaledShadowHandTask : ShadowHandTask { using M = Scaled<ModelShadowHand>; };
 static_assert(ShadowHandTask::M::ND == ShadowHandTask::ND && ShadowHandTask::M::NSENS == ShadowHandTask::NTIPS, "shadow hand model");
 // (the Allegro task observes no fingertip force; a run-time variant of the model may still carry force sensors for gym.acquire_force_sensor_tensor --
 //  the reference's dextreme task puts them on the four fingertips, tasks/dextreme/allegro_hand_dextreme.py:264-269)
@@ -404,7 +408,7 @@ MI_HD void hand_obs_select_elem(const View& v, const HandView& hv, const HandPar
 MI_HD void hand_finalize(const HandView& hv, const HandParams& p) {
     const float num_resets = hv.ws[0], finished = hv.ws[1], cs = hv.cons[0];
     hv.cons[0] = (num_resets > 0.f) ? p.rew.av_factor * finished / num_resets + (1.0f - p.rew.av_factor) * cs : cs;
-    hv.ws[2] += num_resets; hv.ws[3] += finished;     // cumulative since init: what a multi-GPU job all-reduces (parallel.py TaskExtrasReducer)
+    two_sum_acc(hv.ws[2], hv.ws[4], num_resets); two_sum_acc(hv.ws[3], hv.ws[5], finished);     // cumulative since init (compensated: [4], [5] the low parts): what a multi-GPU job all-reduces (parallel.py TaskExtrasReducer)
     hv.ws[0] = 0.f; hv.ws[1] = 0.f;   // last reader of the step's sums: re-zero them here instead of a memset before every post pass
 }
 
@@ -430,10 +434,12 @@ MI_HD void hand_init_env(const View& v, const HandView& hv, const HandParams& p,
     hv.force_prob[e] = hand_force_prob(p, uniform01(v.seed ^ 0x51ED27u, (uint32_t)(v.env_offset + e), 0u, 0u));
     hv.mu_env[e] = -1.f;
     for (int k = 0; k < HS_COLUMNS; ++k) hv.scale[k * N + e] = 1.f;
+    for (int k = 0; k < HT::M::NB; ++k) hv.body_mass_arena[k * N + e] = 1.f;
     for (int k = 0; k < 2 * HT::ND; ++k) hv.limit_shift[k * N + e] = 0.f;
     hv.successes[e] = 0.f; hv.reset_goal[e] = 1; hv.goal_count[e] = 0; hv.ncontact[e] = 0; hv.ndropped[e] = 0;
+    for (int k = 0; k < 4; ++k) hv.npair[k * N + e] = 0;
     v.rew[e] = 0.f; v.reset[e] = 1; v.progress[e] = 0; v.randomize[e] = 0; v.timeout[e] = 0; v.episode[e] = 0; v.ep_ret[e] = 0.f;
-    if (e == 0) { hv.cons[0] = 0.f; hv.ws[0] = hv.ws[1] = hv.ws[2] = hv.ws[3] = 0.f; for (int k = 0; k < 8; ++k) v.stats[k] = 0.f; }
+    if (e == 0) { hv.cons[0] = 0.f; for (int k = 0; k < 8; ++k) hv.ws[k] = 0.f; for (int k = 0; k < 8; ++k) v.stats[k] = 0.f; }
 }
 
 // gym.simulate(): one physics sub-step of hand + object for env e; `rows`: the env's row store (LDS [slot][lane] on the device, a plain
@@ -466,6 +472,8 @@ MI_HD void hand_substep_env(const View& v, const HandView& hv, const SimParams& 
     sim.actor_scale = Strided{hv.scale + e, N};
     sim.limit_shift = Strided{hv.limit_shift + e, N};
     sim.drive_clamp = hv.drive_clamp;
+    sim.pair_k = hv.pair_k;
+    if constexpr (is_scaled<typename HT::M>::value) { if (hv.body_mass != nullptr) sim.body_mass = Strided{hv.body_mass + e, N}; }
 #if defined(MI_TIMING)
     sim.tstamp = tstamp;
 #else
@@ -481,6 +489,7 @@ MI_HD void hand_substep_env(const View& v, const HandView& hv, const SimParams& 
     sfor<4>([&](auto K) MI_LAMBDA { hv.object_state[(3 + K) * N + e] = sim.obj.quat[K]; });
     hv.ncontact[e] = nc & 0xFFFF;
     if (nc >> 16) hv.ndropped[e] += nc >> 16;
+    hv.npair[e] = sim.pair_active;
 }
 
 }  // namespace mi

@@ -33,8 +33,32 @@ def init_distributed(backend=None):
             backend = os.getenv("MI_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")  # "nccl" is RCCL on ROCm
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
+        pin_to_local_cores(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
+
+
+def pin_to_local_cores(local_rank=None, local_world=None):
+    """One process per GPU: give every rank of a node its own contiguous slice of the cores the job may use (sched_setaffinity).  The engine's host
+    side is a single Python thread issuing one launch per step (~25 us of work per 40-170 us step); eight such threads migrating over two sockets
+    contend for nothing but each other's caches and the launch path's locks, and a contiguous slice is also the socket next to the GPU on the usual
+    board layout (GPUs 0-3 on socket 0, 4-7 on socket 1).  MI_NO_AFFINITY=1 leaves the scheduler alone.  Returns the cores chosen, or None."""
+    if os.getenv("MI_NO_AFFINITY") == "1" or not hasattr(os, "sched_setaffinity"):
+        return None
+    local_rank = int(os.getenv("LOCAL_RANK", "0")) if local_rank is None else local_rank
+    local_world = int(os.getenv("LOCAL_WORLD_SIZE", os.getenv("WORLD_SIZE", "1"))) if local_world is None else local_world
+    if local_world <= 1:
+        return None
+    cores = sorted(os.sched_getaffinity(0))
+    per = len(cores) // local_world
+    if per < 1:
+        return None
+    mine = cores[local_rank * per:(local_rank + 1) * per]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    return mine
 
 
 def shard_range(num_envs_global, rank, world):
@@ -58,8 +82,15 @@ class EpisodeStatsReducer:
         self.world = dist.get_world_size() if self.dist else 1
         self.on_gpu = stats_tensor.is_cuda
         self.side = torch.cuda.Stream(device=stats_tensor.device) if self.on_gpu else None
-        self.global_stats = torch.zeros_like(stats_tensor)
+        self.global_stats = self._snapshot_like()
         self._work = None
+
+    def _snapshot_like(self):
+        return torch.zeros_like(self.stats)
+
+    def _snapshot(self):
+        """what is all-reduced: a copy of the statistics tensor (subclasses widen it)"""
+        self.global_stats.copy_(self.stats)
 
     def step(self):
         """Call once per env step; launches the reduction every `interval` steps without blocking the step stream."""
@@ -75,11 +106,11 @@ class EpisodeStatsReducer:
         if self.on_gpu:
             self.side.wait_stream(torch.cuda.current_stream(self.stats.device))
             with torch.cuda.stream(self.side):
-                self.global_stats.copy_(self.stats)
+                self._snapshot()
                 if self.dist:
                     self._work = dist.all_reduce(self.global_stats, op=dist.ReduceOp.SUM, async_op=True)
         else:
-            self.global_stats.copy_(self.stats)
+            self._snapshot()
             if self.dist:
                 self._work = dist.all_reduce(self.global_stats, op=dist.ReduceOp.SUM, async_op=True)
 
@@ -105,10 +136,10 @@ class TaskExtrasReducer(EpisodeStatsReducer):
 
       AnymalTerrain  extras["episode"] as the reference forms it per step (anymal_terrain.py:421-425), over the window and over all ranks:
                      rew_<term> = sum of the episode sums of the envs that reset / their number / max_episode_length_s,
-                     terrain_level = mean level over envs and steps.  Tensor `episode_cum_stats` [16].
+                     terrain_level = mean level over envs and steps.  Tensor `episode_cum_stats` [32] (16 compensated sums: high parts, then low parts).
       ShadowHand / AllegroHand   the consecutive-successes average's numerator and denominator (shadow_hand.py:795-798):
                      mean successes of the episodes that ended in the window, and the job-wide moving average
-                     cs <- av_factor * that + (1 - av_factor) * cs, updated once per window (per step on a single rank).  `reward_workspace[2:4]`.
+                     cs <- av_factor * that + (1 - av_factor) * cs, updated once per window (per step on a single rank).  `reward_workspace[2:4]` (+ low parts `[4:6]`).
     """
 
     ANYMAL_KEYS = ("rew_lin_vel_xy", "rew_lin_vel_z", "rew_ang_vel_z", "rew_ang_vel_xy", "rew_orient", "rew_torques", "rew_joint_acc", "rew_base_height",
@@ -125,20 +156,81 @@ class TaskExtrasReducer(EpisodeStatsReducer):
             raise ValueError(f"{self.task}: no task extras to reduce (its episode statistics go through EpisodeStatsReducer)")
         super().__init__(src, interval, distributed)
         self.env = env
-        self.prev = torch.zeros_like(src, device="cpu")
+        self.prev = torch.zeros_like(self.global_stats, device="cpu")
+        self.base = self.prev.clone()
         self.window = None
         self.consecutive_successes = 0.0
+        self._launched = 0          # reductions started / turned into a window: a window is formed ONCE per completed reduction
+        self._consumed = 0
+
+    # The kernels keep each cumulative sum as a compensated pair of floats (core/rng.hpp two_sum_acc: AnymalTerrain [k] + [16 + k], hands
+    # [2], [3] + [4], [5]); the snapshot that is all-reduced is their float64 sum, so neither the accumulation nor the reduction over the ranks
+    # loses the small per-window increments once the totals are large (a float32 total passes 2^24 after ~1k steps of 4096 envs).
+    def _snapshot_like(self):
+        return torch.zeros(16 if self.task == "AnymalTerrain" else 4, dtype=torch.float64, device=self.stats.device)
+
+    def _snapshot(self):
+        s = self.stats.double()
+        if self.task == "AnymalTerrain":
+            torch.add(s[:16], s[16:32], out=self.global_stats)
+        else:
+            self.global_stats.zero_()
+            self.global_stats[2:4] = s[2:4] + s[4:6]
+
+    def reduce_async(self):
+        # the previous reduction becomes a window before its buffer is overwritten (it has had `interval` steps to complete: the wait is free)
+        if self._launched > self._consumed:
+            self._finish_window()
+        super().reduce_async()
+        self._launched += 1
+
+    def rebase(self):
+        """Forget the snapshot the next window is measured from: the cumulative sums were replaced under the reducer (set_env_state restored
+        an arena), so a difference to the old snapshot means nothing.  The next reduction only re-establishes the baseline."""
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        self._consumed = self._launched
+        self.prev = None
+
+    def poll(self):
+        """the newest completed window, without blocking: None until the first reduction after the baseline has finished"""
+        if self._launched > self._consumed and (self._work is None or self._work.is_completed()) and (
+                not self.on_gpu or self.side.query()):
+            self._finish_window()
+        return self.window
 
     def result(self):
-        """job-wide extras of the last reduced window (blocking)"""
+        """job-wide extras of the last reduced window (blocking).  Calling it again before the next reduction returns the same window."""
+        if self._launched > self._consumed:
+            self._finish_window()
+        return self.window
+
+    def _finish_window(self):
         if self._work is not None:
             self._work.wait()
             self._work = None
         if self.on_gpu:
             self.side.synchronize()
+        self._consumed = self._launched
         cur = self.global_stats.detach().cpu()
+        if self.prev is None or bool((cur[[13, 15]] < self.prev[[13, 15]]).any() if self.task == "AnymalTerrain" else (cur[2] < self.prev[2])):
+            self.prev = cur.clone()         # a baseline (after rebase(), or counters that ran backwards): no window from it
+            self.base = cur.clone()
+            return
         d = cur - self.prev
         self.prev = cur.clone()
+        self.window = self._window_of(d, update_average=True)
+
+    def since_baseline(self):
+        """job-wide extras over everything reduced since the baseline (construction, or the last rebase()): the same quantities as a window's"""
+        if self._launched > self._consumed:
+            self._finish_window()
+        if self.prev is None:
+            return None
+        return self._window_of(self.prev - self.base, update_average=False)
+
+    def _window_of(self, d, update_average):
         if self.task == "AnymalTerrain":
             cnt, steps = float(d[13]), max(float(d[15]), 1.0)          # [15] counts every rank's steps: steps of the window x ranks
             out = {}
@@ -147,12 +239,12 @@ class TaskExtrasReducer(EpisodeStatsReducer):
                     out[name] = float(d[k]) / cnt / float(self.env.max_episode_length_s)
             out["terrain_level"] = float(d[14]) / (self.env.num_envs * steps)        # mean over the envs of every rank and the window's steps
             out["num_resets"] = cnt
-            self.window = out
             return out
         resets, fin = float(d[2]), float(d[3])
-        if resets > 0:
+        if resets > 0 and update_average:
+            # the engine folds every step's finished episodes into its moving average (shadow_hand.py:795-798); job-wide the same update is made
+            # once per window with the window's ratio -- it feeds only `extras`
             av = float(self.env._task_params_struct.rew.av_factor)
             self.consecutive_successes = av * fin / resets + (1.0 - av) * self.consecutive_successes
-        self.window = {"num_resets": resets, "successes_per_reset": (fin / resets) if resets > 0 else 0.0,
-                       "consecutive_successes": self.consecutive_successes}
-        return self.window
+        return {"num_resets": resets, "successes_per_reset": (fin / resets) if resets > 0 else 0.0,
+                "consecutive_successes": self.consecutive_successes}

@@ -776,7 +776,15 @@ class Gym:
             m = np.asarray(a.spec.mass, np.float64)
             driven = np.asarray(self._base_dof_props(sim, sim.robot)["stiffness"]) > 0
             damped = np.asarray(self._base_dof_props(sim, sim.robot)["damping"]) > 0
-            sc[:, 0] = put(pr.body[:n] @ m / m.sum())
+            bm = t.get("hand_body_mass_scale")
+            if bm is not None and a.task == "ShadowHand":
+                # per BODY, as the setter was given them (round 5); the kernels that read the tensor are switched in with the first factor != 1
+                bm[:] = put(pr.body[:n])
+                sc[:, 0] = 1.0
+                if np.any(pr.body[:n] != 1.0):
+                    sim.engine.set_option("hand_body_mass", 1)
+            else:
+                sc[:, 0] = put(pr.body[:n] @ m / m.sum())
             sc[:, 1] = put(pr.damp[:n][:, damped].mean(1) if damped.any() else np.ones(n))
             sc[:, 2] = put(pr.stiff[:n][:, driven].mean(1) if driven.any() else np.ones(n))
             if self.get_asset_tendon_count(a) > 0 and (a.tendon_props is None or any(tp_ != (0.0, 0.0) for tp_ in a.tendon_props)):

@@ -8,7 +8,12 @@ UNMODIFIED, beside the `isaacgym` / `gym` stand-ins (shims/__init__.py already r
   (allegro_hand_dextreme.py:1630).  TorchScript resolves `torch.where` to the builtin, which a Python-level wrapper cannot reach, so inside
   `environment()` `torch.jit.script` is the identity: the task's own jitted functions run eagerly (same arithmetic, same results), with the wrapper.
 
-Everything is undone on exit.  Nothing of the engine depends on this module; tests/test_gymapi_shim.py uses it for the dextreme task only."""
+Everything is undone on exit.  Nothing of the engine depends on this module; tests/test_gymapi_shim.py uses it for the dextreme task only.
+
+NOT THREAD-SAFE, and not for production use: inside `environment()` `torch.where` and `torch.jit.script` are patched PROCESS-WIDE -- a
+concurrent thread sees the patched functions, and a module first imported inside the context keeps its functions un-scripted for the life of the
+process.  Use it from one thread, around the construction and stepping of a legacy task file only.  It serves `tasks/dextreme/`, which SURVEY 2 #16
+marks out of scope: kept for the tests that exist, not developed further."""
 import contextlib
 import sys
 import types

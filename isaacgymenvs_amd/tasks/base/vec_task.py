@@ -134,6 +134,41 @@ class VecTask(Env):
         self.sim_initialized = True
         self.allocate_buffers()
         self.obs_dict = {}
+        self._job_extras = None
+        if config.get("_multi_gpu", False):
+            self._enable_job_extras(int(config.get("_extras_interval", 16)))
+
+    def _enable_job_extras(self, interval):
+        """Sharded run (`make(..., multi_gpu=True)` inside a torch.distributed job): the task's `extras` statistics become JOB-wide -- SURVEY 8e's
+        one collective, a SUM all-reduce of <= 16 numbers on a side stream every `interval` steps (parallel.TaskExtrasReducer); step() publishes
+        each completed window (one window behind, never blocking the step stream) and keeps this rank's own values under `*_rank`.
+        Ant / Humanoid / ... have no task extras of this kind: their episode statistics go through parallel.EpisodeStatsReducer."""
+        import torch.distributed as dist
+        if self.native_task not in ("AnymalTerrain", "ShadowHand", "AllegroHand") or not (dist.is_available() and dist.is_initialized()):
+            return
+        from ...parallel import TaskExtrasReducer
+        self._job_extras = TaskExtrasReducer(self, interval=interval)
+        self._job_window = None
+
+    def _publish_job_extras(self):
+        red = self._job_extras
+        red.step()
+        w = red.poll()
+        if w is None or w is self._job_window:
+            return
+        self._job_window = w
+        dev = self.obs_buf.device
+        if self.native_task == "AnymalTerrain":
+            if "episode_rank" not in self.extras:
+                self.extras["episode_rank"] = self.extras.get("episode", {})
+            # (a window in which nobody reset carries only the terrain level: the reward terms keep their last values, as the reference's dict does)
+            job = dict(self.extras["episode"]) if self.extras.get("episode") is not self.extras["episode_rank"] else {}
+            job.update({k: torch.tensor(v, dtype=torch.float32, device=dev) for k, v in w.items() if k != "num_resets"})
+            self.extras["episode"] = job
+        else:
+            if "consecutive_successes_rank" not in self.extras:
+                self.extras["consecutive_successes_rank"] = self.extras.get("consecutive_successes")
+            self.extras["consecutive_successes"] = torch.tensor(w["consecutive_successes"], dtype=torch.float32, device=dev)
 
     # ------------------------------------------------------------------ sim params (vec_task.py:514-562)
     def _parse_sim_params(self, physics_engine: str, config_sim: Dict[str, Any]) -> native.MiSimParams:
@@ -225,6 +260,8 @@ class VecTask(Env):
             self.obs_buf[:] = self._torch_noise["observations"](self.obs_buf)
             obs = torch.clamp(self.obs_buf, -self.clip_obs, self.clip_obs)
         self._post_step_extras()
+        if self._job_extras is not None:
+            self._publish_job_extras()
         if self._rl_is_sim:          # (vec_task.py:402-408 moves every output to rl_device: the same device here, so the tensors themselves)
             self.extras["time_outs"] = self.timeout_buf
             self.obs_dict["obs"] = obs
@@ -408,13 +445,17 @@ class VecTask(Env):
                     elif isinstance(col, tuple):
                         # one draw per env and body / dof; the engine multiplies the model's own value, so an element whose model value is
                         # zero (an Ant joint has no stiffness) keeps factor 1: `scaling` leaves it zero anyway, `additive` cannot be expressed
+                        dst = scales
+                        if len(col) == 3:      # (tensor name, first column, model values): a tensor of its own (the ShadowHand's per-body link masses)
+                            dst, col = t[col[0]], col[1:]
+                            self._on_body_tensor_written()
                         c0, base = col
                         og = {"v": np.tile(base, (len(ids), 1))}
                         vals = np.asarray(apply_random_samples_array({"v": og["v"].copy()}, og, "v", prm, self.last_step), np.float64)
                         factor = np.where(base > 0, np.clip(vals / np.where(base > 0, base, 1.0), 0.05, 20.0), 1.0)
                         if prm.get("operation") == "additive" and (base <= 0).any() and self.first_randomization:
                             skipped.append(f"{actor}.{group}.{attr} (additive on model values of zero)")
-                        scales[ids, c0:c0 + len(base)] = torch.as_tensor(factor.astype(np.float32), device=self.device)
+                        dst[ids, c0:c0 + len(base)] = torch.as_tensor(factor.astype(np.float32), device=self.device)
                     else:
                         ref_val = self._actor_reference_value(group, attr, actor)
                         og = {"v": np.full(len(ids), ref_val)}
@@ -424,6 +465,9 @@ class VecTask(Env):
         if skipped and self.first_randomization:
             import warnings
             warnings.warn("actor_params entries without an engine counterpart are skipped (reference vec_task.py:752-828): " + ", ".join(skipped))
+
+    def _on_body_tensor_written(self):
+        """hook of the tasks whose kernels read a per-body factor tensor only when told to (ShadowHand: option "hand_body_mass")"""
 
     def _enable_actor_tensors(self):
         """the sub-step kernels of Ant / Humanoid read `actor_scale` / `dof_limit_shift` only when told to (option "actor_tensors")"""
@@ -500,6 +544,7 @@ class VecTask(Env):
                 "control_steps": self.control_steps, "engine_steps": self.engine.get_option("steps"),
                 "gravity": g, "noise": {k: dict(v) for k, v in self.dr_randomizations.items() if isinstance(v, dict) and "dist" in v},
                 "noise_epoch": int(getattr(self, "_noise_epoch", -1)), "actor_tensors": bool(getattr(self, "_actor_tensors_on", False)),
+                "hand_body_mass": bool(getattr(self, "_hand_body_mass_on", False)),
                 "torch_noise_corr": {k: (None if n.corr is None else n.corr.clone()) for k, n in self._torch_noise.items()},
                 "last_rand_step": int(getattr(self, "last_rand_step", -1)), "first_randomization": bool(getattr(self, "first_randomization", True)),
                 "last_step": int(getattr(self, "last_step", -1))}
@@ -515,6 +560,8 @@ class VecTask(Env):
             raise RuntimeError(f"set_env_state: checkpoint of {env_state.get('task', '?')} with {env_state['arena'].numel()} arena bytes does not fit "
                                f"{self.native_task} with {self.engine.arena.numel()}")
         self.engine.arena.copy_(env_state["arena"])
+        if self._job_extras is not None:
+            self._job_extras.rebase()        # the cumulative sums were just replaced: the next reduction is a new baseline, not a window
         self.control_steps = env_state.get("control_steps", 0)
         # the engine's own step counter drives the observation-ring parity, the AnymalTerrain push schedule and the noise counters
         self.engine.set_option("steps", env_state.get("engine_steps", self.control_steps))
@@ -536,6 +583,8 @@ class VecTask(Env):
                 self._torch_noise[name] = _TorchNoise(keys, None if corr is None else corr.clone())
         if env_state.get("actor_tensors") and not getattr(self, "_actor_tensors_on", False):
             self._enable_actor_tensors()
+        if env_state.get("hand_body_mass"):
+            self._on_body_tensor_written()
         for k in ("last_rand_step", "first_randomization", "last_step"):
             if k in env_state:
                 setattr(self, k, env_state[k])

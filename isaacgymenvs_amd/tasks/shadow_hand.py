@@ -229,7 +229,17 @@ class ShadowHand(VecTask):
                           ("object", "scale", "scale"): 6}
 
     def _actor_scale_column(self, actor, group, attr):
+        if (actor, group, attr) == ("hand", "rigid_body_properties", "mass") and "hand_body_mass_scale" in self.engine.tensors:
+            # one draw per env and BODY, as the reference samples the hand's rigid-body property list (vec_task.py:783-828; ShadowHand.yaml:104-110):
+            # the `hand_body_mass_scale` tensor, read by the Sim<Scaled<M>> kernels once option "hand_body_mass" is on.  (Until round 5: one
+            # factor per env, column 0 of `actor_scale`; that column stays 1.)
+            return ("hand_body_mass_scale", 0, np.asarray(self.spec.mass, np.float64))
         return self.HAND_SCALE_COLUMNS.get((actor, group, attr))
+
+    def _on_body_tensor_written(self):
+        if not getattr(self, "_hand_body_mass_on", False):
+            self.engine.set_option("hand_body_mass", 1)
+            self._hand_body_mass_on = True
 
     def _actor_reference_value(self, group, attr, actor=None):
         """what an `additive` draw is relative to (a `scaling` draw is the factor itself)"""

@@ -15,6 +15,7 @@
  *   object  free rigid body (cube: isotropic inertia; egg / pen: principal inertias about the body axes), gravity on
  *   contact hand collision geometry sampled by spheres against the exact box / capsule, first-order ellipsoid; 3 rows per contact
  *           (normal + friction disc), no warm start of object contacts
+ *   pairs   the asset's 18 explicit hand-to-hand contact pairs (shared.xml:31-51, frictionless) as compliant contacts: h_pairs()
  *   solver 0  one Gauss-Seidel sequence: all limit rows, then the contacts in sphere order; at most kmax contacts per env and
  *             body_cap per hand body (the single-wave kernel hand_substep_kernel)
  *   solver 1  BLOCK sweeps (the finger-per-wave kernel hand_substep_mw_kernel): the hand's limbs (0 = forearm / wrist / palm, 1..5 =
@@ -37,6 +38,14 @@ typedef struct {
     const int32_t *limb_of_body;             /* [nb] (solver 1) */
     const int32_t *limb_cap;                 /* [nlimb] (solver 1) */
     const real *fmax;                        /* [nd] drive force limits (0: none), or NULL -- physics.c OrDriveClamp */
+    /* the asset's explicit hand-to-hand contact pairs (MJCF <contact><pair>, reference assets/mjcf/open_ai_assets/hand/shared.xml:31-51;
+     * models/shadow_hand_extras.json "pairs"): side a a capsule (axis end points a0, a1 in the body frame, radius ra) or a box (pair_box: a0 =
+     * centre, a1 = half sizes), side b a capsule; COMPLIANT contacts of stiffness pair_k (0: off) -- h_pairs() below */
+    int32_t npair, pad2;
+    const int32_t *pair_ba, *pair_bb, *pair_box;   /* [npair] */
+    const real *pair_a0, *pair_a1, *pair_ra, *pair_b0, *pair_b1, *pair_rb;   /* [npair*3] / [npair] */
+    real pair_k;
+    int32_t *pair_sides;                     /* [nenv] out (or NULL): pair sides pushed in the last sub-step */
 } OrHand;
 
 static void h_contact_frame(const real *n, real *t1, real *t2) {       /* oracle/hand.py contact_frame */
@@ -79,6 +88,78 @@ static real h_sphere_capsule(const real *c, real r, real rc, real hl, real *n) {
     return nn - rc - r;
 }
 
+/* sphere (centre c in the box frame, radius r) against a box of half sizes a[3]: signed distance, outward normal */
+static real h_sphere_box3(const real *c, real r, const real *a, real *n) {
+    real qc[3], d[3], nd = 0;
+    for (int k = 0; k < 3; k++) { qc[k] = c[k] < -a[k] ? -a[k] : (c[k] > a[k] ? a[k] : c[k]); d[k] = c[k] - qc[k]; nd += d[k] * d[k]; }
+    nd = RSQRT(nd);
+    if (nd > (real)1e-12) { for (int k = 0; k < 3; k++) n[k] = d[k] / nd; return nd - r; }
+    int i = 0;
+    real pen[3];
+    for (int k = 0; k < 3; k++) pen[k] = a[k] - RFABS(c[k]);
+    for (int k = 1; k < 3; k++) if (pen[k] < pen[i]) i = k;
+    n[0] = n[1] = n[2] = 0;
+    n[i] = c[i] >= 0 ? 1 : -1;
+    return -pen[i] - r;
+}
+
+/* The hand-to-hand pairs as compliant contacts (csrc/core/hand_engine.hpp pair_side states the model): for every listed pair whose shapes
+ * overlap by pen > 0 at the start of the sub-step -- capsule axes: exact closest points; the palm box against the thumb tip's capsule sampled by
+ * the spheres at its ends and its middle, the deepest one -- each side s is pushed along u_s (u_a = n from b towards a, u_b = -n) at the contact
+ * point (the middle of the overlap) by F_s = k (pen - h J_s qd+): M += h^2 k J_s^T J_s, rhs += J_s^T k (pen - h J_s qd).  Frictionless (condim 1).
+ * Returns the number of sides pushed. */
+static int h_pairs(const OrModel *m, const OrHand *hd, const Work *w, real h, const real *qd, real (*M)[MAXV], real *rhs) {
+    int sides = 0;
+    static _Thread_local real Jr[MAXV];
+    for (int p = 0; p < hd->npair; p++) {
+        const int ba = hd->pair_ba[p], bb = hd->pair_bb[p];
+        real b0[3], b1[3], t[3], n[3], pc[3], dist;
+        m3v(w->R[bb], hd->pair_b0 + 3 * p, t); for (int c = 0; c < 3; c++) b0[c] = w->r[bb][c] + t[c];
+        m3v(w->R[bb], hd->pair_b1 + 3 * p, t); for (int c = 0; c < 3; c++) b1[c] = w->r[bb][c] + t[c];
+        if (hd->pair_box[p]) {
+            dist = (real)1e30;
+            for (int s = 0; s < 3; s++) {
+                real cw[3], rel[3], cl[3], nl[3], nw[3];
+                for (int c = 0; c < 3; c++) { cw[c] = b0[c] + (real)0.5 * s * (b1[c] - b0[c]); rel[c] = cw[c] - w->r[ba][c]; }
+                m3tv(w->R[ba], rel, cl);
+                for (int c = 0; c < 3; c++) cl[c] -= hd->pair_a0[3 * p + c];
+                real ds = h_sphere_box3(cl, hd->pair_rb[p], hd->pair_a1 + 3 * p, nl);
+                if (ds < dist) {
+                    dist = ds;
+                    m3v(w->R[ba], nl, nw);        /* from the box towards the sphere */
+                    for (int c = 0; c < 3; c++) { n[c] = -nw[c]; pc[c] = cw[c] - nw[c] * (hd->pair_rb[p] + (real)0.5 * ds); }
+                }
+            }
+        } else {
+            real a0[3], a1[3], ca[3], cb[3];
+            m3v(w->R[ba], hd->pair_a0 + 3 * p, t); for (int c = 0; c < 3; c++) a0[c] = w->r[ba][c] + t[c];
+            m3v(w->R[ba], hd->pair_a1 + 3 * p, t); for (int c = 0; c < 3; c++) a1[c] = w->r[ba][c] + t[c];
+            seg_seg_closest(a0, a1, b0, b1, ca, cb);
+            real dv[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]};
+            real d = RSQRT(v3dot(dv, dv));
+            if (d > (real)1e-9) { n[0] = dv[0] / d; n[1] = dv[1] / d; n[2] = dv[2] / d; } else { n[0] = 0; n[1] = 0; n[2] = 1; }
+            dist = d - hd->pair_ra[p] - hd->pair_rb[p];
+            for (int c = 0; c < 3; c++) pc[c] = cb[c] + n[c] * (hd->pair_rb[p] + (real)0.5 * dist);
+        }
+        const real pen = -dist;
+        if (!(pen > 0)) continue;
+        for (int s = 0; s < 2; s++) {
+            const real u[3] = {s ? -n[0] : n[0], s ? -n[1] : n[1], s ? -n[2] : n[2]};
+            point_jac(m, w, s ? bb : ba, pc, u, Jr);
+            real vs = 0;
+            for (int i = 0; i < m->nd; i++) vs += Jr[i] * qd[i];
+            const real a = h * h * hd->pair_k, f = hd->pair_k * (pen - h * vs);
+            for (int i = 0; i < m->nd; i++) {
+                if (Jr[i] == 0) continue;
+                rhs[i] += Jr[i] * f;
+                for (int j = 0; j < m->nd; j++) M[i][j] += a * Jr[i] * Jr[j];
+            }
+            sides++;
+        }
+    }
+    return sides;
+}
+
 #define HMAXC 64      /* contacts per env */
 #define HNV 30        /* 24 hand dofs + 6 object dofs */
 
@@ -87,7 +168,7 @@ typedef struct { int b, si; real pc[3], n[3], t1[3], t2[3]; int row0; } HContact
 /* one sub-step of one env.  st: root13 | q | qd | laml ; obj: pos3 quat4 vel3 angvel3 */
 static void hand_substep(const OrModel *m, const OrParams *p, const OrHand *hd, real h, real *st, real *obj, const real *tgt,
                          const real *fobj, const real *scale, const real *lshift, real mu, real *sensor, real *dof_force, int32_t *ncontact,
-                         int32_t *limb_count) {
+                         int32_t *limb_count, int32_t *pair_sides) {
     static _Thread_local Work w;
     static _Thread_local real J[MAXROWS][MAXV], Bm[MAXROWS][MAXV];
     const int nd = m->nd;
@@ -114,6 +195,10 @@ static void hand_substep(const OrModel *m, const OrParams *p, const OrHand *hd, 
         real a = h * dmp + h * h * k, f = k * viol + (dmp + h * k) * Ld;
         w.M[d0][d0] += a * c0 * c0; w.M[d1][d1] += a * c1 * c1; w.M[d0][d1] += a * c0 * c1; w.M[d1][d0] += a * c0 * c1;
         rhs[d0] -= c0 * f; rhs[d1] -= c1 * f;
+    }
+    {   /* the asset's hand-to-hand contact pairs: compliant contacts */
+        int sides = (hd->npair > 0 && hd->pair_k > 0) ? h_pairs(m, hd, &w, h, qd, w.M, rhs) : 0;
+        if (pair_sides) *pair_sides = sides;
     }
     /* object: mass matrix in world axes */
     real Ro[9], xo[3] = {obj[0], obj[1], obj[2]};
@@ -341,7 +426,8 @@ void or_hand_step(const OrModel *m, const OrParams *p, const OrHand *hd, int nen
         for (int s = 0; s < p->substeps; s++)
             hand_substep(m, p, hd, h, state + (size_t)e * ss, obj + (size_t)e * 13, targets + (size_t)e * nd, obj_force + (size_t)e * 3,
                          scale + (size_t)e * 8, limit_shift + (size_t)e * 2 * nd, mu, sensor + (size_t)e * 6 * m->nsens,
-                         dof_force + (size_t)e * nd, ncontacts + e, limb_counts ? limb_counts + (size_t)e * hd->nlimb : NULL);
+                         dof_force + (size_t)e * nd, ncontacts + e, limb_counts ? limb_counts + (size_t)e * hd->nlimb : NULL,
+                         hd->pair_sides ? hd->pair_sides + e : NULL);
     }
 }
 

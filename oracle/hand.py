@@ -84,8 +84,41 @@ def _hand_struct():
         _fields_ = [(n, C.c_int32) for n in ("nos", "ntend", "kmax", "body_cap", "shape", "solver", "nlimb", "pad")] + \
                    [(n, C.c_void_p) for n in ("os_body", "os_pos", "os_rad", "tend_d0", "tend_d1", "tend_c0", "tend_c1", "tend_lo", "tend_hi")] + \
                    [("tend_stiffness", r), ("tend_damping", r), ("kp", C.c_void_p), ("obj_mass", r), ("obj_inertia", r * 3),
-                    ("obj_dims", r * 3), ("mu", r), ("limb_of_body", C.c_void_p), ("limb_cap", C.c_void_p), ("fmax", C.c_void_p)]
+                    ("obj_dims", r * 3), ("mu", r), ("limb_of_body", C.c_void_p), ("limb_cap", C.c_void_p), ("fmax", C.c_void_p)] + \
+                   [("npair", C.c_int32), ("pad2", C.c_int32)] + \
+                   [(n, C.c_void_p) for n in ("pair_ba", "pair_bb", "pair_box", "pair_a0", "pair_a1", "pair_ra", "pair_b0", "pair_b1", "pair_rb")] + \
+                   [("pair_k", r), ("pair_sides", C.c_void_p)]
     return OrHand
+
+
+PAIR_K = 2.0e4       # N/m: the engine's default stiffness of the compliant hand-to-hand pairs (csrc/mi_engine.hip: hv.pair_k for the ShadowHand)
+
+
+def segment_closest(a0, a1, b0, b1):
+    """closest points of two segments (clamped construction, the order of oracle/physics.c seg_seg_closest)"""
+    d1, d2, rr = a1 - a0, b1 - b0, a0 - b0
+    A, E, F, Cc, B = d1 @ d1, d2 @ d2, d2 @ rr, d1 @ rr, d1 @ d2
+    eps, den = 1e-12, A * E - B * B
+    s = min(max((B * F - Cc * E) / den, 0.0), 1.0) if (den > eps and A > eps) else 0.0
+    t = (B * s + F) / E if E > eps else 0.0
+    tc = min(max(t, 0.0), 1.0)
+    if (t != tc or not E > eps) and A > eps:
+        s = min(max((B * tc - Cc) / A, 0.0), 1.0)
+    return a0 + d1 * s, b0 + d2 * tc
+
+
+def sphere_box3(c_local, r, half):
+    """sphere_box for a box with three half sizes"""
+    half = np.asarray(half, float)
+    d = c_local - np.clip(c_local, -half, half)
+    nd = np.linalg.norm(d)
+    if nd > 1e-12:
+        return nd - r, d / nd
+    pen = half - np.abs(c_local)
+    i = int(np.argmin(pen))
+    n = np.zeros(3)
+    n[i] = 1.0 if c_local[i] >= 0 else -1.0
+    return -pen[i] - r, n
 
 
 class OracleHandEngine:
@@ -131,6 +164,11 @@ class OracleHandEngine:
         # joint damping, drive stiffness, tendon limit stiffness, tendon damping, object mass (+ inertia), object size
         self.scale = np.ones((num_envs, 8))
         self.limit_shift = np.zeros((num_envs, 2 * spec.nd))       # dof_properties.lower / upper: shifts of the lower, then the upper limits
+        # the asset's explicit hand-to-hand contact pairs (shared.xml:31-51; extras["pairs"]) as compliant contacts of stiffness pair_k
+        # (hand.c h_pairs; 0 = off).  Set before the first step.
+        self.pairs = list(extras.get("pairs", []))
+        self.pair_k = PAIR_K if self.pairs else 0.0
+        self.pair_sides = np.zeros(num_envs, np.int32)             # pair sides pushed in the last sub-step
 
     # views on the wrapped engine's state
     @property
@@ -205,6 +243,17 @@ class OracleHandEngine:
             k["limb_cap"] = np.ascontiguousarray(self.blocks["limb_cap"], np.int32)
             hd.nlimb = len(k["limb_cap"])
             hd.limb_of_body, hd.limb_cap = _ptr(k["limb_of_body"]), _ptr(k["limb_cap"])
+        pr = self.pairs
+        k["pair_ba"] = np.ascontiguousarray([q["a"]["body"] for q in pr], np.int32); k["pair_bb"] = np.ascontiguousarray([q["b"]["body"] for q in pr], np.int32)
+        k["pair_box"] = np.ascontiguousarray([int(q["a"]["kind"] == "box") for q in pr], np.int32)
+        for side in "ab":
+            k["pair_%s0" % side] = np.ascontiguousarray([q[side]["p0"] for q in pr], np.float64).reshape(-1)
+            k["pair_%s1" % side] = np.ascontiguousarray([q[side]["p1"] for q in pr], np.float64).reshape(-1)
+            k["pair_r%s" % side] = np.ascontiguousarray([q[side]["r"] for q in pr], np.float64)
+        hd.npair, hd.pair_k = len(pr), float(self.pair_k)
+        for n in ("pair_ba", "pair_bb", "pair_box", "pair_a0", "pair_a1", "pair_ra", "pair_b0", "pair_b1", "pair_rb"):
+            setattr(hd, n, _ptr(k[n]) if len(pr) else None)
+        hd.pair_sides = _ptr(self.pair_sides)
         self._hd = hd
         self._nc32 = np.zeros(self.N, np.int32)
         self.limb_counts = np.zeros((self.N, max(int(hd.nlimb), 1)), np.int32)     # solver "blocks": contacts kept per limb, last sub-step
@@ -218,6 +267,7 @@ class OracleHandEngine:
             e.set_params(**dict(P, gravity=tuple(P["gravity"])))     # (the object's gravity; the hand's is switched off inside hand.c)
             st = e.state
             assert st.shape[1] == 13 + 3 * self.nd and st.flags.c_contiguous
+            self._hd.pair_k = float(self.pair_k)
             mu = None if self.env_mu is None else np.ascontiguousarray(self.env_mu, np.float64)
             tg = np.ascontiguousarray(self.targets, np.float64); fo = np.ascontiguousarray(self.obj_force, np.float64)
             sc = np.ascontiguousarray(self.scale, np.float64); ls = np.ascontiguousarray(self.limit_shift, np.float64)
@@ -251,6 +301,44 @@ class OracleHandEngine:
             cvec = np.zeros(nd); cvec[d0] = c0; cvec[d1] = c1
             Mh += (h * dmp + h * h * k) * np.outer(cvec, cvec)
             rhs -= cvec * (k * viol + (dmp + h * k) * Ld)
+        bp = self._poses(e)
+        O = self.eng.root[e, :3]
+        s_state = np.ascontiguousarray(self.eng.state[e])
+        J3 = np.zeros((3, nd))
+        # the asset's hand-to-hand contact pairs as compliant contacts (hand.c h_pairs): each side of an overlapping pair is pushed along its
+        # outward direction by the implicit spring k (pen - h J qd+)
+        sides = 0
+        for pr in (self.pairs if self.pair_k > 0 else []):
+            ba, bb = pr["a"]["body"], pr["b"]["body"]
+            Ra, ra_, Rb_, rb_ = bp[ba, 3:12].reshape(3, 3), bp[ba, 0:3], bp[bb, 3:12].reshape(3, 3), bp[bb, 0:3]
+            b0, b1 = rb_ + Rb_ @ np.array(pr["b"]["p0"]), rb_ + Rb_ @ np.array(pr["b"]["p1"])
+            if pr["a"]["kind"] == "box":
+                best = None
+                for t_ in (0.0, 0.5, 1.0):
+                    cw = b0 + t_ * (b1 - b0)
+                    ds, nl = sphere_box3(Ra.T @ (cw - ra_) - np.array(pr["a"]["p0"]), pr["b"]["r"], pr["a"]["p1"])
+                    if best is None or ds < best[0]:
+                        nw = Ra @ nl
+                        best = (ds, -nw, cw - nw * (pr["b"]["r"] + 0.5 * ds))
+                dist, n, pc = best
+            else:
+                ca, cb = segment_closest(ra_ + Ra @ np.array(pr["a"]["p0"]), ra_ + Ra @ np.array(pr["a"]["p1"]), b0, b1)
+                dv = ca - cb
+                d = np.linalg.norm(dv)
+                n = dv / d if d > 1e-9 else np.array([0.0, 0.0, 1.0])
+                dist = d - pr["a"]["r"] - pr["b"]["r"]
+                pc = cb + n * (pr["b"]["r"] + 0.5 * dist)
+            pen = -dist
+            if not pen > 0:
+                continue
+            self.pair_pen_max = max(getattr(self, "pair_pen_max", 0.0), pen)      # (numpy backend: the deepest overlap met so far, a diagnostic)
+            for body, u in ((ba, n), (bb, -n)):
+                self.eng.lib.or_point_jac(C.byref(self.eng.model), _ptr(s_state), body, _ptr(np.ascontiguousarray(pc - O)), _ptr(J3))
+                Js = u @ J3
+                Mh += h * h * self.pair_k * np.outer(Js, Js)
+                rhs += Js * self.pair_k * (pen - h * (Js @ qd))
+                sides += 1
+        self.pair_sides[e] = sides
         Minv = np.linalg.inv(Mh)
         v = qd + h * (Minv @ rhs)
         g = np.array(P["gravity"], float)
@@ -275,10 +363,6 @@ class OracleHandEngine:
             vt = -Cc / h if Cc >= 0 else min(-Cc * P["erp"] / h, P["max_depen_vel"])
             fm = float(self.force_limit[d]) if (self.force_limit is not None and kp[d] > 0) else 0.0
             rows.append(dict(Jh=Jh, Jo=np.zeros(6), vt=vt, lam=l0, kind="lim", d=d, s=s, fmax=fm, fa=-kp[d] * (q[d] - tgt[d]), c=D[d] + h * kp[d], rho=0.0))
-        bp = self._poses(e)
-        O = self.eng.root[e, :3]
-        s_state = np.ascontiguousarray(self.eng.state[e])
-        J3 = np.zeros((3, nd))
         ncon = 0
         contacts = []
         per_body = {}

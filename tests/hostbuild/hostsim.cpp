@@ -357,6 +357,12 @@ extern "C" int hs_step_terrain(const char* model, const SimParams* P, int nenv, 
 #ifdef HOSTSIM_HAND
 // Shadow hand + cube: per env  q[24] | qd[24] | laml[24] | target[24] | obj[13]  ->  updated in place; out: sensor[30] | dof_force[24] | ncontact
 // scale: null or [nenv][8] per-env `actor_params` factors (core/hand_engine.hpp HS_*); limit_shift: null or [nenv][48]
+// stiffness of the asset's hand-to-hand contact pairs for the next hs_step_hand / hs_step_hand_mw calls (default: the engine's 2e4 N/m for the Shadow Hand; 0 = off); the pair sides
+// pushed in the last sub-step of the last call's env 0 come back through hs_hand_pair_sides
+static float g_pair_k = 2.0e4f;
+static int g_pair_sides = 0;
+extern "C" void hs_set_hand_pair_stiffness(float k) { g_pair_k = k; }
+extern "C" int hs_hand_pair_sides() { return g_pair_sides; }
 extern "C" int hs_step_hand(const SimParams* P, int nenv, float* state, float* out, const float* root13, float half, float mass, float inertia,
                             float mu, const float* scale, const float* limit_shift) {
     using M = ModelShadowHand;
@@ -375,6 +381,7 @@ extern "C" int hs_step_hand(const SimParams* P, int nenv, float* state, float* o
         static const float no_shift[2 * ND] = {0};
         sim.limit_shift = Strided{const_cast<float*>(limit_shift ? limit_shift + e * 2 * ND : no_shift), 1};
         for (int k = 0; k < 13; ++k) sim.root[k] = root13[k];
+        sim.pair_k = g_pair_k;
         for (int k = 0; k < ND; ++k) { sim.q[k] = s[k]; sim.qd[k] = s[ND + k]; }
         float* ob = s + 4 * ND;
         for (int k = 0; k < 3; ++k) { sim.obj.pos[k] = ob[k]; sim.obj.vel[k] = ob[7 + k]; sim.obj.angvel[k] = ob[10 + k]; }
@@ -385,6 +392,7 @@ extern "C" int hs_step_hand(const SimParams* P, int nenv, float* state, float* o
         for (int it = 0; it < P->substeps; ++it)
             sim.substep_hand(*P, OP, s + 3 * ND, h, RowStore<1>{rows}, Strided{s + 2 * ND, 1}, Strided{o, 1}, Strided{o + 6 * NS, 1}, &nc);
         o[6 * NS + ND] = (float)(nc & 0xFFFF);
+        if (e == 0) g_pair_sides = sim.pair_active;
         for (int k = 0; k < ND; ++k) { s[k] = sim.q[k]; s[ND + k] = sim.qd[k]; }
         for (int k = 0; k < 3; ++k) { ob[k] = sim.obj.pos[k]; ob[7 + k] = sim.obj.vel[k]; ob[10 + k] = sim.obj.angvel[k]; }
         for (int k = 0; k < 4; ++k) ob[3 + k] = sim.obj.quat[k];
@@ -396,7 +404,7 @@ extern "C" int hs_step_hand(const SimParams* P, int nenv, float* state, float* o
 // (dims / inertia3: the object's dimensions and principal inertias for shapes 1, 2)
 struct HandMwJob {
     const SimParams* P; float* s; float* o; const float* root13; ObjectParams OP; const float* scale; const float* lshift; float* rows;
-    pthread_barrier_t* bar; int* nc;
+    pthread_barrier_t* bar; int* nc; int* sides;
 };
 template <int R, int SHAPE>
 static void hand_mw_thread(HandMwJob j) {
@@ -406,6 +414,7 @@ static void hand_mw_thread(HandMwJob j) {
     HandSimMW<M> sim;
     if (j.scale) sim.actor_scale = Strided{const_cast<float*>(j.scale), 1};
     sim.limit_shift = Strided{const_cast<float*>(j.lshift), 1};
+    sim.pair_k = g_pair_k;
     for (int k = 0; k < 13; ++k) sim.root[k] = j.root13[k];
     float* ob = j.s + 4 * ND;
     const float h = j.P->dt / (float)j.P->substeps;
@@ -418,6 +427,7 @@ static void hand_mw_thread(HandMwJob j) {
         sim.template substep_hand_role<R, 1, SHAPE>(*j.P, j.OP, j.s + 3 * ND, h, RowStore<1>{j.rows}, Strided{j.s + 2 * ND, 1}, Strided{j.o, 1},
                                                     Strided{j.o + 6 * NS, 1}, &nc, HostBarrier{j.bar});
         sfor<ND>([&](auto K) { if constexpr (MW::template owns_gi<R>(K)) { j.s[K] = sim.q[K]; j.s[ND + K] = sim.qd[K]; } });
+        j.sides[R] = sim.pair_active;
         if constexpr (R == M::TRUNK_ROLE) {
             for (int k = 0; k < 3; ++k) { ob[k] = sim.obj.pos[k]; ob[7 + k] = sim.obj.vel[k]; ob[10 + k] = sim.obj.angvel[k]; }
             for (int k = 0; k < 4; ++k) ob[3 + k] = sim.obj.quat[k];
@@ -447,10 +457,11 @@ extern "C" int hs_step_hand_mw(const SimParams* P, int nenv, float* state, float
         std::vector<float> rows(HandSimMW<M>::MW_SLOTS, 0.f);
         pthread_barrier_t bar;
         pthread_barrier_init(&bar, nullptr, 4);
-        int nc = 0;
-        HandMwJob j{P, s, o, root13, OP, scale ? scale + e * HS_COLUMNS : nullptr, limit_shift ? limit_shift + e * 2 * ND : no_shift, rows.data(), &bar, &nc};
+        int nc = 0, sides[4] = {0, 0, 0, 0};
+        HandMwJob j{P, s, o, root13, OP, scale ? scale + e * HS_COLUMNS : nullptr, limit_shift ? limit_shift + e * 2 * ND : no_shift, rows.data(), &bar, &nc, sides};
         if (shape == 0) hand_mw_env<OBJ_BOX>(j); else if (shape == 1) hand_mw_env<OBJ_CAPSULE>(j); else hand_mw_env<OBJ_ELLIPSOID>(j);
         pthread_barrier_destroy(&bar);
+        if (e == 0) g_pair_sides = sides[0] + sides[1] + sides[2] + sides[3];
         o[6 * NS + ND] = (float)(nc & 0xFFFF);
     }
     return 0;

@@ -31,7 +31,7 @@ def make_params(d):
 _MODELS = {"cartpole": ("HOSTSIM_CARTPOLE", "-O2"), "ant": ("HOSTSIM_ANT", "-O2"), "anymal": ("HOSTSIM_ANYMAL", "-O2"),
            "quadcopter": ("HOSTSIM_QUADCOPTER", "-O2"), "humanoid": ("HOSTSIM_HUMANOID", "-O2"), "hand": ("HOSTSIM_HAND", "-O1"),
            "bbot": ("HOSTSIM_BBOT", "-O2")}
-_ENTRY_MODEL = {"hs_step_mw_ant": "ant", "hs_step_mw_terrain": "anymal", "hs_step_selfcol": "humanoid", "hs_step_selfcol2": "humanoid", "hs_step_selfcol3": "humanoid", "hs_step_mwc": "humanoid", "hs_step_mwc_fused": "humanoid", "hs_step_terrain": "anymal", "hs_set_slope_threshold": "anymal", "hs_set_walls": "anymal", "hs_ground_contact": "anymal", "hs_step_drive": "quadcopter", "hs_step_hand": "hand", "hs_step_hand_mw": "hand", "hs_hand_fingertips": "hand", "hs_step_bbot": "bbot"}
+_ENTRY_MODEL = {"hs_step_mw_ant": "ant", "hs_step_mw_terrain": "anymal", "hs_step_selfcol": "humanoid", "hs_step_selfcol2": "humanoid", "hs_step_selfcol3": "humanoid", "hs_step_mwc": "humanoid", "hs_step_mwc_fused": "humanoid", "hs_step_terrain": "anymal", "hs_set_slope_threshold": "anymal", "hs_set_walls": "anymal", "hs_ground_contact": "anymal", "hs_step_drive": "quadcopter", "hs_step_hand": "hand", "hs_step_hand_mw": "hand", "hs_hand_fingertips": "hand", "hs_set_hand_pair_stiffness": "hand", "hs_hand_pair_sides": "hand", "hs_step_bbot": "bbot"}
 _libs = {}
 
 

@@ -544,9 +544,13 @@ def test_reference_domain_randomisation_reaches_the_engine(reference_tasks, task
 
     sc0 = t["actor_scale"].detach().cpu().numpy().copy()
     if task == "ShadowHand":
-        # setup-time draws, staged before the engine existed: total hand mass (per-body factors in [0.5, 1.5], mass-weighted), object mass
+        # setup-time draws, staged before the engine existed: the hand's link masses (one factor per BODY and env in [0.5, 1.5] -- the tensor the
+        # Sim<Scaled<M>> kernels read, switched in by option hand_body_mass; column 0 of actor_scale, the one factor per env of rounds 2-4, stays 1),
+        # object mass
         assert sc0.shape == (n, 8)
-        assert (sc0[:, 0] > 0.5).all() and (sc0[:, 0] < 1.5).all() and sc0[:, 0].std() > 0.02
+        bm0 = t["hand_body_mass_scale"].detach().cpu().numpy().copy()
+        assert bm0.shape == (n, nb) and int(eng.get_option("hand_body_mass")) == 1 and np.allclose(sc0[:, 0], 1.0)
+        assert (bm0 >= 0.5 - 1e-6).all() and (bm0 <= 1.5 + 1e-6).all() and bm0.std(0).min() > 0.1 and bm0.std(1).min() > 0.1
         assert (sc0[:, 5] >= 0.5).all() and (sc0[:, 5] <= 1.5).all() and sc0[:, 5].std() > 0.1
         assert (sc0[:, 1] > 0.3).all() and (sc0[:, 1] < 3.0).all() and sc0[:, 1].std() > 0.02          # dof damping: loguniform [0.3, 3], mean over dofs
         assert (sc0[:, 2] > 0.75).all() and (sc0[:, 2] < 1.5).all() and sc0[:, 2].std() > 0.005        # drive stiffness
@@ -572,9 +576,8 @@ def test_reference_domain_randomisation_reaches_the_engine(reference_tasks, task
     assert np.allclose(dp["lower"] - base_dp["lower"], sh[e, :nd], atol=1e-6) and np.allclose(dp["upper"] - base_dp["upper"], sh[e, nd:], atol=1e-6)
     assert np.abs(sh).max() > 1e-4 and np.abs(sh).max() < 0.1
     if task == "ShadowHand":
-        dyn_m = np.asarray(spec.mass)
         per_body = np.array([np.mean((masses / base_m)[np.asarray(ref.sim.asset.body_dyn, int) == b]) for b in range(nb)])
-        assert abs(float(per_body @ dyn_m / dyn_m.sum()) - sc[e, 0]) < 1e-4                    # the hand's kernels take ONE mass factor per env
+        assert np.allclose(per_body, t["hand_body_mass_scale"].detach().cpu().numpy()[e], rtol=1e-5)      # one factor per BODY, as the reference draws them
         obj = gym.find_actor_handle(ref.envs[e], "object")
         m_obj = [gym.get_actor_rigid_body_properties(ref.envs[k], obj)[0].mass for k in (e, e + 1)]
         assert abs(m_obj[0] / m_obj[1] - sc[e, 5] / sc[e + 1, 5]) < 1e-5
@@ -597,7 +600,7 @@ def test_reference_domain_randomisation_reaches_the_engine(reference_tasks, task
     step(30)
     sc1 = t["actor_scale"].detach().cpu().numpy()
     if task == "ShadowHand":
-        assert np.array_equal(sc1[:, 0], sc0[:, 0]) and np.array_equal(sc1[:, 5], sc0[:, 5])           # masses: setup_only
+        assert np.array_equal(t["hand_body_mass_scale"].detach().cpu().numpy(), bm0) and np.array_equal(sc1[:, 5], sc0[:, 5])           # masses: setup_only
         assert (sc1[:, 1] != sc0[:, 1]).mean() > 0.5
     else:
         assert (sc1[:, nb:nb + nd] != sc[:, nb:nb + nd]).any(1).mean() > 0.5

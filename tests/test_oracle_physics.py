@@ -423,6 +423,7 @@ def test_hand_drive_force_limit_known_answer(solver):
         fmax, kp = ex["dof_force_limit"][d], ex["dof_kp"][d]
         for sign in (1.0, -1.0):
             o = OracleHandEngine(spec, ex, 1, sim, sensor_bodies("shadow_hand"), backend="c", **kw)
+            o.pair_k = 0.0          # the closed form is a hand whose links touch nothing: the hand-to-hand pairs off (at mid-range angles fingers overlap)
             o.q[:] = 0.5 * (o.lo + o.up); o.qd[:] = 0.0
             o.targets[:] = o.q
             o.targets[0, d] = o.q[0, d] + sign * 3.0 * fmax / kp           # (targets are not clamped to the joint range here)
@@ -443,6 +444,7 @@ def test_hand_drive_force_limit_known_answer(solver):
             assert abs(o.dof_force[0, d] - sign * fmax) < 1e-9                # what the actuator delivered
             # unclamped, the same drive pushes harder (not three times: the light finger is already limited by the implicit damping h kp)
             u = OracleHandEngine(spec, ex, 1, sim, sensor_bodies("shadow_hand"), backend="c", **kw)
+            u.pair_k = 0.0          # the closed form is a hand whose links touch nothing: the hand-to-hand pairs off (at mid-range angles fingers overlap)
             u.force_limit = None
             u.q[:] = 0.5 * (u.lo + u.up); u.qd[:] = 0.0; u.targets[:] = o.targets; u.obj[:] = 0.0; u.obj[:, 2] = 5.0; u.obj[:, 6] = 1.0
             u.step()
@@ -450,7 +452,9 @@ def test_hand_drive_force_limit_known_answer(solver):
     # inside the force range the clamp is inert: bit-equal to the unclamped drive
     rng = np.random.default_rng(0)
     a = OracleHandEngine(spec, ex, 4, sim, sensor_bodies("shadow_hand"), backend="c", **kw)
+    a.pair_k = 0.0          # the closed form is a hand whose links touch nothing: the hand-to-hand pairs off (at mid-range angles fingers overlap)
     b = OracleHandEngine(spec, ex, 4, sim, sensor_bodies("shadow_hand"), backend="c", **kw)
+    b.pair_k = 0.0          # the closed form is a hand whose links touch nothing: the hand-to-hand pairs off (at mid-range angles fingers overlap)
     b.force_limit = None
     a.q[:] = a.lo + (a.up - a.lo) * rng.uniform(0.3, 0.7, (4, nd))
     a.targets[:] = a.q + rng.uniform(-0.05, 0.05, (4, nd))

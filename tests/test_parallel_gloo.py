@@ -24,6 +24,12 @@ WORKER = textwrap.dedent("""
     import torch.distributed as dist
     rank, world, _ = init_distributed(backend="gloo")
     assert world == 2 and dist.get_backend() == "gloo"
+    # every rank got its own slice of the cores (parallel.pin_to_local_cores, called by init_distributed)
+    mine = sorted(os.sched_getaffinity(0))
+    both = [None, None]
+    dist.all_gather_object(both, mine)
+    if len(set(both[0]) | set(both[1])) >= 2:
+        assert not (set(both[0]) & set(both[1])), both
     lo, hi = shard_range(4097, rank, world)
     sizes = [None, None]
     dist.all_gather_object(sizes, (lo, hi))
@@ -36,11 +42,17 @@ WORKER = textwrap.dedent("""
         cfg = compose(overrides=["task=" + task])
         cfg["task"]["env"]["numEnvs"] = n
         cfg["task"]["_base_seed"] = seed
+        cfg["task"]["_extras_interval"] = 4
         env = isaacgymenvs_amd.make(seed=seed, task=task, num_envs=n, sim_device="cpu", rl_device="cpu", headless=True, multi_gpu=sharded, cfg=cfg)
         total = n * world if sharded else n
         g = torch.Generator().manual_seed(3)
         red = EpisodeStatsReducer(env.engine.tensors["episode_stats"], interval=4) if sharded else None
-        ext = TaskExtrasReducer(env, interval=4, distributed=sharded) if task != "Ant" else None
+        # a sharded env carries its own reducer (VecTask._enable_job_extras: make(multi_gpu=True) inside a job) and routes the windows into
+        # env.extras; the unsharded reference process gets a stand-alone one
+        ext = None
+        if task != "Ant":
+            ext = env._job_extras if sharded else TaskExtrasReducer(env, interval=4, distributed=False)
+            assert ext is not None and (not sharded or ext.dist)
         outs = []
         for s in range(steps):
             a = torch.rand((total, env.num_actions), generator=g) * 2 - 1          # the same global action batch on every rank
@@ -49,8 +61,8 @@ WORKER = textwrap.dedent("""
             outs.append((od["obs"].clone(), rew.clone(), reset.clone()))
             if red is not None:
                 red.step()
-            if ext is not None:
-                ext.step()
+            if ext is not None and not sharded:
+                ext.step()                      # (the sharded env steps its own reducer inside env.step())
         return env, outs, red, ext
 
     # ---- 1. Ant: 2 x 128 sharded == rows of 256 unsharded
@@ -75,11 +87,30 @@ WORKER = textwrap.dedent("""
     sl = slice(rank * 48, (rank + 1) * 48)
     for (o1, r1, d1), (o2, r2, d2) in zip(outs_f, outs_s):
         assert torch.equal(o1[sl], o2) and torch.equal(d1[sl], d2)
-    w_s, w_f = ext_s.result(), ext_f.result()
+    # the whole run (everything reduced since the reducers were made): job-wide == the one process
+    w_s, w_f = ext_s.since_baseline(), ext_f.since_baseline()
     assert w_s["num_resets"] == w_f["num_resets"] and w_f["num_resets"] > 0, (w_s, w_f)
     for k in w_f:
         assert abs(w_s[k] - w_f[k]) < 1e-4 * max(1.0, abs(w_f[k])), (k, w_s[k], w_f[k])
     assert set(TaskExtrasReducer.ANYMAL_KEYS) <= set(w_s) and "terrain_level" in w_s
+    # the last window (4 steps), the same on both as well
+    w_s, w_f = ext_s.result(), ext_f.result()
+    assert w_s["num_resets"] == w_f["num_resets"] and abs(w_s["terrain_level"] - w_f["terrain_level"]) < 1e-6
+    assert ext_s.result() is w_s                       # a second read before the next reduction: the same window, not an empty one
+    # the sharded env published job-wide values into its extras (one window behind at most) and kept its own under *_rank
+    ep = env_s.extras["episode"]
+    assert "episode_rank" in env_s.extras and abs(float(ep["terrain_level"]) - w_s["terrain_level"]) < 0.5
+    # set_env_state replaces the cumulative sums: the reducer re-bases instead of forming a window from the jump
+    st = env_s.get_env_state()
+    env_s.set_env_state(st)
+    assert ext_s.prev is None
+    for s in range(4):
+        env_s.step(torch.zeros((48, env_s.num_actions)))
+    assert ext_s.result() is w_s and ext_s.prev is not None          # the first reduction after a rebase is a baseline
+    for s in range(4):
+        env_s.step(torch.zeros((48, env_s.num_actions)))
+    w2 = ext_s.result()
+    assert w2 is not w_s and w2["num_resets"] >= 0 and 0 <= w2["terrain_level"] < 20
 
     # ---- 3. ShadowHand: successes numerator / denominator
     env_s, outs_s, _, ext_s = rollout("ShadowHand", 32, 12, True)
@@ -87,8 +118,9 @@ WORKER = textwrap.dedent("""
     sl = slice(rank * 32, (rank + 1) * 32)
     for (o1, r1, d1), (o2, r2, d2) in zip(outs_f, outs_s):
         assert torch.equal(o1[sl], o2) and torch.equal(d1[sl], d2)
-    w_s, w_f = ext_s.result(), ext_f.result()
+    w_s, w_f = ext_s.since_baseline(), ext_f.since_baseline()
     assert w_s["num_resets"] == w_f["num_resets"] and abs(w_s["successes_per_reset"] - w_f["successes_per_reset"]) < 1e-6, (w_s, w_f)
+    assert "consecutive_successes_rank" in env_s.extras and float(env_s.extras["consecutive_successes"]) >= 0.0
     dist.barrier()
     if rank == 0:
         print("GLOO_OK")

@@ -126,6 +126,33 @@ def hand_extras(asset_root, spec):
             lo, hi = [float(x) for x in f.get("range").split()]
             tendons.append(dict(name=f.get("name"), dof=[dofs.index(j.get("joint")) for j in js],
                                 coef=[float(j.get("coef")) for j in js], range=[lo, hi]))
+    # The asset's explicit hand-to-hand contact pairs (shared.xml:31-51; the hand's shapes are contype 1 / conaffinity 0, so these <pair>
+    # entries are the ONLY hand-hand contacts MuJoCo -- and an importer that honours them -- generates; condim 1: frictionless).  One entry is
+    # listed twice (C_lfdistal / C_rfdistal, :41 and :45): kept once.  Geometry in the body frames: a capsule as its axis segment + radius,
+    # the palm box as centre + half sizes (side a).
+    names = list(spec.geom_names)
+    pairs, seen = [], set()
+    for pr in shared.find("contact").findall("pair"):
+        ga, gb = pr.get("geom1"), pr.get("geom2")
+        if frozenset((ga, gb)) in seen:
+            continue
+        seen.add(frozenset((ga, gb)))
+        if int(spec.geom_type[names.index(ga)]) != 2 and int(spec.geom_type[names.index(gb)]) == 2:
+            ga, gb = gb, ga                                   # the box is side a
+        side = []
+        for gname in (ga, gb):
+            g = names.index(gname)
+            t, pos = int(spec.geom_type[g]), np.asarray(spec.geom_pos[g], float)
+            R, size = quat_to_mat(np.asarray(spec.geom_quat[g], float)), np.asarray(spec.geom_size[g], float)
+            if t == 1:
+                ax = R @ np.array([0.0, 0.0, size[1]])
+                side.append(dict(geom=gname, body=int(spec.geom_body[g]), kind="capsule", p0=[float(x) for x in pos - ax], p1=[float(x) for x in pos + ax],
+                                 r=float(size[0])))
+            else:
+                assert t == 2 and np.allclose(R, np.eye(3)), gname          # C_palm0: axis-aligned in the palm's frame
+                side.append(dict(geom=gname, body=int(spec.geom_body[g]), kind="box", p0=[float(x) for x in pos], p1=[float(x) for x in size], r=0.0))
+        assert side[1]["kind"] == "capsule" and side[0]["body"] != side[1]["body"]
+        pairs.append(dict(a=side[0], b=side[1], condim=int(pr.get("condim", 3))))
     kp = [0.0] * len(dofs)
     frc = [0.0] * len(dofs)
     act_dof = []
@@ -142,7 +169,8 @@ def hand_extras(asset_root, spec):
     return dict(os_body=[int(s[0]) for s in sph], os_pos=[[float(x) for x in s[1]] for s in sph], os_rad=[float(s[2]) for s in sph],
                 tendons=tendons, tendon_limit_stiffness=30.0, tendon_damping=0.1, dof_kp=kp, dof_force_limit=frc, actuated_dofs=act_dof,
                 mount_quat=[float(x) for x in q],
-                fingertips=["robot0:ffdistal", "robot0:mfdistal", "robot0:rfdistal", "robot0:lfdistal", "robot0:thdistal"])
+                fingertips=["robot0:ffdistal", "robot0:mfdistal", "robot0:rfdistal", "robot0:lfdistal", "robot0:thdistal"],
+                pairs=pairs)
 
 
 # robots the reference generates in code (isaacgymenvs_amd/assets/procedural.py restates the generators)

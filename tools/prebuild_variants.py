@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Rebuild the cached run-time asset variants (isaacgymenvs_amd/_variants/<hash>/) whose library is older than the stock one, for HIP and / or CPU,
 in this container (hipcc cross-compiles gfx950 without a GPU) -- so that a gpurun session that runs the stand-in / run-time-asset tests on the HIP
-backend does not spend its GPU minutes compiling.  Usage: tools/prebuild_variants.py [hip] [cpu]"""
+backend does not spend its GPU minutes compiling.  Usage: tools/prebuild_variants.py [hip] [cpu] [--all]
+--all: also build the flavour a variant directory does not have yet (a variant the CPU tests created here is then ready for the GPU box)."""
 import glob
 import os
 import sys
@@ -11,7 +12,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from isaacgymenvs_amd import native  # noqa: E402
 from isaacgymenvs_amd.assets import runtime  # noqa: E402
 
-kinds = sys.argv[1:] or ["hip"]
+build_missing = "--all" in sys.argv
+kinds = [a for a in sys.argv[1:] if a != "--all"] or ["hip"]
 csrc = os.path.join(os.path.dirname(native.__file__), "csrc")
 for vdir in sorted(glob.glob(os.path.join(runtime.VARIANT_DIR, "*"))):
     gen = os.path.join(vdir, "pkg", "csrc", "gen")
@@ -25,9 +27,9 @@ for vdir in sorted(glob.glob(os.path.join(runtime.VARIANT_DIR, "*"))):
         cpu = kind == "cpu"
         out = os.path.join(vdir, "libmi_engine_cpu.so" if cpu else "libmi_engine.so")
         stock = native.CPU_LIB_PATH if cpu else native.LIB_PATH
-        if not os.path.exists(out):
+        if not os.path.exists(out) and not build_missing:
             continue                              # this variant was never asked for on that backend
-        if os.path.getmtime(out) >= os.path.getmtime(stock):
+        if os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(stock):
             print(f"{os.path.basename(vdir)} {model} {kind}: up to date")
             continue
         t0 = time.time()

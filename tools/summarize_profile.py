@@ -174,6 +174,10 @@ for task, recipe in RECIPE.items():
                     "fp32_flops_per_step": int(tot_f) if tot_f > 0 else None, "live_lanes": round(live[dom[1]], 1) if dom[1] in live else None,
                     "source": f"profiles/{tag}_pmc_summary.md (FETCH_SIZE x {f_fetch:.2f} + WRITE_SIZE x {f_write:.2f}, calibrated on tools/calib/calib_fetch.hip)"}
         out.append(f"| {task} | {', '.join(names)} | {tot_b / 1e6:.2f} MB | {tot_v / 1e6:.2f} M | {tot_t:.1f} |")
+try:       # the library the passes ran on (tools/profile_r5.sh): bench.py withholds these numbers from a run that loads another build
+    tj["_lib_sha256"] = open(os.path.join(src, "lib_sha256.txt")).read().strip()
+except OSError:
+    pass
 json.dump(tj, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 open(os.path.join(dst, f"{tag}_pmc_summary.md"), "w").write("\n".join(out) + "\n")
 print("\n".join(out))
