@@ -23,6 +23,10 @@ struct View {
     float* actor_scale; // [NB + 3 ND][N] per-env scales: link masses per body, then joint damping, stiffness, armature per dof (`actor_params`), null: task has none
     float* root;        // [13][N]
     float* dof;         // [2][ND][N]  (pos block, vel block)
+    float* dof_api = nullptr;   // [2][ND][N] AnymalTerrain: the joint state as of the task's last gym.refresh_dof_state_tensor -- the end of the decimation
+                        // loop, anymal_terrain.py:451; the base class's simulate() calls after it refresh nothing (vec_task.py:379-382) -- which is what
+                        // the task's PD law (first decimation iteration), observations and reward read.  nullptr (every other task; option
+                        // dof_state_lag 0): they read `dof`
     float* tau;         // [ND][N]  dof_actuation_force
     float* lamc;        // [3*NSPH][N]
     float* laml;        // [ND][N]

@@ -142,6 +142,9 @@ static void build_layout(int task, int N, Layout& L, View* v, char* base, int no
         o = L.add("episode_step_stats", MI_F32, {16}, {1}, 16); if (v) v->ep_stats = (float*)P(o);
         o = L.add("episode_means", MI_F32, {16}, {1}, 16); if (v) v->ep_means = (float*)P(o);
         o = L.add("episode_cum_stats", MI_F32, {32}, {1}, 32); if (v) v->ep_cum = (float*)P(o);
+        // the task's dof-state tensor as of its last gym.refresh_dof_state_tensor (anymal_terrain.py:451): one sim step behind `dof_state` after a
+        // step (the base class's simulate() refreshes nothing, vec_task.py:379-382); what its PD law, observations and reward read -- View::dof_api
+        o = L.add("dof_state_refreshed", MI_F32, {n, nd, 2}, {1, n, nd * n}, 2 * nd * n); if (v) v->dof_api = (float*)P(o);
     }
     if (task == T_ARTICULATION) {
         const int64_t nb = m.nb;

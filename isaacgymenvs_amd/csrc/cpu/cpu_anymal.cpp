@@ -39,13 +39,16 @@ HeightfieldGround ground_of(const AnymalTerrainDesc& T) {
 // the PD drive of one sim step (anymal_terrain.py:443-446; anymal.py:203-206 through the dofs' stiffness / damping): what
 // efforts_for_substep (step_kernels.hpp, ActParams mode 1) evaluates on the device
 template <class S>
-inline void pd_torques(const S& sim, float kp0, float kd0, float action_scale, float torque_limit, const float* default_pos, const float* act, float* tau) {
+inline void pd_torques(const S& sim, float kp0, float kd0, float action_scale, float torque_limit, const float* default_pos, const float* act, float* tau,
+                       const float* q_api = nullptr, const float* qd_api = nullptr) {
+    // q_api / qd_api: the joint state of the task's last refresh instead of the sim's own (AnymalTerrain's first decimation iteration, View::dof_api)
     for (int k = 0; k < kAnymalDof; ++k) {
         float kp = kp0, kd = kd0;
         if constexpr (S::SCALED) {
             if (sim.actor_scale.p != nullptr) { kp *= sim.actor_scale(S::AS_STIFF + k); kd *= sim.actor_scale(S::AS_DAMP + k); }
         }
-        const float u = kp * (action_scale * act[k] + default_pos[k] - sim.q[k]) - kd * sim.qd[k];
+        const float qk = q_api ? q_api[k] : sim.q[k], qdk = qd_api ? qd_api[k] : sim.qd[k];
+        const float u = kp * (action_scale * act[k] + default_pos[k] - qk) - kd * qdk;
         tau[k] = fminf(fmaxf(u, -torque_limit), torque_limit);
     }
 }
@@ -64,13 +67,22 @@ void substeps_env(const MiEngine* e, const View& v, int en, const GND& gnd, cons
     float tau[M::NDA], rows[Sim<MM>::ROW_SLOTS > 0 ? Sim<MM>::ROW_SLOTS : 1];
     for (int k = 0; k < M::ND; ++k) tau[k] = v.tau[k * N + en];
     const float mu_env = v.friction ? v.friction[en] : -1.f;
+    const bool lagging = v.dof_api != nullptr && n_pd > 0;       // (AnymalTerrain's control step: step_kernels.hpp ActSource ACT_LAG / ACT_SNAP)
     for (int ss = 0; ss < n_pd + n_hold; ++ss) {
         if (ss < n_pd) {
-            pd_torques(sim, kp, kd, action_scale, torque_limit, default_pos, act, tau);
+            if (lagging && ss == 0) {
+                float qa[M::NDA], qda[M::NDA];
+                for (int k = 0; k < M::ND; ++k) { qa[k] = v.dof_api[k * N + en]; qda[k] = v.dof_api[(M::ND + k) * N + en]; }
+                pd_torques(sim, kp, kd, action_scale, torque_limit, default_pos, act, tau, qa, qda);
+            } else {
+                pd_torques(sim, kp, kd, action_scale, torque_limit, default_pos, act, tau);
+            }
             for (int k = 0; k < M::ND; ++k) v.tau[k * N + en] = tau[k];
         }
         sim.substep(e->P, tau, h, RowStore<1>{rows}, Strided{v.lamc + en, N}, Strided{v.laml + en, N}, Strided{v.sensor + en, N},
                     Strided{v.dof_force + en, N}, gnd, mu_env, Strided{v.netf + en, N});
+        if (lagging && ss == n_pd - 1)      // the task's refresh_dof_state_tensor at the end of its decimation loop
+            for (int k = 0; k < M::ND; ++k) { v.dof_api[k * N + en] = sim.q[k]; v.dof_api[(M::ND + k) * N + en] = sim.qd[k]; }
     }
     for (int k = 0; k < 13; ++k) v.root[k * N + en] = sim.root[k];
     for (int k = 0; k < M::ND; ++k) { v.dof[k * N + en] = sim.q[k]; v.dof[(M::ND + k) * N + en] = sim.qd[k]; }

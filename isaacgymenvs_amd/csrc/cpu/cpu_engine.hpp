@@ -44,6 +44,7 @@ struct MiEngine {
     std::vector<MiTensorDesc> descs;
     unsigned long long steps;
     float* lamp_arena;
+    float* dof_api_arena;
     float* actor_scale_arena;   // the `actor_params` tensors: read by the sub-step once option "actor_tensors" is on (as in mi_engine.hip)
     float* limit_shift_arena;
 };

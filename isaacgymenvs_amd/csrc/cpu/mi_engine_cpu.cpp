@@ -117,6 +117,7 @@ extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const 
     if (arena_bytes < L.off) { delete e; return fail("mi_engine_create: arena too small"); }
     e->descs = L.d;
     e->lamp_arena = e->v.lamp;
+    e->dof_api_arena = e->v.dof_api;
     e->actor_scale_arena = e->v.actor_scale; e->limit_shift_arena = e->v.limit_shift;
     e->v.actor_scale = nullptr; e->v.limit_shift = nullptr;
     e->v.N = num_envs; e->v.env_offset = env_id_offset; e->v.seed = (uint32_t)(seed ^ (seed >> 32));
@@ -144,6 +145,12 @@ extern "C" int mi_engine_set_option(MiEngine* e, const char* key, double value) 
         return 0;
     }
     if (!strcmp(key, "multi_wave") || !strcmp(key, "fused_sub") || !strcmp(key, "fused_post")) return 0;     // GPU launch shapes: nothing to do here
+    if (!strcmp(key, "dof_state_lag")) {        // AnymalTerrain: PD law / observations / reward read the dof state of the task's last refresh (1, default, the
+        // reference's behaviour: anymal_terrain.py:441-455 + vec_task.py:379-382) or the physics state (0).  Switching it on re-synchronises the tensor.
+        if (e->task != T_ANYMAL) return fail("dof_state_lag: an AnymalTerrain option");
+        if (value != 0 && e->v.dof_api == nullptr) memcpy(e->dof_api_arena, e->v.dof, (size_t)2 * kTasks[e->task].nd * e->N * sizeof(float));
+        e->v.dof_api = value != 0 ? e->dof_api_arena : nullptr; return 0;
+    }
     if (!strcmp(key, "hand_body_mass")) {       // ShadowHand: the sub-step reads the per-body link-mass factors of `hand_body_mass_scale` (0, default: it does not)
         if (e->task != T_SHADOWHAND) return fail("hand_body_mass: a ShadowHand option (the Allegro hand's kernels take one mass factor per env)");
         e->hv.body_mass = value != 0 ? e->hv.body_mass_arena : nullptr; return 0;
@@ -199,6 +206,7 @@ extern "C" int mi_engine_get_option(const MiEngine* e, const char* key, double* 
     if (!strcmp(key, "self_collision")) { *out = e->v.lamp != nullptr ? 1.0 : 0.0; return 0; }
     if (!strcmp(key, "multi_wave") || !strcmp(key, "fused_sub") || !strcmp(key, "fused_post")) { *out = 0; return 0; }
     if (!strcmp(key, "drive_force_limit")) { *out = is_hand_task(e->task) ? e->hv.drive_clamp : 0; return 0; }
+    if (!strcmp(key, "dof_state_lag")) { *out = (e->task == T_ANYMAL && e->v.dof_api != nullptr) ? 1 : 0; return 0; }
     if (!strcmp(key, "hand_body_mass")) { *out = (is_hand_task(e->task) && e->hv.body_mass != nullptr) ? 1 : 0; return 0; }
     if (!strcmp(key, "hand_pair_stiffness")) { *out = is_hand_task(e->task) ? e->hv.pair_k : 0; return 0; }
     if (!strcmp(key, "terrain_slope_threshold")) { *out = e->terrain.slope_threshold; return 0; }

@@ -125,12 +125,51 @@ static ActParams act_of(const AnymalParams& tp) {
 // VecTask.step for AnymalTerrain: `decimation` sim steps with the PD torques recomputed before each (:443-451), then
 // control_freq_inv more sim steps with the last torques (the base class simulates again, vec_task.py:379-382; the task
 // YAML has no controlFrequencyInv => 1), then post_physics_step.
+// The task's lagging dof-state tensor (View::dof_api) for the forms that launch once per sim sub-step (fused_sub 0, the one-wave form): the step's
+// FIRST PD evaluation -- on the joint state of the task's last refresh, anymal_terrain.py:443-446 -- by this kernel (it also clamps and stores the
+// actions, vec_task.py:374), so that the first sub-step launch runs on stored efforts; the refresh at the end of the decimation loop is a
+// device-to-device copy.  (The one-launch form does both inside the kernel, mw_kernels.hpp mw_role_fused.)
+__global__ __launch_bounds__(256) void anymal_lag_pd_kernel(View v, ActParams ap, const float* __restrict__ actions_in, int src) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    constexpr int ND = kAnymalDof;
+    if (i >= v.N * ND) return;
+    const int k = i / v.N, e = i - k * v.N;          // consecutive threads: consecutive envs of one dof (SoA)
+    float a;
+    if (src == ACT_FROM_ACTIONS) {
+        a = fminf(fmaxf(actions_in[(size_t)e * ND + k], -ap.clip), ap.clip);
+        v.actions[(size_t)k * v.N + e] = a;
+    } else {
+        a = v.actions[(size_t)k * v.N + e];
+    }
+    const float u = ap.kp * (ap.scale * a + ap.gear[k] - v.dof_api[(size_t)k * v.N + e]) - ap.kd * v.dof_api[(size_t)(ND + k) * v.N + e];
+    v.tau[(size_t)k * v.N + e] = fminf(fmaxf(u, -ap.torque_limit), ap.torque_limit);
+}
+
 hipError_t launch_step_anymal(const View& v, const SimParams& P, const AnymalParams& tp, const AnymalTerrainDesc& T,
                               const float* actions, int cfi, unsigned step_counter, hipStream_t s) {
     const ActParams ap = act_of(tp);
     hipError_t e;
     bool cmdnorm_in_launch = false;
-    if (T.hs != nullptr) {
+    const int n_dec = tp.decimation * P.substeps;
+    const bool fused = v.mw != 0 && v.fused_sub != 0 && (tp.decimation + cfi) * P.substeps > 1;
+    if (T.hs != nullptr && v.dof_api != nullptr && !fused) {
+        // per-sub-step launches with the lagging tensor: [lag PD] sub-step 0 on stored efforts, the rest of the decimation loop with the PD law on the
+        // current state, [refresh], the base class's simulate() calls on the last efforts
+        const int first = prepare_actions(v, ap, actions, ACT_FROM_ACTIONS, s);
+        hipLaunchKernelGGL(anymal_lag_pd_kernel, dim3((v.N * kAnymalDof + 255) / 256), dim3(256), 0, s, v, ap, actions, first);
+        const size_t bytes = (size_t)2 * kAnymalDof * v.N * sizeof(float);
+        if (v.mw != 0) {
+            e = launch_substeps_mw<ModelAnymal, HeightfieldGround>(v, P, ap, actions, n_dec, ACT_STORED_TAU, ACT_FROM_STORED_ACTIONS, s, ground_of(T), 0, nullptr);
+            if (e != hipSuccess) return e;
+            if ((e = hipMemcpyAsync(v.dof_api, v.dof, bytes, hipMemcpyDeviceToDevice, s)) != hipSuccess) return e;
+            e = launch_substeps_mw<ModelAnymal, HeightfieldGround>(v, P, ap, nullptr, cfi * P.substeps, ACT_STORED_TAU, ACT_STORED_TAU, s, ground_of(T), 0, nullptr);
+        } else {
+            e = launch_substeps<ModelAnymal, HeightfieldGround>(v, P, ap, actions, n_dec, ACT_STORED_TAU, ACT_FROM_STORED_ACTIONS, s, ground_of(T));
+            if (e != hipSuccess) return e;
+            if ((e = hipMemcpyAsync(v.dof_api, v.dof, bytes, hipMemcpyDeviceToDevice, s)) != hipSuccess) return e;
+            e = launch_substeps<ModelAnymal, HeightfieldGround>(v, P, ap, nullptr, cfi * P.substeps, ACT_STORED_TAU, ACT_STORED_TAU, s, ground_of(T));
+        }
+    } else if (T.hs != nullptr) {
         if (v.mw != 0) {    // limb-per-wave form: one call (with option fused_sub: one LAUNCH) for the decimation steps + the base class's simulate()
             // (with the fused launch the curriculum pre-pass -- anymal_cmdnorm_env -- runs on the trunk wave at its end: one kernel less)
             cmdnorm_in_launch = tp.curriculum && v.fused_sub != 0 && (tp.decimation + cfi) * P.substeps > 1;

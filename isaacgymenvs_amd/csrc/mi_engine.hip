@@ -273,6 +273,7 @@ struct MiEngine {
     float* actor_scale_arena;
     float* limit_shift_arena;
     float* lamp_arena;     // the self-contact impulse tensor (Humanoid), kept while the option self_collision is 0
+    float* dof_api_arena;  // the refreshed dof-state tensor (AnymalTerrain), kept while the option dof_state_lag is 0
 };
 
 extern "C" int mi_task_info(const char* task, MiTaskInfo* out) {
@@ -357,6 +358,7 @@ extern "C" int mi_engine_create(const char* task, const MiSimParams* sim, const 
     }
     build_layout(t, num_envs, L, &e->v, (char*)arena, nobs);
     e->lamp_arena = e->v.lamp;       // self-collision is on by default where the reference's actor collides with itself
+    e->dof_api_arena = e->v.dof_api; // (AnymalTerrain: the task's lagging dof-state tensor is on by default, as in the reference)
     e->actor_scale_arena = e->v.actor_scale; e->limit_shift_arena = e->v.limit_shift;
     e->v.actor_scale = nullptr; e->v.limit_shift = nullptr;
     memset(&e->hv, 0, sizeof(e->hv));
@@ -429,6 +431,13 @@ extern "C" int mi_engine_set_option(MiEngine* e, const char* key, double value) 
         if (!is_hand_task(e->task)) return fail("tips_in_post: a hand-task option");
         e->hv.tips_in_post = value != 0 ? 1 : 0; return 0;
     }
+    if (!strcmp(key, "dof_state_lag")) {        // AnymalTerrain: PD law / observations / reward read the dof state of the task's last refresh (1, default, the
+        // reference's behaviour: anymal_terrain.py:441-455 + vec_task.py:379-382) or the physics state (0).  Switching it on re-synchronises the tensor.
+        if (e->task != T_ANYMAL) return fail("dof_state_lag: an AnymalTerrain option");
+        if (value != 0 && e->v.dof_api == nullptr)      // back on: the tensor starts from the physics state (a synchronous copy: this is a set-up call)
+            HIP_OK(hipMemcpy(e->dof_api_arena, e->v.dof, (size_t)2 * kTasks[e->task].nd * e->N * sizeof(float), hipMemcpyDeviceToDevice));
+        e->v.dof_api = value != 0 ? e->dof_api_arena : nullptr; return 0;
+    }
     if (!strcmp(key, "hand_body_mass")) {       // ShadowHand: the sub-step reads the per-body link-mass factors of `hand_body_mass_scale` (0, default: it does not)
         if (e->task != T_SHADOWHAND) return fail("hand_body_mass: a ShadowHand option (the Allegro hand's kernels take one mass factor per env)");
         e->hv.body_mass = value != 0 ? e->hv.body_mass_arena : nullptr; return 0;
@@ -485,6 +494,7 @@ extern "C" int mi_engine_get_option(const MiEngine* e, const char* key, double* 
     if (!strcmp(key, "self_collision")) { *out = e->v.lamp != nullptr ? 1.0 : 0.0; return 0; }
     if (!strcmp(key, "multi_wave")) { *out = e->v.mw; return 0; }
     if (!strcmp(key, "drive_force_limit")) { *out = is_hand_task(e->task) ? e->hv.drive_clamp : 0; return 0; }
+    if (!strcmp(key, "dof_state_lag")) { *out = (e->task == T_ANYMAL && e->v.dof_api != nullptr) ? 1 : 0; return 0; }
     if (!strcmp(key, "hand_body_mass")) { *out = (is_hand_task(e->task) && e->hv.body_mass != nullptr) ? 1 : 0; return 0; }
     if (!strcmp(key, "hand_pair_stiffness")) { *out = is_hand_task(e->task) ? e->hv.pair_k : 0; return 0; }
     if (!strcmp(key, "tips_in_post")) { *out = is_hand_task(e->task) ? e->hv.tips_in_post : 0; return 0; }

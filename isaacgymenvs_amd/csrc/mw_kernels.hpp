@@ -306,7 +306,11 @@ __device__ __forceinline__ void mw_role_fused(const MwFusedArgs<GND>& a, float* 
                     if (ap.mode == 0) {
                         t = x * ap.gear[k] * ap.scale;
                     } else {
-                        const float u = ap.kp * (ap.scale * x + ap.gear[k] - sim.q[k]) - ap.kd * sim.qd[k];
+                        float qk = sim.q[k], qdk = sim.qd[k];
+                        if constexpr (GND::HEIGHTFIELD) {      // AnymalTerrain: the launch is one control step of the task, whose first PD evaluation reads
+                            if (i == 0 && v.dof_api != nullptr) { qk = v.dof_api[k * N + e]; qdk = v.dof_api[(ND + k) * N + e]; }    // the dof-state tensor of its last refresh
+                        }
+                        const float u = ap.kp * (ap.scale * x + ap.gear[k] - qk) - ap.kd * qdk;
                         t = fminf(fmaxf(u, -ap.torque_limit), ap.torque_limit);
                     }
                 }
@@ -319,6 +323,12 @@ __device__ __forceinline__ void mw_role_fused(const MwFusedArgs<GND>& a, float* 
 #endif
         sim.template substep_role<R, true>(a.P, tau, h, RowStore<E>{lds_rows + lane}, lamc, laml, sensor, dof_force, a.gnd, mu_env, netf,
                                            i == 0 ? 1 : 2, DevBarrier{});
+        if constexpr (GND::HEIGHTFIELD) {
+            if (i == a.n_sub - a.tail - 1 && v.dof_api != nullptr)       // (uniform) the task's refresh_dof_state_tensor at the end of its decimation loop
+                sfor<ND>([&](auto K) MI_LAMBDA {
+                    if constexpr (S::template owns_gi<R>(M::OFF + K)) { v.dof_api[K * N + e] = sim.q[K]; v.dof_api[(ND + K) * N + e] = sim.qd[K]; }
+                });
+        }
         if (i + 1 < a.n_sub) {
             if constexpr (R == M::TRUNK_ROLE) sfor<13>([&](auto K) MI_LAMBDA { xroot[K * E] = sim.root[K]; });
             __syncthreads();

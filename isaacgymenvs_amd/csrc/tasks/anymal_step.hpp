@@ -63,8 +63,10 @@ MI_HD void anymal_post_env(const View& v, const AnymalParams& p, const AnymalTer
     const uint32_t genv = (uint32_t)(v.env_offset + e);
     float root[13], q[ND], qd[ND], act[ND], tau[ND], last_act[ND], last_qd[ND];
     sfor<13>([&](auto K) MI_LAMBDA { root[K] = v.root[K * N + e]; });
+    // (the task's dof-state tensor: as of its last refresh, one sim step behind the physics -- View::dof_api; option dof_state_lag 0: the physics state)
+    const float* const dofs = (v.dof_api != nullptr) ? v.dof_api : v.dof;
     sfor<ND>([&](auto K) MI_LAMBDA {
-        q[K] = v.dof[K * N + e]; qd[K] = v.dof[(ND + K) * N + e];
+        q[K] = dofs[K * N + e]; qd[K] = dofs[(ND + K) * N + e];
         act[K] = v.actions[K * N + e]; tau[K] = v.tau[K * N + e];
         last_act[K] = v.last_actions[K * N + e]; last_qd[K] = v.last_dof_vel[K * N + e];
     });
@@ -203,6 +205,8 @@ MI_HD void anymal_post_env(const View& v, const AnymalParams& p, const AnymalTer
         if (valid) {
             sfor<13>([&](auto K) MI_LAMBDA { v.root[K * N + e] = root[K]; });
             sfor<ND>([&](auto K) MI_LAMBDA { v.dof[K * N + e] = q[K]; v.dof[(ND + K) * N + e] = qd[K]; });
+            // (reset_idx writes the task's dof tensors and pushes them to the sim, :399-409: the lagging tensor holds the reset values too)
+            if (v.dof_api != nullptr) sfor<ND>([&](auto K) MI_LAMBDA { v.dof_api[K * N + e] = q[K]; v.dof_api[(ND + K) * N + e] = qd[K]; });
             sfor<NSPH3>([&](auto K) MI_LAMBDA { v.lamc[K * N + e] = 0.f; });
             v.terrain_levels[e] = level;
             sfor<3>([&](auto K) MI_LAMBDA { v.env_origins[K * N + e] = origin[K]; });
@@ -291,11 +295,12 @@ MI_HD void anymal_obs_column(const View& v, const AnymalParams& p, const unsigne
     MI_NO_CONTRACT
     constexpr int ND = kAnymalDof;
     const int N = v.N;
+    const float* const dofs = (v.dof_api != nullptr) ? v.dof_api : v.dof;      // (the task's dof-state tensor, see anymal_post_env)
     int k;
     float val, noise_scale;
     if (c < 3) { k = 9 + c; val = v.commands[c * N + e] * (c < 2 ? p.lin_vel_scale : p.ang_vel_scale); noise_scale = 0.f; }
-    else if (c < 3 + ND) { k = 12 + (c - 3); val = v.dof[(c - 3) * N + e] * p.dof_pos_scale; noise_scale = p.noise_dof_pos; }
-    else if (c < 3 + 2 * ND) { k = 24 + (c - 3 - ND); val = v.dof[(ND + c - 3 - ND) * N + e] * p.dof_vel_scale; noise_scale = p.noise_dof_vel; }
+    else if (c < 3 + ND) { k = 12 + (c - 3); val = dofs[(c - 3) * N + e] * p.dof_pos_scale; noise_scale = p.noise_dof_pos; }
+    else if (c < 3 + 2 * ND) { k = 24 + (c - 3 - ND); val = dofs[(ND + c - 3 - ND) * N + e] * p.dof_vel_scale; noise_scale = p.noise_dof_vel; }
     else { k = 176 + (c - 3 - 2 * ND); val = v.actions[(c - 3 - 2 * ND) * N + e]; noise_scale = 0.f; }
     if (p.add_noise) val += (2.f * anymal_rand_step(v.seed, (uint32_t)(v.env_offset + e), step_counter | 0x80000000u, (uint32_t)(16 + k)) - 1.f) * noise_scale;
     const size_t o = (size_t)e * kAnymalObs + k;
@@ -356,6 +361,7 @@ MI_HD void anymal_reset_env(const View& v, const AnymalParams& p, const AnymalTe
     for (int d = 0; d < ND; ++d) {
         v.dof[d * N + e] = p.default_dof_pos[d] * ((1.5f - 0.5f) * uniform01(v.seed, genv, uep, (uint32_t)d) + 0.5f);
         v.dof[(ND + d) * N + e] = (0.1f - (-0.1f)) * uniform01(v.seed, genv, uep, (uint32_t)(ND + d)) + (-0.1f);
+        if (v.dof_api != nullptr) { v.dof_api[d * N + e] = v.dof[d * N + e]; v.dof_api[(ND + d) * N + e] = v.dof[(ND + d) * N + e]; }
         v.last_actions[d * N + e] = 0.f; v.last_dof_vel[d * N + e] = 0.f;
     }
     float root[13];

@@ -117,6 +117,9 @@ class AnymalTerrain(VecTask):
         self.root_states = t["root_states"]
         self.dof_state = t["dof_state"]
         self.dof_pos, self.dof_vel = self.dof_state[..., 0], self.dof_state[..., 1]
+        # the joint state as of the reference task's last gym.refresh_dof_state_tensor: what its PD law, observations and reward read (one sim step
+        # behind `dof_state` after a step -- anymal_terrain.py:441-455, vec_task.py:379-382; engine option dof_state_lag, default 1)
+        self.dof_state_refreshed = t["dof_state_refreshed"]
         self.contact_forces = t["net_contact_force"]
         self.commands = t["commands"]
         self.torques = t["dof_actuation_force"]

@@ -442,8 +442,14 @@ class OracleAnymalTerrainEnv:
     """vec_task.py:360-408 + anymal_terrain.py pre/post_physics_step on oracle/physics.c with the height-field ground."""
 
     def __init__(self, spec, sim_params: dict, params, terrain, num_envs, seed=0, env_id_offset=0, precision="f64",
-                 control_freq_inv=1, solver="gs", blocks=None):
+                 control_freq_inv=1, solver="gs", blocks=None, dof_state_lag=True):
+        """dof_state_lag: the task's `dof_pos` / `dof_vel` are the tensor as of its last `gym.refresh_dof_state_tensor` -- the one at the end of the
+        decimation loop in pre_physics_step (anymal_terrain.py:441-451).  The base class then simulates `control_freq_inv` more times WITHOUT a
+        refresh (vec_task.py:379-382; post_physics_step's own refresh is commented out, :454), so the PD law of the next step's first decimation
+        iteration, the observations' joint columns and the reward's joint terms all see joint positions / velocities that lag the physics by that
+        one sim step (a reset env: the values reset_idx wrote).  False: everything reads the physics state (the engine's option dof_state_lag 0)."""
         from .engine import OracleEngine
+        self.lag = bool(dof_state_lag)
         self.N, self.p, self.nd, self.spec = num_envs, params, spec.nd, spec
         self.eng = OracleEngine(spec, num_envs, params=sim_params, precision=precision, solver=solver, blocks=blocks)
         self.eng.set_ground(terrain.heightsamples, terrain.horizontal_scale, terrain.vertical_scale, terrain.border_size,
@@ -487,6 +493,7 @@ class OracleAnymalTerrainEnv:
         self.init_done = False
         self.reset_idx(np.arange(N))   # :170
         self.init_done = True
+        self.dof_pos, self.dof_vel = self.eng.q.astype(f32).copy(), self.eng.qd.astype(f32).copy()      # the task's dof-state tensor (last refresh)
 
     def reset_idx(self, ids):  # :384-425
         if len(ids) == 0:
@@ -499,6 +506,8 @@ class OracleAnymalTerrainEnv:
         vel = (f32(0.1) - f32(-0.1)) * mi_uniform(self.seed, genv, ep, k + np.uint32(nd)) + f32(-0.1)
         self.eng.q[ids] = self.default_dof_pos[ids] * off
         self.eng.qd[ids] = vel
+        if hasattr(self, "dof_pos"):                 # (:399-400: the reset values are written into the task's tensors, then pushed to the sim)
+            self.dof_pos[ids] = self.eng.q[ids]; self.dof_vel[ids] = self.eng.qd[ids]
         self.update_terrain_level(ids)
         root = np.tile(self.base_init_state, (len(ids), 1))
         root[:, :3] += self.env_origins[ids]
@@ -545,10 +554,11 @@ class OracleAnymalTerrainEnv:
         a = np.clip(actions.astype(f32), -f32(p.clip_actions), f32(p.clip_actions))     # vec_task.py:374
         self.actions = a.copy()
         for _ in range(p.decimation):                                                    # :441-451
-            q, qd = self.eng.q.astype(f32), self.eng.qd.astype(f32)
+            q, qd = (self.dof_pos, self.dof_vel) if self.lag else (self.eng.q.astype(f32), self.eng.qd.astype(f32))
             tq = np.clip(f32(p.kp) * (f32(p.action_scale) * a + self.default_dof_pos - q) - f32(p.kd) * qd, f32(-p.torque_limit), f32(p.torque_limit))
             self.torques = tq.astype(f32)
             self.eng.step(self.torques, env_mu=self.friction)
+            self.dof_pos, self.dof_vel = self.eng.q.astype(f32).copy(), self.eng.qd.astype(f32).copy()      # refresh_dof_state_tensor (:451)
         for _ in range(self.cfi):                                                        # vec_task.py:379-382
             self.eng.step(self.torques, env_mu=self.friction)
         return self.post_physics_step()
@@ -579,7 +589,7 @@ class OracleAnymalTerrainEnv:
             rs |= (kn.astype(f32) > f32(1.)).any(1)
         rs = np.where(self.progress_buf >= p.max_episode_length - 1, True, rs)
         self.reset_buf = rs
-        q, qd = self.eng.q.astype(f32), self.eng.qd.astype(f32)
+        q, qd = (self.dof_pos.copy(), self.dof_vel.copy()) if self.lag else (self.eng.q.astype(f32), self.eng.qd.astype(f32))
         self.rew_buf, terms, self.feet_air_time = anymal_compute_reward(
             p, self.commands, base_lin_vel, base_ang_vel, projected_gravity, root[:, 2], self.torques, self.last_dof_vel, qd, cf,
             self.knee_indices, self.feet_indices, self.last_actions, self.actions, self.feet_air_time, q, self.default_dof_pos,
@@ -590,7 +600,7 @@ class OracleAnymalTerrainEnv:
         self.reset_idx(ids)
         # compute_observations (:302-313): base velocities / gravity are the pre-reset ones, pose and dofs post-reset
         root = self.eng.root.astype(f32)
-        q, qd = self.eng.q.astype(f32), self.eng.qd.astype(f32)
+        q, qd = (self.dof_pos.copy(), self.dof_vel.copy()) if self.lag else (self.eng.q.astype(f32), self.eng.qd.astype(f32))
         mh = anymal_get_heights(root[:, 3:7], root[:, :3], self.height_points, self.hs, self.terrain.border_size,
                                 self.terrain.horizontal_scale, self.terrain.vertical_scale)
         heights = np.clip(root[:, 2:3] - f32(0.5) - mh, f32(-1), f32(1.)) * f32(p.height_meas_scale)

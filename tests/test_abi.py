@@ -264,7 +264,7 @@ def test_hot_kernels_stay_inside_their_register_budgets():
     # the BASELINE sizes launch at the measured counts -- 0 for Ant / ANYmal / the hands' finger waves, 84 / 79 for the Humanoid's limb waves
     assert native.over_sgpr_budget(ru) == {}
     hot = {"substep_mw_fused_post_kernelI8ModelAntNS_11PlaneGroundELi16E": 2, "hand_substep_mw64_kernelINS_14ShadowHandTaskELi0E": 0,
-           "substep_mw_fused_kernelI11ModelAnymalNS_17HeightfieldGroundELi16E": 6, "substep_mwc_kernelI13ModelHumanoid": 90,
+           "substep_mw_fused_kernelI11ModelAnymalNS_17HeightfieldGroundELi16E": 8, "substep_mwc_kernelI13ModelHumanoid": 90,
            "substep_mwc_post_kernelI13ModelHumanoid": 90}
     for frag, cap in hot.items():
         got = [u.get("SGPRs Spill", 0) for k, u in ru.items() if frag in k]

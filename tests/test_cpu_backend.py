@@ -311,12 +311,21 @@ def test_rigid_body_state_tensor_matches_the_oracle_kinematics(task, model):
 # (round 4) AnymalTerrain, Anymal, ShadowHand, AllegroHand through make(..., "cpu", "cpu"): the per-env bodies of the HIP kernels
 # (csrc/tasks/anymal_step.hpp, csrc/tasks/hand_task.hpp) + the engine's one-wave sub-steps, against the independent restatement in its
 # Gauss-Seidel order -- the tests of tests/test_gpu_parity.py for these tasks, runnable without a GPU.
-def test_anymal_terrain_on_cpu_matches_the_cpu_restatement():
+@pytest.mark.parametrize("lag", [True, False])
+def test_anymal_terrain_on_cpu_matches_the_cpu_restatement(lag):
+    """lag True (the default, the reference's behaviour): the PD law's first decimation iteration, the joint observations and the reward's joint
+    terms read the dof-state tensor of the task's last refresh -- one sim step behind the physics (anymal_terrain.py:441-455, vec_task.py:379-382;
+    option dof_state_lag, tensor dof_state_refreshed); False: everything reads the physics state (rounds 1-4).  The two differ."""
     from oracle.tasks import OracleAnymalTerrainEnv
     n, seed = 96, 21
     env = isaacgymenvs_amd.make(seed=seed, task="AnymalTerrain", num_envs=n, sim_device="cpu", rl_device="cpu", headless=True)
+    assert int(env.engine.get_option("dof_state_lag")) == 1
+    if not lag:
+        env.engine.set_option("dof_state_lag", 0)
     orc = OracleAnymalTerrainEnv(load_model("anymal"), _sim_dict(env.sim_params), env._task_params_struct, env.terrain, n, seed=seed, precision="f64",
-                                 solver="gs", blocks=None)
+                                 solver="gs", blocks=None, dof_state_lag=lag)
+    other_orc = OracleAnymalTerrainEnv(load_model("anymal"), _sim_dict(env.sim_params), env._task_params_struct, env.terrain, n, seed=seed, precision="f64",
+                                       solver="gs", blocks=None, dof_state_lag=not lag)
     t = env.engine.tensors
     np.testing.assert_array_equal(t["terrain_types"].numpy(), orc.terrain_types)
     np.testing.assert_allclose(t["friction"].numpy(), orc.friction, rtol=1e-6)
@@ -327,9 +336,14 @@ def test_anymal_terrain_on_cpu_matches_the_cpu_restatement():
         a = torch.rand((n, 12), generator=g) * 2 - 1
         obs_d, rew, reset, extras = env.step(a)
         o_obs, o_rew, o_reset = orc.step(a.numpy())
+        x_obs, _, _ = other_orc.step(a.numpy())
         obs = env.obs_buf.numpy()
         assert np.isfinite(obs).all()
         d = np.abs(obs - o_obs)
+        if step == 1:       # the joint columns of the other setting are somewhere else (dof velocities change by rad/s within one 5 ms sim step)
+            assert np.abs(x_obs - o_obs)[:, 24:36].max() > 20 * max(d[:, 24:36].max(), 1e-4)
+        if lag:
+            np.testing.assert_allclose(env.dof_state_refreshed[..., 0].numpy(), orc.dof_pos, atol=2e-3 * (1 + step))
         other = np.concatenate([d[:, :36], d[:, 176:]], axis=1)     # (the height-scan columns jump by a grid cell at cell borders: statistically)
         ok = other.max(axis=1) < 3e-3 * (1 + step)
         assert ok.mean() > 0.95, (step, ok.mean(), other.max())

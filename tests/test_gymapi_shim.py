@@ -178,32 +178,34 @@ def test_reference_anymal_terrain_runs_on_the_engine_and_matches_the_fused_kerne
     et, nt = eng.tensors, nat.engine.tensors
     for k in ("root_states", "dof_state", "contact_impulse", "limit_impulse", "friction", "net_contact_force"):
         nt[k].copy_(et[k])
+    # the task's dof-state tensor: what the reference last refreshed (one sim step behind the physics state just copied)
+    assert int(nat.engine.get_option("dof_state_lag")) == 1
+    nat.dof_state_refreshed[..., 0].copy_(ref.dof_pos); nat.dof_state_refreshed[..., 1].copy_(ref.dof_vel)
+    lagging = float((et["dof_state"][..., 0] - ref.dof_pos).abs().max())
+    assert lagging > 1e-3                                      # (it does lag: the base class's simulate() moved the joints, nobody refreshed)
     nt["commands"].copy_(ref.commands); nt["last_actions"].copy_(ref.last_actions); nt["last_dof_vel"].copy_(ref.last_dof_vel)
     nt["feet_air_time"].copy_(ref.feet_air_time); nt["env_origins"].copy_(ref.env_origins)
     nat.progress_buf.copy_(ref.progress_buf); nat.reset_buf.copy_(ref.reset_buf.long())
     a = (torch.rand((n, 12), generator=g) * 2 - 1).to(DEV)
     keep = (ref.reset_buf == 0) & (ref.progress_buf < ref.max_episode_length - 3)
     # The reference refreshes its dof tensor inside the decimation loop only (anymal_terrain.py:443-452; the refresh in post_physics_step is
-    # commented out, :455), not after the base class's own simulate() (vec_task.py:382): its joint observations -- and the first PD torque of
-    # the next step -- lag the physics by one sim step.  The fused kernels read the current state.  Compared here on a common footing: the
-    # tensor is refreshed before the step (first torque from the current state) and before the reference's compute_observations is re-run.
-    ref.gym.refresh_dof_state_tensor(ref.sim)
+    # commented out, :455), not after the base class's own simulate() (vec_task.py:382): its joint observations, the reward's joint terms -- and
+    # the first PD torque of the next step -- lag the physics by one sim step.  Since round 5 the fused kernels reproduce that (View::dof_api, the
+    # `dof_state_refreshed` tensor, option dof_state_lag): the reference file's own step and the native step are compared as they are.
     r_obs, r_rew, r_reset, _ = ref.step(a.clone())
     n_obs, n_rew, n_reset, _ = nat.step(a.clone())
     keep &= ~r_reset.bool() & ~n_reset.bool()                 # envs that end here resample commands from different generators
     assert int(keep.sum()) > n // 2
     assert float((et["root_states"] - nt["root_states"]).abs()[keep].max()) < 1e-3       # same physics through both boundaries
     assert float((et["dof_state"] - nt["dof_state"]).abs()[keep].max()) < 5e-3
-    stale = (r_obs["obs"] - n_obs["obs"]).abs()[keep][:, 12:36]
-    ref.gym.refresh_dof_state_tensor(ref.sim)
-    ref.compute_observations()
-    d = (ref.obs_buf - n_obs["obs"]).abs()[keep]
-    assert float(d[:, :36].max()) < 2e-3, float(d[:, :36].max())          # base velocities, gravity, commands, joints
+    assert float((ref.dof_pos - nat.dof_state_refreshed[..., 0]).abs()[keep].max()) < 5e-3          # and the same lagging tensor
+    d = (r_obs["obs"] - n_obs["obs"]).abs()[keep]
+    assert float(d[:, :36].max()) < 2e-3, float(d[:, :36].max())          # base velocities, gravity, commands, joints (the lagging ones)
     assert float(d[:, 36:176].max()) < 2e-3, float(d[:, 36:176].max())    # the 140-point height scan
     assert float(d[:, 176:].max()) < 1e-5                                  # actions
-    assert float(stale.max()) > 10 * float(d[:, 12:36].max())             # (the lag is real: the un-refreshed joint columns are far off)
-    # the reward's joint terms (joint acceleration, hip, torques) see the lagging tensor in the reference: compared loosely
-    assert float((r_rew - n_rew).abs()[keep].max()) < 5e-2 * max(1.0, float(r_rew.abs().max()))
+    fresh = (nt["dof_state"][..., 0] * float(ref.dof_pos_scale) - n_obs["obs"][:, 12:24]).abs()[keep]
+    assert float(fresh.max()) > 10 * float(d[:, 12:24].max())             # (the physics state is somewhere else: the lag is real)
+    assert float((r_rew - n_rew).abs()[keep].max()) < 2e-3 * max(1.0, float(r_rew.abs().max()))       # incl. the joint terms, on the lagging tensor in both
 
 
 def test_reference_shadow_hand_runs_on_the_engine_and_matches_the_fused_kernels(reference_tasks):
