@@ -1168,9 +1168,14 @@ def test_shadow_hand_actor_params_block_of_the_task_config_reaches_the_engine():
     assert not [x for x in w if "actor_params" in str(x.message)], [str(x.message) for x in w]
     t = env.engine.tensors
     sc = t["actor_scale"].cpu().numpy()
-    for col, (a, b) in {0: (0.5, 1.5), 1: (0.3, 3.0), 2: (0.75, 1.5), 3: (0.75, 1.5), 4: (0.3, 3.0), 5: (0.5, 1.5), 6: (0.95, 1.05)}.items():
+    for col, (a, b) in {1: (0.3, 3.0), 2: (0.75, 1.5), 3: (0.75, 1.5), 4: (0.3, 3.0), 5: (0.5, 1.5), 6: (0.95, 1.05)}.items():
         assert sc[:, col].min() >= a - 1e-5 and sc[:, col].max() <= b + 1e-5 and sc[:, col].std() > 0.1 * (b - a), col
     assert float(np.abs(sc[:, 7] - 1).max()) == 0.0
+    # the hand's link masses: one factor per BODY and env (round 5; the reference walks the rigid-body property list, vec_task.py:783-828) in the tensor
+    # the Sim<Scaled<M>> kernels read, switched in by the first write; column 0 of actor_scale -- the one factor per env of rounds 2-4 -- stays 1
+    bm = t["hand_body_mass_scale"].cpu().numpy()
+    assert int(env.engine.get_option("hand_body_mass")) == 1 and float(np.abs(sc[:, 0] - 1).max()) == 0.0
+    assert bm.min() >= 0.5 - 1e-5 and bm.max() <= 1.5 + 1e-5 and bm.std(0).min() > 0.1 and bm.std(1).min() > 0.1
     sh = t["dof_limit_shift"].cpu().numpy()
     assert abs(sh.std() - 0.01) < 0.002 and abs(sh.mean()) < 0.002                       # additive gaussian (0, 0.01), one per joint and env
     fr = t["friction"].cpu().numpy()
@@ -1182,6 +1187,7 @@ def test_shadow_hand_actor_params_block_of_the_task_config_reaches_the_engine():
         env.step(torch.zeros((n, 20), device=DEV))
     sc2 = t["actor_scale"].cpu().numpy()
     np.testing.assert_array_equal(sc2[:, [0, 5, 6]], before[:, [0, 5, 6]])
+    np.testing.assert_array_equal(t["hand_body_mass_scale"].cpu().numpy(), bm)
     assert (sc2[:, 1] != before[:, 1]).mean() > 0.9
     assert torch.isfinite(env.obs_buf).all()
 
