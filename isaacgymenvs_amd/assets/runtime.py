@@ -90,6 +90,7 @@ def header_text(model_name, spec, sensors=None):
 # ------------------------------------------------------------------------------------------------ a NEW kinematic tree: the Articulation task
 GENERIC_MODEL = "articulation"
 MAX_DOF = 32          # include/mi_engine.h MI_MAX_DOF
+MAX_SPHERES = 48      # contact spheres a run-time robot keeps (parse_generic coarsens mesh sampling beyond that)
 
 
 def parse_generic(path, options=None):
@@ -106,6 +107,14 @@ def parse_generic(path, options=None):
         kw.update(mesh_spheres=True, mesh_root=os.path.dirname(os.path.dirname(os.path.abspath(path))),
                   mesh_options=dict(r_cap=0.05, max_count=4))
     spec = load_asset(path, name=GENERIC_MODEL, **kw)
+    # The Articulation kernels unroll one contact block per sphere: past ~48 of them the one-wave sub-step leaves the register regime the build
+    # gate accepts (kuka_allegro_touch_sensor.urdf with 4 spheres per mesh: 82 spheres, 258 spilled SGPRs on gfx950 -- refused).  A robot with many
+    # mesh shapes gets fewer spheres per mesh instead (2, then 1): the same robot, a coarser contact set, on both backends alike.
+    for fewer in (2, 1):
+        if len(spec.sph_body) <= MAX_SPHERES or "mesh_options" not in kw:
+            break
+        kw["mesh_options"] = dict(kw["mesh_options"], max_count=fewer)
+        spec = load_asset(path, name=GENERIC_MODEL, **kw)
     if spec.nd > MAX_DOF:
         raise NotImplementedError(f"{path}: {spec.nd} dofs, the engine's parameter blocks hold {MAX_DOF} (MI_MAX_DOF)")
     return spec

@@ -363,6 +363,108 @@ def test_franka_arm_from_urdf_meshes_runs_osc_hip():
     _franka("cuda:0")
 
 
+KUKA = os.path.join(REF, "assets", "urdf", "kuka_allegro_description", "kuka_allegro_touch_sensor.urdf")
+
+
+def _kuka_allegro(device):
+    """The arm + hand of the reference's allegro_kuka tasks (`tasks/allegro_kuka/allegro_kuka_base.py:559-573`: kuka_allegro_touch_sensor.urdf --
+    a 7-dof iiwa arm carrying the 16-dof Allegro hand, all collision shapes MESHES --, fixed base, collapse_fixed_joints, gravity disabled, every
+    dof a position drive) through `gym.load_asset`: a kinematic tree no compiled model has, so it becomes the Articulation task's robot (23 dofs,
+    spheres inscribed in the meshes' hulls).  One simulate() from the task's default arm pose (`:285`) follows the oracle; driven to targets a
+    little away it settles on them; Jacobian and mass-matrix tensors are consistent with the body states.  (SURVEY 8f.4 lists
+    `kuka_allegro_description` among the asset formats either side of the path; the tasks' scenes -- table, objects -- are not built.)"""
+    import isaacgymenvs_amd.shims as shims
+    from isaacgymenvs_amd import native
+    from oracle.engine import OracleEngine
+    if device == "cpu":
+        native.build_cpu()
+    shims.install(force=True)
+    from isaacgym import gymapi
+    gym = gymapi.acquire_gym()
+    sp = gymapi.SimParams()
+    sp.up_axis, sp.gravity, sp.dt, sp.substeps, sp.use_gpu_pipeline = gymapi.UP_AXIS_Z, gymapi.Vec3(0, 0, -9.81), 1 / 60.0, 2, device != "cpu"
+    sp.physx.num_position_iterations, sp.physx.num_velocity_iterations = 8, 0
+    sim = gym.create_sim(0, -1, gymapi.SIM_PHYSX, sp)
+    gym.add_ground(sim, gymapi.PlaneParams())
+    opts = gymapi.AssetOptions()
+    opts.fix_base_link, opts.flip_visual_attachments, opts.collapse_fixed_joints, opts.disable_gravity = True, False, True, True
+    opts.thickness, opts.angular_damping, opts.linear_damping, opts.default_dof_drive_mode = 0.001, 0.01, 0.01, gymapi.DOF_MODE_POS
+    asset = gym.load_asset(sim, os.path.join(REF, "assets"), "urdf/kuka_allegro_description/kuka_allegro_touch_sensor.urdf", opts)
+    nd = gym.get_asset_dof_count(asset)
+    assert asset.generic and nd == 23                                     # allegro_kuka_base.py: 7 arm + 16 hand dofs
+    names = gym.get_asset_dof_names(asset)
+    assert names[:7] == [f"iiwa7_joint_{k}" for k in range(1, 8)] and sum("index" in x or "middle" in x or "ring" in x or "thumb" in x for x in names) == 16
+    spec = asset.spec
+    assert spec.fixed_base and 20.0 < spec.total_mass() < 40.0            # the URDF's own inertials: 27 kg of arm + 1.8 kg of hand
+    dp = gym.get_asset_dof_properties(asset)
+    dp["driveMode"][:] = gymapi.DOF_MODE_POS
+    dp["stiffness"][:7], dp["damping"][:7] = 400.0, 40.0
+    dp["stiffness"][7:], dp["damping"][7:] = 3.0, 0.1                     # the Allegro hand's gains (allegro_hand.py:256-264)
+    n = 4
+    for i in range(n):
+        env = gym.create_env(sim, gymapi.Vec3(), gymapi.Vec3(), 2)
+        h = gym.create_actor(env, asset, gymapi.Transform(gymapi.Vec3(0.0, 0.8, 0.0)), "allegro", i, 0, 0)        # allegro_kuka_base.py:604-606
+        gym.set_actor_dof_properties(env, h, dp)
+    gym.prepare_sim(sim)                    # compiles the robot's library once (cached)
+    es = asset.engine_spec
+    dof = gym.acquire_dof_state_tensor(sim).view(n, nd, 2)
+    body_names = gym.get_asset_rigid_body_names(asset)
+    rb = gym.acquire_rigid_body_state_tensor(sim).view(n, len(body_names), 13)
+    jac = gym.acquire_jacobian_tensor(sim, "allegro")
+    mm = gym.acquire_mass_matrix_tensor(sim, "allegro")
+    assert tuple(mm.shape) == (n, nd, nd) and jac.shape[0] == n and jac.shape[2:] == (6, nd)
+    q0 = torch.zeros(nd, device=sim.device)
+    q0[:7] = torch.tensor([-1.571, 1.571, -0.000, 1.376, -0.000, 1.485, 2.358])           # "pose v1" (:285)
+    lo, up = np.minimum(es.dof_lower, es.dof_upper), np.maximum(es.dof_lower, es.dof_upper)
+    q0 = torch.max(torch.min(q0, torch.tensor(up, dtype=torch.float32, device=sim.device)), torch.tensor(lo, dtype=torch.float32, device=sim.device))
+    ds = torch.zeros((n, nd, 2), device=sim.device)
+    ds[..., 0] = q0
+    gym.set_dof_state_tensor(sim, ds.view(-1, 2))
+    rng = np.random.default_rng(4)
+    tg = np.clip(q0.cpu().numpy()[None, :] + rng.uniform(-0.15, 0.15, (n, nd)), lo + 0.02, up - 0.02)
+    gym.set_dof_position_target_tensor(sim, torch.tensor(tg, dtype=torch.float32, device=sim.device).view(-1))
+    # ---- one simulate() against the oracle: position drives on every dof, no gravity, whatever touches the ground does so in both
+    prm = dict(dt=1 / 60.0, substeps=2, iters=8, gravity=(0, 0, 0), contact_offset=0.02, rest_offset=0.0, max_depen_vel=100.0, erp=0.5, plane_mu=1.0,
+               ground_z=0.0, cfm=1e-6, warm=1.0)
+    orc = OracleEngine(es, n, params=prm, sensor_bodies=[0], precision="f64")
+    orc.root[:] = sim.engine.tensors["root_states"].cpu().numpy()
+    orc.q[:] = q0.cpu().numpy()
+    kpv, kdv = np.asarray(dp["stiffness"], float), np.asarray(dp["damping"], float)
+    gym.simulate(sim)
+    orc.step_drive_v(np.zeros((n, nd)), kpv, kdv, tg)
+    gym.refresh_dof_state_tensor(sim)
+    np.testing.assert_allclose(dof[..., 0].cpu().numpy(), orc.q, atol=5e-4)
+    np.testing.assert_allclose(dof[..., 1].cpu().numpy(), orc.qd, atol=5e-2)
+    # ---- driven on: the joints settle on their targets (the light finger joints within a second, the arm's 400 / 40 drives too)
+    for it in range(90):
+        gym.simulate(sim)
+    gym.refresh_dof_state_tensor(sim); gym.refresh_rigid_body_state_tensor(sim); gym.refresh_jacobian_tensors(sim); gym.refresh_mass_matrix_tensors(sim)
+    assert torch.isfinite(dof).all()
+    err = np.abs(dof[..., 0].cpu().numpy() - tg)
+    assert err[:, :7].max() < 0.02 and err[:, 7:].max() < 0.05, (err[:, :7].max(), err[:, 7:].max())
+    Mn = mm.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(Mn, Mn.transpose(0, 2, 1), atol=1e-4)
+    assert np.all(np.linalg.eigvalsh(Mn) > 0)
+    # J qd is the twist of every link (qd small but non-zero while the drives settle)
+    qd = dof[..., 1]
+    tw = (jac @ qd[:, None, :, None]).squeeze(-1)                                    # [n, links - 1, 6]
+    dyn = [i for i, nm in enumerate(body_names) if nm in list(spec.body_names)][1:]  # gym bodies that are engine bodies, the fixed base excluded
+    got = rb[:, dyn, 7:13]
+    assert tw.shape[1] == spec.nb - 1
+    np.testing.assert_allclose(tw[:, [list(spec.body_names).index(body_names[i]) - 1 for i in dyn]].cpu().numpy(), got.cpu().numpy(), atol=2e-3)
+
+
+@pytest.mark.skipif(not os.path.isfile(KUKA), reason="the reference's kuka_allegro_description is not reachable")
+def test_kuka_allegro_arm_hand_from_urdf_meshes_cpu():
+    _kuka_allegro("cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.isfile(KUKA), reason="the reference's kuka_allegro_description is not reachable")
+def test_kuka_allegro_arm_hand_from_urdf_meshes_hip():
+    _kuka_allegro("cuda:0")
+
+
 @pytest.mark.skipif(not HAVE_REF, reason="reference tree not reachable")
 @pytest.mark.parametrize("backend", [pytest.param("cpu", marks=pytest.mark.skipif(torch.cuda.is_available(), reason="the HIP variant runs here")),
                                      pytest.param("hip", marks=[pytest.mark.gpu, pytest.mark.skipif(not torch.cuda.is_available(), reason="needs the MI355X")])])

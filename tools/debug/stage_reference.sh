@@ -27,3 +27,12 @@ cp $REF/assets/urdf/franka_description/robots/franka_panda_gripper.urdf $ROOT/ab
 cp $REF/assets/urdf/franka_description/meshes/collision/*.obj $ROOT/ab/ref_stage/assets/urdf/franka_description/meshes/collision/
 find $ROOT/ab/ref_stage -name __pycache__ -type d -prune -exec rm -rf {} +
 echo staged $(find $ROOT/ab/ref_stage -type f | wc -l) files under ab/ref_stage
+# tests/test_articulation.py: the arm + hand of the allegro_kuka tasks (allegro_kuka_base.py:573): the URDF and the COLLISION meshes it names
+K=$ROOT/ab/ref_stage/assets/urdf/kuka_allegro_description
+mkdir -p $K/meshes/allegro $K/meshes/iiwa7/collision $K/meshes/mounts $K/meshes/touchsensor/collision
+cp $REF/assets/urdf/kuka_allegro_description/kuka_allegro_touch_sensor.urdf $K/
+cp $REF/assets/urdf/kuka_allegro_description/meshes/allegro/*.obj $K/meshes/allegro/
+cp $REF/assets/urdf/kuka_allegro_description/meshes/iiwa7/collision/*.obj $K/meshes/iiwa7/collision/
+cp $REF/assets/urdf/kuka_allegro_description/meshes/mounts/*.obj $K/meshes/mounts/
+cp $REF/assets/urdf/kuka_allegro_description/meshes/touchsensor/collision/*.obj $K/meshes/touchsensor/collision/
+echo staged $(find $ROOT/ab/ref_stage -type f | wc -l) files under ab/ref_stage "(with the kuka_allegro arm + hand)"
