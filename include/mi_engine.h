@@ -118,10 +118,33 @@ typedef struct {
  * library carries the AMP humanoid.  Driven through mi_engine_simulate (gym.simulate) only: efforts in dof_actuation_force, position targets in
  * dof_position_targets for the dofs whose drive gains are non-zero (gym DOF_MODE_POS: dof stiffness / damping are the drive's gains).
  * mi_engine_step is refused -- the observation / reward functions of such a task stay the caller's (the reference's own torch code). */
+/* The SCENE beside a fixed-base articulated actor: what the other actors of the reference's table-top envs become (franka_cube_stack.py:204-233,
+ * 323-339: gym.create_box assets -- the table and its stand with fix_base_link, two free cubes -- created in every env beside the arm).  Free boxes
+ * are rigid bodies of the same sub-step (contacts with the actor's collision spheres, the static boxes, the ground plane and each other are rows of
+ * the one Gauss-Seidel solve, csrc/core/scene_engine.hpp); their root states live in tensor "scene_state" [N, MI_SCENE_MAX_FREE, 13]. */
+#define MI_SCENE_MAX_FREE 4
+#define MI_SCENE_MAX_STATIC 4
+typedef struct {
+    int32_t n_free, n_static;              /* 0, 0: no scene -- the actor alone on the ground plane (its spheres against the plane) */
+    int32_t arm_gravity;                   /* 0: asset option disable_gravity on the articulated actor (franka_cube_stack.py:199); the boxes feel the sim's */
+    int32_t pad;
+    float free_half[MI_SCENE_MAX_FREE][3]; /* half sizes */
+    float free_mass[MI_SCENE_MAX_FREE];
+    float free_inertia[MI_SCENE_MAX_FREE][3];  /* principal inertias along the box axes */
+    float free_mu[MI_SCENE_MAX_FREE];      /* shape friction (combined with the other side's by averaging) */
+    float free_init[MI_SCENE_MAX_FREE][7]; /* start pose (create_actor): position, quaternion xyzw */
+    float static_pos[MI_SCENE_MAX_STATIC][3], static_quat[MI_SCENE_MAX_STATIC][4], static_half[MI_SCENE_MAX_STATIC][3], static_mu[MI_SCENE_MAX_STATIC];
+    float arm_mu;                          /* friction of the actor's shapes */
+} MiScene;
+
 typedef struct {
     float kp[MI_MAX_DOF], kd[MI_MAX_DOF];  /* per-dof position-drive gains; kp = kd = 0: no drive on that dof */
     float max_angular_velocity;            /* asset option: clamp of the base's angular speed (rad/s); <= 0: none */
     float init_root[13];                   /* actor start pose (create_actor) + zero velocities */
+    MiScene scene;                         /* free / static boxes beside the actor; fixed-base actors only */
+    float drive_vmax[MI_MAX_DOF];          /* velocity limit of a dof's position drive (the asset's joint velocity limit, URDF <limit velocity=>); <= 0: none.
+                                            * Scenes only: the drive's position error is clamped to vmax * kd / kp, the error at which its spring and damper
+                                            * balance at that speed (franka_panda_gripper.urdf:247 fingers: 0.2 m/s) */
 } MiArticulationParams;
 
 /* task parameters of Ingenuity (ingenuity.py:45-97, 233-282): constants the reference hard-codes in the task file */

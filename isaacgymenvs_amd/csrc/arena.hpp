@@ -67,6 +67,8 @@ struct View {
     float* ep_stats;      // [16] this step: sum of the 13 episode sums over resetting envs, #resets, sum terrain levels
     float* ep_means;      // [16] extras["episode"]: rew_* means / max_episode_length_s, terrain_level mean (:421-425)
     float* targets;       // [ND][N] position targets of the Articulation task's drives (gym.set_dof_position_target_tensor); null otherwise
+    float* scene = nullptr;     // [13 * kSceneMaxFree][N] root states of the free boxes of the Articulation task's scene (core/scene_engine.hpp); null otherwise
+    int* scene_nc = nullptr;    // [2][N] scene contacts taken in the last sub-step, refused for want of a slot since reset
     float* ep_cum;        // [16] the same sums accumulated since init, never re-zeroed: 13 episode sums of the envs that reset, [13] their count,
                           //      [14] sum of the terrain levels of all envs over the steps, [15] the steps -- what a multi-GPU job all-reduces every K
                           //      steps to form job-wide extras["episode"] (parallel.py TaskExtrasReducer)

@@ -150,6 +150,11 @@ static void build_layout(int task, int N, Layout& L, View* v, char* base, int no
         const int64_t nb = m.nb;
         o = L.add("net_contact_force", MI_F32, {n, nb, 3}, {1, 3 * n, n}, 3 * nb * n); if (v) v->netf = (float*)P(o);
         o = L.add("dof_position_targets", MI_F32, {n, nd}, {1, n}, nd * n); if (v) v->targets = (float*)P(o);
+        // the scene beside the actor (core/scene_engine.hpp, MiScene): root states of its free boxes -- gym's actor root state rows of those actors
+        // (franka_cube_stack.py:377-386) -- and its contact counters
+        const int64_t nfb = MI_SCENE_MAX_FREE;
+        o = L.add("scene_state", MI_F32, {n, nfb, 13}, {1, 13 * n, n}, 13 * nfb * n); if (v) v->scene = (float*)P(o);
+        o = L.add("scene_contacts", MI_I32, {n, 2}, {1, n}, 2 * n); if (v) v->scene_nc = (int*)P(o);
     }
     if (task == T_ANYMAL_FLAT) {   // anymal.py:100-125
         const int64_t nb = m.nb;

@@ -1,0 +1,470 @@
+// scene_engine.hpp -- physics sub-step of a fixed-base articulated actor in a SCENE: free rigid boxes and static boxes beside it.
+//
+// Replaces gym.simulate() for the reference's table-top manipulation tasks, whose envs hold more than one actor: reference
+// isaacgymenvs/tasks/franka_cube_stack.py:204-233,323-339 (the Franka arm, a table and its stand -- static boxes, gym.create_box with
+// fix_base_link -- and two free cubes).  Built on the pieces of core/engine.hpp (tree pass, branch-sparse L^T L factor, whitened PGS) the way
+// core/hand_engine.hpp is; what is specific here:
+//   * up to kSceneMaxFree free boxes (three half sizes, principal inertias along the box axes, gravity on) and kSceneMaxStatic static boxes
+//     (pose + half sizes), both RUN-TIME parameters (SceneParams = MiScene of include/mi_engine.h): one compiled robot serves any scene;
+//   * the actor's own gravity follows asset option disable_gravity (franka_cube_stack.py:199), the boxes' follows the sim;
+//   * contacts, every one 3 rows (normal + friction disc) of ONE Gauss-Seidel sequence with the actor's joint-limit rows:
+//       actor sphere (the model's collision spheres, meshes sampled by assets/mesh.py) vs free box / static box   [actor chain | 6 box dofs]
+//       free box corner vs ground plane / static box / other free box (both directions)                            [6 | 6 box dofs]
+//     box-box and box-static manifolds are the CORNER-IN-BOX contacts of both boxes (exact signed distance of a point to a box): face-face
+//     and corner-face configurations (a cube on a table, a cube stacked on a cube, a cube pushed against a cube) are covered, edge-edge
+//     crossings are not.  A stated approximation like every contact model here: physics parity against PhysX is unpinned.
+//   * contact slots are data dependent: at most KARM actor contacts (taken in sphere order, grouped by actor body) and KBOX box contacts
+//     (box order, corner order, then ground / static boxes / free boxes); refusals are counted.
+//   * free boxes live in plain velocity space (their mass matrix is block diagonal: v += M^-1 J^T dl costs 2 cross products), the actor
+//     in the whitened space of its factor.
+// Same maths as oracle/scene.py (dense, numpy, fp64).
+#pragma once
+#include "engine.hpp"
+
+namespace mi {
+
+constexpr int kSceneMaxFree = 4, kSceneMaxStatic = 4;
+struct SceneParams {        // mirrors MiScene (include/mi_engine.h)
+    int n_free, n_static;
+    int arm_gravity;        // 0: asset option disable_gravity on the articulated actor
+    int pad;
+    float free_half[kSceneMaxFree][3], free_mass[kSceneMaxFree], free_inertia[kSceneMaxFree][3], free_mu[kSceneMaxFree];
+    float free_init[kSceneMaxFree][7];      // start pose (create_actor): what reset leaves
+    float static_pos[kSceneMaxStatic][3], static_quat[kSceneMaxStatic][4], static_half[kSceneMaxStatic][3], static_mu[kSceneMaxStatic];
+    float arm_mu;           // friction of the actor's shapes (combined with the other side's by averaging, PhysX's default combine mode)
+};
+
+// point / sphere (centre c in the box frame, radius r) vs box of half sizes a[3]: signed distance, outward normal (box frame)
+MI_HD void scene_sphere_box(const float* c, float r, const float* a, float* dist, float* n) {
+    float d[3], pn[3];
+    sfor<3>([&](auto K) MI_LAMBDA { d[K] = c[K] - fminf(fmaxf(c[K], -a[K]), a[K]); pn[K] = a[K] - fabsf(c[K]); });
+    const float d2 = dot3(d, d);
+    const bool ix = (pn[0] <= pn[1]) && (pn[0] <= pn[2]), iy = !ix && (pn[1] <= pn[2]);
+    const float pen = ix ? pn[0] : (iy ? pn[1] : pn[2]);
+    const bool outside = d2 > 1e-24f;
+    const float inv = MI_RSQ(fmaxf(d2, 1e-30f));
+    *dist = outside ? d2 * inv - r : -pen - r;
+    n[0] = outside ? d[0] * inv : (ix ? (c[0] >= 0.f ? 1.f : -1.f) : 0.f);
+    n[1] = outside ? d[1] * inv : (iy ? (c[1] >= 0.f ? 1.f : -1.f) : 0.f);
+    n[2] = outside ? d[2] * inv : ((!ix && !iy) ? (c[2] >= 0.f ? 1.f : -1.f) : 0.f);
+}
+
+template <class M>
+struct SceneSim : Sim<M> {
+    using B = Sim<M>;
+    static constexpr int NB = M::NB, ND = M::ND, NV = M::NV, OFF = M::OFF, NSPH = M::NSPH, NSENS = M::NSENS, NLIM = B::NLIM, NVA = B::NVA;
+    static_assert(M::FIXED == 1, "SceneSim: a fixed-base actor (the scene's free bodies are boxes)");
+    static constexpr int KARM = 24, KBOX = 24;              // contact slots: actor spheres, box corners
+    static constexpr int HCH = M::MAXCHAIN;
+    // one contact slot: 3 rows over the actor chain (zero for box contacts) | normal n (3), contact point pc rel. O (3) |
+    // Ainv x3, vt_n, lam x3, mu, side A's free box (int bits; -1: the actor / nobody), side B's free box (-1: static)
+    static constexpr int S_GEO = 3 * HCH, S_AUX = S_GEO + 6, S_CSZ = S_AUX + 10;
+    static constexpr int R_LIMG = B::limoff(NLIM);
+    static constexpr int R_CB = R_LIMG + 3 * NLIM;          // limit G | Ainv, vt, lam | contact slots
+    static constexpr int R_BODY = R_CB + (KARM + KBOX) * S_CSZ;     // per actor body: first slot | count << 8
+    static constexpr int ROW_SLOTS = R_BODY + NB;
+
+    float box[kSceneMaxFree][13];                           // free boxes: pos3, quat xyzw, linvel3, angvel3 (world)
+
+    // the spheres of one actor body are consecutive (generated sph_body is non-decreasing)
+    static constexpr bool sph_grouped() { for (int s = 1; s < NSPH; ++s) if (M::sph_body[s] < M::sph_body[s - 1]) return false; return true; }
+    static_assert(sph_grouped(), "collision spheres are listed body by body");
+    static constexpr int sph_first(int b) { for (int s = 0; s < NSPH; ++s) if (M::sph_body[s] == b) return s; return 0; }
+    static constexpr int sph_count(int b) { int n = 0; for (int s = 0; s < NSPH; ++s) n += (M::sph_body[s] == b) ? 1 : 0; return n; }
+
+    // one sub-step of length h.  tau[ND]: efforts; drv: per-dof position drives; laml: warm-start limit impulses; ncontact: contacts taken
+    // (actor + box) | refused for want of a slot << 16
+    template <int RS>
+    MI_HD void substep_scene(const SimParams& P, const SceneParams& SP, const float* tau, const Drive& drv, const float h, const RowStore<RS> rows,
+                             const Strided laml, const Strided dof_force, int* ncontact) {
+        constexpr int ST = RowStore<RS>::stride;
+        float (&q)[M::NDA] = this->q;
+        float (&qd)[M::NDA] = this->qd;
+        float (&root)[13] = this->root;
+        auto G = [&](int row, int c) MI_LAMBDA -> float& { return rows(B::limoff(row) + c); };
+        auto Ainv = [&](int row) MI_LAMBDA -> float& { return rows(R_LIMG + row); };
+        auto vt = [&](int row) MI_LAMBDA -> float& { return rows(R_LIMG + NLIM + row); };
+        auto lam = [&](int row) MI_LAMBDA -> float& { return rows(R_LIMG + 2 * NLIM + row); };
+        const float invh = MI_RCP(h);
+        const int nf = SP.n_free < kSceneMaxFree ? SP.n_free : kSceneMaxFree, ns = SP.n_static < kSceneMaxStatic ? SP.n_static : kSceneMaxStatic;
+        typename B::Ctx c;
+        float (&S)[M::NDA][6] = c.S;
+        float (&L)[M::NM] = c.L;
+        sfor<ND>([&](auto D) MI_LAMBDA {
+            constexpr int d = D;
+            if constexpr (M::dof_limited[d]) lam(B::limrow(d)) = laml(d);
+        });
+        // ------------------------------------------------------------ tree pass (the actor's own gravity: asset option disable_gravity)
+        {
+            SimParams P0 = P;
+            if (!SP.arm_gravity) P0.g[0] = P0.g[1] = P0.g[2] = 0.f;
+            SpI Iroot;
+            float Froot[6];
+            this->template body_pass<0>(P0, c, nullptr, nullptr, nullptr, nullptr, Iroot, Froot);
+        }
+        MI_PHASE();
+        // sphere centres (rel. O) in per-lane memory: the narrow phase walks a body's spheres in a run-time loop (one copy of the code per
+        // BODY, not per sphere -- core/hand_engine.hpp's reason)
+        float xs[3 * M::NSPHA];
+        int pz;
+        MI_OPAQUE_ZERO(pz);
+        sfor<NSPH>([&](auto S_) MI_LAMBDA { sfor<3>([&](auto K) MI_LAMBDA { xs[pz + 3 * S_ + K] = c.xcs[S_][K]; }); });
+        // ------------------------------------------------------------ rhs: efforts, passive spring / damper, implicit position drives
+        float Ldi[NVA], y[NVA];
+        sfor<ND>([&](auto D) MI_LAMBDA {
+            constexpr int d = D, gi = OFF + d;
+            const float K = M::dof_stiffness[d], Dm = M::dof_damping[d];
+            const float kpd = drv.gain_p(d), kdd = drv.gain_d(d);
+            L[M::midx[gi][gi]] += M::dof_armature[d] + h * (Dm + kdd) + h * h * (K + kpd);
+            y[gi] = tau[d] - c.bias[gi] - K * (q[d] - M::dof_springref[d]) - (Dm + h * K) * qd[d] + kpd * (drv.target[d] - q[d]) - (kdd + h * kpd) * qd[d];
+        });
+        MI_PHASE();
+        // ------------------------------------------------------------ H = L^T L
+        sfor_rev<NV>([&](auto K_) MI_LAMBDA {
+            constexpr int k = K_;
+            const float dk2 = fmaxf(L[M::midx[k][k]], 1e-30f);
+            const float inv = MI_RSQ(dk2);
+            L[M::midx[k][k]] = dk2 * inv;
+            Ldi[k] = inv;
+            sfor<M::nanc[k]>([&](auto A_) MI_LAMBDA { L[M::midx[k][M::anc[k][A_]]] *= inv; });
+            sfor<M::nanc[k]>([&](auto A_) MI_LAMBDA {
+                constexpr int i = M::anc[k][A_];
+                const float lki = L[M::midx[k][i]];
+                L[M::midx[i][i]] -= lki * lki;
+                sfor<M::nanc[i]>([&](auto B_) MI_LAMBDA {
+                    constexpr int j = M::anc[i][B_];
+                    L[M::midx[i][j]] -= lki * L[M::midx[k][j]];
+                });
+            });
+        });
+        MI_PHASE();
+        // ------------------------------------------------------------ whitened actor velocity w = L qd + h L^-T rhs; free boxes: v + h g
+        float w[NVA];
+        sfor_rev<NV>([&](auto I_) MI_LAMBDA {
+            constexpr int i = I_;
+            const float z = y[i] * Ldi[i];
+            sfor<M::nanc[i]>([&](auto A_) MI_LAMBDA { y[M::anc[i][A_]] -= L[M::midx[i][M::anc[i][A_]]] * z; });
+            float s = L[M::midx[i][i]] * qd[i];
+            sfor<M::nanc[i]>([&](auto A_) MI_LAMBDA { s += L[M::midx[i][M::anc[i][A_]]] * qd[M::anc[i][A_]]; });
+            w[i] = s + h * z;
+        });
+        float vb[kSceneMaxFree][6];             // lin, ang
+        float Rf[kSceneMaxFree][9], xf[kSceneMaxFree][3], Iinv[kSceneMaxFree][9], imass[kSceneMaxFree];      // pose (centre rel. O), world inverse inertia
+        for (int i = 0; i < nf; ++i) {
+            for (int k = 0; k < 3; ++k) { vb[i][k] = box[i][7 + k] + h * P.g[k]; vb[i][3 + k] = box[i][10 + k]; xf[i][k] = box[i][k] - root[k]; }
+            quat2mat(box[i] + 3, Rf[i]);
+            imass[i] = MI_RCP(SP.free_mass[i]);
+            const float id[3] = {MI_RCP(SP.free_inertia[i][0]), MI_RCP(SP.free_inertia[i][1]), MI_RCP(SP.free_inertia[i][2])};
+            for (int r = 0; r < 3; ++r)
+                for (int cc = 0; cc < 3; ++cc)
+                    Iinv[i][3 * r + cc] = Rf[i][3 * r] * id[0] * Rf[i][3 * cc] + Rf[i][3 * r + 1] * id[1] * Rf[i][3 * cc + 1] + Rf[i][3 * r + 2] * id[2] * Rf[i][3 * cc + 2];
+        }
+        float Rs[kSceneMaxStatic][9], xst[kSceneMaxStatic][3];
+        for (int i = 0; i < ns; ++i) {
+            quat2mat(SP.static_quat[i], Rs[i]);
+            for (int k = 0; k < 3; ++k) xst[i][k] = SP.static_pos[i][k] - root[k];
+        }
+        MI_PHASE();
+        // ------------------------------------------------------------ joint limit rows (as core/engine.hpp)
+        sfor<ND>([&](auto D) MI_LAMBDA {
+            constexpr int d = D, gi = OFF + d;
+            if constexpr (M::dof_limited[d]) {
+                constexpr int row = B::limrow(d);
+                MI_PHASE();
+                const float dl = q[d] - this->template limit_lower<d>(), du = this->template limit_upper<d>() - q[d];
+                const bool lower = dl < du;
+                const float C = lower ? dl : du, s = lower ? 1.f : -1.f;
+                const float lw = lam(row);
+                const float l0 = ((lw * s < 0.f) ? 0.f : fabsf(lw)) * P.warm;
+                float g[M::MAXCHAIN];
+                g[0] = s * Ldi[gi];
+                sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { g[1 + A_] = 0.f; });
+                sfor<M::nanc[gi] + 1>([&](auto K) MI_LAMBDA {
+                    constexpr int k = K;
+                    constexpr int i = (k == 0) ? gi : M::anc[gi][k == 0 ? 0 : k - 1];
+                    if constexpr (k > 0) g[k] *= Ldi[i];
+                    const float z = g[k];
+                    sfor<M::nanc[gi] - k>([&](auto T) MI_LAMBDA {
+                        constexpr int kk = k + 1 + T, j = M::anc[gi][kk - 1];
+                        g[kk] -= L[M::midx[i][j]] * z;
+                    });
+                });
+                float a = P.cfm;
+                sfor<M::nanc[gi] + 1>([&](auto K) MI_LAMBDA { a += g[K] * g[K]; G(row, K) = g[K]; });
+                Ainv(row) = MI_RCP(a);
+                vt(row) = (C >= 0.f) ? -C * invh : fminf(-C * P.erp * invh, P.max_depen_vel);
+                lam(row) = l0;
+                w[gi] += g[0] * l0;
+                sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { w[M::anc[gi][A_]] += g[1 + A_] * l0; });
+            }
+        });
+        MI_PHASE();
+        // the box part of a row: lever x direction, the response of the box to a unit impulse along u at the lever, its share of the diagonal
+        auto box_diag = [&](int i, const float* r, const float* u) MI_LAMBDA -> float {
+            float rx[3], t[3];
+            cross3(r, u, rx);
+            matvec3(Iinv[i], rx, t);
+            return imass[i] + dot3(rx, t);
+        };
+        auto target_velocity = [&](float dist) MI_LAMBDA -> float {
+            const float gap = dist - P.rest_offset;
+            return (gap >= 0.f) ? -gap * invh : fminf(-gap * P.erp * invh, P.max_depen_vel);
+        };
+        // ------------------------------------------------------------ actor contacts: sphere vs free boxes, then static boxes
+        int cnt = 0, refused = 0;
+        sfor<NB>([&](auto B_) MI_LAMBDA {
+            constexpr int b = B_;
+            if constexpr (sph_count(b) > 0) {
+                constexpr int CL = M::chain_len[b], S0 = sph_first(b), SN = sph_count(b);
+                MI_PHASE();
+                const int first = cnt;
+                for (int si = 0; si < SN; ++si) {
+                    const int s = S0 + si;
+                    const float rad = M::sph_rad[s];
+                    const float cs[3] = {xs[pz + 3 * s], xs[pz + 3 * s + 1], xs[pz + 3 * s + 2]};
+                    for (int t = 0; t < nf + ns; ++t) {
+                        const bool fr_ = t < nf;
+                        const int ib = fr_ ? t : t - nf;
+                        const float* Rb_ = fr_ ? Rf[ib] : Rs[ib];
+                        const float* xb_ = fr_ ? xf[ib] : xst[ib];
+                        const float* hb_ = fr_ ? SP.free_half[ib] : SP.static_half[ib];
+                        const float rel[3] = {cs[0] - xb_[0], cs[1] - xb_[1], cs[2] - xb_[2]};
+                        float cl[3], nl[3], dist;
+                        matTvec3(Rb_, rel, cl);
+                        scene_sphere_box(cl, rad, hb_, &dist, nl);
+                        if (!(dist < P.contact_offset)) continue;
+                        if (cnt >= KARM) { refused += 1; continue; }
+                        float fr[3][3], pc[3];
+                        matvec3(Rb_, nl, fr[0]);                    // from the box towards the sphere
+                        contact_frame(fr[0], fr[1], fr[2]);
+                        sfor<3>([&](auto K) MI_LAMBDA { pc[K] = cs[K] - rad * fr[0][K]; });
+                        float* cb = rows.ptr(R_CB + cnt * S_CSZ);
+                        const float rB[3] = {pc[0] - xb_[0], pc[1] - xb_[1], pc[2] - xb_[2]};
+                        sfor<3>([&](auto K) MI_LAMBDA {
+                            constexpr int k = K;
+                            float W[6];
+                            cross3(pc, fr[k], W);
+                            W[3] = fr[k][0]; W[4] = fr[k][1]; W[5] = fr[k][2];
+                            float g[HCH];
+                            sfor<CL>([&](auto C) MI_LAMBDA { g[C] = dot6(S[M::chain[b][C] - OFF], W); });
+                            sfor<CL>([&](auto C) MI_LAMBDA {
+                                constexpr int kk0 = C, ii = M::chain[b][kk0];
+                                const float z = g[kk0] * Ldi[ii];
+                                g[kk0] = z;
+                                sfor<CL - 1 - kk0>([&](auto T) MI_LAMBDA {
+                                    constexpr int kk = kk0 + 1 + T, jj = M::chain[b][kk];
+                                    g[kk] -= L[M::midx[ii][jj]] * z;
+                                });
+                            });
+                            float a = P.cfm;
+                            sfor<CL>([&](auto C) MI_LAMBDA { a += g[C] * g[C]; cb[(k * HCH + C) * ST] = g[C]; });
+                            sfor<HCH - CL>([&](auto C) MI_LAMBDA { cb[(k * HCH + CL + C) * ST] = 0.f; });
+                            if (fr_) a += box_diag(ib, rB, fr[k]);
+                            cb[(S_AUX + k) * ST] = MI_RCP(a);
+                            cb[(S_AUX + 4 + k) * ST] = 0.f;
+                        });
+                        sfor<3>([&](auto I_) MI_LAMBDA { cb[(S_GEO + I_) * ST] = fr[0][I_]; cb[(S_GEO + 3 + I_) * ST] = pc[I_]; });
+                        cb[(S_AUX + 3) * ST] = target_velocity(dist);
+                        cb[(S_AUX + 7) * ST] = 0.5f * (SP.arm_mu + (fr_ ? SP.free_mu[ib] : SP.static_mu[ib]));
+                        cb[(S_AUX + 8) * ST] = __builtin_bit_cast(float, (int)-1);
+                        cb[(S_AUX + 9) * ST] = __builtin_bit_cast(float, fr_ ? ib : (int)-1);
+                        cnt += 1;
+                    }
+                }
+                rows(R_BODY + b) = __builtin_bit_cast(float, first | ((cnt - first) << 8));
+            }
+        });
+        const int narm = cnt;
+        MI_PHASE();
+        // ------------------------------------------------------------ box contacts: the corners of every free box vs the ground plane, the
+        // static boxes, the other free boxes (side A: the corner's box, pushed along n; side B: the box it is in / on)
+        int nbox = 0;
+        for (int i = 0; i < nf; ++i) {
+            for (int cr = 0; cr < 8; ++cr) {
+                const float pl[3] = {(cr & 1) ? SP.free_half[i][0] : -SP.free_half[i][0], (cr & 2) ? SP.free_half[i][1] : -SP.free_half[i][1],
+                                     (cr & 4) ? SP.free_half[i][2] : -SP.free_half[i][2]};
+                float pr[3], pc[3];
+                matvec3(Rf[i], pl, pr);
+                sfor<3>([&](auto K) MI_LAMBDA { pc[K] = xf[i][K] + pr[K]; });
+                for (int t = -1; t < ns + nf; ++t) {
+                    if (t >= ns && t - ns == i) continue;
+                    float n[3], dist, mu_b;
+                    int ib = -1;
+                    if (t < 0) {
+                        n[0] = 0.f; n[1] = 0.f; n[2] = 1.f;
+                        dist = (root[2] + pc[2]) - P.ground_z;
+                        mu_b = P.plane_mu;
+                    } else {
+                        const bool st_ = t < ns;
+                        const int j = st_ ? t : t - ns;
+                        const float* Rb_ = st_ ? Rs[j] : Rf[j];
+                        const float* xb_ = st_ ? xst[j] : xf[j];
+                        const float* hb_ = st_ ? SP.static_half[j] : SP.free_half[j];
+                        const float rel[3] = {pc[0] - xb_[0], pc[1] - xb_[1], pc[2] - xb_[2]};
+                        float cl[3], nl[3];
+                        matTvec3(Rb_, rel, cl);
+                        scene_sphere_box(cl, 0.f, hb_, &dist, nl);
+                        matvec3(Rb_, nl, n);
+                        mu_b = st_ ? SP.static_mu[j] : SP.free_mu[j];
+                        ib = st_ ? -1 : j;
+                    }
+                    if (!(dist < P.contact_offset)) continue;
+                    if (nbox >= KBOX) { refused += 1; continue; }
+                    float fr[3][3];
+                    sfor<3>([&](auto K) MI_LAMBDA { fr[0][K] = n[K]; });
+                    contact_frame(fr[0], fr[1], fr[2]);
+                    float* cb = rows.ptr(R_CB + (KARM + nbox) * S_CSZ);
+                    float rB[3] = {0.f, 0.f, 0.f};
+                    if (ib >= 0) sfor<3>([&](auto K) MI_LAMBDA { rB[K] = pc[K] - xf[ib][K]; });
+                    sfor<3>([&](auto K) MI_LAMBDA {
+                        constexpr int k = K;
+                        float a = P.cfm + box_diag(i, pr, fr[k]);
+                        if (ib >= 0) a += box_diag(ib, rB, fr[k]);
+                        cb[(S_AUX + k) * ST] = MI_RCP(a);
+                        cb[(S_AUX + 4 + k) * ST] = 0.f;
+                    });
+                    sfor<3>([&](auto I_) MI_LAMBDA { cb[(S_GEO + I_) * ST] = n[I_]; cb[(S_GEO + 3 + I_) * ST] = pc[I_]; });
+                    cb[(S_AUX + 3) * ST] = target_velocity(dist);
+                    cb[(S_AUX + 7) * ST] = 0.5f * (SP.free_mu[i] + mu_b);
+                    cb[(S_AUX + 8) * ST] = __builtin_bit_cast(float, i);
+                    cb[(S_AUX + 9) * ST] = __builtin_bit_cast(float, ib);
+                    nbox += 1;
+                }
+            }
+        }
+        *ncontact = (narm + nbox) | (refused << 16);
+        MI_PHASE();
+        // ------------------------------------------------------------ projected Gauss-Seidel sweeps: limits, actor contacts, box contacts
+        // one contact: the normal row, the two tangent rows, then the friction disc (the order of core/hand_engine.hpp).  Btag: the actor body
+        // whose chain the rows span, or -1 for a box contact
+        auto solve_contact = [&](auto Btag, float* cb) MI_LAMBDA {
+            constexpr int b = decltype(Btag)::value;
+            constexpr int CL = b >= 0 ? M::chain_len[b >= 0 ? b : 0] : 0;
+            float g[3][HCH > 0 ? HCH : 1], ainv[3], lm[3], fr[3][3], pc[3];
+            sfor<3>([&](auto K) MI_LAMBDA {
+                sfor<CL>([&](auto C) MI_LAMBDA { g[K][C] = cb[(K * HCH + C) * ST]; });
+                ainv[K] = cb[(S_AUX + K) * ST];
+                lm[K] = cb[(S_AUX + 4 + K) * ST];
+            });
+            sfor<3>([&](auto I_) MI_LAMBDA { fr[0][I_] = cb[(S_GEO + I_) * ST]; pc[I_] = cb[(S_GEO + 3 + I_) * ST]; });
+            contact_frame(fr[0], fr[1], fr[2]);
+            const float vtn = cb[(S_AUX + 3) * ST], mu = cb[(S_AUX + 7) * ST];
+            const int ia = __builtin_bit_cast(int, cb[(S_AUX + 8) * ST]), ib = __builtin_bit_cast(int, cb[(S_AUX + 9) * ST]);
+            float rA[3] = {0.f, 0.f, 0.f}, rB[3] = {0.f, 0.f, 0.f};
+            if (ia >= 0) sfor<3>([&](auto K) MI_LAMBDA { rA[K] = pc[K] - xf[ia][K]; });
+            if (ib >= 0) sfor<3>([&](auto K) MI_LAMBDA { rB[K] = pc[K] - xf[ib][K]; });
+            auto rowvel = [&](int k) MI_LAMBDA {
+                float vn = 0.f;
+                if constexpr (b >= 0) sfor<CL>([&](auto C) MI_LAMBDA { vn += g[k][C] * w[M::chain[b >= 0 ? b : 0][C]]; });
+                if (ia >= 0) { float rx[3]; cross3(rA, fr[k], rx); vn += dot3(fr[k], vb[ia]) + dot3(rx, vb[ia] + 3); }
+                if (ib >= 0) { float rx[3]; cross3(rB, fr[k], rx); vn -= dot3(fr[k], vb[ib]) + dot3(rx, vb[ib] + 3); }
+                return vn;
+            };
+            auto apply = [&](int k, float dl) MI_LAMBDA {
+                if constexpr (b >= 0) sfor<CL>([&](auto C) MI_LAMBDA { w[M::chain[b >= 0 ? b : 0][C]] += g[k][C] * dl; });
+                if (ia >= 0) {
+                    float rx[3], t[3];
+                    cross3(rA, fr[k], rx); matvec3(Iinv[ia], rx, t);
+                    sfor<3>([&](auto C) MI_LAMBDA { vb[ia][C] += fr[k][C] * (imass[ia] * dl); vb[ia][3 + C] += t[C] * dl; });
+                }
+                if (ib >= 0) {
+                    float rx[3], t[3];
+                    cross3(rB, fr[k], rx); matvec3(Iinv[ib], rx, t);
+                    sfor<3>([&](auto C) MI_LAMBDA { vb[ib][C] -= fr[k][C] * (imass[ib] * dl); vb[ib][3 + C] -= t[C] * dl; });
+                }
+            };
+            const float ln = fmaxf(lm[0] - (rowvel(0) - vtn) * ainv[0], 0.f);
+            apply(0, ln - lm[0]);
+            float lt[2];
+            sfor<2>([&](auto K) MI_LAMBDA {
+                const float dl = -rowvel(1 + K) * ainv[1 + K];
+                lt[K] = lm[1 + K] + dl;
+                apply(1 + K, dl);
+            });
+            const float lim = mu * ln;
+            const float n2 = lt[0] * lt[0] + lt[1] * lt[1];
+            const float sc = (n2 > lim * lim) ? lim * MI_RSQ(fmaxf(n2, 1e-30f)) : 1.f;
+            cb[(S_AUX + 4) * ST] = ln;
+            sfor<2>([&](auto K) MI_LAMBDA {
+                const float nl_ = lt[K] * sc;
+                cb[(S_AUX + 5 + K) * ST] = nl_;
+                apply(1 + K, nl_ - lt[K]);
+            });
+        };
+        for (int it = 0; it < P.iters; ++it) {
+            int zero;
+            MI_OPAQUE_ZERO(zero);
+            const RowStore<RS> rit = rows.shifted(zero);
+            sfor<ND>([&](auto D) MI_LAMBDA {
+                constexpr int d = D, gi = OFF + d;
+                if constexpr (M::dof_limited[d]) {
+                    constexpr int row = B::limrow(d), g0 = B::limoff(row);
+                    float g[M::MAXCHAIN];
+                    sfor<M::nanc[gi] + 1>([&](auto K) MI_LAMBDA { g[K] = rit(g0 + K); });
+                    float vn = g[0] * w[gi];
+                    sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { vn += g[1 + A_] * w[M::anc[gi][A_]]; });
+                    const float lo = rit(R_LIMG + 2 * NLIM + row);
+                    const float nl_ = fmaxf(lo - (vn - rit(R_LIMG + NLIM + row)) * rit(R_LIMG + row), 0.f);
+                    const float dl = nl_ - lo;
+                    rit(R_LIMG + 2 * NLIM + row) = nl_;
+                    w[gi] += g[0] * dl;
+                    sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { w[M::anc[gi][A_]] += g[1 + A_] * dl; });
+                }
+            });
+            sfor<NB>([&](auto B_) MI_LAMBDA {
+                constexpr int b = B_;
+                if constexpr (sph_count(b) > 0) {
+                    const int fc = __builtin_bit_cast(int, rit(R_BODY + b));
+                    const int first = fc & 255, nb_ = fc >> 8;
+                    for (int i = 0; i < nb_; ++i) solve_contact(std::integral_constant<int, b>{}, rit.ptr(R_CB + (first + i) * S_CSZ));
+                }
+            });
+            for (int i = 0; i < nbox; ++i) solve_contact(std::integral_constant<int, -1>{}, rit.ptr(R_CB + (KARM + i) * S_CSZ));
+        }
+        MI_PHASE();
+        // ------------------------------------------------------------ back to generalised velocity, outputs
+        float v[NVA];
+        sfor<NV>([&](auto I_) MI_LAMBDA {
+            constexpr int i = I_;
+            float s = w[i];
+            sfor<M::nanc[i]>([&](auto A_) MI_LAMBDA { s -= L[M::midx[i][M::anc[i][A_]]] * v[M::anc[i][A_]]; });
+            v[i] = s * Ldi[i];
+        });
+        sfor<ND>([&](auto D) MI_LAMBDA {
+            constexpr int d = D;
+            float ll = 0.f;
+            if constexpr (M::dof_limited[d]) {
+                constexpr int row = B::limrow(d);
+                ll = (G(row, 0) > 0.f) ? lam(row) : -lam(row);          // G(row, 0) = s / L_dd, s = +1 lower, -1 upper
+            }
+            laml(d) = ll;
+            dof_force(d) = tau[d] - M::dof_stiffness[d] * (q[d] - M::dof_springref[d]) - M::dof_damping[d] * v[OFF + d] + ll * invh
+                           + drv.gain_p(d) * (drv.target[d] - q[d]) - drv.gain_d(d) * v[OFF + d];
+        });
+        // ------------------------------------------------------------ integrate the actor and the boxes (semi-implicit Euler)
+        sfor<ND>([&](auto D) MI_LAMBDA { qd[D] = v[OFF + D]; q[D] += h * qd[D]; });
+        for (int i = 0; i < nf; ++i) {
+            float* vv = vb[i];
+            const float w2 = vv[3] * vv[3] + vv[4] * vv[4] + vv[5] * vv[5], l2 = vv[0] * vv[0] + vv[1] * vv[1] + vv[2] * vv[2];
+            const float sw = (w2 > kMaxAngularVelocity * kMaxAngularVelocity) ? kMaxAngularVelocity * MI_RSQ(w2) : 1.f;
+            const float sl = (l2 > kMaxLinearVelocity * kMaxLinearVelocity) ? kMaxLinearVelocity * MI_RSQ(l2) : 1.f;
+            for (int k = 0; k < 3; ++k) { vv[k] *= sl; vv[3 + k] *= sw; box[i][7 + k] = vv[k]; box[i][10 + k] = vv[3 + k]; box[i][k] += h * vv[k]; }
+            const float* om = vv + 3;
+            const float an = MI_SQRT(dot3(om, om)), th = an * h;
+            float sn, cs;
+            sincosf(0.5f * th, &sn, &cs);
+            const bool big = th > 1e-12f;
+            const float k = big ? sn * MI_RCP(fmaxf(an, 1e-30f)) : 0.5f * h;
+            const float dq[4] = {om[0] * k, om[1] * k, om[2] * k, big ? cs : 1.f};
+            float* Q = box[i] + 3;
+            const float x = dq[3] * Q[0] + dq[0] * Q[3] + dq[1] * Q[2] - dq[2] * Q[1];
+            const float yy = dq[3] * Q[1] - dq[0] * Q[2] + dq[1] * Q[3] + dq[2] * Q[0];
+            const float z = dq[3] * Q[2] + dq[0] * Q[1] - dq[1] * Q[0] + dq[2] * Q[3];
+            const float ww = dq[3] * Q[3] - dq[0] * Q[0] - dq[1] * Q[1] - dq[2] * Q[2];
+            const float n = MI_RSQ(x * x + yy * yy + z * z + ww * ww);
+            Q[0] = x * n; Q[1] = yy * n; Q[2] = z * n; Q[3] = ww * n;
+        }
+    }
+};
+
+}  // namespace mi

@@ -18,6 +18,16 @@ int cpu_articulation_reset(MiEngine* e, const int64_t* ids, int n) {
 int cpu_articulation_simulate(MiEngine* e) {
     const View& v = e->v;
     const ArticulationParams& p = *reinterpret_cast<const ArticulationParams*>(e->artic);
+    if (articulation_has_scene(p)) {          // free / static boxes beside the actor (core/scene_engine.hpp)
+        if constexpr (AM::FIXED == 1) {
+#pragma omp parallel for schedule(static) num_threads(e->num_threads)
+            for (int en = 0; en < v.N; ++en)
+                for (int ss = 0; ss < e->P.substeps; ++ss) articulation_scene_substep_env<AM>(v, e->P, p, en);
+            return 0;
+        } else {
+            return -1;
+        }
+    }
 #pragma omp parallel for schedule(static) num_threads(e->num_threads)
     for (int en = 0; en < v.N; ++en) {
         float rows[Sim<AM>::ROW_SLOTS > 0 ? Sim<AM>::ROW_SLOTS : 1];

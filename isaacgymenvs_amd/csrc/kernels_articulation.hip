@@ -31,6 +31,13 @@ __global__ __launch_bounds__(64) void articulation_substep_kernel(View v, SimPar
         articulation_substep_env<AM>(v, P, p, e, RowStore<1>{rows}, false);
     }
 }
+// the same for an env that holds free / static boxes beside a fixed-base actor (core/scene_engine.hpp): one env per lane, the row store in per-lane
+// memory.  A kernel of its own: the scene's code does not touch the register allocation of the kernel above.
+__global__ __launch_bounds__(64) void articulation_scene_substep_kernel(View v, SimParams P, ArticulationParams p) {
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= v.N) return;
+    if constexpr (AM::FIXED == 1) articulation_scene_substep_env<AM>(v, P, p, e);
+}
 __global__ void articulation_reset_kernel(View v, ArticulationParams p, const long long* __restrict__ ids, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (ids ? n : v.N)) return;
@@ -89,6 +96,11 @@ __global__ __launch_bounds__(64) void articulation_mass_matrix_kernel(View v, Si
 }
 
 hipError_t launch_simulate_articulation(const View& v, const SimParams& P, const ArticulationParams& p, hipStream_t s) {
+    if (articulation_has_scene(p)) {
+        if (AM::FIXED != 1) return hipErrorInvalidValue;
+        for (int i = 0; i < P.substeps; ++i) hipLaunchKernelGGL(articulation_scene_substep_kernel, dim3((v.N + 63) / 64), dim3(64), 0, s, v, P, p);
+        return hipGetLastError();
+    }
     constexpr size_t lds = rows_fit_lds<AM>() ? lds_bytes<AM>() : 0;
     constexpr int LANES = Sim<AM>::LANES;
     static unsigned long long configured = 0ull;

@@ -3,6 +3,7 @@
 #pragma once
 #include "../arena.hpp"
 #include "../core/engine.hpp"
+#include "../core/scene_engine.hpp"
 
 namespace mi {
 
@@ -10,7 +11,46 @@ struct ArticulationParams {   // mirrors MiArticulationParams (include/mi_engine
     float kp[kMaxDof], kd[kMaxDof];
     float max_angular_velocity;
     float init_root[13];
+    SceneParams scene;        // free / static boxes beside the actor (MiScene); n_free = n_static = 0: the actor alone on the ground plane
+    float drive_vmax[kMaxDof];   // scenes: velocity limit of each dof's position drive (<= 0: none)
 };
+
+// gym.simulate() of an env that holds more than the actor (core/scene_engine.hpp): one sub-step of env e.  The row store of this form is a
+// per-lane array (scratch on the device): the scene's contact slots are sized for a table top, not for the LDS.
+static inline bool articulation_has_scene(const ArticulationParams& p) { return p.scene.n_free + p.scene.n_static > 0; }
+template <class M>
+MI_HD void articulation_scene_substep_env(const View& v, const SimParams& P, const ArticulationParams& p, const int e) {
+    constexpr int ND = M::ND;
+    const int N = v.N;
+    SceneSim<M> sim;
+    sfor<13>([&](auto K) MI_LAMBDA { sim.root[K] = v.root[K * N + e]; });
+    float tau[M::NDA], target[M::NDA], kp[M::NDA], kd[M::NDA];
+    sfor<ND>([&](auto K) MI_LAMBDA {
+        sim.q[K] = v.dof[K * N + e]; sim.qd[K] = v.dof[(ND + K) * N + e];
+        tau[K] = v.tau[K * N + e]; target[K] = v.targets[K * N + e];
+        kp[K] = p.kp[K]; kd[K] = p.kd[K];
+        // a velocity-limited drive: its position error is clamped to the error at which spring and damper balance at the limit speed
+        // (kp e = kd vmax), so it approaches its target no faster than vmax and pushes with at most kd vmax
+        if (p.drive_vmax[K] > 0.f && kp[K] > 0.f) {
+            const float emax = p.drive_vmax[K] * kd[K] / kp[K];
+            target[K] = sim.q[K] + fminf(fmaxf(target[K] - sim.q[K], -emax), emax);
+        }
+    });
+    const int nf = p.scene.n_free < kSceneMaxFree ? p.scene.n_free : kSceneMaxFree;
+    for (int i = 0; i < nf; ++i)
+        for (int k = 0; k < 13; ++k) sim.box[i][k] = v.scene[(size_t)(13 * i + k) * N + e];
+    Drive drv{0.f, 0.f, target, nullptr};
+    drv.kpv = kp; drv.kdv = kd;
+    const float h = P.dt / (float)P.substeps;
+    float rows[SceneSim<M>::ROW_SLOTS];
+    int nc = 0;
+    sim.substep_scene(P, p.scene, tau, drv, h, RowStore<1>{rows}, Strided{v.laml + e, N}, Strided{v.dof_force + e, N}, &nc);
+    v.scene_nc[e] = nc & 0xFFFF;
+    v.scene_nc[N + e] += nc >> 16;
+    sfor<ND>([&](auto K) MI_LAMBDA { v.dof[K * N + e] = sim.q[K]; v.dof[(ND + K) * N + e] = sim.qd[K]; });
+    for (int i = 0; i < nf; ++i)
+        for (int k = 0; k < 13; ++k) v.scene[(size_t)(13 * i + k) * N + e] = sim.box[i][k];
+}
 
 // gym.simulate(): one sub-step of env e.  Efforts from dof_actuation_force, position drives (per-dof gains) towards dof_position_targets.
 template <class M, int RS>
@@ -55,6 +95,9 @@ MI_HD void articulation_reset_env(const View& v, const ArticulationParams& p, co
     }
     for (int k = 0; k < 3 * M::NSPH; ++k) v.lamc[k * N + e] = 0.f;
     for (int k = 0; k < 3 * M::NB; ++k) v.netf[k * N + e] = 0.f;
+    for (int i = 0; i < kSceneMaxFree; ++i)
+        for (int k = 0; k < 13; ++k) v.scene[(size_t)(13 * i + k) * N + e] = (i < p.scene.n_free && k < 7) ? p.scene.free_init[i][k] : (k == 6 ? 1.f : 0.f);
+    v.scene_nc[e] = 0; v.scene_nc[N + e] = 0;
     v.progress[e] = 0; v.reset[e] = 0;
 }
 

@@ -144,8 +144,22 @@ class MiBallBalanceParams(C.Structure):
                 ("pin_target", (C.c_float * 3) * 3), ("sensor_pos", (C.c_float * 3) * 3)]
 
 
+MI_SCENE_MAX_FREE, MI_SCENE_MAX_STATIC = 4, 4
+
+
+class MiScene(C.Structure):
+    """include/mi_engine.h MiScene: the free / static boxes beside a fixed-base articulated actor (csrc/core/scene_engine.hpp)"""
+    _fields_ = [("n_free", C.c_int32), ("n_static", C.c_int32), ("arm_gravity", C.c_int32), ("pad", C.c_int32),
+                ("free_half", (C.c_float * 3) * MI_SCENE_MAX_FREE), ("free_mass", C.c_float * MI_SCENE_MAX_FREE),
+                ("free_inertia", (C.c_float * 3) * MI_SCENE_MAX_FREE), ("free_mu", C.c_float * MI_SCENE_MAX_FREE),
+                ("free_init", (C.c_float * 7) * MI_SCENE_MAX_FREE),
+                ("static_pos", (C.c_float * 3) * MI_SCENE_MAX_STATIC), ("static_quat", (C.c_float * 4) * MI_SCENE_MAX_STATIC),
+                ("static_half", (C.c_float * 3) * MI_SCENE_MAX_STATIC), ("static_mu", C.c_float * MI_SCENE_MAX_STATIC), ("arm_mu", C.c_float)]
+
+
 class MiArticulationParams(C.Structure):
-    _fields_ = [("kp", C.c_float * MI_MAX_DOF), ("kd", C.c_float * MI_MAX_DOF), ("max_angular_velocity", C.c_float), ("init_root", C.c_float * 13)]
+    _fields_ = [("kp", C.c_float * MI_MAX_DOF), ("kd", C.c_float * MI_MAX_DOF), ("max_angular_velocity", C.c_float), ("init_root", C.c_float * 13),
+                ("scene", MiScene), ("drive_vmax", C.c_float * MI_MAX_DOF)]
 
 
 class MiHandRewardParams(C.Structure):

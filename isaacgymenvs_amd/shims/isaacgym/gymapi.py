@@ -278,12 +278,14 @@ class _Asset:
         a.options, a.sensors, a.shape_friction, a.tendon_props = options, [], None, None
         a.spec, a.object_type, a.dims, a.generic = None, shape, tuple(float(d) for d in dims), False
         a.body_names, a.body_dyn, a.nshapes = [shape], np.zeros(1, np.int64), 1
+        a.path = None
         return a
 
     def __init__(self, path, options):
         from ...registry import load_extras, load_model, load_selfcol, sensor_bodies
         key = os.path.basename(path)
         self.options = options
+        self.path = path
         self.file_spec = None
         self.sensors = []                      # rigid-body indices in the order create_asset_force_sensor was called
         self.shape_friction = None             # set_asset_rigid_shape_properties: friction of the asset's shapes for the actors created next
@@ -406,6 +408,7 @@ class _Sim:
         self.one_shot_force = False
         self.attractors = []                   # create_rigid_body_attractor, env 0
         self.walked = False                    # a per-env property call has reached an env other than the newest: creation is over
+        self.scene = None                      # prepare_sim: slot -> ("free" | "static", index) of the box actors the engine simulates beside a fixed-base actor
         self.props = None                      # _ActorProps: what the per-env property setters wrote (domain randomisation), staged on the host
 
     # the articulated actor (the engine's robot) and the free objects
@@ -847,7 +850,34 @@ class Gym:
         return env.index * max(len(env.sim.slots), len(env.actors)) + actor if domain == DOMAIN_SIM else actor
 
     def find_actor_rigid_body_handle(self, env, actor, name):
-        return env.sim.slots[actor]["asset"].body_names.index(name)
+        # env domain: the bodies of the env's actors in creation order (franka_cube_stack.py:364-371 indexes the [N, bodies, 13] view of the
+        # rigid-body state tensor with it -- the arm's links first, then one body per box actor)
+        sl = env.sim.slots
+        return sum(len(sl[k]["asset"].body_names) for k in range(actor)) + sl[actor]["asset"].body_names.index(name)
+
+    def get_actor_joint_dict(self, env, actor):
+        """joint name -> joint index; gym numbers an actor's joints like its links: joint k is the one link k + 1 hangs on, fixed joints included
+        while collapse_fixed_joints is off (franka_cube_stack.py:390 looks up 'panda_hand_joint' to pick the hand link's rows of the Jacobian)"""
+        a = env.sim.slots[actor]["asset"]
+        out = {}
+        path = getattr(a, "path", None)
+        if path and path.endswith(".urdf") and os.path.isfile(path):
+            import xml.etree.ElementTree as ET
+            for j in ET.parse(path).getroot().findall("joint"):
+                child = j.find("child").get("link")
+                if child in a.body_names:
+                    out[j.get("name")] = a.body_names.index(child) - 1
+        elif a.spec is not None:
+            for d, nm in enumerate(a.spec.dof_names):      # MJCF: the movable joints; a body with several hinges lists each of them
+                out[nm] = max(a.body_names.index(a.spec.body_names[int(a.spec.dof_body[d])]) - 1, 0)
+        return out
+
+    def get_actor_rigid_body_dict(self, env, actor):
+        return {nm: i for i, nm in enumerate(env.sim.slots[actor]["asset"].body_names)}
+
+    def get_actor_dof_dict(self, env, actor):
+        a = env.sim.slots[actor]["asset"]
+        return {nm: i for i, nm in enumerate(a.spec.dof_names)} if a.spec is not None else {}
 
     def find_actor_dof_handle(self, env, actor, name):
         return list(env.sim.slots[actor]["asset"].spec.dof_names).index(name)
@@ -924,7 +954,54 @@ class Gym:
             tp.max_angular_velocity = float(getattr(asset.options, "max_angular_velocity", 0.0) or 0.0)
             for k in range(7):
                 tp.init_root[k] = float(poses[0, k])
-            if getattr(asset.options, "disable_gravity", False):      # franka_cube_stack.py:186: the only articulated actor of the env does not feel gravity
+            for d in range(nd):          # the asset's joint velocity limits bound the position drives (scenes; include/mi_engine.h drive_vmax)
+                vm = float(dp["velocity"][d]) if "velocity" in dp.dtype.names else 0.0
+                tp.drive_vmax[d] = vm if (modes[d] == DOF_MODE_POS and 0.0 < vm < 1e6) else 0.0
+            boxes = [(k, sl) for k, sl in enumerate(sim.slots) if sl["asset"].spec is None]
+            sim.scene = None
+            if boxes and spec.fixed_base:
+                # the other actors of the env (franka_cube_stack.py:212-233,330-339: gym.create_box assets): the engine's scene of free and
+                # static boxes beside the fixed-base actor (include/mi_engine.h MiScene, csrc/core/scene_engine.hpp)
+                sc, sim.scene = tp.scene, {}
+                sc.arm_gravity = 0 if getattr(asset.options, "disable_gravity", False) else 1
+                mu_arm = rslot["friction"].get(0) if rslot["friction"] else None
+                sc.arm_mu = float(mu_arm if mu_arm is not None else (np.mean(spec.sph_friction) if len(spec.sph_friction) else 1.0))
+                for k, sl in boxes:
+                    a = sl["asset"]
+                    if a.object_type != "box":
+                        raise NotImplementedError(f"scene actors are gym.create_box assets (got a {a.object_type})")
+                    ps = np.asarray(sl["poses"], float)
+                    fixed = bool(getattr(a.options, "fix_base_link", False))
+                    if fixed and np.abs(ps - ps[0]).max() > 1e-9:
+                        raise NotImplementedError("a static box of the scene stands at the same env-local pose in every env")
+                    half = [0.5 * d for d in a.dims]
+                    mu = float(sl["friction"].get(0, 1.0)) if sl["friction"] else 1.0
+                    if fixed:
+                        j = sc.n_static
+                        if j >= native.MI_SCENE_MAX_STATIC:
+                            raise NotImplementedError(f"a scene holds at most {native.MI_SCENE_MAX_STATIC} static boxes")
+                        for c in range(3):
+                            sc.static_pos[j][c], sc.static_half[j][c] = float(ps[0, c]), float(half[c])
+                        for c in range(4):
+                            sc.static_quat[j][c] = float(ps[0, 3 + c])
+                        sc.static_mu[j] = mu
+                        sim.scene[k] = ("static", j)
+                        sc.n_static = j + 1
+                    else:
+                        j = sc.n_free
+                        if j >= native.MI_SCENE_MAX_FREE:
+                            raise NotImplementedError(f"a scene holds at most {native.MI_SCENE_MAX_FREE} free boxes")
+                        dens = float(getattr(a.options, "density", 1000.0) or 1000.0)
+                        m = dens * a.dims[0] * a.dims[1] * a.dims[2]
+                        sc.free_mass[j], sc.free_mu[j] = m, mu
+                        for c in range(3):
+                            o1, o2 = a.dims[(c + 1) % 3], a.dims[(c + 2) % 3]
+                            sc.free_half[j][c], sc.free_inertia[j][c] = float(half[c]), m * (o1 * o1 + o2 * o2) / 12.0
+                        for c in range(7):
+                            sc.free_init[j][c] = float(ps[0, c])
+                        sim.scene[k] = ("free", j)
+                        sc.n_free = j + 1
+            elif getattr(asset.options, "disable_gravity", False):      # franka_cube_stack.py:186: the only articulated actor of the env does not feel gravity
                 for i in range(3):
                     p.gravity[i] = 0.0
             lib_path = runtime.variant_library(asset.model_name, sp, sim.device, sensors=sens)
@@ -1051,6 +1128,12 @@ class Gym:
             for e, val in rslot["friction"].items():
                 mu[e] = val
             t["friction"][:] = mu.to(sim.device)
+        if getattr(sim, "scene", None):
+            for k, (kind, j) in sim.scene.items():
+                if kind == "free":
+                    o = torch.zeros((n, 13), dtype=torch.float32)
+                    o[:, :7] = torch.tensor(sim.slots[k]["poses"], dtype=torch.float32)
+                    t["scene_state"][:, j] = o.to(sim.device)
         if self._object_tensor(sim) is not None:
             k_obj = [k for k, sl in enumerate(sim.slots) if sl["asset"].spec is None]
             if k_obj:
@@ -1073,6 +1156,11 @@ class Gym:
             raise NotImplementedError(f"force sensors on bodies {asset.sensors}: the compiled {asset.model_name} model has them on "
                                       f"{asset.engine_sensor_bodies}")
         self._flush_props(sim)                   # what a setup-time randomisation wrote before the engine existed (shadow_hand.py:224-226)
+        # tensors acquired while the envs were being created (franka_cube_stack.py:356 acquires inside create_sim): the same buffers, filled now
+        for name, fn in (("root", self.refresh_actor_root_state_tensor), ("dof", self.refresh_dof_state_tensor), ("rb", self.refresh_rigid_body_state_tensor),
+                         ("jacobian", self.refresh_jacobian_tensors), ("mass_matrix", self.refresh_mass_matrix_tensors)):
+            if name in sim.bufs:
+                fn(sim)
         return True
 
     # ------------------------------------------------------------------ tensor API
@@ -1082,9 +1170,18 @@ class Gym:
         return sim.bufs[name]
 
     def _object_slots(self, sim):
-        """[(slot, lives in the engine)] of the free objects: the first one is the engine's object, the others (goal) live in the shim"""
+        """[(slot, lives in the engine)] of the free objects: the first one is the engine's object, the others (goal) live in the shim.  In a
+        scene (sim.scene: slot -> ("free" | "static", index), prepare_sim) every free box lives in the engine."""
         ks = [k for k, sl in enumerate(sim.slots) if sl["asset"].spec is None]
+        if getattr(sim, "scene", None):
+            return [(k, sim.scene.get(k, ("", 0))[0] == "free") for k in ks]
         return [(k, i == 0 and self._object_tensor(sim) is not None) for i, k in enumerate(ks)]
+
+    def _object_view(self, sim, k):
+        """the engine's [N, 13] root state of the free object in slot k"""
+        if getattr(sim, "scene", None):
+            return sim.engine.tensors["scene_state"][:, sim.scene[k][1]]
+        return sim.engine.tensors[self._object_tensor(sim)]
 
     _OBJECT_TENSOR = {"ShadowHand": "object_state", "AllegroHand": "object_state", "BallBalance": "ball_states", "Ingenuity": "marker_states"}
 
@@ -1129,9 +1226,24 @@ class Gym:
         return sim.bufs["jacobian"]
 
     def refresh_jacobian_tensors(self, sim):
-        if sim.engine is None:
-            raise RuntimeError("gym.acquire_jacobian_tensor: call gym.prepare_sim first")
+        if sim.engine is None:          # acquired while the envs are being created (franka_cube_stack.py:356,388): filled by prepare_sim
+            a = sim.asset
+            nl, nv = len(a.body_names) - (1 if a.spec.fixed_base else 0), a.spec.nv
+            self._buf(sim, "jacobian", (len(sim.envs), nl, 6, nv))
+            return True
         full = sim.engine.compute_jacobians()
+        a = sim.asset
+        if len(a.body_names) != a.spec.nb or not np.array_equal(np.asarray(a.body_dyn), np.arange(a.spec.nb)):
+            # collapse_fixed_joints off: gym lists every link of the file; a welded link moves with its engine body, its origin at a fixed offset
+            # r from that body's: v_link = v + w x r  =>  the linear rows pick up  (angular rows) x r
+            dyn = torch.as_tensor(np.asarray(a.body_dyn), device=sim.device)
+            sim.engine.refresh_rigid_body_states()
+            q = sim.engine.tensors["rigid_body_state"][:, dyn, 3:7]
+            off_p = torch.tensor(a.body_off_p, dtype=torch.float32, device=sim.device)
+            r = _quat_rotate(q, off_p.expand(q.shape[0], len(dyn), 3))                 # [n, links, 3]
+            full = full[:, dyn].clone()                                                   # [n, links, 6, nv]
+            ang = full[:, :, 3:6].transpose(-1, -2)                                       # [n, links, nv, 3]
+            full[:, :, 0:3] += torch.cross(ang, r.unsqueeze(-2).expand_as(ang), dim=-1).transpose(-1, -2)
         view = full[:, 1:] if sim.asset.spec.fixed_base else full
         buf = sim.bufs.get("jacobian")
         if buf is None:
@@ -1146,7 +1258,8 @@ class Gym:
 
     def refresh_mass_matrix_tensors(self, sim):
         if sim.engine is None:
-            raise RuntimeError("gym.acquire_mass_matrix_tensor: call gym.prepare_sim first")
+            self._buf(sim, "mass_matrix", (len(sim.envs), sim.asset.spec.nv, sim.asset.spec.nv))
+            return True
         buf = sim.bufs.get("mass_matrix")
         if buf is None:
             sim.bufs["mass_matrix"] = sim.engine.compute_mass_matrices()
@@ -1157,15 +1270,19 @@ class Gym:
     def refresh_actor_root_state_tensor(self, sim):
         n, A = len(sim.envs), sim.nactors
         v = self._buf(sim, "root", (n * A, 13)).view(n, A, 13)
+        if sim.engine is None:
+            return True
         v[:, sim.robot].copy_(sim.engine.tensors["root_states"])
         for k, phys in self._object_slots(sim):
             if phys:
-                v[:, k].copy_(sim.engine.tensors[self._object_tensor(sim)])
+                v[:, k].copy_(self._object_view(sim, k))
         return True
 
     def refresh_dof_state_tensor(self, sim):
         n, nd = len(sim.envs), sim.asset.spec.nd
-        self._buf(sim, "dof", (n * nd, 2)).view(n, nd, 2).copy_(sim.engine.tensors["dof_state"])
+        buf = self._buf(sim, "dof", (n * nd, 2))
+        if sim.engine is not None:
+            buf.view(n, nd, 2).copy_(sim.engine.tensors["dof_state"])
         return True
 
     def refresh_force_sensor_tensor(self, sim):
@@ -1196,10 +1313,11 @@ class Gym:
     def refresh_rigid_body_state_tensor(self, sim):
         """[N * (bodies of the articulation + one per free object), 13] (shadow_hand.py:150-175): the engine's rigid_body_state tensor, the
         file's welded links riding on their engine body at their fixed offset, then the objects' root states"""
-        if sim.engine is None:
-            return True
         a = sim.asset
         n, nb = len(sim.envs), len(a.body_names)
+        if sim.engine is None:      # acquired before prepare_sim: one row per body of the arm and per other actor; filled by prepare_sim
+            self._buf(sim, "rb", (n * (nb + len([1 for sl in sim.slots if sl["asset"].spec is None])), 13))
+            return True
         objs = self._object_slots(sim)
         buf = self._buf(sim, "rb", (n * (nb + len(objs)), 13)).view(n, nb + len(objs), 13)
         sim.engine.refresh_rigid_body_states()
@@ -1218,7 +1336,7 @@ class Gym:
         root = sim.bufs.get("root")
         for i, (k, phys) in enumerate(objs):
             if phys:
-                buf[:, nb + i].copy_(sim.engine.tensors[self._object_tensor(sim)])
+                buf[:, nb + i].copy_(self._object_view(sim, k))
             elif root is not None:
                 buf[:, nb + i].copy_(root.view(n, sim.nactors, 13)[:, k])
         return True
@@ -1321,7 +1439,7 @@ class Gym:
         for k, phys in self._object_slots(sim):
             ids = self._envs_of(sim, actor_indices, count, k)
             if phys and len(ids):
-                sim.engine.tensors[self._object_tensor(sim)][ids] = src[ids, k]
+                self._object_view(sim, k)[ids] = src[ids, k]
             # (the goal object: the task's own tensor IS the state)
         if root_states.data_ptr() != self._buf(sim, "root", (n * A, 13)).data_ptr():
             self._buf(sim, "root", (n * A, 13)).view(n, A, 13)[:] = src
@@ -1334,7 +1452,7 @@ class Gym:
             sim.engine.tensors["root_states"].copy_(src[:, sim.robot])
         for k, phys in self._object_slots(sim):
             if phys:
-                sim.engine.tensors[self._object_tensor(sim)].copy_(src[:, k])
+                self._object_view(sim, k).copy_(src[:, k])
         return True
 
     # ------------------------------------------------------------------ stepping

@@ -282,7 +282,7 @@ def _franka(device):
     rb = gym.acquire_rigid_body_state_tensor(sim).view(n, len(names), 13)
     jac = gym.acquire_jacobian_tensor(sim, "franka")
     mm = gym.acquire_mass_matrix_tensor(sim, "franka")
-    assert tuple(jac.shape) == (n, spec.nb - 1, 6, 9) and tuple(mm.shape) == (n, 9, 9)
+    assert tuple(jac.shape) == (n, len(names) - 1, 6, 9) and tuple(mm.shape) == (n, 9, 9)     # one Jacobian per LINK gym lists (collapse_fixed_joints off), base link left out
     q0 = torch.tensor([0.0, 0.1963, 0.0, -2.618, 0.0, 2.9416, 0.7854, 0.035, 0.035], device=sim.device)      # the task's default pose (:75-77)
     ds = torch.zeros((n, 9, 2), device=sim.device)
     ds[..., 0] = q0
@@ -322,7 +322,7 @@ def _franka(device):
         gym.refresh_dof_state_tensor(sim); gym.refresh_rigid_body_state_tensor(sim)
         gym.refresh_jacobian_tensors(sim); gym.refresh_mass_matrix_tensors(sim)
         q, qd = dof[:, :7, 0], dof[:, :7, 1]
-        J = jac[:, e7 - 1, :, :7]                                   # [n, 6, 7]: the fixed base link has no row
+        J = jac[:, l7 - 1, :, :7]                                   # [n, 6, 7]: the fixed base link has no row
         Mq = mm[:, :7, :7]
         x, xd = rb[:, l7, 0:3], rb[:, l7, 7:13]
         np.testing.assert_allclose((J @ qd.unsqueeze(-1)).squeeze(-1).cpu().numpy(), xd.cpu().numpy(), atol=2e-3)     # J qd IS the link's twist

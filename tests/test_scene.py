@@ -1,0 +1,409 @@
+"""Multi-actor envs: a fixed-base articulated actor in a SCENE of free and static boxes (csrc/core/scene_engine.hpp; include/mi_engine.h MiScene).
+
+What the reference does with them: franka_cube_stack.py:204-233,323-339 creates, in every env, the Franka arm, a table and its stand
+(gym.create_box with fix_base_link) and two free cubes; it reads the cubes' rows of the actor root state tensor (:377-386,399-400) and teleports
+them at reset through set_actor_root_state_tensor_indexed (:509-511).  Here: the same scene built through the `isaacgym` stand-in, stepped by the
+product (CPU backend / HIP) and by oracle/scene.py from identical states; first-principles known answers (cubes at rest on the table and on each
+other, the weight carried by the contact rows, a cube pushed by the arm's fingers).  Physics parity against PhysX itself is unpinned (closed)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("MI_REFERENCE_ROOT") or next((p for p in ("/root/reference", os.path.join(_HERE, "..", "ab", "ref_stage"))
+                                                    if os.path.isdir(os.path.join(p, "assets", "urdf", "franka_description"))), "/root/reference")
+FRANKA = os.path.join(REF, "assets", "urdf", "franka_description", "robots", "franka_panda_gripper.urdf")
+pytestmark = pytest.mark.skipif(not os.path.isfile(FRANKA), reason="the reference's franka_description is not reachable")
+
+TABLE_Z, TABLE_T, STAND_H = 1.0, 0.05, 0.1           # franka_cube_stack.py:207-223
+TOP = TABLE_Z + TABLE_T / 2
+SIZE_A, SIZE_B = 0.050, 0.070                        # :225-226
+Q0 = [0.0, 0.1963, 0.0, -2.618, 0.0, 2.9416, 0.7854, 0.035, 0.035]       # the task's default arm pose (:75-77)
+
+
+def _build(device, n=8):
+    """the env of franka_cube_stack.py:180-345, actor by actor"""
+    import isaacgymenvs_amd.shims as shims
+    from isaacgymenvs_amd import native
+    if device == "cpu":
+        native.build_cpu()
+    shims.install(force=True)
+    from isaacgym import gymapi
+    gym = gymapi.acquire_gym()
+    sp = gymapi.SimParams()
+    sp.up_axis, sp.gravity, sp.dt, sp.substeps, sp.use_gpu_pipeline = gymapi.UP_AXIS_Z, gymapi.Vec3(0, 0, -9.81), 1 / 60.0, 2, device != "cpu"
+    sp.physx.num_position_iterations, sp.physx.num_velocity_iterations = 8, 1
+    sp.physx.contact_offset, sp.physx.rest_offset = 0.005, 0.0
+    sim = gym.create_sim(0, -1, gymapi.SIM_PHYSX, sp)
+    gym.add_ground(sim, gymapi.PlaneParams())
+    opts = gymapi.AssetOptions()
+    opts.flip_visual_attachments, opts.fix_base_link, opts.collapse_fixed_joints, opts.disable_gravity = True, True, False, True
+    opts.thickness, opts.default_dof_drive_mode, opts.use_mesh_materials = 0.001, gymapi.DOF_MODE_EFFORT, True
+    franka = gym.load_asset(sim, os.path.join(REF, "assets"), "urdf/franka_description/robots/franka_panda_gripper.urdf", opts)
+    fixed = gymapi.AssetOptions(); fixed.fix_base_link = True
+    table = gym.create_box(sim, 1.2, 1.2, TABLE_T, fixed)
+    stand = gym.create_box(sim, 0.2, 0.2, STAND_H, fixed)
+    cube_a = gym.create_box(sim, SIZE_A, SIZE_A, SIZE_A, gymapi.AssetOptions())
+    cube_b = gym.create_box(sim, SIZE_B, SIZE_B, SIZE_B, gymapi.AssetOptions())
+    dp = gym.get_asset_dof_properties(franka)
+    dp["driveMode"][:7], dp["stiffness"][:7], dp["damping"][:7] = gymapi.DOF_MODE_EFFORT, 0.0, 0.0
+    dp["driveMode"][7:], dp["stiffness"][7:], dp["damping"][7:] = gymapi.DOF_MODE_POS, 5000.0, 100.0
+    T = gymapi.Transform
+    for i in range(n):
+        env = gym.create_env(sim, gymapi.Vec3(), gymapi.Vec3(), 4)
+        h = gym.create_actor(env, franka, T(gymapi.Vec3(-0.45, 0.0, TOP + STAND_H)), "franka", i, 0, 0)
+        gym.set_actor_dof_properties(env, h, dp)
+        gym.create_actor(env, table, T(gymapi.Vec3(0.0, 0.0, TABLE_Z)), "table", i, 1, 0)
+        gym.create_actor(env, stand, T(gymapi.Vec3(-0.5, 0.0, TOP + STAND_H / 2)), "table_stand", i, 1, 0)
+        ia = gym.create_actor(env, cube_a, T(gymapi.Vec3(-1.0, 0.0, 0.0)), "cubeA", i, 2, 0)
+        ib = gym.create_actor(env, cube_b, T(gymapi.Vec3(1.0, 0.0, 0.0)), "cubeB", i, 4, 0)
+    gym.prepare_sim(sim)
+    assert sim.scene == {1: ("static", 0), 2: ("static", 1), 3: ("free", 0), 4: ("free", 1)} and (ia, ib) == (3, 4)
+    assert gym.find_actor_rigid_body_handle(sim.envs[0], ia, "box") == len(franka.body_names) + 2       # env domain: arm links, table, stand, cube A
+    return gym, sim, franka, dp
+
+
+def _oracle(sim, franka, n):
+    from oracle.scene import OracleSceneEngine
+    es, tp, P = franka.engine_spec, sim.engine._tp, sim.engine._sim
+    prm = dict(dt=P.dt, substeps=P.substeps, iters=P.iters, gravity=tuple(P.gravity), contact_offset=P.contact_offset, rest_offset=P.rest_offset,
+               max_depen_vel=P.max_depen_vel, erp=P.erp, plane_mu=P.plane_mu, ground_z=P.ground_z, cfm=P.cfm, warm=P.warm)
+    sc = tp.scene
+    scene = dict(arm_gravity=bool(sc.arm_gravity), arm_mu=float(sc.arm_mu),
+                 free=[dict(half=list(sc.free_half[i]), mass=float(sc.free_mass[i]), inertia=list(sc.free_inertia[i]), mu=float(sc.free_mu[i]),
+                            pose=list(sc.free_init[i])) for i in range(sc.n_free)],
+                 static=[dict(pos=list(sc.static_pos[i]), quat=list(sc.static_quat[i]), half=list(sc.static_half[i]), mu=float(sc.static_mu[i]))
+                         for i in range(sc.n_static)])
+    orc = OracleSceneEngine(es, n, prm, scene, kp=[tp.kp[d] for d in range(es.nd)], kd=[tp.kd[d] for d in range(es.nd)],
+                            drive_vmax=[tp.drive_vmax[d] for d in range(es.nd)])
+    orc.root[:] = sim.engine.tensors["root_states"].cpu().numpy()
+    return orc
+
+
+def _place(gym, sim, n, cube_a, cube_b):
+    """teleport the cubes the way the task does (franka_cube_stack.py:505-511): write their rows of the root tensor, commit them by index"""
+    root = gym.acquire_actor_root_state_tensor(sim).view(n, 5, 13)
+    root[:, 3] = torch.as_tensor(cube_a, dtype=torch.float32, device=sim.device)
+    root[:, 4] = torch.as_tensor(cube_b, dtype=torch.float32, device=sim.device)
+    ids = (torch.arange(n, device=sim.device, dtype=torch.int32).view(n, 1) * 5 + torch.tensor([3, 4], device=sim.device, dtype=torch.int32)).flatten()
+    gym.set_actor_root_state_tensor_indexed(sim, root.view(-1, 13), ids, len(ids))
+    return root
+
+
+def _arm_home(gym, sim, n):
+    q0 = torch.tensor(Q0, device=sim.device)
+    ds = torch.zeros((n, 9, 2), device=sim.device)
+    ds[..., 0] = q0
+    gym.set_dof_state_tensor(sim, ds.view(-1, 2))
+    gym.set_dof_position_target_tensor(sim, q0.repeat(n, 1).view(-1))
+    gym.set_dof_actuation_force_tensor(sim, torch.zeros(n * 9, device=sim.device))
+
+
+def _states(rng, n):
+    """cube A and cube B somewhere on (or a little above / tilted over) the table, one env with A stacked on B, one with A dropped from 10 cm"""
+    a, b = np.zeros((n, 13)), np.zeros((n, 13))
+    a[:, 6] = b[:, 6] = 1.0
+    a[:, 0:2] = rng.uniform(-0.2, 0.2, (n, 2)); b[:, 0:2] = a[:, 0:2] + rng.uniform(0.12, 0.2, (n, 2)) * rng.choice([-1, 1], (n, 2))
+    a[:, 2], b[:, 2] = TOP + SIZE_A / 2, TOP + SIZE_B / 2
+    for s in (a, b):                                       # a yaw for every cube
+        yaw = rng.uniform(-np.pi, np.pi, n)
+        s[:, 5], s[:, 6] = np.sin(yaw / 2), np.cos(yaw / 2)
+    a[0, 0:2] = b[0, 0:2] + [0.004, -0.003]; a[0, 2] = TOP + SIZE_B + SIZE_A / 2           # env 0: A on top of B
+    a[1, 2] += 0.10                                                                            # env 1: A falls 10 cm
+    ax = np.array([1.0, 0.3, 0.0]); ax /= np.linalg.norm(ax)                                   # env 2: B tilted 0.3 rad, lifted clear of the table, comes down on an edge
+    b[2, 3:6], b[2, 6] = ax * np.sin(0.15), np.cos(0.15); b[2, 2] += 0.02
+    a[3, 7:10] = [0.4, -0.2, 0.0]                                                              # env 3: A slides (friction stops it)
+    return a, b
+
+
+def _parity(device):
+    n = 8
+    gym, sim, franka, dp = _build(device, n)
+    a, b = _states(np.random.default_rng(0), n)
+    _arm_home(gym, sim, n)
+    root = _place(gym, sim, n, a, b)
+    orc = _oracle(sim, franka, n)
+    orc.q[:] = np.array(Q0); orc.targets[:] = np.array(Q0)
+    orc.box[:, 0], orc.box[:, 1] = a, b
+    sc = sim.engine.tensors["scene_state"]
+    np.testing.assert_allclose(sc[:, :2].cpu().numpy(), orc.box, atol=1e-6)
+    dof = gym.acquire_dof_state_tensor(sim).view(n, 9, 2)
+    worst, touched = 0.0, 0
+    for step in range(30):
+        gym.simulate(sim)
+        orc.step(np.zeros((n, 9)))
+        gym.refresh_actor_root_state_tensor(sim); gym.refresh_dof_state_tensor(sim)
+        got = root[:, 3:5].cpu().numpy()
+        d = np.abs(got - orc.box)
+        d[..., 3:7] = np.minimum(d[..., 3:7], np.abs(got[..., 3:7] + orc.box[..., 3:7]))
+        # positions / quaternions to 0.3 mm / 1e-3, velocities to 2 cm/s (contact onsets in fp32 against fp64 sit one sub-step apart at worst)
+        assert d[..., :7].max() < 1e-3 and d[..., 7:].max() < 5e-2, (step, d[..., :7].max(), d[..., 7:].max())
+        worst = max(worst, d[..., :7].max())
+        nc = sim.engine.tensors["scene_contacts"].cpu().numpy()
+        assert (nc[:, 0] == orc.ncontacts).all(), (step, nc[:, 0], orc.ncontacts)
+        touched += int(nc[:, 0].sum())
+        np.testing.assert_allclose(dof[..., 0].cpu().numpy(), orc.q, atol=5e-4)
+    assert touched > 30 * n * 4 and int(sim.engine.tensors["scene_contacts"][:, 1].sum()) == 0        # every cube rests on >= 4 corners, nothing was refused
+    # ---- known answers on the settled scene (0.5 s on): nothing sank into the table, the stack stands, the dropped cube lies on the table,
+    # the sliding cube has stopped, the tilted cube lies flat
+    for _ in range(60):
+        gym.simulate(sim)
+        orc.step(np.zeros((n, 9)))
+    gym.refresh_actor_root_state_tensor(sim)
+    A, Bc = root[:, 3].cpu().numpy(), root[:, 4].cpu().numpy()
+    assert np.abs(Bc[:, 2] - (TOP + SIZE_B / 2)).max() < 1.5e-3 and np.abs(A[1:, 2] - (TOP + SIZE_A / 2)).max() < 1.5e-3
+    assert abs(A[0, 2] - (TOP + SIZE_B + SIZE_A / 2)) < 2e-3 and np.abs(A[0, 0:2] - Bc[0, 0:2]).max() < 8e-3         # the stack
+    assert np.abs(A[:, 7:]).max() < 0.05 and np.abs(Bc[:, 7:]).max() < 0.05
+    zc = 1.0 - 2.0 * (Bc[:, 3] ** 2 + Bc[:, 4] ** 2)               # z component of cube B's z axis: the tilted one lies flat again
+    assert np.abs(zc - 1.0).max() < 2e-3
+    # the weight of every cube is carried by its contact rows (oracle side: sum of the normal forces on side A of the box contacts)
+    m = [float(sim.engine._tp.scene.free_mass[i]) for i in range(2)]
+    for e in range(n):
+        fz = [0.0, 0.0]
+        for ia, ib, f in orc.contact_forces[e]:
+            if ia >= 0:
+                fz[ia] += f[2]
+            if ib >= 0:
+                fz[ib] -= f[2]
+        for i in range(2):
+            assert abs(fz[i] - m[i] * 9.81) < 0.03 * m[i] * 9.81 + 1e-3, (e, i, fz[i], m[i] * 9.81)
+    assert abs(m[0] - 1000.0 * SIZE_A ** 3) < 1e-6
+    # and the product agrees with the oracle on that settled state
+    d = np.abs(root[:, 3:5].cpu().numpy()[..., :3] - orc.box[..., :3])
+    assert d.max() < 3e-3, d.max()
+
+
+def test_scene_cubes_on_the_table_follow_the_oracle_cpu():
+    _parity("cpu")
+
+
+@pytest.mark.gpu
+def test_scene_cubes_on_the_table_follow_the_oracle_hip():
+    _parity("cuda:0")
+
+
+def _ori_err(qd_, q_):
+    """rotation vector that takes orientation q_ to qd_ (xyzw): 2 vec(qd * conj(q)), the shorter way round"""
+    x1, y1, z1, w1 = qd_.unbind(-1)
+    x2, y2, z2, w2 = -q_[:, 0], -q_[:, 1], -q_[:, 2], q_[:, 3]
+    w = w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2
+    v = torch.stack([w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], -1)
+    return 2.0 * v * torch.sign(w).unsqueeze(-1)
+
+
+class _Osc:
+    """operational-space control of the hand link on the engine's Jacobian and mass matrix -- the task's control law (franka_cube_stack.py:601-627)
+    restated, with an orientation term that holds the gripper pointing down"""
+
+    def __init__(self, gym, sim, franka, n):
+        self.gym, self.sim, self.n = gym, sim, n
+        names = franka.body_names
+        self.hb, self.site, self.tip = names.index("panda_hand"), names.index("panda_grip_site"), names.index("panda_leftfinger_tip")
+        self.rb = gym.acquire_rigid_body_state_tensor(sim).view(n, -1, 13)
+        self.dof = gym.acquire_dof_state_tensor(sim).view(n, 9, 2)
+        self.jac = gym.acquire_jacobian_tensor(sim, "franka")
+        self.mm = gym.acquire_mass_matrix_tensor(sim, "franka")
+        self.hand = gym.get_actor_joint_dict(sim.envs[0], 0)["panda_hand_joint"]
+        assert self.hand == self.hb - 1 and tuple(self.jac.shape) == (n, len(names) - 1, 6, 9)
+        gym.refresh_rigid_body_state_tensor(sim)
+        self.q_init = self.rb[:, self.hb, 3:7].clone()
+        self.q0 = torch.tensor(Q0, device=sim.device)
+
+    def step(self, goal, fingers):
+        gym, sim, n, rb, dof = self.gym, self.sim, self.n, self.rb, self.dof
+        gym.refresh_jacobian_tensors(sim); gym.refresh_mass_matrix_tensors(sim); gym.refresh_rigid_body_state_tensor(sim); gym.refresh_dof_state_tensor(sim)
+        J, Mq = self.jac[:, self.hand, :, :7], self.mm[:, :7, :7]
+        kp, kd = 150.0, 2.0 * 150.0 ** 0.5
+        dpose = torch.cat([torch.as_tensor(goal, dtype=torch.float32, device=sim.device) - rb[:, self.hb, 0:3], _ori_err(self.q_init, rb[:, self.hb, 3:7])], dim=1)
+        dpose = torch.clamp(dpose, -0.1, 0.1)
+        Minv = torch.inverse(Mq)
+        Lam = torch.inverse(J @ Minv @ J.transpose(1, 2))
+        u = J.transpose(1, 2) @ Lam @ (kp * dpose - kd * rb[:, self.hb, 7:13]).unsqueeze(-1)
+        u_null = Mq @ (2.0 * 10.0 ** 0.5 * -dof[:, :7, 1] + 10.0 * (self.q0[:7] - dof[:, :7, 0])).unsqueeze(-1)
+        u = u + (torch.eye(7, device=sim.device) - J.transpose(1, 2) @ (Lam @ J @ Minv)) @ u_null
+        tau = torch.zeros((n, 9), device=sim.device)
+        tau[:, :7] = torch.clamp(u.squeeze(-1), -80.0, 80.0)
+        tg = self.q0.repeat(n, 1).clone()
+        tg[:, 7:] = fingers
+        gym.set_dof_actuation_force_tensor(sim, tau.view(-1)); gym.set_dof_position_target_tensor(sim, tg.view(-1))
+        gym.simulate(sim)
+
+
+def _push(device):
+    """the closed gripper is lowered beside cube A and swept through it: the cube is pushed along the table (actor sphere vs free box rows) and stays
+    on it; then the gripper is pressed down onto the table top and stops there (actor sphere vs static box rows)"""
+    n = 4
+    gym, sim, franka, dp = _build(device, n)
+    _arm_home(gym, sim, n)
+    a, b = np.zeros((n, 13)), np.zeros((n, 13))
+    a[:, 6] = b[:, 6] = 1.0
+    b[:, 0:3] = [0.3, 0.3, TOP + SIZE_B / 2]
+    a[:, 0:3] = [0.078, 0.0, TOP + SIZE_A / 2]
+    root = _place(gym, sim, n, a, b)
+    osc = _Osc(gym, sim, franka, n)
+    for step in range(300):
+        osc.step([-0.005 + 0.15 * min(max(step - 100, 0), 150) / 150.0, 0.0, TOP + 0.125], 0.0)      # finger tips 2 cm above the table
+    gym.refresh_actor_root_state_tensor(sim)
+    A = root[:, 3].cpu().numpy()
+    assert np.isfinite(A).all() and np.abs(A[:, 2] - (TOP + SIZE_A / 2)).max() < 4e-3        # still lying on the table
+    assert (A[:, 0] > 0.078 + 0.08).all() and np.abs(A[:, 1]).max() < 0.03, A[:, :3]           # pushed 10 cm along +x by the finger tips
+    tip_x = float(osc.rb[0, osc.tip, 0])
+    assert abs(float(A[0, 0]) - tip_x - 0.033) < 0.01                                          # and it sits against them: half a cube + half a finger ahead
+    assert int(sim.engine.tensors["scene_contacts"][:, 0].max()) > 8 + 4
+    for step in range(120):                                                                    # press down: the table holds the gripper
+        osc.step([0.14, 0.0, TOP + 0.05], 0.0)
+    gym.refresh_rigid_body_state_tensor(sim)
+    assert float(osc.rb[:, osc.tip, 2].min()) > TOP - 4e-3 and float(osc.rb[:, osc.tip, 2].max()) < TOP + 0.02
+    assert torch.isfinite(osc.dof).all()
+
+
+def test_scene_arm_pushes_a_cube_cpu():
+    _push("cpu")
+
+
+@pytest.mark.gpu
+def test_scene_arm_pushes_a_cube_hip():
+    _push("cuda:0")
+
+
+def _grasp(device):
+    """what the task is about (franka_cube_stack.py:697-752: lift cube A, carry it over cube B, put it down): open gripper over cube A, down, close
+    (the finger drives are velocity limited, URDF :247), lift -- the cube comes up between the fingers, held by friction alone; carried over cube B
+    and released, it stays on top of it"""
+    n = 4
+    gym, sim, franka, dp = _build(device, n)
+    assert abs(sim.engine._tp.drive_vmax[7] - 0.2) < 1e-6 and sim.engine._tp.drive_vmax[0] == 0.0
+    _arm_home(gym, sim, n)
+    a, b = np.zeros((n, 13)), np.zeros((n, 13))
+    a[:, 6] = b[:, 6] = 1.0
+    a[:, 0:3] = [0.058, 0.0, TOP + SIZE_A / 2]
+    b[:, 0:3] = [0.058, 0.16, TOP + SIZE_B / 2]
+    root = _place(gym, sim, n, a, b)
+    osc = _Osc(gym, sim, franka, n)
+    hx = 0.058 - 0.013                                                 # hand origin over the cube: the grip site sits 13 mm ahead of it at this pose
+    for step in range(100):
+        osc.step([hx, 0.0, TOP + 0.127], 0.04)                         # grip site at the cube's centre, fingers open
+    for step in range(60):
+        osc.step([hx, 0.0, TOP + 0.127], 0.0)                          # close
+    gym.refresh_dof_state_tensor(sim)
+    assert float(osc.dof[:, 7:, 0].min()) > 0.020 and float(osc.dof[:, 7:, 0].max()) < 0.030      # the fingers stopped on the 5 cm cube
+    for step in range(100):
+        osc.step([hx, 0.0, TOP + 0.127 + 0.15 * min(step, 80) / 80.0], 0.0)     # lift 15 cm
+    gym.refresh_actor_root_state_tensor(sim); gym.refresh_rigid_body_state_tensor(sim)
+    A = root[:, 3].cpu().numpy()
+    assert (A[:, 2] > TOP + SIZE_A / 2 + 0.13).all(), A[:, 2]                              # the cube came along
+    assert np.abs(A[:, 2] - osc.rb[:, osc.site, 2].cpu().numpy()).max() < 0.01            # ... between the finger tips
+    for step in range(150):
+        osc.step([hx, 0.16 * min(step, 100) / 100.0, TOP + 0.277], 0.0)                   # carry it over cube B
+    for step in range(80):
+        osc.step([hx, 0.16, TOP + 0.277 - 0.078 * min(step, 60) / 60.0], 0.0)             # down until it stands on B
+    for step in range(80):
+        osc.step([hx, 0.16, TOP + 0.199], 0.04)                                            # let go
+    for step in range(60):
+        osc.step([hx, 0.16, TOP + 0.30], 0.04)                                             # and retreat
+    gym.refresh_actor_root_state_tensor(sim)
+    A, Bc = root[:, 3].cpu().numpy(), root[:, 4].cpu().numpy()
+    assert np.abs(A[:, 2] - (TOP + SIZE_B + SIZE_A / 2)).max() < 4e-3, A[:, 2]             # stacked
+    assert np.abs(A[:, 0:2] - Bc[:, 0:2]).max() < 0.02 and np.abs(A[:, 7:]).max() < 0.05   # ... over B, at rest
+
+
+def test_scene_arm_grasps_lifts_and_stacks_a_cube_cpu():
+    _grasp("cpu")
+
+
+@pytest.mark.gpu
+def test_scene_arm_grasps_lifts_and_stacks_a_cube_hip():
+    _grasp("cuda:0")
+
+
+# ------------------------------------------------------------------------------------------------ the reference's own task file, unmodified
+@pytest.fixture()
+def franka_task():
+    """isaacgymenvs/tasks/franka_cube_stack.py imported as it is, with the stand-ins registered as `isaacgym` / `gym` (the way
+    tests/test_gymapi_shim.py imports the other task files)"""
+    import importlib
+    import sys
+    import types
+    import isaacgymenvs_amd.shims as shims
+    saved = {k: v for k, v in sys.modules.items() if k.split(".")[0] in ("isaacgymenvs", "isaacgym", "gym")}
+    for k in saved:
+        del sys.modules[k]
+    shims.install(force=True)
+    for name, rel in (("isaacgymenvs", "isaacgymenvs"), ("isaacgymenvs.tasks", "isaacgymenvs/tasks"),
+                      ("isaacgymenvs.utils", "isaacgymenvs/utils"), ("isaacgymenvs.tasks.base", "isaacgymenvs/tasks/base")):
+        mod = types.ModuleType(name)
+        mod.__path__ = [os.path.join(REF, rel)]
+        sys.modules[name] = mod
+    mod = importlib.import_module("isaacgymenvs.tasks.franka_cube_stack")
+    vt = importlib.import_module("isaacgymenvs.tasks.base.vec_task")
+    yield mod, vt
+    for k in [k for k in sys.modules if k.split(".")[0] in ("isaacgymenvs", "isaacgym", "gym")]:
+        del sys.modules[k]
+    sys.modules.update(saved)
+
+
+def _reference_task(franka_task, device):
+    from isaacgymenvs_amd import native
+    from isaacgymenvs_amd.utils.config import compose, omegaconf_to_dict
+    from oracle import jit_twins as J
+    if device == "cpu":
+        native.build_cpu()
+    mod, vt = franka_task
+    assert os.path.samefile(mod.__file__, os.path.join(REF, "isaacgymenvs", "tasks", "franka_cube_stack.py"))
+    vt.EXISTING_SIM = None
+    n = 16
+    cfg = omegaconf_to_dict(compose("config", overrides=["task=FrankaCubeStack"], cfg_dir=os.path.join(REF, "isaacgymenvs", "cfg"))["task"])
+    cfg["env"]["numEnvs"] = n
+    cfg["sim"]["use_gpu_pipeline"] = device != "cpu"
+    torch.manual_seed(3)
+    env = mod.FrankaCubeStack(cfg, rl_device=device, sim_device=device, graphics_device_id=-1, headless=True, virtual_screen_capture=False,
+                              force_render=False)
+    sim = env.sim
+    assert sim.scene == {1: ("static", 0), 2: ("static", 1), 3: ("free", 0), 4: ("free", 1)}
+    assert env.num_dofs == 9 and tuple(env._root_state.shape) == (n, 5, 13) and env.obs_buf.shape[1] == 19 and env.num_actions == 7
+    g = torch.Generator().manual_seed(0)
+    table = float(env.reward_settings["table_height"])
+    for step in range(60):
+        act = (torch.rand((n, 7), generator=g) * 2 - 1).to(device)
+        obs, rew, reset, _ = env.step(act)
+        assert torch.isfinite(obs["obs"]).all() and torch.isfinite(rew).all()
+        # the task's own jitted reward (it just ran on the engine's state) against the restated twin on the same states
+        st = {k: v.detach().cpu().numpy() for k, v in env.states.items()}
+        if step % 10 == 0:
+            prog = env.progress_buf.cpu().numpy()
+            r2, _ = J.compute_franka_cube_stack_reward(np.zeros(n, np.int64), prog, act.cpu().numpy(), st, env.reward_settings, env.max_episode_length)
+            env._refresh()
+            st2 = {k: v.detach().cpu().numpy() for k, v in env.states.items()}
+            r3, _ = J.compute_franka_cube_stack_reward(np.zeros(n, np.int64), prog, act.cpu().numpy(), st2, env.reward_settings, env.max_episode_length)
+            np.testing.assert_allclose(r3, r2, rtol=1e-6)        # _refresh is idempotent between steps
+            np.testing.assert_allclose(env.rew_buf.detach().cpu().numpy(), r2, rtol=1e-5, atol=1e-6)
+    # the cubes the task placed at reset (:522-594: on the table, B first, A clear of B) lie on the table: physics holds them there
+    A, B = env._cubeA_state.cpu().numpy(), env._cubeB_state.cpu().numpy()
+    on_a = np.abs(A[:, 2] - (table + env.cubeA_size / 2)) < 3e-3
+    on_b = np.abs(B[:, 2] - (table + env.cubeB_size / 2)) < 3e-3
+    assert on_b.mean() >= 0.8 and on_a.mean() >= 0.7, (A[:, 2], B[:, 2])           # (a flailing arm may knock one about)
+    assert np.isfinite(A).all() and np.isfinite(B).all()
+    assert float(env._eef_state[:, 2].min()) > table - 0.01                        # the gripper does not dive through the table
+    # the arm answers the OSC command: ask every env for +z and the end effector rises
+    z0 = env._eef_state[:, 2].clone()
+    up = torch.zeros((n, 7), device=device); up[:, 2] = 1.0
+    for _ in range(15):
+        env.step(up)
+    assert float((env._eef_state[:, 2] - z0).mean()) > 0.03
+    # episodes end at the horizon and reset_idx puts the cubes back on the table
+    env.progress_buf[:] = env.max_episode_length - 2
+    env.step(torch.zeros((n, 7), device=device)); env.step(torch.zeros((n, 7), device=device))
+    assert int(env.progress_buf.max()) <= 2
+    A = env._cubeA_state.cpu().numpy()
+    assert np.abs(A[:, 2] - (table + env.cubeA_size / 2)).max() < 5e-3 and np.abs(A[:, 7:]).max() < 0.5
+
+
+def test_reference_franka_cube_stack_steps_unmodified_cpu(franka_task):
+    _reference_task(franka_task, "cpu")
+
+
+@pytest.mark.gpu
+def test_reference_franka_cube_stack_steps_unmodified_hip(franka_task):
+    _reference_task(franka_task, "cuda:0")

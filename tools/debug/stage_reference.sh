@@ -7,7 +7,7 @@ REF=${1:-/root/reference}
 D=$ROOT/ab/ref_stage/isaacgymenvs
 rm -rf $ROOT/ab/ref_stage
 mkdir -p $D/tasks/base $D/utils $D/cfg
-for f in cartpole ant humanoid anymal_terrain shadow_hand allegro_hand anymal ball_balance quadcopter ingenuity; do cp $REF/isaacgymenvs/tasks/$f.py $D/tasks/; done
+for f in cartpole ant humanoid anymal_terrain shadow_hand allegro_hand anymal ball_balance quadcopter ingenuity franka_cube_stack; do cp $REF/isaacgymenvs/tasks/$f.py $D/tasks/; done
 cp $REF/isaacgymenvs/tasks/base/vec_task.py $D/tasks/base/
 cp $REF/isaacgymenvs/utils/*.py $D/utils/
 cp -r $REF/isaacgymenvs/cfg/. $D/cfg/
