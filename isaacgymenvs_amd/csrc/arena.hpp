@@ -69,6 +69,7 @@ struct View {
     float* targets;       // [ND][N] position targets of the Articulation task's drives (gym.set_dof_position_target_tensor); null otherwise
     float* scene = nullptr;     // [13 * kSceneMaxFree][N] root states of the free boxes of the Articulation task's scene (core/scene_engine.hpp); null otherwise
     int* scene_nc = nullptr;    // [2][N] scene contacts taken in the last sub-step, refused for want of a slot since reset
+    float* scene_warm = nullptr;   // [4 * 48][N] per contact slot of the last sub-step: feature id (int bits; 0 = empty), impulses (normal, two tangents)
     float* ep_cum;        // [16] the same sums accumulated since init, never re-zeroed: 13 episode sums of the envs that reset, [13] their count,
                           //      [14] sum of the terrain levels of all envs over the steps, [15] the steps -- what a multi-GPU job all-reduces every K
                           //      steps to form job-wide extras["episode"] (parallel.py TaskExtrasReducer)

@@ -15,6 +15,10 @@
 //     crossings are not.  A stated approximation like every contact model here: physics parity against PhysX is unpinned.
 //   * contact slots are data dependent: at most KARM actor contacts (taken in sphere order, grouped by actor body) and KBOX box contacts
 //     (box order, corner order, then ground / static boxes / free boxes); refusals are counted.
+//   * contacts are WARM STARTED although their slots are data dependent: a contact is identified by its feature (actor sphere x target, or box
+//     corner x target -- static numbers), the sub-step leaves (feature, impulses) of every slot in tensor scene_warm, the next one looks its
+//     features up there (<= 48 compares per contact) and starts each contact's sweep from last sub-step's impulses: a cube at rest, a stack, a
+//     cube held between two fingers start every solve from the force they already carry.
 //   * free boxes live in plain velocity space (their mass matrix is block diagonal: v += M^-1 J^T dl costs 2 cross products), the actor
 //     in the whitened space of its factor.
 // Same maths as oracle/scene.py (dense, numpy, fp64).
@@ -58,7 +62,11 @@ struct SceneSim : Sim<M> {
     static constexpr int HCH = M::MAXCHAIN;
     // one contact slot: 3 rows over the actor chain (zero for box contacts) | normal n (3), contact point pc rel. O (3) |
     // Ainv x3, vt_n, lam x3, mu, side A's free box (int bits; -1: the actor / nobody), side B's free box (-1: static)
-    static constexpr int S_GEO = 3 * HCH, S_AUX = S_GEO + 6, S_CSZ = S_AUX + 10;
+    // ... | feature id (int bits, > 0)
+    static constexpr int S_GEO = 3 * HCH, S_AUX = S_GEO + 6, S_CSZ = S_AUX + 11;
+    static constexpr int KSLOT = KARM + KBOX;              // entries of the warm-start tensor: (feature, lam_n, lam_t1, lam_t2) per slot
+    static constexpr int NTGT = kSceneMaxFree + kSceneMaxStatic;
+    static_assert(KSLOT == 48, "tensor scene_warm holds 48 entries per env (arena_layout.hpp)");
     static constexpr int R_LIMG = B::limoff(NLIM);
     static constexpr int R_CB = R_LIMG + 3 * NLIM;          // limit G | Ainv, vt, lam | contact slots
     static constexpr int R_BODY = R_CB + (KARM + KBOX) * S_CSZ;     // per actor body: first slot | count << 8
@@ -74,9 +82,10 @@ struct SceneSim : Sim<M> {
 
     // one sub-step of length h.  tau[ND]: efforts; drv: per-dof position drives; laml: warm-start limit impulses; ncontact: contacts taken
     // (actor + box) | refused for want of a slot << 16
+    // warm: [4 * KSLOT] last sub-step's (feature, impulses) per slot, rewritten at the end (p == nullptr: no warm start)
     template <int RS>
     MI_HD void substep_scene(const SimParams& P, const SceneParams& SP, const float* tau, const Drive& drv, const float h, const RowStore<RS> rows,
-                             const Strided laml, const Strided dof_force, int* ncontact) {
+                             const Strided laml, const Strided dof_force, int* ncontact, const Strided warm = Strided{nullptr, 1}) {
         constexpr int ST = RowStore<RS>::stride;
         float (&q)[M::NDA] = this->q;
         float (&qd)[M::NDA] = this->qd;
@@ -206,6 +215,14 @@ struct SceneSim : Sim<M> {
             matvec3(Iinv[i], rx, t);
             return imass[i] + dot3(rx, t);
         };
+        // last sub-step's impulses of the contact with feature id fid (0, 0, 0 if it did not exist)
+        auto warm_lookup = [&](int fid, float* l0) MI_LAMBDA {
+            l0[0] = l0[1] = l0[2] = 0.f;
+            if (warm.p == nullptr) return;
+            for (int k = 0; k < KSLOT; ++k) {
+                if (__builtin_bit_cast(int, warm(4 * k)) == fid) { l0[0] = warm(4 * k + 1) * P.warm; l0[1] = warm(4 * k + 2) * P.warm; l0[2] = warm(4 * k + 3) * P.warm; }
+            }
+        };
         auto target_velocity = [&](float dist) MI_LAMBDA -> float {
             const float gap = dist - P.rest_offset;
             return (gap >= 0.f) ? -gap * invh : fminf(-gap * P.erp * invh, P.max_depen_vel);
@@ -240,6 +257,9 @@ struct SceneSim : Sim<M> {
                         sfor<3>([&](auto K) MI_LAMBDA { pc[K] = cs[K] - rad * fr[0][K]; });
                         float* cb = rows.ptr(R_CB + cnt * S_CSZ);
                         const float rB[3] = {pc[0] - xb_[0], pc[1] - xb_[1], pc[2] - xb_[2]};
+                        const int fid = 1 + s * NTGT + (fr_ ? ib : kSceneMaxFree + ib);
+                        float l0[3];
+                        warm_lookup(fid, l0);
                         sfor<3>([&](auto K) MI_LAMBDA {
                             constexpr int k = K;
                             float W[6];
@@ -261,8 +281,9 @@ struct SceneSim : Sim<M> {
                             sfor<HCH - CL>([&](auto C) MI_LAMBDA { cb[(k * HCH + CL + C) * ST] = 0.f; });
                             if (fr_) a += box_diag(ib, rB, fr[k]);
                             cb[(S_AUX + k) * ST] = MI_RCP(a);
-                            cb[(S_AUX + 4 + k) * ST] = 0.f;
+                            cb[(S_AUX + 4 + k) * ST] = l0[k];
                         });
+                        cb[(S_AUX + 10) * ST] = __builtin_bit_cast(float, fid);
                         sfor<3>([&](auto I_) MI_LAMBDA { cb[(S_GEO + I_) * ST] = fr[0][I_]; cb[(S_GEO + 3 + I_) * ST] = pc[I_]; });
                         cb[(S_AUX + 3) * ST] = target_velocity(dist);
                         cb[(S_AUX + 7) * ST] = 0.5f * (SP.arm_mu + (fr_ ? SP.free_mu[ib] : SP.static_mu[ib]));
@@ -315,14 +336,18 @@ struct SceneSim : Sim<M> {
                     contact_frame(fr[0], fr[1], fr[2]);
                     float* cb = rows.ptr(R_CB + (KARM + nbox) * S_CSZ);
                     float rB[3] = {0.f, 0.f, 0.f};
+                    const int fid = 1 + NSPH * NTGT + (i * 8 + cr) * (NTGT + 1) + (t + 1);
+                    float l0[3];
+                    warm_lookup(fid, l0);
                     if (ib >= 0) sfor<3>([&](auto K) MI_LAMBDA { rB[K] = pc[K] - xf[ib][K]; });
                     sfor<3>([&](auto K) MI_LAMBDA {
                         constexpr int k = K;
                         float a = P.cfm + box_diag(i, pr, fr[k]);
                         if (ib >= 0) a += box_diag(ib, rB, fr[k]);
                         cb[(S_AUX + k) * ST] = MI_RCP(a);
-                        cb[(S_AUX + 4 + k) * ST] = 0.f;
+                        cb[(S_AUX + 4 + k) * ST] = l0[k];
                     });
+                    cb[(S_AUX + 10) * ST] = __builtin_bit_cast(float, fid);
                     sfor<3>([&](auto I_) MI_LAMBDA { cb[(S_GEO + I_) * ST] = n[I_]; cb[(S_GEO + 3 + I_) * ST] = pc[I_]; });
                     cb[(S_AUX + 3) * ST] = target_velocity(dist);
                     cb[(S_AUX + 7) * ST] = 0.5f * (SP.free_mu[i] + mu_b);
@@ -337,7 +362,8 @@ struct SceneSim : Sim<M> {
         // ------------------------------------------------------------ projected Gauss-Seidel sweeps: limits, actor contacts, box contacts
         // one contact: the normal row, the two tangent rows, then the friction disc (the order of core/hand_engine.hpp).  Btag: the actor body
         // whose chain the rows span, or -1 for a box contact
-        auto solve_contact = [&](auto Btag, float* cb) MI_LAMBDA {
+        // `first` (the first sweep): the slot's impulses are last sub-step's and have not acted yet -- they are applied before the contact is solved
+        auto solve_contact = [&](auto Btag, float* cb, const bool first) MI_LAMBDA {
             constexpr int b = decltype(Btag)::value;
             constexpr int CL = b >= 0 ? M::chain_len[b >= 0 ? b : 0] : 0;
             float g[3][HCH > 0 ? HCH : 1], ainv[3], lm[3], fr[3][3], pc[3];
@@ -373,6 +399,7 @@ struct SceneSim : Sim<M> {
                     sfor<3>([&](auto C) MI_LAMBDA { vb[ib][C] -= fr[k][C] * (imass[ib] * dl); vb[ib][3 + C] -= t[C] * dl; });
                 }
             };
+            if (first) { apply(0, lm[0]); apply(1, lm[1]); apply(2, lm[2]); }
             const float ln = fmaxf(lm[0] - (rowvel(0) - vtn) * ainv[0], 0.f);
             apply(0, ln - lm[0]);
             float lt[2];
@@ -416,10 +443,10 @@ struct SceneSim : Sim<M> {
                 if constexpr (sph_count(b) > 0) {
                     const int fc = __builtin_bit_cast(int, rit(R_BODY + b));
                     const int first = fc & 255, nb_ = fc >> 8;
-                    for (int i = 0; i < nb_; ++i) solve_contact(std::integral_constant<int, b>{}, rit.ptr(R_CB + (first + i) * S_CSZ));
+                    for (int i = 0; i < nb_; ++i) solve_contact(std::integral_constant<int, b>{}, rit.ptr(R_CB + (first + i) * S_CSZ), it == 0);
                 }
             });
-            for (int i = 0; i < nbox; ++i) solve_contact(std::integral_constant<int, -1>{}, rit.ptr(R_CB + (KARM + i) * S_CSZ));
+            for (int i = 0; i < nbox; ++i) solve_contact(std::integral_constant<int, -1>{}, rit.ptr(R_CB + (KARM + i) * S_CSZ), it == 0);
         }
         MI_PHASE();
         // ------------------------------------------------------------ back to generalised velocity, outputs
@@ -441,6 +468,14 @@ struct SceneSim : Sim<M> {
             dof_force(d) = tau[d] - M::dof_stiffness[d] * (q[d] - M::dof_springref[d]) - M::dof_damping[d] * v[OFF + d] + ll * invh
                            + drv.gain_p(d) * (drv.target[d] - q[d]) - drv.gain_d(d) * v[OFF + d];
         });
+        if (warm.p != nullptr) {
+            for (int k = 0; k < KSLOT; ++k) {
+                const bool used = (k < KARM) ? (k < narm) : (k - KARM < nbox);
+                const float* cb = rows.ptr(R_CB + k * S_CSZ);
+                warm(4 * k) = used ? cb[(S_AUX + 10) * ST] : 0.f;
+                sfor<3>([&](auto J) MI_LAMBDA { warm(4 * k + 1 + J) = used ? cb[(S_AUX + 4 + J) * ST] : 0.f; });
+            }
+        }
         // ------------------------------------------------------------ integrate the actor and the boxes (semi-implicit Euler)
         sfor<ND>([&](auto D) MI_LAMBDA { qd[D] = v[OFF + D]; q[D] += h * qd[D]; });
         for (int i = 0; i < nf; ++i) {

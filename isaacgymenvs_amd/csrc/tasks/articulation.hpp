@@ -44,7 +44,7 @@ MI_HD void articulation_scene_substep_env(const View& v, const SimParams& P, con
     const float h = P.dt / (float)P.substeps;
     float rows[SceneSim<M>::ROW_SLOTS];
     int nc = 0;
-    sim.substep_scene(P, p.scene, tau, drv, h, RowStore<1>{rows}, Strided{v.laml + e, N}, Strided{v.dof_force + e, N}, &nc);
+    sim.substep_scene(P, p.scene, tau, drv, h, RowStore<1>{rows}, Strided{v.laml + e, N}, Strided{v.dof_force + e, N}, &nc, Strided{v.scene_warm + e, N});
     v.scene_nc[e] = nc & 0xFFFF;
     v.scene_nc[N + e] += nc >> 16;
     sfor<ND>([&](auto K) MI_LAMBDA { v.dof[K * N + e] = sim.q[K]; v.dof[(ND + K) * N + e] = sim.qd[K]; });
@@ -98,6 +98,7 @@ MI_HD void articulation_reset_env(const View& v, const ArticulationParams& p, co
     for (int i = 0; i < kSceneMaxFree; ++i)
         for (int k = 0; k < 13; ++k) v.scene[(size_t)(13 * i + k) * N + e] = (i < p.scene.n_free && k < 7) ? p.scene.free_init[i][k] : (k == 6 ? 1.f : 0.f);
     v.scene_nc[e] = 0; v.scene_nc[N + e] = 0;
+    for (int k = 0; k < 4 * (24 + 24); ++k) v.scene_warm[(size_t)k * N + e] = 0.f;
     v.progress[e] = 0; v.reset[e] = 0;
 }
 

@@ -489,7 +489,10 @@ CPU_UNITS = [("mi_engine_cpu.cpp", "", "-O2", [], ("cartpole", "ant", "humanoid"
              ("cpu_anymal.cpp", "", "-O2", [], ("anymal",)), ("cpu_articulation.cpp", "", "-O2", [], ("articulation",))] + \
             [("cpu_hand.cpp", f"_{h}", "-O2", [f"-DMI_CPU_HAND={h}"], (_HAND_MODEL[h],)) for h in (0, 1)] + \
             [("cpu_hand_physics.cpp", f"_{h}_{sh}", "-O1", [f"-DMI_CPU_HAND={h}", f"-DMI_CPU_SHAPE={sh}"], (_HAND_MODEL[h],)) for h in (0, 1) for sh in (0, 1, 2)]
-CPU_FLAGS = ["-std=c++17", "-fPIC", "-fopenmp", "-ffp-contract=off"]
+# -fno-gnu-unique: the generated models' constexpr tables that are indexed at run time (ModelArticulation::dof_lower, sph_rad, ...) would otherwise be
+# STB_GNU_UNIQUE symbols, which the dynamic loader binds ACROSS libraries even under RTLD_LOCAL -- two run-time variants of the Articulation robot loaded
+# into one process (a Franka, then a Kuka) then read each other's tables (found in round 5: NaN joint limits in the second robot's reset)
+CPU_FLAGS = ["-std=c++17", "-fPIC", "-fopenmp", "-ffp-contract=off", "-fno-gnu-unique"]
 
 
 def cpu_object(src, suffix):

@@ -1407,7 +1407,7 @@ class Gym:
 
     def _clear_warm_start(self, sim, ids):
         t = sim.engine.tensors
-        for k in ("contact_impulse", "limit_impulse", "self_contact_impulse", "attractor_impulse"):
+        for k in ("contact_impulse", "limit_impulse", "self_contact_impulse", "attractor_impulse", "scene_warm"):
             if k in t:
                 t[k][ids] = 0.0
 
@@ -1440,6 +1440,8 @@ class Gym:
             ids = self._envs_of(sim, actor_indices, count, k)
             if phys and len(ids):
                 self._object_view(sim, k)[ids] = src[ids, k]
+                if getattr(sim, "scene", None):        # a teleported box starts without last sub-step's contact impulses
+                    sim.engine.tensors["scene_warm"][ids] = 0.0
             # (the goal object: the task's own tensor IS the state)
         if root_states.data_ptr() != self._buf(sim, "root", (n * A, 13)).data_ptr():
             self._buf(sim, "root", (n * A, 13)).view(n, A, 13)[:] = src

