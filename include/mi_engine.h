@@ -142,9 +142,9 @@ typedef struct {
     float max_angular_velocity;            /* asset option: clamp of the base's angular speed (rad/s); <= 0: none */
     float init_root[13];                   /* actor start pose (create_actor) + zero velocities */
     MiScene scene;                         /* free / static boxes beside the actor; fixed-base actors only */
-    float drive_vmax[MI_MAX_DOF];          /* velocity limit of a dof's position drive (the asset's joint velocity limit, URDF <limit velocity=>); <= 0: none.
-                                            * Scenes only: the drive's position error is clamped to vmax * kd / kp, the error at which its spring and damper
-                                            * balance at that speed (franka_panda_gripper.urdf:247 fingers: 0.2 m/s) */
+    float drive_vmax[MI_MAX_DOF];          /* the asset's joint velocity limits (URDF <limit velocity=>); <= 0: none.  Scenes only: the solved joint velocities
+                                            * are clamped to them (the simulator's maxJointVelocity), and a position drive's error is clamped to vmax * kd / kp,
+                                            * the error at which its spring and damper balance at that speed (franka_panda_gripper.urdf:247 fingers: 0.2 m/s) */
 } MiArticulationParams;
 
 /* task parameters of Ingenuity (ingenuity.py:45-97, 233-282): constants the reference hard-codes in the task file */

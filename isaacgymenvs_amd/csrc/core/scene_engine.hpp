@@ -70,7 +70,15 @@ struct SceneSim : Sim<M> {
     static constexpr int R_LIMG = B::limoff(NLIM);
     static constexpr int R_CB = R_LIMG + 3 * NLIM;          // limit G | Ainv, vt, lam | contact slots
     static constexpr int R_BODY = R_CB + (KARM + KBOX) * S_CSZ;     // per actor body: first slot | count << 8
-    static constexpr int ROW_SLOTS = R_BODY + NB;
+    // work area behind the slots: what the narrow phase and the sweeps index with a RUN-TIME box number -- the boxes' velocities (lin, ang), centres
+    // rel. O, world inverse inertias, inverse masses, rotations; the static boxes' rotations and centres; the actor's sphere centres.  In the row store
+    // (LDS on the device) because a per-lane array indexed at run time lives in scratch memory, and the sweeps read every velocity right after the
+    // previous row wrote it: with the boxes in scratch each of those ~10^4 read-after-write pairs per sub-step was a round trip to memory (1.7 ms
+    // per sub-step at ANY batch size; profiles/r5t_scene_time.txt)
+    static constexpr int W_VB = R_BODY + NB, W_XF = W_VB + 6 * kSceneMaxFree, W_IINV = W_XF + 3 * kSceneMaxFree, W_IM = W_IINV + 9 * kSceneMaxFree,
+                         W_RF = W_IM + kSceneMaxFree, W_RS = W_RF + 9 * kSceneMaxFree, W_XST = W_RS + 9 * kSceneMaxStatic,
+                         W_XS = W_XST + 3 * kSceneMaxStatic;
+    static constexpr int ROW_SLOTS = W_XS + 3 * M::NSPHA;
 
     float box[kSceneMaxFree][13];                           // free boxes: pos3, quat xyzw, linvel3, angvel3 (world)
 
@@ -83,9 +91,12 @@ struct SceneSim : Sim<M> {
     // one sub-step of length h.  tau[ND]: efforts; drv: per-dof position drives; laml: warm-start limit impulses; ncontact: contacts taken
     // (actor + box) | refused for want of a slot << 16
     // warm: [4 * KSLOT] last sub-step's (feature, impulses) per slot, rewritten at the end (p == nullptr: no warm start)
+    // vmax: [ND] the asset's joint velocity limits (<= 0: none): the solved joint velocities are clamped to them (the simulator enforces
+    // maxJointVelocity; without it an arm under random operational-space commands reaches 70 rad/s and its task's matrix inverses blow up)
     template <int RS>
     MI_HD void substep_scene(const SimParams& P, const SceneParams& SP, const float* tau, const Drive& drv, const float h, const RowStore<RS> rows,
-                             const Strided laml, const Strided dof_force, int* ncontact, const Strided warm = Strided{nullptr, 1}) {
+                             const Strided laml, const Strided dof_force, int* ncontact, const Strided warm = Strided{nullptr, 1},
+                             const float* vmax = nullptr) {
         constexpr int ST = RowStore<RS>::stride;
         float (&q)[M::NDA] = this->q;
         float (&qd)[M::NDA] = this->qd;
@@ -114,10 +125,10 @@ struct SceneSim : Sim<M> {
         MI_PHASE();
         // sphere centres (rel. O) in per-lane memory: the narrow phase walks a body's spheres in a run-time loop (one copy of the code per
         // BODY, not per sphere -- core/hand_engine.hpp's reason)
-        float xs[3 * M::NSPHA];
-        int pz;
-        MI_OPAQUE_ZERO(pz);
-        sfor<NSPH>([&](auto S_) MI_LAMBDA { sfor<3>([&](auto K) MI_LAMBDA { xs[pz + 3 * S_ + K] = c.xcs[S_][K]; }); });
+        auto W = [&](int base, int idx) MI_LAMBDA -> float& { return *rows.ptr(base + idx); };
+        auto ld3 = [&](int base, int i, float* o) MI_LAMBDA { sfor<3>([&](auto K) MI_LAMBDA { o[K] = W(base, 3 * i + K); }); };
+        auto ld9 = [&](int base, int i, float* o) MI_LAMBDA { sfor<9>([&](auto K) MI_LAMBDA { o[K] = W(base, 9 * i + K); }); };
+        sfor<NSPH>([&](auto S_) MI_LAMBDA { sfor<3>([&](auto K) MI_LAMBDA { W(W_XS, 3 * S_ + K) = c.xcs[S_][K]; }); });
         // ------------------------------------------------------------ rhs: efforts, passive spring / damper, implicit position drives
         float Ldi[NVA], y[NVA];
         sfor<ND>([&](auto D) MI_LAMBDA {
@@ -157,21 +168,28 @@ struct SceneSim : Sim<M> {
             sfor<M::nanc[i]>([&](auto A_) MI_LAMBDA { s += L[M::midx[i][M::anc[i][A_]]] * qd[M::anc[i][A_]]; });
             w[i] = s + h * z;
         });
-        float vb[kSceneMaxFree][6];             // lin, ang
-        float Rf[kSceneMaxFree][9], xf[kSceneMaxFree][3], Iinv[kSceneMaxFree][9], imass[kSceneMaxFree];      // pose (centre rel. O), world inverse inertia
-        for (int i = 0; i < nf; ++i) {
-            for (int k = 0; k < 3; ++k) { vb[i][k] = box[i][7 + k] + h * P.g[k]; vb[i][3 + k] = box[i][10 + k]; xf[i][k] = box[i][k] - root[k]; }
-            quat2mat(box[i] + 3, Rf[i]);
-            imass[i] = MI_RCP(SP.free_mass[i]);
+        for (int i = 0; i < nf; ++i) {          // velocities (lin, ang), centre rel. O, rotation, world inverse inertia, inverse mass -> work area
+            float R[9];
+            quat2mat(box[i] + 3, R);
+            sfor<3>([&](auto K) MI_LAMBDA {
+                W(W_VB, 6 * i + K) = box[i][7 + K] + h * P.g[K]; W(W_VB, 6 * i + 3 + K) = box[i][10 + K];
+                W(W_XF, 3 * i + K) = box[i][K] - root[K];
+            });
+            sfor<9>([&](auto K) MI_LAMBDA { W(W_RF, 9 * i + K) = R[K]; });
+            W(W_IM, i) = MI_RCP(SP.free_mass[i]);
             const float id[3] = {MI_RCP(SP.free_inertia[i][0]), MI_RCP(SP.free_inertia[i][1]), MI_RCP(SP.free_inertia[i][2])};
-            for (int r = 0; r < 3; ++r)
-                for (int cc = 0; cc < 3; ++cc)
-                    Iinv[i][3 * r + cc] = Rf[i][3 * r] * id[0] * Rf[i][3 * cc] + Rf[i][3 * r + 1] * id[1] * Rf[i][3 * cc + 1] + Rf[i][3 * r + 2] * id[2] * Rf[i][3 * cc + 2];
+            sfor<3>([&](auto R_) MI_LAMBDA {
+                sfor<3>([&](auto C_) MI_LAMBDA {
+                    constexpr int r = R_, cc = C_;
+                    W(W_IINV, 9 * i + 3 * r + cc) = R[3 * r] * id[0] * R[3 * cc] + R[3 * r + 1] * id[1] * R[3 * cc + 1] + R[3 * r + 2] * id[2] * R[3 * cc + 2];
+                });
+            });
         }
-        float Rs[kSceneMaxStatic][9], xst[kSceneMaxStatic][3];
         for (int i = 0; i < ns; ++i) {
-            quat2mat(SP.static_quat[i], Rs[i]);
-            for (int k = 0; k < 3; ++k) xst[i][k] = SP.static_pos[i][k] - root[k];
+            float R[9];
+            quat2mat(SP.static_quat[i], R);
+            sfor<9>([&](auto K) MI_LAMBDA { W(W_RS, 9 * i + K) = R[K]; });
+            sfor<3>([&](auto K) MI_LAMBDA { W(W_XST, 3 * i + K) = SP.static_pos[i][K] - root[K]; });
         }
         MI_PHASE();
         // ------------------------------------------------------------ joint limit rows (as core/engine.hpp)
@@ -210,16 +228,18 @@ struct SceneSim : Sim<M> {
         MI_PHASE();
         // the box part of a row: lever x direction, the response of the box to a unit impulse along u at the lever, its share of the diagonal
         auto box_diag = [&](int i, const float* r, const float* u) MI_LAMBDA -> float {
-            float rx[3], t[3];
+            float rx[3], t[3], Ii[9];
             cross3(r, u, rx);
-            matvec3(Iinv[i], rx, t);
-            return imass[i] + dot3(rx, t);
+            ld9(W_IINV, i, Ii);
+            matvec3(Ii, rx, t);
+            return W(W_IM, i) + dot3(rx, t);
         };
         // last sub-step's impulses of the contact with feature id fid (0, 0, 0 if it did not exist)
-        auto warm_lookup = [&](int fid, float* l0) MI_LAMBDA {
+        // (actor contacts live in entries [0, KARM), box contacts in [KARM, KSLOT): only the own region is searched)
+        auto warm_lookup = [&](int fid, float* l0, int k0, int k1) MI_LAMBDA {
             l0[0] = l0[1] = l0[2] = 0.f;
             if (warm.p == nullptr) return;
-            for (int k = 0; k < KSLOT; ++k) {
+            for (int k = k0; k < k1; ++k) {
                 if (__builtin_bit_cast(int, warm(4 * k)) == fid) { l0[0] = warm(4 * k + 1) * P.warm; l0[1] = warm(4 * k + 2) * P.warm; l0[2] = warm(4 * k + 3) * P.warm; }
             }
         };
@@ -238,12 +258,14 @@ struct SceneSim : Sim<M> {
                 for (int si = 0; si < SN; ++si) {
                     const int s = S0 + si;
                     const float rad = M::sph_rad[s];
-                    const float cs[3] = {xs[pz + 3 * s], xs[pz + 3 * s + 1], xs[pz + 3 * s + 2]};
+                    float cs[3];
+                    ld3(W_XS, s, cs);
                     for (int t = 0; t < nf + ns; ++t) {
                         const bool fr_ = t < nf;
                         const int ib = fr_ ? t : t - nf;
-                        const float* Rb_ = fr_ ? Rf[ib] : Rs[ib];
-                        const float* xb_ = fr_ ? xf[ib] : xst[ib];
+                        float Rb_[9], xb_[3];
+                        ld9(fr_ ? W_RF : W_RS, ib, Rb_);
+                        ld3(fr_ ? W_XF : W_XST, ib, xb_);
                         const float* hb_ = fr_ ? SP.free_half[ib] : SP.static_half[ib];
                         const float rel[3] = {cs[0] - xb_[0], cs[1] - xb_[1], cs[2] - xb_[2]};
                         float cl[3], nl[3], dist;
@@ -259,7 +281,7 @@ struct SceneSim : Sim<M> {
                         const float rB[3] = {pc[0] - xb_[0], pc[1] - xb_[1], pc[2] - xb_[2]};
                         const int fid = 1 + s * NTGT + (fr_ ? ib : kSceneMaxFree + ib);
                         float l0[3];
-                        warm_lookup(fid, l0);
+                        warm_lookup(fid, l0, 0, KARM);
                         sfor<3>([&](auto K) MI_LAMBDA {
                             constexpr int k = K;
                             float W[6];
@@ -301,12 +323,15 @@ struct SceneSim : Sim<M> {
         // static boxes, the other free boxes (side A: the corner's box, pushed along n; side B: the box it is in / on)
         int nbox = 0;
         for (int i = 0; i < nf; ++i) {
+            float Ri[9], xi[3];
+            ld9(W_RF, i, Ri);
+            ld3(W_XF, i, xi);
             for (int cr = 0; cr < 8; ++cr) {
                 const float pl[3] = {(cr & 1) ? SP.free_half[i][0] : -SP.free_half[i][0], (cr & 2) ? SP.free_half[i][1] : -SP.free_half[i][1],
                                      (cr & 4) ? SP.free_half[i][2] : -SP.free_half[i][2]};
                 float pr[3], pc[3];
-                matvec3(Rf[i], pl, pr);
-                sfor<3>([&](auto K) MI_LAMBDA { pc[K] = xf[i][K] + pr[K]; });
+                matvec3(Ri, pl, pr);
+                sfor<3>([&](auto K) MI_LAMBDA { pc[K] = xi[K] + pr[K]; });
                 for (int t = -1; t < ns + nf; ++t) {
                     if (t >= ns && t - ns == i) continue;
                     float n[3], dist, mu_b;
@@ -318,8 +343,9 @@ struct SceneSim : Sim<M> {
                     } else {
                         const bool st_ = t < ns;
                         const int j = st_ ? t : t - ns;
-                        const float* Rb_ = st_ ? Rs[j] : Rf[j];
-                        const float* xb_ = st_ ? xst[j] : xf[j];
+                        float Rb_[9], xb_[3];
+                        ld9(st_ ? W_RS : W_RF, j, Rb_);
+                        ld3(st_ ? W_XST : W_XF, j, xb_);
                         const float* hb_ = st_ ? SP.static_half[j] : SP.free_half[j];
                         const float rel[3] = {pc[0] - xb_[0], pc[1] - xb_[1], pc[2] - xb_[2]};
                         float cl[3], nl[3];
@@ -338,8 +364,8 @@ struct SceneSim : Sim<M> {
                     float rB[3] = {0.f, 0.f, 0.f};
                     const int fid = 1 + NSPH * NTGT + (i * 8 + cr) * (NTGT + 1) + (t + 1);
                     float l0[3];
-                    warm_lookup(fid, l0);
-                    if (ib >= 0) sfor<3>([&](auto K) MI_LAMBDA { rB[K] = pc[K] - xf[ib][K]; });
+                    warm_lookup(fid, l0, KARM, KSLOT);
+                    if (ib >= 0) sfor<3>([&](auto K) MI_LAMBDA { rB[K] = pc[K] - W(W_XF, 3 * ib + K); });
                     sfor<3>([&](auto K) MI_LAMBDA {
                         constexpr int k = K;
                         float a = P.cfm + box_diag(i, pr, fr[k]);
@@ -377,26 +403,30 @@ struct SceneSim : Sim<M> {
             const float vtn = cb[(S_AUX + 3) * ST], mu = cb[(S_AUX + 7) * ST];
             const int ia = __builtin_bit_cast(int, cb[(S_AUX + 8) * ST]), ib = __builtin_bit_cast(int, cb[(S_AUX + 9) * ST]);
             float rA[3] = {0.f, 0.f, 0.f}, rB[3] = {0.f, 0.f, 0.f};
-            if (ia >= 0) sfor<3>([&](auto K) MI_LAMBDA { rA[K] = pc[K] - xf[ia][K]; });
-            if (ib >= 0) sfor<3>([&](auto K) MI_LAMBDA { rB[K] = pc[K] - xf[ib][K]; });
+            if (ia >= 0) sfor<3>([&](auto K) MI_LAMBDA { rA[K] = pc[K] - W(W_XF, 3 * ia + K); });
+            if (ib >= 0) sfor<3>([&](auto K) MI_LAMBDA { rB[K] = pc[K] - W(W_XF, 3 * ib + K); });
+            // the (at most two) boxes' velocities, inverse inertias and inverse masses: loaded once per contact visit, written back at its end
+            float vA[6], vB[6], IA[9], IB[9], imA = 0.f, imB = 0.f;
+            if (ia >= 0) { sfor<6>([&](auto K) MI_LAMBDA { vA[K] = W(W_VB, 6 * ia + K); }); ld9(W_IINV, ia, IA); imA = W(W_IM, ia); }
+            if (ib >= 0) { sfor<6>([&](auto K) MI_LAMBDA { vB[K] = W(W_VB, 6 * ib + K); }); ld9(W_IINV, ib, IB); imB = W(W_IM, ib); }
             auto rowvel = [&](int k) MI_LAMBDA {
                 float vn = 0.f;
                 if constexpr (b >= 0) sfor<CL>([&](auto C) MI_LAMBDA { vn += g[k][C] * w[M::chain[b >= 0 ? b : 0][C]]; });
-                if (ia >= 0) { float rx[3]; cross3(rA, fr[k], rx); vn += dot3(fr[k], vb[ia]) + dot3(rx, vb[ia] + 3); }
-                if (ib >= 0) { float rx[3]; cross3(rB, fr[k], rx); vn -= dot3(fr[k], vb[ib]) + dot3(rx, vb[ib] + 3); }
+                if (ia >= 0) { float rx[3]; cross3(rA, fr[k], rx); vn += dot3(fr[k], vA) + dot3(rx, vA + 3); }
+                if (ib >= 0) { float rx[3]; cross3(rB, fr[k], rx); vn -= dot3(fr[k], vB) + dot3(rx, vB + 3); }
                 return vn;
             };
             auto apply = [&](int k, float dl) MI_LAMBDA {
                 if constexpr (b >= 0) sfor<CL>([&](auto C) MI_LAMBDA { w[M::chain[b >= 0 ? b : 0][C]] += g[k][C] * dl; });
                 if (ia >= 0) {
                     float rx[3], t[3];
-                    cross3(rA, fr[k], rx); matvec3(Iinv[ia], rx, t);
-                    sfor<3>([&](auto C) MI_LAMBDA { vb[ia][C] += fr[k][C] * (imass[ia] * dl); vb[ia][3 + C] += t[C] * dl; });
+                    cross3(rA, fr[k], rx); matvec3(IA, rx, t);
+                    sfor<3>([&](auto C) MI_LAMBDA { vA[C] += fr[k][C] * (imA * dl); vA[3 + C] += t[C] * dl; });
                 }
                 if (ib >= 0) {
                     float rx[3], t[3];
-                    cross3(rB, fr[k], rx); matvec3(Iinv[ib], rx, t);
-                    sfor<3>([&](auto C) MI_LAMBDA { vb[ib][C] -= fr[k][C] * (imass[ib] * dl); vb[ib][3 + C] -= t[C] * dl; });
+                    cross3(rB, fr[k], rx); matvec3(IB, rx, t);
+                    sfor<3>([&](auto C) MI_LAMBDA { vB[C] -= fr[k][C] * (imB * dl); vB[3 + C] -= t[C] * dl; });
                 }
             };
             if (first) { apply(0, lm[0]); apply(1, lm[1]); apply(2, lm[2]); }
@@ -417,6 +447,8 @@ struct SceneSim : Sim<M> {
                 cb[(S_AUX + 5 + K) * ST] = nl_;
                 apply(1 + K, nl_ - lt[K]);
             });
+            if (ia >= 0) sfor<6>([&](auto K) MI_LAMBDA { W(W_VB, 6 * ia + K) = vA[K]; });
+            if (ib >= 0) sfor<6>([&](auto K) MI_LAMBDA { W(W_VB, 6 * ib + K) = vB[K]; });
         };
         for (int it = 0; it < P.iters; ++it) {
             int zero;
@@ -457,6 +489,7 @@ struct SceneSim : Sim<M> {
             sfor<M::nanc[i]>([&](auto A_) MI_LAMBDA { s -= L[M::midx[i][M::anc[i][A_]]] * v[M::anc[i][A_]]; });
             v[i] = s * Ldi[i];
         });
+        if (vmax != nullptr) sfor<ND>([&](auto D) MI_LAMBDA { if (vmax[D] > 0.f) v[OFF + D] = fminf(fmaxf(v[OFF + D], -vmax[D]), vmax[D]); });
         sfor<ND>([&](auto D) MI_LAMBDA {
             constexpr int d = D;
             float ll = 0.f;
@@ -479,7 +512,8 @@ struct SceneSim : Sim<M> {
         // ------------------------------------------------------------ integrate the actor and the boxes (semi-implicit Euler)
         sfor<ND>([&](auto D) MI_LAMBDA { qd[D] = v[OFF + D]; q[D] += h * qd[D]; });
         for (int i = 0; i < nf; ++i) {
-            float* vv = vb[i];
+            float vv[6];
+            sfor<6>([&](auto K) MI_LAMBDA { vv[K] = W(W_VB, 6 * i + K); });
             const float w2 = vv[3] * vv[3] + vv[4] * vv[4] + vv[5] * vv[5], l2 = vv[0] * vv[0] + vv[1] * vv[1] + vv[2] * vv[2];
             const float sw = (w2 > kMaxAngularVelocity * kMaxAngularVelocity) ? kMaxAngularVelocity * MI_RSQ(w2) : 1.f;
             const float sl = (l2 > kMaxLinearVelocity * kMaxLinearVelocity) ? kMaxLinearVelocity * MI_RSQ(l2) : 1.f;

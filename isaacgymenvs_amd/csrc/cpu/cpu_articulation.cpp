@@ -15,19 +15,25 @@ int cpu_articulation_reset(MiEngine* e, const int64_t* ids, int n) {
     for (int i = 0; i < n; ++i) if (ids[i] >= 0 && ids[i] < e->v.N) articulation_reset_env<AM>(e->v, p, (int)ids[i]);
     return 0;
 }
+template <class M>
+static int scene_simulate(MiEngine* e, const ArticulationParams& p) {
+    if constexpr (M::FIXED == 1) {
+        const View& v = e->v;
+#pragma omp parallel for schedule(static) num_threads(e->num_threads)
+        for (int en = 0; en < v.N; ++en) {
+            float rows[SceneRows<M>::value];
+            for (int ss = 0; ss < e->P.substeps; ++ss)
+                articulation_scene_substep_env<M>(v, e->P, p, en, RowStore<1>{rows}, Strided{v.scene_warm + en, v.N});
+        }
+        return 0;
+    } else {
+        return -1;
+    }
+}
 int cpu_articulation_simulate(MiEngine* e) {
     const View& v = e->v;
     const ArticulationParams& p = *reinterpret_cast<const ArticulationParams*>(e->artic);
-    if (articulation_has_scene(p)) {          // free / static boxes beside the actor (core/scene_engine.hpp)
-        if constexpr (AM::FIXED == 1) {
-#pragma omp parallel for schedule(static) num_threads(e->num_threads)
-            for (int en = 0; en < v.N; ++en)
-                for (int ss = 0; ss < e->P.substeps; ++ss) articulation_scene_substep_env<AM>(v, e->P, p, en);
-            return 0;
-        } else {
-            return -1;
-        }
-    }
+    if (articulation_has_scene(p)) return scene_simulate<AM>(e, p);     // free / static boxes beside the actor (core/scene_engine.hpp)
 #pragma omp parallel for schedule(static) num_threads(e->num_threads)
     for (int en = 0; en < v.N; ++en) {
         float rows[Sim<AM>::ROW_SLOTS > 0 ? Sim<AM>::ROW_SLOTS : 1];

@@ -31,12 +31,26 @@ __global__ __launch_bounds__(64) void articulation_substep_kernel(View v, SimPar
         articulation_substep_env<AM>(v, P, p, e, RowStore<1>{rows}, false);
     }
 }
-// the same for an env that holds free / static boxes beside a fixed-base actor (core/scene_engine.hpp): one env per lane, the row store in per-lane
-// memory.  A kernel of its own: the scene's code does not touch the register allocation of the kernel above.
+// the same for an env that holds free / static boxes beside a fixed-base actor (core/scene_engine.hpp).  A kernel of its own: the scene's code does
+// not touch the register allocation of the kernel above.  SCENE_LANES envs per workgroup, one per lane: the sub-step is a long serial program per
+// env (narrow phase, row build and sweeps walk data-dependent contact lists), so a batch is spread over many small workgroups -- 4096 envs are 512
+// workgroups of 8, two resident per CU -- and the row store (8 KB per env: 48 contact slots) plus last sub-step's warm-start table live in LDS
+// as [slot][lane]: in a per-lane array (scratch) every one of the sub-step's ~10^4 row accesses was a trip to memory (2.1 ms per sub-step at any
+// batch size, profiles/r5t_scene_time.txt).
+constexpr int SCENE_LANES = 8, SCENE_WARM = 4 * 48;
+constexpr int SCENE_ROWS = SceneRows<AM>::value;
 __global__ __launch_bounds__(64) void articulation_scene_substep_kernel(View v, SimParams P, ArticulationParams p) {
-    const int e = blockIdx.x * 64 + threadIdx.x;
+    extern __shared__ float lds_scene[];
+    const int e = blockIdx.x * SCENE_LANES + threadIdx.x;
     if (e >= v.N) return;
-    if constexpr (AM::FIXED == 1) articulation_scene_substep_env<AM>(v, P, p, e);
+    if constexpr (AM::FIXED == 1) {
+        float* rows = lds_scene + threadIdx.x;
+        float* warm = lds_scene + SCENE_ROWS * SCENE_LANES + threadIdx.x;
+        const int N = v.N;
+        for (int k = 0; k < SCENE_WARM; ++k) warm[k * SCENE_LANES] = v.scene_warm[(size_t)k * N + e];
+        articulation_scene_substep_env<AM>(v, P, p, e, RowStore<SCENE_LANES>{rows}, Strided{warm, SCENE_LANES});
+        for (int k = 0; k < SCENE_WARM; ++k) v.scene_warm[(size_t)k * N + e] = warm[k * SCENE_LANES];
+    }
 }
 __global__ void articulation_reset_kernel(View v, ArticulationParams p, const long long* __restrict__ ids, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -98,7 +112,12 @@ __global__ __launch_bounds__(64) void articulation_mass_matrix_kernel(View v, Si
 hipError_t launch_simulate_articulation(const View& v, const SimParams& P, const ArticulationParams& p, hipStream_t s) {
     if (articulation_has_scene(p)) {
         if (AM::FIXED != 1) return hipErrorInvalidValue;
-        for (int i = 0; i < P.substeps; ++i) hipLaunchKernelGGL(articulation_scene_substep_kernel, dim3((v.N + 63) / 64), dim3(64), 0, s, v, P, p);
+        constexpr size_t lds = (size_t)(SCENE_ROWS + SCENE_WARM) * SCENE_LANES * sizeof(float);
+        static_assert(lds <= 80 * 1024, "two scene workgroups per CU");
+        static unsigned long long scene_configured = 0ull;
+        if (hipError_t e = ensure_dynamic_lds((const void*)articulation_scene_substep_kernel, lds, &scene_configured); e != hipSuccess) return e;
+        for (int i = 0; i < P.substeps; ++i)
+            hipLaunchKernelGGL(articulation_scene_substep_kernel, dim3((v.N + SCENE_LANES - 1) / SCENE_LANES), dim3(SCENE_LANES), lds, s, v, P, p);
         return hipGetLastError();
     }
     constexpr size_t lds = rows_fit_lds<AM>() ? lds_bytes<AM>() : 0;

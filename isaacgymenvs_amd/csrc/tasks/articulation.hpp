@@ -12,23 +12,27 @@ struct ArticulationParams {   // mirrors MiArticulationParams (include/mi_engine
     float max_angular_velocity;
     float init_root[13];
     SceneParams scene;        // free / static boxes beside the actor (MiScene); n_free = n_static = 0: the actor alone on the ground plane
-    float drive_vmax[kMaxDof];   // scenes: velocity limit of each dof's position drive (<= 0: none)
+    float drive_vmax[kMaxDof];   // scenes: the asset's velocity limit of each dof (<= 0: none): clamp of the solved joint velocity; bound of a position drive's approach speed
 };
 
-// gym.simulate() of an env that holds more than the actor (core/scene_engine.hpp): one sub-step of env e.  The row store of this form is a
-// per-lane array (scratch on the device): the scene's contact slots are sized for a table top, not for the LDS.
+// gym.simulate() of an env that holds more than the actor (core/scene_engine.hpp): one sub-step of env e.  rows: the row store (device: LDS
+// [slot][lane], host: a per-env array); warm: last sub-step's (feature, impulses) per contact slot, read and rewritten (device: staged in LDS by the
+// kernel, host: the tensor itself).
 static inline bool articulation_has_scene(const ArticulationParams& p) { return p.scene.n_free + p.scene.n_static > 0; }
-template <class M>
-MI_HD void articulation_scene_substep_env(const View& v, const SimParams& P, const ArticulationParams& p, const int e) {
+// floats of the scene form's row store (1 for a floating-base robot, which has no scene form: SceneSim<M> is never instantiated for it)
+template <class M, bool F = (M::FIXED == 1)> struct SceneRows { static constexpr int value = 1; };
+template <class M> struct SceneRows<M, true> { static constexpr int value = SceneSim<M>::ROW_SLOTS; };
+template <class M, int RS>
+MI_HD void articulation_scene_substep_env(const View& v, const SimParams& P, const ArticulationParams& p, const int e, const RowStore<RS> rows, const Strided warm) {
     constexpr int ND = M::ND;
     const int N = v.N;
     SceneSim<M> sim;
     sfor<13>([&](auto K) MI_LAMBDA { sim.root[K] = v.root[K * N + e]; });
-    float tau[M::NDA], target[M::NDA], kp[M::NDA], kd[M::NDA];
+    float tau[M::NDA], target[M::NDA], kp[M::NDA], kd[M::NDA], vmax[M::NDA];
     sfor<ND>([&](auto K) MI_LAMBDA {
         sim.q[K] = v.dof[K * N + e]; sim.qd[K] = v.dof[(ND + K) * N + e];
         tau[K] = v.tau[K * N + e]; target[K] = v.targets[K * N + e];
-        kp[K] = p.kp[K]; kd[K] = p.kd[K];
+        kp[K] = p.kp[K]; kd[K] = p.kd[K]; vmax[K] = p.drive_vmax[K];
         // a velocity-limited drive: its position error is clamped to the error at which spring and damper balance at the limit speed
         // (kp e = kd vmax), so it approaches its target no faster than vmax and pushes with at most kd vmax
         if (p.drive_vmax[K] > 0.f && kp[K] > 0.f) {
@@ -42,9 +46,8 @@ MI_HD void articulation_scene_substep_env(const View& v, const SimParams& P, con
     Drive drv{0.f, 0.f, target, nullptr};
     drv.kpv = kp; drv.kdv = kd;
     const float h = P.dt / (float)P.substeps;
-    float rows[SceneSim<M>::ROW_SLOTS];
     int nc = 0;
-    sim.substep_scene(P, p.scene, tau, drv, h, RowStore<1>{rows}, Strided{v.laml + e, N}, Strided{v.dof_force + e, N}, &nc, Strided{v.scene_warm + e, N});
+    sim.substep_scene(P, p.scene, tau, drv, h, rows, Strided{v.laml + e, N}, Strided{v.dof_force + e, N}, &nc, warm, vmax);
     v.scene_nc[e] = nc & 0xFFFF;
     v.scene_nc[N + e] += nc >> 16;
     sfor<ND>([&](auto K) MI_LAMBDA { v.dof[K * N + e] = sim.q[K]; v.dof[(ND + K) * N + e] = sim.qd[K]; });

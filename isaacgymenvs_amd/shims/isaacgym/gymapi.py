@@ -954,9 +954,9 @@ class Gym:
             tp.max_angular_velocity = float(getattr(asset.options, "max_angular_velocity", 0.0) or 0.0)
             for k in range(7):
                 tp.init_root[k] = float(poses[0, k])
-            for d in range(nd):          # the asset's joint velocity limits bound the position drives (scenes; include/mi_engine.h drive_vmax)
+            for d in range(nd):          # the asset's joint velocity limits (scenes; include/mi_engine.h drive_vmax)
                 vm = float(dp["velocity"][d]) if "velocity" in dp.dtype.names else 0.0
-                tp.drive_vmax[d] = vm if (modes[d] == DOF_MODE_POS and 0.0 < vm < 1e6) else 0.0
+                tp.drive_vmax[d] = vm if 0.0 < vm < 1e6 else 0.0
             boxes = [(k, sl) for k, sl in enumerate(sim.slots) if sl["asset"].spec is None]
             sim.scene = None
             if boxes and spec.fixed_base:

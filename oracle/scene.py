@@ -233,6 +233,9 @@ class OracleSceneEngine:
                 sc = lim / max(nrm, 1e-30) if nrm > lim else 1.0
                 for rt, l in zip((ra, rb), lt):
                     apply(cdat, rt, l * sc - l); rt["lam"] = l * sc
+        for d in range(nd):                      # the asset's joint velocity limits: clamp of the solved velocities
+            if self.drive_vmax[d] > 0:
+                v[d] = min(max(v[d], -self.drive_vmax[d]), self.drive_vmax[d])
         # ---- outputs
         ll = np.zeros(nd)
         for r in rows:

@@ -50,4 +50,4 @@ for n in [int(a) for a in sys.argv[1:]] or [4096]:
     ds = (time.perf_counter() - t) / steps
     nc = env.sim.engine.tensors["scene_contacts"]
     print(f"FrankaCubeStack@{n} on {dev}: {dt * 1e3:.3f} ms per task step ({n / dt / 1e6:.3f} M env-steps/s), {ds * 1e3:.3f} ms per gym.simulate() (2 sub-steps); "
-          f"contacts per env {float(nc[:, 0].float().mean()):.1f}, refused since reset {int(nc[:, 1].sum())}; mean reward {float(env.rew_buf.mean()):.3f}")
+          f"contacts per env {float(nc[:, 0].float().mean()):.1f}, refused since reset {int(nc[:, 1].sum())}; mean reward {float(env.rew_buf.detach().mean()):.3f}, NaN envs {int(torch.isnan(env.obs_buf).any(dim=1).sum())}")
