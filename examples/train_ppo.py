@@ -66,6 +66,28 @@ def logp(mu, logstd, a):
     return (-0.5 * ((a - mu) / logstd.exp()) ** 2 - logstd - 0.9189385332046727).sum(-1)
 
 
+def reference_env(spec, task, num_envs, dev):
+    """one of the reference's own task classes, its file imported unmodified, on this engine through the `isaacgym` stand-in"""
+    import importlib
+    import types
+    import isaacgymenvs_amd.shims as shims
+    from isaacgymenvs_amd.utils.config import compose, omegaconf_to_dict
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref = os.environ.get("MI_REFERENCE_ROOT") or next((p for p in ("/root/reference", os.path.join(root, "ab", "ref_stage"))
+                                                        if os.path.isdir(os.path.join(p, "isaacgymenvs", "tasks"))), "/root/reference")
+    shims.install(force=True)
+    for name, rel in (("isaacgymenvs", "isaacgymenvs"), ("isaacgymenvs.tasks", "isaacgymenvs/tasks"), ("isaacgymenvs.utils", "isaacgymenvs/utils"),
+                      ("isaacgymenvs.tasks.base", "isaacgymenvs/tasks/base")):
+        mod = types.ModuleType(name)
+        mod.__path__ = [os.path.join(ref, rel)]
+        sys.modules[name] = mod
+    module, cls = spec.split(":")
+    m = importlib.import_module("isaacgymenvs.tasks." + module)
+    cfg = omegaconf_to_dict(compose("config", overrides=[f"task={task}"], cfg_dir=os.path.join(ref, "isaacgymenvs", "cfg"))["task"])
+    cfg["env"]["numEnvs"], cfg["sim"]["use_gpu_pipeline"] = num_envs, True
+    return getattr(m, cls)(cfg, rl_device=dev, sim_device=dev, graphics_device_id=-1, headless=True, virtual_screen_capture=False, force_render=False)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--task", default="Ant")
@@ -79,12 +101,17 @@ def main():
     ap.add_argument("--log", default="")
     ap.add_argument("--units", default="256,128,64", help="hidden layer sizes of the MLP (HumanoidPPO.yaml: 400,200,100)")
     ap.add_argument("--lr", type=float, default=3e-4)
+    ap.add_argument("--reference-task", default="", help="module:Class of one of the REFERENCE's own task files, run unmodified through the isaacgym stand-in "
+                    "(e.g. franka_cube_stack:FrankaCubeStack; the reference tree at MI_REFERENCE_ROOT, /root/reference or ab/ref_stage)")
     args = ap.parse_args()
 
     import isaacgymenvs_amd
     dev = "cuda:0"
     torch.manual_seed(args.seed)
-    env = isaacgymenvs_amd.make(seed=args.seed, task=args.task, num_envs=args.num_envs, sim_device=dev, rl_device=dev, headless=True)
+    if args.reference_task:
+        env = reference_env(args.reference_task, args.task, args.num_envs, dev)
+    else:
+        env = isaacgymenvs_amd.make(seed=args.seed, task=args.task, num_envs=args.num_envs, sim_device=dev, rl_device=dev, headless=True)
     N, T, A, O = args.num_envs, args.horizon, env.num_actions, env.num_obs
     net = ActorCritic(O, A, tuple(int(u) for u in args.units.split(","))).to(dev)
     opt = torch.optim.Adam(net.parameters(), lr=args.lr, eps=1e-8)
@@ -110,7 +137,7 @@ def main():
                 B["obs"][t], B["act"][t], B["logp"][t], B["mu"][t] = on, a, logp(mu, ls, a), mu
                 B["val"][t] = val_rms.denorm(v)
                 od, rew, done, extras = env.step(torch.clamp(a, -1.0, 1.0))
-                nobs = od["obs"].clone()
+                nobs, rew = od["obs"].clone(), rew.detach()
                 r = rew * args.reward_scale
                 # time-out bootstrapping (rl_games value_bootstrap): add gamma * V(s_T) for envs cut by the time limit
                 to = extras["time_outs"].float()
