@@ -37,8 +37,11 @@ __global__ __launch_bounds__(64) void articulation_substep_kernel(View v, SimPar
 // workgroups of 8, two resident per CU -- and the row store (8 KB per env: 48 contact slots) plus last sub-step's warm-start table live in LDS
 // as [slot][lane]: in a per-lane array (scratch) every one of the sub-step's ~10^4 row accesses was a trip to memory (2.1 ms per sub-step at any
 // batch size, profiles/r5t_scene_time.txt).
-constexpr int SCENE_LANES = 8, SCENE_WARM = 4 * 48;
+constexpr int SCENE_WARM = 4 * 48;
 constexpr int SCENE_ROWS = SceneRows<AM>::value;
+// (a robot with long kinematic chains has wider contact slots: the Kuka + Allegro's 23 dofs need 99 KB at 8 envs -- one workgroup per CU then; 4 envs per
+//  workgroup if even that does not fit)
+constexpr int SCENE_LANES = ((size_t)(SCENE_ROWS + SCENE_WARM) * 8 * sizeof(float) <= 160 * 1024) ? 8 : 4;
 __global__ __launch_bounds__(64) void articulation_scene_substep_kernel(View v, SimParams P, ArticulationParams p) {
     extern __shared__ float lds_scene[];
     const int e = blockIdx.x * SCENE_LANES + threadIdx.x;
@@ -113,7 +116,7 @@ hipError_t launch_simulate_articulation(const View& v, const SimParams& P, const
     if (articulation_has_scene(p)) {
         if (AM::FIXED != 1) return hipErrorInvalidValue;
         constexpr size_t lds = (size_t)(SCENE_ROWS + SCENE_WARM) * SCENE_LANES * sizeof(float);
-        static_assert(lds <= 80 * 1024, "two scene workgroups per CU");
+        static_assert(lds <= 160 * 1024, "the scene's row store of one workgroup fits the LDS of a CU (two workgroups per CU up to 80 KB: the Franka's 80.5 KB)");
         static unsigned long long scene_configured = 0ull;
         if (hipError_t e = ensure_dynamic_lds((const void*)articulation_scene_substep_kernel, lds, &scene_configured); e != hipSuccess) return e;
         for (int i = 0; i < P.substeps; ++i)
