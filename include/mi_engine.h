@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define MI_MAX_DOF 32
-#define MI_ABI_VERSION 3
+#define MI_ABI_VERSION 4
 
 typedef struct MiEngine MiEngine;
 

@@ -38,9 +38,10 @@ SOURCES = ["mi_engine.hip", "kernels_cartpole.hip", "kernels_ant.hip", "kernels_
 MI_MAX_DOF = 32
 # include/mi_engine.h MI_ABI_VERSION: bumped whenever the arena layout, a parameter struct or an export changes (2: round 4 -- cumulative
 # episode statistics tensors, per-body actor scales, rigid_body_state; 3: round 5 -- compensated cumulative statistics (episode_cum_stats [32],
-# reward_workspace [8]), hand_pair_count, hand_body_mass_scale).  A library of another version is refused when it is loaded, and a state
+# reward_workspace [8]), hand_pair_count, hand_body_mass_scale; 4: round 5, scenes -- MiArticulationParams.scene / drive_vmax, scene_state, scene_contacts,
+# scene_warm).  A library of another version is refused when it is loaded, and a state
 # checkpoint (VecTask.get_env_state) carries the version + arena size it was taken with.
-MI_ABI_VERSION = 3
+MI_ABI_VERSION = 4
 
 # -fno-slp-vectorize: pairing scalars into v_pk_* ops lengthens live ranges in the fully unrolled sub-step
 # (Ant: 230 -> 40 spilled VGPRs without it)

@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert declared == set(native.EXPORTS), declared ^ set(native.EXPORTS)
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.mi_abi_version() == native.MI_ABI_VERSION == 3
+    assert lib.mi_abi_version() == native.MI_ABI_VERSION == 4
 
 
 def test_task_info_and_unknown_task(lib):
