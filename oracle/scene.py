@@ -223,16 +223,12 @@ class OracleSceneEngine:
                         apply(cdat, r, r["lam"])
                 ln = max(rn["lam"] - (rowvel(cdat, rn) - cdat["vtn"]) * rn["Ainv"], 0.0)
                 apply(cdat, rn, ln - rn["lam"]); rn["lam"] = ln
-                lt = []
-                for rt in (ra, rb):
-                    dl = -rowvel(cdat, rt) * rt["Ainv"]
-                    lt.append(rt["lam"] + dl)
-                    apply(cdat, rt, dl)
+                lt = [rt["lam"] - rowvel(cdat, rt) * rt["Ainv"] for rt in (ra, rb)]        # both tangent rows from the same velocity
                 lim = cdat["mu"] * ln
                 nrm = np.hypot(lt[0], lt[1])
                 sc = lim / max(nrm, 1e-30) if nrm > lim else 1.0
                 for rt, l in zip((ra, rb), lt):
-                    apply(cdat, rt, l * sc - l); rt["lam"] = l * sc
+                    apply(cdat, rt, l * sc - rt["lam"]); rt["lam"] = l * sc
         for d in range(nd):                      # the asset's joint velocity limits: clamp of the solved velocities
             if self.drive_vmax[d] > 0:
                 v[d] = min(max(v[d], -self.drive_vmax[d]), self.drive_vmax[d])

@@ -228,6 +228,106 @@ def test_scene_hip_matches_the_cpu_backend_on_every_env_of_a_ragged_batch():
     assert np.median(nh[:, 0]) >= 8 and nh[:, 0].max() > 12        # most cubes already on 4 corners each (tilted / dropped ones are still coming down); stacks / fingers add contacts
 
 
+def _ramp(device, angle_deg, n=2):
+    """a scene whose second static box is a RAMP: a 0.6 x 0.6 x 0.04 m slab pitched by `angle_deg` about y, with a cube lying on it"""
+    import isaacgymenvs_amd.shims as shims
+    from isaacgymenvs_amd import native
+    if device == "cpu":
+        native.build_cpu()
+    shims.install(force=True)
+    from isaacgym import gymapi
+    gym = gymapi.acquire_gym()
+    sp = gymapi.SimParams()
+    sp.up_axis, sp.gravity, sp.dt, sp.substeps, sp.use_gpu_pipeline = gymapi.UP_AXIS_Z, gymapi.Vec3(0, 0, -9.81), 1 / 60.0, 2, device != "cpu"
+    sp.physx.num_position_iterations, sp.physx.num_velocity_iterations = 8, 1
+    sp.physx.contact_offset, sp.physx.rest_offset = 0.005, 0.0
+    sim = gym.create_sim(0, -1, gymapi.SIM_PHYSX, sp)
+    gym.add_ground(sim, gymapi.PlaneParams())
+    opts = gymapi.AssetOptions()
+    opts.flip_visual_attachments, opts.fix_base_link, opts.collapse_fixed_joints, opts.disable_gravity = True, True, False, True
+    opts.thickness, opts.default_dof_drive_mode, opts.use_mesh_materials = 0.001, gymapi.DOF_MODE_EFFORT, True
+    franka = gym.load_asset(sim, os.path.join(REF, "assets"), "urdf/franka_description/robots/franka_panda_gripper.urdf", opts)
+    fixed = gymapi.AssetOptions(); fixed.fix_base_link = True
+    slab = gym.create_box(sim, 0.6, 0.6, 0.04, fixed)
+    cube = gym.create_box(sim, SIZE_A, SIZE_A, SIZE_A, gymapi.AssetOptions())
+    for a_ in (slab, cube):                     # shape friction 0.5 on both sides (the way ant.py / anymal_terrain.py set it on their assets)
+        pr = gym.get_asset_rigid_shape_properties(a_)
+        pr[0].friction = 0.5
+        gym.set_asset_rigid_shape_properties(a_, pr)
+    th = np.radians(angle_deg)
+    q = gymapi.Quat(0.0, float(np.sin(th / 2)), 0.0, float(np.cos(th / 2)))               # pitch about +y: the slab's +x end goes DOWN
+    nrm = np.array([np.sin(th), 0.0, np.cos(th)])                                         # its upper face's normal
+    c0 = np.array([0.5, 0.0, 1.0])
+    pc = c0 + nrm * (0.02 + SIZE_A / 2)                                                   # the cube's centre, resting on the face
+    for i in range(n):
+        env = gym.create_env(sim, gymapi.Vec3(), gymapi.Vec3(), 2)
+        gym.create_actor(env, franka, gymapi.Transform(gymapi.Vec3(-1.5, 0.0, 1.0)), "franka", i, 0, 0)       # far away
+        gym.create_actor(env, slab, gymapi.Transform(gymapi.Vec3(*c0), q), "ramp", i, 1, 0)
+        gym.create_actor(env, cube, gymapi.Transform(gymapi.Vec3(*pc), q), "cube", i, 2, 0)
+    gym.prepare_sim(sim)
+    root = gym.acquire_actor_root_state_tensor(sim).view(n, 3, 13)
+    return gym, sim, root, th, pc
+
+
+def _known_answers(device):
+    """first-principles answers of the box contacts: (1) on a ramp below the friction angle (mu = 0.5: 26.6 degrees) a cube stays put; (2) above it, it
+    slides down with a = g (sin th - mu cos th) (mu < 1: the resultant stays inside the cube's base, it does not tip); (3) a cube sliding on the level table
+    at v0 stops after v0^2 / (2 mu g); (4) a cube dropped from h reaches the table after sqrt(2 h / g) and does not bounce"""
+    g = 9.81
+    gym, sim, root, th, pc = _ramp(device, 20.0)
+    for _ in range(60):
+        gym.simulate(sim)
+    gym.refresh_actor_root_state_tensor(sim)
+    x = root[:, 2].cpu().numpy()
+    assert sim.engine._tp.scene.free_mu[0] == 0.5 and sim.engine._tp.scene.static_mu[0] == 0.5
+    assert np.abs(x[:, 0:3] - pc).max() < 1.5e-3 and np.abs(x[:, 7:10]).max() < 0.01, (x[0, :3], pc)          # (1) static friction holds at 20 degrees
+    gym, sim, root, th, pc = _ramp(device, 40.0)
+    T = 24
+    for _ in range(T):
+        gym.simulate(sim)
+    gym.refresh_actor_root_state_tensor(sim)
+    x = root[:, 2].cpu().numpy()
+    a = g * (np.sin(th) - 0.5 * np.cos(th))                                                # (2) 2.55 m/s^2 down the slope
+    t = T / 60.0
+    down = np.array([np.cos(th), 0.0, -np.sin(th)])
+    s = (x[:, 0:3] - pc) @ down
+    v = x[:, 7:10] @ down
+    assert np.abs(v - a * t).max() < 0.05 * a * t and np.abs(s - 0.5 * a * t * t).max() < 0.08 * 0.5 * a * t * t + 1e-3, (s, 0.5 * a * t * t, v, a * t)
+    assert np.abs((x[:, 0:3] - pc) @ np.array([np.sin(th), 0.0, np.cos(th)])).max() < 1.5e-3                    # ... staying on the face
+    # (3), (4): the table scene
+    n = 2
+    gym, sim, franka, dp = _build(device, n)
+    _arm_home(gym, sim, n)
+    a_, b_ = np.zeros((n, 13)), np.zeros((n, 13))
+    a_[:, 6] = b_[:, 6] = 1.0
+    a_[:, 0:3] = [0.0, -0.3, TOP + SIZE_A / 2]; a_[:, 7] = 0.6                             # slides along +x at 0.6 m/s
+    h = 0.12
+    b_[:, 0:3] = [0.3, 0.3, TOP + SIZE_B / 2 + h]                                          # dropped from 12 cm
+    root = _place(gym, sim, n, a_, b_)
+    t_hit, vmax_up = None, 0.0
+    for k in range(90):
+        gym.simulate(sim)
+        gym.refresh_actor_root_state_tensor(sim)
+        zb, vzb = float(root[0, 4, 2]), float(root[0, 4, 9])
+        if t_hit is None and zb < TOP + SIZE_B / 2 + 2e-3:
+            t_hit = (k + 1) / 60.0
+        if t_hit is not None:
+            vmax_up = max(vmax_up, vzb)
+    A = root[:, 3].cpu().numpy()
+    d_stop = 0.6 ** 2 / (2 * 1.0 * g)                                                      # 18.3 mm
+    assert np.abs(A[:, 0] - d_stop).max() < 0.15 * d_stop + 1e-3 and np.abs(A[:, 7:10]).max() < 5e-3, (A[:, 0], d_stop)
+    assert abs(t_hit - np.sqrt(2 * h / g)) < 1.5 / 60.0 and vmax_up < 0.05, (t_hit, np.sqrt(2 * h / g), vmax_up)      # inelastic landing on time
+
+
+def test_scene_first_principles_known_answers_cpu():
+    _known_answers("cpu")
+
+
+@pytest.mark.gpu
+def test_scene_first_principles_known_answers_hip():
+    _known_answers("cuda:0")
+
+
 def _ori_err(qd_, q_):
     """rotation vector that takes orientation q_ to qd_ (xyzw): 2 vec(qd * conj(q)), the shorter way round"""
     x1, y1, z1, w1 = qd_.unbind(-1)
@@ -339,14 +439,24 @@ def _grasp(device):
     A = root[:, 3].cpu().numpy()
     assert (A[:, 2] > TOP + SIZE_A / 2 + 0.13).all(), A[:, 2]                              # the cube came along
     assert np.abs(A[:, 2] - osc.rb[:, osc.site, 2].cpu().numpy()).max() < 0.01            # ... between the finger tips
-    for step in range(150):
-        osc.step([hx, 0.16 * min(step, 100) / 100.0, TOP + 0.277], 0.0)                   # carry it over cube B
+    def over_b(z, fingers, steps, ramp):
+        """servo the hand so that CUBE A (its position is an observation of the task) comes over cube B: the cube does not sit exactly at the grip site"""
+        gym.refresh_rigid_body_state_tensor(sim)
+        start = osc.rb[:, osc.hb, 0:3].clone()
+        for step in range(steps):
+            gym.refresh_actor_root_state_tensor(sim)
+            want = osc.rb[:, osc.hb, 0:2] + (root[:, 4, 0:2] - root[:, 3, 0:2])
+            f = min(step, ramp) / float(ramp)
+            goal = torch.cat([start[:, 0:2] + f * (want - start[:, 0:2]), torch.full((n, 1), z(step), device=sim.device)], dim=1)
+            osc.step(goal, fingers)
+    over_b(lambda k: TOP + 0.277, 0.0, 150, 100)                                           # carry it over cube B
+    over_b(lambda k: TOP + 0.277 - 0.078 * min(k, 60) / 60.0, 0.0, 80, 1)                  # down until it stands on B
+    gym.refresh_rigid_body_state_tensor(sim)
+    hold = osc.rb[:, osc.hb, 0:3].clone()
     for step in range(80):
-        osc.step([hx, 0.16, TOP + 0.277 - 0.078 * min(step, 60) / 60.0], 0.0)             # down until it stands on B
-    for step in range(80):
-        osc.step([hx, 0.16, TOP + 0.199], 0.04)                                            # let go
+        osc.step(hold, 0.04)                                                               # let go
     for step in range(60):
-        osc.step([hx, 0.16, TOP + 0.30], 0.04)                                             # and retreat
+        osc.step(torch.cat([hold[:, 0:2], torch.full((n, 1), TOP + 0.30, device=sim.device)], dim=1), 0.04)      # and retreat
     gym.refresh_actor_root_state_tensor(sim)
     A, Bc = root[:, 3].cpu().numpy(), root[:, 4].cpu().numpy()
     assert np.abs(A[:, 2] - (TOP + SIZE_B + SIZE_A / 2)).max() < 4e-3, A[:, 2]             # stacked
