@@ -565,7 +565,37 @@ class Gym:
         return len(env.sim.attractors) - 1
 
     def get_rigid_transform(self, env, handle):
-        return Transform()
+        """pose of a rigid body of the env (env-domain handle: find_actor_rigid_body_handle) in the env's frame -- franka_cabinet.py:262,308-310 asks for
+        link poses while the envs are being created.  With the engine alive: the body's row of the rigid-body state tensor; before prepare_sim: the
+        actor's start pose carried down the kinematic tree at zero joint positions."""
+        from ...assets.model import mat_to_quat, quat_to_mat
+        sim = env.sim
+        k, b = 0, int(handle)
+        while k < len(sim.slots) and b >= len(sim.slots[k]["asset"].body_names):
+            b -= len(sim.slots[k]["asset"].body_names)
+            k += 1
+        if k >= len(sim.slots):
+            raise IndexError(f"gym.get_rigid_transform: the env has no rigid body {handle}")
+        a, e = sim.slots[k]["asset"], min(env.index, len(sim.slots[k]["poses"]) - 1)
+        if sim.engine is not None:
+            self.refresh_rigid_body_state_tensor(sim)
+            row = sim.bufs["rb"].view(len(sim.envs), -1, 13)[env.index, int(handle)].cpu().numpy()
+            return Transform(Vec3(*row[0:3]), Quat(*row[3:7]))
+        ps = np.asarray(sim.slots[k]["poses"][e], float)
+        R, p = quat_to_mat(ps[3:7]), ps[0:3].copy()
+        if a.spec is not None:
+            sp, dyn = a.spec, int(a.body_dyn[b])
+            chain = []
+            j = dyn
+            while j > 0:
+                chain.append(j)
+                j = int(sp.parent[j])
+            for j in reversed(chain):                  # zero joint positions: a body sits at its rest offset in its parent's frame
+                p = p + R @ np.asarray(sp.bpos[j], float)
+                R = R @ quat_to_mat(np.asarray(sp.bquat[j], float))
+            p = p + R @ np.asarray(a.body_off_p[b], float)
+            R = R @ quat_to_mat(np.asarray(a.body_off_q[b], float))
+        return Transform(Vec3(*p), Quat(*mat_to_quat(R)))
 
     def debug_print_asset(self, asset):
         print(f"asset: bodies {asset.body_names}")
@@ -1117,8 +1147,9 @@ class Gym:
         root = torch.zeros((n, 13), dtype=torch.float32)
         root[:, :7] = poses
         root = root.to(sim.device)
-        if asset.spec.fixed_base:
+        if asset.spec.fixed_base and not asset.generic:
             root[:, :7] = t["root_states"][:, :7]        # a fixed base stays where the engine mounts it (the rail of the cart-pole, the hand's mount)
+        # (a fixed-base Articulation robot stands where each env's create_actor put it: franka_cube_stack.py:314-323 may draw a start pose per env)
         t["root_states"][:] = root
         if "initial_root_states" in t:
             t["initial_root_states"][:] = root

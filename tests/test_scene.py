@@ -228,6 +228,52 @@ def test_scene_hip_matches_the_cpu_backend_on_every_env_of_a_ragged_batch():
     assert np.median(nh[:, 0]) >= 8 and nh[:, 0].max() > 12        # most cubes already on 4 corners each (tilted / dropped ones are still coming down); stacks / fingers add contacts
 
 
+def test_get_rigid_transform_before_and_after_prepare_sim_cpu():
+    """gym.get_rigid_transform (franka_cabinet.py:262,308-310 calls it while the envs are being created): the start pose carried down the tree at zero joint
+    positions before the engine exists, the rigid-body state tensor's row afterwards -- the same poses while the joints are at zero"""
+    import isaacgymenvs_amd.shims as shims
+    from isaacgymenvs_amd import native
+    native.build_cpu()
+    shims.install(force=True)
+    from isaacgym import gymapi
+    gym = gymapi.acquire_gym()
+    sp = gymapi.SimParams()
+    sp.up_axis, sp.gravity, sp.dt, sp.substeps, sp.use_gpu_pipeline = gymapi.UP_AXIS_Z, gymapi.Vec3(0, 0, -9.81), 1 / 60.0, 2, False
+    sim = gym.create_sim(0, -1, gymapi.SIM_PHYSX, sp)
+    gym.add_ground(sim, gymapi.PlaneParams())
+    opts = gymapi.AssetOptions()
+    opts.flip_visual_attachments, opts.fix_base_link, opts.collapse_fixed_joints, opts.disable_gravity = True, True, False, True
+    opts.thickness, opts.default_dof_drive_mode, opts.use_mesh_materials = 0.001, gymapi.DOF_MODE_EFFORT, True
+    franka = gym.load_asset(sim, os.path.join(REF, "assets"), "urdf/franka_description/robots/franka_panda_gripper.urdf", opts)
+    cube = gym.create_box(sim, SIZE_A, SIZE_A, SIZE_A, gymapi.AssetOptions())
+    yaw = gymapi.Quat(0.0, 0.0, float(np.sin(0.3)), float(np.cos(0.3)))
+    names = ("panda_link0", "panda_link4", "panda_hand", "panda_leftfinger_tip", "panda_grip_site")
+    before = {}
+    for i in range(2):
+        env = gym.create_env(sim, gymapi.Vec3(), gymapi.Vec3(), 2)
+        h = gym.create_actor(env, franka, gymapi.Transform(gymapi.Vec3(-0.45, 0.1 * i, 1.0), yaw), "franka", i, 0, 0)
+        c = gym.create_actor(env, cube, gymapi.Transform(gymapi.Vec3(0.2, 0.0, 1.2)), "cube", i, 1, 0)
+        for nm in names:
+            t = gym.get_rigid_transform(env, gym.find_actor_rigid_body_handle(env, h, nm))
+            before[(i, nm)] = np.array([t.p.x, t.p.y, t.p.z, t.r.x, t.r.y, t.r.z, t.r.w])
+        t = gym.get_rigid_transform(env, gym.find_actor_rigid_body_handle(env, c, "box"))
+        before[(i, "box")] = np.array([t.p.x, t.p.y, t.p.z, t.r.x, t.r.y, t.r.z, t.r.w])
+    assert np.allclose(before[(0, "panda_link0")], [-0.45, 0.0, 1.0, 0.0, 0.0, np.sin(0.3), np.cos(0.3)], atol=1e-6)
+    assert np.allclose(before[(1, "box")], [0.2, 0.0, 1.2, 0, 0, 0, 1]) and before[(0, "panda_hand")][2] > 1.5       # the arm stands straight up at q = 0
+    gym.prepare_sim(sim)
+    ds = torch.zeros((2 * 9, 2))
+    gym.set_dof_state_tensor(sim, ds)                  # (reset leaves the fingers at their lower limit 0 and the arm inside its limits: q = 0 where allowed)
+    q = gym.acquire_dof_state_tensor(sim).view(2, 9, 2)[0, :, 0].numpy()
+    zero = np.abs(q).max() < 1e-6
+    for (i, nm), want in before.items():
+        env = sim.envs[i]
+        k = 1 if nm == "box" else 0
+        t = gym.get_rigid_transform(env, gym.find_actor_rigid_body_handle(env, k, nm))
+        got = np.array([t.p.x, t.p.y, t.p.z, t.r.x, t.r.y, t.r.z, t.r.w])
+        if zero or nm in ("panda_link0", "box"):
+            assert np.abs(got[:3] - want[:3]).max() < 1e-4 and min(np.abs(got[3:] - want[3:]).max(), np.abs(got[3:] + want[3:]).max()) < 1e-4, (nm, got, want)
+
+
 def _ramp(device, angle_deg, n=2):
     """a scene whose second static box is a RAMP: a 0.6 x 0.6 x 0.04 m slab pitched by `angle_deg` about y, with a cube lying on it"""
     import isaacgymenvs_amd.shims as shims
