@@ -673,6 +673,14 @@ class Gym:
             made.add(env.index)
             if env.index == 0:
                 sl["dof_props"] = np.array(props, copy=True)
+            elif "dof_props" in sl and not sl.get("dof_props_warned"):
+                ref = sl["dof_props"]
+                if any(not np.array_equal(np.asarray(props[k]), np.asarray(ref[k])) for k in ("driveMode", "stiffness", "damping")):
+                    # (only env 0's creation-time properties reach the engine's task parameters -- say so when another env's differ)
+                    import warnings
+                    warnings.warn(f"gym.set_actor_dof_properties: env {env.index} sets other drive modes / gains than env 0 while the actor is being "
+                                  "created; the engine's drives are task parameters shared by all envs (env 0's are used)")
+                    sl["dof_props_warned"] = True
             return True
         if actor != sim.robot:
             return True
