@@ -17,11 +17,13 @@ Rank 0 prints ONE JSON line.
               around each group on the launch stream (a second pass right after the timed one), against the 8 TB/s
               HBM3E peak.  `traffic` = calibrated FETCH_SIZE + WRITE_SIZE of the group from the rocprofv3 PMC passes of this
               command, read from profiles/traffic.json (written by tools/summarize_profile.py; null when the file has no entry).
-  cpu_baseline = the CPU oracle (oracle/physics.c via oracle/tasks.py, OpenMP over envs) on a bounded sample of the
-              same workload on this host's cores ("port": the reference's PhysX-CPU path cannot run).
-              `cpu_baseline.product_backend` = the engine's own g++ host build through make(seed, task, N, "cpu", "cpu") at 4 and all threads.
-              `cpu_baseline.reference_jit_fns` = the reference's own jitted obs / reward functions on torch-CPU, from MI_REFERENCE_ROOT, /root/reference
-              (development container) or the task files staged for the stand-in tests under ab/ref_stage (GPU box); else marked absent.
+  cpu_baseline = `value`: the engine's own g++ host build through make(seed, task, N, "cpu", "cpu") -- the reference's sim_device=cpu pipeline=cpu call --
+              at the reference's `num_threads: 4` (cfg/config.yaml:30), on a bounded sample of the same workload ("port": the reference's PhysX-CPU
+              path cannot run, BASELINE.md 2).  `cpu_baseline.product_backend` = that leg at 4 and all threads;
+              `cpu_baseline.oracle_port` = the CPU oracle (oracle/physics.c via oracle/tasks.py, OpenMP over envs), thread sweep, `threads_4` first class;
+              `cpu_baseline.reference_jit_fns` = the reference's own jitted obs / reward functions on torch-CPU at 1 and 4 torch threads,
+              from MI_REFERENCE_ROOT, /root/reference (development container) or the task files staged for the stand-in tests under ab/ref_stage
+              (GPU box); else marked absent.
   extra     = the second headline config (Humanoid num_envs=8192, self-collision on) measured the same way in the same run, at every N;
               extra2 / extra3 = AnymalTerrain@4096 and ShadowHand@16384 (N = 1), or their per-GPU shards 512 / 2048 (N > 1).
               The side legs time max(K / 4, 200) steps after max(W / 4, 50) warm-ups whatever the driver's K / W are, so that a short
@@ -322,15 +324,28 @@ def reference_jit_leg(task, num_envs, budget_s=4.0):
                                              args["lo"], args["up"], 0.2, args["sens"], args["act"], 0.0166, 0.1, args["b0"], args["b1"], 2)
             mod.compute_ant_reward(o[0], torch.zeros(n, dtype=torch.long), torch.zeros(n, dtype=torch.long), args["act"], 0.1, 0.5, o[1], o[2],
                                    0.005, 0.05, 0.1, 0.31, -2.0, 1000.0)
-        for _ in range(3):
-            once()
-        k, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < budget_s:
-            once(); k += 1
-        dt = time.perf_counter() - t0
-        return {"value": n * k / dt, "unit": "env-steps/s (obs + reward only)", "cores": torch.get_num_threads(), "kind": "reference",
-                "sample": f"{k} calls of the reference's jitted compute_ant_observations + compute_ant_reward (ant.py:325-408) on torch-CPU, "
-                          f"{n} envs, {dt:.1f} s -- the obs / reward share only; its physics (PhysX-CPU) cannot run here", "reference_root": ref}
+        # BASELINE.md 3 prescribes the thread counts k in {1, 4, all}; "all" on a 256-thread host is an oversubscription artefact for a
+        # 4096 x 60 problem (6.7 k env-steps/s in round 5, 90x below the 1-thread figure), so the leg reports 1 and 4 (the reference's
+        # `num_threads: 4`, cfg/config.yaml:30) and sets torch's intra-op thread count itself
+        threads_before = torch.get_num_threads()
+        legs = {}
+        try:
+            for c in (1, 4):
+                torch.set_num_threads(c)
+                for _ in range(3):
+                    once()
+                k, t0 = 0, time.perf_counter()
+                while time.perf_counter() - t0 < budget_s / 2:
+                    once(); k += 1
+                dt = time.perf_counter() - t0
+                legs[c] = {"value": n * k / dt, "calls": k, "seconds": round(dt, 2)}
+        finally:
+            torch.set_num_threads(threads_before)
+        return {"value": legs[4]["value"], "unit": "env-steps/s (obs + reward only)", "cores": 4, "kind": "reference",
+                "threads_1": legs[1], "threads_4": legs[4],
+                "sample": f"{legs[4]['calls']} calls of the reference's jitted compute_ant_observations + compute_ant_reward (ant.py:325-408) on torch-CPU "
+                          f"(torch.set_num_threads(4); threads_1: the same at 1 thread), {n} envs, {legs[4]['seconds']:.1f} s -- the obs / reward share "
+                          f"only; its physics (PhysX-CPU) cannot run here", "reference_root": ref}
     except Exception as ex:  # noqa: BLE001 -- a missing / changed reference tree must not break the bench line
         return {"absent": f"{type(ex).__name__}: {ex}"[:200]}
 
@@ -518,7 +533,8 @@ def main():
         "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.task} num_envs={n_env} per GPU ({world * n_env} total), VecTask.step() via Python API, "
-                               f"actions = 2*torch.rand-1 drawn before every step (README.md:48-51), seed 42+rank",
+                               f"actions = 2*torch.rand-1 drawn before every step (README.md:48-51), seed 42+rank; {settle} untimed settle steps "
+                               f"(>= 0.5 s of back-to-back stepping) precede the {args.warmup} warm-ups",
                    "task": args.task, "num_envs_per_gpu": n_env, "parallelism": f"env-shard x{world}",
                    "multi_wave": main_res["multi_wave"], "fused_sub": main_res["fused_sub"], "fused_post": main_res.get("fused_post", 0)},
         "settle": settle, "consistent": main_res["consistent"],
@@ -563,10 +579,23 @@ def main():
             out["extra3"]["job_stats"] = extra3["job_stats"]
     out["box"] = box_probe(device)
     if world == 1 and not args.no_cpu_baseline and args.task in ("Ant", "Humanoid"):
-        out["cpu_baseline"] = cpu_baseline(args.task, n_env, budget_s=args.cpu_budget)
+        # `value` = the like-for-like figure: the engine's own CPU backend through make(..., "cpu", "cpu") at the reference's `num_threads: 4`
+        # (cfg/config.yaml:30).  The oracle port's thread sweep and the reference's own jitted functions are nested beside it.
+        port = cpu_baseline(args.task, n_env, budget_s=args.cpu_budget)
+        prod = cpu_product_backend(args.task, n_env, budget_s=min(args.cpu_budget, 8.0))
         leg = reference_jit_leg(args.task, n_env)
-        out["cpu_baseline"]["reference_jit_fns"] = leg if leg is not None else {"absent": "/root/reference is not reachable on this host"}
-        out["cpu_baseline"]["product_backend"] = cpu_product_backend(args.task, n_env, budget_s=min(args.cpu_budget, 8.0))
+        if "threads_4" in prod:
+            cb = {"value": prod["threads_4"]["value"], "unit": "env-steps/s", "cores": 4, "kind": "port",
+                  "sample": f"{prod['threads_4']['steps']} steps of {args.task} num_envs={n_env} through make(seed, task, N, 'cpu', 'cpu') -- the engine's own host "
+                            f"build (libmi_engine_cpu.so, OpenMP over envs) at the reference's sim.physx.num_threads = 4, {prod['threads_4']['seconds']} s; "
+                            f"stand-in for the reference's PhysX-CPU pipeline, which cannot run here"}
+        else:       # (no CPU library on this host: the oracle port at 4 threads, or at its best count)
+            src = port.get("threads_4", port)
+            cb = {"value": src["value"], "unit": "env-steps/s", "cores": src.get("cores", port["cores"]), "kind": "port", "sample": port["sample"]}
+        cb["product_backend"] = prod
+        cb["oracle_port"] = port
+        cb["reference_jit_fns"] = leg if leg is not None else {"absent": "/root/reference is not reachable on this host"}
+        out["cpu_baseline"] = cb
     sys.stdout.flush()
     print(json.dumps(out), file=json_out, flush=True)
     if dist.is_initialized():

@@ -124,6 +124,7 @@ typedef struct {
  * the one Gauss-Seidel solve, csrc/core/scene_engine.hpp); their root states live in tensor "scene_state" [N, MI_SCENE_MAX_FREE, 13]. */
 #define MI_SCENE_MAX_FREE 4
 #define MI_SCENE_MAX_STATIC 4
+#define MI_SCENE_WARM_SLOTS 48 /* entries per env of tensor "scene_warm": one per contact slot of the scene solve (24 actor + 24 box contacts) */
 typedef struct {
     int32_t n_free, n_static;              /* 0, 0: no scene -- the actor alone on the ground plane (its spheres against the plane) */
     int32_t arm_gravity;                   /* 0: asset option disable_gravity on the articulated actor (franka_cube_stack.py:199); the boxes feel the sim's */

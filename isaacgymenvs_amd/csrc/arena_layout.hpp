@@ -156,7 +156,7 @@ static void build_layout(int task, int N, Layout& L, View* v, char* base, int no
         o = L.add("scene_state", MI_F32, {n, nfb, 13}, {1, 13 * n, n}, 13 * nfb * n); if (v) v->scene = (float*)P(o);
         o = L.add("scene_contacts", MI_I32, {n, 2}, {1, n}, 2 * n); if (v) v->scene_nc = (int*)P(o);
         // warm start of the scene's contacts: (feature id as int bits, impulses x 3) of every contact slot of the last sub-step (SceneSim::KSLOT = 48)
-        o = L.add("scene_warm", MI_F32, {n, 48, 4}, {1, 4 * n, n}, 4 * 48 * n); if (v) v->scene_warm = (float*)P(o);
+        o = L.add("scene_warm", MI_F32, {n, MI_SCENE_WARM_SLOTS, 4}, {1, 4 * n, n}, 4 * MI_SCENE_WARM_SLOTS * n); if (v) v->scene_warm = (float*)P(o);
     }
     if (task == T_ANYMAL_FLAT) {   // anymal.py:100-125
         const int64_t nb = m.nb;

@@ -301,21 +301,18 @@ struct BbotSim : Sim<M> {
                 const float ln = fmaxf(lc[0] - (vrow(I0{}) - vtn) * Ac[0], 0.f);
                 push(I0{}, ln - lc[0]);
                 lc[0] = ln;
-                float lt[2];
-                sfor<2>([&](auto K) MI_LAMBDA {
+                float lt[2], vtg[2];
+                sfor<2>([&](auto K) MI_LAMBDA {      // both tangent rows from the same velocity, then the disc (core/engine.hpp friction_disc), one application
                     using IK = std::integral_constant<int, 1 + decltype(K)::value>;
-                    const float dl = -vrow(IK{}) * Ac[1 + K];
-                    lt[K] = lc[1 + K] + dl;
-                    push(IK{}, dl);
+                    vtg[K] = vrow(IK{});
+                    lt[K] = lc[1 + K] - vtg[K] * Ac[1 + K];
                 });
-                const float lim = bp.mu * ln;
-                const float n2 = lt[0] * lt[0] + lt[1] * lt[1];
-                const float sc = (n2 > lim * lim) ? lim * MI_RSQ(fmaxf(n2, 1e-30f)) : 1.f;
+                friction_disc(lt, lc[1], lc[2], vtg[0], vtg[1], Ac[1], Ac[2], bp.mu * ln);
                 sfor<2>([&](auto K) MI_LAMBDA {
                     using IK = std::integral_constant<int, 1 + decltype(K)::value>;
-                    const float nl = lt[K] * sc;
+                    const float nl = lt[K], dl = nl - lc[1 + K];
                     lc[1 + K] = nl;
-                    push(IK{}, nl - lt[K]);
+                    push(IK{}, dl);
                 });
             }
         }

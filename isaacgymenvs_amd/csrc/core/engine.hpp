@@ -333,6 +333,34 @@ MI_HD void contact_frame(const float* n, float* t1, float* t2) {
     cross3(n, t1, t2);
 }
 
+// The tangential update of one contact (every engine form; oracle/physics.c friction_step states the same rule).  lt[] comes in as the per-row
+// step r_k = lam_k - v_k / a_kk of the two tangent rows, BOTH taken from the same velocity.  Inside the friction disc (|r| <= lim = mu ln: the
+// contact sticks) it stands.  A contact that slides takes ONE step size for both rows instead -- s_k = lam_k - v_k / max(a_11, a_22), never a longer
+// step than either row would take alone -- scaled back onto the disc.  Why: the fixed point of "step, radial projection" has the friction
+// antiparallel to D^-1 v_t, D = diag(a_11, a_22) -- Coulomb's law only when D is a multiple of the identity.  Until round 6 the rows kept their own
+// step sizes (and t1 was applied before t2 was looked at): a Humanoid lying on the ground, sliding at 31 degrees to the tangent axes, was braked along
+// 15 degrees; a cube on a 40 degree ramp slid with mu_eff 0.468 for mu 0.5 (tests/friction_util.py, tests/test_scene.py).  Between the two regimes
+// (|s| < lim < |r|) the result is the point of the segment s -> r that lies ON the circle, so that the update is a continuous function of its inputs
+// (a jump there would let fp32 and fp64 runs part at every stick / slip transition).  Branch-free.
+MI_HD void friction_disc(float (&lt)[2], const float lm1, const float lm2, const float v1, const float v2, const float ainv1, const float ainv2,
+                         const float lim) {
+    const float l2 = lim * lim;
+    const float r0 = lt[0], r1 = lt[1];
+    const bool stick = r0 * r0 + r1 * r1 <= l2;
+    const float ac = fminf(ainv1, ainv2);
+    const float s0 = lm1 - v1 * ac, s1 = lm2 - v2 * ac;
+    const float n2 = s0 * s0 + s1 * s1;
+    const bool slide = n2 >= l2;
+    const float sc = lim * MI_RSQ(fmaxf(n2, 1e-30f));
+    // in between: s + t (r - s) with |.| = lim, t in (0, 1]
+    const float d0 = r0 - s0, d1 = r1 - s1;
+    const float a = fmaxf(d0 * d0 + d1 * d1, 1e-30f), b = s0 * d0 + s1 * d1, c = n2 - l2;
+    const float t = (MI_SQRT(fmaxf(b * b - a * c, 0.f)) - b) * MI_RCP(a);
+    const float m0 = slide ? s0 * sc : s0 + t * d0, m1 = slide ? s1 * sc : s1 + t * d1;
+    lt[0] = stick ? r0 : m0;
+    lt[1] = stick ? r1 : m1;
+}
+
 // strided view of a per-env vector that lives in HBM as SoA [k][env] (device: stride = num_envs) or in a plain
 // array (host build: stride 1)
 struct Strided {
@@ -1643,20 +1671,18 @@ struct Sim {
                             lam(row0) = ln;
                             sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += B.g[0][C] * dl; });
                         }
-                        float lt[2];
+                        float lt[2], vtg[2];
+                        // both tangent rows from the SAME velocity, the disc (friction_disc), ONE application
                         sfor<2>([&](auto K) MI_LAMBDA {
                             float vn = 0.f;
                             sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { vn += B.g[1 + K][C] * w[M::chain[b][C]]; });
-                            const float dl = -vn * B.ainv[1 + K];
-                            lt[K] = B.lam[1 + K] + dl;
-                            sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += B.g[1 + K][C] * dl; });
+                            vtg[K] = vn;
+                            lt[K] = B.lam[1 + K] - vn * B.ainv[1 + K];
                         });
-                        const float lim = mu * ln;
-                        const float n2 = lt[0] * lt[0] + lt[1] * lt[1];
-                        const float sc = (n2 > lim * lim) ? lim * MI_RSQ(fmaxf(n2, 1e-30f)) : 1.f;  // select, no branch
+                        friction_disc(lt, B.lam[1], B.lam[2], vtg[0], vtg[1], B.ainv[1], B.ainv[2], mu * ln);
                         sfor<2>([&](auto K) MI_LAMBDA {
                             constexpr int row = row0 + 1 + K;
-                            const float nl = lt[K] * sc, dl = nl - lt[K];
+                            const float nl = lt[K], dl = nl - B.lam[1 + K];
                             lam(row) = nl;
                             sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += B.g[1 + K][C] * dl; });
                         });
@@ -1708,20 +1734,17 @@ struct Sim {
                         const float dl = ln - lm[0];
                         sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += g[0][C] * dl; });
                     }
-                    float lt[2];
-                    sfor<2>([&](auto K) MI_LAMBDA {
+                    float lt[2], vtg[2];
+                    sfor<2>([&](auto K) MI_LAMBDA {      // (both tangent rows from the same velocity, as above)
                         float vn = 0.f;
                         sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { vn += g[1 + K][C] * w[M::chain[b][C]]; });
-                        const float dl = -vn * ainv[1 + K];
-                        lt[K] = lm[1 + K] + dl;
-                        sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += g[1 + K][C] * dl; });
+                        vtg[K] = vn;
+                        lt[K] = lm[1 + K] - vn * ainv[1 + K];
                     });
-                    const float lim = mu * ln;
-                    const float n2 = lt[0] * lt[0] + lt[1] * lt[1];
-                    const float sc = (n2 > lim * lim) ? lim * MI_RSQ(fmaxf(n2, 1e-30f)) : 1.f;
+                    friction_disc(lt, lm[1], lm[2], vtg[0], vtg[1], ainv[1], ainv[2], mu * ln);
                     cb[(3 * M::MAXCHAIN + 4) * ST] = ln;
                     sfor<2>([&](auto K) MI_LAMBDA {
-                        const float nl = lt[K] * sc, dl = nl - lt[K];
+                        const float nl = lt[K], dl = nl - lm[1 + K];
                         cb[(3 * M::MAXCHAIN + 5 + K) * ST] = nl;
                         sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { w[M::chain[b][C]] += g[1 + K][C] * dl; });
                     });
@@ -1750,20 +1773,17 @@ struct Sim {
                             const float dl = ln - lm[0];
                             sfor<LEN>([&](auto C) MI_LAMBDA { w[M::pg_chain[g][C]] += gq[0][C] * dl; });
                         }
-                        float lt[2];
-                        sfor<2>([&](auto K) MI_LAMBDA {
+                        float lt[2], vtg[2];
+                        sfor<2>([&](auto K) MI_LAMBDA {      // (both tangent rows from the same velocity, as above)
                             float vn = 0.f;
                             sfor<LEN>([&](auto C) MI_LAMBDA { vn += gq[1 + K][C] * w[M::pg_chain[g][C]]; });
-                            const float dl = -vn * ainv[1 + K];
-                            lt[K] = lm[1 + K] + dl;
-                            sfor<LEN>([&](auto C) MI_LAMBDA { w[M::pg_chain[g][C]] += gq[1 + K][C] * dl; });
+                            vtg[K] = vn;
+                            lt[K] = lm[1 + K] - vn * ainv[1 + K];
                         });
-                        const float lim = mu * ln;
-                        const float n2 = lt[0] * lt[0] + lt[1] * lt[1];
-                        const float scl = (n2 > lim * lim) ? lim * MI_RSQ(fmaxf(n2, 1e-30f)) : 1.f;
+                        friction_disc(lt, lm[1], lm[2], vtg[0], vtg[1], ainv[1], ainv[2], mu * ln);
                         pb[(3 * PCH + 4) * ST] = ln;
                         sfor<2>([&](auto K) MI_LAMBDA {
-                            const float nl = lt[K] * scl, dl = nl - lt[K];
+                            const float nl = lt[K], dl = nl - lm[1 + K];
                             pb[(3 * PCH + 5 + K) * ST] = nl;
                             sfor<LEN>([&](auto C) MI_LAMBDA { w[M::pg_chain[g][C]] += gq[1 + K][C] * dl; });
                         });

@@ -488,20 +488,18 @@ struct SimMW : Sim<M> {
                                 actn = (ln > 0.f) ? 1.f : actn;
                                 sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { wupd(std::integral_constant<int, M::chain[b][C]>{}, Bf.g[0][C] * dl); });
                             }
-                            float lt[2];
+                            float lt[2], vtg[2];
+                            // both tangent rows from the SAME velocity, the disc (core/engine.hpp friction_disc; oracle/physics.c solve_blocks), ONE application
                             sfor<2>([&](auto K) MI_LAMBDA {
                                 float vn = 0.f;
                                 sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { vn += Bf.g[1 + K][C] * wget(std::integral_constant<int, M::chain[b][C]>{}); });
-                                const float dl = -vn * ainv[1 + K];
-                                lt[K] = Bf.lam[1 + K] + dl;
-                                sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { wupd(std::integral_constant<int, M::chain[b][C]>{}, Bf.g[1 + K][C] * dl); });
+                                vtg[K] = vn;
+                                lt[K] = Bf.lam[1 + K] - vn * ainv[1 + K];
                             });
-                            const float lim = mu * ln;
-                            const float n2 = lt[0] * lt[0] + lt[1] * lt[1];
-                            const float scl = (n2 > lim * lim) ? lim * MI_RSQ(fmaxf(n2, 1e-30f)) : 1.f;
+                            friction_disc(lt, Bf.lam[1], Bf.lam[2], vtg[0], vtg[1], ainv[1], ainv[2], mu * ln);
                             sfor<2>([&](auto K) MI_LAMBDA {
                                 constexpr int row = row0 + 1 + K;
-                                const float nl = lt[K] * scl, dl = nl - lt[K];
+                                const float nl = lt[K], dl = nl - Bf.lam[1 + K];
                                 lam(row) = nl;
                                 sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { wupd(std::integral_constant<int, M::chain[b][C]>{}, Bf.g[1 + K][C] * dl); });
                             });

@@ -83,7 +83,7 @@ struct SimMWC : SimMW<M> {
     static constexpr int L_VT = C_LIMG, L_LAM = C_LIMG + NLIM;                             // velocity target, impulse
     static constexpr int gcb(int r) { int o = C_LIMG + 2 * NLIM; for (int k = 0; k < r; ++k) o += kcap(k) * gcsz(k); return o; }
     static constexpr int C_SLOTOF = gcb(NR);                                               // one byte per sphere: its slot in the owner's range, -1
-    static constexpr int C_X = C_SLOTOF + (NSPH + 3) / 4;                                  // group -> slot map, then per self contact 8 floats:
+    static constexpr int C_X = C_SLOTOF + (NSPH + 3) / 4;                                  // one spare word (until round 6: the group -> slot map), then per self contact 8 floats:
     static constexpr int XI = 8;                                                           //   point (3), normal (3), bodies word, mu
     static constexpr int A0 = C_X + 1 + XI * KPAIR;                                        // shared region: before B2 ...
     static constexpr int X_LR = A0, X_DT = X_LR + 16 * NLR, X_DY = X_DT + NR * NTE, X_END = X_DY + NR * NVT;
@@ -100,6 +100,26 @@ struct SimMWC : SimMW<M> {
     static_assert((size_t)MWC_SLOTS * LANES * sizeof(float) <= 160 * 1024, "row store + exchange areas fit the LDS of a CU at 32 envs per workgroup");
     static constexpr int PVT = 3 * NV, PLAM = PVT + 1;                                     // inside a self-contact slot
 
+    // ---- chain groups of a role.  The chain of a body is a SUFFIX of the chains of the bodies below it (chains list a body's coordinates from its
+    //      own joint up to the root): a row over the chain of a group's deepest body (its leaf) is the row of ANY body of the group once the
+    //      entries of the joints below that body are set to zero.  The self-contact rows are built once per (contact, group) that way instead of
+    //      once per (contact, body): a lane's body is run-time data, the union of the wave's bodies used to be executed.
+    static constexpr bool chain_suffix(int b, int lf) {
+        if (M::chain_len[b] > M::chain_len[lf]) return false;
+        for (int c = 0; c < M::chain_len[b]; ++c) if (M::chain[b][c] != M::chain[lf][c + M::chain_len[lf] - M::chain_len[b]]) return false;
+        return true;
+    }
+    template <int R> static constexpr bool owned(int b) { return MW::role_of_body(b) == R || (MW::trunk_body(b) && R == M::TRUNK_ROLE); }
+    template <int R> static constexpr bool chain_leaf(int b) {
+        if (!owned<R>(b)) return false;
+        for (int c = 0; c < NB; ++c) if (c != b && owned<R>(c) && M::chain_len[c] > M::chain_len[b] && chain_suffix(b, c)) return false;
+        return true;
+    }
+    template <int R> static constexpr int chain_group(int b) {        // the leaf whose group body b belongs to (the first one that fits), -1: not this role's
+        if (!owned<R>(b)) return -1;
+        for (int c = 0; c < NB; ++c) if (chain_leaf<R>(c) && chain_suffix(b, c)) return c;
+        return -1;
+    }
     template <int R> static constexpr int shape_idx(int gi) { return MW::trunk_gi(gi) ? nl(R) + MW::tidx(gi) : gi - lfirst(R); }
     template <int R> static constexpr bool in_chain(int b, int idx) {
         for (int c = 0; c < M::chain_len[b]; ++c) if (shape_idx<R>(M::chain[b][c]) == idx) return true;
@@ -189,7 +209,6 @@ struct SimMWC : SimMW<M> {
         constexpr int ST = RowStore<RS>::stride;
         const float invh = MI_RCP(h);
         const bool selfcol = (NPG > 0) && (scol != nullptr);
-        unsigned pmap = 0xFFFFFFFFu;
         float pvt[KPAIR], pl0[KPAIR][3];       // velocity targets / warm-start impulses of the contacts, kept until the shared region is free
         sfor<KPAIR>([&](auto J_) MI_LAMBDA { pvt[J_] = 0.f; sfor<3>([&](auto K) MI_LAMBDA { pl0[J_][K] = 0.f; }); });
 #if defined(MI_TIMING)
@@ -256,7 +275,6 @@ struct SimMWC : SimMW<M> {
                         });
                     }
                 }
-                pmap = (pmap & ~(3u << (2 * g))) | ((unsigned)(on ? cntp : 3) << (2 * g));
                 cntp += on ? 1 : 0;
             };
             if (selfcol) {
@@ -272,7 +290,6 @@ struct SimMWC : SimMW<M> {
             MI_STAMP(2);
             if (selfcol) {
                 sfor<NPG - G_SPLIT>([&](auto G_) MI_LAMBDA { group(std::integral_constant<int, G_SPLIT + decltype(G_)::value>{}); });
-                rows(C_X) = __builtin_bit_cast(float, pmap);
                 if (scol->dropped != nullptr && pdrop > 0) MI_ATOMIC_ADD_INT(scol->dropped + scol->dstride, pdrop);
             }
             MI_STAMP(4);
@@ -289,7 +306,8 @@ struct SimMWC : SimMW<M> {
                 const bool onj = bab != 0xFFFFFFFFu;
                 if (MI_WAVE_ANY(onj)) {
                     if (onj) {
-                        sfor<3 * NV>([&](auto I) MI_LAMBDA { rows(P_B + j * P_CSZ + I) = 0.f; });
+                        // (the trunk entries, which every limb role ADDS to; a limb's entries are STORED by the role that owns the limb)
+                        sfor<3>([&](auto K) MI_LAMBDA { sfor<NV>([&](auto I) MI_LAMBDA { if constexpr (MW::trunk_gi(I)) rows(P_B + j * P_CSZ + K * NV + I) = 0.f; }); });
                         rows(P_B + j * P_CSZ + PVT) = pvt[j];
                         sfor<3>([&](auto K) MI_LAMBDA { rows(P_B + j * P_CSZ + PLAM + K) = pl0[j][K]; });
                     }
@@ -314,8 +332,9 @@ struct SimMWC : SimMW<M> {
                 actp = onj ? 1.f : actp;
             });
         } }
-        // warm start of the self-contact rows on the trunk part: every role computes it (same order, same rounding) BEFORE B5 -- afterwards
-        // the sweeps overwrite the impulses in the slots -- and adds it after the blocks' round-0 contributions
+        // warm start of the self-contact rows on the trunk part: computed HERE, from the complete rows, BEFORE B5 -- afterwards the sweeps overwrite the
+        // impulses in the slots -- and published as this block's round-0 contribution to the trunk part, which every role adds last (block order).
+        // (Until round 6 every limb role recomputed it from the rows: 81 LDS loads and 70 units of the limb roles' critical path per sub-step.)
         float dwp[NVT];
         sfor<NVT>([&](auto T_) MI_LAMBDA { dwp[T_] = 0.f; });
         if constexpr (NPG > 0) { if (selfcol) {
@@ -330,7 +349,7 @@ struct SimMWC : SimMW<M> {
                 }
             });
         } }
-        sfor<NVT>([&](auto I) MI_LAMBDA { rows(X_DW + PAIR_ROLE * NVT + I) = 0.f; });
+        sfor<NVT>([&](auto I) MI_LAMBDA { rows(X_DW + PAIR_ROLE * NVT + I) = dwp[I]; });
         rows(X_FLG + PAIR_ROLE) = actp;
         rows(X_TOUCH) = __builtin_bit_cast(float, touch);
         MI_STAMP(10);
@@ -343,7 +362,6 @@ struct SimMWC : SimMW<M> {
             sfor<NR>([&](auto B_) MI_LAMBDA { constexpr int o = X_DW + B_ * NVT + T_; wt[T_] += rows(o); });
         });
         sfor<NVL>([&](auto I) MI_LAMBDA { pw[I] = rows(DOWN + I); });
-        sfor<NVT>([&](auto T_) MI_LAMBDA { wt[T_] += dwp[T_]; });
         for (int it = 0; it < P.iters; ++it) {
             MI_STAMP(15);
             int zero;
@@ -395,21 +413,16 @@ struct SimMWC : SimMW<M> {
                         };
                         const float ln = fmaxf(lm[0] - (dotw(g[0]) - vtn) * ainv[0], 0.f);
                         addw(g[0], ln - lm[0]);
-                        float lt[2];
-                        sfor<2>([&](auto K) MI_LAMBDA {
-                            const float dl = -dotw(g[1 + K]) * ainv[1 + K];
-                            lt[K] = lm[1 + K] + dl;
-                            addw(g[1 + K], dl);
-                        });
-                        const float lim = mu * ln;
-                        const float n2 = lt[0] * lt[0] + lt[1] * lt[1];
-                        const float sc = (n2 > lim * lim) ? lim * MI_RSQ(fmaxf(n2, 1e-30f)) : 1.f;
+                        float lt[2], vtg[2];
+                        // both tangent rows from the SAME velocity, the disc (core/engine.hpp friction_disc; oracle/physics.c solve_blocks), ONE application
+                        sfor<2>([&](auto K) MI_LAMBDA { vtg[K] = dotw(g[1 + K]); lt[K] = lm[1 + K] - vtg[K] * ainv[1 + K]; });
+                        friction_disc(lt, lm[1], lm[2], vtg[0], vtg[1], ainv[1], ainv[2], mu * ln);
                         pb[PLAM * ST] = ln;
                         actn = (ln > 0.f) ? 1.f : actn;
                         sfor<2>([&](auto K) MI_LAMBDA {
-                            const float nl_ = lt[K] * sc;
+                            const float nl_ = lt[K];
                             pb[(PLAM + 1 + K) * ST] = nl_;
-                            addw(g[1 + K], nl_ - lt[K]);
+                            addw(g[1 + K], nl_ - lm[1 + K]);
                         });
                     }
                 }
@@ -435,21 +448,36 @@ struct SimMWC : SimMW<M> {
         }
         MI_STAMP(12);
         // ============================================================ P5: impulses of the groups -> warm start of the next sub-step, world force on side a
+        // The <= KPAIR slots are read once (static addresses, one frame per occupied slot); every group then SELECTS its values from them by the group
+        // number in the slot's bodies word.  (Until round 6 each of the NPG groups looked its slot up through pmap at a run-time address and built its
+        // own frame: 2.5 k instructions on the wave that finishes last -- this loop is the tail of the kernel.)
         if constexpr (NPG > 0) { if (selfcol) {
+            int sg[KPAIR];
+            float sl[KPAIR][3], sf[KPAIR][3];
+            sfor<KPAIR>([&](auto J_) MI_LAMBDA {
+                constexpr int j = J_;
+                const unsigned bab = __builtin_bit_cast(unsigned, (float)rows(C_X + 1 + XI * j + 6));
+                const bool onj = bab != 0xFFFFFFFFu;
+                sg[j] = onj ? (int)(bab >> 24) : -1;
+                sfor<3>([&](auto K) MI_LAMBDA { sl[j][K] = onj ? (float)rows(P_B + j * P_CSZ + PLAM + K) : 0.f; sf[j][K] = 0.f; });
+                if (scol->pairf.p) {
+                    if (MI_WAVE_ANY(onj)) {
+                        float n[3], t1[3], t2[3];
+                        sfor<3>([&](auto I_) MI_LAMBDA { n[I_] = onj ? (float)rows(C_X + 1 + XI * j + 3 + I_) : (I_ == 2 ? 1.f : 0.f); });
+                        contact_frame(n, t1, t2);
+                        sfor<3>([&](auto K) MI_LAMBDA { sf[j][K] = (n[K] * sl[j][0] + t1[K] * sl[j][1] + t2[K] * sl[j][2]) * invh; });
+                    }
+                }
+            });
             sfor<NPG>([&](auto G_) MI_LAMBDA {
                 constexpr int g = G_;
-                const int j = (int)((pmap >> (2 * g)) & 3u);
-                const bool onj = j != 3;
-                const float* pb = rows.ptr(P_B + (onj ? j : 0) * P_CSZ);
-                const float* xi = rows.ptr(C_X + 1 + XI * (onj ? j : 0));
-                const float ln = onj ? pb[PLAM * ST] : 0.f, l1 = onj ? pb[(PLAM + 1) * ST] : 0.f, l2 = onj ? pb[(PLAM + 2) * ST] : 0.f;
-                scol->lamp(3 * g) = ln; scol->lamp(3 * g + 1) = l1; scol->lamp(3 * g + 2) = l2;
-                if (scol->pairf.p) {
-                    float n[3], t1[3], t2[3];
-                    sfor<3>([&](auto I_) MI_LAMBDA { n[I_] = onj ? xi[(3 + I_) * ST] : (I_ == 2 ? 1.f : 0.f); });
-                    contact_frame(n, t1, t2);
-                    sfor<3>([&](auto K) MI_LAMBDA { scol->pairf(3 * g + K) = (n[K] * ln + t1[K] * l1 + t2[K] * l2) * invh; });
-                }
+                float l[3] = {0.f, 0.f, 0.f}, f[3] = {0.f, 0.f, 0.f};
+                sfor<KPAIR>([&](auto J_) MI_LAMBDA {
+                    const bool me = sg[J_] == g;
+                    sfor<3>([&](auto K) MI_LAMBDA { l[K] = me ? sl[J_][K] : l[K]; f[K] = me ? sf[J_][K] : f[K]; });
+                });
+                sfor<3>([&](auto K) MI_LAMBDA { scol->lamp(3 * g + K) = l[K]; });
+                if (scol->pairf.p) sfor<3>([&](auto K) MI_LAMBDA { scol->pairf(3 * g + K) = f[K]; });
             });
         } }
         MI_STAMP(13);
@@ -715,8 +743,6 @@ struct SimMWC : SimMW<M> {
         MI_STAMP(5);
         // ============================================================ self-contact rows: every body of mine adds its half
         if constexpr (R == M::TRUNK_ROLE) sfor<NV>([&](auto I) MI_LAMBDA { if constexpr (MW::trunk_gi(I)) { constexpr int o = XW0 + MW::tidx(I); rows(o) = w[I]; } });
-        float dwp[NVT];
-        sfor<NVT>([&](auto T_) MI_LAMBDA { dwp[T_] = 0.f; });
         if (selfcol) {
             MI_STAMP(6);
             bar();                                                                                   // ---- B3: the pair role has zeroed the dense rows
@@ -728,13 +754,22 @@ struct SimMWC : SimMW<M> {
                 if (!MI_WAVE_ANY(onj)) break;                    // slots fill from the front
                 const int ba = (int)(bab & 255u), bb = (int)((bab >> 8) & 255u);
                 float* pb = rows.ptr(P_B + j * P_CSZ);
-                sfor<NB>([&](auto B_) MI_LAMBDA {
-                    constexpr int b = B_;
-                    if constexpr (MW::template owns_body<R>(b)) {
-                        const bool me = onj && ((ba == b) || (bb == b));
+                // one evaluation per chain GROUP of this role (a leg: one; the trunk role: the trunk's chain and one per arm) for +lambda on side a and
+                // -lambda on side b together: entry C of the row over the group's deepest chain carries [C moves a's body] - [C moves b's body]
+                sfor<NB>([&](auto LF_) MI_LAMBDA {
+                    constexpr int lf = LF_;
+                    if constexpr (chain_leaf<R>(lf)) {
+                        constexpr int CLF = M::chain_len[lf];
+                        int sa = CLF, sb = CLF;                 // first chain entry that moves the side's body (CLF: the body is not in this group)
+                        sfor<NB>([&](auto B_) MI_LAMBDA {
+                            constexpr int b = B_;
+                            if constexpr (chain_group<R>(b) == lf) { constexpr int sk = CLF - M::chain_len[b]; sa = (ba == b) ? sk : sa; sb = (bb == b) ? sk : sb; }
+                        });
+                        const bool me = onj && ((sa < CLF) || (sb < CLF));
+                        float g[3][M::MAXCHAIN];
+                        sfor<3>([&](auto K) MI_LAMBDA { sfor<CLF>([&](auto C) MI_LAMBDA { g[K][C] = 0.f; }); });
                         if (MI_WAVE_ANY(me)) {
                             if (me) {
-                                const float sgn = (ba == b) ? 1.f : -1.f;       // +lambda on side a, -lambda on side b
                                 float x[3], fr[3][3], W[3][6];
                                 sfor<3>([&](auto I_) MI_LAMBDA { x[I_] = xi[I_ * ST]; fr[0][I_] = xi[(3 + I_) * ST]; });
                                 contact_frame(fr[0], fr[1], fr[2]);
@@ -742,31 +777,46 @@ struct SimMWC : SimMW<M> {
                                     cross3(x, fr[K], W[K]);
                                     W[K][3] = fr[K][0]; W[K][4] = fr[K][1]; W[K][5] = fr[K][2];
                                 });
-                                float g[3][M::MAXCHAIN];
-                                rows3(std::integral_constant<int, b>{}, W, g);
+                                sfor<CLF>([&](auto C) MI_LAMBDA {
+                                    constexpr int c = C, gi = M::chain[lf][c];
+                                    const float cc = ((c >= sa) ? 1.f : 0.f) - ((c >= sb) ? 1.f : 0.f);
+                                    if constexpr (gi >= OFF) sfor<3>([&](auto K) MI_LAMBDA { g[K][c] = cc * dot6(S[gi - OFF], W[K]); });
+                                    else if constexpr (gi < 3) sfor<3>([&](auto K) MI_LAMBDA { g[K][c] = cc * W[K][3 + gi]; });
+                                    else sfor<3>([&](auto K) MI_LAMBDA { g[K][c] = cc * W[K][gi - 3]; });
+                                });
+                                sfor<CLF>([&](auto K) MI_LAMBDA {
+                                    constexpr int k = K, i = M::chain[lf][k];
+                                    const float di = Ldi[i];
+                                    const float z0 = g[0][k] * di, z1 = g[1][k] * di, z2 = g[2][k] * di;
+                                    g[0][k] = z0; g[1][k] = z1; g[2][k] = z2;
+                                    sfor<CLF - 1 - k>([&](auto T) MI_LAMBDA {
+                                        constexpr int kk = k + 1 + T, jj = M::chain[lf][kk];
+                                        const float l = L[M::midx[i][jj]];
+                                        g[0][kk] -= l * z0; g[1][kk] -= l * z1; g[2][kk] -= l * z2;
+                                    });
+                                });
+                                // warm start of these rows on the group's own limb coordinates, from the registers (their trunk part: the pair role)
                                 sfor<3>([&](auto K) MI_LAMBDA {
-                                    sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { constexpr int gi = M::chain[b][C]; lds_add(&pb[(K * NV + gi) * ST], sgn * g[K][C]); });
+                                    const float l0 = pb[(PLAM + K) * ST];
+                                    sfor<CLF>([&](auto C) MI_LAMBDA { constexpr int gi = M::chain[lf][C]; if constexpr (!MW::trunk_gi(gi)) w[gi] += g[K][C] * l0; });
+                                });
+                                // trunk entries: added (zeroed by the pair role, other roles add to them too)
+                                sfor<3>([&](auto K) MI_LAMBDA {
+                                    sfor<CLF>([&](auto C) MI_LAMBDA { constexpr int gi = M::chain[lf][C]; if constexpr (MW::trunk_gi(gi)) lds_add(&pb[(K * NV + gi) * ST], g[K][C]); });
                                 });
                             }
                         }
+                        // the group's own limb entries: stored by this role alone, zero where the contact does not touch the limb
+                        if (onj) sfor<3>([&](auto K) MI_LAMBDA {
+                            sfor<CLF>([&](auto C) MI_LAMBDA { constexpr int gi = M::chain[lf][C]; if constexpr (!MW::trunk_gi(gi)) pb[(K * NV + gi) * ST] = g[K][C]; });
+                        });
                     }
                 });
             }
             MI_STAMP(8);
             bar();                                                                                   // ---- B4: rows complete
             MI_STAMP(9);
-            // W: warm start of the self-contact rows on the own limb coordinates; their trunk part (every role alike, see substep_pair)
-            sfor<KPAIR>([&](auto J_) MI_LAMBDA {
-                constexpr int j = J_;
-                const unsigned bab = __builtin_bit_cast(unsigned, (float)rows(C_X + 1 + XI * j + 6));
-                if (bab != 0xFFFFFFFFu) {
-                    sfor<3>([&](auto K) MI_LAMBDA {
-                        const float l0 = rows(P_B + j * P_CSZ + PLAM + K);
-                        sfor<NLR_>([&](auto K2) MI_LAMBDA { w[LF + K2] += rows(P_B + j * P_CSZ + K * NV + LF + K2) * l0; });
-                        sfor<NV>([&](auto I) MI_LAMBDA { if constexpr (MW::trunk_gi(I)) { constexpr int ti = MW::tidx(I); dwp[ti] += rows(P_B + j * P_CSZ + K * NV + I) * l0; } });
-                    });
-                }
-            });
+            // (the warm start of the self-contact rows: own limb coordinates above, trunk part by the pair role -- substep_pair)
         }
         sfor<NVT>([&](auto I) MI_LAMBDA { rows(X_DW + R * NVT + I) = dw[I]; });
         sfor<NLR_>([&](auto K) MI_LAMBDA { constexpr int o = DOWN + lidx(LF + K); rows(o) = w[LF + K]; });     // (round 0 carries the values themselves)
@@ -776,12 +826,11 @@ struct SimMWC : SimMW<M> {
         bar();                                                                                       // ---- B5: round 0 of the exchange is complete
         MI_STAMP(11);
         // ============================================================ P4: block sweeps
-        // round 0: every block's warm-start contribution to the trunk part, in block order; then the self-contact rows' (every role alike)
+        // round 0: every block's warm-start contribution to the trunk part, in block order (the pair block's: the self-contact rows' warm start)
         sfor<NV>([&](auto I) MI_LAMBDA {
             constexpr int i = I;
             if constexpr (MW::trunk_gi(i)) { sfor<NR>([&](auto B_) MI_LAMBDA { constexpr int o = X_DW + B_ * NVT + MW::tidx(i); w[i] += rows(o); }); }
         });
-        sfor<NV>([&](auto I) MI_LAMBDA { if constexpr (MW::trunk_gi(I)) { constexpr int ti = MW::tidx(I); w[I] += dwp[ti]; } });
         const unsigned touch = __builtin_bit_cast(unsigned, (float)rows(X_TOUCH));
         {
             float wtl[NVT], wll[NLR_ > 0 ? NLR_ : 1];
@@ -804,10 +853,6 @@ struct SimMWC : SimMW<M> {
                     constexpr int gi = decltype(GI)::value;
                     if constexpr (MW::trunk_gi(gi)) { constexpr int ti = MW::tidx(gi); return wtl[ti]; } else { constexpr int k = gi - LF; return wll[k]; }
                 };
-                auto wupd = [&](auto GI, const float val) MI_LAMBDA {
-                    constexpr int gi = decltype(GI)::value;
-                    if constexpr (MW::trunk_gi(gi)) { constexpr int ti = MW::tidx(gi); wtl[ti] += omT * val; } else { constexpr int k = gi - LF; wll[k] += om_of<gi>(omT, oml) * val; }
-                };
                 float actn = 0.f;
                 MI_STAMP(16);
                 // ---- own limit rows
@@ -817,11 +862,16 @@ struct SimMWC : SimMW<M> {
                         constexpr int row = B::limrow(d), g0 = B::limoff(row);
                         float g[M::MAXCHAIN];
                         sfor<M::nanc[gi] + 1>([&](auto K) MI_LAMBDA { g[K] = rit(g0 + K); });
-                        float a = P.cfm;
+                        // a row's coordinates: its dof's own limb (one weight: a limb is a path below the trunk) and the trunk -- the weights go onto the
+                        // two partial sums of the diagonal and onto the impulse, not onto every coordinate
+                        float al = 0.f, at = 0.f;
                         sfor<M::nanc[gi] + 1>([&](auto K) MI_LAMBDA {
                             constexpr int k = K, i = (k == 0) ? gi : M::anc[gi][k == 0 ? 0 : k - 1];
-                            a += om_of<i>(omT, oml) * g[k] * g[k];
+                            static_assert(MW::trunk_gi(i) || limb_of_gi(i) == limb_of_gi(gi), "a limit row touches its own limb and the trunk");
+                            if constexpr (MW::trunk_gi(i)) at += g[k] * g[k]; else al += g[k] * g[k];
                         });
+                        const float omL = om_of<gi>(omT, oml);
+                        const float a = P.cfm + omL * al + omT * at;
                         float vn = g[0] * wget(std::integral_constant<int, gi>{});
                         sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { vn += g[1 + A_] * wget(std::integral_constant<int, M::anc[gi][A_]>{}); });
                         const float lo = rit(L_LAM + row);
@@ -829,8 +879,11 @@ struct SimMWC : SimMW<M> {
                         const float dl = nl_ - lo;
                         rit(L_LAM + row) = nl_;
                         actn = (nl_ > 0.f) ? 1.f : actn;
-                        wupd(std::integral_constant<int, gi>{}, g[0] * dl);
-                        sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { wupd(std::integral_constant<int, M::anc[gi][A_]>{}, g[1 + A_] * dl); });
+                        const float dlL = omL * dl, dlT = omT * dl;
+                        sfor<M::nanc[gi] + 1>([&](auto K) MI_LAMBDA {
+                            constexpr int k = K, i = (k == 0) ? gi : M::anc[gi][k == 0 ? 0 : k - 1];
+                            if constexpr (MW::trunk_gi(i)) { constexpr int ti = MW::tidx(i); wtl[ti] += g[k] * dlT; } else { constexpr int kk = i - LF; wll[kk] += g[k] * dlL; }
+                        });
                     }
                 });
                 MI_STAMP(17);
@@ -844,11 +897,14 @@ struct SimMWC : SimMW<M> {
                         float g[3][RLEN], ainv[3], lm[3];
                         sfor<3>([&](auto K) MI_LAMBDA {
                             sfor<RLEN>([&](auto C) MI_LAMBDA { g[K][C] = cb[(K * RLEN + C) * ST]; });
-                            float a = P.cfm;
-                            sfor<NLR_>([&](auto K2) MI_LAMBDA { a += om_of<LF + decltype(K2)::value>(omT, oml) * g[K][K2] * g[K][K2]; });
+                            float alm[NLIMB > 1 ? NLIMB - 1 : 1];                 // the diagonal's partial sums per limb of this role and for the trunk: weights applied once
+                            sfor<NLIMB - 1>([&](auto L_) MI_LAMBDA { alm[L_] = 0.f; });
+                            sfor<NLR_>([&](auto K2) MI_LAMBDA { constexpr int l = limb_of_gi(LF + decltype(K2)::value); alm[l - 1] += g[K][K2] * g[K][K2]; });
                             float at = 0.f;
                             sfor<NVT>([&](auto T_) MI_LAMBDA { at += g[K][NLR_ + T_] * g[K][NLR_ + T_]; });
-                            ainv[K] = MI_RCP(a + omT * at);
+                            float a = P.cfm + omT * at;
+                            sfor<NLIMB - 1>([&](auto L_) MI_LAMBDA { if constexpr (M::role_of_limb[L_ + 1] == R) a += oml[L_] * alm[L_]; });
+                            ainv[K] = MI_RCP(a);
                             lm[K] = cb[(3 * RLEN + 1 + K) * ST];
                         });
                         const float vtn = cb[(3 * RLEN) * ST];
@@ -858,27 +914,25 @@ struct SimMWC : SimMW<M> {
                             sfor<NVT>([&](auto T_) MI_LAMBDA { s += gr[NLR_ + T_] * wtl[T_]; });
                             return s;
                         };
-                        auto addw = [&](const float (&gr)[RLEN], const float dl) MI_LAMBDA {
-                            sfor<NLR_>([&](auto K) MI_LAMBDA { wll[K] += om_of<LF + decltype(K)::value>(omT, oml) * gr[K] * dl; });
-                            sfor<NVT>([&](auto T_) MI_LAMBDA { wtl[T_] += omT * gr[NLR_ + T_] * dl; });
+                        auto addw = [&](const float (&gr)[RLEN], const float dl) MI_LAMBDA {      // (the weights go onto the impulse: one fma per coordinate)
+                            float dlim[NLIMB > 1 ? NLIMB - 1 : 1];
+                            sfor<NLIMB - 1>([&](auto L_) MI_LAMBDA { dlim[L_] = oml[L_] * dl; });
+                            const float dT = omT * dl;
+                            sfor<NLR_>([&](auto K) MI_LAMBDA { constexpr int l = limb_of_gi(LF + decltype(K)::value); wll[K] += gr[K] * dlim[l - 1]; });
+                            sfor<NVT>([&](auto T_) MI_LAMBDA { wtl[T_] += gr[NLR_ + T_] * dT; });
                         };
                         const float ln = fmaxf(lm[0] - (dotw(g[0]) - vtn) * ainv[0], 0.f);
                         addw(g[0], ln - lm[0]);
-                        float lt[2];
-                        sfor<2>([&](auto K) MI_LAMBDA {
-                            const float dl = -dotw(g[1 + K]) * ainv[1 + K];
-                            lt[K] = lm[1 + K] + dl;
-                            addw(g[1 + K], dl);
-                        });
-                        const float lim = mu * ln;
-                        const float n2 = lt[0] * lt[0] + lt[1] * lt[1];
-                        const float sc = (n2 > lim * lim) ? lim * MI_RSQ(fmaxf(n2, 1e-30f)) : 1.f;
+                        float lt[2], vtg[2];
+                        // both tangent rows from the SAME velocity, the disc (core/engine.hpp friction_disc; oracle/physics.c solve_blocks), ONE application
+                        sfor<2>([&](auto K) MI_LAMBDA { vtg[K] = dotw(g[1 + K]); lt[K] = lm[1 + K] - vtg[K] * ainv[1 + K]; });
+                        friction_disc(lt, lm[1], lm[2], vtg[0], vtg[1], ainv[1], ainv[2], mu * ln);
                         cb[(3 * RLEN + 1) * ST] = ln;
                         actn = (ln > 0.f) ? 1.f : actn;
                         sfor<2>([&](auto K) MI_LAMBDA {
-                            const float nl_ = lt[K] * sc;
+                            const float nl_ = lt[K];
                             cb[(3 * RLEN + 2 + K) * ST] = nl_;
-                            addw(g[1 + K], nl_ - lt[K]);
+                            addw(g[1 + K], nl_ - lm[1 + K]);
                         });
                     }
                 }

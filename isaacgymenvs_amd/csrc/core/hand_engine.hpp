@@ -643,19 +643,16 @@ struct HandSim : Sim<M> {
                             const float ln = fmaxf(lm[0] - (rowvel(0) - vtn) * ainv[0], 0.f);
                             apply(0, ln - lm[0]);
                             float lt[2];
-                            sfor<2>([&](auto K) MI_LAMBDA {
-                                const float dl = -rowvel(1 + K) * ainv[1 + K];
-                                lt[K] = lm[1 + K] + dl;
-                                apply(1 + K, dl);
-                            });
-                            const float lim = OP.mu * ln;
-                            const float n2 = lt[0] * lt[0] + lt[1] * lt[1];
-                            const float sc = (n2 > lim * lim) ? lim * MI_RSQ(fmaxf(n2, 1e-30f)) : 1.f;
+                            // both tangent rows from the SAME velocity, the disc projection, ONE application (round 6: as core/scene_engine.hpp; until
+                            // then t1 was solved and applied before t2 was looked at -- a fast-sliding contact's friction pointed off the sliding direction)
+                            float vtg[2];
+                            sfor<2>([&](auto K) MI_LAMBDA { vtg[K] = rowvel(1 + K); lt[K] = lm[1 + K] - vtg[K] * ainv[1 + K]; });
+                            friction_disc(lt, lm[1], lm[2], vtg[0], vtg[1], ainv[1], ainv[2], OP.mu * ln);
                             cb[(H_AUX + 4) * ST] = ln;
                             sfor<2>([&](auto K) MI_LAMBDA {
-                                const float nl_ = lt[K] * sc;
+                                const float nl_ = lt[K];
                                 cb[(H_AUX + 5 + K) * ST] = nl_;
-                                apply(1 + K, nl_ - lt[K]);
+                                apply(1 + K, nl_ - lm[1 + K]);
                             });
                         }
                     }

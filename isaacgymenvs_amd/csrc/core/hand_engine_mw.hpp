@@ -686,21 +686,14 @@ struct HandSimMW : HandSim<M> {
                                 const float ln = fmaxf(lm[0] - (rowvel(0) - vtn) * ainv[0], 0.f);
                                 apply(0, ln - lm[0]);
                                 float lt[2];
-                                sfor<2>([&](auto K) MI_LAMBDA {
-                                    const float dl = -rowvel(1 + K) * ainv[1 + K];
-                                    lt[K] = lm[1 + K] + dl;
-                                    apply(1 + K, dl);
-                                });
-                                const float lim = OP.mu * ln;
-                                const float n2 = lt[0] * lt[0] + lt[1] * lt[1];
-                                const float sc = (n2 > lim * lim) ? lim * MI_RSQ(fmaxf(n2, 1e-30f)) : 1.f;
+                                // both tangent rows from the SAME velocity, the disc projection, ONE application (core/hand_engine.hpp)
+                                float vtg[2];
+                                sfor<2>([&](auto K) MI_LAMBDA { vtg[K] = rowvel(1 + K); lt[K] = lm[1 + K] - vtg[K] * ainv[1 + K]; });
+                                friction_disc(lt, lm[1], lm[2], vtg[0], vtg[1], ainv[1], ainv[2], OP.mu * ln);
                                 gp[G_LAM * ST] = ln;
                                 actn = (ln > 0.f) ? 1.f : actn;
-                                const bool slide = sc != 1.f;
-                                sfor<2>([&](auto K) MI_LAMBDA { gp[(G_LAM + 1 + K) * ST] = lt[K] * sc; });
-                                if (MI_WAVE_ANY(slide)) {       // (sticking contacts: the correction is zero -- skipped when no lane of the wave slides)
-                                    sfor<2>([&](auto K) MI_LAMBDA { apply(1 + K, lt[K] * sc - lt[K]); });
-                                }
+                                sfor<2>([&](auto K) MI_LAMBDA { gp[(G_LAM + 1 + K) * ST] = lt[K]; });
+                                sfor<2>([&](auto K) MI_LAMBDA { apply(1 + K, lt[K] - lm[1 + K]); });
                             }
                         }
                     }

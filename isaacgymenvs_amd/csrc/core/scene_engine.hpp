@@ -66,7 +66,7 @@ struct SceneSim : Sim<M> {
     static constexpr int S_GEO = 3 * HCH, S_AUX = S_GEO + 6, S_CSZ = S_AUX + 11;
     static constexpr int KSLOT = KARM + KBOX;              // entries of the warm-start tensor: (feature, lam_n, lam_t1, lam_t2) per slot
     static constexpr int NTGT = kSceneMaxFree + kSceneMaxStatic;
-    static_assert(KSLOT == 48, "tensor scene_warm holds 48 entries per env (arena_layout.hpp)");
+    static_assert(KSLOT == 48, "tensor scene_warm holds MI_SCENE_WARM_SLOTS = 48 entries per env (include/mi_engine.h; checked against it in tasks/articulation.hpp)");
     static constexpr int R_LIMG = B::limoff(NLIM);
     static constexpr int R_CB = R_LIMG + 3 * NLIM;          // limit G | Ainv, vt, lam | contact slots
     static constexpr int R_BODY = R_CB + (KARM + KBOX) * S_CSZ;     // per actor body: first slot | count << 8
@@ -263,6 +263,9 @@ struct SceneSim : Sim<M> {
                     for (int t = 0; t < nf + ns; ++t) {
                         const bool fr_ = t < nf;
                         const int ib = fr_ ? t : t - nf;
+                        // a body that no dof moves (the fixed base link) against a static box: the row would act on nothing (a = cfm only) and only
+                        // take one of the KARM slots from a finger or a cube
+                        if (CL == 0 && !fr_) continue;
                         float Rb_[9], xb_[3];
                         ld9(fr_ ? W_RF : W_RS, ib, Rb_);
                         ld3(fr_ ? W_XF : W_XST, ib, xb_);
@@ -436,14 +439,13 @@ struct SceneSim : Sim<M> {
             // zero velocity and applying it before t2 is looked at -- the order of core/hand_engine.hpp -- lets the unclamped t1 impulse of a fast
             // sliding corner spin the box, t2 then cancels a lateral velocity that is not there, and after the projection the friction points 20
             // degrees off the sliding direction: a cube on a 40 degree ramp slid with mu_eff = 0.468 instead of 0.5, tests/test_scene.py.)
-            float lt[2];
-            sfor<2>([&](auto K) MI_LAMBDA { lt[K] = lm[1 + K] - rowvel(1 + K) * ainv[1 + K]; });
-            const float lim = mu * ln;
-            const float n2 = lt[0] * lt[0] + lt[1] * lt[1];
-            const float sc = (n2 > lim * lim) ? lim * MI_RSQ(fmaxf(n2, 1e-30f)) : 1.f;
+            // Round 6: a sliding contact repeats the step with one step size for both rows (core/engine.hpp friction_disc), in every engine form.
+            float lt[2], vtg[2];
+            sfor<2>([&](auto K) MI_LAMBDA { vtg[K] = rowvel(1 + K); lt[K] = lm[1 + K] - vtg[K] * ainv[1 + K]; });
+            friction_disc(lt, lm[1], lm[2], vtg[0], vtg[1], ainv[1], ainv[2], mu * ln);
             cb[(S_AUX + 4) * ST] = ln;
             sfor<2>([&](auto K) MI_LAMBDA {
-                const float nl_ = lt[K] * sc;
+                const float nl_ = lt[K];
                 cb[(S_AUX + 5 + K) * ST] = nl_;
                 apply(1 + K, nl_ - lm[1 + K]);
             });

@@ -1,4 +1,6 @@
 // kernels_mw_ant.hip -- multi-wave sub-step of the Ant (one leg per wave), gfx950.
+// (A/B only: MI_EXTRA_HIPCC_FLAGS=-DMI_MW_HAS8=1 also builds the 8-env / two-workgroups-per-CU form of the one-launch kernel -- it needs 414
+//  registers per lane, at two waves per SIMD it spills 384 VGPRs and runs 1.65x slower: profiles/r6c_ant_mw8_two_workgroups_per_cu_ab.txt)
 #include "mw_kernels.hpp"
 #include "gen/model_ant.h"
 

@@ -416,7 +416,10 @@ extern "C" int mi_engine_set_option(MiEngine* e, const char* key, double value) 
     // workgroup, core/hand_engine_mw.hpp).  2: the Humanoid's round-2 form (main wave + self-collision helper).
     if (!strcmp(key, "multi_wave")) {
         const bool hand64 = value == 64 && is_hand_task(e->task);        // full 64-env waves, one workgroup per CU (hand_mw_kernels.hpp)
-        if (value != 0 && value != 32 && value != 2 && !(MI_MW_HAS16 && value == 16) && !hand64) return fail("multi_wave: 0, 16 or 32 (envs per workgroup); 2: main + helper wave; 64: ShadowHand / AllegroHand only");
+        // 8: the Ant's one-launch kernel (sub-steps + post step) on 8-env workgroups, two per CU (mw_kernels.hpp); every other launch of such an engine
+        // takes the 32-env shape
+        const bool ant8 = MI_MW_HAS8 && value == 8 && e->task == T_ANT;       // (an A/B build only: -DMI_MW_HAS8=1)
+        if (value != 0 && value != 32 && value != 2 && !(MI_MW_HAS16 && value == 16) && !hand64 && !ant8) return fail("multi_wave: 0, 16 or 32 (envs per workgroup); 2: main + helper wave; 8: Ant only; 64: ShadowHand / AllegroHand only");
         e->v.mw = (int)value;
         return 0;
     }

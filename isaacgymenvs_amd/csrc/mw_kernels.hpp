@@ -364,8 +364,10 @@ __device__ __forceinline__ void mw_role_fused(const MwFusedArgs<GND>& a, float* 
     });
     if constexpr (R == M::TRUNK_ROLE) sfor<13>([&](auto K) MI_LAMBDA { v.root[K * N + e] = sim.root[K]; });
 }
+// E = 8 (option multi_wave 8, the Ant): TWO workgroups per CU -- every SIMD holds two role waves (of different workgroups) and issues one while the
+// other waits on LDS / memory; the kernel is compiled for two waves per SIMD (<= 256 registers per lane, VGPRs + AGPRs).
 template <class M, class GND, int E, bool HUM>
-__global__ __launch_bounds__(64 * M::NROLE) void substep_mw_fused_post_kernel(MwFusedPostArgs<GND> args_by_value) {
+__global__ __launch_bounds__(64 * M::NROLE, E == 8 ? 2 : 1) void substep_mw_fused_post_kernel(MwFusedPostArgs<GND> args_by_value) {
     extern __shared__ float lds_rows[];   // [MW_SLOTS + 13][E]
     static_assert(M::NROLE == 4, "four roles, one per SIMD of a CU");
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -498,7 +500,13 @@ hipError_t launch_substeps_mw_post(const View& v, const SimParams& P, const ActP
             constexpr size_t plds16 = mw_fused_lds_bytes<M, 16>(), plds32 = mw_fused_lds_bytes<M, 32>();
             const MwFusedPostArgs<PlaneGround> pa{MwFusedArgs<PlaneGround>{v, P, ap, actions, first, rest, n_sub, 0, PlaneGround{}}, tp};
             const dim3 block(64, M::NROLE);
-            if (MI_MW_HAS16 && v.mw == 16) {
+            if (MI_MW_HAS8 && v.mw == 8) {
+                static unsigned long long pconf8 = 0ull;
+                constexpr size_t plds8 = mw_fused_lds_bytes<M, 8>();
+                auto kern = substep_mw_fused_post_kernel<M, PlaneGround, MI_MW_HAS8 ? 8 : 32, HUM>;
+                if (hipError_t e = ensure_dynamic_lds((const void*)kern, plds8, &pconf8); e != hipSuccess) return e;
+                hipLaunchKernelGGL(kern, dim3(xcd_grid<8>(v.N)), block, plds8, s, pa);
+            } else if (MI_MW_HAS16 && v.mw == 16) {
                 auto kern = substep_mw_fused_post_kernel<M, PlaneGround, MI_MW_HAS16 ? 16 : 32, HUM>;
                 if (hipError_t e = ensure_dynamic_lds((const void*)kern, plds16, &pconf16); e != hipSuccess) return e;
                 hipLaunchKernelGGL(kern, dim3(xcd_grid<16>(v.N)), block, plds16, s, pa);

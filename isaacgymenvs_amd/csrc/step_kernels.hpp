@@ -268,6 +268,9 @@ __global__ __launch_bounds__(64) void substep_kernel(View v, SimParams P, ActPar
 #ifndef MI_MW_HAS16
 #define MI_MW_HAS16 1          // also build the 16-envs-per-workgroup variant (best at <= 4096 envs; 0 halves the compile time of kernels_mw_*.hip)
 #endif
+#ifndef MI_MW_HAS8
+#define MI_MW_HAS8 0           // -DMI_MW_HAS8=1 (A/B builds): the 8-envs-per-workgroup, two-workgroups-per-CU variant of the Ant's one-launch kernel
+#endif
 template <class M, class GND>
 constexpr bool mw_capable() {
     // (flat ground with net contact forces = the flat Anymal task: the plain model has the limb-per-wave form, kernels_mw_anymal.hip; its

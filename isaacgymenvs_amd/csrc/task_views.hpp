@@ -86,12 +86,12 @@ static inline void build_hand_layout(int task, int N, Layout& L, HandView* hv, c
     o = L.add("actor_scale", MI_F32, {n, 8}, {1, n}, 8 * n); if (hv) hv->scale = (float*)P(o);
     // `actor_params.hand.dof_properties.lower / upper`: shifts of the 24 lower, then the 24 upper joint limits of each env's hand
     o = L.add("dof_limit_shift", MI_F32, {n, 2 * nd}, {1, n}, 2 * nd * n); if (hv) hv->limit_shift = (float*)P(o);
-    o = L.add("object_contact_dropped", MI_I32, {n}, {1}, n); if (hv) hv->ndropped = (int*)P(o);
+    o = L.add("object_contact_dropped", MI_I32, {n}, {1}, n); if (hv) hv->ndropped = (int*)P(o);   // contacts refused since init: all KMAX slots taken
     // per-BODY factors of the hand's link masses (+ inertias) for `actor_params.hand.rigid_body_properties.mass` (reference vec_task.py:783-828 draws
     // one sample per body); read by the kernels only while option "hand_body_mass" is on (mi_engine_set_option)
     o = L.add("hand_body_mass_scale", MI_F32, {n, (int64_t)kTasks[task].nb}, {1, n}, (int64_t)kTasks[task].nb * n); if (hv) { hv->body_mass_arena = (float*)P(o); hv->body_mass = nullptr; }
     // sides of the asset's hand-to-hand contact pairs (MJCF <contact><pair>) pushed in the last sub-step, per role wave of the finger-per-wave form
-    o = L.add("hand_pair_count", MI_I32, {n, 4}, {1, n}, 4 * n); if (hv) hv->npair = (int*)P(o);   // contacts refused since init: all KMAX slots taken
+    o = L.add("hand_pair_count", MI_I32, {n, 4}, {1, n}, 4 * n); if (hv) hv->npair = (int*)P(o);
     L.off = (L.off + 255) & ~size_t(255);
 }
 

@@ -4,8 +4,12 @@
 #include "../arena.hpp"
 #include "../core/engine.hpp"
 #include "../core/scene_engine.hpp"
+#include "../../../include/mi_engine.h"      // MI_SCENE_* sizes
 
 namespace mi {
+
+// one set of scene sizes for the C ABI (include/mi_engine.h), the arena layout, the kernels and the reset code
+static_assert(kSceneMaxFree == MI_SCENE_MAX_FREE && kSceneMaxStatic == MI_SCENE_MAX_STATIC, "core/scene_engine.hpp and include/mi_engine.h agree on the scene sizes");
 
 struct ArticulationParams {   // mirrors MiArticulationParams (include/mi_engine.h)
     float kp[kMaxDof], kd[kMaxDof];
@@ -35,7 +39,9 @@ MI_HD void articulation_scene_substep_env(const View& v, const SimParams& P, con
         kp[K] = p.kp[K]; kd[K] = p.kd[K]; vmax[K] = p.drive_vmax[K];
         // a velocity-limited drive: its position error is clamped to the error at which spring and damper balance at the limit speed
         // (kp e = kd vmax), so it approaches its target no faster than vmax and pushes with at most kd vmax
-        if (p.drive_vmax[K] > 0.f && kp[K] > 0.f) {
+        // (only for a drive that HAS a damper: with kd = 0 the balance error is 0 and the target would collapse onto q -- such a drive is bounded by
+        // the clamp of the solved joint velocity alone)
+        if (p.drive_vmax[K] > 0.f && kp[K] > 0.f && kd[K] > 0.f) {
             const float emax = p.drive_vmax[K] * kd[K] / kp[K];
             target[K] = sim.q[K] + fminf(fmaxf(target[K] - sim.q[K], -emax), emax);
         }
@@ -101,7 +107,7 @@ MI_HD void articulation_reset_env(const View& v, const ArticulationParams& p, co
     for (int i = 0; i < kSceneMaxFree; ++i)
         for (int k = 0; k < 13; ++k) v.scene[(size_t)(13 * i + k) * N + e] = (i < p.scene.n_free && k < 7) ? p.scene.free_init[i][k] : (k == 6 ? 1.f : 0.f);
     v.scene_nc[e] = 0; v.scene_nc[N + e] = 0;
-    for (int k = 0; k < 4 * (24 + 24); ++k) v.scene_warm[(size_t)k * N + e] = 0.f;
+    for (int k = 0; k < 4 * MI_SCENE_WARM_SLOTS; ++k) v.scene_warm[(size_t)k * N + e] = 0.f;
     v.progress[e] = 0; v.reset[e] = 0;
 }
 

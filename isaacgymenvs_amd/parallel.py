@@ -38,6 +38,27 @@ def init_distributed(backend=None):
     return rank, world, local_rank
 
 
+def _cores_in_topology_order(cores):
+    """the allowed cpus grouped by NUMA node (/sys/devices/system/node/node*/cpulist), nodes in order, so that a contiguous slice is a slice of
+    one socket even where SMT siblings are numbered N .. 2N-1 (raw cpu ids would put ranks 4-7 on the hyperthreads of ranks 0-3); falls back to
+    the ids as given"""
+    import glob
+    allowed, out = set(cores), []
+    try:
+        nodes = sorted(glob.glob("/sys/devices/system/node/node[0-9]*"), key=lambda p: int(p.rsplit("node", 1)[1]))
+        for nd in nodes:
+            ids = []
+            for part in open(os.path.join(nd, "cpulist")).read().strip().split(","):
+                if not part:
+                    continue
+                a, _, b = part.partition("-")
+                ids += list(range(int(a), int(b or a) + 1))
+            out += [c for c in ids if c in allowed]
+    except (OSError, ValueError):
+        return cores
+    return out if len(out) == len(cores) else cores
+
+
 def pin_to_local_cores(local_rank=None, local_world=None):
     """One process per GPU: give every rank of a node its own contiguous slice of the cores the job may use (sched_setaffinity).  The engine's host
     side is a single Python thread issuing one launch per step (~25 us of work per 40-170 us step); eight such threads migrating over two sockets
@@ -46,10 +67,15 @@ def pin_to_local_cores(local_rank=None, local_world=None):
     if os.getenv("MI_NO_AFFINITY") == "1" or not hasattr(os, "sched_setaffinity"):
         return None
     local_rank = int(os.getenv("LOCAL_RANK", "0")) if local_rank is None else local_rank
-    local_world = int(os.getenv("LOCAL_WORLD_SIZE", os.getenv("WORLD_SIZE", "1"))) if local_world is None else local_world
+    if local_world is None:
+        # only the launcher knows how many ranks share this node: without LOCAL_WORLD_SIZE (mpirun / slurm launches) WORLD_SIZE would be the
+        # JOB's size and every rank of a multi-node job would get cores / world of its node -- leave the scheduler alone instead
+        if "LOCAL_WORLD_SIZE" not in os.environ:
+            return None
+        local_world = int(os.environ["LOCAL_WORLD_SIZE"])
     if local_world <= 1:
         return None
-    cores = sorted(os.sched_getaffinity(0))
+    cores = _cores_in_topology_order(sorted(os.sched_getaffinity(0)))
     per = len(cores) // local_world
     if per < 1:
         return None

@@ -135,14 +135,30 @@ class VecTask(Env):
         self.allocate_buffers()
         self.obs_dict = {}
         self._job_extras = None
-        if config.get("_multi_gpu", False):
+        # OPT-IN: the reference's VecTask.step has no collective, and a collective inside step() obliges every rank to call step() the
+        # same number of times.  `multi_gpu=True` alone therefore shards and nothing else; job-wide extras are asked for with
+        # cfg["_job_extras"] = True (or MI_JOB_EXTRAS=1), or later with env.enable_job_extras(interval).
+        if config.get("_multi_gpu", False) and (bool(config.get("_job_extras", False)) or os.getenv("MI_JOB_EXTRAS") == "1"):
             self._enable_job_extras(int(config.get("_extras_interval", 16)))
 
+    def enable_job_extras(self, interval: int = 16):
+        """public switch of the job-wide `extras` (see _enable_job_extras); every rank of the job must call it, and step(), in lockstep"""
+        self._enable_job_extras(int(interval))
+        return self._job_extras is not None
+
+    def disable_job_extras(self):
+        """stop issuing the collective (e.g. before a rank-0-only evaluation loop); the rank's own values return to `extras` with the next step"""
+        if self._job_extras is not None:
+            self._job_extras.rebase()      # waits for the reduction in flight
+        self._job_extras = None
+
     def _enable_job_extras(self, interval):
-        """Sharded run (`make(..., multi_gpu=True)` inside a torch.distributed job): the task's `extras` statistics become JOB-wide -- SURVEY 8e's
+        """Sharded run (`make(..., multi_gpu=True)` inside a torch.distributed job, with cfg["_job_extras"]): the task's `extras` statistics become JOB-wide -- SURVEY 8e's
         one collective, a SUM all-reduce of <= 16 numbers on a side stream every `interval` steps (parallel.TaskExtrasReducer); step() publishes
         each completed window (one window behind, never blocking the step stream) and keeps this rank's own values under `*_rank`.
-        Ant / Humanoid / ... have no task extras of this kind: their episode statistics go through parallel.EpisodeStatsReducer."""
+        LOCKSTEP CONTRACT: while this is on, every rank must call step() the same number of times -- a rank that stops stepping (early exit, a
+        rank-0-only evaluation) leaves the others waiting in the all-reduce until the process group's timeout; call disable_job_extras() on every
+        rank first.  Ant / Humanoid / ... have no task extras of this kind: their episode statistics go through parallel.EpisodeStatsReducer."""
         import torch.distributed as dist
         if self.native_task not in ("AnymalTerrain", "ShadowHand", "AllegroHand") or not (dist.is_available() and dist.is_initialized()):
             return

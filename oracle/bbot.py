@@ -26,7 +26,7 @@ import math
 import numpy as np
 
 from .engine import OracleEngine, _ptr
-from .hand import contact_frame, quat2mat
+from .hand import contact_frame, friction_step, quat2mat
 
 ATT_K, ATT_C = 5e7, 5e3                 # ball_balance.py:287-288
 DRIVE_KP, DRIVE_KD = 4000.0, 100.0      # :276-277
@@ -174,17 +174,13 @@ class OracleBbotEngine:
                     ln = max(rn["lam"] - (vn - rn["vt"]) * rn["Ainv"], 0.0)
                     dl = ln - rn["lam"]; rn["lam"] = ln
                     v += rn["Bt"] * dl; vball += rn["Bb"] * dl
-                    lt = []
-                    for rt in (ra, rb):
-                        vt_ = rt["Jt"] @ v + rt["Jb"] @ vball
-                        dl = -vt_ * rt["Ainv"]
-                        lt.append(rt["lam"] + dl)
-                        v += rt["Bt"] * dl; vball += rt["Bb"] * dl
-                    lim = MU * ln
-                    nrm = np.hypot(lt[0], lt[1])
-                    sc = lim / max(nrm, 1e-30) if nrm > lim else 1.0
-                    for rt, l in zip((ra, rb), lt):
-                        nl_ = l * sc; dl = nl_ - l; rt["lam"] = nl_
+                    # both tangent rows from the SAME velocity, then the disc projection, one application (round 6: solving and applying t1
+                    # before t2 is looked at let a fast-sliding contact's friction point off the sliding direction)
+                    vtan = [rt["Jt"] @ v + rt["Jb"] @ vball for rt in (ra, rb)]
+                    lt = friction_step([rt["lam"] - vt_ * rt["Ainv"] for rt, vt_ in zip((ra, rb), vtan)], (ra["lam"], rb["lam"]), vtan,
+                                       (ra["Ainv"], rb["Ainv"]), MU * ln)
+                    for rt, nl_ in zip((ra, rb), lt):
+                        dl = nl_ - rt["lam"]; rt["lam"] = nl_
                         v += rt["Bt"] * dl; vball += rt["Bb"] * dl
                     i += 3
         # ---- outputs

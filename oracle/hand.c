@@ -348,21 +348,19 @@ static void hand_substep(const OrModel *m, const OrParams *p, const OrHand *hd, 
                 real dl = ln - lam[r0];
                 lam[r0] = ln;
                 for (int i = 0; i < nv; i++) v[i] += Bm[r0][i] * dl;
-                real lt[2];
-                for (int k = 1; k <= 2; k++) {
+                real lt[2], vtan[2];
+                for (int k = 1; k <= 2; k++) {      /* both tangent corrections from the same velocity, then the disc, one application (physics.c friction_step) */
                     int r = r0 + k;
                     real vv = 0;
                     for (int i = 0; i < nv; i++) vv += J[r][i] * v[i];
-                    dl = -vv * Ainv[r];
-                    lt[k - 1] = lam[r] + dl;
-                    for (int i = 0; i < nv; i++) v[i] += Bm[r][i] * dl;
+                    vtan[k - 1] = vv;
+                    lt[k - 1] = lam[r] - vv * Ainv[r];
                 }
-                real lim = mu * ln, nrm = RSQRT(lt[0] * lt[0] + lt[1] * lt[1]);
-                real sc = nrm > lim ? lim / (nrm > (real)1e-30 ? nrm : (real)1e-30) : 1;
+                friction_step(lt, lam[r0 + 1], lam[r0 + 2], vtan, Ainv[r0 + 1], Ainv[r0 + 2], mu * ln);
                 for (int k = 1; k <= 2; k++) {
                     int r = r0 + k;
-                    real nl = lt[k - 1] * sc;
-                    dl = nl - lt[k - 1];
+                    real nl = lt[k - 1];
+                    dl = nl - lam[r];
                     lam[r] = nl;
                     for (int i = 0; i < nv; i++) v[i] += Bm[r][i] * dl;
                 }

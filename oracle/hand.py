@@ -27,6 +27,26 @@ CUBE_MASS = 567.0 * 0.05 ** 3                      # cube_multicolor.urdf: box 0
 CUBE_INERTIA = CUBE_MASS * 0.05 ** 2 / 6.0         # isotropic
 
 
+def friction_step(lt, lam_t, vtan, ainv, lim):
+    """oracle/physics.c friction_step: the per-row step `lt` stands inside the friction disc; a contact that slides takes one step size for both
+    rows (the smaller of the two) and is scaled back onto the disc -- friction antiparallel to the sliding velocity; in between, the point of the
+    segment between the two steps that lies on the circle (continuity)"""
+    r = np.array(lt, float)
+    if np.hypot(r[0], r[1]) <= lim:
+        return [r[0], r[1]]
+    ac = min(ainv)
+    s = np.array([lam_t[0] - vtan[0] * ac, lam_t[1] - vtan[1] * ac])
+    nrm = np.hypot(s[0], s[1])
+    if nrm >= lim:
+        sc = lim / max(nrm, 1e-30)
+        return [s[0] * sc, s[1] * sc]
+    d = r - s
+    a, b, c = max(d @ d, 1e-30), s @ d, s @ s - lim * lim
+    t = (np.sqrt(max(b * b - a * c, 0.0)) - b) / a
+    x = s + t * d
+    return [x[0], x[1]]
+
+
 def quat2mat(q):
     x, y, z, w = q
     return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
@@ -425,17 +445,13 @@ class OracleHandEngine:
                     ln = max(rn["lam"] - (vn - rn["vt"]) * rn["Ainv"], 0.0)
                     dl = ln - rn["lam"]; rn["lam"] = ln
                     v += rn["Bh"] * dl; vobj += rn["Bo"] * dl
-                    lt = []
-                    for rt in (ra, rb):
-                        vt_ = rt["Jh"] @ v + rt["Jo"] @ vobj
-                        dl = -vt_ * rt["Ainv"]
-                        lt.append(rt["lam"] + dl)
-                        v += rt["Bh"] * dl; vobj += rt["Bo"] * dl
-                    lim = mu * ln
-                    nrm = np.hypot(lt[0], lt[1])
-                    sc = lim / max(nrm, 1e-30) if nrm > lim else 1.0
-                    for rt, l in zip((ra, rb), lt):
-                        nl_ = l * sc; dl = nl_ - l; rt["lam"] = nl_
+                    # both tangent rows from the SAME velocity, then the disc projection, one application (round 6: solving and applying t1
+                    # before t2 is looked at let a fast-sliding contact's friction point off the sliding direction)
+                    vtan = [rt["Jh"] @ v + rt["Jo"] @ vobj for rt in (ra, rb)]
+                    lt = friction_step([rt["lam"] - vt_ * rt["Ainv"] for rt, vt_ in zip((ra, rb), vtan)], (ra["lam"], rb["lam"]), vtan,
+                                       (ra["Ainv"], rb["Ainv"]), mu * ln)
+                    for rt, nl_ in zip((ra, rb), lt):
+                        dl = nl_ - rt["lam"]; rt["lam"] = nl_
                         v += rt["Bh"] * dl; vobj += rt["Bo"] * dl
                     i += 3
         # ---- outputs

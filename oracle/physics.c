@@ -528,6 +528,32 @@ static real drive_clamp_update(const OrDriveClamp *cl, int r, real v_d, real a, 
     return dr;
 }
 
+/* The tangential update of one contact: lt[] comes in as the per-row step r_k = lam_k - v_k / a_kk.  Inside the friction disc (|r| <= lim, the
+   contact sticks) it stands.  A contact that slides takes one step size for both rows instead -- s_k = lam_k - v_k / max(a_11, a_22): never a longer
+   step than either row would take alone -- scaled back onto the disc.  Why: the fixed point of "step, radial projection" satisfies
+   lam_t || -(D^-1 v_t); with the per-row D = diag(a_11, a_22) that is not Coulomb's law -- measured before round 6: a Humanoid lying on the ground
+   and sliding at 31 degrees to the tangent axes was braked along 15 degrees --; with D a multiple of the identity it is: friction antiparallel to the
+   sliding velocity (tests/friction_util.py).  Between the regimes (|s| < lim < |r|): the point of the segment s -> r on the circle, which makes the
+   update continuous in its inputs. */
+static void friction_step(real *lt, real lam1, real lam2, const real *vtan, real ainv1, real ainv2, real lim) {
+    real r0 = lt[0], r1 = lt[1], l2 = lim * lim;
+    if (r0 * r0 + r1 * r1 <= l2) return;
+    real ac = ainv1 < ainv2 ? ainv1 : ainv2;
+    real s0 = lam1 - vtan[0] * ac, s1 = lam2 - vtan[1] * ac;
+    real n2 = s0 * s0 + s1 * s1;
+    if (n2 >= l2) {
+        real nrm = RSQRT(n2), sc = lim / (nrm > (real)1e-30 ? nrm : (real)1e-30);
+        lt[0] = s0 * sc; lt[1] = s1 * sc;
+        return;
+    }
+    real d0 = r0 - s0, d1 = r1 - s1;
+    real a = d0 * d0 + d1 * d1, b = s0 * d0 + s1 * d1, c = n2 - l2;
+    if (a < (real)1e-30) a = (real)1e-30;
+    real disc = b * b - a * c;
+    real t = (RSQRT(disc > 0 ? disc : 0) - b) / a;
+    lt[0] = s0 + t * d0; lt[1] = s1 + t * d1;
+}
+
 static void solve_blocks(const OrModel *m, const OrParams *p, Work *wk, int nv, int nrow, real (*J)[MAXV], const real *vt, real *lam,
                          real *v, int nunit, const int *u_row, const int *u_kind, const int *u_blk, const real *u_mu,
                          const int *u_ga, const int *u_gb) {
@@ -600,20 +626,23 @@ static void solve_blocks(const OrModel *m, const OrParams *p, Work *wk, int nv, 
                     for (int i = 0; i < nv; i++) wloc[i] += om[grp[i]] * G[r0][i] * dl;
                 }
                 if (u_kind[u] == 0) continue;
-                real lt[2];
+                /* the two tangent rows TOGETHER: both corrections from the same velocity, the disc projection, one application (round 6; until then
+                   t1 was solved and applied before t2 was looked at: a fast-sliding contact's unclamped t1 impulse turned the body, t2 cancelled a
+                   lateral velocity only that impulse had created, and the projected friction pointed off the sliding direction) */
+                real lt[2], vtan[2];
                 for (int k = 1; k <= 2; k++) {
                     int r = r0 + k;
                     real vn = 0;
                     for (int i = 0; i < nv; i++) vn += G[r][i] * wloc[i];
-                    real dl = -(vn - vt[r]) * Ain[k];
-                    lt[k - 1] = lam[r] + dl;
-                    for (int i = 0; i < nv; i++) wloc[i] += om[grp[i]] * G[r][i] * dl;
+                    vtan[k - 1] = vn - vt[r];
+                    lt[k - 1] = lam[r] - vtan[k - 1] * Ain[k];
                 }
-                real lim = u_mu[u] * lam[r0], nrm = RSQRT(lt[0] * lt[0] + lt[1] * lt[1]);
-                real sc = (nrm > lim) ? lim / (nrm > (real)1e-30 ? nrm : (real)1e-30) : 1;
+                real lim = u_mu[u] * lam[r0];
+                friction_step(lt, lam[r0 + 1], lam[r0 + 2], vtan, Ain[1], Ain[2], lim);
+                real sc = 1;
                 for (int k = 1; k <= 2; k++) {
                     int r = r0 + k;
-                    real nl = lt[k - 1] * sc, dl = nl - lt[k - 1];
+                    real nl = lt[k - 1] * sc, dl = nl - lam[r];
                     lam[r] = nl;
                     if (dl != 0) for (int i = 0; i < nv; i++) wloc[i] += om[grp[i]] * G[r][i] * dl;
                 }
@@ -847,21 +876,23 @@ static void step_env(const OrModel *m, const OrParams *p, const OrGround *gnd, r
                     lam[r] = nl;
                     for (int i = 0; i < nv; i++) v[i] += B[r][i] * dl;
                 }
-                real lt[2];
-                for (int k = 1; k <= 2; k++) { /* unclamped tangential updates */
+                real lt[2], vtan[2];
+                for (int k = 1; k <= 2; k++) { /* both tangential corrections from the same velocity (see solve_blocks) */
                     int r = r0 + k;
                     real vn = 0;
                     for (int i = 0; i < nv; i++) vn += J[r][i] * v[i];
-                    real dl = -(vn - vt[r]) * Ainv[r];
-                    lt[k - 1] = lam[r] + dl;
-                    for (int i = 0; i < nv; i++) v[i] += B[r][i] * dl;
+                    vtan[k - 1] = vn - vt[r];
+                    lt[k - 1] = lam[r] - vtan[k - 1] * Ainv[r];
                 }
-                /* project onto the friction disc |lt| <= mu * ln, apply the correction */
-                real lim = mu * lam[r0], nrm = RSQRT(lt[0] * lt[0] + lt[1] * lt[1]);
-                real sc = (nrm > lim) ? lim / (nrm > (real)1e-30 ? nrm : (real)1e-30) : 1;
+                /* project onto the friction disc |lt| <= mu * ln, apply once.  A contact that SLIDES (the per-row step leaves the disc) repeats the step
+                   with ONE step size for both rows before it is scaled back: the fixed point of "row step, radial projection" has the friction
+                   antiparallel to D^-1 v (D = the rows' diagonal), which is Coulomb's law only when D is a multiple of the identity (friction_step) */
+                real lim = mu * lam[r0];
+                friction_step(lt, lam[r0 + 1], lam[r0 + 2], vtan, Ainv[r0 + 1], Ainv[r0 + 2], lim);
+                real sc = 1;
                 for (int k = 1; k <= 2; k++) {
                     int r = r0 + k;
-                    real nl = lt[k - 1] * sc, dl = nl - lt[k - 1];
+                    real nl = lt[k - 1] * sc, dl = nl - lam[r];
                     lam[r] = nl;
                     if (dl != 0) for (int i = 0; i < nv; i++) v[i] += B[r][i] * dl;
                 }
@@ -880,20 +911,23 @@ static void step_env(const OrModel *m, const OrParams *p, const OrGround *gnd, r
                     lam[r] = nl;
                     for (int i = 0; i < nv; i++) v[i] += B[r][i] * dl;
                 }
-                real lt[2];
-                for (int k = 1; k <= 2; k++) {
+                real lt[2], vtan[2];
+                for (int k = 1; k <= 2; k++) { /* both tangential corrections from the same velocity (see solve_blocks) */
                     int r = r0 + k;
                     real vn = 0;
                     for (int i = 0; i < nv; i++) vn += J[r][i] * v[i];
-                    real dl = -(vn - vt[r]) * Ainv[r];
-                    lt[k - 1] = lam[r] + dl;
-                    for (int i = 0; i < nv; i++) v[i] += B[r][i] * dl;
+                    vtan[k - 1] = vn - vt[r];
+                    lt[k - 1] = lam[r] - vtan[k - 1] * Ainv[r];
                 }
-                real lim = mu * lam[r0], nrm = RSQRT(lt[0] * lt[0] + lt[1] * lt[1]);
-                real sc = (nrm > lim) ? lim / (nrm > (real)1e-30 ? nrm : (real)1e-30) : 1;
+                /* project onto the friction disc |lt| <= mu * ln, apply once.  A contact that SLIDES (the per-row step leaves the disc) repeats the step
+                   with ONE step size for both rows before it is scaled back: the fixed point of "row step, radial projection" has the friction
+                   antiparallel to D^-1 v (D = the rows' diagonal), which is Coulomb's law only when D is a multiple of the identity (friction_step) */
+                real lim = mu * lam[r0];
+                friction_step(lt, lam[r0 + 1], lam[r0 + 2], vtan, Ainv[r0 + 1], Ainv[r0 + 2], lim);
+                real sc = 1;
                 for (int k = 1; k <= 2; k++) {
                     int r = r0 + k;
-                    real nl = lt[k - 1] * sc, dl = nl - lt[k - 1];
+                    real nl = lt[k - 1] * sc, dl = nl - lam[r];
                     lam[r] = nl;
                     if (dl != 0) for (int i = 0; i < nv; i++) v[i] += B[r][i] * dl;
                 }

@@ -20,7 +20,7 @@ import ctypes as C
 import numpy as np
 
 from .engine import OracleEngine, _ptr
-from .hand import contact_frame, quat2mat, sphere_box3
+from .hand import contact_frame, friction_step, quat2mat, sphere_box3
 
 KARM, KBOX = 24, 24                   # csrc/core/scene_engine.hpp SceneSim::KARM / KBOX
 MAX_W, MAX_V = 64.0, 1000.0           # csrc/core/engine.hpp kMaxAngularVelocity / kMaxLinearVelocity
@@ -71,7 +71,7 @@ class OracleSceneEngine:
         P, nd, spec = self.sim, self.nd, self.spec
         q, qd, tgt = self.q[e].copy(), self.qd[e].copy(), self.targets[e].copy()
         for d in range(nd):
-            if self.drive_vmax[d] > 0 and self.kp[d] > 0:
+            if self.drive_vmax[d] > 0 and self.kp[d] > 0 and self.kd[d] > 0:      # (a drive without a damper is bounded by the velocity clamp alone)
                 emax = self.drive_vmax[d] * self.kd[d] / self.kp[d]
                 tgt[d] = q[d] + min(max(tgt[d] - q[d], -emax), emax)
         M, bias = self.eng.dynamics(e)
@@ -115,6 +115,12 @@ class OracleSceneEngine:
             vt = -Cc / h if Cc >= 0 else min(-Cc * P["erp"] / h, P["max_depen_vel"])
             rows.append(dict(kind="lim", Jh=Jh, vt=vt, lam=l0, d=d, s=s))
         contacts = []      # dict(Jh[3][nd] or None, ia, ib, n, t1, t2, pc, vtn, mu)
+        moved = [False] * spec.nb                    # does any dof sit on the body or on one of its ancestors
+        for b_ in range(spec.nb):
+            a = b_
+            while a >= 0 and not moved[b_]:
+                moved[b_] = bool((np.asarray(spec.dof_body) == a).any())
+                a = int(spec.parent[a])
         refused = 0
         narm = 0
         for si in range(len(spec.sph_body)):
@@ -122,6 +128,8 @@ class OracleSceneEngine:
             cs = bp[b, 0:3] + bp[b, 3:12].reshape(3, 3) @ np.asarray(spec.sph_pos[si], float)
             rad = float(spec.sph_rad[si])
             for t in range(nf + len(self.static)):
+                if t >= nf and not moved[b]:
+                    continue               # a body no dof moves (the fixed base link) against a static box: the row would act on nothing
                 if t < nf:
                     Rb, xb, hb, mub, ib = Rf[t], xf[t], self.free[t]["half"], self.free[t]["mu"], t
                 else:
@@ -223,12 +231,11 @@ class OracleSceneEngine:
                         apply(cdat, r, r["lam"])
                 ln = max(rn["lam"] - (rowvel(cdat, rn) - cdat["vtn"]) * rn["Ainv"], 0.0)
                 apply(cdat, rn, ln - rn["lam"]); rn["lam"] = ln
-                lt = [rt["lam"] - rowvel(cdat, rt) * rt["Ainv"] for rt in (ra, rb)]        # both tangent rows from the same velocity
-                lim = cdat["mu"] * ln
-                nrm = np.hypot(lt[0], lt[1])
-                sc = lim / max(nrm, 1e-30) if nrm > lim else 1.0
+                vtan = [rowvel(cdat, rt) for rt in (ra, rb)]                                # both tangent rows from the same velocity
+                lt = friction_step([rt["lam"] - vt_ * rt["Ainv"] for rt, vt_ in zip((ra, rb), vtan)], (ra["lam"], rb["lam"]), vtan,
+                                   (ra["Ainv"], rb["Ainv"]), cdat["mu"] * ln)               # oracle/hand.py: a sliding contact steps isotropically
                 for rt, l in zip((ra, rb), lt):
-                    apply(cdat, rt, l * sc - rt["lam"]); rt["lam"] = l * sc
+                    apply(cdat, rt, l - rt["lam"]); rt["lam"] = l
         for d in range(nd):                      # the asset's joint velocity limits: clamp of the solved velocities
             if self.drive_vmax[d] > 0:
                 v[d] = min(max(v[d], -self.drive_vmax[d]), self.drive_vmax[d])

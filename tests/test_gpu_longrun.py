@@ -26,7 +26,7 @@ def _oracle(task, env, n, seed):
     return OT.OracleBallBalanceEnv(load_model("balance_bot"), sensor_bodies("balance_bot"), sd, p, balance_bot_dims(), n, seed=seed)
 
 
-@pytest.mark.parametrize("task,n,steps", [("Ant", 128, 500), ("Humanoid", 128, 250), ("Quadcopter", 128, 500), ("Ingenuity", 128, 600), ("BallBalance", 96, 300)])
+@pytest.mark.parametrize("task,n,steps", [("Ant", 512, 500), ("Humanoid", 128, 250), ("Quadcopter", 128, 500), ("Ingenuity", 128, 600), ("BallBalance", 96, 300)])
 def test_long_rollout_statistics_match_the_oracle(task, n, steps):
     seed = 17
     env = _make_env(task, n, seed=seed)
@@ -44,6 +44,9 @@ def test_long_rollout_statistics_match_the_oracle(task, n, steps):
             eng = orc.eng.eng if hasattr(orc.eng, "eng") else orc.eng
             O["vmax"] = max(O["vmax"], float(np.abs(eng.qd).max()))
     assert O["resets"] > 0
-    assert abs(G["resets"] - O["resets"]) <= 0.08 * O["resets"] + 4, (G, O)
+    # Two chaotic rollouts that have parted are independent samples: their reset counts differ like two Poisson counts, sigma = sqrt(2 N).  The band is
+    # 4 % of the count (a systematic difference) plus 2.5 sigma (round 5's flat 8 % + 4 was less than ONE sigma at the Ant's ~180 resets and failed on
+    # the first change of the physics that moved the chaos; the Ant now runs 512 envs, ~700 resets, so that the band is 17 % of the count)
+    assert abs(G["resets"] - O["resets"]) <= 0.04 * O["resets"] + 2.5 * np.sqrt(2.0 * O["resets"]) + 2, (G, O)
     assert abs(G["rew"] - O["rew"]) <= 0.12 * abs(O["rew"]) + 0.02 * steps, (G, O)
     assert abs(G["vmax"] - O["vmax"]) <= 0.25 * O["vmax"] + 1.0, (G, O)

@@ -207,6 +207,31 @@ def test_friction_cone_on_a_tilted_plane():
     np.testing.assert_allclose(f[:, 2].sum(), spec.total_mass() * G * np.cos(th), rtol=2e-3)
 
 
+@pytest.mark.parametrize("robot,solver", [("ant", "gs"), ("ant", "blocks"), ("humanoid", "gs"), ("humanoid", "blocks"), ("humanoid", "blocks+caps")])
+def test_friction_opposes_the_sliding_velocity(robot, solver):
+    """Coulomb's law on a tilted plane and on level ground, for the Ant on its foot spheres and the Humanoid lying on its capsules' end spheres
+    (tests/friction_util.py): static below the friction angle; a = g (sin theta - mu cos theta) along the fall line -- a DIAGONAL
+    of the tangent axes -- and nothing across it; stop distance v0^2 / (2 mu g) on the line of the push.  With the rows' own step sizes (before
+    round 6) the Humanoid was braked 16 degrees off its sliding direction: lateral acceleration 0.27 m/s^2, stop 2.2 cm beside the line."""
+    import friction_util as F
+    from isaacgymenvs_amd.assets.model import solver_blocks
+    spec = load_model(robot)
+    kw = dict(solver="blocks", blocks=solver_blocks(spec)) if solver == "blocks" else {}
+    if solver == "blocks+caps":        # as the Humanoid's limb-wave kernels run it: self-collision on, ground contacts capped per wave (4 / 4 / 3)
+        from isaacgymenvs_amd.registry import load_selfcol
+        kw = dict(solver="blocks", blocks=solver_blocks(spec, self_collision=True, wave_caps=True), selfcol=load_selfcol(robot), kpair=3)
+    p = dict(dt=1.0 / 60.0, substeps=2, iters=4, gravity=(0.0, 0.0, -G), contact_offset=0.02, rest_offset=0.0, max_depen_vel=10.0, erp=0.5,
+             plane_mu=1.0, ground_z=0.0, cfm=1e-6, warm=1.0)
+    e = OracleEngine(spec, 1, params=p, sensor_bodies=sensor_bodies(robot), precision="f64", **kw)
+    mu = 0.5
+    out = F.friction_known_answers(F.OracleRig(e, env_mu=np.array([2.0 * mu - 1.0])), spec, robot, mu, 1.0 / 60.0)
+    ae, th, de = out["slide_acc_expected"], out["slide_theta"], out["stop_dist_expected"]
+    strict = robot == "humanoid" or solver == "blocks"      # (the PD-held Ant creeps at cm/s in the one-sequence order at 4 iterations: tests/test_friction.py)
+    assert out["stick_speed"] < (1e-3 if strict else 0.1) and out["stick_shift"] < (0.02 if strict else 0.25), out
+    assert abs(out["slide_acc"][0] - ae) < 0.03 * ae and abs(out["slide_acc_lateral"][0]) < 0.015 * G * np.sin(th), out
+    assert 0.80 * de < out["stop_dist"][0] < 1.05 * de and abs(out["stop_lateral"][0]) < 0.01 * de and out["stop_speed"] < 5e-3, out
+
+
 def test_angular_momentum_of_a_tumbling_body_converges_first_order():
     """Torque-free flight of the articulated Humanoid with all joints moving.  Joint springs / dampers are internal forces, so
     the total angular momentum about the centre of mass (from the oracle's own body velocities) is conserved by the equations of

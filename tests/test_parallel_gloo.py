@@ -43,6 +43,7 @@ WORKER = textwrap.dedent("""
         cfg["task"]["env"]["numEnvs"] = n
         cfg["task"]["_base_seed"] = seed
         cfg["task"]["_extras_interval"] = 4
+        cfg["task"]["_job_extras"] = True          # job-wide extras are opt-in: multi_gpu=True alone issues no collective from step()
         env = isaacgymenvs_amd.make(seed=seed, task=task, num_envs=n, sim_device="cpu", rl_device="cpu", headless=True, multi_gpu=sharded, cfg=cfg)
         total = n * world if sharded else n
         g = torch.Generator().manual_seed(3)
@@ -143,7 +144,7 @@ def test_world_size_2_gloo(tmp_path):
     port = _free_port()
     procs = []
     for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="2")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]

@@ -23,7 +23,7 @@ SIZE_A, SIZE_B = 0.050, 0.070                        # :225-226
 Q0 = [0.0, 0.1963, 0.0, -2.618, 0.0, 2.9416, 0.7854, 0.035, 0.035]       # the task's default arm pose (:75-77)
 
 
-def _build(device, n=8):
+def _build(device, n=8, finger_damping=100.0):
     """the env of franka_cube_stack.py:180-345, actor by actor"""
     import isaacgymenvs_amd.shims as shims
     from isaacgymenvs_amd import native
@@ -49,7 +49,7 @@ def _build(device, n=8):
     cube_b = gym.create_box(sim, SIZE_B, SIZE_B, SIZE_B, gymapi.AssetOptions())
     dp = gym.get_asset_dof_properties(franka)
     dp["driveMode"][:7], dp["stiffness"][:7], dp["damping"][:7] = gymapi.DOF_MODE_EFFORT, 0.0, 0.0
-    dp["driveMode"][7:], dp["stiffness"][7:], dp["damping"][7:] = gymapi.DOF_MODE_POS, 5000.0, 100.0
+    dp["driveMode"][7:], dp["stiffness"][7:], dp["damping"][7:] = gymapi.DOF_MODE_POS, 5000.0, finger_damping
     T = gymapi.Transform
     for i in range(n):
         env = gym.create_env(sim, gymapi.Vec3(), gymapi.Vec3(), 4)
@@ -447,6 +447,42 @@ def _push(device):
     gym.refresh_rigid_body_state_tensor(sim)
     assert float(osc.rb[:, osc.tip, 2].min()) > TOP - 4e-3 and float(osc.rb[:, osc.tip, 2].max()) < TOP + 0.02
     assert torch.isfinite(osc.dof).all()
+
+
+def _undamped_drive(device):
+    """a DOF_MODE_POS dof with a URDF velocity limit, kp > 0 and kd = 0 inside a scene.  The drive's error clamp is `vmax kd / kp` -- the error
+    at which spring and damper balance at the limit speed --, which is 0 without a damper: the target collapsed onto q every sub-step and the finger
+    never moved.  Such a drive is now bounded by the clamp of the solved joint velocity alone: the fingers close at the URDF's 0.2 m/s
+    (franka_panda_gripper.urdf:247) and arrive."""
+    n = 4
+    gym, sim, franka, dp = _build(device, n, finger_damping=0.0)
+    _arm_home(gym, sim, n)
+    a, b = np.zeros((n, 13)), np.zeros((n, 13))
+    a[:, 6] = b[:, 6] = 1.0
+    a[:, 0:3] = [0.3, -0.3, TOP + SIZE_A / 2]; b[:, 0:3] = [0.3, 0.3, TOP + SIZE_B / 2]        # both cubes out of the gripper's way
+    _place(gym, sim, n, a, b)
+    dof = gym.acquire_dof_state_tensor(sim).view(n, 9, 2)
+    tg = torch.tensor(Q0, device=sim.device).repeat(n, 1).clone()
+    tg[:, 7:] = 0.005                                                      # close the fingers from 35 mm to 5 mm
+    gym.set_dof_position_target_tensor(sim, tg.view(-1))
+    vmax = 0.0
+    for step in range(30):
+        gym.simulate(sim)
+        gym.refresh_dof_state_tensor(sim)
+        vmax = max(vmax, float(dof[:, 7:, 1].abs().max()))
+        if step == 2:
+            assert float(dof[:, 7:, 0].max()) < 0.035 - 0.5 * 3 * 0.2 / 60.0, dof[0, 7:, 0]      # they do move, at about the limit speed
+    q = dof[:, 7:, 0].cpu().numpy()
+    assert np.abs(q - 0.005).max() < 2e-3 and vmax <= 0.2 + 1e-3, (q, vmax)
+
+
+def test_scene_position_drive_without_a_damper_moves_cpu():
+    _undamped_drive("cpu")
+
+
+@pytest.mark.gpu
+def test_scene_position_drive_without_a_damper_moves_hip():
+    _undamped_drive("cuda:0")
 
 
 def test_scene_arm_pushes_a_cube_cpu():
