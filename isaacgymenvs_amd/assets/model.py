@@ -1127,8 +1127,13 @@ def self_collision_groups(spec: ModelSpec, pairs=None):
                 groups.setdefault((la, lb), []).append((int(i), int(j)))
             else:
                 groups.setdefault((lb, la), []).append((int(j), int(i)))
+    # Order: by limb pair, but the groups whose two limbs BOTH belong to the trunk role of the limb-per-wave form (the trunk itself, or a limb that
+    # role owns: the Humanoid's arms) come LAST.  That role examines them itself, from the sphere centres its own tree pass leaves behind, while
+    # the pair role works through the others (csrc/core/engine_mwc.hpp, round 6); slots are dealt in table order by every form and by the oracle.
+    _, _, role_of_limb, trunk_role, _ = wave_roles(spec, pair_role=True)
+    own = lambda l: l == 0 or role_of_limb[l] == trunk_role     # noqa: E731
     out = []
-    for (la, lb), gps in sorted(groups.items()):
+    for (la, lb), gps in sorted(groups.items(), key=lambda kv: ((own(kv[0][0]) and own(kv[0][1])), kv[0])):
         out.append(dict(limb_a=la, limb_b=lb, tip_a=limbs[la][-1], tip_b=limbs[lb][-1], pairs=sorted(gps)))
     return out
 

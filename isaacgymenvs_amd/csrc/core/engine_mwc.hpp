@@ -144,6 +144,63 @@ struct SimMWC : SimMW<M> {
         });
     }
 
+    // ---------------------------------------------------------------- who examines a self-collision group
+    // A group whose two limbs BOTH belong to the trunk role (the trunk itself, or a limb that role owns: the Humanoid's arms) is examined by THAT role,
+    // from the sphere centres its own tree pass leaves in c.xcs, in the slack it has before B2; the pair role examines the others.  (Until round 6 the
+    // pair role examined all of them and arrived last at B1 and at B2: every limb role waited ~60 units per sub-step for it, tools/debug/mwc_phases.py.)
+    // The model's table lists the trunk role's groups LAST (assets/model.py self_collision_groups), and slots are dealt in table order: the pair role
+    // fills slots 0 .. before B2, the trunk role continues behind them after B2 -- the order of every other form and of the oracle.
+    static constexpr bool pg_trunk_role(int g) {
+        if (NPG == 0) return false;
+        const int la = M::limb_of_body[M::pg_tip_a[g]], lb = M::limb_of_body[M::pg_tip_b[g]];
+        return (la == 0 || M::role_of_limb[la] == M::TRUNK_ROLE) && (lb == 0 || M::role_of_limb[lb] == M::TRUNK_ROLE);
+    }
+    static constexpr int NPGP = []() constexpr { int n = 0; for (int g = 0; g < (NPG > 0 ? NPG : 0); ++g) { if (pg_trunk_role(g)) break; ++n; } return n; }();
+    static constexpr int NTG = (NPG > 0 ? NPG : 0) - NPGP;                                    // groups of the trunk role
+    static constexpr bool pg_suffix() { for (int g = NPGP; g < (NPG > 0 ? NPG : 0); ++g) if (!pg_trunk_role(g)) return false; return true; }
+    static_assert(pg_suffix(), "the trunk role's self-collision groups are the last ones of the table");
+    // the deepest capsule pair of group g: distance (3e38: none was near), closest points, its index in the group
+    template <int g>
+    MI_HD static void pair_group_search(const SimParams& P, const float (*xa)[3], const float (*capm)[3], float& best, float (&bca)[3], float (&bcb)[3], int& bk) {
+        best = 3.0e38f; bk = 0;
+        sfor<3>([&](auto I_) MI_LAMBDA { bca[I_] = 0.f; bcb[I_] = 0.f; });
+        sfor<M::pg_count[g]>([&](auto K_) MI_LAMBDA {
+            constexpr int k = M::pg_first[g] + K_, ia = M::gp_a[k], ib = M::gp_b[k];
+            constexpr float reach = B::cap_bound(ia) + B::cap_bound(ib);
+            const float dm[3] = {capm[ia][0] - capm[ib][0], capm[ia][1] - capm[ib][1], capm[ia][2] - capm[ib][2]};
+            const float rr = reach + P.contact_offset;
+            if (!MI_WAVE_ANY(dot3(dm, dm) < rr * rr)) return;
+            float ca[3], cb[3];
+            seg_seg_closest<B::cap_is_point(ia), B::cap_is_point(ib)>(xa[M::cap_s0[ia]], xa[M::cap_s1[ia]], xa[M::cap_s0[ib]], xa[M::cap_s1[ib]], ca, cb);
+            const float dv[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]};
+            const float dist = MI_SQRT(dot3(dv, dv)) - (M::cap_rad[ia] + M::cap_rad[ib]);
+            const bool better = dist < best;
+            best = better ? dist : best;
+            sfor<3>([&](auto I_) MI_LAMBDA { bca[I_] = better ? ca[I_] : bca[I_]; bcb[I_] = better ? cb[I_] : bcb[I_]; });
+            bk = better ? K_ : bk;
+        });
+    }
+    // what a contact slot says about pair bk of group g: bodies word (body a | body b << 8 | limb a << 16 | limb b << 20 | g << 24), radius of side b,
+    // friction; and the normal from b towards a
+    template <int g>
+    MI_HD static void pair_group_pick(const int bk, const float (&bca)[3], const float (&bcb)[3], int& bab, float& brb, float& bmu, float (&n)[3]) {
+        bab = 0; brb = 0.f; bmu = 0.f;
+        sfor<M::pg_count[g]>([&](auto K_) MI_LAMBDA {
+            constexpr int k = M::pg_first[g] + K_, ia = M::gp_a[k], ib = M::gp_b[k], ba = M::cap_body[ia], bb = M::cap_body[ib];
+            constexpr int la = M::limb_of_body[ba], lb = M::limb_of_body[bb];     // 0: trunk
+            constexpr int word = ba | (bb << 8) | (la << 16) | (lb << 20) | (g << 24);
+            const bool me = bk == K_;
+            bab = me ? word : bab;
+            brb = me ? M::cap_rad[ib] : brb;
+            bmu = me ? 0.5f * (M::cap_mu[ia] + M::cap_mu[ib]) : bmu;
+        });
+        const float dv[3] = {bca[0] - bcb[0], bca[1] - bcb[1], bca[2] - bcb[2]};
+        const float d2 = dot3(dv, dv);
+        const bool okd = d2 > 1e-18f;
+        const float inv = MI_RSQ(fmaxf(d2, 1e-30f));
+        n[0] = okd ? dv[0] * inv : 0.f; n[1] = okd ? dv[1] * inv : 0.f; n[2] = okd ? dv[2] * inv : 1.f;
+    }
+
     // ---------------------------------------------------------------- positions-only forward kinematics (pair role: all sphere centres)
     template <int b>
     MI_HD void fk_pos(const float* Rp, const float* rp, float (*xa)[3]) {
@@ -200,9 +257,9 @@ struct SimMWC : SimMW<M> {
     // groups 0 .. G_SPLIT - 1 are examined before B1 (while the limb roles run their tree pass), the others before B2
     static constexpr int G_SPLIT = []() constexpr {
         int tot = 0, acc = 0;
-        for (int g = 0; g < (NPG > 0 ? NPG : 0); ++g) tot += M::pg_count[g];
-        for (int g = 0; g < (NPG > 0 ? NPG : 0); ++g) { if (5 * (acc + M::pg_count[g]) > tot) return g; acc += M::pg_count[g]; }
-        return NPG > 0 ? NPG : 0;
+        for (int g = 0; g < NPGP; ++g) tot += M::pg_count[g];
+        for (int g = 0; g < NPGP; ++g) { if (5 * (acc + M::pg_count[g]) > tot) return g; acc += M::pg_count[g]; }
+        return NPGP;
     }();
     template <int RS, class BAR>
     MI_HD void substep_pair(const SimParams& P, const float h, const RowStore<RS> rows, const SelfCol* scol, const BAR& bar) {
@@ -211,57 +268,29 @@ struct SimMWC : SimMW<M> {
         const bool selfcol = (NPG > 0) && (scol != nullptr);
         float pvt[KPAIR], pl0[KPAIR][3];       // velocity targets / warm-start impulses of the contacts, kept until the shared region is free
         sfor<KPAIR>([&](auto J_) MI_LAMBDA { pvt[J_] = 0.f; sfor<3>([&](auto K) MI_LAMBDA { pl0[J_][K] = 0.f; }); });
+        int cntp = 0;                          // slots this role filled (its own groups); the trunk role continues behind them after B2
+        unsigned prevm = 0u;                   // groups whose normal impulse in memory (last sub-step's) is not zero: bit g
 #if defined(MI_TIMING)
         unsigned long long* const tstamp = this->tstamp;
 #endif
         MI_STAMP(0);
         if constexpr (NPG > 0) {
             float xa[NSPH][3], capm[M::NCAP][3];
-            int cntp = 0, pdrop = 0;
+            int pdrop = 0;
             auto group = [&](auto G_) MI_LAMBDA {
                 constexpr int g = decltype(G_)::value;
                 MI_PHASE();
-                float best = 3.0e38f, bca[3] = {0.f, 0.f, 0.f}, bcb[3] = {0.f, 0.f, 0.f};
-                int bk = 0;
-                sfor<M::pg_count[g]>([&](auto K_) MI_LAMBDA {
-                    constexpr int k = M::pg_first[g] + K_, ia = M::gp_a[k], ib = M::gp_b[k];
-                    constexpr float reach = B::cap_bound(ia) + B::cap_bound(ib);
-                    const float dm[3] = {capm[ia][0] - capm[ib][0], capm[ia][1] - capm[ib][1], capm[ia][2] - capm[ib][2]};
-                    const float rr = reach + P.contact_offset;
-                    if (!MI_WAVE_ANY(dot3(dm, dm) < rr * rr)) return;
-                    float ca[3], cb[3];
-                    seg_seg_closest<B::cap_is_point(ia), B::cap_is_point(ib)>(xa[M::cap_s0[ia]], xa[M::cap_s1[ia]], xa[M::cap_s0[ib]], xa[M::cap_s1[ib]], ca, cb);
-                    const float dv[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]};
-                    const float dist = MI_SQRT(dot3(dv, dv)) - (M::cap_rad[ia] + M::cap_rad[ib]);
-                    const bool better = dist < best;
-                    best = better ? dist : best;
-                    sfor<3>([&](auto I_) MI_LAMBDA { bca[I_] = better ? ca[I_] : bca[I_]; bcb[I_] = better ? cb[I_] : bcb[I_]; });
-                    bk = better ? K_ : bk;
-                });
+                float best, bca[3], bcb[3];
+                int bk;
+                pair_group_search<g>(P, xa, capm, best, bca, bcb, bk);
                 const bool near = best < P.contact_offset;
                 const bool on = near && (cntp < KPAIR);
                 pdrop += (near && !on) ? 1 : 0;
                 if (MI_WAVE_ANY(on)) {
                     if (on) {
-                        int bab = 0;
-                        float brb = 0.f, bmu = 0.f;
-                        sfor<M::pg_count[g]>([&](auto K_) MI_LAMBDA {
-                            constexpr int k = M::pg_first[g] + K_, ia = M::gp_a[k], ib = M::gp_b[k], ba = M::cap_body[ia], bb = M::cap_body[ib];
-                            constexpr int la = M::limb_of_body[ba], lb = M::limb_of_body[bb];     // 0: trunk
-                            constexpr int word = ba | (bb << 8) | (la << 16) | (lb << 20) | (g << 24);
-                            const bool me = bk == K_;
-                            bab = me ? word : bab;
-                            brb = me ? M::cap_rad[ib] : brb;
-                            bmu = me ? 0.5f * (M::cap_mu[ia] + M::cap_mu[ib]) : bmu;
-                        });
-                        float n[3];
-                        {
-                            const float dv[3] = {bca[0] - bcb[0], bca[1] - bcb[1], bca[2] - bcb[2]};
-                            const float d2 = dot3(dv, dv);
-                            const bool okd = d2 > 1e-18f;
-                            const float inv = MI_RSQ(fmaxf(d2, 1e-30f));
-                            n[0] = okd ? dv[0] * inv : 0.f; n[1] = okd ? dv[1] * inv : 0.f; n[2] = okd ? dv[2] * inv : 1.f;
-                        }
+                        int bab;
+                        float brb, bmu, n[3];
+                        pair_group_pick<g>(bk, bca, bcb, bab, brb, bmu, n);
                         float* xi = rows.ptr(C_X + 1 + XI * cntp);
                         sfor<3>([&](auto I_) MI_LAMBDA { xi[I_ * ST] = bcb[I_] + n[I_] * (brb + 0.5f * best); xi[(3 + I_) * ST] = n[I_]; });
                         xi[6 * ST] = __builtin_bit_cast(float, bab);
@@ -278,6 +307,7 @@ struct SimMWC : SimMW<M> {
                 cntp += on ? 1 : 0;
             };
             if (selfcol) {
+                sfor<NPG>([&](auto G_) MI_LAMBDA { prevm |= (scol->lamp(3 * G_) != 0.f) ? (1u << G_) : 0u; });
                 fk_pos<0>(nullptr, nullptr, xa);
                 sfor<M::NCAP>([&](auto C_) MI_LAMBDA {
                     sfor<3>([&](auto I_) MI_LAMBDA { capm[C_][I_] = 0.5f * (xa[M::cap_s0[C_]][I_] + xa[M::cap_s1[C_]][I_]); });
@@ -289,7 +319,7 @@ struct SimMWC : SimMW<M> {
             bar();                                                                                   // ---- B1
             MI_STAMP(2);
             if (selfcol) {
-                sfor<NPG - G_SPLIT>([&](auto G_) MI_LAMBDA { group(std::integral_constant<int, G_SPLIT + decltype(G_)::value>{}); });
+                sfor<NPGP - G_SPLIT>([&](auto G_) MI_LAMBDA { group(std::integral_constant<int, G_SPLIT + decltype(G_)::value>{}); });
                 if (scol->dropped != nullptr && pdrop > 0) MI_ATOMIC_ADD_INT(scol->dropped + scol->dstride, pdrop);
             }
             MI_STAMP(4);
@@ -299,18 +329,17 @@ struct SimMWC : SimMW<M> {
         bar();                                                                                       // ---- B2
         MI_STAMP(5);
         if constexpr (NPG > 0) { if (selfcol) {
-            // Z: zero the dense rows of the contacts; their velocity targets and warm-start impulses
+            // Z: zero the dense rows of the contacts this role found; their velocity targets and warm-start impulses.  (Its OWN slots, by count: the
+            // trunk role is filling the slots behind them right now -- with its own Z part -- and their bodies words must not be looked at before B3.)
             sfor<KPAIR>([&](auto J_) MI_LAMBDA {
                 constexpr int j = J_;
-                const unsigned bab = __builtin_bit_cast(unsigned, (float)rows(C_X + 1 + XI * j + 6));
-                const bool onj = bab != 0xFFFFFFFFu;
-                if (MI_WAVE_ANY(onj)) {
-                    if (onj) {
-                        // (the trunk entries, which every limb role ADDS to; a limb's entries are STORED by the role that owns the limb)
-                        sfor<3>([&](auto K) MI_LAMBDA { sfor<NV>([&](auto I) MI_LAMBDA { if constexpr (MW::trunk_gi(I)) rows(P_B + j * P_CSZ + K * NV + I) = 0.f; }); });
-                        rows(P_B + j * P_CSZ + PVT) = pvt[j];
-                        sfor<3>([&](auto K) MI_LAMBDA { rows(P_B + j * P_CSZ + PLAM + K) = pl0[j][K]; });
-                    }
+                // the trunk entries, which every limb role ADDS to (a limb's entries are STORED by the role that owns the limb): of every slot, used or
+                // not -- the trunk role does not have to know, and an unused slot's rows are never read
+                sfor<3>([&](auto K) MI_LAMBDA { sfor<NV>([&](auto I) MI_LAMBDA { if constexpr (MW::trunk_gi(I)) rows(P_B + j * P_CSZ + K * NV + I) = 0.f; }); });
+                const bool onj = j < cntp;
+                if (onj) {
+                    rows(P_B + j * P_CSZ + PVT) = pvt[j];
+                    sfor<3>([&](auto K) MI_LAMBDA { rows(P_B + j * P_CSZ + PLAM + K) = pl0[j][K]; });
                 }
             });
             MI_STAMP(6);
@@ -380,25 +409,47 @@ struct SimMWC : SimMW<M> {
             MI_STAMP(16);
             MI_STAMP(17);
             if constexpr (NPG > 0) { if (selfcol) {
-                for (int j = 0; j < KPAIR; ++j) {
-                    const float* xi = rit.ptr(C_X + 1 + XI * j);
-                    const unsigned bab = __builtin_bit_cast(unsigned, xi[6 * ST]);
-                    const bool onj = bab != 0xFFFFFFFFu;
-                    if (!MI_WAVE_ANY(onj)) break;                // slots fill from the front
+                // The rows of slot j + 1 are loaded while slot j is worked on (as the limb roles' ground slots: this wave is alone on its SIMD).
+                float gq[KPAIR][3][NV], gx[KPAIR][6];                 // dense rows | vt, lam x3, bodies word, mu: statically indexed
+                auto gload_n = [&](auto J_) MI_LAMBDA {              // (ahead: the normal row and the six scalars, as the limb roles' ground slots)
+                    constexpr int j = decltype(J_)::value;
+                    sfor<NV>([&](auto I) MI_LAMBDA { gq[j][0][I] = rit(P_B + j * P_CSZ + I); });
+                    sfor<4>([&](auto I_) MI_LAMBDA { gx[j][I_] = rit(P_B + j * P_CSZ + PVT + I_); });
+                    gx[j][4] = rit(C_X + 1 + XI * j + 6); gx[j][5] = rit(C_X + 1 + XI * j + 7);
+                };
+                auto gload_t = [&](auto J_) MI_LAMBDA {
+                    constexpr int j = decltype(J_)::value;
+                    sfor<2>([&](auto K) MI_LAMBDA { sfor<NV>([&](auto I) MI_LAMBDA { gq[j][1 + K][I] = rit(P_B + j * P_CSZ + (1 + K) * NV + I); }); });
+                };
+#ifndef MI_MWC_PF_PAIR
+#define MI_MWC_PF_PAIR 1
+#endif
+                if constexpr (MI_MWC_PF_PAIR) gload_n(std::integral_constant<int, 0>{});
+                bool open = true;                                // uniform: no empty slot seen yet
+                sfor<KPAIR>([&](auto J_) MI_LAMBDA {
+                    constexpr int j = J_;
+                    if (!open) return;
+                    if constexpr (!MI_MWC_PF_PAIR) gload_n(std::integral_constant<int, j>{});
+                    const bool onj = __builtin_bit_cast(unsigned, gx[j][4]) != 0xFFFFFFFFu;
+                    if (!MI_WAVE_ANY(onj)) { open = false; return; }          // slots fill from the front: nothing behind an empty slot is read
+                    gload_t(std::integral_constant<int, j>{});
+                    if constexpr (MI_MWC_PF_PAIR && j + 1 < KPAIR) gload_n(std::integral_constant<int, j + 1>{});
+                    MI_PHASE();
                     if (onj) {
-                        float* pb = rit.ptr(P_B + j * P_CSZ);
-                        const float mu = xi[7 * ST];
-                        float g[3][NV], ainv[3], lm[3];
+                        const float mu = gx[j][5];
+                        float (&g)[3][NV] = gq[j];
+                        float ainv[3], lm[3];
+                        // the weights of a row's coordinates: one for the trunk part, one per limb -- onto the partial sums of the diagonal and onto the impulse
                         sfor<3>([&](auto K) MI_LAMBDA {
-                            float a = P.cfm;
-                            sfor<NV>([&](auto I) MI_LAMBDA {
-                                g[K][I] = pb[(K * NV + I) * ST];
-                                a += om_of<decltype(I)::value>(omT, oml) * g[K][I] * g[K][I];
-                            });
+                            float ag[NLIMB];
+                            sfor<NLIMB>([&](auto L_) MI_LAMBDA { ag[L_] = 0.f; });
+                            sfor<NV>([&](auto I) MI_LAMBDA { constexpr int l = limb_of_gi(decltype(I)::value); ag[l] += g[K][I] * g[K][I]; });
+                            float a = P.cfm + omT * ag[0];
+                            sfor<NLIMB - 1>([&](auto L_) MI_LAMBDA { a += oml[L_] * ag[L_ + 1]; });
                             ainv[K] = MI_RCP(a);
-                            lm[K] = pb[(PLAM + K) * ST];
+                            lm[K] = gx[j][1 + K];
                         });
-                        const float vtn = pb[PVT * ST];
+                        const float vtn = gx[j][0];
                         auto wref = [&](auto I) MI_LAMBDA -> float& {
                             constexpr int i = decltype(I)::value;
                             if constexpr (MW::trunk_gi(i)) { constexpr int ti = MW::tidx(i); return wtl[ti]; } else { constexpr int li = lidx(i); return pwl[li]; }
@@ -409,7 +460,10 @@ struct SimMWC : SimMW<M> {
                             return s;
                         };
                         auto addw = [&](const float (&gr)[NV], const float dl) MI_LAMBDA {
-                            sfor<NV>([&](auto I) MI_LAMBDA { wref(I) += om_of<decltype(I)::value>(omT, oml) * gr[I] * dl; });
+                            float dg[NLIMB];
+                            dg[0] = omT * dl;
+                            sfor<NLIMB - 1>([&](auto L_) MI_LAMBDA { dg[L_ + 1] = oml[L_] * dl; });
+                            sfor<NV>([&](auto I) MI_LAMBDA { constexpr int l = limb_of_gi(decltype(I)::value); wref(I) += gr[I] * dg[l]; });
                         };
                         const float ln = fmaxf(lm[0] - (dotw(g[0]) - vtn) * ainv[0], 0.f);
                         addw(g[0], ln - lm[0]);
@@ -417,15 +471,15 @@ struct SimMWC : SimMW<M> {
                         // both tangent rows from the SAME velocity, the disc (core/engine.hpp friction_disc; oracle/physics.c solve_blocks), ONE application
                         sfor<2>([&](auto K) MI_LAMBDA { vtg[K] = dotw(g[1 + K]); lt[K] = lm[1 + K] - vtg[K] * ainv[1 + K]; });
                         friction_disc(lt, lm[1], lm[2], vtg[0], vtg[1], ainv[1], ainv[2], mu * ln);
-                        pb[PLAM * ST] = ln;
+                        rit(P_B + j * P_CSZ + PLAM) = ln;
                         actn = (ln > 0.f) ? 1.f : actn;
                         sfor<2>([&](auto K) MI_LAMBDA {
                             const float nl_ = lt[K];
-                            pb[(PLAM + 1 + K) * ST] = nl_;
+                            rit(P_B + j * P_CSZ + PLAM + 1 + K) = nl_;
                             addw(g[1 + K], nl_ - lm[1 + K]);
                         });
                     }
-                }
+                });
             } }
             MI_STAMP(18);
             const float iomT = 1.f / omT;
@@ -472,12 +526,18 @@ struct SimMWC : SimMW<M> {
             sfor<NPG>([&](auto G_) MI_LAMBDA {
                 constexpr int g = G_;
                 float l[3] = {0.f, 0.f, 0.f}, f[3] = {0.f, 0.f, 0.f};
+                bool mine = false;
                 sfor<KPAIR>([&](auto J_) MI_LAMBDA {
                     const bool me = sg[J_] == g;
+                    mine = mine || me;
                     sfor<3>([&](auto K) MI_LAMBDA { l[K] = me ? sl[J_][K] : l[K]; f[K] = me ? sf[J_][K] : f[K]; });
                 });
-                sfor<3>([&](auto K) MI_LAMBDA { scol->lamp(3 * g + K) = l[K]; });
-                if (scol->pairf.p) sfor<3>([&](auto K) MI_LAMBDA { scol->pairf(3 * g + K) = f[K]; });
+                // (a group without a contact now whose impulse in memory is zero already -- nearly all of them -- is left alone: an impulse of zero
+                //  normal part has zero tangential parts and a zero force, friction_disc; 78 stores per env were the tail of the kernel)
+                if (MI_WAVE_ANY(mine || ((prevm >> g) & 1u))) {
+                    sfor<3>([&](auto K) MI_LAMBDA { scol->lamp(3 * g + K) = l[K]; });
+                    if (scol->pairf.p) sfor<3>([&](auto K) MI_LAMBDA { scol->pairf(3 * g + K) = f[K]; });
+                }
             });
         } }
         MI_STAMP(13);
@@ -737,10 +797,64 @@ struct SimMWC : SimMW<M> {
             }
         });
         if (scol != nullptr && scol->dropped != nullptr && ndrop > 0) MI_ATOMIC_ADD_INT(scol->dropped, ndrop);
+        // ---- the trunk role's own self-collision groups (pg_trunk_role: trunk x trunk, trunk x arm, arm x arm): narrow phase on the sphere centres of
+        //      this role's tree pass, in its slack before B2.  Everything a slot holds -- point, normal, bodies word, friction, velocity target, warm-start
+        //      impulses (their loads are in flight across the barrier) -- waits in registers until the pair role's slot count is visible.
+        float tx[NTG > 0 ? NTG : 1][8], tvt[NTG > 0 ? NTG : 1], tl0[NTG > 0 ? NTG : 1][3];
+        bool tnear[NTG > 0 ? NTG : 1];
+        if constexpr (R == M::TRUNK_ROLE && NTG > 0) {
+            if (selfcol) {
+                float capm[M::NCAP][3];
+                sfor<M::NCAP>([&](auto C_) MI_LAMBDA {
+                    if constexpr (owned<R>(M::cap_body[C_])) sfor<3>([&](auto I_) MI_LAMBDA { capm[C_][I_] = 0.5f * (c.xcs[M::cap_s0[C_]][I_] + c.xcs[M::cap_s1[C_]][I_]); });
+                });
+                sfor<NTG>([&](auto T_) MI_LAMBDA {
+                    constexpr int g = NPGP + T_;
+                    MI_PHASE();
+                    float best, bca[3], bcb[3], brb, n[3];
+                    int bk, bab;
+                    pair_group_search<g>(P, c.xcs, capm, best, bca, bcb, bk);
+                    tnear[T_] = best < P.contact_offset;
+                    sfor<8>([&](auto I_) MI_LAMBDA { tx[T_][I_] = 0.f; });
+                    tvt[T_] = 0.f;
+                    sfor<3>([&](auto K) MI_LAMBDA { tl0[T_][K] = 0.f; });
+                    if (MI_WAVE_ANY(tnear[T_])) {
+                        pair_group_pick<g>(bk, bca, bcb, bab, brb, tx[T_][7], n);
+                        sfor<3>([&](auto I_) MI_LAMBDA { tx[T_][I_] = bcb[I_] + n[I_] * (brb + 0.5f * best); tx[T_][3 + I_] = n[I_]; });
+                        tx[T_][6] = __builtin_bit_cast(float, bab);
+                        const float gap = best - P.rest_offset;
+                        tvt[T_] = (gap >= 0.f) ? -gap * invh : fminf(-gap * P.erp * invh, P.max_depen_vel);
+                        sfor<3>([&](auto K) MI_LAMBDA { tl0[T_][K] = scol->lamp(3 * g + K) * P.warm; });
+                    }
+                });
+            }
+        }
         MI_STAMP(3);
         MI_STAMP(4);
         bar();                                                                                       // ---- B2: tree-pass exchange is dead, C_X is published
         MI_STAMP(5);
+        if constexpr (R == M::TRUNK_ROLE && NTG > 0) {
+            if (selfcol) {
+                // slots behind the pair role's, in table order (the trunk entries of every slot's dense rows are zeroed by the pair role meanwhile)
+                int cntp = 0, pdrop = 0;
+                sfor<KPAIR>([&](auto J_) MI_LAMBDA { cntp += (__builtin_bit_cast(unsigned, (float)rows(C_X + 1 + XI * J_ + 6)) != 0xFFFFFFFFu) ? 1 : 0; });
+                sfor<NTG>([&](auto T_) MI_LAMBDA {
+                    const bool on = tnear[T_] && (cntp < KPAIR);
+                    pdrop += (tnear[T_] && !on) ? 1 : 0;
+                    if (MI_WAVE_ANY(on)) {
+                        if (on) {
+                            float* xi = rows.ptr(C_X + 1 + XI * cntp);
+                            sfor<8>([&](auto I_) MI_LAMBDA { xi[I_ * ST] = tx[T_][I_]; });
+                            float* pb = rows.ptr(P_B + cntp * P_CSZ);
+                            pb[PVT * ST] = tvt[T_];
+                            sfor<3>([&](auto K) MI_LAMBDA { pb[(PLAM + K) * ST] = tl0[T_][K]; });
+                        }
+                    }
+                    cntp += on ? 1 : 0;
+                });
+                if (scol->dropped != nullptr && pdrop > 0) MI_ATOMIC_ADD_INT(scol->dropped + scol->dstride, pdrop);
+            }
+        }
         // ============================================================ self-contact rows: every body of mine adds its half
         if constexpr (R == M::TRUNK_ROLE) sfor<NV>([&](auto I) MI_LAMBDA { if constexpr (MW::trunk_gi(I)) { constexpr int o = XW0 + MW::tidx(I); rows(o) = w[I]; } });
         if (selfcol) {
@@ -888,15 +1002,37 @@ struct SimMWC : SimMW<M> {
                 });
                 MI_STAMP(17);
                 // ---- own ground contacts: a lane's j-th contact, whichever sphere it is (fixed row shape [limb | trunk])
-                for (int j = 0; j < KCAP; ++j) {
+                // The rows of slot j + 1 are loaded while slot j is worked on (this wave is alone on its SIMD: nobody else hides the LDS latency, and a slot's
+                // loads used to start only when the slot before it was finished -- a third of the time of this loop); slot j + 1 is not written by slot j.
+                float gq[KCAP > 0 ? KCAP : 1][3][RLEN], gx[KCAP > 0 ? KCAP : 1][4];          // rows | vt, lam x3: statically indexed
+                // (what is in flight across a slot: the NORMAL row and the four scalars of the next one -- 19 registers; its tangent rows are asked for when
+                //  its turn comes and arrive while the normal row is worked on.  All three rows ahead cost the tree pass 50 units in registers: r6n.)
+                auto gload_n = [&](auto J_) MI_LAMBDA {
+                    constexpr int j = decltype(J_)::value;
+                    sfor<RLEN>([&](auto C) MI_LAMBDA { gq[j][0][C] = rit(GCB + j * GCSZ + C); });
+                    sfor<4>([&](auto I_) MI_LAMBDA { gx[j][I_] = rit(GCB + j * GCSZ + 3 * RLEN + I_); });
+                };
+                auto gload_t = [&](auto J_) MI_LAMBDA {
+                    constexpr int j = decltype(J_)::value;
+                    sfor<2>([&](auto K) MI_LAMBDA { sfor<RLEN>([&](auto C) MI_LAMBDA { gq[j][1 + K][C] = rit(GCB + j * GCSZ + (1 + K) * RLEN + C); }); });
+                };
+#ifndef MI_MWC_PF_LEG
+#define MI_MWC_PF_LEG 1
+#endif
+                if constexpr (KCAP > 0 && MI_MWC_PF_LEG) { if (MI_WAVE_ANY(0 < cnt)) gload_n(std::integral_constant<int, 0>{}); }
+                sfor<KCAP>([&](auto J_) MI_LAMBDA {
+                    constexpr int j = J_;
                     const bool onj = j < cnt;
-                    if (!MI_WAVE_ANY(onj)) break;
+                    if (!MI_WAVE_ANY(onj)) return;                // (slots fill from the front)
+                    if constexpr (!MI_MWC_PF_LEG) gload_n(std::integral_constant<int, j>{});
+                    gload_t(std::integral_constant<int, j>{});
+                    if constexpr (MI_MWC_PF_LEG && j + 1 < KCAP) { if (MI_WAVE_ANY(j + 1 < cnt)) gload_n(std::integral_constant<int, j + 1>{}); }
+                    MI_PHASE();
                     if (onj) {
-                        float* cb = rit.ptr(GCB + j * GCSZ);
                         const float mu = 0.5f * ((mu_env >= 0.f ? mu_env : M::sph_mu[0]) + P.plane_mu);
-                        float g[3][RLEN], ainv[3], lm[3];
+                        float (&g)[3][RLEN] = gq[j];
+                        float ainv[3], lm[3];
                         sfor<3>([&](auto K) MI_LAMBDA {
-                            sfor<RLEN>([&](auto C) MI_LAMBDA { g[K][C] = cb[(K * RLEN + C) * ST]; });
                             float alm[NLIMB > 1 ? NLIMB - 1 : 1];                 // the diagonal's partial sums per limb of this role and for the trunk: weights applied once
                             sfor<NLIMB - 1>([&](auto L_) MI_LAMBDA { alm[L_] = 0.f; });
                             sfor<NLR_>([&](auto K2) MI_LAMBDA { constexpr int l = limb_of_gi(LF + decltype(K2)::value); alm[l - 1] += g[K][K2] * g[K][K2]; });
@@ -905,9 +1041,9 @@ struct SimMWC : SimMW<M> {
                             float a = P.cfm + omT * at;
                             sfor<NLIMB - 1>([&](auto L_) MI_LAMBDA { if constexpr (M::role_of_limb[L_ + 1] == R) a += oml[L_] * alm[L_]; });
                             ainv[K] = MI_RCP(a);
-                            lm[K] = cb[(3 * RLEN + 1 + K) * ST];
+                            lm[K] = gx[j][1 + K];
                         });
-                        const float vtn = cb[(3 * RLEN) * ST];
+                        const float vtn = gx[j][0];
                         auto dotw = [&](const float (&gr)[RLEN]) MI_LAMBDA -> float {
                             float s = 0.f;
                             sfor<NLR_>([&](auto K) MI_LAMBDA { s += gr[K] * wll[K]; });
@@ -927,15 +1063,15 @@ struct SimMWC : SimMW<M> {
                         // both tangent rows from the SAME velocity, the disc (core/engine.hpp friction_disc; oracle/physics.c solve_blocks), ONE application
                         sfor<2>([&](auto K) MI_LAMBDA { vtg[K] = dotw(g[1 + K]); lt[K] = lm[1 + K] - vtg[K] * ainv[1 + K]; });
                         friction_disc(lt, lm[1], lm[2], vtg[0], vtg[1], ainv[1], ainv[2], mu * ln);
-                        cb[(3 * RLEN + 1) * ST] = ln;
+                        rit(GCB + j * GCSZ + 3 * RLEN + 1) = ln;
                         actn = (ln > 0.f) ? 1.f : actn;
                         sfor<2>([&](auto K) MI_LAMBDA {
                             const float nl_ = lt[K];
-                            cb[(3 * RLEN + 2 + K) * ST] = nl_;
+                            rit(GCB + j * GCSZ + 3 * RLEN + 2 + K) = nl_;
                             addw(g[1 + K], nl_ - lm[1 + K]);
                         });
                     }
-                }
+                });
                 MI_STAMP(18);
                 // this block's true contributions
                 sfor<NV>([&](auto I) MI_LAMBDA { if constexpr (MW::trunk_gi(I)) { constexpr int ti = MW::tidx(I); xdw(R * NVT + ti) = (wtl[ti] - w[I]) * iomT; } });
