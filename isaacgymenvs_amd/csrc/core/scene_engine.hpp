@@ -439,10 +439,11 @@ struct SceneSim : Sim<M> {
             // zero velocity and applying it before t2 is looked at -- the order of core/hand_engine.hpp -- lets the unclamped t1 impulse of a fast
             // sliding corner spin the box, t2 then cancels a lateral velocity that is not there, and after the projection the friction points 20
             // degrees off the sliding direction: a cube on a 40 degree ramp slid with mu_eff = 0.468 instead of 0.5, tests/test_scene.py.)
-            // Round 6: a sliding contact repeats the step with one step size for both rows (core/engine.hpp friction_disc), in every engine form.
+            // (Round 6: the other engine forms let a sliding contact repeat the step with one step size for both rows -- friction_disc<true>; here the
+            //  rows keep their own: friction_disc<false>, see core/engine.hpp for what the isotropic step did to a grasp.)
             float lt[2], vtg[2];
             sfor<2>([&](auto K) MI_LAMBDA { vtg[K] = rowvel(1 + K); lt[K] = lm[1 + K] - vtg[K] * ainv[1 + K]; });
-            friction_disc(lt, lm[1], lm[2], vtg[0], vtg[1], ainv[1], ainv[2], mu * ln);
+            friction_disc<false>(lt, lm[1], lm[2], vtg[0], vtg[1], ainv[1], ainv[2], mu * ln);
             cb[(S_AUX + 4) * ST] = ln;
             sfor<2>([&](auto K) MI_LAMBDA {
                 const float nl_ = lt[K];

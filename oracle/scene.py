@@ -20,7 +20,7 @@ import ctypes as C
 import numpy as np
 
 from .engine import OracleEngine, _ptr
-from .hand import contact_frame, friction_step, quat2mat, sphere_box3
+from .hand import contact_frame, quat2mat, sphere_box3
 
 KARM, KBOX = 24, 24                   # csrc/core/scene_engine.hpp SceneSim::KARM / KBOX
 MAX_W, MAX_V = 64.0, 1000.0           # csrc/core/engine.hpp kMaxAngularVelocity / kMaxLinearVelocity
@@ -231,11 +231,14 @@ class OracleSceneEngine:
                         apply(cdat, r, r["lam"])
                 ln = max(rn["lam"] - (rowvel(cdat, rn) - cdat["vtn"]) * rn["Ainv"], 0.0)
                 apply(cdat, rn, ln - rn["lam"]); rn["lam"] = ln
-                vtan = [rowvel(cdat, rt) for rt in (ra, rb)]                                # both tangent rows from the same velocity
-                lt = friction_step([rt["lam"] - vt_ * rt["Ainv"] for rt, vt_ in zip((ra, rb), vtan)], (ra["lam"], rb["lam"]), vtan,
-                                   (ra["Ainv"], rb["Ainv"]), cdat["mu"] * ln)               # oracle/hand.py: a sliding contact steps isotropically
+                # both tangent rows from the same velocity, each with its own step size, radial projection onto the disc (csrc/core/engine.hpp
+                # friction_disc<false>: the scene keeps round 5's rule -- the isotropic step of the other engine forms loses a held cube within nine sweeps)
+                lt = [rt["lam"] - rowvel(cdat, rt) * rt["Ainv"] for rt in (ra, rb)]
+                lim = cdat["mu"] * ln
+                nrm = np.hypot(lt[0], lt[1])
+                sc = lim / max(nrm, 1e-30) if nrm > lim else 1.0
                 for rt, l in zip((ra, rb), lt):
-                    apply(cdat, rt, l - rt["lam"]); rt["lam"] = l
+                    apply(cdat, rt, l * sc - rt["lam"]); rt["lam"] = l * sc
         for d in range(nd):                      # the asset's joint velocity limits: clamp of the solved velocities
             if self.drive_vmax[d] > 0:
                 v[d] = min(max(v[d], -self.drive_vmax[d]), self.drive_vmax[d])
