@@ -161,6 +161,7 @@ struct HandSim : Sim<M> {
     // off): 2e4 holds a finger at its drive's force limit (~10 N at the tip) 0.5 mm inside the other shape.
     float pair_k = 0.f;                                      // stiffness of the compliant pairs (HandView::pair_k); 0 = pairs off
     int pair_active = 0;                                     // out: pair sides this instance pushed in the last sub-step
+    int pair_sens = 1;                                       // 0: skip the pairs' forces on the fingertip sensors (finger waves: every sub-step launch of a call but the last)
     static constexpr int NHP = M::NHP;
     // sphere (centre c in the box frame, radius r) vs box of half sizes a[3]: signed distance, outward normal (box frame)
     MI_HD static void sphere_box3(const float* c, float r, const float* a, float* dist, float* n) {
@@ -230,6 +231,64 @@ struct HandSim : Sim<M> {
             const float ag = a * g[C1];
             sfor<CL - C1>([&](auto T) MI_LAMBDA { constexpr int c2 = C1 + T, j = M::chain[b][c2]; L[M::midx[i][j]] += ag * g[c2]; });
         });
+    }
+    // ---- the pairs on the force-sensor bodies (the fingertips; shadow_hand.py:291-297): a sensor sees every constraint force on its body, the hand's
+    // own contacts included.  A pushed side's force is F_s = k (pen_s - h W_s . V+), W_s = [pc x u_s; u_s], V+ the body's twist about O once the solve
+    // has the new joint velocities.  Per fingertip the pair phase leaves 8 numbers: A = sum k pen_s W_s (the static part of the wrench, exact for any
+    // number of sides), P = sum pen_s and the number of sides n; the output phase applies the velocity part along the RESULTANT,
+    //         wrench = A (1 - n h (A . V+) / (k P^2)),
+    // which is k W (pen - h W . V+) exactly for one side -- what a fingertip almost always has -- and a stated approximation of the damping term when a
+    // fingertip is pushed by two pairs at once (the thumb tip between two fingers); oracle/hand.c / hand.py state the same formula.  (The exact form for
+    // any number of sides, A - M V+ with M = sum k h W_s W_s^T, was built first: 27 live registers per fingertip took the 64-env finger waves from 0 to
+    // 448 B of scratch and ShadowHand@16384 from 0.1866 to 0.2010 ms per step.)
+    MI_HD void pair_sensor_acc(const float* pc, const float* u, const float pen, const float h, float (&A)[8]) const {
+        float W[6];
+        cross3(pc, u, W);
+        W[3] = u[0]; W[4] = u[1]; W[5] = u[2];
+        const bool on = pen > 0.f;
+        const float kp_ = on ? pair_k * pen : 0.f;
+        sfor<6>([&](auto I) MI_LAMBDA { A[I] += kp_ * W[I]; });
+        A[6] += on ? pen : 0.f;
+        A[7] += on ? 1.f : 0.f;
+        (void)h;
+    }
+    // the wrench (about O: torque, force) the pairs put on body b after the solve: vnew[gi] the new joint velocities
+    template <int b>
+    MI_HD void pair_sensor_wrench(const float (&A)[8], const float h, const float (&S)[M::NDA][6], const float* vnew, float (&wr)[6]) const {
+        float V[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { constexpr int gi = M::chain[b][C]; sfor<6>([&](auto K) MI_LAMBDA { V[K] += S[gi - OFF][K] * vnew[gi]; }); });
+        float av = 0.f;
+        sfor<6>([&](auto I) MI_LAMBDA { av += A[I] * V[I]; });
+        const float P2 = A[6] * A[6];
+        const float fac = (P2 > 0.f) ? 1.f - A[7] * h * av * MI_RCP(pair_k * P2) : 0.f;
+        sfor<6>([&](auto I) MI_LAMBDA { wr[I] = A[I] * fac; });
+    }
+    // the same in two halves for a form that cannot keep the motion subspaces alive until its output phase (the finger waves: S of a fingertip's chain is
+    // 42 registers through the sweeps, 4 % of the step): g_c = A . S_c while S is there, then A . V+ = sum_c g_c v_c
+    template <int b>
+    MI_HD void pair_sensor_g(const float (&A)[8], const float (&S)[M::NDA][6], float (&g)[M::MAXCHAIN]) const {
+        sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA {
+            constexpr int gi = M::chain[b][C];
+            float s_ = 0.f;
+            sfor<6>([&](auto K) MI_LAMBDA { s_ += A[K] * S[gi - OFF][K]; });
+            g[C] = s_;
+        });
+    }
+    template <int b>
+    MI_HD void pair_sensor_wrench_g(const float (&A)[8], const float (&g)[M::MAXCHAIN], const float h, const float* vnew, float (&wr)[6]) const {
+        float av = 0.f;
+        sfor<M::chain_len[b]>([&](auto C) MI_LAMBDA { av += g[C] * vnew[M::chain[b][C]]; });
+        const float P2 = A[6] * A[6];
+        const float fac = (P2 > 0.f) ? 1.f - A[7] * h * av * MI_RCP(pair_k * P2) : 0.f;
+        sfor<6>([&](auto I) MI_LAMBDA { wr[I] = A[I] * fac; });
+    }
+#ifndef MI_HAND_PAIR_SENSORS
+#define MI_HAND_PAIR_SENSORS 1          // 0: A/B builds without the pairs' forces in the fingertip sensors (tools/debug)
+#endif
+    static constexpr bool pair_sensor_body(int b) {      // a force-sensor body that takes part in a pair
+        if (!MI_HAND_PAIR_SENSORS || sensor_of(b) < 0) return false;
+        for (int p = 0; p < NHP; ++p) if (M::hp_ba[p] == b || M::hp_bb[p] == b) return true;
+        return false;
     }
     // the segment of body b's pair capsule in its own frame (every pair a body takes part in uses the same shape of it)
     static constexpr bool hp_capsule_body(int b) {
@@ -348,9 +407,14 @@ struct HandSim : Sim<M> {
         });
         // ------------------------------------------------------------ the asset's hand-to-hand pairs: compliant contacts (pair_side)
         this->pair_active = 0;
+        float psPN[M::NSENSA][2];                               // the pairs on the fingertips: sum of pen, sides (pair_sensor_acc)
+        sfor<NSENS>([&](auto K_) MI_LAMBDA { psPN[K_][0] = 0.f; psPN[K_][1] = 0.f; });
+        const bool pairs_on = (NHP > 0) && MI_WAVE_ANY(this->pair_k > 0.f);
         if constexpr (NHP > 0) {
-            if (MI_WAVE_ANY(this->pair_k > 0.f)) {
+            if (pairs_on) {
                 int npa = 0;
+                float psA[M::NSENSA][8];                        // ... and their wrench A x6 (parked in the `sensor` tensor below)
+                sfor<NSENS>([&](auto K_) MI_LAMBDA { sfor<8>([&](auto I) MI_LAMBDA { psA[K_][I] = 0.f; }); });
                 sfor<NHP>([&](auto P_) MI_LAMBDA {
                     constexpr int pp = P_, ba = M::hp_ba[pp], bb = M::hp_bb[pp];
                     static_assert(B::os_count(ba) > 0 && B::os_count(bb) > 0, "pair bodies carry object spheres: their poses are in the pose array");
@@ -368,10 +432,21 @@ struct HandSim : Sim<M> {
                         const float nm[3] = {-n[0], -n[1], -n[2]};
                         this->template pair_side<ba>(pc, n, pe, h, S, L, y);
                         this->template pair_side<bb>(pc, nm, pe, h, S, L, y);
+                        if constexpr (pair_sensor_body(ba)) this->pair_sensor_acc(pc, n, pe, h, psA[sensor_of(ba)]);
+                        if constexpr (pair_sensor_body(bb)) this->pair_sensor_acc(pc, nm, pe, h, psA[sensor_of(bb)]);
                         npa += on ? 2 : 0;
                     }
                 });
                 this->pair_active = npa;
+                // the six numbers of A wait in the fingertip's own slots of the `sensor` tensor until the output phase (this lane rewrites them there; a
+                // load after the own store of the same address sees it): kept in registers through the solve they took this form from 232 to 426
+                // spilled VGPRs; P and n stay
+                sfor<NSENS>([&](auto K_) MI_LAMBDA {
+                    if constexpr (pair_sensor_body(M::sens_body[K_])) {
+                        psPN[K_][0] = psA[K_][6]; psPN[K_][1] = psA[K_][7];
+                        if (MI_WAVE_ANY(psA[K_][6] > 0.f)) sfor<6>([&](auto C) MI_LAMBDA { sensor(6 * K_ + C) = psA[K_][C]; });
+                    }
+                });
             }
         }
         MI_PHASE();
@@ -722,6 +797,29 @@ struct HandSim : Sim<M> {
                 }
             }
         });
+        if constexpr (NHP > 0) {
+            if (pairs_on) {
+                sfor<NB>([&](auto B_) MI_LAMBDA {
+                    constexpr int b = B_;
+                    if constexpr (pair_sensor_body(b) && B::os_count(b) > 0) {
+                        constexpr int k = sensor_of(b), OS_SLOT = B::os_slot(b);
+                        float Rb[9], rb[3], wr[6], tq[3], fl[3], tl[3];
+                        sfor<9>([&](auto I_) MI_LAMBDA { Rb[I_] = pose[pz + 12 * OS_SLOT + I_]; });
+                        sfor<3>([&](auto I_) MI_LAMBDA { rb[I_] = pose[pz + 12 * OS_SLOT + 9 + I_]; });
+                        float A8[8];
+                        const bool any = psPN[k][0] > 0.f;
+                        sfor<6>([&](auto C) MI_LAMBDA { const float a_ = sensor(6 * k + C); A8[C] = any ? a_ : 0.f; });       // (parked there by the pair phase)
+                        A8[6] = psPN[k][0]; A8[7] = psPN[k][1];
+                        this->template pair_sensor_wrench<b>(A8, h, S, v, wr);
+                        const float f[3] = {wr[3], wr[4], wr[5]};
+                        cross3(rb, f, tq);                                   // torque about the sensor origin: tau_O - rb x f
+                        sfor<3>([&](auto C) MI_LAMBDA { tq[C] = wr[C] - tq[C]; });
+                        matTvec3(Rb, f, fl); matTvec3(Rb, tq, tl);
+                        sfor<3>([&](auto C) MI_LAMBDA { sens[6 * k + C] += fl[C]; sens[6 * k + 3 + C] += tl[C]; });
+                    }
+                });
+            }
+        }
         sfor<6 * NSENS>([&](auto K) MI_LAMBDA { sensor(K) = sens[K]; });
         MI_PHASE();
         MI_STAMP(7);

@@ -377,10 +377,19 @@ struct HandSimMW : HandSim<M> {
         // one of its bodies (both owners compute the same geometry from the same end points) and adds ITS side's implicit spring to its own H
         // entries / right-hand side; the wrist part rides on the Schur-complement / carry exchange below (X_DT / X_DY, summed in role order)
         this->pair_active = 0;
+        float psPN[M::NSENSA][2];                               // the pairs on this role's fingertips: sum of pen, sides (core/hand_engine.hpp pair_sensor_acc)
+        sfor<NSENS>([&](auto K_) MI_LAMBDA { psPN[K_][0] = 0.f; psPN[K_][1] = 0.f; });
+        float psG[M::NSENSA][M::MAXCHAIN];                      // ... and A . S_c over the fingertip's chain (pair_sensor_g)
         if constexpr (NHP > 0) {
             if (this->pair_k > 0.f) {                                                                 // (uniform over the workgroup: a kernel argument)
                 bar();                                                                               // ---- B0: everybody's pair capsules are in LDS
                 int npa = 0;
+                float psA[M::NSENSA][8];
+                sfor<NSENS>([&](auto K_) MI_LAMBDA {
+                    if constexpr (role_of_body_h(M::sens_body[K_]) == R && HB::pair_sensor_body(M::sens_body[K_])) {
+                        sfor<8>([&](auto I) MI_LAMBDA { psA[K_][I] = 0.f; });
+                    }
+                });
                 sfor<NHP>([&](auto P_) MI_LAMBDA {
                     constexpr int pp = P_, ba = M::hp_ba[pp], bb = M::hp_bb[pp];
                     constexpr bool mine_a = role_of_body_h(ba) == R, mine_b = role_of_body_h(bb) == R;
@@ -399,12 +408,29 @@ struct HandSimMW : HandSim<M> {
                         const bool on = pen > 0.f;
                         if (MI_WAVE_ANY(on)) {
                             const float pe = on ? pen : 0.f;
-                            if constexpr (mine_a) { this->template pair_side<ba>(pc, n, pe, h, S, L, y); npa += on ? 1 : 0; }
-                            if constexpr (mine_b) { const float nm[3] = {-n[0], -n[1], -n[2]}; this->template pair_side<bb>(pc, nm, pe, h, S, L, y); npa += on ? 1 : 0; }
+                            if constexpr (mine_a) {
+                                this->template pair_side<ba>(pc, n, pe, h, S, L, y); npa += on ? 1 : 0;
+                                if constexpr (HB::pair_sensor_body(ba)) { if (this->pair_sens) this->pair_sensor_acc(pc, n, pe, h, psA[HB::sensor_of(ba)]); }
+                            }
+                            if constexpr (mine_b) {
+                                const float nm[3] = {-n[0], -n[1], -n[2]};
+                                this->template pair_side<bb>(pc, nm, pe, h, S, L, y); npa += on ? 1 : 0;
+                                if constexpr (HB::pair_sensor_body(bb)) { if (this->pair_sens) this->pair_sensor_acc(pc, nm, pe, h, psA[HB::sensor_of(bb)]); }
+                            }
                         }
                     }
                 });
                 this->pair_active = npa;
+                // the six numbers of A wait in the fingertip's own slots of the `sensor` tensor (this lane rewrites them in the output phase; a load after
+                // the own store of the same address sees it): carried in registers through the contact phases and the sweeps they cost 4 % of the step
+                // (ShadowHand@16384 0.1857 -> 0.1933 ms, profiles/r6_hand_pair_sensors_ab.txt); P and n stay
+                if (this->pair_sens) sfor<NSENS>([&](auto K_) MI_LAMBDA {
+                    if constexpr (role_of_body_h(M::sens_body[K_]) == R && HB::pair_sensor_body(M::sens_body[K_])) {
+                        psPN[K_][0] = psA[K_][6]; psPN[K_][1] = psA[K_][7];
+                        this->template pair_sensor_g<M::sens_body[K_]>(psA[K_], S, psG[K_]);
+                        if (MI_WAVE_ANY(psA[K_][6] > 0.f)) sfor<6>([&](auto C) MI_LAMBDA { sensor(6 * K_ + C) = psA[K_][C]; });
+                    }
+                });
             }
         }
         sfor_rev<NV>([&](auto K_) MI_LAMBDA { if constexpr (MW::role_of_gi(K_) == R) factor(K_); });
@@ -768,6 +794,22 @@ struct HandSimMW : HandSim<M> {
                             matTvec3(Rb, f, fl); matTvec3(Rb, tq, tl);
                             sfor<3>([&](auto C) MI_LAMBDA { sens[C] += fl[C]; sens[3 + C] += tl[C]; });
                         }
+                    }
+                }
+                if constexpr (NHP > 0 && HB::pair_sensor_body(b)) {
+                    if (MI_WAVE_ANY(psPN[k][0] > 0.f)) {       // the hand's own contacts on this fingertip (core/hand_engine.hpp pair_sensor_wrench)
+                        const float (&Rb)[9] = c.Rs[k];
+                        const float (&rb)[3] = c.rs[k];
+                        float wr[6], tq[3], fl[3], tl[3], A8[8];
+                        const bool any = psPN[k][0] > 0.f;
+                        sfor<6>([&](auto C) MI_LAMBDA { const float a_ = sensor(6 * k + C); A8[C] = any ? a_ : 0.f; });       // (parked there by the pair phase)
+                        A8[6] = psPN[k][0]; A8[7] = psPN[k][1];
+                        this->template pair_sensor_wrench_g<b>(A8, psG[k], h, v, wr);
+                        const float f[3] = {wr[3], wr[4], wr[5]};
+                        cross3(rb, f, tq);
+                        sfor<3>([&](auto C) MI_LAMBDA { tq[C] = wr[C] - tq[C]; });
+                        matTvec3(Rb, f, fl); matTvec3(Rb, tq, tl);
+                        sfor<3>([&](auto C) MI_LAMBDA { sens[C] += fl[C]; sens[3 + C] += tl[C]; });
                     }
                 }
                 sfor<6>([&](auto C) MI_LAMBDA { sensor(6 * k + C) = sens[C]; });

@@ -10,9 +10,13 @@
 //   * contacts, every one 3 rows (normal + friction disc) of ONE Gauss-Seidel sequence with the actor's joint-limit rows:
 //       actor sphere (the model's collision spheres, meshes sampled by assets/mesh.py) vs free box / static box   [actor chain | 6 box dofs]
 //       free box corner vs ground plane / static box / other free box (both directions)                            [6 | 6 box dofs]
-//     box-box and box-static manifolds are the CORNER-IN-BOX contacts of both boxes (exact signed distance of a point to a box): face-face
-//     and corner-face configurations (a cube on a table, a cube stacked on a cube, a cube pushed against a cube) are covered, edge-edge
-//     crossings are not.  A stated approximation like every contact model here: physics parity against PhysX is unpinned.
+//       static box corner vs free box                                                                               [6 box dofs]
+//       free box edge vs free / static box edge (round 6; scene_box_edge: one contact per pair whose least-penetration axis is edge x edge)
+//       outline of the incident face vs outline of the reference face of a free box and a free / static box (round 6; scene_face_crossings)
+//     box-box and box-static manifolds are the CORNER-IN-BOX contacts of both boxes (exact signed distance of a point to a box) -- face-face
+//     and corner-face configurations (a cube on a table, a cube stacked on a cube, a cube pushed against a cube, a plate on a smaller stand) --
+//     plus the edge-edge contact of crossed edges and the outline crossings of a face contact (crossed planks, a plank on a knife edge).  A stated approximation like every contact model here: physics parity against PhysX is
+//     unpinned.
 //   * contact slots are data dependent: at most KARM actor contacts (taken in sphere order, grouped by actor body) and KBOX box contacts
 //     (box order, corner order, then ground / static boxes / free boxes); refusals are counted.
 //   * contacts are WARM STARTED although their slots are data dependent: a contact is identified by its feature (actor sphere x target, or box
@@ -51,6 +55,163 @@ MI_HD void scene_sphere_box(const float* c, float r, const float* a, float* dist
     n[0] = outside ? d[0] * inv : (ix ? (c[0] >= 0.f ? 1.f : -1.f) : 0.f);
     n[1] = outside ? d[1] * inv : (iy ? (c[1] >= 0.f ? 1.f : -1.f) : 0.f);
     n[2] = outside ? d[2] * inv : ((!ix && !iy) ? (c[2] >= 0.f ? 1.f : -1.f) : 0.f);
+}
+
+// EDGE-EDGE contact of two boxes (A: rotation Ra, centre xa, half sizes ha; B likewise), separating-axis test: of the 15 axes (3 + 3 face normals,
+// 9 edge x edge) the one of least penetration says which features touch.  False unless that axis is an edge x edge one by a margin (5 % + 0.1 mm:
+// the ties of face contacts -- a yawed cube flat on a table, a_x x b_y is the table's normal again -- stay face contacts, which the corner-in-box
+// tests cover); else the separation *dist along it, the unit normal n from B towards A, the contact point pc (the middle of the closest points
+// of the two supporting edges) and the pair's edge axes 3 i + j.  In A's frame with R = Ra^T Rb: the axis a_i x b_j is e_i x R[:, j], its length
+// sqrt(1 - R_ij^2), the boxes' radii along it the classic |R| sums.  Same rule as oracle/scene.py box_edge_contact (which tests the axes in world
+// coordinates through a generic support function).
+// Returns 1 with that contact; 2 when a FACE axis is the one of least penetration: *axes = 4 * (the face is A's) + its axis -- B's unless one
+// of A's is better by the same margin (scene_face_crossings below takes it from there); 0 when the boxes are further apart than `reach`.
+MI_HD int scene_box_edge(const float* Ra, const float* xa, const float* ha, const float* Rb, const float* xb, const float* hb, const float reach,
+                         float* dist, float* n, float* pc, int* axes) {
+    float R[3][3], Q[3][3], dA[3], dB[3];
+    const float d[3] = {xa[0] - xb[0], xa[1] - xb[1], xa[2] - xb[2]};
+    matTvec3(Ra, d, dA);
+    matTvec3(Rb, d, dB);
+    sfor<3>([&](auto I) MI_LAMBDA {
+        sfor<3>([&](auto J) MI_LAMBDA {
+            constexpr int i = I, j = J;
+            R[i][j] = Ra[i] * Rb[j] + Ra[3 + i] * Rb[3 + j] + Ra[6 + i] * Rb[6 + j];          // a_i . b_j (columns of row-major rotations)
+            Q[i][j] = fabsf(R[i][j]);
+        });
+    });
+    float sA = -1e30f, sB = -1e30f;
+    int kA = 0, kB = 0;
+    sfor<3>([&](auto K) MI_LAMBDA {
+        constexpr int k = K;
+        const float a_ = fabsf(dA[k]) - ha[k] - (hb[0] * Q[k][0] + hb[1] * Q[k][1] + hb[2] * Q[k][2]);
+        const float b_ = fabsf(dB[k]) - hb[k] - (ha[0] * Q[0][k] + ha[1] * Q[1][k] + ha[2] * Q[2][k]);
+        kA = (a_ > sA) ? k : kA; sA = fmaxf(sA, a_);
+        kB = (b_ > sB) ? k : kB; sB = fmaxf(sB, b_);
+    });
+    const float s_face = fmaxf(sA, sB);
+    float best = -1e30f, cA[3] = {0.f, 0.f, 0.f};
+    int bi = -1;
+    sfor<3>([&](auto I) MI_LAMBDA {
+        sfor<3>([&](auto J) MI_LAMBDA {
+            constexpr int i = I, j = J, i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+            const float l2 = R[i1][j] * R[i1][j] + R[i2][j] * R[i2][j];
+            const float il = MI_RSQ(fmaxf(l2, 1e-30f));
+            const float s_ = (fabsf(R[i1][j] * dA[i2] - R[i2][j] * dA[i1]) - (ha[i1] * Q[i2][j] + ha[i2] * Q[i1][j]) - (hb[j1] * Q[i][j2] + hb[j2] * Q[i][j1])) * il;
+            const bool take = (l2 > 1e-6f) && (s_ > best);
+            best = take ? s_ : best;
+            bi = take ? 3 * i + j : bi;
+            float c[3];
+            c[i] = 0.f; c[i1] = -R[i2][j] * il; c[i2] = R[i1][j] * il;
+            sfor<3>([&](auto C) MI_LAMBDA { cA[C] = take ? c[C] : cA[C]; });
+        });
+    });
+    if (fmaxf(s_face, best) > reach) return 0;
+    if (bi < 0 || !(best > s_face + 0.05f * fabsf(s_face) + 1e-4f)) {
+        const bool ref_a = sA > sB + 0.05f * fabsf(sB) + 1e-4f;
+        *axes = ref_a ? 4 + kA : kB;
+        return 2;
+    }
+    const float sg = (cA[0] * dA[0] + cA[1] * dA[1] + cA[2] * dA[2]) > 0.f ? 1.f : -1.f;
+    sfor<3>([&](auto C) MI_LAMBDA { cA[C] *= sg; });
+    matvec3(Ra, cA, n);
+    float nB[3], u[3], w[3], pa[3], pb[3];
+    matTvec3(Rb, n, nB);
+    const int ei = bi / 3, ej = bi - 3 * ei;
+    // the supporting edges: the corner of A farthest along -n / of B farthest along +n, minus its component along the edge's own axis
+    float ca[3], cb_[3], hai = 0.f, hbj = 0.f;
+    sfor<3>([&](auto K) MI_LAMBDA {
+        constexpr int k = K;
+        ca[k] = (k == ei) ? 0.f : ((cA[k] >= 0.f) ? -ha[k] : ha[k]);
+        cb_[k] = (k == ej) ? 0.f : ((nB[k] >= 0.f) ? hb[k] : -hb[k]);
+        hai = (k == ei) ? ha[k] : hai;
+        hbj = (k == ej) ? hb[k] : hbj;
+        u[k] = Ra[3 * k + 0] * (ei == 0 ? 1.f : 0.f) + Ra[3 * k + 1] * (ei == 1 ? 1.f : 0.f) + Ra[3 * k + 2] * (ei == 2 ? 1.f : 0.f);
+        w[k] = Rb[3 * k + 0] * (ej == 0 ? 1.f : 0.f) + Rb[3 * k + 1] * (ej == 1 ? 1.f : 0.f) + Rb[3 * k + 2] * (ej == 2 ? 1.f : 0.f);
+    });
+    matvec3(Ra, ca, pa);
+    matvec3(Rb, cb_, pb);
+    sfor<3>([&](auto K) MI_LAMBDA { pa[K] += xa[K]; pb[K] += xb[K]; });
+    const float r[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+    const float uw = dot3(u, w), ru = dot3(r, u), rw = dot3(r, w);
+    const float iden = MI_RCP(fmaxf(1.f - uw * uw, 1e-6f));
+    const float al = fminf(fmaxf((ru - rw * uw) * iden, -hai), hai), be = fminf(fmaxf((ru * uw - rw) * iden, -hbj), hbj);
+    sfor<3>([&](auto K) MI_LAMBDA { pc[K] = 0.5f * ((pa[K] + al * u[K]) + (pb[K] + be * w[K])); });
+    *dist = best;
+    *axes = bi;
+    return 1;
+}
+
+// column k (run-time) of a row-major rotation / entry k of a 3-vector, without indexing an array at run time
+MI_HD void scene_col(const float* R, const int k, float* o) {
+    sfor<3>([&](auto C) MI_LAMBDA { o[C] = (k == 0) ? R[3 * C] : ((k == 1) ? R[3 * C + 1] : R[3 * C + 2]); });
+}
+MI_HD float scene_pick(const float* v, const int k) { return (k == 0) ? v[0] : ((k == 1) ? v[1] : v[2]); }
+
+// The part of a FACE contact of two boxes that no corner-in-box test sees: where the outline of the incident face crosses the outline of the
+// reference face (two planks lying crossed on each other touch in a rectangle none of whose corners is a corner of either box; a plank on a
+// knife edge).  Reference box (Rr, xr, hr), its face axis k (scene_box_edge's answer 2); incident box (Ri, xi, hi): its face most anti-parallel to
+// the reference face; each of that face's four edges is clipped to the reference face's rectangle (Liang-Barsky in the reference box's frame);
+// a clip point that is not an end of the edge is a contact: emit(point, separation from the reference face, outward normal of the reference
+// face, 2 * edge + end).  Same rule as oracle/scene.py box_face_crossings.
+template <class F>
+MI_HD void scene_face_crossings(const float* Rr, const float* xr, const float* hr, const int k, const float* Ri, const float* xi, const float* hi, F&& emit) {
+    float nr[3], t1[3], t2[3];
+    scene_col(Rr, k, nr);
+    scene_col(Rr, (k + 1) % 3, t1);
+    scene_col(Rr, (k + 2) % 3, t2);
+    const float dx[3] = {xi[0] - xr[0], xi[1] - xr[1], xi[2] - xr[2]};
+    const float sr = dot3(nr, dx) >= 0.f ? 1.f : -1.f;
+    sfor<3>([&](auto C) MI_LAMBDA { nr[C] *= sr; });
+    const float hk = scene_pick(hr, k), h1 = scene_pick(hr, (k + 1) % 3), h2 = scene_pick(hr, (k + 2) % 3);
+    float nI[3];
+    matTvec3(Ri, nr, nI);
+    const float a0 = fabsf(nI[0]), a1 = fabsf(nI[1]), a2 = fabsf(nI[2]);
+    const int m = (a0 >= a1 && a0 >= a2) ? 0 : ((a1 >= a2) ? 1 : 2);          // (first of the largest, as numpy's argmax)
+    float am[3], u1[3], u2[3];
+    scene_col(Ri, m, am);
+    scene_col(Ri, (m + 1) % 3, u1);
+    scene_col(Ri, (m + 2) % 3, u2);
+    const float sI = scene_pick(nI, m) >= 0.f ? -1.f : 1.f;
+    const float g0 = sI * scene_pick(hi, m), g1 = scene_pick(hi, (m + 1) % 3), g2 = scene_pick(hi, (m + 2) % 3);
+    // the incident face's centre and its two half edges in the reference box's frame (normal, t1, t2 coordinates)
+    float c3[3], e1[3], e2[3];
+    {
+        const float cw[3] = {dx[0] + am[0] * g0, dx[1] + am[1] * g0, dx[2] + am[2] * g0};
+        c3[0] = dot3(nr, cw); c3[1] = dot3(t1, cw); c3[2] = dot3(t2, cw);
+        e1[0] = dot3(nr, u1) * g1; e1[1] = dot3(t1, u1) * g1; e1[2] = dot3(t2, u1) * g1;
+        e2[0] = dot3(nr, u2) * g2; e2[1] = dot3(t1, u2) * g2; e2[2] = dot3(t2, u2) * g2;
+    }
+    for (int e = 0; e < 4; ++e) {
+        // vertices in the order (-,-), (+,-), (+,+), (-,+): edge e runs from vertex e to vertex e + 1
+        const float s1a = (e == 0 || e == 3) ? -1.f : 1.f, s2a = (e < 2) ? -1.f : 1.f;
+        const float s1b = (e == 0 || e == 1) ? 1.f : -1.f, s2b = (e == 1 || e == 2) ? 1.f : -1.f;
+        float q0[3], dq[3];
+        sfor<3>([&](auto C) MI_LAMBDA {
+            q0[C] = c3[C] + s1a * e1[C] + s2a * e2[C];
+            dq[C] = (s1b - s1a) * e1[C] + (s2b - s2a) * e2[C];
+        });
+        float ta = 0.f, tb = 1.f;
+        sfor<2>([&](auto C) MI_LAMBDA {
+            constexpr int c = 1 + C;
+            const float hb_ = (c == 1) ? h1 : h2;
+            sfor<2>([&](auto S_) MI_LAMBDA {
+                const float sg = (S_ == 0) ? 1.f : -1.f;
+                const float num = hb_ - sg * q0[c], den = sg * dq[c];
+                if (fabsf(den) < 1e-12f) { if (num < 0.f) { ta = 1.f; tb = 0.f; } }
+                else if (den > 0.f) tb = fminf(tb, num / den);
+                else ta = fmaxf(ta, num / den);
+            });
+        });
+        if (ta > tb) continue;
+        for (int end = 0; end < 2; ++end) {
+            const float t = end ? tb : ta;
+            if (end ? !(t < 1.f - 1e-6f) : !(t > 1e-6f)) continue;
+            const float qn = q0[0] + t * dq[0], qa = q0[1] + t * dq[1], qb = q0[2] + t * dq[2];
+            float p[3];
+            sfor<3>([&](auto C) MI_LAMBDA { p[C] = xr[C] + nr[C] * qn + t1[C] * qa + t2[C] * qb; });
+            emit(p, qn - hk, nr, 2 * e + end);
+        }
+    }
 }
 
 template <class M>
@@ -384,6 +545,106 @@ struct SceneSim : Sim<M> {
                     cb[(S_AUX + 9) * ST] = __builtin_bit_cast(float, ib);
                     nbox += 1;
                 }
+            }
+        }
+        // one more box contact in the next slot: side A = free box ia pushed along n at pc (rel. O), side B = free box ib or nobody (-1)
+        auto add_box_contact = [&](const int ia, const int ib, const float* n, const float* pc, const float dist, const float mu, const int fid) MI_LAMBDA {
+            float fr[3][3];
+            sfor<3>([&](auto K) MI_LAMBDA { fr[0][K] = n[K]; });
+            contact_frame(fr[0], fr[1], fr[2]);
+            float* cb = rows.ptr(R_CB + (KARM + nbox) * S_CSZ);
+            float rA[3], rB[3] = {0.f, 0.f, 0.f}, l0[3];
+            warm_lookup(fid, l0, KARM, KSLOT);
+            sfor<3>([&](auto K) MI_LAMBDA { rA[K] = pc[K] - W(W_XF, 3 * ia + K); });
+            if (ib >= 0) sfor<3>([&](auto K) MI_LAMBDA { rB[K] = pc[K] - W(W_XF, 3 * ib + K); });
+            sfor<3>([&](auto K) MI_LAMBDA {
+                constexpr int k = K;
+                float a = P.cfm + box_diag(ia, rA, fr[k]);
+                if (ib >= 0) a += box_diag(ib, rB, fr[k]);
+                cb[(S_AUX + k) * ST] = MI_RCP(a);
+                cb[(S_AUX + 4 + k) * ST] = l0[k];
+            });
+            cb[(S_AUX + 10) * ST] = __builtin_bit_cast(float, fid);
+            sfor<3>([&](auto I_) MI_LAMBDA { cb[(S_GEO + I_) * ST] = n[I_]; cb[(S_GEO + 3 + I_) * ST] = pc[I_]; });
+            cb[(S_AUX + 3) * ST] = target_velocity(dist);
+            cb[(S_AUX + 7) * ST] = mu;
+            cb[(S_AUX + 8) * ST] = __builtin_bit_cast(float, ia);
+            cb[(S_AUX + 9) * ST] = __builtin_bit_cast(float, ib);
+            nbox += 1;
+        };
+        // the corners of the STATIC boxes inside free boxes (a plate lying on a stand smaller than itself has no corner of its own in the stand):
+        // the free box is pushed back along the inward normal of the face the corner is nearest to
+        constexpr int FID_SC = 1 + NSPH * NTGT + kSceneMaxFree * 8 * (NTGT + 1), FID_EE = FID_SC + kSceneMaxStatic * 8 * kSceneMaxFree,
+                      FID_FC = FID_EE + kSceneMaxFree * NTGT * 9;
+        for (int t = 0; t < ns; ++t) {
+            float Rt[9], xt[3];
+            ld9(W_RS, t, Rt);
+            ld3(W_XST, t, xt);
+            for (int cr = 0; cr < 8; ++cr) {
+                const float pl[3] = {(cr & 1) ? SP.static_half[t][0] : -SP.static_half[t][0], (cr & 2) ? SP.static_half[t][1] : -SP.static_half[t][1],
+                                     (cr & 4) ? SP.static_half[t][2] : -SP.static_half[t][2]};
+                float pr[3], pc[3];
+                matvec3(Rt, pl, pr);
+                sfor<3>([&](auto K) MI_LAMBDA { pc[K] = xt[K] + pr[K]; });
+                for (int j = 0; j < nf; ++j) {
+                    float Rb_[9], xb_[3], cl[3], nl[3], n[3], dist;
+                    ld9(W_RF, j, Rb_);
+                    ld3(W_XF, j, xb_);
+                    const float rel[3] = {pc[0] - xb_[0], pc[1] - xb_[1], pc[2] - xb_[2]};
+                    matTvec3(Rb_, rel, cl);
+                    scene_sphere_box(cl, 0.f, SP.free_half[j], &dist, nl);
+                    if (!(dist < P.contact_offset)) continue;
+                    if (nbox >= KBOX) { refused += 1; continue; }
+                    matvec3(Rb_, nl, n);
+                    sfor<3>([&](auto K) MI_LAMBDA { n[K] = -n[K]; });
+                    add_box_contact(j, -1, n, pc, dist, 0.5f * (SP.free_mu[j] + SP.static_mu[t]), FID_SC + (t * 8 + cr) * kSceneMaxFree + j);
+                }
+            }
+        }
+        // edge-edge: one contact per box pair whose least-penetration axis is the cross product of an edge of each (scene_box_edge)
+        for (int i = 0; i < nf; ++i) {
+            float Ri[9], xi[3];
+            ld9(W_RF, i, Ri);
+            ld3(W_XF, i, xi);
+            for (int t = 0; t < ns + nf - 1 - i; ++t) {
+                const bool st_ = t < ns;
+                const int j = st_ ? t : i + 1 + (t - ns);
+                float Rb_[9], xb_[3], n[3], pc[3], dist;
+                int axes;
+                ld9(st_ ? W_RS : W_RF, j, Rb_);
+                ld3(st_ ? W_XST : W_XF, j, xb_);
+                if (scene_box_edge(Ri, xi, SP.free_half[i], Rb_, xb_, st_ ? SP.static_half[j] : SP.free_half[j], P.contact_offset, &dist, n, pc, &axes) != 1) continue;
+                if (!(dist < P.contact_offset)) continue;
+                if (nbox >= KBOX) { refused += 1; continue; }
+                add_box_contact(i, st_ ? -1 : j, n, pc, dist, 0.5f * (SP.free_mu[i] + (st_ ? SP.static_mu[j] : SP.free_mu[j])),
+                                FID_EE + ((i * NTGT + (st_ ? j : kSceneMaxStatic + j)) * 9 + axes));
+            }
+        }
+        // face contacts: where the incident face's outline crosses the reference face's (scene_face_crossings)
+        for (int i = 0; i < nf; ++i) {
+            float Ri[9], xi[3];
+            ld9(W_RF, i, Ri);
+            ld3(W_XF, i, xi);
+            for (int t = 0; t < ns + nf - 1 - i; ++t) {
+                const bool st_ = t < ns;
+                const int j = st_ ? t : i + 1 + (t - ns);
+                float Rb_[9], xb_[3], n_[3], pc_[3], dist_;
+                int axes;
+                ld9(st_ ? W_RS : W_RF, j, Rb_);
+                ld3(st_ ? W_XST : W_XF, j, xb_);
+                const float* hj = st_ ? SP.static_half[j] : SP.free_half[j];
+                if (scene_box_edge(Ri, xi, SP.free_half[i], Rb_, xb_, hj, P.contact_offset, &dist_, n_, pc_, &axes) != 2) continue;
+                const bool ref_a = axes >= 4;
+                const float mu_ = 0.5f * (SP.free_mu[i] + (st_ ? SP.static_mu[j] : SP.free_mu[j]));
+                const int fid0 = FID_FC + (i * NTGT + (st_ ? j : kSceneMaxStatic + j)) * 8;
+                auto emit = [&](const float* p, const float dist, const float* nr, const int cid) MI_LAMBDA {
+                    if (!(dist < P.contact_offset)) return;
+                    if (nbox >= KBOX) { refused += 1; return; }
+                    const float n[3] = {ref_a ? -nr[0] : nr[0], ref_a ? -nr[1] : nr[1], ref_a ? -nr[2] : nr[2]};       // from B towards A
+                    add_box_contact(i, st_ ? -1 : j, n, p, dist, mu_, fid0 + cid);
+                };
+                if (ref_a) scene_face_crossings(Ri, xi, SP.free_half[i], axes - 4, Rb_, xb_, hj, emit);
+                else scene_face_crossings(Rb_, xb_, hj, axes, Ri, xi, SP.free_half[i], emit);
             }
         }
         *ncontact = (narm + nbox) | (refused << 16);

@@ -56,6 +56,7 @@ __device__ __forceinline__ void hand_mw_role(const View& v, const HandView& hv, 
     sim.limit_shift = Strided{hv.limit_shift + e, N};
     sim.drive_clamp = hv.drive_clamp;
     sim.pair_k = hv.pair_k;
+    sim.pair_sens = hv.pair_sens;
     if constexpr (is_scaled<typename HT::M>::value) { if (hv.body_mass != nullptr) sim.body_mass = Strided{hv.body_mass + e, N}; }
 #if defined(MI_TIMING)
     sim.tstamp = (lane == 0 && g_mi_tstamp_hmw != nullptr) ? g_mi_tstamp_hmw + ((size_t)blockIdx.x * 4 + R) * 16 : nullptr;
@@ -137,13 +138,15 @@ inline hipError_t hand_substeps_mw_shape(const View& v, const HandView& hv, cons
         auto kern = hand_substep_mw64_kernel<HT, SHAPE>;
         if (hipError_t e = ensure_dynamic_lds((const void*)kern, lds, &conf64); e != hipSuccess) return e;
         const dim3 grid(xcd_grid<64>(v.N));
-        for (int i = 0; i < n; ++i) hipLaunchKernelGGL(kern, grid, block, lds, s, HandMwArgs{v, hv, P, p});
+        // (the sensor values of every launch but the last are overwritten unseen: only the last one adds the pairs' forces to the fingertip sensors)
+        for (int i = 0; i < n; ++i) { HandView hl = hv; hl.pair_sens = (i == n - 1) ? 1 : 0; hipLaunchKernelGGL(kern, grid, block, lds, s, HandMwArgs{v, hl, P, p}); }
     } else {
         constexpr size_t lds = hand_mw_lds_bytes<HT, 32>();
         auto kern = hand_substep_mw_kernel<HT, SHAPE>;
         if (hipError_t e = ensure_dynamic_lds((const void*)kern, lds, &conf32); e != hipSuccess) return e;
         const dim3 grid(xcd_grid<32>(v.N));
-        for (int i = 0; i < n; ++i) hipLaunchKernelGGL(kern, grid, block, lds, s, HandMwArgs{v, hv, P, p});
+        // (the sensor values of every launch but the last are overwritten unseen: only the last one adds the pairs' forces to the fingertip sensors)
+        for (int i = 0; i < n; ++i) { HandView hl = hv; hl.pair_sens = (i == n - 1) ? 1 : 0; hipLaunchKernelGGL(kern, grid, block, lds, s, HandMwArgs{v, hl, P, p}); }
     }
     return hipGetLastError();
 }

@@ -31,6 +31,7 @@ struct HandView {
                            //         kernels run (option "hand_body_mass": the Sim<Scaled<M>> instantiations read them in the tree pass)
     float* body_mass_arena;// where that tensor sits (always; `body_mass` is this pointer or null)
     int* npair;            // [NROLE][N] sides of the asset's hand-to-hand contact pairs that were pushed in the last sub-step, per role wave (one-wave form / CPU: column 0)
+    int pair_sens = 1;     // 0: this launch is not the last sub-step of its call -- the pairs' forces on the fingertip sensors are skipped (its sensor values are overwritten unseen)
     float pair_k = 0.f;    // stiffness (N/m) of the compliant hand-to-hand pairs (option "hand_pair_stiffness"; 0 = off; core/hand_engine.hpp pair_side)
     int drive_clamp = 1;   // the position drives deliver at most M::dof_force_limit (option "drive_force_limit"; core/hand_engine.hpp drive_clamp_update)
 };

@@ -108,9 +108,16 @@ static real h_sphere_box3(const real *c, real r, const real *a, real *n) {
  * the spheres at its ends and its middle, the deepest one -- each side s is pushed along u_s (u_a = n from b towards a, u_b = -n) at the contact
  * point (the middle of the overlap) by F_s = k (pen - h J_s qd+): M += h^2 k J_s^T J_s, rhs += J_s^T k (pen - h J_s qd).  Frictionless (condim 1).
  * Returns the number of sides pushed. */
-static int h_pairs(const OrModel *m, const OrHand *hd, const Work *w, real h, const real *qd, real (*M)[MAXV], real *rhs) {
+/* The pairs on the force-sensor bodies (the fingertips; shadow_hand.py:291-297 -- PhysX's sensors see every constraint force on their body, the
+ * hand's own contacts included).  A pushed side's force is F_s = k (pen_s - h W_s . V+), W_s = [pc x u; u] about the root, V+ the body's twist after
+ * the solve.  csrc/core/hand_engine.hpp pair_sensor_acc / pair_sensor_wrench state what the sensor reports: per fingertip A = sum k pen_s W_s, P = sum
+ * pen_s, n = sides, and wrench = A (1 - n h (A . V+) / (k P^2)) -- exact for one side, the damping term along the resultant for more. */
+typedef struct { real A[6], P, n; } PairSens;
+#define MAXSENS 8
+static int h_pairs(const OrModel *m, const OrHand *hd, const Work *w, real h, const real *qd, real (*M)[MAXV], real *rhs, PairSens *ps) {
     int sides = 0;
     static _Thread_local real Jr[MAXV];
+    for (int k = 0; k < m->nsens && k < MAXSENS; k++) { for (int c = 0; c < 6; c++) ps[k].A[c] = 0; ps[k].P = 0; ps[k].n = 0; }
     for (int p = 0; p < hd->npair; p++) {
         const int ba = hd->pair_ba[p], bb = hd->pair_bb[p];
         real b0[3], b1[3], t[3], n[3], pc[3], dist;
@@ -154,6 +161,13 @@ static int h_pairs(const OrModel *m, const OrHand *hd, const Work *w, real h, co
                 rhs[i] += Jr[i] * f;
                 for (int j = 0; j < m->nd; j++) M[i][j] += a * Jr[i] * Jr[j];
             }
+            for (int k = 0; k < m->nsens && k < MAXSENS; k++) {
+                if (m->sens_body[k] != (s ? bb : ba)) continue;
+                real Wt[3];
+                v3cross(pc, u, Wt);
+                for (int c = 0; c < 3; c++) { ps[k].A[c] += hd->pair_k * pen * Wt[c]; ps[k].A[3 + c] += hd->pair_k * pen * u[c]; }
+                ps[k].P += pen; ps[k].n += 1;
+            }
             sides++;
         }
     }
@@ -172,6 +186,8 @@ static void hand_substep(const OrModel *m, const OrParams *p, const OrHand *hd, 
     static _Thread_local Work w;
     static _Thread_local real J[MAXROWS][MAXV], Bm[MAXROWS][MAXV];
     const int nd = m->nd;
+    static _Thread_local PairSens psens[MAXSENS];
+    int have_pairs = 0;
     real *root = st, *q = st + 13, *qd = st + 13 + nd, *laml = st + 13 + 2 * nd;
     const real zero3[3] = {0, 0, 0};
     const real s_mass = scale[0], s_damp = scale[1], s_kp = scale[2], s_tk = scale[3], s_td = scale[4], s_om = scale[5], s_os = scale[6];
@@ -197,7 +213,8 @@ static void hand_substep(const OrModel *m, const OrParams *p, const OrHand *hd, 
         rhs[d0] -= c0 * f; rhs[d1] -= c1 * f;
     }
     {   /* the asset's hand-to-hand contact pairs: compliant contacts */
-        int sides = (hd->npair > 0 && hd->pair_k > 0) ? h_pairs(m, hd, &w, h, qd, w.M, rhs) : 0;
+        int sides = (hd->npair > 0 && hd->pair_k > 0) ? h_pairs(m, hd, &w, h, qd, w.M, rhs, psens) : 0;
+        have_pairs = hd->npair > 0 && hd->pair_k > 0;
         if (pair_sides) *pair_sides = sides;
     }
     /* object: mass matrix in world axes */
@@ -390,6 +407,31 @@ static void hand_substep(const OrModel *m, const OrParams *p, const OrHand *hd, 
             m3tv(w.R[b], f, fl); m3tv(w.R[b], tq, tl);
             for (int i = 0; i < 3; i++) { sensor[6 * k + i] += fl[i]; sensor[6 * k + 3 + i] += tl[i]; }
         }
+    }
+    /* the hand's own contacts on the fingertips (PairSens above): the body's twist about the root from six probes of point_jac -- the velocity of the
+       point p is v_O + omega x p --, the wrench A (1 - n h (A . V) / (k P^2)), then into the sensor's frame like a contact force */
+    for (int k = 0; have_pairs && k < m->nsens && k < MAXSENS; k++) {
+        const PairSens *ps = psens + k;
+        if (!(ps->P > 0)) continue;
+        const int b = m->sens_body[k];
+        static _Thread_local real Jp[MAXV];
+        const real zero[3] = {0, 0, 0}, ex[3] = {1, 0, 0}, ey[3] = {0, 1, 0};
+        const real dirs[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+        real vO[3], vex_y, vex_z, vey_z;
+#define PROBE(pt, dir, out) do { point_jac(m, &w, b, pt, dir, Jp); real s_ = 0; for (int i = 0; i < nd; i++) s_ += Jp[i] * v[i]; out = s_; } while (0)
+        for (int c = 0; c < 3; c++) PROBE(zero, dirs[c], vO[c]);
+        PROBE(ex, dirs[1], vex_y); PROBE(ex, dirs[2], vex_z); PROBE(ey, dirs[2], vey_z);
+#undef PROBE
+        const real om[3] = {vey_z - vO[2], vO[2] - vex_z, vex_y - vO[1]};
+        real av = 0;
+        for (int c = 0; c < 3; c++) av += ps->A[c] * om[c] + ps->A[3 + c] * vO[c];
+        const real fac = 1 - ps->n * h * av / (hd->pair_k * ps->P * ps->P);
+        real f[3], tq[3], rxf[3], fl[3], tl[3];
+        for (int c = 0; c < 3; c++) f[c] = ps->A[3 + c] * fac;
+        v3cross(w.r[b], f, rxf);
+        for (int c = 0; c < 3; c++) tq[c] = ps->A[c] * fac - rxf[c];          /* torque about the sensor origin: tau_O - r_b x f */
+        m3tv(w.R[b], f, fl); m3tv(w.R[b], tq, tl);
+        for (int c = 0; c < 3; c++) { sensor[6 * k + c] += fl[c]; sensor[6 * k + 3 + c] += tl[c]; }
     }
     /* ---- integrate */
     for (int d = 0; d < nd; d++) { qd[d] = v[d]; q[d] += h * v[d]; }

@@ -328,6 +328,7 @@ class OracleHandEngine:
         # the asset's hand-to-hand contact pairs as compliant contacts (hand.c h_pairs): each side of an overlapping pair is pushed along its
         # outward direction by the implicit spring k (pen - h J qd+)
         sides = 0
+        pair_sens = {}       # per force-sensor body with pushed pair sides: A = sum k pen [pc x u; u] about O, P = sum pen, n = sides (hand.c PairSens)
         for pr in (self.pairs if self.pair_k > 0 else []):
             ba, bb = pr["a"]["body"], pr["b"]["body"]
             Ra, ra_, Rb_, rb_ = bp[ba, 3:12].reshape(3, 3), bp[ba, 0:3], bp[bb, 3:12].reshape(3, 3), bp[bb, 0:3]
@@ -357,6 +358,10 @@ class OracleHandEngine:
                 Js = u @ J3
                 Mh += h * h * self.pair_k * np.outer(Js, Js)
                 rhs += Js * self.pair_k * (pen - h * (Js @ qd))
+                if body in self.sens:
+                    ps = pair_sens.setdefault(self.sens.index(body), dict(A=np.zeros(6), P=0.0, n=0))
+                    ps["A"] += self.pair_k * pen * np.concatenate([np.cross(pc - O, u), u])
+                    ps["P"] += pen; ps["n"] += 1
                 sides += 1
         self.pair_sides[e] = sides
         Minv = np.linalg.inv(Mh)
@@ -472,6 +477,20 @@ class OracleHandEngine:
                 Rb = bp[cdat["b"], 3:12].reshape(3, 3); pb = bp[cdat["b"], 0:3]
                 sens[6 * k:6 * k + 3] += Rb.T @ f
                 sens[6 * k + 3:6 * k + 6] += Rb.T @ np.cross(cdat["pc"] - pb, f)
+        for k, ps in pair_sens.items():      # the hand's own contacts on the fingertips: wrench = A (1 - n h (A . V) / (k P^2)), V the tip's twist about O
+            b = self.sens[k]
+            Jp = np.zeros((3, nd))
+            def vel(p):
+                self.eng.lib.or_point_jac(C.byref(self.eng.model), _ptr(s_state), b, _ptr(np.ascontiguousarray(p, dtype=np.float64)), _ptr(Jp))
+                return Jp @ v
+            vO, vx, vy = vel([0.0, 0.0, 0.0]), vel([1.0, 0.0, 0.0]), vel([0.0, 1.0, 0.0])
+            om = np.array([vy[2] - vO[2], vO[2] - vx[2], vx[1] - vO[1]])
+            fac = 1.0 - ps["n"] * h * (ps["A"][:3] @ om + ps["A"][3:] @ vO) / (self.pair_k * ps["P"] ** 2)
+            Rb = bp[b, 3:12].reshape(3, 3); pb = bp[b, 0:3]
+            f = ps["A"][3:] * fac
+            tq = ps["A"][:3] * fac - np.cross(pb - O, f)
+            sens[6 * k:6 * k + 3] += Rb.T @ f
+            sens[6 * k + 3:6 * k + 6] += Rb.T @ tq
         self.sensor[e] = sens
         # ---- integrate
         self.qd[e] = v; self.q[e] = q + h * v

@@ -9,7 +9,8 @@ isaacgymenvs/tasks/franka_cube_stack.py:204-233,323-339 (arm + table + stand + t
            position drives, joint-limit rows with warm start
   boxes  : free rigid boxes (principal inertias along the box axes, gravity on, velocity clamps 1000 m/s / 64 rad/s), static boxes
   contact: actor collision spheres vs free / static boxes (at most KARM, sphere order, free boxes before static ones); the corners of every
-           free box vs ground plane, static boxes, the other free boxes (at most KBOX); 3 rows each (normal + friction disc); friction = mean of
+           free box vs ground plane, static boxes, the other free boxes, then the static boxes' corners vs the free boxes, then one EDGE-EDGE
+           contact per box pair whose least-penetration axis is edge x edge (at most KBOX together); 3 rows each (normal + friction disc); friction = mean of
            the two sides'; warm start by FEATURE (sphere x target / corner x target): a contact starts its first sweep from the impulses the
            same feature ended the last sub-step with (applied when the sweep reaches it)
 """
@@ -24,6 +25,108 @@ from .hand import contact_frame, quat2mat, sphere_box3
 
 KARM, KBOX = 24, 24                   # csrc/core/scene_engine.hpp SceneSim::KARM / KBOX
 MAX_W, MAX_V = 64.0, 1000.0           # csrc/core/engine.hpp kMaxAngularVelocity / kMaxLinearVelocity
+
+
+def box_edge_contact(Ra, xa, ha, Rb, xb, hb):
+    """Edge-edge contact of two boxes (rotation, centre, half sizes each) by the separating-axis test: among the 15 axes (3 + 3 face normals, 9
+    edge x edge) the one of LEAST penetration says which features touch.  Returns None unless that axis is an edge x edge one -- by a margin
+    (5 % + 0.1 mm), so that the ties of face contacts (a yawed cube flat on a table: a_x x b_y is the table's normal again) stay face contacts,
+    which the corner-in-box tests cover --, else (separation, unit normal from B towards A, contact point, edge axis of A, edge axis of B): the
+    point is the middle of the closest points of the two supporting edges.  (csrc/core/scene_engine.hpp scene_box_edge; crossed edges have no
+    corner inside the other box, so without this a cube pushed edge-on across another's edge passes through it: VERDICT r5 #5 / #9.)"""
+    ha, hb = np.asarray(ha, float), np.asarray(hb, float)
+    d = xa - xb
+
+    def sep(ax):
+        return abs(ax @ d) - sum(ha[k] * abs(ax @ Ra[:, k]) for k in range(3)) - sum(hb[k] * abs(ax @ Rb[:, k]) for k in range(3))
+
+    s_face = max([sep(Ra[:, k]) for k in range(3)] + [sep(Rb[:, k]) for k in range(3)])
+    best = None
+    for i in range(3):
+        for j in range(3):
+            c = np.cross(Ra[:, i], Rb[:, j])
+            l = np.linalg.norm(c)
+            if l < 1e-3:                       # (nearly) parallel edges: a face axis covers the pair
+                continue
+            s = sep(c / l)
+            if best is None or s > best[0]:
+                best = (s, i, j, c / l)
+    if best is None or not best[0] > s_face + 0.05 * abs(s_face) + 1e-4:
+        return None
+    s, i, j, ax = best
+    n = ax if ax @ d > 0 else -ax
+    pa, pb = xa.copy(), xb.copy()
+    for k in range(3):
+        if k != i:
+            pa = pa - (1.0 if n @ Ra[:, k] >= 0 else -1.0) * ha[k] * Ra[:, k]        # the edge of A farthest along -n
+        if k != j:
+            pb = pb + (1.0 if n @ Rb[:, k] >= 0 else -1.0) * hb[k] * Rb[:, k]        # the edge of B farthest along +n
+    u, w = Ra[:, i], Rb[:, j]
+    r, uw = pb - pa, float(Ra[:, i] @ Rb[:, j])
+    den = 1.0 - uw * uw
+    al = min(max(((r @ u) - (r @ w) * uw) / den, -ha[i]), ha[i])
+    be = min(max(((r @ u) * uw - (r @ w)) / den, -hb[j]), hb[j])
+    return s, n, 0.5 * ((pa + al * u) + (pb + be * w)), i, j
+
+
+def box_face_crossings(Ra, xa, ha, Rb, xb, hb):
+    """The part of a FACE contact of two boxes that no corner-in-box test sees: where the outline of the incident face crosses the outline of the
+    reference face (two planks lying crossed on each other touch in a rectangle none of whose corners is a corner of either; a plank on a knife
+    edge).  Reference face: the face axis of least penetration, B's unless one of A's is better by the margin of box_edge_contact (5 % + 0.1 mm;
+    nothing when an edge x edge axis beats the faces by that margin -- box_edge_contact's case); incident face: the other box's face most
+    anti-parallel to it.  Each of its four edges is clipped to the reference face's rectangle (in the reference box's frame); a clip point that is
+    not an end of the edge is a contact: (separation from the reference face, unit normal from B towards A, point, id = 2 * edge + end).
+    csrc/core/scene_engine.hpp scene_face_crossings."""
+    ha, hb = np.asarray(ha, float), np.asarray(hb, float)
+    d = xa - xb
+
+    def sep(ax):
+        return abs(ax @ d) - sum(ha[k] * abs(ax @ Ra[:, k]) for k in range(3)) - sum(hb[k] * abs(ax @ Rb[:, k]) for k in range(3))
+
+    sA, sB = [sep(Ra[:, k]) for k in range(3)], [sep(Rb[:, k]) for k in range(3)]
+    kA, kB = int(np.argmax(sA)), int(np.argmax(sB))
+    s_face = max(sA[kA], sB[kB])
+    for i in range(3):
+        for j in range(3):
+            c = np.cross(Ra[:, i], Rb[:, j])
+            l = np.linalg.norm(c)
+            if l >= 1e-3 and sep(c / l) > s_face + 0.05 * abs(s_face) + 1e-4:
+                return []
+    ref_a = sA[kA] > sB[kB] + 0.05 * abs(sB[kB]) + 1e-4
+    if ref_a:
+        Rr, xr, hr, k, Ri, xi, hi = Ra, xa, ha, kA, Rb, xb, hb
+    else:
+        Rr, xr, hr, k, Ri, xi, hi = Rb, xb, hb, kB, Ra, xa, ha
+    nr = Rr[:, k] * (1.0 if Rr[:, k] @ (xi - xr) >= 0 else -1.0)          # the reference face's outward normal (towards the incident box)
+    m = int(np.argmax(np.abs(Ri.T @ nr)))
+    sI = -1.0 if Ri[:, m] @ nr >= 0 else 1.0
+    m1, m2 = (m + 1) % 3, (m + 2) % 3
+    cI = xi + Ri[:, m] * sI * hi[m]
+    verts = [cI + s1 * hi[m1] * Ri[:, m1] + s2 * hi[m2] * Ri[:, m2] for s1, s2 in ((-1, -1), (1, -1), (1, 1), (-1, 1))]
+    k1, k2 = (k + 1) % 3, (k + 2) % 3
+    out = []
+    for e in range(4):
+        p0, p1 = verts[e], verts[(e + 1) % 4]
+        q0, q1 = Rr.T @ (p0 - xr), Rr.T @ (p1 - xr)
+        t0, t1 = 0.0, 1.0
+        for c_ in (k1, k2):
+            dq = q1[c_] - q0[c_]
+            for bound, sg in ((hr[c_], 1.0), (hr[c_], -1.0)):             # sg * q <= bound
+                num, den = bound - sg * q0[c_], sg * dq
+                if abs(den) < 1e-12:
+                    if num < 0:
+                        t0, t1 = 1.0, 0.0
+                elif den > 0:
+                    t1 = min(t1, num / den)
+                else:
+                    t0 = max(t0, num / den)
+        if t0 > t1:
+            continue
+        for end, t in ((0, t0), (1, t1)):
+            if (end == 0 and t > 1e-6) or (end == 1 and t < 1.0 - 1e-6):
+                p = p0 + t * (p1 - p0)
+                out.append((float(nr @ (p - xr) - hr[k]), (nr if not ref_a else -nr), p, 2 * e + end))
+    return out
 
 
 class OracleSceneEngine:
@@ -176,6 +279,56 @@ class OracleSceneEngine:
                     t1, t2 = contact_frame(n)
                     contacts.append(dict(Jh=None, ia=i, ib=ib, fr=(n, t1, t2), pc=pc, vtn=vtarget(dist), mu=0.5 * (self.free[i]["mu"] + mub),
                                          fid=1 + len(spec.sph_body) * 8 + (i * 8 + cr) * 9 + (t + 1)))
+                    nbox += 1
+        # the corners of the STATIC boxes inside free boxes (a plate lying on a stand smaller than itself has no corner of its own in the stand): the
+        # free box is pushed back along the inward normal of the face the corner is nearest to
+        for t, s_ in enumerate(self.static):
+            hs = np.asarray(s_["half"], float)
+            for cr in range(8):
+                pl = np.array([hs[0] if cr & 1 else -hs[0], hs[1] if cr & 2 else -hs[1], hs[2] if cr & 4 else -hs[2]])
+                pc = np.asarray(s_["pos"], float) + Rs[t] @ pl
+                for j in range(nf):
+                    dist, nl = sphere_box3(Rf[j].T @ (pc - xf[j]), 0.0, self.free[j]["half"])
+                    if not dist < P["contact_offset"]:
+                        continue
+                    if nbox >= KBOX:
+                        refused += 1
+                        continue
+                    n = -(Rf[j] @ nl)
+                    t1, t2 = contact_frame(n)
+                    contacts.append(dict(Jh=None, ia=j, ib=-1, fr=(n, t1, t2), pc=pc, vtn=vtarget(dist), mu=0.5 * (self.free[j]["mu"] + s_["mu"]),
+                                         fid=("sc", t, cr, j)))
+                    nbox += 1
+        # EDGE-EDGE: one contact per box pair whose least-penetration axis is the cross product of an edge of each (box_edge_contact below)
+        for i in range(nf):
+            others = [(("st", t), Rs[t], np.asarray(s_["pos"], float), s_["half"], s_["mu"], -1) for t, s_ in enumerate(self.static)]
+            others += [(("fr", j), Rf[j], xf[j], self.free[j]["half"], self.free[j]["mu"], j) for j in range(i + 1, nf)]
+            for tag, Rb, xb, hb, mub, ib in others:
+                hit = box_edge_contact(Rf[i], xf[i], self.free[i]["half"], Rb, xb, hb)
+                if hit is None or not hit[0] < P["contact_offset"]:
+                    continue
+                if nbox >= KBOX:
+                    refused += 1
+                    continue
+                dist, n, pc, ei, ej = hit
+                t1, t2 = contact_frame(n)
+                contacts.append(dict(Jh=None, ia=i, ib=ib, fr=(n, t1, t2), pc=pc, vtn=vtarget(dist), mu=0.5 * (self.free[i]["mu"] + mub),
+                                     fid=("ee", i, tag, ei, ej)))
+                nbox += 1
+        # FACE contacts: where the incident face's outline crosses the reference face's (box_face_crossings)
+        for i in range(nf):
+            others = [(("st", t), Rs[t], np.asarray(s_["pos"], float), s_["half"], s_["mu"], -1) for t, s_ in enumerate(self.static)]
+            others += [(("fr", j), Rf[j], xf[j], self.free[j]["half"], self.free[j]["mu"], j) for j in range(i + 1, nf)]
+            for tag, Rb, xb, hb, mub, ib in others:
+                for dist, n, pc, cid in box_face_crossings(Rf[i], xf[i], self.free[i]["half"], Rb, xb, hb):
+                    if not dist < P["contact_offset"]:
+                        continue
+                    if nbox >= KBOX:
+                        refused += 1
+                        continue
+                    t1, t2 = contact_frame(n)
+                    contacts.append(dict(Jh=None, ia=i, ib=ib, fr=(n, t1, t2), pc=pc, vtn=vtarget(dist), mu=0.5 * (self.free[i]["mu"] + mub),
+                                         fid=("fc", i, tag, cid)))
                     nbox += 1
         self.ncontacts[e] = narm + nbox
         self.refused[e] += refused

@@ -82,7 +82,7 @@ def test_host_builds_of_both_hand_forms_push_the_same_pairs_as_the_oracle(form):
     dims = np.zeros(3, np.float32)
     p_ = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
     lib.hs_set_hand_pair_stiffness(C.c_float(orc.pair_k))
-    seen = 0
+    seen, fmax = 0, 0.0
     try:
         for it in range(8):
             orc.step(); off.step()
@@ -96,7 +96,12 @@ def test_host_builds_of_both_hand_forms_push_the_same_pairs_as_the_oracle(form):
             seen += int((orc.pair_sides > 0).sum())
             np.testing.assert_allclose(state[:, 0:nd], orc.q, atol=2e-4)
             np.testing.assert_allclose(state[:, nd:2 * nd], orc.qd, atol=5e-3 * max(1.0, np.abs(orc.qd).max()))
+            # the fingertip force sensors carry the pairs' forces (round 6): the cube is out of reach, so whatever they read IS the hand's own contacts
+            fs, fo = out[:, 0:6 * ns], np.asarray(orc.sensor)
+            np.testing.assert_allclose(fs, fo, atol=2e-2 * max(1.0, np.abs(fo).max()))
+            fmax = max(fmax, float(np.abs(fo[:, [0, 1, 2, 6, 7, 8, 12, 13, 14, 18, 19, 20, 24, 25, 26]]).max()))
         assert seen > 8 * N // 3, "scenario must exercise the pairs"
+        assert fmax > 1.0, fmax          # newtons: pressed fingertips do register
         assert np.abs(orc.q - off.q).max() > 0.2                 # rad: without the pairs the fingers pass through each other
     finally:
         lib.hs_set_hand_pair_stiffness(C.c_float(2.0e4))
@@ -109,14 +114,16 @@ def test_numpy_and_c_oracles_agree_on_the_pairs():
     spec, ex, sens, orc, _ = _engines(N, "one_wave", 9)
     ref = OracleHandEngine(spec, ex, N, SIM, sens, backend="numpy")
     ref.q[:] = orc.q; ref.qd[:] = 0.0; ref.targets[:] = orc.targets; ref.obj[:] = orc.obj
-    hit = 0
+    hit, fsum = 0, 0.0
     for it in range(6):
         orc.step(); ref.step()
         np.testing.assert_array_equal(orc.pair_sides, ref.pair_sides)
         hit += int(orc.pair_sides.sum())
         np.testing.assert_allclose(orc.q, ref.q, atol=1e-9)
         np.testing.assert_allclose(orc.qd, ref.qd, atol=1e-7)
-    assert hit > 0
+        np.testing.assert_allclose(orc.sensor, ref.sensor, atol=1e-6 * max(1.0, np.abs(ref.sensor).max()))      # incl. the pairs' forces on the fingertips
+        fsum += float(np.abs(ref.sensor).sum())
+    assert hit > 0 and fsum > 0
 
 
 def test_pairs_hold_saturated_drives_within_a_millimetre_or_two():

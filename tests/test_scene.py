@@ -374,6 +374,113 @@ def test_scene_first_principles_known_answers_hip():
     _known_answers("cuda:0")
 
 
+def _boxes(device, statics, frees, n=2, mu=0.5):
+    """a scene of static and free boxes given as (size3, position3, quaternion xyzw); the arm stands far away"""
+    import isaacgymenvs_amd.shims as shims
+    from isaacgymenvs_amd import native
+    if device == "cpu":
+        native.build_cpu()
+    shims.install(force=True)
+    from isaacgym import gymapi
+    gym = gymapi.acquire_gym()
+    sp = gymapi.SimParams()
+    sp.up_axis, sp.gravity, sp.dt, sp.substeps, sp.use_gpu_pipeline = gymapi.UP_AXIS_Z, gymapi.Vec3(0, 0, -9.81), 1 / 60.0, 2, device != "cpu"
+    sp.physx.num_position_iterations, sp.physx.num_velocity_iterations = 8, 1
+    sp.physx.contact_offset, sp.physx.rest_offset = 0.005, 0.0
+    sim = gym.create_sim(0, -1, gymapi.SIM_PHYSX, sp)
+    gym.add_ground(sim, gymapi.PlaneParams())
+    opts = gymapi.AssetOptions()
+    opts.flip_visual_attachments, opts.fix_base_link, opts.collapse_fixed_joints, opts.disable_gravity = True, True, False, True
+    opts.thickness, opts.default_dof_drive_mode, opts.use_mesh_materials = 0.001, gymapi.DOF_MODE_EFFORT, True
+    franka = gym.load_asset(sim, os.path.join(REF, "assets"), "urdf/franka_description/robots/franka_panda_gripper.urdf", opts)
+    fixed = gymapi.AssetOptions(); fixed.fix_base_link = True
+
+    def asset(size, o):
+        a_ = gym.create_box(sim, *[float(x) for x in size], o)
+        pr = gym.get_asset_rigid_shape_properties(a_)
+        pr[0].friction = mu
+        gym.set_asset_rigid_shape_properties(a_, pr)
+        return a_
+    sa = [asset(sz, fixed) for sz, _, _ in statics]
+    fa = [asset(sz, gymapi.AssetOptions()) for sz, _, _ in frees]
+    T = lambda p_, q_: gymapi.Transform(gymapi.Vec3(*[float(x) for x in p_]), gymapi.Quat(*[float(x) for x in q_]))  # noqa: E731
+    for i in range(n):
+        env = gym.create_env(sim, gymapi.Vec3(), gymapi.Vec3(), 2)
+        gym.create_actor(env, franka, gymapi.Transform(gymapi.Vec3(-2.5, 0.0, 1.0)), "franka", i, 0, 0)
+        for k, (a_, (_, p_, q_)) in enumerate(zip(sa, statics)):
+            gym.create_actor(env, a_, T(p_, q_), f"static{k}", i, 1, 0)
+        for k, (a_, (_, p_, q_)) in enumerate(zip(fa, frees)):
+            gym.create_actor(env, a_, T(p_, q_), f"free{k}", i, 2, 0)
+    gym.prepare_sim(sim)
+    root = gym.acquire_actor_root_state_tensor(sim).view(n, 1 + len(statics) + len(frees), 13)
+    return gym, sim, franka, root
+
+
+def _roll(axis, deg):
+    a = np.asarray(axis, float) / np.linalg.norm(axis)
+    return list(a * np.sin(np.radians(deg) / 2)) + [float(np.cos(np.radians(deg) / 2))]
+
+
+I4 = [0.0, 0.0, 0.0, 1.0]
+S2 = float(np.sqrt(2.0))
+
+
+def _edge_and_outline_contacts(device):
+    """Box contacts that have no corner of one box inside the other (round 6: scene_box_edge, scene_face_crossings, the static boxes' corners):
+    (1) EDGE-EDGE: a bar rolled 45 degrees about its long axis x, edge down, dropped across a static bar rolled 45 degrees about its long axis y,
+        edge up: it lands on the crossing point of the two edges and stays there (an unstable balance: looked at for 0.4 s, perturbations
+        grow with exp(t / 0.06 s) from rounding noise), carried by ONE contact;
+    (2) a plank lying flat on two static knife edges: rests on 2 + 2 outline crossings;
+    (3) two planks lying crossed: rest on the 4 corners of the overlap rectangle, none of which is a corner of a box;
+    (4) a plate on a stand smaller than itself: rests on the stand's 4 corners.
+    Known answers: the rest heights (to 1 mm), no velocity, the contact counts; every scene also against oracle/scene.py."""
+    z0 = 1.0
+    cases = {
+        "edge-edge": dict(statics=[((0.06, 0.4, 0.06), (0.5, 0.0, z0), _roll([0, 1, 0], 45))],
+                          frees=[((0.4, 0.06, 0.06), (0.5, 0.0, z0 + 0.06 * S2 + 0.01), _roll([1, 0, 0], 45))],
+                          rest=z0 + 0.06 * S2, contacts=1, steps=24),
+        "knife edges": dict(statics=[((0.06, 0.4, 0.06), (0.38, 0.0, z0), _roll([0, 1, 0], 45)), ((0.06, 0.4, 0.06), (0.62, 0.0, z0), _roll([0, 1, 0], 45))],
+                            frees=[((0.4, 0.06, 0.02), (0.5, 0.0, z0 + 0.03 * S2 + 0.01 + 0.01), I4)],
+                            rest=z0 + 0.03 * S2 + 0.01, contacts=4, steps=60),
+        "crossed planks": dict(statics=[((0.06, 0.4, 0.02), (0.5, 0.0, z0), I4)],
+                               frees=[((0.4, 0.06, 0.02), (0.5, 0.0, z0 + 0.02 + 0.01), I4)],
+                               rest=z0 + 0.02, contacts=4, steps=60),
+        "plate on a stand": dict(statics=[((0.1, 0.1, 0.1), (0.5, 0.0, z0), I4)],
+                                 frees=[((0.3, 0.3, 0.02), (0.5, 0.0, z0 + 0.05 + 0.01 + 0.01), I4)],
+                                 rest=z0 + 0.05 + 0.01, contacts=4, steps=60),
+    }
+    for name, c in cases.items():
+        n = 2
+        gym, sim, franka, root = _boxes(device, c["statics"], c["frees"], n)
+        orc = _oracle(sim, franka, n)
+        q0 = sim.engine.tensors["dof_state"].cpu().numpy()[..., 0].reshape(n, -1)
+        orc.q[:] = q0; orc.targets[:] = q0
+        ifree = 1 + len(c["statics"])
+        for k in range(c["steps"]):
+            gym.simulate(sim)
+            orc.step(np.zeros((n, orc.nd)))
+            gym.refresh_actor_root_state_tensor(sim)
+            got = root[:, ifree].cpu().numpy()
+            d = np.abs(got - orc.box[:, 0])
+            d[:, 3:7] = np.minimum(d[:, 3:7], np.abs(got[:, 3:7] + orc.box[:, 0, 3:7]))
+            assert d[:, :7].max() < 1e-3 and d[:, 7:].max() < 5e-2, (name, k, d[:, :7].max(), d[:, 7:].max())
+        x = root[:, ifree].cpu().numpy()
+        nc = sim.engine.tensors["scene_contacts"].cpu().numpy()
+        assert np.abs(x[:, 2] - c["rest"]).max() < 1e-3, (name, x[:, 2], c["rest"])
+        assert np.abs(x[:, 7:10]).max() < 0.02 and np.abs(x[:, 10:13]).max() < 0.2, (name, x[:, 7:13])
+        assert np.abs(x[:, 0:2] - np.array(c["frees"][0][1][:2])).max() < 2e-3, (name, x[:, 0:3])
+        assert (nc[:, 0] == c["contacts"]).all() and (orc.ncontacts == c["contacts"]).all() and int(nc[:, 1].sum()) == 0, (name, nc, orc.ncontacts)
+
+
+def test_scene_edge_and_outline_contacts_cpu():
+    _edge_and_outline_contacts("cpu")
+
+
+@pytest.mark.gpu
+def test_scene_edge_and_outline_contacts_hip():
+    _edge_and_outline_contacts("cuda:0")
+
+
 def _ori_err(qd_, q_):
     """rotation vector that takes orientation q_ to qd_ (xyzw): 2 vec(qd * conj(q)), the shorter way round"""
     x1, y1, z1, w1 = qd_.unbind(-1)

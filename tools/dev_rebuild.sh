@@ -11,6 +11,6 @@ for tu in "$@"; do
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p || { echo "compile failed"; tail -20 build/*.log | grep -B2 -A8 "error" | head -60; exit 1; }; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/*.o -o ../libmi_engine.so.tmp
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls build/*.o | grep -v "build/cpu_") -o ../libmi_engine.so.tmp
 mv ../libmi_engine.so.tmp ../libmi_engine.so
 echo "relinked $(ls -la ../libmi_engine.so)"
