@@ -504,7 +504,9 @@ def _resolve_mesh(filename, urdf_path, mesh_root=None):
     URIs lose their prefix) -> an existing path, or None."""
     name = filename.split("package://")[-1]
     here = os.path.dirname(os.path.abspath(urdf_path))
-    roots = ([mesh_root] if mesh_root else []) + [here, os.path.dirname(here), os.path.dirname(os.path.dirname(here))]
+    roots = ([mesh_root] if mesh_root else []) + [here]
+    for _ in range(5):          # a package:// name starts at the package's PARENT directory, which may sit several levels above the URDF (trifingerpro.urdf: three)
+        roots.append(os.path.dirname(roots[-1]))
     for r in roots:
         cand = os.path.join(r, name)
         if os.path.exists(cand):

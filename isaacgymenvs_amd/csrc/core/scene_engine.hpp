@@ -601,26 +601,9 @@ struct SceneSim : Sim<M> {
                 }
             }
         }
-        // edge-edge: one contact per box pair whose least-penetration axis is the cross product of an edge of each (scene_box_edge)
-        for (int i = 0; i < nf; ++i) {
-            float Ri[9], xi[3];
-            ld9(W_RF, i, Ri);
-            ld3(W_XF, i, xi);
-            for (int t = 0; t < ns + nf - 1 - i; ++t) {
-                const bool st_ = t < ns;
-                const int j = st_ ? t : i + 1 + (t - ns);
-                float Rb_[9], xb_[3], n[3], pc[3], dist;
-                int axes;
-                ld9(st_ ? W_RS : W_RF, j, Rb_);
-                ld3(st_ ? W_XST : W_XF, j, xb_);
-                if (scene_box_edge(Ri, xi, SP.free_half[i], Rb_, xb_, st_ ? SP.static_half[j] : SP.free_half[j], P.contact_offset, &dist, n, pc, &axes) != 1) continue;
-                if (!(dist < P.contact_offset)) continue;
-                if (nbox >= KBOX) { refused += 1; continue; }
-                add_box_contact(i, st_ ? -1 : j, n, pc, dist, 0.5f * (SP.free_mu[i] + (st_ ? SP.static_mu[j] : SP.free_mu[j])),
-                                FID_EE + ((i * NTGT + (st_ ? j : kSceneMaxStatic + j)) * 9 + axes));
-            }
-        }
-        // face contacts: where the incident face's outline crosses the reference face's (scene_face_crossings)
+        // per box pair (free box i against the static boxes, then against the free boxes behind it), by the separating-axis test: EDGE-EDGE -- one
+        // contact when the least-penetration axis is the cross product of an edge of each (scene_box_edge) --, or, when a face axis wins, the points
+        // where the incident face's outline crosses the reference face's (scene_face_crossings)
         for (int i = 0; i < nf; ++i) {
             float Ri[9], xi[3];
             ld9(W_RF, i, Ri);
@@ -633,15 +616,22 @@ struct SceneSim : Sim<M> {
                 ld9(st_ ? W_RS : W_RF, j, Rb_);
                 ld3(st_ ? W_XST : W_XF, j, xb_);
                 const float* hj = st_ ? SP.static_half[j] : SP.free_half[j];
-                if (scene_box_edge(Ri, xi, SP.free_half[i], Rb_, xb_, hj, P.contact_offset, &dist_, n_, pc_, &axes) != 2) continue;
-                const bool ref_a = axes >= 4;
+                const int kind = scene_box_edge(Ri, xi, SP.free_half[i], Rb_, xb_, hj, P.contact_offset, &dist_, n_, pc_, &axes);
+                if (kind == 0) continue;
                 const float mu_ = 0.5f * (SP.free_mu[i] + (st_ ? SP.static_mu[j] : SP.free_mu[j]));
-                const int fid0 = FID_FC + (i * NTGT + (st_ ? j : kSceneMaxStatic + j)) * 8;
+                const int pair = i * NTGT + (st_ ? j : kSceneMaxStatic + j);
+                if (kind == 1) {
+                    if (!(dist_ < P.contact_offset)) continue;
+                    if (nbox >= KBOX) { refused += 1; continue; }
+                    add_box_contact(i, st_ ? -1 : j, n_, pc_, dist_, mu_, FID_EE + pair * 9 + axes);
+                    continue;
+                }
+                const bool ref_a = axes >= 4;
                 auto emit = [&](const float* p, const float dist, const float* nr, const int cid) MI_LAMBDA {
                     if (!(dist < P.contact_offset)) return;
                     if (nbox >= KBOX) { refused += 1; return; }
                     const float n[3] = {ref_a ? -nr[0] : nr[0], ref_a ? -nr[1] : nr[1], ref_a ? -nr[2] : nr[2]};       // from B towards A
-                    add_box_contact(i, st_ ? -1 : j, n, p, dist, mu_, fid0 + cid);
+                    add_box_contact(i, st_ ? -1 : j, n, p, dist, mu_, FID_FC + pair * 8 + cid);
                 };
                 if (ref_a) scene_face_crossings(Ri, xi, SP.free_half[i], axes - 4, Rb_, xb_, hj, emit);
                 else scene_face_crossings(Rb_, xb_, hj, axes, Ri, xi, SP.free_half[i], emit);

@@ -3,6 +3,7 @@
 // reference amp/humanoid_amp_base.py:177).  gym.simulate with efforts and per-dof position drives, the rigid-body / Jacobian / mass-matrix tensors.
 // The one-wave sub-step in whichever row-store form the robot's size selects (core/engine.hpp: static rows in LDS, the compact store, or rows in
 // scratch) -- the limb-per-wave forms need role tables that are dealt per robot at build time.
+#include <cstdlib>
 #include "step_kernels.hpp"
 #include "arena_layout.hpp"
 #include "gen/model_articulation.h"
@@ -41,18 +42,22 @@ constexpr int SCENE_WARM = 4 * 48;
 constexpr int SCENE_ROWS = SceneRows<AM>::value;
 // (a robot with long kinematic chains has wider contact slots: the Kuka + Allegro's 23 dofs need 99 KB at 8 envs -- one workgroup per CU then; 4 envs per
 //  workgroup if even that does not fit)
-constexpr int SCENE_LANES = ((size_t)(SCENE_ROWS + SCENE_WARM) * 8 * sizeof(float) <= 160 * 1024) ? 8 : 4;
+constexpr int SCENE_LANES_MAX = ((size_t)(SCENE_ROWS + SCENE_WARM) * 8 * sizeof(float) <= 160 * 1024) ? 8 : 4;
+// Round 6: LANES envs per workgroup is a launch-time choice (scene_lanes below).  The wavefront walks data-dependent contact lists, so its time is that
+// of the env with the most work in every loop (per actor body: the most contacts on that body among its lanes), and a CU holds as many workgroups as
+// their LDS allows: fewer envs per wavefront means less of that divergence and more wavefronts per SIMD to switch between, until the batch fills the chip.
+template <int LANES>
 __global__ __launch_bounds__(64) void articulation_scene_substep_kernel(View v, SimParams P, ArticulationParams p) {
     extern __shared__ float lds_scene[];
-    const int e = blockIdx.x * SCENE_LANES + threadIdx.x;
+    const int e = blockIdx.x * LANES + threadIdx.x;
     if (e >= v.N) return;
     if constexpr (AM::FIXED == 1) {
         float* rows = lds_scene + threadIdx.x;
-        float* warm = lds_scene + SCENE_ROWS * SCENE_LANES + threadIdx.x;
+        float* warm = lds_scene + SCENE_ROWS * LANES + threadIdx.x;
         const int N = v.N;
-        for (int k = 0; k < SCENE_WARM; ++k) warm[k * SCENE_LANES] = v.scene_warm[(size_t)k * N + e];
-        articulation_scene_substep_env<AM>(v, P, p, e, RowStore<SCENE_LANES>{rows}, Strided{warm, SCENE_LANES});
-        for (int k = 0; k < SCENE_WARM; ++k) v.scene_warm[(size_t)k * N + e] = warm[k * SCENE_LANES];
+        for (int k = 0; k < SCENE_WARM; ++k) warm[k * LANES] = v.scene_warm[(size_t)k * N + e];
+        articulation_scene_substep_env<AM>(v, P, p, e, RowStore<LANES>{rows}, Strided{warm, LANES});
+        for (int k = 0; k < SCENE_WARM; ++k) v.scene_warm[(size_t)k * N + e] = warm[k * LANES];
     }
 }
 __global__ void articulation_reset_kernel(View v, ArticulationParams p, const long long* __restrict__ ids, int n) {
@@ -112,16 +117,33 @@ __global__ __launch_bounds__(64) void articulation_mass_matrix_kernel(View v, Si
     for (int k = 0; k < NV * NV; ++k) o[k] = H[k];
 }
 
+// envs per workgroup of the scene sub-step: MI_SCENE_LANES (1, 2, 4, 8: A/B runs) or by batch size
+static int scene_lanes(const int N) {
+    static const int forced = [] { const char* e = getenv("MI_SCENE_LANES"); return e ? atoi(e) : 0; }();
+    int lanes = forced > 0 ? forced : (N <= 2048 ? 1 : (N <= 4096 ? 2 : (N <= 8192 ? 4 : 8)));
+    if (lanes != 1 && lanes != 2 && lanes != 4 && lanes != 8) lanes = 8;
+    return lanes > SCENE_LANES_MAX ? SCENE_LANES_MAX : lanes;
+}
 hipError_t launch_simulate_articulation(const View& v, const SimParams& P, const ArticulationParams& p, hipStream_t s) {
     if (articulation_has_scene(p)) {
         if (AM::FIXED != 1) return hipErrorInvalidValue;
-        constexpr size_t lds = (size_t)(SCENE_ROWS + SCENE_WARM) * SCENE_LANES * sizeof(float);
-        static_assert(lds <= 160 * 1024, "the scene's row store of one workgroup fits the LDS of a CU (two workgroups per CU up to 80 KB: the Franka's 80.5 KB)");
-        static unsigned long long scene_configured = 0ull;
-        if (hipError_t e = ensure_dynamic_lds((const void*)articulation_scene_substep_kernel, lds, &scene_configured); e != hipSuccess) return e;
-        for (int i = 0; i < P.substeps; ++i)
-            hipLaunchKernelGGL(articulation_scene_substep_kernel, dim3((v.N + SCENE_LANES - 1) / SCENE_LANES), dim3(SCENE_LANES), lds, s, v, P, p);
-        return hipGetLastError();
+        static_assert((size_t)(SCENE_ROWS + SCENE_WARM) * SCENE_LANES_MAX * sizeof(float) <= 160 * 1024, "the scene's row store of one workgroup fits the LDS of a CU");
+        const int lanes = scene_lanes(v.N);
+        hipError_t err = hipSuccess;
+        sfor<4>([&](auto L_) {
+            constexpr int LANES = 1 << decltype(L_)::value;
+            if constexpr (LANES <= SCENE_LANES_MAX) {
+                if (lanes == LANES && err == hipSuccess) {
+                    constexpr size_t lds = (size_t)(SCENE_ROWS + SCENE_WARM) * LANES * sizeof(float);
+                    static unsigned long long scene_configured = 0ull;
+                    err = ensure_dynamic_lds((const void*)articulation_scene_substep_kernel<LANES>, lds, &scene_configured);
+                    if (err != hipSuccess) return;
+                    for (int i = 0; i < P.substeps; ++i)
+                        hipLaunchKernelGGL(articulation_scene_substep_kernel<LANES>, dim3((v.N + LANES - 1) / LANES), dim3(LANES), lds, s, v, P, p);
+                }
+            }
+        });
+        return err != hipSuccess ? err : hipGetLastError();
     }
     constexpr size_t lds = rows_fit_lds<AM>() ? lds_bytes<AM>() : 0;
     constexpr int LANES = Sim<AM>::LANES;

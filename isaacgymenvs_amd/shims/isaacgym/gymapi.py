@@ -36,6 +36,7 @@ UP_AXIS_Y, UP_AXIS_Z = 0, 1
 DOF_MODE_NONE, DOF_MODE_POS, DOF_MODE_VEL, DOF_MODE_EFFORT = 0, 1, 2, 3
 MESH_NONE, MESH_COLLISION, MESH_VISUAL, MESH_VISUAL_AND_COLLISION = 0, 1, 2, 3
 DOMAIN_SIM, DOMAIN_ENV, DOMAIN_ACTOR = 0, 1, 2
+INVALID_HANDLE = -1      # what the find_* calls return for an unknown name (trifinger.py:1146,1158 compare against it)
 ENV_SPACE, LOCAL_SPACE, GLOBAL_SPACE = 0, 1, 2
 KEY_ESCAPE, KEY_V, KEY_R = 256, 86, 82
 STATE_NONE, STATE_POS, STATE_VEL, STATE_ALL = 0, 1, 2, 3

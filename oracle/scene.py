@@ -299,36 +299,23 @@ class OracleSceneEngine:
                     contacts.append(dict(Jh=None, ia=j, ib=-1, fr=(n, t1, t2), pc=pc, vtn=vtarget(dist), mu=0.5 * (self.free[j]["mu"] + s_["mu"]),
                                          fid=("sc", t, cr, j)))
                     nbox += 1
-        # EDGE-EDGE: one contact per box pair whose least-penetration axis is the cross product of an edge of each (box_edge_contact below)
+        # per box pair: the EDGE-EDGE contact when the least-penetration axis is the cross product of an edge of each (box_edge_contact), else -- a face
+        # axis wins -- the points where the incident face's outline crosses the reference face's (box_face_crossings)
         for i in range(nf):
             others = [(("st", t), Rs[t], np.asarray(s_["pos"], float), s_["half"], s_["mu"], -1) for t, s_ in enumerate(self.static)]
             others += [(("fr", j), Rf[j], xf[j], self.free[j]["half"], self.free[j]["mu"], j) for j in range(i + 1, nf)]
             for tag, Rb, xb, hb, mub, ib in others:
                 hit = box_edge_contact(Rf[i], xf[i], self.free[i]["half"], Rb, xb, hb)
-                if hit is None or not hit[0] < P["contact_offset"]:
-                    continue
-                if nbox >= KBOX:
-                    refused += 1
-                    continue
-                dist, n, pc, ei, ej = hit
-                t1, t2 = contact_frame(n)
-                contacts.append(dict(Jh=None, ia=i, ib=ib, fr=(n, t1, t2), pc=pc, vtn=vtarget(dist), mu=0.5 * (self.free[i]["mu"] + mub),
-                                     fid=("ee", i, tag, ei, ej)))
-                nbox += 1
-        # FACE contacts: where the incident face's outline crosses the reference face's (box_face_crossings)
-        for i in range(nf):
-            others = [(("st", t), Rs[t], np.asarray(s_["pos"], float), s_["half"], s_["mu"], -1) for t, s_ in enumerate(self.static)]
-            others += [(("fr", j), Rf[j], xf[j], self.free[j]["half"], self.free[j]["mu"], j) for j in range(i + 1, nf)]
-            for tag, Rb, xb, hb, mub, ib in others:
-                for dist, n, pc, cid in box_face_crossings(Rf[i], xf[i], self.free[i]["half"], Rb, xb, hb):
+                found = [] if hit is None else [(hit[0], hit[1], hit[2], ("ee", i, tag, hit[3], hit[4]))]
+                found += [(d_, n_, p_, ("fc", i, tag, cid)) for d_, n_, p_, cid in box_face_crossings(Rf[i], xf[i], self.free[i]["half"], Rb, xb, hb)]
+                for dist, n, pc, fid in found:
                     if not dist < P["contact_offset"]:
                         continue
                     if nbox >= KBOX:
                         refused += 1
                         continue
                     t1, t2 = contact_frame(n)
-                    contacts.append(dict(Jh=None, ia=i, ib=ib, fr=(n, t1, t2), pc=pc, vtn=vtarget(dist), mu=0.5 * (self.free[i]["mu"] + mub),
-                                         fid=("fc", i, tag, cid)))
+                    contacts.append(dict(Jh=None, ia=i, ib=ib, fr=(n, t1, t2), pc=pc, vtn=vtarget(dist), mu=0.5 * (self.free[i]["mu"] + mub), fid=fid))
                     nbox += 1
         self.ncontacts[e] = narm + nbox
         self.refused[e] += refused

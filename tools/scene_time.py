@@ -29,6 +29,8 @@ for n in [int(a) for a in sys.argv[1:]] or [4096]:
     vt.EXISTING_SIM = None
     cfg = omegaconf_to_dict(compose("config", overrides=["task=FrankaCubeStack"], cfg_dir=os.path.join(REF, "isaacgymenvs", "cfg"))["task"])
     cfg["env"]["numEnvs"], cfg["sim"]["use_gpu_pipeline"] = n, dev != "cpu"
+    if os.environ.get("MI_SCENE_ITERS"):       # "pos,vel": how much of a sub-step its sweeps are (A/B of the solver iteration counts, timing only)
+        cfg["sim"]["physx"]["num_position_iterations"], cfg["sim"]["physx"]["num_velocity_iterations"] = [int(x) for x in os.environ["MI_SCENE_ITERS"].split(",")]
     env = task.FrankaCubeStack(cfg, rl_device=dev, sim_device=dev, graphics_device_id=-1, headless=True, virtual_screen_capture=False, force_render=False)
     acts = [2 * torch.rand((n, 7), device=dev) - 1 for _ in range(8)]
     for i in range(30):
