@@ -258,7 +258,10 @@ struct HandSimMW : HandSim<M> {
     // ------------------------------------------------------------------------------------------------ one role of a sub-step
     // target[ND]: drive targets; laml / sensor / dof_force: the own entries are read / written; ncontact: written by TRUNK_ROLE only
     // (contacts kept | refused for want of a slot << 16).  BAR: workgroup barrier (device: s_barrier; host tests: a thread barrier).
-    template <int R, int RS, int SHAPE, class BAR>
+    // PSENS false: the pairs' forces on the fingertip sensors are left out at COMPILE time -- the instantiation for every sub-step launch of a call
+    // but the last, whose sensor values are overwritten unseen (with the run-time flag alone the skipped launch cost as much as the other one:
+    // the code's presence, not its execution, is what the register allocation pays for; profiles/r6_hand_pair_sensors_ab.txt)
+    template <int R, int RS, int SHAPE, bool PSENS = true, class BAR = void>
     MI_HD void substep_hand_role(const SimParams& P, const ObjectParams& OP, const float* target, const float h, const RowStore<RS> rows,
                                  const Strided laml, const Strided sensor, const Strided dof_force, int* ncontact, const BAR& bar) {
         constexpr int ST = RowStore<RS>::stride;
@@ -410,12 +413,12 @@ struct HandSimMW : HandSim<M> {
                             const float pe = on ? pen : 0.f;
                             if constexpr (mine_a) {
                                 this->template pair_side<ba>(pc, n, pe, h, S, L, y); npa += on ? 1 : 0;
-                                if constexpr (HB::pair_sensor_body(ba)) { if (this->pair_sens) this->pair_sensor_acc(pc, n, pe, h, psA[HB::sensor_of(ba)]); }
+                                if constexpr (PSENS && HB::pair_sensor_body(ba)) { if (this->pair_sens) this->pair_sensor_acc(pc, n, pe, h, psA[HB::sensor_of(ba)]); }
                             }
                             if constexpr (mine_b) {
                                 const float nm[3] = {-n[0], -n[1], -n[2]};
                                 this->template pair_side<bb>(pc, nm, pe, h, S, L, y); npa += on ? 1 : 0;
-                                if constexpr (HB::pair_sensor_body(bb)) { if (this->pair_sens) this->pair_sensor_acc(pc, nm, pe, h, psA[HB::sensor_of(bb)]); }
+                                if constexpr (PSENS && HB::pair_sensor_body(bb)) { if (this->pair_sens) this->pair_sensor_acc(pc, nm, pe, h, psA[HB::sensor_of(bb)]); }
                             }
                         }
                     }
@@ -424,7 +427,7 @@ struct HandSimMW : HandSim<M> {
                 // the six numbers of A wait in the fingertip's own slots of the `sensor` tensor (this lane rewrites them in the output phase; a load after
                 // the own store of the same address sees it): carried in registers through the contact phases and the sweeps they cost 4 % of the step
                 // (ShadowHand@16384 0.1857 -> 0.1933 ms, profiles/r6_hand_pair_sensors_ab.txt); P and n stay
-                if (this->pair_sens) sfor<NSENS>([&](auto K_) MI_LAMBDA {
+                if constexpr (PSENS) if (this->pair_sens) sfor<NSENS>([&](auto K_) MI_LAMBDA {
                     if constexpr (role_of_body_h(M::sens_body[K_]) == R && HB::pair_sensor_body(M::sens_body[K_])) {
                         psPN[K_][0] = psA[K_][6]; psPN[K_][1] = psA[K_][7];
                         this->template pair_sensor_g<M::sens_body[K_]>(psA[K_], S, psG[K_]);
@@ -796,7 +799,7 @@ struct HandSimMW : HandSim<M> {
                         }
                     }
                 }
-                if constexpr (NHP > 0 && HB::pair_sensor_body(b)) {
+                if constexpr (NHP > 0 && PSENS && HB::pair_sensor_body(b)) {
                     if (MI_WAVE_ANY(psPN[k][0] > 0.f)) {       // the hand's own contacts on this fingertip (core/hand_engine.hpp pair_sensor_wrench)
                         const float (&Rb)[9] = c.Rs[k];
                         const float (&rb)[3] = c.rs[k];

@@ -29,6 +29,12 @@
 #pragma once
 #include "engine.hpp"
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MI_OPAQUE_VI(x) asm volatile("" : "+v"(x))          // a per-lane integer the optimiser cannot see through
+#else
+#define MI_OPAQUE_VI(x) do { } while (0)
+#endif
+
 namespace mi {
 
 constexpr int kSceneMaxFree = 4, kSceneMaxStatic = 4;
@@ -220,25 +226,35 @@ struct SceneSim : Sim<M> {
     static constexpr int NB = M::NB, ND = M::ND, NV = M::NV, OFF = M::OFF, NSPH = M::NSPH, NSENS = M::NSENS, NLIM = B::NLIM, NVA = B::NVA;
     static_assert(M::FIXED == 1, "SceneSim: a fixed-base actor (the scene's free bodies are boxes)");
     static constexpr int KARM = 24, KBOX = 24;              // contact slots: actor spheres, box corners
-    static constexpr int HCH = M::MAXCHAIN;
+    // the chain part of an actor contact's rows is stored DENSE over the actor's coordinates (zeros off the body's chain): the sweeps then visit the
+    // actor slots in ONE loop with one copy of the contact code.  (Until round 6 the rows were packed along the body's chain and the sweeps went body
+    // by body, each with its own unrolled copy of the contact code: a wavefront walked through all of those copies in every sweep -- the code of a
+    // 10-body arm's sweep loop alone outgrew the instruction cache -- and ran every body's loop to the largest count among its lanes.)
+    static constexpr int HCH = NV;
     // one contact slot: 3 rows over the actor chain (zero for box contacts) | normal n (3), contact point pc rel. O (3) |
     // Ainv x3, vt_n, lam x3, mu, side A's free box (int bits; -1: the actor / nobody), side B's free box (-1: static)
     // ... | feature id (int bits, > 0)
     static constexpr int S_GEO = 3 * HCH, S_AUX = S_GEO + 6, S_CSZ = S_AUX + 11;
     static constexpr int KSLOT = KARM + KBOX;              // entries of the warm-start tensor: (feature, lam_n, lam_t1, lam_t2) per slot
     static constexpr int NTGT = kSceneMaxFree + kSceneMaxStatic;
+    static_assert(kSceneMaxFree * NTGT <= 32, "the box pairs' broad-phase mask is one word");
     static_assert(KSLOT == 48, "tensor scene_warm holds MI_SCENE_WARM_SLOTS = 48 entries per env (include/mi_engine.h; checked against it in tasks/articulation.hpp)");
     static constexpr int R_LIMG = B::limoff(NLIM);
     static constexpr int R_CB = R_LIMG + 3 * NLIM;          // limit G | Ainv, vt, lam | contact slots
-    static constexpr int R_BODY = R_CB + (KARM + KBOX) * S_CSZ;     // per actor body: first slot | count << 8
+    // a box contact's rows span no actor coordinate: its slot is the geometry + scalars only (S_BSZ floats), addressed through a pointer S_GEO floats
+    // before it so that both kinds of slot use the same field offsets (without this the dense rows' 144 more floats per env took the Franka's
+    // workgroup from 80 to 86 KB of LDS: one workgroup per CU instead of two, 0.88 -> 1.31 ms per gym.simulate() at 4096 envs)
+    static constexpr int S_BSZ = S_CSZ - S_GEO, R_BX = R_CB + KARM * S_CSZ - S_GEO;
+    static constexpr int R_BODY = R_CB + KARM * S_CSZ + KBOX * S_BSZ;     // per actor body: first slot | count << 8
     // work area behind the slots: what the narrow phase and the sweeps index with a RUN-TIME box number -- the boxes' velocities (lin, ang), centres
-    // rel. O, world inverse inertias, inverse masses, rotations; the static boxes' rotations and centres; the actor's sphere centres.  In the row store
+    // rel. O, world inverse inertias, inverse masses, rotations; the static boxes' rotations and centres; every box's half sizes (round 6: a pointer into the kernel's parameter struct selected at run
+    // time made the compiler copy the whole struct into scratch memory, 416 -> 1392 B per lane); the actor's sphere centres.  In the row store
     // (LDS on the device) because a per-lane array indexed at run time lives in scratch memory, and the sweeps read every velocity right after the
     // previous row wrote it: with the boxes in scratch each of those ~10^4 read-after-write pairs per sub-step was a round trip to memory (1.7 ms
     // per sub-step at ANY batch size; profiles/r5t_scene_time.txt)
     static constexpr int W_VB = R_BODY + NB, W_XF = W_VB + 6 * kSceneMaxFree, W_IINV = W_XF + 3 * kSceneMaxFree, W_IM = W_IINV + 9 * kSceneMaxFree,
                          W_RF = W_IM + kSceneMaxFree, W_RS = W_RF + 9 * kSceneMaxFree, W_XST = W_RS + 9 * kSceneMaxStatic,
-                         W_XS = W_XST + 3 * kSceneMaxStatic;
+                         W_HF = W_XST + 3 * kSceneMaxStatic, W_HS = W_HF + 3 * kSceneMaxFree, W_XS = W_HS + 3 * kSceneMaxStatic;
     static constexpr int ROW_SLOTS = W_XS + 3 * M::NSPHA;
 
     float box[kSceneMaxFree][13];                           // free boxes: pos3, quat xyzw, linvel3, angvel3 (world)
@@ -257,7 +273,7 @@ struct SceneSim : Sim<M> {
     template <int RS>
     MI_HD void substep_scene(const SimParams& P, const SceneParams& SP, const float* tau, const Drive& drv, const float h, const RowStore<RS> rows,
                              const Strided laml, const Strided dof_force, int* ncontact, const Strided warm = Strided{nullptr, 1},
-                             const float* vmax = nullptr) {
+                             const float* vmax = nullptr, const Strided netf = Strided{nullptr, 1}) {
         constexpr int ST = RowStore<RS>::stride;
         float (&q)[M::NDA] = this->q;
         float (&qd)[M::NDA] = this->qd;
@@ -338,6 +354,7 @@ struct SceneSim : Sim<M> {
             });
             sfor<9>([&](auto K) MI_LAMBDA { W(W_RF, 9 * i + K) = R[K]; });
             W(W_IM, i) = MI_RCP(SP.free_mass[i]);
+            sfor<3>([&](auto K) MI_LAMBDA { W(W_HF, 3 * i + K) = SP.free_half[i][K]; });
             const float id[3] = {MI_RCP(SP.free_inertia[i][0]), MI_RCP(SP.free_inertia[i][1]), MI_RCP(SP.free_inertia[i][2])};
             sfor<3>([&](auto R_) MI_LAMBDA {
                 sfor<3>([&](auto C_) MI_LAMBDA {
@@ -350,7 +367,7 @@ struct SceneSim : Sim<M> {
             float R[9];
             quat2mat(SP.static_quat[i], R);
             sfor<9>([&](auto K) MI_LAMBDA { W(W_RS, 9 * i + K) = R[K]; });
-            sfor<3>([&](auto K) MI_LAMBDA { W(W_XST, 3 * i + K) = SP.static_pos[i][K] - root[K]; });
+            sfor<3>([&](auto K) MI_LAMBDA { W(W_XST, 3 * i + K) = SP.static_pos[i][K] - root[K]; W(W_HS, 3 * i + K) = SP.static_half[i][K]; });
         }
         MI_PHASE();
         // ------------------------------------------------------------ joint limit rows (as core/engine.hpp)
@@ -400,8 +417,15 @@ struct SceneSim : Sim<M> {
         auto warm_lookup = [&](int fid, float* l0, int k0, int k1) MI_LAMBDA {
             l0[0] = l0[1] = l0[2] = 0.f;
             if (warm.p == nullptr) return;
+            // (a region's used entries come first, the others carry feature 0: a lane's search is over at the first of those or at its match; the
+            //  loop ends when every lane's is -- a wave-uniform exit: per-lane `break`s in this loop, inlined at five places, cost 1400 spilled SGPRs)
+            bool open_ = true;
             for (int k = k0; k < k1; ++k) {
-                if (__builtin_bit_cast(int, warm(4 * k)) == fid) { l0[0] = warm(4 * k + 1) * P.warm; l0[1] = warm(4 * k + 2) * P.warm; l0[2] = warm(4 * k + 3) * P.warm; }
+                if (!MI_WAVE_ANY(open_)) break;
+                const int f = __builtin_bit_cast(int, warm(4 * k));
+                const bool hit = open_ && (f == fid);
+                if (hit) { l0[0] = warm(4 * k + 1) * P.warm; l0[1] = warm(4 * k + 2) * P.warm; l0[2] = warm(4 * k + 3) * P.warm; }
+                open_ = open_ && (f != 0) && !hit;
             }
         };
         auto target_velocity = [&](float dist) MI_LAMBDA -> float {
@@ -416,6 +440,38 @@ struct SceneSim : Sim<M> {
                 constexpr int CL = M::chain_len[b], S0 = sph_first(b), SN = sph_count(b);
                 MI_PHASE();
                 const int first = cnt;
+                // broad phase (round 6): the targets the body's bounding sphere (around the box of its collision spheres) reaches.  Conservative -- the
+                // signed distance to a box is 1-Lipschitz, so a culled (body, target) has no sphere within contact_offset of it --: the contacts
+                // and their order are what they were; most links of an arm are nowhere near a cube or the table
+                int tmask = 0;
+                {
+                    float lo[3], hi[3];
+                    sfor<3>([&](auto K) MI_LAMBDA { lo[K] = 1e30f; hi[K] = -1e30f; });
+                    for (int si = 0; si < SN; ++si) {
+                        const float rad = M::sph_rad[S0 + si];
+                        float cs[3];
+                        ld3(W_XS, S0 + si, cs);
+                        sfor<3>([&](auto K) MI_LAMBDA { lo[K] = fminf(lo[K], cs[K] - rad); hi[K] = fmaxf(hi[K], cs[K] + rad); });
+                    }
+                    const float cb3[3] = {0.5f * (lo[0] + hi[0]), 0.5f * (lo[1] + hi[1]), 0.5f * (lo[2] + hi[2])};
+                    const float hd[3] = {0.5f * (hi[0] - lo[0]), 0.5f * (hi[1] - lo[1]), 0.5f * (hi[2] - lo[2])};
+                    const float rbound = MI_SQRT(dot3(hd, hd));
+                    for (int t = 0; t < nf + ns; ++t) {
+                        const bool fr_ = t < nf;
+                        const int ib = fr_ ? t : t - nf;
+                        if (CL == 0 && !fr_) continue;
+                        float Rb_[9], xb_[3], cl[3], nl[3], dist;
+                        ld9(fr_ ? W_RF : W_RS, ib, Rb_);
+                        ld3(fr_ ? W_XF : W_XST, ib, xb_);
+                        const float rel[3] = {cb3[0] - xb_[0], cb3[1] - xb_[1], cb3[2] - xb_[2]};
+                        matTvec3(Rb_, rel, cl);
+                        float hb_[3];
+                        ld3(fr_ ? W_HF : W_HS, ib, hb_);
+                        scene_sphere_box(cl, rbound, hb_, &dist, nl);
+                        tmask |= (dist < P.contact_offset + 1e-4f) ? (1 << t) : 0;
+                    }
+                }
+                if (MI_WAVE_ANY(tmask != 0))
                 for (int si = 0; si < SN; ++si) {
                     const int s = S0 + si;
                     const float rad = M::sph_rad[s];
@@ -427,10 +483,12 @@ struct SceneSim : Sim<M> {
                         // a body that no dof moves (the fixed base link) against a static box: the row would act on nothing (a = cfm only) and only
                         // take one of the KARM slots from a finger or a cube
                         if (CL == 0 && !fr_) continue;
+                        if (!((tmask >> t) & 1)) continue;
                         float Rb_[9], xb_[3];
                         ld9(fr_ ? W_RF : W_RS, ib, Rb_);
                         ld3(fr_ ? W_XF : W_XST, ib, xb_);
-                        const float* hb_ = fr_ ? SP.free_half[ib] : SP.static_half[ib];
+                        float hb_[3];
+                        ld3(fr_ ? W_HF : W_HS, ib, hb_);
                         const float rel[3] = {cs[0] - xb_[0], cs[1] - xb_[1], cs[2] - xb_[2]};
                         float cl[3], nl[3], dist;
                         matTvec3(Rb_, rel, cl);
@@ -451,7 +509,7 @@ struct SceneSim : Sim<M> {
                             float W[6];
                             cross3(pc, fr[k], W);
                             W[3] = fr[k][0]; W[4] = fr[k][1]; W[5] = fr[k][2];
-                            float g[HCH];
+                            float g[M::MAXCHAIN];
                             sfor<CL>([&](auto C) MI_LAMBDA { g[C] = dot6(S[M::chain[b][C] - OFF], W); });
                             sfor<CL>([&](auto C) MI_LAMBDA {
                                 constexpr int kk0 = C, ii = M::chain[b][kk0];
@@ -463,8 +521,8 @@ struct SceneSim : Sim<M> {
                                 });
                             });
                             float a = P.cfm;
-                            sfor<CL>([&](auto C) MI_LAMBDA { a += g[C] * g[C]; cb[(k * HCH + C) * ST] = g[C]; });
-                            sfor<HCH - CL>([&](auto C) MI_LAMBDA { cb[(k * HCH + CL + C) * ST] = 0.f; });
+                            sfor<HCH>([&](auto C) MI_LAMBDA { cb[(k * HCH + C) * ST] = 0.f; });
+                            sfor<CL>([&](auto C) MI_LAMBDA { a += g[C] * g[C]; cb[(k * HCH + M::chain[b][C]) * ST] = g[C]; });
                             if (fr_) a += box_diag(ib, rB, fr[k]);
                             cb[(S_AUX + k) * ST] = MI_RCP(a);
                             cb[(S_AUX + 4 + k) * ST] = l0[k];
@@ -486,18 +544,42 @@ struct SceneSim : Sim<M> {
         // ------------------------------------------------------------ box contacts: the corners of every free box vs the ground plane, the
         // static boxes, the other free boxes (side A: the corner's box, pushed along n; side B: the box it is in / on)
         int nbox = 0;
+        // broad phase of the box pairs (round 6): bit (i * NTGT + t) -- free box i and target t (static boxes first, then the free ones) -- is set when
+        // their bounding spheres come within contact_offset; the corner, edge and outline tests below skip the other pairs (conservative: same contacts)
+        unsigned pmask = 0u;
+        for (int i = 0; i < nf; ++i) {
+            float xi[3];
+            ld3(W_XF, i, xi);
+            float hi_[3];
+            ld3(W_HF, i, hi_);
+            const float ri = MI_SQRT(dot3(hi_, hi_));
+            for (int t = 0; t < ns + nf; ++t) {
+                const bool st_ = t < ns;
+                const int j = st_ ? t : t - ns;
+                if (!st_ && j == i) continue;
+                float xj[3];
+                ld3(st_ ? W_XST : W_XF, j, xj);
+                float hj[3];
+                ld3(st_ ? W_HS : W_HF, j, hj);
+                const float d[3] = {xi[0] - xj[0], xi[1] - xj[1], xi[2] - xj[2]};
+                const float reach = ri + MI_SQRT(dot3(hj, hj)) + P.contact_offset + 1e-4f;
+                pmask |= (dot3(d, d) < reach * reach) ? (1u << (i * NTGT + t)) : 0u;
+            }
+        }
         for (int i = 0; i < nf; ++i) {
             float Ri[9], xi[3];
             ld9(W_RF, i, Ri);
             ld3(W_XF, i, xi);
+            float hi_[3];
+            ld3(W_HF, i, hi_);
             for (int cr = 0; cr < 8; ++cr) {
-                const float pl[3] = {(cr & 1) ? SP.free_half[i][0] : -SP.free_half[i][0], (cr & 2) ? SP.free_half[i][1] : -SP.free_half[i][1],
-                                     (cr & 4) ? SP.free_half[i][2] : -SP.free_half[i][2]};
+                const float pl[3] = {(cr & 1) ? hi_[0] : -hi_[0], (cr & 2) ? hi_[1] : -hi_[1], (cr & 4) ? hi_[2] : -hi_[2]};
                 float pr[3], pc[3];
                 matvec3(Ri, pl, pr);
                 sfor<3>([&](auto K) MI_LAMBDA { pc[K] = xi[K] + pr[K]; });
                 for (int t = -1; t < ns + nf; ++t) {
                     if (t >= ns && t - ns == i) continue;
+                    if (t >= 0 && !((pmask >> (i * NTGT + t)) & 1u)) continue;
                     float n[3], dist, mu_b;
                     int ib = -1;
                     if (t < 0) {
@@ -510,7 +592,8 @@ struct SceneSim : Sim<M> {
                         float Rb_[9], xb_[3];
                         ld9(st_ ? W_RS : W_RF, j, Rb_);
                         ld3(st_ ? W_XST : W_XF, j, xb_);
-                        const float* hb_ = st_ ? SP.static_half[j] : SP.free_half[j];
+                        float hb_[3];
+                        ld3(st_ ? W_HS : W_HF, j, hb_);
                         const float rel[3] = {pc[0] - xb_[0], pc[1] - xb_[1], pc[2] - xb_[2]};
                         float cl[3], nl[3];
                         matTvec3(Rb_, rel, cl);
@@ -524,7 +607,7 @@ struct SceneSim : Sim<M> {
                     float fr[3][3];
                     sfor<3>([&](auto K) MI_LAMBDA { fr[0][K] = n[K]; });
                     contact_frame(fr[0], fr[1], fr[2]);
-                    float* cb = rows.ptr(R_CB + (KARM + nbox) * S_CSZ);
+                    float* cb = rows.ptr(R_BX + nbox * S_BSZ);
                     float rB[3] = {0.f, 0.f, 0.f};
                     const int fid = 1 + NSPH * NTGT + (i * 8 + cr) * (NTGT + 1) + (t + 1);
                     float l0[3];
@@ -552,7 +635,7 @@ struct SceneSim : Sim<M> {
             float fr[3][3];
             sfor<3>([&](auto K) MI_LAMBDA { fr[0][K] = n[K]; });
             contact_frame(fr[0], fr[1], fr[2]);
-            float* cb = rows.ptr(R_CB + (KARM + nbox) * S_CSZ);
+            float* cb = rows.ptr(R_BX + nbox * S_BSZ);
             float rA[3], rB[3] = {0.f, 0.f, 0.f}, l0[3];
             warm_lookup(fid, l0, KARM, KSLOT);
             sfor<3>([&](auto K) MI_LAMBDA { rA[K] = pc[K] - W(W_XF, 3 * ia + K); });
@@ -580,19 +663,23 @@ struct SceneSim : Sim<M> {
             float Rt[9], xt[3];
             ld9(W_RS, t, Rt);
             ld3(W_XST, t, xt);
+            float ht_[3];
+            ld3(W_HS, t, ht_);
             for (int cr = 0; cr < 8; ++cr) {
-                const float pl[3] = {(cr & 1) ? SP.static_half[t][0] : -SP.static_half[t][0], (cr & 2) ? SP.static_half[t][1] : -SP.static_half[t][1],
-                                     (cr & 4) ? SP.static_half[t][2] : -SP.static_half[t][2]};
+                const float pl[3] = {(cr & 1) ? ht_[0] : -ht_[0], (cr & 2) ? ht_[1] : -ht_[1], (cr & 4) ? ht_[2] : -ht_[2]};
                 float pr[3], pc[3];
                 matvec3(Rt, pl, pr);
                 sfor<3>([&](auto K) MI_LAMBDA { pc[K] = xt[K] + pr[K]; });
                 for (int j = 0; j < nf; ++j) {
+                    if (!((pmask >> (j * NTGT + t)) & 1u)) continue;
                     float Rb_[9], xb_[3], cl[3], nl[3], n[3], dist;
                     ld9(W_RF, j, Rb_);
                     ld3(W_XF, j, xb_);
                     const float rel[3] = {pc[0] - xb_[0], pc[1] - xb_[1], pc[2] - xb_[2]};
                     matTvec3(Rb_, rel, cl);
-                    scene_sphere_box(cl, 0.f, SP.free_half[j], &dist, nl);
+                    float hj_[3];
+                    ld3(W_HF, j, hj_);
+                    scene_sphere_box(cl, 0.f, hj_, &dist, nl);
                     if (!(dist < P.contact_offset)) continue;
                     if (nbox >= KBOX) { refused += 1; continue; }
                     matvec3(Rb_, nl, n);
@@ -605,18 +692,21 @@ struct SceneSim : Sim<M> {
         // contact when the least-penetration axis is the cross product of an edge of each (scene_box_edge) --, or, when a face axis wins, the points
         // where the incident face's outline crosses the reference face's (scene_face_crossings)
         for (int i = 0; i < nf; ++i) {
-            float Ri[9], xi[3];
+            float Ri[9], xi[3], hi_[3];
             ld9(W_RF, i, Ri);
             ld3(W_XF, i, xi);
+            ld3(W_HF, i, hi_);
             for (int t = 0; t < ns + nf - 1 - i; ++t) {
                 const bool st_ = t < ns;
                 const int j = st_ ? t : i + 1 + (t - ns);
+                if (!((pmask >> (i * NTGT + (st_ ? j : ns + j))) & 1u)) continue;
                 float Rb_[9], xb_[3], n_[3], pc_[3], dist_;
                 int axes;
                 ld9(st_ ? W_RS : W_RF, j, Rb_);
                 ld3(st_ ? W_XST : W_XF, j, xb_);
-                const float* hj = st_ ? SP.static_half[j] : SP.free_half[j];
-                const int kind = scene_box_edge(Ri, xi, SP.free_half[i], Rb_, xb_, hj, P.contact_offset, &dist_, n_, pc_, &axes);
+                float hj[3];
+                ld3(st_ ? W_HS : W_HF, j, hj);
+                const int kind = scene_box_edge(Ri, xi, hi_, Rb_, xb_, hj, P.contact_offset, &dist_, n_, pc_, &axes);
                 if (kind == 0) continue;
                 const float mu_ = 0.5f * (SP.free_mu[i] + (st_ ? SP.static_mu[j] : SP.free_mu[j]));
                 const int pair = i * NTGT + (st_ ? j : kSceneMaxStatic + j);
@@ -633,19 +723,19 @@ struct SceneSim : Sim<M> {
                     const float n[3] = {ref_a ? -nr[0] : nr[0], ref_a ? -nr[1] : nr[1], ref_a ? -nr[2] : nr[2]};       // from B towards A
                     add_box_contact(i, st_ ? -1 : j, n, p, dist, mu_, FID_FC + pair * 8 + cid);
                 };
-                if (ref_a) scene_face_crossings(Ri, xi, SP.free_half[i], axes - 4, Rb_, xb_, hj, emit);
-                else scene_face_crossings(Rb_, xb_, hj, axes, Ri, xi, SP.free_half[i], emit);
+                if (ref_a) scene_face_crossings(Ri, xi, hi_, axes - 4, Rb_, xb_, hj, emit);
+                else scene_face_crossings(Rb_, xb_, hj, axes, Ri, xi, hi_, emit);
             }
         }
         *ncontact = (narm + nbox) | (refused << 16);
         MI_PHASE();
         // ------------------------------------------------------------ projected Gauss-Seidel sweeps: limits, actor contacts, box contacts
-        // one contact: the normal row, the two tangent rows, then the friction disc (the order of core/hand_engine.hpp).  Btag: the actor body
-        // whose chain the rows span, or -1 for a box contact
+        // one contact: the normal row, the two tangent rows, then the friction disc (the order of core/hand_engine.hpp).  Btag: 0 for an actor
+        // contact, -1 for a box contact
         // `first` (the first sweep): the slot's impulses are last sub-step's and have not acted yet -- they are applied before the contact is solved
         auto solve_contact = [&](auto Btag, float* cb, const bool first) MI_LAMBDA {
-            constexpr int b = decltype(Btag)::value;
-            constexpr int CL = b >= 0 ? M::chain_len[b >= 0 ? b : 0] : 0;
+            constexpr int b = decltype(Btag)::value;                        // 0: an actor contact (rows over the actor's coordinates), -1: a box contact
+            constexpr int CL = b >= 0 ? HCH : 0;
             float g[3][HCH > 0 ? HCH : 1], ainv[3], lm[3], fr[3][3], pc[3];
             sfor<3>([&](auto K) MI_LAMBDA {
                 sfor<CL>([&](auto C) MI_LAMBDA { g[K][C] = cb[(K * HCH + C) * ST]; });
@@ -665,13 +755,13 @@ struct SceneSim : Sim<M> {
             if (ib >= 0) { sfor<6>([&](auto K) MI_LAMBDA { vB[K] = W(W_VB, 6 * ib + K); }); ld9(W_IINV, ib, IB); imB = W(W_IM, ib); }
             auto rowvel = [&](int k) MI_LAMBDA {
                 float vn = 0.f;
-                if constexpr (b >= 0) sfor<CL>([&](auto C) MI_LAMBDA { vn += g[k][C] * w[M::chain[b >= 0 ? b : 0][C]]; });
+                if constexpr (b >= 0) sfor<CL>([&](auto C) MI_LAMBDA { vn += g[k][C] * w[C]; });
                 if (ia >= 0) { float rx[3]; cross3(rA, fr[k], rx); vn += dot3(fr[k], vA) + dot3(rx, vA + 3); }
                 if (ib >= 0) { float rx[3]; cross3(rB, fr[k], rx); vn -= dot3(fr[k], vB) + dot3(rx, vB + 3); }
                 return vn;
             };
             auto apply = [&](int k, float dl) MI_LAMBDA {
-                if constexpr (b >= 0) sfor<CL>([&](auto C) MI_LAMBDA { w[M::chain[b >= 0 ? b : 0][C]] += g[k][C] * dl; });
+                if constexpr (b >= 0) sfor<CL>([&](auto C) MI_LAMBDA { w[C] += g[k][C] * dl; });
                 if (ia >= 0) {
                     float rx[3], t[3];
                     cross3(rA, fr[k], rx); matvec3(IA, rx, t);
@@ -724,15 +814,10 @@ struct SceneSim : Sim<M> {
                     sfor<M::nanc[gi]>([&](auto A_) MI_LAMBDA { w[M::anc[gi][A_]] += g[1 + A_] * dl; });
                 }
             });
-            sfor<NB>([&](auto B_) MI_LAMBDA {
-                constexpr int b = B_;
-                if constexpr (sph_count(b) > 0) {
-                    const int fc = __builtin_bit_cast(int, rit(R_BODY + b));
-                    const int first = fc & 255, nb_ = fc >> 8;
-                    for (int i = 0; i < nb_; ++i) solve_contact(std::integral_constant<int, b>{}, rit.ptr(R_CB + (first + i) * S_CSZ), it == 0);
-                }
-            });
-            for (int i = 0; i < nbox; ++i) solve_contact(std::integral_constant<int, -1>{}, rit.ptr(R_CB + (KARM + i) * S_CSZ), it == 0);
+            // (the slot number is laundered through a register: with a visible induction variable the loop optimiser gives every one of the
+            //  contact's ~100 row-store accesses a strength-reduced address of its own and spills 1400 SGPRs)
+            for (int i = 0; i < narm; ++i) { int ii = i; MI_OPAQUE_VI(ii); solve_contact(std::integral_constant<int, 0>{}, rit.ptr(R_CB + ii * S_CSZ), it == 0); }
+            for (int i = 0; i < nbox; ++i) { int ii = i; MI_OPAQUE_VI(ii); solve_contact(std::integral_constant<int, -1>{}, rit.ptr(R_BX + ii * S_BSZ), it == 0); }
         }
         MI_PHASE();
         // ------------------------------------------------------------ back to generalised velocity, outputs
@@ -755,10 +840,32 @@ struct SceneSim : Sim<M> {
             dof_force(d) = tau[d] - M::dof_stiffness[d] * (q[d] - M::dof_springref[d]) - M::dof_damping[d] * v[OFF + d] + ll * invh
                            + drv.gain_p(d) * (drv.target[d] - q[d]) - drv.gain_d(d) * v[OFF + d];
         });
+        // gym's net contact force tensor, the actor's rows [NB][3]: per actor body the sum of its contacts' forces (world frame, this sub-step)
+        if (netf.p != nullptr) {
+            sfor<NB>([&](auto B_) MI_LAMBDA {
+                constexpr int b = B_;
+                float f[3] = {0.f, 0.f, 0.f};
+                if constexpr (sph_count(b) > 0) {
+                    const int fc = __builtin_bit_cast(int, rows(R_BODY + b));
+                    const int first = fc & 255, nb_ = fc >> 8;
+                    for (int i = 0; i < nb_; ++i) {
+                        const float* cb = rows.ptr(R_CB + (first + i) * S_CSZ);
+                        float fr[3][3];
+                        sfor<3>([&](auto I_) MI_LAMBDA { fr[0][I_] = cb[(S_GEO + I_) * ST]; });
+                        contact_frame(fr[0], fr[1], fr[2]);
+                        sfor<3>([&](auto K) MI_LAMBDA {
+                            const float l_ = cb[(S_AUX + 4 + K) * ST] * invh;
+                            sfor<3>([&](auto C) MI_LAMBDA { f[C] += fr[K][C] * l_; });
+                        });
+                    }
+                }
+                sfor<3>([&](auto C) MI_LAMBDA { netf(3 * b + C) = f[C]; });
+            });
+        }
         if (warm.p != nullptr) {
             for (int k = 0; k < KSLOT; ++k) {
                 const bool used = (k < KARM) ? (k < narm) : (k - KARM < nbox);
-                const float* cb = rows.ptr(R_CB + k * S_CSZ);
+                const float* cb = (k < KARM) ? rows.ptr(R_CB + k * S_CSZ) : rows.ptr(R_BX + (k - KARM) * S_BSZ);
                 warm(4 * k) = used ? cb[(S_AUX + 10) * ST] : 0.f;
                 sfor<3>([&](auto J) MI_LAMBDA { warm(4 * k + 1 + J) = used ? cb[(S_AUX + 4 + J) * ST] : 0.f; });
             }

@@ -21,7 +21,7 @@ constexpr size_t hand_mw_lds_bytes() { return (size_t)HandSimMW<typename HT::M>:
 __device__ unsigned long long* g_mi_tstamp_hmw = nullptr;     // debug builds: per workgroup and role 16 s_memtime stamps
 #endif
 
-template <class HT, int SHAPE, int E, int R>
+template <class HT, int SHAPE, int E, int R, bool PSENS = true>
 __device__ __forceinline__ void hand_mw_role(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, float* lds_rows,
                                              const int e, const int lane) {
     using HM = typename HT::M;
@@ -63,7 +63,7 @@ __device__ __forceinline__ void hand_mw_role(const View& v, const HandView& hv, 
 #endif
     const float h = P.dt / (float)P.substeps;
     int nc = 0;
-    sim.template substep_hand_role<R, E, SHAPE>(P, OP, target, h, RowStore<E>{lds_rows + lane}, Strided{v.laml + e, N},
+    sim.template substep_hand_role<R, E, SHAPE, PSENS>(P, OP, target, h, RowStore<E>{lds_rows + lane}, Strided{v.laml + e, N},
                                                          Strided{v.sensor + e, N}, Strided{v.dof_force + e, N}, &nc, DevBarrier{});
     sfor<ND>([&](auto K) MI_LAMBDA {
         if constexpr (MW::template owns_gi<R>(K)) { v.dof[K * N + e] = sim.q[K]; v.dof[(ND + K) * N + e] = sim.qd[K]; }
@@ -86,7 +86,7 @@ struct HandMwArgs {
     SimParams P;
     HandParams p;
 };
-template <class HT, int SHAPE, int E>
+template <class HT, int SHAPE, int E, bool PSENS = true>
 __device__ __forceinline__ void hand_mw_body(float* lds_rows) {
     static_assert(HT::M::NROLE == 4, "four roles, one per SIMD of a CU");
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -97,13 +97,13 @@ __device__ __forceinline__ void hand_mw_body(float* lds_rows) {
     if (e >= a.v.N) return;                 // all four waves hold the same envs and agree on this
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.y);
 #if defined(MI_HMW_ONLY_ROLE)     // tools/debug only: resource usage of one role's instruction stream
-    if (role == MI_HMW_ONLY_ROLE) hand_mw_role<HT, SHAPE, E, MI_HMW_ONLY_ROLE>(a.v, a.hv, a.P, a.p, lds_rows, e, lane);
+    if (role == MI_HMW_ONLY_ROLE) hand_mw_role<HT, SHAPE, E, MI_HMW_ONLY_ROLE, PSENS>(a.v, a.hv, a.P, a.p, lds_rows, e, lane);
 #else
     switch (role) {
-        case 0: hand_mw_role<HT, SHAPE, E, 0>(a.v, a.hv, a.P, a.p, lds_rows, e, lane); break;
-        case 1: hand_mw_role<HT, SHAPE, E, 1>(a.v, a.hv, a.P, a.p, lds_rows, e, lane); break;
-        case 2: hand_mw_role<HT, SHAPE, E, 2>(a.v, a.hv, a.P, a.p, lds_rows, e, lane); break;
-        default: hand_mw_role<HT, SHAPE, E, 3>(a.v, a.hv, a.P, a.p, lds_rows, e, lane); break;
+        case 0: hand_mw_role<HT, SHAPE, E, 0, PSENS>(a.v, a.hv, a.P, a.p, lds_rows, e, lane); break;
+        case 1: hand_mw_role<HT, SHAPE, E, 1, PSENS>(a.v, a.hv, a.P, a.p, lds_rows, e, lane); break;
+        case 2: hand_mw_role<HT, SHAPE, E, 2, PSENS>(a.v, a.hv, a.P, a.p, lds_rows, e, lane); break;
+        default: hand_mw_role<HT, SHAPE, E, 3, PSENS>(a.v, a.hv, a.P, a.p, lds_rows, e, lane); break;
     }
 #endif
 #else
@@ -111,20 +111,21 @@ __device__ __forceinline__ void hand_mw_body(float* lds_rows) {
 #endif
 }
 // (the kernel arguments are read through the kernarg segment pointer inside hand_mw_body; the host pass of the compiler never executes it)
-template <class HT, int SHAPE>
+// PSENS: with the pairs' forces on the fingertip sensors (the last sub-step launch of a call; core/hand_engine_mw.hpp substep_hand_role)
+template <class HT, int SHAPE, bool PSENS = true>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void hand_substep_mw_kernel(HandMwArgs args_by_value) {
     extern __shared__ float lds_rows[];   // [MW_SLOTS][32]
 #if defined(__HIP_DEVICE_COMPILE__)
     (void)args_by_value;
-    hand_mw_body<HT, SHAPE, 32>(lds_rows);
+    hand_mw_body<HT, SHAPE, 32, PSENS>(lds_rows);
 #endif
 }
-template <class HT, int SHAPE>
+template <class HT, int SHAPE, bool PSENS = true>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void hand_substep_mw64_kernel(HandMwArgs args_by_value) {
     extern __shared__ float lds_rows[];   // [MW_SLOTS][64]
 #if defined(__HIP_DEVICE_COMPILE__)
     (void)args_by_value;
-    hand_mw_body<HT, SHAPE, 64>(lds_rows);
+    hand_mw_body<HT, SHAPE, 64, PSENS>(lds_rows);
 #endif
 }
 
@@ -132,21 +133,27 @@ template <class HT, int SHAPE>
 inline hipError_t hand_substeps_mw_shape(const View& v, const HandView& hv, const SimParams& P, const HandParams& p, int n, hipStream_t s) {
     static unsigned long long conf32 = 0ull, conf64 = 0ull;
     const dim3 block(64, HT::M::NROLE);
+    // the sensor values of every launch but the last are overwritten unseen: only the last one carries the code that adds the pairs' forces to the
+    // fingertip sensors (a model without pairs has one instantiation)
+    constexpr bool SPLIT = HT::M::NHP > 0;
+    static unsigned long long conf32n = 0ull, conf64n = 0ull;
     if (v.mw == 64) {
         constexpr size_t lds = hand_mw_lds_bytes<HT, 64>();
         static_assert(lds <= 160 * 1024, "one 64-env hand workgroup per CU");
-        auto kern = hand_substep_mw64_kernel<HT, SHAPE>;
+        auto kern = hand_substep_mw64_kernel<HT, SHAPE, true>;
+        auto kern_n = hand_substep_mw64_kernel<HT, SHAPE, !SPLIT>;
         if (hipError_t e = ensure_dynamic_lds((const void*)kern, lds, &conf64); e != hipSuccess) return e;
+        if constexpr (SPLIT) { if (hipError_t e = ensure_dynamic_lds((const void*)kern_n, lds, &conf64n); e != hipSuccess) return e; }
         const dim3 grid(xcd_grid<64>(v.N));
-        // (the sensor values of every launch but the last are overwritten unseen: only the last one adds the pairs' forces to the fingertip sensors)
-        for (int i = 0; i < n; ++i) { HandView hl = hv; hl.pair_sens = (i == n - 1) ? 1 : 0; hipLaunchKernelGGL(kern, grid, block, lds, s, HandMwArgs{v, hl, P, p}); }
+        for (int i = 0; i < n; ++i) { HandView hl = hv; hl.pair_sens = (i == n - 1) ? 1 : 0; hipLaunchKernelGGL((i == n - 1) ? kern : kern_n, grid, block, lds, s, HandMwArgs{v, hl, P, p}); }
     } else {
         constexpr size_t lds = hand_mw_lds_bytes<HT, 32>();
-        auto kern = hand_substep_mw_kernel<HT, SHAPE>;
+        auto kern = hand_substep_mw_kernel<HT, SHAPE, true>;
+        auto kern_n = hand_substep_mw_kernel<HT, SHAPE, !SPLIT>;
         if (hipError_t e = ensure_dynamic_lds((const void*)kern, lds, &conf32); e != hipSuccess) return e;
+        if constexpr (SPLIT) { if (hipError_t e = ensure_dynamic_lds((const void*)kern_n, lds, &conf32n); e != hipSuccess) return e; }
         const dim3 grid(xcd_grid<32>(v.N));
-        // (the sensor values of every launch but the last are overwritten unseen: only the last one adds the pairs' forces to the fingertip sensors)
-        for (int i = 0; i < n; ++i) { HandView hl = hv; hl.pair_sens = (i == n - 1) ? 1 : 0; hipLaunchKernelGGL(kern, grid, block, lds, s, HandMwArgs{v, hl, P, p}); }
+        for (int i = 0; i < n; ++i) { HandView hl = hv; hl.pair_sens = (i == n - 1) ? 1 : 0; hipLaunchKernelGGL((i == n - 1) ? kern : kern_n, grid, block, lds, s, HandMwArgs{v, hl, P, p}); }
     }
     return hipGetLastError();
 }

@@ -43,9 +43,11 @@ constexpr int SCENE_ROWS = SceneRows<AM>::value;
 // (a robot with long kinematic chains has wider contact slots: the Kuka + Allegro's 23 dofs need 99 KB at 8 envs -- one workgroup per CU then; 4 envs per
 //  workgroup if even that does not fit)
 constexpr int SCENE_LANES_MAX = ((size_t)(SCENE_ROWS + SCENE_WARM) * 8 * sizeof(float) <= 160 * 1024) ? 8 : 4;
-// Round 6: LANES envs per workgroup is a launch-time choice (scene_lanes below).  The wavefront walks data-dependent contact lists, so its time is that
-// of the env with the most work in every loop (per actor body: the most contacts on that body among its lanes), and a CU holds as many workgroups as
-// their LDS allows: fewer envs per wavefront means less of that divergence and more wavefronts per SIMD to switch between, until the batch fills the chip.
+// Round 6: LANES envs per workgroup is a launch-time choice (scene_lanes below: 4 or 8).  Measured on FrankaCubeStack (profiles/r6s_scene_lanes_ab.txt,
+// ms per gym.simulate() at 1024 / 4096 / 16384 envs): 8 lanes 0.80 / 0.88 / 2.55, 4 lanes 0.74 / 1.03 / 2.70, 2 lanes 0.77 / 1.52 / 4.37, 1 lane
+// 0.97 / 2.31 / 7.86 -- a wavefront with ONE env is slower than one with eight once every SIMD has one: the wavefronts do not wait for each
+// other's divergent loops, they compete for instruction fetch (the kernel holds the whole register file, one wavefront per SIMD, and its code is far
+// larger than the instruction cache).
 template <int LANES>
 __global__ __launch_bounds__(64) void articulation_scene_substep_kernel(View v, SimParams P, ArticulationParams p) {
     extern __shared__ float lds_scene[];
@@ -117,11 +119,11 @@ __global__ __launch_bounds__(64) void articulation_mass_matrix_kernel(View v, Si
     for (int k = 0; k < NV * NV; ++k) o[k] = H[k];
 }
 
-// envs per workgroup of the scene sub-step: MI_SCENE_LANES (1, 2, 4, 8: A/B runs) or by batch size
+// envs per workgroup of the scene sub-step: MI_SCENE_LANES (4, 8: A/B runs) or by batch size
 static int scene_lanes(const int N) {
     static const int forced = [] { const char* e = getenv("MI_SCENE_LANES"); return e ? atoi(e) : 0; }();
-    int lanes = forced > 0 ? forced : (N <= 2048 ? 1 : (N <= 4096 ? 2 : (N <= 8192 ? 4 : 8)));
-    if (lanes != 1 && lanes != 2 && lanes != 4 && lanes != 8) lanes = 8;
+    int lanes = forced > 0 ? forced : (N <= 1024 ? 4 : 8);
+    if (lanes != 4 && lanes != 8) lanes = 8;
     return lanes > SCENE_LANES_MAX ? SCENE_LANES_MAX : lanes;
 }
 hipError_t launch_simulate_articulation(const View& v, const SimParams& P, const ArticulationParams& p, hipStream_t s) {
@@ -130,8 +132,8 @@ hipError_t launch_simulate_articulation(const View& v, const SimParams& P, const
         static_assert((size_t)(SCENE_ROWS + SCENE_WARM) * SCENE_LANES_MAX * sizeof(float) <= 160 * 1024, "the scene's row store of one workgroup fits the LDS of a CU");
         const int lanes = scene_lanes(v.N);
         hipError_t err = hipSuccess;
-        sfor<4>([&](auto L_) {
-            constexpr int LANES = 1 << decltype(L_)::value;
+        sfor<2>([&](auto L_) {
+            constexpr int LANES = 4 << decltype(L_)::value;
             if constexpr (LANES <= SCENE_LANES_MAX) {
                 if (lanes == LANES && err == hipSuccess) {
                     constexpr size_t lds = (size_t)(SCENE_ROWS + SCENE_WARM) * LANES * sizeof(float);

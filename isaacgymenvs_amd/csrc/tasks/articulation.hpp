@@ -53,7 +53,7 @@ MI_HD void articulation_scene_substep_env(const View& v, const SimParams& P, con
     drv.kpv = kp; drv.kdv = kd;
     const float h = P.dt / (float)P.substeps;
     int nc = 0;
-    sim.substep_scene(P, p.scene, tau, drv, h, rows, Strided{v.laml + e, N}, Strided{v.dof_force + e, N}, &nc, warm, vmax);
+    sim.substep_scene(P, p.scene, tau, drv, h, rows, Strided{v.laml + e, N}, Strided{v.dof_force + e, N}, &nc, warm, vmax, Strided{v.netf + e, N});
     v.scene_nc[e] = nc & 0xFFFF;
     v.scene_nc[N + e] += nc >> 16;
     sfor<ND>([&](auto K) MI_LAMBDA { v.dof[K * N + e] = sim.q[K]; v.dof[(ND + K) * N + e] = sim.qd[K]; });

@@ -152,6 +152,7 @@ class OracleSceneEngine:
         self.ncontacts = np.zeros(num_envs, int)
         self.refused = np.zeros(num_envs, int)
         self.contact_forces = [[] for _ in range(num_envs)]     # last sub-step: (ia, ib, world force on side A)
+        self.netf = np.zeros((num_envs, spec.nb, 3))            # last sub-step: net contact force on every actor body (world frame)
         self.lo = np.minimum(spec.dof_lower, spec.dof_upper); self.up = np.maximum(spec.dof_lower, spec.dof_upper)
         sb = np.asarray(spec.sph_body)
         assert np.all(np.diff(sb) >= 0), "collision spheres are listed body by body"
@@ -248,7 +249,7 @@ class OracleSceneEngine:
                 t1, t2 = contact_frame(n)
                 pc = cs - rad * n
                 self.eng.lib.or_point_jac(C.byref(self.eng.model), _ptr(s_state), b, _ptr(np.ascontiguousarray(pc - O)), _ptr(J3))
-                contacts.append(dict(Jh=[u @ J3 for u in (n, t1, t2)], ia=-1, ib=ib, fr=(n, t1, t2), pc=pc, vtn=vtarget(dist),
+                contacts.append(dict(Jh=[u @ J3 for u in (n, t1, t2)], ia=-1, ib=ib, body=b, fr=(n, t1, t2), pc=pc, vtn=vtarget(dist),
                                      mu=0.5 * (self.scene.get("arm_mu", 1.0) + mub), fid=1 + si * 8 + (t if t < nf else 4 + (t - nf))))
                 narm += 1
         nbox = 0
@@ -390,6 +391,11 @@ class OracleSceneEngine:
         self.dof_force[e] = tau - K * (q - np.array(spec.dof_springref, float)) - D * v + ll / h + kp * (tgt - q) - kd * v
         self.warm[e] = {c_["fid"]: tuple(r["lam"] for r in c_["rows"]) for c_ in contacts}
         self.contact_forces[e] = [(c_["ia"], c_["ib"], sum(u * r["lam"] for u, r in zip(c_["fr"], c_["rows"])) / h) for c_ in contacts]
+        # gym's net contact force tensor, the actor's rows: per actor body the sum of its contacts' forces (world frame, this sub-step)
+        self.netf[e] = 0.0
+        for c_, (_, _, f) in zip(contacts, self.contact_forces[e]):
+            if "body" in c_:
+                self.netf[e, c_["body"]] += f
         # ---- integrate
         self.qd[e] = v; self.q[e] = q + h * v
         for i in range(nf):

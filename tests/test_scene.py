@@ -481,6 +481,55 @@ def test_scene_edge_and_outline_contacts_hip():
     _edge_and_outline_contacts("cuda:0")
 
 
+def _netf_parity(device):
+    """the actor's rows of gym's net contact force tensor in a scene (round 6), against oracle/scene.py: cube A sits between the open fingers of
+    the arm at its home pose, the finger drives close on it and hold it (the arm itself, gravity off and without drives, sags a little under the
+    cube's weight); 20 steps from identical states"""
+    n = 2
+    gym, sim, franka, dp = _build(device, n)
+    _arm_home(gym, sim, n)
+    rb = gym.acquire_rigid_body_state_tensor(sim).view(n, -1, 13)
+    gym.simulate(sim)                                               # (one step with the cubes far away: the body states of the home pose)
+    gym.refresh_rigid_body_state_tensor(sim)
+    names = franka.body_names
+    site = rb[0, names.index("panda_grip_site"), 0:3].cpu().numpy()
+    _arm_home(gym, sim, n)
+    a, b = np.zeros((n, 13)), np.zeros((n, 13))
+    a[:, 6] = b[:, 6] = 1.0
+    a[:, 0:3] = site; a[1, 2] += 0.004
+    b[:, 0:3] = [0.3, 0.3, TOP + SIZE_B / 2]
+    root = _place(gym, sim, n, a, b)
+    orc = _oracle(sim, franka, n)
+    tg = np.array(Q0); tg[7:] = 0.0
+    orc.q[:] = np.array(Q0); orc.targets[:] = tg
+    orc.box[:, 0], orc.box[:, 1] = a, b
+    gym.set_dof_position_target_tensor(sim, torch.tensor(np.tile(tg, (n, 1)), dtype=torch.float32, device=sim.device).view(-1))
+    netf = gym.acquire_net_contact_force_tensor(sim).view(n, -1, 3)
+    dyn = [franka.spec.body_names.index(nm) for nm in ("panda_leftfinger", "panda_rightfinger")]
+    rows = [names.index(nm) for nm in ("panda_leftfinger", "panda_rightfinger")]
+    seen = 0.0
+    for step in range(20):
+        gym.simulate(sim)
+        orc.step(np.zeros((n, 9)))
+        gym.refresh_net_contact_force_tensor(sim); gym.refresh_actor_root_state_tensor(sim)
+        got, want = netf[:, rows].cpu().numpy(), orc.netf[:, dyn]
+        assert np.abs(root[:, 3, :3].cpu().numpy() - orc.box[:, 0, :3]).max() < 1e-3
+        assert np.abs(got - want).max() < 0.05 * np.abs(want).max() + 0.05, (step, got, want)
+        seen = max(seen, float(np.abs(want).max()))
+    assert seen > 5.0, seen                                         # the fingers did close on the cube
+    others = [i for i in range(netf.shape[1]) if i not in rows]
+    assert float(netf[:, others].abs().max()) < 1e-6                # nobody else touches anything
+
+
+def test_scene_net_contact_forces_follow_the_oracle_cpu():
+    _netf_parity("cpu")
+
+
+@pytest.mark.gpu
+def test_scene_net_contact_forces_follow_the_oracle_hip():
+    _netf_parity("cuda:0")
+
+
 def _ori_err(qd_, q_):
     """rotation vector that takes orientation q_ to qd_ (xyzw): 2 vec(qd * conj(q)), the shorter way round"""
     x1, y1, z1, w1 = qd_.unbind(-1)
@@ -628,6 +677,16 @@ def _grasp(device):
     A = root[:, 3].cpu().numpy()
     assert (A[:, 2] > TOP + SIZE_A / 2 + 0.13).all(), A[:, 2]                              # the cube came along
     assert np.abs(A[:, 2] - osc.rb[:, osc.site, 2].cpu().numpy()).max() < 0.01            # ... between the finger tips
+    # gym's net contact force tensor on the held cube's two fingers (round 6: scenes fill the actor's rows): friction carries the cube's weight,
+    # the two fingers squeeze with equal and opposite forces of at most the finger drives' kd vmax = 20 N
+    netf = gym.acquire_net_contact_force_tensor(sim).view(n, -1, 3)
+    gym.refresh_net_contact_force_tensor(sim)
+    names = franka.body_names
+    fl, fr_ = netf[:, names.index("panda_leftfinger")].cpu().numpy(), netf[:, names.index("panda_rightfinger")].cpu().numpy()
+    w_cube = float(sim.engine._tp.scene.free_mass[0]) * 9.81
+    assert np.abs(fl[:, 2] + fr_[:, 2] + w_cube).max() < 0.1 * w_cube, (fl, fr_, w_cube)     # the cube hangs on the fingers: they feel its weight, downwards
+    sq = np.linalg.norm(fl[:, :2], axis=1)
+    assert (sq > 2.0).all() and (sq < 21.0).all() and np.abs(fl[:, :2] + fr_[:, :2]).max() < 0.1 * sq.max(), (fl, fr_)
     def over_b(z, fingers, steps, ramp):
         """servo the hand so that CUBE A (its position is an observation of the task) comes over cube B: the cube does not sit exactly at the grip site"""
         gym.refresh_rigid_body_state_tensor(sim)

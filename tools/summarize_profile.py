@@ -145,7 +145,11 @@ RECIPE = {
                            (r"anymal_post_kernel", 1), (r"anymal_heights_kernel", 1),
                            (r"anymal_cmdnorm_kernel", 1)],
     # (round 4: hand_pre4_kernel -- four lanes per env -- replaces hand_pre_kernel, the post kernel's fingertip groups replace hand_tips_kernel)
-    "ShadowHand@16384": [(r"hand_pre4?_kernel", 1), (r"hand_substep(_mw64|_mw)?_kernel<(mi::ShadowHandTask, )?0>", 2), (r"hand_tips_kernel", 1), (r"hand_post_kernel", 1),
+    # (round 6: the finger-wave launch comes in two instantiations -- <.., false> for every sub-step of a call but the last, <.., true> with the pairs'
+    #  forces on the fingertip sensors for the last: one of each per control step; the one-wave form keeps its single name)
+    "ShadowHand@16384": [(r"hand_pre4?_kernel", 1), (r"hand_substep_kernel<(mi::ShadowHandTask, )?0>", 2),
+                         (r"hand_substep(_mw64|_mw)_kernel<(mi::ShadowHandTask, )?0, false>", 1), (r"hand_substep(_mw64|_mw)_kernel<(mi::ShadowHandTask, )?0, true>", 1),
+                         (r"hand_tips_kernel", 1), (r"hand_post_kernel", 1),
                          (r"hand_finalize_kernel", 1)],
 }
 tj = {}
