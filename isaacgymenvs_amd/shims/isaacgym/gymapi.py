@@ -270,6 +270,69 @@ class _ActuatorProps:
         self.kp = self.kv = 0.0
 
 
+def _single_box_urdf(path):
+    """A URDF that is ONE rigid body -- no joint that moves, one link with collision geometry -- read as a box: what the reference's table-top
+    tasks load their objects and stages from (trifinger.py:1169-1255: table_without_border.urdf, cube_multicolor_rrc.urdf; `create_box` is the
+    other way to get one).  A <box> is itself; a <mesh> becomes the box around its vertices (a stated approximation: exact for the plates and
+    cubes these files hold, wrong for a concave shape such as a ring wall -- the caller warns).  Returns None for anything else, else
+    dict(link, dims[3], pos[3], quat[4] -- the box's centre and axes in the link frame --, mass or None, inertia[3] or None, mesh: bool,
+    hollow: bool -- a mesh whose bounding box's vertical axis crosses none of its triangles: a ring; such a body gets NO collision shape)."""
+    import xml.etree.ElementTree as ET
+    from ...assets.model import _floats, _resolve_mesh, rpy_to_quat
+    if not (os.path.isfile(path) and path.lower().endswith(".urdf")):
+        return None
+    try:
+        root = ET.parse(path).getroot()
+    except ET.ParseError:
+        return None
+    if any(j.get("type", "fixed") != "fixed" for j in root.findall("joint")):
+        return None
+    links = [ln for ln in root.findall("link") if ln.find("collision") is not None]
+    if len(links) != 1 or len(links[0].findall("collision")) != 1:
+        return None
+    ln = links[0]
+    col = ln.find("collision")
+    org, geo = col.find("origin"), col.find("geometry")
+    if geo is None or len(geo) == 0:
+        return None
+    pos = _floats(org.get("xyz", "0 0 0"), 3) if org is not None else np.zeros(3)
+    quat = rpy_to_quat(*_floats(org.get("rpy", "0 0 0"), 3)) if org is not None else np.array([0.0, 0.0, 0.0, 1.0])
+    g = geo[0]
+    hollow = False
+    if g.tag == "box":
+        dims, mesh = _floats(g.get("size"), 3), False
+    elif g.tag == "mesh":
+        from ...assets.mesh import load_mesh
+        from ...assets.model import quat_to_mat
+        mpath = _resolve_mesh(g.get("filename"), path)
+        if mpath is None:
+            raise FileNotFoundError(f"{path}: collision mesh {g.get('filename')} not found")
+        V, F = load_mesh(mpath)
+        V = np.asarray(V, float) * (_floats(g.get("scale"), 3) if g.get("scale") else 1.0)
+        lo, hi = V.min(0), V.max(0)
+        dims, mesh = hi - lo, True
+        # hollow (a ring wall such as trifinger's high_table_boundary.stl: the arena is INSIDE its bounding box): the line through the middle of the
+        # bounding box along its shortest horizontal... along z crosses no triangle of the mesh
+        c2 = 0.5 * (lo + hi)[:2]
+        T = V[np.asarray(F, int)][:, :, :2] - c2                     # [faces, 3, 2]: the triangles' xy corners relative to that line
+        d0 = T[:, 0, 0] * T[:, 1, 1] - T[:, 0, 1] * T[:, 1, 0]
+        d1 = T[:, 1, 0] * T[:, 2, 1] - T[:, 1, 1] * T[:, 2, 0]
+        d2 = T[:, 2, 0] * T[:, 0, 1] - T[:, 2, 1] * T[:, 0, 0]
+        hollow = not bool((((d0 >= 0) & (d1 >= 0) & (d2 >= 0)) | ((d0 <= 0) & (d1 <= 0) & (d2 <= 0))).any())
+        pos = pos + quat_to_mat(quat) @ (0.5 * (lo + hi))
+    else:
+        return None
+    mass = inertia = None
+    ine = ln.find("inertial")
+    if ine is not None and ine.find("mass") is not None:
+        mass = float(ine.find("mass").get("value"))
+        it = ine.find("inertia")
+        if it is not None and all(abs(float(it.get(k, 0.0))) < 1e-12 for k in ("ixy", "ixz", "iyz")):
+            inertia = [float(it.get(k)) for k in ("ixx", "iyy", "izz")]
+    return dict(link=ln.get("name"), dims=[float(d) for d in dims], pos=[float(x) for x in pos], quat=[float(x) for x in quat],
+                mass=mass if (mass is not None and mass > 0) else None, inertia=inertia, mesh=mesh, hollow=hollow)
+
+
 class _Asset:
     @classmethod
     def primitive(cls, shape, dims, options):
@@ -280,6 +343,7 @@ class _Asset:
         a.spec, a.object_type, a.dims, a.generic = None, shape, tuple(float(d) for d in dims), False
         a.body_names, a.body_dyn, a.nshapes = [shape], np.zeros(1, np.int64), 1
         a.path = None
+        a.box_pos, a.box_quat, a.mass, a.inertia = (0.0, 0.0, 0.0), (0.0, 0.0, 0.0, 1.0), None, None
         return a
 
     def __init__(self, path, options):
@@ -300,6 +364,21 @@ class _Asset:
             return
         from ...assets import runtime
         self.variant = False                   # a file that differs from the compiled model: its own library (assets/runtime.py)
+        box = None if key in _MODEL_OF_FILE else _single_box_urdf(path)
+        if box is not None:
+            # one rigid body: a box actor of a scene, like gym.create_box's (static with fix_base_link, else free)
+            import warnings
+            if box["hollow"]:
+                warnings.warn(f"gym.load_asset: {key}: the collision mesh of the single body is a ring (its bounding box would swallow what stands inside): "
+                              f"the body is created WITHOUT a collision shape")
+            elif box["mesh"]:
+                warnings.warn(f"gym.load_asset: {key}: the collision mesh of the single body is simulated as its bounding box "
+                              f"({box['dims'][0]:.3f} x {box['dims'][1]:.3f} x {box['dims'][2]:.3f} m)")
+            self.hollow = bool(box["hollow"])
+            self.object_type, self.dims, self.generic = "box", tuple(box["dims"]), False
+            self.box_pos, self.box_quat, self.mass, self.inertia = tuple(box["pos"]), tuple(box["quat"]), box["mass"], box["inertia"]
+            self.body_names, self.body_dyn, self.nshapes = [box["link"]], np.zeros(1, np.int64), 1
+            return
         if key in _MODEL_OF_FILE:
             self.model_name, self.task = _MODEL_OF_FILE[key]
             self.spec = load_model(self.model_name)
@@ -612,7 +691,7 @@ class Gym:
         if env.index == 0:
             if asset.spec is not None and any(sl["asset"].spec is not None for sl in sim.slots):
                 raise NotImplementedError("the shim runs one articulated actor per env (plus free objects)")
-            sim.slots.append(dict(asset=asset, name=name, filter=int(filter), poses=[], friction={}))
+            sim.slots.append(dict(asset=asset, name=name, filter=int(filter), group=int(group), poses=[], friction={}))
         elif k >= len(sim.slots) or sim.slots[k]["asset"] is not asset:
             raise NotImplementedError("every env must create the same actors in the same order")
         sl = sim.slots[k]
@@ -695,6 +774,10 @@ class Gym:
 
     def _base_masses(self, sim, actor):
         a = sim.slots[actor]["asset"]
+        if a.spec is None and a.object_type == "box" and getattr(a, "dims", None) is not None and len(a.dims) == 3 and (getattr(sim, "scene", None) is not None or getattr(sim.asset, "generic", False)):
+            # a box actor of a scene (create_box or a one-body URDF): the file's <inertial> mass, else density x volume (prepare_sim's rule)
+            dens = float(getattr(a.options, "density", 1000.0) or 1000.0)
+            return np.array([float(a.mass) if getattr(a, "mass", None) else dens * a.dims[0] * a.dims[1] * a.dims[2]])
         if a.spec is None:
             return np.array([_object_mass(a.object_type, sim.asset.task if sim.slots and any(sl["asset"].spec is not None for sl in sim.slots) else "ShadowHand")])
         return np.asarray([float(a.spec.mass[int(d)]) for d in a.body_dyn])
@@ -719,7 +802,12 @@ class Gym:
         a = sim.slots[actor]["asset"]
         pr, e = self._props(sim), env.index
         f = _ratio([float(p_.mass) for p_ in props], self._base_masses(sim, actor))
-        if a.spec is None:
+        if a.spec is None and getattr(sim, "scene", None) is not None:
+            if abs(float(f[0]) - 1.0) > 1e-6 and not getattr(sim, "_warned_scene_mass", False):
+                import warnings
+                warnings.warn("set_actor_rigid_body_properties: the boxes of a scene have ONE mass for all envs (MiScene, include/mi_engine.h): per-env masses are not applied")
+                sim._warned_scene_mass = True
+        elif a.spec is None:
             ks = [k for k, sl in enumerate(sim.slots) if sl["asset"].spec is None]
             if actor == ks[0]:                 # the engine's object; the goal copy has no dynamics
                 pr.obj_mass[e] = float(f[0])
@@ -1005,12 +1093,25 @@ class Gym:
                 sc.arm_gravity = 0 if getattr(asset.options, "disable_gravity", False) else 1
                 mu_arm = rslot["friction"].get(0) if rslot["friction"] else None
                 sc.arm_mu = float(mu_arm if mu_arm is not None else (np.mean(spec.sph_friction) if len(spec.sph_friction) else 1.0))
+                from ...assets.model import quat_mul, quat_to_mat
                 for k, sl in boxes:
                     a = sl["asset"]
                     if a.object_type != "box":
                         raise NotImplementedError(f"scene actors are gym.create_box assets (got a {a.object_type})")
-                    ps = np.asarray(sl["poses"], float)
+                    g_r, g_k = rslot.get("group", -1), sl.get("group", -1)
+                    if getattr(a, "hollow", False):
+                        continue       # a ring wall without a collision shape (load_asset warned): lives in the stand-in
+                    if g_r != -1 and g_k != -1 and g_r != g_k:
+                        continue       # another collision group than the robot's in its own env (trifinger.py:561-563: the goal marker): touches nothing, lives in the stand-in
+                    ps = np.asarray(sl["poses"], float).copy()
                     fixed = bool(getattr(a.options, "fix_base_link", False))
+                    off_p, off_q = np.asarray(getattr(a, "box_pos", (0.0, 0.0, 0.0)), float), np.asarray(getattr(a, "box_quat", (0.0, 0.0, 0.0, 1.0)), float)
+                    if np.abs(off_p).max() > 1e-9 or abs(abs(off_q[3]) - 1.0) > 1e-9:
+                        if not fixed:
+                            raise NotImplementedError("a free box of the scene is centred on its link frame (the file's collision origin is not)")
+                        for e_ in range(len(ps)):       # the static box sits at the actor's pose carried to the collision geometry's frame
+                            ps[e_, 0:3] = ps[e_, 0:3] + quat_to_mat(ps[e_, 3:7]) @ off_p
+                            ps[e_, 3:7] = quat_mul(ps[e_, 3:7], off_q)
                     if fixed and np.abs(ps - ps[0]).max() > 1e-9:
                         raise NotImplementedError("a static box of the scene stands at the same env-local pose in every env")
                     half = [0.5 * d for d in a.dims]
@@ -1031,11 +1132,12 @@ class Gym:
                         if j >= native.MI_SCENE_MAX_FREE:
                             raise NotImplementedError(f"a scene holds at most {native.MI_SCENE_MAX_FREE} free boxes")
                         dens = float(getattr(a.options, "density", 1000.0) or 1000.0)
-                        m = dens * a.dims[0] * a.dims[1] * a.dims[2]
+                        m = float(a.mass) if getattr(a, "mass", None) else dens * a.dims[0] * a.dims[1] * a.dims[2]      # (a URDF's <inertial> wins over the density)
                         sc.free_mass[j], sc.free_mu[j] = m, mu
                         for c in range(3):
                             o1, o2 = a.dims[(c + 1) % 3], a.dims[(c + 2) % 3]
-                            sc.free_half[j][c], sc.free_inertia[j][c] = float(half[c]), m * (o1 * o1 + o2 * o2) / 12.0
+                            ine = a.inertia[c] if getattr(a, "inertia", None) else m * (o1 * o1 + o2 * o2) / 12.0
+                            sc.free_half[j][c], sc.free_inertia[j][c] = float(half[c]), float(ine)
                         for c in range(7):
                             sc.free_init[j][c] = float(ps[0, c])
                         sim.scene[k] = ("free", j)

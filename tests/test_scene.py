@@ -530,6 +530,70 @@ def test_scene_net_contact_forces_follow_the_oracle_hip():
     _netf_parity("cuda:0")
 
 
+def test_scene_actors_loaded_from_single_body_urdf_files_cpu(tmp_path):
+    """a scene whose stage and object come from URDF files the way trifinger.py:1169-1255 loads them (gym.load_asset of a one-link file, not
+    gym.create_box): a static plate given as a <box> with a collision origin, a static plate given as a MESH (simulated as its bounding box), a free
+    cube with an <inertial> of its own, and a goal marker in another collision group (touches nothing, lives in the stand-in)"""
+    import isaacgymenvs_amd.shims as shims
+    from isaacgymenvs_amd import native
+    native.build_cpu()
+    shims.install(force=True)
+    from isaacgym import gymapi
+    (tmp_path / "plate.urdf").write_text("""<robot name="plate"><link name="base"/><link name="plate_link">
+      <collision><origin xyz="0 0 -0.01" rpy="0 0 0"/><geometry><box size="0.6 0.6 0.02"/></geometry></collision>
+      <inertial><mass value="2"/><inertia ixx="1" ixy="0" ixz="0" iyy="1" iyz="0" izz="1"/></inertial></link>
+      <joint name="j" type="fixed"><parent link="base"/><child link="plate_link"/></joint></robot>""")
+    # a 0.2 x 0.1 x 0.04 m block as a mesh whose vertices are NOT centred on the link frame: x in [0, 0.2], y in [-0.05, 0.05], z in [0, 0.04]
+    vs = [(x, y, z) for x in (0.0, 0.2) for y in (-0.05, 0.05) for z in (0.0, 0.04)]
+    faces = [(1, 2, 4), (1, 4, 3), (5, 8, 6), (5, 7, 8), (1, 5, 6), (1, 6, 2), (3, 4, 8), (3, 8, 7), (1, 3, 7), (1, 7, 5), (2, 6, 8), (2, 8, 4)]
+    (tmp_path / "block.obj").write_text("".join(f"v {x} {y} {z}\n" for x, y, z in vs) + "".join(f"f {a} {b} {c}\n" for a, b, c in faces))
+    (tmp_path / "block.urdf").write_text("""<robot name="block"><link name="block_link">
+      <collision><geometry><mesh filename="block.obj" scale="1 1 1"/></geometry></collision></link></robot>""")
+    (tmp_path / "cube.urdf").write_text("""<robot name="cube"><link name="object">
+      <collision><origin xyz="0 0 0"/><geometry><box size="0.065 0.065 0.065"/></geometry></collision>
+      <inertial><mass value="0.094"/><inertia ixx="6.6e-5" ixy="0" ixz="0" iyy="6.6e-5" iyz="0" izz="6.6e-5"/></inertial></link></robot>""")
+    gym = gymapi.acquire_gym()
+    sp = gymapi.SimParams()
+    sp.up_axis, sp.gravity, sp.dt, sp.substeps, sp.use_gpu_pipeline = gymapi.UP_AXIS_Z, gymapi.Vec3(0, 0, -9.81), 1 / 60.0, 2, False
+    sp.physx.num_position_iterations, sp.physx.num_velocity_iterations = 8, 1
+    sp.physx.contact_offset, sp.physx.rest_offset = 0.005, 0.0
+    sim = gym.create_sim(0, -1, gymapi.SIM_PHYSX, sp)
+    gym.add_ground(sim, gymapi.PlaneParams())
+    opts = gymapi.AssetOptions()
+    opts.flip_visual_attachments, opts.fix_base_link, opts.collapse_fixed_joints, opts.disable_gravity = True, True, False, True
+    opts.thickness, opts.default_dof_drive_mode, opts.use_mesh_materials = 0.001, gymapi.DOF_MODE_EFFORT, True
+    franka = gym.load_asset(sim, os.path.join(REF, "assets"), "urdf/franka_description/robots/franka_panda_gripper.urdf", opts)
+    fixed = gymapi.AssetOptions(); fixed.fix_base_link = True
+    with pytest.warns(UserWarning, match="bounding box"):
+        block = gym.load_asset(sim, str(tmp_path), "block.urdf", fixed)
+    plate = gym.load_asset(sim, str(tmp_path), "plate.urdf", fixed)
+    cube = gym.load_asset(sim, str(tmp_path), "cube.urdf", gymapi.AssetOptions())
+    goal = gym.load_asset(sim, str(tmp_path), "cube.urdf", fixed)
+    assert gym.get_asset_rigid_body_count(cube) == 1 and gym.get_asset_dof_count(cube) == 0 and gym.get_asset_rigid_shape_count(plate) == 1
+    n, z0 = 2, 1.0
+    T = lambda x, y, z: gymapi.Transform(gymapi.Vec3(x, y, z))  # noqa: E731
+    for i in range(n):
+        env = gym.create_env(sim, gymapi.Vec3(), gymapi.Vec3(), 2)
+        gym.create_actor(env, franka, T(-2.5, 0.0, 1.0), "franka", i, 0, 0)
+        gym.create_actor(env, plate, T(0.5, 0.0, z0), "plate", i, 1, 0)                 # its top face is the link frame's z = 0
+        gym.create_actor(env, block, T(0.4, 0.0, z0), "block", i, 1, 0)                 # lies on the plate: top face at z0 + 0.04
+        gym.create_actor(env, cube, T(0.5, 0.0, z0 + 0.04 + 0.0325 + 0.01), "object", i, 0, 0)       # dropped 1 cm onto the block
+        gym.create_actor(env, goal, T(0.5, 0.0, z0 + 0.0325), "goal", i + n, 0, 0)      # inside the block -- in another collision group
+    gym.prepare_sim(sim)
+    sc = sim.engine._tp.scene
+    assert sim.scene == {1: ("static", 0), 2: ("static", 1), 3: ("free", 0)}               # the goal marker is not part of the scene
+    assert abs(sc.free_mass[0] - 0.094) < 1e-7 and abs(sc.free_inertia[0][0] - 6.6e-5) < 1e-9      # the file's <inertial>, not density x volume
+    assert np.allclose(list(sc.static_pos[0]), [0.5, 0.0, z0 - 0.01]) and np.allclose(list(sc.static_half[0]), [0.3, 0.3, 0.01])
+    assert np.allclose(list(sc.static_pos[1]), [0.5, 0.0, z0 + 0.02], atol=1e-6) and np.allclose(list(sc.static_half[1]), [0.1, 0.05, 0.02], atol=1e-6)
+    root = gym.acquire_actor_root_state_tensor(sim).view(n, 5, 13)
+    for _ in range(60):
+        gym.simulate(sim)
+    gym.refresh_actor_root_state_tensor(sim)
+    x = root.cpu().numpy()
+    assert np.abs(x[:, 3, 2] - (z0 + 0.04 + 0.0325)).max() < 1e-3 and np.abs(x[:, 3, 7:]).max() < 0.02, x[:, 3]     # the cube rests on the block
+    assert np.allclose(x[:, 4, :3], [0.5, 0.0, z0 + 0.0325]) and np.allclose(x[:, 1, :3], [0.5, 0.0, z0])            # marker and plate rows: the actors' poses
+
+
 def _ori_err(qd_, q_):
     """rotation vector that takes orientation q_ to qd_ (xyzw): 2 vec(qd * conj(q)), the shorter way round"""
     x1, y1, z1, w1 = qd_.unbind(-1)
@@ -740,6 +804,7 @@ def franka_task():
         sys.modules[name] = mod
     mod = importlib.import_module("isaacgymenvs.tasks.franka_cube_stack")
     vt = importlib.import_module("isaacgymenvs.tasks.base.vec_task")
+    mod.load = lambda name: importlib.import_module("isaacgymenvs.tasks." + name)       # (the other task files of the same tree: trifinger.py)
     yield mod, vt
     for k in [k for k in sys.modules if k.split(".")[0] in ("isaacgymenvs", "isaacgym", "gym")]:
         del sys.modules[k]
@@ -809,3 +874,74 @@ def test_reference_franka_cube_stack_steps_unmodified_cpu(franka_task):
 @pytest.mark.gpu
 def test_reference_franka_cube_stack_steps_unmodified_hip(franka_task):
     _reference_task(franka_task, "cuda:0")
+
+
+TRIFINGER = os.path.join(REF, "assets", "trifinger", "robot_properties_fingers", "urdf", "pro", "trifingerpro.urdf")
+
+
+def _reference_trifinger(franka_task, device):
+    """The reference's unmodified trifinger.py (round 6): three fingers on a fixed base (gym.load_asset of trifingerpro.urdf with its package://
+    collision meshes -> the Articulation robot), and its stage and object loaded from ONE-BODY URDF files (trifinger.py:1169-1255) -- the table plate
+    (a mesh, simulated as its bounding box: exact for a plate) is the scene's static box, the cube its free box; the goal marker (another collision
+    group, :561-563) and the arena's ring wall (a concave mesh: created without a collision shape, with a warning -- the stated gap) live in the
+    stand-in.  Random actions through the task's own code (torque control with its safety checks, asymmetric observations with fingertip wrenches
+    and joint torques, domain randomisation through apply_randomizations); the task's jitted reward against the restated twin on the same buffers."""
+    from isaacgymenvs_amd import native
+    from isaacgymenvs_amd.utils.config import compose, omegaconf_to_dict
+    from oracle import jit_twins as J
+    if device == "cpu":
+        native.build_cpu()
+    mod0, vt = franka_task
+    mod = mod0.load("trifinger")
+    assert os.path.samefile(mod.__file__, os.path.join(REF, "isaacgymenvs", "tasks", "trifinger.py"))
+    vt.EXISTING_SIM = None
+    n = 16
+    cfg = omegaconf_to_dict(compose("config", overrides=["task=Trifinger"], cfg_dir=os.path.join(REF, "isaacgymenvs", "cfg"))["task"])
+    cfg["env"]["numEnvs"] = n
+    cfg["sim"]["use_gpu_pipeline"] = device != "cpu"
+    torch.manual_seed(3)
+    with pytest.warns(UserWarning, match="WITHOUT a collision shape"):
+        env = mod.Trifinger(cfg, rl_device=device, sim_device=device, graphics_device_id=-1, headless=True, virtual_screen_capture=False, force_render=False)
+    sim = env.sim
+    sc = sim.engine._tp.scene
+    assert sim.scene == {1: ("static", 0), 3: ("free", 0)} and sim.nactors == 5                  # robot, table, (boundary), cube, (goal)
+    assert np.allclose(list(sc.static_half[0]), [0.355, 0.38, 0.005], atol=1e-4) and np.allclose(list(sc.free_half[0]), [0.0325] * 3, atol=1e-6)
+    assert env.num_actions == 9 and env.obs_buf.shape == (n, 41)
+    g = torch.Generator().manual_seed(0)
+    for step in range(80):
+        act = (torch.rand((n, 9), generator=g) * 2 - 1).to(device)
+        obs, rew, reset, _ = env.step(act)
+        assert torch.isfinite(obs["obs"]).all() and torch.isfinite(rew).all(), step
+        if step % 10 == 0:
+            c = lambda t: t.detach().cpu().numpy()  # noqa: E731
+            rt = cfg["env"]["reward_terms"]
+            r2, _, _ = J.compute_trifinger_reward(c(env.obs_buf), np.zeros(n, np.int64), c(env.progress_buf), env.max_episode_length, cfg["sim"]["dt"],
+                                                  rt["finger_move_penalty"]["weight"], rt["finger_reach_object_rate"]["weight"], rt["object_dist"]["weight"],
+                                                  rt["object_rot"]["weight"], env.env_steps_count, c(env._object_goal_poses_buf), c(env._object_state_history[0]),
+                                                  c(env._object_state_history[1]), c(env._fingertips_frames_state_history[0]),
+                                                  c(env._fingertips_frames_state_history[1]), rt["keypoints_dist"]["activate"])
+            np.testing.assert_allclose(c(env.rew_buf), r2, rtol=2e-4, atol=2e-4)
+    # physics: the cube lies on the table plate (z = half its edge; a finger may have knocked it about, nothing throws it through the plate)
+    cube = sim.engine.tensors["scene_state"][:, 0].cpu().numpy()
+    assert np.isfinite(cube).all() and (cube[:, 2] > 0.0325 - 3e-3).all() and (np.abs(cube[:, 2] - 0.0325) < 3e-3).mean() >= 0.7, cube[:, :3]
+    # the fingers answer their torques: the joint positions moved away from the start, inside their limits (the task's own safety clamps)
+    q = env._dof_position.cpu().numpy()
+    assert np.isfinite(q).all() and np.abs(q).max() < 3.0 and q.std(axis=0).max() > 0.01
+    # an episode ends at its horizon and reset_idx puts the cube back on the table
+    env.progress_buf[:] = env.max_episode_length - 2
+    for _ in range(3):
+        env.step(torch.zeros((n, 9), device=device))
+    assert int(env.progress_buf.max()) <= 3
+    cube = sim.engine.tensors["scene_state"][:, 0].cpu().numpy()
+    assert np.abs(cube[:, 2] - 0.0325).max() < 0.02 and np.hypot(cube[:, 0], cube[:, 1]).max() < 0.25
+
+
+@pytest.mark.skipif(not os.path.isfile(TRIFINGER), reason="the reference's trifinger assets are not reachable")
+def test_reference_trifinger_steps_unmodified_cpu(franka_task):
+    _reference_trifinger(franka_task, "cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.isfile(TRIFINGER), reason="the reference's trifinger assets are not reachable")
+def test_reference_trifinger_steps_unmodified_hip(franka_task):
+    _reference_trifinger(franka_task, "cuda:0")

@@ -25,6 +25,10 @@ mkdir -p $D/tasks/dextreme && cp $REF/isaacgymenvs/tasks/dextreme/*.py $D/tasks/
 mkdir -p $ROOT/ab/ref_stage/assets/urdf/franka_description/robots $ROOT/ab/ref_stage/assets/urdf/franka_description/meshes/collision
 cp $REF/assets/urdf/franka_description/robots/franka_panda_gripper.urdf $ROOT/ab/ref_stage/assets/urdf/franka_description/robots/
 cp $REF/assets/urdf/franka_description/meshes/collision/*.obj $ROOT/ab/ref_stage/assets/urdf/franka_description/meshes/collision/
+# tests/test_scene.py: trifinger.py with its robot, stage and object files (round 6: one-body URDF files as scene actors)
+cp $REF/isaacgymenvs/tasks/trifinger.py $D/tasks/
+mkdir -p $ROOT/ab/ref_stage/assets/trifinger && cp -r $REF/assets/trifinger/robot_properties_fingers $REF/assets/trifinger/objects $ROOT/ab/ref_stage/assets/trifinger/
+rm -rf $ROOT/ab/ref_stage/assets/trifinger/robot_properties_fingers/meshes/pro/detailed $ROOT/ab/ref_stage/assets/trifinger/robot_properties_fingers/meshes/edu
 find $ROOT/ab/ref_stage -name __pycache__ -type d -prune -exec rm -rf {} +
 echo staged $(find $ROOT/ab/ref_stage -type f | wc -l) files under ab/ref_stage
 # tests/test_articulation.py: the arm + hand of the allegro_kuka tasks (allegro_kuka_base.py:573): the URDF and the COLLISION meshes it names
