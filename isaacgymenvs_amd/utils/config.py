@@ -136,12 +136,23 @@ def _load_task_yaml(name, cfg_dir):
     # task files may inherit: `defaults: [Ant, _self_]` (reference cfg/task/AntSAC.yaml:2-4)
     dl = t.pop("defaults", None)
     if dl:
-        base = {}
-        for item in dl:
+        # merged in list order, later entries winning; `_self_` is this file's own content (appended when the list does not place it)
+        own, out = t, {}
+        for item in (list(dl) if "_self_" in dl else list(dl) + ["_self_"]):
             if item == "_self_":
-                continue
-            base = _merge(base, _load_task_yaml(item, cfg_dir))
-        t = _merge(base, t)
+                out = _merge(out, own)
+            elif isinstance(item, dict):
+                # a config GROUP of the task (reference cfg/task/AllegroKuka.yaml:1-3 `- env: reorientation` -> cfg/task/env/reorientation.yaml):
+                # the option's content lands under the group's key
+                for group, option in item.items():
+                    gpath = os.path.join(cfg_dir, "task", str(group), str(option) + ".yaml")
+                    if not os.path.exists(gpath):
+                        raise KeyError(f"unknown option '{option}' of task config group '{group}' (looked for {gpath})")
+                    with open(gpath) as f:
+                        out = _merge(out, {str(group): yaml.safe_load(f) or {}})
+            else:
+                out = _merge(out, _load_task_yaml(item, cfg_dir))
+        t = out
     return t
 
 

@@ -139,3 +139,25 @@ def test_legacy_environment_restores_what_it_changes():
     assert {m: m in sys.modules for m in had} == had
     with pytest.raises(RuntimeError):
         torch.where(mask, torch.ones(3), torch.zeros(3))
+
+
+def test_task_config_group_defaults(tmp_path):
+    """`defaults: [_self_, {env: reorientation}]` inside a task file (reference cfg/task/AllegroKuka.yaml:1-3 with cfg/task/env/*.yaml): the
+    option's content lands under the group's key, entries are merged in list order (what follows `_self_` overrides the file's own keys), and an
+    unknown option is an error"""
+    from isaacgymenvs_amd.utils.config import _load_task_yaml
+    (tmp_path / "task" / "env").mkdir(parents=True)
+    (tmp_path / "task" / "env" / "reorientation.yaml").write_text("subtask: reorientation\nepisodeLength: 600\n")
+    (tmp_path / "task" / "Kuka.yaml").write_text("defaults:\n  - _self_\n  - env: reorientation\nname: Kuka\nenv:\n  numEnvs: 8192\n  episodeLength: 400\n")
+    (tmp_path / "task" / "KukaLSTM.yaml").write_text("defaults:\n  - Kuka\n  - _self_\nenv:\n  numEnvs: 64\n")
+    t = _load_task_yaml("Kuka", str(tmp_path))
+    assert t["name"] == "Kuka" and t["env"] == {"subtask": "reorientation", "episodeLength": 600, "numEnvs": 8192}      # the option came after _self_
+    t2 = _load_task_yaml("KukaLSTM", str(tmp_path))
+    assert t2["env"]["numEnvs"] == 64 and t2["env"]["subtask"] == "reorientation"
+    (tmp_path / "task" / "Bad.yaml").write_text("defaults:\n  - env: nothing\nname: Bad\n")
+    with pytest.raises(KeyError):
+        _load_task_yaml("Bad", str(tmp_path))
+    import os
+    if os.path.isdir(REF_TASK_DIR):          # the reference's own file (development container only)
+        ref = _load_task_yaml("AllegroKuka", os.path.dirname(REF_TASK_DIR))
+        assert ref["env"]["subtask"] == "reorientation" and ref["name"] == "AllegroKuka"
