@@ -530,13 +530,14 @@ def test_scene_net_contact_forces_follow_the_oracle_hip():
     _netf_parity("cuda:0")
 
 
-def test_scene_actors_loaded_from_single_body_urdf_files_cpu(tmp_path):
+def _single_body_urdf_scene(tmp_path, device):
     """a scene whose stage and object come from URDF files the way trifinger.py:1169-1255 loads them (gym.load_asset of a one-link file, not
     gym.create_box): a static plate given as a <box> with a collision origin, a static plate given as a MESH (simulated as its bounding box), a free
     cube with an <inertial> of its own, and a goal marker in another collision group (touches nothing, lives in the stand-in)"""
     import isaacgymenvs_amd.shims as shims
     from isaacgymenvs_amd import native
-    native.build_cpu()
+    if device == "cpu":
+        native.build_cpu()
     shims.install(force=True)
     from isaacgym import gymapi
     (tmp_path / "plate.urdf").write_text("""<robot name="plate"><link name="base"/><link name="plate_link">
@@ -554,7 +555,7 @@ def test_scene_actors_loaded_from_single_body_urdf_files_cpu(tmp_path):
       <inertial><mass value="0.094"/><inertia ixx="6.6e-5" ixy="0" ixz="0" iyy="6.6e-5" iyz="0" izz="6.6e-5"/></inertial></link></robot>""")
     gym = gymapi.acquire_gym()
     sp = gymapi.SimParams()
-    sp.up_axis, sp.gravity, sp.dt, sp.substeps, sp.use_gpu_pipeline = gymapi.UP_AXIS_Z, gymapi.Vec3(0, 0, -9.81), 1 / 60.0, 2, False
+    sp.up_axis, sp.gravity, sp.dt, sp.substeps, sp.use_gpu_pipeline = gymapi.UP_AXIS_Z, gymapi.Vec3(0, 0, -9.81), 1 / 60.0, 2, device != "cpu"
     sp.physx.num_position_iterations, sp.physx.num_velocity_iterations = 8, 1
     sp.physx.contact_offset, sp.physx.rest_offset = 0.005, 0.0
     sim = gym.create_sim(0, -1, gymapi.SIM_PHYSX, sp)
@@ -592,6 +593,15 @@ def test_scene_actors_loaded_from_single_body_urdf_files_cpu(tmp_path):
     x = root.cpu().numpy()
     assert np.abs(x[:, 3, 2] - (z0 + 0.04 + 0.0325)).max() < 1e-3 and np.abs(x[:, 3, 7:]).max() < 0.02, x[:, 3]     # the cube rests on the block
     assert np.allclose(x[:, 4, :3], [0.5, 0.0, z0 + 0.0325]) and np.allclose(x[:, 1, :3], [0.5, 0.0, z0])            # marker and plate rows: the actors' poses
+
+
+def test_scene_actors_loaded_from_single_body_urdf_files_cpu(tmp_path):
+    _single_body_urdf_scene(tmp_path, "cpu")
+
+
+@pytest.mark.gpu
+def test_scene_actors_loaded_from_single_body_urdf_files_hip(tmp_path):
+    _single_body_urdf_scene(tmp_path, "cuda:0")
 
 
 def _ori_err(qd_, q_):
